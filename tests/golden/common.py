@@ -1,0 +1,138 @@
+"""Shared by tests/golden/make_golden.py (build container, imports the
+reference) and the tests (both boxes, never touch the reference): deterministic
+weights, replayable random draws, tensor digests and the small case configs.
+
+Weights are NOT stored in the fixtures: they are regenerated from a seed and
+the (name -> shape, dtype) table stored in the fixture, with the CPU torch
+generator (bit-stable across the two boxes: same image, same torch).
+"""
+import zlib
+
+import torch
+
+_TORCH_RAND = torch.rand  # bound early: make_golden.py monkey-patches torch.rand
+
+
+def _scale_for(name, shape):
+    last = name.rsplit(".", 1)[-1]
+    if "running_var" in name:
+        return "var"
+    if "running_mean" in name:
+        return 0.1
+    if "relative_position_index" in name or "num_batches_tracked" in name:
+        return "keep"
+    if len(shape) >= 2:
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+        if "sampling_offsets" in name:
+            return 0.3 / fan_in ** 0.5
+        if "embed.weight" in name or "query_feat" in name or "level_embed" in name or "bias_table" in name:
+            return 0.5
+        return 1.0 / fan_in ** 0.5
+    if last == "weight":
+        return "norm"
+    if "sampling_offsets.bias" in name:
+        return 1.5
+    return 0.05
+
+
+def seeded_weights(table, seed):
+    """table: {name: (shape tuple, dtype str)} -> {name: tensor}."""
+    out = {}
+    for name in sorted(table):
+        shape, dt = table[name]
+        dtype = getattr(torch, dt)
+        g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 31))
+        sc = _scale_for(name, shape)
+        if sc == "keep":
+            continue
+        r = torch.randn(tuple(shape), generator=g, dtype=torch.float64)
+        if sc == "var":
+            t = r.abs() * 0.5 + 0.5
+        elif sc == "norm":
+            t = 1.0 + 0.1 * r
+        else:
+            t = r * sc
+        out[name] = t.to(dtype)
+    return out
+
+
+def table_of(state_dict):
+    return {k: (tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in state_dict.items()}
+
+
+class ReplayRand:
+    """rand(shape) -> uniform [0,1) float32; call k uses generator seed+k."""
+
+    def __init__(self, seed):
+        self.seed = seed
+        self.calls = 0
+
+    def __call__(self, *shape, **kw):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        g = torch.Generator().manual_seed(self.seed + self.calls)
+        self.calls += 1
+        return _TORCH_RAND(shape, generator=g, dtype=torch.float32)
+
+
+def seeded(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(tuple(shape), generator=g, dtype=torch.float64) * scale).to(dtype)
+
+
+def digest(t, n=2048):
+    """Compact pin of a tensor: shape, sums and a strided sample."""
+    t = t.detach().cpu()
+    if t.dtype == torch.bool:
+        t = t.to(torch.uint8)
+    f = t.reshape(-1)
+    stride = max(1, f.numel() // n)
+    return {"shape": torch.tensor(list(t.shape), dtype=torch.int64),
+            "sum": f.double().sum().reshape(1), "abssum": f.double().abs().sum().reshape(1),
+            "sample": f[::stride][:n].clone()}
+
+
+def check_digest(t, d, rtol, atol, what=""):
+    got = digest(t)
+    assert got["shape"].tolist() == d["shape"].tolist(), f"{what}: shape {got['shape'].tolist()} != {d['shape'].tolist()}"
+    torch.testing.assert_close(got["sample"].double(), d["sample"].double(), rtol=rtol, atol=atol, msg=lambda m: f"{what} sample: {m}")
+    n = max(1, t.numel())
+    torch.testing.assert_close(got["abssum"], d["abssum"], rtol=max(rtol, 1e-6), atol=atol * n, msg=lambda m: f"{what} abssum: {m}")
+
+
+# ----------------------------------------------------------------------------- case configs
+TINY = dict(conv_dim=64, mask_dim=64, nheads=8, enc_layers=2, enc_ffn=1024, channels=(16, 32, 64, 128),
+            image=128, batch=1, queries=12, dec_layers=3, dec_ffn=128, num_classes=1,
+            num_points=96, oversample=3.0, importance=0.75, n_targets=3)
+
+C1 = dict(conv_dim=256, mask_dim=256, nheads=8, enc_layers=6, enc_ffn=1024, channels=(256, 512, 1024, 2048),
+          image=256, batch=1, queries=100, dec_layers=9, dec_ffn=2048, num_classes=1,
+          num_points=12544, oversample=3.0, importance=0.75, n_targets=4)
+
+SWIN_TINY = dict(pretrain_img_size=96, patch_size=4, embed_dim=24, depths=(2, 2, 2, 2), num_heads=(2, 2, 4, 4),
+                 window_size=4, image=(72, 88), batch=2)
+
+
+def make_features(cfg, seed):
+    s = cfg["image"]
+    return {f"res{i + 2}": seeded((cfg["batch"], c, s // st, s // st), seed + i)
+            for i, (c, st) in enumerate(zip(cfg["channels"], (4, 8, 16, 32)))}
+
+
+def make_targets(cfg, seed, size=None):
+    """n disjoint blob masks per image (bool [n,S,S]) + zero labels."""
+    s = size or cfg["image"]
+    n = cfg["n_targets"]
+    out = []
+    for b in range(cfg["batch"]):
+        g = torch.Generator().manual_seed(seed + 17 * b)
+        centers = torch.rand((n, 2), generator=g) * 0.5 + 0.25
+        ys, xs = torch.meshgrid(torch.arange(s) / s, torch.arange(s) / s, indexing="ij")
+        d = torch.stack([(ys - c[0]) ** 2 + (xs - c[1]) ** 2 for c in centers])
+        inside = ((ys - 0.5) ** 2 / 0.16 + (xs - 0.5) ** 2 / 0.1) < 1.0
+        lab = d.argmin(0)
+        masks = torch.stack([(lab == k) & inside for k in range(n)])
+        out.append({"labels": torch.zeros(n, dtype=torch.int64), "masks": masks})
+    return out
