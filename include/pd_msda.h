@@ -1,0 +1,77 @@
+/*
+ * pd_msda.h — C-ABI of the multi-scale deformable attention operator
+ * (libpd_hip.so, built from partdistillation_amd/csrc/ for gfx950).
+ *
+ * These two entry points are exactly what the reference's pybind module
+ * `MultiScaleDeformableAttention` binds for this path:
+ *   reference part_distillation/modeling/pixel_decoder/ops/src/vision.cpp:19-22
+ *     m.def("ms_deform_attn_forward",  &ms_deform_attn_forward, ...)
+ *     m.def("ms_deform_attn_backward", &ms_deform_attn_backward, ...)
+ *   dispatched by ops/src/ms_deform_attn.h:26-67 to
+ *   ops/src/cuda/ms_deform_attn_cuda.cu:26-86 (forward) / :89-159 (backward).
+ *
+ * Plain pointers and sizes only — no torch types.  All pointers are DEVICE
+ * pointers (including spatial_shapes / level_start_index, which the reference
+ * also keeps on the device, ms_deform_attn_cuda.cu:41-42).  Tensors are
+ * contiguous row-major:
+ *   value              [batch, spatial_size, num_heads, channels]
+ *   spatial_shapes     int64 [num_levels, 2]   (H_l, W_l)
+ *   level_start_index  int64 [num_levels]
+ *   sampling_loc       [batch, num_query, num_heads, num_levels, num_point, 2]  (x, y) in [0,1]
+ *   attn_weight        [batch, num_query, num_heads, num_levels, num_point]
+ *   output/grad_output [batch, num_query, num_heads*channels]
+ * dtype: PD_F32 or PD_F64 (the reference dispatches float/double only,
+ * ms_deform_attn_cuda.cu:70).  `stream` is a hipStream_t (the reference
+ * launches on the current stream, ms_deform_attn_cuda.cu:71).
+ *
+ * Ownership: inputs are borrowed and never written.  The caller allocates the
+ * outputs; the library overwrites `output` completely and zero-fills
+ * grad_value / grad_sampling_loc / grad_attn_weight itself before accumulating
+ * (the reference returns at::zeros-initialised tensors, .cu:60,127-129).
+ *
+ * Errors: return 0 on success; a negative PD_ERR_* otherwise, with a message
+ * retrievable through pd_last_error() (the reference raises through
+ * AT_ASSERTM, e.g. `batch % im2col_step_ == 0`, .cu:58).  Nothing is launched
+ * when an error is returned.
+ */
+#ifndef PD_MSDA_H
+#define PD_MSDA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { PD_F32 = 0, PD_F64 = 1, PD_BF16 = 2 };
+
+enum {
+  PD_OK = 0,
+  PD_ERR_INVALID_ARG = -1, /* null pointer, non-positive size, unknown dtype */
+  PD_ERR_IM2COL_STEP = -2, /* batch % min(batch, im2col_step) != 0 (reference .cu:58) */
+  PD_ERR_LAUNCH = -3       /* hipGetLastError() after launch was not hipSuccess */
+};
+
+/* replaces MSDA.ms_deform_attn_forward (vision.cpp:20, ms_deform_attn_cuda.cu:26-86) */
+int pd_msda_forward(const void *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                    const void *sampling_loc, const void *attn_weight, void *output,
+                    int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                    int num_query, int num_point, int im2col_step, int dtype, void *stream);
+
+/* replaces MSDA.ms_deform_attn_backward (vision.cpp:21, ms_deform_attn_cuda.cu:89-159) */
+int pd_msda_backward(const void *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                     const void *sampling_loc, const void *attn_weight, const void *grad_output,
+                     void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
+                     int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                     int num_query, int num_point, int im2col_step, int dtype, void *stream);
+
+/* message of the last error on this thread ("" if none) */
+const char *pd_last_error(void);
+
+/* library / ABI version, bumped when a signature changes */
+int pd_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PD_MSDA_H */

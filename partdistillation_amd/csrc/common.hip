@@ -1,0 +1,44 @@
+// Error plumbing + version of libpd_hip.so (C-ABI declared in include/pd_msda.h).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "pd_common.h"
+#include "pd_msda.h"
+
+namespace {
+thread_local char g_err[512] = {0};
+}
+
+int pd_set_error(int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int pd_check_launch(const char *what)
+{
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return PD_OK;
+  return pd_set_error(PD_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+extern "C" const char *pd_last_error(void) { return g_err; }
+extern "C" int pd_abi_version(void) { return 1; }
+
+// experiment knobs (not part of the public ABI contract; used by tools/ only)
+extern int g_pd_dbg_atomic_scope;
+extern int g_pd_dbg_force_generic;
+extern int g_pd_dbg_ablate;
+extern "C" int pd_debug_set(const char *key, int value)
+{
+  if (!key) return PD_ERR_INVALID_ARG;
+  if (!strcmp(key, "msda_bwd_atomic_scope")) { g_pd_dbg_atomic_scope = value; return PD_OK; }
+  if (!strcmp(key, "msda_ablate")) { g_pd_dbg_ablate = value; return PD_OK; }
+  if (!strcmp(key, "msda_force_generic")) { g_pd_dbg_force_generic = value; return PD_OK; }
+  return pd_set_error(PD_ERR_INVALID_ARG, "pd_debug_set: unknown key %s", key);
+}

@@ -1,0 +1,643 @@
+// Multi-scale deformable attention for gfx950 (MI355X) — forward + backward.
+//
+// Semantics follow the reference's intended native op
+// (part_distillation/modeling/pixel_decoder/ops/src/cuda/ms_deform_im2col_cuda.cuh:38-304,
+// ms_deform_attn_cuda.cu:26-159) == its PyTorch fallback
+// (functions/ms_deform_attn_func.py:55-75).  The launch geometry is NOT the
+// reference's (1 thread / output scalar, 32-thread backward blocks):
+//
+//  * fast path (fp32, head_dim 32, the only shape Mask2Former uses): one
+//    (batch, query, head) triple per 8-lane group, each lane owning 4 channels
+//    as a float4.  A corner read is then one 128-byte row per group, issued as
+//    a single global_load_dwordx4 per lane; a 64-lane wavefront covers all 8
+//    heads of one query.  Backward reduces grad_sampling_loc / grad_attn_weight
+//    across the 8 lanes with DPP (no LDS, no barrier) and parks the results so
+//    that the stores are 32/64-byte contiguous per group.
+//  * blockIdx is remapped so that each XCD (block b is dispatched to XCD b%8)
+//    walks one contiguous eighth of the query range: its private 4 MiB L2 then
+//    holds just the band of `value` rows those queries sample.
+//  * generic path (any head_dim, fp32/fp64): forward = one lane per output
+//    scalar; backward = one wavefront per (batch, query, head), lanes striding
+//    over channels, wave-level shuffle reduction.
+//
+// HBM-bound kernel: algorithmic bytes per launch are value + loc + attn + out
+// (forward), see DESIGN.md.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "pd_msda.h"
+#include "pd_common.h"
+
+int g_pd_dbg_force_generic = 0;
+int g_pd_dbg_ablate = 0;
+int g_pd_dbg_atomic_scope = 0;   // experiments only (pd_debug_set): 0 = agent scope, 1 = workgroup scope
+
+namespace {
+
+template <int SCOPE>
+__device__ __forceinline__ void scoped_add(float *p, float v)
+{
+  if (SCOPE == 0) unsafeAtomicAdd(p, v);
+  else if (SCOPE == 2) asm volatile("" ::"v"(p), "v"(v));   // ablation: no atomic at all
+  else (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ----------------------------------------------------------------------------------------- helpers
+__device__ __forceinline__ int xcd_chunked_block(int bid, int nblocks)
+{
+  // nblocks is a multiple of 8 (host rounds up).  XCD k = bid % 8 gets logical
+  // blocks [k*per, (k+1)*per).
+  const int per = nblocks >> 3;
+  return (bid & 7) * per + (bid >> 3);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x)
+{
+  int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true);
+  return x + __int_as_float(y);
+}
+
+// sum over the 8 lanes of an aligned 8-lane group; every lane gets the total
+__device__ __forceinline__ float group8_sum(float x)
+{
+  x = dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]
+  x = dpp_add<0x141>(x);  // row_half_mirror: lane i <-> 7-i inside each 8-lane half row
+  return x;
+}
+
+// reference .cuh:38-89 geometry; `stride_w` = num_heads*channels elements
+template <typename T>
+__device__ __forceinline__ void corner_setup(T h, T w, int H, int W, int stride_w, bool in_range,
+                                             int off[4], bool ok[4], T cw[4], T &lh, T &lw, T &hh, T &hw)
+{
+  const T hf = floor(h), wf = floor(w);
+  int h_low = in_range ? (int)hf : 0, w_low = in_range ? (int)wf : 0;
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  lh = h - hf; lw = w - wf; hh = 1 - lh; hw = 1 - lw;
+  const bool hl = h_low >= 0, wl = w_low >= 0, hh_ok = h_high <= H - 1, wh_ok = w_high <= W - 1;
+  ok[0] = in_range && hl && wl;
+  ok[1] = in_range && hl && wh_ok;
+  ok[2] = in_range && hh_ok && wl;
+  ok[3] = in_range && hh_ok && wh_ok;
+  const int hlc = min(max(h_low, 0), H - 1), hhc = min(max(h_high, 0), H - 1);
+  const int wlc = min(max(w_low, 0), W - 1), whc = min(max(w_high, 0), W - 1);
+  const int hs = W * stride_w;
+  off[0] = hlc * hs + wlc * stride_w;
+  off[1] = hlc * hs + whc * stride_w;
+  off[2] = hhc * hs + wlc * stride_w;
+  off[3] = hhc * hs + whc * stride_w;
+  if (!in_range) { lh = 0; lw = 0; hh = 0; hw = 0; }   // NaN / inf locations contribute exactly nothing
+  cw[0] = hh * hw; cw[1] = hh * lw; cw[2] = lh * hw; cw[3] = lh * lw;
+}
+
+// ----------------------------------------------------------------------------------------- fast forward
+// D == 32, fp32.  256 threads = 32 (b,q,m) triples per block.
+template <int L_, int P_>
+__global__ __launch_bounds__(256, 4) void msda_fwd_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
+                                                     const int64_t *__restrict__ lvl_start, const float *__restrict__ loc,
+                                                     const float *__restrict__ attn, float *__restrict__ out,
+                                                     int S, int M, int Lq, int total_qm)
+{
+  const int lb = xcd_chunked_block(blockIdx.x, gridDim.x);
+  const int qm = lb * 32 + (threadIdx.x >> 3);
+  if (qm >= total_qm) return;
+  const int sub = threadIdx.x & 7;
+  const int m = qm % M;
+  const int b = (qm / M) / Lq;
+  const int stride_w = M * 32;
+  static_assert(P_ == 4, "fast path is written for 4 points per level");
+  const float4 *lp4 = reinterpret_cast<const float4 *>(loc + (int64_t)qm * (L_ * P_ * 2));
+  const float4 *ap4 = reinterpret_cast<const float4 *>(attn + (int64_t)qm * (L_ * P_));
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+  for (int l = 0; l < L_; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const float *vbase = value + ((int64_t)b * S + lvl_start[l]) * stride_w + m * 32 + sub * 4;
+    const float4 l01 = lp4[2 * l], l23 = lp4[2 * l + 1], a4 = ap4[l];
+    const float locs[8] = {l01.x, l01.y, l01.z, l01.w, l23.x, l23.y, l23.z, l23.w};
+    const float aw[4] = {a4.x, a4.y, a4.z, a4.w};
+    float4 v[P_][4];
+    float cwk[P_][4];
+#pragma unroll
+    for (int p = 0; p < P_; ++p) {
+      const float x = locs[2 * p], y = locs[2 * p + 1];
+      const float h_im = y * H - 0.5f, w_im = x * W - 0.5f;
+      const bool in_range = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+      int off[4]; bool ok[4]; float cw[4], lh, lw, hh, hw;
+      corner_setup<float>(h_im, w_im, H, W, stride_w, in_range, off, ok, cw, lh, lw, hh, hw);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[p][k] = *reinterpret_cast<const float4 *>(vbase + off[k]);
+        cwk[p][k] = ok[k] ? cw[k] * aw[p] : 0.f;   // masked corners get weight 0 ...
+        if (!ok[k]) v[p][k] = make_float4(0.f, 0.f, 0.f, 0.f);   // ... and a 0 value (inf/NaN safe)
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < P_; ++p) {
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        val.x += cwk[p][k] * v[p][k].x;
+        val.y += cwk[p][k] * v[p][k].y;
+        val.z += cwk[p][k] * v[p][k].z;
+        val.w += cwk[p][k] * v[p][k].w;
+      }
+      acc.x += val.x; acc.y += val.y; acc.z += val.z; acc.w += val.w;
+    }
+  }
+  *reinterpret_cast<float4 *>(out + (int64_t)qm * 32 + sub * 4) = acc;
+}
+
+// ----------------------------------------------------------------------------------------- fast backward
+template <int L_, int P_, int SCOPE>
+__global__ __launch_bounds__(256) void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
+                                                     const int64_t *__restrict__ lvl_start, const float *__restrict__ loc,
+                                                     const float *__restrict__ attn, const float *__restrict__ grad_out,
+                                                     float *__restrict__ grad_value, float *__restrict__ grad_loc,
+                                                     float *__restrict__ grad_attn, int S, int M, int Lq, int total_qm)
+{
+  const int lb = xcd_chunked_block(blockIdx.x, gridDim.x);
+  const int qm = lb * 32 + (threadIdx.x >> 3);
+  if (qm >= total_qm) return;   // whole 8-lane groups leave together; DPP stays inside a group
+  const int sub = threadIdx.x & 7;
+  const int m = qm % M;
+  const int b = (qm / M) / Lq;
+  const int stride_w = M * 32;
+  constexpr int LP = L_ * P_;
+  const float4 *lp4 = reinterpret_cast<const float4 *>(loc + (int64_t)qm * (LP * 2));
+  const float4 *ap4 = reinterpret_cast<const float4 *>(attn + (int64_t)qm * LP);
+  float locs[LP * 2], aw[LP];
+#pragma unroll
+  for (int i = 0; i < LP * 2 / 4; ++i) {
+    float4 t = lp4[i];
+    locs[4 * i] = t.x; locs[4 * i + 1] = t.y; locs[4 * i + 2] = t.z; locs[4 * i + 3] = t.w;
+  }
+#pragma unroll
+  for (int i = 0; i < LP / 4; ++i) {
+    float4 t = ap4[i];
+    aw[4 * i] = t.x; aw[4 * i + 1] = t.y; aw[4 * i + 2] = t.z; aw[4 * i + 3] = t.w;
+  }
+  const float4 go = *reinterpret_cast<const float4 *>(grad_out + (int64_t)qm * 32 + sub * 4);
+  // results parked per lane: lane `sub` keeps points sub and sub+8 (LP <= 16)
+  static_assert(LP <= 16, "fast path parks at most 16 points");
+  float keep_a[2] = {0.f, 0.f}, keep_x[2] = {0.f, 0.f}, keep_y[2] = {0.f, 0.f};
+#pragma unroll
+  for (int l = 0; l < L_; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const int64_t voff = ((int64_t)b * S + lvl_start[l]) * stride_w + m * 32 + sub * 4;
+    const float *vbase = value + voff;
+    float *gbase = grad_value + voff;
+#pragma unroll
+    for (int p = 0; p < P_; ++p) {
+      const int i = l * P_ + p;
+      const float x = locs[2 * i], y = locs[2 * i + 1], a = aw[i];
+      const float h_im = y * H - 0.5f, w_im = x * W - 0.5f;
+      const bool in_range = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+      int off[4]; bool ok[4]; float cw[4], lh, lw, hh, hw;
+      corner_setup<float>(h_im, w_im, H, W, stride_w, in_range, off, ok, cw, lh, lw, hh, hw);
+      float4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float4 t = *reinterpret_cast<const float4 *>(vbase + off[k]);
+        v[k] = ok[k] ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      // d(val)/dh and d(val)/dw per channel (reference .cuh:122-158), then dot with grad_out
+      const float gs[4] = {go.x, go.y, go.z, go.w};
+      float pa = 0.f, ph = 0.f, pw = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float v1 = (&v[0].x)[c], v2 = (&v[1].x)[c], v3 = (&v[2].x)[c], v4 = (&v[3].x)[c];
+        const float gh = -hw * v1 - lw * v2 + hw * v3 + lw * v4;
+        const float gw = -hh * v1 + hh * v2 - lh * v3 + lh * v4;
+        const float val = cw[0] * v1 + cw[1] * v2 + cw[2] * v3 + cw[3] * v4;
+        pa += gs[c] * val;
+        ph += gs[c] * gh;
+        pw += gs[c] * gw;
+      }
+      // scatter-add grad_value (reference .cuh:130-157 atomicAdd)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (ok[k]) {
+          const float s = cw[k] * a;
+          float *g = gbase + off[k];
+          scoped_add<SCOPE>(g + 0, s * go.x);
+          scoped_add<SCOPE>(g + 1, s * go.y);
+          scoped_add<SCOPE>(g + 2, s * go.z);
+          scoped_add<SCOPE>(g + 3, s * go.w);
+        }
+      }
+      pa = group8_sum(pa);
+      pw = group8_sum(pw) * (a * W);
+      ph = group8_sum(ph) * (a * H);
+      if (sub == (i & 7)) { keep_a[i >> 3] = pa; keep_x[i >> 3] = pw; keep_y[i >> 3] = ph; }
+    }
+  }
+  float *ga = grad_attn + (int64_t)qm * LP;
+  float2 *gl = reinterpret_cast<float2 *>(grad_loc + (int64_t)qm * LP * 2);
+  if (sub < LP) { ga[sub] = keep_a[0]; gl[sub] = make_float2(keep_x[0], keep_y[0]); }
+  if (sub + 8 < LP) { ga[sub + 8] = keep_a[1]; gl[sub + 8] = make_float2(keep_x[1], keep_y[1]); }
+}
+
+// ----------------------------------------------------------------------------------------- tiled backward
+// Self-attention geometry (num_query == spatial_size, query q sits at a pixel of
+// some level).  Measured on MI355X (tools/probes/lds_atomic_probe.hip, bench_msda.py):
+//   * global fp32 atomics retire ~1 dword / clock / L2 channel: the 528 M dword
+//     atomics of one config-2 backward take 2.2 ms with full-line lanes and 6.4 ms
+//     with float4 lanes — so grad_value is NOT scattered to HBM sample by sample;
+//   * ds_add_f32 (LDS float atomic) runs at 0.38 lanes/clk/CU, 42x slower than
+//     ds_add_u32 (16 lanes/clk/CU) — so the LDS accumulator is INTEGER.
+// The unit square is cut into G x G tiles; one workgroup owns (batch, tile, dest
+// level, head): it walks the queries whose pixel centre lies in the tile (all
+// source levels) and accumulates their contributions to the destination level
+// into an LDS window (tile + HALO cells each side, <= WIN x WIN cells x 32
+// channels) as int32 fixed point with a per-(workgroup, channel) power-of-two
+// scale 2^e, e = 22 - exponent(max |grad_out| over the tile's queries): every
+// contribution is |grad_out*attn*w| <= max < 2^22 after scaling and the bilinear
+// x attention weights of one tile's queries sum to < 2^9 per cell, so the int32
+// sum cannot overflow; quantisation error is <= 2^-23 of that max per add (the
+// same order as the fp32 re-association noise of the reference's atomics) and
+// the accumulation is order-independent.  The window is flushed once with
+// full-128-byte-line fp32 atomics.  Samples that land outside the window (large
+// learned offsets) take the direct global atomic, so the result never depends on
+// G, HALO or WIN — the window is only a cache.
+// G is derived in-kernel from the device-resident shapes (the ABI carries no host
+// copy): G = ceil(max level dim / TILE); the host launches GMAX^2 tiles and the
+// surplus blocks exit at once.
+constexpr int kTile = 16, kHalo = 4, kWin = kTile + 2 * kHalo, kGmax = 16;
+
+__device__ __forceinline__ int lds_slot(int cell, int ch) { return cell * 32 + ((ch + (cell & 3)) & 31); }
+
+template <int P_, int ABL>
+__global__ __launch_bounds__(256) void msda_bwd_tiled_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
+                                                           const int64_t *__restrict__ lvl_start, const float *__restrict__ loc,
+                                                           const float *__restrict__ attn, const float *__restrict__ grad_out,
+                                                           float *__restrict__ grad_value, float *__restrict__ grad_loc,
+                                                           float *__restrict__ grad_attn, int S, int M, int L)
+{
+  static_assert(P_ == 4, "tiled path is written for 4 points per level");
+  extern __shared__ __attribute__((aligned(16))) int win[];   // kWin*kWin*32 int32 accumulators + 32 max slots
+  // ---- decode block -> (b, tile, dest level l, head m); heads fastest so the 8 XCDs split the heads
+  int idx = blockIdx.x;
+  const int m = idx % M; idx /= M;
+  const int l = idx % L; idx /= L;
+  const int tile = idx % (kGmax * kGmax);
+  const int b = idx / (kGmax * kGmax);
+  int maxdim = 1;
+  for (int j = 0; j < L; ++j) maxdim = max(maxdim, max((int)shapes[2 * j], (int)shapes[2 * j + 1]));
+  const int G = min(kGmax, (maxdim + kTile - 1) / kTile);
+  if (tile >= G * G) return;
+  const int ty = tile / G, tx = tile % G;
+  const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+  // destination window (clipped); at most kWin x kWin cells are cached
+  const int wy0 = max(0, ty * H / G - kHalo), wx0 = max(0, tx * W / G - kHalo);
+  const int wh = min(min(H, (ty + 1) * H / G + kHalo) - wy0, kWin), ww = min(min(W, (tx + 1) * W / G + kHalo) - wx0, kWin);
+  const int cells = max(wh, 0) * max(ww, 0);
+  int *chmax = win + kWin * kWin * 32;
+  for (int i = threadIdx.x; i < cells * 32; i += 256) win[i] = 0;
+  if (threadIdx.x < 32) chmax[threadIdx.x] = 0;
+  __syncthreads();
+
+  const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int stride_w = M * 32;
+  const int LP = L * P_;
+  const int64_t voff = ((int64_t)b * S + lvl_start[l]) * stride_w + m * 32 + sub * 4;
+  const float *vbase = value + voff;
+  float *gbase = grad_value + voff;
+  // ---- pre-pass: per-channel max |grad_out| over this tile's queries -> fixed-point scale
+  {
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < L; ++j) {
+      const int Hj = (int)shapes[2 * j], Wj = (int)shapes[2 * j + 1];
+      const int ry0 = ty * Hj / G, ry1 = (ty + 1) * Hj / G, rx0 = tx * Wj / G, rx1 = (tx + 1) * Wj / G;
+      const int rw = rx1 - rx0, nq = (ry1 - ry0) * rw;
+      const int qbase = (int)lvl_start[j];
+      for (int i = grp; i < nq; i += 32) {
+        const int q = qbase + (ry0 + i / rw) * Wj + rx0 + i % rw;
+        const float4 go = *reinterpret_cast<const float4 *>(grad_out + (((int64_t)b * S + q) * M + m) * 32 + sub * 4);
+        mx[0] = fmaxf(mx[0], fabsf(go.x)); mx[1] = fmaxf(mx[1], fabsf(go.y));
+        mx[2] = fmaxf(mx[2], fabsf(go.z)); mx[3] = fmaxf(mx[3], fabsf(go.w));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)   // non-negative floats order like their bit patterns; NaN/inf handled below
+      atomicMax(&chmax[sub * 4 + c], __float_as_int(mx[c]));
+  }
+  __syncthreads();
+  float qscale[4], dscale[4];
+  bool fixed_ok = true;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float mxc = __int_as_float(chmax[sub * 4 + c]);
+    int ex;
+    (void)frexpf(mxc, &ex);                       // mxc < 2^ex
+    const bool fin = mxc > 0.f && mxc < 3.0e38f;  // finite, non-zero
+    ex = fin ? min(max(ex, -100), 100) : 0;
+    qscale[c] = ldexpf(1.f, 22 - ex);
+    dscale[c] = ldexpf(1.f, ex - 22);
+    fixed_ok = fixed_ok && (fin || mxc == 0.f);
+  }
+  // a non-finite grad_out anywhere in the tile: bypass the window (plain global atomics propagate it)
+  fixed_ok = __all(fixed_ok);
+  for (int j = 0; j < L; ++j) {
+    const int Hj = (int)shapes[2 * j], Wj = (int)shapes[2 * j + 1];
+    const int ry0 = ty * Hj / G, ry1 = (ty + 1) * Hj / G, rx0 = tx * Wj / G, rx1 = (tx + 1) * Wj / G;
+    const int rw = rx1 - rx0, nq = (ry1 - ry0) * rw;
+    const int qbase = (int)lvl_start[j];
+    for (int i = grp; i < nq; i += 32) {
+      const int q = qbase + (ry0 + i / rw) * Wj + rx0 + i % rw;
+      const int64_t qm = ((int64_t)b * S + q) * M + m;
+      const float4 *lp4 = reinterpret_cast<const float4 *>(loc + (qm * LP + l * P_) * 2);
+      const float4 l01 = lp4[0], l23 = lp4[1];
+      const float4 a4 = *reinterpret_cast<const float4 *>(attn + qm * LP + l * P_);
+      const float4 go = *reinterpret_cast<const float4 *>(grad_out + qm * 32 + sub * 4);
+      const float locs[8] = {l01.x, l01.y, l01.z, l01.w, l23.x, l23.y, l23.z, l23.w};
+      const float aw[4] = {a4.x, a4.y, a4.z, a4.w};
+      const float gs[4] = {go.x, go.y, go.z, go.w};
+      float keep_a = 0.f, keep_x = 0.f, keep_y = 0.f;
+#pragma unroll
+      for (int p = 0; p < P_; ++p) {
+        const float x = locs[2 * p], y = locs[2 * p + 1], a = aw[p];
+        const float h_im = y * H - 0.5f, w_im = x * W - 0.5f;
+        const bool in_range = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+        int off[4]; bool ok[4]; float cw[4], lh, lw, hh, hw;
+        corner_setup<float>(h_im, w_im, H, W, stride_w, in_range, off, ok, cw, lh, lw, hh, hw);
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float4 t = *reinterpret_cast<const float4 *>(vbase + off[k]);
+          v[k] = ok[k] ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float pa = 0.f, ph = 0.f, pw = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float v1 = (&v[0].x)[c], v2 = (&v[1].x)[c], v3 = (&v[2].x)[c], v4 = (&v[3].x)[c];
+          pa += gs[c] * (cw[0] * v1 + cw[1] * v2 + cw[2] * v3 + cw[3] * v4);
+          ph += gs[c] * (-hw * v1 - lw * v2 + hw * v3 + lw * v4);
+          pw += gs[c] * (-hh * v1 + hh * v2 - lh * v3 + lh * v4);
+        }
+        // window coordinates of the low corner (valid when in_range; clamped offsets otherwise unused)
+        const int h_low = in_range ? (int)floorf(h_im) : 0, w_low = in_range ? (int)floorf(w_im) : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (ok[k]) {
+            const float sc = cw[k] * a;
+            const int cy = h_low + (k >> 1) - wy0, cx = w_low + (k & 1) - wx0;
+            if (fixed_ok && cy >= 0 && cy < wh && cx >= 0 && cx < ww) {
+              const int cell = cy * ww + cx;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const int fx = __float2int_rn(sc * gs[c] * qscale[c]);
+                if (ABL & 1) asm volatile("" ::"v"(cell), "v"(fx));
+                else atomicAdd(&win[lds_slot(cell, sub * 4 + c)], fx);   // ds_add_u32
+              }
+            } else {
+              float *g = gbase + off[k];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                if (ABL & 2) asm volatile("" ::"v"(g), "v"(sc * gs[c]));
+                else unsafeAtomicAdd(g + c, sc * gs[c]);
+              }
+            }
+          }
+        }
+        pa = group8_sum(pa);
+        pw = group8_sum(pw) * (a * W);
+        ph = group8_sum(ph) * (a * H);
+        if (sub == p) { keep_a = pa; keep_x = pw; keep_y = ph; }
+      }
+      if (sub < P_) {
+        grad_attn[qm * LP + l * P_ + sub] = keep_a;
+        reinterpret_cast<float2 *>(grad_loc + (qm * LP + l * P_) * 2)[sub] = make_float2(keep_x, keep_y);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- flush: lane = channel, one full 128-byte line per cell per half-wave
+  float *gl = grad_value + ((int64_t)b * S + lvl_start[l]) * stride_w + m * 32;
+  for (int i = threadIdx.x; i < cells * 32; i += 256) {
+    const int cell = i >> 5, ch = i & 31;
+    const int acc = win[lds_slot(cell, ch)];
+    int ex;
+    (void)frexpf(__int_as_float(chmax[ch]), &ex);
+    const float v = (float)acc * ldexpf(1.f, min(max(ex, -100), 100) - 22);
+    if (acc != 0 && !(ABL & 4)) unsafeAtomicAdd(gl + ((int64_t)(wy0 + cell / ww) * W + wx0 + cell % ww) * stride_w + ch, v);
+  }
+}
+
+// ----------------------------------------------------------------------------------------- generic forward
+template <typename T>
+__global__ __launch_bounds__(256) void msda_fwd_generic(const T *__restrict__ value, const int64_t *__restrict__ shapes,
+                                                         const int64_t *__restrict__ lvl_start, const T *__restrict__ loc,
+                                                         const T *__restrict__ attn, T *__restrict__ out,
+                                                         int64_t n, int S, int M, int D, int L, int Lq, int P)
+{
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % D);
+    const int64_t qm = idx / D;
+    const int m = (int)(qm % M);
+    const int b = (int)((qm / M) / Lq);
+    const int stride_w = M * D;
+    int64_t wp = qm * L * P;
+    T col = 0;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const T *vbase = value + ((int64_t)b * S + lvl_start[l]) * stride_w + m * D + c;
+      for (int p = 0; p < P; ++p, ++wp) {
+        const T x = loc[2 * wp], y = loc[2 * wp + 1], a = attn[wp];
+        const T h_im = y * H - (T)0.5, w_im = x * W - (T)0.5;
+        const bool in_range = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+        int off[4]; bool ok[4]; T cw[4], lh, lw, hh, hw;
+        corner_setup<T>(h_im, w_im, H, W, stride_w, in_range, off, ok, cw, lh, lw, hh, hw);
+        T val = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) val += ok[k] ? cw[k] * vbase[off[k]] : (T)0;
+        col += val * a;
+      }
+    }
+    out[idx] = col;
+  }
+}
+
+// ----------------------------------------------------------------------------------------- generic backward
+template <typename T>
+__device__ __forceinline__ T wave_sum(T x)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+// one wavefront per (b,q,m); lanes stride over channels
+template <typename T>
+__global__ __launch_bounds__(256) void msda_bwd_generic(const T *__restrict__ value, const int64_t *__restrict__ shapes,
+                                                         const int64_t *__restrict__ lvl_start, const T *__restrict__ loc,
+                                                         const T *__restrict__ attn, const T *__restrict__ grad_out,
+                                                         T *__restrict__ grad_value, T *__restrict__ grad_loc,
+                                                         T *__restrict__ grad_attn, int64_t total_qm, int S, int M, int D,
+                                                         int L, int Lq, int P)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t qm = wave0; qm < total_qm; qm += nwaves) {
+    const int m = (int)(qm % M);
+    const int b = (int)((qm / M) / Lq);
+    const int stride_w = M * D;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const int64_t voff = ((int64_t)b * S + lvl_start[l]) * stride_w + m * D;
+      for (int p = 0; p < P; ++p) {
+        const int64_t wp = (qm * L + l) * P + p;
+        const T x = loc[2 * wp], y = loc[2 * wp + 1], a = attn[wp];
+        const T h_im = y * H - (T)0.5, w_im = x * W - (T)0.5;
+        const bool in_range = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+        int off[4]; bool ok[4]; T cw[4], lh, lw, hh, hw;
+        corner_setup<T>(h_im, w_im, H, W, stride_w, in_range, off, ok, cw, lh, lw, hh, hw);
+        T pa = 0, ph = 0, pw = 0;
+        for (int c = lane; c < D; c += 64) {
+          const T top = grad_out[qm * D + c];
+          T v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = ok[k] ? value[voff + off[k] + c] : (T)0;
+          const T gh = -hw * v[0] - lw * v[1] + hw * v[2] + lw * v[3];
+          const T gw = -hh * v[0] + hh * v[1] - lh * v[2] + lh * v[3];
+          const T val = cw[0] * v[0] + cw[1] * v[1] + cw[2] * v[2] + cw[3] * v[3];
+          pa += top * val; ph += top * gh; pw += top * gw;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (ok[k]) unsafeAtomicAdd(grad_value + voff + off[k] + c, cw[k] * a * top);
+        }
+        pa = wave_sum(pa); ph = wave_sum(ph); pw = wave_sum(pw);
+        if (lane == 0) {
+          grad_attn[wp] = pa;
+          grad_loc[2 * wp] = pw * a * W;
+          grad_loc[2 * wp + 1] = ph * a * H;
+        }
+      }
+    }
+  }
+}
+
+inline int round_up8(int64_t x) { return (int)((x + 7) / 8 * 8); }
+
+int check_common(const void *const *ptrs, int nptr, int batch, int spatial_size, int num_heads, int channels,
+                 int num_levels, int num_query, int num_point, int im2col_step, int dtype)
+{
+  for (int i = 0; i < nptr; ++i)
+    if (!ptrs[i]) return pd_set_error(PD_ERR_INVALID_ARG, "msda: null pointer argument (index %d)", i);
+  if (batch < 0 || spatial_size < 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 || num_query < 0 || num_point <= 0)
+    return pd_set_error(PD_ERR_INVALID_ARG, "msda: bad sizes batch=%d S=%d M=%d D=%d L=%d Lq=%d P=%d", batch, spatial_size,
+                        num_heads, channels, num_levels, num_query, num_point);
+  if (dtype != PD_F32 && dtype != PD_F64)
+    return pd_set_error(PD_ERR_INVALID_ARG, "msda: dtype %d not supported (float32/float64 only, as the reference)", dtype);
+  if (im2col_step <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "msda: im2col_step must be positive, got %d", im2col_step);
+  if (batch > 0) {
+    const int step = batch < im2col_step ? batch : im2col_step;
+    if (batch % step != 0)
+      return pd_set_error(PD_ERR_IM2COL_STEP, "batch(%d) must divide im2col_step(%d)", batch, step);
+  }
+  return PD_OK;
+}
+
+}  // namespace
+
+extern "C" int pd_msda_forward(const void *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                               const void *sampling_loc, const void *attn_weight, void *output, int batch,
+                               int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                               int num_point, int im2col_step, int dtype, void *stream_)
+{
+  const void *ptrs[] = {value, spatial_shapes, level_start_index, sampling_loc, attn_weight, output};
+  int rc = check_common(ptrs, 6, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, im2col_step, dtype);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t total_qm = (int64_t)batch * num_query * num_heads;
+  if (total_qm == 0) return PD_OK;
+  // (the reference splits the batch into im2col_step chunks only to bound its launch size; one launch here)
+  if (dtype == PD_F32 && channels == 32 && num_levels == 3 && num_point == 4 && total_qm < (1LL << 31)) {
+    const int nblocks = round_up8((total_qm + 31) / 32);
+    hipLaunchKernelGGL((msda_fwd_d32<3, 4>), dim3(nblocks), dim3(256), 0, stream, (const float *)value, spatial_shapes,
+                       level_start_index, (const float *)sampling_loc, (const float *)attn_weight, (float *)output,
+                       spatial_size, num_heads, num_query, (int)total_qm);
+  } else {
+    const int64_t n = total_qm * channels;
+    const int nblocks = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+    if (dtype == PD_F32)
+      hipLaunchKernelGGL(msda_fwd_generic<float>, dim3(nblocks), dim3(256), 0, stream, (const float *)value, spatial_shapes,
+                         level_start_index, (const float *)sampling_loc, (const float *)attn_weight, (float *)output, n,
+                         spatial_size, num_heads, channels, num_levels, num_query, num_point);
+    else
+      hipLaunchKernelGGL(msda_fwd_generic<double>, dim3(nblocks), dim3(256), 0, stream, (const double *)value, spatial_shapes,
+                         level_start_index, (const double *)sampling_loc, (const double *)attn_weight, (double *)output, n,
+                         spatial_size, num_heads, channels, num_levels, num_query, num_point);
+  }
+  return pd_check_launch("pd_msda_forward");
+}
+
+extern "C" int pd_msda_backward(const void *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                const void *sampling_loc, const void *attn_weight, const void *grad_output,
+                                void *grad_value, void *grad_sampling_loc, void *grad_attn_weight, int batch,
+                                int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                int num_point, int im2col_step, int dtype, void *stream_)
+{
+  const void *ptrs[] = {value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                        grad_value, grad_sampling_loc, grad_attn_weight};
+  int rc = check_common(ptrs, 9, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, im2col_step, dtype);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t esz = dtype == PD_F32 ? 4 : 8;
+  const int64_t total_qm = (int64_t)batch * num_query * num_heads;
+  const size_t nv = (size_t)batch * spatial_size * num_heads * channels;
+  const size_t nw = (size_t)total_qm * num_levels * num_point;
+  if (nv) (void)hipMemsetAsync(grad_value, 0, nv * esz, stream);
+  if (total_qm == 0) return pd_check_launch("pd_msda_backward");
+  if (!g_pd_dbg_force_generic && g_pd_dbg_atomic_scope == 0 && dtype == PD_F32 && channels == 32 && num_point == 4 &&
+      num_levels <= 8 && num_query == spatial_size && total_qm < (1LL << 31)) {
+    // self-attention geometry: LDS-windowed accumulation (every grad_loc / grad_attn slot is written once)
+    const int64_t nblocks = (int64_t)batch * kGmax * kGmax * num_levels * num_heads;
+    const size_t lds = ((size_t)kWin * kWin * 32 + 32) * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void *)msda_bwd_tiled_d32<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void *)msda_bwd_tiled_d32<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void *)msda_bwd_tiled_d32<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void *)msda_bwd_tiled_d32<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void *)msda_bwd_tiled_d32<4, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    auto tk = g_pd_dbg_ablate == 1 ? msda_bwd_tiled_d32<4, 1> : g_pd_dbg_ablate == 2 ? msda_bwd_tiled_d32<4, 2>
+            : g_pd_dbg_ablate == 4 ? msda_bwd_tiled_d32<4, 4> : g_pd_dbg_ablate == 7 ? msda_bwd_tiled_d32<4, 7> : msda_bwd_tiled_d32<4, 0>;
+    hipLaunchKernelGGL(tk, dim3((unsigned)nblocks), dim3(256), lds, stream, (const float *)value,
+                       spatial_shapes, level_start_index, (const float *)sampling_loc, (const float *)attn_weight,
+                       (const float *)grad_output, (float *)grad_value, (float *)grad_sampling_loc,
+                       (float *)grad_attn_weight, spatial_size, num_heads, num_levels);
+  } else if (!g_pd_dbg_force_generic && dtype == PD_F32 && channels == 32 && num_levels == 3 && num_point == 4 && total_qm < (1LL << 31)) {
+    // every (b,q,m,l,p) slot of grad_loc / grad_attn is written by the kernel: no memset needed
+    const int nblocks = round_up8((total_qm + 31) / 32);
+    auto kern = g_pd_dbg_atomic_scope == 1 ? msda_bwd_d32<3, 4, 1> : g_pd_dbg_atomic_scope == 2 ? msda_bwd_d32<3, 4, 2> : msda_bwd_d32<3, 4, 0>;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), 0, stream, (const float *)value, spatial_shapes,
+                       level_start_index, (const float *)sampling_loc, (const float *)attn_weight,
+                       (const float *)grad_output, (float *)grad_value, (float *)grad_sampling_loc,
+                       (float *)grad_attn_weight, spatial_size, num_heads, num_query, (int)total_qm);
+  } else {
+    (void)nw;
+    const int64_t nb = (total_qm + 3) / 4;
+    const int nblocks = (int)(nb < 65536 ? nb : 65536);
+    if (dtype == PD_F32)
+      hipLaunchKernelGGL(msda_bwd_generic<float>, dim3(nblocks), dim3(256), 0, stream, (const float *)value, spatial_shapes,
+                         level_start_index, (const float *)sampling_loc, (const float *)attn_weight,
+                         (const float *)grad_output, (float *)grad_value, (float *)grad_sampling_loc,
+                         (float *)grad_attn_weight, total_qm, spatial_size, num_heads, channels, num_levels, num_query,
+                         num_point);
+    else
+      hipLaunchKernelGGL(msda_bwd_generic<double>, dim3(nblocks), dim3(256), 0, stream, (const double *)value,
+                         spatial_shapes, level_start_index, (const double *)sampling_loc, (const double *)attn_weight,
+                         (const double *)grad_output, (double *)grad_value, (double *)grad_sampling_loc,
+                         (double *)grad_attn_weight, total_qm, spatial_size, num_heads, channels, num_levels, num_query,
+                         num_point);
+  }
+  return pd_check_launch("pd_msda_backward");
+}

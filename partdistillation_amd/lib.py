@@ -1,0 +1,71 @@
+"""ctypes binding of libpd_hip.so — the C-ABI declared in include/*.h.
+
+The HIP library is the product: there is NO fallback.  If the shared object is
+missing or a symbol is absent this module raises, and every op built on it
+raises with it (a GPU box must never silently run something else).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpd_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+PD_F32, PD_F64, PD_BF16 = 0, 1, 2
+ABI_VERSION = 1
+
+_c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/*.h declares
+SIGNATURES = {
+    "pd_msda_forward": (_c_int, [_c_vp] * 6 + [_c_int] * 9 + [_c_vp]),
+    "pd_msda_backward": (_c_int, [_c_vp] * 9 + [_c_int] * 9 + [_c_vp]),
+    "pd_last_error": (ctypes.c_char_p, []),
+    "pd_abi_version": (_c_int, []),
+    "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),
+}
+
+_lib = None
+
+
+class PdHipError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile every csrc/*.hip for gfx950 into libpd_hip.so (in-tree)."""
+    args = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    out = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout)
+    if out.returncode != 0:
+        raise PdHipError("building libpd_hip.so failed")
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PdHipError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C partdistillation_amd/csrc`). "
+            "partdistillation_amd has no CPU or PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise PdHipError(f"libpd_hip.so does not export `{name}` (stale build?)") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.pd_abi_version() != ABI_VERSION:
+        raise PdHipError(f"libpd_hip.so ABI {lib.pd_abi_version()} != binding {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise PdHipError(load().pd_last_error().decode() or f"libpd_hip error {rc}")

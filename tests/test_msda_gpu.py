@@ -1,0 +1,185 @@
+"""GPU parity tests of the HIP multi-scale deformable attention operator, called
+through the C-ABI (ctypes -> libpd_hip.so), against the oracle and the goldens.
+Re-implements the three checks of the reference's ops/test.py (:38-91)."""
+import pytest
+import torch
+
+import common as C
+from oracle import msda as omsda
+
+pytestmark = pytest.mark.gpu
+
+
+def _msda():
+    import partdistillation_amd.MultiScaleDeformableAttention as MSDA
+    from partdistillation_amd.modeling.pixel_decoder.ops.functions import MSDeformAttnFunction
+    return MSDA, MSDeformAttnFunction
+
+
+def _mk(N, M, D, shapes, Lq, P, dt, seed=0, spread=0.45):
+    shapes = torch.as_tensor(shapes, dtype=torch.long)
+    lvl = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    L = shapes.shape[0]
+    value = C.seeded((N, S, M, D), seed + 1, dtype=dt)
+    loc = C.seeded((N, Lq, M, L, P, 2), seed + 2, spread, dtype=dt) + 0.5
+    attn = C.seeded((N, Lq, M, L, P), seed + 3, dtype=dt).flatten(-2).softmax(-1).view(N, Lq, M, L, P)
+    gout = C.seeded((N, Lq, M * D), seed + 4, dtype=dt)
+    return value, shapes, lvl, loc, attn, gout
+
+
+def _cuda(*ts):
+    return [t.cuda() for t in ts]
+
+
+def test_reference_fixture_forward_double_and_float(golden):
+    """ops/test.py:38-67: fp64 allclose default tol; fp32 rtol 1e-2 atol 1e-3."""
+    MSDA, Fn = _msda()
+    g = golden("msda")["test_py"]
+    v, sh, lv, lo, at = _cuda(g["value"], g["shapes"], g["lvl"], g["loc"], g["attn"])
+    out64 = Fn.apply(v.double(), sh, lv, lo.double(), at.double(), 2).cpu()
+    assert torch.allclose(out64, g["out_f64"])
+    out32 = Fn.apply(v, sh, lv, lo, at, 2).cpu()
+    assert torch.allclose(out32, g["out_f32"], rtol=1e-2, atol=1e-3)
+    assert torch.allclose(out32, g["out_f32"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("D", [30, 32, 64, 71, 1025])
+def test_backward_double_all_channel_counts(D):
+    """ops/test.py:69-91 exercises D in {30,32,64,71,1025,2048,3096} with gradcheck;
+    here the analytic C oracle is the checker (fp64, atomics reorder only)."""
+    MSDA, Fn = _msda()
+    value, shapes, lvl, loc, attn, gout = _mk(1, 2, D, [(6, 4), (3, 2)], 2, 2, torch.float64, seed=D)
+    v, sh, lv, lo, at, go = _cuda(value, shapes, lvl, loc, attn, gout)
+    v.requires_grad_(), lo.requires_grad_(), at.requires_grad_()
+    out = Fn.apply(v, sh, lv, lo, at, 2)
+    torch.testing.assert_close(out.cpu(), omsda.msda_forward(value, shapes, lvl, loc, attn), rtol=1e-10, atol=1e-12)
+    out.backward(go)
+    gv, gl, ga = omsda.msda_backward(value, shapes, lvl, loc, attn, gout)
+    torch.testing.assert_close(v.grad.cpu(), gv, rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(lo.grad.cpu(), gl, rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(at.grad.cpu(), ga, rtol=1e-9, atol=1e-11)
+
+
+def test_gradcheck_numerical_small():
+    """the reference's own check (ops/test.py:69-84), D=4 and D=32 to keep it quick."""
+    MSDA, Fn = _msda()
+    for D in (4, 32):
+        value, shapes, lvl, loc, attn, _ = _mk(1, 2, D, [(6, 4), (3, 2)], 2, 2, torch.float64, seed=7)
+        v, sh, lv, lo, at = _cuda(value * 0.01, shapes, lvl, loc, attn)
+        v.requires_grad_(), lo.requires_grad_(), at.requires_grad_()
+        assert torch.autograd.gradcheck(Fn.apply, (v, sh, lv, lo, at, 2))
+
+
+@pytest.mark.parametrize("case", ["m2f", "ragged"])
+def test_goldens_forward_backward(golden, case):
+    MSDA, Fn = _msda()
+    g = golden("msda")[case]
+    c = {"m2f": dict(N=1, M=8, D=32, P=4, dt=torch.float32), "ragged": dict(N=2, M=3, D=5, P=3, dt=torch.float64)}[case]
+    shapes, lvl, Lq = g["shapes"], g["lvl"], int(g["Lq"])
+    S, Lv, dt = int(shapes.prod(1).sum()), shapes.shape[0], c["dt"]
+    value = C.seeded((c["N"], S, c["M"], c["D"]), 11, dtype=dt)
+    loc = C.seeded((c["N"], Lq, c["M"], Lv, c["P"], 2), 12, 0.45, dtype=dt) + 0.5
+    attn = C.seeded((c["N"], Lq, c["M"], Lv, c["P"]), 13, dtype=dt).flatten(-2).softmax(-1).view(c["N"], Lq, c["M"], Lv, c["P"])
+    gout = C.seeded((c["N"], Lq, c["M"] * c["D"]), 14, dtype=dt)
+    v, sh, lv, lo, at, go = _cuda(value, shapes, lvl, loc, attn, gout)
+    v.requires_grad_(), lo.requires_grad_(), at.requires_grad_()
+    out = Fn.apply(v, sh, lv, lo, at, 128)
+    tol = dict(rtol=1e-4, atol=1e-5) if dt == torch.float32 else dict(rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(out.cpu(), g["out"], **tol)
+    out.backward(go)
+    torch.testing.assert_close(v.grad.cpu(), g["grad_value"], **tol)
+    torch.testing.assert_close(lo.grad.cpu(), g["grad_loc"], **tol)
+    torch.testing.assert_close(at.grad.cpu(), g["grad_attn"], **tol)
+
+
+@pytest.mark.parametrize("N,Lq", [(1, 1), (2, 37), (3, 100), (2, 0)])
+def test_fast_path_vs_oracle_ragged_sizes(N, Lq):
+    """fp32 / D=32 / L=3 / P=4 fast path incl. partial last block, batch straddling, Lq=0,
+    points far outside the maps."""
+    MSDA, Fn = _msda()
+    value, shapes, lvl, loc, attn, gout = _mk(N, 8, 32, [(5, 3), (9, 11), (16, 20)], Lq, 4, torch.float32, seed=N * 100 + Lq, spread=0.7)
+    v, sh, lv, lo, at, go = _cuda(value, shapes, lvl, loc, attn, gout)
+    out = MSDA.ms_deform_attn_forward(v, sh, lv, lo, at, 128)
+    assert out.shape == (N, Lq, 256)
+    torch.testing.assert_close(out.cpu(), omsda.msda_forward(value, shapes, lvl, loc, attn), rtol=1e-4, atol=1e-5)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, lv, lo, at, go, 128)
+    ov, ol, oa = omsda.msda_backward(value, shapes, lvl, loc, attn, gout)
+    torch.testing.assert_close(gv.cpu(), ov, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gl.cpu(), ol, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ga.cpu(), oa, rtol=1e-4, atol=1e-4)
+
+
+def test_nan_and_out_of_range_locations_contribute_nothing():
+    MSDA, Fn = _msda()
+    value, shapes, lvl, loc, attn, gout = _mk(1, 8, 32, [(4, 4), (8, 8), (16, 16)], 16, 4, torch.float32, seed=5)
+    loc[0, 3] = float("nan")
+    loc[0, 4] = 7.0
+    loc[0, 5] = -3.0
+    v, sh, lv, lo, at, go = _cuda(value, shapes, lvl, loc, attn, gout)
+    out = MSDA.ms_deform_attn_forward(v, sh, lv, lo, at, 128)
+    assert torch.isfinite(out).all()
+    assert out[0, 3:6].abs().sum() == 0
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, lv, lo, at, go, 128)
+    assert torch.isfinite(gv).all() and torch.isfinite(gl).all() and torch.isfinite(ga).all()
+    assert gl[0, 3:6].abs().sum() == 0 and ga[0, 3:6].abs().sum() == 0
+
+
+def test_error_behaviour_matches_reference():
+    """ms_deform_attn_cuda.cu:34-58 / ms_deform_attn.h:45."""
+    MSDA, Fn = _msda()
+    value, shapes, lvl, loc, attn, gout = _mk(3, 2, 4, [(4, 4)], 5, 2, torch.float32)
+    v, sh, lv, lo, at, go = _cuda(value, shapes, lvl, loc, attn, gout)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        MSDA.ms_deform_attn_forward(value, shapes, lvl, loc, attn, 2)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        MSDA.ms_deform_attn_forward(v.transpose(2, 3).contiguous().transpose(2, 3), sh, lv, lo, at, 2)
+    with pytest.raises(RuntimeError, match="must divide im2col_step"):
+        MSDA.ms_deform_attn_forward(v, sh, lv, lo, at, 2)            # 3 % 2 != 0
+    with pytest.raises(RuntimeError, match="must divide im2col_step"):
+        MSDA.ms_deform_attn_backward(v, sh, lv, lo, at, go, 2)
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward(v.half(), sh, lv, lo.half(), at.half(), 3)
+    MSDA.ms_deform_attn_forward(v, sh, lv, lo, at, 3)
+    MSDA.ms_deform_attn_forward(v, sh, lv, lo, at, 128)               # min(batch, step)
+
+
+def test_full_size_linearity_and_torch_crosscheck():
+    """BASELINE config-2 geometry (N=2, 1024^2: 32^2+64^2+128^2 tokens, M=8, D=32,
+    L=3, P=4): size-independent properties — linearity in value and in the
+    attention weights — plus a cross-check against the grid_sample restatement
+    evaluated on the GPU."""
+    MSDA, Fn = _msda()
+    shapes = [(32, 32), (64, 64), (128, 128)]
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    sh = torch.as_tensor(shapes, dtype=torch.long, device="cuda")
+    lv = torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1]))
+    v1 = torch.randn(2, S, 8, 32, device="cuda", generator=g)
+    v2 = torch.randn(2, S, 8, 32, device="cuda", generator=g)
+    loc = torch.rand(2, S, 8, 3, 4, 2, device="cuda", generator=g) * 1.2 - 0.1
+    a1 = torch.rand(2, S, 8, 3, 4, device="cuda", generator=g)
+    a2 = torch.rand(2, S, 8, 3, 4, device="cuda", generator=g)
+    f = lambda v, a: MSDA.ms_deform_attn_forward(v, sh, lv, loc, a, 128)
+    o11, o21, o12 = f(v1, a1), f(v2, a1), f(v1, a2)
+    torch.testing.assert_close(f(2.0 * v1 - 0.5 * v2, a1), 2.0 * o11 - 0.5 * o21, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(f(v1, a1 + 3.0 * a2), o11 + 3.0 * o12, rtol=1e-4, atol=1e-4)
+    ref = omsda.msda_torch(v1, sh.cpu(), loc, a1)
+    torch.testing.assert_close(o11, ref, rtol=1e-4, atol=1e-4)
+    # backward: adjoint identity <out(v), g> == <v, grad_value(g)>  (out is linear in value)
+    go = torch.randn(2, S, 256, device="cuda", generator=g)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v1, sh, lv, loc, a1, go, 128)
+    lhs = (o11.double() * go.double()).sum()
+    rhs = (v1.double() * gv.double()).sum()
+    torch.testing.assert_close(lhs, rhs, rtol=1e-5, atol=1e-3)
+    # grad_attn is the same contraction with attn replaced by its gradient: <ga, a1> == <out, go>
+    torch.testing.assert_close((ga.double() * a1.double()).sum(), lhs, rtol=1e-5, atol=1e-3)
+    # autograd of the torch restatement on the same inputs
+    v1r, locr, a1r = v1.clone().requires_grad_(), loc.clone().requires_grad_(), a1.clone().requires_grad_()
+    omsda.msda_torch(v1r, sh.cpu(), locr, a1r).backward(go)
+    torch.testing.assert_close(gv, v1r.grad, rtol=1e-3, atol=1e-3)
+    # grad_loc is discontinuous where a sample sits exactly on a pixel boundary (floor() flips between
+    # y*H-0.5 and grid_sample's ((2y-1)+1)*H/2-0.5 roundings): allow a 1e-5 fraction of such points
+    bad = ~torch.isclose(gl, locr.grad, rtol=1e-3, atol=2e-2)
+    assert bad.float().mean().item() < 1e-5
+    torch.testing.assert_close(ga, a1r.grad, rtol=1e-3, atol=1e-3)

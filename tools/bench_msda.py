@@ -1,0 +1,73 @@
+"""Micro-benchmark of the HIP MSDA kernels at BASELINE config-2 geometry
+(N=2, 1024^2 image -> 32^2+64^2+128^2 = 21504 tokens, M=8, D=32, L=3, P=4, fp32).
+Prints achieved algorithmic GB/s (fwd 137.6 MB, bwd 275.2 MB per launch)."""
+import argparse
+import json
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import partdistillation_amd.MultiScaleDeformableAttention as MSDA
+
+
+def make(N=2, img=1024, spread=0.02, device="cuda", seed=0):
+    shapes = [(img // 32,) * 2, (img // 16,) * 2, (img // 8,) * 2]
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator(device=device).manual_seed(seed)
+    sh = torch.as_tensor(shapes, dtype=torch.long, device=device)
+    lv = torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1]))
+    value = torch.randn(N, S, 8, 32, device=device, generator=g)
+    # reference points = pixel centres of each level (msdeformattn.py:145-157) + small learned offsets
+    refs = []
+    for h, w in shapes:
+        ys, xs = torch.meshgrid((torch.arange(h, device=device) + 0.5) / h, (torch.arange(w, device=device) + 0.5) / w, indexing="ij")
+        refs.append(torch.stack((xs.reshape(-1), ys.reshape(-1)), -1))
+    ref = torch.cat(refs, 0)[None, :, None, None, None, :]
+    loc = (ref + spread * torch.randn(N, S, 8, 3, 4, 2, device=device, generator=g)).contiguous()
+    attn = torch.softmax(torch.randn(N, S, 8, 12, device=device, generator=g), -1).view(N, S, 8, 3, 4).contiguous()
+    gout = torch.randn(N, S, 256, device=device, generator=g)
+    return value, sh, lv, loc, attn, gout
+
+
+def alg_bytes(N, S, M=8, D=32, L=3, P=4, esz=4):
+    v = N * S * M * D * esz
+    lo = N * S * M * L * P * 2 * esz
+    at = N * S * M * L * P * esz
+    out = N * S * M * D * esz
+    return v + lo + at + out, 2 * (v + lo + at) + out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--img", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--scope", type=int, default=0)
+    ap.add_argument("--generic", type=int, default=0)
+    ap.add_argument("--ablate", type=int, default=0)
+    ap.add_argument("--spread", type=float, default=0.02)
+    a = ap.parse_args()
+    from partdistillation_amd import lib
+    lib.load().pd_debug_set(b"msda_bwd_atomic_scope", a.scope)
+    lib.load().pd_debug_set(b"msda_force_generic", a.generic)
+    lib.load().pd_debug_set(b"msda_ablate", a.ablate)
+    value, sh, lv, loc, attn, gout = make(a.batch, a.img, a.spread)
+    S = value.shape[1]
+    fb, bb = alg_bytes(a.batch, S)
+    for _ in range(5):
+        MSDA.ms_deform_attn_forward(value, sh, lv, loc, attn, 128)
+        MSDA.ms_deform_attn_backward(value, sh, lv, loc, attn, gout, 128)
+    res = {}
+    for name, fn, nbytes in (("fwd", lambda: MSDA.ms_deform_attn_forward(value, sh, lv, loc, attn, 128), fb),
+                             ("bwd", lambda: MSDA.ms_deform_attn_backward(value, sh, lv, loc, attn, gout, 128), bb)):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
+        for s, e in ev:
+            s.record(); fn(); e.record()
+        torch.cuda.synchronize()
+        ts = sorted(s.elapsed_time(e) for s, e in ev)
+        med = ts[len(ts) // 2]
+        res[name] = {"ms_median": med, "ms_min": ts[0], "alg_MB": nbytes / 1e6, "GBps": nbytes / med / 1e6}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
