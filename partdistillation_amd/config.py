@@ -1,0 +1,141 @@
+"""Config keys of the hot path — same names and defaults as the reference's
+``part_distillation/config.py:10-276`` (the key names ARE the API surface, SURVEY
+Appendix F), declared as data.  ``setup_cfg()`` = get_cfg() + every add_*()."""
+from .compat.config import CN, get_cfg
+
+_MASKFORMER2 = {
+    "INPUT": dict(DATASET_MAPPER_NAME="mask_former_semantic", COLOR_AUG_SSD=False, SIZE_DIVISIBILITY=-1,
+                  IMAGE_SIZE_BASE=640, IMAGE_SIZE=1024, MIN_SCALE=0.1, MAX_SCALE=2.0),
+    "INPUT.CROP": dict(SINGLE_CATEGORY_MAX_AREA=1.0),
+    "SOLVER": dict(WEIGHT_DECAY_EMBED=0.0, OPTIMIZER="ADAMW", BACKBONE_MULTIPLIER=0.1),
+    "MODEL.MASK_FORMER": dict(
+        DEEP_SUPERVISION=True, NO_OBJECT_WEIGHT=0.1, CLASS_WEIGHT=1.0, DICE_WEIGHT=1.0, MASK_WEIGHT=20.0,
+        NHEADS=8, DROPOUT=0.1, DIM_FEEDFORWARD=2048, ENC_LAYERS=0, DEC_LAYERS=6, PRE_NORM=False, HIDDEN_DIM=256,
+        NUM_OBJECT_QUERIES=100, TRANSFORMER_IN_FEATURE="res5", ENFORCE_INPUT_PROJ=False, SIZE_DIVISIBILITY=32,
+        TRANSFORMER_DECODER_NAME="MultiScaleMaskedTransformerDecoder", TRAIN_NUM_POINTS=112 * 112,
+        TRAIN_NUM_POINTS_MATCH=112 * 112, TRAIN_NUM_POINTS_LOSS=112 * 112, OVERSAMPLE_RATIO=3.0,
+        IMPORTANCE_SAMPLE_RATIO=0.75, FREEZE_KEYS=[], QUERY_FEATURE_NORMALIZE=False),
+    "MODEL.MASK_FORMER.TEST": dict(SEMANTIC_ON=True, INSTANCE_ON=False, PANOPTIC_ON=False, OBJECT_MASK_THRESHOLD=0.0,
+                                   OVERLAP_THRESHOLD=0.0, SEM_SEG_POSTPROCESSING_BEFORE_INFERENCE=False),
+    "MODEL.SEM_SEG_HEAD": dict(MASK_DIM=256, TRANSFORMER_ENC_LAYERS=0, PIXEL_DECODER_NAME="BasePixelDecoder",
+                               DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES=["res3", "res4", "res5"],
+                               DEFORMABLE_TRANSFORMER_ENCODER_N_POINTS=4, DEFORMABLE_TRANSFORMER_ENCODER_N_HEADS=8),
+    "MODEL.SWIN": dict(PRETRAIN_IMG_SIZE=224, PATCH_SIZE=4, EMBED_DIM=96, DEPTHS=[2, 2, 6, 2], NUM_HEADS=[3, 6, 12, 24],
+                       WINDOW_SIZE=7, MLP_RATIO=4.0, QKV_BIAS=True, QK_SCALE=None, DROP_RATE=0.0, ATTN_DROP_RATE=0.0,
+                       DROP_PATH_RATE=0.3, APE=False, PATCH_NORM=True, OUT_FEATURES=["res2", "res3", "res4", "res5"],
+                       USE_CHECKPOINT=False),
+}
+
+_WANDB = {"WANDB": dict(DISABLE_WANDB=False, GROUP=None, PROJECT="", VIS_PERIOD_TRAIN=200, VIS_PERIOD_TEST=20,
+                        RUN_NAME="output", VIS_TOPK=10),
+          "DATASETS": dict(DEBUG=False), "": dict(VIS_OUTPUT_DIR="")}
+
+_PROPOSAL_LEARNING = {"PROPOSAL_LEARNING": dict(
+    MIN_OBJECT_AREA_RATIO=0.001, MIN_AREA_RATIO=0.0, MIN_SCORE=-1.0, DATASET_PATH_LIST=[], FILTERED_CODE_PATH_LIST=[],
+    EXCLUDE_CODE_PATH="", PATH_ONLY=False, USE_PER_PIXEL_LABEL=True, DATASET_PATH="", LABEL_PERCENTAGE=100,
+    APPLY_MASKING_WITH_OBJECT_MASK=True, POSTPROCESS_TYPES=[], DEBUG=False)}
+
+_CUSTOM_DATASETS = {
+    "CUSTOM_DATASETS": dict(BASE_SIZE=-1, AUG_NAME_LIST=[], USE_MERGED_GT=True, LABEL_PERCENTAGE=100),
+    "CUSTOM_DATASETS.PASCAL_PARTS": dict(IMAGES_DIRNAME="", ANNOTATIONS_DIRNAME="", SUBSET_CLASS_NAMES=[], DEBUG=False),
+    "CUSTOM_DATASETS.CITYSCAPES_PART": dict(IMAGES_DIRNAME="", ANNOTATIONS_DIRNAME="", PATH_ONLY=False, DEBUG=False),
+    "CUSTOM_DATASETS.PART_IMAGENET": dict(IMAGES_DIRNAME="", ANNOTATIONS_DIRNAME="", DEBUG=False)}
+
+_PROPOSAL_GENERATION = {"PROPOSAL_GENERATION": dict(
+    DATASET_NAME="imagenet_22k_train", OBJECT_MASK_TYPE="detic",
+    OBJECT_MASK_PATH="pseudo_labels/object_labels/imagenet_22k_train/detic_predictions/", NUM_SUPERPIXEL_CLUSTERS=4,
+    DISTANCE_METRIC="l2", FEATURE_NORMALIZE=False, BACKBONE_FEATURE_KEY_LIST=["res4"], TOTAL_PARTITIONS=-1,
+    PARTITION_INDEX=-1, BATCH_SIZE=4, WITH_GIVEN_MASK=False, USE_PART_IMAGENET_CLASSES=False,
+    FILTERED_CODE_PATH_LIST=[], EXCLUDE_CODE_PATH="", SINGLE_CLASS_CODE="", DEBUG=False)}
+
+_PART_RANKING = {"PART_RANKING": dict(
+    DATASET_PATH="", DATASET_PATH_LIST=[], FILTERED_CODE_PATH_LIST=[], EXCLUDE_CODE_PATH="", PATH_ONLY=False,
+    NUM_CLUSTERS=8, CLASSIFIER_METRIC="l2", PROPOSAL_KEY="decoder_output", PROPOSAL_FEATURE_NORM=True,
+    MIN_OBJECT_AREA_RATIO=0.001, MIN_AREA_RATIO_1=0.0, MIN_AREA_RATIO_2=0.0, MIN_SCORE_1=0.0, MIN_SCORE_2=0.0,
+    USE_PER_PIXEL_LABEL_DURING_CLUSTERING=True, USE_PER_PIXEL_LABEL_DURING_LABELING=True,
+    APPLY_MASKING_WITH_OBJECT_MASK=True, TOTAL_PARTITIONS=-1, PARTITION_INDEX=-1, DEBUG=False)}
+
+_PART_DISTILLATION = {"PART_DISTILLATION": dict(
+    DATASET_PATH="", DATASET_PATH_LIST=[], FILTERED_CODE_PATH_LIST=[], EXCLUDE_CODE_PATH="", PATH_ONLY=False,
+    USE_PER_PIXEL_LABEL=True, NUM_PART_CLASSES=8, NUM_OBJECT_CLASSES=1000, MIN_OBJECT_AREA_RATIO=0.001,
+    MIN_AREA_RATIO=-1.0, MIN_SCORE=-1.0, USE_ORACLE_CLASSIFIER=False, APPLY_MASKING_WITH_OBJECT_MASK=True,
+    TOTAL_PARTITIONS=-1, PARTITION_INDEX=-1, SET_IMAGE_SQUARE=False, DEBUG=False)}
+
+_PIXEL_GROUPING = {"PIXEL_GROUPING": dict(NUM_SUPERPIXEL_CLUSTERS=4, DISTANCE_METRIC="l2",
+                                          BACKBONE_FEATURE_KEY_LIST=["res4"], FEATURE_NORMALIZE=False, DEBUG=False)}
+_SUPERVISED = {"SUPERVISED_MODEL": dict(USE_PER_PIXEL_LABEL=False, APPLY_MASKING_WITH_OBJECT_MASK=True,
+                                        CLASS_AGNOSTIC_LEARNING=False, CLASS_AGNOSTIC_INFERENCE=False)}
+_FEWSHOT = {"FEWSHOT_LEARNING": dict(LABEL_PERCENTAGE=100)}
+
+# keys of THIS build (not in the reference): how the MI355X path executes; every default keeps reference semantics
+_AMD = {"MODEL.AMD": dict(
+    SPARSE_MASK_LOSS=True,      # training never materialises [B,Q,H/4,W/4] masks; losses read point samples
+    DEVICE_MATCHER=True,        # Hungarian assignment on the GPU (no host round-trip per image per layer)
+    FUSED_OPTIMIZER=True,       # multi-tensor clipped AdamW kernel
+    DDP_BUCKET_MB=25)}
+
+
+def _apply(cfg, table):
+    for path, kv in table.items():
+        node = cfg
+        for part in [p for p in path.split(".") if p]:
+            if part not in node:
+                node[part] = CN()
+            node = node[part]
+        for k, v in kv.items():
+            node[k] = list(v) if isinstance(v, list) else v
+
+
+def add_maskformer2_config(cfg):
+    _apply(cfg, _MASKFORMER2)
+    _apply(cfg, _AMD)
+
+
+def add_wandb_config(cfg):
+    _apply(cfg, _WANDB)
+
+
+def add_proposal_learning_config(cfg):
+    _apply(cfg, _PROPOSAL_LEARNING)
+
+
+def add_custom_datasets_config(cfg):
+    _apply(cfg, _CUSTOM_DATASETS)
+
+
+def add_proposal_generation_config(cfg):
+    _apply(cfg, _PROPOSAL_GENERATION)
+
+
+def add_part_ranking_config(cfg):
+    _apply(cfg, _PART_RANKING)
+
+
+def add_part_distillation_config(cfg):
+    _apply(cfg, _PART_DISTILLATION)
+
+
+def add_pixel_grouping_confing(cfg):     # (sic) the reference's spelling, config.py:258
+    _apply(cfg, _PIXEL_GROUPING)
+
+
+def add_supervised_model_config(cfg):
+    _apply(cfg, _SUPERVISED)
+
+
+def add_fewshot_learning_config(cfg):
+    _apply(cfg, _FEWSHOT)
+
+
+def setup_cfg(config_file=None, opts=()):
+    """get_cfg() + all add_*_config + yaml + KEY VALUE overrides (the reference
+    drivers' ``setup``, part_proposal_train_net.py:129-191, minus datasets)."""
+    cfg = get_cfg()
+    for fn in (add_maskformer2_config, add_wandb_config, add_proposal_learning_config, add_custom_datasets_config,
+               add_proposal_generation_config, add_part_ranking_config, add_part_distillation_config,
+               add_pixel_grouping_confing, add_supervised_model_config, add_fewshot_learning_config):
+        fn(cfg)
+    if config_file:
+        cfg.merge_from_file(config_file)
+    cfg.merge_from_list(list(opts))
+    return cfg

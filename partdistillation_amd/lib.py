@@ -21,6 +21,7 @@ _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 SIGNATURES = {
     "pd_msda_forward": (_c_int, [_c_vp] * 6 + [_c_int] * 9 + [_c_vp]),
     "pd_msda_backward": (_c_int, [_c_vp] * 9 + [_c_int] * 9 + [_c_vp]),
+    "pd_lsa_batched": (_c_int, [_c_vp] * 4 + [_c_int] * 3 + [_c_vp]),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_abi_version": (_c_int, []),
     "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),

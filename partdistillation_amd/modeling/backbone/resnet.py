@@ -1,0 +1,142 @@
+"""ResNet backbone with the detectron2 0.6 ``build_resnet_backbone`` surface
+(SURVEY §8a row a3, Appendix D): BasicStem 7x7/2 + maxpool, bottleneck stages
+[3,4,6,3] (R50) / [3,4,23,3] (R101), stride on the 3x3 unless STRIDE_IN_1X1,
+FrozenBN, outputs res2..res5; state_dict keys ``stem.conv1.*``,
+``res{2..5}.{i}.{conv1,conv2,conv3,shortcut}.{weight,norm.*}``.
+
+The reference takes this class from detectron2 (un-vendored): "parity unpinned"
+by the reference's tests; pinned against oracle/step_ref.py::resnet50_forward.
+Runs channels_last so MIOpen sees NHWC; the frozen-BN affine is folded into
+the conv epilogue as (scale-folded weight, bias) — one conv call per layer.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ...compat import BACKBONE_REGISTRY, ShapeSpec
+from ...compat.layers import Conv2d, FrozenBatchNorm2d, c2_msra_fill, get_norm
+
+
+def _conv_bn(conv, x):
+    """conv followed by its norm; FrozenBN is folded into weight/bias."""
+    norm = conv.norm
+    if isinstance(norm, FrozenBatchNorm2d):
+        scale, bias = norm.scale_bias()
+        w = conv.weight * scale.view(-1, 1, 1, 1).to(conv.weight.dtype)
+        return F.conv2d(x, w, bias.to(conv.weight.dtype), conv.stride, conv.padding, conv.dilation, conv.groups)
+    y = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return norm(y) if norm is not None else y
+
+
+class BasicStem(nn.Module):
+    def __init__(self, in_channels=3, out_channels=64, norm="FrozenBN"):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, 4
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=7, stride=2, padding=3, bias=False,
+                            norm=get_norm(norm, out_channels))
+        c2_msra_fill(self.conv1)
+
+    def forward(self, x):
+        x = F.relu_(_conv_bn(self.conv1, x))
+        return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+
+
+class BottleneckBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, *, bottleneck_channels, stride=1, num_groups=1, norm="FrozenBN",
+                 stride_in_1x1=False, dilation=1):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        self.shortcut = None
+        if in_channels != out_channels:
+            self.shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=stride, bias=False,
+                                   norm=get_norm(norm, out_channels))
+        s1, s3 = (stride, 1) if stride_in_1x1 else (1, stride)
+        self.conv1 = Conv2d(in_channels, bottleneck_channels, kernel_size=1, stride=s1, bias=False,
+                            norm=get_norm(norm, bottleneck_channels))
+        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=s3, padding=dilation,
+                            bias=False, groups=num_groups, dilation=dilation, norm=get_norm(norm, bottleneck_channels))
+        self.conv3 = Conv2d(bottleneck_channels, out_channels, kernel_size=1, bias=False,
+                            norm=get_norm(norm, out_channels))
+        for layer in (self.conv1, self.conv2, self.conv3, self.shortcut):
+            if layer is not None:
+                c2_msra_fill(layer)
+
+    def forward(self, x):
+        out = F.relu_(_conv_bn(self.conv1, x))
+        out = F.relu_(_conv_bn(self.conv2, out))
+        out = _conv_bn(self.conv3, out)
+        sc = _conv_bn(self.shortcut, x) if self.shortcut is not None else x
+        return F.relu_(out + sc)
+
+
+class ResNet(nn.Module):
+    def __init__(self, stem, stages, out_features):
+        super().__init__()
+        self.stem = stem
+        self._out_features = list(out_features)
+        self._out_feature_strides, self._out_feature_channels = {"stem": stem.stride}, {"stem": stem.out_channels}
+        self.stage_names = []
+        cur = stem.stride
+        for i, blocks in enumerate(stages):
+            name = "res" + str(i + 2)
+            self.add_module(name, nn.Sequential(*blocks))
+            self.stage_names.append(name)
+            cur = cur * blocks[0].stride
+            self._out_feature_strides[name] = cur
+            self._out_feature_channels[name] = blocks[-1].out_channels
+
+    @property
+    def size_divisibility(self):
+        return 0
+
+    def forward(self, x):
+        assert x.dim() == 4, f"ResNet takes an input of shape (N, C, H, W). Got {x.shape} instead!"
+        x = x.contiguous(memory_format=torch.channels_last)
+        outputs = {}
+        x = self.stem(x)
+        if "stem" in self._out_features:
+            outputs["stem"] = x
+        for name in self.stage_names:
+            x = getattr(self, name)(x)
+            if name in self._out_features:
+                outputs[name] = x
+        return outputs
+
+    def output_shape(self):
+        return {n: ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n])
+                for n in self._out_features}
+
+    def freeze(self, freeze_at=0):
+        if freeze_at >= 1:
+            for p in self.stem.parameters():
+                p.requires_grad = False
+        for idx, name in enumerate(self.stage_names, start=2):
+            if freeze_at >= idx:
+                for p in getattr(self, name).parameters():
+                    p.requires_grad = False
+        return self
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_backbone(cfg, input_shape):
+    r = cfg.MODEL.RESNETS
+    norm = r.NORM
+    stem = BasicStem(in_channels=input_shape.channels, out_channels=r.STEM_OUT_CHANNELS, norm=norm)
+    depth = r.DEPTH
+    blocks_per_stage = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}[depth]
+    out_features = r.OUT_FEATURES
+    last = max({"res2": 2, "res3": 3, "res4": 4, "res5": 5}[f] for f in out_features)
+    in_c, out_c, bott = r.STEM_OUT_CHANNELS, r.RES2_OUT_CHANNELS, r.NUM_GROUPS * r.WIDTH_PER_GROUP
+    stages = []
+    for idx, stage in enumerate(range(2, last + 1)):
+        dilation = r.RES5_DILATION if stage == 5 else 1
+        first_stride = 1 if idx == 0 or (stage == 5 and dilation == 2) else 2
+        blocks = []
+        for b in range(blocks_per_stage[idx]):
+            blocks.append(BottleneckBlock(in_c, out_c, bottleneck_channels=bott, stride=first_stride if b == 0 else 1,
+                                          num_groups=r.NUM_GROUPS, norm=norm, stride_in_1x1=r.STRIDE_IN_1X1,
+                                          dilation=dilation))
+            in_c = out_c
+        stages.append(blocks)
+        out_c, bott = out_c * 2, bott * 2
+    return ResNet(stem, stages, out_features).freeze(cfg.MODEL.BACKBONE.FREEZE_AT)

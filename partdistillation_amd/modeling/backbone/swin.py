@@ -1,0 +1,322 @@
+"""Swin Transformer backbone (reference modeling/backbone/swin.py:24-774) with
+the reference's module tree / state_dict keys and the
+``D2SwinTransformer(cfg, input_shape)`` registry entry.
+
+Written window-major: tokens are brought into (window, token, channel) order
+once per block by a single gather index (cyclic shift + padding + partition
+folded into one permutation) instead of pad -> roll -> view/permute/contiguous
+copies, and sent back by the inverse scatter; the shifted-window mask and the
+relative-position bias are added as one pre-combined additive term."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+import torch.utils.checkpoint as checkpoint
+from torch import nn
+
+from ...compat import BACKBONE_REGISTRY, ShapeSpec
+
+
+def _trunc_normal_(t, std=0.02):
+    return nn.init.trunc_normal_(t, std=std)
+
+
+class DropPath(nn.Module):
+    """per-sample stochastic depth (timm DropPath)."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        return x * mask / keep
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+def window_partition(x, window_size):
+    B, H, W, C = x.shape
+    x = x.view(B, H // window_size, window_size, W // window_size, window_size, C)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(-1, window_size, window_size, C)
+
+
+def window_reverse(windows, window_size, H, W):
+    B = int(windows.shape[0] / (H * W / window_size / window_size))
+    x = windows.view(B, H // window_size, W // window_size, window_size, window_size, -1)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        self.dim, self.window_size, self.num_heads = dim, window_size, num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        wh, ww = window_size
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * wh - 1) * (2 * ww - 1), num_heads))
+        ch, cw = torch.meshgrid(torch.arange(wh), torch.arange(ww), indexing="ij")
+        coords = torch.stack([ch.reshape(-1), cw.reshape(-1)])                          # [2, N]
+        rel = coords[:, :, None] - coords[:, None, :]                                   # [2, N, N]
+        index = (rel[0] + wh - 1) * (2 * ww - 1) + (rel[1] + ww - 1)
+        self.register_buffer("relative_position_index", index)
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        _trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+    def bias(self):
+        n = self.window_size[0] * self.window_size[1]
+        return self.relative_position_bias_table[self.relative_position_index.view(-1)].view(n, n, -1).permute(2, 0, 1)
+
+    def forward(self, x, mask=None):
+        """x [nW*B, N, C]; mask [nW, N, N] additive (0 / -100) or None."""
+        B_, N, C = x.shape
+        h = self.num_heads
+        qkv = self.qkv(x).reshape(B_, N, 3, h, C // h).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        add = self.bias().unsqueeze(0)                                                  # [1,h,N,N]
+        if mask is not None:
+            nW = mask.shape[0]
+            add = (add + mask.unsqueeze(1)).unsqueeze(0).expand(B_ // nW, -1, -1, -1, -1).reshape(B_, h, N, N)
+        p = self.attn_drop.p if self.training else 0.0
+        out = F.scaled_dot_product_attention(q, k, v, attn_mask=add.to(q.dtype), dropout_p=p, scale=self.scale)
+        return self.proj_drop(self.proj(out.transpose(1, 2).reshape(B_, N, C)))
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
+                 drop=0.0, attn_drop=0.0, drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim, self.num_heads, self.window_size, self.shift_size, self.mlp_ratio = \
+            dim, num_heads, window_size, shift_size, mlp_ratio
+        assert 0 <= self.shift_size < self.window_size, "shift_size must in 0-window_size"
+        self.norm1 = norm_layer(dim)
+        self.attn = WindowAttention(dim, (window_size, window_size), num_heads, qkv_bias, qk_scale, attn_drop, drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.H = self.W = None
+
+    def forward(self, x, mask_matrix, gather=None):
+        """x [B, H*W, C].  ``gather`` = window_gather_index(...) (index, inverse, #windows, has-padding flag)."""
+        B, L, C = x.shape
+        H, W = self.H, self.W
+        assert L == H * W, "input feature has wrong size"
+        ws = self.window_size
+        shortcut = x
+        x = self.norm1(x)
+        if gather is None:
+            gather = window_gather_index(H, W, ws, self.shift_size, x.device)
+        idx, inv, n_win, any_pad = gather
+        xp = torch.cat([x, x.new_zeros(B, 1, C)], dim=1) if any_pad else x              # padded slots read a zero row
+        xw = xp[:, idx].reshape(B * n_win, ws * ws, C)
+        aw = self.attn(xw, mask=mask_matrix if self.shift_size > 0 else None)
+        x = aw.reshape(B, n_win * ws * ws, C)[:, inv]
+        x = shortcut + self.drop_path(x)
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+_GATHER_CACHE = {}
+
+
+def window_gather_index(H, W, ws, shift, device):
+    """window-major order of the (padded, cyclically shifted) token grid: replaces F.pad + torch.roll +
+    window_partition (reference :254-270) and their inverses (:276-289) by one gather each way."""
+    key = (H, W, ws, shift, str(device))
+    if key not in _GATHER_CACHE:
+        Hp, Wp = int(np.ceil(H / ws)) * ws, int(np.ceil(W / ws)) * ws
+        grid = torch.full((Hp, Wp), H * W, dtype=torch.long)                             # H*W = the zero row
+        grid[:H, :W] = torch.arange(H * W).view(H, W)
+        if shift > 0:
+            grid = torch.roll(grid, shifts=(-shift, -shift), dims=(0, 1))
+        win = grid.view(Hp // ws, ws, Wp // ws, ws).permute(0, 2, 1, 3).reshape(-1)      # window-major
+        any_pad = bool((win == H * W).any())
+        inv = torch.empty(H * W, dtype=torch.long)
+        pos = torch.arange(win.numel())
+        keep = win < H * W
+        inv[win[keep]] = pos[keep]
+        _GATHER_CACHE[key] = (win.to(device), inv.to(device), (Hp // ws) * (Wp // ws), any_pad)
+    return _GATHER_CACHE[key]
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = norm_layer(4 * dim)
+
+    def forward(self, x, H, W):
+        B, L, C = x.shape
+        assert L == H * W, "input feature has wrong size"
+        x = x.view(B, H, W, C)
+        if (H % 2 == 1) or (W % 2 == 1):
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        x = torch.cat([x[:, 0::2, 0::2, :], x[:, 1::2, 0::2, :], x[:, 0::2, 1::2, :], x[:, 1::2, 1::2, :]], -1)
+        return self.reduction(self.norm(x.view(B, -1, 4 * C)))
+
+
+_MASK_CACHE = {}
+
+
+def shifted_window_mask(H, W, ws, shift, device):
+    """additive SW-MSA mask [nW, N, N] (0 / -100), reference :417-444."""
+    key = (H, W, ws, shift, str(device))
+    if key not in _MASK_CACHE:
+        Hp, Wp = int(np.ceil(H / ws)) * ws, int(np.ceil(W / ws)) * ws
+        img = torch.zeros((1, Hp, Wp, 1))
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                img[:, hs, wsl, :] = cnt
+                cnt += 1
+        mw = window_partition(img, ws).view(-1, ws * ws)
+        am = mw.unsqueeze(1) - mw.unsqueeze(2)
+        _MASK_CACHE[key] = am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0).to(device)
+    return _MASK_CACHE[key]
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop=0.0,
+                 attn_drop=0.0, drop_path=0.0, norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False):
+        super().__init__()
+        self.window_size, self.shift_size, self.depth, self.use_checkpoint = window_size, window_size // 2, depth, use_checkpoint
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim, num_heads, window_size, 0 if (i % 2 == 0) else window_size // 2, mlp_ratio,
+                                 qkv_bias, qk_scale, drop, attn_drop,
+                                 drop_path[i] if isinstance(drop_path, list) else drop_path, norm_layer=norm_layer)
+            for i in range(depth)])
+        self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
+
+    def forward(self, x, H, W):
+        attn_mask = shifted_window_mask(H, W, self.window_size, self.shift_size, x.device)
+        for blk in self.blocks:
+            blk.H, blk.W = H, W
+            g = window_gather_index(H, W, self.window_size, blk.shift_size, x.device)
+            x = checkpoint.checkpoint(blk, x, attn_mask, g, use_reentrant=False) if self.use_checkpoint else blk(x, attn_mask, g)
+        if self.downsample is not None:
+            return x, H, W, self.downsample(x, H, W), (H + 1) // 2, (W + 1) // 2
+        return x, H, W, x, H, W
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None):
+        super().__init__()
+        self.patch_size = (patch_size, patch_size) if isinstance(patch_size, int) else tuple(patch_size)
+        self.in_chans, self.embed_dim = in_chans, embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+    def forward(self, x):
+        _, _, H, W = x.size()
+        ph, pw = self.patch_size
+        if W % pw != 0:
+            x = F.pad(x, (0, pw - W % pw))
+        if H % ph != 0:
+            x = F.pad(x, (0, 0, 0, ph - H % ph))
+        x = self.proj(x)
+        if self.norm is not None:
+            Wh, Ww = x.size(2), x.size(3)
+            x = self.norm(x.flatten(2).transpose(1, 2)).transpose(1, 2).view(-1, self.embed_dim, Wh, Ww)
+        return x
+
+
+class SwinTransformer(nn.Module):
+    def __init__(self, pretrain_img_size=224, patch_size=4, in_chans=3, embed_dim=96, depths=[2, 2, 6, 2],
+                 num_heads=[3, 6, 12, 24], window_size=7, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0,
+                 attn_drop_rate=0.0, drop_path_rate=0.2, norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
+                 out_indices=(0, 1, 2, 3), frozen_stages=-1, use_checkpoint=False):
+        super().__init__()
+        self.pretrain_img_size, self.num_layers, self.embed_dim = pretrain_img_size, len(depths), embed_dim
+        self.ape, self.patch_norm, self.out_indices, self.frozen_stages = ape, patch_norm, out_indices, frozen_stages
+        self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim, norm_layer if patch_norm else None)
+        if self.ape:
+            ps = (pretrain_img_size, pretrain_img_size) if isinstance(pretrain_img_size, int) else pretrain_img_size
+            pp = (patch_size, patch_size) if isinstance(patch_size, int) else patch_size
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, embed_dim, ps[0] // pp[0], ps[1] // pp[1]))
+            _trunc_normal_(self.absolute_pos_embed, std=0.02)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.layers.append(BasicLayer(
+                dim=int(embed_dim * 2 ** i), depth=depths[i], num_heads=num_heads[i], window_size=window_size,
+                mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate,
+                drop_path=dpr[sum(depths[:i]): sum(depths[: i + 1])], norm_layer=norm_layer,
+                downsample=PatchMerging if (i < self.num_layers - 1) else None, use_checkpoint=use_checkpoint))
+        self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_layers)]
+        for i in out_indices:
+            self.add_module(f"norm{i}", norm_layer(self.num_features[i]))
+        self._freeze_stages()
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.patch_embed.eval()
+            for p in self.patch_embed.parameters():
+                p.requires_grad = False
+        if self.frozen_stages >= 1 and self.ape:
+            self.absolute_pos_embed.requires_grad = False
+        if self.frozen_stages >= 2:
+            self.pos_drop.eval()
+            for i in range(0, self.frozen_stages - 1):
+                self.layers[i].eval()
+                for p in self.layers[i].parameters():
+                    p.requires_grad = False
+
+    def forward(self, x):
+        x = self.patch_embed(x)
+        Wh, Ww = x.size(2), x.size(3)
+        if self.ape:
+            x = x + F.interpolate(self.absolute_pos_embed, size=(Wh, Ww), mode="bicubic")
+        x = self.pos_drop(x.flatten(2).transpose(1, 2))
+        outs = {}
+        for i, layer in enumerate(self.layers):
+            x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww)
+            if i in self.out_indices:
+                x_out = getattr(self, f"norm{i}")(x_out)
+                outs[f"res{i + 2}"] = x_out.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous()
+        return outs
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        return self                      # (the reference forgets the return, swin.py:684-687)
+
+
+@BACKBONE_REGISTRY.register()
+class D2SwinTransformer(SwinTransformer):
+    def __init__(self, cfg, input_shape):
+        s = cfg.MODEL.SWIN
+        super().__init__(s.PRETRAIN_IMG_SIZE, s.PATCH_SIZE, 3, s.EMBED_DIM, list(s.DEPTHS), list(s.NUM_HEADS),
+                         s.WINDOW_SIZE, s.MLP_RATIO, s.QKV_BIAS, s.QK_SCALE, s.DROP_RATE, s.ATTN_DROP_RATE,
+                         s.DROP_PATH_RATE, nn.LayerNorm, s.APE, s.PATCH_NORM, use_checkpoint=s.USE_CHECKPOINT)
+        self._out_features = s.OUT_FEATURES
+        self._out_feature_strides = {"res2": 4, "res3": 8, "res4": 16, "res5": 32}
+        self._out_feature_channels = {f"res{i + 2}": self.num_features[i] for i in range(4)}
+
+    def forward(self, x):
+        assert x.dim() == 4, f"SwinTransformer takes an input of shape (N, C, H, W). Got {x.shape} instead!"
+        y = super().forward(x)
+        return {k: v for k, v in y.items() if k in self._out_features}
+
+    def output_shape(self):
+        return {n: ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n])
+                for n in self._out_features}
+
+    @property
+    def size_divisibility(self):
+        return 32

@@ -1,0 +1,133 @@
+"""``ProposalModel`` meta-architecture — training branch (reference
+part_distillation/proposal_model.py:30-217, 305-338): normalise, pad-batch,
+backbone, MaskFormer head, Hungarian set criterion, loss weighting.
+
+Registered under the reference's name in ``META_ARCH_REGISTRY`` and built from
+the same config keys (``from_config``).  The evaluation / visualisation
+branches (:205-302, 380-475) are SURVEY §8f "next" rows and raise here."""
+from typing import Tuple
+
+import torch
+from torch import nn
+
+from .compat import META_ARCH_REGISTRY, ImageList, build_backbone, build_sem_seg_head, configurable
+from .modeling.criterion import SetCriterion
+from .modeling.matcher import HungarianMatcher
+
+
+def build_criterion(cfg, num_classes, match_points=None, loss_points=None):
+    mf = cfg.MODEL.MASK_FORMER
+    matcher = HungarianMatcher(cost_class=mf.CLASS_WEIGHT, cost_mask=mf.MASK_WEIGHT, cost_dice=mf.DICE_WEIGHT,
+                               num_points=match_points or mf.TRAIN_NUM_POINTS)
+    weight_dict = {"loss_ce": mf.CLASS_WEIGHT, "loss_mask": mf.MASK_WEIGHT, "loss_dice": mf.DICE_WEIGHT}
+    if mf.DEEP_SUPERVISION:
+        base = dict(weight_dict)
+        for i in range(mf.DEC_LAYERS - 1):
+            weight_dict.update({f"{k}_{i}": v for k, v in base.items()})
+    return SetCriterion(num_classes, matcher=matcher, weight_dict=weight_dict, eos_coef=mf.NO_OBJECT_WEIGHT,
+                        losses=["labels", "masks"], num_points=loss_points or mf.TRAIN_NUM_POINTS,
+                        oversample_ratio=mf.OVERSAMPLE_RATIO, importance_sample_ratio=mf.IMPORTANCE_SAMPLE_RATIO)
+
+
+class _MaskFormerTrainBase(nn.Module):
+    """What ProposalModel and PartDistillationModel share on the training path."""
+
+    def _init_common(self, backbone, sem_seg_head, criterion, num_queries, num_classes, size_divisibility, pixel_mean,
+                     pixel_std):
+        self.backbone, self.sem_seg_head, self.criterion = backbone, sem_seg_head, criterion
+        self.num_queries, self.num_classes = num_queries, num_classes
+        if size_divisibility < 0:
+            size_divisibility = self.backbone.size_divisibility
+        self.size_divisibility = size_divisibility
+        self.register_buffer("pixel_mean", torch.Tensor(pixel_mean).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.Tensor(pixel_std).view(-1, 1, 1), False)
+        self.num_train_iterations = 0
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def preprocess(self, batched_inputs):
+        images = [(x["image"].to(self.device, non_blocking=True) - self.pixel_mean) / self.pixel_std for x in batched_inputs]
+        return ImageList.from_tensors(images, self.size_divisibility)
+
+    def _pad_pseudo_masks(self, inputs, images):
+        """zero-pad every image's gt masks to the padded batch size (reference :313-338)."""
+        h_pad, w_pad = images.tensor.shape[-2:]
+        out = []
+        for x in inputs:
+            inst = x["instances"].to(self.device)
+            if not inst.has("gt_masks"):
+                raise ValueError("pseudo label without masks.")
+            m = inst.gt_masks.tensor if hasattr(inst.gt_masks, "tensor") else inst.gt_masks
+            if tuple(m.shape[-2:]) != (h_pad, w_pad):
+                padded = torch.zeros((m.shape[0], h_pad, w_pad), dtype=m.dtype, device=m.device)
+                padded[:, : m.shape[1], : m.shape[2]] = m
+                m = padded
+            out.append((inst, m))
+        return out
+
+    def _weighted(self, losses):
+        wd = self.criterion.weight_dict
+        return {k: v * wd[k] for k, v in losses.items() if k in wd}      # unknown keys are dropped (reference :192-196)
+
+
+@META_ARCH_REGISTRY.register()
+class ProposalModel(_MaskFormerTrainBase):
+    @configurable
+    def __init__(self, *, backbone, sem_seg_head: nn.Module, criterion: nn.Module, num_queries: int, num_classes: int,
+                 size_divisibility: int, pixel_mean: Tuple[float], pixel_std: Tuple[float], test_topk_per_image: int,
+                 dataset_name: str = "", use_wandb: bool = True, wandb_vis_period_train: int = 200,
+                 wandb_vis_period_test: int = 20, wandb_vis_topk: int = 200, use_unique_per_pixel_label: bool = False,
+                 minimum_pseudo_mask_score: float = 0.0, minimum_pseudo_mask_ratio: float = 0.0,
+                 apply_masking_with_object_mask: bool = True):
+        super().__init__()
+        self._init_common(backbone, sem_seg_head, criterion, num_queries, num_classes, size_divisibility, pixel_mean,
+                          pixel_std)
+        self.test_topk_per_image = test_topk_per_image
+        self.use_wandb = use_wandb                                   # accepted for config parity; never used here
+        self.use_unique_per_pixel_label = use_unique_per_pixel_label
+        self.minimum_pseudo_mask_score = minimum_pseudo_mask_score
+        self.minimum_pseudo_mask_ratio = minimum_pseudo_mask_ratio
+        self.apply_masking_with_object_mask = apply_masking_with_object_mask
+
+    @classmethod
+    def from_config(cls, cfg):
+        backbone = build_backbone(cfg)
+        sem_seg_head = build_sem_seg_head(cfg, backbone.output_shape())
+        criterion = build_criterion(cfg, sem_seg_head.num_classes)
+        return dict(backbone=backbone, sem_seg_head=sem_seg_head, criterion=criterion,
+                    num_queries=cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES,
+                    size_divisibility=cfg.MODEL.MASK_FORMER.SIZE_DIVISIBILITY, pixel_mean=cfg.MODEL.PIXEL_MEAN,
+                    pixel_std=cfg.MODEL.PIXEL_STD, num_classes=cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES,
+                    wandb_vis_period_train=cfg.WANDB.VIS_PERIOD_TRAIN, wandb_vis_period_test=cfg.WANDB.VIS_PERIOD_TEST,
+                    wandb_vis_topk=cfg.WANDB.VIS_TOPK, use_wandb=not cfg.WANDB.DISABLE_WANDB,
+                    dataset_name=cfg.DATASETS.TRAIN[0] if len(cfg.DATASETS.TRAIN) else "",
+                    test_topk_per_image=cfg.TEST.DETECTIONS_PER_IMAGE,
+                    use_unique_per_pixel_label=cfg.PROPOSAL_LEARNING.USE_PER_PIXEL_LABEL,
+                    apply_masking_with_object_mask=cfg.PROPOSAL_LEARNING.APPLY_MASKING_WITH_OBJECT_MASK,
+                    minimum_pseudo_mask_ratio=cfg.PROPOSAL_LEARNING.MIN_AREA_RATIO,
+                    minimum_pseudo_mask_score=cfg.PROPOSAL_LEARNING.MIN_SCORE)
+
+    def prepare_targets(self, inputs, images):
+        if not self.training:
+            raise NotImplementedError("ProposalModel evaluation targets: SURVEY §8f 'next' row, not built yet")
+        return self._prepare_pseudo_targets(inputs, images)
+
+    def _prepare_pseudo_targets(self, inputs, images):
+        targets = []
+        for inst, m in self._pad_pseudo_masks(inputs, images):
+            targets.append({"labels": torch.zeros(m.shape[0], dtype=torch.long, device=self.device),   # class-agnostic
+                            "masks": m, "object_masks": m.sum(0, keepdim=True)})
+        return targets
+
+    def forward(self, batched_inputs):
+        images = self.preprocess(batched_inputs)
+        features = self.backbone(images.tensor)
+        targets = self.prepare_targets(batched_inputs, images)
+        outputs = self.sem_seg_head(features)
+        if not self.training:
+            raise NotImplementedError("ProposalModel inference: SURVEY §8f 'next' row, not built yet")
+        losses = self._weighted(self.criterion(outputs, targets))
+        self.num_train_iterations += 1
+        return losses
