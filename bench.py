@@ -1,0 +1,192 @@
+"""Benchmark of the hot path: images/s of one full training step (forward + Hungarian
+criterion + backward + gradient all-reduce + clipped AdamW) of the R50 Mask2Former
+part-proposal model on synthetic 1024x1024 batches, bs=2 per GPU (BASELINE.json
+configs[1]), on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
+  roofline      achieved algorithmic GB/s of the dominant hand-written kernel (MSDA backward), measured with
+                HIP events around every launch inside the timed steps (same stream as the launches)
+  cpu_baseline  the CPU oracle (oracle/step_ref.py, plain PyTorch fp32) timed on this host's cores on a bounded
+                sample of the same workload (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "images/sec training step, R50 Mask2Former 1024² bs=2/GPU, 1/2/4/8 MI355X"
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
+
+
+def msda_alg_bytes(batch, size, heads=8, head_dim=32, levels=3, points=4, esz=4):
+    """value + loc + attn + out (forward); + grad_out, grad_value, grad_loc, grad_attn (backward)."""
+    s = sum((size // st) ** 2 for st in (32, 16, 8))
+    v = batch * s * heads * head_dim * esz
+    lo = batch * s * heads * levels * points * 2 * esz
+    at = batch * s * heads * levels * points * esz
+    return v + lo + at + v, 2 * (v + lo + at) + v
+
+
+def cpu_baseline(cfg_opts, size, seconds_budget=60.0):
+    """time the oracle's training step (fwd + criterion + bwd + clipped AdamW), 1 image, on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import common as C
+    from oracle import step_ref as R
+    from partdistillation_amd.compat import build_model
+    from partdistillation_amd.config import setup_cfg
+    from partdistillation_amd.engine.synthetic import make_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd", "configs", "proposal_learning", "r50_mask2former.yaml"),
+                    ["MODEL.DEVICE", "cpu"] + cfg_opts)
+    torch.manual_seed(0)
+    model = build_model(cfg)                      # only to obtain reference-initialised weights (never run on CPU)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    params = [k for k, v in model.named_parameters()]
+    for k in params:
+        sd[k].requires_grad_(True)
+    del model
+
+    def one_step(s):
+        batch = make_batch(1, s, seed=1234, device="cpu")
+        obatch = [{"image": b["image"], "instances": {"gt_masks": b["instances"].gt_masks.tensor}} for b in batch]
+        g = torch.Generator().manual_seed(0)
+        rand = lambda shape: torch.rand(shape, generator=g)
+        t0 = time.perf_counter()
+        losses = R.proposal_model_losses(sd, obatch, rand)
+        sum(losses.values()).backward()
+        ps = [sd[k] for k in params]
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in ps]
+        state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in ps]
+        with torch.no_grad():
+            R.clipped_adamw_step([p.data for p in ps], grads, state, lrs=[1e-4] * len(ps), wds=[0.05] * len(ps), step=1)
+        dt = time.perf_counter() - t0
+        for p in ps:
+            p.grad = None
+        return dt
+
+    probe = max(256, size // 4)
+    t_probe = one_step(probe)                    # also warms the allocator / thread pool
+    est = t_probe * (size / probe) ** 2
+    if est <= seconds_budget:
+        dt, sample = one_step(size), f"1 image {size}x{size}, one full step (fwd+criterion+bwd+clipped AdamW), fp32"
+        return {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": "port", "sample": sample,
+                "seconds": dt}
+    sample = (f"1 image {probe}x{probe} (1/{(size // probe) ** 2} of the pixels of the {size}x{size} workload; the full-size "
+              f"step was estimated at {est:.0f} s > budget), one full step, fp32; value scaled by the pixel ratio")
+    return {"value": 1.0 / est, "unit": "images/s", "cores": cores, "kind": "port", "sample": sample, "seconds": t_probe}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=2, help="images per GPU")
+    ap.add_argument("--freeze", default="", help='comma list for MODEL.MASK_FORMER.FREEZE_KEYS, e.g. "backbone,encoder"')
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--miopen-find", type=int, default=1, help="1: let MIOpen search conv algorithms during warm-up")
+    ap.add_argument("opts", nargs="*", help="extra KEY VALUE config overrides")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N ...")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    torch.backends.cudnn.benchmark = bool(a.miopen_find)
+
+    from partdistillation_amd import lib
+    lib.load()                                                     # fail loudly if the HIP extension is missing
+    from partdistillation_amd.config import setup_cfg
+    from partdistillation_amd.engine.synthetic import make_batch
+    from partdistillation_amd.engine.trainer import TrainStep
+    from partdistillation_amd.modeling.pixel_decoder.ops.functions import ms_deform_attn_func as msda_fn
+
+    freeze = [k for k in a.freeze.split(",") if k]
+    cfg_opts = ["INPUT.IMAGE_SIZE", str(a.size)] + list(a.opts)
+    if freeze:
+        cfg_opts += ["MODEL.MASK_FORMER.FREEZE_KEYS", str(freeze)]
+    cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd", "configs", "proposal_learning", "r50_mask2former.yaml"), cfg_opts)
+    torch.manual_seed(0)                                           # identical init on every rank (+ broadcast in TrainStep)
+    step = TrainStep(cfg)
+    batches = [make_batch(a.batch, a.size, seed=1234 + rank + 1000 * i, device="cuda") for i in range(4)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(batches[i % len(batches)])
+    barrier()
+    msda_fn.enable_timing(True)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        losses = step(batches[i % len(batches)])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    fwd_ms, bwd_ms = msda_fn.timing_ms()
+    msda_fn.enable_timing(False)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    total_loss = float(sum(losses.values()))
+
+    if rank == 0:
+        images = a.batch * world * a.steps
+        fb, bb = msda_alg_bytes(a.batch, a.size)
+        avg = lambda xs: sum(xs) / max(len(xs), 1)
+        kernels = []
+        if fwd_ms:
+            kernels.append({"kernel": "msda_fwd_d32", "launches": len(fwd_ms), "avg_ms": avg(fwd_ms),
+                            "alg_bytes": fb, "achieved_GBs": fb / avg(fwd_ms) / 1e6})
+        if bwd_ms:
+            kernels.append({"kernel": "msda_bwd_tiled_d32", "launches": len(bwd_ms), "avg_ms": avg(bwd_ms),
+                            "alg_bytes": bb, "achieved_GBs": bb / avg(bwd_ms) / 1e6})
+        dom = max(kernels, key=lambda k: k["avg_ms"] * k["launches"]) if kernels else None
+        out = {
+            "metric": METRIC, "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"R50 Mask2Former part-proposal training step (ProposalModel), {a.size}x{a.size} synthetic, "
+                                   f"bs={a.batch}/GPU, Q=100, 10 prediction heads, bf16 autocast (pixel decoder + matcher fp32)",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                       "finetune": "frozen:" + ",".join(freeze) if freeze else "full",
+                       "final_total_loss": total_loss},
+            "roofline": None if dom is None else {
+                "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": dom["alg_bytes"],
+                "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["launches"], "other_kernels": kernels},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(list(a.opts), a.size)
+            except Exception as e:                                  # the GPU number must still be reported
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

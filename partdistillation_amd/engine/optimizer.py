@@ -1,0 +1,148 @@
+"""Optimizer construction of the training step (reference base_trainer.py:64-148):
+per-parameter hyper-parameters (backbone lr x BACKBONE_MULTIPLIER, no weight
+decay on norm layers / embeddings / relative-position tables, FREEZE_KEYS),
+full-model gradient-norm clipping folded into AdamW, and the WarmupMultiStepLR
+schedule detectron2's ``build_lr_scheduler`` gives the reference drivers."""
+import bisect
+from typing import Dict, List
+
+import torch
+from torch import nn
+
+from ..compat.layers import FrozenBatchNorm2d
+from ..functions import optim as optim_op
+from .flat_params import FlatParams
+
+_NORM_TYPES = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.SyncBatchNorm, nn.GroupNorm, nn.InstanceNorm1d,
+               nn.InstanceNorm2d, nn.InstanceNorm3d, nn.LayerNorm, nn.LocalResponseNorm, FrozenBatchNorm2d)
+
+
+def param_hyperparams(cfg, model) -> List[Dict]:
+    """one entry per trainable parameter: {"param", "name", "lr", "weight_decay"} — the loop of
+    base_trainer.py:88-116 (including its side effect: parameters whose module name contains a
+    FREEZE_KEYS entry get requires_grad=False)."""
+    base_lr, base_wd = cfg.SOLVER.BASE_LR, cfg.SOLVER.WEIGHT_DECAY
+    out, memo = [], set()
+    for module_name, module in model.named_modules():
+        for pname, value in module.named_parameters(recurse=False):
+            if not value.requires_grad or value in memo:
+                continue
+            if any(k in module_name for k in cfg.MODEL.MASK_FORMER.FREEZE_KEYS):
+                value.requires_grad = False
+                continue
+            memo.add(value)
+            lr, wd = base_lr, base_wd
+            if "backbone" in module_name:
+                lr = lr * cfg.SOLVER.BACKBONE_MULTIPLIER
+            if "relative_position_bias_table" in pname or "absolute_pos_embed" in pname:
+                wd = 0.0
+            if isinstance(module, _NORM_TYPES):
+                wd = cfg.SOLVER.WEIGHT_DECAY_NORM
+            if isinstance(module, nn.Embedding):
+                wd = cfg.SOLVER.WEIGHT_DECAY_EMBED
+            out.append({"param": value, "name": f"{module_name}.{pname}" if module_name else pname, "lr": lr,
+                        "weight_decay": wd})
+    return out
+
+
+class FlatClippedAdamW:
+    """AdamW with full-model L2 clipping over flat buffers (HIP kernels pd_sumsq_accumulate + pd_adamw_clipped).
+    ``param_groups`` exposes lr / weight_decay per flat group like a torch optimizer (for LR schedulers)."""
+
+    def __init__(self, entries: List[Dict], betas=(0.9, 0.999), eps=1e-8, clip_norm=0.0):
+        groups: Dict = {}
+        # reverse registration order ~ the order gradients become ready in backward (DDP buckets fill front to back)
+        for e in reversed(entries):
+            key = (e["lr"], e["weight_decay"])
+            g = groups.setdefault(key, {"params": [], "names": [], "lr": e["lr"], "initial_lr": e["lr"],
+                                        "weight_decay": e["weight_decay"]})
+            g["params"].append(e["param"])
+            g["names"].append(e["name"])
+        self.flat = FlatParams(list(groups.values()))
+        self.param_groups = [dict(g.hyper, params=g.params) for g in self.flat.groups]
+        self.betas, self.eps, self.clip_norm = betas, eps, clip_norm
+        self.exp_avg = [torch.zeros_like(g.param) for g in self.flat.groups]
+        self.exp_avg_sq = [torch.zeros_like(g.param) for g in self.flat.groups]
+        dev = self.flat.groups[0].param.device
+        self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.steps = 0
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def grad_norm(self):
+        """device scalar: global L2 norm of the (unclipped) gradients of the last step."""
+        return self._sumsq.sqrt()
+
+    @torch.no_grad()
+    def step(self):
+        self.steps += 1
+        self._sumsq.zero_()
+        if self.clip_norm > 0:
+            for g in self.flat.groups:
+                optim_op.sumsq_accumulate(g.grad, self._sumsq)
+        for g, pg, m, v in zip(self.flat.groups, self.param_groups, self.exp_avg, self.exp_avg_sq):
+            optim_op.adamw_clipped_(g.param, g.grad, m, v, lr=pg["lr"], betas=self.betas, eps=self.eps,
+                                    weight_decay=pg["weight_decay"], step=self.steps,
+                                    grad_sumsq=self._sumsq if self.clip_norm > 0 else None, max_norm=self.clip_norm)
+
+    def state_dict(self):
+        return {"steps": self.steps, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "lr": [pg["lr"] for pg in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.steps = sd["steps"]
+        for a, b in zip(self.exp_avg, sd["exp_avg"]):
+            a.copy_(b)
+        for a, b in zip(self.exp_avg_sq, sd["exp_avg_sq"]):
+            a.copy_(b)
+        for pg, lr in zip(self.param_groups, sd["lr"]):
+            pg["lr"] = lr
+
+
+def build_optimizer(cfg, model):
+    entries = param_hyperparams(cfg, model)
+    if cfg.SOLVER.OPTIMIZER != "ADAMW":
+        raise NotImplementedError(f"no optimizer type {cfg.SOLVER.OPTIMIZER} on the MI355X path (ADAMW only)")
+    cg = cfg.SOLVER.CLIP_GRADIENTS
+    clip = cg.CLIP_VALUE if (cg.ENABLED and cg.CLIP_TYPE == "full_model" and cg.CLIP_VALUE > 0.0) else 0.0
+    return FlatClippedAdamW(entries, clip_norm=clip)
+
+
+class WarmupMultiStepLR:
+    """detectron2 WarmupMultiStepLR (what projects.deeplab.build_lr_scheduler returns for the shipped configs):
+    lr = base * warmup(iter) * gamma ** #(milestones <= iter)."""
+
+    def __init__(self, optimizer, milestones, gamma=0.1, warmup_factor=0.001, warmup_iters=1000, warmup_method="linear"):
+        self.opt, self.milestones, self.gamma = optimizer, sorted(milestones), gamma
+        self.warmup_factor, self.warmup_iters, self.warmup_method = warmup_factor, warmup_iters, warmup_method
+        self.base_lrs = [pg.get("initial_lr", pg["lr"]) for pg in optimizer.param_groups]
+        self.last_iter = 0
+        self._apply()
+
+    def _factor(self, it):
+        w = 1.0
+        if it < self.warmup_iters:
+            if self.warmup_method == "constant":
+                w = self.warmup_factor
+            else:
+                alpha = it / self.warmup_iters
+                w = self.warmup_factor * (1 - alpha) + alpha
+        return w * self.gamma ** bisect.bisect_right(self.milestones, it)
+
+    def _apply(self):
+        f = self._factor(self.last_iter)
+        for pg, b in zip(self.opt.param_groups, self.base_lrs):
+            pg["lr"] = b * f
+
+    def step(self):
+        self.last_iter += 1
+        self._apply()
+
+
+def build_lr_scheduler(cfg, optimizer):
+    s = cfg.SOLVER
+    if s.LR_SCHEDULER_NAME != "WarmupMultiStepLR":
+        raise NotImplementedError(s.LR_SCHEDULER_NAME)
+    return WarmupMultiStepLR(optimizer, [x for x in s.STEPS if x <= s.MAX_ITER], s.GAMMA, s.WARMUP_FACTOR, s.WARMUP_ITERS,
+                             s.WARMUP_METHOD)

@@ -102,6 +102,17 @@ def check_digest(t, d, rtol, atol, what=""):
     torch.testing.assert_close(got["abssum"], d["abssum"], rtol=max(rtol, 1e-6), atol=atol * n, msg=lambda m: f"{what} abssum: {m}")
 
 
+def check_digest_scaled(t, d, frac, what=""):
+    """error measured against the tensor's own scale: max|got - want| <= frac * max|want| (deep gradient chains)."""
+    got = digest(t)
+    assert got["shape"].tolist() == d["shape"].tolist(), f"{what}: shape"
+    want = d["sample"].double()
+    err = (got["sample"].double() - want).abs().max().item()
+    scale = max(want.abs().max().item(), 1e-30)
+    assert err <= frac * scale, f"{what}: max abs err {err:.3e} > {frac} * scale {scale:.3e}"
+    assert abs(got["abssum"].item() - d["abssum"].item()) <= frac * d["abssum"].item() + 1e-30, f"{what}: abssum"
+
+
 # ----------------------------------------------------------------------------- case configs
 TINY = dict(conv_dim=64, mask_dim=64, nheads=8, enc_layers=2, enc_ffn=1024, channels=(16, 32, 64, 128),
             image=128, batch=1, queries=12, dec_layers=3, dec_ffn=128, num_classes=1,

@@ -1,0 +1,321 @@
+"""GPU parity tests of the product path (HIP ops through the C-ABI inside the
+reference-shaped modules) against (a) the goldens captured from the real
+reference modules and (b) the CPU oracle on the same seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import common as C
+from oracle import step_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _shape_specs(cfg):
+    from partdistillation_amd.compat import ShapeSpec
+    return {f"res{i + 2}": ShapeSpec(channels=c, stride=s) for i, (c, s) in enumerate(zip(cfg["channels"], (4, 8, 16, 32)))}
+
+
+def build_pixel_decoder(cfg):
+    from partdistillation_amd.modeling.pixel_decoder.msdeformattn import MSDeformAttnPixelDecoder
+    return MSDeformAttnPixelDecoder(
+        _shape_specs(cfg), transformer_dropout=0.0, transformer_nheads=cfg["nheads"],
+        transformer_dim_feedforward=cfg["enc_ffn"], transformer_enc_layers=cfg["enc_layers"], conv_dim=cfg["conv_dim"],
+        mask_dim=cfg["mask_dim"], norm="GN", transformer_in_features=["res3", "res4", "res5"], common_stride=4)
+
+
+def build_decoder(cfg, part=None):
+    from partdistillation_amd.modeling.transformer_decoder.mask2former_transformer_decoder import MultiScaleMaskedTransformerDecoder
+    from partdistillation_amd.modeling.transformer_decoder.part_distillation_transformer_decoder import PartDistillationTransformerDecoder
+    kw = dict(num_classes=cfg["num_classes"], hidden_dim=cfg["conv_dim"], num_queries=cfg["queries"], nheads=cfg["nheads"],
+              dim_feedforward=cfg["dec_ffn"], dec_layers=cfg["dec_layers"], pre_norm=False, mask_dim=cfg["mask_dim"],
+              enforce_input_project=False, query_feature_normalize=False)
+    if part is None:
+        return MultiScaleMaskedTransformerDecoder(cfg["conv_dim"], True, **kw)
+    return PartDistillationTransformerDecoder(cfg["conv_dim"], True, num_object_classes=part[0], num_part_classes=part[1], **kw)
+
+
+def build_criterion(cfg, num_classes=None):
+    from partdistillation_amd.modeling.criterion import SetCriterion
+    from partdistillation_amd.modeling.matcher import HungarianMatcher
+    nc = num_classes if num_classes is not None else cfg["num_classes"]
+    m = HungarianMatcher(cost_class=2.0, cost_mask=5.0, cost_dice=5.0, num_points=cfg["num_points"])
+    wd = R.weight_dict(cfg["dec_layers"] + 1)
+    return SetCriterion(nc, matcher=m, weight_dict=wd, eos_coef=0.1, losses=["labels", "masks"], num_points=cfg["num_points"],
+                        oversample_ratio=cfg["oversample"], importance_sample_ratio=cfg["importance"]).to(DEV)
+
+
+def load_seeded(module, table, seed):
+    module.load_state_dict(C.seeded_weights(table, seed), strict=False)
+    return module.to(DEV)
+
+
+def dev_targets(targets):
+    return [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in t.items()} for t in targets]
+
+
+# ----------------------------------------------------------------------------- pixel decoder
+def test_pixel_decoder_tiny_vs_reference_golden(golden):
+    g = golden("pixel_decoder_tiny")
+    cfg = C.TINY
+    pd = load_seeded(build_pixel_decoder(cfg), g["table"], 101)
+    feats = {k: v.to(DEV).requires_grad_() for k, v in C.make_features(cfg, 201).items()}
+    mf, enc0, ms = pd.forward_features(feats)
+    C.check_digest(mf, g["mask_features"], 1e-3, 1e-4, "mask_features")
+    C.check_digest(enc0, g["enc0"], 1e-3, 1e-4, "enc0")
+    for i, m in enumerate(ms):
+        C.check_digest(m, g["multi_scale"][i], 1e-3, 1e-4, f"ms{i}")
+    loss = (mf * C.seeded(mf.shape, 301).to(DEV)).sum() + sum((m * C.seeded(m.shape, 302 + i).to(DEV)).sum() for i, m in enumerate(ms))
+    torch.testing.assert_close(loss.double().cpu(), g["loss"], rtol=1e-4, atol=1e-2)
+    loss.backward()
+    named = dict(pd.named_parameters())
+    for k, d in g["grads"].items():
+        C.check_digest(named[k].grad, d, 5e-3, 1e-3, "grad " + k)
+    for k, d in g["grad_feats"].items():
+        C.check_digest(feats[k].grad, d, 5e-3, 1e-3, "grad feat " + k)
+
+
+# ----------------------------------------------------------------------------- decoder
+def _dec_inputs(cfg, seed):
+    s, b = cfg["image"], cfg["batch"]
+    ms = [C.seeded((b, cfg["conv_dim"], s // st, s // st), seed + i).to(DEV) for i, st in enumerate((32, 16, 8))]
+    return ms, C.seeded((b, cfg["mask_dim"], s // 4, s // 4), seed + 7).to(DEV)
+
+
+def test_decoder_tiny_vs_reference_golden(golden):
+    g = golden("decoder_tiny")
+    cfg = C.TINY
+    dec = load_seeded(build_decoder(cfg), g["table"], 102)
+    ms, mf = _dec_inputs(cfg, 401)
+    ms = [m.requires_grad_() for m in ms]
+    mf.requires_grad_()
+    out = dec(ms, mf)
+    torch.testing.assert_close(out["pred_logits"].cpu(), g["pred_logits"], rtol=1e-3, atol=1e-4)
+    C.check_digest(out["pred_masks"], g["pred_masks"], 1e-3, 1e-3, "pred_masks")
+    for i, a in enumerate(out["aux_outputs"]):
+        torch.testing.assert_close(a["pred_logits"].cpu(), g["aux_logits"][i], rtol=1e-3, atol=1e-4)
+        C.check_digest(a["pred_masks"], g["aux_masks"][i], 1e-3, 1e-3, f"aux_masks{i}")
+    C.check_digest(out["decoder_output"], g["decoder_output"], 1e-3, 1e-4, "decoder_output")
+    sd = lambda shape, seed: C.seeded(shape, seed).to(DEV)
+    loss = (out["pred_masks"] * sd(out["pred_masks"].shape, 501)).sum() + (out["pred_logits"] * sd(out["pred_logits"].shape, 502)).sum()
+    for i, a in enumerate(out["aux_outputs"]):
+        loss = loss + (a["pred_masks"] * sd(a["pred_masks"].shape, 510 + i)).sum() * 0.5 + (a["pred_logits"] * sd(a["pred_logits"].shape, 530 + i)).sum()
+    torch.testing.assert_close(loss.double().cpu(), g["loss"], rtol=1e-4, atol=5e-2)
+    loss.backward()
+    named = dict(dec.named_parameters())
+    for k, d in g["grads"].items():
+        C.check_digest(named[k].grad, d, 5e-3, 2e-3, "grad " + k)
+    C.check_digest(mf.grad, g["grad_mf"], 5e-3, 2e-3, "grad mask_features")
+    for i, m in enumerate(ms):
+        C.check_digest(m.grad, g["grad_ms"][i], 5e-3, 2e-3, f"grad ms{i}")
+
+
+# ----------------------------------------------------------------------------- LSA kernel
+@pytest.mark.parametrize("shape", [(100, 4), (4, 100), (12, 3), (7, 7), (1, 5), (5, 1), (200, 8), (100, 0)])
+def test_device_lsa_matches_scipy(shape):
+    from scipy.optimize import linear_sum_assignment
+    from partdistillation_amd.functions import lsa
+    rng = np.random.RandomState(sum(shape) + 1)
+    nb = 24
+    q, n = shape
+    cmax = max(n, 1) + 2
+    cost = np.zeros((nb, q, cmax), np.float32)
+    for b in range(nb):
+        c = rng.randn(q, n).astype(np.float32)
+        if b % 4 == 1:
+            c = np.round(c * 2) / 2                                       # heavy ties
+        cost[b, :, :n] = c
+    rows, cols = lsa.solve_batched(torch.from_numpy(cost).to(DEV), torch.full((nb,), n, dtype=torch.int32))
+    rows, cols = rows.cpu().numpy(), cols.cpu().numpy()
+    k = min(q, n)
+    for b in range(nb):
+        c = cost[b, :, :n].astype(np.float64)
+        r0, c0 = linear_sum_assignment(c)
+        assert (rows[b, k:] == -1).all() and (cols[b, k:] == -1).all()
+        got = sorted(zip(rows[b, :k].tolist(), cols[b, :k].tolist()))
+        assert got == sorted(zip(r0.tolist(), c0.tolist())), f"problem {b}"
+        pc = cost[b, rows[b, :k], cols[b, :k]]
+        assert (np.diff(pc) >= 0).all()                                   # pairs ordered by ascending cost (matcher.py:162)
+
+
+# ----------------------------------------------------------------------------- matcher + criterion
+def _fake_outputs(cfg, seed, k1):
+    b, q, s = cfg["batch"], cfg["queries"], cfg["image"] // 4
+    mk = lambda i: {"pred_logits": C.seeded((b, q, k1), seed + i).to(DEV), "pred_masks": C.seeded((b, q, s, s), seed + 50 + i, 3.0).to(DEV)}
+    out = mk(0)
+    out["aux_outputs"] = [mk(i + 1) for i in range(cfg["dec_layers"])]
+    return out
+
+
+def test_matcher_and_criterion_tiny_vs_reference_golden(golden):
+    g = golden("criterion_tiny")
+    cfg = C.TINY
+    crit = build_criterion(cfg)
+    out = _fake_outputs(cfg, 601, cfg["num_classes"] + 1)
+    for t in [out["pred_logits"], out["pred_masks"]] + [a[k] for a in out["aux_outputs"] for k in ("pred_logits", "pred_masks")]:
+        t.requires_grad_()
+    targets = dev_targets(C.make_targets(cfg, 701))
+    crit.matcher.rand = C.ReplayRand(9000)
+    idx = crit.matcher({k: v for k, v in out.items() if k != "aux_outputs"}, targets)
+    for (i, j), (gi, gj) in zip(idx, g["matcher_indices"]):
+        assert torch.equal(i.cpu(), gi) and torch.equal(j.cpu(), gj)
+    rr = C.ReplayRand(9100)
+    crit.rand = rr
+    losses = crit(out, targets)
+    assert rr.calls == int(g["rand_calls"])
+    assert set(losses) == set(g["losses"])
+    for k, v in g["losses"].items():
+        torch.testing.assert_close(losses[k].double().cpu().reshape(()), v.reshape(()), rtol=1e-4, atol=1e-5, msg=lambda m: f"{k}: {m}")
+    sum(losses.values()).backward()
+    C.check_digest(out["pred_masks"].grad, g["grad_final_masks"], 1e-3, 1e-6, "grad final masks")
+    torch.testing.assert_close(out["pred_logits"].grad.cpu(), g["grad_final_logits"], rtol=1e-3, atol=1e-6)
+    C.check_digest(out["aux_outputs"][0]["pred_masks"].grad, g["grad_aux0_masks"], 1e-3, 1e-6, "grad aux0 masks")
+
+
+# ----------------------------------------------------------------------------- head end to end
+def _head(cfg, g, part=None):
+    pd = load_seeded(build_pixel_decoder(cfg), g["table_pd"], 101)
+    dec = load_seeded(build_decoder(cfg, part), g["table_dec"], 102)
+    crit = build_criterion(cfg, None if part is None else part[1])
+    feats = {k: v.to(DEV) for k, v in C.make_features(cfg, 201).items()}
+    targets = C.make_targets(cfg, 701, size=cfg["image"])
+    if part is not None:
+        for b, t in enumerate(targets):
+            t["labels"] = g["labels"][b]
+            t["gt_object_class"] = int(g["gt_object_class"][b])
+    targets = dev_targets(targets)
+    mf, _, ms = pd.forward_features(feats)
+    out = dec(ms, mf, targets if part is not None else None)
+    rr = C.ReplayRand(9200)
+    crit.rand = rr
+    losses = crit(out, targets)
+    return pd, dec, crit, out, losses, rr
+
+
+@pytest.mark.parametrize("tag", ["tiny", "part", "c1"])
+def test_head_end_to_end_vs_reference_golden(golden, tag):
+    """features -> pixel decoder -> decoder -> Hungarian criterion: the 3*(L+1) losses and a handful of parameter
+    gradients against the reference (C.TINY dims, part-distillation variant, and BASELINE config-1 dims)."""
+    g = golden("head_" + tag)
+    cfg = C.C1 if tag == "c1" else C.TINY
+    part = tuple(g["part"].tolist()) if tag == "part" else None
+    pd, dec, crit, out, losses, rr = _head(cfg, g, part)
+    assert rr.calls == int(g["rand_calls"])
+    torch.testing.assert_close(out["pred_logits"].cpu(), g["pred_logits"], rtol=2e-3, atol=2e-4)
+    if part is not None:
+        assert out["pred_logits"].dtype == torch.float64
+    lt = dict(rtol=2e-3, atol=1e-4)
+    for k, v in g["losses"].items():
+        torch.testing.assert_close(losses[k].double().cpu().reshape(()), v.reshape(()), msg=lambda m: f"{k}: {m}", **lt)
+    wd = crit.weight_dict
+    total = sum(v * wd[k] for k, v in losses.items())
+    torch.testing.assert_close(total.double().cpu().reshape(()), g["total_weighted"].reshape(()), **lt)
+    total.backward()
+    named = {"pixel_decoder." + k: v for k, v in pd.named_parameters()}
+    named.update({"predictor." + k: v for k, v in dec.named_parameters()})
+    for k, d in g["grads"].items():
+        C.check_digest_scaled(named[k].grad, d, 1e-2, "grad " + k)     # fp32 GPU vs fp32 CPU through up to 6+9 layers
+    if part is not None:
+        rows = (dec.class_embed.weight.grad.abs().sum(1) > 0).nonzero().flatten().cpu()
+        assert torch.equal(rows, g["class_embed_grad_rows"])
+
+
+# ----------------------------------------------------------------------------- backbone + full step vs oracle
+def _toy_cfg(extra=()):
+    from partdistillation_amd.config import setup_cfg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return setup_cfg(os.path.join(root, "partdistillation_amd", "configs", "proposal_learning", "r50_mask2former.yaml"),
+                     ["MODEL.MASK_FORMER.NUM_OBJECT_QUERIES", "20", "MODEL.MASK_FORMER.DEC_LAYERS", "4",
+                      "MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS", "2", "MODEL.MASK_FORMER.TRAIN_NUM_POINTS", "256",
+                      "SOLVER.AMP.ENABLED", "False"] + list(extra))
+
+
+def _randomise(model, seed):
+    table = {k: v for k, v in C.table_of(model.state_dict()).items() if not k.startswith("criterion.")}
+    sd = C.seeded_weights(table, seed)
+    model.load_state_dict(sd, strict=False)
+    return {k: v.clone() for k, v in model.state_dict().items()}
+
+
+def test_full_step_fp32_vs_oracle():
+    """ProposalModel (R50 + head + criterion) on two 128x96 / 96x128 images: the weighted loss dict and parameter
+    gradients of the HIP path against oracle/step_ref.proposal_model_losses on the same weights and draws."""
+    from partdistillation_amd.compat import build_model
+    from partdistillation_amd.engine.synthetic import make_batch
+    import partdistillation_amd.modeling, partdistillation_amd.proposal_model  # noqa: F401,E401
+    cfg = _toy_cfg()
+    model = build_model(cfg).train()
+    sd = _randomise(model, 77)
+    batch = make_batch(2, 128, n_parts=3, seed=5, device=DEV)
+    # ragged sizes: crop the second image / masks to 96x128 -> exercises ImageList + mask padding
+    batch[1]["image"] = batch[1]["image"][:, :96].contiguous()
+    batch[1]["instances"].gt_masks.tensor = batch[1]["instances"].gt_masks.tensor[:, :96].contiguous()
+    rr = C.ReplayRand(4242)
+    model.criterion.rand = rr
+    losses = model(batch)
+    total = sum(losses.values())
+    total.backward()
+    # oracle
+    osd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    obatch = [{"image": b["image"].cpu(), "instances": {"gt_masks": b["instances"].gt_masks.tensor.cpu()}} for b in batch]
+    rr2 = C.ReplayRand(4242)
+    olosses = R.proposal_model_losses(osd, obatch, rr2, dec_layers=4, enc_layers=2, num_points=256)
+    assert rr.calls == rr2.calls and set(losses) == set(olosses)
+    for k in olosses:
+        torch.testing.assert_close(losses[k].float().cpu().reshape(()), olosses[k].detach().reshape(()), rtol=2e-3, atol=2e-4,
+                                   msg=lambda m: f"{k}: {m}")
+    sum(olosses.values()).backward()
+    named = dict(model.named_parameters())
+    checked = 0
+    for k in ["backbone.stem.conv1.weight", "backbone.res3.1.conv2.weight", "backbone.res5.0.shortcut.weight",
+              "sem_seg_head.pixel_decoder.input_proj.0.0.weight", "sem_seg_head.pixel_decoder.layer_1.weight",
+              "sem_seg_head.pixel_decoder.transformer.encoder.layers.1.self_attn.sampling_offsets.weight",
+              "sem_seg_head.predictor.query_feat.weight", "sem_seg_head.predictor.class_embed.bias",
+              "sem_seg_head.predictor.transformer_cross_attention_layers.2.multihead_attn.in_proj_weight"]:
+        a, b = named[k].grad.float().cpu(), osd[k].grad
+        scale = b.abs().max().clamp_min(1e-12)
+        assert ((a - b).abs().max() / scale).item() < 2e-2, k
+        checked += 1
+    assert checked == 9
+
+
+def test_fused_clipped_adamw_vs_oracle():
+    from partdistillation_amd.engine.optimizer import FlatClippedAdamW
+    torch.manual_seed(0)
+    shapes = [(33, 7), (5,), (4, 3, 3, 3), (1,)]
+    params = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    entries = [{"param": p, "name": f"p{i}", "lr": 1e-3 * (1 + i % 2), "weight_decay": 0.05 * (i % 3 == 0)} for i, p in enumerate(params)]
+    ref_p = [p.detach().cpu().clone() for p in params]
+    ref_state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in ref_p]
+    opt = FlatClippedAdamW(entries, clip_norm=0.5)
+    for step in range(1, 4):
+        grads = [torch.randn(s) * (3.0 if step == 2 else 0.01) for s in shapes]
+        opt.zero_grad()
+        for p, g in zip(params, grads):
+            p.grad.add_(g.to(DEV))
+        opt.step()
+        total = R.clipped_adamw_step(ref_p, grads, ref_state, lrs=[e["lr"] for e in entries], wds=[e["weight_decay"] for e in entries],
+                                     clip=0.5, step=step)
+        torch.testing.assert_close(opt.grad_norm().float().cpu().reshape(()), total.reshape(()), rtol=1e-5, atol=1e-7)
+        for p, r in zip(params, ref_p):
+            torch.testing.assert_close(p.detach().cpu(), r, rtol=1e-5, atol=1e-6)
+
+
+def test_train_steps_run_and_reduce_loss():
+    """twenty optimisation steps of the bf16-autocast training step on a fixed toy batch: finite, decreasing."""
+    from partdistillation_amd.engine.synthetic import make_batch
+    from partdistillation_amd.engine.trainer import TrainStep
+    cfg = _toy_cfg(["SOLVER.AMP.ENABLED", "True", "SOLVER.BASE_LR", "0.0001", "SOLVER.CLIP_GRADIENTS.CLIP_VALUE", "0.1",
+                    "SOLVER.WARMUP_ITERS", "0"])
+    torch.manual_seed(0)
+    step = TrainStep(cfg)
+    batch = make_batch(2, 128, n_parts=3, seed=9, device=DEV)
+    hist = []
+    for _ in range(20):
+        ld = step(batch)
+        hist.append(float(sum(ld.values())))
+    assert all(np.isfinite(hist)) and len(ld) == 12
+    assert np.mean(hist[-4:]) < np.mean(hist[:4]), hist
