@@ -1,0 +1,94 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel path: the bucketed gradient reducer over the flat
+gradient buffers must give every rank the mean of the per-rank gradients == the single-process gradient of the
+concatenated batch / world, including parameters that receive no gradient, and broadcast_parameters must make the
+replicas identical.  The scalar num_masks all-reduce of the criterion is covered too."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(7, 13)
+        self.conv = torch.nn.Conv2d(3, 5, 3, padding=1)
+        self.b = torch.nn.Linear(13, 3)
+        self.unused = torch.nn.Linear(4, 4)          # never receives a gradient
+        self.big = torch.nn.Linear(64, 300)           # forces several buckets at bucket_mb = 0.01
+
+    def forward(self, x, img):
+        h = self.b(torch.relu(self.a(x)))
+        return h.sum() + self.conv(img).pow(2).mean() + self.big(x.repeat(1, 10)[:, :64]).tanh().sum()
+
+
+def _entries(model):
+    return [{"param": p, "name": n, "lr": 1e-3 if "big" not in n else 1e-4, "weight_decay": 0.0 if n.endswith("bias") else 0.05}
+            for n, p in model.named_parameters()]
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from partdistillation_amd.engine.ddp import BucketedGradReducer, broadcast_parameters
+    from partdistillation_amd.engine.flat_params import FlatParams
+    from partdistillation_amd.modeling.criterion import SetCriterion
+    torch.manual_seed(100 + rank)                    # different init per rank on purpose
+    model = Net()
+    groups = {}
+    for e in reversed(_entries(model)):
+        g = groups.setdefault((e["lr"], e["weight_decay"]), {"params": [], "names": [], "lr": e["lr"], "weight_decay": e["weight_decay"]})
+        g["params"].append(e["param"]); g["names"].append(e["name"])
+    flat = FlatParams(list(groups.values()))
+    broadcast_parameters(flat, 0)
+    reducer = BucketedGradReducer(flat, bucket_mb=0.01)
+    assert len(reducer.buckets) >= 3
+    torch.manual_seed(7)
+    xs, imgs = torch.randn(2 * world, 7), torch.randn(2 * world, 3, 6, 6)
+    for it in range(2):                               # two iterations: hooks/buckets must re-arm
+        flat.zero_grad()
+        model(xs[2 * rank:2 * rank + 2], imgs[2 * rank:2 * rank + 2]).backward()
+        reducer.finish()
+    crit = SetCriterion(1, None, {}, 0.1, [], 4, 3.0, 0.75)
+    nm = crit.num_masks([{"labels": torch.zeros(3 + 2 * rank)}], torch.device("cpu"))
+    torch.save({"params": {n: p.detach().clone() for n, p in model.named_parameters()},
+                "grads": {n: p.grad.detach().clone() for n, p in model.named_parameters()}, "num_masks": nm,
+                "xs": xs, "imgs": imgs}, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_reducer_two_ranks_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    for n in r0["params"]:
+        assert torch.equal(r0["params"][n], r1["params"][n]), f"replicas differ after broadcast: {n}"
+        torch.testing.assert_close(r0["grads"][n], r1["grads"][n], rtol=0, atol=0)
+    # single-process reference: same weights, per-rank losses summed / world
+    model = Net()
+    model.load_state_dict(r0["params"])
+    xs, imgs = r0["xs"], r0["imgs"]
+    loss = sum(model(xs[2 * r:2 * r + 2], imgs[2 * r:2 * r + 2]) for r in range(world)) / world
+    loss.backward()
+    for n, p in model.named_parameters():
+        want = p.grad if p.grad is not None else torch.zeros_like(p)
+        torch.testing.assert_close(r0["grads"][n], want, rtol=1e-5, atol=1e-6, msg=lambda m: f"{n}: {m}")
+    # num_masks = clamp(sum_over_ranks / world, 1) (criterion.py:248-254): (3 + 5) / 2
+    assert float(r0["num_masks"]) == 4.0 and float(r1["num_masks"]) == 4.0
