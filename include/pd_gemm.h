@@ -1,0 +1,32 @@
+/*
+ * pd_gemm.h — C-ABI of the fp32 MFMA GEMMs of libpd_hip.so.
+ *
+ * The reference keeps the pixel decoder in fp32 under AMP
+ * (pixel_decoder/msdeformattn.py:318 `@autocast(enabled=False)`, :324/:348 `.float()`), so its six encoder layers
+ * run ~1.1 TFLOP of fp32 nn.Linear work per step at config 2 (ops/modules/ms_deform_attn.py:102-107,130;
+ * msdeformattn.py:120-124).  These kernels do that work on the matrix cores with v_mfma_f32_32x32x2_f32 (exact fp32
+ * FMA chains, no TF32/bf16 rounding).  Row-major operands, device pointers, `stream` = hipStream_t.
+ */
+#ifndef PD_GEMM_H
+#define PD_GEMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (then ReLU if relu != 0).  K % 4 == 0, lda/ldb/ldc % 4 == 0, 16-byte
+ * aligned pointers.  nn.Linear forward (A = x, B = weight) and its input gradient (A = dy, B = weight^T). */
+int pd_gemm_tn_f32(const float *A, const float *B, const float *bias, float *C, int M, int N, int K, int lda, int ldb,
+                   int ldc, int relu, void *stream);
+
+/* dW[N,K] = dY[M,N]^T . X[M,K]  (nn.Linear weight gradient; contraction over the M rows, split over workgroups and
+ * combined with fp32 atomics: dW is zero-filled by the library first).  N % 4 == 0, K % 4 == 0. */
+int pd_gemm_wgrad_f32(const float *dY, const float *X, float *dW, int M, int N, int K, int ldy, int ldx, int ldw,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PD_GEMM_H */

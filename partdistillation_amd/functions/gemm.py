@@ -1,0 +1,87 @@
+"""fp32 nn.Linear on the matrix cores (pd_gemm_tn_f32 / pd_gemm_wgrad_f32, include/pd_gemm.h): forward, input
+gradient and weight gradient as hand-written MFMA GEMMs; exact fp32 arithmetic (no TF32 / bf16 rounding)."""
+import torch
+from torch.autograd import Function
+
+from .. import lib as _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def gemm_tn(a, b, bias=None, relu=False):
+    """a [M,K], b [N,K] fp32 row-major (last dim contiguous) -> a @ b.T (+bias) (ReLU)."""
+    if not a.is_cuda:
+        raise RuntimeError("pd_gemm_tn_f32 runs on the GPU only (no CPU fallback in partdistillation_amd)")
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        rc = _lib.load().pd_gemm_tn_f32(a.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                        c.data_ptr(), M, N, K, a.stride(0), b.stride(0), N, int(relu), _stream())
+    _lib.check(rc)
+    return c
+
+
+def gemm_wgrad(dy, x):
+    """dy [M,N], x [M,K] -> dy.T @ x  [N,K]."""
+    if not dy.is_cuda:
+        raise RuntimeError("pd_gemm_wgrad_f32 runs on the GPU only (no CPU fallback in partdistillation_amd)")
+    M, N = dy.shape
+    K = x.shape[1]
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        rc = _lib.load().pd_gemm_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), M, N, K, dy.stride(0), x.stride(0), K,
+                                           _stream())
+    _lib.check(rc)
+    return dw
+
+
+# Measured on MI355X (tools/bench_gemm.py, M = 43008 tokens): the library's heuristic is good for the forward and
+# input-gradient shapes (100-125 TFLOP/s fp32) but picks ~44 TFLOP/s kernels for the weight gradient (contraction
+# over the 43008 tokens); pd_gemm_wgrad_f32 runs those at 105-114 TFLOP/s.  `ALL_MFMA` routes all three through
+# the hand-written kernels (used by the tests; 65-97 TFLOP/s on fwd/dgrad today).
+ALL_MFMA = False
+
+
+class LinearF32(Function):
+    """y = x W^T + b on [*, K] fp32 inputs; optional fused ReLU (its mask is recovered from y > 0 in backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(1) != 1 or x2.stride(0) % 4:
+            x2 = x2.contiguous()
+        if ALL_MFMA:
+            y = gemm_tn(x2, weight, bias, relu)
+        else:
+            y = torch.nn.functional.linear(x2, weight, bias)
+            if relu:
+                y = torch.relu_(y)
+        ctx.relu = relu
+        ctx.save_for_backward(x2, weight, y if relu else None)
+        ctx.has_bias = bias is not None
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight, y = ctx.saved_tensors
+        g2 = gy.reshape(-1, gy.shape[-1])
+        if ctx.relu:
+            g2 = g2 * (y > 0)
+        elif g2.stride(1) != 1 or g2.stride(0) % 4:
+            g2 = g2.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = (gemm_tn(g2, weight.t().contiguous()) if ALL_MFMA else g2 @ weight).view(*gy.shape[:-1], weight.shape[1])
+        if ctx.needs_input_grad[1]:
+            gw = gemm_wgrad(g2, x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gw, gb, None
+
+
+def linear_f32(x, weight, bias=None, relu=False):
+    return LinearF32.apply(x, weight, bias, relu)

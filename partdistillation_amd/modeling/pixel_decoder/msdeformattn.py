@@ -14,6 +14,7 @@ from torch.nn.init import normal_
 from ...compat import SEM_SEG_HEADS_REGISTRY, ShapeSpec, configurable
 from ...compat.layers import Conv2d, c2_xavier_fill, get_norm
 from ..transformer_decoder.position_encoding import PositionEmbeddingSine
+from ...functions.gemm import linear_f32
 from .ops.modules import MSDeformAttn
 
 
@@ -34,7 +35,12 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         q = src if pos is None else src + pos
         attn = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)
         src = self.norm1(src + self.dropout1(attn))
-        ffn = self.linear2(self.dropout2(F.relu(self.linear1(src))))
+        lin = MSDeformAttn._linear
+        if self.dropout2.p == 0.0 and src.dtype == torch.float32 and src.is_cuda and not torch.is_autocast_enabled():
+            hidden = linear_f32(src, self.linear1.weight, self.linear1.bias, True)      # bias + ReLU fused
+        else:
+            hidden = self.dropout2(F.relu(self.linear1(src)))
+        ffn = lin(self.linear2, hidden)
         return self.norm2(src + self.dropout3(ffn))
 
 

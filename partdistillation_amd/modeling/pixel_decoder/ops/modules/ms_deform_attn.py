@@ -10,6 +10,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
+from .....functions.gemm import linear_f32
 from ..functions.ms_deform_attn_func import MSDeformAttnFunction
 
 
@@ -54,12 +55,13 @@ class MSDeformAttn(nn.Module):
                 input_padding_mask=None):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
-        value = self.value_proj(input_flatten)
+        lin = self._linear
+        value = lin(self.value_proj, input_flatten)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
-        offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-        weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        offsets = lin(self.sampling_offsets, query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        weights = lin(self.attention_weights, query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
         weights = F.softmax(weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
         if reference_points.shape[-1] == 2:
             normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
@@ -71,4 +73,11 @@ class MSDeformAttn(nn.Module):
             raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
         output = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                             locations.contiguous(), weights.contiguous(), self.im2col_step)
-        return self.output_proj(output)
+        return lin(self.output_proj, output)
+
+    @staticmethod
+    def _linear(layer, x):
+        """fp32 tokens x weights: hand-written MFMA weight-gradient GEMM (functions/gemm.py); other dtypes -> torch."""
+        if x.dtype == torch.float32 and layer.weight.dtype == torch.float32 and x.is_cuda and not torch.is_autocast_enabled():
+            return linear_f32(x, layer.weight, layer.bias)
+        return layer(x)
