@@ -31,6 +31,13 @@ int pd_adamw_clipped(void *param, const void *grad, void *exp_avg, void *exp_avg
                      double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                      const double *grad_sumsq, double max_norm, void *stream);
 
+/* fp32 variant that also writes a bf16 (round-to-nearest-even) copy of the updated parameters to `shadow_bf16`:
+ * the autocast (bf16) modules read that copy directly instead of re-casting every weight every step.
+ * n % 4 == 0, 16-byte aligned buffers (8-byte for the shadow). */
+int pd_adamw_clipped_shadow(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, void *shadow_bf16,
+                            int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
+                            const double *grad_sumsq, double max_norm, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

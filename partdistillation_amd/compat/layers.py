@@ -17,9 +17,25 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features) - eps)
 
+        self._cache = None
+
     def scale_bias(self):
-        scale = self.weight * (self.running_var + self.eps).rsqrt()
-        return scale, self.bias - self.running_mean * scale
+        """(scale, bias) of the equivalent per-channel affine; the four buffers are frozen, so the pair is computed
+        once and reused (invalidated when the buffers are re-loaded or moved)."""
+        c = self._cache
+        if c is None or c[0].device != self.weight.device or c[2] != self.weight._version + self.running_var._version:
+            scale = self.weight * (self.running_var + self.eps).rsqrt()
+            c = (scale, self.bias - self.running_mean * scale, self.weight._version + self.running_var._version)
+            self._cache = c
+        return c[0], c[1]
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._cache = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, recurse=True):
+        self._cache = None
+        return super()._apply(fn, recurse)
 
     def forward(self, x):
         scale, bias = self.scale_bias()

@@ -90,6 +90,40 @@ __global__ __launch_bounds__(256) void adamw_kernel_f32x4(float4 *__restrict__ p
   }
 }
 
+// as adamw_kernel_f32x4, and additionally refreshes the bf16 copy of the parameters that the autocast modules read
+__global__ __launch_bounds__(256) void adamw_kernel_f32x4_shadow(float4 *__restrict__ p, const float4 *__restrict__ g,
+                                                                  float4 *__restrict__ m, float4 *__restrict__ v,
+                                                                  ushort4 *__restrict__ shadow, int64_t n4, float lr, float b1,
+                                                                  float b2, float eps, float wd, float bc1, float sqrt_bc2,
+                                                                  const double *__restrict__ sumsq, float max_norm)
+{
+  float coef = 1.f;
+  if (max_norm > 0.f) {
+    const float total = (float)sqrt(*sumsq);
+    coef = fminf(max_norm / (total + 1e-6f), 1.f);
+  }
+  const float step_size = lr / bc1, decay = 1.f - lr * wd;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 P = p[i], G = g[i], M = m[i], V = v[i];
+    float *pp = &P.x, *gg = &G.x, *mm = &M.x, *vv = &V.x;
+    unsigned short sh[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float gi = gg[c] * coef;
+      const float mi = b1 * mm[c] + (1.f - b1) * gi;
+      const float vi = b2 * vv[c] + (1.f - b2) * gi * gi;
+      pp[c] = pp[c] * decay - step_size * (mi / (sqrtf(vi) / sqrt_bc2 + eps));
+      mm[c] = mi; vv[c] = vi;
+      unsigned u = __float_as_uint(pp[c]);
+      u += 0x7fffu + ((u >> 16) & 1u);
+      sh[c] = (unsigned short)(u >> 16);
+    }
+    p[i] = P; m[i] = M; v[i] = V;
+    shadow[i] = make_ushort4(sh[0], sh[1], sh[2], sh[3]);
+  }
+}
+
 inline int grid_for(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
 
 }  // namespace
@@ -107,6 +141,22 @@ extern "C" int pd_sumsq_accumulate(const void *x, int64_t n, int dtype, double *
     hipLaunchKernelGGL(sumsq_kernel<double>, dim3(grid_for(n)), dim3(256), 0, s, (const double *)x, n, accum);
   }
   return pd_check_launch("pd_sumsq_accumulate");
+}
+
+extern "C" int pd_adamw_clipped_shadow(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, void *shadow_bf16,
+                                       int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                       int step, const double *grad_sumsq, double max_norm, void *stream_)
+{
+  if (n < 0 || step < 1 || (n & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_adamw_clipped_shadow: n=%lld (must be a multiple of 4) step=%d", (long long)n, step);
+  if (n == 0) return PD_OK;
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !shadow_bf16 || (max_norm > 0 && !grad_sumsq))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_adamw_clipped_shadow: null pointer");
+  const double bc1 = 1.0 - pow(beta1, step), sqrt_bc2 = sqrt(1.0 - pow(beta2, step));
+  hipLaunchKernelGGL(adamw_kernel_f32x4_shadow, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream_, (float4 *)param,
+                     (const float4 *)grad, (float4 *)exp_avg, (float4 *)exp_avg_sq, (ushort4 *)shadow_bf16, n / 4, (float)lr,
+                     (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)bc1, (float)sqrt_bc2, grad_sumsq,
+                     (float)max_norm);
+  return pd_check_launch("pd_adamw_clipped_shadow");
 }
 
 extern "C" int pd_adamw_clipped(void *param, const void *grad, void *exp_avg, void *exp_avg_sq, int64_t n, int dtype,

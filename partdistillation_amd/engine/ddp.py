@@ -1,14 +1,12 @@
-"""Data-parallel gradient exchange: one process per GPU, the model
-replicated, gradients averaged with bucketed all-reduces over RCCL/xGMI that
-are issued from autograd hooks on a side HIP stream while backward is still
-running.  The buckets are contiguous SLICES of the flat gradient buffers
-(flat_params.py), so a bucket is reduced in place — no copy-in / copy-out.
+"""Data-parallel gradient exchange: one process per GPU, the model replicated, gradients averaged
+with bucketed all-reduces over RCCL/xGMI that are issued from autograd hooks on a side HIP stream while backward is
+still running.  A bucket is a run of consecutive parameters of one flat group: when the last of its gradients has
+been produced, one multi-tensor kernel gathers them into the bucket's contiguous SLICE of the flat gradient buffer
+(engine/flat_params.py) and the slice is all-reduced in place — no bucket copy-in / copy-out.
 
-The reference gets this from detectron2's ``create_ddp_model`` (torch DDP,
-NCCL); the only other collective on the path is the scalar ``num_masks``
-all-reduce of criterion.py:252-254, kept in modeling/criterion.py.
-Works with any torch.distributed backend ("nccl" = RCCL on ROCm; "gloo" in the
-CPU tests)."""
+The reference gets this from detectron2's ``create_ddp_model`` (torch DDP over NCCL); the only other collective on
+the path is the scalar ``num_masks`` all-reduce of criterion.py:252-254, kept in modeling/criterion.py.
+Works with any torch.distributed backend ("nccl" = RCCL on ROCm; "gloo" in the CPU tests)."""
 from typing import List
 
 import torch
@@ -16,34 +14,32 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("group", "start", "end", "pending", "total", "work")
+    __slots__ = ("group", "t_begin", "t_end", "start", "end", "pending", "total", "work")
 
-    def __init__(self, group, start, end, total):
-        self.group, self.start, self.end, self.total = group, start, end, total
-        self.pending, self.work = total, None
+    def __init__(self, group, t_begin, t_end, start, end):
+        self.group, self.t_begin, self.t_end, self.start, self.end = group, t_begin, t_end, start, end
+        self.total = t_end - t_begin
+        self.pending, self.work = self.total, None
 
 
 class BucketedGradReducer:
-    def __init__(self, flat, bucket_mb: float = 25.0, process_group=None, overlap: bool = True):
-        self.flat, self.pg = flat, process_group
+    def __init__(self, flat, bucket_mb: float = 25.0, process_group=None, overlap: bool = True, optimizer=None):
+        self.flat, self.pg, self.optimizer = flat, process_group, optimizer
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.overlap = overlap
         self.buckets: List[_Bucket] = []
         self._param_bucket = {}
         cap_bytes = int(bucket_mb * 1024 * 1024)
         for gi, g in enumerate(flat.groups):
             cap = max(1, cap_bytes // g.grad.element_size())
-            start, count = 0, 0
-            members = []
-            for p, off in zip(g.params, g.offsets):
-                end = off + (p.numel() + 3) // 4 * 4
-                members.append(p)
-                count += 1
-                if end - start >= cap:
-                    self._add(gi, start, end, members)
-                    start, members, count = end, [], 0
-            if members:
-                self._add(gi, start, g.numel, members)
+            t0 = 0
+            for t, (p, off) in enumerate(zip(g.params, g.offsets)):
+                end = g.offsets[t + 1] if t + 1 < len(g.params) else g.numel
+                if end - g.offsets[t0] >= cap or t + 1 == len(g.params):
+                    b = _Bucket(gi, t0, t + 1, g.offsets[t0], end)
+                    self.buckets.append(b)
+                    for q in g.params[t0:t + 1]:
+                        self._param_bucket[q] = b
+                    t0 = t + 1
         self._use_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         dev = flat.groups[0].grad.device
         self._side = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and overlap) else None
@@ -52,12 +48,6 @@ class BucketedGradReducer:
             for g in flat.groups:
                 for p in g.params:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
-
-    def _add(self, gi, start, end, members):
-        b = _Bucket(gi, start, end, len(members))
-        self.buckets.append(b)
-        for p in members:
-            self._param_bucket[p] = b
 
     # ------------------------------------------------------------------ hooks
     def _on_grad(self, p):
@@ -68,19 +58,18 @@ class BucketedGradReducer:
 
     def _launch(self, b):
         g = self.flat.groups[b.group]
+        g.gather(None, b.t_begin, b.t_end)                       # compute stream: p.grad tensors -> flat slice
         buf = g.grad[b.start:b.end]
         if self._side is not None:
-            self._side.wait_stream(torch.cuda.current_stream(buf.device))    # grads of this bucket are complete
+            self._side.wait_stream(torch.cuda.current_stream(buf.device))
             with torch.cuda.stream(self._side):
                 self._reduce(b, buf)
         else:
             self._reduce(b, buf)
 
     def _reduce(self, b, buf):
-        if self._use_avg:
-            b.work = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
-        else:
-            b.work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
+        b.work = dist.all_reduce(buf, op=op, group=self.pg, async_op=True)
 
     def finish(self):
         """call after backward: reduce buckets whose hooks did not all fire (unused params), wait for the
@@ -102,6 +91,8 @@ class BucketedGradReducer:
             b.work, b.pending = None, b.total
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
+        if self.optimizer is not None:
+            self.optimizer.grads_ready = True                    # step() must not gather again
 
     def remove(self):
         for h in self._hooks:
@@ -113,3 +104,5 @@ def broadcast_parameters(flat, src=0, process_group=None):
     if dist.is_initialized() and dist.get_world_size(process_group) > 1:
         for g in flat.groups:
             dist.broadcast(g.param, src=src, group=process_group)
+            if g.shadow is not None:
+                g.shadow.copy_(g.param)

@@ -17,6 +17,19 @@ _NORM_TYPES = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.SyncBatchNorm,
                nn.InstanceNorm2d, nn.InstanceNorm3d, nn.LayerNorm, nn.LocalResponseNorm, FrozenBatchNorm2d)
 
 
+def _wants_bf16_shadow(module_name, module, pname, value):
+    """weights that torch.autocast would cast to bf16 at every use: conv / linear / attention projection weights and
+    biases of the autocast regions (backbone, transformer predictor).  Norm layers, embeddings, everything in the
+    fp32 pixel decoder and non-fp32 parameters keep fp32 storage."""
+    if value.dtype != torch.float32 or "pixel_decoder" in module_name or "criterion" in module_name:
+        return False
+    if isinstance(module, _NORM_TYPES) or isinstance(module, nn.Embedding):
+        return False
+    if isinstance(module, (nn.Conv2d, nn.Linear)):
+        return True
+    return pname in ("in_proj_weight", "in_proj_bias")            # attention projections (_MHAParams)
+
+
 def param_hyperparams(cfg, model) -> List[Dict]:
     """one entry per trainable parameter: {"param", "name", "lr", "weight_decay"} — the loop of
     base_trainer.py:88-116 (including its side effect: parameters whose module name contains a
@@ -41,7 +54,7 @@ def param_hyperparams(cfg, model) -> List[Dict]:
             if isinstance(module, nn.Embedding):
                 wd = cfg.SOLVER.WEIGHT_DECAY_EMBED
             out.append({"param": value, "name": f"{module_name}.{pname}" if module_name else pname, "lr": lr,
-                        "weight_decay": wd})
+                        "weight_decay": wd, "shadow": _wants_bf16_shadow(module_name, module, pname, value)})
     return out
 
 
@@ -49,13 +62,14 @@ class FlatClippedAdamW:
     """AdamW with full-model L2 clipping over flat buffers (HIP kernels pd_sumsq_accumulate + pd_adamw_clipped).
     ``param_groups`` exposes lr / weight_decay per flat group like a torch optimizer (for LR schedulers)."""
 
-    def __init__(self, entries: List[Dict], betas=(0.9, 0.999), eps=1e-8, clip_norm=0.0):
+    def __init__(self, entries: List[Dict], betas=(0.9, 0.999), eps=1e-8, clip_norm=0.0, bf16_shadow=False):
         groups: Dict = {}
         # reverse registration order ~ the order gradients become ready in backward (DDP buckets fill front to back)
         for e in reversed(entries):
-            key = (e["lr"], e["weight_decay"])
+            shadow = bool(bf16_shadow and e.get("shadow", False))
+            key = (e["lr"], e["weight_decay"], shadow)
             g = groups.setdefault(key, {"params": [], "names": [], "lr": e["lr"], "initial_lr": e["lr"],
-                                        "weight_decay": e["weight_decay"]})
+                                        "weight_decay": e["weight_decay"], "shadow": shadow})
             g["params"].append(e["param"])
             g["names"].append(e["name"])
         self.flat = FlatParams(list(groups.values()))
@@ -66,6 +80,7 @@ class FlatClippedAdamW:
         dev = self.flat.groups[0].param.device
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
         self.steps = 0
+        self.grads_ready = False          # set by the data-parallel reducer when it has already gathered + reduced
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
@@ -78,13 +93,19 @@ class FlatClippedAdamW:
     def step(self):
         self.steps += 1
         self._sumsq.zero_()
-        if self.clip_norm > 0:
+        if self.grads_ready:                               # flat gradients already gathered and all-reduced
+            if self.clip_norm > 0:
+                for g in self.flat.groups:
+                    optim_op.sumsq_accumulate(g.grad, self._sumsq)
+        else:                                              # single process: gather + sum of squares in one pass
             for g in self.flat.groups:
-                optim_op.sumsq_accumulate(g.grad, self._sumsq)
+                g.gather(self._sumsq if self.clip_norm > 0 else None)
+        self.grads_ready = False
         for g, pg, m, v in zip(self.flat.groups, self.param_groups, self.exp_avg, self.exp_avg_sq):
             optim_op.adamw_clipped_(g.param, g.grad, m, v, lr=pg["lr"], betas=self.betas, eps=self.eps,
                                     weight_decay=pg["weight_decay"], step=self.steps,
-                                    grad_sumsq=self._sumsq if self.clip_norm > 0 else None, max_norm=self.clip_norm)
+                                    grad_sumsq=self._sumsq if self.clip_norm > 0 else None, max_norm=self.clip_norm,
+                                    shadow=g.shadow)
 
     def state_dict(self):
         return {"steps": self.steps, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
@@ -102,11 +123,12 @@ class FlatClippedAdamW:
 
 def build_optimizer(cfg, model):
     entries = param_hyperparams(cfg, model)
+    shadow = bool(cfg.SOLVER.AMP.ENABLED) and next(model.parameters()).is_cuda
     if cfg.SOLVER.OPTIMIZER != "ADAMW":
         raise NotImplementedError(f"no optimizer type {cfg.SOLVER.OPTIMIZER} on the MI355X path (ADAMW only)")
     cg = cfg.SOLVER.CLIP_GRADIENTS
     clip = cg.CLIP_VALUE if (cg.ENABLED and cg.CLIP_TYPE == "full_model" and cg.CLIP_VALUE > 0.0) else 0.0
-    return FlatClippedAdamW(entries, clip_norm=clip)
+    return FlatClippedAdamW(entries, clip_norm=clip, bf16_shadow=shadow)
 
 
 class WarmupMultiStepLR:

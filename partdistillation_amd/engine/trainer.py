@@ -26,7 +26,8 @@ class TrainStep:
         self.amp = bool(cfg.SOLVER.AMP.ENABLED)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         broadcast_parameters(self.optimizer.flat, 0, process_group)
-        self.reducer = BucketedGradReducer(self.optimizer.flat, cfg.MODEL.AMD.DDP_BUCKET_MB, process_group)
+        self.reducer = BucketedGradReducer(self.optimizer.flat, cfg.MODEL.AMD.DDP_BUCKET_MB, process_group,
+                                           optimizer=self.optimizer)
         self.iter = 0
 
     def __call__(self, batched_inputs):
@@ -35,10 +36,28 @@ class TrainStep:
         self.optimizer.zero_grad()
         with torch.autocast(device_type=dev_type, dtype=torch.bfloat16, enabled=self.amp):
             loss_dict = self.model(batched_inputs)
-            total = sum(loss_dict.values())
+            total = getattr(loss_dict, "total", None)
+            if total is None:
+                total = sum(loss_dict.values())
         total.backward()
         self.reducer.finish()
         self.optimizer.step()
         self.scheduler.step()
         self.iter += 1
         return loss_dict
+
+    def state_dict(self):
+        """checkpoint with the reference's key names: fp32 master weights (modules hold bf16 copies of some), buffers,
+        optimizer moments and the iteration."""
+        sd = {k: v for k, v in self.model.state_dict().items()}
+        sd.update(self.optimizer.flat.master_state())
+        return {"model": sd, "optimizer": self.optimizer.state_dict(), "iteration": self.iter}
+
+    def load_model_state(self, model_sd, strict=False):
+        """load reference-format weights: into the modules (bf16 copies) AND the fp32 masters."""
+        missing = self.model.load_state_dict(model_sd, strict=strict)
+        masters = self.optimizer.flat.master_state()
+        for k, m in masters.items():
+            if k in model_sd:
+                m.copy_(model_sd[k])
+        return missing

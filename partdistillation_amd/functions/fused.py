@@ -1,0 +1,99 @@
+"""Python faces of the fused bandwidth-bound kernels (include/pd_fused.h)."""
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from .. import lib as _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _nhwc(t):
+    return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+
+class AffineAct(Function):
+    """y = act(x * scale[c] + bias[c] (+ residual)) on bf16 NCHW-shaped, channels-last-stored tensors; scale/bias are
+    constants (frozen BatchNorm), so only x and residual receive gradients."""
+
+    @staticmethod
+    def forward(ctx, x, scale, bias, residual, relu):
+        x = _nhwc(x)
+        res = _nhwc(residual) if residual is not None else None
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().pd_affine_act_fwd_bf16(x.data_ptr(), res.data_ptr() if res is not None else None,
+                                                    scale.data_ptr(), bias.data_ptr(), y.data_ptr(), x.numel(), x.shape[1],
+                                                    int(relu), _stream())
+        _lib.check(rc)
+        ctx.relu, ctx.has_res = relu, residual is not None
+        ctx.save_for_backward(y if relu else None, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, scale = ctx.saved_tensors
+        gy = _nhwc(gy)
+        gx = torch.empty_like(gy, memory_format=torch.channels_last)
+        gres = torch.empty_like(gy, memory_format=torch.channels_last) if ctx.has_res else None
+        with torch.cuda.device(gy.device):
+            rc = _lib.load().pd_affine_act_bwd_bf16(gy.data_ptr(), y.data_ptr() if y is not None else None, scale.data_ptr(),
+                                                    gx.data_ptr(), gres.data_ptr() if gres is not None else None, gy.numel(),
+                                                    gy.shape[1], int(ctx.relu), _stream())
+        _lib.check(rc)
+        return gx, None, None, gres, None
+
+
+def affine_act(x, scale, bias, residual=None, relu=True):
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0):
+        raise RuntimeError("pd_affine_act: bf16 CUDA NCHW tensor with channels % 8 == 0 required (no fallback here)")
+    return AffineAct.apply(x, scale.float().contiguous(), bias.float().contiguous(), residual, relu)
+
+
+class GatherPlan:
+    """static block table for pd_multi_gather_sumsq over a list of (numel, dst_offset) tensors."""
+    CHUNK = 16384
+
+    def __init__(self, numels, dst_offsets, device):
+        bt, bs, bd, bl, first = [], [], [], [], []
+        for t, (n, off) in enumerate(zip(numels, dst_offsets)):
+            first.append(len(bt))
+            for s in range(0, max(n, 1), self.CHUNK):
+                bt.append(t), bs.append(s), bd.append(off + s), bl.append(min(self.CHUNK, n - s))
+        first.append(len(bt))
+        self.first_block = first                                   # tensor t owns blocks [first[t], first[t+1])
+        self.nblocks, self.ntensors = len(bt), len(numels)
+        self.blk_tensor = torch.tensor(bt, dtype=torch.int32, device=device)
+        self.blk_start = torch.tensor(bs, dtype=torch.int64, device=device)
+        self.blk_dst = torch.tensor(bd, dtype=torch.int64, device=device)
+        self.blk_len = torch.tensor(bl, dtype=torch.int32, device=device)
+        pin = device.type == "cuda"
+        self._host_ptrs = torch.zeros(self.ntensors, dtype=torch.int64, pin_memory=pin)
+        self._host_bf16 = torch.zeros(self.ntensors, dtype=torch.int32, pin_memory=pin)
+        self.src_ptrs = torch.zeros(self.ntensors, dtype=torch.int64, device=device)
+        self.src_bf16 = torch.zeros(self.ntensors, dtype=torch.int32, device=device)
+
+    def upload(self, grads, t_begin=0):
+        """grads: tensors or None (-> zeros) of tensors [t_begin, t_begin+len(grads)); records their addresses and
+        element types for the next gather (pinned staging, async copy of just that slice)."""
+        hp, hb = self._host_ptrs.numpy(), self._host_bf16.numpy()
+        for i, g in enumerate(grads, start=t_begin):
+            if g is None:
+                hp[i], hb[i] = 0, 0
+            else:
+                hp[i], hb[i] = g.data_ptr(), 1 if g.dtype == torch.bfloat16 else 0
+        t_end = t_begin + len(grads)
+        self.src_ptrs[t_begin:t_end].copy_(self._host_ptrs[t_begin:t_end], non_blocking=True)
+        self.src_bf16[t_begin:t_end].copy_(self._host_bf16[t_begin:t_end], non_blocking=True)
+
+    def gather(self, dst, sumsq=None, t_begin=0, t_end=None):
+        t_end = self.ntensors if t_end is None else t_end
+        b0, b1 = self.first_block[t_begin], self.first_block[t_end]
+        with torch.cuda.device(dst.device):
+            rc = _lib.load().pd_multi_gather_sumsq(self.src_ptrs.data_ptr(), self.src_bf16.data_ptr(), self.blk_tensor.data_ptr(),
+                                                   self.blk_start.data_ptr(), self.blk_dst.data_ptr(), self.blk_len.data_ptr(),
+                                                   dst.data_ptr(), sumsq.data_ptr() if sumsq is not None else None, b0, b1,
+                                                   _stream())
+        _lib.check(rc)

@@ -15,17 +15,34 @@ import torch.nn.functional as F
 
 from ...compat import BACKBONE_REGISTRY, ShapeSpec
 from ...compat.layers import Conv2d, FrozenBatchNorm2d, c2_msra_fill, get_norm
+from ...functions.fused import affine_act
 
 
-def _conv_bn(conv, x):
-    """conv followed by its norm; FrozenBN is folded into weight/bias."""
+def _conv_bn_act(conv, x, residual=None, relu=True):
+    """conv -> norm (-> + residual) (-> ReLU).
+
+    bf16 autocast on the GPU with a frozen norm (the training configuration): the convolution runs bias-free on the
+    (bf16) filter and ONE HIP kernel applies the frozen-BN affine, the residual add and the ReLU to the NHWC output
+    (functions/fused.py::affine_act) — instead of the fold-multiply, cast, bias pass, add pass and ReLU pass of the
+    unfused chain.  Otherwise (fp32 parity runs, trainable norms): the same arithmetic with torch ops, FrozenBN folded
+    into the filter."""
     norm = conv.norm
-    if isinstance(norm, FrozenBatchNorm2d):
+    frozen = isinstance(norm, FrozenBatchNorm2d)
+    if frozen and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16 \
+            and conv.out_channels % 8 == 0:
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        scale, bias = norm.scale_bias()
+        return affine_act(y, scale, bias, residual, relu)
+    if frozen:
         scale, bias = norm.scale_bias()
         w = conv.weight * scale.view(-1, 1, 1, 1).to(conv.weight.dtype)
-        return F.conv2d(x, w, bias.to(conv.weight.dtype), conv.stride, conv.padding, conv.dilation, conv.groups)
-    y = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
-    return norm(y) if norm is not None else y
+        y = F.conv2d(x, w, bias.to(conv.weight.dtype), conv.stride, conv.padding, conv.dilation, conv.groups)
+    else:
+        y = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+        y = norm(y) if norm is not None else y
+    if residual is not None:
+        y = y + residual
+    return F.relu_(y) if relu else y
 
 
 class BasicStem(nn.Module):
@@ -37,7 +54,7 @@ class BasicStem(nn.Module):
         c2_msra_fill(self.conv1)
 
     def forward(self, x):
-        x = F.relu_(_conv_bn(self.conv1, x))
+        x = _conv_bn_act(self.conv1, x)
         return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
 
 
@@ -62,11 +79,10 @@ class BottleneckBlock(nn.Module):
                 c2_msra_fill(layer)
 
     def forward(self, x):
-        out = F.relu_(_conv_bn(self.conv1, x))
-        out = F.relu_(_conv_bn(self.conv2, out))
-        out = _conv_bn(self.conv3, out)
-        sc = _conv_bn(self.shortcut, x) if self.shortcut is not None else x
-        return F.relu_(out + sc)
+        out = _conv_bn_act(self.conv1, x)
+        out = _conv_bn_act(self.conv2, out)
+        sc = _conv_bn_act(self.shortcut, x, relu=False) if self.shortcut is not None else x
+        return _conv_bn_act(self.conv3, out, residual=sc, relu=True)
 
 
 class ResNet(nn.Module):

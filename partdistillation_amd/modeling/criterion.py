@@ -46,6 +46,8 @@ class SetCriterion(nn.Module):
         self.num_points, self.oversample_ratio, self.importance_sample_ratio = \
             num_points, oversample_ratio, importance_sample_ratio
         self.rand = None            # replay hook for parity tests (see matcher.rand)
+        self._nm_cache = {}
+        self.batched = True         # all heads in one pass (criterion_batched.py); False = the reference's per-head loop
 
     # ------------------------------------------------------------------ losses
     def loss_labels(self, outputs, targets, indices, num_masks):
@@ -104,12 +106,29 @@ class SetCriterion(nn.Module):
 
     def num_masks(self, targets, device):
         """average number of target masks per rank, clamped to >= 1 (reference :248-254), as a device scalar."""
-        n = torch.as_tensor([float(sum(len(t["labels"]) for t in targets))], dtype=torch.float, device=device)
-        if is_dist_avail_and_initialized():
-            torch.distributed.all_reduce(n)
+        count = float(sum(len(t["labels"]) for t in targets))
+        if not is_dist_avail_and_initialized() or get_world_size() == 1:
+            key = (count, str(device))                       # cached constant: no per-step host->device copy
+            if key not in self._nm_cache:
+                self._nm_cache[key] = torch.tensor(max(count, 1.0), dtype=torch.float, device=device)
+            return self._nm_cache[key]
+        n = torch.as_tensor([count], dtype=torch.float, device=device)
+        torch.distributed.all_reduce(n)
         return torch.clamp(n / get_world_size(), min=1)[0]
 
+    def _can_batch(self, outputs, targets):
+        return (self.batched and "aux_outputs" in outputs and outputs["pred_logits"].is_cuda and len(targets) > 0
+                and self.losses == ["labels", "masks"] and all(t["labels"].shape[0] > 0 for t in targets)
+                and outputs["pred_masks"] is not None)
+
     def forward(self, outputs, targets):
+        if self._can_batch(outputs, targets):
+            from .criterion_batched import batched_set_criterion
+            if "_padded_masks" in targets[0]:
+                padded = targets[0]["_padded_masks"]
+            else:
+                padded, _ = nested_tensor_from_tensor_list([t["masks"] for t in targets]).decompose()
+            return batched_set_criterion(self, outputs, targets, padded)
         outputs_without_aux = {k: v for k, v in outputs.items() if k != "aux_outputs"}
         if self.rand is not None:
             self.matcher.rand = self.rand

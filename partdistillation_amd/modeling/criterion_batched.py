@@ -1,0 +1,158 @@
+"""All prediction heads of the set criterion in ONE pass.
+
+The reference (criterion.py:235-270, matcher.py:100-168) loops over the final + 9 auxiliary outputs and, inside the
+matcher, over the images: ~150 tiny launches and one host round trip per (head, image).  Nothing in that loop is
+sequentially dependent — every head's matching depends only on that head's outputs — so here the H heads x B images
+are stacked and processed together with the same arithmetic:
+
+  * point sampling uses the CHANNEL dimension for the batch of masks that share coordinates: the Q query masks of a
+    (head, image) are Q channels of one grid_sample input, the n target masks of an image are n channels, so no mask
+    is repeated or re-cast per call (the reference repeats the coordinates per mask, matcher.py:130-139);
+  * the H*B assignment problems are one launch of pd_lsa_batched;
+  * matched pairs are addressed through index tensors built from host-known sizes (n_b per image), so no
+    boolean-mask indexing / .nonzero() synchronises the host;
+  * importance sampling runs one top-k over all matched masks of all heads.
+
+Random draws follow the reference's order (per head: B matcher draws, then the oversampled and the random point sets
+of loss_masks) when a replay hook is installed, so parity tests can replay them; otherwise three device-side draws.
+Loss values are identical to the per-head loop up to fp32 summation order."""
+import torch
+import torch.nn.functional as F
+
+from ..functions import lsa as lsa_op
+
+
+class LossDict(dict):
+    """dict of per-head losses that also carries their stacked vectors (one autograd node per loss type)."""
+    vectors = None
+    total = None
+
+
+_SEL_CACHE = {}
+
+
+def _pair_selectors(H, B, npair, device):
+    key = (H, B, tuple(npair), str(device))
+    if key not in _SEL_CACHE:
+        sel_h, sel_b, sel_k = [], [], []
+        for h in range(H):
+            for b in range(B):
+                for k in range(npair[b]):
+                    sel_h.append(h), sel_b.append(b), sel_k.append(k)
+        mk = lambda x: torch.tensor(x, dtype=torch.long, device=device)
+        per_image = [mk([i for i, bb in enumerate(sel_b) if bb == b]) for b in range(B)]
+        _SEL_CACHE[key] = (mk(sel_h), mk(sel_b), mk(sel_k), per_image)
+    return _SEL_CACHE[key]
+
+
+_CONST_CACHE = {}
+
+
+def _const(values, dtype, device):
+    key = (tuple(values), dtype, str(device))
+    if key not in _CONST_CACHE:
+        _CONST_CACHE[key] = torch.tensor(list(values), dtype=dtype, device=device)
+    return _CONST_CACHE[key]
+
+
+def _gs(inp, coords):
+    """grid_sample of [N,C,H,W] at coords [N,P,2] in [0,1] (x,y) -> [N,C,P]; bilinear, zeros, align_corners=False."""
+    return F.grid_sample(inp, 2.0 * coords.unsqueeze(2) - 1.0, mode="bilinear", padding_mode="zeros", align_corners=False).squeeze(3)
+
+
+def batched_set_criterion(crit, outputs, targets, padded_masks):
+    """-> LossDict with the reference's 3*H keys.  `padded_masks` bool [B, n_max, Hm, Wm]."""
+    m = crit.matcher
+    dev = outputs["pred_logits"].device
+    aux = outputs["aux_outputs"]
+    logits = torch.stack([outputs["pred_logits"]] + [a["pred_logits"] for a in aux])           # [H,B,Q,K1]
+    masks = torch.stack([outputs["pred_masks"]] + [a["pred_masks"] for a in aux])              # [H,B,Q,h,w]
+    H, B, Q = logits.shape[:3]
+    K1 = logits.shape[-1]
+    ns = [int(t["labels"].shape[0]) for t in targets]
+    nmax = max(ns)
+    npair = [min(Q, n) for n in ns]
+    N_h = sum(npair)
+    Pm, P = m.num_points, crit.num_points
+    kover, kimp = int(P * crit.oversample_ratio), int(crit.importance_sample_ratio * P)
+    krand = P - kimp
+
+    # ---- random draws (reference order when replayed)
+    if crit.rand is not None:
+        mc, oc, rc = [], [], []
+        for _ in range(H):
+            mc.append(torch.stack([crit.rand((1, Pm, 2))[0] for _ in range(B)]))
+            oc.append(crit.rand((N_h, kover, 2)))
+            if krand > 0:
+                rc.append(crit.rand((N_h, krand, 2)))
+        mcoords = torch.stack(mc).to(dev)
+        ocoords = torch.cat(oc).to(dev)
+        rcoords = torch.cat(rc).to(dev) if krand > 0 else None
+    else:
+        mcoords = torch.rand((H, B, Pm, 2), device=dev)
+        ocoords = torch.rand((H * N_h, kover, 2), device=dev)
+        rcoords = torch.rand((H * N_h, krand, 2), device=dev) if krand > 0 else None
+
+    tmask = padded_masks.float()                                                                # [B,nmax,Hm,Wm], once
+    labels_pad = torch.zeros((B, nmax), dtype=torch.long, device=dev)
+    for b, t in enumerate(targets):
+        labels_pad[b, : ns[b]] = t["labels"]
+    ncols = _const([ns[b] for _ in range(H) for b in range(B)], torch.int32, dev)
+
+    with torch.no_grad(), torch.autocast(device_type=dev.type, enabled=False):
+        # ---- matcher costs for all (head, image) problems (matcher.py:108-158)
+        pm = _gs(masks.detach().reshape(H * B, Q, *masks.shape[-2:]).float(), mcoords.reshape(H * B, Pm, 2))    # [HB,Q,Pm]
+        tg = _gs(tmask, mcoords.permute(1, 0, 2, 3).reshape(B, H * Pm, 2))                                      # [B,nmax,H*Pm]
+        tg = tg.reshape(B, nmax, H, Pm).permute(2, 0, 1, 3).reshape(H * B, nmax, Pm)                            # [HB,nmax,Pm]
+        tgt = tg.transpose(1, 2)
+        cost_mask = (F.softplus(pm).sum(-1)[:, :, None] - torch.bmm(pm, tgt)) / Pm
+        sg = pm.sigmoid()
+        cost_dice = 1 - (2 * torch.bmm(sg, tgt) + 1) / (sg.sum(-1)[:, :, None] + tg.sum(-1)[:, None, :] + 1)
+        lf = logits.detach().float()
+        prob = lf.sigmoid() if K1 == 1 else lf.softmax(-1)
+        cost_class = -torch.gather(prob, 3, labels_pad[None, :, None, :].expand(H, B, Q, nmax)).reshape(H * B, Q, nmax)
+        C = m.cost_mask * cost_mask + m.cost_class * cost_class + m.cost_dice * cost_dice
+        rows, cols = lsa_op.solve_batched(C, ncols)                                                             # [HB,nmax]
+        sel_h, sel_b, sel_k, per_image = _pair_selectors(H, B, npair, dev)
+        sel_hb = sel_h * B + sel_b
+        q_idx, j_idx = rows[sel_hb, sel_k], cols[sel_hb, sel_k]
+        # ---- classification targets (criterion.py:126-145)
+        tclass = torch.full((H, B, Q), crit.num_classes, dtype=torch.long, device=dev)
+        tclass[sel_h, sel_b, q_idx] = labels_pad[sel_b, j_idx]
+    num_masks = crit.num_masks(targets, dev)
+
+    with torch.autocast(device_type=dev.type, enabled=False):
+        w = crit.empty_weight
+        nll = F.cross_entropy(logits.float().reshape(H * B, Q, K1).transpose(1, 2), tclass.reshape(H * B, Q), w, reduction="none")
+        loss_ce = nll.reshape(H, B * Q).sum(1) / w[tclass].reshape(H, B * Q).sum(1)
+        # ---- mask losses on the matched pairs (criterion.py:147-207)
+        src = masks[sel_h, sel_b, q_idx][:, None].float()                                       # [N,1,h,w]
+        with torch.no_grad():
+            unc = -_gs(src, ocoords).abs()[:, 0, :]
+            idx = torch.topk(unc, k=kimp, dim=1)[1]
+            coords = torch.gather(ocoords, 1, idx[:, :, None].expand(-1, -1, 2))
+            if krand > 0:
+                coords = torch.cat([coords, rcoords], dim=1)                                    # [N,P,2]
+            labels = torch.empty((coords.shape[0], P), dtype=torch.float32, device=dev)
+            for b in range(B):                                                                  # targets as channels
+                pi = per_image[b]
+                if pi.numel() == 0:
+                    continue
+                s = _gs(tmask[b:b + 1], coords[pi].reshape(1, -1, 2)).reshape(nmax, pi.numel(), P)
+                labels[pi] = s[j_idx[pi], torch.arange(pi.numel(), device=dev)]
+        pl = _gs(src, coords)[:, 0, :]                                                          # [N,P]
+        bce = F.binary_cross_entropy_with_logits(pl, labels, reduction="none").mean(1)
+        ps = pl.sigmoid()
+        dice = 1 - (2 * (ps * labels).sum(-1) + 1) / (ps.sum(-1) + labels.sum(-1) + 1)
+        loss_mask = bce.reshape(H, N_h).sum(1) / num_masks
+        loss_dice = dice.reshape(H, N_h).sum(1) / num_masks
+
+    out = LossDict()
+    out.vectors = {"loss_ce": loss_ce, "loss_mask": loss_mask, "loss_dice": loss_dice}
+    for name, vec in out.vectors.items():
+        parts = vec.unbind(0)
+        out[name] = parts[0]
+        for i in range(H - 1):
+            out[f"{name}_{i}"] = parts[i + 1]
+    out.indices = (rows, cols)
+    return out

@@ -66,7 +66,7 @@ class PartDistillationModel(_MaskFormerTrainBase):
             raise NotImplementedError("PartDistillationModel inference: SURVEY §8f 'next' row, not built yet")
         images = self.preprocess(batched_inputs)
         features = self.backbone(images.tensor)
-        targets = self._prepare_pseudo_targets(batched_inputs, images)
+        targets = self._share_padded_masks(self._prepare_pseudo_targets(batched_inputs, images))
         outputs = self.sem_seg_head(features, mask=targets)
         losses = self._weighted(self.criterion(outputs, targets))
         self.num_train_iterations += 1

@@ -67,9 +67,38 @@ class _MaskFormerTrainBase(nn.Module):
             out.append((inst, m))
         return out
 
+    @staticmethod
+    def _share_padded_masks(targets):
+        """pad the per-image masks to [B, n_max, H, W] ONCE per step; the criterion reads it for each of the
+        prediction heads instead of re-padding ten times (reference criterion.py:167-169 via utils/misc.py:52-74)."""
+        from .utils.misc import nested_tensor_from_tensor_list
+        if len(targets) and all(t["masks"].shape[0] > 0 for t in targets):
+            padded, _ = nested_tensor_from_tensor_list([t["masks"] for t in targets]).decompose()
+            targets[0]["_padded_masks"] = padded
+        return targets
+
     def _weighted(self, losses):
+        """scale by weight_dict, drop unknown keys (reference :192-196).  When the criterion returns stacked per-head
+        vectors the scaling is three vector multiplies and the step's total is three sums (LossDict.total)."""
         wd = self.criterion.weight_dict
-        return {k: v * wd[k] for k, v in losses.items() if k in wd}      # unknown keys are dropped (reference :192-196)
+        vectors = getattr(losses, "vectors", None)
+        if vectors is None:
+            return {k: v * wd[k] for k, v in losses.items() if k in wd}
+        from .modeling.criterion_batched import LossDict
+        out, total = LossDict(), 0.0
+        cache = self.__dict__.setdefault("_wvec", {})
+        for name, vec in vectors.items():
+            keys = [name] + [f"{name}_{i}" for i in range(vec.shape[0] - 1)]
+            ck = (name, vec.shape[0], str(vec.device))
+            if ck not in cache:
+                cache[ck] = torch.tensor([wd.get(k, 0.0) for k in keys], dtype=vec.dtype, device=vec.device)
+            wv = vec * cache[ck]
+            total = total + wv.sum()
+            for k, part in zip(keys, wv.unbind(0)):
+                if k in wd:
+                    out[k] = part
+        out.total = total
+        return out
 
 
 @META_ARCH_REGISTRY.register()
@@ -124,7 +153,7 @@ class ProposalModel(_MaskFormerTrainBase):
     def forward(self, batched_inputs):
         images = self.preprocess(batched_inputs)
         features = self.backbone(images.tensor)
-        targets = self.prepare_targets(batched_inputs, images)
+        targets = self._share_padded_masks(self.prepare_targets(batched_inputs, images))
         outputs = self.sem_seg_head(features)
         if not self.training:
             raise NotImplementedError("ProposalModel inference: SURVEY §8f 'next' row, not built yet")

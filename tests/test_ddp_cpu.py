@@ -66,8 +66,9 @@ def _worker(rank, world, port, tmp):
         reducer.finish()
     crit = SetCriterion(1, None, {}, 0.1, [], 4, 3.0, 0.75)
     nm = crit.num_masks([{"labels": torch.zeros(3 + 2 * rank)}], torch.device("cpu"))
+    flat_grads = {n: g._view(g.grad, p, off).detach().clone() for g in flat.groups for n, p, off in zip(g.names, g.params, g.offsets)}
     torch.save({"params": {n: p.detach().clone() for n, p in model.named_parameters()},
-                "grads": {n: p.grad.detach().clone() for n, p in model.named_parameters()}, "num_masks": nm,
+                "grads": flat_grads, "num_masks": nm,
                 "xs": xs, "imgs": imgs}, os.path.join(tmp, f"rank{rank}.pt"))
     dist.destroy_process_group()
 

@@ -294,8 +294,13 @@ def test_fused_clipped_adamw_vs_oracle():
     for step in range(1, 4):
         grads = [torch.randn(s) * (3.0 if step == 2 else 0.01) for s in shapes]
         opt.zero_grad()
-        for p, g in zip(params, grads):
-            p.grad.add_(g.to(DEV))
+        for i, (p, g) in enumerate(zip(params, grads)):
+            if step == 3 and i == 1:                               # a parameter without gradient -> treated as zeros
+                grads[i] = torch.zeros_like(g)
+            elif p.dim() == 4:                                     # autograd's layout contract: grad strides == param strides
+                p.grad = torch.empty_like(p).copy_(g.to(DEV))
+            else:
+                p.grad = g.to(DEV).contiguous()
         opt.step()
         total = R.clipped_adamw_step(ref_p, grads, ref_state, lrs=[e["lr"] for e in entries], wds=[e["weight_decay"] for e in entries],
                                      clip=0.5, step=step)
@@ -319,3 +324,56 @@ def test_train_steps_run_and_reduce_loss():
         hist.append(float(sum(ld.values())))
     assert all(np.isfinite(hist)) and len(ld) == 12
     assert np.mean(hist[-4:]) < np.mean(hist[:4]), hist
+
+
+# ----------------------------------------------------------------------------- fused kernels
+def test_affine_act_fwd_bwd_vs_torch():
+    from partdistillation_amd.functions.fused import affine_act
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for shape, use_res, relu in (((2, 64, 9, 7), True, True), ((1, 256, 5, 5), False, True), ((3, 8, 4, 6), True, False), ((2, 16, 3, 3), False, False)):
+        x = torch.randn(shape, device=DEV, generator=g).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_()
+        res = torch.randn(shape, device=DEV, generator=g).bfloat16().requires_grad_() if use_res else None
+        scale = torch.rand(shape[1], device=DEV, generator=g) + 0.5
+        bias = torch.randn(shape[1], device=DEV, generator=g)
+        go = torch.randn(shape, device=DEV, generator=g).bfloat16()
+        y = affine_act(x, scale, bias, res, relu)
+        ref = x.float() * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+        if use_res:
+            ref = ref + res.float()
+        ref = ref.relu() if relu else ref
+        torch.testing.assert_close(y.float(), ref.bfloat16().float(), rtol=0, atol=0)      # one rounding at the end: exact
+        ins = (x, res) if use_res else (x,)
+        got = torch.autograd.grad(y, ins, go)
+        mask = (ref.bfloat16() > 0).float() if relu else torch.ones_like(ref)
+        torch.testing.assert_close(got[0].float(), (go.float() * mask * scale.view(1, -1, 1, 1)).bfloat16().float(), rtol=0, atol=0)
+        if use_res:
+            torch.testing.assert_close(got[1].float(), (go.float() * mask), rtol=0, atol=0)
+
+
+def test_bf16_shadow_training_matches_autocast_reference():
+    """bf16-shadow weights + gathered gradients + fused R50 epilogue (the AMP training configuration) against plain
+    torch.autocast on fp32 parameters with torch ops (AMP disabled optimizer path): same losses to bf16 tolerance and
+    the fp32 masters after one step agree."""
+    from partdistillation_amd.engine.synthetic import make_batch
+    from partdistillation_amd.engine.trainer import TrainStep
+    batch = make_batch(2, 128, n_parts=3, seed=11, device=DEV)
+    out = {}
+    for amp in (True, False):
+        cfg = _toy_cfg(["SOLVER.AMP.ENABLED", str(amp), "SOLVER.BASE_LR", "0.0001", "SOLVER.WARMUP_ITERS", "0"])
+        torch.manual_seed(0)
+        step = TrainStep(cfg)
+        rr = C.ReplayRand(777)
+        step.model.criterion.rand = rr
+        losses = step(batch)
+        out[amp] = ({k: float(v) for k, v in losses.items()}, {k: v.detach().float().clone() for k, v in step.state_dict()["model"].items()})
+        if amp:
+            assert any(g.shadow is not None for g in step.optimizer.flat.groups)
+            assert step.model.backbone.stem.conv1.weight.dtype == torch.bfloat16
+            assert step.model.sem_seg_head.pixel_decoder.mask_features.weight.dtype == torch.float32
+    la, lf = out[True][0], out[False][0]
+    for k in lf:
+        assert abs(la[k] - lf[k]) <= 0.08 * abs(lf[k]) + 0.05, (k, la[k], lf[k])         # bf16 autocast vs fp32
+    # the update itself: clipped AdamW moves every weight by <= lr (1e-4) per step in both runs
+    for k, v in out[False][1].items():
+        if v.dtype.is_floating_point and k in out[True][1] and "running" not in k:
+            assert (out[True][1][k] - v).abs().max().item() <= 2.5e-4, k
