@@ -145,6 +145,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         losses = step(batches[i % len(batches)])
+    issue = time.perf_counter() - t0                               # host time to ISSUE the steps (diagnostic)
     barrier()
     elapsed = time.perf_counter() - t0
     fwd_ms, bwd_ms = msda_fn.timing_ms()
@@ -175,7 +176,7 @@ def main():
                                    f"bs={a.batch}/GPU, Q=100, 10 prediction heads, bf16 autocast (pixel decoder + matcher fp32)",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "finetune": "frozen:" + ",".join(freeze) if freeze else "full",
-                       "final_total_loss": total_loss},
+                       "final_total_loss": total_loss, "host_issue_ms_per_step": issue / a.steps * 1e3},
             "roofline": None if dom is None else {
                 "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": dom["alg_bytes"],

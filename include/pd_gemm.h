@@ -22,9 +22,10 @@ int pd_gemm_tn_f32(const float *A, const float *B, const float *bias, float *C, 
                    int ldc, int relu, void *stream);
 
 /* dW[N,K] = dY[M,N]^T . X[M,K]  (nn.Linear weight gradient; contraction over the M rows, split over workgroups and
- * combined with fp32 atomics: dW is zero-filled by the library first).  N % 4 == 0, K % 4 == 0. */
-int pd_gemm_wgrad_f32(const float *dY, const float *X, float *dW, int M, int N, int K, int ldy, int ldx, int ldw,
-                      void *stream);
+ * combined with fp32 atomics: dW is zero-filled by the library first) and, when dB != NULL, the bias gradient
+ * dB[N] = column sums of dY from the same pass.  N % 4 == 0, K % 4 == 0. */
+int pd_gemm_wgrad_f32(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx,
+                      int ldw, void *stream);
 
 #ifdef __cplusplus
 }

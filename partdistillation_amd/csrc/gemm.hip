@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32(const float *__restrict__ 
 constexpr int WM = 16;   // contraction rows per LDS stage
 
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32(const float *__restrict__ dY, const float *__restrict__ X,
-                                                          float *__restrict__ dW, int M, int N, int K, int ldy, int ldx,
-                                                          int ldw, int tiles_k, int tiles, int m_chunk)
+                                                          float *__restrict__ dW, float *__restrict__ dB, int M, int N, int K,
+                                                          int ldy, int ldx, int ldw, int tiles_k, int tiles, int m_chunk)
 {
   __shared__ __attribute__((aligned(16))) float Ys[2][WM][BN];
   __shared__ __attribute__((aligned(16))) float Xs[2][WM][BM];
@@ -157,9 +157,17 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32(const float *__restrict
   }
   __syncthreads();
   const int fc = lane & 31, fm = lane >> 5;
+  // bias gradient dB[n] = sum_m dY[m,n]: the k-tile-0 workgroups add up the dY tile they stage anyway
+  const bool do_bias = dB != nullptr && k0 == 0;
+  const int bc = t & 127, br = (t >> 7) * 8;
+  float bsum = 0.f;
   for (int s = 0; s < steps; ++s) {
     const int buf = s & 1;
     if (s + 1 < steps) gload(mb + (s + 1) * WM);
+    if (do_bias) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) bsum += Ys[buf][br + r][bc];
+    }
 #pragma unroll
     for (int kk = 0; kk < WM / 2; ++kk) {
       float a[2], b[2];
@@ -176,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32(const float *__restrict
     if (s + 1 < steps) lstore(buf ^ 1);
     __syncthreads();
   }
+  if (do_bias && n0 + bc < N) unsafeAtomicAdd(dB + n0 + bc, bsum);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = k0 + wk + j * 32 + (lane & 31);
@@ -216,8 +225,8 @@ extern "C" int pd_gemm_tn_f32(const float *A, const float *B, const float *bias,
   return pd_check_launch("pd_gemm_tn_f32");
 }
 
-extern "C" int pd_gemm_wgrad_f32(const float *dY, const float *X, float *dW, int M, int N, int K, int ldy, int ldx,
-                                 int ldw, void *stream_)
+extern "C" int pd_gemm_wgrad_f32(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy,
+                                 int ldx, int ldw, void *stream_)
 {
   if (M < 0 || N < 0 || K < 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_wgrad_f32: negative size");
   if (N == 0 || K == 0) return PD_OK;
@@ -226,13 +235,14 @@ extern "C" int pd_gemm_wgrad_f32(const float *dY, const float *X, float *dW, int
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_wgrad_f32: N, K, ldy, ldx must be multiples of 4, 16-byte aligned");
   hipStream_t s = (hipStream_t)stream_;
   (void)hipMemset2DAsync(dW, (size_t)ldw * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)N, s);
+  if (dB) (void)hipMemsetAsync(dB, 0, (size_t)N * sizeof(float), s);
   if (M == 0) return pd_check_launch("pd_gemm_wgrad_f32");
   const int tk = (K + BM - 1) / BM, tn = (N + BN - 1) / BN, tiles = tk * tn;
   int splits = (1024 + tiles - 1) / tiles;                      // ~4 workgroups per CU in flight
   int m_chunk = ((M + splits - 1) / splits + WM - 1) / WM * WM;
   if (m_chunk < 4 * WM) m_chunk = 4 * WM;
   splits = (M + m_chunk - 1) / m_chunk;
-  hipLaunchKernelGGL(gemm_wgrad_f32, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, dY, X, dW, M, N, K, ldy, ldx, ldw, tk,
+  hipLaunchKernelGGL(gemm_wgrad_f32, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, dY, X, dW, dB, M, N, K, ldy, ldx, ldw, tk,
                      tiles, m_chunk);
   return pd_check_launch("pd_gemm_wgrad_f32");
 }

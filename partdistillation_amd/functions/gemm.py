@@ -25,18 +25,19 @@ def gemm_tn(a, b, bias=None, relu=False):
     return c
 
 
-def gemm_wgrad(dy, x):
-    """dy [M,N], x [M,K] -> dy.T @ x  [N,K]."""
+def gemm_wgrad(dy, x, with_bias=False):
+    """dy [M,N], x [M,K] -> dy.T @ x  [N,K]  (and dy.sum(0) [N] from the same pass when with_bias)."""
     if not dy.is_cuda:
         raise RuntimeError("pd_gemm_wgrad_f32 runs on the GPU only (no CPU fallback in partdistillation_amd)")
     M, N = dy.shape
     K = x.shape[1]
     dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    db = torch.empty((N,), dtype=torch.float32, device=dy.device) if with_bias else None
     with torch.cuda.device(dy.device):
-        rc = _lib.load().pd_gemm_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), M, N, K, dy.stride(0), x.stride(0), K,
-                                           _stream())
+        rc = _lib.load().pd_gemm_wgrad_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if with_bias else None,
+                                           M, N, K, dy.stride(0), x.stride(0), K, _stream())
     _lib.check(rc)
-    return dw
+    return (dw, db) if with_bias else dw
 
 
 # Measured on MI355X (tools/bench_gemm.py, M = 43008 tokens): the library's heuristic is good for the forward and
@@ -70,15 +71,18 @@ class LinearF32(Function):
         x2, weight, y = ctx.saved_tensors
         g2 = gy.reshape(-1, gy.shape[-1])
         if ctx.relu:
-            g2 = g2 * (y > 0)
+            g2 = torch.ops.aten.threshold_backward(g2.contiguous(), y, 0.0)        # one pass: g * [y > 0]
         elif g2.stride(1) != 1 or g2.stride(0) % 4:
             g2 = g2.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = (gemm_tn(g2, weight.t().contiguous()) if ALL_MFMA else g2 @ weight).view(*gy.shape[:-1], weight.shape[1])
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw = gemm_wgrad(g2, x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gw = gemm_wgrad(g2, x2, with_bias=want_b)
+            if want_b:
+                gw, gb = gw
+        elif want_b:
             gb = g2.sum(0)
         return gx, gw, gb, None
 

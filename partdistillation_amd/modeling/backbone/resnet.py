@@ -28,7 +28,7 @@ def _conv_bn_act(conv, x, residual=None, relu=True):
     into the filter."""
     norm = conv.norm
     frozen = isinstance(norm, FrozenBatchNorm2d)
-    if frozen and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16 \
+    if frozen and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16 \
             and conv.out_channels % 8 == 0:
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         scale, bias = norm.scale_bias()

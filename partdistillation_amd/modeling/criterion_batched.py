@@ -61,14 +61,26 @@ def _gs(inp, coords):
 
 
 def batched_set_criterion(crit, outputs, targets, padded_masks):
-    """-> LossDict with the reference's 3*H keys.  `padded_masks` bool [B, n_max, Hm, Wm]."""
+    """-> LossDict with the reference's 3*H keys.  `padded_masks` bool [B, n_max, Hm, Wm].
+
+    Index conventions: h = criterion order (0 = final output, 1.. = aux_outputs[h-1]; the order of the random draws);
+    d = decoder order (d = aux index, last = final); problems are laid out p = b*H + d so that the stacked mask tensor
+    [B, D, Q, h, w] the decoder produces is consumed without any re-ordering copy."""
     m = crit.matcher
     dev = outputs["pred_logits"].device
     aux = outputs["aux_outputs"]
-    logits = torch.stack([outputs["pred_logits"]] + [a["pred_logits"] for a in aux])           # [H,B,Q,K1]
-    masks = torch.stack([outputs["pred_masks"]] + [a["pred_masks"] for a in aux])              # [H,B,Q,h,w]
-    H, B, Q = logits.shape[:3]
-    K1 = logits.shape[-1]
+    H, (B, Q, K1) = len(aux) + 1, outputs["pred_logits"].shape
+    if "all_masks" in outputs and outputs["all_masks"].shape[1] == H:
+        masks_bd = outputs["all_masks"]                                                          # [B,D,Q,h,w]
+    else:
+        masks_bd = torch.stack([a["pred_masks"] for a in aux] + [outputs["pred_masks"]], dim=1)
+    if "all_logits" in outputs and outputs["all_logits"].shape[0] == H:
+        logits_bd = outputs["all_logits"].transpose(0, 1)                                        # [B,D,Q,K1]
+    else:
+        logits_bd = torch.stack([a["pred_logits"] for a in aux] + [outputs["pred_logits"]], dim=1)
+    dec_of = [H - 1] + list(range(H - 1))                                                        # h -> d
+    h_of = [dec_of.index(d) for d in range(H)]                                                   # d -> h
+    d_of_h, h_of_d = _const(dec_of, torch.long, dev), _const(h_of, torch.long, dev)
     ns = [int(t["labels"].shape[0]) for t in targets]
     nmax = max(ns)
     npair = [min(Q, n) for n in ns]
@@ -77,7 +89,7 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
     kover, kimp = int(P * crit.oversample_ratio), int(crit.importance_sample_ratio * P)
     krand = P - kimp
 
-    # ---- random draws (reference order when replayed)
+    # ---- random draws (reference order when replayed): mcoords [H,B,Pm,2]; o/r coords [H*N_h, *, 2] (h-major)
     if crit.rand is not None:
         mc, oc, rc = [], [], []
         for _ in range(H):
@@ -93,54 +105,56 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
         ocoords = torch.rand((H * N_h, kover, 2), device=dev)
         rcoords = torch.rand((H * N_h, krand, 2), device=dev) if krand > 0 else None
 
-    tmask = padded_masks.float()                                                                # [B,nmax,Hm,Wm], once
+    tmask = padded_masks.float()                                                                 # [B,nmax,Hm,Wm], once
     labels_pad = torch.zeros((B, nmax), dtype=torch.long, device=dev)
     for b, t in enumerate(targets):
         labels_pad[b, : ns[b]] = t["labels"]
-    ncols = _const([ns[b] for _ in range(H) for b in range(B)], torch.int32, dev)
+    ncols = _const([ns[b] for b in range(B) for _ in range(H)], torch.int32, dev)                # per problem p = b*H+d
 
     with torch.no_grad(), torch.autocast(device_type=dev.type, enabled=False):
-        # ---- matcher costs for all (head, image) problems (matcher.py:108-158)
-        pm = _gs(masks.detach().reshape(H * B, Q, *masks.shape[-2:]).float(), mcoords.reshape(H * B, Pm, 2))    # [HB,Q,Pm]
-        tg = _gs(tmask, mcoords.permute(1, 0, 2, 3).reshape(B, H * Pm, 2))                                      # [B,nmax,H*Pm]
-        tg = tg.reshape(B, nmax, H, Pm).permute(2, 0, 1, 3).reshape(H * B, nmax, Pm)                            # [HB,nmax,Pm]
+        # ---- matcher costs for all (image, head) problems (matcher.py:108-158)
+        mc_bd = mcoords[h_of_d].transpose(0, 1)                                                  # [B,D,Pm,2]
+        pm = _gs(masks_bd.detach().reshape(B * H, Q, *masks_bd.shape[-2:]).float(), mc_bd.reshape(B * H, Pm, 2))   # [BD,Q,Pm]
+        tg = _gs(tmask, mc_bd.reshape(B, H * Pm, 2)).reshape(B, nmax, H, Pm).transpose(1, 2).reshape(B * H, nmax, Pm)
         tgt = tg.transpose(1, 2)
         cost_mask = (F.softplus(pm).sum(-1)[:, :, None] - torch.bmm(pm, tgt)) / Pm
         sg = pm.sigmoid()
         cost_dice = 1 - (2 * torch.bmm(sg, tgt) + 1) / (sg.sum(-1)[:, :, None] + tg.sum(-1)[:, None, :] + 1)
-        lf = logits.detach().float()
+        lf = logits_bd.detach().float()
         prob = lf.sigmoid() if K1 == 1 else lf.softmax(-1)
-        cost_class = -torch.gather(prob, 3, labels_pad[None, :, None, :].expand(H, B, Q, nmax)).reshape(H * B, Q, nmax)
+        cost_class = -torch.gather(prob, 3, labels_pad[:, None, None, :].expand(B, H, Q, nmax)).reshape(B * H, Q, nmax)
         C = m.cost_mask * cost_mask + m.cost_class * cost_class + m.cost_dice * cost_dice
-        rows, cols = lsa_op.solve_batched(C, ncols)                                                             # [HB,nmax]
-        sel_h, sel_b, sel_k, per_image = _pair_selectors(H, B, npair, dev)
-        sel_hb = sel_h * B + sel_b
-        q_idx, j_idx = rows[sel_hb, sel_k], cols[sel_hb, sel_k]
+        rows, cols = lsa_op.solve_batched(C, ncols)                                              # [BD,nmax]
+        sel_h, sel_b, sel_k, per_image = _pair_selectors(H, B, npair, dev)                       # pairs, h-major
+        sel_d = d_of_h[sel_h]
+        sel_p = sel_b * H + sel_d
+        q_idx, j_idx = rows[sel_p, sel_k], cols[sel_p, sel_k]
         # ---- classification targets (criterion.py:126-145)
-        tclass = torch.full((H, B, Q), crit.num_classes, dtype=torch.long, device=dev)
-        tclass[sel_h, sel_b, q_idx] = labels_pad[sel_b, j_idx]
+        tclass = torch.full((B, H, Q), crit.num_classes, dtype=torch.long, device=dev)
+        tclass[sel_b, sel_d, q_idx] = labels_pad[sel_b, j_idx]
     num_masks = crit.num_masks(targets, dev)
 
     with torch.autocast(device_type=dev.type, enabled=False):
         w = crit.empty_weight
-        nll = F.cross_entropy(logits.float().reshape(H * B, Q, K1).transpose(1, 2), tclass.reshape(H * B, Q), w, reduction="none")
-        loss_ce = nll.reshape(H, B * Q).sum(1) / w[tclass].reshape(H, B * Q).sum(1)
+        nll = F.cross_entropy(logits_bd.float().reshape(B * H, Q, K1).transpose(1, 2), tclass.reshape(B * H, Q), w, reduction="none")
+        ce_d = nll.reshape(B, H, Q).sum((0, 2)) / w[tclass].sum((0, 2))
+        loss_ce = ce_d[d_of_h]
         # ---- mask losses on the matched pairs (criterion.py:147-207)
-        src = masks[sel_h, sel_b, q_idx][:, None].float()                                       # [N,1,h,w]
+        src = masks_bd[sel_b, sel_d, q_idx][:, None].float()                                     # [N,1,h,w]
         with torch.no_grad():
             unc = -_gs(src, ocoords).abs()[:, 0, :]
             idx = torch.topk(unc, k=kimp, dim=1)[1]
             coords = torch.gather(ocoords, 1, idx[:, :, None].expand(-1, -1, 2))
             if krand > 0:
-                coords = torch.cat([coords, rcoords], dim=1)                                    # [N,P,2]
+                coords = torch.cat([coords, rcoords], dim=1)                                     # [N,P,2]
             labels = torch.empty((coords.shape[0], P), dtype=torch.float32, device=dev)
-            for b in range(B):                                                                  # targets as channels
+            for b in range(B):                                                                   # targets as channels
                 pi = per_image[b]
                 if pi.numel() == 0:
                     continue
                 s = _gs(tmask[b:b + 1], coords[pi].reshape(1, -1, 2)).reshape(nmax, pi.numel(), P)
-                labels[pi] = s[j_idx[pi], torch.arange(pi.numel(), device=dev)]
-        pl = _gs(src, coords)[:, 0, :]                                                          # [N,P]
+                labels[pi] = s[j_idx[pi], _arange(pi.numel(), dev)]
+        pl = _gs(src, coords)[:, 0, :]                                                           # [N,P]
         bce = F.binary_cross_entropy_with_logits(pl, labels, reduction="none").mean(1)
         ps = pl.sigmoid()
         dice = 1 - (2 * (ps * labels).sum(-1) + 1) / (ps.sum(-1) + labels.sum(-1) + 1)
@@ -156,3 +170,13 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
             out[f"{name}_{i}"] = parts[i + 1]
     out.indices = (rows, cols)
     return out
+
+
+_ARANGE = {}
+
+
+def _arange(n, device):
+    key = (n, str(device))
+    if key not in _ARANGE:
+        _ARANGE[key] = torch.arange(n, device=device)
+    return _ARANGE[key]

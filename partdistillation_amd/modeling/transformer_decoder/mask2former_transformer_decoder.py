@@ -227,9 +227,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         mask_embed = self.mask_embed(decoder_output)
         if self.query_feature_normalize:
             mask_embed = F.normalize(mask_embed, p=2, dim=-1)
-        outputs_mask = None
-        if self.dense_masks or not self.training:
-            outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features.to(mask_embed.dtype))
+        outputs_mask = None            # the full-resolution masks of ALL heads are produced by one GEMM in forward()
         if pooled is None:
             pooled = F.interpolate(mask_features, size=attn_mask_target_size, mode="bilinear", align_corners=False)
         with torch.no_grad():
@@ -262,11 +260,18 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             cls, msk, attn_mask, dec_out, emb = self.forward_prediction_heads(output, mask_features, sizes[nxt], pooled[nxt], extra)
             classes.append(cls), masks.append(msk), embeds.append(emb)
         assert len(classes) == self.num_layers + 1
+        # einsum("bqc,bchw->bqhw") of the reference (:449) for all L+1 heads as ONE batched GEMM [B, (L+1)*Q, C] x
+        # [B, C, HW]: ten [200 x 256 x 65536] products are too skinny for the matrix cores one at a time, and the
+        # result is already the stacked [B, heads, Q, H, W] tensor the batched criterion consumes.
+        emb = torch.stack(embeds, 1)                                              # [B, L+1, Q, C]
+        B_, Hh, Qn, Cc = emb.shape
+        mf = mask_features.to(emb.dtype).flatten(2)                               # [B, C, HW]
+        all_masks = torch.bmm(emb.reshape(B_, Hh * Qn, Cc), mf).view(B_, Hh, Qn, *mask_features.shape[-2:])
+        masks = [all_masks[:, i] for i in range(Hh)]
         out = {"pred_logits": classes[-1], "pred_masks": masks[-1], "decoder_output": dec_out,
                "aux_outputs": self._set_aux_loss(classes if self.mask_classification else None, masks),
-               # extras for the sparse (point-sampled) criterion: all heads' mask embeddings + the feature map
-               "mask_embeds": torch.stack(embeds, 0), "mask_features": mask_features,
-               "all_logits": torch.stack(classes, 0)}
+               "all_masks": all_masks,                                            # [B, heads(decoder order), Q, H, W]
+               "mask_embeds": emb, "mask_features": mask_features, "all_logits": torch.stack(classes, 0)}
         self._finish(out, output)
         return out
 

@@ -32,6 +32,9 @@ def test_gemm_wgrad_matches_fp64(M, N, K):
     x = torch.randn(M, K, device="cuda", generator=g)
     want = dy.double().t() @ x.double()
     torch.testing.assert_close(gemm.gemm_wgrad(dy, x).double(), want, rtol=1e-5, atol=2e-6 * M ** 0.5 * 4)
+    dw, db = gemm.gemm_wgrad(dy, x, with_bias=True)
+    torch.testing.assert_close(dw.double(), want, rtol=1e-5, atol=2e-6 * M ** 0.5 * 4)
+    torch.testing.assert_close(db.double(), dy.double().sum(0), rtol=1e-5, atol=2e-6 * M ** 0.5 * 4)
 
 
 def test_linear_f32_autograd_matches_torch():
