@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--freeze", default="", help='comma list for MODEL.MASK_FORMER.FREEZE_KEYS, e.g. "backbone,encoder"')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--miopen-find", type=int, default=1, help="1: let MIOpen search conv algorithms during warm-up")
+    ap.add_argument("--graph", type=int, default=1, help="1: capture the step in a hipGraph (single GPU) and replay it")
     ap.add_argument("opts", nargs="*", help="extra KEY VALUE config overrides")
     a = ap.parse_args()
 
@@ -138,16 +139,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    use_graph = bool(a.graph) and world == 1
     for i in range(a.warmup):
         step(batches[i % len(batches)])
+    if use_graph:
+        step.capture(batches[0])
+        step(batches[1])                                           # one replay before the clock starts
     barrier()
-    msda_fn.enable_timing(True)
     t0 = time.perf_counter()
     for i in range(a.steps):
         losses = step(batches[i % len(batches)])
     issue = time.perf_counter() - t0                               # host time to ISSUE the steps (diagnostic)
     barrier()
     elapsed = time.perf_counter() - t0
+    # per-launch timing of the hand-written MSDA kernels with HIP events on the launch stream.  Events cannot be
+    # recorded between the nodes of a replayed graph, so these launches are timed in extra EAGER steps of the same
+    # workload right after the timed region (when --graph 0 they are timed inside the timed region itself).
+    step._graph = None
+    msda_fn.enable_timing(True)
+    for i in range(3):
+        step(batches[i % len(batches)])
+    torch.cuda.synchronize()
     fwd_ms, bwd_ms = msda_fn.timing_ms()
     msda_fn.enable_timing(False)
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -175,7 +187,7 @@ def main():
             "config": {"workload": f"R50 Mask2Former part-proposal training step (ProposalModel), {a.size}x{a.size} synthetic, "
                                    f"bs={a.batch}/GPU, Q=100, 10 prediction heads, bf16 autocast (pixel decoder + matcher fp32)",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                       "finetune": "frozen:" + ",".join(freeze) if freeze else "full",
+                       "finetune": "frozen:" + ",".join(freeze) if freeze else "full", "hipgraph": use_graph,
                        "final_total_loss": total_loss, "host_issue_ms_per_step": issue / a.steps * 1e3},
             "roofline": None if dom is None else {
                 "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

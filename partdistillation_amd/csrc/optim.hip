@@ -41,8 +41,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const T *__restrict__ x, int
 template <typename T>
 __global__ __launch_bounds__(256) void adamw_kernel(T *__restrict__ p, const T *__restrict__ g, T *__restrict__ m,
                                                      T *__restrict__ v, int64_t n, T lr, T b1, T b2, T eps, T wd,
-                                                     T bc1, T sqrt_bc2, const double *__restrict__ sumsq, T max_norm)
+                                                     T bc1, T sqrt_bc2, const double *__restrict__ sumsq, T max_norm,
+                                                     const float *__restrict__ dyn)
 {
+  if (dyn) { lr = (T)dyn[0]; bc1 = (T)dyn[1]; sqrt_bc2 = (T)dyn[2]; }
   T coef = 1;
   if (max_norm > 0) {
     const T total = (T)sqrt(*sumsq);
@@ -66,8 +68,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(T *__restrict__ p, const T *
 __global__ __launch_bounds__(256) void adamw_kernel_f32x4(float4 *__restrict__ p, const float4 *__restrict__ g,
                                                            float4 *__restrict__ m, float4 *__restrict__ v, int64_t n4,
                                                            float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                           float sqrt_bc2, const double *__restrict__ sumsq, float max_norm)
+                                                           float sqrt_bc2, const double *__restrict__ sumsq, float max_norm,
+                                                           const float *__restrict__ dyn)
 {
+  if (dyn) { lr = dyn[0]; bc1 = dyn[1]; sqrt_bc2 = dyn[2]; }
   float coef = 1.f;
   if (max_norm > 0.f) {
     const float total = (float)sqrt(*sumsq);
@@ -95,8 +99,10 @@ __global__ __launch_bounds__(256) void adamw_kernel_f32x4_shadow(float4 *__restr
                                                                   float4 *__restrict__ m, float4 *__restrict__ v,
                                                                   ushort4 *__restrict__ shadow, int64_t n4, float lr, float b1,
                                                                   float b2, float eps, float wd, float bc1, float sqrt_bc2,
-                                                                  const double *__restrict__ sumsq, float max_norm)
+                                                                  const double *__restrict__ sumsq, float max_norm,
+                                                                  const float *__restrict__ dyn)
 {
+  if (dyn) { lr = dyn[0]; bc1 = dyn[1]; sqrt_bc2 = dyn[2]; }
   float coef = 1.f;
   if (max_norm > 0.f) {
     const float total = (float)sqrt(*sumsq);
@@ -145,7 +151,7 @@ extern "C" int pd_sumsq_accumulate(const void *x, int64_t n, int dtype, double *
 
 extern "C" int pd_adamw_clipped_shadow(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, void *shadow_bf16,
                                        int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay,
-                                       int step, const double *grad_sumsq, double max_norm, void *stream_)
+                                       int step, const double *grad_sumsq, double max_norm, const float *dyn, void *stream_)
 {
   if (n < 0 || step < 1 || (n & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_adamw_clipped_shadow: n=%lld (must be a multiple of 4) step=%d", (long long)n, step);
   if (n == 0) return PD_OK;
@@ -155,13 +161,13 @@ extern "C" int pd_adamw_clipped_shadow(float *param, const float *grad, float *e
   hipLaunchKernelGGL(adamw_kernel_f32x4_shadow, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream_, (float4 *)param,
                      (const float4 *)grad, (float4 *)exp_avg, (float4 *)exp_avg_sq, (ushort4 *)shadow_bf16, n / 4, (float)lr,
                      (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)bc1, (float)sqrt_bc2, grad_sumsq,
-                     (float)max_norm);
+                     (float)max_norm, dyn);
   return pd_check_launch("pd_adamw_clipped_shadow");
 }
 
 extern "C" int pd_adamw_clipped(void *param, const void *grad, void *exp_avg, void *exp_avg_sq, int64_t n, int dtype,
                                 double lr, double beta1, double beta2, double eps, double weight_decay, int step,
-                                const double *grad_sumsq, double max_norm, void *stream_)
+                                const double *grad_sumsq, double max_norm, const float *dyn, void *stream_)
 {
   if (n < 0 || step < 1) return pd_set_error(PD_ERR_INVALID_ARG, "pd_adamw_clipped: n=%lld step=%d", (long long)n, step);
   if (dtype != PD_F32 && dtype != PD_F64) return pd_set_error(PD_ERR_INVALID_ARG, "pd_adamw_clipped: dtype %d", dtype);
@@ -176,17 +182,17 @@ extern "C" int pd_adamw_clipped(void *param, const void *grad, void *exp_avg, vo
     if (n4 > 0)
       hipLaunchKernelGGL(adamw_kernel_f32x4, dim3(grid_for(n4)), dim3(256), 0, s, (float4 *)param, (const float4 *)grad,
                          (float4 *)exp_avg, (float4 *)exp_avg_sq, n4, (float)lr, (float)beta1, (float)beta2, (float)eps,
-                         (float)weight_decay, (float)bc1, (float)sqrt_bc2, grad_sumsq, (float)max_norm);
+                         (float)weight_decay, (float)bc1, (float)sqrt_bc2, grad_sumsq, (float)max_norm, dyn);
     const int64_t done = n4 * 4;
     if (done < n)
       hipLaunchKernelGGL(adamw_kernel<float>, dim3(grid_for(n - done)), dim3(256), 0, s, (float *)param + done,
                          (const float *)grad + done, (float *)exp_avg + done, (float *)exp_avg_sq + done, n - done,
                          (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)bc1,
-                         (float)sqrt_bc2, grad_sumsq, (float)max_norm);
+                         (float)sqrt_bc2, grad_sumsq, (float)max_norm, dyn);
   } else {
     hipLaunchKernelGGL(adamw_kernel<double>, dim3(grid_for(n)), dim3(256), 0, s, (double *)param, (const double *)grad,
                        (double *)exp_avg, (double *)exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrt_bc2,
-                       grad_sumsq, max_norm);
+                       grad_sumsq, max_norm, dyn);
   }
   return pd_check_launch("pd_adamw_clipped");
 }

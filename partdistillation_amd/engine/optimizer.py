@@ -81,6 +81,11 @@ class FlatClippedAdamW:
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
         self.steps = 0
         self.grads_ready = False          # set by the data-parallel reducer when it has already gathered + reduced
+        # per-group {lr, 1-beta1^t, sqrt(1-beta2^t)} live on the device so that a hipGraph-captured step keeps
+        # following the LR schedule / bias corrections when replayed (host refreshes them before every step)
+        ng = len(self.flat.groups)
+        self._dyn_host = torch.zeros((ng, 4), dtype=torch.float32, pin_memory=(dev.type == "cuda"))
+        self._dyn_dev = torch.zeros((ng, 4), dtype=torch.float32, device=dev)
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
@@ -89,9 +94,23 @@ class FlatClippedAdamW:
         """device scalar: global L2 norm of the (unclipped) gradients of the last step."""
         return self._sumsq.sqrt()
 
+    def prepare_step(self):
+        """host side of a step: advance the step count, publish lr / bias corrections to the device."""
+        self.steps += 1
+        b1, b2 = self.betas
+        h = self._dyn_host.numpy()
+        for i, pg in enumerate(self.param_groups):
+            h[i, 0], h[i, 1], h[i, 2] = pg["lr"], 1.0 - b1 ** self.steps, (1.0 - b2 ** self.steps) ** 0.5
+        self._dyn_dev.copy_(self._dyn_host, non_blocking=True)
+
     @torch.no_grad()
     def step(self):
-        self.steps += 1
+        self.prepare_step()
+        self.launch_step()
+
+    @torch.no_grad()
+    def launch_step(self):
+        """device side of a step (capturable in a hipGraph): gather gradients, global norm, clipped AdamW."""
         self._sumsq.zero_()
         if self.grads_ready:                               # flat gradients already gathered and all-reduced
             if self.clip_norm > 0:
@@ -101,11 +120,11 @@ class FlatClippedAdamW:
             for g in self.flat.groups:
                 g.gather(self._sumsq if self.clip_norm > 0 else None)
         self.grads_ready = False
-        for g, pg, m, v in zip(self.flat.groups, self.param_groups, self.exp_avg, self.exp_avg_sq):
+        for i, (g, pg, m, v) in enumerate(zip(self.flat.groups, self.param_groups, self.exp_avg, self.exp_avg_sq)):
             optim_op.adamw_clipped_(g.param, g.grad, m, v, lr=pg["lr"], betas=self.betas, eps=self.eps,
-                                    weight_decay=pg["weight_decay"], step=self.steps,
+                                    weight_decay=pg["weight_decay"], step=max(self.steps, 1),
                                     grad_sumsq=self._sumsq if self.clip_norm > 0 else None, max_norm=self.clip_norm,
-                                    shadow=g.shadow)
+                                    shadow=g.shadow, dyn=self._dyn_dev[i])
 
     def state_dict(self):
         return {"steps": self.steps, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,

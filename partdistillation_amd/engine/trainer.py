@@ -1,14 +1,20 @@
-"""The training step of the reference drivers (detectron2 AMPTrainer.run_step
-as used by part_proposal_train_net.py / part_distillation_train_net.py through
-base_trainer.BaseTrainer): autocast forward -> summed weighted losses ->
+"""The training step of the reference drivers (detectron2 AMPTrainer.run_step as used by part_proposal_train_net.py /
+part_distillation_train_net.py through base_trainer.BaseTrainer): autocast forward -> summed weighted losses ->
 backward (gradient all-reduce overlapped) -> clipped AdamW -> LR schedule.
 
-bf16 autocast needs no GradScaler (the reference's fp16 AMP on V100 does); the
-pixel decoder and the matcher costs stay fp32 as in the reference."""
+bf16 autocast needs no GradScaler (the reference's fp16 AMP on V100 does); the pixel decoder and the matcher costs
+stay fp32 as in the reference.
+
+The step issues ~3 000 kernels; PyTorch's eager dispatch of them costs more host time than the GPU needs to run
+them, so on a single GPU the whole step (forward, criterion, backward, gradient gather, optimizer) is captured ONCE
+into a hipGraph and replayed: the step has no host synchronisation and no data-dependent shapes (device-side
+Hungarian matching, host-known index tables), learning rate and Adam bias corrections are read from device memory,
+and the batch is copied into static input buffers before each replay."""
 import torch
 import torch.distributed as dist
 
 from ..compat import build_model
+from ..compat.structures import BitMasks, Instances
 from .ddp import BucketedGradReducer, broadcast_parameters
 from .optimizer import build_lr_scheduler, build_optimizer
 
@@ -29,9 +35,10 @@ class TrainStep:
         self.reducer = BucketedGradReducer(self.optimizer.flat, cfg.MODEL.AMD.DDP_BUCKET_MB, process_group,
                                            optimizer=self.optimizer)
         self.iter = 0
+        self._graph = None
 
-    def __call__(self, batched_inputs):
-        """one optimisation step; returns the dict of weighted losses (device scalars, no host sync)."""
+    # ------------------------------------------------------------------ eager
+    def _forward_backward(self, batched_inputs):
         dev_type = self.model.device.type
         self.optimizer.zero_grad()
         with torch.autocast(device_type=dev_type, dtype=torch.bfloat16, enabled=self.amp):
@@ -40,12 +47,66 @@ class TrainStep:
             if total is None:
                 total = sum(loss_dict.values())
         total.backward()
+        return loss_dict
+
+    def __call__(self, batched_inputs):
+        """one optimisation step; returns the dict of weighted losses (device scalars, no host sync)."""
+        if self._graph is not None and self._signature(batched_inputs) == self._graph_sig:
+            return self._replay(batched_inputs)
+        loss_dict = self._forward_backward(batched_inputs)
         self.reducer.finish()
         self.optimizer.step()
         self.scheduler.step()
         self.iter += 1
         return loss_dict
 
+    # ------------------------------------------------------------------ hipGraph
+    @staticmethod
+    def _signature(batch):
+        return tuple((tuple(x["image"].shape), tuple(x["instances"].gt_masks.tensor.shape), x.get("gt_object_class", 0) * 0)
+                     for x in batch)
+
+    def capture(self, example_batch, warmup=3):
+        """capture the whole step for batches shaped like `example_batch` (single process only)."""
+        if self.world > 1:
+            raise RuntimeError("hipGraph capture of the step is for the single-GPU path (collectives stay eager)")
+        static = []
+        for x in example_batch:
+            inst = Instances(x["instances"].image_size)
+            inst.gt_masks = BitMasks(x["instances"].gt_masks.tensor.clone())
+            inst.gt_classes = x["instances"].gt_classes.clone()
+            static.append({**{k: v for k, v in x.items() if k not in ("image", "instances")},
+                           "image": x["image"].clone(), "instances": inst})
+        # warm-up on the CURRENT stream (allocator growth, MIOpen/BLAS lazy initialisation).  NB: the usual
+        # "warm up on a side stream" recipe makes the second replay of this graph fault on ROCm 7.2 (observed:
+        # tools/debug_graph2.py cap0 vs DBG_NOSIDE), so no extra stream is created here.
+        for _ in range(warmup):
+            self._forward_backward(static)
+            self.optimizer.step()
+        torch.cuda.synchronize()
+        self.optimizer.steps -= warmup                         # warm-up steps used the real optimizer: rewind the count only
+        graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad()
+        with torch.cuda.graph(graph):
+            loss_dict = self._forward_backward(static)
+            self.optimizer.launch_step()
+        self._graph, self._static, self._static_losses = graph, static, loss_dict
+        self._graph_sig = self._signature(example_batch)
+        return self
+
+    def _replay(self, batch):
+        for s, x in zip(self._static, batch):
+            if s["image"] is not x["image"]:
+                s["image"].copy_(x["image"], non_blocking=True)
+                s["instances"].gt_masks.tensor.copy_(x["instances"].gt_masks.tensor, non_blocking=True)
+                s["instances"].gt_classes.copy_(x["instances"].gt_classes, non_blocking=True)
+        self.optimizer.prepare_step()
+        self._graph.replay()
+        self.scheduler.step()
+        self.iter += 1
+        return self._static_losses
+
+    # ------------------------------------------------------------------ checkpoints
     def state_dict(self):
         """checkpoint with the reference's key names: fp32 master weights (modules hold bf16 copies of some), buffers,
         optimizer moments and the iteration."""
