@@ -112,10 +112,15 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N ...")
+    if os.environ.get("PD_TEST_SHARE_GPU"):            # test hook: N ranks on ONE GPU over gloo (tests/test_ddp_gpu.py)
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if os.environ.get("PD_TEST_SHARE_GPU"):
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
 
     from partdistillation_amd import lib

@@ -80,13 +80,15 @@ class BucketedGradReducer:
             if b.work is None:
                 self._launch(b)
         for b in self.buckets:
-            b.work.wait()
-            if not self._use_avg:
-                buf = self.flat.groups[b.group].grad[b.start:b.end]
-                if self._side is not None:
-                    with torch.cuda.stream(self._side):
-                        buf.div_(self.world)
-                else:
+            buf = self.flat.groups[b.group].grad[b.start:b.end]
+            if self._side is not None:
+                with torch.cuda.stream(self._side):              # the SIDE stream waits for the collective ...
+                    b.work.wait()
+                    if not self._use_avg:
+                        buf.div_(self.world)                     # ... so the division is ordered after its result
+            else:
+                b.work.wait()
+                if not self._use_avg:
                     buf.div_(self.world)
             b.work, b.pending = None, b.total
         if self._side is not None:
