@@ -1,0 +1,433 @@
+// Masked multi-head attention for few queries x many keys (head_dim 32), forward + backward, gfx950.
+//
+// The decoder attends Q = 100..200 queries to up to 25 600 keys with a boolean mask: ~3.4 GFLOP per call at the
+// largest level — nothing for the chip — but the library flash kernel tiles over QUERIES and leaves most CUs idle
+// (230 us forward in profiles/r01_*).  Here the KEYS are split across workgroups:
+//   attn_fwd_partial   one workgroup per (key chunk, head, image): thread = (query, key half); K/V tiles are staged
+//                      in LDS as fp32 and read as wave-uniform (broadcast) rows; online softmax across the tiles of
+//                      the chunk; emits (max, sum, sum p*v) per query
+//   attn_fwd_combine   merges the chunk partials with log-sum-exp weights, writes o and lse
+//   attn_bwd_dq        thread = (query, key half): recomputes p from lse, ds = p*(dO.v - delta), dq += ds*k
+//   attn_bwd_dkv       thread = key: owns dk/dv rows in registers (no atomics), loops over the queries staged in LDS
+// All accumulation is fp32; inputs/outputs are bf16 (autocast) or fp32.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "pd_attention.h"
+#include "pd_common.h"
+#include "pd_msda.h"
+
+namespace {
+
+constexpr int D = 32;          // head dim
+constexpr int QP = 128;        // queries handled per workgroup pass (threads 0..127 and 128..255 = two key halves)
+constexpr int KT = 64;         // keys per LDS tile
+constexpr int KC_FWD = 256;    // keys per workgroup (forward, dq)
+constexpr int KC_DQ = 512;
+
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f)
+{
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct IO;
+template <> struct IO<float> {
+  static __device__ __forceinline__ void load32(const float *p, float *dst)
+  {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 v = reinterpret_cast<const float4 *>(p)[i];
+      dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+    }
+  }
+  static __device__ __forceinline__ void store32(float *p, const float *src)
+  {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) reinterpret_cast<float4 *>(p)[i] = make_float4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+  }
+  static __device__ __forceinline__ void load8(const float *p, float *dst)
+  {
+    const float4 a = reinterpret_cast<const float4 *>(p)[0], b = reinterpret_cast<const float4 *>(p)[1];
+    dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+  }
+};
+template <> struct IO<bf16_t> {
+  static __device__ __forceinline__ void load8(const bf16_t *p, float *dst)
+  {
+    const uint4 v = *reinterpret_cast<const uint4 *>(p);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dst[2 * i] = __uint_as_float(w[i] << 16); dst[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void load32(const bf16_t *p, float *dst)
+  {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load8(p + 8 * i, dst + 8 * i);
+  }
+  static __device__ __forceinline__ void store32(bf16_t *p, const float *src)
+  {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint4 v;
+      unsigned *w = &v.x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (unsigned)f2bf(src[8 * i + 2 * j]) | ((unsigned)f2bf(src[8 * i + 2 * j + 1]) << 16);
+      reinterpret_cast<uint4 *>(p)[i] = v;
+    }
+  }
+};
+
+// stage `rows` consecutive key rows [k0, k0+rows) of head h, image b into LDS as fp32 [KT][D]; rows past Lk are zero
+template <typename T>
+__device__ __forceinline__ void stage_rows(const T *__restrict__ src, float (*dst)[D], int k0, int Lk, int b, int h, int B, int H)
+{
+  // KT*D/8 = 256 groups of 8 elements: one per thread
+  const int r = threadIdx.x >> 2, c = (threadIdx.x & 3) * 8;
+  float tmp[8];
+  if (k0 + r < Lk) IO<T>::load8(src + ((int64_t)(k0 + r) * B + b) * (H * D) + h * D + c, tmp);
+  else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tmp[i] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dst[r][c + i] = tmp[i];
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_partial(const T *__restrict__ q, const T *__restrict__ k, const T *__restrict__ v,
+                                                         const uint8_t *__restrict__ mask, float *__restrict__ part_o,
+                                                         float *__restrict__ part_ml, int B, int H, int Lq, int Lk, float scale,
+                                                         int nchunk, int qpass)
+{
+  __shared__ __attribute__((aligned(16))) float Ks[KT][D];
+  __shared__ __attribute__((aligned(16))) float Vs[KT][D];
+  __shared__ float red[QP][D + 2];
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int qi = qpass * QP + (threadIdx.x & (QP - 1)), half = threadIdx.x >> 7;
+  const bool active = qi < Lq;
+  float qv[D];
+  if (active) {
+    IO<T>::load32(q + ((int64_t)qi * B + b) * (H * D) + h * D, qv);
+#pragma unroll
+    for (int d = 0; d < D; ++d) qv[d] *= scale;
+  }
+  float m_run = -INFINITY, l_run = 0.f, o[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) o[d] = 0.f;
+  const int kbeg = chunk * KC_FWD, kend = min(Lk, kbeg + KC_FWD);
+  for (int k0 = kbeg; k0 < kend; k0 += KT) {
+    __syncthreads();
+    stage_rows<T>(k, Ks, k0, Lk, b, h, B, H);
+    stage_rows<T>(v, Vs, k0, Lk, b, h, B, H);
+    __syncthreads();
+    if (!active) continue;
+    const int kk0 = half * (KT / 2);
+    float s[KT / 2];
+    float m_t = -INFINITY;
+    const uint8_t *mrow = mask ? mask + ((int64_t)b * Lq + qi) * Lk + k0 + kk0 : nullptr;
+#pragma unroll
+    for (int kk = 0; kk < KT / 2; ++kk) {
+      float acc = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) acc += qv[d] * Ks[kk0 + kk][d];
+      const bool blocked = (k0 + kk0 + kk >= Lk) || (mrow && mrow[kk]);
+      s[kk] = blocked ? -INFINITY : acc;
+      m_t = fmaxf(m_t, s[kk]);
+    }
+    const float m_new = fmaxf(m_run, m_t);
+    if (m_new == -INFINITY) continue;                       // everything blocked so far
+    const float alpha = __expf(m_run - m_new);              // m_run = -inf -> 0
+    l_run *= alpha;
+#pragma unroll
+    for (int d = 0; d < D; ++d) o[d] *= alpha;
+#pragma unroll
+    for (int kk = 0; kk < KT / 2; ++kk) {
+      const float p = __expf(s[kk] - m_new);                // blocked -> exp(-inf) = 0
+      l_run += p;
+#pragma unroll
+      for (int d = 0; d < D; ++d) o[d] += p * Vs[kk0 + kk][d];
+    }
+    m_run = m_new;
+  }
+  // merge the two key halves of every query through LDS
+  __syncthreads();
+  const int ql = threadIdx.x & (QP - 1);
+  if (half == 1) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) red[ql][d] = o[d];
+    red[ql][D] = m_run; red[ql][D + 1] = l_run;
+  }
+  __syncthreads();
+  if (half == 0 && active) {
+    const float m2 = red[ql][D], l2 = red[ql][D + 1];
+    const float M = fmaxf(m_run, m2);
+    const float a1 = (M == -INFINITY) ? 0.f : __expf(m_run - M), a2 = (M == -INFINITY) ? 0.f : __expf(m2 - M);
+    const int64_t base = (((int64_t)b * H + h) * nchunk + chunk) * Lq + qi;
+    float *po = part_o + base * D;
+#pragma unroll
+    for (int d = 0; d < D; d += 4)
+      *reinterpret_cast<float4 *>(po + d) = make_float4(a1 * o[d] + a2 * red[ql][d], a1 * o[d + 1] + a2 * red[ql][d + 1],
+                                                        a1 * o[d + 2] + a2 * red[ql][d + 2], a1 * o[d + 3] + a2 * red[ql][d + 3]);
+    part_ml[base * 2] = M;
+    part_ml[base * 2 + 1] = a1 * l_run + a2 * l2;
+  }
+}
+
+// one 32-lane group per (b, h, q): lane = channel
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_combine(const float *__restrict__ part_o, const float *__restrict__ part_ml,
+                                                         T *__restrict__ o, float *__restrict__ lse, int B, int H, int Lq, int nchunk)
+{
+  const int g = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
+  if (g >= B * H * Lq) return;
+  const int qi = g % Lq, bh = g / Lq, h = bh % H, b = bh / H;
+  float M = -INFINITY;
+  for (int c = 0; c < nchunk; ++c) M = fmaxf(M, part_ml[(((int64_t)bh * nchunk + c) * Lq + qi) * 2]);
+  float L = 0.f, acc = 0.f;
+  if (M != -INFINITY) {
+    for (int c = 0; c < nchunk; ++c) {
+      const int64_t base = ((int64_t)bh * nchunk + c) * Lq + qi;
+      const float w = __expf(part_ml[base * 2] - M);
+      L += w * part_ml[base * 2 + 1];
+      acc += w * part_o[base * D + d];
+    }
+  }
+  const float outv = L > 0.f ? acc / L : 0.f;
+  T *dst = o + ((int64_t)qi * B + b) * (H * D) + h * D + d;
+  if (sizeof(T) == 2) *reinterpret_cast<bf16_t *>(dst) = f2bf(outv); else *reinterpret_cast<float *>(dst) = outv;
+  if (d == 0) lse[(int64_t)bh * Lq + qi] = L > 0.f ? M + __logf(L) : -INFINITY;
+}
+
+// ---------------------------------------------------------------------------------------------- backward: dq
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq(const T *__restrict__ q, const T *__restrict__ k, const T *__restrict__ v,
+                                                    const uint8_t *__restrict__ mask, const T *__restrict__ o, const T *__restrict__ d_o,
+                                                    const float *__restrict__ lse, float *__restrict__ part_dq, int B, int H, int Lq,
+                                                    int Lk, float scale, int nchunk, int qpass)
+{
+  __shared__ __attribute__((aligned(16))) float Ks[KT][D];
+  __shared__ __attribute__((aligned(16))) float Vs[KT][D];
+  __shared__ float red[QP][D];
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int qi = qpass * QP + (threadIdx.x & (QP - 1)), half = threadIdx.x >> 7;
+  const bool active = qi < Lq;
+  float qv[D], dov[D], dq[D];
+  float lse_q = 0.f, delta = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) dq[d] = 0.f;
+  if (active) {
+    const int64_t off = ((int64_t)qi * B + b) * (H * D) + h * D;
+    float ov[D];
+    IO<T>::load32(q + off, qv);
+    IO<T>::load32(d_o + off, dov);
+    IO<T>::load32(o + off, ov);
+#pragma unroll
+    for (int d = 0; d < D; ++d) { delta += dov[d] * ov[d]; qv[d] *= scale; }
+    lse_q = lse[((int64_t)b * H + h) * Lq + qi];
+  }
+  const int kbeg = chunk * KC_DQ, kend = min(Lk, kbeg + KC_DQ);
+  for (int k0 = kbeg; k0 < kend; k0 += KT) {
+    __syncthreads();
+    stage_rows<T>(k, Ks, k0, Lk, b, h, B, H);
+    stage_rows<T>(v, Vs, k0, Lk, b, h, B, H);
+    __syncthreads();
+    if (!active || lse_q == -INFINITY) continue;
+    const int kk0 = half * (KT / 2);
+    const uint8_t *mrow = mask ? mask + ((int64_t)b * Lq + qi) * Lk + k0 + kk0 : nullptr;
+#pragma unroll 4
+    for (int kk = 0; kk < KT / 2; ++kk) {
+      const bool blocked = (k0 + kk0 + kk >= Lk) || (mrow && mrow[kk]);
+      if (blocked) continue;
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) { s += qv[d] * Ks[kk0 + kk][d]; dp += dov[d] * Vs[kk0 + kk][d]; }
+      const float ds = __expf(s - lse_q) * (dp - delta);
+#pragma unroll
+      for (int d = 0; d < D; ++d) dq[d] += ds * Ks[kk0 + kk][d];
+    }
+  }
+  __syncthreads();
+  const int ql = threadIdx.x & (QP - 1);
+  if (half == 1) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) red[ql][d] = dq[d];
+  }
+  __syncthreads();
+  if (half == 0 && active) {
+    float *dst = part_dq + ((((int64_t)b * H + h) * nchunk + chunk) * Lq + qi) * D;
+#pragma unroll
+    for (int d = 0; d < D; d += 4)
+      *reinterpret_cast<float4 *>(dst + d) = make_float4((dq[d] + red[ql][d]) * scale, (dq[d + 1] + red[ql][d + 1]) * scale,
+                                                         (dq[d + 2] + red[ql][d + 2]) * scale, (dq[d + 3] + red[ql][d + 3]) * scale);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_reduce(const float *__restrict__ part_dq, T *__restrict__ dq, int B, int H, int Lq, int nchunk)
+{
+  const int g = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
+  if (g >= B * H * Lq) return;
+  const int qi = g % Lq, bh = g / Lq, h = bh % H, b = bh / H;
+  float acc = 0.f;
+  for (int c = 0; c < nchunk; ++c) acc += part_dq[(((int64_t)bh * nchunk + c) * Lq + qi) * D + d];
+  T *dst = dq + ((int64_t)qi * B + b) * (H * D) + h * D + d;
+  if (sizeof(T) == 2) *reinterpret_cast<bf16_t *>(dst) = f2bf(acc); else *reinterpret_cast<float *>(dst) = acc;
+}
+
+// ---------------------------------------------------------------------------------------------- backward: dk, dv
+// thread = key; the queries (q*scale, dO, lse, delta) of this (b, h) are staged through LDS QS at a time
+constexpr int QS = 32;
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv(const T *__restrict__ q, const T *__restrict__ k, const T *__restrict__ v,
+                                                     const uint8_t *__restrict__ mask, const T *__restrict__ o, const T *__restrict__ d_o,
+                                                     const float *__restrict__ lse, T *__restrict__ dk, T *__restrict__ dv, int B,
+                                                     int H, int Lq, int Lk, float scale)
+{
+  __shared__ __attribute__((aligned(16))) float Qs[QS][D];
+  __shared__ __attribute__((aligned(16))) float Os[QS][D];
+  __shared__ float Ls[QS], Ds[QS];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int ki = blockIdx.x * 256 + threadIdx.x;
+  const bool active = ki < Lk;
+  float kv[D], vv[D], dkv[D], dvv[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) { dkv[d] = 0.f; dvv[d] = 0.f; }
+  if (active) {
+    const int64_t off = ((int64_t)ki * B + b) * (H * D) + h * D;
+    IO<T>::load32(k + off, kv);
+    IO<T>::load32(v + off, vv);
+  }
+  for (int q0 = 0; q0 < Lq; q0 += QS) {
+    __syncthreads();
+    {   // stage QS queries: 256 threads = QS rows x 8 groups of 4 channels (q and dO), delta by the row's 8 threads
+      const int r = threadIdx.x >> 3, c = (threadIdx.x & 7) * 4;
+      float part = 0.f;
+      if (q0 + r < Lq) {
+        const int64_t off = ((int64_t)(q0 + r) * B + b) * (H * D) + h * D + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float qx, dox, ox;
+          if (sizeof(T) == 2) {
+            qx = bf2f(reinterpret_cast<const bf16_t *>(q)[off + i]); dox = bf2f(reinterpret_cast<const bf16_t *>(d_o)[off + i]);
+            ox = bf2f(reinterpret_cast<const bf16_t *>(o)[off + i]);
+          } else {
+            qx = reinterpret_cast<const float *>(q)[off + i]; dox = reinterpret_cast<const float *>(d_o)[off + i];
+            ox = reinterpret_cast<const float *>(o)[off + i];
+          }
+          Qs[r][c + i] = qx * scale; Os[r][c + i] = dox;
+          part += dox * ox;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { Qs[r][c + i] = 0.f; Os[r][c + i] = 0.f; }
+      }
+      part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+      if ((threadIdx.x & 7) == 0) {
+        Ds[r] = part;
+        Ls[r] = (q0 + r < Lq) ? lse[((int64_t)b * H + h) * Lq + q0 + r] : -INFINITY;
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+    const int nq = min(QS, Lq - q0);
+    for (int r = 0; r < nq; ++r) {
+      const float lq = Ls[r];
+      if (lq == -INFINITY) continue;
+      if (mask && mask[((int64_t)b * Lq + q0 + r) * Lk + ki]) continue;
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) { s += Qs[r][d] * kv[d]; dp += Os[r][d] * vv[d]; }
+      const float p = __expf(s - lq), ds = p * (dp - Ds[r]);
+#pragma unroll
+      for (int d = 0; d < D; ++d) { dkv[d] += ds * Qs[r][d]; dvv[d] += p * Os[r][d]; }
+    }
+  }
+  if (active) {
+    const int64_t off = ((int64_t)ki * B + b) * (H * D) + h * D;
+    IO<T>::store32(dk + off, dkv);          // Qs already carries the softmax scale: d(q.k*scale)/dk = scale*q
+    IO<T>::store32(dv + off, dvv);
+  }
+}
+
+inline int nchunks(int Lk, int kc) { return Lk <= 0 ? 1 : (Lk + kc - 1) / kc; }
+
+int check(const void *a, const void *b, const void *c, int B, int H, int Lq, int Lk, int dtype, const char *who)
+{
+  if (B < 0 || H <= 0 || Lq < 0 || Lk < 0) return pd_set_error(PD_ERR_INVALID_ARG, "%s: bad sizes B=%d H=%d Lq=%d Lk=%d", who, B, H, Lq, Lk);
+  if (dtype != PD_F32 && dtype != PD_BF16) return pd_set_error(PD_ERR_INVALID_ARG, "%s: dtype %d (float32 / bfloat16 only)", who, dtype);
+  if (B * Lq * Lk != 0 && (!a || !b || !c)) return pd_set_error(PD_ERR_INVALID_ARG, "%s: null pointer", who);
+  return PD_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t pd_attn_workspace_floats(int B, int H, int Lq, int Lk)
+{
+  const int64_t n1 = (int64_t)B * H * nchunks(Lk, KC_FWD) * Lq * (D + 2);
+  const int64_t n2 = (int64_t)B * H * nchunks(Lk, KC_DQ) * Lq * D;
+  return (n1 > n2 ? n1 : n2) + 64;
+}
+
+extern "C" int pd_attn_fwd_d32(const void *q, const void *k, const void *v, const uint8_t *mask, void *o, float *lse,
+                               float *workspace, int B, int H, int Lq, int Lk, float scale, int dtype, void *stream_)
+{
+  int rc = check(q, k, v, B, H, Lq, Lk, dtype, "pd_attn_fwd_d32");
+  if (rc) return rc;
+  if (B * Lq == 0) return PD_OK;
+  if (!o || !lse || !workspace) return pd_set_error(PD_ERR_INVALID_ARG, "pd_attn_fwd_d32: null output");
+  hipStream_t s = (hipStream_t)stream_;
+  const int nc = nchunks(Lk, KC_FWD);
+  float *part_o = workspace, *part_ml = workspace + (int64_t)B * H * nc * Lq * D;
+  for (int qp = 0; qp * QP < Lq; ++qp) {
+    if (dtype == PD_BF16)
+      hipLaunchKernelGGL(attn_fwd_partial<bf16_t>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k,
+                         (const bf16_t *)v, mask, part_o, part_ml, B, H, Lq, Lk, scale, nc, qp);
+    else
+      hipLaunchKernelGGL(attn_fwd_partial<float>, dim3(nc, H, B), dim3(256), 0, s, (const float *)q, (const float *)k,
+                         (const float *)v, mask, part_o, part_ml, B, H, Lq, Lk, scale, nc, qp);
+  }
+  const int groups = B * H * Lq;
+  if (dtype == PD_BF16)
+    hipLaunchKernelGGL(attn_fwd_combine<bf16_t>, dim3((groups + 7) / 8), dim3(256), 0, s, part_o, part_ml, (bf16_t *)o, lse, B, H, Lq, nc);
+  else
+    hipLaunchKernelGGL(attn_fwd_combine<float>, dim3((groups + 7) / 8), dim3(256), 0, s, part_o, part_ml, (float *)o, lse, B, H, Lq, nc);
+  return pd_check_launch("pd_attn_fwd_d32");
+}
+
+extern "C" int pd_attn_bwd_d32(const void *q, const void *k, const void *v, const uint8_t *mask, const void *o, const void *d_o,
+                               const float *lse, void *dq, void *dk, void *dv, float *workspace, int B, int H, int Lq,
+                               int Lk, float scale, int dtype, void *stream_)
+{
+  int rc = check(q, k, v, B, H, Lq, Lk, dtype, "pd_attn_bwd_d32");
+  if (rc) return rc;
+  if (B * Lq * Lk == 0) return PD_OK;
+  if (!o || !d_o || !lse || !dq || !dk || !dv || !workspace) return pd_set_error(PD_ERR_INVALID_ARG, "pd_attn_bwd_d32: null pointer");
+  hipStream_t s = (hipStream_t)stream_;
+  const int nc = nchunks(Lk, KC_DQ);
+  const int groups = B * H * Lq;
+  if (dtype == PD_BF16) {
+    for (int qp = 0; qp * QP < Lq; ++qp)
+      hipLaunchKernelGGL(attn_bwd_dq<bf16_t>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
+                         mask, (const bf16_t *)o, (const bf16_t *)d_o, lse, workspace, B, H, Lq, Lk, scale, nc, qp);
+    hipLaunchKernelGGL(attn_bwd_dq_reduce<bf16_t>, dim3((groups + 7) / 8), dim3(256), 0, s, workspace, (bf16_t *)dq, B, H, Lq, nc);
+    hipLaunchKernelGGL(attn_bwd_dkv<bf16_t>, dim3((Lk + 255) / 256, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k,
+                       (const bf16_t *)v, mask, (const bf16_t *)o, (const bf16_t *)d_o, lse, (bf16_t *)dk, (bf16_t *)dv, B, H, Lq, Lk, scale);
+  } else {
+    for (int qp = 0; qp * QP < Lq; ++qp)
+      hipLaunchKernelGGL(attn_bwd_dq<float>, dim3(nc, H, B), dim3(256), 0, s, (const float *)q, (const float *)k, (const float *)v,
+                         mask, (const float *)o, (const float *)d_o, lse, workspace, B, H, Lq, Lk, scale, nc, qp);
+    hipLaunchKernelGGL(attn_bwd_dq_reduce<float>, dim3((groups + 7) / 8), dim3(256), 0, s, workspace, (float *)dq, B, H, Lq, nc);
+    hipLaunchKernelGGL(attn_bwd_dkv<float>, dim3((Lk + 255) / 256, H, B), dim3(256), 0, s, (const float *)q, (const float *)k,
+                       (const float *)v, mask, (const float *)o, (const float *)d_o, lse, (float *)dk, (float *)dv, B, H, Lq, Lk, scale);
+  }
+  return pd_check_launch("pd_attn_bwd_d32");
+}

@@ -30,6 +30,9 @@ SIGNATURES = {
     "pd_affine_act_fwd_bf16": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, _c_int, _c_vp]),
     "pd_affine_act_bwd_bf16": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, _c_int, _c_vp]),
     "pd_multi_gather_sumsq": (_c_int, [_c_vp] * 8 + [_c_int, _c_int, _c_vp]),
+    "pd_attn_workspace_floats": (ctypes.c_int64, [_c_int] * 4),
+    "pd_attn_fwd_d32": (_c_int, [_c_vp] * 7 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_vp]),
+    "pd_attn_bwd_d32": (_c_int, [_c_vp] * 11 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_vp]),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_abi_version": (_c_int, []),
     "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),
