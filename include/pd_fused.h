@@ -37,6 +37,22 @@ int pd_multi_gather_sumsq(const int64_t *src_ptrs, const int32_t *src_is_bf16, c
                           const int64_t *blk_start, const int64_t *blk_dst, const int32_t *blk_len, float *dst,
                           double *sumsq, int block_begin, int block_end, void *stream);
 
+/*
+ * Channels-last fp32 GroupNorm (+ReLU) building blocks for the pixel decoder's Conv2d -> GroupNorm(32) (-> ReLU) layers
+ * (reference pixel_decoder/msdeformattn.py:236-239, 270-285: nn.GroupNorm(32, conv_dim) / get_norm("GN")).  Maps are
+ * [N, P pixels, C channels] with C the fastest dimension (C = 4*2^k <= 256).  The caller combines the per-(n, c)
+ * sums into group statistics / coefficients (O(N*C) work) between the calls:
+ *   pd_nc_sums_f32   mode 0: out[n,c] = {sum_p x, sum_p x^2};  mode 1: {sum_p g*(x*a[n,c]+b[n,c]), sum_p g} with
+ *                    g = dy, or dy*[y > 0] when relu; `out` (float64 [N, C, 2]) is zeroed by the library
+ *   pd_nc_affine_f32   y = x*a[n,c] + b[n,c], then ReLU if relu
+ *   pd_nc_affine2_f32  dx = g*a[n,c] + x*p[n,c] + r[n,c]
+ */
+int pd_nc_sums_f32(const float *x, const float *dy, const float *y, const float *a, const float *b, double *out, int N, int P,
+                   int C, int mode, int relu, void *stream);
+int pd_nc_affine_f32(const float *x, const float *a, const float *b, float *y, int N, int P, int C, int relu, void *stream);
+int pd_nc_affine2_f32(const float *dy, const float *x, const float *y, const float *a, const float *p, const float *r, float *dx,
+                      int N, int P, int C, int relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,6 +117,91 @@ __global__ __launch_bounds__(256) void multi_gather_sumsq(const int64_t *__restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------- NHWC GroupNorm pieces
+// GroupNorm over channels-last fp32 maps [N, P pixels, C] is built from three streaming kernels with per-(image,
+// channel) coefficients; the O(N*C) algebra between them (group means, rstd, coefficients) is done by the caller.
+//   nc_sums<0>   S0[n,c] = sum_p x,            S1[n,c] = sum_p x*x                      (fp64 accumulation across blocks)
+//   nc_sums<1>   S0[n,c] = sum_p dy*(x*a+b),   S1[n,c] = sum_p dy     (dy masked by y > 0 when relu)
+//   nc_affine    y  = x*a[n,c] + b[n,c] (ReLU)
+//   nc_affine2   dx = dy(masked)*a[n,c] + x*p[n,c] + r[n,c]
+// Thread t owns channel quad t % (C/4) of pixels (t / (C/4)) + k*(256/(C/4)): one wave instruction reads whole pixels.
+template <int MODE>
+__global__ __launch_bounds__(256) void nc_sums(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ y,
+                                                const float *__restrict__ a, const float *__restrict__ b, double *__restrict__ out,
+                                                int P, int C, int pix_per_block, int relu)
+{
+  __shared__ float red[2][256][4];
+  const int n = blockIdx.y, cq = C >> 2, q = threadIdx.x % cq, po = threadIdx.x / cq, pstride = 256 / cq;
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(P, p0 + pix_per_block);
+  const int64_t base = (int64_t)n * P * C + q * 4;
+  float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, av = s0, bv = s0;
+  if (MODE == 1) { av = *reinterpret_cast<const float4 *>(a + n * C + q * 4); bv = *reinterpret_cast<const float4 *>(b + n * C + q * 4); }
+  for (int p = p0 + po; p < p1; p += pstride) {
+    const float4 xv = *reinterpret_cast<const float4 *>(x + base + (int64_t)p * C);
+    if (MODE == 0) {
+      s0.x += xv.x; s0.y += xv.y; s0.z += xv.z; s0.w += xv.w;
+      s1.x += xv.x * xv.x; s1.y += xv.y * xv.y; s1.z += xv.z * xv.z; s1.w += xv.w * xv.w;
+    } else {
+      float4 g = *reinterpret_cast<const float4 *>(dy + base + (int64_t)p * C);
+      if (relu) {
+        const float4 yv = *reinterpret_cast<const float4 *>(y + base + (int64_t)p * C);
+        g.x = yv.x > 0 ? g.x : 0; g.y = yv.y > 0 ? g.y : 0; g.z = yv.z > 0 ? g.z : 0; g.w = yv.w > 0 ? g.w : 0;
+      }
+      s0.x += g.x * (xv.x * av.x + bv.x); s0.y += g.y * (xv.y * av.y + bv.y);
+      s0.z += g.z * (xv.z * av.z + bv.z); s0.w += g.w * (xv.w * av.w + bv.w);
+      s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+    }
+  }
+  red[0][threadIdx.x][0] = s0.x; red[0][threadIdx.x][1] = s0.y; red[0][threadIdx.x][2] = s0.z; red[0][threadIdx.x][3] = s0.w;
+  red[1][threadIdx.x][0] = s1.x; red[1][threadIdx.x][1] = s1.y; red[1][threadIdx.x][2] = s1.z; red[1][threadIdx.x][3] = s1.w;
+  __syncthreads();
+  if (threadIdx.x < C) {                      // one thread per channel sums the pixel-offset copies
+    const int c = threadIdx.x, qq = c >> 2, e = c & 3;
+    double t0 = 0, t1 = 0;
+    for (int k = 0; k < pstride; ++k) { t0 += red[0][k * cq + qq][e]; t1 += red[1][k * cq + qq][e]; }
+    unsafeAtomicAdd(out + ((int64_t)n * C + c) * 2, t0);
+    unsafeAtomicAdd(out + ((int64_t)n * C + c) * 2 + 1, t1);
+  }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void nc_affine(const float4 *__restrict__ x, const float *__restrict__ a, const float *__restrict__ b,
+                                                  float4 *__restrict__ y, int64_t n4, int P, int C)
+{
+  const int cq = C >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, per_img = (int64_t)P * cq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int n = (int)(i / per_img), q = (int)(i % cq);
+    const float4 av = *reinterpret_cast<const float4 *>(a + n * C + q * 4), bv = *reinterpret_cast<const float4 *>(b + n * C + q * 4);
+    float4 v = x[i];
+    v.x = v.x * av.x + bv.x; v.y = v.y * av.y + bv.y; v.z = v.z * av.z + bv.z; v.w = v.w * av.w + bv.w;
+    if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    y[i] = v;
+  }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void nc_affine2(const float4 *__restrict__ dy, const float4 *__restrict__ x, const float4 *__restrict__ y,
+                                                   const float *__restrict__ a, const float *__restrict__ pc, const float *__restrict__ rc,
+                                                   float4 *__restrict__ dx, int64_t n4, int P, int C)
+{
+  const int cq = C >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, per_img = (int64_t)P * cq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int n = (int)(i / per_img), q = (int)(i % cq);
+    const float4 av = *reinterpret_cast<const float4 *>(a + n * C + q * 4), pv = *reinterpret_cast<const float4 *>(pc + n * C + q * 4),
+                 rv = *reinterpret_cast<const float4 *>(rc + n * C + q * 4);
+    float4 g = dy[i];
+    const float4 xv = x[i];
+    if (RELU) {
+      const float4 yv = y[i];
+      g.x = yv.x > 0 ? g.x : 0; g.y = yv.y > 0 ? g.y : 0; g.z = yv.z > 0 ? g.z : 0; g.w = yv.w > 0 ? g.w : 0;
+    }
+    dx[i] = make_float4(g.x * av.x + xv.x * pv.x + rv.x, g.y * av.y + xv.y * pv.y + rv.y, g.z * av.z + xv.z * pv.z + rv.z,
+                        g.w * av.w + xv.w * pv.w + rv.w);
+  }
+}
+
 inline int grid_for(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
 
 }  // namespace
@@ -166,4 +251,55 @@ extern "C" int pd_multi_gather_sumsq(const int64_t *src_ptrs, const int32_t *src
   hipLaunchKernelGGL(multi_gather_sumsq, dim3(block_end - block_begin), dim3(256), 0, (hipStream_t)stream_, src_ptrs, src_is_bf16,
                      blk_tensor, blk_start, blk_dst, blk_len, dst, sumsq, block_begin);
   return pd_check_launch("pd_multi_gather_sumsq");
+}
+
+static int nc_check(int N, int P, int C, const char *who)
+{
+  if (N < 0 || P < 0 || C <= 0 || (C & 3) || (256 % (C >> 2)) != 0 || C > 256)
+    return pd_set_error(PD_ERR_INVALID_ARG, "%s: N=%d P=%d C=%d (C must be 4*2^k <= 256)", who, N, P, C);
+  return PD_OK;
+}
+
+extern "C" int pd_nc_sums_f32(const float *x, const float *dy, const float *y, const float *a, const float *b, double *out,
+                              int N, int P, int C, int mode, int relu, void *stream_)
+{
+  int rc = nc_check(N, P, C, "pd_nc_sums_f32");
+  if (rc) return rc;
+  if (!out) return pd_set_error(PD_ERR_INVALID_ARG, "pd_nc_sums_f32: null output");
+  hipStream_t s = (hipStream_t)stream_;
+  (void)hipMemsetAsync(out, 0, (size_t)N * C * 2 * sizeof(double), s);
+  if ((int64_t)N * P == 0) return pd_check_launch("pd_nc_sums_f32");
+  if (!x || (mode == 1 && (!dy || !a || !b || (relu && !y)))) return pd_set_error(PD_ERR_INVALID_ARG, "pd_nc_sums_f32: null input");
+  const int ppb = 512;
+  dim3 grid((P + ppb - 1) / ppb, N);
+  if (mode == 0) hipLaunchKernelGGL(nc_sums<0>, grid, dim3(256), 0, s, x, dy, y, a, b, out, P, C, ppb, relu);
+  else hipLaunchKernelGGL(nc_sums<1>, grid, dim3(256), 0, s, x, dy, y, a, b, out, P, C, ppb, relu);
+  return pd_check_launch("pd_nc_sums_f32");
+}
+
+extern "C" int pd_nc_affine_f32(const float *x, const float *a, const float *b, float *y, int N, int P, int C, int relu, void *stream_)
+{
+  int rc = nc_check(N, P, C, "pd_nc_affine_f32");
+  if (rc) return rc;
+  const int64_t n4 = (int64_t)N * P * C / 4;
+  if (n4 == 0) return PD_OK;
+  if (!x || !a || !b || !y) return pd_set_error(PD_ERR_INVALID_ARG, "pd_nc_affine_f32: null pointer");
+  hipStream_t s = (hipStream_t)stream_;
+  if (relu) hipLaunchKernelGGL(nc_affine<true>, dim3(grid_for(n4)), dim3(256), 0, s, (const float4 *)x, a, b, (float4 *)y, n4, P, C);
+  else hipLaunchKernelGGL(nc_affine<false>, dim3(grid_for(n4)), dim3(256), 0, s, (const float4 *)x, a, b, (float4 *)y, n4, P, C);
+  return pd_check_launch("pd_nc_affine_f32");
+}
+
+extern "C" int pd_nc_affine2_f32(const float *dy, const float *x, const float *y, const float *a, const float *p, const float *r,
+                                 float *dx, int N, int P, int C, int relu, void *stream_)
+{
+  int rc = nc_check(N, P, C, "pd_nc_affine2_f32");
+  if (rc) return rc;
+  const int64_t n4 = (int64_t)N * P * C / 4;
+  if (n4 == 0) return PD_OK;
+  if (!dy || !x || !a || !p || !r || !dx || (relu && !y)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_nc_affine2_f32: null pointer");
+  hipStream_t s = (hipStream_t)stream_;
+  if (relu) hipLaunchKernelGGL(nc_affine2<true>, dim3(grid_for(n4)), dim3(256), 0, s, (const float4 *)dy, (const float4 *)x, (const float4 *)y, a, p, r, (float4 *)dx, n4, P, C);
+  else hipLaunchKernelGGL(nc_affine2<false>, dim3(grid_for(n4)), dim3(256), 0, s, (const float4 *)dy, (const float4 *)x, (const float4 *)y, a, p, r, (float4 *)dx, n4, P, C);
+  return pd_check_launch("pd_nc_affine2_f32");
 }

@@ -33,6 +33,9 @@ SIGNATURES = {
     "pd_attn_workspace_floats": (ctypes.c_int64, [_c_int] * 4),
     "pd_attn_fwd_d32": (_c_int, [_c_vp] * 7 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_vp]),
     "pd_attn_bwd_d32": (_c_int, [_c_vp] * 11 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_vp]),
+    "pd_nc_sums_f32": (_c_int, [_c_vp] * 6 + [_c_int] * 5 + [_c_vp]),
+    "pd_nc_affine_f32": (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_vp]),
+    "pd_nc_affine2_f32": (_c_int, [_c_vp] * 7 + [_c_int] * 4 + [_c_vp]),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_abi_version": (_c_int, []),
     "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),

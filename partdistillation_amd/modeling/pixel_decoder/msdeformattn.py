@@ -14,6 +14,7 @@ from torch.nn.init import normal_
 from ...compat import SEM_SEG_HEADS_REGISTRY, ShapeSpec, configurable
 from ...compat.layers import Conv2d, c2_xavier_fill, get_norm
 from ..transformer_decoder.position_encoding import PositionEmbeddingSine
+from ...functions.fused import group_norm_nhwc, group_norm_nhwc_supported
 from ...functions.gemm import linear_f32
 from .ops.modules import MSDeformAttn
 
@@ -117,6 +118,17 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         return memory, spatial_shapes, level_start_index, shapes_host
 
 
+def _conv_gn(conv, gn, x, relu=False):
+    """conv -> GroupNorm (-> ReLU); on the GPU in fp32 the norm (+ReLU) is the channels-last HIP GroupNorm
+    (functions/fused.py), so the maps stay NHWC from the backbone to the encoder tokens with no layout copies."""
+    y = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+    if isinstance(gn, nn.GroupNorm) and group_norm_nhwc_supported(y, gn.num_groups):
+        return group_norm_nhwc(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)
+    if gn is not None:
+        y = gn(y)
+    return F.relu(y) if relu else y
+
+
 @SEM_SEG_HEADS_REGISTRY.register()
 class MSDeformAttnPixelDecoder(nn.Module):
     @configurable
@@ -186,7 +198,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
             srcs, pos = [], []
             for idx, f in enumerate(self.transformer_in_features[::-1]):
                 x = features[f].float()
-                srcs.append(self.input_proj[idx](x))
+                srcs.append(_conv_gn(self.input_proj[idx][0], self.input_proj[idx][1], x))
                 pos.append(self.pe_layer(x))
             y, spatial_shapes, level_start_index, shapes_host = self.transformer(srcs, pos)
             bs = y.shape[0]
@@ -194,8 +206,9 @@ class MSDeformAttnPixelDecoder(nn.Module):
             out = [z.transpose(1, 2).reshape(bs, -1, h, w) for z, (h, w) in zip(torch.split(y, sizes, dim=1), shapes_host)]
             for idx, f in enumerate(self.in_features[: self.num_fpn_levels][::-1]):
                 x = features[f].float()
-                cur = self.lateral_convs[idx](x)
+                lat, outc = self.lateral_convs[idx], self.output_convs[idx]
+                cur = _conv_gn(lat, lat.norm, x, relu=lat.activation is not None)
                 y = cur + F.interpolate(out[-1], size=cur.shape[-2:], mode="bilinear", align_corners=False)
-                out.append(self.output_convs[idx](y))
+                out.append(_conv_gn(outc, outc.norm, y, relu=outc.activation is not None))
             multi_scale = out[: self.maskformer_num_feature_levels]
             return self.mask_features(out[-1]), out[0], multi_scale

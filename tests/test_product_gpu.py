@@ -378,3 +378,22 @@ def test_bf16_shadow_training_matches_autocast_reference():
     for k, v in out[False][1].items():
         if v.dtype.is_floating_point and k in out[True][1] and "running" not in k:
             assert (out[True][1][k] - v).abs().max().item() <= 2.5e-4, k
+
+
+@pytest.mark.parametrize("shape,groups,relu", [((2, 256, 17, 9), 32, True), ((1, 64, 8, 8), 32, False), ((3, 128, 5, 11), 8, True)])
+def test_group_norm_nhwc_vs_torch(shape, groups, relu):
+    from partdistillation_amd.functions.fused import group_norm_nhwc
+    g = torch.Generator(device=DEV).manual_seed(shape[1])
+    x = (torch.randn(shape, device=DEV, generator=g) * 2 + 0.7).contiguous(memory_format=torch.channels_last).requires_grad_()
+    w = torch.randn(shape[1], device=DEV, generator=g).requires_grad_()
+    b = torch.randn(shape[1], device=DEV, generator=g).requires_grad_()
+    go = torch.randn(shape, device=DEV, generator=g)
+    y = group_norm_nhwc(x, w, b, groups, 1e-5, relu)
+    xr, wr, br = [t.detach().double().requires_grad_() for t in (x, w, b)]
+    ref = torch.nn.functional.group_norm(xr, groups, wr, br, 1e-5)
+    ref = ref.relu() if relu else ref
+    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=1e-5)
+    got = torch.autograd.grad(y, (x, w, b), go)
+    want = torch.autograd.grad(ref, (xr, wr, br), go.double())
+    for a_, b_ in zip(got, want):
+        torch.testing.assert_close(a_.double(), b_, rtol=1e-4, atol=1e-4)
