@@ -150,13 +150,20 @@ def main():
     use_graph = bool(a.graph) and world == 1
     for i in range(a.warmup):
         step(batches[i % len(batches)])
+    dbg = bool(os.environ.get("PD_DEBUG_GRAPH"))
     if use_graph:
         step.capture(batches[0])
+        if dbg:
+            torch.cuda.synchronize(); print("captured", file=sys.stderr, flush=True)
         step(batches[1])                                           # one replay before the clock starts
+        if dbg:
+            torch.cuda.synchronize(); print("first replay ok", file=sys.stderr, flush=True)
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
         losses = step(batches[i % len(batches)])
+        if dbg:
+            torch.cuda.synchronize(); print("step", i, "ok", file=sys.stderr, flush=True)
     issue = time.perf_counter() - t0                               # host time to ISSUE the steps (diagnostic)
     barrier()
     elapsed = time.perf_counter() - t0

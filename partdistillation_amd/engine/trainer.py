@@ -36,6 +36,7 @@ class TrainStep:
                                            optimizer=self.optimizer)
         self.iter = 0
         self._graph = None
+        self._replay_done = None
 
     # ------------------------------------------------------------------ eager
     def _forward_backward(self, batched_inputs):
@@ -95,6 +96,12 @@ class TrainStep:
         return self
 
     def _replay(self, batch):
+        # ONE replay in flight, fenced by a DEVICE synchronize: on ROCm 7.2 back-to-back replays of this graph fault,
+        # replays separated by torch.cuda.synchronize() never do, and an event recorded on the launch stream after
+        # hipGraphLaunch is not enough (the graph's internal branch streams can still be running) — observed with
+        # tools/debug_graph2.py and bench.py PD_DEBUG_GRAPH.  The wait is free while the step is GPU-bound.
+        if self._replay_done is not None:
+            torch.cuda.synchronize()
         for s, x in zip(self._static, batch):
             if s["image"] is not x["image"]:
                 s["image"].copy_(x["image"], non_blocking=True)
@@ -102,6 +109,9 @@ class TrainStep:
                 s["instances"].gt_classes.copy_(x["instances"].gt_classes, non_blocking=True)
         self.optimizer.prepare_step()
         self._graph.replay()
+        if self._replay_done is None:
+            self._replay_done = torch.cuda.Event()
+        self._replay_done.record()
         self.scheduler.step()
         self.iter += 1
         return self._static_losses

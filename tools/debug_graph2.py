@@ -55,8 +55,12 @@ def run():
 if mode.startswith("cap"):
     step.capture(b, warmup=int(mode[3:]))
     torch.cuda.synchronize(); print("captured", mode, flush=True)
-    for i in range(3):
-        step._graph.replay(); torch.cuda.synchronize(); print("replay", mode, i, float(step._static_losses.total.detach()), flush=True)
+    for i in range(8):
+        if os.environ.get("DBG_COPY"):
+            ld = step(batches[i % 2])
+        else:
+            step._graph.replay()
+        torch.cuda.synchronize(); print("replay", mode, i, float(step._static_losses.total.detach()), flush=True)
     sys.exit(0)
 if mode != "fboptnowarm":
     run(); torch.cuda.synchronize()
