@@ -41,15 +41,32 @@ def msda_alg_bytes(batch, size, heads=8, head_dim=32, levels=3, points=4, esz=4)
     return v + lo + at + v, 2 * (v + lo + at) + v
 
 
-def cpu_baseline(cfg_opts, size, seconds_budget=60.0):
+def cpu_baseline_subprocess(opts, size, timeout=300.0):
+    """run cpu_baseline() in a child process under a hard wall-clock limit (a mis-threaded CPU run must never hold the
+    benchmark hostage: on a 256-core host, torch with 256 intra-op threads took 775 s for the 256x256 probe)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(size)] + list(opts)
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout, text=True).stdout
+        for line in out.splitlines()[::-1]:
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": "no output from the CPU baseline child"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"CPU baseline exceeded {timeout:.0f} s wall clock and was stopped", "kind": "port"}
+
+
+def cpu_baseline(cfg_opts, size, seconds_budget=90.0, threads=None):
     """time the oracle's training step (fwd + criterion + bwd + clipped AdamW), 1 image, on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import common as C
     from oracle import step_ref as R
+    import partdistillation_amd.modeling  # noqa: F401  (registers the classes)
+    import partdistillation_amd.proposal_model  # noqa: F401
     from partdistillation_amd.compat import build_model
     from partdistillation_amd.config import setup_cfg
     from partdistillation_amd.engine.synthetic import make_batch
-    cores = os.cpu_count() or 1
+    cores = threads or min(os.cpu_count() or 1, 32)          # torch's intra-op pool stops scaling (and thrashes) far below 256
     torch.set_num_threads(cores)
     cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd", "configs", "proposal_learning", "r50_mask2former.yaml"),
                     ["MODEL.DEVICE", "cpu"] + cfg_opts)
@@ -79,8 +96,9 @@ def cpu_baseline(cfg_opts, size, seconds_budget=60.0):
             p.grad = None
         return dt
 
-    probe = max(256, size // 4)
-    t_probe = one_step(probe)                    # also warms the allocator / thread pool
+    probe = max(128, size // 4)
+    one_step(probe)                              # warms the allocator / thread pool
+    t_probe = one_step(probe)
     est = t_probe * (size / probe) ** 2
     if est <= seconds_budget:
         dt, sample = one_step(size), f"1 image {size}x{size}, one full step (fwd+criterion+bwd+clipped AdamW), fp32"
@@ -100,6 +118,8 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="images per GPU")
     ap.add_argument("--freeze", default="", help='comma list for MODEL.MASK_FORMER.FREEZE_KEYS, e.g. "backbone,encoder"')
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run only the CPU oracle timing and print it")
+    ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--miopen-find", type=int, default=1, help="1: let MIOpen search conv algorithms during warm-up")
     ap.add_argument("--skip-kernel-timing", action="store_true", help="skip the eager per-launch timing steps (profiling runs)")
     ap.add_argument("--graph", type=int, default=0,
@@ -108,6 +128,9 @@ def main():
     ap.add_argument("opts", nargs="*", help="extra KEY VALUE config overrides")
     a = ap.parse_args()
 
+    if a.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(list(a.opts), a.size, threads=a.cpu_threads or None)), flush=True)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -212,10 +235,7 @@ def main():
                 "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["launches"], "other_kernels": kernels},
         }
         if world == 1 and not a.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(list(a.opts), a.size)
-            except Exception as e:                                  # the GPU number must still be reported
-                out["cpu_baseline"] = {"error": repr(e)}
+            out["cpu_baseline"] = cpu_baseline_subprocess(list(a.opts), a.size)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
