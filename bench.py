@@ -219,6 +219,15 @@ def main():
         if bwd_ms:
             kernels.append({"kernel": "msda_bwd_tiled_d32", "launches": len(bwd_ms), "avg_ms": avg(bwd_ms),
                             "alg_bytes": bb, "achieved_GBs": bb / avg(bwd_ms) / 1e6})
+        pmc = {}
+        try:                                   # HBM bytes per launch from the committed PMC passes (tools/pmc_msda.sh)
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_msda_pmc.json")))
+            if pj["geometry"]["batch"] == a.batch and pj["geometry"]["image"] == a.size:
+                pmc = {k: v["hbm_bytes_corrected"] for k, v in pj["kernels"].items()}
+        except Exception:                      # noqa: BLE001 - traffic stays null
+            pass
+        for kk in kernels:
+            kk["traffic"] = pmc.get(kk["kernel"])
         dom = max(kernels, key=lambda k: k["avg_ms"] * k["launches"]) if kernels else None
         out = {
             "metric": METRIC, "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": a.steps,
@@ -231,7 +240,8 @@ def main():
                        "final_total_loss": total_loss, "host_issue_ms_per_step": issue / a.steps * 1e3},
             "roofline": None if dom is None else {
                 "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": dom["alg_bytes"],
+                "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"),
+                "traffic_source": "profiles/r01_msda_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)", "alg_bytes_per_launch": dom["alg_bytes"],
                 "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["launches"], "other_kernels": kernels},
         }
         if world == 1 and not a.no_cpu_baseline:
