@@ -1,0 +1,76 @@
+/*
+ * pd_rowwise.h — C-ABI of the token-wise ("one wavefront per row") kernels of libpd_hip.so used by the transformer
+ * layers of the training step.  Each replaces a chain of eager PyTorch launches of the reference:
+ *
+ *   pd_add_layernorm_{fwd,bwd}   `tgt = norm(tgt + dropout(sublayer(tgt)))` of every post-norm layer —
+ *                                transformer_decoder/mask2former_transformer_decoder.py:44-54 (self-attention), :102-114
+ *                                (cross-attention), :167-171 (FFN), decoder_norm :438; pixel_decoder/msdeformattn.py
+ *                                MSDeformAttnTransformerEncoderLayer.forward (norm1/norm2) — plus the `with_pos_embed`
+ *                                add (:41-42, :80-81) and the half-precision casts autocast inserts in front of the next
+ *                                GEMM, produced as extra outputs of the same pass.  Row statistics are 64-lane
+ *                                wavefront reductions (DPP), one row per wavefront, 16-byte lanes.
+ *   pd_colsum_acc / pd_relu_bwd_colsum   bias gradients (column sums) of a GEMM, optionally fused with the ReLU
+ *                                backward of the FFN / MLP hidden layer (:167-171, MLP :198-204).
+ *   pd_mem_prep_{fwd,bwd}        decoder memory of one feature level (:392-401): tokens [B,HW,C] + level_embed ->
+ *                                seq-first `memory` and `memory + pos` in the GEMM dtype, one pass.
+ *   pd_attn_mask_u8              `(sigmoid(mask logits) < 0.5)` with fully-blocked rows released (:405, :455-459).
+ *
+ * Device pointers; dtypes are PD_F32 / PD_BF16 (pd_msda.h); `stream` = hipStream_t; returns 0 or a negative PD_ERR_*.
+ * C (the normalised / channel dimension) must be a multiple of 256 and <= 1024.
+ */
+#ifndef PD_ROWWISE_H
+#define PD_ROWWISE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * z = x + res (either may be NULL, not both);  y = LayerNorm(z) * gamma + beta  (biased variance, eps inside the sqrt).
+ *   x       [rows, C] of x_dtype (the sublayer's GEMM output)      res   fp32 [rows, C]
+ * Outputs (each nullable): z fp32 (what the backward needs), y fp32, y_c = y in c_dtype, ypos_c = y + pos[row / pos_div]
+ * in c_dtype (pos fp32 [ceil(rows / pos_div), C]); mean / rstd fp32 [rows] (required).
+ */
+int pd_add_layernorm_fwd(const void *x, int x_dtype, const float *res, const float *gamma, const float *beta, float eps,
+                         float *z, float *y, void *y_c, const float *pos, int pos_div, void *ypos_c, int c_dtype,
+                         float *mean, float *rstd, int rows, int C, void *stream);
+
+/*
+ * g = dy + dy2 + dy_c + dypos_c (each nullable, at least one given; dy / dy2 fp32, dy_c / dypos_c of c_dtype);
+ * dz = LayerNorm backward of g through (z, mean, rstd, gamma):  written to dz (fp32, may alias dy) and, when given, to
+ * dz_c in dzc_dtype.  Accumulated (+=, the caller zeroes them; each nullable):
+ *   dgamma[C] += sum_rows g * xhat      dbeta[C] += sum_rows g      dbias[C] += sum_rows dz
+ *   dpos_acc[row / pos_div, C] += dypos_c[row]   (gradient of the positional table added in the forward)
+ */
+int pd_add_layernorm_bwd(const float *dy, const float *dy2, const void *dy_c, const void *dypos_c, int c_dtype,
+                         const float *z, const float *mean, const float *rstd, const float *gamma, float *dz, void *dz_c,
+                         int dzc_dtype, float *dgamma, float *dbeta, float *dbias, float *dpos_acc, int pos_div,
+                         int rows, int C, void *stream);
+
+/* acc[N] (fp32) += column sums of x [rows, N] (dtype).  N % 128 == 0. */
+int pd_colsum_acc(const void *x, int dtype, int rows, int N, float *acc, void *stream);
+
+/* dh [rows, N] *= (h > 0) in place, then acc[N] += column sums of the result (acc nullable). */
+int pd_relu_bwd_colsum(void *dh, const void *h, int dtype, int rows, int N, float *acc, void *stream);
+
+/*
+ * tok: fp32 tokens of one level, element (b, p, c) at tok[b * tok_batch_stride + p * C + c]; level_embed fp32 [C]
+ * (nullable); pos fp32 [HW, C].  Writes seq-first [HW, B, C] (row p * B + b) in c_dtype:
+ *   mem_c = tok + level_embed        mempos_c = tok + level_embed + pos[p]
+ */
+int pd_mem_prep_fwd(const float *tok, int64_t tok_batch_stride, const float *level_embed, const float *pos, void *mem_c,
+                    void *mempos_c, int c_dtype, int B, int HW, int C, void *stream);
+
+/* dtok[b * dtok_batch_stride + p * C + c] = dmem_c[p * B + b, c] + dmempos_c[p * B + b, c]  (fp32 out; either input nullable) */
+int pd_mem_prep_bwd(const void *dmem_c, const void *dmempos_c, int c_dtype, float *dtok, int64_t dtok_batch_stride, int B,
+                    int HW, int C, void *stream);
+
+/* mask[r, k] = logits[r, k] < 0, except rows where that holds for every k, which become all 0.  logits [rows, n] dtype. */
+int pd_attn_mask_u8(const void *logits, int dtype, int rows, int n, uint8_t *mask, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PD_ROWWISE_H */

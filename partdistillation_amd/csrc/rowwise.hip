@@ -1,0 +1,415 @@
+// Token-wise kernels of the transformer layers (gfx950, wave64): one wavefront owns one row of C = NV4*256 channels,
+// every lane moves 16-byte (fp32) / 8-byte (bf16) pieces so a row is read and written as whole 1 KiB / 512 B bursts,
+// and the row statistics are 64-lane DPP reductions.  C-ABI in include/pd_rowwise.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pd_common.h"
+#include "pd_msda.h"
+#include "pd_rowwise.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f)
+{
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                          // round to nearest even
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t *p)
+{
+  const ushort4 v = *reinterpret_cast<const ushort4 *>(p);
+  return make_float4(bf2f(v.x), bf2f(v.y), bf2f(v.z), bf2f(v.w));
+}
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t *p, float4 v)
+{
+  ushort4 o;
+  o.x = f2bf(v.x); o.y = f2bf(v.y); o.z = f2bf(v.z); o.w = f2bf(v.w);
+  *reinterpret_cast<ushort4 *>(p) = o;
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// sum over the 64 lanes, result in every lane: quad_perm swaps, row_half_mirror, row_mirror inside each row of 16
+// lanes (DPP, no LDS traffic), then two cross-row exchanges
+__device__ __forceinline__ float wave_sum(float v)
+{
+  v += dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);      // row_half_mirror
+  v += dpp_mov<0x140>(v);      // row_mirror
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ add + LayerNorm
+template <int NV4, typename XT, typename CT>
+__global__ __launch_bounds__(256) void add_ln_fwd(const XT *__restrict__ x, const float *__restrict__ res,
+                                                  const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                  float *__restrict__ z, float *__restrict__ y, CT *__restrict__ y_c,
+                                                  const float *__restrict__ pos, int pos_div, CT *__restrict__ ypos_c,
+                                                  float *__restrict__ mean, float *__restrict__ rstd, int rows)
+{
+  constexpr int C = NV4 * 256;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float4 gm[NV4], bt[NV4];
+#pragma unroll
+  for (int j = 0; j < NV4; ++j) {
+    gm[j] = ld4(gamma + j * 256 + lane * 4);
+    bt[j] = ld4(beta + j * 256 + lane * 4);
+  }
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    const int64_t base = (int64_t)r * C + lane * 4;
+    float4 v[NV4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV4; ++j) {
+      v[j] = x ? ld4(x + base + j * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (res) v[j] = add4(v[j], ld4(res + base + j * 256));
+      if (z) st4(z + base + j * 256, v[j]);
+      s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    const float mu = wave_sum(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV4; ++j) {
+      v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+      q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+    }
+    const float rs = rsqrtf(wave_sum(q) * (1.f / C) + eps);
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+    const float *prow = pos ? pos + (int64_t)(r / pos_div) * C + lane * 4 : nullptr;
+#pragma unroll
+    for (int j = 0; j < NV4; ++j) {
+      float4 o;
+      o.x = v[j].x * rs * gm[j].x + bt[j].x;
+      o.y = v[j].y * rs * gm[j].y + bt[j].y;
+      o.z = v[j].z * rs * gm[j].z + bt[j].z;
+      o.w = v[j].w * rs * gm[j].w + bt[j].w;
+      if (y) st4(y + base + j * 256, o);
+      if (y_c) st4(y_c + base + j * 256, o);
+      if (ypos_c) st4(ypos_c + base + j * 256, add4(o, ld4(prow + j * 256)));
+    }
+  }
+}
+
+template <int NV4, typename CT, typename DT>
+__global__ __launch_bounds__(256) void add_ln_bwd(const float *dy, const float *__restrict__ dy2,
+                                                  const CT *__restrict__ dy_c, const CT *__restrict__ dypos_c,
+                                                  const float *__restrict__ z, const float *__restrict__ mean,
+                                                  const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                                  float *dz, DT *__restrict__ dz_c, float *__restrict__ dgamma,
+                                                  float *__restrict__ dbeta, float *__restrict__ dbias,
+                                                  float *__restrict__ dpos_acc, int pos_div, int rows)
+{
+  constexpr int C = NV4 * 256;
+  __shared__ float red[4][3][C];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float4 gm[NV4], ag[NV4], ab[NV4], ad[NV4];
+#pragma unroll
+  for (int j = 0; j < NV4; ++j) {
+    gm[j] = ld4(gamma + j * 256 + lane * 4);
+    ag[j] = ab[j] = ad[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    const int64_t base = (int64_t)r * C + lane * 4;
+    const float mu = mean[r], rs = rstd[r];
+    float4 g[NV4], xh[NV4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV4; ++j) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dy) t = ld4(dy + base + j * 256);
+      if (dy2) t = add4(t, ld4(dy2 + base + j * 256));
+      if (dy_c) t = add4(t, ld4(dy_c + base + j * 256));
+      if (dypos_c) {
+        const float4 p = ld4(dypos_c + base + j * 256);
+        t = add4(t, p);
+        if (dpos_acc) {
+          float *a = dpos_acc + (int64_t)(r / pos_div) * C + j * 256 + lane * 4;
+          atomicAdd(a, p.x); atomicAdd(a + 1, p.y); atomicAdd(a + 2, p.z); atomicAdd(a + 3, p.w);
+        }
+      }
+      float4 h = ld4(z + base + j * 256);
+      h.x = (h.x - mu) * rs; h.y = (h.y - mu) * rs; h.z = (h.z - mu) * rs; h.w = (h.w - mu) * rs;
+      ag[j].x += t.x * h.x; ag[j].y += t.y * h.y; ag[j].z += t.z * h.z; ag[j].w += t.w * h.w;
+      ab[j] = add4(ab[j], t);
+      t.x *= gm[j].x; t.y *= gm[j].y; t.z *= gm[j].z; t.w *= gm[j].w;
+      s1 += (t.x + t.y) + (t.z + t.w);
+      s2 += (t.x * h.x + t.y * h.y) + (t.z * h.z + t.w * h.w);
+      g[j] = t; xh[j] = h;
+    }
+    const float m1 = wave_sum(s1) * (1.f / C), m2 = wave_sum(s2) * (1.f / C);
+#pragma unroll
+    for (int j = 0; j < NV4; ++j) {
+      float4 o;
+      o.x = rs * (g[j].x - m1 - xh[j].x * m2);
+      o.y = rs * (g[j].y - m1 - xh[j].y * m2);
+      o.z = rs * (g[j].z - m1 - xh[j].z * m2);
+      o.w = rs * (g[j].w - m1 - xh[j].w * m2);
+      ad[j] = add4(ad[j], o);
+      st4(dz + base + j * 256, o);
+      if (dz_c) st4(dz_c + base + j * 256, o);
+    }
+  }
+  if (!dgamma && !dbeta && !dbias) return;
+#pragma unroll
+  for (int j = 0; j < NV4; ++j) {
+    st4(&red[wave][0][j * 256 + lane * 4], ag[j]);
+    st4(&red[wave][1][j * 256 + lane * 4], ab[j]);
+    st4(&red[wave][2][j * 256 + lane * 4], ad[j]);
+  }
+  __syncthreads();
+  float *outs[3] = {dgamma, dbeta, dbias};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (!outs[k]) continue;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float s = (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]);
+      atomicAdd(outs[k] + c, s);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void colsum_acc(T *__restrict__ x, const T *__restrict__ h, int rows, int N, int rows_per_blk,
+                                                  float *__restrict__ acc)
+{
+  __shared__ float red[4][128];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c0 = blockIdx.x * 128 + lane * 2;
+  const int r_begin = blockIdx.y * rows_per_blk, r_end = min(rows, r_begin + rows_per_blk);
+  float a0 = 0.f, a1 = 0.f;
+  for (int r = r_begin + wave; r < r_end; r += 4) {
+    T *p = x + (int64_t)r * N + c0;
+    float v0, v1;
+    if constexpr (sizeof(T) == 2) {
+      const unsigned u = *reinterpret_cast<const unsigned *>(p);
+      v0 = bf2f((bf16_t)(u & 0xffffu)); v1 = bf2f((bf16_t)(u >> 16));
+    } else {
+      const float2 u = *reinterpret_cast<const float2 *>(p);
+      v0 = u.x; v1 = u.y;
+    }
+    if (RELU) {
+      float h0, h1;
+      if constexpr (sizeof(T) == 2) {
+        const unsigned u = *reinterpret_cast<const unsigned *>(h + (int64_t)r * N + c0);
+        h0 = bf2f((bf16_t)(u & 0xffffu)); h1 = bf2f((bf16_t)(u >> 16));
+      } else {
+        const float2 u = *reinterpret_cast<const float2 *>(h + (int64_t)r * N + c0);
+        h0 = u.x; h1 = u.y;
+      }
+      if (!(h0 > 0.f)) v0 = 0.f;
+      if (!(h1 > 0.f)) v1 = 0.f;
+      if constexpr (sizeof(T) == 2) *reinterpret_cast<unsigned *>(p) = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+      else *reinterpret_cast<float2 *>(p) = make_float2(v0, v1);
+    }
+    a0 += v0; a1 += v1;
+  }
+  if (!acc) return;
+  red[wave][lane * 2] = a0; red[wave][lane * 2 + 1] = a1;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x;
+    atomicAdd(acc + blockIdx.x * 128 + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ decoder memory
+template <typename CT>
+__global__ __launch_bounds__(256) void mem_prep_fwd(const float *__restrict__ tok, int64_t bstride, const float *__restrict__ lvl,
+                                                    const float *__restrict__ pos, CT *__restrict__ mem, CT *__restrict__ mempos,
+                                                    int B, int HW, int C)
+{
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rows = B * HW;
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    const int p = r / B, b = r - p * B;
+    const float *src = tok + (int64_t)b * bstride + (int64_t)p * C;
+    for (int c = lane * 4; c < C; c += 256) {
+      float4 v = ld4(src + c);
+      if (lvl) v = add4(v, ld4(lvl + c));
+      if (mem) st4(mem + (int64_t)r * C + c, v);
+      if (mempos) st4(mempos + (int64_t)r * C + c, add4(v, ld4(pos + (int64_t)p * C + c)));
+    }
+  }
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void mem_prep_bwd(const CT *__restrict__ dmem, const CT *__restrict__ dmempos,
+                                                    float *__restrict__ dtok, int64_t bstride, int B, int HW, int C)
+{
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rows = B * HW;
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {      // r enumerates the OUTPUT rows (b, p): coalesced stores
+    const int b = r / HW, p = r - b * HW;
+    const int64_t srow = ((int64_t)p * B + b) * C;
+    float *dst = dtok + (int64_t)b * bstride + (int64_t)p * C;
+    for (int c = lane * 4; c < C; c += 256) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dmem) v = ld4(dmem + srow + c);
+      if (dmempos) v = add4(v, ld4(dmempos + srow + c));
+      st4(dst + c, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ attention mask
+template <typename T>
+__global__ __launch_bounds__(256) void attn_mask_u8(const T *__restrict__ logits, int n, uint8_t *__restrict__ mask)
+{
+  __shared__ int any_open;
+  const T *row = logits + (int64_t)blockIdx.x * n;
+  uint8_t *out = mask + (int64_t)blockIdx.x * n;
+  if (threadIdx.x == 0) any_open = 0;
+  __syncthreads();
+  int open = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float v;
+    if constexpr (sizeof(T) == 2) v = bf2f(row[i]); else v = row[i];
+    open |= !(v < 0.f);
+  }
+  if (__ballot(open) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&any_open, 1);
+  __syncthreads();
+  const bool keep = any_open != 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float v;
+    if constexpr (sizeof(T) == 2) v = bf2f(row[i]); else v = row[i];
+    out[i] = (keep && v < 0.f) ? 1 : 0;
+  }
+}
+
+int grid_rows(int rows, int cap) { return max(1, min(cap, (rows + 3) / 4)); }
+
+bool dt_ok(int dt) { return dt == PD_F32 || dt == PD_BF16; }
+
+}  // namespace
+
+#define NV4_SWITCH(C, BODY)                                                                                        \
+  switch ((C) / 256) {                                                                                             \
+    case 1: { constexpr int NV4 = 1; BODY; } break;                                                                \
+    case 2: { constexpr int NV4 = 2; BODY; } break;                                                                \
+    case 3: { constexpr int NV4 = 3; BODY; } break;                                                                \
+    case 4: { constexpr int NV4 = 4; BODY; } break;                                                                \
+    default: return pd_set_error(PD_ERR_INVALID_ARG, "C=%d: supported widths are 256, 512, 768, 1024", (C)); \
+  }
+
+extern "C" int pd_add_layernorm_fwd(const void *x, int x_dtype, const float *res, const float *gamma, const float *beta, float eps,
+                                    float *z, float *y, void *y_c, const float *pos, int pos_div, void *ypos_c, int c_dtype,
+                                    float *mean, float *rstd, int rows, int C, void *stream_)
+{
+  if (rows < 0 || C <= 0 || (C % 256)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_layernorm_fwd: rows=%d C=%d", rows, C);
+  if (rows == 0) return PD_OK;
+  if ((!x && !res) || !gamma || !beta || !mean || !rstd) return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_layernorm_fwd: null pointer");
+  if ((x && !dt_ok(x_dtype)) || ((y_c || ypos_c) && !dt_ok(c_dtype))) return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_layernorm_fwd: dtype");
+  if (ypos_c && (!pos || pos_div <= 0)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_layernorm_fwd: ypos_c needs pos and pos_div > 0");
+  hipStream_t s = (hipStream_t)stream_;
+  dim3 g(grid_rows(rows, 2048)), b(256);
+  const bool xb = x && x_dtype == PD_BF16, cb = c_dtype == PD_BF16;
+#define LAUNCH(XT, CT) hipLaunchKernelGGL((add_ln_fwd<NV4, XT, CT>), g, b, 0, s, (const XT *)x, res, gamma, beta, eps, z, y, (CT *)y_c, pos, pos_div, (CT *)ypos_c, mean, rstd, rows)
+  NV4_SWITCH(C, {
+    if (xb) { if (cb) LAUNCH(bf16_t, bf16_t); else LAUNCH(bf16_t, float); }
+    else { if (cb) LAUNCH(float, bf16_t); else LAUNCH(float, float); }
+  })
+#undef LAUNCH
+  return pd_check_launch("pd_add_layernorm_fwd");
+}
+
+extern "C" int pd_add_layernorm_bwd(const float *dy, const float *dy2, const void *dy_c, const void *dypos_c, int c_dtype,
+                                    const float *z, const float *mean, const float *rstd, const float *gamma, float *dz,
+                                    void *dz_c, int dzc_dtype, float *dgamma, float *dbeta, float *dbias, float *dpos_acc,
+                                    int pos_div, int rows, int C, void *stream_)
+{
+  if (rows < 0 || C <= 0 || (C % 256)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_layernorm_bwd: rows=%d C=%d", rows, C);
+  if (rows == 0) return PD_OK;
+  if ((!dy && !dy2 && !dy_c && !dypos_c) || !z || !mean || !rstd || !gamma || !dz)
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_layernorm_bwd: null pointer");
+  if (((dy_c || dypos_c) && !dt_ok(c_dtype)) || (dz_c && !dt_ok(dzc_dtype))) return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_layernorm_bwd: dtype");
+  if (dpos_acc && pos_div <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_layernorm_bwd: pos_div");
+  hipStream_t s = (hipStream_t)stream_;
+  // the per-column sums leave each workgroup as C atomics per output: cap the grid so a channel sees <= ~1k of them
+  dim3 g(grid_rows(rows, 1024)), b(256);
+  const bool cb = c_dtype == PD_BF16, db = dzc_dtype == PD_BF16;
+#define LAUNCH(CT, DT) hipLaunchKernelGGL((add_ln_bwd<NV4, CT, DT>), g, b, 0, s, dy, dy2, (const CT *)dy_c, (const CT *)dypos_c, z, mean, rstd, gamma, dz, (DT *)dz_c, dgamma, dbeta, dbias, dpos_acc, pos_div, rows)
+  NV4_SWITCH(C, {
+    if (cb) { if (db) LAUNCH(bf16_t, bf16_t); else LAUNCH(bf16_t, float); }
+    else { if (db) LAUNCH(float, bf16_t); else LAUNCH(float, float); }
+  })
+#undef LAUNCH
+  return pd_check_launch("pd_add_layernorm_bwd");
+}
+
+static int colsum_launch(void *x, const void *h, int dtype, int rows, int N, float *acc, bool relu, hipStream_t s, const char *who)
+{
+  if (rows < 0 || N <= 0 || (N % 128) || !dt_ok(dtype)) return pd_set_error(PD_ERR_INVALID_ARG, "%s: rows=%d N=%d dtype=%d", who, rows, N, dtype);
+  if (rows == 0) return PD_OK;
+  if (!x || (relu && !h) || (!relu && !acc)) return pd_set_error(PD_ERR_INVALID_ARG, "%s: null pointer", who);
+  const int rpb = rows <= 4096 ? 64 : 256;
+  dim3 g(N / 128, (rows + rpb - 1) / rpb), b(256);
+  if (dtype == PD_BF16) {
+    if (relu) hipLaunchKernelGGL((colsum_acc<bf16_t, true>), g, b, 0, s, (bf16_t *)x, (const bf16_t *)h, rows, N, rpb, acc);
+    else hipLaunchKernelGGL((colsum_acc<bf16_t, false>), g, b, 0, s, (bf16_t *)x, (const bf16_t *)h, rows, N, rpb, acc);
+  } else {
+    if (relu) hipLaunchKernelGGL((colsum_acc<float, true>), g, b, 0, s, (float *)x, (const float *)h, rows, N, rpb, acc);
+    else hipLaunchKernelGGL((colsum_acc<float, false>), g, b, 0, s, (float *)x, (const float *)h, rows, N, rpb, acc);
+  }
+  return pd_check_launch(who);
+}
+
+extern "C" int pd_colsum_acc(const void *x, int dtype, int rows, int N, float *acc, void *stream_)
+{
+  return colsum_launch(const_cast<void *>(x), nullptr, dtype, rows, N, acc, false, (hipStream_t)stream_, "pd_colsum_acc");
+}
+
+extern "C" int pd_relu_bwd_colsum(void *dh, const void *h, int dtype, int rows, int N, float *acc, void *stream_)
+{
+  return colsum_launch(dh, h, dtype, rows, N, acc, true, (hipStream_t)stream_, "pd_relu_bwd_colsum");
+}
+
+extern "C" int pd_mem_prep_fwd(const float *tok, int64_t tok_batch_stride, const float *level_embed, const float *pos, void *mem_c,
+                               void *mempos_c, int c_dtype, int B, int HW, int C, void *stream_)
+{
+  if (B < 0 || HW < 0 || C <= 0 || (C % 256) || !dt_ok(c_dtype)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_mem_prep_fwd: B=%d HW=%d C=%d", B, HW, C);
+  if (B == 0 || HW == 0) return PD_OK;
+  if (!tok || (!mem_c && !mempos_c) || (mempos_c && !pos)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_mem_prep_fwd: null pointer");
+  dim3 g(grid_rows(B * HW, 4096)), b(256);
+  if (c_dtype == PD_BF16) hipLaunchKernelGGL((mem_prep_fwd<bf16_t>), g, b, 0, (hipStream_t)stream_, tok, tok_batch_stride, level_embed, pos, (bf16_t *)mem_c, (bf16_t *)mempos_c, B, HW, C);
+  else hipLaunchKernelGGL((mem_prep_fwd<float>), g, b, 0, (hipStream_t)stream_, tok, tok_batch_stride, level_embed, pos, (float *)mem_c, (float *)mempos_c, B, HW, C);
+  return pd_check_launch("pd_mem_prep_fwd");
+}
+
+extern "C" int pd_mem_prep_bwd(const void *dmem_c, const void *dmempos_c, int c_dtype, float *dtok, int64_t dtok_batch_stride, int B,
+                               int HW, int C, void *stream_)
+{
+  if (B < 0 || HW < 0 || C <= 0 || (C % 256) || !dt_ok(c_dtype)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_mem_prep_bwd: B=%d HW=%d C=%d", B, HW, C);
+  if (B == 0 || HW == 0) return PD_OK;
+  if (!dtok || (!dmem_c && !dmempos_c)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_mem_prep_bwd: null pointer");
+  dim3 g(grid_rows(B * HW, 4096)), b(256);
+  if (c_dtype == PD_BF16) hipLaunchKernelGGL((mem_prep_bwd<bf16_t>), g, b, 0, (hipStream_t)stream_, (const bf16_t *)dmem_c, (const bf16_t *)dmempos_c, dtok, dtok_batch_stride, B, HW, C);
+  else hipLaunchKernelGGL((mem_prep_bwd<float>), g, b, 0, (hipStream_t)stream_, (const float *)dmem_c, (const float *)dmempos_c, dtok, dtok_batch_stride, B, HW, C);
+  return pd_check_launch("pd_mem_prep_bwd");
+}
+
+extern "C" int pd_attn_mask_u8(const void *logits, int dtype, int rows, int n, uint8_t *mask, void *stream_)
+{
+  if (rows < 0 || n < 0 || !dt_ok(dtype)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_attn_mask_u8: rows=%d n=%d dtype=%d", rows, n, dtype);
+  if (rows == 0 || n == 0) return PD_OK;
+  if (!logits || !mask) return pd_set_error(PD_ERR_INVALID_ARG, "pd_attn_mask_u8: null pointer");
+  if (dtype == PD_BF16) hipLaunchKernelGGL((attn_mask_u8<bf16_t>), dim3(rows), dim3(256), 0, (hipStream_t)stream_, (const bf16_t *)logits, n, mask);
+  else hipLaunchKernelGGL((attn_mask_u8<float>), dim3(rows), dim3(256), 0, (hipStream_t)stream_, (const float *)logits, n, mask);
+  return pd_check_launch("pd_attn_mask_u8");
+}

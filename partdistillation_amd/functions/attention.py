@@ -22,6 +22,29 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def attn_fwd_raw(q, k, v, m8, B, nheads, scale):
+    """q [Lq*B, H*32], k / v [Lk*B, H*32] (seq-first rows l*B + b, contiguous), m8 uint8 [B,Lq,Lk] | None -> (o, lse).
+    No autograd: building block of hand-written backward passes."""
+    Lq, Lk = q.shape[0] // B, k.shape[0] // B
+    o = torch.empty_like(q)
+    lse = torch.empty((B, nheads, Lq), dtype=torch.float32, device=q.device)
+    ws = _workspace(B, nheads, Lq, Lk, q.device)
+    _lib.check(_lib.load().pd_attn_fwd_d32(q.data_ptr(), k.data_ptr(), v.data_ptr(), m8.data_ptr() if m8 is not None else None,
+                                           o.data_ptr(), lse.data_ptr(), ws.data_ptr(), B, nheads, Lq, Lk, float(scale),
+                                           _DT[q.dtype], _stream()))
+    return o, lse
+
+
+def attn_bwd_raw(q, k, v, m8, o, d_o, lse, B, nheads, scale):
+    Lq, Lk = q.shape[0] // B, k.shape[0] // B
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ws = _workspace(B, nheads, Lq, Lk, q.device)
+    _lib.check(_lib.load().pd_attn_bwd_d32(q.data_ptr(), k.data_ptr(), v.data_ptr(), m8.data_ptr() if m8 is not None else None,
+                                           o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                           ws.data_ptr(), B, nheads, Lq, Lk, float(scale), _DT[q.dtype], _stream()))
+    return dq, dk, dv
+
+
 class MaskedAttention32(Function):
     """softmax(q k^T * scale + mask(-inf)) v per head; q [Lq,B,H*32], k/v [Lk,B,H*32] (seq-first, contiguous);
     mask bool [B,Lq,Lk] (True = blocked) or None.  Returns o [Lq,B,H*32]."""

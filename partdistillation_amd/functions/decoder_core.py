@@ -1,0 +1,268 @@
+"""The query side of the masked-attention decoder as ONE autograd node with a hand-written backward.
+
+Reference: transformer_decoder/mask2former_transformer_decoder.py:380-447 — L x (masked cross-attention :102-114,
+self-attention :44-54, FFN :167-171, all post-norm) with a prediction head (:449-459) in front of every layer.  Run
+through eager autograd that loop is ~1 600 launches per training step on 200-row tensors (views, casts, weight slices
+and their zero-filled gradients, three-kernel LayerNorm backwards, ...): the step is bound by issuing them, not by
+executing them.  Here every sub-layer is a fixed sequence of library GEMMs (torch.addmm / mm on
+the bf16 — or fp32 — operands) and hand-written HIP kernels:
+
+  * pd_add_layernorm_{fwd,bwd}  residual + LayerNorm, which also emit the GEMM-dtype copies `y` / `y + query_pos` the
+    next projections read and accumulate LayerNorm / bias / positional-table gradients;
+  * pd_attn_{fwd,bwd}_d32       split-key masked attention (cross- and self-attention);
+  * pd_relu_bwd_colsum / pd_colsum_acc, pd_mem_prep_{fwd,bwd}, pd_attn_mask_u8.
+
+Tensors are seq-first like the reference: row = query * B + image.  The node returns the L+1 normalised decoder
+outputs (decoder_norm applied); the class / mask-embedding heads that carry gradients are evaluated once on the stack
+of all L+1 outputs by the caller, while the per-layer mask prediction that only feeds the next layer's attention
+mask (no gradient: the reference detaches it, :457) runs inside the loop.
+"""
+from typing import List
+
+import torch
+from torch.autograd import Function
+
+from . import rowwise as rw
+from .attention import attn_bwd_raw, attn_fwd_raw
+
+
+class DecoderSpec:
+    """static description handed to DecoderCore (not a tensor argument)."""
+
+    def __init__(self, B, Q, C, nheads, num_layers, sizes, pos_tables, pooled, eps, cdt, num_levels=3):
+        self.B, self.Q, self.C, self.H, self.L = B, Q, C, nheads, num_layers
+        self.sizes, self.pos, self.pooled, self.eps, self.cdt, self.num_levels = sizes, pos_tables, pooled, eps, cdt, num_levels
+
+
+def _lin(x, w, b):
+    return torch.addmm(b, x, w.t())
+
+
+def _lin_relu(x, w, b):
+    return torch.relu_(torch.addmm(b, x, w.t()))
+
+
+class _Acc:
+    """fp32 accumulators (bias / LayerNorm gradients) carved out of one zero-filled buffer."""
+
+    def __init__(self):
+        self.n, self.bias_n = 0, 0
+
+    def take(self, n):
+        off = self.n
+        self.n += n
+        return (off, n)
+
+
+N_GLOBAL = 11        # query_feat, query_embed, level_embed, dn_w, dn_b, mlp (w,b) x 3
+N_LAYER = 18         # cross: in_w in_b out_w out_b n_w n_b | self: same | ffn: w1 b1 w2 b2 n_w n_b
+
+
+class DecoderCore(Function):
+    @staticmethod
+    def forward(ctx, spec: DecoderSpec, *t):
+        ctx.set_materialize_grads(False)
+        B, Q, C, H, L, cdt = spec.B, spec.Q, spec.C, spec.H, spec.L, spec.cdt
+        nl = spec.num_levels
+        xs = t[:nl]
+        g = t[nl:nl + N_GLOBAL]
+        query_feat, query_embed, level_embed, dn_w, dn_b = g[:5]
+        mlp = g[5:11]
+        layers = [t[nl + N_GLOBAL + i * N_LAYER: nl + N_GLOBAL + (i + 1) * N_LAYER] for i in range(L)]
+        R, scale = Q * B, 32 ** -0.5
+        dev = xs[0].device
+
+        mem, mempos = [], []
+        for l in range(nl):
+            m, mp = rw.mem_prep_fwd(xs[l], level_embed[l], spec.pos[l], cdt)
+            mem.append(m), mempos.append(mp)
+        qpos = query_embed.contiguous()                                        # fp32 [Q, C]; row r uses qpos[r // B]
+        tgt = query_feat.unsqueeze(1).expand(Q, B, C).reshape(R, C)             # fp32 copy
+        tgtpos_c = (query_feat + query_embed).to(cdt).unsqueeze(1).expand(Q, B, C).reshape(R, C)
+
+        dec_outs = torch.empty((L + 1, R, C), dtype=torch.float32, device=dev)
+        final_tgt = None
+        saved = []
+        head_stats = []
+
+        def head(i, tgt_f32, lvl):
+            """decoder_norm -> dec_outs[i]; the (gradient-free) mask prediction for the next layer's attention"""
+            _, _, d_c, _, mean, rstd = _ln_into(tgt_f32, dn_w, dn_b, spec.eps, dec_outs[i], cdt)
+            head_stats.append((mean, rstd))
+            if lvl is None:
+                return None
+            e = _lin(_lin_relu(_lin_relu(d_c, mlp[0], mlp[1]), mlp[2], mlp[3]), mlp[4], mlp[5])        # [R, C]
+            ef = torch.empty((B, Q, C), dtype=torch.float32, device=dev)
+            ef.copy_(e.view(Q, B, C).transpose(0, 1))
+            logits = torch.bmm(ef, spec.pooled[lvl])                                                     # [B, Q, HW] fp32
+            return rw.attn_mask_u8(logits)
+
+        mask = head(0, tgt, 0)
+        for i in range(L):
+            lvl = i % nl
+            (ciw, cib, cow, cob, cnw, cnb, siw, sib, sow, sob, snw, snb, w1, b1, w2, b2, fnw, fnb) = layers[i]
+            # ---- masked cross-attention
+            q = _lin(tgtpos_c, ciw[:C], cib[:C])
+            k = _lin(mempos[lvl], ciw[C:2 * C], cib[C:2 * C])
+            v = _lin(mem[lvl], ciw[2 * C:], cib[2 * C:])
+            o, lse = attn_fwd_raw(q, k, v, mask, B, H, scale)
+            z, y, y_c, ypos_c, mean, rstd = rw.add_ln_fwd(_lin(o, cow, cob), tgt, cnw, cnb, spec.eps, c_dtype=cdt, want_yc=True,
+                                                          pos=qpos, pos_div=B, want_ypos=True)
+            cross = (tgtpos_c, q, k, v, mask, o, lse, z, mean, rstd)
+            tgt, tgt_c, tgtpos_c = y, y_c, ypos_c
+            # ---- self-attention
+            q = _lin(tgtpos_c, siw[:C], sib[:C])
+            k = _lin(tgtpos_c, siw[C:2 * C], sib[C:2 * C])
+            v = _lin(tgt_c, siw[2 * C:], sib[2 * C:])
+            o, lse = attn_fwd_raw(q, k, v, None, B, H, scale)
+            z, y, y_c, _, mean, rstd = rw.add_ln_fwd(_lin(o, sow, sob), tgt, snw, snb, spec.eps, c_dtype=cdt, want_yc=True)
+            slf = (tgtpos_c, tgt_c, q, k, v, o, lse, z, mean, rstd)
+            tgt, tgt_c = y, y_c
+            # ---- FFN
+            h = _lin_relu(tgt_c, w1, b1)
+            z, y, _, ypos_c, mean, rstd = rw.add_ln_fwd(_lin(h, w2, b2), tgt, fnw, fnb, spec.eps, c_dtype=cdt, pos=qpos,
+                                                        pos_div=B, want_ypos=True)
+            ffn = (tgt_c, h, z, mean, rstd, y)
+            tgt, tgtpos_c = y, ypos_c
+            saved.append((cross, slf, ffn))
+            mask = head(i + 1, tgt, (i + 1) % nl if i + 1 < L else None)
+        final_tgt = tgt.view(R, C)          # a view: the node must not own one of its own outputs (reference cycle)
+        ctx.spec, ctx.saved, ctx.head_stats = spec, saved, head_stats
+        ctx.mem, ctx.mempos = mem, mempos
+        ctx.params = (query_feat, query_embed, level_embed, dn_w, dn_b, mlp, layers)
+        ctx.x_shapes = [x.shape for x in xs]
+        return dec_outs, final_tgt
+
+    @staticmethod
+    def backward(ctx, d_out, d_final):
+        spec = ctx.spec
+        B, Q, C, H, L, cdt = spec.B, spec.Q, spec.C, spec.H, spec.L, spec.cdt
+        nl = spec.num_levels
+        R, scale = Q * B, 32 ** -0.5
+        query_feat, query_embed, level_embed, dn_w, dn_b, mlp, layers = ctx.params
+        dev = query_feat.device
+        d_out = d_out.contiguous() if d_out is not None else torch.zeros((L + 1, R, C), dtype=torch.float32, device=dev)
+        need_x = [ctx.needs_input_grad[1 + l] for l in range(nl)]
+
+        # fp32 accumulators: [linear biases ... | LayerNorm gammas / betas ... | decoder_norm | query_pos]
+        acc = _Acc()
+        lay = []
+        for i in range(L):
+            lay.append({"cib": acc.take(3 * C), "cob": acc.take(C), "sib": acc.take(3 * C), "sob": acc.take(C),
+                        "b1": acc.take(layers[i][13].numel()), "b2": acc.take(C)})
+        n_bias = acc.n
+        for i in range(L):
+            lay[i].update({"cnw": acc.take(C), "cnb": acc.take(C), "snw": acc.take(C), "snb": acc.take(C),
+                           "fnw": acc.take(C), "fnb": acc.take(C)})
+        s_dnw, s_dnb, s_pos = acc.take(C), acc.take(C), acc.take(Q * C)
+        buf = torch.zeros(acc.n, dtype=torch.float32, device=dev)
+
+        def A(s):
+            return buf[s[0]:s[0] + s[1]]
+
+        dmem: List = [None] * nl
+        dmempos: List = [None] * nl
+        wgrads = [None] * L
+        d_res = d_final.contiguous() if d_final is not None else None        # fp32 gradient w.r.t. the residual stream
+        d_pos_c = None                                                       # GEMM-dtype gradient w.r.t. (tgt + query_pos)
+        for i in reversed(range(L)):
+            lvl = i % nl
+            (ciw, cib, cow, cob, cnw, cnb, siw, sib, sow, sob, snw, snb, w1, b1, w2, b2, fnw, fnb) = layers[i]
+            cross, slf, ffn = ctx.saved[i]
+            # ---- head i+1 (decoder_norm of the FFN output)
+            hm, hr = ctx.head_stats[i + 1]
+            dzh, _ = rw.add_ln_bwd(ffn[5], hm, hr, dn_w, dy=d_out[i + 1], dgamma=A(s_dnw), dbeta=A(s_dnb))
+            # ---- FFN
+            x_c, h, z, mean, rstd, _ = ffn
+            dz, dz_c = rw.add_ln_bwd(z, mean, rstd, fnw, dy=dzh, dy2=d_res, dypos_c=d_pos_c, dz_c_dtype=cdt,
+                                     dgamma=A(lay[i]["fnw"]), dbeta=A(lay[i]["fnb"]), dbias=A(lay[i]["b2"]),
+                                     dpos_acc=A(s_pos) if d_pos_c is not None else None, pos_div=B, out=dzh)
+            g_w2 = torch.mm(dz_c.t(), h)
+            dh = rw.relu_bwd_colsum(torch.mm(dz_c, w2), h, A(lay[i]["b1"]))
+            g_w1 = torch.mm(dh.t(), x_c)
+            dx_c = torch.mm(dh, w1)
+            # ---- self-attention
+            tp_c, t_c, q, k, v, o, lse, z, mean, rstd = slf
+            dz, dz_c = rw.add_ln_bwd(z, mean, rstd, snw, dy=dz, dy_c=dx_c, dz_c_dtype=cdt, dgamma=A(lay[i]["snw"]),
+                                     dbeta=A(lay[i]["snb"]), dbias=A(lay[i]["sob"]), out=dz)
+            g_sow = torch.mm(dz_c.t(), o)
+            dq, dk, dv = attn_bwd_raw(q, k, v, None, o, torch.mm(dz_c, sow), lse, B, H, scale)
+            g_siw = torch.empty_like(siw)
+            torch.mm(dq.t(), tp_c, out=g_siw[:C])
+            torch.mm(dk.t(), tp_c, out=g_siw[C:2 * C])
+            torch.mm(dv.t(), t_c, out=g_siw[2 * C:])
+            sb = A(lay[i]["sib"])
+            rw.colsum_acc(dq, sb[:C]), rw.colsum_acc(dk, sb[C:2 * C]), rw.colsum_acc(dv, sb[2 * C:])
+            d_tp = torch.mm(dq, siw[:C])
+            d_tp.addmm_(dk, siw[C:2 * C])
+            d_tc = torch.mm(dv, siw[2 * C:])
+            # ---- cross-attention
+            tp_c, q, k, v, mask, o, lse, z, mean, rstd = cross
+            dz, dz_c = rw.add_ln_bwd(z, mean, rstd, cnw, dy=dz, dy_c=d_tc, dypos_c=d_tp, dz_c_dtype=cdt,
+                                     dgamma=A(lay[i]["cnw"]), dbeta=A(lay[i]["cnb"]), dbias=A(lay[i]["cob"]),
+                                     dpos_acc=A(s_pos), pos_div=B, out=dz)
+            g_cow = torch.mm(dz_c.t(), o)
+            dq, dk, dv = attn_bwd_raw(q, k, v, mask, o, torch.mm(dz_c, cow), lse, B, H, scale)
+            g_ciw = torch.empty_like(ciw)
+            torch.mm(dq.t(), tp_c, out=g_ciw[:C])
+            torch.mm(dk.t(), ctx.mempos[lvl], out=g_ciw[C:2 * C])
+            torch.mm(dv.t(), ctx.mem[lvl], out=g_ciw[2 * C:])
+            cb = A(lay[i]["cib"])
+            rw.colsum_acc(dq, cb[:C]), rw.colsum_acc(dk, cb[C:2 * C]), rw.colsum_acc(dv, cb[2 * C:])
+            d_pos_c = torch.mm(dq, ciw[:C])                                   # -> previous layer's FFN norm (or the queries)
+            if dmempos[lvl] is None:
+                dmempos[lvl] = torch.mm(dk, ciw[C:2 * C])
+                dmem[lvl] = torch.mm(dv, ciw[2 * C:])
+            else:
+                dmempos[lvl].addmm_(dk, ciw[C:2 * C])
+                dmem[lvl].addmm_(dv, ciw[2 * C:])
+            d_res = dz
+            wgrads[i] = (g_ciw, g_cow, g_siw, g_sow, g_w1, g_w2)
+
+        # ---- head 0 and the learnable queries
+        hm, hr = ctx.head_stats[0]
+        tgt0 = query_feat.unsqueeze(1).expand(Q, B, C).reshape(R, C)
+        dz0, _ = rw.add_ln_bwd(tgt0, hm, hr, dn_w, dy=d_out[0], dgamma=A(s_dnw), dbeta=A(s_dnb))
+        d_pos0 = d_pos_c.float().view(Q, B, C).sum(1)
+        d_query_feat = (dz0 + d_res).view(Q, B, C).sum(1) + d_pos0
+        d_query_embed = A(s_pos).view(Q, C) + d_pos0
+
+        d_xs = [None] * nl
+        d_level = torch.empty_like(level_embed)
+        for l in range(nl):
+            _, _, Hh, Ww = ctx.x_shapes[l]
+            if dmem[l] is None:                                              # level unused (fewer layers than levels)
+                d_level[l].zero_()
+                continue
+            dtok = rw.mem_prep_bwd(dmem[l], dmempos[l], B, Hh, Ww, C)
+            torch.sum(dtok.view(-1, C), dim=0, out=d_level[l])
+            if need_x[l]:
+                d_xs[l] = dtok.view(B, Hh, Ww, C).permute(0, 3, 1, 2)
+
+        bias_c = buf[:n_bias] if layers[0][1].dtype == torch.float32 else buf[:n_bias].to(layers[0][1].dtype)
+
+        def Bc(s):
+            return bias_c[s[0]:s[0] + s[1]]
+
+        grads = [None]                                                        # spec
+        grads += d_xs
+        grads += [d_query_feat, d_query_embed, d_level, A(s_dnw), A(s_dnb)] + [None] * 6
+        for i in range(L):
+            g_ciw, g_cow, g_siw, g_sow, g_w1, g_w2 = wgrads[i]
+            s = lay[i]
+            grads += [g_ciw, Bc(s["cib"]), g_cow, Bc(s["cob"]), A(s["cnw"]), A(s["cnb"]),
+                      g_siw, Bc(s["sib"]), g_sow, Bc(s["sob"]), A(s["snw"]), A(s["snb"]),
+                      g_w1, Bc(s["b1"]), g_w2, Bc(s["b2"]), A(s["fnw"]), A(s["fnb"])]
+        return tuple(grads)
+
+
+def _ln_into(x_f32, gamma, beta, eps, y_out, cdt):
+    """LayerNorm of fp32 rows written straight into `y_out` (a slice of the stacked output) + its GEMM-dtype copy."""
+    rows, C = x_f32.shape
+    from .. import lib as _lib
+    y_c = torch.empty((rows, C), dtype=cdt, device=x_f32.device)
+    stats = torch.empty((2, rows), dtype=torch.float32, device=x_f32.device)
+    _lib.check(_lib.load().pd_add_layernorm_fwd(None, 0, x_f32.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), None,
+                                                y_out.data_ptr(), y_c.data_ptr(), None, 1, None, rw._DT[cdt], stats[0].data_ptr(),
+                                                stats[1].data_ptr(), rows, C, rw._stream()))
+    return None, y_out, y_c, None, stats[0], stats[1]

@@ -1,0 +1,166 @@
+"""ctypes faces of the token-wise kernels (include/pd_rowwise.h).  Plain functions on raw tensors — no autograd: they
+are the building blocks of the hand-written forward/backward passes (functions/decoder_core.py, AddLayerNorm below).
+GPU only; there is no fallback."""
+import torch
+from torch.autograd import Function
+
+from .. import lib as _lib
+
+_DT = {torch.float32: _lib.PD_F32, torch.bfloat16: _lib.PD_BF16}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(t, who):
+    if not t.is_cuda:
+        raise RuntimeError(f"{who} runs on the GPU only (no CPU fallback in partdistillation_amd)")
+
+
+def add_ln_fwd(x, res, gamma, beta, eps, *, want_z=True, want_y=True, c_dtype=None, want_yc=False, pos=None, pos_div=1,
+               want_ypos=False):
+    """-> (z, y, y_c, ypos_c, mean, rstd); x [rows,C] (fp32 | bf16) and / or res fp32 [rows,C]."""
+    ref = x if x is not None else res
+    _need_cuda(ref, "pd_add_layernorm_fwd")
+    rows, C = ref.shape
+    dev = ref.device
+    assert (x is None or x.is_contiguous()) and (res is None or (res.is_contiguous() and res.dtype == torch.float32))
+    z = torch.empty((rows, C), dtype=torch.float32, device=dev) if want_z else None
+    y = torch.empty((rows, C), dtype=torch.float32, device=dev) if want_y else None
+    y_c = torch.empty((rows, C), dtype=c_dtype, device=dev) if want_yc else None
+    ypos_c = torch.empty((rows, C), dtype=c_dtype, device=dev) if want_ypos else None
+    stats = torch.empty((2, rows), dtype=torch.float32, device=dev)
+    if want_ypos:
+        assert pos is not None and pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[-1] == C
+    _lib.check(_lib.load().pd_add_layernorm_fwd(
+        _p(x), _DT[x.dtype] if x is not None else 0, _p(res), gamma.data_ptr(), beta.data_ptr(), float(eps), _p(z), _p(y), _p(y_c),
+        _p(pos) if want_ypos else None, int(pos_div), _p(ypos_c), _DT[c_dtype] if c_dtype is not None else 0,
+        stats[0].data_ptr(), stats[1].data_ptr(), rows, C, _stream()))
+    return z, y, y_c, ypos_c, stats[0], stats[1]
+
+
+def add_ln_bwd(z, mean, rstd, gamma, *, dy=None, dy2=None, dy_c=None, dypos_c=None, dz_c_dtype=None, dgamma=None, dbeta=None,
+               dbias=None, dpos_acc=None, pos_div=1, out=None):
+    """-> (dz fp32, dz_c | None).  dgamma / dbeta / dbias / dpos_acc are fp32 accumulators (+=)."""
+    rows, C = z.shape
+    cd = None
+    for t in (dy_c, dypos_c):
+        if t is not None:
+            assert t.is_contiguous() and (cd is None or cd == t.dtype)
+            cd = t.dtype
+    for t in (dy, dy2):
+        assert t is None or (t.is_contiguous() and t.dtype == torch.float32)
+    dz = out if out is not None else torch.empty((rows, C), dtype=torch.float32, device=z.device)
+    dz_c = torch.empty((rows, C), dtype=dz_c_dtype, device=z.device) if dz_c_dtype is not None else None
+    _lib.check(_lib.load().pd_add_layernorm_bwd(
+        _p(dy), _p(dy2), _p(dy_c), _p(dypos_c), _DT[cd] if cd is not None else 0, z.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+        gamma.data_ptr(), dz.data_ptr(), _p(dz_c), _DT[dz_c_dtype] if dz_c_dtype is not None else 0, _p(dgamma), _p(dbeta),
+        _p(dbias), _p(dpos_acc), int(pos_div), rows, C, _stream()))
+    return dz, dz_c
+
+
+def colsum_acc(x, acc):
+    """acc[N] (fp32) += x.sum(0); x [rows, N] contiguous."""
+    assert x.is_contiguous() and acc.dtype == torch.float32 and acc.numel() == x.shape[1]
+    _lib.check(_lib.load().pd_colsum_acc(x.data_ptr(), _DT[x.dtype], x.shape[0], x.shape[1], acc.data_ptr(), _stream()))
+
+
+def relu_bwd_colsum(dh, h, acc=None):
+    """dh *= (h > 0) in place; acc[N] += dh.sum(0)."""
+    assert dh.is_contiguous() and h.is_contiguous() and dh.dtype == h.dtype and dh.shape == h.shape
+    _lib.check(_lib.load().pd_relu_bwd_colsum(dh.data_ptr(), h.data_ptr(), _DT[dh.dtype], dh.shape[0], dh.shape[1], _p(acc), _stream()))
+    return dh
+
+
+def _token_view(x):
+    """[B,C,H,W] feature map -> (fp32 tensor holding it, batch stride) with element (b, p, c) at b*stride + p*C + c."""
+    B, C, H, W = x.shape
+    t = x.permute(0, 2, 3, 1)
+    if t.dtype != torch.float32 or t.stride(3) != 1 or t.stride(2) != C or t.stride(1) != W * C:
+        t = t.float().contiguous()
+    return t, t.stride(0)
+
+
+def mem_prep_fwd(x, level_embed, pos, c_dtype):
+    """x [B,C,H,W] (any strides; channels-last views are read in place) -> mem_c, mempos_c  [HW*B, C] seq-first."""
+    _need_cuda(x, "pd_mem_prep_fwd")
+    B, C, H, W = x.shape
+    t, bstride = _token_view(x)
+    mem = torch.empty((H * W * B, C), dtype=c_dtype, device=x.device)
+    mempos = torch.empty((H * W * B, C), dtype=c_dtype, device=x.device)
+    _lib.check(_lib.load().pd_mem_prep_fwd(t.data_ptr(), bstride, _p(level_embed), pos.data_ptr(), mem.data_ptr(), mempos.data_ptr(),
+                                           _DT[c_dtype], B, H * W, C, _stream()))
+    return mem, mempos
+
+
+def mem_prep_bwd(dmem, dmempos, B, H, W, C):
+    """-> gradient of the [B,C,H,W] map, as a channels-last view of a fresh [B,HW,C] fp32 buffer."""
+    ref = dmem if dmem is not None else dmempos
+    dtok = torch.empty((B, H * W, C), dtype=torch.float32, device=ref.device)
+    _lib.check(_lib.load().pd_mem_prep_bwd(_p(dmem), _p(dmempos), _DT[ref.dtype], dtok.data_ptr(), H * W * C, B, H * W, C, _stream()))
+    return dtok
+
+
+def attn_mask_u8(logits):
+    """logits [..., n] -> uint8 mask of the same shape: 1 = blocked (logit < 0); rows blocked everywhere are released."""
+    _need_cuda(logits, "pd_attn_mask_u8")
+    assert logits.is_contiguous()
+    n = logits.shape[-1]
+    mask = torch.empty(logits.shape, dtype=torch.uint8, device=logits.device)
+    _lib.check(_lib.load().pd_attn_mask_u8(logits.data_ptr(), _DT[logits.dtype], logits.numel() // max(n, 1), n, mask.data_ptr(), _stream()))
+    return mask
+
+
+def supports_width(C):
+    return C % 256 == 0 and C <= 1024
+
+
+class AddLayerNorm(Function):
+    """y = LayerNorm(x + res); optionally also returns y + pos (fp32).  x fp32|bf16 [..., C], res fp32 or None."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, pos):
+        ctx.set_materialize_grads(False)
+        shape = x.shape
+        C = shape[-1]
+        x2 = x.reshape(-1, C)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        r2 = None
+        if res is not None:
+            r2 = res.reshape(-1, C)
+            r2 = r2 if r2.is_contiguous() else r2.contiguous()
+        p2 = None
+        if pos is not None:
+            p2 = pos.reshape(-1, C)
+            p2 = p2 if p2.is_contiguous() else p2.contiguous()
+            assert p2.shape[0] == x2.shape[0]
+        keep_z = r2 is not None or x2.dtype != torch.float32
+        z, y, _, ypos, mean, rstd = add_ln_fwd(x2, r2, gamma, beta, eps, want_z=keep_z, want_y=True, c_dtype=torch.float32,
+                                               pos=p2, pos_div=1, want_ypos=p2 is not None)
+        ctx.save_for_backward(z if keep_z else x2, mean, rstd, gamma)
+        ctx.has_res, ctx.has_pos, ctx.x_dtype, ctx.shape = res is not None, pos is not None, x.dtype, shape
+        if pos is not None:
+            return y.view(shape), ypos.view(shape)
+        return y.view(shape), None
+
+    @staticmethod
+    def backward(ctx, dy, dypos):
+        z, mean, rstd, gamma = ctx.saved_tensors
+        C = z.shape[1]
+        dy = None if dy is None else dy.reshape(-1, C).contiguous()
+        dypos = None if dypos is None else dypos.reshape(-1, C).contiguous()
+        acc = torch.zeros((2, C), dtype=torch.float32, device=z.device)
+        dz, dz_c = add_ln_bwd(z, mean, rstd, gamma, dy=dy, dy2=dypos, dgamma=acc[0], dbeta=acc[1],
+                              dz_c_dtype=ctx.x_dtype if ctx.x_dtype != torch.float32 else None)
+        dx = (dz_c if dz_c is not None else dz).view(ctx.shape)
+        return dx, (dz.view(ctx.shape) if ctx.has_res else None), acc[0], acc[1], None, (dypos.view(ctx.shape) if ctx.has_pos else None)
+
+
+def add_layer_norm(x, res, norm: torch.nn.LayerNorm, pos=None):
+    """LayerNorm(x + res) with `norm`'s parameters through the fused kernel; -> (y, y + pos | None)."""
+    return AddLayerNorm.apply(x, res, norm.weight, norm.bias, norm.eps, pos)

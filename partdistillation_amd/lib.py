@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpd_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -36,6 +36,14 @@ SIGNATURES = {
     "pd_nc_sums_f32": (_c_int, [_c_vp] * 6 + [_c_int] * 5 + [_c_vp]),
     "pd_nc_affine_f32": (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_vp]),
     "pd_nc_affine2_f32": (_c_int, [_c_vp] * 7 + [_c_int] * 4 + [_c_vp]),
+    "pd_add_layernorm_fwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp,
+                                      _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_vp]),
+    "pd_add_layernorm_bwd": (_c_int, [_c_vp] * 4 + [_c_int] + [_c_vp] * 6 + [_c_int] + [_c_vp] * 4 + [_c_int] * 3 + [_c_vp]),
+    "pd_colsum_acc": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "pd_relu_bwd_colsum": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "pd_mem_prep_fwd": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
+    "pd_mem_prep_bwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
+    "pd_attn_mask_u8": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_abi_version": (_c_int, []),
     "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),

@@ -25,6 +25,8 @@ from torch import Tensor, nn
 from ...compat import TRANSFORMER_DECODER_REGISTRY, configurable
 from ...compat.layers import Conv2d, c2_xavier_fill
 from ...functions.attention import masked_attention_d32
+from ...functions.decoder_core import DecoderCore, DecoderSpec
+from ...functions.rowwise import supports_width
 from .position_encoding import PositionEmbeddingSine
 
 
@@ -201,6 +203,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
         self.query_feature_normalize = query_feature_normalize
         self.dense_masks = True            # False: training never materialises [B,Q,H,W] masks (sparse criterion)
+        self.fused_core = True             # GPU: run the layer loop as one hand-written autograd node (functions/decoder_core.py)
+        self.pre_norm = pre_norm
+        self._pos_rows = {}
 
     @classmethod
     def from_config(cls, cfg, in_channels, mask_classification):
@@ -242,9 +247,81 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             attn_mask = logits < 0                                              # sigmoid(x) < 0.5; [B,Q,HW]
         return outputs_class, outputs_mask, attn_mask, decoder_output, mask_embed
 
+    # ------------------------------------------------------------------ fused layer loop (GPU)
+    def _core_dtype(self, x):
+        """GEMM dtype of the fused core, or None when the generic module path has to run."""
+        w = self.transformer_ffn_layers[0].linear1.weight if self.num_layers else None
+        if (not self.fused_core or w is None or not x[0].is_cuda or self.pre_norm or not supports_width(self.hidden_dim)
+                or self.hidden_dim // self.num_heads != 32
+                or any(not (isinstance(p, nn.Sequential) and len(p) == 0) for p in self.input_proj)
+                or self.transformer_ffn_layers[0].linear1.out_features % 128):
+            return None
+        cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+        if cdt not in (torch.float32, torch.bfloat16) or w.dtype != cdt:
+            return None                    # e.g. autocast over fp32 (unshadowed) weights: the module path casts per use
+        return cdt
+
+    def _pos_table_rows(self, h, w, device):
+        key = (h, w, str(device))
+        if key not in self._pos_rows:
+            self._pos_rows[key] = self.pe_layer.table(h, w, device).flatten(1).t().contiguous().float()      # [HW, C]
+        return self._pos_rows[key]
+
+    def _core_params(self):
+        p = [self.query_feat.weight, self.query_embed.weight, self.level_embed.weight, self.decoder_norm.weight, self.decoder_norm.bias]
+        for l in self.mask_embed.layers:
+            p += [l.weight, l.bias]
+        for i in range(self.num_layers):
+            ca, sa, ff = self.transformer_cross_attention_layers[i], self.transformer_self_attention_layers[i], self.transformer_ffn_layers[i]
+            p += [ca.multihead_attn.in_proj_weight, ca.multihead_attn.in_proj_bias, ca.multihead_attn.out_proj.weight,
+                  ca.multihead_attn.out_proj.bias, ca.norm.weight, ca.norm.bias,
+                  sa.self_attn.in_proj_weight, sa.self_attn.in_proj_bias, sa.self_attn.out_proj.weight, sa.self_attn.out_proj.bias,
+                  sa.norm.weight, sa.norm.bias,
+                  ff.linear1.weight, ff.linear1.bias, ff.linear2.weight, ff.linear2.bias, ff.norm.weight, ff.norm.bias]
+        return p
+
+    def _class_logits_stacked(self, d, extra):
+        """d [L+1, B, Q, C] -> [L+1, B, Q, K+1]"""
+        return self._class_logits(d, extra)
+
+    def _forward_fused(self, x, mask_features, extra, cdt):
+        bs, Q, C, L = x[0].shape[0], self.num_queries, self.hidden_dim, self.num_layers
+        sizes = [tuple(t.shape[-2:]) for t in x]
+        with torch.no_grad():                                                   # the three mask resolutions, once
+            pooled = [F.interpolate(mask_features, size=s, mode="bilinear", align_corners=False).flatten(2).float() for s in sizes]
+        spec = DecoderSpec(bs, Q, C, self.num_heads, L, sizes, [self._pos_table_rows(h, w, x[0].device) for h, w in sizes],
+                           pooled, self.decoder_norm.eps, cdt, self.num_feature_levels)
+        dec_outs, final_tgt = DecoderCore.apply(spec, *x, *self._core_params())          # [L+1, Q*B, C] fp32, [Q*B, C]
+        d = dec_outs.view(L + 1, Q, bs, C).transpose(1, 2)                               # [L+1, B, Q, C]
+        all_logits = self._class_logits_stacked(d, extra) if self.mask_classification else None
+        emb = self.mask_embed(d)                                                         # one MLP pass for the L+1 heads
+        if self.query_feature_normalize:
+            emb = F.normalize(emb, p=2, dim=-1)
+        emb = emb.transpose(0, 1)                                                        # [B, L+1, Q, C]
+        return self._assemble(all_logits, emb, d[-1], mask_features, final_tgt.view(Q, bs, C))
+
+    def _assemble(self, all_logits, emb, dec_out, mask_features, output):
+        """einsum("bqc,bchw->bqhw") of the reference (:449) for all L+1 heads as ONE batched GEMM [B, (L+1)*Q, C] x
+        [B, C, HW]: ten [200 x 256 x 65536] products are too skinny for the matrix cores one at a time, and the
+        result is already the stacked [B, heads, Q, H, W] tensor the batched criterion consumes."""
+        B_, Hh, Qn, Cc = emb.shape
+        mf = mask_features.to(emb.dtype).flatten(2)                               # [B, C, HW]
+        all_masks = torch.bmm(emb.reshape(B_, Hh * Qn, Cc), mf).view(B_, Hh, Qn, *mask_features.shape[-2:])
+        masks = [all_masks[:, i] for i in range(Hh)]
+        classes = list(all_logits.unbind(0)) if self.mask_classification else None
+        out = {"pred_logits": classes[-1] if classes is not None else None, "pred_masks": masks[-1], "decoder_output": dec_out,
+               "aux_outputs": self._set_aux_loss(classes, masks),
+               "all_masks": all_masks,                                            # [B, heads(decoder order), Q, H, W]
+               "mask_embeds": emb, "mask_features": mask_features, "all_logits": all_logits}
+        self._finish(out, output)
+        return out
+
     def forward(self, x, mask_features, mask=None):
         assert len(x) == self.num_feature_levels
         extra = self._prepare_extra(mask)
+        cdt = self._core_dtype(x)
+        if cdt is not None:
+            return self._forward_fused(x, mask_features, extra, cdt)
         src, pos, sizes = self._memory(x)
         bs = src[0].shape[1]
         with torch.no_grad():                                                   # the three mask resolutions, once
@@ -267,20 +344,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             cls, msk, attn_mask, dec_out, emb = self.forward_prediction_heads(output, mask_features, sizes[nxt], pooled[nxt], extra)
             classes.append(cls), masks.append(msk), embeds.append(emb)
         assert len(classes) == self.num_layers + 1
-        # einsum("bqc,bchw->bqhw") of the reference (:449) for all L+1 heads as ONE batched GEMM [B, (L+1)*Q, C] x
-        # [B, C, HW]: ten [200 x 256 x 65536] products are too skinny for the matrix cores one at a time, and the
-        # result is already the stacked [B, heads, Q, H, W] tensor the batched criterion consumes.
-        emb = torch.stack(embeds, 1)                                              # [B, L+1, Q, C]
-        B_, Hh, Qn, Cc = emb.shape
-        mf = mask_features.to(emb.dtype).flatten(2)                               # [B, C, HW]
-        all_masks = torch.bmm(emb.reshape(B_, Hh * Qn, Cc), mf).view(B_, Hh, Qn, *mask_features.shape[-2:])
-        masks = [all_masks[:, i] for i in range(Hh)]
-        out = {"pred_logits": classes[-1], "pred_masks": masks[-1], "decoder_output": dec_out,
-               "aux_outputs": self._set_aux_loss(classes if self.mask_classification else None, masks),
-               "all_masks": all_masks,                                            # [B, heads(decoder order), Q, H, W]
-               "mask_embeds": emb, "mask_features": mask_features, "all_logits": torch.stack(classes, 0)}
-        self._finish(out, output)
-        return out
+        return self._assemble(torch.stack(classes, 0), torch.stack(embeds, 1), dec_out, mask_features, output)
 
     def _prepare_extra(self, mask):
         return None                                                             # `mask` is ignored (:377-378)

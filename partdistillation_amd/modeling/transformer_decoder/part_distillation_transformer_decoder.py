@@ -47,6 +47,11 @@ class PartDistillationTransformerDecoder(MultiScaleMaskedTransformerDecoder):
         with torch.autocast(device_type=decoder_output.device.type, enabled=False):
             return torch.baddbmm(b.unsqueeze(1), decoder_output.double(), w.transpose(1, 2))
 
+    def _class_logits_stacked(self, d, rows):
+        Lp, B, Q, C = d.shape
+        out = self._class_logits(d.transpose(0, 1).reshape(B, Lp * Q, C), rows)                # [B, (L+1)*Q, K+1]
+        return out.view(B, Lp, Q, -1).transpose(0, 1)
+
     def apply_gradient_mask(self, outputs, targets):
         """reference :215-230, for callers that hold full-width logits."""
         K = self.num_part_classes

@@ -1,0 +1,203 @@
+"""GPU parity of the token-wise kernels (include/pd_rowwise.h) against plain PyTorch fp32, and of the fused decoder
+core (functions/decoder_core.py: hand-written backward) against the module-by-module autograd path of the same
+decoder, which the reference goldens pin (tests/test_product_gpu.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import common as C
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _r(shape, seed, scale=1.0, dtype=torch.float32):
+    return (C.seeded(shape, seed) * scale).to(DEV).to(dtype)
+
+
+@pytest.mark.parametrize("rows,Cw,xdt,cdt", [(200, 256, torch.bfloat16, torch.bfloat16), (200, 256, torch.float32, torch.float32),
+                                              (4099, 256, torch.float32, torch.float32), (37, 512, torch.bfloat16, torch.bfloat16),
+                                              (5, 1024, torch.float32, torch.bfloat16)])
+def test_add_layernorm_fwd_bwd_vs_torch(rows, Cw, xdt, cdt):
+    from partdistillation_amd.functions import rowwise as rw
+    B = 2 if rows % 2 == 0 else 1
+    x, res = _r((rows, Cw), 1, 2.0, xdt), _r((rows, Cw), 2)
+    gamma, beta = _r((Cw,), 3) + 1.0, _r((Cw,), 4)
+    pos = _r((rows // B, Cw), 5)
+    z, y, y_c, ypos_c, mean, rstd = rw.add_ln_fwd(x, res, gamma, beta, 1e-5, c_dtype=cdt, want_yc=True, pos=pos, pos_div=B, want_ypos=True)
+    zr = x.float() + res
+    yr = F.layer_norm(zr, (Cw,), gamma, beta, 1e-5)
+    tol = dict(rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(z, zr, **tol)
+    torch.testing.assert_close(y, yr, **tol)
+    torch.testing.assert_close(mean, zr.mean(1), **tol)
+    torch.testing.assert_close(rstd, (zr.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
+    ctol = dict(rtol=1e-2, atol=1e-2) if cdt == torch.bfloat16 else tol
+    torch.testing.assert_close(y_c.float(), yr, **ctol)
+    torch.testing.assert_close(ypos_c.float(), yr + pos.repeat_interleave(B, 0), **ctol)
+    # backward: g = dy + dy2 + dy_c + dypos_c
+    dy, dy2 = _r((rows, Cw), 6), _r((rows, Cw), 7)
+    dy_c, dypos_c = _r((rows, Cw), 8, 1.0, cdt), _r((rows, Cw), 9, 1.0, cdt)
+    acc = torch.zeros((3, Cw), device=DEV)
+    dpos = torch.zeros((rows // B, Cw), device=DEV)
+    dz, dz_c = rw.add_ln_bwd(z, mean, rstd, gamma, dy=dy, dy2=dy2, dy_c=dy_c, dypos_c=dypos_c, dz_c_dtype=cdt, dgamma=acc[0],
+                             dbeta=acc[1], dbias=acc[2], dpos_acc=dpos, pos_div=B)
+    zt = zr.clone().requires_grad_()
+    gt, bt = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    g = dy + dy2 + dy_c.float() + dypos_c.float()
+    F.layer_norm(zt, (Cw,), gt, bt, 1e-5).backward(g)
+    btol = dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dz, zt.grad, **btol)
+    torch.testing.assert_close(dz_c.float(), zt.grad, **(dict(rtol=1e-2, atol=2e-2) if cdt == torch.bfloat16 else btol))
+    stol = dict(rtol=1e-3, atol=1e-3 * max(1.0, rows ** 0.5))
+    torch.testing.assert_close(acc[0], gt.grad, **stol)
+    torch.testing.assert_close(acc[1], bt.grad, **stol)
+    torch.testing.assert_close(acc[2], zt.grad.sum(0), **stol)
+    torch.testing.assert_close(dpos, dypos_c.float().view(rows // B, B, Cw).sum(1), **btol)
+
+
+def test_add_layernorm_autograd_function_matches_layer_norm():
+    from partdistillation_amd.functions.rowwise import add_layer_norm
+    norm = torch.nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(_r((256,), 11) + 1)
+        norm.bias.copy_(_r((256,), 12))
+    x, res, pos = _r((2, 301, 256), 13).requires_grad_(), _r((2, 301, 256), 14).requires_grad_(), _r((2, 301, 256), 15).requires_grad_()
+    y, yp = add_layer_norm(x, res, norm, pos)
+    w1, w2 = _r(y.shape, 16), _r(y.shape, 17)
+    ((y * w1).sum() + (yp * w2).sum()).backward()
+    got = [x.grad.clone(), res.grad.clone(), pos.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone()]
+    for t in (x, res, pos, norm.weight, norm.bias):
+        t.grad = None
+    yr = F.layer_norm(x + res, (256,), norm.weight, norm.bias, norm.eps)
+    ((yr * w1).sum() + ((yr + pos) * w2).sum()).backward()
+    torch.testing.assert_close(y, yr, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(yp, yr + pos, rtol=1e-5, atol=2e-5)
+    for a, b in zip(got, [x.grad, res.grad, pos.grad, norm.weight.grad, norm.bias.grad]):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("rows,N,dt", [(200, 256, torch.bfloat16), (200, 2048, torch.bfloat16), (32768, 256, torch.bfloat16),
+                                        (77, 768, torch.float32), (0, 256, torch.float32)])
+def test_colsum_and_relu_bwd_vs_torch(rows, N, dt):
+    from partdistillation_amd.functions import rowwise as rw
+    x = _r((rows, N), 21, 1.0, dt)
+    acc = torch.ones(N, device=DEV)
+    rw.colsum_acc(x, acc)
+    torch.testing.assert_close(acc, 1 + x.float().sum(0), rtol=1e-3, atol=1e-3 * max(1.0, rows ** 0.5))
+    h = _r((rows, N), 22, 1.0, dt)
+    dh = x.clone()
+    acc2 = torch.zeros(N, device=DEV)
+    rw.relu_bwd_colsum(dh, h, acc2)
+    want = x * (h > 0)
+    assert torch.equal(dh, want)
+    torch.testing.assert_close(acc2, want.float().sum(0), rtol=1e-3, atol=1e-3 * max(1.0, rows ** 0.5))
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_mem_prep_fwd_bwd_vs_torch(cdt):
+    from partdistillation_amd.functions import rowwise as rw
+    B, Cw, H, W = 2, 256, 5, 7
+    tokens = _r((B, H * W + 3, Cw), 31)                                  # a level is a slice of the encoder's token tensor
+    x = tokens[:, 3:].transpose(1, 2).reshape(B, Cw, H, W)               # the channels-last view the pixel decoder hands over
+    lvl, pos = _r((Cw,), 32), _r((H * W, Cw), 33)
+    mem, mempos = rw.mem_prep_fwd(x, lvl, pos, cdt)
+    want = (x.flatten(2) + lvl[None, :, None]).permute(2, 0, 1)          # [HW, B, C]
+    tol = dict(rtol=1e-2, atol=1e-2) if cdt == torch.bfloat16 else dict(rtol=0, atol=0)
+    torch.testing.assert_close(mem.float().view(H * W, B, Cw), want, **tol)
+    torch.testing.assert_close(mempos.float().view(H * W, B, Cw), want + pos[:, None, :], **tol)
+    mem2, _ = rw.mem_prep_fwd(x.contiguous(), lvl, pos, cdt)              # NCHW-contiguous input takes the copy route
+    assert torch.equal(mem2, mem)
+    dmem, dmempos = _r((H * W * B, Cw), 34, 1.0, cdt), _r((H * W * B, Cw), 35, 1.0, cdt)
+    dtok = rw.mem_prep_bwd(dmem, dmempos, B, H, W, Cw)
+    want = (dmem.float() + dmempos.float()).view(H * W, B, Cw).transpose(0, 1)
+    torch.testing.assert_close(dtok, want, rtol=0, atol=0)
+
+
+def test_attn_mask_u8_vs_torch():
+    from partdistillation_amd.functions import rowwise as rw
+    logits = _r((2, 100, 1333), 41)
+    logits[0, 7] = -logits[0, 7].abs() - 0.1                              # blocked everywhere -> released
+    logits[1, 99] = logits[1, 99].abs()
+    m = rw.attn_mask_u8(logits)
+    want = logits < 0
+    want = want & ~want.all(-1, keepdim=True)
+    assert torch.equal(m.bool(), want) and not m[0, 7].any() and want.any()
+    mb = rw.attn_mask_u8(logits.bfloat16())
+    wb = logits.bfloat16() < 0
+    assert torch.equal(mb.bool(), wb & ~wb.all(-1, keepdim=True))
+
+
+# ----------------------------------------------------------------------------- fused decoder core
+def _decoder_pair(dec_layers=4, queries=20, seed=900):
+    from test_product_gpu import build_decoder
+    cfg = dict(C.C1, queries=queries, dec_layers=dec_layers - 1, dec_ffn=512)
+    a = build_decoder(cfg)
+    table = C.table_of(a.state_dict())
+    a.load_state_dict(C.seeded_weights(table, seed), strict=False)
+    a = a.to(DEV)
+    b = build_decoder(cfg).to(DEV)
+    b.load_state_dict(a.state_dict())
+    b.fused_core = False
+    return a, b
+
+
+def _decoder_inputs(seed, B=2, S=64):
+    toks = [_r((B, (S // st) ** 2, 256), seed + i, 0.5) for i, st in enumerate((32, 16, 8))]
+    ms = [t.transpose(1, 2).reshape(B, 256, S // st, S // st) for t, st in zip(toks, (32, 16, 8))]
+    return toks, ms, _r((B, 256, S // 4, S // 4), seed + 7)
+
+
+def _run_decoder(dec, seed, autocast=False):
+    toks, ms, mf = _decoder_inputs(seed)
+    toks = [t.requires_grad_() for t in toks]
+    ms = [t.transpose(1, 2).reshape(m.shape) for t, m in zip(toks, ms)]
+    mf.requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        out = dec(ms, mf)
+    loss = (out["all_masks"].float() * _r(out["all_masks"].shape, seed + 20)).sum() * 0.05
+    loss = loss + (out["all_logits"].float() * _r(out["all_logits"].shape, seed + 21)).sum()
+    loss = loss + (out["decoder_output"].float() * _r(out["decoder_output"].shape, seed + 22)).sum() * 0.1
+    loss.backward()
+    grads = {k: p.grad.float().clone() for k, p in dec.named_parameters() if p.grad is not None}
+    grads.update({f"tok{i}": t.grad.clone() for i, t in enumerate(toks)})
+    grads["mf"] = mf.grad.clone()
+    return out, loss.detach(), grads
+
+
+def test_fused_decoder_core_fp32_matches_module_path():
+    fused, plain = _decoder_pair()
+    assert fused._core_dtype([torch.empty(1, device=DEV)]) == torch.float32
+    o1, l1, g1 = _run_decoder(fused, 950)
+    o2, l2, g2 = _run_decoder(plain, 950)
+    torch.testing.assert_close(o1["all_logits"], o2["all_logits"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(o1["all_masks"], o2["all_masks"], rtol=1e-3, atol=2e-3)
+    torch.testing.assert_close(o1["decoder_output"], o2["decoder_output"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(l1, l2, rtol=1e-4, atol=1e-2)
+    assert set(g1) == set(g2), set(g1) ^ set(g2)
+    for k in g2:
+        scale = g2[k].abs().max().clamp_min(1e-6)
+        err = ((g1[k] - g2[k]).abs().max() / scale).item()
+        assert err < 2e-3, (k, err)
+
+
+def test_fused_decoder_core_bf16_close_to_fp32():
+    """bf16 GEMM operands (shadow weights + autocast), fp32 residual stream: within bf16 noise of the fp32 result"""
+    fused, plain = _decoder_pair(seed=901)
+    for n, p in fused.named_parameters():
+        mod = n.rsplit(".", 1)[0]
+        if ("norm" not in mod and "query_" not in n and "level_embed" not in n and "class_embed" not in n):
+            p.data = p.data.to(torch.bfloat16)
+    o1, l1, g1 = _run_decoder(fused, 960, autocast=True)
+    assert fused._core_dtype([torch.empty(1, device=DEV)]) is None      # outside autocast bf16 weights do not qualify
+    o2, l2, g2 = _run_decoder(plain, 960)
+    err = (o1["decoder_output"].float() - o2["decoder_output"]).abs()          # LayerNorm outputs: O(1) values
+    assert err.mean().item() < 0.02 and (err > 0.1).float().mean().item() < 0.01, (err.mean().item(), err.max().item())
+    agree = ((o1["all_masks"].float() > 0) == (o2["all_masks"] > 0)).float().mean().item()
+    assert agree > 0.97, agree
+    for k in ("query_feat.weight", "query_embed.weight", "level_embed.weight", "decoder_norm.weight",
+              "transformer_ffn_layers.1.linear1.weight", "transformer_cross_attention_layers.0.multihead_attn.in_proj_weight",
+              "transformer_self_attention_layers.2.self_attn.in_proj_bias", "tok0", "tok2"):
+        a, b = g1[k], g2[k]
+        cos = F.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+        assert cos > 0.98, (k, cos)

@@ -1,0 +1,185 @@
+"""Attribute the step's launches to call sites: torch.profiler over a few eager steps of the bench workload, grouped by
+(aten op, input shapes) and by python source line.  Development tool (GPU box): python tools/op_profile.py [--steps 3]"""
+import argparse
+import collections
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class _Mark(torch.autograd.Function):
+    """identity whose backward drops a zero-length profiler range: phase boundary on the autograd thread"""
+
+    @staticmethod
+    def forward(ctx, x, name):
+        ctx.name = name
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        with torch.profiler.record_function("BWD_MARK:" + ctx.name):
+            pass
+        return g, None
+
+
+def _map(o, f):
+    if isinstance(o, torch.Tensor):
+        return f(o) if (o.requires_grad and o.is_floating_point()) else o
+    if isinstance(o, dict):
+        return {k: _map(v, f) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(_map(v, f) for v in o)
+    return o
+
+
+def wrap(obj, attr, name, mark_out=True):
+    inner = getattr(obj, attr)
+
+    def fwd(*a, **k):
+        a = _map(a, lambda t: _Mark.apply(t, name + ":end"))
+        k = _map(k, lambda t: _Mark.apply(t, name + ":end"))
+        with torch.profiler.record_function("FWD:" + name):
+            out = inner(*a, **k)
+        return _map(out, lambda t: _Mark.apply(t, name + ":begin")) if mark_out else out
+    setattr(obj, attr, fwd)
+
+
+def instrument(model):
+    wrap(model.backbone, "forward", "backbone")
+    head = model.sem_seg_head
+    wrap(head.pixel_decoder, "forward_features", "pixel_decoder")
+    enc = head.pixel_decoder.transformer.encoder
+    for i, l in enumerate(enc.layers):
+        wrap(l, "forward", f"enc_layer")
+    wrap(head.predictor, "forward", "predictor")
+    pr = head.predictor
+    for i in range(len(pr.transformer_cross_attention_layers)):
+        wrap(pr.transformer_cross_attention_layers[i], "forward", "dec_cross")
+        wrap(pr.transformer_self_attention_layers[i], "forward", "dec_self")
+        wrap(pr.transformer_ffn_layers[i], "forward", "dec_ffn")
+    wrap(pr, "forward_prediction_heads", "dec_pred_heads")
+    wrap(model.criterion, "forward", "criterion", mark_out=False)
+
+
+def phase_report(prof, n_steps):
+    """launch count / GPU us per phase: forward by FWD: ranges (innermost), backward by the last BWD_MARK seen"""
+    evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU]
+    by_thread = collections.defaultdict(list)
+    for e in evs:
+        by_thread[e.thread].append(e)
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    detail = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for th, L in by_thread.items():
+        L.sort(key=lambda e: (e.time_range.start, -e.time_range.end))
+        stack = []
+        last_mark = None
+        for e in L:
+            while stack and e.time_range.start >= stack[-1][1]:
+                stack.pop()
+            if e.name.startswith("FWD:"):
+                stack.append((e.name[4:], e.time_range.end))
+                continue
+            if e.name.startswith("BWD_MARK:"):
+                last_mark = e.name[9:]
+                continue
+            if not e.kernels:
+                continue
+            if stack:
+                key = "fwd " + stack[-1][0]
+            elif last_mark is not None:
+                nm, kind = last_mark.rsplit(":", 1)
+                key = ("bwd " + nm) if kind == "begin" else ("bwd after " + nm)
+            else:
+                key = "other"
+            if e.name.startswith("Optimizer") or "adamw" in e.name.lower():
+                key = "optimizer"
+            acc[key][0] += len(e.kernels)
+            acc[key][1] += sum(k.duration for k in e.kernels)
+            d = detail[key][(e.name, str(e.input_shapes)[:80])]
+            d[0] += len(e.kernels)
+            d[1] += sum(k.duration for k in e.kernels)
+    out = ["== phases: launches/step, GPU us/step"]
+    for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        out.append(f"{v[0] / n_steps:8.1f} {v[1] / n_steps:10.1f}  {k}")
+    for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        out.append(f"-- {k}: {v[0] / n_steps:.1f} launches, {v[1] / n_steps:.1f} us")
+        for kk, vv in sorted(detail[k].items(), key=lambda kv: -kv[1][0])[:40]:
+            out.append(f"      {vv[0] / n_steps:7.1f} {vv[1] / n_steps:9.1f}  {kk[0]:38s} {kk[1]}")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--top", type=int, default=70)
+    ap.add_argument("--out", default="gpurun_out/op_profile.txt")
+    a = ap.parse_args()
+    os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "partdistillation_amd", "miopen_db"))
+    from partdistillation_amd import lib
+    lib.load()
+    from partdistillation_amd.config import setup_cfg
+    from partdistillation_amd.engine.synthetic import make_batch
+    from partdistillation_amd.engine.trainer import TrainStep
+    torch.backends.cudnn.benchmark = True
+    cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd", "configs", "proposal_learning", "r50_mask2former.yaml"),
+                    ["INPUT.IMAGE_SIZE", str(a.size)])
+    torch.manual_seed(0)
+    step = TrainStep(cfg)
+    batches = [make_batch(a.batch, a.size, seed=1234 + 1000 * i, device="cuda") for i in range(2)]
+    instrument(step.model)
+    for i in range(4):
+        step(batches[i % 2])
+    torch.cuda.synchronize()
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
+        for i in range(a.steps):
+            step(batches[i % 2])
+        torch.cuda.synchronize()
+    lines = phase_report(prof, a.steps)
+    by_shape = collections.defaultdict(lambda: [0, 0.0])
+    by_site = collections.defaultdict(lambda: [0, 0.0])
+    for ev in prof.events():
+        if ev.device_type != torch.autograd.DeviceType.CPU:
+            continue
+        kern = ev.kernels
+        if not kern:
+            continue
+        t = sum(k.duration for k in kern)
+        key = (ev.name, str(ev.input_shapes)[:110])
+        by_shape[key][0] += len(kern)
+        by_shape[key][1] += t
+        site = "?"
+        for fr in (ev.stack or []):
+            if "partdistillation_amd" in fr and "torch/" not in fr:
+                site = fr.split("partdistillation_amd/")[-1][:90]
+                break
+        by_site[(site, ev.name)][0] += len(kern)
+        by_site[(site, ev.name)][1] += t
+    n = a.steps
+    lines.append(f"== by (op, shapes): launches/step, us/step  (top {a.top})")
+    for k, v in sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:a.top]:
+        lines.append(f"{v[0] / n:7.1f} {v[1] / n:9.1f}  {k[0]:40s} {k[1]}")
+    lines.append(f"== by (site, op): launches/step, us/step  (top {a.top * 2})")
+    for k, v in sorted(by_site.items(), key=lambda kv: -kv[1][1])[:a.top * 2]:
+        lines.append(f"{v[0] / n:7.1f} {v[1] / n:9.1f}  {k[1]:40s} {k[0]}")
+    lines.append("== launches by site (sum over ops)")
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for (site, _), v in by_site.items():
+        f = site.split(":")[0].split("(")[0]
+        agg[f][0] += v[0]
+        agg[f][1] += v[1]
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        lines.append(f"{v[0] / n:7.1f} {v[1] / n:9.1f}  {k}")
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    open(a.out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:60]))
+
+
+if __name__ == "__main__":
+    main()
