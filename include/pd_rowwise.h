@@ -14,6 +14,9 @@
  *   pd_mem_prep_{fwd,bwd}        decoder memory of one feature level (:392-401): tokens [B,HW,C] + level_embed ->
  *                                seq-first `memory` and `memory + pos` in the GEMM dtype, one pass.
  *   pd_attn_mask_u8              `(sigmoid(mask logits) < 0.5)` with fully-blocked rows released (:405, :455-459).
+ *   pd_msda_prep_{fwd,bwd}       MSDeformAttn.forward between the projections and the sampling core
+ *                                (pixel_decoder/ops/modules/ms_deform_attn.py:108-117): softmax of the attention logits
+ *                                and `reference_points + offsets / (W_l, H_l)` in one pass, and their backward.
  *
  * Device pointers; dtypes are PD_F32 / PD_BF16 (pd_msda.h); `stream` = hipStream_t; returns 0 or a negative PD_ERR_*.
  * C (the normalised / channel dimension) must be a multiple of 256 and <= 1024.
@@ -69,6 +72,19 @@ int pd_mem_prep_bwd(const void *dmem_c, const void *dmempos_c, int c_dtype, floa
 
 /* mask[r, k] = logits[r, k] < 0, except rows where that holds for every k, which become all 0.  logits [rows, n] dtype. */
 int pd_attn_mask_u8(const void *logits, int dtype, int rows, int n, uint8_t *mask, void *stream);
+
+/*
+ * offs fp32 [tokens, M, L, P, 2], logits fp32 [tokens, M, L*P], ref fp32 [tokens, L, 2] (x, y in [0,1]), spatial_shapes
+ * int64 [L, 2] (H_l, W_l) on the device ->
+ *   loc [tokens, M, L, P, 2] = ref[token, l] + offs / (W_l, H_l)        attn [tokens, M, L*P] = softmax(logits)
+ * exactly the two roundings (divide, add) of the reference expression.
+ */
+int pd_msda_prep_fwd(const float *offs, const float *logits, const float *ref, const int64_t *spatial_shapes, float *loc,
+                     float *attn, int64_t tokens, int M, int L, int P, void *stream);
+
+/* d_offs = gloc / (W_l, H_l);  d_logits = attn * (gattn - sum_j attn_j * gattn_j) */
+int pd_msda_prep_bwd(const float *gloc, const float *gattn, const float *attn, const int64_t *spatial_shapes, float *d_offs,
+                     float *d_logits, int64_t tokens, int M, int L, int P, void *stream);
 
 #ifdef __cplusplus
 }

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd(const float *dy, const float *
         t = add4(t, p);
         if (dpos_acc) {
           float *a = dpos_acc + (int64_t)(r / pos_div) * C + j * 256 + lane * 4;
-          atomicAdd(a, p.x); atomicAdd(a + 1, p.y); atomicAdd(a + 2, p.z); atomicAdd(a + 3, p.w);
+          if (pos_div == 1) st4(a, add4(ld4(a), p));      // one row per positional row: plain read-modify-write
+          else { atomicAdd(a, p.x); atomicAdd(a + 1, p.y); atomicAdd(a + 2, p.z); atomicAdd(a + 3, p.w); }
         }
       }
       float4 h = ld4(z + base + j * 256);
@@ -293,6 +294,62 @@ __global__ __launch_bounds__(256) void attn_mask_u8(const T *__restrict__ logits
   }
 }
 
+// ------------------------------------------------------------------------------------------------ MSDeformAttn prep
+// one thread per (token, head): softmax over the L*P logits, sampling locations = reference point + offset / (W_l, H_l)
+__global__ __launch_bounds__(256) void msda_prep_fwd(const float *__restrict__ offs, const float *__restrict__ logits,
+                                                     const float *__restrict__ ref, const int64_t *__restrict__ shapes,
+                                                     float *__restrict__ loc, float *__restrict__ attn, int64_t total, int M, int L,
+                                                     int P)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int LP = L * P;
+  const int64_t bq = t / M;
+  const float *lg = logits + t * LP;
+  float mx = lg[0];
+  for (int i = 1; i < LP; ++i) mx = fmaxf(mx, lg[i]);
+  float sum = 0.f;
+  for (int i = 0; i < LP; ++i) sum += expf(lg[i] - mx);
+  float *ao = attn + t * LP;
+  for (int i = 0; i < LP; ++i) ao[i] = expf(lg[i] - mx) / sum;
+  const float *of = offs + t * LP * 2;
+  float *lo = loc + t * LP * 2;
+  for (int l = 0; l < L; ++l) {
+    const float w = (float)shapes[l * 2 + 1], h = (float)shapes[l * 2];
+    const float rx = ref[(bq * L + l) * 2], ry = ref[(bq * L + l) * 2 + 1];
+    for (int p = 0; p < P; ++p) {
+      const int i = (l * P + p) * 2;
+      lo[i] = rx + of[i] / w;
+      lo[i + 1] = ry + of[i + 1] / h;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void msda_prep_bwd(const float *__restrict__ gloc, const float *__restrict__ gattn,
+                                                     const float *__restrict__ attn, const int64_t *__restrict__ shapes,
+                                                     float *__restrict__ d_offs, float *__restrict__ d_logits, int64_t total,
+                                                     int M, int L, int P)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int LP = L * P;
+  const float *a = attn + t * LP, *g = gattn + t * LP;
+  float dot = 0.f;
+  for (int i = 0; i < LP; ++i) dot += a[i] * g[i];
+  float *dl = d_logits + t * LP;
+  for (int i = 0; i < LP; ++i) dl[i] = a[i] * (g[i] - dot);
+  const float *gl = gloc + t * LP * 2;
+  float *dof = d_offs + t * LP * 2;
+  for (int l = 0; l < L; ++l) {
+    const float w = (float)shapes[l * 2 + 1], h = (float)shapes[l * 2];
+    for (int p = 0; p < P; ++p) {
+      const int i = (l * P + p) * 2;
+      dof[i] = gl[i] / w;
+      dof[i + 1] = gl[i + 1] / h;
+    }
+  }
+}
+
 int grid_rows(int rows, int cap) { return max(1, min(cap, (rows + 3) / 4)); }
 
 bool dt_ok(int dt) { return dt == PD_F32 || dt == PD_BF16; }
@@ -412,4 +469,28 @@ extern "C" int pd_attn_mask_u8(const void *logits, int dtype, int rows, int n, u
   if (dtype == PD_BF16) hipLaunchKernelGGL((attn_mask_u8<bf16_t>), dim3(rows), dim3(256), 0, (hipStream_t)stream_, (const bf16_t *)logits, n, mask);
   else hipLaunchKernelGGL((attn_mask_u8<float>), dim3(rows), dim3(256), 0, (hipStream_t)stream_, (const float *)logits, n, mask);
   return pd_check_launch("pd_attn_mask_u8");
+}
+
+extern "C" int pd_msda_prep_fwd(const float *offs, const float *logits, const float *ref, const int64_t *spatial_shapes, float *loc,
+                                float *attn, int64_t tokens, int M, int L, int P, void *stream_)
+{
+  if (tokens < 0 || M <= 0 || L <= 0 || P <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_fwd: tokens=%lld M=%d L=%d P=%d", (long long)tokens, M, L, P);
+  if (tokens == 0) return PD_OK;
+  if (!offs || !logits || !ref || !spatial_shapes || !loc || !attn) return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_fwd: null pointer");
+  const int64_t total = tokens * M;
+  hipLaunchKernelGGL(msda_prep_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, offs, logits, ref,
+                     spatial_shapes, loc, attn, total, M, L, P);
+  return pd_check_launch("pd_msda_prep_fwd");
+}
+
+extern "C" int pd_msda_prep_bwd(const float *gloc, const float *gattn, const float *attn, const int64_t *spatial_shapes, float *d_offs,
+                                float *d_logits, int64_t tokens, int M, int L, int P, void *stream_)
+{
+  if (tokens < 0 || M <= 0 || L <= 0 || P <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_bwd: tokens=%lld M=%d L=%d P=%d", (long long)tokens, M, L, P);
+  if (tokens == 0) return PD_OK;
+  if (!gloc || !gattn || !attn || !spatial_shapes || !d_offs || !d_logits) return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_bwd: null pointer");
+  const int64_t total = tokens * M;
+  hipLaunchKernelGGL(msda_prep_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, gloc, gattn, attn,
+                     spatial_shapes, d_offs, d_logits, total, M, L, P);
+  return pd_check_launch("pd_msda_prep_bwd");
 }

@@ -1,0 +1,143 @@
+"""The deformable-attention encoder of the pixel decoder as ONE autograd node with a hand-written backward (fp32).
+
+Reference: pixel_decoder/msdeformattn.py MSDeformAttnTransformerEncoder(Layer) (:96-175) around
+ops/modules/ms_deform_attn.py:86-131.  Per layer, on the [B*S, 256] token matrix (S = 21 504 at 1024x1024):
+
+    value = value_proj(src);  offsets / logits = sampling_offsets / attention_weights(src + pos)
+    loc, attn = pd_msda_prep_fwd(...)                     (softmax + reference point + offset / size, one pass)
+    a = pd_msda_forward(value, loc, attn)                 (the HIP sampling core)
+    src = LayerNorm(src + output_proj(a))                 (pd_add_layernorm_fwd)
+    src = LayerNorm(src + linear2(relu(linear1(src))))    (pd_add_layernorm_fwd, which also emits src + pos for the next layer)
+
+Forward / input-gradient GEMMs are library fp32 GEMMs (addmm / mm), weight gradients the split-K MFMA kernel
+pd_gemm_wgrad_f32; everything between them is one hand-written kernel per step instead of the 3-kernel LayerNorm
+backward, separate residual / positional adds, softmax / divide / add chains and gradient-accumulation adds that
+eager autograd issues.  All arithmetic stays fp32 like the reference (`autocast(enabled=False)`, msdeformattn.py:318).
+"""
+import torch
+from torch.autograd import Function
+
+from .. import MultiScaleDeformableAttention as MSDA
+from .. import lib as _lib
+from . import rowwise as rw
+from .gemm import gemm_wgrad
+
+def _timed(kind, fn, *args):
+    # bench.py's per-launch HIP-event hook lives next to the autograd face of the operator (imported lazily: that module
+    # sits under modeling/, which imports this one)
+    from ..modeling.pixel_decoder.ops.functions.ms_deform_attn_func import _timed as t
+    return t(kind, fn, *args)
+
+
+N_LAYER = 16   # so_w so_b aw_w aw_b vp_w vp_b op_w op_b n1_w n1_b l1_w l1_b l2_w l2_b n2_w n2_b
+
+
+def msda_prep_fwd(offs, logits, ref, shapes, M, L, P):
+    tokens = offs.shape[0]
+    loc = torch.empty((tokens, M, L, P, 2), dtype=torch.float32, device=offs.device)
+    attn = torch.empty((tokens, M, L, P), dtype=torch.float32, device=offs.device)
+    _lib.check(_lib.load().pd_msda_prep_fwd(offs.data_ptr(), logits.data_ptr(), ref.data_ptr(), shapes.data_ptr(), loc.data_ptr(),
+                                            attn.data_ptr(), tokens, M, L, P, rw._stream()))
+    return loc, attn
+
+
+def msda_prep_bwd(gloc, gattn, attn, shapes, tokens, M, L, P):
+    d_offs = torch.empty((tokens, M * L * P * 2), dtype=torch.float32, device=attn.device)
+    d_logits = torch.empty((tokens, M * L * P), dtype=torch.float32, device=attn.device)
+    _lib.check(_lib.load().pd_msda_prep_bwd(gloc.data_ptr(), gattn.data_ptr(), attn.data_ptr(), shapes.data_ptr(), d_offs.data_ptr(),
+                                            d_logits.data_ptr(), tokens, M, L, P, rw._stream()))
+    return d_offs, d_logits
+
+
+class EncoderSpec:
+    def __init__(self, n_heads, n_levels, n_points, eps, im2col_step, reference_points, spatial_shapes, level_start_index):
+        self.M, self.L, self.P, self.eps, self.im2col_step = n_heads, n_levels, n_points, eps, im2col_step
+        self.ref, self.shapes, self.lsi = reference_points, spatial_shapes, level_start_index
+
+
+class EncoderCore(Function):
+    @staticmethod
+    def forward(ctx, spec: EncoderSpec, src, pos, *params):
+        ctx.set_materialize_grads(False)
+        B, S, C = src.shape
+        M, L, P = spec.M, spec.L, spec.P
+        nl = len(params) // N_LAYER
+        T = B * S
+        src2 = src.reshape(T, C)
+        src2 = src2 if src2.is_contiguous() else src2.contiguous()
+        pos2 = pos.reshape(T, C)
+        pos2 = pos2 if pos2.is_contiguous() else pos2.contiguous()
+        ref = spec.ref.reshape(T, L, 2)
+        ref = ref if ref.is_contiguous() else ref.contiguous()
+        q = src2 + pos2
+        saved = []
+        x = src2
+        for i in range(nl):
+            (so_w, so_b, aw_w, aw_b, vp_w, vp_b, op_w, op_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b) = params[i * N_LAYER:(i + 1) * N_LAYER]
+            value = torch.addmm(vp_b, x, vp_w.t())
+            offs = torch.addmm(so_b, q, so_w.t())
+            logits = torch.addmm(aw_b, q, aw_w.t())
+            loc, attn = msda_prep_fwd(offs, logits, ref, spec.shapes, M, L, P)
+            v4, loc6, attn5 = value.view(B, S, M, C // M), loc.view(B, S, M, L, P, 2), attn.view(B, S, M, L, P)
+            a = _timed("fwd", MSDA.ms_deform_attn_forward, v4, spec.shapes, spec.lsi, loc6, attn5, spec.im2col_step).view(T, C)
+            z1, y1, _, _, m1, r1 = rw.add_ln_fwd(torch.addmm(op_b, a, op_w.t()), x, n1_w, n1_b, spec.eps)
+            h = torch.relu_(torch.addmm(l1_b, y1, l1_w.t()))
+            last = i == nl - 1
+            z2, y2, _, ypos, m2, r2 = rw.add_ln_fwd(torch.addmm(l2_b, h, l2_w.t()), y1, n2_w, n2_b, spec.eps, c_dtype=torch.float32,
+                                                    pos=pos2, pos_div=1, want_ypos=not last)
+            saved.append((x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2))
+            x, q = y2, ypos
+        ctx.spec, ctx.saved, ctx.params, ctx.dims = spec, saved, params, (B, S, C, nl)
+        return x.view(B, S, C)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        spec, params = ctx.spec, ctx.params
+        B, S, C, nl = ctx.dims
+        M, L, P = spec.M, spec.L, spec.P
+        T = B * S
+        dev = d_out.device
+        # fp32 accumulators filled by the LayerNorm / ReLU kernels (+=): per layer [n1_w n1_b op_b | n2_w n2_b l2_b | l1_b]
+        F1 = params[10].shape[0]
+        per = 6 * C + F1
+        buf = torch.zeros(nl * per, dtype=torch.float32, device=dev)
+        d_pos = torch.zeros((T, C), dtype=torch.float32, device=dev)
+        grads = [None] * (nl * N_LAYER)
+        dy = d_out.reshape(T, C)
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dy2 = dyq = None                                       # further fp32 terms of d(src_l): via value_proj, via (src + pos)
+        for i in reversed(range(nl)):
+            (so_w, so_b, aw_w, aw_b, vp_w, vp_b, op_w, op_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b) = params[i * N_LAYER:(i + 1) * N_LAYER]
+            x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2 = ctx.saved[i]
+            o = i * per
+            g_n1w, g_n1b, g_opb = buf[o:o + C], buf[o + C:o + 2 * C], buf[o + 2 * C:o + 3 * C]
+            g_n2w, g_n2b, g_l2b = buf[o + 3 * C:o + 4 * C], buf[o + 4 * C:o + 5 * C], buf[o + 5 * C:o + 6 * C]
+            g_l1b = buf[o + 6 * C:o + 6 * C + F1]
+            # ---- FFN + norm2
+            dz2, _ = rw.add_ln_bwd(z2, m2, r2, n2_w, dy=dy, dy2=dy2, dypos_c=dyq, dgamma=g_n2w, dbeta=g_n2b, dbias=g_l2b,
+                                   dpos_acc=d_pos if dyq is not None else None, pos_div=1)
+            g_l2w = gemm_wgrad(dz2, h)
+            dh = rw.relu_bwd_colsum(torch.mm(dz2, l2_w), h, g_l1b)
+            g_l1w = gemm_wgrad(dh, y1)
+            dy1 = torch.mm(dh, l1_w)
+            del dh
+            # ---- deformable attention + norm1
+            dz1, _ = rw.add_ln_bwd(z1, m1, r1, n1_w, dy=dz2, dy2=dy1, dgamma=g_n1w, dbeta=g_n1b, dbias=g_opb, out=dz2)
+            g_opw = gemm_wgrad(dz1, a)
+            da = torch.mm(dz1, op_w).view(B, S, C)
+            gv, gloc, gattn = _timed("bwd", MSDA.ms_deform_attn_backward, v4, spec.shapes, spec.lsi, loc6, attn5, da, spec.im2col_step)
+            d_offs, d_logits = msda_prep_bwd(gloc, gattn, attn5, spec.shapes, T, M, L, P)
+            g_sow, g_sob = gemm_wgrad(d_offs, q, with_bias=True)
+            g_aww, g_awb = gemm_wgrad(d_logits, q, with_bias=True)
+            dq = torch.mm(d_offs, so_w)
+            dq.addmm_(d_logits, aw_w)
+            gv2 = gv.view(T, C)
+            g_vpw, g_vpb = gemm_wgrad(gv2, x, with_bias=True)
+            dxv = torch.mm(gv2, vp_w)
+            grads[i * N_LAYER:(i + 1) * N_LAYER] = [g_sow, g_sob, g_aww, g_awb, g_vpw, g_vpb, g_opw, g_opb, g_n1w, g_n1b,
+                                                     g_l1w, g_l1b, g_l2w, g_l2b, g_n2w, g_n2b]
+            dy, dy2, dyq = dz1, dxv, dq
+        d_pos += dyq
+        d_src = dy + dy2
+        d_src += dyq
+        return (None, d_src.view(B, S, C), d_pos.view(B, S, C), *grads)

@@ -17,6 +17,8 @@ from ..transformer_decoder.position_encoding import PositionEmbeddingSine
 from ...functions.fused import group_norm_nhwc, group_norm_nhwc_supported
 from ...functions.gemm import linear_f32
 from .ops.modules import MSDeformAttn
+from ...functions.encoder_core import EncoderCore, EncoderSpec
+from ...functions.rowwise import supports_width
 
 
 class MSDeformAttnTransformerEncoderLayer(nn.Module):
@@ -75,10 +77,36 @@ class MSDeformAttnTransformerEncoder(nn.Module):
             reference_points = self.get_reference_points(shapes_host or spatial_shapes.tolist(), valid_ratios, src.device)
             if key is not None:                      # valid_ratios == 1 on this path: geometry only
                 self._ref_cache[key] = reference_points
+        if self._fused_ok(src, pos, reference_points, padding_mask):
+            l0 = self.layers[0]
+            spec = EncoderSpec(l0.self_attn.n_heads, l0.self_attn.n_levels, l0.self_attn.n_points, l0.norm1.eps,
+                               l0.self_attn.im2col_step, reference_points, spatial_shapes, level_start_index)
+            return EncoderCore.apply(spec, src, pos, *self._core_params())
         out = src
         for layer in self.layers:
             out = layer(out, pos, reference_points, spatial_shapes, level_start_index, padding_mask)
         return out
+
+    fused_core = True          # GPU fp32: run the layer loop as one hand-written autograd node (functions/encoder_core.py)
+
+    def _fused_ok(self, src, pos, reference_points, padding_mask):
+        if not (self.fused_core and self.num_layers and src.is_cuda and src.dtype == torch.float32 and pos is not None
+                and padding_mask is None and reference_points.shape[-1] == 2 and not torch.is_autocast_enabled("cuda")):
+            return False
+        l0 = self.layers[0]
+        if self.training and any(d.p > 0 for l in self.layers for d in (l.dropout1, l.dropout2, l.dropout3)):
+            return False
+        return (supports_width(src.shape[-1]) and l0.linear1.out_features % 128 == 0
+                and all(p.dtype == torch.float32 for p in l0.parameters()))
+
+    def _core_params(self):
+        p = []
+        for l in self.layers:
+            a = l.self_attn
+            p += [a.sampling_offsets.weight, a.sampling_offsets.bias, a.attention_weights.weight, a.attention_weights.bias,
+                  a.value_proj.weight, a.value_proj.bias, a.output_proj.weight, a.output_proj.bias, l.norm1.weight, l.norm1.bias,
+                  l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias, l.norm2.weight, l.norm2.bias]
+        return p
 
 
 class MSDeformAttnTransformerEncoderOnly(nn.Module):

@@ -201,3 +201,54 @@ def test_fused_decoder_core_bf16_close_to_fp32():
         a, b = g1[k], g2[k]
         cos = F.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
         assert cos > 0.98, (k, cos)
+
+
+# ----------------------------------------------------------------------------- MSDeformAttn prep + fused encoder core
+def test_msda_prep_fwd_bwd_vs_torch():
+    from partdistillation_amd.functions.encoder_core import msda_prep_bwd, msda_prep_fwd
+    T, M, L, P = 333, 8, 3, 4
+    offs, logits = _r((T, M * L * P * 2), 51, 3.0), _r((T, M * L * P), 52, 2.0)
+    ref = _r((T, L, 2), 53).abs()
+    shapes = torch.tensor([[8, 12], [16, 24], [32, 48]], dtype=torch.long, device=DEV)
+    loc, attn = msda_prep_fwd(offs, logits, ref, shapes, M, L, P)
+    ot, lt = offs.clone().requires_grad_(), logits.clone().requires_grad_()
+    normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+    loc_r = ref[:, None, :, None, :] + ot.view(T, M, L, P, 2) / normalizer[None, None, :, None, :]
+    attn_r = F.softmax(lt.view(T, M, L * P), -1).view(T, M, L, P)
+    assert torch.equal(loc, loc_r.detach())                              # same two roundings as the reference expression
+    torch.testing.assert_close(attn, attn_r.detach(), rtol=1e-6, atol=1e-7)
+    gloc, gattn = _r(loc.shape, 54), _r(attn.shape, 55)
+    d_offs, d_logits = msda_prep_bwd(gloc, gattn, attn, shapes, T, M, L, P)
+    ((loc_r * gloc).sum() + (attn_r * gattn).sum()).backward()
+    torch.testing.assert_close(d_offs, ot.grad, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(d_logits, lt.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_fused_encoder_core_matches_module_path():
+    from test_product_gpu import build_pixel_decoder
+    cfg = dict(C.C1, enc_layers=3, enc_ffn=512)
+    a = build_pixel_decoder(cfg)
+    a.load_state_dict(C.seeded_weights(C.table_of(a.state_dict()), 970), strict=False)
+    a = a.to(DEV)
+    b = build_pixel_decoder(cfg).to(DEV)
+    b.load_state_dict(a.state_dict())
+    b.transformer.encoder.fused_core = False
+    feats = {f"res{i + 2}": _r((2, c, 96 // s, 128 // s), 980 + i, 0.5) for i, (c, s) in enumerate(zip(cfg["channels"], (4, 8, 16, 32)))}
+    res = []
+    for m in (a, b):
+        f = {k: v.clone().requires_grad_() for k, v in feats.items()}
+        mf, low, ms = m.forward_features(f)
+        loss = (mf * _r(mf.shape, 990)).sum() + sum((t * _r(t.shape, 991 + i)).sum() for i, t in enumerate(ms))
+        loss.backward()
+        g = {k: p.grad.clone() for k, p in m.named_parameters()}
+        g.update({k: v.grad.clone() for k, v in f.items()})
+        res.append((mf.detach(), [t.detach() for t in ms], g))
+    (mf1, ms1, g1), (mf2, ms2, g2) = res
+    torch.testing.assert_close(mf1, mf2, rtol=1e-4, atol=1e-4)
+    for x, y in zip(ms1, ms2):
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-4)
+    assert set(g1) == set(g2)
+    for k in g2:
+        scale = g2[k].abs().max().clamp_min(1e-6)
+        err = ((g1[k] - g2[k]).abs().max() / scale).item()
+        assert err < 2e-3, (k, err)
