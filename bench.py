@@ -207,6 +207,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     total_loss = float(sum(losses.values()))
+    if total_loss != total_loss or abs(total_loss) == float("inf"):
+        raise SystemExit("bench.py: the loss is not finite after the timed steps - the measurement is invalid")
 
     if rank == 0:
         images = a.batch * world * a.steps

@@ -225,6 +225,8 @@ extern "C" int pd_gemm_tn_f32(const float *A, const float *B, const float *bias,
   return pd_check_launch("pd_gemm_tn_f32");
 }
 
+int g_pd_dbg_wgrad_wgs = 1024;
+
 extern "C" int pd_gemm_wgrad_f32(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy,
                                  int ldx, int ldw, void *stream_)
 {
@@ -238,7 +240,7 @@ extern "C" int pd_gemm_wgrad_f32(const float *dY, const float *X, float *dW, flo
   if (dB) (void)hipMemsetAsync(dB, 0, (size_t)N * sizeof(float), s);
   if (M == 0) return pd_check_launch("pd_gemm_wgrad_f32");
   const int tk = (K + BM - 1) / BM, tn = (N + BN - 1) / BN, tiles = tk * tn;
-  int splits = (1024 + tiles - 1) / tiles;                      // ~4 workgroups per CU in flight
+  int splits = (g_pd_dbg_wgrad_wgs + tiles - 1) / tiles;        // ~4 workgroups per CU in flight
   int m_chunk = ((M + splits - 1) / splits + WM - 1) / WM * WM;
   if (m_chunk < 4 * WM) m_chunk = 4 * WM;
   splits = (M + m_chunk - 1) / m_chunk;

@@ -11,6 +11,7 @@ from torch import nn
 
 from ..compat.layers import FrozenBatchNorm2d
 from ..functions import optim as optim_op
+from ..functions.fused import PinnedRing
 from .flat_params import FlatParams
 
 _NORM_TYPES = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.SyncBatchNorm, nn.GroupNorm, nn.InstanceNorm1d,
@@ -84,7 +85,7 @@ class FlatClippedAdamW:
         # per-group {lr, 1-beta1^t, sqrt(1-beta2^t)} live on the device so that a hipGraph-captured step keeps
         # following the LR schedule / bias corrections when replayed (host refreshes them before every step)
         ng = len(self.flat.groups)
-        self._dyn_host = torch.zeros((ng, 4), dtype=torch.float32, pin_memory=(dev.type == "cuda"))
+        self._dyn_host = PinnedRing((ng, 4), torch.float32, dev.type == "cuda")
         self._dyn_dev = torch.zeros((ng, 4), dtype=torch.float32, device=dev)
 
     def zero_grad(self, set_to_none=False):
@@ -98,10 +99,12 @@ class FlatClippedAdamW:
         """host side of a step: advance the step count, publish lr / bias corrections to the device."""
         self.steps += 1
         b1, b2 = self.betas
-        h = self._dyn_host.numpy()
+        host = self._dyn_host.acquire()
+        h = host.numpy()
         for i, pg in enumerate(self.param_groups):
             h[i, 0], h[i, 1], h[i, 2] = pg["lr"], 1.0 - b1 ** self.steps, (1.0 - b2 ** self.steps) ** 0.5
-        self._dyn_dev.copy_(self._dyn_host, non_blocking=True)
+        self._dyn_dev.copy_(host, non_blocking=True)
+        self._dyn_host.release()
 
     @torch.no_grad()
     def step(self):

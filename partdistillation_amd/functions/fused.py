@@ -52,6 +52,30 @@ def affine_act(x, scale, bias, residual=None, relu=True):
     return AffineAct.apply(x, scale.float().contiguous(), bias.float().contiguous(), residual, relu)
 
 
+class PinnedRing:
+    """Ring of pinned host staging buffers for small host->device tables that are rewritten every step.  A slot is
+    rewritten only after the async copy that read it has executed (one event per slot): the host may run steps ahead
+    of the device without a later step's table overwriting one still waiting to be copied."""
+
+    def __init__(self, shape, dtype, pin, slots=8):
+        self.bufs = [torch.zeros(shape, dtype=dtype, pin_memory=pin) for _ in range(slots)]
+        self.events = [None] * slots
+        self.pin, self.i = pin, -1
+
+    def acquire(self):
+        self.i = (self.i + 1) % len(self.bufs)
+        if self.events[self.i] is not None and not torch.cuda.is_current_stream_capturing():
+            self.events[self.i].synchronize()
+        return self.bufs[self.i]
+
+    def release(self):
+        """call after enqueueing the copy out of the buffer acquire() returned"""
+        if self.pin and not torch.cuda.is_current_stream_capturing():
+            ev = self.events[self.i] or torch.cuda.Event()
+            ev.record()
+            self.events[self.i] = ev
+
+
 class GatherPlan:
     """static block table for pd_multi_gather_sumsq over a list of (numel, dst_offset) tensors."""
     CHUNK = 16384
@@ -70,23 +94,25 @@ class GatherPlan:
         self.blk_dst = torch.tensor(bd, dtype=torch.int64, device=device)
         self.blk_len = torch.tensor(bl, dtype=torch.int32, device=device)
         pin = device.type == "cuda"
-        self._host_ptrs = torch.zeros(self.ntensors, dtype=torch.int64, pin_memory=pin)
-        self._host_bf16 = torch.zeros(self.ntensors, dtype=torch.int32, pin_memory=pin)
+        self._host_ptrs = PinnedRing(self.ntensors, torch.int64, pin)
+        self._host_bf16 = PinnedRing(self.ntensors, torch.int32, pin)
         self.src_ptrs = torch.zeros(self.ntensors, dtype=torch.int64, device=device)
         self.src_bf16 = torch.zeros(self.ntensors, dtype=torch.int32, device=device)
 
     def upload(self, grads, t_begin=0):
         """grads: tensors or None (-> zeros) of tensors [t_begin, t_begin+len(grads)); records their addresses and
         element types for the next gather (pinned staging, async copy of just that slice)."""
-        hp, hb = self._host_ptrs.numpy(), self._host_bf16.numpy()
+        tp, tb = self._host_ptrs.acquire(), self._host_bf16.acquire()
+        hp, hb = tp.numpy(), tb.numpy()
         for i, g in enumerate(grads, start=t_begin):
             if g is None:
                 hp[i], hb[i] = 0, 0
             else:
                 hp[i], hb[i] = g.data_ptr(), 1 if g.dtype == torch.bfloat16 else 0
         t_end = t_begin + len(grads)
-        self.src_ptrs[t_begin:t_end].copy_(self._host_ptrs[t_begin:t_end], non_blocking=True)
-        self.src_bf16[t_begin:t_end].copy_(self._host_bf16[t_begin:t_end], non_blocking=True)
+        self.src_ptrs[t_begin:t_end].copy_(tp[t_begin:t_end], non_blocking=True)
+        self.src_bf16[t_begin:t_end].copy_(tb[t_begin:t_end], non_blocking=True)
+        self._host_ptrs.release(), self._host_bf16.release()
 
     def gather(self, dst, sumsq=None, t_begin=0, t_end=None):
         t_end = self.ntensors if t_end is None else t_end

@@ -126,3 +126,24 @@ def test_swin_matches_reference_golden(golden):
     for k, d in g["grads"].items():
         C.check_digest(named[k].grad, d, 2e-3, 1e-4, "grad " + k)
     C.check_digest(x.grad, g["grad_x"], 2e-3, 1e-4, "grad x")
+
+
+def test_pinned_ring_hands_out_distinct_staging_buffers():
+    """host tables that are rewritten every step must not be staged through ONE reused buffer: the async copy of step n
+    may still be pending when step n+1 is issued (that race produced wrong gradient addresses when the host ran ahead)"""
+    import torch
+    from partdistillation_amd.functions.fused import GatherPlan, PinnedRing
+    ring = PinnedRing(4, torch.int64, pin=False, slots=3)
+    seen = []
+    for i in range(6):
+        buf = ring.acquire()
+        buf.fill_(i)
+        ring.release()
+        seen.append(buf.data_ptr())
+    assert len(set(seen[:3])) == 3 and seen[:3] == seen[3:]
+    plan = GatherPlan([5, 3], [0, 8], torch.device("cpu"))
+    a, b = torch.arange(5.0), torch.ones(3)
+    plan.upload([a, b])
+    assert plan.src_ptrs.tolist() == [a.data_ptr(), b.data_ptr()]
+    plan.upload([None], t_begin=1)
+    assert plan.src_ptrs.tolist() == [a.data_ptr(), 0]
