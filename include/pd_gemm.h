@@ -27,6 +27,11 @@ int pd_gemm_tn_f32(const float *A, const float *B, const float *bias, float *C, 
 int pd_gemm_wgrad_f32(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx,
                       int ldw, void *stream);
 
+/* Same, accumulating: dW += dY^T . X and dB += column sums, into buffers the caller has initialised (one memset for
+ * all the weight gradients of a backward pass instead of one or two per GEMM). */
+int pd_gemm_wgrad_acc_f32(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx,
+                          int ldw, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -295,7 +295,76 @@ __global__ __launch_bounds__(256) void attn_mask_u8(const T *__restrict__ logits
 }
 
 // ------------------------------------------------------------------------------------------------ MSDeformAttn prep
-// one thread per (token, head): softmax over the L*P logits, sampling locations = reference point + offset / (W_l, H_l)
+// one thread per (token, head): softmax over the L*P logits, sampling locations = reference point + offset / (W_l, H_l).
+// LP = L*P values per thread, moved as float4 (LP % 4 == 0, P even): a thread owns 4*LP contiguous bytes of logits / attn
+// and 8*LP of offsets / locations, so a wavefront covers one contiguous span with 16-byte lanes.
+template <int LP4>      // LP / 4
+__global__ __launch_bounds__(256) void msda_prep_fwd_v(const float *__restrict__ offs, const float *__restrict__ logits,
+                                                       const float *__restrict__ ref, const int64_t *__restrict__ shapes,
+                                                       float *__restrict__ loc, float *__restrict__ attn, int64_t total, int M,
+                                                       int L, int P)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int64_t bq = t / M;
+  float4 lg[LP4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < LP4; ++i) {
+    lg[i] = ld4(logits + (t * LP4 + i) * 4);
+    mx = fmaxf(fmaxf(fmaxf(mx, lg[i].x), fmaxf(lg[i].y, lg[i].z)), lg[i].w);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP4; ++i) {
+    lg[i].x = expf(lg[i].x - mx); lg[i].y = expf(lg[i].y - mx); lg[i].z = expf(lg[i].z - mx); lg[i].w = expf(lg[i].w - mx);
+    sum += lg[i].x; sum += lg[i].y; sum += lg[i].z; sum += lg[i].w;           // same left-to-right order as the scalar loop
+  }
+#pragma unroll
+  for (int i = 0; i < LP4; ++i)
+    st4(attn + (t * LP4 + i) * 4, make_float4(lg[i].x / sum, lg[i].y / sum, lg[i].z / sum, lg[i].w / sum));
+  const int half = P / 2;                                  // float4 = two (x, y) points of the same level
+#pragma unroll
+  for (int i = 0; i < 2 * LP4; ++i) {
+    const int l = i / half;
+    const float w = (float)shapes[l * 2 + 1], h = (float)shapes[l * 2];
+    const float rx = ref[(bq * L + l) * 2], ry = ref[(bq * L + l) * 2 + 1];
+    const float4 o = ld4(offs + (t * 2 * LP4 + i) * 4);
+    st4(loc + (t * 2 * LP4 + i) * 4, make_float4(rx + o.x / w, ry + o.y / h, rx + o.z / w, ry + o.w / h));
+  }
+}
+
+template <int LP4>
+__global__ __launch_bounds__(256) void msda_prep_bwd_v(const float *__restrict__ gloc, const float *__restrict__ gattn,
+                                                       const float *__restrict__ attn, const int64_t *__restrict__ shapes,
+                                                       float *__restrict__ d_offs, float *__restrict__ d_logits, int64_t total,
+                                                       int M, int L, int P)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  float4 a[LP4], g[LP4];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP4; ++i) {
+    a[i] = ld4(attn + (t * LP4 + i) * 4);
+    g[i] = ld4(gattn + (t * LP4 + i) * 4);
+    dot += a[i].x * g[i].x; dot += a[i].y * g[i].y; dot += a[i].z * g[i].z; dot += a[i].w * g[i].w;
+  }
+#pragma unroll
+  for (int i = 0; i < LP4; ++i)
+    st4(d_logits + (t * LP4 + i) * 4, make_float4(a[i].x * (g[i].x - dot), a[i].y * (g[i].y - dot), a[i].z * (g[i].z - dot),
+                                                  a[i].w * (g[i].w - dot)));
+  const int half = P / 2;
+#pragma unroll
+  for (int i = 0; i < 2 * LP4; ++i) {
+    const int l = i / half;
+    const float w = (float)shapes[l * 2 + 1], h = (float)shapes[l * 2];
+    const float4 o = ld4(gloc + (t * 2 * LP4 + i) * 4);
+    st4(d_offs + (t * 2 * LP4 + i) * 4, make_float4(o.x / w, o.y / h, o.z / w, o.w / h));
+  }
+}
+
+// any L, P: scalar loops
 __global__ __launch_bounds__(256) void msda_prep_fwd(const float *__restrict__ offs, const float *__restrict__ logits,
                                                      const float *__restrict__ ref, const int64_t *__restrict__ shapes,
                                                      float *__restrict__ loc, float *__restrict__ attn, int64_t total, int M, int L,
@@ -478,8 +547,15 @@ extern "C" int pd_msda_prep_fwd(const float *offs, const float *logits, const fl
   if (tokens == 0) return PD_OK;
   if (!offs || !logits || !ref || !spatial_shapes || !loc || !attn) return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_fwd: null pointer");
   const int64_t total = tokens * M;
-  hipLaunchKernelGGL(msda_prep_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, offs, logits, ref,
-                     spatial_shapes, loc, attn, total, M, L, P);
+  const dim3 g((unsigned)((total + 255) / 256)), b(256);
+  hipStream_t s = (hipStream_t)stream_;
+  const int LP = L * P;
+#define LAUNCH(KER) hipLaunchKernelGGL(KER, g, b, 0, s, offs, logits, ref, spatial_shapes, loc, attn, total, M, L, P)
+  if ((P & 1) == 0 && LP == 12) LAUNCH(msda_prep_fwd_v<3>);
+  else if ((P & 1) == 0 && LP == 16) LAUNCH(msda_prep_fwd_v<4>);
+  else if ((P & 1) == 0 && LP == 8) LAUNCH(msda_prep_fwd_v<2>);
+  else LAUNCH(msda_prep_fwd);
+#undef LAUNCH
   return pd_check_launch("pd_msda_prep_fwd");
 }
 
@@ -490,7 +566,14 @@ extern "C" int pd_msda_prep_bwd(const float *gloc, const float *gattn, const flo
   if (tokens == 0) return PD_OK;
   if (!gloc || !gattn || !attn || !spatial_shapes || !d_offs || !d_logits) return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_bwd: null pointer");
   const int64_t total = tokens * M;
-  hipLaunchKernelGGL(msda_prep_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, gloc, gattn, attn,
-                     spatial_shapes, d_offs, d_logits, total, M, L, P);
+  const dim3 g((unsigned)((total + 255) / 256)), b(256);
+  hipStream_t s = (hipStream_t)stream_;
+  const int LP = L * P;
+#define LAUNCH(KER) hipLaunchKernelGGL(KER, g, b, 0, s, gloc, gattn, attn, spatial_shapes, d_offs, d_logits, total, M, L, P)
+  if ((P & 1) == 0 && LP == 12) LAUNCH(msda_prep_bwd_v<3>);
+  else if ((P & 1) == 0 && LP == 16) LAUNCH(msda_prep_bwd_v<4>);
+  else if ((P & 1) == 0 && LP == 8) LAUNCH(msda_prep_bwd_v<2>);
+  else LAUNCH(msda_prep_bwd);
+#undef LAUNCH
   return pd_check_launch("pd_msda_prep_bwd");
 }

@@ -20,7 +20,7 @@ from torch.autograd import Function
 from .. import MultiScaleDeformableAttention as MSDA
 from .. import lib as _lib
 from . import rowwise as rw
-from .gemm import gemm_wgrad
+from .gemm import gemm_wgrad_acc
 
 def _timed(kind, fn, *args):
     # bench.py's per-launch HIP-event hook lives next to the autograd face of the operator (imported lazily: that module
@@ -97,10 +97,18 @@ class EncoderCore(Function):
         M, L, P = spec.M, spec.L, spec.P
         T = B * S
         dev = d_out.device
-        # fp32 accumulators filled by the LayerNorm / ReLU kernels (+=): per layer [n1_w n1_b op_b | n2_w n2_b l2_b | l1_b]
-        F1 = params[10].shape[0]
-        per = 6 * C + F1
-        buf = torch.zeros(nl * per, dtype=torch.float32, device=dev)
+        # every parameter gradient of the encoder lives in ONE zero-filled fp32 buffer (a single memset): the LayerNorm /
+        # ReLU kernels and the split-K weight-gradient GEMMs all accumulate (+=) into their slices
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        buf = torch.zeros(total, dtype=torch.float32, device=dev)
+
+        def G(i, j):
+            p = params[i * N_LAYER + j]
+            o = offs[i * N_LAYER + j]
+            return buf[o:o + p.numel()].view(p.shape)
         d_pos = torch.zeros((T, C), dtype=torch.float32, device=dev)
         grads = [None] * (nl * N_LAYER)
         dy = d_out.reshape(T, C)
@@ -109,30 +117,28 @@ class EncoderCore(Function):
         for i in reversed(range(nl)):
             (so_w, so_b, aw_w, aw_b, vp_w, vp_b, op_w, op_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b) = params[i * N_LAYER:(i + 1) * N_LAYER]
             x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2 = ctx.saved[i]
-            o = i * per
-            g_n1w, g_n1b, g_opb = buf[o:o + C], buf[o + C:o + 2 * C], buf[o + 2 * C:o + 3 * C]
-            g_n2w, g_n2b, g_l2b = buf[o + 3 * C:o + 4 * C], buf[o + 4 * C:o + 5 * C], buf[o + 5 * C:o + 6 * C]
-            g_l1b = buf[o + 6 * C:o + 6 * C + F1]
+            (g_sow, g_sob, g_aww, g_awb, g_vpw, g_vpb, g_opw, g_opb, g_n1w, g_n1b, g_l1w, g_l1b, g_l2w, g_l2b, g_n2w,
+             g_n2b) = [G(i, j) for j in range(N_LAYER)]
             # ---- FFN + norm2
             dz2, _ = rw.add_ln_bwd(z2, m2, r2, n2_w, dy=dy, dy2=dy2, dypos_c=dyq, dgamma=g_n2w, dbeta=g_n2b, dbias=g_l2b,
                                    dpos_acc=d_pos if dyq is not None else None, pos_div=1)
-            g_l2w = gemm_wgrad(dz2, h)
+            gemm_wgrad_acc(dz2, h, g_l2w)
             dh = rw.relu_bwd_colsum(torch.mm(dz2, l2_w), h, g_l1b)
-            g_l1w = gemm_wgrad(dh, y1)
+            gemm_wgrad_acc(dh, y1, g_l1w)
             dy1 = torch.mm(dh, l1_w)
             del dh
             # ---- deformable attention + norm1
             dz1, _ = rw.add_ln_bwd(z1, m1, r1, n1_w, dy=dz2, dy2=dy1, dgamma=g_n1w, dbeta=g_n1b, dbias=g_opb, out=dz2)
-            g_opw = gemm_wgrad(dz1, a)
+            gemm_wgrad_acc(dz1, a, g_opw)
             da = torch.mm(dz1, op_w).view(B, S, C)
             gv, gloc, gattn = _timed("bwd", MSDA.ms_deform_attn_backward, v4, spec.shapes, spec.lsi, loc6, attn5, da, spec.im2col_step)
             d_offs, d_logits = msda_prep_bwd(gloc, gattn, attn5, spec.shapes, T, M, L, P)
-            g_sow, g_sob = gemm_wgrad(d_offs, q, with_bias=True)
-            g_aww, g_awb = gemm_wgrad(d_logits, q, with_bias=True)
+            gemm_wgrad_acc(d_offs, q, g_sow, g_sob)
+            gemm_wgrad_acc(d_logits, q, g_aww, g_awb)
             dq = torch.mm(d_offs, so_w)
             dq.addmm_(d_logits, aw_w)
             gv2 = gv.view(T, C)
-            g_vpw, g_vpb = gemm_wgrad(gv2, x, with_bias=True)
+            gemm_wgrad_acc(gv2, x, g_vpw, g_vpb)
             dxv = torch.mm(gv2, vp_w)
             grads[i * N_LAYER:(i + 1) * N_LAYER] = [g_sow, g_sob, g_aww, g_awb, g_vpw, g_vpb, g_opw, g_opb, g_n1w, g_n1b,
                                                      g_l1w, g_l1b, g_l2w, g_l2b, g_n2w, g_n2b]

@@ -25,6 +25,15 @@ def gemm_tn(a, b, bias=None, relu=False):
     return c
 
 
+def gemm_wgrad_acc(dy, x, dw, db=None):
+    """dw [N,K] += dy.T @ x, db [N] += dy.sum(0): accumulates into caller-initialised fp32 buffers (no memset launches)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    assert dw.shape == (N, K) and dw.is_contiguous() and (db is None or db.numel() == N)
+    _lib.check(_lib.load().pd_gemm_wgrad_acc_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                                 M, N, K, dy.stride(0), x.stride(0), K, _stream()))
+
+
 def gemm_wgrad(dy, x, with_bias=False):
     """dy [M,N], x [M,K] -> dy.T @ x  [N,K]  (and dy.sum(0) [N] from the same pass when with_bias)."""
     if not dy.is_cuda:

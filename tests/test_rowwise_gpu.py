@@ -204,12 +204,13 @@ def test_fused_decoder_core_bf16_close_to_fp32():
 
 
 # ----------------------------------------------------------------------------- MSDeformAttn prep + fused encoder core
-def test_msda_prep_fwd_bwd_vs_torch():
+@pytest.mark.parametrize("L,P", [(3, 4), (2, 3), (4, 4)])
+def test_msda_prep_fwd_bwd_vs_torch(L, P):
     from partdistillation_amd.functions.encoder_core import msda_prep_bwd, msda_prep_fwd
-    T, M, L, P = 333, 8, 3, 4
+    T, M = 333, 8
     offs, logits = _r((T, M * L * P * 2), 51, 3.0), _r((T, M * L * P), 52, 2.0)
     ref = _r((T, L, 2), 53).abs()
-    shapes = torch.tensor([[8, 12], [16, 24], [32, 48]], dtype=torch.long, device=DEV)
+    shapes = torch.tensor([[8, 12], [16, 24], [32, 48], [5, 7]][:L], dtype=torch.long, device=DEV)
     loc, attn = msda_prep_fwd(offs, logits, ref, shapes, M, L, P)
     ot, lt = offs.clone().requires_grad_(), logits.clone().requires_grad_()
     normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
