@@ -358,6 +358,363 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv(const T *__restrict__ q, con
   }
 }
 
+// ================================================================================================ MFMA path (bf16)
+// Lq <= 128 queries, head dim 32, bf16 operands: both GEMMs of the attention run on v_mfma_f32_32x32x8_bf16_1k.
+// With X and Y row-major and each lane holding 4 consecutive contraction elements of row (lane % 32),
+//     mma(c, x, y):  c[i][j] += sum_k X[i][k] * Y[j][k]        (C = X . Y^T)
+// and the result sits with lane = j (Y row), register e = X row (e&3) + 8*(e>>2) + 4*(lane>>5).  Score tiles are
+// therefore produced directly in the layout the second GEMM wants as an operand (lane = query, 4 consecutive keys
+// per register group, or lane = key, 4 consecutive queries), so nothing is transposed through LDS except the
+// "4 keys at fixed channel" operands (V^T forward, K^T backward), gathered from row-major LDS tiles with 16-bit reads.
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int LR = 36;     // bf16 per padded LDS row of a [rows][32] tile: 72-byte rows, 8-byte reads conflict-free
+constexpr int LT = 132;    // bf16 per padded row of a transposed [32][128] tile
+constexpr int MQ = 128;    // queries the MFMA path covers
+
+typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// round-to-nearest-even fp32 -> bf16 pair: the compiler emits v_cvt_pk_bf16_f32 (gfx950) and, unlike inline asm, knows the
+// wait states an MFMA that reads the result needs
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi)
+{
+  const f32x2 x = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(x, hwbf16x2));
+}
+__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d)
+{
+  union { unsigned u[2]; bf16x4 v; } x;
+  x.u[0] = pk_bf16(a, b); x.u[1] = pk_bf16(c, d);
+  return x.v;
+}
+__device__ __forceinline__ void mma(f32x16 &c, bf16x4 x, bf16x4 y) { c = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(x, y, c, 0, 0, 0); }
+__device__ __forceinline__ bf16x4 lds4(const bf16_t *p) { return *reinterpret_cast<const bf16x4 *>(p); }
+__device__ __forceinline__ bf16x4 gather4(const bf16_t *p, int stride)      // 4 elements `stride` apart
+{
+  bf16x4 r;
+  r[0] = (short)p[0]; r[1] = (short)p[stride]; r[2] = (short)p[2 * stride]; r[3] = (short)p[3 * stride];
+  return r;
+}
+// 4 mask bytes of keys key0..key0+3 of one mask row (as a little-endian u32); bytes at or past Lk read as 0
+__device__ __forceinline__ unsigned mask4(const uint8_t *row, int key0, int Lk, bool aligned)
+{
+  if (key0 >= Lk) return 0u;
+  if (aligned) return *reinterpret_cast<const unsigned *>(row + key0);
+  unsigned m = 0;
+  for (int i = 0; i < 4; ++i)
+    if (key0 + i < Lk) m |= (unsigned)row[key0 + i] << (8 * i);
+  return m;
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k,
+                                                     const bf16_t *__restrict__ v, const uint8_t *__restrict__ mask,
+                                                     bf16_t *__restrict__ o, float *__restrict__ lse, float *__restrict__ part_o,
+                                                     float *__restrict__ part_ml, int B, int H, int Lq, int Lk, float scale,
+                                                     int nchunk)
+{
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[2][32][LR];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[2][32][LR];
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int qi = wave * 32 + r;                     // this lane's query (column of every score tile of the wave)
+  const bool qvalid = qi < Lq;
+  const int64_t rs = (int64_t)H * D;                // elements per (position, image) row
+  bf16x4 qreg[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qreg[s] = bf16x4{0, 0, 0, 0};
+    if (qvalid) qreg[s] = *reinterpret_cast<const bf16x4 *>(q + ((int64_t)qi * B + b) * rs + h * D + 8 * s + 4 * hh);
+  }
+  const int kbeg = chunk * KC_FWD, kend = min(Lk, kbeg + KC_FWD);
+  const int ntile = (kend - kbeg + 31) / 32;
+  // staging: threads 0..127 move the K tile, 128..255 the V tile; 4 x 16 bytes per key row
+  const bf16_t *src = (tid < 128) ? k : v;
+  const int srow = (tid & 127) >> 2, spiece = tid & 3;
+  auto gload = [&](int t) {
+    const int key = kbeg + 32 * t + srow;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (key < kend) val = *reinterpret_cast<const uint4 *>(src + ((int64_t)key * B + b) * rs + h * D + spiece * 8);
+    return val;
+  };
+  auto lstore = [&](int buf, uint4 val) {
+    bf16_t *dst = ((tid < 128) ? &Ks[buf][srow][0] : &Vs[buf][srow][0]) + spiece * 8;
+    *reinterpret_cast<uint2 *>(dst) = make_uint2(val.x, val.y);
+    *reinterpret_cast<uint2 *>(dst + 4) = make_uint2(val.z, val.w);
+  };
+  const bool aligned = (Lk & 3) == 0;
+  const uint8_t *mrow = (MASK && qvalid) ? mask + ((int64_t)b * Lq + qi) * Lk : nullptr;
+  float m_run = -INFINITY, l_part = 0.f;
+  f32x16 oacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+  if (ntile > 0) lstore(0, gload(0));
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const int buf = t & 1, kbase = kbeg + 32 * t;
+    uint4 nxt = make_uint4(0, 0, 0, 0);
+    if (t + 1 < ntile) nxt = gload(t + 1);
+    f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mma(sacc, lds4(&Ks[buf][r][8 * s + 4 * hh]), qreg[s]);        // S^T = K . Q^T
+    float m_t = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int key0 = kbase + 8 * g + 4 * hh;
+      const unsigned m4 = mrow ? mask4(mrow, key0, Lk, aligned) : 0u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool blocked = (key0 + i >= kend) || ((m4 >> (8 * i)) & 0xffu);
+        const float sv = blocked ? -INFINITY : sacc[4 * g + i] * scale;
+        sacc[4 * g + i] = sv;
+        m_t = fmaxf(m_t, sv);
+      }
+    }
+    m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));                 // the two lane halves hold different keys of the same query
+    const float m_new = fmaxf(m_run, m_t);
+    const bool dead = m_new == -INFINITY;                       // everything blocked so far
+    const float alpha = dead ? 1.f : __expf(m_run - m_new);
+    float psum = 0.f;
+    bf16x4 preg[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float p[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        p[i] = dead ? 0.f : __expf(sacc[4 * g + i] - m_new);
+        psum += p[i];
+      }
+      preg[g] = pack4(p[0], p[1], p[2], p[3]);
+    }
+    l_part = l_part * alpha + psum;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[e] *= alpha;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)                                  // O^T[d][query] += V^T[d][keys] . P[query][keys]
+      mma(oacc, gather4(&Vs[buf][8 * j + 4 * hh][r], LR), preg[j]);
+    m_run = m_new;
+    if (t + 1 < ntile) lstore(buf ^ 1, nxt);
+    __syncthreads();
+  }
+  const float l_run = l_part + __shfl_xor(l_part, 32, 64);
+  if (!qvalid) return;
+  const int64_t bh = (int64_t)b * H + h;
+  if (nchunk == 1) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    bf16_t *dst = o + ((int64_t)qi * B + b) * rs + h * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<bf16x4 *>(dst + 8 * g + 4 * hh) = pack4(oacc[4 * g] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv);
+    if (hh == 0) lse[bh * Lq + qi] = l_run > 0.f ? m_run + __logf(l_run) : -INFINITY;
+  } else {
+    const int64_t base = (bh * nchunk + chunk) * Lq + qi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4 *>(part_o + base * D + 8 * g + 4 * hh) = make_float4(oacc[4 * g], oacc[4 * g + 1], oacc[4 * g + 2], oacc[4 * g + 3]);
+    if (hh == 0) { part_ml[base * 2] = m_run; part_ml[base * 2 + 1] = l_run; }
+  }
+}
+
+// one workgroup = KC_DQ keys of one (image, head); wave w owns key tiles w, w+4, ...: dK / dV of a tile are complete
+// in registers after the loop over the query sub-tiles, dQ is accumulated over the wave's tiles, reduced over the
+// four waves through LDS and leaves as one partial per workgroup (attn_bwd_dq_reduce sums the partials).
+template <bool MASK>
+__global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k,
+                                                     const bf16_t *__restrict__ v, const uint8_t *__restrict__ mask,
+                                                     const bf16_t *__restrict__ o, const bf16_t *__restrict__ d_o,
+                                                     const float *__restrict__ lse, float *__restrict__ part_dq,
+                                                     bf16_t *__restrict__ dq, bf16_t *__restrict__ dk, bf16_t *__restrict__ dv,
+                                                     int B, int H, int Lq, int Lk, float scale, int nchunk)
+{
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[MQ][LR];
+  __shared__ __attribute__((aligned(16))) bf16_t Os[MQ][LR];          // dO rows
+  __shared__ __attribute__((aligned(16))) bf16_t Qt[D][LT];
+  __shared__ __attribute__((aligned(16))) bf16_t Ot[D][LT];           // dO^T
+  __shared__ __attribute__((aligned(16))) float Ls[MQ];
+  __shared__ __attribute__((aligned(16))) float Ds[MQ];
+  __shared__ __attribute__((aligned(16))) bf16_t Kw[4][32][LR];       // per-wave K tile for the K^T gathers
+  __shared__ float dqs[MQ][D + 1];
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int64_t rs = (int64_t)H * D;
+  const int64_t bh = (int64_t)b * H + h;
+  // ---- stage all queries of this (image, head): Q, dO row-major and transposed, delta = rowsum(dO * O), lse
+  for (int idx = tid; idx < MQ * 4; idx += 256) {
+    const int row = idx >> 2, piece = idx & 3;
+    uint4 qv = make_uint4(0, 0, 0, 0), gv = qv, ov = qv;
+    if (row < Lq) {
+      const int64_t off = ((int64_t)row * B + b) * rs + h * D + piece * 8;
+      qv = *reinterpret_cast<const uint4 *>(q + off);
+      gv = *reinterpret_cast<const uint4 *>(d_o + off);
+      ov = *reinterpret_cast<const uint4 *>(o + off);
+    }
+    *reinterpret_cast<uint2 *>(&Qs[row][piece * 8]) = make_uint2(qv.x, qv.y);
+    *reinterpret_cast<uint2 *>(&Qs[row][piece * 8 + 4]) = make_uint2(qv.z, qv.w);
+    *reinterpret_cast<uint2 *>(&Os[row][piece * 8]) = make_uint2(gv.x, gv.y);
+    *reinterpret_cast<uint2 *>(&Os[row][piece * 8 + 4]) = make_uint2(gv.z, gv.w);
+    const unsigned qa[4] = {qv.x, qv.y, qv.z, qv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w}, oa[4] = {ov.x, ov.y, ov.z, ov.w};
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Qt[piece * 8 + 2 * i][row] = (bf16_t)(qa[i] & 0xffffu);
+      Qt[piece * 8 + 2 * i + 1][row] = (bf16_t)(qa[i] >> 16);
+      Ot[piece * 8 + 2 * i][row] = (bf16_t)(ga[i] & 0xffffu);
+      Ot[piece * 8 + 2 * i + 1][row] = (bf16_t)(ga[i] >> 16);
+      part += bf2f((bf16_t)(ga[i] & 0xffffu)) * bf2f((bf16_t)(oa[i] & 0xffffu)) + bf2f((bf16_t)(ga[i] >> 16)) * bf2f((bf16_t)(oa[i] >> 16));
+    }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    if (piece == 0) {
+      Ds[row] = part;
+      float l = INFINITY;                       // rows past Lq, and rows whose keys were all blocked: p = exp(s - inf) = 0
+      if (row < Lq) {
+        l = lse[bh * Lq + row];
+        if (l == -INFINITY) l = INFINITY;
+      }
+      Ls[row] = l;
+    }
+  }
+  __syncthreads();
+  const int kbeg = chunk * KC_DQ, kend = min(Lk, kbeg + KC_DQ);
+  const int ntile = (kend - kbeg + 31) / 32;
+  const int nsub = (Lq + 31) / 32;
+  const bool aligned = (Lk & 3) == 0;
+  f32x16 dqacc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dqacc[s][e] = 0.f;
+  for (int t0 = 0; t0 < ntile; t0 += 4) {                    // uniform trip count: every wave reaches the barriers
+    const int t = t0 + wave;
+    const bool tvalid = t < ntile;
+    const int kbase = kbeg + 32 * t;
+    const int key = kbase + r;
+    const bool kvalid = tvalid && key < kend;
+    bf16x4 kreg[4], vreg[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kreg[s] = bf16x4{0, 0, 0, 0};
+      vreg[s] = bf16x4{0, 0, 0, 0};
+      if (kvalid) {
+        const int64_t off = ((int64_t)key * B + b) * rs + h * D + 8 * s + 4 * hh;
+        kreg[s] = *reinterpret_cast<const bf16x4 *>(k + off);
+        vreg[s] = *reinterpret_cast<const bf16x4 *>(v + off);
+      }
+    }
+    __syncthreads();                                           // previous round's K^T gathers are done
+#pragma unroll
+    for (int s = 0; s < 4; ++s) *reinterpret_cast<bf16x4 *>(&Kw[wave][r][8 * s + 4 * hh]) = kreg[s];
+    __syncthreads();
+    bf16x4 ktreg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ktreg[j] = gather4(&Kw[wave][8 * j + 4 * hh][r], LR);
+    f32x16 dkacc, dvacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dkacc[e] = 0.f; dvacc[e] = 0.f; }
+    if (tvalid) {
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        if (sub < nsub) {
+          const int ql = 32 * sub + r;
+          bf16x4 qreg[4], greg[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            qreg[s] = lds4(&Qs[ql][8 * s + 4 * hh]);
+            greg[s] = lds4(&Os[ql][8 * s + 4 * hh]);
+          }
+          // ---- phase A: lane = query, registers = keys
+          f32x16 sT, dpT;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { sT[e] = 0.f; dpT[e] = 0.f; }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) { mma(sT, kreg[s], qreg[s]); mma(dpT, vreg[s], greg[s]); }
+          const float lse_q = Ls[ql], delta_q = Ds[ql];
+          const uint8_t *mrow = (MASK && ql < Lq) ? mask + ((int64_t)b * Lq + ql) * Lk : nullptr;
+          unsigned mybits = 0;                                 // bit i: query (32*sub + i) may not attend key (kbase + lane%32)
+          bf16x4 dsT[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int key0 = kbase + 8 * g + 4 * hh;
+            const unsigned m4 = mrow ? mask4(mrow, key0, Lk, aligned) : 0u;
+            float ds[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const bool blocked = (key0 + i >= kend) || ((m4 >> (8 * i)) & 0xffu);
+              const float p = blocked ? 0.f : __expf(sT[4 * g + i] * scale - lse_q);
+              ds[i] = p * (dpT[4 * g + i] - delta_q);
+              const unsigned long long bal = __ballot(blocked);
+              if (r == 8 * g + i) mybits = (unsigned)bal;              // lanes of half 0 carry key 8g + i
+              if (r == 8 * g + 4 + i) mybits = (unsigned)(bal >> 32);  // lanes of half 1 carry key 8g + 4 + i
+            }
+            dsT[g] = pack4(ds[0], ds[1], ds[2], ds[3]);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mma(dqacc[sub], ktreg[j], dsT[j]);            // dQ^T[d][query] += K^T[d][keys] . dS^T
+          // ---- phase B: lane = key, registers = queries
+          f32x16 sN, dpN;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { sN[e] = 0.f; dpN[e] = 0.f; }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) { mma(sN, qreg[s], kreg[s]); mma(dpN, greg[s], vreg[s]); }
+          bf16x4 pN[4], dsN[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 l4 = *reinterpret_cast<const float4 *>(&Ls[32 * sub + 8 * g + 4 * hh]);
+            const float4 d4 = *reinterpret_cast<const float4 *>(&Ds[32 * sub + 8 * g + 4 * hh]);
+            const float la[4] = {l4.x, l4.y, l4.z, l4.w}, da[4] = {d4.x, d4.y, d4.z, d4.w};
+            float p[4], ds[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const bool blocked = (mybits >> (8 * g + 4 * hh + i)) & 1u;
+              p[i] = blocked ? 0.f : __expf(sN[4 * g + i] * scale - la[i]);
+              ds[i] = p[i] * (dpN[4 * g + i] - da[i]);
+            }
+            pN[g] = pack4(p[0], p[1], p[2], p[3]);
+            dsN[g] = pack4(ds[0], ds[1], ds[2], ds[3]);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            mma(dvacc, lds4(&Ot[r][32 * sub + 8 * j + 4 * hh]), pN[j]);                // dV^T[d][key] += dO^T[d][queries] . P
+            mma(dkacc, lds4(&Qt[r][32 * sub + 8 * j + 4 * hh]), dsN[j]);               // dK^T[d][key] += Q^T[d][queries] . dS
+          }
+        }
+      }
+      if (kvalid) {
+        bf16_t *dkp = dk + ((int64_t)key * B + b) * rs + h * D, *dvp = dv + ((int64_t)key * B + b) * rs + h * D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          *reinterpret_cast<bf16x4 *>(dkp + 8 * g + 4 * hh) = pack4(dkacc[4 * g] * scale, dkacc[4 * g + 1] * scale, dkacc[4 * g + 2] * scale, dkacc[4 * g + 3] * scale);
+          *reinterpret_cast<bf16x4 *>(dvp + 8 * g + 4 * hh) = pack4(dvacc[4 * g], dvacc[4 * g + 1], dvacc[4 * g + 2], dvacc[4 * g + 3]);
+        }
+      }
+    }
+  }
+  // ---- dQ: sum the four waves through LDS, then one partial per workgroup (or dq itself when there is one chunk)
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int d = (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (w == 0) dqs[32 * sub + r][d] = dqacc[sub][e];
+          else dqs[32 * sub + r][d] += dqacc[sub][e];
+        }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < Lq * D; idx += 256) {
+    const int qq = idx >> 5, d = idx & 31;
+    const float val = dqs[qq][d] * scale;
+    if (nchunk == 1) dq[((int64_t)qq * B + b) * rs + h * D + d] = f2bf(val);
+    else part_dq[((bh * nchunk + chunk) * Lq + qq) * D + d] = val;
+  }
+}
+
 inline int nchunks(int Lk, int kc) { return Lk <= 0 ? 1 : (Lk + kc - 1) / kc; }
 
 int check(const void *a, const void *b, const void *c, int B, int H, int Lq, int Lk, int dtype, const char *who)
@@ -369,6 +726,8 @@ int check(const void *a, const void *b, const void *c, int B, int H, int Lq, int
 }
 
 }  // namespace
+
+int g_pd_dbg_attn_scalar = 0;     // experiment knob: 1 forces the scalar kernels for bf16 too
 
 extern "C" int64_t pd_attn_workspace_floats(int B, int H, int Lq, int Lk)
 {
@@ -387,6 +746,14 @@ extern "C" int pd_attn_fwd_d32(const void *q, const void *k, const void *v, cons
   hipStream_t s = (hipStream_t)stream_;
   const int nc = nchunks(Lk, KC_FWD);
   float *part_o = workspace, *part_ml = workspace + (int64_t)B * H * nc * Lq * D;
+  if (dtype == PD_BF16 && Lq <= MQ && Lk > 0 && !g_pd_dbg_attn_scalar) {           // matrix-core path
+    if (mask) hipLaunchKernelGGL(attn_fwd_mfma<true>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
+                                 mask, (bf16_t *)o, lse, part_o, part_ml, B, H, Lq, Lk, scale, nc);
+    else hipLaunchKernelGGL(attn_fwd_mfma<false>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
+                            mask, (bf16_t *)o, lse, part_o, part_ml, B, H, Lq, Lk, scale, nc);
+    if (nc > 1) hipLaunchKernelGGL(attn_fwd_combine<bf16_t>, dim3((B * H * Lq + 7) / 8), dim3(256), 0, s, part_o, part_ml, (bf16_t *)o, lse, B, H, Lq, nc);
+    return pd_check_launch("pd_attn_fwd_d32");
+  }
   for (int qp = 0; qp * QP < Lq; ++qp) {
     if (dtype == PD_BF16)
       hipLaunchKernelGGL(attn_fwd_partial<bf16_t>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k,
@@ -414,6 +781,16 @@ extern "C" int pd_attn_bwd_d32(const void *q, const void *k, const void *v, cons
   hipStream_t s = (hipStream_t)stream_;
   const int nc = nchunks(Lk, KC_DQ);
   const int groups = B * H * Lq;
+  if (dtype == PD_BF16 && Lq <= MQ && !g_pd_dbg_attn_scalar) {                     // matrix-core path
+    if (mask) hipLaunchKernelGGL(attn_bwd_mfma<true>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
+                                 mask, (const bf16_t *)o, (const bf16_t *)d_o, lse, workspace, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv,
+                                 B, H, Lq, Lk, scale, nc);
+    else hipLaunchKernelGGL(attn_bwd_mfma<false>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
+                            mask, (const bf16_t *)o, (const bf16_t *)d_o, lse, workspace, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv,
+                            B, H, Lq, Lk, scale, nc);
+    if (nc > 1) hipLaunchKernelGGL(attn_bwd_dq_reduce<bf16_t>, dim3((groups + 7) / 8), dim3(256), 0, s, workspace, (bf16_t *)dq, B, H, Lq, nc);
+    return pd_check_launch("pd_attn_bwd_d32");
+  }
   if (dtype == PD_BF16) {
     for (int qp = 0; qp * QP < Lq; ++qp)
       hipLaunchKernelGGL(attn_bwd_dq<bf16_t>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,

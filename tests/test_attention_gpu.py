@@ -19,7 +19,8 @@ def _ref(q, k, v, mask, H):
 
 
 @pytest.mark.parametrize("Lq,Lk,B,H,masked", [(100, 16384, 2, 8, True), (100, 4096, 2, 8, True), (100, 1024, 2, 8, True),
-                                              (100, 100, 2, 8, False), (200, 1600, 1, 8, True), (7, 70, 3, 2, True), (130, 257, 1, 4, False)])
+                                              (100, 100, 2, 8, False), (200, 1600, 1, 8, True), (7, 70, 3, 2, True), (130, 257, 1, 4, False),
+                                              (128, 513, 2, 8, True), (33, 31, 1, 1, True), (100, 100, 2, 8, True)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_masked_attention_fwd_bwd(Lq, Lk, B, H, masked, dtype):
     from partdistillation_amd.functions.attention import masked_attention_d32
@@ -45,9 +46,11 @@ def test_masked_attention_fwd_bwd(Lq, Lk, B, H, masked, dtype):
     torch.testing.assert_close(dv.double(), rv, **tol)
 
 
-def test_fully_blocked_rows_give_zero():
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fully_blocked_rows_give_zero(dtype):
     from partdistillation_amd.functions.attention import masked_attention_d32
-    q = torch.randn(5, 1, 64, device="cuda"); k = torch.randn(300, 1, 64, device="cuda"); v = torch.randn(300, 1, 64, device="cuda")
+    q = torch.randn(5, 1, 64, device="cuda").to(dtype); k = torch.randn(300, 1, 64, device="cuda").to(dtype)
+    v = torch.randn(300, 1, 64, device="cuda").to(dtype)
     mask = torch.zeros(1, 5, 300, dtype=torch.bool, device="cuda")
     mask[0, 2] = True
     q.requires_grad_()
