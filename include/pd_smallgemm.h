@@ -1,0 +1,40 @@
+/*
+ * pd_smallgemm.h — C-ABI of the bf16 matrix-core GEMMs for SKINNY activations (tens to a few hundred rows) of
+ * libpd_hip.so: the query side of the masked-attention decoder multiplies [Q*B = 200, 256..2048] activations by
+ * 256 x 256 .. 2048 x 256 weights ~330 times per training step
+ *   reference transformer_decoder/mask2former_transformer_decoder.py:44-54, 102-114, 167-171 (attention in/out
+ *   projections, FFN) and :198-204 (the 3-layer mask-embedding MLP).
+ * A general GEMM library maps such a product to ONE 256 x 256 tile = one workgroup (measured 14-18 us each, and ~20 us
+ * of host time per call to pick it); these kernels cut the same product into 32 x 128 tiles so 14..128 workgroups share
+ * it, take bias / ReLU / ReLU-mask / bias-gradient in the same pass, and are launched directly.
+ *
+ * All matrices row-major bf16 with leading dimensions in ELEMENTS (multiples of 8, 16-byte aligned bases); fp32
+ * accumulation on v_mfma_f32_32x32x8_bf16_1k; results rounded to nearest even.  `stream` = hipStream_t; 0 or PD_ERR_*.
+ */
+#ifndef PD_SMALLGEMM_H
+#define PD_SMALLGEMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Y[M,N] = X[M,K] . W[N,K]^T (+ bias[N]) (then ReLU if relu != 0)      nn.Linear forward.   K % 64 == 0, N % 4 == 0. */
+int pd_sgemm_tn_bf16(const void *X, const void *W, const void *bias, void *Y, int M, int N, int K, int ldx, int ldw, int ldy,
+                     int relu, void *stream);
+
+/* dX[M,K] (+)= dY[M,N] . W[N,K], then dX *= (relu_ref[M,K] > 0) when relu_ref != NULL (ld = ldx)
+ * nn.Linear input gradient, optionally through the ReLU that produced this layer's input.   N % 64 == 0, K % 4 == 0. */
+int pd_sgemm_nn_bf16(const void *dY, const void *W, const void *relu_ref, void *dX, int M, int N, int K, int ldy, int ldw,
+                     int ldx, int accumulate, void *stream);
+
+/* dW[N,K] = dY[M,N]^T . X[M,K];  dB[N] (fp32, nullable) = column sums of dY       nn.Linear weight / bias gradient.
+ * Any M >= 0 (rows past M count as zeros); N % 4 == 0, K % 4 == 0. */
+int pd_sgemm_wgrad_bf16(const void *dY, const void *X, void *dW, float *dB, int M, int N, int K, int ldy, int ldx, int ldw,
+                        void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PD_SMALLGEMM_H */

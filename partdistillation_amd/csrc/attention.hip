@@ -16,6 +16,7 @@
 
 #include "pd_attention.h"
 #include "pd_common.h"
+#include "mfma_bf16.h"
 #include "pd_msda.h"
 
 namespace {
@@ -366,36 +367,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv(const T *__restrict__ q, con
 // therefore produced directly in the layout the second GEMM wants as an operand (lane = query, 4 consecutive keys
 // per register group, or lane = key, 4 consecutive queries), so nothing is transposed through LDS except the
 // "4 keys at fixed channel" operands (V^T forward, K^T backward), gathered from row-major LDS tiles with 16-bit reads.
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using pdmfma::bf16x4;
+using pdmfma::f32x16;
+using pdmfma::gather4;
+using pdmfma::lds4;
+using pdmfma::mma;
+using pdmfma::pack4;
 
 constexpr int LR = 36;     // bf16 per padded LDS row of a [rows][32] tile: 72-byte rows, 8-byte reads conflict-free
 constexpr int LT = 132;    // bf16 per padded row of a transposed [32][128] tile
 constexpr int MQ = 128;    // queries the MFMA path covers
 
-typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// round-to-nearest-even fp32 -> bf16 pair: the compiler emits v_cvt_pk_bf16_f32 (gfx950) and, unlike inline asm, knows the
-// wait states an MFMA that reads the result needs
-__device__ __forceinline__ unsigned pk_bf16(float lo, float hi)
-{
-  const f32x2 x = {lo, hi};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(x, hwbf16x2));
-}
-__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d)
-{
-  union { unsigned u[2]; bf16x4 v; } x;
-  x.u[0] = pk_bf16(a, b); x.u[1] = pk_bf16(c, d);
-  return x.v;
-}
-__device__ __forceinline__ void mma(f32x16 &c, bf16x4 x, bf16x4 y) { c = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(x, y, c, 0, 0, 0); }
-__device__ __forceinline__ bf16x4 lds4(const bf16_t *p) { return *reinterpret_cast<const bf16x4 *>(p); }
-__device__ __forceinline__ bf16x4 gather4(const bf16_t *p, int stride)      // 4 elements `stride` apart
-{
-  bf16x4 r;
-  r[0] = (short)p[0]; r[1] = (short)p[stride]; r[2] = (short)p[2 * stride]; r[3] = (short)p[3 * stride];
-  return r;
-}
 // 4 mask bytes of keys key0..key0+3 of one mask row (as a little-endian u32); bytes at or past Lk read as 0
 __device__ __forceinline__ unsigned mask4(const uint8_t *row, int key0, int Lk, bool aligned)
 {

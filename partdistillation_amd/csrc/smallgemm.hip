@@ -1,0 +1,268 @@
+// bf16 matrix-core GEMMs for skinny activations (gfx950): 32 x 128 output tiles, 64-deep chunks double-buffered through
+// LDS, one 32 x 32 sub-tile per wavefront on v_mfma_f32_32x32x8_bf16_1k.  C-ABI in include/pd_smallgemm.h.
+//   tn     Y = X W^T (+bias)(ReLU)   both operands are read as "row, 4 consecutive k": 8-byte LDS reads
+//   nn     dX = dY W                 the W operand is "4 consecutive n at fixed k": four 16-bit LDS reads
+//   wgrad  dW = dY^T X               both operands are "4 consecutive m at fixed column": 16-bit LDS reads
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mfma_bf16.h"
+#include "pd_common.h"
+#include "pd_msda.h"
+#include "pd_smallgemm.h"
+
+namespace {
+
+using namespace pdmfma;
+
+constexpr int P64 = 68;     // padded LDS row (bf16 elements) of a 64-column tile: 136-byte rows, 8-byte reads conflict-free
+constexpr int P128 = 136;   // padded row of a 128-column tile
+constexpr int P32 = 40;     // padded row of a 32-column tile
+
+// 8 bf16 (16 bytes) of a [nrows x ncols] row-major matrix at (row, col), zeros outside; ncols % 4 == 0, col % 8 == 0
+__device__ __forceinline__ uint4 load_piece(const bf16_t *base, int ld, int row, int col, int nrows, int ncols)
+{
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (row >= nrows || col >= ncols) return v;
+  const bf16_t *p = base + (int64_t)row * ld + col;
+  if (col + 8 <= ncols) return *reinterpret_cast<const uint4 *>(p);
+  const uint2 h = *reinterpret_cast<const uint2 *>(p);                     // 4 valid elements
+  v.x = h.x; v.y = h.y;
+  return v;
+}
+__device__ __forceinline__ void store_piece(bf16_t *dst, uint4 v)          // 8-byte aligned LDS destination
+{
+  *reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
+  *reinterpret_cast<uint2 *>(dst + 4) = make_uint2(v.z, v.w);
+}
+
+// ------------------------------------------------------------------------------------------------ Y = X W^T
+template <bool RELU>
+__global__ __launch_bounds__(256) void sgemm_tn(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
+                                                const bf16_t *__restrict__ bias, bf16_t *__restrict__ Y, int M, int N, int K,
+                                                int ldx, int ldw, int ldy)
+{
+  __shared__ __attribute__((aligned(16))) bf16_t Xs[2][32][P64];
+  __shared__ __attribute__((aligned(16))) bf16_t Ws[2][128][P64];
+  const int nb = blockIdx.x * 128, mb = blockIdx.y * 32;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int prow = tid >> 3, pcol = (tid & 7) * 8;                          // 32 rows x 8 pieces per 256 threads
+  uint4 xr, wr[4];
+  auto gload = [&](int k0) {
+    xr = load_piece(X, ldx, mb + prow, k0 + pcol, M, K);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wr[i] = load_piece(W, ldw, nb + prow + 32 * i, k0 + pcol, N, K);
+  };
+  auto lstore = [&](int buf) {
+    store_piece(&Xs[buf][prow][pcol], xr);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_piece(&Ws[buf][prow + 32 * i][pcol], wr[i]);
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int nchunk = K / 64;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) gload((c + 1) * 64);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)                                             // acc[n][m] += W[n][k..] . X[m][k..]
+      mma(acc, lds4(&Ws[buf][32 * wave + r][8 * s + 4 * hh]), lds4(&Xs[buf][r][8 * s + 4 * hh]));
+    if (c + 1 < nchunk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  const int m = mb + r;
+  if (m >= M) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n0 = nb + 32 * wave + 8 * g + 4 * hh;
+    if (n0 >= N) continue;
+    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    if (bias) {
+      const uint2 b = *reinterpret_cast<const uint2 *>(bias + n0);
+      v[0] += bf_lo(b.x); v[1] += bf_hi(b.x); v[2] += bf_lo(b.y); v[3] += bf_hi(b.y);
+    }
+    if (RELU) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    *reinterpret_cast<bf16x4 *>(Y + (int64_t)m * ldy + n0) = pack4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dX = dY W
+template <bool ACC, bool MASK>
+__global__ __launch_bounds__(256) void sgemm_nn(const bf16_t *__restrict__ dY, const bf16_t *__restrict__ W,
+                                                const bf16_t *__restrict__ ref, bf16_t *__restrict__ dX, int M, int N, int K,
+                                                int ldy, int ldw, int ldx)
+{
+  __shared__ __attribute__((aligned(16))) bf16_t Ys[2][32][P64];
+  __shared__ __attribute__((aligned(16))) bf16_t Ws[2][64][P128];
+  const int kb = blockIdx.x * 128, mb = blockIdx.y * 32;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int yrow = tid >> 3, ycol = (tid & 7) * 8;                          // dY chunk: 32 rows x 8 pieces
+  const int wrow = tid >> 4, wcol = (tid & 15) * 8;                         // W chunk: 64 rows x 16 pieces, 4 per thread
+  uint4 yr, wr[4];
+  auto gload = [&](int n0) {
+    yr = load_piece(dY, ldy, mb + yrow, n0 + ycol, M, N);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wr[i] = load_piece(W, ldw, n0 + wrow + 16 * i, kb + wcol, N, K);
+  };
+  auto lstore = [&](int buf) {
+    store_piece(&Ys[buf][yrow][ycol], yr);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_piece(&Ws[buf][wrow + 16 * i][wcol], wr[i]);
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int nchunk = N / 64;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) gload((c + 1) * 64);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)                                             // acc[k][m] += W^T[k][n..] . dY[m][n..]
+      mma(acc, gather4(&Ws[buf][8 * s + 4 * hh][32 * wave + r], P128), lds4(&Ys[buf][r][8 * s + 4 * hh]));
+    if (c + 1 < nchunk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  const int m = mb + r;
+  if (m >= M) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int k0 = kb + 32 * wave + 8 * g + 4 * hh;
+    if (k0 >= K) continue;
+    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    bf16_t *dst = dX + (int64_t)m * ldx + k0;
+    if (ACC) {
+      const uint2 o = *reinterpret_cast<const uint2 *>(dst);
+      v[0] += bf_lo(o.x); v[1] += bf_hi(o.x); v[2] += bf_lo(o.y); v[3] += bf_hi(o.y);
+    }
+    if (MASK) {
+      const uint2 h = *reinterpret_cast<const uint2 *>(ref + (int64_t)m * ldx + k0);
+      if (!(bf_lo(h.x) > 0.f)) v[0] = 0.f;
+      if (!(bf_hi(h.x) > 0.f)) v[1] = 0.f;
+      if (!(bf_lo(h.y) > 0.f)) v[2] = 0.f;
+      if (!(bf_hi(h.y) > 0.f)) v[3] = 0.f;
+    }
+    *reinterpret_cast<bf16x4 *>(dst) = pack4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dW = dY^T X
+__global__ __launch_bounds__(256) void sgemm_wgrad(const bf16_t *__restrict__ dY, const bf16_t *__restrict__ X,
+                                                   bf16_t *__restrict__ dW, float *__restrict__ dB, int M, int N, int K, int ldy,
+                                                   int ldx, int ldw)
+{
+  __shared__ __attribute__((aligned(16))) bf16_t Ys[2][64][P32];
+  __shared__ __attribute__((aligned(16))) bf16_t Xs[2][64][P128];
+  const int kb = blockIdx.x * 128, nb = blockIdx.y * 32;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int yrow = tid >> 2, ycol = (tid & 3) * 8;                          // dY chunk: 64 rows x 4 pieces
+  const int xrow = tid >> 4, xcol = (tid & 15) * 8;                         // X chunk: 64 rows x 16 pieces, 4 per thread
+  uint4 yr, xr[4];
+  auto gload = [&](int m0) {
+    yr = load_piece(dY, ldy, m0 + yrow, nb + ycol, M, N);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xr[i] = load_piece(X, ldx, m0 + xrow + 16 * i, kb + xcol, M, K);
+  };
+  auto lstore = [&](int buf) {
+    store_piece(&Ys[buf][yrow][ycol], yr);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_piece(&Xs[buf][xrow + 16 * i][xcol], xr[i]);
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const bool do_bias = dB != nullptr && blockIdx.x == 0 && wave == 0;      // the k-tile-0 workgroup also sums its dY columns
+  float bsum = 0.f;
+  const int nchunk = (M + 63) / 64;
+  if (nchunk > 0) { gload(0); lstore(0); }
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) gload((c + 1) * 64);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)                                             // acc[n][k] += dY^T[n][m..] . X^T[k][m..]
+      mma(acc, gather4(&Ys[buf][8 * s + 4 * hh][r], P32), gather4(&Xs[buf][8 * s + 4 * hh][32 * wave + r], P128));
+    if (do_bias) {
+#pragma unroll 8
+      for (int i = 0; i < 32; ++i) bsum += __uint_as_float((unsigned)Ys[buf][32 * hh + i][r] << 16);
+    }
+    if (c + 1 < nchunk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (hh == 0 && nb + r < N) dB[nb + r] = bsum;
+  }
+  const int k = kb + 32 * wave + r;
+  if (k >= K) return;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int n = nb + (e & 3) + 8 * (e >> 2) + 4 * hh;
+    if (n < N) dW[(int64_t)n * ldw + k] = (bf16_t)(pk_bf16(acc[e], 0.f) & 0xffffu);
+  }
+}
+
+bool ok_ptr(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+int check_common(const char *who, const void *a, const void *b, const void *c, int M, int N, int K, int l0, int l1, int l2)
+{
+  if (M < 0 || N < 0 || K < 0) return pd_set_error(PD_ERR_INVALID_ARG, "%s: negative size", who);
+  if (M > 0 && N > 0 && K > 0 && (!a || !b || !c)) return pd_set_error(PD_ERR_INVALID_ARG, "%s: null pointer", who);
+  if ((l0 & 7) || (l1 & 7) || (l2 & 7) || !ok_ptr(a) || !ok_ptr(b) || !ok_ptr(c))
+    return pd_set_error(PD_ERR_INVALID_ARG, "%s: leading dimensions must be multiples of 8 and bases 16-byte aligned", who);
+  return PD_OK;
+}
+
+}  // namespace
+
+extern "C" int pd_sgemm_tn_bf16(const void *X, const void *W, const void *bias, void *Y, int M, int N, int K, int ldx, int ldw,
+                                int ldy, int relu, void *stream_)
+{
+  int rc = check_common("pd_sgemm_tn_bf16", X, W, Y, M, N, K, ldx, ldw, ldy);
+  if (rc) return rc;
+  if ((K % 64) || (N & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_tn_bf16: K=%d must be a multiple of 64 and N=%d of 4", K, N);
+  if (bias && ((uintptr_t)bias & 7)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_tn_bf16: bias must be 8-byte aligned");
+  if (M == 0 || N == 0) return PD_OK;
+  const dim3 g((N + 127) / 128, (M + 31) / 32), b(256);
+  hipStream_t s = (hipStream_t)stream_;
+  if (relu) hipLaunchKernelGGL(sgemm_tn<true>, g, b, 0, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, M, N, K, ldx, ldw, ldy);
+  else hipLaunchKernelGGL(sgemm_tn<false>, g, b, 0, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, M, N, K, ldx, ldw, ldy);
+  return pd_check_launch("pd_sgemm_tn_bf16");
+}
+
+extern "C" int pd_sgemm_nn_bf16(const void *dY, const void *W, const void *relu_ref, void *dX, int M, int N, int K, int ldy,
+                                int ldw, int ldx, int accumulate, void *stream_)
+{
+  int rc = check_common("pd_sgemm_nn_bf16", dY, W, dX, M, N, K, ldy, ldw, ldx);
+  if (rc) return rc;
+  if ((N % 64) || (K & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_nn_bf16: N=%d must be a multiple of 64 and K=%d of 4", N, K);
+  if (M == 0 || K == 0) return PD_OK;
+  const dim3 g((K + 127) / 128, (M + 31) / 32), b(256);
+  hipStream_t s = (hipStream_t)stream_;
+#define LAUNCH(A, R) hipLaunchKernelGGL((sgemm_nn<A, R>), g, b, 0, s, (const bf16_t *)dY, (const bf16_t *)W, (const bf16_t *)relu_ref, (bf16_t *)dX, M, N, K, ldy, ldw, ldx)
+  if (accumulate) { if (relu_ref) LAUNCH(true, true); else LAUNCH(true, false); }
+  else { if (relu_ref) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+  return pd_check_launch("pd_sgemm_nn_bf16");
+}
+
+extern "C" int pd_sgemm_wgrad_bf16(const void *dY, const void *X, void *dW, float *dB, int M, int N, int K, int ldy, int ldx,
+                                   int ldw, void *stream_)
+{
+  int rc = check_common("pd_sgemm_wgrad_bf16", M > 0 ? dY : dW, M > 0 ? X : dW, dW, M, N, K, ldy, ldx, 8);
+  if (rc) return rc;
+  if ((N & 3) || (K & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_wgrad_bf16: N=%d and K=%d must be multiples of 4", N, K);
+  if (N == 0 || K == 0) return PD_OK;
+  const dim3 g((K + 127) / 128, (N + 31) / 32), b(256);
+  hipLaunchKernelGGL(sgemm_wgrad, g, b, 0, (hipStream_t)stream_, (const bf16_t *)dY, (const bf16_t *)X, (bf16_t *)dW, dB, M, N, K, ldy, ldx, ldw);
+  return pd_check_launch("pd_sgemm_wgrad_bf16");
+}

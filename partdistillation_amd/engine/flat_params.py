@@ -21,7 +21,7 @@ from ..functions.fused import GatherPlan
 
 
 def _aligned(n):
-    return (n + 3) // 4 * 4                                       # keep every tensor 16-byte aligned (fp32)
+    return (n + 7) // 8 * 8                                       # every tensor 16-byte aligned in the bf16 copy too
 
 
 class FlatGroup:

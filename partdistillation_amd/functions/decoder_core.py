@@ -23,6 +23,7 @@ import torch
 from torch.autograd import Function
 
 from . import rowwise as rw
+from . import smallgemm as sg
 from .attention import attn_bwd_raw, attn_fwd_raw
 
 
@@ -34,12 +35,47 @@ class DecoderSpec:
         self.sizes, self.pos, self.pooled, self.eps, self.cdt, self.num_levels = sizes, pos_tables, pooled, eps, cdt, num_levels
 
 
-def _lin(x, w, b):
-    return torch.addmm(b, x, w.t())
+SMALL_M = 1024      # rows up to which the skinny-activation kernels (pd_sgemm_*) are used instead of the GEMM library
+
+
+def _small(x, cdt):
+    return cdt == torch.bfloat16 and x.shape[0] <= SMALL_M
+
+
+def _lin(x, w, b, relu=False):
+    """x W^T + b (ReLU)"""
+    if _small(x, x.dtype) and w.shape[1] % 64 == 0:
+        return sg.linear(x, w, b, relu)
+    y = torch.addmm(b, x, w.t())
+    return torch.relu_(y) if relu else y
 
 
 def _lin_relu(x, w, b):
-    return torch.relu_(torch.addmm(b, x, w.t()))
+    return _lin(x, w, b, True)
+
+
+def _dgrad(dy, w, relu_ref=None, out=None, accumulate=False):
+    """dy W (+= into out) (masked by relu_ref > 0)"""
+    if _small(dy, dy.dtype) and w.shape[0] % 64 == 0:
+        return sg.dgrad(dy, w, relu_ref, out, accumulate)
+    if accumulate:
+        out.addmm_(dy, w)
+        dx = out
+    else:
+        dx = torch.mm(dy, w) if out is None else torch.mm(dy, w, out=out)
+    if relu_ref is not None:
+        rw.relu_bwd_colsum(dx, relu_ref, None)
+    return dx
+
+
+def _wgrad(dy, x, out=None, bias_acc=None):
+    """dy^T x -> out (weight gradient);  bias_acc (fp32 accumulator slot, zero on entry) += dy.sum(0)"""
+    if _small(dy, dy.dtype):
+        return sg.wgrad(dy, x, out, bias_acc)
+    dw = torch.mm(dy.t(), x) if out is None else torch.mm(dy.t(), x, out=out)
+    if bias_acc is not None:
+        rw.colsum_acc(dy, bias_acc)
+    return dw
 
 
 class _Acc:
@@ -177,45 +213,43 @@ class DecoderCore(Function):
             dz, dz_c = rw.add_ln_bwd(z, mean, rstd, fnw, dy=dzh, dy2=d_res, dypos_c=d_pos_c, dz_c_dtype=cdt,
                                      dgamma=A(lay[i]["fnw"]), dbeta=A(lay[i]["fnb"]), dbias=A(lay[i]["b2"]),
                                      dpos_acc=A(s_pos) if d_pos_c is not None else None, pos_div=B, out=dzh)
-            g_w2 = torch.mm(dz_c.t(), h)
-            dh = rw.relu_bwd_colsum(torch.mm(dz_c, w2), h, A(lay[i]["b1"]))
-            g_w1 = torch.mm(dh.t(), x_c)
-            dx_c = torch.mm(dh, w1)
+            g_w2 = _wgrad(dz_c, h)
+            dh = _dgrad(dz_c, w2, relu_ref=h)                    # through the ReLU: dh *= (h > 0)
+            g_w1 = _wgrad(dh, x_c, bias_acc=A(lay[i]["b1"]))
+            dx_c = _dgrad(dh, w1)
             # ---- self-attention
             tp_c, t_c, q, k, v, o, lse, z, mean, rstd = slf
             dz, dz_c = rw.add_ln_bwd(z, mean, rstd, snw, dy=dz, dy_c=dx_c, dz_c_dtype=cdt, dgamma=A(lay[i]["snw"]),
                                      dbeta=A(lay[i]["snb"]), dbias=A(lay[i]["sob"]), out=dz)
-            g_sow = torch.mm(dz_c.t(), o)
-            dq, dk, dv = attn_bwd_raw(q, k, v, None, o, torch.mm(dz_c, sow), lse, B, H, scale)
+            g_sow = _wgrad(dz_c, o)
+            dq, dk, dv = attn_bwd_raw(q, k, v, None, o, _dgrad(dz_c, sow), lse, B, H, scale)
             g_siw = torch.empty_like(siw)
-            torch.mm(dq.t(), tp_c, out=g_siw[:C])
-            torch.mm(dk.t(), tp_c, out=g_siw[C:2 * C])
-            torch.mm(dv.t(), t_c, out=g_siw[2 * C:])
             sb = A(lay[i]["sib"])
-            rw.colsum_acc(dq, sb[:C]), rw.colsum_acc(dk, sb[C:2 * C]), rw.colsum_acc(dv, sb[2 * C:])
-            d_tp = torch.mm(dq, siw[:C])
-            d_tp.addmm_(dk, siw[C:2 * C])
-            d_tc = torch.mm(dv, siw[2 * C:])
+            _wgrad(dq, tp_c, g_siw[:C], sb[:C])
+            _wgrad(dk, tp_c, g_siw[C:2 * C], sb[C:2 * C])
+            _wgrad(dv, t_c, g_siw[2 * C:], sb[2 * C:])
+            d_tp = _dgrad(dq, siw[:C])
+            _dgrad(dk, siw[C:2 * C], out=d_tp, accumulate=True)
+            d_tc = _dgrad(dv, siw[2 * C:])
             # ---- cross-attention
             tp_c, q, k, v, mask, o, lse, z, mean, rstd = cross
             dz, dz_c = rw.add_ln_bwd(z, mean, rstd, cnw, dy=dz, dy_c=d_tc, dypos_c=d_tp, dz_c_dtype=cdt,
                                      dgamma=A(lay[i]["cnw"]), dbeta=A(lay[i]["cnb"]), dbias=A(lay[i]["cob"]),
                                      dpos_acc=A(s_pos), pos_div=B, out=dz)
-            g_cow = torch.mm(dz_c.t(), o)
-            dq, dk, dv = attn_bwd_raw(q, k, v, mask, o, torch.mm(dz_c, cow), lse, B, H, scale)
+            g_cow = _wgrad(dz_c, o)
+            dq, dk, dv = attn_bwd_raw(q, k, v, mask, o, _dgrad(dz_c, cow), lse, B, H, scale)
             g_ciw = torch.empty_like(ciw)
-            torch.mm(dq.t(), tp_c, out=g_ciw[:C])
-            torch.mm(dk.t(), ctx.mempos[lvl], out=g_ciw[C:2 * C])
-            torch.mm(dv.t(), ctx.mem[lvl], out=g_ciw[2 * C:])
             cb = A(lay[i]["cib"])
-            rw.colsum_acc(dq, cb[:C]), rw.colsum_acc(dk, cb[C:2 * C]), rw.colsum_acc(dv, cb[2 * C:])
-            d_pos_c = torch.mm(dq, ciw[:C])                                   # -> previous layer's FFN norm (or the queries)
+            _wgrad(dq, tp_c, g_ciw[:C], cb[:C])
+            _wgrad(dk, ctx.mempos[lvl], g_ciw[C:2 * C], cb[C:2 * C])
+            _wgrad(dv, ctx.mem[lvl], g_ciw[2 * C:], cb[2 * C:])
+            d_pos_c = _dgrad(dq, ciw[:C])                                     # -> previous layer's FFN norm (or the queries)
             if dmempos[lvl] is None:
-                dmempos[lvl] = torch.mm(dk, ciw[C:2 * C])
-                dmem[lvl] = torch.mm(dv, ciw[2 * C:])
+                dmempos[lvl] = _dgrad(dk, ciw[C:2 * C])
+                dmem[lvl] = _dgrad(dv, ciw[2 * C:])
             else:
-                dmempos[lvl].addmm_(dk, ciw[C:2 * C])
-                dmem[lvl].addmm_(dv, ciw[2 * C:])
+                _dgrad(dk, ciw[C:2 * C], out=dmempos[lvl], accumulate=True)
+                _dgrad(dv, ciw[2 * C:], out=dmem[lvl], accumulate=True)
             d_res = dz
             wgrads[i] = (g_ciw, g_cow, g_siw, g_sow, g_w1, g_w2)
 

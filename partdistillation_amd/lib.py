@@ -47,6 +47,9 @@ SIGNATURES = {
     "pd_attn_mask_u8": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "pd_msda_prep_fwd": (_c_int, [_c_vp] * 6 + [ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
     "pd_msda_prep_bwd": (_c_int, [_c_vp] * 6 + [ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
+    "pd_sgemm_tn_bf16": (_c_int, [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
+    "pd_sgemm_nn_bf16": (_c_int, [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
+    "pd_sgemm_wgrad_bf16": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_abi_version": (_c_int, []),
     "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),

@@ -1,0 +1,62 @@
+"""GPU parity of the skinny-activation bf16 GEMMs (include/pd_smallgemm.h) against fp32 torch on the same bf16 inputs."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _r(shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, device="cuda", generator=g) * scale).bfloat16()
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 256, 256), (200, 2048, 256), (200, 256, 2048), (2000, 256, 256), (7, 16, 64), (33, 264, 128), (0, 256, 256)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_linear_forward(M, N, K, relu):
+    from partdistillation_amd.functions import smallgemm as sg
+    x, w, b = _r((M, K), 1), _r((N, K), 2, K ** -0.5), _r((N,), 3)
+    y = sg.linear(x, w, b, relu)
+    ref = x.float() @ w.float().t() + b.float()
+    if relu:
+        ref = ref.relu()
+    torch.testing.assert_close(y.float(), ref, rtol=1e-2, atol=1e-2)
+    y2 = sg.linear(x, w, None, relu)
+    ref2 = x.float() @ w.float().t()
+    torch.testing.assert_close(y2.float(), ref2.relu() if relu else ref2, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 256, 256), (200, 2048, 256), (200, 256, 2048), (7, 64, 24), (33, 128, 264)])
+def test_input_gradient(M, N, K):
+    from partdistillation_amd.functions import smallgemm as sg
+    dy, w = _r((M, N), 4), _r((N, K), 5, N ** -0.5)
+    ref = dy.float() @ w.float()
+    torch.testing.assert_close(sg.dgrad(dy, w).float(), ref, rtol=1e-2, atol=1e-2)
+    h = _r((M, K), 6)
+    torch.testing.assert_close(sg.dgrad(dy, w, relu_ref=h).float(), ref * (h > 0), rtol=1e-2, atol=1e-2)
+    base = _r((M, K), 7)
+    out = base.clone()
+    sg.dgrad(dy, w, out=out, accumulate=True)
+    torch.testing.assert_close(out.float(), ref + base.float(), rtol=1e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 256, 256), (200, 2048, 256), (200, 256, 2048), (7, 16, 64), (70, 40, 264), (0, 64, 64)])
+def test_weight_and_bias_gradient(M, N, K):
+    from partdistillation_amd.functions import smallgemm as sg
+    dy, x = _r((M, N), 8), _r((M, K), 9)
+    db = torch.full((N,), 7.0, device="cuda")
+    dw = sg.wgrad(dy, x, bias_out=db)
+    torch.testing.assert_close(dw.float(), dy.float().t() @ x.float(), rtol=1e-2, atol=3e-2 * max(1.0, M ** 0.5 / 4))
+    torch.testing.assert_close(db, dy.float().sum(0), rtol=1e-3, atol=1e-3 * max(1.0, M ** 0.5))
+
+
+def test_slices_of_packed_projection_weight():
+    """in_proj_weight [3C, C] is used through row slices; gradients are written into row slices of one buffer"""
+    from partdistillation_amd.functions import smallgemm as sg
+    C, M = 256, 200
+    w, x, dy = _r((3 * C, C), 10, C ** -0.5), _r((M, C), 11), _r((M, C), 12)
+    torch.testing.assert_close(sg.linear(x, w[C:2 * C]).float(), x.float() @ w[C:2 * C].float().t(), rtol=1e-2, atol=1e-2)
+    g = torch.zeros_like(w)
+    sg.wgrad(dy, x, out=g[2 * C:])
+    torch.testing.assert_close(g[2 * C:].float(), dy.float().t() @ x.float(), rtol=1e-2, atol=1e-1)
+    assert g[:2 * C].abs().sum() == 0
+    torch.testing.assert_close(sg.dgrad(dy, w[:C]).float(), dy.float() @ w[:C].float(), rtol=1e-2, atol=1e-2)
