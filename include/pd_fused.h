@@ -53,6 +53,18 @@ int pd_nc_affine_f32(const float *x, const float *a, const float *b, float *y, i
 int pd_nc_affine2_f32(const float *dy, const float *x, const float *y, const float *a, const float *p, const float *r, float *dx,
                       int N, int P, int C, int relu, void *stream);
 
+/*
+ * The O(N*C) algebra between those passes as one launch each (instead of ~15 / ~20 tiny elementwise launches):
+ *   pd_gn_coeffs_fwd   sums (float64 [N,C,2] from pd_nc_sums mode 0) -> group mean / rstd (biased variance over the
+ *                      P*(C/G) elements of a group, clamped at 0) as per-(n,c) arrays, a = rstd*weight,
+ *                      b = bias - mean*a, xb = -mean*rstd
+ *   pd_gn_coeffs_bwd   sums (mode 1) -> a, p, r of pd_nc_affine2 and the weight / bias gradients gw[C], gb[C]
+ */
+int pd_gn_coeffs_fwd(const double *sums, const float *weight, const float *bias, int N, int C, int G, int P, float eps, float *a,
+                     float *b, float *mean_c, float *rstd_c, float *xb, void *stream);
+int pd_gn_coeffs_bwd(const double *sums, const float *weight, const float *mean_c, const float *rstd_c, int N, int C, int G, int P,
+                     float *a, float *pcoef, float *rcoef, float *gw, float *gb, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,7 +53,7 @@ def _im2col_check(batch, im2col_step):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream()
 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):

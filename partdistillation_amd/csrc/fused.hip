@@ -204,6 +204,63 @@ __global__ __launch_bounds__(256) void nc_affine2(const float4 *__restrict__ dy,
 
 inline int grid_for(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
 
+
+// group statistics -> per-(n, c) coefficients; one thread per (n, c), each re-reads its group's <= 64 channel sums
+__global__ __launch_bounds__(256) void gn_coeffs_fwd(const double *__restrict__ sums, const float *__restrict__ weight,
+                                                     const float *__restrict__ bias, int N, int C, int G, double m, double eps,
+                                                     float *__restrict__ a, float *__restrict__ b, float *__restrict__ mean_c,
+                                                     float *__restrict__ rstd_c, float *__restrict__ xb)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C, cpg = C / G, c0 = (c / cpg) * cpg;
+  double s0 = 0.0, s1 = 0.0;
+  for (int j = 0; j < cpg; ++j) {
+    s0 += sums[((int64_t)n * C + c0 + j) * 2];
+    s1 += sums[((int64_t)n * C + c0 + j) * 2 + 1];
+  }
+  const double mean = s0 / m;
+  double var = s1 / m - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  const float rstd = (float)(1.0 / sqrt(var + eps)), mu = (float)mean;
+  const float av = rstd * weight[c];
+  a[i] = av;
+  b[i] = bias[c] - mu * av;
+  mean_c[i] = mu;
+  rstd_c[i] = rstd;
+  xb[i] = -mu * rstd;
+}
+
+__global__ __launch_bounds__(256) void gn_coeffs_bwd(const double *__restrict__ sums, const float *__restrict__ weight,
+                                                     const float *__restrict__ mean_c, const float *__restrict__ rstd_c, int N,
+                                                     int C, int G, double m, float *__restrict__ a, float *__restrict__ pcoef,
+                                                     float *__restrict__ rcoef, float *__restrict__ gw, float *__restrict__ gb)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C, cpg = C / G, c0 = (c / cpg) * cpg;
+  double S1 = 0.0, S2 = 0.0;
+  for (int j = 0; j < cpg; ++j) {
+    const double w = (double)weight[c0 + j];
+    S1 += sums[((int64_t)n * C + c0 + j) * 2] * w;           // sum_p gamma * dy * x_hat
+    S2 += sums[((int64_t)n * C + c0 + j) * 2 + 1] * w;       // sum_p gamma * dy
+  }
+  S1 /= m; S2 /= m;
+  const double r = (double)rstd_c[i], mu = (double)mean_c[i];
+  a[i] = rstd_c[i] * weight[c];
+  pcoef[i] = (float)(-(r * r) * S1);
+  rcoef[i] = (float)((r * r) * S1 * mu - r * S2);
+  if (n == 0) {
+    double w0 = 0.0, w1 = 0.0;
+    for (int k = 0; k < N; ++k) {
+      w0 += sums[((int64_t)k * C + c) * 2];
+      w1 += sums[((int64_t)k * C + c) * 2 + 1];
+    }
+    gw[c] = (float)w0;
+    gb[c] = (float)w1;
+  }
+}
+
 }  // namespace
 
 extern "C" int pd_affine_act_fwd_bf16(const void *x, const void *residual, const float *scale, const float *bias, void *y,
@@ -302,4 +359,26 @@ extern "C" int pd_nc_affine2_f32(const float *dy, const float *x, const float *y
   if (relu) hipLaunchKernelGGL(nc_affine2<true>, dim3(grid_for(n4)), dim3(256), 0, s, (const float4 *)dy, (const float4 *)x, (const float4 *)y, a, p, r, (float4 *)dx, n4, P, C);
   else hipLaunchKernelGGL(nc_affine2<false>, dim3(grid_for(n4)), dim3(256), 0, s, (const float4 *)dy, (const float4 *)x, (const float4 *)y, a, p, r, (float4 *)dx, n4, P, C);
   return pd_check_launch("pd_nc_affine2_f32");
+}
+
+extern "C" int pd_gn_coeffs_fwd(const double *sums, const float *weight, const float *bias, int N, int C, int G, int P, float eps,
+                                float *a, float *b, float *mean_c, float *rstd_c, float *xb, void *stream_)
+{
+  if (N < 0 || C <= 0 || G <= 0 || (C % G) || P <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gn_coeffs_fwd: N=%d C=%d G=%d P=%d", N, C, G, P);
+  if (N == 0) return PD_OK;
+  if (!sums || !weight || !bias || !a || !b || !mean_c || !rstd_c || !xb) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gn_coeffs_fwd: null pointer");
+  hipLaunchKernelGGL(gn_coeffs_fwd, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream_, sums, weight, bias, N, C, G,
+                     (double)P * (C / G), (double)eps, a, b, mean_c, rstd_c, xb);
+  return pd_check_launch("pd_gn_coeffs_fwd");
+}
+
+extern "C" int pd_gn_coeffs_bwd(const double *sums, const float *weight, const float *mean_c, const float *rstd_c, int N, int C,
+                                int G, int P, float *a, float *pcoef, float *rcoef, float *gw, float *gb, void *stream_)
+{
+  if (N < 0 || C <= 0 || G <= 0 || (C % G) || P <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gn_coeffs_bwd: N=%d C=%d G=%d P=%d", N, C, G, P);
+  if (N == 0) return PD_OK;
+  if (!sums || !weight || !mean_c || !rstd_c || !a || !pcoef || !rcoef || !gw || !gb) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gn_coeffs_bwd: null pointer");
+  hipLaunchKernelGGL(gn_coeffs_bwd, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream_, sums, weight, mean_c, rstd_c, N, C,
+                     G, (double)P * (C / G), a, pcoef, rcoef, gw, gb);
+  return pd_check_launch("pd_gn_coeffs_bwd");
 }

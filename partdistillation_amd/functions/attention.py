@@ -19,7 +19,7 @@ def _workspace(B, H, Lq, Lk, device):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream()
 
 
 def attn_fwd_raw(q, k, v, m8, B, nheads, scale):

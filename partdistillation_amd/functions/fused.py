@@ -7,7 +7,7 @@ from .. import lib as _lib
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream()
 
 
 def _nhwc(t):
@@ -127,58 +127,46 @@ class GatherPlan:
 
 class GroupNormNHWC(Function):
     """GroupNorm (+ optional ReLU) of an fp32 NCHW-shaped, channels-last-stored map, with three streaming HIP kernels
-    per direction (pd_nc_sums / pd_nc_affine / pd_nc_affine2) and O(N*C) torch algebra for the group statistics."""
+    per direction (pd_nc_sums / pd_nc_affine / pd_nc_affine2) and one O(N*C) coefficient kernel (pd_gn_coeffs_*) between them."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, groups, eps, relu):
         N, C, H, W = x.shape
         P = H * W
         lib = _lib.load()
+        st = _stream()
         sums = torch.empty((N, C, 2), dtype=torch.float64, device=x.device)
-        with torch.cuda.device(x.device):
-            _lib.check(lib.pd_nc_sums_f32(x.data_ptr(), None, None, None, None, sums.data_ptr(), N, P, C, 0, 0, _stream()))
-            m = float(P * (C // groups))
-            gs = sums.view(N, groups, C // groups, 2).sum(2)                                  # [N,G,2] float64
-            mean = gs[..., 0] / m
-            var = (gs[..., 1] / m - mean * mean).clamp_min_(0.0)
-            rstd = (var + eps).rsqrt()
-            mean_c = mean.float().repeat_interleave(C // groups, dim=1)                       # [N,C]
-            rstd_c = rstd.float().repeat_interleave(C // groups, dim=1)
-            a = (rstd_c * weight[None, :]).contiguous()
-            b = (bias[None, :] - mean_c * a).contiguous()
-            y = torch.empty_like(x, memory_format=torch.channels_last)
-            _lib.check(lib.pd_nc_affine_f32(x.data_ptr(), a.data_ptr(), b.data_ptr(), y.data_ptr(), N, P, C, int(relu), _stream()))
-        ctx.save_for_backward(x, y if relu else None, weight, mean_c, rstd_c)
+        coef = torch.empty((5, N, C), dtype=torch.float32, device=x.device)          # a, b, mean_c, rstd_c, xb
+        _lib.check(lib.pd_nc_sums_f32(x.data_ptr(), None, None, None, None, sums.data_ptr(), N, P, C, 0, 0, st))
+        _lib.check(lib.pd_gn_coeffs_fwd(sums.data_ptr(), weight.data_ptr(), bias.data_ptr(), N, C, groups, P, float(eps),
+                                        coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
+                                        coef[4].data_ptr(), st))
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        _lib.check(lib.pd_nc_affine_f32(x.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), y.data_ptr(), N, P, C, int(relu), st))
+        ctx.save_for_backward(x, y if relu else None, weight, coef)
         ctx.groups, ctx.relu = groups, relu
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, y, weight, mean_c, rstd_c = ctx.saved_tensors
+        x, y, weight, coef = ctx.saved_tensors
         N, C, H, W = x.shape
         P, G = H * W, ctx.groups
-        cpg = C // G
         gy = _nhwc(gy)
         lib = _lib.load()
-        with torch.cuda.device(x.device):
-            xa, xb = rstd_c.contiguous(), (-mean_c * rstd_c).contiguous()                     # x_hat = x*xa + xb
-            sums = torch.empty((N, C, 2), dtype=torch.float64, device=x.device)
-            _lib.check(lib.pd_nc_sums_f32(x.data_ptr(), gy.data_ptr(), y.data_ptr() if y is not None else None, xa.data_ptr(),
-                                          xb.data_ptr(), sums.data_ptr(), N, P, C, 1, int(ctx.relu), _stream()))
-            s_xhat, s_dy = sums[..., 0], sums[..., 1]                                         # [N,C] float64
-            gw = s_xhat.sum(0).float()
-            gb = s_dy.sum(0).float()
-            m = float(P * cpg)
-            wd = weight.double()[None, :]
-            S1 = (s_xhat * wd).view(N, G, cpg).sum(2).repeat_interleave(cpg, dim=1) / m       # mean_g(gamma*dy*x_hat)
-            S2 = (s_dy * wd).view(N, G, cpg).sum(2).repeat_interleave(cpg, dim=1) / m         # mean_g(gamma*dy)
-            r64, mu64 = rstd_c.double(), mean_c.double()
-            a = (rstd_c * weight[None, :]).contiguous()
-            pcoef = (-(r64 * r64) * S1).float().contiguous()
-            rcoef = ((r64 * r64) * S1 * mu64 - r64 * S2).float().contiguous()
-            dx = torch.empty_like(x, memory_format=torch.channels_last)
-            _lib.check(lib.pd_nc_affine2_f32(gy.data_ptr(), x.data_ptr(), y.data_ptr() if y is not None else None, a.data_ptr(),
-                                             pcoef.data_ptr(), rcoef.data_ptr(), dx.data_ptr(), N, P, C, int(ctx.relu), _stream()))
+        st = _stream()
+        mean_c, rstd_c, xb = coef[2], coef[3], coef[4]                                # x_hat = x*rstd_c + xb
+        sums = torch.empty((N, C, 2), dtype=torch.float64, device=x.device)
+        _lib.check(lib.pd_nc_sums_f32(x.data_ptr(), gy.data_ptr(), y.data_ptr() if y is not None else None, rstd_c.data_ptr(),
+                                      xb.data_ptr(), sums.data_ptr(), N, P, C, 1, int(ctx.relu), st))
+        out = torch.empty((3 * N * C + 2 * C,), dtype=torch.float32, device=x.device)    # a, p, r [N,C] | gw, gb [C]
+        a, pc, rc = out[:N * C], out[N * C:2 * N * C], out[2 * N * C:3 * N * C]
+        gw, gb = out[3 * N * C:3 * N * C + C], out[3 * N * C + C:]
+        _lib.check(lib.pd_gn_coeffs_bwd(sums.data_ptr(), weight.data_ptr(), mean_c.data_ptr(), rstd_c.data_ptr(), N, C, G, P,
+                                        a.data_ptr(), pc.data_ptr(), rc.data_ptr(), gw.data_ptr(), gb.data_ptr(), st))
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        _lib.check(lib.pd_nc_affine2_f32(gy.data_ptr(), x.data_ptr(), y.data_ptr() if y is not None else None, a.data_ptr(),
+                                         pc.data_ptr(), rc.data_ptr(), dx.data_ptr(), N, P, C, int(ctx.relu), st))
         return dx, gw, gb, None, None, None
 
 

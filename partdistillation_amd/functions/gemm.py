@@ -7,7 +7,7 @@ from .. import lib as _lib
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream()
 
 
 def gemm_tn(a, b, bias=None, relu=False):

@@ -18,7 +18,7 @@ def solve_batched(cost, ncols):
         return rows, cols
     with torch.cuda.device(cost.device):
         rc = _lib.load().pd_lsa_batched(cost.data_ptr(), ncols.data_ptr(), rows.data_ptr(), cols.data_ptr(), nb, r, cmax,
-                                        torch.cuda.current_stream().cuda_stream)
+                                        _lib.current_stream())
     _lib.check(rc)
     return rows, cols
 

@@ -16,7 +16,7 @@ def sumsq_accumulate(x, accum):
     _need_cuda(x)
     with torch.cuda.device(x.device):
         rc = _lib.load().pd_sumsq_accumulate(x.data_ptr(), x.numel(), _DT[x.dtype], accum.data_ptr(),
-                                             torch.cuda.current_stream().cuda_stream)
+                                             _lib.current_stream())
     _lib.check(rc)
 
 
@@ -28,12 +28,12 @@ def adamw_clipped_(param, grad, exp_avg, exp_avg_sq, *, lr, betas, eps, weight_d
                 param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), shadow.data_ptr(), param.numel(),
                 float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step),
                 grad_sumsq.data_ptr() if grad_sumsq is not None else None, float(max_norm),
-                dyn.data_ptr() if dyn is not None else None, torch.cuda.current_stream().cuda_stream)
+                dyn.data_ptr() if dyn is not None else None, _lib.current_stream())
             _lib.check(rc)
             return
         rc = _lib.load().pd_adamw_clipped(
             param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(), _DT[param.dtype],
             float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step),
             grad_sumsq.data_ptr() if grad_sumsq is not None else None, float(max_norm),
-            dyn.data_ptr() if dyn is not None else None, torch.cuda.current_stream().cuda_stream)
+            dyn.data_ptr() if dyn is not None else None, _lib.current_stream())
     _lib.check(rc)

@@ -10,7 +10,7 @@ _DT = {torch.float32: _lib.PD_F32, torch.bfloat16: _lib.PD_BF16}
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream()
 
 
 def _p(t):

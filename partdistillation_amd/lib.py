@@ -50,6 +50,8 @@ SIGNATURES = {
     "pd_sgemm_tn_bf16": (_c_int, [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
     "pd_sgemm_nn_bf16": (_c_int, [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
     "pd_sgemm_wgrad_bf16": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),
+    "pd_gn_coeffs_fwd": (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [ctypes.c_float] + [_c_vp] * 6),
+    "pd_gn_coeffs_bwd": (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_vp] * 6),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_abi_version": (_c_int, []),
     "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),
@@ -93,6 +95,13 @@ def load():
         raise PdHipError(f"libpd_hip.so ABI {lib.pd_abi_version()} != binding {ABI_VERSION}: rebuild")
     _lib = lib
     return lib
+
+
+def current_stream():
+    """raw hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream().cuda_stream costs
+    ~9 us of host time per call (Stream object construction); the two C calls below ~0.5 us - it is called once per launch."""
+    import torch
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def check(rc):
