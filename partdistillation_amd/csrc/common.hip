@@ -35,6 +35,7 @@ extern int g_pd_dbg_atomic_scope;
 extern int g_pd_dbg_force_generic;
 extern int g_pd_dbg_ablate;
 extern int g_pd_dbg_wgrad_wgs;
+extern int g_pd_dbg_bwd_threads;
 extern int g_pd_dbg_attn_scalar;
 extern "C" int pd_debug_set(const char *key, int value)
 {
@@ -42,6 +43,7 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!strcmp(key, "msda_bwd_atomic_scope")) { g_pd_dbg_atomic_scope = value; return PD_OK; }
   if (!strcmp(key, "msda_ablate")) { g_pd_dbg_ablate = value; return PD_OK; }
   if (!strcmp(key, "attn_scalar")) { g_pd_dbg_attn_scalar = value; return PD_OK; }
+  if (!strcmp(key, "msda_bwd_threads")) { g_pd_dbg_bwd_threads = value; return PD_OK; }
   if (!strcmp(key, "wgrad_wgs")) { g_pd_dbg_wgrad_wgs = value; return PD_OK; }
   if (!strcmp(key, "msda_force_generic")) { g_pd_dbg_force_generic = value; return PD_OK; }
   return pd_set_error(PD_ERR_INVALID_ARG, "pd_debug_set: unknown key %s", key);

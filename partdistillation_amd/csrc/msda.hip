@@ -31,6 +31,7 @@
 #include "pd_common.h"
 
 int g_pd_dbg_force_generic = 0;
+int g_pd_dbg_bwd_threads = 0;
 int g_pd_dbg_ablate = 0;
 int g_pd_dbg_atomic_scope = 0;   // experiments only (pd_debug_set): 0 = agent scope, 1 = workgroup scope
 
@@ -272,7 +273,7 @@ constexpr int kTile = 16, kHalo = 4, kWin = kTile + 2 * kHalo, kGmax = 16;
 __device__ __forceinline__ int lds_slot(int cell, int ch) { return cell * 32 + ((ch + (cell & 3)) & 31); }
 
 template <int P_, int ABL>
-__global__ __launch_bounds__(256) void msda_bwd_tiled_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
+__global__ __launch_bounds__(1024) void msda_bwd_tiled_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
                                                            const int64_t *__restrict__ lvl_start, const float *__restrict__ loc,
                                                            const float *__restrict__ attn, const float *__restrict__ grad_out,
                                                            float *__restrict__ grad_value, float *__restrict__ grad_loc,
@@ -297,7 +298,8 @@ __global__ __launch_bounds__(256) void msda_bwd_tiled_d32(const float *__restric
   const int wh = min(min(H, (ty + 1) * H / G + kHalo) - wy0, kWin), ww = min(min(W, (tx + 1) * W / G + kHalo) - wx0, kWin);
   const int cells = max(wh, 0) * max(ww, 0);
   int *chmax = win + kWin * kWin * 32;
-  for (int i = threadIdx.x; i < cells * 32; i += 256) win[i] = 0;
+  const int NT = blockDim.x, NG = NT >> 3;      // threads, 8-lane query groups per workgroup
+  for (int i = threadIdx.x; i < cells * 32; i += NT) win[i] = 0;
   if (threadIdx.x < 32) chmax[threadIdx.x] = 0;
   __syncthreads();
 
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256) void msda_bwd_tiled_d32(const float *__restric
       const int ry0 = ty * Hj / G, ry1 = (ty + 1) * Hj / G, rx0 = tx * Wj / G, rx1 = (tx + 1) * Wj / G;
       const int rw = rx1 - rx0, nq = (ry1 - ry0) * rw;
       const int qbase = (int)lvl_start[j];
-      for (int i = grp; i < nq; i += 32) {
+      for (int i = grp; i < nq; i += NG) {
         const int q = qbase + (ry0 + i / rw) * Wj + rx0 + i % rw;
         const float4 go = *reinterpret_cast<const float4 *>(grad_out + (((int64_t)b * S + q) * M + m) * 32 + sub * 4);
         mx[0] = fmaxf(mx[0], fabsf(go.x)); mx[1] = fmaxf(mx[1], fabsf(go.y));
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(256) void msda_bwd_tiled_d32(const float *__restric
     const int ry0 = ty * Hj / G, ry1 = (ty + 1) * Hj / G, rx0 = tx * Wj / G, rx1 = (tx + 1) * Wj / G;
     const int rw = rx1 - rx0, nq = (ry1 - ry0) * rw;
     const int qbase = (int)lvl_start[j];
-    for (int i = grp; i < nq; i += 32) {
+    for (int i = grp; i < nq; i += NG) {
       const int q = qbase + (ry0 + i / rw) * Wj + rx0 + i % rw;
       const int64_t qm = ((int64_t)b * S + q) * M + m;
       const float4 *lp4 = reinterpret_cast<const float4 *>(loc + (qm * LP + l * P_) * 2);
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(256) void msda_bwd_tiled_d32(const float *__restric
   __syncthreads();
   // ---- flush: lane = channel, one full 128-byte line per cell per half-wave
   float *gl = grad_value + ((int64_t)b * S + lvl_start[l]) * stride_w + m * 32;
-  for (int i = threadIdx.x; i < cells * 32; i += 256) {
+  for (int i = threadIdx.x; i < cells * 32; i += NT) {
     const int cell = i >> 5, ch = i & 31;
     const int acc = win[lds_slot(cell, ch)];
     int ex;
@@ -610,7 +612,10 @@ extern "C" int pd_msda_backward(const void *value, const int64_t *spatial_shapes
     }
     auto tk = g_pd_dbg_ablate == 1 ? msda_bwd_tiled_d32<4, 1> : g_pd_dbg_ablate == 2 ? msda_bwd_tiled_d32<4, 2>
             : g_pd_dbg_ablate == 4 ? msda_bwd_tiled_d32<4, 4> : g_pd_dbg_ablate == 7 ? msda_bwd_tiled_d32<4, 7> : msda_bwd_tiled_d32<4, 0>;
-    hipLaunchKernelGGL(tk, dim3((unsigned)nblocks), dim3(256), lds, stream, (const float *)value,
+    // 74 KB of LDS window -> 2 workgroups per CU whatever their size: 512 threads give the gathers 16 waves per CU to hide
+    // their latency behind instead of 8 (measured 0.56 -> see DESIGN.md)
+    const int nthreads = g_pd_dbg_bwd_threads > 0 ? g_pd_dbg_bwd_threads : 512;
+    hipLaunchKernelGGL(tk, dim3((unsigned)nblocks), dim3(nthreads), lds, stream, (const float *)value,
                        spatial_shapes, level_start_index, (const float *)sampling_loc, (const float *)attn_weight,
                        (const float *)grad_output, (float *)grad_value, (float *)grad_sampling_loc,
                        (float *)grad_attn_weight, spatial_size, num_heads, num_levels);

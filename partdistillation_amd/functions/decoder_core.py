@@ -35,11 +35,16 @@ class DecoderSpec:
         self.sizes, self.pos, self.pooled, self.eps, self.cdt, self.num_levels = sizes, pos_tables, pooled, eps, cdt, num_levels
 
 
-SMALL_M = 1024      # rows up to which the skinny-activation kernels (pd_sgemm_*) are used instead of the GEMM library
+import os
+
+# rows up to which the skinny-activation kernels (pd_sgemm_*) replace the GEMM library: forward / input gradient, and the
+# weight gradient (whose contraction runs over the rows inside one workgroup, so it stays small)
+SMALL_M = int(os.environ.get("PD_SGEMM_MAX_M", "1024"))
+SMALL_M_WGRAD = 1024
 
 
-def _small(x, cdt):
-    return cdt == torch.bfloat16 and x.shape[0] <= SMALL_M
+def _small(x, cdt, limit=None):
+    return cdt == torch.bfloat16 and x.shape[0] <= (SMALL_M if limit is None else limit)
 
 
 def _lin(x, w, b, relu=False):
@@ -70,7 +75,7 @@ def _dgrad(dy, w, relu_ref=None, out=None, accumulate=False):
 
 def _wgrad(dy, x, out=None, bias_acc=None):
     """dy^T x -> out (weight gradient);  bias_acc (fp32 accumulator slot, zero on entry) += dy.sum(0)"""
-    if _small(dy, dy.dtype):
+    if _small(dy, dy.dtype, SMALL_M_WGRAD):
         return sg.wgrad(dy, x, out, bias_acc)
     dw = torch.mm(dy.t(), x) if out is None else torch.mm(dy.t(), x, out=out)
     if bias_acc is not None:

@@ -44,12 +44,14 @@ def main():
     ap.add_argument("--scope", type=int, default=0)
     ap.add_argument("--generic", type=int, default=0)
     ap.add_argument("--ablate", type=int, default=0)
+    ap.add_argument("--bwd-threads", type=int, default=0)
     ap.add_argument("--spread", type=float, default=0.02)
     a = ap.parse_args()
     from partdistillation_amd import lib
     lib.load().pd_debug_set(b"msda_bwd_atomic_scope", a.scope)
     lib.load().pd_debug_set(b"msda_force_generic", a.generic)
     lib.load().pd_debug_set(b"msda_ablate", a.ablate)
+    lib.load().pd_debug_set(b"msda_bwd_threads", a.bwd_threads)
     value, sh, lv, loc, attn, gout = make(a.batch, a.img, a.spread)
     S = value.shape[1]
     fb, bb = alg_bytes(a.batch, S)
