@@ -14,6 +14,7 @@
  *   pd_mem_prep_{fwd,bwd}        decoder memory of one feature level (:392-401): tokens [B,HW,C] + level_embed ->
  *                                seq-first `memory` and `memory + pos` in the GEMM dtype, one pass.
  *   pd_attn_mask_u8              `(sigmoid(mask logits) < 0.5)` with fully-blocked rows released (:405, :455-459).
+ *   pd_point_sample_nhwc_f32     point_sample of a channels-last map at points shared by all channels (matcher).
  *   pd_msda_prep_{fwd,bwd}       MSDeformAttn.forward between the projections and the sampling core
  *                                (pixel_decoder/ops/modules/ms_deform_attn.py:108-117): softmax of the attention logits
  *                                and `reference_points + offsets / (W_l, H_l)` in one pass, and their backward.
@@ -85,6 +86,15 @@ int pd_msda_prep_fwd(const float *offs, const float *logits, const float *ref, c
 /* d_offs = gloc / (W_l, H_l);  d_logits = attn * (gattn - sum_j attn_j * gattn_j) */
 int pd_msda_prep_bwd(const float *gloc, const float *gattn, const float *attn, const int64_t *spatial_shapes, float *d_offs,
                      float *d_logits, int64_t tokens, int M, int L, int P, void *stream);
+
+/*
+ * out[b, p, :] = bilinear sample of in[b] (fp32, channels-last [B, H, W, C], C % 4 == 0) at coords[b, p] = (x, y) in
+ * [0, 1]: F.grid_sample(mode="bilinear", padding_mode="zeros", align_corners=False) with grid = 2*coords - 1, for
+ * points shared by all channels (detectron2 point_sample as the matcher uses it, reference matcher.py:128-139, applied
+ * to the mask FEATURES: bilinear sampling commutes with the mask_embed . mask_features product, so the Q masks of a head
+ * need not exist to be sampled).  Same operation order as the torch kernel.
+ */
+int pd_point_sample_nhwc_f32(const float *in, const float *coords, float *out, int B, int H, int W, int C, int P, void *stream);
 
 #ifdef __cplusplus
 }

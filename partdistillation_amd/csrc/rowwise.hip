@@ -419,6 +419,35 @@ __global__ __launch_bounds__(256) void msda_prep_bwd(const float *__restrict__ g
   }
 }
 
+// ------------------------------------------------------------------------------------------------ point sampling
+// F.grid_sample(bilinear, zeros, align_corners=False) of a channels-last map at points that are shared by all C channels:
+// one wavefront per point, lanes across channels (16-byte pieces), so each corner is one contiguous C*4-byte burst.
+__global__ __launch_bounds__(256) void point_sample_nhwc(const float *__restrict__ in, const float *__restrict__ coords,
+                                                         float *__restrict__ out, int B, int H, int W, int C, int P)
+{
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t total = (int64_t)B * P;
+  for (int64_t pt = (int64_t)blockIdx.x * 4 + wave; pt < total; pt += (int64_t)gridDim.x * 4) {
+    const int b = (int)(pt / P);
+    // the exact arithmetic of the torch path: g = 2*c - 1, then ((g + 1) * size - 1) / 2
+    const float gx = 2.0f * coords[pt * 2] - 1.0f, gy = 2.0f * coords[pt * 2 + 1] - 1.0f;
+    const float ix = ((gx + 1.f) * W - 1.f) / 2.f, iy = ((gy + 1.f) * H - 1.f) / 2.f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wnw = (x1 - ix) * (y1 - iy), wne = (ix - x0) * (y1 - iy), wsw = (x1 - ix) * (iy - y0), wse = (ix - x0) * (iy - y0);
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const float *base = in + (int64_t)b * H * W * C;
+    for (int c = lane * 4; c < C; c += 256) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vy0 && vx0) { const float4 v = ld4(base + ((int64_t)y0 * W + x0) * C + c); acc.x += v.x * wnw; acc.y += v.y * wnw; acc.z += v.z * wnw; acc.w += v.w * wnw; }
+      if (vy0 && vx1) { const float4 v = ld4(base + ((int64_t)y0 * W + x1) * C + c); acc.x += v.x * wne; acc.y += v.y * wne; acc.z += v.z * wne; acc.w += v.w * wne; }
+      if (vy1 && vx0) { const float4 v = ld4(base + ((int64_t)y1 * W + x0) * C + c); acc.x += v.x * wsw; acc.y += v.y * wsw; acc.z += v.z * wsw; acc.w += v.w * wsw; }
+      if (vy1 && vx1) { const float4 v = ld4(base + ((int64_t)y1 * W + x1) * C + c); acc.x += v.x * wse; acc.y += v.y * wse; acc.z += v.z * wse; acc.w += v.w * wse; }
+      st4(out + pt * C + c, acc);
+    }
+  }
+}
+
 int grid_rows(int rows, int cap) { return max(1, min(cap, (rows + 3) / 4)); }
 
 bool dt_ok(int dt) { return dt == PD_F32 || dt == PD_BF16; }
@@ -576,4 +605,16 @@ extern "C" int pd_msda_prep_bwd(const float *gloc, const float *gattn, const flo
   else LAUNCH(msda_prep_bwd);
 #undef LAUNCH
   return pd_check_launch("pd_msda_prep_bwd");
+}
+
+extern "C" int pd_point_sample_nhwc_f32(const float *in, const float *coords, float *out, int B, int H, int W, int C, int P,
+                                        void *stream_)
+{
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || P < 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_point_sample_nhwc_f32: B=%d H=%d W=%d C=%d P=%d", B, H, W, C, P);
+  if (B == 0 || P == 0) return PD_OK;
+  if (!in || !coords || !out) return pd_set_error(PD_ERR_INVALID_ARG, "pd_point_sample_nhwc_f32: null pointer");
+  const int64_t total = (int64_t)B * P;
+  const unsigned grid = (unsigned)((total + 3) / 4 < 16384 ? (total + 3) / 4 : 16384);
+  hipLaunchKernelGGL(point_sample_nhwc, dim3(grid), dim3(256), 0, (hipStream_t)stream_, in, coords, out, B, H, W, C, P);
+  return pd_check_launch("pd_point_sample_nhwc_f32");
 }

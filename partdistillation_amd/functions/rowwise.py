@@ -116,6 +116,21 @@ def attn_mask_u8(logits):
     return mask
 
 
+def point_sample_nhwc(x, coords):
+    """x [B,C,H,W] fp32 (channels-last memory is read in place), coords [B,P,2] (x, y) in [0,1] -> [B,P,C]:
+    F.grid_sample(x, 2*coords-1, bilinear, zeros, align_corners=False) for points shared by all channels."""
+    _need_cuda(x, "pd_point_sample_nhwc_f32")
+    B, C, H, W = x.shape
+    t = x.permute(0, 2, 3, 1)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.float().contiguous()
+    coords = coords.float().contiguous()
+    P = coords.shape[1]
+    out = torch.empty((B, P, C), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().pd_point_sample_nhwc_f32(t.data_ptr(), coords.data_ptr(), out.data_ptr(), B, H, W, C, P, _stream()))
+    return out
+
+
 def supports_width(C):
     return C % 256 == 0 and C <= 1024
 

@@ -119,7 +119,7 @@ class SetCriterion(nn.Module):
     def _can_batch(self, outputs, targets):
         return (self.batched and "aux_outputs" in outputs and outputs["pred_logits"].is_cuda and len(targets) > 0
                 and self.losses == ["labels", "masks"] and all(t["labels"].shape[0] > 0 for t in targets)
-                and outputs["pred_masks"] is not None)
+                and (outputs["pred_masks"] is not None or outputs.get("mask_embeds") is not None))
 
     def forward(self, outputs, targets):
         if self._can_batch(outputs, targets):
@@ -129,6 +129,9 @@ class SetCriterion(nn.Module):
             else:
                 padded, _ = nested_tensor_from_tensor_list([t["masks"] for t in targets]).decompose()
             return batched_set_criterion(self, outputs, targets, padded)
+        if outputs.get("pred_masks") is None and outputs.get("mask_embeds") is not None:
+            from .transformer_decoder.mask2former_transformer_decoder import materialize_masks
+            outputs = materialize_masks(dict(outputs))          # the per-head loop needs the dense masks
         outputs_without_aux = {k: v for k, v in outputs.items() if k != "aux_outputs"}
         if self.rand is not None:
             self.matcher.rand = self.rand

@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from ..functions import lsa as lsa_op
+from ..functions import rowwise as rw
 
 
 class LossDict(dict):
@@ -40,8 +41,11 @@ def _pair_selectors(H, B, npair, device):
                 for k in range(npair[b]):
                     sel_h.append(h), sel_b.append(b), sel_k.append(k)
         mk = lambda x: torch.tensor(x, dtype=torch.long, device=device)
-        per_image = [mk([i for i, bb in enumerate(sel_b) if bb == b]) for b in range(B)]
-        _SEL_CACHE[key] = (mk(sel_h), mk(sel_b), mk(sel_k), per_image)
+        per_image_l = [[i for i, bb in enumerate(sel_b) if bb == b] for b in range(B)]
+        per_image = [mk(l) for l in per_image_l]
+        flat = [i for l in per_image_l for i in l]                         # pairs in image-major order
+        inv = mk(sorted(range(len(flat)), key=flat.__getitem__))           # image-major position of pair i
+        _SEL_CACHE[key] = (mk(sel_h), mk(sel_b), mk(sel_k), per_image, inv)
     return _SEL_CACHE[key]
 
 
@@ -70,7 +74,15 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
     dev = outputs["pred_logits"].device
     aux = outputs["aux_outputs"]
     H, (B, Q, K1) = len(aux) + 1, outputs["pred_logits"].shape
-    if "all_masks" in outputs and outputs["all_masks"].shape[1] == H:
+    # sparse: the decoder did not form the [B, D*Q, h, w] masks (mask = mask_embed . mask_features).  Bilinear point
+    # sampling is linear in the map, so the matcher's samples of ALL Q masks at its shared points are
+    # mask_embed . point_sample(mask_features), and only the N matched masks are evaluated densely for the loss.
+    sparse = outputs.get("pred_masks") is None and outputs.get("mask_embeds") is not None
+    masks_bd = None
+    if sparse:
+        emb_bd, mfeat = outputs["mask_embeds"], outputs["mask_features"]                         # [B,D,Q,C], [B,C,h,w]
+        assert emb_bd.shape[1] == H
+    elif outputs.get("all_masks") is not None and outputs["all_masks"].shape[1] == H:
         masks_bd = outputs["all_masks"]                                                          # [B,D,Q,h,w]
     else:
         masks_bd = torch.stack([a["pred_masks"] for a in aux] + [outputs["pred_masks"]], dim=1)
@@ -114,7 +126,13 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
     with torch.no_grad(), torch.autocast(device_type=dev.type, enabled=False):
         # ---- matcher costs for all (image, head) problems (matcher.py:108-158)
         mc_bd = mcoords[h_of_d].transpose(0, 1)                                                  # [B,D,Pm,2]
-        pm = _gs(masks_bd.detach().reshape(B * H, Q, *masks_bd.shape[-2:]).float(), mc_bd.reshape(B * H, Pm, 2))   # [BD,Q,Pm]
+        if sparse:
+            fm = rw.point_sample_nhwc(mfeat.detach(), mc_bd.reshape(B, H * Pm, 2))                # [B, D*Pm, C]
+            e = emb_bd.detach().reshape(B * H, Q, -1)
+            # bf16 mask embeddings (autocast): the reference's mask logits are a bf16 product too (einsum under AMP, :449)
+            pm = torch.bmm(e, fm.view(B * H, Pm, -1).to(e.dtype).transpose(1, 2)).float()
+        else:
+            pm = _gs(masks_bd.detach().reshape(B * H, Q, *masks_bd.shape[-2:]).float(), mc_bd.reshape(B * H, Pm, 2))   # [BD,Q,Pm]
         tg = _gs(tmask, mc_bd.reshape(B, H * Pm, 2)).reshape(B, nmax, H, Pm).transpose(1, 2).reshape(B * H, nmax, Pm)
         tgt = tg.transpose(1, 2)
         cost_mask = (F.softplus(pm).sum(-1)[:, :, None] - torch.bmm(pm, tgt)) / Pm
@@ -125,7 +143,7 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
         cost_class = -torch.gather(prob, 3, labels_pad[:, None, None, :].expand(B, H, Q, nmax)).reshape(B * H, Q, nmax)
         C = m.cost_mask * cost_mask + m.cost_class * cost_class + m.cost_dice * cost_dice
         rows, cols = lsa_op.solve_batched(C, ncols)                                              # [BD,nmax]
-        sel_h, sel_b, sel_k, per_image = _pair_selectors(H, B, npair, dev)                       # pairs, h-major
+        sel_h, sel_b, sel_k, per_image, inv_img = _pair_selectors(H, B, npair, dev)              # pairs, h-major
         sel_d = d_of_h[sel_h]
         sel_p = sel_b * H + sel_d
         q_idx, j_idx = rows[sel_p, sel_k], cols[sel_p, sel_k]
@@ -140,10 +158,16 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
         ce_d = nll.reshape(B, H, Q).sum((0, 2)) / w[tclass].sum((0, 2))
         loss_ce = ce_d[d_of_h]
         # ---- mask losses on the matched pairs (criterion.py:147-207)
-        src = masks_bd[sel_b, sel_d, q_idx][:, None].float()                                     # [N,1,h,w]
+        if sparse:
+            e_sel = emb_bd[sel_b, sel_d, q_idx].float()                                          # [N,C]
+            mf32 = mfeat.float()
+            parts = [e_sel[per_image[b]] @ mf32[b].flatten(1) for b in range(B) if per_image[b].numel()]
+            src = torch.cat(parts)[inv_img].view(-1, 1, *mfeat.shape[-2:])                       # [N,1,h,w]
+        else:
+            src = masks_bd[sel_b, sel_d, q_idx][:, None].float()                                 # [N,1,h,w]
         with torch.no_grad():
             unc = -_gs(src, ocoords).abs()[:, 0, :]
-            idx = torch.topk(unc, k=kimp, dim=1)[1]
+            idx = torch.topk(unc, k=kimp, dim=1, sorted=False)[1]            # the losses are sums over the chosen points
             coords = torch.gather(ocoords, 1, idx[:, :, None].expand(-1, -1, 2))
             if krand > 0:
                 coords = torch.cat([coords, rcoords], dim=1)                                     # [N,P,2]

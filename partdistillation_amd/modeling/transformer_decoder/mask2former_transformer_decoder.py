@@ -152,6 +152,24 @@ class MLP(nn.Module):
         return x
 
 
+def materialize_masks(out):
+    """fills pred_masks / aux_outputs[*].pred_masks / all_masks of a decoder output dict from mask_embeds and
+    mask_features: einsum("bqc,bchw->bqhw") of the reference (:449) for all L+1 heads as ONE batched GEMM
+    [B, (L+1)*Q, C] x [B, C, HW] - ten [200 x 256 x 65536] products are too skinny for the matrix cores one at a time."""
+    emb, mask_features = out["mask_embeds"], out["mask_features"]
+    B_, Hh, Qn, Cc = emb.shape
+    mf = mask_features.to(emb.dtype).flatten(2)                               # [B, C, HW]
+    all_masks = torch.bmm(emb.reshape(B_, Hh * Qn, Cc), mf).view(B_, Hh, Qn, *mask_features.shape[-2:])
+    masks = [all_masks[:, i] for i in range(Hh)]
+    classes = list(out["all_logits"].unbind(0)) if out.get("all_logits") is not None else None
+    out["pred_masks"], out["all_masks"] = masks[-1], all_masks                # all_masks: [B, heads (decoder order), Q, H, W]
+    if classes is not None:
+        out["aux_outputs"] = [{"pred_logits": a, "pred_masks": b} for a, b in zip(classes[:-1], masks[:-1])]
+    else:
+        out["aux_outputs"] = [{"pred_masks": b} for b in masks[:-1]]
+    return out
+
+
 @TRANSFORMER_DECODER_REGISTRY.register()
 class MultiScaleMaskedTransformerDecoder(nn.Module):
     _version = 2
@@ -301,18 +319,18 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         return self._assemble(all_logits, emb, d[-1], mask_features, final_tgt.view(Q, bs, C))
 
     def _assemble(self, all_logits, emb, dec_out, mask_features, output):
-        """einsum("bqc,bchw->bqhw") of the reference (:449) for all L+1 heads as ONE batched GEMM [B, (L+1)*Q, C] x
-        [B, C, HW]: ten [200 x 256 x 65536] products are too skinny for the matrix cores one at a time, and the
-        result is already the stacked [B, heads, Q, H, W] tensor the batched criterion consumes."""
-        B_, Hh, Qn, Cc = emb.shape
-        mf = mask_features.to(emb.dtype).flatten(2)                               # [B, C, HW]
-        all_masks = torch.bmm(emb.reshape(B_, Hh * Qn, Cc), mf).view(B_, Hh, Qn, *mask_features.shape[-2:])
-        masks = [all_masks[:, i] for i in range(Hh)]
         classes = list(all_logits.unbind(0)) if self.mask_classification else None
-        out = {"pred_logits": classes[-1] if classes is not None else None, "pred_masks": masks[-1], "decoder_output": dec_out,
-               "aux_outputs": self._set_aux_loss(classes, masks),
-               "all_masks": all_masks,                                            # [B, heads(decoder order), Q, H, W]
+        out = {"pred_logits": classes[-1] if classes is not None else None, "decoder_output": dec_out,
                "mask_embeds": emb, "mask_features": mask_features, "all_logits": all_logits}
+        if self.dense_masks or not self.training:
+            materialize_masks(out)
+        else:
+            # training with the batched criterion: no [B, heads*Q, H, W] tensor is formed.  The matcher samples the mask
+            # FEATURES at its points (bilinear sampling is linear, so it commutes with the product) and only the matched
+            # masks are evaluated densely (criterion_batched.py); materialize_masks(out) builds the rest on demand.
+            out.update({"pred_masks": None, "all_masks": None,
+                        "aux_outputs": [{"pred_logits": c, "pred_masks": None} for c in classes[:-1]] if classes is not None
+                        else [{"pred_masks": None} for _ in range(emb.shape[1] - 1)]})
         self._finish(out, output)
         return out
 

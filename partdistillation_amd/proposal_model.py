@@ -42,6 +42,10 @@ class _MaskFormerTrainBase(nn.Module):
         self.register_buffer("pixel_mean", torch.Tensor(pixel_mean).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.Tensor(pixel_std).view(-1, 1, 1), False)
         self.num_train_iterations = 0
+        # the batched criterion samples mask features instead of masks: the decoder need not form the dense masks in training
+        predictor = getattr(sem_seg_head, "predictor", None)
+        if hasattr(predictor, "dense_masks"):
+            predictor.dense_masks = not getattr(criterion, "batched", False)
 
     @property
     def device(self):

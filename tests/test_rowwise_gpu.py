@@ -255,3 +255,49 @@ def test_fused_encoder_core_matches_module_path():
         scale = g2[k].abs().max().clamp_min(1e-6)
         err = ((g1[k] - g2[k]).abs().max() / scale).item()
         assert err < 2e-3, (k, err)
+
+
+# ----------------------------------------------------------------------------- point sampling + sparse-mask criterion
+@pytest.mark.parametrize("B,C,H,W,P", [(2, 256, 64, 48, 1000), (1, 8, 5, 7, 33)])
+def test_point_sample_nhwc_vs_grid_sample(B, C, H, W, P):
+    from partdistillation_amd.functions.rowwise import point_sample_nhwc
+    x = _r((B, C, H, W), 61).contiguous(memory_format=torch.channels_last)
+    coords = torch.rand((B, P, 2), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)) * 1.1 - 0.05   # some outside
+    got = point_sample_nhwc(x, coords)
+    ref = F.grid_sample(x, 2.0 * coords.unsqueeze(2) - 1.0, mode="bilinear", padding_mode="zeros", align_corners=False).squeeze(3)
+    torch.testing.assert_close(got, ref.transpose(1, 2), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(point_sample_nhwc(x.contiguous(), coords), got, rtol=0, atol=0)      # NCHW input: copied first
+
+
+def test_sparse_mask_criterion_matches_dense():
+    """decoder without dense masks + batched criterion (mask features sampled, matched masks only) == dense path"""
+    from test_product_gpu import build_criterion, build_decoder, dev_targets
+    cfg = dict(C.C1, queries=20, dec_layers=3, dec_ffn=512, num_points=256)
+    dec = build_decoder(cfg)
+    dec.load_state_dict(C.seeded_weights(C.table_of(dec.state_dict()), 990), strict=False)
+    dec = dec.to(DEV).train()
+    crit = build_criterion(cfg)
+    targets = dev_targets(C.make_targets(dict(cfg, image=64, batch=2), 77, size=64))
+    res = []
+    for dense in (True, False):
+        dec.dense_masks = dense
+        for p_ in dec.parameters():
+            p_.grad = None
+        toks, ms, mf = _decoder_inputs(995)
+        mf = mf.contiguous(memory_format=torch.channels_last).requires_grad_()
+        out = dec(ms, mf)
+        assert (out["pred_masks"] is None) == (not dense)
+        crit.rand = C.ReplayRand(31)
+        losses = crit(out, targets)
+        total = sum(v * crit.weight_dict[k] for k, v in losses.items())
+        total.backward()
+        res.append(({k: v.detach().clone() for k, v in losses.items()}, {k: p_.grad.clone() for k, p_ in dec.named_parameters() if p_.grad is not None},
+                    mf.grad.clone()))
+    (l1, g1, m1), (l2, g2, m2) = res
+    assert set(l1) == set(l2) and set(g1) == set(g2)
+    for k in l1:
+        torch.testing.assert_close(l2[k], l1[k], rtol=1e-4, atol=1e-5, msg=lambda m: f"{k}: {m}")
+    for k in g1:
+        scale = g1[k].abs().max().clamp_min(1e-6)
+        assert ((g2[k] - g1[k]).abs().max() / scale).item() < 2e-3, k
+    assert ((m2 - m1).abs().max() / m1.abs().max()).item() < 2e-3
