@@ -96,6 +96,16 @@ int pd_msda_prep_bwd(const float *gloc, const float *gattn, const float *attn, c
  */
 int pd_point_sample_nhwc_f32(const float *in, const float *coords, float *out, int B, int H, int W, int C, int P, void *stream);
 
+/*
+ * FPN top-down step of the pixel decoder (reference msdeformattn.py:356-358:
+ * `y = cur_fpn + F.interpolate(out[-1], size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)`), channels-last
+ * fp32 [B, H, W, C] / [B, h, w, C]; same source-index arithmetic as torch's upsample_bilinear2d.
+ *   pd_upsample_add_nhwc_f32     y = cur + upsample(lo), any (h, w) -> (H, W)
+ *   pd_upsample2x_bwd_nhwc_f32   dlo = upsample^T(dy) for H = 2h, W = 2w, in gather form (no atomics); d(cur) = dy
+ */
+int pd_upsample_add_nhwc_f32(const float *lo, const float *cur, float *y, int B, int h, int w, int H, int W, int C, void *stream);
+int pd_upsample2x_bwd_nhwc_f32(const float *dy, float *dlo, int B, int h, int w, int C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

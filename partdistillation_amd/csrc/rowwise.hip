@@ -448,6 +448,94 @@ __global__ __launch_bounds__(256) void point_sample_nhwc(const float *__restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------ FPN top-down step
+// y = cur + bilinear_upsample(lo) (align_corners=False, torch's upsample_bilinear2d arithmetic), channels-last fp32;
+// the backward for the exact-2x case in GATHER form: every low-resolution pixel sums its <= 4 x 4 contributing outputs.
+__device__ __forceinline__ void up_src(int dst, float scale, int in_size, int &i0, int &ip, float &l0, float &l1)
+{
+  float src = scale * (dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  ip = (i0 < in_size - 1) ? 1 : 0;
+  l1 = src - i0;
+  l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void upsample_add_nhwc(const float *__restrict__ lo, const float *__restrict__ cur,
+                                                         float *__restrict__ y, int B, int h, int w, int H, int W, int C4,
+                                                         float sh, float sw)
+{
+  const int64_t total = (int64_t)B * H * W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    int64_t t = i / C4;
+    const int ox = (int)(t % W); t /= W;
+    const int oy = (int)(t % H);
+    const int b = (int)(t / H);
+    int y0, yp, x0, xp; float hy0, hy1, wx0, wx1;
+    up_src(oy, sh, h, y0, yp, hy0, hy1);
+    up_src(ox, sw, w, x0, xp, wx0, wx1);
+    const float4 *L = reinterpret_cast<const float4 *>(lo) + (int64_t)b * h * w * C4;
+    const float4 a = L[((int64_t)y0 * w + x0) * C4 + c], bq = L[((int64_t)y0 * w + x0 + xp) * C4 + c];
+    const float4 cq = L[((int64_t)(y0 + yp) * w + x0) * C4 + c], d = L[((int64_t)(y0 + yp) * w + x0 + xp) * C4 + c];
+    const float4 u = reinterpret_cast<const float4 *>(cur)[i];
+    float4 o;
+    o.x = u.x + (hy0 * (wx0 * a.x + wx1 * bq.x) + hy1 * (wx0 * cq.x + wx1 * d.x));
+    o.y = u.y + (hy0 * (wx0 * a.y + wx1 * bq.y) + hy1 * (wx0 * cq.y + wx1 * d.y));
+    o.z = u.z + (hy0 * (wx0 * a.z + wx1 * bq.z) + hy1 * (wx0 * cq.z + wx1 * d.z));
+    o.w = u.w + (hy0 * (wx0 * a.w + wx1 * bq.w) + hy1 * (wx0 * cq.w + wx1 * d.w));
+    reinterpret_cast<float4 *>(y)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample2x_bwd_nhwc(const float *__restrict__ dy, float *__restrict__ dlo, int B, int h,
+                                                           int w, int C4)
+{
+  const int H = 2 * h, W = 2 * w;
+  const int64_t total = (int64_t)B * h * w * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    int64_t t = i / C4;
+    const int ix = (int)(t % w); t /= w;
+    const int iy = (int)(t % h);
+    const int b = (int)(t / h);
+    float wy[4], wx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int oy = 2 * iy - 1 + k, ox = 2 * ix - 1 + k;
+      wy[k] = 0.f; wx[k] = 0.f;
+      if (oy >= 0 && oy < H) {
+        int i0, ip; float l0, l1;
+        up_src(oy, 0.5f, h, i0, ip, l0, l1);
+        if (i0 == iy) wy[k] += l0;
+        if (i0 + ip == iy) wy[k] += l1;
+      }
+      if (ox >= 0 && ox < W) {
+        int i0, ip; float l0, l1;
+        up_src(ox, 0.5f, w, i0, ip, l0, l1);
+        if (i0 == ix) wx[k] += l0;
+        if (i0 + ip == ix) wx[k] += l1;
+      }
+    }
+    const float4 *G = reinterpret_cast<const float4 *>(dy) + (int64_t)b * H * W * C4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      if (wy[ky] == 0.f) continue;
+      const int oy = 2 * iy - 1 + ky;
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        if (wx[kx] == 0.f) continue;
+        const int ox = 2 * ix - 1 + kx;
+        const float wgt = wy[ky] * wx[kx];
+        const float4 g = G[((int64_t)oy * W + ox) * C4 + c];
+        acc.x += wgt * g.x; acc.y += wgt * g.y; acc.z += wgt * g.z; acc.w += wgt * g.w;
+      }
+    }
+    reinterpret_cast<float4 *>(dlo)[i] = acc;
+  }
+}
+
 int grid_rows(int rows, int cap) { return max(1, min(cap, (rows + 3) / 4)); }
 
 bool dt_ok(int dt) { return dt == PD_F32 || dt == PD_BF16; }
@@ -617,4 +705,28 @@ extern "C" int pd_point_sample_nhwc_f32(const float *in, const float *coords, fl
   const unsigned grid = (unsigned)((total + 3) / 4 < 16384 ? (total + 3) / 4 : 16384);
   hipLaunchKernelGGL(point_sample_nhwc, dim3(grid), dim3(256), 0, (hipStream_t)stream_, in, coords, out, B, H, W, C, P);
   return pd_check_launch("pd_point_sample_nhwc_f32");
+}
+
+extern "C" int pd_upsample_add_nhwc_f32(const float *lo, const float *cur, float *y, int B, int h, int w, int H, int W, int C,
+                                        void *stream_)
+{
+  if (B < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_upsample_add_nhwc_f32: bad sizes");
+  if (B == 0) return PD_OK;
+  if (!lo || !cur || !y) return pd_set_error(PD_ERR_INVALID_ARG, "pd_upsample_add_nhwc_f32: null pointer");
+  const int64_t total = (int64_t)B * H * W * (C / 4);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+  hipLaunchKernelGGL(upsample_add_nhwc, dim3(grid), dim3(256), 0, (hipStream_t)stream_, lo, cur, y, B, h, w, H, W, C / 4,
+                     (float)h / (float)H, (float)w / (float)W);
+  return pd_check_launch("pd_upsample_add_nhwc_f32");
+}
+
+extern "C" int pd_upsample2x_bwd_nhwc_f32(const float *dy, float *dlo, int B, int h, int w, int C, void *stream_)
+{
+  if (B < 0 || h <= 0 || w <= 0 || C <= 0 || (C & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_upsample2x_bwd_nhwc_f32: bad sizes");
+  if (B == 0) return PD_OK;
+  if (!dy || !dlo) return pd_set_error(PD_ERR_INVALID_ARG, "pd_upsample2x_bwd_nhwc_f32: null pointer");
+  const int64_t total = (int64_t)B * h * w * (C / 4);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+  hipLaunchKernelGGL(upsample2x_bwd_nhwc, dim3(grid), dim3(256), 0, (hipStream_t)stream_, dy, dlo, B, h, w, C / 4);
+  return pd_check_launch("pd_upsample2x_bwd_nhwc_f32");
 }

@@ -81,7 +81,7 @@ class EncoderCore(Function):
             v4, loc6, attn5 = value.view(B, S, M, C // M), loc.view(B, S, M, L, P, 2), attn.view(B, S, M, L, P)
             a = _timed("fwd", MSDA.ms_deform_attn_forward, v4, spec.shapes, spec.lsi, loc6, attn5, spec.im2col_step).view(T, C)
             z1, y1, _, _, m1, r1 = rw.add_ln_fwd(torch.addmm(op_b, a, op_w.t()), x, n1_w, n1_b, spec.eps)
-            h = torch.relu_(torch.addmm(l1_b, y1, l1_w.t()))
+            h = torch._addmm_activation(l1_b, y1, l1_w.t(), use_gelu=False)          # bias + ReLU in the GEMM epilogue
             last = i == nl - 1
             z2, y2, _, ypos, m2, r2 = rw.add_ln_fwd(torch.addmm(l2_b, h, l2_w.t()), y1, n2_w, n2_b, spec.eps, c_dtype=torch.float32,
                                                     pos=pos2, pos_div=1, want_ypos=not last)

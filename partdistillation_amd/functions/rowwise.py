@@ -179,3 +179,36 @@ class AddLayerNorm(Function):
 def add_layer_norm(x, res, norm: torch.nn.LayerNorm, pos=None):
     """LayerNorm(x + res) with `norm`'s parameters through the fused kernel; -> (y, y + pos | None)."""
     return AddLayerNorm.apply(x, res, norm.weight, norm.bias, norm.eps, pos)
+
+
+class UpsampleAdd(Function):
+    """cur + F.interpolate(lo, size=cur.shape[-2:], mode="bilinear", align_corners=False) on fp32 channels-last maps
+    (exact 2x only: the backward is the gather-form kernel)."""
+
+    @staticmethod
+    def forward(ctx, lo, cur):
+        B, C, h, w = lo.shape
+        H, W = cur.shape[-2:]
+        lo_c = lo.contiguous(memory_format=torch.channels_last)
+        cur_c = cur.contiguous(memory_format=torch.channels_last)
+        y = torch.empty_like(cur_c, memory_format=torch.channels_last)
+        _lib.check(_lib.load().pd_upsample_add_nhwc_f32(lo_c.data_ptr(), cur_c.data_ptr(), y.data_ptr(), B, h, w, H, W, C, _stream()))
+        ctx.dims = (B, C, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, h, w = ctx.dims
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dlo = torch.empty((B, C, h, w), dtype=torch.float32, device=dy.device).contiguous(memory_format=torch.channels_last)
+        _lib.check(_lib.load().pd_upsample2x_bwd_nhwc_f32(dy.data_ptr(), dlo.data_ptr(), B, h, w, C, _stream()))
+        return dlo, dy
+
+
+def upsample_add_supported(lo, cur):
+    return (lo.is_cuda and lo.dtype == torch.float32 and cur.dtype == torch.float32 and lo.shape[1] % 4 == 0
+            and cur.shape[-2] == 2 * lo.shape[-2] and cur.shape[-1] == 2 * lo.shape[-1] and not torch.is_autocast_enabled("cuda"))
+
+
+def upsample_add(lo, cur):
+    return UpsampleAdd.apply(lo, cur)

@@ -53,6 +53,8 @@ SIGNATURES = {
     "pd_gn_coeffs_fwd": (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [ctypes.c_float] + [_c_vp] * 6),
     "pd_gn_coeffs_bwd": (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_vp] * 6),
     "pd_point_sample_nhwc_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
+    "pd_upsample_add_nhwc_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 6 + [_c_vp]),
+    "pd_upsample2x_bwd_nhwc_f32": (_c_int, [_c_vp] * 2 + [_c_int] * 4 + [_c_vp]),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_abi_version": (_c_int, []),
     "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),

@@ -160,8 +160,10 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
         # ---- mask losses on the matched pairs (criterion.py:147-207)
         if sparse:
             e_sel = emb_bd[sel_b, sel_d, q_idx].float()                                          # [N,C]
-            mf32 = mfeat.float()
-            parts = [e_sel[per_image[b]] @ mf32[b].flatten(1) for b in range(B) if per_image[b].numel()]
+            # [hw, C] @ [C, n_b]: with channels-last mask features the operand is read in place and its gradient comes
+            # back channels-last, the layout the 1x1 mask_features convolution's backward wants
+            mf_tok = mfeat.float().permute(0, 2, 3, 1).reshape(B, -1, mfeat.shape[1])            # [B, hw, C]
+            parts = [(mf_tok[b] @ e_sel[per_image[b]].t()).t() for b in range(B) if per_image[b].numel()]
             src = torch.cat(parts)[inv_img].view(-1, 1, *mfeat.shape[-2:])                       # [N,1,h,w]
         else:
             src = masks_bd[sel_b, sel_d, q_idx][:, None].float()                                 # [N,1,h,w]

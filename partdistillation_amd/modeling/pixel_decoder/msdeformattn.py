@@ -18,7 +18,7 @@ from ...functions.fused import group_norm_nhwc, group_norm_nhwc_supported
 from ...functions.gemm import linear_f32
 from .ops.modules import MSDeformAttn
 from ...functions.encoder_core import EncoderCore, EncoderSpec
-from ...functions.rowwise import supports_width
+from ...functions.rowwise import supports_width, upsample_add, upsample_add_supported
 
 
 class MSDeformAttnTransformerEncoderLayer(nn.Module):
@@ -236,7 +236,10 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 x = features[f].float()
                 lat, outc = self.lateral_convs[idx], self.output_convs[idx]
                 cur = _conv_gn(lat, lat.norm, x, relu=lat.activation is not None)
-                y = cur + F.interpolate(out[-1], size=cur.shape[-2:], mode="bilinear", align_corners=False)
+                if upsample_add_supported(out[-1], cur):
+                    y = upsample_add(out[-1], cur)                # one pass; gather-form backward (functions/rowwise.py)
+                else:
+                    y = cur + F.interpolate(out[-1], size=cur.shape[-2:], mode="bilinear", align_corners=False)
                 out.append(_conv_gn(outc, outc.norm, y, relu=outc.activation is not None))
             multi_scale = out[: self.maskformer_num_feature_levels]
             return self.mask_features(out[-1]), out[0], multi_scale

@@ -301,3 +301,21 @@ def test_sparse_mask_criterion_matches_dense():
         scale = g1[k].abs().max().clamp_min(1e-6)
         assert ((g2[k] - g1[k]).abs().max() / scale).item() < 2e-3, k
     assert ((m2 - m1).abs().max() / m1.abs().max()).item() < 2e-3
+
+
+@pytest.mark.parametrize("B,C,h,w", [(2, 256, 16, 24), (1, 8, 1, 1), (1, 4, 5, 3)])
+def test_upsample_add_fwd_bwd_vs_torch(B, C, h, w):
+    from partdistillation_amd.functions.rowwise import upsample_add, upsample_add_supported
+    lo = _r((B, C, h, w), 71).contiguous(memory_format=torch.channels_last).requires_grad_()
+    cur = _r((B, C, 2 * h, 2 * w), 72).contiguous(memory_format=torch.channels_last).requires_grad_()
+    assert upsample_add_supported(lo, cur)
+    y = upsample_add(lo, cur)
+    gy = _r(y.shape, 73)
+    y.backward(gy)
+    g_lo, g_cur = lo.grad.clone(), cur.grad.clone()
+    lo.grad = cur.grad = None
+    ref = cur + F.interpolate(lo, size=cur.shape[-2:], mode="bilinear", align_corners=False)
+    ref.backward(gy)
+    torch.testing.assert_close(y, ref, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(g_lo, lo.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g_cur, cur.grad, rtol=0, atol=0)
