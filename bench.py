@@ -206,7 +206,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    total_loss = float(sum(losses.values()))
+    total_loss = float(sum(v.detach() for v in losses.values()))
     if total_loss != total_loss or abs(total_loss) == float("inf"):
         raise SystemExit("bench.py: the loss is not finite after the timed steps - the measurement is invalid")
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "pd_point_sample_nhwc_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
     "pd_upsample_add_nhwc_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 6 + [_c_vp]),
     "pd_upsample2x_bwd_nhwc_f32": (_c_int, [_c_vp] * 2 + [_c_int] * 4 + [_c_vp]),
+    "pd_scores_argmax_u8": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp]),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_abi_version": (_c_int, []),
     "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),

@@ -109,6 +109,30 @@ class MSDeformAttnTransformerEncoder(nn.Module):
         return p
 
 
+class LevelPos(torch.autograd.Function):
+    """pos = cat_l(pos_embed_l + level_embed[l]) over the flattened levels (reference msdeformattn.py:80-84).  The sine
+    tables carry no gradient; d level_embed[l] is the column sum of d_pos over level l's tokens (pd_colsum_acc) instead
+    of a split + three strided reductions."""
+
+    @staticmethod
+    def forward(ctx, level_embed, *pos_embeds):
+        ctx.sizes = [int(p.shape[2] * p.shape[3]) for p in pos_embeds]
+        return torch.cat([p.flatten(2).transpose(1, 2) + level_embed[i].view(1, 1, -1) for i, p in enumerate(pos_embeds)], 1)
+
+    @staticmethod
+    def backward(ctx, d_pos):
+        from ...functions.rowwise import colsum_acc
+        d_pos = d_pos if d_pos.is_contiguous() else d_pos.contiguous()
+        B, S, C = d_pos.shape
+        d_le = torch.zeros((len(ctx.sizes), C), dtype=torch.float32, device=d_pos.device)
+        start = 0
+        for l, n in enumerate(ctx.sizes):
+            for b in range(B):
+                colsum_acc(d_pos[b, start:start + n], d_le[l])
+            start += n
+        return (d_le,) + (None,) * len(ctx.sizes)
+
+
 class MSDeformAttnTransformerEncoderOnly(nn.Module):
     def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, dim_feedforward=1024, dropout=0.1,
                  activation="relu", num_feature_levels=4, enc_n_points=4):
@@ -139,8 +163,11 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
             self._shape_cache[key] = (sh, torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1])))
         spatial_shapes, level_start_index = self._shape_cache[key]
         src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
-        pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[i].view(1, 1, -1)
-                         for i, p in enumerate(pos_embeds)], 1)
+        if src.is_cuda and src.dtype == torch.float32 and self.level_embed.dtype == torch.float32 and self.d_model % 128 == 0:
+            pos = LevelPos.apply(self.level_embed, *pos_embeds)          # same values; backward = 2 column-sum launches per level
+        else:
+            pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[i].view(1, 1, -1)
+                             for i, p in enumerate(pos_embeds)], 1)
         valid_ratios = src.new_ones((src.shape[0], len(srcs), 2))
         memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, None, shapes_host=shapes_host)
         return memory, spatial_shapes, level_start_index, shapes_host

@@ -147,3 +147,31 @@ def make_targets(cfg, seed, size=None):
         masks = torch.stack([(lab == k) & inside for k in range(n)])
         out.append({"labels": torch.zeros(n, dtype=torch.int64), "masks": masks})
     return out
+
+
+# ----------------------------------------------------------------------------- proposal generation (BASELINE config 4)
+PROPGEN = dict(C3=16, C4=24, K=4, size_div=32, images=[(128, 128, 128, 128), (112, 128, 96, 110)])   # (H, W, out_h, out_w)
+
+
+def make_propgen_inputs(cfg=PROPGEN, seed=4100):
+    """synthetic backbone features (smooth fields + noise), one elliptical object mask per image, image / output sizes"""
+    import torch.nn.functional as F
+    Hp = max(i[0] for i in cfg["images"])
+    Wp = max(i[1] for i in cfg["images"])
+    d = cfg["size_div"]
+    Hp, Wp = (Hp + d - 1) // d * d, (Wp + d - 1) // d * d
+    B = len(cfg["images"])
+    feats = {}
+    for key, ch, stride, s0 in (("res3", cfg["C3"], 8, seed), ("res4", cfg["C4"], 16, seed + 1)):
+        h, w = Hp // stride, Wp // stride
+        base = F.interpolate(seeded((B, ch, 3, 3), s0), size=(h, w), mode="bilinear", align_corners=False)
+        feats[key] = base + 0.15 * seeded((B, ch, h, w), s0 + 10)
+    inputs = []
+    for b, (H, W, oh, ow) in enumerate(cfg["images"]):
+        ys, xs = torch.meshgrid(torch.arange(H) / H, torch.arange(W) / W, indexing="ij")
+        m = ((ys - 0.5) ** 2 / 0.12 + (xs - 0.45) ** 2 / 0.09) < 1.0
+        inputs.append({"image": seeded((3, H, W), seed + 20 + b) * 50 + 100, "mask": m[None].float(),   # float 0/1: the reference resizes it bilinearly
+                       "height": oh, "width": ow,
+                       "file_name": f"img{b}.pth", "file_path": f"/nowhere/img{b}.JPEG", "class_code": "n000", "class_name": "thing",
+                       "gt_object_class": 7})
+    return feats, inputs

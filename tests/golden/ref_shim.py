@@ -131,6 +131,78 @@ class DropPath(nn.Module):
         return x * mask / keep
 
 
+def sem_seg_postprocess(result, img_size, output_height, output_width):
+    """detectron2.modeling.postprocessing.sem_seg_postprocess (0.6): crop the padding, bilinear resize."""
+    result = result[:, : img_size[0], : img_size[1]].expand(1, -1, -1, -1)
+    return F.interpolate(result, size=(output_height, output_width), mode="bilinear", align_corners=False)[0]
+
+
+class _Instances:
+    """detectron2.structures.Instances, as far as the inference branches use it (attribute bag)."""
+
+    def __init__(self, image_size, **kw):
+        self.__dict__["_image_size"] = image_size
+        self.__dict__["_fields"] = dict(kw)
+
+    def __setattr__(self, k, v):
+        self._fields[k] = v
+
+    def __getattr__(self, k):
+        try:
+            return self.__dict__["_fields"][k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def has(self, k):
+        return k in self._fields
+
+    def to(self, *a, **k):
+        return self
+
+
+class _ImageList:
+    """detectron2.structures.ImageList.from_tensors: zero-pad (bottom / right) to the largest size, rounded up to the
+    divisibility."""
+
+    def __init__(self, tensor, image_sizes):
+        self.tensor, self.image_sizes = tensor, image_sizes
+
+    @staticmethod
+    def from_tensors(tensors, size_divisibility=0, pad_value=0.0):
+        sizes = [tuple(t.shape[-2:]) for t in tensors]
+        H, W = max(s[0] for s in sizes), max(s[1] for s in sizes)
+        if size_divisibility > 1:
+            H = (H + size_divisibility - 1) // size_divisibility * size_divisibility
+            W = (W + size_divisibility - 1) // size_divisibility * size_divisibility
+        out = tensors[0].new_full((len(tensors), tensors[0].shape[0], H, W), pad_value)
+        for i, t in enumerate(tensors):
+            out[i, :, : t.shape[-2], : t.shape[-1]] = t
+        return _ImageList(out, sizes)
+
+
+def install_inference_standins():
+    """stand-ins needed only to IMPORT the eval-side meta-architectures (proposal generation): logging / visualisation /
+    serialisation packages that the functions exercised by the goldens never call."""
+    comm = sys.modules["detectron2.utils.comm"]
+    comm.is_main_process = lambda: False
+    comm.synchronize = lambda: None
+    _mod("wandb")
+    _mod("detectron2.data", MetadataCatalog=types.SimpleNamespace(get=lambda name: types.SimpleNamespace(save_path="/tmp/pd_ref_save", class_codes=[])))
+    m = sys.modules["detectron2.modeling"]
+    m.build_backbone = lambda cfg: None
+    _mod("detectron2.modeling.backbone", Backbone=nn.Module)
+    _mod("detectron2.modeling.postprocessing", sem_seg_postprocess=sem_seg_postprocess)
+    _mod("detectron2.structures", ImageList=_ImageList, Instances=_Instances, BitMasks=None)
+    _mod("detectron2.utils.memory", retry_if_cuda_oom=lambda f: f)
+    _mod("detectron2.utils.visualizer", ColorMode=None, Visualizer=object, GenericMask=None, _create_text_labels=None)
+    _mod("pycocotools")
+    _mod("pycocotools.mask")
+    _mod("pydensecrf")
+    _mod("pydensecrf.densecrf")
+    _mod("pydensecrf.utils")
+    return importlib.import_module("part_distillation.proposal_generation_model")
+
+
 def install():
     """Install stand-ins into sys.modules and return the reference leaf modules."""
     if "part_distillation" in sys.modules and getattr(sys.modules["part_distillation"], "_shimmed", False):

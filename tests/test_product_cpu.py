@@ -147,3 +147,24 @@ def test_pinned_ring_hands_out_distinct_staging_buffers():
     assert plan.src_ptrs.tolist() == [a.data_ptr(), b.data_ptr()]
     plan.upload([None], t_begin=1)
     assert plan.src_ptrs.tolist() == [a.data_ptr(), 0]
+
+
+def test_proposal_generation_model_registers_and_builds():
+    """BASELINE config 4 meta-architecture behind the reference's registry name / config keys; its label-map op is
+    GPU-only and fails loudly on the CPU"""
+    import torch
+    import partdistillation_amd.modeling  # noqa: F401
+    import partdistillation_amd.proposal_generation_model as pg
+    from partdistillation_amd.compat import META_ARCH_REGISTRY
+    from partdistillation_amd.config import setup_cfg
+    assert "ProposalGenerationModel" in META_ARCH_REGISTRY
+    cfg = setup_cfg(os.path.join(CONFIGS, "proposal_generation", "r50.yaml"))
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg).eval()
+    assert isinstance(model, pg.ProposalGenerationModel) and model.backbone_feature_key_list == ["res3", "res4"]
+    assert model.distance_metric == "dot" and model.num_superpixel_clusters == 4 and not model.feature_normalize
+    setup_cfg(os.path.join(CONFIGS, "proposal_generation", "swinl.yaml"))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        model._label_map(torch.zeros(4, 4, 4), torch.ones(32, 32, dtype=torch.bool), (32, 32), (32, 32), 32, 32)
+    assert model.training is False
+    with pytest.raises(AssertionError):
+        model.train()([])

@@ -1,0 +1,102 @@
+"""GPU parity of the pixel-grouping proposal generation (BASELINE config 4): label-map kernel, device
+K-means and the whole ProposalGenerationModel against the CPU oracle and the goldens captured from the reference."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import common as C
+from oracle import proposal_generation_ref as P
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("K,h,w,Hp,Wp,H,W", [(4, 16, 16, 128, 128, 128, 128), (4, 16, 16, 128, 128, 112, 120), (7, 5, 9, 40, 72, 33, 70)])
+def test_scores_argmax_kernel_vs_torch(K, h, w, Hp, Wp, H, W):
+    from partdistillation_amd import lib
+    scores = C.seeded((K, h, w), 1).to(DEV)
+    mask = (C.seeded((H, W), 2) > -0.3).to(DEV)
+    labels = torch.empty((H, W), dtype=torch.uint8, device=DEV)
+    lib.check(lib.load().pd_scores_argmax_u8(scores.data_ptr(), mask.to(torch.uint8).data_ptr(), labels.data_ptr(), K, h, w, Hp, Wp, H, W,
+                                             lib.current_stream()))
+    up = F.interpolate(scores[None], size=(Hp, Wp), mode="bilinear", align_corners=False)[0, :, :H, :W]
+    want = torch.where(mask, up.argmax(0) + 1, torch.zeros((), dtype=torch.long, device=DEV))
+    top2 = up.topk(2, dim=0)[0]
+    clear = (top2[0] - top2[1]) > 1e-5                       # leave out numerical near-ties
+    assert torch.equal(labels.long()[clear], want[clear]) and (~clear).float().mean() < 0.01
+    assert (labels[~mask] == 0).all()
+
+
+def test_device_lloyd_matches_oracle_and_sklearn_semantics():
+    from partdistillation_amd.functions.kmeans import kmeans_lloyd
+    rng = np.random.default_rng(5)
+    for N, Cc, K in [(83, 40, 4), (5700, 64, 4), (40, 8, 3)]:
+        blobs = rng.normal(size=(K, Cc)).astype(np.float32) * 2
+        X = (blobs[rng.integers(K, size=N)] + rng.normal(size=(N, Cc)).astype(np.float32)).astype(np.float32)
+        init = X[rng.choice(N, K, replace=False)].copy()
+        c_ref, l_ref, it_ref = P.kmeans_lloyd_np(X, init)
+        c, l, it = kmeans_lloyd(torch.from_numpy(X).to(DEV), K, init=torch.from_numpy(init).to(DEV))
+        assert (l.cpu().numpy() != l_ref).mean() < 2e-3, (N, Cc, K)
+        np.testing.assert_allclose(c.cpu().numpy(), c_ref, rtol=1e-3, atol=1e-3)
+        assert abs(it - it_ref) <= 1
+
+
+def test_kmeans_plusplus_seeding_gives_a_comparable_partition():
+    """own RNG, so not sklearn's partition - but the objective must be in the same league"""
+    from sklearn.cluster import KMeans
+    from partdistillation_amd.functions.kmeans import kmeans_lloyd
+    rng = np.random.default_rng(9)
+    blobs = rng.normal(size=(4, 32)).astype(np.float32) * 3
+    X = (blobs[rng.integers(4, size=2000)] + rng.normal(size=(2000, 32)).astype(np.float32)).astype(np.float32)
+    sk = KMeans(n_clusters=4, random_state=0).fit(X)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    c, l, _ = kmeans_lloyd(torch.from_numpy(X).to(DEV), 4, generator=g)
+    inertia = ((torch.from_numpy(X).to(DEV) - c[l]) ** 2).sum().item()
+    assert inertia < 1.1 * sk.inertia_
+
+
+def _model(metric, norm, feats):
+    from partdistillation_amd.proposal_generation_model import ProposalGenerationModel
+
+    class Stub(torch.nn.Module):
+        size_divisibility = 32
+
+        def forward(self, x):
+            return {k: v.to(x.device) for k, v in feats.items()}
+    m = ProposalGenerationModel(backbone=Stub(), size_divisibility=C.PROPGEN["size_div"], dataset_name="synthetic",
+                                pixel_mean=[123.675, 116.28, 103.53], pixel_std=[58.395, 57.12, 57.375], distance_metric=metric,
+                                backbone_feature_key_list=["res3", "res4"], num_superpixel_clusters=C.PROPGEN["K"],
+                                feature_normalize=norm)
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize("tag,metric,norm", [("dot_0", "dot", False), ("l2_1", "l2", True)])
+def test_proposal_generation_model_vs_reference_golden(golden, tag, metric, norm):
+    """whole model (stub backbone) with the reference's final centroids as the K-means start: the label map from the
+    low-resolution score maps must reproduce the reference's dense full-resolution labelling"""
+    from partdistillation_amd.compat import BitMasks, Instances
+    from partdistillation_amd.utils import rle
+    g = golden("propgen")[tag]
+    feats, inputs = C.make_propgen_inputs()
+    model = _model(metric, norm, feats)
+    model.init_centroids = lambda i: g[i]["centroids"].to(DEV)
+    batched = []
+    for i in inputs:
+        inst = Instances(tuple(i["mask"].shape[-2:]))
+        inst.gt_masks = BitMasks(i["mask"])
+        batched.append({"image": i["image"], "instances": inst, "height": i["height"], "width": i["width"], "file_name": i["file_name"],
+                        "class_code": i["class_code"], "gt_object_class": i["gt_object_class"]})
+    res = model(batched)
+    for r, want in zip(res, g):
+        torch.testing.assert_close(r["centroids"].cpu(), want["centroids"], rtol=1e-3, atol=1e-4)
+        assert r["kmeans_iterations"] <= 2
+        got = model.binary_masks(r).cpu()
+        assert got.shape == want["pseudo_label"].shape
+        mismatch = (got != want["pseudo_label"]).any(0).float().mean().item()
+        assert mismatch < 2e-3, mismatch                     # fp32 re-association at near-ties only
+        assert r["height"] == want["pseudo_label"].shape[1] and r["class_index"] == 7
+        assert abs(r["object_ratio"] - want["object_mask_resized"].float().mean().item()) < 1e-6
+        for j, l in zip(r["part_mask"], r["present_labels"]):
+            seg = j["segmentation"]
+            assert (rle.decode({"size": seg["size"], "counts": seg["counts"]}) == (r["labels"].cpu().numpy() == l)).all()
