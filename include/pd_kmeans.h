@@ -1,0 +1,41 @@
+/*
+ * pd_kmeans.h — C-ABI of the device K-means (Lloyd) iteration of libpd_hip.so, batched over images.
+ *
+ * Replaces `sklearn.cluster.KMeans(n_clusters=K, random_state=0).fit(data)` on the CPU in the reference's pixel grouping
+ * (proposal_generation_model.py:202-211; scikit-learn 1.7 `_kmeans_single_lloyd` semantics: an iteration assigns every
+ * point to argmin_k |c_k|^2 - 2 x.c_k (first minimum) and moves the centres to the cluster means; it stops when no label
+ * changed, or when the squared centre shift <= tol).  The convergence test lives on the device, so the host issues
+ * iterations without reading anything back and looks at `done` only every few iterations.
+ *
+ * Points of all images are concatenated: X fp32 [N, C] (C % 4 == 0, C <= 2048), K <= 4 centres per image; `blocks` is an
+ * int32 [n_blocks, 3] table (image, first point, point count <= 64) so that no workgroup straddles two images.
+ */
+#ifndef PD_KMEANS_H
+#define PD_KMEANS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * E-step + accumulation for every image b with done[b] == 0:
+ *   labels[n] = argmin_k cnorm[b,k] - 2 x_n . centers[b,k]     changed[b] += #(labels[n] != previous labels[n])
+ *   sums[b,k,:] += x_n,  counts[b,k] += 1   for the new label (sums / counts / changed must be zero on entry)
+ */
+int pd_kmeans_assign(const float *X, const int32_t *blocks, int n_blocks, const float *centers, const float *cnorm,
+                     const int32_t *done, int32_t *labels, float *sums, float *counts, int32_t *changed, int C, int K, void *stream);
+
+/*
+ * M-step + convergence for every image b with done[b] == 0:  centers[b,k] = sums / counts (unchanged when the cluster is
+ * empty), cnorm recomputed, n_iter[b] += 1, done[b] = (changed[b] == 0) || (sum_k |new - old|^2 <= tol[b]); then sums,
+ * counts and changed are cleared for the next pd_kmeans_assign.
+ */
+int pd_kmeans_update(float *centers, float *cnorm, float *sums, float *counts, int32_t *changed, const float *tol, int32_t *done,
+                     int32_t *n_iter, int B, int K, int C, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PD_KMEANS_H */

@@ -7,11 +7,17 @@ iteration assigns every point to argmin_k |c_k|^2 - 2 x.c_k (first minimum) and 
 means; it stops when the labels repeat (strict convergence) or when the squared centre shift <= tol, in which case the
 assignment is recomputed once for the final centres.  Differences: the k-means++ seeding uses the device generator
 (numpy's RandomState stream is not reproduced — parity tests inject the initial centres), and empty clusters keep their
-previous centre instead of sklearn's relocation heuristic.  The two GEMM-shaped steps (point x centre scores, one-hot x
-points) are library GEMMs; the whole loop stays on the device with one scalar read-back per iteration."""
+previous centre instead of sklearn's relocation heuristic.
+
+`kmeans_lloyd_batched` is the product path: all images of a batch advance together through pd_kmeans_assign /
+pd_kmeans_update (include/pd_kmeans.h: one wavefront per point, convergence decided on the device, the host looks at the
+`done` flags every few iterations).  `kmeans_lloyd` is the same algorithm in library calls with a read-back per
+iteration (more than 4 clusters or more than 2048 channels)."""
 import math
 
 import torch
+
+from .. import lib as _lib
 
 
 def kmeans_plusplus(X, K, generator=None):
@@ -63,3 +69,46 @@ def kmeans_lloyd(X, K, init=None, max_iter=300, tol=1e-4, generator=None):
     if not strict:
         labels = ((centers * centers).sum(1)[None, :] - 2.0 * (Xc @ centers.t())).argmin(1)
     return centers + mean, labels, it
+
+
+def kmeans_lloyd_batched(datas, K, inits=None, max_iter=300, tol=1e-4, generator=None, check_every=8):
+    """datas: list of [N_b, C] fp32 CUDA tensors (N_b > K) -> (centres [B,K,C], iterations list).  HIP kernels; K <= 4,
+    C % 4 == 0, C <= 2048 (else falls back to kmeans_lloyd per image)."""
+    B, C = len(datas), datas[0].shape[1]
+    dev = datas[0].device
+    if not dev.type == "cuda":
+        raise RuntimeError("pd_kmeans_* run on the GPU only (no CPU fallback in partdistillation_amd)")
+    if K > 4 or C % 4 or C > 2048:
+        out = [kmeans_lloyd(d, K, init=None if inits is None else inits[b], max_iter=max_iter, tol=tol, generator=generator)
+               for b, d in enumerate(datas)]
+        return torch.stack([o[0] for o in out]), [o[2] for o in out]
+    means = [d.float().mean(0) for d in datas]
+    Xs = [d.float() - m for d, m in zip(datas, means)]
+    tols = torch.stack([x.var(0, unbiased=False).mean() * tol for x in Xs]).float().contiguous()
+    centers = torch.stack([(inits[b].float() - means[b]) if inits is not None and inits[b] is not None else kmeans_plusplus(Xs[b], K, generator)
+                           for b in range(B)]).contiguous()                                 # [B,K,C]
+    X = torch.cat(Xs).contiguous()
+    table, off = [], 0
+    for b, x in enumerate(Xs):
+        for s0 in range(0, x.shape[0], 64):
+            table.append((b, off + s0, min(64, x.shape[0] - s0)))
+        off += x.shape[0]
+    blocks = torch.tensor(table, dtype=torch.int32, device=dev)
+    labels = torch.full((X.shape[0],), -1, dtype=torch.int32, device=dev)
+    sums = torch.zeros((B, K, C), dtype=torch.float32, device=dev)
+    counts = torch.zeros((B, K), dtype=torch.float32, device=dev)
+    flags = torch.zeros((3, B), dtype=torch.int32, device=dev)                               # changed, done, n_iter
+    cnorm = (centers * centers).sum(-1).contiguous()
+    lib, st = _lib.load(), _lib.current_stream()
+    it = 0
+    while it < max_iter:
+        for _ in range(min(check_every, max_iter - it)):
+            _lib.check(lib.pd_kmeans_assign(X.data_ptr(), blocks.data_ptr(), len(table), centers.data_ptr(), cnorm.data_ptr(),
+                                            flags[1].data_ptr(), labels.data_ptr(), sums.data_ptr(), counts.data_ptr(),
+                                            flags[0].data_ptr(), C, K, st))
+            _lib.check(lib.pd_kmeans_update(centers.data_ptr(), cnorm.data_ptr(), sums.data_ptr(), counts.data_ptr(), flags[0].data_ptr(),
+                                            tols.data_ptr(), flags[1].data_ptr(), flags[2].data_ptr(), B, K, C, st))
+            it += 1
+        if bool(flags[1].all()):                                                             # the only read-back
+            break
+    return centers + torch.stack(means)[:, None, :], flags[2].tolist()

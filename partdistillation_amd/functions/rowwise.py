@@ -30,6 +30,7 @@ def add_ln_fwd(x, res, gamma, beta, eps, *, want_z=True, want_y=True, c_dtype=No
     rows, C = ref.shape
     dev = ref.device
     assert (x is None or x.is_contiguous()) and (res is None or (res.is_contiguous() and res.dtype == torch.float32))
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C and beta.numel() == C
     z = torch.empty((rows, C), dtype=torch.float32, device=dev) if want_z else None
     y = torch.empty((rows, C), dtype=torch.float32, device=dev) if want_y else None
     y_c = torch.empty((rows, C), dtype=c_dtype, device=dev) if want_yc else None
@@ -48,6 +49,7 @@ def add_ln_bwd(z, mean, rstd, gamma, *, dy=None, dy2=None, dy_c=None, dypos_c=No
                dbias=None, dpos_acc=None, pos_div=1, out=None):
     """-> (dz fp32, dz_c | None).  dgamma / dbeta / dbias / dpos_acc are fp32 accumulators (+=)."""
     rows, C = z.shape
+    assert z.dtype == torch.float32 and gamma.dtype == torch.float32 and mean.dtype == torch.float32
     cd = None
     for t in (dy_c, dypos_c):
         if t is not None:
@@ -91,6 +93,7 @@ def mem_prep_fwd(x, level_embed, pos, c_dtype):
     _need_cuda(x, "pd_mem_prep_fwd")
     B, C, H, W = x.shape
     t, bstride = _token_view(x)
+    assert pos.dtype == torch.float32 and pos.is_contiguous() and (level_embed is None or level_embed.dtype == torch.float32)
     mem = torch.empty((H * W * B, C), dtype=c_dtype, device=x.device)
     mempos = torch.empty((H * W * B, C), dtype=c_dtype, device=x.device)
     _lib.check(_lib.load().pd_mem_prep_fwd(t.data_ptr(), bstride, _p(level_embed), pos.data_ptr(), mem.data_ptr(), mempos.data_ptr(),

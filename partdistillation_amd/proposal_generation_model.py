@@ -19,7 +19,7 @@ from torch import nn
 
 from . import lib as _lib
 from .compat import META_ARCH_REGISTRY, ImageList, build_backbone, configurable
-from .functions.kmeans import kmeans_lloyd
+from .functions.kmeans import kmeans_lloyd_batched
 from .utils import rle
 
 
@@ -90,12 +90,13 @@ class ProposalGenerationModel(nn.Module):
         s = centroids @ feat.reshape(C, h * w)                                         # [K, hw]
         if self.distance_metric == "l2":
             s = 2.0 * s - (centroids * centroids).sum(1)[:, None]
-        return s.reshape(-1, h, w).contiguous()
+        return s.reshape(-1, h, w).float().contiguous()
 
     def _label_map(self, scores, object_mask_resized, pad_hw, image_size, height, width):
         """uint8 [height, width]: 1 + arg-max centroid on the object's pixels, 0 elsewhere."""
         K, h, w = scores.shape
         Hp, Wp = pad_hw
+        assert scores.dtype == torch.float32 and scores.is_contiguous()
         if (height, width) == tuple(image_size) and scores.is_cuda:
             m8 = object_mask_resized.to(torch.uint8).contiguous()
             labels = torch.empty((height, width), dtype=torch.uint8, device=scores.device)
@@ -116,22 +117,36 @@ class ProposalGenerationModel(nn.Module):
         images = [(x["image"].to(self.device) - self.pixel_mean) / self.pixel_std for x in batched_inputs]
         images = ImageList.from_tensors(images, self.size_divisibility)
         targets = self.prepare_mask(batched_inputs, images)
-        features = self._prepare_features(self.backbone(images.tensor))
+        backbone_out = self.backbone(images.tensor)               # may run under the caller's autocast
+        with torch.autocast(device_type=self.device.type, enabled=False):
+            return self._group(batched_inputs, images, targets, self._prepare_features(backbone_out))
+
+    def _group(self, batched_inputs, images, targets, features):
+        """clustering + labelling, always fp32 (the kernels take fp32 score maps)"""
         pad_hw = tuple(images.tensor.shape[-2:])
-        results = []
+        K = self.num_superpixel_clusters
+        prep, datas, inits = [], [], []
         for i, (inp, feat, image_size, tgt) in enumerate(zip(batched_inputs, features, images.image_sizes, targets)):
             height, width = inp.get("height", image_size[0]), inp.get("width", image_size[1])
             masks = tgt["masks"]
             mask_resized = sem_seg_postprocess(masks.float(), image_size, height, width)[0].bool()
             mask_low = F.interpolate(masks[None].float(), size=feat.shape[-2:], mode="nearest")[0, 0].bool()
             data = feat[:, mask_low].t().contiguous()                                      # [N, C] object pixels at 1/8 res
-            if data.shape[0] <= self.num_superpixel_clusters:
-                results.append(None)
-                continue
-            init = self.init_centroids(i) if self.init_centroids is not None else None
-            centroids, _, n_iter = kmeans_lloyd(data, self.num_superpixel_clusters, init=init, generator=self.kmeans_generator)
-            labels = self._label_map(self._scores(feat, centroids), mask_resized, pad_hw, image_size, height, width)
-            results.append(self._result(inp, labels, mask_resized, centroids, n_iter))
+            ok = data.shape[0] > K
+            prep.append((ok, mask_resized, height, width))
+            if ok:
+                datas.append(data)
+                inits.append(self.init_centroids(i) if self.init_centroids is not None else None)
+        results = [None] * len(prep)
+        if datas:                                                                          # all images advance together
+            centroids, n_iters = kmeans_lloyd_batched(datas, K, inits=inits, generator=self.kmeans_generator)
+            j = 0
+            for i, (ok, mask_resized, height, width) in enumerate(prep):
+                if not ok:
+                    continue
+                labels = self._label_map(self._scores(features[i], centroids[j]), mask_resized, pad_hw, images.image_sizes[i], height, width)
+                results[i] = self._result(batched_inputs[i], labels, mask_resized, centroids[j], n_iters[j])
+                j += 1
         self.num_test_iterations += 1
         return results
 
@@ -140,9 +155,13 @@ class ProposalGenerationModel(nn.Module):
         counts = torch.bincount(labels.flatten().long(), minlength=self.num_superpixel_clusters + 1)
         counts_h = counts.tolist()                                                         # one small read-back per image
         present = [l for l in range(1, len(counts_h)) if counts_h[l] > 0]
-        labels_h = labels.cpu().numpy()
+        # run-length form of the column-major label map on the device; only the run table crosses to the host
+        flat = labels.t().contiguous().flatten()
+        starts = torch.cat([flat.new_zeros(1, dtype=torch.long), (flat[1:] != flat[:-1]).nonzero().flatten() + 1])
+        values = flat[starts].cpu().numpy()
+        lengths = torch.diff(starts, append=starts.new_tensor([flat.numel()])).cpu().numpy()
         res = {"file_name": inp.get("file_name"), "file_path": inp.get("file_path"), "class_code": inp.get("class_code"),
-               "class_name": inp.get("class_name"), "part_mask": rle.labels_to_coco_json(labels_h, present),
+               "class_name": inp.get("class_name"), "part_mask": rle.runs_to_coco_json(values, lengths, (H, W), present),
                "object_ratio": int(object_mask.sum().item()) / (H * W), "height": H, "width": W,
                "class_index": inp.get("gt_object_class")}
         if self.root_save_path is not None and res["class_code"] is not None and res["file_name"] is not None:

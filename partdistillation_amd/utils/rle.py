@@ -22,19 +22,25 @@ def mask_to_counts(mask: np.ndarray) -> np.ndarray:
 
 
 def counts_to_string(counts) -> bytes:
-    out = bytearray()
-    cnts = [int(c) for c in counts]
-    for i, c in enumerate(cnts):
-        x = c - cnts[i - 2] if i > 2 else c
-        more = True
-        while more:
-            ch = x & 0x1F
-            x >>= 5
-            more = (x != -1) if (ch & 0x10) else (x != 0)
-            if more:
-                ch |= 0x20
-            out.append(ch + 48)
-    return bytes(out)
+    """vectorised rleToString: all counts advance one 5-bit group per pass (at most 13 passes for int64)"""
+    c = np.asarray(counts, dtype=np.int64).reshape(-1)
+    n = c.shape[0]
+    if n == 0:
+        return b""
+    x = c.copy()
+    if n > 3:
+        x[3:] -= c[1:-2]
+    active = np.ones(n, dtype=bool)
+    cols, valids = [], []
+    while active.any():
+        ch = x & 0x1F
+        x = x >> 5                                                     # arithmetic shift
+        more = np.where((ch & 0x10) != 0, x != -1, x != 0)
+        cols.append(((ch | np.where(more, 0x20, 0)) + 48).astype(np.uint8))
+        valids.append(active.copy())
+        active &= more
+    chars = np.stack(cols, axis=1)                                     # [n, groups], row-major = emission order
+    return chars[np.stack(valids, axis=1)].tobytes()
 
 
 def string_to_counts(s) -> np.ndarray:
@@ -83,4 +89,25 @@ def labels_to_coco_json(labels: np.ndarray, present) -> list:
         rle = encode(labels == l)
         rle["counts"] = rle["counts"].decode("utf-8")
         out.append({"segmentation": rle})
+    return out
+
+
+def runs_to_coco_json(values: np.ndarray, lengths: np.ndarray, size, present) -> list:
+    """same as labels_to_coco_json, from the run-length form of the COLUMN-major flattened label map (values[i] repeated
+    lengths[i] times): the per-label masks are merges of those runs, no per-pixel work."""
+    out = []
+    h, w = int(size[0]), int(size[1])
+    values, lengths = np.asarray(values), np.asarray(lengths, dtype=np.int64)
+    ends = np.cumsum(lengths)
+    for l in present:
+        on = values == l
+        if on.size == 0:
+            counts = np.zeros((0,), dtype=np.int64)
+        else:
+            change = np.flatnonzero(on[1:] != on[:-1]) + 1             # first run of each merged group
+            bounds = np.concatenate(([0], ends[change - 1], [ends[-1]]))
+            counts = np.diff(bounds)
+            if on[0]:
+                counts = np.concatenate(([0], counts))
+        out.append({"segmentation": {"size": [h, w], "counts": counts_to_string(counts).decode("utf-8")}})
     return out

@@ -42,6 +42,28 @@ def test_device_lloyd_matches_oracle_and_sklearn_semantics():
         assert abs(it - it_ref) <= 1
 
 
+def test_batched_hip_lloyd_matches_oracle():
+    """pd_kmeans_assign / pd_kmeans_update, three images of different sizes advancing together, against the sklearn-pinned
+    restatement with the same initial centres: same iteration counts, same centres"""
+    from partdistillation_amd.functions.kmeans import kmeans_lloyd_batched
+    rng = np.random.default_rng(11)
+    datas, inits, refs = [], [], []
+    for N, K in [(83, 4), (5431, 4), (700, 4)]:
+        Cc = 1152
+        blobs = rng.normal(size=(K, Cc)).astype(np.float32)
+        X = (blobs[rng.integers(K, size=N)] + 1.5 * rng.normal(size=(N, Cc)).astype(np.float32)).astype(np.float32)
+        init = X[rng.choice(N, K, replace=False)].copy()
+        datas.append(torch.from_numpy(X).to(DEV)), inits.append(torch.from_numpy(init).to(DEV))
+        refs.append(P.kmeans_lloyd_np(X, init))
+    centers, n_iters = kmeans_lloyd_batched(datas, 4, inits=inits)
+    for b, (c_ref, l_ref, it_ref) in enumerate(refs):
+        np.testing.assert_allclose(centers[b].cpu().numpy(), c_ref, rtol=2e-3, atol=2e-3)
+        assert abs(n_iters[b] - it_ref) <= 1, (b, n_iters[b], it_ref)
+    c3, n3 = kmeans_lloyd_batched([d[:, :40].contiguous() for d in datas[:1]], 3, inits=[inits[0][:3, :40].contiguous()])
+    c_ref, _, it_ref = P.kmeans_lloyd_np(datas[0][:, :40].cpu().numpy(), inits[0][:3, :40].cpu().numpy())
+    np.testing.assert_allclose(c3[0].cpu().numpy(), c_ref, rtol=2e-3, atol=2e-3)
+
+
 def test_kmeans_plusplus_seeding_gives_a_comparable_partition():
     """own RNG, so not sklearn's partition - but the objective must be in the same league"""
     from sklearn.cluster import KMeans
