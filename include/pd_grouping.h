@@ -27,6 +27,20 @@ extern "C" {
 int pd_scores_argmax_u8(const float *scores, const uint8_t *mask, uint8_t *labels, int K, int h, int w, int Hp, int Wp, int H,
                         int W, void *stream);
 
+/*
+ * Per-pixel assignment of the K selected query masks at inference (reference proposal_model.py:220-302:
+ * F.interpolate of [Q, H/4, W/4] logits to the padded image size, `* object mask` (:372-378), `_unique_assignment`
+ * :263-299).  The reference materialises [Q, H, W] fp32 three times (0.4 GB per image and copy at 1024^2, Q = 100);
+ * here the low-resolution logits (26 MB) are interpolated inside the one pass that consumes them:
+ *   v_k   = bilinear(logits_k)(y, x) * (object ? object[y, x] != 0 : 1)
+ *   arg   = argmax_k scores[k] * sigmoid(v_k)   (first maximum)              int16 [H, W]
+ *   obj   = max_k v_k > 0                                                     uint8 [H, W]
+ *   positive[k] += #pixels with v_k > 0         (int32 [K], caller zeroes)
+ * logits fp32 [K, h, w]; bilinear as in pd_scores_argmax_u8 (upsample to (Hp, Wp), top-left H x W crop).
+ */
+int pd_mask_assign(const float *logits, const float *scores, const uint8_t *object, int16_t *arg, uint8_t *obj, int32_t *positive,
+                   int K, int h, int w, int Hp, int Wp, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,145 @@
+"""Evaluation branch of ProposalModel on the device (reference proposal_model.py:220-302, 340-430).
+
+The reference upsamples all Q mask-logit maps to the padded image size, crops / resizes them, gathers the top-k,
+multiplies by the object mask, takes sigmoid, scales by the scores and arg-maxes per pixel — every step a full
+[Q, H, W] fp32 tensor (0.4 GB per image at 1024^2, Q = 100) — and computes mask IoUs on the CPU through pycocotools.
+Here (per-pixel-unique post-processing, the shipped default, no output resize) `pd_mask_assign` interpolates the
+low-resolution logits inside the single pass that consumes them and writes an int16 arg-max map, the object map and the
+per-query positive-pixel counts; areas, the validity filters and the IoUs with the ground-truth parts are histogram
+counts over that map (exact integers, IoU in float64 like pycocotools).  Other settings take the dense route with torch
+ops on the device."""
+import torch
+import torch.nn.functional as F
+
+from . import lib as _lib
+from .compat import Instances
+
+
+def sem_seg_postprocess(result, img_size, output_height, output_width):
+    """detectron2.modeling.postprocessing.sem_seg_postprocess: crop the padding, resize to the original resolution."""
+    result = result[:, : img_size[0], : img_size[1]].expand(1, -1, -1, -1)
+    return F.interpolate(result, size=(output_height, output_width), mode="bilinear", align_corners=False)[0]
+
+
+def mask_iou(pr, gt):
+    """COCO mask IoU (iscrowd = 0) of bool masks [P,H,W] x [n,H,W] -> float64 [P,n]; exact integer counts."""
+    a, b = pr.flatten(1).float(), gt.flatten(1).float()
+    inter = (a @ b.t()).double()                                          # 0/1 products, sums < 2^24: exact in fp32
+    union = a.sum(1).double()[:, None] + b.sum(1).double()[None, :] - inter
+    return torch.where(union > 0, inter / union.clamp_min(1), torch.zeros_like(inter))
+
+
+def _filter(masks_area, obj_area, scores, min_ratio, min_score):
+    """the two `if valid.any(): keep valid` filters of _unique_assignment (:277-285 / :289-297) as an index tensor"""
+    keep = torch.arange(scores.shape[0], device=scores.device)
+    valid = masks_area.double() / obj_area.double() > min_ratio
+    if bool(valid.any()):
+        keep = keep[valid]
+    valid = scores[keep] > min_score
+    if bool(valid.any()):
+        keep = keep[valid]
+    return keep
+
+
+def _match(iou, labels):
+    top1, top1_idx = iou.topk(1, dim=1)
+    fg = (top1 > 0.001).flatten()
+    return fg, labels[top1_idx.flatten()[fg]]
+
+
+def instance_inference_fused(model, mask_cls, logits_low, pad_hw, out_hw, target_masks, target_object_masks, target_labels, topk):
+    """unique-per-pixel post-processing without dense [Q,H,W] tensors; out_hw == un-padded image size."""
+    H, W = out_hw
+    dev = logits_low.device
+    scores = mask_cls.float().softmax(-1)[:, :-1].topk(1, dim=1)[0].flatten()
+    scores, idx = scores.topk(topk, sorted=False)
+    sel = logits_low[idx].float().contiguous()                                        # [K, h, w]
+    K, h, w = sel.shape
+    obj_in = None
+    if model.apply_masking_with_object_mask:
+        obj_in = target_object_masks.sum(dim=0).bool().to(torch.uint8).contiguous()
+    arg = torch.empty((H, W), dtype=torch.int16, device=dev)
+    obj = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    positive = torch.zeros((K,), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().pd_mask_assign(sel.data_ptr(), scores.contiguous().data_ptr(), obj_in.data_ptr() if obj_in is not None else None,
+                                          arg.data_ptr(), obj.data_ptr(), positive.data_ptr(), K, h, w, pad_hw[0], pad_hw[1], H, W,
+                                          _lib.current_stream()))
+    argl, objb = arg.long(), obj.bool()
+    ids = (torch.bincount(argl.flatten(), minlength=K) > 0).nonzero().flatten()       # scoremap.unique()
+    area = torch.bincount(argl[objb], minlength=K)                                    # |(scoremap == k) & obj_map|
+    keep = ids[_filter(area[ids], objb.sum(), scores[ids], model.minimum_pseudo_mask_ratio, model.minimum_pseudo_mask_score)]
+    # IoU with the ground-truth parts from histogram counts over the arg-max map
+    inter = torch.stack([torch.bincount(argl[objb & t], minlength=K) for t in target_masks]).t()[keep].double()    # [P, n]
+    union = area[keep].double()[:, None] + target_masks.flatten(1).sum(1).double()[None, :] - inter
+    iou = torch.where(union > 0, inter / union.clamp_min(1), torch.zeros_like(inter))
+    fg, labels = _match(iou, target_labels)
+    keep = keep[fg]
+    masks = (argl[None] == keep[:, None, None]) & objb[None]
+    return masks, scores[keep], labels
+
+
+def instance_inference_dense(model, mask_cls, mask_pred, target_masks, target_object_masks, target_labels, topk):
+    """the reference's sequence on dense [K,H,W] tensors (plain post-processing, or a resized output)"""
+    scores = mask_cls.float().softmax(-1)[:, :-1].topk(1, dim=1)[0].flatten()
+    scores, idx = scores.topk(topk, sorted=False)
+    mask_pred = mask_pred[idx]
+    if model.apply_masking_with_object_mask:
+        mask_pred = mask_pred * target_object_masks.sum(dim=0, keepdim=True).bool()
+    obj_map = mask_pred.max(dim=0)[0] > 0.0
+    if model.use_unique_per_pixel_label:
+        scoremap = (scores[:, None, None] * mask_pred.sigmoid()).argmax(0)
+        ids = scoremap.unique()
+        masks = (scoremap[None] == ids[:, None, None]) & obj_map[None]
+        scores = scores[ids]
+    else:
+        masks = mask_pred > 0
+    keep = _filter(masks.flatten(1).sum(1), obj_map.sum(), scores, model.minimum_pseudo_mask_ratio, model.minimum_pseudo_mask_score)
+    masks, scores = masks[keep], scores[keep]
+    fg, labels = _match(mask_iou(masks, target_masks), target_labels)
+    return masks[fg], scores[fg], labels
+
+
+def prepare_gt_targets(model, inputs, images):
+    """reference :340-366: part masks / labels (`part_instances`) and object masks (`instances`) padded to the batch size"""
+    h_pad, w_pad = images.tensor.shape[-2:]
+    out = []
+    for x in inputs:
+        parts, objs = x["part_instances"].to(model.device), x["instances"].to(model.device)
+        pm, om = parts.gt_masks.tensor, objs.gt_masks.tensor
+        ppad = torch.zeros((pm.shape[0], h_pad, w_pad), dtype=pm.dtype, device=pm.device)
+        ppad[:, : pm.shape[1], : pm.shape[2]] = pm
+        opad = torch.zeros((om.shape[0], h_pad, w_pad), dtype=om.dtype, device=om.device)
+        opad[:, : om.shape[1], : om.shape[2]] = om
+        out.append({"labels": parts.gt_classes.to(model.device), "masks": ppad, "object_masks": opad})
+    return out
+
+
+@torch.no_grad()
+def inference(model, batched_inputs, targets, images, outputs, vis=False):
+    """reference :220-258 -> [{"proposals": Instances(pred_masks, pred_classes, scores), "gt_masks": Instances(...)}]"""
+    logits_all = outputs["pred_masks"]
+    if logits_all is None:                                   # decoder ran without dense masks
+        from .modeling.transformer_decoder.mask2former_transformer_decoder import materialize_masks
+        logits_all = materialize_masks(dict(outputs))["pred_masks"]
+    pad_hw = tuple(images.tensor.shape[-2:])
+    topk = model.wandb_vis_topk if vis and not model.use_unique_per_pixel_label else model.test_topk_per_image
+    results = []
+    for cls, low, tgt, inp, size in zip(outputs["pred_logits"], logits_all, targets, batched_inputs, images.image_sizes):
+        height, width = inp.get("height", size[0]), inp.get("width", size[1])
+        tm = sem_seg_postprocess(tgt["masks"].float(), size, height, width).bool()
+        to = sem_seg_postprocess(tgt["object_masks"].float(), size, height, width).bool()
+        if model.use_unique_per_pixel_label and (height, width) == tuple(size) and low.is_cuda:
+            masks, scores, labels = instance_inference_fused(model, cls, low, pad_hw, (height, width), tm, to, tgt["labels"], topk)
+        else:
+            dense = F.interpolate(low[None].float(), size=pad_hw, mode="bilinear", align_corners=False)[0]
+            dense = sem_seg_postprocess(dense, size, height, width)
+            masks, scores, labels = instance_inference_dense(model, cls, dense, tm, to, tgt["labels"], topk)
+        if masks.shape[0] == 0:                               # does not contribute to the evaluation (:398-402)
+            masks = torch.zeros((1, height, width), dtype=torch.bool, device=low.device)
+            scores, labels = scores.new_zeros(1), labels.new_zeros(1)
+        r = Instances((height, width))
+        r.pred_masks, r.pred_classes, r.scores = masks, labels, scores
+        gt = Instances((height, width))
+        gt.gt_masks, gt.gt_classes, gt.pred_masks, gt.pred_classes = tm, tgt["labels"], tm, tgt["labels"]
+        results.append({"proposals": r, "gt_masks": gt})
+    return results

@@ -58,6 +58,7 @@ SIGNATURES = {
     "pd_scores_argmax_u8": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp]),
     "pd_kmeans_assign": (_c_int, [_c_vp, _c_vp, _c_int] + [_c_vp] * 7 + [_c_int, _c_int, _c_vp]),
     "pd_kmeans_update": (_c_int, [_c_vp] * 8 + [_c_int] * 3 + [_c_vp]),
+    "pd_mask_assign": (_c_int, [_c_vp] * 6 + [_c_int] * 7 + [_c_vp]),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_abi_version": (_c_int, []),
     "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),

@@ -3,8 +3,8 @@ part_distillation/proposal_model.py:30-217, 305-338): normalise, pad-batch,
 backbone, MaskFormer head, Hungarian set criterion, loss weighting.
 
 Registered under the reference's name in ``META_ARCH_REGISTRY`` and built from
-the same config keys (``from_config``).  The evaluation / visualisation
-branches (:205-302, 380-475) are SURVEY §8f "next" rows and raise here."""
+the same config keys (``from_config``).  The evaluation branch (:205-302, 340-430) lives in
+``inference.py``; the wandb visualisation (:451-475) is out of scope."""
 from typing import Tuple
 
 import torch
@@ -117,7 +117,7 @@ class ProposalModel(_MaskFormerTrainBase):
         super().__init__()
         self._init_common(backbone, sem_seg_head, criterion, num_queries, num_classes, size_divisibility, pixel_mean,
                           pixel_std)
-        self.test_topk_per_image = test_topk_per_image
+        self.test_topk_per_image, self.wandb_vis_topk = test_topk_per_image, wandb_vis_topk
         self.use_wandb = use_wandb                                   # accepted for config parity; never used here
         self.use_unique_per_pixel_label = use_unique_per_pixel_label
         self.minimum_pseudo_mask_score = minimum_pseudo_mask_score
@@ -144,7 +144,8 @@ class ProposalModel(_MaskFormerTrainBase):
 
     def prepare_targets(self, inputs, images):
         if not self.training:
-            raise NotImplementedError("ProposalModel evaluation targets: SURVEY §8f 'next' row, not built yet")
+            from .inference import prepare_gt_targets
+            return prepare_gt_targets(self, inputs, images)
         return self._prepare_pseudo_targets(inputs, images)
 
     def _prepare_pseudo_targets(self, inputs, images):
@@ -157,10 +158,13 @@ class ProposalModel(_MaskFormerTrainBase):
     def forward(self, batched_inputs):
         images = self.preprocess(batched_inputs)
         features = self.backbone(images.tensor)
+        if not self.training:                                          # evaluation branch (reference :205-217)
+            from .inference import inference
+            targets = self.prepare_targets(batched_inputs, images)
+            self.num_test_iterations = getattr(self, "num_test_iterations", 0) + 1
+            return inference(self, batched_inputs, targets, images, self.sem_seg_head(features))
         targets = self._share_padded_masks(self.prepare_targets(batched_inputs, images))
         outputs = self.sem_seg_head(features)
-        if not self.training:
-            raise NotImplementedError("ProposalModel inference: SURVEY §8f 'next' row, not built yet")
         losses = self._weighted(self.criterion(outputs, targets))
         self.num_train_iterations += 1
         return losses

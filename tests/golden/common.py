@@ -175,3 +175,28 @@ def make_propgen_inputs(cfg=PROPGEN, seed=4100):
                        "file_name": f"img{b}.pth", "file_path": f"/nowhere/img{b}.JPEG", "class_code": "n000", "class_name": "thing",
                        "gt_object_class": 7})
     return feats, inputs
+
+
+# ----------------------------------------------------------------------------- inference branch
+INFER = dict(Q=12, topk=8, low=32, size_div=32, images=[(96, 128, 96, 128), (128, 112, 100, 90)])   # (H, W, out_h, out_w)
+
+
+def make_infer_inputs(cfg=INFER, seed=5200):
+    """decoder outputs (class logits [B,Q,2], low-resolution mask logits [B,Q,low,low] made of smooth blobs) and per-image
+    ground truth: 3 part masks + labels (`part_instances`) and the object mask (`instances`)"""
+    import torch.nn.functional as F
+    B, Q, low = len(cfg["images"]), cfg["Q"], cfg["low"]
+    logits = seeded((B, Q, 2), seed) * 2
+    base = F.interpolate(seeded((B, Q, 5, 5), seed + 1) * 3, size=(low, low), mode="bilinear", align_corners=False)
+    masks = base + 0.3 * seeded((B, Q, low, low), seed + 2) - 0.8
+    inputs = []
+    for b, (H, W, oh, ow) in enumerate(cfg["images"]):
+        ys, xs = torch.meshgrid(torch.arange(H) / H, torch.arange(W) / W, indexing="ij")
+        inside = ((ys - 0.5) ** 2 / 0.17 + (xs - 0.5) ** 2 / 0.12) < 1.0
+        g = torch.Generator().manual_seed(seed + 30 + b)
+        centers = torch.rand((3, 2), generator=g) * 0.5 + 0.25
+        lab = torch.stack([(ys - c[0]) ** 2 + (xs - c[1]) ** 2 for c in centers]).argmin(0)
+        parts = torch.stack([(lab == k) & inside for k in range(3)])
+        inputs.append({"image": seeded((3, H, W), seed + 40 + b) * 50 + 100, "part_masks": parts, "part_labels": torch.tensor([2, 0, 1]),
+                       "object_mask": inside[None], "height": oh, "width": ow})
+    return {"pred_logits": logits, "pred_masks": masks}, inputs

@@ -190,16 +190,32 @@ def install_inference_standins():
     _mod("detectron2.data", MetadataCatalog=types.SimpleNamespace(get=lambda name: types.SimpleNamespace(save_path="/tmp/pd_ref_save", class_codes=[])))
     m = sys.modules["detectron2.modeling"]
     m.build_backbone = lambda cfg: None
+    m.build_sem_seg_head = lambda cfg, shape: None
+    _mod("detectron2.data.detection_utils", read_image=None)
     _mod("detectron2.modeling.backbone", Backbone=nn.Module)
     _mod("detectron2.modeling.postprocessing", sem_seg_postprocess=sem_seg_postprocess)
     _mod("detectron2.structures", ImageList=_ImageList, Instances=_Instances, BitMasks=None)
     _mod("detectron2.utils.memory", retry_if_cuda_oom=lambda f: f)
     _mod("detectron2.utils.visualizer", ColorMode=None, Visualizer=object, GenericMask=None, _create_text_labels=None)
     _mod("pycocotools")
-    _mod("pycocotools.mask")
+    # mask IoU of pycocotools (maskApi.c rleIou, iscrowd = 0): |a & b| / |a | b| in double precision.  `encode` keeps the
+    # dense mask; the reference only feeds its result back into `iou` (utils/utils.py:35-42).
+    import numpy as _np
+
+    def _iou(pr, gt, iscrowd):
+        out = _np.zeros((len(pr), len(gt)), dtype=_np.float64)
+        for i, a in enumerate(pr):
+            for j, b in enumerate(gt):
+                a_, b_ = _np.asarray(a).astype(bool), _np.asarray(b).astype(bool)
+                inter, union = float((a_ & b_).sum()), float((a_ | b_).sum())
+                out[i, j] = inter / union if union > 0 else 0.0
+        return out
+    _mod("pycocotools.mask", encode=lambda m: _np.asarray(m), iou=_iou)
     _mod("pydensecrf")
     _mod("pydensecrf.densecrf")
     _mod("pydensecrf.utils")
+    if "detectron2.utils.visualizer" in sys.modules:
+        sys.modules["detectron2.utils.visualizer"].Visualizer = type("Visualizer", (), {})
     return importlib.import_module("part_distillation.proposal_generation_model")
 
 

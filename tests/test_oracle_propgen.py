@@ -69,3 +69,15 @@ def test_coco_rle_round_trip_and_format():
     js = rle.labels_to_coco_json(labels, [1, 2])
     assert [(rle.decode({"size": j["segmentation"]["size"], "counts": j["segmentation"]["counts"]}) == (labels == l)).all()
             for j, l in zip(js, [1, 2])] == [True, True]
+
+
+@pytest.mark.parametrize("tag,unique,min_score", [("unique_1", True, -1.0), ("unique_0", False, 0.3)])
+def test_inference_oracle_matches_reference_golden(golden, tag, unique, min_score):
+    from oracle import inference_ref as I
+    g = golden("infer")[tag]
+    outputs, inputs = C.make_infer_inputs()
+    res = I.inference(outputs, inputs, (128, 128), C.INFER["topk"], unique, 0.02, min_score)
+    for (masks, scores, labels, gt), want in zip(res, g):
+        assert torch.equal(masks, want["pred_masks"]) and torch.equal(labels, want["pred_classes"])
+        torch.testing.assert_close(scores, want["scores"], rtol=0, atol=0)
+        assert torch.equal(gt, want["gt_masks"])

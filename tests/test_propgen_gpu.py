@@ -122,3 +122,68 @@ def test_proposal_generation_model_vs_reference_golden(golden, tag, metric, norm
         for j, l in zip(r["part_mask"], r["present_labels"]):
             seg = j["segmentation"]
             assert (rle.decode({"size": seg["size"], "counts": seg["counts"]}) == (r["labels"].cpu().numpy() == l)).all()
+
+
+# ----------------------------------------------------------------------------- evaluation branch of ProposalModel (§8f-2)
+@pytest.mark.parametrize("tag,unique,min_score", [("unique_1", True, -1.0), ("unique_0", False, 0.3)])
+def test_proposal_model_inference_vs_reference_golden(golden, tag, unique, min_score):
+    """predicted part masks / scores / matched labels of the device evaluation branch against the real reference run:
+    image 0 takes the fused pd_mask_assign route (no output resize, unique labels), image 1 the dense route"""
+    import types
+    from partdistillation_amd import inference as I
+    from partdistillation_amd.compat import BitMasks, ImageList, Instances
+    g = golden("infer")[tag]
+    outputs, inputs = C.make_infer_inputs()
+    outputs = {k: v.to(DEV) for k, v in outputs.items()}
+    model = types.SimpleNamespace(device=torch.device(DEV), test_topk_per_image=C.INFER["topk"], wandb_vis_topk=C.INFER["topk"],
+                                  use_unique_per_pixel_label=unique, minimum_pseudo_mask_ratio=0.02, minimum_pseudo_mask_score=min_score,
+                                  apply_masking_with_object_mask=True)
+    batched = []
+    for i in inputs:
+        parts, objs = Instances(tuple(i["image"].shape[-2:])), Instances(tuple(i["image"].shape[-2:]))
+        parts.gt_masks, parts.gt_classes = BitMasks(i["part_masks"]), i["part_labels"]
+        objs.gt_masks = BitMasks(i["object_mask"])
+        batched.append({"image": i["image"], "part_instances": parts, "instances": objs, "height": i["height"], "width": i["width"]})
+    images = ImageList.from_tensors([i["image"].to(DEV) for i in inputs], C.INFER["size_div"])
+    targets = I.prepare_gt_targets(model, batched, images)
+    res = I.inference(model, batched, targets, images, outputs)
+    for r, want in zip(res, g):
+        p = r["proposals"]
+        assert p.pred_masks.shape == want["pred_masks"].shape, (p.pred_masks.shape, want["pred_masks"].shape)
+        # `scores.topk(k, sorted=False)` leaves the order of the proposals to the implementation (it differs between the
+        # CPU and GPU kernels of torch itself): compare as sets, paired by their (distinct) scores
+        o1, o2 = p.scores.cpu().argsort(), want["scores"].argsort()
+        assert torch.equal(p.pred_classes.cpu()[o1], want["pred_classes"][o2])
+        torch.testing.assert_close(p.scores.cpu()[o1], want["scores"][o2], rtol=1e-5, atol=1e-6)
+        diff = (p.pred_masks.cpu()[o1] != want["pred_masks"][o2]).float().mean().item()
+        assert diff < 2e-3, diff                                       # interpolation / sigmoid rounding at near-ties
+        assert torch.equal(r["gt_masks"].gt_masks.cpu(), want["gt_masks"])
+
+
+def test_proposal_model_eval_end_to_end():
+    """the registered ProposalModel in eval mode: backbone -> head (dense masks at inference) -> device evaluation branch"""
+    import os
+    from partdistillation_amd.compat import BitMasks, Instances, build_model
+    from partdistillation_amd.config import setup_cfg
+    import partdistillation_amd.modeling, partdistillation_amd.proposal_model  # noqa: F401,E401
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = setup_cfg(os.path.join(root, "partdistillation_amd", "configs", "proposal_learning", "r50_mask2former.yaml"),
+                    ["MODEL.MASK_FORMER.NUM_OBJECT_QUERIES", "20", "MODEL.MASK_FORMER.DEC_LAYERS", "3",
+                     "MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS", "1", "TEST.DETECTIONS_PER_IMAGE", "10"])
+    model = build_model(cfg).eval()
+    _, inputs = C.make_infer_inputs()
+    batched = []
+    for i in inputs:
+        parts, objs = Instances(tuple(i["image"].shape[-2:])), Instances(tuple(i["image"].shape[-2:]))
+        parts.gt_masks, parts.gt_classes = BitMasks(i["part_masks"]), i["part_labels"]
+        objs.gt_masks = BitMasks(i["object_mask"])
+        batched.append({"image": i["image"], "part_instances": parts, "instances": objs})
+    with torch.no_grad():
+        res = model(batched)
+    assert len(res) == 2
+    for r, i in zip(res, inputs):
+        p = r["proposals"]
+        assert p.pred_masks.dtype == torch.bool and tuple(p.pred_masks.shape[-2:]) == tuple(i["image"].shape[-2:])
+        assert p.pred_masks.shape[0] == p.scores.shape[0] == p.pred_classes.shape[0] >= 1
+        assert not (p.pred_masks & ~i["object_mask"].to(DEV)).any()            # proposals stay inside the object
+        assert r["gt_masks"].gt_masks.shape[0] == 3
