@@ -91,6 +91,10 @@ def load():
             f"{LIB_PATH} is missing: the HIP extension has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C partdistillation_amd/csrc`). "
             "partdistillation_amd has no CPU or PyTorch fallback.")
+    # PyTorch ships its own libamdhip64 / libhsa-runtime64; libpd_hip.so is linked against the same SONAME.  Import torch
+    # FIRST so that the process has ONE HIP runtime - the one torch's streams and allocations live in.  (Loaded the other way
+    # round, the system runtime wins and every launch fails with "no ROCm-capable device is detected".)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:
