@@ -122,12 +122,45 @@ class SwinTransformerBlock(nn.Module):
         if gather is None:
             gather = window_gather_index(H, W, ws, self.shift_size, x.device)
         idx, inv, n_win, any_pad = gather
-        xp = torch.cat([x, x.new_zeros(B, 1, C)], dim=1) if any_pad else x              # padded slots read a zero row
-        xw = xp[:, idx].reshape(B * n_win, ws * ws, C)
+        xw = _WindowGather.apply(x, idx, inv, any_pad).reshape(B * n_win, ws * ws, C)   # padded slots read a zero row
         aw = self.attn(xw, mask=mask_matrix if self.shift_size > 0 else None)
-        x = aw.reshape(B, n_win * ws * ws, C)[:, inv]
+        x = _WindowScatter.apply(aw.reshape(B, n_win * ws * ws, C), idx, inv, any_pad)
         x = shortcut + self.drop_path(x)
         return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+class _WindowGather(torch.autograd.Function):
+    """tokens [B, L, C] -> window-major slots [B, S, C] (S >= L; padded slots read zeros).  The slot map is a permutation
+    of the tokens plus padding, so the backward is the INVERSE GATHER g[:, inv] - not the sort-based scatter-add torch
+    runs for advanced indexing (indexing_backward_kernel: 20 % of a Swin-B training step)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, inv, any_pad):
+        ctx.save_for_backward(inv)
+        xp = torch.cat([x, x.new_zeros(x.shape[0], 1, x.shape[2])], dim=1) if any_pad else x
+        return xp.index_select(1, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv,) = ctx.saved_tensors
+        return g.index_select(1, inv), None, None, None
+
+
+class _WindowScatter(torch.autograd.Function):
+    """window-major slots [B, S, C] -> tokens [B, L, C] (the inverse of _WindowGather); backward = gather with the slot map,
+    zeros for the padded slots."""
+
+    @staticmethod
+    def forward(ctx, a, idx, inv, any_pad):
+        ctx.save_for_backward(idx)
+        ctx.any_pad = any_pad
+        return a.index_select(1, inv)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        gp = torch.cat([g, g.new_zeros(g.shape[0], 1, g.shape[2])], dim=1) if ctx.any_pad else g
+        return gp.index_select(1, idx), None, None, None
 
 
 _GATHER_CACHE = {}
