@@ -450,3 +450,48 @@ def test_part_distillation_swin_train_steps():
             want = sorted({c * 8 + k for c in (b["gt_object_class"] for b in batch) for k in range(8)} | {400})
             assert rows == want, (rows, want)
     assert all(np.isfinite(hist)) and np.mean(hist[-3:]) < np.mean(hist[:3]), hist
+
+
+def test_loss_curve_matches_oracle_over_optimizer_steps():
+    """north-star 'matching loss curves': three full optimisation steps (forward, Hungarian criterion, backward, global
+    clipping, AdamW) of the HIP training step in fp32 against the CPU oracle on the same weights, batches and random
+    points — per-step losses, the clipped gradient norm and the parameters after the last step."""
+    from partdistillation_amd.engine.synthetic import make_batch
+    from partdistillation_amd.engine.trainer import TrainStep
+    cfg = _toy_cfg(["SOLVER.BASE_LR", "0.0002", "SOLVER.WARMUP_ITERS", "0", "MODEL.MASK_FORMER.DEC_LAYERS", "3"])
+    torch.manual_seed(1)
+    step = TrainStep(cfg)
+    model = step.model.train()
+    sd = _randomise(model, 78)
+    step.load_model_state(sd)
+    batches = [make_batch(2, 96, n_parts=3, seed=50 + i, device=DEV) for i in range(3)]
+    # oracle replica
+    osd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    names, lrs, wds = [], [], []
+    for g in step.optimizer.flat.groups:
+        for n in g.names:
+            names.append(n), lrs.append(g.hyper["lr"]), wds.append(g.hyper["weight_decay"])
+    params = [osd[n] for n in names]
+    state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
+    for it, batch in enumerate(batches, start=1):
+        cur_lrs = {id(p): pg["lr"] for pg in step.optimizer.param_groups for p in pg["params"]}
+        assert all(abs(cur_lrs[id(p)] - lr) < 1e-12 for p, lr in zip([q for g in step.optimizer.flat.groups for q in g.params], lrs))
+        rr = C.ReplayRand(7000 + it)
+        model.criterion.rand = rr
+        losses = step(batch)
+        got = {k: float(v) for k, v in losses.items()}
+        norm = float(step.optimizer.grad_norm())
+        obatch = [{"image": b["image"].cpu(), "instances": {"gt_masks": b["instances"].gt_masks.tensor.cpu()}} for b in batch]
+        olosses = R.proposal_model_losses(osd, obatch, C.ReplayRand(7000 + it), dec_layers=3, enc_layers=2, num_points=256)
+        for p in params:
+            p.grad = None
+        sum(olosses.values()).backward()
+        for k in olosses:
+            assert abs(got[k] - float(olosses[k])) <= 3e-3 * abs(float(olosses[k])) + 3e-4, (it, k, got[k], float(olosses[k]))
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+        with torch.no_grad():
+            total = R.clipped_adamw_step([p.data for p in params], grads, state, lrs=lrs, wds=wds, clip=cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE, step=it)
+        assert abs(norm - float(total)) <= 2e-2 * float(total), (it, norm, float(total))
+    master = step.optimizer.flat.master_state()
+    worst = max(((master[n].detach().cpu() - osd[n].detach()).abs().max() / osd[n].detach().abs().max().clamp_min(1e-6)).item() for n in names)
+    assert worst < 2e-2, worst
