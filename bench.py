@@ -29,6 +29,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 METRIC = "images/sec training step, R50 Mask2Former 1024² bs=2/GPU, 1/2/4/8 MI355X"
+MFMA_FP32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 
 
@@ -107,6 +108,23 @@ def cpu_baseline(cfg_opts, size, seconds_budget=90.0, threads=None):
     sample = (f"1 image {probe}x{probe} (1/{(size // probe) ** 2} of the pixels of the {size}x{size} workload; the full-size "
               f"step was estimated at {est:.0f} s > budget), one full step, fp32; value scaled by the pixel ratio")
     return {"value": 1.0 / est, "unit": "images/s", "cores": cores, "kind": "port", "sample": sample, "seconds": t_probe}
+
+
+def roofline_of(dom, kernels):
+    """roofline object of the kernel with the largest share of the step among the timed hand-written kernels:
+    achieved = algorithmic bytes (or flops) per launch / average launch duration (HIP events on the launch stream)."""
+    if dom is None:
+        return None
+    if "achieved_TFLOPs" in dom:
+        return {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_TFLOPs"], "peak": MFMA_FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": dom["achieved_TFLOPs"] / MFMA_FP32_PEAK_TFLOPS, "traffic": None,
+                "alg_flops_per_launch": dom["alg_flops"], "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["launches"],
+                "peak_source": "MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s", "other_kernels": kernels}
+    return {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"),
+            "traffic_source": "profiles/r01_msda_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)",
+            "alg_bytes_per_launch": dom["alg_bytes"], "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["launches"],
+            "other_kernels": kernels}
 
 
 def main():
@@ -193,15 +211,19 @@ def main():
     # per-launch timing of the hand-written MSDA kernels with HIP events on the launch stream.  Events cannot be
     # recorded between the nodes of a replayed graph, so these launches are timed in extra EAGER steps of the same
     # workload right after the timed region (when --graph 0 they are timed inside the timed region itself).
-    fwd_ms, bwd_ms = [], []
+    fwd_ms, bwd_ms, wgrad = [], [], []
     if not a.skip_kernel_timing:
         step._graph = None
+        from partdistillation_amd.functions import gemm as gemm_fn
         msda_fn.enable_timing(True)
+        gemm_fn.enable_timing(True)
         for i in range(3):
             step(batches[i % len(batches)])
         torch.cuda.synchronize()
         fwd_ms, bwd_ms = msda_fn.timing_ms()
+        wgrad = gemm_fn.timing()
         msda_fn.enable_timing(False)
+        gemm_fn.enable_timing(False)
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -221,6 +243,10 @@ def main():
         if bwd_ms:
             kernels.append({"kernel": "msda_bwd_tiled_d32", "launches": len(bwd_ms), "avg_ms": avg(bwd_ms),
                             "alg_bytes": bb, "achieved_GBs": bb / avg(bwd_ms) / 1e6})
+        if wgrad:                               # fp32 MFMA weight-gradient GEMMs of the encoder (36 launches / step, 6 shapes)
+            t_ms, fl = sum(t for t, _ in wgrad), sum(f for _, f in wgrad)
+            kernels.append({"kernel": "gemm_wgrad_f32", "launches": len(wgrad), "avg_ms": t_ms / len(wgrad),
+                            "alg_flops": fl / len(wgrad), "achieved_TFLOPs": fl / t_ms / 1e9})
         pmc = {}
         try:                                   # HBM bytes per launch from the committed PMC passes (tools/pmc_msda.sh)
             pj = json.load(open(os.path.join(ROOT, "profiles", "r01_msda_pmc.json")))
@@ -240,11 +266,7 @@ def main():
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "finetune": "frozen:" + ",".join(freeze) if freeze else "full", "hipgraph": use_graph,
                        "final_total_loss": total_loss, "host_issue_ms_per_step": issue / a.steps * 1e3},
-            "roofline": None if dom is None else {
-                "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"),
-                "traffic_source": "profiles/r01_msda_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)", "alg_bytes_per_launch": dom["alg_bytes"],
-                "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["launches"], "other_kernels": kernels},
+            "roofline": roofline_of(dom, kernels),
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(list(a.opts), a.size)

@@ -25,13 +25,33 @@ def gemm_tn(a, b, bias=None, relu=False):
     return c
 
 
+# optional per-launch timing hook used by bench.py (HIP events on the launch stream; (start, stop, flops) per launch)
+_TIMING = {"on": False, "wgrad": []}
+
+
+def enable_timing(on=True):
+    _TIMING["on"] = on
+    _TIMING["wgrad"].clear()
+
+
+def timing():
+    """-> [(ms, flops)] of the weight-gradient launches since enable_timing(True); call after a synchronize."""
+    return [(a.elapsed_time(b), f) for a, b, f in _TIMING["wgrad"]]
+
+
 def gemm_wgrad_acc(dy, x, dw, db=None):
     """dw [N,K] += dy.T @ x, db [N] += dy.sum(0): accumulates into caller-initialised fp32 buffers (no memset launches)."""
     M, N = dy.shape
     K = x.shape[1]
     assert dw.shape == (N, K) and dw.is_contiguous() and (db is None or db.numel() == N)
+    if _TIMING["on"]:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
     _lib.check(_lib.load().pd_gemm_wgrad_acc_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
                                                  M, N, K, dy.stride(0), x.stride(0), K, _stream()))
+    if _TIMING["on"]:
+        b.record()
+        _TIMING["wgrad"].append((a, b, 2.0 * M * N * K))
 
 
 def gemm_wgrad(dy, x, with_bias=False):
