@@ -75,17 +75,18 @@ int pd_mem_prep_bwd(const void *dmem_c, const void *dmempos_c, int c_dtype, floa
 int pd_attn_mask_u8(const void *logits, int dtype, int rows, int n, uint8_t *mask, void *stream);
 
 /*
- * offs fp32 [tokens, M, L, P, 2], logits fp32 [tokens, M, L*P], ref fp32 [tokens, L, 2] (x, y in [0,1]), spatial_shapes
- * int64 [L, 2] (H_l, W_l) on the device ->
+ * offs fp32 [tokens, M, L, P, 2] and logits fp32 [tokens, M, L*P] with row strides ld_offs / ld_logits in elements (so both can
+ * be column ranges of ONE projection output), ref fp32 [tokens, L, 2] (x, y in [0,1]), spatial_shapes int64 [L, 2] (H_l, W_l)
+ * on the device ->
  *   loc [tokens, M, L, P, 2] = ref[token, l] + offs / (W_l, H_l)        attn [tokens, M, L*P] = softmax(logits)
  * exactly the two roundings (divide, add) of the reference expression.
  */
 int pd_msda_prep_fwd(const float *offs, const float *logits, const float *ref, const int64_t *spatial_shapes, float *loc,
-                     float *attn, int64_t tokens, int M, int L, int P, void *stream);
+                     float *attn, int64_t tokens, int M, int L, int P, int ld_offs, int ld_logits, void *stream);
 
 /* d_offs = gloc / (W_l, H_l);  d_logits = attn * (gattn - sum_j attn_j * gattn_j) */
 int pd_msda_prep_bwd(const float *gloc, const float *gattn, const float *attn, const int64_t *spatial_shapes, float *d_offs,
-                     float *d_logits, int64_t tokens, int M, int L, int P, void *stream);
+                     float *d_logits, int64_t tokens, int M, int L, int P, int ld_offs, int ld_logits, void *stream);
 
 /*
  * out[b, p, :] = bilinear sample of in[b] (fp32, channels-last [B, H, W, C], C % 4 == 0) at coords[b, p] = (x, y) in

@@ -302,11 +302,14 @@ template <int LP4>      // LP / 4
 __global__ __launch_bounds__(256) void msda_prep_fwd_v(const float *__restrict__ offs, const float *__restrict__ logits,
                                                        const float *__restrict__ ref, const int64_t *__restrict__ shapes,
                                                        float *__restrict__ loc, float *__restrict__ attn, int64_t total, int M,
-                                                       int L, int P)
+                                                       int L, int P, int ldo, int ldl)
 {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int64_t bq = t / M;
+  const int m = (int)(t - bq * M);
+  offs += bq * ldo + (int64_t)m * LP4 * 8 - t * LP4 * 8;          // re-base so the dense indexing below lands in the strided rows
+  logits += bq * ldl + (int64_t)m * LP4 * 4 - t * LP4 * 4;
   float4 lg[LP4];
   float mx = -INFINITY;
 #pragma unroll
@@ -338,10 +341,16 @@ template <int LP4>
 __global__ __launch_bounds__(256) void msda_prep_bwd_v(const float *__restrict__ gloc, const float *__restrict__ gattn,
                                                        const float *__restrict__ attn, const int64_t *__restrict__ shapes,
                                                        float *__restrict__ d_offs, float *__restrict__ d_logits, int64_t total,
-                                                       int M, int L, int P)
+                                                       int M, int L, int P, int ldo, int ldl)
 {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
+  {
+    const int64_t bq = t / M;
+    const int m = (int)(t - bq * M);
+    d_offs += bq * ldo + (int64_t)m * LP4 * 8 - t * LP4 * 8;
+    d_logits += bq * ldl + (int64_t)m * LP4 * 4 - t * LP4 * 4;
+  }
   float4 a[LP4], g[LP4];
   float dot = 0.f;
 #pragma unroll
@@ -368,20 +377,21 @@ __global__ __launch_bounds__(256) void msda_prep_bwd_v(const float *__restrict__
 __global__ __launch_bounds__(256) void msda_prep_fwd(const float *__restrict__ offs, const float *__restrict__ logits,
                                                      const float *__restrict__ ref, const int64_t *__restrict__ shapes,
                                                      float *__restrict__ loc, float *__restrict__ attn, int64_t total, int M, int L,
-                                                     int P)
+                                                     int P, int ldo, int ldl)
 {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int LP = L * P;
   const int64_t bq = t / M;
-  const float *lg = logits + t * LP;
+  const int m = (int)(t - bq * M);
+  const float *lg = logits + bq * ldl + (int64_t)m * LP;
   float mx = lg[0];
   for (int i = 1; i < LP; ++i) mx = fmaxf(mx, lg[i]);
   float sum = 0.f;
   for (int i = 0; i < LP; ++i) sum += expf(lg[i] - mx);
   float *ao = attn + t * LP;
   for (int i = 0; i < LP; ++i) ao[i] = expf(lg[i] - mx) / sum;
-  const float *of = offs + t * LP * 2;
+  const float *of = offs + bq * ldo + (int64_t)m * LP * 2;
   float *lo = loc + t * LP * 2;
   for (int l = 0; l < L; ++l) {
     const float w = (float)shapes[l * 2 + 1], h = (float)shapes[l * 2];
@@ -397,18 +407,20 @@ __global__ __launch_bounds__(256) void msda_prep_fwd(const float *__restrict__ o
 __global__ __launch_bounds__(256) void msda_prep_bwd(const float *__restrict__ gloc, const float *__restrict__ gattn,
                                                      const float *__restrict__ attn, const int64_t *__restrict__ shapes,
                                                      float *__restrict__ d_offs, float *__restrict__ d_logits, int64_t total,
-                                                     int M, int L, int P)
+                                                     int M, int L, int P, int ldo, int ldl)
 {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int LP = L * P;
+  const int64_t bq = t / M;
+  const int m = (int)(t - bq * M);
   const float *a = attn + t * LP, *g = gattn + t * LP;
   float dot = 0.f;
   for (int i = 0; i < LP; ++i) dot += a[i] * g[i];
-  float *dl = d_logits + t * LP;
+  float *dl = d_logits + bq * ldl + (int64_t)m * LP;
   for (int i = 0; i < LP; ++i) dl[i] = a[i] * (g[i] - dot);
   const float *gl = gloc + t * LP * 2;
-  float *dof = d_offs + t * LP * 2;
+  float *dof = d_offs + bq * ldo + (int64_t)m * LP * 2;
   for (int l = 0; l < L; ++l) {
     const float w = (float)shapes[l * 2 + 1], h = (float)shapes[l * 2];
     for (int p = 0; p < P; ++p) {
@@ -658,8 +670,10 @@ extern "C" int pd_attn_mask_u8(const void *logits, int dtype, int rows, int n, u
 }
 
 extern "C" int pd_msda_prep_fwd(const float *offs, const float *logits, const float *ref, const int64_t *spatial_shapes, float *loc,
-                                float *attn, int64_t tokens, int M, int L, int P, void *stream_)
+                                float *attn, int64_t tokens, int M, int L, int P, int ld_offs, int ld_logits, void *stream_)
 {
+  if (ld_offs < M * L * P * 2 || ld_logits < M * L * P || (ld_offs & 3) || (ld_logits & 3))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_fwd: row strides %d / %d (>= row length, multiples of 4)", ld_offs, ld_logits);
   if (tokens < 0 || M <= 0 || L <= 0 || P <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_fwd: tokens=%lld M=%d L=%d P=%d", (long long)tokens, M, L, P);
   if (tokens == 0) return PD_OK;
   if (!offs || !logits || !ref || !spatial_shapes || !loc || !attn) return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_fwd: null pointer");
@@ -667,7 +681,7 @@ extern "C" int pd_msda_prep_fwd(const float *offs, const float *logits, const fl
   const dim3 g((unsigned)((total + 255) / 256)), b(256);
   hipStream_t s = (hipStream_t)stream_;
   const int LP = L * P;
-#define LAUNCH(KER) hipLaunchKernelGGL(KER, g, b, 0, s, offs, logits, ref, spatial_shapes, loc, attn, total, M, L, P)
+#define LAUNCH(KER) hipLaunchKernelGGL(KER, g, b, 0, s, offs, logits, ref, spatial_shapes, loc, attn, total, M, L, P, ld_offs, ld_logits)
   if ((P & 1) == 0 && LP == 12) LAUNCH(msda_prep_fwd_v<3>);
   else if ((P & 1) == 0 && LP == 16) LAUNCH(msda_prep_fwd_v<4>);
   else if ((P & 1) == 0 && LP == 8) LAUNCH(msda_prep_fwd_v<2>);
@@ -677,8 +691,10 @@ extern "C" int pd_msda_prep_fwd(const float *offs, const float *logits, const fl
 }
 
 extern "C" int pd_msda_prep_bwd(const float *gloc, const float *gattn, const float *attn, const int64_t *spatial_shapes, float *d_offs,
-                                float *d_logits, int64_t tokens, int M, int L, int P, void *stream_)
+                                float *d_logits, int64_t tokens, int M, int L, int P, int ld_offs, int ld_logits, void *stream_)
 {
+  if (ld_offs < M * L * P * 2 || ld_logits < M * L * P || (ld_offs & 3) || (ld_logits & 3))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_bwd: row strides %d / %d (>= row length, multiples of 4)", ld_offs, ld_logits);
   if (tokens < 0 || M <= 0 || L <= 0 || P <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_bwd: tokens=%lld M=%d L=%d P=%d", (long long)tokens, M, L, P);
   if (tokens == 0) return PD_OK;
   if (!gloc || !gattn || !attn || !spatial_shapes || !d_offs || !d_logits) return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_bwd: null pointer");
@@ -686,7 +702,7 @@ extern "C" int pd_msda_prep_bwd(const float *gloc, const float *gattn, const flo
   const dim3 g((unsigned)((total + 255) / 256)), b(256);
   hipStream_t s = (hipStream_t)stream_;
   const int LP = L * P;
-#define LAUNCH(KER) hipLaunchKernelGGL(KER, g, b, 0, s, gloc, gattn, attn, spatial_shapes, d_offs, d_logits, total, M, L, P)
+#define LAUNCH(KER) hipLaunchKernelGGL(KER, g, b, 0, s, gloc, gattn, attn, spatial_shapes, d_offs, d_logits, total, M, L, P, ld_offs, ld_logits)
   if ((P & 1) == 0 && LP == 12) LAUNCH(msda_prep_bwd_v<3>);
   else if ((P & 1) == 0 && LP == 16) LAUNCH(msda_prep_bwd_v<4>);
   else if ((P & 1) == 0 && LP == 8) LAUNCH(msda_prep_bwd_v<2>);

@@ -33,19 +33,25 @@ N_LAYER = 16   # so_w so_b aw_w aw_b vp_w vp_b op_w op_b n1_w n1_b l1_w l1_b l2_
 
 
 def msda_prep_fwd(offs, logits, ref, shapes, M, L, P):
+    """offs [tokens, M*L*P*2], logits [tokens, M*L*P]: fp32, unit column stride, any row stride (column ranges of one
+    projection output are fine) -> sampling locations, attention probabilities"""
     tokens = offs.shape[0]
+    assert offs.stride(1) == 1 and logits.stride(1) == 1 and offs.dtype == torch.float32 and logits.dtype == torch.float32
     loc = torch.empty((tokens, M, L, P, 2), dtype=torch.float32, device=offs.device)
     attn = torch.empty((tokens, M, L, P), dtype=torch.float32, device=offs.device)
     _lib.check(_lib.load().pd_msda_prep_fwd(offs.data_ptr(), logits.data_ptr(), ref.data_ptr(), shapes.data_ptr(), loc.data_ptr(),
-                                            attn.data_ptr(), tokens, M, L, P, rw._stream()))
+                                            attn.data_ptr(), tokens, M, L, P, offs.stride(0), logits.stride(0), rw._stream()))
     return loc, attn
 
 
-def msda_prep_bwd(gloc, gattn, attn, shapes, tokens, M, L, P):
-    d_offs = torch.empty((tokens, M * L * P * 2), dtype=torch.float32, device=attn.device)
-    d_logits = torch.empty((tokens, M * L * P), dtype=torch.float32, device=attn.device)
+def msda_prep_bwd(gloc, gattn, attn, shapes, tokens, M, L, P, out=None):
+    """-> (d_offs, d_logits); with `out` [tokens, 3*M*L*P] they are its column ranges [0, 2MLP) and [2MLP, 3MLP)"""
+    n = M * L * P
+    if out is None:
+        out = torch.empty((tokens, 3 * n), dtype=torch.float32, device=attn.device)
+    d_offs, d_logits = out[:, :2 * n], out[:, 2 * n:]
     _lib.check(_lib.load().pd_msda_prep_bwd(gloc.data_ptr(), gattn.data_ptr(), attn.data_ptr(), shapes.data_ptr(), d_offs.data_ptr(),
-                                            d_logits.data_ptr(), tokens, M, L, P, rw._stream()))
+                                            d_logits.data_ptr(), tokens, M, L, P, out.stride(0), out.stride(0), rw._stream()))
     return d_offs, d_logits
 
 
@@ -75,9 +81,11 @@ class EncoderCore(Function):
         for i in range(nl):
             (so_w, so_b, aw_w, aw_b, vp_w, vp_b, op_w, op_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b) = params[i * N_LAYER:(i + 1) * N_LAYER]
             value = torch.addmm(vp_b, x, vp_w.t())
-            offs = torch.addmm(so_b, q, so_w.t())
-            logits = torch.addmm(aw_b, q, aw_w.t())
-            loc, attn = msda_prep_fwd(offs, logits, ref, spec.shapes, M, L, P)
+            # sampling_offsets and attention_weights read the same input: one GEMM against their stacked weights
+            w_oa, b_oa = torch.cat([so_w, aw_w]), torch.cat([so_b, aw_b])
+            oa = torch.addmm(b_oa, q, w_oa.t())                                        # [T, 2MLP + MLP]
+            n_off = so_w.shape[0]
+            loc, attn = msda_prep_fwd(oa[:, :n_off], oa[:, n_off:], ref, spec.shapes, M, L, P)
             v4, loc6, attn5 = value.view(B, S, M, C // M), loc.view(B, S, M, L, P, 2), attn.view(B, S, M, L, P)
             a = _timed("fwd", MSDA.ms_deform_attn_forward, v4, spec.shapes, spec.lsi, loc6, attn5, spec.im2col_step).view(T, C)
             z1, y1, _, _, m1, r1 = rw.add_ln_fwd(torch.addmm(op_b, a, op_w.t()), x, n1_w, n1_b, spec.eps)
@@ -85,7 +93,7 @@ class EncoderCore(Function):
             last = i == nl - 1
             z2, y2, _, ypos, m2, r2 = rw.add_ln_fwd(torch.addmm(l2_b, h, l2_w.t()), y1, n2_w, n2_b, spec.eps, c_dtype=torch.float32,
                                                     pos=pos2, pos_div=1, want_ypos=not last)
-            saved.append((x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2))
+            saved.append((x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, w_oa))
             x, q = y2, ypos
         ctx.spec, ctx.saved, ctx.params, ctx.dims = spec, saved, params, (B, S, C, nl)
         return x.view(B, S, C)
@@ -103,7 +111,14 @@ class EncoderCore(Function):
         for p in params:
             offs.append(total)
             total += (p.numel() + 3) // 4 * 4
+        n_oa = params[0].shape[0] + params[2].shape[0]                  # stacked sampling_offsets + attention_weights rows
+        oa_base, oa_per = total, n_oa * C + (n_oa + 3) // 4 * 4
+        total += nl * oa_per
         buf = torch.zeros(total, dtype=torch.float32, device=dev)
+
+        def OA(i):
+            o = oa_base + i * oa_per
+            return buf[o:o + n_oa * C].view(n_oa, C), buf[o + n_oa * C:o + n_oa * C + n_oa]
 
         def G(i, j):
             p = params[i * N_LAYER + j]
@@ -116,7 +131,7 @@ class EncoderCore(Function):
         dy2 = dyq = None                                       # further fp32 terms of d(src_l): via value_proj, via (src + pos)
         for i in reversed(range(nl)):
             (so_w, so_b, aw_w, aw_b, vp_w, vp_b, op_w, op_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b) = params[i * N_LAYER:(i + 1) * N_LAYER]
-            x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2 = ctx.saved[i]
+            x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, w_oa = ctx.saved[i]
             (g_sow, g_sob, g_aww, g_awb, g_vpw, g_vpb, g_opw, g_opb, g_n1w, g_n1b, g_l1w, g_l1b, g_l2w, g_l2b, g_n2w,
              g_n2b) = [G(i, j) for j in range(N_LAYER)]
             # ---- FFN + norm2
@@ -132,11 +147,13 @@ class EncoderCore(Function):
             gemm_wgrad_acc(dz1, a, g_opw)
             da = torch.mm(dz1, op_w).view(B, S, C)
             gv, gloc, gattn = _timed("bwd", MSDA.ms_deform_attn_backward, v4, spec.shapes, spec.lsi, loc6, attn5, da, spec.im2col_step)
-            d_offs, d_logits = msda_prep_bwd(gloc, gattn, attn5, spec.shapes, T, M, L, P)
-            gemm_wgrad_acc(d_offs, q, g_sow, g_sob)
-            gemm_wgrad_acc(d_logits, q, g_aww, g_awb)
-            dq = torch.mm(d_offs, so_w)
-            dq.addmm_(d_logits, aw_w)
+            d_oa = torch.empty((T, w_oa.shape[0]), dtype=torch.float32, device=dev)
+            msda_prep_bwd(gloc, gattn, attn5, spec.shapes, T, M, L, P, out=d_oa)
+            g_oaw, g_oab = OA(i)
+            gemm_wgrad_acc(d_oa, q, g_oaw, g_oab)                                  # both weight gradients in one split-K GEMM
+            n_off = so_w.shape[0]
+            g_sow, g_aww, g_sob, g_awb = g_oaw[:n_off], g_oaw[n_off:], g_oab[:n_off], g_oab[n_off:]
+            dq = torch.mm(d_oa, w_oa)
             gv2 = gv.view(T, C)
             gemm_wgrad_acc(gv2, x, g_vpw, g_vpb)
             dxv = torch.mm(gv2, vp_w)

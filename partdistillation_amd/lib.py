@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpd_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -45,8 +45,8 @@ SIGNATURES = {
     "pd_mem_prep_fwd": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "pd_mem_prep_bwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
     "pd_attn_mask_u8": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
-    "pd_msda_prep_fwd": (_c_int, [_c_vp] * 6 + [ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
-    "pd_msda_prep_bwd": (_c_int, [_c_vp] * 6 + [ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
+    "pd_msda_prep_fwd": (_c_int, [_c_vp] * 6 + [ctypes.c_int64] + [_c_int] * 5 + [_c_vp]),
+    "pd_msda_prep_bwd": (_c_int, [_c_vp] * 6 + [ctypes.c_int64] + [_c_int] * 5 + [_c_vp]),
     "pd_sgemm_tn_bf16": (_c_int, [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
     "pd_sgemm_nn_bf16": (_c_int, [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
     "pd_sgemm_wgrad_bf16": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),

@@ -220,6 +220,7 @@ def test_msda_prep_fwd_bwd_vs_torch(L, P):
     torch.testing.assert_close(attn, attn_r.detach(), rtol=1e-6, atol=1e-7)
     gloc, gattn = _r(loc.shape, 54), _r(attn.shape, 55)
     d_offs, d_logits = msda_prep_bwd(gloc, gattn, attn, shapes, T, M, L, P)
+    assert d_offs.stride(0) == 3 * M * L * P                           # column ranges of one buffer
     ((loc_r * gloc).sum() + (attn_r * gattn).sum()).backward()
     torch.testing.assert_close(d_offs, ot.grad, rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(d_logits, lt.grad, rtol=1e-4, atol=1e-6)
