@@ -13,6 +13,8 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 from torch import nn
 
+from ...functions.rowwise import add_layer_norm, supports_width
+
 from ...compat import BACKBONE_REGISTRY, ShapeSpec
 
 
@@ -59,6 +61,22 @@ def window_reverse(windows, window_size, H, W):
     return x.permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
 
 
+class _TableLookup(torch.autograd.Function):
+    """table[index] for the relative-position bias; backward = index_add_ (atomics) instead of torch's sort-based
+    indexing backward, which costs ~80 us per block for a 529-row table"""
+
+    @staticmethod
+    def forward(ctx, table, index):
+        ctx.save_for_backward(index)
+        ctx.rows = table.shape[0]
+        return table.index_select(0, index)
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        return torch.zeros((ctx.rows, g.shape[1]), dtype=g.dtype, device=g.device).index_add_(0, index, g), None
+
+
 class WindowAttention(nn.Module):
     def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
         super().__init__()
@@ -80,7 +98,7 @@ class WindowAttention(nn.Module):
 
     def bias(self):
         n = self.window_size[0] * self.window_size[1]
-        return self.relative_position_bias_table[self.relative_position_index.view(-1)].view(n, n, -1).permute(2, 0, 1)
+        return _TableLookup.apply(self.relative_position_bias_table, self.relative_position_index.view(-1)).view(n, n, -1).permute(2, 0, 1)
 
     def forward(self, x, mask=None):
         """x [nW*B, N, C]; mask [nW, N, N] additive (0 / -100) or None."""
@@ -95,6 +113,15 @@ class WindowAttention(nn.Module):
         p = self.attn_drop.p if self.training else 0.0
         out = F.scaled_dot_product_attention(q, k, v, attn_mask=add.to(q.dtype), dropout_p=p, scale=self.scale)
         return self.proj_drop(self.proj(out.transpose(1, 2).reshape(B_, N, C)))
+
+
+def _layer_norm(norm, x):
+    """nn.LayerNorm through the one-wavefront-per-row HIP kernels (functions/rowwise.py) where they apply (GPU, width a
+    multiple of 256 up to 1024: Swin-B stages 2-4, Swin-L stage 3): one backward kernel instead of torch's three"""
+    if (x.is_cuda and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine and norm.weight.dtype == torch.float32
+            and x.dtype in (torch.float32, torch.bfloat16) and supports_width(x.shape[-1])):
+        return add_layer_norm(x, None, norm)[0]
+    return norm(x)
 
 
 class SwinTransformerBlock(nn.Module):
@@ -118,7 +145,7 @@ class SwinTransformerBlock(nn.Module):
         assert L == H * W, "input feature has wrong size"
         ws = self.window_size
         shortcut = x
-        x = self.norm1(x)
+        x = _layer_norm(self.norm1, x)
         if gather is None:
             gather = window_gather_index(H, W, ws, self.shift_size, x.device)
         idx, inv, n_win, any_pad = gather
@@ -126,7 +153,7 @@ class SwinTransformerBlock(nn.Module):
         aw = self.attn(xw, mask=mask_matrix if self.shift_size > 0 else None)
         x = _WindowScatter.apply(aw.reshape(B, n_win * ws * ws, C), idx, inv, any_pad)
         x = shortcut + self.drop_path(x)
-        return x + self.drop_path(self.mlp(self.norm2(x)))
+        return x + self.drop_path(self.mlp(_layer_norm(self.norm2, x)))
 
 
 class _WindowGather(torch.autograd.Function):
