@@ -143,3 +143,93 @@ def inference(model, batched_inputs, targets, images, outputs, vis=False):
         gt.gt_masks, gt.gt_classes, gt.pred_masks, gt.pred_classes = tm, tgt["labels"], tm, tgt["labels"]
         results.append({"proposals": r, "gt_masks": gt})
     return results
+
+
+# ================================================================================================ PartDistillationModel
+def _unique_assignment_with_classes(model, masks, scores, class_labels):
+    """reference part_distillation_model.py:336-383 on the device (its quirks included: see the oracle's docstring).
+    Per-pixel-unique branch: queries that won no pixel drop out, the per-query segments are merged per predicted class
+    (mask = union, score = best score of the class) - all through one arg-max map, no [K,H,W] stacks besides the result."""
+    obj_map = masks.max(dim=0)[0] > 0.0
+    if model.use_unique_per_pixel_label:
+        scoremap = (scores[:, None, None] * masks.sigmoid()).argmax(0)
+        K = masks.shape[0]
+        ids = (torch.bincount(scoremap.flatten(), minlength=K) > 0).nonzero().flatten()            # scoremap.unique()
+        cls_of_query = torch.full((K,), -1, dtype=torch.long, device=masks.device)
+        cls_of_query[ids] = class_labels[ids]
+        new_labels = class_labels[ids].unique()
+        classmap = torch.where(obj_map, cls_of_query[scoremap], torch.full_like(scoremap, -1))   # class of every object pixel
+        new = classmap[None] == new_labels[:, None, None]
+        per_query = torch.where(cls_of_query[None, :] == new_labels[:, None], scores[None, :], scores.new_full((), -1.0))
+        new_scores = per_query[:, ids].max(dim=1)[0]
+        keep = _filter(new.flatten(1).sum(1), obj_map.sum(), new_scores, model.min_pseudo_mask_ratio, model.min_pseudo_mask_score)
+        return new[keep], new_scores[keep], new_labels[keep]
+    pred = scores[:, None, None] * masks.sigmoid()
+    keep = torch.arange(scores.shape[0], device=scores.device)
+    valid = (pred > 0.5).flatten(1).sum(1).double() / obj_map.sum().double() > model.min_pseudo_mask_ratio
+    if bool(valid.any()):
+        masks, keep = pred, keep[valid]                        # (sic) the logits are replaced by score * sigmoid
+    valid = scores[keep] > model.min_pseudo_mask_score
+    if bool(valid.any()):
+        keep = keep[valid]
+    return masks[keep] > 0, scores[keep], class_labels[keep]
+
+
+def instance_inference_with_classification(model, mask_cls, mask_pred, target_mask, target_object_mask, target_labels,
+                                           target_object_label, vis=False):
+    """reference :459-501"""
+    topk = model.wandb_vis_topk if vis and not model.use_unique_per_pixel_label else model.test_topk_per_image
+    nc = model.num_part_classes
+    scores = mask_cls.float().softmax(-1)[:, :-1]
+    labels = torch.arange(nc, device=scores.device).unsqueeze(0).repeat(scores.shape[0], 1).flatten(0, 1)
+    scores, idx = scores.flatten(0, 1).topk(topk, sorted=False)
+    labels = labels[idx]
+    if model.mode == "eval":
+        labels = model.majority_vote_mapping[int(target_object_label)][labels]
+    mask_pred = mask_pred[torch.div(idx, nc, rounding_mode="floor")]
+    if model.apply_masking_with_object_mask:
+        mask_pred = mask_pred * target_object_mask.sum(dim=0, keepdim=True).bool()
+    masks, scores, labels = _unique_assignment_with_classes(model, mask_pred, scores, labels)
+    iou = mask_iou(masks, target_mask)
+    top1, top1_idx = iou.topk(1, dim=1)
+    fg = (top1 > model.fg_score_threshold).flatten()
+    gt_labels = target_labels[top1_idx.flatten()[fg]]
+    masks, scores, labels = masks[fg], scores[fg], labels[fg]
+    if masks.shape[0] == 0:                                   # does not contribute to the evaluation
+        masks = torch.zeros((1,) + tuple(mask_pred.shape[1:]), dtype=torch.bool, device=mask_pred.device)
+        scores = scores.new_zeros(1)
+        labels = gt_labels = torch.full((1,), nc, dtype=torch.long, device=mask_pred.device)
+    r = Instances(tuple(mask_pred.shape[-2:]))
+    r.pred_masks, r.scores, r.pred_classes = masks, scores, (gt_labels if model.use_oracle_classifier else labels)
+    return r
+
+
+def prepare_pd_gt_targets(model, inputs, images):
+    """reference :430-455: like prepare_gt_targets, plus the object class; key names as in the reference"""
+    out = prepare_gt_targets(model, inputs, images)
+    for t, x in zip(out, inputs):
+        t["object_mask"] = t.pop("object_masks")
+        t["gt_object_class"] = x["instances"].to(model.device).gt_classes.to(model.device)
+    return out
+
+
+@torch.no_grad()
+def pd_inference(model, batched_inputs, targets, images, outputs, vis=False):
+    """reference :239-288 -> [{"predictions": Instances, "gt_instances": Instances, "gt_object_label": ...}]"""
+    logits_all = outputs["pred_masks"]
+    if logits_all is None:
+        from .modeling.transformer_decoder.mask2former_transformer_decoder import materialize_masks
+        logits_all = materialize_masks(dict(outputs))["pred_masks"]
+    pad_hw = tuple(images.tensor.shape[-2:])
+    results = []
+    for cls, low, tgt, inp, size in zip(outputs["pred_logits"], logits_all, targets, batched_inputs, images.image_sizes):
+        height, width = inp.get("height", size[0]), inp.get("width", size[1])
+        dense = F.interpolate(low[None].float(), size=pad_hw, mode="bilinear", align_corners=False)[0]
+        dense = sem_seg_postprocess(dense, size, height, width)
+        tm = sem_seg_postprocess(tgt["masks"].float(), size, height, width).bool()
+        to = sem_seg_postprocess(tgt["object_mask"].float(), size, height, width).bool()
+        r = instance_inference_with_classification(model, cls, dense, tm, to, tgt["labels"], tgt["gt_object_class"], vis=vis)
+        gt = Instances((height, width))
+        gt.gt_masks, gt.gt_classes, gt.pred_masks, gt.pred_classes = tm, tgt["labels"], tm, tgt["labels"]
+        results.append({"predictions": r, "gt_instances": gt, "gt_object_label": tgt["gt_object_class"]})
+    return results

@@ -1,5 +1,5 @@
-"""``PartDistillationModel`` meta-architecture — training branch (reference
-part_distillation/part_distillation_model.py:32-236, 405-428): as ProposalModel
+"""``PartDistillationModel`` meta-architecture (reference part_distillation/part_distillation_model.py:32-236,
+405-428; evaluation branch :239-288, 322-398, 430-501 in ``inference.py``): as ProposalModel
 but the targets carry real part labels and the image's object class, and the
 targets are handed to the head (``sem_seg_head(features, mask=targets)``, :205)
 so the float64 class head can slice that object's K part columns."""
@@ -33,6 +33,16 @@ class PartDistillationModel(_MaskFormerTrainBase):
         self.apply_masking_with_object_mask = apply_masking_with_object_mask
         self.use_oracle_classifier = use_oracle_classifier
         self.num_part_classes, self.num_object_classes = num_part_classes, num_object_classes
+        # evaluation branch (reference :57-99): attribute names as the reference
+        self.mode, self.fg_score_threshold, self.wandb_vis_topk = "", 0.1, wandb_vis_topk
+        self.min_pseudo_mask_ratio, self.min_pseudo_mask_score = minimum_pseudo_mask_ratio, minimum_pseudo_mask_score
+        self.majority_vote_mapping = {}
+        self.current_test_iteration = 0
+
+    def update_majority_vote_mapping(self, mapping_dict):
+        """reference :160-163: object class id -> LongTensor [num_part_classes] of merged part labels (from part ranking)"""
+        for cid, mapping in mapping_dict.items():
+            self.majority_vote_mapping[int(cid)] = mapping.to(self.device)
 
     @classmethod
     def from_config(cls, cfg):
@@ -62,10 +72,16 @@ class PartDistillationModel(_MaskFormerTrainBase):
         return targets
 
     def forward(self, batched_inputs):
-        if not self.training:
-            raise NotImplementedError("PartDistillationModel inference: SURVEY §8f 'next' row, not built yet")
         images = self.preprocess(batched_inputs)
         features = self.backbone(images.tensor)
+        if not self.training:                                           # evaluation branch (reference :227-236)
+            from .inference import pd_inference, prepare_pd_gt_targets
+            if self.mode == "save":
+                raise NotImplementedError("PartDistillationModel mode 'save' (pseudo-label export, reference :291-316) is not built")
+            targets = prepare_pd_gt_targets(self, batched_inputs, images)
+            head_targets = [{"gt_object_class": int(t["gt_object_class"])} for t in targets]
+            self.current_test_iteration += 1
+            return pd_inference(self, batched_inputs, targets, images, self.sem_seg_head(features, mask=head_targets))
         targets = self._share_padded_masks(self._prepare_pseudo_targets(batched_inputs, images))
         outputs = self.sem_seg_head(features, mask=targets)
         losses = self._weighted(self.criterion(outputs, targets))

@@ -200,3 +200,7 @@ def make_infer_inputs(cfg=INFER, seed=5200):
         inputs.append({"image": seeded((3, H, W), seed + 40 + b) * 50 + 100, "part_masks": parts, "part_labels": torch.tensor([2, 0, 1]),
                        "object_mask": inside[None], "height": oh, "width": ow})
     return {"pred_logits": logits, "pred_masks": masks}, inputs
+
+
+INFER_PD_CLASSES = 4                                                         # part classes of the class-aware evaluation goldens
+INFER_PD_MAPPING = ([2, 0, 0, 1], [1, 1, 3, 0])                               # majority-vote class mapping of object classes 3 and 4

@@ -81,3 +81,19 @@ def test_inference_oracle_matches_reference_golden(golden, tag, unique, min_scor
         assert torch.equal(masks, want["pred_masks"]) and torch.equal(labels, want["pred_classes"])
         torch.testing.assert_close(scores, want["scores"], rtol=0, atol=0)
         assert torch.equal(gt, want["gt_masks"])
+
+
+@pytest.mark.parametrize("tag,mode,unique,min_score,oracle_cls", [("raw_1", "", True, -1.0, False), ("eval_1", "eval", True, -1.0, False),
+                                                                  ("eval_0", "eval", False, 0.05, True)])
+def test_part_distillation_inference_oracle_matches_reference_golden(golden, tag, mode, unique, min_score, oracle_cls):
+    from oracle import inference_ref as I
+    g = golden("infer_pd")[tag]
+    outputs, inputs = C.make_infer_inputs()
+    K = C.INFER_PD_CLASSES
+    outputs = dict(outputs, pred_logits=C.seeded((len(inputs), C.INFER["Q"], K + 1), 5300) * 2)
+    mapping = {3: torch.tensor(C.INFER_PD_MAPPING[0]), 4: torch.tensor(C.INFER_PD_MAPPING[1])} if mode == "eval" else None
+    res = I.inference_pd(outputs, inputs, [3, 4], (128, 128), K, C.INFER["topk"] * 2, unique, 0.02, min_score, mapping,
+                         oracle_classifier=oracle_cls)
+    for (masks, scores, labels), want in zip(res, g):
+        assert torch.equal(masks, want["pred_masks"]) and torch.equal(labels, want["pred_classes"])
+        torch.testing.assert_close(scores, want["scores"], rtol=0, atol=0)

@@ -450,6 +450,26 @@ def test_part_distillation_swin_train_steps():
             want = sorted({c * 8 + k for c in (b["gt_object_class"] for b in batch) for k in range(8)} | {400})
             assert rows == want, (rows, want)
     assert all(np.isfinite(hist)) and np.mean(hist[-3:]) < np.mean(hist[:3]), hist
+    # evaluation branch of the same model (class-aware proposals, reference part_distillation_model.py:239-288)
+    from partdistillation_amd.compat import BitMasks, Instances
+    model = step.model.eval()
+    model.mode = "eval"
+    model.update_majority_vote_mapping({c: torch.randperm(8) % 3 for c in range(50)})
+    ev = []
+    for b in batch:
+        parts, objs = Instances((128, 128)), Instances((128, 128))
+        parts.gt_masks, parts.gt_classes = b["instances"].gt_masks, b["instances"].gt_classes % 3
+        objs.gt_masks = BitMasks(b["instances"].gt_masks.tensor.any(0, keepdim=True))
+        objs.gt_classes = torch.tensor([int(b["gt_object_class"])])
+        ev.append({"image": b["image"], "part_instances": parts, "instances": objs})
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        res = model(ev)
+    assert len(res) == 2
+    for r, e in zip(res, ev):
+        p = r["predictions"]
+        assert p.pred_masks.dtype == torch.bool and p.pred_masks.shape[0] == p.scores.shape[0] == p.pred_classes.shape[0] >= 1
+        assert int(p.pred_classes.max()) <= 8 and not (p.pred_masks & ~e["instances"].gt_masks.tensor.to(DEV)).any()
+        assert int(r["gt_object_label"]) == int(e["instances"].gt_classes)
 
 
 def test_loss_curve_matches_oracle_over_optimizer_steps():

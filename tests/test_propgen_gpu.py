@@ -187,3 +187,39 @@ def test_proposal_model_eval_end_to_end():
         assert p.pred_masks.shape[0] == p.scores.shape[0] == p.pred_classes.shape[0] >= 1
         assert not (p.pred_masks & ~i["object_mask"].to(DEV)).any()            # proposals stay inside the object
         assert r["gt_masks"].gt_masks.shape[0] == 3
+
+
+@pytest.mark.parametrize("tag,mode,unique,min_score,oracle_cls", [("raw_1", "", True, -1.0, False), ("eval_1", "eval", True, -1.0, False),
+                                                                  ("eval_0", "eval", False, 0.05, True)])
+def test_part_distillation_inference_vs_reference_golden(golden, tag, mode, unique, min_score, oracle_cls):
+    """class-aware evaluation branch of PartDistillationModel on the device against the real reference run"""
+    import types
+    from partdistillation_amd import inference as I
+    from partdistillation_amd.compat import BitMasks, ImageList, Instances
+    g = golden("infer_pd")[tag]
+    outputs, inputs = C.make_infer_inputs()
+    K = C.INFER_PD_CLASSES
+    outputs = {"pred_masks": outputs["pred_masks"].to(DEV), "pred_logits": (C.seeded((len(inputs), C.INFER["Q"], K + 1), 5300) * 2).to(DEV)}
+    model = types.SimpleNamespace(device=torch.device(DEV), test_topk_per_image=C.INFER["topk"] * 2, wandb_vis_topk=C.INFER["topk"] * 2,
+                                  use_unique_per_pixel_label=unique, min_pseudo_mask_ratio=0.02, min_pseudo_mask_score=min_score,
+                                  apply_masking_with_object_mask=True, num_part_classes=K, mode=mode, fg_score_threshold=0.1,
+                                  use_oracle_classifier=oracle_cls,
+                                  majority_vote_mapping={3: torch.tensor(C.INFER_PD_MAPPING[0], device=DEV), 4: torch.tensor(C.INFER_PD_MAPPING[1], device=DEV)})
+    batched = []
+    for b, i in enumerate(inputs):
+        parts, objs = Instances(tuple(i["image"].shape[-2:])), Instances(tuple(i["image"].shape[-2:]))
+        parts.gt_masks, parts.gt_classes = BitMasks(i["part_masks"]), i["part_labels"]
+        objs.gt_masks, objs.gt_classes = BitMasks(i["object_mask"]), torch.tensor([3 + b])
+        batched.append({"image": i["image"], "part_instances": parts, "instances": objs, "height": i["height"], "width": i["width"]})
+    images = ImageList.from_tensors([i["image"].to(DEV) for i in inputs], C.INFER["size_div"])
+    targets = I.prepare_pd_gt_targets(model, batched, images)
+    res = I.pd_inference(model, batched, targets, images, outputs)
+    for r, want in zip(res, g):
+        p = r["predictions"]
+        assert p.pred_masks.shape == want["pred_masks"].shape, (p.pred_masks.shape, want["pred_masks"].shape)
+        key = lambda s, c: torch.argsort(s.double() + c.double() * 1e-9)          # pair proposals by (distinct) score
+        o1, o2 = key(p.scores.cpu(), p.pred_classes.cpu()), key(want["scores"], want["pred_classes"])
+        assert torch.equal(p.pred_classes.cpu()[o1], want["pred_classes"][o2])
+        torch.testing.assert_close(p.scores.cpu()[o1], want["scores"][o2], rtol=1e-5, atol=1e-6)
+        assert (p.pred_masks.cpu()[o1] != want["pred_masks"][o2]).float().mean().item() < 2e-3
+        assert int(r["gt_object_label"]) == int(want["gt_object_label"])
