@@ -515,3 +515,21 @@ def test_loss_curve_matches_oracle_over_optimizer_steps():
     master = step.optimizer.flat.master_state()
     worst = max(((master[n].detach().cpu() - osd[n].detach()).abs().max() / osd[n].detach().abs().max().clamp_min(1e-6)).item() for n in names)
     assert worst < 2e-2, worst
+
+
+def test_training_step_with_an_image_without_masks_takes_the_per_head_loop():
+    """an image with zero pseudo masks cannot go through the batched criterion: the per-head loop runs and materialises the
+    dense masks the decoder skipped (materialize_masks); losses stay finite and the step completes"""
+    from partdistillation_amd.engine.synthetic import make_batch
+    from partdistillation_amd.engine.trainer import TrainStep
+    cfg = _toy_cfg(["SOLVER.AMP.ENABLED", "True"])
+    torch.manual_seed(3)
+    step = TrainStep(cfg)
+    batch = make_batch(2, 96, n_parts=3, seed=8, device=DEV)
+    batch[1]["instances"].gt_masks.tensor = batch[1]["instances"].gt_masks.tensor[:0]
+    batch[1]["instances"].gt_classes = batch[1]["instances"].gt_classes[:0]
+    assert step.model.sem_seg_head.predictor.dense_masks is False
+    losses = step(batch)
+    assert len(losses) == 12 and all(torch.isfinite(v).all() for v in losses.values())
+    full = make_batch(2, 96, n_parts=3, seed=8, device=DEV)
+    assert all(torch.isfinite(v).all() for v in step(full).values())          # and the batched path still works afterwards
