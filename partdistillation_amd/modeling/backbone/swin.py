@@ -13,6 +13,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 from torch import nn
 
+from ...functions import window_attention as wattn
 from ...functions.rowwise import add_layer_norm, supports_width
 
 from ...compat import BACKBONE_REGISTRY, ShapeSpec
@@ -100,17 +101,22 @@ class WindowAttention(nn.Module):
         n = self.window_size[0] * self.window_size[1]
         return _TableLookup.apply(self.relative_position_bias_table, self.relative_position_index.view(-1)).view(n, n, -1).permute(2, 0, 1)
 
-    def forward(self, x, mask=None):
-        """x [nW*B, N, C]; mask [nW, N, N] additive (0 / -100) or None."""
+    def forward(self, x, mask=None, regions=None, n_windows=1):
+        """x [nW*B, N, C]; mask [nW, N, N] additive (0 / -100) or None; regions = the same mask as per-token region
+        labels (functions/window_attention.shifted_window_regions) for the fused kernel."""
         B_, N, C = x.shape
         h = self.num_heads
-        qkv = self.qkv(x).reshape(B_, N, 3, h, C // h).permute(2, 0, 3, 1, 4)
+        qkv = self.qkv(x)
+        p = self.attn_drop.p if self.training else 0.0
+        if wattn.supported(qkv, self.window_size, h, p) and (mask is None) == (regions is None):
+            out = wattn.window_attention(qkv, self.relative_position_bias_table, regions, self.scale, n_windows)
+            return self.proj_drop(self.proj(out))
+        qkv = qkv.reshape(B_, N, 3, h, C // h).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         add = self.bias().unsqueeze(0)                                                  # [1,h,N,N]
         if mask is not None:
             nW = mask.shape[0]
             add = (add + mask.unsqueeze(1)).unsqueeze(0).expand(B_ // nW, -1, -1, -1, -1).reshape(B_, h, N, N)
-        p = self.attn_drop.p if self.training else 0.0
         out = F.scaled_dot_product_attention(q, k, v, attn_mask=add.to(q.dtype), dropout_p=p, scale=self.scale)
         return self.proj_drop(self.proj(out.transpose(1, 2).reshape(B_, N, C)))
 
@@ -150,7 +156,9 @@ class SwinTransformerBlock(nn.Module):
             gather = window_gather_index(H, W, ws, self.shift_size, x.device)
         idx, inv, n_win, any_pad = gather
         xw = _WindowGather.apply(x, idx, inv, any_pad).reshape(B * n_win, ws * ws, C)   # padded slots read a zero row
-        aw = self.attn(xw, mask=mask_matrix if self.shift_size > 0 else None)
+        shifted = self.shift_size > 0
+        regions = wattn.shifted_window_regions(H, W, self.shift_size, x.device) if shifted and ws == wattn.WINDOW else None
+        aw = self.attn(xw, mask=mask_matrix if shifted else None, regions=regions, n_windows=n_win)
         x = _WindowScatter.apply(aw.reshape(B, n_win * ws * ws, C), idx, inv, any_pad)
         x = shortcut + self.drop_path(x)
         return x + self.drop_path(self.mlp(_layer_norm(self.norm2, x)))

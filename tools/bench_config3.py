@@ -12,8 +12,10 @@ from partdistillation_amd.engine.synthetic import make_batch
 from partdistillation_amd.engine.trainer import TrainStep
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+name = os.environ.get("PD_CONFIG", "swinb")          # swinb = config 3, swinl (+ size 1280) = config 5
+extra = os.environ.get("PD_OPTS", "").split()
 torch.backends.cudnn.benchmark = True
-cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd", "configs", "part_distillation", "swinb_mask2former.yaml"), ["INPUT.IMAGE_SIZE", str(size)])
+cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd", "configs", "part_distillation", name + "_mask2former.yaml"), ["INPUT.IMAGE_SIZE", str(size)] + extra)
 torch.manual_seed(0)
 step = TrainStep(cfg)
 batches = [make_batch(2, size, seed=1234 + 1000 * i, device="cuda", part_distillation=True) for i in range(2)]
@@ -26,7 +28,7 @@ for i in range(steps):
 issue = time.perf_counter() - t0
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
-print(json.dumps({"workload": "Swin-B part-distillation step, bs 2, %d^2, 1 GPU" % size, "ms_per_step": el / steps * 1e3,
+print(json.dumps({"workload": "%s part-distillation step, bs 2, %d^2, 1 GPU %s" % (name, size, " ".join(extra)), "ms_per_step": el / steps * 1e3,
                   "host_issue_ms": issue / steps * 1e3, "images_per_s": 2 * steps / el,
                   "loss": float(sum(v.detach() for v in losses.values())), "max_mem_GiB": torch.cuda.max_memory_allocated() / 2**30}))
 if len(sys.argv) > 3:
