@@ -37,6 +37,7 @@ extern int g_pd_dbg_ablate;
 extern int g_pd_dbg_wgrad_wgs;
 extern int g_pd_dbg_bwd_threads;
 extern int g_pd_dbg_attn_scalar;
+extern int g_pd_dbg_wattn;
 extern "C" int pd_debug_set(const char *key, int value)
 {
   if (!key) return PD_ERR_INVALID_ARG;
@@ -45,6 +46,7 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!strcmp(key, "attn_scalar")) { g_pd_dbg_attn_scalar = value; return PD_OK; }
   if (!strcmp(key, "msda_bwd_threads")) { g_pd_dbg_bwd_threads = value; return PD_OK; }
   if (!strcmp(key, "wgrad_wgs")) { g_pd_dbg_wgrad_wgs = value; return PD_OK; }
+  if (!strcmp(key, "wattn_ablate")) { g_pd_dbg_wattn = value; return PD_OK; }
   if (!strcmp(key, "msda_force_generic")) { g_pd_dbg_force_generic = value; return PD_OK; }
   return pd_set_error(PD_ERR_INVALID_ARG, "pd_debug_set: unknown key %s", key);
 }

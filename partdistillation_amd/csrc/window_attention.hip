@@ -1,8 +1,12 @@
 // Swin (shifted-)window attention for gfx950: 12 x 12 windows (144 tokens), head_dim 32, bf16 on
 // v_mfma_f32_16x16x16_bf16_1k, fp32 softmax.  C-ABI and the math it replaces: include/pd_window_attention.h.
 //
-// One WAVEFRONT owns one (window, head) at a time (workgroup = 1 wave, so LDS traffic needs no cross-wave barrier) and
-// walks `chunk` windows of the same head so the bias table / its gradient are staged once.
+// One WORKGROUP of 9 wavefronts owns one (window, head) at a time: the 144 x 32 q / k / v (/ dO) tiles are staged once in
+// LDS (row-major, pitch 36) and wave w owns the w-th 16-row tile — 16 queries in the forward and in the dQ phase of the
+// backward, 16 keys in its dK / dV phase — so every accumulator is complete inside one wave (no cross-wave reduction) and
+// per-wave register state stays small enough for ~5 waves per SIMD (the first version ran one wave per (window, head)
+// with ~400 VGPRs: one wave per SIMD, every MFMA / LDS / exp latency exposed, 10x slower).  The workgroup walks `chunk`
+// windows of the same head so the bias table / its gradient are staged once.
 //
 // MFMA operand convention used below (16x16x16, lane = 16*g + c):
 //     mma16(acc, x, y): acc[i][j] += sum_k X[i][k] * Y[j][k]
@@ -10,10 +14,11 @@
 //     acc: this lane holds acc[i = 4g + e][j = c], e = 0..3
 // A lane therefore ends up with 4 CONSECUTIVE i for one j — which is again the "4 consecutive k" an operand needs, so
 // softmax probabilities feed the next MFMA straight from registers:
-//   forward  S^T = K.Q^T   -> lane: query c, keys 4g+e   -> P is the y-operand of O^T[d][q] = Vt[d][key] . P[q][key]
-//   backward S   = Q.K^T   -> lane: key c, queries 4g+e  -> P / dS are the y-operands of dV^T = dOt.P, dK^T = Qt.dS;
-//                                                           only dQ needs dS transposed (16 x 16 tile through LDS).
-// "t"-suffixed operands (Vt, Qt, dOt) are [32][144] transposes staged in LDS; Kt is gathered from global per key tile.
+//   forward, dQ phase   S^T = K.Q^T -> lane: query c, keys 4g+e  -> P / dS are the y-operands of O^T = Vt.P, dQ^T = Kt.dS
+//   dK / dV phase       S   = Q.K^T -> lane: key c, queries 4g+e -> P / dS are the y-operands of dV^T = dOt.P, dK^T = Qt.dS
+// The x-operands with a "t" need 4 consecutive ROWS of a row-major tile per lane; tr16() gets them with one more MFMA
+// against the identity (acc = X . I^T leaves X[4g+e][c] in the lane = X^T's operand layout; exact, the values are bf16),
+// except Vt in the forward, which is staged transposed once.
 //
 // Relative-position bias: 4 consecutive tokens starting at a multiple of 4 lie in one row of the 12 x 12 window, so with
 // A(t) = t + 11*(t/12) the 4 table indices a lane needs, A(q) - A(key) + 264, are consecutive: one address, 4 LDS reads.
@@ -25,223 +30,215 @@
 #include "pd_msda.h"
 #include "pd_window_attention.h"
 
+int g_pd_dbg_wattn = 0;   // tools/ only: 1 no LDS table-gradient atomics, 2 no global flush, 4 skip dK/dV phase, 8 skip dQ phase
+
 namespace {
 using namespace pdmfma;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int N = 144, D = 32, NT = 9, TBL = 529;
-constexpr int TP = 148;                      // pitch (elements) of the [32][144] transposed LDS tiles
-constexpr int TR = 20;                       // pitch of the 16 x 16 dS transposition tile
+constexpr int N = 144, D = 32, NT = 9, TBL = 529, THREADS = 64 * NT;
+constexpr int RP = 36;                       // pitch (elements) of the row-major [144][32] LDS tiles
+constexpr int TP = 148;                      // pitch of the transposed [32][144] V tile of the forward
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float MASKED = -100.0f * LOG2E;    // the reference's additive -100 in base-2 units
 
 __device__ __forceinline__ void mma16(f32x4 &c, bf16x4 x, bf16x4 y) { c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(x, y, c, 0, 0, 0); }
 __device__ __forceinline__ int rel_a(int t) { return t + 11 * ((t * 171) >> 11); }            // t + 11*(t/12), t < 144
-__device__ __forceinline__ bf16x4 ld4(const bf16_t *p) { return *reinterpret_cast<const bf16x4 *>(p); }
 __device__ __forceinline__ void st4(bf16_t *p, float a, float b, float c, float d) { *reinterpret_cast<bf16x4 *>(p) = pack4(a, b, c, d); }
-
-// rows [144] x 32 columns at `src` (row pitch ld) -> dst[d][row] (pitch TP)
-__device__ __forceinline__ void stage_transposed(const bf16_t *__restrict__ src, int64_t ld, bf16_t *dst, int lane)
+__device__ __forceinline__ bf16x4 tr16(bf16x4 x, bf16x4 ident)                                // X[rows][16] -> X^T operand
 {
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  mma16(a, x, ident);
+  return pack4(a[0], a[1], a[2], a[3]);
+}
+__device__ __forceinline__ bf16x4 identity_operand(int c, int g)
+{
+  bf16x4 r;
 #pragma unroll
-  for (int it = 0; it < 9; ++it) {
-    const int idx = it * 64 + lane, row = idx >> 2, ch = idx & 3;
-    const uint4 v = *reinterpret_cast<const uint4 *>(src + row * ld + ch * 8);
-    bf16_t *d = dst + (ch * 8) * TP + row;
-    d[0 * TP] = (bf16_t)(v.x & 0xffff); d[1 * TP] = (bf16_t)(v.x >> 16);
-    d[2 * TP] = (bf16_t)(v.y & 0xffff); d[3 * TP] = (bf16_t)(v.y >> 16);
-    d[4 * TP] = (bf16_t)(v.z & 0xffff); d[5 * TP] = (bf16_t)(v.z >> 16);
-    d[6 * TP] = (bf16_t)(v.w & 0xffff); d[7 * TP] = (bf16_t)(v.w >> 16);
-  }
+  for (int m = 0; m < 4; ++m) r[m] = (4 * g + m == c) ? (short)0x3F80 : (short)0;
+  return r;
+}
+
+// [144 rows] x 32 columns at `src` (row pitch ld) -> dst[row][col] (pitch RP); one 16-byte chunk per thread
+__device__ __forceinline__ void stage_rows(const bf16_t *__restrict__ src, int64_t ld, bf16_t *dst, int tid)
+{
+  const int row = tid >> 2, ch = tid & 3;
+  const uint4 v = *reinterpret_cast<const uint4 *>(src + row * ld + ch * 8);
+  uint2 *d = reinterpret_cast<uint2 *>(dst + row * RP + ch * 8);
+  d[0] = uint2{v.x, v.y};
+  d[1] = uint2{v.z, v.w};
+}
+// same source -> dst[col][row] (pitch TP)
+__device__ __forceinline__ void stage_transposed(const bf16_t *__restrict__ src, int64_t ld, bf16_t *dst, int tid)
+{
+  const int row = tid >> 2, ch = tid & 3;
+  const uint4 v = *reinterpret_cast<const uint4 *>(src + row * ld + ch * 8);
+  bf16_t *d = dst + (ch * 8) * TP + row;
+  d[0 * TP] = (bf16_t)(v.x & 0xffff); d[1 * TP] = (bf16_t)(v.x >> 16);
+  d[2 * TP] = (bf16_t)(v.y & 0xffff); d[3 * TP] = (bf16_t)(v.y >> 16);
+  d[4 * TP] = (bf16_t)(v.z & 0xffff); d[5 * TP] = (bf16_t)(v.z >> 16);
+  d[6 * TP] = (bf16_t)(v.w & 0xffff); d[7 * TP] = (bf16_t)(v.w >> 16);
 }
 
 template <bool MASK>
-__global__ __launch_bounds__(64) void wattn_fwd(const bf16_t *__restrict__ qkv, const float *__restrict__ table,
-                                                const uint8_t *__restrict__ region, const uint8_t *__restrict__ flags,
-                                                bf16_t *__restrict__ out, float *__restrict__ lse, int B_, int nW, int heads,
-                                                float c1, int chunk)
+__global__ __launch_bounds__(THREADS) void wattn_fwd(const bf16_t *__restrict__ qkv, const float *__restrict__ table,
+                                                     const uint8_t *__restrict__ region, const uint8_t *__restrict__ flags,
+                                                     bf16_t *__restrict__ out, float *__restrict__ lse, int B_, int nW,
+                                                     int heads, float c1, int chunk)
 {
   __shared__ float tbl[TBL + 3];
+  __shared__ __attribute__((aligned(16))) bf16_t ks[N * RP];
   __shared__ __attribute__((aligned(16))) bf16_t vt[D * TP];
-  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, qt = tid >> 6, c = lane & 15, g = lane >> 4, h = blockIdx.y;
   const int C = heads * D;
   const int64_t ld = 3 * C;
-  for (int i = lane; i < TBL; i += 64) tbl[i] = table[i * heads + h] * LOG2E;
+  for (int i = tid; i < TBL; i += THREADS) tbl[i] = table[i * heads + h] * LOG2E;
 
   for (int u = 0; u < chunk; ++u) {
     const int b = blockIdx.x * chunk + u;
     if (b >= B_) break;
     const bf16_t *base = qkv + (int64_t)b * N * ld + h * D;
     __syncthreads();
-    stage_transposed(base + 2 * C, ld, vt, lane);
-    bf16x4 kf[NT][2];
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      kf[kt][0] = ld4(base + C + (16 * kt + c) * ld + 4 * g);
-      kf[kt][1] = ld4(base + C + (16 * kt + c) * ld + 16 + 4 * g);
-    }
+    stage_rows(base + C, ld, ks, tid);
+    stage_transposed(base + 2 * C, ld, vt, tid);
+    const int q = 16 * qt + c;
+    const bf16x4 q0 = *reinterpret_cast<const bf16x4 *>(base + q * ld + 4 * g);
+    const bf16x4 q1 = *reinterpret_cast<const bf16x4 *>(base + q * ld + 16 + 4 * g);
     const int w = b % nW;
     const bool masked = MASK && flags[w] != 0;
     const uint8_t *r = MASK ? region + w * N : nullptr;
+    const unsigned rq = masked ? r[q] : 0u;
     __syncthreads();
-#pragma unroll 1
-    for (int qt = 0; qt < NT; ++qt) {
-      const int q = 16 * qt + c;
-      const bf16x4 q0 = ld4(base + q * ld + 4 * g), q1 = ld4(base + q * ld + 16 + 4 * g);
-      f32x4 s[NT];
+    f32x4 s[NT];
+    const int aq = rel_a(q) + 264 - 3;
+    float m = -INFINITY;
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
-        s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mma16(s[kt], kf[kt][0], q0);
-        mma16(s[kt], kf[kt][1], q1);
-      }
-      const int aq = rel_a(q) + 264 - 3;
-      const unsigned rq = masked ? r[q] : 0u;
-      float m = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
-        const int key0 = 16 * kt + 4 * g;
-        const float *tb = tbl + (aq - rel_a(key0));                     // index for key0+e is tb[3 - e]
-        s[kt][0] = fmaf(s[kt][0], c1, tb[3]); s[kt][1] = fmaf(s[kt][1], c1, tb[2]);
-        s[kt][2] = fmaf(s[kt][2], c1, tb[1]); s[kt][3] = fmaf(s[kt][3], c1, tb[0]);
-        if (masked) {
-          const unsigned rk = *reinterpret_cast<const unsigned *>(r + key0);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (((rk >> (8 * e)) & 255u) != rq) s[kt][e] += MASKED;
-        }
-        m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
-      }
-      m = fmaxf(m, __shfl_xor(m, 16));
-      m = fmaxf(m, __shfl_xor(m, 32));
-      float sum = 0.f;
-      bf16x4 p[NT];
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { s[kt][e] = __builtin_amdgcn_exp2f(s[kt][e] - m); sum += s[kt][e]; }
-        p[kt] = pack4(s[kt][0], s[kt][1], s[kt][2], s[kt][3]);
-      }
-      sum += __shfl_xor(sum, 16);
-      sum += __shfl_xor(sum, 32);
-      f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
-        mma16(o0, lds4(vt + c * TP + 16 * kt + 4 * g), p[kt]);            // O^T[d = 4g+e][q = c]
-        mma16(o1, lds4(vt + (16 + c) * TP + 16 * kt + 4 * g), p[kt]);
-      }
-      const float inv = 1.f / sum;
-      bf16_t *o = out + ((int64_t)b * N + q) * C + h * D + 4 * g;
-      st4(o, o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
-      st4(o + 16, o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
-      if (g == 0) lse[((int64_t)b * heads + h) * N + q] = m + log2f(sum);
+    for (int kt = 0; kt < NT; ++kt) {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mma16(s[kt], lds4(ks + (16 * kt + c) * RP + 4 * g), q0);            // S^T[key = 4g+e][q = c]
+      mma16(s[kt], lds4(ks + (16 * kt + c) * RP + 16 + 4 * g), q1);
     }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      const int key0 = 16 * kt + 4 * g;
+      const float *tb = tbl + (aq - rel_a(key0));                         // index for key0+e is tb[3 - e]
+      s[kt][0] = fmaf(s[kt][0], c1, tb[3]); s[kt][1] = fmaf(s[kt][1], c1, tb[2]);
+      s[kt][2] = fmaf(s[kt][2], c1, tb[1]); s[kt][3] = fmaf(s[kt][3], c1, tb[0]);
+      if (masked) {
+        const unsigned rk = *reinterpret_cast<const unsigned *>(r + key0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (((rk >> (8 * e)) & 255u) != rq) s[kt][e] += MASKED;
+      }
+      m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[kt][e] = __builtin_amdgcn_exp2f(s[kt][e] - m); sum += s[kt][e]; }
+      const bf16x4 p = pack4(s[kt][0], s[kt][1], s[kt][2], s[kt][3]);
+      mma16(o0, lds4(vt + c * TP + 16 * kt + 4 * g), p);                  // O^T[d = 4g+e][q = c]
+      mma16(o1, lds4(vt + (16 + c) * TP + 16 * kt + 4 * g), p);
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.f / sum;
+    bf16_t *o = out + ((int64_t)b * N + q) * C + h * D + 4 * g;
+    st4(o, o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
+    st4(o + 16, o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+    if (g == 0) lse[((int64_t)b * heads + h) * N + q] = m + log2f(sum);
   }
 }
 
-template <bool MASK>
-__global__ __launch_bounds__(64) void wattn_bwd(const bf16_t *__restrict__ qkv, const float *__restrict__ table,
-                                                const uint8_t *__restrict__ region, const uint8_t *__restrict__ flags,
-                                                const bf16_t *__restrict__ out, const bf16_t *__restrict__ dout,
-                                                const float *__restrict__ lse, bf16_t *__restrict__ dqkv,
-                                                float *__restrict__ dtable, int B_, int nW, int heads, float scale, float c1,
-                                                int chunk)
+template <bool MASK, int ABL>
+__global__ __launch_bounds__(THREADS) void wattn_bwd(const bf16_t *__restrict__ qkv, const float *__restrict__ table,
+                                                     const uint8_t *__restrict__ region, const uint8_t *__restrict__ flags,
+                                                     const bf16_t *__restrict__ out, const bf16_t *__restrict__ dout,
+                                                     const float *__restrict__ lse, bf16_t *__restrict__ dqkv,
+                                                     float *__restrict__ dtable, int B_, int nW, int heads, float scale,
+                                                     float c1, int chunk, int ablate)
 {
   __shared__ float tbl[TBL + 3];
-  __shared__ float dtb[TBL + 3];
-  __shared__ __attribute__((aligned(16))) bf16_t qts[D * TP];
-  __shared__ __attribute__((aligned(16))) bf16_t dots[D * TP];
+  __shared__ __attribute__((aligned(16))) bf16_t tiles[4 * N * RP];
   __shared__ __attribute__((aligned(16))) float lse_s[N];
   __shared__ __attribute__((aligned(16))) float delta_s[N];
-  __shared__ __attribute__((aligned(16))) bf16_t tr[2][16 * TR];
-  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4, h = blockIdx.y;
+  bf16_t *qs = tiles, *ks = tiles + N * RP, *vs = tiles + 2 * N * RP, *dos = tiles + 3 * N * RP;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4, h = blockIdx.y;
   const int C = heads * D;
   const int64_t ld = 3 * C;
-  for (int i = lane; i < TBL; i += 64) { tbl[i] = table[i * heads + h] * LOG2E; dtb[i] = 0.f; }
+  const bf16x4 ident = identity_operand(c, g);
+  for (int i = tid; i < TBL; i += THREADS) tbl[i] = table[i * heads + h] * LOG2E;
+  // table gradient: a lane meets the same 36 (query, key) pairs in every window, so it sums dS over the `chunk` windows in
+  // registers; the pairs -> table-entry reduction happens once per workgroup, without atomics (below).  ds_add_f32 costs
+  // ~175 cycles per wave instruction on gfx950 whatever the addresses: per-window LDS atomics were 60 % of the kernel.
+  f32x4 dacc[NT];
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt) dacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int u = 0; u < chunk; ++u) {
     const int b = blockIdx.x * chunk + u;
     if (b >= B_) break;
     const bf16_t *base = qkv + (int64_t)b * N * ld + h * D;
     const bf16_t *dob = dout + (int64_t)b * N * C + h * D;
-    const bf16_t *ob = out + (int64_t)b * N * C + h * D;
     bf16_t *dbase = dqkv + (int64_t)b * N * ld + h * D;
     __syncthreads();
-    stage_transposed(base, ld, qts, lane);
-    stage_transposed(dob, C, dots, lane);
-    for (int row = lane; row < N; row += 64) {                          // delta = rowsum(dO * O), lse
-      float acc = 0.f;
-#pragma unroll
-      for (int ch = 0; ch < 4; ++ch) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(dob + (int64_t)row * C + ch * 8);
-        const uint4 o = *reinterpret_cast<const uint4 *>(ob + (int64_t)row * C + ch * 8);
-        acc += bf_lo(a.x) * bf_lo(o.x) + bf_hi(a.x) * bf_hi(o.x) + bf_lo(a.y) * bf_lo(o.y) + bf_hi(a.y) * bf_hi(o.y)
-             + bf_lo(a.z) * bf_lo(o.z) + bf_hi(a.z) * bf_hi(o.z) + bf_lo(a.w) * bf_lo(o.w) + bf_hi(a.w) * bf_hi(o.w);
-      }
-      delta_s[row] = acc;
-      lse_s[row] = lse[((int64_t)b * heads + h) * N + row];
-    }
-    bf16x4 qf[NT][2], dof[NT][2];
-    f32x4 dq[NT][2];
-#pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
-      qf[qt][0] = ld4(base + (16 * qt + c) * ld + 4 * g);
-      qf[qt][1] = ld4(base + (16 * qt + c) * ld + 16 + 4 * g);
-      dof[qt][0] = ld4(dob + (int64_t)(16 * qt + c) * C + 4 * g);
-      dof[qt][1] = ld4(dob + (int64_t)(16 * qt + c) * C + 16 + 4 * g);
-      dq[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dq[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stage_rows(base, ld, qs, tid);
+    stage_rows(base + C, ld, ks, tid);
+    stage_rows(base + 2 * C, ld, vs, tid);
+    stage_rows(dob, C, dos, tid);
+    {                                                                     // delta = rowsum(dO * O): 4 threads per row
+      const int row = tid >> 2, ch = tid & 3;
+      const uint4 a = *reinterpret_cast<const uint4 *>(dob + (int64_t)row * C + ch * 8);
+      const uint4 o = *reinterpret_cast<const uint4 *>(out + ((int64_t)b * N + row) * C + h * D + ch * 8);
+      float acc = bf_lo(a.x) * bf_lo(o.x) + bf_hi(a.x) * bf_hi(o.x) + bf_lo(a.y) * bf_lo(o.y) + bf_hi(a.y) * bf_hi(o.y)
+                + bf_lo(a.z) * bf_lo(o.z) + bf_hi(a.z) * bf_hi(o.z) + bf_lo(a.w) * bf_lo(o.w) + bf_hi(a.w) * bf_hi(o.w);
+      acc += __shfl_xor(acc, 1);
+      acc += __shfl_xor(acc, 2);
+      if (ch == 0) { delta_s[row] = acc; lse_s[row] = lse[((int64_t)b * heads + h) * N + row]; }
     }
     const int w = b % nW;
     const bool masked = MASK && flags[w] != 0;
     const uint8_t *r = MASK ? region + w * N : nullptr;
     __syncthreads();
-#pragma unroll 1
-    for (int kt = 0; kt < NT; ++kt) {
-      const int key = 16 * kt + c;
-      const bf16_t *kp = base + C + key * ld, *vp = base + 2 * C + key * ld;
-      const bf16x4 k0 = ld4(kp + 4 * g), k1 = ld4(kp + 16 + 4 * g), v0 = ld4(vp + 4 * g), v1 = ld4(vp + 16 + 4 * g);
-      const bf16_t *ktp = base + C + (16 * kt + 4 * g) * ld + c;        // Kt[d = c (+16)][keys 16kt + 4g ..+3]
-      const bf16x4 kt0 = gather4(ktp, (int)ld), kt1 = gather4(ktp + 16, (int)ld);
+
+    if (!(ablate & 4)) {                                                  // ---- phase 1: this wave's 16 KEYS -> dK, dV
+      const int key = 16 * wv + c;
+      const bf16x4 k0 = lds4(ks + key * RP + 4 * g), k1 = lds4(ks + key * RP + 16 + 4 * g);
+      const bf16x4 v0 = lds4(vs + key * RP + 4 * g), v1 = lds4(vs + key * RP + 16 + 4 * g);
       f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = dk0, dv0 = dk0, dv1 = dk0;
       const int ak = rel_a(key) - 264;
       const unsigned rk = masked ? r[key] : 0u;
-#pragma unroll
+#pragma unroll 3
       for (int qt = 0; qt < NT; ++qt) {
+        const bf16x4 qa0 = lds4(qs + (16 * qt + c) * RP + 4 * g), qa1 = lds4(qs + (16 * qt + c) * RP + 16 + 4 * g);
+        const bf16x4 da0 = lds4(dos + (16 * qt + c) * RP + 4 * g), da1 = lds4(dos + (16 * qt + c) * RP + 16 + 4 * g);
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = s;
-        mma16(s, qf[qt][0], k0);                                        // S[q = 4g+e][key = c]
-        mma16(s, qf[qt][1], k1);
-        mma16(dp, dof[qt][0], v0);
-        mma16(dp, dof[qt][1], v1);
+        mma16(s, qa0, k0);                                                // S[q = 4g+e][key = c]
+        mma16(s, qa1, k1);
+        mma16(dp, da0, v0);
+        mma16(dp, da1, v1);
+        const bf16x4 dot0 = tr16(da0, ident), dot1 = tr16(da1, ident), qt0 = tr16(qa0, ident), qt1 = tr16(qa1, ident);
         const int q0 = 16 * qt + 4 * g;
-        const int ti = rel_a(q0) - ak;                                  // table index of (q0 + e, key) is ti + e
+        const float *tb = tbl + (rel_a(q0) - ak);                         // table index of (q0 + e, key) is tb[e]
         const f32x4 L = *reinterpret_cast<const f32x4 *>(lse_s + q0), Dl = *reinterpret_cast<const f32x4 *>(delta_s + q0);
         unsigned rq = 0;
         if (masked) rq = *reinterpret_cast<const unsigned *>(r + q0);
         float p[4], ds[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = fmaf(s[e], c1, tbl[ti + e]);
+          float t = fmaf(s[e], c1, tb[e]);
           if (masked && ((rq >> (8 * e)) & 255u) != rk) t += MASKED;
           p[e] = __builtin_amdgcn_exp2f(t - L[e]);
-          ds[e] = p[e] * (dp[e] - Dl[e]);
-          atomicAdd(&dtb[ti + e], ds[e]);
+          ds[e] = p[e] * (dp[e] - Dl[e]) * scale;
         }
-        const bf16x4 pb = pack4(p[0], p[1], p[2], p[3]);
-        const bf16x4 dsb = pack4(ds[0] * scale, ds[1] * scale, ds[2] * scale, ds[3] * scale);
-        const bf16x4 dot0 = lds4(dots + c * TP + q0), dot1 = lds4(dots + (16 + c) * TP + q0);
-        const bf16x4 qt0 = lds4(qts + c * TP + q0), qt1 = lds4(qts + (16 + c) * TP + q0);
-        mma16(dv0, dot0, pb);                                           // dV^T[d = 4g+e][key = c]
+        const bf16x4 pb = pack4(p[0], p[1], p[2], p[3]), dsb = pack4(ds[0], ds[1], ds[2], ds[3]);
+        mma16(dv0, dot0, pb);                                             // dV^T[d = 4g+e][key = c]
         mma16(dv1, dot1, pb);
         mma16(dk0, qt0, dsb);
         mma16(dk1, qt1, dsb);
-        bf16_t *t = tr[qt & 1];                                         // dS tile -> lane: query c, keys 4g..4g+3
-        t[(4 * g + 0) * TR + c] = (bf16_t)dsb[0]; t[(4 * g + 1) * TR + c] = (bf16_t)dsb[1];
-        t[(4 * g + 2) * TR + c] = (bf16_t)dsb[2]; t[(4 * g + 3) * TR + c] = (bf16_t)dsb[3];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");           // one wave: LDS executes in issue order
-        const bf16x4 dst = lds4(t + c * TR + 4 * g);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        mma16(dq[qt][0], kt0, dst);                                     // dQ^T[d = 4g+e][q = c]
-        mma16(dq[qt][1], kt1, dst);
       }
       bf16_t *dkp = dbase + C + key * ld + 4 * g, *dvp = dbase + 2 * C + key * ld + 4 * g;
       st4(dkp, dk0[0], dk0[1], dk0[2], dk0[3]);
@@ -249,15 +246,78 @@ __global__ __launch_bounds__(64) void wattn_bwd(const bf16_t *__restrict__ qkv, 
       st4(dvp, dv0[0], dv0[1], dv0[2], dv0[3]);
       st4(dvp + 16, dv1[0], dv1[1], dv1[2], dv1[3]);
     }
+    if (!(ablate & 8)) {                                                  // ---- phase 2: this wave's 16 QUERIES -> dQ, dtable
+      const int q = 16 * wv + c;
+      const bf16x4 q0 = lds4(qs + q * RP + 4 * g), q1 = lds4(qs + q * RP + 16 + 4 * g);
+      const bf16x4 d0 = lds4(dos + q * RP + 4 * g), d1 = lds4(dos + q * RP + 16 + 4 * g);
+      const float L = lse_s[q], Dl = delta_s[q];
+      const int aq = rel_a(q) + 264 - 3;
+      const unsigned rq = masked ? r[q] : 0u;
+      f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
 #pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
-      bf16_t *dqp = dbase + (16 * qt + c) * ld + 4 * g;
-      st4(dqp, dq[qt][0][0], dq[qt][0][1], dq[qt][0][2], dq[qt][0][3]);
-      st4(dqp + 16, dq[qt][1][0], dq[qt][1][1], dq[qt][1][2], dq[qt][1][3]);
+      for (int kt = 0; kt < NT; ++kt) {
+        const bf16x4 ka0 = lds4(ks + (16 * kt + c) * RP + 4 * g), ka1 = lds4(ks + (16 * kt + c) * RP + 16 + 4 * g);
+        const bf16x4 va0 = lds4(vs + (16 * kt + c) * RP + 4 * g), va1 = lds4(vs + (16 * kt + c) * RP + 16 + 4 * g);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = s;
+        mma16(s, ka0, q0);                                                // S^T[key = 4g+e][q = c]
+        mma16(s, ka1, q1);
+        mma16(dp, va0, d0);
+        mma16(dp, va1, d1);
+        const bf16x4 kt0 = tr16(ka0, ident), kt1 = tr16(ka1, ident);
+        const int key0 = 16 * kt + 4 * g, ti = aq - rel_a(key0);          // table index of (q, key0 + e) is ti + 3 - e
+        unsigned rk = 0;
+        if (masked) rk = *reinterpret_cast<const unsigned *>(r + key0);
+        float ds[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = fmaf(s[e], c1, tbl[ti + 3 - e]);
+          if (masked && ((rk >> (8 * e)) & 255u) != rq) t += MASKED;
+          const float p = __builtin_amdgcn_exp2f(t - L);
+          ds[e] = p * (dp[e] - Dl);
+        }
+        const bf16x4 dsb = pack4(ds[0] * scale, ds[1] * scale, ds[2] * scale, ds[3] * scale);
+        mma16(dq0, kt0, dsb);                                             // dQ^T[d = 4g+e][q = c]
+        mma16(dq1, kt1, dsb);
+        dacc[kt][0] += ds[0]; dacc[kt][1] += ds[1]; dacc[kt][2] += ds[2]; dacc[kt][3] += ds[3];
+      }
+      bf16_t *dqp = dbase + q * ld + 4 * g;
+      st4(dqp, dq0[0], dq0[1], dq0[2], dq0[3]);
+      st4(dqp + 16, dq1[0], dq1[1], dq1[2], dq1[3]);
     }
   }
-  __syncthreads();
-  for (int i = lane; i < TBL; i += 64) atomicAdd(dtable + i * heads + h, dtb[i]);
+  if (ABL != 1) {
+    // sum of dS over this workgroup's windows, [144 queries][144 keys] fp32, goes through the (now dead) tile space 48
+    // query rows = 4 rows of the 12 x 12 grid at a time; thread i < 529 owns table entry i = (dr + 11) * 23 + (dc + 11)
+    // and adds up the pairs (rq, cq) -> (rq - dr, cq - dc) it is made of: every element is read exactly once
+    float *red = reinterpret_cast<float *>(tiles);
+    const int dr = tid / 23 - 11, dc = tid % 23 - 11;
+    const int c_lo = dc > 0 ? dc : 0, c_hi = dc < 0 ? 12 + dc : 12;
+    float tsum = 0.f;
+    for (int r = 0; r < 3; ++r) {
+      __syncthreads();
+      if (wv / 3 == r) {
+        float *row = red + (16 * (wv - 3 * r) + c) * N + 4 * g;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) *reinterpret_cast<f32x4 *>(row + 16 * kt) = dacc[kt];
+      }
+      __syncthreads();
+      if (tid < TBL) {
+#pragma unroll
+        for (int rl = 0; rl < 4; ++rl) {
+          const int rk = 4 * r + rl - dr;
+          const bool row_ok = rk >= 0 && rk < 12;
+          const float *src = red + 12 * rl * N + 12 * (row_ok ? rk : 0) - dc;
+#pragma unroll
+          for (int cq = 0; cq < 12; ++cq) {                                 // fixed trip count: the 12 loads pipeline
+            const bool ok = row_ok && cq >= c_lo && cq < c_hi;
+            const float v = src[ok ? cq * (N + 1) : c_lo * (N + 1)];
+            tsum += ok ? v : 0.f;
+          }
+        }
+      }
+    }
+    if (tid < TBL) atomicAdd(dtable + tid * heads + h, tsum);
+  }
 }
 
 int check(const void *qkv, const float *table, const uint8_t *region, const uint8_t *flags, int B_, int nW, int heads, const char *who)
@@ -272,12 +332,20 @@ int check(const void *qkv, const float *table, const uint8_t *region, const uint
   return PD_OK;
 }
 
-// windows one wavefront walks: enough wavefronts to fill 256 CUs x 4 SIMDs a few times over, at most 16 windows each
-int chunk_of(int B_, int heads)
+// windows one workgroup walks (<= 8), chosen to minimise (rounds of workgroups over the 256 CUs) x (windows + the
+// per-workgroup fixed cost in window units: table staging, and in the backward the table-gradient reduction, which costs
+// about as much as one window)
+int chunk_of(int B_, int heads, float fixed_cost, int wgs_per_cu)
 {
-  const int64_t units = (int64_t)B_ * heads;
-  int chunk = (int)(units / 8192);
-  return chunk < 1 ? 1 : (chunk > 16 ? 16 : chunk);
+  int best = 1;
+  float best_cost = 1e30f;
+  for (int chunk = 1; chunk <= 8; ++chunk) {
+    const int64_t wgs = (int64_t)heads * ((B_ + chunk - 1) / chunk);
+    const int64_t rounds = (wgs + 256 * wgs_per_cu - 1) / (256 * wgs_per_cu);
+    const float cost = rounds * (chunk + fixed_cost);
+    if (cost < best_cost) { best_cost = cost; best = chunk; }
+  }
+  return best;
 }
 }  // namespace
 
@@ -287,11 +355,11 @@ extern "C" int pd_window_attn_fwd_w12(const void *qkv, const float *table, const
   int rc = check(qkv, table, region, win_flags, B_, nW, heads, "pd_window_attn_fwd_w12");
   if (rc || B_ == 0) return rc;
   if (!out || !lse) return pd_set_error(PD_ERR_INVALID_ARG, "pd_window_attn_fwd_w12: null output");
-  const int chunk = chunk_of(B_, heads);
+  const int chunk = chunk_of(B_, heads, 0.2f, 2);
   const dim3 grid((B_ + chunk - 1) / chunk, heads);
   hipStream_t s = (hipStream_t)stream_;
-  if (region) hipLaunchKernelGGL(wattn_fwd<true>, grid, dim3(64), 0, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk);
-  else hipLaunchKernelGGL(wattn_fwd<false>, grid, dim3(64), 0, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk);
+  if (region) hipLaunchKernelGGL(wattn_fwd<true>, grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk);
+  else hipLaunchKernelGGL(wattn_fwd<false>, grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk);
   return pd_check_launch("pd_window_attn_fwd_w12");
 }
 
@@ -304,10 +372,11 @@ extern "C" int pd_window_attn_bwd_w12(const void *qkv, const float *table, const
   if (!out || !d_out || !lse || !dqkv || !dtable) return pd_set_error(PD_ERR_INVALID_ARG, "pd_window_attn_bwd_w12: null pointer");
   if ((((uintptr_t)out | (uintptr_t)d_out | (uintptr_t)dqkv) & 15) != 0)
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_window_attn_bwd_w12: out / d_out / dqkv must be 16-byte aligned");
-  const int chunk = chunk_of(B_, heads);
+  const int chunk = chunk_of(B_, heads, 1.0f, 1);
   const dim3 grid((B_ + chunk - 1) / chunk, heads);
   hipStream_t s = (hipStream_t)stream_;
-  if (region) hipLaunchKernelGGL(wattn_bwd<true>, grid, dim3(64), 0, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk);
-  else hipLaunchKernelGGL(wattn_bwd<false>, grid, dim3(64), 0, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk);
+  if (g_pd_dbg_wattn & 1) hipLaunchKernelGGL((wattn_bwd<false, 1>), grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn);
+  else if (region) hipLaunchKernelGGL((wattn_bwd<true, 0>), grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn);
+  else hipLaunchKernelGGL((wattn_bwd<false, 0>), grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn);
   return pd_check_launch("pd_window_attn_bwd_w12");
 }

@@ -37,4 +37,4 @@ if len(sys.argv) > 3:
         for i in range(2):
             step(batches[i % 2])
         torch.cuda.synchronize()
-    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=90))
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=70, max_name_column_width=90))
