@@ -23,7 +23,8 @@ _MASKFORMER2 = {
     "MODEL.SWIN": dict(PRETRAIN_IMG_SIZE=224, PATCH_SIZE=4, EMBED_DIM=96, DEPTHS=[2, 2, 6, 2], NUM_HEADS=[3, 6, 12, 24],
                        WINDOW_SIZE=7, MLP_RATIO=4.0, QKV_BIAS=True, QK_SCALE=None, DROP_RATE=0.0, ATTN_DROP_RATE=0.0,
                        DROP_PATH_RATE=0.3, APE=False, PATCH_NORM=True, OUT_FEATURES=["res2", "res3", "res4", "res5"],
-                       USE_CHECKPOINT=False),
+                       USE_CHECKPOINT=False,
+                       FP8_GEMM=False, FP8_MIN_K=384),   # ours (BASELINE config 5): fp8 qkv / proj / MLP GEMMs, functions/fp8.py
 }
 
 _WANDB = {"WANDB": dict(DISABLE_WANDB=False, GROUP=None, PROJECT="", VIS_PERIOD_TRAIN=200, VIS_PERIOD_TEST=20,

@@ -13,10 +13,22 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 from torch import nn
 
+from ...functions import fp8
 from ...functions import window_attention as wattn
 from ...functions.rowwise import add_layer_norm, supports_width
 
 from ...compat import BACKBONE_REGISTRY, ShapeSpec
+
+
+# BASELINE config 5 ("fp8 MFMA GEMMs"): D2SwinTransformer sets these from MODEL.SWIN.FP8_GEMM / FP8_MIN_K; the qkv / proj /
+# MLP Linears with in_features >= FP8_MIN_K then run as fp8 GEMMs (functions/fp8.py) while autocast is on
+FP8 = {"enabled": False, "min_k": 384}
+
+
+def _linear(mod, x):
+    if FP8["enabled"] and torch.is_autocast_enabled() and fp8.supported(x, mod.weight, FP8["min_k"]):
+        return fp8.linear(x, mod.weight, mod.bias)
+    return mod(x)
 
 
 def _trunc_normal_(t, std=0.02):
@@ -47,7 +59,7 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
-        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+        return self.drop(_linear(self.fc2, self.drop(self.act(_linear(self.fc1, x)))))
 
 
 def window_partition(x, window_size):
@@ -106,11 +118,11 @@ class WindowAttention(nn.Module):
         labels (functions/window_attention.shifted_window_regions) for the fused kernel."""
         B_, N, C = x.shape
         h = self.num_heads
-        qkv = self.qkv(x)
+        qkv = _linear(self.qkv, x)
         p = self.attn_drop.p if self.training else 0.0
         if wattn.supported(qkv, self.window_size, h, p) and (mask is None) == (regions is None):
             out = wattn.window_attention(qkv, self.relative_position_bias_table, regions, self.scale, n_windows)
-            return self.proj_drop(self.proj(out))
+            return self.proj_drop(_linear(self.proj, out))
         qkv = qkv.reshape(B_, N, 3, h, C // h).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         add = self.bias().unsqueeze(0)                                                  # [1,h,N,N]
@@ -118,7 +130,7 @@ class WindowAttention(nn.Module):
             nW = mask.shape[0]
             add = (add + mask.unsqueeze(1)).unsqueeze(0).expand(B_ // nW, -1, -1, -1, -1).reshape(B_, h, N, N)
         out = F.scaled_dot_product_attention(q, k, v, attn_mask=add.to(q.dtype), dropout_p=p, scale=self.scale)
-        return self.proj_drop(self.proj(out.transpose(1, 2).reshape(B_, N, C)))
+        return self.proj_drop(_linear(self.proj, out.transpose(1, 2).reshape(B_, N, C)))
 
 
 def _layer_norm(norm, x):
@@ -372,6 +384,7 @@ class D2SwinTransformer(SwinTransformer):
         super().__init__(s.PRETRAIN_IMG_SIZE, s.PATCH_SIZE, 3, s.EMBED_DIM, list(s.DEPTHS), list(s.NUM_HEADS),
                          s.WINDOW_SIZE, s.MLP_RATIO, s.QKV_BIAS, s.QK_SCALE, s.DROP_RATE, s.ATTN_DROP_RATE,
                          s.DROP_PATH_RATE, nn.LayerNorm, s.APE, s.PATCH_NORM, use_checkpoint=s.USE_CHECKPOINT)
+        FP8["enabled"], FP8["min_k"] = bool(s.get("FP8_GEMM", False)), int(s.get("FP8_MIN_K", 384))
         self._out_features = s.OUT_FEATURES
         self._out_feature_strides = {"res2": 4, "res3": 8, "res4": 16, "res5": 32}
         self._out_feature_channels = {f"res{i + 2}": self.num_features[i] for i in range(4)}

@@ -15,7 +15,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 name = os.environ.get("PD_CONFIG", "swinb")          # swinb = config 3, swinl (+ size 1280) = config 5
 extra = os.environ.get("PD_OPTS", "").split()
 torch.backends.cudnn.benchmark = True
-cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd", "configs", "part_distillation", name + "_mask2former.yaml"), ["INPUT.IMAGE_SIZE", str(size)] + extra)
+cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd", "configs", "part_distillation", (name if name.endswith("fp8") else name + "_mask2former") + ".yaml"), ["INPUT.IMAGE_SIZE", str(size)] + extra)
 torch.manual_seed(0)
 step = TrainStep(cfg)
 batches = [make_batch(2, size, seed=1234 + 1000 * i, device="cuda", part_distillation=True) for i in range(2)]
