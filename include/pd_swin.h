@@ -1,0 +1,44 @@
+/*
+ * pd_swin.h — C-ABI of the token-row kernels of the fused Swin block of libpd_hip.so.
+ *
+ * A Swin block is  x' = x + DropPath(proj(W-MSA(window_partition(shift(pad(LN1(x)))))));  out = x' + DropPath(MLP(LN2(x')))
+ *   reference modeling/backbone/swin.py:239-299 (SwinTransformerBlock.forward), window_partition / reverse :73-100,
+ *   F.pad :254-258, torch.roll :261-266, 276-289, DropPath :35-51.
+ * pad + roll + window_partition (and their inverses) are a fixed permutation of token rows plus zero rows, and the
+ * residual adds / DropPath scales are row-wise, so the whole glue between the GEMMs of a block is two calls of ONE
+ * kernel each way:
+ *
+ *   pd_swin_ln_fwd    s[i] = x[i] + rscale[img] * r[rrow(i)]                (skipped when r == NULL: s = x)
+ *                     y[yrow(i)] = bf16(LayerNorm(s[i]) * gamma + beta),  mean / rstd[i] saved;  y[zero rows] = 0
+ *   pd_swin_ln_bwd    ds[i] = dsup[i] + LayerNorm'(dy[yrow(i)]);  dr[rrow(i)] = bf16(rscale[img] * ds[i]);  dr[zero rows] = 0
+ *                     dgamma / dbeta += column sums (atomics into fp32 [C]: the caller zero-fills)
+ *
+ * Rows i = img * L + t (t < L tokens of an image).  A row map (int32 [L], shared by the images) sends token t to a row
+ * of a tensor with `rows_per_image` rows per image: yrow(i) = img * y_rows + ymap[t]; NULL = identity (then *_rows = L).
+ * LN1 of a block: y window-major (ymap = token -> window slot, zero rows = the padded slots), r = the previous block's
+ * MLP output (identity map).  LN2: r = the proj output, window-major (rmap = token -> slot), y token-major.
+ * x, s, dsup, ds: fp32 [R, C];  r, y, dy, dr: bf16;  C % 64 == 0, C <= 1536 (every Swin-T/S/B/L stage width);
+ * rscale: fp32 [images] (DropPath keep mask / keep_prob) or NULL = 1.  `stream` = hipStream_t; returns 0 or PD_ERR_*.
+ */
+#ifndef PD_SWIN_H
+#define PD_SWIN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int pd_swin_ln_fwd(const float *x, const void *r, const int32_t *rmap, int r_rows, const float *rscale, const float *gamma,
+                   const float *beta, float eps, float *s, void *y, const int32_t *ymap, int y_rows, const int32_t *zero_rows,
+                   int n_zero, float *mean, float *rstd, int images, int L, int C, void *stream);
+
+int pd_swin_ln_bwd(const void *dy, const int32_t *ymap, int y_rows, const float *dsup, const float *s, const float *mean,
+                   const float *rstd, const float *gamma, float *ds, void *dr, const int32_t *rmap, int r_rows,
+                   const float *rscale, const int32_t *zero_rows, int n_zero, float *dgamma, float *dbeta, int images, int L,
+                   int C, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PD_SWIN_H */

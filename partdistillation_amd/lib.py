@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpd_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -63,6 +63,10 @@ SIGNATURES = {
     "pd_window_attn_bwd_w12": (_c_int, [_c_vp] * 9 + [_c_int] * 3 + [ctypes.c_float, _c_vp]),
     "pd_fp8_amax": (_c_int, [_c_vp, ctypes.c_int64, _c_int, _c_vp, _c_vp]),
     "pd_fp8_quantize": (_c_int, [_c_vp, ctypes.c_int64, _c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_vp]),
+    "pd_swin_ln_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_int, _c_vp,
+                                _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
+    "pd_swin_ln_bwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp,
+                                _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_abi_version": (_c_int, []),
     "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),
