@@ -26,7 +26,10 @@ __device__ __forceinline__ float wave_sum(float v)
   return v;
 }
 
-constexpr int WAVES = 4;   // rows per workgroup pass
+constexpr int WAVES = 4;   // rows per workgroup pass (forward)
+// waves per workgroup in the backward (their column sums meet in LDS before the atomics): 8, or 4 where 8 copies of the
+// two fp32 [C] sums would not fit the 64 KB of static LDS
+template <int E> struct BwdWaves { static constexpr int value = E >= 12 ? 4 : 8; };
 
 template <int E>
 __global__ __launch_bounds__(64 * WAVES) void ln_fwd(const float *__restrict__ x, const bf16_t *__restrict__ r,
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(64 * WAVES) void ln_fwd(const float *__restrict__ x
 }
 
 template <int E>
-__global__ __launch_bounds__(64 * WAVES) void ln_bwd(const bf16_t *__restrict__ dy, const int32_t *__restrict__ ymap, int y_rows,
+__global__ __launch_bounds__(64 * BwdWaves<E>::value) void ln_bwd(const bf16_t *__restrict__ dy, const int32_t *__restrict__ ymap, int y_rows,
                                                      const float *__restrict__ dsup, const float *__restrict__ s,
                                                      const float *__restrict__ mean, const float *__restrict__ rstd,
                                                      const float *__restrict__ gamma, float *__restrict__ ds, bf16_t *__restrict__ dr,
@@ -84,11 +87,11 @@ __global__ __launch_bounds__(64 * WAVES) void ln_bwd(const bf16_t *__restrict__ 
                                                      const int32_t *__restrict__ zero_rows, int n_zero, float *__restrict__ dgamma,
                                                      float *__restrict__ dbeta, int images, int L, int rows_per_wave)
 {
-  constexpr int C = 64 * E;
-  __shared__ float red[2][WAVES][C];
+  constexpr int C = 64 * E, BWAVES = BwdWaves<E>::value;
+  __shared__ float red[2][BWAVES][C];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t R = (int64_t)images * L;
-  const int64_t first = ((int64_t)blockIdx.x * WAVES + wv) * rows_per_wave;
+  const int64_t first = ((int64_t)blockIdx.x * BWAVES + wv) * rows_per_wave;
   float gm[E], ag[E], ab[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) { gm[e] = gamma[e * 64 + lane]; ag[e] = 0.f; ab[e] = 0.f; }
@@ -134,13 +137,24 @@ __global__ __launch_bounds__(64 * WAVES) void ln_bwd(const bf16_t *__restrict__ 
 #pragma unroll
   for (int e = 0; e < E; ++e) { red[0][wv][e * 64 + lane] = ag[e]; red[1][wv][e * 64 + lane] = ab[e]; }
   __syncthreads();
-  for (int cidx = threadIdx.x; cidx < C; cidx += 64 * WAVES) {
+  for (int cidx = threadIdx.x; cidx < C; cidx += 64 * BWAVES) {
     float ga = 0.f, ba = 0.f;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) { ga += red[0][w][cidx]; ba += red[1][w][cidx]; }
+    for (int w = 0; w < BWAVES; ++w) { ga += red[0][w][cidx]; ba += red[1][w][cidx]; }
     atomicAdd(dgamma + cidx, ga);
     atomicAdd(dbeta + cidx, ba);
   }
+}
+
+template <int E, typename... Args>
+void launch_bwd(int64_t rows, hipStream_t st, Args... args)
+{
+  // rows per wave: ~512 workgroups; every workgroup ends with 2*C atomics, so few, fat workgroups
+  constexpr int BW = BwdWaves<E>::value;
+  int rpw = (int)((rows + 512 * BW - 1) / (512 * BW));
+  rpw = rpw < 2 ? 2 : (rpw > 32 ? 32 : rpw);
+  const dim3 g((unsigned)((rows + (int64_t)BW * rpw - 1) / ((int64_t)BW * rpw))), b(64 * BW);
+  hipLaunchKernelGGL((ln_bwd<E>), g, b, 0, st, args..., rpw);
 }
 
 int check(int images, int L, int C, const char *who)
@@ -196,12 +210,7 @@ extern "C" int pd_swin_ln_bwd(const void *dy, const int32_t *ymap, int y_rows, c
   if (!dy || !s || !mean || !rstd || !gamma || !ds || !dgamma || !dbeta || (n_zero > 0 && !zero_rows) || n_zero < 0)
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_swin_ln_bwd: null pointer");
   const int64_t rows = R + (dr ? (int64_t)images * n_zero : 0);
-  // rows per wave: enough workgroups to fill the chip, few enough that the per-workgroup column-sum atomics stay small
-  int rpw = (int)(rows / (256 * 8 * WAVES));
-  rpw = rpw < 1 ? 1 : (rpw > 16 ? 16 : rpw);
-  const dim3 g((unsigned)((rows + (int64_t)WAVES * rpw - 1) / ((int64_t)WAVES * rpw))), b(64 * WAVES);
-  hipStream_t st = (hipStream_t)stream_;
-  E_SWITCH(C, hipLaunchKernelGGL((ln_bwd<E>), g, b, 0, st, (const bf16_t *)dy, ymap, y_rows, dsup, s, mean, rstd, gamma, ds,
-                                 (bf16_t *)dr, rmap, r_rows, rscale, zero_rows, n_zero, dgamma, dbeta, images, L, rpw));
+  E_SWITCH(C, (launch_bwd<E>(rows, (hipStream_t)stream_, (const bf16_t *)dy, ymap, y_rows, dsup, s, mean, rstd, gamma, ds,
+                             (bf16_t *)dr, rmap, r_rows, rscale, zero_rows, n_zero, dgamma, dbeta, images, L)));
   return pd_check_launch("pd_swin_ln_bwd");
 }

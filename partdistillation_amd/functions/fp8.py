@@ -63,16 +63,16 @@ class Fp8Linear(Function):
             wtq, wt_inv = quantize(weight.detach().t().contiguous(), E4M3)        # [K, N]: the weight is small
             dx = _mm(gq, g_inv, wtq, wt_inv).view(ctx.shape)
         if ctx.needs_input_grad[1]:
-            dw = torch.mm(dy2.t(), x2).float()
+            dw = torch.mm(dy2.t(), x2).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.float().sum(0)
+            db = dy2.sum(0, dtype=torch.float32)
         return dx, dw, db
 
 
 def supported(x, weight, min_k):
     rows = x.numel() // x.shape[-1]
     return (x.is_cuda and weight.shape[1] >= min_k and weight.shape[0] % 16 == 0 and weight.shape[1] % 16 == 0
-            and rows % 16 == 0 and weight.dtype == torch.float32)
+            and rows % 16 == 0 and weight.dtype in (torch.float32, torch.bfloat16))
 
 
 def linear(x, weight, bias):

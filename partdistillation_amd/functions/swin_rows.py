@@ -1,0 +1,42 @@
+"""Token-row kernels of the fused Swin block (pd_swin_ln_fwd / pd_swin_ln_bwd, include/pd_swin.h): residual add with a
+DropPath scale + LayerNorm, reading / writing through row maps (window partition of the padded, shifted grid)."""
+import torch
+
+from .. import lib as _lib
+
+WIDTHS = tuple(64 * e for e in (1, 2, 3, 4, 6, 8, 12, 16, 24))
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def ln_fwd(x, r, rmap, r_rows, rscale, gamma, beta, eps, ymap, y_rows, zero_rows, images, L):
+    """x fp32 [images*L, C]; r bf16 rows (or None) -> (s fp32 [images*L, C] (x itself when r is None), y bf16
+    [images*y_rows, C], mean, rstd)"""
+    if not x.is_cuda:
+        raise RuntimeError("pd_swin_ln_fwd runs on the GPU only (no CPU fallback in partdistillation_amd)")
+    C = x.shape[-1]
+    assert x.dtype == torch.float32 and x.is_contiguous() and gamma.dtype == torch.float32 and (r is None or (r.dtype == torch.bfloat16 and r.is_contiguous()))
+    s = torch.empty_like(x) if r is not None else x
+    y = torch.empty((images * y_rows, C), dtype=torch.bfloat16, device=x.device)
+    stats = torch.empty((2, images * L), dtype=torch.float32, device=x.device)
+    nz = 0 if zero_rows is None else zero_rows.numel()
+    _lib.check(_lib.load().pd_swin_ln_fwd(x.data_ptr(), _p(r), _p(rmap), r_rows, _p(rscale), gamma.data_ptr(), beta.data_ptr(),
+                                          float(eps), s.data_ptr(), y.data_ptr(), _p(ymap), y_rows, _p(zero_rows), nz,
+                                          stats[0].data_ptr(), stats[1].data_ptr(), images, L, C, _lib.current_stream()))
+    return s, y, stats
+
+
+def ln_bwd(dy, ymap, y_rows, dsup, s, stats, gamma, want_dr, rmap, r_rows, rscale, zero_rows, dgamma, dbeta, images, L):
+    """-> (ds fp32 [images*L, C], dr bf16 [images*r_rows, C] or None); dgamma / dbeta (fp32 [C]) are accumulated into"""
+    C = s.shape[-1]
+    assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and (dsup is None or (dsup.dtype == torch.float32 and dsup.is_contiguous()))
+    ds = torch.empty_like(s)
+    dr = torch.empty((images * r_rows, C), dtype=torch.bfloat16, device=s.device) if want_dr else None
+    nz = 0 if (zero_rows is None or not want_dr) else zero_rows.numel()
+    _lib.check(_lib.load().pd_swin_ln_bwd(dy.data_ptr(), _p(ymap), y_rows, _p(dsup), s.data_ptr(), stats[0].data_ptr(),
+                                          stats[1].data_ptr(), gamma.data_ptr(), ds.data_ptr(), _p(dr), _p(rmap), r_rows,
+                                          _p(rscale), _p(zero_rows) if nz else None, nz, dgamma.data_ptr(), dbeta.data_ptr(),
+                                          images, L, C, _lib.current_stream()))
+    return ds, dr

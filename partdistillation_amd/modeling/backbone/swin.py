@@ -23,6 +23,7 @@ from ...compat import BACKBONE_REGISTRY, ShapeSpec
 # BASELINE config 5 ("fp8 MFMA GEMMs"): D2SwinTransformer sets these from MODEL.SWIN.FP8_GEMM / FP8_MIN_K; the qkv / proj /
 # MLP Linears with in_features >= FP8_MIN_K then run as fp8 GEMMs (functions/fp8.py) while autocast is on
 FP8 = {"enabled": False, "min_k": 384}
+FUSED_STAGE = True          # modeling/backbone/swin_core.py where it applies (tests switch it off to compare the two paths)
 
 
 def _linear(mod, x):
@@ -283,11 +284,15 @@ class BasicLayer(nn.Module):
         self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
 
     def forward(self, x, H, W):
-        attn_mask = shifted_window_mask(H, W, self.window_size, self.shift_size, x.device)
-        for blk in self.blocks:
-            blk.H, blk.W = H, W
-            g = window_gather_index(H, W, self.window_size, blk.shift_size, x.device)
-            x = checkpoint.checkpoint(blk, x, attn_mask, g, use_reentrant=False) if self.use_checkpoint else blk(x, attn_mask, g)
+        from . import swin_core
+        if FUSED_STAGE and not FP8["enabled"] and swin_core.supported(self, x):
+            x = swin_core.run_stage(self, x, H, W)                        # the whole stage as one autograd node
+        else:
+            attn_mask = shifted_window_mask(H, W, self.window_size, self.shift_size, x.device)
+            for blk in self.blocks:
+                blk.H, blk.W = H, W
+                g = window_gather_index(H, W, self.window_size, blk.shift_size, x.device)
+                x = checkpoint.checkpoint(blk, x, attn_mask, g, use_reentrant=False) if self.use_checkpoint else blk(x, attn_mask, g)
         if self.downsample is not None:
             return x, H, W, self.downsample(x, H, W), (H + 1) // 2, (W + 1) // 2
         return x, H, W, x, H, W

@@ -1,0 +1,160 @@
+"""One Swin stage (all SwinTransformerBlocks of a BasicLayer, reference modeling/backbone/swin.py:239-299, 446-452) as ONE
+autograd node with a hand-written backward, in the style of functions/decoder_core.py / encoder_core.py.
+
+Per block the forward is 8 launches and the backward 17: the glue between the GEMMs — residual adds, DropPath scales,
+both LayerNorms, F.pad + torch.roll + window_partition and their inverses, the bf16 casts — is the row kernel of
+include/pd_swin.h (once before each attention, once before each MLP), the attention is include/pd_window_attention.h,
+the Linears are library bf16 GEMMs.  The MLP output of block k is never added on its own: it rides into block k+1's
+first row kernel as the pending residual.  Same arithmetic as the module-by-module path under bf16 autocast (fp32
+residual stream, fp32 LayerNorm statistics, bf16 GEMM operands, exact-erf GELU)."""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from ...functions import swin_rows as rows
+from ...functions import window_attention as wattn
+
+N_BLOCK = 13            # norm1.w, norm1.b, qkv.w, qkv.b, table, proj.w, proj.b, norm2.w, norm2.b, fc1.w, fc1.b, fc2.w, fc2.b
+_MAPS = {}
+
+
+def window_maps(H, W, shift, device):
+    """int32 row maps of the padded, cyclically shifted 12 x 12 window partition: token -> window-major slot, the padded
+    slots (zero rows), slots per image, windows per image"""
+    from .swin import window_gather_index
+    key = (H, W, shift, str(device))
+    if key not in _MAPS:
+        win, inv, n_win, _ = window_gather_index(H, W, wattn.WINDOW, shift, device)
+        zero = (win == H * W).nonzero().flatten().to(torch.int32)
+        _MAPS[key] = (inv.to(torch.int32).contiguous(), zero.contiguous() if zero.numel() else None, int(win.numel()), n_win)
+    return _MAPS[key]
+
+
+def _bf(t):
+    return t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)
+
+
+class SwinStage(Function):
+    """x fp32 [B, L, C] -> fp32 [B, L, C].  spec = dict(H, W, heads, shifts [depth], scale, eps, dp = None | fp32
+    [depth, 2, B] DropPath scales (keep mask / keep_prob))."""
+
+    @staticmethod
+    def forward(ctx, x, spec, *params):
+        if not x.is_cuda:
+            raise RuntimeError("the fused Swin stage runs on the GPU only (no CPU fallback in partdistillation_amd)")
+        B, L, C = x.shape
+        H, W, heads, dp = spec["H"], spec["W"], spec["heads"], spec["dp"]
+        depth = len(params) // N_BLOCK
+        cur, r, rscale = x.contiguous().view(B * L, C), None, None
+        saved = []
+        for k in range(depth):
+            n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = params[k * N_BLOCK:(k + 1) * N_BLOCK]
+            shift = spec["shifts"][k]
+            ymap, zero, S, nW = window_maps(H, W, shift, x.device)
+            regions = wattn.shifted_window_regions(H, W, shift, x.device) if shift > 0 else None
+            s1, y1, st1 = rows.ln_fwd(cur, r, None, L, rscale, n1w, n1b, spec["eps"], ymap, S, zero, B, L)
+            qkv = torch.addmm(_bf(qb), y1, _bf(qw).t())
+            ao, lse = wattn.fwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table.contiguous(), regions, spec["scale"], nW)
+            po = torch.addmm(_bf(pb), ao.view(-1, C), _bf(pw).t())
+            sc1 = dp[k, 0] if dp is not None else None
+            s2, y2, st2 = rows.ln_fwd(s1, po, ymap, S, sc1, n2w, n2b, spec["eps"], None, L, None, B, L)
+            h = torch.addmm(_bf(f1b), y2, _bf(f1w).t())
+            a = F.gelu(h)
+            f = torch.addmm(_bf(f2b), a, _bf(f2w).t())
+            saved += [s1, y1, st1, qkv, ao, lse, s2, y2, st2, h, a]
+            cur, r, rscale = s2, f, (dp[k, 1] if dp is not None else None)
+        out = r.view(B, L, C).float()
+        if rscale is not None:
+            out = out * rscale.view(B, 1, 1)
+        out = out.add_(cur.view(B, L, C))
+        ctx.spec, ctx.depth, ctx.shape = spec, depth, (B, L, C)
+        ctx.save_for_backward(*params, *saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        spec, depth, (B, L, C) = ctx.spec, ctx.depth, ctx.shape
+        H, W, dp = spec["H"], spec["W"], spec["dp"]
+        params, saved = ctx.saved_tensors[:depth * N_BLOCK], ctx.saved_tensors[depth * N_BLOCK:]
+        dev = dout.device
+        dsup = dout.contiguous().view(B * L, C)
+        last = dp[depth - 1, 1] if dp is not None else None
+        df = (dsup.view(B, L, C) * last.view(B, 1, 1) if last is not None else dsup).to(torch.bfloat16).view(B * L, C)
+        norm_g = torch.zeros((depth, 4, C), dtype=torch.float32, device=dev)       # dgamma1, dbeta1, dgamma2, dbeta2
+        grads = [None] * (depth * N_BLOCK)
+
+        def like(g, p):
+            return g if g.dtype == p.dtype else g.to(p.dtype)
+
+        for k in reversed(range(depth)):
+            n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = params[k * N_BLOCK:(k + 1) * N_BLOCK]
+            s1, y1, st1, qkv, ao, lse, s2, y2, st2, h, a = saved[k * 11:(k + 1) * 11]
+            shift = spec["shifts"][k]
+            ymap, zero, S, nW = window_maps(H, W, shift, dev)
+            regions = wattn.shifted_window_regions(H, W, shift, dev) if shift > 0 else None
+            g = grads[k * N_BLOCK:(k + 1) * N_BLOCK]
+            # MLP
+            da = torch.mm(df, _bf(f2w))
+            g[11], g[12] = like(torch.mm(df.t(), a), f2w), like(df.sum(0, dtype=torch.float32), f2b)
+            dh = torch.ops.aten.gelu_backward(da, h)
+            dy2 = torch.mm(dh, _bf(f1w))
+            g[9], g[10] = like(torch.mm(dh.t(), y2), f1w), like(dh.sum(0, dtype=torch.float32), f1b)
+            # LayerNorm 2 + the residual it sits on; gradient of the (window-major) proj output rides out as `dr`
+            sc1 = dp[k, 0] if dp is not None else None
+            ds2, dpo = rows.ln_bwd(dy2, None, L, dsup, s2, st2, n2w, True, ymap, S, sc1, zero, norm_g[k, 2], norm_g[k, 3], B, L)
+            dao = torch.mm(dpo, _bf(pw))
+            g[5], g[6] = like(torch.mm(dpo.t(), ao.view(-1, C)), pw), like(dpo.sum(0, dtype=torch.float32), pb)
+            dqkv, dtable = wattn.bwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table.contiguous(), regions, ao,
+                                         dao.view(B * nW, wattn.TOKENS, C), lse, spec["scale"], nW)
+            g[4] = dtable
+            dqkv = dqkv.view(-1, 3 * C)
+            dy1 = torch.mm(dqkv, _bf(qw))
+            g[2], g[3] = like(torch.mm(dqkv.t(), y1), qw), like(dqkv.sum(0, dtype=torch.float32), qb)
+            # LayerNorm 1; for k > 0 its input was (block k-1 stream + DropPath * MLP output): `dr` = that MLP's output gradient
+            prev = (dp[k - 1, 1] if dp is not None else None) if k > 0 else None
+            ds1, df = rows.ln_bwd(dy1, ymap, S, ds2, s1, st1, n1w, k > 0, None, L, prev, None, norm_g[k, 0], norm_g[k, 1], B, L)
+            dsup = ds1
+            g[0], g[1], g[7], g[8] = norm_g[k, 0], norm_g[k, 1], norm_g[k, 2], norm_g[k, 3]
+            grads[k * N_BLOCK:(k + 1) * N_BLOCK] = g
+        return (dsup.view(B, L, C), None, *grads)
+
+
+def block_params(blk):
+    return (blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.relative_position_bias_table,
+            blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+            blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+
+
+def supported(layer, x):
+    """bf16-autocast GPU run of a standard window-12, head_dim-32 stage (Swin-B / Swin-L as shipped) without attention /
+    projection / MLP dropout and without activation checkpointing; anything else takes the module-by-module path."""
+    import torch.nn as nn
+    b0 = layer.blocks[0]
+    C = x.shape[-1]
+    ok = (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and torch.is_autocast_enabled()
+          and torch.get_autocast_dtype("cuda") == torch.bfloat16 and not layer.use_checkpoint
+          and layer.window_size == wattn.WINDOW and C == b0.num_heads * wattn.HEAD_DIM and C in rows.WIDTHS)
+    for blk in layer.blocks:
+        ok = ok and isinstance(blk.norm1, nn.LayerNorm) and isinstance(blk.mlp.act, nn.GELU) and blk.attn.qkv.bias is not None
+        ok = ok and blk.attn.attn_drop.p == 0.0 and blk.attn.proj_drop.p == 0.0 and blk.mlp.drop.p == 0.0
+        ok = ok and getattr(blk.mlp.act, "approximate", "none") == "none" and blk.norm1.eps == b0.norm1.eps == blk.norm2.eps
+    return ok
+
+
+def run_stage(layer, x, H, W):
+    B = x.shape[0]
+    depth = len(layer.blocks)
+    rates = [float(getattr(blk.drop_path, "drop_prob", 0.0) or 0.0) for blk in layer.blocks]
+    dp = None
+    if layer.training and any(r > 0 for r in rates):
+        key = (tuple(rates), str(x.device))
+        if getattr(layer, "_keep_key", None) != key:                      # built once: a host list -> device copy synchronises
+            layer._keep = torch.tensor([1.0 - r for r in rates], dtype=torch.float32, device=x.device).view(depth, 1, 1)
+            layer._keep_key = key
+        dp = (torch.rand((depth, 2, B), device=x.device) + layer._keep).floor_().div_(layer._keep)   # DropPath (:35-51)
+    spec = dict(H=H, W=W, heads=layer.blocks[0].num_heads, shifts=[blk.shift_size for blk in layer.blocks],
+                scale=layer.blocks[0].attn.scale, eps=layer.blocks[0].norm1.eps, dp=dp)
+    params = [p for blk in layer.blocks for p in block_params(blk)]
+    # stages 2-4 receive the bf16 output of PatchMerging's Linear; the module-by-module path (like the reference under AMP)
+    # then keeps a 16-bit residual stream, this one keeps it in fp32 throughout
+    return SwinStage.apply(x.float(), spec, *params)

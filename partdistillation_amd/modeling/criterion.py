@@ -12,6 +12,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..functions.fused import upload_small
+
 from ..utils.misc import (get_uncertain_point_coords_with_randomness, get_world_size, is_dist_avail_and_initialized,
                           nested_tensor_from_tensor_list, point_sample)
 
@@ -112,7 +114,7 @@ class SetCriterion(nn.Module):
             if key not in self._nm_cache:
                 self._nm_cache[key] = torch.tensor(max(count, 1.0), dtype=torch.float, device=device)
             return self._nm_cache[key]
-        n = torch.as_tensor([count], dtype=torch.float, device=device)
+        n = upload_small([count], torch.float, device)                # asynchronous: the host keeps running ahead
         torch.distributed.all_reduce(n)
         return torch.clamp(n / get_world_size(), min=1)[0]
 

@@ -12,6 +12,8 @@ receive an exactly-zero gradient, as the reference's ``outputs.sum()*0`` trick
 import torch
 from torch import nn
 
+from ...functions.fused import upload_small
+
 from ...compat import TRANSFORMER_DECODER_REGISTRY, configurable
 from .mask2former_transformer_decoder import MultiScaleMaskedTransformerDecoder
 
@@ -36,7 +38,7 @@ class PartDistillationTransformerDecoder(MultiScaleMaskedTransformerDecoder):
         targets = mask
         K = self.num_part_classes
         dev = self.class_embed.weight.device
-        cls = torch.as_tensor([int(t["gt_object_class"]) for t in targets], dtype=torch.long, device=dev)
+        cls = upload_small([int(t["gt_object_class"]) for t in targets], torch.long, dev)      # no blocking pageable copy
         rows = cls[:, None] * K + torch.arange(K, device=dev)[None, :]
         last = torch.full((len(targets), 1), self.class_embed.weight.shape[0] - 1, dtype=torch.long, device=dev)
         return torch.cat([rows, last], dim=1)                                   # [B, K+1]

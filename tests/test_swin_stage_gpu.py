@@ -1,0 +1,135 @@
+"""GPU tests of the fused Swin stage: the row kernel (include/pd_swin.h) against torch autograd on the same formula,
+and the whole stage (modeling/backbone/swin_core.py) against the module-by-module path of the same BasicLayer (which is
+pinned to the reference by the swin golden) — same weights, same input, same DropPath masks, bf16 autocast."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, want, frac, what):
+    err = (got.double() - want.double()).abs().max().item()
+    scale = max(want.double().abs().max().item(), 1e-30)
+    assert err <= frac * scale, f"{what}: max abs err {err:.3e} > {frac} * {scale:.3e}"
+
+
+@pytest.mark.parametrize("C", [64, 128, 192, 384, 1024, 1536])
+@pytest.mark.parametrize("mode", ["plain", "ln1", "ln2"])
+def test_row_kernel_matches_torch(C, mode):
+    """plain: y = LN(x).  ln1: pending residual r (identity rows, DropPath scale), y window-major with zero rows.
+    ln2: r window-major through the row map, y token-major."""
+    from partdistillation_amd.functions import swin_rows as rows
+    g = torch.Generator(device="cuda").manual_seed(C + len(mode))
+    B, L, S = 3, 50, 64
+    perm = torch.randperm(S, device="cuda", generator=g)
+    tmap = perm[:L].to(torch.int32).contiguous()                      # token -> slot
+    zero = perm[L:].to(torch.int32).contiguous()                      # padded slots
+    x = torch.randn(B * L, C, device="cuda", generator=g)
+    gamma = torch.randn(C, device="cuda", generator=g)
+    beta = torch.randn(C, device="cuda", generator=g)
+    rscale = torch.tensor([0.0, 1.0 / 0.7, 1.0 / 0.7], device="cuda")
+    r_rows = {"plain": 0, "ln1": L, "ln2": S}[mode]
+    y_rows = S if mode == "ln1" else L
+    r = (torch.randn(B * r_rows, C, device="cuda", generator=g) * 2).to(torch.bfloat16) if mode != "plain" else None
+    dy = torch.randn(B * y_rows, C, device="cuda", generator=g).to(torch.bfloat16)
+    dsup = torch.randn(B * L, C, device="cuda", generator=g)
+    rmap, ymap = (tmap if mode == "ln2" else None), (tmap if mode == "ln1" else None)
+    zy, zr = (zero if mode == "ln1" else None), (zero if mode == "ln2" else None)
+
+    s, y, st = rows.ln_fwd(x, r, rmap, r_rows, rscale if r is not None else None, gamma, beta, 1e-5, ymap, y_rows, zy, B, L)
+    dgm, dbt = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    ds, dr = rows.ln_bwd(dy, ymap, y_rows, dsup, s, st, gamma, r is not None, rmap, r_rows, rscale if r is not None else None,
+                         zr, dgm, dbt, B, L)
+
+    xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    rr = r.float().requires_grad_() if r is not None else None
+    tok = tmap.long()
+    sr = xr.view(B, L, C)
+    if rr is not None:
+        rv = rr.view(B, r_rows, C)
+        rv = rv[:, tok] if mode == "ln2" else rv
+        sr = sr + rscale.view(B, 1, 1) * rv
+    yt = torch.nn.functional.layer_norm(sr, (C,), gr, br, 1e-5)
+    if mode == "ln1":
+        yr = torch.zeros(B, S, C, device="cuda").index_copy(1, tok, yt)
+    else:
+        yr = yt
+    torch.testing.assert_close(s.view(B, L, C), sr.detach(), rtol=1e-6, atol=1e-6)
+    _close(y.view(B, y_rows, C).float(), yr.detach(), 6e-3, "y (bf16 rounding)")
+    if mode == "ln1":
+        assert float(y.view(B, S, C)[:, zero.long()].abs().max()) == 0.0
+    loss = (yr * dy.view(B, y_rows, C).float()).sum() + (sr * dsup.view(B, L, C)).sum()
+    gs = torch.autograd.grad(loss, [xr, gr, br] + ([rr] if rr is not None else []))
+    _close(ds, gs[0], 1e-5, "ds")
+    _close(dgm, gs[1], 1e-4, "dgamma")
+    _close(dbt, gs[2], 1e-4, "dbeta")
+    if rr is not None:
+        _close(dr.float(), gs[3], 6e-3, "dr (bf16 rounding)")
+        if mode == "ln2":
+            assert float(dr.view(B, S, C)[:, zero.long()].abs().max()) == 0.0
+
+
+def test_row_kernel_rejects_unsupported_width():
+    from partdistillation_amd import lib
+    from partdistillation_amd.functions import swin_rows as rows
+    x = torch.zeros(4, 96, device="cuda")
+    with pytest.raises(lib.PdHipError, match="multiple of 64"):
+        rows.ln_fwd(x, None, None, 0, None, torch.ones(96, device="cuda"), torch.zeros(96, device="cuda"), 1e-5, None, 4, None, 1, 4)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        rows.ln_fwd(torch.zeros(4, 64), None, None, 0, None, torch.ones(64), torch.zeros(64), 1e-5, None, 4, None, 1, 4)
+
+
+@pytest.mark.parametrize("dim,heads,H,W,depth,drop", [(64, 2, 30, 26, 2, 0.0), (128, 4, 24, 24, 2, 0.0), (64, 2, 30, 26, 4, 0.4)])
+def test_fused_stage_matches_module_path(dim, heads, H, W, depth, drop):
+    from partdistillation_amd.modeling.backbone import swin, swin_core
+    torch.manual_seed(dim + H)
+    rates = [drop * i / max(depth - 1, 1) for i in range(depth)]
+    layer = swin.BasicLayer(dim=dim, depth=depth, num_heads=heads, window_size=12, drop_path=rates).cuda().train()
+    for blk in layer.blocks:
+        torch.nn.init.normal_(blk.attn.relative_position_bias_table, std=0.5)
+        torch.nn.init.normal_(blk.norm1.weight, 1.0, 0.2)
+        torch.nn.init.normal_(blk.norm2.bias, 0.0, 0.2)
+    B = 2
+    x0 = torch.randn(B, H * W, dim, device="cuda")
+    go = torch.randn(B, H * W, dim, device="cuda")
+    scales = None
+    if drop > 0:
+        keep = torch.tensor([1.0 - r for r in rates], device="cuda").view(depth, 1, 1)
+        scales = (torch.rand(depth, 2, B, device="cuda") + keep).floor() / keep
+        scales[1, 0, 0] = 0.0                                                     # at least one dropped branch
+    res = {}
+    orig_rand, orig_dp = torch.rand, swin.DropPath.forward
+    for fused in (True, False):
+        calls = {"n": 0}
+
+        def dp_forward(self, t):                                                   # module path: the same masks, in call order
+            if self.drop_prob == 0.0:
+                return t
+            k, j = divmod(calls["n"], 2)
+            while rates[k] == 0.0:                                                 # blocks with rate 0 use nn.Identity
+                k += 1
+                calls["n"] += 2
+            calls["n"] += 1
+            return t * scales[k, j].view(B, 1, 1)
+        try:
+            swin.FUSED_STAGE = fused
+            if scales is not None:
+                if fused:
+                    torch.rand = lambda *a, **kw: (scales * torch.tensor([1.0 - r for r in rates], device="cuda").view(depth, 1, 1)
+                                                   + 1.0 - torch.tensor([1.0 - r for r in rates], device="cuda").view(depth, 1, 1)
+                                                   - 1e-3).clamp_min(0.0)
+                else:
+                    swin.DropPath.forward = dp_forward
+            layer.zero_grad()
+            x = x0.clone().requires_grad_()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                assert swin_core.supported(layer, x)
+                y = layer(x, H, W)[0]
+            y.backward(go)
+            res[fused] = (y.detach().float(), x.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()})
+        finally:
+            swin.FUSED_STAGE, torch.rand, swin.DropPath.forward = True, orig_rand, orig_dp
+    _close(res[True][0], res[False][0], 2e-2, "stage output")
+    _close(res[True][1], res[False][1], 3e-2, "input gradient")
+    for k, gr in res[False][2].items():
+        _close(res[True][2][k], gr, 6e-2, "grad " + k)

@@ -10,6 +10,7 @@ from partdistillation_amd.config import setup_cfg
 from partdistillation_amd.engine.synthetic import make_batch
 from partdistillation_amd.engine.trainer import TrainStep
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 384
+
 cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd", "configs", "part_distillation", "swinb_mask2former.yaml"), ["INPUT.IMAGE_SIZE", str(size)])
 torch.manual_seed(0)
 step = TrainStep(cfg)
