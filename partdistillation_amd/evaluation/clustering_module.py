@@ -1,0 +1,55 @@
+"""``ClusteringModule`` (reference part_distillation/evaluation/clustering_module.py:17-80): collects the per-proposal
+features PartRankingModel returns in mode "cluster", and turns them into K-means centroids per object class.
+
+The reference moves every feature to the CPU, gathers them on rank 0 and runs sklearn KMeans(n_clusters, random_state=0)
+per class there.  Here the features stay on the device and each class is clustered by functions/kmeans.py (sklearn's Lloyd
+semantics: centred data, variance-scaled tolerance, first-minimum assignment; k-means++ seeding from a seeded device
+generator — numpy's RandomState stream is not reproduced, `init` injects centres for parity tests).  With several ranks
+the (feature, label) lists are exchanged with all_gather_object and every rank clusters the same data (deterministic, so
+no broadcast of the result is needed)."""
+import copy
+
+import torch
+
+from ..functions import kmeans as _kmeans
+
+
+class ClusteringModule:
+    def __init__(self, distributed=True, num_clusters=8, seed=0):
+        self._distributed, self.num_clusters, self.seed = distributed, num_clusters, seed
+        self.init = None                         # test hook: callable(class id, features) -> [num_clusters, C] initial centres
+        self.reset()
+
+    def reset(self):
+        self._proposal_features, self._class_labels_list = [], []
+
+    def process(self, inputs, outputs):
+        for out in outputs:
+            self._proposal_features.append(out["proposal_features"])
+            self._class_labels_list.append(out["gt_label"])
+
+    def evaluate(self):
+        feats, labels = self._proposal_features, self._class_labels_list
+        if self._distributed and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            dev = feats[0].device if feats else torch.device("cpu")
+            gathered = [None] * torch.distributed.get_world_size()
+            torch.distributed.all_gather_object(gathered, ([f.cpu() for f in feats], [l.cpu() for l in labels]))
+            feats = [f.to(dev) for g in gathered for f in g[0]]
+            labels = [l.to(dev) for g in gathered for l in g[1]]
+        feats = torch.cat(feats, dim=0).float()
+        labels = torch.cat([l.to(feats.device) for l in labels], dim=0)
+        out = {}
+        for cid in labels.unique().tolist():
+            x = feats[labels == cid]
+            if x.shape[0] > self.num_clusters:
+                out[int(cid)] = self._get_cluster_centroids(x, int(cid))
+            else:                                 # too few proposals of this class (reference :66-67)
+                out[int(cid)] = torch.randn(self.num_clusters, x.shape[1], device=x.device)
+        return copy.deepcopy(out)
+
+    def _get_cluster_centroids(self, x, cid):
+        gen = torch.Generator(device=x.device).manual_seed(self.seed)
+        init = self.init(cid, x) if self.init is not None else None
+        centres, _, _ = _kmeans.kmeans_lloyd(x, self.num_clusters, init=init, generator=gen)
+        return centres.float()

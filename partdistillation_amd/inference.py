@@ -233,3 +233,150 @@ def pd_inference(model, batched_inputs, targets, images, outputs, vis=False):
         gt.gt_masks, gt.gt_classes, gt.pred_masks, gt.pred_classes = tm, tgt["labels"], tm, tgt["labels"]
         results.append({"predictions": r, "gt_instances": gt, "gt_object_label": tgt["gt_object_class"]})
     return results
+
+
+# ================================================================================================ PartRankingModel
+def _rank_unique_assignment(model, masks, scores, feats):
+    """reference part_ranking_model.py:359-401 on the device: per-pixel-unique proposals (queries that won no pixel drop
+    out) or plain thresholding, then the area-ratio / score filters (each applied only if something survives it); the
+    proposal features follow the proposals."""
+    obj_map = masks.max(dim=0)[0] > 0.0
+    if model.use_unique_per_pixel_label_during_clustering:
+        scoremap = (scores[:, None, None] * masks.sigmoid()).argmax(0)
+        ids = (torch.bincount(scoremap.flatten(), minlength=masks.shape[0]) > 0).nonzero().flatten()      # scoremap.unique()
+        new = (scoremap[None] == ids[:, None, None]) & obj_map[None]
+        scores, feats = scores[ids], feats[ids]
+    else:
+        new = masks
+    area = (new if new.dtype == torch.bool else new > 0).flatten(1).sum(1)
+    keep = _filter(area, obj_map.sum(), scores, model.min_pseudo_mask_ratio_1, model.min_pseudo_mask_score_1)
+    new = new[keep]
+    return (new if new.dtype == torch.bool else new > 0), scores[keep], feats[keep]
+
+
+def _rank_match_gt(model, masks, scores, extra, target_mask):
+    """reference :288-299: proposals whose best IoU with a ground-truth part exceeds fg_score_threshold"""
+    iou = mask_iou(masks, target_mask)
+    fg = (iou.topk(1, dim=1)[0] > model.fg_score_threshold).flatten()
+    return masks[fg], scores[fg], extra[fg]
+
+
+def rank_use_classifier(model, features, cid):
+    """reference :441-457: nearest-centroid scores, negative squared L2 up to the |x|^2 term ("l2") or dot product"""
+    if cid not in model.classifier:
+        raise ValueError("class ID {} not in classifier. ({})".format(cid, list(model.classifier.keys())))
+    y = model.classifier[cid]
+    xy = features @ y.t()
+    if model.classifier_metric == "l2":
+        return xy - (features * features).sum(dim=1)[:, None] - (y * y).sum(dim=1)[None, :]
+    if model.classifier_metric == "dot":
+        return xy
+    raise ValueError(model.classifier_metric)
+
+
+def rank_instance_inference_with_proposal_feats(model, feats, mask_cls, mask_pred, target_object_mask, vis=False):
+    """reference :517-533 (mode "cluster")"""
+    unique = model.use_unique_per_pixel_label_during_clustering
+    topk = model.wandb_vis_topk if vis and not unique else model.test_topk_per_image
+    scores = mask_cls.float().softmax(-1)[:, :-1].flatten()
+    scores, idx = scores.topk(topk, sorted=False)
+    masks, scores, feats = _rank_unique_assignment(model, mask_pred[idx], scores, feats[idx])
+    if model.apply_masking_with_object_mask:
+        masks = masks * target_object_mask.sum(dim=0, keepdim=True).bool()
+    return masks, scores, feats
+
+
+def rank_instance_inference_with_classification(model, feats, mask_cls, mask_pred, target_mask, target_object_mask, target_label,
+                                                vis=False):
+    """reference :460-513: ranking score x nearest-centroid class probability, top-k over (query, cluster) pairs,
+    majority-vote mapping in mode "eval", per-class merging, ground-truth matching"""
+    import types
+    unique = model.use_unique_per_pixel_label_during_labeling
+    cid = int(target_label)
+    nc = model.classifier[cid].shape[0] if cid in model.classifier else 0
+    object_scores = mask_cls.float().softmax(-1)[:, :1]
+    scores = object_scores * rank_use_classifier(model, feats, cid).softmax(-1)
+    topk = model.wandb_vis_topk if vis and not unique else model.test_topk_per_image
+    labels = torch.arange(nc, device=scores.device).unsqueeze(0).repeat(model.num_queries, 1).flatten()
+    scores, idx = scores.flatten().topk(topk, sorted=False)
+    labels = labels[idx]
+    if model.mode == "eval":
+        if len(model.majority_vote_mapping) == 0:
+            raise ValueError("Class mapping is not registered.")
+        labels = model.majority_vote_mapping[cid][labels]
+    mask_pred = mask_pred[torch.div(idx, nc, rounding_mode="floor")]
+    if model.apply_masking_with_object_mask:
+        mask_pred = mask_pred * target_object_mask.sum(dim=0, keepdim=True).bool()
+    view = types.SimpleNamespace(use_unique_per_pixel_label=unique, min_pseudo_mask_ratio=model.min_pseudo_mask_ratio_2,
+                                 min_pseudo_mask_score=model.min_pseudo_mask_score_2)
+    masks, scores, labels = _unique_assignment_with_classes(view, mask_pred, scores, labels)
+    masks, scores, labels = _rank_match_gt(model, masks, scores, labels, target_mask)
+    if masks.shape[0] == 0:                                   # does not contribute to the evaluation
+        masks = torch.zeros((1,) + tuple(mask_pred.shape[1:]), dtype=torch.bool, device=mask_pred.device)
+        scores, labels = scores.new_zeros(1), torch.zeros(1, dtype=torch.long, device=mask_pred.device)
+    r = Instances(tuple(mask_pred.shape[-2:]))
+    r.pred_masks, r.scores, r.pred_classes = masks, scores, labels
+    return r
+
+
+def rank_prepare_targets(model, inputs, images):
+    """reference :404-438: evaluation inputs carry part_instances + instances (object), labelling inputs only instances"""
+    h_pad, w_pad = images.tensor.shape[-2:]
+
+    def pad(m):
+        out = torch.zeros((m.shape[0], h_pad, w_pad), dtype=m.dtype, device=m.device)
+        out[:, : m.shape[1], : m.shape[2]] = m
+        return out
+    out = []
+    for x in inputs:
+        obj = x["instances"].to(model.device)
+        if "part_instances" in x:
+            part = x["part_instances"].to(model.device)
+            out.append({"part_labels": part.gt_classes.to(model.device), "object_label": obj.gt_classes.to(model.device),
+                        "masks": pad(part.gt_masks.tensor), "object_mask": pad(obj.gt_masks.tensor)})
+        else:
+            m = pad(obj.gt_masks.tensor)
+            out.append({"object_label": obj.gt_classes.to(model.device), "masks": m, "object_mask": m})
+    return out
+
+
+@torch.no_grad()
+def rank_inference(model, batched_inputs, targets, images, outputs, vis=False):
+    """reference :186-258 -> per image {"predictions", "gt_instances", "gt_object_label", "gt_label"
+    (+ "proposal_features" in mode "cluster")}"""
+    logits_all = outputs["pred_masks"]
+    if logits_all is None:
+        from .modeling.transformer_decoder.mask2former_transformer_decoder import materialize_masks
+        logits_all = materialize_masks(dict(outputs))["pred_masks"]
+    feats_all = outputs[model.proposal_key].float()
+    if model.proposal_features_norm:
+        feats_all = F.normalize(feats_all, p=2, dim=-1)
+    pad_hw = tuple(images.tensor.shape[-2:])
+    results = []
+    for cls, low, feats, tgt, inp, size in zip(outputs["pred_logits"], logits_all, feats_all, targets, batched_inputs, images.image_sizes):
+        height, width = inp.get("height", size[0]), inp.get("width", size[1])
+        dense = F.interpolate(low[None].float(), size=pad_hw, mode="bilinear", align_corners=False)[0]
+        dense = sem_seg_postprocess(dense, size, height, width)
+        tm = sem_seg_postprocess(tgt["masks"].float(), size, height, width).bool()
+        to = sem_seg_postprocess(tgt["object_mask"].float(), size, height, width).bool()
+        res = {}
+        if model.mode == "cluster":
+            masks, scores, pf = rank_instance_inference_with_proposal_feats(model, feats, cls, dense, to, vis=vis)
+            masks, scores, pf = _rank_match_gt(model, masks, scores, pf, tm)
+            r = Instances((height, width))
+            r.pred_masks, r.scores = masks.bool(), scores
+            res["predictions"], res["proposal_features"] = r, pf
+            n_rows = pf.shape[0]
+        else:
+            if model.mode == "save":
+                raise NotImplementedError("writing part labels to disk (part_ranking_model.py:262-279) is outside the device path")
+            res["predictions"] = rank_instance_inference_with_classification(model, feats, cls, dense, tm, to, tgt["object_label"], vis=vis)
+            n_rows = feats.shape[0]
+        gt = Instances(tuple(tm.shape[-2:]))
+        gt.gt_masks, gt.pred_masks = tm, tm
+        if "part_labels" in tgt:
+            gt.gt_classes = tgt["part_labels"]
+        res["gt_instances"], res["gt_object_label"] = gt, tgt["object_label"]
+        res["gt_label"] = tgt["object_label"].reshape(-1)[:1].repeat(n_rows)          # (:256) one object label per returned feature row
+        results.append(res)
+    return results

@@ -204,3 +204,29 @@ def make_infer_inputs(cfg=INFER, seed=5200):
 
 INFER_PD_CLASSES = 4                                                         # part classes of the class-aware evaluation goldens
 INFER_PD_MAPPING = ([2, 0, 0, 1], [1, 1, 3, 0])                               # majority-vote class mapping of object classes 3 and 4
+
+
+# ----------------------------------------------------------------------------- part ranking
+RANK = dict(C=16, clusters=3, object_classes=(3, 4), n_feats=(40, 2, 25))       # pooled proposals of object classes 3, 4, 5: class 4 has too few (2 <= clusters)
+
+
+def make_rank_features(cfg=RANK, seed=5400):
+    """decoder_output stand-in [B, Q, C] for the INFER images, and a pool of per-proposal features + object labels for the
+    clustering module: classes 3 and 5 are mixtures of `clusters` well separated blobs, class 4 has only 2 proposals"""
+    feats = seeded((len(INFER["images"]), INFER["Q"], cfg["C"]), seed)
+    pool, labels = [], []
+    for i, (cid, n) in enumerate(zip((3, 4, 5), cfg["n_feats"])):
+        centers = seeded((cfg["clusters"], cfg["C"]), seed + 10 + i) * 4
+        which = torch.arange(n) % cfg["clusters"]
+        pool.append(centers[which] + 0.2 * seeded((n, cfg["C"]), seed + 20 + i))
+        labels.append(torch.full((n,), cid))
+    return feats, pool, labels
+
+
+def rank_centroids(cfg=RANK, seed=5450):
+    """classifier centroids registered for object classes 3 and 4 ([clusters, C])"""
+    import torch.nn.functional as F
+    return {cid: F.normalize(seeded((cfg["clusters"], cfg["C"]), seed + cid), dim=-1) * 3 for cid in cfg["object_classes"]}
+
+
+RANK_MAPPING = ([2, 0, 1], [1, 1, 0])                                          # majority-vote mapping of object classes 3 / 4

@@ -219,6 +219,22 @@ def install_inference_standins():
     return importlib.import_module("part_distillation.proposal_generation_model")
 
 
+def load_clustering_module():
+    """the reference's evaluation/clustering_module.py loaded as a FILE (its package __init__ pulls evaluators that need
+    the COCO / LVIS APIs); stand-ins: a no-op DatasetEvaluator base and single-process comm.all_gather.  sklearn is real."""
+    import importlib.util
+    comm = sys.modules["detectron2.utils.comm"]
+    comm.is_main_process = lambda: True
+    comm.synchronize = lambda: None
+    comm.all_gather = lambda x: [x]
+    _mod("detectron2.evaluation", DatasetEvaluator=object)
+    spec = importlib.util.spec_from_file_location("pd_ref_clustering_module",
+                                                  "/root/reference/part_distillation/evaluation/clustering_module.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def install():
     """Install stand-ins into sys.modules and return the reference leaf modules."""
     if "part_distillation" in sys.modules and getattr(sys.modules["part_distillation"], "_shimmed", False):

@@ -1,0 +1,179 @@
+"""Part ranking: the oracle against the real reference run (tests/golden/infer_rank.pt), the product's
+clustering module and host logic on the CPU, and the product's device inference against the same golden."""
+import types
+
+import pytest
+import torch
+
+import common as C
+
+CASES = [("cluster_l2_1", "cluster", "l2", True, 0.02, 0.05), ("cluster_l2_0", "cluster", "l2", False, 0.0, 0.0),
+         ("raw_l2_1", "", "l2", True, 0.02, 0.0), ("eval_dot_1", "eval", "dot", True, 0.0, 0.05), ("eval_l2_0", "eval", "l2", False, 0.02, 0.05)]
+
+
+def _mapping(dev="cpu"):
+    return {3: torch.tensor(C.RANK_MAPPING[0], device=dev), 4: torch.tensor(C.RANK_MAPPING[1], device=dev)}
+
+
+def _topk(mode):
+    return C.INFER["topk"] if mode == "cluster" else C.INFER["topk"] * 2
+
+
+@pytest.mark.parametrize("tag,mode,metric,unique,ratio,score", CASES)
+def test_oracle_matches_reference_golden(golden, tag, mode, metric, unique, ratio, score):
+    from oracle import part_ranking_ref as R
+    g = golden("infer_rank")[tag]
+    outputs, inputs = C.make_infer_inputs()
+    feats, _, _ = C.make_rank_features()
+    res = R.inference(outputs, feats, inputs, [3, 4], (128, 128), mode, metric, unique, ratio, score, _topk(mode), C.rank_centroids(),
+                      _mapping())
+    for (masks, scores, extra, gt_label), want in zip(res, g):
+        assert torch.equal(masks, want["pred_masks"])
+        torch.testing.assert_close(scores, want["scores"], rtol=1e-6, atol=1e-7)     # exact on the host that made the golden; 1 ulp
+        assert torch.equal(gt_label, want["gt_label"])                              # of softmax / matmul elsewhere
+        if mode == "cluster":
+            torch.testing.assert_close(extra, want["proposal_features"], rtol=1e-6, atol=1e-7)
+        else:
+            assert torch.equal(extra, want["pred_classes"])
+
+
+def test_oracle_clustering_matches_reference_golden(golden):
+    from oracle import part_ranking_ref as R
+    want = golden("infer_rank")["centroids"]
+    _, pool, labels = C.make_rank_features()
+    torch.manual_seed(77)
+    got = R.cluster_centroids(pool, labels, C.RANK["clusters"])
+    assert sorted(got) == sorted(want) == [3, 4, 5]
+    for cid in want:
+        torch.testing.assert_close(got[cid], want[cid], rtol=1e-6, atol=1e-6)
+
+
+def _match_rows(a, b):
+    """pair the rows of two centroid sets by nearest neighbour; -> permuted a"""
+    d = torch.cdist(a.double(), b.double())
+    idx = d.argmin(0)
+    assert sorted(idx.tolist()) == list(range(a.shape[0])), "centroid sets do not pair up one-to-one"
+    return a[idx]
+
+
+def test_clustering_module_matches_reference_centroids(golden):
+    """product ClusteringModule (torch Lloyd with sklearn's semantics, own k-means++ stream) against the reference's sklearn
+    centroids on well separated blobs: the same partition, so the same centroids up to order"""
+    from partdistillation_amd.evaluation import ClusteringModule
+    want = golden("infer_rank")["centroids"]
+    _, pool, labels = C.make_rank_features()
+    cm = ClusteringModule(distributed=False, num_clusters=C.RANK["clusters"])
+    cm.process(None, [{"proposal_features": f, "gt_label": l} for f, l in zip(pool, labels)])
+    got = cm.evaluate()
+    assert sorted(got) == [3, 4, 5] and got[4].shape == (C.RANK["clusters"], C.RANK["C"])     # class 4: 2 proposals -> random centroids
+    for cid in (3, 5):
+        torch.testing.assert_close(_match_rows(got[cid], want[cid]), want[cid], rtol=1e-4, atol=1e-4)
+    cm.reset()
+    assert cm._proposal_features == []
+
+
+def test_part_ranking_model_registers_and_builds():
+    import os
+    import partdistillation_amd.modeling  # noqa: F401
+    import partdistillation_amd.part_ranking_model as prm
+    from partdistillation_amd.compat import META_ARCH_REGISTRY
+    from partdistillation_amd.config import setup_cfg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = setup_cfg(os.path.join(root, "partdistillation_amd", "configs", "proposal_learning", "r50_mask2former.yaml"),
+                    ["MODEL.DEVICE", "cpu", "MODEL.META_ARCHITECTURE", "PartRankingModel", "PART_RANKING.NUM_CLUSTERS", "4"])
+    assert "PartRankingModel" in META_ARCH_REGISTRY
+    model = META_ARCH_REGISTRY.get("PartRankingModel")(cfg).eval()
+    assert isinstance(model, prm.PartRankingModel) and model.num_clusters == 4 and model.classifier_metric == "l2"
+    assert model.proposal_key == "decoder_output" and model.use_unique_per_pixel_label_during_clustering
+    model.register_classifier({7: torch.zeros(4, 256)})
+    assert model.num_classes(torch.tensor(7)) == 4
+    with pytest.raises(AssertionError, match="eval-only"):
+        model.train()([])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,mode,metric,unique,ratio,score", CASES)
+def test_product_inference_vs_reference_golden(golden, tag, mode, metric, unique, ratio, score):
+    from partdistillation_amd import inference as I
+    from partdistillation_amd.compat import BitMasks, ImageList, Instances
+    DEV = "cuda"
+    g = golden("infer_rank")[tag]
+    outputs, inputs = C.make_infer_inputs()
+    feats, _, _ = C.make_rank_features()
+    outputs = {"pred_masks": outputs["pred_masks"].to(DEV), "pred_logits": outputs["pred_logits"].to(DEV), "decoder_output": feats.to(DEV)}
+    model = types.SimpleNamespace(device=torch.device(DEV), test_topk_per_image=_topk(mode), wandb_vis_topk=_topk(mode), mode=mode,
+                                  classifier_metric=metric, num_queries=C.INFER["Q"], fg_score_threshold=0.1,
+                                  use_unique_per_pixel_label_during_clustering=unique, use_unique_per_pixel_label_during_labeling=unique,
+                                  min_pseudo_mask_ratio_1=ratio, min_pseudo_mask_ratio_2=ratio, min_pseudo_mask_score_1=score,
+                                  min_pseudo_mask_score_2=score, apply_masking_with_object_mask=True, proposal_key="decoder_output",
+                                  proposal_features_norm=True, classifier={k: v.to(DEV) for k, v in C.rank_centroids().items()},
+                                  majority_vote_mapping=_mapping(DEV))
+    batched = []
+    for b, i in enumerate(inputs):
+        parts, objs = Instances(tuple(i["image"].shape[-2:])), Instances(tuple(i["image"].shape[-2:]))
+        parts.gt_masks, parts.gt_classes = BitMasks(i["part_masks"]), i["part_labels"]
+        objs.gt_masks, objs.gt_classes = BitMasks(i["object_mask"]), torch.tensor([3 + b])
+        batched.append({"image": i["image"], "part_instances": parts, "instances": objs, "height": i["height"], "width": i["width"]})
+    images = ImageList.from_tensors([i["image"].to(DEV) for i in inputs], C.INFER["size_div"])
+    targets = I.rank_prepare_targets(model, batched, images)
+    res = I.rank_inference(model, batched, targets, images, outputs)
+    for r, want in zip(res, g):
+        p = r["predictions"]
+        assert p.pred_masks.shape == want["pred_masks"].shape, (p.pred_masks.shape, want["pred_masks"].shape)
+        o1, o2 = torch.argsort(p.scores.cpu().double()), torch.argsort(want["scores"].double())       # pair proposals by score
+        torch.testing.assert_close(p.scores.cpu()[o1], want["scores"][o2], rtol=1e-5, atol=1e-6)
+        assert (p.pred_masks.cpu()[o1] != want["pred_masks"][o2]).float().mean().item() < 2e-3
+        assert torch.equal(r["gt_label"].cpu(), want["gt_label"]) and torch.equal(r["gt_object_label"].cpu(), want["gt_object_label"])
+        if mode == "cluster":
+            torch.testing.assert_close(r["proposal_features"].cpu()[o1], want["proposal_features"][o2], rtol=1e-5, atol=1e-6)
+        else:
+            assert torch.equal(p.pred_classes.cpu()[o1], want["pred_classes"][o2])
+
+
+@pytest.mark.gpu
+def test_part_ranking_end_to_end_on_the_device():
+    """cluster pass -> ClusteringModule -> registered nearest-centroid classifier -> labelling pass, R50 part-proposal
+    network with random weights on synthetic images (plumbing of the whole stage on the device)"""
+    import os
+    import partdistillation_amd.modeling  # noqa: F401
+    import partdistillation_amd.part_ranking_model  # noqa: F401
+    from partdistillation_amd.compat import META_ARCH_REGISTRY, BitMasks, Instances
+    from partdistillation_amd.config import setup_cfg
+    from partdistillation_amd.engine.synthetic import make_batch
+    from partdistillation_amd.evaluation import ClusteringModule
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = setup_cfg(os.path.join(root, "partdistillation_amd", "configs", "proposal_learning", "r50_mask2former.yaml"),
+                    ["MODEL.META_ARCHITECTURE", "PartRankingModel", "PART_RANKING.NUM_CLUSTERS", "3", "MODEL.MASK_FORMER.NUM_OBJECT_QUERIES", "20",
+                     "MODEL.MASK_FORMER.DEC_LAYERS", "3", "MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS", "2", "TEST.DETECTIONS_PER_IMAGE", "10"])
+    torch.manual_seed(0)
+    model = META_ARCH_REGISTRY.get("PartRankingModel")(cfg).cuda().eval()
+    model.fg_score_threshold = -1.0                                   # random weights: keep every proposal
+    batch = make_batch(2, 128, n_parts=3, seed=11, device="cuda")
+    for b, x in enumerate(batch):                                    # evaluation inputs: part_instances + object instances
+        parts = x["instances"]
+        obj = Instances(parts.image_size)
+        obj.gt_masks, obj.gt_classes = BitMasks(parts.gt_masks.tensor.any(0, keepdim=True)), torch.tensor([5], device="cuda")
+        parts.gt_classes = torch.arange(len(parts), device="cuda")
+        x["part_instances"], x["instances"] = parts, obj
+    model.mode = "cluster"
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        res = model(batch)
+    assert all(r["proposal_features"].shape[0] == r["predictions"].pred_masks.shape[0] == r["gt_label"].shape[0] for r in res)
+    assert sum(r["proposal_features"].shape[0] for r in res) > 3 and all(int(l) == 5 for r in res for l in r["gt_label"])
+    norms = torch.cat([r["proposal_features"] for r in res]).norm(dim=1)
+    torch.testing.assert_close(norms, torch.ones_like(norms), rtol=1e-4, atol=1e-4)
+    cm = ClusteringModule(distributed=False, num_clusters=3)
+    cm.process(batch, res)
+    cents = cm.evaluate()
+    assert list(cents) == [5] and cents[5].shape == (3, 256) and cents[5].is_cuda
+    model.register_classifier(cents)
+    model.mode = ""
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        res = model(batch)
+    for r in res:
+        p = r["predictions"]
+        assert p.pred_masks.dtype == torch.bool and p.pred_classes.max() < 3 and p.pred_masks.shape[0] == p.scores.shape[0]
+        assert r["gt_label"].shape[0] == 20
+    model.mode = "save"
+    with pytest.raises(NotImplementedError):
+        model(batch)
