@@ -23,7 +23,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # MIOpen's algorithm-search results for this workload's conv shapes ship with the repo (tuning data, like a built
 # artefact): warm-up then skips the exhaustive search on a fresh box.  Must be set before MIOpen initialises.
-os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "partdistillation_amd", "miopen_db"))
+_MIOPEN_DB = os.path.join(ROOT, "partdistillation_amd", "miopen_db")
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "MIOPEN_USER_DB_PATH" not in os.environ:
+    # one private copy per rank: N processes appending to the same user-db files would serialise on MIOpen's file locks
+    import shutil
+    import tempfile
+    _dst = os.path.join(tempfile.gettempdir(), "pd_miopen_db_rank" + os.environ.get("LOCAL_RANK", "0"))
+    try:
+        shutil.copytree(_MIOPEN_DB, _dst, dirs_exist_ok=True)
+        _MIOPEN_DB = _dst
+    except OSError:
+        pass
+os.environ.setdefault("MIOPEN_USER_DB_PATH", _MIOPEN_DB)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
