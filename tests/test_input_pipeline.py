@@ -1,0 +1,134 @@
+"""Device input pipeline.  CPU: the oracle's Pillow restatement bit-exact against Pillow itself (the
+library detectron2's ResizeTransform calls), its RLE decode against the product encoder (pinned to the reference golden
+elsewhere), the product's vectorised coefficient tables against the oracle's loops.  GPU: the device transform bit-exact
+against the oracle for random parameter draws."""
+import numpy as np
+import pytest
+import torch
+
+
+def _scene(rng, H, W, n):
+    img = rng.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    ys, xs = np.mgrid[0:H, 0:W]
+    seeds = rng.rand(n, 2) * [H, W]
+    lab = np.argmin((ys[None] - seeds[:, 0, None, None]) ** 2 + (xs[None] - seeds[:, 1, None, None]) ** 2, axis=0)
+    inside = ((ys - H / 2) ** 2 / (0.17 * H * H) + (xs - W / 2) ** 2 / (0.12 * W * W)) < 1.0
+    masks = np.stack([(lab == i) & inside for i in range(n)])
+    return img, masks
+
+
+@pytest.mark.parametrize("H,W,oh,ow", [(37, 53, 37, 90), (64, 48, 11, 48), (50, 70, 173, 9), (333, 500, 41, 61), (20, 30, 47, 66), (8, 8, 8, 8)])
+def test_oracle_resize_is_pillow_exact(H, W, oh, ow):
+    from PIL import Image
+    from oracle import input_pipeline_ref as R
+    rng = np.random.RandomState(H * W)
+    img = rng.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    assert np.array_equal(R.resize_bilinear_u8(img, oh, ow), np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR)))
+    m = (rng.rand(H, W) > 0.5).astype(np.uint8)
+    assert np.array_equal(R.resize_nearest(m, oh, ow), np.asarray(Image.fromarray(m).resize((ow, oh), Image.NEAREST)))
+
+
+def test_oracle_apply_equals_the_same_steps_done_with_pillow():
+    """flip -> crop -> Pillow resize (BILINEAR image / NEAREST masks) -> crop -> pad, written directly with Pillow"""
+    from PIL import Image
+    from oracle import input_pipeline_ref as R
+    rng = np.random.RandomState(5)
+    img, masks = _scene(rng, 90, 120, 3)
+    for _ in range(6):
+        p = R.draw_params(rng, 90, 120, 64, 0.3, 2.0, "relative_range", (0.8, 0.8))
+        got_i, got_m, got_p = R.apply(img, masks, p)
+        a, mm = (img[:, ::-1], masks[:, :, ::-1]) if p["flip"] else (img, masks)
+        x0, y0, cw, ch = p["crop1"]
+        a, mm = a[y0:y0 + ch, x0:x0 + cw], mm[:, y0:y0 + ch, x0:x0 + cw]
+        rh, rw = p["resize"]
+        a = np.asarray(Image.fromarray(np.ascontiguousarray(a)).resize((rw, rh), Image.BILINEAR))
+        mm = np.stack([np.asarray(Image.fromarray(np.ascontiguousarray(m).astype(np.uint8)).resize((rw, rh), Image.NEAREST)) for m in mm]).astype(bool)
+        ox, oy = p["crop2"]
+        a, mm = a[oy:oy + 64, ox:ox + 64], mm[:, oy:oy + 64, ox:ox + 64]
+        want = np.full((64, 64, 3), 128, np.uint8)
+        want[:a.shape[0], :a.shape[1]] = a
+        wm = np.zeros((3, 64, 64), bool)
+        wm[:, :mm.shape[1], :mm.shape[2]] = mm
+        assert np.array_equal(got_i, want) and np.array_equal(got_m, wm)
+        assert np.array_equal(~got_p[:a.shape[0], :a.shape[1]], np.ones(a.shape[:2], bool)) and got_p.sum() == 64 * 64 - a.shape[0] * a.shape[1]
+
+
+def test_oracle_rle_decode_round_trips_the_product_encoder():
+    from oracle import input_pipeline_ref as R
+    from partdistillation_amd.utils import rle
+    rng = np.random.RandomState(9)
+    _, masks = _scene(rng, 57, 83, 4)
+    for m in list(masks) + [np.zeros((57, 83), bool), np.ones((57, 83), bool)]:
+        enc = rle.encode(m)
+        assert np.array_equal(R.rle_decode(R.rle_string_to_counts(enc["counts"]), 57, 83), m)
+        assert np.array_equal(R.rle_string_to_counts(enc["counts"]), rle.string_to_counts(enc["counts"]))
+
+
+def test_product_tables_equal_oracle_loops():
+    from oracle import input_pipeline_ref as R
+    from partdistillation_amd.data import device_mapper as D
+    rng = np.random.RandomState(2)
+    for _ in range(60):
+        a, b = rng.randint(3, 1300), rng.randint(3, 1300)
+        first = rng.randint(0, b)
+        count = rng.randint(1, b - first + 1)
+        x2, c2, k2 = D.resample_coeffs(a, b, first, count)
+        if a != b:
+            xm, cn, kk = R.resample_coeffs(a, b)
+            assert np.array_equal(xm[first:first + count], x2) and np.array_equal(cn[first:first + count], c2)
+            assert np.array_equal(kk[first:first + count], k2)
+        assert np.array_equal(R.nearest_index(a, b), D.nearest_index(a, b))
+
+
+def test_product_draws_equal_oracle_draws_and_mapper_is_gpu_only():
+    from oracle import input_pipeline_ref as R
+    from partdistillation_amd.data import DeviceProposalMapper
+    m = DeviceProposalMapper(64, 0.1, 2.0, "relative_range", (0.9, 0.9), device="cpu", rng=np.random.RandomState(3))
+    r = np.random.RandomState(3)
+    for _ in range(20):
+        assert m.draw(90, 120) == R.draw_params(r, 90, 120, 64, 0.1, 2.0, "relative_range", (0.9, 0.9))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m.transform(np.zeros((90, 120, 3), np.uint8), [], m.draw(90, 120))
+    sel = R.filter_instances(np.stack([np.ones((4, 4), bool), np.zeros((4, 4), bool), np.eye(4, dtype=bool)]), 0.21)
+    assert sel.tolist() == [0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,S,lo,hi,crop", [(90, 120, 64, 0.1, 2.0, "relative_range"), (300, 200, 128, 0.1, 2.0, None),
+                                              (64, 64, 96, 1.0, 1.0, None), (500, 375, 256, 0.5, 1.5, "relative_range")])
+def test_device_transform_is_bit_exact_against_the_oracle(H, W, S, lo, hi, crop):
+    from oracle import input_pipeline_ref as R
+    from partdistillation_amd.data import DeviceProposalMapper
+    from partdistillation_amd.utils import rle
+    rng = np.random.RandomState(H + S)
+    img, masks = _scene(rng, H, W, 4)
+    masks[3] = False                                                      # an empty pseudo-label
+    segs = [rle.encode(m) for m in masks]
+    mapper = DeviceProposalMapper(S, lo, hi, crop, (0.8, 0.8) if crop else None, min_area_ratio=0.05, rng=rng)
+    for _ in range(8):
+        p = mapper.draw(H, W)
+        oi, om, opad = R.apply(img, masks, p)
+        gi, gm, gpad, area = mapper.transform(img, segs, p)
+        assert gi.shape == (3, S, S) and gi.dtype == torch.uint8 and gm.dtype == torch.bool
+        assert np.array_equal(gi.cpu().numpy(), oi.transpose(2, 0, 1)), p
+        assert np.array_equal(gm.cpu().numpy(), om), p
+        assert np.array_equal(gpad.cpu().numpy(), opad)
+        assert area.cpu().tolist() == om.reshape(4, -1).sum(1).tolist()
+        assert mapper.select(gm, area).cpu().tolist() == R.filter_instances(om, 0.05).tolist()
+
+
+@pytest.mark.gpu
+def test_device_mapper_call_returns_the_reference_mappers_dict():
+    from partdistillation_amd.data import DeviceProposalMapper
+    from partdistillation_amd.utils import rle
+    rng = np.random.RandomState(0)
+    img, masks = _scene(rng, 120, 160, 3)
+    d = {"file_name": "x.jpg", "image_id": "x", "class_code": "n0", "gt_object_class": 7, "image": img,
+         "pseudo_annotations": [{"segmentation": rle.encode(m), "category_id": 0} for m in masks]}
+    mapper = DeviceProposalMapper(96, 0.1, 2.0, "relative_range", (0.9, 0.9), rng=rng)
+    out = mapper(d)
+    assert set(out) >= {"image", "padding_mask", "instances", "height", "width", "gt_object_class", "file_name"} and "pseudo_annotations" not in out
+    inst = out["instances"]
+    assert out["image"].shape == (3, 96, 96) and out["image"].is_cuda and len(inst) >= 1
+    assert inst.gt_masks.tensor.shape[1:] == (96, 96) and inst.gt_masks.tensor.dtype == torch.bool and int(inst.gt_classes.sum()) == 0
+    assert bool((inst.gt_masks.tensor.flatten(1).sum(1) > 0).all())
