@@ -34,6 +34,14 @@ int pd_sgemm_nn_bf16(const void *dY, const void *W, const void *relu_ref, void *
 int pd_sgemm_wgrad_bf16(const void *dY, const void *X, void *dW, float *dB, int M, int N, int K, int ldy, int ldx, int ldw,
                         void *stream);
 
+/* The same product for MANY rows (the 10^4..10^5 tokens of a Swin stage: swin.py:58-70, 128-131 Linear weight gradients):
+ * the M rows are cut into slices that run as separate workgroups, fp32 partial tiles are summed by a second kernel
+ * (deterministic, no atomics).  workspace: fp32, at least pd_sgemm_wgrad_split_workspace(M, N, K) elements, 16-byte
+ * aligned.  M > 0; N % 4 == K % 4 == ldw % 4 == 0; dB (fp32 [N], nullable) = column sums of dY. */
+int64_t pd_sgemm_wgrad_split_workspace(int M, int N, int K);
+int pd_sgemm_wgrad_split_bf16(const void *dY, const void *X, void *dW, float *dB, float *workspace, int M, int N, int K, int ldy,
+                              int ldx, int ldw, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -211,6 +211,103 @@ __global__ __launch_bounds__(256) void sgemm_wgrad(const bf16_t *__restrict__ dY
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dW = dY^T X, many rows
+// The same 32 x 128 tile and 64-row chunks as sgemm_wgrad, but the M rows (10^4..10^5 tokens of a Swin stage) are cut into
+// `gridDim.z` slices: an [N, K] weight gradient has only (N/32)(K/128) ~ 100-200 tiles, too few for 256 CUs when each tile
+// must walk all the rows (the library picks such a kernel: 63 us for M = 8192, N = 1536, K = 512).  Each slice writes
+// its fp32 partial tile (plain stores) and wgrad_reduce sums the slices -> bf16: deterministic, no atomics.
+__global__ __launch_bounds__(256) void sgemm_wgrad_split(const bf16_t *__restrict__ dY, const bf16_t *__restrict__ X,
+                                                         float *__restrict__ part, float *__restrict__ bpart, int M, int N, int K,
+                                                         int ldy, int ldx, int rows_per_split)
+{
+  __shared__ __attribute__((aligned(16))) bf16_t Ys[2][64][P32];
+  __shared__ __attribute__((aligned(16))) bf16_t Xs[2][64][P128];
+  const int kb = blockIdx.x * 128, nb = blockIdx.y * 32, z = blockIdx.z;
+  const int m_begin = z * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int yrow = tid >> 2, ycol = (tid & 3) * 8;
+  const int xrow = tid >> 4, xcol = (tid & 15) * 8;
+  uint4 yr, xr[4];
+  auto gload = [&](int m0) {
+    yr = load_piece(dY, ldy, m0 + yrow, nb + ycol, m_end, N);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xr[i] = load_piece(X, ldx, m0 + xrow + 16 * i, kb + xcol, m_end, K);
+  };
+  auto lstore = [&](int buf) {
+    store_piece(&Ys[buf][yrow][ycol], yr);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_piece(&Xs[buf][xrow + 16 * i][xcol], xr[i]);
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const bool do_bias = bpart != nullptr && blockIdx.x == 0 && wave == 0;
+  float bsum = 0.f;
+  const int nchunk = (m_end - m_begin + 63) / 64;
+  if (nchunk > 0) { gload(m_begin); lstore(0); }
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) gload(m_begin + (c + 1) * 64);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      mma(acc, gather4(&Ys[buf][8 * s + 4 * hh][r], P32), gather4(&Xs[buf][8 * s + 4 * hh][32 * wave + r], P128));
+    if (do_bias) {
+#pragma unroll 8
+      for (int i = 0; i < 32; ++i) bsum += __uint_as_float((unsigned)Ys[buf][32 * hh + i][r] << 16);
+    }
+    if (c + 1 < nchunk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (hh == 0 && nb + r < N) bpart[(int64_t)z * N + nb + r] = bsum;
+  }
+  const int k = kb + 32 * wave + r;
+  if (k >= K) return;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int n = nb + (e & 3) + 8 * (e >> 2) + 4 * hh;
+    if (n < N) part[((int64_t)z * N + n) * K + k] = acc[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce(const float *__restrict__ part, const float *__restrict__ bpart,
+                                                    bf16_t *__restrict__ dW, float *__restrict__ dB, int N, int K, int ldw, int splits)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, nk4 = (int64_t)N * K / 4;
+  if (i < nk4) {
+    float4 a = reinterpret_cast<const float4 *>(part)[i];
+    for (int z = 1; z < splits; ++z) {
+      const float4 b = reinterpret_cast<const float4 *>(part)[z * nk4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const int n = (int)(i * 4 / K), k = (int)(i * 4 - (int64_t)n * K);
+    uint2 o;
+    o.x = pk_bf16(a.x, a.y); o.y = pk_bf16(a.z, a.w);
+    *reinterpret_cast<uint2 *>(dW + (int64_t)n * ldw + k) = o;
+  }
+  if (dB && i < N) {
+    float b = 0.f;
+    for (int z = 0; z < splits; ++z) b += bpart[(int64_t)z * N + i];
+    dB[i] = b;
+  }
+}
+
+// slices of the M rows: ~1024 workgroups in flight, at least 256 rows per slice, slices a multiple of the 64-row chunk
+int wgrad_splits(int M, int N, int K, int *rows_per_split)
+{
+  const int tiles = ((N + 31) / 32) * ((K + 127) / 128);
+  int splits = (1024 + tiles - 1) / tiles;
+  const int max_splits = (M + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int rps = (M + splits - 1) / splits;
+  rps = (rps + 63) / 64 * 64;
+  *rows_per_split = rps;
+  return (M + rps - 1) / rps;
+}
+
 bool ok_ptr(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 int check_common(const char *who, const void *a, const void *b, const void *c, int M, int N, int K, int l0, int l1, int l2)
@@ -266,3 +363,32 @@ extern "C" int pd_sgemm_wgrad_bf16(const void *dY, const void *X, void *dW, floa
   hipLaunchKernelGGL(sgemm_wgrad, g, b, 0, (hipStream_t)stream_, (const bf16_t *)dY, (const bf16_t *)X, (bf16_t *)dW, dB, M, N, K, ldy, ldx, ldw);
   return pd_check_launch("pd_sgemm_wgrad_bf16");
 }
+
+extern "C" int64_t pd_sgemm_wgrad_split_workspace(int M, int N, int K)
+{
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int rps;
+  const int splits = wgrad_splits(M, N, K, &rps);
+  return (int64_t)splits * N * K + (int64_t)splits * N;
+}
+
+extern "C" int pd_sgemm_wgrad_split_bf16(const void *dY, const void *X, void *dW, float *dB, float *workspace, int M, int N, int K,
+                                         int ldy, int ldx, int ldw, void *stream_)
+{
+  int rc = check_common("pd_sgemm_wgrad_split_bf16", M > 0 ? dY : dW, M > 0 ? X : dW, dW, M, N, K, ldy, ldx, 8);
+  if (rc) return rc;
+  if ((N & 3) || (K & 3) || (ldw & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_wgrad_split_bf16: N=%d, K=%d, ldw=%d must be multiples of 4", N, K, ldw);
+  if (N == 0 || K == 0) return PD_OK;
+  if (M <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_wgrad_split_bf16: M must be positive (pd_sgemm_wgrad_bf16 handles M = 0)");
+  if (!workspace || ((uintptr_t)workspace & 15)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_wgrad_split_bf16: workspace null / not 16-byte aligned");
+  int rps;
+  const int splits = wgrad_splits(M, N, K, &rps);
+  float *part = workspace, *bpart = workspace + (int64_t)splits * N * K;
+  hipStream_t st = (hipStream_t)stream_;
+  hipLaunchKernelGGL(sgemm_wgrad_split, dim3((K + 127) / 128, (N + 31) / 32, splits), dim3(256), 0, st, (const bf16_t *)dY, (const bf16_t *)X,
+                     part, dB ? bpart : nullptr, M, N, K, ldy, ldx, rps);
+  const int64_t work = (int64_t)N * K / 4 > N ? (int64_t)N * K / 4 : N;
+  hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, part, bpart, (bf16_t *)dW, dB, N, K, ldw, splits);
+  return pd_check_launch("pd_sgemm_wgrad_split_bf16");
+}
+

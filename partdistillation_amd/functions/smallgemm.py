@@ -51,3 +51,25 @@ def wgrad(dy, x, out=None, bias_out=None):
     _lib.check(_lib.load().pd_sgemm_wgrad_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), bias_out.data_ptr() if bias_out is not None else None,
                                                M, N, K, dy.stride(0), x.stride(0), dw.stride(0), _stream()))
     return dw
+
+
+_WGRAD_WS = {}
+
+
+def wgrad_split(dy, x, want_bias=True):
+    """dy [M,N].T @ x [M,K] for many rows (pd_sgemm_wgrad_split_bf16) -> (dW bf16 [N,K], dB fp32 [N] or None)"""
+    _chk2d(dy, x)
+    M, N = dy.shape
+    K = x.shape[1]
+    L = _lib.load()
+    need = int(L.pd_sgemm_wgrad_split_workspace(M, N, K))
+    key = str(dy.device)
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _WGRAD_WS[key] = torch.empty(need, dtype=torch.float32, device=dy.device)
+    dw = torch.empty((N, K), dtype=torch.bfloat16, device=dy.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_bias else None
+    _lib.check(L.pd_sgemm_wgrad_split_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if want_bias else None, ws.data_ptr(),
+                                           M, N, K, dy.stride(0), x.stride(0), dw.stride(0), _stream()))
+    return dw, db
+

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpd_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -70,6 +70,8 @@ SIGNATURES = {
     "pd_resample_rows_u8": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp] * 3 + [_c_int, _c_int, _c_vp, _c_vp]),
     "pd_resample_cols_u8": (_c_int, [_c_vp] + [_c_int] * 3 + [_c_vp] * 3 + [_c_int] * 5 + [_c_vp, _c_vp]),
     "pd_rle_sample_u8": (_c_int, [_c_vp, _c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 3 + [_c_vp, _c_vp, _c_vp]),
+    "pd_sgemm_wgrad_split_workspace": (ctypes.c_int64, [_c_int] * 3),
+    "pd_sgemm_wgrad_split_bf16": (_c_int, [_c_vp] * 5 + [_c_int] * 6 + [_c_vp]),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_abi_version": (_c_int, []),
     "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),

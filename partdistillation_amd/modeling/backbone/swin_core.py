@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch.autograd import Function
 
+from ...functions import smallgemm
 from ...functions import swin_rows as rows
 from ...functions import window_attention as wattn
 
@@ -32,6 +33,18 @@ def window_maps(H, W, shift, device):
 
 def _bf(t):
     return t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)
+
+
+def _wgrad(dy, x, w, b):
+    """weight + bias gradient of a Linear over all tokens of the stage, in the parameters' dtypes.  Small [N, K] outputs
+    (few tiles, every one walking 10^4..10^5 rows) go to the split-rows matrix-core kernel of include/pd_smallgemm.h —
+    measured 2.3-2.8x the library at K <= 256, break-even at N*K ~ 0.8 M (tools/bench_wgrad_split.py); larger outputs
+    have enough tiles for the library GEMM."""
+    if w.shape[0] * w.shape[1] <= 800_000:
+        dw, db = smallgemm.wgrad_split(dy, x, True)
+    else:
+        dw, db = torch.mm(dy.t(), x), dy.sum(0, dtype=torch.float32)
+    return (dw if dw.dtype == w.dtype else dw.to(w.dtype)), (db if db.dtype == b.dtype else db.to(b.dtype))
 
 
 class SwinStage(Function):
@@ -83,9 +96,6 @@ class SwinStage(Function):
         norm_g = torch.zeros((depth, 4, C), dtype=torch.float32, device=dev)       # dgamma1, dbeta1, dgamma2, dbeta2
         grads = [None] * (depth * N_BLOCK)
 
-        def like(g, p):
-            return g if g.dtype == p.dtype else g.to(p.dtype)
-
         for k in reversed(range(depth)):
             n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = params[k * N_BLOCK:(k + 1) * N_BLOCK]
             s1, y1, st1, qkv, ao, lse, s2, y2, st2, h, a = saved[k * 11:(k + 1) * 11]
@@ -95,21 +105,21 @@ class SwinStage(Function):
             g = grads[k * N_BLOCK:(k + 1) * N_BLOCK]
             # MLP
             da = torch.mm(df, _bf(f2w))
-            g[11], g[12] = like(torch.mm(df.t(), a), f2w), like(df.sum(0, dtype=torch.float32), f2b)
+            g[11], g[12] = _wgrad(df, a, f2w, f2b)
             dh = torch.ops.aten.gelu_backward(da, h)
             dy2 = torch.mm(dh, _bf(f1w))
-            g[9], g[10] = like(torch.mm(dh.t(), y2), f1w), like(dh.sum(0, dtype=torch.float32), f1b)
+            g[9], g[10] = _wgrad(dh, y2, f1w, f1b)
             # LayerNorm 2 + the residual it sits on; gradient of the (window-major) proj output rides out as `dr`
             sc1 = dp[k, 0] if dp is not None else None
             ds2, dpo = rows.ln_bwd(dy2, None, L, dsup, s2, st2, n2w, True, ymap, S, sc1, zero, norm_g[k, 2], norm_g[k, 3], B, L)
             dao = torch.mm(dpo, _bf(pw))
-            g[5], g[6] = like(torch.mm(dpo.t(), ao.view(-1, C)), pw), like(dpo.sum(0, dtype=torch.float32), pb)
+            g[5], g[6] = _wgrad(dpo, ao.view(-1, C), pw, pb)
             dqkv, dtable = wattn.bwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table.contiguous(), regions, ao,
                                          dao.view(B * nW, wattn.TOKENS, C), lse, spec["scale"], nW)
             g[4] = dtable
             dqkv = dqkv.view(-1, 3 * C)
             dy1 = torch.mm(dqkv, _bf(qw))
-            g[2], g[3] = like(torch.mm(dqkv.t(), y1), qw), like(dqkv.sum(0, dtype=torch.float32), qb)
+            g[2], g[3] = _wgrad(dqkv, y1, qw, qb)
             # LayerNorm 1; for k > 0 its input was (block k-1 stream + DropPath * MLP output): `dr` = that MLP's output gradient
             prev = (dp[k - 1, 1] if dp is not None else None) if k > 0 else None
             ds1, df = rows.ln_bwd(dy1, ymap, S, ds2, s1, st1, n1w, k > 0, None, L, prev, None, norm_g[k, 0], norm_g[k, 1], B, L)

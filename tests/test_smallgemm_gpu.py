@@ -60,3 +60,22 @@ def test_slices_of_packed_projection_weight():
     torch.testing.assert_close(g[2 * C:].float(), dy.float().t() @ x.float(), rtol=1e-2, atol=1e-1)
     assert g[:2 * C].abs().sum() == 0
     torch.testing.assert_close(sg.dgrad(dy, w[:C]).float(), dy.float() @ w[:C].float(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 1536, 512), (8192, 512, 2048), (65536, 384, 128), (300, 64, 40), (12800, 2304, 768), (1000, 72, 136)])
+def test_wgrad_split_matches_torch(M, N, K):
+    """dW = dY^T X and dB = column sums of dY over many rows (pd_sgemm_wgrad_split_bf16) against fp32 torch on the
+    bf16-rounded operands; tolerance = bf16 rounding of the result (2^-8) plus fp32 summation-order noise"""
+    from partdistillation_amd.functions import smallgemm
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    dy = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    dw, db = smallgemm.wgrad_split(dy, x, True)
+    want = dy.float().t() @ x.float()
+    assert dw.dtype == torch.bfloat16 and dw.shape == (N, K) and db.dtype == torch.float32
+    err = (dw.float() - want).abs().max().item()
+    assert err <= 6e-3 * want.abs().max().item() + 1e-3, (err, want.abs().max().item())
+    torch.testing.assert_close(db, dy.float().sum(0), rtol=1e-4, atol=1e-2)
+    dw2, none = smallgemm.wgrad_split(dy, x, False)
+    assert none is None and torch.equal(dw2, dw)                                   # deterministic: no atomics
+
