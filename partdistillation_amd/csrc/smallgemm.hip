@@ -216,32 +216,38 @@ __global__ __launch_bounds__(256) void sgemm_wgrad(const bf16_t *__restrict__ dY
 // `gridDim.z` slices: an [N, K] weight gradient has only (N/32)(K/128) ~ 100-200 tiles, too few for 256 CUs when each tile
 // must walk all the rows (the library picks such a kernel: 63 us for M = 8192, N = 1536, K = 512).  Each slice writes
 // its fp32 partial tile (plain stores) and wgrad_reduce sums the slices -> bf16: deterministic, no atomics.
+template <int NB>   // 32-row blocks of N per workgroup: 2 (a 64 x 128 tile, the X operand of an MFMA pair shared) or 1
 __global__ __launch_bounds__(256) void sgemm_wgrad_split(const bf16_t *__restrict__ dY, const bf16_t *__restrict__ X,
                                                          float *__restrict__ part, float *__restrict__ bpart, int M, int N, int K,
                                                          int ldy, int ldx, int rows_per_split)
 {
-  __shared__ __attribute__((aligned(16))) bf16_t Ys[2][64][P32];
+  constexpr int TN = 32 * NB, PY = NB == 2 ? P64 : P32;
+  __shared__ __attribute__((aligned(16))) bf16_t Ys[2][64][PY];
   __shared__ __attribute__((aligned(16))) bf16_t Xs[2][64][P128];
-  const int kb = blockIdx.x * 128, nb = blockIdx.y * 32, z = blockIdx.z;
+  const int kb = blockIdx.x * 128, nb = blockIdx.y * TN, z = blockIdx.z;
   const int m_begin = z * rows_per_split, m_end = min(M, m_begin + rows_per_split);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-  const int yrow = tid >> 2, ycol = (tid & 3) * 8;
+  const int yrow = NB == 2 ? tid >> 3 : tid >> 2, ycol = NB == 2 ? (tid & 7) * 8 : (tid & 3) * 8;     // dY chunk: 64 rows x TN/8 pieces
   const int xrow = tid >> 4, xcol = (tid & 15) * 8;
-  uint4 yr, xr[4];
+  uint4 yr[NB], xr[4];
   auto gload = [&](int m0) {
-    yr = load_piece(dY, ldy, m0 + yrow, nb + ycol, m_end, N);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) yr[i] = load_piece(dY, ldy, m0 + yrow + 32 * i * (NB == 2), nb + ycol, m_end, N);
 #pragma unroll
     for (int i = 0; i < 4; ++i) xr[i] = load_piece(X, ldx, m0 + xrow + 16 * i, kb + xcol, m_end, K);
   };
   auto lstore = [&](int buf) {
-    store_piece(&Ys[buf][yrow][ycol], yr);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) store_piece(&Ys[buf][yrow + 32 * i * (NB == 2)][ycol], yr[i]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) store_piece(&Xs[buf][xrow + 16 * i][xcol], xr[i]);
   };
-  f32x16 acc;
+  f32x16 acc[NB];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  const bool do_bias = bpart != nullptr && blockIdx.x == 0 && wave == 0;
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+  const bool do_bias = bpart != nullptr && blockIdx.x == 0 && wave < NB;      // wave b sums the dY columns of n-block b
   float bsum = 0.f;
   const int nchunk = (m_end - m_begin + 63) / 64;
   if (nchunk > 0) { gload(m_begin); lstore(0); }
@@ -250,26 +256,31 @@ __global__ __launch_bounds__(256) void sgemm_wgrad_split(const bf16_t *__restric
     const int buf = c & 1;
     if (c + 1 < nchunk) gload(m_begin + (c + 1) * 64);
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-      mma(acc, gather4(&Ys[buf][8 * s + 4 * hh][r], P32), gather4(&Xs[buf][8 * s + 4 * hh][32 * wave + r], P128));
+    for (int s = 0; s < 8; ++s) {
+      const bf16x4 xo = gather4(&Xs[buf][8 * s + 4 * hh][32 * wave + r], P128);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) mma(acc[b], gather4(&Ys[buf][8 * s + 4 * hh][32 * b + r], PY), xo);
+    }
     if (do_bias) {
 #pragma unroll 8
-      for (int i = 0; i < 32; ++i) bsum += __uint_as_float((unsigned)Ys[buf][32 * hh + i][r] << 16);
+      for (int i = 0; i < 32; ++i) bsum += __uint_as_float((unsigned)Ys[buf][32 * hh + i][32 * wave + r] << 16);
     }
     if (c + 1 < nchunk) lstore(buf ^ 1);
     __syncthreads();
   }
   if (do_bias) {
     bsum += __shfl_xor(bsum, 32, 64);
-    if (hh == 0 && nb + r < N) bpart[(int64_t)z * N + nb + r] = bsum;
+    if (hh == 0 && nb + 32 * wave + r < N) bpart[(int64_t)z * N + nb + 32 * wave + r] = bsum;
   }
   const int k = kb + 32 * wave + r;
   if (k >= K) return;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int n = nb + (e & 3) + 8 * (e >> 2) + 4 * hh;
-    if (n < N) part[((int64_t)z * N + n) * K + k] = acc[e];
-  }
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = nb + 32 * b + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      if (n < N) part[((int64_t)z * N + n) * K + k] = acc[b][e];
+    }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce(const float *__restrict__ part, const float *__restrict__ bpart,
@@ -295,9 +306,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float *__restrict__ pa
 }
 
 // slices of the M rows: ~1024 workgroups in flight, at least 256 rows per slice, slices a multiple of the 64-row chunk
+int wgrad_tile_n(int N) { return N % 64 == 0 ? 64 : 32; }
 int wgrad_splits(int M, int N, int K, int *rows_per_split)
 {
-  const int tiles = ((N + 31) / 32) * ((K + 127) / 128);
+  const int tn = wgrad_tile_n(N);
+  const int tiles = ((N + tn - 1) / tn) * ((K + 127) / 128);
   int splits = (1024 + tiles - 1) / tiles;
   const int max_splits = (M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
@@ -385,8 +398,12 @@ extern "C" int pd_sgemm_wgrad_split_bf16(const void *dY, const void *X, void *dW
   const int splits = wgrad_splits(M, N, K, &rps);
   float *part = workspace, *bpart = workspace + (int64_t)splits * N * K;
   hipStream_t st = (hipStream_t)stream_;
-  hipLaunchKernelGGL(sgemm_wgrad_split, dim3((K + 127) / 128, (N + 31) / 32, splits), dim3(256), 0, st, (const bf16_t *)dY, (const bf16_t *)X,
-                     part, dB ? bpart : nullptr, M, N, K, ldy, ldx, rps);
+  if (wgrad_tile_n(N) == 64)
+    hipLaunchKernelGGL(sgemm_wgrad_split<2>, dim3((K + 127) / 128, N / 64, splits), dim3(256), 0, st, (const bf16_t *)dY, (const bf16_t *)X,
+                       part, dB ? bpart : nullptr, M, N, K, ldy, ldx, rps);
+  else
+    hipLaunchKernelGGL(sgemm_wgrad_split<1>, dim3((K + 127) / 128, (N + 31) / 32, splits), dim3(256), 0, st, (const bf16_t *)dY, (const bf16_t *)X,
+                       part, dB ? bpart : nullptr, M, N, K, ldy, ldx, rps);
   const int64_t work = (int64_t)N * K / 4 > N ? (int64_t)N * K / 4 : N;
   hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, part, bpart, (bf16_t *)dW, dB, N, K, ldw, splits);
   return pd_check_launch("pd_sgemm_wgrad_split_bf16");

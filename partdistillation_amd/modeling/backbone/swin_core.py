@@ -38,9 +38,9 @@ def _bf(t):
 def _wgrad(dy, x, w, b):
     """weight + bias gradient of a Linear over all tokens of the stage, in the parameters' dtypes.  Small [N, K] outputs
     (few tiles, every one walking 10^4..10^5 rows) go to the split-rows matrix-core kernel of include/pd_smallgemm.h —
-    measured 2.3-2.8x the library at K <= 256, break-even at N*K ~ 0.8 M (tools/bench_wgrad_split.py); larger outputs
+    measured 2.5-3x the library at K <= 256, break-even at N*K ~ 1 M (tools/bench_wgrad_split.py); larger outputs
     have enough tiles for the library GEMM."""
-    if w.shape[0] * w.shape[1] <= 800_000:
+    if w.shape[0] * w.shape[1] <= 1_100_000:
         dw, db = smallgemm.wgrad_split(dy, x, True)
     else:
         dw, db = torch.mm(dy.t(), x), dy.sum(0, dtype=torch.float32)
