@@ -229,6 +229,8 @@ def pd_inference(model, batched_inputs, targets, images, outputs, vis=False):
         tm = sem_seg_postprocess(tgt["masks"].float(), size, height, width).bool()
         to = sem_seg_postprocess(tgt["object_mask"].float(), size, height, width).bool()
         r = instance_inference_with_classification(model, cls, dense, tm, to, tgt["labels"], tgt["gt_object_class"], vis=vis)
+        if model.mode == "save" and not vis:
+            save_part_segmentation(model, inp, r)
         gt = Instances((height, width))
         gt.gt_masks, gt.gt_classes, gt.pred_masks, gt.pred_classes = tm, tgt["labels"], tm, tgt["labels"]
         results.append({"predictions": r, "gt_instances": gt, "gt_object_label": tgt["gt_object_class"]})
@@ -368,9 +370,9 @@ def rank_inference(model, batched_inputs, targets, images, outputs, vis=False):
             res["predictions"], res["proposal_features"] = r, pf
             n_rows = pf.shape[0]
         else:
-            if model.mode == "save":
-                raise NotImplementedError("writing part labels to disk (part_ranking_model.py:262-279) is outside the device path")
             res["predictions"] = rank_instance_inference_with_classification(model, feats, cls, dense, tm, to, tgt["object_label"], vis=vis)
+            if model.mode == "save" and not vis:
+                save_generated_part_labels(model, inp, tgt["object_label"], res["predictions"])
             n_rows = feats.shape[0]
         gt = Instances(tuple(tm.shape[-2:]))
         gt.gt_masks, gt.pred_masks = tm, tm
@@ -380,3 +382,40 @@ def rank_inference(model, batched_inputs, targets, images, outputs, vis=False):
         res["gt_label"] = tgt["object_label"].reshape(-1)[:1].repeat(n_rows)          # (:256) one object label per returned feature row
         results.append(res)
     return results
+
+
+# ================================================================================================ label export ("save" modes)
+def _save_dict(root, inp, res):
+    import os
+    d = os.path.join(root, str(inp["class_code"]))
+    os.makedirs(d, exist_ok=True)
+    torch.save(res, os.path.join(d, str(inp["image_id"])))
+
+
+def save_generated_part_labels(model, inp, label, instance):
+    """reference part_ranking_model.py:262-279: one torch.save-d dict per image under root_save_path/class_code/image_id —
+    the on-disk pseudo-label format the part-distillation dataset reads (COCO RLE dicts with utf-8 counts)."""
+    from .utils import rle
+    masks = instance.pred_masks.cpu()
+    H, W = masks.shape[1:]
+    res = {"file_name": inp["file_name"], "image_id": inp["image_id"], "class_code": inp["class_code"], "height": H, "width": W,
+           "part_masks": rle.masks_to_coco_json(masks), "part_labels": instance.pred_classes.cpu(),
+           "object_ratio": masks.sum().long().item() / (H * W), "part_ratios": masks.flatten(1).sum(-1) / (H * W),
+           "object_class_label": int(label), "part_scores": instance.scores.cpu().numpy()}
+    _save_dict(model.root_save_path, inp, res)
+    return res
+
+
+def save_part_segmentation(model, inp, instance):
+    """reference part_distillation_model.py:290-307"""
+    from .utils import rle
+    masks = instance.pred_masks.cpu()
+    H, W = masks.shape[1:]
+    object_area = masks.sum().long().item()
+    res = {"file_name": inp["file_name"], "image_id": inp["image_id"], "class_code": inp["class_code"], "height": H, "width": W,
+           "part_masks": rle.masks_to_coco_json(masks), "part_labels": instance.pred_classes.cpu(),
+           "part_area_ratios": masks.flatten(1).sum(-1).long() / object_area, "object_ratio": object_area / (H * W),
+           "part_scores": instance.scores.cpu().numpy()}
+    _save_dict(model.root_save_path, inp, res)
+    return res
+

@@ -38,6 +38,9 @@ class PartDistillationModel(_MaskFormerTrainBase):
         self.min_pseudo_mask_ratio, self.min_pseudo_mask_score = minimum_pseudo_mask_ratio, minimum_pseudo_mask_score
         self.majority_vote_mapping = {}
         self.current_test_iteration = 0
+        # mode "save" writes one label file per image below this directory (reference :97-99; created on first use)
+        self.root_save_path = "pseudo_labels/part_labels/part_distillation_predictions/{}/{}_{}/".format(
+            dataset_name, minimum_pseudo_mask_score, minimum_pseudo_mask_ratio)
 
     def update_majority_vote_mapping(self, mapping_dict):
         """reference :160-163: object class id -> LongTensor [num_part_classes] of merged part labels (from part ranking)"""
@@ -76,9 +79,11 @@ class PartDistillationModel(_MaskFormerTrainBase):
         features = self.backbone(images.tensor)
         if not self.training:                                           # evaluation branch (reference :227-236)
             from .inference import pd_inference, prepare_pd_gt_targets
-            if self.mode == "save":
-                raise NotImplementedError("PartDistillationModel mode 'save' (pseudo-label export, reference :291-316) is not built")
-            targets = prepare_pd_gt_targets(self, batched_inputs, images)
+            if self.mode == "save":                                     # pseudo-label export runs on the pseudo targets (:397-399)
+                targets = [{"labels": t["labels"], "masks": t["masks"], "object_mask": t["object_masks"],
+                            "gt_object_class": torch.as_tensor(t["gt_object_class"])} for t in self._prepare_pseudo_targets(batched_inputs, images)]
+            else:
+                targets = prepare_pd_gt_targets(self, batched_inputs, images)
             head_targets = [{"gt_object_class": int(t["gt_object_class"])} for t in targets]
             self.current_test_iteration += 1
             return pd_inference(self, batched_inputs, targets, images, self.sem_seg_head(features, mask=head_targets))

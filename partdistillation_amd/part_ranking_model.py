@@ -3,7 +3,8 @@ evaluation-only — the part-proposal network's forward, then either
   mode "cluster": per-image part proposals with their (L2-normalised) decoder query features, for the clustering module
                   (evaluation/clustering_module.py) that turns them into per-object-class K-means centroids, or
   mode "" / "eval": nearest-centroid part classes for the proposals (register_classifier), merged per class, optionally
-                  renamed through the majority-vote mapping.
+                  renamed through the majority-vote mapping;  mode "save": the same, and every image's labelled parts are
+                  written as the COCO-RLE label file the part-distillation stage trains on (:262-279).
 All post-processing stays on the device (inference.py: rank_*)."""
 from typing import Tuple
 
@@ -42,6 +43,9 @@ class PartRankingModel(nn.Module):
         self.min_pseudo_mask_score_2, self.min_pseudo_mask_ratio_2 = min_pseudo_mask_score_2, min_pseudo_mask_ratio_2
         self.fg_score_threshold, self.num_clusters = fg_score_threshold, num_clusters
         self.dataset_name, self.debug = dataset_name, debug
+        # mode "save" writes one label file per image below this directory (reference :99-100; created on first use)
+        self.root_save_path = "pseudo_labels/part_labels/part_masks_with_class/{}/{}_{}/".format(
+            dataset_name.replace("_pre_labeling", "") if not debug else "debug", classifier_metric, num_clusters)
         self.classifier = {}                     # object class id -> centroids [num_clusters, C] on the device
         self.majority_vote_mapping = {}
         predictor = getattr(sem_seg_head, "predictor", None)

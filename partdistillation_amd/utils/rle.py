@@ -111,3 +111,15 @@ def runs_to_coco_json(values: np.ndarray, lengths: np.ndarray, size, present) ->
                 counts = np.concatenate(([0], counts))
         out.append({"segmentation": {"size": [h, w], "counts": counts_to_string(counts).decode("utf-8")}})
     return out
+
+
+def masks_to_coco_json(masks) -> list:
+    """bool [n, h, w] (numpy or CPU tensor) -> list[{"segmentation": rle}] with utf-8 `counts`: the reference's
+    utils/utils.py:15-32 proposals_to_coco_json (pycocotools encode of every mask)."""
+    out = []
+    for m in np.asarray(masks).astype(bool):
+        r = encode(m)
+        r["counts"] = r["counts"].decode("utf-8")
+        out.append({"segmentation": r})
+    return out
+

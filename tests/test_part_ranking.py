@@ -131,7 +131,7 @@ def test_product_inference_vs_reference_golden(golden, tag, mode, metric, unique
 
 
 @pytest.mark.gpu
-def test_part_ranking_end_to_end_on_the_device():
+def test_part_ranking_end_to_end_on_the_device(tmp_path):
     """cluster pass -> ClusteringModule -> registered nearest-centroid classifier -> labelling pass, R50 part-proposal
     network with random weights on synthetic images (plumbing of the whole stage on the device)"""
     import os
@@ -174,6 +174,16 @@ def test_part_ranking_end_to_end_on_the_device():
         p = r["predictions"]
         assert p.pred_masks.dtype == torch.bool and p.pred_classes.max() < 3 and p.pred_masks.shape[0] == p.scores.shape[0]
         assert r["gt_label"].shape[0] == 20
-    model.mode = "save"
-    with pytest.raises(NotImplementedError):
-        model(batch)
+    model.mode, model.root_save_path = "save", str(tmp_path)
+    for b, x in enumerate(batch):
+        x.update(file_name=f"img{b}.jpg", image_id=f"img{b}", class_code="n0001")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        res = model(batch)
+    from partdistillation_amd.utils import rle
+    for b, r in enumerate(res):                                        # the label file holds exactly the returned parts
+        saved = torch.load(tmp_path / "n0001" / f"img{b}", weights_only=False)
+        p = r["predictions"]
+        assert saved["object_class_label"] == 5 and saved["height"] == 128 and len(saved["part_masks"]) == p.pred_masks.shape[0]
+        back = torch.stack([torch.from_numpy(rle.decode(m["segmentation"])) for m in saved["part_masks"]])
+        assert torch.equal(back, p.pred_masks.cpu()) and torch.equal(saved["part_labels"], p.pred_classes.cpu())
+        assert isinstance(saved["part_masks"][0]["segmentation"]["counts"], str)

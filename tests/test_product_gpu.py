@@ -470,6 +470,21 @@ def test_part_distillation_swin_train_steps():
         assert p.pred_masks.dtype == torch.bool and p.pred_masks.shape[0] == p.scores.shape[0] == p.pred_classes.shape[0] >= 1
         assert int(p.pred_classes.max()) <= 8 and not (p.pred_masks & ~e["instances"].gt_masks.tensor.to(DEV)).any()
         assert int(r["gt_object_label"]) == int(e["instances"].gt_classes)
+    # mode "save" (reference :270-271, 290-307, 397-399): inference on the pseudo targets + one label file per image
+    import tempfile
+    from partdistillation_amd.utils import rle
+    with tempfile.TemporaryDirectory() as tmp:
+        model.mode, model.root_save_path = "save", tmp
+        sv = [dict(b, file_name=f"im{i}.jpg", image_id=f"im{i}", class_code="n77") for i, b in enumerate(batch)]
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            res = model(sv)
+        for i, r in enumerate(res):
+            saved = torch.load(_os.path.join(tmp, "n77", f"im{i}"), weights_only=False)
+            p = r["predictions"]
+            back = torch.stack([torch.from_numpy(rle.decode(m["segmentation"])) for m in saved["part_masks"]])
+            assert torch.equal(back, p.pred_masks.cpu()) and torch.equal(saved["part_labels"], p.pred_classes.cpu())
+            assert set(saved) == {"file_name", "image_id", "class_code", "height", "width", "part_masks", "part_labels",
+                                  "part_area_ratios", "object_ratio", "part_scores"}
 
 
 def test_loss_curve_matches_oracle_over_optimizer_steps():

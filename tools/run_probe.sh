@@ -1,5 +1,3 @@
 mkdir -p gpurun_out
-timeout 600 python tools/bench_config3.py 1024 8 > gpurun_out/config3_wg.log 2>&1
-tail -1 gpurun_out/config3_wg.log
-PD_CONFIG=swinl timeout 600 python tools/bench_config3.py 1280 6 > gpurun_out/config5_wg.log 2>&1
-tail -1 gpurun_out/config5_wg.log
+timeout 1200 python -m pytest tests/test_part_ranking.py tests/test_product_gpu.py tests/test_propgen_gpu.py -x -q -m gpu > gpurun_out/save_test.log 2>&1
+tail -15 gpurun_out/save_test.log
