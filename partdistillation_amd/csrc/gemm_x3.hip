@@ -1,0 +1,174 @@
+// fp32 GEMM on the bf16 matrix cores: every fp32 operand element is split EXACTLY into three bf16 values
+//     x = hi + mid + lo,   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)     (3 x 8 significand bits = fp32's 24)
+// when a tile is staged in LDS, and a product a*b is accumulated in fp32 as six bf16 MFMA terms
+//     lo_a hi_b + hi_a lo_b + mid_a mid_b + mid_a hi_b + hi_a mid_b + hi_a hi_b
+// (each bf16 x bf16 product is exact in fp32; the three dropped terms mid*lo, lo*mid, lo*lo are <= 2^-23 |a b| together —
+// the size of ONE fp32 rounding of the product).  v_mfma_f32_32x32x16_bf16 runs 16 x the rate of v_mfma_f32_32x32x2_f32,
+// so six of them per step are 2.7x the exact-fp32 matrix rate: the fp32 Linears of the deformable-attention encoder
+// (reference msdeformattn.py:120-135, forced fp32 by :318) get matrix-core speed without giving up fp32 results
+// (measured against fp64 in tests/test_gemm_gpu.py: error at the level of the library's fp32 GEMM).
+//
+//   gemm_tn_f32x3   C[M,N] = A[M,K] B[N,K]^T (+bias)(ReLU)   128 x 128 x 16 tiles, 4 waves (2x2) x (2x2) MFMA tiles
+// Two LDS stages of three bf16 planes per operand; the next tile's global loads are issued before the MFMAs of the
+// current one, split and written to the other stage after them (one barrier per 16-wide step).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mfma_bf16.h"
+#include "pd_common.h"
+#include "pd_gemm.h"
+#include "pd_msda.h"
+
+namespace {
+using namespace pdmfma;
+
+constexpr int BM = 128, BN = 128, BK = 16, PITCH = BK + 4;      // bf16 elements per LDS row (40 bytes: 8-byte reads of 32 rows conflict-free)
+
+struct Split4 { uint2 hi, mid, lo; };                            // 4 consecutive k of one row, per plane
+
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l)
+{
+  h = pk_bf16(x0, x1);
+  const float r0 = x0 - bf_lo(h), r1 = x1 - bf_hi(h);           // exact (Sterbenz / leading bits cancel)
+  m = pk_bf16(r0, r1);
+  l = pk_bf16(r0 - bf_lo(m), r1 - bf_hi(m));                    // the remainder has <= 8 significant bits: exact
+}
+__device__ __forceinline__ Split4 split4(float4 v)
+{
+  Split4 s;
+  split2(v.x, v.y, s.hi.x, s.mid.x, s.lo.x);
+  split2(v.z, v.w, s.hi.y, s.mid.y, s.lo.y);
+  return s;
+}
+typedef __bf16 hwbf16x8 __attribute__((ext_vector_type(8)));
+// operand of v_mfma_f32_32x32x16_bf16 (the gfx950 double-K form: 32 cycles per SIMD, twice the rate of the 32x32x8 form):
+// lane l holds 8 consecutive k of row l % 32, starting at 8 * (l / 32) of the 16-wide step.  Two 8-byte LDS reads (the
+// 72-byte row pitch is conflict-free for those).
+__device__ __forceinline__ hwbf16x8 frag(const bf16_t *p)
+{
+  union { uint2 h[2]; hwbf16x8 v; } u;
+  u.h[0] = *reinterpret_cast<const uint2 *>(p);
+  u.h[1] = *reinterpret_cast<const uint2 *>(p + 4);
+  return u.v;
+}
+__device__ __forceinline__ void mma16k(f32x16 &c, hwbf16x8 x, hwbf16x8 y) { c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0); }
+
+__device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
+
+template <bool RELU, int ABL>
+__global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict__ A, const float *__restrict__ B,
+                                                         const float *__restrict__ bias, float *__restrict__ C, int M, int N,
+                                                         int K, int lda, int ldb, int ldc, int ntiles_n)
+{
+  __shared__ __attribute__((aligned(16))) bf16_t As[2][3][BM][PITCH];      // two stages x three planes
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[2][3][BN][PITCH];
+  const int lb = xcd_chunk(blockIdx.x, gridDim.x);
+  const int m0 = (lb / ntiles_n) * BM, n0 = (lb % ntiles_n) * BN;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int lr = t >> 2, lk = (t & 3) * 4;                       // rows lr + 64 j, columns lk .. lk+3 of both tiles
+  float4 ra[2][2], rb[2][2];                                     // two register stages: loads run two steps ahead of their use
+  auto gload = [&](int s, int k0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = lr + 64 * j, k = k0 + lk;
+      ra[s][j] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4 *>(A + (int64_t)(m0 + r) * lda + k) : make_float4(0, 0, 0, 0);
+      rb[s][j] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4 *>(B + (int64_t)(n0 + r) * ldb + k) : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int s, int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      Split4 a, b;
+      if (ABL == 3) { a.hi = make_uint2(pk_bf16(ra[s][j].x, ra[s][j].y), pk_bf16(ra[s][j].z, ra[s][j].w)); a.mid = a.lo = make_uint2(0, 0);
+                      b.hi = make_uint2(pk_bf16(rb[s][j].x, rb[s][j].y), pk_bf16(rb[s][j].z, rb[s][j].w)); b.mid = b.lo = make_uint2(0, 0); }
+      else { a = split4(ra[s][j]); b = split4(rb[s][j]); }
+      const int r = lr + 64 * j;
+      *reinterpret_cast<uint2 *>(&As[buf][0][r][lk]) = a.hi; *reinterpret_cast<uint2 *>(&As[buf][1][r][lk]) = a.mid; *reinterpret_cast<uint2 *>(&As[buf][2][r][lk]) = a.lo;
+      *reinterpret_cast<uint2 *>(&Bs[buf][0][r][lk]) = b.hi; *reinterpret_cast<uint2 *>(&Bs[buf][1][r][lk]) = b.mid; *reinterpret_cast<uint2 *>(&Bs[buf][2][r][lk]) = b.lo;
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int KT = (K + BK - 1) / BK;
+  gload(0, 0);
+  if (KT > 1) gload(1, BK);
+  lstore(0, 0);
+  __syncthreads();
+  const int fr = lane & 31, fk = (lane >> 5) * 8;
+  // step kt computes from LDS stage kt & 1, writes tile kt + 1 (register stage (kt + 1) & 1, loaded during step kt - 1) to the
+  // other LDS stage and issues the loads of tile kt + 2 into the register stage it has just freed
+  auto step = [&](int kt, int par) {
+    hwbf16x8 a[3][2], b[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[p][i] = frag(&As[par][p][wm + i * 32 + fr][fk]);
+        b[p][i] = frag(&Bs[par][p][wn + i * 32 + fr][fk]);
+      }
+    // one partial product at a time over the four accumulators (consecutive MFMAs independent); smallest terms first
+#define TERM(PA, PB)                                                         \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) mma16k(acc[i][j], a[PA][i], b[PB][j]);
+    if (ABL != 1 && ABL != 2) { TERM(2, 0) TERM(0, 2) TERM(1, 1) TERM(1, 0) TERM(0, 1) }
+    if (ABL != 1) { TERM(0, 0) }
+#undef TERM
+    if (ABL == 1) acc[0][0][0] += (float)a[0][0][0] + (float)b[2][1][1] + (float)a[1][1][2] + (float)b[1][0][3] + (float)a[2][0][5] + (float)b[0][0][7];
+    if (kt + 1 < KT) lstore(par ^ 1, par ^ 1);
+    if (kt + 2 < KT) gload(par, (kt + 2) * BK);
+    __syncthreads();
+  };
+  for (int kt = 0; kt < KT; kt += 2) {
+    step(kt, 0);
+    if (kt + 1 < KT) step(kt + 1, 1);
+  }
+  // C layout of the 32x32 MFMA: col = lane & 31 (B row), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (A row)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn + j * 32 + (lane & 31);
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < M) {
+          float v = acc[i][j][e] + bv;
+          if (RELU) v = fmaxf(v, 0.f);
+          C[(int64_t)row * ldc + col] = v;
+        }
+      }
+  }
+}
+}  // namespace
+
+int g_pd_dbg_x3 = 0;   // tools/ only (pd_debug_set "x3_ablate"): 1 no MFMA, 2 only hi*hi, 3 no operand split
+
+extern "C" int pd_gemm_tn_f32x3(const float *A, const float *B, const float *bias, float *C, int M, int N, int K, int lda,
+                                int ldb, int ldc, int relu, void *stream_)
+{
+  if (M < 0 || N < 0 || K < 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f32x3: negative size");
+  if (M == 0 || N == 0) return PD_OK;
+  if (!A || !B || !C) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f32x3: null pointer");
+  if ((K & 3) || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f32x3: K, lda, ldb must be multiples of 4 and A, B 16-byte aligned");
+  const int tn = (N + BN - 1) / BN, tm = (M + BM - 1) / BM;
+  const dim3 g((unsigned)((int64_t)tm * tn)), b(256);
+  hipStream_t st = (hipStream_t)stream_;
+#define LAUNCH(R, AB) hipLaunchKernelGGL((gemm_tn_f32x3<R, AB>), g, b, 0, st, A, B, bias, C, M, N, K, lda, ldb, ldc, tn)
+  if (g_pd_dbg_x3 == 1) LAUNCH(false, 1);
+  else if (g_pd_dbg_x3 == 2) LAUNCH(false, 2);
+  else if (g_pd_dbg_x3 == 3) LAUNCH(false, 3);
+  else if (relu) LAUNCH(true, 0);
+  else LAUNCH(false, 0);
+#undef LAUNCH
+  return pd_check_launch("pd_gemm_tn_f32x3");
+}

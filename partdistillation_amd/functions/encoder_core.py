@@ -20,7 +20,7 @@ from torch.autograd import Function
 from .. import MultiScaleDeformableAttention as MSDA
 from .. import lib as _lib
 from . import rowwise as rw
-from .gemm import gemm_wgrad_acc
+from .gemm import gemm_tn_x3, gemm_wgrad_acc
 
 def _timed(kind, fn, *args):
     # bench.py's per-launch HIP-event hook lives next to the autograd face of the operator (imported lazily: that module
@@ -61,6 +61,21 @@ class EncoderSpec:
         self.ref, self.shapes, self.lsi = reference_points, spatial_shapes, level_start_index
 
 
+USE_X3 = True        # the FFN GEMMs (1024-wide) through pd_gemm_tn_f32x3; tools / tests switch it off to compare
+
+
+def _ffn_gemm(x, w, b=None, relu=False):
+    """x [T, K] @ w [N, K]^T (+ b) (ReLU), fp32.  The two FFN GEMMs of an encoder layer and their input gradients are the
+    large ones of the layer (22.5 GFLOP each at config 2): they run on the bf16 matrix cores with every fp32 operand split
+    exactly into three bf16 values (include/pd_gemm.h: pd_gemm_tn_f32x3, error vs fp64 at the library fp32 GEMM's level;
+    measured 174 vs 211 us and 166 vs 183 us).  The 256-wide projections stay with the library (no gain there)."""
+    if USE_X3 and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.shape[1] % 4 == 0:
+        return gemm_tn_x3(x, w, b, relu)
+    if relu:
+        return torch._addmm_activation(b, x, w.t(), use_gelu=False)
+    return torch.addmm(b, x, w.t()) if b is not None else torch.mm(x, w.t())
+
+
 class EncoderCore(Function):
     @staticmethod
     def forward(ctx, spec: EncoderSpec, src, pos, *params):
@@ -89,9 +104,9 @@ class EncoderCore(Function):
             v4, loc6, attn5 = value.view(B, S, M, C // M), loc.view(B, S, M, L, P, 2), attn.view(B, S, M, L, P)
             a = _timed("fwd", MSDA.ms_deform_attn_forward, v4, spec.shapes, spec.lsi, loc6, attn5, spec.im2col_step).view(T, C)
             z1, y1, _, _, m1, r1 = rw.add_ln_fwd(torch.addmm(op_b, a, op_w.t()), x, n1_w, n1_b, spec.eps)
-            h = torch._addmm_activation(l1_b, y1, l1_w.t(), use_gelu=False)          # bias + ReLU in the GEMM epilogue
+            h = _ffn_gemm(y1, l1_w, l1_b, relu=True)                                 # bias + ReLU in the GEMM epilogue
             last = i == nl - 1
-            z2, y2, _, ypos, m2, r2 = rw.add_ln_fwd(torch.addmm(l2_b, h, l2_w.t()), y1, n2_w, n2_b, spec.eps, c_dtype=torch.float32,
+            z2, y2, _, ypos, m2, r2 = rw.add_ln_fwd(_ffn_gemm(h, l2_w, l2_b), y1, n2_w, n2_b, spec.eps, c_dtype=torch.float32,
                                                     pos=pos2, pos_div=1, want_ypos=not last)
             saved.append((x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, w_oa))
             x, q = y2, ypos
@@ -138,9 +153,9 @@ class EncoderCore(Function):
             dz2, _ = rw.add_ln_bwd(z2, m2, r2, n2_w, dy=dy, dy2=dy2, dypos_c=dyq, dgamma=g_n2w, dbeta=g_n2b, dbias=g_l2b,
                                    dpos_acc=d_pos if dyq is not None else None, pos_div=1)
             gemm_wgrad_acc(dz2, h, g_l2w)
-            dh = rw.relu_bwd_colsum(torch.mm(dz2, l2_w), h, g_l1b)
+            dh = rw.relu_bwd_colsum(_ffn_gemm(dz2, l2_w.t().contiguous()), h, g_l1b)
             gemm_wgrad_acc(dh, y1, g_l1w)
-            dy1 = torch.mm(dh, l1_w)
+            dy1 = _ffn_gemm(dh, l1_w.t().contiguous())
             del dh
             # ---- deformable attention + norm1
             dz1, _ = rw.add_ln_bwd(z1, m1, r1, n1_w, dy=dz2, dy2=dy1, dgamma=g_n1w, dbeta=g_n1b, dbias=g_opb, out=dz2)

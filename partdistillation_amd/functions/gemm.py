@@ -25,6 +25,20 @@ def gemm_tn(a, b, bias=None, relu=False):
     return c
 
 
+def gemm_tn_x3(a, b, bias=None, relu=False):
+    """a [M,K], b [N,K] fp32 -> a @ b.T (+bias) (ReLU) with fp32-level accuracy on the bf16 matrix cores
+    (pd_gemm_tn_f32x3: exact 3-way bf16 split of every operand, 6 partial products, fp32 accumulation)."""
+    if not a.is_cuda:
+        raise RuntimeError("pd_gemm_tn_f32x3 runs on the GPU only (no CPU fallback in partdistillation_amd)")
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().pd_gemm_tn_f32x3(a.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else None, c.data_ptr(),
+                                            M, N, K, a.stride(0), b.stride(0), N, int(relu), _stream()))
+    return c
+
+
 # optional per-launch timing hook used by bench.py (HIP events on the launch stream; (start, stop, flops) per launch)
 _TIMING = {"on": False, "wgrad": []}
 

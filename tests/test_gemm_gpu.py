@@ -57,3 +57,28 @@ def test_linear_f32_autograd_matches_torch():
         torch.testing.assert_close(gw.double(), rw.double(), rtol=1e-5, atol=1e-3)
         torch.testing.assert_close(gb.double(), rb.double(), rtol=1e-5, atol=1e-3)
     G.ALL_MFMA = False
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(43008, 1024, 256, True), (43008, 256, 1024, False), (1344, 288, 256, False), (300, 70, 36, False),
+                                        (129, 257, 20, True)])
+def test_gemm_tn_x3_is_fp32_accurate(M, N, K, relu):
+    """pd_gemm_tn_f32x3 (exact 3-way bf16 split of the fp32 operands, 6 partial products on the bf16 matrix cores) against
+    fp64: its error must stay at the level of the library's own fp32 GEMM (<= 1.5x its maximum error + 1 ulp of the scale),
+    on operands with a wide dynamic range (the split is exact for any finite fp32 value)."""
+    from partdistillation_amd.functions import gemm
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g) * torch.exp(torch.randn(M, 1, device="cuda", generator=g) * 2)
+    w = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    ref = torch.addmm(b.double(), a.double(), w.double().t())
+    lib = torch.addmm(b, a, w.t())
+    if relu:
+        ref, lib = ref.relu(), lib.relu()
+    got = gemm.gemm_tn_x3(a, w, b, relu)
+    assert got.dtype == torch.float32 and got.shape == (M, N)
+    row_scale = (a.double().abs() @ w.double().abs().t() + b.double().abs())               # per-element error scale sum |a||w|
+    e_x3 = ((got.double() - ref).abs() / row_scale).max().item()
+    e_lib = ((lib.double() - ref).abs() / row_scale).max().item()
+    assert e_x3 <= 1.5 * e_lib + 2 ** -23, (e_x3, e_lib)
+    assert e_x3 < 2e-6
+
