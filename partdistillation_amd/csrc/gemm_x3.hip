@@ -55,6 +55,8 @@ __device__ __forceinline__ void mma16k(f32x16 &c, hwbf16x8 x, hwbf16x8 y) { c = 
 
 __device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
 
+__device__ __forceinline__ bool v_never(float x) { return x == 1.2345678e30f; }
+
 template <bool RELU, int ABL>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict__ A, const float *__restrict__ B,
                                                          const float *__restrict__ bias, float *__restrict__ C, int M, int N,
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict_
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (row < M) {
+        if (row < M && (ABL != 4 || v_never(acc[i][j][e]))) {
           float v = acc[i][j][e] + bv;
           if (RELU) v = fmaxf(v, 0.f);
           C[(int64_t)row * ldc + col] = v;
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict_
 }
 }  // namespace
 
-int g_pd_dbg_x3 = 0;   // tools/ only (pd_debug_set "x3_ablate"): 1 no MFMA, 2 only hi*hi, 3 no operand split
+int g_pd_dbg_x3 = 0;   // tools/ only (pd_debug_set "x3_ablate"): 1 no MFMA, 2 only hi*hi, 3 no operand split, 4 no output stores
 
 extern "C" int pd_gemm_tn_f32x3(const float *A, const float *B, const float *bias, float *C, int M, int N, int K, int lda,
                                 int ldb, int ldc, int relu, void *stream_)
@@ -167,6 +169,7 @@ extern "C" int pd_gemm_tn_f32x3(const float *A, const float *B, const float *bia
   if (g_pd_dbg_x3 == 1) LAUNCH(false, 1);
   else if (g_pd_dbg_x3 == 2) LAUNCH(false, 2);
   else if (g_pd_dbg_x3 == 3) LAUNCH(false, 3);
+  else if (g_pd_dbg_x3 == 4) LAUNCH(false, 4);
   else if (relu) LAUNCH(true, 0);
   else LAUNCH(false, 0);
 #undef LAUNCH

@@ -22,11 +22,11 @@ for M, N, K in [(43008, 256, 256), (43008, 288, 256), (43008, 1024, 256), (43008
     rms = [((y.double() - ref).pow(2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item()) for y in (y_lib, y_own, y_x3)]
     tl, to, tx = t(lambda: torch.addmm(b, a, w.t())), t(lambda: gemm.gemm_tn(a, w, b)), t(lambda: gemm.gemm_tn_x3(a, w, b))
     abl = []
-    for k in (1, 2, 3):
+    for k in (1, 2, 3, 4):
         lib.load().pd_debug_set(b"x3_ablate", k)
         abl.append("%d:%.0f" % (k, t(lambda: gemm.gemm_tn_x3(a, w, b))))
     lib.load().pd_debug_set(b"x3_ablate", 0)
-    print("      x3 ablations (1 no MFMA, 2 hi*hi only, 3 no split):", " ".join(abl))
+    print("      x3 ablations (1 no MFMA, 2 hi*hi only, 3 no split, 4 no stores):", " ".join(abl))
     gf = 2.0 * M * N * K / 1e9
     print(f"M={M:6d} N={N:4d} K={K:4d}: library {tl:6.1f} us ({gf/tl*1e-3:5.1f} TF) | exact MFMA {to:6.1f} us | x3 {tx:6.1f} us ({gf/tx*1e-3:5.1f} TF)"
           f" | max err/scale lib {e[0]:.2e} own {e[1]:.2e} x3 {e[2]:.2e} | rel rms lib {rms[0]:.2e} x3 {rms[2]:.2e}")
