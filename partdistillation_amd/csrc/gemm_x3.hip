@@ -78,18 +78,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict_
       rb[s][j] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4 *>(B + (int64_t)(n0 + r) * ldb + k) : make_float4(0, 0, 0, 0);
     }
   };
-  auto lstore = [&](int s, int buf) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      Split4 a, b;
-      if (ABL == 3) { a.hi = make_uint2(pk_bf16(ra[s][j].x, ra[s][j].y), pk_bf16(ra[s][j].z, ra[s][j].w)); a.mid = a.lo = make_uint2(0, 0);
-                      b.hi = make_uint2(pk_bf16(rb[s][j].x, rb[s][j].y), pk_bf16(rb[s][j].z, rb[s][j].w)); b.mid = b.lo = make_uint2(0, 0); }
-      else { a = split4(ra[s][j]); b = split4(rb[s][j]); }
-      const int r = lr + 64 * j;
-      *reinterpret_cast<uint2 *>(&As[buf][0][r][lk]) = a.hi; *reinterpret_cast<uint2 *>(&As[buf][1][r][lk]) = a.mid; *reinterpret_cast<uint2 *>(&As[buf][2][r][lk]) = a.lo;
-      *reinterpret_cast<uint2 *>(&Bs[buf][0][r][lk]) = b.hi; *reinterpret_cast<uint2 *>(&Bs[buf][1][r][lk]) = b.mid; *reinterpret_cast<uint2 *>(&Bs[buf][2][r][lk]) = b.lo;
-    }
+  // split + store one staged float4 (operand 0 = A, 1 = B; j = which of the thread's two rows) of register stage s into LDS
+  // stage buf.  Issued in four pieces BETWEEN the MFMA groups of a step: the matrix pipe works ~128 cycles on a group of
+  // four, the ~25 VALU operations of a piece run in that shadow.
+  auto lstore1 = [&](int s, int buf, int op, int j) {
+    const float4 v = op == 0 ? ra[s][j] : rb[s][j];
+    Split4 x;
+    if (ABL == 3) { x.hi = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)); x.mid = x.lo = make_uint2(0, 0); }
+    else x = split4(v);
+    const int r = lr + 64 * j;
+    bf16_t(*P)[BM][PITCH] = op == 0 ? As[buf] : Bs[buf];
+    *reinterpret_cast<uint2 *>(&P[0][r][lk]) = x.hi; *reinterpret_cast<uint2 *>(&P[1][r][lk]) = x.mid; *reinterpret_cast<uint2 *>(&P[2][r][lk]) = x.lo;
   };
+  auto lstore = [&](int s, int buf) { lstore1(s, buf, 0, 0); lstore1(s, buf, 0, 1); lstore1(s, buf, 1, 0); lstore1(s, buf, 1, 1); };
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -119,11 +120,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict_
 #define TERM(PA, PB)                                                         \
   _Pragma("unroll") for (int i = 0; i < 2; ++i)                              \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) mma16k(acc[i][j], a[PA][i], b[PB][j]);
-    if (ABL != 1 && ABL != 2) { TERM(2, 0) TERM(0, 2) TERM(1, 1) TERM(1, 0) TERM(0, 1) }
+    const bool more = kt + 1 < KT;
+    if (ABL != 1 && ABL != 2) {
+      TERM(2, 0) if (more) lstore1(par ^ 1, par ^ 1, 0, 0);
+      TERM(0, 2) if (more) lstore1(par ^ 1, par ^ 1, 0, 1);
+      TERM(1, 1) if (more) lstore1(par ^ 1, par ^ 1, 1, 0);
+      TERM(1, 0) if (more) lstore1(par ^ 1, par ^ 1, 1, 1);
+      TERM(0, 1)
+    } else if (more) lstore(par ^ 1, par ^ 1);
     if (ABL != 1) { TERM(0, 0) }
 #undef TERM
     if (ABL == 1) acc[0][0][0] += (float)a[0][0][0] + (float)b[2][1][1] + (float)a[1][1][2] + (float)b[1][0][3] + (float)a[2][0][5] + (float)b[0][0][7];
-    if (kt + 1 < KT) lstore(par ^ 1, par ^ 1);
     if (kt + 2 < KT) gload(par, (kt + 2) * BK);
     __syncthreads();
   };
