@@ -38,6 +38,11 @@ int pd_gemm_wgrad_f32(const float *dY, const float *X, float *dW, float *dB, int
 int pd_gemm_wgrad_acc_f32(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx,
                           int ldw, void *stream);
 
+/* pd_gemm_wgrad_acc_f32 with the 3-way bf16 split (see pd_gemm_tn_f32x3): dW += dY^T X, dB += column sums of dY (exact fp32
+ * adds), accumulated into caller-initialised buffers.  Any N, K, M >= 0; no alignment requirement (scalar loads). */
+int pd_gemm_wgrad_acc_f32x3(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx, int ldw,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,6 +157,105 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict_
       }
   }
 }
+
+// ---------------------------------------------------------------------------------------------- weight gradient
+// dW[N,K] += dY[M,N]^T X[M,K] contracts over the ROWS, so an MFMA operand (8 consecutive contraction elements per lane) is
+// 8 consecutive rows of one column: the tiles are staged TRANSPOSED, [column][row pair] with the two rows of a pair packed
+// in one dword (they are the low / high bf16 of the pair's split).  A lane stages one column (scalar 4-byte loads, 256
+// contiguous bytes per wave instruction) so the 32 lanes of a write hit 32 different banks (row pitch 9 dwords, odd).
+constexpr int WS = 16, WPD = WS / 2 + 1;                         // rows per stage, dwords per LDS row
+
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3(const float *__restrict__ dY, const float *__restrict__ X,
+                                                            float *__restrict__ dW, float *__restrict__ dB, int M, int N, int K,
+                                                            int ldy, int ldx, int ldw, int tiles_k, int tiles, int m_chunk)
+{
+  __shared__ unsigned Yt[2][3][BN][WPD];
+  __shared__ unsigned Xt[2][3][BM][WPD];
+  const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+  const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BM;
+  const int mb = split * m_chunk, me = min(M, mb + m_chunk);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+  const int col = t & 127, pg = (t >> 7) * 4;                    // this thread: column `col`, row pairs pg .. pg+3 of the stage
+  const bool ycol_ok = n0 + col < N, xcol_ok = k0 + col < K;
+  float ry[2][8], rx[2][8];                                      // two register stages
+  auto gload = [&](int s, int m) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = m + 2 * pg + q;
+      ry[s][q] = (r < me && ycol_ok) ? dY[(int64_t)r * ldy + n0 + col] : 0.f;
+      rx[s][q] = (r < me && xcol_ok) ? X[(int64_t)r * ldx + k0 + col] : 0.f;
+    }
+  };
+  const bool do_bias = dB != nullptr && k0 == 0;
+  float bsum = 0.f;
+  auto lstore = [&](int s, int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned h, m_, l;
+      split2(ry[s][2 * q], ry[s][2 * q + 1], h, m_, l);
+      Yt[buf][0][col][pg + q] = h; Yt[buf][1][col][pg + q] = m_; Yt[buf][2][col][pg + q] = l;
+      split2(rx[s][2 * q], rx[s][2 * q + 1], h, m_, l);
+      Xt[buf][0][col][pg + q] = h; Xt[buf][1][col][pg + q] = m_; Xt[buf][2][col][pg + q] = l;
+      if (do_bias) bsum += ry[s][2 * q] + ry[s][2 * q + 1];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int steps = (me - mb + WS - 1) / WS;
+  if (steps > 0) {
+    gload(0, mb);
+    if (steps > 1) gload(1, mb + WS);
+    lstore(0, 0);
+  }
+  __syncthreads();
+  const int fr = lane & 31, fd = (lane >> 5) * 4;                // operand: column fr of a 32-block, row pairs fd .. fd+3 (8 rows)
+  auto frag4 = [&](const unsigned *p) {
+    union { unsigned d[4]; hwbf16x8 v; } u;
+    u.d[0] = p[0]; u.d[1] = p[1]; u.d[2] = p[2]; u.d[3] = p[3];
+    return u.v;
+  };
+  auto step = [&](int st, int par) {
+    hwbf16x8 a[3][2], b[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[p][i] = frag4(&Yt[par][p][wn + i * 32 + fr][fd]);
+        b[p][i] = frag4(&Xt[par][p][wk + i * 32 + fr][fd]);
+      }
+#define TERM(PA, PB)                                                         \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) mma16k(acc[i][j], a[PA][i], b[PB][j]);
+    TERM(2, 0) TERM(0, 2) TERM(1, 1) TERM(1, 0) TERM(0, 1) TERM(0, 0)
+#undef TERM
+    if (st + 1 < steps) lstore(par ^ 1, par ^ 1);
+    if (st + 2 < steps) gload(par, mb + (st + 2) * WS);
+    __syncthreads();
+  };
+  for (int st = 0; st < steps; st += 2) {
+    step(st, 0);
+    if (st + 1 < steps) step(st + 1, 1);
+  }
+  if (do_bias && ycol_ok) unsafeAtomicAdd(dB + n0 + col, bsum);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = k0 + wk + j * 32 + (lane & 31);
+    if (c >= K) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = n0 + wn + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < N) unsafeAtomicAdd(dW + (int64_t)row * ldw + c, acc[i][j][e]);
+      }
+  }
+}
 }  // namespace
 
 int g_pd_dbg_x3 = 0;   // tools/ only (pd_debug_set "x3_ablate"): 1 no MFMA, 2 only hi*hi, 3 no operand split, 4 no output stores
@@ -182,3 +281,22 @@ extern "C" int pd_gemm_tn_f32x3(const float *A, const float *B, const float *bia
 #undef LAUNCH
   return pd_check_launch("pd_gemm_tn_f32x3");
 }
+
+extern "C" int pd_gemm_wgrad_acc_f32x3(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx,
+                                       int ldw, void *stream_)
+{
+  if (M < 0 || N < 0 || K < 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_wgrad_acc_f32x3: negative size");
+  if (N == 0 || K == 0 || M == 0) return PD_OK;
+  if (!dW || !dY || !X) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_wgrad_acc_f32x3: null pointer");
+  const int tk = (K + BM - 1) / BM, tn = (N + BN - 1) / BN, tiles = tk * tn;
+  // the contraction is split over workgroups (each ends in a tile of atomics): ~4 workgroups per CU, fewer for few tiles
+  const int target = tiles <= 4 ? 256 : 1024;
+  int splits = (target + tiles - 1) / tiles;
+  int m_chunk = ((M + splits - 1) / splits + WS - 1) / WS * WS;
+  if (m_chunk < 4 * WS) m_chunk = 4 * WS;
+  splits = (M + m_chunk - 1) / m_chunk;
+  hipLaunchKernelGGL(gemm_wgrad_f32x3, dim3((unsigned)(tiles * splits)), dim3(256), 0, (hipStream_t)stream_, dY, X, dW, dB, M, N, K, ldy,
+                     ldx, ldw, tk, tiles, m_chunk);
+  return pd_check_launch("pd_gemm_wgrad_acc_f32x3");
+}
+

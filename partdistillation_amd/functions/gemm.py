@@ -53,16 +53,25 @@ def timing():
     return [(a.elapsed_time(b), f) for a, b, f in _TIMING["wgrad"]]
 
 
-def gemm_wgrad_acc(dy, x, dw, db=None):
-    """dw [N,K] += dy.T @ x, db [N] += dy.sum(0): accumulates into caller-initialised fp32 buffers (no memset launches)."""
+WGRAD_X3 = False     # True: weight gradients through the 3-way bf16 split kernel (pd_gemm_wgrad_acc_f32x3).  Measured at parity
+                     # with the exact-fp32 MFMA kernel (224 vs 223 us at 43008 x 1024 x 256: the transposed staging, not the
+                     # matrix pipe, sets its pace), so the exact kernel stays the default.
+
+
+def gemm_wgrad_acc(dy, x, dw, db=None, x3=None):
+    """dw [N,K] += dy.T @ x, db [N] += dy.sum(0): accumulates into caller-initialised fp32 buffers (no memset launches).
+    x3 (default WGRAD_X3): the fp32-accurate kernel on the bf16 matrix cores instead of the exact-fp32 MFMA one."""
     M, N = dy.shape
     K = x.shape[1]
     assert dw.shape == (N, K) and dw.is_contiguous() and (db is None or db.numel() == N)
+    assert dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.stride(1) == 1 and x.stride(1) == 1
     if _TIMING["on"]:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-    _lib.check(_lib.load().pd_gemm_wgrad_acc_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
-                                                 M, N, K, dy.stride(0), x.stride(0), K, _stream()))
+    L = _lib.load()
+    fn = L.pd_gemm_wgrad_acc_f32x3 if (WGRAD_X3 if x3 is None else x3) else L.pd_gemm_wgrad_acc_f32
+    _lib.check(fn(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
+                  M, N, K, dy.stride(0), x.stride(0), K, _stream()))
     if _TIMING["on"]:
         b.record()
         _TIMING["wgrad"].append((a, b, 2.0 * M * N * K))

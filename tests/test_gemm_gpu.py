@@ -82,3 +82,29 @@ def test_gemm_tn_x3_is_fp32_accurate(M, N, K, relu):
     assert e_x3 <= 1.5 * e_lib + 2 ** -23, (e_x3, e_lib)
     assert e_x3 < 2e-6
 
+
+@pytest.mark.parametrize("M,N,K,bias", [(43008, 1024, 256, True), (43008, 256, 1024, False), (5000, 288, 256, True), (333, 70, 36, True),
+                                        (17, 130, 257, False), (64, 128, 128, True)])
+def test_gemm_wgrad_x3_is_fp32_accurate(M, N, K, bias):
+    """pd_gemm_wgrad_acc_f32x3 against fp64, next to the exact-fp32 MFMA kernel it replaces: dW += dY^T X over the rows
+    (M up to 43008: errors of both are dominated by the fp32 accumulation order), dB exact fp32 column sums."""
+    from partdistillation_amd.functions import gemm
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    dy = torch.randn(M, N, device="cuda", generator=g) * torch.exp(torch.randn(M, 1, device="cuda", generator=g))
+    x = torch.randn(M, K, device="cuda", generator=g)
+    ref = dy.double().t() @ x.double()
+    outs = {}
+    for x3 in ((True, False) if N % 4 == 0 and K % 4 == 0 else (True,)):           # the exact kernel needs N, K multiples of 4
+        dw = torch.full((N, K), 0.5, device="cuda")
+        db = torch.full((N,), -1.0, device="cuda") if bias else None
+        gemm.gemm_wgrad_acc(dy, x, dw, db, x3=x3)
+        outs[x3] = (dw, db)
+    scale = (dy.double().abs().t() @ x.double().abs())
+    e_x3 = ((outs[True][0].double() - 0.5 - ref).abs() / scale).max().item()
+    if False in outs:
+        e_f32 = ((outs[False][0].double() - 0.5 - ref).abs() / scale).max().item()
+        assert e_x3 <= 2.0 * e_f32 + 2 ** -22, (e_x3, e_f32)
+    assert e_x3 < 3e-6
+    if bias:
+        torch.testing.assert_close(outs[True][1].double() + 1.0, dy.double().sum(0), rtol=1e-4, atol=1e-3 * dy.abs().max().item())
+

@@ -30,3 +30,13 @@ for M, N, K in [(43008, 256, 256), (43008, 288, 256), (43008, 1024, 256), (43008
     gf = 2.0 * M * N * K / 1e9
     print(f"M={M:6d} N={N:4d} K={K:4d}: library {tl:6.1f} us ({gf/tl*1e-3:5.1f} TF) | exact MFMA {to:6.1f} us | x3 {tx:6.1f} us ({gf/tx*1e-3:5.1f} TF)"
           f" | max err/scale lib {e[0]:.2e} own {e[1]:.2e} x3 {e[2]:.2e} | rel rms lib {rms[0]:.2e} x3 {rms[2]:.2e}")
+
+print("weight gradients (accumulating): exact-fp32 MFMA kernel vs 3-way split kernel")
+for M, N, K in [(43008, 1024, 256), (43008, 256, 1024), (43008, 256, 256), (43008, 288, 256), (67200, 1024, 256)]:
+    dy = torch.randn(M, N, device="cuda"); x = torch.randn(M, K, device="cuda")
+    dw = torch.zeros(N, K, device="cuda"); db = torch.zeros(N, device="cuda")
+    t0 = t(lambda: gemm.gemm_wgrad_acc(dy, x, dw, db, x3=False))
+    t1 = t(lambda: gemm.gemm_wgrad_acc(dy, x, dw, db, x3=True))
+    gf = 2.0 * M * N * K / 1e9
+    print(f"M={M:6d} N={N:4d} K={K:4d}: exact {t0:6.1f} us ({gf/t0*1e-3:5.1f} TF) | x3 {t1:6.1f} us ({gf/t1*1e-3:5.1f} TF)")
+
