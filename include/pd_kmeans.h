@@ -28,6 +28,18 @@ int pd_kmeans_assign(const float *X, const int32_t *blocks, int n_blocks, const 
                      const int32_t *done, int32_t *labels, float *sums, float *counts, int32_t *changed, int C, int K, void *stream);
 
 /*
+ * The same E-step without atomics (the product path): workgroup i STORES the sums / counts of its slab to
+ * partial_sums[i, K, C] / partial_counts[i, K]; pd_kmeans_reduce then adds up, for every image b that is not done, the slabs
+ * block_range[b] = (first block, number of blocks) — the image's blocks are consecutive in `blocks` — into sums[b] / counts[b]
+ * (overwritten).  ~170 workgroups per image flushing K*C same-address atomics each cost 60 us per iteration at config 4.
+ */
+int pd_kmeans_assign_partial(const float *X, const int32_t *blocks, int n_blocks, const float *centers, const float *cnorm,
+                             const int32_t *done, int32_t *labels, float *partial_sums, float *partial_counts, int32_t *changed,
+                             int C, int K, void *stream);
+int pd_kmeans_reduce(const float *partial_sums, const float *partial_counts, const int32_t *block_range, const int32_t *done,
+                     float *sums, float *counts, int B, int K, int C, void *stream);
+
+/*
  * M-step + convergence for every image b with done[b] == 0:  centers[b,k] = sums / counts (unchanged when the cluster is
  * empty), cnorm recomputed, n_iter[b] += 1, done[b] = (changed[b] == 0) || (sum_k |new - old|^2 <= tol[b]); then sums,
  * counts and changed are cleared for the next pd_kmeans_assign.

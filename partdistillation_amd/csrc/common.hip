@@ -28,7 +28,7 @@ int pd_check_launch(const char *what)
 }
 
 extern "C" const char *pd_last_error(void) { return g_err; }
-extern "C" int pd_abi_version(void) { return 12; }
+extern "C" int pd_abi_version(void) { return 13; }
 
 // experiment knobs (not part of the public ABI contract; used by tools/ only)
 extern int g_pd_dbg_atomic_scope;
@@ -39,6 +39,7 @@ extern int g_pd_dbg_bwd_threads;
 extern int g_pd_dbg_attn_scalar;
 extern int g_pd_dbg_wattn;
 extern int g_pd_dbg_x3;
+extern int g_pd_dbg_kmeans;
 extern "C" int pd_debug_set(const char *key, int value)
 {
   if (!key) return PD_ERR_INVALID_ARG;
@@ -47,6 +48,7 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!strcmp(key, "attn_scalar")) { g_pd_dbg_attn_scalar = value; return PD_OK; }
   if (!strcmp(key, "msda_bwd_threads")) { g_pd_dbg_bwd_threads = value; return PD_OK; }
   if (!strcmp(key, "wgrad_wgs")) { g_pd_dbg_wgrad_wgs = value; return PD_OK; }
+  if (!strcmp(key, "kmeans_ablate")) { g_pd_dbg_kmeans = value; return PD_OK; }
   if (!strcmp(key, "x3_ablate")) { g_pd_dbg_x3 = value; return PD_OK; }
   if (!strcmp(key, "wattn_ablate")) { g_pd_dbg_wattn = value; return PD_OK; }
   if (!strcmp(key, "msda_force_generic")) { g_pd_dbg_force_generic = value; return PD_OK; }

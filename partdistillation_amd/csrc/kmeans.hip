@@ -1,13 +1,13 @@
 // Device K-means (Lloyd) iteration, batched over images (C-ABI in include/pd_kmeans.h).
-// assign: one wavefront per point, lanes across channels (16-byte pieces); the K <= 4 dot products are 64-lane DPP /
-// shuffle reductions; every wave keeps the sums of the points it assigned in registers (K x C/64 floats per lane), the four
-// waves of a workgroup are merged through LDS and leave as one set of atomics.
+// assign: a workgroup per slab of 64 points, two passes (labels, then per-centre sums): see kmeans_assign.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "pd_common.h"
 #include "pd_kmeans.h"
 #include "pd_msda.h"
+
+int g_pd_dbg_kmeans = 0;   // tools/ only: 1 skip the label pass, 2 skip the sums pass, 4 skip its atomics
 
 namespace {
 
@@ -21,99 +21,150 @@ __device__ __forceinline__ float wave_sum(float v)
   return v;
 }
 
+// One workgroup owns a slab of <= 64 points of one image and makes TWO passes over it:
+//   A  (a wavefront per point, lanes across channels, two points in flight): label = argmin_k |c_k|^2 - 2 x.c_k with the
+//      centres read from LDS (staged once per workgroup) — the only pass that comes from HBM;
+//   B  (a thread per 4 channels, all points of the slab, which are now L2-resident): the per-centre sums of the slab in
+//      K float4 registers per thread (the label is workgroup-uniform per point: a scalar branch picks the accumulator),
+//      flushed as one set of atomics per workgroup.
+// The first version kept the K x C running sums in the assigning wave's registers (250 VGPRs, one point at a time per wave):
+// two waves per SIMD and every point's HBM latency exposed — 187 us per Lloyd iteration at 4 x 5431 x 1536, ~5x the
+// bandwidth bound.
+template <bool PARTIAL>   // PARTIAL: the slab's sums / counts are STORED to sums[blockIdx] / counts[blockIdx] (no atomics)
 __global__ __launch_bounds__(256) void kmeans_assign(const float *__restrict__ X, const int32_t *__restrict__ blocks,
                                                      const float *__restrict__ centers, const float *__restrict__ cnorm,
                                                      const int32_t *__restrict__ done, int32_t *__restrict__ labels,
                                                      float *__restrict__ sums, float *__restrict__ counts,
-                                                     int32_t *__restrict__ changed, int C, int K)
+                                                     int32_t *__restrict__ changed, int C, int K, int ablate)
 {
-  extern __shared__ __attribute__((aligned(16))) float red[];                       // [K][C] partial sums of the workgroup + K counts + 1 changed
+  extern __shared__ __attribute__((aligned(16))) float cs[];                        // [K][C] centres, then 64 slab labels + 1 changed
   const int b = blocks[blockIdx.x * 3], first = blocks[blockIdx.x * 3 + 1], npts = blocks[blockIdx.x * 3 + 2];
   if (done[b]) return;
+  int *slab = reinterpret_cast<int *>(cs + (int64_t)K * C);
+  int *rchg = slab + 64;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int npiece = (C + 255) / 256;
   const float *cb = centers + (int64_t)b * K * C;
-  float4 acc[KMAX][PMAX];
+  for (int i = threadIdx.x * 4; i < K * C; i += 1024) *reinterpret_cast<float4 *>(cs + i) = *reinterpret_cast<const float4 *>(cb + i);
+  if (threadIdx.x == 0) *rchg = 0;
+  float cn[KMAX];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k)
-#pragma unroll
-    for (int j = 0; j < PMAX; ++j) acc[k][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  float cnt[KMAX] = {0.f, 0.f, 0.f, 0.f};
-  int nchanged = 0;
-  for (int p = wave; p < npts; p += 4) {
-    const int n = first + p;
-    const float *x = X + (int64_t)n * C;
-    float4 xv[PMAX];
-    float dot[KMAX] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < PMAX; ++j) {
-      const int c = j * 256 + lane * 4;
-      xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < npiece && c < C) {
-        xv[j] = *reinterpret_cast<const float4 *>(x + c);
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-          if (k < K) {
-            const float4 cv = *reinterpret_cast<const float4 *>(cb + (int64_t)k * C + c);
-            dot[k] += xv[j].x * cv.x + xv[j].y * cv.y + xv[j].z * cv.z + xv[j].w * cv.w;
-          }
-        }
-      }
-    }
-    float best = INFINITY;
-    int arg = 0;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      if (k < K) {
-        const float s = cnorm[b * K + k] - 2.f * wave_sum(dot[k]);
-        if (s < best) { best = s; arg = k; }
-      }
-    }
-    if (lane == 0) {
-      nchanged += labels[n] != arg;
-      labels[n] = arg;
-    }
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      if (k == arg) {                                    // wave-uniform
-        cnt[k] += 1.f;
-#pragma unroll
-        for (int j = 0; j < PMAX; ++j) { acc[k][j].x += xv[j].x; acc[k][j].y += xv[j].y; acc[k][j].z += xv[j].z; acc[k][j].w += xv[j].w; }
-      }
-    }
-  }
-  // merge the four waves (one after the other) in LDS, then one set of atomics per workgroup
-  float *rcnt = red + K * C;
-  int *rchg = reinterpret_cast<int *>(rcnt + KMAX);
-  for (int w = 0; w < 4; ++w) {
-    __syncthreads();
-    if (wave == w) {
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
-        if (k < K) {
-#pragma unroll
-          for (int j = 0; j < PMAX; ++j) {
-            const int c = j * 256 + lane * 4;
-            if (j < npiece && c < C) {
-              float4 *dst = reinterpret_cast<float4 *>(red + k * C + c);
-              if (w == 0) *dst = acc[k][j];
-              else { float4 o = *dst; o.x += acc[k][j].x; o.y += acc[k][j].y; o.z += acc[k][j].z; o.w += acc[k][j].w; *dst = o; }
-            }
-          }
-          if (lane == 0) rcnt[k] = (w == 0 ? 0.f : rcnt[k]) + cnt[k];
-        }
-      }
-      if (lane == 0) *rchg = (w == 0 ? 0 : *rchg) + nchanged;
-    }
-  }
+  for (int k = 0; k < KMAX; ++k) cn[k] = k < K ? cnorm[b * K + k] : 0.f;
   __syncthreads();
-  float *sb = sums + (int64_t)b * K * C;
-  for (int i = threadIdx.x; i < K * C; i += 256) {
-    const float v = red[i];
-    if (v != 0.f) atomicAdd(sb + i, v);
+  // ---- pass A: labels
+  int nchanged = 0;
+  for (int p0 = wave; p0 < ((ablate & 1) ? 0 : npts); p0 += 8) {
+    float dot[2][KMAX];
+    float4 xv[2][PMAX];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int p = p0 + 4 * u;
+#pragma unroll
+      for (int j = 0; j < PMAX; ++j) {
+        const int c = j * 256 + lane * 4;
+        xv[u][j] = (p < npts && j < npiece && c < C) ? *reinterpret_cast<const float4 *>(X + (int64_t)(first + p) * C + c)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) dot[u][k] = 0.f;
+#pragma unroll
+      for (int j = 0; j < PMAX; ++j) {
+        const int c = j * 256 + lane * 4;
+        if (j < npiece && c < C) {
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+              const float4 cv = *reinterpret_cast<const float4 *>(cs + k * C + c);
+              dot[u][k] += xv[u][j].x * cv.x + xv[u][j].y * cv.y + xv[u][j].z * cv.z + xv[u][j].w * cv.w;
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int p = p0 + 4 * u;
+      float best = INFINITY;
+      int arg = 0;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) {
+          const float sc = cn[k] - 2.f * wave_sum(dot[u][k]);
+          if (sc < best) { best = sc; arg = k; }
+        }
+      if (lane == 0 && p < npts) {
+        nchanged += labels[first + p] != arg;
+        labels[first + p] = arg;
+        slab[p] = arg;
+      }
+    }
   }
-  if (threadIdx.x < K && rcnt[threadIdx.x] != 0.f) atomicAdd(counts + b * K + threadIdx.x, rcnt[threadIdx.x]);
+  if (lane == 0 && nchanged) atomicAdd(rchg, nchanged);
+  __syncthreads();
+  // ---- pass B: per-centre sums of the slab
+  float *sb = sums + (PARTIAL ? (int64_t)blockIdx.x : (int64_t)b) * K * C;
+  for (int c4 = threadIdx.x; c4 * 4 < ((ablate & 2) ? 0 : C); c4 += 256) {
+    float4 acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *xc = X + (int64_t)first * C + c4 * 4;
+#pragma unroll 4
+    for (int p = 0; p < npts; ++p) {
+      const float4 v = *reinterpret_cast<const float4 *>(xc + (int64_t)p * C);
+      const int l = slab[p];                                           // uniform over the workgroup
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (l == k) { acc[k].x += v.x; acc[k].y += v.y; acc[k].z += v.z; acc[k].w += v.w; }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K && PARTIAL) *reinterpret_cast<float4 *>(sb + (int64_t)k * C + c4 * 4) = acc[k];
+      else if (k < K && !(ablate & 4)) {
+        float *d = sb + (int64_t)k * C + c4 * 4;
+        if (acc[k].x != 0.f) atomicAdd(d, acc[k].x);
+        if (acc[k].y != 0.f) atomicAdd(d + 1, acc[k].y);
+        if (acc[k].z != 0.f) atomicAdd(d + 2, acc[k].z);
+        if (acc[k].w != 0.f) atomicAdd(d + 3, acc[k].w);
+      }
+  }
+  if (threadIdx.x < K) {
+    float n = 0.f;
+    for (int p = 0; p < npts; ++p) n += slab[p] == (int)threadIdx.x ? 1.f : 0.f;
+    if (PARTIAL) counts[(int64_t)blockIdx.x * K + threadIdx.x] = n;
+    else if (n != 0.f) atomicAdd(counts + b * K + threadIdx.x, n);
+  }
   if (threadIdx.x == 0 && *rchg) atomicAdd(changed + b, *rchg);
+}
+
+// sums[b] / counts[b] = sum over the image's slabs of the partial sums pd_kmeans_assign_partial stored (a thread per (k, c)
+// element, slabs of an image are consecutive workgroups): the same-address atomics of ~170 workgroups per image cost 60 us
+// per iteration, these 17 MB of plain reads a few
+__global__ __launch_bounds__(64) void kmeans_reduce(const float *__restrict__ psums, const float *__restrict__ pcounts,
+                                                     const int32_t *__restrict__ range, const int32_t *__restrict__ done,
+                                                     float *__restrict__ sums, float *__restrict__ counts, int K, int C)
+{
+  const int b = blockIdx.y;
+  if (done[b]) return;
+  const int first = range[2 * b], n = range[2 * b + 1];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x, KC = K * C;
+  if (e < KC) {
+    const float *p = psums + (int64_t)first * KC + e;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};               // 8 independent chains: the loads are latency-bound
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += p[(int64_t)(i + u) * KC];
+    }
+    for (; i < n; ++i) a[0] += p[(int64_t)i * KC];
+    sums[(int64_t)b * KC + e] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < K) {
+    float c = 0.f;
+    for (int i = 0; i < n; ++i) c += pcounts[(int64_t)(first + i) * K + threadIdx.x];
+    counts[b * K + threadIdx.x] = c;
+  }
 }
 
 // one workgroup per image
@@ -174,10 +225,37 @@ extern "C" int pd_kmeans_assign(const float *X, const int32_t *blocks, int n_blo
   if (n_blocks == 0) return PD_OK;
   if (!X || !blocks || !centers || !cnorm || !done || !labels || !sums || !counts || !changed)
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_assign: null pointer");
-  const size_t lds = ((size_t)K * C + KMAX + 1) * sizeof(float);
-  hipLaunchKernelGGL(kmeans_assign, dim3(n_blocks), dim3(256), lds, (hipStream_t)stream_, X, blocks, centers, cnorm, done, labels, sums,
-                     counts, changed, C, K);
+  const size_t lds = ((size_t)K * C + 64 + 1) * sizeof(float);
+  hipLaunchKernelGGL(kmeans_assign<false>, dim3(n_blocks), dim3(256), lds, (hipStream_t)stream_, X, blocks, centers, cnorm, done, labels, sums,
+                     counts, changed, C, K, g_pd_dbg_kmeans);
   return pd_check_launch("pd_kmeans_assign");
+}
+
+extern "C" int pd_kmeans_assign_partial(const float *X, const int32_t *blocks, int n_blocks, const float *centers, const float *cnorm,
+                                        const int32_t *done, int32_t *labels, float *partial_sums, float *partial_counts,
+                                        int32_t *changed, int C, int K, void *stream_)
+{
+  if (n_blocks < 0 || C <= 0 || (C & 3) || C > 256 * PMAX || K <= 0 || K > KMAX)
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_assign_partial: n_blocks=%d C=%d (<= 2048, %% 4) K=%d (<= 4)", n_blocks, C, K);
+  if (n_blocks == 0) return PD_OK;
+  if (!X || !blocks || !centers || !cnorm || !done || !labels || !partial_sums || !partial_counts || !changed)
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_assign_partial: null pointer");
+  const size_t lds = ((size_t)K * C + 64 + 1) * sizeof(float);
+  hipLaunchKernelGGL(kmeans_assign<true>, dim3(n_blocks), dim3(256), lds, (hipStream_t)stream_, X, blocks, centers, cnorm, done, labels,
+                     partial_sums, partial_counts, changed, C, K, g_pd_dbg_kmeans);
+  return pd_check_launch("pd_kmeans_assign_partial");
+}
+
+extern "C" int pd_kmeans_reduce(const float *partial_sums, const float *partial_counts, const int32_t *block_range, const int32_t *done,
+                                float *sums, float *counts, int B, int K, int C, void *stream_)
+{
+  if (B < 0 || C <= 0 || K <= 0 || K > KMAX) return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_reduce: B=%d C=%d K=%d", B, C, K);
+  if (B == 0) return PD_OK;
+  if (!partial_sums || !partial_counts || !block_range || !done || !sums || !counts)
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_reduce: null pointer");
+  hipLaunchKernelGGL(kmeans_reduce, dim3((K * C + 63) / 64, B), dim3(64), 0, (hipStream_t)stream_, partial_sums, partial_counts, block_range,
+                     done, sums, counts, K, C);
+  return pd_check_launch("pd_kmeans_reduce");
 }
 
 extern "C" int pd_kmeans_update(float *centers, float *cnorm, float *sums, float *counts, int32_t *changed, const float *tol,

@@ -71,6 +71,10 @@ def kmeans_lloyd(X, K, init=None, max_iter=300, tol=1e-4, generator=None):
     return centers + mean, labels, it
 
 
+SLAB = int(__import__("os").environ.get("PD_KMEANS_SLAB", "32"))
+ATOMIC = bool(int(__import__("os").environ.get("PD_KMEANS_ATOMIC", "0")))     # points per workgroup of pd_kmeans_assign (<= 64)
+
+
 def kmeans_lloyd_batched(datas, K, inits=None, max_iter=300, tol=1e-4, generator=None, check_every=8):
     """datas: list of [N_b, C] fp32 CUDA tensors (N_b > K) -> (centres [B,K,C], iterations list).  HIP kernels; K <= 4,
     C % 4 == 0, C <= 2048 (else falls back to kmeans_lloyd per image)."""
@@ -88,26 +92,38 @@ def kmeans_lloyd_batched(datas, K, inits=None, max_iter=300, tol=1e-4, generator
     centers = torch.stack([(inits[b].float() - means[b]) if inits is not None and inits[b] is not None else kmeans_plusplus(Xs[b], K, generator)
                            for b in range(B)]).contiguous()                                 # [B,K,C]
     X = torch.cat(Xs).contiguous()
-    table, off = [], 0
+    table, ranges, off = [], [], 0
     for b, x in enumerate(Xs):
-        for s0 in range(0, x.shape[0], 64):
-            table.append((b, off + s0, min(64, x.shape[0] - s0)))
+        ranges += [len(table), -(-x.shape[0] // SLAB)]                                       # (first block, number of blocks) of image b
+        for s0 in range(0, x.shape[0], SLAB):
+            table.append((b, off + s0, min(SLAB, x.shape[0] - s0)))
         off += x.shape[0]
-    blocks = torch.tensor(table, dtype=torch.int32, device=dev)
+    from .fused import upload_small
+    blocks = upload_small([v for row in table for v in row], torch.int32, dev).view(-1, 3)   # pinned + async: no stall behind the backbone
+    block_range = upload_small(ranges, torch.int32, dev)
     labels = torch.full((X.shape[0],), -1, dtype=torch.int32, device=dev)
     sums = torch.zeros((B, K, C), dtype=torch.float32, device=dev)
     counts = torch.zeros((B, K), dtype=torch.float32, device=dev)
+    psums = torch.empty((len(table), K, C), dtype=torch.float32, device=dev)                 # per-slab partial sums (no atomics)
+    pcounts = torch.empty((len(table), K), dtype=torch.float32, device=dev)
     flags = torch.zeros((3, B), dtype=torch.int32, device=dev)                               # changed, done, n_iter
     cnorm = (centers * centers).sum(-1).contiguous()
     lib, st = _lib.load(), _lib.current_stream()
+    p = dict(X=X.data_ptr(), blocks=blocks.data_ptr(), centers=centers.data_ptr(), cnorm=cnorm.data_ptr(), done=flags[1].data_ptr(),
+             labels=labels.data_ptr(), psums=psums.data_ptr(), pcounts=pcounts.data_ptr(), changed=flags[0].data_ptr(),
+             range=block_range.data_ptr(), sums=sums.data_ptr(), counts=counts.data_ptr(), tols=tols.data_ptr(), n_iter=flags[2].data_ptr())
     it = 0
     while it < max_iter:
         for _ in range(min(check_every, max_iter - it)):
-            _lib.check(lib.pd_kmeans_assign(X.data_ptr(), blocks.data_ptr(), len(table), centers.data_ptr(), cnorm.data_ptr(),
-                                            flags[1].data_ptr(), labels.data_ptr(), sums.data_ptr(), counts.data_ptr(),
-                                            flags[0].data_ptr(), C, K, st))
-            _lib.check(lib.pd_kmeans_update(centers.data_ptr(), cnorm.data_ptr(), sums.data_ptr(), counts.data_ptr(), flags[0].data_ptr(),
-                                            tols.data_ptr(), flags[1].data_ptr(), flags[2].data_ptr(), B, K, C, st))
+            if ATOMIC:                                                                       # tools only: the first version's accumulation
+                _lib.check(lib.pd_kmeans_assign(p["X"], p["blocks"], len(table), p["centers"], p["cnorm"], p["done"], p["labels"],
+                                                p["sums"], p["counts"], p["changed"], C, K, st))
+            else:
+                _lib.check(lib.pd_kmeans_assign_partial(p["X"], p["blocks"], len(table), p["centers"], p["cnorm"], p["done"], p["labels"],
+                                                        p["psums"], p["pcounts"], p["changed"], C, K, st))
+                _lib.check(lib.pd_kmeans_reduce(p["psums"], p["pcounts"], p["range"], p["done"], p["sums"], p["counts"], B, K, C, st))
+            _lib.check(lib.pd_kmeans_update(p["centers"], p["cnorm"], p["sums"], p["counts"], p["changed"], p["tols"], p["done"],
+                                            p["n_iter"], B, K, C, st))
             it += 1
         if bool(flags[1].all()):                                                             # the only read-back
             break
