@@ -43,6 +43,13 @@ int pd_gemm_wgrad_acc_f32(const float *dY, const float *X, float *dW, float *dB,
 int pd_gemm_wgrad_acc_f32x3(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx, int ldw,
                             void *stream);
 
+/* 3 x 3, stride 1, pad 1 convolution as an implicit GEMM on the same 3-way bf16 split (fp32-level results): the fp32 FPN
+ * output convolution of the pixel decoder (reference pixel_decoder/msdeformattn.py:268-277, run at 1/4 resolution: 77 GFLOP per
+ * 1024^2 image).  X [B,H,W,Ci] and Y [B,H,W,Co] channels-last, Wk [Co][3][3][Ci] (the channels-last filter), bias [Co] or NULL;
+ * Ci % 16 == 0.  The input gradient is the same call on dY with the filter flipped and transposed ([Ci][3][3][Co]). */
+int pd_conv3x3_nhwc_f32x3(const float *X, const float *Wk, const float *bias, float *Y, int B, int H, int W, int Ci, int Co,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,10 +57,13 @@ __device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0
 
 __device__ __forceinline__ bool v_never(float x) { return x == 1.2345678e30f; }
 
-template <bool RELU, int ABL>
+// CONV: A is an NHWC image [*, H, W, Ci] and row m of the GEMM is output pixel m of a 3 x 3, stride 1, pad 1 convolution:
+// K = 9 Ci ordered (tap, channel) like the channels-last filter [Co][3][3][Ci]; a 16-wide k-step lies inside one tap, so the
+// A tile of a step is the input at pixel m + dy W + dx (zeros outside the image) — an implicit GEMM, nothing is unfolded.
+template <bool RELU, int ABL, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict__ A, const float *__restrict__ B,
                                                          const float *__restrict__ bias, float *__restrict__ C, int M, int N,
-                                                         int K, int lda, int ldb, int ldc, int ntiles_n)
+                                                         int K, int lda, int ldb, int ldc, int ntiles_n, int H, int W)
 {
   __shared__ __attribute__((aligned(16))) bf16_t As[2][3][BM][PITCH];      // two stages x three planes
   __shared__ __attribute__((aligned(16))) bf16_t Bs[2][3][BN][PITCH];
@@ -70,11 +73,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict_
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int lr = t >> 2, lk = (t & 3) * 4;                       // rows lr + 64 j, columns lk .. lk+3 of both tiles
   float4 ra[2][2], rb[2][2];                                     // two register stages: loads run two steps ahead of their use
+  int py[2], px[2];                                              // CONV: image row / column of this thread's two A rows
+  if (CONV) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + lr + 64 * j, pix = m % (H * W);
+      py[j] = pix / W;
+      px[j] = pix - py[j] * W;
+    }
+  }
   auto gload = [&](int s, int k0) {
+    int tap = 0, dy = 0, dx = 0, kc = k0 + lk;
+    if (CONV) { tap = (k0 + lk) / lda; kc = (k0 + lk) - tap * lda; dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }   // lda = Ci
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = lr + 64 * j, k = k0 + lk;
-      ra[s][j] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4 *>(A + (int64_t)(m0 + r) * lda + k) : make_float4(0, 0, 0, 0);
+      if (CONV) {
+        const int yy = py[j] + dy, xx = px[j] + dx;
+        const bool ok = m0 + r < M && k < K && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        ra[s][j] = ok ? *reinterpret_cast<const float4 *>(A + ((int64_t)(m0 + r) + dy * W + dx) * lda + kc) : make_float4(0, 0, 0, 0);
+      } else {
+        ra[s][j] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4 *>(A + (int64_t)(m0 + r) * lda + k) : make_float4(0, 0, 0, 0);
+      }
       rb[s][j] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4 *>(B + (int64_t)(n0 + r) * ldb + k) : make_float4(0, 0, 0, 0);
     }
   };
@@ -91,13 +111,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict_
     *reinterpret_cast<uint2 *>(&P[0][r][lk]) = x.hi; *reinterpret_cast<uint2 *>(&P[1][r][lk]) = x.mid; *reinterpret_cast<uint2 *>(&P[2][r][lk]) = x.lo;
   };
   auto lstore = [&](int s, int buf) { lstore1(s, buf, 0, 0); lstore1(s, buf, 0, 1); lstore1(s, buf, 1, 0); lstore1(s, buf, 1, 1); };
-  f32x16 acc[2][2];
+  // two-level accumulation: `acc` collects FLUSH k-steps (256 contraction elements), then is added to `tot` and cleared — the
+  // rounding error of a long contraction (K = 2304 in the 3 x 3 convolution) grows with the square root of the chain length
+  constexpr int FLUSH = 16;
+  f32x16 acc[2][2], tot[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; tot[i][j][e] = 0.f; }
 
   const int KT = (K + BK - 1) / BK;
   gload(0, 0);
@@ -132,12 +155,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict_
 #undef TERM
     if (ABL == 1) acc[0][0][0] += (float)a[0][0][0] + (float)b[2][1][1] + (float)a[1][1][2] + (float)b[1][0][3] + (float)a[2][0][5] + (float)b[0][0][7];
     if (kt + 2 < KT) gload(par, (kt + 2) * BK);
+    if (KT > FLUSH && (kt + 1) % FLUSH == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { tot[i][j][e] += acc[i][j][e]; acc[i][j][e] = 0.f; }
+    }
     __syncthreads();
   };
   for (int kt = 0; kt < KT; kt += 2) {
     step(kt, 0);
     if (kt + 1 < KT) step(kt + 1, 1);
   }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] += tot[i][j][e];
   // C layout of the 32x32 MFMA: col = lane & 31 (B row), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (A row)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -271,7 +308,7 @@ extern "C" int pd_gemm_tn_f32x3(const float *A, const float *B, const float *bia
   const int tn = (N + BN - 1) / BN, tm = (M + BM - 1) / BM;
   const dim3 g((unsigned)((int64_t)tm * tn)), b(256);
   hipStream_t st = (hipStream_t)stream_;
-#define LAUNCH(R, AB) hipLaunchKernelGGL((gemm_tn_f32x3<R, AB>), g, b, 0, st, A, B, bias, C, M, N, K, lda, ldb, ldc, tn)
+#define LAUNCH(R, AB) hipLaunchKernelGGL((gemm_tn_f32x3<R, AB, false>), g, b, 0, st, A, B, bias, C, M, N, K, lda, ldb, ldc, tn, 0, 0)
   if (g_pd_dbg_x3 == 1) LAUNCH(false, 1);
   else if (g_pd_dbg_x3 == 2) LAUNCH(false, 2);
   else if (g_pd_dbg_x3 == 3) LAUNCH(false, 3);
@@ -298,5 +335,21 @@ extern "C" int pd_gemm_wgrad_acc_f32x3(const float *dY, const float *X, float *d
   hipLaunchKernelGGL(gemm_wgrad_f32x3, dim3((unsigned)(tiles * splits)), dim3(256), 0, (hipStream_t)stream_, dY, X, dW, dB, M, N, K, ldy,
                      ldx, ldw, tk, tiles, m_chunk);
   return pd_check_launch("pd_gemm_wgrad_acc_f32x3");
+}
+
+extern "C" int pd_conv3x3_nhwc_f32x3(const float *X, const float *Wk, const float *bias, float *Y, int B, int H, int W, int Ci, int Co,
+                                     void *stream_)
+{
+  if (B < 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || (Ci & 15))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_conv3x3_nhwc_f32x3: B=%d H=%d W=%d Ci=%d (%% 16) Co=%d", B, H, W, Ci, Co);
+  if (B == 0) return PD_OK;
+  if (!X || !Wk || !Y || ((uintptr_t)X & 15) || ((uintptr_t)Wk & 15))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_conv3x3_nhwc_f32x3: null / misaligned pointer");
+  const int64_t M = (int64_t)B * H * W;
+  if (M > 0x7fffffffLL - 4096) return pd_set_error(PD_ERR_INVALID_ARG, "pd_conv3x3_nhwc_f32x3: too many pixels");
+  const int tn = (Co + BN - 1) / BN, tm = (int)((M + BM - 1) / BM);
+  hipLaunchKernelGGL((gemm_tn_f32x3<false, 0, true>), dim3((unsigned)((int64_t)tm * tn)), dim3(256), 0, (hipStream_t)stream_, X, Wk, bias, Y,
+                     (int)M, Co, 9 * Ci, Ci, 9 * Ci, Co, tn, H, W);
+  return pd_check_launch("pd_conv3x3_nhwc_f32x3");
 }
 

@@ -1,0 +1,55 @@
+"""fp32 3 x 3 convolution (stride 1, pad 1) on the bf16 matrix cores with fp32-level accuracy (pd_conv3x3_nhwc_f32x3,
+include/pd_gemm.h): forward and input gradient are implicit GEMMs on the exact 3-way bf16 split of csrc/gemm_x3.hip; the
+weight gradient stays the library's (MIOpen).  Channels-last tensors only (the pixel decoder keeps its maps NHWC)."""
+import torch
+from torch.autograd import Function
+
+from .. import lib as _lib
+
+
+def supported(x, conv):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.weight.dtype == torch.float32
+            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and x.shape[1] % 16 == 0 and conv.weight.shape[0] % 16 == 0
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def _raw(x, wk, bias, co):
+    """x channels-last [B,Ci,H,W]; wk [Co,3,3,Ci] contiguous -> channels-last [B,Co,H,W]"""
+    B, ci, H, W = x.shape
+    y = torch.empty((B, co, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.load().pd_conv3x3_nhwc_f32x3(x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                                 B, H, W, ci, co, _lib.current_stream()))
+    return y
+
+
+class Conv3x3X3(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        if not x.is_cuda:
+            raise RuntimeError("pd_conv3x3_nhwc_f32x3 runs on the GPU only (no CPU fallback in partdistillation_amd)")
+        x = x.contiguous(memory_format=torch.channels_last)
+        wk = weight.permute(0, 2, 3, 1).contiguous()                       # [Co,3,3,Ci]: free when the filter is stored channels-last
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return _raw(x, wk, bias, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        co, ci = weight.shape[0], weight.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dX[p, ci] = sum_tap sum_co dY[p - off(tap), co] W[co, tap, ci]: the same kernel on dY with the taps flipped and the
+            # filter transposed to [Ci][3][3][Co] (2.4 MB at 256 channels)
+            wt = weight.permute(0, 2, 3, 1).reshape(co, 9, ci).flip(1).permute(2, 1, 0).contiguous()
+            dx = _raw(dy, wt, None, ci)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            _, dw, db = torch.ops.aten.convolution_backward(dy, x, weight, [co] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False,
+                                                            [0, 0], 1, [False, True, ctx.has_bias])
+        return dx, dw, db
+
+
+def conv3x3(x, weight, bias=None):
+    return Conv3x3X3.apply(x, weight, bias)

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpd_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -28,6 +28,7 @@ SIGNATURES = {
     "pd_gemm_tn_f32x3": (_c_int, [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
     "pd_gemm_wgrad_f32": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),
     "pd_gemm_wgrad_acc_f32": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),
+    "pd_conv3x3_nhwc_f32x3": (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [_c_vp]),
     "pd_gemm_wgrad_acc_f32x3": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),
     "pd_adamw_clipped_shadow": (_c_int, [_c_vp] * 5 + [ctypes.c_int64] + [ctypes.c_double] * 5 + [_c_int, _c_vp, ctypes.c_double, _c_vp, _c_vp]),
     "pd_affine_act_fwd_bf16": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, _c_int, _c_vp]),

@@ -14,6 +14,7 @@ from torch.nn.init import normal_
 from ...compat import SEM_SEG_HEADS_REGISTRY, ShapeSpec, configurable
 from ...compat.layers import Conv2d, c2_xavier_fill, get_norm
 from ..transformer_decoder.position_encoding import PositionEmbeddingSine
+from ...functions import conv_x3
 from ...functions.fused import group_norm_nhwc, group_norm_nhwc_supported
 from ...functions.gemm import linear_f32
 from .ops.modules import MSDeformAttn
@@ -173,10 +174,16 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         return memory, spatial_shapes, level_start_index, shapes_host
 
 
+CONV_X3 = bool(int(__import__("os").environ.get("PD_CONV_X3", "1")))   # functions/conv_x3.py for the 3 x 3 FPN convolution
+
+
 def _conv_gn(conv, gn, x, relu=False):
     """conv -> GroupNorm (-> ReLU); on the GPU in fp32 the norm (+ReLU) is the channels-last HIP GroupNorm
     (functions/fused.py), so the maps stay NHWC from the backbone to the encoder tokens with no layout copies."""
-    y = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+    if CONV_X3 and conv_x3.supported(x, conv):
+        y = conv_x3.conv3x3(x, conv.weight, conv.bias)       # 3 x 3 FPN convolution: fp32-level results on the bf16 matrix cores
+    else:
+        y = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
     if isinstance(gn, nn.GroupNorm) and group_norm_nhwc_supported(y, gn.num_groups):
         return group_norm_nhwc(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)
     if gn is not None:

@@ -108,3 +108,34 @@ def test_gemm_wgrad_x3_is_fp32_accurate(M, N, K, bias):
     if bias:
         torch.testing.assert_close(outs[True][1].double() + 1.0, dy.double().sum(0), rtol=1e-4, atol=1e-3 * dy.abs().max().item())
 
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,bias", [(2, 64, 64, 256, 256, False), (1, 37, 29, 32, 48, True), (3, 8, 200, 16, 272, True)])
+def test_conv3x3_x3_matches_fp64_convolution(B, H, W, Ci, Co, bias):
+    """pd_conv3x3_nhwc_f32x3 (implicit GEMM on the 3-way bf16 split) forward, input gradient (the same kernel on dY with the
+    flipped, transposed filter) and the library weight gradient against an fp64 convolution; forward / input-gradient errors
+    at the level of the library's fp32 convolution."""
+    import torch.nn.functional as F
+    from partdistillation_amd.functions import conv_x3
+    g = torch.Generator(device="cuda").manual_seed(H * W + Ci)
+    x = torch.randn(B, Ci, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last).requires_grad_()
+    w = (torch.randn(Co, Ci, 3, 3, device="cuda", generator=g) * (9 * Ci) ** -0.5).contiguous(memory_format=torch.channels_last).requires_grad_()
+    b = torch.randn(Co, device="cuda", generator=g).requires_grad_() if bias else None
+    go = torch.randn(B, Co, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    conv = torch.nn.Conv2d(Ci, Co, 3, padding=1, bias=bias).cuda()
+    assert conv_x3.supported(x, conv)
+    y = conv_x3.conv3x3(x, w, b)
+    gx, gw = torch.autograd.grad(y, (x, w), go, retain_graph=bias)
+    xr, wr = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+    yr = F.conv2d(xr, wr, b.detach().double() if bias else None, padding=1)
+    rx, rw = torch.autograd.grad(yr, (xr, wr), go.double())
+    yl = F.conv2d(x.detach(), w.detach(), b.detach() if bias else None, padding=1)
+
+    def err(a, r):
+        return ((a.double() - r).abs().max() / r.abs().max()).item()
+    assert y.is_contiguous(memory_format=torch.channels_last) and y.shape == (B, Co, H, W)
+    assert err(y, yr) <= 2.0 * err(yl, yr) + 2 ** -22, (err(y, yr), err(yl, yr))
+    assert err(gx, rx) < 3e-6 and err(gw, rw) < 2e-5
+    if bias:
+        (gb,) = torch.autograd.grad(y, (b,), go)
+        torch.testing.assert_close(gb.double(), go.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+
