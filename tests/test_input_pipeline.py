@@ -132,3 +132,25 @@ def test_device_mapper_call_returns_the_reference_mappers_dict():
     assert out["image"].shape == (3, 96, 96) and out["image"].is_cuda and len(inst) >= 1
     assert inst.gt_masks.tensor.shape[1:] == (96, 96) and inst.gt_masks.tensor.dtype == torch.bool and int(inst.gt_classes.sum()) == 0
     assert bool((inst.gt_masks.tensor.flatten(1).sum(1) > 0).all())
+
+
+@pytest.mark.gpu
+def test_device_transform_edge_cases():
+    """no pseudo-labels at all, an all-ones mask, and an image smaller than the canvas in one direction only"""
+    from oracle import input_pipeline_ref as R
+    from partdistillation_amd.data import DeviceProposalMapper
+    from partdistillation_amd.utils import rle
+    rng = np.random.RandomState(4)
+    img = rng.randint(0, 256, (40, 300, 3)).astype(np.uint8)
+    mapper = DeviceProposalMapper(128, 1.0, 1.0, None, None, rng=rng)
+    p = mapper.draw(40, 300)
+    gi, gm, gpad, area = mapper.transform(img, [], p)
+    oi, om, opad = R.apply(img, np.zeros((0, 40, 300), bool), p)
+    assert gm.shape == (0, 128, 128) and area.numel() == 0 and np.array_equal(gi.cpu().numpy(), oi.transpose(2, 0, 1))
+    assert mapper.select(gm, area).numel() == 0
+    full = np.ones((1, 40, 300), bool)
+    gi, gm, gpad, area = mapper.transform(img, [rle.encode(full[0])], p)
+    oi, om, opad = R.apply(img, full, p)
+    assert np.array_equal(gm.cpu().numpy(), om) and np.array_equal(gpad.cpu().numpy(), opad) and int(area[0]) == int(om.sum())
+    assert bool(gpad.any()) and not bool(gpad[0, 0])                       # padded below the resized strip
+

@@ -133,3 +133,23 @@ def test_fused_stage_matches_module_path(dim, heads, H, W, depth, drop):
     _close(res[True][1], res[False][1], 3e-2, "input gradient")
     for k, gr in res[False][2].items():
         _close(res[True][2][k], gr, 6e-2, "grad " + k)
+
+
+def test_fused_stage_in_eval_mode_and_without_grad():
+    """inference use (proposal generation, part ranking): eval mode ignores DropPath, no_grad keeps nothing alive, bf16 input
+    (the output of PatchMerging under autocast) is accepted"""
+    from partdistillation_amd.modeling.backbone import swin, swin_core
+    torch.manual_seed(1)
+    layer = swin.BasicLayer(dim=128, depth=2, num_heads=4, window_size=12, drop_path=[0.2, 0.3]).cuda().eval()
+    x = torch.randn(1, 24 * 36, 128, device="cuda")
+    out = {}
+    for fused in (True, False):
+        swin.FUSED_STAGE = fused
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                assert swin_core.supported(layer, x.bfloat16()) == fused or not fused
+                out[fused] = layer(x.bfloat16(), 24, 36)[0].float()
+        finally:
+            swin.FUSED_STAGE = True
+    _close(out[True], out[False], 3e-2, "eval output (bf16 residual stream in the module path)")
+
