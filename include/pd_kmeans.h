@@ -40,6 +40,17 @@ int pd_kmeans_reduce(const float *partial_sums, const float *partial_counts, con
                      float *sums, float *counts, int B, int K, int C, void *stream);
 
 /*
+ * pd_kmeans_reduce and pd_kmeans_update in ONE launch (what the product issues per iteration after pd_kmeans_assign_partial):
+ * centres, norms, iteration count and `done` as pd_kmeans_update would leave them, every floating-point sum in a fixed order
+ * (bit-reproducible).  scratch: fp32, pd_kmeans_reduce_update_scratch_floats(B, K, C) elements; ticket: int32 [B], zero on
+ * first use (left zero).
+ */
+int64_t pd_kmeans_reduce_update_scratch_floats(int B, int K, int C);
+int pd_kmeans_reduce_update(const float *partial_sums, const float *partial_counts, const int32_t *block_range, float *centers,
+                            float *cnorm, int32_t *changed, const float *tol, int32_t *done, int32_t *n_iter, float *scratch,
+                            int32_t *ticket, int B, int K, int C, void *stream);
+
+/*
  * M-step + convergence for every image b with done[b] == 0:  centers[b,k] = sums / counts (unchanged when the cluster is
  * empty), cnorm recomputed, n_iter[b] += 1, done[b] = (changed[b] == 0) || (sum_k |new - old|^2 <= tol[b]); then sums,
  * counts and changed are cleared for the next pd_kmeans_assign.

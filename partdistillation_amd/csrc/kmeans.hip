@@ -214,6 +214,82 @@ __global__ __launch_bounds__(256) void kmeans_update(float *__restrict__ centers
   }
 }
 
+// reduce + M-step + convergence in one launch (the product path): a thread per (k, c) element adds up the image's slab partials
+// in a fixed order, writes the new centre and its contributions to the centre shift and to |c_k|^2; the workgroups of an image
+// leave those as per-workgroup partials and the LAST one to finish (agent-scope ticket) sums them — again in a fixed order, so
+// centres, norms and the stopping decision are bit-reproducible — and decides `done`.
+__global__ __launch_bounds__(256) void kmeans_reduce_update(const float *__restrict__ psums, const float *__restrict__ pcounts,
+                                                            const int32_t *__restrict__ range, float *__restrict__ centers,
+                                                            float *__restrict__ cnorm, int32_t *__restrict__ changed,
+                                                            const float *__restrict__ tol, int32_t *__restrict__ done,
+                                                            int32_t *__restrict__ n_iter, float *__restrict__ scratch,
+                                                            int32_t *__restrict__ ticket, int K, int C)
+{
+  __shared__ float cnt_s[KMAX];
+  __shared__ float red[4][KMAX + 1];
+  __shared__ int last;
+  const int b = blockIdx.y, G = gridDim.x;
+  if (done[b]) return;
+  const int first = range[2 * b], n = range[2 * b + 1], KC = K * C;
+  if (threadIdx.x < K) {
+    float c = 0.f;
+    for (int i = 0; i < n; ++i) c += pcounts[(int64_t)(first + i) * K + threadIdx.x];
+    cnt_s[threadIdx.x] = c;
+  }
+  __syncthreads();
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  float shift = 0.f, nk[KMAX] = {0.f, 0.f, 0.f, 0.f};
+  if (e < KC) {
+    const float *p = psums + (int64_t)first * KC + e;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += p[(int64_t)(i + u) * KC];
+    }
+    for (; i < n; ++i) a[0] += p[(int64_t)i * KC];
+    const float sm = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    const int k = e / C;
+    const float old = centers[(int64_t)b * KC + e];
+    const float nw = cnt_s[k] > 0.f ? sm / cnt_s[k] : old;
+    centers[(int64_t)b * KC + e] = nw;
+    shift = (nw - old) * (nw - old);
+#pragma unroll
+    for (int kk = 0; kk < KMAX; ++kk)
+      if (kk == k) nk[kk] = nw * nw;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  shift = wave_sum(shift);
+#pragma unroll
+  for (int kk = 0; kk < KMAX; ++kk) nk[kk] = wave_sum(nk[kk]);
+  if (lane == 0) {
+    red[wave][KMAX] = shift;
+#pragma unroll
+    for (int kk = 0; kk < KMAX; ++kk) red[wave][kk] = nk[kk];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float *mine = scratch + ((int64_t)b * G + blockIdx.x) * (KMAX + 1);
+#pragma unroll
+    for (int j = 0; j <= KMAX; ++j) mine[j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+    const int t = __hip_atomic_fetch_add(ticket + b, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);   // releases `mine`, acquires the others'
+    last = t == G - 1;
+    if (last) {
+      float tot[KMAX + 1] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < G; ++g) {
+        const float *o = scratch + ((int64_t)b * G + g) * (KMAX + 1);
+#pragma unroll
+        for (int j = 0; j <= KMAX; ++j) tot[j] += __hip_atomic_load(o + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      for (int k = 0; k < K; ++k) cnorm[b * K + k] = tot[k];
+      n_iter[b] += 1;
+      if (changed[b] == 0 || tot[KMAX] <= tol[b]) done[b] = 1;
+      changed[b] = 0;
+      ticket[b] = 0;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int pd_kmeans_assign(const float *X, const int32_t *blocks, int n_blocks, const float *centers, const float *cnorm,
@@ -268,3 +344,23 @@ extern "C" int pd_kmeans_update(float *centers, float *cnorm, float *sums, float
   hipLaunchKernelGGL(kmeans_update, dim3(B), dim3(256), 0, (hipStream_t)stream_, centers, cnorm, sums, counts, changed, tol, done, n_iter, K, C);
   return pd_check_launch("pd_kmeans_update");
 }
+
+extern "C" int64_t pd_kmeans_reduce_update_scratch_floats(int B, int K, int C)
+{
+  if (B <= 0 || K <= 0 || C <= 0) return 0;
+  return (int64_t)B * ((K * C + 255) / 256) * (KMAX + 1);
+}
+
+extern "C" int pd_kmeans_reduce_update(const float *partial_sums, const float *partial_counts, const int32_t *block_range, float *centers,
+                                       float *cnorm, int32_t *changed, const float *tol, int32_t *done, int32_t *n_iter, float *scratch,
+                                       int32_t *ticket, int B, int K, int C, void *stream_)
+{
+  if (B < 0 || C <= 0 || K <= 0 || K > KMAX) return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_reduce_update: B=%d C=%d K=%d", B, C, K);
+  if (B == 0) return PD_OK;
+  if (!partial_sums || !partial_counts || !block_range || !centers || !cnorm || !changed || !tol || !done || !n_iter || !scratch || !ticket)
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_reduce_update: null pointer");
+  hipLaunchKernelGGL(kmeans_reduce_update, dim3((K * C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream_, partial_sums, partial_counts,
+                     block_range, centers, cnorm, changed, tol, done, n_iter, scratch, ticket, K, C);
+  return pd_check_launch("pd_kmeans_reduce_update");
+}
+

@@ -106,12 +106,14 @@ def kmeans_lloyd_batched(datas, K, inits=None, max_iter=300, tol=1e-4, generator
     counts = torch.zeros((B, K), dtype=torch.float32, device=dev)
     psums = torch.empty((len(table), K, C), dtype=torch.float32, device=dev)                 # per-slab partial sums (no atomics)
     pcounts = torch.empty((len(table), K), dtype=torch.float32, device=dev)
-    flags = torch.zeros((3, B), dtype=torch.int32, device=dev)                               # changed, done, n_iter
+    flags = torch.zeros((4, B), dtype=torch.int32, device=dev)                               # changed, done, n_iter, ticket
+    scratch = torch.empty(int(_lib.load().pd_kmeans_reduce_update_scratch_floats(B, K, C)), dtype=torch.float32, device=dev)
     cnorm = (centers * centers).sum(-1).contiguous()
     lib, st = _lib.load(), _lib.current_stream()
     p = dict(X=X.data_ptr(), blocks=blocks.data_ptr(), centers=centers.data_ptr(), cnorm=cnorm.data_ptr(), done=flags[1].data_ptr(),
              labels=labels.data_ptr(), psums=psums.data_ptr(), pcounts=pcounts.data_ptr(), changed=flags[0].data_ptr(),
-             range=block_range.data_ptr(), sums=sums.data_ptr(), counts=counts.data_ptr(), tols=tols.data_ptr(), n_iter=flags[2].data_ptr())
+             range=block_range.data_ptr(), sums=sums.data_ptr(), counts=counts.data_ptr(), tols=tols.data_ptr(), n_iter=flags[2].data_ptr(),
+             scratch=scratch.data_ptr(), ticket=flags[3].data_ptr())
     it = 0
     while it < max_iter:
         for _ in range(min(check_every, max_iter - it)):
@@ -121,9 +123,11 @@ def kmeans_lloyd_batched(datas, K, inits=None, max_iter=300, tol=1e-4, generator
             else:
                 _lib.check(lib.pd_kmeans_assign_partial(p["X"], p["blocks"], len(table), p["centers"], p["cnorm"], p["done"], p["labels"],
                                                         p["psums"], p["pcounts"], p["changed"], C, K, st))
-                _lib.check(lib.pd_kmeans_reduce(p["psums"], p["pcounts"], p["range"], p["done"], p["sums"], p["counts"], B, K, C, st))
-            _lib.check(lib.pd_kmeans_update(p["centers"], p["cnorm"], p["sums"], p["counts"], p["changed"], p["tols"], p["done"],
-                                            p["n_iter"], B, K, C, st))
+                _lib.check(lib.pd_kmeans_reduce_update(p["psums"], p["pcounts"], p["range"], p["centers"], p["cnorm"], p["changed"], p["tols"],
+                                                       p["done"], p["n_iter"], p["scratch"], p["ticket"], B, K, C, st))
+            if ATOMIC:
+                _lib.check(lib.pd_kmeans_update(p["centers"], p["cnorm"], p["sums"], p["counts"], p["changed"], p["tols"], p["done"],
+                                                p["n_iter"], B, K, C, st))
             it += 1
         if bool(flags[1].all()):                                                             # the only read-back
             break
