@@ -88,15 +88,15 @@ def upload_small(values, dtype, device):
     n = len(values)
     if device.type != "cuda":
         return torch.tensor(values, dtype=dtype, device=device)
-    key = (n, dtype, str(device))
+    cap = 1 << max(4, (max(n, 1) - 1).bit_length())           # rings by power-of-two capacity: table lengths vary from batch to batch
+    key = (cap, dtype, str(device))
     ring = _UPLOAD_RINGS.get(key)
     if ring is None:
-        ring = _UPLOAD_RINGS[key] = PinnedRing(n, dtype, pin=True)
+        ring = _UPLOAD_RINGS[key] = PinnedRing(cap, dtype, pin=True)
     buf = ring.acquire()
-    for i, v in enumerate(values):
-        buf[i] = v
+    buf[:n] = torch.tensor(values, dtype=dtype)
     out = torch.empty(n, dtype=dtype, device=device)
-    out.copy_(buf, non_blocking=True)
+    out.copy_(buf[:n], non_blocking=True)
     ring.release()
     return out
 
