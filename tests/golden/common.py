@@ -125,6 +125,12 @@ C1 = dict(conv_dim=256, mask_dim=256, nheads=8, enc_layers=6, enc_ffn=1024, chan
 SWIN_TINY = dict(pretrain_img_size=96, patch_size=4, embed_dim=24, depths=(2, 2, 2, 2), num_heads=(2, 2, 4, 4),
                  window_size=4, image=(72, 88), batch=2)
 
+# the geometry BASELINE configs 3 / 5 run (window 12, head_dim 32 in every stage -> pd_window_attn_*_w12 and the fused Swin
+# stage apply): 100 x 132 image -> 25 x 33 tokens, so every stage pads to the window, shifted blocks straddle region borders,
+# PatchMerging pads odd maps
+SWIN_W12 = dict(pretrain_img_size=96, patch_size=4, embed_dim=64, depths=(2, 2, 2, 2), num_heads=(2, 4, 8, 16),
+                window_size=12, image=(100, 132), batch=2)
+
 
 def make_features(cfg, seed):
     s = cfg["image"]
@@ -230,3 +236,36 @@ def rank_centroids(cfg=RANK, seed=5450):
 
 
 RANK_MAPPING = ([2, 0, 1], [1, 1, 0])                                          # majority-vote mapping of object classes 3 / 4
+
+
+# ----------------------------------------------------------------------------- meta-architecture train branch
+META = dict(TINY, batch=2, images=[(128, 128), (96, 128)], n_parts=(3, 2), part=(5, 4))   # ragged sizes, ragged #masks; (N_obj, K)
+
+
+def stub_backbone_weights(cfg, seed=6100):
+    return [seeded((c, 3, 1, 1), seed + i, 0.6) for i, c in enumerate(cfg["channels"])]
+
+
+def stub_backbone(x, weights):
+    """stand-in backbone shared by the reference run (make_golden.gen_meta), the oracle and the product tests: res{2..5} =
+    1x1 conv (seeded) of the stride-s average pool of the NORMALISED, PADDED image batch — so the features carry the
+    meta-architecture's normalisation and ImageList padding."""
+    import torch.nn.functional as F
+    return {f"res{i + 2}": F.conv2d(F.avg_pool2d(x, s), w.to(x)) for i, (s, w) in enumerate(zip((4, 8, 16, 32), weights))}
+
+
+def make_meta_inputs(cfg=META, seed=6200):
+    """per image: uint8 image [3,H,W], n disjoint bool part masks [n,H,W] inside an ellipse, part labels (distinct, < K),
+    the object class (< N_obj)"""
+    out = []
+    for b, ((H, W), n) in enumerate(zip(cfg["images"], cfg["n_parts"])):
+        g = torch.Generator().manual_seed(seed + b)
+        img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8)
+        ys, xs = torch.meshgrid(torch.arange(H) / H, torch.arange(W) / W, indexing="ij")
+        inside = ((ys - 0.5) ** 2 / 0.16 + (xs - 0.5) ** 2 / 0.1) < 1.0
+        centers = torch.rand((n, 2), generator=g) * 0.5 + 0.25
+        lab = torch.stack([(ys - c[0]) ** 2 + (xs - c[1]) ** 2 for c in centers]).argmin(0)
+        masks = torch.stack([(lab == k) & inside for k in range(n)])
+        out.append({"image": img, "masks": masks, "gt_classes": torch.randperm(cfg["part"][1], generator=g)[:n],
+                    "gt_object_class": (1, 3)[b % 2], "height": H, "width": W})
+    return out

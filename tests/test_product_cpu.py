@@ -168,3 +168,43 @@ def test_proposal_generation_model_registers_and_builds():
     assert model.training is False
     with pytest.raises(AssertionError):
         model.train()([])
+
+
+@pytest.mark.parametrize("tag,freeze", [("full", []), ("frozen", ["backbone", "encoder"])])
+def test_optimizer_param_groups_match_reference_build_optimizer(golden, tag, freeze):
+    """engine.optimizer.param_hyperparams against the table the REAL BaseTrainer.build_optimizer (base_trainer.py:64-148)
+    produced for the same module tree (Swin + MaskFormerHead with the part-distillation decoder; golden `optimizer`):
+    per-parameter lr (backbone x0.1) and weight decay (0 for norms, embeddings, relative-position tables), and the set
+    of parameters FREEZE_KEYS turns off (full fine-tune / backbone + encoder frozen as the shipped scripts do)."""
+    import types
+    from partdistillation_amd.engine.optimizer import param_hyperparams
+    from partdistillation_amd.modeling.backbone.swin import SwinTransformer
+    from partdistillation_amd.modeling.meta_arch.mask_former_head import MaskFormerHead
+    from partdistillation_amd.modeling.pixel_decoder.msdeformattn import MSDeformAttnPixelDecoder
+    from partdistillation_amd.modeling.transformer_decoder.part_distillation_transformer_decoder import PartDistillationTransformerDecoder
+    from partdistillation_amd.compat import ShapeSpec
+    g = golden("optimizer")[tag]
+    cfg, sw = C.TINY, C.SWIN_TINY
+    model = torch.nn.Module()
+    model.backbone = SwinTransformer(pretrain_img_size=sw["pretrain_img_size"], patch_size=sw["patch_size"], embed_dim=sw["embed_dim"],
+                                     depths=list(sw["depths"]), num_heads=list(sw["num_heads"]), window_size=sw["window_size"], drop_path_rate=0.0)
+    shapes = {f"res{i + 2}": ShapeSpec(channels=sw["embed_dim"] * 2 ** i, stride=s) for i, s in enumerate((4, 8, 16, 32))}
+    pdec = MSDeformAttnPixelDecoder(shapes, transformer_dropout=0.0, transformer_nheads=cfg["nheads"], transformer_dim_feedforward=cfg["enc_ffn"],
+                                    transformer_enc_layers=cfg["enc_layers"], conv_dim=cfg["conv_dim"], mask_dim=cfg["mask_dim"], norm="GN",
+                                    transformer_in_features=["res3", "res4", "res5"], common_stride=4)
+    dec = PartDistillationTransformerDecoder(cfg["conv_dim"], True, num_object_classes=5, num_part_classes=4, num_classes=cfg["num_classes"],
+                                             hidden_dim=cfg["conv_dim"], num_queries=cfg["queries"], nheads=cfg["nheads"],
+                                             dim_feedforward=cfg["dec_ffn"], dec_layers=cfg["dec_layers"], pre_norm=False, mask_dim=cfg["mask_dim"],
+                                             enforce_input_project=False, query_feature_normalize=False)
+    model.sem_seg_head = MaskFormerHead(shapes, num_classes=1, pixel_decoder=pdec, transformer_predictor=dec,
+                                        transformer_in_feature="multi_scale_pixel_decoder")
+    ns = types.SimpleNamespace
+    c = ns(SOLVER=ns(WEIGHT_DECAY_NORM=0.0, WEIGHT_DECAY_EMBED=0.0, BASE_LR=1e-4, WEIGHT_DECAY=0.05, BACKBONE_MULTIPLIER=0.1),
+           MODEL=ns(MASK_FORMER=ns(FREEZE_KEYS=freeze)))
+    entries = param_hyperparams(c, model)
+    ours = {e["name"]: (e["lr"], e["weight_decay"]) for e in entries}
+    assert set(ours) == set(g["table"]), (sorted(set(ours) ^ set(g["table"]))[:10])
+    for k, v in g["table"].items():
+        assert abs(ours[k][0] - float(v[0])) < 1e-15 and abs(ours[k][1] - float(v[1])) < 1e-15, (k, ours[k], v.tolist())
+    assert sorted(n for n, p in model.named_parameters() if not p.requires_grad) == g["frozen"]
+    assert g["optimizer_class"] == "FullModelGradientClippingOptimizer" and g["base_class"] == "AdamW"

@@ -548,3 +548,144 @@ def test_training_step_with_an_image_without_masks_takes_the_per_head_loop():
     assert len(losses) == 12 and all(torch.isfinite(v).all() for v in losses.values())
     full = make_batch(2, 96, n_parts=3, seed=8, device=DEV)
     assert all(torch.isfinite(v).all() for v in step(full).values())          # and the batched path still works afterwards
+
+
+# ----------------------------------------------------------------------------- Swin, window 12 (BASELINE configs 3 / 5)
+def _swin_w12(g):
+    from partdistillation_amd.modeling.backbone.swin import SwinTransformer
+    cfg = C.SWIN_W12
+    net = SwinTransformer(pretrain_img_size=cfg["pretrain_img_size"], patch_size=cfg["patch_size"], embed_dim=cfg["embed_dim"],
+                          depths=list(cfg["depths"]), num_heads=list(cfg["num_heads"]), window_size=cfg["window_size"], drop_path_rate=0.0)
+    net.load_state_dict(C.seeded_weights(g["table"], 103), strict=False)
+    return net.to(DEV).train(), C.seeded((cfg["batch"], 3, *cfg["image"]), 901).to(DEV).requires_grad_()
+
+
+def _scaled_err(t, d):
+    got, want = C.digest(t)["sample"].double(), d["sample"].double()
+    assert C.digest(t)["shape"].tolist() == d["shape"].tolist()
+    return ((got - want).abs().max() / want.abs().max().clamp_min(1e-30)).item()
+
+
+def test_swin_w12_fp32_vs_reference_golden(golden):
+    """window 12 / head_dim 32 Swin (padding in every stage, shifted windows over region borders, odd PatchMerging maps) in
+    fp32 on the GPU against the REAL reference SwinTransformer (tests/golden/swin_w12.pt)."""
+    g = golden("swin_w12")
+    net, x = _swin_w12(g)
+    outs = net(x)
+    for k, d in g["outs"].items():
+        C.check_digest(outs[k], d, 1e-3, 1e-4, k)
+    loss = sum((v * C.seeded(v.shape, 910 + i).to(DEV)).sum() for i, (k, v) in enumerate(sorted(outs.items())))
+    loss.backward()
+    named = dict(net.named_parameters())
+    for k, d in g["grads"].items():
+        C.check_digest_scaled(named[k].grad, d, 5e-3, "grad " + k)
+    C.check_digest_scaled(x.grad, g["grad_x"], 5e-3, "grad x")
+
+
+@pytest.mark.parametrize("fused_stage", [True, False])
+def test_swin_w12_bf16_fused_kernels_vs_reference_golden(golden, fused_stage, monkeypatch):
+    """THE path BASELINE configs 3 / 5 run — bf16 autocast, pd_window_attn_{fwd,bwd}_w12 and (fused_stage) the one-node
+    Swin stage of swin_core.py with pd_swin_ln_* row kernels — against the REAL reference SwinTransformer's fp32 CPU
+    outputs and gradients.  Stated tolerance: bf16 GEMM operands (8 significand bits) through 8 blocks: outputs within
+    2e-2 of each map's max, gradients within 4e-2 of each tensor's max.  The test also proves the fused kernels ran."""
+    from partdistillation_amd.functions import window_attention as wattn
+    from partdistillation_amd.modeling.backbone import swin as swin_mod, swin_core
+    g = golden("swin_w12")
+    net, x = _swin_w12(g)
+    calls = {"fwd": 0, "bwd": 0, "stage": 0}
+    f0, b0, s0 = wattn.fwd_raw, wattn.bwd_raw, swin_core.run_stage
+    monkeypatch.setattr(wattn, "fwd_raw", lambda *a, **k: (calls.__setitem__("fwd", calls["fwd"] + 1), f0(*a, **k))[1])
+    monkeypatch.setattr(wattn, "bwd_raw", lambda *a, **k: (calls.__setitem__("bwd", calls["bwd"] + 1), b0(*a, **k))[1])
+    monkeypatch.setattr(swin_core, "run_stage", lambda *a, **k: (calls.__setitem__("stage", calls["stage"] + 1), s0(*a, **k))[1])
+    monkeypatch.setattr(swin_mod, "FUSED_STAGE", fused_stage)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        outs = net(x)
+    loss = sum((v.float() * C.seeded(v.shape, 910 + i).to(DEV)).sum() for i, (k, v) in enumerate(sorted(outs.items())))
+    loss.backward()
+    nblocks = sum(C.SWIN_W12["depths"])
+    assert calls["fwd"] == nblocks and calls["bwd"] == nblocks, calls                  # every block went through the HIP kernels
+    assert calls["stage"] == (len(C.SWIN_W12["depths"]) if fused_stage else 0), calls
+    worst = {}
+    for k, d in g["outs"].items():
+        worst[k] = _scaled_err(outs[k].float(), d)
+        assert worst[k] < 2e-2, (k, worst)
+    named = dict(net.named_parameters())
+    for k, d in list(g["grads"].items()) + [("x", g["grad_x"])]:
+        worst["grad " + k] = _scaled_err((x.grad if k == "x" else named[k].grad).float(), d)
+        assert worst["grad " + k] < 4e-2, (k, worst)
+    print("swin_w12 bf16", "fused" if fused_stage else "modules", {k: f"{v:.2e}" for k, v in worst.items()})
+
+
+# ----------------------------------------------------------------------------- meta-architecture train branch vs the REAL reference models
+class _StubBackbone(torch.nn.Module):
+    size_divisibility = 32
+
+    def __init__(self, weights):
+        super().__init__()
+        self.weights = [w.to(DEV) for w in weights]
+
+    def forward(self, x):
+        return C.stub_backbone(x.float(), self.weights)
+
+
+def _meta_model(name, fx, cfg):
+    from partdistillation_amd.compat import BitMasks, Instances
+    from partdistillation_amd.modeling.meta_arch.mask_former_head import MaskFormerHead
+    from partdistillation_amd.part_distillation_model import PartDistillationModel
+    from partdistillation_amd.proposal_model import ProposalModel
+    part = cfg["part"] if name == "part" else None
+    head = MaskFormerHead(_shape_specs(cfg), num_classes=cfg["num_classes"], pixel_decoder=build_pixel_decoder(cfg),
+                          transformer_predictor=build_decoder(cfg, part), transformer_in_feature="multi_scale_pixel_decoder")
+    head = load_seeded(head, fx["table"], 111)
+    crit = build_criterion(cfg, None if part is None else part[1])
+    kw = dict(backbone=_StubBackbone(C.stub_backbone_weights(cfg)), sem_seg_head=head, criterion=crit, num_queries=cfg["queries"],
+              size_divisibility=32, pixel_mean=[123.675, 116.280, 103.530], pixel_std=[58.395, 57.120, 57.375],
+              test_topk_per_image=10, use_wandb=False)
+    if part is None:
+        model = ProposalModel(num_classes=cfg["num_classes"], dataset_name="none", **kw)
+    else:
+        model = PartDistillationModel(num_classes=part[1], dataset_name="none", num_part_classes=part[1], num_object_classes=part[0], **kw)
+    batch = []
+    for i in C.make_meta_inputs(cfg):
+        inst = Instances((i["height"], i["width"]))
+        inst.gt_masks, inst.gt_classes = BitMasks(i["masks"].to(DEV)), i["gt_classes"].to(DEV)
+        batch.append({"image": i["image"].to(DEV), "instances": inst, "gt_object_class": i["gt_object_class"],
+                      "height": i["height"], "width": i["width"]})
+    return model.to(DEV).train(), head, batch
+
+
+@pytest.mark.parametrize("name", ["proposal", "part"])
+def test_meta_arch_train_branch_vs_reference_golden(golden, name):
+    """ProposalModel.forward / PartDistillationModel.forward (train) of the product on the GPU against the REAL reference
+    models' train branch (tests/golden/meta.pt; proposal_model.py:177-204, 313-338; part_distillation_model.py:197-226,
+    405-428): prepared targets (labels, padded masks, object masks), the weighted losses, parameter gradients and — for
+    part distillation — the exact set of rows of the fp64 class head that receive gradient."""
+    fx = golden("meta")[name]
+    cfg = C.META
+    model, head, batch = _meta_model(name, fx, cfg)
+    images = model.preprocess(batch)
+    assert list(images.tensor.shape) == fx["padded_shape"].tolist()
+    tg = model._prepare_pseudo_targets(batch, images)
+    for t, want in zip(tg, fx["targets"]):
+        assert torch.equal(t["labels"].cpu(), want["labels"]) and str(t["masks"].dtype) == want["masks_dtype"]
+        C.check_digest(t["masks"], want["masks"], 0, 0, "masks")
+        assert str(t["object_masks"].dtype) == want["object_masks_dtype"]
+        C.check_digest(t["object_masks"], want["object_masks"], 0, 0, "object_masks")
+    if name == "part":
+        assert [t["gt_object_class"] for t in tg] == fx["gt_object_class"].tolist()
+    rr = C.ReplayRand(9300)
+    model.criterion.rand = rr
+    losses = model(batch)
+    assert rr.calls == int(fx["rand_calls"]) and set(losses) == set(fx["losses"])
+    for k, v in fx["losses"].items():
+        torch.testing.assert_close(losses[k].double().cpu().reshape(()), v.reshape(()), rtol=2e-3, atol=1e-4, msg=lambda m: f"{k}: {m}")
+    total = sum(losses.values())
+    torch.testing.assert_close(total.double().cpu().reshape(()), fx["total"].reshape(()), rtol=1e-3, atol=1e-4)
+    total.backward()
+    named = dict(head.named_parameters())
+    for k, d in fx["grads"].items():
+        C.check_digest_scaled(named[k].grad, d, 5e-3, "grad " + k)
+    if name == "part":
+        g = named["predictor.class_embed.weight"].grad
+        assert torch.equal((g.abs().sum(1) > 0).nonzero().flatten().cpu(), fx["class_embed_grad_rows"])
+        C.check_digest_scaled(g, fx["class_embed_grad"], 1e-3, "class_embed grad")
