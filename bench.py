@@ -12,6 +12,12 @@ Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
                 HIP events around every launch inside the timed steps (same stream as the launches)
   cpu_baseline  the CPU oracle (oracle/step_ref.py, plain PyTorch fp32) timed on this host's cores on a bounded
                 sample of the same workload (N=1 only)
+  parity        max deviation of the 30 weighted loss terms of ONE benchmarked-precision step (bf16 autocast, the weights
+                the timed steps left behind, one 1024 x 1024 image, replayed random points) from the CPU oracle on identical
+                inputs, N=1 only; the oracle runs in the cpu_baseline child
+  whole_step    algorithmic GFLOP/image x images/s against the composite matrix-core floor of the step
+  categories    GPU time per step by kernel family (own HIP / library GEMM / MIOpen / ATen / copies), measured live with
+                torch.profiler's device activity records over extra steps after the timed region
 """
 import argparse
 import json
@@ -53,11 +59,14 @@ def msda_alg_bytes(batch, size, heads=8, head_dim=32, levels=3, points=4, esz=4)
     return v + lo + at + v, 2 * (v + lo + at) + v
 
 
-def cpu_baseline_subprocess(opts, size, timeout=300.0):
+def cpu_baseline_subprocess(opts, size, timeout=300.0, parity_file=None):
     """run cpu_baseline() in a child process under a hard wall-clock limit (a mis-threaded CPU run must never hold the
     benchmark hostage: on a 256-core host, torch with 256 intra-op threads took 775 s for the 256x256 probe)."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(size)] + list(opts)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(size)]
+    if parity_file:
+        cmd += ["--parity-file", parity_file]
+    cmd += list(opts)
     try:
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout, text=True).stdout
         for line in out.splitlines()[::-1]:
@@ -68,7 +77,33 @@ def cpu_baseline_subprocess(opts, size, timeout=300.0):
         return {"error": f"CPU baseline exceeded {timeout:.0f} s wall clock and was stopped", "kind": "port"}
 
 
-def cpu_baseline(cfg_opts, size, seconds_budget=90.0, threads=None):
+def oracle_parity(parity_file):
+    """the oracle's 30 weighted losses for the step the GPU just ran (weights, image, masks, random-point seed and the
+    product's Hungarian assignments from `parity_file`): losses are evaluated with the product's assignment, the oracle's
+    own optimum is used to report how far (in the oracle's fp32 cost) that assignment is from optimal."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import common as C
+    from oracle import step_ref as R
+    blob = torch.load(parity_file, weights_only=True)
+    rows, cols, n = blob["rows"].long(), blob["cols"].long(), int(blob["n_targets"])
+    H = rows.shape[0]
+    override = [[(rows[H - 1 if h == 0 else h - 1, :n], cols[H - 1 if h == 0 else h - 1, :n])] for h in range(H)]
+    costs = []
+    with torch.no_grad():
+        losses, oidx = R.proposal_model_losses(blob["sd"], [{"image": blob["image"], "instances": {"gt_masks": blob["masks"]}}],
+                                               C.ReplayRand(int(blob["seed"])), return_indices=True, indices_override=override,
+                                               costs=costs)
+    differ, gap = 0, 0.0
+    for h in range(H):
+        cm = costs[h][0].double()
+        (pr, pc), (orow, ocol) = override[h][0], oidx[h][0]
+        best, got = cm[orow, ocol].sum().item(), cm[pr, pc].sum().item()
+        differ += set(zip(pr.tolist(), pc.tolist())) != set(zip(orow.tolist(), ocol.tolist()))
+        gap = max(gap, (got - best) / max(abs(best), 1e-12))
+    return {"losses": {k: float(v) for k, v in losses.items()}, "assignments_differing": differ, "assignment_cost_gap": gap}
+
+
+def cpu_baseline(cfg_opts, size, seconds_budget=90.0, threads=None, parity_file=None):
     """time the oracle's training step (fwd + criterion + bwd + clipped AdamW), 1 image, on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import common as C
@@ -112,13 +147,84 @@ def cpu_baseline(cfg_opts, size, seconds_budget=90.0, threads=None):
     one_step(probe)                              # warms the allocator / thread pool
     t_probe = one_step(probe)
     est = t_probe * (size / probe) ** 2
+    parity = None
+    if parity_file:
+        try:
+            parity = oracle_parity(parity_file)
+        except Exception as e:                   # noqa: BLE001 - the baseline timing must survive a parity failure
+            parity = {"error": repr(e)}
     if est <= seconds_budget:
         dt, sample = one_step(size), f"1 image {size}x{size}, one full step (fwd+criterion+bwd+clipped AdamW), fp32"
         return {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": "port", "sample": sample,
-                "seconds": dt}
+                "seconds": dt, "_parity": parity}
     sample = (f"1 image {probe}x{probe} (1/{(size // probe) ** 2} of the pixels of the {size}x{size} workload; the full-size "
               f"step was estimated at {est:.0f} s > budget), one full step, fp32; value scaled by the pixel ratio")
-    return {"value": 1.0 / est, "unit": "images/s", "cores": cores, "kind": "port", "sample": sample, "seconds": t_probe}
+    return {"value": 1.0 / est, "unit": "images/s", "cores": cores, "kind": "port", "sample": sample, "seconds": t_probe,
+            "_parity": parity}
+
+
+# kernel families for the live per-category table (torch.profiler device records).  First match wins.
+_CATEGORIES = [
+    ("own_msda", r"^msda_"),
+    ("own_fp32_wgrad_mfma", r"^gemm_wgrad_f32"),
+    ("own_fp32x3_gemm_conv", r"^(gemm_tn_f32|gemm_wgrad_f32x3|conv3x3_)"),
+    ("own_attention_mfma", r"^(attn_|wattn_)"),
+    ("own_skinny_bf16_gemm", r"^sgemm_"),
+    ("own_rowwise_norm_optim_misc", r"^(add_ln_|colsum_|mem_prep|attn_mask|point_sample|msda_prep|gn_coeffs|affine_act|nc_|multi_gather|"
+                                    r"sumsq|adamw|lsa_|swin_ln|kmeans|scores_|mask_assign|resample_|rle_|amax_|quantize_|bn_)"),
+    ("library_gemm_fp32", r"^Cijk_.*_S_B"),
+    ("library_gemm_bf16", r"^(Cijk_|.*kernel_batched_gemm|.*kernel_gemm)"),
+    ("miopen_conv", r"(igemm_|grouped_conv|naive_conv|SubTensorOp|batched_transpose|gridwise|Conv|conv|MIOpen|miopen|Im2Col|Col2Im|transpose_)"),
+    ("memset_copy", r"(fillBuffer|copyBuffer|Memcpy|Memset|memcpy|memset)"),
+]
+
+
+def profile_categories(step, batches, nsteps=2):
+    """GPU-busy time per step by kernel family from torch.profiler's device activity records of `nsteps` extra eager
+    steps (after the timed region).  -> (list of {category, ms_per_step, launches_per_step}, busy_ms_per_step, launches)"""
+    import collections
+    import re
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for i in range(nsteps):
+            step(batches[i % len(batches)])
+        torch.cuda.synchronize()
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for e in prof.events():
+        if getattr(e, "device_type", None) is None or "CUDA" not in str(e.device_type):
+            continue
+        us = float(getattr(e, "device_time_total", 0.0) or getattr(e, "cuda_time_total", 0.0) or 0.0)
+        name = re.sub(r"^void ", "", e.name)
+        name = re.sub(r"\(anonymous namespace\)::", "", name)
+        cat = next((c for c, pat in _CATEGORIES if re.search(pat, name)), "torch_aten_other")
+        agg[cat][0] += us
+        agg[cat][1] += 1
+    busy = sum(v[0] for v in agg.values())
+    out = [{"category": c, "ms_per_step": v[0] / 1e3 / nsteps, "launches_per_step": v[1] / nsteps, "share": v[0] / max(busy, 1e-9)}
+           for c, v in sorted(agg.items(), key=lambda kv: -kv[1][0])]
+    return out, busy / 1e3 / nsteps, sum(v[1] for v in agg.values()) / nsteps
+
+
+def category_rooflines(cats, batch, size, freeze):
+    """attach algorithmic work + roofline fraction to the families whose work is a closed form of the workload
+    (encoder tokens M = batch * sum_l (size/stride_l)^2, 6 encoder layers)."""
+    M = batch * sum((size // st) ** 2 for st in (32, 16, 8))
+    hw4 = batch * (size // 4) ** 2
+    enc_w = 0 if "encoder" in freeze else 1                 # frozen encoder: no weight gradients (and the backbone's none either)
+    work = {
+        # fp32 weight gradients of the 6 encoder layers: value/out 256x256, offsets+weights 288x256, FFN 2 x 1024x256
+        "own_fp32_wgrad_mfma": (6 * 2.0 * M * (2 * 256 * 256 + 288 * 256 + 2 * 1024 * 256) * enc_w, MFMA_FP32_PEAK_TFLOPS, "fp32 matrix 157.3 TF"),
+        # encoder FFN forward + input gradient, 3x3 FPN conv forward + input gradient: 6 bf16 MFMA products per fp32 product
+        "own_fp32x3_gemm_conv": (6.0 * (6 * 2 * 2.0 * M * 2 * 256 * 1024 / 2 + 2 * 2.0 * hw4 * 9 * 256 * 256), 2500.0, "bf16 matrix 2.5 PF, 6 bf16 products per fp32 product"),
+        # 256-wide projections of the encoder, forward + input gradient
+        "library_gemm_fp32": (6 * 2 * 2.0 * M * (2 * 256 * 256 + 288 * 256), MFMA_FP32_PEAK_TFLOPS, "fp32 matrix 157.3 TF"),
+    }
+    for c in cats:
+        w = work.get(c["category"])
+        if w and w[0] > 0 and c["ms_per_step"] > 0:
+            tf = w[0] / (c["ms_per_step"] * 1e-3) / 1e12
+            c.update({"alg_gflop_per_step": w[0] / 1e9, "achieved_TFLOPs": tf, "peak_TFLOPs": w[1], "frac": tf / w[1], "peak_note": w[2]})
+    return cats
 
 
 def roofline_of(dom, kernels):
@@ -148,6 +254,9 @@ def main():
     ap.add_argument("--freeze", default="", help='comma list for MODEL.MASK_FORMER.FREEZE_KEYS, e.g. "backbone,encoder"')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run only the CPU oracle timing and print it")
+    ap.add_argument("--parity-file", default="", help="(internal) state the GPU parity step left for the oracle child")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of one benchmarked-precision step")
+    ap.add_argument("--no-categories", action="store_true", help="skip the torch.profiler per-family GPU time table")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--miopen-find", type=int, default=1, help="1: let MIOpen search conv algorithms during warm-up")
     ap.add_argument("--skip-kernel-timing", action="store_true", help="skip the eager per-launch timing steps (profiling runs)")
@@ -158,7 +267,7 @@ def main():
     a = ap.parse_args()
 
     if a.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(list(a.opts), a.size, threads=a.cpu_threads or None)), flush=True)
+        print(json.dumps(cpu_baseline(list(a.opts), a.size, threads=a.cpu_threads or None, parity_file=a.parity_file or None)), flush=True)
         return
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -235,6 +344,30 @@ def main():
         wgrad = gemm_fn.timing()
         msda_fn.enable_timing(False)
         gemm_fn.enable_timing(False)
+    cats = None
+    if rank == 0 and world == 1 and not a.no_categories:
+        try:
+            cats = profile_categories(step, batches)
+        except Exception as e:                                     # noqa: BLE001 - a profiler problem must not cost the bench line
+            cats = ({"error": repr(e)}, None, None)
+    # one step at the benchmarked precision whose 30 losses the CPU oracle recomputes on identical inputs (N=1 only)
+    parity_file, parity_gpu = None, None
+    if rank == 0 and world == 1 and not a.no_parity and not a.no_cpu_baseline and not a.opts and not freeze:
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import common as C
+        one = make_batch(1, a.size, seed=4321, device="cuda")
+        sd = {k: v.detach().float().cpu().clone() for k, v in step.state_dict()["model"].items()}
+        step.model.criterion.rand = C.ReplayRand(2718)
+        real_step, step.optimizer.step = step.optimizer.step, (lambda: None)       # forward + backward only: weights stay as dumped
+        pl = step(one)
+        step.optimizer.step, step.model.criterion.rand = real_step, None
+        rows, cols = pl.indices
+        parity_gpu = {k: float(v) for k, v in pl.items()}
+        fd, parity_file = tempfile.mkstemp(suffix=".pt", prefix="pd_parity_")
+        os.close(fd)
+        torch.save({"sd": sd, "image": one[0]["image"].cpu(), "masks": one[0]["instances"].gt_masks.tensor.cpu(), "seed": torch.tensor(2718),
+                    "rows": rows.cpu(), "cols": cols.cpu(), "n_targets": torch.tensor(one[0]["instances"].gt_masks.tensor.shape[0])}, parity_file)
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -279,8 +412,43 @@ def main():
                        "final_total_loss": total_loss, "host_issue_ms_per_step": issue / a.steps * 1e3},
             "roofline": roofline_of(dom, kernels),
         }
+        # whole-step matrix-core fraction (1 565 GFLOP / image full fine-tune, ~1 030 frozen; of the full
+        # step ~870 GF / image are fp32 pixel-decoder work pinned by the reference's precision contract, the rest bf16)
+        gf_img = 1030.0 if freeze else 1565.0
+        fp32_gf = (870.0 if not freeze else 870.0 * 2 / 3) * a.batch
+        bf16_gf = gf_img * a.batch - fp32_gf
+        floor_ms = fp32_gf / MFMA_FP32_PEAK_TFLOPS + bf16_gf / 2500.0
+        out["whole_step"] = {"alg_gflop_per_image": gf_img, "achieved_TFLOPs": gf_img * out["value"] / world / 1e3,
+                             "composite_floor_ms": floor_ms, "mfma_fraction": floor_ms / out["ms_per_step"],
+                             "note": "floor = fp32 share at the 157.3 TF fp32 matrix peak + bf16 share at 2.5 PF; mfma_fraction = floor / measured step"}
+        if cats is not None:
+            table, busy, launches = cats
+            if busy is None:
+                out["categories"] = table
+            else:
+                out["categories"] = {"gpu_busy_ms_per_step": busy, "launches_per_step": launches, "source": "torch.profiler device records, 2 eager steps after the timed region",
+                                     "families": category_rooflines(table, a.batch, a.size, freeze)}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_subprocess(list(a.opts), a.size)
+            cb = cpu_baseline_subprocess(list(a.opts), a.size, parity_file=parity_file)
+            po = cb.pop("_parity", None) if isinstance(cb, dict) else None
+            out["cpu_baseline"] = cb
+            if parity_gpu is not None and po and "losses" in po:
+                rel = {k: abs(parity_gpu[k] - v) / max(abs(v), 1e-12) for k, v in po["losses"].items()}
+                ab = {k: abs(parity_gpu[k] - v) for k, v in po["losses"].items()}
+                worst = max(rel, key=rel.get)
+                out["parity"] = {"what": "30 weighted losses of one bf16-autocast step (1 image, weights after the timed steps, replayed points) vs the fp32 CPU oracle on identical inputs",
+                                 "n_losses": len(rel), "max_rel_loss_dev": rel[worst], "max_abs_loss_dev": max(ab.values()), "worst_term": worst,
+                                 "total_gpu": sum(parity_gpu.values()), "total_cpu": sum(po["losses"].values()),
+                                 "assignments_differing_from_oracle_optimum": po["assignments_differing"],
+                                 "assignment_cost_gap_rel": po["assignment_cost_gap"], "tolerance_rel": 2e-2,
+                                 "within_tolerance": all(ab[k] <= 2e-2 * abs(po["losses"][k]) + 2e-3 for k in ab)}
+            elif parity_gpu is not None:
+                out["parity"] = {"error": (po or {}).get("error", "the oracle child returned no losses")}
+            if parity_file:
+                try:
+                    os.remove(parity_file)
+                except OSError:
+                    pass
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -257,14 +257,17 @@ def matcher_cost(logits, pred_masks, labels, tgt_masks, coords, w_class, w_mask,
 
 
 @torch.no_grad()
-def hungarian_match(outputs, targets, rand, *, w_class, w_mask, w_dice, num_points):
-    """HungarianMatcher.memory_efficient_forward, modeling/matcher.py:100-168."""
+def hungarian_match(outputs, targets, rand, *, w_class, w_mask, w_dice, num_points, costs=None):
+    """HungarianMatcher.memory_efficient_forward, modeling/matcher.py:100-168.  ``costs``: optional list that receives
+    every image's [Q, n] cost matrix (for the tests' "is this assignment optimal under the oracle's costs" check)."""
     res = []
     for b in range(outputs["pred_logits"].shape[0]):
         coords = rand((1, num_points, 2))
         C = matcher_cost(outputs["pred_logits"][b], outputs["pred_masks"][b], targets[b]["labels"],
                          targets[b]["masks"], coords, w_class, w_mask, w_dice)
         C = C.reshape(C.shape[0], -1).cpu()
+        if costs is not None:
+            costs.append(C.clone())
         row, col = lsa(C)
         order = C[row, col].topk(len(row), largest=False)[1]                 # :162
         res.append((torch.as_tensor(row[order.numpy()], dtype=torch.int64).reshape(-1),
@@ -326,19 +329,27 @@ def loss_masks(pred_masks, targets, indices, num_masks, rand, num_points, oversa
 
 def set_criterion(outputs, targets, rand, *, num_classes, eos_coef=0.1, w_class=2.0, w_mask=5.0, w_dice=5.0,
                   num_points=12544, oversample=3.0, importance=0.75, world_size=1, num_masks_total=None,
-                  match_points=None, return_indices=False):
+                  match_points=None, return_indices=False, indices_override=None, costs=None):
     """SetCriterion.forward, criterion.py:235-270: match + CE + point BCE/dice
-    for the final output and each aux output.  Unweighted losses (30 keys)."""
+    for the final output and each aux output.  Unweighted losses (30 keys).
+    Test hooks: ``costs`` (list) receives the per-(head, image) cost matrices; ``indices_override`` (list per head of
+    per-image (rows, cols)) replaces the assignment the losses are computed with — the matcher still runs (same random
+    draws, its own optimum is what ``return_indices`` hands back)."""
     empty_weight = torch.ones(num_classes + 1)
     empty_weight[-1] = eos_coef
     nm = float(sum(len(t["labels"]) for t in targets)) if num_masks_total is None else float(num_masks_total)
     num_masks = max(nm / world_size, 1.0)
     losses, all_idx = {}, []
     layers = [("", outputs)] + [(f"_{i}", a) for i, a in enumerate(outputs.get("aux_outputs", []))]
-    for suffix, out in layers:
+    for li, (suffix, out) in enumerate(layers):
+        hc = [] if costs is not None else None
         idx = hungarian_match(out, targets, rand, w_class=w_class, w_mask=w_mask, w_dice=w_dice,
-                              num_points=match_points or num_points)
+                              num_points=match_points or num_points, costs=hc)
         all_idx.append(idx)
+        if costs is not None:
+            costs.append(hc)
+        if indices_override is not None:
+            idx = indices_override[li]
         losses["loss_ce" + suffix] = loss_labels(out["pred_logits"], targets, idx, num_classes, empty_weight)
         bce, dice = loss_masks(out["pred_masks"], targets, idx, num_masks, rand, num_points, oversample, importance)
         losses["loss_mask" + suffix], losses["loss_dice" + suffix] = bce, dice
@@ -420,7 +431,8 @@ PIXEL_STD = (58.395, 57.120, 57.375)
 
 def proposal_model_losses(sd, batched_inputs, rand, *, backbone="r50", num_classes=1, dec_layers=10, nheads=8,
                           enc_layers=6, num_points=12544, oversample=3.0, importance=0.75, size_div=32,
-                          world_size=1, part=None, backbone_fn=None):
+                          world_size=1, part=None, backbone_fn=None, match_points=None, return_indices=False,
+                          indices_override=None, costs=None):
     """ProposalModel.forward train branch, proposal_model.py:177-204 (and
     PartDistillationModel.forward :197-226 when ``part=num_part_classes``):
     normalise -> pad -> backbone -> head -> criterion -> weight."""
@@ -437,11 +449,13 @@ def proposal_model_losses(sd, batched_inputs, rand, *, backbone="r50", num_class
     mf, _, ms = pixel_decoder_forward(sd, "sem_seg_head.pixel_decoder", feats, nheads=nheads, enc_layers=enc_layers)
     out = decoder_forward(sd, "sem_seg_head.predictor", ms, mf, nheads=nheads, dec_layers=dec_layers - 1,
                           part=(targets, part) if part is not None else None)
-    losses = set_criterion(out, targets, rand, num_classes=num_classes if part is None else part,
-                           num_points=num_points, oversample=oversample, importance=importance,
-                           world_size=world_size)
+    losses, idx = set_criterion(out, targets, rand, num_classes=num_classes if part is None else part,
+                                num_points=num_points, oversample=oversample, importance=importance,
+                                world_size=world_size, match_points=match_points, return_indices=True,
+                                indices_override=indices_override, costs=costs)
     wd = weight_dict(dec_layers)
-    return {k: v * wd[k] for k, v in losses.items() if k in wd}
+    losses = {k: v * wd[k] for k, v in losses.items() if k in wd}
+    return (losses, idx) if return_indices else losses
 
 
 # ----------------------------------------------------------------------------- optimizer

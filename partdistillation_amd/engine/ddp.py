@@ -14,7 +14,7 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("group", "t_begin", "t_end", "start", "end", "pending", "total", "work")
+    __slots__ = ("group", "t_begin", "t_end", "start", "end", "pending", "total", "work", "index")
 
     def __init__(self, group, t_begin, t_end, start, end):
         self.group, self.t_begin, self.t_end, self.start, self.end = group, t_begin, t_end, start, end
@@ -40,6 +40,9 @@ class BucketedGradReducer:
                     for q in g.params[t0:t + 1]:
                         self._param_bucket[q] = b
                     t0 = t + 1
+        for i, b in enumerate(self.buckets):
+            b.index = i
+        self._next = 0                    # collectives are issued in bucket-index order on every rank (see _on_grad)
         self._use_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         dev = flat.groups[0].grad.device
         self._side = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and overlap) else None
@@ -51,10 +54,15 @@ class BucketedGradReducer:
 
     # ------------------------------------------------------------------ hooks
     def _on_grad(self, p):
+        """a bucket is all-reduced once ITS gradients are complete AND every bucket before it has been issued: the ranks
+        then issue the same collectives in the same order even when the set of parameters that received gradients
+        differs between them in a step (data-dependent branches: empty targets, the per-head criterion loop) — the
+        ordering rule torch DDP enforces.  Buckets held back by an unused parameter go out in finish()."""
         b = self._param_bucket[p]
         b.pending -= 1
-        if b.pending == 0:
-            self._launch(b)
+        while self._next < len(self.buckets) and self.buckets[self._next].pending <= 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def _launch(self, b):
         g = self.flat.groups[b.group]
@@ -76,9 +84,9 @@ class BucketedGradReducer:
         collectives and make the compute stream wait for the side stream."""
         if self.world == 1:
             return
-        for b in self.buckets:
-            if b.work is None:
-                self._launch(b)
+        for b in self.buckets[self._next:]:                      # in index order, like the hooks
+            self._launch(b)
+        self._next = 0
         for b in self.buckets:
             buf = self.flat.groups[b.group].grad[b.start:b.end]
             if self._side is not None:

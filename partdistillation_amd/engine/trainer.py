@@ -64,11 +64,21 @@ class TrainStep:
     # ------------------------------------------------------------------ hipGraph
     @staticmethod
     def _signature(batch):
-        return tuple((tuple(x["image"].shape), tuple(x["instances"].gt_masks.tensor.shape), x.get("gt_object_class", 0) * 0)
+        """everything the captured step read on the HOST (and therefore baked into the graph): tensor shapes and the
+        image's object class (the part-distillation decoder selects class-head rows from it on the host)."""
+        return tuple((tuple(x["image"].shape), tuple(x["instances"].gt_masks.tensor.shape), int(x.get("gt_object_class", -1)))
                      for x in batch)
 
+    def _flat_state(self):
+        opt = self.optimizer
+        return ([g.param for g in opt.flat.groups] + [g.shadow for g in opt.flat.groups if g.shadow is not None]
+                + list(opt.exp_avg) + list(opt.exp_avg_sq))
+
     def capture(self, example_batch, warmup=3):
-        """capture the whole step for batches shaped like `example_batch` (single process only)."""
+        """capture the whole step for batches shaped like `example_batch` (single process only).  The warm-up runs real
+        steps (allocator growth, MIOpen/BLAS lazy initialisation need the full kernel sequence) on a SNAPSHOT of the
+        weights, bf16 shadows and Adam moments that is restored afterwards, so capturing does not move the training
+        trajectory (weights, moments and step count are exactly what they were before the call)."""
         if self.world > 1:
             raise RuntimeError("hipGraph capture of the step is for the single-GPU path (collectives stay eager)")
         static = []
@@ -81,11 +91,18 @@ class TrainStep:
         # warm-up on the CURRENT stream (allocator growth, MIOpen/BLAS lazy initialisation).  NB: the usual
         # "warm up on a side stream" recipe makes the second replay of this graph fault on ROCm 7.2 (observed:
         # tools/debug_graph2.py cap0 vs DBG_NOSIDE), so no extra stream is created here.
+        live = self._flat_state()
+        snapshot = [t.clone() for t in live]
+        steps0 = self.optimizer.steps
         for _ in range(warmup):
             self._forward_backward(static)
             self.optimizer.step()
+        with torch.no_grad():
+            for t, s in zip(live, snapshot):
+                t.copy_(s)
+        self.optimizer.steps = steps0
+        del snapshot
         torch.cuda.synchronize()
-        self.optimizer.steps -= warmup                         # warm-up steps used the real optimizer: rewind the count only
         graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad()
         with torch.cuda.graph(graph):
@@ -123,6 +140,16 @@ class TrainStep:
         sd = {k: v for k, v in self.model.state_dict().items()}
         sd.update(self.optimizer.flat.master_state())
         return {"model": sd, "optimizer": self.optimizer.state_dict(), "iteration": self.iter}
+
+    def load_state_dict(self, sd, strict=False):
+        """resume from state_dict(): weights (modules + fp32 masters), Adam moments and step count, the iteration and the
+        position of the LR schedule (so a reloaded run does not restart the warm-up)."""
+        missing = self.load_model_state(sd["model"], strict=strict)
+        self.optimizer.load_state_dict(sd["optimizer"])
+        self.iter = int(sd["iteration"])
+        self.scheduler.last_iter = self.iter
+        self.scheduler._apply()
+        return missing
 
     def load_model_state(self, model_sd, strict=False):
         """load reference-format weights: into the modules (bf16 copies) AND the fp32 masters."""

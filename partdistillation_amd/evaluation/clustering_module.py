@@ -5,8 +5,9 @@ The reference moves every feature to the CPU, gathers them on rank 0 and runs sk
 per class there.  Here the features stay on the device and each class is clustered by functions/kmeans.py (sklearn's Lloyd
 semantics: centred data, variance-scaled tolerance, first-minimum assignment; k-means++ seeding from a seeded device
 generator — numpy's RandomState stream is not reproduced, `init` injects centres for parity tests).  With several ranks
-the (feature, label) lists are exchanged with all_gather_object and every rank clusters the same data (deterministic, so
-no broadcast of the result is needed)."""
+the (feature, label) lists are exchanged with all_gather_object, rank 0 clusters (classes with too few proposals get
+torch.randn centroids from ITS generator, reference :66-67) and its dictionary is broadcast — every rank ends up with
+rank 0's classifier, as with the reference's `all_gather(cluster_centroids_dict)[0]` (:72-73)."""
 import copy
 
 import torch
@@ -30,22 +31,28 @@ class ClusteringModule:
 
     def evaluate(self):
         feats, labels = self._proposal_features, self._class_labels_list
-        if self._distributed and torch.distributed.is_available() and torch.distributed.is_initialized() \
-                and torch.distributed.get_world_size() > 1:
-            dev = feats[0].device if feats else torch.device("cpu")
-            gathered = [None] * torch.distributed.get_world_size()
-            torch.distributed.all_gather_object(gathered, ([f.cpu() for f in feats], [l.cpu() for l in labels]))
+        dist = torch.distributed
+        multi = self._distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        dev = feats[0].device if feats else torch.device("cpu")
+        if multi:
+            gathered = [None] * dist.get_world_size()
+            dist.all_gather_object(gathered, ([f.cpu() for f in feats], [l.cpu() for l in labels]))
             feats = [f.to(dev) for g in gathered for f in g[0]]
             labels = [l.to(dev) for g in gathered for l in g[1]]
-        feats = torch.cat(feats, dim=0).float()
-        labels = torch.cat([l.to(feats.device) for l in labels], dim=0)
         out = {}
-        for cid in labels.unique().tolist():
-            x = feats[labels == cid]
-            if x.shape[0] > self.num_clusters:
-                out[int(cid)] = self._get_cluster_centroids(x, int(cid))
-            else:                                 # too few proposals of this class (reference :66-67)
-                out[int(cid)] = torch.randn(self.num_clusters, x.shape[1], device=x.device)
+        if not multi or dist.get_rank() == 0:                     # the main process clusters (reference :58-67)
+            feats = torch.cat(feats, dim=0).float()
+            labels = torch.cat([l.to(feats.device) for l in labels], dim=0)
+            for cid in labels.unique().tolist():
+                x = feats[labels == cid]
+                if x.shape[0] > self.num_clusters:
+                    out[int(cid)] = self._get_cluster_centroids(x, int(cid))
+                else:                                 # too few proposals of this class (reference :66-67)
+                    out[int(cid)] = torch.randn(self.num_clusters, x.shape[1], device=x.device)
+        if multi:                                                 # ... and everyone takes ITS result (reference :69-71)
+            box = [{k: v.cpu() for k, v in out.items()}]
+            dist.broadcast_object_list(box, src=0)
+            out = {k: v.to(dev) for k, v in box[0].items()}
         return copy.deepcopy(out)
 
     def _get_cluster_centroids(self, x, cid):

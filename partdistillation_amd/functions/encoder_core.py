@@ -120,6 +120,11 @@ class EncoderCore(Function):
         M, L, P = spec.M, spec.L, spec.P
         T = B * S
         dev = d_out.device
+        # frozen encoder (FREEZE_KEYS contains "encoder", the shipped scripts' setting: base_trainer.py:97-100): none of its
+        # parameters requires a gradient, so the five weight-gradient GEMMs per layer (a third of the encoder's backward
+        # FLOPs) are skipped; the input gradient still flows (input_proj / level_embed in front of it stay trainable)
+        need_w = any(ctx.needs_input_grad[3:])
+        wgrad = gemm_wgrad_acc if need_w else (lambda *a, **k: None)
         # every parameter gradient of the encoder lives in ONE zero-filled fp32 buffer (a single memset): the LayerNorm /
         # ReLU kernels and the split-K weight-gradient GEMMs all accumulate (+=) into their slices
         offs, total = [], 0
@@ -152,25 +157,25 @@ class EncoderCore(Function):
             # ---- FFN + norm2
             dz2, _ = rw.add_ln_bwd(z2, m2, r2, n2_w, dy=dy, dy2=dy2, dypos_c=dyq, dgamma=g_n2w, dbeta=g_n2b, dbias=g_l2b,
                                    dpos_acc=d_pos if dyq is not None else None, pos_div=1)
-            gemm_wgrad_acc(dz2, h, g_l2w)
+            wgrad(dz2, h, g_l2w)
             dh = rw.relu_bwd_colsum(_ffn_gemm(dz2, l2_w.t().contiguous()), h, g_l1b)
-            gemm_wgrad_acc(dh, y1, g_l1w)
+            wgrad(dh, y1, g_l1w)
             dy1 = _ffn_gemm(dh, l1_w.t().contiguous())
             del dh
             # ---- deformable attention + norm1
             dz1, _ = rw.add_ln_bwd(z1, m1, r1, n1_w, dy=dz2, dy2=dy1, dgamma=g_n1w, dbeta=g_n1b, dbias=g_opb, out=dz2)
-            gemm_wgrad_acc(dz1, a, g_opw)
+            wgrad(dz1, a, g_opw)
             da = torch.mm(dz1, op_w).view(B, S, C)
             gv, gloc, gattn = _timed("bwd", MSDA.ms_deform_attn_backward, v4, spec.shapes, spec.lsi, loc6, attn5, da, spec.im2col_step)
             d_oa = torch.empty((T, w_oa.shape[0]), dtype=torch.float32, device=dev)
             msda_prep_bwd(gloc, gattn, attn5, spec.shapes, T, M, L, P, out=d_oa)
             g_oaw, g_oab = OA(i)
-            gemm_wgrad_acc(d_oa, q, g_oaw, g_oab)                                  # both weight gradients in one split-K GEMM
+            wgrad(d_oa, q, g_oaw, g_oab)                                  # both weight gradients in one split-K GEMM
             n_off = so_w.shape[0]
             g_sow, g_aww, g_sob, g_awb = g_oaw[:n_off], g_oaw[n_off:], g_oab[:n_off], g_oab[n_off:]
             dq = torch.mm(d_oa, w_oa)
             gv2 = gv.view(T, C)
-            gemm_wgrad_acc(gv2, x, g_vpw, g_vpb)
+            wgrad(gv2, x, g_vpw, g_vpb)
             dxv = torch.mm(gv2, vp_w)
             grads[i * N_LAYER:(i + 1) * N_LAYER] = [g_sow, g_sob, g_aww, g_awb, g_vpw, g_vpb, g_opw, g_opb, g_n1w, g_n1b,
                                                      g_l1w, g_l1b, g_l2w, g_l2b, g_n2w, g_n2b]
@@ -178,4 +183,6 @@ class EncoderCore(Function):
         d_pos += dyq
         d_src = dy + dy2
         d_src += dyq
+        if not need_w:
+            grads = [None] * len(grads)
         return (None, d_src.view(B, S, C), d_pos.view(B, S, C), *grads)

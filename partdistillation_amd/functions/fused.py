@@ -55,22 +55,34 @@ def affine_act(x, scale, bias, residual=None, relu=True):
 class PinnedRing:
     """Ring of pinned host staging buffers for small host->device tables that are rewritten every step.  A slot is
     rewritten only after the async copy that read it has executed (one event per slot): the host may run steps ahead
-    of the device without a later step's table overwriting one still waiting to be copied."""
+    of the device without a later step's table overwriting one still waiting to be copied.
+
+    While a hipGraph is being captured the copy becomes a memcpy NODE that re-reads its host buffer at every replay,
+    so a ring slot (recycled by later eager uploads) must never back it: acquire() then hands out a DEDICATED pinned
+    buffer that is kept alive for the life of the ring and never written again."""
 
     def __init__(self, shape, dtype, pin, slots=8):
         self.bufs = [torch.zeros(shape, dtype=dtype, pin_memory=pin) for _ in range(slots)]
         self.events = [None] * slots
         self.pin, self.i = pin, -1
+        self.captured = []                                   # buffers baked into captured graphs (never recycled)
+        self._in_capture = False
 
     def acquire(self):
+        if self.pin and torch.cuda.is_current_stream_capturing():
+            buf = torch.zeros_like(self.bufs[0]).pin_memory()
+            self.captured.append(buf)
+            self._in_capture = True
+            return buf
+        self._in_capture = False
         self.i = (self.i + 1) % len(self.bufs)
-        if self.events[self.i] is not None and not torch.cuda.is_current_stream_capturing():
+        if self.events[self.i] is not None:
             self.events[self.i].synchronize()
         return self.bufs[self.i]
 
     def release(self):
         """call after enqueueing the copy out of the buffer acquire() returned"""
-        if self.pin and not torch.cuda.is_current_stream_capturing():
+        if self.pin and not self._in_capture:
             ev = self.events[self.i] or torch.cuda.Event()
             ev.record()
             self.events[self.i] = ev

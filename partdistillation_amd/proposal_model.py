@@ -102,6 +102,7 @@ class _MaskFormerTrainBase(nn.Module):
                 if k in wd:
                     out[k] = part
         out.total = total
+        out.indices = getattr(losses, "indices", None)                # matched (query, target) pairs of every (image, head)
         return out
 
 
