@@ -34,6 +34,7 @@ extern "C" int pd_abi_version(void) { return 15; }
 extern int g_pd_dbg_atomic_scope;
 extern int g_pd_dbg_force_generic;
 extern int g_pd_dbg_ablate;
+extern int g_pd_dbg_bwd_variant;
 extern int g_pd_dbg_wgrad_wgs;
 extern int g_pd_dbg_bwd_threads;
 extern int g_pd_dbg_attn_scalar;
@@ -45,6 +46,7 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!key) return PD_ERR_INVALID_ARG;
   if (!strcmp(key, "msda_bwd_atomic_scope")) { g_pd_dbg_atomic_scope = value; return PD_OK; }
   if (!strcmp(key, "msda_ablate")) { g_pd_dbg_ablate = value; return PD_OK; }
+  if (!strcmp(key, "msda_bwd_variant")) { g_pd_dbg_bwd_variant = value; return PD_OK; }
   if (!strcmp(key, "attn_scalar")) { g_pd_dbg_attn_scalar = value; return PD_OK; }
   if (!strcmp(key, "msda_bwd_threads")) { g_pd_dbg_bwd_threads = value; return PD_OK; }
   if (!strcmp(key, "wgrad_wgs")) { g_pd_dbg_wgrad_wgs = value; return PD_OK; }

@@ -34,6 +34,7 @@ int g_pd_dbg_force_generic = 0;
 int g_pd_dbg_bwd_threads = 0;
 int g_pd_dbg_ablate = 0;
 int g_pd_dbg_atomic_scope = 0;   // experiments only (pd_debug_set): 0 = agent scope, 1 = workgroup scope
+int g_pd_dbg_bwd_variant = 0;    // experiments only: 1 = the per-destination-level tiled backward instead of the all-level owner kernel
 
 namespace {
 
@@ -430,6 +431,295 @@ __global__ __launch_bounds__(1024) void msda_bwd_tiled_d32(const float *__restri
   }
 }
 
+// ----------------------------------------------------------------------------------------- owner backward (all levels per workgroup)
+// What the per-destination-level kernel above was bound by, measured with its ablation switches (tools/bench_msda.py): with
+// every atomic removed the pass still took 0.30 of its 0.38 ms, without the value gathers as well 0.27, without the stores
+// 0.27, without the main loop 0.04 — the loop is bound by VECTOR INSTRUCTION ISSUE, not by memory or atomics: every one of
+// the 8 lanes of a (query, head) repeats the coordinate / corner / window arithmetic of a point, every LDS add paid for
+// its own slot computation and float -> int conversion, and grad_loc / grad_attn cost 12 FMAs per channel.  This kernel
+//   * gives ONE workgroup per (batch, tile, head) the destination windows of ALL three levels (standard pyramid at G = 8
+//     with a halo of 5 cells: 26x26 + 18x18 + 14x14 cells x 132 B = 154 KB of the 160 KB LDS), so a query's sampling
+//     locations, attention weights and grad_out are read by one workgroup instead of three;
+//   * gives a (query, head) to 4 lanes with 8 channels each (the lane-redundant part of the work halves, the cross-lane
+//     sums are 2 DPP steps) and walks (query, level) units: 1008 units over 256 lane groups keep 98 % of the lanes busy,
+//     and neighbouring lane groups work on different levels, i.e. on different windows (fewer same-cell collisions);
+//   * computes grad_attn / grad_loc from the four corner dot products S_k = <grad_out, value row k> (they are linear in
+//     them): 4 packed FMAs per corner and lane, then 12 operations per point;
+//   * rounds a contribution to its fixed-point integer with ONE fused multiply-add (x + 1.5 * 2^23 lands on the integer
+//     grid; bit pattern = 0x4B400000 + integer) and does NOT subtract the offset: the int32 slots wrap modulo 2^32 and the
+//     flush removes count * 0x4B400000, a 33rd word per cell counting the corner contributions it received;
+//   * addresses a cell as cell * 33 + channel: the lane's eight channels are immediate offsets of the ds_add, and the odd
+//     pitch staggers neighbouring cells over the banks (the 16 lane groups of a wavefront meet 2 to a bank, the minimum
+//     for 64 lanes; an XOR swizzle by multiples of 4 left them 8 to a bank);
+//   * takes the common case — all four corners inside the map and inside the window — as straight-line code, per-corner
+//     tests only otherwise, and moves the direct-global-atomic fallback (corner outside every window: large learned
+//     offset) out of the loop into a rolled epilogue that re-reads the point, so it costs the loop no registers;
+//   * uses 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate) for pixel / element indices — the host admits the
+//     kernel only when they fit.
+// Same fixed-point scheme and guarantees as above (order-independent, cannot overflow, result independent of tile / halo
+// sizes).  Levels whose window does not fit the LDS budget (non-pyramid shapes) get no window: direct atomics.
+// 0.378 -> 0.233 ms per launch at config 2 (tools/bench_msda.py, default spread).
+constexpr int kHalo4 = 5, kWin4 = kTile + 2 * kHalo4, kOwnCells4 = 1200;
+
+__device__ __forceinline__ float group4_sum(float x)
+{
+  x = dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]
+  return x;
+}
+
+template <int ABL>
+__global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
+                                                            const int64_t *__restrict__ lvl_start, const float *__restrict__ loc,
+                                                            const float *__restrict__ attn, const float *__restrict__ grad_out,
+                                                            float *__restrict__ grad_value, float *__restrict__ grad_loc,
+                                                            float *__restrict__ grad_attn, int S, int M, int B)
+{
+  constexpr int L = 3, P = 4, LP = L * P;
+  extern __shared__ __attribute__((aligned(16))) int win[];   // kOwnCells4 cells x 33 words + 32 max slots + 32 scales
+  int Hs[L], Ws[L], ls[L], maxdim = 1;
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    Hs[j] = (int)shapes[2 * j]; Ws[j] = (int)shapes[2 * j + 1]; ls[j] = (int)lvl_start[j];
+    maxdim = max(maxdim, max(Hs[j], Ws[j]));
+  }
+  const int G = min(kGmax, (maxdim + kTile - 1) / kTile);
+  // block -> (batch, tile, head), heads fastest, over the ACTIVE tiles only (the host launches kGmax^2 per image: it cannot
+  // see G) and XCD-chunked (block i runs on XCD i % 8): an XCD owns whole (batch, tile)s with all their heads, so a
+  // query's loc / attn rows (all heads in one 768 / 384-byte run) are fetched into ONE L2
+  const int nact = B * G * G * M;
+  int idx;
+  if ((nact & 7) == 0) {
+    const int per = nact >> 3, k = blockIdx.x & 7, j = blockIdx.x >> 3;
+    if (j >= per) return;
+    idx = k * per + j;
+  } else {
+    if ((int)blockIdx.x >= nact) return;
+    idx = blockIdx.x;
+  }
+  const int m = idx % M; idx /= M;
+  const int tile = idx % (G * G);
+  const int b = idx / (G * G);
+  const int ty = tile / G, tx = tile % G;
+  struct LvlP { int H, W, ls, wy0, wx0, wh, ww, wbase; };
+  __shared__ LvlP lvp[L];
+  __shared__ int s_used, s_fixed_ok;
+  if (threadIdx.x == 0) {
+    int used = 0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      LvlP t;
+      t.H = Hs[j]; t.W = Ws[j]; t.ls = ls[j];
+      t.wy0 = max(0, ty * Hs[j] / G - kHalo4); t.wx0 = max(0, tx * Ws[j] / G - kHalo4);
+      t.wh = max(0, min(min(Hs[j], (ty + 1) * Hs[j] / G + kHalo4) - t.wy0, kWin4));
+      t.ww = max(0, min(min(Ws[j], (tx + 1) * Ws[j] / G + kHalo4) - t.wx0, kWin4));
+      if (used + t.wh * t.ww > kOwnCells4) { t.wh = 0; t.ww = 0; }     // no window: direct atomics for this level
+      t.wbase = used;
+      used += t.wh * t.ww;
+      lvp[j] = t;
+    }
+    s_used = used;
+    s_fixed_ok = 1;
+  }
+  int *chmax = win + kOwnCells4 * 33;
+  float *chscale = reinterpret_cast<float *>(chmax + 32);
+  const int NT = blockDim.x;
+  if (threadIdx.x < 32) chmax[threadIdx.x] = 0;
+  __syncthreads();
+  {
+    int4 *w4 = reinterpret_cast<int4 *>(win);
+    const int n4 = (s_used * 33 + 3) >> 2;
+    for (int i = threadIdx.x; i < n4; i += NT) w4[i] = make_int4(0, 0, 0, 0);
+  }
+  const int stride_w = M * 32;
+  // the tile's queries: source level j contributes the pixels [ry0, ry1) x [rx0, rx1)
+  int rx0[L], ry0[L], rw[L], nq[L];
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    ry0[j] = ty * Hs[j] / G; rx0[j] = tx * Ws[j] / G;
+    rw[j] = (tx + 1) * Ws[j] / G - rx0[j];
+    nq[j] = ((ty + 1) * Hs[j] / G - ry0[j]) * rw[j];
+  }
+  const int nq_all = nq[0] + nq[1] + nq[2];
+  auto query_of = [&](int i) {
+    int j = 0;
+    if (i >= nq[0]) { i -= nq[0]; j = 1; if (i >= nq[1]) { i -= nq[1]; j = 2; } }
+    const int rwj = j == 0 ? rw[0] : j == 1 ? rw[1] : rw[2];
+    const int y = i / rwj, x = i - y * rwj;
+    return (j == 0 ? ls[0] + (ry0[0] + y) * Ws[0] + rx0[0] : j == 1 ? ls[1] + (ry0[1] + y) * Ws[1] + rx0[1] : ls[2] + (ry0[2] + y) * Ws[2] + rx0[2]) + x;
+  };
+  // ---- pre-pass: per-channel max |grad_out| over the tile's queries (8 lanes x float4 per query row) -> fixed-point scale
+  {
+    const int sub8 = threadIdx.x & 7, grp8 = threadIdx.x >> 3, NG8 = NT >> 3;
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = grp8; i < nq_all; i += NG8) {
+      const int q = query_of(i);
+      const float4 go = *reinterpret_cast<const float4 *>(grad_out + (((int64_t)b * S + q) * M + m) * 32 + sub8 * 4);
+      mx[0] = fmaxf(mx[0], fabsf(go.x)); mx[1] = fmaxf(mx[1], fabsf(go.y));
+      mx[2] = fmaxf(mx[2], fabsf(go.z)); mx[3] = fmaxf(mx[3], fabsf(go.w));
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) atomicMax(&chmax[sub8 * 4 + c], __float_as_int(mx[c]));   // non-negative floats order like their bits
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const float mxc = __int_as_float(chmax[threadIdx.x]);
+    int ex;
+    (void)frexpf(mxc, &ex);                             // mxc < 2^ex
+    const bool fin = mxc > 0.f && mxc < 3.0e38f;
+    ex = fin ? min(max(ex, -100), 100) : 0;
+    chscale[threadIdx.x] = ldexpf(1.f, 22 - ex);
+    if (!(fin || mxc == 0.f)) s_fixed_ok = 0;           // a non-finite grad_out in the tile: bypass the windows
+  }
+  __syncthreads();
+  const bool fixed_ok = s_fixed_ok != 0;
+  // ---- main pass: a (query, level) unit per 4-lane group; lane `sub` owns channels [8 sub, 8 sub + 8)
+  const int sub = threadIdx.x & 3, grp = threadIdx.x >> 2, NG = NT >> 2;
+  const int nunits = nq_all * L;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  for (int u = grp; u < nunits; u += NG) {
+    const int qi = u / L, l = u - qi * L;
+    const int q = query_of(qi);
+    const int64_t qm = ((int64_t)b * S + q) * M + m;
+    const LvlP lv = lvp[l];
+    const int H = lv.H, W = lv.W;
+    const float4 g0 = *reinterpret_cast<const float4 *>(grad_out + qm * 32 + sub * 8), g1 = *reinterpret_cast<const float4 *>(grad_out + qm * 32 + sub * 8 + 4);
+    const float gs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float4 q0 = *reinterpret_cast<const float4 *>(chscale + sub * 8), q1 = *reinterpret_cast<const float4 *>(chscale + sub * 8 + 4);
+    const f32x2 gq2[4] = {{g0.x * q0.x, g0.y * q0.y}, {g0.z * q0.z, g0.w * q0.w}, {g1.x * q1.x, g1.y * q1.y}, {g1.z * q1.z, g1.w * q1.w}};
+    const f32x2 gs2[4] = {{gs[0], gs[1]}, {gs[2], gs[3]}, {gs[4], gs[5]}, {gs[6], gs[7]}};
+    const f32x2 magic2 = {12582912.f, 12582912.f};
+    const float4 *lp4 = reinterpret_cast<const float4 *>(loc + (qm * LP + l * P) * 2);
+    const float4 l01 = lp4[0], l23 = lp4[1];
+    const float4 a4 = *reinterpret_cast<const float4 *>(attn + qm * LP + l * P);
+    const float locs[8] = {l01.x, l01.y, l01.z, l01.w, l23.x, l23.y, l23.z, l23.w};
+    const float aw[4] = {a4.x, a4.y, a4.z, a4.w};
+    const int64_t voff = ((int64_t)b * S + lv.ls) * stride_w + m * 32 + sub * 8;
+    const float *vbase = value + voff;
+    float *gbase = grad_value + voff;
+    float keep_a = 0.f, keep_x = 0.f, keep_y = 0.f;
+    unsigned slow = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float a = aw[p];
+      const float h_im = locs[2 * p + 1] * H - 0.5f, w_im = locs[2 * p] * W - 0.5f;
+      const bool in_range = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+      // reference .cuh:38-89 geometry, written for the instruction count (24-bit multiplies, one clamp per coordinate)
+      const float hf = floorf(h_im), wf = floorf(w_im);
+      const int h_low = in_range ? (int)hf : 0, w_low = in_range ? (int)wf : 0;
+      float lh = h_im - hf, lw = w_im - wf;
+      if (!in_range) { lh = 0.f; lw = 0.f; }
+      float hh = 1.f - lh, hw = 1.f - lw;
+      if (!in_range) { hh = 0.f; hw = 0.f; }              // NaN / inf / far locations contribute exactly nothing
+      const bool hl = h_low >= 0, wl = w_low >= 0, hhi = h_low + 1 <= H - 1, whi = w_low + 1 <= W - 1;
+      const bool ok[4] = {in_range && hl && wl, in_range && hl && whi, in_range && hhi && wl, in_range && hhi && whi};
+      const int hlc = min(max(h_low, 0), H - 1), hhc = min(max(h_low + 1, 0), H - 1);
+      const int wlc = min(max(w_low, 0), W - 1), whc = min(max(w_low + 1, 0), W - 1);
+      const int r0 = __mul24(hlc, W), r1 = __mul24(hhc, W);
+      const int off[4] = {__mul24(r0 + wlc, stride_w), __mul24(r0 + whc, stride_w), __mul24(r1 + wlc, stride_w), __mul24(r1 + whc, stride_w)};
+      const float cw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+      // a masked corner is dropped AFTER its dot product (select: a NaN in a row the reference would never read cannot leak)
+      float Sk[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 t0 = *reinterpret_cast<const float4 *>(vbase + off[k]), t1 = *reinterpret_cast<const float4 *>(vbase + off[k] + 4);
+        f32x2 d = gs2[0] * f32x2{t0.x, t0.y};
+        d = __builtin_elementwise_fma(gs2[1], f32x2{t0.z, t0.w}, d);
+        d = __builtin_elementwise_fma(gs2[2], f32x2{t1.x, t1.y}, d);
+        d = __builtin_elementwise_fma(gs2[3], f32x2{t1.z, t1.w}, d);
+        Sk[k] = ok[k] ? d.x + d.y : 0.f;
+      }
+      float pa = cw[0] * Sk[0] + cw[1] * Sk[1] + cw[2] * Sk[2] + cw[3] * Sk[3];
+      float ph = hw * (Sk[2] - Sk[0]) + lw * (Sk[3] - Sk[1]);       // reference .cuh:122-158: d/dh, d/dw of the bilinear value
+      float pw = hh * (Sk[1] - Sk[0]) + lh * (Sk[3] - Sk[2]);
+      const int cy0 = h_low - lv.wy0, cx0 = w_low - lv.wx0;
+      auto add_corner = [&](int *h0, float sc) {
+        const f32x2 sc2 = {sc, sc};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x2 f = __builtin_elementwise_fma(sc2, gq2[c], magic2);
+          if (ABL & 1) { asm volatile("" ::"v"(h0), "v"(f.x), "v"(f.y)); }
+          else { atomicAdd(h0 + 2 * c, __float_as_int(f.x)); atomicAdd(h0 + 2 * c + 1, __float_as_int(f.y)); }   // ds_add_u32, immediate offsets
+        }
+        if (sub == 0 && !(ABL & 1)) atomicAdd(h0 + 32 - sub * 8, 1);
+      };
+      if (fixed_ok && ok[0] && ok[3] && (unsigned)cy0 < (unsigned)max(lv.wh - 1, 0) && (unsigned)cx0 < (unsigned)max(lv.ww - 1, 0)) {
+        // all four corners inside the map and inside the cached window (the common case): straight-line code
+        int *h00 = win + (lv.wbase + __mul24(cy0, lv.ww) + cx0) * 33 + sub * 8;
+        int *h10 = h00 + lv.ww * 33;
+        add_corner(h00, cw[0] * a);
+        add_corner(h00 + 33, cw[1] * a);
+        add_corner(h10, cw[2] * a);
+        add_corner(h10 + 33, cw[3] * a);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float sc = cw[k] * a;
+          if (ok[k] && !(fixed_ok && sc == 0.f)) {       // a zero weight (sample exactly on a pixel centre) adds nothing
+            const int cy = cy0 + (k >> 1), cx = cx0 + (k & 1);
+            if (fixed_ok && (unsigned)cy < (unsigned)lv.wh && (unsigned)cx < (unsigned)lv.ww)
+              add_corner(win + (lv.wbase + __mul24(cy, lv.ww) + cx) * 33 + sub * 8, sc);
+            else slow |= 1u << p;                 // a corner outside the cached window (large learned offset): rare, handled below
+          }
+        }
+      }
+      pa = group4_sum(pa);
+      pw = group4_sum(pw) * (a * W);
+      ph = group4_sum(ph) * (a * H);
+      if (sub == p) { keep_a = pa; keep_x = pw; keep_y = ph; }
+      __builtin_amdgcn_sched_barrier(0);          // one point's 8 rows in flight at a time: the next point's would not fit 128 VGPRs
+    }
+    grad_attn[qm * LP + l * P + sub] = keep_a;
+    reinterpret_cast<float2 *>(grad_loc + (qm * LP + l * P) * 2)[sub] = make_float2(keep_x, keep_y);
+    if (slow) {
+      // corners no window caches: direct global atomics (the result never depends on window / halo sizes).  Rolled, re-reading
+      // the point from memory, so that this rare path costs the loop above neither registers nor code
+#pragma unroll 1
+      for (int p = 0; p < P; ++p) {
+        if (!((slow >> p) & 1)) continue;
+        const float2 xy = *reinterpret_cast<const float2 *>(loc + (qm * LP + l * P + p) * 2);
+        const float a = attn[qm * LP + l * P + p];
+        const float h_im = xy.y * H - 0.5f, w_im = xy.x * W - 0.5f;
+        const bool in_range = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+        int off[4]; bool ok[4]; float cw[4], lh, lw, hh, hw;
+        corner_setup<float>(h_im, w_im, H, W, stride_w, in_range, off, ok, cw, lh, lw, hh, hw);
+        const int cy0 = (in_range ? (int)floorf(h_im) : 0) - lv.wy0, cx0 = (in_range ? (int)floorf(w_im) : 0) - lv.wx0;
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+          const int cy = cy0 + (k >> 1), cx = cx0 + (k & 1);
+          const bool cached = fixed_ok && (unsigned)cy < (unsigned)lv.wh && (unsigned)cx < (unsigned)lv.ww;
+          const int o = k == 0 ? off[0] : k == 1 ? off[1] : k == 2 ? off[2] : off[3];
+          const float w_ = k == 0 ? cw[0] : k == 1 ? cw[1] : k == 2 ? cw[2] : cw[3];
+          const bool okk = k == 0 ? ok[0] : k == 1 ? ok[1] : k == 2 ? ok[2] : ok[3];
+          const float sc = w_ * a;
+          if (!okk || cached || (fixed_ok && sc == 0.f)) continue;
+          float *g = gbase + o;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            if (ABL & 2) asm volatile("" ::"v"(g), "v"(sc * gs[c]));
+            else unsafeAtomicAdd(g + c, sc * gs[c]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- flush: lane = channel, one full 128-byte line per cell per half-wave
+#pragma unroll 1
+  for (int l = 0; l < L; ++l) {
+    const LvlP lv = lvp[l];
+    float *gl = grad_value + ((int64_t)b * S + lv.ls) * stride_w + m * 32;
+    const int cells = lv.wh * lv.ww;
+    for (int i = threadIdx.x; i < cells * 32; i += NT) {
+      const int cellw = i >> 5, ch = i & 31;
+      const int *cp = win + (lv.wbase + cellw) * 33;
+      const int acc = (int)((unsigned)cp[ch] - (unsigned)cp[32] * 0x4B400000u);
+      const float v = (float)acc / chscale[ch];           // chscale is a power of two: exact
+      if (acc != 0 && !(ABL & 4)) unsafeAtomicAdd(gl + ((int64_t)(lv.wy0 + cellw / lv.ww) * lv.W + lv.wx0 + cellw % lv.ww) * stride_w + ch, v);
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------------- generic forward
 template <typename T>
 __global__ __launch_bounds__(256) void msda_fwd_generic(const T *__restrict__ value, const int64_t *__restrict__ shapes,
@@ -599,6 +889,20 @@ extern "C" int pd_msda_backward(const void *value, const int64_t *spatial_shapes
   if (!g_pd_dbg_force_generic && g_pd_dbg_atomic_scope == 0 && dtype == PD_F32 && channels == 32 && num_point == 4 &&
       num_levels <= 8 && num_query == spatial_size && total_qm < (1LL << 31)) {
     // self-attention geometry: LDS-windowed accumulation (every grad_loc / grad_attn slot is written once)
+    if (num_levels == 3 && g_pd_dbg_bwd_variant == 0 && spatial_size < (1 << 23) && num_heads * 32 < (1 << 23)) {   // 24-bit index multiplies
+      const size_t lds4 = ((size_t)kOwnCells4 * 33 + 64) * sizeof(int);
+      typedef void (*ofn)(const float *, const int64_t *, const int64_t *, const float *, const float *, const float *, float *, float *,
+                          float *, int, int, int);
+      const int ai = g_pd_dbg_ablate == 1 ? 1 : g_pd_dbg_ablate == 4 ? 2 : g_pd_dbg_ablate == 7 ? 3 : 0;
+      const ofn all4[4] = {msda_bwd_owner4_d32<0>, msda_bwd_owner4_d32<1>, msda_bwd_owner4_d32<4>, msda_bwd_owner4_d32<7>};
+      static bool a4set[4] = {false, false, false, false};
+      if (!a4set[ai]) { (void)hipFuncSetAttribute((const void *)all4[ai], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); a4set[ai] = true; }
+      const int64_t nb4 = (int64_t)batch * kGmax * kGmax * num_heads;
+      hipLaunchKernelGGL(all4[ai], dim3((unsigned)nb4), dim3(1024), lds4, stream, (const float *)value, spatial_shapes, level_start_index,
+                         (const float *)sampling_loc, (const float *)attn_weight, (const float *)grad_output, (float *)grad_value,
+                         (float *)grad_sampling_loc, (float *)grad_attn_weight, spatial_size, num_heads, batch);
+      return pd_check_launch("pd_msda_backward");
+    }
     const int64_t nblocks = (int64_t)batch * kGmax * kGmax * num_levels * num_heads;
     const size_t lds = ((size_t)kWin * kWin * 32 + 32) * sizeof(int);
     static bool attr_set = false;

@@ -46,12 +46,14 @@ def main():
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--bwd-threads", type=int, default=0)
     ap.add_argument("--spread", type=float, default=0.02)
+    ap.add_argument("--variant", type=int, default=0, help="1: the per-destination-level tiled backward")
     a = ap.parse_args()
     from partdistillation_amd import lib
     lib.load().pd_debug_set(b"msda_bwd_atomic_scope", a.scope)
     lib.load().pd_debug_set(b"msda_force_generic", a.generic)
     lib.load().pd_debug_set(b"msda_ablate", a.ablate)
     lib.load().pd_debug_set(b"msda_bwd_threads", a.bwd_threads)
+    lib.load().pd_debug_set(b"msda_bwd_variant", a.variant)
     value, sh, lv, loc, attn, gout = make(a.batch, a.img, a.spread)
     S = value.shape[1]
     fb, bb = alg_bytes(a.batch, S)
@@ -67,7 +69,21 @@ def main():
         torch.cuda.synchronize()
         ts = sorted(s.elapsed_time(e) for s, e in ev)
         med = ts[len(ts) // 2]
-        res[name] = {"ms_median": med, "ms_min": ts[0], "alg_MB": nbytes / 1e6, "GBps": nbytes / med / 1e6}
+        # back-to-back launches under ONE event pair: the GPU-side cost per launch when the host keeps ahead; and the host's
+        # own time per call (if host_ms >= the per-launch figure the numbers are host-bound, not kernel time)
+        import time
+        s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s0.record()
+        for _ in range(a.iters):
+            fn()
+        e0.record()
+        host = (time.perf_counter() - t0) / a.iters * 1e3
+        torch.cuda.synchronize()
+        b2b = s0.elapsed_time(e0) / a.iters
+        res[name] = {"ms_median": med, "ms_min": ts[0], "ms_back_to_back": b2b, "host_ms_per_call": host, "alg_MB": nbytes / 1e6,
+                     "GBps": nbytes / med / 1e6}
     print(json.dumps(res))
 
 
