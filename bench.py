@@ -239,7 +239,7 @@ def roofline_of(dom, kernels):
                 "peak_source": "MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s", "other_kernels": kernels}
     return {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"),
-            "traffic_source": "profiles/r01_msda_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)",
+            "traffic_source": "profiles/r02_msda_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)",
             "alg_bytes_per_launch": dom["alg_bytes"], "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["launches"],
             "other_kernels": kernels}
 
@@ -385,7 +385,7 @@ def main():
             kernels.append({"kernel": "msda_fwd_d32", "launches": len(fwd_ms), "avg_ms": avg(fwd_ms),
                             "alg_bytes": fb, "achieved_GBs": fb / avg(fwd_ms) / 1e6})
         if bwd_ms:
-            kernels.append({"kernel": "msda_bwd_tiled_d32", "launches": len(bwd_ms), "avg_ms": avg(bwd_ms),
+            kernels.append({"kernel": "msda_bwd_owner4_d32", "launches": len(bwd_ms), "avg_ms": avg(bwd_ms),
                             "alg_bytes": bb, "achieved_GBs": bb / avg(bwd_ms) / 1e6})
         if wgrad:                               # fp32 MFMA weight-gradient GEMMs of the encoder (36 launches / step, 6 shapes)
             t_ms, fl = sum(t for t, _ in wgrad), sum(f for _, f in wgrad)
@@ -393,7 +393,7 @@ def main():
                             "alg_flops": fl / len(wgrad), "achieved_TFLOPs": fl / t_ms / 1e9})
         pmc = {}
         try:                                   # HBM bytes per launch from the committed PMC passes (tools/pmc_msda.sh)
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_msda_pmc.json")))
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r02_msda_pmc.json")))
             if pj["geometry"]["batch"] == a.batch and pj["geometry"]["image"] == a.size:
                 pmc = {k: v["hbm_bytes_corrected"] for k, v in pj["kernels"].items()}
         except Exception:                      # noqa: BLE001 - traffic stays null

@@ -9,7 +9,7 @@ import torch
 import partdistillation_amd.MultiScaleDeformableAttention as MSDA
 
 
-def make(N=2, img=1024, spread=0.02, device="cuda", seed=0):
+def make(N=2, img=1024, spread=0.02, device="cuda", seed=0, px=None):
     shapes = [(img // 32,) * 2, (img // 16,) * 2, (img // 8,) * 2]
     S = sum(h * w for h, w in shapes)
     g = torch.Generator(device=device).manual_seed(seed)
@@ -22,7 +22,20 @@ def make(N=2, img=1024, spread=0.02, device="cuda", seed=0):
         ys, xs = torch.meshgrid((torch.arange(h, device=device) + 0.5) / h, (torch.arange(w, device=device) + 0.5) / w, indexing="ij")
         refs.append(torch.stack((xs.reshape(-1), ys.reshape(-1)), -1))
     ref = torch.cat(refs, 0)[None, :, None, None, None, :]
-    loc = (ref + spread * torch.randn(N, S, 8, 3, 4, 2, device=device, generator=g)).contiguous()
+    if px is None:
+        loc = (ref + spread * torch.randn(N, S, 8, 3, 4, 2, device=device, generator=g)).contiguous()
+    else:
+        # what the model produces: offsets in PIXELS of each level (loc = ref + off / (W_l, H_l), ms_deform_attn.py:110-113):
+        # the initialisation grid of ms_deform_attn.py:70-84 (head m looks in direction m, point i at i + 1 pixels) plus
+        # Gaussian noise of `px` pixels
+        import math
+        th = torch.arange(8, device=device) * (2 * math.pi / 8)
+        d = torch.stack((th.cos(), th.sin()), -1)
+        d = d / d.abs().max(-1, keepdim=True)[0]
+        grid = d[:, None, None, :] * torch.arange(1, 5, device=device).view(1, 1, 4, 1)                  # [8,1,4,2]
+        off = grid[None, None] + px * torch.randn(N, S, 8, 3, 4, 2, device=device, generator=g)           # pixels
+        wh = torch.as_tensor([(w, h) for h, w in shapes], dtype=torch.float32, device=device).view(1, 1, 1, 3, 1, 2)
+        loc = (ref + off / wh).contiguous()
     attn = torch.softmax(torch.randn(N, S, 8, 12, device=device, generator=g), -1).view(N, S, 8, 3, 4).contiguous()
     gout = torch.randn(N, S, 256, device=device, generator=g)
     return value, sh, lv, loc, attn, gout
@@ -46,6 +59,7 @@ def main():
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--bwd-threads", type=int, default=0)
     ap.add_argument("--spread", type=float, default=0.02)
+    ap.add_argument("--px", type=float, default=None, help="offsets = init grid + N(0, px) pixels at every level (instead of --spread)")
     ap.add_argument("--variant", type=int, default=0, help="1: the per-destination-level tiled backward")
     a = ap.parse_args()
     from partdistillation_amd import lib
@@ -54,7 +68,7 @@ def main():
     lib.load().pd_debug_set(b"msda_ablate", a.ablate)
     lib.load().pd_debug_set(b"msda_bwd_threads", a.bwd_threads)
     lib.load().pd_debug_set(b"msda_bwd_variant", a.variant)
-    value, sh, lv, loc, attn, gout = make(a.batch, a.img, a.spread)
+    value, sh, lv, loc, attn, gout = make(a.batch, a.img, a.spread, px=a.px)
     S = value.shape[1]
     fb, bb = alg_bytes(a.batch, S)
     for _ in range(5):
