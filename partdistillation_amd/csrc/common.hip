@@ -34,6 +34,7 @@ extern "C" int pd_abi_version(void) { return 15; }
 extern int g_pd_dbg_atomic_scope;
 extern int g_pd_dbg_force_generic;
 extern int g_pd_dbg_ablate;
+extern int g_pd_dbg_x3_narrow;
 extern int g_pd_dbg_bwd_variant;
 extern int g_pd_dbg_wgrad_wgs;
 extern int g_pd_dbg_bwd_threads;
@@ -52,6 +53,7 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!strcmp(key, "wgrad_wgs")) { g_pd_dbg_wgrad_wgs = value; return PD_OK; }
   if (!strcmp(key, "kmeans_ablate")) { g_pd_dbg_kmeans = value; return PD_OK; }
   if (!strcmp(key, "x3_ablate")) { g_pd_dbg_x3 = value; return PD_OK; }
+  if (!strcmp(key, "x3_narrow")) { g_pd_dbg_x3_narrow = value; return PD_OK; }
   if (!strcmp(key, "wattn_ablate")) { g_pd_dbg_wattn = value; return PD_OK; }
   if (!strcmp(key, "msda_force_generic")) { g_pd_dbg_force_generic = value; return PD_OK; }
   return pd_set_error(PD_ERR_INVALID_ARG, "pd_debug_set: unknown key %s", key);

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict_
   // step kt computes from LDS stage kt & 1, writes tile kt + 1 (register stage (kt + 1) & 1, loaded during step kt - 1) to the
   // other LDS stage and issues the loads of tile kt + 2 into the register stage it has just freed
   auto step = [&](int kt, int par) {
+    if (kt + 2 < KT) gload(par, (kt + 2) * BK);        // first thing in the step: a whole step of latency cover (see the wide kernel)
     hwbf16x8 a[3][2], b[3][2];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
@@ -154,7 +155,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict_
     if (ABL != 1) { TERM(0, 0) }
 #undef TERM
     if (ABL == 1) acc[0][0][0] += (float)a[0][0][0] + (float)b[2][1][1] + (float)a[1][1][2] + (float)b[1][0][3] + (float)a[2][0][5] + (float)b[0][0][7];
-    if (kt + 2 < KT) gload(par, (kt + 2) * BK);
     if (KT > FLUSH && (kt + 1) % FLUSH == 0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -187,6 +187,129 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict_
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (row < M && (ABL != 4 || v_never(acc[i][j][e]))) {
+          float v = acc[i][j][e] + bv;
+          if (RELU) v = fmaxf(v, 0.f);
+          C[(int64_t)row * ldc + col] = v;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- wide tiles
+// The 128 x 128 kernel above is bound by the L2 -> LDS operand stream, not by the matrix pipe: every A element is fetched
+// N / 128 times and every B element M / 128 times — 4 M N K (1/BM + 1/BN) bytes, 704 MB for the encoder's 1024 <- 256 Linear at
+// M = 43 008, which the kernel moves in ~100 us with the MFMAs switched off (x3_ablate 1), against 54 us of matrix work.
+// 256 x 256 tiles halve that stream (352 MB): 8 wavefronts (4 x 2), each 64 x 128 of the tile = 2 x 4 MFMA tiles (128
+// accumulator registers), one workgroup per CU, two 120 KB LDS stages of three bf16 planes.  Per 16-wide step a wave issues
+// 48 MFMAs (1 536 cycles) against 18 operand fragments; the B fragments are fetched for two column tiles at a time so that
+// 12 fragments, not 18, are live next to the accumulators.
+// Measured: 176 vs 205-213 us on the 1024 <- 256 Linear, a tie at N = 256 / 512.  Ablations of THIS kernel on that shape: no MFMA
+// 117 us, no output stores 129, no operand split 148 — operand staging (~42) + split (28) + matrix work (59, the full bf16
+// rate) + stores (47, 3.7 TB/s) simply ADD UP: one barrier per 16-wide step keeps the 8 wavefronts in lock-step, so the pipes
+// take turns instead of overlapping.  A 128 x 256 variant with two independent workgroups per CU (to let them drift out of
+// phase) measured the same 181 us; moving the global loads to the top of the step and a conflict-free LDS layout changed
+// nothing either.  What is left to try is a deeper software pipeline (fragments of step k + 1 fetched during step k, i.e.
+// three LDS stages) — the structure, not any single pipe, is the limit.
+constexpr int WBM = 256, WBN = 256;
+
+template <bool RELU, int ABL = 0>        // ABL (tools only): 1 no MFMA, 2 no output stores, 3 no operand split
+__global__ __launch_bounds__(512, 1) void gemm_tn_f32x3_wide(const float *__restrict__ A, const float *__restrict__ B,
+                                                              const float *__restrict__ bias, float *__restrict__ C, int M, int N,
+                                                              int K, int lda, int ldb, int ldc, int ntiles_n)
+{
+  // LDS tile layout: [stage][plane][k half][row][8 bf16] — a 16-wide step is two PANELS of 16-byte row slots.  An MFMA
+  // operand (8 consecutive k of row lane % 32, half lane / 32) is then ONE ds_read_b128 and the 32 lanes of a half read 512
+  // contiguous bytes (conflict-free, full LDS rate); the 40-byte row pitch of the 128 x 128 kernel needs two 8-byte reads
+  // per operand and puts rows r and r + 16 on the same banks.
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];              // As[2][3][2][WBM][8] | Bs[2][3][2][WBN][8]
+  auto As = [&](int buf, int pl, int h, int r) -> bf16_t * { return smem + ((((buf * 3 + pl) * 2 + h) * WBM + r) << 3); };
+  auto Bs = [&](int buf, int pl, int h, int r) -> bf16_t * { return smem + 12 * WBM * 8 + ((((buf * 3 + pl) * 2 + h) * WBN + r) << 3); };
+  const int lb = xcd_chunk(blockIdx.x, gridDim.x);
+  const int m0 = (lb / ntiles_n) * WBM, n0 = (lb % ntiles_n) * WBN;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;
+  const int lr = t >> 2, lk = (t & 3) * 4;                       // rows lr + 128 j, columns lk .. lk+3 of both tiles
+  float4 ra[2][2], rb[2][2];                                     // two register stages: loads run two steps ahead of their use
+  auto gload = [&](int s, int k0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = lr + 128 * j, k = k0 + lk;
+      ra[s][j] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4 *>(A + (int64_t)(m0 + r) * lda + k) : make_float4(0, 0, 0, 0);
+      rb[s][j] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4 *>(B + (int64_t)(n0 + r) * ldb + k) : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto lstore1 = [&](int s, int buf, int op, int j) {
+    const float4 v4 = op == 0 ? ra[s][j] : rb[s][j];
+    Split4 x;
+    if (ABL == 3) { x.hi = make_uint2(pk_bf16(v4.x, v4.y), pk_bf16(v4.z, v4.w)); x.mid = x.lo = make_uint2(0, 0); }
+    else x = split4(v4);
+    const int r = lr + 128 * j;
+    bf16_t *p0 = (op == 0 ? As(buf, 0, lk >> 3, r) : Bs(buf, 0, lk >> 3, r)) + (lk & 7);
+    constexpr int PL = 2 * WBM * 8;                              // plane stride (WBM == WBN)
+    *reinterpret_cast<uint2 *>(p0) = x.hi; *reinterpret_cast<uint2 *>(p0 + PL) = x.mid; *reinterpret_cast<uint2 *>(p0 + 2 * PL) = x.lo;
+  };
+  auto lstore = [&](int s, int buf) { lstore1(s, buf, 0, 0); lstore1(s, buf, 0, 1); lstore1(s, buf, 1, 0); lstore1(s, buf, 1, 1); };
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int KT = (K + BK - 1) / BK;
+  gload(0, 0);
+  if (KT > 1) gload(1, BK);
+  lstore(0, 0);
+  __syncthreads();
+  const int fr = lane & 31, fh = lane >> 5;
+  auto step = [&](int kt, int par) {
+    // the loads of tile kt + 2 go out FIRST (register stage `par` was written to LDS during step kt - 1): they have this
+    // whole step to land before step kt + 1 splits them.  Issued after the MFMAs (as the 128 x 128 kernel did) they were
+    // consumed a sixth of a step later, so every step exposed a full global-load latency.
+    if (kt + 2 < KT) gload(par, (kt + 2) * BK);
+    hwbf16x8 a[3][2];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[pl][i] = *reinterpret_cast<const hwbf16x8 *>(As(par, pl, fh, wm + i * 32 + fr));
+    const bool more = kt + 1 < KT;
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {                             // two column tiles at a time
+      hwbf16x8 b[3][2];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[pl][j] = *reinterpret_cast<const hwbf16x8 *>(Bs(par, pl, fh, wn + (jp * 2 + j) * 32 + fr));
+      // one partial product at a time over the four accumulators (consecutive MFMAs independent); smallest terms first
+#define WTERM(PA, PB)                                                        \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) { if (ABL == 1) acc[i][jp * 2 + j][0] += (float)a[PA][i][0] * (float)b[PB][j][1]; else mma16k(acc[i][jp * 2 + j], a[PA][i], b[PB][j]); }
+      WTERM(2, 0) if (more) lstore1(par ^ 1, par ^ 1, jp, 0);
+      WTERM(0, 2)
+      WTERM(1, 1) if (more) lstore1(par ^ 1, par ^ 1, jp, 1);
+      WTERM(1, 0)
+      WTERM(0, 1)
+      WTERM(0, 0)
+#undef WTERM
+    }
+    __syncthreads();
+  };
+  for (int kt = 0; kt < KT; kt += 2) {
+    step(kt, 0);
+    if (kt + 1 < KT) step(kt + 1, 1);
+  }
+  // C layout of the 32x32 MFMA: col = lane & 31 (B row), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (A row)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = n0 + wn + j * 32 + (lane & 31);
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < M && (ABL != 2 || v_never(acc[i][j][e]))) {
           float v = acc[i][j][e] + bv;
           if (RELU) v = fmaxf(v, 0.f);
           C[(int64_t)row * ldc + col] = v;
@@ -295,6 +418,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3(const float *__restri
 }
 }  // namespace
 
+int g_pd_dbg_x3_narrow = 0;   // tools/ only (pd_debug_set "x3_narrow"): 1 = never use the 256 x 256 kernel
 int g_pd_dbg_x3 = 0;   // tools/ only (pd_debug_set "x3_ablate"): 1 no MFMA, 2 only hi*hi, 3 no operand split, 4 no output stores
 
 extern "C" int pd_gemm_tn_f32x3(const float *A, const float *B, const float *bias, float *C, int M, int N, int K, int lda,
@@ -305,9 +429,31 @@ extern "C" int pd_gemm_tn_f32x3(const float *A, const float *B, const float *bia
   if (!A || !B || !C) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f32x3: null pointer");
   if ((K & 3) || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f32x3: K, lda, ldb must be multiples of 4 and A, B 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream_;
+  // wide tiles where they were measured to pay (tools/bench_gemm_x3_wide.py): the output-heavy 1024-wide Linears (176 vs 205-213 us
+  // at M = 43 008, K = 256); at N = 256 / 512 the two kernels tie or the narrow one wins (more workgroups than CUs matter more)
+  if ((!g_pd_dbg_x3 || g_pd_dbg_x3 > 10) && g_pd_dbg_x3_narrow != 1 && (N % WBN) == 0 && M >= 4 * WBM && (N >= 1024 || g_pd_dbg_x3_narrow == 2)) {
+    const int wtn = N / WBN, wtm = (M + WBM - 1) / WBM;
+    const size_t lds = (size_t)2 * 3 * 2 * (WBM + WBN) * 8 * sizeof(bf16_t);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void *)gemm_tn_f32x3_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void *)gemm_tn_f32x3_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    const dim3 wg((unsigned)((int64_t)wtm * wtn)), wb(512);
+    if (g_pd_dbg_x3 > 10) {
+      auto kf = g_pd_dbg_x3 == 11 ? gemm_tn_f32x3_wide<false, 1> : g_pd_dbg_x3 == 12 ? gemm_tn_f32x3_wide<false, 2> : gemm_tn_f32x3_wide<false, 3>;
+      (void)hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kf, wg, wb, lds, st, A, B, bias, C, M, N, K, lda, ldb, ldc, wtn);
+      return pd_check_launch("pd_gemm_tn_f32x3");
+    }
+    if (relu) hipLaunchKernelGGL(gemm_tn_f32x3_wide<true>, wg, wb, lds, st, A, B, bias, C, M, N, K, lda, ldb, ldc, wtn);
+    else hipLaunchKernelGGL(gemm_tn_f32x3_wide<false>, wg, wb, lds, st, A, B, bias, C, M, N, K, lda, ldb, ldc, wtn);
+    return pd_check_launch("pd_gemm_tn_f32x3");
+  }
   const int tn = (N + BN - 1) / BN, tm = (M + BM - 1) / BM;
   const dim3 g((unsigned)((int64_t)tm * tn)), b(256);
-  hipStream_t st = (hipStream_t)stream_;
 #define LAUNCH(R, AB) hipLaunchKernelGGL((gemm_tn_f32x3<R, AB, false>), g, b, 0, st, A, B, bias, C, M, N, K, lda, ldb, ldc, tn, 0, 0)
   if (g_pd_dbg_x3 == 1) LAUNCH(false, 1);
   else if (g_pd_dbg_x3 == 2) LAUNCH(false, 2);
