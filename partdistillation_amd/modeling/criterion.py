@@ -106,6 +106,17 @@ class SetCriterion(nn.Module):
         assert loss in loss_map, f"do you really want to compute {loss} loss?"
         return loss_map[loss](outputs, targets, indices, num_masks)
 
+    def prefetch_num_masks(self, targets, device):
+        """multi-rank runs: start the scalar all-reduce of reference :252-254 NOW (the meta-architecture calls this as soon as
+        the targets exist, before the backbone runs): it depends only on the targets, so by the time the criterion needs the
+        value the collective finished long ago instead of sitting between the decoder and the losses."""
+        if not is_dist_avail_and_initialized() or get_world_size() == 1:
+            return
+        count = float(sum(len(t["labels"]) for t in targets))
+        n = upload_small([count], torch.float, device)                # asynchronous: the host keeps running ahead
+        work = torch.distributed.all_reduce(n, async_op=True)
+        self._nm_pending = (count, n, work)
+
     def num_masks(self, targets, device):
         """average number of target masks per rank, clamped to >= 1 (reference :248-254), as a device scalar."""
         count = float(sum(len(t["labels"]) for t in targets))
@@ -114,8 +125,13 @@ class SetCriterion(nn.Module):
             if key not in self._nm_cache:
                 self._nm_cache[key] = torch.tensor(max(count, 1.0), dtype=torch.float, device=device)
             return self._nm_cache[key]
-        n = upload_small([count], torch.float, device)                # asynchronous: the host keeps running ahead
-        torch.distributed.all_reduce(n)
+        pending, self._nm_pending = getattr(self, "_nm_pending", None), None
+        if pending is not None and pending[0] == count:
+            _, n, work = pending
+            work.wait()                                      # the compute stream waits for the (long finished) collective
+        else:
+            n = upload_small([count], torch.float, device)
+            torch.distributed.all_reduce(n)
         return torch.clamp(n / get_world_size(), min=1)[0]
 
     def _can_batch(self, outputs, targets):

@@ -25,6 +25,9 @@ class PartDistillationTransformerDecoder(MultiScaleMaskedTransformerDecoder):
         super().__init__(in_channels, mask_classification, *args, **kwargs)
         self.class_embed = nn.Linear(self.hidden_dim, num_part_classes * num_object_classes + 1).double()
         self.num_part_classes = num_part_classes
+        # only the rows _prepare_extra selects receive a non-zero gradient: the data-parallel reducer exchanges just those
+        # (engine/ddp.py: row-sparse groups)
+        self.class_embed.weight._pd_row_sparse = self.class_embed.bias._pd_row_sparse = True
 
     @classmethod
     def from_config(cls, cfg, in_channels, mask_classification):
@@ -41,7 +44,9 @@ class PartDistillationTransformerDecoder(MultiScaleMaskedTransformerDecoder):
         cls = upload_small([int(t["gt_object_class"]) for t in targets], torch.long, dev)      # no blocking pageable copy
         rows = cls[:, None] * K + torch.arange(K, device=dev)[None, :]
         last = torch.full((len(targets), 1), self.class_embed.weight.shape[0] - 1, dtype=torch.long, device=dev)
-        return torch.cat([rows, last], dim=1)                                   # [B, K+1]
+        rows = torch.cat([rows, last], dim=1)                                   # [B, K+1]
+        self.class_embed.weight._pd_rows = self.class_embed.bias._pd_rows = rows.reshape(-1)
+        return rows
 
     def _class_logits(self, decoder_output, rows):
         w = self.class_embed.weight[rows]                                       # [B,K+1,C] float64

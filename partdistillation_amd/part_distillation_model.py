@@ -76,6 +76,9 @@ class PartDistillationModel(_MaskFormerTrainBase):
 
     def forward(self, batched_inputs):
         images = self.preprocess(batched_inputs)
+        if self.training:                # targets first: the num_masks all-reduce overlaps the whole forward (see ProposalModel)
+            targets = self._share_padded_masks(self._prepare_pseudo_targets(batched_inputs, images))
+            self.criterion.prefetch_num_masks(targets, self.device)
         features = self.backbone(images.tensor)
         if not self.training:                                           # evaluation branch (reference :227-236)
             from .inference import pd_inference, prepare_pd_gt_targets
@@ -87,7 +90,6 @@ class PartDistillationModel(_MaskFormerTrainBase):
             head_targets = [{"gt_object_class": int(t["gt_object_class"])} for t in targets]
             self.current_test_iteration += 1
             return pd_inference(self, batched_inputs, targets, images, self.sem_seg_head(features, mask=head_targets))
-        targets = self._share_padded_masks(self._prepare_pseudo_targets(batched_inputs, images))
         outputs = self.sem_seg_head(features, mask=targets)
         losses = self._weighted(self.criterion(outputs, targets))
         self.num_train_iterations += 1

@@ -158,13 +158,17 @@ class ProposalModel(_MaskFormerTrainBase):
 
     def forward(self, batched_inputs):
         images = self.preprocess(batched_inputs)
-        features = self.backbone(images.tensor)
         if not self.training:                                          # evaluation branch (reference :205-217)
             from .inference import inference
+            features = self.backbone(images.tensor)
             targets = self.prepare_targets(batched_inputs, images)
             self.num_test_iterations = getattr(self, "num_test_iterations", 0) + 1
             return inference(self, batched_inputs, targets, images, self.sem_seg_head(features))
+        # targets before the backbone (they depend on the inputs only): the num_masks all-reduce of the criterion is in flight
+        # while the whole forward runs
         targets = self._share_padded_masks(self.prepare_targets(batched_inputs, images))
+        self.criterion.prefetch_num_masks(targets, self.device)
+        features = self.backbone(images.tensor)
         outputs = self.sem_seg_head(features)
         losses = self._weighted(self.criterion(outputs, targets))
         self.num_train_iterations += 1

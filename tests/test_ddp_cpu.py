@@ -93,3 +93,79 @@ def test_bucketed_reducer_two_ranks_gloo(tmp_path):
         torch.testing.assert_close(r0["grads"][n], want, rtol=1e-5, atol=1e-6, msg=lambda m: f"{n}: {m}")
     # num_masks = clamp(sum_over_ranks / world, 1) (criterion.py:248-254): (3 + 5) / 2
     assert float(r0["num_masks"]) == 4.0 and float(r1["num_masks"]) == 4.0
+
+
+# ----------------------------------------------------------------------------- row-sparse class head, prefetched num_masks, divergent graphs
+class SparseNet(torch.nn.Module):
+    """a float64 [rows, C] head of which a step uses a few rows (the part-distillation class head), a dense trunk, and a
+    branch that only SOME ranks take in a step (data-dependent graph)"""
+
+    def __init__(self, rows=40, c=6):
+        super().__init__()
+        self.trunk = torch.nn.Linear(5, c)
+        self.side = torch.nn.Linear(5, c)
+        self.head = torch.nn.Linear(c, rows).double()
+        self.head.weight._pd_row_sparse = self.head.bias._pd_row_sparse = True
+
+    def forward(self, x, rows, use_side):
+        h = self.trunk(x)
+        if use_side:
+            h = h + self.side(x)
+        self.head.weight._pd_rows = self.head.bias._pd_rows = rows
+        w, b = self.head.weight[rows], self.head.bias[rows]
+        return (h.double() @ w.t() + b).pow(2).sum()
+
+
+def _sparse_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from partdistillation_amd.engine.ddp import BucketedGradReducer, broadcast_parameters
+    from partdistillation_amd.engine.flat_params import FlatParams
+    from partdistillation_amd.modeling.criterion import SetCriterion
+    torch.manual_seed(5)
+    model = SparseNet()
+    names = dict((id(p), n) for n, p in model.named_parameters())
+    groups = [{"params": [p for p in reversed(list(model.parameters())) if p.dtype == dt],
+               "names": [names[id(p)] for p in reversed(list(model.parameters())) if p.dtype == dt], "lr": 1e-3, "weight_decay": 0.0}
+              for dt in (torch.float32, torch.float64)]
+    flat = FlatParams(groups)
+    broadcast_parameters(flat, 0)
+    reducer = BucketedGradReducer(flat, bucket_mb=0.00005)
+    assert len(reducer.sparse_groups) == 1 and len(reducer.buckets) >= 2
+    crit = SetCriterion(1, None, {}, 0.1, [], 4, 3.0, 0.75)
+    torch.manual_seed(50 + rank)
+    x = torch.randn(4, 5)
+    # duplicates inside a rank (two images of one class, the shared last row) and rows shared across the ranks
+    rows = torch.tensor([3, 4, 5, 39, 3, 4, 5, 39]) if rank == 0 else torch.tensor([17, 18, 19, 39, 3, 4, 5, 39])
+    targets = [{"labels": torch.zeros(2 + 4 * rank)}]
+    crit.prefetch_num_masks(targets, torch.device("cpu"))          # started before the "forward"
+    flat.zero_grad()
+    model(x, rows, use_side=(rank == 0)).backward()                # rank 1 never touches `side`: hooks fire for different sets
+    reducer.finish()
+    nm = crit.num_masks(targets, torch.device("cpu"))
+    grads = {n: g._view(g.grad, p, off).detach().clone() for g in flat.groups for n, p, off in zip(g.names, g.params, g.offsets)}
+    torch.save({"grads": grads, "x": x, "rows": rows, "num_masks": nm, "params": {n: p.detach().clone() for n, p in model.named_parameters()}},
+               os.path.join(tmp, f"sparse{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_row_sparse_exchange_prefetched_num_masks_and_divergent_graphs(tmp_path):
+    """(1) the float64 class head's gradient is exchanged as touched rows only and equals the dense mean (duplicated rows
+    inside a rank and shared rows across ranks included); (2) buckets are issued in index order although rank 1's graph never
+    reaches the `side` layer; (3) the num_masks all-reduce started before the forward is the one the criterion consumes."""
+    world = 2
+    mp.spawn(_sparse_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"sparse{k}.pt") for k in range(world)]
+    for n in r[0]["grads"]:
+        torch.testing.assert_close(r[0]["grads"][n], r[1]["grads"][n], rtol=0, atol=0)
+    model = SparseNet()
+    model.load_state_dict(r[0]["params"])
+    loss = sum(model(r[k]["x"], r[k]["rows"], use_side=(k == 0)) for k in range(world)) / world
+    loss.backward()
+    for n, p in model.named_parameters():
+        torch.testing.assert_close(r[0]["grads"][n], p.grad, rtol=1e-6, atol=1e-7, msg=lambda m: f"{n}: {m}")
+    g = r[0]["grads"]["head.weight"]
+    assert sorted((g.abs().sum(1) > 0).nonzero().flatten().tolist()) == [3, 4, 5, 17, 18, 19, 39]
+    assert float(r[0]["num_masks"]) == 4.0 and float(r[1]["num_masks"]) == 4.0            # (2 + 6) / 2

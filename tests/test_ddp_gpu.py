@@ -75,3 +75,23 @@ def test_two_rank_step_matches_single_process_mean(tmp_path):
         assert ((d0[n] - want).abs().max() / scale).item() < tol, n
         checked += 1
     assert checked > 100
+
+
+@pytest.mark.timeout(900)
+def test_rccl_two_gpu_bench_line():
+    """the RCCL path itself (backend "nccl" over xGMI), through the driver's own launch line for bench.py --gpus 2.  Needs two
+    visible GPUs: the single-GPU boxes of the development pool skip it, the driver's multi-GPU node runs it."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs for the nccl (RCCL) backend")
+    import json
+    import subprocess
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--size", "256"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=800,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and lines, out.stdout[-3000:]
+    rec = json.loads(lines[-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["scaling"] == "weak"
+    assert rec["value"] > 0 and rec["config"]["final_total_loss"] == rec["config"]["final_total_loss"]
