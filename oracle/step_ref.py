@@ -158,6 +158,27 @@ def pixel_decoder_forward(sd, p, features, *, nheads=8, npoints=4, enc_layers=6,
     return mask_features, outs[0], outs[:3]
 
 
+def base_pixel_decoder_forward(sd, p, features, strides=None):
+    """BasePixelDecoder.forward_features, pixel_decoder/fpn.py:140-158 (norm "GN": no conv bias, GroupNorm(32); nearest
+    top-down upsampling :153; 3 x 3 mask_features :119-127).  -> (mask_features, None, multi_scale[3])"""
+    strides = strides or {"res2": 4, "res3": 8, "res4": 16, "res5": 32}
+    names = sorted(features.keys(), key=lambda k: strides[k])
+    n = len(names)
+    y, ms = None, []
+    for idx, f in enumerate(names[::-1]):
+        k = n - idx                                                        # adapter_{k} / layer_{k}
+        x = features[f]
+        if idx == 0:
+            y = F.relu(group_norm(sd, f"{p}.layer_{k}.norm", F.conv2d(x, sd[f"{p}.layer_{k}.weight"], padding=1)))
+        else:
+            cur = group_norm(sd, f"{p}.adapter_{k}.norm", F.conv2d(x, sd[f"{p}.adapter_{k}.weight"]))
+            y = cur + F.interpolate(y, size=cur.shape[-2:], mode="nearest")
+            y = F.relu(group_norm(sd, f"{p}.layer_{k}.norm", F.conv2d(y, sd[f"{p}.layer_{k}.weight"], padding=1)))
+        if len(ms) < 3:
+            ms.append(y)
+    return F.conv2d(y, sd[p + ".mask_features.weight"], sd[p + ".mask_features.bias"], padding=1), None, ms
+
+
 # ----------------------------------------------------------------------------- transformer decoder
 def mask_embed_mlp(sd, p, x):
     """MLP, mask2former_transformer_decoder.py:196-208 (3 layers)."""

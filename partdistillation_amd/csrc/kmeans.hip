@@ -11,7 +11,7 @@ int g_pd_dbg_kmeans = 0;   // tools/ only: 1 skip the label pass, 2 skip the sum
 
 namespace {
 
-constexpr int KMAX = 4;       // centres per image
+constexpr int KCAP = 8;       // centres per image: kernels are instantiated for KMAX = 4 (pixel grouping, K = 4) and 8 (part ranking, K = 8)
 constexpr int PMAX = 8;       // 16-byte pieces per lane: C <= 2048
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -30,7 +30,7 @@ __device__ __forceinline__ float wave_sum(float v)
 // The first version kept the K x C running sums in the assigning wave's registers (250 VGPRs, one point at a time per wave):
 // two waves per SIMD and every point's HBM latency exposed — 187 us per Lloyd iteration at 4 x 5431 x 1536, ~5x the
 // bandwidth bound.
-template <bool PARTIAL>   // PARTIAL: the slab's sums / counts are STORED to sums[blockIdx] / counts[blockIdx] (no atomics)
+template <int KMAX, bool PARTIAL>   // PARTIAL: the slab's sums / counts are STORED to sums[blockIdx] / counts[blockIdx] (no atomics)
 __global__ __launch_bounds__(256) void kmeans_assign(const float *__restrict__ X, const int32_t *__restrict__ blocks,
                                                      const float *__restrict__ centers, const float *__restrict__ cnorm,
                                                      const int32_t *__restrict__ done, int32_t *__restrict__ labels,
@@ -168,6 +168,7 @@ __global__ __launch_bounds__(64) void kmeans_reduce(const float *__restrict__ ps
 }
 
 // one workgroup per image
+template <int KMAX>
 __global__ __launch_bounds__(256) void kmeans_update(float *__restrict__ centers, float *__restrict__ cnorm, float *__restrict__ sums,
                                                      float *__restrict__ counts, int32_t *__restrict__ changed,
                                                      const float *__restrict__ tol, int32_t *__restrict__ done,
@@ -178,7 +179,9 @@ __global__ __launch_bounds__(256) void kmeans_update(float *__restrict__ centers
   const int b = blockIdx.x;
   if (done[b]) return;
   float shift = 0.f;
-  float nk[KMAX] = {0.f, 0.f, 0.f, 0.f};
+  float nk[KMAX];
+#pragma unroll
+  for (int kk = 0; kk < KMAX; ++kk) nk[kk] = 0.f;
   for (int i = threadIdx.x; i < K * C; i += 256) {
     const int k = i / C;
     const float cntk = counts[b * K + k];
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(256) void kmeans_update(float *__restrict__ centers
 // in a fixed order, writes the new centre and its contributions to the centre shift and to |c_k|^2; the workgroups of an image
 // leave those as per-workgroup partials and the LAST one to finish (agent-scope ticket) sums them — again in a fixed order, so
 // centres, norms and the stopping decision are bit-reproducible — and decides `done`.
+template <int KMAX>
 __global__ __launch_bounds__(256) void kmeans_reduce_update(const float *__restrict__ psums, const float *__restrict__ pcounts,
                                                             const int32_t *__restrict__ range, float *__restrict__ centers,
                                                             float *__restrict__ cnorm, int32_t *__restrict__ changed,
@@ -238,7 +242,9 @@ __global__ __launch_bounds__(256) void kmeans_reduce_update(const float *__restr
   }
   __syncthreads();
   const int e = blockIdx.x * 256 + threadIdx.x;
-  float shift = 0.f, nk[KMAX] = {0.f, 0.f, 0.f, 0.f};
+  float shift = 0.f, nk[KMAX];
+#pragma unroll
+  for (int kk = 0; kk < KMAX; ++kk) nk[kk] = 0.f;
   if (e < KC) {
     const float *p = psums + (int64_t)first * KC + e;
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -275,7 +281,9 @@ __global__ __launch_bounds__(256) void kmeans_reduce_update(const float *__restr
     const int t = __hip_atomic_fetch_add(ticket + b, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);   // releases `mine`, acquires the others'
     last = t == G - 1;
     if (last) {
-      float tot[KMAX + 1] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      float tot[KMAX + 1];
+#pragma unroll
+      for (int j = 0; j <= KMAX; ++j) tot[j] = 0.f;
       for (int g = 0; g < G; ++g) {
         const float *o = scratch + ((int64_t)b * G + g) * (KMAX + 1);
 #pragma unroll
@@ -296,14 +304,18 @@ extern "C" int pd_kmeans_assign(const float *X, const int32_t *blocks, int n_blo
                                 const int32_t *done, int32_t *labels, float *sums, float *counts, int32_t *changed, int C, int K,
                                 void *stream_)
 {
-  if (n_blocks < 0 || C <= 0 || (C & 3) || C > 256 * PMAX || K <= 0 || K > KMAX)
-    return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_assign: n_blocks=%d C=%d (<= 2048, %% 4) K=%d (<= 4)", n_blocks, C, K);
+  if (n_blocks < 0 || C <= 0 || (C & 3) || C > 256 * PMAX || K <= 0 || K > KCAP)
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_assign: n_blocks=%d C=%d (<= 2048, %% 4) K=%d (<= 8)", n_blocks, C, K);
   if (n_blocks == 0) return PD_OK;
   if (!X || !blocks || !centers || !cnorm || !done || !labels || !sums || !counts || !changed)
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_assign: null pointer");
   const size_t lds = ((size_t)K * C + 64 + 1) * sizeof(float);
-  hipLaunchKernelGGL(kmeans_assign<false>, dim3(n_blocks), dim3(256), lds, (hipStream_t)stream_, X, blocks, centers, cnorm, done, labels, sums,
-                     counts, changed, C, K, g_pd_dbg_kmeans);
+  if (K <= 4)
+    hipLaunchKernelGGL((kmeans_assign<4, false>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream_, X, blocks, centers, cnorm, done, labels, sums,
+                       counts, changed, C, K, g_pd_dbg_kmeans);
+  else
+    hipLaunchKernelGGL((kmeans_assign<8, false>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream_, X, blocks, centers, cnorm, done, labels, sums,
+                       counts, changed, C, K, g_pd_dbg_kmeans);
   return pd_check_launch("pd_kmeans_assign");
 }
 
@@ -311,21 +323,25 @@ extern "C" int pd_kmeans_assign_partial(const float *X, const int32_t *blocks, i
                                         const int32_t *done, int32_t *labels, float *partial_sums, float *partial_counts,
                                         int32_t *changed, int C, int K, void *stream_)
 {
-  if (n_blocks < 0 || C <= 0 || (C & 3) || C > 256 * PMAX || K <= 0 || K > KMAX)
-    return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_assign_partial: n_blocks=%d C=%d (<= 2048, %% 4) K=%d (<= 4)", n_blocks, C, K);
+  if (n_blocks < 0 || C <= 0 || (C & 3) || C > 256 * PMAX || K <= 0 || K > KCAP)
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_assign_partial: n_blocks=%d C=%d (<= 2048, %% 4) K=%d (<= 8)", n_blocks, C, K);
   if (n_blocks == 0) return PD_OK;
   if (!X || !blocks || !centers || !cnorm || !done || !labels || !partial_sums || !partial_counts || !changed)
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_assign_partial: null pointer");
   const size_t lds = ((size_t)K * C + 64 + 1) * sizeof(float);
-  hipLaunchKernelGGL(kmeans_assign<true>, dim3(n_blocks), dim3(256), lds, (hipStream_t)stream_, X, blocks, centers, cnorm, done, labels,
-                     partial_sums, partial_counts, changed, C, K, g_pd_dbg_kmeans);
+  if (K <= 4)
+    hipLaunchKernelGGL((kmeans_assign<4, true>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream_, X, blocks, centers, cnorm, done, labels,
+                       partial_sums, partial_counts, changed, C, K, g_pd_dbg_kmeans);
+  else
+    hipLaunchKernelGGL((kmeans_assign<8, true>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream_, X, blocks, centers, cnorm, done, labels,
+                       partial_sums, partial_counts, changed, C, K, g_pd_dbg_kmeans);
   return pd_check_launch("pd_kmeans_assign_partial");
 }
 
 extern "C" int pd_kmeans_reduce(const float *partial_sums, const float *partial_counts, const int32_t *block_range, const int32_t *done,
                                 float *sums, float *counts, int B, int K, int C, void *stream_)
 {
-  if (B < 0 || C <= 0 || K <= 0 || K > KMAX) return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_reduce: B=%d C=%d K=%d", B, C, K);
+  if (B < 0 || C <= 0 || K <= 0 || K > KCAP) return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_reduce: B=%d C=%d K=%d", B, C, K);
   if (B == 0) return PD_OK;
   if (!partial_sums || !partial_counts || !block_range || !done || !sums || !counts)
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_reduce: null pointer");
@@ -337,30 +353,35 @@ extern "C" int pd_kmeans_reduce(const float *partial_sums, const float *partial_
 extern "C" int pd_kmeans_update(float *centers, float *cnorm, float *sums, float *counts, int32_t *changed, const float *tol,
                                 int32_t *done, int32_t *n_iter, int B, int K, int C, void *stream_)
 {
-  if (B < 0 || C <= 0 || K <= 0 || K > KMAX) return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_update: B=%d C=%d K=%d", B, C, K);
+  if (B < 0 || C <= 0 || K <= 0 || K > KCAP) return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_update: B=%d C=%d K=%d", B, C, K);
   if (B == 0) return PD_OK;
   if (!centers || !cnorm || !sums || !counts || !changed || !tol || !done || !n_iter)
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_update: null pointer");
-  hipLaunchKernelGGL(kmeans_update, dim3(B), dim3(256), 0, (hipStream_t)stream_, centers, cnorm, sums, counts, changed, tol, done, n_iter, K, C);
+  if (K <= 4) hipLaunchKernelGGL(kmeans_update<4>, dim3(B), dim3(256), 0, (hipStream_t)stream_, centers, cnorm, sums, counts, changed, tol, done, n_iter, K, C);
+  else hipLaunchKernelGGL(kmeans_update<8>, dim3(B), dim3(256), 0, (hipStream_t)stream_, centers, cnorm, sums, counts, changed, tol, done, n_iter, K, C);
   return pd_check_launch("pd_kmeans_update");
 }
 
 extern "C" int64_t pd_kmeans_reduce_update_scratch_floats(int B, int K, int C)
 {
   if (B <= 0 || K <= 0 || C <= 0) return 0;
-  return (int64_t)B * ((K * C + 255) / 256) * (KMAX + 1);
+  return (int64_t)B * ((K * C + 255) / 256) * ((K <= 4 ? 4 : 8) + 1);
 }
 
 extern "C" int pd_kmeans_reduce_update(const float *partial_sums, const float *partial_counts, const int32_t *block_range, float *centers,
                                        float *cnorm, int32_t *changed, const float *tol, int32_t *done, int32_t *n_iter, float *scratch,
                                        int32_t *ticket, int B, int K, int C, void *stream_)
 {
-  if (B < 0 || C <= 0 || K <= 0 || K > KMAX) return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_reduce_update: B=%d C=%d K=%d", B, C, K);
+  if (B < 0 || C <= 0 || K <= 0 || K > KCAP) return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_reduce_update: B=%d C=%d K=%d", B, C, K);
   if (B == 0) return PD_OK;
   if (!partial_sums || !partial_counts || !block_range || !centers || !cnorm || !changed || !tol || !done || !n_iter || !scratch || !ticket)
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_kmeans_reduce_update: null pointer");
-  hipLaunchKernelGGL(kmeans_reduce_update, dim3((K * C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream_, partial_sums, partial_counts,
-                     block_range, centers, cnorm, changed, tol, done, n_iter, scratch, ticket, K, C);
+  if (K <= 4)
+    hipLaunchKernelGGL(kmeans_reduce_update<4>, dim3((K * C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream_, partial_sums, partial_counts,
+                       block_range, centers, cnorm, changed, tol, done, n_iter, scratch, ticket, K, C);
+  else
+    hipLaunchKernelGGL(kmeans_reduce_update<8>, dim3((K * C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream_, partial_sums, partial_counts,
+                       block_range, centers, cnorm, changed, tol, done, n_iter, scratch, ticket, K, C);
   return pd_check_launch("pd_kmeans_reduce_update");
 }
 

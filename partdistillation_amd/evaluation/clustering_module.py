@@ -43,12 +43,24 @@ class ClusteringModule:
         if not multi or dist.get_rank() == 0:                     # the main process clusters (reference :58-67)
             feats = torch.cat(feats, dim=0).float()
             labels = torch.cat([l.to(feats.device) for l in labels], dim=0)
+            todo = []
             for cid in labels.unique().tolist():
                 x = feats[labels == cid]
                 if x.shape[0] > self.num_clusters:
-                    out[int(cid)] = self._get_cluster_centroids(x, int(cid))
+                    todo.append((int(cid), x))
                 else:                                 # too few proposals of this class (reference :66-67)
                     out[int(cid)] = torch.randn(self.num_clusters, x.shape[1], device=x.device)
+            if todo and todo[0][1].is_cuda and self.num_clusters <= 8 and todo[0][1].shape[1] % 4 == 0:
+                # all object classes advance together in the batched HIP Lloyd kernels (functions/kmeans.py): the convergence test
+                # runs on the device, the host reads the `done` flags every 8 iterations — not once per class and iteration
+                gen = torch.Generator(device=todo[0][1].device).manual_seed(self.seed)
+                inits = [self.init(cid, x) for cid, x in todo] if self.init is not None else None
+                cents, _ = _kmeans.kmeans_lloyd_batched([x for _, x in todo], self.num_clusters, inits=inits, generator=gen)
+                for (cid, _), c in zip(todo, cents):
+                    out[cid] = c.float()
+            else:
+                for cid, x in todo:
+                    out[cid] = self._get_cluster_centroids(x, cid)
         if multi:                                                 # ... and everyone takes ITS result (reference :69-71)
             box = [{k: v.cpu() for k, v in out.items()}]
             dist.broadcast_object_list(box, src=0)

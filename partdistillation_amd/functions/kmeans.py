@@ -76,13 +76,14 @@ ATOMIC = bool(int(__import__("os").environ.get("PD_KMEANS_ATOMIC", "0")))     # 
 
 
 def kmeans_lloyd_batched(datas, K, inits=None, max_iter=300, tol=1e-4, generator=None, check_every=8):
-    """datas: list of [N_b, C] fp32 CUDA tensors (N_b > K) -> (centres [B,K,C], iterations list).  HIP kernels; K <= 4,
-    C % 4 == 0, C <= 2048 (else falls back to kmeans_lloyd per image)."""
+    """datas: list of [N_b, C] fp32 CUDA tensors (N_b > K) -> (centres [B,K,C], iterations list).  HIP kernels; K <= 8
+    (instantiated for 4 = pixel grouping and 8 = part ranking), C % 4 == 0, C <= 2048 (else falls back to kmeans_lloyd per
+    image)."""
     B, C = len(datas), datas[0].shape[1]
     dev = datas[0].device
     if not dev.type == "cuda":
         raise RuntimeError("pd_kmeans_* run on the GPU only (no CPU fallback in partdistillation_amd)")
-    if K > 4 or C % 4 or C > 2048:
+    if K > 8 or C % 4 or C > 2048:
         out = [kmeans_lloyd(d, K, init=None if inits is None else inits[b], max_iter=max_iter, tol=tol, generator=generator)
                for b, d in enumerate(datas)]
         return torch.stack([o[0] for o in out]), [o[2] for o in out]

@@ -64,6 +64,28 @@ def test_batched_hip_lloyd_matches_oracle():
     np.testing.assert_allclose(c3[0].cpu().numpy(), c_ref, rtol=2e-3, atol=2e-3)
 
 
+def test_batched_hip_lloyd_k8_part_ranking_geometry():
+    """the KMAX = 8 instantiation (part ranking: 8 clusters per object class on 256-d query features,
+    evaluation/clustering_module.py:43-70): several classes of different sizes advancing together against the sklearn-pinned
+    restatement with the same initial centres; K = 5 and 7 go through the same instantiation"""
+    from partdistillation_amd.functions.kmeans import kmeans_lloyd_batched
+    rng = np.random.default_rng(23)
+    for K in (8, 5, 7):
+        datas, inits, refs = [], [], []
+        for N in (400, 57, 1300, 9):
+            Cc = 256
+            blobs = rng.normal(size=(K, Cc)).astype(np.float32) * 0.6
+            X = (blobs[rng.integers(K, size=N)] + rng.normal(size=(N, Cc)).astype(np.float32)).astype(np.float32)
+            X /= np.linalg.norm(X, axis=1, keepdims=True)                      # L2-normalised query features
+            init = X[rng.choice(N, K, replace=False)].copy()
+            datas.append(torch.from_numpy(X).to(DEV)), inits.append(torch.from_numpy(init).to(DEV))
+            refs.append(P.kmeans_lloyd_np(X, init))
+        centers, n_iters = kmeans_lloyd_batched(datas, K, inits=inits)
+        for b, (c_ref, l_ref, it_ref) in enumerate(refs):
+            np.testing.assert_allclose(centers[b].cpu().numpy(), c_ref, rtol=2e-3, atol=2e-4, err_msg=f"K={K} class {b}")
+            assert abs(n_iters[b] - it_ref) <= 1, (K, b, n_iters[b], it_ref)
+
+
 def test_kmeans_plusplus_seeding_gives_a_comparable_partition():
     """own RNG, so not sklearn's partition - but the objective must be in the same league"""
     from sklearn.cluster import KMeans
