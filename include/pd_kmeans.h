@@ -7,7 +7,7 @@
  * changed, or when the squared centre shift <= tol).  The convergence test lives on the device, so the host issues
  * iterations without reading anything back and looks at `done` only every few iterations.
  *
- * Points of all images are concatenated: X fp32 [N, C] (C % 4 == 0, C <= 2048), K <= 4 centres per image; `blocks` is an
+ * Points of all images are concatenated: X fp32 [N, C] (C % 4 == 0, C <= 2048), K <= 8 centres per image (kernels instantiated for 4 and 8); `blocks` is an
  * int32 [n_blocks, 3] table (image, first point, point count <= 64) so that no workgroup straddles two images.
  */
 #ifndef PD_KMEANS_H
