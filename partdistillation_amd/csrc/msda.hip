@@ -10,7 +10,9 @@
 //    (batch, query, head) triple per 8-lane group, each lane owning 4 channels
 //    as a float4.  A corner read is then one 128-byte row per group, issued as
 //    a single global_load_dwordx4 per lane; a 64-lane wavefront covers all 8
-//    heads of one query.  Backward reduces grad_sampling_loc / grad_attn_weight
+//    heads of one query.  (A 4-lanes x 8-channels forward with 24-bit index arithmetic and zero-row reads for masked
+//    corners — the recipe that sped the backward up — measured SLOWER, 0.123 vs 0.099 ms: the forward is bound by gather
+//    latency, not by instruction issue.)  Backward reduces grad_sampling_loc / grad_attn_weight
 //    across the 8 lanes with DPP (no LDS, no barrier) and parks the results so
 //    that the stores are 32/64-byte contiguous per group.
 //  * blockIdx is remapped so that each XCD (block b is dispatched to XCD b%8)
