@@ -38,6 +38,18 @@ int pd_gemm_wgrad_f32(const float *dY, const float *X, float *dW, float *dB, int
 int pd_gemm_wgrad_acc_f32(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx,
                           int ldw, void *stream);
 
+/* The FFN's ReLU backward folded into the GEMM epilogues (256 x 256 tiles: N % 256 == 0, M >= 1024):
+ *   pd_gemm_tn_f32x3_relu_bits   C = relu(A B^T + bias) and `bits` <- one bit per element of C (C > 0), laid out in the kernel's
+ *                                own accumulator order; `bits` holds pd_gemm_tn_f32x3_relu_bits_words(M, N) 32-bit words
+ *   pd_gemm_tn_f32x3_relumask    C = (A B^T) where the recorded bit is set, else 0;  colsum[N] += column sums of that C
+ * over the same [M, N]: the gradient w.r.t. the FFN's hidden pre-activation and the bias gradient of its first Linear
+ * (reference msdeformattn.py:120-124 through autograd) without a separate pass over the [M, N] tensor. */
+int64_t pd_gemm_tn_f32x3_relu_bits_words(int M, int N);
+int pd_gemm_tn_f32x3_relu_bits(const float *A, const float *B, const float *bias, float *C, uint32_t *bits, int M, int N, int K, int lda,
+                               int ldb, int ldc, void *stream);
+int pd_gemm_tn_f32x3_relumask(const float *A, const float *B, const uint32_t *bits, float *C, float *colsum, int M, int N, int K, int lda,
+                              int ldb, int ldc, void *stream);
+
 /* pd_gemm_wgrad_acc_f32 with the 3-way bf16 split (see pd_gemm_tn_f32x3): dW += dY^T X, dB += column sums of dY (exact fp32
  * adds), accumulated into caller-initialised buffers.  Any N, K, M >= 0; no alignment requirement (scalar loads). */
 int pd_gemm_wgrad_acc_f32x3(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx, int ldw,

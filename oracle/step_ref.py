@@ -483,11 +483,14 @@ def proposal_model_losses(sd, batched_inputs, rand, *, backbone="r50", num_class
 def clipped_adamw_step(params, grads, state, *, lrs, wds, clip=0.01, betas=(0.9, 0.999), eps=1e-8, step):
     """FullModelGradientClippingOptimizer(AdamW).step, base_trainer.py:118-133:
     global-norm clip (norm type 2, torch.nn.utils.clip_grad_norm_: coef =
-    clip/(total+1e-6) clamped to 1) then torch.optim.AdamW (decoupled WD)."""
-    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    clip/(total+1e-6) clamped to 1) then torch.optim.AdamW (decoupled WD).  A gradient of None = a parameter
+    whose .grad is None: skipped by clip_grad_norm_ and by AdamW alike (weights and moments untouched)."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads if g is not None)).float()
     coef = torch.clamp(clip / (total + 1e-6), max=1.0)
     b1, b2 = betas
     for i, (p, g) in enumerate(zip(params, grads)):
+        if g is None:
+            continue
         g = g * coef
         m, v = state[i]
         p.mul_(1 - lrs[i] * wds[i])

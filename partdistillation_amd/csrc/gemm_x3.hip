@@ -212,10 +212,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict_
 // three LDS stages) — the structure, not any single pipe, is the limit.
 constexpr int WBM = 256, WBN = 256;
 
-template <bool RELU, int ABL = 0>        // ABL (tools only): 1 no MFMA, 2 no output stores, 3 no operand split
+// ReLU backward of the FFN in the epilogue.  The forward (RELU) launch can leave the sign pattern of its output as a BIT per
+// element — one 32-bit word per (workgroup tile, lane, column tile j) holding that lane's 2 x 16 accumulator elements, i.e.
+// in this kernel's own C layout (`bits`, 1/32 of the tensor) — and the MASKSUM launch of the transposed product over the
+// same [M, N] (same tiling, same layout) consumes it: C = (A B^T) where the forward output was > 0, else 0, and colsum[N] +=
+// the column sums of that C (the bias gradient of the Linear in front of the ReLU).  That replaces a separate pass over the
+// [M, N] gradient (pd_relu_bwd_colsum: read 2, write 1 such tensor) by 4 words per lane.  (Reading the fp32 activations
+// themselves in the epilogue instead was measured: +140 us per launch, a net loss.)
+template <bool RELU, int ABL = 0, bool MASKSUM = false>        // ABL (tools only): 1 no MFMA, 2 no output stores, 3 no operand split
 __global__ __launch_bounds__(512, 1) void gemm_tn_f32x3_wide(const float *__restrict__ A, const float *__restrict__ B,
                                                               const float *__restrict__ bias, float *__restrict__ C, int M, int N,
-                                                              int K, int lda, int ldb, int ldc, int ntiles_n)
+                                                              int K, int lda, int ldb, int ldc, int ntiles_n,
+                                                              uint32_t *__restrict__ bits, float *__restrict__ colsum)
 {
   // LDS tile layout: [stage][plane][k half][row][8 bf16] — a 16-wide step is two PANELS of 16-byte row slots.  An MFMA
   // operand (8 consecutive k of row lane % 32, half lane / 32) is then ONE ds_read_b128 and the 32 lanes of a half read 512
@@ -304,6 +312,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f32x3_wide(const float *__rest
     const int col = n0 + wn + j * 32 + (lane & 31);
     if (col >= N) continue;
     const float bv = bias ? bias[col] : 0.f;
+    float csum = 0.f;
+    const int64_t widx = (((int64_t)lb * 8 + wave) * 64 + lane) * 4 + j;
+    uint32_t word = MASKSUM ? bits[widx] : 0u;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -311,10 +322,22 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f32x3_wide(const float *__rest
         const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (row < M && (ABL != 2 || v_never(acc[i][j][e]))) {
           float v = acc[i][j][e] + bv;
-          if (RELU) v = fmaxf(v, 0.f);
+          if (RELU) {
+            v = fmaxf(v, 0.f);
+            word |= (v > 0.f ? 1u : 0u) << (i * 16 + e);
+          }
+          if (MASKSUM) {
+            v = ((word >> (i * 16 + e)) & 1u) ? v : 0.f;
+            csum += v;
+          }
           C[(int64_t)row * ldc + col] = v;
         }
       }
+    if (RELU && bits) bits[widx] = word;
+    if (MASKSUM) {
+      csum += __shfl_xor(csum, 32, 64);                          // the two row halves of the wavefront hold the same column
+      if (lane < 32 && csum != 0.f) unsafeAtomicAdd(colsum + col, csum);
+    }
   }
 }
 
@@ -418,6 +441,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3(const float *__restri
 }
 }  // namespace
 
+static uint32_t *const g_relu_bits = nullptr;   // plain pd_gemm_tn_f32x3 launches do not record the sign bits
 int g_pd_dbg_x3_narrow = 0;   // tools/ only (pd_debug_set "x3_narrow"): 1 = never use the 256 x 256 kernel
 int g_pd_dbg_x3 = 0;   // tools/ only (pd_debug_set "x3_ablate"): 1 no MFMA, 2 only hi*hi, 3 no operand split, 4 no output stores
 
@@ -445,11 +469,11 @@ extern "C" int pd_gemm_tn_f32x3(const float *A, const float *B, const float *bia
     if (g_pd_dbg_x3 > 10) {
       auto kf = g_pd_dbg_x3 == 11 ? gemm_tn_f32x3_wide<false, 1> : g_pd_dbg_x3 == 12 ? gemm_tn_f32x3_wide<false, 2> : gemm_tn_f32x3_wide<false, 3>;
       (void)hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kf, wg, wb, lds, st, A, B, bias, C, M, N, K, lda, ldb, ldc, wtn);
+      hipLaunchKernelGGL(kf, wg, wb, lds, st, A, B, bias, C, M, N, K, lda, ldb, ldc, wtn, (uint32_t *)nullptr, (float *)nullptr);
       return pd_check_launch("pd_gemm_tn_f32x3");
     }
-    if (relu) hipLaunchKernelGGL(gemm_tn_f32x3_wide<true>, wg, wb, lds, st, A, B, bias, C, M, N, K, lda, ldb, ldc, wtn);
-    else hipLaunchKernelGGL(gemm_tn_f32x3_wide<false>, wg, wb, lds, st, A, B, bias, C, M, N, K, lda, ldb, ldc, wtn);
+    if (relu) hipLaunchKernelGGL(gemm_tn_f32x3_wide<true>, wg, wb, lds, st, A, B, bias, C, M, N, K, lda, ldb, ldc, wtn, g_relu_bits, (float *)nullptr);
+    else hipLaunchKernelGGL(gemm_tn_f32x3_wide<false>, wg, wb, lds, st, A, B, bias, C, M, N, K, lda, ldb, ldc, wtn, (uint32_t *)nullptr, (float *)nullptr);
     return pd_check_launch("pd_gemm_tn_f32x3");
   }
   const int tn = (N + BN - 1) / BN, tm = (M + BM - 1) / BM;
@@ -463,6 +487,46 @@ extern "C" int pd_gemm_tn_f32x3(const float *A, const float *B, const float *bia
   else LAUNCH(false, 0);
 #undef LAUNCH
   return pd_check_launch("pd_gemm_tn_f32x3");
+}
+
+extern "C" int64_t pd_gemm_tn_f32x3_relu_bits_words(int M, int N)
+{
+  if (M <= 0 || N <= 0 || (N % WBN)) return 0;
+  return (int64_t)((M + WBM - 1) / WBM) * (N / WBN) * 8 * 64 * 4;
+}
+
+extern "C" int pd_gemm_tn_f32x3_relu_bits(const float *A, const float *B, const float *bias, float *C, uint32_t *bits, int M, int N, int K,
+                                          int lda, int ldb, int ldc, void *stream_)
+{
+  if (M <= 0 || N <= 0 || (N % WBN) || M < 4 * WBM || !bits)
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f32x3_relu_bits: needs N %% 256 == 0, M >= 1024 and a bits buffer");
+  if (!A || !B || !C) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f32x3_relu_bits: null pointer");
+  if ((K & 3) || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f32x3_relu_bits: K, lda, ldb must be multiples of 4 and A, B 16-byte aligned");
+  const int wtn = N / WBN, wtm = (M + WBM - 1) / WBM;
+  const size_t lds = (size_t)2 * 3 * 2 * (WBM + WBN) * 8 * sizeof(bf16_t);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)gemm_tn_f32x3_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL(gemm_tn_f32x3_wide<true>, dim3((unsigned)((int64_t)wtm * wtn)), dim3(512), lds, (hipStream_t)stream_, A, B, bias, C, M, N, K,
+                     lda, ldb, ldc, wtn, bits, (float *)nullptr);
+  return pd_check_launch("pd_gemm_tn_f32x3_relu_bits");
+}
+
+extern "C" int pd_gemm_tn_f32x3_relumask(const float *A, const float *B, const uint32_t *bits, float *C, float *colsum, int M, int N, int K,
+                                         int lda, int ldb, int ldc, void *stream_)
+{
+  if (M < 0 || N < 0 || K < 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f32x3_relumask: negative size");
+  if (M == 0 || N == 0) return PD_OK;
+  if (!A || !B || !C || !bits || !colsum) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f32x3_relumask: null pointer");
+  if ((K & 3) || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || (N % WBN) || M < 4 * WBM)
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f32x3_relumask: K, lda, ldb multiples of 4, N a multiple of 256, M >= 1024, A, B 16-byte aligned");
+  const int wtn = N / WBN, wtm = (M + WBM - 1) / WBM;
+  const size_t lds = (size_t)2 * 3 * 2 * (WBM + WBN) * 8 * sizeof(bf16_t);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)gemm_tn_f32x3_wide<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((gemm_tn_f32x3_wide<false, 0, true>), dim3((unsigned)((int64_t)wtm * wtn)), dim3(512), lds, (hipStream_t)stream_, A, B,
+                     (const float *)nullptr, C, M, N, K, lda, ldb, ldc, wtn, const_cast<uint32_t *>(bits), colsum);
+  return pd_check_launch("pd_gemm_tn_f32x3_relumask");
 }
 
 extern "C" int pd_gemm_wgrad_acc_f32x3(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx,

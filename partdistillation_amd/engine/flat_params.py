@@ -71,8 +71,13 @@ class FlatGroup:
         return out
 
     def gather(self, sumsq=None, t_begin=0, t_end=None):
-        """collect p.grad of params [t_begin, t_end) into the flat gradient buffer (missing gradients -> zeros)."""
+        """collect p.grad of params [t_begin, t_end) into the flat gradient buffer (missing gradients -> zeros; their
+        indices are remembered in `self.nograd` so the optimizer can leave those parameters untouched, as torch.optim.AdamW
+        skips parameters whose .grad is None)."""
         t_end = len(self.params) if t_end is None else t_end
+        if t_begin == 0:
+            self.nograd = []
+        self.nograd = getattr(self, "nograd", []) + [i for i in range(t_begin, t_end) if self.params[i].grad is None]
         if self.plan is not None:
             self.plan.upload(self._grad_sources(t_begin, t_end), t_begin)
             self.plan.gather(self.grad, sumsq, t_begin, t_end)

@@ -122,12 +122,25 @@ class FlatClippedAdamW:
         else:                                              # single process: gather + sum of squares in one pass
             for g in self.flat.groups:
                 g.gather(self._sumsq if self.clip_norm > 0 else None)
+        single = not self.grads_ready                      # (data-parallel runs: an unused parameter is an error in the reference's DDP)
         self.grads_ready = False
         for i, (g, pg, m, v) in enumerate(zip(self.flat.groups, self.param_groups, self.exp_avg, self.exp_avg_sq)):
+            # parameters that received NO gradient this step are left exactly as they are (weights, moments, bf16 copy):
+            # torch.optim.AdamW — the reference's optimizer — skips p.grad is None, while the flat kernel would still apply
+            # weight decay and decay the moments on their zero-filled slots.  Rare (data-dependent branches: empty targets),
+            # so the flat pass stays as it is and the few affected tensors are saved before it and put back after it.
+            keep = []
+            if single:
+                for t in getattr(g, "nograd", ()):
+                    views = [g._view(buf, g.params[t], g.offsets[t]) for buf in (g.param, m, v) + ((g.shadow,) if g.shadow is not None else ())]
+                    keep.append((views, [x.clone() for x in views]))
             optim_op.adamw_clipped_(g.param, g.grad, m, v, lr=pg["lr"], betas=self.betas, eps=self.eps,
                                     weight_decay=pg["weight_decay"], step=max(self.steps, 1),
                                     grad_sumsq=self._sumsq if self.clip_norm > 0 else None, max_norm=self.clip_norm,
                                     shadow=g.shadow, dyn=self._dyn_dev[i])
+            for views, saved in keep:
+                for x, y in zip(views, saved):
+                    x.copy_(y)
 
     def state_dict(self):
         return {"steps": self.steps, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,

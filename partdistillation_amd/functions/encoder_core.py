@@ -20,7 +20,7 @@ from torch.autograd import Function
 from .. import MultiScaleDeformableAttention as MSDA
 from .. import lib as _lib
 from . import rowwise as rw
-from .gemm import gemm_tn_x3, gemm_wgrad_acc
+from .gemm import gemm_tn_x3, gemm_tn_x3_relu_bits, gemm_tn_x3_relumask, gemm_wgrad_acc, relu_bits_supported
 
 def _timed(kind, fn, *args):
     # bench.py's per-launch HIP-event hook lives next to the autograd face of the operator (imported lazily: that module
@@ -104,11 +104,15 @@ class EncoderCore(Function):
             v4, loc6, attn5 = value.view(B, S, M, C // M), loc.view(B, S, M, L, P, 2), attn.view(B, S, M, L, P)
             a = _timed("fwd", MSDA.ms_deform_attn_forward, v4, spec.shapes, spec.lsi, loc6, attn5, spec.im2col_step).view(T, C)
             z1, y1, _, _, m1, r1 = rw.add_ln_fwd(torch.addmm(op_b, a, op_w.t()), x, n1_w, n1_b, spec.eps)
-            h = _ffn_gemm(y1, l1_w, l1_b, relu=True)                                 # bias + ReLU in the GEMM epilogue
+            hbits = None
+            if USE_X3 and relu_bits_supported(T, l1_w.shape[0]):
+                h, hbits = gemm_tn_x3_relu_bits(y1, l1_w, l1_b)                       # + the sign bits the backward's epilogue consumes
+            else:
+                h = _ffn_gemm(y1, l1_w, l1_b, relu=True)                             # bias + ReLU in the GEMM epilogue
             last = i == nl - 1
             z2, y2, _, ypos, m2, r2 = rw.add_ln_fwd(_ffn_gemm(h, l2_w, l2_b), y1, n2_w, n2_b, spec.eps, c_dtype=torch.float32,
                                                     pos=pos2, pos_div=1, want_ypos=not last)
-            saved.append((x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, w_oa))
+            saved.append((x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, w_oa, hbits))
             x, q = y2, ypos
         ctx.spec, ctx.saved, ctx.params, ctx.dims = spec, saved, params, (B, S, C, nl)
         return x.view(B, S, C)
@@ -151,14 +155,17 @@ class EncoderCore(Function):
         dy2 = dyq = None                                       # further fp32 terms of d(src_l): via value_proj, via (src + pos)
         for i in reversed(range(nl)):
             (so_w, so_b, aw_w, aw_b, vp_w, vp_b, op_w, op_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b) = params[i * N_LAYER:(i + 1) * N_LAYER]
-            x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, w_oa = ctx.saved[i]
+            x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, w_oa, hbits = ctx.saved[i]
             (g_sow, g_sob, g_aww, g_awb, g_vpw, g_vpb, g_opw, g_opb, g_n1w, g_n1b, g_l1w, g_l1b, g_l2w, g_l2b, g_n2w,
              g_n2b) = [G(i, j) for j in range(N_LAYER)]
             # ---- FFN + norm2
             dz2, _ = rw.add_ln_bwd(z2, m2, r2, n2_w, dy=dy, dy2=dy2, dypos_c=dyq, dgamma=g_n2w, dbeta=g_n2b, dbias=g_l2b,
                                    dpos_acc=d_pos if dyq is not None else None, pos_div=1)
             wgrad(dz2, h, g_l2w)
-            dh = rw.relu_bwd_colsum(_ffn_gemm(dz2, l2_w.t().contiguous()), h, g_l1b)
+            if hbits is not None:
+                dh = gemm_tn_x3_relumask(dz2, l2_w.t().contiguous(), hbits, g_l1b)  # ReLU backward + bias gradient in the epilogue
+            else:
+                dh = rw.relu_bwd_colsum(_ffn_gemm(dz2, l2_w.t().contiguous()), h, g_l1b)
             wgrad(dh, y1, g_l1w)
             dy1 = _ffn_gemm(dh, l1_w.t().contiguous())
             del dh

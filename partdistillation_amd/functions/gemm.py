@@ -39,6 +39,37 @@ def gemm_tn_x3(a, b, bias=None, relu=False):
     return c
 
 
+def relu_bits_supported(M, N):
+    return N % 256 == 0 and M >= 1024
+
+
+def gemm_tn_x3_relu_bits(a, b, bias):
+    """relu(a @ b.T + bias) and the sign bits of the result in the kernel's accumulator order (pd_gemm_tn_f32x3_relu_bits) for
+    gemm_tn_x3_relumask.  -> (c fp32 [M,N], bits int32 [words])"""
+    assert a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    L = _lib.load()
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    bits = torch.empty(int(L.pd_gemm_tn_f32x3_relu_bits_words(M, N)), dtype=torch.int32, device=a.device)
+    _lib.check(L.pd_gemm_tn_f32x3_relu_bits(a.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else None, c.data_ptr(),
+                                            bits.data_ptr(), M, N, K, a.stride(0), b.stride(0), N, _stream()))
+    return c, bits
+
+
+def gemm_tn_x3_relumask(a, b, bits, colsum):
+    """(a @ b.T) where the recorded ReLU output was > 0, else 0 -> fp32 [M,N]; colsum[N] += its column sums
+    (pd_gemm_tn_f32x3_relumask: the FFN's ReLU backward and first-Linear bias gradient in the GEMM epilogue)."""
+    assert a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    assert bits.dtype == torch.int32 and colsum.dtype == torch.float32 and colsum.numel() == N
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().pd_gemm_tn_f32x3_relumask(a.data_ptr(), b.data_ptr(), bits.data_ptr(), c.data_ptr(), colsum.data_ptr(),
+                                                     M, N, K, a.stride(0), b.stride(0), N, _stream()))
+    return c
+
+
 # optional per-launch timing hook used by bench.py (HIP events on the launch stream; (start, stop, flops) per launch)
 _TIMING = {"on": False, "wgrad": []}
 

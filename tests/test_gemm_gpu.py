@@ -139,3 +139,26 @@ def test_conv3x3_x3_matches_fp64_convolution(B, H, W, Ci, Co, bias):
         (gb,) = torch.autograd.grad(y, (b,), go)
         torch.testing.assert_close(gb.double(), go.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
 
+
+
+@pytest.mark.parametrize("M,N,K,K2", [(4096, 1024, 256, 256), (3000, 256, 64, 128), (1024, 512, 400, 36)])
+def test_gemm_tn_x3_relu_bits_and_relumask_epilogues(M, N, K, K2):
+    """pd_gemm_tn_f32x3_relu_bits (forward: relu(A B^T + b) + sign bits) and pd_gemm_tn_f32x3_relumask (backward: (G W) masked by
+    those bits, column sums accumulated) against fp64 and the two-step path they replace."""
+    from partdistillation_amd.functions import gemm
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    h, bits = gemm.gemm_tn_x3_relu_bits(a, w, b)
+    href = torch.addmm(b.double(), a.double(), w.double().t()).relu()
+    assert ((h.double() - href).abs().max().item() / href.abs().max().item()) < 2e-6
+    g2 = torch.randn(M, K2, device="cuda", generator=g)
+    w2 = torch.randn(N, K2, device="cuda", generator=g) * K2 ** -0.5
+    acc = torch.full((N,), 0.25, device="cuda")
+    got = gemm.gemm_tn_x3_relumask(g2, w2, bits, acc)
+    ref = (g2.double() @ w2.double().t()) * (h > 0)
+    scale = ref.abs().max().item()
+    assert ((got.double() - ref).abs().max().item() / scale) < 2e-6
+    assert torch.equal(got != 0, (h > 0) & (ref != 0))
+    torch.testing.assert_close(acc.double() - 0.25, ref.sum(0), rtol=1e-4, atol=1e-3 * scale)

@@ -295,8 +295,8 @@ def test_fused_clipped_adamw_vs_oracle():
         grads = [torch.randn(s) * (3.0 if step == 2 else 0.01) for s in shapes]
         opt.zero_grad()
         for i, (p, g) in enumerate(zip(params, grads)):
-            if step == 3 and i == 1:                               # a parameter without gradient -> treated as zeros
-                grads[i] = torch.zeros_like(g)
+            if step == 3 and i == 1:                               # a parameter without gradient: skipped like torch.optim.AdamW does
+                grads[i] = None
             elif p.dim() == 4:                                     # autograd's layout contract: grad strides == param strides
                 p.grad = torch.empty_like(p).copy_(g.to(DEV))
             else:
