@@ -203,12 +203,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict_
 // accumulator registers), one workgroup per CU, two 120 KB LDS stages of three bf16 planes.  Per 16-wide step a wave issues
 // 48 MFMAs (1 536 cycles) against 18 operand fragments; the B fragments are fetched for two column tiles at a time so that
 // 12 fragments, not 18, are live next to the accumulators.
-// Measured: 176 vs 205-213 us on the 1024 <- 256 Linear, a tie at N = 256 / 512.  Ablations of THIS kernel on that shape: no MFMA
+// Measured (with the schedule of the step below): 161-169 vs 202-216 us on the 1024 <- 256 Linear, 143 vs 167 on 256 <- 1024, a tie
+// at K = 256 with N = 256 / 512.  Ablations of THIS kernel on that shape: no MFMA
 // 117 us, no output stores 129, no operand split 148 — operand staging (~42) + split (28) + matrix work (59, the full bf16
 // rate) + stores (47, 3.7 TB/s) simply ADD UP: one barrier per 16-wide step keeps the 8 wavefronts in lock-step, so the pipes
-// take turns instead of overlapping.  A 128 x 256 variant with two independent workgroups per CU (to let them drift out of
-// phase) measured the same 181 us; moving the global loads to the top of the step and a conflict-free LDS layout changed
-// nothing either.  What is left to try is a deeper software pipeline (fragments of step k + 1 fetched during step k, i.e.
+// take turns instead of overlapping.  A 128 x 256 variant with two independent workgroups per CU (template parameter WVM = 2,
+// `x3_narrow` 3) measures the same (172 vs 169 us) — so it is not the common barrier; moving the global loads to the top of
+// the step and a conflict-free LDS layout changed nothing either; the guide's register-staging order (write tile t + 1 right
+// after the barrier, re-issue the loads, then compute) is worth 6 % and frees 26 VGPRs.  What is left to try is a deeper software pipeline (fragments of step k + 1 fetched during step k, i.e.
 // three LDS stages) — the structure, not any single pipe, is the limit.
 constexpr int WBM = 256, WBN = 256;
 
@@ -219,8 +221,11 @@ constexpr int WBM = 256, WBN = 256;
 // the column sums of that C (the bias gradient of the Linear in front of the ReLU).  That replaces a separate pass over the
 // [M, N] gradient (pd_relu_bwd_colsum: read 2, write 1 such tensor) by 4 words per lane.  (Reading the fp32 activations
 // themselves in the epilogue instead was measured: +140 us per launch, a net loss.)
-template <bool RELU, int ABL = 0, bool MASKSUM = false>        // ABL (tools only): 1 no MFMA, 2 no output stores, 3 no operand split
-__global__ __launch_bounds__(512, 1) void gemm_tn_f32x3_wide(const float *__restrict__ A, const float *__restrict__ B,
+// WVM = wavefronts along M: 4 -> 256 x 256 tile, 512 threads, one workgroup per CU; 2 -> 128 x 256 tile, 256 threads, TWO
+// independent workgroups per CU (each SIMD then hosts one wave of each: they are not tied by a common barrier and can sit in
+// different phases of their steps).
+template <bool RELU, int ABL = 0, bool MASKSUM = false, int WVM = 4>        // ABL (tools only): 1 no MFMA, 2 no output stores, 3 no operand split
+__global__ __launch_bounds__(128 * WVM, WVM == 4 ? 1 : 2) void gemm_tn_f32x3_wide(const float *__restrict__ A, const float *__restrict__ B,
                                                               const float *__restrict__ bias, float *__restrict__ C, int M, int N,
                                                               int K, int lda, int ldb, int ldc, int ntiles_n,
                                                               uint32_t *__restrict__ bits, float *__restrict__ colsum)
@@ -230,33 +235,43 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f32x3_wide(const float *__rest
   // contiguous bytes (conflict-free, full LDS rate); the 40-byte row pitch of the 128 x 128 kernel needs two 8-byte reads
   // per operand and puts rows r and r + 16 on the same banks.
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];              // As[2][3][2][WBM][8] | Bs[2][3][2][WBN][8]
-  auto As = [&](int buf, int pl, int h, int r) -> bf16_t * { return smem + ((((buf * 3 + pl) * 2 + h) * WBM + r) << 3); };
-  auto Bs = [&](int buf, int pl, int h, int r) -> bf16_t * { return smem + 12 * WBM * 8 + ((((buf * 3 + pl) * 2 + h) * WBN + r) << 3); };
+  constexpr int TBM = 64 * WVM, NTH = 128 * WVM, RPP = NTH / 4, BPASS = WBN / RPP;     // tile rows, threads, rows per load pass, B passes
+  auto As = [&](int buf, int pl, int h, int r) -> bf16_t * { return smem + ((((buf * 3 + pl) * 2 + h) * TBM + r) << 3); };
+  auto Bs = [&](int buf, int pl, int h, int r) -> bf16_t * { return smem + 12 * TBM * 8 + ((((buf * 3 + pl) * 2 + h) * WBN + r) << 3); };
   const int lb = xcd_chunk(blockIdx.x, gridDim.x);
-  const int m0 = (lb / ntiles_n) * WBM, n0 = (lb % ntiles_n) * WBN;
+  const int m0 = (lb / ntiles_n) * TBM, n0 = (lb % ntiles_n) * WBN;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;
-  const int lr = t >> 2, lk = (t & 3) * 4;                       // rows lr + 128 j, columns lk .. lk+3 of both tiles
-  float4 ra[2][2], rb[2][2];                                     // two register stages: loads run two steps ahead of their use
-  auto gload = [&](int s, int k0) {
+  const int lr = t >> 2, lk = (t & 3) * 4;                       // rows lr + RPP j, columns lk .. lk+3 of both tiles
+  float4 ra[2], rb[BPASS];                                       // ONE register stage (see the step)
+  auto gload = [&](int k0) {
+    const int k = k0 + lk;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int r = lr + 128 * j, k = k0 + lk;
-      ra[s][j] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4 *>(A + (int64_t)(m0 + r) * lda + k) : make_float4(0, 0, 0, 0);
-      rb[s][j] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4 *>(B + (int64_t)(n0 + r) * ldb + k) : make_float4(0, 0, 0, 0);
+      const int r = lr + RPP * j;
+      ra[j] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4 *>(A + (int64_t)(m0 + r) * lda + k) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+      const int r = lr + RPP * j;
+      rb[j] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4 *>(B + (int64_t)(n0 + r) * ldb + k) : make_float4(0, 0, 0, 0);
     }
   };
-  auto lstore1 = [&](int s, int buf, int op, int j) {
-    const float4 v4 = op == 0 ? ra[s][j] : rb[s][j];
+  auto lstore1 = [&](int buf, int op, int j) {
+    const float4 v4 = op == 0 ? ra[j] : rb[j];
     Split4 x;
     if (ABL == 3) { x.hi = make_uint2(pk_bf16(v4.x, v4.y), pk_bf16(v4.z, v4.w)); x.mid = x.lo = make_uint2(0, 0); }
     else x = split4(v4);
-    const int r = lr + 128 * j;
+    const int r = lr + RPP * j;
     bf16_t *p0 = (op == 0 ? As(buf, 0, lk >> 3, r) : Bs(buf, 0, lk >> 3, r)) + (lk & 7);
-    constexpr int PL = 2 * WBM * 8;                              // plane stride (WBM == WBN)
+    const int PL = 2 * (op == 0 ? TBM : WBN) * 8;                // plane stride
     *reinterpret_cast<uint2 *>(p0) = x.hi; *reinterpret_cast<uint2 *>(p0 + PL) = x.mid; *reinterpret_cast<uint2 *>(p0 + 2 * PL) = x.lo;
   };
-  auto lstore = [&](int s, int buf) { lstore1(s, buf, 0, 0); lstore1(s, buf, 0, 1); lstore1(s, buf, 1, 0); lstore1(s, buf, 1, 1); };
+  auto lstore = [&](int buf) {
+    lstore1(buf, 0, 0); lstore1(buf, 0, 1);
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) lstore1(buf, 1, j);
+  };
   f32x16 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -265,22 +280,25 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f32x3_wide(const float *__rest
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   const int KT = (K + BK - 1) / BK;
-  gload(0, 0);
-  if (KT > 1) gload(1, BK);
-  lstore(0, 0);
+  gload(0);
+  lstore(0);
+  if (KT > 1) gload(BK);
   __syncthreads();
   const int fr = lane & 31, fh = lane >> 5;
   auto step = [&](int kt, int par) {
-    // the loads of tile kt + 2 go out FIRST (register stage `par` was written to LDS during step kt - 1): they have this
-    // whole step to land before step kt + 1 splits them.  Issued after the MFMAs (as the 128 x 128 kernel did) they were
-    // consumed a sixth of a step later, so every step exposed a full global-load latency.
-    if (kt + 2 < KT) gload(par, (kt + 2) * BK);
+    // the guide's register-staging schedule (T14): right after the barrier, tile kt + 1 (in the registers since the top of step
+    // kt - 1) is split and written to the other LDS buffer, the loads of tile kt + 2 are re-issued into the same registers at
+    // once (a whole step to land), and only then does the wave turn to tile kt's fragments and MFMAs — no barrier between the
+    // staging and the compute, so the waves drift apart inside a step and one's MFMAs cover another's staging
+    if (kt + 1 < KT) {
+      lstore(par ^ 1);
+      if (kt + 2 < KT) gload((kt + 2) * BK);
+    }
     hwbf16x8 a[3][2];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int i = 0; i < 2; ++i) a[pl][i] = *reinterpret_cast<const hwbf16x8 *>(As(par, pl, fh, wm + i * 32 + fr));
-    const bool more = kt + 1 < KT;
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {                             // two column tiles at a time
       hwbf16x8 b[3][2];
@@ -292,9 +310,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f32x3_wide(const float *__rest
 #define WTERM(PA, PB)                                                        \
   _Pragma("unroll") for (int i = 0; i < 2; ++i)                              \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) { if (ABL == 1) acc[i][jp * 2 + j][0] += (float)a[PA][i][0] * (float)b[PB][j][1]; else mma16k(acc[i][jp * 2 + j], a[PA][i], b[PB][j]); }
-      WTERM(2, 0) if (more) lstore1(par ^ 1, par ^ 1, jp, 0);
+      WTERM(2, 0)
       WTERM(0, 2)
-      WTERM(1, 1) if (more) lstore1(par ^ 1, par ^ 1, jp, 1);
+      WTERM(1, 1)
       WTERM(1, 0)
       WTERM(0, 1)
       WTERM(0, 0)
@@ -313,7 +331,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f32x3_wide(const float *__rest
     if (col >= N) continue;
     const float bv = bias ? bias[col] : 0.f;
     float csum = 0.f;
-    const int64_t widx = (((int64_t)lb * 8 + wave) * 64 + lane) * 4 + j;
+    const int64_t widx = (((int64_t)lb * (2 * WVM) + wave) * 64 + lane) * 4 + j;
     uint32_t word = MASKSUM ? bits[widx] : 0u;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -454,9 +472,10 @@ extern "C" int pd_gemm_tn_f32x3(const float *A, const float *B, const float *bia
   if ((K & 3) || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f32x3: K, lda, ldb must be multiples of 4 and A, B 16-byte aligned");
   hipStream_t st = (hipStream_t)stream_;
-  // wide tiles where they were measured to pay (tools/bench_gemm_x3_wide.py): the output-heavy 1024-wide Linears (176 vs 205-213 us
-  // at M = 43 008, K = 256); at N = 256 / 512 the two kernels tie or the narrow one wins (more workgroups than CUs matter more)
-  if ((!g_pd_dbg_x3 || g_pd_dbg_x3 > 10) && g_pd_dbg_x3_narrow != 1 && (N % WBN) == 0 && M >= 4 * WBM && (N >= 1024 || g_pd_dbg_x3_narrow == 2)) {
+  // wide tiles where they were measured to pay (tools/bench_gemm_x3_wide.py, M = 43 008): 1024 <- 256: 161-169 vs 202-216 us; 256 <- 1024:
+  // 143 vs 167; at K = 256 with N = 256 / 512 the two kernels tie or the narrow one wins; few tiles (< 128) leave CUs idle
+  if ((!g_pd_dbg_x3 || g_pd_dbg_x3 > 10) && g_pd_dbg_x3_narrow != 1 && (N % WBN) == 0 && M >= 4 * WBM &&
+      ((int64_t)((M + WBM - 1) / WBM) * (N / WBN) >= 128 || g_pd_dbg_x3_narrow >= 2) && (N >= 1024 || K >= 512 || g_pd_dbg_x3_narrow >= 2)) {
     const int wtn = N / WBN, wtm = (M + WBM - 1) / WBM;
     const size_t lds = (size_t)2 * 3 * 2 * (WBM + WBN) * 8 * sizeof(bf16_t);
     static bool attr = false;
@@ -464,6 +483,14 @@ extern "C" int pd_gemm_tn_f32x3(const float *A, const float *B, const float *bia
       (void)hipFuncSetAttribute((const void *)gemm_tn_f32x3_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       (void)hipFuncSetAttribute((const void *)gemm_tn_f32x3_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr = true;
+    }
+    if (g_pd_dbg_x3_narrow == 3) {                             // tools: 128 x 256 tiles, two workgroups per CU
+      const int htm = (M + 127) / 128;
+      const size_t hlds = (size_t)2 * 3 * 2 * (128 + WBN) * 8 * sizeof(bf16_t);
+      (void)hipFuncSetAttribute((const void *)gemm_tn_f32x3_wide<false, 0, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hlds);
+      hipLaunchKernelGGL((gemm_tn_f32x3_wide<false, 0, false, 2>), dim3((unsigned)((int64_t)htm * wtn)), dim3(256), hlds, st, A, B, bias, C, M, N, K,
+                         lda, ldb, ldc, wtn, (uint32_t *)nullptr, (float *)nullptr);
+      return pd_check_launch("pd_gemm_tn_f32x3");
     }
     const dim3 wg((unsigned)((int64_t)wtm * wtn)), wb(512);
     if (g_pd_dbg_x3 > 10) {

@@ -15,6 +15,8 @@ for M, N, K in [(43008, 256, 256), (43008, 1024, 256), (43008, 256, 1024), (4300
     y_lib = torch.addmm(b, a, w.t())
     L.pd_debug_set(b"x3_narrow", 1); y_n = gemm.gemm_tn_x3(a, w, b); tn = t(lambda: gemm.gemm_tn_x3(a, w, b))
     L.pd_debug_set(b"x3_narrow", 2); y_w2 = gemm.gemm_tn_x3(a, w, b); tw2 = t(lambda: gemm.gemm_tn_x3(a, w, b))
+    L.pd_debug_set(b"x3_narrow", 3); y_w3 = gemm.gemm_tn_x3(a, w, b); tw3 = t(lambda: gemm.gemm_tn_x3(a, w, b))
+    assert (y_w3 - y_w2).abs().max().item() <= 1e-5 * ref.abs().max().item()
     L.pd_debug_set(b"x3_narrow", 0); y_w = gemm.gemm_tn_x3(a, w, b); tw = t(lambda: gemm.gemm_tn_x3(a, w, b))
     yr = gemm.gemm_tn_x3(a, w, b, relu=True)
     tl = t(lambda: torch.addmm(b, a, w.t()))
@@ -22,7 +24,7 @@ for M, N, K in [(43008, 256, 256), (43008, 1024, 256), (43008, 256, 1024), (4300
     e = [((y.double() - ref).abs().max().item() / scale) for y in (y_lib, y_n, y_w)]
     er = ((yr.double() - ref.relu()).abs().max().item() / scale)
     gf = 2.0 * M * N * K / 1e9
-    print(f"M={M:6d} N={N:4d} K={K:4d}: library {tl:6.1f} us ({gf/tl*1e-3:5.1f} TF) | x3 128x128 {tn:6.1f} us | x3 256x256 {tw2:6.1f} us | x3 default {tw:6.1f} us ({gf/tw*1e-3:5.1f} TF fp32-equiv, {6*gf/tw*1e-3:5.0f} TF bf16)"
+    print(f"M={M:6d} N={N:4d} K={K:4d}: library {tl:6.1f} us ({gf/tl*1e-3:5.1f} TF) | x3 128x128 {tn:6.1f} us | x3 256x256 {tw2:6.1f} us | x3 128x256 2/CU {tw3:6.1f} us | x3 default {tw:6.1f} us ({gf/tw*1e-3:5.1f} TF fp32-equiv, {6*gf/tw*1e-3:5.0f} TF bf16)"
           f" | max err/scale lib {e[0]:.2e} narrow {e[1]:.2e} wide {e[2]:.2e} relu {er:.2e}")
 
 print("wide-kernel ablations (us): 11 no MFMA, 12 no output stores, 13 no operand split")
