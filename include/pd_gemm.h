@@ -45,6 +45,14 @@ int pd_gemm_wgrad_acc_f32(const float *dY, const float *X, float *dW, float *dB,
  * over the same [M, N]: the gradient w.r.t. the FFN's hidden pre-activation and the bias gradient of its first Linear
  * (reference msdeformattn.py:120-124 through autograd) without a separate pass over the [M, N] tensor. */
 int64_t pd_gemm_tn_f32x3_relu_bits_words(int M, int N);
+/* Weight operand split ONCE per optimizer step instead of by every row tile of every GEMM:
+ *   pd_split3_bf16        W fp32 [N, K] (row stride ldw) -> planes bf16 [3][N][K] (hi, mid, lo; exact: hi + mid + lo == W), or with
+ *                         transpose != 0 the planes [3][K][N] of W^T (the operand of the input-gradient GEMM)
+ *   pd_gemm_tn_f32x3_pre  pd_gemm_tn_f32x3 with B given as such planes [3][N][K]; mode 0: C = A B^T + bias, 1: relu (+ sign bits when
+ *                         bits != NULL), 2: masked by bits, colsum += column sums.  N % 256 == 0, K % 16 == 0, M >= 1024. */
+int pd_split3_bf16(const float *W, int N, int K, int ldw, int transpose, void *planes, void *stream);
+int pd_gemm_tn_f32x3_pre(const float *A, const void *Bplanes, const float *bias, float *C, uint32_t *bits, float *colsum, int M, int N, int K,
+                         int lda, int ldc, int mode, void *stream);
 int pd_gemm_tn_f32x3_relu_bits(const float *A, const float *B, const float *bias, float *C, uint32_t *bits, int M, int N, int K, int lda,
                                int ldb, int ldc, void *stream);
 int pd_gemm_tn_f32x3_relumask(const float *A, const float *B, const uint32_t *bits, float *C, float *colsum, int M, int N, int K, int lda,

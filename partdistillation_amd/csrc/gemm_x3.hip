@@ -224,7 +224,12 @@ constexpr int WBM = 256, WBN = 256;
 // WVM = wavefronts along M: 4 -> 256 x 256 tile, 512 threads, one workgroup per CU; 2 -> 128 x 256 tile, 256 threads, TWO
 // independent workgroups per CU (each SIMD then hosts one wave of each: they are not tied by a common barrier and can sit in
 // different phases of their steps).
-template <bool RELU, int ABL = 0, bool MASKSUM = false, int WVM = 4>        // ABL (tools only): 1 no MFMA, 2 no output stores, 3 no operand split
+// BPRE: B is not fp32 but its three bf16 planes, split once per optimizer step by pd_split3_bf16 ([3][N][K], row stride K) — B
+// is a weight matrix, re-split here by every one of the M / 256 row tiles otherwise.  Bit-identical to the in-kernel split; measured
+// (tools/bench_gemm_x3_wide.py) it does NOT pay: 174.6 vs 178.6 us on 1024 <- 256, 157 vs 151 on 256 <- 1024, plus the split launch
+// — the bf16 planes are 6 bytes per element to fetch instead of 4, which costs what the saved vector work gained.  Kept as an
+// entry point (off by default in functions/encoder_core.py).
+template <bool RELU, int ABL = 0, bool MASKSUM = false, int WVM = 4, bool BPRE = false>   // ABL (tools only): 1 no MFMA, 2 no output stores, 3 no operand split
 __global__ __launch_bounds__(128 * WVM, WVM == 4 ? 1 : 2) void gemm_tn_f32x3_wide(const float *__restrict__ A, const float *__restrict__ B,
                                                               const float *__restrict__ bias, float *__restrict__ C, int M, int N,
                                                               int K, int lda, int ldb, int ldc, int ntiles_n,
@@ -244,6 +249,10 @@ __global__ __launch_bounds__(128 * WVM, WVM == 4 ? 1 : 2) void gemm_tn_f32x3_wid
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;
   const int lr = t >> 2, lk = (t & 3) * 4;                       // rows lr + RPP j, columns lk .. lk+3 of both tiles
   float4 ra[2], rb[BPASS];                                       // ONE register stage (see the step)
+  uint4 rbp[3];                                                  // BPRE: one (row, k half) unit of each plane per thread (512 threads x 3 = the tile)
+  const bf16_t *Bp = reinterpret_cast<const bf16_t *>(B);
+  const int64_t PS = (int64_t)N * ldb;                           // BPRE: plane stride (ldb = K)
+  const int br = t >> 1, bh = t & 1;
   auto gload = [&](int k0) {
     const int k = k0 + lk;
 #pragma unroll
@@ -251,10 +260,17 @@ __global__ __launch_bounds__(128 * WVM, WVM == 4 ? 1 : 2) void gemm_tn_f32x3_wid
       const int r = lr + RPP * j;
       ra[j] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4 *>(A + (int64_t)(m0 + r) * lda + k) : make_float4(0, 0, 0, 0);
     }
+    if (BPRE) {
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j) {
-      const int r = lr + RPP * j;
-      rb[j] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4 *>(B + (int64_t)(n0 + r) * ldb + k) : make_float4(0, 0, 0, 0);
+      for (int pl = 0; pl < 3; ++pl)
+        rbp[pl] = (n0 + br < N && k0 + bh * 8 < K) ? *reinterpret_cast<const uint4 *>(Bp + pl * PS + (int64_t)(n0 + br) * ldb + k0 + bh * 8)
+                                                   : make_uint4(0, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < BPASS; ++j) {
+        const int r = lr + RPP * j;
+        rb[j] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4 *>(B + (int64_t)(n0 + r) * ldb + k) : make_float4(0, 0, 0, 0);
+      }
     }
   };
   auto lstore1 = [&](int buf, int op, int j) {
@@ -269,8 +285,13 @@ __global__ __launch_bounds__(128 * WVM, WVM == 4 ? 1 : 2) void gemm_tn_f32x3_wid
   };
   auto lstore = [&](int buf) {
     lstore1(buf, 0, 0); lstore1(buf, 0, 1);
+    if (BPRE) {
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j) lstore1(buf, 1, j);
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint4 *>(Bs(buf, pl, bh, br)) = rbp[pl];
+    } else {
+#pragma unroll
+      for (int j = 0; j < BPASS; ++j) lstore1(buf, 1, j);
+    }
   };
   f32x16 acc[2][4];
 #pragma unroll
@@ -514,6 +535,51 @@ extern "C" int pd_gemm_tn_f32x3(const float *A, const float *B, const float *bia
   else LAUNCH(false, 0);
 #undef LAUNCH
   return pd_check_launch("pd_gemm_tn_f32x3");
+}
+
+namespace {
+// W fp32 [N, K] (row stride ldw) -> three bf16 planes [3][R][C], (R, C) = (N, K) or, TR, (K, N) (the planes of W^T)
+template <bool TR>
+__global__ __launch_bounds__(256) void split3_planes(const float *__restrict__ W, int N, int K, int ldw, bf16_t *__restrict__ out)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)N * K;
+  if (i >= total) return;
+  const int r = (int)(i / (TR ? N : K)), c = (int)(i - (int64_t)r * (TR ? N : K));     // output row / column
+  const float x = TR ? W[(int64_t)c * ldw + r] : W[(int64_t)r * ldw + c];
+  unsigned h, m, l;
+  split2(x, 0.f, h, m, l);
+  out[i] = (bf16_t)(h & 0xffffu); out[total + i] = (bf16_t)(m & 0xffffu); out[2 * total + i] = (bf16_t)(l & 0xffffu);
+}
+}  // namespace
+
+extern "C" int pd_split3_bf16(const float *W, int N, int K, int ldw, int transpose, void *planes, void *stream_)
+{
+  if (N <= 0 || K <= 0 || !W || !planes) return pd_set_error(PD_ERR_INVALID_ARG, "pd_split3_bf16: N=%d K=%d or null pointer", N, K);
+  const int64_t total = (int64_t)N * K;
+  const dim3 g((unsigned)((total + 255) / 256)), b(256);
+  if (transpose) hipLaunchKernelGGL(split3_planes<true>, g, b, 0, (hipStream_t)stream_, W, N, K, ldw, (bf16_t *)planes);
+  else hipLaunchKernelGGL(split3_planes<false>, g, b, 0, (hipStream_t)stream_, W, N, K, ldw, (bf16_t *)planes);
+  return pd_check_launch("pd_split3_bf16");
+}
+
+// mode 0: C = A B^T + bias; 1: relu(...) (+ sign bits when `bits`); 2: (A B^T) masked by `bits`, colsum += column sums
+extern "C" int pd_gemm_tn_f32x3_pre(const float *A, const void *Bplanes, const float *bias, float *C, uint32_t *bits, float *colsum, int M,
+                                    int N, int K, int lda, int ldc, int mode, void *stream_)
+{
+  if (M <= 0 || N <= 0 || K <= 0 || (N % WBN) || (K & 15) || M < 4 * WBM || (lda & 3) || ((uintptr_t)A & 15) || ((uintptr_t)Bplanes & 15))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f32x3_pre: needs N %% 256 == 0, K %% 16 == 0, M >= 1024, aligned operands");
+  if (!A || !Bplanes || !C || (mode == 2 && (!bits || !colsum)) || mode < 0 || mode > 2)
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f32x3_pre: null pointer / bad mode");
+  const int wtn = N / WBN, wtm = (M + WBM - 1) / WBM;
+  const size_t lds = (size_t)2 * 3 * 2 * (WBM + WBN) * 8 * sizeof(bf16_t);
+  typedef void (*kfn)(const float *, const float *, const float *, float *, int, int, int, int, int, int, int, uint32_t *, float *);
+  const kfn k = mode == 0 ? (kfn)gemm_tn_f32x3_wide<false, 0, false, 4, true> : mode == 1 ? (kfn)gemm_tn_f32x3_wide<true, 0, false, 4, true>
+                                                                                            : (kfn)gemm_tn_f32x3_wide<false, 0, true, 4, true>;
+  static bool attr[3] = {false, false, false};
+  if (!attr[mode]) { (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[mode] = true; }
+  hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)wtm * wtn)), dim3(512), lds, (hipStream_t)stream_, A, (const float *)Bplanes, bias, C, M, N, K, lda, K,
+                     ldc, wtn, bits, colsum);
+  return pd_check_launch("pd_gemm_tn_f32x3_pre");
 }
 
 extern "C" int64_t pd_gemm_tn_f32x3_relu_bits_words(int M, int N)

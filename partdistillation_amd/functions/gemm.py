@@ -39,6 +39,36 @@ def gemm_tn_x3(a, b, bias=None, relu=False):
     return c
 
 
+def split3(w, transpose=False):
+    """fp32 weight [N,K] -> its three bf16 planes [3,N,K] (or [3,K,N] of w.T): pd_split3_bf16, once per step per weight."""
+    assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1
+    N, K = w.shape
+    out = torch.empty((3, K, N) if transpose else (3, N, K), dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.load().pd_split3_bf16(w.data_ptr(), N, K, w.stride(0), int(transpose), out.data_ptr(), _stream()))
+    return out
+
+
+def pre_supported(M, N, K):
+    return N % 256 == 0 and K % 16 == 0 and M >= 1024 and (-(-M // 256)) * (N // 256) >= 128
+
+
+def gemm_tn_x3_pre(a, planes, bias=None, mode=0, bits=None, colsum=None, want_bits=False):
+    """a [M,K] fp32 @ (planes [3,N,K] of a weight).T — pd_gemm_tn_f32x3_pre.  mode 0 plain, 1 relu (want_bits: also return the sign
+    bits), 2 masked by `bits` with `colsum` += column sums."""
+    assert a.is_cuda and a.dtype == torch.float32 and a.stride(1) == 1 and planes.dtype == torch.bfloat16 and planes.is_contiguous()
+    M, K = a.shape
+    N = planes.shape[1]
+    assert planes.shape[2] == K
+    L = _lib.load()
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if mode == 1 and want_bits:
+        bits = torch.empty(int(L.pd_gemm_tn_f32x3_relu_bits_words(M, N)), dtype=torch.int32, device=a.device)
+    _lib.check(L.pd_gemm_tn_f32x3_pre(a.data_ptr(), planes.data_ptr(), bias.data_ptr() if bias is not None else None, c.data_ptr(),
+                                      bits.data_ptr() if bits is not None else None, colsum.data_ptr() if colsum is not None else None,
+                                      M, N, K, a.stride(0), N, mode, _stream()))
+    return (c, bits) if (mode == 1 and want_bits) else c
+
+
 def relu_bits_supported(M, N):
     return N % 256 == 0 and M >= 1024
 

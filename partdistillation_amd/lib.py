@@ -29,6 +29,8 @@ SIGNATURES = {
     "pd_gemm_tn_f32x3_relumask": (_c_int, [_c_vp] * 5 + [_c_int] * 6 + [_c_vp]),
     "pd_gemm_tn_f32x3_relu_bits": (_c_int, [_c_vp] * 5 + [_c_int] * 6 + [_c_vp]),
     "pd_gemm_tn_f32x3_relu_bits_words": (ctypes.c_int64, [_c_int] * 2),
+    "pd_split3_bf16": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "pd_gemm_tn_f32x3_pre": (_c_int, [_c_vp] * 6 + [_c_int] * 6 + [_c_vp]),
     "pd_gemm_wgrad_f32": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),
     "pd_gemm_wgrad_acc_f32": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),
     "pd_conv3x3_nhwc_f32x3": (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [_c_vp]),

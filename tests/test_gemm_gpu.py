@@ -162,3 +162,33 @@ def test_gemm_tn_x3_relu_bits_and_relumask_epilogues(M, N, K, K2):
     assert ((got.double() - ref).abs().max().item() / scale) < 2e-6
     assert torch.equal(got != 0, (h > 0) & (ref != 0))
     torch.testing.assert_close(acc.double() - 0.25, ref.sum(0), rtol=1e-4, atol=1e-3 * scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(40000, 1024, 256), (33000, 256, 1024), (65536, 512, 64)])
+def test_gemm_tn_x3_with_presplit_weight_planes(M, N, K):
+    """pd_split3_bf16 (exact: hi + mid + lo == W, also for the transposed planes) and pd_gemm_tn_f32x3_pre: bit-identical to
+    pd_gemm_tn_f32x3's wide kernel on the same operands (the same six products in the same order), fp32-accurate against fp64."""
+    from partdistillation_amd import lib
+    from partdistillation_amd.functions import gemm
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    pl = gemm.split3(w)
+    assert torch.equal(pl[0].float() + pl[1].float() + pl[2].float(), w)                    # exact 3-way split
+    plt = gemm.split3(w, transpose=True)
+    assert plt.shape == (3, K, N) and torch.equal(plt.float().sum(0), w.t())
+    got = gemm.gemm_tn_x3_pre(a, pl, b)
+    lib.load().pd_debug_set(b"x3_narrow", 2)                                                # force the 256 x 256 kernel for the comparison
+    same = gemm.gemm_tn_x3(a, w, b)
+    lib.load().pd_debug_set(b"x3_narrow", 0)
+    assert torch.equal(got, same)
+    ref = torch.addmm(b.double(), a.double(), w.double().t())
+    assert ((got.double() - ref).abs().max().item() / ref.abs().max().item()) < 2e-6
+    h, bits = gemm.gemm_tn_x3_pre(a, pl, b, mode=1, want_bits=True)
+    assert torch.equal(h, same.relu())
+    acc = torch.zeros(N, device="cuda")
+    masked = gemm.gemm_tn_x3_pre(a, pl, None, mode=2, bits=bits, colsum=acc)
+    want = (a.double() @ w.double().t()) * (h > 0)
+    assert ((masked.double() - want).abs().max().item() / want.abs().max().item()) < 2e-6
+    torch.testing.assert_close(acc.double(), want.sum(0), rtol=1e-4, atol=1e-3 * want.abs().max().item())

@@ -27,6 +27,15 @@ for M, N, K in [(43008, 256, 256), (43008, 1024, 256), (43008, 256, 1024), (4300
     print(f"M={M:6d} N={N:4d} K={K:4d}: library {tl:6.1f} us ({gf/tl*1e-3:5.1f} TF) | x3 128x128 {tn:6.1f} us | x3 256x256 {tw2:6.1f} us | x3 128x256 2/CU {tw3:6.1f} us | x3 default {tw:6.1f} us ({gf/tw*1e-3:5.1f} TF fp32-equiv, {6*gf/tw*1e-3:5.0f} TF bf16)"
           f" | max err/scale lib {e[0]:.2e} narrow {e[1]:.2e} wide {e[2]:.2e} relu {er:.2e}")
 
+print("pre-split weight planes (pd_gemm_tn_f32x3_pre) vs in-kernel split, 256 x 256 kernel, us")
+for M, N, K in [(43008, 1024, 256), (43008, 256, 1024)]:
+    a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * K ** -0.5; bb = torch.randn(N, device="cuda")
+    L.pd_debug_set(b"x3_narrow", 2)
+    t0 = t(lambda: gemm.gemm_tn_x3(a, w, bb))
+    L.pd_debug_set(b"x3_narrow", 0)
+    pl = gemm.split3(w)
+    t1 = t(lambda: gemm.gemm_tn_x3_pre(a, pl, bb)); ts = t(lambda: gemm.split3(w))
+    print(M, N, K, f"in-kernel {t0:.1f} | pre-split {t1:.1f} (+ split kernel {ts:.1f})")
 print("wide-kernel ablations (us): 11 no MFMA, 12 no output stores, 13 no operand split")
 for M, N, K in [(43008, 1024, 256), (43008, 256, 1024)]:
     a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * K ** -0.5; b = torch.randn(N, device="cuda")
