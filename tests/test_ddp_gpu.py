@@ -95,3 +95,23 @@ def test_rccl_two_gpu_bench_line():
     rec = json.loads(lines[-1])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["scaling"] == "weak"
     assert rec["value"] > 0 and rec["config"]["final_total_loss"] == rec["config"]["final_total_loss"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_sharing_the_gpu_over_gloo():
+    """bench.py's N > 1 path (rank / world from the environment, per-rank batches, barrier + max-over-ranks timing, one JSON line
+    from rank 0, weak scaling) through the driver's launch line, with both ranks on the one GPU of the development box over gloo
+    (bench.py's PD_TEST_SHARE_GPU hook; RCCL refuses two ranks on one device)."""
+    import json
+    import subprocess
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--size", "256"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=800,
+                         env=dict(os.environ, PD_TEST_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["scaling"] == "weak" and rec["steps"] == 3
+    assert rec["value"] > 0 and rec["config"]["final_total_loss"] == rec["config"]["final_total_loss"]
+    assert "cpu_baseline" not in rec and "parity" not in rec                     # N = 1 only
