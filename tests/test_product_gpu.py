@@ -216,8 +216,10 @@ def test_head_end_to_end_vs_reference_golden(golden, tag):
     total.backward()
     named = {"pixel_decoder." + k: v for k, v in pd.named_parameters()}
     named.update({"predictor." + k: v for k, v in dec.named_parameters()})
+    worst = {k: _scaled_err(named[k].grad, d) for k, d in g["grads"].items()}
+    print(f"head_{tag} gradient dev (of tensor max):", {k.split(".", 1)[-1][-40:]: f"{v:.1e}" for k, v in worst.items()})
     for k, d in g["grads"].items():
-        C.check_digest_scaled(named[k].grad, d, 1e-2, "grad " + k)     # fp32 GPU vs fp32 CPU through up to 6+9 layers
+        C.check_digest_scaled(named[k].grad, d, 3e-3, "grad " + k)     # fp32 GPU vs fp32 CPU through up to 6+9 layers; measured <= 1e-6 (toy dims), 9e-4 (config-1 dims)
     if part is not None:
         rows = (dec.class_embed.weight.grad.abs().sum(1) > 0).nonzero().flatten().cpu()
         assert torch.equal(rows, g["class_embed_grad_rows"])
@@ -277,7 +279,8 @@ def test_full_step_fp32_vs_oracle():
               "sem_seg_head.predictor.transformer_cross_attention_layers.2.multihead_attn.in_proj_weight"]:
         a, b = named[k].grad.float().cpu(), osd[k].grad
         scale = b.abs().max().clamp_min(1e-12)
-        assert ((a - b).abs().max() / scale).item() < 2e-2, k
+        print("full step fp32 grad dev", k, f"{((a - b).abs().max() / scale).item():.1e}")
+        assert ((a - b).abs().max() / scale).item() < 3e-3, k          # measured <= 1.2e-6 (head), 7.7e-4 (R50 convolution weights: MIOpen's algorithm choice)
         checked += 1
     assert checked == 9
 
