@@ -41,6 +41,9 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "MIOPEN_USER_DB_PATH" not in o
     except OSError:
         pass
 os.environ.setdefault("MIOPEN_USER_DB_PATH", _MIOPEN_DB)
+if any(x == "--graph" and sys.argv[i + 1:i + 2] not in ([], ["0"]) or (x.startswith("--graph=") and x != "--graph=0")
+       for i, x in enumerate(sys.argv)):
+    os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"          # must precede the first HIP call; see TrainStep.capture()
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -261,8 +264,9 @@ def main():
     ap.add_argument("--miopen-find", type=int, default=1, help="1: let MIOpen search conv algorithms during warm-up")
     ap.add_argument("--skip-kernel-timing", action="store_true", help="skip the eager per-launch timing steps (profiling runs)")
     ap.add_argument("--graph", type=int, default=0,
-                    help="1: capture the whole step in a hipGraph (single GPU) and replay it.  Off by default: replay of the "
-                         "~3 000-node graph intermittently faults on ROCm 7.2 (DESIGN.md §5), eager issue is robust")
+                    help="1: capture the whole step in a hipGraph (single GPU) and replay it, with ROCm's graph packet capture "
+                         "switched off (packet-captured graphs go stale after eager launches on ROCm 7.2).  Off by default: "
+                         "without packet capture a replay costs MORE host CPU than eager issue (DESIGN.md §5 'hipGraph')")
     ap.add_argument("opts", nargs="*", help="extra KEY VALUE config overrides")
     a = ap.parse_args()
 
@@ -335,7 +339,7 @@ def main():
     # workload right after the timed region (when --graph 0 they are timed inside the timed region itself).
     fwd_ms, bwd_ms, wgrad = [], [], []
     if not a.skip_kernel_timing:
-        step._graph = None
+        step.release_graph()
         from partdistillation_amd.functions import gemm as gemm_fn
         msda_fn.enable_timing(True)
         gemm_fn.enable_timing(True)

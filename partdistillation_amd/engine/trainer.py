@@ -10,6 +10,9 @@ them, so on a single GPU the whole step (forward, criterion, backward, gradient 
 into a hipGraph and replayed: the step has no host synchronisation and no data-dependent shapes (device-side
 Hungarian matching, host-known index tables), learning rate and Adam bias corrections are read from device memory,
 and the batch is copied into static input buffers before each replay."""
+import os as _os
+import warnings
+
 import torch
 import torch.distributed as dist
 
@@ -17,6 +20,21 @@ from ..compat import build_model
 from ..compat.structures import BitMasks, Instances
 from .ddp import BucketedGradReducer, broadcast_parameters
 from .optimizer import build_lr_scheduler, build_optimizer
+
+_GRAPH_SYNC = bool(int(_os.environ.get("PD_GRAPH_SYNC", "0")))          # debugging aid: device fence between two replays of the captured step
+
+
+def _detached(loss_dict):
+    out = type(loss_dict)({k: v.detach() for k, v in loss_dict.items()})
+    for name in ("vectors", "total", "indices"):
+        v = getattr(loss_dict, name, None)
+        if isinstance(v, torch.Tensor):
+            v = v.detach()
+        elif isinstance(v, dict):
+            v = {k: (x.detach() if isinstance(x, torch.Tensor) else x) for k, x in v.items()}
+        if v is not None:
+            setattr(out, name, v)
+    return out
 
 
 class TrainStep:
@@ -62,25 +80,51 @@ class TrainStep:
         return loss_dict
 
     # ------------------------------------------------------------------ hipGraph
-    @staticmethod
-    def _signature(batch):
-        """everything the captured step read on the HOST (and therefore baked into the graph): tensor shapes and the
-        image's object class (the part-distillation decoder selects class-head rows from it on the host)."""
-        return tuple((tuple(x["image"].shape), tuple(x["instances"].gt_masks.tensor.shape), int(x.get("gt_object_class", -1)))
-                     for x in batch)
+    def release_graph(self):
+        self._graph = self._static = self._static_losses = self._graph_sig = None
+        self._replay_done = None
+
+    def _signature(self, batch):
+        """everything the captured step read on the HOST (and therefore baked into the graph): tensor shapes and, for
+        the part-distillation model, the image's object class (its decoder selects class-head rows from it on the host;
+        the proposal model never looks at it)."""
+        cls = (lambda x: int(x.get("gt_object_class", -1))) if getattr(self.model, "host_reads_object_class", False) else (lambda x: -1)
+        return tuple((tuple(x["image"].shape), tuple(x["instances"].gt_masks.tensor.shape), cls(x)) for x in batch)
 
     def _flat_state(self):
         opt = self.optimizer
         return ([g.param for g in opt.flat.groups] + [g.shadow for g in opt.flat.groups if g.shadow is not None]
                 + list(opt.exp_avg) + list(opt.exp_avg_sq))
 
-    def capture(self, example_batch, warmup=3):
+    def _segment(self, batch, segment, rehearsal):
+        """the captured sequence ("full"; "fb" / "fwd" are truncations for tools/debug_graph3.py's bisection)"""
+        if segment == "fwd":
+            with torch.no_grad(), torch.autocast(device_type=self.model.device.type, dtype=torch.bfloat16, enabled=self.amp):
+                return self.model(batch)
+        loss_dict = self._forward_backward(batch)
+        if segment == "full":
+            self.optimizer.launch_step() if rehearsal else self.optimizer.step()
+        return loss_dict
+
+    def capture(self, example_batch, warmup=3, _segment="full"):
         """capture the whole step for batches shaped like `example_batch` (single process only).  The warm-up runs real
         steps (allocator growth, MIOpen/BLAS lazy initialisation need the full kernel sequence) on a SNAPSHOT of the
         weights, bf16 shadows and Adam moments that is restored afterwards, so capturing does not move the training
         trajectory (weights, moments and step count are exactly what they were before the call)."""
         if self.world > 1:
             raise RuntimeError("hipGraph capture of the step is for the single-GPU path (collectives stay eager)")
+        if _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+            # ROCm 7.2 instantiates graphs with pre-built AQL packets ("packet capture").  Such a graph goes stale once a
+            # few thousand EAGER launches have been issued since it was instantiated (the input copies between replays
+            # count): its kernels then read wrong arguments — first silently (NaN gradient norm in the replayed
+            # optimizer, tools/debug_graph5.py), later as a memory access fault (tools/debug_graph3.py mixsync: replay,
+            # 3 eager steps, replay -> 5/5 faults; bench.py --graph 1 --steps 2000 faults, --steps 300 does not).  None of
+            # HIP_FORCE_DEV_KERNARG / DEBUG_HIP_KERNARG_COPY_OPT / DEBUG_HIP_FORCE_GRAPH_QUEUES / ... changes that;
+            # DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 does (0 faults, replay == eager), at 60 ms of host CPU per replay of
+            # this ~3 000-node graph, i.e. slower than eager issue (19 ms).  Silent corruption is not an option, so:
+            raise RuntimeError("TrainStep.capture(): set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE the first "
+                               "HIP call of the process (ROCm 7.2 packet-captured graphs go stale after eager launches; "
+                               "see DESIGN.md §5 'hipGraph')")
         static = []
         for x in example_batch:
             inst = Instances(x["instances"].image_size)
@@ -88,15 +132,16 @@ class TrainStep:
             inst.gt_classes = x["instances"].gt_classes.clone()
             static.append({**{k: v for k, v in x.items() if k not in ("image", "instances")},
                            "image": x["image"].clone(), "instances": inst})
-        # warm-up on the CURRENT stream (allocator growth, MIOpen/BLAS lazy initialisation).  NB: the usual
-        # "warm up on a side stream" recipe makes the second replay of this graph fault on ROCm 7.2 (observed:
-        # tools/debug_graph2.py cap0 vs DBG_NOSIDE), so no extra stream is created here.
+        # warm-up on the CURRENT stream (allocator growth, MIOpen/BLAS lazy initialisation); no extra stream is needed.
         live = self._flat_state()
         snapshot = [t.clone() for t in live]
         steps0 = self.optimizer.steps
-        for _ in range(warmup):
-            self._forward_backward(static)
-            self.optimizer.step()
+        from ..functions.fused import PinnedRing
+        for w in range(warmup):
+            if w == warmup - 1:
+                before = PinnedRing.counters()                   # the last warm-up step is the rehearsal of the captured sequence
+            self._segment(static, _segment, rehearsal=w == warmup - 1)
+        PinnedRing.reserve_all(before, PinnedRing.counters())   # dedicated pinned buffers for the uploads the capture will bake in
         with torch.no_grad():
             for t, s in zip(live, snapshot):
                 t.copy_(s)
@@ -106,18 +151,21 @@ class TrainStep:
         graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad()
         with torch.cuda.graph(graph):
-            loss_dict = self._forward_backward(static)
-            self.optimizer.launch_step()
+            loss_dict = self._segment(static, _segment, rehearsal=True)
+        # keep only DETACHED views of the static losses: holding the captured autograd graph alive would also keep its
+        # AccumulateGrad nodes, which are bound to the capture stream — every later EAGER step (a batch with another
+        # signature) would then run its gradient accumulation on that stream, and the next replay faults on ROCm 7.2
+        # (tools/debug_graph3.py mixsync).
+        loss_dict = _detached(loss_dict)
         self._graph, self._static, self._static_losses = graph, static, loss_dict
         self._graph_sig = self._signature(example_batch)
         return self
 
     def _replay(self, batch):
-        # ONE replay in flight, fenced by a DEVICE synchronize: on ROCm 7.2 back-to-back replays of this graph fault,
-        # replays separated by torch.cuda.synchronize() never do, and an event recorded on the launch stream after
-        # hipGraphLaunch is not enough (the graph's internal branch streams can still be running) — observed with
-        # tools/debug_graph2.py and bench.py PD_DEBUG_GRAPH.  The wait is free while the step is GPU-bound.
-        if self._replay_done is not None:
+        # Replays are stream-ordered like any other launch; no host-side fence.  (Round 1 put a device synchronize between
+        # replays against an "intermittent" fault: that was the packet-capture bug capture() now refuses to run with.
+        # PD_GRAPH_SYNC=1 restores the fence for debugging.)
+        if self._replay_done is not None and _GRAPH_SYNC:
             torch.cuda.synchronize()
         for s, x in zip(self._static, batch):
             if s["image"] is not x["image"]:

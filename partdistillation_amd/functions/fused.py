@@ -59,18 +59,44 @@ class PinnedRing:
 
     While a hipGraph is being captured the copy becomes a memcpy NODE that re-reads its host buffer at every replay,
     so a ring slot (recycled by later eager uploads) must never back it: acquire() then hands out a DEDICATED pinned
-    buffer that is kept alive for the life of the ring and never written again."""
+    buffer that is never written again.  Pinned memory cannot be allocated while a stream is capturing, so those
+    buffers are reserved beforehand: every ring counts its acquisitions, TrainStep.capture() measures the count of one
+    (eager) rehearsal step and calls reserve_all() with it."""
+    _all = []                                               # weak references to every ring (for reserve_all / counters)
 
     def __init__(self, shape, dtype, pin, slots=8):
+        import weakref
         self.bufs = [torch.zeros(shape, dtype=dtype, pin_memory=pin) for _ in range(slots)]
         self.events = [None] * slots
         self.pin, self.i = pin, -1
-        self.captured = []                                   # buffers baked into captured graphs (never recycled)
+        self.reserved, self.captured = [], []                # dedicated buffers: waiting for / baked into captured graphs
+        self.count = 0                                       # acquisitions so far
         self._in_capture = False
+        PinnedRing._all.append(weakref.ref(self))
+
+    @classmethod
+    def counters(cls):
+        cls._all = [r for r in cls._all if r() is not None]
+        return {id(r()): r().count for r in cls._all}
+
+    @classmethod
+    def reserve_all(cls, before, after, margin=2):
+        """reserve, in every ring, as many dedicated pinned buffers as it handed out between the two counters() snapshots"""
+        for r in cls._all:
+            ring = r()
+            if ring is None or not ring.pin:
+                continue
+            n = after.get(id(ring), 0) - before.get(id(ring), 0)
+            for _ in range(max(0, n + margin - len(ring.reserved)) if n > 0 else 0):
+                ring.reserved.append(torch.zeros_like(ring.bufs[0]).pin_memory())
 
     def acquire(self):
+        self.count += 1
         if self.pin and torch.cuda.is_current_stream_capturing():
-            buf = torch.zeros_like(self.bufs[0]).pin_memory()
+            if not self.reserved:
+                raise RuntimeError("PinnedRing: a host->device upload inside a hipGraph capture needs a reserved pinned buffer "
+                                   "(TrainStep.capture() reserves them from a rehearsal step; this upload did not occur in it)")
+            buf = self.reserved.pop()
             self.captured.append(buf)
             self._in_capture = True
             return buf

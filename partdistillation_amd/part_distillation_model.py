@@ -14,6 +14,8 @@ from .proposal_model import _MaskFormerTrainBase, build_criterion
 
 @META_ARCH_REGISTRY.register()
 class PartDistillationModel(_MaskFormerTrainBase):
+    host_reads_object_class = True          # the decoder picks class-head rows from gt_object_class on the host (hipGraph signature)
+
     @configurable
     def __init__(self, *, backbone, sem_seg_head: nn.Module, criterion: nn.Module, num_queries: int, num_classes: int,
                  size_divisibility: int, pixel_mean: Tuple[float], pixel_std: Tuple[float], test_topk_per_image: int,
