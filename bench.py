@@ -169,7 +169,7 @@ def cpu_baseline(cfg_opts, size, seconds_budget=90.0, threads=None, parity_file=
 # kernel families for the live per-category table (torch.profiler device records).  First match wins.
 _CATEGORIES = [
     ("own_msda", r"^msda_"),
-    ("own_fp32_wgrad_mfma", r"^gemm_wgrad_f32"),
+    ("own_fp32_wgrad_mfma", r"^(gemm_wgrad_f32|wgrad_tr_reduce)"),
     ("own_fp32x3_gemm_conv", r"^(gemm_tn_f32|gemm_wgrad_f32x3|conv3x3_)"),
     ("own_attention_mfma", r"^(attn_|wattn_)"),
     ("own_skinny_bf16_gemm", r"^sgemm_"),
@@ -214,9 +214,12 @@ def category_rooflines(cats, batch, size, freeze):
     M = batch * sum((size // st) ** 2 for st in (32, 16, 8))
     hw4 = batch * (size // 4) ** 2
     enc_w = 0 if "encoder" in freeze else 1                 # frozen encoder: no weight gradients (and the backbone's none either)
+    from partdistillation_amd.functions import gemm as gemm_fn
+    wg = (6.0, 2500.0, "bf16 matrix 2.5 PF, 6 bf16 products per fp32 product (gemm_wgrad_f32x3_tr)") if gemm_fn.WGRAD_X3 else \
+         (1.0, MFMA_FP32_PEAK_TFLOPS, "fp32 matrix 157.3 TF")
     work = {
         # fp32 weight gradients of the 6 encoder layers: value/out 256x256, offsets+weights 288x256, FFN 2 x 1024x256
-        "own_fp32_wgrad_mfma": (6 * 2.0 * M * (2 * 256 * 256 + 288 * 256 + 2 * 1024 * 256) * enc_w, MFMA_FP32_PEAK_TFLOPS, "fp32 matrix 157.3 TF"),
+        "own_fp32_wgrad_mfma": (wg[0] * 6 * 2.0 * M * (2 * 256 * 256 + 288 * 256 + 2 * 1024 * 256) * enc_w, wg[1], wg[2]),
         # encoder FFN forward + input gradient, 3x3 FPN conv forward + input gradient: 6 bf16 MFMA products per fp32 product
         "own_fp32x3_gemm_conv": (6.0 * (6 * 2 * 2.0 * M * 2 * 256 * 1024 / 2 + 2 * 2.0 * hw4 * 9 * 256 * 256), 2500.0, "bf16 matrix 2.5 PF, 6 bf16 products per fp32 product"),
         # 256-wide projections of the encoder, forward + input gradient
@@ -236,10 +239,12 @@ def roofline_of(dom, kernels):
     if dom is None:
         return None
     if "achieved_TFLOPs" in dom:
-        return {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_TFLOPs"], "peak": MFMA_FP32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": dom["achieved_TFLOPs"] / MFMA_FP32_PEAK_TFLOPS, "traffic": None,
+        peak = dom.get("peak_TFLOPs", MFMA_FP32_PEAK_TFLOPS)
+        return {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_TFLOPs"], "peak": peak,
+                "unit": "TFLOP/s", "frac": dom["achieved_TFLOPs"] / peak, "traffic": None,
                 "alg_flops_per_launch": dom["alg_flops"], "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["launches"],
-                "peak_source": "MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s", "other_kernels": kernels}
+                "peak_source": dom.get("peak_source", "MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s"),
+                "other_kernels": kernels}
     return {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"),
             "traffic_source": "profiles/r02_msda_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)",
@@ -393,10 +398,18 @@ def main():
         if bwd_ms:
             kernels.append({"kernel": "msda_bwd_owner4_d32", "launches": len(bwd_ms), "avg_ms": avg(bwd_ms),
                             "alg_bytes": bb, "achieved_GBs": bb / avg(bwd_ms) / 1e6})
-        if wgrad:                               # fp32 MFMA weight-gradient GEMMs of the encoder (36 launches / step, 6 shapes)
+        if wgrad:                               # fp32 weight-gradient GEMMs of the encoder (30 launches / step, 5 shapes)
             t_ms, fl = sum(t for t, _ in wgrad), sum(f for _, f in wgrad)
-            kernels.append({"kernel": "gemm_wgrad_f32", "launches": len(wgrad), "avg_ms": t_ms / len(wgrad),
-                            "alg_flops": fl / len(wgrad), "achieved_TFLOPs": fl / t_ms / 1e9})
+            from partdistillation_amd.functions import gemm as gemm_fn
+            if gemm_fn.WGRAD_X3:                # each fp32 product = 6 bf16 MFMA products: the work the matrix pipe actually does
+                kernels.append({"kernel": "gemm_wgrad_f32x3_tr", "launches": len(wgrad), "avg_ms": t_ms / len(wgrad),
+                                "alg_flops": 6 * fl / len(wgrad), "achieved_TFLOPs": 6 * fl / t_ms / 1e9, "peak_TFLOPs": 2500.0,
+                                "fp32_equivalent_TFLOPs": fl / t_ms / 1e9,
+                                "peak_source": "MI355X_MICROARCH.md: dense bf16 matrix (v_mfma_f32_32x32x16_bf16) 2.5 PFLOP/s; "
+                                               "alg_flops = 6 bf16 products per fp32 product x 2 M N K (avg_ms includes the partial-tile reduce launch)"})
+            else:
+                kernels.append({"kernel": "gemm_wgrad_f32", "launches": len(wgrad), "avg_ms": t_ms / len(wgrad),
+                                "alg_flops": fl / len(wgrad), "achieved_TFLOPs": fl / t_ms / 1e9})
         pmc = {}
         try:                                   # HBM bytes per launch from the committed PMC passes (tools/pmc_msda.sh)
             pj = json.load(open(os.path.join(ROOT, "profiles", "r02_msda_pmc.json")))

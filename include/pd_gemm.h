@@ -59,9 +59,17 @@ int pd_gemm_tn_f32x3_relumask(const float *A, const float *B, const uint32_t *bi
                               int ldb, int ldc, void *stream);
 
 /* pd_gemm_wgrad_acc_f32 with the 3-way bf16 split (see pd_gemm_tn_f32x3): dW += dY^T X, dB += column sums of dY (exact fp32
- * adds), accumulated into caller-initialised buffers.  Any N, K, M >= 0; no alignment requirement (scalar loads). */
+ * adds), accumulated into caller-initialised buffers.  Any N, K, M >= 0.  Operands whose rows allow 16-byte loads (N, K, ldy, ldx
+ * multiples of 4, 16-byte aligned bases) take the ds_read_b64_tr_b16 transpose-read kernel, anything else the scalar-staged one. */
 int pd_gemm_wgrad_acc_f32x3(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx, int ldw,
                             void *stream);
+/* The same with a caller-provided fp32 workspace (>= pd_gemm_wgrad_f32x3_ws_floats(N, K) elements, 16-byte aligned, free to be
+ * reused by the next call on the same stream): the workgroups that share an output tile leave their partial tiles there with
+ * plain stores and a second kernel sums them into dW, instead of 8.4 M fp32 atomics per call (30-110 us).  A NULL or too small
+ * workspace falls back to the atomics. */
+int64_t pd_gemm_wgrad_f32x3_ws_floats(int N, int K);
+int pd_gemm_wgrad_acc_f32x3_ws(const float *dY, const float *X, float *dW, float *dB, float *workspace, int64_t workspace_floats, int M, int N,
+                               int K, int ldy, int ldx, int ldw, void *stream);
 
 /* 3 x 3, stride 1, pad 1 convolution as an implicit GEMM on the same 3-way bf16 split (fp32-level results): the fp32 FPN
  * output convolution of the pixel decoder (reference pixel_decoder/msdeformattn.py:268-277, run at 1/4 resolution: 77 GFLOP per

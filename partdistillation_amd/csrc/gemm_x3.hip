@@ -478,6 +478,168 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3(const float *__restri
       }
   }
 }
+
+// ---------------------------------------------------------------------------------------------- weight gradient, transpose-read form
+// The same product with the tiles staged the way they lie in memory — [contraction row][column], 16-byte global loads, one
+// 8-byte LDS write per plane — and TRANSPOSED ON THE WAY OUT of LDS by ds_read_b64_tr_b16 (gfx950): within a group of 16
+// lanes, lane i receives element i % 4 of the 8-byte segments addressed by lanes i / 4 + 4 e (e = 0..3 -> the 4 result
+// elements; mapping read off the hardware with tools/probes/tr_read_probe.hip).  Lane s of a group therefore points at
+// row s / 4, columns 4 (s % 4) .. +3 of a [4 rows][16 columns] block and lane i gets column i of the 4 rows: two such reads are the
+// 8 consecutive contraction elements of one column that v_mfma_f32_32x32x16_bf16 wants from lane (column, k half).
+// Row pitch 160 bf16 = 320 bytes: the 4 rows of a read start 16 banks apart, its 32 lanes cover 64 distinct banks.
+constexpr int TWS = 16, TP = 160;
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ hwbf16x8 frag_tr(const bf16_t *p)      // p: this lane's segment of rows 0..3; rows 4..7 are 4 * TP further
+{
+  typedef __attribute__((address_space(3))) v4s16 *lp;
+  union { v4s16 h[2]; hwbf16x8 v; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p));
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p + 4 * TP));
+  return u.v;
+}
+
+template <int ABL>
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3_tr(const float *__restrict__ dY, const float *__restrict__ X,
+                                                               float *__restrict__ dW, float *__restrict__ dB, float *__restrict__ ws,
+                                                               int M, int N, int K, int ldy, int ldx, int ldw, int tiles_k, int tiles,
+                                                               int m_chunk)
+{
+  __shared__ __attribute__((aligned(16))) bf16_t S[2][2][3][TWS][TP];      // stage, operand (dY, X), plane, row, column
+  const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+  const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BM;
+  const int mb = split * m_chunk, me = min(M, mb + m_chunk);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+  const int sr = t >> 5, sc = (t & 31) * 4;                      // staging: rows sr, sr + 8; columns sc .. sc+3
+  const bool ycol_ok = n0 + sc < N, xcol_ok = k0 + sc < K;
+  float4 ry[2][2], rx[2][2];                                     // two register stages
+  auto gload = [&](int s, int m) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = m + sr + 8 * j;
+      ry[s][j] = (r < me && ycol_ok) ? *reinterpret_cast<const float4 *>(dY + (int64_t)r * ldy + n0 + sc) : make_float4(0, 0, 0, 0);
+      rx[s][j] = (r < me && xcol_ok) ? *reinterpret_cast<const float4 *>(X + (int64_t)r * ldx + k0 + sc) : make_float4(0, 0, 0, 0);
+    }
+  };
+  const bool do_bias = dB != nullptr && k0 == 0;
+  float4 bsum = make_float4(0, 0, 0, 0);
+  auto lstore = [&](int s, int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const Split4 y = split4(ry[s][j]), x = split4(rx[s][j]);
+      const int r = sr + 8 * j;
+      *reinterpret_cast<uint2 *>(&S[buf][0][0][r][sc]) = y.hi; *reinterpret_cast<uint2 *>(&S[buf][0][1][r][sc]) = y.mid;
+      *reinterpret_cast<uint2 *>(&S[buf][0][2][r][sc]) = y.lo;
+      *reinterpret_cast<uint2 *>(&S[buf][1][0][r][sc]) = x.hi; *reinterpret_cast<uint2 *>(&S[buf][1][1][r][sc]) = x.mid;
+      *reinterpret_cast<uint2 *>(&S[buf][1][2][r][sc]) = x.lo;
+      if (do_bias) { bsum.x += ry[s][j].x; bsum.y += ry[s][j].y; bsum.z += ry[s][j].z; bsum.w += ry[s][j].w; }
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int steps = (me - mb + TWS - 1) / TWS;
+  if (steps > 0) {
+    gload(0, mb);
+    if (steps > 1) gload(1, mb + TWS);
+    lstore(0, 0);
+  }
+  __syncthreads();
+  const int grp = lane >> 4, sl = lane & 15;
+  const int frow = 8 * (grp >> 1) + (sl >> 2), fcol = 16 * (grp & 1) + 4 * (sl & 3);   // this lane's segment inside a 32-column block
+  auto step = [&](int st, int par) {
+    if (st + 2 < steps) gload(par, mb + (st + 2) * TWS);
+    hwbf16x8 a[3][2], b[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[p][i] = frag_tr(&S[par][0][p][frow][wn + i * 32 + fcol]);
+        b[p][i] = frag_tr(&S[par][1][p][frow][wk + i * 32 + fcol]);
+      }
+#define TERM(PA, PB)                                                         \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) mma16k(acc[i][j], a[PA][i], b[PB][j]);
+    if (ABL != 2) { TERM(2, 0) TERM(0, 2) TERM(1, 1) TERM(1, 0) TERM(0, 1) TERM(0, 0) }
+    else { _Pragma("unroll") for (int p = 0; p < 3; ++p) _Pragma("unroll") for (int i = 0; i < 2; ++i) { acc[i][0][p] += (float)a[p][i][0]; acc[i][1][p] += (float)b[p][i][0]; } }
+#undef TERM
+    if (st + 1 < steps) lstore(par ^ 1, par ^ 1);
+    __syncthreads();
+  };
+  for (int st = 0; st < steps; st += 2) {
+    step(st, 0);
+    if (st + 1 < steps) step(st + 1, 1);
+  }
+  if (do_bias) {
+    // column sums: the 8 staging rows of a column are summed through LDS first — ONE atomic per column and workgroup (8 x splits
+    // same-address atomics per column serialise: 1 024 of them cost ~100 us at 256 x 256)
+    float *red = reinterpret_cast<float *>(&S[0][0][0][0][0]);   // the last step ended with a barrier: the stages are free
+    *reinterpret_cast<float4 *>(red + sr * BN + sc) = bsum;
+    __syncthreads();
+    if (t < BN && n0 + t < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v += red[r * BN + t];
+      unsafeAtomicAdd(dB + n0 + t, v);
+    }
+  }
+  if (ws) {
+    // partial tile in REGISTER order (element (ij, e) of thread t at ((ij * 16 + e) * 256 + t): 1 KB per store instruction);
+    // wgrad_tr_reduce sums the splits and owns the read-modify-write of dW — 8.4 M fp32 atomics per launch cost 30-110 us
+    float *w = ws + ((int64_t)split * tiles + tile) * (BN * BM) + t;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) w[((i * 2 + j) * 16 + e) * 256] = acc[i][j][e];
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = k0 + wk + j * 32 + (lane & 31);
+    if (c >= K) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = n0 + wn + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < N) unsafeAtomicAdd(dW + (int64_t)row * ldw + c, acc[i][j][e]);
+      }
+  }
+}
+
+// dW tile += sum over splits of the partial tiles gemm_wgrad_f32x3_tr left in the workspace (same register-order indexing)
+__global__ __launch_bounds__(256) void wgrad_tr_reduce(const float *__restrict__ ws, float *__restrict__ dW, int N, int K, int ldw, int tiles_k,
+                                                       int tiles, int splits)
+{
+  const int tile = blockIdx.x >> 6, q = blockIdx.x & 63;         // 64 blocks per tile, one (ij, e) each
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ij = q >> 4, e = q & 15, i = ij >> 1, j = ij & 1;
+  const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BM;
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+  // blockIdx.y takes every gridDim.y-th split: 8 independent loads in flight per thread, a few atomics per element at the end
+  const float *p = ws + (int64_t)tile * (BN * BM) + q * 256 + t;
+  const int64_t stride = (int64_t)tiles * (BN * BM);
+  float s0 = 0.f, s1 = 0.f;
+  int sp = blockIdx.y;
+  const int G = gridDim.y;
+  for (; sp + 7 * G < splits; sp += 8 * G) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(sp + u * G) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+  }
+  for (; sp < splits; sp += G) s0 += p[(int64_t)sp * stride];
+  const int c = k0 + wk + j * 32 + (lane & 31);
+  const int row = n0 + wn + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+  if (c < K && row < N) unsafeAtomicAdd(dW + (int64_t)row * ldw + c, s0 + s1);
+}
 }  // namespace
 
 static uint32_t *const g_relu_bits = nullptr;   // plain pd_gemm_tn_f32x3 launches do not record the sign bits
@@ -622,22 +784,53 @@ extern "C" int pd_gemm_tn_f32x3_relumask(const float *A, const float *B, const u
   return pd_check_launch("pd_gemm_tn_f32x3_relumask");
 }
 
-extern "C" int pd_gemm_wgrad_acc_f32x3(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx,
-                                       int ldw, void *stream_)
+static int wgrad_x3_launch(const float *dY, const float *X, float *dW, float *dB, float *ws, int64_t ws_floats, int M, int N, int K, int ldy,
+                           int ldx, int ldw, hipStream_t st, const char *who)
 {
-  if (M < 0 || N < 0 || K < 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_wgrad_acc_f32x3: negative size");
+  if (M < 0 || N < 0 || K < 0) return pd_set_error(PD_ERR_INVALID_ARG, "%s: negative size", who);
   if (N == 0 || K == 0 || M == 0) return PD_OK;
-  if (!dW || !dY || !X) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_wgrad_acc_f32x3: null pointer");
+  if (!dW || !dY || !X) return pd_set_error(PD_ERR_INVALID_ARG, "%s: null pointer", who);
   const int tk = (K + BM - 1) / BM, tn = (N + BN - 1) / BN, tiles = tk * tn;
-  // the contraction is split over workgroups (each ends in a tile of atomics): ~4 workgroups per CU, fewer for few tiles
-  const int target = tiles <= 4 ? 256 : 1024;
-  int splits = (target + tiles - 1) / tiles;
+  // the contraction is split over workgroups (each ends in a tile of atomics, or of plain stores into the workspace).  Two
+  // workgroups are resident per CU, so the launch is sized to ONE round of 512: 1 044 workgroups (the old "~4 per CU" rule at
+  // 256 x 2304) ran as 3 rounds, the last one almost empty — 387 us instead of 260.  g_pd_dbg_x3 22: the old rule.
+  int splits;
+  if (g_pd_dbg_x3 == 22) { const int target = tiles <= 4 ? 256 : 1024; splits = (target + tiles - 1) / tiles; }
+  else splits = tiles >= 512 ? 1 : (512 + tiles / 2) / tiles;
   int m_chunk = ((M + splits - 1) / splits + WS - 1) / WS * WS;
   if (m_chunk < 4 * WS) m_chunk = 4 * WS;
   splits = (M + m_chunk - 1) / m_chunk;
-  hipLaunchKernelGGL(gemm_wgrad_f32x3, dim3((unsigned)(tiles * splits)), dim3(256), 0, (hipStream_t)stream_, dY, X, dW, dB, M, N, K, ldy,
-                     ldx, ldw, tk, tiles, m_chunk);
-  return pd_check_launch("pd_gemm_wgrad_acc_f32x3");
+  // transpose-read form when the operands allow 16-byte row loads (always, in this repo); x3_ablate 21 forces the scalar-staged one
+  const bool vec = !(N & 3) && !(K & 3) && !(ldy & 3) && !(ldx & 3) && !((uintptr_t)dY & 15) && !((uintptr_t)X & 15) && g_pd_dbg_x3 != 21;
+  if (!vec) {
+    hipLaunchKernelGGL(gemm_wgrad_f32x3, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, dY, X, dW, dB, M, N, K, ldy, ldx, ldw, tk, tiles,
+                       m_chunk);
+    return pd_check_launch(who);
+  }
+  if (ws && (ws_floats < (int64_t)tiles * splits * BN * BM || splits < 2 || g_pd_dbg_x3 == 25)) ws = nullptr;   // not worth / does not fit: atomics
+  auto kfn = g_pd_dbg_x3 == 24 ? gemm_wgrad_f32x3_tr<2> : gemm_wgrad_f32x3_tr<0>;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, dY, X, dW, dB, ws, M, N, K, ldy, ldx, ldw, tk, tiles, m_chunk);
+  const int groups = tiles * 64 >= 2048 ? 1 : splits >= 64 ? 8 : splits >= 16 ? 4 : 1;
+  if (ws) hipLaunchKernelGGL(wgrad_tr_reduce, dim3((unsigned)(tiles * 64), groups), dim3(256), 0, st, (const float *)ws, dW, N, K, ldw, tk, tiles, splits);
+  return pd_check_launch(who);
+}
+
+extern "C" int pd_gemm_wgrad_acc_f32x3(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx,
+                                       int ldw, void *stream_)
+{
+  return wgrad_x3_launch(dY, X, dW, dB, nullptr, 0, M, N, K, ldy, ldx, ldw, (hipStream_t)stream_, "pd_gemm_wgrad_acc_f32x3");
+}
+
+extern "C" int64_t pd_gemm_wgrad_f32x3_ws_floats(int N, int K)
+{
+  const int64_t tiles = (int64_t)((K + BM - 1) / BM) * ((N + BN - 1) / BN);
+  return tiles >= 512 ? 0 : (512 + tiles / 2) / tiles * tiles * BN * BM;     // <= 8.5 M floats (34 MB) whatever the shape
+}
+
+extern "C" int pd_gemm_wgrad_acc_f32x3_ws(const float *dY, const float *X, float *dW, float *dB, float *workspace, int64_t workspace_floats,
+                                          int M, int N, int K, int ldy, int ldx, int ldw, void *stream_)
+{
+  return wgrad_x3_launch(dY, X, dW, dB, workspace, workspace_floats, M, N, K, ldy, ldx, ldw, (hipStream_t)stream_, "pd_gemm_wgrad_acc_f32x3_ws");
 }
 
 extern "C" int pd_conv3x3_nhwc_f32x3(const float *X, const float *Wk, const float *bias, float *Y, int B, int H, int W, int Ci, int Co,

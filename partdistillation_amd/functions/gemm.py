@@ -114,9 +114,25 @@ def timing():
     return [(a.elapsed_time(b), f) for a, b, f in _TIMING["wgrad"]]
 
 
-WGRAD_X3 = False     # True: weight gradients through the 3-way bf16 split kernel (pd_gemm_wgrad_acc_f32x3).  Measured at parity
-                     # with the exact-fp32 MFMA kernel (224 vs 223 us at 43008 x 1024 x 256: the transposed staging, not the
-                     # matrix pipe, sets its pace), so the exact kernel stays the default.
+WGRAD_X3 = True      # weight gradients through the 3-way bf16 split kernel (pd_gemm_wgrad_acc_f32x3_ws): fp32-accurate (error vs fp64 at
+                     # the exact kernel's level, tests/test_gemm_gpu.py) and, since its tiles are staged as they lie in memory and
+                     # transposed by ds_read_b64_tr_b16 on the way out of LDS, 1.4-1.6x the exact-fp32 MFMA kernel at M = 43 008
+                     # (tools/bench_wgrad_x3.py: 1024 x 256: 151 vs 230 us, 256 x 256: 51 vs 78, 256 x 2304: 330 vs 517).
+                     # False: the exact-fp32 MFMA kernel (pd_gemm_wgrad_acc_f32).
+
+
+_WGRAD_WS = {}
+
+
+def _wgrad_workspace(device, need):
+    """one persistent fp32 scratch per device for the partial tiles of pd_gemm_wgrad_acc_f32x3_ws (<= 34 MB; consecutive
+    launches on a stream reuse it in order)"""
+    if need <= 0:
+        return None
+    ws = _WGRAD_WS.get(str(device))
+    if ws is None or ws.numel() < need:
+        ws = _WGRAD_WS[str(device)] = torch.empty(max(need, 8912896), dtype=torch.float32, device=device)
+    return ws
 
 
 def gemm_wgrad_acc(dy, x, dw, db=None, x3=None):
@@ -130,9 +146,14 @@ def gemm_wgrad_acc(dy, x, dw, db=None, x3=None):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
     L = _lib.load()
-    fn = L.pd_gemm_wgrad_acc_f32x3 if (WGRAD_X3 if x3 is None else x3) else L.pd_gemm_wgrad_acc_f32
-    _lib.check(fn(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
-                  M, N, K, dy.stride(0), x.stride(0), K, _stream()))
+    if WGRAD_X3 if x3 is None else x3:
+        ws = _wgrad_workspace(dy.device, int(L.pd_gemm_wgrad_f32x3_ws_floats(N, K)))
+        _lib.check(L.pd_gemm_wgrad_acc_f32x3_ws(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                                ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                                M, N, K, dy.stride(0), x.stride(0), K, _stream()))
+    else:
+        _lib.check(L.pd_gemm_wgrad_acc_f32(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                           M, N, K, dy.stride(0), x.stride(0), K, _stream()))
     if _TIMING["on"]:
         b.record()
         _TIMING["wgrad"].append((a, b, 2.0 * M * N * K))
@@ -144,6 +165,12 @@ def gemm_wgrad(dy, x, with_bias=False):
         raise RuntimeError("pd_gemm_wgrad_f32 runs on the GPU only (no CPU fallback in partdistillation_amd)")
     M, N = dy.shape
     K = x.shape[1]
+    if WGRAD_X3 and N % 4 == 0 and K % 4 == 0:
+        buf = torch.zeros(N * K + (N if with_bias else 0), dtype=torch.float32, device=dy.device)      # one fill for both
+        dw, db = buf[:N * K].view(N, K), (buf[N * K:] if with_bias else None)
+        with torch.cuda.device(dy.device):
+            gemm_wgrad_acc(dy, x, dw, db, x3=True)
+        return (dw, db) if with_bias else dw
     dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
     db = torch.empty((N,), dtype=torch.float32, device=dy.device) if with_bias else None
     with torch.cuda.device(dy.device):

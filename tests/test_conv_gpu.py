@@ -1,0 +1,72 @@
+"""GPU tests of the bf16 NHWC backbone convolutions (csrc/conv_bf16.hip) against torch's fp32 convolution of the same
+bf16-valued operands: every distinct geometry of R50 (1x1 / 3x3, stride 1 / 2, 64..2048 channels), ragged images whose pixel
+count is not a multiple of the 128-row tile, the fused frozen-BN + residual + ReLU epilogue and the dgrad addend."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+GEOMS = [  # ci, co, k, stride, H, W, batch
+    (64, 64, 1, 1, 24, 40, 2), (64, 256, 1, 1, 24, 40, 2), (256, 64, 1, 1, 17, 23, 3), (64, 64, 3, 1, 24, 40, 2),
+    (128, 128, 3, 2, 24, 40, 2), (256, 512, 1, 2, 24, 40, 2), (128, 128, 3, 2, 23, 41, 1), (256, 512, 1, 2, 23, 41, 1),
+    (512, 128, 1, 1, 12, 20, 2), (256, 256, 3, 1, 12, 20, 2), (1024, 2048, 1, 2, 12, 10, 1), (512, 512, 3, 1, 6, 5, 2),
+    (2048, 512, 1, 1, 6, 5, 2), (192, 320, 3, 1, 9, 9, 1),
+]
+
+
+def _mk(shape, seed, scale=1.0, cl=True):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    t = (torch.randn(shape, generator=g) * scale).to(torch.bfloat16).to(DEV)
+    return t.contiguous(memory_format=torch.channels_last) if cl and t.dim() == 4 else t
+
+
+@pytest.mark.parametrize("ci,co,k,s,H,W,B", GEOMS)
+def test_conv_fwd_epilogue_vs_torch_fp32(ci, co, k, s, H, W, B):
+    from partdistillation_amd.functions import conv_bf16 as C
+    x, w = _mk((B, ci, H, W), 1), _mk((co, ci, k, k), 2, (ci * k * k) ** -0.5)
+    assert C.supported(x, w, s, k // 2)
+    ref = F.conv2d(x.float(), w.float(), None, s, k // 2)
+    y = C.conv_fwd(x, w, stride=s, pad=k // 2)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    tol = dict(rtol=2 ** -7, atol=2e-2)                              # one bf16 rounding of an O(1) fp32-accumulated sum
+    torch.testing.assert_close(y.float(), ref, **tol)
+    scale = torch.rand(co, device=DEV) + 0.5
+    bias = torch.randn(co, device=DEV)
+    res = _mk(ref.shape, 3)
+    y2 = C.conv_fwd(x, w, scale, bias, res, True, s, k // 2)
+    ref2 = F.relu(ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1) + res.float())
+    torch.testing.assert_close(y2.float(), ref2, **tol)
+    y3 = C.conv_fwd(x, w, scale, bias, None, False, s, k // 2)
+    torch.testing.assert_close(y3.float(), ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), **tol)
+
+
+@pytest.mark.parametrize("ci,co,k,s,H,W,B", GEOMS)
+def test_conv_dgrad_vs_torch_fp32(ci, co, k, s, H, W, B):
+    from partdistillation_amd.functions import conv_bf16 as C
+    x, w = _mk((B, ci, H, W), 1), _mk((co, ci, k, k), 2, (co * k * k) ** -0.5)
+    xf = x.float().requires_grad_(True)
+    ref_y = F.conv2d(xf, w.float(), None, s, k // 2)
+    dz = _mk(ref_y.shape, 4)
+    (ref,) = torch.autograd.grad(ref_y, xf, dz.float())
+    wt = C.transposed_filter(w)
+    assert wt.shape == (ci, k, k, co) and wt.is_contiguous()
+    dx = C.conv_dgrad(dz, wt, x.shape, k, s, k // 2)
+    tol = dict(rtol=2 ** -7, atol=2e-2)
+    assert dx.shape == x.shape and dx.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(dx.float(), ref, **tol)
+    add = _mk(x.shape, 5)
+    dx2 = C.conv_dgrad(dz, wt, x.shape, k, s, k // 2, addend=add)
+    torch.testing.assert_close(dx2.float(), ref + add.float(), **tol)
+
+
+def test_conv_rejects_what_it_does_not_cover():
+    from partdistillation_amd import lib
+    from partdistillation_amd.functions import conv_bf16 as C
+    x, w = _mk((1, 3, 16, 16), 1), _mk((64, 3, 7, 7), 2)
+    assert not C.supported(x, w, 2, 3)
+    with pytest.raises(lib.PdHipError):
+        C.conv_fwd(x, w, stride=2, pad=3)
+    x, w = _mk((1, 64, 8, 8), 1), _mk((96, 64, 1, 1), 2)
+    assert not C.supported(x, w, 1, 0)
