@@ -40,6 +40,14 @@ int pd_conv_bf16_fwd(const void *x, const void *w, const float *scale, const flo
 int pd_conv_bf16_dgrad(const void *dz, const void *wt, const void *addend, void *dx, int batch, int hi, int wi, int ci, int ho, int wo,
                        int co, int k, int stride, int pad, void *stream);
 
+/* dw[co][dy][dx][ci] = sum over b, oy, ox of dz[b,oy,ox,co] * x[b, oy*stride + dy - pad, ox*stride + dx - pad, ci]   (bf16 result,
+ * fp32 accumulation): the gradient of the convolution with respect to its filter, in the filter's own [co][k][k][ci] layout.
+ * Any k, stride, pad (the 7x7 stem excepted only by ci % 8 == 0); ci % 8 == 0, co % 8 == 0.  workspace: fp32, at least
+ * pd_conv_bf16_wgrad_workspace_floats(...) elements, 16-byte aligned, reusable by the next call on the same stream. */
+int64_t pd_conv_bf16_wgrad_workspace_floats(int batch, int ho, int wo, int ci, int co, int k);
+int pd_conv_bf16_wgrad(const void *dz, const void *x, void *dw, float *workspace, int64_t workspace_floats, int batch, int hi, int wi,
+                       int ci, int ho, int wo, int co, int k, int stride, int pad, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

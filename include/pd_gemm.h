@@ -71,6 +71,14 @@ int64_t pd_gemm_wgrad_f32x3_ws_floats(int N, int K);
 int pd_gemm_wgrad_acc_f32x3_ws(const float *dY, const float *X, float *dW, float *dB, float *workspace, int64_t workspace_floats, int M, int N,
                                int K, int ldy, int ldx, int ldw, void *stream);
 
+/* Weight (and bias) gradient of pd_conv3x3_nhwc_f32x3's convolution (3 x 3, stride 1, pad 1; the fp32 FPN output convolution of
+ * the pixel decoder, reference msdeformattn.py:238-257, 348-357), ACCUMULATED into caller-initialised buffers:
+ *   dWk[co][tap][ci] += sum over pixels dY[p][co] X[p + off(tap)][ci],   dB[co] += sum over pixels dY[p][co]   (dB nullable)
+ * dY [B,H,W,Co], X [B,H,W,Ci] NHWC fp32; dWk [Co][3][3][Ci] (the channels-last storage of the [Co][Ci][3][3] filter gradient).
+ * Ci % 128 == 0, Co % 4 == 0.  workspace as in pd_gemm_wgrad_acc_f32x3_ws with (N, K) = (Co, 9 Ci); same 3-way bf16 split. */
+int pd_conv3x3_wgrad_nhwc_f32x3(const float *dY, const float *X, float *dWk, float *dB, float *workspace, int64_t workspace_floats, int B, int H,
+                                int W, int Ci, int Co, void *stream);
+
 /* 3 x 3, stride 1, pad 1 convolution as an implicit GEMM on the same 3-way bf16 split (fp32-level results): the fp32 FPN
  * output convolution of the pixel decoder (reference pixel_decoder/msdeformattn.py:268-277, run at 1/4 resolution: 77 GFLOP per
  * 1024^2 image).  X [B,H,W,Ci] and Y [B,H,W,Co] channels-last, Wk [Co][3][3][Ci] (the channels-last filter), bias [Co] or NULL;

@@ -207,6 +207,201 @@ int launch_conv(const void *S, const void *Wf, const float *scale, const float *
   return pd_check_launch(DGRAD ? "pd_conv_bf16_dgrad" : "pd_conv_bf16_fwd");
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[co][tap][ci] = sum over output pixels m of dz[m][co] * x[pixel(m, tap)][ci]: the contraction runs over the ROWS of both
+// operands, so the tiles are staged as they lie in memory ([pixel][channel], 16-byte loads straight into LDS, no arithmetic) and
+// transposed on the way out by ds_read_b64_tr_b16 (lane mapping: tools/probes/tr_read_probe.hip; same scheme as
+// gemm_wgrad_f32x3_tr in gemm_x3.hip).  128 x 128 output tile per workgroup, 32 pixels per stage (two 16-deep MFMA steps), the
+// pixel range split over workgroups whose fp32 partial tiles go to a workspace in register order; conv_wgrad_reduce sums them
+// and writes bf16.  Column kk of the GEMM = (tap, ci): a thread's 8 columns lie inside one tap (ci % 8 == 0), so a 128-wide tile
+// may span several taps (ci = 64) — each thread gathers with its own tap offset.
+constexpr int WTW = 32, WTP = 160;                       // pixels per stage, bf16 elements per LDS row (320 B: see gemm_x3.hip)
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ hwbf16x8 frag_tr(const bf16_t *p)
+{
+  typedef __attribute__((address_space(3))) v4s16 *lp;
+  union { v4s16 h[2]; hwbf16x8 v; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p));
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p + 4 * WTP));
+  return u.v;
+}
+
+struct WgradGeom {
+  int M, N, K;                // output pixels (all images), co, taps * ci
+  int Ci, kw;
+  int Hi, Wi, Ho, Wo;
+  int stride, pad;
+  int tiles_k, tiles, m_chunk;
+};
+
+// TN x TK output tile = (2 WN) x (2 WK), 4 wavefronts (2 x 2) of WN x WK each; 64-wide tiles for the 64-channel layers of res2 (half
+// of a 128-wide tile would be zeros there — and the fp32 partial tiles are this kernel's second-largest traffic).
+template <int WN, int WK>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr(const bf16_t *__restrict__ dZ, const bf16_t *__restrict__ X,
+                                                              float *__restrict__ ws, WgradGeom g)
+{
+  constexpr int TN = 2 * WN, TK = 2 * WK, NI = WN / 32, KJ = WK / 32;
+  constexpr int PN = TN + 32, PK = TK + 32;              // LDS row pitches: 160 or 96 bf16 = 320 / 192 B, both = 16 banks mod 64
+  constexpr int LY = 256 / (TN / 8), LX = 256 / (TK / 8);   // pixels one pass of the 256 threads stages (16 or 32)
+  __shared__ __attribute__((aligned(16))) bf16_t SY[2][WTW][PN];
+  __shared__ __attribute__((aligned(16))) bf16_t SX[2][WTW][PK];
+  const int tile = blockIdx.x % g.tiles, split = blockIdx.x / g.tiles;
+  const int n0 = (tile / g.tiles_k) * TN, k0 = (tile % g.tiles_k) * TK;
+  const int mb = split * g.m_chunk, me = min(g.M, mb + g.m_chunk);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wn = (wave >> 1) * WN, wk = (wave & 1) * WK;
+  const int yr = t / (TN / 8), yc = (t % (TN / 8)) * 8;  // dz staging: pixels yr + LY j, columns yc .. yc+7
+  const int xr = t / (TK / 8), xcl = (t % (TK / 8)) * 8;
+  const bool ycol_ok = n0 + yc < g.N, xcol_ok = k0 + xcl < g.K;
+  int tdy = 0, tdx = 0, xc = 0;                          // this thread's X columns: one tap, 8 channels
+  {
+    const int kk = xcol_ok ? k0 + xcl : 0, tap = kk / g.Ci;
+    xc = kk - tap * g.Ci;
+    tdy = tap / g.kw - g.pad; tdx = tap - (tap / g.kw) * g.kw - g.pad;
+  }
+  constexpr int JY = WTW / LY, JX = WTW / LX;            // passes per stage (1 or 2)
+  // running coordinates of the pixels the NEXT gload stages for X (called with m = mb, mb + 32, ... in this order)
+  int cb[JX], cy[JX], cx[JX];
+#pragma unroll
+  for (int j = 0; j < JX; ++j) {
+    const int m = min(mb + xr + LX * j, g.M - 1), hw = g.Ho * g.Wo;
+    cb[j] = m / hw;
+    const int rem = m - cb[j] * hw;
+    cy[j] = rem / g.Wo; cx[j] = rem - cy[j] * g.Wo;
+  }
+  uint4 ry[2][JY], rx[2][JX];
+  auto gload = [&](int s, int m) {
+#pragma unroll
+    for (int j = 0; j < JY; ++j) {
+      const int r = m + yr + LY * j;
+      ry[s][j] = (r < me && ycol_ok) ? *reinterpret_cast<const uint4 *>(dZ + (int64_t)r * g.N + n0 + yc) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      const int r = m + xr + LX * j;
+      const int iy = cy[j] * g.stride + tdy, ix = cx[j] * g.stride + tdx;
+      const bool ok = r < me && xcol_ok && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+      rx[s][j] = ok ? *reinterpret_cast<const uint4 *>(X + ((int64_t)(cb[j] * g.Hi + iy) * g.Wi + ix) * g.Ci + xc) : make_uint4(0, 0, 0, 0);
+      cx[j] += WTW;
+      while (cx[j] >= g.Wo) { cx[j] -= g.Wo; if (++cy[j] == g.Ho) { cy[j] = 0; ++cb[j]; } }
+    }
+  };
+  auto lstore = [&](int s, int buf) {
+#pragma unroll
+    for (int j = 0; j < JY; ++j) *reinterpret_cast<uint4 *>(&SY[buf][yr + LY * j][yc]) = ry[s][j];
+#pragma unroll
+    for (int j = 0; j < JX; ++j) *reinterpret_cast<uint4 *>(&SX[buf][xr + LX * j][xcl]) = rx[s][j];
+  };
+  f32x16 acc[NI][KJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < KJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int steps = (me - mb + WTW - 1) / WTW;
+  if (steps > 0) {
+    gload(0, mb);
+    if (steps > 1) gload(1, mb + WTW);
+    lstore(0, 0);
+  }
+  __syncthreads();
+  const int grp = lane >> 4, sl = lane & 15;
+  const int frow = 8 * (grp >> 1) + (sl >> 2), fcol = 16 * (grp & 1) + 4 * (sl & 3);
+  typedef __attribute__((address_space(3))) v4s16 *lp;
+  auto step = [&](int st, int par) {
+    if (st + 2 < steps) gload(par, mb + (st + 2) * WTW);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      hwbf16x8 a[NI], b[KJ];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        union { v4s16 h[2]; hwbf16x8 v; } u;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)&SY[par][ks * 16 + frow][wn + i * 32 + fcol]);
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)&SY[par][ks * 16 + frow + 4][wn + i * 32 + fcol]);
+        a[i] = u.v;
+      }
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) {
+        union { v4s16 h[2]; hwbf16x8 v; } u;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)&SX[par][ks * 16 + frow][wk + j * 32 + fcol]);
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)&SX[par][ks * 16 + frow + 4][wk + j * 32 + fcol]);
+        b[j] = u.v;
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (st + 1 < steps) lstore(par ^ 1, par ^ 1);
+    __syncthreads();
+  };
+  for (int st = 0; st < steps; st += 2) {
+    step(st, 0);
+    if (st + 1 < steps) step(st + 1, 1);
+  }
+  float *w = ws + ((int64_t)split * g.tiles + tile) * (TN * TK) + t;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < KJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) w[((i * KJ + j) * 16 + e) * 256] = acc[i][j][e];
+}
+
+// dW (bf16) = sum over splits of the partial tiles (register order: element (ij, e) of thread t at ((ij * 16 + e) * 256 + t))
+template <int WN, int WK>
+__global__ __launch_bounds__(256) void conv_wgrad_reduce(const float *__restrict__ ws, bf16_t *__restrict__ dW, int N, int K, int tiles_k,
+                                                         int tiles, int splits)
+{
+  constexpr int TN = 2 * WN, TK = 2 * WK, KJ = WK / 32, QN = (WN / 32) * KJ * 16;     // QN (ij, e) pairs per tile
+  const int tile = blockIdx.x / QN, q = blockIdx.x % QN;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ij = q >> 4, e = q & 15, i = ij / KJ, j = ij % KJ;
+  const int n0 = (tile / tiles_k) * TN, k0 = (tile % tiles_k) * TK;
+  const int wn = (wave >> 1) * WN, wk = (wave & 1) * WK;
+  const float *p = ws + (int64_t)tile * (TN * TK) + q * 256 + t;
+  const int64_t stride = (int64_t)tiles * (TN * TK);
+  float s0 = 0.f, s1 = 0.f;
+  int sp = 0;
+  for (; sp + 7 < splits; sp += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(sp + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+  }
+  for (; sp < splits; ++sp) s0 += p[(int64_t)sp * stride];
+  const int c = k0 + wk + j * 32 + (lane & 31);
+  const int row = n0 + wn + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+  if (c < K && row < N) dW[(int64_t)row * K + c] = (bf16_t)(pk_bf16(s0 + s1, 0.f) & 0xffff);
+}
+
+struct WgradPlan { int tn, tk, tiles_k, tiles, splits, m_chunk; };
+WgradPlan wgrad_plan(int M, int N, int K)
+{
+  WgradPlan p;
+  p.tn = N <= 64 ? 64 : 128;
+  p.tk = K <= 64 ? 64 : 128;
+  p.tiles_k = (K + p.tk - 1) / p.tk;
+  p.tiles = p.tiles_k * ((N + p.tn - 1) / p.tn);
+  // two to three workgroups are resident per CU: one round of ~512, at least 8 stages (256 pixels) per workgroup — every
+  // workgroup ends with a tn x tk fp32 partial tile, traffic that rivals the operands' when the pixel ranges get short
+  p.splits = p.tiles >= 512 ? 1 : (512 + p.tiles / 2) / p.tiles;
+  p.m_chunk = ((M + p.splits - 1) / p.splits + WTW - 1) / WTW * WTW;
+  if (p.m_chunk < 8 * WTW) p.m_chunk = 8 * WTW;
+  p.splits = (M + p.m_chunk - 1) / p.m_chunk;
+  return p;
+}
+
+template <int WN, int WK>
+void launch_wgrad(const void *dz, const void *x, void *dw, float *ws, const WgradGeom &g, int splits, hipStream_t st)
+{
+  hipLaunchKernelGGL((conv_wgrad_bf16_tr<WN, WK>), dim3((unsigned)(g.tiles * splits)), dim3(256), 0, st, (const bf16_t *)dz, (const bf16_t *)x, ws, g);
+  hipLaunchKernelGGL((conv_wgrad_reduce<WN, WK>), dim3((unsigned)(g.tiles * (WN / 32) * (WK / 32) * 16)), dim3(256), 0, st, (const float *)ws,
+                     (bf16_t *)dw, g.N, g.K, g.tiles_k, g.tiles, splits);
+}
+
 int check_geom(int batch, int hi, int wi, int ci, int ho, int wo, int co, int k, int stride, int pad)
 {
   if (batch <= 0 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0) return PD_ERR_INVALID_ARG;
@@ -241,4 +436,30 @@ extern "C" int pd_conv_bf16_dgrad(const void *dz, const void *wt, const void *ad
   ConvGeom g{batch * hi * wi, ci, co, k, k * k, ho, wo, hi, wi, stride, pad};
   return ci % 128 == 0 ? launch_conv<128, true>(dz, wt, nullptr, nullptr, addend, dx, g, 0, (hipStream_t)stream)
                        : launch_conv<64, true>(dz, wt, nullptr, nullptr, addend, dx, g, 0, (hipStream_t)stream);
+}
+
+extern "C" int64_t pd_conv_bf16_wgrad_workspace_floats(int batch, int ho, int wo, int ci, int co, int k)
+{
+  const WgradPlan p = wgrad_plan(batch * ho * wo, co, k * k * ci);
+  return (int64_t)p.tiles * p.splits * p.tn * p.tk;
+}
+
+extern "C" int pd_conv_bf16_wgrad(const void *dz, const void *x, void *dw, float *workspace, int64_t workspace_floats, int batch, int hi,
+                                  int wi, int ci, int ho, int wo, int co, int k, int stride, int pad, void *stream)
+{
+  if (!dz || !x || !dw || !workspace) return PD_ERR_INVALID_ARG;
+  if (batch <= 0 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0 || ci % 8 || co % 8 || k < 1 || stride < 1 || pad < 0) return PD_ERR_INVALID_ARG;
+  if (ho != (hi + 2 * pad - k) / stride + 1 || wo != (wi + 2 * pad - k) / stride + 1) return PD_ERR_INVALID_ARG;
+  if ((int64_t)batch * hi * wi >= (1ll << 31) / 8 || (int64_t)batch * ho * wo >= (1ll << 31) - 4096) return PD_ERR_INVALID_ARG;
+  WgradGeom g;
+  g.M = batch * ho * wo; g.N = co; g.K = k * k * ci; g.Ci = ci; g.kw = k; g.Hi = hi; g.Wi = wi; g.Ho = ho; g.Wo = wo; g.stride = stride; g.pad = pad;
+  const WgradPlan p = wgrad_plan(g.M, g.N, g.K);
+  g.tiles_k = p.tiles_k; g.tiles = p.tiles; g.m_chunk = p.m_chunk;
+  if (workspace_floats < (int64_t)p.tiles * p.splits * p.tn * p.tk) return PD_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (p.tn == 128 && p.tk == 128) launch_wgrad<64, 64>(dz, x, dw, workspace, g, p.splits, st);
+  else if (p.tn == 128) launch_wgrad<64, 32>(dz, x, dw, workspace, g, p.splits, st);
+  else if (p.tk == 128) launch_wgrad<32, 64>(dz, x, dw, workspace, g, p.splits, st);
+  else launch_wgrad<32, 32>(dz, x, dw, workspace, g, p.splits, st);
+  return pd_check_launch("pd_conv_bf16_wgrad");
 }

@@ -498,11 +498,14 @@ __device__ __forceinline__ hwbf16x8 frag_tr(const bf16_t *p)      // p: this lan
   return u.v;
 }
 
-template <int ABL>
+// CONV: X is an NHWC image [*, H, W, Ci] (ldx = Ci), K = 9 Ci ordered (tap, channel) like the channels-last filter gradient
+// [Co][3][3][Ci]; Ci % 128 == 0, so a tile's 128 columns lie inside one tap and its X rows are the pixels m + dy W + dx (zeros
+// outside the image): the weight gradient of a 3 x 3, stride 1, pad 1 convolution, nothing unfolded.
+template <int ABL, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3_tr(const float *__restrict__ dY, const float *__restrict__ X,
                                                                float *__restrict__ dW, float *__restrict__ dB, float *__restrict__ ws,
                                                                int M, int N, int K, int ldy, int ldx, int ldw, int tiles_k, int tiles,
-                                                               int m_chunk)
+                                                               int m_chunk, int H, int W)
 {
   __shared__ __attribute__((aligned(16))) bf16_t S[2][2][3][TWS][TP];      // stage, operand (dY, X), plane, row, column
   const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
@@ -513,12 +516,31 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3_tr(const float *__res
   const int sr = t >> 5, sc = (t & 31) * 4;                      // staging: rows sr, sr + 8; columns sc .. sc+3
   const bool ycol_ok = n0 + sc < N, xcol_ok = k0 + sc < K;
   float4 ry[2][2], rx[2][2];                                     // two register stages
-  auto gload = [&](int s, int m) {
+  int cpy[2] = {0, 0}, cpx[2] = {0, 0}, tdy = 0, tdx = 0, xoff = k0 + sc;   // CONV: image coordinates of the rows the NEXT gload stages
+  if (CONV) {
+    const int tap = k0 / ldx;
+    tdy = tap / 3 - 1; tdx = tap - (tap / 3) * 3 - 1;
+    xoff = k0 - tap * ldx + sc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pix = (mb + sr + 8 * j) % (H * W);
+      cpy[j] = pix / W; cpx[j] = pix - cpy[j] * W;
+    }
+  }
+  auto gload = [&](int s, int m) {                               // called with m = mb, mb + 16, mb + 32, ... in this order
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = m + sr + 8 * j;
       ry[s][j] = (r < me && ycol_ok) ? *reinterpret_cast<const float4 *>(dY + (int64_t)r * ldy + n0 + sc) : make_float4(0, 0, 0, 0);
-      rx[s][j] = (r < me && xcol_ok) ? *reinterpret_cast<const float4 *>(X + (int64_t)r * ldx + k0 + sc) : make_float4(0, 0, 0, 0);
+      if (CONV) {
+        const int yy = cpy[j] + tdy, xx = cpx[j] + tdx;
+        const bool ok = r < me && xcol_ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        rx[s][j] = ok ? *reinterpret_cast<const float4 *>(X + ((int64_t)r + tdy * W + tdx) * ldx + xoff) : make_float4(0, 0, 0, 0);
+        cpx[j] += TWS;
+        while (cpx[j] >= W) { cpx[j] -= W; if (++cpy[j] == H) cpy[j] = 0; }
+      } else {
+        rx[s][j] = (r < me && xcol_ok) ? *reinterpret_cast<const float4 *>(X + (int64_t)r * ldx + k0 + sc) : make_float4(0, 0, 0, 0);
+      }
     }
   };
   const bool do_bias = dB != nullptr && k0 == 0;
@@ -785,7 +807,7 @@ extern "C" int pd_gemm_tn_f32x3_relumask(const float *A, const float *B, const u
 }
 
 static int wgrad_x3_launch(const float *dY, const float *X, float *dW, float *dB, float *ws, int64_t ws_floats, int M, int N, int K, int ldy,
-                           int ldx, int ldw, hipStream_t st, const char *who)
+                           int ldx, int ldw, hipStream_t st, const char *who, int convH = 0, int convW = 0)
 {
   if (M < 0 || N < 0 || K < 0) return pd_set_error(PD_ERR_INVALID_ARG, "%s: negative size", who);
   if (N == 0 || K == 0 || M == 0) return PD_OK;
@@ -802,16 +824,19 @@ static int wgrad_x3_launch(const float *dY, const float *X, float *dW, float *dB
   splits = (M + m_chunk - 1) / m_chunk;
   // transpose-read form when the operands allow 16-byte row loads (always, in this repo); x3_ablate 21 forces the scalar-staged one
   const bool vec = !(N & 3) && !(K & 3) && !(ldy & 3) && !(ldx & 3) && !((uintptr_t)dY & 15) && !((uintptr_t)X & 15) && g_pd_dbg_x3 != 21;
+  if (convH && !vec) return pd_set_error(PD_ERR_INVALID_ARG, "%s: channel counts must be multiples of 4 and the tensors 16-byte aligned", who);
   if (!vec) {
     hipLaunchKernelGGL(gemm_wgrad_f32x3, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, dY, X, dW, dB, M, N, K, ldy, ldx, ldw, tk, tiles,
                        m_chunk);
     return pd_check_launch(who);
   }
   if (ws && (ws_floats < (int64_t)tiles * splits * BN * BM || splits < 2 || g_pd_dbg_x3 == 25)) ws = nullptr;   // not worth / does not fit: atomics
-  auto kfn = g_pd_dbg_x3 == 24 ? gemm_wgrad_f32x3_tr<2> : gemm_wgrad_f32x3_tr<0>;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, dY, X, dW, dB, ws, M, N, K, ldy, ldx, ldw, tk, tiles, m_chunk);
+  auto kfn = convH ? gemm_wgrad_f32x3_tr<0, true> : g_pd_dbg_x3 == 24 ? gemm_wgrad_f32x3_tr<2, false> : gemm_wgrad_f32x3_tr<0, false>;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, dY, X, dW, dB, ws, M, N, K, ldy, ldx, ldw, tk, tiles, m_chunk,
+                     convH, convW);
   const int groups = tiles * 64 >= 2048 ? 1 : splits >= 64 ? 8 : splits >= 16 ? 4 : 1;
-  if (ws) hipLaunchKernelGGL(wgrad_tr_reduce, dim3((unsigned)(tiles * 64), groups), dim3(256), 0, st, (const float *)ws, dW, N, K, ldw, tk, tiles, splits);
+  if (ws) hipLaunchKernelGGL(wgrad_tr_reduce, dim3((unsigned)(tiles * 64), groups), dim3(256), 0, st, (const float *)ws, dW, N, K, ldw, tk, tiles,
+                             splits);
   return pd_check_launch(who);
 }
 
@@ -831,6 +856,17 @@ extern "C" int pd_gemm_wgrad_acc_f32x3_ws(const float *dY, const float *X, float
                                           int M, int N, int K, int ldy, int ldx, int ldw, void *stream_)
 {
   return wgrad_x3_launch(dY, X, dW, dB, workspace, workspace_floats, M, N, K, ldy, ldx, ldw, (hipStream_t)stream_, "pd_gemm_wgrad_acc_f32x3_ws");
+}
+
+extern "C" int pd_conv3x3_wgrad_nhwc_f32x3(const float *dY, const float *X, float *dWk, float *dB, float *workspace, int64_t workspace_floats,
+                                           int B, int H, int W, int Ci, int Co, void *stream_)
+{
+  if (B < 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || (Ci % BM) || (Co & 3))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_conv3x3_wgrad_nhwc_f32x3: B=%d H=%d W=%d Ci=%d (%% 128) Co=%d (%% 4)", B, H, W, Ci, Co);
+  const int64_t M = (int64_t)B * H * W;
+  if (M > 0x7fffffffLL - 4096) return pd_set_error(PD_ERR_INVALID_ARG, "pd_conv3x3_wgrad_nhwc_f32x3: too many pixels");
+  return wgrad_x3_launch(dY, X, dWk, dB, workspace, workspace_floats, (int)M, Co, 9 * Ci, Co, Ci, 9 * Ci, (hipStream_t)stream_,
+                         "pd_conv3x3_wgrad_nhwc_f32x3", H, W);
 }
 
 extern "C" int pd_conv3x3_nhwc_f32x3(const float *X, const float *Wk, const float *bias, float *Y, int B, int H, int W, int Ci, int Co,

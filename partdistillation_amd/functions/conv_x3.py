@@ -1,10 +1,13 @@
 """fp32 3 x 3 convolution (stride 1, pad 1) on the bf16 matrix cores with fp32-level accuracy (pd_conv3x3_nhwc_f32x3,
-include/pd_gemm.h): forward and input gradient are implicit GEMMs on the exact 3-way bf16 split of csrc/gemm_x3.hip; the
-weight gradient stays the library's (MIOpen).  Channels-last tensors only (the pixel decoder keeps its maps NHWC)."""
+include/pd_gemm.h): forward and input gradient are implicit GEMMs on the exact 3-way bf16 split of csrc/gemm_x3.hip; the weight
+gradient is the transpose-read split kernel of the encoder's weight gradients with the im2col gather in its staging.  Channels-last tensors only (the pixel decoder keeps its maps NHWC)."""
 import torch
 from torch.autograd import Function
 
 from .. import lib as _lib
+
+
+WGRAD_X3 = True      # False: MIOpen's fp32 weight gradient (1.53 ms at 2 x 256 x 256^2, the transposed-read split kernel: see DESIGN.md)
 
 
 def supported(x, conv):
@@ -45,7 +48,21 @@ class Conv3x3X3(Function):
             # filter transposed to [Ci][3][3][Co] (2.4 MB at 256 channels)
             wt = weight.permute(0, 2, 3, 1).reshape(co, 9, ci).flip(1).permute(2, 1, 0).contiguous()
             dx = _raw(dy, wt, None, ci)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if (want_w or want_b) and WGRAD_X3 and ci % 128 == 0 and co % 4 == 0:
+            # the same split on the weight gradient: contraction over the pixels, tiles transposed on their way out of LDS
+            from .gemm import _wgrad_workspace
+            L = _lib.load()
+            B, _, H, W = x.shape
+            buf = torch.zeros(co * 9 * ci + co, dtype=torch.float32, device=x.device)
+            dwk, dbv = buf[:co * 9 * ci].view(co, 3, 3, ci), buf[co * 9 * ci:]
+            ws = _wgrad_workspace(x.device, int(L.pd_gemm_wgrad_f32x3_ws_floats(co, 9 * ci)))
+            _lib.check(L.pd_conv3x3_wgrad_nhwc_f32x3(dy.data_ptr(), x.data_ptr(), dwk.data_ptr(), dbv.data_ptr() if want_b else None,
+                                                     ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                                     B, H, W, ci, co, _lib.current_stream()))
+            dw = dwk.permute(0, 3, 1, 2) if want_w else None                # [Co,Ci,3,3] view with channels-last strides
+            db = dbv if want_b else None
+        elif want_w or want_b:
             _, dw, db = torch.ops.aten.convolution_backward(dy, x, weight, [co] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False,
                                                             [0, 0], 1, [False, True, ctx.has_bias])
         return dx, dw, db

@@ -35,11 +35,14 @@ SIGNATURES = {
     "pd_gemm_wgrad_acc_f32": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),
     "pd_conv3x3_nhwc_f32x3": (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [_c_vp]),
     "pd_gemm_wgrad_acc_f32x3": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),
+    "pd_conv3x3_wgrad_nhwc_f32x3": (_c_int, [_c_vp] * 5 + [ctypes.c_int64] + [_c_int] * 5 + [_c_vp]),
     "pd_gemm_wgrad_f32x3_ws_floats": (ctypes.c_int64, [_c_int] * 2),
     "pd_gemm_wgrad_acc_f32x3_ws": (_c_int, [_c_vp] * 5 + [ctypes.c_int64] + [_c_int] * 6 + [_c_vp]),
     "pd_adamw_clipped_shadow": (_c_int, [_c_vp] * 5 + [ctypes.c_int64] + [ctypes.c_double] * 5 + [_c_int, _c_vp, ctypes.c_double, _c_vp, _c_vp]),
     "pd_conv_bf16_supported": (_c_int, [_c_int] * 5),
     "pd_conv_bf16_fwd": (_c_int, [_c_vp] * 6 + [_c_int] * 11 + [_c_vp]),
+    "pd_conv_bf16_wgrad_workspace_floats": (ctypes.c_int64, [_c_int] * 6),
+    "pd_conv_bf16_wgrad": (_c_int, [_c_vp] * 4 + [ctypes.c_int64] + [_c_int] * 10 + [_c_vp]),
     "pd_conv_bf16_dgrad": (_c_int, [_c_vp] * 4 + [_c_int] * 10 + [_c_vp]),
     "pd_affine_act_fwd_bf16": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, _c_int, _c_vp]),
     "pd_affine_act_bwd_bf16": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, _c_int, _c_vp]),

@@ -15,7 +15,10 @@ import torch.nn.functional as F
 
 from ...compat import BACKBONE_REGISTRY, ShapeSpec
 from ...compat.layers import Conv2d, FrozenBatchNorm2d, c2_msra_fill, get_norm
+from ...functions import conv_bf16
 from ...functions.fused import affine_act
+
+OWN_WGRAD = bool(int(__import__("os").environ.get("PD_CONV_OWN_WGRAD", "1")))   # 0: MIOpen's filter gradients (tools/ comparisons)
 
 
 def _conv_bn_act(conv, x, residual=None, relu=True):
@@ -30,7 +33,10 @@ def _conv_bn_act(conv, x, residual=None, relu=True):
     frozen = isinstance(norm, FrozenBatchNorm2d)
     if frozen and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16 \
             and conv.out_channels % 8 == 0:
-        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if OWN_WGRAD and conv_bf16.own_wgrad_supported(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
+            y = conv_bf16.conv2d_own_wgrad(x, conv.weight, conv.stride, conv.padding)     # filter gradient: csrc/conv_bf16.hip
+        else:
+            y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         scale, bias = norm.scale_bias()
         return affine_act(y, scale, bias, residual, relu)
     if frozen:

@@ -61,6 +61,22 @@ def test_conv_dgrad_vs_torch_fp32(ci, co, k, s, H, W, B):
     torch.testing.assert_close(dx2.float(), ref + add.float(), **tol)
 
 
+@pytest.mark.parametrize("ci,co,k,s,H,W,B", GEOMS + [(64, 64, 7, 2, 40, 24, 2), (8, 24, 3, 1, 33, 17, 3)])
+def test_conv_wgrad_vs_torch_fp32(ci, co, k, s, H, W, B):
+    """pd_conv_bf16_wgrad (transpose-read kernel + partial-tile reduce) against the fp32 filter gradient: tiles that span several
+    taps (ci = 64, 8), pixel ranges that end inside an image row, strides, a 7 x 7 filter."""
+    from partdistillation_amd.functions import conv_bf16 as C
+    x, w = _mk((B, ci, H, W), 1), _mk((co, ci, k, k), 2, 0.05)
+    wf = w.float().requires_grad_(True)
+    ref_y = F.conv2d(x.float(), wf, None, s, k // 2)
+    dz = _mk(ref_y.shape, 4)
+    (ref,) = torch.autograd.grad(ref_y, wf, dz.float())
+    dw = C.conv_wgrad(dz, x, k, s, k // 2, like=w)
+    assert dw.shape == w.shape and dw.dtype == torch.bfloat16 and dw.stride() == w.stride()
+    err = (dw.float() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2 ** -7, err                                        # one bf16 rounding of an fp32-accumulated sum
+
+
 def test_conv_rejects_what_it_does_not_cover():
     from partdistillation_amd import lib
     from partdistillation_amd.functions import conv_bf16 as C

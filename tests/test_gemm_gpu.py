@@ -109,11 +109,13 @@ def test_gemm_wgrad_x3_is_fp32_accurate(M, N, K, bias):
         torch.testing.assert_close(outs[True][1].double() + 1.0, dy.double().sum(0), rtol=1e-4, atol=1e-3 * dy.abs().max().item())
 
 
-@pytest.mark.parametrize("B,H,W,Ci,Co,bias", [(2, 64, 64, 256, 256, False), (1, 37, 29, 32, 48, True), (3, 8, 200, 16, 272, True)])
+@pytest.mark.parametrize("B,H,W,Ci,Co,bias", [(2, 64, 64, 256, 256, False), (1, 37, 29, 32, 48, True), (3, 8, 200, 16, 272, True),
+                                              (3, 19, 23, 128, 80, True), (2, 5, 7, 256, 256, True)])
 def test_conv3x3_x3_matches_fp64_convolution(B, H, W, Ci, Co, bias):
     """pd_conv3x3_nhwc_f32x3 (implicit GEMM on the 3-way bf16 split) forward, input gradient (the same kernel on dY with the
-    flipped, transposed filter) and the library weight gradient against an fp64 convolution; forward / input-gradient errors
-    at the level of the library's fp32 convolution."""
+    flipped, transposed filter) and the weight / bias gradient (pd_conv3x3_wgrad_nhwc_f32x3 where Ci % 128 == 0: the transpose-read
+    split kernel with the im2col gather in its staging — images narrower than its 16-row stage, pixel counts that are no multiple
+    of anything; the library's otherwise) against an fp64 convolution; errors at the level of the library's fp32 convolution."""
     import torch.nn.functional as F
     from partdistillation_amd.functions import conv_x3
     g = torch.Generator(device="cuda").manual_seed(H * W + Ci)

@@ -23,3 +23,20 @@ for B, S, C in [(2, 256, 256), (2, 320, 256)]:
     y1 = F.conv2d(x, w, None, padding=1); y2 = conv_x3.conv3x3(x, w)
     b_lib = t(lambda: torch.autograd.grad(y1, (x, w), go, retain_graph=True)); b_x3 = t(lambda: torch.autograd.grad(y2, (x, w), go, retain_graph=True))
     print(f"B={B} {S}^2 C={C}: forward library {f_lib:.3f} ms ({gf/f_lib:.0f} GF/ms) x3 {f_x3:.3f} ms ({gf/f_x3:.0f}) | backward (dx + dw) library {b_lib:.3f} ms x3 {b_x3:.3f} ms")
+    wo = t(lambda: torch.autograd.grad(y2, (w,), go, retain_graph=True))
+    conv_x3.WGRAD_X3 = False
+    wl = t(lambda: torch.autograd.grad(y2, (w,), go, retain_graph=True))
+    conv_x3.WGRAD_X3 = True
+    print(f"    weight gradient alone: library {wl:.3f} ms, transpose-read split kernel {wo:.3f} ms ({gf/wo:.0f} GF/ms)")
+    from partdistillation_amd.functions.gemm import _wgrad_workspace
+    L = lib.load()
+    dwk = torch.zeros(C, 3, 3, C, device="cuda"); ws = _wgrad_workspace(x.device, int(L.pd_gemm_wgrad_f32x3_ws_floats(C, 9 * C)))
+    xd = x.detach()
+    def direct():
+        lib.check(L.pd_conv3x3_wgrad_nhwc_f32x3(go.data_ptr(), xd.data_ptr(), dwk.data_ptr(), None, ws.data_ptr(), ws.numel(), B, S, S, C, C, lib.current_stream()))
+    def direct_atomics():
+        lib.check(L.pd_conv3x3_wgrad_nhwc_f32x3(go.data_ptr(), xd.data_ptr(), dwk.data_ptr(), None, None, 0, B, S, S, C, C, lib.current_stream()))
+    from partdistillation_amd.functions import gemm as G
+    dy2, x2 = go.permute(0, 2, 3, 1).reshape(-1, C), torch.randn(B * S * S, 9 * C, device="cuda")
+    dw2 = torch.zeros(C, 9 * C, device="cuda")
+    print(f"    direct C call: workspace {t(direct):.3f} ms, atomics {t(direct_atomics):.3f} ms; plain GEMM of the same size (unfolded X) {t(lambda: G.gemm_wgrad_acc(dy2, x2, dw2, None, x3=True)):.3f} ms")

@@ -53,8 +53,8 @@ def timeit(fn, n=6):
 
 
 tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0, "floor": 0.0}
-tot.update({"own_fwd": 0.0, "own_dgrad": 0.0})
-print(f"{'conv':18s} {'cfg':28s} cnt   fwd_us dgrad_us wgrad_us | own_fwd own_dgrad | GF(one dir)  MB(fwd)  floor_us(one dir: max(hbm@6TB/s, mfma@1.5PF))")
+tot.update({"own_fwd": 0.0, "own_dgrad": 0.0, "own_wgrad": 0.0})
+print(f"{'conv':18s} {'cfg':28s} cnt   fwd_us dgrad_us wgrad_us | own_fwd own_dgrad own_wgrad | GF(one dir)  MB(fwd)  floor_us(one dir: max(hbm@6TB/s, mfma@1.5PF))")
 for (ci, co, k, s, hh), (name, cnt) in uniq.items():
     x = torch.randn(B, ci, hh, hh, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     w = (torch.randn(co, ci, k, k, device="cuda", dtype=torch.bfloat16) * 0.05).contiguous(memory_format=torch.channels_last).requires_grad_(True)
@@ -67,7 +67,9 @@ for (ci, co, k, s, hh), (name, cnt) in uniq.items():
     t_d = timeit(lambda: cb(gy, xd, wd, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False])) if ci > 3 else 0.0
     t_w = timeit(lambda: cb(gy, xd, wd, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False]))
     ho = y.shape[2]
-    o_f = o_d = 0.0
+    o_f = o_d = o_w = 0.0
+    if ci % 8 == 0:
+        o_w = timeit(lambda: OC.conv_wgrad(gy, xd, k, s, pad))
     if OC.supported(xd, wd, s, pad):
         sc, bi = torch.rand(co, device="cuda") + 0.5, torch.randn(co, device="cuda")
         resid = torch.randn_like(y)
@@ -77,8 +79,8 @@ for (ci, co, k, s, hh), (name, cnt) in uniq.items():
     gf = 2.0 * B * ho * ho * co * ci * k * k / 1e9
     mb = (x.numel() + y.numel() + w.numel()) * 2 / 1e6
     floor = max(mb / 6.0e6 * 1e6, gf / 1.5e6 * 1e6)
-    print(f"{name:18s} {f'{ci}->{co} k{k} s{s} @{hh}':28s} {cnt:3d} {t_f:8.1f} {t_d:8.1f} {t_w:8.1f} | {o_f:7.1f} {o_d:8.1f} | {gf:9.1f} {mb:8.1f} {floor:8.1f}")
+    print(f"{name:18s} {f'{ci}->{co} k{k} s{s} @{hh}':28s} {cnt:3d} {t_f:8.1f} {t_d:8.1f} {t_w:8.1f} | {o_f:7.1f} {o_d:8.1f} {o_w:8.1f} | {gf:9.1f} {mb:8.1f} {floor:8.1f}")
     tot["fwd"] += cnt * t_f; tot["dgrad"] += cnt * t_d; tot["wgrad"] += cnt * t_w; tot["floor"] += cnt * floor
-    tot["own_fwd"] += cnt * (o_f or t_f); tot["own_dgrad"] += cnt * (o_d or t_d)
+    tot["own_fwd"] += cnt * (o_f or t_f); tot["own_dgrad"] += cnt * (o_d or t_d); tot["own_wgrad"] += cnt * (o_w or t_w)
 print("totals (us per step):", {k: round(v, 1) for k, v in tot.items()}, "sum", round(tot["fwd"] + tot["dgrad"] + tot["wgrad"], 1),
       "floor x3 dirs", round(3 * tot["floor"], 1))
