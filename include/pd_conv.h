@@ -48,6 +48,21 @@ int64_t pd_conv_bf16_wgrad_workspace_floats(int batch, int ho, int wo, int ci, i
 int pd_conv_bf16_wgrad(const void *dz, const void *x, void *dw, float *workspace, int64_t workspace_floats, int batch, int hi, int wi,
                        int ci, int ho, int wo, int co, int k, int stride, int pad, void *stream);
 
+/* The filter gradients of MANY convolutions in one go (a backbone's, deferred to the end of its backward pass: a single layer's
+ * is a 20-40 us launch that cannot fill the chip).  descs: host array; table_host_pinned / table_device: caller-provided staging
+ * of pd_conv_bf16_wgrad_grouped_table_bytes(count) bytes each (the function fills the pinned one, copies it with an asynchronous
+ * memcpy on `stream` and launches at most four kernel pairs, one per output-tile shape); the pinned buffer must stay untouched
+ * until that copy has executed.  workspace >= pd_conv_bf16_wgrad_grouped_workspace_floats(descs, count).  count <= 256. */
+typedef struct PdConvWgradDesc {
+  const void *dz, *x;
+  void *dw;
+  int32_t batch, hi, wi, ci, ho, wo, co, k, stride, pad;
+} PdConvWgradDesc;
+int64_t pd_conv_bf16_wgrad_grouped_table_bytes(int count);
+int64_t pd_conv_bf16_wgrad_grouped_workspace_floats(const PdConvWgradDesc *descs, int count);
+int pd_conv_bf16_wgrad_grouped(const PdConvWgradDesc *descs, int count, void *table_host_pinned, void *table_device, float *workspace,
+                               int64_t workspace_floats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

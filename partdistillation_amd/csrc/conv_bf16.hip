@@ -237,15 +237,15 @@ struct WgradGeom {
 // TN x TK output tile = (2 WN) x (2 WK), 4 wavefronts (2 x 2) of WN x WK each; 64-wide tiles for the 64-channel layers of res2 (half
 // of a 128-wide tile would be zeros there — and the fp32 partial tiles are this kernel's second-largest traffic).
 template <int WN, int WK>
-__global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr(const bf16_t *__restrict__ dZ, const bf16_t *__restrict__ X,
-                                                              float *__restrict__ ws, WgradGeom g)
+__device__ __forceinline__ void wgrad_body(const bf16_t *__restrict__ dZ, const bf16_t *__restrict__ X, float *__restrict__ ws,
+                                           const WgradGeom &g, int bid)
 {
   constexpr int TN = 2 * WN, TK = 2 * WK, NI = WN / 32, KJ = WK / 32;
   constexpr int PN = TN + 32, PK = TK + 32;              // LDS row pitches: 160 or 96 bf16 = 320 / 192 B, both = 16 banks mod 64
   constexpr int LY = 256 / (TN / 8), LX = 256 / (TK / 8);   // pixels one pass of the 256 threads stages (16 or 32)
   __shared__ __attribute__((aligned(16))) bf16_t SY[2][WTW][PN];
   __shared__ __attribute__((aligned(16))) bf16_t SX[2][WTW][PK];
-  const int tile = blockIdx.x % g.tiles, split = blockIdx.x / g.tiles;
+  const int tile = bid % g.tiles, split = bid / g.tiles;
   const int n0 = (tile / g.tiles_k) * TN, k0 = (tile % g.tiles_k) * TK;
   const int mb = split * g.m_chunk, me = min(g.M, mb + g.m_chunk);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -349,13 +349,47 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr(const bf16_t *__res
       for (int e = 0; e < 16; ++e) w[((i * KJ + j) * 16 + e) * 256] = acc[i][j][e];
 }
 
+template <int WN, int WK>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr(const bf16_t *__restrict__ dZ, const bf16_t *__restrict__ X,
+                                                              float *__restrict__ ws, WgradGeom g)
+{
+  wgrad_body<WN, WK>(dZ, X, ws, g, blockIdx.x);
+}
+
+// GROUPED form: one launch works through a table of problems (the filter gradients of a whole backbone, deferred to the end of
+// its backward pass): block b belongs to the problem p with block_begin[p] <= b < block_begin[p + 1].  A layer's filter
+// gradient alone is a 20-40 us launch that cannot fill the chip (and ends in a second launch for its partial tiles); 52 of them
+// side by side can.
+struct WgradProblem {
+  const bf16_t *dz, *x;
+  bf16_t *dw;
+  int64_t ws_off;                                        // this problem's partial tiles inside the workspace (floats)
+  WgradGeom g;
+  int block_begin, reduce_begin, splits, variant;
+};
+
+__device__ __forceinline__ int find_problem(const WgradProblem *tab, int count, int b, bool reduce)
+{
+  int p = 0;
+  while (p + 1 < count && (reduce ? tab[p + 1].reduce_begin : tab[p + 1].block_begin) <= b) ++p;
+  return p;
+}
+
+template <int WN, int WK>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr_grouped(const WgradProblem *__restrict__ tab, int count, float *__restrict__ ws)
+{
+  const int p = find_problem(tab, count, blockIdx.x, false);
+  const WgradProblem &pr = tab[p];
+  wgrad_body<WN, WK>(pr.dz, pr.x, ws + pr.ws_off, pr.g, blockIdx.x - pr.block_begin);
+}
+
 // dW (bf16) = sum over splits of the partial tiles (register order: element (ij, e) of thread t at ((ij * 16 + e) * 256 + t))
 template <int WN, int WK>
-__global__ __launch_bounds__(256) void conv_wgrad_reduce(const float *__restrict__ ws, bf16_t *__restrict__ dW, int N, int K, int tiles_k,
-                                                         int tiles, int splits)
+__device__ __forceinline__ void reduce_body(const float *__restrict__ ws, bf16_t *__restrict__ dW, int N, int K, int tiles_k, int tiles,
+                                            int splits, int bid)
 {
   constexpr int TN = 2 * WN, TK = 2 * WK, KJ = WK / 32, QN = (WN / 32) * KJ * 16;     // QN (ij, e) pairs per tile
-  const int tile = blockIdx.x / QN, q = blockIdx.x % QN;
+  const int tile = bid / QN, q = bid % QN;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int ij = q >> 4, e = q & 15, i = ij / KJ, j = ij % KJ;
   const int n0 = (tile / tiles_k) * TN, k0 = (tile % tiles_k) * TK;
@@ -377,8 +411,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float *__restrict
   if (c < K && row < N) dW[(int64_t)row * K + c] = (bf16_t)(pk_bf16(s0 + s1, 0.f) & 0xffff);
 }
 
+template <int WN, int WK>
+__global__ __launch_bounds__(256) void conv_wgrad_reduce(const float *__restrict__ ws, bf16_t *__restrict__ dW, int N, int K, int tiles_k,
+                                                         int tiles, int splits)
+{
+  reduce_body<WN, WK>(ws, dW, N, K, tiles_k, tiles, splits, blockIdx.x);
+}
+
+template <int WN, int WK>
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_grouped(const WgradProblem *__restrict__ tab, int count, const float *__restrict__ ws)
+{
+  const int p = find_problem(tab, count, blockIdx.x, true);
+  const WgradProblem &pr = tab[p];
+  reduce_body<WN, WK>(ws + pr.ws_off, pr.dw, pr.g.N, pr.g.K, pr.g.tiles_k, pr.g.tiles, pr.splits, blockIdx.x - pr.reduce_begin);
+}
+
 struct WgradPlan { int tn, tk, tiles_k, tiles, splits, m_chunk; };
-WgradPlan wgrad_plan(int M, int N, int K)
+WgradPlan wgrad_plan(int M, int N, int K, int rows_per_wg = 0)
 {
   WgradPlan p;
   p.tn = N <= 64 ? 64 : 128;
@@ -388,6 +437,7 @@ WgradPlan wgrad_plan(int M, int N, int K)
   // two to three workgroups are resident per CU: one round of ~512, at least 8 stages (256 pixels) per workgroup — every
   // workgroup ends with a tn x tk fp32 partial tile, traffic that rivals the operands' when the pixel ranges get short
   p.splits = p.tiles >= 512 ? 1 : (512 + p.tiles / 2) / p.tiles;
+  if (rows_per_wg > 0) p.splits = (M + rows_per_wg - 1) / rows_per_wg;      // grouped launches: the other problems fill the chip
   p.m_chunk = ((M + p.splits - 1) / p.splits + WTW - 1) / WTW * WTW;
   if (p.m_chunk < 8 * WTW) p.m_chunk = 8 * WTW;
   p.splits = (M + p.m_chunk - 1) / p.m_chunk;
@@ -462,4 +512,82 @@ extern "C" int pd_conv_bf16_wgrad(const void *dz, const void *x, void *dw, float
   else if (p.tk == 128) launch_wgrad<32, 64>(dz, x, dw, workspace, g, p.splits, st);
   else launch_wgrad<32, 32>(dz, x, dw, workspace, g, p.splits, st);
   return pd_check_launch("pd_conv_bf16_wgrad");
+}
+
+// ------------------------------------------------------------------------------------------------ grouped filter gradients
+namespace {
+constexpr int kGroupRows = 2048;                         // pixels per workgroup in a grouped launch
+
+int variant_of(const WgradPlan &p) { return p.tn == 128 ? (p.tk == 128 ? 0 : 1) : (p.tk == 128 ? 2 : 3); }
+
+bool desc_ok(const PdConvWgradDesc &d)
+{
+  if (!d.dz || !d.x || !d.dw) return false;
+  if (d.batch <= 0 || d.hi <= 0 || d.wi <= 0 || d.ho <= 0 || d.wo <= 0 || d.ci % 8 || d.co % 8 || d.k < 1 || d.stride < 1 || d.pad < 0) return false;
+  if (d.ho != (d.hi + 2 * d.pad - d.k) / d.stride + 1 || d.wo != (d.wi + 2 * d.pad - d.k) / d.stride + 1) return false;
+  return (int64_t)d.batch * d.hi * d.wi < (1ll << 31) / 8 && (int64_t)d.batch * d.ho * d.wo < (1ll << 31) - 4096;
+}
+}  // namespace
+
+extern "C" int64_t pd_conv_bf16_wgrad_grouped_table_bytes(int count) { return (int64_t)count * (int64_t)sizeof(WgradProblem); }
+
+extern "C" int64_t pd_conv_bf16_wgrad_grouped_workspace_floats(const PdConvWgradDesc *descs, int count)
+{
+  int64_t total = 0;
+  for (int i = 0; i < count; ++i) {
+    const WgradPlan p = wgrad_plan(descs[i].batch * descs[i].ho * descs[i].wo, descs[i].co, descs[i].k * descs[i].k * descs[i].ci, kGroupRows);
+    total += (int64_t)p.tiles * p.splits * p.tn * p.tk;
+  }
+  return total;
+}
+
+extern "C" int pd_conv_bf16_wgrad_grouped(const PdConvWgradDesc *descs, int count, void *table_host_pinned, void *table_device,
+                                          float *workspace, int64_t workspace_floats, void *stream)
+{
+  if (count < 0 || (count > 0 && (!descs || !table_host_pinned || !table_device || !workspace))) return PD_ERR_INVALID_ARG;
+  if (count == 0) return 0;
+  WgradProblem *tab = reinterpret_cast<WgradProblem *>(table_host_pinned);
+  int n_of[4] = {0, 0, 0, 0}, blocks[4] = {0, 0, 0, 0}, rblocks[4] = {0, 0, 0, 0};
+  // problems sorted by tile variant (four contiguous sub-tables, one launch pair each)
+  int order[4][256];
+  if (count > 256) return PD_ERR_INVALID_ARG;
+  WgradPlan plans[256];
+  for (int i = 0; i < count; ++i) {
+    if (!desc_ok(descs[i])) return PD_ERR_INVALID_ARG;
+    plans[i] = wgrad_plan(descs[i].batch * descs[i].ho * descs[i].wo, descs[i].co, descs[i].k * descs[i].k * descs[i].ci, kGroupRows);
+    const int v = variant_of(plans[i]);
+    order[v][n_of[v]++] = i;
+  }
+  int64_t ws_off = 0;
+  int start[4], at = 0;
+  for (int v = 0; v < 4; ++v) {
+    start[v] = at;
+    for (int q = 0; q < n_of[v]; ++q, ++at) {
+      const int i = order[v][q];
+      const PdConvWgradDesc &d = descs[i];
+      const WgradPlan &p = plans[i];
+      WgradProblem &w = tab[at];
+      w.dz = (const bf16_t *)d.dz; w.x = (const bf16_t *)d.x; w.dw = (bf16_t *)d.dw; w.ws_off = ws_off;
+      w.g.M = d.batch * d.ho * d.wo; w.g.N = d.co; w.g.K = d.k * d.k * d.ci; w.g.Ci = d.ci; w.g.kw = d.k; w.g.Hi = d.hi; w.g.Wi = d.wi;
+      w.g.Ho = d.ho; w.g.Wo = d.wo; w.g.stride = d.stride; w.g.pad = d.pad; w.g.tiles_k = p.tiles_k; w.g.tiles = p.tiles; w.g.m_chunk = p.m_chunk;
+      w.block_begin = blocks[v]; w.reduce_begin = rblocks[v]; w.splits = p.splits; w.variant = v;
+      blocks[v] += p.tiles * p.splits;
+      rblocks[v] += p.tiles * (p.tn / 64) * (p.tk / 64) * 16;
+      ws_off += (int64_t)p.tiles * p.splits * p.tn * p.tk;
+    }
+  }
+  if (ws_off > workspace_floats) return PD_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemcpyAsync(table_device, table_host_pinned, (size_t)count * sizeof(WgradProblem), hipMemcpyHostToDevice, st) != hipSuccess)
+    return PD_ERR_LAUNCH;
+  const WgradProblem *dt = reinterpret_cast<const WgradProblem *>(table_device);
+#define PD_GROUP(V, WN, WK)                                                                                                         \
+  if (n_of[V]) {                                                                                                                    \
+    hipLaunchKernelGGL((conv_wgrad_bf16_tr_grouped<WN, WK>), dim3((unsigned)blocks[V]), dim3(256), 0, st, dt + start[V], n_of[V], workspace); \
+    hipLaunchKernelGGL((conv_wgrad_reduce_grouped<WN, WK>), dim3((unsigned)rblocks[V]), dim3(256), 0, st, dt + start[V], n_of[V],    \
+                       (const float *)workspace);                                                                                   \
+  }
+  PD_GROUP(0, 64, 64) PD_GROUP(1, 64, 32) PD_GROUP(2, 32, 64) PD_GROUP(3, 32, 32)
+#undef PD_GROUP
+  return pd_check_launch("pd_conv_bf16_wgrad_grouped");
 }

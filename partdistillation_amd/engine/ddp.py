@@ -12,6 +12,8 @@ from typing import List
 import torch
 import torch.distributed as dist
 
+from ..functions.conv_bf16 import flush as _flush_deferred_wgrads
+
 
 class _Bucket:
     __slots__ = ("group", "t_begin", "t_end", "start", "end", "pending", "total", "work", "index")
@@ -76,6 +78,7 @@ class BucketedGradReducer:
 
     def _launch(self, b):
         g = self.flat.groups[b.group]
+        _flush_deferred_wgrads()                                 # filter gradients the backbone queued (functions/conv_bf16.py) are due now
         g.gather(None, b.t_begin, b.t_end)                       # compute stream: p.grad tensors -> flat slice
         buf = g.grad[b.start:b.end]
         if self._side is not None:

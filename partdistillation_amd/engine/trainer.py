@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 
 from ..compat import build_model
+from ..functions.conv_bf16 import deferred_wgrads as _deferred_wgrads
 from ..compat.structures import BitMasks, Instances
 from .ddp import BucketedGradReducer, broadcast_parameters
 from .optimizer import build_lr_scheduler, build_optimizer
@@ -65,7 +66,8 @@ class TrainStep:
             total = getattr(loss_dict, "total", None)
             if total is None:
                 total = sum(loss_dict.values())
-        total.backward()
+        with _deferred_wgrads():                             # the backbone's filter gradients: one grouped launch after backward
+            total.backward()
         return loss_dict
 
     def __call__(self, batched_inputs):

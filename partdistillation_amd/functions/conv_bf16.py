@@ -1,6 +1,9 @@
 """Python face of the bf16 NHWC backbone convolutions (include/pd_conv.h, csrc/conv_bf16.hip): one launch = convolution +
 frozen-BN affine + residual add + ReLU; the input gradient = transposed convolution + the gradient arriving over the
 shortcut.  GPU only; no fallback."""
+import contextlib
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -76,6 +79,67 @@ def conv_wgrad(dz, x, k, stride=1, pad=0, like=None):
     return dw
 
 
+class _Desc(ctypes.Structure):                                      # PdConvWgradDesc (include/pd_conv.h)
+    _fields_ = [("dz", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ("batch", "hi", "wi", "ci", "ho", "wo", "co", "k", "stride", "pad")]
+
+
+class _Deferred:
+    """filter gradients queued by Conv2dOwnWgrad.backward while `deferred_wgrads()` is active: (dz, x, address of dw, k, stride, pad)"""
+    active = False
+    queue = []
+    ring = None
+    table_dev = None
+    MAXP = 256
+
+
+@contextlib.contextmanager
+def deferred_wgrads():
+    """Inside this context the filter gradients of Conv2dOwnWgrad are NOT computed when autograd asks for them: backward() hands
+    autograd an allocated-but-unwritten tensor and queues the problem; flush() — called on exit, and by the data-parallel reducer
+    before it reads a bucket's gradients — runs everything queued as ONE grouped launch (pd_conv_bf16_wgrad_grouped).  Only for
+    callers that do not look at .grad of the convolution filters before the flush (engine/trainer.py)."""
+    prev = _Deferred.active
+    _Deferred.active = True
+    try:
+        yield
+    finally:
+        _Deferred.active = prev
+        flush()
+
+
+def flush():
+    q, _Deferred.queue = _Deferred.queue, []
+    if not q:
+        return
+    dev = q[0][0].device
+    L = _lib.load()
+    for lo in range(0, len(q), _Deferred.MAXP):
+        part = q[lo:lo + _Deferred.MAXP]
+        descs = (_Desc * len(part))()
+        for d, (dz, x, dw, k, s, p) in zip(descs, part):
+            d.dz, d.x, d.dw = dz.data_ptr(), x.data_ptr(), dw
+            d.batch, d.ci, d.hi, d.wi = x.shape
+            d.co, d.ho, d.wo = dz.shape[1], dz.shape[2], dz.shape[3]
+            d.k, d.stride, d.pad = k, s, p
+        need = int(L.pd_conv_bf16_wgrad_grouped_workspace_floats(ctypes.byref(descs), len(part)))
+        ws = _WS.get(str(dev))
+        if ws is None or ws.numel() < need:
+            ws = _WS[str(dev)] = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=dev)
+        tbytes = int(L.pd_conv_bf16_wgrad_grouped_table_bytes(_Deferred.MAXP))
+        if _Deferred.ring is None:
+            from .fused import PinnedRing
+            _Deferred.ring = PinnedRing(tbytes, torch.uint8, pin=True)
+        if _Deferred.table_dev is None or _Deferred.table_dev.device != dev:
+            _Deferred.table_dev = torch.empty(tbytes, dtype=torch.uint8, device=dev)
+        host = _Deferred.ring.acquire()
+        with torch.cuda.device(dev):
+            rc = L.pd_conv_bf16_wgrad_grouped(ctypes.byref(descs), len(part), host.data_ptr(), _Deferred.table_dev.data_ptr(), ws.data_ptr(),
+                                              ws.numel(), _stream())
+        _Deferred.ring.release()
+        _lib.check(rc)
+
+
 class Conv2dOwnWgrad(Function):
     """bias-free bf16 NHWC convolution whose FILTER gradient is pd_conv_bf16_wgrad (forward and input gradient: the library's).
     Measured on the 52 such convolutions of R50 at 2 x 1024^2 (tools/bench_r50_convs.py): filter gradients 1.55 ms against
@@ -96,7 +160,13 @@ class Conv2dOwnWgrad(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.ops.aten.convolution_backward(dz, x, weight, None, [s, s], [p, p], [1, 1], False, [0, 0], 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(dz, x, weight.shape[2], s, p, like=weight)
+            if _Deferred.active:
+                dw = torch.empty_strided(weight.shape, weight.stride(), dtype=torch.bfloat16, device=x.device)   # written by flush()
+                # only the ADDRESS is kept: with a second reference alive autograd's AccumulateGrad would not adopt this tensor
+                # as .grad but clone it (unwritten) — the adopted tensor keeps the storage alive until the flush
+                _Deferred.queue.append((dz, x, dw.data_ptr(), weight.shape[2], s, p))
+            else:
+                dw = conv_wgrad(dz, x, weight.shape[2], s, p, like=weight)
         return dx, dw, None, None
 
 

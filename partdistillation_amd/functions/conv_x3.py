@@ -70,3 +70,45 @@ class Conv3x3X3(Function):
 
 def conv3x3(x, weight, bias=None):
     return Conv3x3X3.apply(x, weight, bias)
+
+
+class Conv1x1OwnWgrad(Function):
+    """fp32 1 x 1 convolution on channels-last maps whose filter / bias gradient is the transpose-read split GEMM on the NHWC rows
+    (pd_gemm_wgrad_acc_f32x3_ws: dW = dY^T X, dB = column sums of dY in the same pass); forward and input gradient: the library's.
+    The pixel decoder's input projections, lateral and mask-feature convolutions (reference msdeformattn.py:200-257)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.ops.aten.convolution(x, weight, bias, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .gemm import gemm_wgrad_acc
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        co, ci = weight.shape[0], weight.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if want_w or want_b:
+            buf = torch.zeros(co * ci + co, dtype=torch.float32, device=x.device)
+            dw2, dbv = buf[:co * ci].view(co, ci), buf[co * ci:]
+            rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])          # NHWC storage -> [pixels, channels] view
+            gemm_wgrad_acc(rows(dy), rows(x), dw2, dbv if want_b else None, x3=True)
+            dw = dw2.view(co, ci, 1, 1).as_strided(weight.shape, weight.stride()) if want_w else None
+            db = dbv if want_b else None
+        return dx, dw, db
+
+
+def conv1x1_supported(x, conv):
+    return (WGRAD_X3 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.weight.dtype == torch.float32
+            and tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (0, 0)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and x.shape[1] % 4 == 0 and conv.weight.shape[0] % 4 == 0
+            and x.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled())
+
+
+def conv1x1(x, weight, bias=None):
+    return Conv1x1OwnWgrad.apply(x, weight, bias)

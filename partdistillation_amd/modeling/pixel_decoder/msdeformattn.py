@@ -182,6 +182,8 @@ def _conv_gn(conv, gn, x, relu=False):
     (functions/fused.py), so the maps stay NHWC from the backbone to the encoder tokens with no layout copies."""
     if CONV_X3 and conv_x3.supported(x, conv):
         y = conv_x3.conv3x3(x, conv.weight, conv.bias)       # 3 x 3 FPN convolution: fp32-level results on the bf16 matrix cores
+    elif CONV_X3 and conv_x3.conv1x1_supported(x, conv):
+        y = conv_x3.conv1x1(x, conv.weight, conv.bias)       # library forward / input gradient, split-GEMM filter gradient
     else:
         y = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
     if isinstance(gn, nn.GroupNorm) and group_norm_nhwc_supported(y, gn.num_groups):
@@ -276,4 +278,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                     y = cur + F.interpolate(out[-1], size=cur.shape[-2:], mode="bilinear", align_corners=False)
                 out.append(_conv_gn(outc, outc.norm, y, relu=outc.activation is not None))
             multi_scale = out[: self.maskformer_num_feature_levels]
-            return self.mask_features(out[-1]), out[0], multi_scale
+            mf = self.mask_features
+            if CONV_X3 and mf.norm is None and mf.activation is None and conv_x3.conv1x1_supported(out[-1], mf):
+                return conv_x3.conv1x1(out[-1], mf.weight, mf.bias), out[0], multi_scale
+            return mf(out[-1]), out[0], multi_scale

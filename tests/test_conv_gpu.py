@@ -77,6 +77,36 @@ def test_conv_wgrad_vs_torch_fp32(ci, co, k, s, H, W, B):
     assert err < 2 ** -7, err                                        # one bf16 rounding of an fp32-accumulated sum
 
 
+def test_deferred_grouped_wgrads_equal_the_immediate_ones():
+    """Conv2dOwnWgrad inside deferred_wgrads(): backward hands out unwritten filter gradients and ONE grouped launch per tile shape
+    fills them at flush() — all four tile shapes, strides, ragged pixel counts, two uses of the context in a row."""
+    from partdistillation_amd.functions import conv_bf16 as C
+    geoms = [(64, 64, 1, 1, 24, 40, 2), (64, 256, 1, 1, 24, 40, 2), (256, 64, 1, 1, 17, 23, 3), (64, 64, 3, 1, 24, 40, 2),
+             (128, 128, 3, 2, 23, 41, 1), (256, 512, 1, 2, 23, 41, 1), (512, 512, 3, 1, 6, 5, 2), (2048, 512, 1, 1, 6, 5, 2)]
+    for rep in range(2):
+        xs, ws, ys, gs = [], [], [], []
+        for i, (ci, co, k, s, H, W, B) in enumerate(geoms):
+            x = _mk((B, ci, H, W), 10 * rep + i).requires_grad_(True)
+            w = _mk((co, ci, k, k), 100 + i, 0.05).requires_grad_(True)
+            assert C.own_wgrad_supported(x, w, (s, s), (k // 2, k // 2))
+            y = C.conv2d_own_wgrad(x, w, (s, s), (k // 2, k // 2))
+            xs.append(x), ws.append(w), ys.append(y), gs.append(_mk(y.shape, 200 + i))
+        total = sum((y.float() * g.float()).sum() for y, g in zip(ys, gs))
+        with C.deferred_wgrads():
+            total.backward()
+            assert len(C._Deferred.queue) == len(geoms)
+        assert not C._Deferred.queue and not C._Deferred.active
+        for (ci, co, k, s, H, W, B), x, w, g in zip(geoms, xs, ws, gs):
+            wf = w.detach().float().requires_grad_(True)
+            xf = x.detach().float().requires_grad_(True)
+            rx, rw = torch.autograd.grad(F.conv2d(xf, wf, None, s, k // 2), (xf, wf), g.float())
+            assert w.grad.stride() == w.stride()
+            assert (w.grad.float() - rw).abs().max().item() / rw.abs().max().item() < 2 ** -7
+            assert (x.grad.float() - rx).abs().max().item() / rx.abs().max().item() < 2 ** -6
+            imm = C.conv_wgrad(g, x.detach(), k, s, k // 2, like=w)
+            assert (w.grad.float() - imm.float()).abs().max().item() / rw.abs().max().item() < 2 ** -7
+
+
 def test_conv_rejects_what_it_does_not_cover():
     from partdistillation_amd import lib
     from partdistillation_amd.functions import conv_bf16 as C
