@@ -42,6 +42,19 @@ int64_t pd_sgemm_wgrad_split_workspace(int M, int N, int K);
 int pd_sgemm_wgrad_split_bf16(const void *dY, const void *X, void *dW, float *dB, float *workspace, int M, int N, int K, int ldy,
                               int ldx, int ldw, void *stream);
 
+/* MANY pd_sgemm_wgrad_bf16 problems as one launch (the decoder's backward pass queues its ~70 weight gradients and runs them at
+ * its end: a single one is a 7 us launch on a handful of CUs).  descs: host array; table_host_pinned / table_device: caller-
+ * provided staging of pd_sgemm_wgrad_grouped_table_bytes(count) bytes each — the function fills the pinned one, copies it with
+ * an asynchronous memcpy on `stream`, launches; the pinned buffer must stay untouched until the copy has executed. */
+typedef struct PdSgemmWgradDesc {
+  const void *dY, *X;
+  void *dW;
+  float *dB;
+  int32_t M, N, K, ldy, ldx, ldw;
+} PdSgemmWgradDesc;
+int64_t pd_sgemm_wgrad_grouped_table_bytes(int count);
+int pd_sgemm_wgrad_grouped_bf16(const PdSgemmWgradDesc *descs, int count, void *table_host_pinned, void *table_device, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

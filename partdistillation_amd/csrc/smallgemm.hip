@@ -156,13 +156,13 @@ __global__ __launch_bounds__(256) void sgemm_nn(const bf16_t *__restrict__ dY, c
 }
 
 // ------------------------------------------------------------------------------------------------ dW = dY^T X
-__global__ __launch_bounds__(256) void sgemm_wgrad(const bf16_t *__restrict__ dY, const bf16_t *__restrict__ X,
-                                                   bf16_t *__restrict__ dW, float *__restrict__ dB, int M, int N, int K, int ldy,
-                                                   int ldx, int ldw)
+__device__ __forceinline__ void sgemm_wgrad_body(const bf16_t *__restrict__ dY, const bf16_t *__restrict__ X,
+                                                 bf16_t *__restrict__ dW, float *__restrict__ dB, int M, int N, int K, int ldy,
+                                                 int ldx, int ldw, int bx, int by)
 {
   __shared__ __attribute__((aligned(16))) bf16_t Ys[2][64][P32];
   __shared__ __attribute__((aligned(16))) bf16_t Xs[2][64][P128];
-  const int kb = blockIdx.x * 128, nb = blockIdx.y * 32;
+  const int kb = bx * 128, nb = by * 32;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int yrow = tid >> 2, ycol = (tid & 3) * 8;                          // dY chunk: 64 rows x 4 pieces
   const int xrow = tid >> 4, xcol = (tid & 15) * 8;                         // X chunk: 64 rows x 16 pieces, 4 per thread
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void sgemm_wgrad(const bf16_t *__restrict__ dY
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  const bool do_bias = dB != nullptr && blockIdx.x == 0 && wave == 0;      // the k-tile-0 workgroup also sums its dY columns
+  const bool do_bias = dB != nullptr && bx == 0 && wave == 0;              // the k-tile-0 workgroup also sums its dY columns
   float bsum = 0.f;
   const int nchunk = (M + 63) / 64;
   if (nchunk > 0) { gload(0); lstore(0); }
@@ -209,6 +209,29 @@ __global__ __launch_bounds__(256) void sgemm_wgrad(const bf16_t *__restrict__ dY
     const int n = nb + (e & 3) + 8 * (e >> 2) + 4 * hh;
     if (n < N) dW[(int64_t)n * ldw + k] = (bf16_t)(pk_bf16(acc[e], 0.f) & 0xffffu);
   }
+}
+
+__global__ __launch_bounds__(256) void sgemm_wgrad(const bf16_t *__restrict__ dY, const bf16_t *__restrict__ X,
+                                                   bf16_t *__restrict__ dW, float *__restrict__ dB, int M, int N, int K, int ldy,
+                                                   int ldx, int ldw)
+{
+  sgemm_wgrad_body(dY, X, dW, dB, M, N, K, ldy, ldx, ldw, blockIdx.x, blockIdx.y);
+}
+
+// GROUPED: the ~70 weight gradients of the decoder's backward pass (each a 7 us launch over 200 rows) as ONE launch over a table
+struct SgWgradProblem {
+  const bf16_t *dY, *X;
+  bf16_t *dW;
+  float *dB;
+  int M, N, K, ldy, ldx, ldw, gx, block_begin;
+};
+__global__ __launch_bounds__(256) void sgemm_wgrad_grouped(const SgWgradProblem *__restrict__ tab, int count)
+{
+  int p = 0;
+  while (p + 1 < count && tab[p + 1].block_begin <= (int)blockIdx.x) ++p;
+  const SgWgradProblem &q = tab[p];
+  const int local = blockIdx.x - q.block_begin;
+  sgemm_wgrad_body(q.dY, q.X, q.dW, q.dB, q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, local % q.gx, local / q.gx);
 }
 
 // ------------------------------------------------------------------------------------------------ dW = dY^T X, many rows
@@ -409,3 +432,33 @@ extern "C" int pd_sgemm_wgrad_split_bf16(const void *dY, const void *X, void *dW
   return pd_check_launch("pd_sgemm_wgrad_split_bf16");
 }
 
+
+extern "C" int64_t pd_sgemm_wgrad_grouped_table_bytes(int count) { return (int64_t)count * (int64_t)sizeof(SgWgradProblem); }
+
+extern "C" int pd_sgemm_wgrad_grouped_bf16(const PdSgemmWgradDesc *descs, int count, void *table_host_pinned, void *table_device,
+                                           void *stream_)
+{
+  if (count < 0 || (count > 0 && (!descs || !table_host_pinned || !table_device)))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_wgrad_grouped_bf16: null pointer / negative count");
+  if (count == 0) return PD_OK;
+  SgWgradProblem *tab = reinterpret_cast<SgWgradProblem *>(table_host_pinned);
+  int blocks = 0, n = 0;
+  for (int i = 0; i < count; ++i) {
+    const PdSgemmWgradDesc &d = descs[i];
+    int rc = check_common("pd_sgemm_wgrad_grouped_bf16", d.M > 0 ? d.dY : d.dW, d.M > 0 ? d.X : d.dW, d.dW, d.M, d.N, d.K, d.ldy, d.ldx, 8);
+    if (rc) return rc;
+    if ((d.N & 3) || (d.K & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_wgrad_grouped_bf16: N=%d and K=%d must be multiples of 4", d.N, d.K);
+    if (d.N == 0 || d.K == 0) continue;
+    SgWgradProblem &q = tab[n++];
+    q.dY = (const bf16_t *)d.dY; q.X = (const bf16_t *)d.X; q.dW = (bf16_t *)d.dW; q.dB = d.dB;
+    q.M = d.M; q.N = d.N; q.K = d.K; q.ldy = d.ldy; q.ldx = d.ldx; q.ldw = d.ldw;
+    q.gx = (d.K + 127) / 128; q.block_begin = blocks;
+    blocks += q.gx * ((d.N + 31) / 32);
+  }
+  if (n == 0) return PD_OK;
+  hipStream_t st = (hipStream_t)stream_;
+  if (hipMemcpyAsync(table_device, table_host_pinned, (size_t)n * sizeof(SgWgradProblem), hipMemcpyHostToDevice, st) != hipSuccess)
+    return pd_set_error(PD_ERR_LAUNCH, "pd_sgemm_wgrad_grouped_bf16: table upload failed");
+  hipLaunchKernelGGL(sgemm_wgrad_grouped, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const SgWgradProblem *>(table_device), n);
+  return pd_check_launch("pd_sgemm_wgrad_grouped_bf16");
+}

@@ -73,14 +73,20 @@ def _dgrad(dy, w, relu_ref=None, out=None, accumulate=False):
     return dx
 
 
-def _wgrad(dy, x, out=None, bias_acc=None):
-    """dy^T x -> out (weight gradient);  bias_acc (fp32 accumulator slot, zero on entry) += dy.sum(0)"""
+def _wgrad(dy, x, out=None, bias_acc=None, queue=None):
+    """dy^T x -> out (weight gradient);  bias_acc (fp32 accumulator slot, zero on entry) += dy.sum(0).
+    queue (sg.WgradQueue): the small-row case is only QUEUED there — the backward pass runs all of them as one launch at its end."""
     if _small(dy, dy.dtype, SMALL_M_WGRAD):
+        if queue is not None:
+            return queue.add(dy, x, out, bias_acc)
         return sg.wgrad(dy, x, out, bias_acc)
     dw = torch.mm(dy.t(), x) if out is None else torch.mm(dy.t(), x, out=out)
     if bias_acc is not None:
         rw.colsum_acc(dy, bias_acc)
     return dw
+
+
+GROUP_WGRADS = True   # False: one launch per weight gradient (tools/ comparisons)
 
 
 class _Acc:
@@ -204,6 +210,7 @@ class DecoderCore(Function):
         dmem: List = [None] * nl
         dmempos: List = [None] * nl
         wgrads = [None] * L
+        wq = sg.WgradQueue() if GROUP_WGRADS else None                       # the ~8 weight gradients per layer: one launch at the end
         d_res = d_final.contiguous() if d_final is not None else None        # fp32 gradient w.r.t. the residual stream
         d_pos_c = None                                                       # GEMM-dtype gradient w.r.t. (tgt + query_pos)
         for i in reversed(range(L)):
@@ -218,21 +225,21 @@ class DecoderCore(Function):
             dz, dz_c = rw.add_ln_bwd(z, mean, rstd, fnw, dy=dzh, dy2=d_res, dypos_c=d_pos_c, dz_c_dtype=cdt,
                                      dgamma=A(lay[i]["fnw"]), dbeta=A(lay[i]["fnb"]), dbias=A(lay[i]["b2"]),
                                      dpos_acc=A(s_pos) if d_pos_c is not None else None, pos_div=B, out=dzh)
-            g_w2 = _wgrad(dz_c, h)
+            g_w2 = _wgrad(dz_c, h, queue=wq)
             dh = _dgrad(dz_c, w2, relu_ref=h)                    # through the ReLU: dh *= (h > 0)
-            g_w1 = _wgrad(dh, x_c, bias_acc=A(lay[i]["b1"]))
+            g_w1 = _wgrad(dh, x_c, bias_acc=A(lay[i]["b1"]), queue=wq)
             dx_c = _dgrad(dh, w1)
             # ---- self-attention
             tp_c, t_c, q, k, v, o, lse, z, mean, rstd = slf
             dz, dz_c = rw.add_ln_bwd(z, mean, rstd, snw, dy=dz, dy_c=dx_c, dz_c_dtype=cdt, dgamma=A(lay[i]["snw"]),
                                      dbeta=A(lay[i]["snb"]), dbias=A(lay[i]["sob"]), out=dz)
-            g_sow = _wgrad(dz_c, o)
+            g_sow = _wgrad(dz_c, o, queue=wq)
             dq, dk, dv = attn_bwd_raw(q, k, v, None, o, _dgrad(dz_c, sow), lse, B, H, scale)
             g_siw = torch.empty_like(siw)
             sb = A(lay[i]["sib"])
-            _wgrad(dq, tp_c, g_siw[:C], sb[:C])
-            _wgrad(dk, tp_c, g_siw[C:2 * C], sb[C:2 * C])
-            _wgrad(dv, t_c, g_siw[2 * C:], sb[2 * C:])
+            _wgrad(dq, tp_c, g_siw[:C], sb[:C], queue=wq)
+            _wgrad(dk, tp_c, g_siw[C:2 * C], sb[C:2 * C], queue=wq)
+            _wgrad(dv, t_c, g_siw[2 * C:], sb[2 * C:], queue=wq)
             d_tp = _dgrad(dq, siw[:C])
             _dgrad(dk, siw[C:2 * C], out=d_tp, accumulate=True)
             d_tc = _dgrad(dv, siw[2 * C:])
@@ -241,13 +248,13 @@ class DecoderCore(Function):
             dz, dz_c = rw.add_ln_bwd(z, mean, rstd, cnw, dy=dz, dy_c=d_tc, dypos_c=d_tp, dz_c_dtype=cdt,
                                      dgamma=A(lay[i]["cnw"]), dbeta=A(lay[i]["cnb"]), dbias=A(lay[i]["cob"]),
                                      dpos_acc=A(s_pos), pos_div=B, out=dz)
-            g_cow = _wgrad(dz_c, o)
+            g_cow = _wgrad(dz_c, o, queue=wq)
             dq, dk, dv = attn_bwd_raw(q, k, v, mask, o, _dgrad(dz_c, cow), lse, B, H, scale)
             g_ciw = torch.empty_like(ciw)
             cb = A(lay[i]["cib"])
-            _wgrad(dq, tp_c, g_ciw[:C], cb[:C])
-            _wgrad(dk, ctx.mempos[lvl], g_ciw[C:2 * C], cb[C:2 * C])
-            _wgrad(dv, ctx.mem[lvl], g_ciw[2 * C:], cb[2 * C:])
+            _wgrad(dq, tp_c, g_ciw[:C], cb[:C], queue=wq)
+            _wgrad(dk, ctx.mempos[lvl], g_ciw[C:2 * C], cb[C:2 * C], queue=wq)
+            _wgrad(dv, ctx.mem[lvl], g_ciw[2 * C:], cb[2 * C:], queue=wq)
             d_pos_c = _dgrad(dq, ciw[:C])                                     # -> previous layer's FFN norm (or the queries)
             if dmempos[lvl] is None:
                 dmempos[lvl] = _dgrad(dk, ciw[C:2 * C])
@@ -278,6 +285,8 @@ class DecoderCore(Function):
             if need_x[l]:
                 d_xs[l] = dtok.view(B, Hh, Ww, C).permute(0, 3, 1, 2)
 
+        if wq is not None:
+            wq.run()                                                         # before the bias accumulators below are read
         bias_c = buf[:n_bias] if layers[0][1].dtype == torch.float32 else buf[:n_bias].to(layers[0][1].dtype)
 
         def Bc(s):

@@ -1,5 +1,7 @@
 """ctypes faces of the skinny-activation bf16 GEMMs (include/pd_smallgemm.h).  Raw functions, no autograd: building
 blocks of the hand-written decoder backward (functions/decoder_core.py).  GPU only; there is no fallback."""
+import ctypes
+
 import torch
 
 from .. import lib as _lib
@@ -73,3 +75,55 @@ def wgrad_split(dy, x, want_bias=True):
                                            M, N, K, dy.stride(0), x.stride(0), dw.stride(0), _stream()))
     return dw, db
 
+
+
+class _WgradDesc(ctypes.Structure):                                  # PdSgemmWgradDesc (include/pd_smallgemm.h)
+    _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("dB", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ("M", "N", "K", "ldy", "ldx", "ldw")]
+
+
+class WgradQueue:
+    """weight gradients of one backward pass collected and run as ONE launch (pd_sgemm_wgrad_grouped_bf16).  add() allocates the
+    output and keeps the operands alive; run() launches and forgets them.  Same arithmetic as wgrad()."""
+    MAXP = 128
+    _ring = None
+    _table_dev = {}
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, dy, x, out=None, bias_out=None):
+        _chk2d(dy, x)
+        M, N = dy.shape
+        K = x.shape[1]
+        dw = out if out is not None else torch.empty((N, K), dtype=torch.bfloat16, device=dy.device)
+        assert dw.stride(1) == 1 and (bias_out is None or (bias_out.dtype == torch.float32 and bias_out.numel() == N))
+        self.items.append((dy, x, dw, bias_out))
+        return dw
+
+    def run(self):
+        items, self.items = self.items, []
+        if not items:
+            return
+        L = _lib.load()
+        dev = items[0][0].device
+        cls = WgradQueue
+        for lo in range(0, len(items), cls.MAXP):
+            part = items[lo:lo + cls.MAXP]
+            descs = (_WgradDesc * len(part))()
+            for d, (dy, x, dw, db) in zip(descs, part):
+                d.dY, d.X, d.dW, d.dB = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
+                d.M, d.N, d.K = dy.shape[0], dy.shape[1], x.shape[1]
+                d.ldy, d.ldx, d.ldw = dy.stride(0), x.stride(0), dw.stride(0)
+            tbytes = int(L.pd_sgemm_wgrad_grouped_table_bytes(cls.MAXP))
+            if cls._ring is None:
+                from .fused import PinnedRing
+                cls._ring = PinnedRing(tbytes, torch.uint8, pin=True)
+            tab = cls._table_dev.get(str(dev))
+            if tab is None:
+                tab = cls._table_dev[str(dev)] = torch.empty(tbytes, dtype=torch.uint8, device=dev)
+            host = cls._ring.acquire()
+            with torch.cuda.device(dev):
+                rc = L.pd_sgemm_wgrad_grouped_bf16(ctypes.byref(descs), len(part), host.data_ptr(), tab.data_ptr(), _stream())
+            cls._ring.release()
+            _lib.check(rc)

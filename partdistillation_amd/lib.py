@@ -93,6 +93,8 @@ SIGNATURES = {
     "pd_resample_rows_u8": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp] * 3 + [_c_int, _c_int, _c_vp, _c_vp]),
     "pd_resample_cols_u8": (_c_int, [_c_vp] + [_c_int] * 3 + [_c_vp] * 3 + [_c_int] * 5 + [_c_vp, _c_vp]),
     "pd_rle_sample_u8": (_c_int, [_c_vp, _c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 3 + [_c_vp, _c_vp, _c_vp]),
+    "pd_sgemm_wgrad_grouped_table_bytes": (ctypes.c_int64, [_c_int]),
+    "pd_sgemm_wgrad_grouped_bf16": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp]),
     "pd_sgemm_wgrad_split_workspace": (ctypes.c_int64, [_c_int] * 3),
     "pd_sgemm_wgrad_split_bf16": (_c_int, [_c_vp] * 5 + [_c_int] * 6 + [_c_vp]),
     "pd_last_error": (ctypes.c_char_p, []),
