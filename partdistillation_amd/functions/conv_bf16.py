@@ -85,7 +85,7 @@ class _Desc(ctypes.Structure):                                      # PdConvWgra
 
 
 class _Deferred:
-    """filter gradients queued by Conv2dOwnWgrad.backward while `deferred_wgrads()` is active: (dz, x, address of dw, k, stride, pad)"""
+    """filter gradients queued by Conv2dOwnWgrad.backward while `deferred_wgrads()` is active: ((dz, x) kept alive, their addresses, the address of dw, geometry)"""
     active = False
     queue = []
     ring = None
@@ -108,20 +108,41 @@ def deferred_wgrads():
         flush()
 
 
+def rows_entry(dy, x, dw):
+    """queue entry for dw[N,K] = dy[M,N]^T x[M,K] (bf16 row-major, N % 8 == K % 8 == 0, dw rows K apart): a 1 x 1 "convolution" over
+    M pixels — the decoder's key / value projection weight gradients (M = 10^3..10^5 memory tokens) ride in the same grouped launch"""
+    M, N = dy.shape
+    K = x.shape[1]
+    assert dy.dtype == x.dtype == dw.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous() and dw.stride(0) == K
+    return ((dy, x), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (1, M, 1, K, M, 1, N, 1, 1, 0))
+
+
+def submit(entries):
+    """run these filter-gradient problems: with the deferred queue active they join it, otherwise one grouped launch now"""
+    if not entries:
+        return
+    if _Deferred.active:
+        _Deferred.queue.extend(entries)
+    else:
+        _run(entries)
+
+
 def flush():
     q, _Deferred.queue = _Deferred.queue, []
+    _run(q)
+
+
+def _run(q):
     if not q:
         return
-    dev = q[0][0].device
+    dev = q[0][0][0].device
     L = _lib.load()
     for lo in range(0, len(q), _Deferred.MAXP):
         part = q[lo:lo + _Deferred.MAXP]
         descs = (_Desc * len(part))()
-        for d, (dz, x, dw, k, s, p) in zip(descs, part):
-            d.dz, d.x, d.dw = dz.data_ptr(), x.data_ptr(), dw
-            d.batch, d.ci, d.hi, d.wi = x.shape
-            d.co, d.ho, d.wo = dz.shape[1], dz.shape[2], dz.shape[3]
-            d.k, d.stride, d.pad = k, s, p
+        for d, (_keep, dzp, xp, dwp, geom) in zip(descs, part):
+            d.dz, d.x, d.dw = dzp, xp, dwp
+            d.batch, d.hi, d.wi, d.ci, d.ho, d.wo, d.co, d.k, d.stride, d.pad = geom
         need = int(L.pd_conv_bf16_wgrad_grouped_workspace_floats(ctypes.byref(descs), len(part)))
         ws = _WS.get(str(dev))
         if ws is None or ws.numel() < need:
@@ -164,7 +185,9 @@ class Conv2dOwnWgrad(Function):
                 dw = torch.empty_strided(weight.shape, weight.stride(), dtype=torch.bfloat16, device=x.device)   # written by flush()
                 # only the ADDRESS is kept: with a second reference alive autograd's AccumulateGrad would not adopt this tensor
                 # as .grad but clone it (unwritten) — the adopted tensor keeps the storage alive until the flush
-                _Deferred.queue.append((dz, x, dw.data_ptr(), weight.shape[2], s, p))
+                B, ci, H, W = x.shape
+                _Deferred.queue.append(((dz, x), dz.data_ptr(), x.data_ptr(), dw.data_ptr(),
+                                        (B, H, W, ci, dz.shape[2], dz.shape[3], dz.shape[1], weight.shape[2], s, p)))
             else:
                 dw = conv_wgrad(dz, x, weight.shape[2], s, p, like=weight)
         return dx, dw, None, None

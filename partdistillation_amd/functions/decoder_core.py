@@ -23,6 +23,7 @@ import torch
 from torch.autograd import Function
 
 from . import rowwise as rw
+from . import conv_bf16
 from . import smallgemm as sg
 from .attention import attn_bwd_raw, attn_fwd_raw
 
@@ -73,13 +74,23 @@ def _dgrad(dy, w, relu_ref=None, out=None, accumulate=False):
     return dx
 
 
-def _wgrad(dy, x, out=None, bias_acc=None, queue=None):
+def _wgrad(dy, x, out=None, bias_acc=None, queue=None, big=None):
     """dy^T x -> out (weight gradient);  bias_acc (fp32 accumulator slot, zero on entry) += dy.sum(0).
     queue (sg.WgradQueue): the small-row case is only QUEUED there — the backward pass runs all of them as one launch at its end."""
     if _small(dy, dy.dtype, SMALL_M_WGRAD):
         if queue is not None:
             return queue.add(dy, x, out, bias_acc)
         return sg.wgrad(dy, x, out, bias_acc)
+    if big is not None and dy.dtype == torch.bfloat16 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and dy.is_contiguous() \
+            and x.is_contiguous():
+        # many rows (key / value projections of the memory tokens): the transpose-read filter-gradient kernel of the backbone
+        # (1 x 1 "convolution" over the tokens), queued for the grouped launch — the library's kernel for [256, 32768] x [32768, 256]
+        # takes 114 us
+        dw = out if out is not None else torch.empty((dy.shape[1], x.shape[1]), dtype=torch.bfloat16, device=dy.device)
+        big.append(conv_bf16.rows_entry(dy, x, dw))
+        if bias_acc is not None:
+            rw.colsum_acc(dy, bias_acc)
+        return dw
     dw = torch.mm(dy.t(), x) if out is None else torch.mm(dy.t(), x, out=out)
     if bias_acc is not None:
         rw.colsum_acc(dy, bias_acc)
@@ -211,6 +222,7 @@ class DecoderCore(Function):
         dmempos: List = [None] * nl
         wgrads = [None] * L
         wq = sg.WgradQueue() if GROUP_WGRADS else None                       # the ~8 weight gradients per layer: one launch at the end
+        big = [] if GROUP_WGRADS else None                                   # ... and the two over the memory tokens: conv_bf16's group
         d_res = d_final.contiguous() if d_final is not None else None        # fp32 gradient w.r.t. the residual stream
         d_pos_c = None                                                       # GEMM-dtype gradient w.r.t. (tgt + query_pos)
         for i in reversed(range(L)):
@@ -253,8 +265,8 @@ class DecoderCore(Function):
             g_ciw = torch.empty_like(ciw)
             cb = A(lay[i]["cib"])
             _wgrad(dq, tp_c, g_ciw[:C], cb[:C], queue=wq)
-            _wgrad(dk, ctx.mempos[lvl], g_ciw[C:2 * C], cb[C:2 * C], queue=wq)
-            _wgrad(dv, ctx.mem[lvl], g_ciw[2 * C:], cb[2 * C:], queue=wq)
+            _wgrad(dk, ctx.mempos[lvl], g_ciw[C:2 * C], cb[C:2 * C], queue=wq, big=big)
+            _wgrad(dv, ctx.mem[lvl], g_ciw[2 * C:], cb[2 * C:], queue=wq, big=big)
             d_pos_c = _dgrad(dq, ciw[:C])                                     # -> previous layer's FFN norm (or the queries)
             if dmempos[lvl] is None:
                 dmempos[lvl] = _dgrad(dk, ciw[C:2 * C])
@@ -287,6 +299,7 @@ class DecoderCore(Function):
 
         if wq is not None:
             wq.run()                                                         # before the bias accumulators below are read
+            conv_bf16.submit(big)                                            # joins the backbone's deferred group when that is active
         bias_c = buf[:n_bias] if layers[0][1].dtype == torch.float32 else buf[:n_bias].to(layers[0][1].dtype)
 
         def Bc(s):

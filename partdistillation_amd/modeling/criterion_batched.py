@@ -29,6 +29,33 @@ class LossDict(dict):
     total = None
 
 
+class _TokensTimesRows(torch.autograd.Function):
+    """tok [hw, C] @ rows[n, C]^T -> [hw, n] (fp32): the mask logits of the n matched queries of an image.  The gradient of `rows`
+    contracts over the hw = 65 536 tokens into an [n, C] result — the shape the library serves with a 260 us kernel (2 x per step);
+    here it is the transpose-read split GEMM of the encoder's weight gradients (functions/gemm.py: 30 us)."""
+
+    @staticmethod
+    def forward(ctx, tok, rows):
+        ctx.save_for_backward(tok, rows)
+        return tok @ rows.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..functions.gemm import gemm_wgrad
+        tok, rows = ctx.saved_tensors
+        g = g.contiguous()
+        d_tok = g @ rows if ctx.needs_input_grad[0] else None
+        d_rows = gemm_wgrad(g, tok) if ctx.needs_input_grad[1] else None        # g^T tok
+        return d_tok, d_rows
+
+
+def _tokens_times_rows(tok, rows):
+    if tok.is_cuda and tok.dtype == torch.float32 and rows.dtype == torch.float32 and rows.shape[0] % 4 == 0 and tok.shape[1] % 4 == 0 \
+            and tok.stride(1) == 1 and torch.is_grad_enabled():
+        return _TokensTimesRows.apply(tok, rows)
+    return tok @ rows.t()
+
+
 _SEL_CACHE = {}
 
 
@@ -163,7 +190,7 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
             # [hw, C] @ [C, n_b]: with channels-last mask features the operand is read in place and its gradient comes
             # back channels-last, the layout the 1x1 mask_features convolution's backward wants
             mf_tok = mfeat.float().permute(0, 2, 3, 1).reshape(B, -1, mfeat.shape[1])            # [B, hw, C]
-            parts = [(mf_tok[b] @ e_sel[per_image[b]].t()).t() for b in range(B) if per_image[b].numel()]
+            parts = [_tokens_times_rows(mf_tok[b], e_sel[per_image[b]]).t() for b in range(B) if per_image[b].numel()]
             src = torch.cat(parts)[inv_img].view(-1, 1, *mfeat.shape[-2:])                       # [N,1,h,w]
         else:
             src = masks_bd[sel_b, sel_d, q_idx][:, None].float()                                 # [N,1,h,w]
