@@ -11,7 +11,8 @@ import torch
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from ...functions import smallgemm
+from ...functions import conv_bf16, smallgemm
+from ...functions import rowwise as _rw
 from ...functions import swin_rows as rows
 from ...functions import window_attention as wattn
 
@@ -35,11 +36,26 @@ def _bf(t):
     return t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)
 
 
-def _wgrad(dy, x, w, b):
-    """weight + bias gradient of a Linear over all tokens of the stage, in the parameters' dtypes.  Small [N, K] outputs
-    (few tiles, every one walking 10^4..10^5 rows) go to the split-rows matrix-core kernel of include/pd_smallgemm.h —
-    measured 2.5-3x the library at K <= 256, break-even at N*K ~ 1 M (tools/bench_wgrad_split.py); larger outputs
-    have enough tiles for the library GEMM."""
+TR_WGRAD = False     # True: weight gradients through the transpose-read kernel of csrc/conv_bf16.hip (a Linear over the stage's tokens = a
+                     # 1 x 1 convolution over pixels), queued for the step's grouped launch.  Measured on config 3 (Swin-B, 2 x 1024^2):
+                     # 51.8 ms per step against 49.8 with the split-rows / library kernels below — that kernel is built for the
+                     # HBM-bound filter gradients of R50 (N K / (N + K) <= 64 flop per byte); 18 of Swin-B's 24 blocks have
+                     # 1536 x 512 .. 2048 x 512 outputs over 8 192 tokens, which are compute-bound.
+
+
+def _wgrad(dy, x, w, b, big=None):
+    """weight + bias gradient of a Linear over all tokens of the stage, in the parameters' dtypes.  bf16 parameters (the training
+    configuration): the weight gradient is queued in `big` for conv_bf16's grouped transpose-read launch, the bias gradient is a
+    column sum.  Otherwise: small [N, K] outputs (few tiles, every one walking 10^4..10^5 rows) go to the split-rows matrix-core
+    kernel of include/pd_smallgemm.h — measured 2.5-3x the library at K <= 256, break-even at N*K ~ 1 M
+    (tools/bench_wgrad_split.py); larger outputs have enough tiles for the library GEMM."""
+    if (big is not None and w.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.is_contiguous()
+            and x.is_contiguous() and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0):
+        dw = torch.empty((dy.shape[1], x.shape[1]), dtype=torch.bfloat16, device=dy.device)
+        big.append(conv_bf16.rows_entry(dy, x, dw))
+        db = torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device)
+        _rw.colsum_acc(dy, db)
+        return dw, (db if db.dtype == b.dtype else db.to(b.dtype))
     if w.shape[0] * w.shape[1] <= 1_100_000:
         dw, db = smallgemm.wgrad_split(dy, x, True)
     else:
@@ -95,6 +111,7 @@ class SwinStage(Function):
         df = (dsup.view(B, L, C) * last.view(B, 1, 1) if last is not None else dsup).to(torch.bfloat16).view(B * L, C)
         norm_g = torch.zeros((depth, 4, C), dtype=torch.float32, device=dev)       # dgamma1, dbeta1, dgamma2, dbeta2
         grads = [None] * (depth * N_BLOCK)
+        big = [] if TR_WGRAD else None
 
         for k in reversed(range(depth)):
             n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = params[k * N_BLOCK:(k + 1) * N_BLOCK]
@@ -105,27 +122,29 @@ class SwinStage(Function):
             g = grads[k * N_BLOCK:(k + 1) * N_BLOCK]
             # MLP
             da = torch.mm(df, _bf(f2w))
-            g[11], g[12] = _wgrad(df, a, f2w, f2b)
+            g[11], g[12] = _wgrad(df, a, f2w, f2b, big)
             dh = torch.ops.aten.gelu_backward(da, h)
             dy2 = torch.mm(dh, _bf(f1w))
-            g[9], g[10] = _wgrad(dh, y2, f1w, f1b)
+            g[9], g[10] = _wgrad(dh, y2, f1w, f1b, big)
             # LayerNorm 2 + the residual it sits on; gradient of the (window-major) proj output rides out as `dr`
             sc1 = dp[k, 0] if dp is not None else None
             ds2, dpo = rows.ln_bwd(dy2, None, L, dsup, s2, st2, n2w, True, ymap, S, sc1, zero, norm_g[k, 2], norm_g[k, 3], B, L)
             dao = torch.mm(dpo, _bf(pw))
-            g[5], g[6] = _wgrad(dpo, ao.view(-1, C), pw, pb)
+            g[5], g[6] = _wgrad(dpo, ao.view(-1, C), pw, pb, big)
             dqkv, dtable = wattn.bwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table.contiguous(), regions, ao,
                                          dao.view(B * nW, wattn.TOKENS, C), lse, spec["scale"], nW)
             g[4] = dtable
             dqkv = dqkv.view(-1, 3 * C)
             dy1 = torch.mm(dqkv, _bf(qw))
-            g[2], g[3] = _wgrad(dqkv, y1, qw, qb)
+            g[2], g[3] = _wgrad(dqkv, y1, qw, qb, big)
             # LayerNorm 1; for k > 0 its input was (block k-1 stream + DropPath * MLP output): `dr` = that MLP's output gradient
             prev = (dp[k - 1, 1] if dp is not None else None) if k > 0 else None
             ds1, df = rows.ln_bwd(dy1, ymap, S, ds2, s1, st1, n1w, k > 0, None, L, prev, None, norm_g[k, 0], norm_g[k, 1], B, L)
             dsup = ds1
             g[0], g[1], g[7], g[8] = norm_g[k, 0], norm_g[k, 1], norm_g[k, 2], norm_g[k, 3]
             grads[k * N_BLOCK:(k + 1) * N_BLOCK] = g
+        if big:
+            conv_bf16.submit(big)                                # joins the step's deferred group when engine/trainer.py opened one
         return (dsup.view(B, L, C), None, *grads)
 
 
