@@ -219,7 +219,11 @@ def category_rooflines(cats, batch, size, freeze):
          (1.0, MFMA_FP32_PEAK_TFLOPS, "fp32 matrix 157.3 TF")
     work = {
         # fp32 weight gradients of the 6 encoder layers: value/out 256x256, offsets+weights 288x256, FFN 2 x 1024x256
-        "own_fp32_wgrad_mfma": (wg[0] * 6 * 2.0 * M * (2 * 256 * 256 + 288 * 256 + 2 * 1024 * 256) * enc_w, wg[1], wg[2]),
+        # + (same kernel family since round 2) the filter gradients of the fp32 FPN convolutions: 3 x 3 and two 1 x 1 at stride 4, the
+        # three input projections (2048 / 1024 / 512 -> 256 at strides 32 / 16 / 8); the matched mask-logit gradient of the criterion
+        "own_fp32_wgrad_mfma": (wg[0] * 2.0 * (6 * M * (2 * 256 * 256 + 288 * 256 + 2 * 1024 * 256) * enc_w
+                                         + (hw4 * (9 + 2) * 256 * 256 + sum(batch * (size // st) ** 2 * c * 256 for st, c in ((32, 2048), (16, 1024), (8, 512)))) * enc_w
+                                         + hw4 * 40 * 256), wg[1], wg[2]),
         # encoder FFN forward + input gradient, 3x3 FPN conv forward + input gradient: 6 bf16 MFMA products per fp32 product
         "own_fp32x3_gemm_conv": (6.0 * (6 * 2 * 2.0 * M * 2 * 256 * 1024 / 2 + 2 * 2.0 * hw4 * 9 * 256 * 256), 2500.0, "bf16 matrix 2.5 PF, 6 bf16 products per fp32 product"),
         # 256-wide projections of the encoder, forward + input gradient
