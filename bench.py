@@ -171,6 +171,7 @@ _CATEGORIES = [
     ("own_msda", r"^msda_"),
     ("own_fp32_wgrad_mfma", r"^(gemm_wgrad_f32|wgrad_tr_reduce)"),
     ("own_fp32x3_gemm_conv", r"^(gemm_tn_f32|gemm_wgrad_f32x3|conv3x3_)"),
+    ("own_conv_bf16_filter_grads", r"^conv_(wgrad|igemm)"),
     ("own_attention_mfma", r"^(attn_|wattn_)"),
     ("own_skinny_bf16_gemm", r"^sgemm_"),
     ("own_rowwise_norm_optim_misc", r"^(add_ln_|colsum_|mem_prep|attn_mask|point_sample|msda_prep|gn_coeffs|affine_act|nc_|multi_gather|"

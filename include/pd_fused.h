@@ -27,6 +27,11 @@ int pd_affine_act_fwd_bf16(const void *x, const void *residual, const float *sca
 /* gx = gy * [y > 0 if relu] * scale[c];  gres (nullable) = gy * [y > 0 if relu].  gx may alias gy. */
 int pd_affine_act_bwd_bf16(const void *gy, const void *y, const float *scale, void *gx, void *gres, int64_t n,
                            int channels, int relu, void *stream);
+/* The same with the incoming gradient given as the SUM of two tensors (gy2 nullable): an activation that feeds two consumers (a
+ * bottleneck block's output: the next block's first convolution and its shortcut) gets one gradient from each, and the add that
+ * autograd would launch between them and this kernel is done here instead. */
+int pd_affine_act_bwd2_bf16(const void *gy, const void *gy2, const void *y, const float *scale, void *gx, void *gres, int64_t n,
+                            int channels, int relu, void *stream);
 
 /*
  * For block b in [block_begin, block_end): copy `blk_len[b]` elements from tensor blk_tensor[b] starting at element

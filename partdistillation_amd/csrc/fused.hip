@@ -49,15 +49,20 @@ __global__ __launch_bounds__(256) void affine_act_fwd(const u16x8 *__restrict__ 
   }
 }
 
-template <bool RES, bool RELU>
-__global__ __launch_bounds__(256) void affine_act_bwd(const u16x8 *__restrict__ gy, const u16x8 *__restrict__ y,
+template <bool RES, bool RELU, bool TWO>
+__global__ __launch_bounds__(256) void affine_act_bwd(const u16x8 *__restrict__ gy, const u16x8 *__restrict__ gy2, const u16x8 *__restrict__ y,
                                                        const float *__restrict__ scale, u16x8 *__restrict__ gx,
                                                        u16x8 *__restrict__ gres, int64_t n8, int c8)
 {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
     const int c = (int)(i % c8) * 8;
-    const u16x8 g = gy[i];
+    u16x8 g = gy[i];
+    if (TWO) {                                            // the output fed two consumers: their gradients are summed here (bf16 sum,
+      const u16x8 h = gy2[i];                             // rounded like the separate add kernel autograd would have launched)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[k] = f2bf(bf2f(g[k]) + bf2f(h[k]));
+    }
     u16x8 yy;
     if (RELU) yy = y[i];
     const float4 s0 = *reinterpret_cast<const float4 *>(scale + c), s1 = *reinterpret_cast<const float4 *>(scale + c + 4);
@@ -280,8 +285,8 @@ extern "C" int pd_affine_act_fwd_bf16(const void *x, const void *residual, const
   return pd_check_launch("pd_affine_act_fwd_bf16");
 }
 
-extern "C" int pd_affine_act_bwd_bf16(const void *gy, const void *y, const float *scale, void *gx, void *gres, int64_t n,
-                                      int channels, int relu, void *stream_)
+extern "C" int pd_affine_act_bwd2_bf16(const void *gy, const void *gy2, const void *y, const float *scale, void *gx, void *gres, int64_t n,
+                                       int channels, int relu, void *stream_)
 {
   if (n < 0 || channels <= 0 || (channels & 7) || (n % channels)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_affine_act_bwd_bf16: n=%lld channels=%d", (long long)n, channels);
   if (n == 0) return PD_OK;
@@ -290,11 +295,19 @@ extern "C" int pd_affine_act_bwd_bf16(const void *gy, const void *y, const float
   const int c8 = channels / 8;
   hipStream_t s = (hipStream_t)stream_;
   dim3 g(grid_for(n8)), b(256);
-#define LAUNCH(R, A) hipLaunchKernelGGL((affine_act_bwd<R, A>), g, b, 0, s, (const u16x8 *)gy, (const u16x8 *)y, scale, (u16x8 *)gx, (u16x8 *)gres, n8, c8)
-  if (gres) { if (relu) LAUNCH(true, true); else LAUNCH(true, false); }
-  else { if (relu) LAUNCH(false, true); else LAUNCH(false, false); }
+#define LAUNCH(R, A, T) hipLaunchKernelGGL((affine_act_bwd<R, A, T>), g, b, 0, s, (const u16x8 *)gy, (const u16x8 *)gy2, (const u16x8 *)y, scale, (u16x8 *)gx, (u16x8 *)gres, n8, c8)
+#define LAUNCH2(R, A) do { if (gy2) LAUNCH(R, A, true); else LAUNCH(R, A, false); } while (0)
+  if (gres) { if (relu) LAUNCH2(true, true); else LAUNCH2(true, false); }
+  else { if (relu) LAUNCH2(false, true); else LAUNCH2(false, false); }
+#undef LAUNCH2
 #undef LAUNCH
   return pd_check_launch("pd_affine_act_bwd_bf16");
+}
+
+extern "C" int pd_affine_act_bwd_bf16(const void *gy, const void *y, const float *scale, void *gx, void *gres, int64_t n,
+                                      int channels, int relu, void *stream_)
+{
+  return pd_affine_act_bwd2_bf16(gy, nullptr, y, scale, gx, gres, n, channels, relu, stream_);
 }
 
 extern "C" int pd_multi_gather_sumsq(const int64_t *src_ptrs, const int32_t *src_is_bf16, const int32_t *blk_tensor,

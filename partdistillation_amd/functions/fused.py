@@ -46,10 +46,49 @@ class AffineAct(Function):
         return gx, None, None, gres, None
 
 
-def affine_act(x, scale, bias, residual=None, relu=True):
+class AffineActFork(Function):
+    """AffineAct whose result is handed out TWICE (the tensor and an alias of it) for an activation with two consumers — a bottleneck
+    block's output feeds the next block's first convolution and its shortcut.  Autograd then delivers one gradient per consumer to
+    backward(), and pd_affine_act_bwd2_bf16 sums them on the fly instead of autograd launching an add kernel in between."""
+
+    @staticmethod
+    def forward(ctx, x, scale, bias, residual, relu):
+        x = _nhwc(x)
+        res = _nhwc(residual) if residual is not None else None
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().pd_affine_act_fwd_bf16(x.data_ptr(), res.data_ptr() if res is not None else None,
+                                                    scale.data_ptr(), bias.data_ptr(), y.data_ptr(), x.numel(), x.shape[1],
+                                                    int(relu), _stream())
+        _lib.check(rc)
+        ctx.relu, ctx.has_res = relu, residual is not None
+        ctx.save_for_backward(y if relu else None, scale)
+        return y, y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        y, scale = ctx.saved_tensors
+        if g1 is None:
+            g1, g2 = g2, None
+        g1 = _nhwc(g1)
+        g2 = _nhwc(g2) if g2 is not None else None
+        gx = torch.empty_like(g1, memory_format=torch.channels_last)
+        gres = torch.empty_like(g1, memory_format=torch.channels_last) if ctx.has_res else None
+        with torch.cuda.device(g1.device):
+            rc = _lib.load().pd_affine_act_bwd2_bf16(g1.data_ptr(), g2.data_ptr() if g2 is not None else None,
+                                                     y.data_ptr() if y is not None else None, scale.data_ptr(), gx.data_ptr(),
+                                                     gres.data_ptr() if gres is not None else None, g1.numel(), g1.shape[1],
+                                                     int(ctx.relu), _stream())
+        _lib.check(rc)
+        return gx, None, None, gres, None
+
+
+def affine_act(x, scale, bias, residual=None, relu=True, fork=False):
+    """fork=True -> (y, alias of y): give one to each of the two consumers (see AffineActFork)"""
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0):
         raise RuntimeError("pd_affine_act: bf16 CUDA NCHW tensor with channels % 8 == 0 required (no fallback here)")
-    return AffineAct.apply(x, scale.float().contiguous(), bias.float().contiguous(), residual, relu)
+    fn = AffineActFork if fork else AffineAct
+    return fn.apply(x, scale.float().contiguous(), bias.float().contiguous(), residual, relu)
 
 
 class PinnedRing:

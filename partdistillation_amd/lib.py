@@ -49,6 +49,7 @@ SIGNATURES = {
     "pd_conv_bf16_dgrad": (_c_int, [_c_vp] * 4 + [_c_int] * 10 + [_c_vp]),
     "pd_affine_act_fwd_bf16": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, _c_int, _c_vp]),
     "pd_affine_act_bwd_bf16": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, _c_int, _c_vp]),
+    "pd_affine_act_bwd2_bf16": (_c_int, [_c_vp] * 6 + [ctypes.c_int64, _c_int, _c_int, _c_vp]),
     "pd_multi_gather_sumsq": (_c_int, [_c_vp] * 8 + [_c_int, _c_int, _c_vp]),
     "pd_attn_workspace_floats": (ctypes.c_int64, [_c_int] * 4),
     "pd_attn_fwd_d32": (_c_int, [_c_vp] * 7 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_vp]),

@@ -21,7 +21,7 @@ from ...functions.fused import affine_act
 OWN_WGRAD = bool(int(__import__("os").environ.get("PD_CONV_OWN_WGRAD", "1")))   # 0: MIOpen's filter gradients (tools/ comparisons)
 
 
-def _conv_bn_act(conv, x, residual=None, relu=True):
+def _conv_bn_act(conv, x, residual=None, relu=True, fork=False):
     """conv -> norm (-> + residual) (-> ReLU).
 
     bf16 autocast on the GPU with a frozen norm (the training configuration): the convolution runs bias-free on the
@@ -38,7 +38,7 @@ def _conv_bn_act(conv, x, residual=None, relu=True):
         else:
             y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         scale, bias = norm.scale_bias()
-        return affine_act(y, scale, bias, residual, relu)
+        return affine_act(y, scale, bias, residual, relu, fork=fork)
     if frozen:
         scale, bias = norm.scale_bias()
         w = conv.weight * scale.view(-1, 1, 1, 1).to(conv.weight.dtype)
@@ -48,7 +48,8 @@ def _conv_bn_act(conv, x, residual=None, relu=True):
         y = norm(y) if norm is not None else y
     if residual is not None:
         y = y + residual
-    return F.relu_(y) if relu else y
+    y = F.relu_(y) if relu else y
+    return (y, y) if fork else y
 
 
 class BasicStem(nn.Module):
@@ -84,11 +85,14 @@ class BottleneckBlock(nn.Module):
             if layer is not None:
                 c2_msra_fill(layer)
 
-    def forward(self, x):
+    def forward(self, x, x_sc=None, fork=False):
+        """x_sc: an alias of x for the shortcut branch (see functions/fused.py AffineActFork: the previous block hands its output out
+        twice so that the two gradients meet inside its epilogue kernel); fork: hand THIS block's output out twice -> (out, alias)"""
+        x_sc = x if x_sc is None else x_sc
         out = _conv_bn_act(self.conv1, x)
         out = _conv_bn_act(self.conv2, out)
-        sc = _conv_bn_act(self.shortcut, x, relu=False) if self.shortcut is not None else x
-        return _conv_bn_act(self.conv3, out, residual=sc, relu=True)
+        sc = _conv_bn_act(self.shortcut, x_sc, relu=False) if self.shortcut is not None else x_sc
+        return _conv_bn_act(self.conv3, out, residual=sc, relu=True, fork=fork)
 
 
 class ResNet(nn.Module):
@@ -118,9 +122,16 @@ class ResNet(nn.Module):
         x = self.stem(x)
         if "stem" in self._out_features:
             outputs["stem"] = x
-        for name in self.stage_names:
-            x = getattr(self, name)(x)
-            if name in self._out_features:
+        blocks = [(name, blk) for name in self.stage_names for blk in getattr(self, name)]
+        x_sc = None
+        for i, (name, blk) in enumerate(blocks):
+            last = i + 1 == len(blocks)
+            if isinstance(blk, BottleneckBlock):
+                out = blk(x, x_sc, fork=not last)                    # the output's two consumers: next block's conv1 and shortcut
+                x, x_sc = (out, None) if last else out
+            else:
+                x, x_sc = blk(x), None
+            if (last or blocks[i + 1][0] != name) and name in self._out_features:
                 outputs[name] = x
         return outputs
 
