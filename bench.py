@@ -347,7 +347,7 @@ def main():
     # per-launch timing of the hand-written MSDA kernels with HIP events on the launch stream.  Events cannot be
     # recorded between the nodes of a replayed graph, so these launches are timed in extra EAGER steps of the same
     # workload right after the timed region (when --graph 0 they are timed inside the timed region itself).
-    fwd_ms, bwd_ms, wgrad = [], [], []
+    fwd_ms, bwd_ms, wgrad, x3fwd = [], [], [], []
     if not a.skip_kernel_timing:
         step.release_graph()
         from partdistillation_amd.functions import gemm as gemm_fn
@@ -358,6 +358,7 @@ def main():
         torch.cuda.synchronize()
         fwd_ms, bwd_ms = msda_fn.timing_ms()
         wgrad = gemm_fn.timing()
+        x3fwd = gemm_fn.timing("fwd")
         msda_fn.enable_timing(False)
         gemm_fn.enable_timing(False)
     cats = None
@@ -410,11 +411,20 @@ def main():
                 kernels.append({"kernel": "gemm_wgrad_f32x3_tr", "launches": len(wgrad), "avg_ms": t_ms / len(wgrad),
                                 "alg_flops": 6 * fl / len(wgrad), "achieved_TFLOPs": 6 * fl / t_ms / 1e9, "peak_TFLOPs": 2500.0,
                                 "fp32_equivalent_TFLOPs": fl / t_ms / 1e9,
+                                "fp32_equivalent_frac_of_fp32_matrix_peak": fl / t_ms / 1e9 / MFMA_FP32_PEAK_TFLOPS,
                                 "peak_source": "MI355X_MICROARCH.md: dense bf16 matrix (v_mfma_f32_32x32x16_bf16) 2.5 PFLOP/s; "
                                                "alg_flops = 6 bf16 products per fp32 product x 2 M N K (avg_ms includes the partial-tile reduce launch)"})
             else:
                 kernels.append({"kernel": "gemm_wgrad_f32", "launches": len(wgrad), "avg_ms": t_ms / len(wgrad),
                                 "alg_flops": fl / len(wgrad), "achieved_TFLOPs": fl / t_ms / 1e9})
+        if x3fwd:                               # fp32 forward / input-gradient products on the bf16 matrix cores (FFN Linears, 3 x 3 FPN conv)
+            t_ms, fl = sum(t for t, _ in x3fwd), sum(f for _, f in x3fwd)
+            kernels.append({"kernel": "gemm_tn_f32x3 (+_wide, relu_bits, relumask, conv3x3)", "launches": len(x3fwd), "avg_ms": t_ms / len(x3fwd),
+                            "alg_flops": 6 * fl / len(x3fwd), "achieved_TFLOPs": 6 * fl / t_ms / 1e9, "peak_TFLOPs": 2500.0,
+                            "fp32_equivalent_TFLOPs": fl / t_ms / 1e9,
+                            "fp32_equivalent_frac_of_fp32_matrix_peak": fl / t_ms / 1e9 / MFMA_FP32_PEAK_TFLOPS,
+                            "peak_source": "MI355X_MICROARCH.md: dense bf16 matrix (v_mfma_f32_32x32x16_bf16) 2.5 PFLOP/s; "
+                                           "alg_flops = 6 bf16 products per fp32 product x 2 M N K"})
         pmc = {}
         try:                                   # HBM bytes per launch from the committed PMC passes (tools/pmc_msda.sh)
             pj = json.load(open(os.path.join(ROOT, "profiles", "r02_msda_pmc.json")))

@@ -21,8 +21,10 @@ def _raw(x, wk, bias, co):
     """x channels-last [B,Ci,H,W]; wk [Co,3,3,Ci] contiguous -> channels-last [B,Co,H,W]"""
     B, ci, H, W = x.shape
     y = torch.empty((B, co, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    _lib.check(_lib.load().pd_conv3x3_nhwc_f32x3(x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                                                 B, H, W, ci, co, _lib.current_stream()))
+    from .gemm import _timed_fwd
+    with _timed_fwd(2.0 * B * H * W * 9 * ci * co):
+        _lib.check(_lib.load().pd_conv3x3_nhwc_f32x3(x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                                     B, H, W, ci, co, _lib.current_stream()))
     return y
 
 

@@ -25,6 +25,26 @@ def gemm_tn(a, b, bias=None, relu=False):
     return c
 
 
+_TIMING = {"on": False, "wgrad": [], "fwd": []}
+
+
+class _timed_fwd:
+    """HIP events around one split-GEMM launch on the launch stream (bench.py's per-launch roofline figures)"""
+
+    def __init__(self, flops):
+        self.flops = flops
+
+    def __enter__(self):
+        if _TIMING["on"]:
+            self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _TIMING["on"]:
+            self.b.record()
+            _TIMING["fwd"].append((self.a, self.b, self.flops))
+
+
 def gemm_tn_x3(a, b, bias=None, relu=False):
     """a [M,K], b [N,K] fp32 -> a @ b.T (+bias) (ReLU) with fp32-level accuracy on the bf16 matrix cores
     (pd_gemm_tn_f32x3: exact 3-way bf16 split of every operand, 6 partial products, fp32 accumulation)."""
@@ -34,8 +54,9 @@ def gemm_tn_x3(a, b, bias=None, relu=False):
     M, K = a.shape
     N = b.shape[0]
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    _lib.check(_lib.load().pd_gemm_tn_f32x3(a.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else None, c.data_ptr(),
-                                            M, N, K, a.stride(0), b.stride(0), N, int(relu), _stream()))
+    with _timed_fwd(2.0 * M * N * K):
+        _lib.check(_lib.load().pd_gemm_tn_f32x3(a.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else None, c.data_ptr(),
+                                                M, N, K, a.stride(0), b.stride(0), N, int(relu), _stream()))
     return c
 
 
@@ -82,8 +103,9 @@ def gemm_tn_x3_relu_bits(a, b, bias):
     L = _lib.load()
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
     bits = torch.empty(int(L.pd_gemm_tn_f32x3_relu_bits_words(M, N)), dtype=torch.int32, device=a.device)
-    _lib.check(L.pd_gemm_tn_f32x3_relu_bits(a.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else None, c.data_ptr(),
-                                            bits.data_ptr(), M, N, K, a.stride(0), b.stride(0), N, _stream()))
+    with _timed_fwd(2.0 * M * N * K):
+        _lib.check(L.pd_gemm_tn_f32x3_relu_bits(a.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else None, c.data_ptr(),
+                                                bits.data_ptr(), M, N, K, a.stride(0), b.stride(0), N, _stream()))
     return c, bits
 
 
@@ -95,23 +117,23 @@ def gemm_tn_x3_relumask(a, b, bits, colsum):
     N = b.shape[0]
     assert bits.dtype == torch.int32 and colsum.dtype == torch.float32 and colsum.numel() == N
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    _lib.check(_lib.load().pd_gemm_tn_f32x3_relumask(a.data_ptr(), b.data_ptr(), bits.data_ptr(), c.data_ptr(), colsum.data_ptr(),
-                                                     M, N, K, a.stride(0), b.stride(0), N, _stream()))
+    with _timed_fwd(2.0 * M * N * K):
+        _lib.check(_lib.load().pd_gemm_tn_f32x3_relumask(a.data_ptr(), b.data_ptr(), bits.data_ptr(), c.data_ptr(), colsum.data_ptr(),
+                                                         M, N, K, a.stride(0), b.stride(0), N, _stream()))
     return c
 
 
 # optional per-launch timing hook used by bench.py (HIP events on the launch stream; (start, stop, flops) per launch)
-_TIMING = {"on": False, "wgrad": []}
-
-
 def enable_timing(on=True):
     _TIMING["on"] = on
     _TIMING["wgrad"].clear()
+    _TIMING["fwd"].clear()
 
 
-def timing():
-    """-> [(ms, flops)] of the weight-gradient launches since enable_timing(True); call after a synchronize."""
-    return [(a.elapsed_time(b), f) for a, b, f in _TIMING["wgrad"]]
+def timing(which="wgrad"):
+    """-> [(ms, flops)] of the weight-gradient ("wgrad") or forward / input-gradient split-GEMM ("fwd") launches since
+    enable_timing(True); call after a synchronize."""
+    return [(a.elapsed_time(b), f) for a, b, f in _TIMING[which]]
 
 
 WGRAD_X3 = True      # weight gradients through the 3-way bf16 split kernel (pd_gemm_wgrad_acc_f32x3_ws): fp32-accurate (error vs fp64 at
@@ -125,13 +147,14 @@ _WGRAD_WS = {}
 
 
 def _wgrad_workspace(device, need):
-    """one persistent fp32 scratch per device for the partial tiles of pd_gemm_wgrad_acc_f32x3_ws (<= 34 MB; consecutive
-    launches on a stream reuse it in order)"""
+    """one persistent fp32 scratch per device AND stream for the partial tiles of pd_gemm_wgrad_acc_f32x3_ws (<= 34 MB;
+    consecutive launches on a stream reuse it in order)"""
     if need <= 0:
         return None
-    ws = _WGRAD_WS.get(str(device))
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() < need:
-        ws = _WGRAD_WS[str(device)] = torch.empty(max(need, 8912896), dtype=torch.float32, device=device)
+        ws = _WGRAD_WS[key] = torch.empty(max(need, 8912896), dtype=torch.float32, device=device)
     return ws
 
 
