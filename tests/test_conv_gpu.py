@@ -77,6 +77,19 @@ def test_conv_wgrad_vs_torch_fp32(ci, co, k, s, H, W, B):
     assert err < 2 ** -7, err                                        # one bf16 rounding of an fp32-accumulated sum
 
 
+def test_conv_wgrad_tiny_and_single_pixel_problems():
+    """fewer pixels than one 32-pixel stage, one image of one pixel, more splits than stages: the plan's lower bounds"""
+    from partdistillation_amd.functions import conv_bf16 as C
+    for (ci, co, k, s, H, W, B) in [(64, 64, 1, 1, 1, 1, 1), (128, 256, 3, 1, 2, 3, 1), (8, 8, 1, 1, 5, 5, 2), (256, 64, 3, 2, 3, 3, 4)]:
+        x, w = _mk((B, ci, H, W), 7), _mk((co, ci, k, k), 8, 0.05)
+        wf = w.float().requires_grad_(True)
+        ref_y = F.conv2d(x.float(), wf, None, s, k // 2)
+        dz = _mk(ref_y.shape, 9)
+        (ref,) = torch.autograd.grad(ref_y, wf, dz.float())
+        dw = C.conv_wgrad(dz, x, k, s, k // 2, like=w)
+        assert (dw.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item() + 1e-6
+
+
 def test_deferred_grouped_wgrads_equal_the_immediate_ones():
     """Conv2dOwnWgrad inside deferred_wgrads(): backward hands out unwritten filter gradients and ONE grouped launch per tile shape
     fills them at flush() — all four tile shapes, strides, ragged pixel counts, two uses of the context in a row."""

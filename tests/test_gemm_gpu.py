@@ -109,6 +109,30 @@ def test_gemm_wgrad_x3_is_fp32_accurate(M, N, K, bias):
         torch.testing.assert_close(outs[True][1].double() + 1.0, dy.double().sum(0), rtol=1e-4, atol=1e-3 * dy.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 128, 128), (31, 132, 260), (4100, 40, 256), (2048, 516, 68)])
+def test_gemm_wgrad_x3_transpose_read_edges(M, N, K):
+    """the transpose-read kernel on ragged tiles (N, K no multiples of 128), a single row, row-strided operands (column slices of
+    wider matrices) — through the workspace ABI and through the atomics one (pd_gemm_wgrad_acc_f32x3, no workspace)."""
+    from partdistillation_amd import lib
+    from partdistillation_amd.functions import gemm
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N + K)
+    big_y = torch.randn(M, N + 24, device="cuda", generator=g)
+    big_x = torch.randn(M, K + 12, device="cuda", generator=g)
+    dy, x = big_y[:, 8:8 + N], big_x[:, 4:4 + K]                      # 16-byte aligned column windows, ld > width
+    assert dy.stride(0) == N + 24 and x.stride(0) == K + 12
+    ref = dy.double().t() @ x.double()
+    scale = dy.double().abs().t() @ x.double().abs() + 1e-30
+    dw, db = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+    gemm.gemm_wgrad_acc(dy, x, dw, db, x3=True)
+    assert ((dw.double() - ref).abs() / scale).max().item() < 3e-6
+    torch.testing.assert_close(db.double(), dy.double().sum(0), rtol=1e-4, atol=1e-3)
+    dw2, db2 = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+    lib.check(lib.load().pd_gemm_wgrad_acc_f32x3(dy.data_ptr(), x.data_ptr(), dw2.data_ptr(), db2.data_ptr(), M, N, K, dy.stride(0),
+                                                 x.stride(0), K, lib.current_stream()))
+    assert ((dw2.double() - ref).abs() / scale).max().item() < 3e-6
+    torch.testing.assert_close(db2, db, rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize("B,H,W,Ci,Co,bias", [(2, 64, 64, 256, 256, False), (1, 37, 29, 32, 48, True), (3, 8, 200, 16, 272, True),
                                               (3, 19, 23, 128, 80, True), (2, 5, 7, 256, 256, True)])
 def test_conv3x3_x3_matches_fp64_convolution(B, H, W, Ci, Co, bias):
