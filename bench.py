@@ -408,7 +408,7 @@ def main():
             t_ms, fl = sum(t for t, _ in wgrad), sum(f for _, f in wgrad)
             from partdistillation_amd.functions import gemm as gemm_fn
             if gemm_fn.WGRAD_X3:                # each fp32 product = 6 bf16 MFMA products: the work the matrix pipe actually does
-                kernels.append({"kernel": "gemm_wgrad_f32x3_tr", "launches": len(wgrad), "avg_ms": t_ms / len(wgrad),
+                kernels.append({"kernel": "gemm_wgrad_f32x3_tr (+ wgrad_tr_reduce)", "launches": len(wgrad), "avg_ms": t_ms / len(wgrad),
                                 "alg_flops": 6 * fl / len(wgrad), "achieved_TFLOPs": 6 * fl / t_ms / 1e9, "peak_TFLOPs": 2500.0,
                                 "fp32_equivalent_TFLOPs": fl / t_ms / 1e9,
                                 "fp32_equivalent_frac_of_fp32_matrix_peak": fl / t_ms / 1e9 / MFMA_FP32_PEAK_TFLOPS,
@@ -417,10 +417,12 @@ def main():
             else:
                 kernels.append({"kernel": "gemm_wgrad_f32", "launches": len(wgrad), "avg_ms": t_ms / len(wgrad),
                                 "alg_flops": fl / len(wgrad), "achieved_TFLOPs": fl / t_ms / 1e9})
-        if x3fwd:                               # fp32 forward / input-gradient products on the bf16 matrix cores (FFN Linears, 3 x 3 FPN conv)
-            t_ms, fl = sum(t for t, _ in x3fwd), sum(f for _, f in x3fwd)
-            kernels.append({"kernel": "gemm_tn_f32x3 (+_wide, relu_bits, relumask, conv3x3)", "launches": len(x3fwd), "avg_ms": t_ms / len(x3fwd),
-                            "alg_flops": 6 * fl / len(x3fwd), "achieved_TFLOPs": 6 * fl / t_ms / 1e9, "peak_TFLOPs": 2500.0,
+        labels = sorted({lab for _, (_, lab) in x3fwd})   # fp32 forward / input-gradient products on the bf16 matrix cores, per kernel
+        for lab in labels:
+            sel = [(t, f) for t, (f, l2) in x3fwd if l2 == lab]
+            t_ms, fl = sum(t for t, _ in sel), sum(f for _, f in sel)
+            kernels.append({"kernel": lab, "launches": len(sel), "avg_ms": t_ms / len(sel),
+                            "alg_flops": 6 * fl / len(sel), "achieved_TFLOPs": 6 * fl / t_ms / 1e9, "peak_TFLOPs": 2500.0,
                             "fp32_equivalent_TFLOPs": fl / t_ms / 1e9,
                             "fp32_equivalent_frac_of_fp32_matrix_peak": fl / t_ms / 1e9 / MFMA_FP32_PEAK_TFLOPS,
                             "peak_source": "MI355X_MICROARCH.md: dense bf16 matrix (v_mfma_f32_32x32x16_bf16) 2.5 PFLOP/s; "

@@ -515,8 +515,9 @@ extern "C" int pd_conv_bf16_wgrad(const void *dz, const void *x, void *dw, float
 }
 
 // ------------------------------------------------------------------------------------------------ grouped filter gradients
+int g_pd_dbg_conv_group_rows = 0;                        // tools/ only (pd_debug_set "conv_group_rows")
 namespace {
-constexpr int kGroupRows = 2048;                         // pixels per workgroup in a grouped launch
+#define kGroupRows (g_pd_dbg_conv_group_rows > 0 ? g_pd_dbg_conv_group_rows : 2048)   // pixels per workgroup in a grouped launch
 
 int variant_of(const WgradPlan &p) { return p.tn == 128 ? (p.tk == 128 ? 0 : 1) : (p.tk == 128 ? 2 : 3); }
 

@@ -53,6 +53,9 @@ class TrainStep:
         broadcast_parameters(self.optimizer.flat, 0, process_group)
         self.reducer = BucketedGradReducer(self.optimizer.flat, cfg.MODEL.AMD.DDP_BUCKET_MB, process_group,
                                            optimizer=self.optimizer)
+        if _os.environ.get("PD_CONV_GROUP_ROWS"):               # tools/ experiments
+            from .. import lib as _l
+            _l.load().pd_debug_set(b"conv_group_rows", int(_os.environ["PD_CONV_GROUP_ROWS"]))
         self.iter = 0
         self._graph = None
         self._replay_done = None

@@ -22,7 +22,7 @@ def _raw(x, wk, bias, co):
     B, ci, H, W = x.shape
     y = torch.empty((B, co, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     from .gemm import _timed_fwd
-    with _timed_fwd(2.0 * B * H * W * 9 * ci * co):
+    with _timed_fwd(2.0 * B * H * W * 9 * ci * co, "gemm_tn_f32x3<conv 3x3>"):
         _lib.check(_lib.load().pd_conv3x3_nhwc_f32x3(x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                                                      B, H, W, ci, co, _lib.current_stream()))
     return y

@@ -31,8 +31,8 @@ _TIMING = {"on": False, "wgrad": [], "fwd": []}
 class _timed_fwd:
     """HIP events around one split-GEMM launch on the launch stream (bench.py's per-launch roofline figures)"""
 
-    def __init__(self, flops):
-        self.flops = flops
+    def __init__(self, flops, label):
+        self.flops, self.label = flops, label
 
     def __enter__(self):
         if _TIMING["on"]:
@@ -42,7 +42,7 @@ class _timed_fwd:
     def __exit__(self, *exc):
         if _TIMING["on"]:
             self.b.record()
-            _TIMING["fwd"].append((self.a, self.b, self.flops))
+            _TIMING["fwd"].append((self.a, self.b, (self.flops, self.label)))
 
 
 def gemm_tn_x3(a, b, bias=None, relu=False):
@@ -54,7 +54,7 @@ def gemm_tn_x3(a, b, bias=None, relu=False):
     M, K = a.shape
     N = b.shape[0]
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    with _timed_fwd(2.0 * M * N * K):
+    with _timed_fwd(2.0 * M * N * K, "gemm_tn_f32x3(_wide)"):
         _lib.check(_lib.load().pd_gemm_tn_f32x3(a.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else None, c.data_ptr(),
                                                 M, N, K, a.stride(0), b.stride(0), N, int(relu), _stream()))
     return c
@@ -103,7 +103,7 @@ def gemm_tn_x3_relu_bits(a, b, bias):
     L = _lib.load()
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
     bits = torch.empty(int(L.pd_gemm_tn_f32x3_relu_bits_words(M, N)), dtype=torch.int32, device=a.device)
-    with _timed_fwd(2.0 * M * N * K):
+    with _timed_fwd(2.0 * M * N * K, "gemm_tn_f32x3_wide<relu + sign bits>"):
         _lib.check(L.pd_gemm_tn_f32x3_relu_bits(a.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else None, c.data_ptr(),
                                                 bits.data_ptr(), M, N, K, a.stride(0), b.stride(0), N, _stream()))
     return c, bits
@@ -117,7 +117,7 @@ def gemm_tn_x3_relumask(a, b, bits, colsum):
     N = b.shape[0]
     assert bits.dtype == torch.int32 and colsum.dtype == torch.float32 and colsum.numel() == N
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    with _timed_fwd(2.0 * M * N * K):
+    with _timed_fwd(2.0 * M * N * K, "gemm_tn_f32x3_wide<relu mask + column sums>"):
         _lib.check(_lib.load().pd_gemm_tn_f32x3_relumask(a.data_ptr(), b.data_ptr(), bits.data_ptr(), c.data_ptr(), colsum.data_ptr(),
                                                          M, N, K, a.stride(0), b.stride(0), N, _stream()))
     return c
