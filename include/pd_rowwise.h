@@ -98,6 +98,16 @@ int pd_msda_prep_bwd(const float *gloc, const float *gattn, const float *attn, c
 int pd_point_sample_nhwc_f32(const float *in, const float *coords, float *out, int B, int H, int W, int C, int P, void *stream);
 
 /*
+ * The same sampling of PLANAR maps: out[n, c, p] = bilinear sample of in[n, c] ([N, C, H, W] fp32 contiguous) at coords[n, p] — points
+ * per map, shared by its C channels (detectron2 point_sample as the criterion uses it on the matched mask logits [N, 1, h, w] and on
+ * the target masks, reference criterion.py:165-197), and its gradient with respect to `in`: grad_in (ZERO-FILLED by the caller)
+ * += the bilinear weights times grad_out[n, c, p] (fp32 atomics; single-channel maps of <= 16 LDS tiles are instead WRITTEN in full by a tiled kernel without global atomics — pd_point_sample_planar_bwd_needs_zero() tells which).  Same operation order as torch's grid_sampler in the forward.
+ */
+int pd_point_sample_planar_f32(const float *in, const float *coords, float *out, int N, int C, int H, int W, int P, void *stream);
+int pd_point_sample_planar_bwd_f32(const float *grad_out, const float *coords, float *grad_in, int N, int C, int H, int W, int P, void *stream);
+int pd_point_sample_planar_bwd_needs_zero(int C, int H, int W);
+
+/*
  * FPN top-down step of the pixel decoder (reference msdeformattn.py:356-358:
  * `y = cur_fpn + F.interpolate(out[-1], size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)`), channels-last
  * fp32 [B, H, W, C] / [B, h, w, C]; same source-index arithmetic as torch's upsample_bilinear2d.

@@ -134,6 +134,41 @@ def point_sample_nhwc(x, coords):
     return out
 
 
+class PointSamplePlanar(Function):
+    """x [N,C,H,W] fp32 contiguous, coords [N,P,2] (x, y) in [0,1] -> [N,C,P]: F.grid_sample(x, 2*coords-1, bilinear, zeros,
+    align_corners=False) at per-map points (pd_point_sample_planar_f32); gradient with respect to x only."""
+
+    @staticmethod
+    def forward(ctx, x, coords):
+        N, C, H, W = x.shape
+        P = coords.shape[1]
+        out = torch.empty((N, C, P), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().pd_point_sample_planar_f32(x.data_ptr(), coords.data_ptr(), out.data_ptr(), N, C, H, W, P, _stream()))
+        ctx.save_for_backward(coords)
+        ctx.shape = (N, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (coords,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        L = _lib.load()
+        alloc = torch.zeros if L.pd_point_sample_planar_bwd_needs_zero(C, H, W) else torch.empty
+        gx = alloc((N, C, H, W), dtype=torch.float32, device=g.device)
+        g = g.contiguous()
+        _lib.check(_lib.load().pd_point_sample_planar_bwd_f32(g.data_ptr(), coords.data_ptr(), gx.data_ptr(), N, C, H, W, coords.shape[1], _stream()))
+        return gx, None
+
+
+def point_sample_planar_supported(x, coords):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and coords.dtype == torch.float32
+            and coords.dim() == 3 and coords.shape[0] == x.shape[0] and coords.shape[2] == 2 and not coords.requires_grad)
+
+
+def point_sample_planar(x, coords):
+    return PointSamplePlanar.apply(x, coords.contiguous())
+
+
 def supports_width(C):
     return C % 256 == 0 and C <= 1024
 

@@ -88,6 +88,8 @@ def _const(values, dtype, device):
 
 def _gs(inp, coords):
     """grid_sample of [N,C,H,W] at coords [N,P,2] in [0,1] (x,y) -> [N,C,P]; bilinear, zeros, align_corners=False."""
+    if rw.point_sample_planar_supported(inp, coords):
+        return rw.point_sample_planar(inp, coords)          # HIP kernel: 10 us where the generic grid_sampler takes 50 (200 backward)
     return F.grid_sample(inp, 2.0 * coords.unsqueeze(2) - 1.0, mode="bilinear", padding_mode="zeros", align_corners=False).squeeze(3)
 
 

@@ -322,3 +322,25 @@ def test_upsample_add_fwd_bwd_vs_torch(B, C, h, w):
     torch.testing.assert_close(y, ref, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(g_lo, lo.grad, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(g_cur, cur.grad, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("N,C,H,W,P", [(80, 1, 64, 64, 1000), (1, 4, 96, 128, 5000), (3, 2, 7, 5, 33), (2, 1, 1, 1, 4), (5, 1, 256, 300, 20000),
+                                       (2, 1, 113, 225, 3000), (1, 1, 600, 40, 999)])
+def test_point_sample_planar_vs_grid_sample(N, C, H, W, P):
+    """pd_point_sample_planar_f32 / _bwd_f32 against F.grid_sample (bilinear, zeros, align_corners=False): points on and beyond the
+    borders, per-map points, the gradient with respect to the maps."""
+    import torch.nn.functional as F
+    from partdistillation_amd.functions import rowwise as rw
+    g = torch.Generator(device="cuda").manual_seed(N * 100 + P)
+    x = torch.randn(N, C, H, W, device="cuda", generator=g, requires_grad=True)
+    coords = torch.rand(N, P, 2, device="cuda", generator=g) * 1.2 - 0.1          # some outside [0, 1]
+    coords[:, :4] = torch.tensor([[0.0, 0.0], [1.0, 1.0], [0.5, 0.0], [1.0, 0.5]], device="cuda")
+    assert rw.point_sample_planar_supported(x, coords)
+    y = rw.point_sample_planar(x, coords)
+    ref = F.grid_sample(x, 2.0 * coords.unsqueeze(2) - 1.0, mode="bilinear", padding_mode="zeros", align_corners=False).squeeze(3)
+    assert y.shape == ref.shape == (N, C, P)
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+    go = torch.randn(N, C, P, device="cuda", generator=g)
+    (gx,) = torch.autograd.grad(y, x, go)
+    (rx,) = torch.autograd.grad(ref, x, go)
+    torch.testing.assert_close(gx, rx, rtol=1e-4, atol=1e-4)
