@@ -96,6 +96,8 @@ int pd_msda_prep_bwd(const float *gloc, const float *gattn, const float *attn, c
  * need not exist to be sampled).  Same operation order as the torch kernel.
  */
 int pd_point_sample_nhwc_f32(const float *in, const float *coords, float *out, int B, int H, int W, int C, int P, void *stream);
+/* the same with the samples rounded to bf16 on the way out (the matcher multiplies them by bf16 mask embeddings under autocast) */
+int pd_point_sample_nhwc_f32_bf16(const float *in, const float *coords, void *out, int B, int H, int W, int C, int P, void *stream);
 
 /*
  * The same sampling of PLANAR maps: out[n, c, p] = bilinear sample of in[n, c] ([N, C, H, W] fp32 contiguous) at coords[n, p] — points

@@ -434,8 +434,9 @@ __global__ __launch_bounds__(256) void msda_prep_bwd(const float *__restrict__ g
 // ------------------------------------------------------------------------------------------------ point sampling
 // F.grid_sample(bilinear, zeros, align_corners=False) of a channels-last map at points that are shared by all C channels:
 // one wavefront per point, lanes across channels (16-byte pieces), so each corner is one contiguous C*4-byte burst.
+template <typename TO>
 __global__ __launch_bounds__(256) void point_sample_nhwc(const float *__restrict__ in, const float *__restrict__ coords,
-                                                         float *__restrict__ out, int B, int H, int W, int C, int P)
+                                                         TO *__restrict__ out, int B, int H, int W, int C, int P)
 {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t total = (int64_t)B * P;
@@ -841,8 +842,20 @@ extern "C" int pd_point_sample_nhwc_f32(const float *in, const float *coords, fl
   if (!in || !coords || !out) return pd_set_error(PD_ERR_INVALID_ARG, "pd_point_sample_nhwc_f32: null pointer");
   const int64_t total = (int64_t)B * P;
   const unsigned grid = (unsigned)((total + 3) / 4 < 16384 ? (total + 3) / 4 : 16384);
-  hipLaunchKernelGGL(point_sample_nhwc, dim3(grid), dim3(256), 0, (hipStream_t)stream_, in, coords, out, B, H, W, C, P);
+  hipLaunchKernelGGL(point_sample_nhwc<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, in, coords, out, B, H, W, C, P);
   return pd_check_launch("pd_point_sample_nhwc_f32");
+}
+
+extern "C" int pd_point_sample_nhwc_f32_bf16(const float *in, const float *coords, void *out, int B, int H, int W, int C, int P,
+                                             void *stream_)
+{
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || P < 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_point_sample_nhwc_f32_bf16: B=%d H=%d W=%d C=%d P=%d", B, H, W, C, P);
+  if (B == 0 || P == 0) return PD_OK;
+  if (!in || !coords || !out) return pd_set_error(PD_ERR_INVALID_ARG, "pd_point_sample_nhwc_f32_bf16: null pointer");
+  const int64_t total = (int64_t)B * P;
+  const unsigned grid = (unsigned)((total + 3) / 4 < 16384 ? (total + 3) / 4 : 16384);
+  hipLaunchKernelGGL(point_sample_nhwc<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, in, coords, (bf16_t *)out, B, H, W, C, P);
+  return pd_check_launch("pd_point_sample_nhwc_f32_bf16");
 }
 
 extern "C" int pd_upsample_add_nhwc_f32(const float *lo, const float *cur, float *y, int B, int h, int w, int H, int W, int C,

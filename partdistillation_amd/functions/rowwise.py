@@ -119,9 +119,10 @@ def attn_mask_u8(logits):
     return mask
 
 
-def point_sample_nhwc(x, coords):
+def point_sample_nhwc(x, coords, out_dtype=torch.float32):
     """x [B,C,H,W] fp32 (channels-last memory is read in place), coords [B,P,2] (x, y) in [0,1] -> [B,P,C]:
-    F.grid_sample(x, 2*coords-1, bilinear, zeros, align_corners=False) for points shared by all channels."""
+    F.grid_sample(x, 2*coords-1, bilinear, zeros, align_corners=False) for points shared by all channels.
+    out_dtype bfloat16: the fp32 samples are rounded on the way out (no separate cast pass)."""
     _need_cuda(x, "pd_point_sample_nhwc_f32")
     B, C, H, W = x.shape
     t = x.permute(0, 2, 3, 1)
@@ -129,8 +130,10 @@ def point_sample_nhwc(x, coords):
         t = t.float().contiguous()
     coords = coords.float().contiguous()
     P = coords.shape[1]
-    out = torch.empty((B, P, C), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().pd_point_sample_nhwc_f32(t.data_ptr(), coords.data_ptr(), out.data_ptr(), B, H, W, C, P, _stream()))
+    out = torch.empty((B, P, C), dtype=out_dtype, device=x.device)
+    fn = _lib.load().pd_point_sample_nhwc_f32_bf16 if out_dtype == torch.bfloat16 else _lib.load().pd_point_sample_nhwc_f32
+    assert out_dtype in (torch.float32, torch.bfloat16)
+    _lib.check(fn(t.data_ptr(), coords.data_ptr(), out.data_ptr(), B, H, W, C, P, _stream()))
     return out
 
 

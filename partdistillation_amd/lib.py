@@ -73,6 +73,7 @@ SIGNATURES = {
     "pd_gn_coeffs_fwd": (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [ctypes.c_float] + [_c_vp] * 6),
     "pd_gn_coeffs_bwd": (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_vp] * 6),
     "pd_point_sample_nhwc_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
+    "pd_point_sample_nhwc_f32_bf16": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
     "pd_point_sample_planar_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
     "pd_point_sample_planar_bwd_needs_zero": (_c_int, [_c_int] * 3),
     "pd_point_sample_planar_bwd_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
