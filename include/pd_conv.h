@@ -56,6 +56,7 @@ int pd_conv_bf16_wgrad(const void *dz, const void *x, void *dw, float *workspace
 typedef struct PdConvWgradDesc {
   const void *dz, *x;
   void *dw;
+  float *db;     /* nullable: fp32 [co], += sum over pixels of dz (the bias gradient of a convolution / Linear with bias) */
   int32_t batch, hi, wi, ci, ho, wo, co, k, stride, pad;
 } PdConvWgradDesc;
 int64_t pd_conv_bf16_wgrad_grouped_table_bytes(int count);

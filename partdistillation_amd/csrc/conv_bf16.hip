@@ -238,7 +238,7 @@ struct WgradGeom {
 // of a 128-wide tile would be zeros there — and the fp32 partial tiles are this kernel's second-largest traffic).
 template <int WN, int WK>
 __device__ __forceinline__ void wgrad_body(const bf16_t *__restrict__ dZ, const bf16_t *__restrict__ X, float *__restrict__ ws,
-                                           const WgradGeom &g, int bid)
+                                           const WgradGeom &g, int bid, float *__restrict__ dB = nullptr)
 {
   constexpr int TN = 2 * WN, TK = 2 * WK, NI = WN / 32, KJ = WK / 32;
   constexpr int PN = TN + 32, PK = TK + 32;              // LDS row pitches: 160 or 96 bf16 = 320 / 192 B, both = 16 banks mod 64
@@ -286,7 +286,17 @@ __device__ __forceinline__ void wgrad_body(const bf16_t *__restrict__ dZ, const 
       while (cx[j] >= g.Wo) { cx[j] -= g.Wo; if (++cy[j] == g.Ho) { cy[j] = 0; ++cb[j]; } }
     }
   };
+  const bool do_bias = dB != nullptr && k0 == 0;          // the k-tile-0 workgroups also sum their dz columns (bias gradient)
+  float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto lstore = [&](int s, int buf) {
+    if (do_bias) {
+#pragma unroll
+      for (int j = 0; j < JY; ++j) {
+        const uint4 v = ry[s][j];
+        bs[0] += bf_lo(v.x); bs[1] += bf_hi(v.x); bs[2] += bf_lo(v.y); bs[3] += bf_hi(v.y);
+        bs[4] += bf_lo(v.z); bs[5] += bf_hi(v.z); bs[6] += bf_lo(v.w); bs[7] += bf_hi(v.w);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < JY; ++j) *reinterpret_cast<uint4 *>(&SY[buf][yr + LY * j][yc]) = ry[s][j];
 #pragma unroll
@@ -340,6 +350,17 @@ __device__ __forceinline__ void wgrad_body(const bf16_t *__restrict__ dZ, const 
     step(st, 0);
     if (st + 1 < steps) step(st + 1, 1);
   }
+  if (do_bias) {                                         // the loop ended with a barrier: the stages are free
+    float *red = reinterpret_cast<float *>(&SY[0][0][0]);                 // [LY][TN] floats <= 2 * 32 * PN bf16
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[yr * TN + yc + e] = bs[e];
+    __syncthreads();
+    if (t < TN && n0 + t < g.N) {
+      float v = 0.f;
+      for (int r = 0; r < LY; ++r) v += red[r * TN + t];
+      unsafeAtomicAdd(dB + n0 + t, v);
+    }
+  }
   float *w = ws + ((int64_t)split * g.tiles + tile) * (TN * TK) + t;
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -364,6 +385,7 @@ struct WgradProblem {
   const bf16_t *dz, *x;
   bf16_t *dw;
   int64_t ws_off;                                        // this problem's partial tiles inside the workspace (floats)
+  float *db;                                             // fp32 [co] bias-gradient accumulator (+= column sums of dz), nullable
   WgradGeom g;
   int block_begin, reduce_begin, splits, variant;
 };
@@ -380,7 +402,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr_grouped(const Wgrad
 {
   const int p = find_problem(tab, count, blockIdx.x, false);
   const WgradProblem &pr = tab[p];
-  wgrad_body<WN, WK>(pr.dz, pr.x, ws + pr.ws_off, pr.g, blockIdx.x - pr.block_begin);
+  wgrad_body<WN, WK>(pr.dz, pr.x, ws + pr.ws_off, pr.g, blockIdx.x - pr.block_begin, pr.db);
 }
 
 // dW (bf16) = sum over splits of the partial tiles (register order: element (ij, e) of thread t at ((ij * 16 + e) * 256 + t))
@@ -568,7 +590,7 @@ extern "C" int pd_conv_bf16_wgrad_grouped(const PdConvWgradDesc *descs, int coun
       const PdConvWgradDesc &d = descs[i];
       const WgradPlan &p = plans[i];
       WgradProblem &w = tab[at];
-      w.dz = (const bf16_t *)d.dz; w.x = (const bf16_t *)d.x; w.dw = (bf16_t *)d.dw; w.ws_off = ws_off;
+      w.dz = (const bf16_t *)d.dz; w.x = (const bf16_t *)d.x; w.dw = (bf16_t *)d.dw; w.ws_off = ws_off; w.db = d.db;
       w.g.M = d.batch * d.ho * d.wo; w.g.N = d.co; w.g.K = d.k * d.k * d.ci; w.g.Ci = d.ci; w.g.kw = d.k; w.g.Hi = d.hi; w.g.Wi = d.wi;
       w.g.Ho = d.ho; w.g.Wo = d.wo; w.g.stride = d.stride; w.g.pad = d.pad; w.g.tiles_k = p.tiles_k; w.g.tiles = p.tiles; w.g.m_chunk = p.m_chunk;
       w.block_begin = blocks[v]; w.reduce_begin = rblocks[v]; w.splits = p.splits; w.variant = v;

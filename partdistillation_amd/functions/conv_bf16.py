@@ -80,7 +80,7 @@ def conv_wgrad(dz, x, k, stride=1, pad=0, like=None):
 
 
 class _Desc(ctypes.Structure):                                      # PdConvWgradDesc (include/pd_conv.h)
-    _fields_ = [("dz", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p)] + \
+    _fields_ = [("dz", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("db", ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ("batch", "hi", "wi", "ci", "ho", "wo", "co", "k", "stride", "pad")]
 
 
@@ -108,12 +108,15 @@ def deferred_wgrads():
         flush()
 
 
-def rows_entry(dy, x, dw):
+def rows_entry(dy, x, dw, bias_acc=None):
     """queue entry for dw[N,K] = dy[M,N]^T x[M,K] (bf16 row-major, N % 8 == K % 8 == 0, dw rows K apart): a 1 x 1 "convolution" over
     M pixels — the decoder's key / value projection weight gradients (M = 10^3..10^5 memory tokens) ride in the same grouped launch"""
     M, N = dy.shape
     K = x.shape[1]
     assert dy.dtype == x.dtype == dw.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous() and dw.stride(0) == K
+    if bias_acc is not None:                                  # fp32 [N] accumulator: += dy.sum(0) in the same pass
+        assert bias_acc.dtype == torch.float32 and bias_acc.numel() == N
+        return ((dy, x, bias_acc), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (1, M, 1, K, M, 1, N, 1, 1, 0), bias_acc.data_ptr())
     return ((dy, x), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (1, M, 1, K, M, 1, N, 1, 1, 0))
 
 
@@ -125,6 +128,11 @@ def submit(entries):
         _Deferred.queue.extend(entries)
     else:
         _run(entries)
+
+
+def run_now(entries):
+    """one grouped launch for these problems, whatever the deferred queue's state"""
+    _run(list(entries))
 
 
 def flush():
@@ -140,8 +148,10 @@ def _run(q):
     for lo in range(0, len(q), _Deferred.MAXP):
         part = q[lo:lo + _Deferred.MAXP]
         descs = (_Desc * len(part))()
-        for d, (_keep, dzp, xp, dwp, geom) in zip(descs, part):
+        for d, entry in zip(descs, part):
+            _keep, dzp, xp, dwp, geom = entry[:5]
             d.dz, d.x, d.dw = dzp, xp, dwp
+            d.db = entry[5] if len(entry) > 5 else None
             d.batch, d.hi, d.wi, d.ci, d.ho, d.wo, d.co, d.k, d.stride, d.pad = geom
         need = int(L.pd_conv_bf16_wgrad_grouped_workspace_floats(ctypes.byref(descs), len(part)))
         ws = _WS.get(str(dev))

@@ -87,9 +87,7 @@ def _wgrad(dy, x, out=None, bias_acc=None, queue=None, big=None):
         # (1 x 1 "convolution" over the tokens), queued for the grouped launch — the library's kernel for [256, 32768] x [32768, 256]
         # takes 114 us
         dw = out if out is not None else torch.empty((dy.shape[1], x.shape[1]), dtype=torch.bfloat16, device=dy.device)
-        big.append(conv_bf16.rows_entry(dy, x, dw))
-        if bias_acc is not None:
-            rw.colsum_acc(dy, bias_acc)
+        big.append(conv_bf16.rows_entry(dy, x, dw, bias_acc))               # bias gradient: column sums of dy in the same launch
         return dw
     dw = torch.mm(dy.t(), x) if out is None else torch.mm(dy.t(), x, out=out)
     if bias_acc is not None:
@@ -299,7 +297,7 @@ class DecoderCore(Function):
 
         if wq is not None:
             wq.run()                                                         # before the bias accumulators below are read
-            conv_bf16.submit(big)                                            # joins the backbone's deferred group when that is active
+            conv_bf16.run_now(big)                                           # NOW: their bias sums are read (cast) right below
         bias_c = buf[:n_bias] if layers[0][1].dtype == torch.float32 else buf[:n_bias].to(layers[0][1].dtype)
 
         def Bc(s):

@@ -120,6 +120,24 @@ def test_deferred_grouped_wgrads_equal_the_immediate_ones():
             assert (w.grad.float() - imm.float()).abs().max().item() / rw.abs().max().item() < 2 ** -7
 
 
+def test_rows_problems_with_bias_sums_in_the_grouped_launch():
+    """Linear weight gradients over many rows as 1 x 1 "convolutions" (the decoder's key / value projections), with the bias
+    gradient (column sums of dy, fp32 accumulator) produced by the same launch."""
+    from partdistillation_amd.functions import conv_bf16 as C
+    entries, checks = [], []
+    for i, (M, N, K) in enumerate([(32768, 256, 256), (2048, 256, 256), (777, 64, 128), (5000, 128, 64), (100, 64, 64)]):
+        dy, x = _mk((M, N), 300 + i), _mk((M, K), 400 + i)
+        dw = torch.empty((N, K), dtype=torch.bfloat16, device=DEV)
+        acc = torch.full((N,), 0.5, device=DEV)
+        entries.append(C.rows_entry(dy, x, dw, acc))
+        checks.append((dy, x, dw, acc))
+    C.run_now(entries)
+    for dy, x, dw, acc in checks:
+        ref = dy.float().t() @ x.float()
+        assert (dw.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+        torch.testing.assert_close(acc - 0.5, dy.float().sum(0), rtol=1e-4, atol=2e-2)
+
+
 def test_conv_rejects_what_it_does_not_cover():
     from partdistillation_amd import lib
     from partdistillation_amd.functions import conv_bf16 as C
