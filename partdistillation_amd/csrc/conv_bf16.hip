@@ -543,6 +543,26 @@ namespace {
 
 int variant_of(const WgradPlan &p) { return p.tn == 128 ? (p.tk == 128 ? 0 : 1) : (p.tk == 128 ? 2 : 3); }
 
+// plans of a group: kGroupRows pixels per workgroup, halved for a tile shape whose launch would otherwise hold fewer than ~768
+// workgroups (each tile shape is its own launch: a lone 64 -> 64 1 x 1 layer of res2 is ONE tile — 64 workgroups at 2 048 rows)
+void plan_group(const PdConvWgradDesc *descs, int count, WgradPlan *plans)
+{
+  int rows[4] = {kGroupRows, kGroupRows, kGroupRows, kGroupRows};
+  for (int pass = 0; pass < 4; ++pass) {
+    int blocks[4] = {0, 0, 0, 0};
+    for (int i = 0; i < count; ++i) {
+      const int M = descs[i].batch * descs[i].ho * descs[i].wo, N = descs[i].co, K = descs[i].k * descs[i].k * descs[i].ci;
+      const int v = variant_of(wgrad_plan(M, N, K, kGroupRows));
+      plans[i] = wgrad_plan(M, N, K, rows[v]);
+      blocks[v] += plans[i].tiles * plans[i].splits;
+    }
+    bool again = false;
+    for (int v = 0; v < 4; ++v)
+      if (blocks[v] > 0 && blocks[v] < 768 && rows[v] > 256) { rows[v] /= 2; again = true; }
+    if (!again) break;
+  }
+}
+
 bool desc_ok(const PdConvWgradDesc &d)
 {
   if (!d.dz || !d.x || !d.dw) return false;
@@ -556,11 +576,11 @@ extern "C" int64_t pd_conv_bf16_wgrad_grouped_table_bytes(int count) { return (i
 
 extern "C" int64_t pd_conv_bf16_wgrad_grouped_workspace_floats(const PdConvWgradDesc *descs, int count)
 {
+  if (count <= 0 || count > 256 || !descs) return 0;
+  WgradPlan plans[256];
+  plan_group(descs, count, plans);
   int64_t total = 0;
-  for (int i = 0; i < count; ++i) {
-    const WgradPlan p = wgrad_plan(descs[i].batch * descs[i].ho * descs[i].wo, descs[i].co, descs[i].k * descs[i].k * descs[i].ci, kGroupRows);
-    total += (int64_t)p.tiles * p.splits * p.tn * p.tk;
-  }
+  for (int i = 0; i < count; ++i) total += (int64_t)plans[i].tiles * plans[i].splits * plans[i].tn * plans[i].tk;
   return total;
 }
 
@@ -575,9 +595,10 @@ extern "C" int pd_conv_bf16_wgrad_grouped(const PdConvWgradDesc *descs, int coun
   int order[4][256];
   if (count > 256) return PD_ERR_INVALID_ARG;
   WgradPlan plans[256];
-  for (int i = 0; i < count; ++i) {
+  for (int i = 0; i < count; ++i)
     if (!desc_ok(descs[i])) return PD_ERR_INVALID_ARG;
-    plans[i] = wgrad_plan(descs[i].batch * descs[i].ho * descs[i].wo, descs[i].co, descs[i].k * descs[i].k * descs[i].ci, kGroupRows);
+  plan_group(descs, count, plans);
+  for (int i = 0; i < count; ++i) {
     const int v = variant_of(plans[i]);
     order[v][n_of[v]++] = i;
   }
