@@ -43,6 +43,7 @@ extern int g_pd_dbg_wattn;
 extern int g_pd_dbg_x3;
 extern int g_pd_dbg_kmeans;
 extern int g_pd_dbg_conv_group_rows;
+extern int g_pd_dbg_sgemm_deep;
 extern "C" int pd_debug_set(const char *key, int value)
 {
   if (!key) return PD_ERR_INVALID_ARG;
@@ -53,6 +54,7 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!strcmp(key, "msda_bwd_threads")) { g_pd_dbg_bwd_threads = value; return PD_OK; }
   if (!strcmp(key, "wgrad_wgs")) { g_pd_dbg_wgrad_wgs = value; return PD_OK; }
   if (!strcmp(key, "kmeans_ablate")) { g_pd_dbg_kmeans = value; return PD_OK; }
+  if (!strcmp(key, "sgemm_deep")) { g_pd_dbg_sgemm_deep = value; return PD_OK; }
   if (!strcmp(key, "conv_group_rows")) { g_pd_dbg_conv_group_rows = value; return PD_OK; }
   if (!strcmp(key, "x3_ablate")) { g_pd_dbg_x3 = value; return PD_OK; }
   if (!strcmp(key, "x3_narrow")) { g_pd_dbg_x3_narrow = value; return PD_OK; }

@@ -93,6 +93,56 @@ __global__ __launch_bounds__(256) void sgemm_tn(const bf16_t *__restrict__ X, co
   }
 }
 
+// The same product for K <= 256 with the WHOLE contraction staged at once.  These GEMMs are pure latency: 4 chunks of 64 walked one
+// after the other each wait out a global-load latency (~1.7 us) for 4 MFMAs of work — 12.5 us per launch of which ~5 are launch cost.
+// Here every load of the workgroup (X 32 x K, W 128 x K: 20 x 16 bytes per thread) is in flight together, one LDS stage, one barrier.
+constexpr int PK256 = 256 + 8;                                               // bf16 elements per LDS row (528 B)
+template <bool RELU>
+__global__ __launch_bounds__(256) void sgemm_tn_k256(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
+                                                     const bf16_t *__restrict__ bias, bf16_t *__restrict__ Y, int M, int N, int K,
+                                                     int ldx, int ldw, int ldy)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char sg_smem[];
+  bf16_t(*Xs)[PK256] = reinterpret_cast<bf16_t(*)[PK256]>(sg_smem);                       // [32][PK256]
+  bf16_t(*Ws)[PK256] = reinterpret_cast<bf16_t(*)[PK256]>(sg_smem + 32 * PK256 * sizeof(bf16_t));   // [128][PK256]
+  const int nb = blockIdx.x * 128, mb = blockIdx.y * 32;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int prow = tid >> 5, pcol = (tid & 31) * 8;                          // 8 rows x 32 pieces per pass of the 256 threads
+  uint4 xr[4], wr[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xr[i] = load_piece(X, ldx, mb + prow + 8 * i, pcol, M, K);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wr[i] = load_piece(W, ldw, nb + prow + 8 * i, pcol, N, K);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) store_piece(&Xs[prow + 8 * i][pcol], xr[i]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) store_piece(&Ws[prow + 8 * i][pcol], wr[i]);
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int steps = K / 8;
+  for (int s = 0; s < steps; ++s)                                           // acc[n][m] += W[n][k..] . X[m][k..]
+    mma(acc, lds4(&Ws[32 * wave + r][8 * s + 4 * hh]), lds4(&Xs[r][8 * s + 4 * hh]));
+  const int m = mb + r;
+  if (m >= M) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n0 = nb + 32 * wave + 8 * g + 4 * hh;
+    if (n0 >= N) continue;
+    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    if (bias) {
+      const uint2 b = *reinterpret_cast<const uint2 *>(bias + n0);
+      v[0] += bf_lo(b.x); v[1] += bf_hi(b.x); v[2] += bf_lo(b.y); v[3] += bf_hi(b.y);
+    }
+    if (RELU) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    *reinterpret_cast<bf16x4 *>(Y + (int64_t)m * ldy + n0) = pack4(v[0], v[1], v[2], v[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ dX = dY W
 template <bool ACC, bool MASK>
 __global__ __launch_bounds__(256) void sgemm_nn(const bf16_t *__restrict__ dY, const bf16_t *__restrict__ W,
@@ -132,6 +182,59 @@ __global__ __launch_bounds__(256) void sgemm_nn(const bf16_t *__restrict__ dY, c
     if (c + 1 < nchunk) lstore(buf ^ 1);
     __syncthreads();
   }
+  const int m = mb + r;
+  if (m >= M) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int k0 = kb + 32 * wave + 8 * g + 4 * hh;
+    if (k0 >= K) continue;
+    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    bf16_t *dst = dX + (int64_t)m * ldx + k0;
+    if (ACC) {
+      const uint2 o = *reinterpret_cast<const uint2 *>(dst);
+      v[0] += bf_lo(o.x); v[1] += bf_hi(o.x); v[2] += bf_lo(o.y); v[3] += bf_hi(o.y);
+    }
+    if (MASK) {
+      const uint2 h = *reinterpret_cast<const uint2 *>(ref + (int64_t)m * ldx + k0);
+      if (!(bf_lo(h.x) > 0.f)) v[0] = 0.f;
+      if (!(bf_hi(h.x) > 0.f)) v[1] = 0.f;
+      if (!(bf_lo(h.y) > 0.f)) v[2] = 0.f;
+      if (!(bf_hi(h.y) > 0.f)) v[3] = 0.f;
+    }
+    *reinterpret_cast<bf16x4 *>(dst) = pack4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// dX = dY W for N <= 256 with the whole contraction staged at once (see sgemm_tn_k256)
+constexpr int PN256 = 256 + 8;
+template <bool ACC, bool MASK>
+__global__ __launch_bounds__(256) void sgemm_nn_n256(const bf16_t *__restrict__ dY, const bf16_t *__restrict__ W,
+                                                     const bf16_t *__restrict__ ref, bf16_t *__restrict__ dX, int M, int N, int K,
+                                                     int ldy, int ldw, int ldx)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char sg_smem[];
+  bf16_t(*Ys)[PN256] = reinterpret_cast<bf16_t(*)[PN256]>(sg_smem);                       // [32][PN256]
+  bf16_t(*Ws)[P128] = reinterpret_cast<bf16_t(*)[P128]>(sg_smem + 32 * PN256 * sizeof(bf16_t));     // [256][P128]
+  const int kb = blockIdx.x * 128, mb = blockIdx.y * 32;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int yrow = tid >> 5, ycol = (tid & 31) * 8;                          // dY: 8 rows x 32 pieces per pass
+  const int wrow = tid >> 4, wcol = (tid & 15) * 8;                          // W: 16 rows x 16 pieces per pass
+  uint4 yr[4], wr[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) yr[i] = load_piece(dY, ldy, mb + yrow + 8 * i, ycol, M, N);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wr[i] = load_piece(W, ldw, wrow + 16 * i, kb + wcol, N, K);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) store_piece(&Ys[yrow + 8 * i][ycol], yr[i]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) store_piece(&Ws[wrow + 16 * i][wcol], wr[i]);
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int steps = N / 8;
+  for (int s = 0; s < steps; ++s)                                           // acc[k][m] += W^T[k][n..] . dY[m][n..]
+    mma(acc, gather4(&Ws[8 * s + 4 * hh][32 * wave + r], P128), lds4(&Ys[r][8 * s + 4 * hh]));
   const int m = mb + r;
   if (m >= M) return;
 #pragma unroll
@@ -357,6 +460,8 @@ int check_common(const char *who, const void *a, const void *b, const void *c, i
 
 }  // namespace
 
+int g_pd_dbg_sgemm_deep = 1;   // tools/ only (pd_debug_set "sgemm_deep"): 0 = the chunked kernels also for K / N <= 256
+
 extern "C" int pd_sgemm_tn_bf16(const void *X, const void *W, const void *bias, void *Y, int M, int N, int K, int ldx, int ldw,
                                 int ldy, int relu, void *stream_)
 {
@@ -367,6 +472,18 @@ extern "C" int pd_sgemm_tn_bf16(const void *X, const void *W, const void *bias, 
   if (M == 0 || N == 0) return PD_OK;
   const dim3 g((N + 127) / 128, (M + 31) / 32), b(256);
   hipStream_t s = (hipStream_t)stream_;
+  if (K <= 256 && g_pd_dbg_sgemm_deep) {                 // whole contraction in flight at once (latency-bound products)
+    constexpr size_t lds = (size_t)(32 + 128) * PK256 * sizeof(bf16_t);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void *)sgemm_tn_k256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void *)sgemm_tn_k256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    if (relu) hipLaunchKernelGGL(sgemm_tn_k256<true>, g, b, lds, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, M, N, K, ldx, ldw, ldy);
+    else hipLaunchKernelGGL(sgemm_tn_k256<false>, g, b, lds, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, M, N, K, ldx, ldw, ldy);
+    return pd_check_launch("pd_sgemm_tn_bf16");
+  }
   if (relu) hipLaunchKernelGGL(sgemm_tn<true>, g, b, 0, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, M, N, K, ldx, ldw, ldy);
   else hipLaunchKernelGGL(sgemm_tn<false>, g, b, 0, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, M, N, K, ldx, ldw, ldy);
   return pd_check_launch("pd_sgemm_tn_bf16");
@@ -381,6 +498,22 @@ extern "C" int pd_sgemm_nn_bf16(const void *dY, const void *W, const void *relu_
   if (M == 0 || K == 0) return PD_OK;
   const dim3 g((K + 127) / 128, (M + 31) / 32), b(256);
   hipStream_t s = (hipStream_t)stream_;
+  if (N <= 256 && g_pd_dbg_sgemm_deep) {
+    constexpr size_t lds = (size_t)32 * PN256 * sizeof(bf16_t) + (size_t)256 * P128 * sizeof(bf16_t);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void *)sgemm_nn_n256<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void *)sgemm_nn_n256<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void *)sgemm_nn_n256<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void *)sgemm_nn_n256<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+#define LAUNCHD(A, R) hipLaunchKernelGGL((sgemm_nn_n256<A, R>), g, b, lds, s, (const bf16_t *)dY, (const bf16_t *)W, (const bf16_t *)relu_ref, (bf16_t *)dX, M, N, K, ldy, ldw, ldx)
+    if (accumulate) { if (relu_ref) LAUNCHD(true, true); else LAUNCHD(true, false); }
+    else { if (relu_ref) LAUNCHD(false, true); else LAUNCHD(false, false); }
+#undef LAUNCHD
+    return pd_check_launch("pd_sgemm_nn_bf16");
+  }
 #define LAUNCH(A, R) hipLaunchKernelGGL((sgemm_nn<A, R>), g, b, 0, s, (const bf16_t *)dY, (const bf16_t *)W, (const bf16_t *)relu_ref, (bf16_t *)dX, M, N, K, ldy, ldw, ldx)
   if (accumulate) { if (relu_ref) LAUNCH(true, true); else LAUNCH(true, false); }
   else { if (relu_ref) LAUNCH(false, true); else LAUNCH(false, false); }
