@@ -13,6 +13,7 @@
 // current one, split and written to the other stage after them (one barrier per 16-wide step).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "mfma_bf16.h"
 #include "pd_common.h"
@@ -175,24 +176,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32x3(const float *__restrict_
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] += tot[i][j][e];
-  // C layout of the 32x32 MFMA: col = lane & 31 (B row), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (A row)
+  // C layout of the 32x32 MFMA: col = lane & 31 (B row), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (A row); bias loaded before the
+  // first store and a branch-free path for interior tiles (see the wide kernel's epilogue: guarded stores serialise on vmcnt(0))
+  float bv[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wn + j * 32 + (lane & 31);
-    if (col >= N) continue;
-    const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (row < M && (ABL != 4 || v_never(acc[i][j][e]))) {
-          float v = acc[i][j][e] + bv;
-          if (RELU) v = fmaxf(v, 0.f);
-          C[(int64_t)row * ldc + col] = v;
-        }
-      }
+    bv[j] = (bias && col < N) ? bias[col] : 0.f;
   }
+  const bool full = m0 + BM <= M && n0 + BN <= N;
+  auto store_tile = [&](auto guard) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          float v = acc[i][j][e] + bv[j];
+          if (RELU) v = fmaxf(v, 0.f);
+          if ((!decltype(guard)::value || (row < M && col < N)) && (ABL != 4 || v_never(acc[i][j][e]))) C[(int64_t)row * ldc + col] = v;
+        }
+    }
+  };
+  if (full) store_tile(std::false_type{});
+  else store_tile(std::true_type{});
 }
 
 // ---------------------------------------------------------------------------------------------- wide tiles
@@ -345,39 +354,54 @@ __global__ __launch_bounds__(128 * WVM, WVM == 4 ? 1 : 2) void gemm_tn_f32x3_wid
     step(kt, 0);
     if (kt + 1 < KT) step(kt + 1, 1);
   }
-  // C layout of the 32x32 MFMA: col = lane & 31 (B row), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (A row)
+  // C layout of the 32x32 MFMA: col = lane & 31 (B row), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (A row).
+  // Everything a store depends on is loaded BEFORE the first store, and interior tiles take a branch-free path: with a per-element
+  // `if (row < M)` around the store hipcc puts an s_waitcnt vmcnt(0) into every guarded block (it cannot prove the bias / bits load
+  // has been waited for on that path), and vmcnt counts stores too — every store then waited for the previous one's
+  // acknowledgement, 128 serialised round trips per wave (round 3: ~35 of this kernel's ~185 us at 1024 <- 256).
+  float bv[4];
+  uint32_t word[4];
+  int64_t widx[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int col = n0 + wn + j * 32 + (lane & 31);
-    if (col >= N) continue;
-    const float bv = bias ? bias[col] : 0.f;
-    float csum = 0.f;
-    const int64_t widx = (((int64_t)lb * (2 * WVM) + wave) * 64 + lane) * 4 + j;
-    uint32_t word = MASKSUM ? bits[widx] : 0u;
+    bv[j] = (bias && col < N) ? bias[col] : 0.f;
+    widx[j] = (((int64_t)lb * (2 * WVM) + wave) * 64 + lane) * 4 + j;
+    word[j] = MASKSUM ? bits[widx[j]] : 0u;
+  }
+  const bool full = m0 + TBM <= M && n0 + WBN <= N;
+  auto store_tile = [&](auto guard) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wn + j * 32 + (lane & 31);
+      float csum = 0.f;
+      uint32_t w = word[j];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (row < M && (ABL != 2 || v_never(acc[i][j][e]))) {
-          float v = acc[i][j][e] + bv;
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          const bool ok = !decltype(guard)::value || (row < M && col < N);
+          float v = acc[i][j][e] + bv[j];
           if (RELU) {
             v = fmaxf(v, 0.f);
-            word |= (v > 0.f ? 1u : 0u) << (i * 16 + e);
+            if (ok) w |= (v > 0.f ? 1u : 0u) << (i * 16 + e);
           }
           if (MASKSUM) {
-            v = ((word >> (i * 16 + e)) & 1u) ? v : 0.f;
-            csum += v;
+            v = ((w >> (i * 16 + e)) & 1u) ? v : 0.f;
+            if (ok) csum += v;
           }
-          C[(int64_t)row * ldc + col] = v;
+          if (ok && (ABL != 2 || v_never(acc[i][j][e]))) C[(int64_t)row * ldc + col] = v;
         }
+      if (RELU && bits && col < N) bits[widx[j]] = w;
+      if (MASKSUM) {
+        csum += __shfl_xor(csum, 32, 64);                          // the two row halves of the wavefront hold the same column
+        if (lane < 32 && csum != 0.f && col < N) unsafeAtomicAdd(colsum + col, csum);
       }
-    if (RELU && bits) bits[widx] = word;
-    if (MASKSUM) {
-      csum += __shfl_xor(csum, 32, 64);                          // the two row halves of the wavefront hold the same column
-      if (lane < 32 && csum != 0.f) unsafeAtomicAdd(colsum + col, csum);
     }
-  }
+  };
+  if (full) store_tile(std::false_type{});
+  else store_tile(std::true_type{});
 }
 
 // ---------------------------------------------------------------------------------------------- weight gradient

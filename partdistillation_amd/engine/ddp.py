@@ -7,10 +7,14 @@ been produced, one multi-tensor kernel gathers them into the bucket's contiguous
 The reference gets this from detectron2's ``create_ddp_model`` (torch DDP over NCCL); the only other collective on
 the path is the scalar ``num_masks`` all-reduce of criterion.py:252-254, kept in modeling/criterion.py.
 Works with any torch.distributed backend ("nccl" = RCCL on ROCm; "gloo" in the CPU tests)."""
+import contextlib
+import os
 from typing import List
 
 import torch
 import torch.distributed as dist
+
+_CHECK_SPARSE_ROWS = bool(int(os.environ.get("PD_DDP_CHECK_SPARSE", "0")))   # assert that a row-sparse group's gradient is zero outside its rows
 
 from ..functions.conv_bf16 import flush as _flush_deferred_wgrads
 
@@ -53,6 +57,7 @@ class BucketedGradReducer:
         for i, b in enumerate(self.buckets):
             b.index = i
         self._next = 0                    # collectives are issued in bucket-index order on every rank (see _on_grad)
+        self._row_meta = {}               # sparse group -> (rows, [R max, any rank without a record], event)
         self._use_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         dev = flat.groups[0].grad.device
         self._side = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and overlap) else None
@@ -94,25 +99,81 @@ class BucketedGradReducer:
 
     def _exchange_rows(self, gi):
         """mean over the ranks of a row-sparse group's gradient from the touched rows only.  Every parameter of the group is
-        [rows, ...] and carries `_pd_rows` (LongTensor [R], the rows this rank's step used; R is the same on every rank:
-        images per GPU x (K + 1)).  Equal to the dense all-reduce: untouched rows are exact zeros everywhere."""
+        [rows, ...] and carries `_pd_rows` (LongTensor [R], the rows this rank's step used: images per GPU x (K + 1)).  Equal to
+        the dense all-reduce: untouched rows are exact zeros everywhere.
+        The ranks first agree on ONE path (a MAX all-reduce of [R, no-record flag], 16 bytes): if any rank has no row record this
+        step, or the ranks' R differ (uneven last batch), a rank that went on to all_gather R-sized buffers would hang the others or
+        scatter garbage — so R is padded to the maximum with a sentinel row (-1, dropped on arrival) and a missing record sends
+        everyone down the dense all-reduce.  The record is consumed: a stale list is never exchanged for a later step."""
         g = self.flat.groups[gi]
-        g.gather(None)                                            # local dense gradients -> flat buffer
+        g.gather(None)                                            # local dense gradients -> flat buffer (compute stream)
+        rows, meta_host, ev = self._row_meta.pop(gi)
+        dev = g.grad.device
+        if ev is not None:
+            ev.synchronize()                                      # waits for the 16-byte agreement only (side stream), not for the compute stream
+        r_max, any_missing = int(meta_host[0]), int(meta_host[1])
+        side = self._side
+        if side is not None:                                      # the exchange itself runs on the side stream, behind the bucket all-reduces
+            side.wait_stream(torch.cuda.current_stream(dev))
+        ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+        with ctx:
+            self._exchange_rows_on_stream(g, rows, r_max, any_missing, dev)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
+
+    def _agree_rows(self, gi):
+        """start the ranks' agreement on the row-sparse path of group gi (MAX all-reduce of [R, no-record flag]); issued by
+        finish() right behind the last bucket all-reduce, on the side stream, read back through a pinned buffer"""
+        g = self.flat.groups[gi]
         rows = getattr(g.params[0], "_pd_rows", None)
-        if rows is None:                                          # no row record (parameter unused this step): dense path
+        for p in g.params:
+            if hasattr(p, "_pd_rows"):
+                p._pd_rows = None                                 # consumed: a stale list is never exchanged for a later step
+        dev = g.grad.device
+        host = torch.tensor([0 if rows is None else int(rows.numel()), 1 if rows is None else 0], dtype=torch.int64)
+        if dev.type != "cuda":
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.pg)
+            self._row_meta[gi] = (rows, host, None)
+            return
+        pinned = torch.empty(2, dtype=torch.int64, pin_memory=True)
+        pinned.copy_(host)
+        side = self._side if self._side is not None else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(side):
+            meta = pinned.to(dev, non_blocking=True)
+            dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=self.pg)
+            pinned.copy_(meta, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._row_meta[gi] = (rows, pinned, ev)
+
+    def _exchange_rows_on_stream(self, g, rows, r_max, any_missing, dev):
+        if any_missing or r_max == 0:                             # dense path, on EVERY rank
             dist.all_reduce(g.grad, group=self.pg)
             g.grad.div_(self.world)
             return
-        rows = rows.reshape(-1).to(g.grad.device)
+        rows = rows.reshape(-1).to(dev)
+        if _CHECK_SPARSE_ROWS:                                    # debugging aid: the dense gradient must vanish outside `rows`
+            views_chk = [g._view(g.grad, p, off).reshape(p.shape[0], -1) for p, off in zip(g.params, g.offsets)]
+            for v in views_chk:
+                mask = torch.ones(v.shape[0], dtype=torch.bool, device=dev)
+                mask[rows] = False
+                assert not bool(v[mask].any()), "row-sparse gradient group has non-zero rows outside its row record"
         # a row listed twice (two images of one class, the shared no-object row) holds the SUM already: send it once
         first = ~(rows[:, None] == rows[None, :]).tril(-1).any(1)
         views = [g._view(g.grad, p, off).reshape(p.shape[0], -1) for p, off in zip(g.params, g.offsets)]
         pack = torch.cat([v[rows] for v in views], dim=1) * first[:, None].to(g.grad.dtype)
+        if rows.numel() < r_max:                                  # pad to the agreed size: sentinel rows carry zeros
+            pad = r_max - rows.numel()
+            rows = torch.cat([rows, rows.new_full((pad,), -1)])
+            pack = torch.cat([pack, pack.new_zeros((pad, pack.shape[1]))])
         all_pack = [torch.empty_like(pack) for _ in range(self.world)]
         all_rows = [torch.empty_like(rows) for _ in range(self.world)]
         dist.all_gather(all_pack, pack.contiguous(), group=self.pg)
         dist.all_gather(all_rows, rows.contiguous(), group=self.pg)
         rows_all, pack_all = torch.cat(all_rows), torch.cat(all_pack) / self.world
+        keep = rows_all >= 0
+        if not bool(keep.all()):
+            rows_all, pack_all = rows_all[keep], pack_all[keep]
         col = 0
         for v in views:
             w = v.shape[1]
@@ -128,6 +189,8 @@ class BucketedGradReducer:
         for b in self.buckets[self._next:]:                      # in index order, like the hooks
             self._launch(b)
         self._next = 0
+        for gi in self.sparse_groups:                            # after the LAST bucket on every rank: one collective order for all
+            self._agree_rows(gi)
         for b in self.buckets:
             buf = self.flat.groups[b.group].grad[b.start:b.end]
             if self._side is not None:

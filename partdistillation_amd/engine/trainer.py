@@ -5,11 +5,12 @@ backward (gradient all-reduce overlapped) -> clipped AdamW -> LR schedule.
 bf16 autocast needs no GradScaler (the reference's fp16 AMP on V100 does); the pixel decoder and the matcher costs
 stay fp32 as in the reference.
 
-The step issues ~3 000 kernels; PyTorch's eager dispatch of them costs more host time than the GPU needs to run
-them, so on a single GPU the whole step (forward, criterion, backward, gradient gather, optimizer) is captured ONCE
-into a hipGraph and replayed: the step has no host synchronisation and no data-dependent shapes (device-side
-Hungarian matching, host-known index tables), learning rate and Adam bias corrections are read from device memory,
-and the batch is copied into static input buffers before each replay."""
+The step is issued EAGERLY (the default and the only mode used by bench.py and the tests): it has no host
+synchronisation and no data-dependent shapes (device-side Hungarian matching, host-known index tables; learning rate
+and Adam bias corrections are read from device memory), so the host simply runs ahead of the GPU.  `capture()` can
+record the whole step into one hipGraph, but on ROCm 7.2 the only SAFE replay mode (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0)
+costs more host time than eager issue, so it is opt-in and refuses to run without that setting (DESIGN.md §5
+"hipGraph")."""
 import os as _os
 import warnings
 
@@ -23,6 +24,9 @@ from .ddp import BucketedGradReducer, broadcast_parameters
 from .optimizer import build_lr_scheduler, build_optimizer
 
 _GRAPH_SYNC = bool(int(_os.environ.get("PD_GRAPH_SYNC", "0")))          # debugging aid: device fence between two replays of the captured step
+# read ONCE at import: the HIP runtime reads the variable when it initialises, so a value set later passes a check of os.environ
+# but changes nothing (bench.py --graph 1 sets it before importing torch)
+_PACKET_CAPTURE_AT_IMPORT = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")
 
 
 def _detached(loss_dict):
@@ -88,6 +92,8 @@ class TrainStep:
     def release_graph(self):
         self._graph = self._static = self._static_losses = self._graph_sig = None
         self._replay_done = None
+        from ..functions.fused import PinnedRing
+        PinnedRing.release_captured()                      # the pinned buffers reserved for the uploads baked into the graph
 
     def _signature(self, batch):
         """everything the captured step read on the HOST (and therefore baked into the graph): tensor shapes and, for
@@ -102,7 +108,7 @@ class TrainStep:
                 + list(opt.exp_avg) + list(opt.exp_avg_sq))
 
     def _segment(self, batch, segment, rehearsal):
-        """the captured sequence ("full"; "fb" / "fwd" are truncations for tools/debug_graph3.py's bisection)"""
+        """the captured sequence ("full"; "fb" / "fwd" are truncations used to bisect replay faults)"""
         if segment == "fwd":
             with torch.no_grad(), torch.autocast(device_type=self.model.device.type, dtype=torch.bfloat16, enabled=self.amp):
                 return self.model(batch)
@@ -118,12 +124,13 @@ class TrainStep:
         trajectory (weights, moments and step count are exactly what they were before the call)."""
         if self.world > 1:
             raise RuntimeError("hipGraph capture of the step is for the single-GPU path (collectives stay eager)")
-        if _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+        if warmup < 1:
+            raise ValueError("TrainStep.capture(): warmup must be >= 1 (the last warm-up step is the rehearsal that sizes the pinned buffers)")
+        if _PACKET_CAPTURE_AT_IMPORT != "0":
             # ROCm 7.2 instantiates graphs with pre-built AQL packets ("packet capture").  Such a graph goes stale once a
             # few thousand EAGER launches have been issued since it was instantiated (the input copies between replays
             # count): its kernels then read wrong arguments — first silently (NaN gradient norm in the replayed
-            # optimizer, tools/debug_graph5.py), later as a memory access fault (tools/debug_graph3.py mixsync: replay,
-            # 3 eager steps, replay -> 5/5 faults; bench.py --graph 1 --steps 2000 faults, --steps 300 does not).  None of
+            # optimizer), later as a memory access fault (replay, 3 eager steps, replay -> 5/5 faults; bench.py --graph 1 --steps 2000 faults, --steps 300 does not).  None of
             # HIP_FORCE_DEV_KERNARG / DEBUG_HIP_KERNARG_COPY_OPT / DEBUG_HIP_FORCE_GRAPH_QUEUES / ... changes that;
             # DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 does (0 faults, replay == eager), at 60 ms of host CPU per replay of
             # this ~3 000-node graph, i.e. slower than eager issue (19 ms).  Silent corruption is not an option, so:
@@ -141,7 +148,10 @@ class TrainStep:
         live = self._flat_state()
         snapshot = [t.clone() for t in live]
         steps0 = self.optimizer.steps
+        # the warm-up consumes random numbers (criterion sample points, DropPath): put both generators back afterwards
+        rng_cpu, rng_dev = torch.get_rng_state(), (torch.cuda.get_rng_state() if torch.cuda.is_available() else None)
         from ..functions.fused import PinnedRing
+        before = PinnedRing.counters()
         for w in range(warmup):
             if w == warmup - 1:
                 before = PinnedRing.counters()                   # the last warm-up step is the rehearsal of the captured sequence
@@ -152,6 +162,9 @@ class TrainStep:
                 t.copy_(s)
         self.optimizer.steps = steps0
         del snapshot
+        torch.set_rng_state(rng_cpu)
+        if rng_dev is not None:
+            torch.cuda.set_rng_state(rng_dev)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad()
@@ -160,7 +173,7 @@ class TrainStep:
         # keep only DETACHED views of the static losses: holding the captured autograd graph alive would also keep its
         # AccumulateGrad nodes, which are bound to the capture stream — every later EAGER step (a batch with another
         # signature) would then run its gradient accumulation on that stream, and the next replay faults on ROCm 7.2
-        # (tools/debug_graph3.py mixsync).
+        # (DESIGN.md §5 "hipGraph").
         loss_dict = _detached(loss_dict)
         self._graph, self._static, self._static_losses = graph, static, loss_dict
         self._graph_sig = self._signature(example_batch)

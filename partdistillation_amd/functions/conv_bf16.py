@@ -3,6 +3,7 @@ frozen-BN affine + residual add + ReLU; the input gradient = transposed convolut
 shortcut.  GPU only; no fallback."""
 import contextlib
 import ctypes
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -88,6 +89,7 @@ class _Deferred:
     """filter gradients queued by Conv2dOwnWgrad.backward while `deferred_wgrads()` is active: ((dz, x) kept alive, their addresses, the address of dw, geometry)"""
     active = False
     queue = []
+    adopt = []                                               # (weakref(filter), address handed to autograd): verify_adopted()
     ring = None
     table_dev = None
     MAXP = 256
@@ -106,6 +108,22 @@ def deferred_wgrads():
     finally:
         _Deferred.active = prev
         flush()
+        verify_adopted()
+
+
+def verify_adopted():
+    """every unwritten tensor Conv2dOwnWgrad.backward handed to autograd must have become its filter's .grad (the grouped launch wrote
+    through the raw address): if AccumulateGrad cloned it or added it into an existing .grad — gradient accumulation without
+    zero_grad, a tensor hook on the weight, retain_graph — the filter would silently train on uninitialised memory.  Checked after
+    the backward pass; backward() avoids the known cases by computing such gradients immediately."""
+    pending, _Deferred.adopt = _Deferred.adopt, []
+    for wref, ptr in pending:
+        w = wref()
+        if w is None:
+            continue
+        if w.grad is None or w.grad.data_ptr() != ptr:
+            raise RuntimeError("deferred filter gradient was not adopted as .grad of its weight (shape %s): the grouped launch wrote "
+                               "into an orphaned buffer — run this backward outside deferred_wgrads()" % (tuple(w.shape),))
 
 
 def rows_entry(dy, x, dw, bias_acc=None):
@@ -191,13 +209,17 @@ class Conv2dOwnWgrad(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.ops.aten.convolution_backward(dz, x, weight, None, [s, s], [p, p], [1, 1], False, [0, 0], 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            if _Deferred.active:
+            # deferred only when AccumulateGrad will ADOPT the tensor we return: no existing .grad to add into, no tensor hooks on the
+            # weight, a leaf parameter; anything else gets its gradient computed now
+            adoptable = weight.grad is None and weight.is_leaf and not weight._backward_hooks and torch.is_grad_enabled() is False
+            if _Deferred.active and adoptable:
                 dw = torch.empty_strided(weight.shape, weight.stride(), dtype=torch.bfloat16, device=x.device)   # written by flush()
                 # only the ADDRESS is kept: with a second reference alive autograd's AccumulateGrad would not adopt this tensor
                 # as .grad but clone it (unwritten) — the adopted tensor keeps the storage alive until the flush
                 B, ci, H, W = x.shape
                 _Deferred.queue.append(((dz, x), dz.data_ptr(), x.data_ptr(), dw.data_ptr(),
                                         (B, H, W, ci, dz.shape[2], dz.shape[3], dz.shape[1], weight.shape[2], s, p)))
+                _Deferred.adopt.append((weakref.ref(weight), dw.data_ptr()))
             else:
                 dw = conv_wgrad(dz, x, weight.shape[2], s, p, like=weight)
         return dx, dw, None, None

@@ -63,8 +63,19 @@ class EncoderSpec:
 
 
 USE_X3 = True        # the FFN GEMMs (1024-wide) through pd_gemm_tn_f32x3; tools / tests switch it off to compare
+X3_PROJ = True       # the 256-wide projections (value / offsets+weights / output and their input gradients) on the same kernel: with the
+                     # round-3 epilogue (stores no longer serialised on vmcnt(0)) 256 <- 256 at M = 43 008 runs 47.7 us against the
+                     # library's ~57 (tools/probes/gemm_planes_probe.hip); False: torch.addmm / mm (Tensile fp32)
 PRESPLIT = False     # weight operand split into its bf16 planes once per use (pd_split3_bf16 + pd_gemm_tn_f32x3_pre).  Bit-identical results;
                      # measured 174.6 vs 178.6 us (1024 <- 256) and 157 vs 151 us (256 <- 1024) plus 8 us per split launch: no gain, so off
+
+
+def _proj(x, w, b=None):
+    """x [T, K] @ w [N, K]^T (+ b), fp32: a 256-wide projection of the encoder layer"""
+    if X3_PROJ and USE_X3 and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.stride(1) == 1 \
+            and x.stride(0) % 4 == 0:
+        return gemm_tn_x3(x, w, b)
+    return torch.addmm(b, x, w.t()) if b is not None else torch.mm(x, w.t())
 
 
 def _ffn_gemm(x, w, b=None, relu=False):
@@ -98,15 +109,15 @@ class EncoderCore(Function):
         x = src2
         for i in range(nl):
             (so_w, so_b, aw_w, aw_b, vp_w, vp_b, op_w, op_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b) = params[i * N_LAYER:(i + 1) * N_LAYER]
-            value = torch.addmm(vp_b, x, vp_w.t())
+            value = _proj(x, vp_w, vp_b)
             # sampling_offsets and attention_weights read the same input: one GEMM against their stacked weights
             w_oa, b_oa = torch.cat([so_w, aw_w]), torch.cat([so_b, aw_b])
-            oa = torch.addmm(b_oa, q, w_oa.t())                                        # [T, 2MLP + MLP]
+            oa = _proj(q, w_oa, b_oa)                                                  # [T, 2MLP + MLP]
             n_off = so_w.shape[0]
             loc, attn = msda_prep_fwd(oa[:, :n_off], oa[:, n_off:], ref, spec.shapes, M, L, P)
             v4, loc6, attn5 = value.view(B, S, M, C // M), loc.view(B, S, M, L, P, 2), attn.view(B, S, M, L, P)
             a = _timed("fwd", MSDA.ms_deform_attn_forward, v4, spec.shapes, spec.lsi, loc6, attn5, spec.im2col_step).view(T, C)
-            z1, y1, _, _, m1, r1 = rw.add_ln_fwd(torch.addmm(op_b, a, op_w.t()), x, n1_w, n1_b, spec.eps)
+            z1, y1, _, _, m1, r1 = rw.add_ln_fwd(_proj(a, op_w, op_b), x, n1_w, n1_b, spec.eps)
             hbits = None
             pre = USE_X3 and PRESPLIT and pre_supported(T, l1_w.shape[0], l1_w.shape[1]) and pre_supported(T, l2_w.shape[0], l2_w.shape[1])
             if pre:                       # weights split into their bf16 planes once here, not by every row tile of the GEMMs
@@ -157,6 +168,14 @@ class EncoderCore(Function):
             return buf[o:o + p.numel()].view(p.shape)
         d_pos = torch.zeros((T, C), dtype=torch.float32, device=dev)
         grads = [None] * (nl * N_LAYER)
+        # the input-gradient GEMMs want W^T row-major ([in, out] -> the "B[N, K]" operand with N = in): all layers' transposes in one
+        # stack + one copy per weight shape instead of one small launch per layer and weight
+        def T_all(j):
+            ws = [params[i * N_LAYER + j] for i in range(nl)]
+            return torch.stack(ws).transpose(1, 2).contiguous()
+        l1_t, l2_t = T_all(10), T_all(12)
+        op_t, vp_t = (T_all(6), T_all(4)) if X3_PROJ and USE_X3 else (None, None)
+        oa_t = torch.stack([sv[14] for sv in ctx.saved]).transpose(1, 2).contiguous() if op_t is not None else None
         dy = d_out.reshape(T, C)
         dy = dy if dy.is_contiguous() else dy.contiguous()
         dy2 = dyq = None                                       # further fp32 terms of d(src_l): via value_proj, via (src + pos)
@@ -173,16 +192,16 @@ class EncoderCore(Function):
             if pre:
                 dh = gemm_tn_x3_pre(dz2, split3(l2_w, transpose=True), mode=2, bits=hbits, colsum=g_l1b)
             elif hbits is not None:
-                dh = gemm_tn_x3_relumask(dz2, l2_w.t().contiguous(), hbits, g_l1b)  # ReLU backward + bias gradient in the epilogue
+                dh = gemm_tn_x3_relumask(dz2, l2_t[i], hbits, g_l1b)                # ReLU backward + bias gradient in the epilogue
             else:
-                dh = rw.relu_bwd_colsum(_ffn_gemm(dz2, l2_w.t().contiguous()), h, g_l1b)
+                dh = rw.relu_bwd_colsum(_ffn_gemm(dz2, l2_t[i]), h, g_l1b)
             wgrad(dh, y1, g_l1w)
-            dy1 = gemm_tn_x3_pre(dh, split3(l1_w, transpose=True)) if pre else _ffn_gemm(dh, l1_w.t().contiguous())
+            dy1 = gemm_tn_x3_pre(dh, split3(l1_w, transpose=True)) if pre else _ffn_gemm(dh, l1_t[i])
             del dh
             # ---- deformable attention + norm1
             dz1, _ = rw.add_ln_bwd(z1, m1, r1, n1_w, dy=dz2, dy2=dy1, dgamma=g_n1w, dbeta=g_n1b, dbias=g_opb, out=dz2)
             wgrad(dz1, a, g_opw)
-            da = torch.mm(dz1, op_w).view(B, S, C)
+            da = (_proj(dz1, op_t[i]) if op_t is not None else torch.mm(dz1, op_w)).view(B, S, C)
             gv, gloc, gattn = _timed("bwd", MSDA.ms_deform_attn_backward, v4, spec.shapes, spec.lsi, loc6, attn5, da, spec.im2col_step)
             d_oa = torch.empty((T, w_oa.shape[0]), dtype=torch.float32, device=dev)
             msda_prep_bwd(gloc, gattn, attn5, spec.shapes, T, M, L, P, out=d_oa)
@@ -190,10 +209,10 @@ class EncoderCore(Function):
             wgrad(d_oa, q, g_oaw, g_oab)                                  # both weight gradients in one split-K GEMM
             n_off = so_w.shape[0]
             g_sow, g_aww, g_sob, g_awb = g_oaw[:n_off], g_oaw[n_off:], g_oab[:n_off], g_oab[n_off:]
-            dq = torch.mm(d_oa, w_oa)
+            dq = _proj(d_oa, oa_t[i]) if op_t is not None else torch.mm(d_oa, w_oa)
             gv2 = gv.view(T, C)
             wgrad(gv2, x, g_vpw, g_vpb)
-            dxv = torch.mm(gv2, vp_w)
+            dxv = _proj(gv2, vp_t[i]) if vp_t is not None else torch.mm(gv2, vp_w)
             grads[i * N_LAYER:(i + 1) * N_LAYER] = [g_sow, g_sob, g_aww, g_awb, g_vpw, g_vpb, g_opw, g_opb, g_n1w, g_n1b,
                                                      g_l1w, g_l1b, g_l2w, g_l2b, g_n2w, g_n2b]
             dy, dy2, dyq = dz1, dxv, dq

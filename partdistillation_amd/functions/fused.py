@@ -129,6 +129,15 @@ class PinnedRing:
             for _ in range(max(0, n + margin - len(ring.reserved)) if n > 0 else 0):
                 ring.reserved.append(torch.zeros_like(ring.bufs[0]).pin_memory())
 
+    @classmethod
+    def release_captured(cls):
+        """drop the dedicated pinned buffers of released graphs (TrainStep.release_graph): nothing replays them any more"""
+        for r in cls._all:
+            ring = r()
+            if ring is not None:
+                ring.captured.clear()
+                ring.reserved.clear()
+
     def acquire(self):
         self.count += 1
         if self.pin and torch.cuda.is_current_stream_capturing():
