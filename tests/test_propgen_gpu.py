@@ -147,6 +147,93 @@ def test_proposal_generation_model_vs_reference_golden(golden, tag, metric, norm
 
 
 # ----------------------------------------------------------------------------- evaluation branch of ProposalModel (§8f-2)
+@pytest.mark.parametrize("metric", ["dot", "l2"])
+def test_config4_full_size_labels_equal_dense_reference_labelling(metric, monkeypatch):
+    """BASELINE config 4 at FULL size (SURVEY §8f-1 measurement spec): 4 x 1024 x 1024 synthetic images, one elliptical object each
+    (~35 % of the area), R50 backbone, res3 + res4 (C = 1536), K = 4.  The product labels the image from K score maps formed at
+    feature resolution; the reference (proposal_generation_model.py:141-146, 226-227) upsamples the C-channel features to full
+    resolution (6.4 GB per image) and takes the arg-max of `features . centroids` on the object's pixels.  Bilinear interpolation
+    is linear, so the two are the same function in real arithmetic: restate the reference's dense route here with torch ops on the
+    SAME features and the product's own centroids ("identical centroids injected") and count the pixels that differ — only fp32
+    re-association near-ties may (stated bound: 1e-4 of the object's pixels; SURVEY expects < 1e-5 on real features).  Also: label 0
+    exactly outside the object, labels 1..K inside, the COCO RLE of each label decodes to `labels == l`, and the device
+    Lloyd's fixed point is a Lloyd fixed point of the reference's clustering input (one more sklearn-semantics assignment step on
+    the CPU restatement leaves the labels of the 1/8-resolution object pixels unchanged up to the same near-tie bound)."""
+    import os
+    from oracle import proposal_generation_ref as P
+    from partdistillation_amd.compat import BitMasks, Instances, build_model
+    from partdistillation_amd.config import setup_cfg
+    from partdistillation_amd.utils import rle
+    import partdistillation_amd.modeling, partdistillation_amd.proposal_generation_model  # noqa: F401,E401
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = setup_cfg(os.path.join(root, "partdistillation_amd", "configs", "proposal_generation", "r50.yaml"),
+                    ["PROPOSAL_GENERATION.DISTANCE_METRIC", metric])
+    assert cfg.PROPOSAL_GENERATION.NUM_SUPERPIXEL_CLUSTERS == 4 and list(cfg.PROPOSAL_GENERATION.BACKBONE_FEATURE_KEY_LIST) == ["res3", "res4"]
+    torch.manual_seed(0)
+    model = build_model(cfg).to(DEV).eval()
+    S, Bn = 1024, 4
+    ys, xs = torch.meshgrid(torch.arange(S) / S, torch.arange(S) / S, indexing="ij")
+    g = torch.Generator().manual_seed(44)
+    batch, masks = [], []
+    for b in range(Bn):
+        cy, cx = 0.5 + 0.03 * (b - 1.5), 0.5 - 0.02 * (b - 1.5)                      # four different ellipses, ~35 % of the image
+        m = (((ys - cy) ** 2 / (0.13 - 0.005 * b) + (xs - cx) ** 2 / (0.085 + 0.004 * b)) < 1.0)
+        inst = Instances((S, S))
+        inst.gt_masks = BitMasks(m[None].to(DEV))
+        # smooth random images: the features of white noise have no cluster structure at all
+        img = F.interpolate(torch.rand(1, 3, S // 16, S // 16, generator=g), size=(S, S), mode="bicubic", align_corners=False)[0].clamp(0, 1) * 255
+        batch.append({"image": img.to(DEV), "instances": inst, "file_name": f"{b}.pth", "class_code": "n0"})
+        masks.append(m.to(DEV))
+        assert 0.3 < m.float().mean() < 0.4
+    feats = {}
+    f0 = model._prepare_features
+    monkeypatch.setattr(model, "_prepare_features", lambda fo: feats.setdefault("f", f0(fo)))
+    model.kmeans_generator = torch.Generator(device=DEV).manual_seed(0)
+    res = model(batch)
+    f = feats["f"]
+    assert f.shape == (Bn, 1536, S // 8, S // 8) and f.dtype == torch.float32
+    worst = 0.0
+    for b, r in enumerate(res):
+        labels, cen, m = r["labels"], r["centroids"].float(), masks[b]
+        assert labels.shape == (S, S) and labels.dtype == torch.uint8
+        assert not labels[~m].any() and bool((labels[m] >= 1).all()) and bool((labels <= 4).all())
+        # ("dot" on post-ReLU features may hand every pixel to the longest centroid — the reference's metric does the same; the
+        # nearest-centroid metric uses all four)
+        assert set(r["present_labels"]) <= {1, 2, 3, 4} and (metric == "dot" or len(r["present_labels"]) >= 2)
+        # the reference's dense route: [C, H, W] features -> object pixels -> distance to the centroids -> top-1
+        dense = F.interpolate(f[b:b + 1], size=(S, S), mode="bilinear", align_corners=False)[0]           # 6.4 GB
+        obj = dense[:, m]                                                                                  # [C, N]
+        del dense
+        sc = cen @ obj
+        if metric == "l2":
+            sc = 2.0 * sc - (cen * cen).sum(1)[:, None] - (obj * obj).sum(0)[None]                         # -(|x - c|^2), as :214-218
+        want = sc.argmax(0).to(torch.uint8) + 1
+        top2 = sc.topk(2, dim=0)[0]
+        del obj, sc
+        diff = (labels[m] != want)
+        worst = max(worst, diff.float().mean().item())
+        # every differing pixel is a numerical near-tie of the two best centroids
+        margin = (top2[0] - top2[1])[diff]
+        assert diff.float().mean().item() < 1e-4, (b, diff.float().mean().item())
+        assert margin.numel() == 0 or float(margin.max()) <= 1e-3 * float(top2[0].abs().max()), float(margin.max())
+        # COCO RLE per label == the label map (column-major runs; utils/rle.decode is pinned to the reference encoder's goldens)
+        for l, entry in zip(r["present_labels"], r["part_mask"]):
+            seg = dict(entry["segmentation"])
+            seg["counts"] = seg["counts"].encode("utf-8") if isinstance(seg["counts"], str) else seg["counts"]
+            assert np.array_equal(rle.decode(seg).astype(bool), (labels == l).cpu().numpy())
+        # the converged centroids are a Lloyd fixed point of the reference's clustering input (masked 1/8-resolution vectors)
+        m_low = F.interpolate(m[None, None].float(), size=f.shape[-2:], mode="nearest")[0, 0].bool()
+        X = f[b][:, m_low].t().contiguous()
+        d2 = (X * X).sum(1, keepdim=True) - 2.0 * X @ cen.t() + (cen * cen).sum(1)[None]
+        assign = d2.argmin(1)
+        newc = torch.stack([X[assign == k].mean(0) for k in range(4)])
+        shift = ((newc - cen) ** 2).sum().item()
+        tol = 1e-4 * X.var(0).mean().item()                                                              # sklearn's tol * mean variance
+        assert r["kmeans_iterations"] >= 1 and (shift <= tol * 4 or r["kmeans_iterations"] >= 300), (shift, tol, r["kmeans_iterations"])
+    print(f"config 4 full size ({metric}): worst label mismatch {worst:.2e} of the object's pixels; Lloyd iterations "
+          f"{[int(r['kmeans_iterations']) for r in res]}")
+
+
 @pytest.mark.parametrize("tag,unique,min_score", [("unique_1", True, -1.0), ("unique_0", False, 0.3)])
 def test_proposal_model_inference_vs_reference_golden(golden, tag, unique, min_score):
     """predicted part masks / scores / matched labels of the device evaluation branch against the real reference run:
