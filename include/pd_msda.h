@@ -71,6 +71,15 @@ const char *pd_last_error(void);
 /* library / ABI version, bumped when a signature changes */
 int pd_abi_version(void);
 
+/* tools / bench.py only.  For the Mask2Former geometry (3 levels, 4 points, 32 channels, num_query == spatial_size) pd_msda_backward
+ * has two LDS-window kernels: windows with a 5-cell halo (all 32 channels of a head per workgroup) and with a 9-cell halo (16
+ * channels per workgroup; ~1.7x the cost at small offsets, 3.5x faster at offsets of ~4 cells sigma).  Every launch counts the
+ * sample points that leave the 5-cell windows and publishes {missed, looked-at} to host-mapped memory when it finishes; a launch
+ * takes the 9-cell kernel when the most recent results that have arrived show more than 2 % misses (pd_debug_set("msda_gate_pct",
+ * per_mille); measured break-even: 0.9 % -> 0.28 vs 0.39 ms, 3.9 % -> 0.63 vs 0.40 ms per launch at BASELINE config-2 geometry).  out3 <- {missed, looked-at} of the most recent launch whose result has arrived, and the
+ * variant the most recent launch took (2 = 9-cell halo, 3 = 5-cell halo).  Reads host memory only, never synchronises. */
+int pd_msda_backward_last_gate(unsigned *out3);
+
 #ifdef __cplusplus
 }
 #endif

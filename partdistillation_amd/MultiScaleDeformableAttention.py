@@ -87,3 +87,52 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
             N, S, M, D, L, Lq, P, int(im2col_step), _DT[value.dtype], _stream())
     _lib.check(rc)
     return [gv, gl, ga]
+
+
+# ------------------------------------------------------------------------------------------------------------ torch.library
+# The two entry points above are also registered as PyTorch custom operators (namespace `pd`) with schemas, fake (meta)
+# implementations and an autograd formula, so that torch.compile / torch.export / FakeTensor tracing see a real operator where
+# the reference has its pybind functions (ops/src/vision.cpp:19-22):
+#     torch.ops.pd.ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step) -> Tensor
+#     torch.ops.pd.ms_deform_attn_backward(value, ..., attn_weight, grad_output, im2col_step) -> (Tensor, Tensor, Tensor)
+# Only a "cuda" kernel is registered: on any other device the dispatcher raises, like the reference's AT_ERROR("Not implemented
+# on the CPU") (ms_deform_attn.h:45) — there is no CPU fallback.  The eager training path keeps calling the functions above
+# directly (one Python frame less per launch); `MSDeformAttnFunction` and `torch.ops.pd.ms_deform_attn_forward` are the same kernels.
+def _fwd_schema(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, sampling_loc: torch.Tensor,
+                attn_weight: torch.Tensor, im2col_step: int) -> torch.Tensor:
+    return ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+
+
+def _bwd_schema(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, sampling_loc: torch.Tensor,
+                attn_weight: torch.Tensor, grad_output: torch.Tensor, im2col_step: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    gv, gl, ga = ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step)
+    return gv, gl, ga
+
+
+ms_deform_attn_forward_op = torch.library.custom_op("pd::ms_deform_attn_forward", _fwd_schema, mutates_args=(), device_types="cuda")
+ms_deform_attn_backward_op = torch.library.custom_op("pd::ms_deform_attn_backward", _bwd_schema, mutates_args=(), device_types="cuda")
+
+
+@ms_deform_attn_forward_op.register_fake
+def _(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    return value.new_empty((value.shape[0], sampling_loc.shape[1], value.shape[2] * value.shape[3]))
+
+
+@ms_deform_attn_backward_op.register_fake
+def _(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
+    return torch.empty_like(value), torch.empty_like(sampling_loc), torch.empty_like(attn_weight)
+
+
+def _op_setup_context(ctx, inputs, output):
+    value, shapes, lvl, loc, attn, step = inputs
+    ctx.save_for_backward(value, shapes, lvl, loc, attn)
+    ctx.im2col_step = step
+
+
+def _op_backward(ctx, grad_output):
+    value, shapes, lvl, loc, attn = ctx.saved_tensors
+    gv, gl, ga = ms_deform_attn_backward_op(value, shapes, lvl, loc, attn, grad_output.contiguous(), ctx.im2col_step)
+    return gv, None, None, gl, ga, None
+
+
+ms_deform_attn_forward_op.register_autograd(_op_backward, setup_context=_op_setup_context)

@@ -36,6 +36,7 @@ extern int g_pd_dbg_force_generic;
 extern int g_pd_dbg_ablate;
 extern int g_pd_dbg_x3_narrow;
 extern int g_pd_dbg_bwd_variant;
+extern int g_pd_dbg_msda_gate_pct;
 extern int g_pd_dbg_wgrad_wgs;
 extern int g_pd_dbg_bwd_threads;
 extern int g_pd_dbg_attn_scalar;
@@ -50,6 +51,7 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!strcmp(key, "msda_bwd_atomic_scope")) { g_pd_dbg_atomic_scope = value; return PD_OK; }
   if (!strcmp(key, "msda_ablate")) { g_pd_dbg_ablate = value; return PD_OK; }
   if (!strcmp(key, "msda_bwd_variant")) { g_pd_dbg_bwd_variant = value; return PD_OK; }
+  if (!strcmp(key, "msda_gate_pct")) { g_pd_dbg_msda_gate_pct = value; return PD_OK; }
   if (!strcmp(key, "attn_scalar")) { g_pd_dbg_attn_scalar = value; return PD_OK; }
   if (!strcmp(key, "msda_bwd_threads")) { g_pd_dbg_bwd_threads = value; return PD_OK; }
   if (!strcmp(key, "wgrad_wgs")) { g_pd_dbg_wgrad_wgs = value; return PD_OK; }

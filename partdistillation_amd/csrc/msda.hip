@@ -462,6 +462,13 @@ __global__ __launch_bounds__(1024) void msda_bwd_tiled_d32(const float *__restri
 // sizes).  Levels whose window does not fit the LDS budget (non-pyramid shapes) get no window: direct atomics.
 // 0.378 -> 0.233 ms per launch at config 2 (tools/bench_msda.py, default spread).
 constexpr int kHalo4 = 5, kWin4 = kTile + 2 * kHalo4, kOwnCells4 = 1200;
+// HALF (round 3): the same kernel with the 32 channels of a head split over TWO workgroups.  A cell is then 17 words instead of
+// 33, the same LDS holds 2 330 cells, and the halo grows from 5 to 9 cells (34 x 34 + 26 x 26 + 22 x 22 at the standard
+// pyramid).  Every workgroup still forms the full 32-channel corner dot products (grad_attn / grad_loc need them; only the
+// half-0 workgroup stores them) but accumulates just its 16 channels, so the gather / geometry work doubles: ~0.4 ms per launch
+// instead of 0.23 — and stays there up to offsets of ~4 cells sigma, where the halo-5 kernel spends 2 ms in its global-atomic
+// fallback (40 % of the corners miss its windows).  pd_msda_backward picks per launch from a sampled miss count (below).
+constexpr int kHalo4H = 9, kWin4H = kTile + 2 * kHalo4H, kOwnCells4H = 2330;
 
 __device__ __forceinline__ float group4_sum(float x)
 {
@@ -470,15 +477,20 @@ __device__ __forceinline__ float group4_sum(float x)
   return x;
 }
 
-template <int ABL>
+template <int ABL, bool HALF = false>
 __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
                                                             const int64_t *__restrict__ lvl_start, const float *__restrict__ loc,
                                                             const float *__restrict__ attn, const float *__restrict__ grad_out,
                                                             float *__restrict__ grad_value, float *__restrict__ grad_loc,
-                                                            float *__restrict__ grad_attn, int S, int M, int B)
+                                                            float *__restrict__ grad_attn, int S, int M, int B,
+                                                            unsigned *__restrict__ cnt, unsigned long long *__restrict__ pub)
 {
   constexpr int L = 3, P = 4, LP = L * P;
-  extern __shared__ __attribute__((aligned(16))) int win[];   // kOwnCells4 cells x 33 words + 32 max slots + 32 scales
+  constexpr int HALO = HALF ? kHalo4H : kHalo4, WIN = HALF ? kWin4H : kWin4, CELLS = HALF ? kOwnCells4H : kOwnCells4, CW = HALF ? 17 : 33;
+  // cnt / pub (optional): the kernel counts the sample points that leave the halo-5 windows (cnt[0]) among those it looked at
+  // (cnt[1]); the last workgroup to finish (ticket cnt[2]) publishes both to host-mapped memory and clears the slot.  The host
+  // picks the variant of a LATER launch from what earlier launches published — no second launch, no synchronisation.
+  extern __shared__ __attribute__((aligned(16))) int win[];   // CELLS cells x CW words + 32 max slots + 32 scales
   int Hs[L], Ws[L], ls[L], maxdim = 1;
 #pragma unroll
   for (int j = 0; j < L; ++j) {
@@ -489,7 +501,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
   // block -> (batch, tile, head), heads fastest, over the ACTIVE tiles only (the host launches kGmax^2 per image: it cannot
   // see G) and XCD-chunked (block i runs on XCD i % 8): an XCD owns whole (batch, tile)s with all their heads, so a
   // query's loc / attn rows (all heads in one 768 / 384-byte run) are fetched into ONE L2
-  const int nact = B * G * G * M;
+  const int nact = B * G * G * M * (HALF ? 2 : 1);
   int idx;
   if ((nact & 7) == 0) {
     const int per = nact >> 3, k = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -499,23 +511,32 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
     if ((int)blockIdx.x >= nact) return;
     idx = blockIdx.x;
   }
+  const int half = HALF ? idx & 1 : 0;
+  if (HALF) idx >>= 1;
   const int m = idx % M; idx /= M;
   const int tile = idx % (G * G);
   const int b = idx / (G * G);
   const int ty = tile / G, tx = tile % G;
-  struct LvlP { int H, W, ls, wy0, wx0, wh, ww, wbase; };
+  struct LvlP { int H, W, ls, wy0, wx0, wh, ww, wbase, dy5, dx5, wh5, ww5; };   // (dy5 ..: the halo-5 window inside a halo-9 one)
   __shared__ LvlP lvp[L];
-  __shared__ int s_used, s_fixed_ok;
+  __shared__ int s_used, s_fixed_ok, s_miss;
   if (threadIdx.x == 0) {
+    s_miss = 0;
     int used = 0;
 #pragma unroll
     for (int j = 0; j < L; ++j) {
       LvlP t;
       t.H = Hs[j]; t.W = Ws[j]; t.ls = ls[j];
-      t.wy0 = max(0, ty * Hs[j] / G - kHalo4); t.wx0 = max(0, tx * Ws[j] / G - kHalo4);
-      t.wh = max(0, min(min(Hs[j], (ty + 1) * Hs[j] / G + kHalo4) - t.wy0, kWin4));
-      t.ww = max(0, min(min(Ws[j], (tx + 1) * Ws[j] / G + kHalo4) - t.wx0, kWin4));
-      if (used + t.wh * t.ww > kOwnCells4) { t.wh = 0; t.ww = 0; }     // no window: direct atomics for this level
+      t.wy0 = max(0, ty * Hs[j] / G - HALO); t.wx0 = max(0, tx * Ws[j] / G - HALO);
+      t.wh = max(0, min(min(Hs[j], (ty + 1) * Hs[j] / G + HALO) - t.wy0, WIN));
+      t.ww = max(0, min(min(Ws[j], (tx + 1) * Ws[j] / G + HALO) - t.wx0, WIN));
+      {
+        const int y5 = max(0, ty * Hs[j] / G - kHalo4), x5 = max(0, tx * Ws[j] / G - kHalo4);
+        t.dy5 = y5 - t.wy0; t.dx5 = x5 - t.wx0;
+        t.wh5 = max(0, min(min(Hs[j], (ty + 1) * Hs[j] / G + kHalo4) - y5, kWin4));
+        t.ww5 = max(0, min(min(Ws[j], (tx + 1) * Ws[j] / G + kHalo4) - x5, kWin4));
+      }
+      if (used + t.wh * t.ww > CELLS) { t.wh = 0; t.ww = 0; }     // no window: direct atomics for this level
       t.wbase = used;
       used += t.wh * t.ww;
       lvp[j] = t;
@@ -523,14 +544,14 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
     s_used = used;
     s_fixed_ok = 1;
   }
-  int *chmax = win + kOwnCells4 * 33;
+  int *chmax = win + CELLS * CW;
   float *chscale = reinterpret_cast<float *>(chmax + 32);
   const int NT = blockDim.x;
   if (threadIdx.x < 32) chmax[threadIdx.x] = 0;
   __syncthreads();
   {
     int4 *w4 = reinterpret_cast<int4 *>(win);
-    const int n4 = (s_used * 33 + 3) >> 2;
+    const int n4 = (s_used * CW + 3) >> 2;
     for (int i = threadIdx.x; i < n4; i += NT) w4[i] = make_int4(0, 0, 0, 0);
   }
   const int stride_w = M * 32;
@@ -578,6 +599,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
   // ---- main pass: a (query, level) unit per 4-lane group; lane `sub` owns channels [8 sub, 8 sub + 8)
   const int sub = threadIdx.x & 3, grp = threadIdx.x >> 2, NG = NT >> 2;
   const int nunits = nq_all * L;
+  unsigned nmiss = 0;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   for (int u = grp; u < nunits; u += NG) {
     const int qi = u / L, l = u - qi * L;
@@ -600,7 +622,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
     const float *vbase = value + voff;
     float *gbase = grad_value + voff;
     float keep_a = 0.f, keep_x = 0.f, keep_y = 0.f;
-    unsigned slow = 0;
+    unsigned slow = 0, out5 = 0;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const float a = aw[p];
@@ -635,7 +657,10 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
       float ph = hw * (Sk[2] - Sk[0]) + lw * (Sk[3] - Sk[1]);       // reference .cuh:122-158: d/dh, d/dw of the bilinear value
       float pw = hh * (Sk[1] - Sk[0]) + lh * (Sk[3] - Sk[2]);
       const int cy0 = h_low - lv.wy0, cx0 = w_low - lv.wx0;
+      // does this point leave the halo-5 window?  (HALF: measured against the inner window; otherwise the `slow` bits say it)
+      if (HALF && in_range && !((unsigned)(cy0 - lv.dy5) < (unsigned)max(lv.wh5 - 1, 0) && (unsigned)(cx0 - lv.dx5) < (unsigned)max(lv.ww5 - 1, 0))) out5 |= 1u << p;
       auto add_corner = [&](int *h0, float sc) {
+        if (HALF && (sub >> 1) != half) return;               // the other half's channels belong to the sibling workgroup
         const f32x2 sc2 = {sc, sc};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -643,16 +668,16 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
           if (ABL & 1) { asm volatile("" ::"v"(h0), "v"(f.x), "v"(f.y)); }
           else { atomicAdd(h0 + 2 * c, __float_as_int(f.x)); atomicAdd(h0 + 2 * c + 1, __float_as_int(f.y)); }   // ds_add_u32, immediate offsets
         }
-        if (sub == 0 && !(ABL & 1)) atomicAdd(h0 + 32 - sub * 8, 1);
+        if ((HALF ? (sub & 1) == 0 : sub == 0) && !(ABL & 1)) atomicAdd(h0 + CW - 1, 1);   // (h0 of that lane is the cell's first word)
       };
       if (fixed_ok && ok[0] && ok[3] && (unsigned)cy0 < (unsigned)max(lv.wh - 1, 0) && (unsigned)cx0 < (unsigned)max(lv.ww - 1, 0)) {
         // all four corners inside the map and inside the cached window (the common case): straight-line code
-        int *h00 = win + (lv.wbase + __mul24(cy0, lv.ww) + cx0) * 33 + sub * 8;
-        int *h10 = h00 + lv.ww * 33;
+        int *h00 = win + (lv.wbase + __mul24(cy0, lv.ww) + cx0) * CW + (HALF ? (sub & 1) : sub) * 8;
+        int *h10 = h00 + lv.ww * CW;
         add_corner(h00, cw[0] * a);
-        add_corner(h00 + 33, cw[1] * a);
+        add_corner(h00 + CW, cw[1] * a);
         add_corner(h10, cw[2] * a);
-        add_corner(h10 + 33, cw[3] * a);
+        add_corner(h10 + CW, cw[3] * a);
       } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -660,8 +685,8 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
           if (ok[k] && !(fixed_ok && sc == 0.f)) {       // a zero weight (sample exactly on a pixel centre) adds nothing
             const int cy = cy0 + (k >> 1), cx = cx0 + (k & 1);
             if (fixed_ok && (unsigned)cy < (unsigned)lv.wh && (unsigned)cx < (unsigned)lv.ww)
-              add_corner(win + (lv.wbase + __mul24(cy, lv.ww) + cx) * 33 + sub * 8, sc);
-            else slow |= 1u << p;                 // a corner outside the cached window (large learned offset): rare, handled below
+              add_corner(win + (lv.wbase + __mul24(cy, lv.ww) + cx) * CW + (HALF ? (sub & 1) : sub) * 8, sc);
+            else if (!HALF || (sub >> 1) == half) slow |= 1u << p;   // a corner outside the cached window (large learned offset): handled below
           }
         }
       }
@@ -671,8 +696,11 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
       if (sub == p) { keep_a = pa; keep_x = pw; keep_y = ph; }
       __builtin_amdgcn_sched_barrier(0);          // one point's 8 rows in flight at a time: the next point's would not fit 128 VGPRs
     }
-    grad_attn[qm * LP + l * P + sub] = keep_a;
-    reinterpret_cast<float2 *>(grad_loc + (qm * LP + l * P) * 2)[sub] = make_float2(keep_x, keep_y);
+    if (sub == 0 && half == 0) nmiss += __popc(HALF ? out5 : slow);
+    if (!HALF || half == 0) {
+      grad_attn[qm * LP + l * P + sub] = keep_a;
+      reinterpret_cast<float2 *>(grad_loc + (qm * LP + l * P) * 2)[sub] = make_float2(keep_x, keep_y);
+    }
     if (slow) {
       // corners no window caches: direct global atomics (the result never depends on window / halo sizes).  Rolled, re-reading
       // the point from memory, so that this rare path costs the loop above neither registers nor code
@@ -705,17 +733,32 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
       }
     }
   }
+  if (cnt) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmiss += __shfl_xor(nmiss, o, 64);
+    if ((threadIdx.x & 63) == 0 && nmiss) atomicAdd(&s_miss, (int)nmiss);
+  }
   __syncthreads();
+  if (cnt && threadIdx.x == 0) {
+    if (half == 0) { atomicAdd(cnt, (unsigned)s_miss); atomicAdd(cnt + 1, (unsigned)(nq_all * LP)); }
+    __threadfence();
+    if (atomicAdd(cnt + 2, 1u) == (unsigned)nact - 1u) {      // the last active workgroup: publish and recycle the slot
+      const unsigned mi = atomicAdd(cnt, 0u), to = atomicAdd(cnt + 1, 0u);
+      if (pub) { *pub = ((unsigned long long)mi << 32) | to; __threadfence_system(); }
+      atomicExch(cnt, 0u); atomicExch(cnt + 1, 0u); atomicExch(cnt + 2, 0u);
+    }
+  }
   // ---- flush: lane = channel, one full 128-byte line per cell per half-wave
 #pragma unroll 1
   for (int l = 0; l < L; ++l) {
     const LvlP lv = lvp[l];
     float *gl = grad_value + ((int64_t)b * S + lv.ls) * stride_w + m * 32;
     const int cells = lv.wh * lv.ww;
-    for (int i = threadIdx.x; i < cells * 32; i += NT) {
-      const int cellw = i >> 5, ch = i & 31;
-      const int *cp = win + (lv.wbase + cellw) * 33;
-      const int acc = (int)((unsigned)cp[ch] - (unsigned)cp[32] * 0x4B400000u);
+    constexpr int NCH = HALF ? 16 : 32;                     // channels a cell holds; lane = channel
+    for (int i = threadIdx.x; i < cells * NCH; i += NT) {
+      const int cellw = i / NCH, cl = i % NCH, ch = half * 16 + cl;
+      const int *cp = win + (lv.wbase + cellw) * CW;
+      const int acc = (int)((unsigned)cp[cl] - (unsigned)cp[CW - 1] * 0x4B400000u);
       const float v = (float)acc / chscale[ch];           // chscale is a power of two: exact
       if (acc != 0 && !(ABL & 4)) unsafeAtomicAdd(gl + ((int64_t)(lv.wy0 + cellw / lv.ww) * lv.W + lv.wx0 + cellw % lv.ww) * stride_w + ch, v);
     }
@@ -871,6 +914,90 @@ extern "C" int pd_msda_forward(const void *value, const int64_t *spatial_shapes,
   return pd_check_launch("pd_msda_forward");
 }
 
+// Which LDS-window backward kernel a launch uses is decided on the HOST from what EARLIER launches measured: every gated launch
+// counts the sample points that left the halo-5 windows and its last workgroup writes {missed, looked-at} into host-mapped
+// memory (a ring of 64 slots per device; nothing waits for it).  A launch takes the halo-9 kernel when the most recent results that
+// have ARRIVED (the host runs ahead of the device) show more than g_pd_dbg_msda_gate_pct per mille misses.  Both kernels are correct for any offsets — a stale
+// or missing measurement (the first launches of a run) only costs speed.
+#include <mutex>
+static std::mutex g_gate_mu;
+static unsigned *g_gate_cnt[16] = {nullptr};                 // device: 64 x {missed, looked-at, ticket, pad}
+static unsigned long long *g_gate_pub[16] = {nullptr};       // host-mapped: 64 x (missed << 32 | looked-at)
+static unsigned long long *g_gate_pub_dev[16] = {nullptr};
+static unsigned g_gate_next[16] = {0};
+static int g_gate_last_variant[16] = {0};
+int g_pd_dbg_msda_gate_pct = 20;     // halo-9 kernel when more than this many PER MILLE of the sample points of recent launches left the halo-5 windows
+                                     // (measured break-even: 0.9 % misses -> 0.28 vs 0.39 ms, 3.9 % -> 0.63 vs 0.40 ms)
+
+static bool msda_gate_init(int dev, hipStream_t stream)
+{
+  if (g_gate_cnt[dev]) return true;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(stream, &cs);
+  if (cs != hipStreamCaptureStatusNone) return false;        // no allocation inside a capture
+  void *c = nullptr, *h = nullptr, *hd = nullptr;
+  if (hipMalloc(&c, 64 * 16) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipMemset(c, 0, 64 * 16) != hipSuccess || hipHostMalloc(&h, 64 * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer(&hd, h, 0) != hipSuccess) {
+    (void)hipGetLastError(); (void)hipFree(c);
+    if (h) (void)hipHostFree(h);
+    return false;
+  }
+  memset(h, 0, 64 * 8);
+  g_gate_cnt[dev] = (unsigned *)c; g_gate_pub[dev] = (unsigned long long *)h; g_gate_pub_dev[dev] = (unsigned long long *)hd;
+  return true;
+}
+
+// -> slot index of this launch (or -1: ungated) and whether recent launches call for the halo-9 kernel
+static int msda_gate_pick(hipStream_t stream, bool *want_half)
+{
+  int dev = 0;
+  *want_half = false;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -1;
+  std::lock_guard<std::mutex> lk(g_gate_mu);
+  if (!msda_gate_init(dev, stream)) return -1;
+  const unsigned n = g_gate_next[dev]++;
+  // the host runs ahead of the device: the newest results are usually still in flight (slot == 0).  Take the 6 most recent that
+  // HAVE arrived among the last 63 launches; with none (start of a run, or > 63 launches queued) keep the previous decision.
+  // Hysteresis: up at > gate per-mille misses in any of them, back down only when all are below 0.7 of it.
+  int seen = 0;
+  bool any_high = false, all_low = true;
+  for (unsigned k = 1; k <= 63 && k <= n && seen < 6; ++k) {
+    const unsigned long long v = ((volatile unsigned long long *)g_gate_pub[dev])[(n - k) & 63];
+    const unsigned long long mi = v >> 32, to = v & 0xffffffffull;
+    if (!to) continue;
+    ++seen;
+    if (mi * 1000ull > to * (unsigned long long)g_pd_dbg_msda_gate_pct) any_high = true;
+    if (mi * 10000ull > to * (unsigned long long)g_pd_dbg_msda_gate_pct * 7ull) all_low = false;
+  }
+  static bool state[16] = {false};
+  if (seen) {
+    if (any_high) state[dev] = true;
+    else if (all_low) state[dev] = false;
+  }
+  *want_half = state[dev];
+  g_gate_last_variant[dev] = *want_half ? 2 : 3;
+  return (int)(n & 63);
+}
+
+// tools / bench: {missed, looked-at} sample points of the most recent gated backward launch whose result has arrived on the current
+// device, and the variant (2 = halo 9, 3 = halo 5) the most recent launch took.  Reads host memory only.
+extern "C" int pd_msda_backward_last_gate(unsigned *out3)
+{
+  int dev = 0;
+  if (!out3 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_backward_last_gate: bad argument");
+  out3[0] = out3[1] = out3[2] = 0;
+  std::lock_guard<std::mutex> lk(g_gate_mu);
+  if (!g_gate_pub[dev]) return PD_OK;
+  out3[2] = (unsigned)g_gate_last_variant[dev];
+  const unsigned n = g_gate_next[dev];
+  for (unsigned k = 1; k <= 64 && k <= n; ++k) {
+    const unsigned long long v = ((volatile unsigned long long *)g_gate_pub[dev])[(n - k) & 63];
+    if (v & 0xffffffffull) { out3[0] = (unsigned)(v >> 32); out3[1] = (unsigned)(v & 0xffffffffull); break; }
+  }
+  return PD_OK;
+}
+
 extern "C" int pd_msda_backward(const void *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
                                 const void *sampling_loc, const void *attn_weight, const void *grad_output,
                                 void *grad_value, void *grad_sampling_loc, void *grad_attn_weight, int batch,
@@ -891,18 +1018,38 @@ extern "C" int pd_msda_backward(const void *value, const int64_t *spatial_shapes
   if (!g_pd_dbg_force_generic && g_pd_dbg_atomic_scope == 0 && dtype == PD_F32 && channels == 32 && num_point == 4 &&
       num_levels <= 8 && num_query == spatial_size && total_qm < (1LL << 31)) {
     // self-attention geometry: LDS-windowed accumulation (every grad_loc / grad_attn slot is written once)
-    if (num_levels == 3 && g_pd_dbg_bwd_variant == 0 && spatial_size < (1 << 23) && num_heads * 32 < (1 << 23)) {   // 24-bit index multiplies
-      const size_t lds4 = ((size_t)kOwnCells4 * 33 + 64) * sizeof(int);
+    if (num_levels == 3 && g_pd_dbg_bwd_variant != 1 && spatial_size < (1 << 23) && num_heads * 32 < (1 << 23)) {   // 24-bit index multiplies
+      const size_t lds4 = ((size_t)kOwnCells4 * 33 + 64) * sizeof(int), lds4h = ((size_t)kOwnCells4H * 17 + 64) * sizeof(int);
       typedef void (*ofn)(const float *, const int64_t *, const int64_t *, const float *, const float *, const float *, float *, float *,
-                          float *, int, int, int);
+                          float *, int, int, int, unsigned *, unsigned long long *);
       const int ai = g_pd_dbg_ablate == 1 ? 1 : g_pd_dbg_ablate == 4 ? 2 : g_pd_dbg_ablate == 7 ? 3 : 0;
       const ofn all4[4] = {msda_bwd_owner4_d32<0>, msda_bwd_owner4_d32<1>, msda_bwd_owner4_d32<4>, msda_bwd_owner4_d32<7>};
-      static bool a4set[4] = {false, false, false, false};
+      const ofn half4 = msda_bwd_owner4_d32<0, true>;
+      static bool a4set[5] = {false, false, false, false, false};
       if (!a4set[ai]) { (void)hipFuncSetAttribute((const void *)all4[ai], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); a4set[ai] = true; }
+      if (!a4set[4]) { (void)hipFuncSetAttribute((const void *)half4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4h); a4set[4] = true; }
       const int64_t nb4 = (int64_t)batch * kGmax * kGmax * num_heads;
-      hipLaunchKernelGGL(all4[ai], dim3((unsigned)nb4), dim3(1024), lds4, stream, (const float *)value, spatial_shapes, level_start_index,
-                         (const float *)sampling_loc, (const float *)attn_weight, (const float *)grad_output, (float *)grad_value,
-                         (float *)grad_sampling_loc, (float *)grad_attn_weight, spatial_size, num_heads, batch);
+      // g_pd_dbg_bwd_variant (tools): 0 = picked from what recent launches measured, 2 = always halo 9, 3 = always halo 5
+      bool want_half = g_pd_dbg_bwd_variant == 2;
+      unsigned *cnt = nullptr;
+      unsigned long long *pub = nullptr;
+      if (g_pd_dbg_bwd_variant == 0 && g_pd_dbg_ablate == 0) {
+        const int slot = msda_gate_pick(stream, &want_half);
+        if (slot >= 0) {
+          int dev = 0;
+          (void)hipGetDevice(&dev);
+          cnt = g_gate_cnt[dev] + 4 * slot; pub = g_gate_pub_dev[dev] + slot;
+          ((volatile unsigned long long *)g_gate_pub[dev])[slot] = 0ull;      // "not measured yet" until this launch publishes
+        }
+      }
+      if (!want_half)
+        hipLaunchKernelGGL(all4[ai], dim3((unsigned)nb4), dim3(1024), lds4, stream, (const float *)value, spatial_shapes, level_start_index,
+                           (const float *)sampling_loc, (const float *)attn_weight, (const float *)grad_output, (float *)grad_value,
+                           (float *)grad_sampling_loc, (float *)grad_attn_weight, spatial_size, num_heads, batch, cnt, pub);
+      else
+        hipLaunchKernelGGL(half4, dim3((unsigned)(2 * nb4)), dim3(1024), lds4h, stream, (const float *)value, spatial_shapes, level_start_index,
+                           (const float *)sampling_loc, (const float *)attn_weight, (const float *)grad_output, (float *)grad_value,
+                           (float *)grad_sampling_loc, (float *)grad_attn_weight, spatial_size, num_heads, batch, cnt, pub);
       return pd_check_launch("pd_msda_backward");
     }
     const int64_t nblocks = (int64_t)batch * kGmax * kGmax * num_levels * num_heads;

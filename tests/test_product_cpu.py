@@ -211,3 +211,26 @@ def test_optimizer_param_groups_match_reference_build_optimizer(golden, tag, fre
         assert abs(ours[k][0] - float(v[0])) < 1e-15 and abs(ours[k][1] - float(v[1])) < 1e-15, (k, ours[k], v.tolist())
     assert sorted(n for n, p in model.named_parameters() if not p.requires_grad) == g["frozen"]
     assert g["optimizer_class"] == "FullModelGradientClippingOptimizer" and g["base_class"] == "AdamW"
+
+
+def test_msda_is_a_registered_torch_library_operator():
+    """the operator the reference exposes through pybind (ops/src/vision.cpp:19-22) is a torch.library custom op
+    here — schema, fake implementation (shape inference without a GPU) and autograd registration; only a CUDA kernel exists, so a
+    CPU call raises like the reference's AT_ERROR("Not implemented on the CPU") instead of falling back to anything."""
+    import partdistillation_amd.MultiScaleDeformableAttention as MSDA  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    fwd, bwd = torch.ops.pd.ms_deform_attn_forward.default, torch.ops.pd.ms_deform_attn_backward.default
+    assert str(fwd._schema).startswith("pd::ms_deform_attn_forward(Tensor value, Tensor spatial_shapes, Tensor level_start_index, "
+                                       "Tensor sampling_loc, Tensor attn_weight, SymInt im2col_step) -> Tensor")
+    assert "-> (Tensor, Tensor, Tensor)" in str(bwd._schema)
+    with FakeTensorMode():
+        v = torch.empty(2, 84, 8, 32, device="cuda")
+        sh, lv = torch.empty(3, 2, dtype=torch.long, device="cuda"), torch.empty(3, dtype=torch.long, device="cuda")
+        loc, at = torch.empty(2, 50, 8, 3, 4, 2, device="cuda"), torch.empty(2, 50, 8, 3, 4, device="cuda")
+        out = torch.ops.pd.ms_deform_attn_forward(v, sh, lv, loc, at, 128)
+        assert tuple(out.shape) == (2, 50, 256) and out.device.type == "cuda"
+        gv, gl, ga = torch.ops.pd.ms_deform_attn_backward(v, sh, lv, loc, at, out, 128)
+        assert gv.shape == v.shape and gl.shape == loc.shape and ga.shape == at.shape
+    with pytest.raises(NotImplementedError):
+        torch.ops.pd.ms_deform_attn_forward(torch.zeros(1, 4, 2, 2), torch.tensor([[2, 2]]), torch.tensor([0]), torch.zeros(1, 3, 2, 1, 2, 2),
+                                            torch.zeros(1, 3, 2, 1, 2), 1)

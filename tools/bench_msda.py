@@ -9,7 +9,7 @@ import torch
 import partdistillation_amd.MultiScaleDeformableAttention as MSDA
 
 
-def make(N=2, img=1024, spread=0.02, device="cuda", seed=0, px=None):
+def make(N=2, img=1024, spread=0.02, device="cuda", seed=0, px=None, offsets=None):
     shapes = [(img // 32,) * 2, (img // 16,) * 2, (img // 8,) * 2]
     S = sum(h * w for h, w in shapes)
     g = torch.Generator(device=device).manual_seed(seed)
@@ -33,7 +33,16 @@ def make(N=2, img=1024, spread=0.02, device="cuda", seed=0, px=None):
         d = torch.stack((th.cos(), th.sin()), -1)
         d = d / d.abs().max(-1, keepdim=True)[0]
         grid = d[:, None, None, :] * torch.arange(1, 5, device=device).view(1, 1, 4, 1)                  # [8,1,4,2]
-        off = grid[None, None] + px * torch.randn(N, S, 8, 3, 4, 2, device=device, generator=g)           # pixels
+        if offsets == "trained":
+            # stand-in for a TRAINED model's offset distribution (no checkpoint is available offline): every (head, level, point)
+            # keeps a learned bias = its initialisation ray stretched by a factor in [0.5, 2.5] (up to 10 cells), and the
+            # per-query part is heavy-tailed: 70 % N(0, 1), 25 % N(0, 3), 5 % N(0, 8) cells — at every level, in cells of that level
+            stretch = 0.5 + 2.0 * torch.rand(8, 3, 4, 1, device=device, generator=g)
+            u = torch.rand(N, S, 8, 3, 4, 1, device=device, generator=g)
+            sig = torch.where(u < 0.70, 1.0, torch.where(u < 0.95, 3.0, 8.0))
+            off = (grid * stretch)[None, None] + sig * torch.randn(N, S, 8, 3, 4, 2, device=device, generator=g)
+        else:
+            off = grid[None, None] + px * torch.randn(N, S, 8, 3, 4, 2, device=device, generator=g)       # pixels
         wh = torch.as_tensor([(w, h) for h, w in shapes], dtype=torch.float32, device=device).view(1, 1, 1, 3, 1, 2)
         loc = (ref + off / wh).contiguous()
     attn = torch.softmax(torch.randn(N, S, 8, 12, device=device, generator=g), -1).view(N, S, 8, 3, 4).contiguous()
@@ -60,7 +69,8 @@ def main():
     ap.add_argument("--bwd-threads", type=int, default=0)
     ap.add_argument("--spread", type=float, default=0.02)
     ap.add_argument("--px", type=float, default=None, help="offsets = init grid + N(0, px) pixels at every level (instead of --spread)")
-    ap.add_argument("--variant", type=int, default=0, help="1: the per-destination-level tiled backward")
+    ap.add_argument("--variant", type=int, default=0, help="0: gated per launch (default); 1: the per-destination-level tiled backward; 2: always the halo-9 half-channel kernel; 3: always halo 5")
+    ap.add_argument("--offsets", default=None, choices=[None, "trained"], help="trained: heavy-tailed stand-in for a trained model's offsets")
     a = ap.parse_args()
     from partdistillation_amd import lib
     lib.load().pd_debug_set(b"msda_bwd_atomic_scope", a.scope)
@@ -68,7 +78,7 @@ def main():
     lib.load().pd_debug_set(b"msda_ablate", a.ablate)
     lib.load().pd_debug_set(b"msda_bwd_threads", a.bwd_threads)
     lib.load().pd_debug_set(b"msda_bwd_variant", a.variant)
-    value, sh, lv, loc, attn, gout = make(a.batch, a.img, a.spread, px=a.px)
+    value, sh, lv, loc, attn, gout = make(a.batch, a.img, a.spread, px=(a.px if a.px is not None else (0.0 if a.offsets else None)), offsets=a.offsets)
     S = value.shape[1]
     fb, bb = alg_bytes(a.batch, S)
     for _ in range(5):
@@ -98,6 +108,11 @@ def main():
         b2b = s0.elapsed_time(e0) / a.iters
         res[name] = {"ms_median": med, "ms_min": ts[0], "ms_back_to_back": b2b, "host_ms_per_call": host, "alg_MB": nbytes / 1e6,
                      "GBps": nbytes / med / 1e6}
+    import ctypes
+    g = (ctypes.c_uint * 3)()
+    if lib.load().pd_msda_backward_last_gate(g) == 0 and g[1]:
+        res["bwd"]["halo5_miss_fraction"] = g[0] / g[1]
+        res["bwd"]["variant"] = {2: "halo 9 (half channels)", 3: "halo 5"}.get(int(g[2]), str(int(g[2])))
     print(json.dumps(res))
 
 
