@@ -408,8 +408,14 @@ def main():
             kernels.append({"kernel": "msda_fwd_d32", "launches": len(fwd_ms), "avg_ms": avg(fwd_ms),
                             "alg_bytes": fb, "achieved_GBs": fb / avg(fwd_ms) / 1e6})
         if bwd_ms:
+            import ctypes
+            gate = (ctypes.c_uint * 3)()
+            lib.load().pd_msda_backward_last_gate(gate)      # host memory only: what the backward launches measured / which variant ran
             kernels.append({"kernel": "msda_bwd_owner4_d32", "launches": len(bwd_ms), "avg_ms": avg(bwd_ms),
-                            "alg_bytes": bb, "achieved_GBs": bb / avg(bwd_ms) / 1e6})
+                            "alg_bytes": bb, "achieved_GBs": bb / avg(bwd_ms) / 1e6,
+                            "variant_of_last_launch": {2: "halo 9, 16 channels per workgroup", 3: "halo 5, 32 channels per workgroup"}.get(int(gate[2]), "ungated"),
+                            "halo5_window_miss_fraction": (gate[0] / gate[1]) if gate[1] else None,
+                            "note": "offsets after the timed steps from reference initialisation; tools/msda_sweep.sh covers N(0, sigma) and a trained-model stand-in"})
         if wgrad:                               # fp32 weight-gradient GEMMs of the encoder (30 launches / step, 5 shapes)
             t_ms, fl = sum(t for t, _ in wgrad), sum(f for _, f in wgrad)
             from partdistillation_amd.functions import gemm as gemm_fn

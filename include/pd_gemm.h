@@ -71,6 +71,23 @@ int64_t pd_gemm_wgrad_f32x3_ws_floats(int N, int K);
 int pd_gemm_wgrad_acc_f32x3_ws(const float *dY, const float *X, float *dW, float *dB, float *workspace, int64_t workspace_floats, int M, int N,
                                int K, int ldy, int ldx, int ldw, void *stream);
 
+/* Several pd_gemm_wgrad_acc_f32x3 problems as ONE launch (+ one reduce launch): dW_i[N_i,K_i] += dY_i[M_i,N_i]^T X_i[M_i,K_i],
+ * dB_i += column sums of dY_i (dB nullable).  Weight gradients have no consumer until the optimizer runs, so the encoder queues
+ * its 30 per step during the backward pass and runs them together (reference: the autograd of ops/modules/ms_deform_attn.py:102-130
+ * and msdeformattn.py:120-124): whole rounds of workgroups once instead of 30 times and ~17 partial tiles per output tile instead
+ * of 32-128.  Every problem: N, K, ldy, ldx multiples of 4, 16-byte aligned operands; count <= 256.
+ *   table_host_pinned / table_device: pd_gemm_wgrad_f32x3_grouped_table_bytes(count) bytes each (pinned host staging the call
+ *   fills + its device copy); workspace: >= pd_gemm_wgrad_f32x3_grouped_ws_floats(descs, count) floats (-1: bad problem). */
+typedef struct PdGemmWgradDesc {
+  const float *dY, *X;
+  float *dW, *dB;
+  int M, N, K, ldy, ldx, ldw;
+} PdGemmWgradDesc;
+int64_t pd_gemm_wgrad_f32x3_grouped_table_bytes(int max_count);
+int64_t pd_gemm_wgrad_f32x3_grouped_ws_floats(const PdGemmWgradDesc *descs, int count);
+int pd_gemm_wgrad_f32x3_grouped(const PdGemmWgradDesc *descs, int count, void *table_host_pinned, void *table_device, float *workspace,
+                                int64_t workspace_floats, void *stream);
+
 /* Weight (and bias) gradient of pd_conv3x3_nhwc_f32x3's convolution (3 x 3, stride 1, pad 1; the fp32 FPN output convolution of
  * the pixel decoder, reference msdeformattn.py:238-257, 348-357), ACCUMULATED into caller-initialised buffers:
  *   dWk[co][tap][ci] += sum over pixels dY[p][co] X[p + off(tap)][ci],   dB[co] += sum over pixels dY[p][co]   (dB nullable)

@@ -526,13 +526,12 @@ __device__ __forceinline__ hwbf16x8 frag_tr(const bf16_t *p)      // p: this lan
 // [Co][3][3][Ci]; Ci % 128 == 0, so a tile's 128 columns lie inside one tap and its X rows are the pixels m + dy W + dx (zeros
 // outside the image): the weight gradient of a 3 x 3, stride 1, pad 1 convolution, nothing unfolded.
 template <int ABL, bool CONV>
-__global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3_tr(const float *__restrict__ dY, const float *__restrict__ X,
-                                                               float *__restrict__ dW, float *__restrict__ dB, float *__restrict__ ws,
-                                                               int M, int N, int K, int ldy, int ldx, int ldw, int tiles_k, int tiles,
-                                                               int m_chunk, int H, int W)
+__device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ dW,
+                                              float *__restrict__ dB, float *__restrict__ ws, int M, int N, int K, int ldy, int ldx,
+                                              int ldw, int tiles_k, int tiles, int m_chunk, int H, int W, int bid, int64_t ws_tile0)
 {
   __shared__ __attribute__((aligned(16))) bf16_t S[2][2][3][TWS][TP];      // stage, operand (dY, X), plane, row, column
-  const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+  const int tile = bid % tiles, split = bid / tiles;
   const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BM;
   const int mb = split * m_chunk, me = min(M, mb + m_chunk);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -636,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3_tr(const float *__res
   if (ws) {
     // partial tile in REGISTER order (element (ij, e) of thread t at ((ij * 16 + e) * 256 + t): 1 KB per store instruction);
     // wgrad_tr_reduce sums the splits and owns the read-modify-write of dW — 8.4 M fp32 atomics per launch cost 30-110 us
-    float *w = ws + ((int64_t)split * tiles + tile) * (BN * BM) + t;
+    float *w = ws + (ws_tile0 + (int64_t)split * tiles + tile) * (BN * BM) + t;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -657,6 +656,65 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3_tr(const float *__res
         if (row < N) unsafeAtomicAdd(dW + (int64_t)row * ldw + c, acc[i][j][e]);
       }
   }
+}
+
+template <int ABL, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3_tr(const float *__restrict__ dY, const float *__restrict__ X,
+                                                               float *__restrict__ dW, float *__restrict__ dB, float *__restrict__ ws,
+                                                               int M, int N, int K, int ldy, int ldx, int ldw, int tiles_k, int tiles,
+                                                               int m_chunk, int H, int W)
+{
+  wgrad_tr_body<ABL, CONV>(dY, X, dW, dB, ws, M, N, K, ldy, ldx, ldw, tiles_k, tiles, m_chunk, H, W, (int)blockIdx.x, 0);
+}
+
+// Several weight gradients in ONE launch (pd_gemm_wgrad_f32x3_grouped): a table of problems in device memory, workgroup b belongs
+// to the problem whose [block0, block0 + tiles * splits) contains b.  The encoder's 30 weight gradients per step are independent of
+// everything until the optimizer runs, so they are queued during its backward pass and run here together: every (tile, split)
+// workgroup of the launch walks the same number of rows, the machine is filled in whole rounds once instead of 30 times, and
+// the partial-tile traffic falls from 512 tiles per GEMM to ~17 splits per output tile.
+struct WgradX3Problem {
+  const float *dY, *X;
+  float *dW, *dB;
+  int M, N, K, ldy, ldx, ldw, tiles_k, tiles, m_chunk, splits, block0, pad;
+  int64_t ws_tile0;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3_tr_grouped(const WgradX3Problem *__restrict__ tab, int count, float *__restrict__ ws)
+{
+  int p = 0;
+  while (p + 1 < count && (int)blockIdx.x >= tab[p + 1].block0) ++p;      // <= a few dozen problems: a scalar scan
+  const WgradX3Problem q = tab[p];
+  wgrad_tr_body<0, false>(q.dY, q.X, q.dW, q.dB, ws, q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, q.tiles_k, q.tiles, q.m_chunk, 0, 0,
+                          (int)blockIdx.x - q.block0, q.ws_tile0);
+}
+
+// grouped form of wgrad_tr_reduce: blockIdx.x = 64 x (global output tile index); the problem is found from its first tile
+__global__ __launch_bounds__(256) void wgrad_tr_reduce_grouped(const WgradX3Problem *__restrict__ tab, int count, const float *__restrict__ ws)
+{
+  const int gt = blockIdx.x >> 6, q = blockIdx.x & 63;
+  int p = 0, t0 = 0;
+  while (p + 1 < count && gt >= t0 + tab[p].tiles) { t0 += tab[p].tiles; ++p; }
+  const WgradX3Problem pr = tab[p];
+  const int tile = gt - t0;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ij = q >> 4, e = q & 15, i = ij >> 1, j = ij & 1;
+  const int n0 = (tile / pr.tiles_k) * BN, k0 = (tile % pr.tiles_k) * BM;
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+  const float *src = ws + (pr.ws_tile0 + tile) * (BN * BM) + q * 256 + t;
+  const int64_t stride = (int64_t)pr.tiles * (BN * BM);
+  float s0 = 0.f, s1 = 0.f;
+  int sp = 0;
+  for (; sp + 7 < pr.splits; sp += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(sp + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+  }
+  for (; sp < pr.splits; ++sp) s0 += src[(int64_t)sp * stride];
+  const int c = k0 + wk + j * 32 + (lane & 31);
+  const int row = n0 + wn + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+  if (c < pr.K && row < pr.N) pr.dW[(int64_t)row * pr.ldw + c] += s0 + s1;      // this block owns the element: plain read-modify-write
 }
 
 // dW tile += sum over splits of the partial tiles gemm_wgrad_f32x3_tr left in the workspace (same register-order indexing)
@@ -862,6 +920,69 @@ static int wgrad_x3_launch(const float *dY, const float *X, float *dW, float *dB
   if (ws) hipLaunchKernelGGL(wgrad_tr_reduce, dim3((unsigned)(tiles * 64), groups), dim3(256), 0, st, (const float *)ws, dW, N, K, ldw, tk, tiles,
                              splits);
   return pd_check_launch(who);
+}
+
+
+// ---- grouped weight gradients (include/pd_gemm.h: pd_gemm_wgrad_f32x3_grouped)
+extern "C" int64_t pd_gemm_wgrad_f32x3_grouped_table_bytes(int max_count) { return (int64_t)(max_count > 0 ? max_count : 0) * (int64_t)sizeof(WgradX3Problem); }
+
+static int grouped_plan(const PdGemmWgradDesc *d, int count, WgradX3Problem *tab, int64_t *ws_tiles, int *blocks)
+{
+  int64_t total_tiles = 0;
+  for (int i = 0; i < count; ++i) {
+    if (d[i].M <= 0 || d[i].N <= 0 || d[i].K <= 0 || !d[i].dY || !d[i].X || !d[i].dW) return 1;
+    if ((d[i].N & 3) || (d[i].K & 3) || (d[i].ldy & 3) || (d[i].ldx & 3) || ((uintptr_t)d[i].dY & 15) || ((uintptr_t)d[i].X & 15)) return 1;
+    total_tiles += (int64_t)((d[i].K + BM - 1) / BM) * ((d[i].N + BN - 1) / BN);
+  }
+  // one split count for all problems, chosen so that the launch is a whole number of rounds of 512 resident workgroups (two per
+  // CU): tiles x splits just below a multiple of 512, at least ~6 rounds deep so that unequal M do not leave a ragged tail
+  int splits = (int)((6 * 512) / (total_tiles > 0 ? total_tiles : 1));
+  if (splits < 1) splits = 1;
+  int64_t wt = 0; int b0 = 0;
+  for (int i = 0; i < count; ++i) {
+    WgradX3Problem &q = tab[i];
+    q.dY = d[i].dY; q.X = d[i].X; q.dW = d[i].dW; q.dB = d[i].dB;
+    q.M = d[i].M; q.N = d[i].N; q.K = d[i].K; q.ldy = d[i].ldy; q.ldx = d[i].ldx; q.ldw = d[i].ldw;
+    q.tiles_k = (q.K + BM - 1) / BM; q.tiles = q.tiles_k * ((q.N + BN - 1) / BN);
+    int mc = ((q.M + splits - 1) / splits + TWS - 1) / TWS * TWS;
+    if (mc < 4 * TWS) mc = 4 * TWS;
+    q.m_chunk = mc; q.splits = (q.M + mc - 1) / mc;
+    q.block0 = b0; q.pad = 0; q.ws_tile0 = wt;
+    b0 += q.tiles * q.splits; wt += (int64_t)q.tiles * q.splits;
+  }
+  *ws_tiles = wt; *blocks = b0;
+  return 0;
+}
+
+extern "C" int64_t pd_gemm_wgrad_f32x3_grouped_ws_floats(const PdGemmWgradDesc *descs, int count)
+{
+  if (count <= 0 || count > 256 || !descs) return 0;
+  WgradX3Problem tab[256];
+  int64_t wt = 0; int blocks = 0;
+  if (grouped_plan(descs, count, tab, &wt, &blocks)) return -1;
+  return wt * BN * BM;
+}
+
+extern "C" int pd_gemm_wgrad_f32x3_grouped(const PdGemmWgradDesc *descs, int count, void *table_host_pinned, void *table_device,
+                                           float *workspace, int64_t workspace_floats, void *stream_)
+{
+  if (count == 0) return PD_OK;
+  if (count < 0 || count > 256 || !descs || !table_host_pinned || !table_device || !workspace)
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_wgrad_f32x3_grouped: count=%d (1..256) or null pointer", count);
+  WgradX3Problem *tab = reinterpret_cast<WgradX3Problem *>(table_host_pinned);
+  int64_t wt = 0; int blocks = 0;
+  if (grouped_plan(descs, count, tab, &wt, &blocks))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_wgrad_f32x3_grouped: every problem needs M, N, K > 0, N, K, ldy, ldx multiples of 4, 16-byte aligned operands");
+  if (workspace_floats < wt * BN * BM) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_wgrad_f32x3_grouped: workspace too small");
+  hipStream_t st = (hipStream_t)stream_;
+  if (hipMemcpyAsync(table_device, table_host_pinned, (size_t)count * sizeof(WgradX3Problem), hipMemcpyHostToDevice, st) != hipSuccess)
+    return pd_set_error(PD_ERR_LAUNCH, "pd_gemm_wgrad_f32x3_grouped: table upload failed");
+  const WgradX3Problem *dt = reinterpret_cast<const WgradX3Problem *>(table_device);
+  int64_t tiles = 0;
+  for (int i = 0; i < count; ++i) tiles += tab[i].tiles;
+  hipLaunchKernelGGL(gemm_wgrad_f32x3_tr_grouped, dim3((unsigned)blocks), dim3(256), 0, st, dt, count, workspace);
+  hipLaunchKernelGGL(wgrad_tr_reduce_grouped, dim3((unsigned)(tiles * 64)), dim3(256), 0, st, dt, count, (const float *)workspace);
+  return pd_check_launch("pd_gemm_wgrad_f32x3_grouped");
 }
 
 extern "C" int pd_gemm_wgrad_acc_f32x3(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx,

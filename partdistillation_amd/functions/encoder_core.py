@@ -14,14 +14,16 @@ pd_gemm_wgrad_f32; everything between them is one hand-written kernel per step i
 backward, separate residual / positional adds, softmax / divide / add chains and gradient-accumulation adds that
 eager autograd issues.  All arithmetic stays fp32 like the reference (`autocast(enabled=False)`, msdeformattn.py:318).
 """
+import os
+
 import torch
 from torch.autograd import Function
 
 from .. import MultiScaleDeformableAttention as MSDA
 from .. import lib as _lib
 from . import rowwise as rw
-from .gemm import (gemm_tn_x3, gemm_tn_x3_pre, gemm_tn_x3_relu_bits, gemm_tn_x3_relumask, gemm_wgrad_acc, pre_supported, relu_bits_supported,
-                   split3)
+from .gemm import (WgradQueue, gemm_tn_x3, gemm_tn_x3_pre, gemm_tn_x3_relu_bits, gemm_tn_x3_relumask, gemm_wgrad_acc, pre_supported,
+                   relu_bits_supported, split3)
 
 def _timed(kind, fn, *args):
     # bench.py's per-launch HIP-event hook lives next to the autograd face of the operator (imported lazily: that module
@@ -63,7 +65,9 @@ class EncoderSpec:
 
 
 USE_X3 = True        # the FFN GEMMs (1024-wide) through pd_gemm_tn_f32x3; tools / tests switch it off to compare
-X3_PROJ = True       # the 256-wide projections (value / offsets+weights / output and their input gradients) on the same kernel: with the
+GROUP_WGRADS = os.environ.get("PD_GROUP_WGRADS", "1") != "0"  # the 5 weight gradients of every layer are queued during the backward pass and run as ONE grouped launch at its
+                     # end (functions/gemm.WgradQueue -> pd_gemm_wgrad_f32x3_grouped) instead of 30 launches + 30 reduce launches
+X3_PROJ = os.environ.get("PD_X3_PROJ", "1") != "0"       # the 256-wide projections (value / offsets+weights / output and their input gradients) on the same kernel: with the
                      # round-3 epilogue (stores no longer serialised on vmcnt(0)) 256 <- 256 at M = 43 008 runs 47.7 us against the
                      # library's ~57 (tools/probes/gemm_planes_probe.hip); False: torch.addmm / mm (Tensile fp32)
 PRESPLIT = False     # weight operand split into its bf16 planes once per use (pd_split3_bf16 + pd_gemm_tn_f32x3_pre).  Bit-identical results;
@@ -146,7 +150,9 @@ class EncoderCore(Function):
         # parameters requires a gradient, so the five weight-gradient GEMMs per layer (a third of the encoder's backward
         # FLOPs) are skipped; the input gradient still flows (input_proj / level_embed in front of it stay trainable)
         need_w = any(ctx.needs_input_grad[3:])
-        wgrad = gemm_wgrad_acc if need_w else (lambda *a, **k: None)
+        from . import gemm as _gemm
+        queue = WgradQueue() if (need_w and GROUP_WGRADS and _gemm.WGRAD_X3 and d_out.is_cuda) else None
+        wgrad = (queue.add if queue is not None else gemm_wgrad_acc) if need_w else (lambda *a, **k: None)
         # every parameter gradient of the encoder lives in ONE zero-filled fp32 buffer (a single memset): the LayerNorm /
         # ReLU kernels and the split-K weight-gradient GEMMs all accumulate (+=) into their slices
         offs, total = [], 0
@@ -199,7 +205,8 @@ class EncoderCore(Function):
             dy1 = gemm_tn_x3_pre(dh, split3(l1_w, transpose=True)) if pre else _ffn_gemm(dh, l1_t[i])
             del dh
             # ---- deformable attention + norm1
-            dz1, _ = rw.add_ln_bwd(z1, m1, r1, n1_w, dy=dz2, dy2=dy1, dgamma=g_n1w, dbeta=g_n1b, dbias=g_opb, out=dz2)
+            # (with queued weight gradients dz2 stays alive until the grouped launch: dz1 gets its own buffer)
+            dz1, _ = rw.add_ln_bwd(z1, m1, r1, n1_w, dy=dz2, dy2=dy1, dgamma=g_n1w, dbeta=g_n1b, dbias=g_opb, out=None if queue is not None else dz2)
             wgrad(dz1, a, g_opw)
             da = (_proj(dz1, op_t[i]) if op_t is not None else torch.mm(dz1, op_w)).view(B, S, C)
             gv, gloc, gattn = _timed("bwd", MSDA.ms_deform_attn_backward, v4, spec.shapes, spec.lsi, loc6, attn5, da, spec.im2col_step)
@@ -216,6 +223,8 @@ class EncoderCore(Function):
             grads[i * N_LAYER:(i + 1) * N_LAYER] = [g_sow, g_sob, g_aww, g_awb, g_vpw, g_vpb, g_opw, g_opb, g_n1w, g_n1b,
                                                      g_l1w, g_l1b, g_l2w, g_l2b, g_n2w, g_n2b]
             dy, dy2, dyq = dz1, dxv, dq
+        if queue is not None:
+            queue.flush()
         d_pos += dyq
         d_src = dy + dy2
         d_src += dyq

@@ -1,5 +1,7 @@
 """fp32 nn.Linear on the matrix cores (pd_gemm_tn_f32 / pd_gemm_wgrad_f32, include/pd_gemm.h): forward, input
 gradient and weight gradient as hand-written MFMA GEMMs; exact fp32 arithmetic (no TF32 / bf16 rounding)."""
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -180,6 +182,71 @@ def gemm_wgrad_acc(dy, x, dw, db=None, x3=None):
     if _TIMING["on"]:
         b.record()
         _TIMING["wgrad"].append((a, b, 2.0 * M * N * K))
+
+
+class _WgradDesc(ctypes.Structure):                                 # PdGemmWgradDesc (include/pd_gemm.h)
+    _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("dB", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ("M", "N", "K", "ldy", "ldx", "ldw")]
+
+
+class WgradQueue:
+    """Weight gradients of one backward pass collected and run as ONE grouped launch (pd_gemm_wgrad_f32x3_grouped): nothing
+    consumes a weight gradient before the optimizer, so the encoder queues its 30 per step (5 per layer) instead of launching each
+    when its operands appear.  The queue keeps the operands alive until flush()."""
+    MAXP = 256
+    _ring = None
+    _table_dev = {}
+    _ws = {}
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, dy, x, dw, db=None):
+        M, N = dy.shape
+        K = x.shape[1]
+        assert dw.shape == (N, K) and dw.is_contiguous() and (db is None or db.numel() == N)
+        assert dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.stride(1) == 1 and x.stride(1) == 1
+        self.items.append((dy, x, dw, db))
+
+    def flush(self):
+        items, self.items = self.items, []
+        if not items:
+            return
+        L = _lib.load()
+        dev = items[0][0].device
+        for lo in range(0, len(items), self.MAXP):
+            part = items[lo:lo + self.MAXP]
+            descs = (_WgradDesc * len(part))()
+            flops = 0.0
+            for d, (dy, x, dw, db) in zip(descs, part):
+                d.dY, d.X, d.dW, d.dB = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
+                d.M, d.N, d.K, d.ldy, d.ldx, d.ldw = dy.shape[0], dy.shape[1], x.shape[1], dy.stride(0), x.stride(0), dw.shape[1]
+                flops += 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1]
+            need = int(L.pd_gemm_wgrad_f32x3_grouped_ws_floats(ctypes.byref(descs), len(part)))
+            if need < 0:
+                raise RuntimeError("pd_gemm_wgrad_f32x3_grouped: a queued problem violates the alignment rules (N, K, strides % 4, 16-byte bases)")
+            key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+            ws = WgradQueue._ws.get(key)
+            if ws is None or ws.numel() < need:
+                ws = WgradQueue._ws[key] = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=dev)
+            tbytes = int(L.pd_gemm_wgrad_f32x3_grouped_table_bytes(self.MAXP))
+            if WgradQueue._ring is None:
+                from .fused import PinnedRing
+                WgradQueue._ring = PinnedRing(tbytes, torch.uint8, pin=True)
+            tdev = WgradQueue._table_dev.get(str(dev))
+            if tdev is None:
+                tdev = WgradQueue._table_dev[str(dev)] = torch.empty(tbytes, dtype=torch.uint8, device=dev)
+            host = WgradQueue._ring.acquire()
+            if _TIMING["on"]:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+            with torch.cuda.device(dev):
+                rc = L.pd_gemm_wgrad_f32x3_grouped(ctypes.byref(descs), len(part), host.data_ptr(), tdev.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+            WgradQueue._ring.release()
+            _lib.check(rc)
+            if _TIMING["on"]:
+                b.record()
+                _TIMING["wgrad"].append((a, b, flops))
 
 
 def gemm_wgrad(dy, x, with_bias=False):

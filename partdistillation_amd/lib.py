@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpd_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -38,6 +38,9 @@ SIGNATURES = {
     "pd_gemm_wgrad_acc_f32x3": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),
     "pd_conv3x3_wgrad_nhwc_f32x3": (_c_int, [_c_vp] * 5 + [ctypes.c_int64] + [_c_int] * 5 + [_c_vp]),
     "pd_gemm_wgrad_f32x3_ws_floats": (ctypes.c_int64, [_c_int] * 2),
+    "pd_gemm_wgrad_f32x3_grouped_table_bytes": (ctypes.c_int64, [_c_int]),
+    "pd_gemm_wgrad_f32x3_grouped_ws_floats": (ctypes.c_int64, [_c_vp, _c_int]),
+    "pd_gemm_wgrad_f32x3_grouped": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_vp]),
     "pd_gemm_wgrad_acc_f32x3_ws": (_c_int, [_c_vp] * 5 + [ctypes.c_int64] + [_c_int] * 6 + [_c_vp]),
     "pd_adamw_clipped_shadow": (_c_int, [_c_vp] * 5 + [ctypes.c_int64] + [ctypes.c_double] * 5 + [_c_int, _c_vp, ctypes.c_double, _c_vp, _c_vp]),
     "pd_conv_bf16_supported": (_c_int, [_c_int] * 5),

@@ -218,3 +218,34 @@ def test_gemm_tn_x3_with_presplit_weight_planes(M, N, K):
     want = (a.double() @ w.double().t()) * (h > 0)
     assert ((masked.double() - want).abs().max().item() / want.abs().max().item()) < 2e-6
     torch.testing.assert_close(acc.double(), want.sum(0), rtol=1e-4, atol=1e-3 * want.abs().max().item())
+
+
+def test_grouped_weight_gradients_match_fp64_and_the_single_launches():
+    """pd_gemm_wgrad_f32x3_grouped (functions/gemm.WgradQueue): one encoder layer's five weight gradients at BASELINE config-2 size
+    (43 008 tokens: 256 x 1024, 1024 x 256, 256 x 256, 288 x 256 with its bias gradient, 256 x 256) plus a ragged problem, as ONE
+    launch accumulated INTO pre-filled buffers, against fp64 and against the one-launch-per-gradient path."""
+    from partdistillation_amd.functions import gemm
+    g = torch.Generator(device="cuda").manual_seed(11)
+    T = 43008
+    probs = [(T, 256, 1024, False), (T, 1024, 256, False), (T, 256, 256, True), (T, 288, 256, True), (T, 256, 256, False), (1000, 100, 36, True)]
+    q = gemm.WgradQueue()
+    keep = []
+    for M, N, K, bias in probs:
+        dy = torch.randn(M, N, device="cuda", generator=g)
+        x = torch.randn(M, K, device="cuda", generator=g)
+        dw0 = torch.randn(N, K, device="cuda", generator=g)                # accumulate semantics: dW += ...
+        db0 = torch.randn(N, device="cuda", generator=g) if bias else None
+        dw, db = dw0.clone(), (db0.clone() if bias else None)
+        q.add(dy, x, dw, db)
+        keep.append((dy, x, dw0, db0, dw, db))
+    q.flush()
+    for (M, N, K, bias), (dy, x, dw0, db0, dw, db) in zip(probs, keep):
+        want = dw0.double() + dy.double().t() @ x.double()
+        tol = dict(rtol=1e-5, atol=2e-6 * M ** 0.5 * 4)
+        torch.testing.assert_close(dw.double(), want, **tol)
+        single = dw0.clone()
+        sb = db0.clone() if bias else None
+        gemm.gemm_wgrad_acc(dy, x, single, sb, x3=True)
+        torch.testing.assert_close(dw, single, rtol=1e-5, atol=1e-6 * M ** 0.5 * 4)
+        if bias:
+            torch.testing.assert_close(db.double(), db0.double() + dy.double().sum(0), **tol)
