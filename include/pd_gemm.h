@@ -103,6 +103,23 @@ int pd_conv3x3_wgrad_nhwc_f32x3(const float *dY, const float *X, float *dWk, flo
 int pd_conv3x3_nhwc_f32x3(const float *X, const float *Wk, const float *bias, float *Y, int B, int H, int W, int Ci, int Co,
                           void *stream);
 
+/* fp32 GEMM on the fp16 matrix cores, two planes per operand and three products per term (csrc/gemm_f16x2.hip): every operand
+ * row is scaled by a power of two taken from its absolute maximum, split as hi = fp16(x'), lo = fp16(x' - hi) and a b is
+ * accumulated as hi hi + hi lo + lo hi in fp32 — per-element error <= max(2^-22 |x|, 2^-39 max_row |x|), i.e. the normwise
+ * accuracy of an fp32 GEMM at half the matrix work of pd_gemm_tn_f32x3.  C[M,N] = A[M,K] B[N,K]^T:
+ *   mode 0: + bias;  1: relu(+ bias) and, when bits != NULL, its sign bits (pd_gemm_tn_f16x2_bits_words(M, N) words, the
+ *   kernel's accumulator order; N % 256 == 0, M >= 1024);  2: masked by `bits`, colsum[N] += column sums (bits, colsum required).
+ *   a_amax[M] / b_amax[N]: absolute row maxima of A / B (fp32, any value >= the true maximum within a factor 2^7 keeps full
+ *   accuracy; NULL = the operand is O(1), no scaling).  c_amax[M] (nullable, ZERO-FILLED by the caller): receives the absolute
+ *   row maxima of C (atomic max) — the a_amax of the GEMM that consumes C.
+ * K, lda, ldb multiples of 4, A and B 16-byte aligned.  Reference: the fp32 Linears of the pixel decoder,
+ * pixel_decoder/msdeformattn.py:120-135,318 and ops/modules/ms_deform_attn.py:102-130.
+ * pd_row_amax_f32: out[r] = max_c |X[r][c]| for operands whose producer does not emit the maxima. */
+int64_t pd_gemm_tn_f16x2_bits_words(int M, int N);
+int pd_gemm_tn_f16x2(const float *A, const float *B, const float *bias, float *C, uint32_t *bits, float *colsum, const float *a_amax,
+                     const float *b_amax, float *c_amax, int M, int N, int K, int lda, int ldb, int ldc, int mode, void *stream);
+int pd_row_amax_f32(const float *X, int rows, int cols, int ld, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,17 @@ int pd_add_layernorm_bwd(const float *dy, const float *dy2, const void *dy_c, co
                          int dzc_dtype, float *dgamma, float *dbeta, float *dbias, float *dpos_acc, int pos_div,
                          int rows, int C, void *stream);
 
+/* The two calls above with the absolute row maxima of their outputs written next to them (each nullable): y_amax[rows] = max |y|,
+ * ypos_amax[rows] = max |y + pos| (needs ypos_c), dz_amax[rows] = max |dz| — the row-scaling input of pd_gemm_tn_f16x2
+ * (include/pd_gemm.h) for the GEMMs that consume these tensors, produced where the row is in registers anyway. */
+int pd_add_layernorm_fwd_amax(const void *x, int x_dtype, const float *res, const float *gamma, const float *beta, float eps,
+                              float *z, float *y, void *y_c, const float *pos, int pos_div, void *ypos_c, int c_dtype,
+                              float *mean, float *rstd, float *y_amax, float *ypos_amax, int rows, int C, void *stream);
+int pd_add_layernorm_bwd_amax(const float *dy, const float *dy2, const void *dy_c, const void *dypos_c, int c_dtype,
+                              const float *z, const float *mean, const float *rstd, const float *gamma, float *dz, void *dz_c,
+                              int dzc_dtype, float *dgamma, float *dbeta, float *dbias, float *dpos_acc, int pos_div,
+                              float *dz_amax, int rows, int C, void *stream);
+
 /* acc[N] (fp32) += column sums of x [rows, N] (dtype).  N % 128 == 0. */
 int pd_colsum_acc(const void *x, int dtype, int rows, int N, float *acc, void *stream);
 

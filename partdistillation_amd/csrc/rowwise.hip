@@ -55,13 +55,26 @@ __device__ __forceinline__ float wave_sum(float v)
   return v;
 }
 
+__device__ __forceinline__ float wave_max(float v)
+{
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+__device__ __forceinline__ float amax4(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+
 // ------------------------------------------------------------------------------------------------ add + LayerNorm
 template <int NV4, typename XT, typename CT>
 __global__ __launch_bounds__(256) void add_ln_fwd(const XT *__restrict__ x, const float *__restrict__ res,
                                                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                   float *__restrict__ z, float *__restrict__ y, CT *__restrict__ y_c,
                                                   const float *__restrict__ pos, int pos_div, CT *__restrict__ ypos_c,
-                                                  float *__restrict__ mean, float *__restrict__ rstd, int rows)
+                                                  float *__restrict__ mean, float *__restrict__ rstd, int rows,
+                                                  float *__restrict__ y_amax, float *__restrict__ ypos_amax)
 {
   constexpr int C = NV4 * 256;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -92,6 +105,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd(const XT *__restrict__ x, cons
     const float rs = rsqrtf(wave_sum(q) * (1.f / C) + eps);
     if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
     const float *prow = pos ? pos + (int64_t)(r / pos_div) * C + lane * 4 : nullptr;
+    float my = 0.f, mp = 0.f;                                      // absolute row maxima of y and y + pos (the scaling input of pd_gemm_tn_f16x2)
 #pragma unroll
     for (int j = 0; j < NV4; ++j) {
       float4 o;
@@ -101,8 +115,15 @@ __global__ __launch_bounds__(256) void add_ln_fwd(const XT *__restrict__ x, cons
       o.w = v[j].w * rs * gm[j].w + bt[j].w;
       if (y) st4(y + base + j * 256, o);
       if (y_c) st4(y_c + base + j * 256, o);
-      if (ypos_c) st4(ypos_c + base + j * 256, add4(o, ld4(prow + j * 256)));
+      my = fmaxf(my, amax4(o));
+      if (ypos_c) {
+        const float4 op = add4(o, ld4(prow + j * 256));
+        st4(ypos_c + base + j * 256, op);
+        mp = fmaxf(mp, amax4(op));
+      }
     }
+    if (y_amax) { my = wave_max(my); if (lane == 0) y_amax[r] = my; }
+    if (ypos_amax) { mp = wave_max(mp); if (lane == 0) ypos_amax[r] = mp; }
   }
 }
 
@@ -113,7 +134,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd(const float *dy, const float *
                                                   const float *__restrict__ rstd, const float *__restrict__ gamma,
                                                   float *dz, DT *__restrict__ dz_c, float *__restrict__ dgamma,
                                                   float *__restrict__ dbeta, float *__restrict__ dbias,
-                                                  float *__restrict__ dpos_acc, int pos_div, int rows)
+                                                  float *__restrict__ dpos_acc, int pos_div, int rows, float *__restrict__ dz_amax)
 {
   constexpr int C = NV4 * 256;
   __shared__ float red[4][3][C];
@@ -154,6 +175,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd(const float *dy, const float *
       g[j] = t; xh[j] = h;
     }
     const float m1 = wave_sum(s1) * (1.f / C), m2 = wave_sum(s2) * (1.f / C);
+    float mz = 0.f;
 #pragma unroll
     for (int j = 0; j < NV4; ++j) {
       float4 o;
@@ -164,7 +186,9 @@ __global__ __launch_bounds__(256) void add_ln_bwd(const float *dy, const float *
       ad[j] = add4(ad[j], o);
       st4(dz + base + j * 256, o);
       if (dz_c) st4(dz_c + base + j * 256, o);
+      mz = fmaxf(mz, amax4(o));
     }
+    if (dz_amax) { mz = wave_max(mz); if (lane == 0) dz_amax[r] = mz; }
   }
   if (!dgamma && !dbeta && !dbias) return;
 #pragma unroll
@@ -686,9 +710,9 @@ bool dt_ok(int dt) { return dt == PD_F32 || dt == PD_BF16; }
     default: return pd_set_error(PD_ERR_INVALID_ARG, "C=%d: supported widths are 256, 512, 768, 1024", (C)); \
   }
 
-extern "C" int pd_add_layernorm_fwd(const void *x, int x_dtype, const float *res, const float *gamma, const float *beta, float eps,
-                                    float *z, float *y, void *y_c, const float *pos, int pos_div, void *ypos_c, int c_dtype,
-                                    float *mean, float *rstd, int rows, int C, void *stream_)
+static int add_layernorm_fwd(const void *x, int x_dtype, const float *res, const float *gamma, const float *beta, float eps,
+                             float *z, float *y, void *y_c, const float *pos, int pos_div, void *ypos_c, int c_dtype,
+                             float *mean, float *rstd, int rows, int C, void *stream_, float *y_amax, float *ypos_amax)
 {
   if (rows < 0 || C <= 0 || (C % 256)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_layernorm_fwd: rows=%d C=%d", rows, C);
   if (rows == 0) return PD_OK;
@@ -698,7 +722,7 @@ extern "C" int pd_add_layernorm_fwd(const void *x, int x_dtype, const float *res
   hipStream_t s = (hipStream_t)stream_;
   dim3 g(grid_rows(rows, 2048)), b(256);
   const bool xb = x && x_dtype == PD_BF16, cb = c_dtype == PD_BF16;
-#define LAUNCH(XT, CT) hipLaunchKernelGGL((add_ln_fwd<NV4, XT, CT>), g, b, 0, s, (const XT *)x, res, gamma, beta, eps, z, y, (CT *)y_c, pos, pos_div, (CT *)ypos_c, mean, rstd, rows)
+#define LAUNCH(XT, CT) hipLaunchKernelGGL((add_ln_fwd<NV4, XT, CT>), g, b, 0, s, (const XT *)x, res, gamma, beta, eps, z, y, (CT *)y_c, pos, pos_div, (CT *)ypos_c, mean, rstd, rows, y_amax, ypos_amax)
   NV4_SWITCH(C, {
     if (xb) { if (cb) LAUNCH(bf16_t, bf16_t); else LAUNCH(bf16_t, float); }
     else { if (cb) LAUNCH(float, bf16_t); else LAUNCH(float, float); }
@@ -707,10 +731,25 @@ extern "C" int pd_add_layernorm_fwd(const void *x, int x_dtype, const float *res
   return pd_check_launch("pd_add_layernorm_fwd");
 }
 
-extern "C" int pd_add_layernorm_bwd(const float *dy, const float *dy2, const void *dy_c, const void *dypos_c, int c_dtype,
-                                    const float *z, const float *mean, const float *rstd, const float *gamma, float *dz,
-                                    void *dz_c, int dzc_dtype, float *dgamma, float *dbeta, float *dbias, float *dpos_acc,
-                                    int pos_div, int rows, int C, void *stream_)
+extern "C" int pd_add_layernorm_fwd(const void *x, int x_dtype, const float *res, const float *gamma, const float *beta, float eps,
+                                    float *z, float *y, void *y_c, const float *pos, int pos_div, void *ypos_c, int c_dtype,
+                                    float *mean, float *rstd, int rows, int C, void *stream_)
+{
+  return add_layernorm_fwd(x, x_dtype, res, gamma, beta, eps, z, y, y_c, pos, pos_div, ypos_c, c_dtype, mean, rstd, rows, C, stream_, nullptr, nullptr);
+}
+
+extern "C" int pd_add_layernorm_fwd_amax(const void *x, int x_dtype, const float *res, const float *gamma, const float *beta, float eps,
+                                         float *z, float *y, void *y_c, const float *pos, int pos_div, void *ypos_c, int c_dtype,
+                                         float *mean, float *rstd, float *y_amax, float *ypos_amax, int rows, int C, void *stream_)
+{
+  if (ypos_amax && !ypos_c) return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_layernorm_fwd_amax: ypos_amax needs ypos_c");
+  return add_layernorm_fwd(x, x_dtype, res, gamma, beta, eps, z, y, y_c, pos, pos_div, ypos_c, c_dtype, mean, rstd, rows, C, stream_, y_amax, ypos_amax);
+}
+
+static int add_layernorm_bwd(const float *dy, const float *dy2, const void *dy_c, const void *dypos_c, int c_dtype,
+                             const float *z, const float *mean, const float *rstd, const float *gamma, float *dz,
+                             void *dz_c, int dzc_dtype, float *dgamma, float *dbeta, float *dbias, float *dpos_acc,
+                             int pos_div, int rows, int C, void *stream_, float *dz_amax)
 {
   if (rows < 0 || C <= 0 || (C % 256)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_layernorm_bwd: rows=%d C=%d", rows, C);
   if (rows == 0) return PD_OK;
@@ -722,13 +761,31 @@ extern "C" int pd_add_layernorm_bwd(const float *dy, const float *dy2, const voi
   // the per-column sums leave each workgroup as C atomics per output: cap the grid so a channel sees <= ~1k of them
   dim3 g(grid_rows(rows, 1024)), b(256);
   const bool cb = c_dtype == PD_BF16, db = dzc_dtype == PD_BF16;
-#define LAUNCH(CT, DT) hipLaunchKernelGGL((add_ln_bwd<NV4, CT, DT>), g, b, 0, s, dy, dy2, (const CT *)dy_c, (const CT *)dypos_c, z, mean, rstd, gamma, dz, (DT *)dz_c, dgamma, dbeta, dbias, dpos_acc, pos_div, rows)
+#define LAUNCH(CT, DT) hipLaunchKernelGGL((add_ln_bwd<NV4, CT, DT>), g, b, 0, s, dy, dy2, (const CT *)dy_c, (const CT *)dypos_c, z, mean, rstd, gamma, dz, (DT *)dz_c, dgamma, dbeta, dbias, dpos_acc, pos_div, rows, dz_amax)
   NV4_SWITCH(C, {
     if (cb) { if (db) LAUNCH(bf16_t, bf16_t); else LAUNCH(bf16_t, float); }
     else { if (db) LAUNCH(float, bf16_t); else LAUNCH(float, float); }
   })
 #undef LAUNCH
   return pd_check_launch("pd_add_layernorm_bwd");
+}
+
+extern "C" int pd_add_layernorm_bwd(const float *dy, const float *dy2, const void *dy_c, const void *dypos_c, int c_dtype,
+                                    const float *z, const float *mean, const float *rstd, const float *gamma, float *dz,
+                                    void *dz_c, int dzc_dtype, float *dgamma, float *dbeta, float *dbias, float *dpos_acc,
+                                    int pos_div, int rows, int C, void *stream_)
+{
+  return add_layernorm_bwd(dy, dy2, dy_c, dypos_c, c_dtype, z, mean, rstd, gamma, dz, dz_c, dzc_dtype, dgamma, dbeta, dbias, dpos_acc, pos_div, rows, C,
+                           stream_, nullptr);
+}
+
+extern "C" int pd_add_layernorm_bwd_amax(const float *dy, const float *dy2, const void *dy_c, const void *dypos_c, int c_dtype,
+                                         const float *z, const float *mean, const float *rstd, const float *gamma, float *dz,
+                                         void *dz_c, int dzc_dtype, float *dgamma, float *dbeta, float *dbias, float *dpos_acc,
+                                         int pos_div, float *dz_amax, int rows, int C, void *stream_)
+{
+  return add_layernorm_bwd(dy, dy2, dy_c, dypos_c, c_dtype, z, mean, rstd, gamma, dz, dz_c, dzc_dtype, dgamma, dbeta, dbias, dpos_acc, pos_div, rows, C,
+                           stream_, dz_amax);
 }
 
 static int colsum_launch(void *x, const void *h, int dtype, int rows, int N, float *acc, bool relu, hipStream_t s, const char *who)

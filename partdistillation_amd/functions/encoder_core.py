@@ -22,8 +22,8 @@ from torch.autograd import Function
 from .. import MultiScaleDeformableAttention as MSDA
 from .. import lib as _lib
 from . import rowwise as rw
-from .gemm import (WgradQueue, gemm_tn_x3, gemm_tn_x3_pre, gemm_tn_x3_relu_bits, gemm_tn_x3_relumask, gemm_wgrad_acc, pre_supported,
-                   relu_bits_supported, split3)
+from .gemm import (WgradQueue, gemm_tn_h2, gemm_tn_x3, gemm_tn_x3_pre, gemm_tn_x3_relu_bits, gemm_tn_x3_relumask, gemm_wgrad_acc,
+                   h2_bits_supported, pre_supported, relu_bits_supported, row_amax, split3)
 
 def _timed(kind, fn, *args):
     # bench.py's per-launch HIP-event hook lives next to the autograd face of the operator (imported lazily: that module
@@ -70,6 +70,9 @@ GROUP_WGRADS = os.environ.get("PD_GROUP_WGRADS", "1") != "0"  # the 5 weight gra
 X3_PROJ = os.environ.get("PD_X3_PROJ", "1") != "0"       # the 256-wide projections (value / offsets+weights / output and their input gradients) on the same kernel: with the
                      # round-3 epilogue (stores no longer serialised on vmcnt(0)) 256 <- 256 at M = 43 008 runs 47.7 us against the
                      # library's ~57 (tools/probes/gemm_planes_probe.hip); False: torch.addmm / mm (Tensile fp32)
+H2 = os.environ.get("PD_H2", "1") != "0"   # forward / input-gradient GEMMs on the fp16 two-plane kernel (pd_gemm_tn_f16x2: 3 products per term instead of 6, operand rows
+                     # scaled by powers of two from their absolute maxima, which the LayerNorm kernels and the GEMM epilogues emit as they write the
+                     # rows): 1024 <- 256 at M = 43 008 96 us vs 132 (x3), 256 <- 1024 85 vs 132, 256 <- 256 29 vs 44 (tools/bench_gemm_h2.py)
 PRESPLIT = False     # weight operand split into its bf16 planes once per use (pd_split3_bf16 + pd_gemm_tn_f32x3_pre).  Bit-identical results;
                      # measured 174.6 vs 178.6 us (1024 <- 256) and 157 vs 151 us (256 <- 1024) plus 8 us per split launch: no gain, so off
 
@@ -111,6 +114,10 @@ class EncoderCore(Function):
         q = src2 + pos2
         saved = []
         x = src2
+        h2 = H2 and USE_X3 and X3_PROJ and src2.is_cuda and C % 4 == 0
+        ctx.h2 = h2
+        if h2:
+            return EncoderCore._forward_h2(ctx, spec, src2, pos2, q, ref, params, (B, S, C, nl))
         for i in range(nl):
             (so_w, so_b, aw_w, aw_b, vp_w, vp_b, op_w, op_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b) = params[i * N_LAYER:(i + 1) * N_LAYER]
             value = _proj(x, vp_w, vp_b)
@@ -136,6 +143,55 @@ class EncoderCore(Function):
                                                     pos=pos2, pos_div=1, want_ypos=not last)
             saved.append((x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, w_oa, hbits))
             x, q = y2, ypos
+        ctx.spec, ctx.saved, ctx.params, ctx.dims = spec, saved, params, (B, S, C, nl)
+        return x.view(B, S, C)
+
+    @staticmethod
+    def _forward_h2(ctx, spec, src2, pos2, q, ref, params, dims):
+        """the same layer sequence with every GEMM on pd_gemm_tn_f16x2: each operand travels with the absolute maxima of its rows
+        (LayerNorm outputs and the FFN's hidden activations get them from the kernel that writes them)"""
+        B, S, C, nl = dims
+        M, L, P = spec.M, spec.L, spec.P
+        T = B * S
+        P_ = lambda i, j: params[i * N_LAYER + j]
+        # weights with 256 input columns of all layers in ONE matrix (rows: so, aw, vp, op, l1 per layer) + one row-maxima launch;
+        # the slices of that copy are the GEMM operands (so + aw adjacent = the stacked sampling_offsets / attention_weights matrix)
+        n_off, n_aw, n_l1 = P_(0, 0).shape[0], P_(0, 2).shape[0], P_(0, 10).shape[0]
+        per = n_off + n_aw + 2 * C + n_l1
+        wk = torch.cat([P_(i, j) for i in range(nl) for j in (0, 2, 4, 6, 10)])
+        wk_am = row_amax(wk)
+        b_oa_all = torch.cat([P_(i, j) for i in range(nl) for j in (1, 3)]).view(nl, n_off + n_aw)
+        l2_all = torch.cat([P_(i, 12) for i in range(nl)])                                  # [nl * C, ffn]
+        l2_am = row_amax(l2_all)
+        h_am_all = torch.zeros((nl, T), dtype=torch.float32, device=src2.device)           # atomic-max targets of the FFN epilogues
+        x, x_am, q_am = src2, row_amax(src2), row_amax(q)
+        saved = []
+        for i in range(nl):
+            (so_w, so_b, aw_w, aw_b, vp_w, vp_b, op_w, op_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b) = params[i * N_LAYER:(i + 1) * N_LAYER]
+            o = i * per
+            w_oa, oa_wam = wk[o:o + n_off + n_aw], wk_am[o:o + n_off + n_aw]
+            o += n_off + n_aw
+            vp_c, vp_wam = wk[o:o + C], wk_am[o:o + C]
+            op_c, op_wam = wk[o + C:o + 2 * C], wk_am[o + C:o + 2 * C]
+            l1_c, l1_wam = wk[o + 2 * C:o + 2 * C + n_l1], wk_am[o + 2 * C:o + 2 * C + n_l1]
+            value = gemm_tn_h2(x, vp_c, vp_b, a_amax=x_am, b_amax=vp_wam)
+            oa = gemm_tn_h2(q, w_oa, b_oa_all[i], a_amax=q_am, b_amax=oa_wam)           # [T, 2MLP + MLP]
+            loc, attn = msda_prep_fwd(oa[:, :n_off], oa[:, n_off:], ref, spec.shapes, M, L, P)
+            v4, loc6, attn5 = value.view(B, S, M, C // M), loc.view(B, S, M, L, P, 2), attn.view(B, S, M, L, P)
+            a = _timed("fwd", MSDA.ms_deform_attn_forward, v4, spec.shapes, spec.lsi, loc6, attn5, spec.im2col_step).view(T, C)
+            a_am = row_amax(a)
+            z1, y1, _, _, m1, r1, y1_am, _ = rw.add_ln_fwd(gemm_tn_h2(a, op_c, op_b, a_amax=a_am, b_amax=op_wam), x, n1_w, n1_b, spec.eps, amax=True)
+            h_am = h_am_all[i]
+            if h2_bits_supported(T, n_l1):
+                h, hbits = gemm_tn_h2(y1, l1_c, l1_b, mode=1, want_bits=True, a_amax=y1_am, b_amax=l1_wam, c_amax=h_am)
+            else:
+                h, hbits = gemm_tn_h2(y1, l1_c, l1_b, mode=1, a_amax=y1_am, b_amax=l1_wam, c_amax=h_am), None
+            ffn2 = gemm_tn_h2(h, l2_all[i * C:(i + 1) * C], l2_b, a_amax=h_am, b_amax=l2_am[i * C:(i + 1) * C])
+            last = i == nl - 1
+            z2, y2, _, ypos, m2, r2, y2_am, ypos_am = rw.add_ln_fwd(ffn2, y1, n2_w, n2_b, spec.eps, c_dtype=torch.float32,
+                                                                     pos=pos2, pos_div=1, want_ypos=not last, amax=True)
+            saved.append((x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, w_oa, hbits))
+            x, q, x_am, q_am = y2, ypos, y2_am, ypos_am
         ctx.spec, ctx.saved, ctx.params, ctx.dims = spec, saved, params, (B, S, C, nl)
         return x.view(B, S, C)
 
@@ -182,6 +238,12 @@ class EncoderCore(Function):
         l1_t, l2_t = T_all(10), T_all(12)
         op_t, vp_t = (T_all(6), T_all(4)) if X3_PROJ and USE_X3 else (None, None)
         oa_t = torch.stack([sv[14] for sv in ctx.saved]).transpose(1, 2).contiguous() if op_t is not None else None
+        h2 = getattr(ctx, "h2", False)
+        if h2:
+            # row maxima of the transposed weights (the B operands of the input-gradient GEMMs), one launch per stack
+            t_am = lambda w: row_amax(w.view(-1, w.shape[2])).view(nl, w.shape[1])
+            l1_tam, l2_tam, op_tam, vp_tam, oa_tam = t_am(l1_t), t_am(l2_t), t_am(op_t), t_am(vp_t), t_am(oa_t)
+            dh_am_all = torch.zeros((nl, T), dtype=torch.float32, device=dev)
         dy = d_out.reshape(T, C)
         dy = dy if dy.is_contiguous() else dy.contiguous()
         dy2 = dyq = None                                       # further fp32 terms of d(src_l): via value_proj, via (src + pos)
@@ -191,9 +253,38 @@ class EncoderCore(Function):
             (g_sow, g_sob, g_aww, g_awb, g_vpw, g_vpb, g_opw, g_opb, g_n1w, g_n1b, g_l1w, g_l1b, g_l2w, g_l2b, g_n2w,
              g_n2b) = [G(i, j) for j in range(N_LAYER)]
             # ---- FFN + norm2
-            dz2, _ = rw.add_ln_bwd(z2, m2, r2, n2_w, dy=dy, dy2=dy2, dypos_c=dyq, dgamma=g_n2w, dbeta=g_n2b, dbias=g_l2b,
-                                   dpos_acc=d_pos if dyq is not None else None, pos_div=1)
+            dz2, _, dz2_am = rw.add_ln_bwd(z2, m2, r2, n2_w, dy=dy, dy2=dy2, dypos_c=dyq, dgamma=g_n2w, dbeta=g_n2b, dbias=g_l2b,
+                                           dpos_acc=d_pos if dyq is not None else None, pos_div=1, amax=True)
             wgrad(dz2, h, g_l2w)
+            if h2:
+                if hbits is not None:
+                    dh = gemm_tn_h2(dz2, l2_t[i], None, mode=2, bits=hbits, colsum=g_l1b, a_amax=dz2_am, b_amax=l2_tam[i], c_amax=dh_am_all[i])
+                    dh_am = dh_am_all[i]
+                else:
+                    dh = rw.relu_bwd_colsum(gemm_tn_h2(dz2, l2_t[i], a_amax=dz2_am, b_amax=l2_tam[i]), h, g_l1b)
+                    dh_am = row_amax(dh)
+                wgrad(dh, y1, g_l1w)
+                dy1 = gemm_tn_h2(dh, l1_t[i], a_amax=dh_am, b_amax=l1_tam[i])
+                del dh
+                dz1, _, dz1_am = rw.add_ln_bwd(z1, m1, r1, n1_w, dy=dz2, dy2=dy1, dgamma=g_n1w, dbeta=g_n1b, dbias=g_opb,
+                                               out=None if queue is not None else dz2, amax=True)
+                wgrad(dz1, a, g_opw)
+                da = gemm_tn_h2(dz1, op_t[i], a_amax=dz1_am, b_amax=op_tam[i]).view(B, S, C)
+                gv, gloc, gattn = _timed("bwd", MSDA.ms_deform_attn_backward, v4, spec.shapes, spec.lsi, loc6, attn5, da, spec.im2col_step)
+                d_oa = torch.empty((T, w_oa.shape[0]), dtype=torch.float32, device=dev)
+                msda_prep_bwd(gloc, gattn, attn5, spec.shapes, T, M, L, P, out=d_oa)
+                g_oaw, g_oab = OA(i)
+                wgrad(d_oa, q, g_oaw, g_oab)                                  # both weight gradients in one split-K GEMM
+                n_off = so_w.shape[0]
+                g_sow, g_aww, g_sob, g_awb = g_oaw[:n_off], g_oaw[n_off:], g_oab[:n_off], g_oab[n_off:]
+                dq = gemm_tn_h2(d_oa, oa_t[i], a_amax=row_amax(d_oa), b_amax=oa_tam[i])
+                gv2 = gv.view(T, C)
+                wgrad(gv2, x, g_vpw, g_vpb)
+                dxv = gemm_tn_h2(gv2, vp_t[i], a_amax=row_amax(gv2), b_amax=vp_tam[i])
+                grads[i * N_LAYER:(i + 1) * N_LAYER] = [g_sow, g_sob, g_aww, g_awb, g_vpw, g_vpb, g_opw, g_opb, g_n1w, g_n1b,
+                                                         g_l1w, g_l1b, g_l2w, g_l2b, g_n2w, g_n2b]
+                dy, dy2, dyq = dz1, dxv, dq
+                continue
             pre = hbits is not None and USE_X3 and PRESPLIT and pre_supported(T, l2_w.shape[1], l2_w.shape[0]) and pre_supported(T, l1_w.shape[1], l1_w.shape[0])
             if pre:
                 dh = gemm_tn_x3_pre(dz2, split3(l2_w, transpose=True), mode=2, bits=hbits, colsum=g_l1b)

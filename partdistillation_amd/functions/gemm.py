@@ -62,6 +62,43 @@ def gemm_tn_x3(a, b, bias=None, relu=False):
     return c
 
 
+def row_amax(x):
+    """absolute row maxima of an fp32 matrix (pd_row_amax_f32): the scaling input of gemm_tn_h2 for an operand whose producer
+    does not emit them"""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().pd_row_amax_f32(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), out.data_ptr(), _stream()))
+    return out
+
+
+def h2_bits_supported(M, N):
+    return N % 256 == 0 and M >= 1024
+
+
+def gemm_tn_h2(a, b, bias=None, mode=0, bits=None, colsum=None, a_amax=None, b_amax=None, c_amax=None, want_bits=False):
+    """a [M,K] @ b [N,K].T (+bias) in fp32 on the fp16 matrix cores: two planes per operand, three products per term, operand rows
+    scaled by powers of two from their absolute maxima (pd_gemm_tn_f16x2, include/pd_gemm.h).  mode 0 plain, 1 relu (want_bits: also
+    return the sign bits), 2 masked by `bits` with `colsum` += column sums.  a_amax [M] / b_amax [N]: row maxima of a / b (None:
+    the operand is O(1)); c_amax [M] zero-filled: receives the row maxima of the result."""
+    if not a.is_cuda:
+        raise RuntimeError("pd_gemm_tn_f16x2 runs on the GPU only (no CPU fallback in partdistillation_amd)")
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K
+    for v, n in ((a_amax, M), (b_amax, N), (c_amax, M)):
+        assert v is None or (v.dtype == torch.float32 and v.is_contiguous() and v.numel() == n)
+    L = _lib.load()
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if mode == 1 and want_bits:
+        bits = torch.empty(int(L.pd_gemm_tn_f16x2_bits_words(M, N)), dtype=torch.int32, device=a.device)
+    p = lambda t: t.data_ptr() if t is not None else None
+    with _timed_fwd(2.0 * M * N * K, "gemm_tn_f16x2"):
+        _lib.check(L.pd_gemm_tn_f16x2(a.data_ptr(), b.data_ptr(), p(bias), c.data_ptr(), p(bits), p(colsum), p(a_amax), p(b_amax), p(c_amax),
+                                      M, N, K, a.stride(0), b.stride(0), N, mode, _stream()))
+    return (c, bits) if (mode == 1 and want_bits) else c
+
+
 def split3(w, transpose=False):
     """fp32 weight [N,K] -> its three bf16 planes [3,N,K] (or [3,K,N] of w.T): pd_split3_bf16, once per step per weight."""
     assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1

@@ -23,8 +23,9 @@ def _need_cuda(t, who):
 
 
 def add_ln_fwd(x, res, gamma, beta, eps, *, want_z=True, want_y=True, c_dtype=None, want_yc=False, pos=None, pos_div=1,
-               want_ypos=False):
-    """-> (z, y, y_c, ypos_c, mean, rstd); x [rows,C] (fp32 | bf16) and / or res fp32 [rows,C]."""
+               want_ypos=False, amax=False):
+    """-> (z, y, y_c, ypos_c, mean, rstd); x [rows,C] (fp32 | bf16) and / or res fp32 [rows,C].
+    amax: also -> (..., y_amax, ypos_amax | None), the absolute row maxima of y and y + pos (pd_add_layernorm_fwd_amax)."""
     ref = x if x is not None else res
     _need_cuda(ref, "pd_add_layernorm_fwd")
     rows, C = ref.shape
@@ -38,6 +39,13 @@ def add_ln_fwd(x, res, gamma, beta, eps, *, want_z=True, want_y=True, c_dtype=No
     stats = torch.empty((2, rows), dtype=torch.float32, device=dev)
     if want_ypos:
         assert pos is not None and pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[-1] == C
+    if amax:
+        am = torch.empty((2, rows), dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().pd_add_layernorm_fwd_amax(
+            _p(x), _DT[x.dtype] if x is not None else 0, _p(res), gamma.data_ptr(), beta.data_ptr(), float(eps), _p(z), _p(y), _p(y_c),
+            _p(pos) if want_ypos else None, int(pos_div), _p(ypos_c), _DT[c_dtype] if c_dtype is not None else 0,
+            stats[0].data_ptr(), stats[1].data_ptr(), am[0].data_ptr(), am[1].data_ptr() if want_ypos else None, rows, C, _stream()))
+        return z, y, y_c, ypos_c, stats[0], stats[1], am[0], (am[1] if want_ypos else None)
     _lib.check(_lib.load().pd_add_layernorm_fwd(
         _p(x), _DT[x.dtype] if x is not None else 0, _p(res), gamma.data_ptr(), beta.data_ptr(), float(eps), _p(z), _p(y), _p(y_c),
         _p(pos) if want_ypos else None, int(pos_div), _p(ypos_c), _DT[c_dtype] if c_dtype is not None else 0,
@@ -46,8 +54,9 @@ def add_ln_fwd(x, res, gamma, beta, eps, *, want_z=True, want_y=True, c_dtype=No
 
 
 def add_ln_bwd(z, mean, rstd, gamma, *, dy=None, dy2=None, dy_c=None, dypos_c=None, dz_c_dtype=None, dgamma=None, dbeta=None,
-               dbias=None, dpos_acc=None, pos_div=1, out=None):
-    """-> (dz fp32, dz_c | None).  dgamma / dbeta / dbias / dpos_acc are fp32 accumulators (+=)."""
+               dbias=None, dpos_acc=None, pos_div=1, out=None, amax=False):
+    """-> (dz fp32, dz_c | None).  dgamma / dbeta / dbias / dpos_acc are fp32 accumulators (+=).
+    amax: -> (dz, dz_c, dz_amax), dz_amax [rows] = the absolute row maxima of dz (pd_add_layernorm_bwd_amax)."""
     rows, C = z.shape
     assert z.dtype == torch.float32 and gamma.dtype == torch.float32 and mean.dtype == torch.float32
     cd = None
@@ -59,6 +68,13 @@ def add_ln_bwd(z, mean, rstd, gamma, *, dy=None, dy2=None, dy_c=None, dypos_c=No
         assert t is None or (t.is_contiguous() and t.dtype == torch.float32)
     dz = out if out is not None else torch.empty((rows, C), dtype=torch.float32, device=z.device)
     dz_c = torch.empty((rows, C), dtype=dz_c_dtype, device=z.device) if dz_c_dtype is not None else None
+    if amax:
+        am = torch.empty(rows, dtype=torch.float32, device=z.device)
+        _lib.check(_lib.load().pd_add_layernorm_bwd_amax(
+            _p(dy), _p(dy2), _p(dy_c), _p(dypos_c), _DT[cd] if cd is not None else 0, z.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+            gamma.data_ptr(), dz.data_ptr(), _p(dz_c), _DT[dz_c_dtype] if dz_c_dtype is not None else 0, _p(dgamma), _p(dbeta),
+            _p(dbias), _p(dpos_acc), int(pos_div), am.data_ptr(), rows, C, _stream()))
+        return dz, dz_c, am
     _lib.check(_lib.load().pd_add_layernorm_bwd(
         _p(dy), _p(dy2), _p(dy_c), _p(dypos_c), _DT[cd] if cd is not None else 0, z.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
         gamma.data_ptr(), dz.data_ptr(), _p(dz_c), _DT[dz_c_dtype] if dz_c_dtype is not None else 0, _p(dgamma), _p(dbeta),

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpd_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -27,6 +27,9 @@ SIGNATURES = {
     "pd_adamw_clipped": (_c_int, [_c_vp] * 4 + [ctypes.c_int64, _c_int] + [ctypes.c_double] * 5 + [_c_int, _c_vp, ctypes.c_double, _c_vp, _c_vp]),
     "pd_gemm_tn_f32": (_c_int, [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
     "pd_gemm_tn_f32x3": (_c_int, [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
+    "pd_gemm_tn_f16x2_bits_words": (ctypes.c_int64, [_c_int] * 2),
+    "pd_gemm_tn_f16x2": (_c_int, [_c_vp] * 9 + [_c_int] * 7 + [_c_vp]),
+    "pd_row_amax_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "pd_gemm_tn_f32x3_relumask": (_c_int, [_c_vp] * 5 + [_c_int] * 6 + [_c_vp]),
     "pd_gemm_tn_f32x3_relu_bits": (_c_int, [_c_vp] * 5 + [_c_int] * 6 + [_c_vp]),
     "pd_gemm_tn_f32x3_relu_bits_words": (ctypes.c_int64, [_c_int] * 2),
@@ -64,6 +67,9 @@ SIGNATURES = {
     "pd_add_layernorm_fwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp,
                                       _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_vp]),
     "pd_add_layernorm_bwd": (_c_int, [_c_vp] * 4 + [_c_int] + [_c_vp] * 6 + [_c_int] + [_c_vp] * 4 + [_c_int] * 3 + [_c_vp]),
+    "pd_add_layernorm_fwd_amax": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp,
+                                           _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_vp]),
+    "pd_add_layernorm_bwd_amax": (_c_int, [_c_vp] * 4 + [_c_int] + [_c_vp] * 6 + [_c_int] + [_c_vp] * 4 + [_c_int] + [_c_vp] + [_c_int] * 2 + [_c_vp]),
     "pd_colsum_acc": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "pd_relu_bwd_colsum": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "pd_mem_prep_fwd": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),

@@ -249,3 +249,54 @@ def test_grouped_weight_gradients_match_fp64_and_the_single_launches():
         torch.testing.assert_close(dw, single, rtol=1e-5, atol=1e-6 * M ** 0.5 * 4)
         if bias:
             torch.testing.assert_close(db.double(), db0.double() + dy.double().sum(0), **tol)
+
+
+@pytest.mark.parametrize("M,N,K", [(1500, 256, 256), (2048, 1024, 256), (1100, 256, 1024), (333, 72, 40), (4096, 288, 256)])
+@pytest.mark.parametrize("mag", [1.0, 1e-7, 3e4])
+def test_gemm_tn_h2_is_fp32_accurate_over_the_exponent_range(M, N, K, mag):
+    """pd_gemm_tn_f16x2 (two fp16 planes, three products, rows scaled from their maxima): normwise error vs fp64 at the level of the
+    library's fp32 GEMM for operands from 1e-7 to 3e4 (gradients to activations), rows of very different magnitude, every tile shape;
+    the row maxima it emits are exact."""
+    from partdistillation_amd import lib
+    from partdistillation_amd.functions import gemm
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda") * mag * torch.logspace(-3, 3, M, device="cuda")[torch.randperm(M, device="cuda"), None]
+    w = torch.randn(N, K, device="cuda") * K ** -0.5
+    b = torch.randn(N, device="cuda") * mag
+    ref = torch.addmm(b.double(), a.double(), w.double().t())
+    rown = ref.abs().amax(1, keepdim=True).clamp_min(1e-300)                         # every ROW is judged against its own scale
+    e_lib = ((torch.addmm(b, a, w.t()).double() - ref).abs() / rown).max().item()
+    aa, wa = gemm.row_amax(a), gemm.row_amax(w)
+    assert torch.equal(aa, a.abs().amax(1))
+    for tile in (0, 2, 4) + ((1, 3) if N % 256 == 0 and M >= 1024 else ()):
+        lib.load().pd_debug_set(b"f16x2_tile", tile)
+        try:
+            cm = torch.zeros(M, device="cuda")
+            got = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa, c_amax=cm)
+        finally:
+            lib.load().pd_debug_set(b"f16x2_tile", 0)
+        e = ((got.double() - ref).abs() / rown).max().item()
+        assert e <= 2.0 * e_lib + 2 ** -21 and e < 3e-6, (tile, e, e_lib)
+        assert torch.equal(cm, got.abs().amax(1))
+    r = gemm.gemm_tn_h2(a, w, b, mode=1, a_amax=aa, b_amax=wa)
+    assert ((r.double() - ref.clamp_min(0)).abs() / rown).max().item() < 3e-6
+
+
+def test_gemm_tn_h2_relu_bits_and_mask_epilogues():
+    from partdistillation_amd.functions import gemm
+    torch.manual_seed(5)
+    M, N, K = 2304, 512, 256
+    x = torch.randn(M, K, device="cuda"); w1 = torch.randn(N, K, device="cuda") * K ** -0.5; b1 = torch.randn(N, device="cuda")
+    h, bits = gemm.gemm_tn_h2(x, w1, b1, mode=1, want_bits=True, b_amax=gemm.row_amax(w1))
+    href = torch.addmm(b1.double(), x.double(), w1.double().t()).clamp_min(0)
+    assert ((h.double() - href).abs().max().item() / href.abs().max().item()) < 2e-6
+    dy = torch.randn(M, K, device="cuda") * 1e-5; w2t = torch.randn(N, K, device="cuda") * K ** -0.5
+    acc = torch.full((N,), 0.25, device="cuda")
+    cm = torch.zeros(M, device="cuda")
+    got = gemm.gemm_tn_h2(dy, w2t, None, mode=2, bits=bits, colsum=acc, a_amax=gemm.row_amax(dy), b_amax=gemm.row_amax(w2t), c_amax=cm)
+    ref = (dy.double() @ w2t.double().t()) * (h > 0)
+    scale = ref.abs().max().item()
+    assert ((got.double() - ref).abs().max().item() / scale) < 2e-6
+    assert torch.equal(got != 0, (h > 0) & (ref != 0))
+    assert torch.equal(cm, got.abs().amax(1))
+    torch.testing.assert_close(acc.double() - 0.25, ref.sum(0), rtol=1e-4, atol=1e-2 * scale)   # 0.25 + 2 304 fp32 atomics of ~1e-5 terms
