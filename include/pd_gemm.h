@@ -82,6 +82,7 @@ typedef struct PdGemmWgradDesc {
   const float *dY, *X;
   float *dW, *dB;
   int M, N, K, ldy, ldx, ldw;
+  const float *y_amax, *x_amax;   /* absolute row maxima of dY / X [M] (nullable); read by the _f16x2 form only */
 } PdGemmWgradDesc;
 int64_t pd_gemm_wgrad_f32x3_grouped_table_bytes(int max_count);
 int64_t pd_gemm_wgrad_f32x3_grouped_ws_floats(const PdGemmWgradDesc *descs, int count);
@@ -115,6 +116,16 @@ int pd_conv3x3_nhwc_f32x3(const float *X, const float *Wk, const float *bias, fl
  * K, lda, ldb multiples of 4, A and B 16-byte aligned.  Reference: the fp32 Linears of the pixel decoder,
  * pixel_decoder/msdeformattn.py:120-135,318 and ops/modules/ms_deform_attn.py:102-130.
  * pd_row_amax_f32: out[r] = max_c |X[r][c]| for operands whose producer does not emit the maxima. */
+/* The weight-gradient kernels in the same two-plane form: the contraction runs over the rows, so each workgroup scales its slab
+ * of rows by powers of two from the largest of the slab's row maxima (y_amax / x_amax [M], nullable = O(1) operand) and undoes
+ * them on its partial tile.  Same arguments otherwise as pd_gemm_wgrad_acc_f32x3_ws / pd_gemm_wgrad_f32x3_grouped /
+ * pd_conv3x3_wgrad_nhwc_f32x3; N, K, ldy, ldx multiples of 4, 16-byte aligned operands. */
+int pd_gemm_wgrad_acc_f16x2_ws(const float *dY, const float *X, float *dW, float *dB, const float *y_amax, const float *x_amax,
+                               float *workspace, int64_t workspace_floats, int M, int N, int K, int ldy, int ldx, int ldw, void *stream);
+int pd_gemm_wgrad_f16x2_grouped(const PdGemmWgradDesc *descs, int count, void *table_host_pinned, void *table_device, float *workspace,
+                                int64_t workspace_floats, void *stream);
+int pd_conv3x3_wgrad_nhwc_f16x2(const float *dY, const float *X, float *dWk, float *dB, const float *y_amax, const float *x_amax,
+                                float *workspace, int64_t workspace_floats, int B, int H, int W, int Ci, int Co, void *stream);
 int64_t pd_gemm_tn_f16x2_bits_words(int M, int N);
 int pd_gemm_tn_f16x2(const float *A, const float *B, const float *bias, float *C, uint32_t *bits, float *colsum, const float *a_amax,
                      const float *b_amax, float *c_amax, int M, int N, int K, int lda, int ldb, int ldc, int mode, void *stream);

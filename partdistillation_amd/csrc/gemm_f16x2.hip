@@ -22,47 +22,14 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "f16x2.h"
 #include "pd_common.h"
 #include "pd_gemm.h"
 #include "pd_msda.h"
 
 namespace {
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short h16_t;
-
+using namespace pdh2;
 __device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
-
-// scale / inverse scale of a row from its absolute maximum: biased exponent e of the maximum, clamped to [20, 250];
-// scale 2^(141 - e) puts the maximum into [2^14, 2^15); zero / tiny rows get the largest scale (harmless), inf / nan propagate
-__device__ __forceinline__ void row_scale(float amax, float &s, float &inv)
-{
-  int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
-  e = e < 20 ? 20 : (e > 250 ? 250 : e);
-  s = __uint_as_float((unsigned)(268 - e) << 23);
-  inv = __uint_as_float((unsigned)(e - 14) << 23);
-}
-
-struct SplitH { uint2 hi, lo; };                                   // 4 consecutive k of one row, per plane
-__device__ __forceinline__ void split2h(float x0, float x1, unsigned &h, unsigned &l)
-{
-  const f32x2 x = {x0, x1};
-  const h16x2 hh = __builtin_convertvector(x, h16x2);              // round to nearest even
-  const f32x2 r = {x0 - (float)hh[0], x1 - (float)hh[1]};         // exact
-  const h16x2 ll = __builtin_convertvector(r, h16x2);
-  h = __builtin_bit_cast(unsigned, hh);
-  l = __builtin_bit_cast(unsigned, ll);
-}
-__device__ __forceinline__ SplitH split4h(float4 v, float s)
-{
-  SplitH o;
-  split2h(v.x * s, v.y * s, o.hi.x, o.lo.x);
-  split2h(v.z * s, v.w * s, o.hi.y, o.lo.y);
-  return o;
-}
-__device__ __forceinline__ void mmah(f32x16 &c, h16x8 x, h16x8 y) { c = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0); }
 
 // TM x TN tile, waves laid out (TM / 64) x (TN / WN), each wave 64 x WN = 2 x (WN / 32) MFMA tiles.
 // LDS: [stage][plane][k panel of 8][row][8 halves]: an MFMA operand (8 consecutive k of row lane % 32, panel lane / 32 of the

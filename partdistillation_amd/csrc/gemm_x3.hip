@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "f16x2.h"
 #include "mfma_bf16.h"
 #include "pd_common.h"
 #include "pd_gemm.h"
@@ -525,12 +526,18 @@ __device__ __forceinline__ hwbf16x8 frag_tr(const bf16_t *p)      // p: this lan
 // CONV: X is an NHWC image [*, H, W, Ci] (ldx = Ci), K = 9 Ci ordered (tap, channel) like the channels-last filter gradient
 // [Co][3][3][Ci]; Ci % 128 == 0, so a tile's 128 columns lie inside one tap and its X rows are the pixels m + dy W + dx (zeros
 // outside the image): the weight gradient of a 3 x 3, stride 1, pad 1 convolution, nothing unfolded.
-template <int ABL, bool CONV>
+// H2: the fp16 two-plane form (f16x2.h; three products per term instead of six).  The contraction runs over the rows, so the two
+// operands are scaled per WORKGROUP: by powers of two from the largest row maximum (y_amax / x_amax, the absolute row maxima of dY
+// / X as their producers emit them; NULL = O(1) operand) among the rows [mb, me) this workgroup walks, undone on its partial tile.
+// Rows far below their slab's maximum lose relative, not absolute, accuracy — the sum is dominated by the large rows.
+template <int ABL, bool CONV, bool H2 = false>
 __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ dW,
                                               float *__restrict__ dB, float *__restrict__ ws, int M, int N, int K, int ldy, int ldx,
-                                              int ldw, int tiles_k, int tiles, int m_chunk, int H, int W, int bid, int64_t ws_tile0)
+                                              int ldw, int tiles_k, int tiles, int m_chunk, int H, int W, int bid, int64_t ws_tile0,
+                                              const float *__restrict__ y_amax = nullptr, const float *__restrict__ x_amax = nullptr)
 {
-  __shared__ __attribute__((aligned(16))) bf16_t S[2][2][3][TWS][TP];      // stage, operand (dY, X), plane, row, column
+  constexpr int NP = H2 ? 2 : 3;
+  __shared__ __attribute__((aligned(16))) bf16_t S[2][2][NP][TWS][TP];     // stage, operand (dY, X), plane, row, column
   const int tile = bid % tiles, split = bid / tiles;
   const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BM;
   const int mb = split * m_chunk, me = min(M, mb + m_chunk);
@@ -538,6 +545,26 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ dY, cons
   const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
   const int sr = t >> 5, sc = (t & 31) * 4;                      // staging: rows sr, sr + 8; columns sc .. sc+3
   const bool ycol_ok = n0 + sc < N, xcol_ok = k0 + sc < K;
+  float sy = 1.f, sx = 1.f, inv_yx = 1.f;
+  if (H2 && (y_amax || x_amax)) {
+    float my = 0.f, mx = 0.f;
+    if (y_amax) for (int r = mb + t; r < me; r += 256) my = fmaxf(my, y_amax[r]);
+    // CONV: the X rows of this slab are the pixels r + dy W + dx — the range widened by one image row + 1 bounds them
+    const int xlo = CONV ? max(0, mb - W - 1) : mb, xhi = CONV ? min(M, me + W + 1) : me;
+    if (x_amax) for (int r = xlo + t; r < xhi; r += 256) mx = fmaxf(mx, x_amax[r]);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { my = fmaxf(my, __shfl_xor(my, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+    float *red = reinterpret_cast<float *>(&S[0][0][0][0][0]);
+    if (lane == 0) { red[wave] = my; red[4 + wave] = mx; }
+    __syncthreads();
+    my = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    __syncthreads();
+    float iy = 1.f, ix = 1.f;
+    if (y_amax) pdh2::row_scale(my, sy, iy);
+    if (x_amax) pdh2::row_scale(mx, sx, ix);
+    inv_yx = iy * ix;
+  }
   float4 ry[2][2], rx[2][2];                                     // two register stages
   int cpy[2] = {0, 0}, cpx[2] = {0, 0}, tdy = 0, tdx = 0, xoff = k0 + sc;   // CONV: image coordinates of the rows the NEXT gload stages
   if (CONV) {
@@ -571,12 +598,18 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ dY, cons
   auto lstore = [&](int s, int buf) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const Split4 y = split4(ry[s][j]), x = split4(rx[s][j]);
       const int r = sr + 8 * j;
-      *reinterpret_cast<uint2 *>(&S[buf][0][0][r][sc]) = y.hi; *reinterpret_cast<uint2 *>(&S[buf][0][1][r][sc]) = y.mid;
-      *reinterpret_cast<uint2 *>(&S[buf][0][2][r][sc]) = y.lo;
-      *reinterpret_cast<uint2 *>(&S[buf][1][0][r][sc]) = x.hi; *reinterpret_cast<uint2 *>(&S[buf][1][1][r][sc]) = x.mid;
-      *reinterpret_cast<uint2 *>(&S[buf][1][2][r][sc]) = x.lo;
+      if constexpr (H2) {
+        const pdh2::SplitH y = pdh2::split4h(ry[s][j], sy), x = pdh2::split4h(rx[s][j], sx);
+        *reinterpret_cast<uint2 *>(&S[buf][0][0][r][sc]) = y.hi; *reinterpret_cast<uint2 *>(&S[buf][0][1][r][sc]) = y.lo;
+        *reinterpret_cast<uint2 *>(&S[buf][1][0][r][sc]) = x.hi; *reinterpret_cast<uint2 *>(&S[buf][1][1][r][sc]) = x.lo;
+      } else {
+        const Split4 y = split4(ry[s][j]), x = split4(rx[s][j]);
+        *reinterpret_cast<uint2 *>(&S[buf][0][0][r][sc]) = y.hi; *reinterpret_cast<uint2 *>(&S[buf][0][1][r][sc]) = y.mid;
+        *reinterpret_cast<uint2 *>(&S[buf][0][NP - 1][r][sc]) = y.lo;
+        *reinterpret_cast<uint2 *>(&S[buf][1][0][r][sc]) = x.hi; *reinterpret_cast<uint2 *>(&S[buf][1][1][r][sc]) = x.mid;
+        *reinterpret_cast<uint2 *>(&S[buf][1][NP - 1][r][sc]) = x.lo;
+      }
       if (do_bias) { bsum.x += ry[s][j].x; bsum.y += ry[s][j].y; bsum.z += ry[s][j].z; bsum.w += ry[s][j].w; }
     }
   };
@@ -598,9 +631,9 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ dY, cons
   const int frow = 8 * (grp >> 1) + (sl >> 2), fcol = 16 * (grp & 1) + 4 * (sl & 3);   // this lane's segment inside a 32-column block
   auto step = [&](int st, int par) {
     if (st + 2 < steps) gload(par, mb + (st + 2) * TWS);
-    hwbf16x8 a[3][2], b[3][2];
+    hwbf16x8 a[NP][2], b[NP][2];
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         a[p][i] = frag_tr(&S[par][0][p][frow][wn + i * 32 + fcol]);
@@ -608,9 +641,13 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ dY, cons
       }
 #define TERM(PA, PB)                                                         \
   _Pragma("unroll") for (int i = 0; i < 2; ++i)                              \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) mma16k(acc[i][j], a[PA][i], b[PB][j]);
-    if (ABL != 2) { TERM(2, 0) TERM(0, 2) TERM(1, 1) TERM(1, 0) TERM(0, 1) TERM(0, 0) }
-    else { _Pragma("unroll") for (int p = 0; p < 3; ++p) _Pragma("unroll") for (int i = 0; i < 2; ++i) { acc[i][0][p] += (float)a[p][i][0]; acc[i][1][p] += (float)b[p][i][0]; } }
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                        \
+        if constexpr (H2) pdh2::mmah(acc[i][j], __builtin_bit_cast(pdh2::h16x8, a[PA][i]), __builtin_bit_cast(pdh2::h16x8, b[PB][j])); \
+        else mma16k(acc[i][j], a[PA][i], b[PB][j]);                          \
+      }
+    if constexpr (H2) { TERM(1, 0) TERM(0, 1) TERM(0, 0) }
+    else if (ABL != 2) { TERM(NP - 1, 0) TERM(0, NP - 1) TERM(1, 1) TERM(1, 0) TERM(0, 1) TERM(0, 0) }
+    else { _Pragma("unroll") for (int p = 0; p < NP; ++p) _Pragma("unroll") for (int i = 0; i < 2; ++i) { acc[i][0][p] += (float)a[p][i][0]; acc[i][1][p] += (float)b[p][i][0]; } }
 #undef TERM
     if (st + 1 < steps) lstore(par ^ 1, par ^ 1);
     __syncthreads();
@@ -641,7 +678,7 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ dY, cons
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) w[((i * 2 + j) * 16 + e) * 256] = acc[i][j][e];
+        for (int e = 0; e < 16; ++e) w[((i * 2 + j) * 16 + e) * 256] = H2 ? acc[i][j][e] * inv_yx : acc[i][j][e];
     return;
   }
 #pragma unroll
@@ -653,18 +690,19 @@ __device__ __forceinline__ void wgrad_tr_body(const float *__restrict__ dY, cons
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = n0 + wn + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (row < N) unsafeAtomicAdd(dW + (int64_t)row * ldw + c, acc[i][j][e]);
+        if (row < N) unsafeAtomicAdd(dW + (int64_t)row * ldw + c, H2 ? acc[i][j][e] * inv_yx : acc[i][j][e]);
       }
   }
 }
 
-template <int ABL, bool CONV>
+template <int ABL, bool CONV, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3_tr(const float *__restrict__ dY, const float *__restrict__ X,
                                                                float *__restrict__ dW, float *__restrict__ dB, float *__restrict__ ws,
                                                                int M, int N, int K, int ldy, int ldx, int ldw, int tiles_k, int tiles,
-                                                               int m_chunk, int H, int W)
+                                                               int m_chunk, int H, int W, const float *__restrict__ y_amax,
+                                                               const float *__restrict__ x_amax)
 {
-  wgrad_tr_body<ABL, CONV>(dY, X, dW, dB, ws, M, N, K, ldy, ldx, ldw, tiles_k, tiles, m_chunk, H, W, (int)blockIdx.x, 0);
+  wgrad_tr_body<ABL, CONV, H2>(dY, X, dW, dB, ws, M, N, K, ldy, ldx, ldw, tiles_k, tiles, m_chunk, H, W, (int)blockIdx.x, 0, y_amax, x_amax);
 }
 
 // Several weight gradients in ONE launch (pd_gemm_wgrad_f32x3_grouped): a table of problems in device memory, workgroup b belongs
@@ -677,15 +715,17 @@ struct WgradX3Problem {
   float *dW, *dB;
   int M, N, K, ldy, ldx, ldw, tiles_k, tiles, m_chunk, splits, block0, pad;
   int64_t ws_tile0;
+  const float *y_amax, *x_amax;
 };
 
+template <bool H2>
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3_tr_grouped(const WgradX3Problem *__restrict__ tab, int count, float *__restrict__ ws)
 {
   int p = 0;
   while (p + 1 < count && (int)blockIdx.x >= tab[p + 1].block0) ++p;      // <= a few dozen problems: a scalar scan
   const WgradX3Problem q = tab[p];
-  wgrad_tr_body<0, false>(q.dY, q.X, q.dW, q.dB, ws, q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, q.tiles_k, q.tiles, q.m_chunk, 0, 0,
-                          (int)blockIdx.x - q.block0, q.ws_tile0);
+  wgrad_tr_body<0, false, H2>(q.dY, q.X, q.dW, q.dB, ws, q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, q.tiles_k, q.tiles, q.m_chunk, 0, 0,
+                              (int)blockIdx.x - q.block0, q.ws_tile0, q.y_amax, q.x_amax);
 }
 
 // grouped form of wgrad_tr_reduce: blockIdx.x = 64 x (global output tile index); the problem is found from its first tile
@@ -889,7 +929,8 @@ extern "C" int pd_gemm_tn_f32x3_relumask(const float *A, const float *B, const u
 }
 
 static int wgrad_x3_launch(const float *dY, const float *X, float *dW, float *dB, float *ws, int64_t ws_floats, int M, int N, int K, int ldy,
-                           int ldx, int ldw, hipStream_t st, const char *who, int convH = 0, int convW = 0)
+                           int ldx, int ldw, hipStream_t st, const char *who, int convH = 0, int convW = 0, bool h2 = false,
+                           const float *y_amax = nullptr, const float *x_amax = nullptr)
 {
   if (M < 0 || N < 0 || K < 0) return pd_set_error(PD_ERR_INVALID_ARG, "%s: negative size", who);
   if (N == 0 || K == 0 || M == 0) return PD_OK;
@@ -907,15 +948,17 @@ static int wgrad_x3_launch(const float *dY, const float *X, float *dW, float *dB
   // transpose-read form when the operands allow 16-byte row loads (always, in this repo); x3_ablate 21 forces the scalar-staged one
   const bool vec = !(N & 3) && !(K & 3) && !(ldy & 3) && !(ldx & 3) && !((uintptr_t)dY & 15) && !((uintptr_t)X & 15) && g_pd_dbg_x3 != 21;
   if (convH && !vec) return pd_set_error(PD_ERR_INVALID_ARG, "%s: channel counts must be multiples of 4 and the tensors 16-byte aligned", who);
+  if (h2 && !vec) return pd_set_error(PD_ERR_INVALID_ARG, "%s: N, K, ldy, ldx must be multiples of 4 and dY, X 16-byte aligned", who);
   if (!vec) {
     hipLaunchKernelGGL(gemm_wgrad_f32x3, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, dY, X, dW, dB, M, N, K, ldy, ldx, ldw, tk, tiles,
                        m_chunk);
     return pd_check_launch(who);
   }
   if (ws && (ws_floats < (int64_t)tiles * splits * BN * BM || splits < 2 || g_pd_dbg_x3 == 25)) ws = nullptr;   // not worth / does not fit: atomics
-  auto kfn = convH ? gemm_wgrad_f32x3_tr<0, true> : g_pd_dbg_x3 == 24 ? gemm_wgrad_f32x3_tr<2, false> : gemm_wgrad_f32x3_tr<0, false>;
+  auto kfn = h2 ? (convH ? gemm_wgrad_f32x3_tr<0, true, true> : gemm_wgrad_f32x3_tr<0, false, true>)
+                 : convH ? gemm_wgrad_f32x3_tr<0, true> : g_pd_dbg_x3 == 24 ? gemm_wgrad_f32x3_tr<2, false> : gemm_wgrad_f32x3_tr<0, false>;
   hipLaunchKernelGGL(kfn, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, dY, X, dW, dB, ws, M, N, K, ldy, ldx, ldw, tk, tiles, m_chunk,
-                     convH, convW);
+                     convH, convW, y_amax, x_amax);
   const int groups = tiles * 64 >= 2048 ? 1 : splits >= 64 ? 8 : splits >= 16 ? 4 : 1;
   if (ws) hipLaunchKernelGGL(wgrad_tr_reduce, dim3((unsigned)(tiles * 64), groups), dim3(256), 0, st, (const float *)ws, dW, N, K, ldw, tk, tiles,
                              splits);
@@ -948,6 +991,7 @@ static int grouped_plan(const PdGemmWgradDesc *d, int count, WgradX3Problem *tab
     if (mc < 4 * TWS) mc = 4 * TWS;
     q.m_chunk = mc; q.splits = (q.M + mc - 1) / mc;
     q.block0 = b0; q.pad = 0; q.ws_tile0 = wt;
+    q.y_amax = d[i].y_amax; q.x_amax = d[i].x_amax;
     b0 += q.tiles * q.splits; wt += (int64_t)q.tiles * q.splits;
   }
   *ws_tiles = wt; *blocks = b0;
@@ -963,8 +1007,8 @@ extern "C" int64_t pd_gemm_wgrad_f32x3_grouped_ws_floats(const PdGemmWgradDesc *
   return wt * BN * BM;
 }
 
-extern "C" int pd_gemm_wgrad_f32x3_grouped(const PdGemmWgradDesc *descs, int count, void *table_host_pinned, void *table_device,
-                                           float *workspace, int64_t workspace_floats, void *stream_)
+static int wgrad_grouped(const PdGemmWgradDesc *descs, int count, void *table_host_pinned, void *table_device, float *workspace,
+                         int64_t workspace_floats, void *stream_, bool h2)
 {
   if (count == 0) return PD_OK;
   if (count < 0 || count > 256 || !descs || !table_host_pinned || !table_device || !workspace)
@@ -980,9 +1024,40 @@ extern "C" int pd_gemm_wgrad_f32x3_grouped(const PdGemmWgradDesc *descs, int cou
   const WgradX3Problem *dt = reinterpret_cast<const WgradX3Problem *>(table_device);
   int64_t tiles = 0;
   for (int i = 0; i < count; ++i) tiles += tab[i].tiles;
-  hipLaunchKernelGGL(gemm_wgrad_f32x3_tr_grouped, dim3((unsigned)blocks), dim3(256), 0, st, dt, count, workspace);
+  if (h2) hipLaunchKernelGGL(gemm_wgrad_f32x3_tr_grouped<true>, dim3((unsigned)blocks), dim3(256), 0, st, dt, count, workspace);
+  else hipLaunchKernelGGL(gemm_wgrad_f32x3_tr_grouped<false>, dim3((unsigned)blocks), dim3(256), 0, st, dt, count, workspace);
   hipLaunchKernelGGL(wgrad_tr_reduce_grouped, dim3((unsigned)(tiles * 64)), dim3(256), 0, st, dt, count, (const float *)workspace);
   return pd_check_launch("pd_gemm_wgrad_f32x3_grouped");
+}
+
+extern "C" int pd_gemm_wgrad_f32x3_grouped(const PdGemmWgradDesc *descs, int count, void *table_host_pinned, void *table_device,
+                                           float *workspace, int64_t workspace_floats, void *stream_)
+{
+  return wgrad_grouped(descs, count, table_host_pinned, table_device, workspace, workspace_floats, stream_, false);
+}
+
+extern "C" int pd_gemm_wgrad_f16x2_grouped(const PdGemmWgradDesc *descs, int count, void *table_host_pinned, void *table_device,
+                                           float *workspace, int64_t workspace_floats, void *stream_)
+{
+  return wgrad_grouped(descs, count, table_host_pinned, table_device, workspace, workspace_floats, stream_, true);
+}
+
+extern "C" int pd_gemm_wgrad_acc_f16x2_ws(const float *dY, const float *X, float *dW, float *dB, const float *y_amax, const float *x_amax,
+                                          float *workspace, int64_t workspace_floats, int M, int N, int K, int ldy, int ldx, int ldw, void *stream_)
+{
+  return wgrad_x3_launch(dY, X, dW, dB, workspace, workspace_floats, M, N, K, ldy, ldx, ldw, (hipStream_t)stream_, "pd_gemm_wgrad_acc_f16x2_ws", 0, 0,
+                         true, y_amax, x_amax);
+}
+
+extern "C" int pd_conv3x3_wgrad_nhwc_f16x2(const float *dY, const float *X, float *dWk, float *dB, const float *y_amax, const float *x_amax,
+                                           float *workspace, int64_t workspace_floats, int B, int H, int W, int Ci, int Co, void *stream_)
+{
+  if (B < 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || (Ci % BM) || (Co & 3))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_conv3x3_wgrad_nhwc_f16x2: B=%d H=%d W=%d Ci=%d (%% 128) Co=%d (%% 4)", B, H, W, Ci, Co);
+  const int64_t M = (int64_t)B * H * W;
+  if (M > 0x7fffffffLL - 4096) return pd_set_error(PD_ERR_INVALID_ARG, "pd_conv3x3_wgrad_nhwc_f16x2: too many pixels");
+  return wgrad_x3_launch(dY, X, dWk, dB, workspace, workspace_floats, (int)M, Co, 9 * Ci, Co, Ci, 9 * Ci, (hipStream_t)stream_,
+                         "pd_conv3x3_wgrad_nhwc_f16x2", H, W, true, y_amax, x_amax);
 }
 
 extern "C" int pd_gemm_wgrad_acc_f32x3(const float *dY, const float *X, float *dW, float *dB, int M, int N, int K, int ldy, int ldx,

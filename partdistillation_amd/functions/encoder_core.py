@@ -70,6 +70,7 @@ GROUP_WGRADS = os.environ.get("PD_GROUP_WGRADS", "1") != "0"  # the 5 weight gra
 X3_PROJ = os.environ.get("PD_X3_PROJ", "1") != "0"       # the 256-wide projections (value / offsets+weights / output and their input gradients) on the same kernel: with the
                      # round-3 epilogue (stores no longer serialised on vmcnt(0)) 256 <- 256 at M = 43 008 runs 47.7 us against the
                      # library's ~57 (tools/probes/gemm_planes_probe.hip); False: torch.addmm / mm (Tensile fp32)
+H2_WGRAD = os.environ.get("PD_H2_WGRAD", "1") != "0"   # ... and the weight gradients (pd_gemm_wgrad_f16x2_grouped: slab-wise scales)
 H2 = os.environ.get("PD_H2", "1") != "0"   # forward / input-gradient GEMMs on the fp16 two-plane kernel (pd_gemm_tn_f16x2: 3 products per term instead of 6, operand rows
                      # scaled by powers of two from their absolute maxima, which the LayerNorm kernels and the GEMM epilogues emit as they write the
                      # rows): 1024 <- 256 at M = 43 008 96 us vs 132 (x3), 256 <- 1024 85 vs 132, 256 <- 256 29 vs 44 (tools/bench_gemm_h2.py)
@@ -165,7 +166,7 @@ class EncoderCore(Function):
         l2_am = row_amax(l2_all)
         h_am_all = torch.zeros((nl, T), dtype=torch.float32, device=src2.device)           # atomic-max targets of the FFN epilogues
         x, x_am, q_am = src2, row_amax(src2), row_amax(q)
-        saved = []
+        saved, saved_am = [], []
         for i in range(nl):
             (so_w, so_b, aw_w, aw_b, vp_w, vp_b, op_w, op_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b) = params[i * N_LAYER:(i + 1) * N_LAYER]
             o = i * per
@@ -191,7 +192,9 @@ class EncoderCore(Function):
             z2, y2, _, ypos, m2, r2, y2_am, ypos_am = rw.add_ln_fwd(ffn2, y1, n2_w, n2_b, spec.eps, c_dtype=torch.float32,
                                                                      pos=pos2, pos_div=1, want_ypos=not last, amax=True)
             saved.append((x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, w_oa, hbits))
+            saved_am.append((x_am, q_am, a_am, y1_am, h_am))
             x, q, x_am, q_am = y2, ypos, y2_am, ypos_am
+        ctx.saved_am = saved_am
         ctx.spec, ctx.saved, ctx.params, ctx.dims = spec, saved, params, (B, S, C, nl)
         return x.view(B, S, C)
 
@@ -207,8 +210,16 @@ class EncoderCore(Function):
         # FLOPs) are skipped; the input gradient still flows (input_proj / level_embed in front of it stay trainable)
         need_w = any(ctx.needs_input_grad[3:])
         from . import gemm as _gemm
-        queue = WgradQueue() if (need_w and GROUP_WGRADS and _gemm.WGRAD_X3 and d_out.is_cuda) else None
-        wgrad = (queue.add if queue is not None else gemm_wgrad_acc) if need_w else (lambda *a, **k: None)
+        h2 = getattr(ctx, "h2", False)
+        wh2 = h2 and H2_WGRAD
+        queue = WgradQueue(h2=wh2) if (need_w and GROUP_WGRADS and _gemm.WGRAD_X3 and d_out.is_cuda) else None
+        if not need_w:
+            wgrad = lambda *a, **k: None
+        elif queue is not None:
+            wgrad = (lambda dy_, x_, dw_, db_=None, ya=None, xa=None: queue.add(dy_, x_, dw_, db_, ya if wh2 else None, xa if wh2 else None))
+        else:
+            wgrad = (lambda dy_, x_, dw_, db_=None, ya=None, xa=None: gemm_wgrad_acc(dy_, x_, dw_, db_, h2=wh2, y_amax=ya if wh2 else None,
+                                                                                     x_amax=xa if wh2 else None))
         # every parameter gradient of the encoder lives in ONE zero-filled fp32 buffer (a single memset): the LayerNorm /
         # ReLU kernels and the split-K weight-gradient GEMMs all accumulate (+=) into their slices
         offs, total = [], 0
@@ -238,7 +249,6 @@ class EncoderCore(Function):
         l1_t, l2_t = T_all(10), T_all(12)
         op_t, vp_t = (T_all(6), T_all(4)) if X3_PROJ and USE_X3 else (None, None)
         oa_t = torch.stack([sv[14] for sv in ctx.saved]).transpose(1, 2).contiguous() if op_t is not None else None
-        h2 = getattr(ctx, "h2", False)
         if h2:
             # row maxima of the transposed weights (the B operands of the input-gradient GEMMs), one launch per stack
             t_am = lambda w: row_amax(w.view(-1, w.shape[2])).view(nl, w.shape[1])
@@ -255,36 +265,40 @@ class EncoderCore(Function):
             # ---- FFN + norm2
             dz2, _, dz2_am = rw.add_ln_bwd(z2, m2, r2, n2_w, dy=dy, dy2=dy2, dypos_c=dyq, dgamma=g_n2w, dbeta=g_n2b, dbias=g_l2b,
                                            dpos_acc=d_pos if dyq is not None else None, pos_div=1, amax=True)
-            wgrad(dz2, h, g_l2w)
             if h2:
+                x_am, q_am, a_am, y1_am, h_am = ctx.saved_am[i]
+                wgrad(dz2, h, g_l2w, None, dz2_am, h_am)
                 if hbits is not None:
                     dh = gemm_tn_h2(dz2, l2_t[i], None, mode=2, bits=hbits, colsum=g_l1b, a_amax=dz2_am, b_amax=l2_tam[i], c_amax=dh_am_all[i])
                     dh_am = dh_am_all[i]
                 else:
                     dh = rw.relu_bwd_colsum(gemm_tn_h2(dz2, l2_t[i], a_amax=dz2_am, b_amax=l2_tam[i]), h, g_l1b)
                     dh_am = row_amax(dh)
-                wgrad(dh, y1, g_l1w)
+                wgrad(dh, y1, g_l1w, None, dh_am, y1_am)
                 dy1 = gemm_tn_h2(dh, l1_t[i], a_amax=dh_am, b_amax=l1_tam[i])
                 del dh
                 dz1, _, dz1_am = rw.add_ln_bwd(z1, m1, r1, n1_w, dy=dz2, dy2=dy1, dgamma=g_n1w, dbeta=g_n1b, dbias=g_opb,
                                                out=None if queue is not None else dz2, amax=True)
-                wgrad(dz1, a, g_opw)
+                wgrad(dz1, a, g_opw, None, dz1_am, a_am)
                 da = gemm_tn_h2(dz1, op_t[i], a_amax=dz1_am, b_amax=op_tam[i]).view(B, S, C)
                 gv, gloc, gattn = _timed("bwd", MSDA.ms_deform_attn_backward, v4, spec.shapes, spec.lsi, loc6, attn5, da, spec.im2col_step)
                 d_oa = torch.empty((T, w_oa.shape[0]), dtype=torch.float32, device=dev)
                 msda_prep_bwd(gloc, gattn, attn5, spec.shapes, T, M, L, P, out=d_oa)
                 g_oaw, g_oab = OA(i)
-                wgrad(d_oa, q, g_oaw, g_oab)                                  # both weight gradients in one split-K GEMM
+                d_oa_am = row_amax(d_oa)
+                wgrad(d_oa, q, g_oaw, g_oab, d_oa_am, q_am)                   # both weight gradients in one split-K GEMM
                 n_off = so_w.shape[0]
                 g_sow, g_aww, g_sob, g_awb = g_oaw[:n_off], g_oaw[n_off:], g_oab[:n_off], g_oab[n_off:]
-                dq = gemm_tn_h2(d_oa, oa_t[i], a_amax=row_amax(d_oa), b_amax=oa_tam[i])
+                dq = gemm_tn_h2(d_oa, oa_t[i], a_amax=d_oa_am, b_amax=oa_tam[i])
                 gv2 = gv.view(T, C)
-                wgrad(gv2, x, g_vpw, g_vpb)
-                dxv = gemm_tn_h2(gv2, vp_t[i], a_amax=row_amax(gv2), b_amax=vp_tam[i])
+                gv_am = row_amax(gv2)
+                wgrad(gv2, x, g_vpw, g_vpb, gv_am, x_am)
+                dxv = gemm_tn_h2(gv2, vp_t[i], a_amax=gv_am, b_amax=vp_tam[i])
                 grads[i * N_LAYER:(i + 1) * N_LAYER] = [g_sow, g_sob, g_aww, g_awb, g_vpw, g_vpb, g_opw, g_opb, g_n1w, g_n1b,
                                                          g_l1w, g_l1b, g_l2w, g_l2b, g_n2w, g_n2b]
                 dy, dy2, dyq = dz1, dxv, dq
                 continue
+            wgrad(dz2, h, g_l2w)
             pre = hbits is not None and USE_X3 and PRESPLIT and pre_supported(T, l2_w.shape[1], l2_w.shape[0]) and pre_supported(T, l1_w.shape[1], l1_w.shape[0])
             if pre:
                 dh = gemm_tn_x3_pre(dz2, split3(l2_w, transpose=True), mode=2, bits=hbits, colsum=g_l1b)

@@ -197,9 +197,10 @@ def _wgrad_workspace(device, need):
     return ws
 
 
-def gemm_wgrad_acc(dy, x, dw, db=None, x3=None):
+def gemm_wgrad_acc(dy, x, dw, db=None, x3=None, h2=False, y_amax=None, x_amax=None):
     """dw [N,K] += dy.T @ x, db [N] += dy.sum(0): accumulates into caller-initialised fp32 buffers (no memset launches).
-    x3 (default WGRAD_X3): the fp32-accurate kernel on the bf16 matrix cores instead of the exact-fp32 MFMA one."""
+    x3 (default WGRAD_X3): the fp32-accurate kernel on the bf16 matrix cores instead of the exact-fp32 MFMA one.
+    h2: the fp16 two-plane form (pd_gemm_wgrad_acc_f16x2_ws) with the operands' absolute row maxima y_amax / x_amax [M]."""
     M, N = dy.shape
     K = x.shape[1]
     assert dw.shape == (N, K) and dw.is_contiguous() and (db is None or db.numel() == N)
@@ -208,7 +209,13 @@ def gemm_wgrad_acc(dy, x, dw, db=None, x3=None):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
     L = _lib.load()
-    if WGRAD_X3 if x3 is None else x3:
+    if h2:
+        ws = _wgrad_workspace(dy.device, int(L.pd_gemm_wgrad_f32x3_ws_floats(N, K)))
+        _lib.check(L.pd_gemm_wgrad_acc_f16x2_ws(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                                y_amax.data_ptr() if y_amax is not None else None, x_amax.data_ptr() if x_amax is not None else None,
+                                                ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                                M, N, K, dy.stride(0), x.stride(0), K, _stream()))
+    elif WGRAD_X3 if x3 is None else x3:
         ws = _wgrad_workspace(dy.device, int(L.pd_gemm_wgrad_f32x3_ws_floats(N, K)))
         _lib.check(L.pd_gemm_wgrad_acc_f32x3_ws(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
                                                 ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
@@ -223,7 +230,7 @@ def gemm_wgrad_acc(dy, x, dw, db=None, x3=None):
 
 class _WgradDesc(ctypes.Structure):                                 # PdGemmWgradDesc (include/pd_gemm.h)
     _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("dB", ctypes.c_void_p)] + \
-               [(n, ctypes.c_int32) for n in ("M", "N", "K", "ldy", "ldx", "ldw")]
+               [(n, ctypes.c_int32) for n in ("M", "N", "K", "ldy", "ldx", "ldw")] + [("y_amax", ctypes.c_void_p), ("x_amax", ctypes.c_void_p)]
 
 
 class WgradQueue:
@@ -235,15 +242,19 @@ class WgradQueue:
     _table_dev = {}
     _ws = {}
 
-    def __init__(self):
+    def __init__(self, h2=False):
+        """h2: the fp16 two-plane form (pd_gemm_wgrad_f16x2_grouped); add() then takes the operands' absolute row maxima"""
         self.items = []
+        self.h2 = h2
 
-    def add(self, dy, x, dw, db=None):
+    def add(self, dy, x, dw, db=None, y_amax=None, x_amax=None):
         M, N = dy.shape
         K = x.shape[1]
         assert dw.shape == (N, K) and dw.is_contiguous() and (db is None or db.numel() == N)
         assert dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.stride(1) == 1 and x.stride(1) == 1
-        self.items.append((dy, x, dw, db))
+        for v in (y_amax, x_amax):
+            assert v is None or (self.h2 and v.dtype == torch.float32 and v.is_contiguous() and v.numel() == M)
+        self.items.append((dy, x, dw, db, y_amax, x_amax))
 
     def flush(self):
         items, self.items = self.items, []
@@ -255,8 +266,9 @@ class WgradQueue:
             part = items[lo:lo + self.MAXP]
             descs = (_WgradDesc * len(part))()
             flops = 0.0
-            for d, (dy, x, dw, db) in zip(descs, part):
+            for d, (dy, x, dw, db, ya, xa) in zip(descs, part):
                 d.dY, d.X, d.dW, d.dB = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
+                d.y_amax, d.x_amax = (ya.data_ptr() if ya is not None else None), (xa.data_ptr() if xa is not None else None)
                 d.M, d.N, d.K, d.ldy, d.ldx, d.ldw = dy.shape[0], dy.shape[1], x.shape[1], dy.stride(0), x.stride(0), dw.shape[1]
                 flops += 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1]
             need = int(L.pd_gemm_wgrad_f32x3_grouped_ws_floats(ctypes.byref(descs), len(part)))
@@ -278,7 +290,8 @@ class WgradQueue:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
             with torch.cuda.device(dev):
-                rc = L.pd_gemm_wgrad_f32x3_grouped(ctypes.byref(descs), len(part), host.data_ptr(), tdev.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+                fn = L.pd_gemm_wgrad_f16x2_grouped if self.h2 else L.pd_gemm_wgrad_f32x3_grouped
+                rc = fn(ctypes.byref(descs), len(part), host.data_ptr(), tdev.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
             WgradQueue._ring.release()
             _lib.check(rc)
             if _TIMING["on"]:

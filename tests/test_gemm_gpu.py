@@ -300,3 +300,33 @@ def test_gemm_tn_h2_relu_bits_and_mask_epilogues():
     assert torch.equal(got != 0, (h > 0) & (ref != 0))
     assert torch.equal(cm, got.abs().amax(1))
     torch.testing.assert_close(acc.double() - 0.25, ref.sum(0), rtol=1e-4, atol=1e-2 * scale)   # 0.25 + 2 304 fp32 atomics of ~1e-5 terms
+
+
+@pytest.mark.parametrize("M,N,K", [(43008, 1024, 256), (5000, 288, 256), (2100, 256, 1024), (700, 72, 40)])
+@pytest.mark.parametrize("mag", [1.0, 1e-6])
+def test_gemm_wgrad_h2_matches_fp64(M, N, K, mag):
+    """pd_gemm_wgrad_acc_f16x2_ws / pd_gemm_wgrad_f16x2_grouped: dW += dY^T X with slab-wise power-of-two scales from the row maxima —
+    normwise error vs fp64 at the exact-fp32 kernel's level, for gradient-sized dY with rows of very different magnitude."""
+    from partdistillation_amd.functions import gemm
+    torch.manual_seed(M + N)
+    dy = torch.randn(M, N, device="cuda") * mag * torch.logspace(-2, 2, M, device="cuda")[torch.randperm(M, device="cuda"), None]
+    x = torch.randn(M, K, device="cuda") * (1 + 5 * torch.rand(M, 1, device="cuda"))
+    ref = dy.double().t() @ x.double()
+    scale = ref.abs().max().item()
+    ya, xa = gemm.row_amax(dy), gemm.row_amax(x)
+    dw32 = torch.zeros(N, K, device="cuda"); gemm.gemm_wgrad_acc(dy, x, dw32, x3=False)
+    e32 = ((dw32.double() - ref).abs().max().item() / scale)
+    dw = torch.zeros(N, K, device="cuda"); db = torch.zeros(N, device="cuda")
+    gemm.gemm_wgrad_acc(dy, x, dw, db, h2=True, y_amax=ya, x_amax=xa)
+    e = ((dw.double() - ref).abs().max().item() / scale)
+    assert e <= 2.0 * e32 + 2 ** -21 and e < 3e-6, (e, e32)
+    torch.testing.assert_close(db.double(), dy.double().sum(0), rtol=1e-4, atol=1e-3 * dy.abs().max().item())
+    q = gemm.WgradQueue(h2=True)
+    dw2 = torch.zeros(N, K, device="cuda"); dw3 = torch.zeros(K, K, device="cuda"); db2 = torch.zeros(N, device="cuda")
+    q.add(dy, x, dw2, db2, ya, xa)
+    q.add(x, x, dw3, None, xa, xa)
+    q.flush()
+    assert ((dw2.double() - ref).abs().max().item() / scale) < 3e-6
+    r3 = x.double().t() @ x.double()
+    assert ((dw3.double() - r3).abs().max().item() / r3.abs().max().item()) < 3e-6
+    torch.testing.assert_close(db2, db, rtol=1e-4, atol=1e-3 * dy.abs().max().item())

@@ -36,4 +36,10 @@ for N, K in [(1024, 256), (256, 1024), (256, 256), (512, 256), (192, 256), (256,
         us = timeit(lambda: G.gemm_wgrad_acc(dy, x, dw, db, x3=x3))
         row.append(f"{name}: {us:7.1f} us {2.0 * M * N * K / us / 1e6:6.1f} TF  err {err:.1e} bias {errb:.1e}")
     L.load().pd_debug_set(b"x3_ablate", 0)
+    ya, xa = G.row_amax(dy), G.row_amax(x)
+    dw = torch.zeros(N, K, device="cuda"); db = torch.zeros(N, device="cuda")
+    G.gemm_wgrad_acc(dy, x, dw, db, h2=True, y_amax=ya, x_amax=xa)
+    err = float((dw.double() - ref).abs().max() / ref.abs().max())
+    us = timeit(lambda: G.gemm_wgrad_acc(dy, x, dw, db, h2=True, y_amax=ya, x_amax=xa))
+    row.append(f"f16x2 tr-read+ws: {us:7.1f} us {2.0 * M * N * K / us / 1e6:6.1f} TF  err {err:.1e}")
     print(f"N={N:5d} K={K:5d} | " + " | ".join(row), flush=True)
