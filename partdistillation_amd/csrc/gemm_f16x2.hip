@@ -36,12 +36,16 @@ __device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0
 // 16-wide sub-step) is ONE ds_read_b128 and the 32 lanes of a half read 512 contiguous bytes.
 // MODE 0: C = A B^T + bias; 1: relu(...) and, when bits != NULL, its sign bits in accumulator order; 2: (A B^T) where the
 // recorded bit is set, colsum += column sums.  c_amax != NULL: atomic max of |C| per row (as uint bits; caller zero-fills).
-template <int TM, int TN, int WN, int BKK, int MODE>
+// CONV: A is an NHWC image [*, H, W, Ci] (lda = Ci) and row m of the GEMM is output pixel m of a 3 x 3, stride 1, pad 1
+// convolution, K = 9 Ci ordered (tap, channel) like the channels-last filter [Co][3][3][Ci]: a 16-wide step lies inside one tap and
+// its A tile is the input at pixel m + dy W + dx (zeros outside the image) — an implicit GEMM (gemm_x3.hip's CONV form).  The scale
+// of output row m then has to cover the nine input pixels it reads: the largest of their maxima.
+template <int TM, int TN, int WN, int BKK, int MODE, bool CONV = false>
 __global__ __launch_bounds__((TM / 64) * (TN / WN) * 64, (TM == 256 ? 1 : 2))
 void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ bias, float *__restrict__ C,
                    int M, int N, int K, int lda, int ldb, int ldc, int ntiles_n, uint32_t *__restrict__ bits,
                    float *__restrict__ colsum, const float *__restrict__ a_amax, const float *__restrict__ b_amax,
-                   unsigned *__restrict__ c_amax)
+                   unsigned *__restrict__ c_amax, int H, int W)
 {
   constexpr int WVN = TN / WN, NW = (TM / 64) * WVN, NTH = NW * 64, NJ = WN / 32;
   constexpr int TPR = BKK / 4, RPP = NTH / TPR, APASS = TM / RPP, BPASS = TN / RPP, NPAN = BKK / 8;
@@ -61,7 +65,18 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
     const int g = isa ? m0 + r : n0 + r - TM;
     const float *am = isa ? a_amax : b_amax;
     float s = 1.f, inv = 1.f;
-    if (am && g < (isa ? M : N)) row_scale(am[g], s, inv);
+    if (am && g < (isa ? M : N)) {
+      float mx = am[g];
+      if (CONV && isa) {
+        const int pix = g % (H * W), y = pix / W, x = pix - y * W;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx)
+            if (y + dy >= 0 && y + dy < H && x + dx >= 0 && x + dx < W) mx = fmaxf(mx, am[g + dy * W + dx]);
+      }
+      row_scale(mx, s, inv);
+    }
     sc[r] = s; sc[TM + TN + r] = inv;
   }
   __syncthreads();
@@ -71,12 +86,29 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
 #pragma unroll
   for (int j = 0; j < BPASS; ++j) sb[j] = sc[TM + lr + RPP * j];
   float4 ra[APASS], rb[BPASS];
+  int py[APASS], px[APASS];                                        // CONV: image row / column of this thread's A rows
+  if (CONV) {
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+      const int pix = (m0 + lr + RPP * j) % (H * W);
+      py[j] = pix / W;
+      px[j] = pix - py[j] * W;
+    }
+  }
   auto gload = [&](int k0) {
     const int k = k0 + lk;
+    int dy = 0, dx = 0, kc = k;
+    if (CONV) { const int tap = k / lda; kc = k - tap * lda; dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
       const int r = lr + RPP * j;
-      ra[j] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4 *>(A + (int64_t)(m0 + r) * lda + k) : make_float4(0, 0, 0, 0);
+      if (CONV) {
+        const int yy = py[j] + dy, xx = px[j] + dx;
+        const bool ok = m0 + r < M && k < K && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        ra[j] = ok ? *reinterpret_cast<const float4 *>(A + ((int64_t)(m0 + r) + dy * W + dx) * lda + kc) : make_float4(0, 0, 0, 0);
+      } else {
+        ra[j] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4 *>(A + (int64_t)(m0 + r) * lda + k) : make_float4(0, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int j = 0; j < BPASS; ++j) {
@@ -239,9 +271,10 @@ __global__ __launch_bounds__(256) void row_amax_f32(const float *__restrict__ X,
 
 int g_pd_dbg_f16x2 = 0;   // tools/ only (pd_debug_set "f16x2_tile"): 1 force 256x256x32, 2 force 128x128x32, 3 force 256x256x16, 4 force 128x128x16 (0: by shape, 16-deep)
 
-template <int TM, int TN, int WN, int BKK>
+template <int TM, int TN, int WN, int BKK, bool CONV = false>
 static int launch_f16x2(const float *A, const float *B, const float *bias, float *C, int M, int N, int K, int lda, int ldb, int ldc, int mode,
-                        uint32_t *bits, float *colsum, const float *a_amax, const float *b_amax, float *c_amax, hipStream_t st)
+                        uint32_t *bits, float *colsum, const float *a_amax, const float *b_amax, float *c_amax, hipStream_t st, int H = 0,
+                        int W = 0)
 {
   constexpr int NTH = (TM / 64) * (TN / WN) * 64;
   // stages (2) x planes (2) x (TM + TN) rows x BKK halves + scales; the row-maxima reduction reuses the staging space (NW x 64 x 33 floats)
@@ -249,12 +282,13 @@ static int launch_f16x2(const float *A, const float *B, const float *bias, float
   constexpr size_t lds = (stage > red ? stage : red) + (size_t)2 * (TM + TN) * sizeof(float);
   const int tn = (N + TN - 1) / TN, tm = (M + TM - 1) / TM;
   typedef void (*kfn)(const float *, const float *, const float *, float *, int, int, int, int, int, int, int, uint32_t *, float *, const float *,
-                      const float *, unsigned *);
-  const kfn k = mode == 0 ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 0> : mode == 1 ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 1> : (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 2>;
+                      const float *, unsigned *, int, int);
+  const kfn k = CONV ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 0, CONV>
+                     : mode == 0 ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 0> : mode == 1 ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 1> : (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 2>;
   static bool attr[3] = {false, false, false};
   if (!attr[mode]) { (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[mode] = true; }
   hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)tm * tn)), dim3(NTH), lds, st, A, B, bias, C, M, N, K, lda, ldb, ldc, tn, bits, colsum, a_amax,
-                     b_amax, reinterpret_cast<unsigned *>(c_amax));
+                     b_amax, reinterpret_cast<unsigned *>(c_amax), H, W);
   return pd_check_launch("pd_gemm_tn_f16x2");
 }
 
@@ -290,6 +324,21 @@ extern "C" int pd_gemm_tn_f16x2(const float *A, const float *B, const float *bia
   if (g_pd_dbg_f16x2 == 2) GO(128, 128, 64, 32);
   GO(128, 128, 64, 16);
 #undef GO
+}
+
+extern "C" int pd_conv3x3_nhwc_f16x2(const float *X, const float *Wk, const float *bias, float *Y, const float *x_amax, const float *w_amax,
+                                     float *y_amax, int B, int H, int W, int Ci, int Co, void *stream_)
+{
+  if (B < 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || (Ci & 15))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_conv3x3_nhwc_f16x2: B=%d H=%d W=%d Ci=%d (%% 16) Co=%d", B, H, W, Ci, Co);
+  if (B == 0) return PD_OK;
+  if (!X || !Wk || !Y || ((uintptr_t)X & 15) || ((uintptr_t)Wk & 15)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_conv3x3_nhwc_f16x2: null / misaligned pointer");
+  const int64_t M = (int64_t)B * H * W;
+  if (M > 0x7fffffffLL - 4096) return pd_set_error(PD_ERR_INVALID_ARG, "pd_conv3x3_nhwc_f16x2: too many pixels");
+  hipStream_t st = (hipStream_t)stream_;
+  const bool wide = g_pd_dbg_f16x2 == 3 || (g_pd_dbg_f16x2 != 4 && (Co % 256) == 0 && M >= 65536);
+  if (wide) return launch_f16x2<256, 256, 128, 16, true>(X, Wk, bias, Y, (int)M, Co, 9 * Ci, Ci, 9 * Ci, Co, 0, nullptr, nullptr, x_amax, w_amax, y_amax, st, H, W);
+  return launch_f16x2<128, 128, 64, 16, true>(X, Wk, bias, Y, (int)M, Co, 9 * Ci, Ci, 9 * Ci, Co, 0, nullptr, nullptr, x_amax, w_amax, y_amax, st, H, W);
 }
 
 extern "C" int pd_row_amax_f32(const float *X, int rows, int cols, int ld, float *out, void *stream_)

@@ -7,6 +7,8 @@ from torch.autograd import Function
 from .. import lib as _lib
 
 
+H2 = __import__("os").environ.get("PD_H2_CONV", "1") != "0"   # the fp16 two-plane form (pd_conv3x3_nhwc_f16x2 / pd_conv3x3_wgrad_nhwc_f16x2: three products per
+                     # term instead of six, pixels scaled by powers of two from their channel maxima); False: the 3-plane bf16 kernels
 WGRAD_X3 = True      # False: MIOpen's fp32 weight gradient (1.53 ms at 2 x 256 x 256^2, the transposed-read split kernel: see DESIGN.md)
 
 
@@ -17,11 +19,23 @@ def supported(x, conv):
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
-def _raw(x, wk, bias, co):
+def _pixel_amax(x):
+    """absolute maximum over the channels of every pixel of a channels-last map -> [B*H*W] (the row maxima of its NHWC rows)"""
+    from .gemm import row_amax
+    return row_amax(x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]))
+
+
+def _raw(x, wk, bias, co, x_amax=None):
     """x channels-last [B,Ci,H,W]; wk [Co,3,3,Ci] contiguous -> channels-last [B,Co,H,W]"""
     B, ci, H, W = x.shape
     y = torch.empty((B, co, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    from .gemm import _timed_fwd
+    from .gemm import _timed_fwd, row_amax
+    if x_amax is not None:
+        w_amax = row_amax(wk.view(co, -1))
+        with _timed_fwd(2.0 * B * H * W * 9 * ci * co, "gemm_tn_f16x2<conv 3x3>"):
+            _lib.check(_lib.load().pd_conv3x3_nhwc_f16x2(x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                                         x_amax.data_ptr(), w_amax.data_ptr(), None, B, H, W, ci, co, _lib.current_stream()))
+        return y
     with _timed_fwd(2.0 * B * H * W * 9 * ci * co, "gemm_tn_f32x3<conv 3x3>"):
         _lib.check(_lib.load().pd_conv3x3_nhwc_f32x3(x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                                                      B, H, W, ci, co, _lib.current_stream()))
@@ -35,21 +49,23 @@ class Conv3x3X3(Function):
             raise RuntimeError("pd_conv3x3_nhwc_f32x3 runs on the GPU only (no CPU fallback in partdistillation_amd)")
         x = x.contiguous(memory_format=torch.channels_last)
         wk = weight.permute(0, 2, 3, 1).contiguous()                       # [Co,3,3,Ci]: free when the filter is stored channels-last
-        ctx.save_for_backward(x, weight)
+        x_am = _pixel_amax(x) if H2 else None
+        ctx.save_for_backward(x, weight, x_am)
         ctx.has_bias = bias is not None
-        return _raw(x, wk, bias, weight.shape[0])
+        return _raw(x, wk, bias, weight.shape[0], x_am)
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, x_am = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last)
         co, ci = weight.shape[0], weight.shape[1]
         dx = dw = db = None
+        dy_am = _pixel_amax(dy) if x_am is not None else None
         if ctx.needs_input_grad[0]:
             # dX[p, ci] = sum_tap sum_co dY[p - off(tap), co] W[co, tap, ci]: the same kernel on dY with the taps flipped and the
             # filter transposed to [Ci][3][3][Co] (2.4 MB at 256 channels)
             wt = weight.permute(0, 2, 3, 1).reshape(co, 9, ci).flip(1).permute(2, 1, 0).contiguous()
-            dx = _raw(dy, wt, None, ci)
+            dx = _raw(dy, wt, None, ci, dy_am)
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if (want_w or want_b) and WGRAD_X3 and ci % 128 == 0 and co % 4 == 0:
             # the same split on the weight gradient: contraction over the pixels, tiles transposed on their way out of LDS
@@ -59,9 +75,14 @@ class Conv3x3X3(Function):
             buf = torch.zeros(co * 9 * ci + co, dtype=torch.float32, device=x.device)
             dwk, dbv = buf[:co * 9 * ci].view(co, 3, 3, ci), buf[co * 9 * ci:]
             ws = _wgrad_workspace(x.device, int(L.pd_gemm_wgrad_f32x3_ws_floats(co, 9 * ci)))
-            _lib.check(L.pd_conv3x3_wgrad_nhwc_f32x3(dy.data_ptr(), x.data_ptr(), dwk.data_ptr(), dbv.data_ptr() if want_b else None,
-                                                     ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
-                                                     B, H, W, ci, co, _lib.current_stream()))
+            if x_am is not None:
+                _lib.check(L.pd_conv3x3_wgrad_nhwc_f16x2(dy.data_ptr(), x.data_ptr(), dwk.data_ptr(), dbv.data_ptr() if want_b else None,
+                                                         dy_am.data_ptr(), x_am.data_ptr(), ws.data_ptr() if ws is not None else None,
+                                                         ws.numel() if ws is not None else 0, B, H, W, ci, co, _lib.current_stream()))
+            else:
+                _lib.check(L.pd_conv3x3_wgrad_nhwc_f32x3(dy.data_ptr(), x.data_ptr(), dwk.data_ptr(), dbv.data_ptr() if want_b else None,
+                                                         ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                                         B, H, W, ci, co, _lib.current_stream()))
             dw = dwk.permute(0, 3, 1, 2) if want_w else None                # [Co,Ci,3,3] view with channels-last strides
             db = dbv if want_b else None
         elif want_w or want_b:

@@ -104,13 +104,16 @@ def check_capture_refuses_packet_capture():
     from partdistillation_amd.engine.trainer import TrainStep
     torch.manual_seed(0)
     step = TrainStep(_cfg())
-    os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "1"
+    # the variable is read when the module is imported (the HIP runtime reads it at initialisation: a later os.environ change
+    # would pass a check and change nothing), so this child is started WITHOUT the safe setting
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0"
+    os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"              # too late: must still refuse
     with pytest.raises(RuntimeError, match="DEBUG_CLR_GRAPH_PACKET_CAPTURE=0"):
         step.capture(make_batch(2, 128, n_parts=3, seed=1, device=DEV))
 
 
-def _child(check):
-    env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE="0")
+def _child(check, packet_capture="0"):
+    env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE=packet_capture)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), check], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
@@ -124,7 +127,7 @@ def test_mismatching_batches_run_eagerly_between_replays():
 
 
 def test_capture_refuses_packet_capture():
-    _child("check_capture_refuses_packet_capture")
+    _child("check_capture_refuses_packet_capture", packet_capture="1")
 
 
 def test_object_class_is_part_of_the_signature_only_where_the_step_reads_it():

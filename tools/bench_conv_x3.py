@@ -19,6 +19,15 @@ for B, S, C in [(2, 256, 256), (2, 320, 256)]:
     w = (torch.randn(C, C, 3, 3, device="cuda") * 0.02).contiguous(memory_format=torch.channels_last).requires_grad_()
     go = torch.randn(B, C, S, S, device="cuda").contiguous(memory_format=torch.channels_last)
     gf = 2.0 * B * S * S * C * C * 9 / 1e9
+    for h2 in (True, False):
+        conv_x3.H2 = h2
+        yy = conv_x3.conv3x3(x, w)
+        print(f"  H2={h2}: forward {t(lambda: conv_x3.conv3x3(x, w)):.3f} ms, backward (dx + dw) {t(lambda: torch.autograd.grad(yy, (x, w), go, retain_graph=True)):.3f} ms, dw alone {t(lambda: torch.autograd.grad(yy, (w,), go, retain_graph=True)):.3f} ms")
+    for tile in (3, 4):
+        lib.load().pd_debug_set(b"f16x2_tile", tile); conv_x3.H2 = True
+        print(f"  H2 tile {tile}: forward {t(lambda: conv_x3.conv3x3(x, w)):.3f} ms")
+    lib.load().pd_debug_set(b"f16x2_tile", 0)
+    conv_x3.H2 = False
     f_lib = t(lambda: F.conv2d(x, w, None, padding=1)); f_x3 = t(lambda: conv_x3.conv3x3(x, w))
     y1 = F.conv2d(x, w, None, padding=1); y2 = conv_x3.conv3x3(x, w)
     b_lib = t(lambda: torch.autograd.grad(y1, (x, w), go, retain_graph=True)); b_x3 = t(lambda: torch.autograd.grad(y2, (x, w), go, retain_graph=True))
