@@ -170,7 +170,7 @@ def cpu_baseline(cfg_opts, size, seconds_budget=90.0, threads=None, parity_file=
 _CATEGORIES = [
     ("own_msda", r"^msda_"),
     ("own_fp32_wgrad_mfma", r"^(gemm_wgrad_f32|wgrad_tr_reduce)"),
-    ("own_fp32x3_gemm_conv", r"^(gemm_tn_f32|gemm_wgrad_f32x3|conv3x3_)"),
+    ("own_fp32x3_gemm_conv", r"^(gemm_tn_f32|gemm_tn_f16x2|row_amax_f32|gemm_wgrad_f32x3|conv3x3_)"),
     ("own_conv_bf16_filter_grads", r"^conv_(wgrad|igemm)"),
     ("own_attention_mfma", r"^(attn_|wattn_)"),
     ("own_skinny_bf16_gemm", r"^sgemm_"),
@@ -216,7 +216,8 @@ def category_rooflines(cats, batch, size, freeze):
     hw4 = batch * (size // 4) ** 2
     enc_w = 0 if "encoder" in freeze else 1                 # frozen encoder: no weight gradients (and the backbone's none either)
     from partdistillation_amd.functions import gemm as gemm_fn
-    wg = (6.0, 2500.0, "bf16 matrix 2.5 PF, 6 bf16 products per fp32 product (gemm_wgrad_f32x3_tr)") if gemm_fn.WGRAD_X3 else \
+    np_w, np_f = products_per_fp32_product()
+    wg = (np_w, 2500.0, f"16-bit matrix 2.5 PF, {np_w:.0f} 16-bit products per fp32 product (gemm_wgrad_f32x3_tr)") if gemm_fn.WGRAD_X3 else \
          (1.0, MFMA_FP32_PEAK_TFLOPS, "fp32 matrix 157.3 TF")
     work = {
         # fp32 weight gradients of the 6 encoder layers: value/out 256x256, offsets+weights 288x256, FFN 2 x 1024x256
@@ -225,10 +226,10 @@ def category_rooflines(cats, batch, size, freeze):
         "own_fp32_wgrad_mfma": (wg[0] * 2.0 * (6 * M * (2 * 256 * 256 + 288 * 256 + 2 * 1024 * 256) * enc_w
                                          + (hw4 * (9 + 2) * 256 * 256 + sum(batch * (size // st) ** 2 * c * 256 for st, c in ((32, 2048), (16, 1024), (8, 512)))) * enc_w
                                          + hw4 * 40 * 256), wg[1], wg[2]),
-        # encoder FFN forward + input gradient, 3x3 FPN conv forward + input gradient: 6 bf16 MFMA products per fp32 product
-        "own_fp32x3_gemm_conv": (6.0 * (6 * 2 * 2.0 * M * 2 * 256 * 1024 / 2 + 2 * 2.0 * hw4 * 9 * 256 * 256), 2500.0, "bf16 matrix 2.5 PF, 6 bf16 products per fp32 product"),
-        # 256-wide projections of the encoder, forward + input gradient
-        "library_gemm_fp32": (6 * 2 * 2.0 * M * (2 * 256 * 256 + 288 * 256), MFMA_FP32_PEAK_TFLOPS, "fp32 matrix 157.3 TF"),
+        # encoder FFN + 256-wide projections forward + input gradient, 3x3 FPN conv forward + input gradient: np_f 16-bit MFMA products
+        # per fp32 product (3 in the fp16 two-plane form, 6 in the bf16 three-plane form)
+        "own_fp32x3_gemm_conv": (np_f * (6 * 2 * 2.0 * M * (2 * 256 * 1024 + 2 * 256 * 256 + 288 * 256) + 2 * 2.0 * hw4 * 9 * 256 * 256), 2500.0,
+                                 f"16-bit matrix 2.5 PF, {np_f:.0f} 16-bit products per fp32 product"),
     }
     for c in cats:
         w = work.get(c["category"])
@@ -236,6 +237,13 @@ def category_rooflines(cats, batch, size, freeze):
             tf = w[0] / (c["ms_per_step"] * 1e-3) / 1e12
             c.update({"alg_gflop_per_step": w[0] / 1e9, "achieved_TFLOPs": tf, "peak_TFLOPs": w[1], "frac": tf / w[1], "peak_note": w[2]})
     return cats
+
+
+def products_per_fp32_product():
+    """-> (weight-gradient kernels, forward / input-gradient kernels): 16-bit MFMA products the fp32 pixel-decoder kernels issue per
+    fp32 product — 3 in the fp16 two-plane form (csrc/gemm_f16x2.hip), 6 in the bf16 three-plane form (csrc/gemm_x3.hip)"""
+    from partdistillation_amd.functions import encoder_core as ec
+    return (3.0 if (ec.H2 and ec.H2_WGRAD) else 6.0), (3.0 if ec.H2 else 6.0)
 
 
 def roofline_of(dom, kernels):
@@ -419,13 +427,15 @@ def main():
         if wgrad:                               # fp32 weight-gradient GEMMs of the encoder (30 launches / step, 5 shapes)
             t_ms, fl = sum(t for t, _ in wgrad), sum(f for _, f in wgrad)
             from partdistillation_amd.functions import gemm as gemm_fn
-            if gemm_fn.WGRAD_X3:                # each fp32 product = 6 bf16 MFMA products: the work the matrix pipe actually does
-                kernels.append({"kernel": "gemm_wgrad_f32x3_tr (+ wgrad_tr_reduce)", "launches": len(wgrad), "avg_ms": t_ms / len(wgrad),
-                                "alg_flops": 6 * fl / len(wgrad), "achieved_TFLOPs": 6 * fl / t_ms / 1e9, "peak_TFLOPs": 2500.0,
+            if gemm_fn.WGRAD_X3:                # each fp32 product = npw 16-bit MFMA products: the work the matrix pipe actually does
+                npw = products_per_fp32_product()[0]
+                kernels.append({"kernel": "gemm_wgrad_f32x3_tr_grouped<f16x2> (+ wgrad_tr_reduce_grouped)" if npw == 3 else "gemm_wgrad_f32x3_tr (+ wgrad_tr_reduce)",
+                                "launches": len(wgrad), "avg_ms": t_ms / len(wgrad),
+                                "alg_flops": npw * fl / len(wgrad), "achieved_TFLOPs": npw * fl / t_ms / 1e9, "peak_TFLOPs": 2500.0,
                                 "fp32_equivalent_TFLOPs": fl / t_ms / 1e9,
                                 "fp32_equivalent_frac_of_fp32_matrix_peak": fl / t_ms / 1e9 / MFMA_FP32_PEAK_TFLOPS,
-                                "peak_source": "MI355X_MICROARCH.md: dense bf16 matrix (v_mfma_f32_32x32x16_bf16) 2.5 PFLOP/s; "
-                                               "alg_flops = 6 bf16 products per fp32 product x 2 M N K (avg_ms includes the partial-tile reduce launch)"})
+                                "peak_source": "MI355X_MICROARCH.md: dense 16-bit matrix (v_mfma_f32_32x32x16_f16 / _bf16) 2.5 PFLOP/s; "
+                                               f"alg_flops = {npw:.0f} 16-bit products per fp32 product x 2 M N K (avg_ms includes the partial-tile reduce launch)"})
             else:
                 kernels.append({"kernel": "gemm_wgrad_f32", "launches": len(wgrad), "avg_ms": t_ms / len(wgrad),
                                 "alg_flops": fl / len(wgrad), "achieved_TFLOPs": fl / t_ms / 1e9})
@@ -433,12 +443,13 @@ def main():
         for lab in labels:
             sel = [(t, f) for t, (f, l2) in x3fwd if l2 == lab]
             t_ms, fl = sum(t for t, _ in sel), sum(f for _, f in sel)
+            npf = 3.0 if "f16x2" in lab else 6.0
             kernels.append({"kernel": lab, "launches": len(sel), "avg_ms": t_ms / len(sel),
-                            "alg_flops": 6 * fl / len(sel), "achieved_TFLOPs": 6 * fl / t_ms / 1e9, "peak_TFLOPs": 2500.0,
+                            "alg_flops": npf * fl / len(sel), "achieved_TFLOPs": npf * fl / t_ms / 1e9, "peak_TFLOPs": 2500.0,
                             "fp32_equivalent_TFLOPs": fl / t_ms / 1e9,
                             "fp32_equivalent_frac_of_fp32_matrix_peak": fl / t_ms / 1e9 / MFMA_FP32_PEAK_TFLOPS,
-                            "peak_source": "MI355X_MICROARCH.md: dense bf16 matrix (v_mfma_f32_32x32x16_bf16) 2.5 PFLOP/s; "
-                                           "alg_flops = 6 bf16 products per fp32 product x 2 M N K"})
+                            "peak_source": "MI355X_MICROARCH.md: dense 16-bit matrix (v_mfma_f32_32x32x16_f16 / _bf16) 2.5 PFLOP/s; "
+                                           f"alg_flops = {npf:.0f} 16-bit products per fp32 product x 2 M N K"})
         pmc = {}
         try:                                   # HBM bytes per launch from the committed PMC passes (tools/pmc_msda.sh)
             pj = json.load(open(os.path.join(ROOT, "profiles", "r02_msda_pmc.json")))

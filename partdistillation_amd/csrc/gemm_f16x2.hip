@@ -40,7 +40,7 @@ __device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0
 // convolution, K = 9 Ci ordered (tap, channel) like the channels-last filter [Co][3][3][Ci]: a 16-wide step lies inside one tap and
 // its A tile is the input at pixel m + dy W + dx (zeros outside the image) — an implicit GEMM (gemm_x3.hip's CONV form).  The scale
 // of output row m then has to cover the nine input pixels it reads: the largest of their maxima.
-template <int TM, int TN, int WN, int BKK, int MODE, bool CONV = false>
+template <int TM, int TN, int WN, int BKK, int MODE, bool CONV = false, int NRS = 1>
 __global__ __launch_bounds__((TM / 64) * (TN / WN) * 64, (TM == 256 ? 1 : 2))
 void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ bias, float *__restrict__ C,
                    int M, int N, int K, int lda, int ldb, int ldc, int ntiles_n, uint32_t *__restrict__ bits,
@@ -85,7 +85,7 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
   for (int j = 0; j < APASS; ++j) sa[j] = sc[lr + RPP * j];
 #pragma unroll
   for (int j = 0; j < BPASS; ++j) sb[j] = sc[TM + lr + RPP * j];
-  float4 ra[APASS], rb[BPASS];
+  float4 ra[NRS][APASS], rb[NRS][BPASS];                           // NRS register stages: global loads run NRS steps ahead of their split
   int py[APASS], px[APASS];                                        // CONV: image row / column of this thread's A rows
   if (CONV) {
 #pragma unroll
@@ -95,7 +95,7 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
       px[j] = pix - py[j] * W;
     }
   }
-  auto gload = [&](int k0) {
+  auto gload = [&](int rs, int k0) {
     const int k = k0 + lk;
     int dy = 0, dx = 0, kc = k;
     if (CONV) { const int tap = k / lda; kc = k - tap * lda; dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
@@ -105,27 +105,27 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
       if (CONV) {
         const int yy = py[j] + dy, xx = px[j] + dx;
         const bool ok = m0 + r < M && k < K && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        ra[j] = ok ? *reinterpret_cast<const float4 *>(A + ((int64_t)(m0 + r) + dy * W + dx) * lda + kc) : make_float4(0, 0, 0, 0);
+        ra[rs][j] = ok ? *reinterpret_cast<const float4 *>(A + ((int64_t)(m0 + r) + dy * W + dx) * lda + kc) : make_float4(0, 0, 0, 0);
       } else {
-        ra[j] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4 *>(A + (int64_t)(m0 + r) * lda + k) : make_float4(0, 0, 0, 0);
+        ra[rs][j] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4 *>(A + (int64_t)(m0 + r) * lda + k) : make_float4(0, 0, 0, 0);
       }
     }
 #pragma unroll
     for (int j = 0; j < BPASS; ++j) {
       const int r = lr + RPP * j;
-      rb[j] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4 *>(B + (int64_t)(n0 + r) * ldb + k) : make_float4(0, 0, 0, 0);
+      rb[rs][j] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4 *>(B + (int64_t)(n0 + r) * ldb + k) : make_float4(0, 0, 0, 0);
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int rs, int buf) {
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
-      const SplitH x = split4h(ra[j], sa[j]);
+      const SplitH x = split4h(ra[rs][j], sa[j]);
       h16_t *p = As(buf, 0, lk >> 3, lr + RPP * j) + (lk & 7);
       *reinterpret_cast<uint2 *>(p) = x.hi; *reinterpret_cast<uint2 *>(p + NPAN * TM * 8) = x.lo;
     }
 #pragma unroll
     for (int j = 0; j < BPASS; ++j) {
-      const SplitH x = split4h(rb[j], sb[j]);
+      const SplitH x = split4h(rb[rs][j], sb[j]);
       h16_t *p = Bs(buf, 0, lk >> 3, lr + RPP * j) + (lk & 7);
       *reinterpret_cast<uint2 *>(p) = x.hi; *reinterpret_cast<uint2 *>(p + NPAN * TN * 8) = x.lo;
     }
@@ -138,17 +138,19 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   const int KT = (K + BKK - 1) / BKK;
-  gload(0);
-  lstore(0);
-  if (KT > 1) gload(BKK);
+  gload(0, 0);
+  lstore(0, 0);
+  if (KT > 1) gload(NRS == 2 ? 1 : 0, BKK);
+  if (NRS == 2 && KT > 2) gload(0, 2 * BKK);
   __syncthreads();
   const int fr = lane & 31, fh = lane >> 5;
   auto step = [&](int kt, int par) {
     // register-staging order of the 3-plane kernel: tile kt + 1 is split and written right after the barrier, the loads of tile
     // kt + 2 re-issued into the same registers, then the wave turns to tile kt's fragments
     if (kt + 1 < KT) {
-      lstore(par ^ 1);
-      if (kt + 2 < KT) gload((kt + 2) * BKK);
+      const int rs = NRS == 2 ? (par ^ 1) : 0;                     // tile kt + 1 sits in register stage (kt + 1) & 1
+      lstore(rs, par ^ 1);
+      if (kt + 1 + NRS < KT) gload(rs, (kt + 1 + NRS) * BKK);
     }
 #pragma unroll
     for (int ks = 0; ks < BKK / 16; ++ks) {
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256) void row_amax_f32(const float *__restrict__ X,
 
 int g_pd_dbg_f16x2 = 0;   // tools/ only (pd_debug_set "f16x2_tile"): 1 force 256x256x32, 2 force 128x128x32, 3 force 256x256x16, 4 force 128x128x16 (0: by shape, 16-deep)
 
-template <int TM, int TN, int WN, int BKK, bool CONV = false>
+template <int TM, int TN, int WN, int BKK, bool CONV = false, int NRS = 1>
 static int launch_f16x2(const float *A, const float *B, const float *bias, float *C, int M, int N, int K, int lda, int ldb, int ldc, int mode,
                         uint32_t *bits, float *colsum, const float *a_amax, const float *b_amax, float *c_amax, hipStream_t st, int H = 0,
                         int W = 0)
@@ -283,8 +285,9 @@ static int launch_f16x2(const float *A, const float *B, const float *bias, float
   const int tn = (N + TN - 1) / TN, tm = (M + TM - 1) / TM;
   typedef void (*kfn)(const float *, const float *, const float *, float *, int, int, int, int, int, int, int, uint32_t *, float *, const float *,
                       const float *, unsigned *, int, int);
-  const kfn k = CONV ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 0, CONV>
-                     : mode == 0 ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 0> : mode == 1 ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 1> : (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 2>;
+  const kfn k = CONV ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 0, CONV, NRS>
+                     : mode == 0 ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 0, false, NRS> : mode == 1 ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 1, false, NRS>
+                                                                                                  : (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 2, false, NRS>;
   static bool attr[3] = {false, false, false};
   if (!attr[mode]) { (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[mode] = true; }
   hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)tm * tn)), dim3(NTH), lds, st, A, B, bias, C, M, N, K, lda, ldb, ldc, tn, bits, colsum, a_amax,
@@ -311,17 +314,23 @@ extern "C" int pd_gemm_tn_f16x2(const float *A, const float *B, const float *bia
   const bool need_wide = bits != nullptr;
   if (need_wide && ((N % 256) || M < 1024)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: sign bits need N %% 256 == 0 and M >= 1024");
   const bool wide_ok = (N % 256) == 0 && M >= 1024;
-  const bool wide = need_wide || g_pd_dbg_f16x2 == 1 || g_pd_dbg_f16x2 == 3 ||
+  const bool wide = need_wide || g_pd_dbg_f16x2 == 1 || g_pd_dbg_f16x2 == 3 || g_pd_dbg_f16x2 == 13 || g_pd_dbg_f16x2 == 5 || g_pd_dbg_f16x2 == 15 ||
                     (g_pd_dbg_f16x2 == 0 && wide_ok && (int64_t)((M + 255) / 256) * (N / 256) >= 128 && (N >= 1024 || K >= 512));
 #define GO(TM, TN, WN, BKK) return launch_f16x2<TM, TN, WN, BKK>(A, B, bias, C, M, N, K, lda, ldb, ldc, mode, bits, colsum, a_amax, b_amax, c_amax, st)
   // 16-deep steps beat 32-deep ones on every encoder shape (tools/bench_gemm_h2.py, M = 43 008: 1024 <- 256 96.8 vs 103.7 us,
   // 256 <- 1024 85.4 vs 90.9, 256 <- 256 29.3 vs 32.9): half the LDS per workgroup, more workgroups in flight
   if (wide) {
     if (!wide_ok) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: 256 x 256 tiles need N %% 256 == 0 and M >= 1024");
+    if (g_pd_dbg_f16x2 == 5) GO(128, 256, 128, 16);
+    if (g_pd_dbg_f16x2 == 15) return launch_f16x2<128, 256, 128, 16, false, 2>(A, B, bias, C, M, N, K, lda, ldb, ldc, mode, bits, colsum, a_amax, b_amax, c_amax, st);
     if (g_pd_dbg_f16x2 == 1) GO(256, 256, 128, 32);
-    GO(256, 256, 128, 16);
+    // two register stages (loads two steps ahead of their split): 97.0 vs 99.9 us on 1024 <- 256, 85.3 vs 87.9 on 256 <- 1024; the
+    // 128 x 128 kernel does not gain (its three workgroups per CU already interleave); 128 x 256 tiles with two workgroups per CU: no gain
+    if (g_pd_dbg_f16x2 == 3) GO(256, 256, 128, 16);
+    return launch_f16x2<256, 256, 128, 16, false, 2>(A, B, bias, C, M, N, K, lda, ldb, ldc, mode, bits, colsum, a_amax, b_amax, c_amax, st);
   }
   if (g_pd_dbg_f16x2 == 2) GO(128, 128, 64, 32);
+  if (g_pd_dbg_f16x2 == 14) return launch_f16x2<128, 128, 64, 16, false, 2>(A, B, bias, C, M, N, K, lda, ldb, ldc, mode, bits, colsum, a_amax, b_amax, c_amax, st);
   GO(128, 128, 64, 16);
 #undef GO
 }

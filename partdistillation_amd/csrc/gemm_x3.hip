@@ -57,6 +57,7 @@ __device__ __forceinline__ void mma16k(f32x16 &c, hwbf16x8 x, hwbf16x8 y) { c = 
 
 __device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
 
+__device__ int g_wgrad_xcd = 1;   // tools only (pd_debug_set "wgrad_xcd" 0: launch order = logical order)
 __device__ __forceinline__ bool v_never(float x) { return x == 1.2345678e30f; }
 
 // CONV: A is an NHWC image [*, H, W, Ci] and row m of the GEMM is output pixel m of a 3 x 3, stride 1, pad 1 convolution:
@@ -702,7 +703,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3_tr(const float *__res
                                                                int m_chunk, int H, int W, const float *__restrict__ y_amax,
                                                                const float *__restrict__ x_amax)
 {
-  wgrad_tr_body<ABL, CONV, H2>(dY, X, dW, dB, ws, M, N, K, ldy, ldx, ldw, tiles_k, tiles, m_chunk, H, W, (int)blockIdx.x, 0, y_amax, x_amax);
+  // XCD-aware order (block i runs on XCD i % 8): the output tiles of one slab of rows are consecutive LOGICAL blocks, i.e. land on
+  // the same XCD at about the same time and share the slab's dY / X columns in its L2 instead of fetching them into all eight
+  const int lb = g_wgrad_xcd ? xcd_chunk((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  wgrad_tr_body<ABL, CONV, H2>(dY, X, dW, dB, ws, M, N, K, ldy, ldx, ldw, tiles_k, tiles, m_chunk, H, W, lb, 0, y_amax, x_amax);
 }
 
 // Several weight gradients in ONE launch (pd_gemm_wgrad_f32x3_grouped): a table of problems in device memory, workgroup b belongs
@@ -721,11 +725,12 @@ struct WgradX3Problem {
 template <bool H2>
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3_tr_grouped(const WgradX3Problem *__restrict__ tab, int count, float *__restrict__ ws)
 {
+  const int lb = g_wgrad_xcd ? xcd_chunk((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;     // see gemm_wgrad_f32x3_tr
   int p = 0;
-  while (p + 1 < count && (int)blockIdx.x >= tab[p + 1].block0) ++p;      // <= a few dozen problems: a scalar scan
+  while (p + 1 < count && lb >= tab[p + 1].block0) ++p;                   // <= a few dozen problems: a scalar scan
   const WgradX3Problem q = tab[p];
   wgrad_tr_body<0, false, H2>(q.dY, q.X, q.dW, q.dB, ws, q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, q.tiles_k, q.tiles, q.m_chunk, 0, 0,
-                              (int)blockIdx.x - q.block0, q.ws_tile0, q.y_amax, q.x_amax);
+                              lb - q.block0, q.ws_tile0, q.y_amax, q.x_amax);
 }
 
 // grouped form of wgrad_tr_reduce: blockIdx.x = 64 x (global output tile index); the problem is found from its first tile
@@ -786,6 +791,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_reduce(const float *__restrict__
 }
 }  // namespace
 
+extern "C" void pd_dbg_set_wgrad_xcd(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_xcd), &v, sizeof(int)); }
 static uint32_t *const g_relu_bits = nullptr;   // plain pd_gemm_tn_f32x3 launches do not record the sign bits
 int g_pd_dbg_x3_narrow = 0;   // tools/ only (pd_debug_set "x3_narrow"): 1 = never use the 256 x 256 kernel
 int g_pd_dbg_x3 = 0;   // tools/ only (pd_debug_set "x3_ablate"): 1 no MFMA, 2 only hi*hi, 3 no operand split, 4 no output stores

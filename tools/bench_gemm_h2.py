@@ -11,7 +11,7 @@ def t(f, n=30):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 torch.manual_seed(0)
 for M, N, K in [(43008, 1024, 256), (43008, 256, 1024), (43008, 256, 256), (43008, 288, 256), (43008, 512, 256), (5000, 256, 1000)]:
-    for scale_a in (1.0, 3e-6):
+    for scale_a in (1.0,):
         a = torch.randn(M, K, device="cuda") * scale_a * (1 + 10 * torch.rand(M, 1, device="cuda")); w = torch.randn(N, K, device="cuda") * K ** -0.5; b = torch.randn(N, device="cuda") * scale_a
         ref = torch.addmm(b.double(), a.double(), w.double().t()); scale = ref.abs().max().item()
         aa, wa = gemm.row_amax(a), gemm.row_amax(w)
@@ -19,8 +19,8 @@ for M, N, K in [(43008, 1024, 256), (43008, 256, 1024), (43008, 256, 256), (4300
         err = lambda y: ((y.double() - ref).abs().max().item() / scale)
         y_lib = torch.addmm(b, a, w.t()); y_x3 = gemm.gemm_tn_x3(a, w, b)
         res = []
-        for tile in (0, 1, 3, 2, 4):
-            if tile in (1, 3) and (N % 256 or M < 1024): continue
+        for tile in (3, 13, 5, 15, 4):
+            if tile in (1, 3, 13, 5, 15) and (N % 256 or M < 1024): continue
             L.pd_debug_set(b"f16x2_tile", tile)
             y = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
             cm = torch.zeros(M, device="cuda"); y2 = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa, c_amax=cm)
