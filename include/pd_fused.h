@@ -55,6 +55,12 @@ int pd_multi_gather_sumsq(const int64_t *src_ptrs, const int32_t *src_is_bf16, c
 int pd_nc_sums_f32(const float *x, const float *dy, const float *y, const float *a, const float *b, double *out, int N, int P,
                    int C, int mode, int relu, void *stream);
 int pd_nc_affine_f32(const float *x, const float *a, const float *b, float *y, int N, int P, int C, int relu, void *stream);
+/* pd_nc_affine_f32 / pd_nc_affine2_f32 that also write the absolute maximum over the channels of every output pixel, amax[N * P]
+ * (C == 256 only: one wavefront = one pixel) — the row-scaling input of pd_gemm_tn_f16x2 / pd_conv3x3_nhwc_f16x2 (pd_gemm.h) for the
+ * convolution that consumes the map, produced where the pixel is in registers anyway. */
+int pd_nc_affine_amax_f32(const float *x, const float *a, const float *b, float *y, float *amax, int N, int P, int C, int relu, void *stream);
+int pd_nc_affine2_amax_f32(const float *dy, const float *x, const float *y, const float *a, const float *p, const float *r, float *dx,
+                           float *amax, int N, int P, int C, int relu, void *stream);
 int pd_nc_affine2_f32(const float *dy, const float *x, const float *y, const float *a, const float *p, const float *r, float *dx,
                       int N, int P, int C, int relu, void *stream);
 

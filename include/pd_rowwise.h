@@ -128,6 +128,8 @@ int pd_point_sample_planar_bwd_needs_zero(int C, int H, int W);
  *   pd_upsample2x_bwd_nhwc_f32   dlo = upsample^T(dy) for H = 2h, W = 2w, in gather form (no atomics); d(cur) = dy
  */
 int pd_upsample_add_nhwc_f32(const float *lo, const float *cur, float *y, int B, int h, int w, int H, int W, int C, void *stream);
+/* the same with amax[B * H * W] = absolute maximum over the channels of every output pixel (C == 256 only) */
+int pd_upsample_add_amax_nhwc_f32(const float *lo, const float *cur, float *y, float *amax, int B, int h, int w, int H, int W, int C, void *stream);
 int pd_upsample2x_bwd_nhwc_f32(const float *dy, float *dlo, int B, int h, int w, int C, void *stream);
 
 #ifdef __cplusplus

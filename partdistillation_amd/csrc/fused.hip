@@ -169,9 +169,19 @@ __global__ __launch_bounds__(256) void nc_sums(const float *__restrict__ x, cons
   }
 }
 
+// amax (nullable; C == 256 only: the 64 lanes of a wavefront then hold exactly one pixel): absolute maximum over the channels of every
+// output pixel — the row-scaling input of pd_gemm_tn_f16x2 / pd_conv3x3_nhwc_f16x2 for the convolution that reads this map
+__device__ __forceinline__ void pixel_amax_store(float4 v, float *__restrict__ amax, int64_t i)
+{
+  float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) amax[i >> 6] = m;
+}
+
 template <bool RELU>
 __global__ __launch_bounds__(256) void nc_affine(const float4 *__restrict__ x, const float *__restrict__ a, const float *__restrict__ b,
-                                                  float4 *__restrict__ y, int64_t n4, int P, int C)
+                                                  float4 *__restrict__ y, int64_t n4, int P, int C, float *__restrict__ amax)
 {
   const int cq = C >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x, per_img = (int64_t)P * cq;
@@ -182,13 +192,14 @@ __global__ __launch_bounds__(256) void nc_affine(const float4 *__restrict__ x, c
     v.x = v.x * av.x + bv.x; v.y = v.y * av.y + bv.y; v.z = v.z * av.z + bv.z; v.w = v.w * av.w + bv.w;
     if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     y[i] = v;
+    if (amax) pixel_amax_store(v, amax, i);
   }
 }
 
 template <bool RELU>
 __global__ __launch_bounds__(256) void nc_affine2(const float4 *__restrict__ dy, const float4 *__restrict__ x, const float4 *__restrict__ y,
                                                    const float *__restrict__ a, const float *__restrict__ pc, const float *__restrict__ rc,
-                                                   float4 *__restrict__ dx, int64_t n4, int P, int C)
+                                                   float4 *__restrict__ dx, int64_t n4, int P, int C, float *__restrict__ amax)
 {
   const int cq = C >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x, per_img = (int64_t)P * cq;
@@ -202,8 +213,10 @@ __global__ __launch_bounds__(256) void nc_affine2(const float4 *__restrict__ dy,
       const float4 yv = y[i];
       g.x = yv.x > 0 ? g.x : 0; g.y = yv.y > 0 ? g.y : 0; g.z = yv.z > 0 ? g.z : 0; g.w = yv.w > 0 ? g.w : 0;
     }
-    dx[i] = make_float4(g.x * av.x + xv.x * pv.x + rv.x, g.y * av.y + xv.y * pv.y + rv.y, g.z * av.z + xv.z * pv.z + rv.z,
-                        g.w * av.w + xv.w * pv.w + rv.w);
+    const float4 o = make_float4(g.x * av.x + xv.x * pv.x + rv.x, g.y * av.y + xv.y * pv.y + rv.y, g.z * av.z + xv.z * pv.z + rv.z,
+                                 g.w * av.w + xv.w * pv.w + rv.w);
+    dx[i] = o;
+    if (amax) pixel_amax_store(o, amax, i);
   }
 }
 
@@ -347,31 +360,55 @@ extern "C" int pd_nc_sums_f32(const float *x, const float *dy, const float *y, c
   return pd_check_launch("pd_nc_sums_f32");
 }
 
-extern "C" int pd_nc_affine_f32(const float *x, const float *a, const float *b, float *y, int N, int P, int C, int relu, void *stream_)
+static int nc_affine_launch(const float *x, const float *a, const float *b, float *y, int N, int P, int C, int relu, void *stream_, float *amax)
 {
   int rc = nc_check(N, P, C, "pd_nc_affine_f32");
+  if (amax && C != 256) return pd_set_error(PD_ERR_INVALID_ARG, "pd_nc_affine_amax_f32: pixel maxima need C == 256");
   if (rc) return rc;
   const int64_t n4 = (int64_t)N * P * C / 4;
   if (n4 == 0) return PD_OK;
   if (!x || !a || !b || !y) return pd_set_error(PD_ERR_INVALID_ARG, "pd_nc_affine_f32: null pointer");
   hipStream_t s = (hipStream_t)stream_;
-  if (relu) hipLaunchKernelGGL(nc_affine<true>, dim3(grid_for(n4)), dim3(256), 0, s, (const float4 *)x, a, b, (float4 *)y, n4, P, C);
-  else hipLaunchKernelGGL(nc_affine<false>, dim3(grid_for(n4)), dim3(256), 0, s, (const float4 *)x, a, b, (float4 *)y, n4, P, C);
+  if (relu) hipLaunchKernelGGL(nc_affine<true>, dim3(grid_for(n4)), dim3(256), 0, s, (const float4 *)x, a, b, (float4 *)y, n4, P, C, amax);
+  else hipLaunchKernelGGL(nc_affine<false>, dim3(grid_for(n4)), dim3(256), 0, s, (const float4 *)x, a, b, (float4 *)y, n4, P, C, amax);
   return pd_check_launch("pd_nc_affine_f32");
 }
 
-extern "C" int pd_nc_affine2_f32(const float *dy, const float *x, const float *y, const float *a, const float *p, const float *r,
-                                 float *dx, int N, int P, int C, int relu, void *stream_)
+extern "C" int pd_nc_affine_f32(const float *x, const float *a, const float *b, float *y, int N, int P, int C, int relu, void *stream_)
+{
+  return nc_affine_launch(x, a, b, y, N, P, C, relu, stream_, nullptr);
+}
+
+extern "C" int pd_nc_affine_amax_f32(const float *x, const float *a, const float *b, float *y, float *amax, int N, int P, int C, int relu, void *stream_)
+{
+  return nc_affine_launch(x, a, b, y, N, P, C, relu, stream_, amax);
+}
+
+static int nc_affine2_launch(const float *dy, const float *x, const float *y, const float *a, const float *p, const float *r,
+                             float *dx, int N, int P, int C, int relu, void *stream_, float *amax)
 {
   int rc = nc_check(N, P, C, "pd_nc_affine2_f32");
+  if (amax && C != 256) return pd_set_error(PD_ERR_INVALID_ARG, "pd_nc_affine2_amax_f32: pixel maxima need C == 256");
   if (rc) return rc;
   const int64_t n4 = (int64_t)N * P * C / 4;
   if (n4 == 0) return PD_OK;
   if (!dy || !x || !a || !p || !r || !dx || (relu && !y)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_nc_affine2_f32: null pointer");
   hipStream_t s = (hipStream_t)stream_;
-  if (relu) hipLaunchKernelGGL(nc_affine2<true>, dim3(grid_for(n4)), dim3(256), 0, s, (const float4 *)dy, (const float4 *)x, (const float4 *)y, a, p, r, (float4 *)dx, n4, P, C);
-  else hipLaunchKernelGGL(nc_affine2<false>, dim3(grid_for(n4)), dim3(256), 0, s, (const float4 *)dy, (const float4 *)x, (const float4 *)y, a, p, r, (float4 *)dx, n4, P, C);
+  if (relu) hipLaunchKernelGGL(nc_affine2<true>, dim3(grid_for(n4)), dim3(256), 0, s, (const float4 *)dy, (const float4 *)x, (const float4 *)y, a, p, r, (float4 *)dx, n4, P, C, amax);
+  else hipLaunchKernelGGL(nc_affine2<false>, dim3(grid_for(n4)), dim3(256), 0, s, (const float4 *)dy, (const float4 *)x, (const float4 *)y, a, p, r, (float4 *)dx, n4, P, C, amax);
   return pd_check_launch("pd_nc_affine2_f32");
+}
+
+extern "C" int pd_nc_affine2_f32(const float *dy, const float *x, const float *y, const float *a, const float *p, const float *r,
+                                 float *dx, int N, int P, int C, int relu, void *stream_)
+{
+  return nc_affine2_launch(dy, x, y, a, p, r, dx, N, P, C, relu, stream_, nullptr);
+}
+
+extern "C" int pd_nc_affine2_amax_f32(const float *dy, const float *x, const float *y, const float *a, const float *p, const float *r,
+                                      float *dx, float *amax, int N, int P, int C, int relu, void *stream_)
+{
+  return nc_affine2_launch(dy, x, y, a, p, r, dx, N, P, C, relu, stream_, amax);
 }
 
 extern "C" int pd_gn_coeffs_fwd(const double *sums, const float *weight, const float *bias, int N, int C, int G, int P, float eps,

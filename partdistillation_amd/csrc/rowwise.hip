@@ -622,7 +622,7 @@ __device__ __forceinline__ void up_src(int dst, float scale, int in_size, int &i
 
 __global__ __launch_bounds__(256) void upsample_add_nhwc(const float *__restrict__ lo, const float *__restrict__ cur,
                                                          float *__restrict__ y, int B, int h, int w, int H, int W, int C4,
-                                                         float sh, float sw)
+                                                         float sh, float sw, float *__restrict__ amax)
 {
   const int64_t total = (int64_t)B * H * W * C4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -644,6 +644,12 @@ __global__ __launch_bounds__(256) void upsample_add_nhwc(const float *__restrict
     o.z = u.z + (hy0 * (wx0 * a.z + wx1 * bq.z) + hy1 * (wx0 * cq.z + wx1 * d.z));
     o.w = u.w + (hy0 * (wx0 * a.w + wx1 * bq.w) + hy1 * (wx0 * cq.w + wx1 * d.w));
     reinterpret_cast<float4 *>(y)[i] = o;
+    if (amax) {                                                    // C4 == 64: a wavefront holds one output pixel
+      float m = amax4(o);
+#pragma unroll
+      for (int of = 32; of; of >>= 1) m = fmaxf(m, __shfl_xor(m, of, 64));
+      if ((threadIdx.x & 63) == 0) amax[i >> 6] = m;
+    }
   }
 }
 
@@ -915,17 +921,29 @@ extern "C" int pd_point_sample_nhwc_f32_bf16(const float *in, const float *coord
   return pd_check_launch("pd_point_sample_nhwc_f32_bf16");
 }
 
-extern "C" int pd_upsample_add_nhwc_f32(const float *lo, const float *cur, float *y, int B, int h, int w, int H, int W, int C,
-                                        void *stream_)
+static int upsample_add_launch(const float *lo, const float *cur, float *y, int B, int h, int w, int H, int W, int C, void *stream_, float *amax)
 {
+  if (amax && C != 256) return pd_set_error(PD_ERR_INVALID_ARG, "pd_upsample_add_amax_nhwc_f32: pixel maxima need C == 256");
   if (B < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_upsample_add_nhwc_f32: bad sizes");
   if (B == 0) return PD_OK;
   if (!lo || !cur || !y) return pd_set_error(PD_ERR_INVALID_ARG, "pd_upsample_add_nhwc_f32: null pointer");
   const int64_t total = (int64_t)B * H * W * (C / 4);
   const unsigned grid = (unsigned)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
   hipLaunchKernelGGL(upsample_add_nhwc, dim3(grid), dim3(256), 0, (hipStream_t)stream_, lo, cur, y, B, h, w, H, W, C / 4,
-                     (float)h / (float)H, (float)w / (float)W);
+                     (float)h / (float)H, (float)w / (float)W, amax);
   return pd_check_launch("pd_upsample_add_nhwc_f32");
+}
+
+extern "C" int pd_upsample_add_nhwc_f32(const float *lo, const float *cur, float *y, int B, int h, int w, int H, int W, int C,
+                                        void *stream_)
+{
+  return upsample_add_launch(lo, cur, y, B, h, w, H, W, C, stream_, nullptr);
+}
+
+extern "C" int pd_upsample_add_amax_nhwc_f32(const float *lo, const float *cur, float *y, float *amax, int B, int h, int w, int H, int W, int C,
+                                             void *stream_)
+{
+  return upsample_add_launch(lo, cur, y, B, h, w, H, W, C, stream_, amax);
 }
 
 extern "C" int pd_upsample2x_bwd_nhwc_f32(const float *dy, float *dlo, int B, int h, int w, int C, void *stream_)

@@ -5,6 +5,8 @@ import contextlib
 import ctypes
 import weakref
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -189,6 +191,15 @@ def _run(q):
         _lib.check(rc)
 
 
+GEMM_1X1_FWD = os.environ.get("PD_GEMM_1X1_FWD", "0") != "0"
+GEMM_1X1_DGRAD = os.environ.get("PD_GEMM_1X1_DGRAD", "1") != "0"
+
+
+def _is_plain_1x1(x, weight, stride, padding):
+    return (weight.shape[2] == 1 and weight.shape[3] == 1 and stride == 1 and padding == 0 and x.is_contiguous(memory_format=torch.channels_last)
+            and weight.is_contiguous())
+
+
 class Conv2dOwnWgrad(Function):
     """bias-free bf16 NHWC convolution whose FILTER gradient is pd_conv_bf16_wgrad (forward and input gradient: the library's).
     Measured on the 52 such convolutions of R50 at 2 x 1024^2 (tools/bench_r50_convs.py): filter gradients 1.55 ms against
@@ -198,6 +209,10 @@ class Conv2dOwnWgrad(Function):
     def forward(ctx, x, weight, stride, padding):
         ctx.save_for_backward(x, weight)
         ctx.stride, ctx.padding = stride, padding
+        if GEMM_1X1_FWD and _is_plain_1x1(x, weight, stride, padding):
+            B, ci, H, W = x.shape
+            y = torch.mm(x.permute(0, 2, 3, 1).reshape(-1, ci), weight.view(weight.shape[0], ci).t())
+            return y.view(B, H, W, weight.shape[0]).permute(0, 3, 1, 2)
         return torch.ops.aten.convolution(x, weight, None, [stride, stride], [padding, padding], [1, 1], False, [0, 0], 1)
 
     @staticmethod
@@ -207,7 +222,14 @@ class Conv2dOwnWgrad(Function):
         dz = _nhwc(dz)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dz, x, weight, None, [s, s], [p, p], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            if GEMM_1X1_DGRAD and _is_plain_1x1(x, weight, s, p):
+                # a 1 x 1, stride-1 convolution on NHWC rows is a plain GEMM: dX[M, Ci] = dZ[M, Co] W[Co, Ci].  The library's GEMM needs no
+                # zero-filled output (MIOpen's split-K input-gradient kernels do: a SubTensorOpWithScalar1d launch each)
+                B, ci, H, W = x.shape
+                dx = torch.mm(dz.permute(0, 2, 3, 1).reshape(-1, dz.shape[1]), weight.view(weight.shape[0], ci))
+                dx = dx.view(B, H, W, ci).permute(0, 3, 1, 2)
+            else:
+                dx = torch.ops.aten.convolution_backward(dz, x, weight, None, [s, s], [p, p], [1, 1], False, [0, 0], 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             # deferred only when AccumulateGrad will ADOPT the tensor we return: no existing .grad to add into, no tensor hooks on the
             # weight, a leaf parameter; anything else gets its gradient computed now

@@ -9,6 +9,7 @@ from .. import lib as _lib
 
 H2 = __import__("os").environ.get("PD_H2_CONV", "1") != "0"   # the fp16 two-plane form (pd_conv3x3_nhwc_f16x2 / pd_conv3x3_wgrad_nhwc_f16x2: three products per
                      # term instead of six, pixels scaled by powers of two from their channel maxima); False: the 3-plane bf16 kernels
+H2_1X1 = __import__("os").environ.get("PD_H2_1X1", "1") != "0"   # ... and the 1 x 1 convolutions (forward / input gradient / filter gradient as GEMMs on the NHWC rows)
 WGRAD_X3 = True      # False: MIOpen's fp32 weight gradient (1.53 ms at 2 x 256 x 256^2, the transposed-read split kernel: see DESIGN.md)
 
 
@@ -21,8 +22,10 @@ def supported(x, conv):
 
 def _pixel_amax(x):
     """absolute maximum over the channels of every pixel of a channels-last map -> [B*H*W] (the row maxima of its NHWC rows)"""
+    from . import amax_cache
     from .gemm import row_amax
-    return row_amax(x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]))
+    am = amax_cache.get(x)
+    return am if am is not None else row_amax(x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]))
 
 
 def _raw(x, wk, bias, co, x_amax=None):
@@ -96,31 +99,52 @@ def conv3x3(x, weight, bias=None):
 
 
 class Conv1x1OwnWgrad(Function):
-    """fp32 1 x 1 convolution on channels-last maps whose filter / bias gradient is the transpose-read split GEMM on the NHWC rows
-    (pd_gemm_wgrad_acc_f32x3_ws: dW = dY^T X, dB = column sums of dY in the same pass); forward and input gradient: the library's.
-    The pixel decoder's input projections, lateral and mask-feature convolutions (reference msdeformattn.py:200-257)."""
+    """fp32 1 x 1 convolution on channels-last maps = a GEMM on the NHWC rows.  H2 (default): forward, input gradient and filter /
+    bias gradient on the fp16 two-plane kernels (pd_gemm_tn_f16x2 / pd_gemm_wgrad_acc_f16x2_ws) with the pixels' channel maxima as
+    row scales (taken from functions/amax_cache when the producing kernel left them there).  Otherwise: library forward / input
+    gradient, 3-plane bf16 filter gradient.  The pixel decoder's input projections, lateral and mask-feature convolutions
+    (reference msdeformattn.py:200-257)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if H2 and H2_1X1 and x.is_contiguous(memory_format=torch.channels_last):
+            from .gemm import gemm_tn_h2, row_amax
+            B, ci, Hh, Ww = x.shape
+            co = weight.shape[0]
+            x_am = _pixel_amax(x)
+            w2 = weight.reshape(co, ci)
+            y = gemm_tn_h2(x.permute(0, 2, 3, 1).reshape(-1, ci), w2, bias, a_amax=x_am, b_amax=row_amax(w2))
+            ctx.save_for_backward(x, weight, x_am)
+            return y.view(B, Hh, Ww, co).permute(0, 3, 1, 2)
+        ctx.save_for_backward(x, weight, None)
         return torch.ops.aten.convolution(x, weight, bias, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
 
     @staticmethod
     def backward(ctx, dy):
-        from .gemm import gemm_wgrad_acc
-        x, weight = ctx.saved_tensors
+        from .gemm import gemm_tn_h2, gemm_wgrad_acc, row_amax
+        x, weight, x_am = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last)
         co, ci = weight.shape[0], weight.shape[1]
         dx = dw = db = None
+        rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])          # NHWC storage -> [pixels, channels] view
+        h2 = x_am is not None
+        dy_am = _pixel_amax(dy) if h2 else None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            if h2:
+                wt = weight.reshape(co, ci).t().contiguous()                       # [Ci, Co]: the B operand of dX = dY W
+                B, _, Hh, Ww = x.shape
+                dx = gemm_tn_h2(rows(dy), wt, None, a_amax=dy_am, b_amax=row_amax(wt)).view(B, Hh, Ww, ci).permute(0, 3, 1, 2)
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0]
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if want_w or want_b:
             buf = torch.zeros(co * ci + co, dtype=torch.float32, device=x.device)
             dw2, dbv = buf[:co * ci].view(co, ci), buf[co * ci:]
-            rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])          # NHWC storage -> [pixels, channels] view
-            gemm_wgrad_acc(rows(dy), rows(x), dw2, dbv if want_b else None, x3=True)
+            if h2:
+                gemm_wgrad_acc(rows(dy), rows(x), dw2, dbv if want_b else None, h2=True, y_amax=dy_am, x_amax=x_am)
+            else:
+                gemm_wgrad_acc(rows(dy), rows(x), dw2, dbv if want_b else None, x3=True)
             dw = dw2.view(co, ci, 1, 1).as_strided(weight.shape, weight.stride()) if want_w else None
             db = dbv if want_b else None
         return dx, dw, db

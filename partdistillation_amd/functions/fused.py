@@ -3,6 +3,8 @@ import numpy as np
 import torch
 from torch.autograd import Function
 
+from . import amax_cache
+
 from .. import lib as _lib
 
 
@@ -253,7 +255,13 @@ class GroupNormNHWC(Function):
                                         coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
                                         coef[4].data_ptr(), st))
         y = torch.empty_like(x, memory_format=torch.channels_last)
-        _lib.check(lib.pd_nc_affine_f32(x.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), y.data_ptr(), N, P, C, int(relu), st))
+        if C == 256:            # + the pixel maxima the fp16 two-plane convolutions that read y scale their rows with (functions/amax_cache.py)
+            am = torch.empty(N * P, dtype=torch.float32, device=x.device)
+            _lib.check(lib.pd_nc_affine_amax_f32(x.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), y.data_ptr(), am.data_ptr(), N, P, C, int(relu), st))
+            ctx.y_am = am
+        else:
+            _lib.check(lib.pd_nc_affine_f32(x.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), y.data_ptr(), N, P, C, int(relu), st))
+            ctx.y_am = None
         ctx.save_for_backward(x, y if relu else None, weight, coef)
         ctx.groups, ctx.relu = groups, relu
         return y
@@ -276,8 +284,14 @@ class GroupNormNHWC(Function):
         _lib.check(lib.pd_gn_coeffs_bwd(sums.data_ptr(), weight.data_ptr(), mean_c.data_ptr(), rstd_c.data_ptr(), N, C, G, P,
                                         a.data_ptr(), pc.data_ptr(), rc.data_ptr(), gw.data_ptr(), gb.data_ptr(), st))
         dx = torch.empty_like(x, memory_format=torch.channels_last)
-        _lib.check(lib.pd_nc_affine2_f32(gy.data_ptr(), x.data_ptr(), y.data_ptr() if y is not None else None, a.data_ptr(),
-                                         pc.data_ptr(), rc.data_ptr(), dx.data_ptr(), N, P, C, int(ctx.relu), st))
+        if C == 256:
+            am = torch.empty(N * P, dtype=torch.float32, device=x.device)
+            _lib.check(lib.pd_nc_affine2_amax_f32(gy.data_ptr(), x.data_ptr(), y.data_ptr() if y is not None else None, a.data_ptr(),
+                                                  pc.data_ptr(), rc.data_ptr(), dx.data_ptr(), am.data_ptr(), N, P, C, int(ctx.relu), st))
+            amax_cache.put(dx, am)
+        else:
+            _lib.check(lib.pd_nc_affine2_f32(gy.data_ptr(), x.data_ptr(), y.data_ptr() if y is not None else None, a.data_ptr(),
+                                             pc.data_ptr(), rc.data_ptr(), dx.data_ptr(), N, P, C, int(ctx.relu), st))
         return dx, gw, gb, None, None, None
 
 
@@ -290,4 +304,8 @@ def group_norm_nhwc_supported(x, groups):
 def group_norm_nhwc(x, weight, bias, groups=32, eps=1e-5, relu=False):
     if not group_norm_nhwc_supported(x, groups):
         raise RuntimeError("pd group norm: fp32 CUDA NCHW-shaped tensor with C = 4*2^k <= 256 required (no fallback here)")
-    return GroupNormNHWC.apply(_nhwc(x), weight, bias, groups, eps, relu)
+    y = GroupNormNHWC.apply(_nhwc(x), weight, bias, groups, eps, relu)
+    am = getattr(y.grad_fn, "y_am", None) if y.grad_fn is not None else None
+    if am is not None:
+        amax_cache.put(y, am)
+    return y

@@ -249,7 +249,13 @@ class UpsampleAdd(Function):
         lo_c = lo.contiguous(memory_format=torch.channels_last)
         cur_c = cur.contiguous(memory_format=torch.channels_last)
         y = torch.empty_like(cur_c, memory_format=torch.channels_last)
-        _lib.check(_lib.load().pd_upsample_add_nhwc_f32(lo_c.data_ptr(), cur_c.data_ptr(), y.data_ptr(), B, h, w, H, W, C, _stream()))
+        if C == 256:            # + the pixel maxima for the fp16 two-plane 3 x 3 convolution that reads y (functions/amax_cache.py)
+            am = torch.empty(B * H * W, dtype=torch.float32, device=y.device)
+            _lib.check(_lib.load().pd_upsample_add_amax_nhwc_f32(lo_c.data_ptr(), cur_c.data_ptr(), y.data_ptr(), am.data_ptr(), B, h, w, H, W, C, _stream()))
+            ctx.y_am = am
+        else:
+            _lib.check(_lib.load().pd_upsample_add_nhwc_f32(lo_c.data_ptr(), cur_c.data_ptr(), y.data_ptr(), B, h, w, H, W, C, _stream()))
+            ctx.y_am = None
         ctx.dims = (B, C, h, w)
         return y
 
@@ -268,4 +274,9 @@ def upsample_add_supported(lo, cur):
 
 
 def upsample_add(lo, cur):
-    return UpsampleAdd.apply(lo, cur)
+    y = UpsampleAdd.apply(lo, cur)
+    am = getattr(y.grad_fn, "y_am", None) if y.grad_fn is not None else None
+    if am is not None:
+        from . import amax_cache
+        amax_cache.put(y, am)
+    return y

@@ -67,6 +67,9 @@ SIGNATURES = {
     "pd_attn_bwd_d32": (_c_int, [_c_vp] * 11 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_vp]),
     "pd_nc_sums_f32": (_c_int, [_c_vp] * 6 + [_c_int] * 5 + [_c_vp]),
     "pd_nc_affine_f32": (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_vp]),
+    "pd_nc_affine_amax_f32": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),
+    "pd_nc_affine2_amax_f32": (_c_int, [_c_vp] * 8 + [_c_int] * 4 + [_c_vp]),
+    "pd_upsample_add_amax_nhwc_f32": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),
     "pd_nc_affine2_f32": (_c_int, [_c_vp] * 7 + [_c_int] * 4 + [_c_vp]),
     "pd_add_layernorm_fwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp,
                                       _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_vp]),
