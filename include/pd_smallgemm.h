@@ -29,6 +29,19 @@ int pd_sgemm_tn_bf16(const void *X, const void *W, const void *bias, void *Y, in
 int pd_sgemm_nn_bf16(const void *dY, const void *W, const void *relu_ref, void *dX, int M, int N, int K, int ldy, int ldw,
                      int ldx, int accumulate, void *stream);
 
+/* The two products above for a LONG contraction over few rows (the decoder FFN: K = 2048 in pd_sgemm_tn, N = 2048 in pd_sgemm_nn; 14
+ * output tiles that each walked the whole contraction as a chain of load latencies): the contraction is cut into 256-wide slices that
+ * run as separate workgroups with all their loads in flight, fp32 partial tiles go to `workspace` and the last workgroup of a tile
+ * to arrive sums them in slice order (deterministic) and applies the epilogue.  Contraction % 256 == 0 and >= 512.
+ *   workspace: >= pd_sgemm_split_workspace_floats(M, output columns, contraction) floats; tickets: pd_sgemm_split_tickets(M, output
+ *   columns) int32, ZERO before the first use (every launch leaves them zero); neither may be shared by launches that can overlap. */
+int64_t pd_sgemm_split_workspace_floats(int M, int out_cols, int contraction);
+int64_t pd_sgemm_split_tickets(int M, int out_cols);
+int pd_sgemm_tn_splitk_bf16(const void *X, const void *W, const void *bias, void *Y, float *workspace, int64_t workspace_floats, int *tickets,
+                            int M, int N, int K, int ldx, int ldw, int ldy, int relu, void *stream);
+int pd_sgemm_nn_splitn_bf16(const void *dY, const void *W, const void *relu_ref, void *dX, float *workspace, int64_t workspace_floats,
+                            int *tickets, int M, int N, int K, int ldy, int ldw, int ldx, int accumulate, void *stream);
+
 /* dW[N,K] = dY[M,N]^T . X[M,K];  dB[N] (fp32, nullable) = column sums of dY       nn.Linear weight / bias gradient.
  * Any M >= 0 (rows past M count as zeros); N % 4 == 0, K % 4 == 0. */
 int pd_sgemm_wgrad_bf16(const void *dY, const void *X, void *dW, float *dB, int M, int N, int K, int ldy, int ldx, int ldw,

@@ -143,6 +143,85 @@ __global__ __launch_bounds__(256) void sgemm_tn_k256(const bf16_t *__restrict__ 
   }
 }
 
+// Long contractions over few rows (the decoder FFN's second Linear: [200, 2048] -> 256, 14 output tiles): walked chunk by chunk in
+// ONE workgroup per tile they are a chain of global-load latencies on 14 of the 256 CUs (39 us).  Here the contraction is cut into
+// 256-wide slices (blockIdx.z), each exactly the all-loads-in-flight kernel above; a slice leaves its fp32 accumulators in a
+// workspace (accumulator order: element e of thread t at e * 256 + t) and the LAST workgroup of a tile to arrive (agent-scope
+// ticket, reset for the next launch) adds the slices up in slice order — deterministic — and runs the epilogue.
+// EPI 0: Y = sum + bias (ReLU); EPI 1 (the nn form below shares the reduction).
+__device__ __forceinline__ bool splitk_arrive(float *__restrict__ ws, int *__restrict__ tickets, int tile, int tiles, int slices, const f32x16 &acc)
+{
+  __shared__ int s_last;
+  float *mine = ws + ((int64_t)blockIdx.z * tiles + tile) * (32 * 128);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) mine[e * 256 + threadIdx.x] = acc[e];
+  __threadfence();                                                          // this thread's partials visible device-wide ...
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(tickets + tile, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == slices - 1;
+  __syncthreads();
+  if (!s_last) return false;
+  __threadfence();                                                          // ... before the last arrival reads the others'
+  if (threadIdx.x == 0) tickets[tile] = 0;
+  return true;
+}
+__device__ __forceinline__ void splitk_sum(const float *__restrict__ ws, int tile, int tiles, int slices, f32x16 &acc)
+{
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int sl = 0; sl < slices; ++sl) {
+    const float *o = ws + ((int64_t)sl * tiles + tile) * (32 * 128);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += __hip_atomic_load(o + e * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void sgemm_tn_splitk(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
+                                                       const bf16_t *__restrict__ bias, bf16_t *__restrict__ Y, float *__restrict__ ws,
+                                                       int *__restrict__ tickets, int M, int N, int K, int ldx, int ldw, int ldy)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char sg_smem[];
+  bf16_t(*Xs)[PK256] = reinterpret_cast<bf16_t(*)[PK256]>(sg_smem);                       // [32][PK256]
+  bf16_t(*Ws)[PK256] = reinterpret_cast<bf16_t(*)[PK256]>(sg_smem + 32 * PK256 * sizeof(bf16_t));   // [128][PK256]
+  const int nb = blockIdx.x * 128, mb = blockIdx.y * 32, k0 = blockIdx.z * 256;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int prow = tid >> 5, pcol = (tid & 31) * 8;
+  uint4 xr[4], wr[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xr[i] = load_piece(X, ldx, mb + prow + 8 * i, k0 + pcol, M, K);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wr[i] = load_piece(W, ldw, nb + prow + 8 * i, k0 + pcol, N, K);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) store_piece(&Xs[prow + 8 * i][pcol], xr[i]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) store_piece(&Ws[prow + 8 * i][pcol], wr[i]);
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int s = 0; s < 32; ++s) mma(acc, lds4(&Ws[32 * wave + r][8 * s + 4 * hh]), lds4(&Xs[r][8 * s + 4 * hh]));
+  const int tiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x, slices = gridDim.z;
+  if (!splitk_arrive(ws, tickets, tile, tiles, slices, acc)) return;
+  splitk_sum(ws, tile, tiles, slices, acc);
+  const int m = mb + r;
+  if (m >= M) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n0 = nb + 32 * wave + 8 * g + 4 * hh;
+    if (n0 >= N) continue;
+    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    if (bias) {
+      const uint2 b = *reinterpret_cast<const uint2 *>(bias + n0);
+      v[0] += bf_lo(b.x); v[1] += bf_hi(b.x); v[2] += bf_lo(b.y); v[3] += bf_hi(b.y);
+    }
+    if (RELU) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    *reinterpret_cast<bf16x4 *>(Y + (int64_t)m * ldy + n0) = pack4(v[0], v[1], v[2], v[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ dX = dY W
 template <bool ACC, bool MASK>
 __global__ __launch_bounds__(256) void sgemm_nn(const bf16_t *__restrict__ dY, const bf16_t *__restrict__ W,
@@ -235,6 +314,60 @@ __global__ __launch_bounds__(256) void sgemm_nn_n256(const bf16_t *__restrict__ 
   const int steps = N / 8;
   for (int s = 0; s < steps; ++s)                                           // acc[k][m] += W^T[k][n..] . dY[m][n..]
     mma(acc, gather4(&Ws[8 * s + 4 * hh][32 * wave + r], P128), lds4(&Ys[r][8 * s + 4 * hh]));
+  const int m = mb + r;
+  if (m >= M) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int k0 = kb + 32 * wave + 8 * g + 4 * hh;
+    if (k0 >= K) continue;
+    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    bf16_t *dst = dX + (int64_t)m * ldx + k0;
+    if (ACC) {
+      const uint2 o = *reinterpret_cast<const uint2 *>(dst);
+      v[0] += bf_lo(o.x); v[1] += bf_hi(o.x); v[2] += bf_lo(o.y); v[3] += bf_hi(o.y);
+    }
+    if (MASK) {
+      const uint2 h = *reinterpret_cast<const uint2 *>(ref + (int64_t)m * ldx + k0);
+      if (!(bf_lo(h.x) > 0.f)) v[0] = 0.f;
+      if (!(bf_hi(h.x) > 0.f)) v[1] = 0.f;
+      if (!(bf_lo(h.y) > 0.f)) v[2] = 0.f;
+      if (!(bf_hi(h.y) > 0.f)) v[3] = 0.f;
+    }
+    *reinterpret_cast<bf16x4 *>(dst) = pack4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// dX = dY W with a long contraction (N = 2048: the decoder FFN's first Linear, input gradient) cut into 256-wide slices of N, one
+// all-loads-in-flight workgroup each; partial tiles and the last-arrival reduction as in sgemm_tn_splitk
+template <bool ACC, bool MASK>
+__global__ __launch_bounds__(256) void sgemm_nn_splitn(const bf16_t *__restrict__ dY, const bf16_t *__restrict__ W,
+                                                       const bf16_t *__restrict__ ref, bf16_t *__restrict__ dX, float *__restrict__ ws,
+                                                       int *__restrict__ tickets, int M, int N, int K, int ldy, int ldw, int ldx)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char sg_smem[];
+  bf16_t(*Ys)[PN256] = reinterpret_cast<bf16_t(*)[PN256]>(sg_smem);                       // [32][PN256]
+  bf16_t(*Ws)[P128] = reinterpret_cast<bf16_t(*)[P128]>(sg_smem + 32 * PN256 * sizeof(bf16_t));     // [256][P128]
+  const int kb = blockIdx.x * 128, mb = blockIdx.y * 32, n0s = blockIdx.z * 256;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int yrow = tid >> 5, ycol = (tid & 31) * 8;
+  const int wrow = tid >> 4, wcol = (tid & 15) * 8;
+  uint4 yr[4], wr[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) yr[i] = load_piece(dY, ldy, mb + yrow + 8 * i, n0s + ycol, M, N);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wr[i] = load_piece(W, ldw, n0s + wrow + 16 * i, kb + wcol, N, K);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) store_piece(&Ys[yrow + 8 * i][ycol], yr[i]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) store_piece(&Ws[wrow + 16 * i][wcol], wr[i]);
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int s = 0; s < 32; ++s) mma(acc, gather4(&Ws[8 * s + 4 * hh][32 * wave + r], P128), lds4(&Ys[r][8 * s + 4 * hh]));
+  const int tiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x, slices = gridDim.z;
+  if (!splitk_arrive(ws, tickets, tile, tiles, slices, acc)) return;
+  splitk_sum(ws, tile, tiles, slices, acc);
   const int m = mb + r;
   if (m >= M) return;
 #pragma unroll
@@ -487,6 +620,64 @@ extern "C" int pd_sgemm_tn_bf16(const void *X, const void *W, const void *bias, 
   if (relu) hipLaunchKernelGGL(sgemm_tn<true>, g, b, 0, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, M, N, K, ldx, ldw, ldy);
   else hipLaunchKernelGGL(sgemm_tn<false>, g, b, 0, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, M, N, K, ldx, ldw, ldy);
   return pd_check_launch("pd_sgemm_tn_bf16");
+}
+
+extern "C" int64_t pd_sgemm_split_workspace_floats(int M, int out_cols, int contraction)
+{
+  if (M <= 0 || out_cols <= 0 || contraction <= 0) return 0;
+  return (int64_t)((contraction + 255) / 256) * ((M + 31) / 32) * ((out_cols + 127) / 128) * (32 * 128);
+}
+extern "C" int64_t pd_sgemm_split_tickets(int M, int out_cols) { return (M <= 0 || out_cols <= 0) ? 0 : (int64_t)((M + 31) / 32) * ((out_cols + 127) / 128); }
+
+extern "C" int pd_sgemm_tn_splitk_bf16(const void *X, const void *W, const void *bias, void *Y, float *workspace, int64_t workspace_floats,
+                                       int *tickets, int M, int N, int K, int ldx, int ldw, int ldy, int relu, void *stream_)
+{
+  int rc = check_common("pd_sgemm_tn_splitk_bf16", X, W, Y, M, N, K, ldx, ldw, ldy);
+  if (rc) return rc;
+  if ((K % 256) || K < 512 || (N & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_tn_splitk_bf16: K=%d must be a multiple of 256, >= 512, and N=%d of 4", K, N);
+  if (bias && ((uintptr_t)bias & 7)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_tn_splitk_bf16: bias must be 8-byte aligned");
+  if (M == 0 || N == 0) return PD_OK;
+  if (!workspace || !tickets || workspace_floats < pd_sgemm_split_workspace_floats(M, N, K))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_tn_splitk_bf16: workspace / tickets missing or too small");
+  const dim3 g((N + 127) / 128, (M + 31) / 32, K / 256), b(256);
+  constexpr size_t lds = (size_t)(32 + 128) * PK256 * sizeof(bf16_t);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)sgemm_tn_splitk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)sgemm_tn_splitk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipStream_t s = (hipStream_t)stream_;
+  if (relu) hipLaunchKernelGGL(sgemm_tn_splitk<true>, g, b, lds, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, workspace, tickets, M, N, K, ldx, ldw, ldy);
+  else hipLaunchKernelGGL(sgemm_tn_splitk<false>, g, b, lds, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, workspace, tickets, M, N, K, ldx, ldw, ldy);
+  return pd_check_launch("pd_sgemm_tn_splitk_bf16");
+}
+
+extern "C" int pd_sgemm_nn_splitn_bf16(const void *dY, const void *W, const void *relu_ref, void *dX, float *workspace, int64_t workspace_floats,
+                                       int *tickets, int M, int N, int K, int ldy, int ldw, int ldx, int accumulate, void *stream_)
+{
+  int rc = check_common("pd_sgemm_nn_splitn_bf16", dY, W, dX, M, N, K, ldy, ldw, ldx);
+  if (rc) return rc;
+  if ((N % 256) || N < 512 || (K & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_nn_splitn_bf16: N=%d must be a multiple of 256, >= 512, and K=%d of 4", N, K);
+  if (M == 0 || K == 0) return PD_OK;
+  if (!workspace || !tickets || workspace_floats < pd_sgemm_split_workspace_floats(M, K, N))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_nn_splitn_bf16: workspace / tickets missing or too small");
+  const dim3 g((K + 127) / 128, (M + 31) / 32, N / 256), b(256);
+  constexpr size_t lds = (size_t)32 * PN256 * sizeof(bf16_t) + (size_t)256 * P128 * sizeof(bf16_t);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)sgemm_nn_splitn<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)sgemm_nn_splitn<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)sgemm_nn_splitn<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)sgemm_nn_splitn<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipStream_t s = (hipStream_t)stream_;
+#define LAUNCHS(A, R) hipLaunchKernelGGL((sgemm_nn_splitn<A, R>), g, b, lds, s, (const bf16_t *)dY, (const bf16_t *)W, (const bf16_t *)relu_ref, (bf16_t *)dX, workspace, tickets, M, N, K, ldy, ldw, ldx)
+  if (accumulate) { if (relu_ref) LAUNCHS(true, true); else LAUNCHS(true, false); }
+  else { if (relu_ref) LAUNCHS(false, true); else LAUNCHS(false, false); }
+#undef LAUNCHS
+  return pd_check_launch("pd_sgemm_nn_splitn_bf16");
 }
 
 extern "C" int pd_sgemm_nn_bf16(const void *dY, const void *W, const void *relu_ref, void *dX, int M, int N, int K, int ldy,

@@ -20,12 +20,32 @@ def supported(K_tn=None, N_nn=None):
     return (K_tn is None or K_tn % 64 == 0) and (N_nn is None or N_nn % 64 == 0)
 
 
+SPLIT = __import__("os").environ.get("PD_SGEMM_SPLIT", "1") != "0"   # long contractions (>= 512, % 256 == 0) over few rows as 256-wide slices
+_SPLIT_WS = {}
+
+
+def _split_ws(dev, floats, tickets):
+    """fp32 partial-tile workspace + zeroed ticket counters per device and stream (launches on one stream run in order)"""
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    e = _SPLIT_WS.get(key)
+    if e is None or e[0].numel() < floats or e[1].numel() < tickets:
+        e = _SPLIT_WS[key] = (torch.empty(max(floats, 1 << 20), dtype=torch.float32, device=dev),
+                              torch.zeros(max(tickets, 256), dtype=torch.int32, device=dev))
+    return e
+
+
 def linear(x, w, b=None, relu=False, out=None):
     """x [M,K] @ w[N,K].T (+ b) (ReLU) -> [M,N]   (bf16; K % 64 == 0)"""
     _chk2d(x, w)
     M, K = x.shape
     N = w.shape[0]
     y = out if out is not None else torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    if SPLIT and K >= 512 and K % 256 == 0 and M <= 1024:
+        L = _lib.load()
+        ws, tk = _split_ws(x.device, int(L.pd_sgemm_split_workspace_floats(M, N, K)), int(L.pd_sgemm_split_tickets(M, N)))
+        _lib.check(L.pd_sgemm_tn_splitk_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(), ws.data_ptr(),
+                                             ws.numel(), tk.data_ptr(), M, N, K, x.stride(0), w.stride(0), y.stride(0), int(relu), _stream()))
+        return y
     _lib.check(_lib.load().pd_sgemm_tn_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(),
                                             M, N, K, x.stride(0), w.stride(0), y.stride(0), int(relu), _stream()))
     return y
@@ -38,6 +58,13 @@ def dgrad(dy, w, relu_ref=None, out=None, accumulate=False):
     K = w.shape[1]
     dx = out if out is not None else torch.empty((M, K), dtype=torch.bfloat16, device=dy.device)
     assert relu_ref is None or (relu_ref.shape == dx.shape and relu_ref.stride() == dx.stride())
+    if SPLIT and N >= 512 and N % 256 == 0 and M <= 1024:
+        L = _lib.load()
+        ws, tk = _split_ws(dy.device, int(L.pd_sgemm_split_workspace_floats(M, K, N)), int(L.pd_sgemm_split_tickets(M, K)))
+        _lib.check(L.pd_sgemm_nn_splitn_bf16(dy.data_ptr(), w.data_ptr(), relu_ref.data_ptr() if relu_ref is not None else None, dx.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), tk.data_ptr(), M, N, K, dy.stride(0), w.stride(0), dx.stride(0),
+                                             int(accumulate), _stream()))
+        return dx
     _lib.check(_lib.load().pd_sgemm_nn_bf16(dy.data_ptr(), w.data_ptr(), relu_ref.data_ptr() if relu_ref is not None else None,
                                             dx.data_ptr(), M, N, K, dy.stride(0), w.stride(0), dx.stride(0), int(accumulate), _stream()))
     return dx

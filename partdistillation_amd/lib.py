@@ -84,6 +84,10 @@ SIGNATURES = {
     "pd_attn_mask_u8": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "pd_msda_prep_fwd": (_c_int, [_c_vp] * 6 + [ctypes.c_int64] + [_c_int] * 5 + [_c_vp]),
     "pd_msda_prep_bwd": (_c_int, [_c_vp] * 6 + [ctypes.c_int64] + [_c_int] * 5 + [_c_vp]),
+    "pd_sgemm_split_workspace_floats": (ctypes.c_int64, [_c_int] * 3),
+    "pd_sgemm_split_tickets": (ctypes.c_int64, [_c_int] * 2),
+    "pd_sgemm_tn_splitk_bf16": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_vp] + [_c_int] * 7 + [_c_vp]),
+    "pd_sgemm_nn_splitn_bf16": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_vp] + [_c_int] * 7 + [_c_vp]),
     "pd_sgemm_tn_bf16": (_c_int, [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
     "pd_sgemm_nn_bf16": (_c_int, [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
     "pd_sgemm_wgrad_bf16": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),

@@ -79,3 +79,28 @@ def test_wgrad_split_matches_torch(M, N, K):
     dw2, none = smallgemm.wgrad_split(dy, x, False)
     assert none is None and torch.equal(dw2, dw)                                   # deterministic: no atomics
 
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 256, 2048), (1000, 384, 512), (33, 72, 768)])
+def test_split_contraction_forms_repeat_and_match_the_single_workgroup_kernels(M, N, K, monkeypatch):
+    """pd_sgemm_tn_splitk_bf16 / pd_sgemm_nn_splitn_bf16 (contraction cut into 256-wide slices, last workgroup of a tile sums the fp32
+    partial tiles in slice order): equal to fp32 torch, bit-identical from call to call (the ticket counters return to zero, the sum order
+    is fixed) and close to the chunk-walking kernels they replace."""
+    from partdistillation_amd.functions import smallgemm as sg
+    x, w, b = _r((M, K), 11), _r((N, K), 12, K ** -0.5), _r((N,), 13)
+    ref = (x.float() @ w.float().t() + b.float()).relu()
+    ys = [sg.linear(x, w, b, True) for _ in range(3)]
+    torch.testing.assert_close(ys[0].float(), ref, rtol=1e-2, atol=1e-2)
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    dy, w2 = _r((M, K), 14), _r((K, N), 15, K ** -0.5)             # contraction over K (>= 512) here
+    h = _r((M, N), 16)
+    base = _r((M, N), 17)
+    outs = []
+    for _ in range(2):
+        o = base.clone()
+        sg.dgrad(dy, w2, relu_ref=h, out=o, accumulate=True)
+        outs.append(o)
+    torch.testing.assert_close(outs[0].float(), (dy.float() @ w2.float() + base.float()) * (h > 0), rtol=1e-2, atol=2e-2)
+    assert torch.equal(outs[0], outs[1])
+    monkeypatch.setattr(sg, "SPLIT", False)
+    torch.testing.assert_close(sg.linear(x, w, b, True).float(), ys[0].float(), rtol=1e-2, atol=1e-2)
