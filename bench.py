@@ -251,6 +251,15 @@ def roofline_of(dom, kernels):
     achieved = algorithmic bytes (or flops) per launch / average launch duration (HIP events on the launch stream)."""
     if dom is None:
         return None
+    if "bound" in dom:                                             # a GEMM entry with both floors: report the one that binds
+        mf = dom["bound"] == "mfma"
+        return {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved_TFLOPs"] if mf else dom["achieved_GBs"],
+                "peak": dom["peak_TFLOPs"] if mf else HBM_PEAK_GBS, "unit": "TFLOP/s" if mf else "GB/s",
+                "frac": dom["mfma_frac"] if mf else dom["hbm_frac"], "traffic": dom.get("traffic"),
+                "traffic_source": "profiles/r03_gemm_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 per MI355X_MICROARCH.md)",
+                "other_floor_frac": dom["hbm_frac"] if mf else dom["mfma_frac"],
+                "alg_flops_per_launch": dom["alg_flops"], "alg_bytes_per_launch": dom["alg_bytes"], "avg_launch_ms": dom["avg_ms"],
+                "launches_timed": dom["launches"], "peak_source": dom["peak_source"], "other_kernels": kernels}
     if "achieved_TFLOPs" in dom:
         peak = dom.get("peak_TFLOPs", MFMA_FP32_PEAK_TFLOPS)
         return {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_TFLOPs"], "peak": peak,
@@ -424,38 +433,40 @@ def main():
                             "variant_of_last_launch": {2: "halo 9, 16 channels per workgroup", 3: "halo 5, 32 channels per workgroup"}.get(int(gate[2]), "ungated"),
                             "halo5_window_miss_fraction": (gate[0] / gate[1]) if gate[1] else None,
                             "note": "offsets after the timed steps from reference initialisation; tools/msda_sweep.sh covers N(0, sigma) and a trained-model stand-in"})
-        if wgrad:                               # fp32 weight-gradient GEMMs of the encoder (30 launches / step, 5 shapes)
-            t_ms, fl = sum(t for t, _ in wgrad), sum(f for _, f in wgrad)
-            from partdistillation_amd.functions import gemm as gemm_fn
-            if gemm_fn.WGRAD_X3:                # each fp32 product = npw 16-bit MFMA products: the work the matrix pipe actually does
-                npw = products_per_fp32_product()[0]
-                kernels.append({"kernel": "gemm_wgrad_f32x3_tr_grouped<f16x2> (+ wgrad_tr_reduce_grouped)" if npw == 3 else "gemm_wgrad_f32x3_tr (+ wgrad_tr_reduce)",
-                                "launches": len(wgrad), "avg_ms": t_ms / len(wgrad),
-                                "alg_flops": npw * fl / len(wgrad), "achieved_TFLOPs": npw * fl / t_ms / 1e9, "peak_TFLOPs": 2500.0,
-                                "fp32_equivalent_TFLOPs": fl / t_ms / 1e9,
-                                "fp32_equivalent_frac_of_fp32_matrix_peak": fl / t_ms / 1e9 / MFMA_FP32_PEAK_TFLOPS,
-                                "peak_source": "MI355X_MICROARCH.md: dense 16-bit matrix (v_mfma_f32_32x32x16_f16 / _bf16) 2.5 PFLOP/s; "
-                                               f"alg_flops = {npw:.0f} 16-bit products per fp32 product x 2 M N K (avg_ms includes the partial-tile reduce launch)"})
-            else:
-                kernels.append({"kernel": "gemm_wgrad_f32", "launches": len(wgrad), "avg_ms": t_ms / len(wgrad),
-                                "alg_flops": fl / len(wgrad), "achieved_TFLOPs": fl / t_ms / 1e9})
-        labels = sorted({lab for _, (_, lab) in x3fwd})   # fp32 forward / input-gradient products on the bf16 matrix cores, per kernel
-        for lab in labels:
-            sel = [(t, f) for t, (f, l2) in x3fwd if l2 == lab]
-            t_ms, fl = sum(t for t, _ in sel), sum(f for _, f in sel)
-            npf = 3.0 if "f16x2" in lab else 6.0
-            kernels.append({"kernel": lab, "launches": len(sel), "avg_ms": t_ms / len(sel),
-                            "alg_flops": npf * fl / len(sel), "achieved_TFLOPs": npf * fl / t_ms / 1e9, "peak_TFLOPs": 2500.0,
-                            "fp32_equivalent_TFLOPs": fl / t_ms / 1e9,
-                            "fp32_equivalent_frac_of_fp32_matrix_peak": fl / t_ms / 1e9 / MFMA_FP32_PEAK_TFLOPS,
-                            "peak_source": "MI355X_MICROARCH.md: dense 16-bit matrix (v_mfma_f32_32x32x16_f16 / _bf16) 2.5 PFLOP/s; "
-                                           f"alg_flops = {npf:.0f} 16-bit products per fp32 product x 2 M N K"})
+        def gemm_entry(name, sel, nprod, note):
+            """roofline entry of one timed GEMM kernel + shape: both floors — nprod 16-bit products per fp32 product at the 2.5 PF matrix peak,
+            and operands + result once each at 8 TB/s — and the one that binds (the larger floor)"""
+            t_ms = sum(t for t, _ in sel)
+            fl, by = sum(f[0] for _, f in sel), sum(f[1] for _, f in sel)
+            n = len(sel)
+            mfma_floor_ms, hbm_floor_ms = nprod * fl / 2500.0e12 * 1e3, by / (HBM_PEAK_GBS * 1e9) * 1e3
+            e = {"kernel": name, "launches": n, "avg_ms": t_ms / n, "alg_flops": nprod * fl / n, "alg_bytes": by / n,
+                 "achieved_TFLOPs": nprod * fl / t_ms / 1e9, "peak_TFLOPs": 2500.0, "achieved_GBs": by / t_ms / 1e6,
+                 "mfma_frac": mfma_floor_ms / t_ms, "hbm_frac": hbm_floor_ms / t_ms, "bound": "mfma" if mfma_floor_ms >= hbm_floor_ms else "hbm",
+                 "fp32_equivalent_TFLOPs": fl / t_ms / 1e9,
+                 "peak_source": "MI355X_MICROARCH.md: dense 16-bit matrix (v_mfma_f32_32x32x16_f16 / _bf16) 2.5 PFLOP/s and HBM3E 8 TB/s; "
+                                f"alg_flops = {nprod:.0f} 16-bit products per fp32 product x 2 M N K, alg_bytes = operands + result once each; " + note}
+            return e
+        if wgrad:                               # fp32 weight-gradient GEMMs: the encoder's grouped launch and the single ones (convolutions, criterion)
+            for kind in sorted({f[2] for _, f in wgrad}):
+                sel = [(t, f) for t, f in wgrad if f[2] == kind]
+                nprod = 3.0 if kind.startswith("h2") else 6.0 if kind.startswith("x3") else 1.0
+                name = {"h2 grouped": "gemm_wgrad_f32x3_tr_grouped<f16x2> (+ wgrad_tr_reduce_grouped)", "h2": "gemm_wgrad_f32x3_tr<f16x2> (+ wgrad_tr_reduce)",
+                        "x3 grouped": "gemm_wgrad_f32x3_tr_grouped (+ wgrad_tr_reduce_grouped)", "x3": "gemm_wgrad_f32x3_tr (+ wgrad_tr_reduce)"}.get(kind, kind)
+                kernels.append(gemm_entry(name, sel, nprod, "avg_ms includes the partial-tile reduce launch"))
+        for lab in sorted({f[1] for _, f in x3fwd}):   # fp32 forward / input-gradient products on the 16-bit matrix cores, per kernel and shape
+            sel = [(t, f) for t, f in x3fwd if f[1] == lab]
+            kernels.append(gemm_entry(lab, [(t, (f[0], f[2])) for t, f in sel], 3.0 if "f16x2" in lab else 6.0, ""))
         pmc = {}
         try:                                   # HBM bytes per launch from the committed PMC passes (tools/pmc_msda.sh)
             pj = json.load(open(os.path.join(ROOT, "profiles", "r02_msda_pmc.json")))
             if pj["geometry"]["batch"] == a.batch and pj["geometry"]["image"] == a.size:
                 pmc = {k: v["hbm_bytes_corrected"] for k, v in pj["kernels"].items()}
         except Exception:                      # noqa: BLE001 - traffic stays null
+            pass
+        try:                                   # ... and of the GEMM kernels (tools/pmc_gemm.sh), keyed like the timed kernels
+            pmc.update({k: v["hbm_bytes_corrected_avg_per_launch"] for k, v in json.load(open(os.path.join(ROOT, "profiles", "r03_gemm_pmc.json"))).items()})
+        except Exception:                      # noqa: BLE001
             pass
         for kk in kernels:
             kk["traffic"] = pmc.get(kk["kernel"])

@@ -120,6 +120,11 @@ int pd_conv3x3_nhwc_f32x3(const float *X, const float *Wk, const float *bias, fl
  * of rows by powers of two from the largest of the slab's row maxima (y_amax / x_amax [M], nullable = O(1) operand) and undoes
  * them on its partial tile.  Same arguments otherwise as pd_gemm_wgrad_acc_f32x3_ws / pd_gemm_wgrad_f32x3_grouped /
  * pd_conv3x3_wgrad_nhwc_f32x3; N, K, ldy, ldx multiples of 4, 16-byte aligned operands. */
+/* workspace sizes of the two-plane weight gradients (they take 256 x 256 output tiles where the output has more than one 128-tile in
+ * both directions: half the operand re-reads of the 128 x 128 kernel, which runs at the memory system's limit on them) */
+int64_t pd_gemm_wgrad_f16x2_ws_floats(int N, int K);
+int pd_gemm_wgrad_f16x2_takes_wide_tiles(int N, int K);   /* 1: this output shape runs on 256 x 256 tiles (a grouped launch does when ALL its problems do) */
+int64_t pd_gemm_wgrad_f16x2_grouped_ws_floats(const PdGemmWgradDesc *descs, int count);
 int pd_gemm_wgrad_acc_f16x2_ws(const float *dY, const float *X, float *dW, float *dB, const float *y_amax, const float *x_amax,
                                float *workspace, int64_t workspace_floats, int M, int N, int K, int ldy, int ldx, int ldw, void *stream);
 int pd_gemm_wgrad_f16x2_grouped(const PdGemmWgradDesc *descs, int count, void *table_host_pinned, void *table_device, float *workspace,

@@ -36,6 +36,7 @@ extern int g_pd_dbg_force_generic;
 extern int g_pd_dbg_ablate;
 extern int g_pd_dbg_x3_narrow;
 extern int g_pd_dbg_f16x2;
+extern int g_pd_dbg_wgrad_wide;
 extern "C" void pd_dbg_set_wgrad_xcd(int v);
 extern int g_pd_dbg_bwd_variant;
 extern int g_pd_dbg_msda_gate_pct;
@@ -62,6 +63,7 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!strcmp(key, "conv_group_rows")) { g_pd_dbg_conv_group_rows = value; return PD_OK; }
   if (!strcmp(key, "x3_ablate")) { g_pd_dbg_x3 = value; return PD_OK; }
   if (!strcmp(key, "f16x2_tile")) { g_pd_dbg_f16x2 = value; return PD_OK; }
+  if (!strcmp(key, "wgrad_wide")) { g_pd_dbg_wgrad_wide = value; return PD_OK; }
   if (!strcmp(key, "wgrad_xcd")) { pd_dbg_set_wgrad_xcd(value); return PD_OK; }
   if (!strcmp(key, "x3_narrow")) { g_pd_dbg_x3_narrow = value; return PD_OK; }
   if (!strcmp(key, "wattn_ablate")) { g_pd_dbg_wattn = value; return PD_OK; }

@@ -709,6 +709,223 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3_tr(const float *__res
   wgrad_tr_body<ABL, CONV, H2>(dY, X, dW, dB, ws, M, N, K, ldy, ldx, ldw, tiles_k, tiles, m_chunk, H, W, lb, 0, y_amax, x_amax);
 }
 
+// ---------------------------------------------------------------------------------------------- weight gradient, 256 x 256 tiles (f16x2)
+// The 128 x 128 kernel above re-reads every slab of rows once per output tile that needs its columns: 2.8 x the algorithmic bytes
+// at the encoder's five weight gradients (rocprofv3 FETCH_SIZE / WRITE_SIZE: 1.97 GB per layer against 0.71 GB, profiles/r03_gemm_pmc.json) —
+// 11.8 GB per step in 1.6 ms, i.e. the kernel runs at the memory system's limit ON ITS OWN RE-READS.  256 x 256 tiles halve them:
+// 8 wavefronts (4 x 2), each 64 x 128 of the tile (2 x 4 MFMA tiles, 128 accumulator registers), one workgroup per CU, 16-row stages
+// of two fp16 planes per operand (74 KB), the same transpose reads on a 576-byte row pitch (= 16 banks mod 64 like the 320-byte one).
+constexpr int WTD = 256, WTP = 288, WNT = 512;
+__device__ __forceinline__ hwbf16x8 frag_trw(const bf16_t *p)      // frag_tr on the wide tile's row pitch
+{
+  typedef __attribute__((address_space(3))) v4s16 *lp;
+  union { v4s16 h[2]; hwbf16x8 v; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p));
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p + 4 * WTP));
+  return u.v;
+}
+
+template <bool CONV>
+__device__ __forceinline__ void wgrad_h2w_body(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ dW,
+                                               float *__restrict__ dB, float *__restrict__ ws, int M, int N, int K, int ldy, int ldx,
+                                               int ldw, int tiles_k, int tiles, int m_chunk, int H, int W, int bid, int64_t ws_tile0,
+                                               const float *__restrict__ y_amax, const float *__restrict__ x_amax)
+{
+  extern __shared__ __attribute__((aligned(16))) bf16_t Sw[];                // [stage 2][operand 2][plane 2][TWS][WTP]
+  auto S = [&](int buf, int op, int pl, int r) -> bf16_t * { return Sw + ((((buf * 2 + op) * 2 + pl) * TWS + r) * WTP); };
+  const int tile = bid % tiles, split = bid / tiles;
+  const int n0 = (tile / tiles_k) * WTD, k0 = (tile % tiles_k) * WTD;
+  const int mb = split * m_chunk, me = min(M, mb + m_chunk);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;
+  const int sr = t >> 6, sc = (t & 63) * 4;                      // staging: rows sr, sr + 8; columns sc .. sc+3
+  const bool ycol_ok = n0 + sc < N, xcol_ok = k0 + sc < K;
+  float sy = 1.f, sx = 1.f, inv_yx = 1.f;
+  if (y_amax || x_amax) {                                        // slab-wise power-of-two scales (see wgrad_tr_body)
+    float my = 0.f, mx = 0.f;
+    if (y_amax) for (int r = mb + t; r < me; r += WNT) my = fmaxf(my, y_amax[r]);
+    const int xlo = CONV ? max(0, mb - W - 1) : mb, xhi = CONV ? min(M, me + W + 1) : me;
+    if (x_amax) for (int r = xlo + t; r < xhi; r += WNT) mx = fmaxf(mx, x_amax[r]);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { my = fmaxf(my, __shfl_xor(my, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+    float *red = reinterpret_cast<float *>(Sw);
+    if (lane == 0) { red[wave] = my; red[8 + wave] = mx; }
+    __syncthreads();
+    my = mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { my = fmaxf(my, red[i]); mx = fmaxf(mx, red[8 + i]); }
+    __syncthreads();
+    float iy = 1.f, ix = 1.f;
+    if (y_amax) pdh2::row_scale(my, sy, iy);
+    if (x_amax) pdh2::row_scale(mx, sx, ix);
+    inv_yx = iy * ix;
+  }
+  float4 ry[2][2], rx[2][2];                                     // two register stages
+  int cpy[2] = {0, 0}, cpx[2] = {0, 0}, tdy = 0, tdx = 0, xoff = k0 + sc;
+  if (CONV) {
+    const int tap = k0 / ldx;
+    tdy = tap / 3 - 1; tdx = tap - (tap / 3) * 3 - 1;
+    xoff = k0 - tap * ldx + sc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pix = (mb + sr + 8 * j) % (H * W);
+      cpy[j] = pix / W; cpx[j] = pix - cpy[j] * W;
+    }
+  }
+  auto gload = [&](int s, int m) {                               // called with m = mb, mb + 16, mb + 32, ... in this order
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = m + sr + 8 * j;
+      ry[s][j] = (r < me && ycol_ok) ? *reinterpret_cast<const float4 *>(dY + (int64_t)r * ldy + n0 + sc) : make_float4(0, 0, 0, 0);
+      if (CONV) {
+        const int yy = cpy[j] + tdy, xx = cpx[j] + tdx;
+        const bool ok = r < me && xcol_ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        rx[s][j] = ok ? *reinterpret_cast<const float4 *>(X + ((int64_t)r + tdy * W + tdx) * ldx + xoff) : make_float4(0, 0, 0, 0);
+        cpx[j] += TWS;
+        while (cpx[j] >= W) { cpx[j] -= W; if (++cpy[j] == H) cpy[j] = 0; }
+      } else {
+        rx[s][j] = (r < me && xcol_ok) ? *reinterpret_cast<const float4 *>(X + (int64_t)r * ldx + k0 + sc) : make_float4(0, 0, 0, 0);
+      }
+    }
+  };
+  const bool do_bias = dB != nullptr && k0 == 0;
+  float4 bsum = make_float4(0, 0, 0, 0);
+  auto lstore = [&](int s, int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = sr + 8 * j;
+      const pdh2::SplitH y = pdh2::split4h(ry[s][j], sy), x = pdh2::split4h(rx[s][j], sx);
+      *reinterpret_cast<uint2 *>(S(buf, 0, 0, r) + sc) = y.hi; *reinterpret_cast<uint2 *>(S(buf, 0, 1, r) + sc) = y.lo;
+      *reinterpret_cast<uint2 *>(S(buf, 1, 0, r) + sc) = x.hi; *reinterpret_cast<uint2 *>(S(buf, 1, 1, r) + sc) = x.lo;
+      if (do_bias) { bsum.x += ry[s][j].x; bsum.y += ry[s][j].y; bsum.z += ry[s][j].z; bsum.w += ry[s][j].w; }
+    }
+  };
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int steps = (me - mb + TWS - 1) / TWS;
+  if (steps > 0) {
+    gload(0, mb);
+    if (steps > 1) gload(1, mb + TWS);
+    lstore(0, 0);
+  }
+  __syncthreads();
+  const int grp = lane >> 4, sl = lane & 15;
+  const int frow = 8 * (grp >> 1) + (sl >> 2), fcol = 16 * (grp & 1) + 4 * (sl & 3);
+  auto step = [&](int st, int par) {
+    if (st + 2 < steps) gload(par, mb + (st + 2) * TWS);
+    hwbf16x8 a[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[p][i] = frag_trw(S(par, 0, p, frow) + wn + i * 32 + fcol);
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {                             // two column tiles at a time (8, not 16, X fragments live)
+      hwbf16x8 b[2][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[p][j] = frag_trw(S(par, 1, p, frow) + wk + (jp * 2 + j) * 32 + fcol);
+#define WTERM(PA, PB)                                                        \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                          \
+        pdh2::mmah(acc[i][jp * 2 + j], __builtin_bit_cast(pdh2::h16x8, a[PA][i]), __builtin_bit_cast(pdh2::h16x8, b[PB][j]));
+      WTERM(1, 0) WTERM(0, 1) WTERM(0, 0)
+#undef WTERM
+    }
+    if (st + 1 < steps) lstore(par ^ 1, par ^ 1);
+    __syncthreads();
+  };
+  for (int st = 0; st < steps; st += 2) {
+    step(st, 0);
+    if (st + 1 < steps) step(st + 1, 1);
+  }
+  if (do_bias) {
+    float *red = reinterpret_cast<float *>(Sw);                  // the last step ended with a barrier: the stages are free
+    *reinterpret_cast<float4 *>(red + sr * WTD + sc) = bsum;
+    __syncthreads();
+    if (t < WTD && n0 + t < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v += red[r * WTD + t];
+      unsafeAtomicAdd(dB + n0 + t, v);
+    }
+  }
+  if (ws) {
+    // partial tile in REGISTER order (element (ij, e) of thread t at ((ij * 16 + e) * 512 + t), ij = 4 i + j)
+    float *w = ws + (ws_tile0 + (int64_t)split * tiles + tile) * (WTD * WTD) + t;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) w[((i * 4 + j) * 16 + e) * WNT] = acc[i][j][e] * inv_yx;
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = k0 + wk + j * 32 + (lane & 31);
+    if (c >= K) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = n0 + wn + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < N) unsafeAtomicAdd(dW + (int64_t)row * ldw + c, acc[i][j][e] * inv_yx);
+      }
+  }
+}
+
+template <bool CONV>
+__global__ __launch_bounds__(512, 1) void gemm_wgrad_f16x2_wide(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ dW,
+                                                                float *__restrict__ dB, float *__restrict__ ws, int M, int N, int K, int ldy, int ldx,
+                                                                int ldw, int tiles_k, int tiles, int m_chunk, int H, int W,
+                                                                const float *__restrict__ y_amax, const float *__restrict__ x_amax)
+{
+  wgrad_h2w_body<CONV>(dY, X, dW, dB, ws, M, N, K, ldy, ldx, ldw, tiles_k, tiles, m_chunk, H, W, xcd_chunk((int)blockIdx.x, (int)gridDim.x), 0,
+                       y_amax, x_amax);
+}
+
+// element (q = ij * 16 + e, thread t) of a wide partial tile -> (output row, column) of the tile
+__device__ __forceinline__ void h2w_coord(int q, int t, int &row, int &col)
+{
+  const int lane = t & 63, wave = t >> 6, ij = q >> 4, e = q & 15, i = ij >> 2, j = ij & 3;
+  row = (wave >> 1) * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+  col = (wave & 1) * 128 + j * 32 + (lane & 31);
+}
+
+// dW tile += sum over splits of the partial tiles (128 blocks of 512 threads per tile, one (ij, e) each; blockIdx.y takes every
+// gridDim.y-th split and finishes with an atomic, gridDim.y == 1 owns its element)
+__global__ __launch_bounds__(512) void wgrad_h2w_reduce(const float *__restrict__ ws, float *__restrict__ dW, int N, int K, int ldw, int tiles_k,
+                                                        int tiles, int splits)
+{
+  const int tile = blockIdx.x >> 7, q = blockIdx.x & 127, t = threadIdx.x;
+  const int n0 = (tile / tiles_k) * WTD, k0 = (tile % tiles_k) * WTD;
+  const float *p = ws + (int64_t)tile * (WTD * WTD) + q * WNT + t;
+  const int64_t stride = (int64_t)tiles * (WTD * WTD);
+  float s0 = 0.f, s1 = 0.f;
+  int sp = blockIdx.y;
+  const int G = gridDim.y;
+  for (; sp + 7 * G < splits; sp += 8 * G) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(sp + u * G) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+  }
+  for (; sp < splits; sp += G) s0 += p[(int64_t)sp * stride];
+  int row, col;
+  h2w_coord(q, t, row, col);
+  if (k0 + col < K && n0 + row < N) {
+    float *d = dW + (int64_t)(n0 + row) * ldw + k0 + col;
+    if (G == 1) *d += s0 + s1; else unsafeAtomicAdd(d, s0 + s1);
+  }
+}
+
 // Several weight gradients in ONE launch (pd_gemm_wgrad_f32x3_grouped): a table of problems in device memory, workgroup b belongs
 // to the problem whose [block0, block0 + tiles * splits) contains b.  The encoder's 30 weight gradients per step are independent of
 // everything until the optimizer runs, so they are queued during its backward pass and run here together: every (tile, split)
@@ -760,6 +977,41 @@ __global__ __launch_bounds__(256) void wgrad_tr_reduce_grouped(const WgradX3Prob
   const int c = k0 + wk + j * 32 + (lane & 31);
   const int row = n0 + wn + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
   if (c < pr.K && row < pr.N) pr.dW[(int64_t)row * pr.ldw + c] += s0 + s1;      // this block owns the element: plain read-modify-write
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_wgrad_f16x2_wide_grouped(const WgradX3Problem *__restrict__ tab, int count, float *__restrict__ ws)
+{
+  const int lb = xcd_chunk((int)blockIdx.x, (int)gridDim.x);
+  int p = 0;
+  while (p + 1 < count && lb >= tab[p + 1].block0) ++p;
+  const WgradX3Problem q = tab[p];
+  wgrad_h2w_body<false>(q.dY, q.X, q.dW, q.dB, ws, q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, q.tiles_k, q.tiles, q.m_chunk, 0, 0, lb - q.block0, q.ws_tile0,
+                        q.y_amax, q.x_amax);
+}
+
+__global__ __launch_bounds__(512) void wgrad_h2w_reduce_grouped(const WgradX3Problem *__restrict__ tab, int count, const float *__restrict__ ws)
+{
+  const int gt = blockIdx.x >> 7, q = blockIdx.x & 127, t = threadIdx.x;
+  int p = 0, t0 = 0;
+  while (p + 1 < count && gt >= t0 + tab[p].tiles) { t0 += tab[p].tiles; ++p; }
+  const WgradX3Problem pr = tab[p];
+  const int tile = gt - t0;
+  const int n0 = (tile / pr.tiles_k) * WTD, k0 = (tile % pr.tiles_k) * WTD;
+  const float *src = ws + (pr.ws_tile0 + tile) * (WTD * WTD) + q * WNT + t;
+  const int64_t stride = (int64_t)pr.tiles * (WTD * WTD);
+  float s0 = 0.f, s1 = 0.f;
+  int sp = 0;
+  for (; sp + 7 < pr.splits; sp += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(sp + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+  }
+  for (; sp < pr.splits; ++sp) s0 += src[(int64_t)sp * stride];
+  int row, col;
+  h2w_coord(q, t, row, col);
+  if (k0 + col < pr.K && n0 + row < pr.N) pr.dW[(int64_t)(n0 + row) * pr.ldw + k0 + col] += s0 + s1;
 }
 
 // dW tile += sum over splits of the partial tiles gemm_wgrad_f32x3_tr left in the workspace (same register-order indexing)
@@ -934,6 +1186,16 @@ extern "C" int pd_gemm_tn_f32x3_relumask(const float *A, const float *B, const u
   return pd_check_launch("pd_gemm_tn_f32x3_relumask");
 }
 
+int g_pd_dbg_wgrad_wide = 1;   // tools only (pd_debug_set "wgrad_wide" 0: the 128 x 128 kernel for every f16x2 weight gradient)
+// the f16x2 weight gradient takes 256 x 256 tiles when the output has several of them (measured at M = 43 008, tools/bench_wgrad_x3.py:
+// 1024 x 256 104 vs 126 us, 256 x 2304 195 vs 257; a single 256 x 256 tile LOSES, 48 vs 42 us — 256 slices of rows each leave a 256 KB
+// partial tile) and, for the 3 x 3 convolution, a tile's 256 X columns lie inside one tap
+static bool wgrad_wide_ok(int N, int K, int conv_ci)
+{
+  return g_pd_dbg_wgrad_wide && N > 128 && K > 128 && (N >= 1024 || K >= 1024) && (conv_ci == 0 || conv_ci % WTD == 0);
+}
+extern "C" int pd_gemm_wgrad_f16x2_takes_wide_tiles(int N, int K) { return wgrad_wide_ok(N, K, 0) ? 1 : 0; }
+
 static int wgrad_x3_launch(const float *dY, const float *X, float *dW, float *dB, float *ws, int64_t ws_floats, int M, int N, int K, int ldy,
                            int ldx, int ldw, hipStream_t st, const char *who, int convH = 0, int convW = 0, bool h2 = false,
                            const float *y_amax = nullptr, const float *x_amax = nullptr)
@@ -960,6 +1222,28 @@ static int wgrad_x3_launch(const float *dY, const float *X, float *dW, float *dB
                        m_chunk);
     return pd_check_launch(who);
   }
+  if (h2 && wgrad_wide_ok(N, K, convH ? ldx : 0)) {
+    // 256 x 256 tiles, one workgroup per CU: one round of 256
+    const int wtk = (K + WTD - 1) / WTD, wtn = (N + WTD - 1) / WTD, wtiles = wtk * wtn;
+    int wsplits = wtiles >= 256 ? 1 : (256 + wtiles / 2) / wtiles;
+    int mc = ((M + wsplits - 1) / wsplits + TWS - 1) / TWS * TWS;
+    if (mc < 4 * TWS) mc = 4 * TWS;
+    wsplits = (M + mc - 1) / mc;
+    if (ws && (ws_floats < (int64_t)wtiles * wsplits * WTD * WTD || wsplits < 2)) ws = nullptr;
+    constexpr size_t lds = (size_t)2 * 2 * 2 * TWS * WTP * sizeof(bf16_t);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void *)gemm_wgrad_f16x2_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void *)gemm_wgrad_f16x2_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    auto kw = convH ? gemm_wgrad_f16x2_wide<true> : gemm_wgrad_f16x2_wide<false>;
+    hipLaunchKernelGGL(kw, dim3((unsigned)(wtiles * wsplits)), dim3(WNT), lds, st, dY, X, dW, dB, ws, M, N, K, ldy, ldx, ldw, wtk, wtiles, mc, convH, convW,
+                       y_amax, x_amax);
+    const int wgroups = wtiles * 128 >= 2048 ? 1 : wsplits >= 64 ? 8 : wsplits >= 16 ? 4 : 1;
+    if (ws) hipLaunchKernelGGL(wgrad_h2w_reduce, dim3((unsigned)(wtiles * 128), wgroups), dim3(WNT), 0, st, (const float *)ws, dW, N, K, ldw, wtk, wtiles, wsplits);
+    return pd_check_launch(who);
+  }
   if (ws && (ws_floats < (int64_t)tiles * splits * BN * BM || splits < 2 || g_pd_dbg_x3 == 25)) ws = nullptr;   // not worth / does not fit: atomics
   auto kfn = h2 ? (convH ? gemm_wgrad_f32x3_tr<0, true, true> : gemm_wgrad_f32x3_tr<0, false, true>)
                  : convH ? gemm_wgrad_f32x3_tr<0, true> : g_pd_dbg_x3 == 24 ? gemm_wgrad_f32x3_tr<2, false> : gemm_wgrad_f32x3_tr<0, false>;
@@ -975,24 +1259,31 @@ static int wgrad_x3_launch(const float *dY, const float *X, float *dW, float *dB
 // ---- grouped weight gradients (include/pd_gemm.h: pd_gemm_wgrad_f32x3_grouped)
 extern "C" int64_t pd_gemm_wgrad_f32x3_grouped_table_bytes(int max_count) { return (int64_t)(max_count > 0 ? max_count : 0) * (int64_t)sizeof(WgradX3Problem); }
 
-static int grouped_plan(const PdGemmWgradDesc *d, int count, WgradX3Problem *tab, int64_t *ws_tiles, int *blocks)
+static bool grouped_wide(const PdGemmWgradDesc *d, int count)
+{
+  for (int i = 0; i < count; ++i) if (!wgrad_wide_ok(d[i].N, d[i].K, 0)) return false;
+  return count > 0;
+}
+
+// TD: tile edge (128, or 256 for the wide f16x2 kernel: one workgroup per CU, rounds of 256)
+static int grouped_plan(const PdGemmWgradDesc *d, int count, WgradX3Problem *tab, int64_t *ws_tiles, int *blocks, int TD = BM)
 {
   int64_t total_tiles = 0;
   for (int i = 0; i < count; ++i) {
     if (d[i].M <= 0 || d[i].N <= 0 || d[i].K <= 0 || !d[i].dY || !d[i].X || !d[i].dW) return 1;
     if ((d[i].N & 3) || (d[i].K & 3) || (d[i].ldy & 3) || (d[i].ldx & 3) || ((uintptr_t)d[i].dY & 15) || ((uintptr_t)d[i].X & 15)) return 1;
-    total_tiles += (int64_t)((d[i].K + BM - 1) / BM) * ((d[i].N + BN - 1) / BN);
+    total_tiles += (int64_t)((d[i].K + TD - 1) / TD) * ((d[i].N + TD - 1) / TD);
   }
   // one split count for all problems, chosen so that the launch is a whole number of rounds of 512 resident workgroups (two per
   // CU): tiles x splits just below a multiple of 512, at least ~6 rounds deep so that unequal M do not leave a ragged tail
-  int splits = (int)((6 * 512) / (total_tiles > 0 ? total_tiles : 1));
+  int splits = (int)((6 * (TD == BM ? 512 : 256)) / (total_tiles > 0 ? total_tiles : 1));
   if (splits < 1) splits = 1;
   int64_t wt = 0; int b0 = 0;
   for (int i = 0; i < count; ++i) {
     WgradX3Problem &q = tab[i];
     q.dY = d[i].dY; q.X = d[i].X; q.dW = d[i].dW; q.dB = d[i].dB;
     q.M = d[i].M; q.N = d[i].N; q.K = d[i].K; q.ldy = d[i].ldy; q.ldx = d[i].ldx; q.ldw = d[i].ldw;
-    q.tiles_k = (q.K + BM - 1) / BM; q.tiles = q.tiles_k * ((q.N + BN - 1) / BN);
+    q.tiles_k = (q.K + TD - 1) / TD; q.tiles = q.tiles_k * ((q.N + TD - 1) / TD);
     int mc = ((q.M + splits - 1) / splits + TWS - 1) / TWS * TWS;
     if (mc < 4 * TWS) mc = 4 * TWS;
     q.m_chunk = mc; q.splits = (q.M + mc - 1) / mc;
@@ -1021,15 +1312,25 @@ static int wgrad_grouped(const PdGemmWgradDesc *descs, int count, void *table_ho
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_wgrad_f32x3_grouped: count=%d (1..256) or null pointer", count);
   WgradX3Problem *tab = reinterpret_cast<WgradX3Problem *>(table_host_pinned);
   int64_t wt = 0; int blocks = 0;
-  if (grouped_plan(descs, count, tab, &wt, &blocks))
+  const bool wide = h2 && grouped_wide(descs, count);
+  const int TD = wide ? WTD : BM;
+  if (grouped_plan(descs, count, tab, &wt, &blocks, TD))
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_wgrad_f32x3_grouped: every problem needs M, N, K > 0, N, K, ldy, ldx multiples of 4, 16-byte aligned operands");
-  if (workspace_floats < wt * BN * BM) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_wgrad_f32x3_grouped: workspace too small");
+  if (workspace_floats < wt * TD * TD) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_wgrad_f32x3_grouped: workspace too small");
   hipStream_t st = (hipStream_t)stream_;
   if (hipMemcpyAsync(table_device, table_host_pinned, (size_t)count * sizeof(WgradX3Problem), hipMemcpyHostToDevice, st) != hipSuccess)
     return pd_set_error(PD_ERR_LAUNCH, "pd_gemm_wgrad_f32x3_grouped: table upload failed");
   const WgradX3Problem *dt = reinterpret_cast<const WgradX3Problem *>(table_device);
   int64_t tiles = 0;
   for (int i = 0; i < count; ++i) tiles += tab[i].tiles;
+  if (wide) {
+    constexpr size_t lds = (size_t)2 * 2 * 2 * TWS * WTP * sizeof(bf16_t);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)gemm_wgrad_f16x2_wide_grouped, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(gemm_wgrad_f16x2_wide_grouped, dim3((unsigned)blocks), dim3(WNT), lds, st, dt, count, workspace);
+    hipLaunchKernelGGL(wgrad_h2w_reduce_grouped, dim3((unsigned)(tiles * 128)), dim3(WNT), 0, st, dt, count, (const float *)workspace);
+    return pd_check_launch("pd_gemm_wgrad_f16x2_grouped");
+  }
   if (h2) hipLaunchKernelGGL(gemm_wgrad_f32x3_tr_grouped<true>, dim3((unsigned)blocks), dim3(256), 0, st, dt, count, workspace);
   else hipLaunchKernelGGL(gemm_wgrad_f32x3_tr_grouped<false>, dim3((unsigned)blocks), dim3(256), 0, st, dt, count, workspace);
   hipLaunchKernelGGL(wgrad_tr_reduce_grouped, dim3((unsigned)(tiles * 64)), dim3(256), 0, st, dt, count, (const float *)workspace);
@@ -1046,6 +1347,25 @@ extern "C" int pd_gemm_wgrad_f16x2_grouped(const PdGemmWgradDesc *descs, int cou
                                            float *workspace, int64_t workspace_floats, void *stream_)
 {
   return wgrad_grouped(descs, count, table_host_pinned, table_device, workspace, workspace_floats, stream_, true);
+}
+
+extern "C" int64_t pd_gemm_wgrad_f16x2_ws_floats(int N, int K)
+{
+  const int64_t narrow = pd_gemm_wgrad_f32x3_ws_floats(N, K);
+  if (N <= 0 || K <= 0) return narrow;
+  const int64_t wt = (int64_t)((K + WTD - 1) / WTD) * ((N + WTD - 1) / WTD);
+  const int64_t wide = wt >= 256 ? 0 : (256 + wt / 2) / wt * wt * WTD * WTD;
+  return wide > narrow ? wide : narrow;                          // whichever tile shape the launch takes
+}
+
+extern "C" int64_t pd_gemm_wgrad_f16x2_grouped_ws_floats(const PdGemmWgradDesc *descs, int count)
+{
+  if (count <= 0 || count > 256 || !descs) return 0;
+  WgradX3Problem tab[256];
+  int64_t wt = 0; int blocks = 0;
+  const int TD = grouped_wide(descs, count) ? WTD : BM;
+  if (grouped_plan(descs, count, tab, &wt, &blocks, TD)) return -1;
+  return wt * TD * TD;
 }
 
 extern "C" int pd_gemm_wgrad_acc_f16x2_ws(const float *dY, const float *X, float *dW, float *dB, const float *y_amax, const float *x_amax,

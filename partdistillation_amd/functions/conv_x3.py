@@ -35,7 +35,7 @@ def _raw(x, wk, bias, co, x_amax=None):
     from .gemm import _timed_fwd, row_amax
     if x_amax is not None:
         w_amax = row_amax(wk.view(co, -1))
-        with _timed_fwd(2.0 * B * H * W * 9 * ci * co, "gemm_tn_f16x2<conv 3x3>"):
+        with _timed_fwd(2.0 * B * H * W * 9 * ci * co, f"gemm_tn_f16x2<256x256, conv 3x3> {co}<-9x{ci} M={B * H * W}", 4.0 * (B * H * W * (ci + co) + 9 * ci * co)):
             _lib.check(_lib.load().pd_conv3x3_nhwc_f16x2(x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                                                          x_amax.data_ptr(), w_amax.data_ptr(), None, B, H, W, ci, co, _lib.current_stream()))
         return y
@@ -77,7 +77,7 @@ class Conv3x3X3(Function):
             B, _, H, W = x.shape
             buf = torch.zeros(co * 9 * ci + co, dtype=torch.float32, device=x.device)
             dwk, dbv = buf[:co * 9 * ci].view(co, 3, 3, ci), buf[co * 9 * ci:]
-            ws = _wgrad_workspace(x.device, int(L.pd_gemm_wgrad_f32x3_ws_floats(co, 9 * ci)))
+            ws = _wgrad_workspace(x.device, int((L.pd_gemm_wgrad_f16x2_ws_floats if x_am is not None else L.pd_gemm_wgrad_f32x3_ws_floats)(co, 9 * ci)))
             if x_am is not None:
                 _lib.check(L.pd_conv3x3_wgrad_nhwc_f16x2(dy.data_ptr(), x.data_ptr(), dwk.data_ptr(), dbv.data_ptr() if want_b else None,
                                                          dy_am.data_ptr(), x_am.data_ptr(), ws.data_ptr() if ws is not None else None,

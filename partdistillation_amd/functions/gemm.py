@@ -33,8 +33,9 @@ _TIMING = {"on": False, "wgrad": [], "fwd": []}
 class _timed_fwd:
     """HIP events around one split-GEMM launch on the launch stream (bench.py's per-launch roofline figures)"""
 
-    def __init__(self, flops, label):
-        self.flops, self.label = flops, label
+    def __init__(self, flops, label, nbytes=0.0):
+        """flops = 2 M N K (fp32-equivalent); nbytes = the operands and the result once each (algorithmic HBM bytes)"""
+        self.flops, self.label, self.nbytes = flops, label, nbytes
 
     def __enter__(self):
         if _TIMING["on"]:
@@ -44,7 +45,7 @@ class _timed_fwd:
     def __exit__(self, *exc):
         if _TIMING["on"]:
             self.b.record()
-            _TIMING["fwd"].append((self.a, self.b, (self.flops, self.label)))
+            _TIMING["fwd"].append((self.a, self.b, (self.flops, self.label, self.nbytes)))
 
 
 def gemm_tn_x3(a, b, bias=None, relu=False):
@@ -93,7 +94,8 @@ def gemm_tn_h2(a, b, bias=None, mode=0, bits=None, colsum=None, a_amax=None, b_a
     if mode == 1 and want_bits:
         bits = torch.empty(int(L.pd_gemm_tn_f16x2_bits_words(M, N)), dtype=torch.int32, device=a.device)
     p = lambda t: t.data_ptr() if t is not None else None
-    with _timed_fwd(2.0 * M * N * K, "gemm_tn_f16x2"):
+    shape = "wide" if (N % 256 == 0 and M >= 1024 and (-(-M // 256)) * (N // 256) >= 128 and (N >= 1024 or K >= 512)) or bits is not None else "narrow"
+    with _timed_fwd(2.0 * M * N * K, f"gemm_tn_f16x2<{'256x256' if shape == 'wide' else '128x128'}> {N}<-{K} M={M}", 4.0 * (M * K + N * K + M * N)):
         _lib.check(L.pd_gemm_tn_f16x2(a.data_ptr(), b.data_ptr(), p(bias), c.data_ptr(), p(bits), p(colsum), p(a_amax), p(b_amax), p(c_amax),
                                       M, N, K, a.stride(0), b.stride(0), N, mode, _stream()))
     return (c, bits) if (mode == 1 and want_bits) else c
@@ -210,7 +212,7 @@ def gemm_wgrad_acc(dy, x, dw, db=None, x3=None, h2=False, y_amax=None, x_amax=No
         a.record()
     L = _lib.load()
     if h2:
-        ws = _wgrad_workspace(dy.device, int(L.pd_gemm_wgrad_f32x3_ws_floats(N, K)))
+        ws = _wgrad_workspace(dy.device, int(L.pd_gemm_wgrad_f16x2_ws_floats(N, K)))
         _lib.check(L.pd_gemm_wgrad_acc_f16x2_ws(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
                                                 y_amax.data_ptr() if y_amax is not None else None, x_amax.data_ptr() if x_amax is not None else None,
                                                 ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
@@ -225,7 +227,7 @@ def gemm_wgrad_acc(dy, x, dw, db=None, x3=None, h2=False, y_amax=None, x_amax=No
                                            M, N, K, dy.stride(0), x.stride(0), K, _stream()))
     if _TIMING["on"]:
         b.record()
-        _TIMING["wgrad"].append((a, b, 2.0 * M * N * K))
+        _TIMING["wgrad"].append((a, b, (2.0 * M * N * K, 4.0 * (M * N + M * K + N * K), "h2" if h2 else "x3")))
 
 
 class _WgradDesc(ctypes.Structure):                                 # PdGemmWgradDesc (include/pd_gemm.h)
@@ -262,16 +264,24 @@ class WgradQueue:
             return
         L = _lib.load()
         dev = items[0][0].device
-        for lo in range(0, len(items), self.MAXP):
-            part = items[lo:lo + self.MAXP]
+        if self.h2:
+            # a grouped launch runs on 256 x 256 tiles only when all its problems suit them: the large outputs (the FFN's) and the
+            # rest go as two launches
+            wide = [it for it in items if L.pd_gemm_wgrad_f16x2_takes_wide_tiles(it[0].shape[1], it[1].shape[1])]
+            rest = [it for it in items if not L.pd_gemm_wgrad_f16x2_takes_wide_tiles(it[0].shape[1], it[1].shape[1])]
+            parts = [g[lo:lo + self.MAXP] for g in (wide, rest) for lo in range(0, len(g), self.MAXP)]
+        else:
+            parts = [items[lo:lo + self.MAXP] for lo in range(0, len(items), self.MAXP)]
+        for part in parts:
             descs = (_WgradDesc * len(part))()
-            flops = 0.0
+            flops = nbytes = 0.0
             for d, (dy, x, dw, db, ya, xa) in zip(descs, part):
                 d.dY, d.X, d.dW, d.dB = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
                 d.y_amax, d.x_amax = (ya.data_ptr() if ya is not None else None), (xa.data_ptr() if xa is not None else None)
                 d.M, d.N, d.K, d.ldy, d.ldx, d.ldw = dy.shape[0], dy.shape[1], x.shape[1], dy.stride(0), x.stride(0), dw.shape[1]
                 flops += 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1]
-            need = int(L.pd_gemm_wgrad_f32x3_grouped_ws_floats(ctypes.byref(descs), len(part)))
+                nbytes += 4.0 * (dy.shape[0] * (dy.shape[1] + x.shape[1]) + dy.shape[1] * x.shape[1])
+            need = int((L.pd_gemm_wgrad_f16x2_grouped_ws_floats if self.h2 else L.pd_gemm_wgrad_f32x3_grouped_ws_floats)(ctypes.byref(descs), len(part)))
             if need < 0:
                 raise RuntimeError("pd_gemm_wgrad_f32x3_grouped: a queued problem violates the alignment rules (N, K, strides % 4, 16-byte bases)")
             key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
@@ -296,7 +306,7 @@ class WgradQueue:
             _lib.check(rc)
             if _TIMING["on"]:
                 b.record()
-                _TIMING["wgrad"].append((a, b, flops))
+                _TIMING["wgrad"].append((a, b, (flops, nbytes, "h2 grouped" if self.h2 else "x3 grouped")))
 
 
 def gemm_wgrad(dy, x, with_bias=False):

@@ -27,6 +27,9 @@ SIGNATURES = {
     "pd_adamw_clipped": (_c_int, [_c_vp] * 4 + [ctypes.c_int64, _c_int] + [ctypes.c_double] * 5 + [_c_int, _c_vp, ctypes.c_double, _c_vp, _c_vp]),
     "pd_gemm_tn_f32": (_c_int, [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
     "pd_gemm_tn_f32x3": (_c_int, [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
+    "pd_gemm_wgrad_f16x2_takes_wide_tiles": (_c_int, [_c_int] * 2),
+    "pd_gemm_wgrad_f16x2_ws_floats": (ctypes.c_int64, [_c_int] * 2),
+    "pd_gemm_wgrad_f16x2_grouped_ws_floats": (ctypes.c_int64, [_c_vp, _c_int]),
     "pd_gemm_wgrad_acc_f16x2_ws": (_c_int, [_c_vp] * 7 + [ctypes.c_int64] + [_c_int] * 6 + [_c_vp]),
     "pd_gemm_wgrad_f16x2_grouped": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_vp]),
     "pd_conv3x3_wgrad_nhwc_f16x2": (_c_int, [_c_vp] * 7 + [ctypes.c_int64] + [_c_int] * 5 + [_c_vp]),

@@ -42,8 +42,8 @@ for N, K in [(1024, 256), (256, 1024), (256, 256), (512, 256), (192, 256), (256,
     err = float((dw.double() - ref).abs().max() / ref.abs().max())
     us = timeit(lambda: G.gemm_wgrad_acc(dy, x, dw, db, h2=True, y_amax=ya, x_amax=xa))
     row.append(f"f16x2 tr-read+ws: {us:7.1f} us {2.0 * M * N * K / us / 1e6:6.1f} TF  err {err:.1e}")
-    L.load().pd_debug_set(b"wgrad_xcd", 0)
+    L.load().pd_debug_set(b"wgrad_wide", 0)
     us0 = timeit(lambda: G.gemm_wgrad_acc(dy, x, dw, db, h2=True, y_amax=ya, x_amax=xa))
-    L.load().pd_debug_set(b"wgrad_xcd", 1)
-    row.append(f"f16x2 launch-order blocks: {us0:7.1f} us")
+    L.load().pd_debug_set(b"wgrad_wide", 1)
+    row.append(f"f16x2 128x128 tiles: {us0:7.1f} us")
     print(f"N={N:5d} K={K:5d} | " + " | ".join(row), flush=True)

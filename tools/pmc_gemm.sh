@@ -6,28 +6,33 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_gemm; mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcg_$C
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcg_$C -o p -- python tools/pmc_gemm_driver.py > $OUT/run_$C.log 2>&1
+  PMC_LABELS=/tmp/pmc_labels.json rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcg_$C -o p -- python tools/pmc_gemm_driver.py > $OUT/run_$C.log 2>&1
   cp /tmp/pmcg_$C/p_counter_collection.csv $OUT/${C}.csv 2>/dev/null
 done
 python - <<'PY'
 import csv, collections, json, os, re
 out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out/pmc_gemm")
+lab = json.load(open("/tmp/pmc_labels.json"))
 res = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     p = os.path.join(out, c + ".csv")
     if not os.path.exists(p):
         continue
-    for r in csv.DictReader(open(p)):
-        if r["Counter_Name"] != c:
-            continue
-        m = re.search(r"(gemm_tn_f32x3_wide<[^>]*>|gemm_tn_f32x3<[^>]*>|gemm_wgrad_f32x3_tr<[^>]*>|wgrad_tr_reduce)", r["Kernel_Name"])
-        if m:
-            res[m.group(1)][c].append(float(r["Counter_Value"]))
+    rows = [r for r in csv.DictReader(open(p)) if r["Counter_Name"] == c]
+    rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
+    fwd = [r for r in rows if re.search(r"gemm_tn_f16x2<", r["Kernel_Name"])]
+    assert len(fwd) == len(lab["fwd"]), (len(fwd), len(lab["fwd"]))
+    for r, l in zip(fwd, lab["fwd"]):                       # dispatch order = the order the driver issued them in
+        res[l][c].append(float(r["Counter_Value"]))
+    g = [r for r in rows if re.search(r"gemm_wgrad_f32x3_tr_grouped|wgrad_tr_reduce_grouped", r["Kernel_Name"])]
+    for i in range(0, len(g), 2):                           # main kernel + its reduce: one bench.py "kernel"
+        res["gemm_wgrad_f32x3_tr_grouped<f16x2> (+ wgrad_tr_reduce_grouped)"][c].append(sum(float(r["Counter_Value"]) for r in g[i:i + 2]))
 summary = {}
 for k, d in res.items():
     f, w = d.get("FETCH_SIZE", []), d.get("WRITE_SIZE", [])
     summary[k] = {"launches": max(len(f), len(w)), "FETCH_SIZE_KB_avg_per_launch": sum(f) / max(len(f), 1), "WRITE_SIZE_KB_avg_per_launch": sum(w) / max(len(w), 1),
-                  "hbm_bytes_corrected_avg_per_launch": (2 * sum(f) / max(len(f), 1) + sum(w) / max(len(w), 1)) * 1024}
+                  "hbm_bytes_corrected_avg_per_launch": (2 * sum(f) / max(len(f), 1) + sum(w) / max(len(w), 1)) * 1024,
+                  "note": "FETCH_SIZE x 2 (gfx950 counts 64-byte units as 32: MI355X_MICROARCH.md) + WRITE_SIZE, KB -> bytes; the grouped weight-gradient entry is the driver's 5-problem layer (1/6 of the step's launch)"}
     print(k, summary[k])
 json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
 PY
