@@ -42,6 +42,14 @@ int pd_sgemm_tn_splitk_bf16(const void *X, const void *W, const void *bias, void
 int pd_sgemm_nn_splitn_bf16(const void *dY, const void *W, const void *relu_ref, void *dX, float *workspace, int64_t workspace_floats,
                             int *tickets, int M, int N, int K, int ldy, int ldw, int ldx, int accumulate, void *stream);
 
+/* One prediction head of the masked-attention decoder in one launch (reference mask2former_transformer_decoder.py:449-459 +
+ * :198-204; the in-loop mask prediction carries no gradient, :457):  dec_out[R,256] = LayerNorm(tgt) in fp32 with mean / rstd [R];
+ * when ef != NULL also e = W3 relu(W2 relu(W1 bf16(dec_out) + b1) + b2) + b3 (bf16 weights [256,256] / biases [256], fp32 accumulation,
+ * bf16 roundings where the three Linears would round) written batch-major in fp32: ef[b][q][:] = e[q B + b][:], R = Q B rows. */
+int pd_decoder_head_bf16(const float *tgt, const float *ln_w, const float *ln_b, float eps, const void *w1, const void *b1, const void *w2,
+                         const void *b2, const void *w3, const void *b3, float *dec_out, float *mean, float *rstd, float *ef, int R, int B, int C,
+                         void *stream);
+
 /* dW[N,K] = dY[M,N]^T . X[M,K];  dB[N] (fp32, nullable) = column sums of dY       nn.Linear weight / bias gradient.
  * Any M >= 0 (rows past M count as zeros); N % 4 == 0, K % 4 == 0. */
 int pd_sgemm_wgrad_bf16(const void *dY, const void *X, void *dW, float *dB, int M, int N, int K, int ldy, int ldx, int ldw,

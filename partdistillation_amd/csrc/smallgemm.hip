@@ -222,6 +222,97 @@ __global__ __launch_bounds__(256) void sgemm_tn_splitk(const bf16_t *__restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------ decoder prediction head
+// decoder_norm + the 3-layer mask-embedding MLP of ONE prediction head in one launch (reference mask2former_transformer_decoder.py:
+// 449-459 + :198-204; the per-layer mask prediction only feeds the next layer's attention mask and carries no gradient, :457):
+//   d = LayerNorm(tgt) (fp32: written to dec_out, with its statistics for the backward pass of the gradient-carrying heads)
+//   e = W3 relu(W2 relu(W1 bf16(d) + b1) + b2) + b3      (bf16 operands, fp32 accumulation, bf16 between the layers)
+//   ef[b][q][:] = fp32(e[q B + b][:])                     (batch-major: the operand of the mask-logit product)
+// A workgroup owns 32 rows; each layer's 256 x 256 weight passes through LDS with all its loads in flight.  Was 4 launches + a
+// transposing copy per head.
+__global__ __launch_bounds__(256) void decoder_head_256(const float *__restrict__ tgt, const float *__restrict__ ln_w, const float *__restrict__ ln_b,
+                                                        float eps, const bf16_t *__restrict__ w1, const bf16_t *__restrict__ b1,
+                                                        const bf16_t *__restrict__ w2, const bf16_t *__restrict__ b2,
+                                                        const bf16_t *__restrict__ w3, const bf16_t *__restrict__ b3, float *__restrict__ dec_out,
+                                                        float *__restrict__ mean, float *__restrict__ rstd, float *__restrict__ ef, int R, int B)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char sg_smem[];
+  bf16_t(*Xs)[PK256] = reinterpret_cast<bf16_t(*)[PK256]>(sg_smem);                       // [32][PK256]
+  bf16_t(*Ws)[PK256] = reinterpret_cast<bf16_t(*)[PK256]>(sg_smem + 32 * PK256 * sizeof(bf16_t));   // [256][PK256]
+  const int mb = blockIdx.x * 32;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  // ---- LayerNorm: a wavefront per row (64 lanes x 4 channels)
+  {
+    const float4 gm = *reinterpret_cast<const float4 *>(ln_w + lane * 4), bt = *reinterpret_cast<const float4 *>(ln_b + lane * 4);
+    for (int i = 0; i < 8; ++i) {
+      const int row = wave * 8 + i, m = mb + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < R) v = *reinterpret_cast<const float4 *>(tgt + (int64_t)m * 256 + lane * 4);
+      float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+      for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mu = s * (1.f / 256);
+      v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
+      float q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+      for (int o = 32; o; o >>= 1) q += __shfl_xor(q, o, 64);
+      const float rs = rsqrtf(q * (1.f / 256) + eps);
+      float4 o4 = make_float4(v.x * rs * gm.x + bt.x, v.y * rs * gm.y + bt.y, v.z * rs * gm.z + bt.z, v.w * rs * gm.w + bt.w);
+      if (m < R) {
+        *reinterpret_cast<float4 *>(dec_out + (int64_t)m * 256 + lane * 4) = o4;
+        if (lane == 0) { mean[m] = mu; rstd[m] = rs; }
+      } else {
+        o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      *reinterpret_cast<bf16x4 *>(&Xs[row][lane * 4]) = pack4(o4.x, o4.y, o4.z, o4.w);
+    }
+  }
+  if (!ef) return;                                               // the last head: no mask prediction follows
+  const int prow = tid >> 5, pcol = (tid & 31) * 8;
+#pragma unroll 1
+  for (int layer = 0; layer < 3; ++layer) {
+    const bf16_t *W = layer == 0 ? w1 : layer == 1 ? w2 : w3;
+    const bf16_t *bias = layer == 0 ? b1 : layer == 1 ? b2 : b3;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                       // 2 x 16 pieces of 16 bytes per thread in flight
+      uint4 wr[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) wr[i] = *reinterpret_cast<const uint4 *>(W + (int64_t)(half * 128 + prow + 8 * i) * 256 + pcol);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) store_piece(&Ws[half * 128 + prow + 8 * i][pcol], wr[i]);
+    }
+    __syncthreads();                                             // Ws (and the Xs rows of the previous phase) complete
+    f32x16 acc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+    for (int s = 0; s < 32; ++s) {                               // acc[n][m] += W[n][k..] . X[m][k..]
+      const bf16x4 x = lds4(&Xs[r][8 * s + 4 * hh]);
+      mma(acc[0], lds4(&Ws[64 * wave + r][8 * s + 4 * hh]), x);
+      mma(acc[1], lds4(&Ws[64 * wave + 32 + r][8 * s + 4 * hh]), x);
+    }
+    __syncthreads();                                             // every wave is done with Xs / Ws
+    const int m = mb + r;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n0 = 64 * wave + 32 * blk + 8 * g + 4 * hh;
+        const uint2 bb = *reinterpret_cast<const uint2 *>(bias + n0);
+        float v[4] = {acc[blk][4 * g] + bf_lo(bb.x), acc[blk][4 * g + 1] + bf_hi(bb.x), acc[blk][4 * g + 2] + bf_lo(bb.y), acc[blk][4 * g + 3] + bf_hi(bb.y)};
+        if (layer < 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+          *reinterpret_cast<bf16x4 *>(&Xs[r][n0]) = pack4(v[0], v[1], v[2], v[3]);     // the next layer's input (rounded like a bf16 Linear's output)
+        } else if (m < R) {
+          const int q = m / B, b = m - q * B, Q = R / B;         // rounded to bf16 like the Linear's output, then widened
+          *reinterpret_cast<float4 *>(ef + ((int64_t)b * Q + q) * 256 + n0) =
+              make_float4(bf_lo(pk_bf16(v[0], 0.f)), bf_lo(pk_bf16(v[1], 0.f)), bf_lo(pk_bf16(v[2], 0.f)), bf_lo(pk_bf16(v[3], 0.f)));
+        }
+      }
+    // (the next layer's weight stores are followed by a barrier before anyone reads Xs again)
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ dX = dY W
 template <bool ACC, bool MASK>
 __global__ __launch_bounds__(256) void sgemm_nn(const bf16_t *__restrict__ dY, const bf16_t *__restrict__ W,
@@ -620,6 +711,22 @@ extern "C" int pd_sgemm_tn_bf16(const void *X, const void *W, const void *bias, 
   if (relu) hipLaunchKernelGGL(sgemm_tn<true>, g, b, 0, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, M, N, K, ldx, ldw, ldy);
   else hipLaunchKernelGGL(sgemm_tn<false>, g, b, 0, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, M, N, K, ldx, ldw, ldy);
   return pd_check_launch("pd_sgemm_tn_bf16");
+}
+
+extern "C" int pd_decoder_head_bf16(const float *tgt, const float *ln_w, const float *ln_b, float eps, const void *w1, const void *b1, const void *w2,
+                                    const void *b2, const void *w3, const void *b3, float *dec_out, float *mean, float *rstd, float *ef, int R, int B,
+                                    int C, void *stream_)
+{
+  if (R < 0 || B <= 0 || C != 256 || (R % B)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_decoder_head_bf16: R=%d B=%d C=%d (C must be 256, R a multiple of B)", R, B, C);
+  if (R == 0) return PD_OK;
+  if (!tgt || !ln_w || !ln_b || !dec_out || !mean || !rstd || (ef && (!w1 || !b1 || !w2 || !b2 || !w3 || !b3)))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_decoder_head_bf16: null pointer");
+  constexpr size_t lds = (size_t)(32 + 256) * PK256 * sizeof(bf16_t);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)decoder_head_256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL(decoder_head_256, dim3((R + 31) / 32), dim3(256), lds, (hipStream_t)stream_, tgt, ln_w, ln_b, eps, (const bf16_t *)w1,
+                     (const bf16_t *)b1, (const bf16_t *)w2, (const bf16_t *)b2, (const bf16_t *)w3, (const bf16_t *)b3, dec_out, mean, rstd, ef, R, B);
+  return pd_check_launch("pd_decoder_head_bf16");
 }
 
 extern "C" int64_t pd_sgemm_split_workspace_floats(int M, int out_cols, int contraction)

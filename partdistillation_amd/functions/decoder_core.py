@@ -96,6 +96,7 @@ def _wgrad(dy, x, out=None, bias_acc=None, queue=None, big=None):
 
 
 GROUP_WGRADS = True   # False: one launch per weight gradient (tools/ comparisons)
+FUSED_HEAD = os.environ.get("PD_FUSED_HEAD", "1") != "0"   # decoder_norm + mask-embedding MLP of a prediction head as one launch (pd_decoder_head_bf16)
 
 
 class _Acc:
@@ -141,8 +142,23 @@ class DecoderCore(Function):
         saved = []
         head_stats = []
 
+        fused_head = (FUSED_HEAD and cdt == torch.bfloat16 and C == 256 and all(tuple(mlp[j].shape) == (256, 256) for j in (0, 2, 4))
+                      and all(mlp[j].is_contiguous() and mlp[j].dtype == torch.bfloat16 for j in range(6)))
+
         def head(i, tgt_f32, lvl):
             """decoder_norm -> dec_outs[i]; the (gradient-free) mask prediction for the next layer's attention"""
+            if fused_head:                                         # LayerNorm + the 3-layer MLP + the batch-major fp32 copy: one launch
+                from .. import lib as _lib
+                stats = torch.empty((2, R), dtype=torch.float32, device=dev)
+                ef = torch.empty((B, Q, C), dtype=torch.float32, device=dev) if lvl is not None else None
+                _lib.check(_lib.load().pd_decoder_head_bf16(tgt_f32.data_ptr(), dn_w.data_ptr(), dn_b.data_ptr(), float(spec.eps), mlp[0].data_ptr(),
+                                                            mlp[1].data_ptr(), mlp[2].data_ptr(), mlp[3].data_ptr(), mlp[4].data_ptr(), mlp[5].data_ptr(),
+                                                            dec_outs[i].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                                                            ef.data_ptr() if ef is not None else None, R, B, C, rw._stream()))
+                head_stats.append((stats[0], stats[1]))
+                if lvl is None:
+                    return None
+                return rw.attn_mask_u8(torch.bmm(ef, spec.pooled[lvl]))
             _, _, d_c, _, mean, rstd = _ln_into(tgt_f32, dn_w, dn_b, spec.eps, dec_outs[i], cdt)
             head_stats.append((mean, rstd))
             if lvl is None:

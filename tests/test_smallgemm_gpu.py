@@ -104,3 +104,35 @@ def test_split_contraction_forms_repeat_and_match_the_single_workgroup_kernels(M
     assert torch.equal(outs[0], outs[1])
     monkeypatch.setattr(sg, "SPLIT", False)
     torch.testing.assert_close(sg.linear(x, w, b, True).float(), ys[0].float(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("Q,B", [(100, 2), (37, 3), (7, 1)])
+def test_fused_decoder_head_matches_layernorm_and_the_three_linears(Q, B):
+    """pd_decoder_head_bf16 = decoder_norm (fp32) + the 3-layer mask-embedding MLP (bf16 operands, bf16 roundings between the layers) +
+    the batch-major fp32 copy, against the kernels it replaces (pd_add_layernorm_fwd + 3 x pd_sgemm_tn_bf16 + transpose)."""
+    import torch.nn.functional as F
+    from partdistillation_amd import lib
+    from partdistillation_amd.functions import smallgemm as sg
+    R, C = Q * B, 256
+    g = torch.Generator(device="cuda").manual_seed(Q)
+    tgt = torch.randn(R, C, device="cuda", generator=g) * 3 + 0.5
+    lw, lb = torch.randn(C, device="cuda", generator=g) * 0.2 + 1, torch.randn(C, device="cuda", generator=g) * 0.1
+    ws = [_r((C, C), 20 + i, C ** -0.5) for i in range(3)]
+    bs = [_r((C,), 30 + i, 0.5) for i in range(3)]
+    dec = torch.empty(R, C, device="cuda"); stats = torch.empty(2, R, device="cuda"); ef = torch.full((B, Q, C), float("nan"), device="cuda")
+    L = lib.load()
+    lib.check(L.pd_decoder_head_bf16(tgt.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-5, ws[0].data_ptr(), bs[0].data_ptr(), ws[1].data_ptr(), bs[1].data_ptr(),
+                                     ws[2].data_ptr(), bs[2].data_ptr(), dec.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ef.data_ptr(), R, B, C,
+                                     lib.current_stream()))
+    ref = F.layer_norm(tgt, (C,), lw, lb, 1e-5)
+    torch.testing.assert_close(dec, ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(stats[0], tgt.mean(1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(stats[1], (tgt.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-5, atol=1e-6)
+    e = sg.linear(sg.linear(sg.linear(dec.bfloat16(), ws[0], bs[0], True), ws[1], bs[1], True), ws[2], bs[2])
+    want = e.view(Q, B, C).transpose(0, 1).float()
+    assert not torch.isnan(ef).any()
+    torch.testing.assert_close(ef, want, rtol=2e-2, atol=2e-2)                     # same roundings, different summation order
+    dec2 = torch.empty(R, C, device="cuda")
+    lib.check(L.pd_decoder_head_bf16(tgt.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-5, None, None, None, None, None, None, dec2.data_ptr(),
+                                     stats[0].data_ptr(), stats[1].data_ptr(), None, R, B, C, lib.current_stream()))
+    assert torch.equal(dec2, dec)
