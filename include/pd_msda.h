@@ -59,6 +59,13 @@ int pd_msda_forward(const void *value, const int64_t *spatial_shapes, const int6
                     int num_query, int num_point, int im2col_step, int dtype, void *stream);
 
 /* replaces MSDA.ms_deform_attn_backward (vision.cpp:21, ms_deform_attn_cuda.cu:89-159) */
+/* pd_msda_forward that also leaves the absolute maximum of every output row (all heads of a query) in row_amax[batch * num_query]
+ * (ZERO-FILLED by the caller; atomic max) — the row-scaling input of pd_gemm_tn_f16x2 (pd_gemm.h) for the output projection that
+ * reads the result.  fp32, channels = 32, 3 levels, 4 points only (the kernel of the hot path); not part of the reference's operator. */
+int pd_msda_forward_amax(const void *value, const int64_t *spatial_shapes, const int64_t *level_start_index, const void *sampling_loc,
+                         const void *attn_weight, void *output, float *row_amax, int batch, int spatial_size, int num_heads, int channels,
+                         int num_levels, int num_query, int num_point, int im2col_step, int dtype, void *stream);
+
 int pd_msda_backward(const void *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
                      const void *sampling_loc, const void *attn_weight, const void *grad_output,
                      void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,

@@ -98,6 +98,9 @@ int pd_msda_prep_fwd(const float *offs, const float *logits, const float *ref, c
 /* d_offs = gloc / (W_l, H_l);  d_logits = attn * (gattn - sum_j attn_j * gattn_j) */
 int pd_msda_prep_bwd(const float *gloc, const float *gattn, const float *attn, const int64_t *spatial_shapes, float *d_offs,
                      float *d_logits, int64_t tokens, int M, int L, int P, int ld_offs, int ld_logits, void *stream);
+/* the same with row_amax[tokens] = max |.| over each token's d_offs and d_logits (8 heads, L P in {8, 12, 16}) for pd_gemm_tn_f16x2 */
+int pd_msda_prep_bwd_amax(const float *gloc, const float *gattn, const float *attn, const int64_t *spatial_shapes, float *d_offs, float *d_logits,
+                          float *row_amax, int64_t tokens, int M, int L, int P, int ld_offs, int ld_logits, void *stream);
 
 /*
  * out[b, p, :] = bilinear sample of in[b] (fp32, channels-last [B, H, W, C], C % 4 == 0) at coords[b, p] = (x, y) in

@@ -104,7 +104,7 @@ template <int L_, int P_>
 __global__ __launch_bounds__(256, 4) void msda_fwd_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
                                                      const int64_t *__restrict__ lvl_start, const float *__restrict__ loc,
                                                      const float *__restrict__ attn, float *__restrict__ out,
-                                                     int S, int M, int Lq, int total_qm)
+                                                     int S, int M, int Lq, int total_qm, unsigned *__restrict__ row_amax)
 {
   const int lb = xcd_chunked_block(blockIdx.x, gridDim.x);
   const int qm = lb * 32 + (threadIdx.x >> 3);
@@ -154,6 +154,13 @@ __global__ __launch_bounds__(256, 4) void msda_fwd_d32(const float *__restrict__
     }
   }
   *reinterpret_cast<float4 *>(out + (int64_t)qm * 32 + sub * 4) = acc;
+  if (row_amax) {
+    // absolute maximum of the output ROW (all heads of the query) for the fp16 two-plane GEMM that reads it (pd_gemm.h): the 8 lanes
+    // of the (query, head) group reduce, one atomic max per group into the zero-filled array (non-negative floats order like their bits)
+    float mx = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+    if (sub == 0 && mx > 0.f) atomicMax(row_amax + qm / M, __float_as_uint(mx));
+  }
 }
 
 // ----------------------------------------------------------------------------------------- fast backward
@@ -882,10 +889,10 @@ int check_common(const void *const *ptrs, int nptr, int batch, int spatial_size,
 
 }  // namespace
 
-extern "C" int pd_msda_forward(const void *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+static int msda_forward_launch(const void *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
                                const void *sampling_loc, const void *attn_weight, void *output, int batch,
                                int spatial_size, int num_heads, int channels, int num_levels, int num_query,
-                               int num_point, int im2col_step, int dtype, void *stream_)
+                               int num_point, int im2col_step, int dtype, void *stream_, float *row_amax)
 {
   const void *ptrs[] = {value, spatial_shapes, level_start_index, sampling_loc, attn_weight, output};
   int rc = check_common(ptrs, 6, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, im2col_step, dtype);
@@ -898,8 +905,9 @@ extern "C" int pd_msda_forward(const void *value, const int64_t *spatial_shapes,
     const int nblocks = round_up8((total_qm + 31) / 32);
     hipLaunchKernelGGL((msda_fwd_d32<3, 4>), dim3(nblocks), dim3(256), 0, stream, (const float *)value, spatial_shapes,
                        level_start_index, (const float *)sampling_loc, (const float *)attn_weight, (float *)output,
-                       spatial_size, num_heads, num_query, (int)total_qm);
+                       spatial_size, num_heads, num_query, (int)total_qm, reinterpret_cast<unsigned *>(row_amax));
   } else {
+    if (row_amax) return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_forward_amax: row maxima come from the fp32, D = 32, L = 3, P = 4 kernel only");
     const int64_t n = total_qm * channels;
     const int nblocks = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
     if (dtype == PD_F32)
@@ -912,6 +920,24 @@ extern "C" int pd_msda_forward(const void *value, const int64_t *spatial_shapes,
                          spatial_size, num_heads, channels, num_levels, num_query, num_point);
   }
   return pd_check_launch("pd_msda_forward");
+}
+
+extern "C" int pd_msda_forward(const void *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                               const void *sampling_loc, const void *attn_weight, void *output, int batch,
+                               int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                               int num_point, int im2col_step, int dtype, void *stream_)
+{
+  return msda_forward_launch(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, output, batch, spatial_size, num_heads, channels,
+                             num_levels, num_query, num_point, im2col_step, dtype, stream_, nullptr);
+}
+
+extern "C" int pd_msda_forward_amax(const void *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                    const void *sampling_loc, const void *attn_weight, void *output, float *row_amax, int batch,
+                                    int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                    int num_point, int im2col_step, int dtype, void *stream_)
+{
+  return msda_forward_launch(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, output, batch, spatial_size, num_heads, channels,
+                             num_levels, num_query, num_point, im2col_step, dtype, stream_, row_amax);
 }
 
 // Which LDS-window backward kernel a launch uses is decided on the HOST from what EARLIER launches measured: every gated launch

@@ -365,16 +365,18 @@ template <int LP4>
 __global__ __launch_bounds__(256) void msda_prep_bwd_v(const float *__restrict__ gloc, const float *__restrict__ gattn,
                                                        const float *__restrict__ attn, const int64_t *__restrict__ shapes,
                                                        float *__restrict__ d_offs, float *__restrict__ d_logits, int64_t total,
-                                                       int M, int L, int P, int ldo, int ldl)
+                                                       int M, int L, int P, int ldo, int ldl, float *__restrict__ row_amax)
 {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
+  const int64_t bq0 = t / M;
   {
-    const int64_t bq = t / M;
+    const int64_t bq = bq0;
     const int m = (int)(t - bq * M);
     d_offs += bq * ldo + (int64_t)m * LP4 * 8 - t * LP4 * 8;
     d_logits += bq * ldl + (int64_t)m * LP4 * 4 - t * LP4 * 4;
   }
+  float amx = 0.f;                                               // row_amax (M == 8 only): max |.| over the token's d_offs and d_logits
   float4 a[LP4], g[LP4];
   float dot = 0.f;
 #pragma unroll
@@ -384,16 +386,24 @@ __global__ __launch_bounds__(256) void msda_prep_bwd_v(const float *__restrict__
     dot += a[i].x * g[i].x; dot += a[i].y * g[i].y; dot += a[i].z * g[i].z; dot += a[i].w * g[i].w;
   }
 #pragma unroll
-  for (int i = 0; i < LP4; ++i)
-    st4(d_logits + (t * LP4 + i) * 4, make_float4(a[i].x * (g[i].x - dot), a[i].y * (g[i].y - dot), a[i].z * (g[i].z - dot),
-                                                  a[i].w * (g[i].w - dot)));
+  for (int i = 0; i < LP4; ++i) {
+    const float4 o = make_float4(a[i].x * (g[i].x - dot), a[i].y * (g[i].y - dot), a[i].z * (g[i].z - dot), a[i].w * (g[i].w - dot));
+    st4(d_logits + (t * LP4 + i) * 4, o);
+    amx = fmaxf(amx, amax4(o));
+  }
   const int half = P / 2;
 #pragma unroll
   for (int i = 0; i < 2 * LP4; ++i) {
     const int l = i / half;
     const float w = (float)shapes[l * 2 + 1], h = (float)shapes[l * 2];
     const float4 o = ld4(gloc + (t * 2 * LP4 + i) * 4);
-    st4(d_offs + (t * 2 * LP4 + i) * 4, make_float4(o.x / w, o.y / h, o.z / w, o.w / h));
+    const float4 r = make_float4(o.x / w, o.y / h, o.z / w, o.w / h);
+    st4(d_offs + (t * 2 * LP4 + i) * 4, r);
+    amx = fmaxf(amx, amax4(r));
+  }
+  if (row_amax) {                                                // the 8 heads of a token are 8 consecutive lanes
+    amx = fmaxf(amx, __shfl_xor(amx, 1, 64)); amx = fmaxf(amx, __shfl_xor(amx, 2, 64)); amx = fmaxf(amx, __shfl_xor(amx, 4, 64));
+    if ((threadIdx.x & 7) == 0) row_amax[bq0] = amx;
   }
 }
 
@@ -876,9 +886,11 @@ extern "C" int pd_msda_prep_fwd(const float *offs, const float *logits, const fl
   return pd_check_launch("pd_msda_prep_fwd");
 }
 
-extern "C" int pd_msda_prep_bwd(const float *gloc, const float *gattn, const float *attn, const int64_t *spatial_shapes, float *d_offs,
-                                float *d_logits, int64_t tokens, int M, int L, int P, int ld_offs, int ld_logits, void *stream_)
+static int msda_prep_bwd_launch(const float *gloc, const float *gattn, const float *attn, const int64_t *spatial_shapes, float *d_offs,
+                                float *d_logits, int64_t tokens, int M, int L, int P, int ld_offs, int ld_logits, void *stream_, float *row_amax)
 {
+  if (row_amax && (M != 8 || (P & 1) || (L * P != 12 && L * P != 16 && L * P != 8)))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_bwd_amax: row maxima need 8 heads and L P in {8, 12, 16} (the vector kernels)");
   if (ld_offs < M * L * P * 2 || ld_logits < M * L * P || (ld_offs & 3) || (ld_logits & 3))
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_bwd: row strides %d / %d (>= row length, multiples of 4)", ld_offs, ld_logits);
   if (tokens < 0 || M <= 0 || L <= 0 || P <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_prep_bwd: tokens=%lld M=%d L=%d P=%d", (long long)tokens, M, L, P);
@@ -888,13 +900,25 @@ extern "C" int pd_msda_prep_bwd(const float *gloc, const float *gattn, const flo
   const dim3 g((unsigned)((total + 255) / 256)), b(256);
   hipStream_t s = (hipStream_t)stream_;
   const int LP = L * P;
-#define LAUNCH(KER) hipLaunchKernelGGL(KER, g, b, 0, s, gloc, gattn, attn, spatial_shapes, d_offs, d_logits, total, M, L, P, ld_offs, ld_logits)
+#define LAUNCH(KER) hipLaunchKernelGGL(KER, g, b, 0, s, gloc, gattn, attn, spatial_shapes, d_offs, d_logits, total, M, L, P, ld_offs, ld_logits, row_amax)
   if ((P & 1) == 0 && LP == 12) LAUNCH(msda_prep_bwd_v<3>);
   else if ((P & 1) == 0 && LP == 16) LAUNCH(msda_prep_bwd_v<4>);
   else if ((P & 1) == 0 && LP == 8) LAUNCH(msda_prep_bwd_v<2>);
-  else LAUNCH(msda_prep_bwd);
+  else hipLaunchKernelGGL(msda_prep_bwd, g, b, 0, s, gloc, gattn, attn, spatial_shapes, d_offs, d_logits, total, M, L, P, ld_offs, ld_logits);
 #undef LAUNCH
   return pd_check_launch("pd_msda_prep_bwd");
+}
+
+extern "C" int pd_msda_prep_bwd(const float *gloc, const float *gattn, const float *attn, const int64_t *spatial_shapes, float *d_offs,
+                                float *d_logits, int64_t tokens, int M, int L, int P, int ld_offs, int ld_logits, void *stream_)
+{
+  return msda_prep_bwd_launch(gloc, gattn, attn, spatial_shapes, d_offs, d_logits, tokens, M, L, P, ld_offs, ld_logits, stream_, nullptr);
+}
+
+extern "C" int pd_msda_prep_bwd_amax(const float *gloc, const float *gattn, const float *attn, const int64_t *spatial_shapes, float *d_offs,
+                                     float *d_logits, float *row_amax, int64_t tokens, int M, int L, int P, int ld_offs, int ld_logits, void *stream_)
+{
+  return msda_prep_bwd_launch(gloc, gattn, attn, spatial_shapes, d_offs, d_logits, tokens, M, L, P, ld_offs, ld_logits, stream_, row_amax);
 }
 
 extern "C" int pd_point_sample_nhwc_f32(const float *in, const float *coords, float *out, int B, int H, int W, int C, int P,

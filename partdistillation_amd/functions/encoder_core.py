@@ -47,15 +47,35 @@ def msda_prep_fwd(offs, logits, ref, shapes, M, L, P):
     return loc, attn
 
 
-def msda_prep_bwd(gloc, gattn, attn, shapes, tokens, M, L, P, out=None):
-    """-> (d_offs, d_logits); with `out` [tokens, 3*M*L*P] they are its column ranges [0, 2MLP) and [2MLP, 3MLP)"""
+def msda_prep_bwd(gloc, gattn, attn, shapes, tokens, M, L, P, out=None, amax=None):
+    """-> (d_offs, d_logits); with `out` [tokens, 3*M*L*P] they are its column ranges [0, 2MLP) and [2MLP, 3MLP).
+    amax [tokens] fp32: receives max |.| of every token's row of `out` (pd_msda_prep_bwd_amax; 8 heads, L P in {8, 12, 16})"""
     n = M * L * P
     if out is None:
         out = torch.empty((tokens, 3 * n), dtype=torch.float32, device=attn.device)
     d_offs, d_logits = out[:, :2 * n], out[:, 2 * n:]
+    if amax is not None:
+        _lib.check(_lib.load().pd_msda_prep_bwd_amax(gloc.data_ptr(), gattn.data_ptr(), attn.data_ptr(), shapes.data_ptr(), d_offs.data_ptr(),
+                                                     d_logits.data_ptr(), amax.data_ptr(), tokens, M, L, P, out.stride(0), out.stride(0), rw._stream()))
+        return d_offs, d_logits
     _lib.check(_lib.load().pd_msda_prep_bwd(gloc.data_ptr(), gattn.data_ptr(), attn.data_ptr(), shapes.data_ptr(), d_offs.data_ptr(),
                                             d_logits.data_ptr(), tokens, M, L, P, out.stride(0), out.stride(0), rw._stream()))
     return d_offs, d_logits
+
+
+def prep_amax_supported(M, L, P):
+    return M == 8 and P % 2 == 0 and L * P in (8, 12, 16)
+
+
+def msda_forward_amax(value, shapes, lsi, loc, attn, im2col_step, row_amax):
+    """MSDA.ms_deform_attn_forward that also leaves the absolute maxima of the output rows in `row_amax` [B * S] (zero-filled by the
+    caller; pd_msda_forward_amax: fp32, 32 channels per head, 3 levels, 4 points)"""
+    B, S, M, D = value.shape
+    Lq, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
+    out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    _lib.check(_lib.load().pd_msda_forward_amax(value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(), attn.data_ptr(), out.data_ptr(),
+                                                row_amax.data_ptr(), B, S, M, D, L, Lq, P, int(im2col_step), _lib.PD_F32, rw._stream()))
+    return out
 
 
 class EncoderSpec:
@@ -164,7 +184,9 @@ class EncoderCore(Function):
         b_oa_all = torch.cat([P_(i, j) for i in range(nl) for j in (1, 3)]).view(nl, n_off + n_aw)
         l2_all = torch.cat([P_(i, 12) for i in range(nl)])                                  # [nl * C, ffn]
         l2_am = row_amax(l2_all)
-        h_am_all = torch.zeros((nl, T), dtype=torch.float32, device=src2.device)           # atomic-max targets of the FFN epilogues
+        fwd_amax = C // M == 32 and L == 3 and P == 4 and src2.dtype == torch.float32       # the MSDA kernel that can emit its rows' maxima
+        zam = torch.zeros((2 * nl if fwd_amax else nl, T), dtype=torch.float32, device=src2.device)   # atomic-max targets: FFN epilogues, MSDA outputs
+        h_am_all, a_am_all = zam[:nl], (zam[nl:] if fwd_amax else None)
         x, x_am, q_am = src2, row_amax(src2), row_amax(q)
         saved, saved_am = [], []
         for i in range(nl):
@@ -179,8 +201,12 @@ class EncoderCore(Function):
             oa = gemm_tn_h2(q, w_oa, b_oa_all[i], a_amax=q_am, b_amax=oa_wam)           # [T, 2MLP + MLP]
             loc, attn = msda_prep_fwd(oa[:, :n_off], oa[:, n_off:], ref, spec.shapes, M, L, P)
             v4, loc6, attn5 = value.view(B, S, M, C // M), loc.view(B, S, M, L, P, 2), attn.view(B, S, M, L, P)
-            a = _timed("fwd", MSDA.ms_deform_attn_forward, v4, spec.shapes, spec.lsi, loc6, attn5, spec.im2col_step).view(T, C)
-            a_am = row_amax(a)
+            if fwd_amax:
+                a_am = a_am_all[i]
+                a = _timed("fwd", msda_forward_amax, v4, spec.shapes, spec.lsi, loc6, attn5, spec.im2col_step, a_am).view(T, C)
+            else:
+                a = _timed("fwd", MSDA.ms_deform_attn_forward, v4, spec.shapes, spec.lsi, loc6, attn5, spec.im2col_step).view(T, C)
+                a_am = row_amax(a)
             z1, y1, _, _, m1, r1, y1_am, _ = rw.add_ln_fwd(gemm_tn_h2(a, op_c, op_b, a_amax=a_am, b_amax=op_wam), x, n1_w, n1_b, spec.eps, amax=True)
             h_am = h_am_all[i]
             if h2_bits_supported(T, n_l1):
@@ -283,9 +309,13 @@ class EncoderCore(Function):
                 da = gemm_tn_h2(dz1, op_t[i], a_amax=dz1_am, b_amax=op_tam[i]).view(B, S, C)
                 gv, gloc, gattn = _timed("bwd", MSDA.ms_deform_attn_backward, v4, spec.shapes, spec.lsi, loc6, attn5, da, spec.im2col_step)
                 d_oa = torch.empty((T, w_oa.shape[0]), dtype=torch.float32, device=dev)
-                msda_prep_bwd(gloc, gattn, attn5, spec.shapes, T, M, L, P, out=d_oa)
+                if prep_amax_supported(M, L, P):
+                    d_oa_am = torch.empty(T, dtype=torch.float32, device=dev)
+                    msda_prep_bwd(gloc, gattn, attn5, spec.shapes, T, M, L, P, out=d_oa, amax=d_oa_am)
+                else:
+                    msda_prep_bwd(gloc, gattn, attn5, spec.shapes, T, M, L, P, out=d_oa)
+                    d_oa_am = row_amax(d_oa)
                 g_oaw, g_oab = OA(i)
-                d_oa_am = row_amax(d_oa)
                 wgrad(d_oa, q, g_oaw, g_oab, d_oa_am, q_am)                   # both weight gradients in one split-K GEMM
                 n_off = so_w.shape[0]
                 g_sow, g_aww, g_sob, g_awb = g_oaw[:n_off], g_oaw[n_off:], g_oab[:n_off], g_oab[n_off:]

@@ -224,6 +224,28 @@ def test_msda_prep_fwd_bwd_vs_torch(L, P):
     ((loc_r * gloc).sum() + (attn_r * gattn).sum()).backward()
     torch.testing.assert_close(d_offs, ot.grad, rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(d_logits, lt.grad, rtol=1e-4, atol=1e-6)
+    from partdistillation_amd.functions.encoder_core import prep_amax_supported
+    if prep_amax_supported(M, L, P):               # the same launch with the rows' absolute maxima (pd_msda_prep_bwd_amax): bit-identical outputs
+        out = torch.empty((T, 3 * M * L * P), dtype=torch.float32, device=DEV)
+        am = torch.full((T,), -1.0, device=DEV)
+        d2, l2 = msda_prep_bwd(gloc, gattn, attn, shapes, T, M, L, P, out=out, amax=am)
+        assert torch.equal(d2, d_offs) and torch.equal(l2, d_logits) and torch.equal(am, out.abs().amax(1))
+
+
+def test_msda_forward_amax_is_the_forward_plus_exact_row_maxima():
+    from partdistillation_amd import MultiScaleDeformableAttention as MSDA
+    from partdistillation_amd.functions.encoder_core import msda_forward_amax
+    B, M, D, L, P = 2, 8, 32, 3, 4
+    shapes = torch.tensor([[6, 9], [12, 18], [24, 36]], dtype=torch.long, device=DEV)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    value = _r((B, S, M, D), 61, 2.0) * torch.logspace(-3, 2, S, device=DEV).view(1, S, 1, 1)
+    loc = torch.rand((B, S, M, L, P, 2), device=DEV, generator=torch.Generator(device=DEV).manual_seed(62)) * 1.2 - 0.1
+    attn = torch.softmax(_r((B, S, M, L * P), 63), -1).view(B, S, M, L, P)
+    want = MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, attn, 64)
+    am = torch.zeros(B * S, device=DEV)
+    got = msda_forward_amax(value, shapes, lsi, loc, attn, 64, am)
+    assert torch.equal(got, want) and torch.equal(am, want.view(B * S, -1).abs().amax(1))
 
 
 def test_fused_encoder_core_matches_module_path():
