@@ -42,6 +42,16 @@ int pd_sgemm_tn_splitk_bf16(const void *X, const void *W, const void *bias, void
 int pd_sgemm_nn_splitn_bf16(const void *dY, const void *W, const void *relu_ref, void *dX, float *workspace, int64_t workspace_floats,
                             int *tickets, int M, int N, int K, int ldy, int ldw, int ldx, int accumulate, void *stream);
 
+/* Up to four independent pd_sgemm_tn_bf16 products with a common K <= 256 (K % 64 == 0) in ONE launch: the q / k / v projections of an
+ * attention block (two inputs, three slices of the packed in_proj weight; reference mask2former_transformer_decoder.py:44-54, 102-114
+ * through nn.MultiheadAttention).  Rows may differ per problem (the cross-attention's keys / values run over the memory tokens). */
+typedef struct PdSgemmTnDesc {
+  const void *X, *W, *bias;   /* bias nullable */
+  void *Y;
+  int32_t M, N, ldx, ldw, ldy;
+} PdSgemmTnDesc;
+int pd_sgemm_tn_multi_bf16(const PdSgemmTnDesc *descs, int count, int K, void *stream);
+
 /* One prediction head of the masked-attention decoder in one launch (reference mask2former_transformer_decoder.py:449-459 +
  * :198-204; the in-loop mask prediction carries no gradient, :457):  dec_out[R,256] = LayerNorm(tgt) in fp32 with mean / rstd [R];
  * when ef != NULL also e = W3 relu(W2 relu(W1 bf16(dec_out) + b1) + b2) + b3 (bf16 weights [256,256] / biases [256], fp32 accumulation,

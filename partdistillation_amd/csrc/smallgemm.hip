@@ -4,6 +4,7 @@
 //   nn     dX = dY W                 the W operand is "4 consecutive n at fixed k": four 16-bit LDS reads
 //   wgrad  dW = dY^T X               both operands are "4 consecutive m at fixed column": 16-bit LDS reads
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdint.h>
 
 #include "mfma_bf16.h"
@@ -138,6 +139,58 @@ __global__ __launch_bounds__(256) void sgemm_tn_k256(const bf16_t *__restrict__ 
     if (RELU) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    *reinterpret_cast<bf16x4 *>(Y + (int64_t)m * ldy + n0) = pack4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// Up to four independent K <= 256 products in ONE launch (blockIdx.z = problem): the q / k / v projections of an attention block read
+// two different inputs and three slices of one packed weight — three 7 us launches (and, for the cross-attention's keys and values
+// over the memory tokens, two library GEMMs) become one.  Same body as sgemm_tn_k256; the problem table travels as a kernel argument.
+struct SgTnMulti {
+  const bf16_t *X[4], *W[4], *bias[4];
+  bf16_t *Y[4];
+  int M[4], N[4], ldx[4], ldw[4], ldy[4];
+};
+__global__ __launch_bounds__(256) void sgemm_tn_k256_multi(const SgTnMulti p, int K)
+{
+  const int z = blockIdx.z;
+  const int M = p.M[z], N = p.N[z];
+  const int nb = blockIdx.x * 128, mb = blockIdx.y * 32;
+  if (nb >= N || mb >= M) return;                                            // the grid covers the largest problem
+  const bf16_t *X = p.X[z], *W = p.W[z], *bias = p.bias[z];
+  bf16_t *Y = p.Y[z];
+  const int ldx = p.ldx[z], ldw = p.ldw[z], ldy = p.ldy[z];
+  extern __shared__ __attribute__((aligned(16))) unsigned char sg_smem[];
+  bf16_t(*Xs)[PK256] = reinterpret_cast<bf16_t(*)[PK256]>(sg_smem);
+  bf16_t(*Ws)[PK256] = reinterpret_cast<bf16_t(*)[PK256]>(sg_smem + 32 * PK256 * sizeof(bf16_t));
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int prow = tid >> 5, pcol = (tid & 31) * 8;
+  uint4 xr[4], wr[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xr[i] = load_piece(X, ldx, mb + prow + 8 * i, pcol, M, K);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wr[i] = load_piece(W, ldw, nb + prow + 8 * i, pcol, N, K);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) store_piece(&Xs[prow + 8 * i][pcol], xr[i]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) store_piece(&Ws[prow + 8 * i][pcol], wr[i]);
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int steps = K / 8;
+  for (int s = 0; s < steps; ++s) mma(acc, lds4(&Ws[32 * wave + r][8 * s + 4 * hh]), lds4(&Xs[r][8 * s + 4 * hh]));
+  const int m = mb + r;
+  if (m >= M) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n0 = nb + 32 * wave + 8 * g + 4 * hh;
+    if (n0 >= N) continue;
+    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    if (bias) {
+      const uint2 b = *reinterpret_cast<const uint2 *>(bias + n0);
+      v[0] += bf_lo(b.x); v[1] += bf_hi(b.x); v[2] += bf_lo(b.y); v[3] += bf_hi(b.y);
     }
     *reinterpret_cast<bf16x4 *>(Y + (int64_t)m * ldy + n0) = pack4(v[0], v[1], v[2], v[3]);
   }
@@ -711,6 +764,29 @@ extern "C" int pd_sgemm_tn_bf16(const void *X, const void *W, const void *bias, 
   if (relu) hipLaunchKernelGGL(sgemm_tn<true>, g, b, 0, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, M, N, K, ldx, ldw, ldy);
   else hipLaunchKernelGGL(sgemm_tn<false>, g, b, 0, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, M, N, K, ldx, ldw, ldy);
   return pd_check_launch("pd_sgemm_tn_bf16");
+}
+
+extern "C" int pd_sgemm_tn_multi_bf16(const PdSgemmTnDesc *d, int count, int K, void *stream_)
+{
+  if (count <= 0 || count > 4 || !d) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_tn_multi_bf16: count=%d (1..4)", count);
+  if (K <= 0 || K > 256 || (K % 64)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_tn_multi_bf16: K=%d must be a multiple of 64, <= 256", K);
+  SgTnMulti p;
+  memset(&p, 0, sizeof(p));
+  int maxm = 0, maxn = 0;
+  for (int i = 0; i < count; ++i) {
+    int rc = check_common("pd_sgemm_tn_multi_bf16", d[i].X, d[i].W, d[i].Y, d[i].M, d[i].N, K, d[i].ldx, d[i].ldw, d[i].ldy);
+    if (rc) return rc;
+    if ((d[i].N & 3) || (d[i].bias && ((uintptr_t)d[i].bias & 7))) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_tn_multi_bf16: N %% 4 / bias alignment");
+    p.X[i] = (const bf16_t *)d[i].X; p.W[i] = (const bf16_t *)d[i].W; p.bias[i] = (const bf16_t *)d[i].bias; p.Y[i] = (bf16_t *)d[i].Y;
+    p.M[i] = d[i].M; p.N[i] = d[i].N; p.ldx[i] = d[i].ldx; p.ldw[i] = d[i].ldw; p.ldy[i] = d[i].ldy;
+    maxm = d[i].M > maxm ? d[i].M : maxm; maxn = d[i].N > maxn ? d[i].N : maxn;
+  }
+  if (maxm == 0 || maxn == 0) return PD_OK;
+  constexpr size_t lds = (size_t)(32 + 128) * PK256 * sizeof(bf16_t);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)sgemm_tn_k256_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL(sgemm_tn_k256_multi, dim3((maxn + 127) / 128, (maxm + 31) / 32, count), dim3(256), lds, (hipStream_t)stream_, p, K);
+  return pd_check_launch("pd_sgemm_tn_multi_bf16");
 }
 
 extern "C" int pd_decoder_head_bf16(const float *tgt, const float *ln_w, const float *ln_b, float eps, const void *w1, const void *b1, const void *w2,

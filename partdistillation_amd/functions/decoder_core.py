@@ -96,6 +96,7 @@ def _wgrad(dy, x, out=None, bias_acc=None, queue=None, big=None):
 
 
 GROUP_WGRADS = True   # False: one launch per weight gradient (tools/ comparisons)
+MULTI_QKV = os.environ.get("PD_MULTI_QKV", "1") != "0"     # the q / k / v projections of an attention block as one launch (pd_sgemm_tn_multi_bf16)
 FUSED_HEAD = os.environ.get("PD_FUSED_HEAD", "1") != "0"   # decoder_norm + mask-embedding MLP of a prediction head as one launch (pd_decoder_head_bf16)
 
 
@@ -174,18 +175,25 @@ class DecoderCore(Function):
             lvl = i % nl
             (ciw, cib, cow, cob, cnw, cnb, siw, sib, sow, sob, snw, snb, w1, b1, w2, b2, fnw, fnb) = layers[i]
             # ---- masked cross-attention
-            q = _lin(tgtpos_c, ciw[:C], cib[:C])
-            k = _lin(mempos[lvl], ciw[C:2 * C], cib[C:2 * C])
-            v = _lin(mem[lvl], ciw[2 * C:], cib[2 * C:])
+            multi = MULTI_QKV and cdt == torch.bfloat16 and C <= 256 and C % 64 == 0
+            if multi:                                              # q, k, v projections: one launch (two inputs, three weight slices)
+                q, k, v = sg.linear_multi([(tgtpos_c, ciw[:C], cib[:C]), (mempos[lvl], ciw[C:2 * C], cib[C:2 * C]), (mem[lvl], ciw[2 * C:], cib[2 * C:])])
+            else:
+                q = _lin(tgtpos_c, ciw[:C], cib[:C])
+                k = _lin(mempos[lvl], ciw[C:2 * C], cib[C:2 * C])
+                v = _lin(mem[lvl], ciw[2 * C:], cib[2 * C:])
             o, lse = attn_fwd_raw(q, k, v, mask, B, H, scale)
             z, y, y_c, ypos_c, mean, rstd = rw.add_ln_fwd(_lin(o, cow, cob), tgt, cnw, cnb, spec.eps, c_dtype=cdt, want_yc=True,
                                                           pos=qpos, pos_div=B, want_ypos=True)
             cross = (tgtpos_c, q, k, v, mask, o, lse, z, mean, rstd)
             tgt, tgt_c, tgtpos_c = y, y_c, ypos_c
             # ---- self-attention
-            q = _lin(tgtpos_c, siw[:C], sib[:C])
-            k = _lin(tgtpos_c, siw[C:2 * C], sib[C:2 * C])
-            v = _lin(tgt_c, siw[2 * C:], sib[2 * C:])
+            if multi:
+                q, k, v = sg.linear_multi([(tgtpos_c, siw[:C], sib[:C]), (tgtpos_c, siw[C:2 * C], sib[C:2 * C]), (tgt_c, siw[2 * C:], sib[2 * C:])])
+            else:
+                q = _lin(tgtpos_c, siw[:C], sib[:C])
+                k = _lin(tgtpos_c, siw[C:2 * C], sib[C:2 * C])
+                v = _lin(tgt_c, siw[2 * C:], sib[2 * C:])
             o, lse = attn_fwd_raw(q, k, v, None, B, H, scale)
             z, y, y_c, _, mean, rstd = rw.add_ln_fwd(_lin(o, sow, sob), tgt, snw, snb, spec.eps, c_dtype=cdt, want_yc=True)
             slf = (tgtpos_c, tgt_c, q, k, v, o, lse, z, mean, rstd)

@@ -51,6 +51,27 @@ def linear(x, w, b=None, relu=False, out=None):
     return y
 
 
+class _TnDesc(ctypes.Structure):                                     # PdSgemmTnDesc (include/pd_smallgemm.h)
+    _fields_ = [("X", ctypes.c_void_p), ("W", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("Y", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ("M", "N", "ldx", "ldw", "ldy")]
+
+
+def linear_multi(problems):
+    """[(x [M_i,K], w [N_i,K], b | None)] (<= 4, one K <= 256) -> [y_i] as ONE launch (pd_sgemm_tn_multi_bf16)"""
+    K = problems[0][0].shape[1]
+    descs = (_TnDesc * len(problems))()
+    outs = []
+    for d, (x, w, b) in zip(descs, problems):
+        _chk2d(x, w)
+        assert x.shape[1] == K and w.shape[1] == K
+        y = torch.empty((x.shape[0], w.shape[0]), dtype=torch.bfloat16, device=x.device)
+        d.X, d.W, d.bias, d.Y = x.data_ptr(), w.data_ptr(), (b.data_ptr() if b is not None else None), y.data_ptr()
+        d.M, d.N, d.ldx, d.ldw, d.ldy = x.shape[0], w.shape[0], x.stride(0), w.stride(0), y.stride(0)
+        outs.append(y)
+    _lib.check(_lib.load().pd_sgemm_tn_multi_bf16(ctypes.byref(descs), len(problems), K, _stream()))
+    return outs
+
+
 def dgrad(dy, w, relu_ref=None, out=None, accumulate=False):
     """dy [M,N] @ w [N,K] -> [M,K], optionally accumulated into `out` and masked by relu_ref > 0   (N % 64 == 0)"""
     _chk2d(dy, w)

@@ -136,3 +136,20 @@ def test_fused_decoder_head_matches_layernorm_and_the_three_linears(Q, B):
     lib.check(L.pd_decoder_head_bf16(tgt.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-5, None, None, None, None, None, None, dec2.data_ptr(),
                                      stats[0].data_ptr(), stats[1].data_ptr(), None, R, B, C, lib.current_stream()))
     assert torch.equal(dec2, dec)
+
+
+def test_multi_problem_launch_equals_the_single_launches():
+    """pd_sgemm_tn_multi_bf16: the q / k / v projections of an attention block (different inputs, row counts and weight slices) as one
+    launch, bit-identical to pd_sgemm_tn_bf16 on each problem."""
+    from partdistillation_amd.functions import smallgemm as sg
+    C = 256
+    w, b = _r((3 * C, C), 40, C ** -0.5), _r((3 * C,), 41)
+    xq, xk, xv = _r((200, C), 42), _r((2 * 4096, C), 43), _r((2 * 4096 + 5, C), 44)
+    probs = [(xq, w[:C], b[:C]), (xk, w[C:2 * C], b[C:2 * C]), (xv, w[2 * C:], None)]
+    got = sg.linear_multi(probs)
+    for y, (x, ww, bb) in zip(got, probs):
+        assert torch.equal(y, sg.linear(x, ww, bb))
+        ref = x.float() @ ww.float().t() + (bb.float() if bb is not None else 0)
+        torch.testing.assert_close(y.float(), ref, rtol=1e-2, atol=1e-2)
+    one = sg.linear_multi(probs[:1])
+    assert torch.equal(one[0], got[0])
