@@ -451,7 +451,7 @@ def main():
             for kind in sorted({f[2] for _, f in wgrad}):
                 sel = [(t, f) for t, f in wgrad if f[2] == kind]
                 nprod = 3.0 if kind.startswith("h2") else 6.0 if kind.startswith("x3") else 1.0
-                name = {"h2 grouped": "gemm_wgrad_f32x3_tr_grouped<f16x2> (+ wgrad_tr_reduce_grouped)", "h2": "gemm_wgrad_f32x3_tr<f16x2> (+ wgrad_tr_reduce)",
+                name = {"h2 grouped": "gemm_wgrad_f16x2_wide_grouped / gemm_wgrad_f32x3_tr_grouped<f16x2> (+ their reduces)", "h2": "gemm_wgrad_f32x3_tr<f16x2> (+ wgrad_tr_reduce)",
                         "x3 grouped": "gemm_wgrad_f32x3_tr_grouped (+ wgrad_tr_reduce_grouped)", "x3": "gemm_wgrad_f32x3_tr (+ wgrad_tr_reduce)"}.get(kind, kind)
                 kernels.append(gemm_entry(name, sel, nprod, "avg_ms includes the partial-tile reduce launch"))
         for lab in sorted({f[1] for _, f in x3fwd}):   # fp32 forward / input-gradient products on the 16-bit matrix cores, per kernel and shape

@@ -35,7 +35,7 @@ def _raw(x, wk, bias, co, x_amax=None):
     from .gemm import _timed_fwd, row_amax
     if x_amax is not None:
         w_amax = row_amax(wk.view(co, -1))
-        with _timed_fwd(2.0 * B * H * W * 9 * ci * co, f"gemm_tn_f16x2<256x256, conv 3x3> {co}<-9x{ci} M={B * H * W}", 4.0 * (B * H * W * (ci + co) + 9 * ci * co)):
+        with _timed_fwd(2.0 * B * H * W * 9 * ci * co, "gemm_tn_f16x2<256, 256, 128, 16, 0, conv 3x3>", 4.0 * (B * H * W * (ci + co) + 9 * ci * co)):
             _lib.check(_lib.load().pd_conv3x3_nhwc_f16x2(x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                                                          x_amax.data_ptr(), w_amax.data_ptr(), None, B, H, W, ci, co, _lib.current_stream()))
         return y

@@ -24,15 +24,16 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     assert len(fwd) == len(lab["fwd"]), (len(fwd), len(lab["fwd"]))
     for r, l in zip(fwd, lab["fwd"]):                       # dispatch order = the order the driver issued them in
         res[l][c].append(float(r["Counter_Value"]))
-    g = [r for r in rows if re.search(r"gemm_wgrad_f32x3_tr_grouped|wgrad_tr_reduce_grouped", r["Kernel_Name"])]
-    for i in range(0, len(g), 2):                           # main kernel + its reduce: one bench.py "kernel"
-        res["gemm_wgrad_f32x3_tr_grouped<f16x2> (+ wgrad_tr_reduce_grouped)"][c].append(sum(float(r["Counter_Value"]) for r in g[i:i + 2]))
+    g = [r for r in rows if re.search(r"gemm_wgrad_f32x3_tr_grouped|wgrad_tr_reduce_grouped|gemm_wgrad_f16x2_wide_grouped|wgrad_h2w_reduce_grouped", r["Kernel_Name"])]
+    for i in range(0, len(g), 4):                           # the layer's five weight gradients: wide group + narrow group, each with its reduce
+        # bench.py times the step's TWO grouped launches (6 layers' problems, wide and narrow tiles) and reports the average of the two
+        res["gemm_wgrad_f16x2_wide_grouped / gemm_wgrad_f32x3_tr_grouped<f16x2> (+ their reduces)"][c].append(0.5 * sum(float(r["Counter_Value"]) for r in g[i:i + 4]))
 summary = {}
 for k, d in res.items():
     f, w = d.get("FETCH_SIZE", []), d.get("WRITE_SIZE", [])
     summary[k] = {"launches": max(len(f), len(w)), "FETCH_SIZE_KB_avg_per_launch": sum(f) / max(len(f), 1), "WRITE_SIZE_KB_avg_per_launch": sum(w) / max(len(w), 1),
                   "hbm_bytes_corrected_avg_per_launch": (2 * sum(f) / max(len(f), 1) + sum(w) / max(len(w), 1)) * 1024,
-                  "note": "FETCH_SIZE x 2 (gfx950 counts 64-byte units as 32: MI355X_MICROARCH.md) + WRITE_SIZE, KB -> bytes; the grouped weight-gradient entry is the driver's 5-problem layer (1/6 of the step's launch)"}
+                  "note": "FETCH_SIZE x 2 (gfx950 counts 64-byte units as 32: MI355X_MICROARCH.md) + WRITE_SIZE, KB -> bytes; averages over the mix one encoder layer issues (tools/pmc_gemm_driver.py)"}
     print(k, summary[k])
 json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
 PY

@@ -1,6 +1,7 @@
-"""The fp32 GEMM kernels of the pixel decoder (fp16 two-plane form) at the encoder's shapes (BASELINE config 2: 43 008 tokens) and the
-3 x 3 FPN convolution, a few launches each, for the rocprofv3 PMC passes of tools/pmc_gemm.sh (HBM bytes per launch next to the
-algorithmic bytes).  Writes the sequence of bench.py kernel labels it issued to $PMC_LABELS (one per library call, in order)."""
+"""The fp32 GEMM kernels of the pixel decoder (fp16 two-plane form) in the mix ONE encoder layer issues them at BASELINE config 2 (43 008
+tokens; forward + backward: 10 forward / input-gradient GEMMs, the five weight gradients as the two grouped launches) and the 3 x 3 FPN
+convolution, for the rocprofv3 PMC passes of tools/pmc_gemm.sh (HBM bytes per launch next to the algorithmic bytes).  Writes the
+sequence of bench.py kernel labels it issued to $PMC_LABELS (one per library call, in order)."""
 import json, os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -18,18 +19,19 @@ col = torch.zeros(1024, device="cuda")
 img = torch.randn(2, 256, 256, 256, device="cuda").contiguous(memory_format=torch.channels_last)
 wk = (torch.randn(256, 256, 3, 3, device="cuda") * 0.02).contiguous(memory_format=torch.channels_last)
 gemm.enable_timing(True)
-labels = []
+g = lambda a, n, k, bias=None, **kw: gemm.gemm_tn_h2(x[a], w[(n, k)], bias, a_amax=am[a], b_amax=wam[(n, k)], **kw)
 for it in range(int(os.environ.get("ITERS", "3"))):
-    h, bits = gemm.gemm_tn_h2(x[256], w[(1024, 256)], b1024, mode=1, want_bits=True, a_amax=am[256], b_amax=wam[(1024, 256)])   # linear1 + ReLU
-    gemm.gemm_tn_h2(x[1024], w[(256, 1024)], b256, a_amax=am[1024], b_amax=wam[(256, 1024)])                                   # linear2
-    gemm.gemm_tn_h2(x[256], w[(1024, 256)], None, mode=2, bits=bits, colsum=col, a_amax=am[256], b_amax=wam[(1024, 256)])      # d(hidden), masked
-    gemm.gemm_tn_h2(x[256], w[(256, 256)], b256, a_amax=am[256], b_amax=wam[(256, 256)])                                       # a 256-wide projection
-    gemm.gemm_tn_h2(x[256], w[(288, 256)], None, a_amax=am[256], b_amax=wam[(288, 256)])                                       # offsets + weights
+    g(256, 256, 256, b256); g(256, 288, 256); g(256, 256, 256, b256)              # forward: value, offsets + weights, output projection
+    h, bits = g(256, 1024, 256, b1024, mode=1, want_bits=True)                     # linear1 + ReLU (+ sign bits)
+    g(1024, 256, 1024, b256)                                                       # linear2
+    g(256, 1024, 256, mode=2, bits=bits, colsum=col)                               # backward: d(hidden), masked
+    g(1024, 256, 1024)                                                             # d(FFN input)
+    g(256, 256, 256); g(288, 256, 288); g(256, 256, 256)                           # d(attention output), d(query), d(value input)
     conv_x3._raw(img, wk.permute(0, 2, 3, 1).contiguous(), None, 256, conv_x3._pixel_amax(img))
-    q = gemm.WgradQueue(h2=True)                                                  # the layer's five weight gradients, grouped
-    for dy, xx in ((256, 1024), (1024, 256), (256, 256), (288, 256), (256, 256)):
-        q.add(x[dy], x[xx], torch.zeros(dy, xx, device="cuda"), None, am[dy], am[xx])
+    q = gemm.WgradQueue(h2=True)                                                   # the five weight gradients of SIX layers, as the step queues
+    for layer in range(6):                                                         # them: two grouped launches (wide / narrow tiles) + their reduces
+        for dy, xx in ((256, 1024), (1024, 256), (256, 256), (288, 256), (256, 256)):
+            q.add(x[dy], x[xx], torch.zeros(dy, xx, device="cuda"), None, am[dy], am[xx])
     q.flush()
 torch.cuda.synchronize()
-fw = [f[1] for _, f in gemm.timing("fwd")]
-json.dump({"fwd": fw, "wgrad_grouped_every": 6}, open(os.environ.get("PMC_LABELS", "/tmp/pmc_labels.json"), "w"))
+json.dump({"fwd": [f[1] for _, f in gemm.timing("fwd")]}, open(os.environ.get("PMC_LABELS", "/tmp/pmc_labels.json"), "w"))
