@@ -45,7 +45,7 @@ __global__ __launch_bounds__((TM / 64) * (TN / WN) * 64, (TM == 256 ? 1 : 2))
 void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ bias, float *__restrict__ C,
                    int M, int N, int K, int lda, int ldb, int ldc, int ntiles_n, uint32_t *__restrict__ bits,
                    float *__restrict__ colsum, const float *__restrict__ a_amax, const float *__restrict__ b_amax,
-                   unsigned *__restrict__ c_amax, int H, int W)
+                   unsigned *__restrict__ c_amax, int H, int W, int tap_minor)
 {
   constexpr int WVN = TN / WN, NW = (TM / 64) * WVN, NTH = NW * 64, NJ = WN / 32;
   constexpr int TPR = BKK / 4, RPP = NTH / TPR, APASS = TM / RPP, BPASS = TN / RPP, NPAN = BKK / 8;
@@ -97,8 +97,16 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
   }
   auto gload = [&](int rs, int k0) {
     const int k = k0 + lk;
-    int dy = 0, dx = 0, kc = k;
-    if (CONV) { const int tap = k / lda; kc = k - tap * lda; dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+    int dy = 0, dx = 0, kc = k, kb = k;                            // kc: channel of A, kb: column of B
+    if (CONV) {
+      // contraction order (channel block, tap), NOT (tap, channel): the nine taps of a 16-channel block re-touch the same three pixel
+      // rows within nine steps, while they are still in the XCD's L2.  In (tap, channel) order a tap pass streams the whole 256 KB x 32
+      // workgroups before the next tap comes back to the same lines: every tap was a fabric fetch (PMC: 1.37 GB per launch for 0.27 GB).
+      int tap;
+      if (tap_minor) { const int s = k0 / BKK; const int cb = s / 9; tap = s - cb * 9; kc = cb * BKK + lk; kb = tap * lda + kc; }
+      else { tap = k / lda; kc = k - tap * lda; }
+      dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1;
+    }
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
       const int r = lr + RPP * j;
@@ -113,7 +121,7 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
 #pragma unroll
     for (int j = 0; j < BPASS; ++j) {
       const int r = lr + RPP * j;
-      rb[rs][j] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4 *>(B + (int64_t)(n0 + r) * ldb + k) : make_float4(0, 0, 0, 0);
+      rb[rs][j] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4 *>(B + (int64_t)(n0 + r) * ldb + kb) : make_float4(0, 0, 0, 0);
     }
   };
   auto lstore = [&](int rs, int buf) {
@@ -284,14 +292,14 @@ static int launch_f16x2(const float *A, const float *B, const float *bias, float
   constexpr size_t lds = (stage > red ? stage : red) + (size_t)2 * (TM + TN) * sizeof(float);
   const int tn = (N + TN - 1) / TN, tm = (M + TM - 1) / TM;
   typedef void (*kfn)(const float *, const float *, const float *, float *, int, int, int, int, int, int, int, uint32_t *, float *, const float *,
-                      const float *, unsigned *, int, int);
+                      const float *, unsigned *, int, int, int);
   const kfn k = CONV ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 0, CONV, NRS>
                      : mode == 0 ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 0, false, NRS> : mode == 1 ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 1, false, NRS>
                                                                                                   : (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 2, false, NRS>;
   static bool attr[3] = {false, false, false};
   if (!attr[mode]) { (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[mode] = true; }
   hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)tm * tn)), dim3(NTH), lds, st, A, B, bias, C, M, N, K, lda, ldb, ldc, tn, bits, colsum, a_amax,
-                     b_amax, reinterpret_cast<unsigned *>(c_amax), H, W);
+                     b_amax, reinterpret_cast<unsigned *>(c_amax), H, W, g_pd_dbg_f16x2 == 21 ? 0 : 1);
   return pd_check_launch("pd_gemm_tn_f16x2");
 }
 
