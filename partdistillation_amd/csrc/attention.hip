@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t *__restrict__ 
                                                      const bf16_t *__restrict__ o, const bf16_t *__restrict__ d_o,
                                                      const float *__restrict__ lse, float *__restrict__ part_dq,
                                                      bf16_t *__restrict__ dq, bf16_t *__restrict__ dk, bf16_t *__restrict__ dv,
-                                                     int B, int H, int Lq, int Lk, float scale, int nchunk)
+                                                     int B, int H, int Lq, int Lk, float scale, int nchunk, int kc)
 {
   __shared__ __attribute__((aligned(16))) bf16_t Qs[MQ][LR];
   __shared__ __attribute__((aligned(16))) bf16_t Os[MQ][LR];          // dO rows
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t *__restrict__ 
     }
   }
   __syncthreads();
-  const int kbeg = chunk * KC_DQ, kend = min(Lk, kbeg + KC_DQ);
+  const int kbeg = chunk * kc, kend = min(Lk, kbeg + kc);          // kc keys per workgroup (128 / 256 / 512: see mfma_bwd_chunk)
   const int ntile = (kend - kbeg + 31) / 32;
   const int nsub = (Lq + 31) / 32;
   const bool aligned = (Lk & 3) == 0;
@@ -585,6 +585,16 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t *__restrict__ 
         kreg[s] = *reinterpret_cast<const bf16x4 *>(k + off);
         vreg[s] = *reinterpret_cast<const bf16x4 *>(v + off);
       }
+    }
+    // the mask bytes of this round's 4 query sub-tiles x 4 key groups, all in flight together and under the barriers below: read where
+    // they are used (one dependent 4-byte load per key group) they were up to 16 global-load latencies in a row per round
+    unsigned m4s[4][4];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      const int ql = 32 * sub + r;
+      const uint8_t *mrow = (MASK && tvalid && sub < nsub && ql < Lq) ? mask + ((int64_t)b * Lq + ql) * Lk : nullptr;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) m4s[sub][g] = mrow ? mask4(mrow, kbase + 8 * g + 4 * hh, Lk, aligned) : 0u;
     }
     __syncthreads();                                           // previous round's K^T gathers are done
 #pragma unroll
@@ -614,13 +624,12 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t *__restrict__ 
 #pragma unroll
           for (int s = 0; s < 4; ++s) { mma(sT, kreg[s], qreg[s]); mma(dpT, vreg[s], greg[s]); }
           const float lse_q = Ls[ql], delta_q = Ds[ql];
-          const uint8_t *mrow = (MASK && ql < Lq) ? mask + ((int64_t)b * Lq + ql) * Lk : nullptr;
           unsigned mybits = 0;                                 // bit i: query (32*sub + i) may not attend key (kbase + lane%32)
           bf16x4 dsT[4];
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int key0 = kbase + 8 * g + 4 * hh;
-            const unsigned m4 = mrow ? mask4(mrow, key0, Lk, aligned) : 0u;
+            const unsigned m4 = m4s[sub][g];
             float ds[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -698,6 +707,15 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t *__restrict__ 
 }
 
 inline int nchunks(int Lk, int kc) { return Lk <= 0 ? 1 : (Lk + kc - 1) / kc; }
+// keys per workgroup of attn_bwd_mfma: a workgroup walks its keys 128 at a time (4 waves x 32) and a round costs ~15 us whatever the
+// machine's load, so KC_DQ = 512 keys are 4 rounds in a row — fine at 16 384 keys (512 workgroups), wasteful at 1 024 (32 workgroups on
+// 256 CUs).  Fewer keys per workgroup until ~256 workgroups exist: 1 024 keys -> 128 per workgroup (1 round), 4 096 -> 256.
+inline int mfma_bwd_chunk(int B, int H, int Lk)
+{
+  int kc = KC_DQ;
+  while (kc > 128 && (int64_t)B * H * nchunks(Lk, kc) < 256) kc >>= 1;
+  return kc;
+}
 
 int check(const void *a, const void *b, const void *c, int B, int H, int Lq, int Lk, int dtype, const char *who)
 {
@@ -714,7 +732,7 @@ int g_pd_dbg_attn_scalar = 0;     // experiment knob: 1 forces the scalar kernel
 extern "C" int64_t pd_attn_workspace_floats(int B, int H, int Lq, int Lk)
 {
   const int64_t n1 = (int64_t)B * H * nchunks(Lk, KC_FWD) * Lq * (D + 2);
-  const int64_t n2 = (int64_t)B * H * nchunks(Lk, KC_DQ) * Lq * D;
+  const int64_t n2 = (int64_t)B * H * nchunks(Lk, 128) * Lq * D;   // the matrix-core backward may cut the keys as fine as 128 per workgroup
   return (n1 > n2 ? n1 : n2) + 64;
 }
 
@@ -761,18 +779,19 @@ extern "C" int pd_attn_bwd_d32(const void *q, const void *k, const void *v, cons
   if (B * Lq * Lk == 0) return PD_OK;
   if (!o || !d_o || !lse || !dq || !dk || !dv || !workspace) return pd_set_error(PD_ERR_INVALID_ARG, "pd_attn_bwd_d32: null pointer");
   hipStream_t s = (hipStream_t)stream_;
-  const int nc = nchunks(Lk, KC_DQ);
   const int groups = B * H * Lq;
   if (dtype == PD_BF16 && Lq <= MQ && !g_pd_dbg_attn_scalar) {                     // matrix-core path
+    const int kc = mfma_bwd_chunk(B, H, Lk), nc = nchunks(Lk, kc);
     if (mask) hipLaunchKernelGGL(attn_bwd_mfma<true>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
                                  mask, (const bf16_t *)o, (const bf16_t *)d_o, lse, workspace, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv,
-                                 B, H, Lq, Lk, scale, nc);
+                                 B, H, Lq, Lk, scale, nc, kc);
     else hipLaunchKernelGGL(attn_bwd_mfma<false>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
                             mask, (const bf16_t *)o, (const bf16_t *)d_o, lse, workspace, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv,
-                            B, H, Lq, Lk, scale, nc);
+                            B, H, Lq, Lk, scale, nc, kc);
     if (nc > 1) hipLaunchKernelGGL(attn_bwd_dq_reduce<bf16_t>, dim3((groups + 7) / 8), dim3(256), 0, s, workspace, (bf16_t *)dq, B, H, Lq, nc);
     return pd_check_launch("pd_attn_bwd_d32");
   }
+  const int nc = nchunks(Lk, KC_DQ);
   if (dtype == PD_BF16) {
     for (int qp = 0; qp * QP < Lq; ++qp)
       hipLaunchKernelGGL(attn_bwd_dq<bf16_t>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
