@@ -159,7 +159,14 @@ __global__ __launch_bounds__(256, 4) void msda_fwd_d32(const float *__restrict__
     // of the (query, head) group reduce, one atomic max per group into the zero-filled array (non-negative floats order like their bits)
     float mx = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
     mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
-    if (sub == 0 && mx > 0.f) atomicMax(row_amax + qm / M, __float_as_uint(mx));
+    if (M == 8) {
+      // a wavefront's eight groups are the eight heads of ONE query (32 groups per block, total a multiple of 8): reduce across them
+      // and store — eight atomics of one wave instruction on one address serialise (they cost this kernel 35 us per launch)
+      mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if ((threadIdx.x & 63) == 0) row_amax[qm / M] = __float_as_uint(mx);
+    } else if (sub == 0 && mx > 0.f) {
+      atomicMax(row_amax + qm / M, __float_as_uint(mx));
+    }
   }
 }
 
