@@ -169,12 +169,12 @@ def cpu_baseline(cfg_opts, size, seconds_budget=90.0, threads=None, parity_file=
 # kernel families for the live per-category table (torch.profiler device records).  First match wins.
 _CATEGORIES = [
     ("own_msda", r"^msda_"),
-    ("own_fp32_wgrad_mfma", r"^(gemm_wgrad_f32|wgrad_tr_reduce)"),
+    ("own_fp32_wgrad_mfma", r"^(gemm_wgrad_f32|gemm_wgrad_f16x2|wgrad_tr_reduce|wgrad_h2w_reduce)"),
     ("own_fp32x3_gemm_conv", r"^(gemm_tn_f32|gemm_tn_f16x2|row_amax_f32|gemm_wgrad_f32x3|conv3x3_)"),
     ("own_conv_bf16_filter_grads", r"^conv_(wgrad|igemm)"),
     ("own_attention_mfma", r"^(attn_|wattn_)"),
     ("own_skinny_bf16_gemm", r"^sgemm_"),
-    ("own_rowwise_norm_optim_misc", r"^(add_ln_|colsum_|mem_prep|attn_mask|point_sample|msda_prep|gn_coeffs|affine_act|nc_|multi_gather|"
+    ("own_rowwise_norm_optim_misc", r"^(add_ln_|colsum_|mem_prep|attn_mask|point_sample|msda_prep|gn_coeffs|affine_act|nc_|multi_gather|decoder_head|upsample|"
                                     r"sumsq|adamw|lsa_|swin_ln|kmeans|scores_|mask_assign|resample_|rle_|amax_|quantize_|bn_)"),
     ("library_gemm_fp32", r"^Cijk_.*_S_B"),
     ("library_gemm_bf16", r"^(Cijk_|.*kernel_batched_gemm|.*kernel_gemm)"),
