@@ -19,6 +19,13 @@
 extern "C" {
 #endif
 
+/* 3 x 3, stride 2, pad 1 max pooling of the R50 stem on bf16 NHWC maps [B,H,W,C], C % 8 == 0 (detectron2 BasicStem: F.max_pool2d):
+ * y [B,OH,OW,C] with OH = (H - 1) / 2 + 1; argmax: one byte per output element (8 per 64-bit word, same element order as y) = the
+ * window position 0..8 of the maximum, the FIRST one in row-major window order (ATen's tie rule).  The backward gathers: every
+ * input pixel adds the gradients of the <= 4 windows whose recorded maximum it is. */
+int pd_maxpool3s2_fwd_bf16(const void *x, void *y, void *argmax, int B, int H, int W, int C, void *stream);
+int pd_maxpool3s2_bwd_bf16(const void *dy, const void *argmax, void *dx, int B, int H, int W, int C, void *stream);
+
 /* y = act(x * scale[c] + bias[c] (+ residual)); x, residual (nullable), y: bf16, channels-last (c fastest,
  * `channels` % 8 == 0, n % channels == 0); scale, bias: fp32 [channels]; relu != 0 applies max(.,0). y may alias x. */
 int pd_affine_act_fwd_bf16(const void *x, const void *residual, const float *scale, const float *bias, void *y,

@@ -21,6 +21,86 @@ __device__ __forceinline__ unsigned short f2bf(float f)
   return (unsigned short)(u >> 16);
 }
 
+// ------------------------------------------------------------------------------------------------ stem max pooling
+// 3 x 3, stride 2, pad 1 max pooling of the R50 stem on bf16 NHWC maps (reference: detectron2 BasicStem, F.max_pool2d): the forward
+// also leaves the window position of the maximum (0..8, the FIRST maximum in row-major window order like ATen's kernel: after a ReLU
+// most windows hold ties at 0) as one byte per output element, and the backward is a GATHER — every input pixel looks at the <= 4
+// windows that cover it — instead of ATen's zero-fill + scatter through 8-byte indices (67 MB of indices at 2 x 64 x 512^2).
+__global__ __launch_bounds__(256) void maxpool3s2_fwd(const u16x8 *__restrict__ x, u16x8 *__restrict__ y, unsigned long long *__restrict__ arg,
+                                                      int B, int H, int W, int OH, int OW, int c8)
+{
+  const int64_t total = (int64_t)B * OH * OW * c8, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % c8);
+    int64_t t = i / c8;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float best[8];
+    unsigned pos[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; pos[e] = 0; }
+    bool first = true;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int iy = 2 * oy - 1 + dy, ix = 2 * ox - 1 + dx;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        const u16x8 v = x[(((int64_t)b * H + iy) * W + ix) * c8 + c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = bf2f(v[e]);
+          if (first || f > best[e] || f != f) { best[e] = f; pos[e] = dy * 3 + dx; }       // ATen: (val > max) || isnan(val); first valid tap seeds
+        }
+        first = false;
+      }
+    u16x8 o;
+    unsigned long long a = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o[e] = f2bf(best[e]); a |= (unsigned long long)pos[e] << (8 * e); }
+    y[i] = o;
+    arg[i] = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool3s2_bwd(const u16x8 *__restrict__ dy, const unsigned long long *__restrict__ arg, u16x8 *__restrict__ dx,
+                                                      int B, int H, int W, int OH, int OW, int c8)
+{
+  const int64_t total = (int64_t)B * H * W * c8, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % c8);
+    int64_t t = i / c8;
+    const int ix = (int)(t % W); t /= W;
+    const int iy = (int)(t % H);
+    const int b = (int)(t / H);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // windows oy with 2 oy - 1 <= iy <= 2 oy + 1
+    const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1, ox0 = ix >> 1, ox1 = (ix + 1) >> 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int oy = a ? oy1 : oy0;
+      if ((a && oy1 == oy0) || oy >= OH) continue;
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int ox = bb ? ox1 : ox0;
+        if ((bb && ox1 == ox0) || ox >= OW) continue;
+        const unsigned want = (unsigned)((iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1)));
+        const int64_t o = (((int64_t)b * OH + oy) * OW + ox) * c8 + c;
+        const unsigned long long ar = arg[o];
+        const u16x8 g = dy[o];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (((ar >> (8 * e)) & 0xffu) == want) acc[e] += bf2f(g[e]);
+      }
+    }
+    u16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = f2bf(acc[e]);
+    dx[i] = r;
+  }
+}
+
 template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void affine_act_fwd(const u16x8 *__restrict__ x, const u16x8 *__restrict__ res,
                                                        const float *__restrict__ scale, const float *__restrict__ bias,
@@ -280,6 +360,32 @@ __global__ __launch_bounds__(256) void gn_coeffs_bwd(const double *__restrict__ 
 }
 
 }  // namespace
+
+extern "C" int pd_maxpool3s2_fwd_bf16(const void *x, void *y, void *argmax, int B, int H, int W, int C, void *stream_)
+{
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_maxpool3s2_fwd_bf16: B=%d H=%d W=%d C=%d (%% 8)", B, H, W, C);
+  if (B == 0) return PD_OK;
+  if (!x || !y || !argmax) return pd_set_error(PD_ERR_INVALID_ARG, "pd_maxpool3s2_fwd_bf16: null pointer");
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const int64_t total = (int64_t)B * OH * OW * (C / 8);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(maxpool3s2_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const u16x8 *)x, (u16x8 *)y, (unsigned long long *)argmax, B, H, W,
+                     OH, OW, C / 8);
+  return pd_check_launch("pd_maxpool3s2_fwd_bf16");
+}
+
+extern "C" int pd_maxpool3s2_bwd_bf16(const void *dy, const void *argmax, void *dx, int B, int H, int W, int C, void *stream_)
+{
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_maxpool3s2_bwd_bf16: B=%d H=%d W=%d C=%d (%% 8)", B, H, W, C);
+  if (B == 0) return PD_OK;
+  if (!dy || !dx || !argmax) return pd_set_error(PD_ERR_INVALID_ARG, "pd_maxpool3s2_bwd_bf16: null pointer");
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const int64_t total = (int64_t)B * H * W * (C / 8);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(maxpool3s2_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const u16x8 *)dy, (const unsigned long long *)argmax, (u16x8 *)dx, B, H, W,
+                     OH, OW, C / 8);
+  return pd_check_launch("pd_maxpool3s2_bwd_bf16");
+}
 
 extern "C" int pd_affine_act_fwd_bf16(const void *x, const void *residual, const float *scale, const float *bias, void *y,
                                       int64_t n, int channels, int relu, void *stream_)

@@ -16,6 +16,40 @@ def _nhwc(t):
     return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
 
 
+class MaxPool3x3S2(Function):
+    """F.max_pool2d(x, 3, stride=2, padding=1) on bf16 channels-last maps (the R50 stem) with hand-written kernels: the forward records the
+    window position of the maximum in one byte per element, the backward gathers (pd_maxpool3s2_{fwd,bwd}_bf16)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _nhwc(x)
+        B, C, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((B, C, OH, OW), dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+        arg = torch.empty(B * OH * OW * C, dtype=torch.uint8, device=x.device)
+        _lib.check(_lib.load().pd_maxpool3s2_fwd_bf16(x.data_ptr(), y.data_ptr(), arg.data_ptr(), B, H, W, C, _stream()))
+        ctx.save_for_backward(arg)
+        ctx.dims = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (arg,) = ctx.saved_tensors
+        B, C, H, W = ctx.dims
+        gy = _nhwc(gy)
+        gx = torch.empty((B, C, H, W), dtype=gy.dtype, device=gy.device).contiguous(memory_format=torch.channels_last)
+        _lib.check(_lib.load().pd_maxpool3s2_bwd_bf16(gy.data_ptr(), arg.data_ptr(), gx.data_ptr(), B, H, W, C, _stream()))
+        return gx
+
+
+def max_pool3x3s2_supported(x):
+    return x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last)
+
+
+def max_pool3x3s2(x):
+    return MaxPool3x3S2.apply(x)
+
+
 class AffineAct(Function):
     """y = act(x * scale[c] + bias[c] (+ residual)) on bf16 NCHW-shaped, channels-last-stored tensors; scale/bias are
     constants (frozen BatchNorm), so only x and residual receive gradients."""

@@ -61,6 +61,8 @@ SIGNATURES = {
     "pd_conv_bf16_wgrad_grouped_workspace_floats": (ctypes.c_int64, [_c_vp, _c_int]),
     "pd_conv_bf16_wgrad_grouped": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_vp]),
     "pd_conv_bf16_dgrad": (_c_int, [_c_vp] * 4 + [_c_int] * 10 + [_c_vp]),
+    "pd_maxpool3s2_fwd_bf16": (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),
+    "pd_maxpool3s2_bwd_bf16": (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),
     "pd_affine_act_fwd_bf16": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, _c_int, _c_vp]),
     "pd_affine_act_bwd_bf16": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, _c_int, _c_vp]),
     "pd_affine_act_bwd2_bf16": (_c_int, [_c_vp] * 6 + [ctypes.c_int64, _c_int, _c_int, _c_vp]),

@@ -147,3 +147,22 @@ def test_conv_rejects_what_it_does_not_cover():
         C.conv_fwd(x, w, stride=2, pad=3)
     x, w = _mk((1, 64, 8, 8), 1), _mk((96, 64, 1, 1), 2)
     assert not C.supported(x, w, 1, 0)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 64, 96), (1, 8, 7, 5), (3, 16, 33, 18)])
+def test_own_maxpool_matches_aten_forward_and_backward_including_ties(B, C, H, W):
+    """pd_maxpool3s2_{fwd,bwd}_bf16 vs F.max_pool2d(3, 2, 1) on post-ReLU-like bf16 maps (most windows tie at 0: the gradient must go to
+    the FIRST maximum in window order, as ATen routes it): outputs and input gradients bit-identical."""
+    import torch.nn.functional as F
+    from partdistillation_amd.functions.fused import max_pool3x3s2, max_pool3x3s2_supported
+    g = torch.Generator(device="cuda").manual_seed(H * W)
+    x = torch.randn(B, C, H, W, device="cuda", generator=g).relu().bfloat16().contiguous(memory_format=torch.channels_last)
+    x[:, :, ::3] = 0
+    assert max_pool3x3s2_supported(x)
+    x1, x2 = x.clone().requires_grad_(), x.clone().requires_grad_()
+    y1, y2 = max_pool3x3s2(x1), F.max_pool2d(x2, 3, 2, 1)
+    assert torch.equal(y1, y2)
+    go = torch.randn(y2.shape, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    y1.backward(go); y2.backward(go)
+    torch.testing.assert_close(x1.grad.float(), x2.grad.float(), rtol=1e-2, atol=1e-2)   # up to 4 bf16 addends per pixel: summation order
+    assert torch.equal(x1.grad != 0, x2.grad != 0)
