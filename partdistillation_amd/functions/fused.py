@@ -129,8 +129,10 @@ def affine_act(x, scale, bias, residual=None, relu=True, fork=False):
 
 class PinnedRing:
     """Ring of pinned host staging buffers for small host->device tables that are rewritten every step.  A slot is
-    rewritten only after the async copy that read it has executed (one event per slot): the host may run steps ahead
-    of the device without a later step's table overwriting one still waiting to be copied.
+    rewritten only after the async copy that read it has executed: the host may run steps ahead of the device without a
+    later step's table overwriting one still waiting to be copied.  One event per BLOCK of 8 slots (recorded after the
+    block's last slot, waited for before its first slot is handed out again a lap later) instead of one per upload:
+    the step makes ~45 such uploads and a hipEventRecord costs the host 10-14 us each.
 
     While a hipGraph is being captured the copy becomes a memcpy NODE that re-reads its host buffer at every replay,
     so a ring slot (recycled by later eager uploads) must never back it: acquire() then hands out a DEDICATED pinned
@@ -139,10 +141,13 @@ class PinnedRing:
     (eager) rehearsal step and calls reserve_all() with it."""
     _all = []                                               # weak references to every ring (for reserve_all / counters)
 
-    def __init__(self, shape, dtype, pin, slots=8):
+    BLOCK = 8
+
+    def __init__(self, shape, dtype, pin, slots=32):
         import weakref
+        assert slots % self.BLOCK == 0 and slots >= 2 * self.BLOCK
         self.bufs = [torch.zeros(shape, dtype=dtype, pin_memory=pin) for _ in range(slots)]
-        self.events = [None] * slots
+        self.events = [None] * (slots // self.BLOCK)
         self.pin, self.i = pin, -1
         self.reserved, self.captured = [], []                # dedicated buffers: waiting for / baked into captured graphs
         self.count = 0                                       # acquisitions so far
@@ -186,16 +191,17 @@ class PinnedRing:
             return buf
         self._in_capture = False
         self.i = (self.i + 1) % len(self.bufs)
-        if self.events[self.i] is not None:
-            self.events[self.i].synchronize()
+        if self.i % self.BLOCK == 0 and self.events[self.i // self.BLOCK] is not None:
+            self.events[self.i // self.BLOCK].synchronize()   # the copies out of this block's slots, one lap ago, have executed
         return self.bufs[self.i]
 
     def release(self):
         """call after enqueueing the copy out of the buffer acquire() returned"""
-        if self.pin and not self._in_capture:
-            ev = self.events[self.i] or torch.cuda.Event()
+        if self.pin and not self._in_capture and self.i % self.BLOCK == self.BLOCK - 1:
+            b = self.i // self.BLOCK
+            ev = self.events[b] or torch.cuda.Event()
             ev.record()
-            self.events[self.i] = ev
+            self.events[b] = ev
 
 
 _UPLOAD_RINGS = {}

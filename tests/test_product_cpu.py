@@ -136,14 +136,14 @@ def test_pinned_ring_hands_out_distinct_staging_buffers():
     may still be pending when step n+1 is issued (that race produced wrong gradient addresses when the host ran ahead)"""
     import torch
     from partdistillation_amd.functions.fused import GatherPlan, PinnedRing
-    ring = PinnedRing(4, torch.int64, pin=False, slots=3)
+    ring = PinnedRing(4, torch.int64, pin=False, slots=16)     # two blocks of 8 slots, one completion event per block
     seen = []
-    for i in range(6):
+    for i in range(32):
         buf = ring.acquire()
         buf.fill_(i)
         ring.release()
         seen.append(buf.data_ptr())
-    assert len(set(seen[:3])) == 3 and seen[:3] == seen[3:]
+    assert len(set(seen[:16])) == 16 and seen[:16] == seen[16:]
     plan = GatherPlan([5, 3], [0, 8], torch.device("cpu"))
     a, b = torch.arange(5.0), torch.ones(3)
     plan.upload([a, b])
