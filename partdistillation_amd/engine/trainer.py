@@ -23,6 +23,10 @@ from ..compat.structures import BitMasks, Instances
 from .ddp import BucketedGradReducer, broadcast_parameters
 from .optimizer import build_lr_scheduler, build_optimizer
 
+# the backward pass issued from the CALLING thread instead of autograd's device thread: its ~500 nodes are mostly Python callbacks (the
+# hand-written backward passes), so the worker thread spent its time taking the GIL from the waiting main thread — host issue of the
+# step 24.2 -> 21.1 ms where the host is the limiter (512 x 512), nothing changes where the GPU is.  One process drives one GPU here.
+_SINGLE_THREAD_BWD = bool(int(_os.environ.get("PD_SINGLE_THREAD_BWD", "1")))
 _GRAPH_SYNC = bool(int(_os.environ.get("PD_GRAPH_SYNC", "0")))          # debugging aid: device fence between two replays of the captured step
 # read ONCE at import: the HIP runtime reads the variable when it initialises, so a value set later passes a check of os.environ
 # but changes nothing (bench.py --graph 1 sets it before importing torch)
@@ -74,7 +78,11 @@ class TrainStep:
             if total is None:
                 total = sum(loss_dict.values())
         with _deferred_wgrads():                             # the backbone's filter gradients: one grouped launch after backward
-            total.backward()
+            if _SINGLE_THREAD_BWD:
+                with torch.autograd.set_multithreading_enabled(False):    
+                    total.backward()
+            else:
+                total.backward()
         return loss_dict
 
     def __call__(self, batched_inputs):
