@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) void nc_sums(const float *__restrict__ x, cons
   const int64_t base = (int64_t)n * P * C + q * 4;
   float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, av = s0, bv = s0;
   if (MODE == 1) { av = *reinterpret_cast<const float4 *>(a + n * C + q * 4); bv = *reinterpret_cast<const float4 *>(b + n * C + q * 4); }
+#pragma unroll 4
   for (int p = p0 + po; p < p1; p += pstride) {
     const float4 xv = *reinterpret_cast<const float4 *>(x + base + (int64_t)p * C);
     if (MODE == 0) {
@@ -459,7 +460,9 @@ extern "C" int pd_nc_sums_f32(const float *x, const float *dy, const float *y, c
   (void)hipMemsetAsync(out, 0, (size_t)N * C * 2 * sizeof(double), s);
   if ((int64_t)N * P == 0) return pd_check_launch("pd_nc_sums_f32");
   if (!x || (mode == 1 && (!dy || !a || !b || (relu && !y)))) return pd_set_error(PD_ERR_INVALID_ARG, "pd_nc_sums_f32: null input");
-  const int ppb = 512;
+  // pixels per block: 512 gave 256 blocks of 4 wavefronts at 2 x 256^2 — one dependent 16-byte load per thread and iteration on a quarter-
+  // occupied machine (1.6 TB/s); 128 pixels = 1 024 blocks, four loads in flight per thread
+  const int ppb = (int64_t)N * P >= 32768 ? 128 : 512;
   dim3 grid((P + ppb - 1) / ppb, N);
   if (mode == 0) hipLaunchKernelGGL(nc_sums<0>, grid, dim3(256), 0, s, x, dy, y, a, b, out, P, C, ppb, relu);
   else hipLaunchKernelGGL(nc_sums<1>, grid, dim3(256), 0, s, x, dy, y, a, b, out, P, C, ppb, relu);

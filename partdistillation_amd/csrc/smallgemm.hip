@@ -326,13 +326,12 @@ __global__ __launch_bounds__(256) void decoder_head_256(const float *__restrict_
   for (int layer = 0; layer < 3; ++layer) {
     const bf16_t *W = layer == 0 ? w1 : layer == 1 ? w2 : w3;
     const bf16_t *bias = layer == 0 ? b1 : layer == 1 ? b2 : b3;
+    {                                                            // the whole 128 KB weight in flight at once: 32 pieces of 16 bytes per thread
+      uint4 wr[32];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {                       // 2 x 16 pieces of 16 bytes per thread in flight
-      uint4 wr[16];
+      for (int i = 0; i < 32; ++i) wr[i] = *reinterpret_cast<const uint4 *>(W + (int64_t)(prow + 8 * i) * 256 + pcol);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) wr[i] = *reinterpret_cast<const uint4 *>(W + (int64_t)(half * 128 + prow + 8 * i) * 256 + pcol);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) store_piece(&Ws[half * 128 + prow + 8 * i][pcol], wr[i]);
+      for (int i = 0; i < 32; ++i) store_piece(&Ws[prow + 8 * i][pcol], wr[i]);
     }
     __syncthreads();                                             // Ws (and the Xs rows of the previous phase) complete
     f32x16 acc[2];

@@ -94,11 +94,15 @@ def gemm_tn_h2(a, b, bias=None, mode=0, bits=None, colsum=None, a_amax=None, b_a
     if mode == 1 and want_bits:
         bits = torch.empty(int(L.pd_gemm_tn_f16x2_bits_words(M, N)), dtype=torch.int32, device=a.device)
     p = lambda t: t.data_ptr() if t is not None else None
-    shape = "wide" if (N % 256 == 0 and M >= 1024 and (-(-M // 256)) * (N // 256) >= 128 and (N >= 1024 or K >= 512)) or bits is not None else "narrow"
+    args = (a.data_ptr(), b.data_ptr(), p(bias), c.data_ptr(), p(bits), p(colsum), p(a_amax), p(b_amax), p(c_amax), M, N, K, a.stride(0), b.stride(0), N, mode,
+            _stream())
+    if not _TIMING["on"]:                                  # the hot path: no label formatting, no context manager
+        _lib.check(L.pd_gemm_tn_f16x2(*args))
+        return (c, bits) if (mode == 1 and want_bits) else c
+    wide = (N % 256 == 0 and M >= 1024 and (-(-M // 256)) * (N // 256) >= 128 and (N >= 1024 or K >= 512)) or bits is not None
     # (one label per kernel instantiation, as rocprofv3 names them: the per-launch averages of bench.py and of the profile agree)
-    with _timed_fwd(2.0 * M * N * K, f"gemm_tn_f16x2<{'256, 256, 128, 16' if shape == 'wide' else '128, 128, 64, 16'}, {mode}>", 4.0 * (M * K + N * K + M * N)):
-        _lib.check(L.pd_gemm_tn_f16x2(a.data_ptr(), b.data_ptr(), p(bias), c.data_ptr(), p(bits), p(colsum), p(a_amax), p(b_amax), p(c_amax),
-                                      M, N, K, a.stride(0), b.stride(0), N, mode, _stream()))
+    with _timed_fwd(2.0 * M * N * K, f"gemm_tn_f16x2<{'256, 256, 128, 16' if wide else '128, 128, 64, 16'}, {mode}>", 4.0 * (M * K + N * K + M * N)):
+        _lib.check(L.pd_gemm_tn_f16x2(*args))
     return (c, bits) if (mode == 1 and want_bits) else c
 
 
