@@ -163,7 +163,17 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
             sh = torch.as_tensor(shapes_host, dtype=torch.long, device=srcs[0].device)
             self._shape_cache[key] = (sh, torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1])))
         spatial_shapes, level_start_index = self._shape_cache[key]
-        src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        if srcs[0].is_cuda:
+            # the levels' tokens side by side: three strided copies (torch.cat's batched-copy kernel takes 76 us for these 44 MB)
+            B_, C_ = srcs[0].shape[0], srcs[0].shape[1]
+            sizes = [h * w for h, w in shapes_host]
+            src = torch.empty((B_, sum(sizes), C_), dtype=srcs[0].dtype, device=srcs[0].device)
+            o = 0
+            for s_, n in zip(srcs, sizes):
+                src[:, o:o + n].copy_(s_.flatten(2).transpose(1, 2))
+                o += n
+        else:
+            src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         if src.is_cuda and src.dtype == torch.float32 and self.level_embed.dtype == torch.float32 and self.d_model % 128 == 0:
             pos = LevelPos.apply(self.level_embed, *pos_embeds)          # same values; backward = 2 column-sum launches per level
         else:

@@ -77,7 +77,11 @@ class _MaskFormerTrainBase(nn.Module):
         prediction heads instead of re-padding ten times (reference criterion.py:167-169 via utils/misc.py:52-74)."""
         from .utils.misc import nested_tensor_from_tensor_list
         if len(targets) and all(t["masks"].shape[0] > 0 for t in targets):
-            padded, _ = nested_tensor_from_tensor_list([t["masks"] for t in targets]).decompose()
+            ms = [t["masks"] for t in targets]
+            if all(m.shape == ms[0].shape for m in ms):             # nothing to pad (the usual case: same crop size, same number of parts):
+                padded = torch.stack(ms)                            # one copy instead of two fills + the padding mask nobody reads
+            else:
+                padded, _ = nested_tensor_from_tensor_list(ms).decompose()
             targets[0]["_padded_masks"] = padded
         return targets
 
