@@ -122,6 +122,8 @@ int pd_point_sample_nhwc_f32_bf16(const float *in, const float *coords, void *ou
 int pd_point_sample_planar_f32(const float *in, const float *coords, float *out, int N, int C, int H, int W, int P, void *stream);
 int pd_point_sample_planar_bwd_f32(const float *grad_out, const float *coords, float *grad_in, int N, int C, int H, int W, int P, void *stream);
 int pd_point_sample_planar_bwd_needs_zero(int C, int H, int W);
+/* the same question for N maps (more than 65 535 maps always take the accumulating kernel): what callers should use */
+int pd_point_sample_planar_bwd_needs_zero_n(int N, int C, int H, int W);
 
 /*
  * FPN top-down step of the pixel decoder (reference msdeformattn.py:356-358:

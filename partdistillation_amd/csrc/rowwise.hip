@@ -1017,7 +1017,10 @@ extern "C" int pd_point_sample_planar_bwd_f32(const float *grad_out, const float
   return pd_check_launch("pd_point_sample_planar_bwd_f32");
 }
 
-extern "C" int pd_point_sample_planar_bwd_needs_zero(int C, int H, int W)
+// mirrors the dispatch of pd_point_sample_planar_bwd_f32 EXACTLY (the tiled kernel writes every element, the scatter kernel accumulates):
+// with N maps > 65 535 the scatter kernel runs whatever the tile count
+extern "C" int pd_point_sample_planar_bwd_needs_zero_n(int N, int C, int H, int W)
 {
-  return !(C == 1 && ((W + PST - 1) / PST) * ((H + PST - 1) / PST) <= 16);
+  return !(C == 1 && ((W + PST - 1) / PST) * ((H + PST - 1) / PST) <= 16 && N <= 65535);
 }
+extern "C" int pd_point_sample_planar_bwd_needs_zero(int C, int H, int W) { return pd_point_sample_planar_bwd_needs_zero_n(1, C, H, W); }

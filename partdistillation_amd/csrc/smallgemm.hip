@@ -221,10 +221,16 @@ __device__ __forceinline__ void splitk_sum(const float *__restrict__ ws, int til
 {
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  // plain loads: the agent-scope fence of splitk_arrive() has invalidated this CU's L1 and nothing here has read these addresses
+  // since; all of a slice's 16 loads are independent (agent-scope atomic loads were issued one by one: 23 us per launch)
+#pragma unroll 2
   for (int sl = 0; sl < slices; ++sl) {
-    const float *o = ws + ((int64_t)sl * tiles + tile) * (32 * 128);
+    const float *o = ws + ((int64_t)sl * tiles + tile) * (32 * 128) + threadIdx.x;
+    float v[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] += __hip_atomic_load(o + e * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int e = 0; e < 16; ++e) v[e] = __builtin_nontemporal_load(o + e * 256);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += v[e];
   }
 }
 

@@ -172,7 +172,7 @@ class PointSamplePlanar(Function):
         (coords,) = ctx.saved_tensors
         N, C, H, W = ctx.shape
         L = _lib.load()
-        alloc = torch.zeros if L.pd_point_sample_planar_bwd_needs_zero(C, H, W) else torch.empty
+        alloc = torch.zeros if L.pd_point_sample_planar_bwd_needs_zero_n(N, C, H, W) else torch.empty
         gx = alloc((N, C, H, W), dtype=torch.float32, device=g.device)
         g = g.contiguous()
         _lib.check(_lib.load().pd_point_sample_planar_bwd_f32(g.data_ptr(), coords.data_ptr(), gx.data_ptr(), N, C, H, W, coords.shape[1], _stream()))

@@ -106,6 +106,7 @@ SIGNATURES = {
     "pd_point_sample_nhwc_f32_bf16": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
     "pd_point_sample_planar_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
     "pd_point_sample_planar_bwd_needs_zero": (_c_int, [_c_int] * 3),
+    "pd_point_sample_planar_bwd_needs_zero_n": (_c_int, [_c_int] * 4),
     "pd_point_sample_planar_bwd_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
     "pd_upsample_add_nhwc_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 6 + [_c_vp]),
     "pd_upsample2x_bwd_nhwc_f32": (_c_int, [_c_vp] * 2 + [_c_int] * 4 + [_c_vp]),
