@@ -27,6 +27,12 @@
 #include "pd_gemm.h"
 #include "pd_msda.h"
 
+// tools/ablate_gemm_h2.sh builds diagnostic copies of this file with -DPD_ABL=<bits> (1: no MFMA, 2: no LDS fragment reads, 4: no split /
+// LDS writes, 8: no global operand loads, 16: no C stores, 32: unit scales without reading the maxima); the product build has PD_ABL 0
+#ifndef PD_ABL
+#define PD_ABL 0
+#endif
+
 namespace {
 using namespace pdh2;
 __device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
@@ -65,7 +71,7 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
     const int g = isa ? m0 + r : n0 + r - TM;
     const float *am = isa ? a_amax : b_amax;
     float s = 1.f, inv = 1.f;
-    if (am && g < (isa ? M : N)) {
+    if (!(PD_ABL & 32) && am && g < (isa ? M : N)) {
       float mx = am[g];
       if (CONV && isa) {
         const int pix = g % (H * W), y = pix / W, x = pix - y * W;
@@ -96,6 +102,13 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
     }
   }
   auto gload = [&](int rs, int k0) {
+    if (PD_ABL & 8) {
+#pragma unroll
+      for (int j = 0; j < APASS; ++j) ra[rs][j] = make_float4(1.f, 0.5f, 0.25f, (float)k0);
+#pragma unroll
+      for (int j = 0; j < BPASS; ++j) rb[rs][j] = make_float4(1.f, 0.5f, 0.25f, (float)k0);
+      return;
+    }
     const int k = k0 + lk;
     int dy = 0, dx = 0, kc = k, kb = k;                            // kc: channel of A, kb: column of B
     if (CONV) {
@@ -125,6 +138,13 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
     }
   };
   auto lstore = [&](int rs, int buf) {
+    if (PD_ABL & 4) {
+#pragma unroll
+      for (int j = 0; j < APASS; ++j) asm volatile("" ::"v"(ra[rs][j].x), "v"(ra[rs][j].y), "v"(ra[rs][j].z), "v"(ra[rs][j].w));
+#pragma unroll
+      for (int j = 0; j < BPASS; ++j) asm volatile("" ::"v"(rb[rs][j].x), "v"(rb[rs][j].y), "v"(rb[rs][j].z), "v"(rb[rs][j].w));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
       const SplitH x = split4h(ra[rs][j], sa[j]);
@@ -161,7 +181,7 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
       if (kt + 1 + NRS < KT) gload(rs, (kt + 1 + NRS) * BKK);
     }
 #pragma unroll
-    for (int ks = 0; ks < BKK / 16; ++ks) {
+    for (int ks = 0; ks < ((PD_ABL & 2) ? 0 : BKK / 16); ++ks) {
       h16x8 a[2][2];
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
@@ -174,9 +194,15 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
           for (int j = 0; j < 2; ++j) b[pl][j] = *reinterpret_cast<const h16x8 *>(Bs(par, pl, 2 * ks + fh, wn + (jp * 2 + j) * 32 + fr));
+#if PD_ABL & 1
+#define HTERM(PA, PB)                                                        \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(a[PA][i]), "v"(b[PB][j]));
+#else
 #define HTERM(PA, PB)                                                        \
   _Pragma("unroll") for (int i = 0; i < 2; ++i)                              \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) mmah(acc[i][jp * 2 + j], a[PA][i], b[PB][j]);
+#endif
         HTERM(1, 0)
         HTERM(0, 1)
         HTERM(0, 0)
@@ -228,7 +254,8 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
             v = ((word[j] >> (i * 16 + e)) & 1u) ? v : 0.f;
             if (ok) csum[j] += v;
           }
-          if (ok) { C[(int64_t)row * ldc + col] = v; rm = fmaxf(rm, fabsf(v)); }
+          if (PD_ABL & 16) { asm volatile("" ::"v"(v)); rm = fmaxf(rm, fabsf(v)); }
+          else if (ok) { C[(int64_t)row * ldc + col] = v; rm = fmaxf(rm, fabsf(v)); }
         }
         if (c_amax) red[rl * 33 + (lane & 31)] = rm;
       }

@@ -28,13 +28,21 @@ def main():
     with open(a.trace) as f:
         rd = csv.DictReader(f)
         for r in rd:
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+            try:
+                wg = 1
+                for ax in "XYZ":
+                    wg *= max(1, int(r["Grid_Size_" + ax]) // max(1, int(r["Workgroup_Size_" + ax])))
+            except (KeyError, ValueError):
+                wg = 0
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], wg))
     t_end = max(r[1] for r in rows)
+    wgs = collections.defaultdict(int)
     t0 = t_end - int(a.last_ms * 1e6)
     agg = collections.defaultdict(lambda: [0, 0])
     busy = 0
-    for s, e, n in rows:
+    for s, e, n, wg in rows:
         if s >= t0:
+            wgs[n] += wg
             agg[n][0] += 1
             agg[n][1] += e - s
             busy += e - s
@@ -44,11 +52,11 @@ def main():
     if a.out:
         with open(a.out, "w") as f:
             w = csv.writer(f)
-            w.writerow(["kernel", "calls", "calls_per_step", "total_us", "us_per_step", "avg_us", "pct_of_busy"])
+            w.writerow(["kernel", "calls", "calls_per_step", "total_us", "us_per_step", "avg_us", "pct_of_busy", "avg_workgroups"])
             for n, (c, t) in items:
-                w.writerow([short(n), c, f"{c / a.steps:.1f}", f"{t / 1e3:.1f}", f"{t / 1e3 / a.steps:.1f}", f"{t / 1e3 / c:.2f}", f"{100 * t / busy:.2f}"])
+                w.writerow([short(n), c, f"{c / a.steps:.1f}", f"{t / 1e3:.1f}", f"{t / 1e3 / a.steps:.1f}", f"{t / 1e3 / c:.2f}", f"{100 * t / busy:.2f}", f"{wgs[n] / c:.0f}"])
     for n, (c, t) in items[: a.top]:
-        print(f"{t / 1e3 / a.steps:9.1f} us/step {100 * t / busy:5.1f}%  x{c / a.steps:6.1f}  avg {t / 1e3 / c:8.1f} us  {short(n)[:120]}")
+        print(f"{t / 1e3 / a.steps:9.1f} us/step {100 * t / busy:5.1f}%  x{c / a.steps:6.1f}  avg {t / 1e3 / c:8.1f} us  wg {wgs[n] / c:7.0f}  {short(n)[:120]}")
 
 
 if __name__ == "__main__":
