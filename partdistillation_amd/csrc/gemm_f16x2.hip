@@ -28,7 +28,7 @@
 #include "pd_msda.h"
 
 // tools/ablate_gemm_h2.sh builds diagnostic copies of this file with -DPD_ABL=<bits> (1: no MFMA, 2: no LDS fragment reads, 4: no split /
-// LDS writes, 8: no global operand loads, 16: no C stores, 32: unit scales without reading the maxima); the product build has PD_ABL 0
+// LDS writes, 8: no global operand loads, 16: no C stores, 32: unit scales without reading the maxima, 64: row stream without the weight loads); the product build has PD_ABL 0
 #ifndef PD_ABL
 #define PD_ABL 0
 #endif
@@ -46,7 +46,7 @@ __device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0
 // convolution, K = 9 Ci ordered (tap, channel) like the channels-last filter [Co][3][3][Ci]: a 16-wide step lies inside one tap and
 // its A tile is the input at pixel m + dy W + dx (zeros outside the image) — an implicit GEMM (gemm_x3.hip's CONV form).  The scale
 // of output row m then has to cover the nine input pixels it reads: the largest of their maxima.
-template <int TM, int TN, int WN, int BKK, int MODE, bool CONV = false, int NRS = 1>
+template <int TM, int TN, int WN, int BKK, int MODE, bool CONV = false, int NRS = 1, int FAST = 0>
 __global__ __launch_bounds__((TM / 64) * (TN / WN) * 64, (TM == 256 ? 1 : 2))
 void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ bias, float *__restrict__ C,
                    int M, int N, int K, int lda, int ldb, int ldc, int ntiles_n, uint32_t *__restrict__ bits,
@@ -211,7 +211,85 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
     }
     __syncthreads();
   };
-  for (int kt = 0; kt < KT; kt += 2) {
+  int kt0 = 0;
+  if constexpr (FAST != 0 && BKK == 16) {
+    // Interior workgroups (whole tile inside C, K a multiple of 32): the same step as ONE basic block — no bounds branches around
+    // the loads (the tile after the last is clamped onto the last: an L2 hit nobody reads) — so that the scheduler may lay the
+    // split's VALU work, the LDS stores and the next loads into the shadow of the matrix instructions (sched_group_barrier:
+    // one MFMA, then its share of the VALU / DS / VMEM instructions).  The last two steps run through the guarded form below.
+    // CONV: the halo test becomes a select on a load from an address that always exists (the centre pixel's), not a branch.
+    if (m0 + TM <= M && n0 + TN <= N && (K % (2 * BKK)) == 0 && KT >= 4 && (!CONV || tap_minor)) {
+      const float *pa[APASS], *pb[BPASS];
+#pragma unroll
+      for (int j = 0; j < APASS; ++j) pa[j] = A + (int64_t)(m0 + lr + RPP * j) * lda + lk;
+#pragma unroll
+      for (int j = 0; j < BPASS; ++j) pb[j] = B + (int64_t)(n0 + lr + RPP * j) * ldb + lk;
+      auto fstep = [&](int kt, int par) {
+        const int rs = NRS == 2 ? (par ^ 1) : 0;
+        int kn = min((kt + 1 + NRS) * BKK, K - BKK), knb = kn, dy = 0, dx = 0;
+        if (CONV) {                                                 // (channel block, tap) order: step s = 9 cb + tap
+          const int sidx = kn / BKK, cb = sidx / 9, tap = sidx - cb * 9;
+          dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1;
+          kn = cb * BKK; knb = tap * lda + kn;
+        }
+        h16x8 a[2][2], b[2][NJ];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[pl][i] = *reinterpret_cast<const h16x8 *>(As(par, pl, fh, wm + i * 32 + fr));
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) b[pl][j] = *reinterpret_cast<const h16x8 *>(Bs(par, pl, fh, wn + j * 32 + fr));
+        }
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) {
+          const SplitH x = split4h(ra[rs][j], sa[j]);
+          h16_t *p = As(par ^ 1, 0, lk >> 3, lr + RPP * j) + (lk & 7);
+          *reinterpret_cast<uint2 *>(p) = x.hi; *reinterpret_cast<uint2 *>(p + NPAN * TM * 8) = x.lo;
+          if (CONV) {
+            const int yy = py[j] + dy, xx = px[j] + dx;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const float4 v = *reinterpret_cast<const float4 *>(pa[j] + (ok ? (dy * W + dx) * lda : 0) + kn);
+            ra[rs][j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+          } else {
+            ra[rs][j] = *reinterpret_cast<const float4 *>(pa[j] + kn);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+          const SplitH x = split4h(rb[rs][j], sb[j]);
+          h16_t *p = Bs(par ^ 1, 0, lk >> 3, lr + RPP * j) + (lk & 7);
+          *reinterpret_cast<uint2 *>(p) = x.hi; *reinterpret_cast<uint2 *>(p + NPAN * TN * 8) = x.lo;
+          rb[rs][j] = *reinterpret_cast<const float4 *>(pb[j] + knb);
+        }
+#define FTERM(PA, PB)                                                        \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                              \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) mmah(acc[i][j], a[PA][i], b[PB][j]);
+        FTERM(1, 0)
+        FTERM(0, 1)
+        FTERM(0, 0)
+#undef FTERM
+        if constexpr (FAST == 1) {
+          constexpr int NM = 6 * NJ, NV = (12 * (APASS + BPASS) + 8 + NM - 1) / NM, EV = NM / (APASS + BPASS);
+          __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * NJ, 0);
+#pragma unroll
+          for (int g = 0; g < NM; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+            if (g % EV == EV - 1) {
+              __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+          }
+        }
+        __syncthreads();
+      };
+      for (; kt0 + 2 < KT; kt0 += 2) {
+        fstep(kt0, 0);
+        fstep(kt0 + 1, 1);
+      }
+    }
+  }
+  for (int kt = kt0; kt < KT; kt += 2) {
     step(kt, 0);
     if (kt + 1 < KT) step(kt + 1, 1);
   }
@@ -304,11 +382,188 @@ __global__ __launch_bounds__(256) void row_amax_f32(const float *__restrict__ X,
   if (lane == 0) out[row] = v;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_rows_f16x2_k256: the K = 256 shapes of the encoder (value / output projections, the 1 x 1 convolutions on 256 channels;
+// M = 43 520 .. 131 072 rows, N = 256 per panel) as a ROW STREAM.  The tiled kernel above runs all its workgroups at once and in
+// phase — everyone loads, then everyone multiplies, then everyone stores (ablation, tools/ablate_gemm_h2.py: 10.5 us fixed + 9.5
+// loads + 11 products = the 31 us of a launch whose traffic takes 11) — and re-splits the weight tile in every workgroup and step.
+// Here ONE persistent workgroup per CU (8 wavefronts) keeps its whole weight panel split in REGISTERS — wavefront w holds columns
+// 32 w .. 32 w + 31 of the panel for all of K as MFMA operands, 2 planes x 16 steps x 4 VGPRs = 128 — and streams 32-row tiles of
+// A through a double-buffered 2-plane LDS image: A is read from HBM once, by one wavefront per row in whole 1 KB lines; loads run
+// two tiles ahead in registers (64 KB per CU in flight all the time), one barrier per tile (48 MFMAs per wavefront) instead of one
+// per 16-deep step, and the C stores of tile t drain under the products of tile t + 1.
+// EXPERIMENTAL, not the product's choice (pd_debug_set("f16x2_tile", 61) selects it): correct (tests/test_gemm_gpu.py) and 3-8 % faster
+// than the tiled kernel in isolation (43 520 x 256 <- 256: 31.0 vs 32.7 us), but 0.2 ms SLOWER over the training step (24.86 vs
+// 24.65 ms, same-box A/B).  Its own ablation (tools/ablate_gemm_h2.py) shows why it stops there: the weight panel's fetch as MFMA
+// fragments (32-byte pieces of 32 rows per load instruction, 256 KB per CU, 64 MB over the chip from L2) costs 8 us before the first
+// product, and the fragment reads, the C stores and the products still add up (4.7 + 4.7 + 4.5 us) instead of overlapping.
+// LDS image of a tile: [plane][k panel of 8 (32)][row (32)][8 halves], k panels 528 bytes apart (512 + 16: the 64 lanes of a row's
+// wavefront store 8 bytes each into 32 different k panels — without the pad all of them on the same four banks).
+constexpr int RS_PANEL = 528, RS_PLANE = 32 * RS_PANEL, RS_BUF = 2 * RS_PLANE;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool AM>   // AM: both operands come with row maxima (scaled rows); false: neither (unit scales)
+__global__ __launch_bounds__(512)
+void gemm_rows_f16x2_k256(const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ bias, float *__restrict__ C,
+                          int M, int npanels, int lda, int ldb, int ldc, const float *__restrict__ a_amax,
+                          const float *__restrict__ b_amax, unsigned *__restrict__ c_amax)
+{
+  // the two images are two objects: the stores into one provably do not alias the fragment reads of the other, so the scheduler
+  // may move them (and the split feeding them) up between the matrix instructions
+  __shared__ __attribute__((aligned(16))) unsigned char lds0[RS_BUF], lds1[RS_BUF];
+  __shared__ __attribute__((aligned(16))) float sinv0[32], sinv1[32], sdump[64];    // inverse row scales of the staged tiles; unread slots
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 31, fh = lane >> 5;   // w in an SGPR: row addresses and row maxima become scalar
+  // workgroup -> (row group, panel): the panels of one row group sit on the same XCD (ids 8 apart) and share A in its L2
+  const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int panel = q % npanels, rg = (q / npanels) * 8 + x, nrg = (gridDim.x / 8 / npanels) * 8;
+  const int ntile = (M + 31) >> 5;
+  const int t0 = (int)((int64_t)rg * ntile / nrg), t1 = (int)((int64_t)(rg + 1) * ntile / nrg), T = t1 - t0;
+  if (T <= 0) return;
+  const int n0 = panel * 256 + w * 32;
+
+  float4 R[2][4];
+  float am[2][4];
+  auto gload = [&](int rs, int tile) {
+    tile = min(tile, t1 - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = min(tile * 32 + w + 8 * j, M - 1);
+      if (PD_ABL & 8) R[rs][j] = make_float4(1.f, 0.5f, 0.25f, (float)row);
+      else R[rs][j] = *reinterpret_cast<const float4 *>(A + (int64_t)row * lda + 4 * lane);
+      am[rs][j] = AM ? a_amax[row] : 0.f;
+    }
+  };
+  auto split_store = [&](int rs, int buf) {
+    float invs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float s = 1.f;
+      invs[j] = 1.f;
+      if (AM) row_scale(am[rs][j], s, invs[j]);
+      const SplitH v = split4h(R[rs][j], s);
+      unsigned char *p = (buf ? lds1 : lds0) + (lane >> 1) * RS_PANEL + (w + 8 * j) * 16 + (lane & 1) * 8;
+      if (PD_ABL & 4) { asm volatile("" ::"v"(R[rs][j].x), "v"(R[rs][j].y), "v"(R[rs][j].z), "v"(R[rs][j].w)); continue; }
+      *reinterpret_cast<uint2 *>(p) = v.hi;
+      *reinterpret_cast<uint2 *>(p + RS_PLANE) = v.lo;
+    }
+    // lanes 0..3 leave the four inverse scales; the other lanes store into unread slots (no branch in the step)
+    const unsigned l0 = -(unsigned)(lane == 0), l1 = -(unsigned)(lane == 1), l2 = -(unsigned)(lane == 2);
+    const unsigned iv = (__float_as_uint(invs[0]) & l0) | (__float_as_uint(invs[1]) & l1) | (__float_as_uint(invs[2]) & l2) |
+                        (__float_as_uint(invs[3]) & ~(l0 | l1 | l2));
+    *reinterpret_cast<unsigned *>(lane < 4 ? (buf ? sinv1 : sinv0) + w + 8 * lane : sdump + lane) = iv;
+  };
+  gload(0, t0);
+  gload(1, t0 + 1);
+  // this wavefront's 32 columns of the weight panel, split once: lane (fr, fh) holds k = 16 s + 8 fh .. + 7 of row n0 + fr
+  h16x8 bh[16], bl[16];
+  float ibv = 1.f;
+  {
+    float sbv = 1.f;
+    if (AM) row_scale(b_amax[n0 + fr], sbv, ibv);
+    const float *bp = B + (int64_t)(n0 + fr) * ldb + 8 * fh;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const SplitH u = split4h((PD_ABL & 64) ? make_float4(1.f, 2.f, (float)s, sbv) : *reinterpret_cast<const float4 *>(bp + 16 * s), sbv),
+                   v = split4h((PD_ABL & 64) ? make_float4(1.f, 2.f, (float)s, ibv) : *reinterpret_cast<const float4 *>(bp + 16 * s + 4), sbv);
+      bh[s] = __builtin_bit_cast(h16x8, u32x4{u.hi.x, u.hi.y, v.hi.x, v.hi.y});
+      bl[s] = __builtin_bit_cast(h16x8, u32x4{u.lo.x, u.lo.y, v.lo.x, v.lo.y});
+    }
+  }
+  const float bv = bias ? bias[n0 + fr] : 0.f;
+  split_store(0, 0);
+  gload(0, t0 + 2);
+  __syncthreads();
+
+  auto iter = [&](int it, int par) {
+    const unsigned char *base = (par ? lds1 : lds0) + fh * RS_PANEL + fr * 16;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < ((PD_ABL & 1) ? 0 : 16); ++s) {
+      const h16x8 ah = (PD_ABL & 2) ? bl[15 - s] : *reinterpret_cast<const h16x8 *>(base + 2 * s * RS_PANEL);
+      const h16x8 al = (PD_ABL & 2) ? bh[15 - s] : *reinterpret_cast<const h16x8 *>(base + 2 * s * RS_PANEL + RS_PLANE);
+#ifdef PD_ROWS_TWO_CHAINS
+      if (s & 1) { mmah(acc1, al, bh[s]); mmah(acc0, ah, bl[s]); mmah(acc1, ah, bh[s]); }
+      else       { mmah(acc0, al, bh[s]); mmah(acc1, ah, bl[s]); mmah(acc0, ah, bh[s]); }
+#else
+      mmah(acc0, al, bh[s]); mmah(acc0, ah, bl[s]); mmah(acc0, ah, bh[s]);
+#endif
+    }
+    // tile it + 1 into the other image, its registers re-loaded with tile it + 3 (past the end: the last tile again, unread)
+    split_store(par ^ 1, par ^ 1);
+    gload(par ^ 1, t0 + it + 3);
+    // lay the split (VALU), its LDS stores and the loads into the shadow of the 48 matrix instructions
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      if (s & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      if ((s & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);                              // the epilogue's VALU work is not material for the groups above
+    // C rows of the 32 x 32 accumulator: (e & 3) + 8 (e >> 2) + 4 fh, column fr
+    const int row0 = (t0 + it) * 32;
+    float o[16];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const float4 ia = *reinterpret_cast<const float4 *>((par ? sinv1 : sinv0) + 8 * qd + 4 * fh);
+      o[4 * qd + 0] = (acc0[4 * qd + 0] + acc1[4 * qd + 0]) * (ia.x * ibv) + bv;
+      o[4 * qd + 1] = (acc0[4 * qd + 1] + acc1[4 * qd + 1]) * (ia.y * ibv) + bv;
+      o[4 * qd + 2] = (acc0[4 * qd + 2] + acc1[4 * qd + 2]) * (ia.z * ibv) + bv;
+      o[4 * qd + 3] = (acc0[4 * qd + 3] + acc1[4 * qd + 3]) * (ia.w * ibv) + bv;
+    }
+    float *cp = C + (int64_t)row0 * ldc + n0 + fr;
+    if (PD_ABL & 16) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(o[e]));
+    } else if (row0 + 32 <= M) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) cp[(int64_t)((e & 3) + 8 * (e >> 2) + 4 * fh) * ldc] = o[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rl = (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (row0 + rl < M) cp[(int64_t)rl * ldc] = o[e];
+      }
+    }
+    if (c_amax) {
+      // row maxima over this wavefront's 32 columns: a halving butterfly over the 32 lanes of a half (16 values -> 8 -> .. -> 1:
+      // 15 exchanges instead of 16 x 5), lane pair (2 i, 2 i + 1) ends with row e = lane bits [4:1]
+      float v[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = fabsf(o[e]);
+#pragma unroll
+      for (int n = 8, m = 16; n >= 1; n >>= 1, m >>= 1) {
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+          const float mine = up ? v[n + i] : v[i], send = up ? v[i] : v[n + i];
+          v[i] = fmaxf(mine, __shfl_xor(send, m, 64));
+        }
+      }
+      const float r = fmaxf(v[0], __shfl_xor(v[0], 1, 64));
+      const int e = (lane >> 1) & 15, rl = (e & 3) + 8 * (e >> 2) + 4 * fh;
+      if (!(lane & 1) && row0 + rl < M && r > 0.f) atomicMax(c_amax + row0 + rl, __float_as_uint(r));
+    }
+    __syncthreads();
+  };
+  for (int it = 0; it < T; it += 2) {
+    iter(it, 0);
+    if (it + 1 < T) iter(it + 1, 1);
+  }
+}
+
 }  // namespace
 
-int g_pd_dbg_f16x2 = 0;   // tools/ only (pd_debug_set "f16x2_tile"): 1 force 256x256x32, 2 force 128x128x32, 3 force 256x256x16, 4 force 128x128x16 (0: by shape, 16-deep)
+int g_pd_dbg_f16x2 = 0;   // tools/ only (pd_debug_set "f16x2_tile"): see pd_gemm_tn_f16x2
 
-template <int TM, int TN, int WN, int BKK, bool CONV = false, int NRS = 1>
+template <int TM, int TN, int WN, int BKK, bool CONV = false, int NRS = 1, int FAST = 0>
 static int launch_f16x2(const float *A, const float *B, const float *bias, float *C, int M, int N, int K, int lda, int ldb, int ldc, int mode,
                         uint32_t *bits, float *colsum, const float *a_amax, const float *b_amax, float *c_amax, hipStream_t st, int H = 0,
                         int W = 0)
@@ -320,9 +575,9 @@ static int launch_f16x2(const float *A, const float *B, const float *bias, float
   const int tn = (N + TN - 1) / TN, tm = (M + TM - 1) / TM;
   typedef void (*kfn)(const float *, const float *, const float *, float *, int, int, int, int, int, int, int, uint32_t *, float *, const float *,
                       const float *, unsigned *, int, int, int);
-  const kfn k = CONV ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 0, CONV, NRS>
-                     : mode == 0 ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 0, false, NRS> : mode == 1 ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 1, false, NRS>
-                                                                                                  : (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 2, false, NRS>;
+  const kfn k = CONV ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 0, CONV, NRS, FAST>
+                     : mode == 0 ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 0, false, NRS, FAST>
+                                 : mode == 1 ? (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 1, false, NRS, FAST> : (kfn)gemm_tn_f16x2<TM, TN, WN, BKK, 2, false, NRS, FAST>;
   static bool attr[3] = {false, false, false};
   if (!attr[mode]) { (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[mode] = true; }
   hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)tm * tn)), dim3(NTH), lds, st, A, B, bias, C, M, N, K, lda, ldb, ldc, tn, bits, colsum, a_amax,
@@ -345,28 +600,45 @@ extern "C" int pd_gemm_tn_f16x2(const float *A, const float *B, const float *bia
   if ((K & 3) || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: K, lda, ldb must be multiples of 4 and A, B 16-byte aligned");
   hipStream_t st = (hipStream_t)stream_;
+  const int dbg = g_pd_dbg_f16x2;
+  if (dbg == 61 && mode == 0 && K == 256 && (N % 256) == 0 && M >= 8192 && (a_amax == nullptr) == (b_amax == nullptr)) {
+    // row stream (gemm_rows_f16x2_k256, experimental: see the kernel's header): one persistent workgroup per CU, panels of a row group on one XCD
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = 256; }
+    const int np = N / 256, G = (ncu / (8 * np)) * 8 * np;
+    if (G > 0) {
+      if (a_amax)
+        hipLaunchKernelGGL(gemm_rows_f16x2_k256<true>, dim3((unsigned)G), dim3(512), 0, st, A, B, bias, C, M, np, lda, ldb, ldc, a_amax, b_amax,
+                           reinterpret_cast<unsigned *>(c_amax));
+      else
+        hipLaunchKernelGGL(gemm_rows_f16x2_k256<false>, dim3((unsigned)G), dim3(512), 0, st, A, B, bias, C, M, np, lda, ldb, ldc, a_amax, b_amax,
+                           reinterpret_cast<unsigned *>(c_amax));
+      return pd_check_launch("pd_gemm_tn_f16x2 (row stream)");
+    }
+  }
   // the sign bits are laid out in the 256 x 256 kernel's accumulator order: bits / mask launches must take that kernel
   const bool need_wide = bits != nullptr;
   if (need_wide && ((N % 256) || M < 1024)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: sign bits need N %% 256 == 0 and M >= 1024");
   const bool wide_ok = (N % 256) == 0 && M >= 1024;
-  const bool wide = need_wide || g_pd_dbg_f16x2 == 1 || g_pd_dbg_f16x2 == 3 || g_pd_dbg_f16x2 == 13 || g_pd_dbg_f16x2 == 5 || g_pd_dbg_f16x2 == 15 ||
-                    (g_pd_dbg_f16x2 == 0 && wide_ok && (int64_t)((M + 255) / 256) * (N / 256) >= 128 && (N >= 1024 || K >= 512));
-#define GO(TM, TN, WN, BKK) return launch_f16x2<TM, TN, WN, BKK>(A, B, bias, C, M, N, K, lda, ldb, ldc, mode, bits, colsum, a_amax, b_amax, c_amax, st)
-  // 16-deep steps beat 32-deep ones on every encoder shape (tools/bench_gemm_h2.py, M = 43 008: 1024 <- 256 96.8 vs 103.7 us,
-  // 256 <- 1024 85.4 vs 90.9, 256 <- 256 29.3 vs 32.9): half the LDS per workgroup, more workgroups in flight
+  const bool by_shape = dbg == 0 || dbg == 61 || dbg == 70;
+  const bool wide = need_wide || dbg == 3 || dbg == 13 || (by_shape && wide_ok && (int64_t)((M + 255) / 256) * (N / 256) >= 128 && (N >= 1024 || K >= 512));
+#define GO(TM, TN, WN, NRS, FAST) return launch_f16x2<TM, TN, WN, 16, false, NRS, FAST>(A, B, bias, C, M, N, K, lda, ldb, ldc, mode, bits, colsum, a_amax, b_amax, c_amax, st)
+  // Measured and dropped (tools/bench_gemm_h2.py, M = 43 008): 32-deep steps (1024 <- 256 103.7 vs 96.8 us, 256 <- 1024 90.9 vs 85.4,
+  // 256 <- 256 32.9 vs 29.3: half the workgroups in flight), 128 x 256 tiles with two workgroups per CU (no gain).
+  // Two register stages (loads two steps ahead of their split): 97.0 vs 99.9 us on 1024 <- 256, 85.3 vs 87.9 on 256 <- 1024.
+  // Interior workgroups take the branch-free, interleaved step (FAST = 1): 1024 <- 256 109 -> 92 us, 256 <- 1024 91 -> 79 us (wide tiles),
+  // 256 <- 1024 94 -> 87 us (128 x 128 tiles) at M = 43 520; the step 24.9 -> 24.65 ms.
+  // pd_debug_set("f16x2_tile"): 3 / 13 wide tiles with one / two register stages and the guarded step, 4 / 14 the same for 128 x 128
+  // tiles, 70 the guarded step by shape, 61 the row stream where it applies, 21 the (tap, channel) contraction order of the convolution
   if (wide) {
     if (!wide_ok) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: 256 x 256 tiles need N %% 256 == 0 and M >= 1024");
-    if (g_pd_dbg_f16x2 == 5) GO(128, 256, 128, 16);
-    if (g_pd_dbg_f16x2 == 15) return launch_f16x2<128, 256, 128, 16, false, 2>(A, B, bias, C, M, N, K, lda, ldb, ldc, mode, bits, colsum, a_amax, b_amax, c_amax, st);
-    if (g_pd_dbg_f16x2 == 1) GO(256, 256, 128, 32);
-    // two register stages (loads two steps ahead of their split): 97.0 vs 99.9 us on 1024 <- 256, 85.3 vs 87.9 on 256 <- 1024; the
-    // 128 x 128 kernel does not gain (its three workgroups per CU already interleave); 128 x 256 tiles with two workgroups per CU: no gain
-    if (g_pd_dbg_f16x2 == 3) GO(256, 256, 128, 16);
-    return launch_f16x2<256, 256, 128, 16, false, 2>(A, B, bias, C, M, N, K, lda, ldb, ldc, mode, bits, colsum, a_amax, b_amax, c_amax, st);
+    if (dbg == 3) GO(256, 256, 128, 1, 0);
+    if (dbg == 13 || dbg == 70) GO(256, 256, 128, 2, 0);
+    GO(256, 256, 128, 2, 1);
   }
-  if (g_pd_dbg_f16x2 == 2) GO(128, 128, 64, 32);
-  if (g_pd_dbg_f16x2 == 14) return launch_f16x2<128, 128, 64, 16, false, 2>(A, B, bias, C, M, N, K, lda, ldb, ldc, mode, bits, colsum, a_amax, b_amax, c_amax, st);
-  GO(128, 128, 64, 16);
+  if (dbg == 4 || dbg == 70) GO(128, 128, 64, 1, 0);
+  if (dbg == 14) GO(128, 128, 64, 2, 0);
+  GO(128, 128, 64, 2, 1);
 #undef GO
 }
 
@@ -381,8 +653,12 @@ extern "C" int pd_conv3x3_nhwc_f16x2(const float *X, const float *Wk, const floa
   if (M > 0x7fffffffLL - 4096) return pd_set_error(PD_ERR_INVALID_ARG, "pd_conv3x3_nhwc_f16x2: too many pixels");
   hipStream_t st = (hipStream_t)stream_;
   const bool wide = g_pd_dbg_f16x2 == 3 || (g_pd_dbg_f16x2 != 4 && (Co % 256) == 0 && M >= 65536);
-  if (wide) return launch_f16x2<256, 256, 128, 16, true>(X, Wk, bias, Y, (int)M, Co, 9 * Ci, Ci, 9 * Ci, Co, 0, nullptr, nullptr, x_amax, w_amax, y_amax, st, H, W);
-  return launch_f16x2<128, 128, 64, 16, true>(X, Wk, bias, Y, (int)M, Co, 9 * Ci, Ci, 9 * Ci, Co, 0, nullptr, nullptr, x_amax, w_amax, y_amax, st, H, W);
+  if (g_pd_dbg_f16x2 == 70 || g_pd_dbg_f16x2 == 21) {               // the guarded step
+    if (wide) return launch_f16x2<256, 256, 128, 16, true>(X, Wk, bias, Y, (int)M, Co, 9 * Ci, Ci, 9 * Ci, Co, 0, nullptr, nullptr, x_amax, w_amax, y_amax, st, H, W);
+    return launch_f16x2<128, 128, 64, 16, true>(X, Wk, bias, Y, (int)M, Co, 9 * Ci, Ci, 9 * Ci, Co, 0, nullptr, nullptr, x_amax, w_amax, y_amax, st, H, W);
+  }
+  if (wide) return launch_f16x2<256, 256, 128, 16, true, 1, 1>(X, Wk, bias, Y, (int)M, Co, 9 * Ci, Ci, 9 * Ci, Co, 0, nullptr, nullptr, x_amax, w_amax, y_amax, st, H, W);
+  return launch_f16x2<128, 128, 64, 16, true, 1, 1>(X, Wk, bias, Y, (int)M, Co, 9 * Ci, Ci, 9 * Ci, Co, 0, nullptr, nullptr, x_amax, w_amax, y_amax, st, H, W);
 }
 
 extern "C" int pd_row_amax_f32(const float *X, int rows, int cols, int ld, float *out, void *stream_)

@@ -178,6 +178,11 @@ def load():
         fn.restype, fn.argtypes = res, args
     if lib.pd_abi_version() != ABI_VERSION:
         raise PdHipError(f"libpd_hip.so ABI {lib.pd_abi_version()} != binding {ABI_VERSION}: rebuild")
+    # development knobs of the kernels (tools/ab_bench.sh): PD_DEBUG_SET="key=value,key=value" -> pd_debug_set at load
+    for kv in filter(None, os.environ.get("PD_DEBUG_SET", "").split(",")):
+        k, v = kv.split("=")
+        if lib.pd_debug_set(k.encode(), int(v)) != 0:
+            raise PdHipError(f"PD_DEBUG_SET: unknown key `{k}`")
     _lib = lib
     return lib
 

@@ -274,7 +274,8 @@ def test_gemm_tn_h2_is_fp32_accurate_over_the_exponent_range(M, N, K, mag):
     e_lib = ((torch.addmm(b, a, w.t()).double() - ref).abs() / rown).max().item()
     aa, wa = gemm.row_amax(a), gemm.row_amax(w)
     assert torch.equal(aa, a.abs().amax(1))
-    for tile in (0, 2, 4) + ((1, 3) if N % 256 == 0 and M >= 1024 else ()):
+    # 0: the product's choice (interleaved interior step); 70: the guarded step by shape; 4 / 14, 3 / 13: forced tile shapes and register stages
+    for tile in (0, 70, 4, 14) + ((3, 13) if N % 256 == 0 and M >= 1024 else ()):
         lib.load().pd_debug_set(b"f16x2_tile", tile)
         try:
             cm = torch.zeros(M, device="cuda")
@@ -286,6 +287,34 @@ def test_gemm_tn_h2_is_fp32_accurate_over_the_exponent_range(M, N, K, mag):
         assert torch.equal(cm, got.abs().amax(1))
     r = gemm.gemm_tn_h2(a, w, b, mode=1, a_amax=aa, b_amax=wa)
     assert ((r.double() - ref.clamp_min(0)).abs() / rown).max().item() < 3e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(8300, 256, 256), (9001, 512, 256), (43520, 1024, 256)])
+@pytest.mark.parametrize("scaled", [True, False])
+def test_gemm_tn_h2_row_stream_matches_the_tiled_kernel(M, N, K, scaled):
+    """gemm_rows_f16x2_k256 (the experimental persistent row-stream form of the K = 256 shapes, pd_debug_set("f16x2_tile", 61)):
+    fp32-accurate against fp64, exact row maxima, ragged last tile, several column panels."""
+    from partdistillation_amd import lib
+    from partdistillation_amd.functions import gemm
+    torch.manual_seed(M + N)
+    a = torch.randn(M, K, device="cuda") * (torch.logspace(-3, 3, M, device="cuda")[torch.randperm(M, device="cuda"), None] if scaled else 1.0)
+    w = torch.randn(N, K, device="cuda") * K ** -0.5
+    b = torch.randn(N, device="cuda")
+    ref = torch.addmm(b.double(), a.double(), w.double().t())
+    rown = ref.abs().amax(1, keepdim=True)
+    aa, wa = (gemm.row_amax(a), gemm.row_amax(w)) if scaled else (None, None)
+    tiled = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
+    lib.load().pd_debug_set(b"f16x2_tile", 61)
+    try:
+        cm = torch.zeros(M, device="cuda")
+        got = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa, c_amax=cm)
+        again = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
+    finally:
+        lib.load().pd_debug_set(b"f16x2_tile", 0)
+    assert torch.equal(got, again)
+    assert ((got.double() - ref).abs() / rown).max().item() < 3e-6
+    assert ((got.double() - tiled.double()).abs() / rown).max().item() < 1e-6
+    assert torch.equal(cm, got.abs().amax(1))
 
 
 def test_gemm_tn_h2_relu_bits_and_mask_epilogues():

@@ -3,7 +3,7 @@ once per process).  Results are NOT valid products: the point is which part of t
 import os, subprocess, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
-NAMES = {1: "no-mfma", 2: "no-ldsread", 4: "no-split/ldswrite", 8: "no-gload", 16: "no-cstore", 32: "no-scales"}
+NAMES = {1: "no-mfma", 2: "no-ldsread", 4: "no-split/ldswrite", 8: "no-gload", 16: "no-cstore", 32: "no-scales", 64: "no-wload(rows)"}
 
 
 def child(k):
@@ -13,7 +13,7 @@ def child(k):
     L = lib.load()
     from partdistillation_amd.functions import gemm
     out = []
-    for M, N, K, tile in [(43520, 256, 256, 4), (43520, 256, 1024, 4), (43520, 1024, 256, 13), (43520, 256, 1024, 13)]:
+    for M, N, K, tile in [(43520, 256, 256, 61), (43520, 1024, 256, 61), (43520, 256, 256, 70), (43520, 256, 1024, 70), (43520, 1024, 256, 70)]:
         a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * K ** -0.5; b = torch.randn(N, device="cuda")
         aa, wa = gemm.row_amax(a), gemm.row_amax(w)
         L.pd_debug_set(b"f16x2_tile", tile)
@@ -24,13 +24,14 @@ def child(k):
         for _ in range(40): f()
         e1.record(); torch.cuda.synchronize()
         out.append(f"{e0.elapsed_time(e1) / 40 * 1e3:6.1f}")
-    print(f"ABL {k:3d} {'+'.join(v for b, v in NAMES.items() if k & b) or 'full':45s} " + "  ".join(out), flush=True)
+    kk = int(str(k).split("x")[0])
+    print(f"ABL {k:>4s} {'+'.join(v for b, v in NAMES.items() if kk & b) or 'full':45s} " + "  ".join(out), flush=True)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--child":
-        child(int(sys.argv[2]))
+        child(sys.argv[2])
     else:
-        print("columns (us): 128-tile 256<-256 | 128-tile 256<-1024 | 256-tile(NRS2) 1024<-256 | 256-tile(NRS2) 256<-1024; M = 43520")
-        for k in [int(x) for x in sys.argv[1:]]:
+        print("columns (us): row stream 256<-256 | row stream 1024<-256 | tiled 256<-256 | tiled 256<-1024 | tiled 1024<-256 (tiled: the guarded step, which carries the ablation bits); M = 43520")
+        for k in sys.argv[1:]:
             subprocess.run([sys.executable, __file__, "--child", str(k)], check=False)

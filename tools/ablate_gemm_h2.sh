@@ -7,7 +7,7 @@ make -s -j8
 mkdir -p ../../build/abl
 OTHERS=$(ls *.o | grep -v '^gemm_f16x2.o$')
 for k in "$@"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -I../../include -I. -DPD_ABL=$k -c gemm_f16x2.hip -o ../../build/abl/gemm_f16x2_$k.o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -I../../include -I. -DPD_ABL=${k%%x*} $( [[ $k == *x* ]] && echo -DPD_ROWS_TWO_CHAINS ) -c gemm_f16x2.hip -o ../../build/abl/gemm_f16x2_$k.o &
 done
 wait
 for k in "$@"; do

@@ -23,7 +23,7 @@ for B, S, C in [(2, 256, 256), (2, 320, 256)]:
         conv_x3.H2 = h2
         yy = conv_x3.conv3x3(x, w)
         print(f"  H2={h2}: forward {t(lambda: conv_x3.conv3x3(x, w)):.3f} ms, backward (dx + dw) {t(lambda: torch.autograd.grad(yy, (x, w), go, retain_graph=True)):.3f} ms, dw alone {t(lambda: torch.autograd.grad(yy, (w,), go, retain_graph=True)):.3f} ms")
-    for tile in (3, 4, 21, 0):
+    for tile in (70, 21, 0):                                   # the guarded step, the (tap, channel) order, the product (interleaved step)
         lib.load().pd_debug_set(b"f16x2_tile", tile); conv_x3.H2 = True
         print(f"  H2 tile {tile}: forward {t(lambda: conv_x3.conv3x3(x, w)):.3f} ms")
     lib.load().pd_debug_set(b"f16x2_tile", 0)
