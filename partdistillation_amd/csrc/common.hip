@@ -38,6 +38,7 @@ extern int g_pd_dbg_x3_narrow;
 extern int g_pd_dbg_f16x2;
 extern int g_pd_dbg_wgrad_wide;
 extern "C" void pd_dbg_set_wgrad_xcd(int v);
+extern "C" void pd_dbg_set_wgrad_fast(int v);
 extern int g_pd_dbg_bwd_variant;
 extern int g_pd_dbg_msda_gate_pct;
 extern int g_pd_dbg_wgrad_wgs;
@@ -65,6 +66,7 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!strcmp(key, "f16x2_tile")) { g_pd_dbg_f16x2 = value; return PD_OK; }
   if (!strcmp(key, "wgrad_wide")) { g_pd_dbg_wgrad_wide = value; return PD_OK; }
   if (!strcmp(key, "wgrad_xcd")) { pd_dbg_set_wgrad_xcd(value); return PD_OK; }
+  if (!strcmp(key, "wgrad_fast")) { pd_dbg_set_wgrad_fast(value); return PD_OK; }
   if (!strcmp(key, "x3_narrow")) { g_pd_dbg_x3_narrow = value; return PD_OK; }
   if (!strcmp(key, "wattn_ablate")) { g_pd_dbg_wattn = value; return PD_OK; }
   if (!strcmp(key, "msda_force_generic")) { g_pd_dbg_force_generic = value; return PD_OK; }

@@ -58,6 +58,7 @@ __device__ __forceinline__ void mma16k(f32x16 &c, hwbf16x8 x, hwbf16x8 y) { c = 
 __device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
 
 __device__ int g_wgrad_xcd = 1;   // tools only (pd_debug_set "wgrad_xcd" 0: launch order = logical order)
+__device__ int g_wgrad_fast = 1;  // tools only (pd_debug_set "wgrad_fast" 0: the guarded step everywhere)
 __device__ __forceinline__ bool v_never(float x) { return x == 1.2345678e30f; }
 
 // CONV: A is an NHWC image [*, H, W, Ci] and row m of the GEMM is output pixel m of a 3 x 3, stride 1, pad 1 convolution:
@@ -840,7 +841,69 @@ __device__ __forceinline__ void wgrad_h2w_body(const float *__restrict__ dY, con
     if (st + 1 < steps) lstore(par ^ 1, par ^ 1);
     __syncthreads();
   };
-  for (int st = 0; st < steps; st += 2) {
+  int st0 = 0;
+  // Interior tiles (all 256 columns of both operands inside, whole 16-row stages): the same step as ONE basic block — no bounds
+  // branches around the loads, the convolution's halo test a select on a load from the centre pixel's (always valid) address — with
+  // the split, the LDS stores and the next loads laid between the matrix instructions (gemm_f16x2.hip's interleaved step).
+  // The last two steps run through the guarded form.
+  if (g_wgrad_fast && n0 + WTD <= N && k0 + WTD <= K && ((me - mb) % TWS) == 0 && steps >= 4 && (!CONV || W >= TWS)) {
+    const float *py0 = dY + (int64_t)(mb + sr) * ldy + n0 + sc, *px0 = X + (int64_t)(mb + sr) * ldx + (CONV ? xoff : k0 + sc);
+    auto fstep = [&](int st, int par) {
+      const int64_t m = (int64_t)(st + 2) * TWS;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        ry[par][j] = *reinterpret_cast<const float4 *>(py0 + (m + 8 * j) * ldy);
+        if (CONV) {
+          const int yy = cpy[j] + tdy, xx = cpx[j] + tdx;
+          const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+          const float4 v = *reinterpret_cast<const float4 *>(px0 + (m + 8 * j + (ok ? tdy * W + tdx : 0)) * ldx);
+          rx[par][j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+          cpx[j] += TWS;
+          const bool wrap = cpx[j] >= W;
+          cpx[j] -= wrap ? W : 0;
+          cpy[j] = wrap ? (cpy[j] + 1 == H ? 0 : cpy[j] + 1) : cpy[j];
+        } else {
+          rx[par][j] = *reinterpret_cast<const float4 *>(px0 + (m + 8 * j) * ldx);
+        }
+      }
+      hwbf16x8 a[2][2], b[2][4];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[p][i] = frag_trw(S(par, 0, p, frow) + wn + i * 32 + fcol);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[p][j] = frag_trw(S(par, 1, p, frow) + wk + j * 32 + fcol);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = sr + 8 * j;
+        const pdh2::SplitH y = pdh2::split4h(ry[par ^ 1][j], sy), x = pdh2::split4h(rx[par ^ 1][j], sx);
+        *reinterpret_cast<uint2 *>(S(par ^ 1, 0, 0, r) + sc) = y.hi; *reinterpret_cast<uint2 *>(S(par ^ 1, 0, 1, r) + sc) = y.lo;
+        *reinterpret_cast<uint2 *>(S(par ^ 1, 1, 0, r) + sc) = x.hi; *reinterpret_cast<uint2 *>(S(par ^ 1, 1, 1, r) + sc) = x.lo;
+        bsum.x += ry[par ^ 1][j].x; bsum.y += ry[par ^ 1][j].y; bsum.z += ry[par ^ 1][j].z; bsum.w += ry[par ^ 1][j].w;   // read only when do_bias
+      }
+#define WFTERM(PA, PB)                                                       \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                              \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                          \
+        pdh2::mmah(acc[i][j], __builtin_bit_cast(pdh2::h16x8, a[PA][i]), __builtin_bit_cast(pdh2::h16x8, b[PB][j]));
+      WFTERM(1, 0) WFTERM(0, 1) WFTERM(0, 0)
+#undef WFTERM
+      __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);
+#pragma unroll
+      for (int g = 0; g < 24; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        if (g % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if (g % 6 == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __syncthreads();
+    };
+    for (; st0 + 3 < steps; st0 += 2) {
+      fstep(st0, 0);
+      fstep(st0 + 1, 1);
+    }
+  }
+  for (int st = st0; st < steps; st += 2) {
     step(st, 0);
     if (st + 1 < steps) step(st + 1, 1);
   }
@@ -1044,6 +1107,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_reduce(const float *__restrict__
 }  // namespace
 
 extern "C" void pd_dbg_set_wgrad_xcd(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_xcd), &v, sizeof(int)); }
+extern "C" void pd_dbg_set_wgrad_fast(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_fast), &v, sizeof(int)); }
 static uint32_t *const g_relu_bits = nullptr;   // plain pd_gemm_tn_f32x3 launches do not record the sign bits
 int g_pd_dbg_x3_narrow = 0;   // tools/ only (pd_debug_set "x3_narrow"): 1 = never use the 256 x 256 kernel
 int g_pd_dbg_x3 = 0;   // tools/ only (pd_debug_set "x3_ablate"): 1 no MFMA, 2 only hi*hi, 3 no operand split, 4 no output stores
