@@ -85,6 +85,13 @@ int pd_mem_prep_bwd(const void *dmem_c, const void *dmempos_c, int c_dtype, floa
 /* mask[r, k] = logits[r, k] < 0, except rows where that holds for every k, which become all 0.  logits [rows, n] dtype. */
 int pd_attn_mask_u8(const void *logits, int dtype, int rows, int n, uint8_t *mask, void *stream);
 
+/* The Hungarian matcher's per-point terms in one pass (reference modeling/matcher.py:108-158: batch_sigmoid_ce_loss_jit and
+ * batch_dice_loss_jit on the sampled points; replaces .float(), F.softplus, .sigmoid() and two .sum(-1) over [B * heads * Q, points]):
+ * x [rows, n] fp32 / bf16 -> x_f32 [rows, n] (nullable), sigmoid_x [rows, n], softplus_sum [rows] = sum_k softplus(x[r, k]) (beta 1,
+ * threshold 20), sigmoid_sum [rows] = sum_k sigmoid(x[r, k]). */
+int pd_matcher_point_terms(const void *x, int dtype, int rows, int n, float *x_f32, float *sigmoid_x, float *softplus_sum,
+                           float *sigmoid_sum, void *stream);
+
 /*
  * offs fp32 [tokens, M, L, P, 2] and logits fp32 [tokens, M, L*P] with row strides ld_offs / ld_logits in elements (so both can
  * be column ranges of ONE projection output), ref fp32 [tokens, L, 2] (x, y in [0,1]), spatial_shapes int64 [L, 2] (H_l, W_l)

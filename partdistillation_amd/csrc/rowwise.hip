@@ -318,6 +318,39 @@ __global__ __launch_bounds__(256) void attn_mask_u8(const T *__restrict__ logits
   }
 }
 
+// ------------------------------------------------------------------------------------------------ matcher costs
+// One pass over the matcher's point logits x [rows, n] (reference matcher.py:108-158 batch_sigmoid_ce_loss / batch_dice_loss on
+// the sampled points): x as fp32 (the operand of the x . target product), sigmoid(x), and per row sum softplus(x) and
+// sum sigmoid(x) — ATen ran a cast, softplus, sigmoid and two reductions over the 100 MB tensor (183 us).  softplus as torch's
+// (beta 1, threshold 20: x above it is returned as is).  One workgroup per row; fp32 sums, lanes -> wavefront -> workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void matcher_point_terms(const T *__restrict__ x, int n, float *__restrict__ xf, float *__restrict__ sg,
+                                                           float *__restrict__ sp_sum, float *__restrict__ sg_sum)
+{
+  __shared__ float red[2][4];
+  const T *row = x + (int64_t)blockIdx.x * n;
+  float *xo = xf ? xf + (int64_t)blockIdx.x * n : nullptr, *so = sg + (int64_t)blockIdx.x * n;
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float v;
+    if constexpr (sizeof(T) == 2) v = bf2f(row[i]); else v = row[i];
+    const float e = expf(-fabsf(v));
+    const float sp = v > 20.f ? v : fmaxf(v, 0.f) + log1pf(e);
+    const float s = 1.f / (1.f + expf(-v));
+    if (xo) xo[i] = v;
+    so[i] = s;
+    a += sp; b += s;
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sp_sum[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    sg_sum[blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ MSDeformAttn prep
 // one thread per (token, head): softmax over the L*P logits, sampling locations = reference point + offset / (W_l, H_l).
 // LP = L*P values per thread, moved as float4 (LP % 4 == 0, P even): a thread owns 4*LP contiguous bytes of logits / attn
@@ -863,6 +896,17 @@ extern "C" int pd_attn_mask_u8(const void *logits, int dtype, int rows, int n, u
   if (dtype == PD_BF16) hipLaunchKernelGGL((attn_mask_u8<bf16_t>), dim3(rows), dim3(256), 0, (hipStream_t)stream_, (const bf16_t *)logits, n, mask);
   else hipLaunchKernelGGL((attn_mask_u8<float>), dim3(rows), dim3(256), 0, (hipStream_t)stream_, (const float *)logits, n, mask);
   return pd_check_launch("pd_attn_mask_u8");
+}
+
+extern "C" int pd_matcher_point_terms(const void *x, int dtype, int rows, int n, float *x_f32, float *sigmoid_x, float *softplus_sum,
+                                      float *sigmoid_sum, void *stream_)
+{
+  if (rows < 0 || n < 0 || !dt_ok(dtype)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_matcher_point_terms: rows=%d n=%d dtype=%d", rows, n, dtype);
+  if (rows == 0) return PD_OK;
+  if (!x || !sigmoid_x || !softplus_sum || !sigmoid_sum) return pd_set_error(PD_ERR_INVALID_ARG, "pd_matcher_point_terms: null pointer");
+  if (dtype == PD_BF16) hipLaunchKernelGGL((matcher_point_terms<bf16_t>), dim3(rows), dim3(256), 0, (hipStream_t)stream_, (const bf16_t *)x, n, x_f32, sigmoid_x, softplus_sum, sigmoid_sum);
+  else hipLaunchKernelGGL((matcher_point_terms<float>), dim3(rows), dim3(256), 0, (hipStream_t)stream_, (const float *)x, n, x_f32, sigmoid_x, softplus_sum, sigmoid_sum);
+  return pd_check_launch("pd_matcher_point_terms");
 }
 
 extern "C" int pd_msda_prep_fwd(const float *offs, const float *logits, const float *ref, const int64_t *spatial_shapes, float *loc,

@@ -25,7 +25,7 @@ class MaxPool3x3S2(Function):
         x = _nhwc(x)
         B, C, H, W = x.shape
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        y = torch.empty((B, C, OH, OW), dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+        y = torch.empty((B, C, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         arg = torch.empty(B * OH * OW * C, dtype=torch.uint8, device=x.device)
         _lib.check(_lib.load().pd_maxpool3s2_fwd_bf16(x.data_ptr(), y.data_ptr(), arg.data_ptr(), B, H, W, C, _stream()))
         ctx.save_for_backward(arg)
@@ -37,7 +37,7 @@ class MaxPool3x3S2(Function):
         (arg,) = ctx.saved_tensors
         B, C, H, W = ctx.dims
         gy = _nhwc(gy)
-        gx = torch.empty((B, C, H, W), dtype=gy.dtype, device=gy.device).contiguous(memory_format=torch.channels_last)
+        gx = torch.empty((B, C, H, W), dtype=gy.dtype, device=gy.device, memory_format=torch.channels_last)
         _lib.check(_lib.load().pd_maxpool3s2_bwd_bf16(gy.data_ptr(), arg.data_ptr(), gx.data_ptr(), B, H, W, C, _stream()))
         return gx
 

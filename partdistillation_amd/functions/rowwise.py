@@ -135,6 +135,24 @@ def attn_mask_u8(logits):
     return mask
 
 
+def matcher_point_terms(x, want_f32=True):
+    """x [..., n] fp32 / bf16 point logits -> (x as fp32 | None, sigmoid(x), sum softplus(x) over n, sum sigmoid(x) over n): the
+    Hungarian matcher's per-point terms in one pass (pd_matcher_point_terms)"""
+    _need_cuda(x, "pd_matcher_point_terms")
+    assert x.is_contiguous() and x.dtype in _DT
+    n = x.shape[-1]
+    rows = x.numel() // max(n, 1)
+    xf = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_f32 else None
+    sg = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if x.numel() == 0:                                          # no points (or no rows): empty maps, zero sums
+        z = torch.zeros(x.shape[:-1], dtype=torch.float32, device=x.device)
+        return xf, sg, z, z.clone()
+    sums = torch.empty((2,) + tuple(x.shape[:-1]), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().pd_matcher_point_terms(x.data_ptr(), _DT[x.dtype], rows, n, xf.data_ptr() if xf is not None else None, sg.data_ptr(),
+                                                  sums[0].data_ptr(), sums[1].data_ptr(), _stream()))
+    return xf, sg, sums[0], sums[1]
+
+
 def point_sample_nhwc(x, coords, out_dtype=torch.float32):
     """x [B,C,H,W] fp32 (channels-last memory is read in place), coords [B,P,2] (x, y) in [0,1] -> [B,P,C]:
     F.grid_sample(x, 2*coords-1, bilinear, zeros, align_corners=False) for points shared by all channels.
@@ -263,7 +281,7 @@ class UpsampleAdd(Function):
     def backward(ctx, dy):
         B, C, h, w = ctx.dims
         dy = dy.contiguous(memory_format=torch.channels_last)
-        dlo = torch.empty((B, C, h, w), dtype=torch.float32, device=dy.device).contiguous(memory_format=torch.channels_last)
+        dlo = torch.empty((B, C, h, w), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
         _lib.check(_lib.load().pd_upsample2x_bwd_nhwc_f32(dy.data_ptr(), dlo.data_ptr(), B, h, w, C, _stream()))
         return dlo, dy
 

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libpd_hip.so") 
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -87,6 +87,7 @@ SIGNATURES = {
     "pd_mem_prep_fwd": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "pd_mem_prep_bwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
     "pd_attn_mask_u8": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "pd_matcher_point_terms": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
     "pd_msda_prep_fwd": (_c_int, [_c_vp] * 6 + [ctypes.c_int64] + [_c_int] * 5 + [_c_vp]),
     "pd_msda_prep_bwd_amax": (_c_int, [_c_vp] * 7 + [ctypes.c_int64] + [_c_int] * 5 + [_c_vp]),
     "pd_msda_forward_amax": (_c_int, [_c_vp] * 7 + [_c_int] * 9 + [_c_vp]),

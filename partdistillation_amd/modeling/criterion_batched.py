@@ -199,14 +199,20 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
             fm = rw.point_sample_nhwc(mfeat.detach(), mc_bd.reshape(B, H * Pm, 2),                # [B, D*Pm, C], already in e's dtype
                                       out_dtype=e.dtype if e.dtype == torch.bfloat16 else torch.float32)
             # bf16 mask embeddings (autocast): the reference's mask logits are a bf16 product too (einsum under AMP, :449)
-            pm = torch.bmm(e, fm.view(B * H, Pm, -1).to(e.dtype).transpose(1, 2)).float()
+            pm = torch.bmm(e, fm.view(B * H, Pm, -1).to(e.dtype).transpose(1, 2))
         else:
             pm = _gs(masks_bd.detach().reshape(B * H, Q, *masks_bd.shape[-2:]).float(), mc_bd.reshape(B * H, Pm, 2))   # [BD,Q,Pm]
         tg = _gs(tmask, mc_bd.reshape(B, H * Pm, 2)).reshape(B, nmax, H, Pm).transpose(1, 2).reshape(B * H, nmax, Pm)
         tgt = tg.transpose(1, 2)
-        cost_mask = (F.softplus(pm).sum(-1)[:, :, None] - torch.bmm(pm, tgt)) / Pm
-        sg = pm.sigmoid()
-        cost_dice = 1 - (2 * torch.bmm(sg, tgt) + 1) / (sg.sum(-1)[:, :, None] + tg.sum(-1)[:, None, :] + 1)
+        if pm.is_cuda and pm.is_contiguous() and pm.dtype in (torch.float32, torch.bfloat16):
+            # .float(), softplus, sigmoid and their two row sums in one pass over the [B heads Q, points] logits (pd_matcher_point_terms)
+            pm, sg, sp_sum, sg_sum = rw.matcher_point_terms(pm)
+        else:
+            pm = pm.float()
+            sg = pm.sigmoid()
+            sp_sum, sg_sum = F.softplus(pm).sum(-1), sg.sum(-1)
+        cost_mask = (sp_sum[:, :, None] - torch.bmm(pm, tgt)) / Pm
+        cost_dice = 1 - (2 * torch.bmm(sg, tgt) + 1) / (sg_sum[:, :, None] + tg.sum(-1)[:, None, :] + 1)
         lf = logits_bd.detach().float()
         prob = lf.sigmoid() if K1 == 1 else lf.softmax(-1)
         cost_class = -torch.gather(prob, 3, labels_pad[:, None, None, :].expand(B, H, Q, nmax)).reshape(B * H, Q, nmax)

@@ -118,7 +118,28 @@ class LevelPos(torch.autograd.Function):
     @staticmethod
     def forward(ctx, level_embed, *pos_embeds):
         ctx.sizes = [int(p.shape[2] * p.shape[3]) for p in pos_embeds]
-        return torch.cat([p.flatten(2).transpose(1, 2) + level_embed[i].view(1, 1, -1) for i, p in enumerate(pos_embeds)], 1)
+        # every level's sum written straight into its rows of the result (three add launches; adds + torch.cat were 117 us for 44 MB)
+        B, C = pos_embeds[0].shape[:2]
+        out = torch.empty((B, sum(ctx.sizes), C), dtype=pos_embeds[0].dtype, device=pos_embeds[0].device)
+        # the sine tables are per-shape constants broadcast over the batch (PositionEmbeddingSine.table): their token-major form
+        # [S, C] is kept, so a step reads contiguous rows instead of transposing three NCHW tables
+        flat = None
+        if all(p.stride(0) == 0 for p in pos_embeds):
+            key = tuple((p.data_ptr(), tuple(p.shape)) for p in pos_embeds)
+            hit = LevelPos._flat.get(key)
+            if hit is None:
+                if len(LevelPos._flat) >= 8:
+                    LevelPos._flat.clear()
+                hit = LevelPos._flat[key] = (torch.cat([p[0].flatten(1).t() for p in pos_embeds]).contiguous(), pos_embeds)   # (+ the sources: the addresses stay theirs)
+            flat = hit[0]
+        o = 0
+        for i, (p, n) in enumerate(zip(pos_embeds, ctx.sizes)):
+            a = flat[o:o + n].unsqueeze(0).expand(B, -1, -1) if flat is not None else p.flatten(2).transpose(1, 2)
+            torch.add(a, level_embed[i].view(1, 1, -1), out=out[:, o:o + n])
+            o += n
+        return out
+
+    _flat = {}
 
     @staticmethod
     def backward(ctx, d_pos):
@@ -132,6 +153,32 @@ class LevelPos(torch.autograd.Function):
                 colsum_acc(d_pos[b, start:start + n], d_le[l])
             start += n
         return (d_le,) + (None,) * len(ctx.sizes)
+
+
+class CatLevels(torch.autograd.Function):
+    """the levels' tokens side by side, [B, sum h_l w_l, C] from NCHW-shaped maps: three strided copies into one buffer (torch.cat's
+    batched-copy kernel takes 76 us for these 44 MB).  Its own autograd node because the backward of slice assignments
+    (CopySlices) clones the whole gradient once per level (78 us); the gradients of a concatenation are just views."""
+
+    @staticmethod
+    def forward(ctx, *srcs):
+        ctx.shapes = [tuple(s.shape) for s in srcs]
+        B, C = srcs[0].shape[:2]
+        sizes = [s.shape[2] * s.shape[3] for s in srcs]
+        out = torch.empty((B, sum(sizes), C), dtype=srcs[0].dtype, device=srcs[0].device)
+        o = 0
+        for s_, n in zip(srcs, sizes):
+            out[:, o:o + n].copy_(s_.flatten(2).transpose(1, 2))
+            o += n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for (B, C, h, w) in ctx.shapes:
+            outs.append(g[:, o:o + h * w].transpose(1, 2).reshape(B, C, h, w))      # a view: NHWC storage inside g
+            o += h * w
+        return tuple(outs)
 
 
 class MSDeformAttnTransformerEncoderOnly(nn.Module):
@@ -164,14 +211,7 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
             self._shape_cache[key] = (sh, torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1])))
         spatial_shapes, level_start_index = self._shape_cache[key]
         if srcs[0].is_cuda:
-            # the levels' tokens side by side: three strided copies (torch.cat's batched-copy kernel takes 76 us for these 44 MB)
-            B_, C_ = srcs[0].shape[0], srcs[0].shape[1]
-            sizes = [h * w for h, w in shapes_host]
-            src = torch.empty((B_, sum(sizes), C_), dtype=srcs[0].dtype, device=srcs[0].device)
-            o = 0
-            for s_, n in zip(srcs, sizes):
-                src[:, o:o + n].copy_(s_.flatten(2).transpose(1, 2))
-                o += n
+            src = CatLevels.apply(*srcs)
         else:
             src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         if src.is_cuda and src.dtype == torch.float32 and self.level_embed.dtype == torch.float32 and self.d_model % 128 == 0:

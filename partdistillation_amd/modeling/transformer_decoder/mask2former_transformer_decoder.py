@@ -307,6 +307,10 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         sizes = [tuple(t.shape[-2:]) for t in x]
         with torch.no_grad():                                                   # the three mask resolutions, once
             pooled = [F.interpolate(mask_features, size=s, mode="bilinear", align_corners=False).flatten(2).float() for s in sizes]
+            if cdt == torch.bfloat16 and torch.is_autocast_enabled():
+                # the heads' mask logits are autocast bmm's: the B operand in the GEMM dtype once per level, not once per head
+                # (the same rounding, nine cast launches less)
+                pooled = [p.to(cdt) for p in pooled]
         spec = DecoderSpec(bs, Q, C, self.num_heads, L, sizes, [self._pos_table_rows(h, w, x[0].device) for h, w in sizes],
                            pooled, self.decoder_norm.eps, cdt, self.num_feature_levels)
         dec_outs, final_tgt = DecoderCore.apply(spec, *x, *self._core_params())          # [L+1, Q*B, C] fp32, [Q*B, C]

@@ -366,3 +366,21 @@ def test_point_sample_planar_vs_grid_sample(N, C, H, W, P):
     (gx,) = torch.autograd.grad(y, x, go)
     (rx,) = torch.autograd.grad(ref, x, go)
     torch.testing.assert_close(gx, rx, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(20, 100, 12544), (3, 7, 130), (1, 1, 1), (4, 5, 0)])
+def test_matcher_point_terms_match_torch(dtype, shape):
+    """pd_matcher_point_terms: the matcher's .float() / softplus / sigmoid / row sums in one pass (reference matcher.py:108-158),
+    over the logit range softplus switches branches in (|x| up to 40)."""
+    from partdistillation_amd.functions import rowwise as rw
+    torch.manual_seed(sum(shape))
+    x = (torch.randn(shape, device="cuda") * 12).to(dtype)
+    if x.numel() > 4:
+        x.view(-1)[:4] = torch.tensor([0.0, 20.0, 20.5, -45.0], device="cuda").to(dtype)
+    xf, sg, sp_sum, sg_sum = rw.matcher_point_terms(x)
+    ref = x.float()
+    assert torch.equal(xf, ref)
+    torch.testing.assert_close(sg, ref.sigmoid(), rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(sp_sum, torch.nn.functional.softplus(ref.double()).sum(-1).float(), rtol=2e-6, atol=1e-5)
+    torch.testing.assert_close(sg_sum, ref.double().sigmoid().sum(-1).float(), rtol=2e-6, atol=1e-5)
