@@ -55,10 +55,11 @@ int pd_sgemm_tn_multi_bf16(const PdSgemmTnDesc *descs, int count, int K, void *s
 /* One prediction head of the masked-attention decoder in one launch (reference mask2former_transformer_decoder.py:449-459 +
  * :198-204; the in-loop mask prediction carries no gradient, :457):  dec_out[R,256] = LayerNorm(tgt) in fp32 with mean / rstd [R];
  * when ef != NULL also e = W3 relu(W2 relu(W1 bf16(dec_out) + b1) + b2) + b3 (bf16 weights [256,256] / biases [256], fp32 accumulation,
- * bf16 roundings where the three Linears would round) written batch-major in fp32: ef[b][q][:] = e[q B + b][:], R = Q B rows. */
+ * bf16 roundings where the three Linears would round) written batch-major: ef[b][q][:] = e[q B + b][:], R = Q B rows, as fp32
+ * (the bf16 values widened) or, ef_bf16 != 0, as bf16 (what an autocast bmm would cast them back to). */
 int pd_decoder_head_bf16(const float *tgt, const float *ln_w, const float *ln_b, float eps, const void *w1, const void *b1, const void *w2,
-                         const void *b2, const void *w3, const void *b3, float *dec_out, float *mean, float *rstd, float *ef, int R, int B, int C,
-                         void *stream);
+                         const void *b2, const void *w3, const void *b3, float *dec_out, float *mean, float *rstd, void *ef, int ef_bf16, int R,
+                         int B, int C, void *stream);
 
 /* dW[N,K] = dY[M,N]^T . X[M,K];  dB[N] (fp32, nullable) = column sums of dY       nn.Linear weight / bias gradient.
  * Any M >= 0 (rows past M count as zeros); N % 4 == 0, K % 4 == 0. */

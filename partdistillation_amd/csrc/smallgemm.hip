@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void decoder_head_256(const float *__restrict_
                                                         float eps, const bf16_t *__restrict__ w1, const bf16_t *__restrict__ b1,
                                                         const bf16_t *__restrict__ w2, const bf16_t *__restrict__ b2,
                                                         const bf16_t *__restrict__ w3, const bf16_t *__restrict__ b3, float *__restrict__ dec_out,
-                                                        float *__restrict__ mean, float *__restrict__ rstd, float *__restrict__ ef, int R, int B)
+                                                        float *__restrict__ mean, float *__restrict__ rstd, void *__restrict__ ef_, int ef_bf16,
+                                                        int R, int B)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char sg_smem[];
   bf16_t(*Xs)[PK256] = reinterpret_cast<bf16_t(*)[PK256]>(sg_smem);                       // [32][PK256]
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void decoder_head_256(const float *__restrict_
       *reinterpret_cast<bf16x4 *>(&Xs[row][lane * 4]) = pack4(o4.x, o4.y, o4.z, o4.w);
     }
   }
-  if (!ef) return;                                               // the last head: no mask prediction follows
+  if (!ef_) return;                                              // the last head: no mask prediction follows
   const int prow = tid >> 5, pcol = (tid & 31) * 8;
 #pragma unroll 1
   for (int layer = 0; layer < 3; ++layer) {
@@ -363,8 +364,11 @@ __global__ __launch_bounds__(256) void decoder_head_256(const float *__restrict_
           *reinterpret_cast<bf16x4 *>(&Xs[r][n0]) = pack4(v[0], v[1], v[2], v[3]);     // the next layer's input (rounded like a bf16 Linear's output)
         } else if (m < R) {
           const int q = m / B, b = m - q * B, Q = R / B;         // rounded to bf16 like the Linear's output, then widened
-          *reinterpret_cast<float4 *>(ef + ((int64_t)b * Q + q) * 256 + n0) =
-              make_float4(bf_lo(pk_bf16(v[0], 0.f)), bf_lo(pk_bf16(v[1], 0.f)), bf_lo(pk_bf16(v[2], 0.f)), bf_lo(pk_bf16(v[3], 0.f)));
+          if (ef_bf16)                                           // the product that follows runs in bf16 (autocast): no widening, no cast launch
+            *reinterpret_cast<bf16x4 *>(reinterpret_cast<bf16_t *>(ef_) + ((int64_t)b * Q + q) * 256 + n0) = pack4(v[0], v[1], v[2], v[3]);
+          else
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(ef_) + ((int64_t)b * Q + q) * 256 + n0) =
+                make_float4(bf_lo(pk_bf16(v[0], 0.f)), bf_lo(pk_bf16(v[1], 0.f)), bf_lo(pk_bf16(v[2], 0.f)), bf_lo(pk_bf16(v[3], 0.f)));
         }
       }
     // (the next layer's weight stores are followed by a barrier before anyone reads Xs again)
@@ -795,8 +799,8 @@ extern "C" int pd_sgemm_tn_multi_bf16(const PdSgemmTnDesc *d, int count, int K, 
 }
 
 extern "C" int pd_decoder_head_bf16(const float *tgt, const float *ln_w, const float *ln_b, float eps, const void *w1, const void *b1, const void *w2,
-                                    const void *b2, const void *w3, const void *b3, float *dec_out, float *mean, float *rstd, float *ef, int R, int B,
-                                    int C, void *stream_)
+                                    const void *b2, const void *w3, const void *b3, float *dec_out, float *mean, float *rstd, void *ef, int ef_bf16,
+                                    int R, int B, int C, void *stream_)
 {
   if (R < 0 || B <= 0 || C != 256 || (R % B)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_decoder_head_bf16: R=%d B=%d C=%d (C must be 256, R a multiple of B)", R, B, C);
   if (R == 0) return PD_OK;
@@ -806,7 +810,7 @@ extern "C" int pd_decoder_head_bf16(const float *tgt, const float *ln_w, const f
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)decoder_head_256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   hipLaunchKernelGGL(decoder_head_256, dim3((R + 31) / 32), dim3(256), lds, (hipStream_t)stream_, tgt, ln_w, ln_b, eps, (const bf16_t *)w1,
-                     (const bf16_t *)b1, (const bf16_t *)w2, (const bf16_t *)b2, (const bf16_t *)w3, (const bf16_t *)b3, dec_out, mean, rstd, ef, R, B);
+                     (const bf16_t *)b1, (const bf16_t *)w2, (const bf16_t *)b2, (const bf16_t *)w3, (const bf16_t *)b3, dec_out, mean, rstd, ef, ef_bf16, R, B);
   return pd_check_launch("pd_decoder_head_bf16");
 }
 

@@ -271,6 +271,15 @@ class EncoderCore(Function):
         # stack + one copy per weight shape instead of one small launch per layer and weight
         def T_all(j):
             ws = [params[i * N_LAYER + j] for i in range(nl)]
+            # the layers' parameters usually sit at one spacing in a flat buffer (engine/flat_params.py): the stack is then a strided
+            # VIEW and the transposed copy the only launch (torch.stack was a second one per weight kind, 42 us per step)
+            d = (ws[1].data_ptr() - ws[0].data_ptr()) if nl > 1 else 0
+            es = ws[0].element_size()
+            if nl > 1 and d > 0 and d % es == 0 and all(w.is_contiguous() and w.shape == ws[0].shape for w in ws) \
+                    and all(ws[i].data_ptr() - ws[0].data_ptr() == i * d for i in range(nl)) \
+                    and all(w.untyped_storage().data_ptr() == ws[0].untyped_storage().data_ptr() for w in ws):
+                N_, K_ = ws[0].shape
+                return torch.as_strided(ws[0], (nl, N_, K_), (d // es, K_, 1)).transpose(1, 2).contiguous()
             return torch.stack(ws).transpose(1, 2).contiguous()
         l1_t, l2_t = T_all(10), T_all(12)
         op_t, vp_t = (T_all(6), T_all(4)) if X3_PROJ and USE_X3 else (None, None)

@@ -93,7 +93,7 @@ SIGNATURES = {
     "pd_msda_forward_amax": (_c_int, [_c_vp] * 7 + [_c_int] * 9 + [_c_vp]),
     "pd_msda_prep_bwd": (_c_int, [_c_vp] * 6 + [ctypes.c_int64] + [_c_int] * 5 + [_c_vp]),
     "pd_sgemm_tn_multi_bf16": (_c_int, [_c_vp, _c_int, _c_int, _c_vp]),
-    "pd_decoder_head_bf16": (_c_int, [_c_vp] * 3 + [ctypes.c_float] + [_c_vp] * 10 + [_c_int] * 3 + [_c_vp]),
+    "pd_decoder_head_bf16": (_c_int, [_c_vp] * 3 + [ctypes.c_float] + [_c_vp] * 10 + [_c_int] * 4 + [_c_vp]),
     "pd_sgemm_split_workspace_floats": (ctypes.c_int64, [_c_int] * 3),
     "pd_sgemm_split_tickets": (ctypes.c_int64, [_c_int] * 2),
     "pd_sgemm_tn_splitk_bf16": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_vp] + [_c_int] * 7 + [_c_vp]),

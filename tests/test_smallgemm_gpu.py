@@ -122,7 +122,7 @@ def test_fused_decoder_head_matches_layernorm_and_the_three_linears(Q, B):
     dec = torch.empty(R, C, device="cuda"); stats = torch.empty(2, R, device="cuda"); ef = torch.full((B, Q, C), float("nan"), device="cuda")
     L = lib.load()
     lib.check(L.pd_decoder_head_bf16(tgt.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-5, ws[0].data_ptr(), bs[0].data_ptr(), ws[1].data_ptr(), bs[1].data_ptr(),
-                                     ws[2].data_ptr(), bs[2].data_ptr(), dec.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ef.data_ptr(), R, B, C,
+                                     ws[2].data_ptr(), bs[2].data_ptr(), dec.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ef.data_ptr(), 0, R, B, C,
                                      lib.current_stream()))
     ref = F.layer_norm(tgt, (C,), lw, lb, 1e-5)
     torch.testing.assert_close(dec, ref, rtol=1e-5, atol=1e-5)
@@ -132,9 +132,14 @@ def test_fused_decoder_head_matches_layernorm_and_the_three_linears(Q, B):
     want = e.view(Q, B, C).transpose(0, 1).float()
     assert not torch.isnan(ef).any()
     torch.testing.assert_close(ef, want, rtol=2e-2, atol=2e-2)                     # same roundings, different summation order
+    ef16 = torch.full((B, Q, C), float("nan"), device="cuda", dtype=torch.bfloat16)   # the bf16 form: exactly the values the fp32 form widened
+    lib.check(L.pd_decoder_head_bf16(tgt.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-5, ws[0].data_ptr(), bs[0].data_ptr(), ws[1].data_ptr(), bs[1].data_ptr(),
+                                     ws[2].data_ptr(), bs[2].data_ptr(), dec.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ef16.data_ptr(), 1, R, B, C,
+                                     lib.current_stream()))
+    assert torch.equal(ef16.float(), ef)
     dec2 = torch.empty(R, C, device="cuda")
     lib.check(L.pd_decoder_head_bf16(tgt.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-5, None, None, None, None, None, None, dec2.data_ptr(),
-                                     stats[0].data_ptr(), stats[1].data_ptr(), None, R, B, C, lib.current_stream()))
+                                     stats[0].data_ptr(), stats[1].data_ptr(), None, 0, R, B, C, lib.current_stream()))
     assert torch.equal(dec2, dec)
 
 
