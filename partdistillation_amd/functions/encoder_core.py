@@ -118,6 +118,16 @@ def _ffn_gemm(x, w, b=None, relu=False):
     return torch.addmm(b, x, w.t()) if b is not None else torch.mm(x, w.t())
 
 
+class _Stack:
+    """[layers, ...] tensor indexed by layer, stored in either layer order (rev: the last layer first)"""
+
+    def __init__(self, t, rev):
+        self.t, self.rev = t, rev
+
+    def __getitem__(self, i):
+        return self.t[self.t.shape[0] - 1 - i if self.rev else i]
+
+
 class EncoderCore(Function):
     @staticmethod
     def forward(ctx, spec: EncoderSpec, src, pos, *params):
@@ -271,22 +281,23 @@ class EncoderCore(Function):
         # stack + one copy per weight shape instead of one small launch per layer and weight
         def T_all(j):
             ws = [params[i * N_LAYER + j] for i in range(nl)]
-            # the layers' parameters usually sit at one spacing in a flat buffer (engine/flat_params.py): the stack is then a strided
-            # VIEW and the transposed copy the only launch (torch.stack was a second one per weight kind, 42 us per step)
+            # the layers' parameters usually sit at one spacing in a flat buffer (engine/flat_params.py, last layer first): the stack is
+            # then a strided VIEW and the transposed copy the only launch (torch.stack was a second one per weight kind, 42 us per step)
             d = (ws[1].data_ptr() - ws[0].data_ptr()) if nl > 1 else 0
             es = ws[0].element_size()
-            if nl > 1 and d > 0 and d % es == 0 and all(w.is_contiguous() and w.shape == ws[0].shape for w in ws) \
+            if nl > 1 and d != 0 and d % es == 0 and all(w.is_contiguous() and w.shape == ws[0].shape for w in ws) \
                     and all(ws[i].data_ptr() - ws[0].data_ptr() == i * d for i in range(nl)) \
                     and all(w.untyped_storage().data_ptr() == ws[0].untyped_storage().data_ptr() for w in ws):
                 N_, K_ = ws[0].shape
-                return torch.as_strided(ws[0], (nl, N_, K_), (d // es, K_, 1)).transpose(1, 2).contiguous()
-            return torch.stack(ws).transpose(1, 2).contiguous()
+                base = ws[0] if d > 0 else ws[-1]                 # lowest address first; _Stack maps the layer index back
+                return _Stack(torch.as_strided(base, (nl, N_, K_), (abs(d) // es, K_, 1)).transpose(1, 2).contiguous(), d < 0)
+            return _Stack(torch.stack(ws).transpose(1, 2).contiguous(), False)
         l1_t, l2_t = T_all(10), T_all(12)
         op_t, vp_t = (T_all(6), T_all(4)) if X3_PROJ and USE_X3 else (None, None)
-        oa_t = torch.stack([sv[14] for sv in ctx.saved]).transpose(1, 2).contiguous() if op_t is not None else None
+        oa_t = _Stack(torch.stack([sv[14] for sv in ctx.saved]).transpose(1, 2).contiguous(), False) if op_t is not None else None
         if h2:
             # row maxima of the transposed weights (the B operands of the input-gradient GEMMs), one launch per stack
-            t_am = lambda w: row_amax(w.view(-1, w.shape[2])).view(nl, w.shape[1])
+            t_am = lambda w: _Stack(row_amax(w.t.view(-1, w.t.shape[2])).view(nl, w.t.shape[1]), w.rev)
             l1_tam, l2_tam, op_tam, vp_tam, oa_tam = t_am(l1_t), t_am(l2_t), t_am(op_t), t_am(vp_t), t_am(oa_t)
             dh_am_all = torch.zeros((nl, T), dtype=torch.float32, device=dev)
         dy = d_out.reshape(T, C)
