@@ -520,7 +520,7 @@ def main():
                                  "n_losses": len(rel), "max_rel_loss_dev": rel[worst], "max_abs_loss_dev": max(ab.values()), "worst_term": worst,
                                  "total_gpu": sum(parity_gpu.values()), "total_cpu": sum(po["losses"].values()),
                                  "assignments_differing_from_oracle_optimum": po["assignments_differing"],
-                                 "assignment_cost_gap_rel": po["assignment_cost_gap"], "tolerance_rel": 2e-2,
+                                 "assignment_cost_gap_rel": po["assignment_cost_gap"], "tolerance_rel": 2e-2, "tolerance_abs": 2e-3,   # |gpu - cpu| <= rel |cpu| + abs per term
                                  "within_tolerance": all(ab[k] <= 2e-2 * abs(po["losses"][k]) + 2e-3 for k in ab)}
             elif parity_gpu is not None:
                 out["parity"] = {"error": (po or {}).get("error", "the oracle child returned no losses")}

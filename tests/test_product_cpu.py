@@ -234,3 +234,29 @@ def test_msda_is_a_registered_torch_library_operator():
     with pytest.raises(NotImplementedError):
         torch.ops.pd.ms_deform_attn_forward(torch.zeros(1, 4, 2, 2), torch.tensor([[2, 2]]), torch.tensor([0]), torch.zeros(1, 3, 2, 1, 2, 2),
                                             torch.zeros(1, 3, 2, 1, 2), 1)
+
+
+def test_cat_levels_is_torch_cat_with_view_gradients():
+    """modeling/pixel_decoder/msdeformattn.CatLevels: the encoder's level tokens side by side; same values and gradients as
+    torch.cat of the flattened maps, and the gradients are views of the incoming gradient (no copies)."""
+    from partdistillation_amd.modeling.pixel_decoder.msdeformattn import CatLevels
+    torch.manual_seed(0)
+    srcs = [torch.randn(2, 8, h, w, requires_grad=True) for h, w in [(2, 3), (4, 6), (8, 12)]]
+    ref = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+    out = CatLevels.apply(*srcs)
+    assert torch.equal(out, ref)
+    g = torch.randn_like(out)
+    for a, b in zip(torch.autograd.grad(ref, srcs, g), torch.autograd.grad(out, srcs, g)):
+        assert torch.equal(a, b)
+        assert b.untyped_storage().data_ptr() == g.untyped_storage().data_ptr()
+
+
+def test_pseudo_targets_form_object_masks_on_first_read():
+    from partdistillation_amd.proposal_model import _PseudoTargets
+    m = torch.rand(3, 5, 7) > 0.5
+    t = _PseudoTargets({"labels": torch.zeros(3, dtype=torch.long), "masks": m})
+    assert "object_masks" not in t
+    om = t["object_masks"]
+    assert om.dtype == torch.int64 and torch.equal(om, m.sum(0, keepdim=True)) and "object_masks" in t
+    with pytest.raises(KeyError):
+        t["nothing"]

@@ -535,6 +535,39 @@ def test_loss_curve_matches_oracle_over_optimizer_steps():
     assert worst < 2e-2, worst
 
 
+def test_preprocess_and_level_positions_fast_paths_equal_the_plain_forms():
+    """ProposalModel.preprocess writes (x - mean) / std of same-size images straight into a channels-last batch, LevelPos adds the level
+    embedding to a cached token-major sine table: both bit-identical to the plain torch forms (reference proposal_model.py:163-165,
+    msdeformattn.py:80-84), for float and uint8 images and across repeated calls (the cache)."""
+    import partdistillation_amd.modeling  # noqa: F401  (registers the classes)
+    import partdistillation_amd.proposal_model  # noqa: F401
+    from partdistillation_amd.compat import build_model
+    from partdistillation_amd.compat.structures import ImageList
+    from partdistillation_amd.modeling.pixel_decoder.msdeformattn import LevelPos
+    from partdistillation_amd.modeling.transformer_decoder.position_encoding import PositionEmbeddingSine
+    model = build_model(_toy_cfg()).to(DEV)
+    for dt in (torch.float32, torch.uint8):
+        imgs = [(torch.rand(3, 64, 96, device=DEV) * 255).to(dt) for _ in range(2)]
+        got = model.preprocess([{"image": i} for i in imgs])
+        want = ImageList.from_tensors([(i - model.pixel_mean) / model.pixel_std for i in imgs], model.size_divisibility)
+        assert torch.equal(got.tensor, want.tensor) and got.image_sizes == want.image_sizes
+        assert got.tensor.is_contiguous(memory_format=torch.channels_last)
+    ragged = [torch.rand(3, 64, 96, device=DEV), torch.rand(3, 48, 80, device=DEV)]                     # different sizes: the padding path
+    got = model.preprocess([{"image": i} for i in ragged])
+    want = ImageList.from_tensors([(i - model.pixel_mean) / model.pixel_std for i in ragged], model.size_divisibility)
+    assert torch.equal(got.tensor, want.tensor)
+    pe = PositionEmbeddingSine(128, normalize=True)
+    maps = [torch.empty(2, 256, h, w, device=DEV) for h, w in [(4, 6), (8, 12), (16, 24)]]
+    pos = [pe(m) for m in maps]
+    for seed in (0, 1):                                                                                 # second call: the cached table
+        le = torch.randn(3, 256, device=DEV, generator=torch.Generator(device=DEV).manual_seed(600 + seed)).requires_grad_()
+        want = torch.cat([p.flatten(2).transpose(1, 2) + le[i].view(1, 1, -1) for i, p in enumerate(pos)], 1)
+        got = LevelPos.apply(le, *pos)
+        assert torch.equal(got, want)
+        g = torch.randn(want.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(610 + seed))
+        torch.testing.assert_close(torch.autograd.grad(got, le, g)[0], torch.autograd.grad(want, le, g)[0], rtol=1e-5, atol=1e-4)
+
+
 def test_training_step_with_an_image_without_masks_takes_the_per_head_loop():
     """an image with zero pseudo masks cannot go through the batched criterion: the per-head loop runs and materialises the
     dense masks the decoder skipped (materialize_masks); losses stay finite and the step completes"""
