@@ -11,10 +11,15 @@ from partdistillation_amd.config import setup_cfg
 from partdistillation_amd.engine.synthetic import make_batch
 from partdistillation_amd.engine.trainer import TrainStep
 torch.backends.cudnn.benchmark = True
-cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd/configs/proposal_learning/r50_mask2former.yaml"), [])
+name = os.environ.get("PD_CONFIG", "")                # "" = config 2 (R50 proposal learning); swinb = config 3, swinl = config 5 (SIZE=1280)
+size = int(os.environ.get("SIZE", "1024"))
+if name:
+    cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd/configs/part_distillation", name + "_mask2former.yaml"), ["INPUT.IMAGE_SIZE", str(size)])
+else:
+    cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd/configs/proposal_learning/r50_mask2former.yaml"), ["INPUT.IMAGE_SIZE", str(size)])
 torch.manual_seed(0)
 step = TrainStep(cfg)
-batches = [make_batch(2, 1024, seed=1234 + 1000 * i, device="cuda") for i in range(2)]
+batches = [make_batch(2, size, seed=1234 + 1000 * i, device="cuda", part_distillation=bool(name)) for i in range(2)]
 for i in range(6):
     step(batches[i % 2])
 torch.cuda.synchronize()
