@@ -50,11 +50,16 @@ def fwd_raw(qkv, table, regions, scale, n_windows):
     return out, lse
 
 
-def bwd_raw(qkv, table, regions, out, d_out, lse, scale, n_windows):
+def bwd_raw(qkv, table, regions, out, d_out, lse, scale, n_windows, dtable=None):
+    """dtable: a ZERO-FILLED fp32 [529, heads] slot for the bias-table gradient (a stage hands out slices of one buffer, one fill
+    for all its blocks); None allocates one"""
     B_, heads = qkv.shape[0], table.shape[1]
     assert d_out.is_contiguous() and d_out.dtype == torch.bfloat16
     dqkv = torch.empty_like(qkv)
-    dtable = torch.zeros_like(table)
+    if dtable is None:
+        dtable = torch.zeros_like(table)
+    else:
+        assert dtable.shape == table.shape and dtable.dtype == table.dtype and dtable.is_contiguous()
     reg, flags = regions if regions is not None else (None, None)
     _lib.check(_lib.load().pd_window_attn_bwd_w12(qkv.data_ptr(), table.data_ptr(), reg.data_ptr() if reg is not None else None,
                                                   flags.data_ptr() if flags is not None else None, out.data_ptr(), d_out.data_ptr(),

@@ -70,10 +70,11 @@ class PartDistillationModel(_MaskFormerTrainBase):
                     num_object_classes=pd.NUM_OBJECT_CLASSES)
 
     def _prepare_pseudo_targets(self, inputs, images):
+        from .proposal_model import _count_masks
         targets = []
         for x, (inst, m) in zip(inputs, self._pad_pseudo_masks(inputs, images)):
             targets.append({"labels": inst.gt_classes.long().to(self.device), "masks": m,
-                            "object_masks": m.sum(0, keepdim=True), "gt_object_class": int(x["gt_object_class"])})
+                            "object_masks": _count_masks(m), "gt_object_class": int(x["gt_object_class"])})
         return targets
 
     def forward(self, batched_inputs):

@@ -121,13 +121,21 @@ class _MaskFormerTrainBase(nn.Module):
         return out
 
 
+def _count_masks(m):
+    """m.sum(0, keepdim=True) of the reference's prepare_targets (int64 count of the part masks covering a pixel).  For bool masks the
+    bytes are summed as uint8 with an int64 accumulator: ATen otherwise first writes an int64 copy of the masks (33 MB per image)."""
+    if m.dtype == torch.bool:
+        return m.view(torch.uint8).sum(0, keepdim=True, dtype=torch.int64)
+    return m.sum(0, keepdim=True)
+
+
 class _PseudoTargets(dict):
     """a training target; "object_masks" (the union count of the part masks, reference proposal_model.py prepare_targets) is formed
     when somebody reads it: the proposal criterion does not, and the bool -> int64 cast + sum over [n, 1024, 1024] cost 95 us per step"""
 
     def __missing__(self, key):
         if key == "object_masks":
-            v = self["masks"].sum(0, keepdim=True)
+            v = _count_masks(self["masks"])
             self[key] = v
             return v
         raise KeyError(key)
