@@ -51,7 +51,8 @@ for i in range(3):
     step(batches[i % 4])
 pr.disable()
 torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats("tottime")
 import io
-buf = io.StringIO(); st.stream = buf; st.print_stats(45)
-print("\n".join(l[:170] for l in buf.getvalue().splitlines()[:70]))
+for key, n in (("tottime", 45), ("cumtime", 60)):
+    st = pstats.Stats(pr); st.sort_stats(key)
+    buf = io.StringIO(); st.stream = buf; st.print_stats(n)
+    print("\n".join(l[:170] for l in buf.getvalue().splitlines()[:n + 12]))
