@@ -13,7 +13,7 @@
  *               grad_sampling_loc / grad_attn_weight; scatter-add grad_value)
  * which is the same function as the PyTorch fallback the reference actually
  * runs (functions/ms_deform_attn_func.py:55-75, F.grid_sample bilinear /
- * zeros / align_corners=False) — pinned against it in tests/test_oracle_msda.py
+ * zeros / align_corners=False) — pinned against it in tests/test_oracle.py
  * with the reference's own fixture (ops/test.py:27-34, torch.manual_seed(3)).
  *
  * Layouts (all contiguous, row-major):

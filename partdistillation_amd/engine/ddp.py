@@ -29,8 +29,10 @@ class _Bucket:
 
 
 class BucketedGradReducer:
-    def __init__(self, flat, bucket_mb: float = 25.0, process_group=None, overlap: bool = True, optimizer=None):
+    def __init__(self, flat, bucket_mb: float = 25.0, process_group=None, overlap: bool = True, optimizer=None, sparse_rows_cap: int = 256):
         self.flat, self.pg, self.optimizer = flat, process_group, optimizer
+        self.sparse_rows_cap = int(sparse_rows_cap)       # rows per rank of the static row-sparse exchange (_exchange_rows); same on every rank
+        self._overflow = []
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.buckets: List[_Bucket] = []
         self._param_bucket = {}
@@ -57,7 +59,6 @@ class BucketedGradReducer:
         for i, b in enumerate(self.buckets):
             b.index = i
         self._next = 0                    # collectives are issued in bucket-index order on every rank (see _on_grad)
-        self._row_meta = {}               # sparse group -> (rows, [R max, any rank without a record], event)
         self._use_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         dev = flat.groups[0].grad.device
         self._side = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and overlap) else None
@@ -101,79 +102,85 @@ class BucketedGradReducer:
         """mean over the ranks of a row-sparse group's gradient from the touched rows only.  Every parameter of the group is
         [rows, ...] and carries `_pd_rows` (LongTensor [R], the rows this rank's step used: images per GPU x (K + 1)).  Equal to
         the dense all-reduce: untouched rows are exact zeros everywhere.
-        The ranks first agree on ONE path (a MAX all-reduce of [R, no-record flag], 16 bytes): if any rank has no row record this
-        step, or the ranks' R differ (uneven last batch), a rank that went on to all_gather R-sized buffers would hang the others or
-        scatter garbage — so R is padded to the maximum with a sentinel row (-1, dropped on arrival) and a missing record sends
-        everyone down the dense all-reduce.  The record is consumed: a stale list is never exchanged for a later step."""
+        The exchange has a STATIC shape — `sparse_rows_cap` rows per rank (a config constant, identical on every rank), a rank's
+        list padded with the sentinel row -1 whose payload is zero — so the ranks need no agreement round and the host reads
+        nothing back: the whole exchange is enqueued on the side stream behind the bucket all-reduces while the GPU is still in
+        backward (round 3 agreed on the size with a 16-byte all-reduce and two blocking host reads per step).  A rank whose step
+        kept no row record sends the non-zero rows of its local gradient, found on the device (top-`cap` rows by "has a non-zero
+        entry"); a rank with no gradient at all sends only sentinels.  More touched rows than the cap is a configuration error: the
+        host-known case (a record longer than the cap) raises here, the device-found case is flagged and raised at the next step."""
         g = self.flat.groups[gi]
         g.gather(None)                                            # local dense gradients -> flat buffer (compute stream)
-        rows, meta_host, ev = self._row_meta.pop(gi)
-        dev = g.grad.device
-        if ev is not None:
-            ev.synchronize()                                      # waits for the 16-byte agreement only (side stream), not for the compute stream
-        r_max, any_missing = int(meta_host[0]), int(meta_host[1])
-        side = self._side
-        if side is not None:                                      # the exchange itself runs on the side stream, behind the bucket all-reduces
-            side.wait_stream(torch.cuda.current_stream(dev))
-        ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
-        with ctx:
-            self._exchange_rows_on_stream(g, rows, r_max, any_missing, dev)
-        if side is not None:
-            torch.cuda.current_stream(dev).wait_stream(side)
-
-    def _agree_rows(self, gi):
-        """start the ranks' agreement on the row-sparse path of group gi (MAX all-reduce of [R, no-record flag]); issued by
-        finish() right behind the last bucket all-reduce, on the side stream, read back through a pinned buffer"""
-        g = self.flat.groups[gi]
         rows = getattr(g.params[0], "_pd_rows", None)
         for p in g.params:
             if hasattr(p, "_pd_rows"):
                 p._pd_rows = None                                 # consumed: a stale list is never exchanged for a later step
         dev = g.grad.device
-        host = torch.tensor([0 if rows is None else int(rows.numel()), 1 if rows is None else 0], dtype=torch.int64)
-        if dev.type != "cuda":
-            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.pg)
-            self._row_meta[gi] = (rows, host, None)
-            return
-        pinned = torch.empty(2, dtype=torch.int64, pin_memory=True)
-        pinned.copy_(host)
-        side = self._side if self._side is not None else torch.cuda.current_stream(dev)
-        with torch.cuda.stream(side):
-            meta = pinned.to(dev, non_blocking=True)
-            dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=self.pg)
-            pinned.copy_(meta, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        self._row_meta[gi] = (rows, pinned, ev)
+        cap = self.sparse_rows_cap
+        if rows is not None and rows.numel() > cap:
+            raise RuntimeError(f"row-sparse gradient group: {rows.numel()} touched rows exceed MODEL.AMD.DDP_SPARSE_ROWS_CAP = {cap}")
+        self._check_overflow()
+        side = self._side
+        if side is not None:                                      # the exchange itself runs on the side stream, behind the bucket all-reduces
+            side.wait_stream(torch.cuda.current_stream(dev))
+        ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+        with ctx:
+            self._exchange_rows_on_stream(g, rows, cap, dev)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
 
-    def _exchange_rows_on_stream(self, g, rows, r_max, any_missing, dev):
-        if any_missing or r_max == 0:                             # dense path, on EVERY rank
-            dist.all_reduce(g.grad, group=self.pg)
-            g.grad.div_(self.world)
-            return
+    def _check_overflow(self):
+        """raise if an EARLIER step's device-side row search found more touched rows than the cap (read without blocking: the flag
+        of a step is looked at once its copy to pinned memory has completed)"""
+        keep = []
+        for flag, ev in self._overflow:
+            if ev is None or ev.query():
+                if int(flag[0]) != 0:
+                    raise RuntimeError(f"row-sparse gradient group: a step without a row record touched more than "
+                                       f"MODEL.AMD.DDP_SPARSE_ROWS_CAP = {self.sparse_rows_cap} rows; its gradient was truncated")
+            else:
+                keep.append((flag, ev))
+        self._overflow = keep
+
+    def _exchange_rows_on_stream(self, g, rows, cap, dev):
+        views = [g._view(g.grad, p, off).reshape(p.shape[0], -1) for p, off in zip(g.params, g.offsets)]
+        if rows is None:
+            # no record: the touched rows are the rows with a non-zero entry — found on the device in a fixed-size form
+            nz = views[0].ne(0).any(1)
+            for v in views[1:]:
+                nz |= v.ne(0).any(1)
+            k = min(cap, nz.numel())
+            val, idx = torch.topk(nz.to(torch.float32), k)
+            rows = torch.where(val > 0, idx, idx.new_full((), -1))
+            over = (nz.sum() > cap).to(torch.int64).reshape(1)
+            if dev.type == "cuda":
+                pinned = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+                pinned.copy_(over, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                self._overflow.append((pinned, ev))
+            else:
+                self._overflow.append((over, None))
         rows = rows.reshape(-1).to(dev)
+        if rows.numel() < cap:                                    # pad to the static size: sentinel rows carry zeros
+            rows = torch.cat([rows, rows.new_full((cap - rows.numel(),), -1)])
+        valid = rows >= 0
+        src = rows.clamp_min(0)
         if _CHECK_SPARSE_ROWS:                                    # debugging aid: the dense gradient must vanish outside `rows`
-            views_chk = [g._view(g.grad, p, off).reshape(p.shape[0], -1) for p, off in zip(g.params, g.offsets)]
-            for v in views_chk:
+            for v in views:
                 mask = torch.ones(v.shape[0], dtype=torch.bool, device=dev)
-                mask[rows] = False
+                mask[src[valid]] = False
                 assert not bool(v[mask].any()), "row-sparse gradient group has non-zero rows outside its row record"
         # a row listed twice (two images of one class, the shared no-object row) holds the SUM already: send it once
-        first = ~(rows[:, None] == rows[None, :]).tril(-1).any(1)
-        views = [g._view(g.grad, p, off).reshape(p.shape[0], -1) for p, off in zip(g.params, g.offsets)]
-        pack = torch.cat([v[rows] for v in views], dim=1) * first[:, None].to(g.grad.dtype)
-        if rows.numel() < r_max:                                  # pad to the agreed size: sentinel rows carry zeros
-            pad = r_max - rows.numel()
-            rows = torch.cat([rows, rows.new_full((pad,), -1)])
-            pack = torch.cat([pack, pack.new_zeros((pad, pack.shape[1]))])
+        first = ~((rows[:, None] == rows[None, :]).tril(-1).any(1)) & valid
+        pack = torch.cat([v[src] for v in views], dim=1) * first[:, None].to(g.grad.dtype)
         all_pack = [torch.empty_like(pack) for _ in range(self.world)]
         all_rows = [torch.empty_like(rows) for _ in range(self.world)]
         dist.all_gather(all_pack, pack.contiguous(), group=self.pg)
         dist.all_gather(all_rows, rows.contiguous(), group=self.pg)
-        rows_all, pack_all = torch.cat(all_rows), torch.cat(all_pack) / self.world
-        keep = rows_all >= 0
-        if not bool(keep.all()):
-            rows_all, pack_all = rows_all[keep], pack_all[keep]
+        # sentinel rows arrive with an all-zero payload: clamped to row 0 they zero it (its gradient is rebuilt from the payloads
+        # of the ranks that touched it, or is an exact zero anyway) and add zeros — no host branch, no compaction
+        rows_all, pack_all = torch.cat(all_rows).clamp_min(0), torch.cat(all_pack) / self.world
         col = 0
         for v in views:
             w = v.shape[1]
@@ -189,8 +196,6 @@ class BucketedGradReducer:
         for b in self.buckets[self._next:]:                      # in index order, like the hooks
             self._launch(b)
         self._next = 0
-        for gi in self.sparse_groups:                            # after the LAST bucket on every rank: one collective order for all
-            self._agree_rows(gi)
         for b in self.buckets:
             buf = self.flat.groups[b.group].grad[b.start:b.end]
             if self._side is not None:

@@ -60,7 +60,7 @@ class TrainStep:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         broadcast_parameters(self.optimizer.flat, 0, process_group)
         self.reducer = BucketedGradReducer(self.optimizer.flat, cfg.MODEL.AMD.DDP_BUCKET_MB, process_group,
-                                           optimizer=self.optimizer)
+                                           optimizer=self.optimizer, sparse_rows_cap=int(cfg.MODEL.AMD.get("DDP_SPARSE_ROWS_CAP", 256)))
         if _os.environ.get("PD_CONV_GROUP_ROWS"):               # tools/ experiments
             from .. import lib as _l
             _l.load().pd_debug_set(b"conv_group_rows", int(_os.environ["PD_CONV_GROUP_ROWS"]))

@@ -92,6 +92,7 @@ class _Deferred:
     active = False
     queue = []
     adopt = []                                               # (weakref(filter), address handed to autograd): verify_adopted()
+    queued = set()                                           # id(filter) of every filter with a gradient in the queue: a second use computes now
     ring = None
     table_dev = None
     MAXP = 256
@@ -105,12 +106,18 @@ def deferred_wgrads():
     callers that do not look at .grad of the convolution filters before the flush (engine/trainer.py)."""
     prev = _Deferred.active
     _Deferred.active = True
+    ok = False
     try:
         yield
+        ok = True
     finally:
         _Deferred.active = prev
-        flush()
-        verify_adopted()
+        if ok:
+            flush()
+            verify_adopted()
+        else:                                                # backward itself failed: do not replace its exception with ours
+            _Deferred.queue, _Deferred.adopt = [], []
+            _Deferred.queued.clear()
 
 
 def verify_adopted():
@@ -157,6 +164,7 @@ def run_now(entries):
 
 def flush():
     q, _Deferred.queue = _Deferred.queue, []
+    _Deferred.queued.clear()
     _run(q)
 
 
@@ -233,8 +241,15 @@ class Conv2dOwnWgrad(Function):
         if ctx.needs_input_grad[1]:
             # deferred only when AccumulateGrad will ADOPT the tensor we return: no existing .grad to add into, no tensor hooks on the
             # weight, a leaf parameter; anything else gets its gradient computed now
-            adoptable = weight.grad is None and weight.is_leaf and not weight._backward_hooks and torch.is_grad_enabled() is False
+            # a filter used TWICE in one graph: autograd sums the two returned tensors in place before AccumulateGrad sees them, the
+            # pointer check of verify_adopted() would pass and the grouped launch overwrite the sum with one use's gradient
+            adoptable = (weight.grad is None and weight.is_leaf and not weight._backward_hooks and torch.is_grad_enabled() is False
+                         and id(weight) not in _Deferred.queued)
+            if _Deferred.active and id(weight) in _Deferred.queued:
+                flush()                                      # the first use's tensor is written BEFORE autograd adds this use's gradient to it
+                _Deferred.adopt = [(r, p_) for r, p_ in _Deferred.adopt if r() is not weight]   # the sum need not live at that address
             if _Deferred.active and adoptable:
+                _Deferred.queued.add(id(weight))
                 dw = torch.empty_strided(weight.shape, weight.stride(), dtype=torch.bfloat16, device=x.device)   # written by flush()
                 # only the ADDRESS is kept: with a second reference alive autograd's AccumulateGrad would not adopt this tensor
                 # as .grad but clone it (unwritten) — the adopted tensor keeps the storage alive until the flush

@@ -149,6 +149,7 @@ class PinnedRing:
         self.bufs = [torch.zeros(shape, dtype=dtype, pin_memory=pin) for _ in range(slots)]
         self.events = [None] * (slots // self.BLOCK)
         self.pin, self.i = pin, -1
+        self._block_stream = None                            # raw stream the current block's uploads were enqueued on
         self.reserved, self.captured = [], []                # dedicated buffers: waiting for / baked into captured graphs
         self.count = 0                                       # acquisitions so far
         self._in_capture = False
@@ -191,17 +192,39 @@ class PinnedRing:
             return buf
         self._in_capture = False
         self.i = (self.i + 1) % len(self.bufs)
-        if self.i % self.BLOCK == 0 and self.events[self.i // self.BLOCK] is not None:
-            self.events[self.i // self.BLOCK].synchronize()   # the copies out of this block's slots, one lap ago, have executed
+        if self.i % self.BLOCK == 0:
+            evs = self.events[self.i // self.BLOCK]
+            if evs is not None:
+                for ev in evs:
+                    ev.synchronize()                          # the copies out of this block's slots, one lap ago, have executed
+                self.events[self.i // self.BLOCK] = None
+            self._block_stream = None
         return self.bufs[self.i]
 
     def release(self):
-        """call after enqueueing the copy out of the buffer acquire() returned"""
-        if self.pin and not self._in_capture and self.i % self.BLOCK == self.BLOCK - 1:
-            b = self.i // self.BLOCK
-            ev = self.events[b] or torch.cuda.Event()
+        """call after enqueueing the copy out of the buffer acquire() returned.  One completion event covers a block of BLOCK slots
+        as long as their copies were enqueued on ONE stream (the event of the block's last slot is recorded on it); a slot whose copy
+        went to another stream (the data-parallel side stream, a warm-up stream) gets an event of its own on that stream."""
+        if not self.pin or self._in_capture:
+            return
+        b = self.i // self.BLOCK
+        st = _lib.current_stream()
+        if self._block_stream is None:
+            self._block_stream = st
+        last = self.i % self.BLOCK == self.BLOCK - 1
+        if st != self._block_stream or last:
+            ev = torch.cuda.Event()
             ev.record()
-            self.events[b] = ev
+            if self.events[b] is None:
+                self.events[b] = []
+            self.events[b].append(ev)
+            if st != self._block_stream and not last:
+                return
+            if st != self._block_stream:                      # the block's last slot on a foreign stream: the home stream's slots need theirs too
+                with torch.cuda.stream(torch.cuda.ExternalStream(self._block_stream)):
+                    ev2 = torch.cuda.Event()
+                    ev2.record()
+                self.events[b].append(ev2)
 
 
 _UPLOAD_RINGS = {}

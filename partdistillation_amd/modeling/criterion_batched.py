@@ -206,7 +206,9 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
         tgt = tg.transpose(1, 2)
         if pm.is_cuda and pm.is_contiguous() and pm.dtype in (torch.float32, torch.bfloat16):
             # .float(), softplus, sigmoid and their two row sums in one pass over the [B heads Q, points] logits (pd_matcher_point_terms)
-            pm, sg, sp_sum, sg_sum = rw.matcher_point_terms(pm)
+            pm32 = pm.dtype == torch.float32                                  # already fp32: no second copy of the logits (100 MB at config 2)
+            xf, sg, sp_sum, sg_sum = rw.matcher_point_terms(pm, want_f32=not pm32)
+            pm = pm if pm32 else xf
         else:
             pm = pm.float()
             sg = pm.sigmoid()

@@ -44,7 +44,7 @@ def test_reference_fixture_forward_double_and_float(golden):
     assert torch.allclose(out32, g["out_f32"], rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("D", [30, 32, 64, 71, 1025])
+@pytest.mark.parametrize("D", [30, 32, 64, 71, 1025, 2048, 3096])
 def test_backward_double_all_channel_counts(D):
     """ops/test.py:69-91 exercises D in {30,32,64,71,1025,2048,3096} with gradcheck;
     here the analytic C oracle is the checker (fp64, atomics reorder only)."""
