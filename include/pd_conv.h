@@ -58,6 +58,8 @@ typedef struct PdConvWgradDesc {
   void *dw;
   float *db;     /* nullable: fp32 [co], += sum over pixels of dz (the bias gradient of a convolution / Linear with bias) */
   int32_t batch, hi, wi, ci, ho, wo, co, k, stride, pad;
+  const float *scale;   /* nullable: fp32 [co], dw[co][...] is multiplied by scale[co] (the frozen-BN scale when dz is the gradient
+                           BEHIND the affine: pd_igemm.h's fused backbone) */
 } PdConvWgradDesc;
 int64_t pd_conv_bf16_wgrad_grouped_table_bytes(int count);
 int64_t pd_conv_bf16_wgrad_grouped_workspace_floats(const PdConvWgradDesc *descs, int count);

@@ -28,7 +28,7 @@ int pd_check_launch(const char *what)
 }
 
 extern "C" const char *pd_last_error(void) { return g_err; }
-extern "C" int pd_abi_version(void) { return 18; }
+extern "C" int pd_abi_version(void) { return 19; }
 
 // experiment knobs (not part of the public ABI contract; used by tools/ only)
 extern int g_pd_dbg_atomic_scope;
@@ -49,6 +49,7 @@ extern int g_pd_dbg_x3;
 extern int g_pd_dbg_kmeans;
 extern int g_pd_dbg_conv_group_rows;
 extern int g_pd_dbg_sgemm_deep;
+extern int g_ig_bn, g_ig_nst, g_ig_splits;
 extern "C" int pd_debug_set(const char *key, int value)
 {
   if (!key) return PD_ERR_INVALID_ARG;
@@ -60,6 +61,9 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!strcmp(key, "msda_bwd_threads")) { g_pd_dbg_bwd_threads = value; return PD_OK; }
   if (!strcmp(key, "wgrad_wgs")) { g_pd_dbg_wgrad_wgs = value; return PD_OK; }
   if (!strcmp(key, "kmeans_ablate")) { g_pd_dbg_kmeans = value; return PD_OK; }
+  if (!strcmp(key, "ig_bn")) { g_ig_bn = value; return PD_OK; }
+  if (!strcmp(key, "ig_nst")) { g_ig_nst = value; return PD_OK; }
+  if (!strcmp(key, "ig_splits")) { g_ig_splits = value; return PD_OK; }
   if (!strcmp(key, "sgemm_deep")) { g_pd_dbg_sgemm_deep = value; return PD_OK; }
   if (!strcmp(key, "conv_group_rows")) { g_pd_dbg_conv_group_rows = value; return PD_OK; }
   if (!strcmp(key, "x3_ablate")) { g_pd_dbg_x3 = value; return PD_OK; }

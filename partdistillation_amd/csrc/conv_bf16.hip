@@ -386,6 +386,7 @@ struct WgradProblem {
   bf16_t *dw;
   int64_t ws_off;                                        // this problem's partial tiles inside the workspace (floats)
   float *db;                                             // fp32 [co] bias-gradient accumulator (+= column sums of dz), nullable
+  const float *scale;                                    // fp32 [co], nullable: dW rows are multiplied by it (frozen-BN scale of the fused backbone)
   WgradGeom g;
   int block_begin, reduce_begin, splits, variant;
 };
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr_grouped(const Wgrad
 // dW (bf16) = sum over splits of the partial tiles (register order: element (ij, e) of thread t at ((ij * 16 + e) * 256 + t))
 template <int WN, int WK>
 __device__ __forceinline__ void reduce_body(const float *__restrict__ ws, bf16_t *__restrict__ dW, int N, int K, int tiles_k, int tiles,
-                                            int splits, int bid)
+                                            int splits, int bid, const float *__restrict__ rscale = nullptr)
 {
   constexpr int TN = 2 * WN, TK = 2 * WK, KJ = WK / 32, QN = (WN / 32) * KJ * 16;     // QN (ij, e) pairs per tile
   const int tile = bid / QN, q = bid % QN;
@@ -430,7 +431,7 @@ __device__ __forceinline__ void reduce_body(const float *__restrict__ ws, bf16_t
   for (; sp < splits; ++sp) s0 += p[(int64_t)sp * stride];
   const int c = k0 + wk + j * 32 + (lane & 31);
   const int row = n0 + wn + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-  if (c < K && row < N) dW[(int64_t)row * K + c] = (bf16_t)(pk_bf16(s0 + s1, 0.f) & 0xffff);
+  if (c < K && row < N) dW[(int64_t)row * K + c] = (bf16_t)(pk_bf16((s0 + s1) * (rscale ? rscale[row] : 1.f), 0.f) & 0xffff);
 }
 
 template <int WN, int WK>
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_grouped(const WgradProb
 {
   const int p = find_problem(tab, count, blockIdx.x, true);
   const WgradProblem &pr = tab[p];
-  reduce_body<WN, WK>(ws + pr.ws_off, pr.dw, pr.g.N, pr.g.K, pr.g.tiles_k, pr.g.tiles, pr.splits, blockIdx.x - pr.reduce_begin);
+  reduce_body<WN, WK>(ws + pr.ws_off, pr.dw, pr.g.N, pr.g.K, pr.g.tiles_k, pr.g.tiles, pr.splits, blockIdx.x - pr.reduce_begin, pr.scale);
 }
 
 struct WgradPlan { int tn, tk, tiles_k, tiles, splits, m_chunk; };
@@ -611,7 +612,7 @@ extern "C" int pd_conv_bf16_wgrad_grouped(const PdConvWgradDesc *descs, int coun
       const PdConvWgradDesc &d = descs[i];
       const WgradPlan &p = plans[i];
       WgradProblem &w = tab[at];
-      w.dz = (const bf16_t *)d.dz; w.x = (const bf16_t *)d.x; w.dw = (bf16_t *)d.dw; w.ws_off = ws_off; w.db = d.db;
+      w.dz = (const bf16_t *)d.dz; w.x = (const bf16_t *)d.x; w.dw = (bf16_t *)d.dw; w.ws_off = ws_off; w.db = d.db; w.scale = d.scale;
       w.g.M = d.batch * d.ho * d.wo; w.g.N = d.co; w.g.K = d.k * d.k * d.ci; w.g.Ci = d.ci; w.g.kw = d.k; w.g.Hi = d.hi; w.g.Wi = d.wi;
       w.g.Ho = d.ho; w.g.Wo = d.wo; w.g.stride = d.stride; w.g.pad = d.pad; w.g.tiles_k = p.tiles_k; w.g.tiles = p.tiles; w.g.m_chunk = p.m_chunk;
       w.block_begin = blocks[v]; w.reduce_begin = rblocks[v]; w.splits = p.splits; w.variant = v;

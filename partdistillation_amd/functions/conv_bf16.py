@@ -84,7 +84,7 @@ def conv_wgrad(dz, x, k, stride=1, pad=0, like=None):
 
 class _Desc(ctypes.Structure):                                      # PdConvWgradDesc (include/pd_conv.h)
     _fields_ = [("dz", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("db", ctypes.c_void_p)] + \
-               [(n, ctypes.c_int32) for n in ("batch", "hi", "wi", "ci", "ho", "wo", "co", "k", "stride", "pad")]
+               [(n, ctypes.c_int32) for n in ("batch", "hi", "wi", "ci", "ho", "wo", "co", "k", "stride", "pad")] + [("scale", ctypes.c_void_p)]
 
 
 class _Deferred:
@@ -180,6 +180,7 @@ def _run(q):
             _keep, dzp, xp, dwp, geom = entry[:5]
             d.dz, d.x, d.dw = dzp, xp, dwp
             d.db = entry[5] if len(entry) > 5 else None
+            d.scale = entry[6] if len(entry) > 6 else None
             d.batch, d.hi, d.wi, d.ci, d.ho, d.wo, d.co, d.k, d.stride, d.pad = geom
         need = int(L.pd_conv_bf16_wgrad_grouped_workspace_floats(ctypes.byref(descs), len(part)))
         ws = _WS.get(str(dev))

@@ -1,0 +1,88 @@
+"""Python face of the bf16 implicit-GEMM family (include/pd_igemm.h, csrc/igemm_bf16.hip): convolution / Linear forward and input
+gradient with the affine, residual, activation and gate in the epilogue.  GPU only; no fallback."""
+import ctypes
+
+import torch
+
+from .. import lib as _lib
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+GATE_NONE, GATE_RELU, GATE_GELU = 0, 1, 2
+RES_DENSE, RES_UP2 = 0, 1
+
+
+class PdIgemm(ctypes.Structure):                                     # include/pd_igemm.h
+    _fields_ = [(n, ctypes.c_void_p) for n in ("src", "w", "scale", "bias", "res", "res2", "gate", "out", "out_pre")] + \
+               [(n, ctypes.c_int32) for n in ("batch", "hs", "ws", "cs", "ho", "wo", "n", "k", "stride", "pad", "dgrad", "act", "gate_mode", "res_mode")]
+
+
+class PdFilterTranspose(ctypes.Structure):                           # include/pd_igemm.h
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("co", ctypes.c_int32), ("taps", ctypes.c_int32),
+                ("ci", ctypes.c_int32)]
+
+
+_WS = {}
+
+
+def workspace(dev, nbytes):
+    """zero-initialised scratch for the split-K tickets + slabs of one stream (the kernel leaves the tickets zero)"""
+    key = (str(dev), _lib.current_stream())
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WS[key] = torch.zeros(max(int(nbytes), 64 << 20), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def supported(cs, n, k=1, stride=1, pad=0):
+    return bool(_lib.load().pd_igemm_bf16_supported(int(cs), int(n), int(k), int(stride), int(pad)))
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def run(src, w, out, *, batch, hs, ws, cs, ho, wo, n, k=1, stride=1, pad=0, dgrad=False, scale=None, bias=None, res=None, gate=None,
+        out_pre=None, res2=None, act=ACT_NONE, gate_mode=GATE_NONE, res_mode=RES_DENSE):
+    """raw launch: every tensor is a contiguous bf16 buffer in the layout pd_igemm.h names (scale / bias fp32)"""
+    if not src.is_cuda:
+        raise RuntimeError("pd_igemm_bf16: CUDA tensors required (partdistillation_amd has no CPU fallback)")
+    d = PdIgemm(_p(src), _p(w), _p(scale), _p(bias), _p(res), _p(res2), _p(gate), _p(out), _p(out_pre), batch, hs, ws, cs, ho, wo, n, k, stride, pad,
+                int(dgrad), act, gate_mode if gate is not None else GATE_NONE, res_mode)
+    L = _lib.load()
+    need = int(L.pd_igemm_bf16_workspace_bytes(ctypes.byref(d)))
+    if need < 0:
+        _lib.check(-1)
+    wsb = workspace(src.device, need) if need else None
+    _lib.check(L.pd_igemm_bf16(ctypes.byref(d), _p(wsb), wsb.numel() if wsb is not None else 0, _lib.current_stream()))
+    return out
+
+
+def linear(x, w, bias=None, act=ACT_NONE, res=None, gate=None, gate_mode=GATE_NONE, want_pre=False, scale=None):
+    """x [M, K] bf16 row-major, w [N, K] bf16 -> act(x w^T * scale + bias + res) * gate'  [M, N] bf16 (and the pre-activation)"""
+    M, K = x.shape
+    N = w.shape[0]
+    assert x.dtype == w.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous() and w.shape[1] == K
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    pre = torch.empty((M, N), dtype=torch.bfloat16, device=x.device) if want_pre else None
+    run(x, w, out, batch=1, hs=M, ws=1, cs=K, ho=M, wo=1, n=N, scale=scale, bias=bias, res=res, gate=gate, out_pre=pre, act=act, gate_mode=gate_mode)
+    return (out, pre) if want_pre else out
+
+
+def conv_nhwc(x, w, *, k, stride=1, pad=0, scale=None, bias=None, res=None, act=ACT_NONE, gate=None, gate_mode=GATE_NONE, res_mode=RES_DENSE):
+    """x [B, H, W, Ci] bf16 contiguous (NHWC), w [Co, k, k, Ci] bf16 -> [B, Ho, Wo, Co]"""
+    B, H, W, Ci = x.shape
+    Co = w.shape[0]
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((B, Ho, Wo, Co), dtype=torch.bfloat16, device=x.device)
+    return run(x, w, out, batch=B, hs=H, ws=W, cs=Ci, ho=Ho, wo=Wo, n=Co, k=k, stride=stride, pad=pad, scale=scale, bias=bias, res=res, gate=gate,
+               act=act, gate_mode=gate_mode, res_mode=res_mode)
+
+
+def conv_dgrad_nhwc(dz, wt, in_hw, *, k, stride=1, pad=0, res=None, gate=None, gate_mode=GATE_NONE, res_mode=RES_DENSE):
+    """dz [B, Ho, Wo, Co] bf16, wt [Ci, k, k, Co] (the transposed filter) -> dx [B, H, W, Ci] (+ res) (* gate mask)"""
+    B, Ho, Wo, Co = dz.shape
+    Ci = wt.shape[0]
+    H, W = in_hw
+    out = torch.empty((B, H, W, Ci), dtype=torch.bfloat16, device=dz.device)
+    return run(dz, wt, out, batch=B, hs=Ho, ws=Wo, cs=Co, ho=H, wo=W, n=Ci, k=k, stride=stride, pad=pad, dgrad=True, res=res, gate=gate,
+               gate_mode=gate_mode, res_mode=res_mode)

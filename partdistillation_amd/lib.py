@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libpd_hip.so") 
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -134,6 +134,14 @@ SIGNATURES = {
     "pd_sgemm_wgrad_grouped_bf16": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp]),
     "pd_sgemm_wgrad_split_workspace": (ctypes.c_int64, [_c_int] * 3),
     "pd_sgemm_wgrad_split_bf16": (_c_int, [_c_vp] * 5 + [_c_int] * 6 + [_c_vp]),
+    "pd_igemm_bf16_supported": (_c_int, [_c_int] * 5),
+    "pd_igemm_bf16_workspace_bytes": (ctypes.c_int64, [_c_vp]),
+    "pd_igemm_bf16": (_c_int, [_c_vp, _c_vp, ctypes.c_int64, _c_vp]),
+    "pd_igemm_bf16_time": (_c_int, [_c_vp, _c_vp, ctypes.c_int64, _c_int, _c_vp, _c_vp]),
+    "pd_igemm_bf16_seq_workspace_bytes": (ctypes.c_int64, [_c_vp, _c_int]),
+    "pd_igemm_bf16_seq": (_c_int, [_c_vp, _c_int, _c_vp, ctypes.c_int64, _c_vp]),
+    "pd_filter_transpose_table_bytes": (ctypes.c_int64, [_c_int]),
+    "pd_filter_transpose_grouped": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp]),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_abi_version": (_c_int, []),
     "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),

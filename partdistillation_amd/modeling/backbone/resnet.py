@@ -126,6 +126,11 @@ class ResNet(nn.Module):
         if "stem" in self._out_features:
             outputs["stem"] = x
         blocks = [(name, blk) for name in self.stage_names for blk in getattr(self, name)]
+        from . import resnet_core
+        if resnet_core.supported([b for _, b in blocks], x):
+            # res2 .. res5 as ONE autograd node on the fused implicit-GEMM kernels (resnet_core.py): 52 launches per direction from C++
+            outputs.update(resnet_core.run_body(self, x, [b for _, b in blocks], [n for n, _ in blocks]))
+            return {k: v for k, v in outputs.items() if k in self._out_features}
         x_sc = None
         for i, (name, blk) in enumerate(blocks):
             last = i + 1 == len(blocks)
