@@ -49,6 +49,7 @@ typedef struct PdIgemm {
   int32_t k, stride, pad;
   int32_t dgrad;                      /* 0: forward gather, 1: input-gradient gather */
   int32_t act, gate_mode, res_mode;
+  int32_t bias_bf16;                  /* != 0: `bias` points to bf16 values (an nn.Linear bias kept in 16 bits), not fp32 */
 } PdIgemm;
 
 /* workspace the split-K schedule of this problem needs: fp32 partial tiles + one ticket word per tile (0 when it runs unsplit).

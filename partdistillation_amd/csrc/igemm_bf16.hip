@@ -57,7 +57,7 @@ struct IgArgs {
   int Cs, kw, cch, KT;                                   // source channels, filter width, 64-channel chunks per tap, K-steps
   int Hs, Ws, Ho, Wo;
   int stride, pad, dgrad;
-  int act, gate_mode, res_mode;
+  int act, gate_mode, res_mode, bias_bf16;
   int splits, kt_per;
   int ntn, ntiles;
 };
@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : (NST == 2 || BN == 64) ? 2 : 1)
   float sbv = 0.f;
   if (t < 2 * BN) {
     const float *src = t < BN ? a.scale : a.bias;
-    sbv = src ? src[n0 + (t < BN ? t : t - BN)] : (t < BN ? 1.f : 0.f);
+    if (t >= BN && a.bias && a.bias_bf16) sbv = __uint_as_float((unsigned)reinterpret_cast<const bf16_t *>(a.bias)[n0 + t - BN] << 16);
+    else sbv = src ? src[n0 + (t < BN ? t : t - BN)] : (t < BN ? 1.f : 0.f);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -375,7 +376,7 @@ int make_plan(const PdIgemm *p, Plan &pl)
   if (M > 0x7fffffff / 2 || (int64_t)p->batch * p->hs * p->ws > 0x7fffffff / 2) return pd_set_error(PD_ERR_INVALID_ARG, "pd_igemm_bf16: grid too large");
   a.M = (int)M; a.N = p->n; a.Cs = p->cs; a.kw = p->k; a.cch = p->cs / 64; a.KT = p->k * p->k * a.cch;
   a.Hs = p->hs; a.Ws = p->ws; a.Ho = p->ho; a.Wo = p->wo; a.stride = p->stride; a.pad = p->pad; a.dgrad = p->dgrad;
-  a.act = p->act; a.gate_mode = p->gate_mode; a.res_mode = p->res_mode;
+  a.act = p->act; a.gate_mode = p->gate_mode; a.res_mode = p->res_mode; a.bias_bf16 = p->bias_bf16;
   // tile width: 128 columns, or 64 when n is not a multiple of 128 or when 128-wide tiles would leave most workgroup slots empty
   const int mt = (a.M + BM - 1) / BM;
   pl.bn = (p->n % 128 == 0) ? 128 : 64;

@@ -13,7 +13,7 @@ RES_DENSE, RES_UP2 = 0, 1
 
 class PdIgemm(ctypes.Structure):                                     # include/pd_igemm.h
     _fields_ = [(n, ctypes.c_void_p) for n in ("src", "w", "scale", "bias", "res", "res2", "gate", "out", "out_pre")] + \
-               [(n, ctypes.c_int32) for n in ("batch", "hs", "ws", "cs", "ho", "wo", "n", "k", "stride", "pad", "dgrad", "act", "gate_mode", "res_mode")]
+               [(n, ctypes.c_int32) for n in ("batch", "hs", "ws", "cs", "ho", "wo", "n", "k", "stride", "pad", "dgrad", "act", "gate_mode", "res_mode", "bias_bf16")]
 
 
 class PdFilterTranspose(ctypes.Structure):                           # include/pd_igemm.h
@@ -47,7 +47,7 @@ def run(src, w, out, *, batch, hs, ws, cs, ho, wo, n, k=1, stride=1, pad=0, dgra
     if not src.is_cuda:
         raise RuntimeError("pd_igemm_bf16: CUDA tensors required (partdistillation_amd has no CPU fallback)")
     d = PdIgemm(_p(src), _p(w), _p(scale), _p(bias), _p(res), _p(res2), _p(gate), _p(out), _p(out_pre), batch, hs, ws, cs, ho, wo, n, k, stride, pad,
-                int(dgrad), act, gate_mode if gate is not None else GATE_NONE, res_mode)
+                int(dgrad), act, gate_mode if gate is not None else GATE_NONE, res_mode, int(bias is not None and bias.dtype == torch.bfloat16))
     L = _lib.load()
     need = int(L.pd_igemm_bf16_workspace_bytes(ctypes.byref(d)))
     if need < 0:
@@ -86,3 +86,78 @@ def conv_dgrad_nhwc(dz, wt, in_hw, *, k, stride=1, pad=0, res=None, gate=None, g
     out = torch.empty((B, H, W, Ci), dtype=torch.bfloat16, device=dz.device)
     return run(dz, wt, out, batch=B, hs=Ho, ws=Wo, cs=Co, ho=H, wo=W, n=Ci, k=k, stride=stride, pad=pad, dgrad=True, res=res, gate=gate,
                gate_mode=gate_mode, res_mode=res_mode)
+
+
+_TR = {}
+
+
+def transposed(weights):
+    """[N_i, K_i] bf16 row-major weights -> their [K_i, N_i] transposes (the "weight" operand of the input-gradient GEMMs), all in ONE
+    grouped launch into one fresh buffer; the descriptor table is cached per list of weight addresses"""
+    from .fused import PinnedRing
+    key = tuple(w.data_ptr() for w in weights)
+    L = _lib.load()
+    dev = weights[0].device
+    hit = _TR.get(key)
+    if hit is None:
+        descs = (PdFilterTranspose * len(weights))()
+        offs, total = [], 0
+        for w in weights:
+            assert w.dtype == torch.bfloat16 and w.is_contiguous() and w.dim() == 2
+            offs.append(total)
+            total += (w.numel() + 127) // 128 * 128
+        tb = int(L.pd_filter_transpose_table_bytes(len(weights)))
+        hit = _TR[key] = (descs, offs, total, PinnedRing(tb, torch.uint8, pin=True), torch.empty(tb, dtype=torch.uint8, device=dev))
+        if len(_TR) > 64:
+            _TR.pop(next(iter(_TR)))
+    descs, offs, total, ring, tdev = hit
+    buf = torch.empty(total, dtype=torch.bfloat16, device=dev)
+    base = buf.data_ptr()
+    for d, w, o in zip(descs, weights, offs):
+        d.src, d.dst, d.scale, d.co, d.taps, d.ci = w.data_ptr(), base + 2 * o, None, w.shape[0], 1, w.shape[1]
+    host = ring.acquire()
+    rc = L.pd_filter_transpose_grouped(descs, len(weights), host.data_ptr(), tdev.data_ptr(), _lib.current_stream())
+    ring.release()
+    _lib.check(rc)
+    return [buf[o:o + w.numel()].view(w.shape[1], w.shape[0]) for w, o in zip(weights, offs)]
+
+
+class OwnLinear(torch.autograd.Function):
+    """y = x w^T (+ b) on pd_igemm_bf16 with own input / weight gradients (nn.Linear under bf16 autocast: F.linear would cast x and run
+    the library GEMM).  x [..., K] any float dtype (cast to bf16 like autocast does), w [N, K] bf16, b bf16 / fp32 or None."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        x2 = x2 if x2.dtype == torch.bfloat16 else x2.to(torch.bfloat16)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        y = linear(x2, w, b)
+        ctx.save_for_backward(x2, w)
+        ctx.has_b, ctx.shp, ctx.xdt = b is not None, shp, x.dtype
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import conv_bf16
+        from . import rowwise as rw
+        x2, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, w.shape[0])
+        dy2 = dy2 if dy2.dtype == torch.bfloat16 else dy2.to(torch.bfloat16)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = linear(dy2, transposed([w])[0]).view(ctx.shp)
+            dx = dx if dx.dtype == ctx.xdt else dx.to(ctx.xdt)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            conv_bf16.run_now([conv_bf16.rows_entry(dy2, x2, dw)])
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = torch.zeros(w.shape[0], dtype=torch.float32, device=dy.device)
+            rw.colsum_acc(dy2, db)
+        return dx, dw, db
+
+
+def own_linear_supported(x, w):
+    return (x.is_cuda and w.dtype == torch.bfloat16 and w.is_contiguous() and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)

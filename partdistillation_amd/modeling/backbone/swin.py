@@ -252,7 +252,12 @@ class PatchMerging(nn.Module):
         # 2 * (column parity) + (row parity).  Same values; the backward is one permuted copy too instead of four zero-fills, four
         # strided copies and three gradient sums per merge (reference swin.py:325-337)
         x = x.view(B, Hp // 2, 2, Wp // 2, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, -1, 4 * C)
-        return self.reduction(self.norm(x))
+        x = self.norm(x)
+        from ...functions import igemm
+        from . import swin_core
+        if swin_core.OWN_GEMM and self.reduction.bias is None and igemm.own_linear_supported(x, self.reduction.weight):
+            return igemm.OwnLinear.apply(x, self.reduction.weight, None)           # pd_igemm_bf16 forward / input gradient, own weight gradient
+        return self.reduction(x)
 
 
 _MASK_CACHE = {}

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from ...functions import conv_bf16, smallgemm
+from ...functions import conv_bf16, igemm, smallgemm
 from ...functions import rowwise as _rw
 from ...functions import swin_rows as rows
 from ...functions import window_attention as wattn
@@ -34,6 +34,22 @@ def window_maps(H, W, shift, device):
 
 def _bf(t):
     return t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)
+
+
+OWN_GEMM = __import__("os").environ.get("PD_SWIN_OWN_GEMM", "1") != "0"   # qkv / proj / fc1 (+ GELU) / fc2 and their input gradients (+ GELU') on
+                     # pd_igemm_bf16 (include/pd_igemm.h) instead of the library's addmm / mm + separate GELU kernels
+
+
+def _own(x, *ws):
+    return (OWN_GEMM and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous()
+            and all(w.dtype == torch.bfloat16 and w.is_contiguous() and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0 for w in ws))
+
+
+def _lin(x, w, b):
+    """x [M, K] bf16 @ w [N, K]^T + b"""
+    if _own(x, w):
+        return igemm.linear(x, w, b)
+    return torch.addmm(_bf(b), x, _bf(w).t())
 
 
 TR_WGRAD = False     # True: weight gradients through the transpose-read kernel of csrc/conv_bf16.hip (a Linear over the stage's tokens = a
@@ -108,14 +124,17 @@ class SwinStage(Function):
             ymap, zero, S, nW = window_maps(H, W, shift, x.device)
             regions = wattn.shifted_window_regions(H, W, shift, x.device) if shift > 0 else None
             s1, y1, st1 = rows.ln_fwd(cur, r, None, L, rscale, n1w, n1b, spec["eps"], ymap, S, zero, B, L)
-            qkv = torch.addmm(_bf(qb), y1, _bf(qw).t())
+            qkv = _lin(y1, qw, qb)
             ao, lse = wattn.fwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table.contiguous(), regions, spec["scale"], nW)
-            po = torch.addmm(_bf(pb), ao.view(-1, C), _bf(pw).t())
+            po = _lin(ao.view(-1, C), pw, pb)
             sc1 = dp[k, 0] if dp is not None else None
             s2, y2, st2 = rows.ln_fwd(s1, po, ymap, S, sc1, n2w, n2b, spec["eps"], None, L, None, B, L)
-            h = torch.addmm(_bf(f1b), y2, _bf(f1w).t())
-            a = F.gelu(h)
-            f = torch.addmm(_bf(f2b), a, _bf(f2w).t())
+            if _own(y2, f1w):
+                a, h = igemm.linear(y2, f1w, f1b, act=igemm.ACT_GELU, want_pre=True)     # bias + exact-erf GELU in the GEMM epilogue; h kept for GELU'
+            else:
+                h = torch.addmm(_bf(f1b), y2, _bf(f1w).t())
+                a = F.gelu(h)
+            f = _lin(a, f2w, f2b)
             saved += [s1, y1, st1, qkv, ao, lse, s2, y2, st2, h, a]
             cur, r, rscale = s2, f, (dp[k, 1] if dp is not None else None)
         out = r.view(B, L, C).float()
@@ -142,30 +161,39 @@ class SwinStage(Function):
         tables_g = torch.zeros((depth,) + tuple(tab0.shape), dtype=tab0.dtype, device=dev) \
             if all(params[k * N_BLOCK + 4].shape == tab0.shape and params[k * N_BLOCK + 4].dtype == tab0.dtype for k in range(depth)) else None
 
+        own = _own(df, *[params[k * N_BLOCK + j] for k in range(depth) for j in (2, 5, 9, 11)])
+        if own:                                                  # W^T of the stage's 4 x depth Linears: one grouped launch
+            wts = igemm.transposed([params[k * N_BLOCK + j] for k in range(depth) for j in (2, 5, 9, 11)])
         for k in reversed(range(depth)):
             n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = params[k * N_BLOCK:(k + 1) * N_BLOCK]
             s1, y1, st1, qkv, ao, lse, s2, y2, st2, h, a = saved[k * 11:(k + 1) * 11]
+            if own:
+                qw_t, pw_t, f1w_t, f2w_t = wts[4 * k:4 * k + 4]
             shift = spec["shifts"][k]
             ymap, zero, S, nW = window_maps(H, W, shift, dev)
             regions = wattn.shifted_window_regions(H, W, shift, dev) if shift > 0 else None
             g = grads[k * N_BLOCK:(k + 1) * N_BLOCK]
             # MLP
-            da = torch.mm(df, _bf(f2w))
             g[11], g[12] = _wgrad(df, a, f2w, f2b, big)
-            dh = torch.ops.aten.gelu_backward(da, h)
-            dy2 = torch.mm(dh, _bf(f1w))
+            if own:
+                dh = igemm.linear(df, f2w_t, gate=h, gate_mode=igemm.GATE_GELU)        # (df W2) * GELU'(h) in the epilogue
+                dy2 = igemm.linear(dh, f1w_t)
+            else:
+                da = torch.mm(df, _bf(f2w))
+                dh = torch.ops.aten.gelu_backward(da, h)
+                dy2 = torch.mm(dh, _bf(f1w))
             g[9], g[10] = _wgrad(dh, y2, f1w, f1b, big)
             # LayerNorm 2 + the residual it sits on; gradient of the (window-major) proj output rides out as `dr`
             sc1 = dp[k, 0] if dp is not None else None
             ds2, dpo = rows.ln_bwd(dy2, None, L, dsup, s2, st2, n2w, True, ymap, S, sc1, zero, norm_g[k, 2], norm_g[k, 3], B, L)
-            dao = torch.mm(dpo, _bf(pw))
+            dao = igemm.linear(dpo, pw_t) if own else torch.mm(dpo, _bf(pw))
             g[5], g[6] = _wgrad(dpo, ao.view(-1, C), pw, pb, big)
             dqkv, dtable = wattn.bwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table.contiguous(), regions, ao,
                                          dao.view(B * nW, wattn.TOKENS, C), lse, spec["scale"], nW,
                                          dtable=tables_g[k] if tables_g is not None else None)
             g[4] = dtable
             dqkv = dqkv.view(-1, 3 * C)
-            dy1 = torch.mm(dqkv, _bf(qw))
+            dy1 = igemm.linear(dqkv.contiguous(), qw_t) if own else torch.mm(dqkv, _bf(qw))
             g[2], g[3] = _wgrad(dqkv, y1, qw, qb, big)
             # LayerNorm 1; for k > 0 its input was (block k-1 stream + DropPath * MLP output): `dr` = that MLP's output gradient
             prev = (dp[k - 1, 1] if dp is not None else None) if k > 0 else None
