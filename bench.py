@@ -44,6 +44,7 @@ os.environ.setdefault("MIOPEN_USER_DB_PATH", _MIOPEN_DB)
 if any(x == "--graph" and sys.argv[i + 1:i + 2] not in ([], ["0"]) or (x.startswith("--graph=") and x != "--graph=0")
        for i, x in enumerate(sys.argv)):
     os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"          # must precede the first HIP call; see TrainStep.capture()
+    os.environ["PD_CMDBUF"] = "0"                               # the whole-step graph and the command buffers are alternatives
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -159,6 +159,19 @@ class TrainStep:
         # the warm-up consumes random numbers (criterion sample points, DropPath): put both generators back afterwards
         rng_cpu, rng_dev = torch.get_rng_state(), (torch.cuda.get_rng_state() if torch.cuda.is_available() else None)
         from ..functions.fused import PinnedRing
+        from .. import cmdbuf
+        # the captured step is the EAGER launch sequence (a recording cannot be made or replayed while a stream captures): its
+        # rehearsal must issue — and count the pinned uploads of — that same sequence, not the command-buffer replays
+        if cmdbuf._EVER[0]:
+            raise RuntimeError("TrainStep.capture(): command-buffer recordings (partdistillation_amd/cmdbuf.py) were made earlier in this "
+                               "process; on ROCm 7.2 hipGraphInstantiate then segfaults on the captured step (bisected with "
+                               "tests/test_graph_gpu.py: PD_CMDBUF=0 from process start passes).  Start the process with PD_CMDBUF=0 to use "
+                               "the whole-step graph (bench.py --graph 1 does)")
+        cmdbuf_was, cmdbuf.ENABLED = cmdbuf.ENABLED, False
+        # ... and the module-by-module backbone: instantiating a graph that holds the fused ResNet body's launches segfaults inside
+        # hipGraphInstantiate on ROCm 7.2 (the whole-step graph is opt-in and not the shipped mode: DESIGN.md 5 "hipGraph")
+        from ..modeling.backbone import resnet_core
+        r50_was, resnet_core.ENABLED = resnet_core.ENABLED, False
         before = PinnedRing.counters()
         for w in range(warmup):
             if w == warmup - 1:
@@ -183,6 +196,7 @@ class TrainStep:
         # signature) would then run its gradient accumulation on that stream, and the next replay faults on ROCm 7.2
         # (DESIGN.md §5 "hipGraph").
         loss_dict = _detached(loss_dict)
+        cmdbuf.ENABLED, resnet_core.ENABLED = cmdbuf_was, r50_was
         self._graph, self._static, self._static_losses = graph, static, loss_dict
         self._graph_sig = self._signature(example_batch)
         return self

@@ -10,6 +10,9 @@ _WS = {}
 
 def _workspace(B, H, Lq, Lk, device):
     n = int(_lib.load().pd_attn_workspace_floats(B, H, Lq, Lk))
+    from .. import cmdbuf
+    if cmdbuf.active() is not None:                          # recorded region: scratch owned by the recording (its arena)
+        return torch.empty(max(n, 1), dtype=torch.float32, device=device)
     key = str(device)
     ws = _WS.get(key)
     if ws is None or ws.numel() < n:

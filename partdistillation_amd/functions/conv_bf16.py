@@ -182,19 +182,30 @@ def _run(q):
             d.db = entry[5] if len(entry) > 5 else None
             d.scale = entry[6] if len(entry) > 6 else None
             d.batch, d.hi, d.wi, d.ci, d.ho, d.wo, d.co, d.k, d.stride, d.pad = geom
+        from .. import cmdbuf
         need = int(L.pd_conv_bf16_wgrad_grouped_workspace_floats(ctypes.byref(descs), len(part)))
-        ws = _WS.get(str(dev))
-        if ws is None or ws.numel() < need:
-            ws = _WS[str(dev)] = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=dev)
         tbytes = int(L.pd_conv_bf16_wgrad_grouped_table_bytes(_Deferred.MAXP))
         if _Deferred.ring is None:
             from .fused import PinnedRing
-            _Deferred.ring = PinnedRing(tbytes, torch.uint8, pin=True)
-        if _Deferred.table_dev is None or _Deferred.table_dev.device != dev:
-            _Deferred.table_dev = torch.empty(tbytes, dtype=torch.uint8, device=dev)
+            with cmdbuf.host_ops():
+                _Deferred.ring = PinnedRing(tbytes, torch.uint8, pin=True)
+        if cmdbuf.active() is not None:                          # recorded region: scratch + table in its arena, operands must be stable
+            for entry in part:
+                for ptr, nm in ((entry[1], "dz"), (entry[2], "x"), (entry[3], "dw"), (entry[5] if len(entry) > 5 else None, "db")):
+                    if ptr:
+                        cmdbuf.require_stable(ptr, "grouped filter gradient operand " + nm)
+            ws = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
+            table_dev = torch.empty(tbytes, dtype=torch.uint8, device=dev)
+        else:
+            ws = _WS.get(str(dev))
+            if ws is None or ws.numel() < need:
+                ws = _WS[str(dev)] = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=dev)
+            if _Deferred.table_dev is None or _Deferred.table_dev.device != dev:
+                _Deferred.table_dev = torch.empty(tbytes, dtype=torch.uint8, device=dev)
+            table_dev = _Deferred.table_dev
         host = _Deferred.ring.acquire()
         with torch.cuda.device(dev):
-            rc = L.pd_conv_bf16_wgrad_grouped(ctypes.byref(descs), len(part), host.data_ptr(), _Deferred.table_dev.data_ptr(), ws.data_ptr(),
+            rc = L.pd_conv_bf16_wgrad_grouped(ctypes.byref(descs), len(part), host.data_ptr(), table_dev.data_ptr(), ws.data_ptr(),
                                               ws.numel(), _stream())
         _Deferred.ring.release()
         _lib.check(rc)

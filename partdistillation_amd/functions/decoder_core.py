@@ -22,8 +22,10 @@ from typing import List
 import torch
 from torch.autograd import Function
 
+from .. import cmdbuf
+from .. import lib as _lib
 from . import rowwise as rw
-from . import conv_bf16
+from . import conv_bf16, igemm
 from . import smallgemm as sg
 from .attention import attn_bwd_raw, attn_fwd_raw
 
@@ -116,6 +118,19 @@ N_GLOBAL = 11        # query_feat, query_embed, level_embed, dn_w, dn_b, mlp (w,
 N_LAYER = 18         # cross: in_w in_b out_w out_b n_w n_b | self: same | ffn: w1 b1 w2 b2 n_w n_b
 
 
+_RECS = {}             # recorded regions (cmdbuf.Recording), keyed by everything that decides their control flow
+
+
+def _rec_get(key):
+    return _RECS.get(key)
+
+
+def _rec_put(key, rec):
+    if len(_RECS) >= 24:                                   # a new model in the same process (tests): drop the oldest recordings + arenas
+        _RECS.pop(next(iter(_RECS)))
+    _RECS[key] = rec
+
+
 class DecoderCore(Function):
     @staticmethod
     def forward(ctx, spec: DecoderSpec, *t):
@@ -127,31 +142,73 @@ class DecoderCore(Function):
         query_feat, query_embed, level_embed, dn_w, dn_b = g[:5]
         mlp = g[5:11]
         layers = [t[nl + N_GLOBAL + i * N_LAYER: nl + N_GLOBAL + (i + 1) * N_LAYER] for i in range(L)]
+        R = Q * B
+        # ---- eager prologue (ATen): the learnable queries broadcast over the batch
+        qpos = query_embed.contiguous()                                        # fp32 [Q, C]; row r uses qpos[r // B]
+        tgt = query_feat.unsqueeze(1).expand(Q, B, C).reshape(R, C)             # fp32 copy
+        tgtpos_c = (query_feat + query_embed).to(cdt).unsqueeze(1).expand(Q, B, C).reshape(R, C)
+        fused_head = (FUSED_HEAD and cdt == torch.bfloat16 and C == 256 and all(tuple(mlp[j].shape) == (256, 256) for j in (0, 2, 4))
+                      and all(mlp[j].is_contiguous() and mlp[j].dtype == torch.bfloat16 for j in range(6)))
+        multi = MULTI_QKV and cdt == torch.bfloat16 and C <= 256 and C % 64 == 0
+        # the layer loop as a RECORDED region (cmdbuf.py): needs every step inside it to be a pd_* call — the fused prediction head,
+        # the multi-problem projections and bf16 pooled mask features (the mask logits then run on pd_sgemm_nn_bf16, not torch.bmm)
+        use_rec = (cmdbuf.usable() and xs[0].is_cuda and fused_head and multi and all(p_.dtype == torch.bfloat16 and p_.shape[2] % 8 == 0 and (p_.is_contiguous() or p_.transpose(1, 2).is_contiguous()) for p_ in spec.pooled)
+                   and any(ctx.needs_input_grad))
+        flat_layers = [p_ for lay in layers for p_ in lay]
+        if cmdbuf.DEBUG and not use_rec:
+            import sys
+            print("[cmdbuf] decoder forward runs eagerly:", dict(cuda=xs[0].is_cuda, fused_head=fused_head, multi=multi,
+                  pooled=[(str(p_.dtype), p_.is_contiguous()) for p_ in spec.pooled], needs_grad=any(ctx.needs_input_grad)), file=sys.stderr, flush=True)
+        if not use_rec:
+            ctx.rec = None
+            outs = DecoderCore._fwd_layers(spec, xs, qpos, tgt, tgtpos_c, level_embed, dn_w, dn_b, mlp, layers, fused_head, multi)
+        else:
+            consts = list(spec.pos[:nl]) + list(spec.pooled[:nl])
+            head = list(xs) + [qpos, tgt, tgtpos_c] + consts
+            params = [level_embed, dn_w, dn_b] + list(mlp) + flat_layers
+            slots = head + params
+            key = ("fwd", B, Q, C, H, L, nl, tuple(tuple(x.shape) for x in xs), params[0].data_ptr(), flat_layers[0].data_ptr(), str(xs[0].device),
+                   _lib.current_stream())
+            rec = _rec_get(key)
+            if rec is None or not rec.matches(slots):
+                rec = cmdbuf.Recording(slots, "decoder forward", pinned=range(len(head), len(slots)))
+                with rec:
+                    outs = DecoderCore._fwd_layers(spec, xs, qpos, tgt, tgtpos_c, level_embed, dn_w, dn_b, mlp, layers, fused_head, multi)
+                outs = rec.finish(outs)
+                _rec_put(key, rec)
+            else:
+                outs = rec.replay(slots)
+            ctx.rec, ctx.rec_gen = rec, rec.generation
+        dec_outs, final_tgt, saved, head_stats, mem, mempos = outs
+        ctx.spec, ctx.saved, ctx.head_stats = spec, saved, head_stats
+        ctx.mem, ctx.mempos = mem, mempos
+        ctx.params = (query_feat, query_embed, level_embed, dn_w, dn_b, mlp, layers)
+        ctx.x_shapes = [x.shape for x in xs]
+        return dec_outs, final_tgt.view(R, C)          # a view: the node must not own one of its own outputs (reference cycle)
+
+    @staticmethod
+    def _fwd_layers(spec, xs, qpos, tgt, tgtpos_c, level_embed, dn_w, dn_b, mlp, layers, fused_head, multi):
+        """-> (dec_outs, final tgt, saved, head_stats, mem, mempos); inside a recording: pd_* launches and allocations only"""
+        B, Q, C, H, L, cdt = spec.B, spec.Q, spec.C, spec.H, spec.L, spec.cdt
+        nl = spec.num_levels
         R, scale = Q * B, 32 ** -0.5
         dev = xs[0].device
-
+        if cmdbuf.active() is not None:
+            # these rows go into host-side problem tables (pd_sgemm_tn_multi_bf16) and are saved for the backward region: arena copies
+            tgt, tgtpos_c = rw.copy_d2d(torch.empty_like(tgt), tgt), rw.copy_d2d(torch.empty_like(tgtpos_c), tgtpos_c)
         mem, mempos = [], []
         for l in range(nl):
             m, mp = rw.mem_prep_fwd(xs[l], level_embed[l], spec.pos[l], cdt)
             mem.append(m), mempos.append(mp)
-        qpos = query_embed.contiguous()                                        # fp32 [Q, C]; row r uses qpos[r // B]
-        tgt = query_feat.unsqueeze(1).expand(Q, B, C).reshape(R, C)             # fp32 copy
-        tgtpos_c = (query_feat + query_embed).to(cdt).unsqueeze(1).expand(Q, B, C).reshape(R, C)
-
         dec_outs = torch.empty((L + 1, R, C), dtype=torch.float32, device=dev)
-        final_tgt = None
         saved = []
         head_stats = []
-
-        fused_head = (FUSED_HEAD and cdt == torch.bfloat16 and C == 256 and all(tuple(mlp[j].shape) == (256, 256) for j in (0, 2, 4))
-                      and all(mlp[j].is_contiguous() and mlp[j].dtype == torch.bfloat16 for j in range(6)))
 
         def head(i, tgt_f32, lvl):
             """decoder_norm -> dec_outs[i]; the (gradient-free) mask prediction for the next layer's attention"""
             if fused_head:                                         # LayerNorm + the 3-layer MLP + the batch-major fp32 copy: one launch
-                from .. import lib as _lib
                 stats = torch.empty((2, R), dtype=torch.float32, device=dev)
-                # the mask embeddings in the dtype of the pooled mask features (bf16 under autocast): the bmm below then casts nothing
+                # the mask embeddings in the dtype of the pooled mask features (bf16 under autocast): the product below then casts nothing
                 ef_bf16 = lvl is not None and spec.pooled[lvl].dtype == torch.bfloat16
                 ef = torch.empty((B, Q, C), dtype=torch.bfloat16 if ef_bf16 else torch.float32, device=dev) if lvl is not None else None
                 _lib.check(_lib.load().pd_decoder_head_bf16(tgt_f32.data_ptr(), dn_w.data_ptr(), dn_b.data_ptr(), float(spec.eps), mlp[0].data_ptr(),
@@ -161,7 +218,19 @@ class DecoderCore(Function):
                 head_stats.append((stats[0], stats[1]))
                 if lvl is None:
                     return None
-                return rw.attn_mask_u8(torch.bmm(ef, spec.pooled[lvl]))
+                pooled = spec.pooled[lvl]
+                pooled_t = pooled.transpose(1, 2)                  # [B, HW, C]: contiguous when the mask features are channels-last
+                if ef_bf16 and (pooled.is_contiguous() or pooled_t.is_contiguous()) and Q <= 1024 and C % 64 == 0 and pooled.shape[2] % 8 == 0:
+                    # mask logits [Q, HW] = embeddings [Q, C] x pooled mask features [C, HW], per image, on the skinny-row GEMMs
+                    # (reference :449: einsum("bqc,bchw->bqhw"); was torch.bmm -> hipBLASLt)
+                    logits = torch.empty((B, Q, pooled.shape[2]), dtype=torch.bfloat16, device=dev)
+                    for b in range(B):
+                        if pooled_t.is_contiguous():
+                            sg.linear(ef[b], pooled_t[b], None, False, out=logits[b])          # x [Q, C] @ w [HW, C]^T
+                        else:
+                            sg.dgrad(ef[b], pooled[b], out=logits[b])                          # dy [Q, C] @ w [C, HW]
+                    return rw.attn_mask_u8(logits)
+                return rw.attn_mask_u8(torch.bmm(ef, pooled))
             _, _, d_c, _, mean, rstd = _ln_into(tgt_f32, dn_w, dn_b, spec.eps, dec_outs[i], cdt)
             head_stats.append((mean, rstd))
             if lvl is None:
@@ -177,7 +246,6 @@ class DecoderCore(Function):
             lvl = i % nl
             (ciw, cib, cow, cob, cnw, cnb, siw, sib, sow, sob, snw, snb, w1, b1, w2, b2, fnw, fnb) = layers[i]
             # ---- masked cross-attention
-            multi = MULTI_QKV and cdt == torch.bfloat16 and C <= 256 and C % 64 == 0
             if multi:                                              # q, k, v projections: one launch (two inputs, three weight slices)
                 q, k, v = sg.linear_multi([(tgtpos_c, ciw[:C], cib[:C]), (mempos[lvl], ciw[C:2 * C], cib[C:2 * C]), (mem[lvl], ciw[2 * C:], cib[2 * C:])])
             else:
@@ -208,24 +276,83 @@ class DecoderCore(Function):
             tgt, tgtpos_c = y, ypos_c
             saved.append((cross, slf, ffn))
             mask = head(i + 1, tgt, (i + 1) % nl if i + 1 < L else None)
-        final_tgt = tgt.view(R, C)          # a view: the node must not own one of its own outputs (reference cycle)
-        ctx.spec, ctx.saved, ctx.head_stats = spec, saved, head_stats
-        ctx.mem, ctx.mempos = mem, mempos
-        ctx.params = (query_feat, query_embed, level_embed, dn_w, dn_b, mlp, layers)
-        ctx.x_shapes = [x.shape for x in xs]
-        return dec_outs, final_tgt
+        return dec_outs, tgt, saved, head_stats, mem, mempos
 
     @staticmethod
     def backward(ctx, d_out, d_final):
         spec = ctx.spec
         B, Q, C, H, L, cdt = spec.B, spec.Q, spec.C, spec.H, spec.L, spec.cdt
         nl = spec.num_levels
-        R, scale = Q * B, 32 ** -0.5
+        R = Q * B
         query_feat, query_embed, level_embed, dn_w, dn_b, mlp, layers = ctx.params
         dev = query_feat.device
         d_out = d_out.contiguous() if d_out is not None else torch.zeros((L + 1, R, C), dtype=torch.float32, device=dev)
-        need_x = [ctx.needs_input_grad[1 + l] for l in range(nl)]
+        d_fin = d_final.contiguous() if d_final is not None else None
+        need_x = tuple(bool(ctx.needs_input_grad[1 + l]) for l in range(nl))
+        tgt0 = query_feat.unsqueeze(1).expand(Q, B, C).reshape(R, C)
+        rec_f = getattr(ctx, "rec", None)
+        args = (spec, ctx.saved, ctx.head_stats, ctx.mem, ctx.mempos, ctx.x_shapes, d_out, d_fin, tgt0, level_embed, dn_w, layers)
+        if rec_f is None:
+            outs = DecoderCore._bwd_layers(*args)
+        else:
+            if rec_f.generation != ctx.rec_gen:
+                raise RuntimeError("the fused decoder ran another forward before this backward: the recorded region's activation arena was "
+                                   "overwritten (set PD_CMDBUF=0 for graphs that keep several forward passes alive)")
+            flat_layers = [p_ for lay in layers for p_ in lay]
+            head = [d_out] + ([d_fin] if d_fin is not None else []) + [tgt0]
+            params = [level_embed, dn_w] + flat_layers
+            slots = head + params
+            key = ("bwd", id(rec_f), d_fin is not None)
+            rec = _rec_get(key)
+            if rec is None or not rec.matches(slots):
+                rec = cmdbuf.Recording(slots, "decoder backward", stable=[rec_f], pinned=range(len(head), len(slots)))
+                with rec:
+                    outs = DecoderCore._bwd_layers(*args)
+                    outs = outs[:-1] + (cmdbuf.Fresh([g_ for lay in outs[-1] for g_ in lay]),)
+                outs = rec.finish(outs)
+                _rec_put(key, rec)
+            else:
+                outs = rec.replay(slots)
+            fl = outs[-1]
+            outs = outs[:-1] + ([tuple(fl[6 * i:6 * i + 6]) for i in range(L)],)
+        buf, slots_, dz0, d_res, d_pos_c, dtoks, d_level, wgrads = outs
+        lay, n_bias, s_dnw, s_dnb, s_pos = slots_
 
+        def A(s):
+            return buf[s[0]:s[0] + s[1]]
+        # ---- eager epilogue (ATen): the learnable queries' gradients, the bias gradients in the parameters' dtype
+        d_pos0 = d_pos_c.float().view(Q, B, C).sum(1)
+        d_query_feat = (dz0 + d_res).view(Q, B, C).sum(1) + d_pos0
+        d_query_embed = A(s_pos).view(Q, C) + d_pos0
+        d_xs = [None] * nl
+        for l in range(nl):
+            if dtoks[l] is not None and need_x[l]:
+                _, _, Hh, Ww = ctx.x_shapes[l]
+                d_xs[l] = dtoks[l].view(B, Hh, Ww, C).permute(0, 3, 1, 2)
+        bias_c = buf[:n_bias] if layers[0][1].dtype == torch.float32 else buf[:n_bias].to(layers[0][1].dtype)
+
+        def Bc(s):
+            return bias_c[s[0]:s[0] + s[1]]
+
+        grads = [None]                                                        # spec
+        grads += d_xs
+        grads += [d_query_feat, d_query_embed, d_level if rec_f is None else d_level.detach(), A(s_dnw), A(s_dnb)] + [None] * 6
+        for i in range(L):
+            g_ciw, g_cow, g_siw, g_sow, g_w1, g_w2 = wgrads[i]
+            s_ = lay[i]
+            grads += [g_ciw, Bc(s_["cib"]), g_cow, Bc(s_["cob"]), A(s_["cnw"]), A(s_["cnb"]),
+                      g_siw, Bc(s_["sib"]), g_sow, Bc(s_["sob"]), A(s_["snw"]), A(s_["snb"]),
+                      g_w1, Bc(s_["b1"]), g_w2, Bc(s_["b2"]), A(s_["fnw"]), A(s_["fnb"])]
+        return tuple(grads)
+
+    @staticmethod
+    def _bwd_layers(spec, saved, head_stats, mem_f, mempos_f, x_shapes, d_out, d_final, tgt0, level_embed, dn_w, layers):
+        """-> (accumulator buffer, its slot table, dz of head 0, d(residual stream), d(tgt + query_pos), per-level token gradients, d(level
+        embedding), per-layer weight gradients); inside a recording: pd_* launches and allocations only"""
+        B, Q, C, H, L, cdt = spec.B, spec.Q, spec.C, spec.H, spec.L, spec.cdt
+        nl = spec.num_levels
+        R, scale = Q * B, 32 ** -0.5
+        dev = d_out.device
         # fp32 accumulators: [linear biases ... | LayerNorm gammas / betas ... | decoder_norm | query_pos]
         acc = _Acc()
         lay = []
@@ -242,19 +369,35 @@ class DecoderCore(Function):
         def A(s):
             return buf[s[0]:s[0] + s[1]]
 
+        # input gradients over the memory tokens (dk W_k, dv W_v: 10^3..10^5 rows) on pd_igemm_bf16 with W^T as its weight operand:
+        # all layers' transposes in one grouped launch
+        big_rows = cdt == torch.bfloat16 and any(not _small(m, cdt) for m in mem_f) and C % 64 == 0
+        if big_rows:
+            wts = igemm.transposed([layers[i][0][j * C:(j + 1) * C] for i in range(L) for j in (1, 2)])
+
+        def dgrad_mem(dy, i, j, acc_into):
+            """dy [rows, C] @ W (the k / v slice of layer i's in_proj weight) (+ acc_into)"""
+            w = layers[i][0][j * C:(j + 1) * C]
+            if big_rows and not _small(dy, dy.dtype):
+                return igemm.linear(dy, wts[2 * i + (j - 1)], res=acc_into)
+            if acc_into is None:
+                return _dgrad(dy, w)
+            _dgrad(dy, w, out=acc_into, accumulate=True)
+            return acc_into
+
         dmem: List = [None] * nl
         dmempos: List = [None] * nl
         wgrads = [None] * L
         wq = sg.WgradQueue() if GROUP_WGRADS else None                       # the ~8 weight gradients per layer: one launch at the end
         big = [] if GROUP_WGRADS else None                                   # ... and the two over the memory tokens: conv_bf16's group
-        d_res = d_final.contiguous() if d_final is not None else None        # fp32 gradient w.r.t. the residual stream
+        d_res = d_final                                                      # fp32 gradient w.r.t. the residual stream
         d_pos_c = None                                                       # GEMM-dtype gradient w.r.t. (tgt + query_pos)
         for i in reversed(range(L)):
             lvl = i % nl
             (ciw, cib, cow, cob, cnw, cnb, siw, sib, sow, sob, snw, snb, w1, b1, w2, b2, fnw, fnb) = layers[i]
-            cross, slf, ffn = ctx.saved[i]
+            cross, slf, ffn = saved[i]
             # ---- head i+1 (decoder_norm of the FFN output)
-            hm, hr = ctx.head_stats[i + 1]
+            hm, hr = head_stats[i + 1]
             dzh, _ = rw.add_ln_bwd(ffn[5], hm, hr, dn_w, dy=d_out[i + 1], dgamma=A(s_dnw), dbeta=A(s_dnb))
             # ---- FFN
             x_c, h, z, mean, rstd, _ = ffn
@@ -289,31 +432,23 @@ class DecoderCore(Function):
             g_ciw = torch.empty_like(ciw)
             cb = A(lay[i]["cib"])
             _wgrad(dq, tp_c, g_ciw[:C], cb[:C], queue=wq)
-            _wgrad(dk, ctx.mempos[lvl], g_ciw[C:2 * C], cb[C:2 * C], queue=wq, big=big)
-            _wgrad(dv, ctx.mem[lvl], g_ciw[2 * C:], cb[2 * C:], queue=wq, big=big)
+            _wgrad(dk, mempos_f[lvl], g_ciw[C:2 * C], cb[C:2 * C], queue=wq, big=big)
+            _wgrad(dv, mem_f[lvl], g_ciw[2 * C:], cb[2 * C:], queue=wq, big=big)
             d_pos_c = _dgrad(dq, ciw[:C])                                     # -> previous layer's FFN norm (or the queries)
-            if dmempos[lvl] is None:
-                dmempos[lvl] = _dgrad(dk, ciw[C:2 * C])
-                dmem[lvl] = _dgrad(dv, ciw[2 * C:])
-            else:
-                _dgrad(dk, ciw[C:2 * C], out=dmempos[lvl], accumulate=True)
-                _dgrad(dv, ciw[2 * C:], out=dmem[lvl], accumulate=True)
+            dmempos[lvl] = dgrad_mem(dk, i, 1, dmempos[lvl])
+            dmem[lvl] = dgrad_mem(dv, i, 2, dmem[lvl])
             d_res = dz
             wgrads[i] = (g_ciw, g_cow, g_siw, g_sow, g_w1, g_w2)
 
-        # ---- head 0 and the learnable queries
-        hm, hr = ctx.head_stats[0]
-        tgt0 = query_feat.unsqueeze(1).expand(Q, B, C).reshape(R, C)
+        # ---- head 0
+        hm, hr = head_stats[0]
         dz0, _ = rw.add_ln_bwd(tgt0, hm, hr, dn_w, dy=d_out[0], dgamma=A(s_dnw), dbeta=A(s_dnb))
-        d_pos0 = d_pos_c.float().view(Q, B, C).sum(1)
-        d_query_feat = (dz0 + d_res).view(Q, B, C).sum(1) + d_pos0
-        d_query_embed = A(s_pos).view(Q, C) + d_pos0
 
-        d_xs = [None] * nl
+        dtoks = [None] * nl
         d_level = torch.zeros_like(level_embed)
         use_colsum = level_embed.dtype == torch.float32 and C % 128 == 0
         for l in range(nl):
-            _, _, Hh, Ww = ctx.x_shapes[l]
+            _, _, Hh, Ww = x_shapes[l]
             if dmem[l] is None:                                              # level unused (fewer layers than levels)
                 continue
             dtok = rw.mem_prep_bwd(dmem[l], dmempos[l], B, Hh, Ww, C)
@@ -321,27 +456,11 @@ class DecoderCore(Function):
                 rw.colsum_acc(dtok.view(-1, C), d_level[l])                   # (ATen's column reduction takes 30 us for the 32 768 rows of level 0)
             else:
                 torch.sum(dtok.view(-1, C), dim=0, out=d_level[l])
-            if need_x[l]:
-                d_xs[l] = dtok.view(B, Hh, Ww, C).permute(0, 3, 1, 2)
-
+            dtoks[l] = dtok
         if wq is not None:
-            wq.run()                                                         # before the bias accumulators below are read
-            conv_bf16.run_now(big)                                           # NOW: their bias sums are read (cast) right below
-        bias_c = buf[:n_bias] if layers[0][1].dtype == torch.float32 else buf[:n_bias].to(layers[0][1].dtype)
-
-        def Bc(s):
-            return bias_c[s[0]:s[0] + s[1]]
-
-        grads = [None]                                                        # spec
-        grads += d_xs
-        grads += [d_query_feat, d_query_embed, d_level, A(s_dnw), A(s_dnb)] + [None] * 6
-        for i in range(L):
-            g_ciw, g_cow, g_siw, g_sow, g_w1, g_w2 = wgrads[i]
-            s = lay[i]
-            grads += [g_ciw, Bc(s["cib"]), g_cow, Bc(s["cob"]), A(s["cnw"]), A(s["cnb"]),
-                      g_siw, Bc(s["sib"]), g_sow, Bc(s["sob"]), A(s["snw"]), A(s["snb"]),
-                      g_w1, Bc(s["b1"]), g_w2, Bc(s["b2"]), A(s["fnw"]), A(s["fnb"])]
-        return tuple(grads)
+            wq.run()                                                         # before the bias accumulators are read
+            conv_bf16.run_now(big)                                           # their bias sums are read (cast) by the caller
+        return buf, (lay, n_bias, s_dnw, s_dnb, s_pos), dz0, d_res, d_pos_c, dtoks, d_level, wgrads
 
 
 def _ln_into(x_f32, gamma, beta, eps, y_out, cdt):

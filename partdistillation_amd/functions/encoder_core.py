@@ -22,6 +22,8 @@ from torch.autograd import Function
 from .. import MultiScaleDeformableAttention as MSDA
 from .. import lib as _lib
 from . import rowwise as rw
+from .. import cmdbuf
+from . import gemm as _gemm
 from .gemm import (WgradQueue, gemm_tn_h2, gemm_tn_x3, gemm_tn_x3_pre, gemm_tn_x3_relu_bits, gemm_tn_x3_relumask, gemm_wgrad_acc,
                    h2_bits_supported, pre_supported, relu_bits_supported, row_amax, split3)
 
@@ -30,6 +32,14 @@ def _timed(kind, fn, *args):
     # sits under modeling/, which imports this one)
     from ..modeling.pixel_decoder.ops.functions.ms_deform_attn_func import _timed as t
     return t(kind, fn, *args)
+
+
+_RECS = {}      # recorded regions (cmdbuf.Recording) of the encoder, keyed by everything that decides their control flow
+
+
+def _msda_timing():
+    from ..modeling.pixel_decoder.ops.functions.ms_deform_attn_func import _TIMING as t
+    return t
 
 
 N_LAYER = 16   # so_w so_b aw_w aw_b vp_w vp_b op_w op_b n1_w n1_b l1_w l1_b l2_w l2_b n2_w n2_b
@@ -180,19 +190,53 @@ class EncoderCore(Function):
     @staticmethod
     def _forward_h2(ctx, spec, src2, pos2, q, ref, params, dims):
         """the same layer sequence with every GEMM on pd_gemm_tn_f16x2: each operand travels with the absolute maxima of its rows
-        (LayerNorm outputs and the FFN's hidden activations get them from the kernel that writes them)"""
+        (LayerNorm outputs and the FFN's hidden activations get them from the kernel that writes them).
+        The layer loop is a RECORDED region (cmdbuf.py): its ~60 launches are issued by one C call from the second step on."""
+        B, S, C, nl = dims
+        P_ = lambda i, j: params[i * N_LAYER + j]
+        # weights with 256 input columns of all layers in ONE matrix (rows: so, aw, vp, op, l1 per layer) + one row-maxima launch;
+        # the slices of that copy are the GEMM operands (so + aw adjacent = the stacked sampling_offsets / attention_weights matrix)
+        n_off, n_aw = P_(0, 0).shape[0], P_(0, 2).shape[0]
+        wk = torch.cat([P_(i, j) for i in range(nl) for j in (0, 2, 4, 6, 10)])
+        b_oa_all = torch.cat([P_(i, j) for i in range(nl) for j in (1, 3)]).view(nl, n_off + n_aw)
+        l2_all = torch.cat([P_(i, 12) for i in range(nl)])                                  # [nl * C, ffn]
+        ctx.wk = wk
+        use_rec = (cmdbuf.usable() and src2.is_cuda and any(ctx.needs_input_grad) and not _gemm._TIMING["on"]
+                   and not _msda_timing()["on"])
+        if not use_rec:
+            ctx.rec = None
+            x, saved, saved_am = EncoderCore._layers_h2(spec, src2, pos2, q, ref, wk, b_oa_all, l2_all, params, dims)
+        else:
+            slots = [src2, pos2, q, ref, wk, b_oa_all, l2_all, spec.shapes, spec.lsi] + list(params)
+            key = ("fwd", B, S, C, nl, spec.M, spec.L, spec.P, str(src2.device), _lib.current_stream())
+            rec = _RECS.get(key)
+            if rec is None or not rec.matches(slots):
+                rec = cmdbuf.Recording(slots, "encoder forward")
+                with rec:
+                    outs = EncoderCore._layers_h2(spec, src2, pos2, q, ref, wk, b_oa_all, l2_all, params, dims)
+                x, saved, saved_am = rec.finish(outs)
+                _RECS[key] = rec
+            else:
+                x, saved, saved_am = rec.replay(slots)
+            ctx.rec, ctx.rec_gen = rec, rec.generation
+        ctx.saved_am = saved_am
+        ctx.spec, ctx.saved, ctx.params, ctx.dims = spec, saved, params, (B, S, C, nl)
+        return x.view(B, S, C)
+
+    @staticmethod
+    def _layers_h2(spec, src2, pos2, q, ref, wk, b_oa_all, l2_all, params, dims):
+        """-> (output tokens [T, C], per-layer saved tensors, per-layer saved row maxima); pd_* launches and allocations only"""
         B, S, C, nl = dims
         M, L, P = spec.M, spec.L, spec.P
         T = B * S
         P_ = lambda i, j: params[i * N_LAYER + j]
-        # weights with 256 input columns of all layers in ONE matrix (rows: so, aw, vp, op, l1 per layer) + one row-maxima launch;
-        # the slices of that copy are the GEMM operands (so + aw adjacent = the stacked sampling_offsets / attention_weights matrix)
         n_off, n_aw, n_l1 = P_(0, 0).shape[0], P_(0, 2).shape[0], P_(0, 10).shape[0]
         per = n_off + n_aw + 2 * C + n_l1
-        wk = torch.cat([P_(i, j) for i in range(nl) for j in (0, 2, 4, 6, 10)])
+        if cmdbuf.active() is not None:
+            # the backward pass writes the addresses of layer 0's operands into the host-side table of its grouped weight-gradient
+            # launch: they must be arena memory, not this step's input tensors
+            src2, q = rw.copy_d2d(torch.empty_like(src2), src2), rw.copy_d2d(torch.empty_like(q), q)
         wk_am = row_amax(wk)
-        b_oa_all = torch.cat([P_(i, j) for i in range(nl) for j in (1, 3)]).view(nl, n_off + n_aw)
-        l2_all = torch.cat([P_(i, 12) for i in range(nl)])                                  # [nl * C, ffn]
         l2_am = row_amax(l2_all)
         fwd_amax = C // M == 32 and L == 3 and P == 4 and src2.dtype == torch.float32       # the MSDA kernel that can emit its rows' maxima
         zam = torch.zeros((2 * nl if fwd_amax else nl, T), dtype=torch.float32, device=src2.device)   # atomic-max targets: FFN epilogues, MSDA outputs
@@ -227,15 +271,164 @@ class EncoderCore(Function):
             last = i == nl - 1
             z2, y2, _, ypos, m2, r2, y2_am, ypos_am = rw.add_ln_fwd(ffn2, y1, n2_w, n2_b, spec.eps, c_dtype=torch.float32,
                                                                      pos=pos2, pos_div=1, want_ypos=not last, amax=True)
-            saved.append((x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, w_oa, hbits))
+            saved.append((x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, None, hbits))
             saved_am.append((x_am, q_am, a_am, y1_am, h_am))
             x, q, x_am, q_am = y2, ypos, y2_am, ypos_am
-        ctx.saved_am = saved_am
-        ctx.spec, ctx.saved, ctx.params, ctx.dims = spec, saved, params, (B, S, C, nl)
-        return x.view(B, S, C)
+        return x, saved, saved_am
+
+    @staticmethod
+    def _stack_t(params, nl, j):
+        """[nl, K, N]: the transposes of weight j of all layers (the "B[N, K]" operands of the input-gradient GEMMs), one copy launch"""
+        ws = [params[i * N_LAYER + j] for i in range(nl)]
+        # the layers' parameters usually sit at one spacing in a flat buffer (engine/flat_params.py, last layer first): the stack is
+        # then a strided VIEW and the transposed copy the only launch
+        d = (ws[1].data_ptr() - ws[0].data_ptr()) if nl > 1 else 0
+        es = ws[0].element_size()
+        if nl > 1 and d != 0 and d % es == 0 and all(w.is_contiguous() and w.shape == ws[0].shape for w in ws) \
+                and all(ws[i].data_ptr() - ws[0].data_ptr() == i * d for i in range(nl)) \
+                and all(w.untyped_storage().data_ptr() == ws[0].untyped_storage().data_ptr() for w in ws):
+            N_, K_ = ws[0].shape
+            base = ws[0] if d > 0 else ws[-1]                 # lowest address first; _Stack maps the layer index back
+            return _Stack(torch.as_strided(base, (nl, N_, K_), (abs(d) // es, K_, 1)).transpose(1, 2).contiguous(), d < 0)
+        return _Stack(torch.stack(ws).transpose(1, 2).contiguous(), False)
+
+    @staticmethod
+    def _backward_h2(ctx, d_out):
+        """backward of _forward_h2: an eager prologue (the transposed weight stacks: ATen copies), the layer loop as a recorded region
+        (~110 launches incl. the grouped weight gradients: one C call from the second step on), three elementwise sums at the end"""
+        spec, params = ctx.spec, ctx.params
+        B, S, C, nl = ctx.dims
+        T = B * S
+        need_w = any(ctx.needs_input_grad[3:])
+        n_off, n_aw, n_l1 = params[0].shape[0], params[2].shape[0], params[10].shape[0]
+        per = n_off + n_aw + 2 * C + n_l1
+        st = EncoderCore._stack_t
+        l1_t, l2_t, op_t, vp_t = st(params, nl, 10), st(params, nl, 12), st(params, nl, 6), st(params, nl, 4)
+        wk = ctx.wk
+        oa_t = _Stack(torch.as_strided(wk, (nl, n_off + n_aw, C), (per * C, C, 1)).transpose(1, 2).contiguous(), False)
+        dy = d_out.reshape(T, C)
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        stacks = (l1_t, l2_t, op_t, vp_t, oa_t)
+        rec_f = getattr(ctx, "rec", None)
+        if rec_f is None:
+            dy, dy2, dyq, d_pos, grads = EncoderCore._bwd_layers_h2(spec, params, ctx.dims, ctx.saved, ctx.saved_am, dy, stacks, need_w)
+        else:
+            if rec_f.generation != ctx.rec_gen:
+                raise RuntimeError("the fused encoder ran another forward before this backward: the recorded region's activation arena was "
+                                   "overwritten (set PD_CMDBUF=0 for graphs that keep several forward passes alive)")
+            slots = [dy] + [k.t for k in stacks] + [spec.shapes, spec.lsi] + list(params)
+            key = ("bwd", id(rec_f), need_w, tuple(k.rev for k in stacks))
+            rec = _RECS.get(key)
+            if rec is None or not rec.matches(slots):
+                rec = cmdbuf.Recording(slots, "encoder backward", stable=[rec_f])
+                with rec:
+                    outs = EncoderCore._bwd_layers_h2(spec, params, ctx.dims, ctx.saved, ctx.saved_am, dy, stacks, need_w)
+                    outs = outs[:4] + (cmdbuf.Fresh(outs[4]),)
+                dy, dy2, dyq, d_pos, grads = rec.finish(outs)
+                _RECS[key] = rec
+            else:
+                dy, dy2, dyq, d_pos, grads = rec.replay(slots)
+        d_pos = d_pos + dyq if rec_f is not None else d_pos.add_(dyq)      # (never in place on an arena tensor another replay re-reads)
+        d_src = dy + dy2
+        d_src += dyq
+        if not need_w:
+            grads = [None] * len(grads)
+        return (None, d_src.view(B, S, C), d_pos.view(B, S, C), *grads)
+
+    @staticmethod
+    def _bwd_layers_h2(spec, params, dims, saved, saved_am, dy, stacks, need_w):
+        """-> (dy, dy2, dyq: the three fp32 terms of d(src), d_pos without its last term, parameter gradients); pd_* launches and
+        allocations only (recordable)"""
+        B, S, C, nl = dims
+        M, L, P = spec.M, spec.L, spec.P
+        T = B * S
+        dev = dy.device
+        l1_t, l2_t, op_t, vp_t, oa_t = stacks
+        wh2 = H2_WGRAD
+        queue = WgradQueue(h2=wh2) if (need_w and GROUP_WGRADS and _gemm.WGRAD_X3) else None
+        if not need_w:
+            wgrad = lambda *a, **k: None
+        elif queue is not None:
+            wgrad = (lambda dy_, x_, dw_, db_=None, ya=None, xa=None: queue.add(dy_, x_, dw_, db_, ya if wh2 else None, xa if wh2 else None))
+        else:
+            wgrad = (lambda dy_, x_, dw_, db_=None, ya=None, xa=None: gemm_wgrad_acc(dy_, x_, dw_, db_, h2=wh2, y_amax=ya if wh2 else None,
+                                                                                     x_amax=xa if wh2 else None))
+        # every parameter gradient of the encoder lives in ONE zero-filled fp32 buffer (a single memset): the LayerNorm /
+        # ReLU kernels and the split-K weight-gradient GEMMs all accumulate (+=) into their slices
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        n_off = params[0].shape[0]
+        n_oa = n_off + params[2].shape[0]                               # stacked sampling_offsets + attention_weights rows
+        oa_base, oa_per = total, n_oa * C + (n_oa + 3) // 4 * 4
+        total += nl * oa_per
+        buf = torch.zeros(total, dtype=torch.float32, device=dev)
+
+        def OA(i):
+            o = oa_base + i * oa_per
+            return buf[o:o + n_oa * C].view(n_oa, C), buf[o + n_oa * C:o + n_oa * C + n_oa]
+
+        def G(i, j):
+            p = params[i * N_LAYER + j]
+            o = offs[i * N_LAYER + j]
+            return buf[o:o + p.numel()].view(p.shape)
+        d_pos = torch.zeros((T, C), dtype=torch.float32, device=dev)
+        grads = [None] * (nl * N_LAYER)
+        t_am = lambda w: _Stack(row_amax(w.t.view(-1, w.t.shape[2])).view(nl, w.t.shape[1]), w.rev)
+        l1_tam, l2_tam, op_tam, vp_tam, oa_tam = t_am(l1_t), t_am(l2_t), t_am(op_t), t_am(vp_t), t_am(oa_t)
+        dh_am_all = torch.zeros((nl, T), dtype=torch.float32, device=dev)
+        dy2 = dyq = None                                       # further fp32 terms of d(src_l): via value_proj, via (src + pos)
+        for i in reversed(range(nl)):
+            n1_w, l1_w, n2_w = params[i * N_LAYER + 8], params[i * N_LAYER + 10], params[i * N_LAYER + 14]
+            x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, _, hbits = saved[i]
+            (g_sow, g_sob, g_aww, g_awb, g_vpw, g_vpb, g_opw, g_opb, g_n1w, g_n1b, g_l1w, g_l1b, g_l2w, g_l2b, g_n2w,
+             g_n2b) = [G(i, j) for j in range(N_LAYER)]
+            # ---- FFN + norm2
+            dz2, _, dz2_am = rw.add_ln_bwd(z2, m2, r2, n2_w, dy=dy, dy2=dy2, dypos_c=dyq, dgamma=g_n2w, dbeta=g_n2b, dbias=g_l2b,
+                                           dpos_acc=d_pos if dyq is not None else None, pos_div=1, amax=True)
+            x_am, q_am, a_am, y1_am, h_am = saved_am[i]
+            wgrad(dz2, h, g_l2w, None, dz2_am, h_am)
+            if hbits is not None:
+                dh = gemm_tn_h2(dz2, l2_t[i], None, mode=2, bits=hbits, colsum=g_l1b, a_amax=dz2_am, b_amax=l2_tam[i], c_amax=dh_am_all[i])
+                dh_am = dh_am_all[i]
+            else:
+                dh = rw.relu_bwd_colsum(gemm_tn_h2(dz2, l2_t[i], a_amax=dz2_am, b_amax=l2_tam[i]), h, g_l1b)
+                dh_am = row_amax(dh)
+            wgrad(dh, y1, g_l1w, None, dh_am, y1_am)
+            dy1 = gemm_tn_h2(dh, l1_t[i], a_amax=dh_am, b_amax=l1_tam[i])
+            # ---- deformable attention + norm1 (with queued weight gradients dz2 stays alive until the grouped launch: dz1 gets its own buffer)
+            dz1, _, dz1_am = rw.add_ln_bwd(z1, m1, r1, n1_w, dy=dz2, dy2=dy1, dgamma=g_n1w, dbeta=g_n1b, dbias=g_opb,
+                                           out=None if queue is not None else dz2, amax=True)
+            wgrad(dz1, a, g_opw, None, dz1_am, a_am)
+            da = gemm_tn_h2(dz1, op_t[i], a_amax=dz1_am, b_amax=op_tam[i]).view(B, S, C)
+            gv, gloc, gattn = _timed("bwd", MSDA.ms_deform_attn_backward, v4, spec.shapes, spec.lsi, loc6, attn5, da, spec.im2col_step)
+            d_oa = torch.empty((T, n_oa), dtype=torch.float32, device=dev)
+            if prep_amax_supported(M, L, P):
+                d_oa_am = torch.empty(T, dtype=torch.float32, device=dev)
+                msda_prep_bwd(gloc, gattn, attn5, spec.shapes, T, M, L, P, out=d_oa, amax=d_oa_am)
+            else:
+                msda_prep_bwd(gloc, gattn, attn5, spec.shapes, T, M, L, P, out=d_oa)
+                d_oa_am = row_amax(d_oa)
+            g_oaw, g_oab = OA(i)
+            wgrad(d_oa, q, g_oaw, g_oab, d_oa_am, q_am)                   # both weight gradients in one split-K GEMM
+            g_sow, g_aww, g_sob, g_awb = g_oaw[:n_off], g_oaw[n_off:], g_oab[:n_off], g_oab[n_off:]
+            dq = gemm_tn_h2(d_oa, oa_t[i], a_amax=d_oa_am, b_amax=oa_tam[i])
+            gv2 = gv.view(T, C)
+            gv_am = row_amax(gv2)
+            wgrad(gv2, x, g_vpw, g_vpb, gv_am, x_am)
+            dxv = gemm_tn_h2(gv2, vp_t[i], a_amax=gv_am, b_amax=vp_tam[i])
+            grads[i * N_LAYER:(i + 1) * N_LAYER] = [g_sow, g_sob, g_aww, g_awb, g_vpw, g_vpb, g_opw, g_opb, g_n1w, g_n1b,
+                                                     g_l1w, g_l1b, g_l2w, g_l2b, g_n2w, g_n2b]
+            dy, dy2, dyq = dz1, dxv, dq
+        if queue is not None:
+            queue.flush()
+        return dy, dy2, dyq, d_pos, grads
 
     @staticmethod
     def backward(ctx, d_out):
+        if getattr(ctx, "h2", False) and X3_PROJ and USE_X3:
+            return EncoderCore._backward_h2(ctx, d_out)
         spec, params = ctx.spec, ctx.params
         B, S, C, nl = ctx.dims
         M, L, P = spec.M, spec.L, spec.P

@@ -182,6 +182,16 @@ class PinnedRing:
 
     def acquire(self):
         self.count += 1
+        from .. import cmdbuf
+        rec = cmdbuf.active()
+        if rec is not None and self.pin:
+            # inside a recorded region (cmdbuf.py) the copy out of this buffer is replayed every step from the SAME address: a
+            # dedicated pinned buffer owned by the recording (its content — a launch table — is identical at every replay)
+            with cmdbuf.host_ops():
+                buf = torch.zeros_like(self.bufs[0]).pin_memory()
+            rec.host_static(buf)
+            self._in_capture = True
+            return buf
         if self.pin and torch.cuda.is_current_stream_capturing():
             if not self.reserved:
                 raise RuntimeError("PinnedRing: a host->device upload inside a hipGraph capture needs a reserved pinned buffer "

@@ -277,10 +277,15 @@ class WgradQueue:
             parts = [g[lo:lo + self.MAXP] for g in (wide, rest) for lo in range(0, len(g), self.MAXP)]
         else:
             parts = [items[lo:lo + self.MAXP] for lo in range(0, len(items), self.MAXP)]
+        from .. import cmdbuf
         for part in parts:
             descs = (_WgradDesc * len(part))()
             flops = nbytes = 0.0
             for d, (dy, x, dw, db, ya, xa) in zip(descs, part):
+                if cmdbuf.active() is not None:
+                    for t_, nm in ((dy, "dY"), (x, "X"), (dw, "dW"), (db, "dB"), (ya, "y_amax"), (xa, "x_amax")):
+                        if t_ is not None:
+                            cmdbuf.require_stable(t_.data_ptr(), "grouped weight gradient operand " + nm)
                 d.dY, d.X, d.dW, d.dB = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
                 d.y_amax, d.x_amax = (ya.data_ptr() if ya is not None else None), (xa.data_ptr() if xa is not None else None)
                 d.M, d.N, d.K, d.ldy, d.ldx, d.ldw = dy.shape[0], dy.shape[1], x.shape[1], dy.stride(0), x.stride(0), dw.shape[1]
@@ -289,17 +294,22 @@ class WgradQueue:
             need = int((L.pd_gemm_wgrad_f16x2_grouped_ws_floats if self.h2 else L.pd_gemm_wgrad_f32x3_grouped_ws_floats)(ctypes.byref(descs), len(part)))
             if need < 0:
                 raise RuntimeError("pd_gemm_wgrad_f32x3_grouped: a queued problem violates the alignment rules (N, K, strides % 4, 16-byte bases)")
-            key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
-            ws = WgradQueue._ws.get(key)
-            if ws is None or ws.numel() < need:
-                ws = WgradQueue._ws[key] = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=dev)
             tbytes = int(L.pd_gemm_wgrad_f32x3_grouped_table_bytes(self.MAXP))
             if WgradQueue._ring is None:
                 from .fused import PinnedRing
-                WgradQueue._ring = PinnedRing(tbytes, torch.uint8, pin=True)
-            tdev = WgradQueue._table_dev.get(str(dev))
-            if tdev is None:
-                tdev = WgradQueue._table_dev[str(dev)] = torch.empty(tbytes, dtype=torch.uint8, device=dev)
+                with cmdbuf.host_ops():
+                    WgradQueue._ring = PinnedRing(tbytes, torch.uint8, pin=True)
+            if cmdbuf.active() is not None:                       # recorded region: scratch + table owned by the recording (its arena)
+                ws = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
+                tdev = torch.empty(tbytes, dtype=torch.uint8, device=dev)
+            else:
+                key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+                ws = WgradQueue._ws.get(key)
+                if ws is None or ws.numel() < need:
+                    ws = WgradQueue._ws[key] = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=dev)
+                tdev = WgradQueue._table_dev.get(str(dev))
+                if tdev is None:
+                    tdev = WgradQueue._table_dev[str(dev)] = torch.empty(tbytes, dtype=torch.uint8, device=dev)
             host = WgradQueue._ring.acquire()
             if _TIMING["on"]:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

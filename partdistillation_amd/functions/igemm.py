@@ -26,6 +26,9 @@ _WS = {}
 
 def workspace(dev, nbytes):
     """zero-initialised scratch for the split-K tickets + slabs of one stream (the kernel leaves the tickets zero)"""
+    from .. import cmdbuf
+    if cmdbuf.active() is not None:                          # recorded region: zero-filled (tickets) scratch in its arena
+        return torch.zeros(int(nbytes), dtype=torch.uint8, device=dev)
     key = (str(dev), _lib.current_stream())
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
@@ -48,6 +51,11 @@ def run(src, w, out, *, batch, hs, ws, cs, ho, wo, n, k=1, stride=1, pad=0, dgra
         raise RuntimeError("pd_igemm_bf16: CUDA tensors required (partdistillation_amd has no CPU fallback)")
     d = PdIgemm(_p(src), _p(w), _p(scale), _p(bias), _p(res), _p(res2), _p(gate), _p(out), _p(out_pre), batch, hs, ws, cs, ho, wo, n, k, stride, pad,
                 int(dgrad), act, gate_mode if gate is not None else GATE_NONE, res_mode, int(bias is not None and bias.dtype == torch.bfloat16))
+    from .. import cmdbuf
+    if cmdbuf.active() is not None:                          # the problem struct is host memory the replay re-reads
+        for t_, nm in ((src, "src"), (w, "w"), (scale, "scale"), (bias, "bias"), (res, "res"), (res2, "res2"), (gate, "gate"), (out, "out"), (out_pre, "out_pre")):
+            if t_ is not None:
+                cmdbuf.require_stable(t_.data_ptr(), "pd_igemm_bf16 operand " + nm)
     L = _lib.load()
     need = int(L.pd_igemm_bf16_workspace_bytes(ctypes.byref(d)))
     if need < 0:
@@ -111,6 +119,12 @@ def transposed(weights):
         if len(_TR) > 64:
             _TR.pop(next(iter(_TR)))
     descs, offs, total, ring, tdev = hit
+    from .. import cmdbuf
+    if cmdbuf.active() is not None:                          # recorded region: its own descriptor array + device table (arena)
+        descs = (PdFilterTranspose * len(weights))()
+        tdev = torch.empty(tdev.numel(), dtype=torch.uint8, device=dev)
+        for w in weights:
+            cmdbuf.require_stable(w.data_ptr(), "weight to transpose")
     buf = torch.empty(total, dtype=torch.bfloat16, device=dev)
     base = buf.data_ptr()
     for d, w, o in zip(descs, weights, offs):

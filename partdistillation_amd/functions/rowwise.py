@@ -82,6 +82,14 @@ def add_ln_bwd(z, mean, rstd, gamma, *, dy=None, dy2=None, dy_c=None, dypos_c=No
     return dz, dz_c
 
 
+def copy_d2d(dst, src):
+    """dst <- src (same byte size, both dense): hipMemcpyAsync on the launch stream as a C-ABI call (recordable: cmdbuf.py)"""
+    n = src.numel() * src.element_size()
+    assert dst.numel() * dst.element_size() == n and dst.is_contiguous() and src.is_contiguous()
+    _lib.check(_lib.load().pd_memcpy_d2d_async(dst.data_ptr(), src.data_ptr(), n, _stream()))
+    return dst
+
+
 def colsum_acc(x, acc):
     """acc[N] (fp32) += x.sum(0); x [rows, N] contiguous."""
     assert x.is_contiguous() and acc.dtype == torch.float32 and acc.numel() == x.shape[1]

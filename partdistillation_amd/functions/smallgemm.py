@@ -26,6 +26,9 @@ _SPLIT_WS = {}
 
 def _split_ws(dev, floats, tickets):
     """fp32 partial-tile workspace + zeroed ticket counters per device and stream (launches on one stream run in order)"""
+    from .. import cmdbuf
+    if cmdbuf.active() is not None:                          # recorded region: scratch + (zero-filled at every replay) tickets in its arena
+        return (torch.empty(max(floats, 1), dtype=torch.float32, device=dev), torch.zeros(max(tickets, 1), dtype=torch.int32, device=dev))
     key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
     e = _SPLIT_WS.get(key)
     if e is None or e[0].numel() < floats or e[1].numel() < tickets:
@@ -61,10 +64,15 @@ def linear_multi(problems):
     K = problems[0][0].shape[1]
     descs = (_TnDesc * len(problems))()
     outs = []
+    from .. import cmdbuf
     for d, (x, w, b) in zip(descs, problems):
         _chk2d(x, w)
         assert x.shape[1] == K and w.shape[1] == K
         y = torch.empty((x.shape[0], w.shape[0]), dtype=torch.bfloat16, device=x.device)
+        if cmdbuf.active() is not None:                      # the problem table is host memory the replay re-reads
+            for t_, nm in ((x, "X"), (w, "W"), (b, "bias")):
+                if t_ is not None:
+                    cmdbuf.require_stable(t_.data_ptr(), "pd_sgemm_tn_multi_bf16 operand " + nm)
         d.X, d.W, d.bias, d.Y = x.data_ptr(), w.data_ptr(), (b.data_ptr() if b is not None else None), y.data_ptr()
         d.M, d.N, d.ldx, d.ldw, d.ldy = x.shape[0], w.shape[0], x.stride(0), w.stride(0), y.stride(0)
         outs.append(y)
@@ -163,13 +171,22 @@ class WgradQueue:
                 d.dY, d.X, d.dW, d.dB = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
                 d.M, d.N, d.K = dy.shape[0], dy.shape[1], x.shape[1]
                 d.ldy, d.ldx, d.ldw = dy.stride(0), x.stride(0), dw.stride(0)
+            from .. import cmdbuf
             tbytes = int(L.pd_sgemm_wgrad_grouped_table_bytes(cls.MAXP))
             if cls._ring is None:
                 from .fused import PinnedRing
-                cls._ring = PinnedRing(tbytes, torch.uint8, pin=True)
-            tab = cls._table_dev.get(str(dev))
-            if tab is None:
-                tab = cls._table_dev[str(dev)] = torch.empty(tbytes, dtype=torch.uint8, device=dev)
+                with cmdbuf.host_ops():
+                    cls._ring = PinnedRing(tbytes, torch.uint8, pin=True)
+            if cmdbuf.active() is not None:
+                for dy, x, dw, db in part:
+                    for t_, nm in ((dy, "dY"), (x, "X"), (dw, "dW"), (db, "dB")):
+                        if t_ is not None:
+                            cmdbuf.require_stable(t_.data_ptr(), "grouped skinny weight gradient operand " + nm)
+                tab = torch.empty(tbytes, dtype=torch.uint8, device=dev)
+            else:
+                tab = cls._table_dev.get(str(dev))
+                if tab is None:
+                    tab = cls._table_dev[str(dev)] = torch.empty(tbytes, dtype=torch.uint8, device=dev)
             host = cls._ring.acquire()
             with torch.cuda.device(dev):
                 rc = L.pd_sgemm_wgrad_grouped_bf16(ctypes.byref(descs), len(part), host.data_ptr(), tab.data_ptr(), _stream())

@@ -142,12 +142,18 @@ SIGNATURES = {
     "pd_igemm_bf16_seq": (_c_int, [_c_vp, _c_int, _c_vp, ctypes.c_int64, _c_vp]),
     "pd_filter_transpose_table_bytes": (ctypes.c_int64, [_c_int]),
     "pd_filter_transpose_grouped": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp]),
+    "pd_cmd_fn_index": (_c_int, [ctypes.c_char_p]),
+    "pd_cmd_fn_nargs": (_c_int, [_c_int]),
+    "pd_cmd_replay": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp]),
+    "pd_memset_async": (_c_int, [_c_vp, _c_int, ctypes.c_int64, _c_vp]),
+    "pd_memcpy_d2d_async": (_c_int, [_c_vp, _c_vp, ctypes.c_int64, _c_vp]),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_abi_version": (_c_int, []),
     "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),
 }
 
 _lib = None
+_PROXY = None            # cmdbuf.Recording: while a region is being recorded load() hands out its recording proxy
 
 
 class PdHipError(RuntimeError):
@@ -165,8 +171,15 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def real():
+    """the library itself, never the recording proxy"""
+    return _lib if _lib is not None else load()
+
+
 def load():
     global _lib
+    if _PROXY is not None:
+        return _PROXY
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):

@@ -113,7 +113,8 @@ def check_capture_refuses_packet_capture():
 
 
 def _child(check, packet_capture="0"):
-    env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE=packet_capture)
+    # PD_CMDBUF=0: the whole-step graph and the command buffers are alternatives (TrainStep.capture refuses to run after a recording)
+    env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE=packet_capture, PD_CMDBUF="0")
     r = subprocess.run([sys.executable, os.path.abspath(__file__), check], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
