@@ -57,8 +57,11 @@ def usable():
 class _Arena:
     CHUNK = 64 << 20
 
-    def __init__(self, device):
+    def __init__(self, device, chunk=None):
         self.device, self.chunks, self.off = device, [], 0
+        self.used = []                                              # bytes handed out of each chunk
+        if chunk:
+            self.CHUNK = chunk
 
     def alloc(self, nbytes):
         nbytes = max(int(nbytes), 1)
@@ -69,9 +72,11 @@ class _Arena:
                 self.chunks.append(_REAL["empty"](max(self.CHUNK, al), dtype=torch.uint8, device=self.device))
             finally:
                 _Purity.paused -= 1
+            self.used.append(0)
             self.off = 0
         c, o = self.chunks[-1], self.off
         self.off += al
+        self.used[-1] = self.off
         return c, o
 
     def contains(self, ptr):
@@ -129,7 +134,7 @@ def require_stable(ptr, what):
     rec = _ACTIVE
     if rec is None or not ptr:
         return
-    ok = rec.arena.contains(ptr) or any(r.arena.contains(ptr) for r in rec._stable)
+    ok = rec._in_arena(ptr)
     if not ok:
         for i in rec._pinned:
             b, n = rec._slot_ranges[i]
@@ -212,6 +217,7 @@ class Recording:
         self._rec_slots = list(slots)                               # alive during the recording only
         dev = next((t.device for t in slots if t.is_cuda), torch.device("cuda", torch.cuda.current_device()))
         self.arena = _Arena(dev)
+        self.zero_arena = _Arena(dev, 8 << 20)                               # torch.zeros / zeros_like: cleared by ONE memset per chunk at replay start
         self._cmds, self._keep, self._host = [], [], []
         self._stream = None
         self.cmds = None
@@ -224,11 +230,19 @@ class Recording:
         self._keep.append(t)
         self._host.append((t.data_ptr(), max(t.numel() * t.element_size(), 1)))
 
-    def _alloc(self, shape, dtype, strides=None):
+    def _alloc(self, shape, dtype, strides=None, zero=False):
         dtype = dtype or torch.get_default_dtype()
         n = 1
         for s in shape:
             n *= int(s)
+        arena = self.zero_arena if zero else self.arena
+        if zero and strides is None:
+            # every zero-filled buffer of the region is a FRESH piece of the zero arena (never handed out twice), so clearing the
+            # whole arena once at the start of a replay equals clearing each buffer where the region asked for it: ~40 memset launches
+            # per step become one or two.  This first execution clears the piece right here (unrecorded).
+            c, o = arena.alloc(n * _itemsize(dtype))
+            _lib.check(_lib.real().pd_memset_async(c.data_ptr() + o, 0, max(n * _itemsize(dtype), 1), self._stream))
+            return c[o:o + n * _itemsize(dtype)].view(dtype).view(tuple(shape))
         if strides is None:
             c, o = self.arena.alloc(n * _itemsize(dtype))
             return c[o:o + n * _itemsize(dtype)].view(dtype).view(tuple(shape))
@@ -236,10 +250,14 @@ class Recording:
         c, o = self.arena.alloc(ext * _itemsize(dtype))
         return c[o:o + max(ext, 1) * _itemsize(dtype)].view(dtype).as_strided(tuple(shape), tuple(strides))
 
+    def _in_arena(self, ptr):
+        return (self.arena.contains(ptr) or self.zero_arena.contains(ptr)
+                or any(r.arena.contains(ptr) or r.zero_arena.contains(ptr) for r in self._stable))
+
     def _classify(self, ptr, last, name, i):
         if ptr == 0:
             return LITERAL, 0
-        if self.arena.contains(ptr) or any(r.arena.contains(ptr) for r in self._stable):
+        if self._in_arena(ptr):
             return LITERAL, ptr
         for s, (b, n) in enumerate(self._slot_ranges):
             if b <= ptr < b + max(n, 1):
@@ -299,9 +317,8 @@ class Recording:
         def zeros(*size, dtype=None, device=None, **kw):
             if not _is_cuda(device):
                 return _REAL["zeros"](*size, dtype=dtype, device=device, **kw)
-            t = empty(*size, dtype=dtype, device=device)
-            _lib.check(rec._proxy.pd_memset_async(t.data_ptr(), 0, t.numel() * t.element_size(), rec._stream))
-            return t
+            shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+            return rec._alloc(shape, dtype, zero=True)
 
         def empty_like(t, dtype=None, memory_format=None, **kw):
             if not t.is_cuda:
@@ -320,6 +337,8 @@ class Recording:
         def zeros_like(t, dtype=None, **kw):
             if not t.is_cuda:
                 return _REAL["zeros_like"](t, dtype=dtype, **kw)
+            if t.is_contiguous():
+                return rec._alloc(tuple(t.shape), dtype or t.dtype, zero=True)
             o = empty_like(t, dtype=dtype)
             _lib.check(rec._proxy.pd_memset_async(o.data_ptr(), 0, _extent_bytes(o), rec._stream))
             return o
@@ -347,6 +366,15 @@ class Recording:
             print(f"[cmdbuf] recorded {self.name}: {len(self._cmds)} calls, {len(self.slot_meta)} slots, arena {self.arena.nbytes() >> 20} MiB, "
                   f"error={et.__name__ if et else None}", file=sys.stderr, flush=True)
         if et is None:
+            pre = []
+            idx = int(_lib.real().pd_cmd_fn_index(b"pd_memset_async"))
+            for c, used in zip(self.zero_arena.chunks, self.zero_arena.used):   # the zero arena: cleared first thing at every replay
+                k = PdCmd()
+                k.fn, k.nargs = idx, 4
+                k.a[0], k.a[1], k.a[2], k.a[3] = c.data_ptr(), 0, used, 0
+                k.kind[0], k.kind[1], k.kind[2], k.kind[3] = LITERAL, LITERAL, LITERAL, STREAM
+                pre.append(k)
+            self._cmds = pre + self._cmds
             self.cmds = (PdCmd * len(self._cmds))(*self._cmds)
             self._bases = (ctypes.c_uint64 * max(len(self.slot_meta), 1))()
         self._cmds = None
@@ -371,7 +399,7 @@ class Recording:
                 for i, t in enumerate(slots):
                     if o is t:
                         return SlotRef(i)
-                if o.is_cuda and o.numel() and not (self.arena.contains(o.data_ptr()) or any(r.arena.contains(o.data_ptr()) for r in self._stable)):
+                if o.is_cuda and o.numel() and not self._in_arena(o.data_ptr()):
                     raise RecorderError(f"{self.name}: the region returns a tensor that is neither in the arena nor one of its slots (a view of a slot? "
                                         "return the slot itself or copy it inside the region)")
                 return o

@@ -27,8 +27,11 @@ _WS = {}
 def workspace(dev, nbytes):
     """zero-initialised scratch for the split-K tickets + slabs of one stream (the kernel leaves the tickets zero)"""
     from .. import cmdbuf
-    if cmdbuf.active() is not None:                          # recorded region: zero-filled (tickets) scratch in its arena
-        return torch.zeros(int(nbytes), dtype=torch.uint8, device=dev)
+    if cmdbuf.active() is not None:
+        # recorded region: scratch in its arena; the ticket words at its head are cleared ONCE, now (the kernel leaves them zero)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.real().pd_memset_async(ws.data_ptr(), 0, min(int(nbytes), 16384), _lib.current_stream()))
+        return ws
     key = (str(dev), _lib.current_stream())
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:

@@ -819,14 +819,15 @@ def test_full_step_bf16_autocast_vs_oracle():
         assert abs(float(losses[k]) - float(olosses[k])) <= 2e-2 * abs(float(olosses[k])) + 2e-3, (k, float(losses[k]), float(olosses[k]))
 
 
-GRAD_TOL_FP32_FULL = 2e-2       # of the tensor maximum; tightened to 3 x the measured worst case once profiles/r04_parity.json holds it
+GRAD_TOL_FP32_FULL = 4e-3       # of the tensor maximum: 3 x the measured worst case (1.1e-3, the stem filter: profiles/r04_parity.json)
 
 
 @pytest.mark.parametrize("amp", [False, True])
 def test_config2_full_size_step_vs_oracle(amp):
     """BASELINE config 2 at FULL size — R50, 1024 x 1024, Q = 100, 10 prediction heads, 12 544 points, reference init —
     one image through the HIP training step (fp32, and the benchmarked bf16 autocast) against the CPU oracle: all 30
-    weighted losses (fp32: rel 2e-3; bf16: rel 2e-2 + 2e-3 abs), the Hungarian assignments of the 10 heads
+    weighted losses (fp32: rel 3e-4 + 1e-4 abs = 3 x the measured deviation, see profiles/r04_parity.json; bf16: rel 2e-2 + 2e-3 abs,
+    BASELINE.md §4), the Hungarian assignments of the 10 heads
     (optimal under the oracle's fp32 costs to 1e-4 / 2e-2 of the optimal cost: with 100 untrained queries some optima are
     near-ties that re-association noise — let alone bf16 — can flip), and in fp32 a set of parameter gradients."""
     from partdistillation_amd.config import setup_cfg
@@ -854,7 +855,7 @@ def test_config2_full_size_step_vs_oracle(amp):
     osd = {k: v.requires_grad_(v.is_floating_point() and not amp) for k, v in sd.items()}
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     olosses, differ, gap = _oracle_with_product_matches(losses, osd, batch, 31337, 1, 10, [4], grad=not amp)
-    rel = 2e-2 if amp else 2e-3
+    rel = 2e-2 if amp else 3e-4         # fp32: 3 x the measured 9.3e-5 (profiles/r04_parity.json; BASELINE.md 4 proposes 1e-4)
     dev = {k: abs(float(losses[k]) - float(olosses[k])) / max(abs(float(olosses[k])), 1e-12) for k in olosses}
     print(f"config 2 full size, amp={amp}: max rel loss dev {max(dev.values()):.2e}; {differ} of 10 assignments differ from the "
           f"oracle's optimum, worst relative cost gap {gap:.1e}")
