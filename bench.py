@@ -176,6 +176,7 @@ _CATEGORIES = [
     ("own_msda", r"^msda_"),
     ("own_fp32_wgrad_mfma", r"^(gemm_wgrad_f32|gemm_wgrad_f16x2|wgrad_tr_reduce|wgrad_h2w_reduce)"),
     ("own_fp32x3_gemm_conv", r"^(gemm_tn_f32|gemm_tn_f16x2|row_amax_f32|gemm_wgrad_f32x3|conv3x3_)"),
+    ("own_igemm_bf16_conv_linear", r"^(igemm_bf16|filter_transpose_grouped)"),
     ("own_conv_bf16_filter_grads", r"^conv_(wgrad|igemm)"),
     ("own_attention_mfma", r"^(attn_|wattn_)"),
     ("own_skinny_bf16_gemm", r"^sgemm_"),
@@ -236,6 +237,12 @@ def category_rooflines(cats, batch, size, freeze):
         "own_fp32x3_gemm_conv": ((6 * 2 * 2.0 * M * (2 * 256 * 1024 + 2 * 256 * 256 + 288 * 256) + 2 * 2.0 * hw4 * 9 * 256 * 256), 2500.0,
                                  f"16-bit matrix 2.5 PF, {np_f:.0f} 16-bit products per fp32 product", np_f),
     }
+    # R50 bottleneck body forward + input gradient on pd_igemm_bf16 (52 convolutions per direction: 166 GFLOP per image and direction at
+    # 1024 x 1024, tools/bench_igemm.py) + the decoder's key / value input gradients over the memory tokens (9 layers x 2 x [B HW_l, 256] x [256, 256])
+    r50_dirs = 1 if "backbone" in freeze else 2
+    work["own_igemm_bf16_conv_linear"] = (166.0e9 * batch * (size / 1024.0) ** 2 * r50_dirs
+                                          + 3 * 2 * 2.0 * 256 * 256 * sum(batch * (size // st) ** 2 for st in (32, 16, 8)), 2500.0,
+                                          "bf16 matrix 2.5 PF (v_mfma_f32_32x32x16_bf16)", 1.0)
     for c in cats:
         w = work.get(c["category"])
         if w and w[0] > 0 and c["ms_per_step"] > 0:

@@ -52,7 +52,7 @@ def _lin(x, w, b):
     return torch.addmm(_bf(b), x, _bf(w).t())
 
 
-TR_WGRAD = False     # True: weight gradients through the transpose-read kernel of csrc/conv_bf16.hip (a Linear over the stage's tokens = a
+TR_WGRAD = __import__("os").environ.get("PD_SWIN_TR_WGRAD", "0") != "0"     # True: weight gradients through the transpose-read kernel of csrc/conv_bf16.hip (a Linear over the stage's tokens = a
                      # 1 x 1 convolution over pixels), queued for the step's grouped launch.  Measured on config 3 (Swin-B, 2 x 1024^2):
                      # 51.8 ms per step against 49.8 with the split-rows / library kernels below — that kernel is built for the
                      # HBM-bound filter gradients of R50 (N K / (N + K) <= 64 flop per byte); 18 of Swin-B's 24 blocks have
