@@ -76,6 +76,24 @@ typedef struct PdFilterTranspose {
 int64_t pd_filter_transpose_table_bytes(int count);
 int pd_filter_transpose_grouped(const PdFilterTranspose *descs, int count, void *table_host_pinned, void *table_device, void *stream);
 
+/* ---- weight gradient of a Linear / 1 x 1 convolution over m rows (csrc/wgrad_bf16.hip):
+ *   dw[n][k] = row_scale[n] * sum_m dy[m][n] * x[m][k]   (bf16 operands, fp32 accumulation; result bf16, or fp32 with dw_f32; row stride ldw elements)
+ *   db[n]   += sum_m dy[m][n]                            (fp32, nullable; the caller zero-fills or accumulates)
+ * What autograd's MmBackward / ConvolutionBackward(weight) computes for nn.Linear (swin.py:34-36, 127-129, 312) under bf16 autocast.
+ * n, k, ldy, ldx multiples of 8; operands 16-byte aligned.  Two launches when the rows are cut into slices (fp32 partial tiles, then their sum in
+ * slice order: deterministic).  workspace: pd_wgrad_bf16_workspace_bytes(p) bytes, no initial state; its first 16 KB are never touched, so the
+ * buffer that holds pd_igemm_bf16's tickets can be passed. */
+typedef struct PdWgrad {
+  const void *dy, *x;
+  void *dw;
+  float *db;                          /* nullable */
+  const float *row_scale;             /* nullable */
+  int32_t m, n, k, ldy, ldx, ldw;
+  int32_t dw_f32;                     /* != 0: dw points to fp32 (the gradient of an fp32 master weight: no 16-bit rounding, no cast pass) */
+} PdWgrad;
+int64_t pd_wgrad_bf16_workspace_bytes(const PdWgrad *p);
+int pd_wgrad_bf16(const PdWgrad *p, void *workspace, int64_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

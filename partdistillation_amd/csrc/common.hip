@@ -28,7 +28,7 @@ int pd_check_launch(const char *what)
 }
 
 extern "C" const char *pd_last_error(void) { return g_err; }
-extern "C" int pd_abi_version(void) { return 20; }
+extern "C" int pd_abi_version(void) { return 21; }
 
 // experiment knobs (not part of the public ABI contract; used by tools/ only)
 extern int g_pd_dbg_atomic_scope;
@@ -50,6 +50,7 @@ extern int g_pd_dbg_kmeans;
 extern int g_pd_dbg_conv_group_rows;
 extern int g_pd_dbg_sgemm_deep;
 extern int g_ig_bn, g_ig_nst, g_ig_splits;
+extern int g_wg_nst, g_wg_splits, g_wg_mode;
 extern "C" int pd_debug_set(const char *key, int value)
 {
   if (!key) return PD_ERR_INVALID_ARG;
@@ -61,6 +62,9 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!strcmp(key, "msda_bwd_threads")) { g_pd_dbg_bwd_threads = value; return PD_OK; }
   if (!strcmp(key, "wgrad_wgs")) { g_pd_dbg_wgrad_wgs = value; return PD_OK; }
   if (!strcmp(key, "kmeans_ablate")) { g_pd_dbg_kmeans = value; return PD_OK; }
+  if (!strcmp(key, "wg_nst")) { g_wg_nst = value; return PD_OK; }
+  if (!strcmp(key, "wg_splits")) { g_wg_splits = value; return PD_OK; }
+  if (!strcmp(key, "wg_mode")) { g_wg_mode = value; return PD_OK; }
   if (!strcmp(key, "ig_bn")) { g_ig_bn = value; return PD_OK; }
   if (!strcmp(key, "ig_nst")) { g_ig_nst = value; return PD_OK; }
   if (!strcmp(key, "ig_splits")) { g_ig_splits = value; return PD_OK; }

@@ -21,16 +21,26 @@ class PdFilterTranspose(ctypes.Structure):                           # include/p
                 ("ci", ctypes.c_int32)]
 
 
+class PdWgrad(ctypes.Structure):                                     # include/pd_igemm.h
+    _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("db", ctypes.c_void_p), ("row_scale", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ("m", "n", "k", "ldy", "ldx", "ldw", "dw_f32")]
+
+
 _WS = {}
 
 
 def workspace(dev, nbytes):
     """zero-initialised scratch for the split-K tickets + slabs of one stream (the kernel leaves the tickets zero)"""
     from .. import cmdbuf
-    if cmdbuf.active() is not None:
-        # recorded region: scratch in its arena; the ticket words at its head are cleared ONCE, now (the kernel leaves them zero)
-        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-        _lib.check(_lib.real().pd_memset_async(ws.data_ptr(), 0, min(int(nbytes), 16384), _lib.current_stream()))
+    rec = cmdbuf.active()
+    if rec is not None:
+        # recorded region: ONE scratch in its arena, shared by the region's launches like the per-stream buffer below (stream order keeps
+        # them apart); the ticket words at its head are cleared ONCE, now (pd_igemm_bf16 leaves them zero, pd_wgrad_bf16 never touches them)
+        ws = getattr(rec, "_ig_scratch", None)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(int(nbytes), 40 << 20), dtype=torch.uint8, device=dev)
+            _lib.check(_lib.real().pd_memset_async(ws.data_ptr(), 0, 16384, _lib.current_stream()))
+            rec._ig_scratch = ws
         return ws
     key = (str(dev), _lib.current_stream())
     ws = _WS.get(key)
@@ -166,11 +176,17 @@ class OwnLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = linear(dy2, transposed([w])[0]).view(ctx.shp)
             dx = dx if dx.dtype == ctx.xdt else dx.to(ctx.xdt)
+        want_db = ctx.has_b and ctx.needs_input_grad[2]
+        if want_db:
+            db = torch.zeros(w.shape[0], dtype=torch.float32, device=dy.device)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            conv_bf16.run_now([conv_bf16.rows_entry(dy2, x2, dw)])
-        if ctx.has_b and ctx.needs_input_grad[2]:
-            db = torch.zeros(w.shape[0], dtype=torch.float32, device=dy.device)
+            if wgrad_supported(dy2, x2):
+                wgrad(dy2, x2, dw, db)                      # the column sums of dy ride along
+                want_db = False
+            else:
+                conv_bf16.run_now([conv_bf16.rows_entry(dy2, x2, dw)])
+        if want_db:
             rw.colsum_acc(dy2, db)
         return dx, dw, db
 
@@ -178,3 +194,37 @@ class OwnLinear(torch.autograd.Function):
 def own_linear_supported(x, w):
     return (x.is_cuda and w.dtype == torch.bfloat16 and w.is_contiguous() and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
             and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
+def wgrad_supported(dy, x):
+    return (dy.is_cuda and dy.dtype == x.dtype == torch.bfloat16 and dy.dim() == x.dim() == 2 and dy.stride(1) == x.stride(1) == 1 and dy.shape[1] % 8 == 0
+            and x.shape[1] % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
+
+
+def wgrad_prefers_library(M, N, K):
+    """few rows under a large [N, K] result: hundreds of 128 x 128 tiles with a few dozen 64-row stages each — the library's GEMM measured
+    40 us against 45 (Swin-B stage 4 fc1, 2 592 x 1 024 -> 4 096) and 115 against 155 (Swin-L), tools/bench_swin_wgrad.py"""
+    return N * K >= 3_000_000 and M <= 8192
+
+
+def wgrad(dy, x, dw=None, db=None, row_scale=None, out_dtype=torch.bfloat16):
+    """dy [M, N], x [M, K] bf16 -> dw [N, K] (bf16 or fp32: dw's dtype, else out_dtype) = dy^T x (pd_wgrad_bf16); db (fp32 [N], optional) += dy.sum(0)"""
+    M, N = dy.shape
+    K = x.shape[1]
+    if dw is None:
+        dw = torch.empty((N, K), dtype=out_dtype, device=dy.device)
+    assert dw.dtype in (torch.bfloat16, torch.float32) and dw.stride(1) == 1 and (db is None or (db.dtype == torch.float32 and db.numel() == N))
+    d = PdWgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _p(db), _p(row_scale), M, N, K, dy.stride(0), x.stride(0), dw.stride(0),
+                1 if dw.dtype == torch.float32 else 0)
+    from .. import cmdbuf
+    if cmdbuf.active() is not None:
+        for t_, nm in ((dy, "dy"), (x, "x"), (dw, "dw"), (db, "db"), (row_scale, "row_scale")):
+            if t_ is not None:
+                cmdbuf.require_stable(t_.data_ptr(), "pd_wgrad_bf16 operand " + nm)
+    L = _lib.load()
+    need = int(L.pd_wgrad_bf16_workspace_bytes(ctypes.byref(d)))
+    if need < 0:
+        _lib.check(-1)
+    wsb = workspace(dy.device, need) if need else None
+    _lib.check(L.pd_wgrad_bf16(ctypes.byref(d), _p(wsb), wsb.numel() if wsb is not None else 0, _lib.current_stream()))
+    return dw

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libpd_hip.so") 
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -140,6 +140,9 @@ SIGNATURES = {
     "pd_igemm_bf16_time": (_c_int, [_c_vp, _c_vp, ctypes.c_int64, _c_int, _c_vp, _c_vp]),
     "pd_igemm_bf16_seq_workspace_bytes": (ctypes.c_int64, [_c_vp, _c_int]),
     "pd_igemm_bf16_seq": (_c_int, [_c_vp, _c_int, _c_vp, ctypes.c_int64, _c_vp]),
+    "pd_wgrad_bf16_workspace_bytes": (ctypes.c_int64, [_c_vp]),
+    "pd_wgrad_bf16": (_c_int, [_c_vp, _c_vp, ctypes.c_int64, _c_vp]),
+    "pd_wgrad_bf16_time": (_c_int, [_c_vp, _c_vp, ctypes.c_int64, _c_int, _c_vp, _c_vp]),
     "pd_filter_transpose_table_bytes": (ctypes.c_int64, [_c_int]),
     "pd_filter_transpose_grouped": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp]),
     "pd_cmd_fn_index": (_c_int, [ctypes.c_char_p]),

@@ -11,6 +11,8 @@ import torch
 import torch.nn.functional as F
 from torch.autograd import Function
 
+from ... import cmdbuf
+from ... import lib as _lib
 from ...functions import conv_bf16, igemm, smallgemm
 from ...functions import rowwise as _rw
 from ...functions import swin_rows as rows
@@ -62,7 +64,9 @@ TR_WGRAD = __import__("os").environ.get("PD_SWIN_TR_WGRAD", "0") != "0"     # Tr
 def _wgrad(dy, x, w, b, big=None):
     """weight + bias gradient of a Linear over all tokens of the stage, in the parameters' dtypes.  bf16 parameters (the training
     configuration): the weight gradient is queued in `big` for conv_bf16's grouped transpose-read launch, the bias gradient is a
-    column sum.  Otherwise: small [N, K] outputs (few tiles, every one walking 10^4..10^5 rows) go to the split-rows matrix-core
+    column sum.  Otherwise pd_wgrad_bf16 (include/pd_igemm.h) for bf16 operands — 36-46 us at the 10 368-token stage of Swin-B against
+    72-79 for the library and 85-115 for the split-rows kernel, profiles/r04_swin_wgrad_sweep.txt — except few-row / large-result
+    shapes (igemm.wgrad_prefers_library).  Without it: small [N, K] outputs (few tiles, every one walking 10^4..10^5 rows) go to the split-rows matrix-core
     kernel of include/pd_smallgemm.h — measured 2.5-3x the library at K <= 256, break-even at N*K ~ 1 M
     (tools/bench_wgrad_split.py); larger outputs have enough tiles for the library GEMM."""
     if (big is not None and w.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.is_contiguous()
@@ -72,7 +76,10 @@ def _wgrad(dy, x, w, b, big=None):
         db = torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device)
         _rw.colsum_acc(dy, db)
         return dw, db                                        # fp32: cast with the stage's other bias gradients (_cast_bias_grads)
-    if w.shape[0] * w.shape[1] <= 1_100_000:
+    if OWN_GEMM and igemm.wgrad_supported(dy, x) and (cmdbuf.active() is not None or not igemm.wgrad_prefers_library(dy.shape[0], dy.shape[1], x.shape[1])):
+        db = torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device)
+        dw = igemm.wgrad(dy, x, None, db, out_dtype=w.dtype if w.dtype == torch.float32 else torch.bfloat16)   # dW and the column sums of dY in one pass over dY
+    elif w.shape[0] * w.shape[1] <= 1_100_000:
         dw, db = smallgemm.wgrad_split(dy, x, True)
     else:
         dw = torch.mm(dy.t(), x)
@@ -105,27 +112,101 @@ def _cast_bias_grads(grads, params, slots):
             o += n
 
 
+_RECS = {}             # recorded regions (cmdbuf.Recording) per stage geometry
+
+
+def _rec_put(key, rec):
+    if len(_RECS) >= 32:
+        _RECS.pop(next(iter(_RECS)))
+    _RECS[key] = rec
+
+
+def _stage_consts(spec, device):
+    """the cached index tensors the stage's kernels read (row maps, padded rows, shift regions): built (ATen) before a recorded region,
+    declared to it as address-stable slots"""
+    out = []
+    for shift in sorted(set(spec["shifts"])):
+        ymap, zero, _, _ = window_maps(spec["H"], spec["W"], shift, device)
+        out += [ymap] + ([zero] if zero is not None else [])
+        if shift > 0:
+            out += list(wattn.shifted_window_regions(spec["H"], spec["W"], shift, device))
+    return out
+
+
 class SwinStage(Function):
     """x fp32 [B, L, C] -> fp32 [B, L, C].  spec = dict(H, W, heads, shifts [depth], scale, eps, dp = None | fp32
-    [depth, 2, B] DropPath scales (keep mask / keep_prob))."""
+    [depth, 2, B] DropPath scales (keep mask / keep_prob)).
+
+    With every Linear on pd_igemm_bf16 / pd_wgrad_bf16 the block loops are pd_* launches and allocations only, and run as RECORDED regions
+    (cmdbuf.py): 8 x depth launches forward, 21 x depth backward replayed by one C call each instead of ~30 Python calls per block —
+    the host issued a Swin-B step in 35.7 ms against 35 ms of GPU work before (tools/bench_config3.py)."""
 
     @staticmethod
     def forward(ctx, x, spec, *params):
         if not x.is_cuda:
             raise RuntimeError("the fused Swin stage runs on the GPU only (no CPU fallback in partdistillation_amd)")
+        ctx.set_materialize_grads(False)
         B, L, C = x.shape
-        H, W, heads, dp = spec["H"], spec["W"], spec["heads"], spec["dp"]
+        dp = spec["dp"]
         depth = len(params) // N_BLOCK
-        cur, r, rscale = x.contiguous().view(B * L, C), None, None
+        x2 = x.contiguous().view(B * L, C)
+        weights = [params[k * N_BLOCK + j] for k in range(depth) for j in (2, 5, 9, 11)]
+        use_rec = (cmdbuf.usable() and OWN_GEMM and x2.dtype == torch.float32 and any(ctx.needs_input_grad)
+                   and all(w.dtype == torch.bfloat16 and w.is_contiguous() and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0 for w in weights)
+                   and all(p.is_contiguous() for p in params))
+        if not use_rec:
+            ctx.rec = None
+            r, cur, saved = SwinStage._fwd_blocks(x2, spec, params, dp)
+        else:
+            consts = _stage_consts(spec, x.device)
+            head = [x2] + ([dp] if dp is not None else [])
+            slots = head + list(params) + consts
+            key = ("fwd", B, L, C, spec["H"], spec["W"], spec["heads"], tuple(spec["shifts"]), dp is not None, params[0].data_ptr(), str(x.device),
+                   _lib.current_stream())
+            rec = _RECS.get(key)
+            if rec is None or not rec.matches(slots):
+                rec = cmdbuf.Recording(slots, "swin stage forward", pinned=range(len(head), len(slots)))
+                with rec:
+                    outs = SwinStage._fwd_blocks(x2, spec, params, dp)
+                outs = rec.finish(outs)
+                _rec_put(key, rec)
+            else:
+                outs = rec.replay(slots)
+            r, cur, saved = outs
+            ctx.rec, ctx.rec_gen = rec, rec.generation
+        # ---- eager epilogue (ATen): the last block's MLP output joins the stream
+        rscale = dp[depth - 1, 1] if dp is not None else None
+        out = r.view(B, L, C).float()
+        if rscale is not None:
+            out = out * rscale.view(B, 1, 1)
+        out = out.add_(cur.view(B, L, C))
+        ctx.spec, ctx.depth, ctx.shape, ctx.saved = spec, depth, (B, L, C), saved
+        ctx.save_for_backward(*params)
+        return out
+
+    @staticmethod
+    def _fwd_blocks(x2, spec, params, dp):
+        """-> (MLP output of the last block bf16, residual stream before it fp32, saved activations); inside a recording: pd_* launches
+        and allocations only"""
+        H, W = spec["H"], spec["W"]
+        C = x2.shape[1]
+        depth = len(params) // N_BLOCK
+        B = x2.shape[0] // (H * W)
+        L = H * W
+        cur = x2
+        if cmdbuf.active() is not None:                        # saved for the backward region (block 0's stream IS the input): an arena copy
+            cur = _rw.copy_d2d(torch.empty_like(x2), x2)
+        r, rscale = None, None
         saved = []
         for k in range(depth):
             n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = params[k * N_BLOCK:(k + 1) * N_BLOCK]
             shift = spec["shifts"][k]
-            ymap, zero, S, nW = window_maps(H, W, shift, x.device)
-            regions = wattn.shifted_window_regions(H, W, shift, x.device) if shift > 0 else None
+            ymap, zero, S, nW = window_maps(H, W, shift, x2.device)
+            regions = wattn.shifted_window_regions(H, W, shift, x2.device) if shift > 0 else None
+            table = table if table.is_contiguous() else table.contiguous()
             s1, y1, st1 = rows.ln_fwd(cur, r, None, L, rscale, n1w, n1b, spec["eps"], ymap, S, zero, B, L)
             qkv = _lin(y1, qw, qb)
-            ao, lse = wattn.fwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table.contiguous(), regions, spec["scale"], nW)
+            ao, lse = wattn.fwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table, regions, spec["scale"], nW)
             po = _lin(ao.view(-1, C), pw, pb)
             sc1 = dp[k, 0] if dp is not None else None
             s2, y2, st2 = rows.ln_fwd(s1, po, ymap, S, sc1, n2w, n2b, spec["eps"], None, L, None, B, L)
@@ -137,26 +218,59 @@ class SwinStage(Function):
             f = _lin(a, f2w, f2b)
             saved += [s1, y1, st1, qkv, ao, lse, s2, y2, st2, h, a]
             cur, r, rscale = s2, f, (dp[k, 1] if dp is not None else None)
-        out = r.view(B, L, C).float()
-        if rscale is not None:
-            out = out * rscale.view(B, 1, 1)
-        out = out.add_(cur.view(B, L, C))
-        ctx.spec, ctx.depth, ctx.shape = spec, depth, (B, L, C)
-        ctx.save_for_backward(*params, *saved)
-        return out
+        return r, cur, saved
 
     @staticmethod
     def backward(ctx, dout):
         spec, depth, (B, L, C) = ctx.spec, ctx.depth, ctx.shape
-        H, W, dp = spec["H"], spec["W"], spec["dp"]
-        params, saved = ctx.saved_tensors[:depth * N_BLOCK], ctx.saved_tensors[depth * N_BLOCK:]
-        dev = dout.device
+        dp = spec["dp"]
+        params, saved = ctx.saved_tensors, ctx.saved
+        if dout is None:
+            return (None,) * (2 + len(params))
+        # ---- eager prologue (ATen): the gradient of the last block's MLP output in 16 bits
         dsup = dout.contiguous().view(B * L, C)
+        dsup = dsup if dsup.dtype == torch.float32 else dsup.float()
         last = dp[depth - 1, 1] if dp is not None else None
         df = (dsup.view(B, L, C) * last.view(B, 1, 1) if last is not None else dsup).to(torch.bfloat16).view(B * L, C)
+        rec_f = getattr(ctx, "rec", None)
+        if rec_f is None:
+            dx, grads = SwinStage._bwd_blocks(spec, params, saved, dsup, df, dp, (B, L, C))
+        else:
+            if rec_f.generation != ctx.rec_gen:
+                raise RuntimeError("the fused Swin stage ran another forward before this backward: the recorded region's activation arena was "
+                                   "overwritten (set PD_CMDBUF=0 for graphs that keep several forward passes of one stage alive)")
+            consts = _stage_consts(spec, dout.device)
+            head = [dsup, df] + ([dp] if dp is not None else [])
+            slots = head + list(params) + consts
+            key = ("bwd", id(rec_f))
+            rec = _RECS.get(key)
+            if rec is None or not rec.matches(slots):
+                rec = cmdbuf.Recording(slots, "swin stage backward", stable=[rec_f], pinned=range(len(head), len(slots)))
+                with rec:
+                    dx, grads = SwinStage._bwd_blocks(spec, params, saved, dsup, df, dp, (B, L, C))
+                    outs = (dx, cmdbuf.Fresh(grads))
+                outs = rec.finish(outs)
+                _rec_put(key, rec)
+            else:
+                outs = rec.replay(slots)
+            dx, grads = outs
+        grads = list(grads)
+        _cast_bias_grads(grads, params, [k * N_BLOCK + j for k in range(depth) for j in (3, 6, 10, 12)])
+        return (dx.view(B, L, C), None, *grads)
+
+    @staticmethod
+    def _bwd_blocks(spec, params, saved, dsup, df, dp, shape):
+        """-> (gradient of the stage input fp32 [B * L, C], the 13 x depth parameter gradients); inside a recording: pd_* launches and
+        allocations only"""
+        B, L, C = shape
+        H, W = spec["H"], spec["W"]
+        depth = len(params) // N_BLOCK
+        dev = dsup.device
+        if cmdbuf.active() is not None:                        # df goes into problem structs (host memory the replay re-reads): an arena copy
+            df = _rw.copy_d2d(torch.empty_like(df), df)
         norm_g = torch.zeros((depth, 4, C), dtype=torch.float32, device=dev)       # dgamma1, dbeta1, dgamma2, dbeta2
         grads = [None] * (depth * N_BLOCK)
-        big = [] if TR_WGRAD else None
+        big = [] if TR_WGRAD and cmdbuf.active() is None else None
         tab0 = params[4]
         tables_g = torch.zeros((depth,) + tuple(tab0.shape), dtype=tab0.dtype, device=dev) \
             if all(params[k * N_BLOCK + 4].shape == tab0.shape and params[k * N_BLOCK + 4].dtype == tab0.dtype for k in range(depth)) else None
@@ -173,6 +287,7 @@ class SwinStage(Function):
             ymap, zero, S, nW = window_maps(H, W, shift, dev)
             regions = wattn.shifted_window_regions(H, W, shift, dev) if shift > 0 else None
             g = grads[k * N_BLOCK:(k + 1) * N_BLOCK]
+            table = table if table.is_contiguous() else table.contiguous()
             # MLP
             g[11], g[12] = _wgrad(df, a, f2w, f2b, big)
             if own:
@@ -188,12 +303,12 @@ class SwinStage(Function):
             ds2, dpo = rows.ln_bwd(dy2, None, L, dsup, s2, st2, n2w, True, ymap, S, sc1, zero, norm_g[k, 2], norm_g[k, 3], B, L)
             dao = igemm.linear(dpo, pw_t) if own else torch.mm(dpo, _bf(pw))
             g[5], g[6] = _wgrad(dpo, ao.view(-1, C), pw, pb, big)
-            dqkv, dtable = wattn.bwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table.contiguous(), regions, ao,
+            dqkv, dtable = wattn.bwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table, regions, ao,
                                          dao.view(B * nW, wattn.TOKENS, C), lse, spec["scale"], nW,
                                          dtable=tables_g[k] if tables_g is not None else None)
             g[4] = dtable
             dqkv = dqkv.view(-1, 3 * C)
-            dy1 = igemm.linear(dqkv.contiguous(), qw_t) if own else torch.mm(dqkv, _bf(qw))
+            dy1 = igemm.linear(dqkv, qw_t) if own else torch.mm(dqkv, _bf(qw))
             g[2], g[3] = _wgrad(dqkv, y1, qw, qb, big)
             # LayerNorm 1; for k > 0 its input was (block k-1 stream + DropPath * MLP output): `dr` = that MLP's output gradient
             prev = (dp[k - 1, 1] if dp is not None else None) if k > 0 else None
@@ -203,8 +318,7 @@ class SwinStage(Function):
             grads[k * N_BLOCK:(k + 1) * N_BLOCK] = g
         if big:
             conv_bf16.submit(big)                                # joins the step's deferred group when engine/trainer.py opened one
-        _cast_bias_grads(grads, params, [k * N_BLOCK + j for k in range(depth) for j in (3, 6, 10, 12)])
-        return (dsup.view(B, L, C), None, *grads)
+        return dsup, grads
 
 
 def block_params(blk):

@@ -144,6 +144,48 @@ def test_every_tile_and_pipeline_variant_gives_the_same_result(knobs):
     _close(yc, F.conv2d(xc.float().permute(0, 3, 1, 2), wc.float().permute(0, 3, 1, 2), None, 2, 1).permute(0, 2, 3, 1))
 
 
+@pytest.mark.parametrize("M,K,N,knobs", [(4000, 128, 384, {}), (10368, 512, 2048, {}), (1000 + 13, 192, 576, {}), (139392, 128, 128, {}), (2592, 1024, 3072, {}),
+                                         (777, 64, 8, {}), (5000, 256, 256, dict(wg_nst=1, wg_splits=1)), (5000, 256, 256, dict(wg_nst=2, wg_splits=7)),
+                                         (300, 1536, 384, dict(wg_nst=1, wg_splits=1))])
+def test_linear_weight_gradient_vs_torch(M, K, N, knobs):
+    """pd_wgrad_bf16: dW = dY^T X (+ bias gradient, + row scale) on strided row views, every schedule; deterministic from run to run"""
+    ig = _ig()
+    from partdistillation_amd import lib
+    L = lib.load()
+    dyf, xf = _rand((M, N + 8), 31), _rand((M, K + 16), 32)
+    dy, x = dyf[:, :N], xf[:, 8:8 + K]                                            # row strides larger than the widths, 16-byte aligned bases
+    rs = torch.rand(N, device=DEV) + 0.5
+    db = torch.full((N,), 3.0, device=DEV)
+    try:
+        for k_, v in knobs.items():
+            lib.check(L.pd_debug_set(k_.encode(), v))
+        dw = ig.wgrad(dy, x, db=db, row_scale=rs)
+        dw2 = ig.wgrad(dy, x)
+        dw3 = ig.wgrad(dy, x)
+        dw32 = ig.wgrad(dy, x, out_dtype=torch.float32)
+    finally:
+        for k_ in knobs:
+            L.pd_debug_set(k_.encode(), 0)
+    ref = dy.float().t() @ x.float()
+    _close(dw2, ref, 5e-3)
+    _close(dw, ref * rs[:, None], 5e-3)
+    assert torch.equal(dw2, dw3)
+    assert dw32.dtype == torch.float32 and torch.equal(dw32.to(torch.bfloat16), dw2)           # the same sums, before the rounding
+    _close(dw32, ref, 2e-3)
+    torch.testing.assert_close(db, 3.0 + dy.float().sum(0), rtol=2e-3, atol=2e-3 * float(dy.float().abs().sum(0).max()))
+
+
+def test_weight_gradient_leaves_the_shared_workspace_tickets_alone():
+    """pd_wgrad_bf16 and the split-K schedule of pd_igemm_bf16 share one workspace: the tickets at its start must still read zero"""
+    ig = _ig()
+    x, w = _rand((256, 4096), 5), _rand((128, 4096), 6)
+    y0 = ig.linear(x, w)                                                         # 2 tiles, 64 K-steps: split-K (tickets in use)
+    ig.wgrad(_rand((40000, 256), 7), _rand((40000, 128), 8))                     # slabs written into the same buffer
+    y1 = ig.linear(x, w)
+    assert torch.equal(y0, y1)
+    _close(y1, x.float() @ w.float().t())
+
+
 def test_unsupported_geometry_raises():
     ig = _ig()
     from partdistillation_amd.lib import PdHipError

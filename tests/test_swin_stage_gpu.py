@@ -153,3 +153,49 @@ def test_fused_stage_in_eval_mode_and_without_grad():
             swin.FUSED_STAGE = True
     _close(out[True], out[False], 3e-2, "eval output (bf16 residual stream in the module path)")
 
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.3])
+def test_recorded_stage_replays_equal_the_eager_launches(drop):
+    """bf16 Linear weights (the training configuration: engine/flat_params.py shadows) put every Linear of the stage on pd_igemm_bf16 /
+    pd_wgrad_bf16, and the block loops then run as recorded regions (cmdbuf.py): the first step records, the next ones replay with new
+    inputs, new DropPath masks — and must give what the same launches issued one by one give"""
+    from partdistillation_amd import cmdbuf
+    from partdistillation_amd.modeling.backbone import swin, swin_core
+    torch.manual_seed(7)
+    H, W, dim, depth = 30, 26, 128, 2
+    layer = swin.BasicLayer(dim=dim, depth=depth, num_heads=4, window_size=12, drop_path=[0.0, drop]).cuda().train()
+    for blk in layer.blocks:
+        torch.nn.init.normal_(blk.attn.relative_position_bias_table, std=0.5)
+        for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
+            lin.weight.data = lin.weight.data.to(torch.bfloat16)
+    xs = [torch.randn(2, H * W, dim, device="cuda") for _ in range(3)]
+    gos = [torch.randn(2, H * W, dim, device="cuda") for _ in range(3)]
+
+    def run(enabled):
+        out = []
+        was = cmdbuf.ENABLED
+        cmdbuf.ENABLED = enabled
+        try:
+            for i in range(3):
+                torch.manual_seed(100 + i)                                         # the same DropPath draws in both modes
+                layer.zero_grad(set_to_none=True)
+                x = xs[i].clone().requires_grad_()
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = layer(x, H, W)[0]
+                y.backward(gos[i])
+                out.append((y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()}))
+        finally:
+            cmdbuf.ENABLED = was
+        return out
+
+    n0 = len(swin_core._RECS)
+    rec = run(True)
+    assert len(swin_core._RECS) == n0 + 2, "the stage did not run as recorded regions"
+    eager = run(False)
+    for i in range(3):
+        assert torch.equal(rec[i][0], eager[i][0]), f"step {i}: output"
+        assert torch.equal(rec[i][1], eager[i][1]), f"step {i}: input gradient"
+        for k, g in eager[i][2].items():
+            _close(rec[i][2][k].float(), g.float(), 1e-5, f"step {i}: grad {k}")   # LayerNorm / table gradients: atomics
+    assert not torch.equal(rec[1][0], rec[2][0])
