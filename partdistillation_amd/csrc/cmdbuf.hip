@@ -30,6 +30,7 @@
 #include "pd_input.h"
 #include "pd_kmeans.h"
 #include "pd_msda.h"
+#include "pd_mx8.h"
 #include "pd_optim.h"
 #include "pd_rowwise.h"
 #include "pd_smallgemm.h"
@@ -127,6 +128,9 @@ const Entry kTable[] = {
   PD_E(pd_msda_prep_bwd_amax),
   PD_E(pd_msda_prep_fwd),
   PD_E(pd_multi_gather_sumsq),
+  PD_E(pd_mx8_gemm),
+  PD_E(pd_mx8_quantize_bf16),
+  PD_E(pd_mx8_quantize_grouped),
   PD_E(pd_nc_affine2_amax_f32),
   PD_E(pd_nc_affine2_f32),
   PD_E(pd_nc_affine_amax_f32),
