@@ -22,7 +22,6 @@
 #include "pd_attention.h"
 #include "pd_conv.h"
 #include "pd_criterion.h"
-#include "pd_fp8.h"
 #include "pd_fused.h"
 #include "pd_gemm.h"
 #include "pd_grouping.h"
@@ -88,8 +87,6 @@ const Entry kTable[] = {
   PD_E(pd_conv_bf16_wgrad_grouped),
   PD_E(pd_decoder_head_bf16),
   PD_E(pd_filter_transpose_grouped),
-  PD_E(pd_fp8_amax),
-  PD_E(pd_fp8_quantize),
   PD_E(pd_gemm_tn_f16x2),
   PD_E(pd_gemm_tn_f32),
   PD_E(pd_gemm_tn_f32x3),

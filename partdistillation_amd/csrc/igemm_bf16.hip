@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gelu.h"
 #include "mfma_bf16.h"
 #include "pd_common.h"
 #include "pd_igemm.h"
@@ -63,11 +64,8 @@ struct IgArgs {
 };
 
 __device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad_f(float x)
-{
-  return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
-}
+__device__ __forceinline__ float gelu_f(float x) { return pdgelu::gelu(x); }
+__device__ __forceinline__ float gelu_grad_f(float x) { return pdgelu::gelu_grad(x); }
 
 // lanes l < 32 and l + 32 hold the channel quads [8q .. 8q+3] and [8q+4 .. 8q+7] of pixel l for q = 0..3.  After swapping the upper
 // half of quad 2p with the lower half of quad 2p + 1, lane l < 32 holds channels 16p .. 16p+7 and lane l + 32 channels 16p+8 .. 16p+15.

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gelu.h"
 #include "mfma_bf16.h"
 #include "pd_common.h"
 #include "pd_igemm.h"
@@ -146,11 +147,8 @@ struct MxArgs {
 };
 
 __device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad_f(float x)
-{
-  return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
-}
+__device__ __forceinline__ float gelu_f(float x) { return pdgelu::gelu(x); }
+__device__ __forceinline__ float gelu_grad_f(float x) { return pdgelu::gelu_grad(x); }
 __device__ __forceinline__ void swap_halves(float &a, float &b)
 {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);

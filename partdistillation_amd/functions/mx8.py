@@ -10,6 +10,8 @@ from .igemm import ACT_GELU, ACT_NONE, GATE_GELU, GATE_NONE   # noqa: F401  (sam
 
 E4M3, E5M2 = 0, 1
 BLOCK = 32
+GRAD_FORMAT = int(__import__("os").environ.get("PD_MX8_GRAD_FORMAT", E5M2))   # element format of the gradients entering the input-gradient GEMMs
+                                                     # (activations and weights: e4m3)
 
 
 class PdMx8Gemm(ctypes.Structure):                                   # include/pd_mx8.h

@@ -121,8 +121,6 @@ SIGNATURES = {
     "pd_mask_assign": (_c_int, [_c_vp] * 6 + [_c_int] * 7 + [_c_vp]),
     "pd_window_attn_fwd_w12": (_c_int, [_c_vp] * 6 + [_c_int] * 3 + [ctypes.c_float, _c_vp]),
     "pd_window_attn_bwd_w12": (_c_int, [_c_vp] * 9 + [_c_int] * 3 + [ctypes.c_float, _c_vp]),
-    "pd_fp8_amax": (_c_int, [_c_vp, ctypes.c_int64, _c_int, _c_vp, _c_vp]),
-    "pd_fp8_quantize": (_c_int, [_c_vp, ctypes.c_int64, _c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_vp]),
     "pd_swin_ln_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_int, _c_vp,
                                 _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
     "pd_swin_ln_bwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp,

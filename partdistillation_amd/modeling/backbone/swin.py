@@ -20,8 +20,9 @@ from ...functions.rowwise import add_layer_norm, supports_width
 from ...compat import BACKBONE_REGISTRY, ShapeSpec
 
 
-# BASELINE config 5 ("fp8 MFMA GEMMs"): D2SwinTransformer sets these from MODEL.SWIN.FP8_GEMM / FP8_MIN_K; the qkv / proj /
-# MLP Linears with in_features >= FP8_MIN_K then run as fp8 GEMMs (functions/fp8.py) while autocast is on
+# BASELINE config 5 ("fp8 MFMA GEMMs"): D2SwinTransformer sets these from MODEL.SWIN.FP8_GEMM / FP8_MIN_K; the qkv / proj / MLP Linears
+# of the stages with C >= FP8_MIN_K then run as MX-fp8 GEMMs on own kernels (include/pd_mx8.h) while autocast is on: inside the fused
+# stage (swin_core.py), or one by one through functions/fp8.py on the module-by-module path
 FP8 = {"enabled": False, "min_k": 384}
 FUSED_STAGE = True          # modeling/backbone/swin_core.py where it applies (tests switch it off to compare the two paths)
 
@@ -294,7 +295,10 @@ class BasicLayer(nn.Module):
 
     def forward(self, x, H, W):
         from . import swin_core
-        if FUSED_STAGE and not FP8["enabled"] and swin_core.supported(self, x):
+        fused = FUSED_STAGE and swin_core.supported(self, x)
+        if fused and FP8["enabled"] and swin_core.wants_mx8(x.shape[-1]) and not swin_core.mx8_ready(self):
+            fused = False                                                 # fp8 asked for, fp32 module weights: the Linears go one by one (functions/fp8.py)
+        if fused:
             x = swin_core.run_stage(self, x, H, W)                        # the whole stage as one autograd node
         else:
             attn_mask = shifted_window_mask(H, W, self.window_size, self.shift_size, x.device)

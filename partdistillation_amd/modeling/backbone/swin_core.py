@@ -4,8 +4,9 @@ autograd node with a hand-written backward, in the style of functions/decoder_co
 Per block the forward is 8 launches and the backward 17: the glue between the GEMMs — residual adds, DropPath scales,
 both LayerNorms, F.pad + torch.roll + window_partition and their inverses, the bf16 casts — is the row kernel of
 include/pd_swin.h (once before each attention, once before each MLP), the attention is include/pd_window_attention.h,
-the Linears are library bf16 GEMMs.  The MLP output of block k is never added on its own: it rides into block k+1's
-first row kernel as the pending residual.  Same arithmetic as the module-by-module path under bf16 autocast (fp32
+the Linears are pd_igemm_bf16 (include/pd_igemm.h) — or, with MODEL.SWIN.FP8_GEMM on a stage whose width allows it, pd_mx8_gemm
+(include/pd_mx8.h: MX-fp8 operands, BASELINE config 5).  The MLP output of block k is never added on its own: it rides into block
+k+1's first row kernel as the pending residual.  Same arithmetic as the module-by-module path under bf16 autocast (fp32
 residual stream, fp32 LayerNorm statistics, bf16 GEMM operands, exact-erf GELU)."""
 import torch
 import torch.nn.functional as F
@@ -13,7 +14,7 @@ from torch.autograd import Function
 
 from ... import cmdbuf
 from ... import lib as _lib
-from ...functions import conv_bf16, igemm, smallgemm
+from ...functions import conv_bf16, igemm, mx8, smallgemm
 from ...functions import rowwise as _rw
 from ...functions import swin_rows as rows
 from ...functions import window_attention as wattn
@@ -45,6 +46,10 @@ OWN_GEMM = __import__("os").environ.get("PD_SWIN_OWN_GEMM", "1") != "0"   # qkv 
 def _own(x, *ws):
     return (OWN_GEMM and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous()
             and all(w.dtype == torch.bfloat16 and w.is_contiguous() and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0 for w in ws))
+
+
+def _own_w(*ws):
+    return OWN_GEMM and all(w.is_cuda and w.dtype == torch.bfloat16 and w.is_contiguous() and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0 for w in ws)
 
 
 def _lin(x, w, b):
@@ -162,7 +167,7 @@ class SwinStage(Function):
             head = [x2] + ([dp] if dp is not None else [])
             slots = head + list(params) + consts
             key = ("fwd", B, L, C, spec["H"], spec["W"], spec["heads"], tuple(spec["shifts"]), dp is not None, params[0].data_ptr(), str(x.device),
-                   _lib.current_stream())
+                   _lib.current_stream(), bool(spec.get("mx8")))
             rec = _RECS.get(key)
             if rec is None or not rec.matches(slots):
                 rec = cmdbuf.Recording(slots, "swin stage forward", pinned=range(len(head), len(slots)))
@@ -198,6 +203,9 @@ class SwinStage(Function):
             cur = _rw.copy_d2d(torch.empty_like(x2), x2)
         r, rscale = None, None
         saved = []
+        mx = bool(spec.get("mx8")) and _own_w(*[params[k * N_BLOCK + j] for k in range(depth) for j in (2, 5, 9, 11)])
+        if mx:                                                  # the stage's 4 x depth weights as MX e4m3 along their input axis: one launch
+            wq = mx8.quantize_grouped([params[k * N_BLOCK + j] for k in range(depth) for j in (2, 5, 9, 11)], mx8.E4M3)
         for k in range(depth):
             n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = params[k * N_BLOCK:(k + 1) * N_BLOCK]
             shift = spec["shifts"][k]
@@ -205,17 +213,21 @@ class SwinStage(Function):
             regions = wattn.shifted_window_regions(H, W, shift, x2.device) if shift > 0 else None
             table = table if table.is_contiguous() else table.contiguous()
             s1, y1, st1 = rows.ln_fwd(cur, r, None, L, rscale, n1w, n1b, spec["eps"], ymap, S, zero, B, L)
-            qkv = _lin(y1, qw, qb)
+            qkv = mx8.linear(mx8.quantize(y1), wq[4 * k], qb) if mx else _lin(y1, qw, qb)
             ao, lse = wattn.fwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table, regions, spec["scale"], nW)
-            po = _lin(ao.view(-1, C), pw, pb)
+            po = mx8.linear(mx8.quantize(ao.view(-1, C)), wq[4 * k + 1], pb) if mx else _lin(ao.view(-1, C), pw, pb)
             sc1 = dp[k, 0] if dp is not None else None
             s2, y2, st2 = rows.ln_fwd(s1, po, ymap, S, sc1, n2w, n2b, spec["eps"], None, L, None, B, L)
-            if _own(y2, f1w):
+            if mx:                                              # fc1's epilogue hands fc2 its operand: GELU(h) again as MX e4m3 along the 4 C axis
+                a, h, aq = mx8.linear(mx8.quantize(y2), wq[4 * k + 2], f1b, act=mx8.ACT_GELU, want_pre=True, out_mx=mx8.E4M3)
+                f = mx8.linear(aq, wq[4 * k + 3], f2b)
+            elif _own(y2, f1w):
                 a, h = igemm.linear(y2, f1w, f1b, act=igemm.ACT_GELU, want_pre=True)     # bias + exact-erf GELU in the GEMM epilogue; h kept for GELU'
             else:
                 h = torch.addmm(_bf(f1b), y2, _bf(f1w).t())
                 a = F.gelu(h)
-            f = _lin(a, f2w, f2b)
+            if not mx:
+                f = _lin(a, f2w, f2b)
             saved += [s1, y1, st1, qkv, ao, lse, s2, y2, st2, h, a]
             cur, r, rscale = s2, f, (dp[k, 1] if dp is not None else None)
         return r, cur, saved
@@ -278,6 +290,10 @@ class SwinStage(Function):
         own = _own(df, *[params[k * N_BLOCK + j] for k in range(depth) for j in (2, 5, 9, 11)])
         if own:                                                  # W^T of the stage's 4 x depth Linears: one grouped launch
             wts = igemm.transposed([params[k * N_BLOCK + j] for k in range(depth) for j in (2, 5, 9, 11)])
+        mx = bool(spec.get("mx8")) and own
+        if mx:                                                   # ... and those again as MX e4m3 along THEIR contraction axis (the output features)
+            wtq = mx8.quantize_grouped(wts, mx8.E4M3)
+            gf = mx8.GRAD_FORMAT
         for k in reversed(range(depth)):
             n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = params[k * N_BLOCK:(k + 1) * N_BLOCK]
             s1, y1, st1, qkv, ao, lse, s2, y2, st2, h, a = saved[k * 11:(k + 1) * 11]
@@ -290,7 +306,10 @@ class SwinStage(Function):
             table = table if table.is_contiguous() else table.contiguous()
             # MLP
             g[11], g[12] = _wgrad(df, a, f2w, f2b, big)
-            if own:
+            if mx:                                               # gradients travel as MX e5m2; the weight gradients keep reading the bf16 copies
+                dh, dhq = mx8.linear(mx8.quantize(df, gf), wtq[4 * k + 3], gate=h, gate_mode=mx8.GATE_GELU, a_fmt=gf, out_mx=gf)
+                dy2 = mx8.linear(dhq, wtq[4 * k + 2], a_fmt=gf)
+            elif own:
                 dh = igemm.linear(df, f2w_t, gate=h, gate_mode=igemm.GATE_GELU)        # (df W2) * GELU'(h) in the epilogue
                 dy2 = igemm.linear(dh, f1w_t)
             else:
@@ -301,14 +320,14 @@ class SwinStage(Function):
             # LayerNorm 2 + the residual it sits on; gradient of the (window-major) proj output rides out as `dr`
             sc1 = dp[k, 0] if dp is not None else None
             ds2, dpo = rows.ln_bwd(dy2, None, L, dsup, s2, st2, n2w, True, ymap, S, sc1, zero, norm_g[k, 2], norm_g[k, 3], B, L)
-            dao = igemm.linear(dpo, pw_t) if own else torch.mm(dpo, _bf(pw))
+            dao = mx8.linear(mx8.quantize(dpo, gf), wtq[4 * k + 1], a_fmt=gf) if mx else igemm.linear(dpo, pw_t) if own else torch.mm(dpo, _bf(pw))
             g[5], g[6] = _wgrad(dpo, ao.view(-1, C), pw, pb, big)
             dqkv, dtable = wattn.bwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table, regions, ao,
                                          dao.view(B * nW, wattn.TOKENS, C), lse, spec["scale"], nW,
                                          dtable=tables_g[k] if tables_g is not None else None)
             g[4] = dtable
             dqkv = dqkv.view(-1, 3 * C)
-            dy1 = igemm.linear(dqkv, qw_t) if own else torch.mm(dqkv, _bf(qw))
+            dy1 = mx8.linear(mx8.quantize(dqkv, gf), wtq[4 * k], a_fmt=gf) if mx else igemm.linear(dqkv, qw_t) if own else torch.mm(dqkv, _bf(qw))
             g[2], g[3] = _wgrad(dqkv, y1, qw, qb, big)
             # LayerNorm 1; for k > 0 its input was (block k-1 stream + DropPath * MLP output): `dr` = that MLP's output gradient
             prev = (dp[k - 1, 1] if dp is not None else None) if k > 0 else None
@@ -343,6 +362,18 @@ def supported(layer, x):
     return ok
 
 
+def wants_mx8(C):
+    """MODEL.SWIN.FP8_GEMM (BASELINE config 5): a stage runs its Linears on pd_mx8_gemm when its width reaches FP8_MIN_K and every
+    contraction of the block (C, 3 C, 4 C: forward and input gradient) is whole 128-byte K-steps"""
+    from .swin import FP8
+    return bool(FP8["enabled"] and C >= FP8["min_k"] and C % 128 == 0)
+
+
+def mx8_ready(layer):
+    """the stage's weights are what the MX path of the fused stage takes (bf16 copies of the master weights, as engine/flat_params.py keeps them)"""
+    return _own_w(*[w for blk in layer.blocks for w in (blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight)])
+
+
 def run_stage(layer, x, H, W):
     B = x.shape[0]
     depth = len(layer.blocks)
@@ -355,7 +386,7 @@ def run_stage(layer, x, H, W):
             layer._keep_key = key
         dp = (torch.rand((depth, 2, B), device=x.device) + layer._keep).floor_().div_(layer._keep)   # DropPath (:35-51)
     spec = dict(H=H, W=W, heads=layer.blocks[0].num_heads, shifts=[blk.shift_size for blk in layer.blocks],
-                scale=layer.blocks[0].attn.scale, eps=layer.blocks[0].norm1.eps, dp=dp)
+                scale=layer.blocks[0].attn.scale, eps=layer.blocks[0].norm1.eps, dp=dp, mx8=wants_mx8(x.shape[-1]) and mx8_ready(layer))
     params = [p for blk in layer.blocks for p in block_params(blk)]
     # stages 2-4 receive the bf16 output of PatchMerging's Linear; the module-by-module path (like the reference under AMP)
     # then keeps a 16-bit residual stream, this one keeps it in fp32 throughout

@@ -955,7 +955,8 @@ def test_config5_full_size_swinl_part_distillation_step_vs_oracle(fp8, monkeypat
     """BASELINE config 5 at FULL size — Swin-L (embed 192, heads 6/12/24/48, window 12), 1280 x 1280, PartDistillationModel with the
     fp64 class head over 1000 object classes x 8 parts, Q = 100, 10 heads — loaded from the SHIPPED yaml files
     (configs/part_distillation/swinl_mask2former.yaml and ..._fp8.yaml: `MODEL.SWIN.FP8_GEMM True`, every qkv / proj / MLP Linear with
-    K >= 384 as an e4m3 x e4m3 forward / e5m2 x e4m3 input-gradient GEMM, per-tensor current scaling, fp32 accumulation), one image
+    of a stage with C >= 384 as an MX-fp8 GEMM on own kernels (include/pd_mx8.h: e4m3 x e4m3 forward, e5m2 x e4m3 input gradient, 32-element
+    blocks with E8M0 exponents, fp32 accumulation), one image
     through the HIP training step under bf16 autocast against the fp32 CPU oracle (oracle/swin_ref.py + oracle/step_ref.py, pinned to
     the real reference modules): the 30 weighted losses, Hungarian assignments judged by their cost gap under the oracle's fp32
     costs.  Stated tolerances: bf16 rel 2e-2 + 2e-3 abs (as configs 2 / 3; measured 9.5e-4); fp8 rel 3e-2 + 3e-3 abs
@@ -965,7 +966,7 @@ def test_config5_full_size_swinl_part_distillation_step_vs_oracle(fp8, monkeypat
     from partdistillation_amd.config import setup_cfg
     from partdistillation_amd.engine.synthetic import make_batch
     from partdistillation_amd.engine.trainer import TrainStep
-    from partdistillation_amd.functions import fp8 as fp8_mod
+    from partdistillation_amd.functions import mx8 as fp8_mod
     from partdistillation_amd.modeling.backbone import swin as swin_mod
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     monkeypatch.setitem(swin_mod.FP8, "enabled", False)                  # restored after the test (D2SwinTransformer sets the module switch)
@@ -986,12 +987,12 @@ def test_config5_full_size_swinl_part_distillation_step_vs_oracle(fp8, monkeypat
     batch = make_batch(1, 1280, seed=5321, device=DEV, part_distillation=True)
     step.model.criterion.rand = C.ReplayRand(555)
     opt_step, step.optimizer.step = step.optimizer.step, (lambda: None)
-    n0 = calls["n"]
     losses = step(batch)
     step.optimizer.step = opt_step
     assert len(losses) == 30 and step.model.sem_seg_head.predictor.class_embed.weight.dtype == torch.float64
-    # fp8: stages 2-4 (K = 384 / 768 / 1536; 22 of the 24 blocks) run qkv, proj, fc1, fc2 through functions/fp8.linear
-    assert (calls["n"] - n0 >= 4 * 22) if fp8 else (calls["n"] == 0), calls
+    # fp8: stages 2-4 (C = 384 / 768 / 1536; 22 of the 24 blocks) run qkv, proj, fc1, fc2 forward and input gradient through pd_mx8_gemm
+    # (counted over the run: the steps after the first replay the stage's recorded command buffer from C++)
+    assert (calls["n"] >= 8 * 22) if fp8 else (calls["n"] == 0), calls
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     sw = cfg.MODEL.SWIN
     bb = lambda s_, p_, x: swin_ref.swin_forward(s_, p_, x, depths=list(sw.DEPTHS), num_heads=list(sw.NUM_HEADS), window_size=sw.WINDOW_SIZE,
@@ -1015,10 +1016,11 @@ def test_config5_full_size_swinl_part_distillation_step_vs_oracle(fp8, monkeypat
 
 def test_swin_w12_fp8_gemms_vs_reference_golden(golden, monkeypatch):
     """BASELINE config 5's numerics ("fp8 MFMA GEMMs"): the window-12 Swin with every qkv / proj / MLP Linear as an fp8 GEMM
-    (e4m3 operands forward, e5m2 gradients, per-tensor current scaling, fp32 accumulation; functions/fp8.py) against the REAL
+    (MX e4m3 operands forward, MX e5m2 gradients, fp32 accumulation; functions/fp8.py on include/pd_mx8.h) against the REAL
     reference SwinTransformer's fp32 outputs and gradients — not against our own bf16 run.  Stated tolerance: e4m3 keeps 3
-    mantissa bits (2^-4 per element); through 8 blocks the maps stay within 6e-2 of their maximum and the gradients within
-    1.5e-1 of theirs."""
+    mantissa bits (2^-4 per element), e5m2 two; through the 6 blocks x 4 Linears of stages 2-4 (stage 1, C = 64, has no whole 128-byte
+    K-step and stays bf16) the maps stay within 1.2e-1 of their maximum (measured 8.6e-2 at res5, 5e-3 at res2) and the gradients
+    within 2e-1 of theirs (measured 1.3e-1; 1.25e-1 with e4m3 gradients, PD_MX8_GRAD_FORMAT=0)."""
     from partdistillation_amd.functions import fp8
     from partdistillation_amd.modeling.backbone import swin as swin_mod
     g = golden("swin_w12")
@@ -1032,11 +1034,11 @@ def test_swin_w12_fp8_gemms_vs_reference_golden(golden, monkeypatch):
         outs = net(x)
     loss = sum((v.float() * C.seeded(v.shape, 910 + i).to(DEV)).sum() for i, (k, v) in enumerate(sorted(outs.items())))
     loss.backward()
-    # qkv / proj of every block (window-major rows are a multiple of 16) + the MLPs of the stages whose token count is
-    assert calls["n"] >= 2 * sum(C.SWIN_W12["depths"]), calls
+    # stages 2-4 (C = 128 / 256 / 512: whole 128-byte K-steps in every contraction) run qkv, proj, fc1, fc2 through functions/fp8.linear
+    assert calls["n"] >= 4 * sum(C.SWIN_W12["depths"][1:]), calls
     worst = {k: _scaled_err(outs[k].float(), d) for k, d in g["outs"].items()}
     named = dict(net.named_parameters())
     for k, d in list(g["grads"].items()) + [("x", g["grad_x"])]:
         worst["grad " + k] = _scaled_err((x.grad if k == "x" else named[k].grad).float(), d)
     print("swin_w12 fp8", {k: f"{v:.2e}" for k, v in worst.items()})
-    assert all(v < (1.5e-1 if k.startswith("grad") else 6e-2) for k, v in worst.items()), worst
+    assert all(v < (2e-1 if k.startswith("grad") else 1.2e-1) for k, v in worst.items()), worst
