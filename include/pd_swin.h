@@ -17,7 +17,7 @@
  * of a tensor with `rows_per_image` rows per image: yrow(i) = img * y_rows + ymap[t]; NULL = identity (then *_rows = L).
  * LN1 of a block: y window-major (ymap = token -> window slot, zero rows = the padded slots), r = the previous block's
  * MLP output (identity map).  LN2: r = the proj output, window-major (rmap = token -> slot), y token-major.
- * x, s, dsup, ds: fp32 [R, C];  r, y, dy, dr: bf16;  C % 64 == 0, C <= 1536 (every Swin-T/S/B/L stage width);
+ * x, s, dsup, ds: fp32 [R, C] (16-byte aligned);  r, y, dy, dr: bf16 (8-byte aligned);  C % 64 == 0, C <= 1536 (every Swin-T/S/B/L stage width);
  * rscale: fp32 [images] (DropPath keep mask / keep_prob) or NULL = 1.  `stream` = hipStream_t; returns 0 or PD_ERR_*.
  */
 #ifndef PD_SWIN_H
@@ -29,14 +29,19 @@
 extern "C" {
 #endif
 
+/* y_q / y_s (nullable, together): y again as an MX-fp8 operand (include/pd_mx8.h: [rows][C] fp8 of q_format, [rows][C / 32] E8M0 bytes,
+ * rows as y) — quantised from the bf16 values y holds, zero rows included */
 int pd_swin_ln_fwd(const float *x, const void *r, const int32_t *rmap, int r_rows, const float *rscale, const float *gamma,
                    const float *beta, float eps, float *s, void *y, const int32_t *ymap, int y_rows, const int32_t *zero_rows,
-                   int n_zero, float *mean, float *rstd, int images, int L, int C, void *stream);
+                   int n_zero, float *mean, float *rstd, int images, int L, int C, void *y_q, void *y_s, int q_format, void *stream);
 
+/* dr_q / dr_s (nullable, together; need dr): dr again as an MX-fp8 operand, rows as dr.
+ * n_rep / rep_stride: the column sums go to copy (workgroup % n_rep) of dgamma / dbeta, copies rep_stride floats apart (all zero-filled by
+ * the caller, who sums them): ~500 workgroups adding into the same 2 C addresses serialise; n_rep = 1 is the single accumulator */
 int pd_swin_ln_bwd(const void *dy, const int32_t *ymap, int y_rows, const float *dsup, const float *s, const float *mean,
                    const float *rstd, const float *gamma, float *ds, void *dr, const int32_t *rmap, int r_rows,
                    const float *rscale, const int32_t *zero_rows, int n_zero, float *dgamma, float *dbeta, int images, int L,
-                   int C, void *stream);
+                   int C, void *dr_q, void *dr_s, int q_format, int n_rep, int64_t rep_stride, void *stream);
 
 #ifdef __cplusplus
 }

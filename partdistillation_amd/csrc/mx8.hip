@@ -21,6 +21,7 @@
 
 #include "gelu.h"
 #include "mfma_bf16.h"
+#include "mx8_quant.h"
 #include "pd_common.h"
 #include "pd_igemm.h"
 #include "pd_msda.h"
@@ -38,35 +39,7 @@ typedef __attribute__((address_space(1))) const void *glb_ptr;
 constexpr int BM = 128, BKB = 128;                         // rows per tile, bytes (= elements) per row of a K-step
 __device__ __attribute__((aligned(128))) unsigned char g_mx_zero_line[128];
 
-// shared exponent of a block with absolute maximum `amax`: the smallest X with amax 2^-X <= FMAX = 1.75 * 2^EMAX, clamped to
-// [-126, 126] (both 2^X and 2^-X are normal floats).  Returns the E8M0 byte; mult = 2^-X.
-template <int FMT>
-__device__ __forceinline__ unsigned mx_exponent(float amax, float &mult)
-{
-  constexpr int EMAX = FMT == PD_MX8_E4M3 ? 8 : 15;
-  const unsigned bits = __float_as_uint(amax);
-  int X = (int)((bits >> 23) & 255u) - 127 - EMAX + ((bits & 0x7fffffu) > 0x600000u ? 1 : 0);
-  X = min(max(X, -126), 126);
-  mult = __uint_as_float((unsigned)(127 - X) << 23);
-  return (unsigned)(X + 127);
-}
-
-template <int FMT>
-__device__ __forceinline__ uint2 mx_pack8(const float (&v)[8], float mult)
-{
-  float t[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) t[e] = v[e] * mult;          // |t| <= the format maximum by the choice of X (an exact power-of-two product): no clamp; a NaN stays one
-  uint2 w = {0u, 0u};
-  if (FMT == PD_MX8_E4M3) {
-    w.x = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], w.x, false); w.x = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], w.x, true);
-    w.y = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], w.y, false); w.y = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], w.y, true);
-  } else {
-    w.x = __builtin_amdgcn_cvt_pk_bf8_f32(t[0], t[1], w.x, false); w.x = __builtin_amdgcn_cvt_pk_bf8_f32(t[2], t[3], w.x, true);
-    w.y = __builtin_amdgcn_cvt_pk_bf8_f32(t[4], t[5], w.y, false); w.y = __builtin_amdgcn_cvt_pk_bf8_f32(t[6], t[7], w.y, true);
-  }
-  return w;
-}
+using namespace pdmx;
 
 // ------------------------------------------------------------------------------------------------ standalone quantisation
 // one lane = 8 consecutive elements (16 bytes in, 8 out), four lanes = one block: the block maximum is two quad-permute steps

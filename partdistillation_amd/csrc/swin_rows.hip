@@ -1,12 +1,19 @@
 // Token-row kernels of the fused Swin block (include/pd_swin.h): residual add (+ DropPath scale) + LayerNorm with row
-// maps, forward and backward.  One wavefront per token row, lane l holds channels l, l + 64, ... (E = C / 64 registers),
-// so every load / store instruction of a wave covers 256 contiguous bytes (fp32) or 128 (bf16); HBM-bound, one pass.
+// maps, forward and backward.  One wavefront per token row; HBM-bound, one pass.
+// Lane map (round 4): lane l holds the FOUR consecutive channels 4 (l + 64 j) .. + 3 of chunk j (C / 4 float4 per row, ceil(C / 256)
+// chunks; widths that do not fill the last chunk leave its upper lanes idle), so a load / store instruction moves 16 bytes per lane
+// (fp32) or 8 (bf16) — a quarter of the memory instructions of the one-channel-per-lane map it replaces (lane l: channels l, l + 64, ..)
+// — and a 32-channel block of the row is EIGHT ADJACENT LANES: the rows can leave as MX-fp8 operands of the next GEMM
+// (include/pd_mx8.h; block maximum = three DPP steps) next to their bf16 copy, without a pass of their own.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mx8_quant.h"
 #include "pd_common.h"
 #include "pd_msda.h"
 #include "pd_swin.h"
+
+int g_swin_ln_abl = 0;     // pd_debug_set "swin_ln_abl" (tools/ only): 1 = skip the column-sum atomics of the backward
 
 namespace {
 typedef unsigned short bf16_t;
@@ -31,8 +38,43 @@ constexpr int WAVES = 4;   // rows per workgroup pass (forward)
 // two fp32 [C] sums would not fit the 64 KB of static LDS
 template <int E> struct BwdWaves { static constexpr int value = E >= 12 ? 4 : 8; };
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// maximum over the 8 lanes of an aligned group (a 32-channel block of the row), in every lane
+__device__ __forceinline__ float group8_max(float v)
+{
+  v = fmaxf(v, dpp_f<0xB1>(v));      // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_f<0x4E>(v));      // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_f<0x141>(v));     // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d)
+{
+  return make_uint2((unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16), (unsigned)f2bf(c) | ((unsigned)f2bf(d) << 16));
+}
+__device__ __forceinline__ float4 unpack_bf16x4(uint2 u)
+{
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+// the four values a lane just rounded to bf16, again as MX fp8: block = the lane's aligned group of 8
+template <int FMT>
+__device__ __forceinline__ void emit_mx(uint2 bf, uint8_t *qrow, uint8_t *srow, int v4)
+{
+  const float4 o = unpack_bf16x4(bf);                                   // quantise what the bf16 copy holds
+  const float m = group8_max(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+  float mult;
+  const unsigned byte = pdmx::mx_exponent<FMT>(m, mult);
+  *reinterpret_cast<unsigned *>(qrow + 4 * v4) = pdmx::mx_pack4<FMT>(o.x, o.y, o.z, o.w, mult);
+  if ((v4 & 7) == 0) srow[v4 >> 3] = (uint8_t)byte;
+}
+
+// One channel per lane and register (lane l: channels l, l + 64, ..): the map of rounds 1-3, kept for the narrow stages (C <= 192: a row
+// is at most 48 float4 — the four-channel map leaves a quarter to three quarters of the lanes idle and measured 15-25 % slower there)
 template <int E>
-__global__ __launch_bounds__(64 * WAVES) void ln_fwd(const float *__restrict__ x, const bf16_t *__restrict__ r,
+__global__ __launch_bounds__(64 * WAVES) void ln_fwd_narrow(const float *__restrict__ x, const bf16_t *__restrict__ r,
                                                      const int32_t *__restrict__ rmap, int r_rows, const float *__restrict__ rscale,
                                                      const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                      float *__restrict__ s, bf16_t *__restrict__ y, const int32_t *__restrict__ ymap,
@@ -79,15 +121,16 @@ __global__ __launch_bounds__(64 * WAVES) void ln_fwd(const float *__restrict__ x
 }
 
 template <int E>
-__global__ __launch_bounds__(64 * BwdWaves<E>::value) void ln_bwd(const bf16_t *__restrict__ dy, const int32_t *__restrict__ ymap, int y_rows,
+__global__ __launch_bounds__(64 * BwdWaves<E>::value) void ln_bwd_narrow(const bf16_t *__restrict__ dy, const int32_t *__restrict__ ymap, int y_rows,
                                                      const float *__restrict__ dsup, const float *__restrict__ s,
                                                      const float *__restrict__ mean, const float *__restrict__ rstd,
                                                      const float *__restrict__ gamma, float *__restrict__ ds, bf16_t *__restrict__ dr,
                                                      const int32_t *__restrict__ rmap, int r_rows, const float *__restrict__ rscale,
                                                      const int32_t *__restrict__ zero_rows, int n_zero, float *__restrict__ dgamma,
-                                                     float *__restrict__ dbeta, int images, int L, int rows_per_wave)
+                                                     float *__restrict__ dbeta, int images, int L, int rows_per_wave, int n_rep, int64_t rep_stride)
 {
   constexpr int C = 64 * E, BWAVES = BwdWaves<E>::value;
+  dgamma += (int64_t)(blockIdx.x % n_rep) * rep_stride; dbeta += (int64_t)(blockIdx.x % n_rep) * rep_stride;
   __shared__ float red[2][BWAVES][C];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t R = (int64_t)images * L;
@@ -146,21 +189,199 @@ __global__ __launch_bounds__(64 * BwdWaves<E>::value) void ln_bwd(const bf16_t *
   }
 }
 
-template <int E, typename... Args>
-void launch_bwd(int64_t rows, hipStream_t st, Args... args)
+// MXF: -1 no MX copy, else the fp8 format of y_q
+template <int E, int MXF>
+__global__ __launch_bounds__(64 * WAVES) void ln_fwd(const float *__restrict__ x, const bf16_t *__restrict__ r,
+                                                     const int32_t *__restrict__ rmap, int r_rows, const float *__restrict__ rscale,
+                                                     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                     float *__restrict__ s, bf16_t *__restrict__ y, const int32_t *__restrict__ ymap,
+                                                     int y_rows, const int32_t *__restrict__ zero_rows, int n_zero,
+                                                     float *__restrict__ mean, float *__restrict__ rstd, int images, int L,
+                                                     uint8_t *__restrict__ y_q, uint8_t *__restrict__ y_s)
+{
+  constexpr int C = 64 * E, V4 = 16 * E, NJ = (V4 + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  const int64_t R = (int64_t)images * L;
+  const int64_t i = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (i >= R) {                                                         // trailing waves zero the padded rows of y
+    const int64_t z = i - R;
+    if (z < (int64_t)images * n_zero) {
+      const int64_t row = (z / n_zero) * y_rows + zero_rows[z % n_zero];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int v4 = lane + 64 * j;
+        if (v4 < V4) {
+          *reinterpret_cast<uint2 *>(y + row * C + 4 * v4) = make_uint2(0u, 0u);
+          if (MXF >= 0) { *reinterpret_cast<unsigned *>(y_q + row * C + 4 * v4) = 0u; if ((v4 & 7) == 0) y_s[row * (C / 32) + (v4 >> 3)] = 0; }
+        }
+      }
+    }
+    return;
+  }
+  const int img = (int)(i / L), t = (int)(i - (int64_t)img * L);
+  float4 v[NJ];
+  const float *xr = x + i * C;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) v[j] = (lane + 64 * j < V4) ? *reinterpret_cast<const float4 *>(xr + 4 * (lane + 64 * j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r) {
+    const bf16_t *rr = r + ((int64_t)img * r_rows + (rmap ? rmap[t] : t)) * C;
+    const float sc = rscale ? rscale[img] : 1.f;
+    float *sr = s + i * C;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (lane + 64 * j < V4) {
+        const float4 q = unpack_bf16x4(*reinterpret_cast<const uint2 *>(rr + 4 * (lane + 64 * j)));
+        v[j].x = fmaf(sc, q.x, v[j].x); v[j].y = fmaf(sc, q.y, v[j].y); v[j].z = fmaf(sc, q.z, v[j].z); v[j].w = fmaf(sc, q.w, v[j].w);
+        *reinterpret_cast<float4 *>(sr + 4 * (lane + 64 * j)) = v[j];
+      }
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  const float mu = wave_sum(sum) * (1.f / C);
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    if (lane + 64 * j < V4) {
+      const float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
+      sq += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(sq) * (1.f / C) + eps);
+  if (lane == 0) { mean[i] = mu; rstd[i] = rs; }
+  const int64_t yrow = (int64_t)img * y_rows + (ymap ? ymap[t] : t);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int v4 = lane + 64 * j;
+    if (v4 < V4) {                                                      // (whole groups of 8 lanes: V4 is a multiple of 8)
+      const float4 g = *reinterpret_cast<const float4 *>(gamma + 4 * v4), bt = *reinterpret_cast<const float4 *>(beta + 4 * v4);
+      const uint2 o = pack_bf16x4(fmaf((v[j].x - mu) * rs, g.x, bt.x), fmaf((v[j].y - mu) * rs, g.y, bt.y),
+                                  fmaf((v[j].z - mu) * rs, g.z, bt.z), fmaf((v[j].w - mu) * rs, g.w, bt.w));
+      *reinterpret_cast<uint2 *>(y + yrow * C + 4 * v4) = o;
+      if (MXF >= 0) emit_mx<(MXF >= 0 ? MXF : 0)>(o, y_q + yrow * C, y_s + yrow * (C / 32), v4);
+    }
+  }
+}
+
+template <int E, int MXF>
+__global__ __launch_bounds__(64 * BwdWaves<E>::value) void ln_bwd(const bf16_t *__restrict__ dy, const int32_t *__restrict__ ymap, int y_rows,
+                                                     const float *__restrict__ dsup, const float *__restrict__ s,
+                                                     const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                     const float *__restrict__ gamma, float *__restrict__ ds, bf16_t *__restrict__ dr,
+                                                     const int32_t *__restrict__ rmap, int r_rows, const float *__restrict__ rscale,
+                                                     const int32_t *__restrict__ zero_rows, int n_zero, float *__restrict__ dgamma,
+                                                     float *__restrict__ dbeta, int images, int L, int rows_per_wave,
+                                                     uint8_t *__restrict__ dr_q, uint8_t *__restrict__ dr_s, int abl, int n_rep, int64_t rep_stride)
+{
+  constexpr int C = 64 * E, BWAVES = BwdWaves<E>::value, V4 = 16 * E, NJ = (V4 + 63) / 64;
+  // column sums: every workgroup ends with 2 C atomic adds; ~500 workgroups on the same 2 C addresses serialise (19 of the 47 us of a
+  // 14 112 x 768 launch) — the caller may hand n_rep zero-filled copies rep_stride floats apart and sum them once per stage
+  dgamma += (int64_t)(blockIdx.x % n_rep) * rep_stride; dbeta += (int64_t)(blockIdx.x % n_rep) * rep_stride;
+  __shared__ float red[2][BWAVES][C];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t R = (int64_t)images * L;
+  const int64_t first = ((int64_t)blockIdx.x * BWAVES + wv) * rows_per_wave;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 gm[NJ], ag[NJ], ab[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { gm[j] = (lane + 64 * j < V4) ? *reinterpret_cast<const float4 *>(gamma + 4 * (lane + 64 * j)) : zero4; ag[j] = zero4; ab[j] = zero4; }
+  for (int64_t i = first; i < first + rows_per_wave; ++i) {
+    if (i >= R) {
+      const int64_t z = i - R;
+      if (dr && z < (int64_t)images * n_zero) {
+        const int64_t row = (z / n_zero) * r_rows + zero_rows[z % n_zero];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int v4 = lane + 64 * j;
+          if (v4 < V4) {
+            *reinterpret_cast<uint2 *>(dr + row * C + 4 * v4) = make_uint2(0u, 0u);
+            if (MXF >= 0) { *reinterpret_cast<unsigned *>(dr_q + row * C + 4 * v4) = 0u; if ((v4 & 7) == 0) dr_s[row * (C / 32) + (v4 >> 3)] = 0; }
+          }
+        }
+      }
+      continue;
+    }
+    const int img = (int)(i / L), t = (int)(i - (int64_t)img * L);
+    const bf16_t *dyr = dy + ((int64_t)img * y_rows + (ymap ? ymap[t] : t)) * C;
+    const float *sr = s + i * C;
+    const float mu = mean[i], rs = rstd[i];
+    float4 g[NJ], xh[NJ], up[NJ];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int v4 = lane + 64 * j;
+      const bool act = v4 < V4;
+      const float4 d = act ? unpack_bf16x4(*reinterpret_cast<const uint2 *>(dyr + 4 * v4)) : zero4;
+      const float4 sv = act ? *reinterpret_cast<const float4 *>(sr + 4 * v4) : make_float4(mu, mu, mu, mu);
+      up[j] = (act && dsup) ? *reinterpret_cast<const float4 *>(dsup + i * C + 4 * v4) : zero4;
+      xh[j] = make_float4((sv.x - mu) * rs, (sv.y - mu) * rs, (sv.z - mu) * rs, (sv.w - mu) * rs);
+      ag[j].x = fmaf(d.x, xh[j].x, ag[j].x); ag[j].y = fmaf(d.y, xh[j].y, ag[j].y); ag[j].z = fmaf(d.z, xh[j].z, ag[j].z); ag[j].w = fmaf(d.w, xh[j].w, ag[j].w);
+      ab[j].x += d.x; ab[j].y += d.y; ab[j].z += d.z; ab[j].w += d.w;
+      g[j] = make_float4(d.x * gm[j].x, d.y * gm[j].y, d.z * gm[j].z, d.w * gm[j].w);
+      a += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+      b += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+    }
+    a = wave_sum(a) * (1.f / C);
+    b = wave_sum(b) * (1.f / C);
+    float *dsr = ds + i * C;
+    const float sc = rscale ? rscale[img] : 1.f;
+    const int64_t rrow = (int64_t)img * r_rows + (rmap ? rmap[t] : t);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int v4 = lane + 64 * j;
+      if (v4 < V4) {
+        float4 d;
+        d.x = rs * (g[j].x - a - xh[j].x * b) + up[j].x; d.y = rs * (g[j].y - a - xh[j].y * b) + up[j].y;
+        d.z = rs * (g[j].z - a - xh[j].z * b) + up[j].z; d.w = rs * (g[j].w - a - xh[j].w * b) + up[j].w;
+        *reinterpret_cast<float4 *>(dsr + 4 * v4) = d;
+        if (dr) {
+          const uint2 o = pack_bf16x4(sc * d.x, sc * d.y, sc * d.z, sc * d.w);
+          *reinterpret_cast<uint2 *>(dr + rrow * C + 4 * v4) = o;
+          if (MXF >= 0) emit_mx<(MXF >= 0 ? MXF : 0)>(o, dr_q + rrow * C, dr_s + rrow * (C / 32), v4);
+        }
+      }
+    }
+  }
+  if (abl & 1) return;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int v4 = lane + 64 * j;
+    if (v4 < V4) { *reinterpret_cast<float4 *>(&red[0][wv][4 * v4]) = ag[j]; *reinterpret_cast<float4 *>(&red[1][wv][4 * v4]) = ab[j]; }
+  }
+  __syncthreads();
+  for (int cidx = threadIdx.x; cidx < C; cidx += 64 * BWAVES) {
+    float ga = 0.f, ba = 0.f;
+#pragma unroll
+    for (int w = 0; w < BWAVES; ++w) { ga += red[0][w][cidx]; ba += red[1][w][cidx]; }
+    atomicAdd(dgamma + cidx, ga);
+    atomicAdd(dbeta + cidx, ba);
+  }
+}
+
+template <int E>
+void bwd_geometry(int64_t rows, dim3 &g, dim3 &b, int &rpw)
 {
   // rows per wave: ~512 workgroups; every workgroup ends with 2*C atomics, so few, fat workgroups
   constexpr int BW = BwdWaves<E>::value;
-  int rpw = (int)((rows + 512 * BW - 1) / (512 * BW));
+  rpw = (int)((rows + 512 * BW - 1) / (512 * BW));
   rpw = rpw < 2 ? 2 : (rpw > 32 ? 32 : rpw);
-  const dim3 g((unsigned)((rows + (int64_t)BW * rpw - 1) / ((int64_t)BW * rpw))), b(64 * BW);
-  hipLaunchKernelGGL((ln_bwd<E>), g, b, 0, st, args..., rpw);
+  g = dim3((unsigned)((rows + (int64_t)BW * rpw - 1) / ((int64_t)BW * rpw)));
+  b = dim3(64 * BW);
 }
 
 int check(int images, int L, int C, const char *who)
 {
   if (images < 0 || L < 0) return pd_set_error(PD_ERR_INVALID_ARG, "%s: negative sizes", who);
   if (C <= 0 || C % 64 != 0 || C > 1536) return pd_set_error(PD_ERR_INVALID_ARG, "%s: C = %d must be a multiple of 64 up to 1536", who, C);
+  return PD_OK;
+}
+
+int check_mx(const void *q, const void *sc, int fmt, const char *who)
+{
+  if ((q != nullptr) != (sc != nullptr)) return pd_set_error(PD_ERR_INVALID_ARG, "%s: the MX element and scale pointers come together", who);
+  if (q && fmt != PD_MX8_E4M3 && fmt != PD_MX8_E5M2) return pd_set_error(PD_ERR_INVALID_ARG, "%s: unknown fp8 format %d", who, fmt);
+  if ((uintptr_t)q & 3) return pd_set_error(PD_ERR_INVALID_ARG, "%s: misaligned MX element pointer", who);
   return PD_OK;
 }
 
@@ -182,35 +403,55 @@ int check(int images, int L, int C, const char *who)
 extern "C" int pd_swin_ln_fwd(const float *x, const void *r, const int32_t *rmap, int r_rows, const float *rscale,
                               const float *gamma, const float *beta, float eps, float *s, void *y, const int32_t *ymap,
                               int y_rows, const int32_t *zero_rows, int n_zero, float *mean, float *rstd, int images, int L, int C,
-                              void *stream_)
+                              void *y_q, void *y_s, int q_format, void *stream_)
 {
   int rc = check(images, L, C, "pd_swin_ln_fwd");
   if (rc) return rc;
+  if ((rc = check_mx(y_q, y_s, q_format, "pd_swin_ln_fwd")) != PD_OK) return rc;
   const int64_t R = (int64_t)images * L;
   if (R == 0) return PD_OK;
   if (!x || !gamma || !beta || !y || !mean || !rstd || (r && !s) || (n_zero > 0 && !zero_rows) || n_zero < 0)
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_swin_ln_fwd: null pointer");
+  if (((uintptr_t)x | (uintptr_t)s | (uintptr_t)gamma | (uintptr_t)beta) & 15 || ((uintptr_t)r | (uintptr_t)y) & 7)
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_swin_ln_fwd: misaligned pointer (fp32 rows 16 bytes, bf16 rows 8)");
   const int64_t rows = R + (int64_t)images * n_zero;
   const dim3 g((unsigned)((rows + WAVES - 1) / WAVES)), b(64 * WAVES);
   hipStream_t st = (hipStream_t)stream_;
-  E_SWITCH(C, hipLaunchKernelGGL((ln_fwd<E>), g, b, 0, st, x, (const bf16_t *)r, rmap, r_rows, rscale, gamma, beta, eps, s,
-                                 (bf16_t *)y, ymap, y_rows, zero_rows, n_zero, mean, rstd, images, L));
+#define FWD(MXF) hipLaunchKernelGGL((ln_fwd<E, MXF>), g, b, 0, st, x, (const bf16_t *)r, rmap, r_rows, rscale, gamma, beta, eps, s, (bf16_t *)y, ymap, \
+                                    y_rows, zero_rows, n_zero, mean, rstd, images, L, (uint8_t *)y_q, (uint8_t *)y_s)
+  E_SWITCH(C, if (!y_q && E <= 3) hipLaunchKernelGGL((ln_fwd_narrow<E>), g, b, 0, st, x, (const bf16_t *)r, rmap, r_rows, rscale, gamma, beta, eps, s,
+                                                        (bf16_t *)y, ymap, y_rows, zero_rows, n_zero, mean, rstd, images, L);
+              else if (!y_q) FWD(-1); else if (q_format == PD_MX8_E4M3) FWD(PD_MX8_E4M3); else FWD(PD_MX8_E5M2));
+#undef FWD
   return pd_check_launch("pd_swin_ln_fwd");
 }
 
 extern "C" int pd_swin_ln_bwd(const void *dy, const int32_t *ymap, int y_rows, const float *dsup, const float *s, const float *mean,
                               const float *rstd, const float *gamma, float *ds, void *dr, const int32_t *rmap, int r_rows,
                               const float *rscale, const int32_t *zero_rows, int n_zero, float *dgamma, float *dbeta, int images,
-                              int L, int C, void *stream_)
+                              int L, int C, void *dr_q, void *dr_s, int q_format, int n_rep, int64_t rep_stride, void *stream_)
 {
+  if (n_rep < 1 || (n_rep > 1 && rep_stride < C)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_swin_ln_bwd: n_rep >= 1 copies at least C floats apart");
   int rc = check(images, L, C, "pd_swin_ln_bwd");
   if (rc) return rc;
+  if ((rc = check_mx(dr_q, dr_s, q_format, "pd_swin_ln_bwd")) != PD_OK) return rc;
+  if (dr_q && !dr) return pd_set_error(PD_ERR_INVALID_ARG, "pd_swin_ln_bwd: the MX copy of dr needs dr");
   const int64_t R = (int64_t)images * L;
   if (R == 0) return PD_OK;
   if (!dy || !s || !mean || !rstd || !gamma || !ds || !dgamma || !dbeta || (n_zero > 0 && !zero_rows) || n_zero < 0)
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_swin_ln_bwd: null pointer");
+  if (((uintptr_t)s | (uintptr_t)dsup | (uintptr_t)ds | (uintptr_t)gamma) & 15 || ((uintptr_t)dy | (uintptr_t)dr) & 7)
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_swin_ln_bwd: misaligned pointer (fp32 rows 16 bytes, bf16 rows 8)");
   const int64_t rows = R + (dr ? (int64_t)images * n_zero : 0);
-  E_SWITCH(C, (launch_bwd<E>(rows, (hipStream_t)stream_, (const bf16_t *)dy, ymap, y_rows, dsup, s, mean, rstd, gamma, ds,
-                             (bf16_t *)dr, rmap, r_rows, rscale, zero_rows, n_zero, dgamma, dbeta, images, L)));
+  hipStream_t st = (hipStream_t)stream_;
+  dim3 g, b;
+  int rpw = 0;
+#define BWD(MXF) hipLaunchKernelGGL((ln_bwd<E, MXF>), g, b, 0, st, (const bf16_t *)dy, ymap, y_rows, dsup, s, mean, rstd, gamma, ds, (bf16_t *)dr, rmap, \
+                                    r_rows, rscale, zero_rows, n_zero, dgamma, dbeta, images, L, rpw, (uint8_t *)dr_q, (uint8_t *)dr_s, g_swin_ln_abl, n_rep, rep_stride)
+  E_SWITCH(C, bwd_geometry<E>(rows, g, b, rpw);
+              if (!dr_q && E <= 3) hipLaunchKernelGGL((ln_bwd_narrow<E>), g, b, 0, st, (const bf16_t *)dy, ymap, y_rows, dsup, s, mean, rstd, gamma, ds, (bf16_t *)dr,
+                                                      rmap, r_rows, rscale, zero_rows, n_zero, dgamma, dbeta, images, L, rpw, n_rep, rep_stride);
+              else if (!dr_q) BWD(-1); else if (q_format == PD_MX8_E4M3) BWD(PD_MX8_E4M3); else BWD(PD_MX8_E5M2));
+#undef BWD
   return pd_check_launch("pd_swin_ln_bwd");
 }

@@ -11,9 +11,10 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
-def ln_fwd(x, r, rmap, r_rows, rscale, gamma, beta, eps, ymap, y_rows, zero_rows, images, L):
+def ln_fwd(x, r, rmap, r_rows, rscale, gamma, beta, eps, ymap, y_rows, zero_rows, images, L, mx=None):
     """x fp32 [images*L, C]; r bf16 rows (or None) -> (s fp32 [images*L, C] (x itself when r is None), y bf16
-    [images*y_rows, C], mean, rstd)"""
+    [images*y_rows, C], [mean, rstd]) and, with mx = an fp8 format of functions/mx8.py, y again as an MX operand (q uint8 [rows, C],
+    scales uint8 [rows, C / 32])"""
     if not x.is_cuda:
         raise RuntimeError("pd_swin_ln_fwd runs on the GPU only (no CPU fallback in partdistillation_amd)")
     C = x.shape[-1]
@@ -22,21 +23,28 @@ def ln_fwd(x, r, rmap, r_rows, rscale, gamma, beta, eps, ymap, y_rows, zero_rows
     y = torch.empty((images * y_rows, C), dtype=torch.bfloat16, device=x.device)
     stats = torch.empty((2, images * L), dtype=torch.float32, device=x.device)
     nz = 0 if zero_rows is None else zero_rows.numel()
+    yq = torch.empty((images * y_rows, C), dtype=torch.uint8, device=x.device) if mx is not None else None
+    ys = torch.empty((images * y_rows, C // 32), dtype=torch.uint8, device=x.device) if mx is not None else None
     _lib.check(_lib.load().pd_swin_ln_fwd(x.data_ptr(), _p(r), _p(rmap), r_rows, _p(rscale), gamma.data_ptr(), beta.data_ptr(),
                                           float(eps), s.data_ptr(), y.data_ptr(), _p(ymap), y_rows, _p(zero_rows), nz,
-                                          stats[0].data_ptr(), stats[1].data_ptr(), images, L, C, _lib.current_stream()))
-    return s, y, stats
+                                          stats[0].data_ptr(), stats[1].data_ptr(), images, L, C, _p(yq), _p(ys), mx if mx is not None else 0,
+                                          _lib.current_stream()))
+    return (s, y, stats) if mx is None else (s, y, stats, (yq, ys))
 
 
-def ln_bwd(dy, ymap, y_rows, dsup, s, stats, gamma, want_dr, rmap, r_rows, rscale, zero_rows, dgamma, dbeta, images, L):
-    """-> (ds fp32 [images*L, C], dr bf16 [images*r_rows, C] or None); dgamma / dbeta (fp32 [C]) are accumulated into"""
+def ln_bwd(dy, ymap, y_rows, dsup, s, stats, gamma, want_dr, rmap, r_rows, rscale, zero_rows, dgamma, dbeta, images, L, mx=None, n_rep=1, rep_stride=0):
+    """-> (ds fp32 [images*L, C], dr bf16 [images*r_rows, C] or None) and, with mx = an fp8 format and want_dr, dr again as an MX operand;
+    dgamma / dbeta (fp32 [C]) are accumulated into — copy (workgroup % n_rep) of them, rep_stride floats apart, when n_rep > 1 (the caller sums)"""
     C = s.shape[-1]
     assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and (dsup is None or (dsup.dtype == torch.float32 and dsup.is_contiguous()))
     ds = torch.empty_like(s)
     dr = torch.empty((images * r_rows, C), dtype=torch.bfloat16, device=s.device) if want_dr else None
     nz = 0 if (zero_rows is None or not want_dr) else zero_rows.numel()
+    mx = mx if want_dr else None
+    dq = torch.empty((images * r_rows, C), dtype=torch.uint8, device=s.device) if mx is not None else None
+    dsc = torch.empty((images * r_rows, C // 32), dtype=torch.uint8, device=s.device) if mx is not None else None
     _lib.check(_lib.load().pd_swin_ln_bwd(dy.data_ptr(), _p(ymap), y_rows, _p(dsup), s.data_ptr(), stats[0].data_ptr(),
                                           stats[1].data_ptr(), gamma.data_ptr(), ds.data_ptr(), _p(dr), _p(rmap), r_rows,
                                           _p(rscale), _p(zero_rows) if nz else None, nz, dgamma.data_ptr(), dbeta.data_ptr(),
-                                          images, L, C, _lib.current_stream()))
-    return ds, dr
+                                          images, L, C, _p(dq), _p(dsc), mx if mx is not None else 0, int(n_rep), int(rep_stride), _lib.current_stream()))
+    return (ds, dr) if mx is None else (ds, dr, (dq, dsc))

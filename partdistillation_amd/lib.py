@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libpd_hip.so") 
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -122,9 +122,9 @@ SIGNATURES = {
     "pd_window_attn_fwd_w12": (_c_int, [_c_vp] * 6 + [_c_int] * 3 + [ctypes.c_float, _c_vp]),
     "pd_window_attn_bwd_w12": (_c_int, [_c_vp] * 9 + [_c_int] * 3 + [ctypes.c_float, _c_vp]),
     "pd_swin_ln_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_int, _c_vp,
-                                _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
+                                _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_vp]),
     "pd_swin_ln_bwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp,
-                                _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
+                                _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_int, ctypes.c_int64, _c_vp]),
     "pd_resample_rows_u8": (_c_int, [_c_vp] + [_c_int] * 6 + [_c_vp] * 3 + [_c_int, _c_int, _c_vp, _c_vp]),
     "pd_resample_cols_u8": (_c_int, [_c_vp] + [_c_int] * 3 + [_c_vp] * 3 + [_c_int] * 5 + [_c_vp, _c_vp]),
     "pd_rle_sample_u8": (_c_int, [_c_vp, _c_vp] + [_c_int] * 4 + [_c_vp, _c_vp] + [_c_int] * 3 + [_c_vp, _c_vp, _c_vp]),

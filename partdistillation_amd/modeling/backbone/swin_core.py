@@ -19,6 +19,7 @@ from ...functions import rowwise as _rw
 from ...functions import swin_rows as rows
 from ...functions import window_attention as wattn
 
+NREP = 8                 # copies of a stage's LayerNorm column-sum accumulators (see _bwd_blocks)
 N_BLOCK = 13            # norm1.w, norm1.b, qkv.w, qkv.b, table, proj.w, proj.b, norm2.w, norm2.b, fc1.w, fc1.b, fc2.w, fc2.b
 _MAPS = {}
 
@@ -212,21 +213,26 @@ class SwinStage(Function):
             ymap, zero, S, nW = window_maps(H, W, shift, x2.device)
             regions = wattn.shifted_window_regions(H, W, shift, x2.device) if shift > 0 else None
             table = table if table.is_contiguous() else table.contiguous()
-            s1, y1, st1 = rows.ln_fwd(cur, r, None, L, rscale, n1w, n1b, spec["eps"], ymap, S, zero, B, L)
-            qkv = mx8.linear(mx8.quantize(y1), wq[4 * k], qb) if mx else _lin(y1, qw, qb)
+            if mx:                                              # the LayerNorm rows leave as MX e4m3 operands next to their bf16 copy
+                s1, y1, st1, y1q = rows.ln_fwd(cur, r, None, L, rscale, n1w, n1b, spec["eps"], ymap, S, zero, B, L, mx=mx8.E4M3)
+                qkv = mx8.linear(y1q, wq[4 * k], qb)
+            else:
+                s1, y1, st1 = rows.ln_fwd(cur, r, None, L, rscale, n1w, n1b, spec["eps"], ymap, S, zero, B, L)
+                qkv = _lin(y1, qw, qb)
             ao, lse = wattn.fwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table, regions, spec["scale"], nW)
             po = mx8.linear(mx8.quantize(ao.view(-1, C)), wq[4 * k + 1], pb) if mx else _lin(ao.view(-1, C), pw, pb)
             sc1 = dp[k, 0] if dp is not None else None
-            s2, y2, st2 = rows.ln_fwd(s1, po, ymap, S, sc1, n2w, n2b, spec["eps"], None, L, None, B, L)
             if mx:                                              # fc1's epilogue hands fc2 its operand: GELU(h) again as MX e4m3 along the 4 C axis
-                a, h, aq = mx8.linear(mx8.quantize(y2), wq[4 * k + 2], f1b, act=mx8.ACT_GELU, want_pre=True, out_mx=mx8.E4M3)
+                s2, y2, st2, y2q = rows.ln_fwd(s1, po, ymap, S, sc1, n2w, n2b, spec["eps"], None, L, None, B, L, mx=mx8.E4M3)
+                a, h, aq = mx8.linear(y2q, wq[4 * k + 2], f1b, act=mx8.ACT_GELU, want_pre=True, out_mx=mx8.E4M3)
                 f = mx8.linear(aq, wq[4 * k + 3], f2b)
-            elif _own(y2, f1w):
-                a, h = igemm.linear(y2, f1w, f1b, act=igemm.ACT_GELU, want_pre=True)     # bias + exact-erf GELU in the GEMM epilogue; h kept for GELU'
             else:
-                h = torch.addmm(_bf(f1b), y2, _bf(f1w).t())
-                a = F.gelu(h)
-            if not mx:
+                s2, y2, st2 = rows.ln_fwd(s1, po, ymap, S, sc1, n2w, n2b, spec["eps"], None, L, None, B, L)
+                if _own(y2, f1w):
+                    a, h = igemm.linear(y2, f1w, f1b, act=igemm.ACT_GELU, want_pre=True)     # bias + exact-erf GELU in the GEMM epilogue; h kept for GELU'
+                else:
+                    h = torch.addmm(_bf(f1b), y2, _bf(f1w).t())
+                    a = F.gelu(h)
                 f = _lin(a, f2w, f2b)
             saved += [s1, y1, st1, qkv, ao, lse, s2, y2, st2, h, a]
             cur, r, rscale = s2, f, (dp[k, 1] if dp is not None else None)
@@ -280,7 +286,10 @@ class SwinStage(Function):
         dev = dsup.device
         if cmdbuf.active() is not None:                        # df goes into problem structs (host memory the replay re-reads): an arena copy
             df = _rw.copy_d2d(torch.empty_like(df), df)
-        norm_g = torch.zeros((depth, 4, C), dtype=torch.float32, device=dev)       # dgamma1, dbeta1, dgamma2, dbeta2
+        # dgamma1, dbeta1, dgamma2, dbeta2 of every block, in NREP copies the LayerNorm' workgroups spread their column-sum atomics over
+        # (pd_swin.h: ~500 workgroups adding into the same 2 C addresses serialise: 19 of 47 us at [14 112, 768]); summed once below
+        norm_r = torch.zeros((NREP, depth, 4, C), dtype=torch.float32, device=dev)
+        norm_g, rep = norm_r[0], dict(n_rep=NREP, rep_stride=depth * 4 * C)
         grads = [None] * (depth * N_BLOCK)
         big = [] if TR_WGRAD and cmdbuf.active() is None else None
         tab0 = params[4]
@@ -293,7 +302,7 @@ class SwinStage(Function):
         mx = bool(spec.get("mx8")) and own
         if mx:                                                   # ... and those again as MX e4m3 along THEIR contraction axis (the output features)
             wtq = mx8.quantize_grouped(wts, mx8.E4M3)
-            gf = mx8.GRAD_FORMAT
+            gf, dfq = mx8.GRAD_FORMAT, None
         for k in reversed(range(depth)):
             n1w, n1b, qw, qb, table, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = params[k * N_BLOCK:(k + 1) * N_BLOCK]
             s1, y1, st1, qkv, ao, lse, s2, y2, st2, h, a = saved[k * 11:(k + 1) * 11]
@@ -307,7 +316,9 @@ class SwinStage(Function):
             # MLP
             g[11], g[12] = _wgrad(df, a, f2w, f2b, big)
             if mx:                                               # gradients travel as MX e5m2; the weight gradients keep reading the bf16 copies
-                dh, dhq = mx8.linear(mx8.quantize(df, gf), wtq[4 * k + 3], gate=h, gate_mode=mx8.GATE_GELU, a_fmt=gf, out_mx=gf)
+                if dfq is None:                                  # the last block's df comes from the eager prologue: a pass of its own
+                    dfq = mx8.quantize(df, gf)
+                dh, dhq = mx8.linear(dfq, wtq[4 * k + 3], gate=h, gate_mode=mx8.GATE_GELU, a_fmt=gf, out_mx=gf)
                 dy2 = mx8.linear(dhq, wtq[4 * k + 2], a_fmt=gf)
             elif own:
                 dh = igemm.linear(df, f2w_t, gate=h, gate_mode=igemm.GATE_GELU)        # (df W2) * GELU'(h) in the epilogue
@@ -319,8 +330,12 @@ class SwinStage(Function):
             g[9], g[10] = _wgrad(dh, y2, f1w, f1b, big)
             # LayerNorm 2 + the residual it sits on; gradient of the (window-major) proj output rides out as `dr`
             sc1 = dp[k, 0] if dp is not None else None
-            ds2, dpo = rows.ln_bwd(dy2, None, L, dsup, s2, st2, n2w, True, ymap, S, sc1, zero, norm_g[k, 2], norm_g[k, 3], B, L)
-            dao = mx8.linear(mx8.quantize(dpo, gf), wtq[4 * k + 1], a_fmt=gf) if mx else igemm.linear(dpo, pw_t) if own else torch.mm(dpo, _bf(pw))
+            if mx:                                               # the rows LayerNorm' writes leave as MX operands of the next input-gradient GEMM
+                ds2, dpo, dpoq = rows.ln_bwd(dy2, None, L, dsup, s2, st2, n2w, True, ymap, S, sc1, zero, norm_g[k, 2], norm_g[k, 3], B, L, mx=gf, **rep)
+                dao = mx8.linear(dpoq, wtq[4 * k + 1], a_fmt=gf)
+            else:
+                ds2, dpo = rows.ln_bwd(dy2, None, L, dsup, s2, st2, n2w, True, ymap, S, sc1, zero, norm_g[k, 2], norm_g[k, 3], B, L, **rep)
+                dao = igemm.linear(dpo, pw_t) if own else torch.mm(dpo, _bf(pw))
             g[5], g[6] = _wgrad(dpo, ao.view(-1, C), pw, pb, big)
             dqkv, dtable = wattn.bwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table, regions, ao,
                                          dao.view(B * nW, wattn.TOKENS, C), lse, spec["scale"], nW,
@@ -331,10 +346,16 @@ class SwinStage(Function):
             g[2], g[3] = _wgrad(dqkv, y1, qw, qb, big)
             # LayerNorm 1; for k > 0 its input was (block k-1 stream + DropPath * MLP output): `dr` = that MLP's output gradient
             prev = (dp[k - 1, 1] if dp is not None else None) if k > 0 else None
-            ds1, df = rows.ln_bwd(dy1, ymap, S, ds2, s1, st1, n1w, k > 0, None, L, prev, None, norm_g[k, 0], norm_g[k, 1], B, L)
+            if mx and k > 0:
+                ds1, df, dfq = rows.ln_bwd(dy1, ymap, S, ds2, s1, st1, n1w, True, None, L, prev, None, norm_g[k, 0], norm_g[k, 1], B, L, mx=gf, **rep)
+            else:
+                ds1, df = rows.ln_bwd(dy1, ymap, S, ds2, s1, st1, n1w, k > 0, None, L, prev, None, norm_g[k, 0], norm_g[k, 1], B, L, **rep)
             dsup = ds1
-            g[0], g[1], g[7], g[8] = norm_g[k, 0], norm_g[k, 1], norm_g[k, 2], norm_g[k, 3]
             grads[k * N_BLOCK:(k + 1) * N_BLOCK] = g
+        norm_t = torch.zeros((depth, 4, C), dtype=torch.float32, device=dev)
+        _rw.colsum_acc(norm_r.view(NREP, depth * 4 * C), norm_t.view(-1))          # the copies' sum
+        for k in range(depth):
+            grads[k * N_BLOCK + 0], grads[k * N_BLOCK + 1], grads[k * N_BLOCK + 7], grads[k * N_BLOCK + 8] = norm_t[k, 0], norm_t[k, 1], norm_t[k, 2], norm_t[k, 3]
         if big:
             conv_bf16.submit(big)                                # joins the step's deferred group when engine/trainer.py opened one
         return dsup, grads

@@ -13,7 +13,7 @@ def _close(got, want, frac, what):
     assert err <= frac * scale, f"{what}: max abs err {err:.3e} > {frac} * {scale:.3e}"
 
 
-@pytest.mark.parametrize("C", [64, 128, 192, 384, 1024, 1536])
+@pytest.mark.parametrize("C", [64, 128, 192, 384, 512, 768, 1024, 1536])
 @pytest.mark.parametrize("mode", ["plain", "ln1", "ln2"])
 def test_row_kernel_matches_torch(C, mode):
     """plain: y = LN(x).  ln1: pending residual r (identity rows, DropPath scale), y window-major with zero rows.
@@ -67,6 +67,24 @@ def test_row_kernel_matches_torch(C, mode):
         _close(dr.float(), gs[3], 6e-3, "dr (bf16 rounding)")
         if mode == "ln2":
             assert float(dr.view(B, S, C)[:, zero.long()].abs().max()) == 0.0
+    # the MX-fp8 copies (include/pd_mx8.h) of y and dr: the same bf16 rows, quantised bit-exactly as oracle/mx8_ref.py does (zero rows included)
+    from oracle import mx8_ref as MX
+    for fmt in (0, 1):
+        s2, y2, st2, (yq, ys) = rows.ln_fwd(x, r, rmap, r_rows, rscale if r is not None else None, gamma, beta, 1e-5, ymap, y_rows, zy, B, L, mx=fmt)
+        # (C <= 192 without the MX copy runs the one-channel-per-lane kernels: another summation order, so "close", not "equal")
+        _close(y2.float(), y.float(), 1e-2, "y next to its MX copy"); torch.testing.assert_close(s2, s, rtol=1e-6, atol=1e-6)
+        rq, rs = MX.quantize(y2.cpu(), fmt)
+        assert torch.equal(yq.cpu(), rq)
+        live = (y2.float().view(-1, C // 32, 32).abs().amax(-1) > 0).cpu()         # an all-zero block's exponent byte is free (the kernel writes 0 for zero rows)
+        assert torch.equal(ys.cpu()[live], rs[live])
+        if r is not None:
+            g8 = torch.zeros(8, 2, C, device="cuda")                                 # the column sums spread over 8 copies
+            d2 = rows.ln_bwd(dy, ymap, y_rows, dsup, s, st, gamma, True, rmap, r_rows, rscale, zr, g8[0, 0], g8[0, 1], B, L, mx=fmt, n_rep=8, rep_stride=2 * C)
+            _close(d2[0], ds, 1e-5, "ds next to the MX copy"); _close(d2[1].float(), dr.float(), 1e-2, "dr next to its MX copy")
+            _close(g8.sum(0)[0], dgm, 1e-4, "dgamma from 8 copies"); _close(g8.sum(0)[1], dbt, 1e-4, "dbeta from 8 copies")
+            rq, rs = MX.quantize(d2[1].cpu(), fmt)
+            live = (d2[1].float().view(-1, C // 32, 32).abs().amax(-1) > 0).cpu()
+            assert torch.equal(d2[2][0].cpu(), rq) and torch.equal(d2[2][1].cpu()[live], rs[live])
 
 
 def test_row_kernel_rejects_unsupported_width():
