@@ -8,6 +8,7 @@
 #include "pd_msda.h"
 #include "pd_rowwise.h"
 
+int g_ln_bwd_cap = 0;     // pd_debug_set "ln_bwd_cap" (tools/ only): workgroups of pd_add_layernorm_bwd at most (0 = 256)
 namespace {
 
 typedef unsigned short bf16_t;
@@ -127,8 +128,12 @@ __global__ __launch_bounds__(256) void add_ln_fwd(const XT *__restrict__ x, cons
   }
 }
 
-template <int NV4, typename CT, typename DT>
-__global__ __launch_bounds__(256) void add_ln_bwd(const float *dy, const float *__restrict__ dy2,
+// WAVES wavefronts per workgroup, each walking rows; their column sums meet in LDS and leave as 3 C atomic adds per workgroup.  Those
+// adds are what bounds the launch when workgroups are many: the chip retires ~40 G fp32 atomics per second, 1 024 workgroups x 768 adds
+// took 21 of the 42 us at [43 008, 256] (tools/bench_add_ln.py; spreading them over 16 copies of the accumulators changed nothing: it is
+// the total, not the depth per address).  Hence FAT workgroups: 16 wavefronts (C = 256), a grid of a few hundred.
+template <int NV4, typename CT, typename DT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void add_ln_bwd(const float *dy, const float *__restrict__ dy2,
                                                   const CT *__restrict__ dy_c, const CT *__restrict__ dypos_c,
                                                   const float *__restrict__ z, const float *__restrict__ mean,
                                                   const float *__restrict__ rstd, const float *__restrict__ gamma,
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd(const float *dy, const float *
                                                   float *__restrict__ dpos_acc, int pos_div, int rows, float *__restrict__ dz_amax)
 {
   constexpr int C = NV4 * 256;
-  __shared__ float red[4][3][C];
+  __shared__ float red[WAVES][3][C];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float4 gm[NV4], ag[NV4], ab[NV4], ad[NV4];
 #pragma unroll
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd(const float *dy, const float *
     gm[j] = ld4(gamma + j * 256 + lane * 4);
     ag[j] = ab[j] = ad[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+  for (int r = blockIdx.x * WAVES + wave; r < rows; r += gridDim.x * WAVES) {
     const int64_t base = (int64_t)r * C + lane * 4;
     const float mu = mean[r], rs = rstd[r];
     float4 g[NV4], xh[NV4];
@@ -198,14 +203,14 @@ __global__ __launch_bounds__(256) void add_ln_bwd(const float *dy, const float *
     st4(&red[wave][2][j * 256 + lane * 4], ad[j]);
   }
   __syncthreads();
-  float *outs[3] = {dgamma, dbeta, dbias};
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
+  float *const outs[3] = {dgamma, dbeta, dbias};
+  for (int i = threadIdx.x; i < 3 * C; i += 64 * WAVES) {
+    const int k = i / C, c = i - k * C;
     if (!outs[k]) continue;
-    for (int c = threadIdx.x; c < C; c += 256) {
-      const float s = (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]);
-      atomicAdd(outs[k] + c, s);
-    }
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) sum += red[w][k][c];
+    atomicAdd(outs[k] + c, sum);
   }
 }
 
@@ -807,14 +812,27 @@ static int add_layernorm_bwd(const float *dy, const float *dy2, const void *dy_c
   if (((dy_c || dypos_c) && !dt_ok(c_dtype)) || (dz_c && !dt_ok(dzc_dtype))) return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_layernorm_bwd: dtype");
   if (dpos_acc && pos_div <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_layernorm_bwd: pos_div");
   hipStream_t s = (hipStream_t)stream_;
-  // the per-column sums leave each workgroup as C atomics per output: cap the grid so a channel sees <= ~1k of them
-  dim3 g(grid_rows(rows, 1024)), b(256);
+  // fat workgroups, few of them (see the kernel): 16 / 8 / 4 wavefronts by width (48 KB of column sums in LDS), >= 4 rows per wavefront,
+  // at most 256 workgroups (one per CU: 23.6 us at [43 008, 256] against 26.4 with 512 and 42.0 with 1 024 four-wavefront workgroups)
   const bool cb = c_dtype == PD_BF16, db = dzc_dtype == PD_BF16;
-#define LAUNCH(CT, DT) hipLaunchKernelGGL((add_ln_bwd<NV4, CT, DT>), g, b, 0, s, dy, dy2, (const CT *)dy_c, (const CT *)dypos_c, z, mean, rstd, gamma, dz, (DT *)dz_c, dgamma, dbeta, dbias, dpos_acc, pos_div, rows, dz_amax)
+#define LAUNCH(CT, DT, WV) hipLaunchKernelGGL((add_ln_bwd<NV4, CT, DT, WV>), g, b, 0, s, dy, dy2, (const CT *)dy_c, (const CT *)dypos_c, z, mean, rstd, gamma, dz, (DT *)dz_c, dgamma, dbeta, dbias, dpos_acc, pos_div, rows, dz_amax)
+#define LAUNCH_W(WV)                                                                    \
+  if (cb) { if (db) LAUNCH(bf16_t, bf16_t, WV); else LAUNCH(bf16_t, float, WV); }      \
+  else { if (db) LAUNCH(float, bf16_t, WV); else LAUNCH(float, float, WV); }
   NV4_SWITCH(C, {
-    if (cb) { if (db) LAUNCH(bf16_t, bf16_t); else LAUNCH(bf16_t, float); }
-    else { if (db) LAUNCH(float, bf16_t); else LAUNCH(float, float); }
+    constexpr int FAT = NV4 == 1 ? 16 : NV4 == 2 ? 8 : 4;
+    if (rows >= 8192 && FAT > 4) {
+      const int cap = g_ln_bwd_cap > 0 ? g_ln_bwd_cap : 256;
+      const dim3 g(max(1, min(cap, (rows + 4 * FAT - 1) / (4 * FAT))));
+      const dim3 b(64 * FAT);
+      LAUNCH_W(FAT)
+    } else {                                             // few rows (the decoder's 200): one row per wavefront at a time, as many workgroups as rows / 4
+      const dim3 g(grid_rows(rows, 1024));
+      const dim3 b(256);
+      LAUNCH_W(4)
+    }
   })
+#undef LAUNCH_W
 #undef LAUNCH
   return pd_check_launch("pd_add_layernorm_bwd");
 }
