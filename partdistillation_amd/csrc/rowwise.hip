@@ -8,7 +8,7 @@
 #include "pd_msda.h"
 #include "pd_rowwise.h"
 
-int g_ln_bwd_cap = 0;     // pd_debug_set "ln_bwd_cap" (tools/ only): workgroups of pd_add_layernorm_bwd at most (0 = 256)
+int g_ln_bwd_cap = 0;     // pd_debug_set "ln_bwd_cap" (tools/ only): workgroups of pd_add_layernorm_bwd at most (0 = 256; < 0: four-wavefront workgroups whatever the rows)
 namespace {
 
 typedef unsigned short bf16_t;
@@ -821,7 +821,7 @@ static int add_layernorm_bwd(const float *dy, const float *dy2, const void *dy_c
   else { if (db) LAUNCH(float, bf16_t, WV); else LAUNCH(float, float, WV); }
   NV4_SWITCH(C, {
     constexpr int FAT = NV4 == 1 ? 16 : NV4 == 2 ? 8 : 4;
-    if (rows >= 8192 && FAT > 4) {
+    if (rows >= 8192 && FAT > 4 && g_ln_bwd_cap >= 0) {
       const int cap = g_ln_bwd_cap > 0 ? g_ln_bwd_cap : 256;
       const dim3 g(max(1, min(cap, (rows + 4 * FAT - 1) / (4 * FAT))));
       const dim3 b(64 * FAT);

@@ -17,7 +17,10 @@ def _r(shape, seed, scale=1.0, dtype=torch.float32):
 
 @pytest.mark.parametrize("rows,Cw,xdt,cdt", [(200, 256, torch.bfloat16, torch.bfloat16), (200, 256, torch.float32, torch.float32),
                                               (4099, 256, torch.float32, torch.float32), (37, 512, torch.bfloat16, torch.bfloat16),
-                                              (5, 1024, torch.float32, torch.bfloat16)])
+                                              (5, 1024, torch.float32, torch.bfloat16),
+                                              # >= 8 192 rows: the backward's fat workgroups (16 / 8 wavefronts, <= 256 workgroups)
+                                              (43008, 256, torch.float32, torch.float32), (8195, 256, torch.bfloat16, torch.bfloat16),
+                                              (9000, 512, torch.float32, torch.bfloat16), (8192, 1024, torch.float32, torch.float32)])
 def test_add_layernorm_fwd_bwd_vs_torch(rows, Cw, xdt, cdt):
     from partdistillation_amd.functions import rowwise as rw
     B = 2 if rows % 2 == 0 else 1
