@@ -115,8 +115,13 @@ def kmeans_lloyd_batched(datas, K, inits=None, max_iter=300, tol=1e-4, generator
              labels=labels.data_ptr(), psums=psums.data_ptr(), pcounts=pcounts.data_ptr(), changed=flags[0].data_ptr(),
              range=block_range.data_ptr(), sums=sums.data_ptr(), counts=counts.data_ptr(), tols=tols.data_ptr(), n_iter=flags[2].data_ptr(),
              scratch=scratch.data_ptr(), ticket=flags[3].data_ptr())
+    # convergence is decided on the device; the host only has to STOP issuing.  It looks at the `done` flags through non-blocking copies to
+    # pinned memory and keeps issuing while a copy is in flight: a blocking read every `check_every` iterations left the GPU idle while the
+    # host caught up (8 ms of wall time for 4.7 ms of kernels at config 4).  Iterations issued after every image is done are ~4 us no-ops.
     it = 0
-    while it < max_iter:
+    pending = []                                                                             # (event, pinned snapshot of the done flags)
+    finished = False
+    while it < max_iter and not finished:
         for _ in range(min(check_every, max_iter - it)):
             if ATOMIC:                                                                       # tools only: the first version's accumulation
                 _lib.check(lib.pd_kmeans_assign(p["X"], p["blocks"], len(table), p["centers"], p["cnorm"], p["done"], p["labels"],
@@ -130,6 +135,15 @@ def kmeans_lloyd_batched(datas, K, inits=None, max_iter=300, tol=1e-4, generator
                 _lib.check(lib.pd_kmeans_update(p["centers"], p["cnorm"], p["sums"], p["counts"], p["changed"], p["tols"], p["done"],
                                                 p["n_iter"], B, K, C, st))
             it += 1
-        if bool(flags[1].all()):                                                             # the only read-back
-            break
+        snap = torch.empty(B, dtype=torch.int32, pin_memory=True)
+        snap.copy_(flags[1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        pending.append((ev, snap))
+        if len(pending) > 2:                                                                 # at most two chunks ahead of what the host has seen
+            pending[0][0].synchronize()
+        while pending and pending[0][0].query():
+            if bool(pending.pop(0)[1].all()):
+                finished = True
+                break
     return centers + torch.stack(means)[:, None, :], flags[2].tolist()

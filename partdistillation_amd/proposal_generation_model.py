@@ -153,16 +153,19 @@ class ProposalGenerationModel(nn.Module):
     def _result(self, inp, labels, object_mask, centroids, n_iter):
         H, W = labels.shape
         counts = torch.bincount(labels.flatten().long(), minlength=self.num_superpixel_clusters + 1)
-        counts_h = counts.tolist()                                                         # one small read-back per image
-        present = [l for l in range(1, len(counts_h)) if counts_h[l] > 0]
-        # run-length form of the column-major label map on the device; only the run table crosses to the host
+        # run-length form of the column-major label map on the device; only the run table crosses to the host — in ONE copy with the label
+        # counts and the object's area (was five blocking reads per image)
         flat = labels.t().contiguous().flatten()
         starts = torch.cat([flat.new_zeros(1, dtype=torch.long), (flat[1:] != flat[:-1]).nonzero().flatten() + 1])
-        values = flat[starts].cpu().numpy()
-        lengths = torch.diff(starts, append=starts.new_tensor([flat.numel()])).cpu().numpy()
+        lengths = torch.diff(starts, append=starts.new_tensor([flat.numel()]))
+        packed = torch.cat([counts, object_mask.sum().reshape(1), flat[starts].long(), lengths]).cpu().numpy()
+        nk = counts.numel()
+        counts_h, area, runs = packed[:nk].tolist(), int(packed[nk]), packed[nk + 1:]
+        values, lengths = runs[:runs.size // 2].astype("uint8"), runs[runs.size // 2:]
+        present = [l for l in range(1, len(counts_h)) if counts_h[l] > 0]
         res = {"file_name": inp.get("file_name"), "file_path": inp.get("file_path"), "class_code": inp.get("class_code"),
                "class_name": inp.get("class_name"), "part_mask": rle.runs_to_coco_json(values, lengths, (H, W), present),
-               "object_ratio": int(object_mask.sum().item()) / (H * W), "height": H, "width": W,
+               "object_ratio": area / (H * W), "height": H, "width": W,
                "class_index": inp.get("gt_object_class")}
         if self.root_save_path is not None and res["class_code"] is not None and res["file_name"] is not None:
             d = os.path.join(self.root_save_path, res["class_code"])
