@@ -93,6 +93,12 @@ typedef struct PdWgrad {
 } PdWgrad;
 int64_t pd_wgrad_bf16_workspace_bytes(const PdWgrad *p);
 int pd_wgrad_bf16(const PdWgrad *p, void *workspace, int64_t workspace_bytes, void *stream);
+/* `count` <= PD_WGRAD_SEQ_MAX problems by one call (the four Linears of a Swin block): their main launches back to back, then ONE launch for
+ * all their slice sums.  The workspace holds every problem's slabs side by side: pd_wgrad_bf16_seq_workspace_bytes.  The list is host memory,
+ * read before the call returns. */
+#define PD_WGRAD_SEQ_MAX 8
+int64_t pd_wgrad_bf16_seq_workspace_bytes(const PdWgrad *list, int count);
+int pd_wgrad_bf16_seq(const PdWgrad *list, int count, void *workspace, int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

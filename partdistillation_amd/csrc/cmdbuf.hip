@@ -159,6 +159,7 @@ const Entry kTable[] = {
   PD_E(pd_upsample_add_amax_nhwc_f32),
   PD_E(pd_upsample_add_nhwc_f32),
   PD_E(pd_wgrad_bf16),
+  PD_E(pd_wgrad_bf16_seq),
   PD_E(pd_window_attn_bwd_w12),
   PD_E(pd_window_attn_fwd_w12),
 };

@@ -273,13 +273,13 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : 2) void wgrad_bf16(WgArgs a)
 // arrive — agent-scope release / ticket / acquire, as csrc/igemm_bf16.hip does for its few-tile problems — sum the slabs inside the main
 // kernel: 17 us of a 58 us launch at 4 slices of 64 tiles, 200 us at 16 slices of 256 tiles; one workgroup walking `splits` x 64 KB with 16
 // loads in flight, plus an L2 write-back per release and an invalidate per acquire.)
-__global__ __launch_bounds__(256) void wgrad_bf16_reduce(WgArgs a)
+__device__ __forceinline__ void wgrad_reduce_body(const WgArgs &a, const int block)
 {
   // 64 float4 positions of a tile per workgroup; the slices are cut into four runs, one per wavefront (8 loads in flight per thread), whose
   // sums are added in run order through LDS — few-tile problems have 32..128 slices and only tiles x 64 workgroups to hide the latency with
   __shared__ float4 part[4][64];
   const int t = threadIdx.x, pos = t & 63, g = t >> 6;
-  const int tile = blockIdx.x >> 6, sub = blockIdx.x & 63;
+  const int tile = block >> 6, sub = block & 63;
   const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
   const float *s0 = a.slabs + (int64_t)tile * a.splits * SLAB_FLOATS;
   const int run = (a.splits + 3) >> 2, s_end = min(a.splits, (g + 1) * run);
@@ -324,6 +324,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce(WgArgs a)
       a.dB[tn * TILE + c] += b;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce(WgArgs a) { wgrad_reduce_body(a, (int)blockIdx.x); }
+
+// the reduce passes of up to PD_WGRAD_SEQ_MAX problems as ONE launch (pd_wgrad_bf16_seq): the four weight gradients of a Swin block each
+// paid a ~10 us second launch of a few hundred small workgroups
+struct WgGroup { WgArgs a[PD_WGRAD_SEQ_MAX]; int first_block[PD_WGRAD_SEQ_MAX + 1]; int count; };
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce_grouped(WgGroup g)
+{
+  int i = 0;
+  while (i + 1 < g.count && (int)blockIdx.x >= g.first_block[i + 1]) ++i;        // (block-uniform)
+  wgrad_reduce_body(g.a[i], (int)blockIdx.x - g.first_block[i]);
 }
 
 struct WgPlan { WgArgs a; int nst; int64_t slab_bytes; };
@@ -398,6 +410,49 @@ extern "C" int pd_wgrad_bf16(const PdWgrad *p, void *workspace, int64_t workspac
   if (rc2 != PD_OK || pl.a.splits == 1 || (pl.a.mode & 4)) return rc2;
   hipLaunchKernelGGL(wgrad_bf16_reduce, dim3((unsigned)(pl.a.tiles * 64)), dim3(256), 0, st, pl.a);
   return pd_check_launch("pd_wgrad_bf16 (reduce)");
+}
+
+extern "C" int64_t pd_wgrad_bf16_seq_workspace_bytes(const PdWgrad *list, int count)
+{
+  if (!list || count <= 0 || count > PD_WGRAD_SEQ_MAX) return -1;
+  int64_t slabs = 0;
+  for (int i = 0; i < count; ++i) {
+    WgPlan pl;
+    if (wg_plan(list + i, pl) != PD_OK) return -1;
+    slabs += pl.slab_bytes;
+  }
+  return slabs ? slabs + WG_HEADER_BYTES : 0;
+}
+
+extern "C" int pd_wgrad_bf16_seq(const PdWgrad *list, int count, void *workspace, int64_t workspace_bytes, void *stream)
+{
+  if (!list || count <= 0 || count > PD_WGRAD_SEQ_MAX) return pd_set_error(PD_ERR_INVALID_ARG, "pd_wgrad_bf16_seq: 1..%d problems", PD_WGRAD_SEQ_MAX);
+  WgPlan pl[PD_WGRAD_SEQ_MAX];
+  int64_t need = 0;
+  for (int i = 0; i < count; ++i) {
+    const int rc = wg_plan(list + i, pl[i]);
+    if (rc != PD_OK) return rc;
+    need += pl[i].slab_bytes;
+  }
+  if (need && (!workspace || workspace_bytes < need + WG_HEADER_BYTES))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_wgrad_bf16_seq: workspace of %lld bytes needed (%lld given)", (long long)(need + WG_HEADER_BYTES), (long long)workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char *slab = reinterpret_cast<unsigned char *>(workspace) + WG_HEADER_BYTES;
+  WgGroup g;
+  g.count = 0;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {                      // every problem its own slab range: the reduce passes run after ALL the main kernels
+    if (pl[i].slab_bytes) { pl[i].a.slabs = reinterpret_cast<float *>(slab); slab += pl[i].slab_bytes; }
+    const int rc = pl[i].nst == 1 ? wg_launch<1>(pl[i], st) : wg_launch<2>(pl[i], st);
+    if (rc != PD_OK) return rc;
+    if (pl[i].a.splits > 1 && !(pl[i].a.mode & 4)) {
+      g.a[g.count] = pl[i].a; g.first_block[g.count] = blocks; blocks += pl[i].a.tiles * 64; ++g.count;
+    }
+  }
+  if (!g.count) return PD_OK;
+  g.first_block[g.count] = blocks;
+  hipLaunchKernelGGL(wgrad_bf16_reduce_grouped, dim3((unsigned)blocks), dim3(256), 0, st, g);
+  return pd_check_launch("pd_wgrad_bf16_seq (reduce)");
 }
 
 extern "C" int pd_wgrad_bf16_time(const PdWgrad *p, void *workspace, int64_t workspace_bytes, int iters, float *us, void *stream)

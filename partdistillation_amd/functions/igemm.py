@@ -228,3 +228,29 @@ def wgrad(dy, x, dw=None, db=None, row_scale=None, out_dtype=torch.bfloat16):
     wsb = workspace(dy.device, need) if need else None
     _lib.check(L.pd_wgrad_bf16(ctypes.byref(d), _p(wsb), wsb.numel() if wsb is not None else 0, _lib.current_stream()))
     return dw
+
+
+WGRAD_SEQ_MAX = 8                                                    # PD_WGRAD_SEQ_MAX of include/pd_igemm.h
+
+
+def wgrad_seq(items):
+    """items: [(dy [M, N], x [M, K], dw [N, K] bf16 / fp32, db fp32 [N] or None)], at most 8 -> the weight gradients of all of them by ONE call
+    (pd_wgrad_bf16_seq: the main launches back to back, one launch for all their slice sums); db += dy.sum(0)"""
+    assert 0 < len(items) <= WGRAD_SEQ_MAX
+    descs = (PdWgrad * len(items))()
+    from .. import cmdbuf
+    rec = cmdbuf.active() is not None
+    for d, (dy, x, dw, db) in zip(descs, items):
+        assert wgrad_supported(dy, x) and dw.dtype in (torch.bfloat16, torch.float32) and dw.stride(1) == 1 and (db is None or (db.dtype == torch.float32 and db.numel() == dy.shape[1]))
+        d.dy, d.x, d.dw, d.db, d.row_scale = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _p(db), None
+        d.m, d.n, d.k, d.ldy, d.ldx, d.ldw, d.dw_f32 = dy.shape[0], dy.shape[1], x.shape[1], dy.stride(0), x.stride(0), dw.stride(0), int(dw.dtype == torch.float32)
+        if rec:
+            for t_, nm in ((dy, "dy"), (x, "x"), (dw, "dw"), (db, "db")):
+                if t_ is not None:
+                    cmdbuf.require_stable(t_.data_ptr(), "pd_wgrad_bf16_seq operand " + nm)
+    L = _lib.load()
+    need = int(L.pd_wgrad_bf16_seq_workspace_bytes(descs, len(items)))
+    if need < 0:
+        _lib.check(-1)
+    wsb = workspace(items[0][0].device, need) if need else None
+    _lib.check(L.pd_wgrad_bf16_seq(descs, len(items), _p(wsb), wsb.numel() if wsb is not None else 0, _lib.current_stream()))

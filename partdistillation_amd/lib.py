@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libpd_hip.so") 
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -140,6 +140,8 @@ SIGNATURES = {
     "pd_igemm_bf16_seq": (_c_int, [_c_vp, _c_int, _c_vp, ctypes.c_int64, _c_vp]),
     "pd_wgrad_bf16_workspace_bytes": (ctypes.c_int64, [_c_vp]),
     "pd_wgrad_bf16": (_c_int, [_c_vp, _c_vp, ctypes.c_int64, _c_vp]),
+    "pd_wgrad_bf16_seq_workspace_bytes": (ctypes.c_int64, [_c_vp, _c_int]),
+    "pd_wgrad_bf16_seq": (_c_int, [_c_vp, _c_int, _c_vp, ctypes.c_int64, _c_vp]),
     "pd_wgrad_bf16_time": (_c_int, [_c_vp, _c_vp, ctypes.c_int64, _c_int, _c_vp, _c_vp]),
     "pd_mx8_quantize_bf16": (_c_int, [_c_vp, ctypes.c_int64, _c_int, ctypes.c_int64, _c_int, _c_vp, _c_vp, _c_vp]),
     "pd_mx8_quantize_table_bytes": (ctypes.c_int64, [_c_int]),

@@ -67,7 +67,7 @@ TR_WGRAD = __import__("os").environ.get("PD_SWIN_TR_WGRAD", "0") != "0"     # Tr
                      # 1536 x 512 .. 2048 x 512 outputs over 8 192 tokens, which are compute-bound.
 
 
-def _wgrad(dy, x, w, b, big=None):
+def _wgrad(dy, x, w, b, big=None, pend=None):
     """weight + bias gradient of a Linear over all tokens of the stage, in the parameters' dtypes.  bf16 parameters (the training
     configuration): the weight gradient is queued in `big` for conv_bf16's grouped transpose-read launch, the bias gradient is a
     column sum.  Otherwise pd_wgrad_bf16 (include/pd_igemm.h) for bf16 operands — 36-46 us at the 10 368-token stage of Swin-B against
@@ -84,6 +84,10 @@ def _wgrad(dy, x, w, b, big=None):
         return dw, db                                        # fp32: cast with the stage's other bias gradients (_cast_bias_grads)
     if OWN_GEMM and igemm.wgrad_supported(dy, x) and (cmdbuf.active() is not None or not igemm.wgrad_prefers_library(dy.shape[0], dy.shape[1], x.shape[1])):
         db = torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device)
+        if pend is not None:                                     # queued: the block's four weight gradients leave by ONE call (pd_wgrad_bf16_seq)
+            dw = torch.empty((dy.shape[1], x.shape[1]), dtype=w.dtype if w.dtype == torch.float32 else torch.bfloat16, device=dy.device)
+            pend.append((dy, x, dw, db))
+            return dw, db
         dw = igemm.wgrad(dy, x, None, db, out_dtype=w.dtype if w.dtype == torch.float32 else torch.bfloat16)   # dW and the column sums of dY in one pass over dY
     elif w.shape[0] * w.shape[1] <= 1_100_000:
         dw, db = smallgemm.wgrad_split(dy, x, True)
@@ -314,7 +318,8 @@ class SwinStage(Function):
             g = grads[k * N_BLOCK:(k + 1) * N_BLOCK]
             table = table if table.is_contiguous() else table.contiguous()
             # MLP
-            g[11], g[12] = _wgrad(df, a, f2w, f2b, big)
+            pend = [] if own else None
+            g[11], g[12] = _wgrad(df, a, f2w, f2b, big, pend)
             if mx:                                               # gradients travel as MX e5m2; the weight gradients keep reading the bf16 copies
                 if dfq is None:                                  # the last block's df comes from the eager prologue: a pass of its own
                     dfq = mx8.quantize(df, gf)
@@ -327,7 +332,7 @@ class SwinStage(Function):
                 da = torch.mm(df, _bf(f2w))
                 dh = torch.ops.aten.gelu_backward(da, h)
                 dy2 = torch.mm(dh, _bf(f1w))
-            g[9], g[10] = _wgrad(dh, y2, f1w, f1b, big)
+            g[9], g[10] = _wgrad(dh, y2, f1w, f1b, big, pend)
             # LayerNorm 2 + the residual it sits on; gradient of the (window-major) proj output rides out as `dr`
             sc1 = dp[k, 0] if dp is not None else None
             if mx:                                               # the rows LayerNorm' writes leave as MX operands of the next input-gradient GEMM
@@ -336,14 +341,16 @@ class SwinStage(Function):
             else:
                 ds2, dpo = rows.ln_bwd(dy2, None, L, dsup, s2, st2, n2w, True, ymap, S, sc1, zero, norm_g[k, 2], norm_g[k, 3], B, L, **rep)
                 dao = igemm.linear(dpo, pw_t) if own else torch.mm(dpo, _bf(pw))
-            g[5], g[6] = _wgrad(dpo, ao.view(-1, C), pw, pb, big)
+            g[5], g[6] = _wgrad(dpo, ao.view(-1, C), pw, pb, big, pend)
             dqkv, dtable = wattn.bwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table, regions, ao,
                                          dao.view(B * nW, wattn.TOKENS, C), lse, spec["scale"], nW,
                                          dtable=tables_g[k] if tables_g is not None else None)
             g[4] = dtable
             dqkv = dqkv.view(-1, 3 * C)
             dy1 = mx8.linear(mx8.quantize(dqkv, gf), wtq[4 * k], a_fmt=gf) if mx else igemm.linear(dqkv, qw_t) if own else torch.mm(dqkv, _bf(qw))
-            g[2], g[3] = _wgrad(dqkv, y1, qw, qb, big)
+            g[2], g[3] = _wgrad(dqkv, y1, qw, qb, big, pend)
+            if pend:
+                igemm.wgrad_seq(pend)
             # LayerNorm 1; for k > 0 its input was (block k-1 stream + DropPath * MLP output): `dr` = that MLP's output gradient
             prev = (dp[k - 1, 1] if dp is not None else None) if k > 0 else None
             if mx and k > 0:

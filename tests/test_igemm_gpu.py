@@ -193,3 +193,22 @@ def test_unsupported_geometry_raises():
         ig.linear(_rand((64, 48), 1), _rand((64, 48), 2))
     with pytest.raises(RuntimeError):
         ig.linear(torch.zeros((64, 64), dtype=torch.bfloat16), torch.zeros((64, 64), dtype=torch.bfloat16))
+
+
+def test_wgrad_seq_equals_the_single_launches():
+    """pd_wgrad_bf16_seq (the four weight gradients of a Swin block by one call: main launches back to back, ONE launch for all their slice
+    sums) gives bit-identical dW / dB to pd_wgrad_bf16 per problem (same slices, same summation order), sliced and unsliced problems mixed"""
+    ig = _ig()
+    M = 5000
+    shapes = [(1536, 512), (512, 512), (2048, 512), (512, 2048), (64, 64)]                 # (N, K): qkv, proj, fc1, fc2 of Swin-B stage 3 + a one-tile problem
+    items, singles = [], []
+    for i, (N, K) in enumerate(shapes):
+        dy, x = _rand((M, N), 50 + i), _rand((M, K), 60 + i)
+        dw, db = torch.empty((N, K), dtype=torch.bfloat16 if i % 2 == 0 else torch.float32, device=DEV), torch.zeros(N, device=DEV)
+        items.append((dy, x, dw, db))
+        db1 = torch.zeros(N, device=DEV)
+        singles.append((ig.wgrad(dy, x, None, db1, out_dtype=dw.dtype), db1))
+    ig.wgrad_seq(items)
+    for (dy, x, dw, db), (dw1, db1) in zip(items, singles):
+        assert torch.equal(dw, dw1) and torch.equal(db, db1)
+        _close(dw, dy.float().t() @ x.float())
