@@ -38,13 +38,16 @@
 extern "C" {
 #endif
 
+/* out_q / out_s (nullable, together): `out` again as an MX-fp8 operand (include/pd_mx8.h: [B_ * 144][C] fp8 of q_format, [B_ * 144][C / 32]
+ * E8M0 bytes) for the proj Linear — a (token, head) piece is one 32-element block */
 int pd_window_attn_fwd_w12(const void *qkv, const float *table, const uint8_t *region, const uint8_t *win_flags, void *out,
-                           float *lse, int B_, int nW, int heads, float scale, void *stream);
+                           float *lse, int B_, int nW, int heads, float scale, void *out_q, void *out_s, int q_format, void *stream);
 
-/* dqkv is written completely; dtable is accumulated into. */
+/* dqkv is written completely; dtable is accumulated into.  dqkv_q / dqkv_s (nullable, together): dqkv again as an MX-fp8 operand
+ * ([B_ * 144][3 C], [B_ * 144][3 C / 32]) for the input gradient of the qkv Linear. */
 int pd_window_attn_bwd_w12(const void *qkv, const float *table, const uint8_t *region, const uint8_t *win_flags,
                            const void *out, const void *d_out, const float *lse, void *dqkv, float *dtable, int B_, int nW,
-                           int heads, float scale, void *stream);
+                           int heads, float scale, void *dqkv_q, void *dqkv_s, int q_format, void *stream);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "mfma_bf16.h"
+#include "mx8_quant.h"
 #include "pd_common.h"
 #include "pd_msda.h"
 #include "pd_window_attention.h"
@@ -45,6 +46,32 @@ constexpr float MASKED = -100.0f * LOG2E;    // the reference's additive -100 in
 __device__ __forceinline__ void mma16(f32x4 &c, bf16x4 x, bf16x4 y) { c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(x, y, c, 0, 0, 0); }
 __device__ __forceinline__ int rel_a(int t) { return t + 11 * ((t * 171) >> 11); }            // t + 11*(t/12), t < 144
 __device__ __forceinline__ void st4(bf16_t *p, float a, float b, float c, float d) { *reinterpret_cast<bf16x4 *>(p) = pack4(a, b, c, d); }
+// The 32 channels of one (token, head) piece sit in four lanes (g = 0..3 of the same c), 8 values each (4 g .. 4 g + 3 and 16 + 4 g ..):
+// exactly one block of the MX-fp8 operand format (include/pd_mx8.h), so the piece can leave as the next GEMM's operand next to its bf16
+// copy — quantised from the bf16-rounded values, block maximum = two cross-lane steps.  q: the piece's 32 bytes, s: its exponent byte.
+template <int FMT>
+__device__ __forceinline__ void st_mx_piece(uint8_t *q, uint8_t *s, int g, const f32x4 &a, const f32x4 &b)
+{
+  const bf16x4 ra = pack4(a[0], a[1], a[2], a[3]), rb = pack4(b[0], b[1], b[2], b[3]);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float((unsigned)(unsigned short)ra[e] << 16); v[4 + e] = __uint_as_float((unsigned)(unsigned short)rb[e] << 16); }
+  float m = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+  m = fmaxf(m, __shfl_xor(m, 16));
+  m = fmaxf(m, __shfl_xor(m, 32));
+  float mult;
+  const unsigned byte = pdmx::mx_exponent<FMT>(m, mult);
+  *reinterpret_cast<unsigned *>(q + 4 * g) = pdmx::mx_pack4<FMT>(v[0], v[1], v[2], v[3], mult);
+  *reinterpret_cast<unsigned *>(q + 16 + 4 * g) = pdmx::mx_pack4<FMT>(v[4], v[5], v[6], v[7], mult);
+  if (g == 0) *s = (uint8_t)byte;
+}
+__device__ __forceinline__ void st_mx_piece(int fmt, uint8_t *q, uint8_t *s, int g, const f32x4 &a, const f32x4 &b)
+{
+  if (fmt == PD_MX8_E4M3) st_mx_piece<PD_MX8_E4M3>(q, s, g, a, b);
+  else st_mx_piece<PD_MX8_E5M2>(q, s, g, a, b);
+}
 __device__ __forceinline__ bf16x4 tr16(bf16x4 x, bf16x4 ident)                                // X[rows][16] -> X^T operand
 {
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -84,7 +111,7 @@ template <bool MASK>
 __global__ __launch_bounds__(THREADS) void wattn_fwd(const bf16_t *__restrict__ qkv, const float *__restrict__ table,
                                                      const uint8_t *__restrict__ region, const uint8_t *__restrict__ flags,
                                                      bf16_t *__restrict__ out, float *__restrict__ lse, int B_, int nW,
-                                                     int heads, float c1, int chunk)
+                                                     int heads, float c1, int chunk, uint8_t *__restrict__ out_q, uint8_t *__restrict__ out_s, int qfmt)
 {
   __shared__ float tbl[TBL + 3];
   __shared__ __attribute__((aligned(16))) bf16_t ks[N * RP];
@@ -147,8 +174,10 @@ __global__ __launch_bounds__(THREADS) void wattn_fwd(const bf16_t *__restrict__ 
     sum += __shfl_xor(sum, 32);
     const float inv = 1.f / sum;
     bf16_t *o = out + ((int64_t)b * N + q) * C + h * D + 4 * g;
-    st4(o, o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
-    st4(o + 16, o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+    o0 *= inv; o1 *= inv;
+    st4(o, o0[0], o0[1], o0[2], o0[3]);
+    st4(o + 16, o1[0], o1[1], o1[2], o1[3]);
+    if (out_q) st_mx_piece(qfmt, out_q + ((int64_t)b * N + q) * C + h * D, out_s + ((int64_t)b * N + q) * (C / 32) + h, g, o0, o1);
     if (g == 0) lse[((int64_t)b * heads + h) * N + q] = m + log2f(sum);
   }
 }
@@ -159,7 +188,7 @@ __global__ __launch_bounds__(THREADS) void wattn_bwd(const bf16_t *__restrict__ 
                                                      const bf16_t *__restrict__ out, const bf16_t *__restrict__ dout,
                                                      const float *__restrict__ lse, bf16_t *__restrict__ dqkv,
                                                      float *__restrict__ dtable, int B_, int nW, int heads, float scale,
-                                                     float c1, int chunk, int ablate)
+                                                     float c1, int chunk, int ablate, uint8_t *__restrict__ dq_q, uint8_t *__restrict__ dq_s, int qfmt)
 {
   __shared__ float tbl[TBL + 3];
   __shared__ __attribute__((aligned(16))) bf16_t tiles[4 * N * RP];
@@ -245,6 +274,11 @@ __global__ __launch_bounds__(THREADS) void wattn_bwd(const bf16_t *__restrict__ 
       st4(dkp + 16, dk1[0], dk1[1], dk1[2], dk1[3]);
       st4(dvp, dv0[0], dv0[1], dv0[2], dv0[3]);
       st4(dvp + 16, dv1[0], dv1[1], dv1[2], dv1[3]);
+      if (dq_q) {                                                         // dqkv again as an MX operand: rows of 3 C elements, 3 C / 32 exponents
+        const int64_t row = (int64_t)b * N + key;
+        st_mx_piece(qfmt, dq_q + row * ld + C + h * D, dq_s + row * (ld / 32) + C / 32 + h, g, dk0, dk1);
+        st_mx_piece(qfmt, dq_q + row * ld + 2 * C + h * D, dq_s + row * (ld / 32) + 2 * (C / 32) + h, g, dv0, dv1);
+      }
     }
     if (!(ablate & 8)) {                                                  // ---- phase 2: this wave's 16 QUERIES -> dQ, dtable
       const int q = 16 * wv + c;
@@ -283,6 +317,7 @@ __global__ __launch_bounds__(THREADS) void wattn_bwd(const bf16_t *__restrict__ 
       bf16_t *dqp = dbase + q * ld + 4 * g;
       st4(dqp, dq0[0], dq0[1], dq0[2], dq0[3]);
       st4(dqp + 16, dq1[0], dq1[1], dq1[2], dq1[3]);
+      if (dq_q) st_mx_piece(qfmt, dq_q + ((int64_t)b * N + q) * ld + h * D, dq_s + ((int64_t)b * N + q) * (ld / 32) + h, g, dq0, dq1);
     }
   }
   if (ABL != 1) {
@@ -350,23 +385,28 @@ int chunk_of(int B_, int heads, float fixed_cost, int wgs_per_cu)
 }  // namespace
 
 extern "C" int pd_window_attn_fwd_w12(const void *qkv, const float *table, const uint8_t *region, const uint8_t *win_flags,
-                                      void *out, float *lse, int B_, int nW, int heads, float scale, void *stream_)
+                                      void *out, float *lse, int B_, int nW, int heads, float scale, void *out_q, void *out_s, int q_format,
+                                      void *stream_)
 {
+  if ((out_q != nullptr) != (out_s != nullptr) || (out_q && q_format != PD_MX8_E4M3 && q_format != PD_MX8_E5M2) || ((uintptr_t)out_q & 3))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_window_attn_fwd_w12: the MX copy needs both pointers (4-byte aligned elements) and a known format");
   int rc = check(qkv, table, region, win_flags, B_, nW, heads, "pd_window_attn_fwd_w12");
   if (rc || B_ == 0) return rc;
   if (!out || !lse) return pd_set_error(PD_ERR_INVALID_ARG, "pd_window_attn_fwd_w12: null output");
   const int chunk = chunk_of(B_, heads, 0.2f, 2);
   const dim3 grid((B_ + chunk - 1) / chunk, heads);
   hipStream_t s = (hipStream_t)stream_;
-  if (region) hipLaunchKernelGGL(wattn_fwd<true>, grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk);
-  else hipLaunchKernelGGL(wattn_fwd<false>, grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk);
+  if (region) hipLaunchKernelGGL(wattn_fwd<true>, grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk, (uint8_t *)out_q, (uint8_t *)out_s, q_format);
+  else hipLaunchKernelGGL(wattn_fwd<false>, grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk, (uint8_t *)out_q, (uint8_t *)out_s, q_format);
   return pd_check_launch("pd_window_attn_fwd_w12");
 }
 
 extern "C" int pd_window_attn_bwd_w12(const void *qkv, const float *table, const uint8_t *region, const uint8_t *win_flags,
                                       const void *out, const void *d_out, const float *lse, void *dqkv, float *dtable, int B_,
-                                      int nW, int heads, float scale, void *stream_)
+                                      int nW, int heads, float scale, void *dqkv_q, void *dqkv_s, int q_format, void *stream_)
 {
+  if ((dqkv_q != nullptr) != (dqkv_s != nullptr) || (dqkv_q && q_format != PD_MX8_E4M3 && q_format != PD_MX8_E5M2) || ((uintptr_t)dqkv_q & 3))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_window_attn_bwd_w12: the MX copy needs both pointers (4-byte aligned elements) and a known format");
   int rc = check(qkv, table, region, win_flags, B_, nW, heads, "pd_window_attn_bwd_w12");
   if (rc || B_ == 0) return rc;
   if (!out || !d_out || !lse || !dqkv || !dtable) return pd_set_error(PD_ERR_INVALID_ARG, "pd_window_attn_bwd_w12: null pointer");
@@ -375,8 +415,8 @@ extern "C" int pd_window_attn_bwd_w12(const void *qkv, const float *table, const
   const int chunk = chunk_of(B_, heads, 1.0f, 1);
   const dim3 grid((B_ + chunk - 1) / chunk, heads);
   hipStream_t s = (hipStream_t)stream_;
-  if (g_pd_dbg_wattn & 1) hipLaunchKernelGGL((wattn_bwd<false, 1>), grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn);
-  else if (region) hipLaunchKernelGGL((wattn_bwd<true, 0>), grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn);
-  else hipLaunchKernelGGL((wattn_bwd<false, 0>), grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn);
+  if (g_pd_dbg_wattn & 1) hipLaunchKernelGGL((wattn_bwd<false, 1>), grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn, (uint8_t *)dqkv_q, (uint8_t *)dqkv_s, q_format);
+  else if (region) hipLaunchKernelGGL((wattn_bwd<true, 0>), grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn, (uint8_t *)dqkv_q, (uint8_t *)dqkv_s, q_format);
+  else hipLaunchKernelGGL((wattn_bwd<false, 0>), grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn, (uint8_t *)dqkv_q, (uint8_t *)dqkv_s, q_format);
   return pd_check_launch("pd_window_attn_bwd_w12");
 }

@@ -38,21 +38,27 @@ def shifted_window_regions(H, W, shift, device):
     return _REGIONS[key]
 
 
-def fwd_raw(qkv, table, regions, scale, n_windows):
+def fwd_raw(qkv, table, regions, scale, n_windows, mx=None):
+    """-> (out bf16 [B_, 144, C], lse) and, with mx = an fp8 format of functions/mx8.py, out again as an MX operand (q uint8 [B_ * 144, C],
+    exponents uint8 [B_ * 144, C / 32])"""
     B_, heads = qkv.shape[0], table.shape[1]
     assert qkv.is_contiguous() and qkv.dtype == torch.bfloat16 and table.dtype == torch.float32 and table.is_contiguous()
     out = torch.empty((B_, TOKENS, heads * HEAD_DIM), dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty((B_, heads, TOKENS), dtype=torch.float32, device=qkv.device)
     reg, flags = regions if regions is not None else (None, None)
+    C = heads * HEAD_DIM
+    oq = torch.empty((B_ * TOKENS, C), dtype=torch.uint8, device=qkv.device) if mx is not None else None
+    osc = torch.empty((B_ * TOKENS, C // 32), dtype=torch.uint8, device=qkv.device) if mx is not None else None
     _lib.check(_lib.load().pd_window_attn_fwd_w12(qkv.data_ptr(), table.data_ptr(), reg.data_ptr() if reg is not None else None,
                                                   flags.data_ptr() if flags is not None else None, out.data_ptr(), lse.data_ptr(),
-                                                  B_, n_windows, heads, float(scale), _lib.current_stream()))
-    return out, lse
+                                                  B_, n_windows, heads, float(scale), oq.data_ptr() if mx is not None else None,
+                                                  osc.data_ptr() if mx is not None else None, mx if mx is not None else 0, _lib.current_stream()))
+    return (out, lse) if mx is None else (out, lse, (oq, osc))
 
 
-def bwd_raw(qkv, table, regions, out, d_out, lse, scale, n_windows, dtable=None):
+def bwd_raw(qkv, table, regions, out, d_out, lse, scale, n_windows, dtable=None, mx=None):
     """dtable: a ZERO-FILLED fp32 [529, heads] slot for the bias-table gradient (a stage hands out slices of one buffer, one fill
-    for all its blocks); None allocates one"""
+    for all its blocks); None allocates one.  mx = an fp8 format: -> (dqkv, dtable, (q, exponents)), dqkv again as an MX operand"""
     B_, heads = qkv.shape[0], table.shape[1]
     assert d_out.is_contiguous() and d_out.dtype == torch.bfloat16
     dqkv = torch.empty_like(qkv)
@@ -61,11 +67,15 @@ def bwd_raw(qkv, table, regions, out, d_out, lse, scale, n_windows, dtable=None)
     else:
         assert dtable.shape == table.shape and dtable.dtype == table.dtype and dtable.is_contiguous()
     reg, flags = regions if regions is not None else (None, None)
+    C3 = qkv.shape[-1]
+    dq = torch.empty((B_ * TOKENS, C3), dtype=torch.uint8, device=qkv.device) if mx is not None else None
+    dsc = torch.empty((B_ * TOKENS, C3 // 32), dtype=torch.uint8, device=qkv.device) if mx is not None else None
     _lib.check(_lib.load().pd_window_attn_bwd_w12(qkv.data_ptr(), table.data_ptr(), reg.data_ptr() if reg is not None else None,
                                                   flags.data_ptr() if flags is not None else None, out.data_ptr(), d_out.data_ptr(),
                                                   lse.data_ptr(), dqkv.data_ptr(), dtable.data_ptr(), B_, n_windows, heads,
-                                                  float(scale), _lib.current_stream()))
-    return dqkv, dtable
+                                                  float(scale), dq.data_ptr() if mx is not None else None, dsc.data_ptr() if mx is not None else None,
+                                                  mx if mx is not None else 0, _lib.current_stream()))
+    return (dqkv, dtable) if mx is None else (dqkv, dtable, (dq, dsc))
 
 
 class WindowAttention12(Function):

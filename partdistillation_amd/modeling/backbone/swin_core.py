@@ -223,8 +223,12 @@ class SwinStage(Function):
             else:
                 s1, y1, st1 = rows.ln_fwd(cur, r, None, L, rscale, n1w, n1b, spec["eps"], ymap, S, zero, B, L)
                 qkv = _lin(y1, qw, qb)
-            ao, lse = wattn.fwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table, regions, spec["scale"], nW)
-            po = mx8.linear(mx8.quantize(ao.view(-1, C)), wq[4 * k + 1], pb) if mx else _lin(ao.view(-1, C), pw, pb)
+            if mx:                                              # a (token, head) piece of the attention output is one MX block: it leaves quantised
+                ao, lse, aoq = wattn.fwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table, regions, spec["scale"], nW, mx=mx8.E4M3)
+                po = mx8.linear(aoq, wq[4 * k + 1], pb)
+            else:
+                ao, lse = wattn.fwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table, regions, spec["scale"], nW)
+                po = _lin(ao.view(-1, C), pw, pb)
             sc1 = dp[k, 0] if dp is not None else None
             if mx:                                              # fc1's epilogue hands fc2 its operand: GELU(h) again as MX e4m3 along the 4 C axis
                 s2, y2, st2, y2q = rows.ln_fwd(s1, po, ymap, S, sc1, n2w, n2b, spec["eps"], None, L, None, B, L, mx=mx8.E4M3)
@@ -342,12 +346,19 @@ class SwinStage(Function):
                 ds2, dpo = rows.ln_bwd(dy2, None, L, dsup, s2, st2, n2w, True, ymap, S, sc1, zero, norm_g[k, 2], norm_g[k, 3], B, L, **rep)
                 dao = igemm.linear(dpo, pw_t) if own else torch.mm(dpo, _bf(pw))
             g[5], g[6] = _wgrad(dpo, ao.view(-1, C), pw, pb, big, pend)
-            dqkv, dtable = wattn.bwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table, regions, ao,
-                                         dao.view(B * nW, wattn.TOKENS, C), lse, spec["scale"], nW,
-                                         dtable=tables_g[k] if tables_g is not None else None)
+            if mx:
+                dqkv, dtable, dqkvq = wattn.bwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table, regions, ao,
+                                                    dao.view(B * nW, wattn.TOKENS, C), lse, spec["scale"], nW,
+                                                    dtable=tables_g[k] if tables_g is not None else None, mx=gf)
+                dqkv = dqkv.view(-1, 3 * C)
+                dy1 = mx8.linear(dqkvq, wtq[4 * k], a_fmt=gf)
+            else:
+                dqkv, dtable = wattn.bwd_raw(qkv.view(B * nW, wattn.TOKENS, 3 * C), table, regions, ao,
+                                             dao.view(B * nW, wattn.TOKENS, C), lse, spec["scale"], nW,
+                                             dtable=tables_g[k] if tables_g is not None else None)
+                dqkv = dqkv.view(-1, 3 * C)
+                dy1 = igemm.linear(dqkv, qw_t) if own else torch.mm(dqkv, _bf(qw))
             g[4] = dtable
-            dqkv = dqkv.view(-1, 3 * C)
-            dy1 = mx8.linear(mx8.quantize(dqkv, gf), wtq[4 * k], a_fmt=gf) if mx else igemm.linear(dqkv, qw_t) if own else torch.mm(dqkv, _bf(qw))
             g[2], g[3] = _wgrad(dqkv, y1, qw, qb, big, pend)
             if pend:
                 igemm.wgrad_seq(pend)

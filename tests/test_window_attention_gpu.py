@@ -75,6 +75,21 @@ def test_window_attention_fwd_bwd(heads, images, H, W, shift):
     _close(out, ro, 2e-2, "out")
     _close(dqkv, rq, 2e-2, "dqkv")
     _close(dtable, rt, 2e-2, "dtable")
+    # the MX-fp8 copies of out / dqkv (include/pd_mx8.h: a (token, head) piece = one 32-element block): the same bf16 tensors, and their
+    # quantisation bit-exact against oracle/mx8_ref.py
+    from oracle import mx8_ref as MX
+    q_, t_ = qkv.detach(), table.detach()
+    out0, lse0 = wa.fwd_raw(q_, t_, regions, scale, nW)
+    for fmt in (0, 1):
+        out1, lse1, (oq, osc) = wa.fwd_raw(q_, t_, regions, scale, nW, mx=fmt)
+        assert torch.equal(out1, out0) and torch.equal(lse1, lse0)
+        rq8, rs8 = MX.quantize(out1.view(-1, C).cpu(), fmt)
+        assert torch.equal(oq.cpu(), rq8) and torch.equal(osc.cpu(), rs8)
+        d0, dt0 = wa.bwd_raw(q_, t_, regions, out0, go, lse0, scale, nW)
+        d1, dt1, (dq8, ds8) = wa.bwd_raw(q_, t_, regions, out0, go, lse0, scale, nW, mx=fmt)
+        assert torch.equal(d1, d0)
+        rq8, rs8 = MX.quantize(d1.view(-1, 3 * C).cpu(), fmt)
+        assert torch.equal(dq8.cpu(), rq8) and torch.equal(ds8.cpu(), rs8)
 
 
 def test_window_attention_rejects_bad_arguments():
