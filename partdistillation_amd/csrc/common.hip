@@ -48,6 +48,7 @@ extern int g_pd_dbg_wattn;
 extern int g_pd_dbg_x3;
 extern int g_pd_dbg_kmeans;
 extern int g_pd_dbg_conv_group_rows;
+extern int g_pd_dbg_conv_xcd_major;
 extern int g_pd_dbg_sgemm_deep;
 extern int g_ig_bn, g_ig_nst, g_ig_splits;
 extern int g_mx_bn, g_mx_nst;
@@ -77,6 +78,7 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!strcmp(key, "ig_splits")) { g_ig_splits = value; return PD_OK; }
   if (!strcmp(key, "sgemm_deep")) { g_pd_dbg_sgemm_deep = value; return PD_OK; }
   if (!strcmp(key, "conv_group_rows")) { g_pd_dbg_conv_group_rows = value; return PD_OK; }
+  if (!strcmp(key, "conv_xcd_major")) { g_pd_dbg_conv_xcd_major = value; return PD_OK; }
   if (!strcmp(key, "x3_ablate")) { g_pd_dbg_x3 = value; return PD_OK; }
   if (!strcmp(key, "f16x2_tile")) { g_pd_dbg_f16x2 = value; return PD_OK; }
   if (!strcmp(key, "wgrad_wide")) { g_pd_dbg_wgrad_wide = value; return PD_OK; }

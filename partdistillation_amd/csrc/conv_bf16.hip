@@ -398,12 +398,29 @@ __device__ __forceinline__ int find_problem(const WgradProblem *tab, int count, 
   return p;
 }
 
+// Workgroup g runs on XCD g % 8 and the XCDs' L2s do not share lines.  The tiles of ONE slice of pixels read the same dZ / X rows (a 3 x 3
+// layer's nine taps: five 128-wide K tiles over the same pixels), so they should meet in ONE L2: the problem's workgroups are renumbered
+// XCD-major — position = (workgroups of the problem on lower-numbered XCDs) + (rank among this XCD's) — and position p is (slice p / tiles,
+// tile p % tiles): an XCD then owns runs of whole slices.  A bijection for any first block / count.
+__device__ __forceinline__ int xcd_major_position(int first, int n, int g)
+{
+  const int x = g & 7;
+  int pos = 0;
+#pragma unroll
+  for (int y = 0; y < 7; ++y) {
+    const int f = first + ((y - first) & 7);               // the problem's first workgroup on XCD y
+    if (y < x && f < first + n) pos += (first + n - 1 - f) / 8 + 1;
+  }
+  return pos + (g - (first + ((x - first) & 7))) / 8;
+}
+
 template <int WN, int WK>
-__global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr_grouped(const WgradProblem *__restrict__ tab, int count, float *__restrict__ ws)
+__global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr_grouped(const WgradProblem *__restrict__ tab, int count, float *__restrict__ ws, int xcd_major)
 {
   const int p = find_problem(tab, count, blockIdx.x, false);
   const WgradProblem &pr = tab[p];
-  wgrad_body<WN, WK>(pr.dz, pr.x, ws + pr.ws_off, pr.g, blockIdx.x - pr.block_begin, pr.db);
+  const int bid = xcd_major ? xcd_major_position(pr.block_begin, pr.g.tiles * pr.splits, (int)blockIdx.x) : (int)blockIdx.x - pr.block_begin;
+  wgrad_body<WN, WK>(pr.dz, pr.x, ws + pr.ws_off, pr.g, bid, pr.db);
 }
 
 // dW (bf16) = sum over splits of the partial tiles (register order: element (ij, e) of thread t at ((ij * 16 + e) * 256 + t))
@@ -539,6 +556,7 @@ extern "C" int pd_conv_bf16_wgrad(const void *dz, const void *x, void *dw, float
 
 // ------------------------------------------------------------------------------------------------ grouped filter gradients
 int g_pd_dbg_conv_group_rows = 0;                        // tools/ only (pd_debug_set "conv_group_rows")
+int g_pd_dbg_conv_xcd_major = 1;                         // tools/ only (pd_debug_set "conv_xcd_major"): 0 = the tiles of a slice round-robin over the XCDs
 namespace {
 #define kGroupRows (g_pd_dbg_conv_group_rows > 0 ? g_pd_dbg_conv_group_rows : 2048)   // pixels per workgroup in a grouped launch
 
@@ -628,7 +646,7 @@ extern "C" int pd_conv_bf16_wgrad_grouped(const PdConvWgradDesc *descs, int coun
   const WgradProblem *dt = reinterpret_cast<const WgradProblem *>(table_device);
 #define PD_GROUP(V, WN, WK)                                                                                                         \
   if (n_of[V]) {                                                                                                                    \
-    hipLaunchKernelGGL((conv_wgrad_bf16_tr_grouped<WN, WK>), dim3((unsigned)blocks[V]), dim3(256), 0, st, dt + start[V], n_of[V], workspace); \
+    hipLaunchKernelGGL((conv_wgrad_bf16_tr_grouped<WN, WK>), dim3((unsigned)blocks[V]), dim3(256), 0, st, dt + start[V], n_of[V], workspace, g_pd_dbg_conv_xcd_major); \
     hipLaunchKernelGGL((conv_wgrad_reduce_grouped<WN, WK>), dim3((unsigned)rblocks[V]), dim3(256), 0, st, dt + start[V], n_of[V],    \
                        (const float *)workspace);                                                                                   \
   }
