@@ -20,6 +20,7 @@
 
 #include "mfma_bf16.h"
 #include "pd_common.h"
+#include "xcd.h"
 #include "pd_conv.h"
 #include "pd_msda.h"
 
@@ -398,28 +399,15 @@ __device__ __forceinline__ int find_problem(const WgradProblem *tab, int count, 
   return p;
 }
 
-// Workgroup g runs on XCD g % 8 and the XCDs' L2s do not share lines.  The tiles of ONE slice of pixels read the same dZ / X rows (a 3 x 3
-// layer's nine taps: five 128-wide K tiles over the same pixels), so they should meet in ONE L2: the problem's workgroups are renumbered
-// XCD-major — position = (workgroups of the problem on lower-numbered XCDs) + (rank among this XCD's) — and position p is (slice p / tiles,
-// tile p % tiles): an XCD then owns runs of whole slices.  A bijection for any first block / count.
-__device__ __forceinline__ int xcd_major_position(int first, int n, int g)
-{
-  const int x = g & 7;
-  int pos = 0;
-#pragma unroll
-  for (int y = 0; y < 7; ++y) {
-    const int f = first + ((y - first) & 7);               // the problem's first workgroup on XCD y
-    if (y < x && f < first + n) pos += (first + n - 1 - f) / 8 + 1;
-  }
-  return pos + (g - (first + ((x - first) & 7))) / 8;
-}
-
+// The tiles of ONE slice of pixels read the same dZ / X rows (a 3 x 3 layer's nine taps: five 128-wide K tiles over the same pixels), so they
+// should meet in ONE L2: the problem's workgroups are renumbered XCD-major (xcd.h) and position p is (slice p / tiles, tile p % tiles) — an XCD
+// then owns runs of whole slices.
 template <int WN, int WK>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr_grouped(const WgradProblem *__restrict__ tab, int count, float *__restrict__ ws, int xcd_major)
 {
   const int p = find_problem(tab, count, blockIdx.x, false);
   const WgradProblem &pr = tab[p];
-  const int bid = xcd_major ? xcd_major_position(pr.block_begin, pr.g.tiles * pr.splits, (int)blockIdx.x) : (int)blockIdx.x - pr.block_begin;
+  const int bid = xcd_major ? pd_xcd_major(pr.block_begin, pr.g.tiles * pr.splits, (int)blockIdx.x) : (int)blockIdx.x - pr.block_begin;
   wgrad_body<WN, WK>(pr.dz, pr.x, ws + pr.ws_off, pr.g, bid, pr.db);
 }
 

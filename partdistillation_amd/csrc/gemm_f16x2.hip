@@ -24,6 +24,7 @@
 
 #include "f16x2.h"
 #include "pd_common.h"
+#include "xcd.h"
 #include "pd_gemm.h"
 #include "pd_msda.h"
 
@@ -35,7 +36,7 @@
 
 namespace {
 using namespace pdh2;
-__device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
+__device__ __forceinline__ int xcd_chunk(int bid, int nb) { return pd_xcd_chunk(bid, nb); }   // xcd.h: any workgroup count
 
 // TM x TN tile, waves laid out (TM / 64) x (TN / WN), each wave 64 x WN = 2 x (WN / 32) MFMA tiles.
 // LDS: [stage][plane][k panel of 8][row][8 halves]: an MFMA operand (8 consecutive k of row lane % 32, panel lane / 32 of the

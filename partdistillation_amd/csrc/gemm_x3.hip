@@ -18,6 +18,7 @@
 #include "f16x2.h"
 #include "mfma_bf16.h"
 #include "pd_common.h"
+#include "xcd.h"
 #include "pd_gemm.h"
 #include "pd_msda.h"
 
@@ -55,7 +56,7 @@ __device__ __forceinline__ hwbf16x8 frag(const bf16_t *p)
 }
 __device__ __forceinline__ void mma16k(f32x16 &c, hwbf16x8 x, hwbf16x8 y) { c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0); }
 
-__device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
+__device__ __forceinline__ int xcd_chunk(int bid, int nb) { return pd_xcd_chunk(bid, nb); }   // xcd.h: any workgroup count
 
 __device__ int g_wgrad_xcd = 1;   // tools only (pd_debug_set "wgrad_xcd" 0: launch order = logical order)
 __device__ int g_wgrad_fast = 1;  // tools only (pd_debug_set "wgrad_fast" 0: the guarded step everywhere)

@@ -30,6 +30,7 @@
 #include "gelu.h"
 #include "mfma_bf16.h"
 #include "pd_common.h"
+#include "xcd.h"
 #include "pd_igemm.h"
 #include "pd_msda.h"
 
@@ -63,7 +64,7 @@ struct IgArgs {
   int ntn, ntiles;
 };
 
-__device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
+__device__ __forceinline__ int xcd_chunk(int bid, int nb) { return pd_xcd_chunk(bid, nb); }   // xcd.h: any workgroup count
 __device__ __forceinline__ float gelu_f(float x) { return pdgelu::gelu(x); }
 __device__ __forceinline__ float gelu_grad_f(float x) { return pdgelu::gelu_grad(x); }
 

@@ -25,6 +25,7 @@
 
 #include "mfma_bf16.h"
 #include "pd_common.h"
+#include "xcd.h"
 #include "pd_igemm.h"
 #include "pd_msda.h"
 
@@ -54,7 +55,7 @@ struct WgArgs {
   int mode;                                              // tools/ only, bits: 1 no arithmetic, 2 no global loads, 4 no epilogue
 };
 
-__device__ __forceinline__ int xcd_chunk(int bid, int nb) { return (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
+__device__ __forceinline__ int xcd_chunk(int bid, int nb) { return pd_xcd_chunk(bid, nb); }   // xcd.h: any workgroup count
 
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
