@@ -190,15 +190,39 @@ __global__ __launch_bounds__(256) void attn_fwd_combine(const float *__restrict_
   const int g = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
   if (g >= B * H * Lq) return;
   const int qi = g % Lq, bh = g / Lq, h = bh % H, b = bh / H;
+  // (up to 64 chunks at 16 384 keys: the loads of eight chunks are issued together — one load per iteration was a chain of ~60 latencies)
   float M = -INFINITY;
-  for (int c = 0; c < nchunk; ++c) M = fmaxf(M, part_ml[(((int64_t)bh * nchunk + c) * Lq + qi) * 2]);
+  const float2 *ml = reinterpret_cast<const float2 *>(part_ml) + (int64_t)bh * nchunk * Lq + qi;
+  const float *po = part_o + ((int64_t)bh * nchunk * Lq + qi) * D + d;
+  int c = 0;
+  for (; c + 8 <= nchunk; c += 8) {
+    float m8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) m8[u] = ml[(int64_t)(c + u) * Lq].x;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) M = fmaxf(M, m8[u]);
+  }
+  for (; c < nchunk; ++c) M = fmaxf(M, ml[(int64_t)c * Lq].x);
   float L = 0.f, acc = 0.f;
   if (M != -INFINITY) {
-    for (int c = 0; c < nchunk; ++c) {
-      const int64_t base = ((int64_t)bh * nchunk + c) * Lq + qi;
-      const float w = __expf(part_ml[base * 2] - M);
-      L += w * part_ml[base * 2 + 1];
-      acc += w * part_o[base * D + d];
+    c = 0;
+    for (; c + 8 <= nchunk; c += 8) {
+      float2 s8[8];
+      float o8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s8[u] = ml[(int64_t)(c + u) * Lq]; o8[u] = po[(int64_t)(c + u) * Lq * D]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {                        // same chunk order as the one-by-one loop: identical sums
+        const float w = __expf(s8[u].x - M);
+        L += w * s8[u].y;
+        acc += w * o8[u];
+      }
+    }
+    for (; c < nchunk; ++c) {
+      const float2 sv = ml[(int64_t)c * Lq];
+      const float w = __expf(sv.x - M);
+      L += w * sv.y;
+      acc += w * po[(int64_t)c * Lq * D];
     }
   }
   const float outv = L > 0.f ? acc / L : 0.f;
