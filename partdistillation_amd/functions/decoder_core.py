@@ -50,6 +50,9 @@ def _small(x, cdt, limit=None):
     return cdt == torch.bfloat16 and x.shape[0] <= (SMALL_M if limit is None else limit)
 
 
+KV_IGEMM_ROWS = int(__import__("os").environ.get("PD_KV_IGEMM_ROWS", "4096"))   # memory rows from which the decoder's key / value projections run on pd_igemm_bf16
+
+
 def _lin(x, w, b, relu=False):
     """x W^T + b (ReLU)"""
     if _small(x, x.dtype) and w.shape[1] % 64 == 0:
@@ -246,7 +249,13 @@ class DecoderCore(Function):
             lvl = i % nl
             (ciw, cib, cow, cob, cnw, cnb, siw, sib, sow, sob, snw, snb, w1, b1, w2, b2, fnw, fnb) = layers[i]
             # ---- masked cross-attention
-            if multi:                                              # q, k, v projections: one launch (two inputs, three weight slices)
+            if multi and mem[lvl].shape[0] >= KV_IGEMM_ROWS and igemm.supported(C, C):
+                # key / value projections over >= 4 096 memory rows are real GEMMs (level 2: 32 768 x 256 -> 256 twice): on pd_igemm_bf16
+                # 2 x 18 us where the skinny multi-problem launch took 89 (107 TFLOP/s); the 200-row query projection stays a skinny launch
+                q = _lin(tgtpos_c, ciw[:C], cib[:C])
+                k = igemm.linear(mempos[lvl], ciw[C:2 * C], cib[C:2 * C])
+                v = igemm.linear(mem[lvl], ciw[2 * C:], cib[2 * C:])
+            elif multi:                                            # q, k, v projections: one launch (two inputs, three weight slices)
                 q, k, v = sg.linear_multi([(tgtpos_c, ciw[:C], cib[:C]), (mempos[lvl], ciw[C:2 * C], cib[C:2 * C]), (mem[lvl], ciw[2 * C:], cib[2 * C:])])
             else:
                 q = _lin(tgtpos_c, ciw[:C], cib[:C])
