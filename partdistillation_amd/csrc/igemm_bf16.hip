@@ -378,15 +378,20 @@ int make_plan(const PdIgemm *p, Plan &pl)
   a.act = p->act; a.gate_mode = p->gate_mode; a.res_mode = p->res_mode; a.bias_bf16 = p->bias_bf16;
   // tile width: 128 columns, or 64 when n is not a multiple of 128 or when 128-wide tiles would leave most workgroup slots empty
   const int mt = (a.M + BM - 1) / BM;
+  const bool plain = p->k == 1 && p->stride == 1 && !p->dgrad && p->hs == p->ho && p->ws == p->wo;   // (the instantiation launch() picks)
   pl.bn = (p->n % 128 == 0) ? 128 : 64;
-  if (pl.bn == 128 && (mt * (p->n / 128) < 512 || (p->n < 384 && a.KT < 8))) pl.bn = 64;
+  // 64-wide tiles when 128-wide ones would leave most workgroup slots empty.  Plain-rows problems (Linears, 1 x 1 convolutions) flip at ~400
+  // tiles, not 512 (second sweep, profiles/r04_igemm_sweep_v2.txt: 4 608 x 1 536 <- 1 536, 432 tiles: 31.7 us 128-wide, 38.4 64-wide;
+  // <- 6 144: 108 vs 136; 10 368 x 512 <- 2 048, 324 tiles: 38.2 vs 33.4)
+  if (pl.bn == 128 && (mt * (p->n / 128) < (plain ? 400 : 512) || (p->n < 384 && a.KT < 8))) pl.bn = 64;
   if (g_ig_bn == 64 || (g_ig_bn == 128 && p->n % 128 == 0)) pl.bn = g_ig_bn;
   a.ntn = p->n / pl.bn;
   a.ntiles = mt * a.ntn;
   // stages: one (32 KB, four workgroups per CU) for short contractions, two (one step of prefetch, two per CU) for long ones
-  // (tools/bench_igemm.py sweep: 128-wide tiles run best on one stage with four workgroups per CU up to K = 4096; 64-wide tiles
-  // with the ring from K = 1024, with one step of prefetch from K = 512)
-  pl.nst = pl.bn == 128 ? (a.KT >= 64 ? 2 : 1) : (a.KT >= 16 ? 3 : a.KT >= 8 ? 2 : 1);
+  // (tools/bench_igemm.py sweep: 128-wide tiles run best on one stage with four workgroups per CU up to K = 4096; 64-wide tiles with one
+  // step of prefetch from K = 512 — and, for the gathered (3 x 3 / strided) problems only, with the three-stage ring from K = 1024: plain
+  // rows measured 33.4 vs 41.2 us (10 368 x 512 <- 2 048) and 40.7 vs 42.0 (2 592 x 1 024 <- 4 096) in favour of two stages)
+  pl.nst = pl.bn == 128 ? (a.KT >= 64 ? 2 : 1) : (a.KT >= 16 && !plain ? 3 : a.KT >= 8 ? 2 : 1);
   if (g_ig_nst >= 1 && g_ig_nst <= 3) pl.nst = g_ig_nst;
   // split-K: only when the tiles alone leave most workgroup slots empty AND the contraction is long (every split costs a
   // 32-64 KB slab written and read back)
