@@ -229,7 +229,13 @@ def test_config4_full_size_labels_equal_dense_reference_labelling(metric, monkey
         newc = torch.stack([X[assign == k].mean(0) for k in range(4)])
         shift = ((newc - cen) ** 2).sum().item()
         tol = 1e-4 * X.var(0).mean().item()                                                              # sklearn's tol * mean variance
-        assert r["kmeans_iterations"] >= 1 and (shift <= tol * 4 or r["kmeans_iterations"] >= 300), (shift, tol, r["kmeans_iterations"])
+        # a point whose two nearest centres tie to fp32 re-association noise may sit in the other cluster here than on the device: each
+        # such point moves two centres by at most |x - c| / (cluster size) — (2 |x|_max / n_min)^2 of squared shift per near-tie point
+        top2 = (-d2).topk(2, dim=1)[0]
+        near = int(((top2[:, 0] - top2[:, 1]) <= 1e-4 * d2.abs().max()).sum())
+        n_min = min(int((assign == k).sum()) for k in range(4))
+        slack = near * (2.0 * float(X.norm(dim=1).max()) / max(n_min, 1)) ** 2
+        assert r["kmeans_iterations"] >= 1 and (shift <= tol * 4 + slack or r["kmeans_iterations"] >= 300), (shift, tol, slack, near, r["kmeans_iterations"])
     print(f"config 4 full size ({metric}): worst label mismatch {worst:.2e} of the object's pixels; Lloyd iterations "
           f"{[int(r['kmeans_iterations']) for r in res]}")
 
