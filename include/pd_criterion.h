@@ -1,14 +1,23 @@
 /*
- * pd_criterion.h — C-ABI of the matcher / criterion kernels of libpd_hip.so.
+ * pd_criterion.h — C-ABI of the matcher / criterion kernels of libpd_hip.so: the assignment solver, and the arithmetic between the
+ * sampled point logits and the losses of modeling/criterion.py / modeling/matcher.py, which the reference (and rounds 1-3 here) run
+ * as chains of eager elementwise / reduction / top-k launches over small tensors.
  *
- * These replace, on the device, work the reference does through PyTorch +
- * SciPy on the host side of the training step:
- *   pd_lsa_batched   scipy.optimize.linear_sum_assignment + the cost-ordered
- *                    pair sort, reference part_distillation/modeling/matcher.py:159-163
- *                    (there: C.cpu() -> SciPy -> topk; one D2H sync per image
- *                    per decoder layer).
- * All pointers are device pointers; `stream` is a hipStream_t.  Return 0 or a
- * negative PD_ERR_* (pd_msda.h); message via pd_last_error().
+ *   pd_lsa_batched            scipy.optimize.linear_sum_assignment + the cost-ordered pair sort, reference matcher.py:159-163
+ *                             (there: C.cpu() -> SciPy -> topk; one D2H sync per image per decoder layer).
+ *   pd_matcher_costs          the Hungarian cost matrix of every (image, head) problem in one pass over the point logits —
+ *                             reference matcher.py:108-158 (batch_sigmoid_ce_loss_jit :38-62, batch_dice_loss_jit :13-35, cost_class
+ *                             :122, the weighted sum :150-154).  Replaces softplus / sigmoid / two row sums, two batched GEMMs with
+ *                             n_targets output columns, a softmax gather and ~20 elementwise launches; the fp32 copies of the
+ *                             logits and their sigmoids (2 x 100 MB at BASELINE config 2) are never written.
+ *   pd_mask_point_losses_*    sigmoid_ce_loss (criterion.py:50-69) and dice_loss (:25-47) of the matched masks at their sampled
+ *                             points, per mask, and their gradient with respect to the point logits.
+ *   pd_uncertain_points       get_uncertain_point_coords_with_randomness (criterion.py:181-189, detectron2 point_rend): of K
+ *                             oversampled points per mask keep the k with the smallest |logit| (calculate_uncertainty :72-88 is
+ *                             -|logit|), followed by the mask's random points — replaces abs, neg, a multi-block top-k, a gather
+ *                             and a concatenation.
+ *
+ * Device pointers, fp32 unless stated; `stream` = hipStream_t; returns 0 or a negative PD_ERR_* (pd_msda.h).
  */
 #ifndef PD_CRITERION_H
 #define PD_CRITERION_H
@@ -32,7 +41,43 @@ extern "C" {
 int pd_lsa_batched(const float *cost, const int32_t *ncols, int64_t *out_rows, int64_t *out_cols,
                    int nbatch, int nrows, int ncols_max, void *stream);
 
+/*
+ * Problem p = b * heads + d (image b, decoder output d) has Q queries and n_targets (padded) target columns.
+ *   x        [problems, Q, n] point logits of the queries, dtype PD_F32 / PD_BF16 (converted to fp32 on load)
+ *   t        target masks sampled at the same points: t[b * t_image_stride + d * t_head_stride + j * t_target_stride + i], i < n
+ *            (so the sampler's [B, n_targets, heads * n] output is read in place)
+ *   prob     [problems, Q, classes] class probabilities (softmax / sigmoid of the logits), labels int64 [B, n_targets]
+ *   cost     [problems, Q, n_targets] =
+ *              w_mask  * (sum_i softplus(x_i) - sum_i x_i t_ji) / n
+ *            + w_dice  * (1 - (2 sum_i sigmoid(x_i) t_ji + 1) / (sum_i sigmoid(x_i) + sum_i t_ji + 1))
+ *            - w_class * prob[label_j]
+ * softplus as torch's (beta 1, threshold 20).  Padded columns (all-zero targets, label 0) get finite costs nobody reads.
+ */
+int pd_matcher_costs(const void *x, int dtype, const float *t, int64_t t_image_stride, int64_t t_head_stride, int64_t t_target_stride,
+                     const float *prob, const int64_t *labels, float *cost, int problems, int heads, int Q, int n, int n_targets,
+                     int classes, float w_mask, float w_class, float w_dice, void *stream);
+
+/*
+ * x, y [rows, n] (point logits, sampled target masks in [0, 1]) ->
+ *   bce[r]  = mean_i ( max(x, 0) - x y + log1p(exp(-|x|)) )                       (F.binary_cross_entropy_with_logits, mean over points)
+ *   dice[r] = 1 - (2 sum_i s_i y_i + 1) / (sum_i s_i + sum_i y_i + 1),  s = sigmoid(x)
+ *   stats   [rows, 3] = (sum s y, sum s, sum y): what the backward needs besides x and y
+ */
+int pd_mask_point_losses_fwd(const float *x, const float *y, float *bce, float *dice, float *stats, int rows, int n, void *stream);
+/* dx[r, i] = d_bce[r] * (s_i - y_i) / n - d_dice[r] * (2 y_i den - num) / den^2 * s_i (1 - s_i),  num = 2 sum s y + 1, den = sum s + sum y + 1 */
+int pd_mask_point_losses_bwd(const float *x, const float *y, const float *stats, const float *d_bce, const float *d_dice, float *dx,
+                             int rows, int n, void *stream);
+
+/*
+ * logits [rows, K], coords [rows, K, 2], random_coords [rows, n_random, 2] (nullable when n_random = 0) ->
+ * out [rows, k + n_random, 2]: the coordinates of the k points with the smallest |logit| — those below the k-th smallest value in index
+ * order, then the lowest-index points equal to it —, then the row's random coordinates.  Deterministic.  1 <= k <= K <= PD_UNCERTAIN_MAX_K.
+ */
+#define PD_UNCERTAIN_MAX_K 40960
+int pd_uncertain_points(const float *logits, const float *coords, const float *random_coords, float *out, int rows, int K, int k,
+                        int n_random, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
-#endif /* PD_CRITERION_H */
+#endif

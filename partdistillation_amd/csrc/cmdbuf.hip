@@ -111,6 +111,9 @@ const Entry kTable[] = {
   PD_E(pd_kmeans_update),
   PD_E(pd_lsa_batched),
   PD_E(pd_mask_assign),
+  PD_E(pd_mask_point_losses_bwd),
+  PD_E(pd_mask_point_losses_fwd),
+  PD_E(pd_matcher_costs),
   PD_E(pd_matcher_point_terms),
   PD_E(pd_maxpool3s2_bwd_bf16),
   PD_E(pd_maxpool3s2_fwd_bf16),
@@ -155,6 +158,7 @@ const Entry kTable[] = {
   PD_E(pd_sumsq_accumulate),
   PD_E(pd_swin_ln_bwd),
   PD_E(pd_swin_ln_fwd),
+  PD_E(pd_uncertain_points),
   PD_E(pd_upsample2x_bwd_nhwc_f32),
   PD_E(pd_upsample_add_amax_nhwc_f32),
   PD_E(pd_upsample_add_nhwc_f32),

@@ -1,0 +1,94 @@
+"""Python faces of the set criterion's kernels (include/pd_criterion.h, csrc/criterion.hip): the Hungarian cost matrices of all (image,
+head) problems in one pass, the BCE / dice losses of the matched masks at their points (with their gradient), and the selection of the
+most uncertain oversampled points.  GPU only; the callers keep the plain torch expressions for CPU tensors (the oracle-side tests)."""
+import torch
+from torch.autograd import Function
+
+from .. import lib as _lib
+
+_DT = {torch.float32: 0, torch.bfloat16: 2}
+MAX_K = 40960
+
+
+def _stream():
+    return _lib.current_stream()
+
+
+def matcher_costs_supported(x, t, prob, labels):
+    return (x.is_cuda and x.dtype in _DT and x.is_contiguous() and t.dtype == torch.float32 and t.stride(-1) == 1
+            and prob.dtype == torch.float32 and labels.dtype == torch.int64)
+
+
+def matcher_costs(x, t, prob, labels, heads, w_mask, w_class, w_dice):
+    """x [B * heads, Q, n] point logits (bf16 / fp32), t [B, n_targets, heads, n] fp32 VIEW of the sampled target masks (any strides with a
+    unit last one), prob [B * heads, Q, classes] fp32, labels [B, n_targets] int64 -> cost [B * heads, Q, n_targets] fp32
+    (reference matcher.py:108-158)"""
+    if not x.is_cuda:
+        raise RuntimeError("pd_matcher_costs runs on the GPU only (no CPU fallback in partdistillation_amd)")
+    problems, Q, n = x.shape
+    B, nt = t.shape[0], t.shape[1]
+    assert problems == B * heads and t.shape == (B, nt, heads, n) and t.stride(3) == 1 and labels.shape == (B, nt), (x.shape, t.shape, labels.shape)
+    prob = prob.contiguous()
+    labels = labels.contiguous()
+    cost = torch.empty((problems, Q, nt), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().pd_matcher_costs(x.data_ptr(), _DT[x.dtype], t.data_ptr(), t.stride(0), t.stride(2), t.stride(1), prob.data_ptr(),
+                                            labels.data_ptr(), cost.data_ptr(), problems, heads, Q, n, nt, prob.shape[-1], float(w_mask),
+                                            float(w_class), float(w_dice), _stream()))
+    return cost
+
+
+class MaskPointLosses(Function):
+    """pl, labels [N, P] fp32 -> (bce [N] = mean over the points of BCE-with-logits, dice [N]); gradient with respect to pl only
+    (reference criterion.py:25-69)"""
+
+    @staticmethod
+    def forward(ctx, pl, labels):
+        if not pl.is_cuda:
+            raise RuntimeError("pd_mask_point_losses runs on the GPU only (no CPU fallback in partdistillation_amd)")
+        pl, labels = pl.contiguous(), labels.contiguous()
+        N, P = pl.shape
+        out = torch.empty((2, N), dtype=torch.float32, device=pl.device)
+        stats = torch.empty((N, 3), dtype=torch.float32, device=pl.device)
+        _lib.check(_lib.load().pd_mask_point_losses_fwd(pl.data_ptr(), labels.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), stats.data_ptr(),
+                                                        N, P, _stream()))
+        ctx.save_for_backward(pl, labels, stats)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, d_bce, d_dice):
+        pl, labels, stats = ctx.saved_tensors
+        N, P = pl.shape
+        dx = torch.empty_like(pl)
+        gb = d_bce.contiguous().float() if d_bce is not None else None
+        gd = d_dice.contiguous().float() if d_dice is not None else None
+        _lib.check(_lib.load().pd_mask_point_losses_bwd(pl.data_ptr(), labels.data_ptr(), stats.data_ptr(), gb.data_ptr() if gb is not None else None,
+                                                        gd.data_ptr() if gd is not None else None, dx.data_ptr(), N, P, _stream()))
+        return dx, None
+
+
+def mask_point_losses_supported(pl, labels):
+    return pl.is_cuda and pl.dtype == torch.float32 and labels.dtype == torch.float32 and pl.dim() == 2 and pl.shape == labels.shape and pl.shape[1] > 0
+
+
+def mask_point_losses(pl, labels):
+    return MaskPointLosses.apply(pl, labels)
+
+
+def uncertain_points_supported(logits, coords, k):
+    return (logits.is_cuda and logits.dtype == torch.float32 and coords.dtype == torch.float32 and logits.dim() == 2
+            and 1 <= k <= logits.shape[1] <= MAX_K)
+
+
+def uncertain_points(logits, coords, k, random_coords=None):
+    """logits [N, K] fp32, coords [N, K, 2], random_coords [N, R, 2] | None -> [N, k + R, 2]: the coordinates of the k points with the
+    smallest |logit| (below the threshold value in index order, then its lowest-index ties), then the random ones (reference criterion.py:181-189; no gradient)"""
+    if not logits.is_cuda:
+        raise RuntimeError("pd_uncertain_points runs on the GPU only (no CPU fallback in partdistillation_amd)")
+    logits, coords = logits.contiguous(), coords.contiguous()
+    N, K = logits.shape
+    R = 0 if random_coords is None else random_coords.shape[1]
+    rnd = random_coords.contiguous().float() if R else None
+    out = torch.empty((N, k + R, 2), dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.load().pd_uncertain_points(logits.data_ptr(), coords.data_ptr(), rnd.data_ptr() if rnd is not None else None, out.data_ptr(),
+                                               N, K, k, R, _stream()))
+    return out

@@ -19,6 +19,7 @@ Loss values are identical to the per-head loop up to fp32 summation order."""
 import torch
 import torch.nn.functional as F
 
+from ..functions import criterion_ops as cops
 from ..functions import lsa as lsa_op
 from ..functions import rowwise as rw
 
@@ -202,23 +203,23 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
             pm = torch.bmm(e, fm.view(B * H, Pm, -1).to(e.dtype).transpose(1, 2))
         else:
             pm = _gs(masks_bd.detach().reshape(B * H, Q, *masks_bd.shape[-2:]).float(), mc_bd.reshape(B * H, Pm, 2))   # [BD,Q,Pm]
-        tg = _gs(tmask, mc_bd.reshape(B, H * Pm, 2)).reshape(B, nmax, H, Pm).transpose(1, 2).reshape(B * H, nmax, Pm)
-        tgt = tg.transpose(1, 2)
-        if pm.is_cuda and pm.is_contiguous() and pm.dtype in (torch.float32, torch.bfloat16):
-            # .float(), softplus, sigmoid and their two row sums in one pass over the [B heads Q, points] logits (pd_matcher_point_terms)
-            pm32 = pm.dtype == torch.float32                                  # already fp32: no second copy of the logits (100 MB at config 2)
-            xf, sg, sp_sum, sg_sum = rw.matcher_point_terms(pm, want_f32=not pm32)
-            pm = pm if pm32 else xf
+        tg4 = _gs(tmask, mc_bd.reshape(B, H * Pm, 2)).reshape(B, nmax, H, Pm)                    # the sampler's layout: targets x heads
+        lf = logits_bd.detach().float()
+        prob = lf.sigmoid() if K1 == 1 else lf.softmax(-1)
+        if cops.matcher_costs_supported(pm, tg4, prob, labels_pad) and nmax > 0:
+            # softplus / sigmoid sums, the two products with the targets, the class term and the weighted sum: one pass over the point
+            # logits (pd_matcher_costs); neither fp32 copy of the logits is formed
+            C = cops.matcher_costs(pm, tg4, prob.reshape(B * H, Q, K1), labels_pad, H, m.cost_mask, m.cost_class, m.cost_dice)
         else:
+            tg = tg4.transpose(1, 2).reshape(B * H, nmax, Pm)
+            tgt = tg.transpose(1, 2)
             pm = pm.float()
             sg = pm.sigmoid()
             sp_sum, sg_sum = F.softplus(pm).sum(-1), sg.sum(-1)
-        cost_mask = (sp_sum[:, :, None] - torch.bmm(pm, tgt)) / Pm
-        cost_dice = 1 - (2 * torch.bmm(sg, tgt) + 1) / (sg_sum[:, :, None] + tg.sum(-1)[:, None, :] + 1)
-        lf = logits_bd.detach().float()
-        prob = lf.sigmoid() if K1 == 1 else lf.softmax(-1)
-        cost_class = -torch.gather(prob, 3, labels_pad[:, None, None, :].expand(B, H, Q, nmax)).reshape(B * H, Q, nmax)
-        C = m.cost_mask * cost_mask + m.cost_class * cost_class + m.cost_dice * cost_dice
+            cost_mask = (sp_sum[:, :, None] - torch.bmm(pm, tgt)) / Pm
+            cost_dice = 1 - (2 * torch.bmm(sg, tgt) + 1) / (sg_sum[:, :, None] + tg.sum(-1)[:, None, :] + 1)
+            cost_class = -torch.gather(prob, 3, labels_pad[:, None, None, :].expand(B, H, Q, nmax)).reshape(B * H, Q, nmax)
+            C = m.cost_mask * cost_mask + m.cost_class * cost_class + m.cost_dice * cost_dice
         rows, cols = lsa_op.solve_batched(C, ncols)                                              # [BD,nmax]
         sel_h, sel_b, sel_k, per_image, inv_img = _pair_selectors(H, B, npair, dev)              # pairs, h-major
         sel_d = d_of_h[sel_h]
@@ -245,11 +246,16 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
         else:
             src = masks_bd[sel_b, sel_d, q_idx][:, None].float()                                 # [N,1,h,w]
         with torch.no_grad():
-            unc = -_gs(src, ocoords).abs()[:, 0, :]
-            idx = torch.topk(unc, k=kimp, dim=1, sorted=False)[1]            # the losses are sums over the chosen points
-            coords = torch.gather(ocoords, 1, idx[:, :, None].expand(-1, -1, 2))
-            if krand > 0:
-                coords = torch.cat([coords, rcoords], dim=1)                                     # [N,P,2]
+            samp = _gs(src, ocoords)[:, 0, :]                                 # [N, kover]
+            if cops.uncertain_points_supported(samp, ocoords, kimp):
+                # the kimp oversampled points with the smallest |logit|, then the random ones: radix select + compaction, one launch
+                # (pd_uncertain_points; was abs, neg, a ~20-launch top-k, gather, cat).  The losses are sums over the chosen points.
+                coords = cops.uncertain_points(samp, ocoords, kimp, rcoords if krand > 0 else None)   # [N,P,2]
+            else:
+                idx = torch.topk(-samp.abs(), k=kimp, dim=1, sorted=False)[1]
+                coords = torch.gather(ocoords, 1, idx[:, :, None].expand(-1, -1, 2))
+                if krand > 0:
+                    coords = torch.cat([coords, rcoords], dim=1)                                 # [N,P,2]
             labels = torch.empty((coords.shape[0], P), dtype=torch.float32, device=dev)
             for b in range(B):                                                                   # targets as channels
                 pi = per_image[b]
@@ -258,9 +264,12 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
                 s = _gs(tmask[b:b + 1], coords[pi].reshape(1, -1, 2)).reshape(nmax, pi.numel(), P)
                 labels[pi] = s[j_idx[pi], _arange(pi.numel(), dev)]
         pl = _gs(src, coords)[:, 0, :]                                                           # [N,P]
-        bce = F.binary_cross_entropy_with_logits(pl, labels, reduction="none").mean(1)
-        ps = pl.sigmoid()
-        dice = 1 - (2 * (ps * labels).sum(-1) + 1) / (ps.sum(-1) + labels.sum(-1) + 1)
+        if cops.mask_point_losses_supported(pl, labels):
+            bce, dice = cops.mask_point_losses(pl, labels)                    # per mask, forward and backward one launch each
+        else:
+            bce = F.binary_cross_entropy_with_logits(pl, labels, reduction="none").mean(1)
+            ps = pl.sigmoid()
+            dice = 1 - (2 * (ps * labels).sum(-1) + 1) / (ps.sum(-1) + labels.sum(-1) + 1)
         loss_mask = bce.reshape(H, N_h).sum(1) / num_masks
         loss_dice = dice.reshape(H, N_h).sum(1) / num_masks
 

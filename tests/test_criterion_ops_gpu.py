@@ -1,0 +1,117 @@
+"""GPU parity of the set criterion's kernels (include/pd_criterion.h, csrc/criterion.hip) against the plain torch expressions of the
+reference's matcher / criterion (matcher.py:13-62, 108-158; criterion.py:25-88, 181-189), evaluated in fp64 where a sum is involved.  The
+full-size step tests (tests/test_product_gpu.py) cover the same kernels inside the step against the CPU oracle."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,H,Q,n,nt,K1", [(2, 10, 100, 12544, 4, 2), (1, 3, 5, 257, 1, 1), (2, 2, 7, 1000, 9, 5), (3, 1, 4, 64, 17, 3),
+                                            (2, 4, 100, 112 * 112, 2, 2)])
+def test_matcher_costs_match_the_torch_expressions(dtype, B, H, Q, n, nt, K1):
+    """cost = w_mask * sigmoid-CE + w_class * (-prob[label]) + w_dice * dice over all (image, head) problems, the target samples read in
+    the sampler's [B, targets, heads * points] layout; logits over the range where softplus switches branches.  Tolerance: 2e-5 relative
+    to the cost's magnitude (fp32 sums over up to 12 544 points in a different order than the library GEMM)."""
+    from partdistillation_amd.functions import criterion_ops as cops
+    torch.manual_seed(B * 1000 + n + nt)
+    x = (torch.randn(B * H, Q, n, device=DEV) * 8).to(dtype)
+    x.view(-1)[:4] = torch.tensor([0.0, 20.0, 20.5, -45.0], device=DEV).to(dtype)
+    t_flat = (torch.rand(B, nt, H * n, device=DEV) > 0.6).float() * torch.rand(B, nt, H * n, device=DEV)     # bilinear samples of 0/1 masks
+    t_flat[:, -1] = 0                                                                                          # a padded (all-zero) target
+    t4 = t_flat.view(B, nt, H, n)
+    logits = torch.randn(B, H, Q, K1, device=DEV)
+    prob = logits.sigmoid() if K1 == 1 else logits.softmax(-1)
+    labels = torch.randint(0, K1, (B, nt), device=DEV)
+    wm, wc, wd = 5.0, 2.0, 5.0
+    assert cops.matcher_costs_supported(x, t4, prob, labels)
+    got = cops.matcher_costs(x, t4, prob.reshape(B * H, Q, K1), labels, H, wm, wc, wd)
+    xd = x.double()
+    tg = t4.transpose(1, 2).reshape(B * H, nt, n).double()
+    sp, sg = F.softplus(xd).sum(-1), xd.sigmoid()
+    cost_mask = (sp[:, :, None] - torch.bmm(xd, tg.transpose(1, 2))) / n
+    cost_dice = 1 - (2 * torch.bmm(sg, tg.transpose(1, 2)) + 1) / (sg.sum(-1)[:, :, None] + tg.sum(-1)[:, None, :] + 1)
+    cost_class = -torch.gather(prob.double(), 3, labels[:, None, None, :].expand(B, H, Q, nt)).reshape(B * H, Q, nt)
+    ref = wm * cost_mask + wc * cost_class + wd * cost_dice
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    err = float((got.double() - ref).abs().max() / ref.abs().max())
+    print(f"matcher costs {dtype} B={B} H={H} Q={Q} n={n} targets={nt}: max |err| / max |cost| = {err:.2e}")
+    assert err <= 2e-5
+
+
+@pytest.mark.parametrize("N,P", [(80, 12544), (1, 1), (7, 300), (3, 4099)])
+def test_mask_point_losses_match_torch(N, P):
+    """per-mask BCE-with-logits mean and dice at the sampled points, and their gradient (criterion.py:25-69), against fp64 autograd"""
+    from partdistillation_amd.functions import criterion_ops as cops
+    torch.manual_seed(N + P)
+    x = (torch.randn(N, P, device=DEV) * 6).requires_grad_(True)
+    y = ((torch.rand(N, P, device=DEV) > 0.5).float() * torch.rand(N, P, device=DEV)).contiguous()
+    assert cops.mask_point_losses_supported(x, y)
+    bce, dice = cops.mask_point_losses(x, y)
+    gb, gd = torch.randn(N, device=DEV), torch.randn(N, device=DEV)
+    (gx,) = torch.autograd.grad((bce * gb).sum() + (dice * gd).sum(), x)
+    xd = x.detach().double().requires_grad_(True)
+    yd = y.double()
+    rb = F.binary_cross_entropy_with_logits(xd, yd, reduction="none").mean(1)
+    ps = xd.sigmoid()
+    rd = 1 - (2 * (ps * yd).sum(-1) + 1) / (ps.sum(-1) + yd.sum(-1) + 1)
+    (rx,) = torch.autograd.grad((rb * gb.double()).sum() + (rd * gd.double()).sum(), xd)
+    torch.testing.assert_close(bce.double(), rb.detach(), rtol=3e-6, atol=1e-7)
+    torch.testing.assert_close(dice.double(), rd.detach(), rtol=3e-6, atol=3e-7)
+    assert float((gx.double() - rx).abs().max()) <= 3e-6 * float(rx.abs().max()) + 1e-12
+    # one of the two upstream gradients absent
+    bce2, dice2 = cops.mask_point_losses(x, y)
+    (g1,) = torch.autograd.grad((bce2 * gb).sum(), x)
+    (r1,) = torch.autograd.grad((F.binary_cross_entropy_with_logits(xd, yd, reduction="none").mean(1) * gb.double()).sum(), xd)
+    assert float((g1.double() - r1).abs().max()) <= 3e-6 * float(r1.abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("N,K,k,R", [(80, 37632, 9408, 3136), (3, 40960, 40960, 0), (5, 1000, 1, 7), (2, 1025, 512, 0), (4, 64, 63, 2)])
+def test_uncertain_points_select_what_topk_selects(N, K, k, R):
+    """the k oversampled points with the smallest |logit| (= top-k of -|logit|, criterion.py:72-88, 181-189) followed by the random ones;
+    the chosen SET equals torch.topk's (no ties in continuous draws)"""
+    from partdistillation_amd.functions import criterion_ops as cops
+    torch.manual_seed(K + k)
+    v = torch.randn(N, K, device=DEV) * 5
+    coords = torch.rand(N, K, 2, device=DEV)
+    coords[:, :, 0] = torch.arange(K, device=DEV, dtype=torch.float32)        # x = the point's index (exact in fp32), y random
+    rnd = torch.rand(N, R, 2, device=DEV) if R else None
+    assert cops.uncertain_points_supported(v, coords, k)
+    out = cops.uncertain_points(v, coords, k, rnd)
+    assert out.shape == (N, k + R, 2)
+    got = out[:, :k, 0].long()
+    assert torch.equal(torch.gather(coords[:, :, 1], 1, got), out[:, :k, 1])  # each output pair is one input pair
+    idx = torch.topk(-v.abs(), k=k, dim=1, sorted=False)[1].sort(1)[0]
+    assert torch.equal(got.sort(1)[0], idx)
+    assert torch.equal(got[:, :k - 1], got[:, :k - 1].sort(1)[0])             # below the threshold: index order (the threshold's point last)
+    if R:
+        assert torch.equal(out[:, k:], rnd)
+
+
+def test_uncertain_points_break_ties_by_index():
+    """equal |logit| at the threshold: the lowest indices are taken; exact zeros, sign-symmetric values and a row of one repeated value"""
+    from partdistillation_amd.functions import criterion_ops as cops
+    K, k = 3000, 1200
+    v = torch.randint(-3, 4, (4, K), device=DEV).float()                  # seven distinct |values| only: the threshold bin is hundreds wide
+    v[3] = 2.5
+    coords = torch.arange(K, device=DEV, dtype=torch.float32)[None, :, None].expand(4, K, 2).contiguous()
+    out = cops.uncertain_points(v, coords, k)
+    for r in range(4):
+        a = v[r].abs()
+        T = torch.sort(a)[0][k - 1]
+        less, eq = torch.nonzero(a < T)[:, 0], torch.nonzero(a == T)[:, 0]
+        want = torch.cat([less, eq[:k - less.numel()]])                    # everything below the threshold, then its lowest-index ties
+        assert torch.equal(out[r, :, 0].long(), want), r
+
+
+def test_criterion_ops_refuse_cpu_tensors():
+    from partdistillation_amd.functions import criterion_ops as cops
+    with pytest.raises(RuntimeError, match="GPU only"):
+        cops.uncertain_points(torch.zeros(1, 4), torch.zeros(1, 4, 2), 2)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        cops.MaskPointLosses.apply(torch.zeros(1, 4), torch.zeros(1, 4))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        cops.matcher_costs(torch.zeros(1, 1, 4), torch.zeros(1, 1, 1, 4), torch.zeros(1, 1, 1), torch.zeros(1, 1, dtype=torch.long), 1, 1, 1, 1)
