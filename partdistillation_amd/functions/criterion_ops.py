@@ -8,6 +8,7 @@ from .. import lib as _lib
 
 _DT = {torch.float32: 0, torch.bfloat16: 2}
 MAX_K = 40960
+ENABLED = __import__("os").environ.get("PD_CRITERION_KERNELS", "1") != "0"      # 0: the torch expressions (tools/ A/B runs)
 
 
 def _stream():
@@ -15,7 +16,7 @@ def _stream():
 
 
 def matcher_costs_supported(x, t, prob, labels):
-    return (x.is_cuda and x.dtype in _DT and x.is_contiguous() and t.dtype == torch.float32 and t.stride(-1) == 1
+    return (ENABLED and x.is_cuda and x.dtype in _DT and x.is_contiguous() and t.dtype == torch.float32 and t.stride(-1) == 1
             and prob.dtype == torch.float32 and labels.dtype == torch.int64)
 
 
@@ -67,7 +68,7 @@ class MaskPointLosses(Function):
 
 
 def mask_point_losses_supported(pl, labels):
-    return pl.is_cuda and pl.dtype == torch.float32 and labels.dtype == torch.float32 and pl.dim() == 2 and pl.shape == labels.shape and pl.shape[1] > 0
+    return ENABLED and pl.is_cuda and pl.dtype == torch.float32 and labels.dtype == torch.float32 and pl.dim() == 2 and pl.shape == labels.shape and pl.shape[1] > 0
 
 
 def mask_point_losses(pl, labels):
@@ -75,7 +76,7 @@ def mask_point_losses(pl, labels):
 
 
 def uncertain_points_supported(logits, coords, k):
-    return (logits.is_cuda and logits.dtype == torch.float32 and coords.dtype == torch.float32 and logits.dim() == 2
+    return (ENABLED and logits.is_cuda and logits.dtype == torch.float32 and coords.dtype == torch.float32 and logits.dim() == 2
             and 1 <= k <= logits.shape[1] <= MAX_K)
 
 

@@ -112,7 +112,7 @@ def _pair_selectors(H, B, npair, device):
         per_image = [mk(l) for l in per_image_l]
         flat = [i for l in per_image_l for i in l]                         # pairs in image-major order
         inv = mk(sorted(range(len(flat)), key=flat.__getitem__))           # image-major position of pair i
-        _SEL_CACHE[key] = (mk(sel_h), mk(sel_b), mk(sel_k), per_image, inv)
+        _SEL_CACHE[key] = (mk(sel_h), mk(sel_b), mk(sel_k), per_image, inv, mk(flat), [len(l) for l in per_image_l])
     return _SEL_CACHE[key]
 
 
@@ -221,7 +221,7 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
             cost_class = -torch.gather(prob, 3, labels_pad[:, None, None, :].expand(B, H, Q, nmax)).reshape(B * H, Q, nmax)
             C = m.cost_mask * cost_mask + m.cost_class * cost_class + m.cost_dice * cost_dice
         rows, cols = lsa_op.solve_batched(C, ncols)                                              # [BD,nmax]
-        sel_h, sel_b, sel_k, per_image, inv_img = _pair_selectors(H, B, npair, dev)              # pairs, h-major
+        sel_h, sel_b, sel_k, per_image, inv_img, img_major, img_counts = _pair_selectors(H, B, npair, dev)   # pairs, h-major
         sel_d = d_of_h[sel_h]
         sel_p = sel_b * H + sel_d
         q_idx, j_idx = rows[sel_p, sel_k], cols[sel_p, sel_k]
@@ -234,15 +234,21 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
         w = crit.empty_weight
         nll = F.cross_entropy(logits_bd.float().reshape(B * H, Q, K1).transpose(1, 2), tclass.reshape(B * H, Q), w, reduction="none")
         ce_d = nll.reshape(B, H, Q).sum((0, 2)) / w[tclass].sum((0, 2))
-        loss_ce = ce_d[d_of_h]
+        loss_ce = ce_d.index_select(0, d_of_h)           # (index_select: its backward is one index_add; x[idx] sorts the indices: 6 launches)
         # ---- mask losses on the matched pairs (criterion.py:147-207)
         if sparse:
-            e_sel = emb_bd[sel_b, sel_d, q_idx].float()                                          # [N,C]
+            # the matched queries' embeddings, gathered ONCE and already in image-major order: rows of the flat [B heads Q, C] matrix
+            emb_db = emb_bd.transpose(0, 1)                                                      # the decoder's own [heads, B, Q, C] layout
+            if emb_db.is_contiguous():
+                emb_rows, flat_idx = emb_db.reshape(H * B * Q, -1), (sel_d * B + sel_b) * Q + q_idx      # a view: no copy of the embeddings
+            else:
+                emb_rows, flat_idx = emb_bd.reshape(B * H * Q, -1), (sel_b * H + sel_d) * Q + q_idx
+            e_img = emb_rows.index_select(0, flat_idx.index_select(0, img_major)).float()        # [N,C]
             # [hw, C] @ [C, n_b]: with channels-last mask features the operand is read in place and its gradient comes
             # back channels-last, the layout the 1x1 mask_features convolution's backward wants
             mf_tok = mfeat.float().permute(0, 2, 3, 1).reshape(B, -1, mfeat.shape[1])            # [B, hw, C]
-            parts = [p.t() for p in _tokens_times_rows_batched(mf_tok, [e_sel[per_image[b]] for b in range(B)]) if p.numel()]
-            src = torch.cat(parts)[inv_img].view(-1, 1, *mfeat.shape[-2:])                       # [N,1,h,w]
+            parts = [p.t() for p in _tokens_times_rows_batched(mf_tok, list(e_img.split(img_counts))) if p.numel()]
+            src = torch.cat(parts).index_select(0, inv_img).view(-1, 1, *mfeat.shape[-2:])       # [N,1,h,w], pair (h-major) order
         else:
             src = masks_bd[sel_b, sel_d, q_idx][:, None].float()                                 # [N,1,h,w]
         with torch.no_grad():

@@ -24,6 +24,7 @@ from torch import Tensor, nn
 
 from ...compat import TRANSFORMER_DECODER_REGISTRY, configurable
 from ...compat.layers import Conv2d, c2_xavier_fill
+from ...functions import mlp_own
 from ...functions.attention import masked_attention_d32
 from ...functions.decoder_core import DecoderCore, DecoderSpec
 from ...functions.rowwise import supports_width
@@ -145,6 +146,8 @@ class MLP(nn.Module):
         self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
     def forward(self, x):
+        if mlp_own.supported(x, self.layers):                   # bf16 autocast on the GPU: one autograd node on own kernels
+            return mlp_own.mlp(x, self.layers)
         for i, layer in enumerate(self.layers):
             x = layer(x)
             if i < self.num_layers - 1:

@@ -115,3 +115,40 @@ def test_criterion_ops_refuse_cpu_tensors():
         cops.MaskPointLosses.apply(torch.zeros(1, 4), torch.zeros(1, 4))
     with pytest.raises(RuntimeError, match="GPU only"):
         cops.matcher_costs(torch.zeros(1, 1, 4), torch.zeros(1, 1, 1, 4), torch.zeros(1, 1, 1), torch.zeros(1, 1, dtype=torch.long), 1, 1, 1, 1)
+
+
+@pytest.mark.parametrize("rows_shape", [(10, 2, 100), (3, 64), (1, 200)])
+def test_own_mlp_node_matches_the_module_path_under_autocast(rows_shape):
+    """functions/mlp_own.py: the mask-embedding MLP as one node on pd_igemm_bf16 / pd_wgrad_bf16 against nn.Linear + ReLU under bf16 autocast
+    (reference mask2former_transformer_decoder.py:198-204) — the same bf16 roundings between the layers, so outputs and gradients agree to
+    bf16 resolution of their magnitudes (2^-7 relative to the tensor maximum; measured ~4e-3)."""
+    from partdistillation_amd.functions import mlp_own
+    from partdistillation_amd.modeling.transformer_decoder.mask2former_transformer_decoder import MLP
+    torch.manual_seed(len(rows_shape))
+    ref = MLP(256, 256, 256, 3).to(DEV)
+    own = MLP(256, 256, 256, 3).to(DEV)
+    own.load_state_dict(ref.state_dict())
+    for p in own.parameters():
+        p.data = p.data.to(torch.bfloat16)                       # the shadowed (bf16) parameters of the training step
+    x = torch.randn(*rows_shape, 256, device=DEV)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    go = torch.randn(*rows_shape, 256, device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert mlp_own.supported(x2, own.layers)
+        y_ref = x1
+        for i, l in enumerate(ref.layers):                       # the module path (MLP.forward would take the own node here too)
+            y_ref = l(y_ref)
+            y_ref = F.relu(y_ref) if i < 2 else y_ref
+        y_own = own(x2)
+    assert y_own.dtype == torch.bfloat16 and y_own.shape == y_ref.shape
+    (y_ref.float() * go).sum().backward()
+    (y_own.float() * go).sum().backward()
+
+    def close(a, b, what):
+        err = float((a.float() - b.float()).abs().max() / b.float().abs().max())
+        assert err <= 2 ** -7, (what, err)
+    close(y_own, y_ref, "y")
+    close(x2.grad, x1.grad, "dx")
+    for (n, p), q in zip(own.named_parameters(), ref.parameters()):
+        assert p.grad.dtype == p.dtype
+        close(p.grad, q.grad, n)
