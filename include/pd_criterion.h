@@ -70,8 +70,9 @@ int pd_mask_point_losses_bwd(const float *x, const float *y, const float *stats,
 
 /*
  * logits [rows, K], coords [rows, K, 2], random_coords [rows, n_random, 2] (nullable when n_random = 0) ->
- * out [rows, k + n_random, 2]: the coordinates of the k points with the smallest |logit| — those below the k-th smallest value in index
- * order, then the lowest-index points equal to it —, then the row's random coordinates.  Deterministic.  1 <= k <= K <= PD_UNCERTAIN_MAX_K.
+ * out [rows, k + n_random, 2]: the coordinates of the k points with the smallest |logit| — every point below the k-th smallest value,
+ * then as many of the points equal to it as are needed —, then the row's random coordinates.  Which ties are taken and the order of the
+ * k points are fixed by the kernel's thread layout (deterministic; the losses are sums over the points).  1 <= k <= K <= PD_UNCERTAIN_MAX_K.
  */
 #define PD_UNCERTAIN_MAX_K 40960
 int pd_uncertain_points(const float *logits, const float *coords, const float *random_coords, float *out, int rows, int K, int k,

@@ -9,7 +9,7 @@
 //   mask_point_losses   a workgroup per matched mask: BCE-with-logits mean and dice of its sampled points; the backward recomputes the
 //                       sigmoid instead of storing it (criterion.py:25-69)
 //   uncertain_points    a workgroup per matched mask: radix select (4 x 8 bits, keys in registers) of the k-th smallest |logit| among the
-//                       K oversampled points, then an index-ordered compaction of the chosen coordinates (criterion.py:72-88, 181-189)
+//                       K oversampled points, then a scan-ordered compaction of the chosen coordinates (criterion.py:72-88, 181-189)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -29,16 +29,27 @@ __device__ __forceinline__ float wave_sum(float v)
 __device__ __forceinline__ float softplus_t(float v, float e) { return v > 20.f ? v : fmaxf(v, 0.f) + log1pf(e); }   // e = exp(-|v|)
 
 // ------------------------------------------------------------------------------------------------ matcher costs
-constexpr int QR = 4, JT = 8;       // query rows per workgroup, target columns per pass
-constexpr int NACC = QR * (2 + 2 * JT) + JT;
+constexpr int QR = 4, MT = 512;               // query rows per workgroup, threads; JT = target columns per pass (4: two workgroups per CU)
 
-template <typename T>
-__global__ __launch_bounds__(256) void matcher_costs(const T *__restrict__ x, const float *__restrict__ t, int64_t t_sb, int64_t t_sd,
-                                                     int64_t t_sj, const float *__restrict__ prob, const int64_t *__restrict__ labels,
-                                                     float *__restrict__ cost, int heads, int Q, int n, int nt, int classes, float w_mask,
-                                                     float w_class, float w_dice)
+// softplus(v) and sigmoid(v) from ONE exponential: e = exp(-|v|), sigmoid = v >= 0 ? 1 / (1 + e) : e / (1 + e), softplus = max(v, 0) +
+// log(1 + e) (torch's threshold-20 branch returns v there, which differs from this by < 2.1e-9).  The hardware exp2 / log2 behind __expf /
+// __logf are good to ~1e-6 relative / 1e-7 absolute here — the sums run over 10^4 points of O(1) terms.
+__device__ __forceinline__ void sp_sg(float v, float &sp, float &sg)
 {
-  __shared__ float red[4][NACC];
+  const float e = __expf(-fabsf(v));
+  const float r = __frcp_rn(1.f + e);
+  sg = v >= 0.f ? r : e * r;
+  sp = fmaxf(v, 0.f) + __logf(1.f + e);
+}
+
+template <typename T, int VEC, int JT>
+__global__ __launch_bounds__(MT, JT == 4 ? 2 : 1) void matcher_costs(const T *__restrict__ x, const float *__restrict__ t, int64_t t_sb, int64_t t_sd,
+                                                    int64_t t_sj, const float *__restrict__ prob, const int64_t *__restrict__ labels,
+                                                    float *__restrict__ cost, int heads, int Q, int n, int nt, int classes, float w_mask,
+                                                    float w_class, float w_dice)
+{
+  constexpr int NACC = QR * (2 + 2 * JT) + JT;
+  __shared__ float red[MT / 64][NACC];
   const int qtiles = (Q + QR - 1) / QR;
   const int p = blockIdx.x / qtiles, q0 = (blockIdx.x - p * qtiles) * QR;
   const int b = p / heads, d = p - b * heads;
@@ -55,25 +66,44 @@ __global__ __launch_bounds__(256) void matcher_costs(const T *__restrict__ x, co
     }
 #pragma unroll
     for (int j = 0; j < JT; ++j) ts[j] = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
-      float tv[JT];
+    for (int i = threadIdx.x * VEC; i < n; i += MT * VEC) {
+      float tv[JT][VEC], xv[QR][VEC];
 #pragma unroll
-      for (int j = 0; j < JT; ++j) {
-        tv[j] = j0 + j < nt ? tp[(int64_t)(j0 + j) * t_sj + i] : 0.f;
-        ts[j] += tv[j];
+      for (int j = 0; j < JT; ++j) {                               // all loads of the step first: one memory latency per step
+        if (j0 + j < nt) {
+          if constexpr (VEC == 2) { const float2 u = *reinterpret_cast<const float2 *>(tp + (int64_t)(j0 + j) * t_sj + i); tv[j][0] = u.x; tv[j][1] = u.y; }
+          else tv[j][0] = tp[(int64_t)(j0 + j) * t_sj + i];
+        } else {
+#pragma unroll
+          for (int u = 0; u < VEC; ++u) tv[j][u] = 0.f;
+        }
       }
 #pragma unroll
       for (int r = 0; r < QR; ++r) {
-        if (q0 + r >= Q) continue;
-        float v;
-        if constexpr (sizeof(T) == 2) v = bf2f(xp[(int64_t)r * n + i]); else v = xp[(int64_t)r * n + i];
-        const float e = expf(-fabsf(v));
-        const float s = 1.f / (1.f + expf(-v));
-        sp[r] += softplus_t(v, e);
-        sg[r] += s;
-#pragma unroll
-        for (int j = 0; j < JT; ++j) { xt[r][j] = fmaf(v, tv[j], xt[r][j]); st[r][j] = fmaf(s, tv[j], st[r][j]); }
+        const T *xr = xp + (int64_t)(q0 + r < Q ? r : 0) * n + i;   // rows beyond Q re-read row 0 (their results are not stored)
+        if constexpr (sizeof(T) == 2) {
+          if constexpr (VEC == 2) { const unsigned u = *reinterpret_cast<const unsigned *>(xr); xv[r][0] = bf2f((bf16_t)(u & 0xffffu)); xv[r][1] = bf2f((bf16_t)(u >> 16)); }
+          else xv[r][0] = bf2f(xr[0]);
+        } else {
+          if constexpr (VEC == 2) { const float2 u = *reinterpret_cast<const float2 *>(xr); xv[r][0] = u.x; xv[r][1] = u.y; }
+          else xv[r][0] = xr[0];
+        }
       }
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) ts[j] += tv[j][u];
+#pragma unroll
+      for (int r = 0; r < QR; ++r)
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) {
+          float a, s;
+          sp_sg(xv[r][u], a, s);
+          sp[r] += a;
+          sg[r] += s;
+#pragma unroll
+          for (int j = 0; j < JT; ++j) { xt[r][j] = fmaf(xv[r][u], tv[j][u], xt[r][j]); st[r][j] = fmaf(s, tv[j][u], st[r][j]); }
+        }
     }
     // lanes -> wavefront -> workgroup
     float *mine = red[wave];
@@ -96,7 +126,12 @@ __global__ __launch_bounds__(256) void matcher_costs(const T *__restrict__ x, co
     if (threadIdx.x < QR * JT) {
       const int r = threadIdx.x / JT, j = threadIdx.x - r * JT;
       if (q0 + r < Q && j0 + j < nt) {
-        auto tot = [&](int k) { return (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]); };
+        auto tot = [&](int k) {
+          float a = 0.f;
+#pragma unroll
+          for (int w = 0; w < MT / 64; ++w) a += red[w][k];
+          return a;
+        };
         const float spr = tot(r * (2 + 2 * JT)), sgr = tot(r * (2 + 2 * JT) + 1);
         const float xtj = tot(r * (2 + 2 * JT) + 2 + j), stj = tot(r * (2 + 2 * JT) + 2 + JT + j), tsj = tot(QR * (2 + 2 * JT) + j);
         const float cm = (spr - xtj) / (float)n;
@@ -111,25 +146,40 @@ __global__ __launch_bounds__(256) void matcher_costs(const T *__restrict__ x, co
 }
 
 // ------------------------------------------------------------------------------------------------ mask point losses
-__global__ __launch_bounds__(256) void mask_point_losses_fwd(const float *__restrict__ x, const float *__restrict__ y,
-                                                             float *__restrict__ bce, float *__restrict__ dice, float *__restrict__ stats, int n)
+constexpr int LT = 1024;                          // threads per mask in the forward: all of a row's loads in flight at once
+template <int VEC>
+__global__ __launch_bounds__(LT) void mask_point_losses_fwd(const float *__restrict__ x, const float *__restrict__ y,
+                                                            float *__restrict__ bce, float *__restrict__ dice, float *__restrict__ stats, int n)
 {
-  __shared__ float red[4][4];
+  __shared__ float red[LT / 64][4];
   const float *xr = x + (int64_t)blockIdx.x * n, *yr = y + (int64_t)blockIdx.x * n;
   float a = 0.f, sy = 0.f, s1 = 0.f, y1 = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float v = xr[i], t = yr[i];
-    const float e = expf(-fabsf(v));
-    a += fmaxf(v, 0.f) - v * t + log1pf(e);
-    const float s = 1.f / (1.f + expf(-v));
-    sy = fmaf(s, t, sy); s1 += s; y1 += t;
+  for (int i = threadIdx.x * VEC; i < n; i += LT * VEC) {
+    float v[VEC], t[VEC];
+    if constexpr (VEC == 4) {
+      const float4 a4 = *reinterpret_cast<const float4 *>(xr + i), b4 = *reinterpret_cast<const float4 *>(yr + i);
+      v[0] = a4.x; v[1] = a4.y; v[2] = a4.z; v[3] = a4.w; t[0] = b4.x; t[1] = b4.y; t[2] = b4.z; t[3] = b4.w;
+    } else { v[0] = xr[i]; t[0] = yr[i]; }
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      const float e = expf(-fabsf(v[u]));
+      a += fmaxf(v[u], 0.f) - v[u] * t[u] + log1pf(e);
+      const float r = 1.f / (1.f + e);
+      const float s = v[u] >= 0.f ? r : e * r;
+      sy = fmaf(s, t[u], sy); s1 += s; y1 += t[u];
+    }
   }
   a = wave_sum(a); sy = wave_sum(sy); s1 = wave_sum(s1); y1 = wave_sum(y1);
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { red[wave][0] = a; red[wave][1] = sy; red[wave][2] = s1; red[wave][3] = y1; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    auto tot = [&](int k) { return (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]); };
+    auto tot = [&](int k) {
+      float r = 0.f;
+#pragma unroll
+      for (int w = 0; w < LT / 64; ++w) r += red[w][k];
+      return r;
+    };
     const float A = tot(0), SY = tot(1), S1 = tot(2), Y1 = tot(3);
     bce[blockIdx.x] = A / (float)n;
     dice[blockIdx.x] = 1.f - (2.f * SY + 1.f) / (S1 + Y1 + 1.f);
@@ -155,7 +205,7 @@ __global__ __launch_bounds__(256) void mask_point_losses_bwd(const float *__rest
 }
 
 // ------------------------------------------------------------------------------------------------ uncertain points
-constexpr int UT = 1024, UV = PD_UNCERTAIN_MAX_K / UT;            // threads per row, keys per thread (a contiguous run of the row)
+constexpr int UT = 1024, UV = PD_UNCERTAIN_MAX_K / UT;            // threads per row, keys per thread
 
 __device__ __forceinline__ int block_excl_scan(int v, int *wsum, int &total)
 {
@@ -181,6 +231,25 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wsum, int &total)
   return before + inc - v;
 }
 
+// adds 1 to hist[bin] for every active lane.  The first digit of |logit| is its exponent: a handful of bins take nearly every key, and a
+// ds_add with 64 lanes on one address is serialised — so the lanes that share the first active lane's bin are counted with a ballot and
+// added once (up to PEEL rounds), whoever is left adds for itself.
+template <int PEEL>
+__device__ __noinline__ void hist_add(int *hist, int bin, bool active)
+{
+#pragma unroll
+  for (int r = 0; r < PEEL; ++r) {
+    const unsigned long long act = __ballot(active);
+    if (!act) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const int lb = __shfl(bin, leader, 64);
+    const unsigned long long same = __ballot(active && bin == lb);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lb], __popcll(same));
+    active = active && bin != lb;
+  }
+  if (active) atomicAdd(&hist[bin], 1);
+}
+
 __global__ __launch_bounds__(UT) void uncertain_points(const float *__restrict__ logits, const float2 *__restrict__ coords,
                                                        const float2 *__restrict__ rnd, float2 *__restrict__ out, int K, int k, int n_random)
 {
@@ -190,12 +259,11 @@ __global__ __launch_bounds__(UT) void uncertain_points(const float *__restrict__
   __shared__ int s_remaining;
   const int row = blockIdx.x, tid = threadIdx.x;
   const float *lr = logits + (int64_t)row * K;
-  const int per = (K + UT - 1) / UT;                               // <= UV
-  const int lo = tid * per;
+  const int per = (K + UT - 1) / UT;                               // <= UV; thread tid owns points tid, tid + UT, ... (coalesced)
   unsigned key[UV];
 #pragma unroll
   for (int m = 0; m < UV; ++m) {
-    const int i = lo + m;
+    const int i = m * UT + tid;
     key[m] = (m < per && i < K) ? (__float_as_uint(lr[i]) & 0x7fffffffu) : 0xffffffffu;     // |logit| as an ordered integer; padding sorts last
   }
   unsigned prefix = 0, mask = 0;
@@ -204,9 +272,15 @@ __global__ __launch_bounds__(UT) void uncertain_points(const float *__restrict__
   for (int shift = 24; shift >= 0; shift -= 8) {
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
+    if (shift == 24) {
 #pragma unroll
-    for (int m = 0; m < UV; ++m)
-      if (key[m] != 0xffffffffu && (key[m] & mask) == prefix) atomicAdd(&hist[(key[m] >> shift) & 255], 1);
+      for (int m = 0; m < UV; ++m)
+        if (m < per) hist_add<4>(hist, (int)(key[m] >> 24), key[m] != 0xffffffffu);
+    } else {
+#pragma unroll
+      for (int m = 0; m < UV; ++m)
+        if (key[m] != 0xffffffffu && (key[m] & mask) == prefix) atomicAdd(&hist[(key[m] >> shift) & 255], 1);
+    }
     __syncthreads();
     if (tid < 64) {                                                // one wavefront: 4 bins per lane, scan, find the bin of the k-th key
       int c[4], s = 0;
@@ -235,7 +309,8 @@ __global__ __launch_bounds__(UT) void uncertain_points(const float *__restrict__
     mask |= 255u << shift;
     __syncthreads();
   }
-  // prefix = the k-th smallest key T; `remaining` of the keys equal to T are taken (lowest indices), every smaller key is
+  // prefix = the k-th smallest key T; every smaller key is taken, and `remaining` of the keys equal to T — the first in the (thread, round)
+  // order of this kernel, a fixed choice.  Output order: the smaller keys by (thread, round), then the ties.
   int nless = 0, neq = 0;
 #pragma unroll
   for (int m = 0; m < UV; ++m) { nless += key[m] < prefix; neq += key[m] == prefix; }
@@ -246,9 +321,18 @@ __global__ __launch_bounds__(UT) void uncertain_points(const float *__restrict__
   const float2 *crow = coords + (int64_t)row * K;
   int a = pos_less, e = pos_eq;
 #pragma unroll
-  for (int m = 0; m < UV; ++m) {
-    if (key[m] < prefix) orow[a++] = crow[lo + m];
-    else if (key[m] == prefix) { if (e < remaining) orow[tot_less + e] = crow[lo + m]; ++e; }
+  for (int m0 = 0; m0 < UV; m0 += 8) {                             // eight coordinate loads in flight, then the (conditional) stores:
+    float2 c[8];                                                   // a load inside the branch would be one memory round trip per point
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = (m0 + u) * UT + tid;
+      c[u] = (key[m0 + u] <= prefix) ? crow[i] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (key[m0 + u] < prefix) orow[a++] = c[u];
+      else if (key[m0 + u] == prefix) { if (e < remaining) orow[tot_less + e] = c[u]; ++e; }
+    }
   }
   for (int i = tid; i < n_random; i += UT) orow[k + i] = rnd[(int64_t)row * n_random + i];
 }
@@ -263,13 +347,16 @@ extern "C" int pd_matcher_costs(const void *x, int dtype, const float *t, int64_
                         n_targets, classes, dtype);
   if (problems == 0 || Q == 0 || n_targets == 0) return PD_OK;
   if (!x || !t || !prob || !labels || !cost) return pd_set_error(PD_ERR_INVALID_ARG, "pd_matcher_costs: null pointer");
-  const dim3 g((unsigned)(problems * ((Q + QR - 1) / QR))), b(256);
-  if (dtype == PD_BF16)
-    hipLaunchKernelGGL((matcher_costs<bf16_t>), g, b, 0, (hipStream_t)stream_, (const bf16_t *)x, t, t_image_stride, t_head_stride, t_target_stride,
-                       prob, labels, cost, heads, Q, n, n_targets, classes, w_mask, w_class, w_dice);
-  else
-    hipLaunchKernelGGL((matcher_costs<float>), g, b, 0, (hipStream_t)stream_, (const float *)x, t, t_image_stride, t_head_stride, t_target_stride,
-                       prob, labels, cost, heads, Q, n, n_targets, classes, w_mask, w_class, w_dice);
+  const dim3 g((unsigned)(problems * ((Q + QR - 1) / QR))), b(MT);
+  // two points per lane when every row starts on an even element (8-byte target loads, 4- / 8-byte logit loads)
+  const bool v2 = !(n & 1) && !((t_image_stride | t_head_stride | t_target_stride) & 1) && !((uintptr_t)t & 7) && !((uintptr_t)x & 7);
+#define PD_MC(T, V, J) hipLaunchKernelGGL((matcher_costs<T, V, J>), g, b, 0, (hipStream_t)stream_, (const T *)x, t, t_image_stride, t_head_stride, \
+                                          t_target_stride, prob, labels, cost, heads, Q, n, n_targets, classes, w_mask, w_class, w_dice)
+#define PD_MCJ(T, V) do { if (n_targets <= 4 || (n_targets > 8 && n_targets <= 12)) PD_MC(T, V, 4); else PD_MC(T, V, 8); } while (0)
+  if (dtype == PD_BF16) { if (v2) PD_MCJ(bf16_t, 2); else PD_MCJ(bf16_t, 1); }
+  else { if (v2) PD_MCJ(float, 2); else PD_MCJ(float, 1); }
+#undef PD_MCJ
+#undef PD_MC
   return pd_check_launch("pd_matcher_costs");
 }
 
@@ -278,7 +365,10 @@ extern "C" int pd_mask_point_losses_fwd(const float *x, const float *y, float *b
   if (rows < 0 || n <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_mask_point_losses_fwd: rows=%d n=%d", rows, n);
   if (rows == 0) return PD_OK;
   if (!x || !y || !bce || !dice || !stats) return pd_set_error(PD_ERR_INVALID_ARG, "pd_mask_point_losses_fwd: null pointer");
-  hipLaunchKernelGGL(mask_point_losses_fwd, dim3(rows), dim3(256), 0, (hipStream_t)stream_, x, y, bce, dice, stats, n);
+  if (!(n & 3) && !(((uintptr_t)x | (uintptr_t)y) & 15))
+    hipLaunchKernelGGL(mask_point_losses_fwd<4>, dim3(rows), dim3(LT), 0, (hipStream_t)stream_, x, y, bce, dice, stats, n);
+  else
+    hipLaunchKernelGGL(mask_point_losses_fwd<1>, dim3(rows), dim3(LT), 0, (hipStream_t)stream_, x, y, bce, dice, stats, n);
   return pd_check_launch("pd_mask_point_losses_fwd");
 }
 

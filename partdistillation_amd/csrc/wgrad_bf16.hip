@@ -360,7 +360,9 @@ int wg_plan(const PdWgrad *p, WgPlan &pl)
   // with two resident workgroups (two stages of 32 KB each) and ~0.9 us with one; a slice costs its 64 KB slab written and read back,
   // ~0.27 us per MB on top of ~5 us for the second launch.  So: fill the 512 resident slots once, but keep runs of >= 512 rows (>= 1024
   // when there are so few tiles that the slabs of ONE tile are the reduce kernel's serial chain).
-  const int rmin = a.tiles <= 16 ? 1024 : 512;
+  int rmin = a.tiles <= 16 ? 1024 : 512;
+  if (a.tiles * (a.M / rmin > 1 ? a.M / rmin : 1) < 32) rmin = 256;     // a few tiles over a few thousand rows (the decoder's 2 000-row MLP: 4 tiles
+                                                                         // ran as 4 workgroups x 32 stages, 42 us): shorter runs, 7 slabs per tile
   int splits = a.tiles >= 512 ? 1 : 512 / a.tiles;
   if (splits > a.M / rmin) splits = a.M / rmin;
   if (splits < 1) splits = 1;

@@ -82,7 +82,7 @@ def uncertain_points_supported(logits, coords, k):
 
 def uncertain_points(logits, coords, k, random_coords=None):
     """logits [N, K] fp32, coords [N, K, 2], random_coords [N, R, 2] | None -> [N, k + R, 2]: the coordinates of the k points with the
-    smallest |logit| (below the threshold value in index order, then its lowest-index ties), then the random ones (reference criterion.py:181-189; no gradient)"""
+    smallest |logit| (a fixed order; ties at the threshold: a fixed choice), then the random ones (reference criterion.py:181-189; no gradient)"""
     if not logits.is_cuda:
         raise RuntimeError("pd_uncertain_points runs on the GPU only (no CPU fallback in partdistillation_amd)")
     logits, coords = logits.contiguous(), coords.contiguous()
