@@ -12,6 +12,7 @@
  *                             logits and their sigmoids (2 x 100 MB at BASELINE config 2) are never written.
  *   pd_mask_point_losses_*    sigmoid_ce_loss (criterion.py:50-69) and dice_loss (:25-47) of the matched masks at their sampled
  *                             points, per mask, and their gradient with respect to the point logits.
+ *   pd_point_sample_u8        the target masks at the matcher's / the loss's points, read as stored bytes.
  *   pd_uncertain_points       get_uncertain_point_coords_with_randomness (criterion.py:181-189, detectron2 point_rend): of K
  *                             oversampled points per mask keep the k with the smallest |logit| (calculate_uncertainty :72-88 is
  *                             -|logit|), followed by the mask's random points — replaces abs, neg, a multi-block top-k, a gather
@@ -77,6 +78,14 @@ int pd_mask_point_losses_bwd(const float *x, const float *y, const float *stats,
 #define PD_UNCERTAIN_MAX_K 40960
 int pd_uncertain_points(const float *logits, const float *coords, const float *random_coords, float *out, int rows, int K, int k,
                         int n_random, void *stream);
+
+/*
+ * Bilinear samples (F.grid_sample: bilinear, zeros padding, align_corners=False — detectron2 point_sample) of one-byte 0 / non-0 masks
+ * maps [M, H, W] as they are stored (the reference samples `.float()` copies: matcher.py:130-139, criterion.py:196-199):
+ *   out[r, p] = sample of map map_idx[r] (row r when map_idx is NULL) at coords[r / coords_div, p]   (coords [ceil(rows / coords_div), P, 2] in [0, 1])
+ */
+int pd_point_sample_u8(const uint8_t *maps, const int64_t *map_idx, const float *coords, float *out, int rows, int P, int H, int W,
+                       int coords_div, void *stream);
 
 #ifdef __cplusplus
 }

@@ -140,6 +140,7 @@ const Entry kTable[] = {
   PD_E(pd_point_sample_nhwc_f32_bf16),
   PD_E(pd_point_sample_planar_bwd_f32),
   PD_E(pd_point_sample_planar_f32),
+  PD_E(pd_point_sample_u8),
   PD_E(pd_relu_bwd_colsum),
   PD_E(pd_resample_cols_u8),
   PD_E(pd_resample_rows_u8),

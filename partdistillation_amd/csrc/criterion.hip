@@ -336,7 +336,47 @@ __global__ __launch_bounds__(UT) void uncertain_points(const float *__restrict__
   }
   for (int i = tid; i < n_random; i += UT) orow[k + i] = rnd[(int64_t)row * n_random + i];
 }
+// ------------------------------------------------------------------------------------------------ target masks at points
+// F.grid_sample(bilinear, zeros, align_corners=False) of one-byte 0 / 1 masks (the padded target masks as stored: no fp32 copy of them)
+// at per-row points: row r reads map map_idx[r] (or r) at the coordinates of row r / coords_div.  One lane per point; the arithmetic is
+// the planar sampler's (rowwise.hip), the four corners are bytes.
+__global__ __launch_bounds__(256) void point_sample_u8(const uint8_t *__restrict__ maps, const int64_t *__restrict__ map_idx,
+                                                       const float *__restrict__ coords, float *__restrict__ out, int64_t total, int P, int H,
+                                                       int W, int coords_div)
+{
+  for (int64_t pt = (int64_t)blockIdx.x * 256 + threadIdx.x; pt < total; pt += (int64_t)gridDim.x * 256) {
+    const int64_t r = pt / P;
+    const int p = (int)(pt - r * P);
+    const int64_t m = map_idx ? map_idx[r] : r;
+    const float2 c = *reinterpret_cast<const float2 *>(coords + ((r / coords_div) * P + p) * 2);
+    const float gx = 2.0f * c.x - 1.0f, gy = 2.0f * c.y - 1.0f;
+    const float ix = ((gx + 1.f) * W - 1.f) / 2.f, iy = ((gy + 1.f) * H - 1.f) / 2.f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wnw = (x1 - ix) * (y1 - iy), wne = (ix - x0) * (y1 - iy), wsw = (x1 - ix) * (iy - y0), wse = (ix - x0) * (iy - y0);
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const uint8_t *mp = maps + m * (int64_t)H * W;
+    float acc = 0.f;
+    if (vy0 && vx0) acc += (mp[(int64_t)y0 * W + x0] ? 1.f : 0.f) * wnw;
+    if (vy0 && vx1) acc += (mp[(int64_t)y0 * W + x1] ? 1.f : 0.f) * wne;
+    if (vy1 && vx0) acc += (mp[(int64_t)y1 * W + x0] ? 1.f : 0.f) * wsw;
+    if (vy1 && vx1) acc += (mp[(int64_t)y1 * W + x1] ? 1.f : 0.f) * wse;
+    out[pt] = acc;
+  }
+}
 }  // namespace
+
+extern "C" int pd_point_sample_u8(const uint8_t *maps, const int64_t *map_idx, const float *coords, float *out, int rows, int P, int H, int W,
+                                  int coords_div, void *stream_)
+{
+  if (rows < 0 || P < 0 || H <= 0 || W <= 0 || coords_div <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_point_sample_u8: rows=%d P=%d H=%d W=%d coords_div=%d", rows, P, H, W, coords_div);
+  if (rows == 0 || P == 0) return PD_OK;
+  if (!maps || !coords || !out) return pd_set_error(PD_ERR_INVALID_ARG, "pd_point_sample_u8: null pointer");
+  const int64_t total = (int64_t)rows * P;
+  const unsigned grid = (unsigned)((total + 255) / 256 > 65536 * 16 ? 65536 * 16 : (total + 255) / 256);
+  hipLaunchKernelGGL(point_sample_u8, dim3(grid), dim3(256), 0, (hipStream_t)stream_, maps, map_idx, coords, out, total, P, H, W, coords_div);
+  return pd_check_launch("pd_point_sample_u8");
+}
 
 extern "C" int pd_matcher_costs(const void *x, int dtype, const float *t, int64_t t_image_stride, int64_t t_head_stride,
                                 int64_t t_target_stride, const float *prob, const int64_t *labels, float *cost, int problems, int heads, int Q,

@@ -93,3 +93,26 @@ def uncertain_points(logits, coords, k, random_coords=None):
     _lib.check(_lib.load().pd_uncertain_points(logits.data_ptr(), coords.data_ptr(), rnd.data_ptr() if rnd is not None else None, out.data_ptr(),
                                                N, K, k, R, _stream()))
     return out
+
+
+def point_sample_masks_supported(masks, coords):
+    return (ENABLED and masks.is_cuda and masks.dtype in (torch.bool, torch.uint8) and masks.is_contiguous() and masks.dim() >= 3
+            and coords.dtype == torch.float32 and coords.dim() == 3 and coords.shape[2] == 2)
+
+
+def point_sample_masks(masks, coords, map_idx=None, coords_div=1):
+    """masks bool / uint8 [..., H, W] (M maps), coords [R_c, P, 2] in [0, 1], map_idx int64 [rows] | None (rows = M, row r reads map r)
+    -> fp32 [rows, P]: bilinear samples (zeros padding, align_corners=False) of map map_idx[r] at coords[r // coords_div]; no gradient"""
+    if not masks.is_cuda:
+        raise RuntimeError("pd_point_sample_u8 runs on the GPU only (no CPU fallback in partdistillation_amd)")
+    H, W = masks.shape[-2:]
+    M = masks.numel() // max(H * W, 1)
+    rows = M if map_idx is None else map_idx.numel()
+    coords = coords.contiguous()
+    P = coords.shape[1]
+    assert coords.shape[0] * coords_div >= rows, (coords.shape, coords_div, rows)
+    mi = None if map_idx is None else map_idx.contiguous()
+    out = torch.empty((rows, P), dtype=torch.float32, device=masks.device)
+    _lib.check(_lib.load().pd_point_sample_u8(masks.data_ptr(), mi.data_ptr() if mi is not None else None, coords.data_ptr(), out.data_ptr(), rows, P,
+                                              H, W, coords_div, _stream()))
+    return out

@@ -186,7 +186,9 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
         ocoords = torch.rand((H * N_h, kover, 2), device=dev)
         rcoords = torch.rand((H * N_h, krand, 2), device=dev) if krand > 0 else None
 
-    tmask = padded_masks.float()                                                                 # [B,nmax,Hm,Wm], once
+    # the target masks are sampled as the bytes they are stored in (pd_point_sample_u8) on the GPU; the fp32 copy is the torch path's
+    byte_masks = cops.point_sample_masks_supported(padded_masks, ocoords) and nmax > 0
+    tmask = None if byte_masks else padded_masks.float()                                         # [B,nmax,Hm,Wm], once
     labels_pad = torch.zeros((B, nmax), dtype=torch.long, device=dev)
     for b, t in enumerate(targets):
         labels_pad[b, : ns[b]] = t["labels"]
@@ -203,7 +205,10 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
             pm = torch.bmm(e, fm.view(B * H, Pm, -1).to(e.dtype).transpose(1, 2))
         else:
             pm = _gs(masks_bd.detach().reshape(B * H, Q, *masks_bd.shape[-2:]).float(), mc_bd.reshape(B * H, Pm, 2))   # [BD,Q,Pm]
-        tg4 = _gs(tmask, mc_bd.reshape(B, H * Pm, 2)).reshape(B, nmax, H, Pm)                    # the sampler's layout: targets x heads
+        if byte_masks:                                                                           # row (b, j): map b * nmax + j at image b's points
+            tg4 = cops.point_sample_masks(padded_masks, mc_bd.reshape(B, H * Pm, 2), None, nmax).view(B, nmax, H, Pm)
+        else:
+            tg4 = _gs(tmask, mc_bd.reshape(B, H * Pm, 2)).reshape(B, nmax, H, Pm)                # the sampler's layout: targets x heads
         lf = logits_bd.detach().float()
         prob = lf.sigmoid() if K1 == 1 else lf.softmax(-1)
         if cops.matcher_costs_supported(pm, tg4, prob, labels_pad) and nmax > 0:
@@ -262,13 +267,17 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
                 coords = torch.gather(ocoords, 1, idx[:, :, None].expand(-1, -1, 2))
                 if krand > 0:
                     coords = torch.cat([coords, rcoords], dim=1)                                 # [N,P,2]
-            labels = torch.empty((coords.shape[0], P), dtype=torch.float32, device=dev)
-            for b in range(B):                                                                   # targets as channels
-                pi = per_image[b]
-                if pi.numel() == 0:
-                    continue
-                s = _gs(tmask[b:b + 1], coords[pi].reshape(1, -1, 2)).reshape(nmax, pi.numel(), P)
-                labels[pi] = s[j_idx[pi], _arange(pi.numel(), dev)]
+            if byte_masks:
+                # pair n reads ITS target (image sel_b[n], target j_idx[n]) at ITS points: one launch, no n_targets-fold oversampling
+                labels = cops.point_sample_masks(padded_masks, coords, sel_b * nmax + j_idx)     # [N,P]
+            else:
+                labels = torch.empty((coords.shape[0], P), dtype=torch.float32, device=dev)
+                for b in range(B):                                                               # targets as channels
+                    pi = per_image[b]
+                    if pi.numel() == 0:
+                        continue
+                    s = _gs(tmask[b:b + 1], coords[pi].reshape(1, -1, 2)).reshape(nmax, pi.numel(), P)
+                    labels[pi] = s[j_idx[pi], _arange(pi.numel(), dev)]
         pl = _gs(src, coords)[:, 0, :]                                                           # [N,P]
         if cops.mask_point_losses_supported(pl, labels):
             bce, dice = cops.mask_point_losses(pl, labels)                    # per mask, forward and backward one launch each

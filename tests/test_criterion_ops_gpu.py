@@ -155,3 +155,28 @@ def test_own_mlp_node_matches_the_module_path_under_autocast(rows_shape):
     for (n, p), q in zip(own.named_parameters(), ref.parameters()):
         assert p.grad.dtype == p.dtype
         close(p.grad, q.grad, n)
+
+
+@pytest.mark.parametrize("shape,P", [((2, 4, 64, 48), 500), ((1, 1, 7, 9), 33), ((3, 2, 128, 128), 4096)])
+def test_point_sample_masks_equals_grid_sample_of_the_float_copy(shape, P):
+    """pd_point_sample_u8: the padded target masks sampled as stored (bool bytes) — bit-identical to the planar fp32 sampler on
+    `.float()` copies and equal to F.grid_sample (bilinear, zeros, align_corners=False; matcher.py:130-139, criterion.py:196-199) within
+    fp32 rounding, in both forms: every map of an image at the image's points, and one chosen map per row at the row's points"""
+    from partdistillation_amd.functions import criterion_ops as cops
+    from partdistillation_amd.functions import rowwise as rw
+    B, nmax, H, W = shape
+    torch.manual_seed(H + P)
+    masks = torch.rand(shape, device=DEV) > 0.5
+    coords = torch.rand(B, P, 2, device=DEV) * 1.1 - 0.05                    # some points outside [0, 1]: zeros padding
+    assert cops.point_sample_masks_supported(masks, coords)
+    got = cops.point_sample_masks(masks, coords, None, nmax).view(B, nmax, P)
+    ref = F.grid_sample(masks.float(), 2.0 * coords.unsqueeze(2) - 1.0, mode="bilinear", padding_mode="zeros", align_corners=False).squeeze(3)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-6)
+    assert torch.equal(got, rw.point_sample_planar(masks.float(), coords))
+    N = 11
+    idx = torch.randint(0, B * nmax, (N,), device=DEV)
+    c2 = torch.rand(N, P, 2, device=DEV)
+    got2 = cops.point_sample_masks(masks, c2, idx)
+    ref2 = F.grid_sample(masks.float().view(B * nmax, 1, H, W)[idx], 2.0 * c2.unsqueeze(2) - 1.0, mode="bilinear", padding_mode="zeros",
+                         align_corners=False)[:, 0, :, 0]
+    torch.testing.assert_close(got2, ref2, rtol=1e-5, atol=1e-6)
