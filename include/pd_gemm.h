@@ -139,6 +139,13 @@ int64_t pd_gemm_tn_f16x2_bits_words(int M, int N);
 int pd_gemm_tn_f16x2(const float *A, const float *B, const float *bias, float *C, uint32_t *bits, float *colsum, const float *a_amax,
                      const float *b_amax, float *c_amax, int M, int N, int K, int lda, int ldb, int ldc, int mode, void *stream);
 int pd_row_amax_f32(const float *X, int rows, int cols, int ld, float *out, void *stream);
+/* pd_gemm_tn_f16x2 (mode 0, no row maxima out) with the result rounded to bf16 on the way out (C_bf16 [M, ldc] bf16): the input gradient of a
+ * 1 x 1 convolution whose input was a bf16 backbone map — autograd's cast of the fp32 gradient (a pass of its own) is the epilogue. */
+int pd_gemm_tn_f16x2_bf16out(const float *A, const float *B, const float *bias, void *C_bf16, const float *a_amax, const float *b_amax, int M, int N,
+                             int K, int lda, int ldb, int ldc, void *stream);
+/* X bf16 [rows, cols] contiguous (cols % 8 == 0) -> Y fp32 [rows, cols] = X and row_amax[r] = max_c |X[r, c]| in one pass: the reference's
+ * `features[f].float()` in front of the pixel decoder's 1 x 1 convolutions (msdeformattn.py:324, 338) fused with the row-maxima pass. */
+int pd_cast_bf16_f32_amax(const void *X_bf16, int rows, int cols, float *Y, float *row_amax, void *stream);
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,7 @@ const Entry kTable[] = {
   PD_E(pd_attn_bwd_d32),
   PD_E(pd_attn_fwd_d32),
   PD_E(pd_attn_mask_u8),
+  PD_E(pd_cast_bf16_f32_amax),
   PD_E(pd_colsum_acc),
   PD_E(pd_conv3x3_nhwc_f16x2),
   PD_E(pd_conv3x3_nhwc_f32x3),
@@ -88,6 +89,7 @@ const Entry kTable[] = {
   PD_E(pd_decoder_head_bf16),
   PD_E(pd_filter_transpose_grouped),
   PD_E(pd_gemm_tn_f16x2),
+  PD_E(pd_gemm_tn_f16x2_bf16out),
   PD_E(pd_gemm_tn_f32),
   PD_E(pd_gemm_tn_f32x3),
   PD_E(pd_gemm_tn_f32x3_pre),

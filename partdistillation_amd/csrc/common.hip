@@ -28,7 +28,7 @@ int pd_check_launch(const char *what)
 }
 
 extern "C" const char *pd_last_error(void) { return g_err; }
-extern "C" int pd_abi_version(void) { return 27; }
+extern "C" int pd_abi_version(void) { return 28; }
 
 // experiment knobs (not part of the public ABI contract; used by tools/ only)
 extern int g_pd_dbg_atomic_scope;
@@ -54,6 +54,7 @@ extern int g_ig_bn, g_ig_nst, g_ig_splits;
 extern int g_mx_bn, g_mx_nst;
 extern int g_swin_ln_abl;
 extern int g_ln_bwd_cap;
+extern int g_crit_abl;
 extern int g_wg_nst, g_wg_splits, g_wg_mode;
 extern "C" int pd_debug_set(const char *key, int value)
 {
@@ -72,6 +73,7 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!strcmp(key, "ig_bn")) { g_ig_bn = value; return PD_OK; }
   if (!strcmp(key, "ig_nst")) { g_ig_nst = value; return PD_OK; }
   if (!strcmp(key, "mx_bn")) { g_mx_bn = value; return PD_OK; }
+  if (!strcmp(key, "crit_abl")) { g_crit_abl = value; return PD_OK; }
   if (!strcmp(key, "ln_bwd_cap")) { g_ln_bwd_cap = value; return PD_OK; }
   if (!strcmp(key, "swin_ln_abl")) { g_swin_ln_abl = value; return PD_OK; }
   if (!strcmp(key, "mx_nst")) { g_mx_nst = value; return PD_OK; }

@@ -17,6 +17,8 @@
 #include "pd_criterion.h"
 #include "pd_msda.h"
 
+int g_crit_abl = 0;                                  // pd_debug_set "crit_abl" (tools/bench_criterion_ops.py only): phases of uncertain_points removed
+
 namespace {
 typedef unsigned short bf16_t;
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
@@ -251,7 +253,7 @@ __device__ __noinline__ void hist_add(int *hist, int bin, bool active)
 }
 
 __global__ __launch_bounds__(UT) void uncertain_points(const float *__restrict__ logits, const float2 *__restrict__ coords,
-                                                       const float2 *__restrict__ rnd, float2 *__restrict__ out, int K, int k, int n_random)
+                                                       const float2 *__restrict__ rnd, float2 *__restrict__ out, int K, int k, int n_random, int abl)
 {
   __shared__ int hist[256];
   __shared__ int wsum[UT / 64];
@@ -264,7 +266,8 @@ __global__ __launch_bounds__(UT) void uncertain_points(const float *__restrict__
 #pragma unroll
   for (int m = 0; m < UV; ++m) {
     const int i = m * UT + tid;
-    key[m] = (m < per && i < K) ? (__float_as_uint(lr[i]) & 0x7fffffffu) : 0xffffffffu;     // |logit| as an ordered integer; padding sorts last
+    const unsigned bits = __float_as_uint(lr[i < K ? i : K - 1]);                           // unconditional (clamped) loads: all in flight at once
+    key[m] = (m < per && i < K) ? (bits & 0x7fffffffu) : 0xffffffffu;                       // |logit| as an ordered integer; padding sorts last
   }
   unsigned prefix = 0, mask = 0;
   int remaining = k;
@@ -272,10 +275,12 @@ __global__ __launch_bounds__(UT) void uncertain_points(const float *__restrict__
   for (int shift = 24; shift >= 0; shift -= 8) {
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    if (shift == 24) {
+    if (shift == 24 && !(abl & 1)) {
 #pragma unroll
       for (int m = 0; m < UV; ++m)
         if (m < per) hist_add<4>(hist, (int)(key[m] >> 24), key[m] != 0xffffffffu);
+    } else if (abl & 2) {
+      if (tid == 0) hist[(prefix >> shift) & 255 ? 1 : 1] = K;     // (timing only) no counting at all
     } else {
 #pragma unroll
       for (int m = 0; m < UV; ++m)
@@ -320,13 +325,14 @@ __global__ __launch_bounds__(UT) void uncertain_points(const float *__restrict__
   float2 *orow = out + (int64_t)row * (k + n_random);
   const float2 *crow = coords + (int64_t)row * K;
   int a = pos_less, e = pos_eq;
+  if (abl & 4) return;                                             // (timing only) no compaction
 #pragma unroll
   for (int m0 = 0; m0 < UV; m0 += 8) {                             // eight coordinate loads in flight, then the (conditional) stores:
     float2 c[8];                                                   // a load inside the branch would be one memory round trip per point
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = (m0 + u) * UT + tid;
-      c[u] = (key[m0 + u] <= prefix) ? crow[i] : make_float2(0.f, 0.f);
+      c[u] = crow[i < K ? i : K - 1];                              // (clamped, not predicated: a predicated load is its own basic block)
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -431,6 +437,6 @@ extern "C" int pd_uncertain_points(const float *logits, const float *coords, con
   if (rows == 0) return PD_OK;
   if (!logits || !coords || !out || (n_random && !random_coords)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_uncertain_points: null pointer");
   hipLaunchKernelGGL(uncertain_points, dim3(rows), dim3(UT), 0, (hipStream_t)stream_, logits, (const float2 *)coords, (const float2 *)random_coords,
-                     (float2 *)out, K, k, n_random);
+                     (float2 *)out, K, k, n_random, g_crit_abl);
   return pd_check_launch("pd_uncertain_points");
 }

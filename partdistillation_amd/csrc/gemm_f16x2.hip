@@ -37,6 +37,13 @@
 namespace {
 using namespace pdh2;
 __device__ __forceinline__ int xcd_chunk(int bid, int nb) { return pd_xcd_chunk(bid, nb); }   // xcd.h: any workgroup count
+__device__ __forceinline__ unsigned short f2bf_rne(float f)
+{
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
 
 // TM x TN tile, waves laid out (TM / 64) x (TN / WN), each wave 64 x WN = 2 x (WN / 32) MFMA tiles.
 // LDS: [stage][plane][k panel of 8][row][8 halves]: an MFMA operand (8 consecutive k of row lane % 32, panel lane / 32 of the
@@ -334,7 +341,11 @@ void gemm_tn_f16x2(const float *__restrict__ A, const float *__restrict__ B, con
             if (ok) csum[j] += v;
           }
           if (PD_ABL & 16) { asm volatile("" ::"v"(v)); rm = fmaxf(rm, fabsf(v)); }
-          else if (ok) { C[(int64_t)row * ldc + col] = v; rm = fmaxf(rm, fabsf(v)); }
+          else if (ok) {
+            if (!CONV && (H & 1)) reinterpret_cast<unsigned short *>(C)[(int64_t)row * ldc + col] = f2bf_rne(v);   // H = flags when not a convolution
+            else C[(int64_t)row * ldc + col] = v;
+            rm = fmaxf(rm, fabsf(v));
+          }
         }
         if (c_amax) red[rl * 33 + (lane & 31)] = rm;
       }
@@ -383,6 +394,31 @@ __global__ __launch_bounds__(256) void row_amax_f32(const float *__restrict__ X,
   if (lane == 0) out[row] = v;
 }
 
+
+// bf16 rows -> their fp32 copy AND their absolute maxima in one pass (the backbone's bf16 feature maps entering the fp32 pixel decoder:
+// was a cast launch + a row-maxima launch, i.e. the fp32 copy written and read back).  One wavefront per row, 8 channels per lane-step.
+__global__ __launch_bounds__(256) void cast_bf16_f32_amax(const unsigned short *__restrict__ X, int rows, int cols, float *__restrict__ Y,
+                                                          float *__restrict__ out)
+{
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const unsigned short *p = X + (int64_t)row * cols;
+  float *q = Y + (int64_t)row * cols;
+  float v = 0.f;
+  for (int c = lane * 8; c < cols; c += 512) {
+    const uint4 u = *reinterpret_cast<const uint4 *>(p + c);
+    float f[8];
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u); f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u); f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v = fmaxf(v, fabsf(f[k]));
+    *reinterpret_cast<float4 *>(q + c) = make_float4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<float4 *>(q + c + 4) = make_float4(f[4], f[5], f[6], f[7]);
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if (lane == 0) out[row] = v;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // gemm_rows_f16x2_k256: the K = 256 shapes of the encoder (value / output projections, the 1 x 1 convolutions on 256 channels;
@@ -592,8 +628,8 @@ extern "C" int64_t pd_gemm_tn_f16x2_bits_words(int M, int N)
   return (int64_t)((M + 255) / 256) * (N / 256) * 8 * 64 * 4;
 }
 
-extern "C" int pd_gemm_tn_f16x2(const float *A, const float *B, const float *bias, float *C, uint32_t *bits, float *colsum, const float *a_amax,
-                                const float *b_amax, float *c_amax, int M, int N, int K, int lda, int ldb, int ldc, int mode, void *stream_)
+static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias, float *C, uint32_t *bits, float *colsum, const float *a_amax,
+                             const float *b_amax, float *c_amax, int M, int N, int K, int lda, int ldb, int ldc, int mode, void *stream_, int flags)
 {
   if (M < 0 || N < 0 || K < 0 || mode < 0 || mode > 2) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: negative size / bad mode");
   if (M == 0 || N == 0) return PD_OK;
@@ -602,7 +638,7 @@ extern "C" int pd_gemm_tn_f16x2(const float *A, const float *B, const float *bia
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: K, lda, ldb must be multiples of 4 and A, B 16-byte aligned");
   hipStream_t st = (hipStream_t)stream_;
   const int dbg = g_pd_dbg_f16x2;
-  if (dbg == 61 && mode == 0 && K == 256 && (N % 256) == 0 && M >= 8192 && (a_amax == nullptr) == (b_amax == nullptr)) {
+  if (dbg == 61 && !flags && mode == 0 && K == 256 && (N % 256) == 0 && M >= 8192 && (a_amax == nullptr) == (b_amax == nullptr)) {
     // row stream (gemm_rows_f16x2_k256, experimental: see the kernel's header): one persistent workgroup per CU, panels of a row group on one XCD
     static int ncu = 0;
     if (!ncu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = 256; }
@@ -623,7 +659,7 @@ extern "C" int pd_gemm_tn_f16x2(const float *A, const float *B, const float *bia
   const bool wide_ok = (N % 256) == 0 && M >= 1024;
   const bool by_shape = dbg == 0 || dbg == 61 || dbg == 70;
   const bool wide = need_wide || dbg == 3 || dbg == 13 || (by_shape && wide_ok && (int64_t)((M + 255) / 256) * (N / 256) >= 128 && (N >= 1024 || K >= 512));
-#define GO(TM, TN, WN, NRS, FAST) return launch_f16x2<TM, TN, WN, 16, false, NRS, FAST>(A, B, bias, C, M, N, K, lda, ldb, ldc, mode, bits, colsum, a_amax, b_amax, c_amax, st)
+#define GO(TM, TN, WN, NRS, FAST) return launch_f16x2<TM, TN, WN, 16, false, NRS, FAST>(A, B, bias, C, M, N, K, lda, ldb, ldc, mode, bits, colsum, a_amax, b_amax, c_amax, st, flags)
   // Measured and dropped (tools/bench_gemm_h2.py, M = 43 008): 32-deep steps (1024 <- 256 103.7 vs 96.8 us, 256 <- 1024 90.9 vs 85.4,
   // 256 <- 256 32.9 vs 29.3: half the workgroups in flight), 128 x 256 tiles with two workgroups per CU (no gain).
   // Two register stages (loads two steps ahead of their split): 97.0 vs 99.9 us on 1024 <- 256, 85.3 vs 87.9 on 256 <- 1024.
@@ -641,6 +677,28 @@ extern "C" int pd_gemm_tn_f16x2(const float *A, const float *B, const float *bia
   if (dbg == 14) GO(128, 128, 64, 2, 0);
   GO(128, 128, 64, 2, 1);
 #undef GO
+}
+
+extern "C" int pd_gemm_tn_f16x2(const float *A, const float *B, const float *bias, float *C, uint32_t *bits, float *colsum, const float *a_amax,
+                                const float *b_amax, float *c_amax, int M, int N, int K, int lda, int ldb, int ldc, int mode, void *stream_)
+{
+  return gemm_tn_f16x2_impl(A, B, bias, C, bits, colsum, a_amax, b_amax, c_amax, M, N, K, lda, ldb, ldc, mode, stream_, 0);
+}
+
+extern "C" int pd_gemm_tn_f16x2_bf16out(const float *A, const float *B, const float *bias, void *C_bf16, const float *a_amax, const float *b_amax,
+                                        int M, int N, int K, int lda, int ldb, int ldc, void *stream_)
+{
+  return gemm_tn_f16x2_impl(A, B, bias, reinterpret_cast<float *>(C_bf16), nullptr, nullptr, a_amax, b_amax, nullptr, M, N, K, lda, ldb, ldc, 0, stream_, 1);
+}
+
+extern "C" int pd_cast_bf16_f32_amax(const void *X_bf16, int rows, int cols, float *Y, float *row_amax, void *stream_)
+{
+  if (rows < 0 || cols <= 0 || (cols & 7)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_cast_bf16_f32_amax: rows=%d cols=%d (a multiple of 8)", rows, cols);
+  if (rows == 0) return PD_OK;
+  if (!X_bf16 || !Y || !row_amax || ((uintptr_t)X_bf16 & 15) || ((uintptr_t)Y & 15)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_cast_bf16_f32_amax: null / misaligned pointer");
+  hipLaunchKernelGGL(cast_bf16_f32_amax, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, (const unsigned short *)X_bf16, rows, cols, Y,
+                     row_amax);
+  return pd_check_launch("pd_cast_bf16_f32_amax");
 }
 
 extern "C" int pd_conv3x3_nhwc_f16x2(const float *X, const float *Wk, const float *bias, float *Y, const float *x_amax, const float *w_amax,

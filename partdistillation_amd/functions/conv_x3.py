@@ -108,21 +108,30 @@ class Conv1x1OwnWgrad(Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.has_bias = bias is not None
+        ctx.x_bf16 = x.dtype == torch.bfloat16
         if H2 and H2_1X1 and x.is_contiguous(memory_format=torch.channels_last):
-            from .gemm import gemm_tn_h2, row_amax
+            from .gemm import cast_rows_amax, gemm_tn_h2, row_amax
             B, ci, Hh, Ww = x.shape
             co = weight.shape[0]
-            x_am = _pixel_amax(x)
+            if ctx.x_bf16:
+                # a bf16 backbone map (the reference's `features[f].float()`, msdeformattn.py:324, 338): its fp32 copy and its pixels' channel
+                # maxima in ONE pass, and the input gradient goes back as bf16 from the GEMM's epilogue (no cast launches either way)
+                x2, x_am = cast_rows_amax(x.permute(0, 2, 3, 1).reshape(-1, ci))
+                x = x2.view(B, Hh, Ww, ci).permute(0, 3, 1, 2)
+            else:
+                x_am = _pixel_amax(x)
             w2 = weight.reshape(co, ci)
             y = gemm_tn_h2(x.permute(0, 2, 3, 1).reshape(-1, ci), w2, bias, a_amax=x_am, b_amax=row_amax(w2))
             ctx.save_for_backward(x, weight, x_am)
             return y.view(B, Hh, Ww, co).permute(0, 3, 1, 2)
+        if ctx.x_bf16:
+            x = x.float()
         ctx.save_for_backward(x, weight, None)
         return torch.ops.aten.convolution(x, weight, bias, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
 
     @staticmethod
     def backward(ctx, dy):
-        from .gemm import gemm_tn_h2, gemm_wgrad_acc, row_amax
+        from .gemm import gemm_tn_h2, gemm_tn_h2_bf16out, gemm_wgrad_acc, row_amax
         x, weight, x_am = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last)
         co, ci = weight.shape[0], weight.shape[1]
@@ -134,9 +143,11 @@ class Conv1x1OwnWgrad(Function):
             if h2:
                 wt = weight.reshape(co, ci).t().contiguous()                       # [Ci, Co]: the B operand of dX = dY W
                 B, _, Hh, Ww = x.shape
-                dx = gemm_tn_h2(rows(dy), wt, None, a_amax=dy_am, b_amax=row_amax(wt)).view(B, Hh, Ww, ci).permute(0, 3, 1, 2)
+                mm = gemm_tn_h2_bf16out if ctx.x_bf16 else gemm_tn_h2
+                dx = mm(rows(dy), wt, None, a_amax=dy_am, b_amax=row_amax(wt)).view(B, Hh, Ww, ci).permute(0, 3, 1, 2)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+                dx = dx.to(torch.bfloat16) if ctx.x_bf16 else dx
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if want_w or want_b:
             buf = torch.zeros(co * ci + co, dtype=torch.float32, device=x.device)
@@ -151,7 +162,8 @@ class Conv1x1OwnWgrad(Function):
 
 
 def conv1x1_supported(x, conv):
-    return (WGRAD_X3 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.weight.dtype == torch.float32
+    return (WGRAD_X3 and x.is_cuda and (x.dtype == torch.float32 or (x.dtype == torch.bfloat16 and H2 and H2_1X1 and x.shape[1] % 8 == 0))
+            and x.dim() == 4 and conv.weight.dtype == torch.float32
             and tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (0, 0)
             and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and x.shape[1] % 4 == 0 and conv.weight.shape[0] % 4 == 0
             and x.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled())

@@ -72,6 +72,29 @@ def row_amax(x):
     return out
 
 
+def cast_rows_amax(x):
+    """x bf16 [rows, cols] contiguous (cols % 8 == 0) -> (x as fp32, absolute row maxima [rows]) in one pass (pd_cast_bf16_f32_amax)"""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous() and x.shape[1] % 8 == 0
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    am = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().pd_cast_bf16_f32_amax(x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), am.data_ptr(), _stream()))
+    return y, am
+
+
+def gemm_tn_h2_bf16out(a, b, bias=None, a_amax=None, b_amax=None):
+    """gemm_tn_h2 (mode 0) with the result rounded to bf16 in the epilogue (pd_gemm_tn_f16x2_bf16out)"""
+    if not a.is_cuda:
+        raise RuntimeError("pd_gemm_tn_f16x2_bf16out runs on the GPU only (no CPU fallback in partdistillation_amd)")
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1 and b.shape[1] == a.shape[1]
+    M, K = a.shape
+    N = b.shape[0]
+    c = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    p = lambda t: t.data_ptr() if t is not None else None
+    _lib.check(_lib.load().pd_gemm_tn_f16x2_bf16out(a.data_ptr(), b.data_ptr(), p(bias), c.data_ptr(), p(a_amax), p(b_amax), M, N, K, a.stride(0),
+                                                    b.stride(0), N, _stream()))
+    return c
+
+
 def h2_bits_supported(M, N):
     return N % 256 == 0 and M >= 1024
 

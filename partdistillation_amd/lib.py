@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libpd_hip.so") 
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -36,6 +36,8 @@ SIGNATURES = {
     "pd_conv3x3_nhwc_f16x2": (_c_int, [_c_vp] * 7 + [_c_int] * 5 + [_c_vp]),
     "pd_gemm_tn_f16x2_bits_words": (ctypes.c_int64, [_c_int] * 2),
     "pd_gemm_tn_f16x2": (_c_int, [_c_vp] * 9 + [_c_int] * 7 + [_c_vp]),
+    "pd_gemm_tn_f16x2_bf16out": (_c_int, [_c_vp] * 6 + [_c_int] * 6 + [_c_vp]),
+    "pd_cast_bf16_f32_amax": (_c_int, [_c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp]),
     "pd_row_amax_f32": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "pd_gemm_tn_f32x3_relumask": (_c_int, [_c_vp] * 5 + [_c_int] * 6 + [_c_vp]),
     "pd_gemm_tn_f32x3_relu_bits": (_c_int, [_c_vp] * 5 + [_c_int] * 6 + [_c_vp]),

@@ -227,6 +227,15 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
 CONV_X3 = bool(int(__import__("os").environ.get("PD_CONV_X3", "1")))   # functions/conv_x3.py for the 3 x 3 FPN convolution
 
 
+def _as_fp32_input(x, conv):
+    """the reference's `features[f].float()` (:324, 338).  A bf16 channels-last backbone map whose consumer is the own 1 x 1 convolution stays
+    bf16 here: that node makes the fp32 copy together with the row maxima it needs anyway and returns a bf16 input gradient
+    (functions/conv_x3.Conv1x1OwnWgrad) — the same values, two cast launches and one row-maxima launch less per level."""
+    if x.dtype == torch.bfloat16 and CONV_X3 and conv_x3.conv1x1_supported(x, conv) and x.requires_grad:
+        return x
+    return x.float()
+
+
 def _conv_gn(conv, gn, x, relu=False):
     """conv -> GroupNorm (-> ReLU); on the GPU in fp32 the norm (+ReLU) is the channels-last HIP GroupNorm
     (functions/fused.py), so the maps stay NHWC from the backbone to the encoder tokens with no layout copies."""
@@ -311,7 +320,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         with torch.autocast(device_type=next(iter(features.values())).device.type, enabled=False):
             srcs, pos = [], []
             for idx, f in enumerate(self.transformer_in_features[::-1]):
-                x = features[f].float()
+                x = _as_fp32_input(features[f], self.input_proj[idx][0])
                 srcs.append(_conv_gn(self.input_proj[idx][0], self.input_proj[idx][1], x))
                 pos.append(self.pe_layer(x))
             y, spatial_shapes, level_start_index, shapes_host = self.transformer(srcs, pos)
@@ -319,7 +328,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
             sizes = [h * w for h, w in shapes_host]
             out = [z.transpose(1, 2).reshape(bs, -1, h, w) for z, (h, w) in zip(torch.split(y, sizes, dim=1), shapes_host)]
             for idx, f in enumerate(self.in_features[: self.num_fpn_levels][::-1]):
-                x = features[f].float()
+                x = _as_fp32_input(features[f], self.lateral_convs[idx])
                 lat, outc = self.lateral_convs[idx], self.output_convs[idx]
                 cur = _conv_gn(lat, lat.norm, x, relu=lat.activation is not None)
                 if upsample_add_supported(out[-1], cur):

@@ -365,3 +365,34 @@ def test_gemm_wgrad_h2_matches_fp64(M, N, K, mag):
     r3 = x.double().t() @ x.double()
     assert ((dw3.double() - r3).abs().max().item() / r3.abs().max().item()) < 3e-6
     torch.testing.assert_close(db2, db, rtol=1e-4, atol=1e-3 * dy.abs().max().item())
+
+
+@pytest.mark.parametrize("B,Ci,H,W,Co", [(2, 256, 64, 48, 256), (1, 2048, 9, 7, 256), (2, 512, 33, 20, 256)])
+def test_conv1x1_node_with_a_bf16_map_equals_the_float_cast_form(B, Ci, H, W, Co):
+    """functions/conv_x3.Conv1x1OwnWgrad fed a bf16 channels-last backbone map (reference msdeformattn.py:324, 338: `features[f].float()` then
+    the 1 x 1 convolution): pd_cast_bf16_f32_amax makes the fp32 copy and the row maxima in one pass, pd_gemm_tn_f16x2_bf16out returns the
+    input gradient as bf16.  Against the same node on `x.float()` with autograd's casts: output bit-identical (same fp32 operands, same kernel), filter / bias
+    gradients equal to round-off, the input gradient equal to the bf16 rounding of the fp32 one."""
+    from partdistillation_amd.functions import conv_x3, gemm
+    g = torch.Generator(device="cuda").manual_seed(B + Ci + H)
+    xb = (torch.randn(B, Ci, H, W, device="cuda", generator=g) * 3).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Co, Ci, 1, 1, device="cuda", generator=g) * 0.05
+    b = torch.randn(Co, device="cuda", generator=g)
+    go = torch.randn(B, Co, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    # the fused cast: exact copy + exact maxima
+    rows = xb.permute(0, 2, 3, 1).reshape(-1, Ci)
+    x32, am = gemm.cast_rows_amax(rows)
+    assert torch.equal(x32, rows.float()) and torch.equal(am, rows.float().abs().amax(1))
+    outs = []
+    for as_bf16 in (True, False):
+        x = xb.clone().requires_grad_(True)
+        wp, bp = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = conv_x3.conv1x1(x if as_bf16 else x.float(), wp, bp)
+        y.backward(go)
+        assert x.grad.dtype == torch.bfloat16
+        outs.append((y.detach(), x.grad, wp.grad, bp.grad))
+    (y1, dx1, dw1, db1), (y0, dx0, dw0, db0) = outs
+    assert torch.equal(y1, y0)
+    for a, c in ((dw1, dw0), (db1, db0)):                         # the filter gradient's partial tiles are combined in arrival order: round-off only
+        assert float((a - c).abs().max()) <= 2e-6 * float(c.abs().max())
+    assert torch.equal(dx1, dx0)                                  # the epilogue's round-to-nearest-even is torch's cast
