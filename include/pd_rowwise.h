@@ -136,12 +136,14 @@ int pd_point_sample_planar_bwd_needs_zero_n(int N, int C, int H, int W);
  * FPN top-down step of the pixel decoder (reference msdeformattn.py:356-358:
  * `y = cur_fpn + F.interpolate(out[-1], size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)`), channels-last
  * fp32 [B, H, W, C] / [B, h, w, C]; same source-index arithmetic as torch's upsample_bilinear2d.
- *   pd_upsample_add_nhwc_f32     y = cur + upsample(lo), any (h, w) -> (H, W)
+ *   pd_upsample_add_nhwc_f32     y = cur + upsample(lo), any (h, w) -> (H, W); lo_batch_stride: floats between the images of lo (0 = h w C;
+ *                                larger when lo is one level of a [B, tokens, C] tensor, read in place)
  *   pd_upsample2x_bwd_nhwc_f32   dlo = upsample^T(dy) for H = 2h, W = 2w, in gather form (no atomics); d(cur) = dy
  */
-int pd_upsample_add_nhwc_f32(const float *lo, const float *cur, float *y, int B, int h, int w, int H, int W, int C, void *stream);
+int pd_upsample_add_nhwc_f32(const float *lo, int64_t lo_batch_stride, const float *cur, float *y, int B, int h, int w, int H, int W, int C, void *stream);
 /* the same with amax[B * H * W] = absolute maximum over the channels of every output pixel (C == 256 only) */
-int pd_upsample_add_amax_nhwc_f32(const float *lo, const float *cur, float *y, float *amax, int B, int h, int w, int H, int W, int C, void *stream);
+int pd_upsample_add_amax_nhwc_f32(const float *lo, int64_t lo_batch_stride, const float *cur, float *y, float *amax, int B, int h, int w, int H, int W, int C,
+                                  void *stream);
 int pd_upsample2x_bwd_nhwc_f32(const float *dy, float *dlo, int B, int h, int w, int C, void *stream);
 
 #ifdef __cplusplus

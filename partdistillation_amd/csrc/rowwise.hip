@@ -670,7 +670,7 @@ __device__ __forceinline__ void up_src(int dst, float scale, int in_size, int &i
 
 __global__ __launch_bounds__(256) void upsample_add_nhwc(const float *__restrict__ lo, const float *__restrict__ cur,
                                                          float *__restrict__ y, int B, int h, int w, int H, int W, int C4,
-                                                         float sh, float sw, float *__restrict__ amax)
+                                                         float sh, float sw, float *__restrict__ amax, int64_t lo_bs4)
 {
   const int64_t total = (int64_t)B * H * W * C4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(256) void upsample_add_nhwc(const float *__restrict
     int y0, yp, x0, xp; float hy0, hy1, wx0, wx1;
     up_src(oy, sh, h, y0, yp, hy0, hy1);
     up_src(ox, sw, w, x0, xp, wx0, wx1);
-    const float4 *L = reinterpret_cast<const float4 *>(lo) + (int64_t)b * h * w * C4;
+    const float4 *L = reinterpret_cast<const float4 *>(lo) + (int64_t)b * lo_bs4;         // lo_bs4: batch stride of lo in float4 (a level of a token tensor)
     const float4 a = L[((int64_t)y0 * w + x0) * C4 + c], bq = L[((int64_t)y0 * w + x0 + xp) * C4 + c];
     const float4 cq = L[((int64_t)(y0 + yp) * w + x0) * C4 + c], d = L[((int64_t)(y0 + yp) * w + x0 + xp) * C4 + c];
     const float4 u = reinterpret_cast<const float4 *>(cur)[i];
@@ -1007,8 +1007,10 @@ extern "C" int pd_point_sample_nhwc_f32_bf16(const float *in, const float *coord
   return pd_check_launch("pd_point_sample_nhwc_f32_bf16");
 }
 
-static int upsample_add_launch(const float *lo, const float *cur, float *y, int B, int h, int w, int H, int W, int C, void *stream_, float *amax)
+static int upsample_add_launch(const float *lo, int64_t lo_bs, const float *cur, float *y, int B, int h, int w, int H, int W, int C, void *stream_, float *amax)
 {
+  if (lo_bs == 0) lo_bs = (int64_t)h * w * C;
+  if (lo_bs < (int64_t)h * w * C || (lo_bs & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_upsample_add_nhwc_f32: lo_batch_stride %lld (>= h w C, a multiple of 4)", (long long)lo_bs);
   if (amax && C != 256) return pd_set_error(PD_ERR_INVALID_ARG, "pd_upsample_add_amax_nhwc_f32: pixel maxima need C == 256");
   if (B < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_upsample_add_nhwc_f32: bad sizes");
   if (B == 0) return PD_OK;
@@ -1016,20 +1018,20 @@ static int upsample_add_launch(const float *lo, const float *cur, float *y, int 
   const int64_t total = (int64_t)B * H * W * (C / 4);
   const unsigned grid = (unsigned)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
   hipLaunchKernelGGL(upsample_add_nhwc, dim3(grid), dim3(256), 0, (hipStream_t)stream_, lo, cur, y, B, h, w, H, W, C / 4,
-                     (float)h / (float)H, (float)w / (float)W, amax);
+                     (float)h / (float)H, (float)w / (float)W, amax, lo_bs / 4);
   return pd_check_launch("pd_upsample_add_nhwc_f32");
 }
 
-extern "C" int pd_upsample_add_nhwc_f32(const float *lo, const float *cur, float *y, int B, int h, int w, int H, int W, int C,
+extern "C" int pd_upsample_add_nhwc_f32(const float *lo, int64_t lo_batch_stride, const float *cur, float *y, int B, int h, int w, int H, int W, int C,
                                         void *stream_)
 {
-  return upsample_add_launch(lo, cur, y, B, h, w, H, W, C, stream_, nullptr);
+  return upsample_add_launch(lo, lo_batch_stride, cur, y, B, h, w, H, W, C, stream_, nullptr);
 }
 
-extern "C" int pd_upsample_add_amax_nhwc_f32(const float *lo, const float *cur, float *y, float *amax, int B, int h, int w, int H, int W, int C,
-                                             void *stream_)
+extern "C" int pd_upsample_add_amax_nhwc_f32(const float *lo, int64_t lo_batch_stride, const float *cur, float *y, float *amax, int B, int h, int w, int H,
+                                             int W, int C, void *stream_)
 {
-  return upsample_add_launch(lo, cur, y, B, h, w, H, W, C, stream_, amax);
+  return upsample_add_launch(lo, lo_batch_stride, cur, y, B, h, w, H, W, C, stream_, amax);
 }
 
 extern "C" int pd_upsample2x_bwd_nhwc_f32(const float *dy, float *dlo, int B, int h, int w, int C, void *stream_)

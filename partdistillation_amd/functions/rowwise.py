@@ -272,15 +272,20 @@ class UpsampleAdd(Function):
     def forward(ctx, lo, cur):
         B, C, h, w = lo.shape
         H, W = cur.shape[-2:]
-        lo_c = lo.contiguous(memory_format=torch.channels_last)
+        # lo as one level of a [B, tokens, C] tensor (the encoder's output): dense NHWC images a batch stride apart — read in place
+        if lo.stride()[1:] == (1, w * C, C) and lo.stride(0) >= h * w * C and lo.stride(0) % 4 == 0:
+            lo_c, lo_bs = lo, lo.stride(0)
+        else:
+            lo_c, lo_bs = lo.contiguous(memory_format=torch.channels_last), 0
         cur_c = cur.contiguous(memory_format=torch.channels_last)
         y = torch.empty_like(cur_c, memory_format=torch.channels_last)
         if C == 256:            # + the pixel maxima for the fp16 two-plane 3 x 3 convolution that reads y (functions/amax_cache.py)
             am = torch.empty(B * H * W, dtype=torch.float32, device=y.device)
-            _lib.check(_lib.load().pd_upsample_add_amax_nhwc_f32(lo_c.data_ptr(), cur_c.data_ptr(), y.data_ptr(), am.data_ptr(), B, h, w, H, W, C, _stream()))
+            _lib.check(_lib.load().pd_upsample_add_amax_nhwc_f32(lo_c.data_ptr(), lo_bs, cur_c.data_ptr(), y.data_ptr(), am.data_ptr(), B, h, w, H, W, C,
+                                                                 _stream()))
             ctx.y_am = am
         else:
-            _lib.check(_lib.load().pd_upsample_add_nhwc_f32(lo_c.data_ptr(), cur_c.data_ptr(), y.data_ptr(), B, h, w, H, W, C, _stream()))
+            _lib.check(_lib.load().pd_upsample_add_nhwc_f32(lo_c.data_ptr(), lo_bs, cur_c.data_ptr(), y.data_ptr(), B, h, w, H, W, C, _stream()))
             ctx.y_am = None
         ctx.dims = (B, C, h, w)
         return y

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libpd_hip.so") 
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -76,7 +76,7 @@ SIGNATURES = {
     "pd_nc_affine_f32": (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_vp]),
     "pd_nc_affine_amax_f32": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),
     "pd_nc_affine2_amax_f32": (_c_int, [_c_vp] * 8 + [_c_int] * 4 + [_c_vp]),
-    "pd_upsample_add_amax_nhwc_f32": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_vp]),
+    "pd_upsample_add_amax_nhwc_f32": (_c_int, [_c_vp, ctypes.c_int64] + [_c_vp] * 3 + [_c_int] * 6 + [_c_vp]),
     "pd_nc_affine2_f32": (_c_int, [_c_vp] * 7 + [_c_int] * 4 + [_c_vp]),
     "pd_add_layernorm_fwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp,
                                       _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_vp]),
@@ -116,7 +116,7 @@ SIGNATURES = {
     "pd_point_sample_planar_bwd_needs_zero": (_c_int, [_c_int] * 3),
     "pd_point_sample_planar_bwd_needs_zero_n": (_c_int, [_c_int] * 4),
     "pd_point_sample_planar_bwd_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
-    "pd_upsample_add_nhwc_f32": (_c_int, [_c_vp] * 3 + [_c_int] * 6 + [_c_vp]),
+    "pd_upsample_add_nhwc_f32": (_c_int, [_c_vp, ctypes.c_int64] + [_c_vp] * 2 + [_c_int] * 6 + [_c_vp]),
     "pd_upsample2x_bwd_nhwc_f32": (_c_int, [_c_vp] * 2 + [_c_int] * 4 + [_c_vp]),
     "pd_scores_argmax_u8": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp]),
     "pd_kmeans_assign": (_c_int, [_c_vp, _c_vp, _c_int] + [_c_vp] * 7 + [_c_int, _c_int, _c_vp]),

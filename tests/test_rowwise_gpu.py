@@ -347,6 +347,13 @@ def test_upsample_add_fwd_bwd_vs_torch(B, C, h, w):
     torch.testing.assert_close(y, ref, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(g_lo, lo.grad, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(g_cur, cur.grad, rtol=0, atol=0)
+    # lo as one level of a [B, tokens, C] tensor (the pixel decoder's case): read in place through its batch stride, same result
+    if C % 4 == 0:
+        tokens = torch.zeros((B, 3 * h * w + 5 * 4, C), device=DEV)
+        tokens[:, 8:8 + h * w] = lo.detach().permute(0, 2, 3, 1).reshape(B, h * w, C)
+        lo_view = tokens[:, 8:8 + h * w].transpose(1, 2).reshape(B, C, h, w)
+        assert not lo_view.is_contiguous(memory_format=torch.channels_last) or B == 1
+        assert torch.equal(upsample_add(lo_view, cur.detach()), y.detach())
 
 
 @pytest.mark.parametrize("N,C,H,W,P", [(80, 1, 64, 64, 1000), (1, 4, 96, 128, 5000), (3, 2, 7, 5, 33), (2, 1, 1, 1, 4), (5, 1, 256, 300, 20000),
