@@ -355,6 +355,10 @@ def main():
     if os.environ.get("PD_TEST_SHARE_GPU"):            # test hook: N ranks on ONE GPU over gloo (tests/test_ddp_gpu.py)
         local = 0
     torch.cuda.set_device(local)
+    force = world == 1 and os.environ.get("PD_DDP_FORCE", "0") == "1"   # one rank, every collective of the step through RCCL anyway (development)
+    if force:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("PD_TEST_SHARE_GPU"):
@@ -580,7 +584,7 @@ def main():
                 except OSError:
                     pass
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force:
         dist.destroy_process_group()
 
 

@@ -73,7 +73,7 @@ _AMD = {"MODEL.AMD": dict(
     SPARSE_MASK_LOSS=True,      # training never materialises [B,Q,H/4,W/4] masks; losses read point samples
     DEVICE_MATCHER=True,        # Hungarian assignment on the GPU (no host round-trip per image per layer)
     FUSED_OPTIMIZER=True,       # multi-tensor clipped AdamW kernel
-    DDP_BUCKET_MB=25,
+    DDP_BUCKET_MB=32,
     DDP_SPARSE_ROWS_CAP=256)}       # rows per rank of the row-sparse class-head exchange (>= images per GPU x (parts + 1)); engine/ddp.py
 
 

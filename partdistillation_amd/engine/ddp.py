@@ -1,6 +1,6 @@
 """Data-parallel gradient exchange: one process per GPU, the model replicated, gradients averaged
-with bucketed all-reduces over RCCL/xGMI that are issued from autograd hooks on a side HIP stream while backward is
-still running.  A bucket is a run of consecutive parameters of one flat group: when the last of its gradients has
+with bucketed all-reduces over RCCL/xGMI that are issued from autograd hooks while backward is still running (the
+process group runs them on its own stream; finish() makes the compute stream wait for them).  A bucket is a run of consecutive parameters of one flat group: when the last of its gradients has
 been produced, one multi-tensor kernel gathers them into the bucket's contiguous SLICE of the flat gradient buffer
 (engine/flat_params.py) and the slice is all-reduced in place — no bucket copy-in / copy-out.
 
@@ -28,12 +28,19 @@ class _Bucket:
         self.pending, self.work = self.total, None
 
 
+class _NoWork:
+    def wait(self):
+        return True
+
+
 class BucketedGradReducer:
     def __init__(self, flat, bucket_mb: float = 25.0, process_group=None, overlap: bool = True, optimizer=None, sparse_rows_cap: int = 256):
         self.flat, self.pg, self.optimizer = flat, process_group, optimizer
         self.sparse_rows_cap = int(sparse_rows_cap)       # rows per rank of the static row-sparse exchange (_exchange_rows); same on every rank
         self._overflow = []
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        from ..utils.misc import collectives_active
+        self.active = self.world > 1 or collectives_active()       # (one rank with PD_DDP_FORCE=1: the collectives run with a single participant)
         self.buckets: List[_Bucket] = []
         self._param_bucket = {}
         cap_bytes = int(bucket_mb * 1024 * 1024)
@@ -42,7 +49,7 @@ class BucketedGradReducer:
         # image's object class, every other row's gradient is exactly zero on every rank.  They get no buckets: finish()
         # exchanges just the touched rows — ~35 KB per rank instead of the dense buffer.
         self.sparse_groups = [gi for gi, g in enumerate(flat.groups)
-                              if self.world > 1 and all(getattr(p, "_pd_row_sparse", False) for p in g.params)]
+                              if self.active and all(getattr(p, "_pd_row_sparse", False) for p in g.params)]
         for gi, g in enumerate(flat.groups):
             if gi in self.sparse_groups:
                 continue
@@ -61,9 +68,15 @@ class BucketedGradReducer:
         self._next = 0                    # collectives are issued in bucket-index order on every rank (see _on_grad)
         self._use_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         dev = flat.groups[0].grad.device
+        # The collectives overlap with backward either way: torch's NCCL (= RCCL) process group runs them on ITS stream and `work.wait()`
+        # (finish()) is a stream-level wait.  A private side stream in front of that (rounds 2-3; PD_DDP_SIDE_STREAM=1) doubles the
+        # cross-stream events per bucket: measured with the collectives forced on one GPU (PD_DDP_FORCE=1, 25 MB buckets) 24.00 ms
+        # per step with it, 23.15 without, 22.40 with no data parallelism at all.
+        overlap = overlap and os.environ.get("PD_DDP_SIDE_STREAM", "0") == "1"
         self._side = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and overlap) else None
+        self._skip_reduce = os.environ.get("PD_DDP_SKIP_REDUCE", "0") == "1"        # (development: everything but the collective itself)
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for gi, g in enumerate(flat.groups):
                 if gi in self.sparse_groups:
                     continue
@@ -96,6 +109,9 @@ class BucketedGradReducer:
 
     def _reduce(self, b, buf):
         op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
+        if self._skip_reduce:
+            b.work = _NoWork()
+            return
         b.work = dist.all_reduce(buf, op=op, group=self.pg, async_op=True)
 
     def _exchange_rows(self, gi):
@@ -191,7 +207,7 @@ class BucketedGradReducer:
     def finish(self):
         """call after backward: reduce buckets whose hooks did not all fire (unused params), wait for the
         collectives and make the compute stream wait for the side stream."""
-        if self.world == 1:
+        if not self.active:
             return
         for b in self.buckets[self._next:]:                      # in index order, like the hooks
             self._launch(b)
@@ -222,7 +238,8 @@ class BucketedGradReducer:
 
 def broadcast_parameters(flat, src=0, process_group=None):
     """one broadcast per flat group so every rank starts from rank `src`'s weights."""
-    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+    from ..utils.misc import collectives_active
+    if dist.is_initialized() and (dist.get_world_size(process_group) > 1 or collectives_active()):
         for g in flat.groups:
             dist.broadcast(g.param, src=src, group=process_group)
             if g.shadow is not None:

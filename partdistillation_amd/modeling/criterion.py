@@ -14,7 +14,7 @@ from torch import nn
 
 from ..functions.fused import upload_small
 
-from ..utils.misc import (get_uncertain_point_coords_with_randomness, get_world_size, is_dist_avail_and_initialized,
+from ..utils.misc import (collectives_active, get_uncertain_point_coords_with_randomness, get_world_size, is_dist_avail_and_initialized,
                           nested_tensor_from_tensor_list, point_sample)
 
 
@@ -110,7 +110,7 @@ class SetCriterion(nn.Module):
         """multi-rank runs: start the scalar all-reduce of reference :252-254 NOW (the meta-architecture calls this as soon as
         the targets exist, before the backbone runs): it depends only on the targets, so by the time the criterion needs the
         value the collective finished long ago instead of sitting between the decoder and the losses."""
-        if not is_dist_avail_and_initialized() or get_world_size() == 1:
+        if not collectives_active():
             return
         count = float(sum(len(t["labels"]) for t in targets))
         n = upload_small([count], torch.float, device)                # asynchronous: the host keeps running ahead
@@ -120,7 +120,7 @@ class SetCriterion(nn.Module):
     def num_masks(self, targets, device):
         """average number of target masks per rank, clamped to >= 1 (reference :248-254), as a device scalar."""
         count = float(sum(len(t["labels"]) for t in targets))
-        if not is_dist_avail_and_initialized() or get_world_size() == 1:
+        if not collectives_active():
             key = (count, str(device))                       # cached constant: no per-step host->device copy
             if key not in self._nm_cache:
                 self._nm_cache[key] = torch.tensor(max(count, 1.0), dtype=torch.float, device=device)

@@ -42,6 +42,14 @@ def get_world_size():
     return dist.get_world_size() if is_dist_avail_and_initialized() else 1
 
 
+def collectives_active():
+    """do the data-parallel collectives run?  More than one rank — or ONE rank with PD_DDP_FORCE=1, which sends every collective of the step
+    (bucket all-reduces, the row-sparse exchange, the num_masks all-reduce) through the backend with a single participant: how the RCCL
+    call sequence is exercised on a one-GPU box (tests/test_ddp_gpu.py); the results equal the plain single-process step's"""
+    import os
+    return is_dist_avail_and_initialized() and (dist.get_world_size() > 1 or os.environ.get("PD_DDP_FORCE", "0") == "1")
+
+
 def point_sample(input, point_coords, **kwargs):
     """detectron2 point_sample: coords in [0,1]x[0,1] (x,y)."""
     import torch.nn.functional as F

@@ -176,3 +176,53 @@ def test_two_rank_part_distillation_row_sparse_class_head(tmp_path):
     assert w.dtype == torch.float32 or w.dtype == torch.float64
     rows = sorted((w.abs().sum(1) > 0).nonzero().flatten().tolist())
     assert rows == sorted({c * 8 + k for c in classes for k in range(8)} | {400}), (rows, classes)
+
+
+def _rccl_worker(rank, world, port, tmp, part):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PD_DDP_FORCE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from partdistillation_amd.engine.trainer import TrainStep
+    from partdistillation_amd.engine.synthetic import make_batch
+    torch.manual_seed(321 if part else 123)
+    step = TrainStep(_pd_cfg() if part else _cfg())
+    assert step.world == 1 and step.reducer.active and len(step.reducer._hooks) > 100
+    assert len(step.reducer.sparse_groups) == (1 if part else 0)
+    batch = _pd_batch(0) if part else make_batch(1, 128, n_parts=3, seed=40, device="cuda")
+    g = _grads(step, batch, 950 if part else 900)
+    g2 = _grads(step, batch, 951 if part else 901)                      # a second step: the buckets re-arm, the pending counts reset
+    torch.cuda.synchronize()
+    torch.save((g, g2), os.path.join(tmp, "rccl.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("part", [False, True])
+def test_collectives_through_rccl_with_one_rank(tmp_path, part):
+    """Every collective of the data-parallel step through the RCCL backend ("nccl") on this one GPU: PD_DDP_FORCE=1 makes a one-rank job
+    issue the bucket all-reduces (ReduceOp.AVG on the side stream, hooks firing during backward), the parameter broadcast, the criterion's
+    early num_masks all-reduce and — for the part-distillation model — the static row-sparse exchange of the fp64 class head.  With one
+    participant the results must equal the plain single-process step's; what the test buys is that the RCCL call sequence (ops, dtypes,
+    streams, async handles) has run before a multi-GPU node sees it."""
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    mp.spawn(_rccl_worker, args=(1, port, str(tmp_path), part), nprocs=1, join=True)
+    got, got2 = torch.load(tmp_path / "rccl.pt")
+    sys.path.insert(0, ROOT)
+    from partdistillation_amd.engine.synthetic import make_batch
+    from partdistillation_amd.engine.trainer import TrainStep
+    torch.manual_seed(321 if part else 123)
+    step = TrainStep(_pd_cfg() if part else _cfg())
+    assert not step.reducer.active
+    batch = _pd_batch(0) if part else make_batch(1, 128, n_parts=3, seed=40, device="cuda")
+    want = _grads(step, batch, 950 if part else 900)
+    want2 = _grads(step, batch, 951 if part else 901)
+    checked = 0
+    for a, b in ((got, want), (got2, want2)):
+        for n in b:
+            scale = b[n].abs().max().clamp_min(1e-12)
+            tol = 1e-1 if n.startswith("backbone.") else 3e-3            # (the tolerances of the two-rank test above, and why)
+            assert ((a[n] - b[n]).abs().max() / scale).item() < tol, n
+            checked += 1
+    assert checked > 200
