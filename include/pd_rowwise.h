@@ -146,6 +146,20 @@ int pd_upsample_add_amax_nhwc_f32(const float *lo, int64_t lo_batch_stride, cons
                                   void *stream);
 int pd_upsample2x_bwd_nhwc_f32(const float *dy, float *dlo, int B, int h, int w, int C, void *stream);
 
+/*
+ * dst_i [batch, cols, rows] (contiguous) = src_i [batch, rows, cols]^T, fp32, for up to PD_TRANSPOSE_MAX problems in one launch.  src_i may
+ * be strided: src_batch_stride / src_row_stride in floats (unit column stride) — the layers' weights where they lie in the flat parameter
+ * buffer.  The transposed weight stacks of the fp32 encoder's input-gradient GEMMs (dX = dY W needs W^T as the [N, K] operand).
+ */
+#define PD_TRANSPOSE_MAX 8
+typedef struct {
+  const void *src;
+  void *dst;
+  int64_t src_batch_stride, src_row_stride;
+  int32_t batch, rows, cols, reserved;
+} PdTransposeProblem;
+int pd_transpose_batched_f32(const PdTransposeProblem *problems, int count, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -161,6 +161,7 @@ const Entry kTable[] = {
   PD_E(pd_sumsq_accumulate),
   PD_E(pd_swin_ln_bwd),
   PD_E(pd_swin_ln_fwd),
+  PD_E(pd_transpose_batched_f32),
   PD_E(pd_uncertain_points),
   PD_E(pd_upsample2x_bwd_nhwc_f32),
   PD_E(pd_upsample_add_amax_nhwc_f32),

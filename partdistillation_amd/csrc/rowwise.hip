@@ -3,6 +3,7 @@
 // and the row statistics are 64-lane DPP reductions.  C-ABI in include/pd_rowwise.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "pd_common.h"
 #include "pd_msda.h"
@@ -751,6 +752,38 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_nhwc(const float *__restri
 
 int grid_rows(int rows, int cap) { return max(1, min(cap, (rows + 3) / 4)); }
 
+// ------------------------------------------------------------------------------------------------ batched fp32 transposes
+// dst_i [batch, cols, rows] = src_i [batch, rows, cols]^T for up to PD_TRANSPOSE_MAX problems in ONE launch (the encoder backward's five
+// transposed weight stacks: five strided ATen copies of ~12 us each for 18 MB).  32 x 32 tiles through LDS, coalesced both ways.
+struct TrBatch { PdTransposeProblem p[PD_TRANSPOSE_MAX]; int first_tile[PD_TRANSPOSE_MAX + 1]; int count; };
+
+__global__ __launch_bounds__(256) void transpose_batched_f32(TrBatch tb)
+{
+  __shared__ float tile[32][33];
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < PD_TRANSPOSE_MAX; ++i) pi += (i < tb.count && (int)blockIdx.x >= tb.first_tile[i]) ? 1 : 0;
+  const PdTransposeProblem &pr = tb.p[pi];
+  const int tr = (pr.rows + 31) / 32, tc = (pr.cols + 31) / 32;
+  int t = blockIdx.x - tb.first_tile[pi];
+  const int b = t / (tr * tc); t -= b * tr * tc;
+  const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float *src = (const float *)pr.src + (int64_t)b * pr.src_batch_stride;
+  float *dst = (float *)pr.dst + (int64_t)b * pr.rows * pr.cols;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    if (r < pr.rows && c < pr.cols) tile[ty + 8 * k][tx] = src[(int64_t)r * pr.src_row_stride + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (r < pr.rows && c < pr.cols) dst[(int64_t)c * pr.rows + r] = tile[tx][ty + 8 * k];
+  }
+}
+
 bool dt_ok(int dt) { return dt == PD_F32 || dt == PD_BF16; }
 
 }  // namespace
@@ -1088,3 +1121,24 @@ extern "C" int pd_point_sample_planar_bwd_needs_zero_n(int N, int C, int H, int 
   return !(C == 1 && ((W + PST - 1) / PST) * ((H + PST - 1) / PST) <= 16 && N <= 65535);
 }
 extern "C" int pd_point_sample_planar_bwd_needs_zero(int C, int H, int W) { return pd_point_sample_planar_bwd_needs_zero_n(1, C, H, W); }
+
+extern "C" int pd_transpose_batched_f32(const PdTransposeProblem *problems, int count, void *stream_)
+{
+  if (count < 0 || count > PD_TRANSPOSE_MAX || (count && !problems)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_transpose_batched_f32: count=%d (0..%d)", count, PD_TRANSPOSE_MAX);
+  TrBatch tb;
+  memset(&tb, 0, sizeof(tb));
+  int tiles = 0;
+  for (int i = 0; i < count; ++i) {
+    const PdTransposeProblem &p = problems[i];
+    if (p.batch < 0 || p.rows < 0 || p.cols < 0 || p.src_row_stride < p.cols) return pd_set_error(PD_ERR_INVALID_ARG, "pd_transpose_batched_f32: problem %d", i);
+    if (p.batch && p.rows && p.cols && (!p.src || !p.dst)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_transpose_batched_f32: null pointer");
+    tb.p[i] = p;
+    tb.first_tile[i] = tiles;
+    tiles += p.batch * ((p.rows + 31) / 32) * ((p.cols + 31) / 32);
+  }
+  tb.first_tile[count] = tiles;
+  tb.count = count;
+  if (tiles == 0) return PD_OK;
+  hipLaunchKernelGGL(transpose_batched_f32, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream_, tb);
+  return pd_check_launch("pd_transpose_batched_f32");
+}

@@ -128,6 +128,14 @@ def _ffn_gemm(x, w, b=None, relu=False):
     return torch.addmm(b, x, w.t()) if b is not None else torch.mm(x, w.t())
 
 
+import ctypes as _ct
+
+
+class _TrProblem(_ct.Structure):                                     # PdTransposeProblem, include/pd_rowwise.h
+    _fields_ = [("src", _ct.c_void_p), ("dst", _ct.c_void_p), ("src_batch_stride", _ct.c_int64), ("src_row_stride", _ct.c_int64),
+                ("batch", _ct.c_int32), ("rows", _ct.c_int32), ("cols", _ct.c_int32), ("reserved", _ct.c_int32)]
+
+
 class _Stack:
     """[layers, ...] tensor indexed by layer, stored in either layer order (rev: the last layer first)"""
 
@@ -293,6 +301,41 @@ class EncoderCore(Function):
         return _Stack(torch.stack(ws).transpose(1, 2).contiguous(), False)
 
     @staticmethod
+    def _stacks_t_one_launch(params, nl, wk, n_oa, per, C):
+        """the five transposed weight stacks of _backward_h2 (linear1, linear2, output_proj, value_proj of every layer from the flat
+        parameter buffer, and the stacked sampling_offsets + attention_weights rows of `wk`) by ONE pd_transpose_batched_f32 launch into one
+        buffer — or None when the layers' weights do not sit at one spacing (then the per-stack ATen copies run)"""
+        import ctypes
+        from .. import lib as _lib
+        probs, views, total = [], [], 0
+        for j in (10, 12, 6, 4):
+            ws = [params[i * N_LAYER + j] for i in range(nl)]
+            d = (ws[1].data_ptr() - ws[0].data_ptr()) if nl > 1 else 0
+            es = ws[0].element_size()
+            ok = (ws[0].is_cuda and ws[0].dtype == torch.float32 and all(w.is_contiguous() and w.shape == ws[0].shape for w in ws)
+                  and (nl == 1 or (d != 0 and d % es == 0 and all(ws[i].data_ptr() - ws[0].data_ptr() == i * d for i in range(nl)))))
+            if not ok:
+                return None
+            N_, K_ = ws[0].shape
+            base = ws[0] if d >= 0 else ws[-1]
+            probs.append((base.data_ptr(), abs(d) // es if nl > 1 else N_ * K_, K_, nl, N_, K_, d < 0))
+        if not (wk.is_cuda and wk.dtype == torch.float32 and wk.is_contiguous()):
+            return None
+        probs.append((wk.data_ptr(), per * C, C, nl, n_oa, C, False))
+        for p_ in probs:
+            total += p_[3] * p_[4] * p_[5]
+        buf = torch.empty(total, dtype=torch.float32, device=wk.device)
+        descs = (_TrProblem * len(probs))()
+        off = 0
+        for d_, (src, bs, rs, batch, rows, cols, rev) in zip(descs, probs):
+            d_.src, d_.dst, d_.src_batch_stride, d_.src_row_stride = src, buf.data_ptr() + 4 * off, bs, rs
+            d_.batch, d_.rows, d_.cols, d_.reserved = batch, rows, cols, 0
+            views.append(_Stack(buf[off:off + batch * rows * cols].view(batch, cols, rows), rev))
+            off += batch * rows * cols
+        _lib.check(_lib.load().pd_transpose_batched_f32(ctypes.byref(descs), len(probs), _lib.current_stream()))
+        return views
+
+    @staticmethod
     def _backward_h2(ctx, d_out):
         """backward of _forward_h2: an eager prologue (the transposed weight stacks: ATen copies), the layer loop as a recorded region
         (~110 launches incl. the grouped weight gradients: one C call from the second step on), three elementwise sums at the end"""
@@ -302,10 +345,14 @@ class EncoderCore(Function):
         need_w = any(ctx.needs_input_grad[3:])
         n_off, n_aw, n_l1 = params[0].shape[0], params[2].shape[0], params[10].shape[0]
         per = n_off + n_aw + 2 * C + n_l1
-        st = EncoderCore._stack_t
-        l1_t, l2_t, op_t, vp_t = st(params, nl, 10), st(params, nl, 12), st(params, nl, 6), st(params, nl, 4)
         wk = ctx.wk
-        oa_t = _Stack(torch.as_strided(wk, (nl, n_off + n_aw, C), (per * C, C, 1)).transpose(1, 2).contiguous(), False)
+        stacks5 = EncoderCore._stacks_t_one_launch(params, nl, wk, n_off + n_aw, per, C)
+        if stacks5 is not None:
+            l1_t, l2_t, op_t, vp_t, oa_t = stacks5
+        else:
+            st = EncoderCore._stack_t
+            l1_t, l2_t, op_t, vp_t = st(params, nl, 10), st(params, nl, 12), st(params, nl, 6), st(params, nl, 4)
+            oa_t = _Stack(torch.as_strided(wk, (nl, n_off + n_aw, C), (per * C, C, 1)).transpose(1, 2).contiguous(), False)
         dy = d_out.reshape(T, C)
         dy = dy if dy.is_contiguous() else dy.contiguous()
         stacks = (l1_t, l2_t, op_t, vp_t, oa_t)

@@ -394,3 +394,23 @@ def test_matcher_point_terms_match_torch(dtype, shape):
     torch.testing.assert_close(sg, ref.sigmoid(), rtol=2e-6, atol=1e-7)
     torch.testing.assert_close(sp_sum, torch.nn.functional.softplus(ref.double()).sum(-1).float(), rtol=2e-6, atol=1e-5)
     torch.testing.assert_close(sg_sum, ref.double().sigmoid().sum(-1).float(), rtol=2e-6, atol=1e-5)
+
+
+def test_batched_transpose_of_strided_weight_stacks():
+    """pd_transpose_batched_f32: several [batch, rows, cols] -> [batch, cols, rows] problems in one launch, sources strided like layer
+    weights in a flat parameter buffer (batch stride > rows * cols, row stride > cols), ragged 32 x 32 tiles"""
+    import ctypes
+    from partdistillation_amd import lib as L
+    from partdistillation_amd.functions.encoder_core import _TrProblem
+    flat = _r((3 * 70000,), 11)
+    shapes = [(3, 70000, 300, 100, 300), (2, 40000, 40, 33, 37), (1, 5, 5, 1, 5), (3, 1024 * 20, 1024, 20, 1024)]   # batch, batch stride, row stride, rows, cols
+    descs = (_TrProblem * len(shapes))()
+    outs = []
+    for d, (b, bs, rs, rows, cols) in zip(descs, shapes):
+        out = torch.empty((b, cols, rows), device=DEV)
+        d.src, d.dst, d.src_batch_stride, d.src_row_stride, d.batch, d.rows, d.cols = flat.data_ptr() + 4 * 16, out.data_ptr(), bs, rs, b, rows, cols
+        outs.append(out)
+    L.check(L.load().pd_transpose_batched_f32(ctypes.byref(descs), len(shapes), L.current_stream()))
+    for out, (b, bs, rs, rows, cols) in zip(outs, shapes):
+        src = torch.as_strided(flat, (b, rows, cols), (bs, rs, 1), 16)
+        assert torch.equal(out, src.transpose(1, 2))
