@@ -147,6 +147,15 @@ int pd_upsample_add_amax_nhwc_f32(const float *lo, int64_t lo_batch_stride, cons
 int pd_upsample2x_bwd_nhwc_f32(const float *dy, float *dlo, int B, int h, int w, int C, void *stream);
 
 /*
+ * F.interpolate(x, size=(heights[i], widths[i]), mode="bilinear", align_corners=False) of a channels-last fp32 map x [B, H, W, C] for up to
+ * PD_RESIZE_MAX sizes in one launch; outs[i] [B, heights[i] * widths[i], C] in out_dtype (PD_F32 / PD_BF16: rounded on the way out).  The
+ * decoder's pooled mask features (reference mask2former_transformer_decoder.py:452, one resize per level).  heights / widths / outs: HOST arrays.
+ */
+#define PD_RESIZE_MAX 4
+int pd_resize_bilinear_nhwc_f32(const float *x, int B, int H, int W, int C, const int *heights, const int *widths, void *const *outs, int count,
+                                int out_dtype, void *stream);
+
+/*
  * dst_i [batch, cols, rows] (contiguous) = src_i [batch, rows, cols]^T, fp32, for up to PD_TRANSPOSE_MAX problems in one launch.  src_i may
  * be strided: src_batch_stride / src_row_stride in floats (unit column stride) — the layers' weights where they lie in the flat parameter
  * buffer.  The transposed weight stacks of the fp32 encoder's input-gradient GEMMs (dX = dY W needs W^T as the [N, K] operand).

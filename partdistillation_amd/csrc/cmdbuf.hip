@@ -146,6 +146,7 @@ const Entry kTable[] = {
   PD_E(pd_relu_bwd_colsum),
   PD_E(pd_resample_cols_u8),
   PD_E(pd_resample_rows_u8),
+  PD_E(pd_resize_bilinear_nhwc_f32),
   PD_E(pd_rle_sample_u8),
   PD_E(pd_row_amax_f32),
   PD_E(pd_scores_argmax_u8),

@@ -702,6 +702,41 @@ __global__ __launch_bounds__(256) void upsample_add_nhwc(const float *__restrict
   }
 }
 
+// F.interpolate(x, size, mode="bilinear", align_corners=False) of a channels-last fp32 map to up to PD_RESIZE_MAX sizes in ONE launch, the
+// results written as [B, h w, C] rows in bf16 or fp32 (the decoder's three pooled copies of the mask features, reference
+// mask2former_transformer_decoder.py:452: three ATen resizes + casts).  One lane per 4 channels of an output pixel; torch's arithmetic.
+struct ResizeLevels { void *out[PD_RESIZE_MAX]; int h[PD_RESIZE_MAX], w[PD_RESIZE_MAX]; int64_t first[PD_RESIZE_MAX + 1]; int count; };
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void resize_bilinear_nhwc_multi(const float *__restrict__ x, int B, int H, int W, int C4, ResizeLevels lv)
+{
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < lv.first[lv.count]; i += (int64_t)gridDim.x * 256) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < PD_RESIZE_MAX; ++k) l += (k < lv.count && i >= lv.first[k]) ? 1 : 0;
+    const int h = lv.h[l], w = lv.w[l];
+    int64_t t = i - lv.first[l];
+    const int c = (int)(t % C4); t /= C4;
+    const int ox = (int)(t % w); t /= w;
+    const int oy = (int)(t % h);
+    const int b = (int)(t / h);
+    int y0, yp, x0, xp; float hy0, hy1, wx0, wx1;
+    up_src(oy, (float)H / (float)h, H, y0, yp, hy0, hy1);
+    up_src(ox, (float)W / (float)w, W, x0, xp, wx0, wx1);
+    const float4 *L = reinterpret_cast<const float4 *>(x) + (int64_t)b * H * W * C4;
+    const float4 a = L[((int64_t)y0 * W + x0) * C4 + c], bq = L[((int64_t)y0 * W + x0 + xp) * C4 + c];
+    const float4 cq = L[((int64_t)(y0 + yp) * W + x0) * C4 + c], d = L[((int64_t)(y0 + yp) * W + x0 + xp) * C4 + c];
+    float4 o;
+    o.x = hy0 * (wx0 * a.x + wx1 * bq.x) + hy1 * (wx0 * cq.x + wx1 * d.x);
+    o.y = hy0 * (wx0 * a.y + wx1 * bq.y) + hy1 * (wx0 * cq.y + wx1 * d.y);
+    o.z = hy0 * (wx0 * a.z + wx1 * bq.z) + hy1 * (wx0 * cq.z + wx1 * d.z);
+    o.w = hy0 * (wx0 * a.w + wx1 * bq.w) + hy1 * (wx0 * cq.w + wx1 * d.w);
+    const int64_t oi = (((int64_t)b * h + oy) * w + ox) * C4 + c;
+    if (BF16) st4(reinterpret_cast<bf16_t *>(lv.out[l]) + oi * 4, o);
+    else st4(reinterpret_cast<float *>(lv.out[l]) + oi * 4, o);
+  }
+}
+
 __global__ __launch_bounds__(256) void upsample2x_bwd_nhwc(const float *__restrict__ dy, float *__restrict__ dlo, int B, int h,
                                                            int w, int C4)
 {
@@ -1141,4 +1176,26 @@ extern "C" int pd_transpose_batched_f32(const PdTransposeProblem *problems, int 
   if (tiles == 0) return PD_OK;
   hipLaunchKernelGGL(transpose_batched_f32, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream_, tb);
   return pd_check_launch("pd_transpose_batched_f32");
+}
+
+extern "C" int pd_resize_bilinear_nhwc_f32(const float *x, int B, int H, int W, int C, const int *heights, const int *widths, void *const *outs,
+                                           int count, int out_dtype, void *stream_)
+{
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || count < 0 || count > PD_RESIZE_MAX || (out_dtype != PD_F32 && out_dtype != PD_BF16))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_resize_bilinear_nhwc_f32: B=%d H=%d W=%d C=%d count=%d dtype=%d", B, H, W, C, count, out_dtype);
+  if (B == 0 || count == 0) return PD_OK;
+  if (!x || !heights || !widths || !outs) return pd_set_error(PD_ERR_INVALID_ARG, "pd_resize_bilinear_nhwc_f32: null pointer");
+  ResizeLevels lv;
+  memset(&lv, 0, sizeof(lv));
+  int64_t total = 0;
+  for (int i = 0; i < count; ++i) {
+    if (heights[i] <= 0 || widths[i] <= 0 || !outs[i]) return pd_set_error(PD_ERR_INVALID_ARG, "pd_resize_bilinear_nhwc_f32: level %d", i);
+    lv.out[i] = outs[i]; lv.h[i] = heights[i]; lv.w[i] = widths[i]; lv.first[i] = total;
+    total += (int64_t)B * heights[i] * widths[i] * (C / 4);
+  }
+  lv.first[count] = total; lv.count = count;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  if (out_dtype == PD_BF16) hipLaunchKernelGGL(resize_bilinear_nhwc_multi<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, x, B, H, W, C / 4, lv);
+  else hipLaunchKernelGGL(resize_bilinear_nhwc_multi<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, x, B, H, W, C / 4, lv);
+  return pd_check_launch("pd_resize_bilinear_nhwc_f32");
 }

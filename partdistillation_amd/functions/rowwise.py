@@ -214,6 +214,26 @@ def point_sample_planar(x, coords):
     return PointSamplePlanar.apply(x, coords.contiguous())
 
 
+def resize_bilinear_rows(x, sizes, out_dtype=torch.float32):
+    """x fp32 [B, C, H, W] stored channels-last -> [F.interpolate(x, size=s, mode="bilinear", align_corners=False) as rows [B, h w, C] for s in
+    sizes] in out_dtype, ONE launch (pd_resize_bilinear_nhwc_f32); no gradient"""
+    import ctypes
+    _need_cuda(x, "pd_resize_bilinear_nhwc_f32")
+    B, C, H, W = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last) and C % 4 == 0 and 0 < len(sizes) <= 4
+    outs = [torch.empty((B, h * w, C), dtype=out_dtype, device=x.device) for h, w in sizes]
+    hs = (ctypes.c_int * len(sizes))(*[int(h) for h, _ in sizes])
+    ws = (ctypes.c_int * len(sizes))(*[int(w) for _, w in sizes])
+    ptrs = (ctypes.c_void_p * len(sizes))(*[o.data_ptr() for o in outs])
+    _lib.check(_lib.load().pd_resize_bilinear_nhwc_f32(x.data_ptr(), B, H, W, C, hs, ws, ptrs, len(sizes), _DT[out_dtype], _stream()))
+    return outs
+
+
+def resize_bilinear_rows_supported(x, sizes):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 4 == 0 and 0 < len(sizes) <= 4
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
 def supports_width(C):
     return C % 256 == 0 and C <= 1024
 

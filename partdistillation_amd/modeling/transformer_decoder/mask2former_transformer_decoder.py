@@ -27,7 +27,7 @@ from ...compat.layers import Conv2d, c2_xavier_fill
 from ...functions import mlp_own
 from ...functions.attention import masked_attention_d32
 from ...functions.decoder_core import DecoderCore, DecoderSpec
-from ...functions.rowwise import supports_width
+from ...functions.rowwise import resize_bilinear_rows, resize_bilinear_rows_supported, supports_width
 from .position_encoding import PositionEmbeddingSine
 
 
@@ -309,11 +309,17 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         bs, Q, C, L = x[0].shape[0], self.num_queries, self.hidden_dim, self.num_layers
         sizes = [tuple(t.shape[-2:]) for t in x]
         with torch.no_grad():                                                   # the three mask resolutions, once
-            pooled = [F.interpolate(mask_features, size=s, mode="bilinear", align_corners=False).flatten(2).float() for s in sizes]
-            if cdt == torch.bfloat16 and torch.is_autocast_enabled():
-                # the heads' mask logits are autocast bmm's: the B operand in the GEMM dtype once per level, not once per head
-                # (the same rounding, nine cast launches less)
-                pooled = [p.to(cdt) for p in pooled]
+            to_cdt = cdt == torch.bfloat16 and torch.is_autocast_enabled()
+            if resize_bilinear_rows_supported(mask_features, sizes):
+                # all levels by one launch, written as [B, HW, C] rows in the GEMM dtype (three ATen resizes + three casts before)
+                rows = resize_bilinear_rows(mask_features.detach(), sizes, cdt if to_cdt else torch.float32)
+                pooled = [r.transpose(1, 2) for r in rows]                      # [B, C, HW] views, as flatten(2) of the channels-last maps were
+            else:
+                pooled = [F.interpolate(mask_features, size=s, mode="bilinear", align_corners=False).flatten(2).float() for s in sizes]
+                if to_cdt:
+                    # the heads' mask logits are autocast bmm's: the B operand in the GEMM dtype once per level, not once per head
+                    # (the same rounding, nine cast launches less)
+                    pooled = [p.to(cdt) for p in pooled]
         spec = DecoderSpec(bs, Q, C, self.num_heads, L, sizes, [self._pos_table_rows(h, w, x[0].device) for h, w in sizes],
                            pooled, self.decoder_norm.eps, cdt, self.num_feature_levels)
         dec_outs, final_tgt = DecoderCore.apply(spec, *x, *self._core_params())          # [L+1, Q*B, C] fp32, [Q*B, C]

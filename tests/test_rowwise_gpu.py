@@ -414,3 +414,19 @@ def test_batched_transpose_of_strided_weight_stacks():
     for out, (b, bs, rs, rows, cols) in zip(outs, shapes):
         src = torch.as_strided(flat, (b, rows, cols), (bs, rs, 1), 16)
         assert torch.equal(out, src.transpose(1, 2))
+
+
+@pytest.mark.parametrize("B,C,H,W,sizes", [(2, 256, 64, 64, [(8, 8), (16, 16), (32, 32)]), (1, 8, 13, 9, [(5, 7), (26, 18), (13, 9), (1, 1)]),
+                                           (2, 64, 32, 48, [(12, 20)])])
+def test_multi_size_bilinear_resize_equals_interpolate(B, C, H, W, sizes):
+    """pd_resize_bilinear_nhwc_f32: every pooled copy of the mask features by one launch (reference mask2former_transformer_decoder.py:452:
+    F.interpolate(..., mode="bilinear", align_corners=False) per level), rows [B, h w, C]; fp32 equal to ATen's to rounding, bf16 = its cast"""
+    from partdistillation_amd.functions.rowwise import resize_bilinear_rows, resize_bilinear_rows_supported
+    x = _r((B, C, H, W), 5).contiguous(memory_format=torch.channels_last)
+    assert resize_bilinear_rows_supported(x, sizes)
+    got = resize_bilinear_rows(x, sizes)
+    got16 = resize_bilinear_rows(x, sizes, torch.bfloat16)
+    for (h, w), g, g16 in zip(sizes, got, got16):
+        ref = F.interpolate(x, size=(h, w), mode="bilinear", align_corners=False).flatten(2).transpose(1, 2)     # [B, hw, C]
+        torch.testing.assert_close(g, ref, rtol=1e-6, atol=1e-6)
+        assert torch.equal(g16, g.to(torch.bfloat16))
