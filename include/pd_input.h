@@ -40,6 +40,14 @@ int pd_resample_cols_u8(const uint8_t *tmp, int tmp_rows, int tmp_w, int r0, con
 int pd_rle_sample_u8(const int32_t *starts, const int32_t *offsets, int n_masks, int H, int W, int flip, const int32_t *src_x,
                      const int32_t *src_y, int vh, int vw, int S, uint8_t *out, int32_t *area, void *stream);
 
+/*
+ * out [B, H, W, 3] fp32 (the channels-last storage of the [B, 3, H, W] batch) = (images[b] - mean) / std for B same-size planar uint8
+ * images [3, H, W] — the model's preprocess (reference proposal_model.py:251-253 / part_distillation_model.py: `(x - pixel_mean) /
+ * pixel_std` per image) in one launch.  images: HOST array of B device pointers; mean3 / std3: HOST arrays of 3 floats.
+ */
+#define PD_NORMALIZE_MAX_IMAGES 16
+int pd_normalize_u8_nhwc(const uint8_t *const *images, int B, int H, int W, const float *mean3, const float *std3, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,3 +122,41 @@ extern "C" int pd_rle_sample_u8(const int32_t *starts, const int32_t *offsets, i
                      src_y, vh, vw, S, out, area);
   return pd_check_launch("pd_rle_sample_u8");
 }
+
+// (x - mean) / std of B same-size planar uint8 images [3, H, W] written straight into the channels-last fp32 batch the backbone reads
+// (reference proposal_model.py / part_distillation_model.py: `(x - self.pixel_mean) / self.pixel_std` per image, then ImageList.from_tensors)
+// — one launch for the batch (was a subtraction per image plus a division over the batch).  The same two fp32 operations per value.
+namespace {
+struct NormImages { const uint8_t *img[PD_NORMALIZE_MAX_IMAGES]; float mean[3], std[3]; };
+
+__global__ __launch_bounds__(256) void normalize_u8_nhwc(NormImages in, float *__restrict__ out, int B, int64_t hw)
+{
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * hw; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i / hw);
+    const int64_t px = i - (int64_t)b * hw;
+    const uint8_t *p = in.img[b];
+    const float r = ((float)p[px] - in.mean[0]) / in.std[0];
+    const float g = ((float)p[hw + px] - in.mean[1]) / in.std[1];
+    const float bl = ((float)p[2 * hw + px] - in.mean[2]) / in.std[2];
+    float *o = out + i * 3;
+    o[0] = r; o[1] = g; o[2] = bl;
+  }
+}
+}  // namespace
+
+extern "C" int pd_normalize_u8_nhwc(const uint8_t *const *images, int B, int H, int W, const float *mean3, const float *std3, float *out, void *stream_)
+{
+  if (B < 0 || B > PD_NORMALIZE_MAX_IMAGES || H <= 0 || W <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_normalize_u8_nhwc: B=%d (<= %d) H=%d W=%d", B, PD_NORMALIZE_MAX_IMAGES, H, W);
+  if (B == 0) return PD_OK;
+  if (!images || !mean3 || !std3 || !out) return pd_set_error(PD_ERR_INVALID_ARG, "pd_normalize_u8_nhwc: null pointer");
+  NormImages in;
+  for (int b = 0; b < B; ++b) {
+    if (!images[b]) return pd_set_error(PD_ERR_INVALID_ARG, "pd_normalize_u8_nhwc: null image %d", b);
+    in.img[b] = images[b];
+  }
+  for (int c = 0; c < 3; ++c) { in.mean[c] = mean3[c]; in.std[c] = std3[c]; }
+  const int64_t hw = (int64_t)H * W, total = (int64_t)B * hw;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(normalize_u8_nhwc, dim3(grid), dim3(256), 0, (hipStream_t)stream_, in, out, B, hw);
+  return pd_check_launch("pd_normalize_u8_nhwc");
+}

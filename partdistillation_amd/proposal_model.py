@@ -59,6 +59,17 @@ class _MaskFormerTrainBase(nn.Module):
             # same-size images that need no padding (the training crops): (x - mean) / std written straight into the channels-last batch
             # the backbone wants — B + 1 launches instead of 2 B (normalise) + 1 + B (pad-and-copy) + 1 (layout)
             out = torch.empty((len(imgs),) + tuple(imgs[0].shape), dtype=torch.float32, device=self.device, memory_format=torch.channels_last)
+            if all(i.dtype == torch.uint8 and i.is_contiguous() for i in imgs) and imgs[0].shape[0] == 3 and len(imgs) <= 16:
+                # decoded uint8 pictures (the data pipeline's and the benchmark's form): the whole batch by one launch
+                import ctypes
+                from . import lib as _lib
+                if getattr(self, "_norm_host", None) is None:                    # the constants, read from the buffers once
+                    self._norm_host = ((ctypes.c_float * 3)(*self.pixel_mean.flatten().tolist()), (ctypes.c_float * 3)(*self.pixel_std.flatten().tolist()))
+                ptrs = (ctypes.c_void_p * len(imgs))(*[i.data_ptr() for i in imgs])
+                with torch.cuda.device(self.device):
+                    _lib.check(_lib.load().pd_normalize_u8_nhwc(ptrs, len(imgs), int(h), int(w), self._norm_host[0], self._norm_host[1], out.data_ptr(),
+                                                                 _lib.current_stream()))
+                return ImageList(out, [(int(h), int(w))] * len(imgs))
             for i, im in enumerate(imgs):
                 torch.sub(im, self.pixel_mean, out=out[i])
             out.div_(self.pixel_std)
