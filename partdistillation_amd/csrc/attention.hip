@@ -19,6 +19,8 @@
 #include "mfma_bf16.h"
 #include "pd_msda.h"
 
+int g_attn_bwd_kc = 0;            // pd_debug_set "attn_bwd_kc" (tools/): keys per workgroup of attn_bwd_mfma forced to 128 / 256 / 512
+
 namespace {
 
 constexpr int D = 32;          // head dim
@@ -736,6 +738,7 @@ inline int nchunks(int Lk, int kc) { return Lk <= 0 ? 1 : (Lk + kc - 1) / kc; }
 // 256 CUs).  Fewer keys per workgroup until ~256 workgroups exist: 1 024 keys -> 128 per workgroup (1 round), 4 096 -> 256.
 inline int mfma_bwd_chunk(int B, int H, int Lk)
 {
+  if (g_attn_bwd_kc == 128 || g_attn_bwd_kc == 256 || g_attn_bwd_kc == 512) return g_attn_bwd_kc;
   int kc = KC_DQ;
   while (kc > 128 && (int64_t)B * H * nchunks(Lk, kc) < 256) kc >>= 1;
   return kc;

@@ -55,6 +55,7 @@ extern int g_mx_bn, g_mx_nst;
 extern int g_swin_ln_abl;
 extern int g_ln_bwd_cap;
 extern int g_crit_abl;
+extern int g_attn_bwd_kc;
 extern int g_wg_nst, g_wg_splits, g_wg_mode;
 extern "C" int pd_debug_set(const char *key, int value)
 {
@@ -73,6 +74,7 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!strcmp(key, "ig_bn")) { g_ig_bn = value; return PD_OK; }
   if (!strcmp(key, "ig_nst")) { g_ig_nst = value; return PD_OK; }
   if (!strcmp(key, "mx_bn")) { g_mx_bn = value; return PD_OK; }
+  if (!strcmp(key, "attn_bwd_kc")) { g_attn_bwd_kc = value; return PD_OK; }
   if (!strcmp(key, "crit_abl")) { g_crit_abl = value; return PD_OK; }
   if (!strcmp(key, "ln_bwd_cap")) { g_ln_bwd_cap = value; return PD_OK; }
   if (!strcmp(key, "swin_ln_abl")) { g_swin_ln_abl = value; return PD_OK; }
