@@ -116,7 +116,9 @@ def transposed(weights):
     """[N_i, K_i] bf16 row-major weights -> their [K_i, N_i] transposes (the "weight" operand of the input-gradient GEMMs), all in ONE
     grouped launch into one fresh buffer; the descriptor table is cached per list of weight addresses"""
     from .fused import PinnedRing
-    key = tuple(w.data_ptr() for w in weights)
+    # (address AND shape: the allocator hands a freed model's addresses to the next one, whose layers may be shaped differently — offsets and
+    #  buffer size cached under the bare addresses would then be another model's: out-of-bounds transposes)
+    key = tuple((w.data_ptr(), tuple(w.shape)) for w in weights)
     L = _lib.load()
     dev = weights[0].device
     hit = _TR.get(key)

@@ -54,7 +54,7 @@ def quantize_grouped(tensors, fmt=E4M3):
     from .. import cmdbuf
     L = _lib.load()
     dev = tensors[0].device
-    key = tuple(t.data_ptr() for t in tensors)
+    key = tuple((t.data_ptr(), tuple(t.shape)) for t in tensors)       # (address and shape: a re-used address may hold another model's layer)
     hit = _QT.get(key)
     if hit is None:
         offs, total = [], 0
