@@ -212,3 +212,19 @@ def test_wgrad_seq_equals_the_single_launches():
     for (dy, x, dw, db), (dw1, db1) in zip(items, singles):
         assert torch.equal(dw, dw1) and torch.equal(db, db1)
         _close(dw, dy.float().t() @ x.float())
+
+
+def test_grouped_tables_are_keyed_by_shape_as_well_as_address():
+    """igemm.transposed / mx8.quantize_grouped cache table staging, offsets and the output size per operand list.  Two weights of different
+    shapes at ONE address (the allocator recycles a freed copy's address for the next layer's) must not share an entry: the second call
+    used to get the first one's buffer size — an out-of-bounds transpose."""
+    from partdistillation_amd.functions import igemm, mx8
+    buf = (torch.randn(512 * 128, device="cuda") * 2).to(torch.bfloat16)
+    w1, w2 = buf[:128 * 128].view(128, 128), buf.view(512, 128)
+    assert w1.data_ptr() == w2.data_ptr()
+    for w in (w1, w2, w1):
+        (t,) = igemm.transposed([w])
+        assert t.shape == (w.shape[1], w.shape[0]) and torch.equal(t, w.t())
+        ((q, s),) = mx8.quantize_grouped([w])
+        q1, s1 = mx8.quantize(w)
+        assert q.shape == w.shape and torch.equal(q, q1) and torch.equal(s, s1)
