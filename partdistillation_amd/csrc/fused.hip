@@ -176,7 +176,20 @@ __global__ __launch_bounds__(256) void multi_gather_sumsq(const int64_t *__restr
     for (int i = threadIdx.x; i < len; i += 256) d[i] = 0.f;
   } else if (is_bf16[t]) {
     const unsigned short *s = reinterpret_cast<const unsigned short *>(base) + start;
-    for (int i = threadIdx.x; i < len; i += 256) { const float v = bf2f(s[i]); d[i] = v; acc += v * v; }
+    if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {               // eight bf16 per lane-step: one 16-byte load, two 16-byte stores
+      const int l8 = len >> 3;
+      for (int i = threadIdx.x; i < l8; i += 256) {
+        const uint4 u = reinterpret_cast<const uint4 *>(s)[i];
+        const float4 a = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+        const float4 c = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+        reinterpret_cast<float4 *>(d)[2 * i] = a;
+        reinterpret_cast<float4 *>(d)[2 * i + 1] = c;
+        acc += (a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w) + (c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w);
+      }
+      for (int i = (l8 << 3) + threadIdx.x; i < len; i += 256) { const float v = bf2f(s[i]); d[i] = v; acc += v * v; }
+    } else {
+      for (int i = threadIdx.x; i < len; i += 256) { const float v = bf2f(s[i]); d[i] = v; acc += v * v; }
+    }
   } else {
     const float *s = reinterpret_cast<const float *>(base) + start;
     if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {

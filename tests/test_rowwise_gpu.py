@@ -430,3 +430,31 @@ def test_multi_size_bilinear_resize_equals_interpolate(B, C, H, W, sizes):
         ref = F.interpolate(x, size=(h, w), mode="bilinear", align_corners=False).flatten(2).transpose(1, 2)     # [B, hw, C]
         torch.testing.assert_close(g, ref, rtol=1e-6, atol=1e-6)
         assert torch.equal(g16, g.to(torch.bfloat16))
+
+
+def test_gradient_gather_mixed_dtypes_and_sum_of_squares():
+    """pd_multi_gather_sumsq through functions/fused.GatherPlan: bf16 / fp32 / missing gradients of ragged sizes gathered into the flat fp32
+    buffer (16-byte lanes where source and destination are aligned, scalar tails, zeros for a missing gradient) + the global sum of squares;
+    a second gather with unchanged addresses (the table upload is skipped) gives the same"""
+    from partdistillation_amd.functions.fused import GatherPlan
+    numels = [16384 * 2 + 40, 7, 100000, 24, 16384, 3]
+    offs, tot = [], 0
+    for n in numels:
+        offs.append(tot)
+        tot += (n + 7) // 8 * 8
+    plan = GatherPlan(numels, offs, torch.device(DEV))
+    g = torch.Generator(device=DEV).manual_seed(5)
+    grads = [torch.randn(numels[0], device=DEV, generator=g).to(torch.bfloat16), torch.randn(numels[1], device=DEV, generator=g).to(torch.bfloat16),
+             torch.randn(numels[2], device=DEV, generator=g), None, torch.randn(numels[4] + 1, device=DEV, generator=g).to(torch.bfloat16)[1:],
+             torch.randn(numels[5], device=DEV, generator=g)]
+    for _ in range(2):
+        flat = torch.full((tot,), 7.0, device=DEV)
+        ss = torch.zeros(1, dtype=torch.float64, device=DEV)
+        plan.upload(grads)
+        plan.gather(flat, ss)
+        want = 0.0
+        for gr, n, o in zip(grads, numels, offs):
+            ref = torch.zeros(n, device=DEV) if gr is None else gr.float()
+            assert torch.equal(flat[o:o + n], ref)
+            want += float(ref.double().pow(2).sum())
+        assert abs(float(ss) - want) <= 1e-6 * want
