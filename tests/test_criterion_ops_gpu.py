@@ -180,3 +180,46 @@ def test_point_sample_masks_equals_grid_sample_of_the_float_copy(shape, P):
     ref2 = F.grid_sample(masks.float().view(B * nmax, 1, H, W)[idx], 2.0 * c2.unsqueeze(2) - 1.0, mode="bilinear", padding_mode="zeros",
                          align_corners=False)[:, 0, :, 0]
     torch.testing.assert_close(got2, ref2, rtol=1e-5, atol=1e-6)
+
+
+def test_batched_criterion_with_ragged_target_counts_equals_the_torch_expressions(monkeypatch):
+    """Images with DIFFERENT numbers of target masks (3 and 5: padded target columns, padded labels, per-problem column counts): the training
+    losses and gradients of the proposal model with the criterion kernels (pd_matcher_costs, pd_point_sample_u8, pd_uncertain_points,
+    pd_mask_point_losses_*) against the same model with the plain torch expressions (PD_CRITERION_KERNELS=0 — the path the reference goldens
+    pin), identical weights and replayed random draws.  fp32, so what differs is summation order: losses to 1e-4, gradients to 2e-3 of
+    their maximum (a flipped near-tie in the importance sampling moves single points)."""
+    import os, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import common as C
+    from partdistillation_amd.compat import build_model
+    from partdistillation_amd.config import setup_cfg
+    from partdistillation_amd.engine.synthetic import make_batch
+    from partdistillation_amd.functions import criterion_ops as cops
+    import partdistillation_amd.modeling, partdistillation_amd.proposal_model  # noqa: F401,E401
+    cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd", "configs", "proposal_learning", "r50_mask2former.yaml"),
+                    ["MODEL.MASK_FORMER.NUM_OBJECT_QUERIES", "20", "MODEL.MASK_FORMER.DEC_LAYERS", "3", "MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS", "1",
+                     "MODEL.MASK_FORMER.TRAIN_NUM_POINTS", "512", "SOLVER.AMP.ENABLED", "False"])
+    torch.manual_seed(0)
+    model = build_model(cfg).to(DEV).train()
+    batch = make_batch(1, 128, n_parts=3, seed=5, device=DEV) + make_batch(1, 128, n_parts=5, seed=6, device=DEV)
+    assert [len(b["instances"]) for b in batch] == [3, 5]
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(cops, "ENABLED", on)
+        model.zero_grad(set_to_none=True)
+        model.criterion.rand = C.ReplayRand(777)
+        losses = model(batch)
+        total = sum(losses.values())
+        total.backward()
+        res[on] = ({k: float(v) for k, v in losses.items()},
+                   {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None and ("predictor" in n or "mask_features" in n)})
+    la, lb = res[True][0], res[False][0]
+    assert set(la) == set(lb) and len(la) == 9                      # three heads x (ce, mask, dice)
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-4 * max(abs(lb[k]), 1.0), (k, la[k], lb[k])
+    ga, gb = res[True][1], res[False][1]
+    assert set(ga) == set(gb) and len(ga) > 50
+    worst = max(float((ga[n] - gb[n]).abs().max() / gb[n].abs().max().clamp_min(1e-12)) for n in gb)
+    print(f"ragged targets, criterion kernels vs torch expressions: worst gradient deviation {worst:.2e} of the tensor maximum")
+    assert worst <= 2e-3
