@@ -155,6 +155,10 @@ int pd_upsample2x_bwd_nhwc_f32(const float *dy, float *dlo, int B, int h, int w,
 int pd_resize_bilinear_nhwc_f32(const float *x, int B, int H, int W, int C, const int *heights, const int *widths, void *const *outs, int count,
                                 int out_dtype, void *stream);
 
+/* out1 = (a + b) + c, out2 = d + c over n fp32 elements (n % 4 == 0, 16-byte aligned): the three elementwise sums that end the encoder's backward
+ * (d(src) = its three terms, d(pos) = accumulator + last term; reference msdeformattn.py:41-42 `with_pos_embed` backward) as one launch */
+int pd_sum3_sum2_f32(const float *a, const float *b, const float *c, const float *d, float *out1, float *out2, int64_t n, void *stream);
+
 /*
  * dst_i [batch, cols, rows] (contiguous) = src_i [batch, rows, cols]^T, fp32, for up to PD_TRANSPOSE_MAX problems in one launch.  src_i may
  * be strided: src_batch_stride / src_row_stride in floats (unit column stride) — the layers' weights where they lie in the flat parameter

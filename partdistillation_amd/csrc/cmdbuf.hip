@@ -160,6 +160,7 @@ const Entry kTable[] = {
   PD_E(pd_sgemm_wgrad_grouped_bf16),
   PD_E(pd_sgemm_wgrad_split_bf16),
   PD_E(pd_split3_bf16),
+  PD_E(pd_sum3_sum2_f32),
   PD_E(pd_sumsq_accumulate),
   PD_E(pd_swin_ln_bwd),
   PD_E(pd_swin_ln_fwd),

@@ -829,6 +829,18 @@ __global__ __launch_bounds__(256) void transpose_batched_f32(TrBatch tb)
   }
 }
 
+// out1 = (a + b) + c and out2 = d + c in one pass (the end of the encoder's backward: d(src) from its three fp32 terms, d(pos) from its
+// accumulator and the last term — three ATen launches over [43 008, 256] before)
+__global__ __launch_bounds__(256) void sum3_sum2_f32(const float4 *__restrict__ a, const float4 *__restrict__ b, const float4 *__restrict__ c,
+                                                     const float4 *__restrict__ d, float4 *__restrict__ o1, float4 *__restrict__ o2, int64_t n4)
+{
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 x = a[i], y = b[i], z = c[i], w = d[i];
+    o1[i] = make_float4((x.x + y.x) + z.x, (x.y + y.y) + z.y, (x.z + y.z) + z.z, (x.w + y.w) + z.w);
+    o2[i] = make_float4(w.x + z.x, w.y + z.y, w.z + z.z, w.w + z.w);
+  }
+}
+
 bool dt_ok(int dt) { return dt == PD_F32 || dt == PD_BF16; }
 
 }  // namespace
@@ -1208,4 +1220,17 @@ extern "C" int pd_resize_bilinear_nhwc_f32(const float *x, int B, int H, int W, 
   if (out_dtype == PD_BF16) hipLaunchKernelGGL(resize_bilinear_nhwc_multi<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, x, B, H, W, C / 4, lv);
   else hipLaunchKernelGGL(resize_bilinear_nhwc_multi<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, x, B, H, W, C / 4, lv);
   return pd_check_launch("pd_resize_bilinear_nhwc_f32");
+}
+
+extern "C" int pd_sum3_sum2_f32(const float *a, const float *b, const float *c, const float *d, float *out1, float *out2, int64_t n, void *stream_)
+{
+  if (n < 0 || (n & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_sum3_sum2_f32: n=%lld (a multiple of 4)", (long long)n);
+  if (n == 0) return PD_OK;
+  if (!a || !b || !c || !d || !out1 || !out2 || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)out1 | (uintptr_t)out2) & 15))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_sum3_sum2_f32: null / misaligned pointer");
+  const int64_t n4 = n / 4;
+  const unsigned grid = (unsigned)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(sum3_sum2_f32, dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const float4 *)a, (const float4 *)b, (const float4 *)c,
+                     (const float4 *)d, (float4 *)out1, (float4 *)out2, n4);
+  return pd_check_launch("pd_sum3_sum2_f32");
 }

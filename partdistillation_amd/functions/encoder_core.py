@@ -375,9 +375,17 @@ class EncoderCore(Function):
                 _RECS[key] = rec
             else:
                 dy, dy2, dyq, d_pos, grads = rec.replay(slots)
-        d_pos = d_pos + dyq if rec_f is not None else d_pos.add_(dyq)      # (never in place on an arena tensor another replay re-reads)
-        d_src = dy + dy2
-        d_src += dyq
+        if all(t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == dy.numel() for t_ in (dy, dy2, dyq, d_pos)) \
+                and dy.numel() % 4 == 0:
+            # d(src) = (dy + dy2) + dyq and d(pos) = d_pos + dyq by one launch (the same sums, in the same order)
+            d_src, d_pos_out = torch.empty_like(dy), torch.empty_like(d_pos)
+            _lib.check(_lib.load().pd_sum3_sum2_f32(dy.data_ptr(), dy2.data_ptr(), dyq.data_ptr(), d_pos.data_ptr(), d_src.data_ptr(),
+                                                    d_pos_out.data_ptr(), dy.numel(), _lib.current_stream()))
+            d_pos = d_pos_out
+        else:
+            d_pos = d_pos + dyq if rec_f is not None else d_pos.add_(dyq)      # (never in place on an arena tensor another replay re-reads)
+            d_src = dy + dy2
+            d_src += dyq
         if not need_w:
             grads = [None] * len(grads)
         return (None, d_src.view(B, S, C), d_pos.view(B, S, C), *grads)

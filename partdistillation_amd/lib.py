@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libpd_hip.so") 
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -89,6 +89,7 @@ SIGNATURES = {
     "pd_mem_prep_fwd": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "pd_mem_prep_bwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
     "pd_attn_mask_u8": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "pd_sum3_sum2_f32": (_c_int, [_c_vp] * 6 + [ctypes.c_int64, _c_vp]),
     "pd_transpose_batched_f32": (_c_int, [_c_vp, _c_int, _c_vp]),
     "pd_normalize_u8_nhwc": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
     "pd_resize_bilinear_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 3 + [_c_int, _c_int, _c_vp]),
