@@ -128,6 +128,45 @@ class Fresh:
         self.items = list(items)
 
 
+def unalias_grads(params, owns):
+    """call BEFORE a region whose returned parameter gradients live in persistent memory (a recording's arena, the fused ResNet
+    plan's arena) overwrites that memory: AccumulateGrad adopts such a gradient as `.grad` WITHOUT a copy, so a `.grad` that survived
+    the previous step (gradient accumulation over micro-batches, zero_grad(set_to_none=False), a stock torch optimizer — anything but
+    engine/flat_params.py, which drops `.grad` after gathering it) still points into the memory about to be rewritten.  Every such
+    `.grad` is moved to storage of its own first; autograd then accumulates the new gradient into it as usual (g1 + g2, not 2 * g2).
+    owns(ptr) -> bool tells whether an address belongs to the persistent memory in question."""
+    for p in params:
+        g = getattr(p, "grad", None)
+        if g is not None and g.is_cuda and g.numel() and owns(g.data_ptr()):
+            p.grad = g.clone()
+
+
+class LRU(dict):
+    """a bounded cache of plans / recordings (each owns persistent arenas of 10^8 .. 10^10 bytes per input shape: training with
+    ResizeShortestEdge + RandomCrop, or inference on arbitrary image sizes, must not accumulate one arena set per shape).  get() marks
+    an entry as the most recently used; put() drops the least recently used entries beyond `cap` and hands them to `on_evict`."""
+
+    def __init__(self, cap, on_evict=None):
+        super().__init__()
+        self.cap, self.on_evict = cap, on_evict
+
+    def get(self, key, default=None):
+        if key in self:
+            v = self.pop(key)
+            self[key] = v
+            return v
+        return default
+
+    def put(self, key, value):
+        self.pop(key, None)
+        self[key] = value
+        while len(self) > self.cap:
+            k = next(iter(self))
+            v = self.pop(k)
+            if self.on_evict is not None:
+                self.on_evict(k, v, self)
+
+
 def require_stable(ptr, what):
     """inside a recorded region: `ptr` is about to be written into HOST memory the replay re-reads (a descriptor table) — it must be a
     persistent address (an arena), not a slot"""
@@ -249,6 +288,10 @@ class Recording:
         ext = (sum((int(s) - 1) * int(st) for s, st in zip(shape, strides)) + 1) if n else 0
         c, o = self.arena.alloc(ext * _itemsize(dtype))
         return c[o:o + max(ext, 1) * _itemsize(dtype)].view(dtype).as_strided(tuple(shape), tuple(strides))
+
+    def owns(self, ptr):
+        """is `ptr` inside THIS recording's arenas (memory the next replay rewrites)?"""
+        return self.arena.contains(ptr) or self.zero_arena.contains(ptr)
 
     def _in_arena(self, ptr):
         return (self.arena.contains(ptr) or self.zero_arena.contains(ptr)

@@ -123,8 +123,11 @@ class BucketedGradReducer:
         nothing back: the whole exchange is enqueued on the side stream behind the bucket all-reduces while the GPU is still in
         backward (round 3 agreed on the size with a 16-byte all-reduce and two blocking host reads per step).  A rank whose step
         kept no row record sends the non-zero rows of its local gradient, found on the device (top-`cap` rows by "has a non-zero
-        entry"); a rank with no gradient at all sends only sentinels.  More touched rows than the cap is a configuration error: the
-        host-known case (a record longer than the cap) raises here, the device-found case is flagged and raised at the next step."""
+        entry"); a rank with no gradient at all sends only sentinels.  More touched rows than the cap is a configuration error
+        (TrainStep validates the cap against images per rank x (K + 1) at construction): the rank it happens on — host-known, a record
+        longer than the cap, or device-found — sends its first `cap` rows and an OVERFLOW FLAG in an extra element of its row vector;
+        every rank reads the gathered flags of all ranks and all of them raise at the same point (their next step's check), instead
+        of one rank raising before its collective and the others hanging in theirs."""
         g = self.flat.groups[gi]
         g.gather(None)                                            # local dense gradients -> flat buffer (compute stream)
         rows = getattr(g.params[0], "_pd_rows", None)
@@ -133,8 +136,9 @@ class BucketedGradReducer:
                 p._pd_rows = None                                 # consumed: a stale list is never exchanged for a later step
         dev = g.grad.device
         cap = self.sparse_rows_cap
-        if rows is not None and rows.numel() > cap:
-            raise RuntimeError(f"row-sparse gradient group: {rows.numel()} touched rows exceed MODEL.AMD.DDP_SPARSE_ROWS_CAP = {cap}")
+        # (a record longer than the cap is NOT raised here: this rank alone would leave the others blocked in all_gather until the
+        # process group's timeout.  The overflow travels with the gathered rows instead — every rank sees every rank's flag — and all
+        # ranks raise together at their next _check_overflow(); see _exchange_rows_on_stream)
         self._check_overflow()
         side = self._side
         if side is not None:                                      # the exchange itself runs on the side stream, behind the bucket all-reduces
@@ -152,14 +156,15 @@ class BucketedGradReducer:
         for flag, ev in self._overflow:
             if ev is None or ev.query():
                 if int(flag[0]) != 0:
-                    raise RuntimeError(f"row-sparse gradient group: a step without a row record touched more than "
-                                       f"MODEL.AMD.DDP_SPARSE_ROWS_CAP = {self.sparse_rows_cap} rows; its gradient was truncated")
+                    raise RuntimeError(f"row-sparse gradient group: a rank's step touched more than MODEL.AMD.DDP_SPARSE_ROWS_CAP = "
+                                       f"{self.sparse_rows_cap} rows; that step's gradient was truncated (raised on every rank)")
             else:
                 keep.append((flag, ev))
         self._overflow = keep
 
     def _exchange_rows_on_stream(self, g, rows, cap, dev):
         views = [g._view(g.grad, p, off).reshape(p.shape[0], -1) for p, off in zip(g.params, g.offsets)]
+        over = None
         if rows is None:
             # no record: the touched rows are the rows with a non-zero entry — found on the device in a fixed-size form
             nz = views[0].ne(0).any(1)
@@ -169,15 +174,10 @@ class BucketedGradReducer:
             val, idx = torch.topk(nz.to(torch.float32), k)
             rows = torch.where(val > 0, idx, idx.new_full((), -1))
             over = (nz.sum() > cap).to(torch.int64).reshape(1)
-            if dev.type == "cuda":
-                pinned = torch.zeros(1, dtype=torch.int64, pin_memory=True)
-                pinned.copy_(over, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(dev))
-                self._overflow.append((pinned, ev))
-            else:
-                self._overflow.append((over, None))
         rows = rows.reshape(-1).to(dev)
+        if over is None:
+            over = torch.full((1,), int(rows.numel() > cap), dtype=torch.int64, device=dev)
+            rows = rows[:cap]                                     # (host-known overflow: flagged, every rank raises at its next check)
         if rows.numel() < cap:                                    # pad to the static size: sentinel rows carry zeros
             rows = torch.cat([rows, rows.new_full((cap - rows.numel(),), -1)])
         valid = rows >= 0
@@ -190,10 +190,21 @@ class BucketedGradReducer:
         # a row listed twice (two images of one class, the shared no-object row) holds the SUM already: send it once
         first = ~((rows[:, None] == rows[None, :]).tril(-1).any(1)) & valid
         pack = torch.cat([v[src] for v in views], dim=1) * first[:, None].to(g.grad.dtype)
+        rows_flag = torch.cat([rows, over.to(rows.dtype)])        # [cap + 1]: the rows and this rank's overflow flag
         all_pack = [torch.empty_like(pack) for _ in range(self.world)]
-        all_rows = [torch.empty_like(rows) for _ in range(self.world)]
+        all_rows = [torch.empty_like(rows_flag) for _ in range(self.world)]
         dist.all_gather(all_pack, pack.contiguous(), group=self.pg)
-        dist.all_gather(all_rows, rows.contiguous(), group=self.pg)
+        dist.all_gather(all_rows, rows_flag.contiguous(), group=self.pg)
+        any_over = torch.stack([r[cap] for r in all_rows]).max().reshape(1)        # identical on every rank
+        if dev.type == "cuda":
+            pinned = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+            pinned.copy_(any_over, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self._overflow.append((pinned, ev))
+        else:
+            self._overflow.append((any_over, None))
+        all_rows = [r[:cap] for r in all_rows]
         # sentinel rows arrive with an all-zero payload: clamped to row 0 they zero it (its gradient is rebuilt from the payloads
         # of the ranks that touched it, or is an exact zero anyway) and add zeros — no host branch, no compaction
         rows_all, pack_all = torch.cat(all_rows).clamp_min(0), torch.cat(all_pack) / self.world

@@ -61,6 +61,13 @@ class TrainStep:
         broadcast_parameters(self.optimizer.flat, 0, process_group)
         self.reducer = BucketedGradReducer(self.optimizer.flat, cfg.MODEL.AMD.DDP_BUCKET_MB, process_group,
                                            optimizer=self.optimizer, sparse_rows_cap=int(cfg.MODEL.AMD.get("DDP_SPARSE_ROWS_CAP", 256)))
+        if self.reducer.sparse_groups:
+            # the static row-sparse exchange sends `cap` rows per rank: a step touches (K + 1) class-head rows per image
+            per_rank = -(-int(cfg.SOLVER.IMS_PER_BATCH) // max(self.world, 1))
+            need = per_rank * (int(cfg.PART_DISTILLATION.NUM_PART_CLASSES) + 1)
+            if need > self.reducer.sparse_rows_cap:
+                raise ValueError(f"MODEL.AMD.DDP_SPARSE_ROWS_CAP = {self.reducer.sparse_rows_cap} is below images per rank x (parts + 1) = "
+                                 f"{per_rank} x {int(cfg.PART_DISTILLATION.NUM_PART_CLASSES) + 1} = {need}: raise the cap (it is a static exchange size, the same on every rank)")
         if _os.environ.get("PD_CONV_GROUP_ROWS"):               # tools/ experiments
             from .. import lib as _l
             _l.load().pd_debug_set(b"conv_group_rows", int(_os.environ["PD_CONV_GROUP_ROWS"]))
@@ -129,7 +136,10 @@ class TrainStep:
         """capture the whole step for batches shaped like `example_batch` (single process only).  The warm-up runs real
         steps (allocator growth, MIOpen/BLAS lazy initialisation need the full kernel sequence) on a SNAPSHOT of the
         weights, bf16 shadows and Adam moments that is restored afterwards, so capturing does not move the training
-        trajectory (weights, moments and step count are exactly what they were before the call)."""
+        trajectory (weights, moments and step count are exactly what they were before the call).
+        Requires a process started with PD_CMDBUF=0 (after any command-buffer recording hipGraphInstantiate segfaults on ROCm 7.2;
+        the call raises instead) and DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 — see INTEGRATION.md "hipGraph".  The command buffers and the
+        fused ResNet body are switched off for the duration of the call and restored on every exit path."""
         if self.world > 1:
             raise RuntimeError("hipGraph capture of the step is for the single-GPU path (collectives stay eager)")
         if warmup < 1:
@@ -172,31 +182,33 @@ class TrainStep:
         # hipGraphInstantiate on ROCm 7.2 (the whole-step graph is opt-in and not the shipped mode: DESIGN.md 5 "hipGraph")
         from ..modeling.backbone import resnet_core
         r50_was, resnet_core.ENABLED = resnet_core.ENABLED, False
-        before = PinnedRing.counters()
-        for w in range(warmup):
-            if w == warmup - 1:
-                before = PinnedRing.counters()                   # the last warm-up step is the rehearsal of the captured sequence
-            self._segment(static, _segment, rehearsal=w == warmup - 1)
-        PinnedRing.reserve_all(before, PinnedRing.counters())   # dedicated pinned buffers for the uploads the capture will bake in
-        with torch.no_grad():
-            for t, s in zip(live, snapshot):
-                t.copy_(s)
-        self.optimizer.steps = steps0
-        del snapshot
-        torch.set_rng_state(rng_cpu)
-        if rng_dev is not None:
-            torch.cuda.set_rng_state(rng_dev)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        self.optimizer.zero_grad()
-        with torch.cuda.graph(graph):
-            loss_dict = self._segment(static, _segment, rehearsal=True)
-        # keep only DETACHED views of the static losses: holding the captured autograd graph alive would also keep its
-        # AccumulateGrad nodes, which are bound to the capture stream — every later EAGER step (a batch with another
-        # signature) would then run its gradient accumulation on that stream, and the next replay faults on ROCm 7.2
-        # (DESIGN.md §5 "hipGraph").
-        loss_dict = _detached(loss_dict)
-        cmdbuf.ENABLED, resnet_core.ENABLED = cmdbuf_was, r50_was
+        try:                                                    # whatever happens below (out of memory, a refused graph): both switches come back
+            before = PinnedRing.counters()
+            for w in range(warmup):
+                if w == warmup - 1:
+                    before = PinnedRing.counters()                   # the last warm-up step is the rehearsal of the captured sequence
+                self._segment(static, _segment, rehearsal=w == warmup - 1)
+            PinnedRing.reserve_all(before, PinnedRing.counters())   # dedicated pinned buffers for the uploads the capture will bake in
+            with torch.no_grad():
+                for t, s in zip(live, snapshot):
+                    t.copy_(s)
+            self.optimizer.steps = steps0
+            del snapshot
+            torch.set_rng_state(rng_cpu)
+            if rng_dev is not None:
+                torch.cuda.set_rng_state(rng_dev)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            self.optimizer.zero_grad()
+            with torch.cuda.graph(graph):
+                loss_dict = self._segment(static, _segment, rehearsal=True)
+            # keep only DETACHED views of the static losses: holding the captured autograd graph alive would also keep its
+            # AccumulateGrad nodes, which are bound to the capture stream — every later EAGER step (a batch with another
+            # signature) would then run its gradient accumulation on that stream, and the next replay faults on ROCm 7.2
+            # (DESIGN.md §5 "hipGraph").
+            loss_dict = _detached(loss_dict)
+        finally:
+            cmdbuf.ENABLED, resnet_core.ENABLED = cmdbuf_was, r50_was
         self._graph, self._static, self._static_losses = graph, static, loss_dict
         self._graph_sig = self._signature(example_batch)
         return self

@@ -121,17 +121,28 @@ N_GLOBAL = 11        # query_feat, query_embed, level_embed, dn_w, dn_b, mlp (w,
 N_LAYER = 18         # cross: in_w in_b out_w out_b n_w n_b | self: same | ffn: w1 b1 w2 b2 n_w n_b
 
 
-_RECS = {}             # recorded regions (cmdbuf.Recording), keyed by everything that decides their control flow
+def _drop_backward_of(key, rec, cache):
+    for k in [k for k in cache if k[0] == "bwd" and k[1] == id(rec)]:      # a backward recording pins its forward recording's arenas
+        cache.pop(k)
+
+
+_RECS = cmdbuf.LRU(24, _drop_backward_of)      # recorded regions (cmdbuf.Recording), keyed by everything that decides their control flow
 
 
 def _rec_get(key):
     return _RECS.get(key)
 
 
+def _flat_params(o):
+    if isinstance(o, torch.Tensor):
+        return [o]
+    if isinstance(o, (list, tuple)):
+        return [t for x in o for t in _flat_params(x)]
+    return []
+
+
 def _rec_put(key, rec):
-    if len(_RECS) >= 24:                                   # a new model in the same process (tests): drop the oldest recordings + arenas
-        _RECS.pop(next(iter(_RECS)))
-    _RECS[key] = rec
+    _RECS.put(key, rec)                                    # beyond 24: the least recently used recordings + their arenas go
 
 
 class DecoderCore(Function):
@@ -321,6 +332,7 @@ class DecoderCore(Function):
                 outs = rec.finish(outs)
                 _rec_put(key, rec)
             else:
+                cmdbuf.unalias_grads(_flat_params(ctx.params), rec.owns)
                 outs = rec.replay(slots)
             fl = outs[-1]
             outs = outs[:-1] + ([tuple(fl[6 * i:6 * i + 6]) for i in range(L)],)

@@ -34,7 +34,15 @@ def _timed(kind, fn, *args):
     return t(kind, fn, *args)
 
 
-_RECS = {}      # recorded regions (cmdbuf.Recording) of the encoder, keyed by everything that decides their control flow
+def _drop_backward_of(key, rec, cache):
+    # a backward recording keeps its forward recording's arenas alive (stable=[rec_f]) and is keyed by id(rec_f): it goes with it
+    for k in [k for k in cache if k[0] == "bwd" and k[1] == id(rec)]:
+        cache.pop(k)
+
+
+# recorded regions (cmdbuf.Recording) of the encoder, keyed by everything that decides their control flow.  Each forward / backward pair
+# owns >= 2 x (64 + 8) MiB .. ~10 GB of arenas at 1024^2: bounded, least recently used first (variable input shapes)
+_RECS = cmdbuf.LRU(int(__import__("os").environ.get("PD_ENCODER_REC_CAP", "6")), _drop_backward_of)
 
 
 def _msda_timing():
@@ -223,7 +231,7 @@ class EncoderCore(Function):
                 with rec:
                     outs = EncoderCore._layers_h2(spec, src2, pos2, q, ref, wk, b_oa_all, l2_all, params, dims)
                 x, saved, saved_am = rec.finish(outs)
-                _RECS[key] = rec
+                _RECS.put(key, rec)
             else:
                 x, saved, saved_am = rec.replay(slots)
             ctx.rec, ctx.rec_gen = rec, rec.generation
@@ -372,8 +380,9 @@ class EncoderCore(Function):
                     outs = EncoderCore._bwd_layers_h2(spec, params, ctx.dims, ctx.saved, ctx.saved_am, dy, stacks, need_w)
                     outs = outs[:4] + (cmdbuf.Fresh(outs[4]),)
                 dy, dy2, dyq, d_pos, grads = rec.finish(outs)
-                _RECS[key] = rec
+                _RECS.put(key, rec)
             else:
+                cmdbuf.unalias_grads(params, rec.owns)
                 dy, dy2, dyq, d_pos, grads = rec.replay(slots)
         if all(t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == dy.numel() for t_ in (dy, dy2, dyq, d_pos)) \
                 and dy.numel() % 4 == 0:

@@ -26,7 +26,11 @@ from ...compat.layers import FrozenBatchNorm2d
 from ...functions import conv_bf16, igemm
 from ...functions.fused import PinnedRing
 
-_PLANS = {}
+# one Plan (= one persistent arena holding every activation, gradient, transposed filter and filter gradient of the body: ~3.5 GB at
+# 2 x 1024^2) per (network, input shape, grad mode) — bounded, least recently used first: the reference's mappers crop / resize to
+# varying sizes and inference shapes differ per batch
+from ... import cmdbuf as _cmdbuf
+_PLANS = _cmdbuf.LRU(int(__import__("os").environ.get("PD_R50_PLAN_CAP", "4")))
 ENABLED = bool(int(__import__("os").environ.get("PD_R50_FUSED", "1")))
 
 
@@ -120,6 +124,9 @@ class Plan:
 
     def ptr(self, off):
         return self.base + 2 * off
+
+    def owns(self, ptr):
+        return self.base <= ptr < self.base + 2 * self.arena.numel()
 
     def view(self, off, b, h, w, c):
         """NCHW-shaped view with channels_last strides of the arena's [b][h][w][c] block at `off`"""
@@ -355,6 +362,7 @@ class R50Body(Function):
             raise RuntimeError("the fused ResNet body ran another forward before this backward: its activation arena was overwritten "
                                "(set PD_R50_FUSED=0 for graphs that keep several forward passes alive)")
         (x0,) = ctx.saved_tensors
+        _cmdbuf.unalias_grads(plan.weights(), plan.owns)             # a `.grad` that survived the last step still points at the arena's dW
         gx0, dws = plan.run_backward(x0, gouts, ctx.needs_input_grad[0], ctx.needs_input_grad[2:])
         return (gx0, None, *dws)
 
@@ -398,6 +406,7 @@ def run_body(resnet, x0, blocks, stage_of_block):
     key = (id(resnet), tuple(x0.shape), str(x0.device), grad)
     plan = _PLANS.get(key)
     if plan is None or not plan.valid():
-        plan = _PLANS[key] = Plan(blocks, x0, [n for n in resnet._out_features if n != "stem"], stage_of_block, grad)
+        plan = Plan(blocks, x0, [n for n in resnet._out_features if n != "stem"], stage_of_block, grad)
+        _PLANS.put(key, plan)
     outs = R50Body.apply(x0, plan, *plan.weights()) if grad else plan.run_forward(x0)
     return dict(zip(plan.out_names, outs))

@@ -122,13 +122,16 @@ def _cast_bias_grads(grads, params, slots):
             o += n
 
 
-_RECS = {}             # recorded regions (cmdbuf.Recording) per stage geometry
+def _drop_backward_of(key, rec, cache):
+    for k in [k for k in cache if k[0] == "bwd" and k[1] == id(rec)]:      # a backward recording pins its forward recording's arenas
+        cache.pop(k)
+
+
+_RECS = cmdbuf.LRU(32, _drop_backward_of)             # recorded regions (cmdbuf.Recording) per stage geometry, least recently used out first
 
 
 def _rec_put(key, rec):
-    if len(_RECS) >= 32:
-        _RECS.pop(next(iter(_RECS)))
-    _RECS[key] = rec
+    _RECS.put(key, rec)
 
 
 def _stage_consts(spec, device):
@@ -278,6 +281,7 @@ class SwinStage(Function):
                 outs = rec.finish(outs)
                 _rec_put(key, rec)
             else:
+                cmdbuf.unalias_grads(params, rec.owns)
                 outs = rec.replay(slots)
             dx, grads = outs
         grads = list(grads)

@@ -229,6 +229,52 @@ def test_row_sparse_exchange_uneven_rows_and_missing_record(tmp_path):
             torch.testing.assert_close(r[0]["steps"][step]["grads"][n], p.grad, rtol=1e-6, atol=1e-7, msg=lambda m: f"step {step} {n}: {m}")
 
 
+# ----------------------------------------------------------------------------- more touched rows than the cap: all ranks fail TOGETHER
+def _overflow_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from partdistillation_amd.engine.ddp import BucketedGradReducer, broadcast_parameters
+    from partdistillation_amd.engine.flat_params import FlatParams
+    torch.manual_seed(5)
+    model = SparseNet()
+    names = dict((id(p), n) for n, p in model.named_parameters())
+    groups = [{"params": [p for p in reversed(list(model.parameters())) if p.dtype == dt],
+               "names": [names[id(p)] for p in reversed(list(model.parameters())) if p.dtype == dt], "lr": 1e-3, "weight_decay": 0.0}
+              for dt in (torch.float32, torch.float64)]
+    flat = FlatParams(groups)
+    broadcast_parameters(flat, 0)
+    reducer = BucketedGradReducer(flat, bucket_mb=0.00005, sparse_rows_cap=4)
+    # step 0: ONLY rank 1's record (6 rows) exceeds the cap of 4.  Nobody may raise before the collectives (the other rank would hang in
+    # all_gather); step 1: BOTH ranks raise at the check that opens their exchange, with the same message
+    plans = [(torch.tensor([3, 4, 39]), torch.tensor([17, 18, 19, 20, 21, 39])), (torch.tensor([1, 39]), torch.tensor([2, 39]))]
+    raised = []
+    for it, (r0, r1) in enumerate(plans):
+        flat.zero_grad()
+        model(torch.randn(4, 5), r0 if rank == 0 else r1, use_side=True).backward()
+        try:
+            reducer.finish()
+            raised.append(None)
+        except RuntimeError as e:
+            raised.append(str(e))
+    torch.save(raised, os.path.join(tmp, f"overflow{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_row_sparse_overflow_is_raised_on_every_rank_together(tmp_path):
+    """a rank whose step touched more rows than DDP_SPARSE_ROWS_CAP must not raise before its collectives (the others would
+    block in all_gather until the process group's timeout): the flag travels with the gathered rows and every rank raises at the
+    same point of the next step."""
+    world = 2
+    mp.spawn(_overflow_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"overflow{k}.pt") for k in range(world)]
+    for k in range(world):
+        assert r[k][0] is None, r[k]
+        assert r[k][1] is not None and "DDP_SPARSE_ROWS_CAP = 4" in r[k][1], r[k]
+
+
 # ----------------------------------------------------------------------------- bucket issue schedule on the real config-2 parameter list
 def test_bucket_issue_schedule_config2():
     """VERDICT r2 item 7a.  The reducer issues buckets strictly in index order over ALL flat groups, so a group whose parameters are

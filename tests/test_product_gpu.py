@@ -820,24 +820,53 @@ def test_full_step_bf16_autocast_vs_oracle():
 
 
 GRAD_TOL_FP32_FULL = 4e-3       # of the tensor maximum: 3 x the measured worst case (1.1e-3, the stem filter: profiles/r04_parity.json)
+GRAD_TOL_BF16_BACKBONE = 1e-1   # bf16 backbone filter gradients vs the oracle's fp32 ones, of the tensor maximum (tightened to 3 x measured below)
+# fp32 losses.  History of the number (profiles/r04_parity.json over its seven commits): 9.3e-5 once (ccb9444: worst term loss_mask_3, with the
+# gradients of mask_features / mask_embed at 1e-4 of their maximum), 1.9e-7 .. 2.9e-7 in the six records since (worst term always a
+# loss_ce_*, those two gradients at 7e-7 .. 9e-7).  No code of the fp32 forward path changed in between (git diff ccb9444 630e9da touches
+# Swin, MX-fp8, the LayerNorm BACKWARD and the bf16 weight gradients only): 9.3e-5 is the signature of ONE of the 12 544 importance-sampled
+# points of one head differing between GPU and CPU (1 / 12 544 = 8.0e-5; detectron2's sampler keeps the top-k of -|logit| over 37 632
+# candidates, and a near-tie at the k-th place resolves by the last bit of the logit — MIOpen picks its fp32 convolution algorithm per
+# box).  The rule below therefore is: terms without a discrete choice behind them (loss_ce*) within 5e-6 (17 x measured), the
+# mask / dice pair of at most TWO heads may carry up to three swapped points (3e-4), everything else within 5e-6 too.
+FP32_LOSS_REL, FP32_LOSS_REL_SWAPPED, FP32_LOSS_ABS = 5e-6, 3e-4, 1e-6
+
+
+def _check_fp32_losses(losses, olosses):
+    dev = {k: abs(float(losses[k]) - float(olosses[k])) for k in olosses}
+    loose = [k for k in olosses if dev[k] > FP32_LOSS_REL * abs(float(olosses[k])) + FP32_LOSS_ABS]
+    heads = {k.replace("loss_mask", "").replace("loss_dice", "") for k in loose}
+    assert all(k.startswith(("loss_mask", "loss_dice")) for k in loose) and len(heads) <= 2, (loose, {k: dev[k] for k in loose})
+    for k in loose:
+        assert dev[k] <= FP32_LOSS_REL_SWAPPED * abs(float(olosses[k])) + FP32_LOSS_ABS, (k, float(losses[k]), float(olosses[k]))
+    return len(loose)
+
+
+def _full_size_step(amp, extra=()):
+    from partdistillation_amd.config import setup_cfg
+    from partdistillation_amd.engine.trainer import TrainStep
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = setup_cfg(os.path.join(root, "partdistillation_amd", "configs", "proposal_learning", "r50_mask2former.yaml"),
+                    ["INPUT.IMAGE_SIZE", "1024", "SOLVER.AMP.ENABLED", str(amp), "SOLVER.WARMUP_ITERS", "0"] + list(extra))
+    torch.manual_seed(0)
+    return cfg, TrainStep(cfg)
+
+
+BACKBONE_GRADS = ["backbone.stem.conv1.weight", "backbone.res2.0.conv1.weight", "backbone.res4.3.conv2.weight", "backbone.res5.2.conv3.weight"]
 
 
 @pytest.mark.parametrize("amp", [False, True])
 def test_config2_full_size_step_vs_oracle(amp):
     """BASELINE config 2 at FULL size — R50, 1024 x 1024, Q = 100, 10 prediction heads, 12 544 points, reference init —
     one image through the HIP training step (fp32, and the benchmarked bf16 autocast) against the CPU oracle: all 30
-    weighted losses (fp32: rel 3e-4 + 1e-4 abs = 3 x the measured deviation, see profiles/r04_parity.json; bf16: rel 2e-2 + 2e-3 abs,
+    weighted losses (fp32: the rule of _check_fp32_losses, 5e-6 with an allowance for swapped sample points; bf16: rel 2e-2 + 2e-3 abs,
     BASELINE.md §4), the Hungarian assignments of the 10 heads
     (optimal under the oracle's fp32 costs to 1e-4 / 2e-2 of the optimal cost: with 100 untrained queries some optima are
-    near-ties that re-association noise — let alone bf16 — can flip), and in fp32 a set of parameter gradients."""
-    from partdistillation_amd.config import setup_cfg
+    near-ties that re-association noise — let alone bf16 — can flip), in fp32 a set of parameter gradients from the stem to the last
+    decoder layer, and under bf16 autocast — the benchmarked kernels: pd_igemm_bf16 forward / input gradient, conv_wgrad_bf16_tr —
+    four backbone filter gradients against the ORACLE's fp32 gradients."""
     from partdistillation_amd.engine.synthetic import make_batch
-    from partdistillation_amd.engine.trainer import TrainStep
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cfg = setup_cfg(os.path.join(root, "partdistillation_amd", "configs", "proposal_learning", "r50_mask2former.yaml"),
-                    ["INPUT.IMAGE_SIZE", "1024", "SOLVER.AMP.ENABLED", str(amp), "SOLVER.WARMUP_ITERS", "0"])
-    torch.manual_seed(0)
-    step = TrainStep(cfg)
+    cfg, step = _full_size_step(amp)
     # two real optimisation steps first: at the reference's initialisation the sampling offsets are EXACTLY the integer grid
     # of ms_deform_attn.py:70-84 (zero weight, grid bias), every sample sits exactly on a pixel centre and the gradient
     # w.r.t. the sampling location is a one-sided derivative whose side is decided by the last bit of loc * W - 0.5 — the
@@ -852,35 +881,139 @@ def test_config2_full_size_step_vs_oracle(amp):
     losses = step(batch)
     step.optimizer.step = opt_step
     assert len(losses) == 30
-    osd = {k: v.requires_grad_(v.is_floating_point() and not amp) for k, v in sd.items()}
+    if amp:
+        from partdistillation_amd.modeling.backbone import resnet_core
+        assert resnet_core.ENABLED and step.model.backbone.stem.conv1.weight.dtype == torch.bfloat16     # the benchmarked kernels ran
+    osd = {k: v.requires_grad_(v.is_floating_point()) for k, v in sd.items()}
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    olosses, differ, gap = _oracle_with_product_matches(losses, osd, batch, 31337, 1, 10, [4], grad=not amp)
-    rel = 2e-2 if amp else 3e-4         # fp32: 3 x the measured 9.3e-5 (profiles/r04_parity.json; BASELINE.md 4 proposes 1e-4)
+    olosses, differ, gap = _oracle_with_product_matches(losses, osd, batch, 31337, 1, 10, [4], grad=True)
     dev = {k: abs(float(losses[k]) - float(olosses[k])) / max(abs(float(olosses[k])), 1e-12) for k in olosses}
     print(f"config 2 full size, amp={amp}: max rel loss dev {max(dev.values()):.2e}; {differ} of 10 assignments differ from the "
           f"oracle's optimum, worst relative cost gap {gap:.1e}")
     rec = {"max_rel_loss_dev": max(dev.values()), "worst_term": max(dev, key=dev.get), "assignments_differing": differ, "assignment_cost_gap_rel": gap,
-           "tolerance_rel": rel, "tolerance_abs": 2e-3 if amp else 1e-4, "tolerance_cost_gap": 2e-2 if amp else 1e-4,
+           "tolerance_rel": 2e-2 if amp else FP32_LOSS_REL, "tolerance_abs": 2e-3 if amp else FP32_LOSS_ABS, "tolerance_cost_gap": 2e-2 if amp else 1e-4,
            "max_abs_loss_dev": max(abs(float(losses[k]) - float(olosses[k])) for k in olosses), "precision": "bf16 autocast" if amp else "fp32"}
     _record_parity(f"config2_full_size_{'bf16' if amp else 'fp32'}", **rec)
     assert gap <= (2e-2 if amp else 1e-4)
-    for k in olosses:
-        assert abs(float(losses[k]) - float(olosses[k])) <= rel * abs(float(olosses[k])) + (2e-3 if amp else 1e-4), (k, float(losses[k]), float(olosses[k]))
-    if not amp:
+    if amp:
+        for k in olosses:
+            assert abs(float(losses[k]) - float(olosses[k])) <= 2e-2 * abs(float(olosses[k])) + 2e-3, (k, float(losses[k]), float(olosses[k]))
+    else:
+        rec["terms_with_swapped_points"] = _check_fp32_losses(losses, olosses)
+        rec["tolerance_rel_swapped_points"] = FP32_LOSS_REL_SWAPPED
+    sum(olosses.values()).backward()
+    named = dict(step.model.named_parameters())
+    worst = {}
+    keys = BACKBONE_GRADS if amp else BACKBONE_GRADS + [
+        "sem_seg_head.pixel_decoder.input_proj.2.0.weight",
+        "sem_seg_head.pixel_decoder.transformer.encoder.layers.5.self_attn.sampling_offsets.weight",
+        "sem_seg_head.pixel_decoder.transformer.encoder.layers.0.linear1.weight", "sem_seg_head.pixel_decoder.layer_1.weight",
+        "sem_seg_head.pixel_decoder.mask_features.weight", "sem_seg_head.predictor.query_feat.weight",
+        "sem_seg_head.predictor.transformer_cross_attention_layers.8.multihead_attn.in_proj_weight",
+        "sem_seg_head.predictor.mask_embed.layers.2.weight"]
+    for k in keys:
+        a, b = named[k].grad.float().cpu(), osd[k].grad
+        worst[k] = ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+    tol = GRAD_TOL_BF16_BACKBONE if amp else GRAD_TOL_FP32_FULL
+    print(f"config 2 full size amp={amp} gradient dev vs the oracle's fp32 gradients (of tensor max):", {k.split(".", 1)[-1]: f"{v:.1e}" for k, v in worst.items()})
+    _record_parity(f"config2_full_size_{'bf16' if amp else 'fp32'}", **rec, gradient_dev_of_tensor_max=worst, tolerance_gradient=tol)
+    assert max(worst.values()) < tol, worst
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_config2_full_size_batch_of_two_vs_oracle(amp):
+    """the BENCHMARKED shape — two 1024 x 1024 images per step (bench.py, BASELINE config 2) — against the CPU oracle on the same weights,
+    batch and random points: 30 weighted losses, each a mean over BOTH images' matched masks (num_masks = 8), the 20 assignment problems
+    judged by their cost gap.  Tolerances as the one-image test."""
+    from partdistillation_amd.engine.synthetic import make_batch
+    cfg, step = _full_size_step(amp)
+    for i in range(2):
+        step(make_batch(2, 1024, seed=910 + i, device=DEV))
+    sd = {k: v.detach().float().cpu().clone() for k, v in step.state_dict()["model"].items()}
+    batch = make_batch(2, 1024, seed=2234, device=DEV)
+    step.model.criterion.rand = C.ReplayRand(41337)
+    opt_step, step.optimizer.step = step.optimizer.step, (lambda: None)
+    losses = step(batch)
+    step.optimizer.step = opt_step
+    ns = [int(b["instances"].gt_masks.tensor.shape[0]) for b in batch]
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    olosses, differ, gap = _oracle_with_product_matches(losses, sd, batch, 41337, 2, 10, ns)
+    dev = {k: abs(float(losses[k]) - float(olosses[k])) / max(abs(float(olosses[k])), 1e-12) for k in olosses}
+    print(f"config 2 full size B = 2, amp={amp}: max rel loss dev {max(dev.values()):.2e} ({max(dev, key=dev.get)}); {differ} of 20 assignments differ, "
+          f"worst relative cost gap {gap:.1e}")
+    rec = dict(max_rel_loss_dev=max(dev.values()), worst_term=max(dev, key=dev.get), assignments_differing=differ, assignment_cost_gap_rel=gap,
+               batch=2, precision="bf16 autocast" if amp else "fp32", tolerance_rel=2e-2 if amp else FP32_LOSS_REL,
+               max_abs_loss_dev=max(abs(float(losses[k]) - float(olosses[k])) for k in olosses))
+    assert len(losses) == 30 and gap <= (2e-2 if amp else 1e-4)
+    if amp:
+        for k in olosses:
+            assert abs(float(losses[k]) - float(olosses[k])) <= 2e-2 * abs(float(olosses[k])) + 2e-3, (k, float(losses[k]), float(olosses[k]))
+    else:
+        rec["terms_with_swapped_points"] = _check_fp32_losses(losses, olosses)
+    _record_parity(f"config2_full_size_b2_{'bf16' if amp else 'fp32'}", **rec)
+
+
+CURVE_TOL = {False: (2e-3, 2e-4, 2e-2), True: (3e-2, 3e-3, 1e-1)}     # (loss rel, loss abs, gradient norm rel) per precision; see the records
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_config2_full_size_loss_curve_vs_oracle(amp):
+    """north-star "matching loss curves vs. reference" at FULL size: five complete optimisation steps (forward, Hungarian criterion,
+    backward, full-model clipping, AdamW) of config 2 — one 1024 x 1024 image per step, fp32 and the benchmarked bf16 autocast — next to
+    oracle/step_ref.py stepping ITS OWN copy of the weights on the CPU (fp32, oracle AdamW) from the same start, batches and replayed
+    random points.  The two trajectories are only coupled through the Hungarian assignment (the oracle evaluates the product's, judged
+    by its cost gap under the oracle's costs, as in the one-step tests: a flipped near-tie would otherwise fork the curves).  Compared per
+    step: the 30 weighted losses and the clipped global gradient norm; after the last step the parameters."""
+    from partdistillation_amd.engine.synthetic import make_batch
+    cfg, step = _full_size_step(amp)
+    for i in range(2):                                                                   # leave the degenerate initialisation
+        step(make_batch(1, 1024, seed=900 + i, device=DEV))
+    with torch.no_grad():                                                                # a fresh optimizer on both sides
+        for t in list(step.optimizer.exp_avg) + list(step.optimizer.exp_avg_sq):
+            t.zero_()
+    step.optimizer.steps = 0
+    osd = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in step.state_dict()["model"].items()}
+    names, lrs, wds = [], [], []
+    for g in step.optimizer.flat.groups:
+        for n in g.names:
+            names.append(n), lrs.append(g.hyper["lr"]), wds.append(g.hyper["weight_decay"])
+    params = [osd[n] for n in names]
+    state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    rel, ab, nrel = CURVE_TOL[amp]
+    curve = []
+    for it in range(1, 6):
+        batch = make_batch(1, 1024, seed=3000 + it, device=DEV)
+        step.model.criterion.rand = C.ReplayRand(8000 + it)
+        losses = step(batch)
+        got = {k: float(v) for k, v in losses.items()}
+        norm = float(step.optimizer.grad_norm())
+        n = int(batch[0]["instances"].gt_masks.tensor.shape[0])
+        for p in params:
+            p.grad = None
+        olosses, differ, gap = _oracle_with_product_matches(losses, osd, batch, 8000 + it, 1, 10, [n], grad=True)
         sum(olosses.values()).backward()
-        named = dict(step.model.named_parameters())
-        worst = {}
-        for k in ["backbone.stem.conv1.weight", "backbone.res4.3.conv2.weight", "sem_seg_head.pixel_decoder.input_proj.2.0.weight",
-                  "sem_seg_head.pixel_decoder.transformer.encoder.layers.5.self_attn.sampling_offsets.weight",
-                  "sem_seg_head.pixel_decoder.transformer.encoder.layers.0.linear1.weight", "sem_seg_head.pixel_decoder.layer_1.weight",
-                  "sem_seg_head.pixel_decoder.mask_features.weight", "sem_seg_head.predictor.query_feat.weight",
-                  "sem_seg_head.predictor.transformer_cross_attention_layers.8.multihead_attn.in_proj_weight",
-                  "sem_seg_head.predictor.mask_embed.layers.2.weight"]:
-            a, b = named[k].grad.float().cpu(), osd[k].grad
-            worst[k] = ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
-        print("config 2 full size fp32 gradient dev (of tensor max):", {k.split(".", 2)[-1]: f"{v:.1e}" for k, v in worst.items()})
-        _record_parity("config2_full_size_fp32", **rec, gradient_dev_of_tensor_max=worst, tolerance_gradient=GRAD_TOL_FP32_FULL)
-        assert max(worst.values()) < GRAD_TOL_FP32_FULL, worst
+        grads = [p.grad for p in params]
+        with torch.no_grad():
+            total = R.clipped_adamw_step([p.data for p in params], grads, state, lrs=lrs, wds=wds, clip=cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE, step=it)
+        dev = {k: abs(got[k] - float(olosses[k])) / max(abs(float(olosses[k])), 1e-12) for k in olosses}
+        curve.append({"step": it, "total_product": sum(got.values()), "total_oracle": float(sum(olosses.values())), "max_rel_loss_dev": max(dev.values()),
+                      "worst_term": max(dev, key=dev.get), "grad_norm_product": norm, "grad_norm_oracle": float(total),
+                      "assignments_differing": differ, "assignment_cost_gap_rel": gap})
+        print(f"full-size curve amp={amp} step {it}: total {curve[-1]['total_product']:.4f} vs {curve[-1]['total_oracle']:.4f}, max rel dev "
+              f"{max(dev.values()):.2e} ({max(dev, key=dev.get)}), grad norm {norm:.4f} vs {float(total):.4f}, cost gap {gap:.1e}")
+        _record_parity(f"config2_full_size_curve_{'bf16' if amp else 'fp32'}", curve=curve, tolerance_rel=rel, tolerance_abs=ab, tolerance_grad_norm_rel=nrel,
+                       precision="bf16 autocast" if amp else "fp32")
+        assert gap <= (2e-2 if amp else 1e-4)
+        for k in olosses:
+            assert abs(got[k] - float(olosses[k])) <= rel * abs(float(olosses[k])) + ab, (it, k, got[k], float(olosses[k]))
+        assert abs(norm - float(total)) <= nrel * float(total), (it, norm, float(total))
+    master = step.optimizer.flat.master_state()
+    worst = max(((master[n].detach().float().cpu() - osd[n].detach()).abs().max() / osd[n].detach().abs().max().clamp_min(1e-6)).item() for n in names)
+    print(f"full-size curve amp={amp}: parameters after 5 steps within {worst:.2e} of their scale")
+    _record_parity(f"config2_full_size_curve_{'bf16' if amp else 'fp32'}", curve=curve, params_dev_of_scale_after_5_steps=worst, tolerance_rel=rel,
+                   tolerance_abs=ab, tolerance_grad_norm_rel=nrel, precision="bf16 autocast" if amp else "fp32")
+    assert worst < (5e-2 if amp else 2e-2), worst
 
 
 def test_base_pixel_decoder_gpu_vs_reference_golden(golden):
@@ -1042,3 +1175,89 @@ def test_swin_w12_fp8_gemms_vs_reference_golden(golden, monkeypatch):
         worst["grad " + k] = _scaled_err((x.grad if k == "x" else named[k].grad).float(), d)
     print("swin_w12 fp8", {k: f"{v:.2e}" for k, v in worst.items()})
     assert all(v < (2e-1 if k.startswith("grad") else 1.2e-1) for k, v in worst.items()), worst
+
+
+# ----------------------------------------------------------------------------- persistent-arena gradients outside engine/flat_params.py
+def test_gradient_accumulation_over_micro_batches_with_recorded_regions():
+    """the recorded backward regions (encoder / decoder cores) and the fused ResNet body hand autograd parameter gradients that live
+    in their persistent arenas; AccumulateGrad adopts them as `.grad` without a copy.  A caller that keeps `.grad` across backward
+    passes — gradient accumulation over micro-batches, a stock optimizer with zero_grad(set_to_none=False) — must still get g1 + g2
+    (not 2 * g2 from the rewritten arena): cmdbuf.unalias_grads moves a surviving `.grad` to its own storage before the replay."""
+    from partdistillation_amd import cmdbuf
+    from partdistillation_amd.engine.synthetic import make_batch
+    from partdistillation_amd.engine.trainer import TrainStep
+    from partdistillation_amd.modeling.backbone import resnet_core
+    assert cmdbuf.ENABLED and resnet_core.ENABLED
+    cfg = _toy_cfg(["SOLVER.AMP.ENABLED", "True", "SOLVER.WARMUP_ITERS", "0"])
+    torch.manual_seed(0)
+    step = TrainStep(cfg)
+    model = step.model
+    batches = [make_batch(2, 128, n_parts=3, seed=70 + i, device=DEV) for i in range(2)]
+    params = dict(model.named_parameters())
+
+    def fwd_bwd(b, seed):
+        model.criterion.rand = C.ReplayRand(seed)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ld = model(b)
+            total = getattr(ld, "total", None)
+            total = sum(ld.values()) if total is None else total
+        from partdistillation_amd.functions.conv_bf16 import deferred_wgrads
+        with deferred_wgrads():
+            total.backward()
+
+    singles = []
+    for i, b in enumerate(batches):                                   # g1 and g2 on their own (the first call records, the second replays)
+        step.optimizer.zero_grad()
+        fwd_bwd(b, 900 + i)
+        singles.append({k: p.grad.detach().float().clone() for k, p in params.items() if p.grad is not None})
+    step.optimizer.zero_grad()
+    for i, b in enumerate(batches):                                   # accumulated: `.grad` survives the second backward
+        fwd_bwd(b, 900 + i)
+    torch.cuda.synchronize()
+    checked = 0
+    for k, p in params.items():
+        if k not in singles[0] or k not in singles[1]:
+            continue
+        want = singles[0][k] + singles[1][k]
+        scale = want.abs().max().clamp_min(1e-12)
+        err = ((p.grad.float() - want).abs().max() / scale).item()
+        twice = ((p.grad.float() - 2 * singles[1][k]).abs().max() / scale).item()
+        # bf16 gradients: two roundings + reordered atomics; the aliasing bug gives 2 * g2, which is far from g1 + g2
+        assert err < 3e-2, (k, err, twice)
+        checked += 1
+    assert checked > 100
+    # and with zero_grad(set_to_none=False)-style in-place clearing: `.grad` tensors that still alias an arena are moved before the replay
+    for p in params.values():
+        if p.grad is not None:
+            p.grad.zero_()
+    fwd_bwd(batches[1], 901)
+    torch.cuda.synchronize()
+    for k in ("backbone.res2.0.conv1.weight", "sem_seg_head.pixel_decoder.transformer.encoder.layers.0.linear1.weight",
+              "sem_seg_head.predictor.transformer_ffn_layers.0.linear1.weight"):
+        want = singles[1][k]
+        assert ((params[k].grad.float() - want).abs().max() / want.abs().max().clamp_min(1e-12)).item() < 3e-2, k
+
+
+def test_plan_and_recording_caches_are_bounded():
+    """one fused-ResNet plan / encoder recording pair per input shape owns persistent arenas; training with random crops or inference on
+    arbitrary sizes must not accumulate them: the caches are LRU-bounded and a forward recording's eviction drops its backward twin."""
+    from partdistillation_amd import cmdbuf
+    from partdistillation_amd.engine.synthetic import make_batch
+    from partdistillation_amd.engine.trainer import TrainStep
+    from partdistillation_amd.functions import encoder_core
+    from partdistillation_amd.modeling.backbone import resnet_core
+    lru = cmdbuf.LRU(2)
+    for i in range(5):
+        lru.put(i, i)
+    assert list(lru) == [3, 4] and lru.get(3) == 3 and list(lru) == [4, 3]
+    cfg = _toy_cfg(["SOLVER.AMP.ENABLED", "True", "SOLVER.WARMUP_ITERS", "0"])
+    torch.manual_seed(0)
+    step = TrainStep(cfg)
+    for size in (64, 96, 128, 160, 192, 224, 256, 288):
+        step(make_batch(1, size, n_parts=2, seed=size, device=DEV))
+    torch.cuda.synchronize()
+    assert len(resnet_core._PLANS) <= resnet_core._PLANS.cap and len(encoder_core._RECS) <= encoder_core._RECS.cap
+    fwd_ids = {id(v) for k, v in encoder_core._RECS.items() if k[0] == "fwd"}
+    assert all(k[1] in fwd_ids for k in encoder_core._RECS if k[0] == "bwd")              # no backward recording outlives its forward one
+    ld = step(make_batch(1, 64, n_parts=2, seed=64, device=DEV))                           # an evicted shape is simply recorded again
+    assert all(float(v) == float(v) for v in ld.values())
