@@ -324,8 +324,9 @@ def loss_labels(logits, targets, indices, num_classes, empty_weight):
     return F.cross_entropy(logits.transpose(1, 2), tcls, empty_weight)
 
 
-def loss_masks(pred_masks, targets, indices, num_masks, rand, num_points, oversample, importance):
-    """criterion.py:147-207 (+ nested_tensor padding utils/misc.py:52-74)."""
+def loss_masks(pred_masks, targets, indices, num_masks, rand, num_points, oversample, importance, points_override=None, points_out=None):
+    """criterion.py:147-207 (+ nested_tensor padding utils/misc.py:52-74).  Test hooks: ``points_out`` (list) receives the sample
+    points this head chose; ``points_override`` ([N, P, 2]) replaces them for the losses — the sampler still runs (same random draws)."""
     bidx = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(indices)])
     sidx = torch.cat([s for s, _ in indices])
     tidx = torch.cat([j for _, j in indices])
@@ -340,6 +341,10 @@ def loss_masks(pred_masks, targets, indices, num_masks, rand, num_points, oversa
     tgt = padded.to(src)[bidx, tidx][:, None]
     with torch.no_grad():
         coords = uncertain_points(src, rand, num_points, oversample, importance)
+        if points_out is not None:
+            points_out.append(coords)
+        if points_override is not None:
+            coords = points_override.to(coords)
         labels = point_sample(tgt, coords).squeeze(1)
     logits = point_sample(src, coords).squeeze(1)
     bce = F.binary_cross_entropy_with_logits(logits, labels, reduction="none").mean(1).sum() / num_masks
@@ -350,12 +355,13 @@ def loss_masks(pred_masks, targets, indices, num_masks, rand, num_points, oversa
 
 def set_criterion(outputs, targets, rand, *, num_classes, eos_coef=0.1, w_class=2.0, w_mask=5.0, w_dice=5.0,
                   num_points=12544, oversample=3.0, importance=0.75, world_size=1, num_masks_total=None,
-                  match_points=None, return_indices=False, indices_override=None, costs=None):
+                  match_points=None, return_indices=False, indices_override=None, costs=None, points_override=None, points_out=None):
     """SetCriterion.forward, criterion.py:235-270: match + CE + point BCE/dice
     for the final output and each aux output.  Unweighted losses (30 keys).
     Test hooks: ``costs`` (list) receives the per-(head, image) cost matrices; ``indices_override`` (list per head of
     per-image (rows, cols)) replaces the assignment the losses are computed with — the matcher still runs (same random
-    draws, its own optimum is what ``return_indices`` hands back)."""
+    draws, its own optimum is what ``return_indices`` hands back); ``points_override`` / ``points_out`` (lists per head) do the
+    same for the importance-sampled loss points (see loss_masks)."""
     empty_weight = torch.ones(num_classes + 1)
     empty_weight[-1] = eos_coef
     nm = float(sum(len(t["labels"]) for t in targets)) if num_masks_total is None else float(num_masks_total)
@@ -372,7 +378,8 @@ def set_criterion(outputs, targets, rand, *, num_classes, eos_coef=0.1, w_class=
         if indices_override is not None:
             idx = indices_override[li]
         losses["loss_ce" + suffix] = loss_labels(out["pred_logits"], targets, idx, num_classes, empty_weight)
-        bce, dice = loss_masks(out["pred_masks"], targets, idx, num_masks, rand, num_points, oversample, importance)
+        bce, dice = loss_masks(out["pred_masks"], targets, idx, num_masks, rand, num_points, oversample, importance,
+                               points_override=None if points_override is None else points_override[li], points_out=points_out)
         losses["loss_mask" + suffix], losses["loss_dice" + suffix] = bce, dice
     return (losses, all_idx) if return_indices else losses
 
@@ -453,7 +460,7 @@ PIXEL_STD = (58.395, 57.120, 57.375)
 def proposal_model_losses(sd, batched_inputs, rand, *, backbone="r50", num_classes=1, dec_layers=10, nheads=8,
                           enc_layers=6, num_points=12544, oversample=3.0, importance=0.75, size_div=32,
                           world_size=1, part=None, backbone_fn=None, match_points=None, return_indices=False,
-                          indices_override=None, costs=None):
+                          indices_override=None, costs=None, points_override=None, points_out=None):
     """ProposalModel.forward train branch, proposal_model.py:177-204 (and
     PartDistillationModel.forward :197-226 when ``part=num_part_classes``):
     normalise -> pad -> backbone -> head -> criterion -> weight."""
@@ -473,7 +480,7 @@ def proposal_model_losses(sd, batched_inputs, rand, *, backbone="r50", num_class
     losses, idx = set_criterion(out, targets, rand, num_classes=num_classes if part is None else part,
                                 num_points=num_points, oversample=oversample, importance=importance,
                                 world_size=world_size, match_points=match_points, return_indices=True,
-                                indices_override=indices_override, costs=costs)
+                                indices_override=indices_override, costs=costs, points_override=points_override, points_out=points_out)
     wd = weight_dict(dec_layers)
     losses = {k: v * wd[k] for k, v in losses.items() if k in wd}
     return (losses, idx) if return_indices else losses

@@ -35,7 +35,7 @@ _PACKET_CAPTURE_AT_IMPORT = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")
 
 def _detached(loss_dict):
     out = type(loss_dict)({k: v.detach() for k, v in loss_dict.items()})
-    for name in ("vectors", "total", "indices"):
+    for name in ("vectors", "total", "indices", "points"):
         v = getattr(loss_dict, name, None)
         if isinstance(v, torch.Tensor):
             v = v.detach()

@@ -28,6 +28,8 @@ class LossDict(dict):
     """dict of per-head losses that also carries their stacked vectors (one autograd node per loss type)."""
     vectors = None
     total = None
+    indices = None
+    points = None
 
 
 class _TokensTimesRows(torch.autograd.Function):
@@ -296,6 +298,7 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
         for i in range(H - 1):
             out[f"{name}_{i}"] = parts[i + 1]
     out.indices = (rows, cols)
+    out.points = coords.detach()          # [H * N_h, P, 2], h-major pair order: the loss points this step chose (parity tests replay them in the oracle)
     return out
 
 

@@ -129,6 +129,7 @@ class _MaskFormerTrainBase(nn.Module):
                     out[k] = part
         out.total = total
         out.indices = getattr(losses, "indices", None)                # matched (query, target) pairs of every (image, head)
+        out.points = getattr(losses, "points", None)                  # the importance-sampled loss points of every matched pair
         return out
 
 

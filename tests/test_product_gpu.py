@@ -764,22 +764,32 @@ def _oracle_batch(batch):
              "gt_object_class": int(b.get("gt_object_class", 0))} for b in batch]
 
 
-def _oracle_with_product_matches(losses, osd, batch, seed, B, H, ns, grad=False, **kw):
+def _oracle_with_product_matches(losses, osd, batch, seed, B, H, ns, grad=False, product_points=False, **kw):
     """run the CPU oracle on the same weights / batch / random points.  The oracle's matcher runs (its optimum and its
     fp32 cost matrices come back), but its LOSSES are evaluated with the assignment the product chose, so the loss
     comparison measures arithmetic, not the discrete outcome of a near-tie in the Hungarian problem (BASELINE.md §4:
     "indices exact given identical cost matrix").  How far the product's assignment is from the oracle's optimum is
     reported separately as the relative COST GAP under the oracle's own costs (0 when the assignments coincide).
-    -> (oracle losses, number of differing (head, image) assignments, worst relative cost gap)"""
+    product_points=True does the same for the importance-sampled loss points (detectron2's sampler keeps the 9 408 least certain of
+    37 632 candidates per mask: under bf16 the two sides rank slightly different logits, and a different SAMPLE of points is sampling
+    noise in the gradients, not arithmetic): the oracle's sampler runs, the fraction of its points the product did not choose is
+    returned as a fourth value, and the oracle's losses are evaluated at the product's points.
+    -> (oracle losses, number of differing (head, image) assignments, worst relative cost gap[, fraction of differing points])"""
     rows, cols = (t.cpu().long() for t in losses.indices)
     override = []
     for h in range(H):
         d = H - 1 if h == 0 else h - 1
         override.append([(rows[b * H + d, :ns[b]], cols[b * H + d, :ns[b]]) for b in range(B)])
     costs = []
+    points, own_points = None, []
+    if product_points:
+        pts = losses.points.float().cpu()
+        n_h = pts.shape[0] // H
+        points = [pts[h * n_h:(h + 1) * n_h] for h in range(H)]
     with torch.set_grad_enabled(grad):
         olosses, oidx = R.proposal_model_losses(osd, _oracle_batch(batch), C.ReplayRand(seed), return_indices=True,
-                                                indices_override=override, costs=costs, **kw)
+                                                indices_override=override, costs=costs, points_override=points,
+                                                points_out=own_points if product_points else None, **kw)
     differ, gap = 0, 0.0
     for h in range(H):
         for b in range(B):
@@ -789,6 +799,15 @@ def _oracle_with_product_matches(losses, osd, batch, seed, B, H, ns, grad=False,
             assert sorted(pc.tolist()) == sorted(ocol.tolist()) and len(set(pr.tolist())) == len(pr)      # a valid assignment
             differ += set(zip(pr.tolist(), pc.tolist())) != set(zip(orow.tolist(), ocol.tolist()))
             gap = max(gap, (got - best) / max(abs(best), 1e-12))
+    if product_points:
+        # both sides draw the same candidates: a chosen point is identified by its coordinates
+        nd, nt = 0, 0
+        for h in range(H):
+            for a, b in zip(points[h], own_points[h]):
+                sa = {tuple(x) for x in a.tolist()}
+                nd += sum(tuple(x) not in sa for x in b.tolist())
+                nt += b.shape[0]
+        return olosses, differ, gap, nd / max(nt, 1)
     return olosses, differ, gap
 
 
@@ -886,13 +905,18 @@ def test_config2_full_size_step_vs_oracle(amp):
         assert resnet_core.ENABLED and step.model.backbone.stem.conv1.weight.dtype == torch.bfloat16     # the benchmarked kernels ran
     osd = {k: v.requires_grad_(v.is_floating_point()) for k, v in sd.items()}
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    olosses, differ, gap = _oracle_with_product_matches(losses, osd, batch, 31337, 1, 10, [4], grad=True)
+    # bf16: the oracle's losses at the PRODUCT's sample points (its own sampler runs too: the fraction of differing points is recorded);
+    # fp32: no override — identical point sets are part of what the fp32 leg verifies (_check_fp32_losses)
+    res = _oracle_with_product_matches(losses, osd, batch, 31337, 1, 10, [4], grad=True, product_points=amp)
+    olosses, differ, gap = res[:3]
+    pts_differ = res[3] if amp else 0.0
     dev = {k: abs(float(losses[k]) - float(olosses[k])) / max(abs(float(olosses[k])), 1e-12) for k in olosses}
     print(f"config 2 full size, amp={amp}: max rel loss dev {max(dev.values()):.2e}; {differ} of 10 assignments differ from the "
-          f"oracle's optimum, worst relative cost gap {gap:.1e}")
+          f"oracle's optimum, worst relative cost gap {gap:.1e}; {pts_differ:.2%} of the oracle's importance-sampled points not among the product's")
     rec = {"max_rel_loss_dev": max(dev.values()), "worst_term": max(dev, key=dev.get), "assignments_differing": differ, "assignment_cost_gap_rel": gap,
            "tolerance_rel": 2e-2 if amp else FP32_LOSS_REL, "tolerance_abs": 2e-3 if amp else FP32_LOSS_ABS, "tolerance_cost_gap": 2e-2 if amp else 1e-4,
-           "max_abs_loss_dev": max(abs(float(losses[k]) - float(olosses[k])) for k in olosses), "precision": "bf16 autocast" if amp else "fp32"}
+           "max_abs_loss_dev": max(abs(float(losses[k]) - float(olosses[k])) for k in olosses), "precision": "bf16 autocast" if amp else "fp32",
+           "sample_points_differing_fraction": pts_differ}
     _record_parity(f"config2_full_size_{'bf16' if amp else 'fp32'}", **rec)
     assert gap <= (2e-2 if amp else 1e-4)
     if amp:
@@ -911,12 +935,15 @@ def test_config2_full_size_step_vs_oracle(amp):
         "sem_seg_head.pixel_decoder.mask_features.weight", "sem_seg_head.predictor.query_feat.weight",
         "sem_seg_head.predictor.transformer_cross_attention_layers.8.multihead_attn.in_proj_weight",
         "sem_seg_head.predictor.mask_embed.layers.2.weight"]
+    rel_l2 = {}
     for k in keys:
         a, b = named[k].grad.float().cpu(), osd[k].grad
         worst[k] = ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+        rel_l2[k] = ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
     tol = GRAD_TOL_BF16_BACKBONE if amp else GRAD_TOL_FP32_FULL
-    print(f"config 2 full size amp={amp} gradient dev vs the oracle's fp32 gradients (of tensor max):", {k.split(".", 1)[-1]: f"{v:.1e}" for k, v in worst.items()})
-    _record_parity(f"config2_full_size_{'bf16' if amp else 'fp32'}", **rec, gradient_dev_of_tensor_max=worst, tolerance_gradient=tol)
+    print(f"config 2 full size amp={amp} gradient dev vs the oracle's fp32 gradients (of tensor max):", {k.split(".", 1)[-1]: f"{v:.1e}" for k, v in worst.items()},
+          "relative L2:", {k.split(".", 1)[-1]: f"{v:.1e}" for k, v in rel_l2.items()})
+    _record_parity(f"config2_full_size_{'bf16' if amp else 'fp32'}", **rec, gradient_dev_of_tensor_max=worst, gradient_rel_l2=rel_l2, tolerance_gradient=tol)
     assert max(worst.values()) < tol, worst
 
 
