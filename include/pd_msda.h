@@ -58,7 +58,6 @@ int pd_msda_forward(const void *value, const int64_t *spatial_shapes, const int6
                     int batch, int spatial_size, int num_heads, int channels, int num_levels,
                     int num_query, int num_point, int im2col_step, int dtype, void *stream);
 
-/* replaces MSDA.ms_deform_attn_backward (vision.cpp:21, ms_deform_attn_cuda.cu:89-159) */
 /* pd_msda_forward that also leaves the absolute maximum of every output row (all heads of a query) in row_amax[batch * num_query]
  * (ZERO-FILLED by the caller; atomic max) — the row-scaling input of pd_gemm_tn_f16x2 (pd_gemm.h) for the output projection that
  * reads the result.  fp32, channels = 32, 3 levels, 4 points only (the kernel of the hot path); not part of the reference's operator. */
@@ -66,11 +65,41 @@ int pd_msda_forward_amax(const void *value, const int64_t *spatial_shapes, const
                          const void *attn_weight, void *output, float *row_amax, int batch, int spatial_size, int num_heads, int channels,
                          int num_levels, int num_query, int num_point, int im2col_step, int dtype, void *stream);
 
+/* replaces MSDA.ms_deform_attn_backward (vision.cpp:21, ms_deform_attn_cuda.cu:89-159) */
 int pd_msda_backward(const void *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
                      const void *sampling_loc, const void *attn_weight, const void *grad_output,
                      void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
                      int batch, int spatial_size, int num_heads, int channels, int num_levels,
                      int num_query, int num_point, int im2col_step, int dtype, void *stream);
+
+/* ---- the module path's fused form (round 5; NOT part of the reference's operator ABI, which is the two functions above) ----
+ * MSDeformAttn.forward (reference ops/modules/ms_deform_attn.py:86-131) feeds the operator
+ *   attention_weights = softmax(Linear_aw(query)) over the L P samples of a head      (:110-111)
+ *   sampling_locations = reference_points + Linear_so(query) / (W_l, H_l)              (:108, :114-117)
+ * The fused pair takes the RAW output of those two projections — one matrix `oa` [batch * num_query, ld_oa] fp32 with the
+ * sampling offsets in columns [0, 2 M L P) ordered (head, level, point, xy) and the attention logits in columns [2 M L P, 3 M L P)
+ * ordered (head, level, point), i.e. exactly the two Linear outputs side by side — and the 2-d reference points
+ * `ref` [batch * num_query, L, 2], and performs both steps in the kernels' registers: no sampling_loc / attn_weight tensors, no
+ * separate softmax / location kernels in either direction.
+ *   forward : output [batch, num_query, M * 32]; stats [batch * num_query * M, 2] <- {max logit, 1 / sum exp} of every (query, head)
+ *             (the backward re-forms a probability with one exponential); row_amax (optional, ZERO-FILLED by the caller) as
+ *             pd_msda_forward_amax.
+ *   backward: grad_value [batch, S, M, 32] (zero-filled by the library, as pd_msda_backward) and d_oa [batch * num_query, ld_doa] =
+ *             the gradient of `oa` in the same column layout (every element written once): d offset = grad_sampling_loc / (W, H),
+ *             d logit = a (g - sum_j a_j g_j) (sum_j a_j g_j = <grad_output, fwd_output>; the kernel sums its own per-level partials and does not read fwd_output);
+ *             d_oa_amax (optional; the library zero-fills it) receives max |.| of every row of d_oa; scratch = batch * num_query * M * L
+ *             floats of working memory (contents undefined afterwards).
+ * Served geometry (pd_msda_fused_supported): fp32, 32 channels per head, 3 levels, 4 points, num_query == spatial_size (the
+ * pixel decoder's encoder self-attention).  Other geometries: form loc / attn (pd_msda_prep_fwd, pd_rowwise.h) and call the
+ * operator above.  Semantics of the sampling itself: ms_deform_im2col_cuda.cuh:38-164, 242-304, unchanged. */
+int pd_msda_fused_supported(int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query, int num_point);
+int pd_msda_fused_forward(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index, const float *oa, int ld_oa,
+                          const float *ref, float *output, float *stats, float *row_amax, int batch, int spatial_size, int num_heads,
+                          int channels, int num_levels, int num_query, int num_point, void *stream);
+int pd_msda_fused_backward(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index, const float *oa, int ld_oa,
+                           const float *ref, const float *stats, const float *fwd_output, const float *grad_output, float *grad_value,
+                           float *d_oa, int ld_doa, float *d_oa_amax, float *scratch, int batch, int spatial_size, int num_heads, int channels,
+                           int num_levels, int num_query, int num_point, void *stream);
 
 /* message of the last error on this thread ("" if none) */
 const char *pd_last_error(void);

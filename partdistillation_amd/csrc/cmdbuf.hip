@@ -126,6 +126,8 @@ const Entry kTable[] = {
   PD_E(pd_msda_backward),
   PD_E(pd_msda_forward),
   PD_E(pd_msda_forward_amax),
+  PD_E(pd_msda_fused_backward),
+  PD_E(pd_msda_fused_forward),
   PD_E(pd_msda_prep_bwd),
   PD_E(pd_msda_prep_bwd_amax),
   PD_E(pd_msda_prep_fwd),

@@ -100,11 +100,21 @@ __device__ __forceinline__ void corner_setup(T h, T w, int H, int W, int stride_
 
 // ----------------------------------------------------------------------------------------- fast forward
 // D == 32, fp32.  256 threads = 32 (b,q,m) triples per block.
-template <int L_, int P_>
+// FUSED (round 5, pd_msda_fused_forward): the kernel reads the RAW output row of the merged sampling_offsets / attention_weights
+// projection instead of materialised sampling locations and attention probabilities — `loc` is then that matrix ([batch * Lq, ld_oa]:
+// columns [0, 2 M L P) the offsets in (head, level, point, xy) order, [2 M L P, 3 M L P) the logits in (head, level, point) order, i.e.
+// ms_deform_attn.py:108-111's two views), `attn` the reference points [batch * Lq, L, 2] — and forms
+//   softmax over the head's L P logits          (ms_deform_attn.py:111)
+//   loc = reference point + offset / (W_l, H_l)  (ms_deform_attn.py:114-117)
+// in registers (every lane of the 8-lane group redundantly: ~80 instructions next to the ~900 of the gathers).  The softmax
+// statistics {max, 1 / sum} of every (query, head) go to `stats` (8 bytes: the backward re-forms a probability with ONE exponential).
+// Saves the prep launch and the 144-byte-per-(query, head) round trip of loc / attn through memory.
+template <int L_, int P_, bool FUSED = false>
 __global__ __launch_bounds__(256, 4) void msda_fwd_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
                                                      const int64_t *__restrict__ lvl_start, const float *__restrict__ loc,
                                                      const float *__restrict__ attn, float *__restrict__ out,
-                                                     int S, int M, int Lq, int total_qm, unsigned *__restrict__ row_amax)
+                                                     int S, int M, int Lq, int total_qm, unsigned *__restrict__ row_amax,
+                                                     int ld_oa = 0, float2 *__restrict__ stats = nullptr)
 {
   const int lb = xcd_chunked_block(blockIdx.x, gridDim.x);
   const int qm = lb * 32 + (threadIdx.x >> 3);
@@ -114,14 +124,56 @@ __global__ __launch_bounds__(256, 4) void msda_fwd_d32(const float *__restrict__
   const int b = (qm / M) / Lq;
   const int stride_w = M * 32;
   static_assert(P_ == 4, "fast path is written for 4 points per level");
-  const float4 *lp4 = reinterpret_cast<const float4 *>(loc + (int64_t)qm * (L_ * P_ * 2));
-  const float4 *ap4 = reinterpret_cast<const float4 *>(attn + (int64_t)qm * (L_ * P_));
+  const float4 *lp4, *ap4 = nullptr;
+  const float *refp = nullptr;
+  float prob[FUSED ? L_ * P_ : 1];
+  if constexpr (FUSED) {
+    const int64_t bq = qm / M;
+    const float *row = loc + bq * ld_oa;
+    lp4 = reinterpret_cast<const float4 *>(row + m * (L_ * P_ * 2));
+    const float4 *lg4 = reinterpret_cast<const float4 *>(row + M * (L_ * P_ * 2) + m * (L_ * P_));
+    refp = attn + bq * (L_ * 2);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < L_; ++i) {
+      const float4 t = lg4[i];
+      prob[4 * i] = t.x; prob[4 * i + 1] = t.y; prob[4 * i + 2] = t.z; prob[4 * i + 3] = t.w;
+      mx = fmaxf(fmaxf(fmaxf(mx, t.x), fmaxf(t.y, t.z)), t.w);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < L_ * P_; ++i) { prob[i] = __expf(prob[i] - mx); sum += prob[i]; }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int i = 0; i < L_ * P_; ++i) prob[i] *= inv;
+    if (stats && sub == 0) stats[qm] = make_float2(mx, inv);
+  } else {
+    lp4 = reinterpret_cast<const float4 *>(loc + (int64_t)qm * (L_ * P_ * 2));
+    ap4 = reinterpret_cast<const float4 *>(attn + (int64_t)qm * (L_ * P_));
+  }
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
   for (int l = 0; l < L_; ++l) {
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
     const float *vbase = value + ((int64_t)b * S + lvl_start[l]) * stride_w + m * 32 + sub * 4;
-    const float4 l01 = lp4[2 * l], l23 = lp4[2 * l + 1], a4 = ap4[l];
+    float4 l01 = lp4[2 * l], l23 = lp4[2 * l + 1], a4;
+    if constexpr (FUSED) {
+      const float rx = refp[2 * l], ry = refp[2 * l + 1];
+      const float fw = (float)W, fh = (float)H;
+      if (((W & (W - 1)) | (H & (H - 1))) == 0) {            // powers of two (the usual pyramid): x * (1 / W) IS x / W, bit for bit
+        const float iw = 1.f / fw, ih = 1.f / fh;
+        l01 = make_float4(rx + l01.x * iw, ry + l01.y * ih, rx + l01.z * iw, ry + l01.w * ih);
+        l23 = make_float4(rx + l23.x * iw, ry + l23.y * ih, rx + l23.z * iw, ry + l23.w * ih);
+      } else {
+        l01 = make_float4(rx + l01.x / fw, ry + l01.y / fh, rx + l01.z / fw, ry + l01.w / fh);
+        l23 = make_float4(rx + l23.x / fw, ry + l23.y / fh, rx + l23.z / fw, ry + l23.w / fh);
+      }
+      // (l is a runtime index: select instead of indexing the register array)
+      a4 = l == 0 ? make_float4(prob[0], prob[1], prob[2], prob[3]) : l == 1 ? make_float4(prob[4 % (L_ * P_)], prob[5 % (L_ * P_)], prob[6 % (L_ * P_)], prob[7 % (L_ * P_)])
+                                                                             : make_float4(prob[8 % (L_ * P_)], prob[9 % (L_ * P_)], prob[10 % (L_ * P_)], prob[11 % (L_ * P_)]);
+    } else {
+      a4 = ap4[l];
+    }
     const float locs[8] = {l01.x, l01.y, l01.z, l01.w, l23.x, l23.y, l23.z, l23.w};
     const float aw[4] = {a4.x, a4.y, a4.z, a4.w};
     float4 v[P_][4];
@@ -491,13 +543,42 @@ __device__ __forceinline__ float group4_sum(float x)
   return x;
 }
 
-template <int ABL, bool HALF = false>
+// FUSED (round 5, pd_msda_fused_backward): the module path's form of this kernel.  `loc` is the RAW projection output the fused forward
+// read ([B S, ld_oa]: offsets | logits, see msda_fwd_d32), `attn` is unused; a unit re-forms its level's sampling locations
+// (reference point + offset / (W, H)) and attention probabilities (exp(logit - max) / sum from the forward's 8-byte statistics) in
+// registers, and instead of grad_sampling_loc / grad_attn_weight it writes the gradient of that projection output directly
+// (`f.d_oa`, same column layout):
+//   d offset = grad_loc / (W, H)                                       (ms_deform_attn.py:114-117 backwards)
+//   d logit  = a (g - sum_j a_j g_j) with sum_j a_j g_j = <grad_out, out>   (softmax backwards; g_j = <grad_out, sampled value j>, and
+//              out = sum_j a_j (sampled value j) is the forward's output row `f.fout`: one 32-channel dot product per unit, no pass
+//              over the other levels' units)
+// plus the rows' absolute maxima for the two-plane GEMM that reads d_oa (atomic max into the zero-filled f.doa_amax).  The
+// msda_prep_bwd launch and the 144-byte-per-(query, head) round trip of grad_loc / grad_attn are gone.
+struct FusedBwd {
+  const float *ref = nullptr;          // [B S, L, 2]
+  const float2 *stats = nullptr;       // [B S M] {max logit, 1 / sum exp}
+  const float *fout = nullptr;         // [B S, M 32] the forward's output
+  float *d_oa = nullptr;               // [B S, ld_doa]
+  unsigned *doa_amax = nullptr;        // [B S] or null
+  float *gdot = nullptr;               // [B S M L] scratch: sum over a level's points of a g per (query, head, level), written and read by the owning workgroup
+  int ld_oa = 0, ld_doa = 0;
+};
+
+__device__ __forceinline__ float group4_max(float x)
+{
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true)));
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true)));
+  return x;
+}
+
+template <int ABL, bool HALF = false, bool FUSED = false>
 __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
                                                             const int64_t *__restrict__ lvl_start, const float *__restrict__ loc,
                                                             const float *__restrict__ attn, const float *__restrict__ grad_out,
                                                             float *__restrict__ grad_value, float *__restrict__ grad_loc,
                                                             float *__restrict__ grad_attn, int S, int M, int B,
-                                                            unsigned *__restrict__ cnt, unsigned long long *__restrict__ pub)
+                                                            unsigned *__restrict__ cnt, unsigned long long *__restrict__ pub,
+                                                            FusedBwd f = FusedBwd())
 {
   constexpr int L = 3, P = 4, LP = L * P;
   constexpr int HALO = HALF ? kHalo4H : kHalo4, WIN = HALF ? kWin4H : kWin4, CELLS = HALF ? kOwnCells4H : kOwnCells4, CW = HALF ? 17 : 33;
@@ -627,9 +708,30 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
     const f32x2 gq2[4] = {{g0.x * q0.x, g0.y * q0.y}, {g0.z * q0.z, g0.w * q0.w}, {g1.x * q1.x, g1.y * q1.y}, {g1.z * q1.z, g1.w * q1.w}};
     const f32x2 gs2[4] = {{gs[0], gs[1]}, {gs[2], gs[3]}, {gs[4], gs[5]}, {gs[6], gs[7]}};
     const f32x2 magic2 = {12582912.f, 12582912.f};
-    const float4 *lp4 = reinterpret_cast<const float4 *>(loc + (qm * LP + l * P) * 2);
-    const float4 l01 = lp4[0], l23 = lp4[1];
-    const float4 a4 = *reinterpret_cast<const float4 *>(attn + qm * LP + l * P);
+    float4 l01, l23, a4;
+    if constexpr (FUSED) {
+      const int bq = b * S + q;
+      const float *row = loc + (int64_t)bq * f.ld_oa + m * LP + l * P;        // (+ the same again for the offsets: two floats per point)
+      const float4 lg = *reinterpret_cast<const float4 *>(row + M * (LP * 2));
+      const float2 st = f.stats[qm];
+      a4 = make_float4(__expf(lg.x - st.x) * st.y, __expf(lg.y - st.x) * st.y, __expf(lg.z - st.x) * st.y, __expf(lg.w - st.x) * st.y);
+      const float4 *op4 = reinterpret_cast<const float4 *>(row + m * LP + l * P);
+      l01 = op4[0]; l23 = op4[1];
+      const float2 rf = *reinterpret_cast<const float2 *>(f.ref + ((int64_t)bq * L + l) * 2);
+      const float fw = (float)W, fh = (float)H;
+      if (((W & (W - 1)) | (H & (H - 1))) == 0) {          // powers of two: the product with 1 / W is the quotient, bit for bit
+        const float inv_w = 1.f / fw, inv_h = 1.f / fh;
+        l01 = make_float4(rf.x + l01.x * inv_w, rf.y + l01.y * inv_h, rf.x + l01.z * inv_w, rf.y + l01.w * inv_h);
+        l23 = make_float4(rf.x + l23.x * inv_w, rf.y + l23.y * inv_h, rf.x + l23.z * inv_w, rf.y + l23.w * inv_h);
+      } else {
+        l01 = make_float4(rf.x + l01.x / fw, rf.y + l01.y / fh, rf.x + l01.z / fw, rf.y + l01.w / fh);
+        l23 = make_float4(rf.x + l23.x / fw, rf.y + l23.y / fh, rf.x + l23.z / fw, rf.y + l23.w / fh);
+      }
+    } else {
+      const float4 *lp4 = reinterpret_cast<const float4 *>(loc + (qm * LP + l * P) * 2);
+      l01 = lp4[0]; l23 = lp4[1];
+      a4 = *reinterpret_cast<const float4 *>(attn + qm * LP + l * P);
+    }
     const float locs[8] = {l01.x, l01.y, l01.z, l01.w, l23.x, l23.y, l23.z, l23.w};
     const float aw[4] = {a4.x, a4.y, a4.z, a4.w};
     const int64_t voff = ((int64_t)b * S + lv.ls) * stride_w + m * 32 + sub * 8;
@@ -705,15 +807,33 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
         }
       }
       pa = group4_sum(pa);
-      pw = group4_sum(pw) * (a * W);
-      ph = group4_sum(ph) * (a * H);
+      if constexpr (FUSED) {
+        // a g (the softmax backward subtracts a sum_j a_j g_j in the closing pass); d offset = (pw a W) / W = pw a
+        pa = a * pa;
+        pw = group4_sum(pw) * a;
+        ph = group4_sum(ph) * a;
+      } else {
+        pw = group4_sum(pw) * (a * W);
+        ph = group4_sum(ph) * (a * H);
+      }
       if (sub == p) { keep_a = pa; keep_x = pw; keep_y = ph; }
       __builtin_amdgcn_sched_barrier(0);          // one point's 8 rows in flight at a time: the next point's would not fit 128 VGPRs
     }
     if (sub == 0 && half == 0) nmiss += __popc(HALF ? out5 : slow);
     if (!HALF || half == 0) {
-      grad_attn[qm * LP + l * P + sub] = keep_a;
-      reinterpret_cast<float2 *>(grad_loc + (qm * LP + l * P) * 2)[sub] = make_float2(keep_x, keep_y);
+      if constexpr (FUSED) {
+        const int bq = b * S + q;
+        float *drow = f.d_oa + (int64_t)bq * f.ld_doa;
+        drow[M * (LP * 2) + m * LP + l * P + sub] = keep_a;
+        reinterpret_cast<float2 *>(drow + m * (LP * 2) + l * (P * 2))[sub] = make_float2(keep_x, keep_y);
+        if (!(ABL & 64)) {
+          const float part = group4_sum(keep_a);                     // this level's share of sum_j a_j g_j
+          if (sub == 0) f.gdot[qm * L + l] = part;
+        }
+      } else {
+        grad_attn[qm * LP + l * P + sub] = keep_a;
+        reinterpret_cast<float2 *>(grad_loc + (qm * LP + l * P) * 2)[sub] = make_float2(keep_x, keep_y);
+      }
     }
     if (slow) {
       // corners no window caches: direct global atomics (the result never depends on window / halo sizes).  Rolled, re-reading
@@ -721,8 +841,20 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
 #pragma unroll 1
       for (int p = 0; p < P; ++p) {
         if (!((slow >> p) & 1)) continue;
-        const float2 xy = *reinterpret_cast<const float2 *>(loc + (qm * LP + l * P + p) * 2);
-        const float a = attn[qm * LP + l * P + p];
+        float2 xy;
+        float a;
+        if constexpr (FUSED) {                                 // (rare path: the point re-formed from the raw projection row)
+          const int bq = b * S + q;
+          const float *row = loc + (int64_t)bq * f.ld_oa;
+          const float2 of = *reinterpret_cast<const float2 *>(row + m * (LP * 2) + (l * P + p) * 2);
+          const float2 rf = *reinterpret_cast<const float2 *>(f.ref + ((int64_t)bq * L + l) * 2);
+          const float2 st = f.stats[qm];
+          a = __expf(row[M * (LP * 2) + m * LP + l * P + p] - st.x) * st.y;
+          xy = make_float2(rf.x + of.x / (float)W, rf.y + of.y / (float)H);
+        } else {
+          xy = *reinterpret_cast<const float2 *>(loc + (qm * LP + l * P + p) * 2);
+          a = attn[qm * LP + l * P + p];
+        }
         const float h_im = xy.y * H - 0.5f, w_im = xy.x * W - 0.5f;
         const bool in_range = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
         int off[4]; bool ok[4]; float cw[4], lh, lw, hh, hw;
@@ -753,13 +885,39 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
     if ((threadIdx.x & 63) == 0 && nmiss) atomicAdd(&s_miss, (int)nmiss);
   }
   __syncthreads();
-  if (cnt && threadIdx.x == 0) {
-    if (half == 0) { atomicAdd(cnt, (unsigned)s_miss); atomicAdd(cnt + 1, (unsigned)(nq_all * LP)); }
-    __threadfence();
-    if (atomicAdd(cnt + 2, 1u) == (unsigned)nact - 1u) {      // the last active workgroup: publish and recycle the slot
-      const unsigned mi = atomicAdd(cnt, 0u), to = atomicAdd(cnt + 1, 0u);
-      if (pub) { *pub = ((unsigned long long)mi << 32) | to; __threadfence_system(); }
-      atomicExch(cnt, 0u); atomicExch(cnt + 1, 0u); atomicExch(cnt + 2, 0u);
+  if constexpr (FUSED && !(ABL & 32)) {
+    // closing pass of the softmax backward: d logit_j = a_j g_j - a_j sum_i a_i g_i.  The main pass left a_j g_j in d_oa and every
+    // (query, level) unit's partial sum in scratch (plain stores of this workgroup, ordered by the barrier above; summed here in level
+    // order: deterministic); a thread takes one (query, head): 12 probabilities re-formed from the logits, 48 bytes rewritten, and the
+    // absolute maximum of the head's 36 gradient values joins the row maximum with ONE atomic.
+    if (!HALF || half == 0) {
+      for (int i = threadIdx.x; i < nq_all; i += NT) {
+        const int q = query_of(i);
+        const int64_t bq = (int64_t)b * S + q, qm = bq * M + m;
+        const float sum = (f.gdot[qm * L] + f.gdot[qm * L + 1]) + f.gdot[qm * L + 2];
+        const float2 st = f.stats[qm];
+        const float4 *lg4 = reinterpret_cast<const float4 *>(loc + bq * f.ld_oa + M * (LP * 2) + m * LP);
+        float4 *dl4 = reinterpret_cast<float4 *>(f.d_oa + bq * f.ld_doa + M * (LP * 2) + m * LP);
+        const float4 *do4 = reinterpret_cast<const float4 *>(f.d_oa + bq * f.ld_doa + m * (LP * 2));
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+          const float4 lg = lg4[j];
+          float4 t = dl4[j];
+          t.x -= __expf(lg.x - st.x) * st.y * sum; t.y -= __expf(lg.y - st.x) * st.y * sum;
+          t.z -= __expf(lg.z - st.x) * st.y * sum; t.w -= __expf(lg.w - st.x) * st.y * sum;
+          dl4[j] = t;
+          mx = fmaxf(mx, fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))));
+        }
+        if (f.doa_amax && !(ABL & 8)) {
+#pragma unroll
+          for (int j = 0; j < 2 * L; ++j) {
+            const float4 o = do4[j];
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+          }
+          if (mx > 0.f) atomicMax(f.doa_amax + bq, __float_as_uint(mx));                  // non-negative floats order like their bits
+        }
+      }
     }
   }
   // ---- flush: lane = channel, one full 128-byte line per cell per half-wave
@@ -775,6 +933,25 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
       const int acc = (int)((unsigned)cp[cl] - (unsigned)cp[CW - 1] * 0x4B400000u);
       const float v = (float)acc / chscale[ch];           // chscale is a power of two: exact
       if (acc != 0 && !(ABL & 4)) unsafeAtomicAdd(gl + ((int64_t)(lv.wy0 + cellw / lv.ww) * lv.W + lv.wx0 + cellw % lv.ww) * stride_w + ch, v);
+    }
+  }
+  // the launch's miss statistics (the gate of LATER launches) leave last: the ticket's agent-scope fence then has nothing of this
+  // workgroup's closing pass / flush to wait out or to write back twice
+  if (cnt && threadIdx.x == 0) {
+    // relaxed agent-scope atomics, NO fence between the counts and the ticket: the three words share one 16-byte slot (one memory
+    // channel; a wavefront's atomics to it are performed in issue order), and what they feed is a speed heuristic — a count that
+    // missed a straggler would only shade a later launch's choice of window size.  A __threadfence() here made every workgroup wait
+    // for the write-back of the lines it had just written, with its CU idle (one workgroup per CU): 6 us per launch in the operator
+    // kernel, 19 us in the fused one.
+    if (half == 0) {
+      (void)__hip_atomic_fetch_add(cnt, (unsigned)s_miss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      (void)__hip_atomic_fetch_add(cnt + 1, (unsigned)(nq_all * LP), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (__hip_atomic_fetch_add(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nact - 1u) {   // the last active workgroup: publish and recycle the slot
+      const unsigned mi = __hip_atomic_fetch_add(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned to = __hip_atomic_fetch_add(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (pub) { *pub = ((unsigned long long)mi << 32) | to; __threadfence_system(); }
+      atomicExch(cnt, 0u); atomicExch(cnt + 1, 0u); atomicExch(cnt + 2, 0u);
     }
   }
 }
@@ -1054,7 +1231,7 @@ extern "C" int pd_msda_backward(const void *value, const int64_t *spatial_shapes
     if (num_levels == 3 && g_pd_dbg_bwd_variant != 1 && spatial_size < (1 << 23) && num_heads * 32 < (1 << 23)) {   // 24-bit index multiplies
       const size_t lds4 = ((size_t)kOwnCells4 * 33 + 64) * sizeof(int), lds4h = ((size_t)kOwnCells4H * 17 + 64) * sizeof(int);
       typedef void (*ofn)(const float *, const int64_t *, const int64_t *, const float *, const float *, const float *, float *, float *,
-                          float *, int, int, int, unsigned *, unsigned long long *);
+                          float *, int, int, int, unsigned *, unsigned long long *, FusedBwd);
       const int ai = g_pd_dbg_ablate == 1 ? 1 : g_pd_dbg_ablate == 4 ? 2 : g_pd_dbg_ablate == 7 ? 3 : 0;
       const ofn all4[4] = {msda_bwd_owner4_d32<0>, msda_bwd_owner4_d32<1>, msda_bwd_owner4_d32<4>, msda_bwd_owner4_d32<7>};
       const ofn half4 = msda_bwd_owner4_d32<0, true>;
@@ -1078,11 +1255,11 @@ extern "C" int pd_msda_backward(const void *value, const int64_t *spatial_shapes
       if (!want_half)
         hipLaunchKernelGGL(all4[ai], dim3((unsigned)nb4), dim3(1024), lds4, stream, (const float *)value, spatial_shapes, level_start_index,
                            (const float *)sampling_loc, (const float *)attn_weight, (const float *)grad_output, (float *)grad_value,
-                           (float *)grad_sampling_loc, (float *)grad_attn_weight, spatial_size, num_heads, batch, cnt, pub);
+                           (float *)grad_sampling_loc, (float *)grad_attn_weight, spatial_size, num_heads, batch, cnt, pub, FusedBwd());
       else
         hipLaunchKernelGGL(half4, dim3((unsigned)(2 * nb4)), dim3(1024), lds4h, stream, (const float *)value, spatial_shapes, level_start_index,
                            (const float *)sampling_loc, (const float *)attn_weight, (const float *)grad_output, (float *)grad_value,
-                           (float *)grad_sampling_loc, (float *)grad_attn_weight, spatial_size, num_heads, batch, cnt, pub);
+                           (float *)grad_sampling_loc, (float *)grad_attn_weight, spatial_size, num_heads, batch, cnt, pub, FusedBwd());
       return pd_check_launch("pd_msda_backward");
     }
     const int64_t nblocks = (int64_t)batch * kGmax * kGmax * num_levels * num_heads;
@@ -1131,4 +1308,88 @@ extern "C" int pd_msda_backward(const void *value, const int64_t *spatial_shapes
                          num_point);
   }
   return pd_check_launch("pd_msda_backward");
+}
+
+// ----------------------------------------------------------------------------------------- fused module path (round 5)
+// MSDeformAttn.forward (ms_deform_attn.py:86-131) hands the operator softmax(attention_weights(query)) and reference_points +
+// sampling_offsets(query) / (W, H).  pd_msda_fused_* take the projections' RAW output instead and do those two steps in the kernels'
+// registers (see msda_fwd_d32<.., FUSED> / msda_bwd_owner4_d32<.., FUSED>).  pd_msda_forward / pd_msda_backward — the reference's
+// operator ABI — are unchanged; the fused pair is what the module path of this package calls when pd_msda_fused_supported says so.
+extern "C" int pd_msda_fused_supported(int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query, int num_point)
+{
+  const int64_t total_qm = (int64_t)batch * num_query * num_heads;
+  return (!g_pd_dbg_force_generic && g_pd_dbg_atomic_scope == 0 && g_pd_dbg_bwd_variant != 1 && channels == 32 && num_point == 4 && num_levels == 3 &&
+          num_query == spatial_size && total_qm > 0 && total_qm < (1LL << 31) && spatial_size < (1 << 23) && num_heads * 32 < (1 << 23)) ? 1 : 0;
+}
+
+extern "C" int pd_msda_fused_forward(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index, const float *oa,
+                                     int ld_oa, const float *ref, float *output, float *stats, float *row_amax, int batch, int spatial_size,
+                                     int num_heads, int channels, int num_levels, int num_query, int num_point, void *stream_)
+{
+  const void *ptrs[] = {value, spatial_shapes, level_start_index, oa, ref, output, stats};
+  int rc = check_common(ptrs, 7, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, 1, PD_F32);
+  if (rc) return rc;
+  if (!pd_msda_fused_supported(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_fused_forward: geometry not served (ask pd_msda_fused_supported; fp32, 32 channels, 3 levels, 4 points, queries == pixels)");
+  if (ld_oa < 3 * num_heads * num_levels * num_point || (ld_oa & 3) || ((uintptr_t)oa & 15))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_fused_forward: projection rows need >= 3 M L P columns, a stride that is a multiple of 4 and a 16-byte aligned base");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t total_qm = (int64_t)batch * num_query * num_heads;
+  const int nblocks = round_up8((total_qm + 31) / 32);
+  hipLaunchKernelGGL((msda_fwd_d32<3, 4, true>), dim3(nblocks), dim3(256), 0, stream, value, spatial_shapes, level_start_index, oa, ref, output,
+                     spatial_size, num_heads, num_query, (int)total_qm, reinterpret_cast<unsigned *>(row_amax), ld_oa, reinterpret_cast<float2 *>(stats));
+  return pd_check_launch("pd_msda_fused_forward");
+}
+
+extern "C" int pd_msda_fused_backward(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index, const float *oa,
+                                      int ld_oa, const float *ref, const float *stats, const float *fwd_output, const float *grad_output,
+                                      float *grad_value, float *d_oa, int ld_doa, float *d_oa_amax, float *scratch, int batch, int spatial_size, int num_heads,
+                                      int channels, int num_levels, int num_query, int num_point, void *stream_)
+{
+  const void *ptrs[] = {value, spatial_shapes, level_start_index, oa, ref, stats, fwd_output, grad_output, grad_value, d_oa, scratch};
+  int rc = check_common(ptrs, 11, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, 1, PD_F32);
+  if (rc) return rc;
+  if (!pd_msda_fused_supported(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_fused_backward: geometry not served (ask pd_msda_fused_supported)");
+  const int n3 = 3 * num_heads * num_levels * num_point;
+  if (ld_oa < n3 || ld_doa < n3 || ((ld_oa | ld_doa) & 3) || (((uintptr_t)oa | (uintptr_t)d_oa) & 15))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_fused_backward: projection rows need >= 3 M L P columns, strides that are multiples of 4 and 16-byte aligned bases");
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t nv = (size_t)batch * spatial_size * num_heads * channels;
+  (void)hipMemsetAsync(grad_value, 0, nv * sizeof(float), stream);
+  if (d_oa_amax) (void)hipMemsetAsync(d_oa_amax, 0, (size_t)batch * num_query * sizeof(float), stream);
+  const size_t lds4 = ((size_t)kOwnCells4 * 33 + 64) * sizeof(int), lds4h = ((size_t)kOwnCells4H * 17 + 64) * sizeof(int);
+  const auto k5 = g_pd_dbg_ablate == 8 ? msda_bwd_owner4_d32<8, false, true> : g_pd_dbg_ablate == 32 ? msda_bwd_owner4_d32<32, false, true>
+                : g_pd_dbg_ablate == 96 ? msda_bwd_owner4_d32<96, false, true> : msda_bwd_owner4_d32<0, false, true>;
+  const auto k9 = msda_bwd_owner4_d32<0, true, true>;
+  static bool attr = false;
+  if (g_pd_dbg_ablate) (void)hipFuncSetAttribute((const void *)k5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)k5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+    (void)hipFuncSetAttribute((const void *)k9, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4h);
+    attr = true;
+  }
+  const int64_t nb4 = (int64_t)batch * kGmax * kGmax * num_heads;
+  bool want_half = g_pd_dbg_bwd_variant == 2;
+  unsigned *cnt = nullptr;
+  unsigned long long *pub = nullptr;
+  if (g_pd_dbg_bwd_variant == 0) {                           // the same measured choice between the halo-5 and halo-9 windows as pd_msda_backward
+    const int slot = msda_gate_pick(stream, &want_half);
+    if (slot >= 0) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      cnt = g_gate_cnt[dev] + 4 * slot; pub = g_gate_pub_dev[dev] + slot;
+      ((volatile unsigned long long *)g_gate_pub[dev])[slot] = 0ull;
+    }
+  }
+  FusedBwd f;
+  f.ref = ref; f.stats = reinterpret_cast<const float2 *>(stats); f.fout = fwd_output; f.d_oa = d_oa;
+  f.doa_amax = reinterpret_cast<unsigned *>(d_oa_amax); f.ld_oa = ld_oa; f.ld_doa = ld_doa; f.gdot = scratch;
+  if (!want_half)
+    hipLaunchKernelGGL(k5, dim3((unsigned)nb4), dim3(1024), lds4, stream, value, spatial_shapes, level_start_index, oa, (const float *)nullptr,
+                       grad_output, grad_value, (float *)nullptr, (float *)nullptr, spatial_size, num_heads, batch, cnt, pub, f);
+  else
+    hipLaunchKernelGGL(k9, dim3((unsigned)(2 * nb4)), dim3(1024), lds4h, stream, value, spatial_shapes, level_start_index, oa, (const float *)nullptr,
+                       grad_output, grad_value, (float *)nullptr, (float *)nullptr, spatial_size, num_heads, batch, cnt, pub, f);
+  return pd_check_launch("pd_msda_fused_backward");
 }

@@ -96,6 +96,45 @@ def msda_forward_amax(value, shapes, lsi, loc, attn, im2col_step, row_amax):
     return out
 
 
+FUSED_MSDA = os.environ.get("PD_MSDA_FUSED", "1") != "0"   # softmax + sampling locations inside the MSDA kernels (pd_msda_fused_*): no prep launches
+
+
+def msda_fused_supported(B, S, M, D, L, Lq, P):
+    return FUSED_MSDA and bool(_lib.load().pd_msda_fused_supported(B, S, M, D, L, Lq, P))
+
+
+def msda_fused_forward(value, shapes, lsi, oa, ref, row_amax):
+    """value [B, S, M, 32]; oa [B * S, >= 3 M L P] fp32 = the raw sampling_offsets | attention_weights projection output; ref [B * S, L, 2]
+    -> (output [B * S, M * 32], softmax statistics [B * S * M, 2]); row_amax [B * S] (zero-filled) receives the output rows' maxima"""
+    B, S, M, D = value.shape
+    L = int(shapes.shape[0])
+    P = oa.shape[1] // (3 * M * L)
+    assert oa.stride(1) == 1 and oa.dtype == torch.float32 and ref.is_contiguous() and ref.numel() == B * S * L * 2
+    out = torch.empty((B * S, M * D), dtype=torch.float32, device=value.device)
+    stats = torch.empty((B * S * M, 2), dtype=torch.float32, device=value.device)
+    _lib.check(_lib.load().pd_msda_fused_forward(value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), oa.data_ptr(), oa.stride(0), ref.data_ptr(),
+                                                 out.data_ptr(), stats.data_ptr(), row_amax.data_ptr() if row_amax is not None else None,
+                                                 B, S, M, D, L, S, P, rw._stream()))
+    return out, stats
+
+
+def msda_fused_backward(value, shapes, lsi, oa, ref, stats, out, grad_out):
+    """-> (grad_value [B, S, M, 32], d_oa [B * S, 3 M L P] = the gradient of the raw projection output, its rows' maxima [B * S])"""
+    B, S, M, D = value.shape
+    L = int(shapes.shape[0])
+    n_oa = oa.shape[1]
+    P = n_oa // (3 * M * L)
+    gv = torch.empty_like(value)
+    d_oa = torch.empty((B * S, n_oa), dtype=torch.float32, device=value.device)
+    d_oa_am = torch.empty(B * S, dtype=torch.float32, device=value.device)
+    scratch = torch.empty(B * S * M * L, dtype=torch.float32, device=value.device)
+    grad_out = grad_out if grad_out.is_contiguous() else grad_out.contiguous()
+    _lib.check(_lib.load().pd_msda_fused_backward(value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), oa.data_ptr(), oa.stride(0), ref.data_ptr(),
+                                                  stats.data_ptr(), out.data_ptr(), grad_out.data_ptr(), gv.data_ptr(), d_oa.data_ptr(), d_oa.stride(0),
+                                                  d_oa_am.data_ptr(), scratch.data_ptr(), B, S, M, D, L, S, P, rw._stream()))
+    return gv, d_oa, d_oa_am
+
+
 class EncoderSpec:
     def __init__(self, n_heads, n_levels, n_points, eps, im2col_step, reference_points, spatial_shapes, level_start_index):
         self.M, self.L, self.P, self.eps, self.im2col_step = n_heads, n_levels, n_points, eps, im2col_step
@@ -269,9 +308,20 @@ class EncoderCore(Function):
             l1_c, l1_wam = wk[o + 2 * C:o + 2 * C + n_l1], wk_am[o + 2 * C:o + 2 * C + n_l1]
             value = gemm_tn_h2(x, vp_c, vp_b, a_amax=x_am, b_amax=vp_wam)
             oa = gemm_tn_h2(q, w_oa, b_oa_all[i], a_amax=q_am, b_amax=oa_wam)           # [T, 2MLP + MLP]
-            loc, attn = msda_prep_fwd(oa[:, :n_off], oa[:, n_off:], ref, spec.shapes, M, L, P)
-            v4, loc6, attn5 = value.view(B, S, M, C // M), loc.view(B, S, M, L, P, 2), attn.view(B, S, M, L, P)
-            if fwd_amax:
+            v4 = value.view(B, S, M, C // M)
+            fused = fwd_amax and n_off == 2 * n_aw and msda_fused_supported(B, S, M, C // M, L, S, P)
+            if fused:
+                # softmax over the head's L P logits and reference point + offset / (W, H) inside the kernel: `oa` and the 8-byte softmax
+                # statistics take the places of loc / attn among the saved tensors (the backward kernel re-forms both)
+                a_am = a_am_all[i]
+                a, stats = _timed("fwd", msda_fused_forward, v4, spec.shapes, spec.lsi, oa, ref, a_am)
+                loc6, attn5 = oa, stats
+            else:
+                loc, attn = msda_prep_fwd(oa[:, :n_off], oa[:, n_off:], ref, spec.shapes, M, L, P)
+                loc6, attn5 = loc.view(B, S, M, L, P, 2), attn.view(B, S, M, L, P)
+            if fused:
+                pass
+            elif fwd_amax:
                 a_am = a_am_all[i]
                 a = _timed("fwd", msda_forward_amax, v4, spec.shapes, spec.lsi, loc6, attn5, spec.im2col_step, a_am).view(T, C)
             else:
@@ -287,7 +337,7 @@ class EncoderCore(Function):
             last = i == nl - 1
             z2, y2, _, ypos, m2, r2, y2_am, ypos_am = rw.add_ln_fwd(ffn2, y1, n2_w, n2_b, spec.eps, c_dtype=torch.float32,
                                                                      pos=pos2, pos_div=1, want_ypos=not last, amax=True)
-            saved.append((x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, None, hbits))
+            saved.append((x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, ref if fused else None, hbits))
             saved_am.append((x_am, q_am, a_am, y1_am, h_am))
             x, q, x_am, q_am = y2, ypos, y2_am, ypos_am
         return x, saved, saved_am
@@ -364,20 +414,22 @@ class EncoderCore(Function):
         dy = d_out.reshape(T, C)
         dy = dy if dy.is_contiguous() else dy.contiguous()
         stacks = (l1_t, l2_t, op_t, vp_t, oa_t)
+        ref = spec.ref.reshape(T, spec.L, 2)                       # (the fused MSDA backward re-forms the sampling locations from it)
+        ref = ref if ref.is_contiguous() else ref.contiguous()
         rec_f = getattr(ctx, "rec", None)
         if rec_f is None:
-            dy, dy2, dyq, d_pos, grads = EncoderCore._bwd_layers_h2(spec, params, ctx.dims, ctx.saved, ctx.saved_am, dy, stacks, need_w)
+            dy, dy2, dyq, d_pos, grads = EncoderCore._bwd_layers_h2(spec, params, ctx.dims, ctx.saved, ctx.saved_am, dy, stacks, need_w, ref)
         else:
             if rec_f.generation != ctx.rec_gen:
                 raise RuntimeError("the fused encoder ran another forward before this backward: the recorded region's activation arena was "
                                    "overwritten (set PD_CMDBUF=0 for graphs that keep several forward passes alive)")
-            slots = [dy] + [k.t for k in stacks] + [spec.shapes, spec.lsi] + list(params)
+            slots = [dy] + [k.t for k in stacks] + [spec.shapes, spec.lsi, ref] + list(params)
             key = ("bwd", id(rec_f), need_w, tuple(k.rev for k in stacks))
             rec = _RECS.get(key)
             if rec is None or not rec.matches(slots):
                 rec = cmdbuf.Recording(slots, "encoder backward", stable=[rec_f])
                 with rec:
-                    outs = EncoderCore._bwd_layers_h2(spec, params, ctx.dims, ctx.saved, ctx.saved_am, dy, stacks, need_w)
+                    outs = EncoderCore._bwd_layers_h2(spec, params, ctx.dims, ctx.saved, ctx.saved_am, dy, stacks, need_w, ref)
                     outs = outs[:4] + (cmdbuf.Fresh(outs[4]),)
                 dy, dy2, dyq, d_pos, grads = rec.finish(outs)
                 _RECS.put(key, rec)
@@ -400,7 +452,7 @@ class EncoderCore(Function):
         return (None, d_src.view(B, S, C), d_pos.view(B, S, C), *grads)
 
     @staticmethod
-    def _bwd_layers_h2(spec, params, dims, saved, saved_am, dy, stacks, need_w):
+    def _bwd_layers_h2(spec, params, dims, saved, saved_am, dy, stacks, need_w, ref):
         """-> (dy, dy2, dyq: the three fp32 terms of d(src), d_pos without its last term, parameter gradients); pd_* launches and
         allocations only (recordable)"""
         B, S, C, nl = dims
@@ -445,7 +497,7 @@ class EncoderCore(Function):
         dy2 = dyq = None                                       # further fp32 terms of d(src_l): via value_proj, via (src + pos)
         for i in reversed(range(nl)):
             n1_w, l1_w, n2_w = params[i * N_LAYER + 8], params[i * N_LAYER + 10], params[i * N_LAYER + 14]
-            x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, _, hbits = saved[i]
+            x, q, v4, loc6, attn5, a, z1, m1, r1, y1, h, z2, m2, r2, fused_ref, hbits = saved[i]
             (g_sow, g_sob, g_aww, g_awb, g_vpw, g_vpb, g_opw, g_opb, g_n1w, g_n1b, g_l1w, g_l1b, g_l2w, g_l2b, g_n2w,
              g_n2b) = [G(i, j) for j in range(N_LAYER)]
             # ---- FFN + norm2
@@ -466,9 +518,15 @@ class EncoderCore(Function):
                                            out=None if queue is not None else dz2, amax=True)
             wgrad(dz1, a, g_opw, None, dz1_am, a_am)
             da = gemm_tn_h2(dz1, op_t[i], a_amax=dz1_am, b_amax=op_tam[i]).view(B, S, C)
-            gv, gloc, gattn = _timed("bwd", MSDA.ms_deform_attn_backward, v4, spec.shapes, spec.lsi, loc6, attn5, da, spec.im2col_step)
-            d_oa = torch.empty((T, n_oa), dtype=torch.float32, device=dev)
-            if prep_amax_supported(M, L, P):
+            if fused_ref is not None:
+                # (loc6, attn5) hold the raw projection output and the softmax statistics: the kernel writes d(projection output) itself
+                gv, d_oa, d_oa_am = _timed("bwd", msda_fused_backward, v4, spec.shapes, spec.lsi, loc6, ref, attn5, a, da)
+            else:
+                gv, gloc, gattn = _timed("bwd", MSDA.ms_deform_attn_backward, v4, spec.shapes, spec.lsi, loc6, attn5, da, spec.im2col_step)
+                d_oa = torch.empty((T, n_oa), dtype=torch.float32, device=dev)
+            if fused_ref is not None:
+                pass
+            elif prep_amax_supported(M, L, P):
                 d_oa_am = torch.empty(T, dtype=torch.float32, device=dev)
                 msda_prep_bwd(gloc, gattn, attn5, spec.shapes, T, M, L, P, out=d_oa, amax=d_oa_am)
             else:

@@ -239,3 +239,122 @@ def test_torch_library_operator_matches_the_function_and_passes_opcheck():
     torch.library.opcheck(torch.ops.pd.ms_deform_attn_forward.default, (v2.detach().requires_grad_(), sh, lv, lo2.detach().requires_grad_(),
                                                                        at2.detach().requires_grad_(), 128),
                           test_utils=("test_schema", "test_faketensor", "test_autograd_registration", "test_aot_dispatch_static"))
+
+
+# ----------------------------------------------------------------------------- the module path's fused form (pd_msda_fused_*)
+def _fused_case(shapes, B, seed, off_scale):
+    """-> raw projection output oa [B S, 288] (offsets | logits), reference points [B S, 3, 2], value, grad_out and — formed on the CPU
+    exactly as ms_deform_attn.py:108-117 does — the sampling locations and attention probabilities they stand for"""
+    M, D, L, P = 8, 32, 3, 4
+    shapes = torch.as_tensor(shapes, dtype=torch.long)
+    lvl = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    value = C.seeded((B, S, M, D), seed + 1)
+    offs = C.seeded((B * S, M, L, P, 2), seed + 2, off_scale)                       # pixels
+    logits = C.seeded((B * S, M, L * P), seed + 3, 2.0)
+    oa = torch.cat([offs.reshape(B * S, -1), logits.reshape(B * S, -1)], 1).contiguous()
+    # the encoder's reference points: pixel centres of every level's grid, normalised (msdeformattn.py:88-103 with valid ratios of 1)
+    pts = []
+    for h, w in shapes.tolist():
+        ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h) / h, torch.linspace(0.5, w - 0.5, w) / w, indexing="ij")
+        pts.append(torch.stack((xs.reshape(-1), ys.reshape(-1)), -1))
+    ref = torch.cat(pts)[None, :, None, :].expand(B, S, L, 2).reshape(B * S, L, 2).contiguous()
+    gout = C.seeded((B, S, M * D), seed + 4)
+    return value, shapes, lvl, oa, ref, gout, (B, S, M, D, L, P)
+
+
+def _loc_attn(oa, ref, shapes, dims):
+    B, S, M, D, L, P = dims
+    n = M * L * P
+    norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).to(oa.dtype)               # (W, H)
+    loc = ref[:, None, :, None, :] + oa[:, :2 * n].view(B * S, M, L, P, 2) / norm[None, None, :, None, :]
+    attn = oa[:, 2 * n:].view(B * S, M, L * P).softmax(-1).view(B * S, M, L, P)
+    return loc.view(B, S, M, L, P, 2), attn.view(B, S, M, L, P)
+
+
+@pytest.mark.parametrize("variant", [0, 2, 3])
+@pytest.mark.parametrize("shapes,off_scale", [([(32, 32), (16, 16), (8, 8)], 2.0), ([(24, 20), (12, 10), (6, 5)], 3.0), ([(64, 64), (32, 32), (16, 16)], 9.0)])
+def test_fused_forward_backward_vs_oracle(shapes, off_scale, variant):
+    """pd_msda_fused_forward / _backward (softmax over a head's 12 logits and reference point + offset / (W, H) formed inside the
+    kernels, the gradient of the RAW projection output written by the backward kernel) against the C oracle run on the locations /
+    probabilities torch forms from the same numbers, chained through their definition in float64 (ms_deform_attn.py:108-117):
+    power-of-two and other level sizes, offsets of a few pixels (window hits) up to ~30 (the global-atomic path), both LDS-window
+    variants forced and the measured choice.  Forward rtol 1e-5; grad_value as the unfused kernel's test (2e-5 of its maximum);
+    d_oa rtol 1e-4 + 2e-5 of its maximum; the rows' maxima exact for what was written."""
+    from partdistillation_amd import lib
+    from partdistillation_amd.functions import encoder_core as EC
+    value, sh, lvl, oa, ref, gout, dims = _fused_case(shapes, 2, 11 + int(off_scale), off_scale)
+    B, S, M, D, L, P = dims
+    assert EC.msda_fused_supported(B, S, M, D, L, S, P)
+    loc, attn = _loc_attn(oa, ref, sh, dims)
+    want = omsda.msda_forward(value, sh, lvl, loc, attn)
+    v, shd, lvd, oad, refd, god = _cuda(value, sh, lvl, oa, ref, gout)
+    am = torch.zeros(B * S, device="cuda")
+    out, stats = EC.msda_fused_forward(v, shd, lvd, oad, refd, am)
+    torch.testing.assert_close(out.cpu().view(B, S, M * D), want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(am.cpu(), out.abs().amax(1).cpu(), rtol=0, atol=0)
+    lg = oa[:, 2 * M * L * P:].reshape(B * S * M, L * P)
+    torch.testing.assert_close(stats[:, 0].cpu(), lg.amax(1), rtol=0, atol=0)
+    torch.testing.assert_close(stats[:, 1].cpu(), 1.0 / (lg - lg.amax(1, keepdim=True)).exp().sum(1), rtol=1e-5, atol=0)
+    Lh = lib.load()
+    Lh.pd_debug_set(b"msda_bwd_variant", variant)
+    try:
+        gv, d_oa, d_am = EC.msda_fused_backward(v, shd, lvd, oad, refd, stats, out, god)
+        torch.cuda.synchronize()
+    finally:
+        Lh.pd_debug_set(b"msda_bwd_variant", 0)
+    ov, ol, og = omsda.msda_backward(value, sh, lvl, loc, attn, gout)
+    # chain rule in float64: d offset = grad_loc / (W, H); d logit = a (g - sum a g)
+    norm = torch.stack([sh[:, 1], sh[:, 0]], -1).double()
+    d_off = ol.double().view(B * S, M, L, P, 2) / norm[None, None, :, None, :]
+    a64, g64 = attn.double().view(B * S, M, L * P), og.double().view(B * S, M, L * P)
+    d_lg = a64 * (g64 - (a64 * g64).sum(-1, keepdim=True))
+    want_doa = torch.cat([d_off.reshape(B * S, -1), d_lg.reshape(B * S, -1)], 1).float()
+    scale = ov.abs().max().item()
+    assert ((gv.cpu() - ov).abs() <= 2e-5 * scale).all(), (gv.cpu() - ov).abs().max().item() / scale
+    err = (d_oa.cpu() - want_doa).abs()
+    bound = 2e-5 * want_doa.abs().max() + 1e-4 * want_doa.abs()
+    # a sample within rounding distance of a cell border takes the other one-sided derivative (as in the unfused test): 1e-5 of them
+    assert (err > bound).float().mean().item() <= 1e-5, (err.max().item(), want_doa.abs().max().item())
+    torch.testing.assert_close(d_am.cpu(), d_oa.abs().amax(1).cpu(), rtol=0, atol=0)
+
+
+def test_fused_path_equals_prep_plus_operator_in_the_encoder_layer():
+    """the encoder core with PD_MSDA_FUSED on and off (pd_msda_prep_fwd + pd_msda_forward_amax / pd_msda_backward + pd_msda_prep_bwd_amax):
+    same outputs and gradients to reordered-atomics noise — and the fused run really took the fused kernels."""
+    from partdistillation_amd.functions import encoder_core as EC
+    torch.manual_seed(0)
+    cfg = {**C.TINY, "conv_dim": 256, "mask_dim": 256, "enc_ffn": 512, "batch": 2}       # 8 heads x 32 channels: the geometry the fused kernels serve
+    pd = build_pixel_decoder_small(cfg)
+    feats = {k: v.cuda().requires_grad_() for k, v in C.make_features(cfg, 231).items()}
+    res = {}
+    calls = {"n": 0}
+    f0 = EC.msda_fused_forward
+    EC.msda_fused_forward = lambda *a: (calls.__setitem__("n", calls["n"] + 1), f0(*a))[1]
+    try:
+        for fused in (True, False):
+            EC.FUSED_MSDA = fused
+            for p in pd.parameters():
+                p.grad = None
+            mf, enc, ms = pd.forward_features(feats)
+            loss = (mf * C.seeded(mf.shape, 5).cuda()).sum() + sum((m * C.seeded(m.shape, 6 + i).cuda()).sum() for i, m in enumerate(ms))
+            gf = torch.autograd.grad(loss, list(feats.values()) + [p for p in pd.parameters() if p.requires_grad], allow_unused=True)
+            res[fused] = ([mf.detach()] + [m.detach() for m in ms], [g.detach() if g is not None else None for g in gf])
+    finally:
+        EC.FUSED_MSDA, EC.msda_fused_forward = True, f0
+    assert calls["n"] >= cfg["enc_layers"]
+    for a, b in zip(res[True][0], res[False][0]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+    for a, b in zip(res[True][1], res[False][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert ((a - b).abs().max() <= 2e-4 * b.abs().max().clamp_min(1e-6)).item(), ((a - b).abs().max().item(), b.abs().max().item())
+
+
+def build_pixel_decoder_small(cfg):
+    from partdistillation_amd.compat import ShapeSpec
+    from partdistillation_amd.modeling.pixel_decoder.msdeformattn import MSDeformAttnPixelDecoder
+    specs = {f"res{i + 2}": ShapeSpec(channels=c, stride=s) for i, (c, s) in enumerate(zip(cfg["channels"], (4, 8, 16, 32)))}
+    return MSDeformAttnPixelDecoder(specs, transformer_dropout=0.0, transformer_nheads=cfg["nheads"], transformer_dim_feedforward=cfg["enc_ffn"],
+                                    transformer_enc_layers=cfg["enc_layers"], conv_dim=cfg["conv_dim"], mask_dim=cfg["mask_dim"], norm="GN",
+                                    transformer_in_features=["res3", "res4", "res5"], common_stride=4).cuda()

@@ -839,7 +839,16 @@ def test_full_step_bf16_autocast_vs_oracle():
 
 
 GRAD_TOL_FP32_FULL = 4e-3       # of the tensor maximum: 3 x the measured worst case (1.1e-3, the stem filter: profiles/r04_parity.json)
-GRAD_TOL_BF16_BACKBONE = 1e-1   # bf16 backbone filter gradients vs the oracle's fp32 ones, of the tensor maximum (tightened to 3 x measured below)
+# bf16 backbone filter gradients (pd_igemm_bf16 forward / input gradient, conv_wgrad_bf16_tr) vs the ORACLE's fp32 gradients at the same
+# assignment and the same sample points, relative L2 (and of the tensor maximum): ~2.5 x the measured values of profiles/r05_parity.json
+# (stem 0.13, res2.0.conv1 0.05-0.07, res4.3.conv2 0.04, res5.2.conv3 0.03).  The deviation grows towards the stem because it is NOT
+# rounding noise of the backward kernels (those agree with torch's fp32 convolutions to 4e-3 per launch, tests/test_r50_fused_gpu.py,
+# and independent roundings would average out over the 10^5..10^6 positions a filter gradient sums): the bf16 FORWARD moves the
+# features by ~1 %, hence the mask logits, hence (sigmoid - label) wherever a logit is near zero — a gradient is a difference of large
+# terms, and every layer below inherits the change.  The library's bf16 kernels (PD_R50_FUSED=0: MIOpen) deviate from fp32 alike
+# (tests/test_r50_fused_gpu.py asserts the fused body's end-to-end deviation against that yardstick).
+GRAD_TOL_BF16_BACKBONE = {"backbone.stem.conv1.weight": 0.32, "backbone.res2.0.conv1.weight": 0.18, "backbone.res4.3.conv2.weight": 0.12,
+                          "backbone.res5.2.conv3.weight": 0.08}
 # fp32 losses.  History of the number (profiles/r04_parity.json over its seven commits): 9.3e-5 once (ccb9444: worst term loss_mask_3, with the
 # gradients of mask_features / mask_embed at 1e-4 of their maximum), 1.9e-7 .. 2.9e-7 in the six records since (worst term always a
 # loss_ce_*, those two gradients at 7e-7 .. 9e-7).  No code of the fp32 forward path changed in between (git diff ccb9444 630e9da touches
@@ -944,7 +953,11 @@ def test_config2_full_size_step_vs_oracle(amp):
     print(f"config 2 full size amp={amp} gradient dev vs the oracle's fp32 gradients (of tensor max):", {k.split(".", 1)[-1]: f"{v:.1e}" for k, v in worst.items()},
           "relative L2:", {k.split(".", 1)[-1]: f"{v:.1e}" for k, v in rel_l2.items()})
     _record_parity(f"config2_full_size_{'bf16' if amp else 'fp32'}", **rec, gradient_dev_of_tensor_max=worst, gradient_rel_l2=rel_l2, tolerance_gradient=tol)
-    assert max(worst.values()) < tol, worst
+    if amp:
+        for k in keys:
+            assert worst[k] < tol[k] and rel_l2[k] < tol[k], (k, worst[k], rel_l2[k], tol[k])
+    else:
+        assert max(worst.values()) < tol, worst
 
 
 @pytest.mark.parametrize("amp", [False, True])

@@ -9,7 +9,9 @@ import torch
 import partdistillation_amd.MultiScaleDeformableAttention as MSDA
 
 
-def make(N=2, img=1024, spread=0.02, device="cuda", seed=0, px=None, offsets=None):
+def make(N=2, img=1024, spread=0.02, device="cuda", seed=0, px=None, offsets=None, raw=False):
+    """raw=True: additionally the inputs of the fused form (pd_msda_fused_*) that stand for the same locations / probabilities:
+    oa [N S, 288] = offsets in pixels | logits, and the reference points [N S, 3, 2]"""
     shapes = [(img // 32,) * 2, (img // 16,) * 2, (img // 8,) * 2]
     S = sum(h * w for h, w in shapes)
     g = torch.Generator(device=device).manual_seed(seed)
@@ -45,8 +47,15 @@ def make(N=2, img=1024, spread=0.02, device="cuda", seed=0, px=None, offsets=Non
             off = grid[None, None] + px * torch.randn(N, S, 8, 3, 4, 2, device=device, generator=g)       # pixels
         wh = torch.as_tensor([(w, h) for h, w in shapes], dtype=torch.float32, device=device).view(1, 1, 1, 3, 1, 2)
         loc = (ref + off / wh).contiguous()
-    attn = torch.softmax(torch.randn(N, S, 8, 12, device=device, generator=g), -1).view(N, S, 8, 3, 4).contiguous()
+    logits = torch.randn(N, S, 8, 12, device=device, generator=g)
+    attn = torch.softmax(logits, -1).view(N, S, 8, 3, 4).contiguous()
     gout = torch.randn(N, S, 256, device=device, generator=g)
+    if raw:
+        wh = torch.as_tensor([(w, h) for h, w in shapes], dtype=torch.float32, device=device).view(1, 1, 1, 3, 1, 2)
+        off_px = (loc - ref) * wh
+        oa = torch.cat([off_px.reshape(N * S, -1), logits.reshape(N * S, -1)], 1).contiguous()
+        ref3 = ref.expand(N, S, 1, 3, 1, 2).reshape(N * S, 3, 2).contiguous()
+        return value, sh, lv, loc, attn, gout, oa, ref3
     return value, sh, lv, loc, attn, gout
 
 
@@ -70,6 +79,7 @@ def main():
     ap.add_argument("--spread", type=float, default=0.02)
     ap.add_argument("--px", type=float, default=None, help="offsets = init grid + N(0, px) pixels at every level (instead of --spread)")
     ap.add_argument("--variant", type=int, default=0, help="0: gated per launch (default); 1: the per-destination-level tiled backward; 2: always the halo-9 half-channel kernel; 3: always halo 5")
+    ap.add_argument("--fused", type=int, default=0, help="1: pd_msda_fused_forward / _backward (softmax + locations inside the kernels) instead of the operator")
     ap.add_argument("--offsets", default=None, choices=[None, "trained"], help="trained: heavy-tailed stand-in for a trained model's offsets")
     a = ap.parse_args()
     from partdistillation_amd import lib
@@ -78,15 +88,23 @@ def main():
     lib.load().pd_debug_set(b"msda_ablate", a.ablate)
     lib.load().pd_debug_set(b"msda_bwd_threads", a.bwd_threads)
     lib.load().pd_debug_set(b"msda_bwd_variant", a.variant)
-    value, sh, lv, loc, attn, gout = make(a.batch, a.img, a.spread, px=(a.px if a.px is not None else (0.0 if a.offsets else None)), offsets=a.offsets)
+    value, sh, lv, loc, attn, gout, oa, ref3 = make(a.batch, a.img, a.spread, px=(a.px if a.px is not None else (0.0 if a.offsets else None)), offsets=a.offsets, raw=True)
     S = value.shape[1]
     fb, bb = alg_bytes(a.batch, S)
+    if a.fused:
+        from partdistillation_amd.functions import encoder_core as EC
+        am = torch.zeros(a.batch * S, device="cuda")
+        out_f, stats = EC.msda_fused_forward(value, sh, lv, oa, ref3, am)
+        f_fwd = lambda: EC.msda_fused_forward(value, sh, lv, oa, ref3, am)
+        f_bwd = lambda: EC.msda_fused_backward(value, sh, lv, oa, ref3, stats, out_f, gout)
+    else:
+        f_fwd = lambda: MSDA.ms_deform_attn_forward(value, sh, lv, loc, attn, 128)
+        f_bwd = lambda: MSDA.ms_deform_attn_backward(value, sh, lv, loc, attn, gout, 128)
     for _ in range(5):
-        MSDA.ms_deform_attn_forward(value, sh, lv, loc, attn, 128)
-        MSDA.ms_deform_attn_backward(value, sh, lv, loc, attn, gout, 128)
+        f_fwd()
+        f_bwd()
     res = {}
-    for name, fn, nbytes in (("fwd", lambda: MSDA.ms_deform_attn_forward(value, sh, lv, loc, attn, 128), fb),
-                             ("bwd", lambda: MSDA.ms_deform_attn_backward(value, sh, lv, loc, attn, gout, 128), bb)):
+    for name, fn, nbytes in (("fwd", f_fwd, fb), ("bwd", f_bwd, bb)):
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
         for s, e in ev:
             s.record(); fn(); e.record()
