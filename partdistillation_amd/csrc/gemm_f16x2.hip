@@ -596,6 +596,162 @@ void gemm_rows_f16x2_k256(const float *__restrict__ A, const float *__restrict__
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_ra_f16x2_k256 (round 5): the K = 256 products (value / output / offset projections and their input gradients, the 1 x 1
+// convolutions on 256 channels) with the A operand going global memory -> REGISTERS -> matrix cores, never through LDS.
+// What bounds the tiled kernel above on these shapes is not bytes or products but the chain load -> split -> LDS store -> barrier ->
+// fragment read that every 16-deep step of every workgroup walks in phase (ablation: 10.5 us fixed + 9.5 loads + 11 products of a 31 us
+// launch whose traffic takes 11).  Here:
+//   * a wavefront OWNS 32 rows of A for all of K and a block of NTL x 32 columns of C.  The v_mfma_f32_32x32x16_f16 operand of a lane
+//     (row lane % 32, 8 consecutive k of block lane / 32) is read straight from memory: per 32-wide chunk of k a lane loads the 64
+//     contiguous bytes [32 c + 16 (lane / 32), + 16) of its row (4 x global_load_dwordx4 issued back to back: the wavefront touches each
+//     128-byte line of its 32 rows exactly once, as a whole), splits them into the two fp16 planes in registers and multiplies.  No A
+//     tile in LDS, no barrier in the K loop, loads one chunk (4 KB per wavefront) ahead.  The contraction order inside a chunk is
+//     (lane / 32, 8-k group): the weight fragments are read to match.
+//   * the workgroup's NTL x 32 columns of the weight matrix are split ONCE, in the prologue, into a resident LDS image
+//     [plane][k panel of 8][column][8 halves] (128 columns: 129 KB, panels padded by 16 bytes against the staging stores' bank
+//     conflicts); a fragment is one ds_read_b128, 512 contiguous bytes per half-wave.
+//   * 12 wavefronts per workgroup (3 per SIMD, <= 168 VGPRs): 384 rows x 128 columns; the column blocks of a row block are
+//     neighbours in the XCD-chunked block order, so the second reader of the A rows finds them in that XCD's L2.
+// Epilogue as the tiled kernel: row / column scales undone, bias, optional bf16 output, optional row maxima of C (atomic max).
+constexpr int RA_PSTRIDE_PAD = 16;
+template <int NTL, int NWAVE, bool AM, int RABL = 0>
+__global__ __launch_bounds__(NWAVE * 64)
+void gemm_ra_f16x2_k256(const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ bias, float *__restrict__ C,
+                        int M, int N, int lda, int ldb, int ldc, int nblk_n, const float *__restrict__ a_amax,
+                        const float *__restrict__ b_amax, unsigned *__restrict__ c_amax, int flags)
+{
+  constexpr int NT = NTL * 32, PST = NT * 16 + RA_PSTRIDE_PAD, PLANE = 32 * PST, NTH = NWAVE * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ra_lds[];     // 2 planes, then NT inverse column scales, then NWAVE x 32 inverse row scales
+  float *sib = reinterpret_cast<float *>(ra_lds + 2 * PLANE);
+  float *sia = sib + NT;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 31, fh = lane >> 5;
+  const int lb = xcd_chunk(blockIdx.x, gridDim.x);
+  const int nb = lb % nblk_n, mb = lb / nblk_n;
+  const int n0 = nb * NT, row0 = (mb * NWAVE + wave) * 32;
+  // ---- this lane's row of A: scale, first chunk in flight before anything else
+  const int arow = min(row0 + fr, M - 1);
+  const float *ap = A + (int64_t)arow * lda + 16 * fh;
+  constexpr int PF = 3;                                              // chunks of A in flight ahead of the one being multiplied
+  // chunk order rotated per wavefront (the sum does not care): at any moment the workgroup's loads spread over all eight 128-byte
+  // columns of the 1 KB rows instead of every wavefront asking for the same column — rows 1 KB apart map to few memory channels
+  const int rot = __builtin_amdgcn_readfirstlane((wave + lb) & 7);
+  float4 raw[PF + 1][4];
+#pragma unroll
+  for (int c = 0; c < PF; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) raw[c][i] = (RABL & 1) ? make_float4(1.f, 0.5f, (float)c, (float)i) : *reinterpret_cast<const float4 *>(ap + 32 * ((c + rot) & 7) + 4 * i);
+  float sa = 1.f, ia = 1.f;
+  if (AM) row_scale(a_amax[arow], sa, ia);
+  if (lane < 32) sia[wave * 32 + fr] = ia;
+  // ---- the weight block, split once into the resident image: all of a thread's loads first (one memory latency, not one per piece)
+  {
+    constexpr int NIT = (NT * 64 + NTH - 1) / NTH;
+    float4 wv[NIT];
+    float wsb[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = t + it * NTH, n = idx >> 6, k4 = idx & 63, gn = n0 + n;
+      wv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      wsb[it] = 0.f;
+      if (!(RABL & 16) && idx < NT * 64 && gn < N) {
+        wv[it] = *reinterpret_cast<const float4 *>(B + (int64_t)gn * ldb + 4 * k4);
+        if (AM) wsb[it] = b_amax[gn];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = t + it * NTH, n = idx >> 6, k4 = idx & 63;
+      if (!(RABL & 16) && idx < NT * 64) {
+        float sb = 1.f, ibv = 1.f;
+        if (AM && n0 + n < N) row_scale(wsb[it], sb, ibv);
+        const SplitH x = split4h(wv[it], sb);
+        unsigned char *p = ra_lds + (k4 >> 1) * PST + n * 16 + (k4 & 1) * 8;
+        *reinterpret_cast<uint2 *>(p) = x.hi;
+        *reinterpret_cast<uint2 *>(p + PLANE) = x.lo;
+        if (k4 == 0) sib[n] = ibv;
+      }
+    }
+  }
+  __syncthreads();
+  f32x16 acc[NTL];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  const unsigned char *bbase = ra_lds + fr * 16;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c + PF < 8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) raw[(c + PF) % (PF + 1)][i] = (RABL & 1) ? make_float4(1.f, 0.5f, (float)c, (float)i) : *reinterpret_cast<const float4 *>(ap + 32 * ((c + PF + rot) & 7) + 4 * i);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const SplitH u = split4h(raw[c % (PF + 1)][2 * j], sa), v = split4h(raw[c % (PF + 1)][2 * j + 1], sa);
+      const h16x8 ah = __builtin_bit_cast(h16x8, u32x4{u.hi.x, u.hi.y, v.hi.x, v.hi.y});
+      const h16x8 al = __builtin_bit_cast(h16x8, u32x4{u.lo.x, u.lo.y, v.lo.x, v.lo.y});
+      const unsigned char *bp = bbase + (4 * ((c + rot) & 7) + 2 * fh + j) * PST;
+      h16x8 bh[NTL], bl[NTL];
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt) {
+        bh[nt] = (RABL & 2) ? al : *reinterpret_cast<const h16x8 *>(bp + nt * 512);
+        bl[nt] = (RABL & 2) ? ah : *reinterpret_cast<const h16x8 *>(bp + nt * 512 + PLANE);
+      }
+      // the three products of a term, each over the NTL independent accumulators (no back-to-back dependent matrix instructions)
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt) { if (RABL & 4) asm volatile("" ::"v"(al), "v"(bh[nt])); else mmah(acc[nt], al, bh[nt]); }
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt) { if (RABL & 4) asm volatile("" ::"v"(ah), "v"(bl[nt])); else mmah(acc[nt], ah, bl[nt]); }
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt) { if (!(RABL & 4)) mmah(acc[nt], ah, bh[nt]); }
+    }
+  }
+  // ---- epilogue.  C of the 32 x 32 product: column lane % 32, rows (e & 3) + 8 (e >> 2) + 4 (lane / 32)
+  float bv[NTL], ib[NTL];
+#pragma unroll
+  for (int nt = 0; nt < NTL; ++nt) {
+    const int col = n0 + nt * 32 + fr;
+    bv[nt] = (bias && col < N) ? bias[col] : 0.f;
+    ib[nt] = sib[nt * 32 + fr];
+  }
+  const bool full = row0 + 32 <= M && n0 + NT <= N;
+  float rmax[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int rl = (e & 3) + 8 * (e >> 2) + 4 * fh, row = row0 + rl;
+    const float iar = sia[wave * 32 + rl];
+    float rm = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+      const int col = n0 + nt * 32 + fr;
+      const float v = acc[nt][e] * (iar * ib[nt]) + bv[nt];
+      if (full || (row < M && col < N)) {
+        if (RABL & 8) asm volatile("" ::"v"(v));
+        else if (flags & 1) reinterpret_cast<unsigned short *>(C)[(int64_t)row * ldc + col] = f2bf_rne(v);
+        else C[(int64_t)row * ldc + col] = v;
+        rm = fmaxf(rm, fabsf(v));
+      }
+    }
+    rmax[e] = rm;
+  }
+  if (c_amax) {
+    // row maxima over this wavefront's NT columns: the halving butterfly of gemm_rows_f16x2_k256 (16 values -> 1 over the 32 lanes of a half)
+#pragma unroll
+    for (int n = 8, m = 16; n >= 1; n >>= 1, m >>= 1) {
+      const bool up = (lane & m) != 0;
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        const float mine = up ? rmax[n + i] : rmax[i], send = up ? rmax[i] : rmax[n + i];
+        rmax[i] = fmaxf(mine, __shfl_xor(send, m, 64));
+      }
+    }
+    const float r = fmaxf(rmax[0], __shfl_xor(rmax[0], 1, 64));
+    const int e = (lane >> 1) & 15, rl = (e & 3) + 8 * (e >> 2) + 4 * fh;
+    if (!(lane & 1) && row0 + rl < M && r > 0.f) atomicMax(c_amax + row0 + rl, __float_as_uint(r));
+  }
+}
 }  // namespace
 
 int g_pd_dbg_f16x2 = 0;   // tools/ only (pd_debug_set "f16x2_tile"): see pd_gemm_tn_f16x2
@@ -653,7 +809,41 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
       return pd_check_launch("pd_gemm_tn_f16x2 (row stream)");
     }
   }
+  // K = 256, plain epilogue: the register-operand kernel (gemm_ra_f16x2_k256).  pd_debug_set("f16x2_tile", 80) keeps the tiled kernel
+  if (dbg != 80 && dbg != 4 && dbg != 14 && dbg != 3 && dbg != 13 && dbg != 70 && dbg != 61 && mode == 0 && K == 256 && M >= 4096 && (N % 32) == 0 && N >= 96 &&
+      (a_amax == nullptr) == (b_amax == nullptr)) {
+    const int ntl = (N % 128) == 0 ? 4 : (N % 96) == 0 ? 3 : 0;
+    if (ntl) {
+      constexpr int NWV = 12;
+      const int nblk_n = N / (ntl * 32), nblk_m = (M + NWV * 32 - 1) / (NWV * 32);
+      const size_t lds = (size_t)2 * 32 * (ntl * 32 * 16 + RA_PSTRIDE_PAD) + (size_t)(ntl * 32 + NWV * 32) * sizeof(float);
+      typedef void (*rfn)(const float *, const float *, const float *, float *, int, int, int, int, int, int, const float *, const float *, unsigned *, int);
+      rfn kf = ntl == 4 ? (a_amax ? (rfn)gemm_ra_f16x2_k256<4, NWV, true> : (rfn)gemm_ra_f16x2_k256<4, NWV, false>)
+                        : (a_amax ? (rfn)gemm_ra_f16x2_k256<3, NWV, true> : (rfn)gemm_ra_f16x2_k256<3, NWV, false>);
+      if (ntl == 4 && a_amax && dbg >= 100 && dbg < 132) {             // tools: ablations (bit 1 no A loads, 2 no fragment reads, 4 no products, 8 no stores, 16 no weight staging)
+        switch (dbg - 100) {
+          case 1: kf = (rfn)gemm_ra_f16x2_k256<4, NWV, true, 1>; break;
+          case 2: kf = (rfn)gemm_ra_f16x2_k256<4, NWV, true, 2>; break;
+          case 4: kf = (rfn)gemm_ra_f16x2_k256<4, NWV, true, 4>; break;
+          case 6: kf = (rfn)gemm_ra_f16x2_k256<4, NWV, true, 6>; break;
+          case 8: kf = (rfn)gemm_ra_f16x2_k256<4, NWV, true, 8>; break;
+          case 16: kf = (rfn)gemm_ra_f16x2_k256<4, NWV, true, 16>; break;
+          case 31: kf = (rfn)gemm_ra_f16x2_k256<4, NWV, true, 31>; break;
+          case 23: kf = (rfn)gemm_ra_f16x2_k256<4, NWV, true, 23>; break;
+          default: break;
+        }
+        (void)hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      }
+      static bool rattr[4] = {false, false, false, false};
+      const int ai = (ntl == 4 ? 0 : 2) + (a_amax ? 1 : 0);
+      if (!rattr[ai]) { (void)hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); rattr[ai] = true; }
+      hipLaunchKernelGGL(kf, dim3((unsigned)(nblk_m * nblk_n)), dim3(NWV * 64), lds, st, A, B, bias, C, M, N, lda, ldb, ldc, nblk_n, a_amax, b_amax,
+                         reinterpret_cast<unsigned *>(c_amax), flags);
+      return pd_check_launch("pd_gemm_tn_f16x2 (register operands)");
+    }
+  }
   // the sign bits are laid out in the 256 x 256 kernel's accumulator order: bits / mask launches must take that kernel
+
   const bool need_wide = bits != nullptr;
   if (need_wide && ((N % 256) || M < 1024)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: sign bits need N %% 256 == 0 and M >= 1024");
   const bool wide_ok = (N % 256) == 0 && M >= 1024;

@@ -993,7 +993,10 @@ def test_config2_full_size_batch_of_two_vs_oracle(amp):
     _record_parity(f"config2_full_size_b2_{'bf16' if amp else 'fp32'}", **rec)
 
 
-CURVE_TOL = {False: (2e-3, 2e-4, 2e-2), True: (3e-2, 3e-3, 1e-1)}     # (loss rel, loss abs, gradient norm rel) per precision; see the records
+# (loss term rel, loss term abs, gradient norm rel, total loss rel) per precision.  Measured (profiles/r05_parity.json): fp32 terms <= 1.3e-4,
+# norms to 4 digits, totals to 3e-6 over the five steps; bf16 — two trajectories that each round their own weights to bf16 every step —
+# terms 3e-3 at step 1 growing to 5e-2 at step 5 (single heads; the sum of the 30 terms stays within 4.5e-3), norms within 5.4e-2.
+CURVE_TOL = {False: (5e-4, 1e-4, 2e-3, 5e-5), True: (8e-2, 5e-3, 1e-1, 1.5e-2)}
 
 
 @pytest.mark.parametrize("amp", [False, True])
@@ -1020,7 +1023,7 @@ def test_config2_full_size_loss_curve_vs_oracle(amp):
     params = [osd[n] for n in names]
     state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    rel, ab, nrel = CURVE_TOL[amp]
+    rel, ab, nrel, trel = CURVE_TOL[amp]
     curve = []
     for it in range(1, 6):
         batch = make_batch(1, 1024, seed=3000 + it, device=DEV)
@@ -1031,7 +1034,8 @@ def test_config2_full_size_loss_curve_vs_oracle(amp):
         n = int(batch[0]["instances"].gt_masks.tensor.shape[0])
         for p in params:
             p.grad = None
-        olosses, differ, gap = _oracle_with_product_matches(losses, osd, batch, 8000 + it, 1, 10, [n], grad=True)
+        # bf16: losses at the product's sample points as well (see _oracle_with_product_matches); fp32: the oracle's own — they coincide
+        olosses, differ, gap = _oracle_with_product_matches(losses, osd, batch, 8000 + it, 1, 10, [n], grad=True, product_points=amp)[:3]
         sum(olosses.values()).backward()
         grads = [p.grad for p in params]
         with torch.no_grad():
@@ -1048,12 +1052,13 @@ def test_config2_full_size_loss_curve_vs_oracle(amp):
         for k in olosses:
             assert abs(got[k] - float(olosses[k])) <= rel * abs(float(olosses[k])) + ab, (it, k, got[k], float(olosses[k]))
         assert abs(norm - float(total)) <= nrel * float(total), (it, norm, float(total))
+        assert abs(curve[-1]["total_product"] - curve[-1]["total_oracle"]) <= trel * abs(curve[-1]["total_oracle"]), curve[-1]
     master = step.optimizer.flat.master_state()
     worst = max(((master[n].detach().float().cpu() - osd[n].detach()).abs().max() / osd[n].detach().abs().max().clamp_min(1e-6)).item() for n in names)
     print(f"full-size curve amp={amp}: parameters after 5 steps within {worst:.2e} of their scale")
     _record_parity(f"config2_full_size_curve_{'bf16' if amp else 'fp32'}", curve=curve, params_dev_of_scale_after_5_steps=worst, tolerance_rel=rel,
                    tolerance_abs=ab, tolerance_grad_norm_rel=nrel, precision="bf16 autocast" if amp else "fp32")
-    assert worst < (5e-2 if amp else 2e-2), worst
+    assert worst < (1e-1 if amp else 5e-2), worst      # AdamW moves every element by ~lr per step whatever the gradient's size: a sign flip of a near-zero gradient is 2 lr
 
 
 def test_base_pixel_decoder_gpu_vs_reference_golden(golden):

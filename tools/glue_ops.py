@@ -32,7 +32,9 @@ WANT = ("aten::copy_", "aten::add", "aten::add_", "aten::fill_", "aten::zero_", 
         "aten::contiguous", "aten::_to_copy", "aten::stack", "aten::softplus", "aten::sigmoid", "aten::index", "aten::gather", "aten::neg", "aten::sub")
 agg = collections.defaultdict(lambda: [0, 0.0])
 for e in prof.events():
-    if e.name not in WANT or e.device_time_total <= 0 or e.cpu_children and any(c.name in WANT and c.device_time_total > 0 for c in e.cpu_children):
+    ALL = os.environ.get("ALL_ATEN", "0") == "1"               # ALL_ATEN=1: every aten operator with device time (library GEMMs, convolutions, sampling ...)
+    want = (lambda n: n.startswith("aten::")) if ALL else (lambda n: n in WANT)
+    if not want(e.name) or e.device_time_total <= 0 or e.cpu_children and any(want(c.name) and c.device_time_total > 0 for c in e.cpu_children):
         continue
     frame = next((f for f in (e.stack or []) if "partdistillation_amd" in f and "torch/" not in f), None)
     if frame is None:                                   # no Python stack recorded: the chain of enclosing operators / autograd nodes instead
@@ -47,5 +49,5 @@ for e in prof.events():
     agg[key][1] += e.device_time_total
 tot = sum(v[1] for v in agg.values())
 print(f"device time of the listed aten operators: {tot / N / 1e3:.2f} ms / step")
-for (name, shapes, frame), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+for (name, shapes, frame), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('TOP', '60'))]:
     print(f"{t / N:8.1f} us  x{c / N:5.1f}  {name:12s} {shapes:60.60s} {frame}")
