@@ -809,8 +809,14 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
       return pd_check_launch("pd_gemm_tn_f16x2 (row stream)");
     }
   }
-  // K = 256, plain epilogue: the register-operand kernel (gemm_ra_f16x2_k256).  pd_debug_set("f16x2_tile", 80) keeps the tiled kernel
-  if (dbg != 80 && dbg != 4 && dbg != 14 && dbg != 3 && dbg != 13 && dbg != 70 && dbg != 61 && mode == 0 && K == 256 && M >= 4096 && (N % 32) == 0 && N >= 96 &&
+  // K = 256, plain epilogue: the register-operand kernel (gemm_ra_f16x2_k256) — EXPERIMENTAL, pd_debug_set("f16x2_tile", 90) (100 + bits: its
+  // ablations).  Correct (tests/test_gemm_gpu.py) and SLOWER than the tiled kernel: 35.6 vs 30.4 us at 43 008 x 256 <- 256, 99.6 vs 77.5 at 131 072
+  // rows, 123 vs 91 at N = 1024.  Its ablation (tools/debug/ra_ablate.py, 32 768 rows, one round of 172 workgroups): 8.9 us with every load,
+  // product and store removed (launch + weight staging skeleton), 14.8 with only the C stores, +6 for the A loads, +5 for the weight staging,
+  // +7 for fragments and products — the kernel's phases ADD UP: one 132 KB workgroup per CU, one round, every workgroup stages, loads,
+  // multiplies and stores in step with all the others, so memory is either read or written, never both.  The per-CU share of these shapes
+  // (168 rows x 256 columns) is ~10 us of work under ~20 us of fixed cost, whatever the operand path; see DESIGN.md (round 5).
+  if ((dbg == 90 || (dbg >= 100 && dbg < 132)) && mode == 0 && K == 256 && M >= 4096 && (N % 32) == 0 && N >= 96 &&
       (a_amax == nullptr) == (b_amax == nullptr)) {
     const int ntl = (N % 128) == 0 ? 4 : (N % 96) == 0 ? 3 : 0;
     if (ntl) {

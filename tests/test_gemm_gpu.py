@@ -317,6 +317,34 @@ def test_gemm_tn_h2_row_stream_matches_the_tiled_kernel(M, N, K, scaled):
     assert torch.equal(cm, got.abs().amax(1))
 
 
+@pytest.mark.parametrize("M,N,K", [(8300, 256, 256), (9001, 288, 256), (13000, 1024, 256)])
+@pytest.mark.parametrize("scaled", [True, False])
+def test_gemm_tn_h2_register_operand_kernel_matches_the_tiled_kernel(M, N, K, scaled):
+    """gemm_ra_f16x2_k256 (round 5, experimental: A rows global -> registers -> matrix cores, the weight block resident in LDS;
+    pd_debug_set("f16x2_tile", 90)): fp32-accurate against fp64, exact row maxima, ragged last row block, 128- and 96-column blocks."""
+    from partdistillation_amd import lib
+    from partdistillation_amd.functions import gemm
+    torch.manual_seed(M + N)
+    a = torch.randn(M, K, device="cuda") * (torch.logspace(-3, 3, M, device="cuda")[torch.randperm(M, device="cuda"), None] if scaled else 1.0)
+    w = torch.randn(N, K, device="cuda") * K ** -0.5
+    b = torch.randn(N, device="cuda")
+    ref = torch.addmm(b.double(), a.double(), w.double().t())
+    rown = ref.abs().amax(1, keepdim=True)
+    aa, wa = (gemm.row_amax(a), gemm.row_amax(w)) if scaled else (None, None)
+    tiled = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
+    lib.load().pd_debug_set(b"f16x2_tile", 90)
+    try:
+        cm = torch.zeros(M, device="cuda")
+        got = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa, c_amax=cm)
+        again = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
+    finally:
+        lib.load().pd_debug_set(b"f16x2_tile", 0)
+    assert torch.equal(got, again)
+    assert ((got.double() - ref).abs() / rown).max().item() < 3e-6
+    assert ((got.double() - tiled.double()).abs() / rown).max().item() < 1e-6
+    assert torch.equal(cm, got.abs().amax(1))
+
+
 def test_gemm_tn_h2_relu_bits_and_mask_epilogues():
     from partdistillation_amd.functions import gemm
     torch.manual_seed(5)

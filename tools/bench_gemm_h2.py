@@ -19,9 +19,9 @@ for M, N, K in [(43008, 256, 256), (43008, 288, 256), (43500, 256, 256), (131072
         err = lambda y: ((y.double() - ref).abs().max().item() / scale)
         y_lib = torch.addmm(b, a, w.t()); y_x3 = gemm.gemm_tn_x3(a, w, b)
         res = []
-        for tile in (0, 80, 70, 61, 13, 4):
+        for tile in (0, 90, 70, 61, 13, 4):
             if tile in (1, 3, 13, 5, 15, 51, 52) and (N % 256 or M < 1024): continue
-            # 0: the product's choice (K = 256: register operands; else interleaved interior step); 80: the tiled kernel where 0 takes the register-operand one; 70: the guarded step by shape; 61: the row stream where it applies; 13 / 4: forced wide / narrow tiles, guarded step
+            # 0: the product's choice (interleaved interior step); 90: the experimental register-operand kernel where it applies (K = 256); 70: the guarded step by shape; 61: the row stream where it applies; 13 / 4: forced wide / narrow tiles, guarded step
             L.pd_debug_set(b"f16x2_tile", tile)
             y = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
             cm = torch.zeros(M, device="cuda"); y2 = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa, c_amax=cm)
