@@ -27,20 +27,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# MIOpen's algorithm-search results for this workload's conv shapes ship with the repo (tuning data, like a built
-# artefact): warm-up then skips the exhaustive search on a fresh box.  Must be set before MIOpen initialises.
-_MIOPEN_DB = os.path.join(ROOT, "partdistillation_amd", "miopen_db")
-if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "MIOPEN_USER_DB_PATH" not in os.environ:
-    # one private copy per rank: N processes appending to the same user-db files would serialise on MIOpen's file locks
-    import shutil
+# No shipped MIOpen find-db any more (round 5: the stem was the last library convolution of this workload).  Paths that still reach MIOpen
+# (PD_OWN_STEM=0, PD_R50_FUSED=0 comparisons) keep their search results in a private per-rank directory.
+if "MIOPEN_USER_DB_PATH" not in os.environ:
     import tempfile
-    _dst = os.path.join(tempfile.gettempdir(), "pd_miopen_db_rank" + os.environ.get("LOCAL_RANK", "0"))
-    try:
-        shutil.copytree(_MIOPEN_DB, _dst, dirs_exist_ok=True)
-        _MIOPEN_DB = _dst
-    except OSError:
-        pass
-os.environ.setdefault("MIOPEN_USER_DB_PATH", _MIOPEN_DB)
+    os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(tempfile.gettempdir(), "pd_miopen_db_rank" + os.environ.get("LOCAL_RANK", "0"))
+    os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
 if any(x == "--graph" and sys.argv[i + 1:i + 2] not in ([], ["0"]) or (x.startswith("--graph=") and x != "--graph=0")
        for i, x in enumerate(sys.argv)):
     os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"          # must precede the first HIP call; see TrainStep.capture()

@@ -33,6 +33,7 @@
 #include "pd_optim.h"
 #include "pd_rowwise.h"
 #include "pd_smallgemm.h"
+#include "pd_stem.h"
 #include "pd_swin.h"
 #include "pd_window_attention.h"
 
@@ -162,6 +163,8 @@ const Entry kTable[] = {
   PD_E(pd_sgemm_wgrad_grouped_bf16),
   PD_E(pd_sgemm_wgrad_split_bf16),
   PD_E(pd_split3_bf16),
+  PD_E(pd_stem7x7_fwd),
+  PD_E(pd_stem7x7_wgrad),
   PD_E(pd_sum3_sum2_f32),
   PD_E(pd_sumsq_accumulate),
   PD_E(pd_swin_ln_bwd),

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libpd_hip.so") 
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -22,6 +22,9 @@ SIGNATURES = {
     "pd_msda_forward": (_c_int, [_c_vp] * 6 + [_c_int] * 9 + [_c_vp]),
     "pd_msda_backward": (_c_int, [_c_vp] * 9 + [_c_int] * 9 + [_c_vp]),
     "pd_msda_backward_last_gate": (_c_int, [_c_vp]),
+    "pd_stem7x7_fwd": (_c_int, [_c_vp, _c_int] + [_c_vp] * 4 + [_c_int] * 4 + [_c_vp]),
+    "pd_stem_wgrad_workspace_floats": (ctypes.c_int64, []),
+    "pd_stem7x7_wgrad": (_c_int, [_c_vp, _c_int] + [_c_vp] * 4 + [_c_int, _c_vp] + [_c_int] * 4 + [_c_vp]),
     "pd_msda_fused_supported": (_c_int, [_c_int] * 7),
     "pd_msda_fused_forward": (_c_int, [_c_vp] * 4 + [_c_int] + [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
     "pd_msda_fused_backward": (_c_int, [_c_vp] * 4 + [_c_int] + [_c_vp] * 6 + [_c_int, _c_vp, _c_vp] + [_c_int] * 7 + [_c_vp]),

@@ -16,9 +16,11 @@ import torch.nn.functional as F
 from ...compat import BACKBONE_REGISTRY, ShapeSpec
 from ...compat.layers import Conv2d, FrozenBatchNorm2d, c2_msra_fill, get_norm
 from ...functions import conv_bf16
+from ...functions import stem as _stem
 from ...functions.fused import affine_act, max_pool3x3s2, max_pool3x3s2_supported
 
 OWN_MAXPOOL = bool(int(__import__("os").environ.get("PD_OWN_MAXPOOL", "1")))    # the stem's max pooling on pd_maxpool3s2_{fwd,bwd}_bf16 (0: ATen)
+OWN_STEM = bool(int(__import__("os").environ.get("PD_OWN_STEM", "1")))          # the 7 x 7 stem on pd_stem7x7_{fwd,wgrad} (0: MIOpen + pd_affine_act)
 OWN_WGRAD = bool(int(__import__("os").environ.get("PD_CONV_OWN_WGRAD", "1")))   # 0: MIOpen's filter gradients (tools/ comparisons)
 
 
@@ -62,7 +64,10 @@ class BasicStem(nn.Module):
         c2_msra_fill(self.conv1)
 
     def forward(self, x):
-        x = _conv_bn_act(self.conv1, x)
+        if OWN_STEM and _stem.supported(x, self.conv1):
+            x = _stem.stem_conv(x, self.conv1)                      # convolution + frozen-BN affine + ReLU: one launch (include/pd_stem.h)
+        else:
+            x = _conv_bn_act(self.conv1, x)
         if OWN_MAXPOOL and max_pool3x3s2_supported(x):
             return max_pool3x3s2(x)
         return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)

@@ -154,7 +154,6 @@ def test_object_class_is_part_of_the_signature_only_where_the_step_reads_it():
 
 if __name__ == "__main__":
     sys.path.insert(0, ROOT)
-    os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "partdistillation_amd", "miopen_db"))
     globals()[sys.argv[1]]()
     torch.cuda.synchronize()
     print("ok", sys.argv[1])

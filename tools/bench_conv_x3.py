@@ -3,7 +3,6 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
-os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "partdistillation_amd", "miopen_db"))
 from partdistillation_amd import lib; lib.load()
 from partdistillation_amd.functions import conv_x3
 torch.backends.cudnn.benchmark = True

@@ -14,7 +14,6 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--classes", type=int, default=100)
 ap.add_argument("--per-class", type=int, default=400)
 a = ap.parse_args()
-os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "partdistillation_amd", "miopen_db"))
 from partdistillation_amd import lib
 lib.load()
 import partdistillation_amd.modeling, partdistillation_amd.part_ranking_model  # noqa: F401,E401

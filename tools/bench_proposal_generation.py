@@ -14,7 +14,6 @@ ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--amp", type=int, default=0, help="1: bf16 autocast for the backbone")
 a = ap.parse_args()
-os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "partdistillation_amd", "miopen_db"))
 from partdistillation_amd import lib
 lib.load()
 import partdistillation_amd.modeling, partdistillation_amd.proposal_generation_model  # noqa: F401,E401

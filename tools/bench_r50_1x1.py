@@ -2,7 +2,6 @@
 bf16 kernels (sgemm_tn / sgemm_nn / wgrad_split) against MIOpen's conv (tools/bench_r50_convs.py), device time per call."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(ROOT, 'partdistillation_amd', 'miopen_db'))
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, ROOT)

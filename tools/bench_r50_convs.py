@@ -3,7 +3,6 @@ R50: stride on the 3x3), bf16 channels_last, timed through torch (MIOpen) forwar
 floors beside it.  python tools/bench_r50_convs.py [--size 1024] [--batch 2]"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(ROOT, 'partdistillation_amd', 'miopen_db'))
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, ROOT)

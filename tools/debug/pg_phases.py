@@ -2,7 +2,6 @@ import os, sys, time, json
 ROOT = "/root/repo"
 sys.path.insert(0, ROOT)
 import torch
-os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "partdistillation_amd", "miopen_db"))
 from partdistillation_amd import lib; lib.load()
 import partdistillation_amd.modeling, partdistillation_amd.proposal_generation_model as pgm
 from partdistillation_amd.compat import BitMasks, Instances, build_model

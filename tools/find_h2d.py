@@ -3,7 +3,6 @@ line that issued it.  A pageable source inside a hipGraph-captured region is a b
 that was a temporary."""
 import os, sys, traceback, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(ROOT, 'partdistillation_amd', 'miopen_db'))
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 from torch.utils._pytree import tree_flatten

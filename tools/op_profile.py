@@ -120,7 +120,6 @@ def main():
     ap.add_argument("--top", type=int, default=70)
     ap.add_argument("--out", default="gpurun_out/op_profile.txt")
     a = ap.parse_args()
-    os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "partdistillation_amd", "miopen_db"))
     from partdistillation_amd import lib
     lib.load()
     from partdistillation_amd.config import setup_cfg
