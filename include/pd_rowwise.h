@@ -155,6 +155,12 @@ int pd_upsample2x_bwd_nhwc_f32(const float *dy, float *dlo, int B, int h, int w,
 int pd_resize_bilinear_nhwc_f32(const float *x, int B, int H, int W, int C, const int *heights, const int *widths, void *const *outs, int count,
                                 int out_dtype, void *stream);
 
+
+/* q = a + b (fp32 [rows, cols], cols % 4 == 0), optionally a_copy = a, and the absolute maxima of every row of a and of q (the row scales of
+ * pd_gemm_tn_f16x2, pd_gemm.h) in ONE pass: the entry of the pixel decoder's encoder (reference msdeformattn.py:120 `with_pos_embed(src, pos)`:
+ * query = src + pos feeds the offset / weight projections, src the value projection). */
+int pd_add_rows_amax_f32(const float *a, const float *b, float *q, float *a_copy, float *a_amax, float *q_amax, int rows, int cols, void *stream);
+
 /* out1 = (a + b) + c, out2 = d + c over n fp32 elements (n % 4 == 0, 16-byte aligned): the three elementwise sums that end the encoder's backward
  * (d(src) = its three terms, d(pos) = accumulator + last term; reference msdeformattn.py:41-42 `with_pos_embed` backward) as one launch */
 int pd_sum3_sum2_f32(const float *a, const float *b, const float *c, const float *d, float *out1, float *out2, int64_t n, void *stream);

@@ -71,6 +71,7 @@ const Entry kTable[] = {
   PD_E(pd_add_layernorm_bwd_amax),
   PD_E(pd_add_layernorm_fwd),
   PD_E(pd_add_layernorm_fwd_amax),
+  PD_E(pd_add_rows_amax_f32),
   PD_E(pd_affine_act_bwd2_bf16),
   PD_E(pd_affine_act_bwd_bf16),
   PD_E(pd_affine_act_fwd_bf16),

@@ -830,6 +830,30 @@ __global__ __launch_bounds__(256) void transpose_batched_f32(TrBatch tb)
 }
 
 // out1 = (a + b) + c and out2 = d + c in one pass (the end of the encoder's backward: d(src) from its three fp32 terms, d(pos) from its
+
+// the encoder's entry in one pass (was an ATen add, two device-to-device copies and two row-maxima launches): q = a + b, an optional copy
+// of a (the recorded region needs its first operand at an address of its own), and the absolute maxima of the rows of a and of q — the
+// row scales of the two-plane GEMMs that read them.  One wavefront per row, 16 bytes per lane and pass.
+__global__ __launch_bounds__(256) void add_rows_amax_f32(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ q,
+                                                         float *__restrict__ a_copy, float *__restrict__ a_amax, float *__restrict__ q_amax,
+                                                         int rows, int cols)
+{
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int64_t base = (int64_t)row * cols;
+  float ma = 0.f, mq = 0.f;
+  for (int c = lane * 4; c < cols; c += 256) {
+    const float4 x = ld4(a + base + c), y = ld4(b + base + c);
+    const float4 s = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    st4(q + base + c, s);
+    if (a_copy) st4(a_copy + base + c, x);
+    ma = fmaxf(ma, amax4(x)); mq = fmaxf(mq, amax4(s));
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, o, 64)); mq = fmaxf(mq, __shfl_xor(mq, o, 64)); }
+  if (lane == 0) { a_amax[row] = ma; q_amax[row] = mq; }
+}
+
 // accumulator and the last term — three ATen launches over [43 008, 256] before)
 __global__ __launch_bounds__(256) void sum3_sum2_f32(const float4 *__restrict__ a, const float4 *__restrict__ b, const float4 *__restrict__ c,
                                                      const float4 *__restrict__ d, float4 *__restrict__ o1, float4 *__restrict__ o2, int64_t n4)
@@ -1220,6 +1244,17 @@ extern "C" int pd_resize_bilinear_nhwc_f32(const float *x, int B, int H, int W, 
   if (out_dtype == PD_BF16) hipLaunchKernelGGL(resize_bilinear_nhwc_multi<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, x, B, H, W, C / 4, lv);
   else hipLaunchKernelGGL(resize_bilinear_nhwc_multi<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, x, B, H, W, C / 4, lv);
   return pd_check_launch("pd_resize_bilinear_nhwc_f32");
+}
+
+extern "C" int pd_add_rows_amax_f32(const float *a, const float *b, float *q, float *a_copy, float *a_amax, float *q_amax, int rows, int cols,
+                                    void *stream_)
+{
+  if (rows < 0 || cols <= 0 || (cols & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_rows_amax_f32: rows=%d cols=%d (a multiple of 4)", rows, cols);
+  if (rows == 0) return PD_OK;
+  if (!a || !b || !q || !a_amax || !q_amax || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)q | (uintptr_t)a_copy) & 15))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_add_rows_amax_f32: null / misaligned pointer");
+  hipLaunchKernelGGL(add_rows_amax_f32, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, a, b, q, a_copy, a_amax, q_amax, rows, cols);
+  return pd_check_launch("pd_add_rows_amax_f32");
 }
 
 extern "C" int pd_sum3_sum2_f32(const float *a, const float *b, const float *c, const float *d, float *out1, float *out2, int64_t n, void *stream_)

@@ -207,13 +207,13 @@ class EncoderCore(Function):
         pos2 = pos2 if pos2.is_contiguous() else pos2.contiguous()
         ref = spec.ref.reshape(T, L, 2)
         ref = ref if ref.is_contiguous() else ref.contiguous()
-        q = src2 + pos2
         saved = []
         x = src2
         h2 = H2 and USE_X3 and X3_PROJ and src2.is_cuda and C % 4 == 0
         ctx.h2 = h2
-        if h2:
-            return EncoderCore._forward_h2(ctx, spec, src2, pos2, q, ref, params, (B, S, C, nl))
+        if h2:                                  # (query = src + pos is formed inside, with the operands' row maxima: pd_add_rows_amax_f32)
+            return EncoderCore._forward_h2(ctx, spec, src2, pos2, None, ref, params, (B, S, C, nl))
+        q = src2 + pos2
         for i in range(nl):
             (so_w, so_b, aw_w, aw_b, vp_w, vp_b, op_w, op_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b) = params[i * N_LAYER:(i + 1) * N_LAYER]
             value = _proj(x, vp_w, vp_b)
@@ -262,7 +262,7 @@ class EncoderCore(Function):
             ctx.rec = None
             x, saved, saved_am = EncoderCore._layers_h2(spec, src2, pos2, q, ref, wk, b_oa_all, l2_all, params, dims)
         else:
-            slots = [src2, pos2, q, ref, wk, b_oa_all, l2_all, spec.shapes, spec.lsi] + list(params)
+            slots = [src2, pos2, ref, wk, b_oa_all, l2_all, spec.shapes, spec.lsi] + list(params)
             key = ("fwd", B, S, C, nl, spec.M, spec.L, spec.P, str(src2.device), _lib.current_stream())
             rec = _RECS.get(key)
             if rec is None or not rec.matches(slots):
@@ -287,16 +287,26 @@ class EncoderCore(Function):
         P_ = lambda i, j: params[i * N_LAYER + j]
         n_off, n_aw, n_l1 = P_(0, 0).shape[0], P_(0, 2).shape[0], P_(0, 10).shape[0]
         per = n_off + n_aw + 2 * C + n_l1
-        if cmdbuf.active() is not None:
-            # the backward pass writes the addresses of layer 0's operands into the host-side table of its grouped weight-gradient
-            # launch: they must be arena memory, not this step's input tensors
-            src2, q = rw.copy_d2d(torch.empty_like(src2), src2), rw.copy_d2d(torch.empty_like(q), q)
+        x_am = q_am = None
+        if q is None and src2.dtype == torch.float32 and pos2.dtype == torch.float32 and C % 4 == 0:
+            # q = src + pos, both operands' row maxima and — inside a recording — a copy of src at an arena address (the backward pass
+            # writes the addresses of layer 0's operands into the host-side table of its grouped weight-gradient launch) in ONE launch
+            q, src_c, x_am, q_am = rw.add_rows_amax(src2, pos2, copy_a=cmdbuf.active() is not None)
+            src2 = src_c if src_c is not None else src2
+        else:
+            if q is None:
+                assert cmdbuf.active() is None
+                q = src2 + pos2
+            if cmdbuf.active() is not None:
+                src2, q = rw.copy_d2d(torch.empty_like(src2), src2), rw.copy_d2d(torch.empty_like(q), q)
         wk_am = row_amax(wk)
         l2_am = row_amax(l2_all)
         fwd_amax = C // M == 32 and L == 3 and P == 4 and src2.dtype == torch.float32       # the MSDA kernel that can emit its rows' maxima
         zam = torch.zeros((2 * nl if fwd_amax else nl, T), dtype=torch.float32, device=src2.device)   # atomic-max targets: FFN epilogues, MSDA outputs
         h_am_all, a_am_all = zam[:nl], (zam[nl:] if fwd_amax else None)
-        x, x_am, q_am = src2, row_amax(src2), row_amax(q)
+        x = src2
+        if x_am is None:
+            x_am, q_am = row_amax(src2), row_amax(q)
         saved, saved_am = [], []
         for i in range(nl):
             (so_w, so_b, aw_w, aw_b, vp_w, vp_b, op_w, op_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b) = params[i * N_LAYER:(i + 1) * N_LAYER]

@@ -90,6 +90,18 @@ def copy_d2d(dst, src):
     return dst
 
 
+def add_rows_amax(a, b, copy_a=False):
+    """-> (q = a + b, a copy of a or None, row maxima of a, row maxima of q): fp32 [rows, cols] contiguous, one launch (pd_add_rows_amax_f32)"""
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2
+    q = torch.empty_like(a)
+    ac = torch.empty_like(a) if copy_a else None
+    am = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
+    qm = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().pd_add_rows_amax_f32(a.data_ptr(), b.data_ptr(), q.data_ptr(), ac.data_ptr() if ac is not None else None, am.data_ptr(),
+                                                qm.data_ptr(), a.shape[0], a.shape[1], _stream()))
+    return q, ac, am, qm
+
+
 def colsum_acc(x, acc):
     """acc[N] (fp32) += x.sum(0); x [rows, N] contiguous."""
     assert x.is_contiguous() and acc.dtype == torch.float32 and acc.numel() == x.shape[1]

@@ -95,6 +95,7 @@ SIGNATURES = {
     "pd_mem_prep_fwd": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "pd_mem_prep_bwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
     "pd_attn_mask_u8": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "pd_add_rows_amax_f32": (_c_int, [_c_vp] * 6 + [_c_int, _c_int, _c_vp]),
     "pd_sum3_sum2_f32": (_c_int, [_c_vp] * 6 + [ctypes.c_int64, _c_vp]),
     "pd_transpose_batched_f32": (_c_int, [_c_vp, _c_int, _c_vp]),
     "pd_normalize_u8_nhwc": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),

@@ -458,3 +458,16 @@ def test_gradient_gather_mixed_dtypes_and_sum_of_squares():
             assert torch.equal(flat[o:o + n], ref)
             want += float(ref.double().pow(2).sum())
         assert abs(float(ss) - want) <= 1e-6 * want
+
+
+def test_add_rows_amax_one_pass_equals_the_separate_ops():
+    """pd_add_rows_amax_f32: q = a + b, the optional copy of a and both row maxima equal the ATen add / copy / abs-max (bit for bit)."""
+    from partdistillation_amd.functions import rowwise as rw
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for rows, cols in ((43, 256), (1000, 64), (7, 1024)):
+        a = torch.randn(rows, cols, device="cuda", generator=g) * torch.logspace(-3, 3, rows, device="cuda")[:, None]
+        b = torch.randn(rows, cols, device="cuda", generator=g)
+        for cp in (False, True):
+            q, ac, am, qm = rw.add_rows_amax(a, b, copy_a=cp)
+            assert torch.equal(q, a + b) and torch.equal(am, a.abs().amax(1)) and torch.equal(qm, (a + b).abs().amax(1))
+            assert (ac is None) == (not cp) and (ac is None or (torch.equal(ac, a) and ac.data_ptr() != a.data_ptr()))
