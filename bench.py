@@ -103,7 +103,8 @@ def oracle_parity(parity_file):
 
 
 def cpu_baseline(cfg_opts, size, seconds_budget=90.0, threads=None, parity_file=None):
-    """time the oracle's training step (fwd + criterion + bwd + clipped AdamW), 1 image, on the host cores."""
+    """time the oracle's training step (fwd + criterion + bwd + clipped AdamW) on the host cores: the benchmarked batch of 2 images when
+    that fits the time budget, else one image."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import common as C
     from oracle import step_ref as R
@@ -124,8 +125,8 @@ def cpu_baseline(cfg_opts, size, seconds_budget=90.0, threads=None, parity_file=
         sd[k].requires_grad_(True)
     del model
 
-    def one_step(s):
-        batch = make_batch(1, s, seed=1234, device="cpu")
+    def one_step(s, nb=1):
+        batch = make_batch(nb, s, seed=1234, device="cpu")
         obatch = [{"image": b["image"], "instances": {"gt_masks": b["instances"].gt_masks.tensor}} for b in batch]
         g = torch.Generator().manual_seed(0)
         rand = lambda shape: torch.rand(shape, generator=g)
@@ -152,6 +153,10 @@ def cpu_baseline(cfg_opts, size, seconds_budget=90.0, threads=None, parity_file=
             parity = oracle_parity(parity_file)
         except Exception as e:                   # noqa: BLE001 - the baseline timing must survive a parity failure
             parity = {"error": repr(e)}
+    if 2.2 * est <= seconds_budget:              # the GPU line's own batch: 2 images per step
+        dt = one_step(size, 2)
+        sample = f"2 images {size}x{size} (the benchmarked batch), one full step (fwd+criterion+bwd+clipped AdamW), fp32"
+        return {"value": 2.0 / dt, "unit": "images/s", "cores": cores, "kind": "port", "sample": sample, "seconds": dt, "_parity": parity}
     if est <= seconds_budget:
         dt, sample = one_step(size), (f"1 image {size}x{size}, one full step (fwd+criterion+bwd+clipped AdamW), fp32 - deviation from SURVEY 8(d): "
                                       "the GPU line steps bs=2 per GPU, the CPU sample is ONE image (value is images/s, so the ratio is per image)")
@@ -575,6 +580,19 @@ def main():
                     os.remove(parity_file)
                 except OSError:
                     pass
+        if world == 1 and not a.no_cpu_baseline and not freeze and not a.opts and (a.batch, a.size) == (2, 1024):
+            # the shipped scripts' setting (reference sh_files/proposal_learning/train_multi.sh:8: FREEZE_KEYS backbone + encoder) next to the
+            # full fine-tune the line reports (SURVEY 8d asks for both): the same bench in a child process, timing only
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--freeze", "backbone,encoder", "--steps", str(a.steps), "--warmup", str(a.warmup),
+                                    "--no-cpu-baseline", "--no-categories", "--no-parity", "--skip-kernel-timing"], stdout=subprocess.PIPE,
+                                   stderr=subprocess.DEVNULL, timeout=600, text=True).stdout
+                fz = next((json.loads(l) for l in r.splitlines()[::-1] if l.startswith('{"metric"')), None)
+                out["frozen_backbone_encoder"] = ({"value": fz["value"], "unit": fz["unit"], "ms_per_step": fz["ms_per_step"], "steps": fz["steps"],
+                                                   "finetune": fz["config"]["finetune"]} if fz else {"error": "no line from the child"})
+            except Exception as e:                      # noqa: BLE001 - an extra key must never take the line down
+                out["frozen_backbone_encoder"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1 or force:
         dist.destroy_process_group()
