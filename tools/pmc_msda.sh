@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_msda; mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -o p -- python tools/bench_msda.py --iters 10 --px 0.5 --fused ${FUSED:-1} > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -o p -- python tools/bench_msda.py --iters 10 --px 0.5 --fused ${FUSED:-1} --ablate ${ABLATE:-0} --variant ${VARIANT:-0} > /dev/null 2>&1
   cp /tmp/pmc_$C/p_counter_collection.csv $OUT/${C}.csv 2>/dev/null
 done
 python - <<'PY'
