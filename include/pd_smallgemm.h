@@ -42,6 +42,12 @@ int pd_sgemm_tn_splitk_bf16(const void *X, const void *W, const void *bias, void
 int pd_sgemm_nn_splitn_bf16(const void *dY, const void *W, const void *relu_ref, void *dX, float *workspace, int64_t workspace_floats,
                             int *tickets, int M, int N, int K, int ldy, int ldw, int ldx, int accumulate, void *stream);
 
+/* `batch` equally shaped products Y_b [M, N] = X_b [M, K] W_b [N, K]^T (bf16, fp32 accumulation, K <= 256 and % 64 == 0, N % 4 == 0) in one
+ * launch; element strides between consecutive problems.  The matcher's point logits of all (image, head) problems
+ * (reference matcher.py:108-125: out_mask = point_sample(pred_masks) = mask_embed . point_sample(mask_features)). */
+int pd_sgemm_tn_batched_bf16(const void *X, const void *W, void *Y, int M, int N, int K, int ldx, int ldw, int ldy, int batch,
+                             int64_t stride_x, int64_t stride_w, int64_t stride_y, void *stream);
+
 /* Up to four independent pd_sgemm_tn_bf16 products with a common K <= 256 (K % 64 == 0) in ONE launch: the q / k / v projections of an
  * attention block (two inputs, three slices of the packed in_proj weight; reference mask2former_transformer_decoder.py:44-54, 102-114
  * through nn.MultiheadAttention).  Rows may differ per problem (the cross-attention's keys / values run over the memory tokens). */

@@ -113,6 +113,8 @@ const Entry kTable[] = {
   PD_E(pd_kmeans_reduce),
   PD_E(pd_kmeans_reduce_update),
   PD_E(pd_kmeans_update),
+  PD_E(pd_layernorm_rows_f32_bwd),
+  PD_E(pd_layernorm_rows_f32_fwd),
   PD_E(pd_lsa_batched),
   PD_E(pd_mask_assign),
   PD_E(pd_mask_point_losses_bwd),
@@ -157,6 +159,7 @@ const Entry kTable[] = {
   PD_E(pd_scores_argmax_u8),
   PD_E(pd_sgemm_nn_bf16),
   PD_E(pd_sgemm_nn_splitn_bf16),
+  PD_E(pd_sgemm_tn_batched_bf16),
   PD_E(pd_sgemm_tn_bf16),
   PD_E(pd_sgemm_tn_multi_bf16),
   PD_E(pd_sgemm_tn_splitk_bf16),

@@ -101,8 +101,10 @@ constexpr int PK256 = 256 + 8;                                               // 
 template <bool RELU>
 __global__ __launch_bounds__(256) void sgemm_tn_k256(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
                                                      const bf16_t *__restrict__ bias, bf16_t *__restrict__ Y, int M, int N, int K,
-                                                     int ldx, int ldw, int ldy)
+                                                     int ldx, int ldw, int ldy, int64_t bsx = 0, int64_t bsw = 0, int64_t bsy = 0)
 {
+  // blockIdx.z = problem of a batch of equally shaped products (element strides bsx / bsw / bsy; pd_sgemm_tn_batched_bf16)
+  X += blockIdx.z * bsx; W += blockIdx.z * bsw; Y += blockIdx.z * bsy;
   extern __shared__ __attribute__((aligned(16))) unsigned char sg_smem[];
   bf16_t(*Xs)[PK256] = reinterpret_cast<bf16_t(*)[PK256]>(sg_smem);                       // [32][PK256]
   bf16_t(*Ws)[PK256] = reinterpret_cast<bf16_t(*)[PK256]>(sg_smem + 32 * PK256 * sizeof(bf16_t));   // [128][PK256]
@@ -773,6 +775,24 @@ extern "C" int pd_sgemm_tn_bf16(const void *X, const void *W, const void *bias, 
   if (relu) hipLaunchKernelGGL(sgemm_tn<true>, g, b, 0, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, M, N, K, ldx, ldw, ldy);
   else hipLaunchKernelGGL(sgemm_tn<false>, g, b, 0, s, (const bf16_t *)X, (const bf16_t *)W, (const bf16_t *)bias, (bf16_t *)Y, M, N, K, ldx, ldw, ldy);
   return pd_check_launch("pd_sgemm_tn_bf16");
+}
+
+// `batch` equally shaped products Y_b = X_b W_b^T in ONE launch (K <= 256): the Hungarian matcher's point logits of all (image, head)
+// problems, [Q, C] x [points, C]^T each (reference matcher.py:108-125 through the linearity of point sampling) — was torch.bmm
+extern "C" int pd_sgemm_tn_batched_bf16(const void *X, const void *W, void *Y, int M, int N, int K, int ldx, int ldw, int ldy, int batch,
+                                        int64_t stride_x, int64_t stride_w, int64_t stride_y, void *stream_)
+{
+  int rc = check_common("pd_sgemm_tn_batched_bf16", X, W, Y, M, N, K, ldx, ldw, ldy);
+  if (rc) return rc;
+  if (K > 256 || (K % 64) || (N & 3) || batch < 0 || batch > 65535 || ((stride_x | stride_w) & 7) || (stride_y & 3))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_sgemm_tn_batched_bf16: K=%d (a multiple of 64, <= 256), N=%d (%% 4), batch=%d, strides %% 8 / 4", K, N, batch);
+  if (M == 0 || N == 0 || batch == 0) return PD_OK;
+  constexpr size_t lds = (size_t)(32 + 128) * PK256 * sizeof(bf16_t);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)sgemm_tn_k256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL(sgemm_tn_k256<false>, dim3((N + 127) / 128, (M + 31) / 32, batch), dim3(256), lds, (hipStream_t)stream_, (const bf16_t *)X, (const bf16_t *)W,
+                     (const bf16_t *)nullptr, (bf16_t *)Y, M, N, K, ldx, ldw, ldy, stride_x, stride_w, stride_y);
+  return pd_check_launch("pd_sgemm_tn_batched_bf16");
 }
 
 extern "C" int pd_sgemm_tn_multi_bf16(const PdSgemmTnDesc *d, int count, int K, void *stream_)

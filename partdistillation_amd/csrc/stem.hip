@@ -12,11 +12,14 @@
 //   forward : C^T[channel][pixel] = W . X^T — the accumulator then holds 4 consecutive CHANNELS of one pixel per register quad (lane =
 //             pixel), the layout the NHWC store wants; the 64 x 176 filter sits in registers (88 VGPRs) for the life of a persistent
 //             workgroup; epilogue scale / bias / ReLU / bf16.
-//   gradient: dW[channel][k'] = sum over pixels — the contraction runs over pixels, along which neither operand is contiguous, so the
-//             fragments are 2-byte LDS gathers (8 per operand: pixel stride 144 B in the masked-gradient tile, 12 B in the patch).  The tile's
-//             (y > 0 ? gy : 0) is formed while staging (no frozen-BN / ReLU backward pass: the stem has no input gradient), partial sums
-//             stay in registers over a workgroup's tiles and leave as ONE fp32 block per workgroup; a second kernel adds the blocks in
-//             workgroup order, applies the frozen-BN scale and rounds.
+//   gradient: dW[channel][k'] = sum over pixels — the contraction runs over pixels, along which neither operand is contiguous: both tiles are laid
+//             out in LDS pixel-major as they are produced (the masked gradient [pixel][64], the im2col rows [pixel][7 x 24] copied 48 bytes at a
+//             time from the patch) and transposed on the way out by ds_read_b64_tr_b16.  The tile's (y > 0 ? gy : 0) is formed while staging (no
+//             frozen-BN / ReLU backward pass: the stem has no input gradient), partial sums stay in registers over a workgroup's tiles and
+//             leave as ONE fp32 block per workgroup; a second kernel adds the blocks in a fixed order, applies the frozen-BN scale and rounds.
+//   Measured at 2 x 1024^2 (rocprofv3, tools/bench_stem.py): forward 55 us (MIOpen 66 + frozen-BN / ReLU pass 21 + input cast 8), gradient 60 + 8 us
+//   (MIOpen 113 + its fill 13 + frozen-BN / ReLU backward 30).  First versions: 85 us forward with per-lane 2-byte global loads of the filter
+//   (700 uncoalesced wave loads per workgroup) and 8-byte stores at a 128-byte lane stride; 220 us gradient with 2-byte LDS gathers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

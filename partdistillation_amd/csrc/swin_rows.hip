@@ -385,6 +385,119 @@ int check_mx(const void *q, const void *sc, int fmt, const char *who)
   return PD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Plain fp32 LayerNorm over token rows, forward and backward: the per-stage OUTPUT norms of the Swin backbone (reference
+// modeling/backbone/swin.py:675-680 `norm_layer = getattr(self, f"norm{i}"); x_out = norm_layer(x_out)`), which autocast keeps in fp32 — input
+// the stage's fp32 residual stream, output the fp32 map the pixel decoder reads.  Rounds 1-4 left them to ATen (0.97 ms per Swin-B step,
+// 1.93 ms per Swin-L step).  One wavefront per row, 16 bytes per lane and chunk, C % 4 == 0, C <= 1536 (NQ = ceil(C / 256) chunks).
+template <int NQ>
+__global__ __launch_bounds__(256) void ln_rows_f32_fwd(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       float eps, float *__restrict__ y, float *__restrict__ mean, float *__restrict__ rstd,
+                                                       int64_t rows, int C)
+{
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float *xr = x + row * C;
+  float4 v[NQ];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int c = 4 * (lane + 64 * j);
+    v[j] = c < C ? *reinterpret_cast<const float4 *>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mu = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    if (4 * (lane + 64 * j) < C) {
+      const float a = v[j].x - mu, b = v[j].y - mu, c2 = v[j].z - mu, d = v[j].w - mu;
+      sq += (a * a + b * b) + (c2 * c2 + d * d);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rs = rsqrtf(sq / (float)C + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  float *yr = y + row * C;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int c = 4 * (lane + 64 * j);
+    if (c < C) {
+      const float4 g = *reinterpret_cast<const float4 *>(gamma + c), b = *reinterpret_cast<const float4 *>(beta + c);
+      *reinterpret_cast<float4 *>(yr + c) = make_float4(fmaf((v[j].x - mu) * rs, g.x, b.x), fmaf((v[j].y - mu) * rs, g.y, b.y),
+                                                        fmaf((v[j].z - mu) * rs, g.z, b.z), fmaf((v[j].w - mu) * rs, g.w, b.w));
+    }
+  }
+}
+
+// dx = rstd (gh - mean_c(gh) - xhat mean_c(gh xhat)), gh = dy gamma;  dgamma += sum_rows dy xhat;  dbeta += sum_rows dy.  8 wavefronts per
+// workgroup, each walking rows; their column sums meet in LDS and leave as 2 C atomics per workgroup (few, fat workgroups: see pd_add_layernorm_bwd)
+template <int NQ> struct RowsBwdWaves { static constexpr int value = NQ >= 4 ? 4 : 8; };   // (column sums of all wavefronts in <= 48 KB of LDS)
+template <int NQ>
+__global__ __launch_bounds__(64 * RowsBwdWaves<NQ>::value) void ln_rows_f32_bwd(const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ mean,
+                                                       const float *__restrict__ rstd, const float *__restrict__ gamma, float *__restrict__ dx,
+                                                       float *__restrict__ dgamma, float *__restrict__ dbeta, int64_t rows, int C)
+{
+  constexpr int WV = RowsBwdWaves<NQ>::value;
+  __shared__ float red[WV][2][NQ * 256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float4 gm[NQ], ag[NQ], ab[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int c = 4 * (lane + 64 * j);
+    gm[j] = c < C ? *reinterpret_cast<const float4 *>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int64_t row = (int64_t)blockIdx.x * WV + wave; row < rows; row += (int64_t)gridDim.x * WV) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 g[NQ], xh[NQ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int c = 4 * (lane + 64 * j);
+      if (c < C) {
+        g[j] = *reinterpret_cast<const float4 *>(dy + row * C + c);
+        const float4 xv = *reinterpret_cast<const float4 *>(x + row * C + c);
+        xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+      } else {
+        g[j] = xh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      ag[j].x += g[j].x * xh[j].x; ag[j].y += g[j].y * xh[j].y; ag[j].z += g[j].z * xh[j].z; ag[j].w += g[j].w * xh[j].w;
+      ab[j].x += g[j].x; ab[j].y += g[j].y; ab[j].z += g[j].z; ab[j].w += g[j].w;
+      g[j].x *= gm[j].x; g[j].y *= gm[j].y; g[j].z *= gm[j].z; g[j].w *= gm[j].w;
+      s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+      s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int c = 4 * (lane + 64 * j);
+      if (c < C)
+        *reinterpret_cast<float4 *>(dx + row * C + c) = make_float4(rs * (g[j].x - m1 - xh[j].x * m2), rs * (g[j].y - m1 - xh[j].y * m2),
+                                                                    rs * (g[j].z - m1 - xh[j].z * m2), rs * (g[j].w - m1 - xh[j].w * m2));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    *reinterpret_cast<float4 *>(&red[wave][0][4 * (lane + 64 * j)]) = ag[j];
+    *reinterpret_cast<float4 *>(&red[wave][1][4 * (lane + 64 * j)]) = ab[j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 64 * WV) {
+    const int k = i / C, c = i - k * C;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < WV; ++w) sum += red[w][k][c];
+    atomicAdd((k ? dbeta : dgamma) + c, sum);
+  }
+}
+
 #define E_SWITCH(C, BODY)                                             \
   switch ((C) / 64) {                                                 \
     case 1: { constexpr int E = 1; BODY; } break;                     \
@@ -454,4 +567,44 @@ extern "C" int pd_swin_ln_bwd(const void *dy, const int32_t *ymap, int y_rows, c
               else if (!dr_q) BWD(-1); else if (q_format == PD_MX8_E4M3) BWD(PD_MX8_E4M3); else BWD(PD_MX8_E5M2));
 #undef BWD
   return pd_check_launch("pd_swin_ln_bwd");
+}
+
+extern "C" int pd_layernorm_rows_f32_fwd(const float *x, const float *gamma, const float *beta, float eps, float *y, float *mean, float *rstd,
+                                         int64_t rows, int C, void *stream_)
+{
+  if (rows < 0 || C <= 0 || (C & 3) || C > 1536) return pd_set_error(PD_ERR_INVALID_ARG, "pd_layernorm_rows_f32_fwd: rows=%lld C=%d (a multiple of 4 up to 1536)", (long long)rows, C);
+  if (rows == 0) return PD_OK;
+  if (!x || !gamma || !beta || !y || !mean || !rstd || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_layernorm_rows_f32_fwd: null / misaligned pointer");
+  const dim3 g((unsigned)((rows + 3) / 4)), b(256);
+  hipStream_t st = (hipStream_t)stream_;
+  switch ((C + 255) / 256) {
+    case 1: hipLaunchKernelGGL(ln_rows_f32_fwd<1>, g, b, 0, st, x, gamma, beta, eps, y, mean, rstd, rows, C); break;
+    case 2: hipLaunchKernelGGL(ln_rows_f32_fwd<2>, g, b, 0, st, x, gamma, beta, eps, y, mean, rstd, rows, C); break;
+    case 3: hipLaunchKernelGGL(ln_rows_f32_fwd<3>, g, b, 0, st, x, gamma, beta, eps, y, mean, rstd, rows, C); break;
+    case 4: hipLaunchKernelGGL(ln_rows_f32_fwd<4>, g, b, 0, st, x, gamma, beta, eps, y, mean, rstd, rows, C); break;
+    default: hipLaunchKernelGGL(ln_rows_f32_fwd<6>, g, b, 0, st, x, gamma, beta, eps, y, mean, rstd, rows, C); break;
+  }
+  return pd_check_launch("pd_layernorm_rows_f32_fwd");
+}
+
+extern "C" int pd_layernorm_rows_f32_bwd(const float *dy, const float *x, const float *mean, const float *rstd, const float *gamma, float *dx,
+                                         float *dgamma, float *dbeta, int64_t rows, int C, void *stream_)
+{
+  if (rows < 0 || C <= 0 || (C & 3) || C > 1536) return pd_set_error(PD_ERR_INVALID_ARG, "pd_layernorm_rows_f32_bwd: rows=%lld C=%d (a multiple of 4 up to 1536)", (long long)rows, C);
+  if (rows == 0) return PD_OK;
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)gamma) & 15))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_layernorm_rows_f32_bwd: null / misaligned pointer");
+  int64_t nb = (rows + 31) / 32;                                  // >= 4 rows per wavefront, at most 256 workgroups
+  const dim3 g((unsigned)(nb < 1 ? 1 : (nb > 256 ? 256 : nb)));
+  const dim3 b(C > 768 ? 256 : 512);
+  hipStream_t st = (hipStream_t)stream_;
+  switch ((C + 255) / 256) {
+    case 1: hipLaunchKernelGGL(ln_rows_f32_bwd<1>, g, b, 0, st, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C); break;
+    case 2: hipLaunchKernelGGL(ln_rows_f32_bwd<2>, g, b, 0, st, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C); break;
+    case 3: hipLaunchKernelGGL(ln_rows_f32_bwd<3>, g, b, 0, st, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C); break;
+    case 4: hipLaunchKernelGGL(ln_rows_f32_bwd<4>, g, b, 0, st, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C); break;
+    default: hipLaunchKernelGGL(ln_rows_f32_bwd<6>, g, b, 0, st, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C); break;
+  }
+  return pd_check_launch("pd_layernorm_rows_f32_bwd");
 }

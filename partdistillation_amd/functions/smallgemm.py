@@ -54,6 +54,22 @@ def linear(x, w, b=None, relu=False, out=None):
     return y
 
 
+def bmm_tn(x, w):
+    """x [Bt, M, K] @ w [Bt, N, K]^T -> [Bt, M, N] (bf16, K <= 256, % 64 == 0): ONE launch (pd_sgemm_tn_batched_bf16)"""
+    assert x.dtype == w.dtype == torch.bfloat16 and x.dim() == 3 and w.dim() == 3 and x.is_contiguous() and w.is_contiguous() and x.shape[0] == w.shape[0]
+    Bt, M, K = x.shape
+    N = w.shape[1]
+    y = torch.empty((Bt, M, N), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().pd_sgemm_tn_batched_bf16(x.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, K, K, N, Bt, M * K, N * K, M * N, _stream()))
+    return y
+
+
+def bmm_tn_supported(x, w):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 3 and w.dim() == 3 and x.is_contiguous() and w.is_contiguous()
+            and x.shape[2] <= 256 and x.shape[2] % 64 == 0 and w.shape[1] % 4 == 0 and (x.shape[1] * x.shape[2]) % 8 == 0 and (w.shape[1] * w.shape[2]) % 8 == 0
+            and (x.shape[1] * w.shape[1]) % 4 == 0)
+
+
 class _TnDesc(ctypes.Structure):                                     # PdSgemmTnDesc (include/pd_smallgemm.h)
     _fields_ = [("X", ctypes.c_void_p), ("W", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("Y", ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ("M", "N", "ldx", "ldw", "ldy")]

@@ -48,3 +48,42 @@ def ln_bwd(dy, ymap, y_rows, dsup, s, stats, gamma, want_dr, rmap, r_rows, rscal
                                           _p(rscale), _p(zero_rows) if nz else None, nz, dgamma.data_ptr(), dbeta.data_ptr(),
                                           images, L, C, _p(dq), _p(dsc), mx if mx is not None else 0, int(n_rep), int(rep_stride), _lib.current_stream()))
     return (ds, dr) if mx is None else (ds, dr, (dq, dsc))
+
+
+class _RowsLayerNorm(torch.autograd.Function):
+    """fp32 LayerNorm over the last dimension on pd_layernorm_rows_f32_{fwd,bwd} (the Swin stages' output norms, reference swin.py:675-680)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        stats = torch.empty((2, rows), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().pd_layernorm_rows_f32_fwd(x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), y.data_ptr(), stats[0].data_ptr(),
+                                                         stats[1].data_ptr(), rows, C, _lib.current_stream()))
+        ctx.save_for_backward(x2, stats, gamma)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, stats, gamma = ctx.saved_tensors
+        C = x2.shape[1]
+        g = dy.reshape(-1, C)
+        g = g if (g.is_contiguous() and g.dtype == torch.float32) else g.float().contiguous()
+        dx = torch.empty_like(x2)
+        dgb = torch.zeros((2, C), dtype=torch.float32, device=x2.device)
+        _lib.check(_lib.load().pd_layernorm_rows_f32_bwd(g.data_ptr(), x2.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), gamma.data_ptr(), dx.data_ptr(),
+                                                         dgb[0].data_ptr(), dgb[1].data_ptr(), x2.shape[0], C, _lib.current_stream()))
+        return dx.view(ctx.shape), dgb[0], dgb[1], None
+
+
+def rows_layer_norm_supported(x, ln):
+    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1536 and ln.weight is not None and ln.bias is not None
+            and ln.weight.dtype == torch.float32 and ln.bias.dtype == torch.float32 and tuple(ln.normalized_shape) == (x.shape[-1],))
+
+
+def rows_layer_norm(x, ln):
+    return _RowsLayerNorm.apply(x, ln.weight, ln.bias, ln.eps)

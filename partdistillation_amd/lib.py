@@ -110,6 +110,7 @@ SIGNATURES = {
     "pd_msda_prep_bwd_amax": (_c_int, [_c_vp] * 7 + [ctypes.c_int64] + [_c_int] * 5 + [_c_vp]),
     "pd_msda_forward_amax": (_c_int, [_c_vp] * 7 + [_c_int] * 9 + [_c_vp]),
     "pd_msda_prep_bwd": (_c_int, [_c_vp] * 6 + [ctypes.c_int64] + [_c_int] * 5 + [_c_vp]),
+    "pd_sgemm_tn_batched_bf16": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [ctypes.c_int64] * 3 + [_c_vp]),
     "pd_sgemm_tn_multi_bf16": (_c_int, [_c_vp, _c_int, _c_int, _c_vp]),
     "pd_decoder_head_bf16": (_c_int, [_c_vp] * 3 + [ctypes.c_float] + [_c_vp] * 10 + [_c_int] * 4 + [_c_vp]),
     "pd_sgemm_split_workspace_floats": (ctypes.c_int64, [_c_int] * 3),
@@ -139,6 +140,8 @@ SIGNATURES = {
     "pd_mask_assign": (_c_int, [_c_vp] * 6 + [_c_int] * 7 + [_c_vp]),
     "pd_window_attn_fwd_w12": (_c_int, [_c_vp] * 6 + [_c_int] * 3 + [ctypes.c_float, _c_vp, _c_vp, _c_int, _c_vp]),
     "pd_window_attn_bwd_w12": (_c_int, [_c_vp] * 9 + [_c_int] * 3 + [ctypes.c_float, _c_vp, _c_vp, _c_int, _c_vp]),
+    "pd_layernorm_rows_f32_fwd": (_c_int, [_c_vp] * 3 + [ctypes.c_float] + [_c_vp] * 3 + [ctypes.c_int64, _c_int, _c_vp]),
+    "pd_layernorm_rows_f32_bwd": (_c_int, [_c_vp] * 8 + [ctypes.c_int64, _c_int, _c_vp]),
     "pd_swin_ln_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_int, _c_vp,
                                 _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_vp]),
     "pd_swin_ln_bwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp,

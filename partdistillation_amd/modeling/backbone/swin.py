@@ -15,6 +15,7 @@ from torch import nn
 
 from ...functions import fp8
 from ...functions import window_attention as wattn
+from ...functions import swin_rows as _swin_rows
 from ...functions.rowwise import add_layer_norm, supports_width
 
 from ...compat import BACKBONE_REGISTRY, ShapeSpec
@@ -24,6 +25,7 @@ from ...compat import BACKBONE_REGISTRY, ShapeSpec
 # of the stages with C >= FP8_MIN_K then run as MX-fp8 GEMMs on own kernels (include/pd_mx8.h) while autocast is on: inside the fused
 # stage (swin_core.py), or one by one through functions/fp8.py on the module-by-module path
 FP8 = {"enabled": False, "min_k": 384}
+OWN_OUT_NORM = __import__("os").environ.get("PD_SWIN_OWN_OUT_NORM", "1") != "0"   # the stages' output LayerNorms on pd_layernorm_rows_f32_* (0: ATen)
 FUSED_STAGE = True          # modeling/backbone/swin_core.py where it applies (tests switch it off to compare the two paths)
 
 
@@ -385,7 +387,11 @@ class SwinTransformer(nn.Module):
         for i, layer in enumerate(self.layers):
             x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww)
             if i in self.out_indices:
-                x_out = getattr(self, f"norm{i}")(x_out)
+                ln = getattr(self, f"norm{i}")
+                if OWN_OUT_NORM and _swin_rows.rows_layer_norm_supported(x_out, ln):
+                    x_out = _swin_rows.rows_layer_norm(x_out, ln)            # fp32 rows in, fp32 rows out: pd_layernorm_rows_f32_* (ATen: 1 - 2 ms per step)
+                else:
+                    x_out = ln(x_out)
                 o = x_out.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2)
                 # on the GPU the tokens ARE the channels-last storage of the [B, C, H, W] map the pixel decoder wants: no NCHW copy
                 # (reference :634 .contiguous(); the copy, the convolution's copy back and their two backward copies were 0.5 ms at config 3)

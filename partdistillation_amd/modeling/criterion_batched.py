@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from ..functions import criterion_ops as cops
 from ..functions import lsa as lsa_op
 from ..functions import rowwise as rw
+from ..functions import smallgemm as _sg
 
 
 class LossDict(dict):
@@ -204,7 +205,11 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
             fm = rw.point_sample_nhwc(mfeat.detach(), mc_bd.reshape(B, H * Pm, 2),                # [B, D*Pm, C], already in e's dtype
                                       out_dtype=e.dtype if e.dtype == torch.bfloat16 else torch.float32)
             # bf16 mask embeddings (autocast): the reference's mask logits are a bf16 product too (einsum under AMP, :449)
-            pm = torch.bmm(e, fm.view(B * H, Pm, -1).to(e.dtype).transpose(1, 2))
+            fmv = fm.view(B * H, Pm, -1).to(e.dtype)
+            if _sg.bmm_tn_supported(e, fmv):
+                pm = _sg.bmm_tn(e, fmv)                                  # all (image, head) problems: one launch of the skinny bf16 kernel
+            else:
+                pm = torch.bmm(e, fmv.transpose(1, 2))
         else:
             pm = _gs(masks_bd.detach().reshape(B * H, Q, *masks_bd.shape[-2:]).float(), mc_bd.reshape(B * H, Pm, 2))   # [BD,Q,Pm]
         if byte_masks:                                                                           # row (b, j): map b * nmax + j at image b's points

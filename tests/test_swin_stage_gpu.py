@@ -217,3 +217,26 @@ def test_recorded_stage_replays_equal_the_eager_launches(drop):
         for k, g in eager[i][2].items():
             _close(rec[i][2][k].float(), g.float(), 1e-5, f"step {i}: grad {k}")   # LayerNorm / table gradients: atomics
     assert not torch.equal(rec[1][0], rec[2][0])
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 128), (777, 192), (513, 384), (300, 768), (260, 1024), (130, 1536), (5, 256)])
+def test_rows_layer_norm_f32_vs_torch(rows, C):
+    """pd_layernorm_rows_f32_fwd / _bwd (the Swin stages' output norms, reference swin.py:675-680) against torch.nn.functional.layer_norm in
+    float64: every stage width of Swin-T / B / L, outputs and all three gradients."""
+    from partdistillation_amd.functions import swin_rows
+    g = torch.Generator(device="cuda").manual_seed(rows + C)
+    x = (torch.randn(2, rows, C, device="cuda", generator=g) * 3 + 0.5).requires_grad_()
+    ln = torch.nn.LayerNorm(C).cuda()
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.normal_(0, 0.3)
+    assert swin_rows.rows_layer_norm_supported(x, ln)
+    y = swin_rows.rows_layer_norm(x, ln)
+    go = torch.randn(y.shape, device="cuda", generator=g)
+    gx, gw, gb = torch.autograd.grad(y, (x, ln.weight, ln.bias), go)
+    xd, wd, bd = x.detach().double().requires_grad_(), ln.weight.detach().double().requires_grad_(), ln.bias.detach().double().requires_grad_()
+    ref = torch.nn.functional.layer_norm(xd, (C,), wd, bd, ln.eps)
+    rx, rw_, rb = torch.autograd.grad(ref, (xd, wd, bd), go.double())
+    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gx.double(), rx, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gw.double(), rw_, rtol=1e-4, atol=1e-4 * rw_.abs().max().item())
+    torch.testing.assert_close(gb.double(), rb, rtol=1e-4, atol=1e-4 * rb.abs().max().item())
