@@ -33,6 +33,16 @@ class _NoWork:
         return True
 
 
+class _WeakPublish:
+    def __init__(self, reducer):
+        import weakref
+        self.ref = weakref.ref(reducer)
+
+    def __call__(self, p, grad):
+        r = self.ref()
+        return bool(r is not None and r.publish(p, grad))
+
+
 class BucketedGradReducer:
     def __init__(self, flat, bucket_mb: float = 25.0, process_group=None, overlap: bool = True, optimizer=None, sparse_rows_cap: int = 256):
         self.flat, self.pg, self.optimizer = flat, process_group, optimizer
@@ -76,7 +86,13 @@ class BucketedGradReducer:
         self._side = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and overlap) else None
         self._skip_reduce = os.environ.get("PD_DDP_SKIP_REDUCE", "0") == "1"        # (development: everything but the collective itself)
         self._hooks = []
+        self._early = False
         if self.active:
+            # the fused ResNet body (one autograd node: its filter gradients would all arrive when its backward returns) hands a stage's
+            # gradients over as soon as that stage is done: modeling/backbone/resnet_core.py calls publish(parameter, gradient)
+            from ..modeling.backbone import resnet_core
+            resnet_core.PUBLISH = _WeakPublish(self)        # (weak: a finished trainer's reducer is not kept alive by the module global)
+            self._early = True
             for gi, g in enumerate(flat.groups):
                 if gi in self.sparse_groups:
                     continue
@@ -84,6 +100,16 @@ class BucketedGradReducer:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     # ------------------------------------------------------------------ hooks
+    def publish(self, p, grad):
+        """a gradient that did NOT come through autograd's AccumulateGrad (a fused node publishing per stage): install it as p.grad and
+        count the parameter as complete, exactly as the post-accumulate hook would.  -> False when p is not one of this reducer's
+        parameters (the caller then returns the gradient to autograd as usual)"""
+        if p not in self._param_bucket:
+            return False
+        p.grad = grad
+        self._on_grad(p)
+        return True
+
     def _on_grad(self, p):
         """a bucket is all-reduced once ITS gradients are complete AND every bucket before it has been issued: the ranks
         then issue the same collectives in the same order even when the set of parameters that received gradients
@@ -245,6 +271,10 @@ class BucketedGradReducer:
     def remove(self):
         for h in self._hooks:
             h.remove()
+        if self._early:
+            from ..modeling.backbone import resnet_core
+            if isinstance(resnet_core.PUBLISH, _WeakPublish) and resnet_core.PUBLISH.ref() is self:
+                resnet_core.PUBLISH = None
 
 
 def broadcast_parameters(flat, src=0, process_group=None):

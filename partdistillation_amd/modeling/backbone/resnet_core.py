@@ -32,6 +32,13 @@ from ...functions.fused import PinnedRing
 from ... import cmdbuf as _cmdbuf
 _PLANS = _cmdbuf.LRU(int(__import__("os").environ.get("PD_R50_PLAN_CAP", "4")))
 ENABLED = bool(int(__import__("os").environ.get("PD_R50_FUSED", "1")))
+# Data-parallel runs: `PUBLISH(parameter)` is the gradient reducer's per-parameter "gradient complete" entry (engine/ddp.py sets it while a
+# reducer with > 1 participant is alive).  The node then walks its backward STAGE BY STAGE (res5 -> res2): a stage's input-gradient launches,
+# that stage's grouped filter-gradient launch, `.grad` of its filters set and published — so the buckets holding res5 / res4 / res3 leave for the
+# wire while the lower stages still compute, instead of all ~94 MB after the last launch of the body.  None: one sequence, one
+# grouped filter-gradient launch, gradients returned to autograd (the single-GPU path: 4 C calls instead of 10).
+PUBLISH = None
+PER_STAGE = bool(int(__import__("os").environ.get("PD_R50_STAGE_HANDOVER", "1")))
 
 
 def _align(n, a=128):
@@ -98,6 +105,7 @@ class Plan:
         self.arena = torch.empty(total, dtype=torch.bfloat16, device=dev)
         self.base = self.arena.data_ptr()
         self.ones = torch.ones(max(d["cout"] for d in info), dtype=torch.float32, device=dev)
+        self.stage_of_block = list(stage_of_block)
         self.out_blocks = {}                                # stage name -> index of its last block
         for bi, st in enumerate(stage_of_block):
             self.out_blocks[st] = bi
@@ -180,8 +188,12 @@ class Plan:
         self.tr = []                                        # (conv) of every transposed filter
         wg = []                                             # filter-gradient descriptors (ctypes) + which need x0
         self.wg_x0 = []
+        self.stage_ranges = []                              # per stage, last first: [name, first launch, end launch, first filter, end filter]
         for bi in reversed(range(n)):
             d = self.info[bi]
+            st_name = self.stage_of_block[bi]
+            if not self.stage_ranges or self.stage_ranges[-1][0] != st_name:
+                self.stage_ranges.append([st_name, len(lst), len(lst), len(wg), len(wg)])
             c1, c2, c3, cs = self.convs[4 * bi:4 * bi + 4]
             prev = self.info[bi - 1] if bi > 0 else None
 
@@ -227,6 +239,7 @@ class Plan:
                 if x is None:
                     self.wg_x0.append(len(wg))
                 wg.append((c, w))
+            self.stage_ranges[-1][2], self.stage_ranges[-1][4] = len(lst), len(wg)
         self.bwd = (igemm.PdIgemm * len(lst))(*lst)
         self.ext_entries = ext_entries
         self.last_name = next((nm for nm, last in self.out_blocks.items() if last == n - 1), None)
@@ -267,16 +280,18 @@ class Plan:
             outs.append(self.view(d["out"], B, d["ho"], d["wo"], d["cout"]))
         return outs
 
-    def _wgrad_descs(self, mask):
-        """ctypes descriptor array of the filters whose gradient is wanted (cached per requires-grad pattern)"""
-        hit = self._wg_cache.get(mask)
+    def _wgrad_descs(self, mask, lo=0, hi=None):
+        """ctypes descriptor array of the filters [lo, hi) of wg_all whose gradient is wanted (cached per requires-grad pattern and range)"""
+        hi = len(self.wg_all) if hi is None else hi
+        key = (mask, lo, hi)
+        hit = self._wg_cache.get(key)
         if hit is None:
-            sel = [(i, w) for i, ((c, w), m) in enumerate(zip(self.wg_all, mask)) if m]
+            sel = [(i, w) for i, ((c, w), m) in enumerate(zip(self.wg_all, mask)) if m and lo <= i < hi]
             arr = (conv_bf16._Desc * len(sel))()
             for j, (_, w) in enumerate(sel):
                 ctypes.memmove(ctypes.addressof(arr[j]), ctypes.addressof(w), ctypes.sizeof(conv_bf16._Desc))
             x0_idx = [j for j, (i, _) in enumerate(sel) if i in self.wg_x0]
-            hit = self._wg_cache[mask] = (arr, x0_idx)
+            hit = self._wg_cache[key] = (arr, x0_idx)
         return hit
 
     def run_backward(self, x0, gouts, need_x0, need_w):
@@ -311,18 +326,28 @@ class Plan:
             self.bwd[i].res2 = nhwc(g, None).data_ptr() if g is not None else None
         count = len(self.bwd) if need_x0 else len(self.bwd) - (2 if self.convs[3] is not None else 1)
         ws = self._ws()
-        _lib.check(L.pd_igemm_bf16_seq(self.bwd, count, ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, st))
-        # filter gradients: one grouped launch (per tile shape) over every convolution that wants one
         dws = [None] * len(need_w)
-        if any(need_w):
-            order = [c for c, _ in self.wg_all]
-            pos = {id(c): j for j, c in enumerate(c for c in self.convs if c is not None)}
-            mask = tuple(bool(need_w[pos[id(c)]]) for c in order)
-            arr, x0_idx = self._wgrad_descs(mask)
+        order = [c for c, _ in self.wg_all]
+        pos = {id(c): j for j, c in enumerate(c for c in self.convs if c is not None)}
+        mask = tuple(bool(need_w[pos[id(c)]]) for c in order)
+        publish = PUBLISH if (PER_STAGE and any(need_w)) else None
+        esz = ctypes.sizeof(igemm.PdIgemm)
+
+        def launches(a, b):
+            b = min(b, count)
+            if b > a:
+                sub = (igemm.PdIgemm * (b - a)).from_address(ctypes.addressof(self.bwd) + a * esz)
+                _lib.check(L.pd_igemm_bf16_seq(sub, b - a, ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, st))
+
+        def filter_gradients(lo, hi):
+            """one grouped launch (per tile shape) over the convolutions [lo, hi) of wg_all that want a gradient -> their positions"""
+            arr, x0_idx = self._wgrad_descs(mask, lo, hi)
+            n = len(arr)
+            if n == 0:
+                return []
             p0 = x0.data_ptr()
             for j in x0_idx:
                 arr[j].x = p0
-            n = len(arr)
             need = int(L.pd_conv_bf16_wgrad_grouped_workspace_floats(arr, n))
             wsf = conv_bf16._WS.get(str(self.dev))
             if wsf is None or wsf.numel() < need:
@@ -337,11 +362,29 @@ class Plan:
             rc = L.pd_conv_bf16_wgrad_grouped(arr, n, hostt.data_ptr(), D.table_dev.data_ptr(), wsf.data_ptr(), wsf.numel(), st)
             D.ring.release()
             _lib.check(rc)
-            for c in order:
+            done = []
+            for i in range(lo, hi):
+                c = order[i]
                 j = pos[id(c)]
                 if need_w[j]:
                     wt = c.mod.weight
                     dws[j] = self.arena.as_strided(wt.shape, wt.stride(), c.dw_off)
+                    done.append(j)
+            return done
+
+        if publish is None:
+            launches(0, len(self.bwd))
+            if any(need_w):
+                filter_gradients(0, len(order))
+        else:
+            # stage by stage, last stage first: its gradients are complete (and on their way) while the stages below still compute
+            weights = self.weights()
+            for _, a, b, lo, hi in self.stage_ranges:
+                launches(a, b)
+                for j in filter_gradients(lo, hi):
+                    p = weights[j]
+                    if p.grad is None and publish(p, dws[j]):    # handed over here: autograd gets no gradient for it (no second accumulation)
+                        dws[j] = None
         gx0 = self.view(self.gx0_off, *[self.shape[i] for i in (0, 2, 3, 1)]) if need_x0 else None
         del keep
         return gx0, dws

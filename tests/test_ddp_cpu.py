@@ -316,3 +316,81 @@ def test_bucket_issue_schedule_config2():
     print(f"{len(log)} buckets, {total / 1e6:.1f} MB; {before_last / total:.1%} of the bytes issued before the last hook; issue points "
           f"{[round(e[2] / len(params), 2) for e in log]}")
     assert before_last >= 0.8 * total                                            # (3)
+
+
+# ----------------------------------------------------------------------------- gradients handed over from INSIDE a fused node (per stage)
+class _StagedBackward(torch.autograd.Function):
+    """stand-in for the fused ResNet body (modeling/backbone/resnet_core.py): one autograd node over several layers that, in data-parallel
+    runs, publishes each layer's weight gradient to the reducer from inside its backward — last layer first — and returns None for it"""
+
+    @staticmethod
+    def forward(ctx, x, publish, *ws):
+        ctx.publish, ctx.ws = publish, ws
+        acts = [x]
+        for w in ws:
+            acts.append(torch.tanh(acts[-1] @ w.t()))
+        ctx.acts = acts
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = [None] * len(ctx.ws)
+        for i in reversed(range(len(ctx.ws))):
+            g = g * (1 - ctx.acts[i + 1] ** 2)
+            dw = g.t() @ ctx.acts[i]
+            g = g @ ctx.ws[i]
+            if ctx.publish is None or not ctx.publish(ctx.ws[i], dw):
+                grads[i] = dw
+        return (g, None, *grads)
+
+
+def _staged_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from partdistillation_amd.engine.ddp import BucketedGradReducer, broadcast_parameters
+    from partdistillation_amd.engine.flat_params import FlatParams
+    from partdistillation_amd.modeling.backbone import resnet_core
+    torch.manual_seed(3)
+    ws = [torch.nn.Parameter(torch.randn(24, 24) * 0.3) for _ in range(4)]
+    head = torch.nn.Parameter(torch.randn(5, 24) * 0.3)
+    names = [f"body.{i}" for i in range(4)] + ["head"]
+    flat = FlatParams([{"params": list(reversed(ws + [head])), "names": list(reversed(names)), "lr": 1e-3, "weight_decay": 0.0}])
+    broadcast_parameters(flat, 0)
+    reducer = BucketedGradReducer(flat, bucket_mb=0.002)
+    assert len(reducer.buckets) >= 3 and resnet_core.PUBLISH is not None
+    torch.manual_seed(20 + rank)
+    x = torch.randn(6, 24)
+    out = {}
+    for mode in ("published", "hooks"):
+        issued = []
+        launch0 = reducer._launch
+        reducer._launch = lambda b, _l=launch0: (issued.append(b.index), _l(b))[1]
+        flat.zero_grad()
+        y = _StagedBackward.apply(x, resnet_core.PUBLISH if mode == "published" else None, *ws)
+        (y @ head.t()).pow(2).sum().backward()
+        reducer.finish()
+        reducer._launch = launch0
+        g = flat.groups[0]
+        out[mode] = ({n: g._view(g.grad, p, off).detach().clone() for n, p, off in zip(g.names, g.params, g.offsets)}, issued)
+    torch.save(out, os.path.join(tmp, f"staged{rank}.pt"))
+    reducer.remove()
+    assert resnet_core.PUBLISH is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gradients_published_from_inside_a_fused_node_equal_the_hook_path(tmp_path):
+    """the fused ResNet body hands its gradients to the reducer stage by stage from inside its backward
+    (BucketedGradReducer.publish) instead of through autograd's hooks when the node returns.  The reduced gradients are identical to the
+    hook path's on both ranks, every bucket is issued exactly once and in index order."""
+    world = 2
+    mp.spawn(_staged_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"staged{k}.pt") for k in range(world)]
+    for k in range(world):
+        for n in r[k]["published"][0]:
+            torch.testing.assert_close(r[k]["published"][0][n], r[k]["hooks"][0][n], rtol=0, atol=0)
+            torch.testing.assert_close(r[0]["published"][0][n], r[k]["published"][0][n], rtol=0, atol=0)
+        for mode in ("published", "hooks"):
+            idx = r[k][mode][1]
+            assert idx == sorted(idx) and len(set(idx)) == len(idx) and len(idx) >= 3, (mode, idx)

@@ -189,3 +189,33 @@ def test_backward_after_a_second_forward_raises(monkeypatch):
         net(x)
     with pytest.raises(RuntimeError, match="another forward"):
         a["res5"].float().sum().backward()
+
+
+def test_per_stage_gradient_hand_over_equals_the_single_hand_over(monkeypatch):
+    """data-parallel form of the node: with a gradient publisher installed the backward runs stage by stage — res5's
+    input-gradient launches, res5's grouped filter-gradient launch, its filters' gradients published, then res4 ... — and returns no filter
+    gradient to autograd.  Same gradients as the one-sequence form, every filter published exactly once, res5 before res4 before res3
+    before res2."""
+    from partdistillation_amd.modeling.backbone import resnet_core
+    net = _backbone(3)
+    x = torch.randn(2, 3, 128, 160, device=DEV)
+    _, gx_a, grads_a = _run(net, x, True, monkeypatch)
+    order = []
+    names = {id(p): n for n, p in net.named_parameters()}
+
+    def publish(p, g):
+        assert p.grad is None
+        p.grad = g
+        order.append(names[id(p)])
+        return True
+
+    monkeypatch.setattr(resnet_core, "PUBLISH", publish)
+    _, gx_b, grads_b = _run(net, x, True, monkeypatch)
+    body = [n for n in grads_a if not n.startswith("stem.")]
+    assert sorted(order) == sorted(body) and len(set(order)) == len(order)
+    stages = [n.split(".")[0] for n in order]
+    assert stages == sorted(stages, reverse=True), stages                  # res5 ... res2
+    assert torch.equal(gx_a, gx_b)
+    for n in grads_a:
+        a, b = grads_a[n], grads_b[n]
+        assert ((a - b).abs().max() <= 1e-3 * a.abs().max().clamp_min(1e-12)).item(), (n, (a - b).abs().max().item(), a.abs().max().item())
