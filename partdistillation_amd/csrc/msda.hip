@@ -114,10 +114,27 @@ __global__ __launch_bounds__(256, 4) void msda_fwd_d32(const float *__restrict__
                                                      const int64_t *__restrict__ lvl_start, const float *__restrict__ loc,
                                                      const float *__restrict__ attn, float *__restrict__ out,
                                                      int S, int M, int Lq, int total_qm, unsigned *__restrict__ row_amax,
-                                                     int ld_oa = 0, float2 *__restrict__ stats = nullptr)
+                                                     int ld_oa = 0, float2 *__restrict__ stats = nullptr, int band_major = 0)
 {
   const int lb = xcd_chunked_block(blockIdx.x, gridDim.x);
-  const int qm = lb * 32 + (threadIdx.x >> 3);
+  int qm = lb * 32 + (threadIdx.x >> 3);
+  if constexpr (FUSED) {
+    // Self-attention over the pyramid (queries == pixels): XCD k (a contiguous eighth of the logical blocks) takes band k of EVERY level of
+    // every image instead of a contiguous eighth of the concatenated levels — the queries of one band sample the same band (+ halo) of all
+    // three levels' value rows, 1 / 8 of `value` per image (2.75 MB at config 2: inside the XCD's 4 MB L2), where the first XCDs used to
+    // hold whole small levels whose queries sample every row of every level.  Needs M == 8 (4 queries per block), level sizes % 32 == 0.
+    const int n0 = (int)(shapes[0] * shapes[1]), n1 = (int)(shapes[2] * shapes[3]), n2 = (int)(shapes[4] * shapes[5]);
+    if (band_major && M == 8 && Lq == S && n0 + n1 + n2 == S && !((n0 | n1 | n2) & 31) && (gridDim.x & 7) == 0 && total_qm == (int)gridDim.x * 32) {
+      const int per = gridDim.x >> 3, k = lb / per, p = (lb - k * per) * 4 + (threadIdx.x >> 6);       // query index inside XCD k's share
+      const int sq = S >> 3, bimg = p / sq, r = p - bimg * sq;
+      const int b0 = n0 >> 3, b1 = n1 >> 3, b2 = n2 >> 3;
+      int q;
+      if (r < b0) q = k * b0 + r;
+      else if (r < b0 + b1) q = n0 + k * b1 + (r - b0);
+      else q = n0 + n1 + k * b2 + (r - b0 - b1);
+      qm = (bimg * S + q) * 8 + ((threadIdx.x >> 3) & 7);
+    }
+  }
   if (qm >= total_qm) return;
   const int sub = threadIdx.x & 7;
   const int m = qm % M;
@@ -1337,7 +1354,8 @@ extern "C" int pd_msda_fused_forward(const float *value, const int64_t *spatial_
   const int64_t total_qm = (int64_t)batch * num_query * num_heads;
   const int nblocks = round_up8((total_qm + 31) / 32);
   hipLaunchKernelGGL((msda_fwd_d32<3, 4, true>), dim3(nblocks), dim3(256), 0, stream, value, spatial_shapes, level_start_index, oa, ref, output,
-                     spatial_size, num_heads, num_query, (int)total_qm, reinterpret_cast<unsigned *>(row_amax), ld_oa, reinterpret_cast<float2 *>(stats));
+                     spatial_size, num_heads, num_query, (int)total_qm, reinterpret_cast<unsigned *>(row_amax), ld_oa, reinterpret_cast<float2 *>(stats),
+                     g_pd_dbg_ablate == 128 ? 0 : 1);
   return pd_check_launch("pd_msda_fused_forward");
 }
 
