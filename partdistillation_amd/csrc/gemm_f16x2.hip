@@ -20,6 +20,7 @@
 // ops/modules/ms_deform_attn.py:102-130 projections).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 
 #include "f16x2.h"
@@ -440,11 +441,14 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_amax(const unsigned short *
 constexpr int RS_PANEL = 528, RS_PLANE = 32 * RS_PANEL, RS_BUF = 2 * RS_PLANE;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool AM>   // AM: both operands come with row maxima (scaled rows); false: neither (unit scales)
+// MODE (round 5): 0 bias; 1 ReLU and its sign bits (16 per lane and tile, stored as one half-word at ((tile * npanels + panel) * 8 + wave) * 64 + lane:
+// this kernel's own order — a mode-2 launch over the same [M, N] reads them back); 2 keep where the bit is set + column sums into `colsum`.
+template <bool AM, int MODE = 0>   // AM: both operands come with row maxima (scaled rows); false: neither (unit scales)
 __global__ __launch_bounds__(512)
 void gemm_rows_f16x2_k256(const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ bias, float *__restrict__ C,
                           int M, int npanels, int lda, int ldb, int ldc, const float *__restrict__ a_amax,
-                          const float *__restrict__ b_amax, unsigned *__restrict__ c_amax)
+                          const float *__restrict__ b_amax, unsigned *__restrict__ c_amax, unsigned short *__restrict__ bits = nullptr,
+                          float *__restrict__ colsum = nullptr)
 {
   // the two images are two objects: the stores into one provably do not alias the fragment reads of the other, so the scheduler
   // may move them (and the split feeding them) up between the matrix instructions
@@ -508,6 +512,7 @@ void gemm_rows_f16x2_k256(const float *__restrict__ A, const float *__restrict__
     }
   }
   const float bv = bias ? bias[n0 + fr] : 0.f;
+  float csum = 0.f;                                                  // MODE 2: column sum of this lane's column over its rows
   split_store(0, 0);
   gload(0, t0 + 2);
   __syncthreads();
@@ -555,6 +560,22 @@ void gemm_rows_f16x2_k256(const float *__restrict__ A, const float *__restrict__
       o[4 * qd + 2] = (acc0[4 * qd + 2] + acc1[4 * qd + 2]) * (ia.z * ibv) + bv;
       o[4 * qd + 3] = (acc0[4 * qd + 3] + acc1[4 * qd + 3]) * (ia.w * ibv) + bv;
     }
+    if (MODE != 0) {
+      const int64_t widx = (((int64_t)(t0 + it) * npanels + panel) * 8 + w) * 64 + lane;
+      unsigned word = MODE == 2 ? (unsigned)bits[widx] : 0u;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rl = (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (MODE == 1) {
+          o[e] = fmaxf(o[e], 0.f);
+          word |= (o[e] > 0.f ? 1u : 0u) << e;
+        } else {
+          o[e] = ((word >> e) & 1u) ? o[e] : 0.f;
+          if (row0 + rl < M) csum += o[e];
+        }
+      }
+      if (MODE == 1 && bits) bits[widx] = (unsigned short)word;
+    }
     float *cp = C + (int64_t)row0 * ldc + n0 + fr;
     if (PD_ABL & 16) {
 #pragma unroll
@@ -593,6 +614,10 @@ void gemm_rows_f16x2_k256(const float *__restrict__ A, const float *__restrict__
   for (int it = 0; it < T; it += 2) {
     iter(it, 0);
     if (it + 1 < T) iter(it + 1, 1);
+  }
+  if (MODE == 2) {                                                   // this wavefront's 32 columns over all its rows: one atomic per column
+    csum += __shfl_xor(csum, 32, 64);
+    if (lane < 32 && csum != 0.f) unsafeAtomicAdd(colsum + n0 + fr, csum);
   }
 }
 
@@ -754,6 +779,7 @@ void gemm_ra_f16x2_k256(const float *__restrict__ A, const float *__restrict__ B
 }
 }  // namespace
 
+static const bool g_rows_relu = []() { const char *e = getenv("PD_H2_ROWS_RELU"); return !e || e[0] != '0'; }();   // A/B switch (default on)
 int g_pd_dbg_f16x2 = 0;   // tools/ only (pd_debug_set "f16x2_tile"): see pd_gemm_tn_f16x2
 
 template <int TM, int TN, int WN, int BKK, bool CONV = false, int NRS = 1, int FAST = 0>
@@ -794,7 +820,8 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: K, lda, ldb must be multiples of 4 and A, B 16-byte aligned");
   hipStream_t st = (hipStream_t)stream_;
   const int dbg = g_pd_dbg_f16x2;
-  if (dbg == 61 && !flags && mode == 0 && K == 256 && (N % 256) == 0 && M >= 8192 && (a_amax == nullptr) == (b_amax == nullptr)) {
+  static const bool rows_k256 = []() { const char *e = getenv("PD_H2_ROWS_K256"); return e && e[0] == '1'; }();   // A/B switch (default off)
+  if ((dbg == 61 || (rows_k256 && dbg == 0)) && !flags && mode == 0 && K == 256 && (N % 256) == 0 && M >= 8192 && (a_amax == nullptr) == (b_amax == nullptr)) {
     // row stream (gemm_rows_f16x2_k256, experimental: see the kernel's header): one persistent workgroup per CU, panels of a row group on one XCD
     static int ncu = 0;
     if (!ncu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = 256; }
@@ -848,8 +875,25 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
       return pd_check_launch("pd_gemm_tn_f16x2 (register operands)");
     }
   }
+  // N = 1024 <- K = 256 with the ReLU epilogues (the encoder FFN's first Linear and the input gradient of its second: modes 1 / 2 with sign
+  // bits): the row stream in its own bit order.  The choice depends on (M, N, K) and the switches only, so the mode-1 launch that writes a
+  // layer's bits and the mode-2 launch that reads them agree.  pd_debug_set("f16x2_tile", 62) / PD_H2_ROWS_RELU=0 keep the tiled kernel.
+  if (dbg != 62 && dbg != 3 && dbg != 13 && dbg != 70 && !flags && (mode == 1 || mode == 2) && bits && K == 256 && (N % 256) == 0 && N >= 512 && M >= 8192 &&
+      a_amax && b_amax && g_rows_relu) {
+    static int ncu2 = 0;
+    if (!ncu2) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&ncu2, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu2 < 8) ncu2 = 256; }
+    const int np = N / 256, G = (ncu2 / (8 * np)) * 8 * np;
+    if (G > 0) {
+      if (mode == 1)
+        hipLaunchKernelGGL((gemm_rows_f16x2_k256<true, 1>), dim3((unsigned)G), dim3(512), 0, st, A, B, bias, C, M, np, lda, ldb, ldc, a_amax, b_amax,
+                           reinterpret_cast<unsigned *>(c_amax), reinterpret_cast<unsigned short *>(bits), colsum);
+      else
+        hipLaunchKernelGGL((gemm_rows_f16x2_k256<true, 2>), dim3((unsigned)G), dim3(512), 0, st, A, B, bias, C, M, np, lda, ldb, ldc, a_amax, b_amax,
+                           reinterpret_cast<unsigned *>(c_amax), reinterpret_cast<unsigned short *>(bits), colsum);
+      return pd_check_launch("pd_gemm_tn_f16x2 (row stream, ReLU epilogue)");
+    }
+  }
   // the sign bits are laid out in the 256 x 256 kernel's accumulator order: bits / mask launches must take that kernel
-
   const bool need_wide = bits != nullptr;
   if (need_wide && ((N % 256) || M < 1024)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: sign bits need N %% 256 == 0 and M >= 1024");
   const bool wide_ok = (N % 256) == 0 && M >= 1024;

@@ -365,6 +365,38 @@ def test_gemm_tn_h2_relu_bits_and_mask_epilogues():
     torch.testing.assert_close(acc.double() - 0.25, ref.sum(0), rtol=1e-4, atol=1e-2 * scale)   # 0.25 + 2 304 fp32 atomics of ~1e-5 terms
 
 
+@pytest.mark.parametrize("M", [8300, 43008])
+@pytest.mark.parametrize("tile", [0, 62])
+def test_gemm_tn_h2_relu_epilogues_on_the_row_stream(M, tile):
+    """N = 1024 <- K = 256 with the ReLU epilogues (the encoder FFN: linear1 + ReLU + sign bits forward, the masked input gradient + bias
+    column sums backward) on the row-stream kernel (round 5: its own bit order) and, with pd_debug_set("f16x2_tile", 62), on the tiled
+    kernel: fp32-accurate against fp64, the mask of the backward launch = the forward's ReLU pattern, exact row maxima, ragged last tile."""
+    from partdistillation_amd import lib
+    from partdistillation_amd.functions import gemm
+    torch.manual_seed(M)
+    N, K = 1024, 256
+    x = torch.randn(M, K, device="cuda") * (1 + 5 * torch.rand(M, 1, device="cuda")); w1 = torch.randn(N, K, device="cuda") * K ** -0.5; b1 = torch.randn(N, device="cuda")
+    lib.load().pd_debug_set(b"f16x2_tile", tile)
+    try:
+        hm = torch.zeros(M, device="cuda")
+        h, bits = gemm.gemm_tn_h2(x, w1, b1, mode=1, want_bits=True, a_amax=gemm.row_amax(x), b_amax=gemm.row_amax(w1), c_amax=hm)
+        href = torch.addmm(b1.double(), x.double(), w1.double().t()).clamp_min(0)
+        assert ((h.double() - href).abs().max().item() / href.abs().max().item()) < 3e-6
+        assert torch.equal(hm, h.abs().amax(1))
+        dy = torch.randn(M, K, device="cuda") * 1e-4; w2t = torch.randn(N, K, device="cuda") * K ** -0.5
+        acc = torch.zeros(N, device="cuda")
+        cm = torch.zeros(M, device="cuda")
+        got = gemm.gemm_tn_h2(dy, w2t, None, mode=2, bits=bits, colsum=acc, a_amax=gemm.row_amax(dy), b_amax=gemm.row_amax(w2t), c_amax=cm)
+    finally:
+        lib.load().pd_debug_set(b"f16x2_tile", 0)
+    ref = (dy.double() @ w2t.double().t()) * (h > 0)
+    scale = ref.abs().max().item()
+    assert ((got.double() - ref).abs().max().item() / scale) < 3e-6
+    assert torch.equal(got != 0, (h > 0) & (ref != 0))
+    assert torch.equal(cm, got.abs().amax(1))
+    torch.testing.assert_close(acc.double(), ref.sum(0), rtol=1e-4, atol=2e-5 * scale * M ** 0.5)
+
+
 @pytest.mark.parametrize("M,N,K", [(43008, 1024, 256), (5000, 288, 256), (2100, 256, 1024), (700, 72, 40)])
 @pytest.mark.parametrize("mag", [1.0, 1e-6])
 def test_gemm_wgrad_h2_matches_fp64(M, N, K, mag):
