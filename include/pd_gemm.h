@@ -131,6 +131,10 @@ int pd_gemm_wgrad_f16x2_grouped(const PdGemmWgradDesc *descs, int count, void *t
                                 int64_t workspace_floats, void *stream);
 int pd_conv3x3_wgrad_nhwc_f16x2(const float *dY, const float *X, float *dWk, float *dB, const float *y_amax, const float *x_amax,
                                 float *workspace, int64_t workspace_floats, int B, int H, int W, int Ci, int Co, void *stream);
+/* host-only query (tools / bench.py labels): the kernel pd_gemm_tn_f16x2 takes for a problem — 0 = 128 x 128 tiles, 1 = 256 x 256 tiles,
+ * 2 = the row stream (K = 256), 3 = the opt-in register-operand kernel */
+int pd_gemm_tn_f16x2_which(int M, int N, int K, int mode, int has_bits, int has_amax);
+
 /* pd_conv3x3_nhwc_f32x3 in the two-plane form: x_amax [B H W] = absolute maxima of X's pixels over their channels, w_amax [Co] =
  * row maxima of Wk (both nullable), y_amax [B H W] (nullable, zero-filled by the caller) receives those of Y.  Ci % 16 == 0. */
 int pd_conv3x3_nhwc_f16x2(const float *X, const float *Wk, const float *bias, float *Y, const float *x_amax, const float *w_amax, float *y_amax,

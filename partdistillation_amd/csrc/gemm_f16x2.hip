@@ -820,7 +820,9 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: K, lda, ldb must be multiples of 4 and A, B 16-byte aligned");
   hipStream_t st = (hipStream_t)stream_;
   const int dbg = g_pd_dbg_f16x2;
-  static const bool rows_k256 = []() { const char *e = getenv("PD_H2_ROWS_K256"); return e && e[0] == '1'; }();   // A/B switch (default off)
+  // (round 5: the row stream is the product's choice for these shapes again — 22.06 -> 22.00 ms per step in two same-box A/B pairs, where round 3
+  // measured it 0.2 ms slower; PD_H2_ROWS_K256=0 / pd_debug_set("f16x2_tile", 80) keep the tiled kernel)
+  static const bool rows_k256 = []() { const char *e = getenv("PD_H2_ROWS_K256"); return !e || e[0] != '0'; }();
   if ((dbg == 61 || (rows_k256 && dbg == 0)) && !flags && mode == 0 && K == 256 && (N % 256) == 0 && M >= 8192 && (a_amax == nullptr) == (b_amax == nullptr)) {
     // row stream (gemm_rows_f16x2_k256, experimental: see the kernel's header): one persistent workgroup per CU, panels of a row group on one XCD
     static int ncu = 0;
@@ -897,7 +899,7 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
   const bool need_wide = bits != nullptr;
   if (need_wide && ((N % 256) || M < 1024)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: sign bits need N %% 256 == 0 and M >= 1024");
   const bool wide_ok = (N % 256) == 0 && M >= 1024;
-  const bool by_shape = dbg == 0 || dbg == 61 || dbg == 70;
+  const bool by_shape = dbg == 0 || dbg == 61 || dbg == 70 || dbg == 80 || dbg == 62;
   const bool wide = need_wide || dbg == 3 || dbg == 13 || (by_shape && wide_ok && (int64_t)((M + 255) / 256) * (N / 256) >= 128 && (N >= 1024 || K >= 512));
 #define GO(TM, TN, WN, NRS, FAST) return launch_f16x2<TM, TN, WN, 16, false, NRS, FAST>(A, B, bias, C, M, N, K, lda, ldb, ldc, mode, bits, colsum, a_amax, b_amax, c_amax, st, flags)
   // Measured and dropped (tools/bench_gemm_h2.py, M = 43 008): 32-deep steps (1024 <- 256 103.7 vs 96.8 us, 256 <- 1024 90.9 vs 85.4,
@@ -917,6 +919,21 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
   if (dbg == 14) GO(128, 128, 64, 2, 0);
   GO(128, 128, 64, 2, 1);
 #undef GO
+}
+
+// which kernel pd_gemm_tn_f16x2 launches for a problem (tools / bench.py labels): 0 = 128 x 128 tiles, 1 = 256 x 256 tiles, 2 = the row stream
+// (gemm_rows_f16x2_k256), 3 = the register-operand kernel (opt-in).  Mirrors the dispatch of gemm_tn_f16x2_impl.
+extern "C" int pd_gemm_tn_f16x2_which(int M, int N, int K, int mode, int has_bits, int has_amax)
+{
+  const int dbg = g_pd_dbg_f16x2;
+  static const bool rows_k256 = []() { const char *e = getenv("PD_H2_ROWS_K256"); return !e || e[0] != '0'; }();
+  if ((dbg == 61 || (rows_k256 && dbg == 0)) && mode == 0 && K == 256 && (N % 256) == 0 && M >= 8192) return 2;
+  if ((dbg == 90 || (dbg >= 100 && dbg < 132)) && mode == 0 && K == 256 && M >= 4096 && (N % 32) == 0 && N >= 96 && ((N % 128) == 0 || (N % 96) == 0)) return 3;
+  if (dbg != 62 && dbg != 3 && dbg != 13 && dbg != 70 && (mode == 1 || mode == 2) && has_bits && K == 256 && (N % 256) == 0 && N >= 512 && M >= 8192 && has_amax && g_rows_relu) return 2;
+  const bool wide_ok = (N % 256) == 0 && M >= 1024;
+  const bool by_shape = dbg == 0 || dbg == 61 || dbg == 70 || dbg == 80 || dbg == 62;
+  const bool wide = has_bits || dbg == 3 || dbg == 13 || (by_shape && wide_ok && (int64_t)((M + 255) / 256) * (N / 256) >= 128 && (N >= 1024 || K >= 512));
+  return wide ? 1 : 0;
 }
 
 extern "C" int pd_gemm_tn_f16x2(const float *A, const float *B, const float *bias, float *C, uint32_t *bits, float *colsum, const float *a_amax,

@@ -122,9 +122,11 @@ def gemm_tn_h2(a, b, bias=None, mode=0, bits=None, colsum=None, a_amax=None, b_a
     if not _TIMING["on"]:                                  # the hot path: no label formatting, no context manager
         _lib.check(L.pd_gemm_tn_f16x2(*args))
         return (c, bits) if (mode == 1 and want_bits) else c
-    wide = (N % 256 == 0 and M >= 1024 and (-(-M // 256)) * (N // 256) >= 128 and (N >= 1024 or K >= 512)) or bits is not None
+    which = int(L.pd_gemm_tn_f16x2_which(M, N, K, mode, int(bits is not None), int(a_amax is not None and b_amax is not None)))
     # (one label per kernel instantiation, as rocprofv3 names them: the per-launch averages of bench.py and of the profile agree)
-    with _timed_fwd(2.0 * M * N * K, f"gemm_tn_f16x2<{'256, 256, 128, 16' if wide else '128, 128, 64, 16'}, {mode}>", 4.0 * (M * K + N * K + M * N)):
+    label = (f"gemm_rows_f16x2_k256<true, {mode}>" if which == 2 else f"gemm_ra_f16x2_k256<{mode}>" if which == 3
+             else f"gemm_tn_f16x2<{'256, 256, 128, 16' if which == 1 else '128, 128, 64, 16'}, {mode}>")
+    with _timed_fwd(2.0 * M * N * K, label, 4.0 * (M * K + N * K + M * N)):
         _lib.check(L.pd_gemm_tn_f16x2(*args))
     return (c, bits) if (mode == 1 and want_bits) else c
 

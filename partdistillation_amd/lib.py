@@ -40,6 +40,7 @@ SIGNATURES = {
     "pd_gemm_wgrad_f16x2_grouped": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_vp]),
     "pd_conv3x3_wgrad_nhwc_f16x2": (_c_int, [_c_vp] * 7 + [ctypes.c_int64] + [_c_int] * 5 + [_c_vp]),
     "pd_conv3x3_nhwc_f16x2": (_c_int, [_c_vp] * 7 + [_c_int] * 5 + [_c_vp]),
+    "pd_gemm_tn_f16x2_which": (_c_int, [_c_int] * 6),
     "pd_gemm_tn_f16x2_bits_words": (ctypes.c_int64, [_c_int] * 2),
     "pd_gemm_tn_f16x2": (_c_int, [_c_vp] * 9 + [_c_int] * 7 + [_c_vp]),
     "pd_gemm_tn_f16x2_bf16out": (_c_int, [_c_vp] * 6 + [_c_int] * 6 + [_c_vp]),

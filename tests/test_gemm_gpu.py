@@ -303,7 +303,11 @@ def test_gemm_tn_h2_row_stream_matches_the_tiled_kernel(M, N, K, scaled):
     ref = torch.addmm(b.double(), a.double(), w.double().t())
     rown = ref.abs().amax(1, keepdim=True)
     aa, wa = (gemm.row_amax(a), gemm.row_amax(w)) if scaled else (None, None)
-    tiled = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
+    lib.load().pd_debug_set(b"f16x2_tile", 80)                      # (the tiled kernel: the default takes the row stream for K = 256 since round 5)
+    try:
+        tiled = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
+    finally:
+        lib.load().pd_debug_set(b"f16x2_tile", 0)
     lib.load().pd_debug_set(b"f16x2_tile", 61)
     try:
         cm = torch.zeros(M, device="cuda")
@@ -331,7 +335,11 @@ def test_gemm_tn_h2_register_operand_kernel_matches_the_tiled_kernel(M, N, K, sc
     ref = torch.addmm(b.double(), a.double(), w.double().t())
     rown = ref.abs().amax(1, keepdim=True)
     aa, wa = (gemm.row_amax(a), gemm.row_amax(w)) if scaled else (None, None)
-    tiled = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
+    lib.load().pd_debug_set(b"f16x2_tile", 80)                      # (the tiled kernel: the default takes the row stream for K = 256 since round 5)
+    try:
+        tiled = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
+    finally:
+        lib.load().pd_debug_set(b"f16x2_tile", 0)
     lib.load().pd_debug_set(b"f16x2_tile", 90)
     try:
         cm = torch.zeros(M, device="cuda")
