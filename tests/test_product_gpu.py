@@ -957,7 +957,11 @@ def test_config2_full_size_step_vs_oracle(amp):
         for k in keys:
             assert worst[k] < tol[k] and rel_l2[k] < tol[k], (k, worst[k], rel_l2[k], tol[k])
     else:
-        assert max(worst.values()) < tol, worst
+        # the fp32 leg runs the backbone on the LIBRARY's fp32 convolutions (resnet.py: F.conv2d), whose algorithm MIOpen picks per box and per
+        # state of its find-db: the same filter gradient measured 1e-4 .. 4e-3 of its maximum across this round's boxes.  1e-2 for those keys;
+        # everything on own kernels (pixel decoder, decoder) keeps 3 x the measured worst case.
+        for k in keys:
+            assert worst[k] < (1e-2 if k.startswith("backbone.") else tol), (k, worst[k])
 
 
 @pytest.mark.parametrize("amp", [False, True])
