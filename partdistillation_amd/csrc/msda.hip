@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "pd_msda.h"
@@ -1353,9 +1354,10 @@ extern "C" int pd_msda_fused_forward(const float *value, const int64_t *spatial_
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t total_qm = (int64_t)batch * num_query * num_heads;
   const int nblocks = round_up8((total_qm + 31) / 32);
+  static const bool band_env = []() { const char *e = getenv("PD_MSDA_BAND"); return !e || e[0] != '0'; }();   // A/B switch
   hipLaunchKernelGGL((msda_fwd_d32<3, 4, true>), dim3(nblocks), dim3(256), 0, stream, value, spatial_shapes, level_start_index, oa, ref, output,
                      spatial_size, num_heads, num_query, (int)total_qm, reinterpret_cast<unsigned *>(row_amax), ld_oa, reinterpret_cast<float2 *>(stats),
-                     g_pd_dbg_ablate == 128 ? 0 : 1);
+                     (g_pd_dbg_ablate == 128 || !band_env) ? 0 : 1);
   return pd_check_launch("pd_msda_fused_forward");
 }
 
