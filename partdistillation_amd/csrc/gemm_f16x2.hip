@@ -900,7 +900,9 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
   if (need_wide && ((N % 256) || M < 1024)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: sign bits need N %% 256 == 0 and M >= 1024");
   const bool wide_ok = (N % 256) == 0 && M >= 1024;
   const bool by_shape = dbg == 0 || dbg == 61 || dbg == 70 || dbg == 80 || dbg == 62;
-  const bool wide = need_wide || dbg == 3 || dbg == 13 || (by_shape && wide_ok && (int64_t)((M + 255) / 256) * (N / 256) >= 128 && (N >= 1024 || K >= 512));
+  static const bool wide_deepk = []() { const char *e = getenv("PD_H2_WIDE_DEEPK"); return e && e[0] == '1'; }();   // 256 x 256 tiles for N < 1024, K >= 512: faster in isolation (256 <- 1024: 80.7 vs 96.8 us), 0.15 ms SLOWER over the step (round 5 A/B: 22.01 vs 21.86 ms): off; PD_H2_WIDE_DEEPK=1 restores
+  const bool wide = need_wide || dbg == 3 || dbg == 13 || (by_shape && wide_ok && (int64_t)((M + 255) / 256) * (N / 256) >= 128 && (N >= 1024 || (K >= 512 && wide_deepk)));
+  static const bool fast_env = []() { const char *e = getenv("PD_H2_FAST"); return !e || e[0] != '0'; }();   // A/B switch: the interleaved interior step
 #define GO(TM, TN, WN, NRS, FAST) return launch_f16x2<TM, TN, WN, 16, false, NRS, FAST>(A, B, bias, C, M, N, K, lda, ldb, ldc, mode, bits, colsum, a_amax, b_amax, c_amax, st, flags)
   // Measured and dropped (tools/bench_gemm_h2.py, M = 43 008): 32-deep steps (1024 <- 256 103.7 vs 96.8 us, 256 <- 1024 90.9 vs 85.4,
   // 256 <- 256 32.9 vs 29.3: half the workgroups in flight), 128 x 256 tiles with two workgroups per CU (no gain).
@@ -913,10 +915,11 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
     if (!wide_ok) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: 256 x 256 tiles need N %% 256 == 0 and M >= 1024");
     if (dbg == 3) GO(256, 256, 128, 1, 0);
     if (dbg == 13 || dbg == 70) GO(256, 256, 128, 2, 0);
+    if (!fast_env) GO(256, 256, 128, 2, 0);
     GO(256, 256, 128, 2, 1);
   }
   if (dbg == 4 || dbg == 70) GO(128, 128, 64, 1, 0);
-  if (dbg == 14) GO(128, 128, 64, 2, 0);
+  if (dbg == 14 || !fast_env) GO(128, 128, 64, 2, 0);
   GO(128, 128, 64, 2, 1);
 #undef GO
 }
@@ -932,7 +935,8 @@ extern "C" int pd_gemm_tn_f16x2_which(int M, int N, int K, int mode, int has_bit
   if (dbg != 62 && dbg != 3 && dbg != 13 && dbg != 70 && (mode == 1 || mode == 2) && has_bits && K == 256 && (N % 256) == 0 && N >= 512 && M >= 8192 && has_amax && g_rows_relu) return 2;
   const bool wide_ok = (N % 256) == 0 && M >= 1024;
   const bool by_shape = dbg == 0 || dbg == 61 || dbg == 70 || dbg == 80 || dbg == 62;
-  const bool wide = has_bits || dbg == 3 || dbg == 13 || (by_shape && wide_ok && (int64_t)((M + 255) / 256) * (N / 256) >= 128 && (N >= 1024 || K >= 512));
+  static const bool wide_deepk = []() { const char *e = getenv("PD_H2_WIDE_DEEPK"); return e && e[0] == '1'; }();
+  const bool wide = has_bits || dbg == 3 || dbg == 13 || (by_shape && wide_ok && (int64_t)((M + 255) / 256) * (N / 256) >= 128 && (N >= 1024 || (K >= 512 && wide_deepk)));
   return wide ? 1 : 0;
 }
 
