@@ -120,6 +120,7 @@ def _pair_selectors(H, B, npair, device):
 
 
 _CONST_CACHE = {}
+_DERIVED = {}
 
 
 def _const(values, dtype, device):
@@ -234,12 +235,19 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
             C = m.cost_mask * cost_mask + m.cost_class * cost_class + m.cost_dice * cost_dice
         rows, cols = lsa_op.solve_batched(C, ncols)                                              # [BD,nmax]
         sel_h, sel_b, sel_k, per_image, inv_img, img_major, img_counts = _pair_selectors(H, B, npair, dev)   # pairs, h-major
-        sel_d = d_of_h[sel_h]
-        sel_p = sel_b * H + sel_d
-        q_idx, j_idx = rows[sel_p, sel_k], cols[sel_p, sel_k]
+        # everything about the pair list that does not depend on the matcher's output is computed once per (heads, batch, target counts)
+        # (was ~10 launches of index arithmetic on 80-element tensors per step)
+        dk = (H, B, tuple(npair), Q, nmax, str(dev))
+        der = _DERIVED.get(dk)
+        if der is None:
+            sd = d_of_h[sel_h]
+            sp = sel_b * H + sd
+            der = _DERIVED[dk] = (sd, sp, sp * rows.shape[1] + sel_k, (sd * B + sel_b) * Q, (sel_b * H + sd) * Q, sel_b * nmax)
+        sel_d, sel_p, lin_pk, base_db, base_bd, base_tgt = der
+        q_idx, j_idx = rows.reshape(-1).index_select(0, lin_pk), cols.reshape(-1).index_select(0, lin_pk)
         # ---- classification targets (criterion.py:126-145)
         tclass = torch.full((B, H, Q), crit.num_classes, dtype=torch.long, device=dev)
-        tclass[sel_b, sel_d, q_idx] = labels_pad[sel_b, j_idx]
+        tclass.view(-1).index_copy_(0, base_bd + q_idx, labels_pad.view(-1).index_select(0, base_tgt + j_idx))     # [b, d, q] <- labels[b, j]
     num_masks = crit.num_masks(targets, dev)
 
     with torch.autocast(device_type=dev.type, enabled=False):
@@ -252,9 +260,9 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
             # the matched queries' embeddings, gathered ONCE and already in image-major order: rows of the flat [B heads Q, C] matrix
             emb_db = emb_bd.transpose(0, 1)                                                      # the decoder's own [heads, B, Q, C] layout
             if emb_db.is_contiguous():
-                emb_rows, flat_idx = emb_db.reshape(H * B * Q, -1), (sel_d * B + sel_b) * Q + q_idx      # a view: no copy of the embeddings
+                emb_rows, flat_idx = emb_db.reshape(H * B * Q, -1), base_db + q_idx      # a view: no copy of the embeddings
             else:
-                emb_rows, flat_idx = emb_bd.reshape(B * H * Q, -1), (sel_b * H + sel_d) * Q + q_idx
+                emb_rows, flat_idx = emb_bd.reshape(B * H * Q, -1), base_bd + q_idx
             e_img = emb_rows.index_select(0, flat_idx.index_select(0, img_major)).float()        # [N,C]
             # [hw, C] @ [C, n_b]: with channels-last mask features the operand is read in place and its gradient comes
             # back channels-last, the layout the 1x1 mask_features convolution's backward wants
@@ -276,7 +284,7 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
                     coords = torch.cat([coords, rcoords], dim=1)                                 # [N,P,2]
             if byte_masks:
                 # pair n reads ITS target (image sel_b[n], target j_idx[n]) at ITS points: one launch, no n_targets-fold oversampling
-                labels = cops.point_sample_masks(padded_masks, coords, sel_b * nmax + j_idx)     # [N,P]
+                labels = cops.point_sample_masks(padded_masks, coords, base_tgt + j_idx)     # [N,P]
             else:
                 labels = torch.empty((coords.shape[0], P), dtype=torch.float32, device=dev)
                 for b in range(B):                                                               # targets as channels
