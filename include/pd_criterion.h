@@ -87,6 +87,29 @@ int pd_uncertain_points(const float *logits, const float *coords, const float *r
 int pd_point_sample_u8(const uint8_t *maps, const int64_t *map_idx, const float *coords, float *out, int rows, int P, int H, int W,
                        int coords_div, void *stream);
 
+/*
+ * Mask logits of the matched (query, target) pairs and their gradients: the rows the criterion keeps of
+ * einsum("bqc,bchw->bqhw", mask_embed, mask_features) (mask2former_transformer_decoder.py:441-459; criterion.py:147-160 src_masks = pred_masks[src_idx]).
+ *   tok        [B, T, C]  channels-last mask features as tokens (T = h w), fp32, C == PD_PAIR_LOGITS_CHANNELS
+ *   e          [N, C]     the pairs' mask embeddings, fp32, grouped by image: image b owns rows [img_start[b], img_start[b + 1])
+ *   img_start  HOST int32 [B + 1], img_start[0] = 0, img_start[B] = N, B <= PD_PAIR_LOGITS_MAX_IMAGES
+ *   out_row    int64 [N] (device) row of out / g that pair i of e is written to / read from (a permutation; NULL: row i)
+ *   out, g     [N, T]     out[out_row[i], t] = sum_c e[i, c] tok[b(i), t, c]
+ *   d_tok      [B, T, C]  d_tok[b, t, c] = sum_{i in image b} g[out_row[i], t] e[i, c]   (zeros for an image without pairs)
+ *   d_e        [N, C]     d_e[i, c] = sum_t g[out_row[i], t] tok[b(i), t, c]; workspace: pd_pair_logits_workspace_floats(T, C, N) floats (partial sums
+ *                         per slab of tokens, added in slab order: deterministic)
+ * Arithmetic: fp32 products, fp32 accumulation (v_mfma_f32_16x16x4_f32).  All pointers 16-byte aligned.
+ */
+#define PD_PAIR_LOGITS_CHANNELS 256
+#define PD_PAIR_LOGITS_MAX_IMAGES 32
+int pd_pair_logits_fwd(const float *tok, const float *e, const int32_t *img_start, const int64_t *out_row, float *out, int B, int T, int C, int N,
+                       void *stream);
+int pd_pair_logits_bwd_tok(const float *g, const float *e, const int32_t *img_start, const int64_t *out_row, float *d_tok, int B, int T, int C, int N,
+                           void *stream);
+int64_t pd_pair_logits_workspace_floats(int T, int C, int N);
+int pd_pair_logits_bwd_rows(const float *g, const float *tok, const int32_t *img_start, const int64_t *out_row, float *d_e, float *workspace, int B,
+                            int T, int C, int N, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

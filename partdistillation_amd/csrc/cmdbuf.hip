@@ -145,6 +145,9 @@ const Entry kTable[] = {
   PD_E(pd_nc_affine_f32),
   PD_E(pd_nc_sums_f32),
   PD_E(pd_normalize_u8_nhwc),
+  PD_E(pd_pair_logits_bwd_rows),
+  PD_E(pd_pair_logits_bwd_tok),
+  PD_E(pd_pair_logits_fwd),
   PD_E(pd_point_sample_nhwc_f32),
   PD_E(pd_point_sample_nhwc_f32_bf16),
   PD_E(pd_point_sample_planar_bwd_f32),

@@ -116,3 +116,66 @@ def point_sample_masks(masks, coords, map_idx=None, coords_div=1):
     _lib.check(_lib.load().pd_point_sample_u8(masks.data_ptr(), mi.data_ptr() if mi is not None else None, coords.data_ptr(), out.data_ptr(), rows, P,
                                               H, W, coords_div, _stream()))
     return out
+
+
+PAIR_LOGITS = ENABLED and __import__("os").environ.get("PD_PAIR_LOGITS", "1") != "0"     # 0: one library GEMM per image (tools/ A/B runs)
+_IMG_START = {}
+
+
+def _img_start(counts):
+    key = tuple(int(c) for c in counts)
+    if key not in _IMG_START:
+        import ctypes
+        acc = [0]
+        for c in key:
+            acc.append(acc[-1] + c)
+        _IMG_START[key] = (ctypes.c_int32 * len(acc))(*acc)
+    return _IMG_START[key]
+
+
+def pair_logits_supported(tok, e):
+    return (PAIR_LOGITS and tok.is_cuda and tok.dtype == torch.float32 and e.dtype == torch.float32 and tok.dim() == 3 and tok.is_contiguous()
+            and tok.shape[2] == 256 and tok.shape[0] <= 32 and e.dim() == 2 and e.shape[1] == 256 and e.shape[0] > 0)
+
+
+class PairLogits(Function):
+    """tok [B, T, 256] fp32 (channels-last mask features as tokens), e [N, 256] fp32 (the matched pairs' mask embeddings, grouped by image:
+    counts[b] rows for image b), out_row int64 [N] (row of the result that pair i of e lands in) -> [N, T]: the mask logits of the matched
+    pairs only (reference: the rows src_masks = pred_masks[src_idx] of the decoder's einsum, criterion.py:147-160).  Both gradients."""
+
+    @staticmethod
+    def forward(ctx, tok, e, out_row, counts):
+        if not tok.is_cuda:
+            raise RuntimeError("pd_pair_logits runs on the GPU only (no CPU fallback in partdistillation_amd)")
+        e = e.contiguous()
+        B, T, C = tok.shape
+        N = e.shape[0]
+        assert sum(counts) == N and len(counts) == B and out_row.shape == (N,) and out_row.dtype == torch.int64
+        out = torch.empty((N, T), dtype=torch.float32, device=tok.device)
+        _lib.check(_lib.load().pd_pair_logits_fwd(tok.data_ptr(), e.data_ptr(), _img_start(counts), out_row.data_ptr(), out.data_ptr(), B, T, C, N,
+                                                  _stream()))
+        ctx.save_for_backward(tok, e, out_row)
+        ctx.counts = counts
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        tok, e, out_row = ctx.saved_tensors
+        B, T, C = tok.shape
+        N = e.shape[0]
+        g = g.contiguous()
+        lib, start = _lib.load(), _img_start(ctx.counts)
+        d_tok = d_e = None
+        if ctx.needs_input_grad[0]:
+            d_tok = torch.empty_like(tok)
+            _lib.check(lib.pd_pair_logits_bwd_tok(g.data_ptr(), e.data_ptr(), start, out_row.data_ptr(), d_tok.data_ptr(), B, T, C, N, _stream()))
+        if ctx.needs_input_grad[1]:
+            d_e = torch.empty_like(e)
+            ws = torch.empty((lib.pd_pair_logits_workspace_floats(T, C, N),), dtype=torch.float32, device=tok.device)
+            _lib.check(lib.pd_pair_logits_bwd_rows(g.data_ptr(), tok.data_ptr(), start, out_row.data_ptr(), d_e.data_ptr(), ws.data_ptr(), B, T, C, N,
+                                                   _stream()))
+        return d_tok, d_e, None, None
+
+
+def pair_logits(tok, e, out_row, counts):
+    return PairLogits.apply(tok, e, out_row, list(counts))

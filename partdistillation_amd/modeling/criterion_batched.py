@@ -267,12 +267,16 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
             # [hw, C] @ [C, n_b]: with channels-last mask features the operand is read in place and its gradient comes
             # back channels-last, the layout the 1x1 mask_features convolution's backward wants
             mf_tok = mfeat.float().permute(0, 2, 3, 1).reshape(B, -1, mfeat.shape[1])            # [B, hw, C]
-            parts = [p.t() for p in _tokens_times_rows_batched(mf_tok, list(e_img.split(img_counts))) if p.numel()]
-            src = torch.cat(parts).index_select(0, inv_img).view(-1, 1, *mfeat.shape[-2:])       # [N,1,h,w], pair (h-major) order
+            if cops.pair_logits_supported(mf_tok, e_img):
+                # one launch: the N matched pairs' logits written in pair order (pd_pair_logits_fwd; fp32 matrix cores)
+                src = cops.pair_logits(mf_tok, e_img, img_major, img_counts).view(-1, 1, *mfeat.shape[-2:])
+            else:
+                parts = [p.t() for p in _tokens_times_rows_batched(mf_tok, list(e_img.split(img_counts))) if p.numel()]
+                src = torch.cat(parts).index_select(0, inv_img).view(-1, 1, *mfeat.shape[-2:])   # [N,1,h,w], pair (h-major) order
         else:
             src = masks_bd[sel_b, sel_d, q_idx][:, None].float()                                 # [N,1,h,w]
         with torch.no_grad():
-            samp = _gs(src, ocoords)[:, 0, :]                                 # [N, kover]
+            samp = _gs(src, ocoords).squeeze(1)                               # [N, kover]
             if cops.uncertain_points_supported(samp, ocoords, kimp):
                 # the kimp oversampled points with the smallest |logit|, then the random ones: radix select + compaction, one launch
                 # (pd_uncertain_points; was abs, neg, a ~20-launch top-k, gather, cat).  The losses are sums over the chosen points.
@@ -293,7 +297,7 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
                         continue
                     s = _gs(tmask[b:b + 1], coords[pi].reshape(1, -1, 2)).reshape(nmax, pi.numel(), P)
                     labels[pi] = s[j_idx[pi], _arange(pi.numel(), dev)]
-        pl = _gs(src, coords)[:, 0, :]                                                           # [N,P]
+        pl = _gs(src, coords).squeeze(1)                                                         # [N,P] (a view both ways: select's backward fills and copies)
         if cops.mask_point_losses_supported(pl, labels):
             bce, dice = cops.mask_point_losses(pl, labels)                    # per mask, forward and backward one launch each
         else:

@@ -157,6 +157,35 @@ def test_own_mlp_node_matches_the_module_path_under_autocast(rows_shape):
         close(p.grad, q.grad, n)
 
 
+@pytest.mark.parametrize("counts,T", [([40, 40], 65536), ([40, 0, 7], 1000), ([100, 5], 1027), ([0, 3], 64), ([1], 4), ([48, 49, 16], 2050)])
+def test_pair_logits_forward_and_gradients_vs_fp64(counts, T):
+    """pd_pair_logits_*: the matched pairs' mask logits out[row(i)] = tok[b(i)] e[i] and both gradients against the same products in fp64:
+    images without pairs, more pairs than one pass holds (> 48), token counts that are not multiples of the tiles (and of 4: scalar
+    edges), a permuted output order.  fp32 products and sums: 2e-6 of the result's scale for K = 256, 1e-5 for the sums over T."""
+    from partdistillation_amd.functions import criterion_ops as cops
+    torch.manual_seed(T + len(counts))
+    B, N, C = len(counts), sum(counts), 256
+    tok = torch.randn(B, T, C, device=DEV, requires_grad=True)
+    e = torch.randn(N, C, device=DEV, requires_grad=True)
+    out_row = torch.randperm(N, device=DEV)
+    assert cops.pair_logits_supported(tok, e)
+    out = cops.pair_logits(tok, e, out_row, counts)
+    g = torch.randn(N, T, device=DEV)
+    out.backward(g)
+    img = torch.repeat_interleave(torch.arange(B, device=DEV), torch.tensor(counts, device=DEV))
+    t64, e64 = tok.detach().double().requires_grad_(True), e.detach().double().requires_grad_(True)
+    ref = torch.empty(N, T, dtype=torch.float64, device=DEV)
+    ref[out_row] = torch.einsum("ntc,nc->nt", t64[img], e64)
+    ref.backward(g.double())
+    scale = lambda x: float(x.abs().max().clamp_min(1e-30))
+    assert float((out.double() - ref).abs().max()) <= 2e-6 * scale(ref)
+    assert float((tok.grad.double() - t64.grad).abs().max()) <= 2e-6 * scale(t64.grad) + 1e-30
+    assert float((e.grad.double() - e64.grad).abs().max()) <= 1e-5 * scale(e64.grad)
+    for b, c in enumerate(counts):
+        if c == 0:
+            assert float(tok.grad[b].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("shape,P", [((2, 4, 64, 48), 500), ((1, 1, 7, 9), 33), ((3, 2, 128, 128), 4096)])
 def test_point_sample_masks_equals_grid_sample_of_the_float_copy(shape, P):
     """pd_point_sample_u8: the padded target masks sampled as stored (bool bytes) — bit-identical to the planar fp32 sampler on

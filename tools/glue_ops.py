@@ -51,3 +51,16 @@ tot = sum(v[1] for v in agg.values())
 print(f"device time of the listed aten operators: {tot / N / 1e3:.2f} ms / step")
 for (name, shapes, frame), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('TOP', '60'))]:
     print(f"{t / N:8.1f} us  x{c / N:5.1f}  {name:12s} {shapes:60.60s} {frame}")
+# memsets / device copies (runtime calls, not aten operators with device time of their own): which operator or autograd node issues them
+rt = collections.defaultdict(int)
+for e in prof.events():
+    if not any(s in e.name for s in ("hipMemset", "hipMemcpy", "Memset", "Memcpy")) or e.name.startswith("aten::"):
+        continue
+    chain, q = [], e.cpu_parent
+    while q is not None and len(chain) < 5:
+        chain.append(q.name + (" " + str(q.input_shapes)[:50] if q.input_shapes else ""))
+        q = q.cpu_parent
+    rt[(e.name, " < ".join(chain) or "(no operator: libpd_hip.so / recorded region)")] += 1
+print("memsets and copies per step, by issuing operator:")
+for (name, chain), c in sorted(rt.items(), key=lambda kv: -kv[1]):
+    print(f"  x{c / N:5.1f}  {name:22s} {chain[:200]}")
