@@ -166,6 +166,19 @@ int pd_add_rows_amax_f32(const float *a, const float *b, float *q, float *a_copy
 int pd_sum3_sum2_f32(const float *a, const float *b, const float *c, const float *d, float *out1, float *out2, int64_t n, void *stream);
 
 /*
+ * Linear layer with few output columns (K <= 8): the decoder's class head over all prediction heads' queries (reference
+ * mask2former_transformer_decoder.py:223 class_embed = nn.Linear(hidden_dim, num_classes + 1), applied at :446).
+ *   forward   y [R, K] fp32 = x [R, C] (bf16) w [K, C]^T + b [K]      (w, b in wb_dtype: PD_F32 / PD_BF16; b nullable; C % 4 == 0)
+ *   backward  dx_out [R, C] (dx_dtype; nullable) = dx_in (bf16, nullable: the gradient another consumer of x already produced) + dy [R, K] w;
+ *             dw [K, C] (w_dtype) = dy^T x;  db [K] (b_dtype; nullable) = column sums of dy.  `partial`: pd_skinny_linear_partial_floats(R, C, K)
+ *             floats — per-workgroup partial sums added in workgroup order (deterministic).  fp32 products and sums.
+ */
+int pd_skinny_linear_fwd(const void *x_bf16, const void *w, const void *b, int wb_dtype, float *y, int R, int C, int K, void *stream);
+int64_t pd_skinny_linear_partial_floats(int R, int C, int K);
+int pd_skinny_linear_bwd(const void *x_bf16, const void *w, int w_dtype, const float *dy, const void *dx_in_bf16, void *dx_out, int dx_dtype,
+                         float *partial, void *dw, void *db, int b_dtype, int R, int C, int K, void *stream);
+
+/*
  * dst_i [batch, cols, rows] (contiguous) = src_i [batch, rows, cols]^T, fp32, for up to PD_TRANSPOSE_MAX problems in one launch.  src_i may
  * be strided: src_batch_stride / src_row_stride in floats (unit column stride) — the layers' weights where they lie in the flat parameter
  * buffer.  The transposed weight stacks of the fp32 encoder's input-gradient GEMMs (dX = dY W needs W^T as the [N, K] operand).

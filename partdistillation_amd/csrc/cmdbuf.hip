@@ -169,6 +169,8 @@ const Entry kTable[] = {
   PD_E(pd_sgemm_wgrad_bf16),
   PD_E(pd_sgemm_wgrad_grouped_bf16),
   PD_E(pd_sgemm_wgrad_split_bf16),
+  PD_E(pd_skinny_linear_bwd),
+  PD_E(pd_skinny_linear_fwd),
   PD_E(pd_split3_bf16),
   PD_E(pd_stem7x7_fwd),
   PD_E(pd_stem7x7_wgrad),

@@ -1246,6 +1246,142 @@ extern "C" int pd_resize_bilinear_nhwc_f32(const float *x, int B, int H, int W, 
   return pd_check_launch("pd_resize_bilinear_nhwc_f32");
 }
 
+// ------------------------------------------------------------------------------------------------ skinny linear (class head)
+// y = x w^T + b for K <= 8 output columns (the decoder's class head: [heads B Q = 2 000, 256] x [K + 1 = 2, 256]^T, reference
+// mask2former_transformer_decoder.py:223, 446).  The library serves the forward in 5 us and the weight gradient [2, 2000] x [2000, 256] in
+// 41 us; here a wavefront per row forward, and ONE backward pass per 16 rows that forms d x (added to the mask-embedding MLP's d x, which
+// shares the input), and per-workgroup partial d w / d b that skinny_linear_reduce adds in workgroup order.
+namespace {
+constexpr int SK_MAXK = 8, SK_RB = 16;
+__device__ __forceinline__ float4 ldw4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 ldw4(const bf16_t *p) { return ld4(p); }
+__device__ __forceinline__ float ldw1(const float *p) { return *p; }
+__device__ __forceinline__ float ldw1(const bf16_t *p) { return bf2f(*p); }
+__device__ __forceinline__ void stw1(float *p, float v) { *p = v; }
+__device__ __forceinline__ void stw1(bf16_t *p, float v) { *p = f2bf(v); }
+
+template <typename WT>
+__global__ __launch_bounds__(256) void skinny_linear_fwd(const bf16_t *__restrict__ x, const WT *__restrict__ w, const WT *__restrict__ b,
+                                                         float *__restrict__ y, int R, int C, int K)
+{
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  float acc[SK_MAXK];
+#pragma unroll
+  for (int k = 0; k < SK_MAXK; ++k) acc[k] = 0.f;
+  for (int c = 4 * lane; c < C; c += 256) {
+    const float4 xv = ld4(x + (int64_t)row * C + c);
+#pragma unroll
+    for (int k = 0; k < SK_MAXK; ++k)
+      if (k < K) {
+        const float4 wv = ldw4(w + (int64_t)k * C + c);
+        acc[k] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < SK_MAXK; ++k)
+    if (k < K) {
+      const float v = wave_sum(acc[k]);
+      if (lane == 0) y[(int64_t)row * K + k] = v + (b ? ldw1(b + k) : 0.f);
+    }
+}
+
+// partial [workgroups][K][C + 1]: column C holds the bias partial
+template <typename WT, typename DXT>
+__global__ __launch_bounds__(256) void skinny_linear_bwd(const bf16_t *__restrict__ x, const WT *__restrict__ w, const float *__restrict__ dy,
+                                                         const bf16_t *__restrict__ dx_in, DXT *__restrict__ dx_out, float *__restrict__ partial,
+                                                         int R, int C, int K)
+{
+  __shared__ float dys[SK_RB][SK_MAXK];
+  const int r0 = blockIdx.x * SK_RB, nr = min(SK_RB, R - r0);
+  if (threadIdx.x < SK_RB * SK_MAXK) {
+    const int r = threadIdx.x / SK_MAXK, k = threadIdx.x % SK_MAXK;
+    dys[r][k] = (r < nr && k < K) ? dy[(int64_t)(r0 + r) * K + k] : 0.f;
+  }
+  __syncthreads();
+  float *pw = partial + (int64_t)blockIdx.x * K * (C + 1);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float wk[SK_MAXK], dw[SK_MAXK];
+#pragma unroll
+    for (int k = 0; k < SK_MAXK; ++k) wk[k] = k < K ? ldw1(w + (int64_t)k * C + c) : 0.f, dw[k] = 0.f;
+    for (int r = 0; r < nr; ++r) {
+      const int64_t at = (int64_t)(r0 + r) * C + c;
+      const float xv = bf2f(x[at]);
+      float d = dx_in ? bf2f(dx_in[at]) : 0.f;
+#pragma unroll
+      for (int k = 0; k < SK_MAXK; ++k) d += dys[r][k] * wk[k], dw[k] += dys[r][k] * xv;
+      if (dx_out) stw1(dx_out + at, d);
+    }
+#pragma unroll
+    for (int k = 0; k < SK_MAXK; ++k)
+      if (k < K) pw[k * (C + 1) + c] = dw[k];
+  }
+  if (threadIdx.x < K) {
+    float s = 0.f;
+    for (int r = 0; r < nr; ++r) s += dys[r][threadIdx.x];
+    pw[threadIdx.x * (C + 1) + C] = s;
+  }
+}
+
+template <typename WT, typename BT>
+__global__ __launch_bounds__(256) void skinny_linear_reduce(const float *__restrict__ partial, WT *__restrict__ dw, BT *__restrict__ db, int groups, int C, int K)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x, n = K * (C + 1);
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int g = 0;
+  for (; g + 3 < groups; g += 4) {
+    s0 += partial[(int64_t)g * n + i], s1 += partial[(int64_t)(g + 1) * n + i];
+    s2 += partial[(int64_t)(g + 2) * n + i], s3 += partial[(int64_t)(g + 3) * n + i];
+  }
+  for (; g < groups; ++g) s0 += partial[(int64_t)g * n + i];
+  const float s = (s0 + s1) + (s2 + s3);
+  const int k = i / (C + 1), c = i - k * (C + 1);
+  if (c < C) stw1(dw + (int64_t)k * C + c, s);
+  else if (db) stw1(db + k, s);
+}
+}  // namespace
+
+extern "C" int pd_skinny_linear_fwd(const void *x_bf16, const void *w, const void *b, int wb_dtype, float *y, int R, int C, int K, void *stream_)
+{
+  if (R < 0 || C <= 0 || (C & 3) || K <= 0 || K > SK_MAXK || !dt_ok(wb_dtype))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_skinny_linear_fwd: R=%d C=%d (a multiple of 4) K=%d (<= %d) dtype=%d", R, C, K, SK_MAXK, wb_dtype);
+  if (R == 0) return PD_OK;
+  if (!x_bf16 || !w || !y || (((uintptr_t)x_bf16 | (uintptr_t)w) & 7)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_skinny_linear_fwd: null / misaligned pointer");
+  const dim3 g((unsigned)((R + 3) / 4)), t(256);
+  if (wb_dtype == PD_BF16)
+    hipLaunchKernelGGL(skinny_linear_fwd<bf16_t>, g, t, 0, (hipStream_t)stream_, (const bf16_t *)x_bf16, (const bf16_t *)w, (const bf16_t *)b, y, R, C, K);
+  else
+    hipLaunchKernelGGL(skinny_linear_fwd<float>, g, t, 0, (hipStream_t)stream_, (const bf16_t *)x_bf16, (const float *)w, (const float *)b, y, R, C, K);
+  return pd_check_launch("pd_skinny_linear_fwd");
+}
+
+extern "C" int64_t pd_skinny_linear_partial_floats(int R, int C, int K) { return (int64_t)((R + SK_RB - 1) / SK_RB) * K * (C + 1); }
+
+extern "C" int pd_skinny_linear_bwd(const void *x_bf16, const void *w, int w_dtype, const float *dy, const void *dx_in_bf16, void *dx_out, int dx_dtype,
+                                    float *partial, void *dw, void *db, int b_dtype, int R, int C, int K, void *stream_)
+{
+  if (R < 0 || C <= 0 || K <= 0 || K > SK_MAXK || !dt_ok(w_dtype) || !dt_ok(dx_dtype) || !dt_ok(b_dtype))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_skinny_linear_bwd: R=%d C=%d K=%d (<= %d) dtypes %d %d %d", R, C, K, SK_MAXK, w_dtype, dx_dtype, b_dtype);
+  if (!x_bf16 || !w || !dy || !partial || !dw) return pd_set_error(PD_ERR_INVALID_ARG, "pd_skinny_linear_bwd: null pointer");
+  const int groups = (R + SK_RB - 1) / SK_RB;
+  hipStream_t s = (hipStream_t)stream_;
+  if (groups) {
+    const dim3 g((unsigned)groups), t(256);
+#define PD_SK(WT, DXT) hipLaunchKernelGGL((skinny_linear_bwd<WT, DXT>), g, t, 0, s, (const bf16_t *)x_bf16, (const WT *)w, dy, (const bf16_t *)dx_in_bf16, \
+                                          (DXT *)dx_out, partial, R, C, K)
+    if (w_dtype == PD_BF16) { if (dx_dtype == PD_BF16) PD_SK(bf16_t, bf16_t); else PD_SK(bf16_t, float); }
+    else { if (dx_dtype == PD_BF16) PD_SK(float, bf16_t); else PD_SK(float, float); }
+#undef PD_SK
+  }
+  const dim3 g2((unsigned)((K * (C + 1) + 255) / 256)), t2(256);
+#define PD_SKR(WT, BT) hipLaunchKernelGGL((skinny_linear_reduce<WT, BT>), g2, t2, 0, s, partial, (WT *)dw, (BT *)db, groups, C, K)
+  if (w_dtype == PD_BF16) { if (b_dtype == PD_BF16) PD_SKR(bf16_t, bf16_t); else PD_SKR(bf16_t, float); }
+  else { if (b_dtype == PD_BF16) PD_SKR(float, bf16_t); else PD_SKR(float, float); }
+#undef PD_SKR
+  return pd_check_launch("pd_skinny_linear_bwd");
+}
+
 extern "C" int pd_add_rows_amax_f32(const float *a, const float *b, float *q, float *a_copy, float *a_amax, float *q_amax, int rows, int cols,
                                     void *stream_)
 {

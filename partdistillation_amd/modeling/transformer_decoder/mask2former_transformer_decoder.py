@@ -324,8 +324,12 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
                            pooled, self.decoder_norm.eps, cdt, self.num_feature_levels)
         dec_outs, final_tgt = DecoderCore.apply(spec, *x, *self._core_params())          # [L+1, Q*B, C] fp32, [Q*B, C]
         d = dec_outs.view(L + 1, Q, bs, C).transpose(1, 2)                               # [L+1, B, Q, C]
-        all_logits = self._class_logits_stacked(d, extra) if self.mask_classification else None
-        emb = self.mask_embed(d)                                                         # one MLP pass for the L+1 heads
+        if (self.mask_classification and type(self)._class_logits is MultiScaleMaskedTransformerDecoder._class_logits
+                and mlp_own.heads_supported(d, self.class_embed, self.mask_embed.layers)):
+            all_logits, emb = mlp_own.heads(d, self.class_embed, self.mask_embed.layers)  # class head + MLP: one node, one bf16 copy of d
+        else:
+            all_logits = self._class_logits_stacked(d, extra) if self.mask_classification else None
+            emb = self.mask_embed(d)                                                     # one MLP pass for the L+1 heads
         if self.query_feature_normalize:
             emb = F.normalize(emb, p=2, dim=-1)
         emb = emb.transpose(0, 1)                                                        # [B, L+1, Q, C]

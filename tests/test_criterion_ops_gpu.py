@@ -157,6 +157,45 @@ def test_own_mlp_node_matches_the_module_path_under_autocast(rows_shape):
         close(p.grad, q.grad, n)
 
 
+@pytest.mark.parametrize("rows_shape,K", [((10, 2, 100), 2), ((3, 70), 8), ((1, 203), 1)])
+def test_own_heads_node_class_head_and_mlp_vs_fp32_module_path(rows_shape, K):
+    """functions/mlp_own.py HeadsOwn: class head (pd_skinny_linear_*: bf16 input, fp32 products, fp32 logits) + the mask-embedding MLP as one
+    node, against nn.Linear in fp32 on the SAME bf16-rounded input and weights (class head: 1e-5 of the magnitudes — only the summation order
+    differs; the input gradient carries the MLP's bf16 gradient: 2^-7) — a transposed (non-contiguous) input as the decoder hands over."""
+    from partdistillation_amd.functions import mlp_own
+    from partdistillation_amd.modeling.transformer_decoder.mask2former_transformer_decoder import MLP
+    import torch.nn as nn
+    torch.manual_seed(K)
+    mlp_ref, mlp_o = MLP(256, 256, 256, 3).to(DEV), MLP(256, 256, 256, 3).to(DEV)
+    cls_ref, cls_o = nn.Linear(256, K).to(DEV), nn.Linear(256, K).to(DEV)
+    mlp_o.load_state_dict(mlp_ref.state_dict()), cls_o.load_state_dict(cls_ref.state_dict())
+    for p in list(mlp_o.parameters()) + list(cls_o.parameters()):
+        p.data = p.data.to(torch.bfloat16)
+    for p, q in zip(cls_ref.parameters(), cls_o.parameters()):
+        p.data = q.data.float()                                       # the reference head holds the bf16-rounded values in fp32
+    x = torch.randn(*rows_shape[::-1], 256, device=DEV).to(torch.bfloat16).float()
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    tr = (lambda t: t.transpose(0, 1)) if len(rows_shape) == 2 else (lambda t: t.permute(2, 1, 0, 3))
+    gl, ge = torch.randn(*rows_shape, K, device=DEV), torch.randn(*rows_shape, 256, device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert mlp_own.heads_supported(tr(x2), cls_o, mlp_o.layers)
+        logits, emb = mlp_own.heads(tr(x2), cls_o, mlp_o.layers)
+        emb_ref = mlp_own.mlp(tr(x1), mlp_o.layers)                  # the MLP node alone (tested above against the module path)
+    log_ref = cls_ref(tr(x1))
+    assert logits.dtype == torch.float32 and logits.shape == (*rows_shape, K) and emb.dtype == torch.bfloat16
+    ((logits * gl).sum() + (emb.float() * ge).sum()).backward()
+    ((log_ref * gl).sum() + (emb_ref.float() * ge).sum()).backward()
+    rel = lambda a, b: float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-30))
+    assert rel(logits, log_ref) <= 1e-5
+    assert float((emb.float() - emb_ref.float()).abs().max()) == 0.0
+    assert rel(x2.grad, x1.grad) <= 2 ** -7
+    for p, q in zip(cls_o.parameters(), cls_ref.parameters()):
+        assert p.grad.dtype == torch.bfloat16
+        assert rel(p.grad, q.grad) <= 2 ** -8                          # fp32 sums, rounded once to the bf16 parameter gradient
+    for p, q in zip(mlp_o.parameters(), mlp_o.parameters()):
+        assert p.grad is not None
+
+
 @pytest.mark.parametrize("counts,T", [([40, 40], 65536), ([40, 0, 7], 1000), ([100, 5], 1027), ([0, 3], 64), ([1], 4), ([48, 49, 16], 2050)])
 def test_pair_logits_forward_and_gradients_vs_fp64(counts, T):
     """pd_pair_logits_*: the matched pairs' mask logits out[row(i)] = tok[b(i)] e[i] and both gradients against the same products in fp64:
