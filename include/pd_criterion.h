@@ -88,6 +88,23 @@ int pd_point_sample_u8(const uint8_t *maps, const int64_t *map_idx, const float 
                        int coords_div, void *stream);
 
 /*
+ * The criterion's three loss vectors [3, H] (rows: loss_ce, loss_mask, loss_dice; column h = head in criterion order: 0 = final output,
+ * 1.. = aux_outputs[h - 1]) in one launch, and their gradient in one:
+ *   vec[0, h] = sum_{b, q} w[t] (logsumexp(x) - x[t]) / sum_{b, q} w[t],  x = logits[b, d_of_h[h], q, :], t = tclass[b, d_of_h[h], q]
+ *               (F.cross_entropy(src_logits.transpose(1, 2), target_classes, empty_weight), criterion.py:126-145)
+ *   vec[1, h] = sum_n bce[h, n] / num_masks,  vec[2, h] = sum_n dice[h, n] / num_masks        (criterion.py:203-206; bce / dice [H, Nh])
+ *   logits: element (b, d, q, k) at b * image_stride + d * head_stride + q * K1 + k (fp32); tclass int64 [B, H, Q] with d in the middle;
+ *   class_weight [K1]; d_of_h int64 [H]; num_masks: device scalar.  lse [B, H, Q] and den [H] (indexed by d) are what the backward keeps.
+ *   backward: d_logits (same strides as logits), d_bce, d_dice [H, Nh] from dvec [3, H].
+ */
+int pd_loss_vectors_fwd(const float *logits, int64_t image_stride, int64_t head_stride, const int64_t *tclass, const float *class_weight,
+                        const int64_t *d_of_h, const float *bce, const float *dice, const float *num_masks, float *vec, float *lse, float *den, int B,
+                        int H, int Q, int K1, int Nh, void *stream);
+int pd_loss_vectors_bwd(const float *logits, int64_t image_stride, int64_t head_stride, const int64_t *tclass, const float *class_weight,
+                        const int64_t *d_of_h, const float *num_masks, const float *lse, const float *den, const float *dvec, float *d_logits,
+                        float *d_bce, float *d_dice, int B, int H, int Q, int K1, int Nh, void *stream);
+
+/*
  * Mask logits of the matched (query, target) pairs and their gradients: the rows the criterion keeps of
  * einsum("bqc,bchw->bqhw", mask_embed, mask_features) (mask2former_transformer_decoder.py:441-459; criterion.py:147-160 src_masks = pred_masks[src_idx]).
  *   tok        [B, T, C]  channels-last mask features as tokens (T = h w), fp32, C == PD_PAIR_LOGITS_CHANNELS

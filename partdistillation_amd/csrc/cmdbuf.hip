@@ -115,6 +115,8 @@ const Entry kTable[] = {
   PD_E(pd_kmeans_update),
   PD_E(pd_layernorm_rows_f32_bwd),
   PD_E(pd_layernorm_rows_f32_fwd),
+  PD_E(pd_loss_vectors_bwd),
+  PD_E(pd_loss_vectors_fwd),
   PD_E(pd_lsa_batched),
   PD_E(pd_mask_assign),
   PD_E(pd_mask_point_losses_bwd),

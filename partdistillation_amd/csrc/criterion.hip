@@ -372,6 +372,103 @@ __global__ __launch_bounds__(256) void point_sample_u8(const uint8_t *__restrict
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ the three loss vectors
+// One workgroup per prediction head h (criterion order; d = d_of_h[h] its place in the decoder's stack): the weighted cross entropy of
+// the head's B Q queries (F.cross_entropy with class weights: sum w[t] nll / sum w[t], criterion.py:126-145) and the sums of its matched
+// masks' BCE / dice terms over num_masks (criterion.py:203-206).  Was log_softmax + nll_loss + two reductions + an index + a division, and
+// two reductions + two divisions, and their ~20 backward launches.
+namespace {
+__device__ __forceinline__ float block_sum_256(float v, float *red)
+{
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void loss_vectors_fwd(const float *__restrict__ logits, int64_t sb, int64_t sd, const int64_t *__restrict__ tclass,
+                                                        const float *__restrict__ w, const int64_t *__restrict__ d_of_h, const float *__restrict__ bce,
+                                                        const float *__restrict__ dice, const float *__restrict__ num_masks, float *__restrict__ vec,
+                                                        float *__restrict__ lse, float *__restrict__ den, int B, int H, int Q, int K1, int Nh)
+{
+  __shared__ float red[4];
+  const int h = blockIdx.x, d = (int)d_of_h[h];
+  float num = 0.f, dn = 0.f;
+  for (int i = threadIdx.x; i < B * Q; i += 256) {
+    const int b = i / Q, q = i - b * Q;
+    const float *x = logits + b * sb + d * sd + (int64_t)q * K1;
+    const int64_t at = ((int64_t)b * H + d) * Q + q;
+    const int t = (int)tclass[at];
+    float m = x[0];
+    for (int k = 1; k < K1; ++k) m = fmaxf(m, x[k]);
+    float sum = 0.f;
+    for (int k = 0; k < K1; ++k) sum += expf(x[k] - m);
+    const float l = m + logf(sum), wt = w[t];
+    lse[at] = l;
+    num += wt * (l - x[t]);
+    dn += wt;
+  }
+  num = block_sum_256(num, red);
+  dn = block_sum_256(dn, red);
+  float sm = 0.f, sdc = 0.f;
+  for (int n = threadIdx.x; n < Nh; n += 256) sm += bce[(int64_t)h * Nh + n], sdc += dice[(int64_t)h * Nh + n];
+  sm = block_sum_256(sm, red);
+  sdc = block_sum_256(sdc, red);
+  if (threadIdx.x == 0) {
+    const float nm = *num_masks;
+    vec[h] = num / dn;
+    vec[H + h] = sm / nm;
+    vec[2 * H + h] = sdc / nm;
+    den[d] = dn;
+  }
+}
+
+// d logits[b, d, q, k] = dvec[0, h] / den[d] * w[t] (softmax_k - [k == t]);  d bce[n] = dvec[1, h(n)] / num_masks, d dice likewise
+__global__ __launch_bounds__(256) void loss_vectors_bwd(const float *__restrict__ logits, int64_t sb, int64_t sd, const int64_t *__restrict__ tclass,
+                                                        const float *__restrict__ w, const int64_t *__restrict__ d_of_h, const float *__restrict__ num_masks,
+                                                        const float *__restrict__ lse, const float *__restrict__ den, const float *__restrict__ dvec,
+                                                        float *__restrict__ d_logits, float *__restrict__ d_bce, float *__restrict__ d_dice, int B, int H,
+                                                        int Q, int K1, int Nh)
+{
+  const int h = blockIdx.x, d = (int)d_of_h[h];
+  const float gce = dvec[h] / den[d], nm = *num_masks;
+  for (int i = threadIdx.x; i < B * Q; i += 256) {
+    const int b = i / Q, q = i - b * Q;
+    const int64_t off = b * sb + d * sd + (int64_t)q * K1, at = ((int64_t)b * H + d) * Q + q;
+    const int t = (int)tclass[at];
+    const float c = gce * w[t], l = lse[at];
+    for (int k = 0; k < K1; ++k) d_logits[off + k] = c * (expf(logits[off + k] - l) - (k == t ? 1.f : 0.f));
+  }
+  const float gm = dvec[H + h] / nm, gd = dvec[2 * H + h] / nm;
+  for (int n = threadIdx.x; n < Nh; n += 256) d_bce[(int64_t)h * Nh + n] = gm, d_dice[(int64_t)h * Nh + n] = gd;
+}
+}  // namespace
+
+extern "C" int pd_loss_vectors_fwd(const float *logits, int64_t image_stride, int64_t head_stride, const int64_t *tclass, const float *class_weight,
+                                   const int64_t *d_of_h, const float *bce, const float *dice, const float *num_masks, float *vec, float *lse, float *den,
+                                   int B, int H, int Q, int K1, int Nh, void *stream_)
+{
+  if (B <= 0 || H <= 0 || Q <= 0 || K1 <= 0 || Nh < 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_loss_vectors_fwd: B=%d H=%d Q=%d K1=%d Nh=%d", B, H, Q, K1, Nh);
+  if (!logits || !tclass || !class_weight || !d_of_h || !num_masks || !vec || !lse || !den || (Nh && (!bce || !dice)))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_loss_vectors_fwd: null pointer");
+  hipLaunchKernelGGL(loss_vectors_fwd, dim3((unsigned)H), dim3(256), 0, (hipStream_t)stream_, logits, image_stride, head_stride, tclass, class_weight, d_of_h,
+                     bce, dice, num_masks, vec, lse, den, B, H, Q, K1, Nh);
+  return pd_check_launch("pd_loss_vectors_fwd");
+}
+
+extern "C" int pd_loss_vectors_bwd(const float *logits, int64_t image_stride, int64_t head_stride, const int64_t *tclass, const float *class_weight,
+                                   const int64_t *d_of_h, const float *num_masks, const float *lse, const float *den, const float *dvec, float *d_logits,
+                                   float *d_bce, float *d_dice, int B, int H, int Q, int K1, int Nh, void *stream_)
+{
+  if (B <= 0 || H <= 0 || Q <= 0 || K1 <= 0 || Nh < 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_loss_vectors_bwd: B=%d H=%d Q=%d K1=%d Nh=%d", B, H, Q, K1, Nh);
+  if (!logits || !tclass || !class_weight || !d_of_h || !num_masks || !lse || !den || !dvec || !d_logits || (Nh && (!d_bce || !d_dice)))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_loss_vectors_bwd: null pointer");
+  hipLaunchKernelGGL(loss_vectors_bwd, dim3((unsigned)H), dim3(256), 0, (hipStream_t)stream_, logits, image_stride, head_stride, tclass, class_weight, d_of_h,
+                     num_masks, lse, den, dvec, d_logits, d_bce, d_dice, B, H, Q, K1, Nh);
+  return pd_check_launch("pd_loss_vectors_bwd");
+}
+
 extern "C" int pd_point_sample_u8(const uint8_t *maps, const int64_t *map_idx, const float *coords, float *out, int rows, int P, int H, int W,
                                   int coords_div, void *stream_)
 {

@@ -1376,8 +1376,12 @@ extern "C" int pd_msda_fused_backward(const float *value, const int64_t *spatial
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_fused_backward: projection rows need >= 3 M L P columns, strides that are multiples of 4 and 16-byte aligned bases");
   hipStream_t stream = (hipStream_t)stream_;
   const size_t nv = (size_t)batch * spatial_size * num_heads * channels;
-  (void)hipMemsetAsync(grad_value, 0, nv * sizeof(float), stream);
-  if (d_oa_amax) (void)hipMemsetAsync(d_oa_amax, 0, (size_t)batch * num_query * sizeof(float), stream);
+  if (d_oa_amax == grad_value + nv) {              // the module path allocates them back to back: one clear
+    (void)hipMemsetAsync(grad_value, 0, (nv + (size_t)batch * num_query) * sizeof(float), stream);
+  } else {
+    (void)hipMemsetAsync(grad_value, 0, nv * sizeof(float), stream);
+    if (d_oa_amax) (void)hipMemsetAsync(d_oa_amax, 0, (size_t)batch * num_query * sizeof(float), stream);
+  }
   const size_t lds4 = ((size_t)kOwnCells4 * 33 + 64) * sizeof(int), lds4h = ((size_t)kOwnCells4H * 17 + 64) * sizeof(int);
   const auto k5 = g_pd_dbg_ablate == 8 ? msda_bwd_owner4_d32<8, false, true> : g_pd_dbg_ablate == 32 ? msda_bwd_owner4_d32<32, false, true>
                 : g_pd_dbg_ablate == 96 ? msda_bwd_owner4_d32<96, false, true> : msda_bwd_owner4_d32<0, false, true>;

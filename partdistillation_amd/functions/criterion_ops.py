@@ -118,7 +118,7 @@ def point_sample_masks(masks, coords, map_idx=None, coords_div=1):
     return out
 
 
-PAIR_LOGITS = ENABLED and __import__("os").environ.get("PD_PAIR_LOGITS", "1") != "0"     # 0: one library GEMM per image (tools/ A/B runs)
+PAIR_LOGITS = __import__("os").environ.get("PD_PAIR_LOGITS", "1") != "0"     # 0: one library GEMM per image (tools/ A/B runs)
 _IMG_START = {}
 
 
@@ -134,7 +134,7 @@ def _img_start(counts):
 
 
 def pair_logits_supported(tok, e):
-    return (PAIR_LOGITS and tok.is_cuda and tok.dtype == torch.float32 and e.dtype == torch.float32 and tok.dim() == 3 and tok.is_contiguous()
+    return (ENABLED and PAIR_LOGITS and tok.is_cuda and tok.dtype == torch.float32 and e.dtype == torch.float32 and tok.dim() == 3 and tok.is_contiguous()
             and tok.shape[2] == 256 and tok.shape[0] <= 32 and e.dim() == 2 and e.shape[1] == 256 and e.shape[0] > 0)
 
 
@@ -179,3 +179,54 @@ class PairLogits(Function):
 
 def pair_logits(tok, e, out_row, counts):
     return PairLogits.apply(tok, e, out_row, list(counts))
+
+
+LOSS_VECTORS = __import__("os").environ.get("PD_LOSS_VECTORS", "1") != "0"    # 0: the torch expressions (tools/ A/B runs)
+
+
+def loss_vectors_supported(logits_bd, tclass, class_weight):
+    return (ENABLED and LOSS_VECTORS and logits_bd.is_cuda and logits_bd.dtype == torch.float32 and logits_bd.dim() == 4 and tclass.dtype == torch.int64
+            and tclass.is_contiguous() and class_weight.dtype == torch.float32 and torch.is_grad_enabled())
+
+
+class LossVectors(Function):
+    """logits [B, H, Q, K1] fp32 (any image / head strides), tclass int64 [B, H, Q], class_weight [K1], d_of_h int64 [H], bce / dice [H * Nh]
+    (criterion order), num_masks (device scalar) -> [3, H]: loss_ce, loss_mask, loss_dice of every head in criterion order
+    (reference criterion.py:126-145, 203-206).  Gradients with respect to logits, bce, dice."""
+
+    @staticmethod
+    def forward(ctx, logits, tclass, class_weight, d_of_h, bce, dice, num_masks):
+        if not logits.is_cuda:
+            raise RuntimeError("pd_loss_vectors runs on the GPU only (no CPU fallback in partdistillation_amd)")
+        if logits.stride(3) != 1 or logits.stride(2) != logits.shape[3]:
+            logits = logits.contiguous()
+        B, H, Q, K1 = logits.shape
+        bce, dice = bce.contiguous().float(), dice.contiguous().float()
+        assert bce.numel() % H == 0 and dice.numel() == bce.numel()
+        Nh = bce.numel() // H
+        nm = num_masks if num_masks.dtype == torch.float32 else num_masks.float()
+        vec = torch.empty((3, H), dtype=torch.float32, device=logits.device)
+        lse = torch.empty((B, H, Q), dtype=torch.float32, device=logits.device)
+        den = torch.empty((H,), dtype=torch.float32, device=logits.device)
+        _lib.check(_lib.load().pd_loss_vectors_fwd(logits.data_ptr(), logits.stride(0), logits.stride(1), tclass.data_ptr(), class_weight.data_ptr(),
+                                                   d_of_h.data_ptr(), bce.data_ptr(), dice.data_ptr(), nm.data_ptr(), vec.data_ptr(), lse.data_ptr(),
+                                                   den.data_ptr(), B, H, Q, K1, Nh, _stream()))
+        ctx.save_for_backward(logits, tclass, class_weight, d_of_h, nm, lse, den)
+        ctx.Nh = Nh
+        return vec
+
+    @staticmethod
+    def backward(ctx, dvec):
+        logits, tclass, class_weight, d_of_h, nm, lse, den = ctx.saved_tensors
+        B, H, Q, K1 = logits.shape
+        dvec = dvec.contiguous()
+        d_logits = torch.empty_strided(logits.shape, logits.stride(), dtype=torch.float32, device=logits.device)
+        d_bd = torch.empty((2, H * ctx.Nh), dtype=torch.float32, device=logits.device)
+        _lib.check(_lib.load().pd_loss_vectors_bwd(logits.data_ptr(), logits.stride(0), logits.stride(1), tclass.data_ptr(), class_weight.data_ptr(),
+                                                   d_of_h.data_ptr(), nm.data_ptr(), lse.data_ptr(), den.data_ptr(), dvec.data_ptr(), d_logits.data_ptr(),
+                                                   d_bd[0].data_ptr(), d_bd[1].data_ptr(), B, H, Q, K1, ctx.Nh, _stream()))
+        return d_logits, None, None, None, d_bd[0], d_bd[1], None
+
+
+def loss_vectors(logits, tclass, class_weight, d_of_h, bce, dice, num_masks):
+    return LossVectors.apply(logits, tclass, class_weight, d_of_h, bce, dice, num_masks)

@@ -124,9 +124,10 @@ def msda_fused_backward(value, shapes, lsi, oa, ref, stats, out, grad_out):
     L = int(shapes.shape[0])
     n_oa = oa.shape[1]
     P = n_oa // (3 * M * L)
-    gv = torch.empty_like(value)
+    # grad_value and the row maxima are both accumulated into (atomics): one allocation, so that the operator clears them with one memset
+    both = torch.empty(value.numel() + B * S, dtype=torch.float32, device=value.device)
+    gv, d_oa_am = both[:value.numel()].view(value.shape), both[value.numel():]
     d_oa = torch.empty((B * S, n_oa), dtype=torch.float32, device=value.device)
-    d_oa_am = torch.empty(B * S, dtype=torch.float32, device=value.device)
     scratch = torch.empty(B * S * M * L, dtype=torch.float32, device=value.device)
     grad_out = grad_out if grad_out.is_contiguous() else grad_out.contiguous()
     _lib.check(_lib.load().pd_msda_fused_backward(value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), oa.data_ptr(), oa.stride(0), ref.data_ptr(),

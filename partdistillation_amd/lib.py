@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libpd_hip.so") 
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -110,6 +110,8 @@ SIGNATURES = {
     "pd_skinny_linear_fwd": (_c_int, [_c_vp] * 3 + [_c_int, _c_vp] + [_c_int] * 3 + [_c_vp]),
     "pd_skinny_linear_partial_floats": (ctypes.c_int64, [_c_int] * 3),
     "pd_skinny_linear_bwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp] + [_c_int] * 4 + [_c_vp]),
+    "pd_loss_vectors_fwd": (_c_int, [_c_vp, ctypes.c_int64, ctypes.c_int64] + [_c_vp] * 9 + [_c_int] * 5 + [_c_vp]),
+    "pd_loss_vectors_bwd": (_c_int, [_c_vp, ctypes.c_int64, ctypes.c_int64] + [_c_vp] * 10 + [_c_int] * 5 + [_c_vp]),
     "pd_pair_logits_fwd": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),
     "pd_pair_logits_bwd_tok": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),
     "pd_pair_logits_workspace_floats": (ctypes.c_int64, [_c_int] * 3),

@@ -31,6 +31,7 @@ class LossDict(dict):
     total = None
     indices = None
     points = None
+    stacked = None
 
 
 class _TokensTimesRows(torch.autograd.Function):
@@ -252,9 +253,13 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
 
     with torch.autocast(device_type=dev.type, enabled=False):
         w = crit.empty_weight
-        nll = F.cross_entropy(logits_bd.float().reshape(B * H, Q, K1).transpose(1, 2), tclass.reshape(B * H, Q), w, reduction="none")
-        ce_d = nll.reshape(B, H, Q).sum((0, 2)) / w[tclass].sum((0, 2))
-        loss_ce = ce_d.index_select(0, d_of_h)           # (index_select: its backward is one index_add; x[idx] sorts the indices: 6 launches)
+        logits_f = logits_bd.float()
+        fused_vectors = None                             # set below when pd_loss_vectors forms all three vectors (it needs bce / dice)
+        lv_ok = cops.loss_vectors_supported(logits_f, tclass, w) and N_h > 0
+        if not lv_ok:
+            nll = F.cross_entropy(logits_f.reshape(B * H, Q, K1).transpose(1, 2), tclass.reshape(B * H, Q), w, reduction="none")
+            ce_d = nll.reshape(B, H, Q).sum((0, 2)) / w[tclass].sum((0, 2))
+            loss_ce = ce_d.index_select(0, d_of_h)       # (index_select: its backward is one index_add; x[idx] sorts the indices: 6 launches)
         # ---- mask losses on the matched pairs (criterion.py:147-207)
         if sparse:
             # the matched queries' embeddings, gathered ONCE and already in image-major order: rows of the flat [B heads Q, C] matrix
@@ -304,11 +309,17 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
             bce = F.binary_cross_entropy_with_logits(pl, labels, reduction="none").mean(1)
             ps = pl.sigmoid()
             dice = 1 - (2 * (ps * labels).sum(-1) + 1) / (ps.sum(-1) + labels.sum(-1) + 1)
-        loss_mask = bce.reshape(H, N_h).sum(1) / num_masks
-        loss_dice = dice.reshape(H, N_h).sum(1) / num_masks
+        if lv_ok:
+            # class-weighted cross entropy of every head and the per-head sums of the mask terms: one launch, one for all their gradients
+            fused_vectors = cops.loss_vectors(logits_f, tclass, w, d_of_h, bce, dice, num_masks)        # [3, H]
+            loss_ce, loss_mask, loss_dice = fused_vectors.unbind(0)
+        else:
+            loss_mask = bce.reshape(H, N_h).sum(1) / num_masks
+            loss_dice = dice.reshape(H, N_h).sum(1) / num_masks
 
     out = LossDict()
     out.vectors = {"loss_ce": loss_ce, "loss_mask": loss_mask, "loss_dice": loss_dice}
+    out.stacked = fused_vectors                            # [3, H] in the order of `vectors` when one node produced them
     for name, vec in out.vectors.items():
         parts = vec.unbind(0)
         out[name] = parts[0]

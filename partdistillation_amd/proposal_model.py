@@ -117,6 +117,21 @@ class _MaskFormerTrainBase(nn.Module):
         from .modeling.criterion_batched import LossDict
         out, total = LossDict(), 0.0
         cache = self.__dict__.setdefault("_wvec", {})
+        stacked = getattr(losses, "stacked", None)
+        if stacked is not None:                                       # one node made the three vectors: one multiply, one sum
+            names = list(vectors)
+            ck = ("stacked", tuple(names), stacked.shape[1], str(stacked.device))
+            if ck not in cache:
+                cache[ck] = torch.tensor([[wd.get(k, 0.0) for k in [n] + [f"{n}_{i}" for i in range(stacked.shape[1] - 1)]] for n in names],
+                                         dtype=stacked.dtype, device=stacked.device)
+            wv = stacked * cache[ck]
+            for n, row in zip(names, wv.unbind(0)):
+                for k, part in zip([n] + [f"{n}_{i}" for i in range(stacked.shape[1] - 1)], row.unbind(0)):
+                    if k in wd:
+                        out[k] = part
+            out.total = wv.sum()
+            out.indices, out.points = getattr(losses, "indices", None), getattr(losses, "points", None)
+            return out
         for name, vec in vectors.items():
             keys = [name] + [f"{name}_{i}" for i in range(vec.shape[0] - 1)]
             ck = (name, vec.shape[0], str(vec.device))

@@ -196,6 +196,34 @@ def test_own_heads_node_class_head_and_mlp_vs_fp32_module_path(rows_shape, K):
         assert p.grad is not None
 
 
+@pytest.mark.parametrize("B,H,Q,K1,Nh", [(2, 10, 100, 2, 8), (3, 4, 37, 9, 1), (1, 1, 300, 1, 5), (2, 3, 5, 130, 300)])
+def test_loss_vectors_equal_the_torch_expressions(B, H, Q, K1, Nh):
+    """pd_loss_vectors_*: class-weighted cross entropy of every head (logits read through the decoder's [heads, B, Q, K] strides), the heads'
+    BCE / dice sums over num_masks, and their gradients, against F.cross_entropy / sum / division in fp64."""
+    from partdistillation_amd.functions import criterion_ops as cops
+    torch.manual_seed(B + H + Q)
+    raw = (torch.randn(H, B, Q, K1, device=DEV) * 4).requires_grad_(True)
+    logits = raw.transpose(0, 1)                                          # [B, H, Q, K1] view
+    tclass = torch.randint(0, K1, (B, H, Q), device=DEV)
+    w = torch.rand(K1, device=DEV) + 0.1
+    d_of_h = torch.tensor([H - 1] + list(range(H - 1)), device=DEV)
+    bce, dice = torch.rand(H * Nh, device=DEV, requires_grad=True), torch.rand(H * Nh, device=DEV, requires_grad=True)
+    nm = torch.tensor(7.0, device=DEV)
+    assert cops.loss_vectors_supported(logits, tclass, w)
+    vec = cops.loss_vectors(logits, tclass, w, d_of_h, bce, dice, nm)
+    gv = torch.randn(3, H, device=DEV)
+    (vec * gv).sum().backward()
+    r64, b64, d64 = raw.detach().double().requires_grad_(True), bce.detach().double().requires_grad_(True), dice.detach().double().requires_grad_(True)
+    l64 = r64.transpose(0, 1)
+    nll = F.cross_entropy(l64.reshape(B * H, Q, K1).transpose(1, 2), tclass.reshape(B * H, Q), w.double(), reduction="none").reshape(B, H, Q)
+    ce = (nll.sum((0, 2)) / w.double()[tclass].sum((0, 2)))[d_of_h]
+    ref = torch.stack([ce, b64.reshape(H, Nh).sum(1) / 7.0, d64.reshape(H, Nh).sum(1) / 7.0])
+    (ref * gv.double()).sum().backward()
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert rel(vec, ref) <= 2e-6
+    assert rel(raw.grad, r64.grad) <= 5e-6 and rel(bce.grad, b64.grad) <= 1e-6 and rel(dice.grad, d64.grad) <= 1e-6
+
+
 @pytest.mark.parametrize("counts,T", [([40, 40], 65536), ([40, 0, 7], 1000), ([100, 5], 1027), ([0, 3], 64), ([1], 4), ([48, 49, 16], 2050)])
 def test_pair_logits_forward_and_gradients_vs_fp64(counts, T):
     """pd_pair_logits_*: the matched pairs' mask logits out[row(i)] = tok[b(i)] e[i] and both gradients against the same products in fp64:
