@@ -397,10 +397,12 @@ def test_bf16_shadow_training_matches_autocast_reference():
             assert (out[True][1][k] - v).abs().max().item() <= 2.5e-4, k
 
 
-@pytest.mark.parametrize("shape,groups,relu", [((2, 256, 17, 9), 32, True), ((1, 64, 8, 8), 32, False), ((3, 128, 5, 11), 8, True)])
-def test_group_norm_nhwc_vs_torch(shape, groups, relu):
+@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("shape,groups,relu", [((2, 256, 17, 9), 32, True), ((1, 64, 8, 8), 32, False), ((3, 128, 5, 11), 8, True),
+                                               ((5, 256, 6, 7), 32, False)])
+def test_group_norm_nhwc_vs_torch(shape, groups, relu, seed):
     from partdistillation_amd.functions.fused import group_norm_nhwc
-    g = torch.Generator(device=DEV).manual_seed(shape[1])
+    g = torch.Generator(device=DEV).manual_seed(shape[1] + seed)
     x = (torch.randn(shape, device=DEV, generator=g) * 2 + 0.7).contiguous(memory_format=torch.channels_last).requires_grad_()
     w = torch.randn(shape[1], device=DEV, generator=g).requires_grad_()
     b = torch.randn(shape[1], device=DEV, generator=g).requires_grad_()
