@@ -215,7 +215,8 @@ def test_per_stage_gradient_hand_over_equals_the_single_hand_over(monkeypatch):
     assert sorted(order) == sorted(body) and len(set(order)) == len(order)
     stages = [n.split(".")[0] for n in order]
     assert stages == sorted(stages, reverse=True), stages                  # res5 ... res2
-    assert torch.equal(gx_a, gx_b)
+    # (the image's gradient leaves through the library's stem convolution, whose algorithm choice may differ from call to call)
+    assert ((gx_a - gx_b).abs().max() <= 1e-3 * gx_a.abs().max()).item()
     for n in grads_a:
         a, b = grads_a[n], grads_b[n]
         assert ((a - b).abs().max() <= 1e-3 * a.abs().max().clamp_min(1e-12)).item(), (n, (a - b).abs().max().item(), a.abs().max().item())
