@@ -51,6 +51,21 @@ int pd_kmeans_reduce_update(const float *partial_sums, const float *partial_coun
                             int32_t *ticket, int B, int K, int C, void *stream);
 
 /*
+ * The E-step with distance bounds (Hamerly 2010), exact: same labels / partial sums / counts / `changed` as pd_kmeans_assign_partial, but a point
+ * whose bounds prove that its fp32 argmin is still its label is not read, and a slab without a changed label keeps the partial sums of an
+ * earlier call.  State kept by the caller between the calls of one run: ub, lb, xnorm fp32 [N] (contents irrelevant while labels[n] < 0) and
+ * cshift fp32 [B, 2, 8] = per image (how far centre k moved in the last update, the largest move of any OTHER centre), zero before the first
+ * update, afterwards written by pd_kmeans_reduce_update_shift (pd_kmeans_reduce_update with that one more output).  `labels` must be -1 before
+ * the first call of a run; partial_sums / partial_counts must be the buffers of the previous call.
+ */
+int pd_kmeans_assign_bounded(const float *X, const int32_t *blocks, int n_blocks, const float *centers, const float *cnorm, const int32_t *done,
+                             int32_t *labels, float *partial_sums, float *partial_counts, int32_t *changed, float *ub, float *lb, float *xnorm,
+                             const float *cshift, int C, int K, void *stream);
+int pd_kmeans_reduce_update_shift(const float *partial_sums, const float *partial_counts, const int32_t *block_range, float *centers, float *cnorm,
+                                  int32_t *changed, const float *tol, int32_t *done, int32_t *n_iter, float *scratch, int32_t *ticket, float *cshift,
+                                  int B, int K, int C, void *stream);
+
+/*
  * M-step + convergence for every image b with done[b] == 0:  centers[b,k] = sums / counts (unchanged when the cluster is
  * empty), cnorm recomputed, n_iter[b] += 1, done[b] = (changed[b] == 0) || (sum_k |new - old|^2 <= tol[b]); then sums,
  * counts and changed are cleared for the next pd_kmeans_assign.

@@ -109,9 +109,11 @@ const Entry kTable[] = {
   PD_E(pd_igemm_bf16),
   PD_E(pd_igemm_bf16_seq),
   PD_E(pd_kmeans_assign),
+  PD_E(pd_kmeans_assign_bounded),
   PD_E(pd_kmeans_assign_partial),
   PD_E(pd_kmeans_reduce),
   PD_E(pd_kmeans_reduce_update),
+  PD_E(pd_kmeans_reduce_update_shift),
   PD_E(pd_kmeans_update),
   PD_E(pd_layernorm_rows_f32_bwd),
   PD_E(pd_layernorm_rows_f32_fwd),

@@ -28,7 +28,7 @@ int pd_check_launch(const char *what)
 }
 
 extern "C" const char *pd_last_error(void) { return g_err; }
-extern "C" int pd_abi_version(void) { return 38; }
+extern "C" int pd_abi_version(void) { return 39; }
 
 // experiment knobs (not part of the public ABI contract; used by tools/ only)
 extern int g_pd_dbg_atomic_scope;

@@ -118,6 +118,9 @@ def kmeans_lloyd(X, K, init=None, max_iter=300, tol=1e-4, generator=None):
 SEED_LOOP = bool(int(__import__("os").environ.get("PD_KMEANS_SEED_LOOP", "0")))   # tools only: k-means++ seeding image by image (the first version)
 SLAB = int(__import__("os").environ.get("PD_KMEANS_SLAB", "32"))
 ATOMIC = bool(int(__import__("os").environ.get("PD_KMEANS_ATOMIC", "0")))     # points per workgroup of pd_kmeans_assign (<= 64)
+TRACE = bool(int(__import__("os").environ.get("PD_KMEANS_TRACE", "0")))
+BOUNDED = bool(int(__import__("os").environ.get("PD_KMEANS_BOUNDED", "1")))   # E-step with distance bounds (pd_kmeans_assign_bounded: exact, same results);
+                                                                               # 0: every point against every centre in every iteration
 
 
 def kmeans_lloyd_batched(datas, K, inits=None, max_iter=300, tol=1e-4, generator=None, check_every=8):
@@ -159,6 +162,8 @@ def kmeans_lloyd_batched(datas, K, inits=None, max_iter=300, tol=1e-4, generator
     flags = torch.zeros((4, B), dtype=torch.int32, device=dev)                               # changed, done, n_iter, ticket
     scratch = torch.empty(int(_lib.load().pd_kmeans_reduce_update_scratch_floats(B, K, C)), dtype=torch.float32, device=dev)
     cnorm = (centers * centers).sum(-1).contiguous()
+    bounds = torch.empty((3, X.shape[0]), dtype=torch.float32, device=dev)                   # ub, lb, |x|^2 (read only once a point has a label)
+    cshift = torch.zeros((B, 2, 8), dtype=torch.float32, device=dev)                         # centre moves of the last update (bounded E-step)
     lib, st = _lib.load(), _lib.current_stream()
     p = dict(X=X.data_ptr(), blocks=blocks.data_ptr(), centers=centers.data_ptr(), cnorm=cnorm.data_ptr(), done=flags[1].data_ptr(),
              labels=labels.data_ptr(), psums=psums.data_ptr(), pcounts=pcounts.data_ptr(), changed=flags[0].data_ptr(),
@@ -175,6 +180,12 @@ def kmeans_lloyd_batched(datas, K, inits=None, max_iter=300, tol=1e-4, generator
             if ATOMIC:                                                                       # tools only: the first version's accumulation
                 _lib.check(lib.pd_kmeans_assign(p["X"], p["blocks"], len(table), p["centers"], p["cnorm"], p["done"], p["labels"],
                                                 p["sums"], p["counts"], p["changed"], C, K, st))
+            elif BOUNDED:
+                _lib.check(lib.pd_kmeans_assign_bounded(p["X"], p["blocks"], len(table), p["centers"], p["cnorm"], p["done"], p["labels"],
+                                                        p["psums"], p["pcounts"], p["changed"], bounds[0].data_ptr(), bounds[1].data_ptr(),
+                                                        bounds[2].data_ptr(), cshift.data_ptr(), C, K, st))
+                _lib.check(lib.pd_kmeans_reduce_update_shift(p["psums"], p["pcounts"], p["range"], p["centers"], p["cnorm"], p["changed"], p["tols"],
+                                                             p["done"], p["n_iter"], p["scratch"], p["ticket"], cshift.data_ptr(), B, K, C, st))
             else:
                 _lib.check(lib.pd_kmeans_assign_partial(p["X"], p["blocks"], len(table), p["centers"], p["cnorm"], p["done"], p["labels"],
                                                         p["psums"], p["pcounts"], p["changed"], C, K, st))
@@ -184,6 +195,15 @@ def kmeans_lloyd_batched(datas, K, inits=None, max_iter=300, tol=1e-4, generator
                 _lib.check(lib.pd_kmeans_update(p["centers"], p["cnorm"], p["sums"], p["counts"], p["changed"], p["tols"], p["done"],
                                                 p["n_iter"], B, K, C, st))
             it += 1
+            if TRACE and BOUNDED:                                                            # tools only: which share of the points the NEXT E-step will read
+                img = torch.repeat_interleave(torch.arange(B, device=dev), torch.tensor([x.shape[0] for x in Xs], device=dev))
+                a = labels.long().clamp_min(0)
+                u = (bounds[0] + cshift[img, 0, a]) * 1.000001
+                l = (bounds[1] - cshift[img, 1, a]) * 0.999999
+                skip = (l > u) & (l * l - u * u > 2e-3 * (bounds[2] + cnorm.max(1).values[img])) & ~flags[1].bool()[img]
+                live = ~flags[1].bool()[img]
+                print(f"iteration {it}: done {flags[1].tolist()}, points to read {int((live & ~skip).sum())} of {int(live.sum())} live, "
+                      f"centre moves {[round(float(v), 4) for v in cshift[:, 0, :K].max(1).values]}")
         snap = torch.empty(B, dtype=torch.int32, pin_memory=True)
         snap.copy_(flags[1], non_blocking=True)
         ev = torch.cuda.Event()

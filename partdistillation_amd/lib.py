@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PD_LIB_PATH") or os.path.join(_HERE, "libpd_hip.so") 
 CSRC = os.path.join(_HERE, "csrc")
 
 PD_F32, PD_F64, PD_BF16 = 0, 1, 2
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -146,6 +146,8 @@ SIGNATURES = {
     "pd_kmeans_reduce": (_c_int, [_c_vp] * 6 + [_c_int] * 3 + [_c_vp]),
     "pd_kmeans_reduce_update_scratch_floats": (ctypes.c_int64, [_c_int] * 3),
     "pd_kmeans_reduce_update": (_c_int, [_c_vp] * 11 + [_c_int] * 3 + [_c_vp]),
+    "pd_kmeans_assign_bounded": (_c_int, [_c_vp, _c_vp, _c_int] + [_c_vp] * 11 + [_c_int, _c_int, _c_vp]),
+    "pd_kmeans_reduce_update_shift": (_c_int, [_c_vp] * 12 + [_c_int] * 3 + [_c_vp]),
     "pd_kmeans_update": (_c_int, [_c_vp] * 8 + [_c_int] * 3 + [_c_vp]),
     "pd_mask_assign": (_c_int, [_c_vp] * 6 + [_c_int] * 7 + [_c_vp]),
     "pd_window_attn_fwd_w12": (_c_int, [_c_vp] * 6 + [_c_int] * 3 + [ctypes.c_float, _c_vp, _c_vp, _c_int, _c_vp]),

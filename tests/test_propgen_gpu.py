@@ -64,6 +64,31 @@ def test_batched_hip_lloyd_matches_oracle():
     np.testing.assert_allclose(c3[0].cpu().numpy(), c_ref, rtol=2e-3, atol=2e-3)
 
 
+def test_bounded_e_step_is_bit_identical_to_the_exhaustive_one(monkeypatch):
+    """pd_kmeans_assign_bounded (distance bounds: most points are not read after the first iterations; slabs without a changed label keep their
+    partial sums) against pd_kmeans_assign_partial: the SAME centres bit for bit and the same iteration counts — well separated blobs, heavily
+    overlapping ones (long runs, many points near a boundary), L2-normalised part-ranking features with K = 8, one cluster fewer than blobs."""
+    from partdistillation_amd.functions import kmeans as km
+    rng = np.random.default_rng(5)
+    cases = []
+    for N, K, Cc, spread, norm in [(5431, 4, 1536, 1.5, False), (3000, 4, 1536, 6.0, False), (1300, 8, 256, 1.0, True), (900, 3, 64, 2.5, False),
+                                   (70, 4, 1536, 1.0, False)]:
+        blobs = rng.normal(size=(K + 1, Cc)).astype(np.float32)
+        X = (blobs[rng.integers(K + 1, size=N)] + spread * rng.normal(size=(N, Cc)).astype(np.float32)).astype(np.float32)
+        if norm:
+            X /= np.linalg.norm(X, axis=1, keepdims=True)
+        cases.append((K, torch.from_numpy(X).to(DEV), torch.from_numpy(X[rng.choice(N, K, replace=False)].copy()).to(DEV)))
+    for K in (4, 8, 3):
+        datas, inits = [c[1] for c in cases if c[0] == K], [c[2] for c in cases if c[0] == K]
+        out = {}
+        for on in (False, True):
+            monkeypatch.setattr(km, "BOUNDED", on)
+            out[on] = km.kmeans_lloyd_batched(datas, K, inits=inits)
+        assert out[True][1] == out[False][1], (K, out[True][1], out[False][1])
+        assert torch.equal(out[True][0], out[False][0]), K
+        assert max(out[True][1]) >= 5
+
+
 def test_batched_hip_lloyd_k8_part_ranking_geometry():
     """the KMAX = 8 instantiation (part ranking: 8 clusters per object class on 256-d query features,
     evaluation/clustering_module.py:43-70): several classes of different sizes advancing together against the sklearn-pinned
