@@ -777,6 +777,191 @@ void gemm_ra_f16x2_k256(const float *__restrict__ A, const float *__restrict__ B
     if (!(lane & 1) && row0 + rl < M && r > 0.f) atomicMax(c_amax + row0 + rl, __float_as_uint(r));
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_kres_f16x2 (round 5): the deep-K products with 256 output columns (the encoder FFN's second Linear 256 <- 1024 and the input
+// gradient of its first: 12 launches of ~95 us per step) with the K loop OUTSIDE and the accumulators of a whole row block resident.
+// The tiled kernel gives these shapes 672 tiles of 128 x 128 on 256 CUs (2.6 rounds -> 3) and reads A twice (once per column tile).  Here
+// one persistent workgroup per CU owns a block of 192 rows x 256 columns: 8 wavefronts = 2 row groups (96 rows: three 32-row MFMA
+// tiles) x 4 column groups (64 columns), 6 accumulator tiles = 96 registers per lane — 192 x 256 fp32 results stay in registers for all
+// of K.  Per 32-deep chunk the block's A rows (24 KB) and the weight panel's slice (32 KB, from L2) are read by all 512 threads, split and
+// laid into double-buffered two-plane LDS images (the row stream's [k panel of 8][row][8 halves] layout: a fragment is one ds_read_b128);
+// the loads run TWO chunks ahead in registers, one barrier per chunk.  Per 16-deep step and wavefront: 10 fragment reads, 18 matrix
+// instructions.  A is read once, C written once.  EXPERIMENTAL, not the product's choice: see the dispatch in gemm_tn_f16x2_impl.  (First version: the weights went global -> registers per step, behind the chunk's A
+// loads in the in-order load queue — every step waited for HBM: 98 us against the tiled kernel's 86.)
+constexpr int KR_RB = 192, KR_KC = 32;
+constexpr int KR_APANEL = KR_RB * 16 + 16, KR_APLANE = (KR_KC / 8) * KR_APANEL, KR_ABUF = 2 * KR_APLANE;
+constexpr int KR_BPANEL = 256 * 16 + 16, KR_BPLANE = (KR_KC / 8) * KR_BPANEL, KR_BBUF = 2 * KR_BPLANE;
+constexpr size_t KR_LDS = (size_t)2 * (KR_ABUF + KR_BBUF) + KR_RB * sizeof(float);
+
+template <bool AM, int KABL = 0>     // KABL (tools only): 1 no split / LDS stores in the loop, 2 no products, 4 no fragment reads, 8 no global loads in the loop
+__global__ __launch_bounds__(512)
+void gemm_kres_f16x2(const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ bias, float *__restrict__ C, int M, int K,
+                     int lda, int ldb, int ldc, int npanels, const float *__restrict__ a_amax, const float *__restrict__ b_amax)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char kr_lds[];
+  unsigned char *const aimg = kr_lds, *const bimg = kr_lds + 2 * KR_ABUF;
+  float *sinv = reinterpret_cast<float *>(kr_lds + 2 * (KR_ABUF + KR_BBUF));
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 31, fh = lane >> 5;
+  const int rgp = w >> 2, cg = w & 3;                                  // row group (96 rows), column group (64 columns)
+  const int nblk = (M + KR_RB - 1) / KR_RB, NC = K / KR_KC;
+  const int arow = t >> 3, ac4 = t & 7;                                 // staging: 8 threads per row (32 k = 8 float4); A rows arow + 64 j (3), B rows arow + 64 j (4)
+  for (int work = blockIdx.x; work < nblk * npanels; work += gridDim.x) {
+    const int blk = work / npanels, panel = work - blk * npanels, row0 = blk * KR_RB, c0 = panel * 256, n0 = c0 + cg * 64;
+    float sa[3], sb[4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float inv = 1.f;
+      sa[j] = 1.f;
+      if (AM) row_scale(a_amax[min(row0 + arow + 64 * j, M - 1)], sa[j], inv);
+      if (ac4 == 0) sinv[arow + 64 * j] = inv;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float inv = 1.f;
+      sb[j] = 1.f;
+      if (AM) row_scale(b_amax[c0 + arow + 64 * j], sb[j], inv);
+    }
+    float ibv[2] = {1.f, 1.f};
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      float sc = 1.f;
+      if (AM) row_scale(b_amax[n0 + 32 * cb + fr], sc, ibv[cb]);
+    }
+    float4 RA[2][3], RB[2][4];
+    auto gload = [&](int rs, int kc) {
+      kc = min(kc, NC - 1);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        RA[rs][j] = *reinterpret_cast<const float4 *>(A + (int64_t)min(row0 + arow + 64 * j, M - 1) * lda + kc * KR_KC + 4 * ac4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) RB[rs][j] = *reinterpret_cast<const float4 *>(B + (int64_t)(c0 + arow + 64 * j) * ldb + kc * KR_KC + 4 * ac4);
+    };
+    auto split_store = [&](int rs, int buf) {
+      unsigned char *ab = aimg + buf * KR_ABUF + (ac4 >> 1) * KR_APANEL + (ac4 & 1) * 8;
+      unsigned char *bb = bimg + buf * KR_BBUF + (ac4 >> 1) * KR_BPANEL + (ac4 & 1) * 8;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const SplitH v = split4h(RA[rs][j], sa[j]);
+        unsigned char *p = ab + (arow + 64 * j) * 16;
+        *reinterpret_cast<uint2 *>(p) = v.hi;
+        *reinterpret_cast<uint2 *>(p + KR_APLANE) = v.lo;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const SplitH v = split4h(RB[rs][j], sb[j]);
+        unsigned char *p = bb + (arow + 64 * j) * 16;
+        *reinterpret_cast<uint2 *>(p) = v.hi;
+        *reinterpret_cast<uint2 *>(p + KR_BPLANE) = v.lo;
+      }
+    };
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ti][cb][e] = 0.f;
+    gload(0, 0);
+    gload(1, 1);
+    split_store(0, 0);
+    gload(0, 2);
+    __syncthreads();
+    auto chunk = [&](int kc, int par) {
+      const unsigned char *ab = aimg + par * KR_ABUF + fh * KR_APANEL + (96 * rgp + fr) * 16;
+      const unsigned char *bb = bimg + par * KR_BBUF + fh * KR_BPANEL + (64 * cg + fr) * 16;
+#pragma unroll
+      for (int s = 0; s < KR_KC / 16; ++s) {
+        h16x8 ah[3], al[3], bh[2], bl[2];
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti) {
+          if (KABL & 4) {
+            ah[ti] = __builtin_bit_cast(h16x8, u32x4{(unsigned)s, (unsigned)ti, 1u, 2u});
+            al[ti] = ah[ti];
+          } else {
+            ah[ti] = *reinterpret_cast<const h16x8 *>(ab + 2 * s * KR_APANEL + ti * 32 * 16);
+            al[ti] = *reinterpret_cast<const h16x8 *>(ab + 2 * s * KR_APANEL + ti * 32 * 16 + KR_APLANE);
+          }
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          if (KABL & 4) {
+            bh[cb] = __builtin_bit_cast(h16x8, u32x4{(unsigned)s, (unsigned)cb, 3u, 4u});
+            bl[cb] = bh[cb];
+          } else {
+            bh[cb] = *reinterpret_cast<const h16x8 *>(bb + 2 * s * KR_BPANEL + cb * 32 * 16);
+            bl[cb] = *reinterpret_cast<const h16x8 *>(bb + 2 * s * KR_BPANEL + cb * 32 * 16 + KR_BPLANE);
+          }
+        }
+        if (KABL & 2) {
+#pragma unroll
+          for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[ti][cb][0] += (float)ah[ti][0] * (float)bl[cb][1] + (float)al[ti][2] * (float)bh[cb][3];
+          continue;
+        }
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) mmah(acc[ti][cb], al[ti], bh[cb]);
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) mmah(acc[ti][cb], ah[ti], bl[cb]);
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) mmah(acc[ti][cb], ah[ti], bh[cb]);
+      }
+      // chunk kc + 1 (register stage par ^ 1) into the other images, its registers re-loaded with chunk kc + 3.  AFTER the products in program
+      // order: the fragment reads above then precede these LDS stores (which may alias them as far as the compiler knows), and the split and
+      // the stores are free to move up between the matrix instructions
+      if (!(KABL & 1)) split_store(par ^ 1, par ^ 1);
+      if (!(KABL & 8)) gload(par ^ 1, kc + 3);
+      if (KABL == 0) {
+        // lay the next chunk's split (VALU), its LDS stores, the loads and the second step's fragment reads into the shadow of the 36 matrix
+        // instructions — in program order all of it precedes them, and eight wavefronts in step would run the phases one after the other
+        // (ablation, tools/debug/kres_ablate.py: 17 us skeleton + 27 staging + 17 fragment reads + 40 products = the 101 us of a launch)
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);             // the first step's fragments
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {                                   // first step's products: the split's arithmetic, the second step's fragments
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          if (i < 10) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {                                   // second step's products: the rest of the split, the LDS stores, the loads
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          if (i < 14) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          if (i % 2 == 0 && i < 14) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+      __syncthreads();
+    };
+    for (int kc = 0; kc < NC; kc += 2) {
+      chunk(kc, 0);
+      if (kc + 1 < NC) chunk(kc + 1, 1);
+    }
+    // C rows of a 32 x 32 accumulator: (e & 3) + 8 (e >> 2) + 4 fh, column fr
+#pragma unroll
+    for (int ti = 0; ti < 3; ++ti) {
+      const int rl0 = 96 * rgp + 32 * ti;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const int col = n0 + 32 * cb + fr;
+        const float bv = bias ? bias[col] : 0.f;
+        float *cp = C + (int64_t)(row0 + rl0) * ldc + col;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int rl = (e & 3) + 8 * (e >> 2) + 4 * fh;
+          if (row0 + rl0 + rl < M) cp[(int64_t)rl * ldc] = acc[ti][cb][e] * (sinv[rl0 + rl] * ibv[cb]) + bv;
+        }
+      }
+    }
+    __syncthreads();                                                     // sinv and the images are rewritten by the next block
+  }
+}
 }  // namespace
 
 static const bool g_rows_relu = []() { const char *e = getenv("PD_H2_ROWS_RELU"); return !e || e[0] != '0'; }();   // A/B switch (default on)
@@ -895,6 +1080,45 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
       return pd_check_launch("pd_gemm_tn_f16x2 (row stream, ReLU epilogue)");
     }
   }
+  // deep K, 256-column panels, plain epilogue: K outside, a row block's accumulators resident (gemm_kres_f16x2) — EXPERIMENTAL, opt-in
+  // (PD_H2_KRES=1 / pd_debug_set("f16x2_tile", 91); 200 + bits: its ablations).  Correct (tests/test_gemm_gpu.py) and NOT faster: 256 <- 1024 at
+  // M = 43 008 103 us against the tiled kernel's 92 on the same box (82 vs 85 on another).  tools/debug/kres_ablate.py: 17 us with an empty
+  // loop (launch, prologue, the C stores), +27 staging (loads, split, LDS stores, barrier), +17 fragment reads, +40 products = 101: one
+  // 116 KB workgroup per CU, eight wavefronts in step, and the compiler keeps the split's VALU block out of the matrix instructions' shadow
+  // whatever sched_group_barrier asks for (256 VGPRs: no room for a second set of fragments) — the phases add up, as in every variant before.
+  static const bool kres_env = []() { const char *e = getenv("PD_H2_KRES"); return e && e[0] == '1'; }();
+  if (((kres_env && dbg == 0) || dbg == 91 || (dbg >= 200 && dbg < 216)) && !flags && mode == 0 && !bits && !c_amax && K >= 512 && (K % KR_KC) == 0 && (N % 256) == 0 && N <= 512 && M >= 8192 &&
+      (a_amax == nullptr) == (b_amax == nullptr)) {
+    static int ncu3 = 0;
+    if (!ncu3) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&ncu3, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu3 < 8) ncu3 = 256; }
+    const int np = N / 256, nwork = ((M + KR_RB - 1) / KR_RB) * np, G = nwork < ncu3 ? nwork : ncu3;
+    static bool kattr = false;
+    if (!kattr) {
+      (void)hipFuncSetAttribute((const void *)gemm_kres_f16x2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KR_LDS);
+      (void)hipFuncSetAttribute((const void *)gemm_kres_f16x2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KR_LDS);
+      kattr = true;
+    }
+    if (a_amax && dbg >= 200 && dbg < 216) {                           // tools: ablations of the loop's phases (timing only)
+      typedef void (*kfn2)(const float *, const float *, const float *, float *, int, int, int, int, int, int, const float *, const float *);
+      kfn2 kf = nullptr;
+      switch (dbg - 200) {
+        case 1: kf = gemm_kres_f16x2<true, 1>; break;
+        case 2: kf = gemm_kres_f16x2<true, 2>; break;
+        case 4: kf = gemm_kres_f16x2<true, 4>; break;
+        case 6: kf = gemm_kres_f16x2<true, 6>; break;
+        case 8: kf = gemm_kres_f16x2<true, 8>; break;
+        case 9: kf = gemm_kres_f16x2<true, 9>; break;
+        case 15: kf = gemm_kres_f16x2<true, 15>; break;
+        default: kf = gemm_kres_f16x2<true, 0>; break;
+      }
+      (void)hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KR_LDS);
+      hipLaunchKernelGGL(kf, dim3((unsigned)G), dim3(512), KR_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
+      return pd_check_launch("pd_gemm_tn_f16x2 (resident accumulators, ablation)");
+    }
+    if (a_amax) hipLaunchKernelGGL(gemm_kres_f16x2<true>, dim3((unsigned)G), dim3(512), KR_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
+    else hipLaunchKernelGGL(gemm_kres_f16x2<false>, dim3((unsigned)G), dim3(512), KR_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
+    return pd_check_launch("pd_gemm_tn_f16x2 (resident accumulators)");
+  }
   // the sign bits are laid out in the 256 x 256 kernel's accumulator order: bits / mask launches must take that kernel
   const bool need_wide = bits != nullptr;
   if (need_wide && ((N % 256) || M < 1024)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: sign bits need N %% 256 == 0 and M >= 1024");
@@ -925,7 +1149,8 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
 }
 
 // which kernel pd_gemm_tn_f16x2 launches for a problem (tools / bench.py labels): 0 = 128 x 128 tiles, 1 = 256 x 256 tiles, 2 = the row stream
-// (gemm_rows_f16x2_k256), 3 = the register-operand kernel (opt-in).  Mirrors the dispatch of gemm_tn_f16x2_impl.
+// (gemm_rows_f16x2_k256), 3 = the register-operand kernel (opt-in), 4 = resident accumulators (gemm_kres_f16x2, opt-in; a launch that asks
+// for output row maxima takes the tiled kernel).  Mirrors the dispatch of gemm_tn_f16x2_impl.
 extern "C" int pd_gemm_tn_f16x2_which(int M, int N, int K, int mode, int has_bits, int has_amax)
 {
   const int dbg = g_pd_dbg_f16x2;
@@ -933,6 +1158,8 @@ extern "C" int pd_gemm_tn_f16x2_which(int M, int N, int K, int mode, int has_bit
   if ((dbg == 61 || (rows_k256 && dbg == 0)) && mode == 0 && K == 256 && (N % 256) == 0 && M >= 8192) return 2;
   if ((dbg == 90 || (dbg >= 100 && dbg < 132)) && mode == 0 && K == 256 && M >= 4096 && (N % 32) == 0 && N >= 96 && ((N % 128) == 0 || (N % 96) == 0)) return 3;
   if (dbg != 62 && dbg != 3 && dbg != 13 && dbg != 70 && (mode == 1 || mode == 2) && has_bits && K == 256 && (N % 256) == 0 && N >= 512 && M >= 8192 && has_amax && g_rows_relu) return 2;
+  static const bool kres_env = []() { const char *e = getenv("PD_H2_KRES"); return e && e[0] == '1'; }();
+  if (((kres_env && dbg == 0) || dbg == 91) && mode == 0 && !has_bits && K >= 512 && (K % KR_KC) == 0 && (N % 256) == 0 && N <= 512 && M >= 8192) return 4;
   const bool wide_ok = (N % 256) == 0 && M >= 1024;
   const bool by_shape = dbg == 0 || dbg == 61 || dbg == 70 || dbg == 80 || dbg == 62;
   static const bool wide_deepk = []() { const char *e = getenv("PD_H2_WIDE_DEEPK"); return e && e[0] == '1'; }();

@@ -321,6 +321,39 @@ def test_gemm_tn_h2_row_stream_matches_the_tiled_kernel(M, N, K, scaled):
     assert torch.equal(cm, got.abs().amax(1))
 
 
+@pytest.mark.parametrize("M,N,K", [(43008, 256, 1024), (8300, 512, 512), (9001, 256, 576), (8192, 256, 2048)])
+@pytest.mark.parametrize("scaled", [True, False])
+def test_gemm_tn_h2_resident_accumulators_match_fp64_and_the_tiled_kernel(M, N, K, scaled):
+    """gemm_kres_f16x2 (deep K, 256-column panels: K outside, a 192-row block's accumulators resident; experimental,
+    pd_debug_set("f16x2_tile", 91)): fp32-accurate against fp64, within 1e-6 of the tiled kernel, ragged last row block, two column panels,
+    K not a power of two, with / without bias and row scales."""
+    from partdistillation_amd import lib
+    from partdistillation_amd.functions import gemm
+    L = lib.load()
+    torch.manual_seed(M + K)
+    a = torch.randn(M, K, device="cuda") * (torch.logspace(-3, 3, M, device="cuda")[torch.randperm(M, device="cuda"), None] if scaled else 1.0)
+    w = torch.randn(N, K, device="cuda") * K ** -0.5
+    b = torch.randn(N, device="cuda") if M % 2 else None
+    ref = a.double() @ w.double().t() + (b.double() if b is not None else 0.0)
+    rown = ref.abs().amax(1, keepdim=True)
+    aa, wa = (gemm.row_amax(a), gemm.row_amax(w)) if scaled else (None, None)
+    L.pd_debug_set(b"f16x2_tile", 80)
+    try:
+        tiled = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
+    finally:
+        L.pd_debug_set(b"f16x2_tile", 0)
+    L.pd_debug_set(b"f16x2_tile", 91)
+    try:
+        assert L.pd_gemm_tn_f16x2_which(M, N, K, 0, 0, int(scaled)) == 4
+        got = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
+        again = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
+    finally:
+        L.pd_debug_set(b"f16x2_tile", 0)
+    assert torch.equal(got, again)
+    assert ((got.double() - ref).abs() / rown).max().item() < 3e-6
+    assert ((got.double() - tiled.double()).abs() / rown).max().item() < 1e-6
+
+
 @pytest.mark.parametrize("M,N,K", [(8300, 256, 256), (9001, 288, 256), (13000, 1024, 256)])
 @pytest.mark.parametrize("scaled", [True, False])
 def test_gemm_tn_h2_register_operand_kernel_matches_the_tiled_kernel(M, N, K, scaled):
