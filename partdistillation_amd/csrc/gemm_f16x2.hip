@@ -867,6 +867,29 @@ void gemm_kres_f16x2(const float *__restrict__ A, const float *__restrict__ B, c
     split_store(0, 0);
     gload(0, 2);
     __syncthreads();
+    // one staged item: A rows (j < 3) or weight rows (j - 3) of register stage rs -> the images `buf`
+    auto stage_item = [&](int rs, int buf, int j) {
+      if (j < 3) {
+        const SplitH v = split4h(RA[rs][j], sa[j]);
+        unsigned char *p = aimg + buf * KR_ABUF + (ac4 >> 1) * KR_APANEL + (ac4 & 1) * 8 + (arow + 64 * j) * 16;
+        *reinterpret_cast<uint2 *>(p) = v.hi;
+        *reinterpret_cast<uint2 *>(p + KR_APLANE) = v.lo;
+      } else {
+        const SplitH v = split4h(RB[rs][j - 3], sb[j - 3]);
+        unsigned char *p = bimg + buf * KR_BBUF + (ac4 >> 1) * KR_BPANEL + (ac4 & 1) * 8 + (arow + 64 * (j - 3)) * 16;
+        *reinterpret_cast<uint2 *>(p) = v.hi;
+        *reinterpret_cast<uint2 *>(p + KR_BPLANE) = v.lo;
+      }
+    };
+    auto load_item = [&](int rs, int kc, int j) {
+      kc = min(kc, NC - 1);
+      if (j < 3) RA[rs][j] = *reinterpret_cast<const float4 *>(A + (int64_t)min(row0 + arow + 64 * j, M - 1) * lda + kc * KR_KC + 4 * ac4);
+      else RB[rs][j - 3] = *reinterpret_cast<const float4 *>(B + (int64_t)(c0 + arow + 64 * (j - 3)) * ldb + kc * KR_KC + 4 * ac4);
+    };
+    // The order below is the order of the instruction stream (sched_barrier between the pieces): left to itself the compiler emits the split's
+    // ~100 VALU instructions as one block before or after the 36 matrix instructions, and eight wavefronts in step then run staging, fragment
+    // reads and products one after the other (tools/debug/kres_ablate.py).  Step 0's products carry the split and the LDS stores of the next
+    // chunk (register stage par ^ 1 -> images par ^ 1), step 1's the loads of chunk kc + 3 into the freed registers.
     auto chunk = [&](int kc, int par) {
       const unsigned char *ab = aimg + par * KR_ABUF + fh * KR_APANEL + (96 * rgp + fr) * 16;
       const unsigned char *bb = bimg + par * KR_BBUF + fh * KR_BPANEL + (64 * cg + fr) * 16;
@@ -893,48 +916,18 @@ void gemm_kres_f16x2(const float *__restrict__ A, const float *__restrict__ B, c
             bl[cb] = *reinterpret_cast<const h16x8 *>(bb + 2 * s * KR_BPANEL + cb * 32 * 16 + KR_BPLANE);
           }
         }
-        if (KABL & 2) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int ti = 0; ti < 3; ++ti)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[ti][cb][0] += (float)ah[ti][0] * (float)bl[cb][1] + (float)al[ti][2] * (float)bh[cb][3];
-          continue;
-        }
-#pragma unroll
-        for (int ti = 0; ti < 3; ++ti)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) mmah(acc[ti][cb], al[ti], bh[cb]);
-#pragma unroll
-        for (int ti = 0; ti < 3; ++ti)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) mmah(acc[ti][cb], ah[ti], bl[cb]);
-#pragma unroll
-        for (int ti = 0; ti < 3; ++ti)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) mmah(acc[ti][cb], ah[ti], bh[cb]);
-      }
-      // chunk kc + 1 (register stage par ^ 1) into the other images, its registers re-loaded with chunk kc + 3.  AFTER the products in program
-      // order: the fragment reads above then precede these LDS stores (which may alias them as far as the compiler knows), and the split and
-      // the stores are free to move up between the matrix instructions
-      if (!(KABL & 1)) split_store(par ^ 1, par ^ 1);
-      if (!(KABL & 8)) gload(par ^ 1, kc + 3);
-      if (KABL == 0) {
-        // lay the next chunk's split (VALU), its LDS stores, the loads and the second step's fragment reads into the shadow of the 36 matrix
-        // instructions — in program order all of it precedes them, and eight wavefronts in step would run the phases one after the other
-        // (ablation, tools/debug/kres_ablate.py: 17 us skeleton + 27 staging + 17 fragment reads + 40 products = the 101 us of a launch)
-        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);             // the first step's fragments
-#pragma unroll
-        for (int i = 0; i < 18; ++i) {                                   // first step's products: the split's arithmetic, the second step's fragments
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-          if (i < 10) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 18; ++i) {                                   // second step's products: the rest of the split, the LDS stores, the loads
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-          if (i < 14) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-          if (i % 2 == 0 && i < 14) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        for (int i = 0; i < 18; ++i) {
+          const int pr = i / 6, ti = (i % 6) >> 1, cb = i & 1;
+          if (KABL & 2) acc[ti][cb][0] += (float)ah[ti][0] * (float)bl[cb][1] + (float)al[ti][2] * (float)bh[cb][3];
+          else if (pr == 0) mmah(acc[ti][cb], al[ti], bh[cb]);
+          else if (pr == 1) mmah(acc[ti][cb], ah[ti], bl[cb]);
+          else mmah(acc[ti][cb], ah[ti], bh[cb]);
+          if (s == 0 && !(KABL & 1) && (i % 5) == 1) stage_item(par ^ 1, par ^ 1, i / 5);            // items 0 .. 3 after products 1, 6, 11, 16
+          if (s == 0 && !(KABL & 1) && (i == 3 || i == 8 || i == 13)) stage_item(par ^ 1, par ^ 1, 4 + (i - 3) / 5);   // items 4 .. 6
+          if (s == 1 && !(KABL & 8) && (i & 1) == 0 && i < 14) load_item(par ^ 1, kc + 3, i >> 1);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       __syncthreads();
@@ -1085,7 +1078,8 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
   // M = 43 008 103 us against the tiled kernel's 92 on the same box (82 vs 85 on another).  tools/debug/kres_ablate.py: 17 us with an empty
   // loop (launch, prologue, the C stores), +27 staging (loads, split, LDS stores, barrier), +17 fragment reads, +40 products = 101: one
   // 116 KB workgroup per CU, eight wavefronts in step, and the compiler keeps the split's VALU block out of the matrix instructions' shadow
-  // whatever sched_group_barrier asks for (256 VGPRs: no room for a second set of fragments) — the phases add up, as in every variant before.
+  // whatever sched_group_barrier asks for, and a hand-ordered stream (sched_barrier between the pieces, as the kernel has it now) changes nothing:
+  // 256 VGPRs leave no room for a second set of fragments, both wavefronts of a SIMD wait for their LDS reads together — the phases add up.
   static const bool kres_env = []() { const char *e = getenv("PD_H2_KRES"); return e && e[0] == '1'; }();
   if (((kres_env && dbg == 0) || dbg == 91 || (dbg >= 200 && dbg < 216)) && !flags && mode == 0 && !bits && !c_amax && K >= 512 && (K % KR_KC) == 0 && (N % 256) == 0 && N <= 512 && M >= 8192 &&
       (a_amax == nullptr) == (b_amax == nullptr)) {
