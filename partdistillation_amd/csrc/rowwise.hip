@@ -1252,7 +1252,7 @@ extern "C" int pd_resize_bilinear_nhwc_f32(const float *x, int B, int H, int W, 
 // 41 us; here a wavefront per row forward, and ONE backward pass per 16 rows that forms d x (added to the mask-embedding MLP's d x, which
 // shares the input), and per-workgroup partial d w / d b that skinny_linear_reduce adds in workgroup order.
 namespace {
-constexpr int SK_MAXK = 8, SK_RB = 16;
+constexpr int SK_MAXK = 8, SK_RB = 32;
 __device__ __forceinline__ float4 ldw4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float4 ldw4(const bf16_t *p) { return ld4(p); }
 __device__ __forceinline__ float ldw1(const float *p) { return *p; }
