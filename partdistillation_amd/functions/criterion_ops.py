@@ -126,6 +126,8 @@ def _img_start(counts):
     key = tuple(int(c) for c in counts)
     if key not in _IMG_START:
         import ctypes
+        if len(_IMG_START) >= 4096:
+            _IMG_START.clear()
         acc = [0]
         for c in key:
             acc.append(acc[-1] + c)

@@ -73,6 +73,7 @@ class HeadsOwn(Function):
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
         R, C, K = x2.shape[0], x2.shape[1], cw.shape[0]
         logits = torch.empty((R, K), dtype=torch.float32, device=x.device)
+        cb_dtype = cb.dtype
         cw, cb = cw.contiguous(), cb.to(cw.dtype).contiguous()
         _lib.check(_lib.load().pd_skinny_linear_fwd(x2.data_ptr(), cw.data_ptr(), cb.data_ptr(), _DT[cw.dtype], logits.data_ptr(), R, C, K,
                                                     _lib.current_stream()))
@@ -80,7 +81,7 @@ class HeadsOwn(Function):
         for i in range(n):
             acts.append(igemm.linear(acts[-1], params[2 * i], params[2 * i + 1], act=igemm.ACT_RELU if i < n - 1 else igemm.ACT_NONE))
         ctx.save_for_backward(cw, *acts[:-1], *params[0::2])
-        ctx.n, ctx.shp, ctx.xdt, ctx.bdt, ctx.cbdt = n, shp, x.dtype, [params[2 * i + 1].dtype for i in range(n)], cb.dtype
+        ctx.n, ctx.shp, ctx.xdt, ctx.bdt, ctx.cbdt, ctx.cb_param_dtype = n, shp, x.dtype, [params[2 * i + 1].dtype for i in range(n)], cb.dtype, cb_dtype
         return logits.view(*shp[:-1], K), acts[-1].view(*shp[:-1], params[2 * (n - 1)].shape[0])
 
     @staticmethod
@@ -130,6 +131,7 @@ class HeadsOwn(Function):
                                                 _DT[ctx.xdt], part.data_ptr(), dcw.data_ptr(), dcb.data_ptr(), _DT[ctx.cbdt], R, C, K,
                                                 _lib.current_stream()))
             dx = dx.view(ctx.shp) if dx is not None else None
+            dcb = dcb if dcb.dtype == ctx.cb_param_dtype else dcb.to(ctx.cb_param_dtype)      # (a bias kept in another dtype than the weight)
         elif dx_mlp is not None:
             dx = dx_mlp.view(ctx.shp)
             dx = dx if dx.dtype == ctx.xdt else dx.to(ctx.xdt)

@@ -106,6 +106,8 @@ _SEL_CACHE = {}
 def _pair_selectors(H, B, npair, device):
     key = (H, B, tuple(npair), str(device))
     if key not in _SEL_CACHE:
+        if len(_SEL_CACHE) >= _CACHE_CAP:                                  # target counts vary per batch on real data: bounded
+            _SEL_CACHE.clear(), _DERIVED.clear()
         sel_h, sel_b, sel_k = [], [], []
         for h in range(H):
             for b in range(B):
@@ -122,6 +124,7 @@ def _pair_selectors(H, B, npair, device):
 
 _CONST_CACHE = {}
 _DERIVED = {}
+_CACHE_CAP = 512
 
 
 def _const(values, dtype, device):
@@ -241,6 +244,8 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
         dk = (H, B, tuple(npair), Q, nmax, str(dev))
         der = _DERIVED.get(dk)
         if der is None:
+            if len(_DERIVED) >= _CACHE_CAP:
+                _DERIVED.clear()
             sd = d_of_h[sel_h]
             sp = sel_b * H + sd
             der = _DERIVED[dk] = (sd, sp, sp * rows.shape[1] + sel_k, (sd * B + sel_b) * Q, (sel_b * H + sd) * Q, sel_b * nmax)
