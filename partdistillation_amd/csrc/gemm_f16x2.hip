@@ -955,6 +955,198 @@ void gemm_kres_f16x2(const float *__restrict__ A, const float *__restrict__ B, c
     __syncthreads();                                                     // sinv and the images are rewritten by the next block
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_kpc_f16x2 (round 5): gemm_kres_f16x2's data path with PRODUCER and CONSUMER wavefronts instead of workgroup barriers.  Every structure of
+// this family so far ends the same way: the wavefronts of a workgroup meet at a barrier per chunk, so they wait for memory, split, read
+// fragments and multiply in step — the phases add up.  Here 4 producer wavefronts only load / split / store the chunk images (two register
+// stages: loads two chunks ahead), 8 consumer wavefronts only read fragments and multiply (192 rows x 256 columns resident, as gemm_kres);
+// they meet through two LDS counters per image — `full` (4 producer arrivals per chunk) and `empty` (8 consumer arrivals) — that a
+// wavefront polls on its own (s_sleep between polls); no s_barrier inside the K loop.
+constexpr size_t KP_LDS = (size_t)2 * (KR_ABUF + KR_BBUF) + KR_RB * sizeof(float) + 4 * sizeof(int);
+
+__device__ __forceinline__ void kp_wait_ge(int *p, int target)
+{
+  while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+}
+
+template <bool AM, int KABL = 0>     // KABL (tools only): 2 no products, 4 no fragment reads, 8 no global loads in the loop, 1 no split / LDS stores
+__global__ __launch_bounds__(768)
+void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ bias, float *__restrict__ C, int M, int K,
+                    int lda, int ldb, int ldc, int npanels, const float *__restrict__ a_amax, const float *__restrict__ b_amax)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char kp_lds[];
+  unsigned char *const aimg = kp_lds, *const bimg = kp_lds + 2 * KR_ABUF;
+  float *sinv = reinterpret_cast<float *>(kp_lds + 2 * (KR_ABUF + KR_BBUF));
+  int *ctr = reinterpret_cast<int *>(sinv + KR_RB);                     // full[0], full[1], empty[0], empty[1]
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nblk = (M + KR_RB - 1) / KR_RB, NC = K / KR_KC;
+  // the two roles are two loops over the same work list (their barriers pair up: two per block), so that neither keeps the other's registers live
+  if (w >= 8) {
+    // ---------------- producers: 256 threads, 8 per row (32 k = 8 float4): A rows prow + 32 j (6), weight rows prow + 32 j (8)
+    const int pt = t - 512, prow = pt >> 3, pc4 = pt & 7;
+    for (int work = blockIdx.x; work < nblk * npanels; work += gridDim.x) {
+      const int blk = work / npanels, panel = work - blk * npanels, row0 = blk * KR_RB, c0 = panel * 256;
+      if (pt < 4) ctr[pt] = 0;
+      if (pt < KR_RB) {
+        float sc = 1.f, inv = 1.f;
+        if (AM) row_scale(a_amax[min(row0 + pt, M - 1)], sc, inv);
+        sinv[pt] = inv;
+      }
+      __syncthreads();
+      float sa[6], sb[8];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        float inv;
+        sa[j] = 1.f;
+        if (AM) row_scale(a_amax[min(row0 + prow + 32 * j, M - 1)], sa[j], inv);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float inv;
+        sb[j] = 1.f;
+        if (AM) row_scale(b_amax[c0 + prow + 32 * j], sb[j], inv);
+      }
+      // a chunk is staged as two halves (A rows 0 .. 95 + weight rows 0 .. 127, then the rest): two halves in flight = 56 registers — a whole
+      // chunk per stage (112) spilled — and 57 KB per CU on the way, more than latency x the CU's share of the bandwidth needs
+      float4 RA[2][3], RB[2][4];
+      auto gload = [&](int rs, int u) {                                  // half u & 1 of chunk u >> 1
+        const int kc = min(u >> 1, NC - 1), h = u & 1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          RA[rs][j] = *reinterpret_cast<const float4 *>(A + (int64_t)min(row0 + prow + 32 * (3 * h + j), M - 1) * lda + kc * KR_KC + 4 * pc4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          RB[rs][j] = *reinterpret_cast<const float4 *>(B + (int64_t)(c0 + prow + 32 * (4 * h + j)) * ldb + kc * KR_KC + 4 * pc4);
+      };
+      auto split_store = [&](int rs, int buf, int h) {
+        unsigned char *ab = aimg + buf * KR_ABUF + (pc4 >> 1) * KR_APANEL + (pc4 & 1) * 8;
+        unsigned char *bb = bimg + buf * KR_BBUF + (pc4 >> 1) * KR_BPANEL + (pc4 & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const SplitH v = split4h(RA[rs][j], h ? sa[3 + j] : sa[j]);
+          unsigned char *p = ab + (prow + 32 * (3 * h + j)) * 16;
+          *reinterpret_cast<uint2 *>(p) = v.hi;
+          *reinterpret_cast<uint2 *>(p + KR_APLANE) = v.lo;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const SplitH v = split4h(RB[rs][j], h ? sb[4 + j] : sb[j]);
+          unsigned char *p = bb + (prow + 32 * (4 * h + j)) * 16;
+          *reinterpret_cast<uint2 *>(p) = v.hi;
+          *reinterpret_cast<uint2 *>(p + KR_BPLANE) = v.lo;
+        }
+      };
+      gload(0, 0);
+      gload(1, 1);
+      for (int c = 0; c < NC; c += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+          const int cc = c + par;
+          if (cc >= NC) break;
+          kp_wait_ge(ctr + 2 + par, 8 * (cc >> 1));                      // the consumers are done with this image's previous chunk
+          if (!(KABL & 1)) split_store(0, par, 0);
+          if (!(KABL & 8)) gload(0, 2 * cc + 2);
+          if (!(KABL & 1)) split_store(1, par, 1);
+          if (!(KABL & 8)) gload(1, 2 * cc + 3);
+          if (lane == 0) __hip_atomic_fetch_add(ctr + par, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      __syncthreads();                                                   // counters, sinv and the images are rewritten by the next block
+    }
+    return;
+  }
+  // ---------------- consumers: 2 row groups (96 rows) x 4 column groups (64 columns)
+  const int fr = lane & 31, fh = lane >> 5, rgp = w >> 2, cg = w & 3;
+  for (int work = blockIdx.x; work < nblk * npanels; work += gridDim.x) {
+    const int blk = work / npanels, panel = work - blk * npanels, row0 = blk * KR_RB, n0 = panel * 256 + cg * 64;
+    __syncthreads();
+    float ibv[2] = {1.f, 1.f};
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      float sc = 1.f;
+      if (AM) row_scale(b_amax[n0 + 32 * cb + fr], sc, ibv[cb]);
+    }
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ti][cb][e] = 0.f;
+    for (int c = 0; c < NC; c += 2) {
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int cc = c + par;
+        if (cc >= NC) break;
+        kp_wait_ge(ctr + par, 4 * ((cc >> 1) + 1));                      // all four producers have stored this chunk
+        const unsigned char *ab = aimg + par * KR_ABUF + fh * KR_APANEL + (96 * rgp + fr) * 16;
+        const unsigned char *bb = bimg + par * KR_BBUF + fh * KR_BPANEL + (64 * cg + fr) * 16;
+#pragma unroll
+        for (int s = 0; s < KR_KC / 16; ++s) {
+          h16x8 ah[3], al[3], bh[2], bl[2];
+#pragma unroll
+          for (int ti = 0; ti < 3; ++ti) {
+            if (KABL & 4) {
+              ah[ti] = __builtin_bit_cast(h16x8, u32x4{(unsigned)s, (unsigned)ti, 1u, (unsigned)cc});
+              al[ti] = ah[ti];
+            } else {
+              ah[ti] = *reinterpret_cast<const h16x8 *>(ab + 2 * s * KR_APANEL + ti * 32 * 16);
+              al[ti] = *reinterpret_cast<const h16x8 *>(ab + 2 * s * KR_APANEL + ti * 32 * 16 + KR_APLANE);
+            }
+          }
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            if (KABL & 4) {
+              bh[cb] = __builtin_bit_cast(h16x8, u32x4{(unsigned)s, (unsigned)cb, 3u, (unsigned)cc});
+              bl[cb] = bh[cb];
+            } else {
+              bh[cb] = *reinterpret_cast<const h16x8 *>(bb + 2 * s * KR_BPANEL + cb * 32 * 16);
+              bl[cb] = *reinterpret_cast<const h16x8 *>(bb + 2 * s * KR_BPANEL + cb * 32 * 16 + KR_BPLANE);
+            }
+          }
+          if (KABL & 2) {
+#pragma unroll
+            for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb) acc[ti][cb][0] += (float)ah[ti][0] * (float)bl[cb][1] + (float)al[ti][2] * (float)bh[cb][3];
+            continue;
+          }
+#pragma unroll
+          for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) mmah(acc[ti][cb], al[ti], bh[cb]);
+#pragma unroll
+          for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) mmah(acc[ti][cb], ah[ti], bl[cb]);
+#pragma unroll
+          for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) mmah(acc[ti][cb], ah[ti], bh[cb]);
+        }
+        // (the fragments are in registers: every LDS read of this image has completed) hand the image back
+        if (lane == 0) __hip_atomic_fetch_add(ctr + 2 + par, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+#pragma unroll
+    for (int ti = 0; ti < 3; ++ti) {
+      const int rl0 = 96 * rgp + 32 * ti;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const int col = n0 + 32 * cb + fr;
+        const float bv = bias ? bias[col] : 0.f;
+        float *cp = C + (int64_t)(row0 + rl0) * ldc + col;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int rl = (e & 3) + 8 * (e >> 2) + 4 * fh;
+          if (row0 + rl0 + rl < M) cp[(int64_t)rl * ldc] = acc[ti][cb][e] * (sinv[rl0 + rl] * ibv[cb]) + bv;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
 }  // namespace
 
 static const bool g_rows_relu = []() { const char *e = getenv("PD_H2_ROWS_RELU"); return !e || e[0] != '0'; }();   // A/B switch (default on)
@@ -1112,6 +1304,40 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
     if (a_amax) hipLaunchKernelGGL(gemm_kres_f16x2<true>, dim3((unsigned)G), dim3(512), KR_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
     else hipLaunchKernelGGL(gemm_kres_f16x2<false>, dim3((unsigned)G), dim3(512), KR_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
     return pd_check_launch("pd_gemm_tn_f16x2 (resident accumulators)");
+  }
+  // the same shapes with producer / consumer wavefronts (gemm_kpc_f16x2): PD_H2_KPC=1 / pd_debug_set("f16x2_tile", 92)
+  static const bool kpc_env = []() { const char *e = getenv("PD_H2_KPC"); return e && e[0] == '1'; }();
+  if (((kpc_env && dbg == 0) || dbg == 92 || (dbg >= 220 && dbg < 236)) && !flags && mode == 0 && !bits && !c_amax && K >= 512 && (K % KR_KC) == 0 && (N % 256) == 0 && N <= 512 && M >= 8192 &&
+      (a_amax == nullptr) == (b_amax == nullptr)) {
+    static int ncu4 = 0;
+    if (!ncu4) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&ncu4, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu4 < 8) ncu4 = 256; }
+    const int np = N / 256, nwork = ((M + KR_RB - 1) / KR_RB) * np, G = nwork < ncu4 ? nwork : ncu4;
+    static bool pattr = false;
+    if (!pattr) {
+      (void)hipFuncSetAttribute((const void *)gemm_kpc_f16x2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KP_LDS);
+      (void)hipFuncSetAttribute((const void *)gemm_kpc_f16x2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KP_LDS);
+      pattr = true;
+    }
+    if (a_amax && dbg >= 220 && dbg < 236) {                           // tools: ablations of the two roles (timing only)
+      typedef void (*kfn3)(const float *, const float *, const float *, float *, int, int, int, int, int, int, const float *, const float *);
+      kfn3 kf = nullptr;
+      switch (dbg - 220) {
+        case 1: kf = gemm_kpc_f16x2<true, 1>; break;
+        case 2: kf = gemm_kpc_f16x2<true, 2>; break;
+        case 4: kf = gemm_kpc_f16x2<true, 4>; break;
+        case 6: kf = gemm_kpc_f16x2<true, 6>; break;
+        case 8: kf = gemm_kpc_f16x2<true, 8>; break;
+        case 9: kf = gemm_kpc_f16x2<true, 9>; break;
+        case 15: kf = gemm_kpc_f16x2<true, 15>; break;
+        default: kf = gemm_kpc_f16x2<true, 0>; break;
+      }
+      (void)hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KP_LDS);
+      hipLaunchKernelGGL(kf, dim3((unsigned)G), dim3(768), KP_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
+      return pd_check_launch("pd_gemm_tn_f16x2 (producer / consumer wavefronts, ablation)");
+    }
+    if (a_amax) hipLaunchKernelGGL(gemm_kpc_f16x2<true>, dim3((unsigned)G), dim3(768), KP_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
+    else hipLaunchKernelGGL(gemm_kpc_f16x2<false>, dim3((unsigned)G), dim3(768), KP_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
+    return pd_check_launch("pd_gemm_tn_f16x2 (producer / consumer wavefronts)");
   }
   // the sign bits are laid out in the 256 x 256 kernel's accumulator order: bits / mask launches must take that kernel
   const bool need_wide = bits != nullptr;

@@ -323,7 +323,8 @@ def test_gemm_tn_h2_row_stream_matches_the_tiled_kernel(M, N, K, scaled):
 
 @pytest.mark.parametrize("M,N,K", [(43008, 256, 1024), (8300, 512, 512), (9001, 256, 576), (8192, 256, 2048)])
 @pytest.mark.parametrize("scaled", [True, False])
-def test_gemm_tn_h2_resident_accumulators_match_fp64_and_the_tiled_kernel(M, N, K, scaled):
+@pytest.mark.parametrize("variant", [91, 92])           # 91: barriers per chunk (gemm_kres_f16x2); 92: producer / consumer wavefronts (gemm_kpc_f16x2)
+def test_gemm_tn_h2_resident_accumulators_match_fp64_and_the_tiled_kernel(M, N, K, scaled, variant):
     """gemm_kres_f16x2 (deep K, 256-column panels: K outside, a 192-row block's accumulators resident; experimental,
     pd_debug_set("f16x2_tile", 91)): fp32-accurate against fp64, within 1e-6 of the tiled kernel, ragged last row block, two column panels,
     K not a power of two, with / without bias and row scales."""
@@ -342,9 +343,9 @@ def test_gemm_tn_h2_resident_accumulators_match_fp64_and_the_tiled_kernel(M, N, 
         tiled = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
     finally:
         L.pd_debug_set(b"f16x2_tile", 0)
-    L.pd_debug_set(b"f16x2_tile", 91)
+    L.pd_debug_set(b"f16x2_tile", variant)
     try:
-        assert L.pd_gemm_tn_f16x2_which(M, N, K, 0, 0, int(scaled)) == 4
+        assert variant != 91 or L.pd_gemm_tn_f16x2_which(M, N, K, 0, 0, int(scaled)) == 4
         got = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
         again = gemm.gemm_tn_h2(a, w, b, a_amax=aa, b_amax=wa)
     finally:
