@@ -842,14 +842,14 @@ void gemm_kres_f16x2(const float *__restrict__ A, const float *__restrict__ B, c
       unsigned char *bb = bimg + buf * KR_BBUF + (ac4 >> 1) * KR_BPANEL + (ac4 & 1) * 8;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const SplitH v = split4h(RA[rs][j], sa[j]);
+        const SplitH v = split4h_u(RA[rs][j], sa[j]);
         unsigned char *p = ab + (arow + 64 * j) * 16;
         *reinterpret_cast<uint2 *>(p) = v.hi;
         *reinterpret_cast<uint2 *>(p + KR_APLANE) = v.lo;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const SplitH v = split4h(RB[rs][j], sb[j]);
+        const SplitH v = split4h_u(RB[rs][j], sb[j]);
         unsigned char *p = bb + (arow + 64 * j) * 16;
         *reinterpret_cast<uint2 *>(p) = v.hi;
         *reinterpret_cast<uint2 *>(p + KR_BPLANE) = v.lo;
@@ -870,12 +870,12 @@ void gemm_kres_f16x2(const float *__restrict__ A, const float *__restrict__ B, c
     // one staged item: A rows (j < 3) or weight rows (j - 3) of register stage rs -> the images `buf`
     auto stage_item = [&](int rs, int buf, int j) {
       if (j < 3) {
-        const SplitH v = split4h(RA[rs][j], sa[j]);
+        const SplitH v = split4h_u(RA[rs][j], sa[j]);
         unsigned char *p = aimg + buf * KR_ABUF + (ac4 >> 1) * KR_APANEL + (ac4 & 1) * 8 + (arow + 64 * j) * 16;
         *reinterpret_cast<uint2 *>(p) = v.hi;
         *reinterpret_cast<uint2 *>(p + KR_APLANE) = v.lo;
       } else {
-        const SplitH v = split4h(RB[rs][j - 3], sb[j - 3]);
+        const SplitH v = split4h_u(RB[rs][j - 3], sb[j - 3]);
         unsigned char *p = bimg + buf * KR_BBUF + (ac4 >> 1) * KR_BPANEL + (ac4 & 1) * 8 + (arow + 64 * (j - 3)) * 16;
         *reinterpret_cast<uint2 *>(p) = v.hi;
         *reinterpret_cast<uint2 *>(p + KR_BPLANE) = v.lo;
@@ -965,12 +965,41 @@ void gemm_kres_f16x2(const float *__restrict__ A, const float *__restrict__ B, c
 // wavefront polls on its own (s_sleep between polls); no s_barrier inside the K loop.
 constexpr size_t KP_LDS = (size_t)2 * (KR_ABUF + KR_BBUF) + KR_RB * sizeof(float) + 4 * sizeof(int);
 
-__device__ __forceinline__ void kp_wait_ge(int *p, int target)
+// W [N, K] fp32 -> two fp16 planes [2][N][K] with the rows scaled by row_scale(amax[row]) (the B operand of gemm_kpc_f16x2<.., BP>)
+__global__ __launch_bounds__(256) void split_planes_f16x2(const float *__restrict__ Wm, int ldw, const float *__restrict__ amax, unsigned short *__restrict__ planes,
+                                                          int N, int K)
 {
-  while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x, k4 = K / 4;
+  if (i4 >= (int64_t)N * k4) return;
+  const int row = (int)(i4 / k4), c = (int)(i4 - (int64_t)row * k4) * 4;
+  float sc = 1.f, inv = 1.f;
+  if (amax) row_scale(amax[row], sc, inv);
+  const SplitH v = split4h_u(*reinterpret_cast<const float4 *>(Wm + (int64_t)row * ldw + c), sc);
+  *reinterpret_cast<uint2 *>(planes + (int64_t)row * K + c) = v.hi;
+  *reinterpret_cast<uint2 *>(planes + ((int64_t)N + row) * K + c) = v.lo;
 }
 
-template <bool AM, int KABL = 0>     // KABL (tools only): 2 no products, 4 no fragment reads, 8 no global loads in the loop, 1 no split / LDS stores
+// tools only (KABL & 16): wall-clock stamps of workgroup 0's first consumer and first producer wavefront, read back by pd_debug_read_kpc_trace
+__device__ unsigned long long g_kp_trace[2][64][8];
+__device__ __forceinline__ void kp_stamp(int role, int chunk, int ev)
+{
+  if (chunk < 64) g_kp_trace[role][chunk][ev] = __builtin_readcyclecounter();
+}
+
+// The counters and the data they guard both live in LDS, which serves a CU's wavefronts in order: the arrival that made the count was issued
+// after the LDS accesses it reports (s_waitcnt before it), so a RELAXED poll and a compiler barrier are enough.  An acquire load makes the
+// compiler wait for vmcnt(0) as well — every global load the producer has in flight (tools/debug/kpc_trace.py: 3 000 of a chunk's 5 000 cycles).
+__device__ __forceinline__ void kp_wait_ge(int *p, int target)
+{
+  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+
+template <bool AM, int KABL = 0, bool BP = false>     // KABL (tools only): 2 no products, 4 no fragment reads, 8 no global loads in the loop, 1 no split / LDS stores
+// BP: the weights come PRE-SPLIT — `B` points at two fp16 planes [2][256 npanels][K] (hi, lo; rows scaled by row_scale(b_amax), written by
+// split_planes_f16x2) — and go global -> LDS without touching the VALU: the stamps (tools/debug/kpc_trace.py) show that the split's VALU work does
+// not overlap the consumers' matrix instructions on a SIMD (a half's 970 cycles of split + stores become 3 050 while they multiply, 1 600 while
+// they only read fragments): the chunk period is split time + product time, which is what "the phases add up" was in every kernel of this family.
 __global__ __launch_bounds__(768)
 void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ bias, float *__restrict__ C, int M, int K,
                     int lda, int ldb, int ldc, int npanels, const float *__restrict__ a_amax, const float *__restrict__ b_amax)
@@ -1007,49 +1036,86 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
         sb[j] = 1.f;
         if (AM) row_scale(b_amax[c0 + prow + 32 * j], sb[j], inv);
       }
-      // a chunk is staged as two halves (A rows 0 .. 95 + weight rows 0 .. 127, then the rest): two halves in flight = 56 registers — a whole
-      // chunk per stage (112) spilled — and 57 KB per CU on the way, more than latency x the CU's share of the bandwidth needs
-      float4 RA[2][3], RB[2][4];
+      // a chunk is staged as two halves (A rows 0 .. 95 + weight rows 0 .. 127, then the rest), THREE halves in flight (84 registers; a whole
+      // chunk per stage, 2 x 56, spilled).  The stamps of the first version (two halves in flight, tools/debug/kpc_trace.py) showed the
+      // producers as the bottleneck: per chunk 970 cycles of split + stores per half, ~1 900 cycles waiting for loads issued a chunk earlier
+      // (memory latency under this load is > 4 000 cycles), and the consumers idle 57 % of the time waiting for `full`.
+      // buffer loads: one 32-bit byte offset per staged row (a 64-bit pointer each, 28 registers, spilled — and a spill reload waits for
+      // vmcnt(0), i.e. for every load in flight); the chunk's k offset rides in the scalar offset; rows past M are out of range and read as 0
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (int)((int64_t)M * lda * 4), 0x00020000);
+      // BP: planes [2][npanels * 256][K] halves; piece q = pt + 256 j of a half: plane q >> 9, column (q & 511) >> 2 of the half's 128, k panel q & 3
+      const int64_t bbytes = BP ? (int64_t)2 * npanels * 256 * K * 2 : (int64_t)(c0 + 256) * ldb * 4;
+      const __amdgpu_buffer_rsrc_t rbs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)bbytes, 0x00020000);
+      unsigned oa[6], ob[8];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) oa[j] = ((unsigned)(row0 + prow + 32 * j) * (unsigned)lda + 4u * pc4) * 4u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (BP) {
+          const int q = pt + 256 * (j & 3), h = j >> 2, plane = q >> 9, col = 128 * h + ((q & 511) >> 2), pan = q & 3;
+          ob[j] = (unsigned)(((int64_t)plane * npanels * 256 + c0 + col) * K + 8 * pan) * 2u;
+        } else {
+          ob[j] = ((unsigned)(c0 + prow + 32 * j) * (unsigned)ldb + 4u * pc4) * 4u;
+        }
+      }
+      float4 RA[3][3], RB[3][4];
       auto gload = [&](int rs, int u) {                                  // half u & 1 of chunk u >> 1
-        const int kc = min(u >> 1, NC - 1), h = u & 1;
+        const int ko = min(u >> 1, NC - 1) * (KR_KC * 4), h = u & 1;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-          RA[rs][j] = *reinterpret_cast<const float4 *>(A + (int64_t)min(row0 + prow + 32 * (3 * h + j), M - 1) * lda + kc * KR_KC + 4 * pc4);
+        for (int j = 0; j < 3; ++j) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, h ? oa[3 + j] : oa[j], ko, 0);
+          RA[rs][j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          RB[rs][j] = *reinterpret_cast<const float4 *>(B + (int64_t)(c0 + prow + 32 * (4 * h + j)) * ldb + kc * KR_KC + 4 * pc4);
+        for (int j = 0; j < 4; ++j) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rbs, h ? ob[4 + j] : ob[j], BP ? ko / 2 : ko, 0);      // (planes: 2 bytes per k)
+          RB[rs][j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
       };
       auto split_store = [&](int rs, int buf, int h) {
         unsigned char *ab = aimg + buf * KR_ABUF + (pc4 >> 1) * KR_APANEL + (pc4 & 1) * 8;
         unsigned char *bb = bimg + buf * KR_BBUF + (pc4 >> 1) * KR_BPANEL + (pc4 & 1) * 8;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const SplitH v = split4h(RA[rs][j], h ? sa[3 + j] : sa[j]);
+          const SplitH v = split4h_u(RA[rs][j], h ? sa[3 + j] : sa[j]);
           unsigned char *p = ab + (prow + 32 * (3 * h + j)) * 16;
           *reinterpret_cast<uint2 *>(p) = v.hi;
           *reinterpret_cast<uint2 *>(p + KR_APLANE) = v.lo;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const SplitH v = split4h(RB[rs][j], h ? sb[4 + j] : sb[j]);
-          unsigned char *p = bb + (prow + 32 * (4 * h + j)) * 16;
-          *reinterpret_cast<uint2 *>(p) = v.hi;
-          *reinterpret_cast<uint2 *>(p + KR_BPLANE) = v.lo;
+          if (BP) {                                                        // a 16-byte piece of a plane IS an LDS slot: [k panel][column][8 halves]
+            const int q = pt + 256 * j, plane = q >> 9, col = 128 * h + ((q & 511) >> 2), pan = q & 3;
+            *reinterpret_cast<float4 *>(bimg + buf * KR_BBUF + plane * KR_BPLANE + pan * KR_BPANEL + col * 16) = RB[rs][j];
+          } else {
+            const SplitH v = split4h_u(RB[rs][j], h ? sb[4 + j] : sb[j]);
+            unsigned char *p = bb + (prow + 32 * (4 * h + j)) * 16;
+            *reinterpret_cast<uint2 *>(p) = v.hi;
+            *reinterpret_cast<uint2 *>(p + KR_BPLANE) = v.lo;
+          }
         }
       };
       gload(0, 0);
       gload(1, 1);
-      for (int c = 0; c < NC; c += 2) {
+      gload(2, 2);
+      const int NH = 2 * NC;
+      for (int u0 = 0; u0 < NH; u0 += 6) {
 #pragma unroll
-        for (int par = 0; par < 2; ++par) {
-          const int cc = c + par;
-          if (cc >= NC) break;
-          kp_wait_ge(ctr + 2 + par, 8 * (cc >> 1));                      // the consumers are done with this image's previous chunk
-          if (!(KABL & 1)) split_store(0, par, 0);
-          if (!(KABL & 8)) gload(0, 2 * cc + 2);
-          if (!(KABL & 1)) split_store(1, par, 1);
-          if (!(KABL & 8)) gload(1, 2 * cc + 3);
-          if (lane == 0) __hip_atomic_fetch_add(ctr + par, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int k6 = 0; k6 < 6; ++k6) {
+          const int u = u0 + k6;
+          if (u >= NH) break;
+          const int cc = u >> 1, par = cc & 1, h = k6 & 1, rs = k6 % 3;
+          const bool tr = (KABL & 16) && blockIdx.x == 0 && w == 8 && lane == 0;
+          if (h == 0) {
+            if (tr) kp_stamp(1, cc, 0);
+            kp_wait_ge(ctr + 2 + par, 8 * (cc >> 1));                    // the consumers are done with this image's previous chunk
+            if (tr) kp_stamp(1, cc, 1);
+          }
+          if (KABL & 16) { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); if (tr) kp_stamp(1, cc, 2 + 2 * h); }   // this half's loads have landed (14 younger ones may be out)
+          if (!(KABL & 1)) split_store(rs, par, h);
+          if (!(KABL & 8)) gload(rs, u + 3);
+          if (KABL & 16) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (tr) kp_stamp(1, cc, 3 + 2 * h); }
+          if (h == 1 && lane == 0) __hip_atomic_fetch_add(ctr + par, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
       __syncthreads();                                                   // counters, sinv and the images are rewritten by the next block
@@ -1079,7 +1145,10 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
       for (int par = 0; par < 2; ++par) {
         const int cc = c + par;
         if (cc >= NC) break;
+        const bool tr = (KABL & 16) && blockIdx.x == 0 && w == 0 && lane == 0;
+        if (tr) kp_stamp(0, cc, 0);
         kp_wait_ge(ctr + par, 4 * ((cc >> 1) + 1));                      // all four producers have stored this chunk
+        if (tr) kp_stamp(0, cc, 1);
         const unsigned char *ab = aimg + par * KR_ABUF + fh * KR_APANEL + (96 * rgp + fr) * 16;
         const unsigned char *bb = bimg + par * KR_BBUF + fh * KR_BPANEL + (64 * cg + fr) * 16;
 #pragma unroll
@@ -1112,6 +1181,7 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
               for (int cb = 0; cb < 2; ++cb) acc[ti][cb][0] += (float)ah[ti][0] * (float)bl[cb][1] + (float)al[ti][2] * (float)bh[cb][3];
             continue;
           }
+          if (KABL & 16) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (tr) kp_stamp(0, cc, 3 + s); }   // this step's ten fragments are in
 #pragma unroll
           for (int ti = 0; ti < 3; ++ti)
 #pragma unroll
@@ -1126,6 +1196,7 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
             for (int cb = 0; cb < 2; ++cb) mmah(acc[ti][cb], ah[ti], bh[cb]);
         }
         // (the fragments are in registers: every LDS read of this image has completed) hand the image back
+        if (tr) kp_stamp(0, cc, 2);
         if (lane == 0) __hip_atomic_fetch_add(ctr + 2 + par, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
@@ -1305,9 +1376,11 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
     else hipLaunchKernelGGL(gemm_kres_f16x2<false>, dim3((unsigned)G), dim3(512), KR_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
     return pd_check_launch("pd_gemm_tn_f16x2 (resident accumulators)");
   }
-  // the same shapes with producer / consumer wavefronts (gemm_kpc_f16x2): PD_H2_KPC=1 / pd_debug_set("f16x2_tile", 92)
-  static const bool kpc_env = []() { const char *e = getenv("PD_H2_KPC"); return e && e[0] == '1'; }();
-  if (((kpc_env && dbg == 0) || dbg == 92 || (dbg >= 220 && dbg < 236)) && !flags && mode == 0 && !bits && !c_amax && K >= 512 && (K % KR_KC) == 0 && (N % 256) == 0 && N <= 512 && M >= 8192 &&
+  // the same shapes with producer / consumer wavefronts (gemm_kpc_f16x2) — the PRODUCT'S CHOICE since its split uses unpacked VALU instructions
+  // (f16x2.h split4h_u): 256 <- 1024 at M = 43 008 76-78 us against the tiled kernel's 92-94, the step 21.82 -> 21.65 ms (three same-box A/B pairs).
+  // PD_H2_KPC=0 / pd_debug_set("f16x2_tile", 80) keep the tiled kernel; 92 / 93 select it with fp32 weights / pre-split weight planes.
+  static const bool kpc_env = []() { const char *e = getenv("PD_H2_KPC"); return !e || e[0] != '0'; }();
+  if (((kpc_env && dbg == 0) || dbg == 92 || dbg == 93 || dbg == 94 || (dbg >= 220 && dbg < 236)) && (int64_t)M * lda * 4 < (1ll << 31) && (int64_t)N * ldb * 4 < (1ll << 31) && !flags && mode == 0 && !bits && !c_amax && K >= 512 && (K % KR_KC) == 0 && (N % 256) == 0 && N <= 512 && M >= 8192 &&
       (a_amax == nullptr) == (b_amax == nullptr)) {
     static int ncu4 = 0;
     if (!ncu4) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&ncu4, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu4 < 8) ncu4 = 256; }
@@ -1318,7 +1391,7 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
       (void)hipFuncSetAttribute((const void *)gemm_kpc_f16x2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KP_LDS);
       pattr = true;
     }
-    if (a_amax && dbg >= 220 && dbg < 236) {                           // tools: ablations of the two roles (timing only)
+    if (a_amax && dbg >= 220 && dbg < 236 && dbg != 234) {             // tools: ablations of the two roles (timing only); 234: stamps of the planes form, below
       typedef void (*kfn3)(const float *, const float *, const float *, float *, int, int, int, int, int, int, const float *, const float *);
       kfn3 kf = nullptr;
       switch (dbg - 220) {
@@ -1329,11 +1402,38 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
         case 8: kf = gemm_kpc_f16x2<true, 8>; break;
         case 9: kf = gemm_kpc_f16x2<true, 9>; break;
         case 15: kf = gemm_kpc_f16x2<true, 15>; break;
+        case 12: kf = gemm_kpc_f16x2<true, 16>; break;        // 232: stamps (pd_debug_read_kpc_trace)
+        case 13: kf = gemm_kpc_f16x2<true, 18>; break;        // 233: stamps, no products
         default: kf = gemm_kpc_f16x2<true, 0>; break;
       }
       (void)hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KP_LDS);
       hipLaunchKernelGGL(kf, dim3((unsigned)G), dim3(768), KP_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
       return pd_check_launch("pd_gemm_tn_f16x2 (producer / consumer wavefronts, ablation)");
+    }
+    static const bool kpc_bp = []() { const char *e = getenv("PD_H2_KPC_PLANES"); return e && e[0] == '1'; }();   // (not faster once the split is unpacked: 78.5 vs 77 us)
+    if ((kpc_bp && dbg != 94 && dbg != 92) || dbg == 93 || dbg == 234) {
+      // weights pre-split into planes by one small launch (a per-process scratch: launches of one stream are ordered)
+      static unsigned short *planes = nullptr;
+      static int64_t planes_cap = 0;
+      const int64_t need = (int64_t)2 * N * K;
+      if (need > planes_cap) {
+        if (planes) (void)hipFree(planes);
+        if (hipMalloc(reinterpret_cast<void **>(&planes), (size_t)need * 2) != hipSuccess) { planes = nullptr; planes_cap = 0; return pd_set_error(PD_ERR_LAUNCH, "pd_gemm_tn_f16x2: no memory for the weight planes"); }
+        planes_cap = need;
+      }
+      hipLaunchKernelGGL(split_planes_f16x2, dim3((unsigned)(((int64_t)N * (K / 4) + 255) / 256)), dim3(256), 0, st, B, ldb, b_amax, planes, N, K);
+      static bool battr = false;
+      if (!battr) {
+        (void)hipFuncSetAttribute((const void *)(gemm_kpc_f16x2<true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KP_LDS);
+        (void)hipFuncSetAttribute((const void *)(gemm_kpc_f16x2<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KP_LDS);
+        (void)hipFuncSetAttribute((const void *)(gemm_kpc_f16x2<true, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KP_LDS);
+        battr = true;
+      }
+      const float *bpl = reinterpret_cast<const float *>(planes);
+      if (dbg == 234) hipLaunchKernelGGL((gemm_kpc_f16x2<true, 16, true>), dim3((unsigned)G), dim3(768), KP_LDS, st, A, bpl, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
+      else if (a_amax) hipLaunchKernelGGL((gemm_kpc_f16x2<true, 0, true>), dim3((unsigned)G), dim3(768), KP_LDS, st, A, bpl, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
+      else hipLaunchKernelGGL((gemm_kpc_f16x2<false, 0, true>), dim3((unsigned)G), dim3(768), KP_LDS, st, A, bpl, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
+      return pd_check_launch("pd_gemm_tn_f16x2 (producer / consumer wavefronts, weight planes)");
     }
     if (a_amax) hipLaunchKernelGGL(gemm_kpc_f16x2<true>, dim3((unsigned)G), dim3(768), KP_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
     else hipLaunchKernelGGL(gemm_kpc_f16x2<false>, dim3((unsigned)G), dim3(768), KP_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
@@ -1369,8 +1469,8 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
 }
 
 // which kernel pd_gemm_tn_f16x2 launches for a problem (tools / bench.py labels): 0 = 128 x 128 tiles, 1 = 256 x 256 tiles, 2 = the row stream
-// (gemm_rows_f16x2_k256), 3 = the register-operand kernel (opt-in), 4 = resident accumulators (gemm_kres_f16x2, opt-in; a launch that asks
-// for output row maxima takes the tiled kernel).  Mirrors the dispatch of gemm_tn_f16x2_impl.
+// (gemm_rows_f16x2_k256), 3 = the register-operand kernel (opt-in), 4 = resident accumulators (gemm_kres_f16x2, opt-in), 5 = the same with
+// producer / consumer wavefronts (gemm_kpc_f16x2; a launch that asks for output row maxima takes the tiled kernel).  Mirrors the dispatch of gemm_tn_f16x2_impl.
 extern "C" int pd_gemm_tn_f16x2_which(int M, int N, int K, int mode, int has_bits, int has_amax)
 {
   const int dbg = g_pd_dbg_f16x2;
@@ -1378,6 +1478,8 @@ extern "C" int pd_gemm_tn_f16x2_which(int M, int N, int K, int mode, int has_bit
   if ((dbg == 61 || (rows_k256 && dbg == 0)) && mode == 0 && K == 256 && (N % 256) == 0 && M >= 8192) return 2;
   if ((dbg == 90 || (dbg >= 100 && dbg < 132)) && mode == 0 && K == 256 && M >= 4096 && (N % 32) == 0 && N >= 96 && ((N % 128) == 0 || (N % 96) == 0)) return 3;
   if (dbg != 62 && dbg != 3 && dbg != 13 && dbg != 70 && (mode == 1 || mode == 2) && has_bits && K == 256 && (N % 256) == 0 && N >= 512 && M >= 8192 && has_amax && g_rows_relu) return 2;
+  static const bool kpc_env = []() { const char *e = getenv("PD_H2_KPC"); return !e || e[0] != '0'; }();
+  if (((kpc_env && dbg == 0) || dbg == 92 || dbg == 93) && mode == 0 && !has_bits && K >= 512 && (K % KR_KC) == 0 && (N % 256) == 0 && N <= 512 && M >= 8192) return 5;
   static const bool kres_env = []() { const char *e = getenv("PD_H2_KRES"); return e && e[0] == '1'; }();
   if (((kres_env && dbg == 0) || dbg == 91) && mode == 0 && !has_bits && K >= 512 && (K % KR_KC) == 0 && (N % 256) == 0 && N <= 512 && M >= 8192) return 4;
   const bool wide_ok = (N % 256) == 0 && M >= 1024;
@@ -1435,4 +1537,9 @@ extern "C" int pd_row_amax_f32(const float *X, int rows, int cols, int ld, float
   if (!X || !out) return pd_set_error(PD_ERR_INVALID_ARG, "pd_row_amax_f32: null pointer");
   hipLaunchKernelGGL(row_amax_f32, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, X, rows, cols, ld, out);
   return pd_check_launch("pd_row_amax_f32");
+}
+
+extern "C" int pd_debug_read_kpc_trace(unsigned long long *dst)
+{
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_kp_trace), sizeof(unsigned long long) * 2 * 64 * 8) == hipSuccess ? PD_OK : PD_ERR_LAUNCH;
 }

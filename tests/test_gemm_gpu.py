@@ -323,7 +323,7 @@ def test_gemm_tn_h2_row_stream_matches_the_tiled_kernel(M, N, K, scaled):
 
 @pytest.mark.parametrize("M,N,K", [(43008, 256, 1024), (8300, 512, 512), (9001, 256, 576), (8192, 256, 2048)])
 @pytest.mark.parametrize("scaled", [True, False])
-@pytest.mark.parametrize("variant", [91, 92])           # 91: barriers per chunk (gemm_kres_f16x2); 92: producer / consumer wavefronts (gemm_kpc_f16x2)
+@pytest.mark.parametrize("variant", [91, 92, 93])       # 91: barriers per chunk (gemm_kres_f16x2); 92 / 93: producer / consumer wavefronts (gemm_kpc_f16x2) with fp32 weights / pre-split weight planes
 def test_gemm_tn_h2_resident_accumulators_match_fp64_and_the_tiled_kernel(M, N, K, scaled, variant):
     """gemm_kres_f16x2 (deep K, 256-column panels: K outside, a 192-row block's accumulators resident; experimental,
     pd_debug_set("f16x2_tile", 91)): fp32-accurate against fp64, within 1e-6 of the tiled kernel, ragged last row block, two column panels,

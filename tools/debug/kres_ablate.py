@@ -16,7 +16,7 @@ def t(n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 for name, v in [("tiled 128 x 128", 80), ("resident accumulators", 91), ("  no split / LDS stores", 201), ("  no products", 202), ("  no fragment reads", 204),
-                ("  no fragment reads, no products", 206), ("  no global loads", 208), ("  no loads, no stores to LDS", 209), ("  nothing in the loop", 215), ("producer / consumer wavefronts", 92), ("  no split / LDS stores", 221),
+                ("  no fragment reads, no products", 206), ("  no global loads", 208), ("  no loads, no stores to LDS", 209), ("  nothing in the loop", 215), ("producer / consumer", 92), ("producer / consumer, weight planes", 93), ("  no split / LDS stores", 221),
                 ("  no products", 222), ("  no fragment reads", 224), ("  no fragment reads, no products", 226), ("  no global loads", 228), ("  no loads, no stores to LDS", 229),
                 ("  nothing in the loop", 235)]:
     L.pd_debug_set(b"f16x2_tile", v)
