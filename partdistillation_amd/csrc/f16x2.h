@@ -31,7 +31,7 @@ __device__ __forceinline__ void split2h(float x0, float x1, unsigned &h, unsigne
   h = __builtin_bit_cast(unsigned, hh);
   l = __builtin_bit_cast(unsigned, ll);
 }
-__device__ __forceinline__ SplitH split4h(float4 v, float s)
+__device__ __forceinline__ SplitH split4h_p(float4 v, float s)
 {
   SplitH o;
   split2h(v.x * s, v.y * s, o.hi.x, o.lo.x);
@@ -60,6 +60,15 @@ __device__ __forceinline__ SplitH split4h_u(float4 v, float s)
   split2h_u(np_mul(v.x, s), np_mul(v.y, s), o.hi.x, o.lo.x);
   split2h_u(np_mul(v.z, s), np_mul(v.w, s), o.hi.y, o.lo.y);
   return o;
+}
+// split4h: the packed form unless a translation unit is built with -DPD_F16X2_UNPACKED_SPLIT (A/B builds)
+__device__ __forceinline__ SplitH split4h(float4 v, float s)
+{
+#ifdef PD_F16X2_UNPACKED_SPLIT
+  return split4h_u(v, s);
+#else
+  return split4h_p(v, s);
+#endif
 }
 __device__ __forceinline__ void mmah(f32x16 &c, h16x8 x, h16x8 y) { c = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0); }
 

@@ -443,6 +443,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // MODE (round 5): 0 bias; 1 ReLU and its sign bits (16 per lane and tile, stored as one half-word at ((tile * npanels + panel) * 8 + wave) * 64 + lane:
 // this kernel's own order — a mode-2 launch over the same [M, N] reads them back); 2 keep where the bit is set + column sums into `colsum`.
+// the row stream stages with the UNPACKED split (f16x2.h): 256 <- 256 31.5 -> 29.9 us, 131 072 rows 73 -> 61 us, the step 21.44 -> 21.32 ms (three
+// same-box A/B pairs); -DPD_ROWS_PACKED_SPLIT restores v_pk_mul_f32 / v_pk_fma_f32
+#ifdef PD_ROWS_PACKED_SPLIT
+#define ROWS_SPLIT split4h
+#else
+#define ROWS_SPLIT split4h_u
+#endif
 template <bool AM, int MODE = 0>   // AM: both operands come with row maxima (scaled rows); false: neither (unit scales)
 __global__ __launch_bounds__(512)
 void gemm_rows_f16x2_k256(const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ bias, float *__restrict__ C,
@@ -482,7 +489,7 @@ void gemm_rows_f16x2_k256(const float *__restrict__ A, const float *__restrict__
       float s = 1.f;
       invs[j] = 1.f;
       if (AM) row_scale(am[rs][j], s, invs[j]);
-      const SplitH v = split4h(R[rs][j], s);
+      const SplitH v = ROWS_SPLIT(R[rs][j], s);
       unsigned char *p = (buf ? lds1 : lds0) + (lane >> 1) * RS_PANEL + (w + 8 * j) * 16 + (lane & 1) * 8;
       if (PD_ABL & 4) { asm volatile("" ::"v"(R[rs][j].x), "v"(R[rs][j].y), "v"(R[rs][j].z), "v"(R[rs][j].w)); continue; }
       *reinterpret_cast<uint2 *>(p) = v.hi;
@@ -1380,7 +1387,7 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
   // (f16x2.h split4h_u): 256 <- 1024 at M = 43 008 76-78 us against the tiled kernel's 92-94, the step 21.82 -> 21.65 ms (three same-box A/B pairs).
   // PD_H2_KPC=0 / pd_debug_set("f16x2_tile", 80) keep the tiled kernel; 92 / 93 select it with fp32 weights / pre-split weight planes.
   static const bool kpc_env = []() { const char *e = getenv("PD_H2_KPC"); return !e || e[0] != '0'; }();
-  if (((kpc_env && dbg == 0) || dbg == 92 || dbg == 93 || dbg == 94 || (dbg >= 220 && dbg < 236)) && (int64_t)M * lda * 4 < (1ll << 31) && (int64_t)N * ldb * 4 < (1ll << 31) && !flags && mode == 0 && !bits && !c_amax && K >= 512 && (K % KR_KC) == 0 && (N % 256) == 0 && N <= 512 && M >= 8192 &&
+  if (((kpc_env && dbg == 0) || dbg == 92 || dbg == 93 || dbg == 94 || (dbg >= 220 && dbg < 236)) && (int64_t)M * lda * 4 < (1ll << 31) && (int64_t)N * ldb * 4 < (1ll << 31) && !flags && mode == 0 && !bits && !c_amax && (K >= 512 || (dbg == 92 && K >= 128)) && (K % KR_KC) == 0 && (N % 256) == 0 && (N <= 512 || dbg == 92) && M >= 8192 &&
       (a_amax == nullptr) == (b_amax == nullptr)) {
     static int ncu4 = 0;
     if (!ncu4) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&ncu4, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu4 < 8) ncu4 = 256; }
