@@ -1002,15 +1002,29 @@ __device__ __forceinline__ void kp_wait_ge(int *p, int target)
   asm volatile("" ::: "memory");
 }
 
-template <bool AM, int KABL = 0, bool BP = false>     // KABL (tools only): 2 no products, 4 no fragment reads, 8 no global loads in the loop, 1 no split / LDS stores
+template <bool AM, int KABL = 0, bool BP = false, bool CONV = false>     // KABL (tools only): 2 no products, 4 no fragment reads, 8 no global loads in the loop, 1 no split / LDS stores
 // BP: the weights come PRE-SPLIT — `B` points at two fp16 planes [2][256 npanels][K] (hi, lo; rows scaled by row_scale(b_amax), written by
 // split_planes_f16x2) — and go global -> LDS without touching the VALU: the stamps (tools/debug/kpc_trace.py) show that the split's VALU work does
 // not overlap the consumers' matrix instructions on a SIMD (a half's 970 cycles of split + stores become 3 050 while they multiply, 1 600 while
 // they only read fragments): the chunk period is split time + product time, which is what "the phases add up" was in every kernel of this family.
 __global__ __launch_bounds__(768)
 void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ bias, float *__restrict__ C, int M, int K,
-                    int lda, int ldb, int ldc, int npanels, const float *__restrict__ a_amax, const float *__restrict__ b_amax)
+                    int lda, int ldb, int ldc, int npanels, const float *__restrict__ a_amax, const float *__restrict__ b_amax, int H = 0, int W = 0)
 {
+  // CONV: A is an NHWC image [*, H, W, Ci = lda], row m = output pixel m of a 3 x 3 / stride 1 / pad 1 convolution, K = 9 Ci in (tap, channel)
+  // order (gemm_tn_f16x2's CONV form): a 32-deep chunk lies inside one tap; its rows are the input at pixel m + dy W + dx — the same byte offset
+  // for every row, added to the row's buffer offset; rows whose tap falls outside the image get an out-of-range offset and read zeros.  A
+  // row's scale covers the nine pixels it reads (the largest of their maxima).
+  auto conv_amax = [&](int row) -> float {
+    float mx = a_amax[row];
+    const int pix = row % (H * W), y = pix / W, x = pix - y * W;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx)
+        if (y + dy >= 0 && y + dy < H && x + dx >= 0 && x + dx < W) mx = fmaxf(mx, a_amax[row + dy * W + dx]);
+    return mx;
+  };
   extern __shared__ __attribute__((aligned(16))) unsigned char kp_lds[];
   unsigned char *const aimg = kp_lds, *const bimg = kp_lds + 2 * KR_ABUF;
   float *sinv = reinterpret_cast<float *>(kp_lds + 2 * (KR_ABUF + KR_BBUF));
@@ -1026,7 +1040,7 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
       if (pt < 4) ctr[pt] = 0;
       if (pt < KR_RB) {
         float sc = 1.f, inv = 1.f;
-        if (AM) row_scale(a_amax[min(row0 + pt, M - 1)], sc, inv);
+        if (AM) row_scale(CONV ? conv_amax(min(row0 + pt, M - 1)) : a_amax[min(row0 + pt, M - 1)], sc, inv);
         sinv[pt] = inv;
       }
       __syncthreads();
@@ -1035,7 +1049,7 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
       for (int j = 0; j < 6; ++j) {
         float inv;
         sa[j] = 1.f;
-        if (AM) row_scale(a_amax[min(row0 + prow + 32 * j, M - 1)], sa[j], inv);
+        if (AM) row_scale(CONV ? conv_amax(min(row0 + prow + 32 * j, M - 1)) : a_amax[min(row0 + prow + 32 * j, M - 1)], sa[j], inv);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -1054,8 +1068,17 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
       const int64_t bbytes = BP ? (int64_t)2 * npanels * 256 * K * 2 : (int64_t)(c0 + 256) * ldb * 4;
       const __amdgpu_buffer_rsrc_t rbs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)bbytes, 0x00020000);
       unsigned oa[6], ob[8];
+      unsigned pyx[6];                                                   // CONV: (image row << 16) | column of the staged rows; 0xffffffff past M
 #pragma unroll
-      for (int j = 0; j < 6; ++j) oa[j] = ((unsigned)(row0 + prow + 32 * j) * (unsigned)lda + 4u * pc4) * 4u;
+      for (int j = 0; j < 6; ++j) {
+        const int row = row0 + prow + 32 * j;
+        oa[j] = ((unsigned)row * (unsigned)lda + 4u * pc4) * 4u;
+        pyx[j] = 0u;
+        if (CONV) {
+          const int pix = row % (H * W), y = pix / W;
+          pyx[j] = row < M ? ((unsigned)y << 16) | (unsigned)(pix - y * W) : 0xffffffffu;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (BP) {
@@ -1067,10 +1090,23 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
       }
       float4 RA[3][3], RB[3][4];
       auto gload = [&](int rs, int u) {                                  // half u & 1 of chunk u >> 1
-        const int ko = min(u >> 1, NC - 1) * (KR_KC * 4), h = u & 1;
+        const int kcl = min(u >> 1, NC - 1), ko = kcl * (KR_KC * 4), h = u & 1;
+        int dy = 0, dx = 0, shift = 0;
+        if (CONV) {
+          const int cbn = lda / KR_KC, tap = kcl / cbn, cb = kcl - tap * cbn;
+          dy = tap / 3 - 1;
+          dx = tap - 3 * (tap / 3) - 1;
+          shift = ((dy * W + dx) * lda + cb * KR_KC) * 4;
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, h ? oa[3 + j] : oa[j], ko, 0);
+          unsigned off = h ? oa[3 + j] : oa[j];
+          if (CONV) {
+            const unsigned yx = h ? pyx[3 + j] : pyx[j];
+            const bool ok = (unsigned)((int)(yx >> 16) + dy) < (unsigned)H && (unsigned)((int)(yx & 0xffffu) + dx) < (unsigned)W && yx != 0xffffffffu;
+            off = ok ? off + (unsigned)shift : 0x80000000u;
+          }
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, off, CONV ? 0 : ko, 0);
           RA[rs][j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
 #pragma unroll
@@ -1399,7 +1435,7 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
       pattr = true;
     }
     if (a_amax && dbg >= 220 && dbg < 236 && dbg != 234) {             // tools: ablations of the two roles (timing only); 234: stamps of the planes form, below
-      typedef void (*kfn3)(const float *, const float *, const float *, float *, int, int, int, int, int, int, const float *, const float *);
+      typedef void (*kfn3)(const float *, const float *, const float *, float *, int, int, int, int, int, int, const float *, const float *, int, int);
       kfn3 kf = nullptr;
       switch (dbg - 220) {
         case 1: kf = gemm_kpc_f16x2<true, 1>; break;
@@ -1414,7 +1450,7 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
         default: kf = gemm_kpc_f16x2<true, 0>; break;
       }
       (void)hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KP_LDS);
-      hipLaunchKernelGGL(kf, dim3((unsigned)G), dim3(768), KP_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
+      hipLaunchKernelGGL(kf, dim3((unsigned)G), dim3(768), KP_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax, 0, 0);
       return pd_check_launch("pd_gemm_tn_f16x2 (producer / consumer wavefronts, ablation)");
     }
     static const bool kpc_bp = []() { const char *e = getenv("PD_H2_KPC_PLANES"); return e && e[0] == '1'; }();   // (not faster once the split is unpacked: 78.5 vs 77 us)
@@ -1437,13 +1473,13 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
         battr = true;
       }
       const float *bpl = reinterpret_cast<const float *>(planes);
-      if (dbg == 234) hipLaunchKernelGGL((gemm_kpc_f16x2<true, 16, true>), dim3((unsigned)G), dim3(768), KP_LDS, st, A, bpl, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
-      else if (a_amax) hipLaunchKernelGGL((gemm_kpc_f16x2<true, 0, true>), dim3((unsigned)G), dim3(768), KP_LDS, st, A, bpl, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
-      else hipLaunchKernelGGL((gemm_kpc_f16x2<false, 0, true>), dim3((unsigned)G), dim3(768), KP_LDS, st, A, bpl, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
+      if (dbg == 234) hipLaunchKernelGGL((gemm_kpc_f16x2<true, 16, true>), dim3((unsigned)G), dim3(768), KP_LDS, st, A, bpl, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax, 0, 0);
+      else if (a_amax) hipLaunchKernelGGL((gemm_kpc_f16x2<true, 0, true>), dim3((unsigned)G), dim3(768), KP_LDS, st, A, bpl, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax, 0, 0);
+      else hipLaunchKernelGGL((gemm_kpc_f16x2<false, 0, true>), dim3((unsigned)G), dim3(768), KP_LDS, st, A, bpl, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax, 0, 0);
       return pd_check_launch("pd_gemm_tn_f16x2 (producer / consumer wavefronts, weight planes)");
     }
-    if (a_amax) hipLaunchKernelGGL(gemm_kpc_f16x2<true>, dim3((unsigned)G), dim3(768), KP_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
-    else hipLaunchKernelGGL(gemm_kpc_f16x2<false>, dim3((unsigned)G), dim3(768), KP_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax);
+    if (a_amax) hipLaunchKernelGGL(gemm_kpc_f16x2<true>, dim3((unsigned)G), dim3(768), KP_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax, 0, 0);
+    else hipLaunchKernelGGL(gemm_kpc_f16x2<false>, dim3((unsigned)G), dim3(768), KP_LDS, st, A, B, bias, C, M, K, lda, ldb, ldc, np, a_amax, b_amax, 0, 0);
     return pd_check_launch("pd_gemm_tn_f16x2 (producer / consumer wavefronts)");
   }
   // the sign bits are laid out in the 256 x 256 kernel's accumulator order: bits / mask launches must take that kernel
@@ -1528,6 +1564,24 @@ extern "C" int pd_conv3x3_nhwc_f16x2(const float *X, const float *Wk, const floa
   const int64_t M = (int64_t)B * H * W;
   if (M > 0x7fffffffLL - 4096) return pd_set_error(PD_ERR_INVALID_ARG, "pd_conv3x3_nhwc_f16x2: too many pixels");
   hipStream_t st = (hipStream_t)stream_;
+  // producer / consumer wavefronts (gemm_kpc_f16x2<.., CONV>): opt-in (PD_H2_KPC_CONV=1 / pd_debug_set("f16x2_tile", 92)) — correct, and at
+  // config 2's 2 x 256^2 x 256 slower than the tiled kernel (0.496 vs 0.452 ms: 683 row blocks on 256 CUs are 2.67 rounds of 72 chunks each);
+  // 3 % faster at 2 x 320^2 (0.808 vs 0.831 ms)
+  static const bool kpc_conv = []() { const char *e = getenv("PD_H2_KPC_CONV"); return e && e[0] == '1'; }();
+  if (((kpc_conv && g_pd_dbg_f16x2 == 0) || g_pd_dbg_f16x2 == 92) && x_amax && w_amax && !y_amax && (Co % 256) == 0 && (Ci % KR_KC) == 0 && M >= 8192 &&
+      H < 65536 && W < 65536 && M * Ci * 4 < (1ll << 31) && (int64_t)Co * 9 * Ci * 4 < (1ll << 31)) {
+    static int ncu5 = 0;
+    if (!ncu5) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&ncu5, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu5 < 8) ncu5 = 256; }
+    const int np = Co / 256, nwork = (int)((M + KR_RB - 1) / KR_RB) * np, G = nwork < ncu5 ? nwork : ncu5;
+    static bool cattr = false;
+    if (!cattr) {
+      (void)hipFuncSetAttribute((const void *)(gemm_kpc_f16x2<true, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KP_LDS);
+      cattr = true;
+    }
+    hipLaunchKernelGGL((gemm_kpc_f16x2<true, 0, false, true>), dim3((unsigned)G), dim3(768), KP_LDS, st, X, Wk, bias, Y, (int)M, 9 * Ci, Ci, 9 * Ci, Co, np, x_amax,
+                       w_amax, H, W);
+    return pd_check_launch("pd_conv3x3_nhwc_f16x2 (producer / consumer wavefronts)");
+  }
   const bool wide = g_pd_dbg_f16x2 == 3 || (g_pd_dbg_f16x2 != 4 && (Co % 256) == 0 && M >= 65536);
   if (g_pd_dbg_f16x2 == 70 || g_pd_dbg_f16x2 == 21) {               // the guarded step
     if (wide) return launch_f16x2<256, 256, 128, 16, true>(X, Wk, bias, Y, (int)M, Co, 9 * Ci, Ci, 9 * Ci, Co, 0, nullptr, nullptr, x_amax, w_amax, y_amax, st, H, W);

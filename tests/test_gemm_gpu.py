@@ -173,6 +173,32 @@ def test_conv3x3_x3_matches_fp64_convolution(B, H, W, Ci, Co, bias, h2, monkeypa
 
 
 
+def test_conv3x3_on_producer_consumer_wavefronts_equals_the_tiled_kernel():
+    """gemm_kpc_f16x2<.., CONV> (opt-in, pd_debug_set("f16x2_tile", 92)): the 3 x 3 convolution's implicit GEMM with the tap shift added to the
+    rows' buffer offsets and out-of-image taps read as zeros — against the tiled kernel on the same operands (same split, same products, another
+    summation order) and against fp64; an image size whose last row block is ragged."""
+    import torch.nn.functional as F
+    from partdistillation_amd import lib
+    from partdistillation_amd.functions import conv_x3
+    L = lib.load()
+    torch.manual_seed(3)
+    x = torch.randn(2, 256, 70, 61, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = torch.randn(256, 256, 3, 3, device="cuda") * 0.02
+    b = torch.randn(256, device="cuda")
+    wk = w.permute(0, 2, 3, 1).contiguous()
+    am = conv_x3._pixel_amax(x)
+    tiled = conv_x3._raw(x, wk, b, 256, am)
+    L.pd_debug_set(b"f16x2_tile", 92)
+    try:
+        got = conv_x3._raw(x, wk, b, 256, am)
+    finally:
+        L.pd_debug_set(b"f16x2_tile", 0)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    scale = ref.abs().amax(1, keepdim=True)
+    assert ((got.double() - ref).abs() / scale).max().item() < 5e-6
+    assert ((got.double() - tiled.double()).abs() / scale).max().item() < 5e-6        # (another fp32 summation order over K = 2 304: 2e-6 measured)
+
+
 @pytest.mark.parametrize("M,N,K,K2", [(4096, 1024, 256, 256), (3000, 256, 64, 128), (1024, 512, 400, 36)])
 def test_gemm_tn_x3_relu_bits_and_relumask_epilogues(M, N, K, K2):
     """pd_gemm_tn_f32x3_relu_bits (forward: relu(A B^T + b) + sign bits) and pd_gemm_tn_f32x3_relumask (backward: (G W) masked by
