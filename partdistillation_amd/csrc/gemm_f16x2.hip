@@ -1068,15 +1068,19 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
       const int64_t bbytes = BP ? (int64_t)2 * npanels * 256 * K * 2 : (int64_t)(c0 + 256) * ldb * 4;
       const __amdgpu_buffer_rsrc_t rbs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)bbytes, 0x00020000);
       unsigned oa[6], ob[8];
-      unsigned pyx[6];                                                   // CONV: (image row << 16) | column of the staged rows; 0xffffffff past M
+      unsigned pyx[6];                                                   // CONV: bit t = tap t of the staged row lies inside the image (0 past M)
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         const int row = row0 + prow + 32 * j;
         oa[j] = ((unsigned)row * (unsigned)lda + 4u * pc4) * 4u;
         pyx[j] = 0u;
-        if (CONV) {
-          const int pix = row % (H * W), y = pix / W;
-          pyx[j] = row < M ? ((unsigned)y << 16) | (unsigned)(pix - y * W) : 0xffffffffu;
+        if (CONV && row < M) {
+          const int pix = row % (H * W), y = pix / W, x = pix - y * W;
+#pragma unroll
+          for (int t9 = 0; t9 < 9; ++t9) {
+            const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+            pyx[j] |= (unsigned)(y + dy >= 0 && y + dy < H && x + dx >= 0 && x + dx < W) << t9;
+          }
         }
       }
 #pragma unroll
@@ -1091,21 +1095,18 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
       float4 RA[3][3], RB[3][4];
       auto gload = [&](int rs, int u) {                                  // half u & 1 of chunk u >> 1
         const int kcl = min(u >> 1, NC - 1), ko = kcl * (KR_KC * 4), h = u & 1;
-        int dy = 0, dx = 0, shift = 0;
+        int tap = 0, shift = 0;
         if (CONV) {
-          const int cbn = lda / KR_KC, tap = kcl / cbn, cb = kcl - tap * cbn;
-          dy = tap / 3 - 1;
-          dx = tap - 3 * (tap / 3) - 1;
+          // (Ci / 32 is a power of two — the dispatcher checks —: no integer division in the loop; tap / 3 by comparison)
+          const int lcb = __builtin_ctz((unsigned)(lda / KR_KC));
+          tap = kcl >> lcb;
+          const int cb = kcl - (tap << lcb), t3 = (tap >= 3) + (tap >= 6), dy = t3 - 1, dx = tap - 3 * t3 - 1;
           shift = ((dy * W + dx) * lda + cb * KR_KC) * 4;
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           unsigned off = h ? oa[3 + j] : oa[j];
-          if (CONV) {
-            const unsigned yx = h ? pyx[3 + j] : pyx[j];
-            const bool ok = (unsigned)((int)(yx >> 16) + dy) < (unsigned)H && (unsigned)((int)(yx & 0xffffu) + dx) < (unsigned)W && yx != 0xffffffffu;
-            off = ok ? off + (unsigned)shift : 0x80000000u;
-          }
+          if (CONV) off = (((h ? pyx[3 + j] : pyx[j]) >> tap) & 1u) ? off + (unsigned)shift : 0x80000000u;
           const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, off, CONV ? 0 : ko, 0);
           RA[rs][j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
@@ -1568,7 +1569,7 @@ extern "C" int pd_conv3x3_nhwc_f16x2(const float *X, const float *Wk, const floa
   // config 2's 2 x 256^2 x 256 slower than the tiled kernel (0.496 vs 0.452 ms: 683 row blocks on 256 CUs are 2.67 rounds of 72 chunks each);
   // 3 % faster at 2 x 320^2 (0.808 vs 0.831 ms)
   static const bool kpc_conv = []() { const char *e = getenv("PD_H2_KPC_CONV"); return e && e[0] == '1'; }();
-  if (((kpc_conv && g_pd_dbg_f16x2 == 0) || g_pd_dbg_f16x2 == 92) && x_amax && w_amax && !y_amax && (Co % 256) == 0 && (Ci % KR_KC) == 0 && M >= 8192 &&
+  if (((kpc_conv && g_pd_dbg_f16x2 == 0) || g_pd_dbg_f16x2 == 92 || g_pd_dbg_f16x2 == 234) && x_amax && w_amax && !y_amax && (Co % 256) == 0 && (Ci % KR_KC) == 0 && ((Ci / KR_KC) & (Ci / KR_KC - 1)) == 0 && M >= 8192 &&
       H < 65536 && W < 65536 && M * Ci * 4 < (1ll << 31) && (int64_t)Co * 9 * Ci * 4 < (1ll << 31)) {
     static int ncu5 = 0;
     if (!ncu5) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&ncu5, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu5 < 8) ncu5 = 256; }
@@ -1577,6 +1578,12 @@ extern "C" int pd_conv3x3_nhwc_f16x2(const float *X, const float *Wk, const floa
     if (!cattr) {
       (void)hipFuncSetAttribute((const void *)(gemm_kpc_f16x2<true, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KP_LDS);
       cattr = true;
+    }
+    if (g_pd_dbg_f16x2 == 234) {                                       // tools: phase stamps (tools/debug/kpc_trace.py conv)
+      (void)hipFuncSetAttribute((const void *)(gemm_kpc_f16x2<true, 16, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KP_LDS);
+      hipLaunchKernelGGL((gemm_kpc_f16x2<true, 16, false, true>), dim3((unsigned)G), dim3(768), KP_LDS, st, X, Wk, bias, Y, (int)M, 9 * Ci, Ci, 9 * Ci, Co, np, x_amax,
+                         w_amax, H, W);
+      return pd_check_launch("pd_conv3x3_nhwc_f16x2 (producer / consumer wavefronts, stamps)");
     }
     hipLaunchKernelGGL((gemm_kpc_f16x2<true, 0, false, true>), dim3((unsigned)G), dim3(768), KP_LDS, st, X, Wk, bias, Y, (int)M, 9 * Ci, Ci, 9 * Ci, Co, np, x_amax,
                        w_amax, H, W);

@@ -7,11 +7,20 @@ import torch
 from partdistillation_amd import lib; L = lib.load()
 from partdistillation_amd.functions import gemm
 M, N, K = 43008, 256, 1024
-a, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * K ** -0.5
-aa, wa = gemm.row_amax(a), gemm.row_amax(w)
-L.pd_debug_set(b"f16x2_tile", int(sys.argv[1]) if len(sys.argv) > 1 else 232)
-for _ in range(3):
-    gemm.gemm_tn_h2(a, w, None, a_amax=aa, b_amax=wa)
+if len(sys.argv) > 1 and sys.argv[1] == "conv":                  # the 3 x 3 convolution form (2 x 256^2 x 256): first 32 of its 72 chunks
+    from partdistillation_amd.functions import conv_x3
+    x = torch.randn(2, 256, 256, 256, device="cuda").contiguous(memory_format=torch.channels_last)
+    wk = (torch.randn(256, 256, 3, 3, device="cuda") * 0.02).permute(0, 2, 3, 1).contiguous()
+    am = conv_x3._pixel_amax(x)
+    L.pd_debug_set(b"f16x2_tile", 234)
+    for _ in range(3):
+        conv_x3._raw(x, wk, None, 256, am)
+else:
+    a, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * K ** -0.5
+    aa, wa = gemm.row_amax(a), gemm.row_amax(w)
+    L.pd_debug_set(b"f16x2_tile", int(sys.argv[1]) if len(sys.argv) > 1 else 232)
+    for _ in range(3):
+        gemm.gemm_tn_h2(a, w, None, a_amax=aa, b_amax=wa)
 torch.cuda.synchronize()
 L.pd_debug_set(b"f16x2_tile", 0)
 buf = (ctypes.c_ulonglong * (2 * 64 * 8))()
