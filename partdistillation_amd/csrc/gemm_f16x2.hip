@@ -970,7 +970,7 @@ void gemm_kres_f16x2(const float *__restrict__ A, const float *__restrict__ B, c
 // stages: loads two chunks ahead), 8 consumer wavefronts only read fragments and multiply (192 rows x 256 columns resident, as gemm_kres);
 // they meet through two LDS counters per image — `full` (4 producer arrivals per chunk) and `empty` (8 consumer arrivals) — that a
 // wavefront polls on its own (s_sleep between polls); no s_barrier inside the K loop.
-constexpr size_t KP_LDS = (size_t)2 * (KR_ABUF + KR_BBUF) + KR_RB * sizeof(float) + 4 * sizeof(int);
+constexpr size_t KP_LDS = (size_t)2 * (KR_ABUF + KR_BBUF) + 2 * KR_RB * sizeof(float) + 4 * sizeof(int);
 
 // W [N, K] fp32 -> two fp16 planes [2][N][K] with the rows scaled by row_scale(amax[row]) (the B operand of gemm_kpc_f16x2<.., BP>)
 __global__ __launch_bounds__(256) void split_planes_f16x2(const float *__restrict__ Wm, int ldw, const float *__restrict__ amax, unsigned short *__restrict__ planes,
@@ -1027,23 +1027,26 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
   };
   extern __shared__ __attribute__((aligned(16))) unsigned char kp_lds[];
   unsigned char *const aimg = kp_lds, *const bimg = kp_lds + 2 * KR_ABUF;
-  float *sinv = reinterpret_cast<float *>(kp_lds + 2 * (KR_ABUF + KR_BBUF));
-  int *ctr = reinterpret_cast<int *>(sinv + KR_RB);                     // full[0], full[1], empty[0], empty[1]
+  float *sinv = reinterpret_cast<float *>(kp_lds + 2 * (KR_ABUF + KR_BBUF));   // [2][KR_RB]: inverse row scales of the current and the next work item
+  int *ctr = reinterpret_cast<int *>(sinv + 2 * KR_RB);                 // full[0], full[1], empty[0], empty[1]: counts over the whole launch
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int nblk = (M + KR_RB - 1) / KR_RB, NC = K / KR_KC;
-  // the two roles are two loops over the same work list (their barriers pair up: two per block), so that neither keeps the other's registers live
+  // The two roles are two loops over the same work list.  NO barrier between work items: the counters run on over the whole launch (chunk g of
+  // this workgroup uses image g & 1), so the producers stage the next item's first chunks while the consumers still store the last one's results
+  // (with a barrier per item a K = 256 item cost ~33 us for ~10 us of chunks).
+  if (t < 4) ctr[t] = 0;
+  __syncthreads();
   if (w >= 8) {
     // ---------------- producers: 256 threads, 8 per row (32 k = 8 float4): A rows prow + 32 j (6), weight rows prow + 32 j (8)
     const int pt = t - 512, prow = pt >> 3, pc4 = pt & 7;
-    for (int work = blockIdx.x; work < nblk * npanels; work += gridDim.x) {
+    int g0 = 0, seq = 0;                                                   // chunks this workgroup has staged before the current item; items done
+    for (int work = blockIdx.x; work < nblk * npanels; work += gridDim.x, g0 += NC, ++seq) {
       const int blk = work / npanels, panel = work - blk * npanels, row0 = blk * KR_RB, c0 = panel * 256;
-      if (pt < 4) ctr[pt] = 0;
-      if (pt < KR_RB) {
+      if (pt < KR_RB) {                                                    // (slot seq & 1 was last read in the epilogue of item seq - 2: over before the consumers took item seq - 1's chunks)
         float sc = 1.f, inv = 1.f;
         if (AM) row_scale(CONV ? conv_amax(min(row0 + pt, M - 1)) : a_amax[min(row0 + pt, M - 1)], sc, inv);
-        sinv[pt] = inv;
+        sinv[(seq & 1) * KR_RB + pt] = inv;
       }
-      __syncthreads();
       float sa[6], sb[8];
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
@@ -1148,11 +1151,11 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
         for (int k6 = 0; k6 < 6; ++k6) {
           const int u = u0 + k6;
           if (u >= NH) break;
-          const int cc = u >> 1, par = cc & 1, h = k6 & 1, rs = k6 % 3;
-          const bool tr = (KABL & 16) && blockIdx.x == 0 && w == 8 && lane == 0;
+          const int cc = u >> 1, gc = g0 + cc, par = gc & 1, h = k6 & 1, rs = k6 % 3;
+          const bool tr = (KABL & 16) && blockIdx.x == 0 && w == 8 && lane == 0 && seq == 0;
           if (h == 0) {
             if (tr) kp_stamp(1, cc, 0);
-            kp_wait_ge(ctr + 2 + par, 8 * (cc >> 1));                    // the consumers are done with this image's previous chunk
+            kp_wait_ge(ctr + 2 + par, 8 * (gc >> 1));                    // the consumers are done with this image's previous chunk
             if (tr) kp_stamp(1, cc, 1);
           }
           if (KABL & 16) { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); if (tr) kp_stamp(1, cc, 2 + 2 * h); }   // this half's loads have landed (14 younger ones may be out)
@@ -1162,15 +1165,15 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
           if (h == 1 && lane == 0) __hip_atomic_fetch_add(ctr + par, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
-      __syncthreads();                                                   // counters, sinv and the images are rewritten by the next block
     }
     return;
   }
   // ---------------- consumers: 2 row groups (96 rows) x 4 column groups (64 columns)
   const int fr = lane & 31, fh = lane >> 5, rgp = w >> 2, cg = w & 3;
-  for (int work = blockIdx.x; work < nblk * npanels; work += gridDim.x) {
+  int g0 = 0, seq = 0;
+  for (int work = blockIdx.x; work < nblk * npanels; work += gridDim.x, g0 += NC, ++seq) {
     const int blk = work / npanels, panel = work - blk * npanels, row0 = blk * KR_RB, n0 = panel * 256 + cg * 64;
-    __syncthreads();
+    const float *sinv_it = sinv + (seq & 1) * KR_RB;
     float ibv[2] = {1.f, 1.f};
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
@@ -1186,12 +1189,12 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
         for (int e = 0; e < 16; ++e) acc[ti][cb][e] = 0.f;
     for (int c = 0; c < NC; c += 2) {
 #pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        const int cc = c + par;
+      for (int par0 = 0; par0 < 2; ++par0) {
+        const int cc = c + par0, gc = g0 + cc, par = gc & 1;
         if (cc >= NC) break;
-        const bool tr = (KABL & 16) && blockIdx.x == 0 && w == 0 && lane == 0;
+        const bool tr = (KABL & 16) && blockIdx.x == 0 && w == 0 && lane == 0 && seq == 0;
         if (tr) kp_stamp(0, cc, 0);
-        kp_wait_ge(ctr + par, 4 * ((cc >> 1) + 1));                      // all four producers have stored this chunk
+        kp_wait_ge(ctr + par, 4 * ((gc >> 1) + 1));                      // all four producers have stored this chunk
         if (tr) kp_stamp(0, cc, 1);
         const unsigned char *ab = aimg + par * KR_ABUF + fh * KR_APANEL + (96 * rgp + fr) * 16;
         const unsigned char *bb = bimg + par * KR_BBUF + fh * KR_BPANEL + (64 * cg + fr) * 16;
@@ -1255,11 +1258,10 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int rl = (e & 3) + 8 * (e >> 2) + 4 * fh;
-          if (row0 + rl0 + rl < M) cp[(int64_t)rl * ldc] = acc[ti][cb][e] * (sinv[rl0 + rl] * ibv[cb]) + bv;
+          if (row0 + rl0 + rl < M) cp[(int64_t)rl * ldc] = acc[ti][cb][e] * (sinv_it[rl0 + rl] * ibv[cb]) + bv;
         }
       }
     }
-    __syncthreads();
   }
 }
 }  // namespace
