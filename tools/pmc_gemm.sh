@@ -20,7 +20,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         continue
     rows = [r for r in csv.DictReader(open(p)) if r["Counter_Name"] == c]
     rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
-    fwd = [r for r in rows if re.search(r"gemm_tn_f16x2<", r["Kernel_Name"])]
+    fwd = [r for r in rows if re.search(r"gemm_tn_f16x2<|gemm_rows_f16x2_k256<|gemm_kpc_f16x2<|gemm_kres_f16x2<", r["Kernel_Name"])]   # (whichever kernel of the family a shape takes)
     assert len(fwd) == len(lab["fwd"]), (len(fwd), len(lab["fwd"]))
     for r, l in zip(fwd, lab["fwd"]):                       # dispatch order = the order the driver issued them in
         res[l][c].append(float(r["Counter_Value"]))
