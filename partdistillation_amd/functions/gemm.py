@@ -127,7 +127,7 @@ def gemm_tn_h2(a, b, bias=None, mode=0, bits=None, colsum=None, a_amax=None, b_a
     if which in (4, 5) and c_amax is not None:
         which = 0                                          # (a launch that wants output row maxima takes the tiled kernel)
     label = (f"gemm_rows_f16x2_k256<true, {mode}>" if which == 2 else f"gemm_ra_f16x2_k256<{mode}>" if which == 3
-             else "gemm_kres_f16x2<true, 0>" if which == 4 else "gemm_kpc_f16x2<true, 0, false>" if which == 5
+             else "gemm_kres_f16x2<true, 0>" if which == 4 else "gemm_kpc_f16x2<true, 0, false, false>" if which == 5
              else f"gemm_tn_f16x2<{'256, 256, 128, 16' if which == 1 else '128, 128, 64, 16'}, {mode}>")
     with _timed_fwd(2.0 * M * N * K, label, 4.0 * (M * K + N * K + M * N)):
         _lib.check(L.pd_gemm_tn_f16x2(*args))
