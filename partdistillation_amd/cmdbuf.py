@@ -141,6 +141,15 @@ def unalias_grads(params, owns):
             p.grad = g.clone()
 
 
+_ALL_CACHES = []                                   # every LRU of the process (drop_all)
+
+
+def drop_all():
+    """forget every cached plan / recording of the process (their arenas return to the allocator once nothing else holds them)"""
+    for c in _ALL_CACHES:
+        c.clear()
+
+
 class LRU(dict):
     """a bounded cache of plans / recordings (each owns persistent arenas of 10^8 .. 10^10 bytes per input shape: training with
     ResizeShortestEdge + RandomCrop, or inference on arbitrary image sizes, must not accumulate one arena set per shape).  get() marks
@@ -149,6 +158,7 @@ class LRU(dict):
     def __init__(self, cap, on_evict=None):
         super().__init__()
         self.cap, self.on_evict = cap, on_evict
+        _ALL_CACHES.append(self)
 
     def get(self, key, default=None):
         if key in self:
@@ -158,7 +168,9 @@ class LRU(dict):
         return default
 
     def put(self, key, value):
-        self.pop(key, None)
+        old = self.pop(key, None)
+        if old is not None and old is not value and self.on_evict is not None:
+            self.on_evict(key, old, self)                     # a re-recorded region: whatever pins the replaced entry's arenas goes with it
         self[key] = value
         while len(self) > self.cap:
             k = next(iter(self))

@@ -1426,7 +1426,7 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
   // (f16x2.h split4h_u): 256 <- 1024 at M = 43 008 76-78 us against the tiled kernel's 92-94, the step 21.82 -> 21.65 ms (three same-box A/B pairs).
   // PD_H2_KPC=0 / pd_debug_set("f16x2_tile", 80) keep the tiled kernel; 92 / 93 select it with fp32 weights / pre-split weight planes.
   static const bool kpc_env = []() { const char *e = getenv("PD_H2_KPC"); return !e || e[0] != '0'; }();
-  if (((kpc_env && dbg == 0) || dbg == 92 || dbg == 93 || dbg == 94 || (dbg >= 220 && dbg < 236)) && (int64_t)M * lda * 4 < (1ll << 31) && (int64_t)N * ldb * 4 < (1ll << 31) && !flags && mode == 0 && !bits && !c_amax && (K >= 512 || (dbg == 92 && K >= 128)) && (K % KR_KC) == 0 && (N % 256) == 0 && (N <= 512 || dbg == 92) && M >= 8192 &&
+  if (((kpc_env && dbg == 0) || dbg == 92 || dbg == 93 || dbg == 94 || (dbg >= 220 && dbg < 236)) && (int64_t)M * lda * 4 < (1ll << 31) && (int64_t)N * ldb * 4 < (1ll << 31) && !flags && mode == 0 && !bits && !c_amax && (K >= 512 || (dbg == 92 && K >= 128)) && (K % KR_KC) == 0 && K / KR_KC >= 3 /* the double-buffered inverse-scale slot is reused two chunks later */ && (N % 256) == 0 && (N <= 512 || dbg == 92) && M >= 8192 &&
       (a_amax == nullptr) == (b_amax == nullptr)) {
     static int ncu4 = 0;
     if (!ncu4) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&ncu4, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu4 < 8) ncu4 = 256; }

@@ -210,7 +210,7 @@ class EncoderCore(Function):
         ref = ref if ref.is_contiguous() else ref.contiguous()
         saved = []
         x = src2
-        h2 = H2 and USE_X3 and X3_PROJ and src2.is_cuda and C % 4 == 0
+        h2 = H2 and USE_X3 and X3_PROJ and src2.is_cuda and C % 4 == 0 and src2.dtype == torch.float32 and pos2.dtype == torch.float32
         ctx.h2 = h2
         if h2:                                  # (query = src + pos is formed inside, with the operands' row maxima: pd_add_rows_amax_f32)
             return EncoderCore._forward_h2(ctx, spec, src2, pos2, None, ref, params, (B, S, C, nl))
