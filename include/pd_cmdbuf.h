@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PD_CMD_MAX_ARGS 32
+#define PD_CMD_MAX_ARGS 48
 #define PD_CMD_LITERAL (-1)
 #define PD_CMD_STREAM (-2)
 

@@ -26,7 +26,7 @@ from torch.utils._python_dispatch import TorchDispatchMode
 
 from . import lib as _lib
 
-MAX_ARGS = 32
+MAX_ARGS = 48
 LITERAL, STREAM = -1, -2
 ENABLED = __import__("os").environ.get("PD_CMDBUF", "1") != "0"
 DEBUG = __import__("os").environ.get("PD_CMDBUF_DEBUG", "0") != "0"

@@ -21,6 +21,7 @@
 #include "pd_cmdbuf.h"
 #include "pd_attention.h"
 #include "pd_conv.h"
+#include "pd_declayer.h"
 #include "pd_criterion.h"
 #include "pd_fused.h"
 #include "pd_gemm.h"
@@ -88,6 +89,10 @@ const Entry kTable[] = {
   PD_E(pd_conv_bf16_fwd),
   PD_E(pd_conv_bf16_wgrad),
   PD_E(pd_conv_bf16_wgrad_grouped),
+  PD_E(pd_dec_bwd_a),
+  PD_E(pd_dec_bwd_b),
+  PD_E(pd_dec_fwd_a),
+  PD_E(pd_dec_fwd_b),
   PD_E(pd_decoder_head_bf16),
   PD_E(pd_filter_transpose_grouped),
   PD_E(pd_gemm_tn_f16x2),
