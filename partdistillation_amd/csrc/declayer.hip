@@ -12,6 +12,7 @@
 // taken in the same order as there.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pd_common.h"
 #include "pd_msda.h"
@@ -26,6 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int C = 256, FF = 2048, RB = 16, NTH = 512, NW = 8;
+__device__ __forceinline__ int row_block(int pin) { return pin ? (int)(blockIdx.x >> 3) : (int)blockIdx.x; }
 constexpr int PA = C + 8;        // bf16 elements per LDS row of a [16][256] tile (528 B)
 constexpr int PH = FF + 8;       // ... of the [16][2048] hidden tile
 constexpr int PZ = C + 4;        // floats per LDS row of an fp32 [16][256] tile
@@ -200,11 +202,12 @@ struct FwdA {
   const bf16_t *o; const float *res, *qpos; int pos_div;
   const bf16_t *w_o, *b_o; const float *ln_w, *ln_b; float eps;
   const bf16_t *w_qkv, *b_qkv;
-  float *z, *stats, *y; bf16_t *y_c, *ypos_c, *q, *k, *v; int R;
+  float *z, *stats, *y; bf16_t *y_c, *ypos_c, *q, *k, *v; int R, pin;
 };
 
 __global__ __launch_bounds__(NTH) void dec_fwd_a(const FwdA a)
 {
+  if (a.pin && (blockIdx.x & 7)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t *X0 = reinterpret_cast<bf16_t *>(smem);                  // o rows, later q
   bf16_t *X1 = X0 + RB * PA;                                       // y_c, later k (after the projections read it)
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(NTH) void dec_fwd_a(const FwdA a)
   float *Zs = reinterpret_cast<float *>(X4 + RB * PA);             // [16][PZ]
   bf16_t *Bs = reinterpret_cast<bf16_t *>(Zs + RB * PZ);           // biases: o [256] | qkv [768]
   float *Ls = reinterpret_cast<float *>(Bs + 4 * C);               // ln_w | ln_b
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = blockIdx.x * RB, R = a.R;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = row_block(a.pin) * RB, R = a.R;
   const bf16_t *xs_off = nullptr; (void)xs_off;
   WBlk wa, wb;
   wload(wa, a.w_o, C, 32 * wave, 0, lane);
@@ -283,11 +286,12 @@ struct FwdB {
   const bf16_t *w_1, *b_1, *w_2, *b_2; const float *ln3_w, *ln3_b, *dn_w, *dn_b;
   const bf16_t *m_w[3], *m_b[3], *wq_next, *bq_next; float eps;
   float *z2, *stats2; bf16_t *y2_c, *h; float *z3, *stats3, *y3; bf16_t *ypos_c; float *dec_out, *hstats;
-  bf16_t *ef, *qc_next; int R, flags;
+  bf16_t *ef, *qc_next; int R, flags, pin;
 };
 
 __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
 {
+  if (a.pin && (blockIdx.x & 7)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t *X0 = reinterpret_cast<bf16_t *>(smem);
   bf16_t *X1 = X0 + RB * PA;
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
   float *Ls = reinterpret_cast<float *>(Bs + (C + FF + C + 3 * C + C));      // ln2 w,b | ln3 w,b | dn w,b
   float *Ys = Ls + 6 * C;                                          // [16][PZ] residual stream rows (res, then y2): owner lanes only
   float *Ps = Ys + RB * PZ;                                        // [16][PZ] positional rows
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = blockIdx.x * RB, R = a.R;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = row_block(a.pin) * RB, R = a.R;
   const bool layer = a.flags & 1, mlp = a.flags & 2;
   constexpr int B1 = C, B2 = C + FF, BM = 2 * C + FF, BQ = 5 * C + FF;
   WBlk wa, wb;
@@ -452,11 +456,12 @@ struct BwdB {
   const bf16_t *dqc_next, *wqT_next; const float *d_out, *d_res, *y3, *hstats, *dn_w; float *dgb_dn;
   const float *z3, *stats3, *ln3_w; float *dgb3, *db3, *pos_acc; int pos_div;
   const bf16_t *w2T, *h, *w1T; const float *z2, *stats2, *ln2_w; float *dgb2, *db2; const bf16_t *woT;
-  bf16_t *dz3_c, *dh; float *dz2; bf16_t *dz2_c, *d_o; int R;
+  bf16_t *dz3_c, *dh; float *dz2; bf16_t *dz2_c, *d_o; int R, pin;
 };
 
 __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
 {
+  if (a.pin && (blockIdx.x & 7)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t *X0 = reinterpret_cast<bf16_t *>(smem);
   bf16_t *X1 = X0 + RB * PA;
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
   float *Zs = reinterpret_cast<float *>(Hs + RB * PH);             // [16][PZ]
   float *red = Zs + RB * PZ;                                       // [8 waves][5][256]
   float *Ls = red + NW * 5 * C;                                    // dn_w | ln3_w | ln2_w
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = blockIdx.x * RB, R = a.R;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = row_block(a.pin) * RB, R = a.R;
   const bool nxt = a.dqc_next != nullptr;
   const int hb = FF / NW * wave;
   WBlk wa, wb;
@@ -628,11 +633,12 @@ constexpr size_t kSmemBwdB = (size_t)2 * RB * PA * 2 + (size_t)RB * PH * 2 + (si
 // =================================================================================================== backward A
 struct BwdA {
   const bf16_t *dq, *dk, *dv, *wqkvT; const float *dz_in, *z, *stats, *ln_w; float *dgb, *db, *pos_acc; int pos_div;
-  const bf16_t *woT; float *dz1; bf16_t *dz1_c, *d_o; int R;
+  const bf16_t *woT; float *dz1; bf16_t *dz1_c, *d_o; int R, pin;
 };
 
 __global__ __launch_bounds__(NTH) void dec_bwd_a(const BwdA a)
 {
+  if (a.pin && (blockIdx.x & 7)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t *X0 = reinterpret_cast<bf16_t *>(smem);
   bf16_t *X1 = X0 + RB * PA;
@@ -640,7 +646,7 @@ __global__ __launch_bounds__(NTH) void dec_bwd_a(const BwdA a)
   float *Zs = reinterpret_cast<float *>(X2 + RB * PA);             // d_tc
   float *Z2 = Zs + RB * PZ;                                        // d_tp
   float *red = Z2 + RB * PZ;                                       // [8][3][256]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = blockIdx.x * RB, R = a.R;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = row_block(a.pin) * RB, R = a.R;
   WBlk wa, wb;
   wload(wa, a.wqkvT, 3 * C, 32 * wave, 0, lane);
   tile_in(X0, a.dq, r0, R, tid);
@@ -706,6 +712,12 @@ __global__ __launch_bounds__(NTH) void dec_bwd_a(const BwdA a)
 }
 constexpr size_t kSmemBwdA = (size_t)3 * RB * PA * 2 + (size_t)2 * RB * PZ * 4 + (size_t)NW * 3 * C * 4;
 
+int g_pin = -1;
+int pin_mode()
+{
+  if (g_pin < 0) { const char *e = getenv("PD_DEC_XCD_PIN"); g_pin = e ? atoi(e) : 0; }
+  return g_pin;
+}
 template <class K>
 int allow_smem(K kernel, size_t bytes, const char *who)
 {
@@ -726,8 +738,8 @@ extern "C" int pd_dec_fwd_a(const void *o, const float *res, const float *qpos, 
   static int ok = allow_smem(dec_fwd_a, kSmemFwdA, "pd_dec_fwd_a");
   if (ok != PD_OK) return ok;
   FwdA a{(const bf16_t *)o, res, qpos, pos_div, (const bf16_t *)w_o, (const bf16_t *)b_o, ln_w, ln_b, eps, (const bf16_t *)w_qkv, (const bf16_t *)b_qkv,
-         z, stats, y, (bf16_t *)y_c, (bf16_t *)ypos_c, (bf16_t *)q, (bf16_t *)k, (bf16_t *)v, R};
-  hipLaunchKernelGGL(dec_fwd_a, dim3((R + RB - 1) / RB), dim3(NTH), kSmemFwdA, (hipStream_t)stream, a);
+         z, stats, y, (bf16_t *)y_c, (bf16_t *)ypos_c, (bf16_t *)q, (bf16_t *)k, (bf16_t *)v, R, pin_mode()};
+  hipLaunchKernelGGL(dec_fwd_a, dim3(((R + RB - 1) / RB) * (pin_mode() ? 8 : 1)), dim3(NTH), kSmemFwdA, (hipStream_t)stream, a);
   return pd_check_launch("pd_dec_fwd_a");
 }
 
@@ -752,8 +764,8 @@ extern "C" int pd_dec_fwd_b(const void *o, const float *res, const float *qpos, 
          (const bf16_t *)w_2, (const bf16_t *)b_2, ln3_w, ln3_b, dn_w, dn_b,
          {(const bf16_t *)m0_w, (const bf16_t *)m1_w, (const bf16_t *)m2_w}, {(const bf16_t *)m0_b, (const bf16_t *)m1_b, (const bf16_t *)m2_b},
          (const bf16_t *)wq_next, (const bf16_t *)bq_next, eps, z2, stats2, (bf16_t *)y2_c, (bf16_t *)h, z3, stats3, y3, (bf16_t *)ypos_c, dec_out, hstats,
-         (bf16_t *)ef, (bf16_t *)qc_next, R, flags};
-  hipLaunchKernelGGL(dec_fwd_b, dim3((R + RB - 1) / RB), dim3(NTH), kSmemFwdB, (hipStream_t)stream, a);
+         (bf16_t *)ef, (bf16_t *)qc_next, R, flags, pin_mode()};
+  hipLaunchKernelGGL(dec_fwd_b, dim3(((R + RB - 1) / RB) * (pin_mode() ? 8 : 1)), dim3(NTH), kSmemFwdB, (hipStream_t)stream, a);
   return pd_check_launch("pd_dec_fwd_b");
 }
 
@@ -772,8 +784,8 @@ extern "C" int pd_dec_bwd_b(const void *dqc_next, const void *wqT_next, const fl
   if (ok != PD_OK) return ok;
   BwdB a{(const bf16_t *)dqc_next, (const bf16_t *)wqT_next, d_out, d_res, y3, hstats, dn_w, dgb_dn, z3, stats3, ln3_w, dgb3, db3, pos_acc, pos_div,
          (const bf16_t *)w2T, (const bf16_t *)h, (const bf16_t *)w1T, z2, stats2, ln2_w, dgb2, db2, (const bf16_t *)woT, (bf16_t *)dz3_c, (bf16_t *)dh, dz2,
-         (bf16_t *)dz2_c, (bf16_t *)d_o, R};
-  hipLaunchKernelGGL(dec_bwd_b, dim3((R + RB - 1) / RB), dim3(NTH), kSmemBwdB, (hipStream_t)stream, a);
+         (bf16_t *)dz2_c, (bf16_t *)d_o, R, pin_mode()};
+  hipLaunchKernelGGL(dec_bwd_b, dim3(((R + RB - 1) / RB) * (pin_mode() ? 8 : 1)), dim3(NTH), kSmemBwdB, (hipStream_t)stream, a);
   return pd_check_launch("pd_dec_bwd_b");
 }
 
@@ -787,7 +799,7 @@ extern "C" int pd_dec_bwd_a(const void *dq, const void *dk, const void *dv, cons
   static int ok = allow_smem(dec_bwd_a, kSmemBwdA, "pd_dec_bwd_a");
   if (ok != PD_OK) return ok;
   BwdA a{(const bf16_t *)dq, (const bf16_t *)dk, (const bf16_t *)dv, (const bf16_t *)wqkvT, dz_in, z, stats, ln_w, dgb, db, pos_acc, pos_div,
-         (const bf16_t *)woT, dz1, (bf16_t *)dz1_c, (bf16_t *)d_o, R};
-  hipLaunchKernelGGL(dec_bwd_a, dim3((R + RB - 1) / RB), dim3(NTH), kSmemBwdA, (hipStream_t)stream, a);
+         (const bf16_t *)woT, dz1, (bf16_t *)dz1_c, (bf16_t *)d_o, R, pin_mode()};
+  hipLaunchKernelGGL(dec_bwd_a, dim3(((R + RB - 1) / RB) * (pin_mode() ? 8 : 1)), dim3(NTH), kSmemBwdA, (hipStream_t)stream, a);
   return pd_check_launch("pd_dec_bwd_a");
 }
