@@ -17,8 +17,11 @@
  * the same fp32 sums) follows the unfused kernels of csrc/smallgemm.hip / csrc/rowwise.hip step by step.
  *
  * Conventions: C = 256 channels, feed-forward width 2048; rows r = query * B + image (seq-first like the reference); all activations
- * row-major and contiguous ([R, C] / [R, 2048]); weights bf16 row-major [out, in] (forward) or their transposes [in, out] (backward:
- * pd_filter_transpose_grouped); biases bf16; LayerNorm weights fp32; `stats` = [2, R] fp32 (mean row, then rstd row).
+ * row-major and contiguous ([R, C] / [R, 2048]); biases bf16; LayerNorm weights fp32; `stats` = [2, R] fp32 (mean row, then rstd row).
+ * WEIGHTS are passed PACKED (pd_dec_pack_grouped, once per optimisation step): a workgroup can pull ~57 GB/s from memory when every wave
+ * instruction reads 1 KB contiguous and ~30 GB/s in the 16-rows-x-64-bytes pattern an MFMA operand has in a row-major matrix
+ * (tools/probes/stream_probe.hip), and that stream is what bounds these kernels.  Forward kernels take pack(W) of the [out, in] weight,
+ * backward kernels pack(W^T) ("...T" arguments; transpose = 1 packs straight from the [out, in] weight).
  * `stream` = hipStream_t.  Return 0 or PD_ERR_*.
  */
 #ifndef PD_DECLAYER_H
@@ -29,6 +32,18 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* W_eff = src ([rows, cols] bf16 row-major) or its transpose -> dst in block order: 32 output rows x 256 contraction elements per 16 KB
+ * block, block (nb, kc) at element offset (nb * (K / 256) + kc) * 8192, 16-byte piece (i = 8 t + s, lane) of a block =
+ * W_eff[32 nb + 16 t + (lane & 15)][256 kc + 32 s + 8 (lane >> 4) .. + 7].  Output rows % 32 == 0, contraction % 256 == 0; dst holds
+ * rows * cols elements.  All problems in ONE launch; table_host_pinned / table_device: pd_dec_pack_table_bytes(count) bytes each. */
+typedef struct PdDecPack {
+  const void *src;
+  void *dst;
+  int32_t rows, cols, transpose;
+} PdDecPack;
+int64_t pd_dec_pack_table_bytes(int count);
+int pd_dec_pack_grouped(const PdDecPack *descs, int count, void *table_host_pinned, void *table_device, void *stream);
 
 /* x = bf16(o W_o^T + b_o);  z = x + res;  y = LayerNorm(z) * ln_w + ln_b;  y_c = bf16(y);  ypos_c = bf16(y + qpos[r / pos_div]);
  * q = bf16(ypos_c W_q^T + b_q), k = bf16(ypos_c W_k^T + b_k), v = bf16(y_c W_v^T + b_v)   (w_qkv = [W_q; W_k; W_v], [3C, C]) */

@@ -93,6 +93,7 @@ const Entry kTable[] = {
   PD_E(pd_dec_bwd_b),
   PD_E(pd_dec_fwd_a),
   PD_E(pd_dec_fwd_b),
+  PD_E(pd_dec_pack_grouped),
   PD_E(pd_decoder_head_bf16),
   PD_E(pd_filter_transpose_grouped),
   PD_E(pd_gemm_tn_f16x2),

@@ -2,17 +2,19 @@
 //
 // A workgroup of 8 wavefronts owns RB = 16 rows of the [R, 256] query tensor for a chain of row-local operators.  Every product is
 //     Y^T[n][m] = sum_k W[n][k] X[m][k]      on v_mfma_f32_16x16x32_bf16 with  A = a 16 x 32 block of W  (lane: row n = lane & 15,
-//                                             8 consecutive k from 8 (lane >> 4)), loaded STRAIGHT from global memory (16 bytes per lane),
+//                                             8 consecutive k from 8 (lane >> 4)), loaded STRAIGHT from global memory (16 bytes per lane)
+//                                             out of a PACKED copy of the weight in which that operand is 1 KB contiguous (dec_pack_grouped),
 //                                             B = the rows' activations from LDS (lane: row m = lane & 15, the same 8 k),
 // so a lane ends with 4 consecutive output channels n = 4 (lane >> 4) .. + 3 of row m = lane & 15 (row-major 8-byte pieces).  A wavefront
 // owns 32 of the 256 output columns; its "weight block" = 32 rows x 256 k = 16 x 16 bytes per lane is the unit of the software pipeline:
 // the block after the one being multiplied is always in flight, across phase boundaries too (weight addresses depend on nothing).  The
-// kernels are bound by that stream (a workgroup pulls every weight of its chain once: 0.5 .. 2.7 MB from L2), not by the matrix pipe.
+// kernels are bound by that stream (a workgroup pulls every weight of its chain once: 0.5 .. 2.7 MB), not by the matrix pipe: read in the
+// operand's row-major pattern (16 rows x 64 bytes per wave instruction) it ran at 30-36 GB/s per workgroup, from the packed copy at
+// ~108 GB/s (pd_dec_fwd_b 79 -> 25.5 us; tools/probes/stream_probe.hip).
 // LayerNorm (forward and backward) runs wave-per-row on the fp32 rows in LDS with the DPP reductions of csrc/rowwise.hip, so its sums are
 // taken in the same order as there.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "pd_common.h"
 #include "pd_msda.h"
@@ -27,9 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int C = 256, FF = 2048, RB = 16, NTH = 512, NW = 8;
-__device__ __forceinline__ int row_block(int pin) { return pin ? (int)(blockIdx.x >> 3) : (int)blockIdx.x; }
 constexpr int PA = C + 8;        // bf16 elements per LDS row of a [16][256] tile (528 B)
-constexpr int PH = FF + 8;       // ... of the [16][2048] hidden tile
 constexpr int PZ = C + 4;        // floats per LDS row of an fp32 [16][256] tile
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
@@ -66,14 +66,6 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 
 // ---- one weight block of a wavefront: rows n0 .. n0 + 31 (two 16-row tiles), 256 contraction elements from k0
 struct WBlk { uint4 v[2][8]; };
-__device__ __forceinline__ void wload(WBlk &w, const bf16_t *__restrict__ W, int ld, int n0, int k0, int lane)
-{
-  const bf16_t *p = W + (size_t)(n0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4);
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int s = 0; s < 8; ++s) w.v[t][s] = *reinterpret_cast<const uint4 *>(p + (size_t)t * 16 * ld + 32 * s);
-}
 // acc[t][..] += W block . X^T;  xs = &X_lds[lane & 15][k0 + 8 (lane >> 4)]
 __device__ __forceinline__ void wmma(f32x4 (&acc)[2], const WBlk &w, const bf16_t *xs)
 {
@@ -197,37 +189,45 @@ __device__ __forceinline__ void flush_colsums(const float *red, float *const (&o
   }
 }
 
+// ---- packed weights: a wavefront's block (32 rows x 256 k) is 16 KB contiguous, instruction i = 8 t + s reads 1 KB (pd_dec_pack_grouped)
+constexpr int BLK = 8192;                                           // bf16 elements per block
+__device__ __forceinline__ void wloadp(WBlk &w, const bf16_t *__restrict__ blk, int lane)
+{
+  const bf16_t *p = blk + lane * 8;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) w.v[t][s] = *reinterpret_cast<const uint4 *>(p + (t * 8 + s) * 512);
+}
+
 // =================================================================================================== forward A
 struct FwdA {
   const bf16_t *o; const float *res, *qpos; int pos_div;
   const bf16_t *w_o, *b_o; const float *ln_w, *ln_b; float eps;
   const bf16_t *w_qkv, *b_qkv;
-  float *z, *stats, *y; bf16_t *y_c, *ypos_c, *q, *k, *v; int R, pin;
+  float *z, *stats, *y; bf16_t *y_c, *ypos_c, *q, *k, *v; int R;
 };
 
 __global__ __launch_bounds__(NTH) void dec_fwd_a(const FwdA a)
 {
-  if (a.pin && (blockIdx.x & 7)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t *X0 = reinterpret_cast<bf16_t *>(smem);                  // o rows, later q
-  bf16_t *X1 = X0 + RB * PA;                                       // y_c, later k (after the projections read it)
+  bf16_t *X1 = X0 + RB * PA;                                       // y_c
   bf16_t *X2 = X1 + RB * PA;                                       // ypos_c
   bf16_t *X3 = X2 + RB * PA;                                       // k
   bf16_t *X4 = X3 + RB * PA;                                       // v
   float *Zs = reinterpret_cast<float *>(X4 + RB * PA);             // [16][PZ]
   bf16_t *Bs = reinterpret_cast<bf16_t *>(Zs + RB * PZ);           // biases: o [256] | qkv [768]
   float *Ls = reinterpret_cast<float *>(Bs + 4 * C);               // ln_w | ln_b
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = row_block(a.pin) * RB, R = a.R;
-  const bf16_t *xs_off = nullptr; (void)xs_off;
-  WBlk wa, wb;
-  wload(wa, a.w_o, C, 32 * wave, 0, lane);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = blockIdx.x * RB, R = a.R;
+  WBlk w[2];
+  wloadp(w[0], a.w_o + (size_t)wave * BLK, lane);
   tile_in(X0, a.o, r0, R, tid);
   lds_copy_bf16(Bs, a.b_o, C, tid);
   lds_copy_bf16(Bs + C, a.b_qkv, 3 * C, tid);
   lds_copy_f32(Ls, a.ln_w, C, tid);
   lds_copy_f32(Ls + C, a.ln_b, C, tid);
-  // the LayerNorm phase's rows of this wavefront: 2 wave, 2 wave + 1
-  float4 res[2], pos[2];
+  float4 res[2], pos[2];                                           // the LayerNorm phase's rows of this wavefront: 2 wave, 2 wave + 1
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = min(r0 + 2 * wave + i, R - 1);
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(NTH) void dec_fwd_a(const FwdA a)
   const int xo = (lane & 15) * PA + 8 * (lane >> 4);
   f32x4 acc[2];
   zero_acc(acc);
-  wload(wb, a.w_qkv, C, 32 * wave, 0, lane);                       // q rows
-  wmma(acc, wa, X0 + xo);
+  wloadp(w[1], a.w_qkv + (size_t)wave * BLK, lane);                // q rows
+  wmma(acc, w[0], X0 + xo);
   store_tile_f32r<true>(acc, Bs, 32 * wave, Zs, 32 * wave, lane);
   __syncthreads();
 #pragma unroll
@@ -260,17 +260,16 @@ __global__ __launch_bounds__(NTH) void dec_fwd_a(const FwdA a)
   __syncthreads();
   tile_out(a.y_c, X1, r0, R, tid);
   tile_out(a.ypos_c, X2, r0, R, tid);
-  // q, k from ypos_c; v from y_c
-  zero_acc(acc);
-  wload(wa, a.w_qkv, C, C + 32 * wave, 0, lane);                   // k rows
-  wmma(acc, wb, X2 + xo);
+  zero_acc(acc);                                                   // q, k from ypos_c; v from y_c
+  wloadp(w[0], a.w_qkv + (size_t)(8 + wave) * BLK, lane);          // k rows
+  wmma(acc, w[1], X2 + xo);
   store_tile_bf16<true, false>(acc, Bs + C, 32 * wave, X0, PA, 32 * wave, lane);
   zero_acc(acc);
-  wload(wb, a.w_qkv, C, 2 * C + 32 * wave, 0, lane);               // v rows
-  wmma(acc, wa, X2 + xo);
+  wloadp(w[1], a.w_qkv + (size_t)(16 + wave) * BLK, lane);         // v rows
+  wmma(acc, w[0], X2 + xo);
   store_tile_bf16<true, false>(acc, Bs + 2 * C, 32 * wave, X3, PA, 32 * wave, lane);
   zero_acc(acc);
-  wmma(acc, wb, X1 + xo);
+  wmma(acc, w[1], X1 + xo);
   store_tile_bf16<true, false>(acc, Bs + 3 * C, 32 * wave, X4, PA, 32 * wave, lane);
   __syncthreads();
   tile_out(a.q, X0, r0, R, tid);
@@ -286,28 +285,33 @@ struct FwdB {
   const bf16_t *w_1, *b_1, *w_2, *b_2; const float *ln3_w, *ln3_b, *dn_w, *dn_b;
   const bf16_t *m_w[3], *m_b[3], *wq_next, *bq_next; float eps;
   float *z2, *stats2; bf16_t *y2_c, *h; float *z3, *stats3, *y3; bf16_t *ypos_c; float *dec_out, *hstats;
-  bf16_t *ef, *qc_next; int R, flags, pin;
+  bf16_t *ef, *qc_next; int R;
 };
 
+// (Measured and dropped: P workgroups per row block that each take 1 / P of the hidden columns and meet in fp32 slabs, the last to arrive
+//  finishing the layer — 25.5 us with one workgroup per row block against 33 / 38 / 56 us at P = 2 / 4 / 8: the seam costs more than the
+//  shorter weight stream saves.)
+template <bool LAYER, bool MLP>
 __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
 {
-  if (a.pin && (blockIdx.x & 7)) return;
+  constexpr int P = 1, NB = 8 / P, HW = FF / P, PHS = HW + 8;     // blocks per wavefront and phase; hidden columns / LDS pitch
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t *X0 = reinterpret_cast<bf16_t *>(smem);
   bf16_t *X1 = X0 + RB * PA;
   bf16_t *X2 = X1 + RB * PA;
-  bf16_t *Hs = X2 + RB * PA;                                       // [16][PH]
-  float *Zs = reinterpret_cast<float *>(Hs + RB * PH);             // [16][PZ]
+  bf16_t *Hs = X2 + RB * PA;                                       // [16][PHS] (at least one [16][PA] tile)
+  float *Zs = reinterpret_cast<float *>(Hs + RB * (PHS > PA ? PHS : PA));   // [16][PZ]
   bf16_t *Bs = reinterpret_cast<bf16_t *>(Zs + RB * PZ);           // b_o 256 | b_1 2048 | b_2 256 | m_b 3 x 256 | bq 256
-  float *Ls = reinterpret_cast<float *>(Bs + (C + FF + C + 3 * C + C));      // ln2 w,b | ln3 w,b | dn w,b
+  float *Ls = reinterpret_cast<float *>(Bs + (6 * C + FF));        // ln2 w,b | ln3 w,b | dn w,b
   float *Ys = Ls + 6 * C;                                          // [16][PZ] residual stream rows (res, then y2): owner lanes only
   float *Ps = Ys + RB * PZ;                                        // [16][PZ] positional rows
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = row_block(a.pin) * RB, R = a.R;
-  const bool layer = a.flags & 1, mlp = a.flags & 2;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, R = a.R;
+  const int rb = blockIdx.x / P, p = blockIdx.x - rb * P, r0 = rb * RB;
   constexpr int B1 = C, B2 = C + FF, BM = 2 * C + FF, BQ = 5 * C + FF;
-  WBlk wa, wb;
-  if (layer) {
-    wload(wa, a.w_o, C, 32 * wave, 0, lane);
+  constexpr int I0 = LAYER ? 2 * NB + 1 : 0;                       // index of the first MLP block in this wavefront's block sequence
+  WBlk w[2];
+  if (LAYER) {
+    wloadp(w[0], a.w_o + (size_t)wave * BLK, lane);
     tile_in(X0, a.o, r0, R, tid);
     lds_copy_bf16(Bs, a.b_o, C, tid);
     lds_copy_bf16(Bs + B1, a.b_1, FF, tid);
@@ -316,20 +320,18 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
     lds_copy_f32(Ls + C, a.ln2_b, C, tid);
     lds_copy_f32(Ls + 2 * C, a.ln3_w, C, tid);
     lds_copy_f32(Ls + 3 * C, a.ln3_b, C, tid);
-  } else if (mlp) {
-    wload(wa, a.m_w[0], C, 32 * wave, 0, lane);
+  } else if (MLP) {
+    wloadp(w[0], a.m_w[0] + (size_t)wave * BLK, lane);
   }
-  if (mlp) {
+  if (MLP) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) lds_copy_bf16(Bs + BM + j * C, a.m_b[j], C, tid);
     lds_copy_bf16(Bs + BQ, a.bq_next, C, tid);
   }
   lds_copy_f32(Ls + 4 * C, a.dn_w, C, tid);
   lds_copy_f32(Ls + 5 * C, a.dn_b, C, tid);
-  // the residual stream / positional rows of this wavefront's LayerNorm phases (rows 2 wave, 2 wave + 1; a lane's own 4 channels):
-  // parked in LDS so that they do not sit in registers under the products
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 2; ++i) {                                    // parked in LDS: not in registers under the products
     const int row = 2 * wave + i, m = min(r0 + row, R - 1);
     st4(Ys + row * PZ + 4 * lane, ld4(a.res + (size_t)m * C + 4 * lane));
     st4(Ps + row * PZ + 4 * lane, ld4(a.qpos + (size_t)(m / a.pos_div) * C + 4 * lane));
@@ -337,11 +339,12 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
   __syncthreads();
   const int xo = (lane & 15) * PA + 8 * (lane >> 4);
   f32x4 acc[2];
-  if (layer) {
-    // ---- attention output projection + residual + LayerNorm
+  if (LAYER) {
+    // ---- attention output projection + residual + LayerNorm (every workgroup of the row block)
+    const int nb1 = p * (64 / P) + wave * NB;                      // this wavefront's first 32-row block of linear1
     zero_acc(acc);
-    wload(wb, a.w_1, C, FF / NW * wave, 0, lane);                  // first block of linear1
-    wmma(acc, wa, X0 + xo);
+    wloadp(w[1], a.w_1 + (size_t)nb1 * BLK, lane);
+    wmma(acc, w[0], X0 + xo);
     store_tile_f32r<true>(acc, Bs, 32 * wave, Zs, 32 * wave, lane);
     __syncthreads();
 #pragma unroll
@@ -352,44 +355,40 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
       const float4 y = ln_row(zv, ld4(Ls + 4 * lane), ld4(Ls + C + 4 * lane), a.eps, mu, rs);
       st_bf4(X1 + row * PA + 4 * lane, y);
       st4(Ys + row * PZ + 4 * lane, y);
-      if (m < R) {
+      if (p == 0 && m < R) {
         st4(a.z2 + (size_t)m * C + 4 * lane, zv);
         if (lane == 0) { a.stats2[m] = mu; a.stats2[R + m] = rs; }
       }
     }
     __syncthreads();
-    tile_out(a.y2_c, X1, r0, R, tid);
-    // ---- linear1 + ReLU: a wavefront's 256 hidden columns as 8 blocks of 32
-    const int hb = FF / NW * wave;
+    if (p == 0) tile_out(a.y2_c, X1, r0, R, tid);
+    // ---- linear1 + ReLU: NB blocks of 32 hidden columns per wavefront
 #pragma unroll
-    for (int c = 0; c < 8; c += 2) {
-      wload(wa, a.w_1, C, hb + 32 * (c + 1), 0, lane);
+    for (int c = 0; c < NB; ++c) {
+      const int i = 1 + c;
+      if (c + 1 < NB) wloadp(w[(i + 1) & 1], a.w_1 + (size_t)(nb1 + c + 1) * BLK, lane);
+      else wloadp(w[(i + 1) & 1], a.w_2 + (size_t)(wave * 8 + p * NB) * BLK, lane);       // first block of linear2
       zero_acc(acc);
-      wmma(acc, wb, X1 + xo);
-      store_tile_bf16<true, true>(acc, Bs + B1, hb + 32 * c, Hs, PH, hb + 32 * c, lane);
-      if (c + 2 < 8) wload(wb, a.w_1, C, hb + 32 * (c + 2), 0, lane);
-      else wload(wb, a.w_2, FF, 32 * wave, 0, lane);               // first block of linear2
-      zero_acc(acc);
-      wmma(acc, wa, X1 + xo);
-      store_tile_bf16<true, true>(acc, Bs + B1, hb + 32 * (c + 1), Hs, PH, hb + 32 * (c + 1), lane);
+      wmma(acc, w[i & 1], X1 + xo);
+      const int lc = (wave * NB + c) * 32;                         // local hidden column
+      store_tile_bf16<true, true>(acc, Bs + B1, p * HW + lc, Hs, PHS, lc, lane);
     }
     __syncthreads();
     // the hidden rows leave for the backward pass (16-byte pieces)
 #pragma unroll
-    for (int i = 0; i < FF * RB / 8 / NTH; ++i) {
-      const int idx = i * NTH + tid, row = idx >> 8, col = (idx & 255) * 8;
-      if (r0 + row < R) *reinterpret_cast<uint4 *>(a.h + (size_t)(r0 + row) * FF + col) = *reinterpret_cast<const uint4 *>(Hs + row * PH + col);
+    for (int i = 0; i < HW * RB / 8 / NTH; ++i) {
+      const int idx = i * NTH + tid, row = idx / (HW / 8), col = (idx % (HW / 8)) * 8;
+      if (r0 + row < R) *reinterpret_cast<uint4 *>(a.h + (size_t)(r0 + row) * FF + p * HW + col) = *reinterpret_cast<const uint4 *>(Hs + row * PHS + col);
     }
-    // ---- linear2: 8 blocks of the contraction
-    const int ho = (lane & 15) * PH + 8 * (lane >> 4);
+    // ---- linear2 over this workgroup's hidden columns
+    const int ho = (lane & 15) * PHS + 8 * (lane >> 4);
     zero_acc(acc);
 #pragma unroll
-    for (int c = 0; c < 8; c += 2) {
-      wload(wa, a.w_2, FF, 32 * wave, 256 * (c + 1), lane);
-      wmma(acc, wb, Hs + ho + 256 * c);
-      if (c + 2 < 8) wload(wb, a.w_2, FF, 32 * wave, 256 * (c + 2), lane);
-      else if (mlp) wload(wb, a.m_w[0], C, 32 * wave, 0, lane);
-      wmma(acc, wa, Hs + ho + 256 * (c + 1));
+    for (int c = 0; c < NB; ++c) {
+      const int i = NB + 1 + c;
+      if (c + 1 < NB) wloadp(w[(i + 1) & 1], a.w_2 + (size_t)(wave * 8 + p * NB + c + 1) * BLK, lane);
+      else if (MLP) wloadp(w[(i + 1) & 1], a.m_w[0] + (size_t)wave * BLK, lane);
+      wmma(acc, w[i & 1], Hs + ho + 256 * c);
     }
     store_tile_f32r<true>(acc, Bs + B2, 32 * wave, Zs, 32 * wave, lane);
     __syncthreads();
@@ -400,7 +399,7 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
     const int row = 2 * wave + i, m = r0 + row;
     float4 y3 = ld4(Ys + row * PZ + 4 * lane);
     float mu, rs;
-    if (layer) {
+    if (LAYER) {
       const float4 zv = add4(ld4(Zs + row * PZ + 4 * lane), y3);
       y3 = ln_row(zv, ld4(Ls + 2 * C + 4 * lane), ld4(Ls + 3 * C + 4 * lane), a.eps, mu, rs);
       if (m < R) {
@@ -419,25 +418,24 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
   }
   __syncthreads();
   tile_out(a.ypos_c, X2, r0, R, tid);
-  if (!mlp) return;
+  if (!MLP) return;
   // ---- mask-embedding MLP (bf16 between the layers, like three bf16 Linears) and the next layer's query projection
-  if (!layer) wb = wa;
   zero_acc(acc);
-  wload(wa, a.m_w[1], C, 32 * wave, 0, lane);
-  wmma(acc, wb, X0 + xo);
+  wloadp(w[(I0 + 1) & 1], a.m_w[1] + (size_t)wave * BLK, lane);
+  wmma(acc, w[I0 & 1], X0 + xo);
   store_tile_bf16<true, true>(acc, Bs + BM, 32 * wave, X1, PA, 32 * wave, lane);
   __syncthreads();
   zero_acc(acc);
-  wload(wb, a.m_w[2], C, 32 * wave, 0, lane);
-  wmma(acc, wa, X1 + xo);
+  wloadp(w[I0 & 1], a.m_w[2] + (size_t)wave * BLK, lane);
+  wmma(acc, w[(I0 + 1) & 1], X1 + xo);
   store_tile_bf16<true, true>(acc, Bs + BM + C, 32 * wave, X0, PA, 32 * wave, lane);
   __syncthreads();
   zero_acc(acc);
-  wload(wa, a.wq_next, C, 32 * wave, 0, lane);
-  wmma(acc, wb, X0 + xo);
+  wloadp(w[(I0 + 1) & 1], a.wq_next + (size_t)wave * BLK, lane);
+  wmma(acc, w[I0 & 1], X0 + xo);
   store_tile_bf16<true, false>(acc, Bs + BM + 2 * C, 32 * wave, X1, PA, 32 * wave, lane);
   zero_acc(acc);
-  wmma(acc, wa, X2 + xo);
+  wmma(acc, w[(I0 + 1) & 1], X2 + xo);
   store_tile_bf16<true, false>(acc, Bs + BQ, 32 * wave, Hs, PA, 32 * wave, lane);       // (the hidden tile is free: its first rows take qc)
   __syncthreads();
   tile_out(a.qc_next, Hs, r0, R, tid);
@@ -449,46 +447,48 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
     }
   }
 }
-constexpr size_t kSmemFwdB = (size_t)3 * RB * PA * 2 + (size_t)RB * PH * 2 + (size_t)3 * RB * PZ * 4 + (size_t)(6 * C + FF) * 2 + 6 * C * 4;
+constexpr size_t kSmemFwdB = (size_t)3 * RB * PA * 2 + (size_t)RB * (FF + 8) * 2 + (size_t)3 * RB * PZ * 4 + (size_t)(6 * C + FF) * 2 + 6 * C * 4;
 
 // =================================================================================================== backward B
 struct BwdB {
   const bf16_t *dqc_next, *wqT_next; const float *d_out, *d_res, *y3, *hstats, *dn_w; float *dgb_dn;
   const float *z3, *stats3, *ln3_w; float *dgb3, *db3, *pos_acc; int pos_div;
   const bf16_t *w2T, *h, *w1T; const float *z2, *stats2, *ln2_w; float *dgb2, *db2; const bf16_t *woT;
-  bf16_t *dz3_c, *dh; float *dz2; bf16_t *dz2_c, *d_o; int R, pin;
+  bf16_t *dz3_c, *dh; float *dz2; bf16_t *dz2_c, *d_o; int R;
 };
 
+template <bool NXT>
 __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
 {
-  if (a.pin && (blockIdx.x & 7)) return;
+  constexpr int P = 1, NB = 8 / P, HW = FF / P, PHS = HW + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t *X0 = reinterpret_cast<bf16_t *>(smem);
   bf16_t *X1 = X0 + RB * PA;
-  bf16_t *Hs = X1 + RB * PA;                                       // h rows (mask), overwritten in place by dh
-  float *Zs = reinterpret_cast<float *>(Hs + RB * PH);             // [16][PZ]
+  bf16_t *Hs = X1 + RB * PA;                                       // h columns of this workgroup (mask), overwritten in place by dh
+  float *Zs = reinterpret_cast<float *>(Hs + RB * PHS);            // [16][PZ]
   float *red = Zs + RB * PZ;                                       // [8 waves][5][256]
   float *Ls = red + NW * 5 * C;                                    // dn_w | ln3_w | ln2_w
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = row_block(a.pin) * RB, R = a.R;
-  const bool nxt = a.dqc_next != nullptr;
-  const int hb = FF / NW * wave;
-  WBlk wa, wb;
-  if (nxt) {
-    wload(wa, a.wqT_next, C, 32 * wave, 0, lane);
+  float *Gs = Ls + 3 * C;                                          // [16][PZ] dz3 rows (owner lanes only)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, R = a.R;
+  const int rb = blockIdx.x / P, p = blockIdx.x - rb * P, r0 = rb * RB;
+  const int nb2 = p * (64 / P) + wave * NB;                        // this wavefront's first block of W_2^T
+  constexpr int I0 = NXT ? 1 : 0;
+  WBlk w[2];
+  if (NXT) {
+    wloadp(w[0], a.wqT_next + (size_t)wave * BLK, lane);
     tile_in(X0, a.dqc_next, r0, R, tid);
   } else {
-    wload(wb, a.w2T, C, hb, 0, lane);
+    wloadp(w[0], a.w2T + (size_t)nb2 * BLK, lane);
   }
 #pragma unroll
-  for (int i = 0; i < FF * RB / 8 / NTH; ++i) {
-    const int idx = i * NTH + tid, row = idx >> 8, col = (idx & 255) * 8;
-    *reinterpret_cast<uint4 *>(Hs + row * PH + col) = *reinterpret_cast<const uint4 *>(a.h + (size_t)min(r0 + row, R - 1) * FF + col);
+  for (int i = 0; i < HW * RB / 8 / NTH; ++i) {
+    const int idx = i * NTH + tid, row = idx / (HW / 8), col = (idx % (HW / 8)) * 8;
+    *reinterpret_cast<uint4 *>(Hs + row * PHS + col) = *reinterpret_cast<const uint4 *>(a.h + (size_t)min(r0 + row, R - 1) * FF + p * HW + col);
   }
   lds_copy_f32(Ls, a.dn_w, C, tid);
   lds_copy_f32(Ls + C, a.ln3_w, C, tid);
   lds_copy_f32(Ls + 2 * C, a.ln2_w, C, tid);
-  // this wavefront's rows of the LayerNorm phases
-  float4 dy[2], y3v[2], z3v[2];
+  float4 dy[2], y3v[2], z3v[2];                                    // this wavefront's rows of the LayerNorm phases
   float st[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -502,14 +502,13 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
   __syncthreads();
   const int xo = (lane & 15) * PA + 8 * (lane >> 4);
   f32x4 acc[2];
-  if (nxt) {                                                       // d(y3 + pos) from the next layer's cross-attention queries
+  if (NXT) {                                                       // d(y3 + pos) from the next layer's cross-attention queries
     zero_acc(acc);
-    wload(wb, a.w2T, C, hb, 0, lane);
-    wmma(acc, wa, X0 + xo);
+    wloadp(w[1], a.w2T + (size_t)nb2 * BLK, lane);
+    wmma(acc, w[0], X0 + xo);
     store_tile_f32r<false>(acc, nullptr, 0, Zs, 32 * wave, lane);
     __syncthreads();
   }
-  float4 g3[2];                                                    // dz3 rows (fp32), kept for the next LayerNorm backward
   {
     float4 ag_dn = zero4(), ab_dn = zero4(), ag = zero4(), ab = zero4(), ad = zero4();
     const float4 gdn = ld4(Ls + 4 * lane), g3w = ld4(Ls + C + 4 * lane);
@@ -519,61 +518,58 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
       const bool valid = mr < R;
       float4 t = ln_row_bwd(dy[i], y3v[i], st[i][0], st[i][1], gdn, ag_dn, ab_dn);          // decoder_norm backward
       if (a.d_res && valid) t = add4(t, ld4(a.d_res + (size_t)mr * C + 4 * lane));
-      if (nxt && valid) {
-        const float4 p = ld4(Zs + row * PZ + 4 * lane);
-        t = add4(t, p);
-        float *pa = a.pos_acc + (size_t)(mr / a.pos_div) * C + 4 * lane;
-        atomicAdd(pa, p.x); atomicAdd(pa + 1, p.y); atomicAdd(pa + 2, p.z); atomicAdd(pa + 3, p.w);
+      if (NXT && valid) {
+        const float4 ps = ld4(Zs + row * PZ + 4 * lane);
+        t = add4(t, ps);
+        if (p == 0) {
+          float *pa = a.pos_acc + (size_t)(mr / a.pos_div) * C + 4 * lane;
+          atomicAdd(pa, ps.x); atomicAdd(pa + 1, ps.y); atomicAdd(pa + 2, ps.z); atomicAdd(pa + 3, ps.w);
+        }
       }
       if (!valid) t = zero4();
       const float4 o = ln_row_bwd(t, z3v[i], st[i][2], st[i][3], g3w, ag, ab);
       ad = add4(ad, o);
-      g3[i] = o;
+      st4(Gs + row * PZ + 4 * lane, o);
       st_bf4(X0 + row * PA + 4 * lane, o);
     }
     float *rw = red + wave * 5 * C + 4 * lane;
     st4(rw, ag_dn); st4(rw + C, ab_dn); st4(rw + 2 * C, ag); st4(rw + 3 * C, ab); st4(rw + 4 * C, ad);
   }
   __syncthreads();
-  tile_out(a.dz3_c, X0, r0, R, tid);
-  {
+  if (p == 0) {
+    tile_out(a.dz3_c, X0, r0, R, tid);
     float *const outs[5] = {a.dgb_dn, a.dgb_dn + C, a.dgb3, a.dgb3 + C, a.db3};
     flush_colsums<5>(red, outs, tid);
   }
-  // ---- dh = (dz3_c W_2) (h > 0): 8 blocks of 32 hidden columns per wavefront
+  // ---- dh = (dz3_c W_2) (h > 0): NB blocks of 32 hidden columns per wavefront
 #pragma unroll
-  for (int c = 0; c < 8; c += 2) {
+  for (int c = 0; c < NB; ++c) {
+    const int i = I0 + c;
+    if (c + 1 < NB) wloadp(w[(i + 1) & 1], a.w2T + (size_t)(nb2 + c + 1) * BLK, lane);
+    else wloadp(w[(i + 1) & 1], a.w1T + (size_t)(wave * 8 + p * NB) * BLK, lane);          // first block of the d(linear1 input) product
+    zero_acc(acc);
+    wmma(acc, w[i & 1], X0 + xo);
+    const int m = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      WBlk &cur = u ? wa : wb;
-      WBlk &oth = u ? wb : wa;
-      const int cc = c + u;
-      if (cc + 1 < 8) wload(oth, a.w2T, C, hb + 32 * (cc + 1), 0, lane);
-      else wload(oth, a.w1T, FF, 32 * wave, 0, lane);              // first block of the d(linear1 input) product
-      zero_acc(acc);
-      wmma(acc, cur, X0 + xo);
-      const int m = lane & 15, g = lane >> 4;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        bf16_t *p = Hs + m * PH + hb + 32 * cc + 16 * t + 4 * g;
-        const uint2 hv = *reinterpret_cast<const uint2 *>(p);
-        float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
-        if (!(bf_lo(hv.x) > 0.f)) v[0] = 0.f;
-        if (!(bf_hi(hv.x) > 0.f)) v[1] = 0.f;
-        if (!(bf_lo(hv.y) > 0.f)) v[2] = 0.f;
-        if (!(bf_hi(hv.y) > 0.f)) v[3] = 0.f;
-        *reinterpret_cast<uint2 *>(p) = pack4(v[0], v[1], v[2], v[3]);
-      }
+    for (int t = 0; t < 2; ++t) {
+      bf16_t *hp = Hs + m * PHS + (wave * NB + c) * 32 + 16 * t + 4 * g;
+      const uint2 hv = *reinterpret_cast<const uint2 *>(hp);
+      float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+      if (!(bf_lo(hv.x) > 0.f)) v[0] = 0.f;
+      if (!(bf_hi(hv.x) > 0.f)) v[1] = 0.f;
+      if (!(bf_lo(hv.y) > 0.f)) v[2] = 0.f;
+      if (!(bf_hi(hv.y) > 0.f)) v[3] = 0.f;
+      *reinterpret_cast<uint2 *>(hp) = pack4(v[0], v[1], v[2], v[3]);
     }
   }
-  __syncthreads();                                                 // (8 blocks: the last prefetch went into wb... see below)
+  __syncthreads();
 #pragma unroll
-  for (int i = 0; i < FF * RB / 8 / NTH; ++i) {
-    const int idx = i * NTH + tid, row = idx >> 8, col = (idx & 255) * 8;
-    if (r0 + row < R) *reinterpret_cast<uint4 *>(a.dh + (size_t)(r0 + row) * FF + col) = *reinterpret_cast<const uint4 *>(Hs + row * PH + col);
+  for (int i = 0; i < HW * RB / 8 / NTH; ++i) {
+    const int idx = i * NTH + tid, row = idx / (HW / 8), col = (idx % (HW / 8)) * 8;
+    if (r0 + row < R) *reinterpret_cast<uint4 *>(a.dh + (size_t)(r0 + row) * FF + p * HW + col) = *reinterpret_cast<const uint4 *>(Hs + row * PHS + col);
   }
-  // ---- dx = dh W_1: 8 blocks of the contraction; block 0 sits in wb (the 8th prefetch above: cc = 7 is u = 1, oth = wb)
-  const int ho = (lane & 15) * PH + 8 * (lane >> 4);
+  // ---- dx = dh W_1 over this workgroup's hidden columns
+  const int ho = (lane & 15) * PHS + 8 * (lane >> 4);
   float4 z2v[2];
   float st2[2][2];
 #pragma unroll
@@ -584,12 +580,11 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
   }
   zero_acc(acc);
 #pragma unroll
-  for (int c = 0; c < 8; c += 2) {
-    wload(wa, a.w1T, FF, 32 * wave, 256 * (c + 1), lane);
-    wmma(acc, wb, Hs + ho + 256 * c);
-    if (c + 2 < 8) wload(wb, a.w1T, FF, 32 * wave, 256 * (c + 2), lane);
-    else wload(wb, a.woT, C, 32 * wave, 0, lane);
-    wmma(acc, wa, Hs + ho + 256 * (c + 1));
+  for (int c = 0; c < NB; ++c) {
+    const int i = I0 + NB + c;
+    if (c + 1 < NB) wloadp(w[(i + 1) & 1], a.w1T + (size_t)(wave * 8 + p * NB + c + 1) * BLK, lane);
+    else wloadp(w[(i + 1) & 1], a.woT + (size_t)wave * BLK, lane);
+    wmma(acc, w[i & 1], Hs + ho + 256 * c);
   }
   store_tile_f32r<false>(acc, nullptr, 0, Zs, 32 * wave, lane);
   __syncthreads();
@@ -599,7 +594,7 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = 2 * wave + i, mr = r0 + row;
-      float4 t = add4(g3[i], ld4(Zs + row * PZ + 4 * lane));
+      float4 t = add4(ld4(Gs + row * PZ + 4 * lane), ld4(Zs + row * PZ + 4 * lane));
       if (mr >= R) t = zero4();
       const float4 o = ln_row_bwd(t, z2v[i], st2[i][0], st2[i][1], g2w, ag, ab);
       ad = add4(ad, o);
@@ -611,34 +606,30 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
   }
   __syncthreads();
   tile_out(a.dz2_c, X0, r0, R, tid);
-  {
-    // (stride of a wavefront's partials is still 5 arrays)
-    for (int i = tid; i < 3 * C; i += NTH) {
-      const int k = i / C, c = i - k * C;
-      float s = 0.f;
+  for (int i = tid; i < 3 * C; i += NTH) {                         // (stride of a wavefront's partials is still 5 arrays)
+    const int k = i / C, c = i - k * C;
+    float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) s += red[(w * 5 + k) * C + c];
-      atomicAdd((k == 0 ? a.dgb2 : k == 1 ? a.dgb2 + C : a.db2) + c, s);
-    }
+    for (int wv = 0; wv < NW; ++wv) s += red[(wv * 5 + k) * C + c];
+    atomicAdd((k == 0 ? a.dgb2 : k == 1 ? a.dgb2 + C : a.db2) + c, s);
   }
   // ---- d(attention output) = dz2_c W_o
   zero_acc(acc);
-  wmma(acc, wb, X0 + xo);
+  wmma(acc, w[(I0 + 2 * NB) & 1], X0 + xo);
   store_tile_bf16<false, false>(acc, nullptr, 0, X1, PA, 32 * wave, lane);
   __syncthreads();
   tile_out(a.d_o, X1, r0, R, tid);
 }
-constexpr size_t kSmemBwdB = (size_t)2 * RB * PA * 2 + (size_t)RB * PH * 2 + (size_t)RB * PZ * 4 + (size_t)NW * 5 * C * 4 + 3 * C * 4;
+constexpr size_t kSmemBwdB = (size_t)2 * RB * PA * 2 + (size_t)RB * (FF + 8) * 2 + (size_t)2 * RB * PZ * 4 + (size_t)NW * 5 * C * 4 + 3 * C * 4;
 
 // =================================================================================================== backward A
 struct BwdA {
   const bf16_t *dq, *dk, *dv, *wqkvT; const float *dz_in, *z, *stats, *ln_w; float *dgb, *db, *pos_acc; int pos_div;
-  const bf16_t *woT; float *dz1; bf16_t *dz1_c, *d_o; int R, pin;
+  const bf16_t *woT; float *dz1; bf16_t *dz1_c, *d_o; int R;
 };
 
 __global__ __launch_bounds__(NTH) void dec_bwd_a(const BwdA a)
 {
-  if (a.pin && (blockIdx.x & 7)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t *X0 = reinterpret_cast<bf16_t *>(smem);
   bf16_t *X1 = X0 + RB * PA;
@@ -646,9 +637,9 @@ __global__ __launch_bounds__(NTH) void dec_bwd_a(const BwdA a)
   float *Zs = reinterpret_cast<float *>(X2 + RB * PA);             // d_tc
   float *Z2 = Zs + RB * PZ;                                        // d_tp
   float *red = Z2 + RB * PZ;                                       // [8][3][256]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = row_block(a.pin) * RB, R = a.R;
-  WBlk wa, wb;
-  wload(wa, a.wqkvT, 3 * C, 32 * wave, 0, lane);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = blockIdx.x * RB, R = a.R;
+  WBlk w[2];
+  wloadp(w[0], a.wqkvT + (size_t)(wave * 3) * BLK, lane);          // [C, 3C]: three contraction blocks per 32 rows
   tile_in(X0, a.dq, r0, R, tid);
   tile_in(X1, a.dk, r0, R, tid);
   tile_in(X2, a.dv, r0, R, tid);
@@ -667,14 +658,14 @@ __global__ __launch_bounds__(NTH) void dec_bwd_a(const BwdA a)
   const int xo = (lane & 15) * PA + 8 * (lane >> 4);
   f32x4 acc[2];
   zero_acc(acc);
-  wload(wb, a.wqkvT, 3 * C, 32 * wave, C, lane);
-  wmma(acc, wa, X0 + xo);
-  wload(wa, a.wqkvT, 3 * C, 32 * wave, 2 * C, lane);
-  wmma(acc, wb, X1 + xo);
+  wloadp(w[1], a.wqkvT + (size_t)(wave * 3 + 1) * BLK, lane);
+  wmma(acc, w[0], X0 + xo);
+  wloadp(w[0], a.wqkvT + (size_t)(wave * 3 + 2) * BLK, lane);
+  wmma(acc, w[1], X1 + xo);
   store_tile_f32r<false>(acc, nullptr, 0, Z2, 32 * wave, lane);
   zero_acc(acc);
-  wload(wb, a.woT, C, 32 * wave, 0, lane);
-  wmma(acc, wa, X2 + xo);
+  wloadp(w[1], a.woT + (size_t)wave * BLK, lane);
+  wmma(acc, w[0], X2 + xo);
   store_tile_f32r<false>(acc, nullptr, 0, Zs, 32 * wave, lane);
   __syncthreads();
   {
@@ -682,11 +673,11 @@ __global__ __launch_bounds__(NTH) void dec_bwd_a(const BwdA a)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = 2 * wave + i, mr = r0 + row;
-      const float4 p = ld4(Z2 + row * PZ + 4 * lane);
-      float4 t = add4(add4(dzi[i], ld4(Zs + row * PZ + 4 * lane)), p);
+      const float4 ps = ld4(Z2 + row * PZ + 4 * lane);
+      float4 t = add4(add4(dzi[i], ld4(Zs + row * PZ + 4 * lane)), ps);
       if (mr < R) {
         float *pa = a.pos_acc + (size_t)(mr / a.pos_div) * C + 4 * lane;
-        atomicAdd(pa, p.x); atomicAdd(pa + 1, p.y); atomicAdd(pa + 2, p.z); atomicAdd(pa + 3, p.w);
+        atomicAdd(pa, ps.x); atomicAdd(pa + 1, ps.y); atomicAdd(pa + 2, ps.z); atomicAdd(pa + 3, ps.w);
       } else {
         t = zero4();
       }
@@ -705,19 +696,61 @@ __global__ __launch_bounds__(NTH) void dec_bwd_a(const BwdA a)
     flush_colsums<3>(red, outs, tid);
   }
   zero_acc(acc);
-  wmma(acc, wb, X0 + xo);
+  wmma(acc, w[1], X0 + xo);
   store_tile_bf16<false, false>(acc, nullptr, 0, X1, PA, 32 * wave, lane);
   __syncthreads();
   tile_out(a.d_o, X1, r0, R, tid);
 }
 constexpr size_t kSmemBwdA = (size_t)3 * RB * PA * 2 + (size_t)2 * RB * PZ * 4 + (size_t)NW * 3 * C * 4;
 
-int g_pin = -1;
-int pin_mode()
+// =================================================================================================== weight packing
+// W_eff[n][k] (= src[n][k], or src[k][n] when transposed) -> blocks of 32 n x 256 k, block (nb, kc) at ((nb (K / 256) + kc) BLK), inside a
+// block 16-byte piece (i = 8 t + s, lane) = W_eff[32 nb + 16 t + (lane & 15)][256 kc + 32 s + 8 (lane >> 4) .. + 7]: what wloadp reads
+struct PackProblem { const bf16_t *src; bf16_t *dst; int rows, cols, transpose, first_block; };
+
+__global__ __launch_bounds__(256) void dec_pack_grouped(const PackProblem *__restrict__ tab, int count)
 {
-  if (g_pin < 0) { const char *e = getenv("PD_DEC_XCD_PIN"); g_pin = e ? atoi(e) : 0; }
-  return g_pin;
+  __shared__ __attribute__((aligned(16))) bf16_t tile[256][40];    // transposed problems: [k][n] as read (32 n + pad)
+  int lo = 0, hi = count - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_block <= bid) lo = mid; else hi = mid - 1;
+  }
+  const PackProblem pr = tab[lo];
+  const int local = bid - pr.first_block;
+  const int K = pr.transpose ? pr.rows : pr.cols, kcn = K / 256, nb = local / kcn, kc = local - nb * kcn;
+  bf16_t *dst = pr.dst + (size_t)local * BLK;
+  const int tid = threadIdx.x;
+  if (!pr.transpose) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int piece = j * 256 + tid, i = piece >> 6, lane = piece & 63, t = i >> 3, s = i & 7;
+      const uint4 v = *reinterpret_cast<const uint4 *>(pr.src + (size_t)(32 * nb + 16 * t + (lane & 15)) * pr.cols + 256 * kc + 32 * s + 8 * (lane >> 4));
+      *reinterpret_cast<uint4 *>(dst + (size_t)piece * 8) = v;
+    }
+    return;
+  }
+  // src rows k = 256 kc .. + 255, columns n = 32 nb .. + 31: 64 bytes per row
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int piece = j * 256 + tid, k = piece >> 2, c8 = (piece & 3) * 8;
+    *reinterpret_cast<uint4 *>(&tile[k][c8]) = *reinterpret_cast<const uint4 *>(pr.src + (size_t)(256 * kc + k) * pr.cols + 32 * nb + c8);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int piece = j * 256 + tid, i = piece >> 6, lane = piece & 63, t = i >> 3, s = i & 7;
+    const int n = 16 * t + (lane & 15), k0 = 32 * s + 8 * (lane >> 4);
+    unsigned short e[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) e[q] = tile[k0 + q][n];
+    uint4 o;
+    o.x = e[0] | ((unsigned)e[1] << 16); o.y = e[2] | ((unsigned)e[3] << 16); o.z = e[4] | ((unsigned)e[5] << 16); o.w = e[6] | ((unsigned)e[7] << 16);
+    *reinterpret_cast<uint4 *>(dst + (size_t)piece * 8) = o;
+  }
 }
+
 template <class K>
 int allow_smem(K kernel, size_t bytes, const char *who)
 {
@@ -726,7 +759,46 @@ int allow_smem(K kernel, size_t bytes, const char *who)
   return PD_OK;
 }
 
+template <bool LAYER, bool MLP>
+int launch_fwd_b(const FwdB &a, hipStream_t s)
+{
+  static int ok = allow_smem(dec_fwd_b<LAYER, MLP>, kSmemFwdB, "pd_dec_fwd_b");
+  if (ok != PD_OK) return ok;
+  hipLaunchKernelGGL((dec_fwd_b<LAYER, MLP>), dim3((a.R + RB - 1) / RB), dim3(NTH), kSmemFwdB, s, a);
+  return pd_check_launch("pd_dec_fwd_b");
+}
+template <bool NXT>
+int launch_bwd_b(const BwdB &a, hipStream_t s)
+{
+  static int ok = allow_smem(dec_bwd_b<NXT>, kSmemBwdB, "pd_dec_bwd_b");
+  if (ok != PD_OK) return ok;
+  hipLaunchKernelGGL((dec_bwd_b<NXT>), dim3((a.R + RB - 1) / RB), dim3(NTH), kSmemBwdB, s, a);
+  return pd_check_launch("pd_dec_bwd_b");
+}
+
 }  // namespace
+
+extern "C" int64_t pd_dec_pack_table_bytes(int count) { return (int64_t)count * sizeof(PackProblem); }
+
+extern "C" int pd_dec_pack_grouped(const PdDecPack *descs, int count, void *table_host_pinned, void *table_device, void *stream)
+{
+  if (count <= 0) return PD_OK;
+  if (!descs || !table_host_pinned || !table_device) return pd_set_error(PD_ERR_INVALID_ARG, "pd_dec_pack_grouped: null pointer");
+  PackProblem *h = reinterpret_cast<PackProblem *>(table_host_pinned);
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const PdDecPack &d = descs[i];
+    const int N = d.transpose ? d.cols : d.rows, K = d.transpose ? d.rows : d.cols;
+    if (!d.src || !d.dst || N <= 0 || K <= 0 || N % 32 || K % 256)
+      return pd_set_error(PD_ERR_INVALID_ARG, "pd_dec_pack_grouped: problem %d: output rows %% 32 == 0 and contraction %% 256 == 0 required (%d x %d)", i, N, K);
+    h[i] = PackProblem{(const bf16_t *)d.src, (bf16_t *)d.dst, d.rows, d.cols, d.transpose, blocks};
+    blocks += (N / 32) * (K / 256);
+  }
+  if (hipMemcpyAsync(table_device, h, (size_t)count * sizeof(PackProblem), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
+    return pd_set_error(PD_ERR_LAUNCH, "pd_dec_pack_grouped: table upload failed");
+  hipLaunchKernelGGL(dec_pack_grouped, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const PackProblem *)table_device, count);
+  return pd_check_launch("pd_dec_pack_grouped");
+}
 
 extern "C" int pd_dec_fwd_a(const void *o, const float *res, const float *qpos, int pos_div, const void *w_o, const void *b_o, const float *ln_w,
                             const float *ln_b, float eps, const void *w_qkv, const void *b_qkv, float *z, float *stats, float *y, void *y_c,
@@ -738,8 +810,8 @@ extern "C" int pd_dec_fwd_a(const void *o, const float *res, const float *qpos, 
   static int ok = allow_smem(dec_fwd_a, kSmemFwdA, "pd_dec_fwd_a");
   if (ok != PD_OK) return ok;
   FwdA a{(const bf16_t *)o, res, qpos, pos_div, (const bf16_t *)w_o, (const bf16_t *)b_o, ln_w, ln_b, eps, (const bf16_t *)w_qkv, (const bf16_t *)b_qkv,
-         z, stats, y, (bf16_t *)y_c, (bf16_t *)ypos_c, (bf16_t *)q, (bf16_t *)k, (bf16_t *)v, R, pin_mode()};
-  hipLaunchKernelGGL(dec_fwd_a, dim3(((R + RB - 1) / RB) * (pin_mode() ? 8 : 1)), dim3(NTH), kSmemFwdA, (hipStream_t)stream, a);
+         z, stats, y, (bf16_t *)y_c, (bf16_t *)ypos_c, (bf16_t *)q, (bf16_t *)k, (bf16_t *)v, R};
+  hipLaunchKernelGGL(dec_fwd_a, dim3((R + RB - 1) / RB), dim3(NTH), kSmemFwdA, (hipStream_t)stream, a);
   return pd_check_launch("pd_dec_fwd_a");
 }
 
@@ -758,15 +830,14 @@ extern "C" int pd_dec_fwd_b(const void *o, const float *res, const float *qpos, 
   if (mlp && (!m0_w || !m0_b || !m1_w || !m1_b || !m2_w || !m2_b || !wq_next || !bq_next || !ef || !qc_next))
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_dec_fwd_b: null pointer (head part)");
   if (R <= 0 || pos_div <= 0 || R % pos_div) return pd_set_error(PD_ERR_INVALID_ARG, "pd_dec_fwd_b: R = %d, pos_div = %d", R, pos_div);
-  static int ok = allow_smem(dec_fwd_b, kSmemFwdB, "pd_dec_fwd_b");
-  if (ok != PD_OK) return ok;
   FwdB a{(const bf16_t *)o, res, qpos, pos_div, (const bf16_t *)w_o, (const bf16_t *)b_o, ln2_w, ln2_b, (const bf16_t *)w_1, (const bf16_t *)b_1,
          (const bf16_t *)w_2, (const bf16_t *)b_2, ln3_w, ln3_b, dn_w, dn_b,
          {(const bf16_t *)m0_w, (const bf16_t *)m1_w, (const bf16_t *)m2_w}, {(const bf16_t *)m0_b, (const bf16_t *)m1_b, (const bf16_t *)m2_b},
          (const bf16_t *)wq_next, (const bf16_t *)bq_next, eps, z2, stats2, (bf16_t *)y2_c, (bf16_t *)h, z3, stats3, y3, (bf16_t *)ypos_c, dec_out, hstats,
-         (bf16_t *)ef, (bf16_t *)qc_next, R, flags, pin_mode()};
-  hipLaunchKernelGGL(dec_fwd_b, dim3(((R + RB - 1) / RB) * (pin_mode() ? 8 : 1)), dim3(NTH), kSmemFwdB, (hipStream_t)stream, a);
-  return pd_check_launch("pd_dec_fwd_b");
+         (bf16_t *)ef, (bf16_t *)qc_next, R};
+  hipStream_t s = (hipStream_t)stream;
+  if (!layer) return mlp ? launch_fwd_b<false, true>(a, s) : launch_fwd_b<false, false>(a, s);
+  return mlp ? launch_fwd_b<true, true>(a, s) : launch_fwd_b<true, false>(a, s);
 }
 
 extern "C" int pd_dec_bwd_b(const void *dqc_next, const void *wqT_next, const float *d_out, const float *d_res, const float *y3, const float *hstats,
@@ -780,13 +851,11 @@ extern "C" int pd_dec_bwd_b(const void *dqc_next, const void *wqT_next, const fl
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_dec_bwd_b: null pointer");
   if ((dqc_next != nullptr) != (wqT_next != nullptr) || (dqc_next && !pos_acc)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_dec_bwd_b: next-layer operands");
   if (R <= 0 || pos_div <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_dec_bwd_b: R = %d, pos_div = %d", R, pos_div);
-  static int ok = allow_smem(dec_bwd_b, kSmemBwdB, "pd_dec_bwd_b");
-  if (ok != PD_OK) return ok;
   BwdB a{(const bf16_t *)dqc_next, (const bf16_t *)wqT_next, d_out, d_res, y3, hstats, dn_w, dgb_dn, z3, stats3, ln3_w, dgb3, db3, pos_acc, pos_div,
          (const bf16_t *)w2T, (const bf16_t *)h, (const bf16_t *)w1T, z2, stats2, ln2_w, dgb2, db2, (const bf16_t *)woT, (bf16_t *)dz3_c, (bf16_t *)dh, dz2,
-         (bf16_t *)dz2_c, (bf16_t *)d_o, R, pin_mode()};
-  hipLaunchKernelGGL(dec_bwd_b, dim3(((R + RB - 1) / RB) * (pin_mode() ? 8 : 1)), dim3(NTH), kSmemBwdB, (hipStream_t)stream, a);
-  return pd_check_launch("pd_dec_bwd_b");
+         (bf16_t *)dz2_c, (bf16_t *)d_o, R};
+  hipStream_t s = (hipStream_t)stream;
+  return a.dqc_next ? launch_bwd_b<true>(a, s) : launch_bwd_b<false>(a, s);
 }
 
 extern "C" int pd_dec_bwd_a(const void *dq, const void *dk, const void *dv, const void *wqkvT, const float *dz_in, const float *z, const float *stats,
@@ -799,7 +868,7 @@ extern "C" int pd_dec_bwd_a(const void *dq, const void *dk, const void *dv, cons
   static int ok = allow_smem(dec_bwd_a, kSmemBwdA, "pd_dec_bwd_a");
   if (ok != PD_OK) return ok;
   BwdA a{(const bf16_t *)dq, (const bf16_t *)dk, (const bf16_t *)dv, (const bf16_t *)wqkvT, dz_in, z, stats, ln_w, dgb, db, pos_acc, pos_div,
-         (const bf16_t *)woT, dz1, (bf16_t *)dz1_c, (bf16_t *)d_o, R, pin_mode()};
-  hipLaunchKernelGGL(dec_bwd_a, dim3(((R + RB - 1) / RB) * (pin_mode() ? 8 : 1)), dim3(NTH), kSmemBwdA, (hipStream_t)stream, a);
+         (const bf16_t *)woT, dz1, (bf16_t *)dz1_c, (bf16_t *)d_o, R};
+  hipLaunchKernelGGL(dec_bwd_a, dim3((R + RB - 1) / RB), dim3(NTH), kSmemBwdA, (hipStream_t)stream, a);
   return pd_check_launch("pd_dec_bwd_a");
 }

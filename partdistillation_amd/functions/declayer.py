@@ -2,6 +2,8 @@
 tensors, no autograd — the building blocks of functions/decoder_core.py's hand-written forward / backward.  GPU only, no fallback.
 
 Reference: transformer_decoder/mask2former_transformer_decoder.py:395-439 (the layer loop), :449-459 (prediction head)."""
+import ctypes
+
 import torch
 
 from .. import lib as _lib
@@ -22,6 +24,52 @@ def supported(C_, ff, cdt):
     return C_ == C and ff == FF and cdt == bf16
 
 
+class _PackDesc(ctypes.Structure):                                  # PdDecPack (include/pd_declayer.h)
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("transpose", ctypes.c_int32)]
+
+
+_PK = {}
+
+
+def pack(weights, transpose=False):
+    """[N_i, K_i] bf16 row-major weights -> their packed copies (pd_dec_pack_grouped: block order of the fused kernels' weight stream), of
+    the weights themselves (forward kernels) or of their transposes (backward kernels), all in ONE launch into one fresh buffer.
+    -> list of flat bf16 tensors.  The descriptor table is cached per list of (address, shape)."""
+    from .fused import PinnedRing
+    key = (tuple((w.data_ptr(), tuple(w.shape)) for w in weights), bool(transpose))
+    L = _lib.load()
+    dev = weights[0].device
+    hit = _PK.get(key)
+    if hit is None:
+        offs, total = [], 0
+        for w in weights:
+            assert w.dtype == bf16 and w.is_contiguous() and w.dim() == 2
+            n, k = (w.shape[1], w.shape[0]) if transpose else w.shape
+            assert n % 32 == 0 and k % 256 == 0, (n, k)
+            offs.append(total)
+            total += w.numel()
+        tb = int(L.pd_dec_pack_table_bytes(len(weights)))
+        hit = _PK[key] = ((_PackDesc * len(weights))(), offs, total, PinnedRing(tb, torch.uint8, pin=True), torch.empty(tb, dtype=torch.uint8, device=dev))
+        if len(_PK) > 16:
+            _PK.pop(next(iter(_PK)))
+    descs, offs, total, ring, tdev = hit
+    from .. import cmdbuf
+    if cmdbuf.active() is not None:                          # recorded region: its own descriptor array + device table (arena)
+        descs = (_PackDesc * len(weights))()
+        tdev = torch.empty(tdev.numel(), dtype=torch.uint8, device=dev)
+        for w in weights:
+            cmdbuf.require_stable(w.data_ptr(), "weight to pack")
+    buf = torch.empty(total, dtype=bf16, device=dev)
+    base = buf.data_ptr()
+    for d, w, o in zip(descs, weights, offs):
+        d.src, d.dst, d.rows, d.cols, d.transpose = w.data_ptr(), base + 2 * o, w.shape[0], w.shape[1], int(bool(transpose))
+    host = ring.acquire()
+    rc = L.pd_dec_pack_grouped(descs, len(weights), host.data_ptr(), tdev.data_ptr(), _stream())
+    ring.release()
+    _lib.check(rc)
+    return [buf[o:o + w.numel()] for w, o in zip(weights, offs)]
+
+
 def _e(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
 
@@ -40,7 +88,7 @@ def fwd_a(o, res, qpos, pos_div, w_o, b_o, ln_w, ln_b, eps, w_qkv, b_qkv):
 
 
 def fwd_b(o, res, qpos, pos_div, lay, dn_w, dn_b, mlp, q_next, eps, dec_out):
-    """lay = (w_o, b_o, ln2_w, ln2_b, w_1, b_1, w_2, b_2, ln3_w, ln3_b) or None (the head in front of the first layer: y3 = res);
+    """(all weights PACKED: pack())  lay = (w_o, b_o, ln2_w, ln2_b, w_1, b_1, w_2, b_2, ln3_w, ln3_b) or None (the head in front of the first layer: y3 = res);
     mlp = the six mask-embedding MLP tensors and q_next = (W_q, b_q) of the next layer's cross-attention, or None / None after the last layer.
     dec_out: the [R, C] fp32 row block of the stacked decoder outputs this head writes.
     -> dict(z2, stats2, y2_c, h, z3, stats3, y3 | None ..., ypos_c, hstats, ef | None, qc | None)"""

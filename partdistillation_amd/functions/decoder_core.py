@@ -26,6 +26,7 @@ from .. import cmdbuf
 from .. import lib as _lib
 from . import rowwise as rw
 from . import conv_bf16, igemm
+from . import declayer as dl
 from . import smallgemm as sg
 from .attention import attn_bwd_raw, attn_fwd_raw
 
@@ -103,6 +104,9 @@ def _wgrad(dy, x, out=None, bias_acc=None, queue=None, big=None):
 GROUP_WGRADS = True   # False: one launch per weight gradient (tools/ comparisons)
 MULTI_QKV = os.environ.get("PD_MULTI_QKV", "1") != "0"     # the q / k / v projections of an attention block as one launch (pd_sgemm_tn_multi_bf16)
 FUSED_HEAD = os.environ.get("PD_FUSED_HEAD", "1") != "0"   # decoder_norm + mask-embedding MLP of a prediction head as one launch (pd_decoder_head_bf16)
+# the row-local chains of a layer as four launches (pd_dec_fwd_a / _b, pd_dec_bwd_b / _a: csrc/declayer.hip) instead of ~25: 16 rows per
+# workgroup, weights streamed once per workgroup from a packed copy
+FUSED_LAYER = os.environ.get("PD_DEC_FUSED", "1") != "0"
 
 
 class _Acc:
@@ -166,8 +170,15 @@ class DecoderCore(Function):
         multi = MULTI_QKV and cdt == torch.bfloat16 and C <= 256 and C % 64 == 0
         # the layer loop as a RECORDED region (cmdbuf.py): needs every step inside it to be a pd_* call — the fused prediction head,
         # the multi-problem projections and bf16 pooled mask features (the mask logits then run on pd_sgemm_nn_bf16, not torch.bmm)
-        use_rec = (cmdbuf.usable() and xs[0].is_cuda and fused_head and multi and all(p_.dtype == torch.bfloat16 and p_.shape[2] % 8 == 0 and (p_.is_contiguous() or p_.transpose(1, 2).is_contiguous()) for p_ in spec.pooled)
-                   and any(ctx.needs_input_grad))
+        pooled_ok = all(p_.dtype == torch.bfloat16 and p_.shape[2] % 8 == 0 and (p_.is_contiguous() or p_.transpose(1, 2).is_contiguous()) for p_ in spec.pooled)
+        use_rec = (cmdbuf.usable() and xs[0].is_cuda and fused_head and multi and pooled_ok and any(ctx.needs_input_grad))
+        # fused layer kernels: bf16, C = 256, feed-forward 2048, contiguous bf16 weights / biases, fp32 LayerNorm weights, bf16 pooled mask features
+        fused_layer = (FUSED_LAYER and xs[0].is_cuda and fused_head and multi and pooled_ok and Q <= 1024 and igemm.supported(C, C) and
+                       all(dl.supported(C, lay[12].shape[0], cdt) and tuple(lay[12].shape) == (dl.FF, C) and tuple(lay[14].shape) == (C, dl.FF) and
+                           all(lay[j].dtype == torch.bfloat16 and lay[j].is_contiguous() for j in (0, 1, 2, 3, 6, 7, 8, 9, 12, 13, 14, 15)) and
+                           all(lay[j].dtype == torch.float32 for j in (4, 5, 10, 11, 16, 17)) for lay in layers) and
+                       dn_w.dtype == torch.float32 and query_embed.dtype == torch.float32)
+        ctx.fused_layer = fused_layer
         flat_layers = [p_ for lay in layers for p_ in lay]
         if cmdbuf.DEBUG and not use_rec:
             import sys
@@ -175,19 +186,19 @@ class DecoderCore(Function):
                   pooled=[(str(p_.dtype), p_.is_contiguous()) for p_ in spec.pooled], needs_grad=any(ctx.needs_input_grad)), file=sys.stderr, flush=True)
         if not use_rec:
             ctx.rec = None
-            outs = DecoderCore._fwd_layers(spec, xs, qpos, tgt, tgtpos_c, level_embed, dn_w, dn_b, mlp, layers, fused_head, multi)
+            outs = DecoderCore._fwd_layers(spec, xs, qpos, tgt, tgtpos_c, level_embed, dn_w, dn_b, mlp, layers, fused_head, multi, fused_layer)
         else:
             consts = list(spec.pos[:nl]) + list(spec.pooled[:nl])
             head = list(xs) + [qpos, tgt, tgtpos_c] + consts
             params = [level_embed, dn_w, dn_b] + list(mlp) + flat_layers
             slots = head + params
             key = ("fwd", B, Q, C, H, L, nl, tuple(tuple(x.shape) for x in xs), params[0].data_ptr(), flat_layers[0].data_ptr(), str(xs[0].device),
-                   _lib.current_stream())
+                   _lib.current_stream(), fused_layer)
             rec = _rec_get(key)
             if rec is None or not rec.matches(slots):
                 rec = cmdbuf.Recording(slots, "decoder forward", pinned=range(len(head), len(slots)))
                 with rec:
-                    outs = DecoderCore._fwd_layers(spec, xs, qpos, tgt, tgtpos_c, level_embed, dn_w, dn_b, mlp, layers, fused_head, multi)
+                    outs = DecoderCore._fwd_layers(spec, xs, qpos, tgt, tgtpos_c, level_embed, dn_w, dn_b, mlp, layers, fused_head, multi, fused_layer)
                 outs = rec.finish(outs)
                 _rec_put(key, rec)
             else:
@@ -201,8 +212,10 @@ class DecoderCore(Function):
         return dec_outs, final_tgt.view(R, C)          # a view: the node must not own one of its own outputs (reference cycle)
 
     @staticmethod
-    def _fwd_layers(spec, xs, qpos, tgt, tgtpos_c, level_embed, dn_w, dn_b, mlp, layers, fused_head, multi):
+    def _fwd_layers(spec, xs, qpos, tgt, tgtpos_c, level_embed, dn_w, dn_b, mlp, layers, fused_head, multi, fused_layer=False):
         """-> (dec_outs, final tgt, saved, head_stats, mem, mempos); inside a recording: pd_* launches and allocations only"""
+        if fused_layer:
+            return DecoderCore._fwd_layers_fused(spec, xs, qpos, tgt, tgtpos_c, level_embed, dn_w, dn_b, mlp, layers)
         B, Q, C, H, L, cdt = spec.B, spec.Q, spec.C, spec.H, spec.L, spec.cdt
         nl = spec.num_levels
         R, scale = Q * B, 32 ** -0.5
@@ -299,6 +312,79 @@ class DecoderCore(Function):
         return dec_outs, tgt, saved, head_stats, mem, mempos
 
     @staticmethod
+    def _mask_from_ef(spec, ef, lvl):
+        """attention mask of the next layer: mask logits [Q, HW] = embeddings [Q, C] x pooled mask features [C, HW] per image (reference
+        :449 einsum + :452-456), thresholded to bytes"""
+        B, Q = spec.B, spec.Q
+        pooled = spec.pooled[lvl]
+        pooled_t = pooled.transpose(1, 2)                          # [B, HW, C]: contiguous when the mask features are channels-last
+        logits = torch.empty((B, Q, pooled.shape[2]), dtype=torch.bfloat16, device=ef.device)
+        for b in range(B):
+            if pooled_t.is_contiguous():
+                sg.linear(ef[b], pooled_t[b], None, False, out=logits[b])
+            else:
+                sg.dgrad(ef[b], pooled[b], out=logits[b])
+        return rw.attn_mask_u8(logits)
+
+    @staticmethod
+    def _fwd_layers_fused(spec, xs, qpos, tgt, tgtpos_c, level_embed, dn_w, dn_b, mlp, layers):
+        """the layer loop on the fused kernels of csrc/declayer.hip: per layer [key / value projections over the memory tokens, masked
+        cross-attention] pd_dec_fwd_a [self-attention] pd_dec_fwd_b [mask logits of the next layer's attention mask]"""
+        B, Q, C, H, L, cdt = spec.B, spec.Q, spec.C, spec.H, spec.L, spec.cdt
+        nl = spec.num_levels
+        R, scale = Q * B, 32 ** -0.5
+        dev = xs[0].device
+        if cmdbuf.active() is not None:
+            tgt = rw.copy_d2d(torch.empty_like(tgt), tgt)
+        mem, mempos = [], []
+        for l in range(nl):
+            m, mp = rw.mem_prep_fwd(xs[l], level_embed[l], spec.pos[l], cdt)
+            mem.append(m), mempos.append(mp)
+        dec_outs = torch.empty((L + 1, R, C), dtype=torch.float32, device=dev)
+        saved, head_stats = [], []
+        # every weight of the loop in the kernels' block order: one launch per step
+        per = 6
+        pk = dl.pack([w_ for lay in layers for w_ in (lay[0][:C], lay[2], lay[6], lay[8], lay[12], lay[14])] + [mlp[0], mlp[2], mlp[4]])
+        mlp_p = [pk[per * L], mlp[1], pk[per * L + 1], mlp[3], pk[per * L + 2], mlp[5]]
+
+        def qnext(i):
+            return (pk[per * i], layers[i][1][:C])
+
+        r = dl.fwd_b(None, tgt, qpos, B, None, dn_w, dn_b, mlp_p, qnext(0), spec.eps, dec_outs[0])
+        head_stats.append((r["hstats"][0], r["hstats"][1]))
+        mask = DecoderCore._mask_from_ef(spec, r["ef"], 0)
+        tgtpos_c, qc = r["ypos_c"], r["qc"]
+        for i in range(L):
+            lvl = i % nl
+            (ciw, cib, cow, cob, cnw, cnb, siw, sib, sow, sob, snw, snb, w1, b1, w2, b2, fnw, fnb) = layers[i]
+            _, p_co, p_si, p_so, p_w1, p_w2 = pk[per * i:per * i + per]
+            # ---- masked cross-attention (the query projection ran in the previous head's launch)
+            if mem[lvl].shape[0] >= KV_IGEMM_ROWS:
+                k = igemm.linear(mempos[lvl], ciw[C:2 * C], cib[C:2 * C])
+                v = igemm.linear(mem[lvl], ciw[2 * C:], cib[2 * C:])
+            else:
+                k, v = sg.linear_multi([(mempos[lvl], ciw[C:2 * C], cib[C:2 * C]), (mem[lvl], ciw[2 * C:], cib[2 * C:])])
+            o, lse = attn_fwd_raw(qc, k, v, mask, B, H, scale)
+            z1, st1, y1, y1_c, y1pos_c, sq, sk, sv = dl.fwd_a(o, tgt, qpos, B, p_co, cob, cnw, cnb, spec.eps, p_si, sib)
+            cross = (tgtpos_c, qc, k, v, mask, o, lse, z1, st1[0], st1[1])
+            # ---- self-attention
+            o_s, lse_s = attn_fwd_raw(sq, sk, sv, None, B, H, scale)
+            slf = (y1pos_c, y1_c, sq, sk, sv, o_s, lse_s, None, None, None)
+            # ---- output projection + LN, FFN + LN, head (+ the next layer's query projection)
+            last = i + 1 == L
+            r = dl.fwd_b(o_s, y1, qpos, B, (p_so, sob, snw, snb, p_w1, b1, p_w2, b2, fnw, fnb), dn_w, dn_b, None if last else mlp_p,
+                         None if last else qnext(i + 1), spec.eps, dec_outs[i + 1])
+            slf = slf[:7] + (r["z2"], r["stats2"][0], r["stats2"][1])
+            ffn = (r["y2_c"], r["h"], r["z3"], r["stats3"][0], r["stats3"][1], r["y3"])
+            saved.append((cross, slf, ffn))
+            head_stats.append((r["hstats"][0], r["hstats"][1]))
+            tgt, tgtpos_c = r["y3"], r["ypos_c"]
+            if not last:
+                qc = r["qc"]
+                mask = DecoderCore._mask_from_ef(spec, r["ef"], (i + 1) % nl)
+        return dec_outs, tgt, saved, head_stats, mem, mempos
+
+    @staticmethod
     def backward(ctx, d_out, d_final):
         spec = ctx.spec
         B, Q, C, H, L, cdt = spec.B, spec.Q, spec.C, spec.H, spec.L, spec.cdt
@@ -311,7 +397,7 @@ class DecoderCore(Function):
         need_x = tuple(bool(ctx.needs_input_grad[1 + l]) for l in range(nl))
         tgt0 = query_feat.unsqueeze(1).expand(Q, B, C).reshape(R, C)
         rec_f = getattr(ctx, "rec", None)
-        args = (spec, ctx.saved, ctx.head_stats, ctx.mem, ctx.mempos, ctx.x_shapes, d_out, d_fin, tgt0, level_embed, dn_w, layers)
+        args = (spec, ctx.saved, ctx.head_stats, ctx.mem, ctx.mempos, ctx.x_shapes, d_out, d_fin, tgt0, level_embed, dn_w, layers, getattr(ctx, "fused_layer", False))
         if rec_f is None:
             outs = DecoderCore._bwd_layers(*args)
         else:
@@ -367,7 +453,7 @@ class DecoderCore(Function):
         return tuple(grads)
 
     @staticmethod
-    def _bwd_layers(spec, saved, head_stats, mem_f, mempos_f, x_shapes, d_out, d_final, tgt0, level_embed, dn_w, layers):
+    def _bwd_layers(spec, saved, head_stats, mem_f, mempos_f, x_shapes, d_out, d_final, tgt0, level_embed, dn_w, layers, fused_layer=False):
         """-> (accumulator buffer, its slot table, dz of head 0, d(residual stream), d(tgt + query_pos), per-level token gradients, d(level
         embedding), per-layer weight gradients); inside a recording: pd_* launches and allocations only"""
         B, Q, C, H, L, cdt = spec.B, spec.Q, spec.C, spec.H, spec.L, spec.cdt
@@ -413,10 +499,52 @@ class DecoderCore(Function):
         big = [] if GROUP_WGRADS else None                                   # ... and the two over the memory tokens: conv_bf16's group
         d_res = d_final                                                      # fp32 gradient w.r.t. the residual stream
         d_pos_c = None                                                       # GEMM-dtype gradient w.r.t. (tgt + query_pos)
+        if fused_layer:                                                      # every transposed weight of the loop in block order: one launch
+            pkT = dl.pack([w_ for lay_ in layers for w_ in (lay_[0][:C], lay_[2], lay_[6], lay_[8], lay_[12], lay_[14])], transpose=True)
+            dq_next = None                                                   # d(cross-attention queries) of layer i + 1
+
+            def A2(s0):                                                      # [dgamma | dbeta]: adjacent accumulator slots
+                return buf[s0[0]:s0[0] + 2 * s0[1]]
         for i in reversed(range(L)):
             lvl = i % nl
             (ciw, cib, cow, cob, cnw, cnb, siw, sib, sow, sob, snw, snb, w1, b1, w2, b2, fnw, fnb) = layers[i]
             cross, slf, ffn = saved[i]
+            if fused_layer:
+                cqT, coT, siT, soT, w1T, w2T = pkT[6 * i:6 * i + 6]
+                hm, hr = head_stats[i + 1]
+                x_c, h, z3, m3, r3, y3 = ffn
+                tp_c, t_c, q, k, v, o, lse, z2, m2, r2 = slf
+                # (mean, rstd) pairs are the two rows of one [2, R] tensor: the kernels take its base
+                dz3_c, dh, dz2, dz2_c, d_os = dl.bwd_b(dq_next, pkT[6 * (i + 1)] if dq_next is not None else None, d_out[i + 1], d_res, y3, hm, dn_w,
+                                                       A2(s_dnw), z3, m3, fnw, A2(lay[i]["fnw"]), A(lay[i]["b2"]),
+                                                       A(s_pos) if dq_next is not None else None, B, w2T, h, w1T, z2, m2, snw, A2(lay[i]["snw"]),
+                                                       A(lay[i]["sob"]), soT)
+                g_w2 = _wgrad(dz3_c, h, queue=wq)
+                g_w1 = _wgrad(dh, x_c, bias_acc=A(lay[i]["b1"]), queue=wq)
+                g_sow = _wgrad(dz2_c, o, queue=wq)
+                dq, dk, dv = attn_bwd_raw(q, k, v, None, o, d_os, lse, B, H, scale)
+                g_siw = torch.empty_like(siw)
+                sb = A(lay[i]["sib"])
+                _wgrad(dq, tp_c, g_siw[:C], sb[:C], queue=wq)
+                _wgrad(dk, tp_c, g_siw[C:2 * C], sb[C:2 * C], queue=wq)
+                _wgrad(dv, t_c, g_siw[2 * C:], sb[2 * C:], queue=wq)
+                tp_c, q, k, v, mask, o, lse, z1, m1, r1 = cross
+                dz1, dz1_c, d_oc = dl.bwd_a(dq, dk, dv, siT, dz2, z1, m1, cnw, A2(lay[i]["cnw"]), A(lay[i]["cob"]), A(s_pos), B, coT)
+                g_cow = _wgrad(dz1_c, o, queue=wq)
+                dq, dk, dv = attn_bwd_raw(q, k, v, mask, o, d_oc, lse, B, H, scale)
+                g_ciw = torch.empty_like(ciw)
+                cb = A(lay[i]["cib"])
+                _wgrad(dq, tp_c, g_ciw[:C], cb[:C], queue=wq)
+                _wgrad(dk, mempos_f[lvl], g_ciw[C:2 * C], cb[C:2 * C], queue=wq, big=big)
+                _wgrad(dv, mem_f[lvl], g_ciw[2 * C:], cb[2 * C:], queue=wq, big=big)
+                dmempos[lvl] = dgrad_mem(dk, i, 1, dmempos[lvl])
+                dmem[lvl] = dgrad_mem(dv, i, 2, dmem[lvl])
+                dq_next = dq
+                if i == 0:
+                    d_pos_c = _dgrad(dq, ciw[:C])                            # -> the learnable queries (eager epilogue)
+                d_res = dz1
+                wgrads[i] = (g_ciw, g_cow, g_siw, g_sow, g_w1, g_w2)
+                continue
             # ---- head i+1 (decoder_norm of the FFN output)
             hm, hr = head_stats[i + 1]
             dzh, _ = rw.add_ln_bwd(ffn[5], hm, hr, dn_w, dy=d_out[i + 1], dgamma=A(s_dnw), dbeta=A(s_dnb))

@@ -61,7 +61,9 @@ def test_forward_kernels_vs_unfused(Q, B):
     q_r = sg.linear(yp_r, p["si_w"][:C], p["si_b"][:C])
     k_r = sg.linear(yp_r, p["si_w"][C:2 * C], p["si_b"][C:2 * C])
     v_r = sg.linear(yc_r, p["si_w"][2 * C:], p["si_b"][2 * C:])
-    z, st, y, yc, yp, q, k, v = dl.fwd_a(o, tgt, qpos, B, p["co_w"], p["co_b"], p["cn"][0], p["cn"][1], eps, p["si_w"], p["si_b"])
+    pk = dict(zip(("co_w", "si_w", "so_w", "w1", "w2", "m0", "m1", "m2", "cq_w"),
+                  dl.pack([p["co_w"], p["si_w"], p["so_w"], p["w1"], p["w2"], p["mlp"][0], p["mlp"][2], p["mlp"][4], p["cq_w"]])))
+    z, st, y, yc, yp, q, k, v = dl.fwd_a(o, tgt, qpos, B, pk["co_w"], p["co_b"], p["cn"][0], p["cn"][1], eps, pk["si_w"], p["si_b"])
     _close(z, z_r, "z1"); _close(y, y_r, "y1", ulps=4); _close(yc, yc_r, "y1_c", ulps=4); _close(yp, yp_r, "y1pos_c", ulps=4)
     _close(st[0], m_r, "mean1"); _close(st[1], r_r, "rstd1", ulps=4)
     _close(q, q_r, "q", ulps=6); _close(k, k_r, "k", ulps=6); _close(v, v_r, "v", ulps=6)
@@ -81,9 +83,10 @@ def test_forward_kernels_vs_unfused(Q, B):
     for j in range(3):
         e = sg.linear(e, p["mlp"][2 * j], p["mlp"][2 * j + 1], j < 2)
     qc_r = sg.linear(y3p_r, p["cq_w"], p["cq_b"])
-    lay = (p["so_w"], p["so_b"], p["sn"][0], p["sn"][1], p["w1"], p["b1"], p["w2"], p["b2"], p["fn"][0], p["fn"][1])
+    lay = (pk["so_w"], p["so_b"], p["sn"][0], p["sn"][1], pk["w1"], p["b1"], pk["w2"], p["b2"], p["fn"][0], p["fn"][1])
+    mlp_p = [pk["m0"], p["mlp"][1], pk["m1"], p["mlp"][3], pk["m2"], p["mlp"][5]]
     dec_out = torch.empty(R, C, device=dev)
-    r = dl.fwd_b(o_s, y_r, qpos, B, lay, p["dn"][0], p["dn"][1], p["mlp"], (p["cq_w"], p["cq_b"]), eps, dec_out)
+    r = dl.fwd_b(o_s, y_r, qpos, B, lay, p["dn"][0], p["dn"][1], mlp_p, (pk["cq_w"], p["cq_b"]), eps, dec_out)
     _close(r["z2"], z2_r, "z2"); _close(r["y2_c"], y2c_r, "y2_c", ulps=4); _close(r["stats2"][0], m2_r, "mean2"); _close(r["stats2"][1], r2_r, "rstd2", ulps=4)
     _close(r["h"], h_r, "h", ulps=6); _close(r["z3"], z3_r, "z3", ulps=6); _close(r["y3"], y3_r, "y3", ulps=8)
     _close(r["ypos_c"], y3p_r, "y3pos_c", ulps=8); _close(dec_out, d_t, "dec_out", ulps=8)
@@ -91,7 +94,7 @@ def test_forward_kernels_vs_unfused(Q, B):
     _close(r["qc"], qc_r, "qc", ulps=12, mean_tol=5e-3)
     # the head in front of the first layer: y3 = the input rows
     dec0 = torch.empty(R, C, device=dev)
-    r0 = dl.fwd_b(None, tgt, qpos, B, None, p["dn"][0], p["dn"][1], p["mlp"], (p["cq_w"], p["cq_b"]), eps, dec0)
+    r0 = dl.fwd_b(None, tgt, qpos, B, None, p["dn"][0], p["dn"][1], mlp_p, (pk["cq_w"], p["cq_b"]), eps, dec0)
     d0 = torch.nn.functional.layer_norm(tgt, (C,), p["dn"][0], p["dn"][1], eps)
     _close(dec0, d0, "dec_out 0")
     e = d0.to(bf)
@@ -125,9 +128,11 @@ def test_backward_kernels_vs_unfused(Q, B, last):
     h = rnd(R, FF).clamp_min(0).to(bf)
     d_out, d_res = rnd(R, C, scale=0.05), (None if last else rnd(R, C, scale=0.05))
     dqc = None if last else rnd(R, C, scale=0.05).to(bf)
-    wT = igemm.transposed([p["cq_w"], p["w2"], p["w1"], p["so_w"], p["si_w"], p["co_w"]])
-    cqT, w2T, w1T, soT, siT, coT = wT
-    assert w2T.shape == (FF, C) and w1T.shape == (C, FF) and siT.shape == (C, 3 * C)
+    cqT, w2T, w1T, soT, siT, coT = dl.pack([p["cq_w"], p["w2"], p["w1"], p["so_w"], p["si_w"], p["co_w"]], transpose=True)
+    # the transposing pack equals the plain pack of the explicitly transposed weight
+    tr = igemm.transposed([p["w2"], p["si_w"]])
+    chk = dl.pack([t.contiguous() for t in tr])
+    assert torch.equal(chk[0], w2T) and torch.equal(chk[1], siT)
 
     def accs():
         return {k_: torch.zeros(n, device=dev) for k_, n in (("dn", 2 * C), ("g3", 2 * C), ("b3", C), ("g2", 2 * C), ("b2", C), ("g1", 2 * C), ("b1", C), ("pos", Q * C))}

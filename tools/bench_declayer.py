@@ -13,7 +13,10 @@ p, g = _params(dev, 3)
 o = torch.randn(R, C, generator=g).to(dev).to(bf)
 tgt = torch.randn(R, C, generator=g).to(dev)
 qpos = torch.randn(Q, C, generator=g).to(dev)
-lay = (p["so_w"], p["so_b"], p["sn"][0], p["sn"][1], p["w1"], p["b1"], p["w2"], p["b2"], p["fn"][0], p["fn"][1])
+pk = dict(zip(("co_w", "si_w", "so_w", "w1", "w2", "m0", "m1", "m2", "cq_w"),
+              dl.pack([p["co_w"], p["si_w"], p["so_w"], p["w1"], p["w2"], p["mlp"][0], p["mlp"][2], p["mlp"][4], p["cq_w"]])))
+lay = (pk["so_w"], p["so_b"], p["sn"][0], p["sn"][1], pk["w1"], p["b1"], pk["w2"], p["b2"], p["fn"][0], p["fn"][1])
+mlp_p = [pk["m0"], p["mlp"][1], pk["m1"], p["mlp"][3], pk["m2"], p["mlp"][5]]
 dec_out = torch.empty(R, C, device=dev)
 
 
@@ -42,14 +45,15 @@ def unf_b():
     return y3
 
 
-print("fwd_a fused   us", round(timeit(lambda: dl.fwd_a(o, tgt, qpos, B, p["co_w"], p["co_b"], p["cn"][0], p["cn"][1], eps, p["si_w"], p["si_b"])), 1))
+print("fwd_a fused   us", round(timeit(lambda: dl.fwd_a(o, tgt, qpos, B, pk["co_w"], p["co_b"], p["cn"][0], p["cn"][1], eps, pk["si_w"], p["si_b"])), 1))
 print("fwd_a unfused us (3 launches)", round(timeit(unf_a), 1))
-print("fwd_b fused   us", round(timeit(lambda: dl.fwd_b(o, tgt, qpos, B, lay, p["dn"][0], p["dn"][1], p["mlp"], (p["cq_w"], p["cq_b"]), eps, dec_out)), 1))
+print("fwd_b fused   us", round(timeit(lambda: dl.fwd_b(o, tgt, qpos, B, lay, p["dn"][0], p["dn"][1], mlp_p, (pk["cq_w"], p["cq_b"]), eps, dec_out)), 1))
 print("fwd_b fused, no head MLP us", round(timeit(lambda: dl.fwd_b(o, tgt, qpos, B, lay, p["dn"][0], p["dn"][1], None, None, eps, dec_out)), 1))
-print("fwd_b head only us", round(timeit(lambda: dl.fwd_b(None, tgt, qpos, B, None, p["dn"][0], p["dn"][1], p["mlp"], (p["cq_w"], p["cq_b"]), eps, dec_out)), 1))
+print("fwd_b head only us", round(timeit(lambda: dl.fwd_b(None, tgt, qpos, B, None, p["dn"][0], p["dn"][1], mlp_p, (pk["cq_w"], p["cq_b"]), eps, dec_out)), 1))
 print("fwd_b unfused us (5 launches, without head + q)", round(timeit(unf_b), 1))
-wT = igemm.transposed([p["cq_w"], p["w2"], p["w1"], p["so_w"], p["si_w"], p["co_w"]])
-cqT, w2T, w1T, soT, siT, coT = wT
+cqT, w2T, w1T, soT, siT, coT = dl.pack([p["cq_w"], p["w2"], p["w1"], p["so_w"], p["si_w"], p["co_w"]], transpose=True)
+allw = [p["co_w"], p["si_w"], p["so_w"], p["w1"], p["w2"], p["mlp"][0], p["mlp"][2], p["mlp"][4], p["cq_w"]] * 9
+print("pack 9 layers forward us", round(timeit(lambda: dl.pack(allw), 50), 1), " backward (transposing) us", round(timeit(lambda: dl.pack(allw, True), 50), 1))
 z3, z2, z1, y3 = (torch.randn(R, C, device=dev) for _ in range(4))
 st = torch.stack([torch.zeros(R, device=dev), torch.ones(R, device=dev)]).contiguous()
 h = torch.randn(R, FF, device=dev).clamp_min(0).to(bf)
