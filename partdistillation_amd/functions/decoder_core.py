@@ -318,6 +318,8 @@ class DecoderCore(Function):
         B, Q = spec.B, spec.Q
         pooled = spec.pooled[lvl]
         pooled_t = pooled.transpose(1, 2)                          # [B, HW, C]: contiguous when the mask features are channels-last
+        if pooled_t.is_contiguous() and sg.bmm_tn_supported(ef, pooled_t):
+            return rw.attn_mask_u8(sg.bmm_tn(ef, pooled_t))            # all images in one launch
         logits = torch.empty((B, Q, pooled.shape[2]), dtype=torch.bfloat16, device=ef.device)
         for b in range(B):
             if pooled_t.is_contiguous():
