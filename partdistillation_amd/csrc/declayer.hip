@@ -64,18 +64,6 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// ---- one weight block of a wavefront: rows n0 .. n0 + 31 (two 16-row tiles), 256 contraction elements from k0
-struct WBlk { uint4 v[2][8]; };
-// acc[t][..] += W block . X^T;  xs = &X_lds[lane & 15][k0 + 8 (lane >> 4)]
-__device__ __forceinline__ void wmma(f32x4 (&acc)[2], const WBlk &w, const bf16_t *xs)
-{
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const hwbf16x8 x = *reinterpret_cast<const hwbf16x8 *>(xs + 32 * s);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hwbf16x8, w.v[0][s]), x, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hwbf16x8, w.v[1][s]), x, acc[1], 0, 0, 0);
-  }
-}
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[2])
 {
 #pragma unroll
@@ -191,14 +179,29 @@ __device__ __forceinline__ void flush_colsums(const float *red, float *const (&o
 
 // ---- packed weights: a wavefront's block (32 rows x 256 k) is 16 KB contiguous, instruction i = 8 t + s reads 1 KB (pd_dec_pack_grouped)
 constexpr int BLK = 8192;                                           // bf16 elements per block
-__device__ __forceinline__ void wloadp(WBlk &w, const bf16_t *__restrict__ blk, int lane)
+// The pipeline's unit is HALF a block (its 128 first / last contraction elements: 8 loads); a wavefront keeps THREE halves in flight
+// beside the one it multiplies (four 32-register buffers, 24 KB per wavefront on the way instead of 16 with whole blocks one ahead).
+struct WHalf { uint4 v[2][4]; };
+__device__ __forceinline__ void wloadh(WHalf &w, const bf16_t *__restrict__ blk, int half, int lane)
 {
-  const bf16_t *p = blk + lane * 8;
+  const bf16_t *p = blk + lane * 8 + half * (4 * 512);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) w.v[t][s] = *reinterpret_cast<const uint4 *>(p + (t * 8 + s) * 512);
+    for (int s = 0; s < 4; ++s) w.v[t][s] = *reinterpret_cast<const uint4 *>(p + (t * 8 + s) * 512);
 }
+__device__ __forceinline__ void wmmah(f32x4 (&acc)[2], const WHalf &w, const bf16_t *xs)
+{
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const hwbf16x8 x = *reinterpret_cast<const hwbf16x8 *>(xs + 32 * s);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hwbf16x8, w.v[0][s]), x, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hwbf16x8, w.v[1][s]), x, acc[1], 0, 0, 0);
+  }
+}
+// half h of a wavefront's block sequence (bp(b) = base of its b-th block, NBLK blocks): issue / multiply; indices are compile-time at every use
+#define PD_HP(h) do { if ((h) < 2 * NBLK) wloadh(w[(h) & 3], bp((h) >> 1), (h) & 1, lane); } while (0)
+#define PD_BLK(b, XS) do { PD_HP(2 * (b) + 3); wmmah(acc, w[(2 * (b)) & 3], (XS)); PD_HP(2 * (b) + 4); wmmah(acc, w[(2 * (b) + 1) & 3], (XS) + 128); } while (0)
 
 // =================================================================================================== forward A
 struct FwdA {
@@ -220,8 +223,10 @@ __global__ __launch_bounds__(NTH) void dec_fwd_a(const FwdA a)
   bf16_t *Bs = reinterpret_cast<bf16_t *>(Zs + RB * PZ);           // biases: o [256] | qkv [768]
   float *Ls = reinterpret_cast<float *>(Bs + 4 * C);               // ln_w | ln_b
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = blockIdx.x * RB, R = a.R;
-  WBlk w[2];
-  wloadp(w[0], a.w_o + (size_t)wave * BLK, lane);
+  constexpr int NBLK = 4;                                          // W_o | W_q | W_k | W_v
+  auto bp = [&](int b) { return b == 0 ? a.w_o + (size_t)wave * BLK : a.w_qkv + (size_t)((b - 1) * 8 + wave) * BLK; };
+  WHalf w[4];
+  PD_HP(0); PD_HP(1); PD_HP(2);
   tile_in(X0, a.o, r0, R, tid);
   lds_copy_bf16(Bs, a.b_o, C, tid);
   lds_copy_bf16(Bs + C, a.b_qkv, 3 * C, tid);
@@ -238,8 +243,7 @@ __global__ __launch_bounds__(NTH) void dec_fwd_a(const FwdA a)
   const int xo = (lane & 15) * PA + 8 * (lane >> 4);
   f32x4 acc[2];
   zero_acc(acc);
-  wloadp(w[1], a.w_qkv + (size_t)wave * BLK, lane);                // q rows
-  wmma(acc, w[0], X0 + xo);
+  PD_BLK(0, X0 + xo);
   store_tile_f32r<true>(acc, Bs, 32 * wave, Zs, 32 * wave, lane);
   __syncthreads();
 #pragma unroll
@@ -261,15 +265,13 @@ __global__ __launch_bounds__(NTH) void dec_fwd_a(const FwdA a)
   tile_out(a.y_c, X1, r0, R, tid);
   tile_out(a.ypos_c, X2, r0, R, tid);
   zero_acc(acc);                                                   // q, k from ypos_c; v from y_c
-  wloadp(w[0], a.w_qkv + (size_t)(8 + wave) * BLK, lane);          // k rows
-  wmma(acc, w[1], X2 + xo);
+  PD_BLK(1, X2 + xo);
   store_tile_bf16<true, false>(acc, Bs + C, 32 * wave, X0, PA, 32 * wave, lane);
   zero_acc(acc);
-  wloadp(w[1], a.w_qkv + (size_t)(16 + wave) * BLK, lane);         // v rows
-  wmma(acc, w[0], X2 + xo);
+  PD_BLK(2, X2 + xo);
   store_tile_bf16<true, false>(acc, Bs + 2 * C, 32 * wave, X3, PA, 32 * wave, lane);
   zero_acc(acc);
-  wmma(acc, w[1], X1 + xo);
+  PD_BLK(3, X1 + xo);
   store_tile_bf16<true, false>(acc, Bs + 3 * C, 32 * wave, X4, PA, 32 * wave, lane);
   __syncthreads();
   tile_out(a.q, X0, r0, R, tid);
@@ -309,9 +311,17 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
   const int rb = blockIdx.x / P, p = blockIdx.x - rb * P, r0 = rb * RB;
   constexpr int B1 = C, B2 = C + FF, BM = 2 * C + FF, BQ = 5 * C + FF;
   constexpr int I0 = LAYER ? 2 * NB + 1 : 0;                       // index of the first MLP block in this wavefront's block sequence
-  WBlk w[2];
+  constexpr int NBLK = I0 + (MLP ? 4 : 0);                         // W_o | W_1 x 8 | W_2 x 8 | M_0 M_1 M_2 | W_q of the next layer
+  auto bp = [&](int b) -> const bf16_t * {
+    if (LAYER && b == 0) return a.w_o + (size_t)wave * BLK;
+    if (LAYER && b <= NB) return a.w_1 + (size_t)(8 * wave + b - 1) * BLK;
+    if (LAYER && b <= 2 * NB) return a.w_2 + (size_t)(8 * wave + b - NB - 1) * BLK;
+    const int j = b - I0;
+    return (j == 0 ? a.m_w[0] : j == 1 ? a.m_w[1] : j == 2 ? a.m_w[2] : a.wq_next) + (size_t)wave * BLK;
+  };
+  WHalf w[4];
+  PD_HP(0); PD_HP(1); PD_HP(2);
   if (LAYER) {
-    wloadp(w[0], a.w_o + (size_t)wave * BLK, lane);
     tile_in(X0, a.o, r0, R, tid);
     lds_copy_bf16(Bs, a.b_o, C, tid);
     lds_copy_bf16(Bs + B1, a.b_1, FF, tid);
@@ -320,8 +330,6 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
     lds_copy_f32(Ls + C, a.ln2_b, C, tid);
     lds_copy_f32(Ls + 2 * C, a.ln3_w, C, tid);
     lds_copy_f32(Ls + 3 * C, a.ln3_b, C, tid);
-  } else if (MLP) {
-    wloadp(w[0], a.m_w[0] + (size_t)wave * BLK, lane);
   }
   if (MLP) {
 #pragma unroll
@@ -341,10 +349,8 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
   f32x4 acc[2];
   if (LAYER) {
     // ---- attention output projection + residual + LayerNorm (every workgroup of the row block)
-    const int nb1 = p * (64 / P) + wave * NB;                      // this wavefront's first 32-row block of linear1
     zero_acc(acc);
-    wloadp(w[1], a.w_1 + (size_t)nb1 * BLK, lane);
-    wmma(acc, w[0], X0 + xo);
+    PD_BLK(0, X0 + xo);
     store_tile_f32r<true>(acc, Bs, 32 * wave, Zs, 32 * wave, lane);
     __syncthreads();
 #pragma unroll
@@ -365,11 +371,8 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
     // ---- linear1 + ReLU: NB blocks of 32 hidden columns per wavefront
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-      const int i = 1 + c;
-      if (c + 1 < NB) wloadp(w[(i + 1) & 1], a.w_1 + (size_t)(nb1 + c + 1) * BLK, lane);
-      else wloadp(w[(i + 1) & 1], a.w_2 + (size_t)(wave * 8 + p * NB) * BLK, lane);       // first block of linear2
       zero_acc(acc);
-      wmma(acc, w[i & 1], X1 + xo);
+      PD_BLK(1 + c, X1 + xo);
       const int lc = (wave * NB + c) * 32;                         // local hidden column
       store_tile_bf16<true, true>(acc, Bs + B1, p * HW + lc, Hs, PHS, lc, lane);
     }
@@ -385,10 +388,7 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
     zero_acc(acc);
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-      const int i = NB + 1 + c;
-      if (c + 1 < NB) wloadp(w[(i + 1) & 1], a.w_2 + (size_t)(wave * 8 + p * NB + c + 1) * BLK, lane);
-      else if (MLP) wloadp(w[(i + 1) & 1], a.m_w[0] + (size_t)wave * BLK, lane);
-      wmma(acc, w[i & 1], Hs + ho + 256 * c);
+      PD_BLK(NB + 1 + c, Hs + ho + 256 * c);
     }
     store_tile_f32r<true>(acc, Bs + B2, 32 * wave, Zs, 32 * wave, lane);
     __syncthreads();
@@ -421,21 +421,18 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
   if (!MLP) return;
   // ---- mask-embedding MLP (bf16 between the layers, like three bf16 Linears) and the next layer's query projection
   zero_acc(acc);
-  wloadp(w[(I0 + 1) & 1], a.m_w[1] + (size_t)wave * BLK, lane);
-  wmma(acc, w[I0 & 1], X0 + xo);
+  PD_BLK(I0, X0 + xo);
   store_tile_bf16<true, true>(acc, Bs + BM, 32 * wave, X1, PA, 32 * wave, lane);
   __syncthreads();
   zero_acc(acc);
-  wloadp(w[I0 & 1], a.m_w[2] + (size_t)wave * BLK, lane);
-  wmma(acc, w[(I0 + 1) & 1], X1 + xo);
+  PD_BLK(I0 + 1, X1 + xo);
   store_tile_bf16<true, true>(acc, Bs + BM + C, 32 * wave, X0, PA, 32 * wave, lane);
   __syncthreads();
   zero_acc(acc);
-  wloadp(w[(I0 + 1) & 1], a.wq_next + (size_t)wave * BLK, lane);
-  wmma(acc, w[I0 & 1], X0 + xo);
+  PD_BLK(I0 + 2, X0 + xo);
   store_tile_bf16<true, false>(acc, Bs + BM + 2 * C, 32 * wave, X1, PA, 32 * wave, lane);
   zero_acc(acc);
-  wmma(acc, w[(I0 + 1) & 1], X2 + xo);
+  PD_BLK(I0 + 3, X2 + xo);
   store_tile_bf16<true, false>(acc, Bs + BQ, 32 * wave, Hs, PA, 32 * wave, lane);       // (the hidden tile is free: its first rows take qc)
   __syncthreads();
   tile_out(a.qc_next, Hs, r0, R, tid);
@@ -471,15 +468,15 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
   float *Gs = Ls + 3 * C;                                          // [16][PZ] dz3 rows (owner lanes only)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, R = a.R;
   const int rb = blockIdx.x / P, p = blockIdx.x - rb * P, r0 = rb * RB;
-  const int nb2 = p * (64 / P) + wave * NB;                        // this wavefront's first block of W_2^T
-  constexpr int I0 = NXT ? 1 : 0;
-  WBlk w[2];
-  if (NXT) {
-    wloadp(w[0], a.wqT_next + (size_t)wave * BLK, lane);
-    tile_in(X0, a.dqc_next, r0, R, tid);
-  } else {
-    wloadp(w[0], a.w2T + (size_t)nb2 * BLK, lane);
-  }
+  constexpr int I0 = NXT ? 1 : 0, NBLK = I0 + 2 * NB + 1;          // (W_q^T of the next layer) | W_2^T x 8 | W_1^T x 8 | W_o^T
+  auto bp = [&](int b) -> const bf16_t * {
+    if (NXT && b == 0) return a.wqT_next + (size_t)wave * BLK;
+    const int j = b - I0;
+    return j < NB ? a.w2T + (size_t)(8 * wave + j) * BLK : j < 2 * NB ? a.w1T + (size_t)(8 * wave + j - NB) * BLK : a.woT + (size_t)wave * BLK;
+  };
+  WHalf w[4];
+  PD_HP(0); PD_HP(1); PD_HP(2);
+  if (NXT) tile_in(X0, a.dqc_next, r0, R, tid);
 #pragma unroll
   for (int i = 0; i < HW * RB / 8 / NTH; ++i) {
     const int idx = i * NTH + tid, row = idx / (HW / 8), col = (idx % (HW / 8)) * 8;
@@ -504,8 +501,7 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
   f32x4 acc[2];
   if (NXT) {                                                       // d(y3 + pos) from the next layer's cross-attention queries
     zero_acc(acc);
-    wloadp(w[1], a.w2T + (size_t)nb2 * BLK, lane);
-    wmma(acc, w[0], X0 + xo);
+    PD_BLK(0, X0 + xo);
     store_tile_f32r<false>(acc, nullptr, 0, Zs, 32 * wave, lane);
     __syncthreads();
   }
@@ -544,11 +540,8 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
   // ---- dh = (dz3_c W_2) (h > 0): NB blocks of 32 hidden columns per wavefront
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
-    const int i = I0 + c;
-    if (c + 1 < NB) wloadp(w[(i + 1) & 1], a.w2T + (size_t)(nb2 + c + 1) * BLK, lane);
-    else wloadp(w[(i + 1) & 1], a.w1T + (size_t)(wave * 8 + p * NB) * BLK, lane);          // first block of the d(linear1 input) product
     zero_acc(acc);
-    wmma(acc, w[i & 1], X0 + xo);
+    PD_BLK(I0 + c, X0 + xo);
     const int m = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -581,10 +574,7 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
   zero_acc(acc);
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
-    const int i = I0 + NB + c;
-    if (c + 1 < NB) wloadp(w[(i + 1) & 1], a.w1T + (size_t)(wave * 8 + p * NB + c + 1) * BLK, lane);
-    else wloadp(w[(i + 1) & 1], a.woT + (size_t)wave * BLK, lane);
-    wmma(acc, w[i & 1], Hs + ho + 256 * c);
+    PD_BLK(I0 + NB + c, Hs + ho + 256 * c);
   }
   store_tile_f32r<false>(acc, nullptr, 0, Zs, 32 * wave, lane);
   __syncthreads();
@@ -615,7 +605,7 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
   }
   // ---- d(attention output) = dz2_c W_o
   zero_acc(acc);
-  wmma(acc, w[(I0 + 2 * NB) & 1], X0 + xo);
+  PD_BLK(I0 + 2 * NB, X0 + xo);
   store_tile_bf16<false, false>(acc, nullptr, 0, X1, PA, 32 * wave, lane);
   __syncthreads();
   tile_out(a.d_o, X1, r0, R, tid);
@@ -638,8 +628,10 @@ __global__ __launch_bounds__(NTH) void dec_bwd_a(const BwdA a)
   float *Z2 = Zs + RB * PZ;                                        // d_tp
   float *red = Z2 + RB * PZ;                                       // [8][3][256]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r0 = blockIdx.x * RB, R = a.R;
-  WBlk w[2];
-  wloadp(w[0], a.wqkvT + (size_t)(wave * 3) * BLK, lane);          // [C, 3C]: three contraction blocks per 32 rows
+  constexpr int NBLK = 4;                                          // [W_q; W_k; W_v]^T ([C, 3C]: three contraction blocks per 32 rows) | W_o^T
+  auto bp = [&](int b) { return b < 3 ? a.wqkvT + (size_t)(wave * 3 + b) * BLK : a.woT + (size_t)wave * BLK; };
+  WHalf w[4];
+  PD_HP(0); PD_HP(1); PD_HP(2);
   tile_in(X0, a.dq, r0, R, tid);
   tile_in(X1, a.dk, r0, R, tid);
   tile_in(X2, a.dv, r0, R, tid);
@@ -658,14 +650,11 @@ __global__ __launch_bounds__(NTH) void dec_bwd_a(const BwdA a)
   const int xo = (lane & 15) * PA + 8 * (lane >> 4);
   f32x4 acc[2];
   zero_acc(acc);
-  wloadp(w[1], a.wqkvT + (size_t)(wave * 3 + 1) * BLK, lane);
-  wmma(acc, w[0], X0 + xo);
-  wloadp(w[0], a.wqkvT + (size_t)(wave * 3 + 2) * BLK, lane);
-  wmma(acc, w[1], X1 + xo);
+  PD_BLK(0, X0 + xo);
+  PD_BLK(1, X1 + xo);
   store_tile_f32r<false>(acc, nullptr, 0, Z2, 32 * wave, lane);
   zero_acc(acc);
-  wloadp(w[1], a.woT + (size_t)wave * BLK, lane);
-  wmma(acc, w[0], X2 + xo);
+  PD_BLK(2, X2 + xo);
   store_tile_f32r<false>(acc, nullptr, 0, Zs, 32 * wave, lane);
   __syncthreads();
   {
@@ -696,7 +685,7 @@ __global__ __launch_bounds__(NTH) void dec_bwd_a(const BwdA a)
     flush_colsums<3>(red, outs, tid);
   }
   zero_acc(acc);
-  wmma(acc, w[1], X0 + xo);
+  PD_BLK(3, X0 + xo);
   store_tile_bf16<false, false>(acc, nullptr, 0, X1, PA, 32 * wave, lane);
   __syncthreads();
   tile_out(a.d_o, X1, r0, R, tid);
@@ -705,7 +694,7 @@ constexpr size_t kSmemBwdA = (size_t)3 * RB * PA * 2 + (size_t)2 * RB * PZ * 4 +
 
 // =================================================================================================== weight packing
 // W_eff[n][k] (= src[n][k], or src[k][n] when transposed) -> blocks of 32 n x 256 k, block (nb, kc) at ((nb (K / 256) + kc) BLK), inside a
-// block 16-byte piece (i = 8 t + s, lane) = W_eff[32 nb + 16 t + (lane & 15)][256 kc + 32 s + 8 (lane >> 4) .. + 7]: what wloadp reads
+// block 16-byte piece (i = 8 t + s, lane) = W_eff[32 nb + 16 t + (lane & 15)][256 kc + 32 s + 8 (lane >> 4) .. + 7]: what wloadh reads
 struct PackProblem { const bf16_t *src; bf16_t *dst; int rows, cols, transpose, first_block; };
 
 __global__ __launch_bounds__(256) void dec_pack_grouped(const PackProblem *__restrict__ tab, int count)
