@@ -1250,8 +1250,13 @@ extern "C" int pd_msda_backward(const void *value, const int64_t *spatial_shapes
       const size_t lds4 = ((size_t)kOwnCells4 * 33 + 64) * sizeof(int), lds4h = ((size_t)kOwnCells4H * 17 + 64) * sizeof(int);
       typedef void (*ofn)(const float *, const int64_t *, const int64_t *, const float *, const float *, const float *, float *, float *,
                           float *, int, int, int, unsigned *, unsigned long long *, FusedBwd);
+#ifdef PD_PROBES                                                     // ablation instantiations: the probe library only (make probes)
       const int ai = g_pd_dbg_ablate == 1 ? 1 : g_pd_dbg_ablate == 4 ? 2 : g_pd_dbg_ablate == 7 ? 3 : 0;
       const ofn all4[4] = {msda_bwd_owner4_d32<0>, msda_bwd_owner4_d32<1>, msda_bwd_owner4_d32<4>, msda_bwd_owner4_d32<7>};
+#else
+      const int ai = 0;
+      const ofn all4[1] = {msda_bwd_owner4_d32<0>};
+#endif
       const ofn half4 = msda_bwd_owner4_d32<0, true>;
       static bool a4set[5] = {false, false, false, false, false};
       if (!a4set[ai]) { (void)hipFuncSetAttribute((const void *)all4[ai], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); a4set[ai] = true; }
@@ -1285,14 +1290,20 @@ extern "C" int pd_msda_backward(const void *value, const int64_t *spatial_shapes
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void *)msda_bwd_tiled_d32<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#ifdef PD_PROBES
       (void)hipFuncSetAttribute((const void *)msda_bwd_tiled_d32<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       (void)hipFuncSetAttribute((const void *)msda_bwd_tiled_d32<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       (void)hipFuncSetAttribute((const void *)msda_bwd_tiled_d32<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       (void)hipFuncSetAttribute((const void *)msda_bwd_tiled_d32<4, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
       attr_set = true;
     }
+#ifdef PD_PROBES
     auto tk = g_pd_dbg_ablate == 1 ? msda_bwd_tiled_d32<4, 1> : g_pd_dbg_ablate == 2 ? msda_bwd_tiled_d32<4, 2>
             : g_pd_dbg_ablate == 4 ? msda_bwd_tiled_d32<4, 4> : g_pd_dbg_ablate == 7 ? msda_bwd_tiled_d32<4, 7> : msda_bwd_tiled_d32<4, 0>;
+#else
+    auto tk = msda_bwd_tiled_d32<4, 0>;
+#endif
     // 74 KB of LDS window -> 2 workgroups per CU whatever their size: 512 threads give the gathers 16 waves per CU to hide
     // their latency behind instead of 8 (measured 0.56 -> see DESIGN.md)
     const int nthreads = g_pd_dbg_bwd_threads > 0 ? g_pd_dbg_bwd_threads : 512;
@@ -1383,8 +1394,12 @@ extern "C" int pd_msda_fused_backward(const float *value, const int64_t *spatial
     if (d_oa_amax) (void)hipMemsetAsync(d_oa_amax, 0, (size_t)batch * num_query * sizeof(float), stream);
   }
   const size_t lds4 = ((size_t)kOwnCells4 * 33 + 64) * sizeof(int), lds4h = ((size_t)kOwnCells4H * 17 + 64) * sizeof(int);
+#ifdef PD_PROBES
   const auto k5 = g_pd_dbg_ablate == 8 ? msda_bwd_owner4_d32<8, false, true> : g_pd_dbg_ablate == 32 ? msda_bwd_owner4_d32<32, false, true>
                 : g_pd_dbg_ablate == 96 ? msda_bwd_owner4_d32<96, false, true> : msda_bwd_owner4_d32<0, false, true>;
+#else
+  const auto k5 = msda_bwd_owner4_d32<0, false, true>;
+#endif
   const auto k9 = msda_bwd_owner4_d32<0, true, true>;
   static bool attr = false;
   if (g_pd_dbg_ablate) (void)hipFuncSetAttribute((const void *)k5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);

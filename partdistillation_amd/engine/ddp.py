@@ -191,6 +191,7 @@ class BucketedGradReducer:
     def _exchange_rows_on_stream(self, g, rows, cap, dev):
         views = [g._view(g.grad, p, off).reshape(p.shape[0], -1) for p, off in zip(g.params, g.offsets)]
         over = None
+        no_record, beyond = rows is None, None
         if rows is None:
             # no record: the touched rows are the rows with a non-zero entry — found on the device in a fixed-size form
             nz = views[0].ne(0).any(1)
@@ -203,7 +204,8 @@ class BucketedGradReducer:
         rows = rows.reshape(-1).to(dev)
         if over is None:
             over = torch.full((1,), int(rows.numel() > cap), dtype=torch.int64, device=dev)
-            rows = rows[:cap]                                     # (host-known overflow: flagged, every rank raises at its next check)
+            beyond = rows[cap:] if rows.numel() > cap else None  # host-known overflow: these rows' local gradient is never exchanged
+            rows = rows[:cap]                                     # (flagged: every rank raises at its next check)
         if rows.numel() < cap:                                    # pad to the static size: sentinel rows carry zeros
             rows = torch.cat([rows, rows.new_full((cap - rows.numel(),), -1)])
         valid = rows >= 0
@@ -231,14 +233,22 @@ class BucketedGradReducer:
         else:
             self._overflow.append((any_over, None))
         all_rows = [r[:cap] for r in all_rows]
+        # A truncated exchange is never APPLIED: when any rank's flag is set the group's gradient of this step is zero on every
+        # rank — decided on the device from the gathered flags, identical everywhere, no host read — and the error surfaces at the next
+        # _check_overflow() (the next step, or check_now() before a checkpoint / at the end of training).
+        ok = (any_over == 0).to(g.grad.dtype)
         # sentinel rows arrive with an all-zero payload: clamped to row 0 they zero it (its gradient is rebuilt from the payloads
         # of the ranks that touched it, or is an exact zero anyway) and add zeros — no host branch, no compaction
-        rows_all, pack_all = torch.cat(all_rows).clamp_min(0), torch.cat(all_pack) / self.world
+        rows_all, pack_all = torch.cat(all_rows).clamp_min(0), torch.cat(all_pack) * (ok / self.world)
         col = 0
         for v in views:
             w = v.shape[1]
             v[rows_all] = 0                                       # (v is a view of the flat gradient buffer)
             v.index_add_(0, rows_all, pack_all[:, col:col + w])
+            if beyond is not None:
+                v[beyond] = 0                                     # rows this rank could not send
+            elif no_record:
+                v.mul_(ok)                                        # (rows beyond the device-side search's cap, if any: the dense pass of this path)
             col += w
 
     def finish(self):
@@ -267,6 +277,14 @@ class BucketedGradReducer:
             self._exchange_rows(gi)
         if self.optimizer is not None:
             self.optimizer.grads_ready = True                    # step() must not gather again
+
+    def check_now(self):
+        """wait for the overflow flags of the steps issued so far and raise if one is set: before a checkpoint is written and after the
+        last step (the per-step check is non-blocking and looks at EARLIER steps only)"""
+        for flag, ev in self._overflow:
+            if ev is not None:
+                ev.synchronize()
+        self._check_overflow()
 
     def remove(self):
         for h in self._hooks:

@@ -61,6 +61,7 @@ class TrainStep:
         broadcast_parameters(self.optimizer.flat, 0, process_group)
         self.reducer = BucketedGradReducer(self.optimizer.flat, cfg.MODEL.AMD.DDP_BUCKET_MB, process_group,
                                            optimizer=self.optimizer, sparse_rows_cap=int(cfg.MODEL.AMD.get("DDP_SPARSE_ROWS_CAP", 256)))
+        self._rows_per_image = int(cfg.PART_DISTILLATION.NUM_PART_CLASSES) + 1 if self.reducer.sparse_groups else 0
         if self.reducer.sparse_groups:
             # the static row-sparse exchange sends `cap` rows per rank: a step touches (K + 1) class-head rows per image
             per_rank = -(-int(cfg.SOLVER.IMS_PER_BATCH) // max(self.world, 1))
@@ -96,6 +97,9 @@ class TrainStep:
         """one optimisation step; returns the dict of weighted losses (device scalars, no host sync)."""
         if self._graph is not None and self._signature(batched_inputs) == self._graph_sig:
             return self._replay(batched_inputs)
+        if self.reducer.sparse_groups and len(batched_inputs) * self._rows_per_image > self.reducer.sparse_rows_cap:
+            raise ValueError(f"this step's {len(batched_inputs)} images x (parts + 1) = {len(batched_inputs) * self._rows_per_image} class-head rows exceed "
+                             f"MODEL.AMD.DDP_SPARSE_ROWS_CAP = {self.reducer.sparse_rows_cap} (every rank must be given at most cap // (parts + 1) images)")
         loss_dict = self._forward_backward(batched_inputs)
         self.reducer.finish()
         self.optimizer.step()
@@ -237,6 +241,7 @@ class TrainStep:
     def state_dict(self):
         """checkpoint with the reference's key names: fp32 master weights (modules hold bf16 copies of some), buffers,
         optimizer moments and the iteration."""
+        self.reducer.check_now()                           # a truncated row-sparse exchange of a step already taken raises here, not after the save
         sd = {k: v for k, v in self.model.state_dict().items()}
         sd.update(self.optimizer.flat.master_state())
         return {"model": sd, "optimizer": self.optimizer.state_dict(), "iteration": self.iter}

@@ -82,21 +82,29 @@ def seeded(shape, seed, scale=1.0, dtype=torch.float32):
     return (torch.randn(tuple(shape), generator=g, dtype=torch.float64) * scale).to(dtype)
 
 
+FULL_LIMIT = 1 << 20      # bytes: tensors up to this size are pinned element by element ("full"), larger ones by the strided sample only
+
+
 def digest(t, n=2048):
-    """Compact pin of a tensor: shape, sums and a strided sample."""
+    """Pin of a tensor: shape, sums, a strided sample and — up to FULL_LIMIT bytes — every element."""
     t = t.detach().cpu()
     if t.dtype == torch.bool:
         t = t.to(torch.uint8)
     f = t.reshape(-1)
     stride = max(1, f.numel() // n)
-    return {"shape": torch.tensor(list(t.shape), dtype=torch.int64),
-            "sum": f.double().sum().reshape(1), "abssum": f.double().abs().sum().reshape(1),
-            "sample": f[::stride][:n].clone()}
+    d = {"shape": torch.tensor(list(t.shape), dtype=torch.int64),
+         "sum": f.double().sum().reshape(1), "abssum": f.double().abs().sum().reshape(1),
+         "sample": f[::stride][:n].clone()}
+    if 0 < f.numel() * f.element_size() <= FULL_LIMIT:
+        d["full"] = f.clone()
+    return d
 
 
 def check_digest(t, d, rtol, atol, what=""):
     got = digest(t)
     assert got["shape"].tolist() == d["shape"].tolist(), f"{what}: shape {got['shape'].tolist()} != {d['shape'].tolist()}"
+    if "full" in d:                          # every element (fixtures regenerated in round 6)
+        torch.testing.assert_close(t.detach().cpu().reshape(-1).double(), d["full"].double(), rtol=rtol, atol=atol, msg=lambda m: f"{what} (element-wise): {m}")
     torch.testing.assert_close(got["sample"].double(), d["sample"].double(), rtol=rtol, atol=atol, msg=lambda m: f"{what} sample: {m}")
     n = max(1, t.numel())
     torch.testing.assert_close(got["abssum"], d["abssum"], rtol=max(rtol, 1e-6), atol=atol * n, msg=lambda m: f"{what} abssum: {m}")
@@ -106,10 +114,12 @@ def check_digest_scaled(t, d, frac, what=""):
     """error measured against the tensor's own scale: max|got - want| <= frac * max|want| (deep gradient chains)."""
     got = digest(t)
     assert got["shape"].tolist() == d["shape"].tolist(), f"{what}: shape"
-    want = d["sample"].double()
-    err = (got["sample"].double() - want).abs().max().item()
+    full = "full" in d
+    want = (d["full"] if full else d["sample"]).double()
+    have = (t.detach().cpu().reshape(-1).to(torch.uint8 if t.dtype == torch.bool else t.dtype) if full else got["sample"]).double()
+    err = (have - want).abs().max().item()
     scale = max(want.abs().max().item(), 1e-30)
-    assert err <= frac * scale, f"{what}: max abs err {err:.3e} > {frac} * scale {scale:.3e}"
+    assert err <= frac * scale, f"{what}: max abs err {err:.3e} > {frac} * scale {scale:.3e}" + (" (element-wise)" if full else "")
     assert abs(got["abssum"].item() - d["abssum"].item()) <= frac * d["abssum"].item() + 1e-30, f"{what}: abssum"
 
 

@@ -318,6 +318,64 @@ def test_bucket_issue_schedule_config2():
     assert before_last >= 0.8 * total                                            # (3)
 
 
+def test_bucket_issue_schedule_config2_at_node_granularity():
+    """VERDICT r5 item 8.  The schedule test above fires one hook per parameter; in the product the fused cores are ONE autograd node each
+    (functions/decoder_core.py DecoderCore, functions/encoder_core.py EncoderCore: their weight gradients are grouped launches at the end of
+    the node's backward, so all of a node's gradients arrive when it returns) and the fused ResNet body publishes per stage
+    (resnet_core.py -> BucketedGradReducer.publish).  Here the hooks fire at THAT granularity — a node's parameters all at once, nodes in
+    backward order — and each event carries the share of the backward pass's kernel time that has elapsed when it fires (config 2 at
+    1024 x 1024, profiles/r06_bench_n1_*_steady_kernel_stats.csv: criterion 0.7 ms, decoder core 2.9, mask features / FPN 1.5, encoder core
+    5.6, input projections 0.3, res5 0.35, res4 0.55, res3 0.45, res2 + stem 0.9 of a 13.3 ms backward).  Checked: buckets leave in index
+    order; >= 80 % of the gradient bytes are issued before the LAST node returns (measured 86.3 %: the last bucket, 24 MB, is the stem's).
+    What the granularity costs is visible in the second figure: only 38.9 % of the bytes are on the wire with a fifth of the backward
+    still to run, because the bucket that holds the encoder's 6 M parameters cannot leave before the encoder core returns at 0.80 and
+    every later bucket queues behind it (index order) — per-layer hand-over from inside EncoderCore.backward is what would move it,
+    at the price of splitting its two grouped weight-gradient launches."""
+    from partdistillation_amd.compat import build_model
+    from partdistillation_amd.config import setup_cfg
+    from partdistillation_amd.engine.ddp import BucketedGradReducer
+    from partdistillation_amd.engine.optimizer import build_optimizer
+    import partdistillation_amd.modeling, partdistillation_amd.proposal_model  # noqa: F401,E401
+    cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd", "configs", "proposal_learning", "r50_mask2former.yaml"), ["MODEL.DEVICE", "cpu"])
+    model = build_model(cfg)
+    flat = build_optimizer(cfg, model).flat
+    reducer = BucketedGradReducer(flat, bucket_mb=cfg.MODEL.AMD.DDP_BUCKET_MB)
+    named = [(n, p) for n, p in model.named_parameters() if p in reducer._param_bucket]
+
+    def node_of(n):
+        if ".predictor." in n:
+            return "heads" if (".class_embed." in n or ".mask_embed." in n) else "decoder core"
+        if ".pixel_decoder.transformer." in n:
+            return "encoder core"
+        if ".pixel_decoder.input_proj." in n:
+            return "input projections"
+        if ".pixel_decoder." in n:
+            return "mask features / FPN"
+        for st in ("res5", "res4", "res3", "res2", "stem"):
+            if f"backbone.{st}." in n:
+                return st
+        raise AssertionError(n)
+
+    # (node, elapsed share of the backward's kernel time when its gradients are handed over)
+    schedule = [("heads", 0.05), ("decoder core", 0.27), ("mask features / FPN", 0.38), ("encoder core", 0.80), ("input projections", 0.83),
+                ("res5", 0.86), ("res4", 0.90), ("res3", 0.93), ("res2", 0.97), ("stem", 1.00)]
+    groups = {k: [p for n, p in named if node_of(n) == k] for k, _ in schedule}
+    assert sum(len(v) for v in groups.values()) == len(named) and all(groups[k] for k, _ in schedule)
+    log, now = [], [0.0]
+    reducer._launch = lambda b: log.append((b.index, (b.end - b.start) * flat.groups[b.group].grad.element_size(), now[0]))
+    for k, t in schedule:
+        now[0] = t
+        for p in groups[k]:
+            reducer._on_grad(p)
+    assert [e[0] for e in log] == sorted(e[0] for e in log) and len(log) == len(reducer.buckets)
+    total = sum(e[1] for e in log)
+    before_last = sum(e[1] for e in log if e[2] < 1.0)
+    early = sum(e[1] for e in log if e[2] <= 0.80)
+    print(f"node granularity: {len(log)} buckets, {total / 1e6:.1f} MB; issued before the last node returns {before_last / total:.1%}, with >= 20 % of the "
+          f"backward still to run {early / total:.1%}; issue points {[e[2] for e in log]}")
+    assert before_last >= 0.8 * total and early >= 0.35 * total
+
+
 # ----------------------------------------------------------------------------- gradients handed over from INSIDE a fused node (per stage)
 class _StagedBackward(torch.autograd.Function):
     """stand-in for the fused ResNet body (modeling/backbone/resnet_core.py): one autograd node over several layers that, in data-parallel

@@ -613,8 +613,11 @@ def _swin_w12(g):
 
 
 def _scaled_err(t, d):
-    got, want = C.digest(t)["sample"].double(), d["sample"].double()
     assert C.digest(t)["shape"].tolist() == d["shape"].tolist()
+    if "full" in d:                                                  # every element of the reference's tensor (fixtures of round 6)
+        got, want = t.detach().cpu().reshape(-1).double(), d["full"].double()
+    else:
+        got, want = C.digest(t)["sample"].double(), d["sample"].double()
     return ((got - want).abs().max() / want.abs().max().clamp_min(1e-30)).item()
 
 
@@ -849,8 +852,14 @@ GRAD_TOL_FP32_FULL = 4e-3       # of the tensor maximum: 3 x the measured worst 
 # features by ~1 %, hence the mask logits, hence (sigmoid - label) wherever a logit is near zero — a gradient is a difference of large
 # terms, and every layer below inherits the change.  The library's bf16 kernels (PD_R50_FUSED=0: MIOpen) deviate from fp32 alike
 # (tests/test_r50_fused_gpu.py asserts the fused body's end-to-end deviation against that yardstick).
-GRAD_TOL_BF16_BACKBONE = {"backbone.stem.conv1.weight": 0.32, "backbone.res2.0.conv1.weight": 0.18, "backbone.res4.3.conv2.weight": 0.12,
-                          "backbone.res5.2.conv3.weight": 0.08}
+# Round 6: the bounds are 1.6 x the values measured over rounds 5-6 (relative L2 0.13 / 0.048 / 0.040 / 0.023, largest element deviation
+# 0.104 / 0.065 / 0.044 / 0.043 of the tensor maximum) — they were 0.32 / 0.18 / 0.12 / 0.08 for both.  What they guard is the END-TO-END
+# deviation of a bf16 step (forward included); a backward kernel that lost a few per cent of a gradient is caught per launch by
+# tests/test_r50_fused_gpu.py / test_stem_gpu.py / test_igemm_gpu.py (4e-3 of the tensor maximum against torch fp32 on the SAME operands).
+GRAD_TOL_BF16_BACKBONE = {"backbone.stem.conv1.weight": 0.21, "backbone.res2.0.conv1.weight": 0.08, "backbone.res4.3.conv2.weight": 0.065,
+                          "backbone.res5.2.conv3.weight": 0.04}
+GRAD_TOL_BF16_BACKBONE_MAX = {"backbone.stem.conv1.weight": 0.17, "backbone.res2.0.conv1.weight": 0.105, "backbone.res4.3.conv2.weight": 0.07,
+                              "backbone.res5.2.conv3.weight": 0.07}
 # fp32 losses.  History of the number (profiles/r04_parity.json over its seven commits): 9.3e-5 once (ccb9444: worst term loss_mask_3, with the
 # gradients of mask_features / mask_embed at 1e-4 of their maximum), 1.9e-7 .. 2.9e-7 in the six records since (worst term always a
 # loss_ce_*, those two gradients at 7e-7 .. 9e-7).  No code of the fp32 forward path changed in between (git diff ccb9444 630e9da touches
@@ -957,7 +966,7 @@ def test_config2_full_size_step_vs_oracle(amp):
     _record_parity(f"config2_full_size_{'bf16' if amp else 'fp32'}", **rec, gradient_dev_of_tensor_max=worst, gradient_rel_l2=rel_l2, tolerance_gradient=tol)
     if amp:
         for k in keys:
-            assert worst[k] < tol[k] and rel_l2[k] < tol[k], (k, worst[k], rel_l2[k], tol[k])
+            assert worst[k] < GRAD_TOL_BF16_BACKBONE_MAX[k] and rel_l2[k] < tol[k], (k, worst[k], rel_l2[k], GRAD_TOL_BF16_BACKBONE_MAX[k], tol[k])
     else:
         # the fp32 leg runs the backbone on the LIBRARY's fp32 convolutions (resnet.py: F.conv2d), whose algorithm MIOpen picks per box and per
         # state of its find-db: the same filter gradient measured 1e-4 .. 4e-3 of its maximum across this round's boxes.  1e-2 for those keys;
@@ -1006,6 +1015,7 @@ def test_config2_full_size_batch_of_two_vs_oracle(amp):
 # bf16 — two trajectories that each round their own weights to bf16 every step — terms 1e-3 at step 1 growing to 1.7e-2 (single heads; the sum of the
 # 30 terms stays within 5e-4), norms within 1.6e-2 (at the product's sample points).  The first two fp32 steps are asserted 20 x tighter.
 CURVE_TOL = {False: (2e-2, 1e-3, 1e-2, 1e-3), True: (8e-2, 5e-3, 1e-1, 1.5e-2)}
+UPDATE_TOL = {False: (0.30, 0.60), True: (0.90, 1.20)}   # (median, 90th percentile) of the per-tensor relative L2 of the five steps' updates: provisional, see profiles/r06_parity.json
 CURVE_TOL_FP32_EARLY = (1e-3, 1e-4, 5e-4, 5e-5)          # steps 1-2 of the fp32 curve (measured 2.6e-7 / 9.5e-5; step 3 is 3e-4 .. 1e-3 depending on
                                                          # which fp32 convolution algorithms MIOpen's timing picked on the box)
 
@@ -1032,6 +1042,7 @@ def test_config2_full_size_loss_curve_vs_oracle(amp):
         for n in g.names:
             names.append(n), lrs.append(g.hyper["lr"]), wds.append(g.hyper["weight_decay"])
     params = [osd[n] for n in names]
+    start = {n: osd[n].detach().clone() for n in names}                                  # (the five steps' UPDATES are compared at the end)
     state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     curve = []
@@ -1069,10 +1080,26 @@ def test_config2_full_size_loss_curve_vs_oracle(amp):
     # bias is 5 lr large after five steps on BOTH sides, and the sign of a noise-level gradient component decides which way it went
     worst = max(((master[n].detach().float().cpu() - osd[n].detach()).abs().max() / max(osd[n].detach().abs().max().item(), 5 * lr)).item()
                 for n, lr in zip(names, lrs))
-    print(f"full-size curve amp={amp}: parameters after 5 steps within {worst:.2e} of their scale")
+    # the five steps' UPDATES per tensor, relative L2 (a bound that can fail: a wrong update direction of a tensor is ~1.4, a missing one 1.0).
+    # AdamW's first steps move every element by ~lr whatever its gradient's size, so elements whose gradient is noise-level go either way on
+    # both sides and the per-tensor figure has a floor that grows with the share of such elements: reported for every tensor, asserted on the
+    # weight matrices (>= 4 096 elements) through the median and the 90th percentile over tensors.
+    upd = {}
+    for n in names:
+        if osd[n].numel() < 4096:
+            continue
+        du_o = osd[n].detach() - start[n]
+        du_p = master[n].detach().float().cpu() - start[n]
+        upd[n] = ((du_p - du_o).norm() / du_o.norm().clamp_min(1e-30)).item()
+    vals = sorted(upd.values())
+    med, p90 = vals[len(vals) // 2], vals[int(0.9 * (len(vals) - 1))]
+    print(f"full-size curve amp={amp}: parameters after 5 steps within {worst:.2e} of their scale; update deviation (relative L2 per tensor) median {med:.3f}, "
+          f"90th percentile {p90:.3f}, max {vals[-1]:.3f} over {len(vals)} weight matrices")
     _record_parity(f"config2_full_size_curve_{'bf16' if amp else 'fp32'}", curve=curve, params_dev_of_scale_after_5_steps=worst, tolerance_rel=rel,
-                   tolerance_abs=ab, tolerance_grad_norm_rel=nrel, precision="bf16 autocast" if amp else "fp32")
-    assert worst < (2.0 if amp else 0.5), worst       # (bf16: a flipped sign of a noise-level gradient component is 2 lr per step = 2.0 of the 5 lr scale at most)
+                   tolerance_abs=ab, tolerance_grad_norm_rel=nrel, precision="bf16 autocast" if amp else "fp32",
+                   update_rel_l2_median=med, update_rel_l2_p90=p90, update_rel_l2_max=vals[-1])
+    assert worst < (1.2 if amp else 0.06), worst      # measured 0.68-0.94 (bf16: below one full sign flip over the five steps = 2.0) / 0.019-0.032 (fp32)
+    assert med < UPDATE_TOL[amp][0] and p90 < UPDATE_TOL[amp][1], (med, p90, vals[-1])
 
 
 def test_base_pixel_decoder_gpu_vs_reference_golden(golden):
