@@ -1015,7 +1015,9 @@ def test_config2_full_size_batch_of_two_vs_oracle(amp):
 # bf16 — two trajectories that each round their own weights to bf16 every step — terms 1e-3 at step 1 growing to 1.7e-2 (single heads; the sum of the
 # 30 terms stays within 5e-4), norms within 1.6e-2 (at the product's sample points).  The first two fp32 steps are asserted 20 x tighter.
 CURVE_TOL = {False: (2e-2, 1e-3, 1e-2, 1e-3), True: (8e-2, 5e-3, 1e-1, 1.5e-2)}
-UPDATE_TOL = {False: (0.30, 0.60), True: (0.90, 1.20)}   # (median, 90th percentile) of the per-tensor relative L2 of the five steps' updates: provisional, see profiles/r06_parity.json
+# (median, 90th percentile, max) over the weight matrices of the per-tensor relative L2 of the five steps' updates.  Measured (profiles/r06_parity.json):
+# fp32 0.0035 / 0.011 / 0.026, bf16 0.109 / 0.19 / 0.30 — a tensor whose update went the wrong way would read ~1.4, a missing one 1.0
+UPDATE_TOL = {False: (0.01, 0.03, 0.08), True: (0.20, 0.35, 0.60)}
 CURVE_TOL_FP32_EARLY = (1e-3, 1e-4, 5e-4, 5e-5)          # steps 1-2 of the fp32 curve (measured 2.6e-7 / 9.5e-5; step 3 is 3e-4 .. 1e-3 depending on
                                                          # which fp32 convolution algorithms MIOpen's timing picked on the box)
 
@@ -1098,8 +1100,8 @@ def test_config2_full_size_loss_curve_vs_oracle(amp):
     _record_parity(f"config2_full_size_curve_{'bf16' if amp else 'fp32'}", curve=curve, params_dev_of_scale_after_5_steps=worst, tolerance_rel=rel,
                    tolerance_abs=ab, tolerance_grad_norm_rel=nrel, precision="bf16 autocast" if amp else "fp32",
                    update_rel_l2_median=med, update_rel_l2_p90=p90, update_rel_l2_max=vals[-1])
-    assert worst < (1.2 if amp else 0.06), worst      # measured 0.68-0.94 (bf16: below one full sign flip over the five steps = 2.0) / 0.019-0.032 (fp32)
-    assert med < UPDATE_TOL[amp][0] and p90 < UPDATE_TOL[amp][1], (med, p90, vals[-1])
+    assert worst < (1.2 if amp else 0.09), worst      # measured 0.68-0.94 (bf16: below one full sign flip over the five steps = 2.0) / 0.019-0.045 (fp32)
+    assert med < UPDATE_TOL[amp][0] and p90 < UPDATE_TOL[amp][1] and vals[-1] < UPDATE_TOL[amp][2], (med, p90, vals[-1])
 
 
 def test_base_pixel_decoder_gpu_vs_reference_golden(golden):
