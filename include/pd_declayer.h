@@ -45,6 +45,13 @@ typedef struct PdDecPack {
 int64_t pd_dec_pack_table_bytes(int count);
 int pd_dec_pack_grouped(const PdDecPack *descs, int count, void *table_host_pinned, void *table_device, void *stream);
 
+/* pd_dec_fwd_b / pd_dec_bwd_b with a workspace run the FFN part as TWO launches: pd_dec_split() workgroups per row block (PD_DEC_SPLIT = 2 | 4 | 8,
+ * default 4; 1: one launch) each take 1 / split of the hidden columns and leave fp32 partial rows in the workspace, the second launch (one
+ * workgroup per row block) sums them in slab order and finishes the chain.  workspace: pd_dec_workspace_bytes(R) bytes, no initial state, not
+ * shared by launches that can overlap; NULL: one launch. */
+int pd_dec_split(void);
+int64_t pd_dec_workspace_bytes(int R);
+
 /* x = bf16(o W_o^T + b_o);  z = x + res;  y = LayerNorm(z) * ln_w + ln_b;  y_c = bf16(y);  ypos_c = bf16(y + qpos[r / pos_div]);
  * q = bf16(ypos_c W_q^T + b_q), k = bf16(ypos_c W_k^T + b_k), v = bf16(y_c W_v^T + b_v)   (w_qkv = [W_q; W_k; W_v], [3C, C]) */
 int pd_dec_fwd_a(const void *o, const float *res, const float *qpos, int pos_div, const void *w_o, const void *b_o, const float *ln_w,
@@ -62,7 +69,7 @@ int pd_dec_fwd_b(const void *o, const float *res, const float *qpos, int pos_div
                  const float *ln3_b, const float *dn_w, const float *dn_b, const void *m0_w, const void *m0_b, const void *m1_w,
                  const void *m1_b, const void *m2_w, const void *m2_b, const void *wq_next, const void *bq_next, float eps, float *z2,
                  float *stats2, void *y2_c, void *h, float *z3, float *stats3, float *y3, void *ypos_c, float *dec_out, float *hstats,
-                 void *ef, void *qc_next, int R, int flags, void *stream);
+                 void *ef, void *qc_next, void *workspace, int R, int flags, void *stream);
 
 /* backward of pd_dec_fwd_b's layer part (no gradient flows through the mask-embedding MLP inside the loop: the reference detaches
  * the per-layer mask prediction, :457; the gradient-carrying heads run outside on the stack of decoder outputs):
@@ -77,7 +84,7 @@ int pd_dec_bwd_b(const void *dqc_next, const void *wqT_next, const float *d_out,
                  const float *dn_w, float *dgb_dn, const float *z3, const float *stats3, const float *ln3_w, float *dgb3, float *db3,
                  float *pos_acc, int pos_div, const void *w2T, const void *h, const void *w1T, const float *z2, const float *stats2,
                  const float *ln2_w, float *dgb2, float *db2, const void *woT, void *dz3_c, void *dh, float *dz2, void *dz2_c, void *d_o,
-                 int R, void *stream);
+                 void *workspace, int R, void *stream);
 
 /* backward of pd_dec_fwd_a:
  *   d_tp = bf16(dq W_q + dk W_k), d_tc = bf16(dv W_v)             (wqkvT = [W_q; W_k; W_v]^T, [C, 3C])

@@ -15,6 +15,7 @@
 // taken in the same order as there.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pd_common.h"
 #include "pd_msda.h"
@@ -203,6 +204,23 @@ __device__ __forceinline__ void wmmah(f32x4 (&acc)[2], const WHalf &w, const bf1
 #define PD_HP(h) do { if ((h) < 2 * NBLK) wloadh(w[(h) & 3], bp((h) >> 1), (h) & 1, lane); } while (0)
 #define PD_BLK(b, XS) do { PD_HP(2 * (b) + 3); wmmah(acc, w[(2 * (b)) & 3], (XS)); PD_HP(2 * (b) + 4); wmmah(acc, w[(2 * (b) + 1) & 3], (XS) + 128); } while (0)
 
+// ---- the FFN cut in two launches (PART 1 / PART 2 of dec_fwd_b / dec_bwd_b): PART 1 runs P workgroups per row block, each with 1 / P of the
+// hidden columns, and leaves fp32 partial rows [16][256] in its slab; PART 2 (one workgroup per row block, the NEXT launch: the kernel
+// boundary is the synchronisation) sums the slabs in slab order.  An in-launch seam (ticket + last arriver) measured 33 / 38 / 56 us at
+// P = 2 / 4 / 8 against 25.5 for one workgroup per row block; two launches pay one boundary (~1.5 us) instead.
+__device__ __forceinline__ void slab_store(float *__restrict__ slab, const f32x4 (&acc)[2], int nb, int lane)
+{
+  const int m = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) st4(slab + m * C + nb + 16 * t + 4 * g, make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]));
+}
+__device__ __forceinline__ float4 slab_sum(const float *__restrict__ slabs, int P, int row, int lane)
+{
+  float4 s = zero4();
+  for (int p = 0; p < P; ++p) s = add4(s, ld4(slabs + (size_t)p * (RB * C) + row * C + 4 * lane));
+  return s;
+}
+
 // =================================================================================================== forward A
 struct FwdA {
   const bf16_t *o; const float *res, *qpos; int pos_div;
@@ -287,16 +305,19 @@ struct FwdB {
   const bf16_t *w_1, *b_1, *w_2, *b_2; const float *ln3_w, *ln3_b, *dn_w, *dn_b;
   const bf16_t *m_w[3], *m_b[3], *wq_next, *bq_next; float eps;
   float *z2, *stats2; bf16_t *y2_c, *h; float *z3, *stats3, *y3; bf16_t *ypos_c; float *dec_out, *hstats;
-  bf16_t *ef, *qc_next; int R;
+  bf16_t *ef, *qc_next; int R; float *slabs, *rows; int nsplit;
 };
 
 // (Measured and dropped: P workgroups per row block that each take 1 / P of the hidden columns and meet in fp32 slabs, the last to arrive
 //  finishing the layer — 25.5 us with one workgroup per row block against 33 / 38 / 56 us at P = 2 / 4 / 8: the seam costs more than the
 //  shorter weight stream saves.)
-template <bool LAYER, bool MLP>
+// PART 0: the whole chain, one workgroup per row block.  PART 1 (grid x P): output projection + LN + this workgroup's hidden columns through
+// linear1 / linear2 -> slab (and, from p = 0, the fp32 rows of y2).  PART 2 (LAYER = false here): y3 from the slabs, then the head.
+template <int P, int PART, bool LAYER, bool MLP>
 __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
 {
-  constexpr int P = 1, NB = 8 / P, HW = FF / P, PHS = HW + 8;     // blocks per wavefront and phase; hidden columns / LDS pitch
+  static_assert(PART != 2 || !LAYER, "PART 2 starts behind the FFN");
+  constexpr int NB = 8 / P, HW = FF / P, PHS = HW + 8;            // blocks per wavefront and phase; hidden columns / LDS pitch of this workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t *X0 = reinterpret_cast<bf16_t *>(smem);
   bf16_t *X1 = X0 + RB * PA;
@@ -311,11 +332,11 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
   const int rb = blockIdx.x / P, p = blockIdx.x - rb * P, r0 = rb * RB;
   constexpr int B1 = C, B2 = C + FF, BM = 2 * C + FF, BQ = 5 * C + FF;
   constexpr int I0 = LAYER ? 2 * NB + 1 : 0;                       // index of the first MLP block in this wavefront's block sequence
-  constexpr int NBLK = I0 + (MLP ? 4 : 0);                         // W_o | W_1 x 8 | W_2 x 8 | M_0 M_1 M_2 | W_q of the next layer
+  constexpr int NBLK = I0 + (MLP && PART != 1 ? 4 : 0);            // W_o | W_1 x NB | W_2 x NB | M_0 M_1 M_2 | W_q of the next layer
   auto bp = [&](int b) -> const bf16_t * {
     if (LAYER && b == 0) return a.w_o + (size_t)wave * BLK;
-    if (LAYER && b <= NB) return a.w_1 + (size_t)(8 * wave + b - 1) * BLK;
-    if (LAYER && b <= 2 * NB) return a.w_2 + (size_t)(8 * wave + b - NB - 1) * BLK;
+    if (LAYER && b <= NB) return a.w_1 + (size_t)(p * (64 / P) + wave * NB + b - 1) * BLK;
+    if (LAYER && b <= 2 * NB) return a.w_2 + (size_t)(8 * wave + p * NB + b - NB - 1) * BLK;
     const int j = b - I0;
     return (j == 0 ? a.m_w[0] : j == 1 ? a.m_w[1] : j == 2 ? a.m_w[2] : a.wq_next) + (size_t)wave * BLK;
   };
@@ -331,7 +352,12 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
     lds_copy_f32(Ls + 2 * C, a.ln3_w, C, tid);
     lds_copy_f32(Ls + 3 * C, a.ln3_b, C, tid);
   }
-  if (MLP) {
+  if (PART == 2) {
+    lds_copy_bf16(Bs + B2, a.b_2, C, tid);
+    lds_copy_f32(Ls + 2 * C, a.ln3_w, C, tid);
+    lds_copy_f32(Ls + 3 * C, a.ln3_b, C, tid);
+  }
+  if (MLP && PART != 1) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) lds_copy_bf16(Bs + BM + j * C, a.m_b[j], C, tid);
     lds_copy_bf16(Bs + BQ, a.bq_next, C, tid);
@@ -341,7 +367,8 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {                                    // parked in LDS: not in registers under the products
     const int row = 2 * wave + i, m = min(r0 + row, R - 1);
-    st4(Ys + row * PZ + 4 * lane, ld4(a.res + (size_t)m * C + 4 * lane));
+    // PART 2: the residual rows are PART 1's y2 (workspace); otherwise the kernel's input rows
+    st4(Ys + row * PZ + 4 * lane, ld4((PART == 2 ? a.rows : a.res) + (size_t)m * C + 4 * lane));
     st4(Ps + row * PZ + 4 * lane, ld4(a.qpos + (size_t)(m / a.pos_div) * C + 4 * lane));
   }
   __syncthreads();
@@ -363,6 +390,7 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
       st4(Ys + row * PZ + 4 * lane, y);
       if (p == 0 && m < R) {
         st4(a.z2 + (size_t)m * C + 4 * lane, zv);
+        if (PART == 1) st4(a.rows + (size_t)m * C + 4 * lane, y);
         if (lane == 0) { a.stats2[m] = mu; a.stats2[R + m] = rs; }
       }
     }
@@ -390,6 +418,10 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
     for (int c = 0; c < NB; ++c) {
       PD_BLK(NB + 1 + c, Hs + ho + 256 * c);
     }
+    if (PART == 1) {
+      slab_store(a.slabs + (size_t)(rb * P + p) * (RB * C), acc, 32 * wave, lane);
+      return;
+    }
     store_tile_f32r<true>(acc, Bs + B2, 32 * wave, Zs, 32 * wave, lane);
     __syncthreads();
   }
@@ -399,8 +431,15 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
     const int row = 2 * wave + i, m = r0 + row;
     float4 y3 = ld4(Ys + row * PZ + 4 * lane);
     float mu, rs;
-    if (LAYER) {
-      const float4 zv = add4(ld4(Zs + row * PZ + 4 * lane), y3);
+    if (LAYER || PART == 2) {
+      float4 x3;
+      if (PART == 2) {                                             // the slabs' sum + bias, rounded like the bf16 Linear's output
+        x3 = add4(slab_sum(a.slabs + (size_t)rb * a.nsplit * (RB * C), a.nsplit, row, lane), bf4(Bs + B2 + 4 * lane));
+        x3 = make_float4(rbf(x3.x), rbf(x3.y), rbf(x3.z), rbf(x3.w));
+      } else {
+        x3 = ld4(Zs + row * PZ + 4 * lane);
+      }
+      const float4 zv = add4(x3, y3);
       y3 = ln_row(zv, ld4(Ls + 2 * C + 4 * lane), ld4(Ls + 3 * C + 4 * lane), a.eps, mu, rs);
       if (m < R) {
         st4(a.z3 + (size_t)m * C + 4 * lane, zv);
@@ -444,20 +483,26 @@ __global__ __launch_bounds__(NTH) void dec_fwd_b(const FwdB a)
     }
   }
 }
-constexpr size_t kSmemFwdB = (size_t)3 * RB * PA * 2 + (size_t)RB * (FF + 8) * 2 + (size_t)3 * RB * PZ * 4 + (size_t)(6 * C + FF) * 2 + 6 * C * 4;
+template <int P>
+constexpr size_t smem_fwd_b()
+{
+  return (size_t)3 * RB * PA * 2 + (size_t)RB * ((FF / P + 8) > PA ? (FF / P + 8) : PA) * 2 + (size_t)3 * RB * PZ * 4 + (size_t)(6 * C + FF) * 2 + 6 * C * 4;
+}
 
 // =================================================================================================== backward B
 struct BwdB {
   const bf16_t *dqc_next, *wqT_next; const float *d_out, *d_res, *y3, *hstats, *dn_w; float *dgb_dn;
   const float *z3, *stats3, *ln3_w; float *dgb3, *db3, *pos_acc; int pos_div;
   const bf16_t *w2T, *h, *w1T; const float *z2, *stats2, *ln2_w; float *dgb2, *db2; const bf16_t *woT;
-  bf16_t *dz3_c, *dh; float *dz2; bf16_t *dz2_c, *d_o; int R;
+  bf16_t *dz3_c, *dh; float *dz2; bf16_t *dz2_c, *d_o; int R; float *slabs, *rows; int nsplit;
 };
 
-template <bool NXT>
+// PART 0: the whole chain.  PART 1 (grid x P): (d_pos) + both LayerNorm backwards + this workgroup's hidden columns of dh and its share of
+// dx -> slab (from p = 0: dz3_c, the column sums, the fp32 rows of dz3).  PART 2: dx from the slabs, LayerNorm backward, d_o.
+template <int P, int PART, bool NXT>
 __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
 {
-  constexpr int P = 1, NB = 8 / P, HW = FF / P, PHS = HW + 8;
+  constexpr int NB = 8 / P, HW = FF / P, PHS = HW + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t *X0 = reinterpret_cast<bf16_t *>(smem);
   bf16_t *X1 = X0 + RB * PA;
@@ -468,14 +513,22 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
   float *Gs = Ls + 3 * C;                                          // [16][PZ] dz3 rows (owner lanes only)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, R = a.R;
   const int rb = blockIdx.x / P, p = blockIdx.x - rb * P, r0 = rb * RB;
-  constexpr int I0 = NXT ? 1 : 0, NBLK = I0 + 2 * NB + 1;          // (W_q^T of the next layer) | W_2^T x 8 | W_1^T x 8 | W_o^T
+  constexpr int I0 = NXT ? 1 : 0;                                  // (W_q^T of the next layer) | W_2^T x NB | W_1^T x NB | W_o^T
+  constexpr int IW = PART == 2 ? 0 : I0 + 2 * NB;                  // index of the W_o^T block (PART 2: its only block)
+  constexpr int NBLK = PART == 1 ? I0 + 2 * NB : IW + 1;
   auto bp = [&](int b) -> const bf16_t * {
+    if (PART == 2) return a.woT + (size_t)wave * BLK;
     if (NXT && b == 0) return a.wqT_next + (size_t)wave * BLK;
     const int j = b - I0;
-    return j < NB ? a.w2T + (size_t)(8 * wave + j) * BLK : j < 2 * NB ? a.w1T + (size_t)(8 * wave + j - NB) * BLK : a.woT + (size_t)wave * BLK;
+    return j < NB ? a.w2T + (size_t)(p * (64 / P) + wave * NB + j) * BLK
+                  : j < 2 * NB ? a.w1T + (size_t)(8 * wave + p * NB + j - NB) * BLK : a.woT + (size_t)wave * BLK;
   };
   WHalf w[4];
   PD_HP(0); PD_HP(1); PD_HP(2);
+  const int xo = (lane & 15) * PA + 8 * (lane >> 4);
+  f32x4 acc[2];
+  lds_copy_f32(Ls + 2 * C, a.ln2_w, C, tid);
+  if (PART != 2) {
   if (NXT) tile_in(X0, a.dqc_next, r0, R, tid);
 #pragma unroll
   for (int i = 0; i < HW * RB / 8 / NTH; ++i) {
@@ -484,7 +537,6 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
   }
   lds_copy_f32(Ls, a.dn_w, C, tid);
   lds_copy_f32(Ls + C, a.ln3_w, C, tid);
-  lds_copy_f32(Ls + 2 * C, a.ln2_w, C, tid);
   float4 dy[2], y3v[2], z3v[2];                                    // this wavefront's rows of the LayerNorm phases
   float st[2][4];
 #pragma unroll
@@ -497,8 +549,6 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
     st[i][2] = a.stats3[m]; st[i][3] = a.stats3[R + m];
   }
   __syncthreads();
-  const int xo = (lane & 15) * PA + 8 * (lane >> 4);
-  f32x4 acc[2];
   if (NXT) {                                                       // d(y3 + pos) from the next layer's cross-attention queries
     zero_acc(acc);
     PD_BLK(0, X0 + xo);
@@ -527,6 +577,7 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
       ad = add4(ad, o);
       st4(Gs + row * PZ + 4 * lane, o);
       st_bf4(X0 + row * PA + 4 * lane, o);
+      if (PART == 1 && p == 0 && valid) st4(a.rows + (size_t)mr * C + 4 * lane, o);        // dz3 (fp32) for PART 2
     }
     float *rw = red + wave * 5 * C + 4 * lane;
     st4(rw, ag_dn); st4(rw + C, ab_dn); st4(rw + 2 * C, ag); st4(rw + 3 * C, ab); st4(rw + 4 * C, ad);
@@ -563,20 +614,30 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
   }
   // ---- dx = dh W_1 over this workgroup's hidden columns
   const int ho = (lane & 15) * PHS + 8 * (lane >> 4);
-  float4 z2v[2];
-  float st2[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = min(r0 + 2 * wave + i, R - 1);
-    z2v[i] = ld4(a.z2 + (size_t)m * C + 4 * lane);
-    st2[i][0] = a.stats2[m]; st2[i][1] = a.stats2[R + m];
-  }
   zero_acc(acc);
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
     PD_BLK(I0 + NB + c, Hs + ho + 256 * c);
   }
+  if (PART == 1) {
+    slab_store(a.slabs + (size_t)(rb * P + p) * (RB * C), acc, 32 * wave, lane);
+    return;
+  }
   store_tile_f32r<false>(acc, nullptr, 0, Zs, 32 * wave, lane);
+  }                                                                // (PART != 2)
+  float4 z2v[2];
+  float st2[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 2 * wave + i, m = min(r0 + row, R - 1);
+    z2v[i] = ld4(a.z2 + (size_t)m * C + 4 * lane);
+    st2[i][0] = a.stats2[m]; st2[i][1] = a.stats2[R + m];
+    if (PART == 2) {                                               // dz3 from PART 1's rows, dx = the slabs' sum rounded like the bf16 product's output
+      st4(Gs + row * PZ + 4 * lane, ld4(a.rows + (size_t)m * C + 4 * lane));
+      const float4 dx = slab_sum(a.slabs + (size_t)rb * a.nsplit * (RB * C), a.nsplit, row, lane);
+      st4(Zs + row * PZ + 4 * lane, make_float4(rbf(dx.x), rbf(dx.y), rbf(dx.z), rbf(dx.w)));
+    }
+  }
   __syncthreads();
   {
     float4 ag = zero4(), ab = zero4(), ad = zero4();
@@ -605,12 +666,16 @@ __global__ __launch_bounds__(NTH) void dec_bwd_b(const BwdB a)
   }
   // ---- d(attention output) = dz2_c W_o
   zero_acc(acc);
-  PD_BLK(I0 + 2 * NB, X0 + xo);
+  PD_BLK(IW, X0 + xo);
   store_tile_bf16<false, false>(acc, nullptr, 0, X1, PA, 32 * wave, lane);
   __syncthreads();
   tile_out(a.d_o, X1, r0, R, tid);
 }
-constexpr size_t kSmemBwdB = (size_t)2 * RB * PA * 2 + (size_t)RB * (FF + 8) * 2 + (size_t)2 * RB * PZ * 4 + (size_t)NW * 5 * C * 4 + 3 * C * 4;
+template <int P>
+constexpr size_t smem_bwd_b()
+{
+  return (size_t)2 * RB * PA * 2 + (size_t)RB * (FF / P + 8) * 2 + (size_t)2 * RB * PZ * 4 + (size_t)NW * 5 * C * 4 + 3 * C * 4;
+}
 
 // =================================================================================================== backward A
 struct BwdA {
@@ -748,25 +813,53 @@ int allow_smem(K kernel, size_t bytes, const char *who)
   return PD_OK;
 }
 
-template <bool LAYER, bool MLP>
+int g_split = -1;                                                  // workgroups per row block of the FFN launches (PD_DEC_SPLIT = 1: one launch; 2 | 4 | 8: two launches)
+int split_mode()
+{
+  if (g_split < 0) {
+    const char *e = getenv("PD_DEC_SPLIT");
+    const int v = e ? atoi(e) : 4;
+    g_split = (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4;
+  }
+  return g_split;
+}
+
+template <int P, int PART, bool LAYER, bool MLP>
 int launch_fwd_b(const FwdB &a, hipStream_t s)
 {
-  static int ok = allow_smem(dec_fwd_b<LAYER, MLP>, kSmemFwdB, "pd_dec_fwd_b");
+  static int ok = allow_smem(dec_fwd_b<P, PART, LAYER, MLP>, smem_fwd_b<P>(), "pd_dec_fwd_b");
   if (ok != PD_OK) return ok;
-  hipLaunchKernelGGL((dec_fwd_b<LAYER, MLP>), dim3((a.R + RB - 1) / RB), dim3(NTH), kSmemFwdB, s, a);
+  hipLaunchKernelGGL((dec_fwd_b<P, PART, LAYER, MLP>), dim3(((a.R + RB - 1) / RB) * (PART == 1 ? P : 1)), dim3(NTH), smem_fwd_b<P>(), s, a);
   return pd_check_launch("pd_dec_fwd_b");
 }
-template <bool NXT>
+// the layer part as two launches: P workgroups per row block through the FFN, then one per row block from the slabs
+template <int P>
+int launch_fwd_b_split(const FwdB &a, bool mlp, hipStream_t s)
+{
+  const int rc = launch_fwd_b<P, 1, true, false>(a, s);
+  if (rc != PD_OK) return rc;
+  return mlp ? launch_fwd_b<1, 2, false, true>(a, s) : launch_fwd_b<1, 2, false, false>(a, s);
+}
+template <int P, int PART, bool NXT>
 int launch_bwd_b(const BwdB &a, hipStream_t s)
 {
-  static int ok = allow_smem(dec_bwd_b<NXT>, kSmemBwdB, "pd_dec_bwd_b");
+  static int ok = allow_smem(dec_bwd_b<P, PART, NXT>, smem_bwd_b<P>(), "pd_dec_bwd_b");
   if (ok != PD_OK) return ok;
-  hipLaunchKernelGGL((dec_bwd_b<NXT>), dim3((a.R + RB - 1) / RB), dim3(NTH), kSmemBwdB, s, a);
+  hipLaunchKernelGGL((dec_bwd_b<P, PART, NXT>), dim3(((a.R + RB - 1) / RB) * (PART == 1 ? P : 1)), dim3(NTH), smem_bwd_b<P>(), s, a);
   return pd_check_launch("pd_dec_bwd_b");
+}
+template <int P>
+int launch_bwd_b_split(const BwdB &a, hipStream_t s)
+{
+  const int rc = a.dqc_next ? launch_bwd_b<P, 1, true>(a, s) : launch_bwd_b<P, 1, false>(a, s);
+  if (rc != PD_OK) return rc;
+  return launch_bwd_b<1, 2, false>(a, s);
 }
 
 }  // namespace
 
+extern "C" int pd_dec_split(void) { return split_mode(); }
+extern "C" int64_t pd_dec_workspace_bytes(int R) { return R <= 0 ? 0 : (int64_t)((R + RB - 1) / RB) * (8 + 1) * RB * C * 4; }
 extern "C" int64_t pd_dec_pack_table_bytes(int count) { return (int64_t)count * sizeof(PackProblem); }
 
 extern "C" int pd_dec_pack_grouped(const PdDecPack *descs, int count, void *table_host_pinned, void *table_device, void *stream)
@@ -809,7 +902,7 @@ extern "C" int pd_dec_fwd_b(const void *o, const float *res, const float *qpos, 
                             const float *ln3_b, const float *dn_w, const float *dn_b, const void *m0_w, const void *m0_b, const void *m1_w,
                             const void *m1_b, const void *m2_w, const void *m2_b, const void *wq_next, const void *bq_next, float eps, float *z2,
                             float *stats2, void *y2_c, void *h, float *z3, float *stats3, float *y3, void *ypos_c, float *dec_out, float *hstats,
-                            void *ef, void *qc_next, int R, int flags, void *stream)
+                            void *ef, void *qc_next, void *workspace, int R, int flags, void *stream)
 {
   const bool layer = flags & 1, mlp = flags & 2;
   if (!res || !qpos || !dn_w || !dn_b || !ypos_c || !dec_out || !hstats) return pd_set_error(PD_ERR_INVALID_ARG, "pd_dec_fwd_b: null pointer");
@@ -823,17 +916,23 @@ extern "C" int pd_dec_fwd_b(const void *o, const float *res, const float *qpos, 
          (const bf16_t *)w_2, (const bf16_t *)b_2, ln3_w, ln3_b, dn_w, dn_b,
          {(const bf16_t *)m0_w, (const bf16_t *)m1_w, (const bf16_t *)m2_w}, {(const bf16_t *)m0_b, (const bf16_t *)m1_b, (const bf16_t *)m2_b},
          (const bf16_t *)wq_next, (const bf16_t *)bq_next, eps, z2, stats2, (bf16_t *)y2_c, (bf16_t *)h, z3, stats3, y3, (bf16_t *)ypos_c, dec_out, hstats,
-         (bf16_t *)ef, (bf16_t *)qc_next, R};
+         (bf16_t *)ef, (bf16_t *)qc_next, R, reinterpret_cast<float *>(workspace),
+         reinterpret_cast<float *>(workspace) + (size_t)((R + RB - 1) / RB) * 8 * RB * C, (layer && workspace) ? split_mode() : 1};
   hipStream_t s = (hipStream_t)stream;
-  if (!layer) return mlp ? launch_fwd_b<false, true>(a, s) : launch_fwd_b<false, false>(a, s);
-  return mlp ? launch_fwd_b<true, true>(a, s) : launch_fwd_b<true, false>(a, s);
+  if (!layer) return mlp ? launch_fwd_b<1, 0, false, true>(a, s) : launch_fwd_b<1, 0, false, false>(a, s);
+  switch (a.nsplit) {
+    case 2: return launch_fwd_b_split<2>(a, mlp, s);
+    case 4: return launch_fwd_b_split<4>(a, mlp, s);
+    case 8: return launch_fwd_b_split<8>(a, mlp, s);
+    default: return mlp ? launch_fwd_b<1, 0, true, true>(a, s) : launch_fwd_b<1, 0, true, false>(a, s);
+  }
 }
 
 extern "C" int pd_dec_bwd_b(const void *dqc_next, const void *wqT_next, const float *d_out, const float *d_res, const float *y3, const float *hstats,
                             const float *dn_w, float *dgb_dn, const float *z3, const float *stats3, const float *ln3_w, float *dgb3, float *db3,
                             float *pos_acc, int pos_div, const void *w2T, const void *h, const void *w1T, const float *z2, const float *stats2,
                             const float *ln2_w, float *dgb2, float *db2, const void *woT, void *dz3_c, void *dh, float *dz2, void *dz2_c, void *d_o,
-                            int R, void *stream)
+                            void *workspace, int R, void *stream)
 {
   if (!d_out || !y3 || !hstats || !dn_w || !dgb_dn || !z3 || !stats3 || !ln3_w || !dgb3 || !db3 || !w2T || !h || !w1T || !z2 || !stats2 || !ln2_w ||
       !dgb2 || !db2 || !woT || !dz3_c || !dh || !dz2 || !dz2_c || !d_o)
@@ -842,9 +941,15 @@ extern "C" int pd_dec_bwd_b(const void *dqc_next, const void *wqT_next, const fl
   if (R <= 0 || pos_div <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_dec_bwd_b: R = %d, pos_div = %d", R, pos_div);
   BwdB a{(const bf16_t *)dqc_next, (const bf16_t *)wqT_next, d_out, d_res, y3, hstats, dn_w, dgb_dn, z3, stats3, ln3_w, dgb3, db3, pos_acc, pos_div,
          (const bf16_t *)w2T, (const bf16_t *)h, (const bf16_t *)w1T, z2, stats2, ln2_w, dgb2, db2, (const bf16_t *)woT, (bf16_t *)dz3_c, (bf16_t *)dh, dz2,
-         (bf16_t *)dz2_c, (bf16_t *)d_o, R};
+         (bf16_t *)dz2_c, (bf16_t *)d_o, R, reinterpret_cast<float *>(workspace),
+         reinterpret_cast<float *>(workspace) + (size_t)((R + RB - 1) / RB) * 8 * RB * C, workspace ? split_mode() : 1};
   hipStream_t s = (hipStream_t)stream;
-  return a.dqc_next ? launch_bwd_b<true>(a, s) : launch_bwd_b<false>(a, s);
+  switch (a.nsplit) {
+    case 2: return launch_bwd_b_split<2>(a, s);
+    case 4: return launch_bwd_b_split<4>(a, s);
+    case 8: return launch_bwd_b_split<8>(a, s);
+    default: return a.dqc_next ? launch_bwd_b<1, 0, true>(a, s) : launch_bwd_b<1, 0, false>(a, s);
+  }
 }
 
 extern "C" int pd_dec_bwd_a(const void *dq, const void *dk, const void *dv, const void *wqkvT, const float *dz_in, const float *z, const float *stats,

@@ -70,6 +70,11 @@ def pack(weights, transpose=False):
     return [buf[o:o + w.numel()] for w, o in zip(weights, offs)]
 
 
+def workspace(R, dev):
+    """scratch of the two-launch FFN (fp32 slabs + one fp32 row block); no initial state"""
+    return torch.empty(int(_lib.load().pd_dec_workspace_bytes(int(R))), dtype=torch.uint8, device=dev)
+
+
 def _e(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
 
@@ -87,7 +92,7 @@ def fwd_a(o, res, qpos, pos_div, w_o, b_o, ln_w, ln_b, eps, w_qkv, b_qkv):
     return z, stats, y, y_c, ypos_c, q, k, v
 
 
-def fwd_b(o, res, qpos, pos_div, lay, dn_w, dn_b, mlp, q_next, eps, dec_out):
+def fwd_b(o, res, qpos, pos_div, lay, dn_w, dn_b, mlp, q_next, eps, dec_out, ws=None):
     """(all weights PACKED: pack())  lay = (w_o, b_o, ln2_w, ln2_b, w_1, b_1, w_2, b_2, ln3_w, ln3_b) or None (the head in front of the first layer: y3 = res);
     mlp = the six mask-embedding MLP tensors and q_next = (W_q, b_q) of the next layer's cross-attention, or None / None after the last layer.
     dec_out: the [R, C] fp32 row block of the stacked decoder outputs this head writes.
@@ -108,12 +113,12 @@ def fwd_b(o, res, qpos, pos_div, lay, dn_w, dn_b, mlp, q_next, eps, dec_out):
     _lib.check(_lib.load().pd_dec_fwd_b(_p(o), res.data_ptr(), qpos.data_ptr(), int(pos_div), *[_p(t) for t in L], dn_w.data_ptr(), dn_b.data_ptr(),
                                         *[_p(t) for t in M], _p(Qn[0]), _p(Qn[1]), float(eps), _p(g("z2")), _p(g("stats2")), _p(g("y2_c")), _p(g("h")),
                                         _p(g("z3")), _p(g("stats3")), _p(g("y3")), out["ypos_c"].data_ptr(), dec_out.data_ptr(), out["hstats"].data_ptr(),
-                                        _p(g("ef")), _p(g("qc")), R, (1 if layer else 0) | (2 if head else 0), _stream()))
+                                        _p(g("ef")), _p(g("qc")), _p(ws), R, (1 if layer else 0) | (2 if head else 0), _stream()))
     return out
 
 
 def bwd_b(dqc_next, wqT_next, d_out, d_res, y3, hstats, dn_w, dgb_dn, z3, stats3, ln3_w, dgb3, db3, pos_acc, pos_div, w2T, h, w1T, z2, stats2,
-          ln2_w, dgb2, db2, woT):
+          ln2_w, dgb2, db2, woT, ws=None):
     """-> (dz3_c, dh, dz2, dz2_c, d_o); accumulators (dgb_* = [dgamma | dbeta] fp32 [2C], db* [C], pos_acc [Q, C]) are added to"""
     R, dev = z3.shape[0], z3.device
     dz3_c, dz2_c, d_o = (_e((R, C), bf16, dev) for _ in range(3))
@@ -123,7 +128,7 @@ def bwd_b(dqc_next, wqT_next, d_out, d_res, y3, hstats, dn_w, dgb_dn, z3, stats3
                                         dgb_dn.data_ptr(), z3.data_ptr(), stats3.data_ptr(), ln3_w.data_ptr(), dgb3.data_ptr(), db3.data_ptr(), _p(pos_acc),
                                         int(pos_div), w2T.data_ptr(), h.data_ptr(), w1T.data_ptr(), z2.data_ptr(), stats2.data_ptr(), ln2_w.data_ptr(),
                                         dgb2.data_ptr(), db2.data_ptr(), woT.data_ptr(), dz3_c.data_ptr(), dh.data_ptr(), dz2.data_ptr(), dz2_c.data_ptr(),
-                                        d_o.data_ptr(), R, _stream()))
+                                        d_o.data_ptr(), _p(ws), R, _stream()))
     return dz3_c, dh, dz2, dz2_c, d_o
 
 

@@ -352,6 +352,7 @@ class DecoderCore(Function):
         def qnext(i):
             return (pk[per * i], layers[i][1][:C])
 
+        ws = dl.workspace(R, dev)                                  # the two-launch FFN's slabs (reused by every layer: the launches are ordered)
         r = dl.fwd_b(None, tgt, qpos, B, None, dn_w, dn_b, mlp_p, qnext(0), spec.eps, dec_outs[0])
         head_stats.append((r["hstats"][0], r["hstats"][1]))
         mask = DecoderCore._mask_from_ef(spec, r["ef"], 0)
@@ -375,7 +376,7 @@ class DecoderCore(Function):
             # ---- output projection + LN, FFN + LN, head (+ the next layer's query projection)
             last = i + 1 == L
             r = dl.fwd_b(o_s, y1, qpos, B, (p_so, sob, snw, snb, p_w1, b1, p_w2, b2, fnw, fnb), dn_w, dn_b, None if last else mlp_p,
-                         None if last else qnext(i + 1), spec.eps, dec_outs[i + 1])
+                         None if last else qnext(i + 1), spec.eps, dec_outs[i + 1], ws)
             slf = slf[:7] + (r["z2"], r["stats2"][0], r["stats2"][1])
             ffn = (r["y2_c"], r["h"], r["z3"], r["stats3"][0], r["stats3"][1], r["y3"])
             saved.append((cross, slf, ffn))
@@ -503,6 +504,7 @@ class DecoderCore(Function):
         d_pos_c = None                                                       # GEMM-dtype gradient w.r.t. (tgt + query_pos)
         if fused_layer:                                                      # every transposed weight of the loop in block order: one launch
             pkT = dl.pack([w_ for lay_ in layers for w_ in (lay_[0][:C], lay_[2], lay_[6], lay_[8], lay_[12], lay_[14])], transpose=True)
+            ws = dl.workspace(R, dev)
             dq_next = None                                                   # d(cross-attention queries) of layer i + 1
 
             def A2(s0):                                                      # [dgamma | dbeta]: adjacent accumulator slots
@@ -520,7 +522,7 @@ class DecoderCore(Function):
                 dz3_c, dh, dz2, dz2_c, d_os = dl.bwd_b(dq_next, pkT[6 * (i + 1)] if dq_next is not None else None, d_out[i + 1], d_res, y3, hm, dn_w,
                                                        A2(s_dnw), z3, m3, fnw, A2(lay[i]["fnw"]), A(lay[i]["b2"]),
                                                        A(s_pos) if dq_next is not None else None, B, w2T, h, w1T, z2, m2, snw, A2(lay[i]["snw"]),
-                                                       A(lay[i]["sob"]), soT)
+                                                       A(lay[i]["sob"]), soT, ws)
                 g_w2 = _wgrad(dz3_c, h, queue=wq)
                 g_w1 = _wgrad(dh, x_c, bias_acc=A(lay[i]["b1"]), queue=wq)
                 g_sow = _wgrad(dz2_c, o, queue=wq)

@@ -125,8 +125,10 @@ SIGNATURES = {
     "pd_decoder_head_bf16": (_c_int, [_c_vp] * 3 + [ctypes.c_float] + [_c_vp] * 10 + [_c_int] * 4 + [_c_vp]),
     # include/pd_declayer.h
     "pd_dec_fwd_a": (_c_int, [_c_vp] * 3 + [_c_int] + [_c_vp] * 4 + [ctypes.c_float] + [_c_vp] * 10 + [_c_int] + [_c_vp]),
-    "pd_dec_fwd_b": (_c_int, [_c_vp] * 3 + [_c_int] + [_c_vp] * 20 + [ctypes.c_float] + [_c_vp] * 12 + [_c_int] * 2 + [_c_vp]),
-    "pd_dec_bwd_b": (_c_int, [_c_vp] * 14 + [_c_int] + [_c_vp] * 14 + [_c_int] + [_c_vp]),
+    "pd_dec_fwd_b": (_c_int, [_c_vp] * 3 + [_c_int] + [_c_vp] * 20 + [ctypes.c_float] + [_c_vp] * 13 + [_c_int] * 2 + [_c_vp]),
+    "pd_dec_bwd_b": (_c_int, [_c_vp] * 14 + [_c_int] + [_c_vp] * 15 + [_c_int] + [_c_vp]),
+    "pd_dec_split": (_c_int, []),
+    "pd_dec_workspace_bytes": (ctypes.c_int64, [_c_int]),
     "pd_dec_pack_table_bytes": (ctypes.c_int64, [_c_int]),
     "pd_dec_pack_grouped": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp]),
     "pd_dec_bwd_a": (_c_int, [_c_vp] * 11 + [_c_int] + [_c_vp] * 4 + [_c_int] + [_c_vp]),

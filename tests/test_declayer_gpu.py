@@ -46,8 +46,9 @@ def _params(dev, seed):
     return p, g
 
 
+@pytest.mark.parametrize("split", [False, True])          # True: the FFN as two launches (PD_DEC_SPLIT workgroups per row block, then one)
 @pytest.mark.parametrize("Q,B", [(100, 2), (100, 3), (7, 1), (16, 1)])
-def test_forward_kernels_vs_unfused(Q, B):
+def test_forward_kernels_vs_unfused(Q, B, split):
     dev = _dev()
     from partdistillation_amd.functions import declayer as dl, rowwise as rw, smallgemm as sg
     R, eps = Q * B, 1e-5
@@ -85,8 +86,9 @@ def test_forward_kernels_vs_unfused(Q, B):
     qc_r = sg.linear(y3p_r, p["cq_w"], p["cq_b"])
     lay = (pk["so_w"], p["so_b"], p["sn"][0], p["sn"][1], pk["w1"], p["b1"], pk["w2"], p["b2"], p["fn"][0], p["fn"][1])
     mlp_p = [pk["m0"], p["mlp"][1], pk["m1"], p["mlp"][3], pk["m2"], p["mlp"][5]]
+    ws = dl.workspace(R, dev) if split else None
     dec_out = torch.empty(R, C, device=dev)
-    r = dl.fwd_b(o_s, y_r, qpos, B, lay, p["dn"][0], p["dn"][1], mlp_p, (pk["cq_w"], p["cq_b"]), eps, dec_out)
+    r = dl.fwd_b(o_s, y_r, qpos, B, lay, p["dn"][0], p["dn"][1], mlp_p, (pk["cq_w"], p["cq_b"]), eps, dec_out, ws)
     _close(r["z2"], z2_r, "z2"); _close(r["y2_c"], y2c_r, "y2_c", ulps=4); _close(r["stats2"][0], m2_r, "mean2"); _close(r["stats2"][1], r2_r, "rstd2", ulps=4)
     _close(r["h"], h_r, "h", ulps=6); _close(r["z3"], z3_r, "z3", ulps=6); _close(r["y3"], y3_r, "y3", ulps=8)
     _close(r["ypos_c"], y3p_r, "y3pos_c", ulps=8); _close(dec_out, d_t, "dec_out", ulps=8)
@@ -106,12 +108,13 @@ def test_forward_kernels_vs_unfused(Q, B):
     _close(r0["qc"], sg.linear(tp0, p["cq_w"], p["cq_b"]), "qc 0", ulps=4)
     # the last layer: no head MLP
     dec9 = torch.empty(R, C, device=dev)
-    r9 = dl.fwd_b(o_s, y_r, qpos, B, lay, p["dn"][0], p["dn"][1], None, None, eps, dec9)
+    r9 = dl.fwd_b(o_s, y_r, qpos, B, lay, p["dn"][0], p["dn"][1], None, None, eps, dec9, ws)
     assert torch.equal(dec9, dec_out) and torch.equal(r9["y3"], r["y3"]) and torch.equal(r9["h"], r["h"])
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("Q,B,last", [(100, 2, False), (100, 2, True), (100, 3, False), (7, 1, False)])
-def test_backward_kernels_vs_unfused(Q, B, last):
+def test_backward_kernels_vs_unfused(Q, B, last, split):
     dev = _dev()
     from partdistillation_amd.functions import declayer as dl, igemm, rowwise as rw, smallgemm as sg
     R, eps = Q * B, 1e-5
@@ -150,7 +153,7 @@ def test_backward_kernels_vs_unfused(Q, B, last):
     # ---- fused B
     F = accs()
     dz3c, dh, dz2, dz2c, do = dl.bwd_b(dqc, None if last else cqT, d_out, d_res, y3, hst, p["dn"][0], F["dn"], z3, st3, p["fn"][0], F["g3"], F["b3"],
-                                       None if last else F["pos"], B, w2T, h, w1T, z2, st2, p["sn"][0], F["g2"], F["b2"], soT)
+                                       None if last else F["pos"], B, w2T, h, w1T, z2, st2, p["sn"][0], F["g2"], F["b2"], soT, dl.workspace(R, dev) if split else None)
     _close(dz3c, dz3c_r, "dz3_c", ulps=3); _close(dh, dh_r, "dh", ulps=4); _close(dz2, dz2_r, "dz2", ulps=4); _close(dz2c, dz2c_r, "dz2_c", ulps=4)
     _close(do, do_r, "d_o", ulps=6, mean_tol=5e-3)
     for k_ in ("dn", "g3", "b3", "g2", "b2", "pos"):

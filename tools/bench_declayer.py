@@ -18,6 +18,7 @@ pk = dict(zip(("co_w", "si_w", "so_w", "w1", "w2", "m0", "m1", "m2", "cq_w"),
 lay = (pk["so_w"], p["so_b"], p["sn"][0], p["sn"][1], pk["w1"], p["b1"], pk["w2"], p["b2"], p["fn"][0], p["fn"][1])
 mlp_p = [pk["m0"], p["mlp"][1], pk["m1"], p["mlp"][3], pk["m2"], p["mlp"][5]]
 dec_out = torch.empty(R, C, device=dev)
+ws = dl.workspace(R, dev) if os.environ.get("WS", "1") == "1" else None
 
 
 def timeit(fn, n=200):
@@ -47,9 +48,9 @@ def unf_b():
 
 print("fwd_a fused   us", round(timeit(lambda: dl.fwd_a(o, tgt, qpos, B, pk["co_w"], p["co_b"], p["cn"][0], p["cn"][1], eps, pk["si_w"], p["si_b"])), 1))
 print("fwd_a unfused us (3 launches)", round(timeit(unf_a), 1))
-print("fwd_b fused   us", round(timeit(lambda: dl.fwd_b(o, tgt, qpos, B, lay, p["dn"][0], p["dn"][1], mlp_p, (pk["cq_w"], p["cq_b"]), eps, dec_out)), 1))
-print("fwd_b fused, no head MLP us", round(timeit(lambda: dl.fwd_b(o, tgt, qpos, B, lay, p["dn"][0], p["dn"][1], None, None, eps, dec_out)), 1))
-print("fwd_b head only us", round(timeit(lambda: dl.fwd_b(None, tgt, qpos, B, None, p["dn"][0], p["dn"][1], mlp_p, (pk["cq_w"], p["cq_b"]), eps, dec_out)), 1))
+print("fwd_b fused   us", round(timeit(lambda: dl.fwd_b(o, tgt, qpos, B, lay, p["dn"][0], p["dn"][1], mlp_p, (pk["cq_w"], p["cq_b"]), eps, dec_out, ws)), 1))
+print("fwd_b fused, no head MLP us", round(timeit(lambda: dl.fwd_b(o, tgt, qpos, B, lay, p["dn"][0], p["dn"][1], None, None, eps, dec_out, ws)), 1))
+print("fwd_b head only us", round(timeit(lambda: dl.fwd_b(None, tgt, qpos, B, None, p["dn"][0], p["dn"][1], mlp_p, (pk["cq_w"], p["cq_b"]), eps, dec_out, ws)), 1))
 print("fwd_b unfused us (5 launches, without head + q)", round(timeit(unf_b), 1))
 cqT, w2T, w1T, soT, siT, coT = dl.pack([p["cq_w"], p["w2"], p["w1"], p["so_w"], p["si_w"], p["co_w"]], transpose=True)
 allw = [p["co_w"], p["si_w"], p["so_w"], p["w1"], p["w2"], p["mlp"][0], p["mlp"][2], p["mlp"][4], p["cq_w"]] * 9
@@ -61,7 +62,7 @@ d_out, d_res = torch.randn(R, C, device=dev), torch.randn(R, C, device=dev)
 dqc = torch.randn(R, C, device=dev).to(bf)
 F = {k_: torch.zeros(n, device=dev) for k_, n in (("dn", 2 * C), ("g3", 2 * C), ("b3", C), ("g2", 2 * C), ("b2", C), ("g1", 2 * C), ("b1", C), ("pos", Q * C))}
 print("bwd_b fused us", round(timeit(lambda: dl.bwd_b(dqc, cqT, d_out, d_res, y3, st, p["dn"][0], F["dn"], z3, st, p["fn"][0], F["g3"], F["b3"], F["pos"], B, w2T, h, w1T, z2, st,
-                                                      p["sn"][0], F["g2"], F["b2"], soT)), 1))
+                                                      p["sn"][0], F["g2"], F["b2"], soT, ws)), 1))
 print("bwd_a fused us", round(timeit(lambda: dl.bwd_a(dqc, dqc, dqc, siT, d_res, z1, st, p["cn"][0], F["g1"], F["b1"], F["pos"], B, coT)), 1))
 
 
