@@ -177,7 +177,7 @@ _CATEGORIES = [
     ("own_igemm_bf16_conv_linear", r"^(igemm_bf16|filter_transpose_grouped|wgrad_bf16|stem_|maxpool3s2)"),
     ("own_conv_bf16_filter_grads", r"^conv_(wgrad|igemm)"),
     ("own_attention_mfma", r"^(attn_|wattn_)"),
-    ("own_decoder_fused", r"^(dec_layer_|dec_head_|decoder_head)"),
+    ("own_decoder_fused", r"^(dec_fwd_|dec_bwd_|dec_pack_|decoder_head)"),
     ("own_skinny_bf16_gemm", r"^sgemm_"),
     ("own_criterion", r"^(pair_logits|loss_vectors|mask_point_losses|uncertain_points|matcher_|point_sample|skinny_linear|lsa_)"),
     ("own_rowwise_norm_optim_misc", r"^(add_ln_|colsum_|mem_prep|msda_prep|gn_coeffs|affine_act|nc_|multi_gather|upsample|layernorm_rows|ln_rows|"
