@@ -45,7 +45,7 @@ constexpr int BM = 128, BKB = 128;                       // rows per tile, BYTES
 __device__ __attribute__((aligned(128))) unsigned char g_zero_line[128];   // zero-initialised: the source of every masked row
 
 }  // namespace
-int g_ig_bn = 0, g_ig_nst = 0, g_ig_splits = 0;              // pd_debug_set "ig_bn" / "ig_nst" / "ig_splits" (tools/ only; 0 = automatic)
+int g_ig_bn = 0, g_ig_nst = 0, g_ig_splits = 0, g_ig_patch = 1;              // pd_debug_set "ig_bn" / "ig_nst" / "ig_splits" (tools/ only; 0 = automatic)
 namespace {
 
 struct IgArgs {
@@ -74,6 +74,76 @@ __device__ __forceinline__ void swap_halves(float &a, float &b)
 {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+
+// the epilogue of one 32-pixel sub-tile of a wavefront (result pixel m of this lane, 64 columns from n0 + wn): acc * scale + bias (+ residuals) ->
+// optional pre-activation copy -> activation -> gate -> bf16, 8 consecutive channels per lane (see swap_halves)
+template <int BN>
+__device__ __forceinline__ void epilogue_rows(const IgArgs &a, const f32x16 &c0, const f32x16 &c1, const float *sb, int m, bool rowok, int n0, int wn, int kh)
+{
+  int64_t roff = 0;
+  bool has_res = a.res != nullptr;
+  if (a.res && a.res_mode == PD_IG_RES_UP2) {
+    const int mm = rowok ? m : 0, hw = a.Ho * a.Wo, b = mm / hw, rem = mm - b * hw, y = rem / a.Wo, x = rem - y * a.Wo;
+    has_res = ((y | x) & 1) == 0;
+    roff = ((int64_t)(b * (a.Ho >> 1) + (y >> 1)) * (a.Wo >> 1) + (x >> 1)) * a.N;
+  } else {
+    roff = (int64_t)m * a.N;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const f32x16 &c = i ? c1 : c0;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = c[8 * p + e]; v[4 + e] = c[8 * p + 4 + e]; }
+      // v[0..3] = quad 2p, v[4..7] = quad 2p+1 of this lane; after the swaps: 8 consecutive channels
+#pragma unroll
+      for (int e = 0; e < 4; ++e) swap_halves(v[e], v[4 + e]);
+      // lane < 32: v[0..3] = own quad 2p (ch +0..3), v[4..7] = partner's quad 2p (ch +4..7);  lane >= 32: quad 2p+1 likewise
+      const int cl = wn + i * 32 + p * 16 + kh * 8, cc = n0 + cl;
+      {
+        const float4 s0 = *reinterpret_cast<const float4 *>(sb + cl), s1 = *reinterpret_cast<const float4 *>(sb + cl + 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(sb + BN + cl), b1 = *reinterpret_cast<const float4 *>(sb + BN + cl + 4);
+        v[0] = v[0] * s0.x + b0.x; v[1] = v[1] * s0.y + b0.y; v[2] = v[2] * s0.z + b0.z; v[3] = v[3] * s0.w + b0.w;
+        v[4] = v[4] * s1.x + b1.x; v[5] = v[5] * s1.y + b1.y; v[6] = v[6] * s1.z + b1.z; v[7] = v[7] * s1.w + b1.w;
+      }
+      if (!rowok) continue;
+      const int64_t off = (int64_t)m * a.N + cc;
+      if (has_res) {
+        const uint4 r = *reinterpret_cast<const uint4 *>(a.res + roff + cc);
+        v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
+        v[4] += bf_lo(r.z); v[5] += bf_hi(r.z); v[6] += bf_lo(r.w); v[7] += bf_hi(r.w);
+      }
+      if (a.res2) {
+        const uint4 r = *reinterpret_cast<const uint4 *>(a.res2 + off);
+        v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
+        v[4] += bf_lo(r.z); v[5] += bf_hi(r.z); v[6] += bf_lo(r.w); v[7] += bf_hi(r.w);
+      }
+      if (a.Ypre)
+        *reinterpret_cast<uint4 *>(a.Ypre + off) = make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7]));
+      if (a.act == PD_IG_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (a.act == PD_IG_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      }
+      if (a.gate) {
+        const uint4 r = *reinterpret_cast<const uint4 *>(a.gate + off);
+        const float g[8] = {bf_lo(r.x), bf_hi(r.x), bf_lo(r.y), bf_hi(r.y), bf_lo(r.z), bf_hi(r.z), bf_lo(r.w), bf_hi(r.w)};
+        if (a.gate_mode == PD_IG_GATE_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = g[e] > 0.f ? v[e] : 0.f;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(g[e]);
+        }
+      }
+      *reinterpret_cast<uint4 *>(a.Y + off) = make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7]));
+    }
+  }
 }
 
 template <int BN, int NST, bool P1>
@@ -285,77 +355,129 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : (NST == 2 || BN == 64) ? 2 : 1)
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
     const int m = m0 + wm + j * 32 + fr;
-    const bool rowok = m < a.M;
-    int64_t roff = 0;
-    bool has_res = a.res != nullptr;
-    if (a.res && a.res_mode == PD_IG_RES_UP2) {
-      const int mm = rowok ? m : 0, hw = a.Ho * a.Wo, b = mm / hw, rem = mm - b * hw, y = rem / a.Wo, x = rem - y * a.Wo;
-      has_res = ((y | x) & 1) == 0;
-      roff = ((int64_t)(b * (a.Ho >> 1) + (y >> 1)) * (a.Wo >> 1) + (x >> 1)) * a.N;
-    } else {
-      roff = (int64_t)m * a.N;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = acc[i][j][8 * p + e]; v[4 + e] = acc[i][j][8 * p + 4 + e]; }
-        // v[0..3] = quad 2p, v[4..7] = quad 2p+1 of this lane; after the swaps: 8 consecutive channels
-#pragma unroll
-        for (int e = 0; e < 4; ++e) swap_halves(v[e], v[4 + e]);
-        // lane < 32: v[0..3] = own quad 2p (ch +0..3), v[4..7] = partner's quad 2p (ch +4..7);  lane >= 32: quad 2p+1 likewise
-        const int cl = wn + i * 32 + p * 16 + kh * 8, c = n0 + cl;
-        {
-          const float *sb = reinterpret_cast<const float *>(smem + SB_OFF);
-          const float4 s0 = *reinterpret_cast<const float4 *>(sb + cl), s1 = *reinterpret_cast<const float4 *>(sb + cl + 4);
-          const float4 b0 = *reinterpret_cast<const float4 *>(sb + BN + cl), b1 = *reinterpret_cast<const float4 *>(sb + BN + cl + 4);
-          v[0] = v[0] * s0.x + b0.x; v[1] = v[1] * s0.y + b0.y; v[2] = v[2] * s0.z + b0.z; v[3] = v[3] * s0.w + b0.w;
-          v[4] = v[4] * s1.x + b1.x; v[5] = v[5] * s1.y + b1.y; v[6] = v[6] * s1.z + b1.z; v[7] = v[7] * s1.w + b1.w;
-        }
-        if (!rowok) continue;
-        const int64_t off = (int64_t)m * a.N + c;
-        if (has_res) {
-          const uint4 r = *reinterpret_cast<const uint4 *>(a.res + roff + c);
-          v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
-          v[4] += bf_lo(r.z); v[5] += bf_hi(r.z); v[6] += bf_lo(r.w); v[7] += bf_hi(r.w);
-        }
-        if (a.res2) {
-          const uint4 r = *reinterpret_cast<const uint4 *>(a.res2 + off);
-          v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
-          v[4] += bf_lo(r.z); v[5] += bf_hi(r.z); v[6] += bf_lo(r.w); v[7] += bf_hi(r.w);
-        }
-        if (a.Ypre)
-          *reinterpret_cast<uint4 *>(a.Ypre + off) = make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7]));
-        if (a.act == PD_IG_ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (a.act == PD_IG_ACT_GELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-        }
-        if (a.gate) {
-          const uint4 r = *reinterpret_cast<const uint4 *>(a.gate + off);
-          const float g[8] = {bf_lo(r.x), bf_hi(r.x), bf_lo(r.y), bf_hi(r.y), bf_lo(r.z), bf_hi(r.z), bf_lo(r.w), bf_hi(r.w)};
-          if (a.gate_mode == PD_IG_GATE_RELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = g[e] > 0.f ? v[e] : 0.f;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(g[e]);
-          }
-        }
-        *reinterpret_cast<uint4 *>(a.Y + off) = make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7]));
-      }
-    }
+    epilogue_rows<BN>(a, acc[0][j], acc[1][j], reinterpret_cast<const float *>(smem + SB_OFF), m, m < a.M, n0, wn, kh);
   }
+}
+
+// ------------------------------------------------------------------------------------------------ 3 x 3, stride 1: patch form
+// The gathered kernel above fetches the A tile of every K-step again — for a 3 x 3 convolution the nine taps of a channel chunk read the SAME
+// source pixels nine times through L2 (one shifted copy per tap), and a step can only start when its 24 KB have landed.  Here a tile is an
+// 8 x 16 BLOCK of result pixels; the source patch of a 64-channel chunk (10 x 18 pixels x 128 bytes, zero rows outside the image) goes into
+// LDS ONCE and the nine taps read their fragments from it at shifted rows (same XOR swizzle, keyed by the patch row), so a step only waits for
+// its 8 KB weight tile: 2.3 x fewer bytes per tile at 64 channels (23 + 72 KB instead of 216), and the patch of chunk c + 1 streams in under
+// the nine steps of chunk c.  Forward (source row = result row - 1 + dy) and input gradient (result row + 1 - dy: the caller's transposed
+// filter, as above).  64-column tiles, weight tiles on a three-stage ring, two workgroups per CU.
+constexpr int TH3 = 8, TW3 = 16, PW3 = TW3 + 2, PROWS3 = (TH3 + 2) * PW3, PPIECES3 = 24;       // 180 patch rows in 24 pieces of 8 rows (the last 12 rows: zeros)
+constexpr int PATCH3 = PPIECES3 * 1024;
+
+__global__ __launch_bounds__(256, 2) void igemm3x3_bf16(IgArgs a)
+{
+  constexpr int BN = 64, NBJ = 2, BT = BN * BKB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *const patch = smem;                      // [2][PATCH3]
+  unsigned char *const bring = smem + 2 * PATCH3;        // [3][BT]
+  const float *const sb = reinterpret_cast<const float *>(smem + 2 * PATCH3 + 3 * BT);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lb = xcd_chunk(blockIdx.x, gridDim.x);
+  const int mt = lb / a.ntn, n0 = (lb - mt * a.ntn) * BN;
+  const int txn = (a.Wo + TW3 - 1) / TW3, tyn = (a.Ho + TH3 - 1) / TH3;
+  const int b = mt / (tyn * txn), r_ = mt - b * (tyn * txn), ty0 = (r_ / txn) * TH3, tx0 = (r_ - (r_ / txn) * txn) * TW3;
+  const int lrow = lane >> 3, lch = lane & 7;
+  const bf16_t *zline = reinterpret_cast<const bf16_t *>(g_zero_line);
+  float sbv = 0.f;
+  if (t < 2 * BN) {
+    const float *src = t < BN ? a.scale : a.bias;
+    if (t >= BN && a.bias && a.bias_bf16) sbv = __uint_as_float((unsigned)reinterpret_cast<const bf16_t *>(a.bias)[n0 + t - BN] << 16);
+    else sbv = src ? src[n0 + (t < BN ? t : t - BN)] : (t < BN ? 1.f : 0.f);
+  }
+  // ---- the six patch rows this thread fetches per channel chunk (piece wave * 6 + j: rows 8 piece + lane / 8, 16-byte chunk lane & 7)
+  const bf16_t *pp[6];
+  bool pok[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int pr = (wave * 6 + j) * 8 + lrow, py = pr / PW3, px = pr - py * PW3;
+    const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
+    pok[j] = pr < PROWS3 && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+    pp[j] = pok[j] ? a.S + ((int64_t)(b * a.Hs + sy) * a.Ws + sx) * a.Cs + (lch ^ ((pr >> 1) & 7)) * 8 : zline + lch * 8;
+  }
+  const bf16_t *wb[NBJ];
+  const int ldw = a.KT * 64;
+#pragma unroll
+  for (int j = 0; j < NBJ; ++j) {
+    const int row = (wave * NBJ + j) * 8 + lrow;
+    wb[j] = a.Wf + (int64_t)(n0 + row) * ldw + (lch ^ ((row >> 1) & 7)) * 8;
+  }
+  auto issue_patch = [&](int c, int buf) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(pok[j] ? pp[j] + c * 64 : pp[j]), (lds_ptr)(patch + buf * PATCH3 + (wave * 6 + j) * 1024), 16, 0, 0);
+  };
+  auto issue_b = [&](int step, int buf) {                  // step = 9 c + tap; the filter's K index is tap * cch + c
+    const int c = step / 9, tap = step - 9 * c, kt = tap * a.cch + c;
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(wb[j] + (int64_t)kt * 64), (lds_ptr)(bring + buf * BT + (wave * NBJ + j) * 1024), 16, 0, 0);
+  };
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  const int fr = lane & 31, kh = lane >> 5, sw = (fr >> 1) & 7;
+  int foff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) foff[ks] = ((ks * 2 + kh) ^ sw) * 16;
+  const int pty = 2 * wave + (fr >> 4), ptx = fr & 15;     // this lane's result pixel inside the block
+  auto compute = [&](int step, int bbuf) {
+    const int c = step / 9, tap = step - 9 * c, dy = tap / 3, dx = tap - 3 * dy;
+    const int pr = (pty + (a.dgrad ? 2 - dy : dy)) * PW3 + ptx + (a.dgrad ? 2 - dx : dx), psw = (pr >> 1) & 7;
+    const unsigned char *As = patch + (c & 1) * PATCH3 + pr * BKB, *Bs = bring + bbuf * BT;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      hwbf16x8 wf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const hwbf16x8 *>(Bs + (i * 32 + fr) * BKB + foff[ks]);
+      const hwbf16x8 af = *reinterpret_cast<const hwbf16x8 *>(As + ((ks * 2 + kh) ^ psw) * 16);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af, acc[i], 0, 0, 0);
+    }
+  };
+  if (t < 2 * BN) reinterpret_cast<float *>(smem + 2 * PATCH3 + 3 * BT)[t] = sbv;
+  // ---- the step loop: weight tiles two steps ahead on the ring; chunk c + 1's patch is issued in the slot of chunk c's first step.
+  // Counted waits (loads complete in issue order): behind step s's weight tile the queue holds step s + 1's tile (2 pieces per wavefront)
+  // and, when the previous slot also issued a patch, its 6 pieces
+  const int nsteps = 9 * a.cch;
+  issue_patch(0, 0);
+  issue_b(0, 0);
+  if (nsteps > 1) issue_b(1, 1);
+  int bbuf = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) {
+      const int ps = s - 1;                                // the slot before this wait issued: weights of step s + 1, and a patch when it was a chunk's first step
+      const bool patch_behind = ps >= 0 && ps % 9 == 0 && ps / 9 + 1 < a.cch;
+      if (patch_behind) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                          // step s (and its chunk's patch) landed for everyone; everyone is done reading step s - 1's stage
+    if (s % 9 == 0 && s / 9 + 1 < a.cch) issue_patch(s / 9 + 1, (s / 9 + 1) & 1);
+    if (s + 2 < nsteps) issue_b(s + 2, bbuf == 0 ? 2 : bbuf - 1);
+    compute(s, bbuf);
+    bbuf = bbuf == 2 ? 0 : bbuf + 1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int y = ty0 + pty, x = tx0 + ptx;
+  const bool rowok = y < a.Ho && x < a.Wo;
+  const int m = rowok ? (b * a.Ho + y) * a.Wo + x : 0;
+  epilogue_rows<BN>(a, acc[0], acc[1], sb, m, rowok, n0, 0, kh);
 }
 
 struct Plan {
   IgArgs a;
   int bn, nst;
   int64_t slab_bytes;
+  bool patch3;                                           // 3 x 3 stride 1: igemm3x3_bf16
 };
 
 int make_plan(const PdIgemm *p, Plan &pl)
@@ -406,6 +528,20 @@ int make_plan(const PdIgemm *p, Plan &pl)
   a.kt_per = (a.KT + splits - 1) / splits;
   a.splits = (a.KT + a.kt_per - 1) / a.kt_per;
   pl.slab_bytes = a.splits > 1 ? (int64_t)a.ntiles * a.splits * BM * pl.bn * 4 : 0;
+  // 3 x 3, stride 1, same-size grids: the patch form, when its 8 x 16 blocks fill the chip without split-K (res5's 16 blocks x 8 column tiles keep
+  // the gathered kernel's split-K); pd_debug_set("ig_patch", 0) keeps the gathered kernel, 2 forces the patch form wherever it is defined
+  pl.patch3 = false;
+  if (p->k == 3 && p->stride == 1 && p->pad == 1 && p->hs == p->ho && p->ws == p->wo && g_ig_patch != 0) {
+    const int blocks = p->batch * ((p->ho + TH3 - 1) / TH3) * ((p->wo + TW3 - 1) / TW3) * (p->n / 64);
+    if (blocks >= 192 || g_ig_patch == 2) {
+      pl.patch3 = true;
+      pl.bn = 64; pl.nst = 3;
+      a.ntn = p->n / 64;
+      a.ntiles = blocks;
+      a.splits = 1; a.kt_per = a.KT;
+      pl.slab_bytes = 0;
+    }
+  }
   return PD_OK;
 }
 
@@ -435,6 +571,13 @@ int launch(const Plan &pl, hipStream_t stream)
 
 int launch_plan(const Plan &pl, hipStream_t st)
 {
+  if (pl.patch3) {
+    constexpr size_t lds = (size_t)2 * PATCH3 + 3 * 64 * BKB + 2 * 64 * sizeof(float);
+    static bool attr3 = false;
+    if (!attr3) { (void)hipFuncSetAttribute((const void *)igemm3x3_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr3 = true; }
+    hipLaunchKernelGGL(igemm3x3_bf16, dim3((unsigned)pl.a.ntiles), dim3(256), lds, st, pl.a);
+    return pd_check_launch("pd_igemm_bf16 (3 x 3 patch form)");
+  }
   if (pl.bn == 128) return pl.nst == 3 ? launch<128, 3>(pl, st) : pl.nst == 2 ? launch<128, 2>(pl, st) : launch<128, 1>(pl, st);
   return pl.nst == 3 ? launch<64, 3>(pl, st) : pl.nst == 2 ? launch<64, 2>(pl, st) : launch<64, 1>(pl, st);
 }
