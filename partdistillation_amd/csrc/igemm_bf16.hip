@@ -26,6 +26,7 @@
 //     16-byte residual / gate loads) without a trip through LDS and without its two barriers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gelu.h"
 #include "mfma_bf16.h"
@@ -45,7 +46,8 @@ constexpr int BM = 128, BKB = 128;                       // rows per tile, BYTES
 __device__ __attribute__((aligned(128))) unsigned char g_zero_line[128];   // zero-initialised: the source of every masked row
 
 }  // namespace
-int g_ig_bn = 0, g_ig_nst = 0, g_ig_splits = 0, g_ig_patch = 1;              // pd_debug_set "ig_bn" / "ig_nst" / "ig_splits" (tools/ only; 0 = automatic)
+int g_ig_bn = 0, g_ig_nst = 0, g_ig_splits = 0;
+int g_ig_patch = []() { const char *e = getenv("PD_IG_PATCH"); return e ? atoi(e) : 1; }();   // 0: the gathered kernel for the 3 x 3 convolutions too (A/B)              // pd_debug_set "ig_bn" / "ig_nst" / "ig_splits" (tools/ only; 0 = automatic)
 namespace {
 
 struct IgArgs {
