@@ -50,7 +50,7 @@ extern int g_pd_dbg_kmeans;
 extern int g_pd_dbg_conv_group_rows;
 extern int g_pd_dbg_conv_xcd_major;
 extern int g_pd_dbg_sgemm_deep;
-extern int g_ig_bn, g_ig_nst, g_ig_splits, g_ig_patch;
+extern int g_ig_bn, g_ig_nst, g_ig_splits, g_ig_patch, g_ig_pcls;
 extern int g_mx_bn, g_mx_nst;
 extern int g_swin_ln_abl;
 extern int g_ln_bwd_cap;
@@ -73,6 +73,7 @@ extern "C" int pd_debug_set(const char *key, int value)
   if (!strcmp(key, "wg_mode")) { g_wg_mode = value; return PD_OK; }
   if (!strcmp(key, "ig_bn")) { g_ig_bn = value; return PD_OK; }
   if (!strcmp(key, "ig_patch")) { g_ig_patch = value; return PD_OK; }
+  if (!strcmp(key, "ig_pcls")) { g_ig_pcls = value; return PD_OK; }
   if (!strcmp(key, "ig_nst")) { g_ig_nst = value; return PD_OK; }
   if (!strcmp(key, "mx_bn")) { g_mx_bn = value; return PD_OK; }
   if (!strcmp(key, "attn_bwd_kc")) { g_attn_bwd_kc = value; return PD_OK; }

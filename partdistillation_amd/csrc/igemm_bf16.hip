@@ -47,6 +47,7 @@ __device__ __attribute__((aligned(128))) unsigned char g_zero_line[128];   // ze
 
 }  // namespace
 int g_ig_bn = 0, g_ig_nst = 0, g_ig_splits = 0;
+int g_ig_pcls = []() { const char *e = getenv("PD_IG_PCLS"); return e ? atoi(e) : 1; }();
 int g_ig_patch = []() { const char *e = getenv("PD_IG_PATCH"); return e ? atoi(e) : 1; }();   // 0: the gathered kernel for the 3 x 3 convolutions too (A/B)              // pd_debug_set "ig_bn" / "ig_nst" / "ig_splits" (tools/ only; 0 = automatic)
 namespace {
 
@@ -64,6 +65,7 @@ struct IgArgs {
   int act, gate_mode, res_mode, bias_bf16;
   int splits, kt_per;
   int ntn, ntiles;
+  int pcls, tpc;                                         // stride-2 input gradient by parity class: tiles per class (see make_plan)
 };
 
 __device__ __forceinline__ int xcd_chunk(int bid, int nb) { return pd_xcd_chunk(bid, nb); }   // xcd.h: any workgroup count
@@ -159,8 +161,12 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : (NST == 2 || BN == 64) ? 2 : 1)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lb = xcd_chunk(blockIdx.x, gridDim.x);
   const int tile = lb / a.splits, split = lb - tile * a.splits;
-  const int m0 = (tile / a.ntn) * BM, n0 = (tile % a.ntn) * BN;
-  const int kt0 = split * a.kt_per, kt1 = min(a.KT, kt0 + a.kt_per);
+  // parity classes (stride-2 input gradient): the row tiles of result pixels (2 py + cy, 2 px + cx) of ONE class (cy, cx) — a class only meets the
+  // taps of its own parity (1, 2, 2 or 4 of the 9), so its contraction has ntap x cch steps instead of 9 x cch of which 3 / 4 multiply zeros
+  const int mtile = tile / a.ntn, cls = a.pcls ? mtile / a.tpc : 0, cy = cls >> 1, cx = cls & 1;
+  const int m0 = (a.pcls ? mtile - cls * a.tpc : mtile) * BM, n0 = (tile % a.ntn) * BN;
+  const int ntx = cx ? 2 : 1, KTc = a.pcls ? (cy ? 2 : 1) * ntx * a.cch : a.KT;
+  const int kt0 = split * a.kt_per, kt1 = min(KTc, kt0 + a.kt_per);
   const int wm = BN == 128 ? (wave >> 1) * 64 : wave * 32, wn = BN == 128 ? (wave & 1) * 64 : 0;
 
   // ---- the four A rows this thread fetches (16-byte chunk lane & 7 of rows (wave * 4 + j) * 8 + lane / 8)
@@ -185,7 +191,15 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : (NST == 2 || BN == 64) ? 2 : 1)
       bb[j] = m < a.M ? 0 : -1; y0[j] = 0; x0[j] = 0;
       continue;
     }
-    if (m < a.M) {
+    if (a.pcls) {
+      const int hh = a.Ho >> 1, wh = a.Wo >> 1, hw = hh * wh;
+      if (m < a.M >> 2) {
+        const int b = m / hw, rem = m - b * hw, py = rem / wh, px = rem - py * wh;
+        bb[j] = b * a.Hs * a.Ws; y0[j] = 2 * py + cy + a.pad; x0[j] = 2 * px + cx + a.pad;
+      } else {
+        bb[j] = -1; y0[j] = 0; x0[j] = 0;
+      }
+    } else if (m < a.M) {
       const int hw = a.Ho * a.Wo, b = m / hw, rem = m - b * hw, oy = rem / a.Wo, ox = rem - oy * a.Wo;
       bb[j] = b * a.Hs * a.Ws;
       y0[j] = a.dgrad ? oy + a.pad : oy * a.stride - a.pad;
@@ -213,8 +227,15 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : (NST == 2 || BN == 64) ? 2 : 1)
         __builtin_amdgcn_global_load_lds((glb_ptr)(wb[j] + (int64_t)kt * 64), (lds_ptr)(Bs + (wave * NBJ + j) * 1024), 16, 0, 0);
       return;
     }
-    const int tap = kt / a.cch, c0 = (kt - tap * a.cch) * 64;
-    const int dy = tap / a.kw, dx = tap - dy * a.kw;
+    int tap = kt / a.cch;
+    const int c0 = (kt - tap * a.cch) * 64;
+    int dy = tap / a.kw, dx = tap - dy * a.kw;
+    int64_t kw_ = kt;                                      // the filter's K-step of this (tap, chunk)
+    if (a.pcls) {                                          // tap = index into the class's tap list: dy in {1} | {0, 2}, dx likewise
+      const int ty_ = tap / ntx, tx_ = tap - ty_ * ntx;
+      dy = cy ? 2 * ty_ : 1; dx = cx ? 2 * tx_ : 1;
+      kw_ = (int64_t)(dy * a.kw + dx) * a.cch + (kt - tap * a.cch);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int sy, sx;
@@ -234,7 +255,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : (NST == 2 || BN == 64) ? 2 : 1)
     }
 #pragma unroll
     for (int j = 0; j < NBJ; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(wb[j] + (int64_t)kt * 64), (lds_ptr)(Bs + (wave * NBJ + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)(wb[j] + kw_ * 64), (lds_ptr)(Bs + (wave * NBJ + j) * 1024), 16, 0, 0);
   };
 
   f32x16 acc[2][MI];
@@ -356,8 +377,15 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : (NST == 2 || BN == 64) ? 2 : 1)
   // ---- epilogue, straight from the accumulators (see swap_halves)
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
-    const int m = m0 + wm + j * 32 + fr;
-    epilogue_rows<BN>(a, acc[0][j], acc[1][j], reinterpret_cast<const float *>(smem + SB_OFF), m, m < a.M, n0, wn, kh);
+    int m = m0 + wm + j * 32 + fr;
+    bool rowok = m < a.M;
+    if (a.pcls) {                                          // class-local pixel -> its row of the result grid
+      const int hh = a.Ho >> 1, wh = a.Wo >> 1, hw = hh * wh;
+      rowok = m < a.M >> 2;
+      const int mm = rowok ? m : 0, b = mm / hw, rem = mm - b * hw, py = rem / wh, px = rem - py * wh;
+      m = (b * a.Ho + 2 * py + cy) * a.Wo + 2 * px + cx;
+    }
+    epilogue_rows<BN>(a, acc[0][j], acc[1][j], reinterpret_cast<const float *>(smem + SB_OFF), m, rowok, n0, wn, kh);
   }
 }
 
@@ -530,6 +558,20 @@ int make_plan(const PdIgemm *p, Plan &pl)
   a.kt_per = (a.KT + splits - 1) / splits;
   a.splits = (a.KT + a.kt_per - 1) / a.kt_per;
   pl.slab_bytes = a.splits > 1 ? (int64_t)a.ntiles * a.splits * BM * pl.bn * 4 : 0;
+  // stride-2 3 x 3 input gradient on an even result grid: parity classes (no split-K; pd_debug_set("ig_pcls", 0) keeps the nine-tap walk)
+  a.pcls = 0; a.tpc = 0;
+  if (p->dgrad && p->k == 3 && p->stride == 2 && !((p->ho | p->wo) & 1) && g_ig_pcls != 0) {
+    a.pcls = 1;
+    a.tpc = (a.M / 4 + BM - 1) / BM;
+    pl.bn = (p->n % 128 == 0 && a.tpc * 4 * (p->n / 128) >= 384) ? 128 : 64;
+    if (g_ig_bn == 64 || (g_ig_bn == 128 && p->n % 128 == 0)) pl.bn = g_ig_bn;
+    a.ntn = p->n / pl.bn;
+    a.ntiles = 4 * a.tpc * a.ntn;
+    pl.nst = pl.bn == 128 ? 2 : 3;
+    if (g_ig_nst >= 1 && g_ig_nst <= 3) pl.nst = g_ig_nst;
+    a.splits = 1; a.kt_per = a.KT;
+    pl.slab_bytes = 0;
+  }
   // 3 x 3, stride 1, same-size grids: the patch form, when its 8 x 16 blocks fill the chip without split-K (res5's 16 blocks x 8 column tiles keep
   // the gathered kernel's split-K); pd_debug_set("ig_patch", 0) keeps the gathered kernel, 2 forces the patch form wherever it is defined
   pl.patch3 = false;
