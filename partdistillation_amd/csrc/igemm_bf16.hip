@@ -80,6 +80,58 @@ __device__ __forceinline__ void swap_halves(float &a, float &b)
   a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
 }
 
+// split-K seam: this workgroup's partial tile -> its slab; the LAST workgroup of the tile to arrive (agent-scope release / ticket / acquire) sums
+// all slabs in split order (deterministic) and goes on to the epilogue (-> true); the others are done (-> false)
+template <int MI>
+__device__ __forceinline__ bool splitk_seam(const IgArgs &a, f32x16 (&acc)[2][MI], int tile, int split, int t, unsigned char *smem)
+{
+  float4 *slab = reinterpret_cast<float4 *>(a.slabs) + ((int64_t)tile * a.splits + split) * (2 * MI * 4 * 256);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        slab[((i * MI + j) * 4 + q) * 256 + t] = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int *flag = reinterpret_cast<int *>(smem);
+  if (t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned old = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == (unsigned)(a.splits - 1);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left zero for the next launch
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  if (*flag == 0) return false;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const float4 *s0 = reinterpret_cast<const float4 *>(a.slabs) + (int64_t)tile * a.splits * (2 * MI * 4 * 256);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  for (int sp = 0; sp < a.splits; ++sp) {
+    const float4 *sl = s0 + (int64_t)sp * (2 * MI * 4 * 256);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = sl[((i * MI + j) * 4 + q) * 256 + t];
+          acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+        }
+  }
+  return true;
+}
+
 // the epilogue of one 32-pixel sub-tile of a wavefront (result pixel m of this lane, 64 columns from n0 + wn): acc * scale + bias (+ residuals) ->
 // optional pre-activation copy -> activation -> gate -> bf16, 8 consecutive channels per lane (see swap_halves)
 template <int BN>
@@ -327,52 +379,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : (NST == 2 || BN == 64) ? 2 : 1)
   }
 
   // ---- split-K: partial tile -> slab; the last workgroup of the tile to arrive sums all slabs in split order
-  if (a.splits > 1) {
-    float4 *slab = reinterpret_cast<float4 *>(a.slabs) + ((int64_t)tile * a.splits + split) * (2 * MI * 4 * 256);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < MI; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          slab[((i * MI + j) * 4 + q) * 256 + t] = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int *flag = reinterpret_cast<int *>(smem);
-    if (t == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned old = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = old == (unsigned)(a.splits - 1);
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left zero for the next launch
-      }
-      *flag = last;
-    }
-    __syncthreads();
-    if (*flag == 0) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const float4 *s0 = reinterpret_cast<const float4 *>(a.slabs) + (int64_t)tile * a.splits * (2 * MI * 4 * 256);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < MI; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    for (int s = 0; s < a.splits; ++s) {
-      const float4 *sl = s0 + (int64_t)s * (2 * MI * 4 * 256);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 v = sl[((i * MI + j) * 4 + q) * 256 + t];
-            acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
-          }
-    }
-  }
+  if (a.splits > 1 && !splitk_seam<MI>(a, acc, tile, split, t, smem)) return;
 
   // ---- epilogue, straight from the accumulators (see swap_halves)
 #pragma unroll
@@ -409,7 +416,9 @@ __global__ __launch_bounds__(256, 2) void igemm3x3_bf16(IgArgs a)
   const float *const sb = reinterpret_cast<const float *>(smem + 2 * PATCH3 + 3 * BT);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lb = xcd_chunk(blockIdx.x, gridDim.x);
-  const int mt = lb / a.ntn, n0 = (lb - mt * a.ntn) * BN;
+  const int tile = lb / a.splits, split = lb - tile * a.splits;     // split-K over the channel chunks (few blocks under a long contraction: res5)
+  const int mt = tile / a.ntn, n0 = (tile - mt * a.ntn) * BN;
+  const int cbeg = split * a.kt_per, cend = min(a.cch, cbeg + a.kt_per);   // (kt_per = channel chunks per split here)
   const int txn = (a.Wo + TW3 - 1) / TW3, tyn = (a.Ho + TH3 - 1) / TH3;
   const int b = mt / (tyn * txn), r_ = mt - b * (tyn * txn), ty0 = (r_ / txn) * TH3, tx0 = (r_ - (r_ / txn) * txn) * TW3;
   const int lrow = lane >> 3, lch = lane & 7;
@@ -442,24 +451,24 @@ __global__ __launch_bounds__(256, 2) void igemm3x3_bf16(IgArgs a)
     for (int j = 0; j < 6; ++j)
       __builtin_amdgcn_global_load_lds((glb_ptr)(pok[j] ? pp[j] + c * 64 : pp[j]), (lds_ptr)(patch + buf * PATCH3 + (wave * 6 + j) * 1024), 16, 0, 0);
   };
-  auto issue_b = [&](int step, int buf) {                  // step = 9 c + tap; the filter's K index is tap * cch + c
-    const int c = step / 9, tap = step - 9 * c, kt = tap * a.cch + c;
+  auto issue_b = [&](int step, int buf) {                  // step = 9 (c - cbeg) + tap; the filter's K index is tap * cch + c
+    const int c = cbeg + step / 9, tap = step - 9 * (c - cbeg), kt = tap * a.cch + c;
 #pragma unroll
     for (int j = 0; j < NBJ; ++j)
       __builtin_amdgcn_global_load_lds((glb_ptr)(wb[j] + (int64_t)kt * 64), (lds_ptr)(bring + buf * BT + (wave * NBJ + j) * 1024), 16, 0, 0);
   };
-  f32x16 acc[2];
+  f32x16 acc[2][1];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.f;
   const int fr = lane & 31, kh = lane >> 5, sw = (fr >> 1) & 7;
   int foff[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) foff[ks] = ((ks * 2 + kh) ^ sw) * 16;
   const int pty = 2 * wave + (fr >> 4), ptx = fr & 15;     // this lane's result pixel inside the block
   auto compute = [&](int step, int bbuf) {
-    const int c = step / 9, tap = step - 9 * c, dy = tap / 3, dx = tap - 3 * dy;
+    const int c = step / 9, tap = step - 9 * c, dy = tap / 3, dx = tap - 3 * dy;       // (c: chunk index inside this split)
     const int pr = (pty + (a.dgrad ? 2 - dy : dy)) * PW3 + ptx + (a.dgrad ? 2 - dx : dx), psw = (pr >> 1) & 7;
     const unsigned char *As = patch + (c & 1) * PATCH3 + pr * BKB, *Bs = bring + bbuf * BT;
 #pragma unroll
@@ -469,38 +478,39 @@ __global__ __launch_bounds__(256, 2) void igemm3x3_bf16(IgArgs a)
       for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const hwbf16x8 *>(Bs + (i * 32 + fr) * BKB + foff[ks]);
       const hwbf16x8 af = *reinterpret_cast<const hwbf16x8 *>(As + ((ks * 2 + kh) ^ psw) * 16);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af, acc[i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af, acc[i][0], 0, 0, 0);
     }
   };
   if (t < 2 * BN) reinterpret_cast<float *>(smem + 2 * PATCH3 + 3 * BT)[t] = sbv;
   // ---- the step loop: weight tiles two steps ahead on the ring; chunk c + 1's patch is issued in the slot of chunk c's first step.
   // Counted waits (loads complete in issue order): behind step s's weight tile the queue holds step s + 1's tile (2 pieces per wavefront)
   // and, when the previous slot also issued a patch, its 6 pieces
-  const int nsteps = 9 * a.cch;
-  issue_patch(0, 0);
+  const int ncl = cend - cbeg, nsteps = 9 * ncl;           // (patch buffers alternate with the LOCAL chunk index)
+  issue_patch(cbeg, 0);
   issue_b(0, 0);
   if (nsteps > 1) issue_b(1, 1);
   int bbuf = 0;
   for (int s = 0; s < nsteps; ++s) {
     if (s + 1 < nsteps) {
       const int ps = s - 1;                                // the slot before this wait issued: weights of step s + 1, and a patch when it was a chunk's first step
-      const bool patch_behind = ps >= 0 && ps % 9 == 0 && ps / 9 + 1 < a.cch;
+      const bool patch_behind = ps >= 0 && ps % 9 == 0 && ps / 9 + 1 < ncl;
       if (patch_behind) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                          // step s (and its chunk's patch) landed for everyone; everyone is done reading step s - 1's stage
-    if (s % 9 == 0 && s / 9 + 1 < a.cch) issue_patch(s / 9 + 1, (s / 9 + 1) & 1);
+    if (s % 9 == 0 && s / 9 + 1 < ncl) issue_patch(cbeg + s / 9 + 1, (s / 9 + 1) & 1);
     if (s + 2 < nsteps) issue_b(s + 2, bbuf == 0 ? 2 : bbuf - 1);
     compute(s, bbuf);
     bbuf = bbuf == 2 ? 0 : bbuf + 1;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
+  if (a.splits > 1 && !splitk_seam<1>(a, acc, tile, split, t, smem)) return;
   const int y = ty0 + pty, x = tx0 + ptx;
   const bool rowok = y < a.Ho && x < a.Wo;
   const int m = rowok ? (b * a.Ho + y) * a.Wo + x : 0;
-  epilogue_rows<BN>(a, acc[0], acc[1], sb, m, rowok, n0, 0, kh);
+  epilogue_rows<BN>(a, acc[0][0], acc[1][0], sb, m, rowok, n0, 0, kh);
 }
 
 struct Plan {
@@ -577,13 +587,19 @@ int make_plan(const PdIgemm *p, Plan &pl)
   pl.patch3 = false;
   if (p->k == 3 && p->stride == 1 && p->pad == 1 && p->hs == p->ho && p->ws == p->wo && g_ig_patch != 0) {
     const int blocks = p->batch * ((p->ho + TH3 - 1) / TH3) * ((p->wo + TW3 - 1) / TW3) * (p->n / 64);
-    if (blocks >= 192 || g_ig_patch == 2) {
+    if (blocks <= 4096) {                                  // (ticket array of the split-K seam)
       pl.patch3 = true;
       pl.bn = 64; pl.nst = 3;
       a.ntn = p->n / 64;
       a.ntiles = blocks;
-      a.splits = 1; a.kt_per = a.KT;
-      pl.slab_bytes = 0;
+      // few blocks under many channel chunks (res5: 128 blocks x 8 chunks): the chunks are split over workgroups, fp32 slabs + last arriver
+      int sp = 1;
+      if (blocks < 192 && a.cch >= 4) sp = blocks <= 64 ? 4 : blocks <= 128 ? 3 : 2;
+      if (g_ig_splits > 0) sp = g_ig_splits;
+      if (sp > a.cch) sp = a.cch;
+      a.kt_per = (a.cch + sp - 1) / sp;                    // channel chunks per split
+      a.splits = (a.cch + a.kt_per - 1) / a.kt_per;
+      pl.slab_bytes = a.splits > 1 ? (int64_t)a.ntiles * a.splits * BM * 64 * 4 : 0;
     }
   }
   return PD_OK;
@@ -619,7 +635,7 @@ int launch_plan(const Plan &pl, hipStream_t st)
     constexpr size_t lds = (size_t)2 * PATCH3 + 3 * 64 * BKB + 2 * 64 * sizeof(float);
     static bool attr3 = false;
     if (!attr3) { (void)hipFuncSetAttribute((const void *)igemm3x3_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr3 = true; }
-    hipLaunchKernelGGL(igemm3x3_bf16, dim3((unsigned)pl.a.ntiles), dim3(256), lds, st, pl.a);
+    hipLaunchKernelGGL(igemm3x3_bf16, dim3((unsigned)(pl.a.ntiles * pl.a.splits)), dim3(256), lds, st, pl.a);
     return pd_check_launch("pd_igemm_bf16 (3 x 3 patch form)");
   }
   if (pl.bn == 128) return pl.nst == 3 ? launch<128, 3>(pl, st) : pl.nst == 2 ? launch<128, 2>(pl, st) : launch<128, 1>(pl, st);
