@@ -403,7 +403,9 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : (NST == 2 || BN == 64) ? 2 : 1)
 // LDS ONCE and the nine taps read their fragments from it at shifted rows (same XOR swizzle, keyed by the patch row), so a step only waits for
 // its 8 KB weight tile: 2.3 x fewer bytes per tile at 64 channels (23 + 72 KB instead of 216), and the patch of chunk c + 1 streams in under
 // the nine steps of chunk c.  Forward (source row = result row - 1 + dy) and input gradient (result row + 1 - dy: the caller's transposed
-// filter, as above).  64-column tiles, weight tiles on a three-stage ring, two workgroups per CU.
+// filter, as above).  64-column tiles, weight tiles on a three-stage ring, two workgroups per CU.  (Measured and dropped: a four-stage ring — three
+// steps ahead, patch buffers trimmed to 180 rows so that two workgroups still fit a CU — 639 vs 619 us over the step's 26 launches: the steps do not
+// wait for their weight tiles.)
 constexpr int TH3 = 8, TW3 = 16, PW3 = TW3 + 2, PROWS3 = (TH3 + 2) * PW3, PPIECES3 = 24;       // 180 patch rows in 24 pieces of 8 rows (the last 12 rows: zeros)
 constexpr int PATCH3 = PPIECES3 * 1024;
 
