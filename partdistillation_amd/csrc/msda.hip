@@ -25,6 +25,7 @@
 // HBM-bound kernel: algorithmic bytes per launch are value + loc + attn + out
 // (forward), see DESIGN.md.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,6 +38,7 @@ int g_pd_dbg_force_generic = 0;
 int g_pd_dbg_bwd_threads = 0;
 int g_pd_dbg_ablate = 0;
 int g_pd_dbg_atomic_scope = 0;   // experiments only (pd_debug_set): 0 = agent scope, 1 = workgroup scope
+int g_msda_fwd_q4 = []() { const char *e = getenv("PD_MSDA_FWD_Q4"); return e ? atoi(e) : 1; }();   // 0: the 8-lane forward kernels (A/B)
 int g_pd_dbg_bwd_variant = 0;    // experiments only: 1 = the per-destination-level tiled backward instead of the all-level owner kernel
 
 namespace {
@@ -234,6 +236,157 @@ __global__ __launch_bounds__(256, 4) void msda_fwd_d32(const float *__restrict__
       // and store — eight atomics of one wave instruction on one address serialise (they cost this kernel 35 us per launch)
       mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       if ((threadIdx.x & 63) == 0) row_amax[qm / M] = __float_as_uint(mx);
+    } else if (sub == 0 && mx > 0.f) {
+      atomicMax(row_amax + qm / M, __float_as_uint(mx));
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------- fast forward, 4 lanes per (query, head)  (round 6)
+// msda_fwd_d32 spends most of its instructions on work all 8 lanes of a (query, head) group do alike: the 12-way softmax and, per sampling
+// point, ~45 instructions of geometry (floor, clamps, four offsets, four masks, four weights) — 540 of its ~890 instructions per lane.  Here a
+// (query, head) is FOUR lanes that own 8 channels each (4 sub .. + 3 and 16 + 4 sub .. + 3: a wave instruction still reads 64 contiguous
+// bytes per group) and lane `sub` works out point `sub` of each level ONCE — 3 points per lane instead of 12 — then hands the point's four
+// offsets, four weights (mask and attention weight folded in) and mask bits round the quad as DPP quad_perm broadcasts (9 moves per point).
+// The softmax is one exponential per lane and level + two quad reductions.  Per (query, head): ~2 800 issued instructions instead of ~7 100.
+// A masked corner loads from a zero row (the reference never reads it: a NaN there must not leak through a 0 weight).
+__device__ __attribute__((aligned(128))) float g_msda_zero_row[32];
+
+template <int P>
+__device__ __forceinline__ int quad_bcast_i(int x) { return __builtin_amdgcn_update_dpp(0, x, P * 0x55, 0xF, 0xF, true); }
+template <int P>
+__device__ __forceinline__ float quad_bcast_f(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), P * 0x55, 0xF, 0xF, true)); }
+__device__ __forceinline__ float quad_max(float x)
+{
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true)));
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true)));
+  return x;
+}
+__device__ __forceinline__ float quad_sum(float x)
+{
+  x = dpp_add<0xB1>(x);
+  x = dpp_add<0x4E>(x);
+  return x;
+}
+
+template <int L_, int P_, bool FUSED>
+__global__ __launch_bounds__(256, 4) void msda_fwd_q4(const float *__restrict__ value, const int64_t *__restrict__ shapes,
+                                                    const int64_t *__restrict__ lvl_start, const float *__restrict__ loc,
+                                                    const float *__restrict__ attn, float *__restrict__ out,
+                                                    int S, int M, int Lq, int total_qm, unsigned *__restrict__ row_amax,
+                                                    int ld_oa = 0, float2 *__restrict__ stats = nullptr, int band_major = 0)
+{
+  static_assert(P_ == 4, "one sampling point per lane of the quad");
+  const int lb = xcd_chunked_block(blockIdx.x, gridDim.x);
+  int qm = lb * 64 + (threadIdx.x >> 2);
+  if constexpr (FUSED) {
+    // band-major query order (see msda_fwd_d32): 8 queries x 8 heads per block here
+    const int n0 = (int)(shapes[0] * shapes[1]), n1 = (int)(shapes[2] * shapes[3]), n2 = (int)(shapes[4] * shapes[5]);
+    if (band_major && M == 8 && Lq == S && n0 + n1 + n2 == S && !((n0 | n1 | n2) & 63) && (gridDim.x & 7) == 0 && total_qm == (int)gridDim.x * 64) {
+      const int per = gridDim.x >> 3, k = lb / per, p = (lb - k * per) * 8 + (threadIdx.x >> 5);
+      const int sq = S >> 3, bimg = p / sq, r = p - bimg * sq;
+      const int b0 = n0 >> 3, b1 = n1 >> 3, b2 = n2 >> 3;
+      int q;
+      if (r < b0) q = k * b0 + r;
+      else if (r < b0 + b1) q = n0 + k * b1 + (r - b0);
+      else q = n0 + n1 + k * b2 + (r - b0 - b1);
+      qm = (bimg * S + q) * 8 + ((threadIdx.x >> 2) & 7);
+    }
+  }
+  if (qm >= total_qm) return;                              // (uniform inside a quad)
+  const int sub = threadIdx.x & 3;
+  const int m = qm % M;
+  const int b = (qm / M) / Lq;
+  const int stride_w = M * 32;
+  // ---- this lane's point of every level: location and attention weight
+  float px[L_], py[L_], pa[L_];
+  if constexpr (FUSED) {
+    const int64_t bq = qm / M;
+    const float *row = loc + bq * ld_oa;
+    const float *offs = row + m * (L_ * P_ * 2) + sub * 2, *lg = row + M * (L_ * P_ * 2) + m * (L_ * P_) + sub;
+    const float *refp = attn + bq * (L_ * 2);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int l = 0; l < L_; ++l) { pa[l] = lg[l * P_]; mx = fmaxf(mx, pa[l]); }
+    mx = quad_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int l = 0; l < L_; ++l) { pa[l] = __expf(pa[l] - mx); sum += pa[l]; }
+    const float inv = 1.f / quad_sum(sum);
+#pragma unroll
+    for (int l = 0; l < L_; ++l) pa[l] *= inv;
+    if (stats && sub == 0) stats[qm] = make_float2(mx, inv);
+#pragma unroll
+    for (int l = 0; l < L_; ++l) {
+      const float2 o = *reinterpret_cast<const float2 *>(offs + l * (P_ * 2));
+      const float rx = refp[2 * l], ry = refp[2 * l + 1];
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const float fw = (float)W, fh = (float)H;
+      if (((W & (W - 1)) | (H & (H - 1))) == 0) { px[l] = rx + o.x * (1.f / fw); py[l] = ry + o.y * (1.f / fh); }   // powers of two: the product IS the quotient
+      else { px[l] = rx + o.x / fw; py[l] = ry + o.y / fh; }
+    }
+  } else {
+#pragma unroll
+    for (int l = 0; l < L_; ++l) {
+      const float2 o = *reinterpret_cast<const float2 *>(loc + ((int64_t)qm * (L_ * P_) + l * P_ + sub) * 2);
+      px[l] = o.x; py[l] = o.y;
+      pa[l] = attn[(int64_t)qm * (L_ * P_) + l * P_ + sub];
+    }
+  }
+  const float *zrow = g_msda_zero_row + sub * 4;
+  float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+#pragma unroll
+  for (int l = 0; l < L_; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const float *vbase = value + ((int64_t)b * S + lvl_start[l]) * stride_w + m * 32 + sub * 4;
+    const float h_im = py[l] * H - 0.5f, w_im = px[l] * W - 0.5f;
+    const bool in_range = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+    int off[4]; bool ok[4]; float cw[4], lh, lw, hh, hw;
+    corner_setup<float>(h_im, w_im, H, W, stride_w, in_range, off, ok, cw, lh, lw, hh, hw);
+    float wk[4];
+    int okm = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { wk[k] = ok[k] ? cw[k] * pa[l] : 0.f; okm |= ok[k] ? 1 << k : 0; }
+    // ---- the level's four points in turn, two at a time in flight: lane p's geometry to the whole quad
+    auto point = [&](auto PC, float4 (&v)[4][2], float (&w4)[4]) {
+      constexpr int Pn = decltype(PC)::value;
+      const int bm = quad_bcast_i<Pn>(okm);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int bo = quad_bcast_i<Pn>(off[k]);
+        w4[k] = quad_bcast_f<Pn>(wk[k]);
+        const float *src = (bm >> k) & 1 ? vbase + bo : zrow;
+        v[k][0] = *reinterpret_cast<const float4 *>(src);
+        v[k][1] = *reinterpret_cast<const float4 *>(src + 16);
+      }
+    };
+    auto accumulate = [&](const float4 (&v)[4][2], const float (&w4)[4]) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc0.x += w4[k] * v[k][0].x; acc0.y += w4[k] * v[k][0].y; acc0.z += w4[k] * v[k][0].z; acc0.w += w4[k] * v[k][0].w;
+        acc1.x += w4[k] * v[k][1].x; acc1.y += w4[k] * v[k][1].y; acc1.z += w4[k] * v[k][1].z; acc1.w += w4[k] * v[k][1].w;
+      }
+    };
+    float4 va[4][2], vb[4][2];
+    float wa[4], wb[4];
+    point(std::integral_constant<int, 0>(), va, wa);
+    point(std::integral_constant<int, 1>(), vb, wb);
+    accumulate(va, wa);
+    point(std::integral_constant<int, 2>(), va, wa);
+    accumulate(vb, wb);
+    point(std::integral_constant<int, 3>(), vb, wb);
+    accumulate(va, wa);
+    accumulate(vb, wb);
+  }
+  *reinterpret_cast<float4 *>(out + (int64_t)qm * 32 + sub * 4) = acc0;
+  *reinterpret_cast<float4 *>(out + (int64_t)qm * 32 + 16 + sub * 4) = acc1;
+  if (row_amax) {
+    float mx = fmaxf(fmaxf(fmaxf(fabsf(acc0.x), fabsf(acc0.y)), fmaxf(fabsf(acc0.z), fabsf(acc0.w))),
+                     fmaxf(fmaxf(fabsf(acc1.x), fabsf(acc1.y)), fmaxf(fabsf(acc1.z), fabsf(acc1.w))));
+    mx = quad_max(mx);
+    if (M == 8) {                                          // a half wavefront = the eight heads of one query: reduce across them, one plain store
+      mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      if ((threadIdx.x & 31) == 0) row_amax[qm / M] = __float_as_uint(mx);
     } else if (sub == 0 && mx > 0.f) {
       atomicMax(row_amax + qm / M, __float_as_uint(mx));
     }
@@ -1104,6 +1257,13 @@ static int msda_forward_launch(const void *value, const int64_t *spatial_shapes,
   if (total_qm == 0) return PD_OK;
   // (the reference splits the batch into im2col_step chunks only to bound its launch size; one launch here)
   if (dtype == PD_F32 && channels == 32 && num_levels == 3 && num_point == 4 && total_qm < (1LL << 31)) {
+    if (g_msda_fwd_q4) {                                  // four lanes per (query, head), a point's geometry once per quad (round 6)
+      const int nblocks = round_up8((total_qm + 63) / 64);
+      hipLaunchKernelGGL((msda_fwd_q4<3, 4, false>), dim3(nblocks), dim3(256), 0, stream, (const float *)value, spatial_shapes,
+                         level_start_index, (const float *)sampling_loc, (const float *)attn_weight, (float *)output,
+                         spatial_size, num_heads, num_query, (int)total_qm, reinterpret_cast<unsigned *>(row_amax));
+      return pd_check_launch("pd_msda_forward");
+    }
     const int nblocks = round_up8((total_qm + 31) / 32);
     hipLaunchKernelGGL((msda_fwd_d32<3, 4>), dim3(nblocks), dim3(256), 0, stream, (const float *)value, spatial_shapes,
                        level_start_index, (const float *)sampling_loc, (const float *)attn_weight, (float *)output,
@@ -1364,8 +1524,15 @@ extern "C" int pd_msda_fused_forward(const float *value, const int64_t *spatial_
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_msda_fused_forward: projection rows need >= 3 M L P columns, a stride that is a multiple of 4 and a 16-byte aligned base");
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t total_qm = (int64_t)batch * num_query * num_heads;
-  const int nblocks = round_up8((total_qm + 31) / 32);
   static const bool band_env = []() { const char *e = getenv("PD_MSDA_BAND"); return !e || e[0] != '0'; }();   // A/B switch
+  if (g_msda_fwd_q4) {
+    const int nb4 = round_up8((total_qm + 63) / 64);
+    hipLaunchKernelGGL((msda_fwd_q4<3, 4, true>), dim3(nb4), dim3(256), 0, stream, value, spatial_shapes, level_start_index, oa, ref, output,
+                       spatial_size, num_heads, num_query, (int)total_qm, reinterpret_cast<unsigned *>(row_amax), ld_oa, reinterpret_cast<float2 *>(stats),
+                       (g_pd_dbg_ablate == 128 || !band_env) ? 0 : 1);
+    return pd_check_launch("pd_msda_fused_forward");
+  }
+  const int nblocks = round_up8((total_qm + 31) / 32);
   hipLaunchKernelGGL((msda_fwd_d32<3, 4, true>), dim3(nblocks), dim3(256), 0, stream, value, spatial_shapes, level_start_index, oa, ref, output,
                      spatial_size, num_heads, num_query, (int)total_qm, reinterpret_cast<unsigned *>(row_amax), ld_oa, reinterpret_cast<float2 *>(stats),
                      (g_pd_dbg_ablate == 128 || !band_env) ? 0 : 1);
