@@ -480,7 +480,7 @@ def main():
         avg = lambda xs: sum(xs) / max(len(xs), 1)
         kernels = []
         if fwd_ms:
-            kernels.append({"kernel": "msda_fwd_d32", "launches": len(fwd_ms), "avg_ms": avg(fwd_ms),
+            kernels.append({"kernel": "msda_fwd_d32" if os.environ.get("PD_MSDA_FWD_Q4", "1") == "0" else "msda_fwd_q4", "launches": len(fwd_ms), "avg_ms": avg(fwd_ms),
                             "alg_bytes": fb, "achieved_GBs": fb / avg(fwd_ms) / 1e6})
         if bwd_ms:
             import ctypes
