@@ -74,6 +74,7 @@ __device__ __forceinline__ float gelu_grad_f(float x) { return pdgelu::gelu_grad
 
 // lanes l < 32 and l + 32 hold the channel quads [8q .. 8q+3] and [8q+4 .. 8q+7] of pixel l for q = 0..3.  After swapping the upper
 // half of quad 2p with the lower half of quad 2p + 1, lane l < 32 holds channels 16p .. 16p+7 and lane l + 32 channels 16p+8 .. 16p+15.
+__device__ __forceinline__ void pin_regs(uint4 &r) { asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
 __device__ __forceinline__ void swap_halves(float &a, float &b)
 {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
@@ -130,76 +131,6 @@ __device__ __forceinline__ bool splitk_seam(const IgArgs &a, f32x16 (&acc)[2][MI
         }
   }
   return true;
-}
-
-// the epilogue of one 32-pixel sub-tile of a wavefront (result pixel m of this lane, 64 columns from n0 + wn): acc * scale + bias (+ residuals) ->
-// optional pre-activation copy -> activation -> gate -> bf16, 8 consecutive channels per lane (see swap_halves)
-template <int BN>
-__device__ __forceinline__ void epilogue_rows(const IgArgs &a, const f32x16 &c0, const f32x16 &c1, const float *sb, int m, bool rowok, int n0, int wn, int kh)
-{
-  int64_t roff = 0;
-  bool has_res = a.res != nullptr;
-  if (a.res && a.res_mode == PD_IG_RES_UP2) {
-    const int mm = rowok ? m : 0, hw = a.Ho * a.Wo, b = mm / hw, rem = mm - b * hw, y = rem / a.Wo, x = rem - y * a.Wo;
-    has_res = ((y | x) & 1) == 0;
-    roff = ((int64_t)(b * (a.Ho >> 1) + (y >> 1)) * (a.Wo >> 1) + (x >> 1)) * a.N;
-  } else {
-    roff = (int64_t)m * a.N;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const f32x16 &c = i ? c1 : c0;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = c[8 * p + e]; v[4 + e] = c[8 * p + 4 + e]; }
-      // v[0..3] = quad 2p, v[4..7] = quad 2p+1 of this lane; after the swaps: 8 consecutive channels
-#pragma unroll
-      for (int e = 0; e < 4; ++e) swap_halves(v[e], v[4 + e]);
-      // lane < 32: v[0..3] = own quad 2p (ch +0..3), v[4..7] = partner's quad 2p (ch +4..7);  lane >= 32: quad 2p+1 likewise
-      const int cl = wn + i * 32 + p * 16 + kh * 8, cc = n0 + cl;
-      {
-        const float4 s0 = *reinterpret_cast<const float4 *>(sb + cl), s1 = *reinterpret_cast<const float4 *>(sb + cl + 4);
-        const float4 b0 = *reinterpret_cast<const float4 *>(sb + BN + cl), b1 = *reinterpret_cast<const float4 *>(sb + BN + cl + 4);
-        v[0] = v[0] * s0.x + b0.x; v[1] = v[1] * s0.y + b0.y; v[2] = v[2] * s0.z + b0.z; v[3] = v[3] * s0.w + b0.w;
-        v[4] = v[4] * s1.x + b1.x; v[5] = v[5] * s1.y + b1.y; v[6] = v[6] * s1.z + b1.z; v[7] = v[7] * s1.w + b1.w;
-      }
-      if (!rowok) continue;
-      const int64_t off = (int64_t)m * a.N + cc;
-      if (has_res) {
-        const uint4 r = *reinterpret_cast<const uint4 *>(a.res + roff + cc);
-        v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
-        v[4] += bf_lo(r.z); v[5] += bf_hi(r.z); v[6] += bf_lo(r.w); v[7] += bf_hi(r.w);
-      }
-      if (a.res2) {
-        const uint4 r = *reinterpret_cast<const uint4 *>(a.res2 + off);
-        v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
-        v[4] += bf_lo(r.z); v[5] += bf_hi(r.z); v[6] += bf_lo(r.w); v[7] += bf_hi(r.w);
-      }
-      if (a.Ypre)
-        *reinterpret_cast<uint4 *>(a.Ypre + off) = make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7]));
-      if (a.act == PD_IG_ACT_RELU) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      } else if (a.act == PD_IG_ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-      }
-      if (a.gate) {
-        const uint4 r = *reinterpret_cast<const uint4 *>(a.gate + off);
-        const float g[8] = {bf_lo(r.x), bf_hi(r.x), bf_lo(r.y), bf_hi(r.y), bf_lo(r.z), bf_hi(r.z), bf_lo(r.w), bf_hi(r.w)};
-        if (a.gate_mode == PD_IG_GATE_RELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = g[e] > 0.f ? v[e] : 0.f;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(g[e]);
-        }
-      }
-      *reinterpret_cast<uint4 *>(a.Y + off) = make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7]));
-    }
-  }
 }
 
 template <int BN, int NST, bool P1>
@@ -392,7 +323,9 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : (NST == 2 || BN == 64) ? 2 : 1)
       const int mm = rowok ? m : 0, b = mm / hw, rem = mm - b * hw, py = rem / wh, px = rem - py * wh;
       m = (b * a.Ho + 2 * py + cy) * a.Wo + 2 * px + cx;
     }
-    epilogue_rows<BN>(a, acc[0][j], acc[1][j], reinterpret_cast<const float *>(smem + SB_OFF), m, rowok, n0, wn, kh);
+    const float *sb = reinterpret_cast<const float *>(smem + SB_OFF);
+    constexpr bool EPI_PIPE = !(BN == 128 && NST == 1);    // (that instantiation lives on 128 VGPRs: one batch of operands at a time)
+#include "igemm_epilogue.inc"
   }
 }
 
@@ -512,7 +445,9 @@ __global__ __launch_bounds__(256, 2) void igemm3x3_bf16(IgArgs a)
   const int y = ty0 + pty, x = tx0 + ptx;
   const bool rowok = y < a.Ho && x < a.Wo;
   const int m = rowok ? (b * a.Ho + y) * a.Wo + x : 0;
-  epilogue_rows<BN>(a, acc[0][0], acc[1][0], sb, m, rowok, n0, 0, kh);
+  constexpr int j = 0, wn = 0;
+  constexpr bool EPI_PIPE = true;
+#include "igemm_epilogue.inc"
 }
 
 struct Plan {

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--out", default=None)
     ap.add_argument("--top", type=int, default=60)
+    ap.add_argument("--list", default=None, help="regex: list every launch of the LAST step whose kernel name matches, in issue order")
     a = ap.parse_args()
     csv.field_size_limit(1 << 30)
     rows = []
@@ -46,6 +47,12 @@ def main():
             agg[n][0] += 1
             agg[n][1] += e - s
             busy += e - s
+    if a.list:
+        t1 = t_end - int(a.last_ms * 1e6 / a.steps)
+        pat = re.compile(a.list)
+        for s, e, n, wg in sorted(rows):
+            if s >= t1 and pat.search(n):
+                print(f"  +{(s - t1) / 1e3:9.1f} us  {(e - s) / 1e3:8.1f} us  wg {wg:6d}  {short(n)[:90]}")
     items = sorted(agg.items(), key=lambda kv: -kv[1][1])
     print(f"window {a.last_ms:.1f} ms, kernel-busy {busy / 1e6:.2f} ms ({busy / 1e6 / a.steps:.2f} ms/step over {a.steps} steps), "
           f"{sum(v[0] for v in agg.values())} launches ({sum(v[0] for v in agg.values()) / a.steps:.0f}/step), {len(items)} distinct kernels")
