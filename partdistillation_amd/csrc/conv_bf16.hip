@@ -271,18 +271,29 @@ __device__ __forceinline__ void wgrad_body(const bf16_t *__restrict__ dZ, const 
     cy[j] = rem / g.Wo; cx[j] = rem - cy[j] * g.Wo;
   }
   uint4 ry[2][JY], rx[2][JX];
+  // Every load is UNCONDITIONAL — a row past the slice, a tap outside the image or a column past the matrix reads element 0 of its tensor and
+  // is zeroed in registers: behind per-lane branches the compiler cannot count the loads in flight and waits vmcnt(0) in front of the LDS stores,
+  // i.e. for the loads issued at the TOP of the same step — a prefetch distance of one step's MFMAs (~0.3 us) where the memory latency is 1-2 us
+  // (SQ counters, tools/debug/wgrad_pmc.sh: waves waiting 48 % of their cycles).  Straight-line loads get counted waits (vmcnt(6) / vmcnt(4) in the
+  // loop, none of 0), and the barriers are the raw instruction behind s_waitcnt lgkmcnt(0): __syncthreads() would drain the loads too.
+  // (A zero LINE as the masked source — the igemm kernels' idiom — made clang keep rx / ry in scratch here; the masked value does not.)
   auto gload = [&](int s, int m) {
 #pragma unroll
     for (int j = 0; j < JY; ++j) {
       const int r = m + yr + LY * j;
-      ry[s][j] = (r < me && ycol_ok) ? *reinterpret_cast<const uint4 *>(dZ + (int64_t)r * g.N + n0 + yc) : make_uint4(0, 0, 0, 0);
+      const bool oky = r < me && ycol_ok;
+      uint4 v = *reinterpret_cast<const uint4 *>(dZ + (oky ? (int64_t)r * g.N + n0 + yc : 0));
+      v.x = oky ? v.x : 0u; v.y = oky ? v.y : 0u; v.z = oky ? v.z : 0u; v.w = oky ? v.w : 0u;
+      ry[s][j] = v;
     }
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
       const int r = m + xr + LX * j;
       const int iy = cy[j] * g.stride + tdy, ix = cx[j] * g.stride + tdx;
       const bool ok = r < me && xcol_ok && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
-      rx[s][j] = ok ? *reinterpret_cast<const uint4 *>(X + ((int64_t)(cb[j] * g.Hi + iy) * g.Wi + ix) * g.Ci + xc) : make_uint4(0, 0, 0, 0);
+      uint4 v = *reinterpret_cast<const uint4 *>(X + (ok ? ((int64_t)(cb[j] * g.Hi + iy) * g.Wi + ix) * g.Ci + xc : 0));
+      v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+      rx[s][j] = v;
       cx[j] += WTW;
       while (cx[j] >= g.Wo) { cx[j] -= g.Wo; if (++cy[j] == g.Ho) { cy[j] = 0; ++cb[j]; } }
     }
@@ -311,17 +322,16 @@ __device__ __forceinline__ void wgrad_body(const bf16_t *__restrict__ dZ, const 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   const int steps = (me - mb + WTW - 1) / WTW;
-  if (steps > 0) {
-    gload(0, mb);
-    if (steps > 1) gload(1, mb + WTW);
-    lstore(0, 0);
-  }
-  __syncthreads();
+  gload(0, mb);                                           // (stages past the slice are zero rows: loaded, stored and multiplied like any other —
+  gload(1, mb + WTW);                                     //  the loop below runs an even number of steps with no branch around a load or a wait)
+  lstore(0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   const int grp = lane >> 4, sl = lane & 15;
   const int frow = 8 * (grp >> 1) + (sl >> 2), fcol = 16 * (grp & 1) + 4 * (sl & 3);
   typedef __attribute__((address_space(3))) v4s16 *lp;
   auto step = [&](int st, int par) {
-    if (st + 2 < steps) gload(par, mb + (st + 2) * WTW);
+    gload(par, mb + (st + 2) * WTW);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       hwbf16x8 a[NI], b[KJ];
@@ -344,13 +354,16 @@ __device__ __forceinline__ void wgrad_body(const bf16_t *__restrict__ dZ, const 
 #pragma unroll
         for (int j = 0; j < KJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (st + 1 < steps) lstore(par ^ 1, par ^ 1);
-    __syncthreads();
+    lstore(par ^ 1, par ^ 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (the raw barrier: __syncthreads() would drain the loads in flight)
+    __builtin_amdgcn_s_barrier();
   };
   for (int st = 0; st < steps; st += 2) {
     step(st, 0);
-    if (st + 1 < steps) step(st + 1, 1);
+    step(st + 1, 1);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the two zero stages still in flight
+  __syncthreads();
   if (do_bias) {                                         // the loop ended with a barrier: the stages are free
     float *red = reinterpret_cast<float *>(&SY[0][0][0]);                 // [LY][TN] floats <= 2 * 32 * PN bf16
 #pragma unroll
@@ -408,7 +421,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr_grouped(const Wgrad
   const int p = find_problem(tab, count, blockIdx.x, false);
   const WgradProblem &pr = tab[p];
   const int bid = xcd_major ? pd_xcd_major(pr.block_begin, pr.g.tiles * pr.splits, (int)blockIdx.x) : (int)blockIdx.x - pr.block_begin;
-  wgrad_body<WN, WK>(pr.dz, pr.x, ws + pr.ws_off, pr.g, bid, pr.db);
+  wgrad_body<WN, WK>(pd_as_global(pr.dz), pd_as_global(pr.x), ws + pr.ws_off, pr.g, bid, pd_as_global(pr.db));   // (pd_common.h: table pointers would be FLAT)
 }
 
 // dW (bf16) = sum over splits of the partial tiles (register order: element (ij, e) of thread t at ((ij * 16 + e) * 256 + t))
@@ -451,7 +464,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_grouped(const WgradProb
 {
   const int p = find_problem(tab, count, blockIdx.x, true);
   const WgradProblem &pr = tab[p];
-  reduce_body<WN, WK>(ws + pr.ws_off, pr.dw, pr.g.N, pr.g.K, pr.g.tiles_k, pr.g.tiles, pr.splits, blockIdx.x - pr.reduce_begin, pr.scale);
+  reduce_body<WN, WK>(ws + pr.ws_off, pd_as_global(pr.dw), pr.g.N, pr.g.K, pr.g.tiles_k, pr.g.tiles, pr.splits, blockIdx.x - pr.reduce_begin, pd_as_global(pr.scale));
 }
 
 struct WgradPlan { int tn, tk, tiles_k, tiles, splits, m_chunk; };

@@ -771,7 +771,8 @@ __global__ __launch_bounds__(256) void dec_pack_grouped(const PackProblem *__res
     const int mid = (lo + hi + 1) >> 1;
     if (tab[mid].first_block <= bid) lo = mid; else hi = mid - 1;
   }
-  const PackProblem pr = tab[lo];
+  PackProblem pr = tab[lo];
+  pr.src = pd_as_global(pr.src); pr.dst = pd_as_global(pr.dst);                      // (pd_common.h: table pointers would be FLAT)
   const int local = bid - pr.first_block;
   const int K = pr.transpose ? pr.rows : pr.cols, kcn = K / 256, nb = local / kcn, kc = local - nb * kcn;
   bf16_t *dst = pr.dst + (size_t)local * BLK;

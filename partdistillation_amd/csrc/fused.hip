@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void multi_gather_sumsq(const int64_t *__restr
   if (base == 0) {
     for (int i = threadIdx.x; i < len; i += 256) d[i] = 0.f;
   } else if (is_bf16[t]) {
-    const unsigned short *s = reinterpret_cast<const unsigned short *>(base) + start;
+    const unsigned short *s = pd_as_global(reinterpret_cast<const unsigned short *>(base)) + start;   // (pd_common.h: a pointer read from memory would be FLAT)
     if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {               // eight bf16 per lane-step: one 16-byte load, two 16-byte stores
       const int l8 = len >> 3;
       for (int i = threadIdx.x; i < l8; i += 256) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void multi_gather_sumsq(const int64_t *__restr
       for (int i = threadIdx.x; i < len; i += 256) { const float v = bf2f(s[i]); d[i] = v; acc += v * v; }
     }
   } else {
-    const float *s = reinterpret_cast<const float *>(base) + start;
+    const float *s = pd_as_global(reinterpret_cast<const float *>(base)) + start;
     if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
       const int l4 = len >> 2;
       for (int i = threadIdx.x; i < l4; i += 256) {

@@ -1010,8 +1010,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_f32x3_tr_grouped(const Wgra
   int p = 0;
   while (p + 1 < count && lb >= tab[p + 1].block0) ++p;                   // <= a few dozen problems: a scalar scan
   const WgradX3Problem q = tab[p];
-  wgrad_tr_body<0, false, H2>(q.dY, q.X, q.dW, q.dB, ws, q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, q.tiles_k, q.tiles, q.m_chunk, 0, 0,
-                              lb - q.block0, q.ws_tile0, q.y_amax, q.x_amax);
+  wgrad_tr_body<0, false, H2>(pd_as_global(q.dY), pd_as_global(q.X), pd_as_global(q.dW), pd_as_global(q.dB), ws, q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, q.tiles_k, q.tiles, q.m_chunk, 0, 0,
+                              lb - q.block0, q.ws_tile0, pd_as_global(q.y_amax), pd_as_global(q.x_amax));   // (pd_common.h: table pointers would be FLAT)
 }
 
 // grouped form of wgrad_tr_reduce: blockIdx.x = 64 x (global output tile index); the problem is found from its first tile
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_reduce_grouped(const WgradX3Prob
   for (; sp < pr.splits; ++sp) s0 += src[(int64_t)sp * stride];
   const int c = k0 + wk + j * 32 + (lane & 31);
   const int row = n0 + wn + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-  if (c < pr.K && row < pr.N) pr.dW[(int64_t)row * pr.ldw + c] += s0 + s1;      // this block owns the element: plain read-modify-write
+  if (c < pr.K && row < pr.N) pd_as_global(pr.dW)[(int64_t)row * pr.ldw + c] += s0 + s1;      // this block owns the element: plain read-modify-write
 }
 
 __global__ __launch_bounds__(512, 1) void gemm_wgrad_f16x2_wide_grouped(const WgradX3Problem *__restrict__ tab, int count, float *__restrict__ ws)
@@ -1049,8 +1049,8 @@ __global__ __launch_bounds__(512, 1) void gemm_wgrad_f16x2_wide_grouped(const Wg
   int p = 0;
   while (p + 1 < count && lb >= tab[p + 1].block0) ++p;
   const WgradX3Problem q = tab[p];
-  wgrad_h2w_body<false>(q.dY, q.X, q.dW, q.dB, ws, q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, q.tiles_k, q.tiles, q.m_chunk, 0, 0, lb - q.block0, q.ws_tile0,
-                        q.y_amax, q.x_amax);
+  wgrad_h2w_body<false>(pd_as_global(q.dY), pd_as_global(q.X), pd_as_global(q.dW), pd_as_global(q.dB), ws, q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, q.tiles_k, q.tiles, q.m_chunk, 0, 0, lb - q.block0, q.ws_tile0,
+                        pd_as_global(q.y_amax), pd_as_global(q.x_amax));
 }
 
 __global__ __launch_bounds__(512) void wgrad_h2w_reduce_grouped(const WgradX3Problem *__restrict__ tab, int count, const float *__restrict__ ws)
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(512) void wgrad_h2w_reduce_grouped(const WgradX3Pro
   for (; sp < pr.splits; ++sp) s0 += src[(int64_t)sp * stride];
   int row, col;
   h2w_coord(q, t, row, col);
-  if (k0 + col < pr.K && n0 + row < pr.N) pr.dW[(int64_t)(n0 + row) * pr.ldw + k0 + col] += s0 + s1;
+  if (k0 + col < pr.K && n0 + row < pr.N) pd_as_global(pr.dW)[(int64_t)(n0 + row) * pr.ldw + k0 + col] += s0 + s1;
 }
 
 // dW tile += sum over splits of the partial tiles gemm_wgrad_f32x3_tr left in the workspace (same register-order indexing)

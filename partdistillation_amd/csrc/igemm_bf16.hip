@@ -627,7 +627,8 @@ __global__ __launch_bounds__(256) void filter_transpose_grouped(const TrProblem 
     const int mid = (lo + hi + 1) >> 1;
     if (tab[mid].first_block <= bid) lo = mid; else hi = mid - 1;
   }
-  const TrProblem p = tab[lo];
+  TrProblem p = tab[lo];
+  p.src = pd_as_global(p.src); p.dst = pd_as_global(p.dst); p.scale = pd_as_global(p.scale);      // (pd_common.h: table pointers would be FLAT)
   const int local = bid - p.first_block;
   const int nci = p.ci / 64, nco = p.co / 64;
   const int tap = local / (nci * nco), r = local - tap * nci * nco, bco = r / nci, bci = r - bco * nci;

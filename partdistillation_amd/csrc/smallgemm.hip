@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void sgemm_wgrad_grouped(const SgWgradProblem 
   while (p + 1 < count && tab[p + 1].block_begin <= (int)blockIdx.x) ++p;
   const SgWgradProblem &q = tab[p];
   const int local = blockIdx.x - q.block_begin;
-  sgemm_wgrad_body(q.dY, q.X, q.dW, q.dB, q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, local % q.gx, local / q.gx);
+  sgemm_wgrad_body(pd_as_global(q.dY), pd_as_global(q.X), pd_as_global(q.dW), pd_as_global(q.dB), q.M, q.N, q.K, q.ldy, q.ldx, q.ldw, local % q.gx, local / q.gx);   // (pd_common.h: table pointers would be FLAT)
 }
 
 // ------------------------------------------------------------------------------------------------ dW = dY^T X, many rows
