@@ -10,6 +10,8 @@
  *                             :122, the weighted sum :150-154).  Replaces softplus / sigmoid / two row sums, two batched GEMMs with
  *                             n_targets output columns, a softmax gather and ~20 elementwise launches; the fp32 copies of the
  *                             logits and their sigmoids (2 x 100 MB at BASELINE config 2) are never written.
+ *   pd_match_point_logits     the logits of all Q masks at the matcher's points straight from the mask features (matcher.py:108-125):
+ *                             sampler + batched product in one kernel, the sampled features stay in LDS.
  *   pd_mask_point_losses_*    sigmoid_ce_loss (criterion.py:50-69) and dice_loss (:25-47) of the matched masks at their sampled
  *                             points, per mask, and their gradient with respect to the point logits.
  *   pd_point_sample_u8        the target masks at the matcher's / the loss's points, read as stored bytes.
@@ -57,6 +59,18 @@ int pd_lsa_batched(const float *cost, const int32_t *ncols, int64_t *out_rows, i
 int pd_matcher_costs(const void *x, int dtype, const float *t, int64_t t_image_stride, int64_t t_head_stride, int64_t t_target_stride,
                      const float *prob, const int64_t *labels, float *cost, int problems, int heads, int Q, int n, int n_targets,
                      int classes, float w_mask, float w_class, float w_dice, void *stream);
+
+/*
+ * The matcher's point logits of every (image, head) problem in ONE launch, without the sampled features in memory (reference matcher.py:108-125:
+ * point_sample(out_mask, point_coords) with out_mask = mask_embed . mask_features — bilinear sampling is linear in the map, so the logits are
+ * mask_embed . point_sample(mask_features)):
+ *   feat_nhwc [B, H, W, C] fp32 mask features (channels last), coords [B, heads * points, 2] (x, y) in [0, 1] — problem p = b * heads + d owns
+ *   points [d * points, (d + 1) * points) of image b —, emb [B * heads, Q, C] bf16  ->  out [B * heads, Q, points] bf16
+ *   out[p, q, i] = bf16( sum_c emb[p, q, c] * bf16( grid_sample(feat[b], coords[p, i])[c] ) )      (bilinear, zeros padding, align_corners = False)
+ * — bit-identical to pd_point_sample_nhwc_f32_bf16 followed by pd_sgemm_tn_batched_bf16.  C == 256, Q <= 128, points % 4 == 0.
+ */
+int pd_match_point_logits(const float *feat_nhwc, const float *coords, const void *emb, void *out, int B, int heads, int Q, int points,
+                          int H, int W, int C, void *stream);
 
 /*
  * x, y [rows, n] (point logits, sampled target masks in [0, 1]) ->

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mfma_bf16.h"
 #include "pd_common.h"
 #include "pd_criterion.h"
 #include "pd_msda.h"
@@ -370,7 +371,102 @@ __global__ __launch_bounds__(256) void point_sample_u8(const uint8_t *__restrict
     out[pt] = acc;
   }
 }
+
+// ------------------------------------------------------------------------------------------------ matcher point logits, fused
+// The matcher's logits of all Q masks at its random points (reference matcher.py:108-125: point_sample(out_mask, point_coords) per image
+// and head) are, by the linearity of bilinear sampling, mask_embed . point_sample(mask_features): rounds 2-5 ran that as a sampler launch
+// (250 880 points x 256 channels: 1 GB of corner rows gathered, 128 MB of bf16 samples written: 159 us) followed by a batched skinny GEMM that
+// read them back with 32 x 128 tiles at one workgroup per CU (143 us for 12.8 GFLOP).  Here a workgroup samples 64 points of one (image, head)
+// problem straight into LDS as the bf16 MFMA operand (a wavefront per point: each corner one 1 KB burst, two points = eight loads in flight
+// per lane) and multiplies them with the problem's query embeddings, which each wavefront holds in registers as the other operand (32 queries x
+// 256 channels = 64 VGPRs); the samples never leave the CU.  Arithmetic as the two launches: fp32 bilinear sum in the sampler's order, one
+// rounding to bf16, v_mfma_f32_32x32x8_bf16_1k over k = 0 .. 255 in order, one rounding of the logit to bf16 — the results are bit-identical.
+constexpr int MPL_PTS = 64, MPL_C = 256, MPL_PITCH = 260;    // 520-byte LDS rows: the 8-byte fragment reads of 32 rows touch every bank once
+template <int TPW>                                           // point tiles per workgroup (the embeddings' fragments are loaded once)
+__global__ __launch_bounds__(256, 4) void match_point_logits(const float *__restrict__ feat, const float *__restrict__ coords,
+                                                             const bf16_t *__restrict__ emb, bf16_t *__restrict__ out, int heads, int Q, int Pm,
+                                                             int H, int W)
+{
+  using namespace pdmfma;
+  __shared__ __attribute__((aligned(16))) bf16_t Fs[MPL_PTS][MPL_PITCH];
+  const int prob = blockIdx.y, b = prob / heads;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  const int q = 32 * wave + r;
+  bf16x4 ef[32];                                             // Y operand: query q, channels 8 s + 4 hh .. + 3
+  {
+    const bf16_t *e = emb + ((int64_t)prob * Q + min(q, Q - 1)) * MPL_C + 4 * hh;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) ef[s] = *reinterpret_cast<const bf16x4 *>(e + 8 * s);
+  }
+  const float *base = feat + (int64_t)b * H * W * MPL_C + lane * 4;
+  const float *cr = coords + (int64_t)prob * Pm * 2;
+  for (int tile = 0; tile < TPW; ++tile) {
+    const int p0 = ((int)blockIdx.x * TPW + tile) * MPL_PTS;
+    if (p0 >= Pm) break;
+    if (tile) __syncthreads();                               // the previous tile's fragment reads are done
+#pragma unroll 1
+    for (int i = 0; i < 16; i += 2) {
+      float4 v[2][4];
+      float wt[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int pt = min(p0 + 16 * wave + i + u, Pm - 1);
+        // the exact arithmetic of point_sample_nhwc (rowwise.hip) / the torch path: g = 2 c - 1, then ((g + 1) size - 1) / 2
+        const float gx = 2.0f * cr[pt * 2] - 1.0f, gy = 2.0f * cr[pt * 2 + 1] - 1.0f;
+        const float ix = ((gx + 1.f) * W - 1.f) / 2.f, iy = ((gy + 1.f) * H - 1.f) / 2.f;
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+        const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+        // a corner outside the map: weight 0 on a clamped (valid) address, so that all eight loads are straight-line code
+        wt[u][0] = vy0 && vx0 ? (x1 - ix) * (y1 - iy) : 0.f; wt[u][1] = vy0 && vx1 ? (ix - x0) * (y1 - iy) : 0.f;
+        wt[u][2] = vy1 && vx0 ? (x1 - ix) * (iy - y0) : 0.f; wt[u][3] = vy1 && vx1 ? (ix - x0) * (iy - y0) : 0.f;
+        const int xa = min(max(x0, 0), W - 1), xb = min(max(x1, 0), W - 1), ya = min(max(y0, 0), H - 1), yb = min(max(y1, 0), H - 1);
+        v[u][0] = *reinterpret_cast<const float4 *>(base + ((int64_t)ya * W + xa) * MPL_C);
+        v[u][1] = *reinterpret_cast<const float4 *>(base + ((int64_t)ya * W + xb) * MPL_C);
+        v[u][2] = *reinterpret_cast<const float4 *>(base + ((int64_t)yb * W + xa) * MPL_C);
+        v[u][3] = *reinterpret_cast<const float4 *>(base + ((int64_t)yb * W + xb) * MPL_C);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc.x += v[u][c].x * wt[u][c]; acc.y += v[u][c].y * wt[u][c]; acc.z += v[u][c].z * wt[u][c]; acc.w += v[u][c].w * wt[u][c];
+        }
+        *reinterpret_cast<bf16x4 *>(&Fs[16 * wave + i + u][lane * 4]) = pack4(acc.x, acc.y, acc.z, acc.w);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) mma(acc, lds4(&Fs[32 * t + r][8 * s + 4 * hh]), ef[s]);   // acc[point][query] (mfma_bf16.h)
+      if (q < Q) {
+        bf16_t *o = out + ((int64_t)prob * Q + q) * Pm + p0 + 32 * t + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (p0 + 32 * t + 8 * g + 4 * hh < Pm) *reinterpret_cast<bf16x4 *>(o + 8 * g) = pack4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+      }
+    }
+  }
+}
 }  // namespace
+
+extern "C" int pd_match_point_logits(const float *feat_nhwc, const float *coords, const void *emb, void *out, int B, int heads, int Q, int Pm,
+                                     int H, int W, int C, void *stream_)
+{
+  if (B < 0 || heads <= 0 || Q <= 0 || Q > 128 || Pm <= 0 || (Pm & 3) || H <= 0 || W <= 0 || C != MPL_C)
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_match_point_logits: B=%d heads=%d Q=%d (<= 128) points=%d (%% 4) H=%d W=%d C=%d (256)", B, heads, Q, Pm, H, W, C);
+  if (B == 0) return PD_OK;
+  if (!feat_nhwc || !coords || !emb || !out) return pd_set_error(PD_ERR_INVALID_ARG, "pd_match_point_logits: null pointer");
+  constexpr int TPW = 2;
+  hipLaunchKernelGGL(match_point_logits<TPW>, dim3((unsigned)((Pm + MPL_PTS * TPW - 1) / (MPL_PTS * TPW)), (unsigned)(B * heads)), dim3(256), 0,
+                     (hipStream_t)stream_, feat_nhwc, coords, (const bf16_t *)emb, (bf16_t *)out, heads, Q, Pm, H, W);
+  return pd_check_launch("pd_match_point_logits");
+}
 
 // ------------------------------------------------------------------------------------------------ the three loss vectors
 // One workgroup per prediction head h (criterion order; d = d_of_h[h] its place in the decoder's stack): the weighted cross entropy of

@@ -1,6 +1,8 @@
 """Python faces of the set criterion's kernels (include/pd_criterion.h, csrc/criterion.hip): the Hungarian cost matrices of all (image,
 head) problems in one pass, the BCE / dice losses of the matched masks at their points (with their gradient), and the selection of the
 most uncertain oversampled points.  GPU only; the callers keep the plain torch expressions for CPU tensors (the oracle-side tests)."""
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -36,6 +38,36 @@ def matcher_costs(x, t, prob, labels, heads, w_mask, w_class, w_dice):
                                             labels.data_ptr(), cost.data_ptr(), problems, heads, Q, n, nt, prob.shape[-1], float(w_mask),
                                             float(w_class), float(w_dice), _stream()))
     return cost
+
+
+MATCH_FUSED = os.environ.get("PD_MATCH_FUSED", "1") != "0"      # 0: sampler + batched product as two launches (A/B)
+
+
+def match_point_logits_supported(mfeat, coords, emb):
+    """mfeat [B, C, H, W] fp32 in channels-last memory, coords [B, heads * points, 2] fp32, emb [B * heads, Q, C] bf16 contiguous"""
+    if not (ENABLED and MATCH_FUSED and mfeat.is_cuda and mfeat.dim() == 4 and emb.dim() == 3 and emb.dtype == torch.bfloat16 and emb.is_contiguous()):
+        return False
+    B, C, H, W = mfeat.shape
+    if mfeat.dtype != torch.float32 or not mfeat.permute(0, 2, 3, 1).is_contiguous() or C != 256 or emb.shape[2] != C or emb.shape[1] > 128:
+        return False
+    heads = emb.shape[0] // max(B, 1)
+    return heads * B == emb.shape[0] and coords.shape[0] == B and coords.shape[1] % heads == 0 and (coords.shape[1] // heads) % 4 == 0
+
+
+def match_point_logits(mfeat, coords, emb):
+    """-> [B * heads, Q, points] bf16: the logits of all Q masks of every (image, head) problem at its points, = emb . point_sample(mfeat)
+    (pd_match_point_logits: reference matcher.py:108-125 through the linearity of point sampling; the sampled features stay on the CU).
+    GPU only, no fallback."""
+    if not mfeat.is_cuda:
+        raise RuntimeError("pd_match_point_logits runs on the GPU only (no CPU fallback in partdistillation_amd)")
+    B, C, H, W = mfeat.shape
+    BH, Q, _ = emb.shape
+    heads = BH // B
+    coords = coords.float().contiguous()
+    Pm = coords.shape[1] // heads
+    out = torch.empty((BH, Q, Pm), dtype=torch.bfloat16, device=mfeat.device)
+    _lib.check(_lib.load().pd_match_point_logits(mfeat.data_ptr(), coords.data_ptr(), emb.data_ptr(), out.data_ptr(), B, heads, Q, Pm, H, W, C, _stream()))
+    return out
 
 
 class MaskPointLosses(Function):

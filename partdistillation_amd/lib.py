@@ -102,6 +102,7 @@ SIGNATURES = {
     "pd_normalize_u8_nhwc": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
     "pd_resize_bilinear_nhwc_f32": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 3 + [_c_int, _c_int, _c_vp]),
     "pd_matcher_point_terms": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "pd_match_point_logits": (_c_int, [_c_vp] * 4 + [_c_int] * 7 + [_c_vp]),
     "pd_matcher_costs": (_c_int, [_c_vp, _c_int, _c_vp] + [ctypes.c_int64] * 3 + [_c_vp] * 3 + [_c_int] * 6 + [ctypes.c_float] * 3 + [_c_vp]),
     "pd_mask_point_losses_fwd": (_c_int, [_c_vp] * 5 + [_c_int, _c_int, _c_vp]),
     "pd_mask_point_losses_bwd": (_c_int, [_c_vp] * 6 + [_c_int, _c_int, _c_vp]),

@@ -207,6 +207,10 @@ def batched_set_criterion(crit, outputs, targets, padded_masks):
         mc_bd = mcoords[h_of_d].transpose(0, 1)                                                  # [B,D,Pm,2]
         if sparse:
             e = emb_bd.detach().reshape(B * H, Q, -1)
+            mfd, mcf = mfeat.detach(), mc_bd.reshape(B, H * Pm, 2)
+        if sparse and cops.match_point_logits_supported(mfd, mcf, e):
+            pm = cops.match_point_logits(mfd, mcf, e)                    # sampler + product in one kernel: the sampled features stay in LDS
+        elif sparse:
             fm = rw.point_sample_nhwc(mfeat.detach(), mc_bd.reshape(B, H * Pm, 2),                # [B, D*Pm, C], already in e's dtype
                                       out_dtype=e.dtype if e.dtype == torch.bfloat16 else torch.float32)
             # bf16 mask embeddings (autocast): the reference's mask logits are a bf16 product too (einsum under AMP, :449)

@@ -42,6 +42,34 @@ def test_matcher_costs_match_the_torch_expressions(dtype, B, H, Q, n, nt, K1):
     assert err <= 2e-5
 
 
+@pytest.mark.parametrize("B,heads,Q,Pm,H,W", [(2, 10, 100, 12544, 256, 256), (1, 1, 1, 4, 5, 7), (2, 3, 100, 132, 64, 48), (3, 2, 37, 1000, 33, 40),
+                                               (1, 4, 128, 64, 16, 16)])
+def test_match_point_logits_equal_the_sampler_followed_by_the_batched_product(B, heads, Q, Pm, H, W):
+    """pd_match_point_logits (sampler + product in one kernel, the sampled features in LDS only) against the two launches it replaces —
+    pd_point_sample_nhwc_f32_bf16, then pd_sgemm_tn_batched_bf16 —: BIT-identical (same fp32 bilinear sum, same roundings, same MFMA and k order),
+    and against torch fp64 on the same operands (grid_sample of the fp32 map, bf16 product) within bf16 rounding.  Points include the map's
+    border and positions outside [0, 1] (zero padding), the last point tile is ragged, Q is not a multiple of 32."""
+    from partdistillation_amd.functions import criterion_ops as cops, rowwise as rw, smallgemm as sg
+    torch.manual_seed(B * 100 + Pm)
+    mf = torch.randn(B, 256, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+    co = torch.rand(B, heads * Pm, 2, device=DEV) * 1.1 - 0.05
+    co.view(-1)[:6] = torch.tensor([0.0, 0.0, 1.0, 1.0, 0.5, -0.2], device=DEV)[: min(6, co.numel())]
+    e = (torch.randn(B * heads, Q, 256, device=DEV) * 0.3).bfloat16()
+    assert cops.match_point_logits_supported(mf, co, e)
+    got = cops.match_point_logits(mf, co, e)
+    fm = rw.point_sample_nhwc(mf, co, out_dtype=torch.bfloat16).view(B * heads, Pm, 256)
+    assert got.shape == (B * heads, Q, Pm) and got.dtype == torch.bfloat16
+    if sg.bmm_tn_supported(e, fm) and Pm % 8 == 0:                   # (the batched product wants rows of 16 bytes)
+        two = sg.bmm_tn(e, fm)
+        assert torch.equal(got, two), float((got.float() - two.float()).abs().max())
+    ref = F.grid_sample(mf.double(), (2 * co.double() - 1).view(B, heads * Pm, 1, 2), mode="bilinear", padding_mode="zeros", align_corners=False)
+    ref = ref[..., 0].transpose(1, 2).reshape(B * heads, Pm, 256).float().bfloat16().double()              # [B heads, Pm, C], rounded as the operand is
+    ref = torch.bmm(e.double(), ref.transpose(1, 2))
+    err = float((got.double() - ref).abs().max() / ref.abs().max())
+    print(f"match point logits B={B} heads={heads} Q={Q} points={Pm} map {H}x{W}: max |err| / max |logit| = {err:.2e}")
+    assert err <= 1.2e-2            # one bf16 rounding of the result (2^-8) + operand roundings that differ by an ulp of the fp32 bilinear sum
+
+
 @pytest.mark.parametrize("N,P", [(80, 12544), (1, 1), (7, 300), (3, 4099)])
 def test_mask_point_losses_match_torch(N, P):
     """per-mask BCE-with-logits mean and dice at the sampled points, and their gradient (criterion.py:25-69), against fp64 autograd"""
