@@ -1,6 +1,7 @@
 // Fused bandwidth-bound kernels (gfx950): affine+residual+ReLU epilogue of the frozen-BN backbone convolutions
 // (bf16 NHWC, 16-byte lanes) and the multi-tensor gradient gather with fused sum of squares.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 
@@ -473,9 +474,15 @@ extern "C" int pd_nc_sums_f32(const float *x, const float *dy, const float *y, c
   (void)hipMemsetAsync(out, 0, (size_t)N * C * 2 * sizeof(double), s);
   if ((int64_t)N * P == 0) return pd_check_launch("pd_nc_sums_f32");
   if (!x || (mode == 1 && (!dy || !a || !b || (relu && !y)))) return pd_set_error(PD_ERR_INVALID_ARG, "pd_nc_sums_f32: null input");
-  // pixels per block: 512 gave 256 blocks of 4 wavefronts at 2 x 256^2 — one dependent 16-byte load per thread and iteration on a quarter-
-  // occupied machine (1.6 TB/s); 128 pixels = 1 024 blocks, four loads in flight per thread
-  const int ppb = (int64_t)N * P >= 32768 ? 128 : 512;
+  // pixels per block (tools/debug/nc_sums_sweep.py, round 6).  Every block ends in 2 C fp64 atomics on the SAME 2 C addresses per image, and those
+  // serialise in L2: at 2 x 256^2 x 256 the launch costs ~15 us + 29 ns per block (16 / 128 / 512 pixels per block: 252 / 45 / 25 us), so the large
+  // maps take few, long blocks; the small maps were the opposite problem — 4 or 16 blocks of 512 pixels are 128 dependent iterations per thread
+  // on an empty machine (the per-launch trace showed 14-27 us for 2-8 MB) — and take many short ones.  Backward mode streams three operands:
+  // its optimum sits at shorter blocks.
+  static const int ppb_env = []() { const char *e = getenv("PD_NC_PPB"); return e ? atoi(e) : 0; }();      // tools/ A/B only
+  const int64_t np = (int64_t)N * P;
+  int ppb = mode == 0 ? (np >= 131072 ? 512 : np >= 32768 ? 256 : np >= 8192 ? 128 : 64) : (np >= 131072 ? 256 : np >= 32768 ? 128 : 32);
+  if (ppb_env > 0) ppb = ppb_env;
   dim3 grid((P + ppb - 1) / ppb, N);
   if (mode == 0) hipLaunchKernelGGL(nc_sums<0>, grid, dim3(256), 0, s, x, dy, y, a, b, out, P, C, ppb, relu);
   else hipLaunchKernelGGL(nc_sums<1>, grid, dim3(256), 0, s, x, dy, y, a, b, out, P, C, ppb, relu);
