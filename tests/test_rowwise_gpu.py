@@ -131,6 +131,22 @@ def test_attn_mask_u8_vs_torch():
     assert torch.equal(mb.bool(), wb & ~wb.all(-1, keepdim=True))
 
 
+@pytest.mark.parametrize("n", [16384, 4096, 1024, 8, 1336])
+def test_attn_mask_u8_bf16_rows_of_eight_with_special_values(n):
+    """the 16-byte-piece kernel (bf16 rows, n % 8 == 0, n <= 16 384) decides v < 0 on the bf16 BITS: -0.0, NaN of either sign and +-inf must
+    come out as torch's comparison has them; an all-blocked row is released; the last piece of a short row is partial"""
+    from partdistillation_amd.functions import rowwise as rw
+    logits = _r((3, 7, n), 43 + n).bfloat16()
+    sp = torch.tensor([-0.0, 0.0, float("nan"), -float("nan"), float("inf"), -float("inf"), -1e-30, 1e-30], device=logits.device).bfloat16()
+    logits[0, 0, :8] = sp
+    logits[1, 3] = -logits[1, 3].abs() - 0.1
+    logits[2, 6] = logits[2, 6].abs()
+    m = rw.attn_mask_u8(logits)
+    wb = logits < 0
+    want = wb & ~wb.all(-1, keepdim=True)
+    assert m.dtype == torch.uint8 and torch.equal(m.bool(), want) and not m[1, 3].any() and int(m.max()) == 1
+
+
 # ----------------------------------------------------------------------------- fused decoder core
 def _decoder_pair(dec_layers=4, queries=20, seed=900):
     from test_product_gpu import build_decoder
