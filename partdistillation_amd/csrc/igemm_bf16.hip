@@ -494,6 +494,9 @@ int make_plan(const PdIgemm *p, Plan &pl)
   if (g_ig_nst >= 1 && g_ig_nst <= 3) pl.nst = g_ig_nst;
   // split-K: only when the tiles alone leave most workgroup slots empty AND the contraction is long (every split costs a
   // 32-64 KB slab written and read back)
+  // (round 6: in ISOLATION res5's 1 x 1 over 2 048 channels — 128 tiles x 32 K-steps — runs 18.3 us unsplit and 30.0 us in three splits, but
+  // the step does not move with the rule changed to "KT >= 48" (19.04 vs 19.04 ms, two same-box pairs): inside the step the 2 MB of weights
+  // come from HBM and 384 workgroups pull them faster than 128.  Rule kept.)
   int splits = 1;
   if (a.ntiles <= 128 && a.KT >= 16) {
     splits = (384 + a.ntiles - 1) / a.ntiles;
