@@ -32,10 +32,21 @@ int64_t pd_attn_workspace_floats(int B, int H, int Lq, int Lk);
 int pd_attn_fwd_d32(const void *q, const void *k, const void *v, const uint8_t *mask, void *o, float *lse,
                     float *workspace, int B, int H, int Lq, int Lk, float scale, int dtype, void *stream);
 
+/* The same with k and v as COLUMN SLICES of a wider row-major matrix: ld_kv elements between consecutive (key, image) rows (>= H * 32, a multiple
+ * of 8).  bf16, <= 128 queries (the matrix-core kernels) only.  The decoder's key / value projections of the layers that share a memory level
+ * are one product [rows, layers * 256]; each layer's attention reads its 256 columns in place. */
+int pd_attn_fwd_d32_ld(const void *q, const void *k, const void *v, const uint8_t *mask, void *o, float *lse,
+                       float *workspace, int B, int H, int Lq, int Lk, float scale, int dtype, int ld_kv, void *stream);
+
 /* dq/dk/dv are written completely (no accumulation into their previous contents). */
 int pd_attn_bwd_d32(const void *q, const void *k, const void *v, const uint8_t *mask, const void *o, const void *d_o,
                     const float *lse, void *dq, void *dk, void *dv, float *workspace, int B, int H, int Lq, int Lk,
                     float scale, int dtype, void *stream);
+
+/* k / v strided as in pd_attn_fwd_d32_ld; dq / dk / dv dense. */
+int pd_attn_bwd_d32_ld(const void *q, const void *k, const void *v, const uint8_t *mask, const void *o, const void *d_o,
+                       const float *lse, void *dq, void *dk, void *dv, float *workspace, int B, int H, int Lq, int Lk,
+                       float scale, int dtype, int ld_kv, void *stream);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,9 @@ typedef struct PdIgemm {
   int32_t dgrad;                      /* 0: forward gather, 1: input-gradient gather */
   int32_t act, gate_mode, res_mode;
   int32_t bias_bf16;                  /* != 0: `bias` points to bf16 values (an nn.Linear bias kept in 16 bits), not fp32 */
+  int32_t out_col_slab;               /* S != 0 (a multiple of 128 dividing n): `out` is [n / S][m][S] — columns [j S, (j + 1) S) of the product form their own
+                                         dense [m][S] matrix (several Linears over the same rows as ONE product, each result usable on its own);
+                                         res / res2 / gate / out_pre must be null */
 } PdIgemm;
 
 /* workspace the split-K schedule of this problem needs: fp32 partial tiles + one ticket word per tile (0 when it runs unsplit).

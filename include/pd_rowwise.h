@@ -192,6 +192,15 @@ typedef struct {
 } PdTransposeProblem;
 int pd_transpose_batched_f32(const PdTransposeProblem *problems, int count, void *stream);
 
+/* `count` (<= PD_COPY_MAX_SEGS) dense byte ranges dst_i <- src_i in ONE launch (concatenations of slices of several tensors). */
+#define PD_COPY_MAX_SEGS 48
+typedef struct PdCopySeg {
+  const void *src;
+  void *dst;
+  int64_t bytes;
+} PdCopySeg;
+int pd_copy_segments(const PdCopySeg *segs, int count, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

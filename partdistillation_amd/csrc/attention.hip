@@ -420,8 +420,10 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t *__restrict__ 
                                                      const bf16_t *__restrict__ v, const uint8_t *__restrict__ mask,
                                                      bf16_t *__restrict__ o, float *__restrict__ lse, float *__restrict__ part_o,
                                                      float *__restrict__ part_ml, int B, int H, int Lq, int Lk, float scale,
-                                                     int nchunk)
+                                                     int nchunk, int ldkv)
 {
+  // ldkv: elements between consecutive (key, image) rows of k and v — H * 32 for dense tensors, more when k / v are column slices of a wider
+  // matrix (the decoder's key / value projections of the layers that share a memory level come out of ONE product: functions/decoder_core.py)
   __shared__ __attribute__((aligned(16))) bf16_t Ks[2][32][LR];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[2][32][LR];
   const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t *__restrict__ 
   auto gload = [&](int t) {
     const int key = kbeg + 32 * t + srow;
     uint4 val = make_uint4(0, 0, 0, 0);
-    if (key < kend) val = *reinterpret_cast<const uint4 *>(src + ((int64_t)key * B + b) * rs + h * D + spiece * 8);
+    if (key < kend) val = *reinterpret_cast<const uint4 *>(src + ((int64_t)key * B + b) * ldkv + h * D + spiece * 8);
     return val;
   };
   auto lstore = [&](int buf, uint4 val) {
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t *__restrict__ 
                                                      const bf16_t *__restrict__ o, const bf16_t *__restrict__ d_o,
                                                      const float *__restrict__ lse, float *__restrict__ part_dq,
                                                      bf16_t *__restrict__ dq, bf16_t *__restrict__ dk, bf16_t *__restrict__ dv,
-                                                     int B, int H, int Lq, int Lk, float scale, int nchunk, int kc)
+                                                     int B, int H, int Lq, int Lk, float scale, int nchunk, int kc, int ldkv)
 {
   __shared__ __attribute__((aligned(16))) bf16_t Qs[MQ][LR];
   __shared__ __attribute__((aligned(16))) bf16_t Os[MQ][LR];          // dO rows
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t *__restrict__ 
       kreg[s] = bf16x4{0, 0, 0, 0};
       vreg[s] = bf16x4{0, 0, 0, 0};
       if (kvalid) {
-        const int64_t off = ((int64_t)key * B + b) * rs + h * D + 8 * s + 4 * hh;
+        const int64_t off = ((int64_t)key * B + b) * ldkv + h * D + 8 * s + 4 * hh;        // (k / v rows: ldkv apart; dk / dv are dense)
         kreg[s] = *reinterpret_cast<const bf16x4 *>(k + off);
         vreg[s] = *reinterpret_cast<const bf16x4 *>(v + off);
       }
@@ -766,8 +768,17 @@ extern "C" int64_t pd_attn_workspace_floats(int B, int H, int Lq, int Lk)
 extern "C" int pd_attn_fwd_d32(const void *q, const void *k, const void *v, const uint8_t *mask, void *o, float *lse,
                                float *workspace, int B, int H, int Lq, int Lk, float scale, int dtype, void *stream_)
 {
+  return pd_attn_fwd_d32_ld(q, k, v, mask, o, lse, workspace, B, H, Lq, Lk, scale, dtype, H * D, stream_);
+}
+
+extern "C" int pd_attn_fwd_d32_ld(const void *q, const void *k, const void *v, const uint8_t *mask, void *o, float *lse,
+                                  float *workspace, int B, int H, int Lq, int Lk, float scale, int dtype, int ld_kv, void *stream_)
+{
   int rc = check(q, k, v, B, H, Lq, Lk, dtype, "pd_attn_fwd_d32");
   if (rc) return rc;
+  if (ld_kv < H * D || (ld_kv & 7)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_attn_fwd_d32_ld: ld_kv=%d (>= H * 32, a multiple of 8)", ld_kv);
+  if (ld_kv != H * D && !(dtype == PD_BF16 && Lq <= MQ && Lk > 0 && !g_pd_dbg_attn_scalar))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_attn_fwd_d32_ld: strided k / v only on the matrix-core path (bf16, <= %d queries)", MQ);
   if (B * Lq == 0) return PD_OK;
   if (!o || !lse || !workspace) return pd_set_error(PD_ERR_INVALID_ARG, "pd_attn_fwd_d32: null output");
   hipStream_t s = (hipStream_t)stream_;
@@ -775,9 +786,9 @@ extern "C" int pd_attn_fwd_d32(const void *q, const void *k, const void *v, cons
   float *part_o = workspace, *part_ml = workspace + (int64_t)B * H * nc * Lq * D;
   if (dtype == PD_BF16 && Lq <= MQ && Lk > 0 && !g_pd_dbg_attn_scalar) {           // matrix-core path
     if (mask) hipLaunchKernelGGL(attn_fwd_mfma<true>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
-                                 mask, (bf16_t *)o, lse, part_o, part_ml, B, H, Lq, Lk, scale, nc);
+                                 mask, (bf16_t *)o, lse, part_o, part_ml, B, H, Lq, Lk, scale, nc, ld_kv);
     else hipLaunchKernelGGL(attn_fwd_mfma<false>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
-                            mask, (bf16_t *)o, lse, part_o, part_ml, B, H, Lq, Lk, scale, nc);
+                            mask, (bf16_t *)o, lse, part_o, part_ml, B, H, Lq, Lk, scale, nc, ld_kv);
     if (nc > 1) hipLaunchKernelGGL(attn_fwd_combine<bf16_t>, dim3((B * H * Lq + 7) / 8), dim3(256), 0, s, part_o, part_ml, (bf16_t *)o, lse, B, H, Lq, nc);
     return pd_check_launch("pd_attn_fwd_d32");
   }
@@ -801,8 +812,18 @@ extern "C" int pd_attn_bwd_d32(const void *q, const void *k, const void *v, cons
                                const float *lse, void *dq, void *dk, void *dv, float *workspace, int B, int H, int Lq,
                                int Lk, float scale, int dtype, void *stream_)
 {
+  return pd_attn_bwd_d32_ld(q, k, v, mask, o, d_o, lse, dq, dk, dv, workspace, B, H, Lq, Lk, scale, dtype, H * D, stream_);
+}
+
+extern "C" int pd_attn_bwd_d32_ld(const void *q, const void *k, const void *v, const uint8_t *mask, const void *o, const void *d_o,
+                                  const float *lse, void *dq, void *dk, void *dv, float *workspace, int B, int H, int Lq,
+                                  int Lk, float scale, int dtype, int ld_kv, void *stream_)
+{
   int rc = check(q, k, v, B, H, Lq, Lk, dtype, "pd_attn_bwd_d32");
   if (rc) return rc;
+  if (ld_kv < H * D || (ld_kv & 3)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_attn_bwd_d32_ld: ld_kv=%d (>= H * 32, a multiple of 4)", ld_kv);
+  if (ld_kv != H * D && !(dtype == PD_BF16 && Lq <= MQ && !g_pd_dbg_attn_scalar))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_attn_bwd_d32_ld: strided k / v only on the matrix-core path (bf16, <= %d queries)", MQ);
   if (B * Lq * Lk == 0) return PD_OK;
   if (!o || !d_o || !lse || !dq || !dk || !dv || !workspace) return pd_set_error(PD_ERR_INVALID_ARG, "pd_attn_bwd_d32: null pointer");
   hipStream_t s = (hipStream_t)stream_;
@@ -811,10 +832,10 @@ extern "C" int pd_attn_bwd_d32(const void *q, const void *k, const void *v, cons
     const int kc = mfma_bwd_chunk(B, H, Lk), nc = nchunks(Lk, kc);
     if (mask) hipLaunchKernelGGL(attn_bwd_mfma<true>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
                                  mask, (const bf16_t *)o, (const bf16_t *)d_o, lse, workspace, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv,
-                                 B, H, Lq, Lk, scale, nc, kc);
+                                 B, H, Lq, Lk, scale, nc, kc, ld_kv);
     else hipLaunchKernelGGL(attn_bwd_mfma<false>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
                             mask, (const bf16_t *)o, (const bf16_t *)d_o, lse, workspace, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv,
-                            B, H, Lq, Lk, scale, nc, kc);
+                            B, H, Lq, Lk, scale, nc, kc, ld_kv);
     if (nc > 1) hipLaunchKernelGGL(attn_bwd_dq_reduce<bf16_t>, dim3((groups + 7) / 8), dim3(256), 0, s, workspace, (bf16_t *)dq, B, H, Lq, nc);
     return pd_check_launch("pd_attn_bwd_d32");
   }

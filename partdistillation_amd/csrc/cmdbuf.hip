@@ -130,6 +130,9 @@ const Entry kTable[] = {
   PD_E(pd_mask_point_losses_bwd),
   PD_E(pd_mask_point_losses_fwd),
   PD_E(pd_matcher_costs),
+  PD_E(pd_copy_segments),
+  PD_E(pd_attn_fwd_d32_ld),
+  PD_E(pd_attn_bwd_d32_ld),
   PD_E(pd_match_point_logits),
   PD_E(pd_matcher_point_terms),
   PD_E(pd_maxpool3s2_bwd_bf16),

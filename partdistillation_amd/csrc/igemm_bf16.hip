@@ -66,6 +66,7 @@ struct IgArgs {
   int splits, kt_per;
   int ntn, ntiles;
   int pcls, tpc;                                         // stride-2 input gradient by parity class: tiles per class (see make_plan)
+  int slabN;                                             // PdIgemm.out_col_slab
 };
 
 __device__ __forceinline__ int xcd_chunk(int bid, int nb) { return pd_xcd_chunk(bid, nb); }   // xcd.h: any workgroup count
@@ -475,6 +476,9 @@ int make_plan(const PdIgemm *p, Plan &pl)
   a.M = (int)M; a.N = p->n; a.Cs = p->cs; a.kw = p->k; a.cch = p->cs / 64; a.KT = p->k * p->k * a.cch;
   a.Hs = p->hs; a.Ws = p->ws; a.Ho = p->ho; a.Wo = p->wo; a.stride = p->stride; a.pad = p->pad; a.dgrad = p->dgrad;
   a.act = p->act; a.gate_mode = p->gate_mode; a.res_mode = p->res_mode; a.bias_bf16 = p->bias_bf16;
+  a.slabN = p->out_col_slab;
+  if (a.slabN && ((a.slabN & 127) || a.slabN < 0 || p->n % a.slabN || p->res || p->res2 || p->gate || p->out_pre))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_igemm_bf16: out_col_slab=%d (a multiple of 128 dividing n=%d; no res / res2 / gate / out_pre)", a.slabN, p->n);
   // tile width: 128 columns, or 64 when n is not a multiple of 128 or when 128-wide tiles would leave most workgroup slots empty
   const int mt = (a.M + BM - 1) / BM;
   const bool plain = p->k == 1 && p->stride == 1 && !p->dgrad && p->hs == p->ho && p->ws == p->wo;   // (the instantiation launch() picks)

@@ -1062,6 +1062,48 @@ extern "C" int pd_mem_prep_bwd(const void *dmem_c, const void *dmempos_c, int c_
   return pd_check_launch("pd_mem_prep_bwd");
 }
 
+// ------------------------------------------------------------------------------------------------ grouped copies
+// Up to PD_COPY_MAX_SEGS dense byte ranges copied by ONE launch (the table travels as the kernel argument): concatenating slices of several
+// parameter tensors — the decoder's per-level key / value weights — was a torch.cat (a 5 us launch) per destination.
+struct CopySegs {
+  const unsigned char *src[PD_COPY_MAX_SEGS];
+  unsigned char *dst[PD_COPY_MAX_SEGS];
+  int64_t bytes[PD_COPY_MAX_SEGS];
+};
+__global__ __launch_bounds__(256) void copy_segments(const CopySegs sg)
+{
+  const int seg = blockIdx.y;
+  const unsigned char *src = sg.src[seg];
+  unsigned char *dst = sg.dst[seg];
+  const int64_t n = sg.bytes[seg];
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    const int64_t n16 = n >> 4;
+    for (int64_t i = tid; i < n16; i += nth) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+    for (int64_t i = (n16 << 4) + tid; i < n; i += nth) dst[i] = src[i];
+  } else {
+    for (int64_t i = tid; i < n; i += nth) dst[i] = src[i];
+  }
+}
+
+extern "C" int pd_copy_segments(const PdCopySeg *segs, int count, void *stream_)
+{
+  if (count < 0 || count > PD_COPY_MAX_SEGS || (count > 0 && !segs)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_copy_segments: count=%d (<= %d)", count, PD_COPY_MAX_SEGS);
+  if (count == 0) return PD_OK;
+  CopySegs sg;
+  int64_t longest = 0;
+  for (int i = 0; i < count; ++i) {
+    if (segs[i].bytes < 0 || (segs[i].bytes > 0 && (!segs[i].src || !segs[i].dst))) return pd_set_error(PD_ERR_INVALID_ARG, "pd_copy_segments: segment %d", i);
+    sg.src[i] = (const unsigned char *)segs[i].src; sg.dst[i] = (unsigned char *)segs[i].dst; sg.bytes[i] = segs[i].bytes;
+    if (segs[i].bytes > longest) longest = segs[i].bytes;
+  }
+  for (int i = count; i < PD_COPY_MAX_SEGS; ++i) { sg.src[i] = nullptr; sg.dst[i] = nullptr; sg.bytes[i] = 0; }
+  int bx = (int)((longest + 256 * 16 * 4 - 1) / (256 * 16 * 4));      // ~4 pieces of 16 bytes per thread of the longest segment
+  bx = bx < 1 ? 1 : bx > 64 ? 64 : bx;
+  hipLaunchKernelGGL(copy_segments, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, (hipStream_t)stream_, sg);
+  return pd_check_launch("pd_copy_segments");
+}
+
 extern "C" int pd_attn_mask_u8(const void *logits, int dtype, int rows, int n, uint8_t *mask, void *stream_)
 {
   if (rows < 0 || n < 0 || !dt_ok(dtype)) return pd_set_error(PD_ERR_INVALID_ARG, "pd_attn_mask_u8: rows=%d n=%d dtype=%d", rows, n, dtype);

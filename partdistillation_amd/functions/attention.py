@@ -25,26 +25,33 @@ def _stream():
     return _lib.current_stream()
 
 
+def _ld_kv(k, v):
+    """k / v [rows, H*32]: dense, or equal-stride column slices of wider row-major matrices (pd_attn_*_d32_ld)"""
+    assert k.dim() == 2 and k.shape == v.shape and k.stride(1) == 1 and v.stride(1) == 1 and k.stride(0) == v.stride(0) >= k.shape[1]
+    return k.stride(0)
+
+
 def attn_fwd_raw(q, k, v, m8, B, nheads, scale):
-    """q [Lq*B, H*32], k / v [Lk*B, H*32] (seq-first rows l*B + b, contiguous), m8 uint8 [B,Lq,Lk] | None -> (o, lse).
-    No autograd: building block of hand-written backward passes."""
+    """q [Lq*B, H*32] contiguous, k / v [Lk*B, H*32] (seq-first rows l*B + b; dense or column slices of a wider matrix),
+    m8 uint8 [B,Lq,Lk] | None -> (o, lse).  No autograd: building block of hand-written backward passes."""
     Lq, Lk = q.shape[0] // B, k.shape[0] // B
     o = torch.empty_like(q)
     lse = torch.empty((B, nheads, Lq), dtype=torch.float32, device=q.device)
     ws = _workspace(B, nheads, Lq, Lk, q.device)
-    _lib.check(_lib.load().pd_attn_fwd_d32(q.data_ptr(), k.data_ptr(), v.data_ptr(), m8.data_ptr() if m8 is not None else None,
-                                           o.data_ptr(), lse.data_ptr(), ws.data_ptr(), B, nheads, Lq, Lk, float(scale),
-                                           _DT[q.dtype], _stream()))
+    _lib.check(_lib.load().pd_attn_fwd_d32_ld(q.data_ptr(), k.data_ptr(), v.data_ptr(), m8.data_ptr() if m8 is not None else None,
+                                              o.data_ptr(), lse.data_ptr(), ws.data_ptr(), B, nheads, Lq, Lk, float(scale),
+                                              _DT[q.dtype], _ld_kv(k, v), _stream()))
     return o, lse
 
 
 def attn_bwd_raw(q, k, v, m8, o, d_o, lse, B, nheads, scale):
     Lq, Lk = q.shape[0] // B, k.shape[0] // B
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    dq = torch.empty_like(q)
+    dk, dv = (torch.empty(k.shape, dtype=k.dtype, device=k.device) for _ in range(2))          # dense, whatever k / v are
     ws = _workspace(B, nheads, Lq, Lk, q.device)
-    _lib.check(_lib.load().pd_attn_bwd_d32(q.data_ptr(), k.data_ptr(), v.data_ptr(), m8.data_ptr() if m8 is not None else None,
-                                           o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
-                                           ws.data_ptr(), B, nheads, Lq, Lk, float(scale), _DT[q.dtype], _stream()))
+    _lib.check(_lib.load().pd_attn_bwd_d32_ld(q.data_ptr(), k.data_ptr(), v.data_ptr(), m8.data_ptr() if m8 is not None else None,
+                                              o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                              ws.data_ptr(), B, nheads, Lq, Lk, float(scale), _DT[q.dtype], _ld_kv(k, v), _stream()))
     return dq, dk, dv
 
 

@@ -13,7 +13,7 @@ RES_DENSE, RES_UP2 = 0, 1
 
 class PdIgemm(ctypes.Structure):                                     # include/pd_igemm.h
     _fields_ = [(n, ctypes.c_void_p) for n in ("src", "w", "scale", "bias", "res", "res2", "gate", "out", "out_pre")] + \
-               [(n, ctypes.c_int32) for n in ("batch", "hs", "ws", "cs", "ho", "wo", "n", "k", "stride", "pad", "dgrad", "act", "gate_mode", "res_mode", "bias_bf16")]
+               [(n, ctypes.c_int32) for n in ("batch", "hs", "ws", "cs", "ho", "wo", "n", "k", "stride", "pad", "dgrad", "act", "gate_mode", "res_mode", "bias_bf16", "out_col_slab")]
 
 
 class PdFilterTranspose(ctypes.Structure):                           # include/pd_igemm.h
@@ -58,12 +58,13 @@ def _p(t):
 
 
 def run(src, w, out, *, batch, hs, ws, cs, ho, wo, n, k=1, stride=1, pad=0, dgrad=False, scale=None, bias=None, res=None, gate=None,
-        out_pre=None, res2=None, act=ACT_NONE, gate_mode=GATE_NONE, res_mode=RES_DENSE):
+        out_pre=None, res2=None, act=ACT_NONE, gate_mode=GATE_NONE, res_mode=RES_DENSE, out_col_slab=0):
     """raw launch: every tensor is a contiguous bf16 buffer in the layout pd_igemm.h names (scale / bias fp32)"""
     if not src.is_cuda:
         raise RuntimeError("pd_igemm_bf16: CUDA tensors required (partdistillation_amd has no CPU fallback)")
     d = PdIgemm(_p(src), _p(w), _p(scale), _p(bias), _p(res), _p(res2), _p(gate), _p(out), _p(out_pre), batch, hs, ws, cs, ho, wo, n, k, stride, pad,
-                int(dgrad), act, gate_mode if gate is not None else GATE_NONE, res_mode, int(bias is not None and bias.dtype == torch.bfloat16))
+                int(dgrad), act, gate_mode if gate is not None else GATE_NONE, res_mode, int(bias is not None and bias.dtype == torch.bfloat16),
+                int(out_col_slab))
     from .. import cmdbuf
     if cmdbuf.active() is not None:                          # the problem struct is host memory the replay re-reads
         for t_, nm in ((src, "src"), (w, "w"), (scale, "scale"), (bias, "bias"), (res, "res"), (res2, "res2"), (gate, "gate"), (out, "out"), (out_pre, "out_pre")):
@@ -78,11 +79,17 @@ def run(src, w, out, *, batch, hs, ws, cs, ho, wo, n, k=1, stride=1, pad=0, dgra
     return out
 
 
-def linear(x, w, bias=None, act=ACT_NONE, res=None, gate=None, gate_mode=GATE_NONE, want_pre=False, scale=None):
-    """x [M, K] bf16 row-major, w [N, K] bf16 -> act(x w^T * scale + bias + res) * gate'  [M, N] bf16 (and the pre-activation)"""
+def linear(x, w, bias=None, act=ACT_NONE, res=None, gate=None, gate_mode=GATE_NONE, want_pre=False, scale=None, out_col_slab=0):
+    """x [M, K] bf16 row-major, w [N, K] bf16 -> act(x w^T * scale + bias + res) * gate'  [M, N] bf16 (and the pre-activation).
+    out_col_slab S (a multiple of 128 dividing N; no res / gate / pre): the result is [N / S, M, S] — several Linears over the same rows run as
+    ONE product, each one's [M, S] result a dense matrix of its own."""
     M, K = x.shape
     N = w.shape[0]
     assert x.dtype == w.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous() and w.shape[1] == K
+    if out_col_slab:
+        assert N % out_col_slab == 0 and res is None and gate is None and not want_pre
+        out = torch.empty((N // out_col_slab, M, out_col_slab), dtype=torch.bfloat16, device=x.device)
+        return run(x, w, out, batch=1, hs=M, ws=1, cs=K, ho=M, wo=1, n=N, scale=scale, bias=bias, act=act, out_col_slab=out_col_slab)
     out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
     pre = torch.empty((M, N), dtype=torch.bfloat16, device=x.device) if want_pre else None
     run(x, w, out, batch=1, hs=M, ws=1, cs=K, ho=M, wo=1, n=N, scale=scale, bias=bias, res=res, gate=gate, out_pre=pre, act=act, gate_mode=gate_mode)

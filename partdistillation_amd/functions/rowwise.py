@@ -1,6 +1,8 @@
 """ctypes faces of the token-wise kernels (include/pd_rowwise.h).  Plain functions on raw tensors — no autograd: they
 are the building blocks of the hand-written forward/backward passes (functions/decoder_core.py, AddLayerNorm below).
 GPU only; there is no fallback."""
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -88,6 +90,28 @@ def copy_d2d(dst, src):
     assert dst.numel() * dst.element_size() == n and dst.is_contiguous() and src.is_contiguous()
     _lib.check(_lib.load().pd_memcpy_d2d_async(dst.data_ptr(), src.data_ptr(), n, _stream()))
     return dst
+
+
+class _CopySeg(ctypes.Structure):                                   # PdCopySeg (include/pd_rowwise.h)
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_int64)]
+
+
+MAX_COPY_SEGS = 48
+
+
+def copy_segments(pairs):
+    """[(dst, src), ...] dense tensors of equal byte size: all copies in ONE launch (pd_copy_segments) — concatenations of slices of
+    several tensors without a torch.cat per destination.  Inside a recorded region the sources must be stable (parameters)."""
+    from .. import cmdbuf
+    assert 0 < len(pairs) <= MAX_COPY_SEGS
+    segs = (_CopySeg * len(pairs))()
+    for sgm, (dst, src) in zip(segs, pairs):
+        n = src.numel() * src.element_size()
+        assert dst.numel() * dst.element_size() == n and dst.is_contiguous() and src.is_contiguous()
+        if cmdbuf.active() is not None:
+            cmdbuf.require_stable(src.data_ptr(), "source of a grouped copy")
+        sgm.src, sgm.dst, sgm.bytes = src.data_ptr(), dst.data_ptr(), n
+    _lib.check(_lib.load().pd_copy_segments(segs, len(pairs), _stream()))
 
 
 def add_rows_amax(a, b, copy_a=False):

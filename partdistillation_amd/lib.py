@@ -79,6 +79,8 @@ SIGNATURES = {
     "pd_attn_workspace_floats": (ctypes.c_int64, [_c_int] * 4),
     "pd_attn_fwd_d32": (_c_int, [_c_vp] * 7 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_vp]),
     "pd_attn_bwd_d32": (_c_int, [_c_vp] * 11 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_vp]),
+    "pd_attn_fwd_d32_ld": (_c_int, [_c_vp] * 7 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_int, _c_vp]),
+    "pd_attn_bwd_d32_ld": (_c_int, [_c_vp] * 11 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_int, _c_vp]),
     "pd_nc_sums_f32": (_c_int, [_c_vp] * 6 + [_c_int] * 5 + [_c_vp]),
     "pd_nc_affine_f32": (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_vp]),
     "pd_nc_affine_amax_f32": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),
@@ -198,6 +200,7 @@ SIGNATURES = {
     "pd_cmd_replay": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp]),
     "pd_memset_async": (_c_int, [_c_vp, _c_int, ctypes.c_int64, _c_vp]),
     "pd_memcpy_d2d_async": (_c_int, [_c_vp, _c_vp, ctypes.c_int64, _c_vp]),
+    "pd_copy_segments": (_c_int, [_c_vp, _c_int, _c_vp]),
     "pd_last_error": (ctypes.c_char_p, []),
     "pd_abi_version": (_c_int, []),
     "pd_debug_set": (_c_int, [ctypes.c_char_p, _c_int]),

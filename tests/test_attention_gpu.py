@@ -58,3 +58,45 @@ def test_fully_blocked_rows_give_zero(dtype):
     assert torch.isfinite(o).all() and o[2].abs().sum() == 0
     o.sum().backward()
     assert torch.isfinite(q.grad).all() and q.grad[2].abs().sum() == 0
+
+
+@pytest.mark.parametrize("Lq,Lk,B,H,masked,cols,at", [(100, 16384, 2, 8, True, 768, 256), (100, 1024, 2, 8, True, 768, 512), (7, 97, 1, 2, False, 192, 64),
+                                                       (128, 300, 3, 4, True, 256, 128)])
+def test_strided_keys_and_values_equal_their_dense_copies(Lq, Lk, B, H, masked, cols, at):
+    """pd_attn_fwd_d32_ld / pd_attn_bwd_d32_ld: k and v as column slices [at, at + H * 32) of wider [Lk * B, cols] matrices (the decoder's
+    key / value projections of the layers that share a memory level come out of one product) — forward output, lse and all three gradients
+    must be BIT-identical to the calls on dense copies of the slices."""
+    from partdistillation_amd.functions.attention import attn_bwd_raw, attn_fwd_raw
+    torch.manual_seed(Lq * 7 + Lk)
+    C = H * 32
+    q = torch.randn(Lq * B, C, device="cuda").bfloat16()
+    kw, vw = torch.randn(Lk * B, cols, device="cuda").bfloat16(), torch.randn(Lk * B, cols, device="cuda").bfloat16()
+    ks, vs = kw[:, at:at + C], vw[:, at:at + C]
+    kd, vd = ks.contiguous(), vs.contiguous()
+    m8 = None
+    if masked:
+        m8 = (torch.rand(B, Lq, Lk, device="cuda") < 0.4).to(torch.uint8)
+        m8[:, :, 0] = 0
+    scale = 32 ** -0.5
+    o1, l1 = attn_fwd_raw(q, ks, vs, m8, B, H, scale)
+    o2, l2 = attn_fwd_raw(q, kd, vd, m8, B, H, scale)
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+    d_o = torch.randn_like(o1)
+    g1 = attn_bwd_raw(q, ks, vs, m8, o1, d_o, l1, B, H, scale)
+    g2 = attn_bwd_raw(q, kd, vd, m8, o2, d_o, l2, B, H, scale)
+    for a, b in zip(g1, g2):
+        assert a.is_contiguous() and torch.equal(a, b)
+
+
+def test_copy_segments_concatenates_slices_in_one_launch():
+    from partdistillation_amd.functions import rowwise as rw
+    torch.manual_seed(3)
+    srcs = [torch.randn(3 * 256, 256, device="cuda").bfloat16() for _ in range(3)] + [torch.randn(768, device="cuda").bfloat16() for _ in range(3)]
+    wcat, bcat = torch.empty(768, 256, device="cuda", dtype=torch.bfloat16), torch.empty(768, device="cuda", dtype=torch.bfloat16)
+    odd = torch.arange(37, device="cuda", dtype=torch.uint8)
+    odd_dst = torch.zeros(40, device="cuda", dtype=torch.uint8)
+    pairs = [(wcat[j * 256:(j + 1) * 256], srcs[j][256:512]) for j in range(3)] + [(bcat[j * 256:(j + 1) * 256], srcs[3 + j][256:512]) for j in range(3)]
+    pairs.append((odd_dst[3:40], odd))                                   # unaligned destination, odd byte count
+    rw.copy_segments(pairs)
+    assert torch.equal(wcat, torch.cat([s_[256:512] for s_ in srcs[:3]])) and torch.equal(bcat, torch.cat([s_[256:512] for s_ in srcs[3:]]))
+    assert torch.equal(odd_dst[3:], odd) and int(odd_dst[:3].sum()) == 0

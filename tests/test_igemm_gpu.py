@@ -228,3 +228,22 @@ def test_grouped_tables_are_keyed_by_shape_as_well_as_address():
         ((q, s),) = mx8.quantize_grouped([w])
         q1, s1 = mx8.quantize(w)
         assert q.shape == w.shape and torch.equal(q, q1) and torch.equal(s, s1)
+
+
+@pytest.mark.parametrize("M,K,N,S", [(32768, 256, 768, 256), (2048, 256, 768, 256), (1000, 320, 512, 128), (130, 64, 256, 256)])
+def test_column_slabs_are_the_dense_results_of_the_separate_linears(M, K, N, S):
+    """PdIgemm.out_col_slab: several Linears over the same rows as ONE product whose [N / S, M, S] output holds each Linear's result as a
+    dense matrix — bit-identical to the separate launches (same tiles, same K order), ragged last row tile included; misuse raises."""
+    from partdistillation_amd.functions import igemm as ig
+    from partdistillation_amd.lib import PdHipError
+    torch.manual_seed(M + N)
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
+    b = torch.randn(N, device="cuda").bfloat16()
+    got = ig.linear(x, w, b, out_col_slab=S)
+    assert got.shape == (N // S, M, S) and got.is_contiguous()
+    for j in range(N // S):
+        want = ig.linear(x, w[j * S:(j + 1) * S].contiguous(), b[j * S:(j + 1) * S].contiguous())
+        assert torch.equal(got[j], want), (j, float((got[j].float() - want.float()).abs().max()))
+    with pytest.raises((PdHipError, AssertionError)):
+        ig.linear(x, w, b, out_col_slab=96)
