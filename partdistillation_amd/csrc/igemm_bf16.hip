@@ -387,8 +387,7 @@ __global__ __launch_bounds__(256, 2) void igemm3x3_bf16(IgArgs a)
     for (int j = 0; j < 6; ++j)
       __builtin_amdgcn_global_load_lds((glb_ptr)(pok[j] ? pp[j] + c * 64 : pp[j]), (lds_ptr)(patch + buf * PATCH3 + (wave * 6 + j) * 1024), 16, 0, 0);
   };
-  auto issue_b = [&](int step, int buf) {                  // step = 9 (c - cbeg) + tap; the filter's K index is tap * cch + c
-    const int c = cbeg + step / 9, tap = step - 9 * (c - cbeg), kt = tap * a.cch + c;
+  auto issue_b = [&](int kt, int buf) {                    // kt: the filter's K index tap * cch + c of the step's (tap, chunk)
 #pragma unroll
     for (int j = 0; j < NBJ; ++j)
       __builtin_amdgcn_global_load_lds((glb_ptr)(wb[j] + (int64_t)kt * 64), (lds_ptr)(bring + buf * BT + (wave * NBJ + j) * 1024), 16, 0, 0);
@@ -403,10 +402,10 @@ __global__ __launch_bounds__(256, 2) void igemm3x3_bf16(IgArgs a)
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) foff[ks] = ((ks * 2 + kh) ^ sw) * 16;
   const int pty = 2 * wave + (fr >> 4), ptx = fr & 15;     // this lane's result pixel inside the block
-  auto compute = [&](int step, int bbuf) {
-    const int c = step / 9, tap = step - 9 * c, dy = tap / 3, dx = tap - 3 * dy;       // (c: chunk index inside this split)
-    const int pr = (pty + (a.dgrad ? 2 - dy : dy)) * PW3 + ptx + (a.dgrad ? 2 - dx : dx), psw = (pr >> 1) & 7;
-    const unsigned char *As = patch + (c & 1) * PATCH3 + pr * BKB, *Bs = bring + bbuf * BT;
+  const int pr0 = pty * PW3 + ptx;                         // this lane's patch row under tap (0, 0)
+  auto compute = [&](const unsigned char *Pc, int off, int bbuf) __attribute__((always_inline)) {   // off: the tap's patch-row offset
+    const int pr = pr0 + off, psw = (pr >> 1) & 7;
+    const unsigned char *As = Pc + pr * BKB, *Bs = bring + bbuf * BT;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       hwbf16x8 wf[2];
@@ -420,25 +419,36 @@ __global__ __launch_bounds__(256, 2) void igemm3x3_bf16(IgArgs a)
   if (t < 2 * BN) reinterpret_cast<float *>(smem + 2 * PATCH3 + 3 * BT)[t] = sbv;
   // ---- the step loop: weight tiles two steps ahead on the ring; chunk c + 1's patch is issued in the slot of chunk c's first step.
   // Counted waits (loads complete in issue order): behind step s's weight tile the queue holds step s + 1's tile (2 pieces per wavefront)
-  // and, when the previous slot also issued a patch, its 6 pieces
-  const int ncl = cend - cbeg, nsteps = 9 * ncl;           // (patch buffers alternate with the LOCAL chunk index)
+  // and, when the previous slot also issued a patch, its 6 pieces.
+  // The nine taps of a chunk are UNROLLED with the tap a compile-time constant (round 6, second pass): as one loop over s = 9 c + tap the
+  // step was 749 instructions around its 8 MFMAs — s / 9 and s % 9 three times over, the tap's (dy, dx), the ring position as a rotating
+  // variable with three copies of the issue code — i.e. bound by instruction issue (2 600 cycles per step against 256 of matrix work).  Nine
+  // steps are a multiple of the three ring stages, so the ring position is tap % 3.
+  const int ncl = cend - cbeg;                             // (patch buffers alternate with the LOCAL chunk index)
   issue_patch(cbeg, 0);
-  issue_b(0, 0);
-  if (nsteps > 1) issue_b(1, 1);
-  int bbuf = 0;
-  for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) {
-      const int ps = s - 1;                                // the slot before this wait issued: weights of step s + 1, and a patch when it was a chunk's first step
-      const bool patch_behind = ps >= 0 && ps % 9 == 0 && ps / 9 + 1 < ncl;
-      if (patch_behind) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  issue_b(cbeg, 0);
+  issue_b(a.cch + cbeg, 1);
+  for (int cl = 0; cl < ncl; ++cl) {
+    const bool more = cl + 1 < ncl;
+    const unsigned char *Pc = patch + (cl & 1) * PATCH3;
+    const int c = cbeg + cl;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap == 8) {
+        if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (tap == 1) {                               // the slot before issued chunk c + 1's patch (6 pieces) in front of step 2's weights
+        if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                        // this step (and its chunk's patch) landed for everyone; everyone is done reading the previous step's stage
+      if (tap == 0 && more) issue_patch(c + 1, (cl + 1) & 1);
+      constexpr int dummy = 0; (void)dummy;
+      const int tap2 = (tap + 2) % 9, carry = (tap + 2) / 9;                   // the step two ahead
+      if (carry == 0 || more) issue_b(tap2 * a.cch + c + carry, (tap + 2) % 3);
+      const int dy = tap / 3, dx = tap - 3 * dy;
+      compute(Pc, a.dgrad ? (2 - dy) * PW3 + (2 - dx) : dy * PW3 + dx, tap % 3);
     }
-    __builtin_amdgcn_s_barrier();                          // step s (and its chunk's patch) landed for everyone; everyone is done reading step s - 1's stage
-    if (s % 9 == 0 && s / 9 + 1 < ncl) issue_patch(cbeg + s / 9 + 1, (s / 9 + 1) & 1);
-    if (s + 2 < nsteps) issue_b(s + 2, bbuf == 0 ? 2 : bbuf - 1);
-    compute(s, bbuf);
-    bbuf = bbuf == 2 ? 0 : bbuf + 1;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
