@@ -237,7 +237,11 @@ struct WgradGeom {
 
 // TN x TK output tile = (2 WN) x (2 WK), 4 wavefronts (2 x 2) of WN x WK each; 64-wide tiles for the 64-channel layers of res2 (half
 // of a 128-wide tile would be zeros there — and the fp32 partial tiles are this kernel's second-largest traffic).
-template <int WN, int WK>
+// P1: a 1 x 1 stride-1 problem (36 of R50's 52 convolutions, the decoder's key / value projections): the X row of output pixel m IS row m — no
+// tap, no (image, y, x) bookkeeping, no bounds but the slice's end.  The general gather spends ~40 vector instructions per 16-byte load on
+// them; with 8 MFMAs per stage the loop was 260-350 instructions per stage, i.e. bound by instruction issue (SQ counters: matrix pipe busy
+// 12 %, round 6).
+template <int WN, int WK, bool P1>
 __device__ __forceinline__ void wgrad_body(const bf16_t *__restrict__ dZ, const bf16_t *__restrict__ X, float *__restrict__ ws,
                                            const WgradGeom &g, int bid, float *__restrict__ dB = nullptr)
 {
@@ -255,20 +259,22 @@ __device__ __forceinline__ void wgrad_body(const bf16_t *__restrict__ dZ, const 
   const int xr = t / (TK / 8), xcl = (t % (TK / 8)) * 8;
   const bool ycol_ok = n0 + yc < g.N, xcol_ok = k0 + xcl < g.K;
   int tdy = 0, tdx = 0, xc = 0;                          // this thread's X columns: one tap, 8 channels
-  {
-    const int kk = xcol_ok ? k0 + xcl : 0, tap = kk / g.Ci;
-    xc = kk - tap * g.Ci;
-    tdy = tap / g.kw - g.pad; tdx = tap - (tap / g.kw) * g.kw - g.pad;
-  }
   constexpr int JY = WTW / LY, JX = WTW / LX;            // passes per stage (1 or 2)
   // running coordinates of the pixels the NEXT gload stages for X (called with m = mb, mb + 32, ... in this order)
   int cb[JX], cy[JX], cx[JX];
+  if (P1) {
+    xc = xcol_ok ? k0 + xcl : 0;
+  } else {
+    const int kk = xcol_ok ? k0 + xcl : 0, tap = kk / g.Ci;
+    xc = kk - tap * g.Ci;
+    tdy = tap / g.kw - g.pad; tdx = tap - (tap / g.kw) * g.kw - g.pad;
 #pragma unroll
-  for (int j = 0; j < JX; ++j) {
-    const int m = min(mb + xr + LX * j, g.M - 1), hw = g.Ho * g.Wo;
-    cb[j] = m / hw;
-    const int rem = m - cb[j] * hw;
-    cy[j] = rem / g.Wo; cx[j] = rem - cy[j] * g.Wo;
+    for (int j = 0; j < JX; ++j) {
+      const int m = min(mb + xr + LX * j, g.M - 1), hw = g.Ho * g.Wo;
+      cb[j] = m / hw;
+      const int rem = m - cb[j] * hw;
+      cy[j] = rem / g.Wo; cx[j] = rem - cy[j] * g.Wo;
+    }
   }
   uint4 ry[2][JY], rx[2][JX];
   // Every load is UNCONDITIONAL — a row past the slice, a tap outside the image or a column past the matrix reads element 0 of its tensor and
@@ -289,6 +295,13 @@ __device__ __forceinline__ void wgrad_body(const bf16_t *__restrict__ dZ, const 
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
       const int r = m + xr + LX * j;
+      if (P1) {
+        const bool ok = r < me && xcol_ok;
+        uint4 v = *reinterpret_cast<const uint4 *>(X + (ok ? (int64_t)r * g.Ci + xc : 0));
+        v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+        rx[s][j] = v;
+        continue;
+      }
       const int iy = cy[j] * g.stride + tdy, ix = cx[j] * g.stride + tdx;
       const bool ok = r < me && xcol_ok && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
       uint4 v = *reinterpret_cast<const uint4 *>(X + (ok ? ((int64_t)(cb[j] * g.Hi + iy) * g.Wi + ix) * g.Ci + xc : 0));
@@ -388,7 +401,8 @@ template <int WN, int WK>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr(const bf16_t *__restrict__ dZ, const bf16_t *__restrict__ X,
                                                               float *__restrict__ ws, WgradGeom g)
 {
-  wgrad_body<WN, WK>(dZ, X, ws, g, blockIdx.x);
+  if (g.kw == 1 && g.stride == 1) wgrad_body<WN, WK, true>(dZ, X, ws, g, blockIdx.x);
+  else wgrad_body<WN, WK, false>(dZ, X, ws, g, blockIdx.x);
 }
 
 // GROUPED form: one launch works through a table of problems (the filter gradients of a whole backbone, deferred to the end of
@@ -421,7 +435,10 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr_grouped(const Wgrad
   const int p = find_problem(tab, count, blockIdx.x, false);
   const WgradProblem &pr = tab[p];
   const int bid = xcd_major ? pd_xcd_major(pr.block_begin, pr.g.tiles * pr.splits, (int)blockIdx.x) : (int)blockIdx.x - pr.block_begin;
-  wgrad_body<WN, WK>(pd_as_global(pr.dz), pd_as_global(pr.x), ws + pr.ws_off, pr.g, bid, pd_as_global(pr.db));   // (pd_common.h: table pointers would be FLAT)
+  if (pr.g.kw == 1 && pr.g.stride == 1)                  // (pd_common.h: table pointers would be FLAT)
+    wgrad_body<WN, WK, true>(pd_as_global(pr.dz), pd_as_global(pr.x), ws + pr.ws_off, pr.g, bid, pd_as_global(pr.db));
+  else
+    wgrad_body<WN, WK, false>(pd_as_global(pr.dz), pd_as_global(pr.x), ws + pr.ws_off, pr.g, bid, pd_as_global(pr.db));
 }
 
 // dW (bf16) = sum over splits of the partial tiles (register order: element (ij, e) of thread t at ((ij * 16 + e) * 256 + t))
