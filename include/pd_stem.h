@@ -2,7 +2,7 @@
  * pd_stem.h — the ResNet stem convolution (7 x 7, stride 2, padding 3, 3 -> 64 channels) of libpd_hip.so, forward and filter gradient.
  *
  * Replaces, on the hot path, what the reference gets from detectron2 0.6 `BasicStem` (un-vendored; selected by
- * /root/reference/configs/mask2former/coco/instance-segmentation/Base-COCO-InstanceSegmentation.yaml:2-15 `build_resnet_backbone`,
+ * the reference's configs/mask2former/coco/instance-segmentation/Base-COCO-InstanceSegmentation.yaml:2-15 `build_resnet_backbone`,
  * STEM_OUT_CHANNELS 64, NORM FrozenBN):  conv1 = Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False, norm=FrozenBN) followed
  * by ReLU (and a 3 x 3 / 2 max pooling, pd_maxpool3s2_*_bf16 in pd_fused.h).  Rounds 1-4 ran this layer on MIOpen (forward + filter
  * gradient) with a separate frozen-BN / ReLU pass; it was the last library convolution of BASELINE config 2.
