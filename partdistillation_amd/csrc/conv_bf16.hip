@@ -397,12 +397,11 @@ __device__ __forceinline__ void wgrad_body(const bf16_t *__restrict__ dZ, const 
       for (int e = 0; e < 16; ++e) w[((i * KJ + j) * 16 + e) * 256] = acc[i][j][e];
 }
 
-template <int WN, int WK>
+template <int WN, int WK, bool P1>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr(const bf16_t *__restrict__ dZ, const bf16_t *__restrict__ X,
                                                               float *__restrict__ ws, WgradGeom g)
 {
-  if (g.kw == 1 && g.stride == 1) wgrad_body<WN, WK, true>(dZ, X, ws, g, blockIdx.x);
-  else wgrad_body<WN, WK, false>(dZ, X, ws, g, blockIdx.x);
+  wgrad_body<WN, WK, P1>(dZ, X, ws, g, blockIdx.x);
 }
 
 // GROUPED form: one launch works through a table of problems (the filter gradients of a whole backbone, deferred to the end of
@@ -429,16 +428,15 @@ __device__ __forceinline__ int find_problem(const WgradProblem *tab, int count, 
 // The tiles of ONE slice of pixels read the same dZ / X rows (a 3 x 3 layer's nine taps: five 128-wide K tiles over the same pixels), so they
 // should meet in ONE L2: the problem's workgroups are renumbered XCD-major (xcd.h) and position p is (slice p / tiles, tile p % tiles) — an XCD
 // then owns runs of whole slices.
-template <int WN, int WK>
+// (the 1 x 1 stride-1 problems of a tile shape are a launch of their own — P1 — so that each kernel carries ONE loop: with both bodies behind a
+//  branch the kernel took 169 VGPRs and the 3 x 3 workgroups of the R50 launch ran 20 % slower)
+template <int WN, int WK, bool P1>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr_grouped(const WgradProblem *__restrict__ tab, int count, float *__restrict__ ws, int xcd_major)
 {
   const int p = find_problem(tab, count, blockIdx.x, false);
   const WgradProblem &pr = tab[p];
   const int bid = xcd_major ? pd_xcd_major(pr.block_begin, pr.g.tiles * pr.splits, (int)blockIdx.x) : (int)blockIdx.x - pr.block_begin;
-  if (pr.g.kw == 1 && pr.g.stride == 1)                  // (pd_common.h: table pointers would be FLAT)
-    wgrad_body<WN, WK, true>(pd_as_global(pr.dz), pd_as_global(pr.x), ws + pr.ws_off, pr.g, bid, pd_as_global(pr.db));
-  else
-    wgrad_body<WN, WK, false>(pd_as_global(pr.dz), pd_as_global(pr.x), ws + pr.ws_off, pr.g, bid, pd_as_global(pr.db));
+  wgrad_body<WN, WK, P1>(pd_as_global(pr.dz), pd_as_global(pr.x), ws + pr.ws_off, pr.g, bid, pd_as_global(pr.db));   // (pd_common.h: table pointers would be FLAT)
 }
 
 // dW (bf16) = sum over splits of the partial tiles (register order: element (ij, e) of thread t at ((ij * 16 + e) * 256 + t)).
@@ -517,7 +515,10 @@ WgradPlan wgrad_plan(int M, int N, int K, int rows_per_wg = 0)
 template <int WN, int WK>
 void launch_wgrad(const void *dz, const void *x, void *dw, float *ws, const WgradGeom &g, int splits, hipStream_t st)
 {
-  hipLaunchKernelGGL((conv_wgrad_bf16_tr<WN, WK>), dim3((unsigned)(g.tiles * splits)), dim3(256), 0, st, (const bf16_t *)dz, (const bf16_t *)x, ws, g);
+  if (g.kw == 1 && g.stride == 1)
+    hipLaunchKernelGGL((conv_wgrad_bf16_tr<WN, WK, true>), dim3((unsigned)(g.tiles * splits)), dim3(256), 0, st, (const bf16_t *)dz, (const bf16_t *)x, ws, g);
+  else
+    hipLaunchKernelGGL((conv_wgrad_bf16_tr<WN, WK, false>), dim3((unsigned)(g.tiles * splits)), dim3(256), 0, st, (const bf16_t *)dz, (const bf16_t *)x, ws, g);
   hipLaunchKernelGGL((conv_wgrad_reduce<WN, WK>), dim3((unsigned)(g.tiles * (WN / 32) * (WK / 32) * 16 / RQ)), dim3(256), 0, st, (const float *)ws,
                      (bf16_t *)dw, g.N, g.K, g.tiles_k, g.tiles, splits);
 }
@@ -639,7 +640,7 @@ extern "C" int pd_conv_bf16_wgrad_grouped(const PdConvWgradDesc *descs, int coun
   if (count < 0 || (count > 0 && (!descs || !table_host_pinned || !table_device || !workspace))) return PD_ERR_INVALID_ARG;
   if (count == 0) return 0;
   WgradProblem *tab = reinterpret_cast<WgradProblem *>(table_host_pinned);
-  int n_of[4] = {0, 0, 0, 0}, blocks[4] = {0, 0, 0, 0}, rblocks[4] = {0, 0, 0, 0};
+  int n_of[4] = {0, 0, 0, 0}, n_p1[4] = {0, 0, 0, 0}, blocks[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, rblocks[4] = {0, 0, 0, 0};
   // problems sorted by tile variant (four contiguous sub-tables, one launch pair each)
   int order[4][256];
   if (count > 256) return PD_ERR_INVALID_ARG;
@@ -647,10 +648,14 @@ extern "C" int pd_conv_bf16_wgrad_grouped(const PdConvWgradDesc *descs, int coun
   for (int i = 0; i < count; ++i)
     if (!desc_ok(descs[i])) return PD_ERR_INVALID_ARG;
   plan_group(descs, count, plans);
-  for (int i = 0; i < count; ++i) {
-    const int v = variant_of(plans[i]);
-    order[v][n_of[v]++] = i;
-  }
+  for (int pass = 0; pass < 2; ++pass)                    // a variant's 1 x 1 stride-1 problems first: they are a launch of their own (P1)
+    for (int i = 0; i < count; ++i) {
+      const int v = variant_of(plans[i]);
+      const bool p1 = descs[i].k == 1 && descs[i].stride == 1;
+      if (p1 != (pass == 0)) continue;
+      order[v][n_of[v]++] = i;
+      n_p1[v] += p1;
+    }
   int64_t ws_off = 0;
   int start[4], at = 0;
   for (int v = 0; v < 4; ++v) {
@@ -663,8 +668,9 @@ extern "C" int pd_conv_bf16_wgrad_grouped(const PdConvWgradDesc *descs, int coun
       w.dz = (const bf16_t *)d.dz; w.x = (const bf16_t *)d.x; w.dw = (bf16_t *)d.dw; w.ws_off = ws_off; w.db = d.db; w.scale = d.scale;
       w.g.M = d.batch * d.ho * d.wo; w.g.N = d.co; w.g.K = d.k * d.k * d.ci; w.g.Ci = d.ci; w.g.kw = d.k; w.g.Hi = d.hi; w.g.Wi = d.wi;
       w.g.Ho = d.ho; w.g.Wo = d.wo; w.g.stride = d.stride; w.g.pad = d.pad; w.g.tiles_k = p.tiles_k; w.g.tiles = p.tiles; w.g.m_chunk = p.m_chunk;
-      w.block_begin = blocks[v]; w.reduce_begin = rblocks[v]; w.splits = p.splits; w.variant = v;
-      blocks[v] += p.tiles * p.splits;
+      const int p1 = q < n_p1[v] ? 1 : 0;
+      w.block_begin = blocks[v][p1]; w.reduce_begin = rblocks[v]; w.splits = p.splits; w.variant = v;
+      blocks[v][p1] += p.tiles * p.splits;
       rblocks[v] += p.tiles * (p.tn / 64) * (p.tk / 64) * 16 / RQ;
       ws_off += (int64_t)p.tiles * p.splits * p.tn * p.tk;
     }
@@ -676,7 +682,10 @@ extern "C" int pd_conv_bf16_wgrad_grouped(const PdConvWgradDesc *descs, int coun
   const WgradProblem *dt = reinterpret_cast<const WgradProblem *>(table_device);
 #define PD_GROUP(V, WN, WK)                                                                                                         \
   if (n_of[V]) {                                                                                                                    \
-    hipLaunchKernelGGL((conv_wgrad_bf16_tr_grouped<WN, WK>), dim3((unsigned)blocks[V]), dim3(256), 0, st, dt + start[V], n_of[V], workspace, g_pd_dbg_conv_xcd_major); \
+    if (n_p1[V])                                                                                                                    \
+      hipLaunchKernelGGL((conv_wgrad_bf16_tr_grouped<WN, WK, true>), dim3((unsigned)blocks[V][1]), dim3(256), 0, st, dt + start[V], n_p1[V], workspace, g_pd_dbg_conv_xcd_major); \
+    if (n_of[V] > n_p1[V])                                                                                                          \
+      hipLaunchKernelGGL((conv_wgrad_bf16_tr_grouped<WN, WK, false>), dim3((unsigned)blocks[V][0]), dim3(256), 0, st, dt + start[V] + n_p1[V], n_of[V] - n_p1[V], workspace, g_pd_dbg_conv_xcd_major); \
     hipLaunchKernelGGL((conv_wgrad_reduce_grouped<WN, WK>), dim3((unsigned)rblocks[V]), dim3(256), 0, st, dt + start[V], n_of[V],    \
                        (const float *)workspace);                                                                                   \
   }
