@@ -429,7 +429,9 @@ __device__ __forceinline__ int find_problem(const WgradProblem *tab, int count, 
 // should meet in ONE L2: the problem's workgroups are renumbered XCD-major (xcd.h) and position p is (slice p / tiles, tile p % tiles) — an XCD
 // then owns runs of whole slices.
 // (the 1 x 1 stride-1 problems of a tile shape are a launch of their own — P1 — so that each kernel carries ONE loop: with both bodies behind a
-//  branch the kernel took 169 VGPRs and the 3 x 3 workgroups of the R50 launch ran 20 % slower)
+//  branch the kernel took 169 VGPRs and the 3 x 3 workgroups of the R50 launch ran 20 % slower.  Measured and dropped: a third class for the
+//  stride-1 "same" 3 x 3 problems with one running row offset instead of the (image, y, x) -> address chain — its launch of 1 440 workgroups and
+//  the 816 strided ones left over took 145 + 132 us where the common launch takes 249; step 18.78 vs 18.83 ms)
 template <int WN, int WK, bool P1>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_tr_grouped(const WgradProblem *__restrict__ tab, int count, float *__restrict__ ws, int xcd_major)
 {
