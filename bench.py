@@ -174,15 +174,15 @@ _CATEGORIES = [
     ("own_fp32_wgrad_mfma", r"^(gemm_wgrad_f32|gemm_wgrad_f16x2|wgrad_tr_reduce|wgrad_h2w_reduce)"),
     # every forward / input-gradient kernel of the fp32 pixel decoder (tiled, row-stream, producer / consumer) + the row-maxima passes that feed them
     ("own_fp32x3_gemm_conv", r"^(gemm_tn_f32|gemm_tn_f16x2|gemm_kpc_f16x2|gemm_rows_f16x2|row_amax_f32|add_rows_amax|cast_bf16_f32_amax|gemm_wgrad_f32x3|conv3x3_)"),
-    ("own_igemm_bf16_conv_linear", r"^(igemm_bf16|filter_transpose_grouped|wgrad_bf16|stem_|maxpool3s2)"),
+    ("own_igemm_bf16_conv_linear", r"^(igemm_bf16|igemm3x3_bf16|filter_transpose_grouped|wgrad_bf16|stem_|maxpool3s2)"),
     ("own_conv_bf16_filter_grads", r"^conv_(wgrad|igemm)"),
     ("own_attention_mfma", r"^(attn_|wattn_)"),
     ("own_decoder_fused", r"^(dec_fwd_|dec_bwd_|dec_pack_|decoder_head)"),
     ("own_skinny_bf16_gemm", r"^sgemm_"),
-    ("own_criterion", r"^(pair_logits|loss_vectors|mask_point_losses|uncertain_points|matcher_|point_sample|skinny_linear|lsa_)"),
+    ("own_criterion", r"^(pair_logits|loss_vectors|mask_point_losses|uncertain_points|matcher_|match_point_logits|point_sample|skinny_linear|lsa_)"),
     ("own_rowwise_norm_optim_misc", r"^(add_ln_|colsum_|mem_prep|msda_prep|gn_coeffs|affine_act|nc_|multi_gather|upsample|layernorm_rows|ln_rows|"
                                     r"sumsq|adamw|swin_ln|kmeans|scores_|mask_assign|resample_|resize_|normalize_|rle_|amax_|quantize_|bn_|sum3_|transpose_batched|"
-                                    r"copy_d2d|relu_bwd|mx8_)"),
+                                    r"copy_d2d|copy_segments|relu_bwd|mx8_)"),
     ("library_gemm_fp32", r"^Cijk_.*_S_B"),
     ("library_gemm_bf16", r"^(Cijk_|.*kernel_batched_gemm|.*kernel_gemm)"),
     ("miopen_conv", r"(igemm_|grouped_conv|naive_conv|SubTensorOp|batched_transpose|gridwise|MIOpen|miopen|Im2Col|Col2Im)"),
