@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t *__restrict__ 
 // in registers after the loop over the query sub-tiles, dQ is accumulated over the wave's tiles, reduced over the
 // four waves through LDS and leaves as one partial per workgroup (attn_bwd_dq_reduce sums the partials).
 template <bool MASK>
-__global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k,
+__global__ __launch_bounds__(256, 2) void attn_bwd_mfma(const bf16_t *__restrict__ q, const bf16_t *__restrict__ k,
                                                      const bf16_t *__restrict__ v, const uint8_t *__restrict__ mask,
                                                      const bf16_t *__restrict__ o, const bf16_t *__restrict__ d_o,
                                                      const float *__restrict__ lse, float *__restrict__ part_dq,
