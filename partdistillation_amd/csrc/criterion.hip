@@ -363,11 +363,15 @@ __global__ __launch_bounds__(256) void point_sample_u8(const uint8_t *__restrict
     const float wnw = (x1 - ix) * (y1 - iy), wne = (ix - x0) * (y1 - iy), wsw = (x1 - ix) * (iy - y0), wse = (ix - x0) * (iy - y0);
     const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
     const uint8_t *mp = maps + m * (int64_t)H * W;
+    // the four corner bytes as straight-line loads from clamped (always valid) addresses, a corner outside the map contributing an exact 0 —
+    // behind `if (valid)` each load was followed by its own s_waitcnt: four dependent memory round trips per point
+    const int xa = min(max(x0, 0), W - 1), xb = min(max(x1, 0), W - 1), ya = min(max(y0, 0), H - 1), yb = min(max(y1, 0), H - 1);
+    const uint8_t b00 = mp[(int64_t)ya * W + xa], b01 = mp[(int64_t)ya * W + xb], b10 = mp[(int64_t)yb * W + xa], b11 = mp[(int64_t)yb * W + xb];
     float acc = 0.f;
-    if (vy0 && vx0) acc += (mp[(int64_t)y0 * W + x0] ? 1.f : 0.f) * wnw;
-    if (vy0 && vx1) acc += (mp[(int64_t)y0 * W + x1] ? 1.f : 0.f) * wne;
-    if (vy1 && vx0) acc += (mp[(int64_t)y1 * W + x0] ? 1.f : 0.f) * wsw;
-    if (vy1 && vx1) acc += (mp[(int64_t)y1 * W + x1] ? 1.f : 0.f) * wse;
+    acc += ((vy0 && vx0 && b00) ? 1.f : 0.f) * wnw;
+    acc += ((vy0 && vx1 && b01) ? 1.f : 0.f) * wne;
+    acc += ((vy1 && vx0 && b10) ? 1.f : 0.f) * wsw;
+    acc += ((vy1 && vx1 && b11) ? 1.f : 0.f) * wse;
     out[pt] = acc;
   }
 }
