@@ -554,13 +554,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_mfma(const bf16_t *__restrict
   // ---- stage all queries of this (image, head): Q, dO row-major and transposed, delta = rowsum(dO * O), lse
   for (int idx = tid; idx < MQ * 4; idx += 256) {
     const int row = idx >> 2, piece = idx & 3;
-    uint4 qv = make_uint4(0, 0, 0, 0), gv = qv, ov = qv;
-    if (row < Lq) {
-      const int64_t off = ((int64_t)row * B + b) * rs + h * D + piece * 8;
-      qv = *reinterpret_cast<const uint4 *>(q + off);
-      gv = *reinterpret_cast<const uint4 *>(d_o + off);
-      ov = *reinterpret_cast<const uint4 *>(o + off);
-    }
+    // (straight-line loads from a clamped row, zeroed past Lq: behind `if (row < Lq)` each of the three was a memory round trip of its own)
+    const bool live = row < Lq;
+    const int64_t off = ((int64_t)(live ? row : 0) * B + b) * rs + h * D + piece * 8;
+    uint4 qv = *reinterpret_cast<const uint4 *>(q + off), gv = *reinterpret_cast<const uint4 *>(d_o + off), ov = *reinterpret_cast<const uint4 *>(o + off);
+    if (!live) { qv = make_uint4(0, 0, 0, 0); gv = qv; ov = qv; }
     *reinterpret_cast<uint2 *>(&Qs[row][piece * 8]) = make_uint2(qv.x, qv.y);
     *reinterpret_cast<uint2 *>(&Qs[row][piece * 8 + 4]) = make_uint2(qv.z, qv.w);
     *reinterpret_cast<uint2 *>(&Os[row][piece * 8]) = make_uint2(gv.x, gv.y);
