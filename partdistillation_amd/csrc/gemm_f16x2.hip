@@ -633,7 +633,9 @@ void gemm_rows_f16x2_k256(const float *__restrict__ A, const float *__restrict__
 constexpr int KR_RB = 192, KR_KC = 32;
 constexpr int KR_APANEL = KR_RB * 16 + 16, KR_APLANE = (KR_KC / 8) * KR_APANEL, KR_ABUF = 2 * KR_APLANE;
 constexpr int KR_BPANEL = 256 * 16 + 16, KR_BPLANE = (KR_KC / 8) * KR_BPANEL, KR_BBUF = 2 * KR_BPLANE;
-constexpr size_t KR_LDS = (size_t)2 * (KR_ABUF + KR_BBUF) + KR_RB * sizeof(float);
+#ifdef PD_PROBES
+constexpr size_t KR_LDS = (size_t)2 * (KR_ABUF + KR_BBUF) + KR_RB * sizeof(float);      // (gemm_kres_f16x2's layout: tools/probes)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // gemm_kpc_f16x2 (round 5): gemm_kres_f16x2's data path with PRODUCER and CONSUMER wavefronts instead of workgroup barriers.  Every structure of

@@ -443,7 +443,6 @@ __global__ __launch_bounds__(256, 2) void igemm3x3_bf16(IgArgs a)
       }
       __builtin_amdgcn_s_barrier();                        // this step (and its chunk's patch) landed for everyone; everyone is done reading the previous step's stage
       if (tap == 0 && more) issue_patch(c + 1, (cl + 1) & 1);
-      constexpr int dummy = 0; (void)dummy;
       const int tap2 = (tap + 2) % 9, carry = (tap + 2) / 9;                   // the step two ahead
       if (carry == 0 || more) issue_b(tap2 * a.cch + c + carry, (tap + 2) % 3);
       const int dy = tap / 3, dx = tap - 3 * dy;
