@@ -200,6 +200,8 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : (NST == 2 || BN == 64) ? 2 : 1)
     wb[j] = a.Wf + (int64_t)(n0 + row) * ldw + (lch ^ ((row >> 1) & 7)) * 8;
   }
 
+  int cur_tap = -1;                                        // (gathered form) the tap whose row offsets roff[] hold
+  int64_t cur_kw = 0, roff[4] = {-1, -1, -1, -1};
   auto issue = [&](int kt, int buf) {
     unsigned char *As = smem + buf * STAGE, *Bs = As + BM * BKB;
     if (P1) {
@@ -211,32 +213,42 @@ __global__ __launch_bounds__(256, NST == 1 ? 4 : (NST == 2 || BN == 64) ? 2 : 1)
         __builtin_amdgcn_global_load_lds((glb_ptr)(wb[j] + (int64_t)kt * 64), (lds_ptr)(Bs + (wave * NBJ + j) * 1024), 16, 0, 0);
       return;
     }
-    int tap = kt / a.cch;
-    const int c0 = (kt - tap * a.cch) * 64;
-    int dy = tap / a.kw, dx = tap - dy * a.kw;
-    int64_t kw_ = kt;                                      // the filter's K-step of this (tap, chunk)
-    if (a.pcls) {                                          // tap = index into the class's tap list: dy in {1} | {0, 2}, dx likewise
-      const int ty_ = tap / ntx, tx_ = tap - ty_ * ntx;
-      dy = cy ? 2 * ty_ : 1; dx = cx ? 2 * tx_ : 1;
-      kw_ = (int64_t)(dy * a.kw + dx) * a.cch + (kt - tap * a.cch);
+    const int tap = kt / a.cch, c0 = (kt - tap * a.cch) * 64;
+    // the four rows' source pixels under a tap — bounds, (y, x) -> element offset with its 64-bit multiply — only when the TAP changes (every
+    // cch steps; K-steps arrive in order): recomputed per step they made the step ~410 instructions around 8-16 MFMAs (round 6, the same
+    // finding as the patch kernel's)
+    if (tap != cur_tap) {
+      cur_tap = tap;
+      int dy = tap / a.kw, dx = tap - dy * a.kw;
+      cur_kw = (int64_t)tap * a.cch;                       // the filter's first K-step of this tap
+      if (a.pcls) {                                        // tap = index into the class's tap list: dy in {1} | {0, 2}, dx likewise
+        const int ty_ = tap / ntx, tx_ = tap - ty_ * ntx;
+        dy = cy ? 2 * ty_ : 1; dx = cx ? 2 * tx_ : 1;
+        cur_kw = (int64_t)(dy * a.kw + dx) * a.cch;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int sy, sx;
+        bool ok = bb[j] >= 0;
+        if (a.dgrad) {
+          const int ty = y0[j] - dy, tx = x0[j] - dx;
+          ok = ok && ty >= 0 && tx >= 0;
+          if (a.stride == 2) { ok = ok && ((ty | tx) & 1) == 0; sy = ty >> 1; sx = tx >> 1; }
+          else { sy = ty; sx = tx; }
+          ok = ok && sy < a.Hs && sx < a.Ws;
+        } else {
+          sy = y0[j] + dy; sx = x0[j] + dx;
+          ok = ok && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+        }
+        roff[j] = ok ? ((int64_t)(bb[j] + sy * a.Ws + sx)) * a.Cs + akc[j] : -1;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      int sy, sx;
-      bool ok = bb[j] >= 0;
-      if (a.dgrad) {
-        const int ty = y0[j] - dy, tx = x0[j] - dx;
-        ok = ok && ty >= 0 && tx >= 0;
-        if (a.stride == 2) { ok = ok && ((ty | tx) & 1) == 0; sy = ty >> 1; sx = tx >> 1; }
-        else { sy = ty; sx = tx; }
-        ok = ok && sy < a.Hs && sx < a.Ws;
-      } else {
-        sy = y0[j] + dy; sx = x0[j] + dx;
-        ok = ok && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
-      }
-      const bf16_t *p = ok ? a.S + ((int64_t)(bb[j] + sy * a.Ws + sx)) * a.Cs + c0 + akc[j] : zline + lch * 8;
+      const bf16_t *p = roff[j] >= 0 ? a.S + roff[j] + c0 : zline + lch * 8;
       __builtin_amdgcn_global_load_lds((glb_ptr)p, (lds_ptr)(As + (wave * 4 + j) * 1024), 16, 0, 0);
     }
+    const int64_t kw_ = cur_kw + (kt - tap * a.cch);
 #pragma unroll
     for (int j = 0; j < NBJ; ++j)
       __builtin_amdgcn_global_load_lds((glb_ptr)(wb[j] + kw_ * 64), (lds_ptr)(Bs + (wave * NBJ + j) * 1024), 16, 0, 0);
