@@ -420,9 +420,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t *__restrict__ 
                                                      const bf16_t *__restrict__ v, const uint8_t *__restrict__ mask,
                                                      bf16_t *__restrict__ o, float *__restrict__ lse, float *__restrict__ part_o,
                                                      float *__restrict__ part_ml, int B, int H, int Lq, int Lk, float scale,
-                                                     int nchunk, int ldkv)
+                                                     int nchunk, int ldkv, int kc)
 {
-  // ldkv: elements between consecutive (key, image) rows of k and v — H * 32 for dense tensors, more when k / v are column slices of a wider
+  // kc: keys per workgroup (mfma_fwd_chunk).  ldkv: elements between consecutive (key, image) rows of k and v — H * 32 for dense tensors, more when k / v are column slices of a wider
   // matrix (the decoder's key / value projections of the layers that share a memory level come out of ONE product: functions/decoder_core.py)
   __shared__ __attribute__((aligned(16))) bf16_t Ks[2][32][LR];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[2][32][LR];
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t *__restrict__ 
     qreg[s] = bf16x4{0, 0, 0, 0};
     if (qvalid) qreg[s] = *reinterpret_cast<const bf16x4 *>(q + ((int64_t)qi * B + b) * rs + h * D + 8 * s + 4 * hh);
   }
-  const int kbeg = chunk * KC_FWD, kend = min(Lk, kbeg + KC_FWD);
+  const int kbeg = chunk * kc, kend = min(Lk, kbeg + kc);
   const int ntile = (kend - kbeg + 31) / 32;
   // staging: threads 0..127 move the K tile, 128..255 the V tile; 4 x 16 bytes per key row
   const bf16_t *src = (tid < 128) ? k : v;
@@ -733,6 +733,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_mfma(const bf16_t *__restrict
 }
 
 inline int nchunks(int Lk, int kc) { return Lk <= 0 ? 1 : (Lk + kc - 1) / kc; }
+// keys per workgroup of attn_fwd_mfma: KC_FWD = 256 keys are 8 tiles in a row at ~2 us each; at 1 024 / 4 096 keys that is 64 / 256 workgroups on
+// 256 CUs.  Fewer keys per workgroup (down to 64) until ~512 workgroups exist — only where the keys are split over workgroups anyway (a single
+// chunk needs no combine launch, and stays single).
+inline int mfma_fwd_chunk(int B, int H, int Lk)
+{
+  int kc = KC_FWD;
+  if (Lk > KC_FWD)
+    while (kc > 64 && (int64_t)B * H * nchunks(Lk, kc) < 512) kc >>= 1;
+  return kc;
+}
 // keys per workgroup of attn_bwd_mfma: a workgroup walks its keys 128 at a time (4 waves x 32) and a round costs ~15 us whatever the
 // machine's load, so KC_DQ = 512 keys are 4 rounds in a row — fine at 16 384 keys (512 workgroups), wasteful at 1 024 (32 workgroups on
 // 256 CUs).  Fewer keys per workgroup until ~256 workgroups exist: 1 024 keys -> 128 per workgroup (1 round), 4 096 -> 256.
@@ -758,7 +768,7 @@ int g_pd_dbg_attn_scalar = 0;     // experiment knob: 1 forces the scalar kernel
 
 extern "C" int64_t pd_attn_workspace_floats(int B, int H, int Lq, int Lk)
 {
-  const int64_t n1 = (int64_t)B * H * nchunks(Lk, KC_FWD) * Lq * (D + 2);
+  const int64_t n1 = (int64_t)B * H * nchunks(Lk, mfma_fwd_chunk(B, H, Lk)) * Lq * (D + 2);
   const int64_t n2 = (int64_t)B * H * nchunks(Lk, 128) * Lq * D;   // the matrix-core backward may cut the keys as fine as 128 per workgroup
   return (n1 > n2 ? n1 : n2) + 64;
 }
@@ -780,16 +790,18 @@ extern "C" int pd_attn_fwd_d32_ld(const void *q, const void *k, const void *v, c
   if (B * Lq == 0) return PD_OK;
   if (!o || !lse || !workspace) return pd_set_error(PD_ERR_INVALID_ARG, "pd_attn_fwd_d32: null output");
   hipStream_t s = (hipStream_t)stream_;
-  const int nc = nchunks(Lk, KC_FWD);
-  float *part_o = workspace, *part_ml = workspace + (int64_t)B * H * nc * Lq * D;
   if (dtype == PD_BF16 && Lq <= MQ && Lk > 0 && !g_pd_dbg_attn_scalar) {           // matrix-core path
+    const int kc = mfma_fwd_chunk(B, H, Lk), nc = nchunks(Lk, kc);
+    float *part_o = workspace, *part_ml = workspace + (int64_t)B * H * nc * Lq * D;
     if (mask) hipLaunchKernelGGL(attn_fwd_mfma<true>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
-                                 mask, (bf16_t *)o, lse, part_o, part_ml, B, H, Lq, Lk, scale, nc, ld_kv);
+                                 mask, (bf16_t *)o, lse, part_o, part_ml, B, H, Lq, Lk, scale, nc, ld_kv, kc);
     else hipLaunchKernelGGL(attn_fwd_mfma<false>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
-                            mask, (bf16_t *)o, lse, part_o, part_ml, B, H, Lq, Lk, scale, nc, ld_kv);
+                            mask, (bf16_t *)o, lse, part_o, part_ml, B, H, Lq, Lk, scale, nc, ld_kv, kc);
     if (nc > 1) hipLaunchKernelGGL(attn_fwd_combine<bf16_t>, dim3((B * H * Lq + 7) / 8), dim3(256), 0, s, part_o, part_ml, (bf16_t *)o, lse, B, H, Lq, nc);
     return pd_check_launch("pd_attn_fwd_d32");
   }
+  const int nc = nchunks(Lk, KC_FWD);
+  float *part_o = workspace, *part_ml = workspace + (int64_t)B * H * nc * Lq * D;
   for (int qp = 0; qp * QP < Lq; ++qp) {
     if (dtype == PD_BF16)
       hipLaunchKernelGGL(attn_fwd_partial<bf16_t>, dim3(nc, H, B), dim3(256), 0, s, (const bf16_t *)q, (const bf16_t *)k,
