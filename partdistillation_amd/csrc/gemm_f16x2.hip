@@ -932,6 +932,15 @@ void gemm_kpc_f16x2(const float *__restrict__ A, const float *__restrict__ B, co
 static const bool g_rows_relu = []() { const char *e = getenv("PD_H2_ROWS_RELU"); return !e || e[0] != '0'; }();   // A/B switch (default on)
 int g_pd_dbg_f16x2 = 0;   // tools/ only (pd_debug_set "f16x2_tile"): see pd_gemm_tn_f16x2
 
+// the producer / consumer kernel runs ONE 192-row work item per workgroup at a time: a problem with few items (the FPN's res4 input projection:
+// 43 on 256 CUs: 54 us) leaves most of the chip idle.  PD_H2_KPC_MIN_ITEMS=128 sends such problems to the tiled kernel (44-48 us for that launch) —
+// measured over the step on two boxes: 18.19 -> 18.12 ms and 18.54 -> 18.57 ms, i.e. nothing; the default (0) keeps the producer / consumer kernel
+static bool kpc_items_ok(int M, int N)
+{
+  static const int min_items = []() { const char *e = getenv("PD_H2_KPC_MIN_ITEMS"); return e ? atoi(e) : 0; }();
+  return ((M + KR_RB - 1) / KR_RB) * (N / 256) >= min_items;
+}
+
 template <int TM, int TN, int WN, int BKK, bool CONV = false, int NRS = 1, int FAST = 0>
 static int launch_f16x2(const float *A, const float *B, const float *bias, float *C, int M, int N, int K, int lda, int ldb, int ldc, int mode,
                         uint32_t *bits, float *colsum, const float *a_amax, const float *b_amax, float *c_amax, hipStream_t st, int H = 0,
@@ -1093,7 +1102,7 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
   // (f16x2.h split4h_u): 256 <- 1024 at M = 43 008 76-78 us against the tiled kernel's 92-94, the step 21.82 -> 21.65 ms (three same-box A/B pairs).
   // PD_H2_KPC=0 / pd_debug_set("f16x2_tile", 80) keep the tiled kernel; 92 / 93 select it with fp32 weights / pre-split weight planes.
   static const bool kpc_env = []() { const char *e = getenv("PD_H2_KPC"); return !e || e[0] != '0'; }();
-  if (((kpc_env && dbg == 0) || dbg == 92 || dbg == 93 || dbg == 94 || (dbg >= 220 && dbg < 236)) && (int64_t)M * lda * 4 < (1ll << 31) && (int64_t)N * ldb * 4 < (1ll << 31) && !flags && mode == 0 && !bits && !c_amax && (K >= 512 || (dbg == 92 && K >= 128)) && (K % KR_KC) == 0 && K / KR_KC >= 3 /* the double-buffered inverse-scale slot is reused two chunks later */ && (N % 256) == 0 && (N <= 512 || dbg == 92) && M >= 8192 &&
+  if (((kpc_env && dbg == 0) || dbg == 92 || dbg == 93 || dbg == 94 || (dbg >= 220 && dbg < 236)) && (int64_t)M * lda * 4 < (1ll << 31) && (int64_t)N * ldb * 4 < (1ll << 31) && !flags && mode == 0 && !bits && !c_amax && (K >= 512 || (dbg == 92 && K >= 128)) && (K % KR_KC) == 0 && K / KR_KC >= 3 /* the double-buffered inverse-scale slot is reused two chunks later */ && (N % 256) == 0 && (N <= 512 || dbg == 92) && M >= 8192 && kpc_items_ok(M, N) &&
       (a_amax == nullptr) == (b_amax == nullptr)) {
     static int ncu4 = 0;
     if (!ncu4) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&ncu4, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu4 < 8) ncu4 = 256; }
@@ -1177,6 +1186,8 @@ static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias,
     if (!fast_env) GO(256, 256, 128, 2, 0);
     GO(256, 256, 128, 2, 1);
   }
+  // (measured and dropped, round 6: 32-deep steps for the few-tile, long-contraction problems — the FPN's res5 input projection, 32 tiles x 128
+  //  steps of 16: 70 us — run 76.6 us)
   if (dbg == 4 || dbg == 70) GO(128, 128, 64, 1, 0);
   if (dbg == 14 || !fast_env) GO(128, 128, 64, 2, 0);
   GO(128, 128, 64, 2, 1);
@@ -1196,7 +1207,7 @@ extern "C" int pd_gemm_tn_f16x2_which(int M, int N, int K, int mode, int has_bit
 #endif
   if (dbg != 62 && dbg != 3 && dbg != 13 && dbg != 70 && (mode == 1 || mode == 2) && has_bits && K == 256 && (N % 256) == 0 && N >= 512 && M >= 8192 && has_amax && g_rows_relu) return 2;
   static const bool kpc_env = []() { const char *e = getenv("PD_H2_KPC"); return !e || e[0] != '0'; }();
-  if (((kpc_env && dbg == 0) || dbg == 92 || dbg == 93) && mode == 0 && !has_bits && K >= 512 && (K % KR_KC) == 0 && (N % 256) == 0 && N <= 512 && M >= 8192) return 5;
+  if (((kpc_env && dbg == 0) || dbg == 92 || dbg == 93) && mode == 0 && !has_bits && K >= 512 && (K % KR_KC) == 0 && (N % 256) == 0 && N <= 512 && M >= 8192 && kpc_items_ok(M, N)) return 5;
 #ifdef PD_PROBES
   static const bool kres_env = []() { const char *e = getenv("PD_H2_KRES"); return e && e[0] == '1'; }();
   if (((kres_env && dbg == 0) || dbg == 91) && mode == 0 && !has_bits && K >= 512 && (K % KR_KC) == 0 && (N % 256) == 0 && N <= 512 && M >= 8192) return 4;
