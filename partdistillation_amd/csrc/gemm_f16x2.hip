@@ -526,6 +526,10 @@ void gemm_rows_f16x2_k256(const float *__restrict__ A, const float *__restrict__
 
   auto iter = [&](int it, int par) {
     const unsigned char *base = (par ? lds1 : lds0) + fh * RS_PANEL + fr * 16;
+    // MODE 2: the tile's sign bits are fetched HERE, under the 48 matrix instructions — read in the epilogue, where they are used, each tile's
+    // stores waited for a global load's latency (the mode-2 launches ran 119 us against mode 1's 88 on the same shape)
+    unsigned wbits = 0u;
+    if (MODE == 2) wbits = (unsigned)bits[(((int64_t)(t0 + it) * npanels + panel) * 8 + w) * 64 + lane];
     f32x16 acc0, acc1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
@@ -569,7 +573,8 @@ void gemm_rows_f16x2_k256(const float *__restrict__ A, const float *__restrict__
     }
     if (MODE != 0) {
       const int64_t widx = (((int64_t)(t0 + it) * npanels + panel) * 8 + w) * 64 + lane;
-      unsigned word = MODE == 2 ? (unsigned)bits[widx] : 0u;
+      unsigned word = 0u;
+      if (MODE == 2) { asm volatile("" : "+v"(wbits)); word = wbits; }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int rl = (e & 3) + 8 * (e >> 2) + 4 * fh;
