@@ -450,6 +450,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #else
 #define ROWS_SPLIT split4h_u
 #endif
+__device__ int g_rows_wstage = 1;      // 0 (PD_H2_ROWS_WSTAGE=0, set by the launcher through hipMemcpyToSymbol): the weight fragments straight from memory (A/B)
 template <bool AM, int MODE = 0>   // AM: both operands come with row maxima (scaled rows); false: neither (unit scales)
 __global__ __launch_bounds__(512)
 void gemm_rows_f16x2_k256(const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ bias, float *__restrict__ C,
@@ -509,13 +510,50 @@ void gemm_rows_f16x2_k256(const float *__restrict__ A, const float *__restrict__
   {
     float sbv = 1.f;
     if (AM) row_scale(b_amax[n0 + fr], sbv, ibv);
-    const float *bp = B + (int64_t)(n0 + fr) * ldb + 8 * fh;
+    if (g_rows_wstage) {
+      // The wavefront's 32 x 256 weight slab arrives in four passes of 64 k — a load instruction reads 256 contiguous bytes of each of 4 rows —
+      // and is dealt to the lanes through the still unused tile images: as MFMA fragments straight from memory an instruction touched 32 rows x
+      // 32 bytes, the pattern in which one workgroup pulls ~30 GB/s (tools/probes/stream_probe.hip) — 256 KB per workgroup, ~8 us in front of
+      // the first product of every launch.  Every pass fills fragments 4 R .. 4 R + 3 of ALL lanes (no divergence, no selects).
+      constexpr int WP = 66;                                           // floats per staged row (264 bytes: 8-byte pieces, rows 2 banks apart)
+      float *wl = reinterpret_cast<float *>(w < 4 ? lds0 : lds1) + (w & 3) * (32 * WP);    // 32 rows x 64 k per pass and wavefront: 4 x 8 448 bytes per image
+      const float *bsrc = B + (int64_t)(n0 + (lane >> 4)) * ldb + 4 * (lane & 15);
+      float *wdst = wl + (lane >> 4) * WP + 4 * (lane & 15);
+      const float *wsrc = wl + fr * WP + 8 * fh;
+      float4 wa[8], wb[8];                                             // the next pass's pieces fly while this one is dealt
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const SplitH u = split4h((PD_ABL & 64) ? make_float4(1.f, 2.f, (float)s, sbv) : *reinterpret_cast<const float4 *>(bp + 16 * s), sbv),
-                   v = split4h((PD_ABL & 64) ? make_float4(1.f, 2.f, (float)s, ibv) : *reinterpret_cast<const float4 *>(bp + 16 * s + 4), sbv);
-      bh[s] = __builtin_bit_cast(h16x8, u32x4{u.hi.x, u.hi.y, v.hi.x, v.hi.y});
-      bl[s] = __builtin_bit_cast(h16x8, u32x4{u.lo.x, u.lo.y, v.lo.x, v.lo.y});
+      for (int i = 0; i < 8; ++i) wa[i] = *reinterpret_cast<const float4 *>(bsrc + (int64_t)(4 * i) * ldb);
+#define PD_WPASS(R, CUR, NXT)                                                                                                  \
+      {                                                                                                                        \
+        if (R < 3) {                                                                                                           \
+          _Pragma("unroll") for (int i = 0; i < 8; ++i) NXT[i] = *reinterpret_cast<const float4 *>(bsrc + (int64_t)(4 * i) * ldb + 64 * (R + 1)); \
+        }                                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                        \
+          *reinterpret_cast<float2 *>(wdst + 4 * i * WP) = make_float2(CUR[i].x, CUR[i].y);                                    \
+          *reinterpret_cast<float2 *>(wdst + 4 * i * WP + 2) = make_float2(CUR[i].z, CUR[i].w);                                \
+        }                                                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       /* (a wavefront reads only what it wrote itself: no barrier) */ \
+        _Pragma("unroll") for (int sq = 0; sq < 4; ++sq) {                                                                     \
+          const float2 f0 = *reinterpret_cast<const float2 *>(wsrc + 16 * sq), f1 = *reinterpret_cast<const float2 *>(wsrc + 16 * sq + 2), \
+                       f2 = *reinterpret_cast<const float2 *>(wsrc + 16 * sq + 4), f3 = *reinterpret_cast<const float2 *>(wsrc + 16 * sq + 6); \
+          const SplitH u = split4h(make_float4(f0.x, f0.y, f1.x, f1.y), sbv), v = split4h(make_float4(f2.x, f2.y, f3.x, f3.y), sbv); \
+          bh[4 * R + sq] = __builtin_bit_cast(h16x8, u32x4{u.hi.x, u.hi.y, v.hi.x, v.hi.y});                                   \
+          bl[4 * R + sq] = __builtin_bit_cast(h16x8, u32x4{u.lo.x, u.lo.y, v.lo.x, v.lo.y});                                   \
+        }                                                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       /* the reads are done before the next pass overwrites the rows */ \
+      }
+      PD_WPASS(0, wa, wb) PD_WPASS(1, wb, wa) PD_WPASS(2, wa, wb) PD_WPASS(3, wb, wa)
+#undef PD_WPASS
+      __syncthreads();                                                 // everyone is done with its staging rows: the tile images are free
+    } else {
+      const float *bp = B + (int64_t)(n0 + fr) * ldb + 8 * fh;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const SplitH u = split4h((PD_ABL & 64) ? make_float4(1.f, 2.f, (float)s, sbv) : *reinterpret_cast<const float4 *>(bp + 16 * s), sbv),
+                     v = split4h((PD_ABL & 64) ? make_float4(1.f, 2.f, (float)s, ibv) : *reinterpret_cast<const float4 *>(bp + 16 * s + 4), sbv);
+        bh[s] = __builtin_bit_cast(h16x8, u32x4{u.hi.x, u.hi.y, v.hi.x, v.hi.y});
+        bl[s] = __builtin_bit_cast(h16x8, u32x4{u.lo.x, u.lo.y, v.lo.x, v.lo.y});
+      }
     }
   }
   const float bv = bias ? bias[n0 + fr] : 0.f;
@@ -977,6 +1015,13 @@ extern "C" int64_t pd_gemm_tn_f16x2_bits_words(int M, int N)
 static int gemm_tn_f16x2_impl(const float *A, const float *B, const float *bias, float *C, uint32_t *bits, float *colsum, const float *a_amax,
                              const float *b_amax, float *c_amax, int M, int N, int K, int lda, int ldb, int ldc, int mode, void *stream_, int flags)
 {
+  static const bool wstage_set = []() {                      // PD_H2_ROWS_WSTAGE=0: the row stream's weight fragments straight from memory (A/B)
+    const char *e = getenv("PD_H2_ROWS_WSTAGE");
+    const int v = e ? atoi(e) : 1;
+    if (v != 1) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rows_wstage), &v, sizeof(int));
+    return true;
+  }();
+  (void)wstage_set;
   if (M < 0 || N < 0 || K < 0 || mode < 0 || mode > 2) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: negative size / bad mode");
   if (M == 0 || N == 0) return PD_OK;
   if (!A || !B || !C || (mode == 2 && (!bits || !colsum))) return pd_set_error(PD_ERR_INVALID_ARG, "pd_gemm_tn_f16x2: null pointer");
