@@ -43,8 +43,9 @@ int pd_swin_ln_bwd(const void *dy, const int32_t *ymap, int y_rows, const float 
                    const float *rscale, const int32_t *zero_rows, int n_zero, float *dgamma, float *dbeta, int images, int L,
                    int C, void *dr_q, void *dr_s, int q_format, int n_rep, int64_t rep_stride, void *stream);
 
-/* Plain fp32 LayerNorm over `rows` token rows of C channels (C % 4 == 0, C <= 1536), forward and backward: the Swin backbone's per-stage
- * OUTPUT norms (reference modeling/backbone/swin.py:675-680), which stay fp32 under autocast.  mean / rstd [rows] are saved by the forward;
+/* Plain fp32 LayerNorm over `rows` token rows of C channels (C % 4 == 0, C <= 3072), forward and backward: the Swin backbone's per-stage
+ * OUTPUT norms (reference modeling/backbone/swin.py:675-680), PatchMerging's norm over 4 C channels (:339) and the patch embedding's (:565),
+ * which stay fp32 under autocast.  mean / rstd [rows] are saved by the forward;
  * the backward ACCUMULATES into dgamma / dbeta (fp32 [C], zero-filled by the caller) and overwrites dx. */
 int pd_layernorm_rows_f32_fwd(const float *x, const float *gamma, const float *beta, float eps, float *y, float *mean, float *rstd, int64_t rows,
                               int C, void *stream);

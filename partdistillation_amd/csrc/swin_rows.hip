@@ -389,7 +389,8 @@ int check_mx(const void *q, const void *sc, int fmt, const char *who)
 // Plain fp32 LayerNorm over token rows, forward and backward: the per-stage OUTPUT norms of the Swin backbone (reference
 // modeling/backbone/swin.py:675-680 `norm_layer = getattr(self, f"norm{i}"); x_out = norm_layer(x_out)`), which autocast keeps in fp32 — input
 // the stage's fp32 residual stream, output the fp32 map the pixel decoder reads.  Rounds 1-4 left them to ATen (0.97 ms per Swin-B step,
-// 1.93 ms per Swin-L step).  One wavefront per row, 16 bytes per lane and chunk, C % 4 == 0, C <= 1536 (NQ = ceil(C / 256) chunks).
+// 1.93 ms per Swin-L step).  One wavefront per row, 16 bytes per lane and chunk, C % 4 == 0, C <= 3072 (NQ = ceil(C / 256) chunks; the widths above 1536 are PatchMerging's
+// LayerNorm over 4 C channels, reference :339, and the patch embedding's norm :565 — both ATen through round 5: 0.6 ms per Swin-B step).
 template <int NQ>
 __global__ __launch_bounds__(256) void ln_rows_f32_fwd(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        float eps, float *__restrict__ y, float *__restrict__ mean, float *__restrict__ rstd,
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256) void ln_rows_f32_fwd(const float *__restrict__
 
 // dx = rstd (gh - mean_c(gh) - xhat mean_c(gh xhat)), gh = dy gamma;  dgamma += sum_rows dy xhat;  dbeta += sum_rows dy.  8 wavefronts per
 // workgroup, each walking rows; their column sums meet in LDS and leave as 2 C atomics per workgroup (few, fat workgroups: see pd_add_layernorm_bwd)
-template <int NQ> struct RowsBwdWaves { static constexpr int value = NQ >= 4 ? 4 : 8; };   // (column sums of all wavefronts in <= 48 KB of LDS)
+template <int NQ> struct RowsBwdWaves { static constexpr int value = NQ >= 12 ? 2 : (NQ >= 4 ? 4 : 8); };   // (column sums of all wavefronts in <= 64 KB of LDS)
 template <int NQ>
 __global__ __launch_bounds__(64 * RowsBwdWaves<NQ>::value) void ln_rows_f32_bwd(const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ mean,
                                                        const float *__restrict__ rstd, const float *__restrict__ gamma, float *__restrict__ dx,
@@ -572,7 +573,7 @@ extern "C" int pd_swin_ln_bwd(const void *dy, const int32_t *ymap, int y_rows, c
 extern "C" int pd_layernorm_rows_f32_fwd(const float *x, const float *gamma, const float *beta, float eps, float *y, float *mean, float *rstd,
                                          int64_t rows, int C, void *stream_)
 {
-  if (rows < 0 || C <= 0 || (C & 3) || C > 1536) return pd_set_error(PD_ERR_INVALID_ARG, "pd_layernorm_rows_f32_fwd: rows=%lld C=%d (a multiple of 4 up to 1536)", (long long)rows, C);
+  if (rows < 0 || C <= 0 || (C & 3) || C > 3072) return pd_set_error(PD_ERR_INVALID_ARG, "pd_layernorm_rows_f32_fwd: rows=%lld C=%d (a multiple of 4 up to 3072)", (long long)rows, C);
   if (rows == 0) return PD_OK;
   if (!x || !gamma || !beta || !y || !mean || !rstd || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15))
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_layernorm_rows_f32_fwd: null / misaligned pointer");
@@ -583,7 +584,9 @@ extern "C" int pd_layernorm_rows_f32_fwd(const float *x, const float *gamma, con
     case 2: hipLaunchKernelGGL(ln_rows_f32_fwd<2>, g, b, 0, st, x, gamma, beta, eps, y, mean, rstd, rows, C); break;
     case 3: hipLaunchKernelGGL(ln_rows_f32_fwd<3>, g, b, 0, st, x, gamma, beta, eps, y, mean, rstd, rows, C); break;
     case 4: hipLaunchKernelGGL(ln_rows_f32_fwd<4>, g, b, 0, st, x, gamma, beta, eps, y, mean, rstd, rows, C); break;
-    default: hipLaunchKernelGGL(ln_rows_f32_fwd<6>, g, b, 0, st, x, gamma, beta, eps, y, mean, rstd, rows, C); break;
+    case 5: case 6: hipLaunchKernelGGL(ln_rows_f32_fwd<6>, g, b, 0, st, x, gamma, beta, eps, y, mean, rstd, rows, C); break;
+    case 7: case 8: hipLaunchKernelGGL(ln_rows_f32_fwd<8>, g, b, 0, st, x, gamma, beta, eps, y, mean, rstd, rows, C); break;
+    default: hipLaunchKernelGGL(ln_rows_f32_fwd<12>, g, b, 0, st, x, gamma, beta, eps, y, mean, rstd, rows, C); break;
   }
   return pd_check_launch("pd_layernorm_rows_f32_fwd");
 }
@@ -591,20 +594,22 @@ extern "C" int pd_layernorm_rows_f32_fwd(const float *x, const float *gamma, con
 extern "C" int pd_layernorm_rows_f32_bwd(const float *dy, const float *x, const float *mean, const float *rstd, const float *gamma, float *dx,
                                          float *dgamma, float *dbeta, int64_t rows, int C, void *stream_)
 {
-  if (rows < 0 || C <= 0 || (C & 3) || C > 1536) return pd_set_error(PD_ERR_INVALID_ARG, "pd_layernorm_rows_f32_bwd: rows=%lld C=%d (a multiple of 4 up to 1536)", (long long)rows, C);
+  if (rows < 0 || C <= 0 || (C & 3) || C > 3072) return pd_set_error(PD_ERR_INVALID_ARG, "pd_layernorm_rows_f32_bwd: rows=%lld C=%d (a multiple of 4 up to 3072)", (long long)rows, C);
   if (rows == 0) return PD_OK;
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)gamma) & 15))
     return pd_set_error(PD_ERR_INVALID_ARG, "pd_layernorm_rows_f32_bwd: null / misaligned pointer");
   int64_t nb = (rows + 31) / 32;                                  // >= 4 rows per wavefront, at most 256 workgroups
   const dim3 g((unsigned)(nb < 1 ? 1 : (nb > 256 ? 256 : nb)));
-  const dim3 b(C > 768 ? 256 : 512);
+  const dim3 b(C > 2048 ? 128 : (C > 768 ? 256 : 512));
   hipStream_t st = (hipStream_t)stream_;
   switch ((C + 255) / 256) {
     case 1: hipLaunchKernelGGL(ln_rows_f32_bwd<1>, g, b, 0, st, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C); break;
     case 2: hipLaunchKernelGGL(ln_rows_f32_bwd<2>, g, b, 0, st, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C); break;
     case 3: hipLaunchKernelGGL(ln_rows_f32_bwd<3>, g, b, 0, st, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C); break;
     case 4: hipLaunchKernelGGL(ln_rows_f32_bwd<4>, g, b, 0, st, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C); break;
-    default: hipLaunchKernelGGL(ln_rows_f32_bwd<6>, g, b, 0, st, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C); break;
+    case 5: case 6: hipLaunchKernelGGL(ln_rows_f32_bwd<6>, g, b, 0, st, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C); break;
+    case 7: case 8: hipLaunchKernelGGL(ln_rows_f32_bwd<8>, g, b, 0, st, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C); break;
+    default: hipLaunchKernelGGL(ln_rows_f32_bwd<12>, g, b, 0, st, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C); break;
   }
   return pd_check_launch("pd_layernorm_rows_f32_bwd");
 }

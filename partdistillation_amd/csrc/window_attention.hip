@@ -31,7 +31,7 @@
 #include "pd_msda.h"
 #include "pd_window_attention.h"
 
-int g_pd_dbg_wattn = 0;   // tools/ only: 1 no LDS table-gradient atomics, 2 no global flush, 4 skip dK/dV phase, 8 skip dQ phase
+int g_pd_dbg_wattn = 0;   // tools/ only: 1 no table gradient at all (its own instantiation), 2 no global flush, 4 skip dK/dV phase, 8 skip dQ phase, 16 skip the table-gradient reduction
 
 namespace {
 using namespace pdmfma;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(THREADS) void wattn_bwd(const bf16_t *__restrict__ 
       if (dq_q) st_mx_piece(qfmt, dq_q + ((int64_t)b * N + q) * ld + h * D, dq_s + ((int64_t)b * N + q) * (ld / 32) + h, g, dq0, dq1);
     }
   }
-  if (ABL != 1) {
+  if (ABL != 1 && !(ablate & 16)) {
     // sum of dS over this workgroup's windows, [144 queries][144 keys] fp32, goes through the (now dead) tile space 48
     // query rows = 4 rows of the 12 x 12 grid at a time; thread i < 529 owns table entry i = (dr + 11) * 23 + (dc + 11)
     // and adds up the pairs (rq, cq) -> (rq - dr, cq - dc) it is made of: every element is read exactly once
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(THREADS) void wattn_bwd(const bf16_t *__restrict__ 
         }
       }
     }
-    if (tid < TBL) atomicAdd(dtable + tid * heads + h, tsum);
+    if (tid < TBL && !(ablate & 2)) atomicAdd(dtable + tid * heads + h, tsum);
   }
 }
 

@@ -51,7 +51,8 @@ def ln_bwd(dy, ymap, y_rows, dsup, s, stats, gamma, want_dr, rmap, r_rows, rscal
 
 
 class _RowsLayerNorm(torch.autograd.Function):
-    """fp32 LayerNorm over the last dimension on pd_layernorm_rows_f32_{fwd,bwd} (the Swin stages' output norms, reference swin.py:675-680)"""
+    """fp32 LayerNorm over the last dimension on pd_layernorm_rows_f32_{fwd,bwd} (the Swin stages' output norms, reference swin.py:675-680; the patch-merging
+    norms over 4 C channels :339 and the patch embedding's :565)"""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
@@ -81,7 +82,7 @@ class _RowsLayerNorm(torch.autograd.Function):
 
 
 def rows_layer_norm_supported(x, ln):
-    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1536 and ln.weight is not None and ln.bias is not None
+    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 3072 and ln.weight is not None and ln.bias is not None
             and ln.weight.dtype == torch.float32 and ln.bias.dtype == torch.float32 and tuple(ln.normalized_shape) == (x.shape[-1],))
 
 

@@ -25,6 +25,7 @@ from ...compat import BACKBONE_REGISTRY, ShapeSpec
 # of the stages with C >= FP8_MIN_K then run as MX-fp8 GEMMs on own kernels (include/pd_mx8.h) while autocast is on: inside the fused
 # stage (swin_core.py), or one by one through functions/fp8.py on the module-by-module path
 FP8 = {"enabled": False, "min_k": 384}
+OWN_MERGE_NORM = __import__("os").environ.get("PD_SWIN_OWN_MERGE_NORM", "1") != "0"   # patch embedding / merging LayerNorms likewise (0: ATen)
 OWN_OUT_NORM = __import__("os").environ.get("PD_SWIN_OWN_OUT_NORM", "1") != "0"   # the stages' output LayerNorms on pd_layernorm_rows_f32_* (0: ATen)
 FUSED_STAGE = True          # modeling/backbone/swin_core.py where it applies (tests switch it off to compare the two paths)
 
@@ -237,6 +238,17 @@ def window_gather_index(H, W, ws, shift, device):
     return _GATHER_CACHE[key]
 
 
+def _rows_norm(norm, x):
+    """fp32 LayerNorm of token rows on pd_layernorm_rows_f32_* where it applies (GPU, fp32 rows, width <= 3072), like the stages' output norms
+    (ATen: one forward and three backward kernels per norm, 0.6 ms per Swin-B step for the four norms of patch embedding / merging)"""
+    if OWN_MERGE_NORM and isinstance(norm, nn.LayerNorm) and x.is_cuda:
+        if x.dtype == torch.bfloat16 and torch.is_autocast_enabled():          # (autocast runs layer_norm in fp32: the same cast ATen would make)
+            x = x.float()
+        if _swin_rows.rows_layer_norm_supported(x, norm):
+            return _swin_rows.rows_layer_norm(x, norm)
+    return norm(x)
+
+
 class PatchMerging(nn.Module):
     def __init__(self, dim, norm_layer=nn.LayerNorm):
         super().__init__()
@@ -255,7 +267,7 @@ class PatchMerging(nn.Module):
         # 2 * (column parity) + (row parity).  Same values; the backward is one permuted copy too instead of four zero-fills, four
         # strided copies and three gradient sums per merge (reference swin.py:325-337)
         x = x.view(B, Hp // 2, 2, Wp // 2, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, -1, 4 * C)
-        x = self.norm(x)
+        x = _rows_norm(self.norm, x)
         from ...functions import igemm
         from . import swin_core
         if swin_core.OWN_GEMM and self.reduction.bias is None and igemm.own_linear_supported(x, self.reduction.weight):
@@ -331,7 +343,7 @@ class PatchEmbed(nn.Module):
         x = self.proj(x)
         if self.norm is not None:
             Wh, Ww = x.size(2), x.size(3)
-            x = self.norm(x.flatten(2).transpose(1, 2)).transpose(1, 2).view(-1, self.embed_dim, Wh, Ww)
+            x = _rows_norm(self.norm, x.flatten(2).transpose(1, 2)).transpose(1, 2).view(-1, self.embed_dim, Wh, Ww)
         return x
 
 

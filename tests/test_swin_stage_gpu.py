@@ -219,10 +219,10 @@ def test_recorded_stage_replays_equal_the_eager_launches(drop):
     assert not torch.equal(rec[1][0], rec[2][0])
 
 
-@pytest.mark.parametrize("rows,C", [(1000, 128), (777, 192), (513, 384), (300, 768), (260, 1024), (130, 1536), (5, 256)])
+@pytest.mark.parametrize("rows,C", [(1000, 128), (777, 192), (513, 384), (300, 768), (260, 1024), (130, 1536), (5, 256), (301, 2048), (77, 3072), (200, 1280)])
 def test_rows_layer_norm_f32_vs_torch(rows, C):
     """pd_layernorm_rows_f32_fwd / _bwd (the Swin stages' output norms, reference swin.py:675-680) against torch.nn.functional.layer_norm in
-    float64: every stage width of Swin-T / B / L, outputs and all three gradients."""
+    float64: every stage width of Swin-T / B / L and the 4 C widths of their patch-merging norms (:339), outputs and all three gradients."""
     from partdistillation_amd.functions import swin_rows
     g = torch.Generator(device="cuda").manual_seed(rows + C)
     x = (torch.randn(2, rows, C, device="cuda", generator=g) * 3 + 0.5).requires_grad_()

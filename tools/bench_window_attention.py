@@ -28,7 +28,7 @@ for name, stages in (("config 3 Swin-B 1024^2 bs2", [(264, 4), (132, 8), (72, 16
             tf = t(lambda: wa.fwd_raw(qkv, table, reg, 32 ** -0.5, nW))
             tb = t(lambda: wa.bwd_raw(qkv, table, reg, out, go, lse, 32 ** -0.5, nW))
             abl = []
-            for a in (1, 4, 8, 12, 13):
+            for a in (1, 2, 16, 4, 8, 12, 14, 28, 13):
                 lib.load().pd_debug_set(b"wattn_ablate", a)
                 abl.append("%d:%.0f" % (a, t(lambda: wa.bwd_raw(qkv, table, reg, out, go, lse, 32 ** -0.5, nW))))
             lib.load().pd_debug_set(b"wattn_ablate", 0)
