@@ -1,8 +1,9 @@
 // Swin (shifted-)window attention for gfx950: 12 x 12 windows (144 tokens), head_dim 32, bf16 on
 // v_mfma_f32_16x16x16_bf16_1k, fp32 softmax.  C-ABI and the math it replaces: include/pd_window_attention.h.
 //
-// One WORKGROUP of 9 wavefronts owns one (window, head) at a time: the 144 x 32 q / k / v (/ dO) tiles are staged once in
-// LDS (row-major, pitch 36) and wave w owns the w-th 16-row tile — 16 queries in the forward and in the dQ phase of the
+// One WORKGROUP of 9 wavefronts owns one (window, head) at a time: the 144 x 32 k / v (/ q / dO / O) tiles land in LDS once
+// (row-major, written by global_load_lds, the next window's while this one is computed: see "tiles come global -> LDS" below) and wave w
+// owns the w-th 16-row tile — 16 queries in the forward and in the dQ phase of the
 // backward, 16 keys in its dK / dV phase — so every accumulator is complete inside one wave (no cross-wave reduction) and
 // per-wave register state stays small enough for ~5 waves per SIMD (the first version ran one wave per (window, head)
 // with ~400 VGPRs: one wave per SIMD, every MFMA / LDS / exp latency exposed, 10x slower).  The workgroup walks `chunk`
@@ -16,9 +17,9 @@
 // softmax probabilities feed the next MFMA straight from registers:
 //   forward, dQ phase   S^T = K.Q^T -> lane: query c, keys 4g+e  -> P / dS are the y-operands of O^T = Vt.P, dQ^T = Kt.dS
 //   dK / dV phase       S   = Q.K^T -> lane: key c, queries 4g+e -> P / dS are the y-operands of dV^T = dOt.P, dK^T = Qt.dS
-// The x-operands with a "t" need 4 consecutive ROWS of a row-major tile per lane; tr16() gets them with one more MFMA
-// against the identity (acc = X . I^T leaves X[4g+e][c] in the lane = X^T's operand layout; exact, the values are bf16),
-// except Vt in the forward, which is staged transposed once.
+// The x-operands with a "t" need 4 consecutive ROWS of a row-major tile per lane: they come from the transposing LDS read ds_read_b64_tr_b16
+// (below; through round 5 the backward spent an MFMA against the identity on each and the forward staged V transposed through registers,
+// eight 2-byte LDS writes per thread).
 //
 // Relative-position bias: 4 consecutive tokens starting at a multiple of 4 lie in one row of the 12 x 12 window, so with
 // A(t) = t + 11*(t/12) the 4 table indices a lane needs, A(q) - A(key) + 264, are consecutive: one address, 4 LDS reads.
@@ -31,15 +32,13 @@
 #include "pd_msda.h"
 #include "pd_window_attention.h"
 
-int g_pd_dbg_wattn = 0;   // tools/ only: 1 no table gradient at all (its own instantiation), 2 no global flush, 4 skip dK/dV phase, 8 skip dQ phase, 16 skip the table-gradient reduction
+int g_pd_dbg_wattn = 0;   // tools/ only: 1 no table gradient at all (its own instantiation), 2 no global flush, 4 skip dK/dV phase, 8 skip dQ phase, 16 skip the table-gradient reduction; forward: 32 loads only, 64 no table staging
 
 namespace {
 using namespace pdmfma;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int N = 144, D = 32, NT = 9, TBL = 529, THREADS = 64 * NT;
-constexpr int RP = 36;                       // pitch (elements) of the row-major [144][32] LDS tiles
-constexpr int TP = 148;                      // pitch of the transposed [32][144] V tile of the forward
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float MASKED = -100.0f * LOG2E;    // the reference's additive -100 in base-2 units
 
@@ -72,87 +71,97 @@ __device__ __forceinline__ void st_mx_piece(int fmt, uint8_t *q, uint8_t *s, int
   if (fmt == PD_MX8_E4M3) st_mx_piece<PD_MX8_E4M3>(q, s, g, a, b);
   else st_mx_piece<PD_MX8_E5M2>(q, s, g, a, b);
 }
-__device__ __forceinline__ bf16x4 tr16(bf16x4 x, bf16x4 ident)                                // X[rows][16] -> X^T operand
+// ---- tiles come global -> LDS DIRECTLY (global_load_lds_dwordx4: no staging registers, no wait until the data is needed), the next
+// window's while this one is computed.  A [144][32] bf16 tile is 144 rows of 64 bytes, unpadded — the instruction writes lane i's 16
+// bytes at base + 16 i — with the four 16-byte chunks of row r stored at slot chunk ^ swz(r), swz(r) = bit 3 of r | bit 2 of r << 1: the 8-byte operand
+// reads of 16 consecutive rows (rows r, r + 4, r + 8, r + 12 share a 16-bank window: four different slots) and the transposing reads below
+// (rows r, r + 4 of an 8-row group: slot pairs {0, 1} ^ swz differ) are both free of bank conflicts in the 64-bank model of the guide (the
+// padded pitch-36 layout of the forward cannot be written by the instruction).  The transposed operands (4 consecutive ROWS of one column per
+// lane) come from ds_read_b64_tr_b16 — lane (c, g) points at row 4 g + c / 4, elements 4 (c % 4) .. +3 and receives column c of rows 4 g .. 4 g + 3
+// (mapping: tools/probes/tr_read_probe.hip) — where rounds 3-5 spent an MFMA against the identity + a repack on each (6 of 20 MFMAs per tile pair).  Round 6 measured the register-staged version: 21 of 91 us per launch at Swin-B's third stage were the exposed load + two
+// barriers of each window (tools/bench_window_attention.py, ablation 13).
+typedef __attribute__((address_space(3))) void *lds_ptr;
+typedef __attribute__((address_space(1))) const void *glb_ptr;
+constexpr int TILE_B = N * 64;                                   // bytes of one tile
+constexpr int L_DELTA = 2176, L_LSE = 2752, L_REG = 7360, L_OT = 12288, L_TILES = L_OT + TILE_B, BWD_LDS = L_TILES + 2 * 4 * TILE_B;
+constexpr int LSE_B = 9 * 64, REG_B = 9 * 256;                   // per buffer: 64 floats / 256 bytes per 16-row block (its first 16 entries used)
+__device__ __forceinline__ bf16x4 rd8(const unsigned char *p) { return *reinterpret_cast<const bf16x4 *>(p); }
+__device__ __forceinline__ bf16x4 rdtr(const unsigned char *p)
 {
-  f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  mma16(a, x, ident);
-  return pack4(a[0], a[1], a[2], a[3]);
+  typedef __attribute__((address_space(3))) bf16x4 *lp;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)p);
 }
-__device__ __forceinline__ bf16x4 identity_operand(int c, int g)
-{
-  bf16x4 r;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) r[m] = (4 * g + m == c) ? (short)0x3F80 : (short)0;
-  return r;
-}
-
-// [144 rows] x 32 columns at `src` (row pitch ld) -> dst[row][col] (pitch RP); one 16-byte chunk per thread
-__device__ __forceinline__ void stage_rows(const bf16_t *__restrict__ src, int64_t ld, bf16_t *dst, int tid)
-{
-  const int row = tid >> 2, ch = tid & 3;
-  const uint4 v = *reinterpret_cast<const uint4 *>(src + row * ld + ch * 8);
-  uint2 *d = reinterpret_cast<uint2 *>(dst + row * RP + ch * 8);
-  d[0] = uint2{v.x, v.y};
-  d[1] = uint2{v.z, v.w};
-}
-// same source -> dst[col][row] (pitch TP)
-__device__ __forceinline__ void stage_transposed(const bf16_t *__restrict__ src, int64_t ld, bf16_t *dst, int tid)
-{
-  const int row = tid >> 2, ch = tid & 3;
-  const uint4 v = *reinterpret_cast<const uint4 *>(src + row * ld + ch * 8);
-  bf16_t *d = dst + (ch * 8) * TP + row;
-  d[0 * TP] = (bf16_t)(v.x & 0xffff); d[1 * TP] = (bf16_t)(v.x >> 16);
-  d[2 * TP] = (bf16_t)(v.y & 0xffff); d[3 * TP] = (bf16_t)(v.y >> 16);
-  d[4 * TP] = (bf16_t)(v.z & 0xffff); d[5 * TP] = (bf16_t)(v.z >> 16);
-  d[6 * TP] = (bf16_t)(v.w & 0xffff); d[7 * TP] = (bf16_t)(v.w >> 16);
-}
+__device__ __forceinline__ int swz(int row) { return ((row >> 3) & 1) | (((row >> 2) & 1) << 1); }
+// byte offset inside a 16-row block of the 8-byte piece p (elements 4 p .. 4 p + 3) of row `row` (0..15)
+__device__ __forceinline__ int piece_at(int row, int p) { return row * 64 + ((((p >> 1) ^ swz(row)) & 3) << 4) + ((p & 1) << 3); }
 
 template <bool MASK>
 __global__ __launch_bounds__(THREADS) void wattn_fwd(const bf16_t *__restrict__ qkv, const float *__restrict__ table,
                                                      const uint8_t *__restrict__ region, const uint8_t *__restrict__ flags,
                                                      bf16_t *__restrict__ out, float *__restrict__ lse, int B_, int nW,
-                                                     int heads, float c1, int chunk, uint8_t *__restrict__ out_q, uint8_t *__restrict__ out_s, int qfmt)
+                                                     int heads, float c1, int chunk, uint8_t *__restrict__ out_q, uint8_t *__restrict__ out_s, int qfmt, int ablate)
 {
   __shared__ float tbl[TBL + 3];
-  __shared__ __attribute__((aligned(16))) bf16_t ks[N * RP];
-  __shared__ __attribute__((aligned(16))) bf16_t vt[D * TP];
-  const int tid = threadIdx.x, lane = tid & 63, qt = tid >> 6, c = lane & 15, g = lane >> 4, h = blockIdx.y;
+  __shared__ __attribute__((aligned(1024))) unsigned char kv[2 * 2 * TILE_B];        // [buffer][K, V] tiles, chunk-swizzled rows of 64 bytes
+  __shared__ __attribute__((aligned(16))) unsigned char reg_all[2 * REG_B];
+  const int tid = threadIdx.x, lane = tid & 63, qt = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, g = lane >> 4, h = blockIdx.y;
   const int C = heads * D;
   const int64_t ld = 3 * C;
-  for (int i = tid; i < TBL; i += THREADS) tbl[i] = table[i * heads + h] * LOG2E;
+  auto issue = [&](int b, int buf) {                                      // K and V of window b (+ its region labels): this lane's 16 bytes of each
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+    const int lrow = 16 * qt + (lo >> 2), lch = (lo & 3) ^ swz(lo >> 2), l3 = lo < 3 ? lo : 3;
+    const bf16_t *base = qkv + (int64_t)b * N * ld + h * D + lrow * (int)ld + lch * 8;
+    unsigned char *t = kv + buf * 2 * TILE_B + qt * 1024;
+    __builtin_amdgcn_global_load_lds((glb_ptr)(base + C), (lds_ptr)t, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(base + 2 * C), (lds_ptr)(t + TILE_B), 16, 0, 0);
+    if (MASK) __builtin_amdgcn_global_load_lds((glb_ptr)(region + (int64_t)(b % nW) * N + 16 * qt + 4 * l3), (lds_ptr)(reg_all + buf * REG_B + qt * 256), 4, 0, 0);
+  };
+  const int off0 = piece_at(c, g), off1 = piece_at(c, 4 + g), toff0 = piece_at(4 * g + (c >> 2), c & 3), toff1 = piece_at(4 * g + (c >> 2), 4 + (c & 3));
+  const int q = 16 * qt + c;
+  const int b0 = blockIdx.x * chunk, n_units = min(chunk, B_ - b0);
+  // this wave's query rows as MFMA operands come straight from memory, one window ahead like the tiles (loads issued BEFORE the tile loads of
+  // the same window: vmcnt counts in order, so nothing in the compute part ever waits behind a tile load)
+  bf16x4 qn0 = {0, 0, 0, 0}, qn1 = qn0;
+  if (n_units > 0) {
+    const bf16_t *qb = qkv + (int64_t)b0 * N * ld + h * D + q * ld;
+    qn0 = *reinterpret_cast<const bf16x4 *>(qb + 4 * g); qn1 = *reinterpret_cast<const bf16x4 *>(qb + 16 + 4 * g);
+    issue(b0, 0);
+  }
+  unsigned long long mbits = 0;
+  if (MASK) mbits = __ballot(lane < n_units && flags[(b0 + (lane < n_units ? lane : 0)) % nW] != 0);
+  if (!(ablate & 64)) for (int i = tid; i < TBL; i += THREADS) tbl[i] = table[i * heads + h] * LOG2E;
 
-  for (int u = 0; u < chunk; ++u) {
-    const int b = blockIdx.x * chunk + u;
-    if (b >= B_) break;
-    const bf16_t *base = qkv + (int64_t)b * N * ld + h * D;
-    __syncthreads();
-    stage_rows(base + C, ld, ks, tid);
-    stage_transposed(base + 2 * C, ld, vt, tid);
-    const int q = 16 * qt + c;
-    const bf16x4 q0 = *reinterpret_cast<const bf16x4 *>(base + q * ld + 4 * g);
-    const bf16x4 q1 = *reinterpret_cast<const bf16x4 *>(base + q * ld + 16 + 4 * g);
-    const int w = b % nW;
-    const bool masked = MASK && flags[w] != 0;
-    const uint8_t *r = MASK ? region + w * N : nullptr;
-    const unsigned rq = masked ? r[q] : 0u;
-    __syncthreads();
+  for (int u = 0; u < n_units; ++u) {
+    const int b = b0 + u, buf = u & 1;
+    const unsigned char *ks = kv + buf * 2 * TILE_B, *vs = ks + TILE_B, *r = reg_all + buf * REG_B;
+    __syncthreads();                                                      // window u is in LDS (and q in registers); window u - 1 is done with
+    const bf16x4 q0 = qn0, q1 = qn1;
+    if (u + 1 < n_units) {
+      const bf16_t *qb = qkv + (int64_t)(b + 1) * N * ld + h * D + q * ld;
+      qn0 = *reinterpret_cast<const bf16x4 *>(qb + 4 * g); qn1 = *reinterpret_cast<const bf16x4 *>(qb + 16 + 4 * g);
+      issue(b + 1, buf ^ 1);
+    }
+    if (ablate & 32) continue;
+    const bool masked = MASK && ((mbits >> u) & 1);
+    const unsigned rq = masked ? r[qt * 256 + c] : 0u;
     f32x4 s[NT];
-    const int aq = rel_a(q) + 264 - 3;
+    int aq = rel_a(q) + 264 - 3, gt = g;
+    asm volatile("" : "+v"(aq), "+v"(gt));
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
       s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      mma16(s[kt], lds4(ks + (16 * kt + c) * RP + 4 * g), q0);            // S^T[key = 4g+e][q = c]
-      mma16(s[kt], lds4(ks + (16 * kt + c) * RP + 16 + 4 * g), q1);
+      mma16(s[kt], rd8(ks + kt * 1024 + off0), q0);                       // S^T[key = 4g+e][q = c]
+      mma16(s[kt], rd8(ks + kt * 1024 + off1), q1);
     }
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
-      const int key0 = 16 * kt + 4 * g;
-      const float *tb = tbl + (aq - rel_a(key0));                         // index for key0+e is tb[3 - e]
+      const float *tb = tbl + (aq - rel_a(16 * kt + 4 * gt));             // index for key0+e is tb[3 - e]
       s[kt][0] = fmaf(s[kt][0], c1, tb[3]); s[kt][1] = fmaf(s[kt][1], c1, tb[2]);
       s[kt][2] = fmaf(s[kt][2], c1, tb[1]); s[kt][3] = fmaf(s[kt][3], c1, tb[0]);
       if (masked) {
-        const unsigned rk = *reinterpret_cast<const unsigned *>(r + key0);
+        const unsigned rk = *reinterpret_cast<const unsigned *>(r + kt * 256 + 4 * g);
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (((rk >> (8 * e)) & 255u) != rq) s[kt][e] += MASKED;
       }
@@ -167,8 +176,8 @@ __global__ __launch_bounds__(THREADS) void wattn_fwd(const bf16_t *__restrict__ 
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s[kt][e] = __builtin_amdgcn_exp2f(s[kt][e] - m); sum += s[kt][e]; }
       const bf16x4 p = pack4(s[kt][0], s[kt][1], s[kt][2], s[kt][3]);
-      mma16(o0, lds4(vt + c * TP + 16 * kt + 4 * g), p);                  // O^T[d = 4g+e][q = c]
-      mma16(o1, lds4(vt + (16 + c) * TP + 16 * kt + 4 * g), p);
+      mma16(o0, rdtr(vs + kt * 1024 + toff0), p);                         // O^T[d = 4g+e][q = c]: V^T read transposed out of the row-major tile
+      mma16(o1, rdtr(vs + kt * 1024 + toff1), p);
     }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
@@ -190,15 +199,13 @@ __global__ __launch_bounds__(THREADS) void wattn_bwd(const bf16_t *__restrict__ 
                                                      float *__restrict__ dtable, int B_, int nW, int heads, float scale,
                                                      float c1, int chunk, int ablate, uint8_t *__restrict__ dq_q, uint8_t *__restrict__ dq_s, int qfmt)
 {
-  __shared__ float tbl[TBL + 3];
-  __shared__ __attribute__((aligned(16))) bf16_t tiles[4 * N * RP];
-  __shared__ __attribute__((aligned(16))) float lse_s[N];
-  __shared__ __attribute__((aligned(16))) float delta_s[N];
-  bf16_t *qs = tiles, *ks = tiles + N * RP, *vs = tiles + 2 * N * RP, *dos = tiles + 3 * N * RP;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4, h = blockIdx.y;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  float *tbl = reinterpret_cast<float *>(lds);
+  float *delta_s = reinterpret_cast<float *>(lds + L_DELTA), *lse_all = reinterpret_cast<float *>(lds + L_LSE);
+  unsigned char *reg_all = lds + L_REG, *otile = lds + L_OT, *tiles = lds + L_TILES;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, g = lane >> 4, h = blockIdx.y;   // (wv in a scalar register: LDS bases of the wave's blocks stay out of the vector registers)
   const int C = heads * D;
   const int64_t ld = 3 * C;
-  const bf16x4 ident = identity_operand(c, g);
   for (int i = tid; i < TBL; i += THREADS) tbl[i] = table[i * heads + h] * LOG2E;
   // table gradient: a lane meets the same 36 (query, key) pairs in every window, so it sums dS over the `chunk` windows in
   // registers; the pairs -> table-entry reduction happens once per workgroup, without atomics (below).  ds_add_f32 costs
@@ -207,58 +214,82 @@ __global__ __launch_bounds__(THREADS) void wattn_bwd(const bf16_t *__restrict__ 
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt) dacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int u = 0; u < chunk; ++u) {
-    const int b = blockIdx.x * chunk + u;
-    if (b >= B_) break;
-    const bf16_t *base = qkv + (int64_t)b * N * ld + h * D;
-    const bf16_t *dob = dout + (int64_t)b * N * C + h * D;
+  // this lane's piece of every tile: LDS slot lane & 3 of row 16 wv + lane / 4 holds chunk slot ^ swz(row) of that row.  (The offsets
+  // are recomputed from an opaque lane id at every issue: kept across the phases they were the three spilled 64-bit values of the kernel.)
+  auto issue = [&](int b, int buf) {
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+    const int lrow = 16 * wv + (lo >> 2), lch = (lo & 3) ^ swz(lo >> 2);
+    const int go_qkv = lrow * (int)ld + lch * 8, go_o = lrow * C + lch * 8, l15 = lo < 15 ? lo : 15, l3 = lo < 3 ? lo : 3;
+    const bf16_t *base = qkv + (int64_t)b * N * ld + h * D + go_qkv;
+    const bf16_t *dob = dout + (int64_t)b * N * C + h * D + go_o, *ob = out + (int64_t)b * N * C + h * D + go_o;
+    unsigned char *t = tiles + buf * 4 * TILE_B + wv * 1024;
+    __builtin_amdgcn_global_load_lds((glb_ptr)base, (lds_ptr)t, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(base + C), (lds_ptr)(t + TILE_B), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(base + 2 * C), (lds_ptr)(t + 2 * TILE_B), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)dob, (lds_ptr)(t + 3 * TILE_B), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)ob, (lds_ptr)(otile + wv * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(lse + ((int64_t)b * heads + h) * N + 16 * wv + l15), (lds_ptr)(lse_all + buf * LSE_B + wv * 64), 4, 0, 0);
+    if (MASK) __builtin_amdgcn_global_load_lds((glb_ptr)(region + (int64_t)(b % nW) * N + 16 * wv + 4 * l3), (lds_ptr)(reg_all + buf * REG_B + wv * 256), 4, 0, 0);
+  };
+  // operand reads: row 16 kt + c, pieces g and 4 + g;  transposed operand reads: this lane's address is row 16 kt + 4 g + c / 4, pieces c % 4 and 4 + c % 4
+  const int off0 = piece_at(c, g), off1 = piece_at(c, 4 + g), toff0 = piece_at(4 * g + (c >> 2), c & 3), toff1 = piece_at(4 * g + (c >> 2), 4 + (c & 3));
+
+  const int b0 = blockIdx.x * chunk, n_units = min(chunk, B_ - b0);
+  if (n_units > 0) issue(b0, 0);
+  // which of this workgroup's windows carry a mask (chunk <= 8): one vote in the prologue instead of a dependent global load per window
+  unsigned long long mbits = 0;
+  if (MASK) mbits = __ballot(lane < n_units && flags[(b0 + (lane < n_units ? lane : 0)) % nW] != 0);
+  for (int u = 0; u < n_units; ++u) {
+    const int b = b0 + u, buf = u & 1;
+    const unsigned char *tb = tiles + buf * 4 * TILE_B;
+    const float *lse_s = lse_all + buf * LSE_B;
+    const unsigned char *r = reg_all + buf * REG_B;
     bf16_t *dbase = dqkv + (int64_t)b * N * ld + h * D;
-    __syncthreads();
-    stage_rows(base, ld, qs, tid);
-    stage_rows(base + C, ld, ks, tid);
-    stage_rows(base + 2 * C, ld, vs, tid);
-    stage_rows(dob, C, dos, tid);
-    {                                                                     // delta = rowsum(dO * O): 4 threads per row
-      const int row = tid >> 2, ch = tid & 3;
-      const uint4 a = *reinterpret_cast<const uint4 *>(dob + (int64_t)row * C + ch * 8);
-      const uint4 o = *reinterpret_cast<const uint4 *>(out + ((int64_t)b * N + row) * C + h * D + ch * 8);
+    __syncthreads();                                                      // (waits for this wavefront's loads, then for everyone's): window u is in LDS; window u - 1 is done with.
+                                                                          // (Its vmcnt(0) also waits for the dQ stores just issued: holding them back until after the barriers measured no gain.)
+    {                                                                     // delta = rowsum(dO * O): 4 threads per row, the same slot of both tiles
+      const uint4 a = *reinterpret_cast<const uint4 *>(tb + 3 * TILE_B + tid * 16), o = *reinterpret_cast<const uint4 *>(otile + tid * 16);
       float acc = bf_lo(a.x) * bf_lo(o.x) + bf_hi(a.x) * bf_hi(o.x) + bf_lo(a.y) * bf_lo(o.y) + bf_hi(a.y) * bf_hi(o.y)
                 + bf_lo(a.z) * bf_lo(o.z) + bf_hi(a.z) * bf_hi(o.z) + bf_lo(a.w) * bf_lo(o.w) + bf_hi(a.w) * bf_hi(o.w);
       acc += __shfl_xor(acc, 1);
       acc += __shfl_xor(acc, 2);
-      if (ch == 0) { delta_s[row] = acc; lse_s[row] = lse[((int64_t)b * heads + h) * N + row]; }
+      if ((tid & 3) == 0) delta_s[tid >> 2] = acc;
     }
-    const int w = b % nW;
-    const bool masked = MASK && flags[w] != 0;
-    const uint8_t *r = MASK ? region + w * N : nullptr;
+    const bool masked = MASK && ((mbits >> u) & 1);
     __syncthreads();
+    if (u + 1 < n_units) issue(b + 1, buf ^ 1);                           // lands while this window is computed (the O tile is free again after delta)
+    const unsigned char *qs = tb, *ks = tb + TILE_B, *vs = tb + 2 * TILE_B, *dos = tb + 3 * TILE_B;
 
     if (!(ablate & 4)) {                                                  // ---- phase 1: this wave's 16 KEYS -> dK, dV
       const int key = 16 * wv + c;
-      const bf16x4 k0 = lds4(ks + key * RP + 4 * g), k1 = lds4(ks + key * RP + 16 + 4 * g);
-      const bf16x4 v0 = lds4(vs + key * RP + 4 * g), v1 = lds4(vs + key * RP + 16 + 4 * g);
+      const bf16x4 k0 = rd8(ks + wv * 1024 + off0), k1 = rd8(ks + wv * 1024 + off1);
+      const bf16x4 v0 = rd8(vs + wv * 1024 + off0), v1 = rd8(vs + wv * 1024 + off1);
       f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = dk0, dv0 = dk0, dv1 = dk0;
-      const int ak = rel_a(key) - 264;
-      const unsigned rk = masked ? r[key] : 0u;
+      // (lane constants the nine table addresses derive from, made opaque per unit: hoisted out of the unit loop they cost ~20 registers
+      // the kernel does not have — 24 spilled dwords reloaded inside the phases, 10 us per launch at Swin-B's third stage)
+      int ak = rel_a(key) - 264, gt = g;
+      asm volatile("" : "+v"(ak), "+v"(gt));
+      const unsigned rk = masked ? r[wv * 256 + c] : 0u;
 #pragma unroll 3
       for (int qt = 0; qt < NT; ++qt) {
-        const bf16x4 qa0 = lds4(qs + (16 * qt + c) * RP + 4 * g), qa1 = lds4(qs + (16 * qt + c) * RP + 16 + 4 * g);
-        const bf16x4 da0 = lds4(dos + (16 * qt + c) * RP + 4 * g), da1 = lds4(dos + (16 * qt + c) * RP + 16 + 4 * g);
+        const bf16x4 qa0 = rd8(qs + qt * 1024 + off0), qa1 = rd8(qs + qt * 1024 + off1);
+        const bf16x4 da0 = rd8(dos + qt * 1024 + off0), da1 = rd8(dos + qt * 1024 + off1);
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = s;
         mma16(s, qa0, k0);                                                // S[q = 4g+e][key = c]
         mma16(s, qa1, k1);
         mma16(dp, da0, v0);
         mma16(dp, da1, v1);
-        const bf16x4 dot0 = tr16(da0, ident), dot1 = tr16(da1, ident), qt0 = tr16(qa0, ident), qt1 = tr16(qa1, ident);
-        const int q0 = 16 * qt + 4 * g;
-        const float *tb = tbl + (rel_a(q0) - ak);                         // table index of (q0 + e, key) is tb[e]
-        const f32x4 L = *reinterpret_cast<const f32x4 *>(lse_s + q0), Dl = *reinterpret_cast<const f32x4 *>(delta_s + q0);
+        const bf16x4 dot0 = rdtr(dos + qt * 1024 + toff0), dot1 = rdtr(dos + qt * 1024 + toff1);      // dO^T, Q^T: rows 4 g .. 4 g + 3 of column c
+        const bf16x4 qt0 = rdtr(qs + qt * 1024 + toff0), qt1 = rdtr(qs + qt * 1024 + toff1);
+        const float *tbp = tbl + (rel_a(16 * qt + 4 * gt) - ak);          // table index of (q0 + e, key) is tbp[e]
+        const f32x4 L = *reinterpret_cast<const f32x4 *>(lse_s + qt * 64 + 4 * g), Dl = *reinterpret_cast<const f32x4 *>(delta_s + 16 * qt + 4 * g);
         unsigned rq = 0;
-        if (masked) rq = *reinterpret_cast<const unsigned *>(r + q0);
+        if (masked) rq = *reinterpret_cast<const unsigned *>(r + qt * 256 + 4 * g);
         float p[4], ds[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = fmaf(s[e], c1, tb[e]);
+          float t = fmaf(s[e], c1, tbp[e]);
           if (masked && ((rq >> (8 * e)) & 255u) != rk) t += MASKED;
           p[e] = __builtin_amdgcn_exp2f(t - L[e]);
           ds[e] = p[e] * (dp[e] - Dl[e]) * scale;
@@ -282,25 +313,26 @@ __global__ __launch_bounds__(THREADS) void wattn_bwd(const bf16_t *__restrict__ 
     }
     if (!(ablate & 8)) {                                                  // ---- phase 2: this wave's 16 QUERIES -> dQ, dtable
       const int q = 16 * wv + c;
-      const bf16x4 q0 = lds4(qs + q * RP + 4 * g), q1 = lds4(qs + q * RP + 16 + 4 * g);
-      const bf16x4 d0 = lds4(dos + q * RP + 4 * g), d1 = lds4(dos + q * RP + 16 + 4 * g);
-      const float L = lse_s[q], Dl = delta_s[q];
-      const int aq = rel_a(q) + 264 - 3;
-      const unsigned rq = masked ? r[q] : 0u;
+      const bf16x4 q0 = rd8(qs + wv * 1024 + off0), q1 = rd8(qs + wv * 1024 + off1);
+      const bf16x4 d0 = rd8(dos + wv * 1024 + off0), d1 = rd8(dos + wv * 1024 + off1);
+      const float L = lse_s[wv * 64 + c], Dl = delta_s[q];
+      int aq = rel_a(q) + 264 - 3, gt = g;
+      asm volatile("" : "+v"(aq), "+v"(gt));
+      const unsigned rq = masked ? r[wv * 256 + c] : 0u;
       f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
-        const bf16x4 ka0 = lds4(ks + (16 * kt + c) * RP + 4 * g), ka1 = lds4(ks + (16 * kt + c) * RP + 16 + 4 * g);
-        const bf16x4 va0 = lds4(vs + (16 * kt + c) * RP + 4 * g), va1 = lds4(vs + (16 * kt + c) * RP + 16 + 4 * g);
+        const bf16x4 ka0 = rd8(ks + kt * 1024 + off0), ka1 = rd8(ks + kt * 1024 + off1);
+        const bf16x4 va0 = rd8(vs + kt * 1024 + off0), va1 = rd8(vs + kt * 1024 + off1);
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = s;
         mma16(s, ka0, q0);                                                // S^T[key = 4g+e][q = c]
         mma16(s, ka1, q1);
         mma16(dp, va0, d0);
         mma16(dp, va1, d1);
-        const bf16x4 kt0 = tr16(ka0, ident), kt1 = tr16(ka1, ident);
-        const int key0 = 16 * kt + 4 * g, ti = aq - rel_a(key0);          // table index of (q, key0 + e) is ti + 3 - e
+        const bf16x4 kt0 = rdtr(ks + kt * 1024 + toff0), kt1 = rdtr(ks + kt * 1024 + toff1);
+        const int ti = aq - rel_a(16 * kt + 4 * gt);                      // table index of (q, key0 + e) is ti + 3 - e
         unsigned rk = 0;
-        if (masked) rk = *reinterpret_cast<const unsigned *>(r + key0);
+        if (masked) rk = *reinterpret_cast<const unsigned *>(r + kt * 256 + 4 * g);
         float ds[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -324,7 +356,7 @@ __global__ __launch_bounds__(THREADS) void wattn_bwd(const bf16_t *__restrict__ 
     // sum of dS over this workgroup's windows, [144 queries][144 keys] fp32, goes through the (now dead) tile space 48
     // query rows = 4 rows of the 12 x 12 grid at a time; thread i < 529 owns table entry i = (dr + 11) * 23 + (dc + 11)
     // and adds up the pairs (rq, cq) -> (rq - dr, cq - dc) it is made of: every element is read exactly once
-    float *red = reinterpret_cast<float *>(tiles);
+    float *red = reinterpret_cast<float *>(tiles);                           // (no load is in flight: the last window issued none)
     const int dr = tid / 23 - 11, dc = tid % 23 - 11;
     const int c_lo = dc > 0 ? dc : 0, c_hi = dc < 0 ? 12 + dc : 12;
     float tsum = 0.f;
@@ -396,8 +428,8 @@ extern "C" int pd_window_attn_fwd_w12(const void *qkv, const float *table, const
   const int chunk = chunk_of(B_, heads, 0.2f, 2);
   const dim3 grid((B_ + chunk - 1) / chunk, heads);
   hipStream_t s = (hipStream_t)stream_;
-  if (region) hipLaunchKernelGGL(wattn_fwd<true>, grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk, (uint8_t *)out_q, (uint8_t *)out_s, q_format);
-  else hipLaunchKernelGGL(wattn_fwd<false>, grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk, (uint8_t *)out_q, (uint8_t *)out_s, q_format);
+  if (region) hipLaunchKernelGGL(wattn_fwd<true>, grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk, (uint8_t *)out_q, (uint8_t *)out_s, q_format, g_pd_dbg_wattn);
+  else hipLaunchKernelGGL(wattn_fwd<false>, grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk, (uint8_t *)out_q, (uint8_t *)out_s, q_format, g_pd_dbg_wattn);
   return pd_check_launch("pd_window_attn_fwd_w12");
 }
 
@@ -415,8 +447,15 @@ extern "C" int pd_window_attn_bwd_w12(const void *qkv, const float *table, const
   const int chunk = chunk_of(B_, heads, 1.0f, 1);
   const dim3 grid((B_ + chunk - 1) / chunk, heads);
   hipStream_t s = (hipStream_t)stream_;
-  if (g_pd_dbg_wattn & 1) hipLaunchKernelGGL((wattn_bwd<false, 1>), grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn, (uint8_t *)dqkv_q, (uint8_t *)dqkv_s, q_format);
-  else if (region) hipLaunchKernelGGL((wattn_bwd<true, 0>), grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn, (uint8_t *)dqkv_q, (uint8_t *)dqkv_s, q_format);
-  else hipLaunchKernelGGL((wattn_bwd<false, 0>), grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn, (uint8_t *)dqkv_q, (uint8_t *)dqkv_s, q_format);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)wattn_bwd<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    (void)hipFuncSetAttribute((const void *)wattn_bwd<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    (void)hipFuncSetAttribute((const void *)wattn_bwd<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    attr = true;
+  }
+  if (g_pd_dbg_wattn & 1) hipLaunchKernelGGL((wattn_bwd<false, 1>), grid, dim3(THREADS), BWD_LDS, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn, (uint8_t *)dqkv_q, (uint8_t *)dqkv_s, q_format);
+  else if (region) hipLaunchKernelGGL((wattn_bwd<true, 0>), grid, dim3(THREADS), BWD_LDS, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn, (uint8_t *)dqkv_q, (uint8_t *)dqkv_s, q_format);
+  else hipLaunchKernelGGL((wattn_bwd<false, 0>), grid, dim3(THREADS), BWD_LDS, s, (const bf16_t *)qkv, table, region, win_flags, (const bf16_t *)out, (const bf16_t *)d_out, lse, (bf16_t *)dqkv, dtable, B_, nW, heads, scale, scale * LOG2E, chunk, g_pd_dbg_wattn, (uint8_t *)dqkv_q, (uint8_t *)dqkv_s, q_format);
   return pd_check_launch("pd_window_attn_bwd_w12");
 }

@@ -395,6 +395,9 @@ class SwinTransformer(nn.Module):
         if self.ape:
             x = x + F.interpolate(self.absolute_pos_embed, size=(Wh, Ww), mode="bicubic")
         x = self.pos_drop(x.flatten(2).transpose(1, 2))
+        if FUSED_STAGE and x.is_cuda and self.training:
+            from . import swin_core
+            swin_core.draw_drop_path(self, x.shape[0], x.device)
         outs = {}
         for i, layer in enumerate(self.layers):
             x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww)

@@ -417,12 +417,33 @@ def mx8_ready(layer):
     return _own_w(*[w for blk in layer.blocks for w in (blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight)])
 
 
+def draw_drop_path(net, B, device):
+    """the DropPath scales (keep mask / keep_prob, reference :35-51) of EVERY stage of the backbone in four launches — random numbers, + keep_prob,
+    floor, / keep_prob — instead of four per stage; run_stage() picks its [depth, 2, B] slice up"""
+    rates = [float(getattr(blk.drop_path, "drop_prob", 0.0) or 0.0) for layer in net.layers for blk in layer.blocks]
+    if not net.training or not any(r > 0 for r in rates):
+        return
+    key = (tuple(rates), str(device))
+    if getattr(net, "_keep_key", None) != key:                            # built once: a host list -> device copy synchronises
+        net._keep = torch.tensor([1.0 - r for r in rates], dtype=torch.float32, device=device).view(len(rates), 1, 1)
+        net._keep_key = key
+    dp = (torch.rand((len(rates), 2, B), device=device) + net._keep).floor_().div_(net._keep)
+    o = 0
+    for layer in net.layers:
+        d = len(layer.blocks)
+        if layer.training and any(r > 0 for r in rates[o:o + d]):
+            layer._dp_drawn = dp[o:o + d]
+        o += d
+
+
 def run_stage(layer, x, H, W):
     B = x.shape[0]
     depth = len(layer.blocks)
     rates = [float(getattr(blk.drop_path, "drop_prob", 0.0) or 0.0) for blk in layer.blocks]
-    dp = None
-    if layer.training and any(r > 0 for r in rates):
+    dp = layer.__dict__.pop("_dp_drawn", None)                            # drawn for all stages at once by draw_drop_path()
+    if dp is not None and (tuple(dp.shape) != (depth, 2, B) or dp.device != x.device or not layer.training):
+        dp = None
+    if dp is None and layer.training and any(r > 0 for r in rates):
         key = (tuple(rates), str(x.device))
         if getattr(layer, "_keep_key", None) != key:                      # built once: a host list -> device copy synchronises
             layer._keep = torch.tensor([1.0 - r for r in rates], dtype=torch.float32, device=x.device).view(depth, 1, 1)
