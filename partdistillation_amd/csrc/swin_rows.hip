@@ -33,6 +33,9 @@ __device__ __forceinline__ float wave_sum(float v)
   return v;
 }
 
+// the float lane k (uniform) holds, in a scalar register
+__device__ __forceinline__ float lane_f(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+
 constexpr int WAVES = 4;   // rows per workgroup pass (forward)
 // waves per workgroup in the backward (their column sums meet in LDS before the atomics): 8, or 4 where 8 copies of the
 // two fp32 [C] sums would not fit the 64 KB of static LDS
@@ -138,26 +141,41 @@ __global__ __launch_bounds__(64 * BwdWaves<E>::value) void ln_bwd_narrow(const b
   float gm[E], ag[E], ab[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) { gm[e] = gamma[e * 64 + lane]; ag[e] = 0.f; ab[e] = 0.f; }
-  for (int64_t i = first; i < first + rows_per_wave; ++i) {
-    if (i >= R) {
-      const int64_t z = i - R;
-      if (dr && z < (int64_t)images * n_zero) {
-        bf16_t *rr = dr + ((z / n_zero) * r_rows + zero_rows[z % n_zero]) * C;
+  // row bookkeeping of all this wave's rows in one go + the next row's inputs in flight under the current one: see ln_bwd below
+  const int nrows = (int)(first >= R ? 0 : (R - first < rows_per_wave ? R - first : rows_per_wave));
+  int yrow_l = 0, rrow_l = 0;
+  float mu_l = 0.f, rs_l = 0.f, sc_l = 1.f;
+  if (lane < nrows) {
+    const int64_t il = first + lane;
+    const int img = (int)(il / L), t = (int)(il - (int64_t)img * L);
+    yrow_l = img * y_rows + (ymap ? ymap[t] : t);
+    rrow_l = img * r_rows + (rmap ? rmap[t] : t);
+    mu_l = mean[il]; rs_l = rstd[il];
+    if (rscale) sc_l = rscale[img];
+  }
+  struct RowIn { bf16_t d[E]; float sv[E], up[E]; };
+  auto load_row = [&](int k, RowIn &w) {
+    const int64_t i = first + k;
+    const bf16_t *dyr = dy + (int64_t)__builtin_amdgcn_readlane(yrow_l, k) * C;
 #pragma unroll
-        for (int e = 0; e < E; ++e) rr[e * 64 + lane] = 0;
-      }
-      continue;
+    for (int e = 0; e < E; ++e) {
+      w.d[e] = dyr[e * 64 + lane];
+      w.sv[e] = s[i * C + e * 64 + lane];
+      w.up[e] = dsup ? dsup[i * C + e * 64 + lane] : 0.f;
     }
-    const int img = (int)(i / L), t = (int)(i - (int64_t)img * L);
-    const bf16_t *dyr = dy + ((int64_t)img * y_rows + (ymap ? ymap[t] : t)) * C;
-    const float *sr = s + i * C;
-    const float mu = mean[i], rs = rstd[i];
+  };
+  RowIn cur, nxt;
+  if (nrows > 0) load_row(0, cur);
+  for (int k = 0; k < nrows; ++k) {
+    if (k + 1 < nrows) load_row(k + 1, nxt);
+    const int64_t i = first + k;
+    const float mu = lane_f(mu_l, k), rs = lane_f(rs_l, k), sc = lane_f(sc_l, k);
     float g[E], xh[E];
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const float d = bf2f(dyr[e * 64 + lane]);
-      xh[e] = (sr[e * 64 + lane] - mu) * rs;
+      const float d = bf2f(cur.d[e]);
+      xh[e] = (cur.sv[e] - mu) * rs;
       ag[e] = fmaf(d, xh[e], ag[e]);
       ab[e] += d;
       g[e] = d * gm[e];
@@ -167,16 +185,23 @@ __global__ __launch_bounds__(64 * BwdWaves<E>::value) void ln_bwd_narrow(const b
     a = wave_sum(a) * (1.f / C);
     b = wave_sum(b) * (1.f / C);
     float *dsr = ds + i * C;
-    const float sc = rscale ? rscale[img] : 1.f;
-    bf16_t *rr = dr ? dr + ((int64_t)img * r_rows + (rmap ? rmap[t] : t)) * C : nullptr;
+    bf16_t *rr = dr ? dr + (int64_t)__builtin_amdgcn_readlane(rrow_l, k) * C : nullptr;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      float d = rs * (g[e] - a - xh[e] * b);
-      if (dsup) d += dsup[i * C + e * 64 + lane];
+      const float d = rs * (g[e] - a - xh[e] * b) + cur.up[e];
       dsr[e * 64 + lane] = d;
       if (rr) rr[e * 64 + lane] = f2bf(sc * d);
     }
+    cur = nxt;
   }
+  if (dr)
+    for (int64_t i = first + nrows; i < first + rows_per_wave; ++i) {     // trailing rows of the launch zero the padded rows of dr
+      const int64_t z = i - R;
+      if (z < 0 || z >= (int64_t)images * n_zero) continue;
+      bf16_t *rr = dr + ((z / n_zero) * r_rows + zero_rows[z % n_zero]) * C;
+#pragma unroll
+      for (int e = 0; e < E; ++e) rr[e * 64 + lane] = 0;
+    }
 #pragma unroll
   for (int e = 0; e < E; ++e) { red[0][wv][e * 64 + lane] = ag[e]; red[1][wv][e * 64 + lane] = ab[e]; }
   __syncthreads();
@@ -286,35 +311,50 @@ __global__ __launch_bounds__(64 * BwdWaves<E>::value) void ln_bwd(const bf16_t *
   float4 gm[NJ], ag[NJ], ab[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) { gm[j] = (lane + 64 * j < V4) ? *reinterpret_cast<const float4 *>(gamma + 4 * (lane + 64 * j)) : zero4; ag[j] = zero4; ab[j] = zero4; }
-  for (int64_t i = first; i < first + rows_per_wave; ++i) {
-    if (i >= R) {
-      const int64_t z = i - R;
-      if (dr && z < (int64_t)images * n_zero) {
-        const int64_t row = (z / n_zero) * r_rows + zero_rows[z % n_zero];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int v4 = lane + 64 * j;
-          if (v4 < V4) {
-            *reinterpret_cast<uint2 *>(dr + row * C + 4 * v4) = make_uint2(0u, 0u);
-            if (MXF >= 0) { *reinterpret_cast<unsigned *>(dr_q + row * C + 4 * v4) = 0u; if ((v4 & 7) == 0) dr_s[row * (C / 32) + (v4 >> 3)] = 0; }
-          }
-        }
-      }
-      continue;
-    }
-    const int img = (int)(i / L), t = (int)(i - (int64_t)img * L);
-    const bf16_t *dyr = dy + ((int64_t)img * y_rows + (ymap ? ymap[t] : t)) * C;
+  // Row bookkeeping of ALL this wave's rows at once, lane k for row first + k (rows_per_wave <= 32): the row-map entries, mean / rstd and the
+  // DropPath scale are one coalesced load each instead of a dependent load in front of every row's data, and the loop below reads them
+  // with v_readlane.  Round 6: a wave walked its rows one after the other — map entry, then the row, then the reductions, then the next map
+  // entry — 19.7 us for 85 MB at Swin-B's third stage (three rows per wave), 106 us for 200 MB at the first (32 rows per wave).
+  const int nrows = (int)(first >= R ? 0 : (R - first < rows_per_wave ? R - first : rows_per_wave));
+  int yrow_l = 0, rrow_l = 0;
+  float mu_l = 0.f, rs_l = 0.f, sc_l = 1.f;
+  if (lane < nrows) {
+    const int64_t il = first + lane;
+    const int img = (int)(il / L), t = (int)(il - (int64_t)img * L);
+    yrow_l = img * y_rows + (ymap ? ymap[t] : t);
+    rrow_l = img * r_rows + (rmap ? rmap[t] : t);
+    mu_l = mean[il]; rs_l = rstd[il];
+    if (rscale) sc_l = rscale[img];
+  }
+  struct RowIn { uint2 d[NJ]; float4 sv[NJ], up[NJ]; };
+  auto load_row = [&](int k, RowIn &w) {                                 // the three input rows of row first + k: issued one row ahead of their use
+    const int64_t i = first + k;
+    const bf16_t *dyr = dy + (int64_t)__builtin_amdgcn_readlane(yrow_l, k) * C;
     const float *sr = s + i * C;
-    const float mu = mean[i], rs = rstd[i];
-    float4 g[NJ], xh[NJ], up[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int v4 = lane + 64 * j;
+      if (NJ * 64 == V4 || v4 < V4) {
+        w.d[j] = *reinterpret_cast<const uint2 *>(dyr + 4 * v4);
+        w.sv[j] = *reinterpret_cast<const float4 *>(sr + 4 * v4);
+        w.up[j] = dsup ? *reinterpret_cast<const float4 *>(dsup + i * C + 4 * v4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  RowIn cur, nxt;
+  if (nrows > 0) load_row(0, cur);
+  for (int k = 0; k < nrows; ++k) {
+    if (k + 1 < nrows) load_row(k + 1, nxt);
+    const int64_t i = first + k;
+    const float mu = lane_f(mu_l, k), rs = lane_f(rs_l, k), sc = lane_f(sc_l, k);
+    float4 g[NJ], xh[NJ];
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int v4 = lane + 64 * j;
-      const bool act = v4 < V4;
-      const float4 d = act ? unpack_bf16x4(*reinterpret_cast<const uint2 *>(dyr + 4 * v4)) : zero4;
-      const float4 sv = act ? *reinterpret_cast<const float4 *>(sr + 4 * v4) : make_float4(mu, mu, mu, mu);
-      up[j] = (act && dsup) ? *reinterpret_cast<const float4 *>(dsup + i * C + 4 * v4) : zero4;
+      const bool act = NJ * 64 == V4 || v4 < V4;
+      const float4 d = act ? unpack_bf16x4(cur.d[j]) : zero4;
+      const float4 sv = act ? cur.sv[j] : make_float4(mu, mu, mu, mu);
       xh[j] = make_float4((sv.x - mu) * rs, (sv.y - mu) * rs, (sv.z - mu) * rs, (sv.w - mu) * rs);
       ag[j].x = fmaf(d.x, xh[j].x, ag[j].x); ag[j].y = fmaf(d.y, xh[j].y, ag[j].y); ag[j].z = fmaf(d.z, xh[j].z, ag[j].z); ag[j].w = fmaf(d.w, xh[j].w, ag[j].w);
       ab[j].x += d.x; ab[j].y += d.y; ab[j].z += d.z; ab[j].w += d.w;
@@ -325,15 +365,15 @@ __global__ __launch_bounds__(64 * BwdWaves<E>::value) void ln_bwd(const bf16_t *
     a = wave_sum(a) * (1.f / C);
     b = wave_sum(b) * (1.f / C);
     float *dsr = ds + i * C;
-    const float sc = rscale ? rscale[img] : 1.f;
-    const int64_t rrow = (int64_t)img * r_rows + (rmap ? rmap[t] : t);
+    const int64_t rrow = __builtin_amdgcn_readlane(rrow_l, k);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int v4 = lane + 64 * j;
-      if (v4 < V4) {
+      if (NJ * 64 == V4 || v4 < V4) {
+        const float4 up = cur.up[j];
         float4 d;
-        d.x = rs * (g[j].x - a - xh[j].x * b) + up[j].x; d.y = rs * (g[j].y - a - xh[j].y * b) + up[j].y;
-        d.z = rs * (g[j].z - a - xh[j].z * b) + up[j].z; d.w = rs * (g[j].w - a - xh[j].w * b) + up[j].w;
+        d.x = rs * (g[j].x - a - xh[j].x * b) + up.x; d.y = rs * (g[j].y - a - xh[j].y * b) + up.y;
+        d.z = rs * (g[j].z - a - xh[j].z * b) + up.z; d.w = rs * (g[j].w - a - xh[j].w * b) + up.w;
         *reinterpret_cast<float4 *>(dsr + 4 * v4) = d;
         if (dr) {
           const uint2 o = pack_bf16x4(sc * d.x, sc * d.y, sc * d.z, sc * d.w);
@@ -342,7 +382,22 @@ __global__ __launch_bounds__(64 * BwdWaves<E>::value) void ln_bwd(const bf16_t *
         }
       }
     }
+    cur = nxt;
   }
+  if (dr)                                                                 // trailing rows of the launch zero the padded rows of dr
+    for (int64_t i = first + nrows; i < first + rows_per_wave; ++i) {
+      const int64_t z = i - R;
+      if (z < 0 || z >= (int64_t)images * n_zero) continue;
+      const int64_t row = (z / n_zero) * r_rows + zero_rows[z % n_zero];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int v4 = lane + 64 * j;
+        if (v4 < V4) {
+          *reinterpret_cast<uint2 *>(dr + row * C + 4 * v4) = make_uint2(0u, 0u);
+          if (MXF >= 0) { *reinterpret_cast<unsigned *>(dr_q + row * C + 4 * v4) = 0u; if ((v4 & 7) == 0) dr_s[row * (C / 32) + (v4 >> 3)] = 0; }
+        }
+      }
+    }
   if (abl & 1) return;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
@@ -362,7 +417,8 @@ __global__ __launch_bounds__(64 * BwdWaves<E>::value) void ln_bwd(const bf16_t *
 template <int E>
 void bwd_geometry(int64_t rows, dim3 &g, dim3 &b, int &rpw)
 {
-  // rows per wave: ~512 workgroups; every workgroup ends with 2*C atomics, so few, fat workgroups
+  // rows per wave: ~512 workgroups; every workgroup ends with 2*C atomics, so few, fat workgroups (1024 / 2048 workgroups of 16 / 8 rows per
+  // wave measured the same with the sums in 8 copies and worse without)
   constexpr int BW = BwdWaves<E>::value;
   rpw = (int)((rows + 512 * BW - 1) / (512 * BW));
   rpw = rpw < 2 ? 2 : (rpw > 32 ? 32 : rpw);
