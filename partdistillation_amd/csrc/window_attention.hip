@@ -71,6 +71,20 @@ __device__ __forceinline__ void st_mx_piece(int fmt, uint8_t *q, uint8_t *s, int
   if (fmt == PD_MX8_E4M3) st_mx_piece<PD_MX8_E4M3>(q, s, g, a, b);
   else st_mx_piece<PD_MX8_E5M2>(q, s, g, a, b);
 }
+__device__ __forceinline__ bf16x4 tr16(bf16x4 x, bf16x4 ident)                                // X[rows][16] -> X^T operand: acc = X . I^T (exact: the values are bf16)
+{
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  mma16(a, x, ident);
+  return pack4(a[0], a[1], a[2], a[3]);
+}
+__device__ __forceinline__ bf16x4 identity_operand(int c, int g)
+{
+  bf16x4 r;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) r[m] = (4 * g + m == c) ? (short)0x3F80 : (short)0;
+  return r;
+}
+
 // ---- tiles come global -> LDS DIRECTLY (global_load_lds_dwordx4: no staging registers, no wait until the data is needed), the next
 // window's while this one is computed.  A [144][32] bf16 tile is 144 rows of 64 bytes, unpadded — the instruction writes lane i's 16
 // bytes at base + 16 i — with the four 16-byte chunks of row r stored at slot chunk ^ swz(r), swz(r) = bit 3 of r | bit 2 of r << 1: the 8-byte operand
@@ -84,7 +98,7 @@ typedef __attribute__((address_space(3))) void *lds_ptr;
 typedef __attribute__((address_space(1))) const void *glb_ptr;
 constexpr int TILE_B = N * 64;                                   // bytes of one tile
 constexpr int L_DELTA = 2176, L_LSE = 2752, L_REG = 7360, L_OT = 12288, L_TILES = L_OT + TILE_B, BWD_LDS = L_TILES + 2 * 4 * TILE_B;
-constexpr int LSE_B = 9 * 64, REG_B = 9 * 256;                   // per buffer: 64 floats / 256 bytes per 16-row block (its first 16 entries used)
+constexpr int LSE_B = 9 * 64, REG_B = 9 * 256, FWD_TBL = 4 * TILE_B + 2 * REG_B, FWD_LDS = FWD_TBL + (TBL + 3) * 4;                   // per buffer: 64 floats / 256 bytes per 16-row block (its first 16 entries used)
 __device__ __forceinline__ bf16x4 rd8(const unsigned char *p) { return *reinterpret_cast<const bf16x4 *>(p); }
 __device__ __forceinline__ bf16x4 rdtr(const unsigned char *p)
 {
@@ -101,9 +115,12 @@ __global__ __launch_bounds__(THREADS) void wattn_fwd(const bf16_t *__restrict__ 
                                                      bf16_t *__restrict__ out, float *__restrict__ lse, int B_, int nW,
                                                      int heads, float c1, int chunk, uint8_t *__restrict__ out_q, uint8_t *__restrict__ out_s, int qfmt, int ablate)
 {
-  __shared__ float tbl[TBL + 3];
-  __shared__ __attribute__((aligned(1024))) unsigned char kv[2 * 2 * TILE_B];        // [buffer][K, V] tiles, chunk-swizzled rows of 64 bytes
-  __shared__ __attribute__((aligned(16))) unsigned char reg_all[2 * REG_B];
+  // (dynamic LDS like the backward: with static arrays the compiler put s_waitcnt vmcnt(0) — the loads in flight for the NEXT window — in front
+  // of the first plain read of this one)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  unsigned char *kv = lds;                                                // [buffer][K, V] tiles, chunk-swizzled rows of 64 bytes
+  unsigned char *reg_all = lds + 4 * TILE_B;                              // [buffer][REG_B]
+  float *tbl = reinterpret_cast<float *>(lds + FWD_TBL);
   const int tid = threadIdx.x, lane = tid & 63, qt = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, g = lane >> 4, h = blockIdx.y;
   const int C = heads * D;
   const int64_t ld = 3 * C;
@@ -232,9 +249,6 @@ __global__ __launch_bounds__(THREADS) void wattn_bwd(const bf16_t *__restrict__ 
     __builtin_amdgcn_global_load_lds((glb_ptr)(lse + ((int64_t)b * heads + h) * N + 16 * wv + l15), (lds_ptr)(lse_all + buf * LSE_B + wv * 64), 4, 0, 0);
     if (MASK) __builtin_amdgcn_global_load_lds((glb_ptr)(region + (int64_t)(b % nW) * N + 16 * wv + 4 * l3), (lds_ptr)(reg_all + buf * REG_B + wv * 256), 4, 0, 0);
   };
-  // operand reads: row 16 kt + c, pieces g and 4 + g;  transposed operand reads: this lane's address is row 16 kt + 4 g + c / 4, pieces c % 4 and 4 + c % 4
-  const int off0 = piece_at(c, g), off1 = piece_at(c, 4 + g), toff0 = piece_at(4 * g + (c >> 2), c & 3), toff1 = piece_at(4 * g + (c >> 2), 4 + (c & 3));
-
   const int b0 = blockIdx.x * chunk, n_units = min(chunk, B_ - b0);
   if (n_units > 0) issue(b0, 0);
   // which of this workgroup's windows carry a mask (chunk <= 8): one vote in the prologue instead of a dependent global load per window
@@ -258,8 +272,12 @@ __global__ __launch_bounds__(THREADS) void wattn_bwd(const bf16_t *__restrict__ 
     }
     const bool masked = MASK && ((mbits >> u) & 1);
     __syncthreads();
-    if (u + 1 < n_units) issue(b + 1, buf ^ 1);                           // lands while this window is computed (the O tile is free again after delta)
     const unsigned char *qs = tb, *ks = tb + TILE_B, *vs = tb + 2 * TILE_B, *dos = tb + 3 * TILE_B;
+    // operand reads: row 16 kt + c, pieces g and 4 + g;  transposed operand reads: this lane's address is row 16 kt + 4 g + c / 4, pieces c % 4 and
+    // 4 + c % 4.  (Rebuilt per window from opaque lane ids: carried across the windows they were spilled and reloaded behind the barrier.)
+    int cu = c, gu = g;
+    asm volatile("" : "+v"(cu), "+v"(gu));
+    const int off0 = piece_at(cu, gu), off1 = piece_at(cu, 4 + gu), toff0 = piece_at(4 * gu + (cu >> 2), cu & 3), toff1 = piece_at(4 * gu + (cu >> 2), 4 + (cu & 3));
 
     if (!(ablate & 4)) {                                                  // ---- phase 1: this wave's 16 KEYS -> dK, dV
       const int key = 16 * wv + c;
@@ -311,13 +329,18 @@ __global__ __launch_bounds__(THREADS) void wattn_bwd(const bf16_t *__restrict__ 
         st_mx_piece(qfmt, dq_q + row * ld + 2 * C + h * D, dq_s + row * (ld / 32) + 2 * (C / 32) + h, g, dv0, dv1);
       }
     }
+    // The next window's loads go out HERE, between the phases: the compiler puts s_waitcnt vmcnt(0) in front of the first transposing read that
+    // follows a global -> LDS load (it cannot tell the buffers apart; seen in the ISA) — issued before phase 1, the loads were waited for at its
+    // first read.  Phase 2 therefore takes K^T the old way, by an MFMA against the identity from the plain fragments, and has no such read.
+    if (u + 1 < n_units) issue(b + 1, buf ^ 1);                           // (the O tile is free again after delta; the other buffer since the last barrier)
     if (!(ablate & 8)) {                                                  // ---- phase 2: this wave's 16 QUERIES -> dQ, dtable
       const int q = 16 * wv + c;
       const bf16x4 q0 = rd8(qs + wv * 1024 + off0), q1 = rd8(qs + wv * 1024 + off1);
       const bf16x4 d0 = rd8(dos + wv * 1024 + off0), d1 = rd8(dos + wv * 1024 + off1);
       const float L = lse_s[wv * 64 + c], Dl = delta_s[q];
-      int aq = rel_a(q) + 264 - 3, gt = g;
-      asm volatile("" : "+v"(aq), "+v"(gt));
+      int aq = rel_a(q) + 264 - 3, gt = g, ct = c;
+      asm volatile("" : "+v"(aq), "+v"(gt), "+v"(ct));
+      const bf16x4 ident = identity_operand(ct, gt);                      // (rebuilt per window: two registers the phases do not have to carry)
       const unsigned rq = masked ? r[wv * 256 + c] : 0u;
       f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
 #pragma unroll
@@ -329,7 +352,7 @@ __global__ __launch_bounds__(THREADS) void wattn_bwd(const bf16_t *__restrict__ 
         mma16(s, ka1, q1);
         mma16(dp, va0, d0);
         mma16(dp, va1, d1);
-        const bf16x4 kt0 = rdtr(ks + kt * 1024 + toff0), kt1 = rdtr(ks + kt * 1024 + toff1);
+        const bf16x4 kt0 = tr16(ka0, ident), kt1 = tr16(ka1, ident);
         const int ti = aq - rel_a(16 * kt + 4 * gt);                      // table index of (q, key0 + e) is ti + 3 - e
         unsigned rk = 0;
         if (masked) rk = *reinterpret_cast<const unsigned *>(r + kt * 256 + 4 * g);
@@ -428,8 +451,8 @@ extern "C" int pd_window_attn_fwd_w12(const void *qkv, const float *table, const
   const int chunk = chunk_of(B_, heads, 0.2f, 2);
   const dim3 grid((B_ + chunk - 1) / chunk, heads);
   hipStream_t s = (hipStream_t)stream_;
-  if (region) hipLaunchKernelGGL(wattn_fwd<true>, grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk, (uint8_t *)out_q, (uint8_t *)out_s, q_format, g_pd_dbg_wattn);
-  else hipLaunchKernelGGL(wattn_fwd<false>, grid, dim3(THREADS), 0, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk, (uint8_t *)out_q, (uint8_t *)out_s, q_format, g_pd_dbg_wattn);
+  if (region) hipLaunchKernelGGL(wattn_fwd<true>, grid, dim3(THREADS), FWD_LDS, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk, (uint8_t *)out_q, (uint8_t *)out_s, q_format, g_pd_dbg_wattn);
+  else hipLaunchKernelGGL(wattn_fwd<false>, grid, dim3(THREADS), FWD_LDS, s, (const bf16_t *)qkv, table, region, win_flags, (bf16_t *)out, lse, B_, nW, heads, scale * LOG2E, chunk, (uint8_t *)out_q, (uint8_t *)out_s, q_format, g_pd_dbg_wattn);
   return pd_check_launch("pd_window_attn_fwd_w12");
 }
 

@@ -1,5 +1,5 @@
 """Host issue time of the training step by section (no device synchronisation inside the step: wall time the calling thread spends
-issuing each part), plus cProfile's top Python functions by own time.  Development tool (GPU box): python tools/host_sections.py"""
+issuing each part), plus cProfile's top Python functions by own time.  Development tool (GPU box): [PD_CONFIG=swinb] python tools/host_sections.py"""
 import cProfile, os, pstats, sys, time, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,10 +10,13 @@ from partdistillation_amd.engine.synthetic import make_batch
 from partdistillation_amd.engine.trainer import TrainStep
 S = int(os.environ.get("SIZE", "1024"))
 torch.backends.cudnn.benchmark = True
-cfg = setup_cfg(os.path.join(ROOT, "partdistillation_amd/configs/proposal_learning/r50_mask2former.yaml"), ["INPUT.IMAGE_SIZE", str(S)])
+NAME = os.environ.get("PD_CONFIG", "")             # "": BASELINE config 2 (R50 proposal learning); swinb / swinl: configs 3 / 5 (part distillation)
+YAML = "partdistillation_amd/configs/proposal_learning/r50_mask2former.yaml" if not NAME else \
+    "partdistillation_amd/configs/part_distillation/%s.yaml" % (NAME if NAME.endswith("fp8") else NAME + "_mask2former")
+cfg = setup_cfg(os.path.join(ROOT, YAML), ["INPUT.IMAGE_SIZE", str(S)])
 torch.manual_seed(0)
 step = TrainStep(cfg)
-batches = [make_batch(2, S, seed=1234 + 1000 * i, device="cuda") for i in range(4)]
+batches = [make_batch(2, S, seed=1234 + 1000 * i, device="cuda", part_distillation=bool(NAME)) for i in range(4)]
 for i in range(8):
     step(batches[i % 4])
 torch.cuda.synchronize()
