@@ -785,6 +785,8 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
   const int ty = tile / G, tx = tile % G;
   struct LvlP { int H, W, ls, wy0, wx0, wh, ww, wbase, dy5, dx5, wh5, ww5; };   // (dy5 ..: the halo-5 window inside a halo-9 one)
   __shared__ LvlP lvp[L];
+  struct QLv { int rw, w, base, first, n, pad0, pad1, pad2; };   // the tile's queries of source level j: rows of rw pixels in a map of width w, from query `base`; `first` = queries of the levels before
+  __shared__ QLv lq[L];
   __shared__ int s_used, s_fixed_ok, s_miss;
   if (threadIdx.x == 0) {
     s_miss = 0;
@@ -809,6 +811,13 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
     }
     s_used = used;
     s_fixed_ok = 1;
+    int first = 0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      const int ry0 = ty * Hs[j] / G, rx0 = tx * Ws[j] / G, rw = (tx + 1) * Ws[j] / G - rx0, n = ((ty + 1) * Hs[j] / G - ry0) * rw;
+      lq[j] = QLv{rw, Ws[j], ls[j] + ry0 * Ws[j] + rx0, first, n, 0, 0, 0};
+      first += n;
+    }
   }
   int *chmax = win + CELLS * CW;
   float *chscale = reinterpret_cast<float *>(chmax + 32);
@@ -822,20 +831,15 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
   }
   const int stride_w = M * 32;
   // the tile's queries: source level j contributes the pixels [ry0, ry1) x [rx0, rx1)
-  int rx0[L], ry0[L], rw[L], nq[L];
-#pragma unroll
-  for (int j = 0; j < L; ++j) {
-    ry0[j] = ty * Hs[j] / G; rx0[j] = tx * Ws[j] / G;
-    rw[j] = (tx + 1) * Ws[j] / G - rx0[j];
-    nq[j] = ((ty + 1) * Hs[j] / G - ry0[j]) * rw[j];
-  }
-  const int nq_all = nq[0] + nq[1] + nq[2];
+  // (level constants of a query in LDS, not in arrays: of `j == 0 ? rw[0] : j == 1 ? rw[1] : rw[2]` the compiler made rw[j] on a STACK array — the
+  // kernel sits at its limit of scalar registers as well as vector ones — i.e. a scratch load in front of every query's loads, in the pre-pass, the
+  // main loop and the epilogue; as separate scalars they became a scratch table again)
+  const int nq0 = __builtin_amdgcn_readfirstlane(lq[0].n), nq01 = nq0 + __builtin_amdgcn_readfirstlane(lq[1].n);
+  const int nq_all = nq01 + __builtin_amdgcn_readfirstlane(lq[2].n);
   auto query_of = [&](int i) {
-    int j = 0;
-    if (i >= nq[0]) { i -= nq[0]; j = 1; if (i >= nq[1]) { i -= nq[1]; j = 2; } }
-    const int rwj = j == 0 ? rw[0] : j == 1 ? rw[1] : rw[2];
-    const int y = i / rwj, x = i - y * rwj;
-    return (j == 0 ? ls[0] + (ry0[0] + y) * Ws[0] + rx0[0] : j == 1 ? ls[1] + (ry0[1] + y) * Ws[1] + rx0[1] : ls[2] + (ry0[2] + y) * Ws[2] + rx0[2]) + x;
+    const QLv t = lq[(i >= nq0 ? 1 : 0) + (i >= nq01 ? 1 : 0)];
+    const int il = i - t.first, y = il / t.rw, x = il - y * t.rw;
+    return t.base + y * t.w + x;
   };
   // ---- pre-pass: per-channel max |grad_out| over the tile's queries (8 lanes x float4 per query row) -> fixed-point scale
   {
@@ -870,10 +874,16 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
   for (int u = grp; u < nunits; u += NG) {
     const int qi = u / L, l = u - qi * L;
     const int q = query_of(qi);
-    const int64_t qm = ((int64_t)b * S + q) * M + m;
+    int mv = m;                                            // (likewise the head index: its 64-bit copy was a spilled scalar pair)
+    asm volatile("" : "+v"(mv));
+    const int64_t qm = ((int64_t)b * S + q) * M + mv;
     const LvlP lv = lvp[l];
     const int H = lv.H, W = lv.W;
-    const float4 g0 = *reinterpret_cast<const float4 *>(grad_out + qm * 32 + sub * 8), g1 = *reinterpret_cast<const float4 *>(grad_out + qm * 32 + sub * 8 + 4);
+    // (the lane's channel offset made opaque per unit: `pointer + 8 sub` and `32 m + 8 sub` as loop-invariant 64-bit lane values were spilled and
+    // reloaded at the top of every unit — the kernel has no register to carry them in)
+    int subv = sub;
+    asm volatile("" : "+v"(subv));
+    const float4 g0 = *reinterpret_cast<const float4 *>(grad_out + qm * 32 + subv * 8), g1 = *reinterpret_cast<const float4 *>(grad_out + qm * 32 + subv * 8 + 4);
     const float gs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
     const float4 q0 = *reinterpret_cast<const float4 *>(chscale + sub * 8), q1 = *reinterpret_cast<const float4 *>(chscale + sub * 8 + 4);
     const f32x2 gq2[4] = {{g0.x * q0.x, g0.y * q0.y}, {g0.z * q0.z, g0.w * q0.w}, {g1.x * q1.x, g1.y * q1.y}, {g1.z * q1.z, g1.w * q1.w}};
@@ -882,11 +892,11 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
     float4 l01, l23, a4;
     if constexpr (FUSED) {
       const int bq = b * S + q;
-      const float *row = loc + (int64_t)bq * f.ld_oa + m * LP + l * P;        // (+ the same again for the offsets: two floats per point)
+      const float *row = loc + (int64_t)bq * f.ld_oa + mv * LP + l * P;        // (+ the same again for the offsets: two floats per point)
       const float4 lg = *reinterpret_cast<const float4 *>(row + M * (LP * 2));
       const float2 st = f.stats[qm];
       a4 = make_float4(__expf(lg.x - st.x) * st.y, __expf(lg.y - st.x) * st.y, __expf(lg.z - st.x) * st.y, __expf(lg.w - st.x) * st.y);
-      const float4 *op4 = reinterpret_cast<const float4 *>(row + m * LP + l * P);
+      const float4 *op4 = reinterpret_cast<const float4 *>(row + mv * LP + l * P);
       l01 = op4[0]; l23 = op4[1];
       const float2 rf = *reinterpret_cast<const float2 *>(f.ref + ((int64_t)bq * L + l) * 2);
       const float fw = (float)W, fh = (float)H;
@@ -905,7 +915,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
     }
     const float locs[8] = {l01.x, l01.y, l01.z, l01.w, l23.x, l23.y, l23.z, l23.w};
     const float aw[4] = {a4.x, a4.y, a4.z, a4.w};
-    const int64_t voff = ((int64_t)b * S + lv.ls) * stride_w + m * 32 + sub * 8;
+    const int64_t voff = ((int64_t)b * S + lv.ls) * stride_w + mv * 32 + subv * 8;
     const float *vbase = value + voff;
     float *gbase = grad_value + voff;
     float keep_a = 0.f, keep_x = 0.f, keep_y = 0.f;
@@ -995,8 +1005,8 @@ __global__ __launch_bounds__(1024) void msda_bwd_owner4_d32(const float *__restr
       if constexpr (FUSED) {
         const int bq = b * S + q;
         float *drow = f.d_oa + (int64_t)bq * f.ld_doa;
-        drow[M * (LP * 2) + m * LP + l * P + sub] = keep_a;
-        reinterpret_cast<float2 *>(drow + m * (LP * 2) + l * (P * 2))[sub] = make_float2(keep_x, keep_y);
+        drow[M * (LP * 2) + mv * LP + l * P + sub] = keep_a;
+        reinterpret_cast<float2 *>(drow + mv * (LP * 2) + l * (P * 2))[sub] = make_float2(keep_x, keep_y);
         if (!(ABL & 64)) {
           const float part = group4_sum(keep_a);                     // this level's share of sum_j a_j g_j
           if (sub == 0) f.gdot[qm * L + l] = part;
