@@ -240,3 +240,34 @@ def test_rows_layer_norm_f32_vs_torch(rows, C):
     torch.testing.assert_close(gx.double(), rx, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(gw.double(), rw_, rtol=1e-4, atol=1e-4 * rw_.abs().max().item())
     torch.testing.assert_close(gb.double(), rb, rtol=1e-4, atol=1e-4 * rb.abs().max().item())
+
+
+def test_drop_path_scales_of_all_stages_are_drawn_at_once_and_used():
+    """swin_core.draw_drop_path (reference DropPath :35-51, one Bernoulli(keep) / keep scale per block, branch and image): every stage gets its own
+    [depth, 2, B] slice of ONE draw, the values are 0 or 1 / keep_prob of that block, and run_stage consumes the slice (a second forward without a new
+    draw falls back to drawing its own)."""
+    from partdistillation_amd.modeling.backbone import swin, swin_core
+    torch.manual_seed(3)
+    net = swin.SwinTransformer(embed_dim=64, depths=[2, 2], num_heads=[2, 4], window_size=12, drop_path_rate=0.5, out_indices=(0, 1)).cuda().train()
+    B = 3
+    swin_core.draw_drop_path(net, B, torch.device("cuda"))
+    rates = [float(getattr(blk.drop_path, "drop_prob", 0.0) or 0.0) for layer in net.layers for blk in layer.blocks]     # (the first block's is nn.Identity: rate 0)
+    o = 0
+    for layer in net.layers:
+        d = len(layer.blocks)
+        dp = layer._dp_drawn
+        assert tuple(dp.shape) == (d, 2, B) and dp.is_contiguous()
+        for k in range(d):
+            keep = 1.0 - rates[o + k]
+            v = dp[k].flatten().tolist()
+            assert all(abs(t) < 1e-12 or abs(t - 1.0 / keep) < 1e-5 for t in v), (k, v)
+        o += d
+    assert net.layers[0]._dp_drawn.data_ptr() != net.layers[1]._dp_drawn.data_ptr()
+    x = torch.randn(B, 3, 96, 96, device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = net(x)                                       # draws again (the slices above are replaced), runs the fused stages
+    assert all(not hasattr(layer, "_dp_drawn") for layer in net.layers), "run_stage consumes its slice"
+    assert all(torch.isfinite(v.float()).all() for v in out.values())
+    net.eval()
+    swin_core.draw_drop_path(net, B, torch.device("cuda"))
+    assert all(not hasattr(layer, "_dp_drawn") for layer in net.layers), "no scales in eval mode"
