@@ -52,6 +52,15 @@ int pd_layernorm_rows_f32_fwd(const float *x, const float *gamma, const float *b
 int pd_layernorm_rows_f32_bwd(const float *dy, const float *x, const float *mean, const float *rstd, const float *gamma, float *dx, float *dgamma,
                               float *dbeta, int64_t rows, int C, void *stream);
 
+/* Patch merging's gather + LayerNorm (reference modeling/backbone/swin.py:325-339, `x = cat([x0, x1, x2, x3], -1); x = self.norm(x)`): x fp32 [B, H, W, C]
+ * (H, W even) -> y bf16 [B (H/2) (W/2), 4 C], channel block 2 cp + rp of a merged row = pixel (2 i + rp, 2 j + cp) — the order of
+ * modeling/backbone/swin.py's permuted view — normalised over the 4 C channels in fp32 (mean / rstd [rows] saved).  The backward overwrites dx fp32
+ * [B, H, W, C] (every pixel belongs to one merged row) and ACCUMULATES into dgamma / dbeta (fp32 [4 C], zero-filled by the caller).  C % 4 == 0, 4 C <= 3072. */
+int pd_swin_merge_ln_fwd(const float *x, const float *gamma, const float *beta, float eps, void *y, float *mean, float *rstd, int B, int H, int W, int C,
+                         void *stream);
+int pd_swin_merge_ln_bwd(const void *dy, const float *x, const float *mean, const float *rstd, const float *gamma, float *dx, float *dgamma, float *dbeta,
+                         int B, int H, int W, int C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

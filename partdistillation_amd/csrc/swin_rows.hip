@@ -555,6 +555,126 @@ __global__ __launch_bounds__(64 * RowsBwdWaves<NQ>::value) void ln_rows_f32_bwd(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Patch merging's gather + LayerNorm (reference modeling/backbone/swin.py:325-339): the 2 x 2 neighbours (2 i + rp, 2 j + cp) of the fp32 stage output,
+// concatenated as channel block 2 cp + rp of a 4 C row, normalised in fp32 and written in bf16 — the operand of the reduction Linear.  Through round 6's
+// first half this was a permuted copy (ATen), a LayerNorm over the copy (fp32 out) and a cast: 370 MB of traffic for 100 at Swin-B's first merge; the backward
+// a cast, the LayerNorm' and the permuted copy back.  One wavefront per merged row, 16 bytes per lane and chunk like ln_rows_f32_*; every input pixel belongs
+// to exactly one merged row, so the backward's dx is a plain store.
+__device__ __forceinline__ int64_t merge_src(int64_t row, int c, int H, int W, int C)       // element offset of channel c (of 4 C) of merged row `row` in x [B, H, W, C]
+{
+  const int Wh = W >> 1, Hh = H >> 1;
+  const int64_t b = row / ((int64_t)Hh * Wh);
+  const int rem = (int)(row - b * Hh * Wh), i = rem / Wh, j = rem - i * Wh;
+  const int k = c / C, cin = c - k * C;
+  return ((b * H + 2 * i + (k & 1)) * W + 2 * j + (k >> 1)) * (int64_t)C + cin;
+}
+
+template <int NQ>
+__global__ __launch_bounds__(256) void ln_merge_fwd(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                    bf16_t *__restrict__ y, float *__restrict__ mean, float *__restrict__ rstd, int64_t rows, int H, int W, int C)
+{
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, C4 = 4 * C;
+  if (row >= rows) return;
+  float4 v[NQ];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int c = 4 * (lane + 64 * j);
+    v[j] = c < C4 ? *reinterpret_cast<const float4 *>(x + merge_src(row, c, H, W, C)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mu = sum / (float)C4;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    if (4 * (lane + 64 * j) < C4) {
+      const float a = v[j].x - mu, b = v[j].y - mu, c2 = v[j].z - mu, d = v[j].w - mu;
+      sq += (a * a + b * b) + (c2 * c2 + d * d);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rs = rsqrtf(sq / (float)C4 + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  bf16_t *yr = y + row * C4;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int c = 4 * (lane + 64 * j);
+    if (c < C4) {
+      const float4 g = *reinterpret_cast<const float4 *>(gamma + c), b = *reinterpret_cast<const float4 *>(beta + c);
+      *reinterpret_cast<uint2 *>(yr + c) = pack_bf16x4(fmaf((v[j].x - mu) * rs, g.x, b.x), fmaf((v[j].y - mu) * rs, g.y, b.y),
+                                                        fmaf((v[j].z - mu) * rs, g.z, b.z), fmaf((v[j].w - mu) * rs, g.w, b.w));
+    }
+  }
+}
+
+template <int NQ>
+__global__ __launch_bounds__(64 * RowsBwdWaves<NQ>::value) void ln_merge_bwd(const bf16_t *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ mean,
+                                                       const float *__restrict__ rstd, const float *__restrict__ gamma, float *__restrict__ dx,
+                                                       float *__restrict__ dgamma, float *__restrict__ dbeta, int64_t rows, int H, int W, int C)
+{
+  constexpr int WV = RowsBwdWaves<NQ>::value;
+  __shared__ float red[WV][2][NQ * 256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, C4 = 4 * C;
+  float4 gm[NQ], ag[NQ], ab[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int c = 4 * (lane + 64 * j);
+    gm[j] = c < C4 ? *reinterpret_cast<const float4 *>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int64_t row = (int64_t)blockIdx.x * WV + wave; row < rows; row += (int64_t)gridDim.x * WV) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 g[NQ], xh[NQ];
+    int64_t src[NQ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int c = 4 * (lane + 64 * j);
+      src[j] = 0;
+      if (c < C4) {
+        src[j] = merge_src(row, c, H, W, C);
+        g[j] = unpack_bf16x4(*reinterpret_cast<const uint2 *>(dy + row * C4 + c));
+        const float4 xv = *reinterpret_cast<const float4 *>(x + src[j]);
+        xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+      } else {
+        g[j] = xh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      ag[j].x += g[j].x * xh[j].x; ag[j].y += g[j].y * xh[j].y; ag[j].z += g[j].z * xh[j].z; ag[j].w += g[j].w * xh[j].w;
+      ab[j].x += g[j].x; ab[j].y += g[j].y; ab[j].z += g[j].z; ab[j].w += g[j].w;
+      g[j].x *= gm[j].x; g[j].y *= gm[j].y; g[j].z *= gm[j].z; g[j].w *= gm[j].w;
+      s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+      s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    const float m1 = s1 / (float)C4, m2 = s2 / (float)C4;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      if (4 * (lane + 64 * j) < C4)
+        *reinterpret_cast<float4 *>(dx + src[j]) = make_float4(rs * (g[j].x - m1 - xh[j].x * m2), rs * (g[j].y - m1 - xh[j].y * m2),
+                                                               rs * (g[j].z - m1 - xh[j].z * m2), rs * (g[j].w - m1 - xh[j].w * m2));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    *reinterpret_cast<float4 *>(&red[wave][0][4 * (lane + 64 * j)]) = ag[j];
+    *reinterpret_cast<float4 *>(&red[wave][1][4 * (lane + 64 * j)]) = ab[j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C4; i += 64 * WV) {
+    const int k = i / C4, c = i - k * C4;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < WV; ++w) sum += red[w][k][c];
+    atomicAdd((k ? dbeta : dgamma) + c, sum);
+  }
+}
+
 #define E_SWITCH(C, BODY)                                             \
   switch ((C) / 64) {                                                 \
     case 1: { constexpr int E = 1; BODY; } break;                     \
@@ -669,3 +789,54 @@ extern "C" int pd_layernorm_rows_f32_bwd(const float *dy, const float *x, const 
   }
   return pd_check_launch("pd_layernorm_rows_f32_bwd");
 }
+
+#define NQ_SWITCH(C4, BODY)                                           \
+  switch (((C4) + 255) / 256) {                                       \
+    case 1: { constexpr int NQ = 1; BODY; } break;                    \
+    case 2: { constexpr int NQ = 2; BODY; } break;                    \
+    case 3: { constexpr int NQ = 3; BODY; } break;                    \
+    case 4: { constexpr int NQ = 4; BODY; } break;                    \
+    case 5: case 6: { constexpr int NQ = 6; BODY; } break;            \
+    case 7: case 8: { constexpr int NQ = 8; BODY; } break;            \
+    default: { constexpr int NQ = 12; BODY; } break;                  \
+  }
+
+static int merge_check(int B, int H, int W, int C, const char *who)
+{
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1) || (C & 3) || 4 * C > 3072)
+    return pd_set_error(PD_ERR_INVALID_ARG, "%s: B=%d H=%d W=%d C=%d (even H and W, C a multiple of 4, 4 C <= 3072)", who, B, H, W, C);
+  return PD_OK;
+}
+
+extern "C" int pd_swin_merge_ln_fwd(const float *x, const float *gamma, const float *beta, float eps, void *y, float *mean, float *rstd, int B, int H, int W,
+                                    int C, void *stream_)
+{
+  int rc = merge_check(B, H, W, C, "pd_swin_merge_ln_fwd");
+  if (rc) return rc;
+  const int64_t rows = (int64_t)B * (H / 2) * (W / 2);
+  if (rows == 0) return PD_OK;
+  if (!x || !gamma || !beta || !y || !mean || !rstd || (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) || ((uintptr_t)y & 7))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_swin_merge_ln_fwd: null / misaligned pointer");
+  const dim3 g((unsigned)((rows + 3) / 4)), b(256);
+  hipStream_t st = (hipStream_t)stream_;
+  NQ_SWITCH(4 * C, hipLaunchKernelGGL(ln_merge_fwd<NQ>, g, b, 0, st, x, gamma, beta, eps, (bf16_t *)y, mean, rstd, rows, H, W, C));
+  return pd_check_launch("pd_swin_merge_ln_fwd");
+}
+
+extern "C" int pd_swin_merge_ln_bwd(const void *dy, const float *x, const float *mean, const float *rstd, const float *gamma, float *dx, float *dgamma,
+                                    float *dbeta, int B, int H, int W, int C, void *stream_)
+{
+  int rc = merge_check(B, H, W, C, "pd_swin_merge_ln_bwd");
+  if (rc) return rc;
+  const int64_t rows = (int64_t)B * (H / 2) * (W / 2);
+  if (rows == 0) return PD_OK;
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || (((uintptr_t)x | (uintptr_t)dx | (uintptr_t)gamma) & 15) || ((uintptr_t)dy & 7))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_swin_merge_ln_bwd: null / misaligned pointer");
+  int64_t nb = (rows + 31) / 32;                                  // >= 4 rows per wavefront, at most 256 workgroups
+  const dim3 g((unsigned)(nb < 1 ? 1 : (nb > 256 ? 256 : nb)));
+  const dim3 b(4 * C > 2048 ? 128 : (4 * C > 768 ? 256 : 512));
+  hipStream_t st = (hipStream_t)stream_;
+  NQ_SWITCH(4 * C, hipLaunchKernelGGL(ln_merge_bwd<NQ>, g, b, 0, st, (const bf16_t *)dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, H, W, C));
+  return pd_check_launch("pd_swin_merge_ln_bwd");
+}
+

@@ -88,3 +88,45 @@ def rows_layer_norm_supported(x, ln):
 
 def rows_layer_norm(x, ln):
     return _RowsLayerNorm.apply(x, ln.weight, ln.bias, ln.eps)
+
+
+class _MergeLayerNorm(torch.autograd.Function):
+    """PatchMerging's 2 x 2 gather + LayerNorm over 4 C channels on pd_swin_merge_ln_{fwd,bwd} (reference swin.py:325-339): x fp32 [B, H W, C] -> bf16
+    [B, (H/2)(W/2), 4 C], the operand of the reduction Linear; the gradient arrives in 16 bits from that Linear and leaves as fp32 dx"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, H, W):
+        B, L, C = x.shape
+        x = x if x.is_contiguous() else x.contiguous()
+        rows = B * (H // 2) * (W // 2)
+        y = torch.empty((B, rows // B, 4 * C), dtype=torch.bfloat16, device=x.device)
+        stats = torch.empty((2, rows), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().pd_swin_merge_ln_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                                                    B, H, W, C, _lib.current_stream()))
+        ctx.save_for_backward(x, stats, gamma)
+        ctx.hw = (H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, gamma = ctx.saved_tensors
+        B, L, C = x.shape
+        H, W = ctx.hw
+        g = dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16)
+        g = g if g.is_contiguous() else g.contiguous()
+        dx = torch.empty_like(x)
+        dgb = torch.zeros((2, 4 * C), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().pd_swin_merge_ln_bwd(g.data_ptr(), x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), gamma.data_ptr(), dx.data_ptr(),
+                                                    dgb[0].data_ptr(), dgb[1].data_ptr(), B, H, W, C, _lib.current_stream()))
+        return dx, dgb[0], dgb[1], None, None, None
+
+
+def merge_layer_norm_supported(x, H, W, ln):
+    C = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[1] == H * W and H % 2 == 0 and W % 2 == 0 and C % 4 == 0 and 4 * C <= 3072
+            and ln.weight is not None and ln.bias is not None and ln.weight.dtype == torch.float32 and ln.bias.dtype == torch.float32
+            and tuple(ln.normalized_shape) == (4 * C,))
+
+
+def merge_layer_norm(x, H, W, ln):
+    return _MergeLayerNorm.apply(x, ln.weight, ln.bias, ln.eps, H, W)

@@ -25,6 +25,7 @@ from ...compat import BACKBONE_REGISTRY, ShapeSpec
 # of the stages with C >= FP8_MIN_K then run as MX-fp8 GEMMs on own kernels (include/pd_mx8.h) while autocast is on: inside the fused
 # stage (swin_core.py), or one by one through functions/fp8.py on the module-by-module path
 FP8 = {"enabled": False, "min_k": 384}
+MERGE_FUSED = __import__("os").environ.get("PD_SWIN_MERGE_FUSED", "1") != "0"   # PatchMerging's gather + LayerNorm + bf16 cast as pd_swin_merge_ln_* (0: permuted copy, row LayerNorm, cast)
 OWN_MERGE_NORM = __import__("os").environ.get("PD_SWIN_OWN_MERGE_NORM", "1") != "0"   # patch embedding / merging LayerNorms likewise (0: ATen)
 OWN_OUT_NORM = __import__("os").environ.get("PD_SWIN_OWN_OUT_NORM", "1") != "0"   # the stages' output LayerNorms on pd_layernorm_rows_f32_* (0: ATen)
 FUSED_STAGE = True          # modeling/backbone/swin_core.py where it applies (tests switch it off to compare the two paths)
@@ -259,6 +260,12 @@ class PatchMerging(nn.Module):
     def forward(self, x, H, W):
         B, L, C = x.shape
         assert L == H * W, "input feature has wrong size"
+        from ...functions import igemm
+        from . import swin_core
+        if (OWN_MERGE_NORM and MERGE_FUSED and isinstance(self.norm, nn.LayerNorm) and self.reduction.bias is None and swin_core.OWN_GEMM
+                and igemm.own_linear_supported(x, self.reduction.weight) and _swin_rows.merge_layer_norm_supported(x, H, W, self.norm)):
+            # (bf16 autocast with 16-bit weights, the training configuration:) gather + LayerNorm in one kernel, bf16 out — no permuted copy, no casts
+            return igemm.OwnLinear.apply(_swin_rows.merge_layer_norm(x, H, W, self.norm), self.reduction.weight, None)
         x = x.view(B, H, W, C)
         if (H % 2 == 1) or (W % 2 == 1):
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))

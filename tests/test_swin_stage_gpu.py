@@ -271,3 +271,36 @@ def test_drop_path_scales_of_all_stages_are_drawn_at_once_and_used():
     net.eval()
     swin_core.draw_drop_path(net, B, torch.device("cuda"))
     assert all(not hasattr(layer, "_dp_drawn") for layer in net.layers), "no scales in eval mode"
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 6, 128), (1, 4, 10, 192), (3, 6, 6, 256), (2, 4, 4, 384), (1, 6, 4, 512), (2, 2, 4, 768), (1, 2, 2, 64)])
+def test_patch_merging_gather_layer_norm_vs_torch(B, H, W, C):
+    """pd_swin_merge_ln_fwd / _bwd (reference swin.py:325-339: the four strided slices concatenated, then LayerNorm over 4 C) against the
+    permuted view + torch.nn.functional.layer_norm in float64: the bf16 output within bf16 rounding, dx / dgamma / dbeta from a bf16 upstream gradient."""
+    from partdistillation_amd.functions import swin_rows
+    g = torch.Generator(device="cuda").manual_seed(H * W + C)
+    x = (torch.randn(B, H * W, C, device="cuda", generator=g) * 2 + 0.3).requires_grad_()
+    ln = torch.nn.LayerNorm(4 * C).cuda()
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.normal_(0, 0.3)
+    assert swin_rows.merge_layer_norm_supported(x, H, W, ln)
+    y = swin_rows.merge_layer_norm(x, H, W, ln)
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == (B, H * W // 4, 4 * C)
+    go = torch.randn(y.shape, device="cuda", generator=g).to(torch.bfloat16)
+    gx, gw, gb = torch.autograd.grad(y, (x, ln.weight, ln.bias), go)
+    xd, wd, bd = x.detach().double().requires_grad_(), ln.weight.detach().double().requires_grad_(), ln.bias.detach().double().requires_grad_()
+    xm = xd.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, -1, 4 * C)       # channel block 2 cp + rp (modeling/backbone/swin.py)
+    # the same rows as the reference's cat([x[0::2, 0::2], x[1::2, 0::2], x[0::2, 1::2], x[1::2, 1::2]], -1)
+    x4 = xd.view(B, H, W, C)
+    cat = torch.cat([x4[:, 0::2, 0::2], x4[:, 1::2, 0::2], x4[:, 0::2, 1::2], x4[:, 1::2, 1::2]], -1).reshape(B, -1, 4 * C)
+    assert torch.equal(xm, cat)
+    ref = torch.nn.functional.layer_norm(xm, (4 * C,), wd, bd, ln.eps)
+    rx, rw_, rb = torch.autograd.grad(ref, (xd, wd, bd), go.double())
+    _close(y.double(), ref, 6e-3, "y (bf16 rounding)")
+    torch.testing.assert_close(gx.double(), rx, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gw.double(), rw_, rtol=1e-4, atol=1e-4 * rw_.abs().max().item())
+    torch.testing.assert_close(gb.double(), rb, rtol=1e-4, atol=1e-4 * rb.abs().max().item())
+    with pytest.raises(RuntimeError, match="even H and W"):
+        from partdistillation_amd import lib
+        lib.check(lib.load().pd_swin_merge_ln_fwd(x.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), 1e-5, y.data_ptr(), y.data_ptr(), y.data_ptr(), 1, 3, 4, C,
+                                                  lib.current_stream()))
