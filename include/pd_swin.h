@@ -61,6 +61,15 @@ int pd_swin_merge_ln_fwd(const float *x, const float *gamma, const float *beta, 
 int pd_swin_merge_ln_bwd(const void *dy, const float *x, const float *mean, const float *rstd, const float *gamma, float *dx, float *dgamma, float *dbeta,
                          int B, int H, int W, int C, void *stream);
 
+/* The end of a fused Swin stage with its output norm (reference swin.py:234-236 + :675-680): s = cur + rscale[row / L] * r (cur fp32, r bf16 — the last block's MLP
+ * output —, rscale fp32 [images] or NULL = 1: DropPath), y = LayerNorm(s) * gamma + beta, both fp32 [rows, C]; mean / rstd [rows] saved.  Backward: dy = gradient of
+ * y, dsum = gradient of s from the rest of the network (or NULL); dsup = dsum + LayerNorm'(dy) (fp32: the stream's gradient), df = bf16(rscale * dsup) (the MLP
+ * output's gradient); ACCUMULATES into dgamma / dbeta (zero-filled by the caller).  C % 4 == 0, C <= 3072. */
+int pd_swin_tail_ln_fwd(const float *cur, const void *r, const float *rscale, int L, const float *gamma, const float *beta, float eps, float *s, float *y,
+                        float *mean, float *rstd, int64_t rows, int C, void *stream);
+int pd_swin_tail_ln_bwd(const float *dy, const float *dsum, const float *s, const float *mean, const float *rstd, const float *gamma, const float *rscale, int L,
+                        float *dsup, void *df, float *dgamma, float *dbeta, int64_t rows, int C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,6 +135,8 @@ const Entry kTable[] = {
   PD_E(pd_attn_bwd_d32_ld),
   PD_E(pd_match_point_logits),
   PD_E(pd_swin_merge_ln_fwd),
+  PD_E(pd_swin_tail_ln_fwd),
+  PD_E(pd_swin_tail_ln_bwd),
   PD_E(pd_swin_merge_ln_bwd),
   PD_E(pd_matcher_point_terms),
   PD_E(pd_maxpool3s2_bwd_bf16),

@@ -675,6 +675,133 @@ __global__ __launch_bounds__(64 * RowsBwdWaves<NQ>::value) void ln_merge_bwd(con
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The END of a fused Swin stage: the last block's MLP output joins the residual stream (s = cur + DropPath scale * r, the stage's fp32 output, reference
+// swin.py:234-236) and the stage's output norm (:675-680) reads it — one kernel instead of a cast, a product, a sum (ATen) and the row LayerNorm; the backward
+// forms the stream's gradient (LayerNorm' of the norm's gradient + whatever arrives for s from the next stage) and its 16-bit DropPath-scaled copy, the two
+// tensors the stage's recorded backward starts from, instead of the row LayerNorm', autograd's sum, a product and a cast.
+template <int NQ>
+__global__ __launch_bounds__(256) void ln_tail_fwd(const float *__restrict__ cur, const bf16_t *__restrict__ r, const float *__restrict__ rscale, int L,
+                                                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float *__restrict__ s,
+                                                   float *__restrict__ y, float *__restrict__ mean, float *__restrict__ rstd, int64_t rows, int C)
+{
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float sc = rscale ? rscale[row / L] : 1.f;
+  float4 v[NQ];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int c = 4 * (lane + 64 * j);
+    if (c < C) {
+      const float4 x = *reinterpret_cast<const float4 *>(cur + row * C + c);
+      const float4 rr = unpack_bf16x4(*reinterpret_cast<const uint2 *>(r + row * C + c));
+      {
+        // (the ATen chain rounds the product before the sum — out = r.float() * scale, then + cur —; __fmul_rn / __fadd_rn are plain operators to hipcc
+        // and contract into one fma: the pragma keeps the two roundings, the stage output stays bit-identical to the unfused path)
+#pragma clang fp contract(off)
+        const float px = rr.x * sc, py = rr.y * sc, pz = rr.z * sc, pw = rr.w * sc;
+        v[j] = make_float4(px + x.x, py + x.y, pz + x.z, pw + x.w);
+      }
+      *reinterpret_cast<float4 *>(s + row * C + c) = v[j];
+    } else {
+      v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mu = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    if (4 * (lane + 64 * j) < C) {
+      const float a = v[j].x - mu, b = v[j].y - mu, c2 = v[j].z - mu, d = v[j].w - mu;
+      sq += (a * a + b * b) + (c2 * c2 + d * d);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rs = rsqrtf(sq / (float)C + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int c = 4 * (lane + 64 * j);
+    if (c < C) {
+      const float4 g = *reinterpret_cast<const float4 *>(gamma + c), b = *reinterpret_cast<const float4 *>(beta + c);
+      *reinterpret_cast<float4 *>(y + row * C + c) = make_float4(fmaf((v[j].x - mu) * rs, g.x, b.x), fmaf((v[j].y - mu) * rs, g.y, b.y),
+                                                                 fmaf((v[j].z - mu) * rs, g.z, b.z), fmaf((v[j].w - mu) * rs, g.w, b.w));
+    }
+  }
+}
+
+template <int NQ>
+__global__ __launch_bounds__(64 * RowsBwdWaves<NQ>::value) void ln_tail_bwd(const float *__restrict__ dy, const float *__restrict__ dsum, const float *__restrict__ s,
+                                                       const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                                       const float *__restrict__ rscale, int L, float *__restrict__ dsup, bf16_t *__restrict__ df,
+                                                       float *__restrict__ dgamma, float *__restrict__ dbeta, int64_t rows, int C)
+{
+  constexpr int WV = RowsBwdWaves<NQ>::value;
+  __shared__ float red[WV][2][NQ * 256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float4 gm[NQ], ag[NQ], ab[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int c = 4 * (lane + 64 * j);
+    gm[j] = c < C ? *reinterpret_cast<const float4 *>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int64_t row = (int64_t)blockIdx.x * WV + wave; row < rows; row += (int64_t)gridDim.x * WV) {
+    const float mu = mean[row], rs = rstd[row], sc = rscale ? rscale[row / L] : 1.f;
+    float4 g[NQ], xh[NQ], up[NQ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int c = 4 * (lane + 64 * j);
+      if (c < C) {
+        g[j] = *reinterpret_cast<const float4 *>(dy + row * C + c);
+        const float4 xv = *reinterpret_cast<const float4 *>(s + row * C + c);
+        up[j] = dsum ? *reinterpret_cast<const float4 *>(dsum + row * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+      } else {
+        g[j] = xh[j] = up[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      ag[j].x += g[j].x * xh[j].x; ag[j].y += g[j].y * xh[j].y; ag[j].z += g[j].z * xh[j].z; ag[j].w += g[j].w * xh[j].w;
+      ab[j].x += g[j].x; ab[j].y += g[j].y; ab[j].z += g[j].z; ab[j].w += g[j].w;
+      g[j].x *= gm[j].x; g[j].y *= gm[j].y; g[j].z *= gm[j].z; g[j].w *= gm[j].w;
+      s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+      s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int c = 4 * (lane + 64 * j);
+      if (c < C) {
+        const float4 d = make_float4(up[j].x + rs * (g[j].x - m1 - xh[j].x * m2), up[j].y + rs * (g[j].y - m1 - xh[j].y * m2),
+                                     up[j].z + rs * (g[j].z - m1 - xh[j].z * m2), up[j].w + rs * (g[j].w - m1 - xh[j].w * m2));
+        *reinterpret_cast<float4 *>(dsup + row * C + c) = d;
+        *reinterpret_cast<uint2 *>(df + row * C + c) = pack_bf16x4(d.x * sc, d.y * sc, d.z * sc, d.w * sc);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    *reinterpret_cast<float4 *>(&red[wave][0][4 * (lane + 64 * j)]) = ag[j];
+    *reinterpret_cast<float4 *>(&red[wave][1][4 * (lane + 64 * j)]) = ab[j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 64 * WV) {
+    const int k = i / C, c = i - k * C;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < WV; ++w) sum += red[w][k][c];
+    atomicAdd((k ? dbeta : dgamma) + c, sum);
+  }
+}
+
 #define E_SWITCH(C, BODY)                                             \
   switch ((C) / 64) {                                                 \
     case 1: { constexpr int E = 1; BODY; } break;                     \
@@ -800,6 +927,35 @@ extern "C" int pd_layernorm_rows_f32_bwd(const float *dy, const float *x, const 
     case 7: case 8: { constexpr int NQ = 8; BODY; } break;            \
     default: { constexpr int NQ = 12; BODY; } break;                  \
   }
+
+extern "C" int pd_swin_tail_ln_fwd(const float *cur, const void *r, const float *rscale, int L, const float *gamma, const float *beta, float eps, float *s,
+                                   float *y, float *mean, float *rstd, int64_t rows, int C, void *stream_)
+{
+  if (rows < 0 || C <= 0 || (C & 3) || C > 3072 || L <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_swin_tail_ln_fwd: rows=%lld C=%d L=%d (C a multiple of 4 up to 3072)", (long long)rows, C, L);
+  if (rows == 0) return PD_OK;
+  if (!cur || !r || !gamma || !beta || !s || !y || !mean || !rstd || (((uintptr_t)cur | (uintptr_t)s | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) || ((uintptr_t)r & 7))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_swin_tail_ln_fwd: null / misaligned pointer");
+  const dim3 g((unsigned)((rows + 3) / 4)), b(256);
+  hipStream_t st = (hipStream_t)stream_;
+  NQ_SWITCH(C, hipLaunchKernelGGL(ln_tail_fwd<NQ>, g, b, 0, st, cur, (const bf16_t *)r, rscale, L, gamma, beta, eps, s, y, mean, rstd, rows, C));
+  return pd_check_launch("pd_swin_tail_ln_fwd");
+}
+
+extern "C" int pd_swin_tail_ln_bwd(const float *dy, const float *dsum, const float *s, const float *mean, const float *rstd, const float *gamma, const float *rscale,
+                                   int L, float *dsup, void *df, float *dgamma, float *dbeta, int64_t rows, int C, void *stream_)
+{
+  if (rows < 0 || C <= 0 || (C & 3) || C > 3072 || L <= 0) return pd_set_error(PD_ERR_INVALID_ARG, "pd_swin_tail_ln_bwd: rows=%lld C=%d L=%d (C a multiple of 4 up to 3072)", (long long)rows, C, L);
+  if (rows == 0) return PD_OK;
+  if (!dy || !s || !mean || !rstd || !gamma || !dsup || !df || !dgamma || !dbeta
+      || (((uintptr_t)dy | (uintptr_t)dsum | (uintptr_t)s | (uintptr_t)dsup | (uintptr_t)gamma) & 15) || ((uintptr_t)df & 7))
+    return pd_set_error(PD_ERR_INVALID_ARG, "pd_swin_tail_ln_bwd: null / misaligned pointer");
+  int64_t nb = (rows + 31) / 32;
+  const dim3 g((unsigned)(nb < 1 ? 1 : (nb > 256 ? 256 : nb)));
+  const dim3 b(C > 2048 ? 128 : (C > 768 ? 256 : 512));
+  hipStream_t st = (hipStream_t)stream_;
+  NQ_SWITCH(C, hipLaunchKernelGGL(ln_tail_bwd<NQ>, g, b, 0, st, dy, dsum, s, mean, rstd, gamma, rscale, L, dsup, (bf16_t *)df, dgamma, dbeta, rows, C));
+  return pd_check_launch("pd_swin_tail_ln_bwd");
+}
 
 static int merge_check(int B, int H, int W, int C, const char *who)
 {

@@ -130,3 +130,32 @@ def merge_layer_norm_supported(x, H, W, ln):
 
 def merge_layer_norm(x, H, W, ln):
     return _MergeLayerNorm.apply(x, ln.weight, ln.bias, ln.eps, H, W)
+
+
+def tail_ln_supported(C, nw, nb):
+    return (C % 4 == 0 and C <= 3072 and nw is not None and nb is not None and nw.dtype == torch.float32 and nb.dtype == torch.float32
+            and nw.numel() == C and nb.numel() == C and nw.is_contiguous() and nb.is_contiguous())
+
+
+def tail_ln_fwd(cur, r, rscale, L, gamma, beta, eps):
+    """the end of a fused Swin stage + its output norm (pd_swin_tail_ln_fwd): cur fp32 [rows, C], r bf16 [rows, C], rscale fp32 [images] or None
+    -> (s = cur + rscale r fp32, y = LN(s) fp32, [mean, rstd])"""
+    rows, C = cur.shape
+    assert cur.dtype == torch.float32 and cur.is_contiguous() and r.dtype == torch.bfloat16 and r.is_contiguous() and r.shape == cur.shape
+    s, y = torch.empty_like(cur), torch.empty_like(cur)
+    stats = torch.empty((2, rows), dtype=torch.float32, device=cur.device)
+    _lib.check(_lib.load().pd_swin_tail_ln_fwd(cur.data_ptr(), r.data_ptr(), _p(rscale), int(L), gamma.data_ptr(), beta.data_ptr(), float(eps), s.data_ptr(),
+                                               y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), rows, C, _lib.current_stream()))
+    return s, y, stats
+
+
+def tail_ln_bwd(dy, dsum, s, stats, gamma, rscale, L):
+    """-> (dsup fp32 = dsum + LayerNorm'(dy), df bf16 = rscale dsup, dgamma, dbeta)"""
+    rows, C = s.shape
+    assert dy.dtype == torch.float32 and dy.is_contiguous() and (dsum is None or (dsum.dtype == torch.float32 and dsum.is_contiguous()))
+    dsup = torch.empty_like(s)
+    df = torch.empty((rows, C), dtype=torch.bfloat16, device=s.device)
+    dgb = torch.zeros((2, C), dtype=torch.float32, device=s.device)
+    _lib.check(_lib.load().pd_swin_tail_ln_bwd(dy.data_ptr(), _p(dsum), s.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), gamma.data_ptr(), _p(rscale), int(L),
+                                               dsup.data_ptr(), df.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), rows, C, _lib.current_stream()))
+    return dsup, df, dgb[0], dgb[1]

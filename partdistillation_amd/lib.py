@@ -166,6 +166,8 @@ SIGNATURES = {
     "pd_window_attn_bwd_w12": (_c_int, [_c_vp] * 9 + [_c_int] * 3 + [ctypes.c_float, _c_vp, _c_vp, _c_int, _c_vp]),
     "pd_layernorm_rows_f32_fwd": (_c_int, [_c_vp] * 3 + [ctypes.c_float] + [_c_vp] * 3 + [ctypes.c_int64, _c_int, _c_vp]),
     "pd_layernorm_rows_f32_bwd": (_c_int, [_c_vp] * 8 + [ctypes.c_int64, _c_int, _c_vp]),
+    "pd_swin_tail_ln_fwd": (_c_int, [_c_vp] * 3 + [_c_int] + [_c_vp] * 2 + [ctypes.c_float] + [_c_vp] * 4 + [ctypes.c_int64, _c_int, _c_vp]),
+    "pd_swin_tail_ln_bwd": (_c_int, [_c_vp] * 7 + [_c_int] + [_c_vp] * 4 + [ctypes.c_int64, _c_int, _c_vp]),
     "pd_swin_merge_ln_fwd": (_c_int, [_c_vp] * 3 + [ctypes.c_float] + [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),
     "pd_swin_merge_ln_bwd": (_c_int, [_c_vp] * 8 + [_c_int] * 4 + [_c_vp]),
     "pd_swin_ln_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_int, _c_vp,

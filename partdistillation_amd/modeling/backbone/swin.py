@@ -314,13 +314,16 @@ class BasicLayer(nn.Module):
             for i in range(depth)])
         self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, out_norm=None):
+        """out_norm: the backbone's norm{i} of this stage's output, or None; the fused stage applies it inside its closing kernel and hands the result back
+        as `self.normed` (None when it did not)"""
         from . import swin_core
         fused = FUSED_STAGE and swin_core.supported(self, x)
         if fused and FP8["enabled"] and swin_core.wants_mx8(x.shape[-1]) and not swin_core.mx8_ready(self):
             fused = False                                                 # fp8 asked for, fp32 module weights: the Linears go one by one (functions/fp8.py)
+        self.normed = None
         if fused:
-            x = swin_core.run_stage(self, x, H, W)                        # the whole stage as one autograd node
+            x, self.normed = swin_core.run_stage(self, x, H, W, out_norm)  # the whole stage as one autograd node
         else:
             attn_mask = shifted_window_mask(H, W, self.window_size, self.shift_size, x.device)
             for blk in self.blocks:
@@ -407,10 +410,13 @@ class SwinTransformer(nn.Module):
             swin_core.draw_drop_path(self, x.shape[0], x.device)
         outs = {}
         for i, layer in enumerate(self.layers):
-            x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww)
+            ln = getattr(self, f"norm{i}") if i in self.out_indices else None
+            x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww, ln if OWN_OUT_NORM else None)
             if i in self.out_indices:
-                ln = getattr(self, f"norm{i}")
-                if OWN_OUT_NORM and _swin_rows.rows_layer_norm_supported(x_out, ln):
+                normed, layer.normed = layer.normed, None
+                if normed is not None:
+                    x_out = normed                                           # the fused stage's closing kernel already normalised its output
+                elif OWN_OUT_NORM and _swin_rows.rows_layer_norm_supported(x_out, ln):
                     x_out = _swin_rows.rows_layer_norm(x_out, ln)            # fp32 rows in, fp32 rows out: pd_layernorm_rows_f32_* (ATen: 1 - 2 ms per step)
                 else:
                     x_out = ln(x_out)

@@ -19,6 +19,7 @@ from ...functions import rowwise as _rw
 from ...functions import swin_rows as rows
 from ...functions import window_attention as wattn
 
+TAIL_FUSED = __import__("os").environ.get("PD_SWIN_TAIL_FUSED", "1") != "0"    # stage end + output norm as pd_swin_tail_ln_* (0: ATen chain + the row LayerNorm)
 NREP = 8                 # copies of a stage's LayerNorm column-sum accumulators (see _bwd_blocks)
 N_BLOCK = 13            # norm1.w, norm1.b, qkv.w, qkv.b, table, proj.w, proj.b, norm2.w, norm2.b, fc1.w, fc1.b, fc2.w, fc2.b
 _MAPS = {}
@@ -155,7 +156,9 @@ class SwinStage(Function):
     the host issued a Swin-B step in 35.7 ms against 35 ms of GPU work before (tools/bench_config3.py)."""
 
     @staticmethod
-    def forward(ctx, x, spec, *params):
+    def forward(ctx, x, spec, nw, nb, *params):
+        """nw / nb: weight and bias of the stage's OUTPUT norm (reference swin.py:675-680) or None; with them the node returns (stage output, its norm) and
+        the joining of the last block's MLP output with the stream runs inside the norm's kernel (pd_swin_tail_ln_*), otherwise (stage output, None)"""
         if not x.is_cuda:
             raise RuntimeError("the fused Swin stage runs on the GPU only (no CPU fallback in partdistillation_amd)")
         ctx.set_materialize_grads(False)
@@ -187,15 +190,23 @@ class SwinStage(Function):
                 outs = rec.replay(slots)
             r, cur, saved = outs
             ctx.rec, ctx.rec_gen = rec, rec.generation
-        # ---- eager epilogue (ATen): the last block's MLP output joins the stream
+        # ---- eager epilogue: the last block's MLP output joins the stream — inside the output norm's kernel when the stage has one
         rscale = dp[depth - 1, 1] if dp is not None else None
+        ctx.spec, ctx.depth, ctx.shape, ctx.saved = spec, depth, (B, L, C), saved
+        ctx.tail = False
+        if nw is not None and TAIL_FUSED and rows.tail_ln_supported(C, nw, nb) and r.dtype == torch.bfloat16 and cur.dtype == torch.float32:
+            rs = rscale.contiguous() if rscale is not None else None
+            out, y, st = rows.tail_ln_fwd(cur.view(B * L, C), r.view(B * L, C), rs, L, nw, nb, spec["out_eps"])
+            out = out.view(B, L, C)
+            ctx.tail = True
+            ctx.save_for_backward(nw, out, st, rs, *params)               # (`out` is the node's own output: saved the way autograd wants outputs saved)
+            return out, y.view(B, L, C)
         out = r.view(B, L, C).float()
         if rscale is not None:
             out = out * rscale.view(B, 1, 1)
         out = out.add_(cur.view(B, L, C))
-        ctx.spec, ctx.depth, ctx.shape, ctx.saved = spec, depth, (B, L, C), saved
-        ctx.save_for_backward(*params)
-        return out
+        ctx.save_for_backward(nw if nw is not None else params[0], *params)
+        return out, None
 
     @staticmethod
     def _fwd_blocks(x2, spec, params, dp):
@@ -250,17 +261,31 @@ class SwinStage(Function):
         return r, cur, saved
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dy=None):
         spec, depth, (B, L, C) = ctx.spec, ctx.depth, ctx.shape
         dp = spec["dp"]
-        params, saved = ctx.saved_tensors, ctx.saved
-        if dout is None:
-            return (None,) * (2 + len(params))
-        # ---- eager prologue (ATen): the gradient of the last block's MLP output in 16 bits
-        dsup = dout.contiguous().view(B * L, C)
-        dsup = dsup if dsup.dtype == torch.float32 else dsup.float()
-        last = dp[depth - 1, 1] if dp is not None else None
-        df = (dsup.view(B, L, C) * last.view(B, 1, 1) if last is not None else dsup).to(torch.bfloat16).view(B * L, C)
+        sv, saved = ctx.saved_tensors, ctx.saved
+        nw, params = sv[0], (sv[4:] if ctx.tail else sv[1:])
+        if dout is None and (dy is None or not ctx.tail):
+            return (None,) * (4 + len(params))
+        g_nw = g_nb = None
+        if ctx.tail and dy is not None:
+            # ---- eager prologue, one kernel: stream gradient = (gradient of the stage output from the next stage) + LayerNorm'(gradient of its norm), and its
+            # DropPath-scaled 16-bit copy (the gradient of the last block's MLP output)
+            s_out, st, rs = sv[1], sv[2], sv[3]
+            dyc = dy.contiguous().view(B * L, C)
+            dyc = dyc if dyc.dtype == torch.float32 else dyc.float()
+            dsum = None
+            if dout is not None:
+                dsum = dout.contiguous().view(B * L, C)
+                dsum = dsum if dsum.dtype == torch.float32 else dsum.float()
+            dsup, df, g_nw, g_nb = rows.tail_ln_bwd(dyc, dsum, s_out.view(B * L, C), st, nw, rs, L)
+        else:
+            # ---- eager prologue (ATen): the gradient of the last block's MLP output in 16 bits
+            dsup = dout.contiguous().view(B * L, C)
+            dsup = dsup if dsup.dtype == torch.float32 else dsup.float()
+            last = dp[depth - 1, 1] if dp is not None else None
+            df = (dsup.view(B, L, C) * last.view(B, 1, 1) if last is not None else dsup).to(torch.bfloat16).view(B * L, C)
         rec_f = getattr(ctx, "rec", None)
         if rec_f is None:
             dx, grads = SwinStage._bwd_blocks(spec, params, saved, dsup, df, dp, (B, L, C))
@@ -268,7 +293,7 @@ class SwinStage(Function):
             if rec_f.generation != ctx.rec_gen:
                 raise RuntimeError("the fused Swin stage ran another forward before this backward: the recorded region's activation arena was "
                                    "overwritten (set PD_CMDBUF=0 for graphs that keep several forward passes of one stage alive)")
-            consts = _stage_consts(spec, dout.device)
+            consts = _stage_consts(spec, dsup.device)
             head = [dsup, df] + ([dp] if dp is not None else [])
             slots = head + list(params) + consts
             key = ("bwd", id(rec_f))
@@ -286,7 +311,7 @@ class SwinStage(Function):
             dx, grads = outs
         grads = list(grads)
         _cast_bias_grads(grads, params, [k * N_BLOCK + j for k in range(depth) for j in (3, 6, 10, 12)])
-        return (dx.view(B, L, C), None, *grads)
+        return (dx.view(B, L, C), None, g_nw, g_nb, *grads)
 
     @staticmethod
     def _bwd_blocks(spec, params, saved, dsup, df, dp, shape):
@@ -436,7 +461,8 @@ def draw_drop_path(net, B, device):
         o += d
 
 
-def run_stage(layer, x, H, W):
+def run_stage(layer, x, H, W, out_norm=None):
+    """-> (stage output fp32 [B, L, C], LayerNorm of it by `out_norm` (an nn.LayerNorm: the backbone's norm{i}) or None when out_norm is None / not fusable)"""
     B = x.shape[0]
     depth = len(layer.blocks)
     rates = [float(getattr(blk.drop_path, "drop_prob", 0.0) or 0.0) for blk in layer.blocks]
@@ -449,9 +475,14 @@ def run_stage(layer, x, H, W):
             layer._keep = torch.tensor([1.0 - r for r in rates], dtype=torch.float32, device=x.device).view(depth, 1, 1)
             layer._keep_key = key
         dp = (torch.rand((depth, 2, B), device=x.device) + layer._keep).floor_().div_(layer._keep)   # DropPath (:35-51)
+    nw = nb = None
+    if (out_norm is not None and isinstance(out_norm, torch.nn.LayerNorm) and out_norm.elementwise_affine and out_norm.bias is not None
+            and tuple(out_norm.normalized_shape) == (x.shape[-1],)):
+        nw, nb = out_norm.weight, out_norm.bias
     spec = dict(H=H, W=W, heads=layer.blocks[0].num_heads, shifts=[blk.shift_size for blk in layer.blocks],
-                scale=layer.blocks[0].attn.scale, eps=layer.blocks[0].norm1.eps, dp=dp, mx8=wants_mx8(x.shape[-1]) and mx8_ready(layer))
+                scale=layer.blocks[0].attn.scale, eps=layer.blocks[0].norm1.eps, dp=dp, mx8=wants_mx8(x.shape[-1]) and mx8_ready(layer),
+                out_eps=out_norm.eps if nw is not None else 0.0)
     params = [p for blk in layer.blocks for p in block_params(blk)]
     # stages 2-4 receive the bf16 output of PatchMerging's Linear; the module-by-module path (like the reference under AMP)
     # then keeps a 16-bit residual stream, this one keeps it in fp32 throughout
-    return SwinStage.apply(x.float(), spec, *params)
+    return SwinStage.apply(x.float(), spec, nw, nb, *params)

@@ -304,3 +304,76 @@ def test_patch_merging_gather_layer_norm_vs_torch(B, H, W, C):
         from partdistillation_amd import lib
         lib.check(lib.load().pd_swin_merge_ln_fwd(x.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), 1e-5, y.data_ptr(), y.data_ptr(), y.data_ptr(), 1, 3, 4, C,
                                                   lib.current_stream()))
+
+
+@pytest.mark.parametrize("B,L,C,scaled,with_dsum", [(2, 50, 128, True, True), (3, 33, 192, False, True), (2, 20, 512, True, False), (1, 7, 1536, True, True),
+                                                     (2, 9, 2048, False, False)])
+def test_stage_tail_layer_norm_kernels_vs_torch(B, L, C, scaled, with_dsum):
+    """pd_swin_tail_ln_fwd / _bwd: s = cur + scale[image] * float(r) exactly as the ATen chain forms it (cast, product, sum), y = LayerNorm(s) and the backward's
+    (dsum + LayerNorm'(dy), its scaled bf16 copy, dgamma, dbeta) against float64"""
+    from partdistillation_amd.functions import swin_rows as rows
+    g = torch.Generator(device="cuda").manual_seed(B * L + C)
+    cur = torch.randn(B * L, C, device="cuda", generator=g) * 2
+    r = torch.randn(B * L, C, device="cuda", generator=g).to(torch.bfloat16)
+    sc = torch.tensor([1.0 / 0.7, 0.0, 1.0 / 0.9][:B], device="cuda") if scaled else None          # (products that round)
+    gamma = torch.rand(C, device="cuda", generator=g) + 0.5
+    beta = torch.randn(C, device="cuda", generator=g) * 0.3
+    assert rows.tail_ln_supported(C, gamma, beta)
+    s, y, st = rows.tail_ln_fwd(cur, r, sc, L, gamma, beta, 1e-5)
+    want_s = r.view(B, L, C).float()
+    if sc is not None:
+        want_s = want_s * sc.view(B, 1, 1)
+    want_s = want_s.add_(cur.view(B, L, C)).view(B * L, C)
+    assert torch.equal(s, want_s), "the stage output is the ATen chain's, bit for bit"
+    sd, gd, bd = s.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    ref = torch.nn.functional.layer_norm(sd, (C,), gd, bd, 1e-5)
+    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=1e-5)
+    dy = torch.randn(B * L, C, device="cuda", generator=g)
+    dsum = torch.randn(B * L, C, device="cuda", generator=g) if with_dsum else None
+    dsup, df, dg, db = rows.tail_ln_bwd(dy, dsum, s, st, gamma, sc, L)
+    rs_, rg, rb = torch.autograd.grad(ref, (sd, gd, bd), dy.double())
+    want = rs_ + (dsum.double() if dsum is not None else 0.0)
+    torch.testing.assert_close(dsup.double(), want, rtol=1e-4, atol=1e-5)
+    want_df = dsup.view(B, L, C) * sc.view(B, 1, 1) if sc is not None else dsup.view(B, L, C)
+    assert torch.equal(df.view(B, L, C), want_df.to(torch.bfloat16)), "the 16-bit copy is the rounded scaled stream gradient"
+    torch.testing.assert_close(dg.double(), rg, rtol=1e-4, atol=1e-4 * rg.abs().max().item())
+    torch.testing.assert_close(db.double(), rb, rtol=1e-4, atol=1e-4 * rb.abs().max().item())
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.3])
+def test_fused_stage_tail_equals_the_aten_chain_plus_row_norm(drop):
+    """a BasicLayer with its output norm: the stage's closing kernel (pd_swin_tail_ln_*) against the ATen epilogue + pd_layernorm_rows_f32 — same DropPath draw,
+    identical stage output, norm output / all gradients within fp32 summation order"""
+    from partdistillation_amd.modeling.backbone import swin, swin_core
+    from partdistillation_amd.functions import swin_rows
+    torch.manual_seed(11)
+    dim, depth, H, W, B = 128, 2, 24, 24, 2
+    layer = swin.BasicLayer(dim=dim, depth=depth, num_heads=4, window_size=12, drop_path=[0.0, drop]).cuda().train()
+    ln = torch.nn.LayerNorm(dim).cuda()
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.normal_(0, 0.2)
+    x0 = torch.randn(B, H * W, dim, device="cuda")
+    g1, g2 = torch.randn(B, H * W, dim, device="cuda"), torch.randn(B, H * W, dim, device="cuda")
+    res = {}
+    for fused in (True, False):
+        swin_core.TAIL_FUSED = fused
+        try:
+            torch.manual_seed(5)                                     # the same DropPath draw
+            x = x0.clone().requires_grad_()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = layer(x, H, W, ln)
+            xo, normed = out[0], layer.normed
+            assert (normed is not None) == fused
+            if normed is None:
+                normed = swin_rows.rows_layer_norm(xo, ln)
+            params = [x, ln.weight, ln.bias] + [p for p in layer.parameters()]
+            grads = torch.autograd.grad((xo * g1).sum() + (normed * g2).sum(), params, allow_unused=True)
+            res[fused] = (xo.detach(), normed.detach(), grads)
+        finally:
+            swin_core.TAIL_FUSED = True
+    assert torch.equal(res[True][0], res[False][0])
+    _close(res[True][1], res[False][1], 1e-5, "norm output")
+    for a, b in zip(res[True][2], res[False][2]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            _close(a.float(), b.float(), 2e-2 if a.dtype == torch.bfloat16 else 2e-3, "gradient")
