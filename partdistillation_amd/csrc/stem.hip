@@ -97,38 +97,44 @@ __device__ __forceinline__ void stage_patch(bf16_t *patch, const void *x, int b,
 // the fast path split into its two halves, so that a tile's pieces can be in flight while the previous tile is multiplied: every thread
 // owns PF_N pieces (7 rows x 198 pieces of 4 elements / 256 threads)
 constexpr int PF_NCH = (PROW + 6) / 4, PF_N = (7 * PF_NCH + 255) / 256;
-struct PatchRegs { unsigned lo[PF_N], hi[PF_N]; };
+// (Round 6: the pieces are kept RAW and loaded unconditionally — from a clamped address, dropped by value when stored.  Converted to bf16 inside
+// `if (in range) { load; convert }` every piece was waited for on the spot, one after the other: the "flight" was six serial round trips in front
+// of the multiplication it was meant to hide under, tools/debug/serial_loads.py.)
+template <bool XF32> struct PatchRegs { float4 raw[PF_N]; unsigned ok; };
+template <> struct PatchRegs<false> { uint2 raw[PF_N]; unsigned ok; };
+__device__ __forceinline__ void load_piece(float4 &v, const void *x, int64_t g) { v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(x) + g); }
+__device__ __forceinline__ void load_piece(uint2 &v, const void *x, int64_t g) { v = *reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(x) + g); }
 template <bool XF32>
-__device__ __forceinline__ void patch_load(PatchRegs &r, const void *x, int b, int oy, int ox0, int H, int W, int t)
+__device__ __forceinline__ void patch_load(PatchRegs<XF32> &r, const void *x, int b, int oy, int ox0, int H, int W, int t)
 {
   const int ix0 = 2 * ox0 - 4;
+  r.ok = 0u;
 #pragma unroll
   for (int i = 0; i < PF_N; ++i) {
     const int idx = t + 256 * i, ky = idx / PF_NCH, m = idx - ky * PF_NCH;
     const int iy = 2 * oy - 3 + ky, el = ix0 * 3 + 4 * m;
-    r.lo[i] = 0u; r.hi[i] = 0u;
-    if (idx < 7 * PF_NCH && iy >= 0 && iy < H && el >= 0 && el < 3 * W) {
-      const int64_t g = ((int64_t)b * H + iy) * W * 3 + el;
-      if (XF32) {
-        const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(x) + g);
-        r.lo[i] = pk_bf16(v.x, v.y); r.hi[i] = pk_bf16(v.z, v.w);
-      } else {
-        const uint2 v = *reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(x) + g);
-        r.lo[i] = v.x; r.hi[i] = v.y;
-      }
-    }
+    const bool in = idx < 7 * PF_NCH && iy >= 0 && iy < H && el >= 0 && el < 3 * W;
+    const int64_t g = in ? ((int64_t)b * H + iy) * W * 3 + el : 0;
+    r.ok |= (in ? 1u : 0u) << i;
+    load_piece(r.raw[i], x, g);
   }
 }
-__device__ __forceinline__ void patch_store(bf16_t *patch, const PatchRegs &r, int t)
+__device__ __forceinline__ void piece_bits(const float4 &v, unsigned &lo, unsigned &hi) { lo = pk_bf16(v.x, v.y); hi = pk_bf16(v.z, v.w); }
+__device__ __forceinline__ void piece_bits(const uint2 &v, unsigned &lo, unsigned &hi) { lo = v.x; hi = v.y; }
+template <bool XF32>
+__device__ __forceinline__ void patch_store(bf16_t *patch, const PatchRegs<XF32> &r, int t)
 {
 #pragma unroll
   for (int i = 0; i < PF_N; ++i) {
     const int idx = t + 256 * i, ky = idx / PF_NCH, m = idx - ky * PF_NCH;
     if (idx < 7 * PF_NCH) {
+      unsigned lo, hi;
+      piece_bits(r.raw[i], lo, hi);
+      if (!((r.ok >> i) & 1u)) { lo = 0u; hi = 0u; }
       bf16_t *d = patch + ky * PITCH + 1 + 4 * m;
-      d[0] = (bf16_t)(r.lo[i] & 0xffffu);
-      *reinterpret_cast<unsigned *>(d + 1) = (r.lo[i] >> 16) | (r.hi[i] << 16);
-      d[3] = (bf16_t)(r.hi[i] >> 16);
+      d[0] = (bf16_t)(lo & 0xffffu);
+      *reinterpret_cast<unsigned *>(d + 1) = (lo >> 16) | (hi << 16);
+      d[3] = (bf16_t)(hi >> 16);
     }
   }
 }
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256) void stem_fwd(const void *__restrict__ x, cons
   __syncthreads();
   for (int i = t; i < 7 * PITCH; i += 256) patch[i] = 0;                    // (the pad beyond a row's elements stays zero)
   __syncthreads();
-  PatchRegs pr;
+  PatchRegs<XF32> pr;
   if (fast && (int)blockIdx.x < ntiles) {
     const int tile = blockIdx.x, tx = tile % tiles_x, r = tile / tiles_x;
     patch_load<XF32>(pr, x, r / Ho, r % Ho, tx * TP, H, W, t);
@@ -264,30 +270,38 @@ __global__ __launch_bounds__(256) void stem_wgrad(const void *__restrict__ x, co
   const int grp = lane >> 4, sl = lane & 15;
   const int frow = 8 * (grp >> 1) + (sl >> 2), fcol = 16 * (grp & 1) + 4 * (sl & 3);
   __syncthreads();
-  // a thread's share of a tile's masked gradient: 4 pieces of 8 channels (pixels t / 8 + 32 i)
-  auto g_load = [&](uint4 (&gr)[4], int b, int oy, int ox0) {
+  // a thread's share of a tile's masked gradient: 4 pieces of 8 channels (pixels t / 8 + 32 i).  Loaded RAW and unconditionally (clamped pixel), masked
+  // when stored to LDS: with the ReLU mask formed right behind each conditional pair of loads, the four pairs were four serial round trips
+  struct GRegs { uint4 g[4], a[4]; };
+  auto g_load = [&](GRegs &gr, int b, int oy, int ox0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int p = (t >> 3) + 32 * i, c8 = (t & 7) * 8;
-      uint4 g = make_uint4(0u, 0u, 0u, 0u);
-      if (ox0 + p < Wo) {
-        const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox0 + p) * 64 + c8;
-        g = *reinterpret_cast<const uint4 *>(gy + o);
-        if (yact) {
-          const uint4 a = *reinterpret_cast<const uint4 *>(yact + o);
-          // y is relu(.) rounded to bf16: positive <=> a non-zero, non-negative pattern
-          auto m = [](unsigned gv, unsigned av) {
-            const unsigned lo = ((av & 0xffffu) != 0u && !(av & 0x8000u)) ? 0xffffu : 0u, hi = ((av >> 16) != 0u && !(av & 0x80000000u)) ? 0xffff0000u : 0u;
-            return gv & (lo | hi);
-          };
-          g = make_uint4(m(g.x, a.x), m(g.y, a.y), m(g.z, a.z), m(g.w, a.w));
-        }
-      }
-      gr[i] = g;
+      const int p = min((t >> 3) + 32 * i, Wo - 1 - ox0), c8 = (t & 7) * 8;
+      const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox0 + p) * 64 + c8;
+      gr.g[i] = *reinterpret_cast<const uint4 *>(gy + o);
+      gr.a[i] = yact ? *reinterpret_cast<const uint4 *>(yact + o) : make_uint4(0u, 0u, 0u, 0u);
     }
   };
-  PatchRegs pr;
-  uint4 gr[4];
+  auto g_store = [&](const GRegs &gr, int ox0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = (t >> 3) + 32 * i;
+      uint4 g = gr.g[i];
+      if (yact) {
+        const uint4 a = gr.a[i];
+        // y is relu(.) rounded to bf16: positive <=> a non-zero, non-negative pattern
+        auto m = [](unsigned gv, unsigned av) {
+          const unsigned lo = ((av & 0xffffu) != 0u && !(av & 0x8000u)) ? 0xffffu : 0u, hi = ((av >> 16) != 0u && !(av & 0x80000000u)) ? 0xffff0000u : 0u;
+          return gv & (lo | hi);
+        };
+        g = make_uint4(m(g.x, a.x), m(g.y, a.y), m(g.z, a.z), m(g.w, a.w));
+      }
+      if (ox0 + p >= Wo) g = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4 *>(SY + p * SYP + (t & 7) * 8) = g;
+    }
+  };
+  PatchRegs<XF32> pr;
+  GRegs gr;
   if ((int)blockIdx.x < ntiles) {
     const int tile = blockIdx.x, tx = tile % tiles_x, r = tile / tiles_x;
     if (fast) patch_load<XF32>(pr, x, r / Ho, r % Ho, tx * TP, H, W, t);
@@ -297,8 +311,7 @@ __global__ __launch_bounds__(256) void stem_wgrad(const void *__restrict__ x, co
     const int tx = tile % tiles_x, r = tile / tiles_x, oy = r % Ho, b = r / Ho, ox0 = tx * TP;
     if (fast) patch_store(patch, pr, t);
     else stage_patch<XF32>(patch, x, b, oy, ox0, H, W, t, 256, false);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(SY + ((t >> 3) + 32 * i) * SYP + (t & 7) * 8) = gr[i];
+    g_store(gr, ox0);
     {
       const int nx = tile + gridDim.x;
       if (nx < ntiles) {                                            // the next tile's operands fly while this one is multiplied
